@@ -1,0 +1,608 @@
+/*
+ * euler_oracle.c — TEST ORACLE, not product code (see euler_oracle.h).
+ *
+ * CPU restatement of the cgmb/euler per-frame simulation path with a run-time grid.  Written
+ * from the behaviour of the reference (file:line cited per function), keeping the per-cell
+ * operation order so that, compiled without FMA contraction and without -ffast-math, it is
+ * bit-identical to the compiled reference at X=100,Y=40 (checked in tests/).
+ *
+ * Conventions: every field is a flat row-major [Y][X] array, index i = y*X + x.  A U sample
+ * (x,y) sits between P cells (x,y) and (x+1,y); a V sample between (x,y) and (x,y+1).
+ */
+#include "euler_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* reference constants, main.c:58-60 */
+static const float H_CELL  = 1.f;   /* k_side_length */
+static const float DENSITY = 1.f;   /* k_density */
+static const float GRAVITY = -10.f; /* k_gravity */
+
+#define AT(s, y, x) ((size_t)(y) * (size_t)(s)->X + (size_t)(x))
+
+/* ---------------------------------------------------------------- allocation */
+
+eo_sim* eo_create(int X, int Y) {
+  if (X < 4 || Y < 4) return NULL;
+  eo_sim* s = (eo_sim*)calloc(1, sizeof(eo_sim));
+  if (!s) return NULL;
+  size_t C = (size_t)X * (size_t)Y;
+  s->X = X; s->Y = Y;
+  s->u = calloc(C, sizeof(float));    s->v = calloc(C, sizeof(float));
+  s->utmp = calloc(C, sizeof(float)); s->vtmp = calloc(C, sizeof(float));
+  s->solid = calloc(C, 1); s->source = calloc(C, 1); s->sink = calloc(C, 1);
+  s->count = calloc(C, 1); s->prev_count = calloc(C, 1);
+  s->max_markers = 4 * C;
+  s->markers = calloc(s->max_markers, sizeof(eo_vec2f));
+  s->a_diag = calloc(C, 1);
+  s->precon = calloc(C, sizeof(double)); s->q = calloc(C, sizeof(double));
+  s->b = calloc(C, sizeof(double)); s->p = calloc(C, sizeof(double));
+  s->r = calloc(C, sizeof(double)); s->z = calloc(C, sizeof(double));
+  s->s = calloc(C, sizeof(double));
+  s->rng_state = 0x9bd185c449534b91ull; /* main.c:204 */
+  s->max_iterations = 100;              /* main.c:735 */
+  s->tol = (double)1e-6f;               /* main.c:736: a float literal widened */
+  return s;
+}
+
+void eo_destroy(eo_sim* s) {
+  if (!s) return;
+  free(s->u); free(s->v); free(s->utmp); free(s->vtmp);
+  free(s->solid); free(s->source); free(s->sink); free(s->count); free(s->prev_count);
+  free(s->markers); free(s->a_diag); free(s->precon); free(s->q);
+  free(s->b); free(s->p); free(s->r); free(s->z); free(s->s);
+  free(s);
+}
+
+/* ---------------------------------------------------------------- rng (misc/rng.c:5-20, main.c:203-207) */
+
+static float eo_randf(eo_sim* s) {
+  uint64_t x = s->rng_state;
+  x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+  s->rng_state = x;
+  uint32_t hi = (uint32_t)((x * 0x2545F4914F6CDD1Dull) >> 32);
+  return (float)(hi / (double)UINT32_MAX); /* closed interval [0,1] */
+}
+
+/* ---------------------------------------------------------------- typed cell properties (main.c:119-156) */
+
+static inline int prop(const eo_sim* s, const uint8_t* g, int x, int y, int type) {
+  size_t i = AT(s, y, x);
+  switch (type) {
+    case EO_U: return (g[i] != 0) | (g[i + 1] != 0);
+    case EO_V: return (g[i] != 0) | (g[i + (size_t)s->X] != 0);
+    default:   return g[i] != 0;
+  }
+}
+static inline int ext_x(const eo_sim* s, int type) { return type == EO_U ? s->X - 1 : s->X; }
+static inline int ext_y(const eo_sim* s, int type) { return type == EO_V ? s->Y - 1 : s->Y; }
+
+/* ---------------------------------------------------------------- marker binning (main.c:102-117) */
+
+void eo_refresh_marker_counts(eo_sim* s) {
+  size_t C = (size_t)s->X * (size_t)s->Y;
+  memcpy(s->prev_count, s->count, C);
+  memset(s->count, 0, C);
+  size_t i = 0;
+  while (i < s->n_markers) {
+    int x = (int)floorf(s->markers[i].x / H_CELL);
+    int y = (int)floorf(s->markers[i].y / H_CELL);
+    size_t c = AT(s, y, x);
+    if (s->sink[c] || s->solid[c]) {
+      /* swap-with-last; the swapped-in marker is examined next (main.c:112) */
+      s->markers[i] = s->markers[--s->n_markers];
+    } else {
+      s->count[c]++; /* uint8 wrap is part of the semantics */
+      ++i;
+    }
+  }
+}
+
+/* ---------------------------------------------------------------- scenario (main.c:209-274) */
+
+static void finish_init(eo_sim* s, const uint8_t* fluid) {
+  int X = s->X, Y = s->Y;
+  for (int y = 0; y < Y; ++y) { s->sink[AT(s, y, 0)] = 1; s->sink[AT(s, y, X - 1)] = 1; }
+  for (int x = 0; x < X; ++x) { s->sink[AT(s, 0, x)] = 1; s->sink[AT(s, Y - 1, x)] = 1; }
+  /* 4 jittered markers per fluid cell, x outer / y inner, x drawn before y (main.c:255-266) */
+  size_t n = 0;
+  for (int i = 0; i < X; ++i)
+    for (int j = 0; j < Y; ++j)
+      if (fluid[AT(s, j, i)])
+        for (int k = 0; k < 4; ++k) {
+          float fx = i + (k < 2 ? 0 : 0.5f) + (eo_randf(s) / 2);
+          float fy = j + (k % 2 ? 0 : 0.5f) + (eo_randf(s) / 2);
+          s->markers[n].x = H_CELL * fx;
+          s->markers[n].y = H_CELL * fy;
+          ++n;
+        }
+  s->n_markers = n;
+  eo_refresh_marker_counts(s);
+}
+
+static void set_cell(eo_sim* s, uint8_t* fluid, int x, int y, char c) {
+  size_t i = AT(s, y, x);
+  if (c == 'X') s->solid[i] = 1;
+  else if (c == '0') fluid[i] = 1;
+  else if (c == '?') { fluid[i] = 1; s->source[i] = 1; }
+  else if (c == '=') s->sink[i] = 1;
+}
+
+int eo_load_scenario_mem(eo_sim* s, const char* text, int len, int upscale) {
+  int X = s->X, Y = s->Y;
+  size_t C = (size_t)X * (size_t)Y;
+  uint8_t* fluid = calloc(C, 1);
+  if (!fluid) return -1;
+  if (!upscale) {
+    /* streaming parse: first line -> y=Y-2, first char -> x=1; over-long lines discarded */
+    int i = 0;
+    for (int y = Y - 2; y > 0 && i < len; --y) {
+      int x;
+      for (x = 1; x < X - 1 && i < len; ++x) {
+        char c = text[i++];
+        if (c == '\n') break;
+        set_cell(s, fluid, x, y, c);
+      }
+      if (x == X - 1) { while (i < len && text[i++] != '\n') {} }
+    }
+  } else {
+    /* ch(x,y) = file[floor((Y-2-y)*Hf/(Y-2))][floor((x-1)*Wf/(X-2))] */
+    int nlines = 0, Wf = 0;
+    for (int i = 0, w = 0; i <= len; ++i) {
+      if (i == len || text[i] == '\n') {
+        if (i < len || w > 0) { nlines++; if (w > Wf) Wf = w; }
+        w = 0;
+      } else w++;
+    }
+    if (nlines == 0 || Wf == 0) { free(fluid); return -2; }
+    const char** line = malloc(sizeof(char*) * (size_t)nlines);
+    int* linelen = malloc(sizeof(int) * (size_t)nlines);
+    int k = 0, st = 0;
+    for (int i = 0; i <= len; ++i)
+      if (i == len || text[i] == '\n') {
+        if (i < len || i > st) { line[k] = text + st; linelen[k] = i - st; k++; }
+        st = i + 1;
+      }
+    for (int y = 1; y <= Y - 2; ++y) {
+      long fr = ((long)(Y - 2 - y) * nlines) / (Y - 2);
+      for (int x = 1; x <= X - 2; ++x) {
+        long fc = ((long)(x - 1) * Wf) / (X - 2);
+        char c = (fc < linelen[fr]) ? line[fr][fc] : ' ';
+        set_cell(s, fluid, x, y, c);
+      }
+    }
+    free(line); free(linelen);
+  }
+  finish_init(s, fluid);
+  free(fluid);
+  return 0;
+}
+
+int eo_load_scenario_file(eo_sim* s, const char* path, int upscale) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return -1;
+  fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+  char* buf = malloc((size_t)n + 1);
+  if (!buf || fread(buf, 1, (size_t)n, f) != (size_t)n) { fclose(f); free(buf); return -1; }
+  fclose(f);
+  int rc = eo_load_scenario_mem(s, buf, (int)n, upscale);
+  free(buf);
+  return rc;
+}
+
+int eo_load_half_tank(eo_sim* s) {
+  int X = s->X, Y = s->Y;
+  uint8_t* fluid = calloc((size_t)X * (size_t)Y, 1);
+  if (!fluid) return -1;
+  for (int y = 1; y <= Y - 2; ++y)
+    for (int x = 1; x <= X - 2; ++x) {
+      size_t i = AT(s, y, x);
+      if (y == 1 || y == Y - 2 || x == 1 || x == X - 2) s->solid[i] = 1;
+      else if (y < Y / 2) fluid[i] = 1;
+    }
+  finish_init(s, fluid);
+  free(fluid);
+  return 0;
+}
+
+/* ---------------------------------------------------------------- sources (main.c:276-298) */
+
+void eo_update_fluid_sources(eo_sim* s) {
+  int X = s->X, Y = s->Y;
+  s->source_exhausted |= (s->n_markers == s->max_markers - 1);
+  for (int y = 0; y < Y; ++y)
+    for (int x = 0; x < X; ++x) {
+      size_t i = AT(s, y, x);
+      if (s->source[i] && !s->source_exhausted && s->count[i] < 4) {
+        /* main.c:288 v2f(x+randf(), y+randf()): argument evaluation order is unspecified in C;
+         * the compiled reference (gcc, x86-64) evaluates right-to-left, so y is drawn FIRST.
+         * The golden fixtures pin this order. */
+        float ry = eo_randf(s), rx = eo_randf(s);
+        s->markers[s->n_markers].x = H_CELL * (x + rx);
+        s->markers[s->n_markers].y = H_CELL * (y + ry);
+        s->n_markers++;
+        s->count[i]++;
+        s->source_exhausted |= (s->n_markers == s->max_markers - 1);
+      }
+    }
+}
+
+/* ---------------------------------------------------------------- extrapolation (main.c:158-185) */
+
+void eo_extrapolate(eo_sim* s, float* q, int type) {
+  int ex = ext_x(s, type), ey = ext_y(s, type);
+  for (int y = 0; y < ey; ++y)
+    for (int x = 0; x < ex; ++x) {
+      if (prop(s, s->prev_count, x, y, type) || !prop(s, s->count, x, y, type)) continue;
+      int x0 = x > 0 ? x - 1 : 0, x1 = x + 1 < ex ? x + 1 : ex - 1;
+      int y0 = y > 0 ? y - 1 : 0, y1 = y + 1 < ey ? y + 1 : ey - 1;
+      float total = 0.f; int n = 0;
+      for (int yy = y0; yy <= y1; ++yy)
+        for (int xx = x0; xx <= x1; ++xx)
+          if (prop(s, s->prev_count, xx, yy, type)) { total += q[AT(s, yy, xx)]; n++; }
+      q[AT(s, y, x)] = total / n; /* n==0 -> 0/0, as the Release reference (assert off) */
+    }
+}
+
+/* ---------------------------------------------------------------- masked bilinear (main.c:300-364) */
+
+static inline float lerp1(float x0, float x1, float f) { return (1.f - f) * x0 + f * x1; }
+static inline float pick_frac(float f, int start_ok, int end_ok) {
+  return !start_ok ? 1.f : (!end_ok ? 0.f : f);
+}
+static inline float clampf_(float lo, float x, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+float eo_interpolate(const eo_sim* s, const float* q, float ix, float iy, int type) {
+  ix = clampf_(0, ix, nextafterf((float)(ext_x(s, type) - 1), 0));
+  iy = clampf_(0, iy, nextafterf((float)(ext_y(s, type) - 1), 0));
+  float wx, wy;
+  float fx = modff(ix, &wx), fy = modff(iy, &wy);
+  int bx = (int)wx, by = (int)wy;
+  int v00 = prop(s, s->count, bx, by, type),     v01 = prop(s, s->count, bx + 1, by, type);
+  int v10 = prop(s, s->count, bx, by + 1, type), v11 = prop(s, s->count, bx + 1, by + 1, type);
+  float q00 = v00 ? q[AT(s, by, bx)] : 0.f,     q01 = v01 ? q[AT(s, by, bx + 1)] : 0.f;
+  float q10 = v10 ? q[AT(s, by + 1, bx)] : 0.f, q11 = v11 ? q[AT(s, by + 1, bx + 1)] : 0.f;
+  /* vertical lerp per column, then horizontal (main.c:322-330) */
+  float lf = pick_frac(fy, v00, v10), rf = pick_frac(fy, v01, v11);
+  float lv = lerp1(q00, q10, lf), rv = lerp1(q01, q11, rf);
+  float hf = pick_frac(fx, v00 | v10, v01 | v11);
+  return lerp1(lv, rv, hf);
+}
+
+/* ---------------------------------------------------------------- velocity advection (main.c:378-422) */
+
+void eo_advect_u(const eo_sim* s, const float* u, const float* v, float dt, float* out) {
+  for (int y = 0; y < s->Y; ++y)
+    for (int x = 0; x < s->X - 1; ++x) {
+      if (!prop(s, s->count, x, y, EO_U)) continue;
+      float dx = u[AT(s, y, x)];
+      float dy = eo_interpolate(s, v, x + 0.5f, y - 0.5f, EO_V);
+      float px = x - dx * dt / H_CELL, py = y - dy * dt / H_CELL;
+      out[AT(s, y, x)] = eo_interpolate(s, u, px, py, EO_U);
+    }
+}
+
+void eo_advect_v(const eo_sim* s, const float* u, const float* v, float dt, float* out) {
+  for (int y = 0; y < s->Y - 1; ++y)
+    for (int x = 0; x < s->X; ++x) {
+      if (!prop(s, s->count, x, y, EO_V)) continue;
+      float dy = v[AT(s, y, x)];
+      float dx = eo_interpolate(s, u, x - 0.5f, y + 0.5f, EO_U);
+      float px = x - dx * dt / H_CELL, py = y - dy * dt / H_CELL;
+      out[AT(s, y, x)] = eo_interpolate(s, v, px, py, EO_V);
+    }
+}
+
+/* ---------------------------------------------------------------- marker advection (main.c:440-537) */
+
+static inline float time_to(float p0, float p1, float vel) {
+  return fabsf(vel) > 0.f ? (p1 - p0) / vel : FLT_MAX;
+}
+
+/* NOTE (main.c:464,501,518): the reference subtracts t_prev from its *parameter* dt inside the
+ * marker loop, so a collision that happens after a cell crossing shortens dt for every LATER
+ * marker in the array.  Marker order is therefore observable; it is reproduced exactly here
+ * (init order main.c:255-266, swap-with-last main.c:112, source appends main.c:288). */
+void eo_advect_markers(eo_sim* s, float dt) {
+  for (size_t m = 0; m < s->n_markers; ++m) {
+    float px = s->markers[m].x, py = s->markers[m].y;
+    float vx = eo_interpolate(s, s->u, px / H_CELL - 1.f, py / H_CELL - 0.5f, EO_U);
+    float vy = eo_interpolate(s, s->v, px / H_CELL - 0.5f, py / H_CELL - 1.f, EO_V);
+    int xi = (int)floorf(px / H_CELL), yi = (int)floorf(py / H_CELL);
+
+    int xdir = vx > 0 ? 1 : -1, nxi = xi + (vx > 0 ? 1 : 0);
+    float npx = nxi * H_CELL;
+    float tx = time_to(px, npx, vx);
+    int xoff = vx < 0 ? -1 : 0;
+
+    int ydir = vy > 0 ? 1 : -1, nyi = yi + (vy > 0 ? 1 : 0);
+    float npy = nyi * H_CELL;
+    float ty = time_to(py, npy, vy);
+    int yoff = vy < 0 ? -1 : 0;
+
+    float t_prev = 0.f, t_near = fminf(tx, ty);
+    while (t_near < dt) {
+      if (tx < ty) {
+        if (s->solid[AT(s, yi, nxi + xoff)]) {
+          px = px + t_prev * vx; py = py + t_prev * vy;
+          dt -= t_prev; t_near = 0; vx = 0.f; tx = FLT_MAX;
+          ty = time_to(py, npy, vy);
+        } else {
+          xi = nxi; nxi = xi + xdir; npx = nxi * H_CELL;
+          tx = time_to(px, npx, vx);
+        }
+      } else {
+        if (s->solid[AT(s, nyi + yoff, xi)]) {
+          px = px + t_prev * vx; py = py + t_prev * vy;
+          dt -= t_prev; t_near = 0; vy = 0.f; ty = FLT_MAX;
+          tx = time_to(px, npx, vx);
+        } else {
+          yi = nyi; nyi = yi + ydir; npy = nyi * H_CELL;
+          ty = time_to(py, npy, vy);
+        }
+      }
+      t_prev = t_near;
+      t_near = fminf(tx, ty);
+    }
+    float t = (t_near < FLT_MAX) ? dt : t_prev;
+    s->markers[m].x = px + t * vx;
+    s->markers[m].y = py + t * vy;
+  }
+}
+
+/* ---------------------------------------------------------------- forces, bounds, dt (main.c:539-545, 808-841) */
+
+void eo_apply_body_forces(const eo_sim* s, float* v, float dt) {
+  for (int y = 0; y < s->Y - 1; ++y)
+    for (int x = 0; x < s->X; ++x) v[AT(s, y, x)] += GRAVITY * dt;
+}
+
+void eo_zero_bounds(const eo_sim* s, float* q, int type) {
+  int ex = ext_x(s, type), ey = ext_y(s, type);
+  for (int y = 0; y < ey; ++y)
+    for (int x = 0; x < ex; ++x)
+      if (!prop(s, s->count, x, y, type) || prop(s, s->solid, x, y, type)) q[AT(s, y, x)] = 0.f;
+}
+
+static float max_square(const eo_sim* s, const float* q, int type) {
+  int ex = ext_x(s, type), ey = ext_y(s, type);
+  float m = 0;
+  for (int y = 0; y < ey; ++y)
+    for (int x = 0; x < ex; ++x) { float sq = q[AT(s, y, x)] * q[AT(s, y, x)]; if (sq > m) m = sq; }
+  return m;
+}
+
+float eo_calculate_timestep(const eo_sim* s, float frame_time) {
+  const float max_distance = 0.75f * H_CELL;
+  float vmax = sqrtf(max_square(s, s->u, EO_U) + max_square(s, s->v, EO_V));
+  return fminf(max_distance / vmax, frame_time); /* 0.75/0 = +inf -> frame_time */
+}
+
+/* ---------------------------------------------------------------- pressure projection (main.c:547-806) */
+
+#define FLUID(s, y, x) ((s)->count[AT(s, y, x)] != 0)
+
+void eo_build_system(eo_sim* s, float dt, const float* u, const float* v) {
+  int X = s->X, Y = s->Y;
+  size_t C = (size_t)X * (size_t)Y;
+  const double k_inv_scale = (H_CELL * H_CELL) * DENSITY / dt; /* float expr widened, main.c:713 */
+  memset(s->b, 0, C * sizeof(double));
+  for (int y = 0; y < Y; ++y)
+    for (int x = 0; x < X; ++x) {
+      if (!FLUID(s, y, x)) continue;
+      size_t i = AT(s, y, x);
+      double divergence = (u[i] - u[i - 1] + v[i] - v[i - X]) / H_CELL; /* float, then widened */
+      s->b[i] = -divergence * k_inv_scale;
+      s->a_diag[i] = (int8_t)(4 - s->solid[i - 1] - s->solid[i + 1] - s->solid[i - X] - s->solid[i + X]);
+    }
+}
+
+void eo_apply_preconditioner(eo_sim* s, const double* r, double* z) {
+  int X = s->X, Y = s->Y;
+  size_t C = (size_t)X * (size_t)Y;
+  double* pre = s->precon; double* q = s->q;
+  /* E^-1 of the IC(0) factor, recomputed every call as the reference does (main.c:586-600).
+   * NOTE the reference's "minus" coefficients: get_a_minus_i(y,x) = get_a_plus_i(y,x-1) =
+   * is_fluid(y,x) ? -1 : 0 (main.c:561-575), i.e. ALWAYS -1 for the fluid cell being visited,
+   * whatever the left/lower neighbour is.  So the stale precon[] of a neighbour that is no
+   * longer fluid DOES enter e (precon[] persists across calls and substeps, main.c:577), and
+   * in the forward solve the neighbour term is (-1*precon)*q with q=+0 on non-fluid cells. */
+  for (int y = 0; y < Y; ++y)
+    for (int x = 0; x < X; ++x) {
+      if (!FLUID(s, y, x)) continue;
+      size_t i = AT(s, y, x);
+      double a = s->a_diag[i];
+      double cl = -1 * pre[i - 1];
+      double cb = -1 * pre[i - X];
+      double e = a - cl * cl - cb * cb;
+      if (e < 0.25 * a) e = a != 0 ? a : 1;
+      pre[i] = 1 / sqrt(e);
+    }
+  /* L q = r (main.c:602-613) */
+  memset(q, 0, C * sizeof(double));
+  for (int y = 0; y < Y; ++y)
+    for (int x = 0; x < X; ++x) {
+      if (!FLUID(s, y, x)) continue;
+      size_t i = AT(s, y, x);
+      double t = r[i] - -1 * pre[i - 1] * q[i - 1]
+                      - -1 * pre[i - X] * q[i - X];
+      q[i] = t * pre[i];
+    }
+  /* L^T z = q (main.c:615-626) */
+  memset(z, 0, C * sizeof(double));
+  for (int y = Y; y--;)
+    for (int x = X; x--;) {
+      if (!FLUID(s, y, x)) continue;
+      size_t i = AT(s, y, x);
+      double t = q[i] - (FLUID(s, y, x + 1) ? -1 : 0) * pre[i] * z[i + 1]
+                      - (FLUID(s, y + 1, x) ? -1 : 0) * pre[i] * z[i + X];
+      z[i] = t * pre[i];
+    }
+}
+
+double eo_dot(const eo_sim* s, const double* a, const double* b) {
+  double total = 0.f;
+  size_t C = (size_t)s->X * (size_t)s->Y;
+  for (size_t i = 0; i < C; ++i) if (s->count[i]) total += a[i] * b[i];
+  return total;
+}
+
+double eo_inf_norm(const eo_sim* s, const double* r) {
+  double m = 0.f;
+  size_t C = (size_t)s->X * (size_t)s->Y;
+  for (size_t i = 0; i < C; ++i) if (s->count[i]) { double a = fabs(r[i]); if (a > m) m = a; }
+  return m;
+}
+
+void eo_apply_a(const eo_sim* s, const double* in, double* out) {
+  int X = s->X, Y = s->Y;
+  for (int y = 0; y < Y; ++y)
+    for (int x = 0; x < X; ++x) {
+      if (!FLUID(s, y, x)) continue;
+      size_t i = AT(s, y, x);
+      out[i] = s->a_diag[i] * in[i]
+             - (FLUID(s, y, x + 1) ? in[i + 1] : 0)
+             - (FLUID(s, y + 1, x) ? in[i + X] : 0)
+             - (FLUID(s, y, x - 1) ? in[i - 1] : 0)
+             - (FLUID(s, y - 1, x) ? in[i - X] : 0);
+    }
+}
+
+static void axpy_fluid(const eo_sim* s, const double* a, double k, double* c) { /* fmadd, main.c:694 */
+  size_t C = (size_t)s->X * (size_t)s->Y;
+  for (size_t i = 0; i < C; ++i) if (s->count[i]) c[i] += a[i] * k;
+}
+
+int eo_project(eo_sim* s, float dt, const float* u, const float* v, float* uout, float* vout) {
+  int X = s->X, Y = s->Y;
+  size_t C = (size_t)X * (size_t)Y;
+  eo_build_system(s, dt, u, v);
+  double *p = s->p, *r = s->r, *z = s->z, *sv = s->s;
+  memset(p, 0, C * sizeof(double));
+  memcpy(r, s->b, C * sizeof(double));
+  int iters = 0;
+  int nonzero = 0;
+  for (size_t i = 0; i < C && !nonzero; ++i) if (s->count[i] && r[i] != 0.f) nonzero = 1;
+  s->last_residual = 0;
+  if (nonzero) {
+    eo_apply_preconditioner(s, r, z);
+    memcpy(sv, z, C * sizeof(double));
+    double sigma = eo_dot(s, z, r);
+    for (int it = 0; it < s->max_iterations; ++it) {
+      eo_apply_a(s, sv, z);
+      iters++;
+      double alpha = sigma / eo_dot(s, z, sv);
+      axpy_fluid(s, sv, alpha, p);
+      axpy_fluid(s, z, -alpha, r);
+      s->last_residual = eo_inf_norm(s, r);
+      if (s->last_residual <= s->tol) break;
+      eo_apply_preconditioner(s, r, z);
+      double sigma_new = eo_dot(s, z, r);
+      double beta = sigma_new / sigma;
+      for (size_t i = 0; i < C; ++i) if (s->count[i]) sv[i] = z[i] + beta * sv[i];
+      sigma = sigma_new;
+    }
+  }
+  for (size_t i = 0; i < C; ++i) if (s->count[i] && p[i] < 0.f) p[i] = 0.f; /* main.c:773-779 */
+
+  const float neg_inv = -(1.f / (DENSITY * H_CELL)); /* accel(), main.c:705-707 */
+  for (int y = 0; y < Y; ++y)
+    for (int x = 0; x < X - 1; ++x) {
+      size_t i = AT(s, y, x);
+      if (prop(s, s->solid, x, y, EO_U)) uout[i] = 0.f;
+      else if (prop(s, s->count, x, y, EO_U)) uout[i] = u[i] + (neg_inv * (float)(p[i + 1] - p[i])) * dt;
+      else uout[i] = 0.f;
+    }
+  for (int y = 0; y < Y - 1; ++y)
+    for (int x = 0; x < X; ++x) {
+      size_t i = AT(s, y, x);
+      if (prop(s, s->solid, x, y, EO_V)) vout[i] = 0.f;
+      else if (prop(s, s->count, x, y, EO_V)) vout[i] = v[i] + (neg_inv * (float)(p[i + X] - p[i])) * dt;
+      else vout[i] = 0.f;
+    }
+  s->last_pcg_iterations = iters;
+  s->total_pcg_iterations += (uint64_t)iters;
+  return iters;
+}
+
+/* ---------------------------------------------------------------- step driver (main.c:843-900) */
+
+int eo_substep(eo_sim* s, float dt) {
+  eo_advect_markers(s, dt);
+  eo_refresh_marker_counts(s);
+  eo_update_fluid_sources(s);
+  eo_extrapolate(s, s->u, EO_U);
+  eo_extrapolate(s, s->v, EO_V);
+  eo_zero_bounds(s, s->u, EO_U);
+  eo_zero_bounds(s, s->v, EO_V);
+  eo_advect_u(s, s->u, s->v, dt, s->utmp);
+  eo_advect_v(s, s->u, s->v, dt, s->vtmp);
+  eo_apply_body_forces(s, s->vtmp, dt);
+  eo_zero_bounds(s, s->utmp, EO_U);
+  eo_zero_bounds(s, s->vtmp, EO_V);
+  int it = eo_project(s, dt, s->utmp, s->vtmp, s->u, s->v);
+  s->total_substeps++;
+  s->last_dt = dt;
+  return it;
+}
+
+void eo_step(eo_sim* s) {
+  float frame_time = 0.1f;
+  int iters = 0, n = 0;
+  for (int step = 0; frame_time > 0.f && step < 8; ++step) {
+    float dt = eo_calculate_timestep(s, frame_time);
+    frame_time -= dt;
+    iters += eo_substep(s, dt);
+    n++;
+  }
+  s->last_substeps = n;
+  s->last_pcg_iterations = iters;
+  s->frame_count++;
+}
+
+/* ---------------------------------------------------------------- render (main.c:914-951) */
+
+int eo_render_rows(const eo_sim* s, int wx, int wy, char* out, int cap) {
+  static const char* sym[4] = {" ", "o", "O", "0"};
+  const char* BLUE = "\x1B[34m"; const char* RESET = "\x1B[0m"; const char* CLR = "\x1b[K";
+  int n = 0;
+#define PUT(str) do { const char* _p = (str); while (*_p) { if (n < cap) out[n] = *_p; n++; _p++; } } while (0)
+  int X = s->X, Y = s->Y;
+  int y_cutoff = (Y - 1 - wy) > 1 ? (Y - 1 - wy) : 1;
+  for (int y = Y - 1; y-- > y_cutoff;) {
+    int prev_water = 0;
+    for (int x = 1; x < X - 1 && x < wx + 1; x++) {
+      size_t i = AT(s, y, x);
+      if (s->solid[i]) {
+        if (prev_water) PUT(RESET);
+        PUT("X");
+        prev_water = 0;
+      } else if (s->sink[i]) {
+        if (prev_water) PUT(RESET);
+        PUT("="); /* the reference leaves prev_water untouched here (main.c:927-931) */
+      } else {
+        int k = s->count[i] < 3 ? s->count[i] : 3;
+        int has_water = k > 0;
+        if (!prev_water && has_water) PUT(BLUE);
+        else if (prev_water && !has_water) PUT(RESET);
+        PUT(sym[k]);
+        prev_water = has_water;
+      }
+    }
+    PUT(RESET); PUT(CLR);
+    if (y > y_cutoff) PUT("\r\n");
+  }
+#undef PUT
+  return n;
+}
+
+uint64_t eo_fnv1a64(const void* data, size_t n) {
+  const unsigned char* p = (const unsigned char*)data;
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
+  return h;
+}

@@ -1,0 +1,97 @@
+/*
+ * euler_oracle.h — TEST ORACLE, not product code.
+ *
+ * A from-scratch CPU restatement of the cgmb/euler simulation path (reference main.c:102-900)
+ * with a run-time grid size.  It exists so that
+ *   (1) tests/ can check the HIP path bit-for-bit / to tolerance on grids the reference cannot
+ *       run (the reference grid is a compile-time enum, main.c:22-25), and
+ *   (2) bench.py's `cpu_baseline` leg can time "the reference CPU path" on the GPU node.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call this.
+ * The product library (euler_amd/csrc) never does.
+ *
+ * Pinning: at X=100,Y=40 the oracle is checked bit-for-bit against the compiled, unmodified
+ * reference (oracle/_ref/libeuler_ref.so) and against the committed fixtures in tests/golden/
+ * (tests/test_oracle_golden.py, tests/test_oracle_vs_ref.py).
+ */
+#ifndef EULER_ORACLE_H
+#define EULER_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct eo_vec2f { float x, y; } eo_vec2f;
+
+typedef struct eo_sim {
+  int X, Y;                 /* grid size (reference: enum X=100,Y=40, main.c:22-25) */
+  float *u, *v, *utmp, *vtmp;           /* main.c:64-67, all [Y][X] */
+  uint8_t *solid, *source, *sink;       /* main.c:71-73 */
+  uint8_t *count, *prev_count;          /* g_marker_count / g_prev_marker_count, main.c:96-97 */
+  eo_vec2f *markers;                    /* main.c:95, capacity 4*X*Y */
+  size_t n_markers, max_markers;        /* main.c:92-93 */
+  int source_exhausted;                 /* main.c:94 */
+  uint64_t rng_state;                   /* main.c:204 (static inside randf) */
+  int8_t *a_diag;                       /* g_a, main.c:552 (stale on non-fluid cells) */
+  double *precon, *q;                   /* g_precon, g_q, main.c:577-578 (precon persists) */
+  double *b, *p, *r, *z, *s;            /* stack locals of project(), main.c:716-745 */
+  /* solver parameters (reference constants main.c:735-736, 849, 851, 838) */
+  int max_iterations;                   /* 100 */
+  double tol;                           /* (double)1e-6f */
+  /* counters the reference does not keep */
+  uint64_t total_substeps, total_pcg_iterations;
+  int last_substeps, last_pcg_iterations;
+  double last_residual;
+  float last_dt;
+  uint32_t frame_count;
+} eo_sim;
+
+eo_sim* eo_create(int X, int Y);
+void    eo_destroy(eo_sim* s);
+
+/* Scenario text -> solid/source/sink + jittered markers (main.c:209-274).
+ * upscale = 0: the reference's streaming parser at the native resolution.
+ * upscale = 1: SURVEY.md §8d nearest-neighbour resample of the W x H text onto the interior. */
+int eo_load_scenario_mem(eo_sim* s, const char* text, int len, int upscale);
+int eo_load_scenario_file(eo_sim* s, const char* path, int upscale);
+/* Synthetic half-filled tank: solid ring at 1 / N-2, fluid y in [2,Y/2). */
+int eo_load_half_tank(eo_sim* s);
+
+/* One frame = sim_step() (main.c:843-900): <= 8 CFL substeps of 0.1 s total. */
+void  eo_step(eo_sim* s);
+/* One substep with a given dt (stages 2-11 of sim_step). Returns PCG iterations. */
+int   eo_substep(eo_sim* s, float dt);
+
+/* individual stages, in sim_step order (for teacher-forced tests) */
+float eo_calculate_timestep(const eo_sim* s, float frame_time);        /* main.c:834-841 */
+void  eo_advect_markers(eo_sim* s, float dt);                          /* main.c:464-537 */
+void  eo_refresh_marker_counts(eo_sim* s);                             /* main.c:102-117 */
+void  eo_update_fluid_sources(eo_sim* s);                              /* main.c:276-298 */
+void  eo_extrapolate(eo_sim* s, float* q, int type);                   /* main.c:173-185 */
+void  eo_zero_bounds(const eo_sim* s, float* q, int type);             /* main.c:822-832 */
+void  eo_advect_u(const eo_sim* s, const float* u, const float* v, float dt, float* out);
+void  eo_advect_v(const eo_sim* s, const float* u, const float* v, float dt, float* out);
+void  eo_apply_body_forces(const eo_sim* s, float* v, float dt);       /* main.c:539-545 */
+int   eo_project(eo_sim* s, float dt, const float* u, const float* v, float* uout, float* vout);
+float eo_interpolate(const eo_sim* s, const float* q, float ix, float iy, int type);
+
+/* PCG building blocks (main.c:580-702), exposed for kernel-level parity tests. */
+void   eo_build_system(eo_sim* s, float dt, const float* u, const float* v); /* b, a_diag */
+void   eo_apply_preconditioner(eo_sim* s, const double* r, double* z);
+void   eo_apply_a(const eo_sim* s, const double* in, double* out);
+double eo_dot(const eo_sim* s, const double* a, const double* b);
+double eo_inf_norm(const eo_sim* s, const double* r);
+
+/* ASCII frame as draw_rows() emits it (main.c:914-951), no cursor codes. Returns length. */
+int eo_render_rows(const eo_sim* s, int wx, int wy, char* out, int cap);
+
+uint64_t eo_fnv1a64(const void* data, size_t n);
+
+enum { EO_P = 0, EO_U = 1, EO_V = 2 };
+
+#ifdef __cplusplus
+}
+#endif
+#endif
