@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on BASELINE.json's configuration.
+
+metric   cells*steps/s of the whole sim_step() path (one step = one 0.1 s frame = up to 8 CFL
+         substeps, each with a <=100-iteration PCG pressure projection), plus the achieved HBM
+         rate of the dominant pressure-solve kernel against the MI355X roofline.
+workload N=1: configs[1], the 1024x1024 dam break (block layout upscaled), synthetic.
+         The reference's precision mix is kept: float fields, double PCG vectors.
+         The dam hangs in the air for ~60 frames of free fall (zero divergence, no pressure
+         solve); the bench first "prerolls" untimed to the first frame that needs the solver so
+         that the timed window is inside the expensive phase, never the free-fall phase.
+
+One JSON line on stdout (rank 0).  Inputs are resident in HBM when the timed region starts.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+# algorithmic bytes per grid cell per launch (w = 8 for double vectors, 1 mask byte)
+W = 8
+ALGO_BYTES = {
+    "forward_solve": 3 * W + 1,    # read r, precon; write q
+    "backward_solve": 3 * W + 1,   # read q, precon; write z     (dot(z,r) is a separate launch here)
+    "apply_a": 2 * W + 1,          # read s; write z (+ in-register dot partial)
+    "dot": 2 * W + 1,              # read z, r
+    "update_pr": 6 * W + 1,        # read s, z, p, r; write p, r
+    "update_search": 3 * W + 1,    # read z, s; write s
+}
+PCG_BYTES_PER_CELL_ITER = 18 * W + 5   # 149 B, the figure BASELINE.md prescribes for IC(0) PCG
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=1024, help="N of the NxN grid (default: configs[1] = 1024)")
+    ap.add_argument("--workload", default="dam_break", choices=["dam_break", "half_tank", "waterfall"])
+    ap.add_argument("--dot-mode", default="tree", choices=["tree", "sequential"])
+    ap.add_argument("--precond", default="ic0", choices=["ic0", "jacobi"])
+    ap.add_argument("--max-preroll", type=int, default=90)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the hipEvent per-kernel timing (used under rocprofv3)")
+    ap.add_argument("--profile-all", action="store_true", help="time every kernel class (diagnostics)")
+    return ap.parse_args()
+
+
+def build_native_oracle():
+    """cpu_baseline leg only: compile the oracle for THIS host (reference flags -O3 -ffast-math
+    -march=native, CMakeLists.txt:11,18, and strict IEEE) into a temp dir."""
+    src = os.path.join(ROOT, "oracle", "euler_oracle.c")
+    out = {}
+    d = tempfile.mkdtemp(prefix="euler_oracle_")
+    for name, flags in (("strict", ["-O3", "-ffp-contract=off"]), ("reference_flags", ["-O3", "-ffast-math", "-march=native"])):
+        so = os.path.join(d, "liboracle_%s.so" % name)
+        subprocess.check_call(["gcc", "-std=gnu99", "-fPIC", "-shared"] + flags + ["-o", so, src, "-lm"])
+        out[name] = so
+    return out
+
+
+def cpu_baseline(sim, ea, steps_budget_s=12.0):
+    """Time the CPU oracle (kind 'port': the from-scratch restatement proven bit-identical to the
+    compiled reference at 100x40) on this host, single thread like the reference, starting from the
+    SAME state the GPU timing starts from.  Bounded sample: one frame (<= 8 substeps)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib
+    libs = build_native_oracle()
+    res = {}
+    snap = {n: sim.get(f) for f, n in ((ea.F_U, "u"), (ea.F_V, "v"), (ea.F_SOLID, "solid"), (ea.F_SOURCE, "source"),
+                                        (ea.F_SINK, "sink"), (ea.F_COUNT, "count"), (ea.F_PREV_COUNT, "prev_count"),
+                                        (ea.F_PRECON, "precon"), (ea.F_MARKERS, "markers"))}
+    st = sim.stats()
+    for name, so in libs.items():
+        o = oracle_lib.Oracle(sim.X, sim.Y, lib_path=so)
+        for n in ("u", "v", "solid", "source", "sink", "count", "prev_count", "precon"):
+            getattr(o, n)[...] = snap[n]
+        o.set_markers(snap["markers"])
+        o.c.rng_state = st.rng_state
+        o.c.source_exhausted = st.source_exhausted
+        t0 = time.perf_counter()
+        nsteps = 0
+        while True:
+            o.step()
+            nsteps += 1
+            if time.perf_counter() - t0 > steps_budget_s or nsteps >= 3:
+                break
+        dt = time.perf_counter() - t0
+        res[name] = dict(value=sim.X * sim.Y * nsteps / dt, seconds=dt, steps=nsteps,
+                         substeps=int(o.c.total_substeps), pcg_iterations=int(o.c.total_pcg_iterations))
+        if name == "strict":
+            res["_oracle_after"] = (o.u.copy(), o.v.copy(), (o.count > 0).copy(), nsteps)
+        o.close()
+    return res
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import euler_amd as ea
+    from euler_amd import scenarios
+
+    N = args.size
+    dot_mode = ea.DOT_TREE if args.dot_mode == "tree" else ea.DOT_SEQUENTIAL
+    precond = ea.PRECOND_IC0 if args.precond == "ic0" else ea.PRECOND_JACOBI
+    sim = ea.Simulation(N, N, device=local_rank, dot_mode=dot_mode, precond=precond)
+    if args.workload == "dam_break":
+        sim.load_text(scenarios.dam_break(), upscale=True)
+    elif args.workload == "waterfall":
+        sim.load_text(scenarios.waterfall(), upscale=True)
+    else:
+        sim.load_half_tank()
+
+    # untimed preroll to the first frame that needs the pressure solver (see module docstring)
+    preroll = 0
+    while preroll < args.max_preroll:
+        sim.step()
+        preroll += 1
+        if sim.stats().last_pcg_iterations > 0:
+            break
+
+    # CPU baseline from the same state (rank 0, N=1 only)
+    cpu = None
+    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(sim, ea)
+
+    # in-run parity note: advance the GPU by the same number of frames the strict-IEEE oracle ran
+    parity = None
+    warm_done = 0
+    if cpu and "_oracle_after" in cpu:
+        import numpy as np
+        ou, ov, ofl, k = cpu.pop("_oracle_after")
+        for _ in range(k):
+            sim.step()
+        warm_done = k
+        gu, gv, gfl = sim.get(ea.F_U), sim.get(ea.F_V), sim.get(ea.F_COUNT) > 0
+        parity = {"frames": k, "max_abs_du": float(np.abs(gu - ou).max()), "max_abs_dv": float(np.abs(gv - ov).max()),
+                  "fluid_cells_differing": int((gfl != ofl).sum()), "vs": "oracle (strict IEEE build) from the same state"}
+    for _ in range(max(args.warmup - warm_done, 0)):
+        sim.step()
+
+    dominant = "backward_solve" if precond == ea.PRECOND_IC0 else "update_pr"
+    timed_classes = list(ALGO_BYTES) if not args.no_kernel_timing else []
+    if args.profile_all:
+        timed_classes = ea.profile_class_names()
+    sim.profile_reset()
+    if timed_classes:
+        sim.profile_enable(timed_classes)
+    st0 = sim.stats()
+
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sim.step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    st1 = sim.stats()
+    prof = sim.profile() if timed_classes else {}
+    sim.profile_enable([])
+    substeps = st1.total_substeps - st0.total_substeps
+    iters = st1.total_pcg_iterations - st0.total_pcg_iterations
+    cells = N * N
+
+    if rank != 0:
+        if dist:
+            dist.destroy_process_group()
+        return
+
+    roof = None
+    kern = {}
+    for name, (ms, launches) in prof.items():
+        entry = {"ms_total": round(ms, 3), "launches": int(launches), "avg_us": round(1e3 * ms / launches, 2)}
+        if name in ALGO_BYTES:
+            entry["algo_GBps"] = round(ALGO_BYTES[name] * cells / (ms / launches * 1e-3) / 1e9, 1)
+        kern[name] = entry
+    if dominant in prof:
+        ms, launches = prof[dominant]
+        achieved = ALGO_BYTES[dominant] * cells / (ms / launches * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                "algorithmic_bytes_per_launch": ALGO_BYTES[dominant] * cells,
+                "avg_launch_us": round(1e3 * ms / launches, 2), "launches": int(launches)}
+    pcg_ms = sum(prof[k][0] for k in ALGO_BYTES if k in prof) + sum(prof[k][0] for k in ("reduce_final",) if k in prof)
+    pcg_gbps = PCG_BYTES_PER_CELL_ITER * cells * iters / (pcg_ms * 1e-3) / 1e9 if pcg_ms and iters else None
+
+    cpu_obj = None
+    if cpu:
+        ref = cpu["reference_flags"]
+        cpu_obj = {"value": round(ref["value"], 1), "unit": "cells*steps/s", "cores": 1, "kind": "port",
+                   "sample": "%d frame(s) (%d substeps, %d PCG iterations) of the same %dx%d %s state the GPU timing starts from; "
+                             "oracle/euler_oracle.c built -O3 -ffast-math -march=native (the reference's CMake flags), single thread"
+                             % (ref["steps"], ref["substeps"], ref["pcg_iterations"], N, N, args.workload),
+                   "strict_ieee_value": round(cpu["strict"]["value"], 1), "cpu_model": cpu_model(),
+                   "host_cores_available": os.cpu_count()}
+
+    out = {
+        "metric": "cells*steps/sec of sim_step() (dam-break frames incl. PCG pressure projection)",
+        "value": cells * args.steps * max(args.gpus, 1) / elapsed,
+        "unit": "cells*steps/s",
+        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32 fields, f64 PCG (the reference's mix)",
+        "data": "synthetic",
+        "config": {"workload": "%dx%d %s, %s" % (N, N, args.workload, "block layout upscaled" if args.workload == "dam_break" else "synthetic"),
+                   "grid": [N, N], "preroll_frames": preroll, "precond": args.precond, "dot_mode": args.dot_mode,
+                   "max_iterations": 100, "tol": 1e-6,
+                   "parallelism": "1 GPU" if args.gpus == 1 else "%d independent replicas (row-slab decomposition: see DESIGN.md)" % args.gpus},
+        "substeps": int(substeps), "pcg_iterations": int(iters),
+        "cells_substeps_per_s": cells * substeps / elapsed,
+        "markers": int(st1.n_markers), "fluid_cells": int(st1.fluid_cells),
+        "roofline": roof,
+        "pcg_aggregate": {"algorithmic_GBps": round(pcg_gbps, 1) if pcg_gbps else None,
+                          "bytes_per_cell_iteration": PCG_BYTES_PER_CELL_ITER, "kernel_ms": round(pcg_ms, 2)},
+        "kernels": kern,
+        "cpu_baseline": cpu_obj,
+        "parity_in_run": parity,
+        "device": sim.device_name(),
+    }
+    print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,294 @@
+"""euler_amd — host-side binding of libeuler_hip.so, the MI355X-native simulation path of
+cgmb/euler (reference main.c: sim_init :209, sim_step :843, draw :953).
+
+This module is plumbing over the C ABI declared in include/euler.h (ctypes; no torch types cross
+the boundary).  There is NO CPU implementation behind it: if the shared library is missing, or
+no gfx950 device is present, construction fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libeuler_hip.so")
+
+# --- enums of include/euler.h ------------------------------------------------------------------
+DOT_AUTO, DOT_SEQUENTIAL, DOT_TREE = 0, 1, 2
+PRECOND_IC0, PRECOND_JACOBI = 0, 1
+SWEEP_AUTO, SWEEP_BAND, SWEEP_SIMPLE = 0, 1, 2
+(F_U, F_V, F_UTMP, F_VTMP, F_SOLID, F_SOURCE, F_SINK, F_COUNT, F_PREV_COUNT, F_MARKERS, F_PRECON,
+ F_PRESSURE, F_PCG_B, F_PCG_R, F_PCG_Z, F_PCG_S, F_PCG_Q, F_CELLMASK) = range(18)
+(STAGE_ADVECT_MARKERS, STAGE_REFRESH_COUNTS, STAGE_SOURCES, STAGE_EXTRAPOLATE, STAGE_ADVECT_VELOCITY,
+ STAGE_PROJECT) = range(6)
+(OP_BUILD_SYSTEM, OP_PRECON_FACTOR, OP_FORWARD_SOLVE, OP_BACKWARD_SOLVE, OP_APPLY_A, OP_DOT_ZR, OP_DOT_ZS,
+ OP_INF_NORM_R, OP_UPDATE_PR, OP_UPDATE_SEARCH) = range(10)
+
+_FIELD_DTYPE = {
+    F_U: np.float32, F_V: np.float32, F_UTMP: np.float32, F_VTMP: np.float32,
+    F_SOLID: np.uint8, F_SOURCE: np.uint8, F_SINK: np.uint8, F_COUNT: np.uint8, F_PREV_COUNT: np.uint8,
+    F_MARKERS: np.float32, F_PRECON: np.float64, F_PRESSURE: np.float64, F_PCG_B: np.float64,
+    F_PCG_R: np.float64, F_PCG_Z: np.float64, F_PCG_S: np.float64, F_PCG_Q: np.float64, F_CELLMASK: np.uint8,
+}
+
+
+class EulerError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libeuler_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("X", C.c_int32), ("Y", C.c_int32), ("device", C.c_int32),
+        ("max_iterations", C.c_int32), ("tol", C.c_double), ("dot_mode", C.c_int32), ("precond", C.c_int32),
+        ("sweep_mode", C.c_int32), ("max_substeps", C.c_int32), ("frame_time", C.c_float),
+        ("viscosity", C.c_float), ("pcg_poll_interval", C.c_int32), ("reserved", C.c_int32 * 8),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("frames", C.c_uint64), ("total_substeps", C.c_uint64), ("total_pcg_iterations", C.c_uint64),
+        ("last_substeps", C.c_int32), ("last_pcg_iterations", C.c_int32), ("last_residual", C.c_double),
+        ("last_dt", C.c_float), ("n_markers", C.c_uint64), ("source_exhausted", C.c_int32),
+        ("rng_state", C.c_uint64), ("marker_dt_events", C.c_uint64), ("marker_multi_events", C.c_uint64),
+        ("fluid_cells", C.c_uint64),
+    ]
+
+
+_lib = None
+
+EXPORTS = [
+    "euler_config_default", "euler_create", "euler_destroy", "euler_last_error", "euler_abi_version",
+    "euler_load_scenario_mem", "euler_load_scenario_file", "euler_load_half_tank", "euler_parse_scenario",
+    "euler_seed_markers", "euler_step", "euler_timestep", "euler_substep", "euler_stage", "euler_pcg_op",
+    "euler_get_field", "euler_set_field", "euler_set_markers", "euler_set_rng", "euler_get_stats",
+    "euler_field_bytes", "euler_render", "euler_render_grids", "euler_profile_enable",
+    "euler_profile_class_count", "euler_profile_class_name", "euler_profile_get", "euler_profile_reset",
+    "euler_measure_copy_bandwidth", "euler_device_name",
+]
+
+
+def load_library():
+    """dlopen libeuler_hip.so (built in-tree by `make -C euler_amd/csrc`). Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "euler_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C euler_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u64, f32, f64 = C.c_void_p, C.c_int32, C.c_uint64, C.c_float, C.c_double
+    sig = {
+        "euler_config_default": (C.c_int, [C.POINTER(Config)]),
+        "euler_create": (C.c_int, [C.POINTER(Config), C.POINTER(vp)]),
+        "euler_destroy": (None, [vp]),
+        "euler_last_error": (C.c_char_p, []),
+        "euler_abi_version": (C.c_int, []),
+        "euler_load_scenario_mem": (C.c_int, [vp, C.c_char_p, i32, i32]),
+        "euler_load_scenario_file": (C.c_int, [vp, C.c_char_p, i32]),
+        "euler_load_half_tank": (C.c_int, [vp]),
+        "euler_parse_scenario": (C.c_int, [C.c_char_p, i32, i32, i32, i32, vp, vp, vp, vp]),
+        "euler_seed_markers": (C.c_int, [vp, i32, i32, C.POINTER(u64), vp, C.POINTER(u64)]),
+        "euler_step": (C.c_int, [vp]),
+        "euler_timestep": (C.c_int, [vp, f32, C.POINTER(f32)]),
+        "euler_substep": (C.c_int, [vp, f32]),
+        "euler_stage": (C.c_int, [vp, i32, f32]),
+        "euler_pcg_op": (C.c_int, [vp, i32, f32, f64, C.POINTER(f64)]),
+        "euler_get_field": (C.c_int, [vp, i32, vp, C.c_size_t]),
+        "euler_set_field": (C.c_int, [vp, i32, vp, C.c_size_t]),
+        "euler_set_markers": (C.c_int, [vp, vp, u64]),
+        "euler_set_rng": (C.c_int, [vp, u64, i32]),
+        "euler_get_stats": (C.c_int, [vp, C.POINTER(Stats)]),
+        "euler_field_bytes": (C.c_size_t, [vp, i32]),
+        "euler_render": (C.c_int, [vp, i32, i32, C.c_char_p, i32, C.POINTER(i32)]),
+        "euler_render_grids": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, C.c_char_p, i32, C.POINTER(i32)]),
+        "euler_profile_enable": (C.c_int, [vp, u64]),
+        "euler_profile_class_count": (C.c_int, []),
+        "euler_profile_class_name": (C.c_char_p, [i32]),
+        "euler_profile_get": (C.c_int, [vp, i32, C.POINTER(f64), C.POINTER(u64)]),
+        "euler_profile_reset": (C.c_int, [vp]),
+        "euler_measure_copy_bandwidth": (C.c_int, [vp, C.c_size_t, i32, C.POINTER(f64)]),
+        "euler_device_name": (C.c_int, [vp, C.c_char_p, i32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)   # AttributeError here = a symbol include/euler.h declares is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise EulerError(rc, load_library().euler_last_error().decode(errors="replace"))
+
+
+# --- host-only helpers (no GPU) ------------------------------------------------------------------
+def parse_scenario(text, X, Y, upscale=False):
+    """Scenario text -> (solid, source, sink, fluid) uint8 [Y][X] (reference main.c:217-252)."""
+    if isinstance(text, str):
+        text = text.encode()
+    out = [np.zeros((Y, X), np.uint8) for _ in range(4)]
+    _check(load_library().euler_parse_scenario(text, len(text), X, Y, int(upscale), *[a.ctypes.data for a in out]))
+    return tuple(out)
+
+
+def seed_markers(fluid, rng_state=0x9bd185c449534b91):
+    """Four jittered markers per fluid cell (reference main.c:255-266). Returns (markers[n,2], rng_state)."""
+    fluid = np.ascontiguousarray(fluid, np.uint8)
+    Y, X = fluid.shape
+    m = np.zeros((4 * X * Y, 2), np.float32)
+    st, n = C.c_uint64(rng_state), C.c_uint64(0)
+    _check(load_library().euler_seed_markers(fluid.ctypes.data, X, Y, C.byref(st), m.ctypes.data, C.byref(n)))
+    return m[: n.value].copy(), st.value
+
+
+def render_grids(solid, sink, count, wx, wy):
+    """draw_rows() over host grids (reference main.c:914-951)."""
+    Y, X = count.shape
+    L = load_library()
+    n = C.c_int32(0)
+    a = [np.ascontiguousarray(g, np.uint8) for g in (solid, sink, count)]
+    _check(L.euler_render_grids(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, X, Y, wx, wy, None, 0, C.byref(n)))
+    buf = C.create_string_buffer(max(n.value, 1))
+    _check(L.euler_render_grids(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, X, Y, wx, wy, buf, n.value, C.byref(n)))
+    return buf.raw[: n.value]
+
+
+def profile_class_names():
+    L = load_library()
+    return [L.euler_profile_class_name(i).decode() for i in range(L.euler_profile_class_count())]
+
+
+class Simulation:
+    """One simulation on one MI355X.  Mirrors the reference's surface: sim_init / sim_step / draw,
+    plus state access for parity tests."""
+
+    def __init__(self, X=100, Y=40, device=0, dot_mode=DOT_AUTO, precond=PRECOND_IC0, sweep_mode=SWEEP_AUTO,
+                 max_iterations=100, tol=None, pcg_poll_interval=8):
+        self.L = load_library()
+        cfg = Config()
+        _check(self.L.euler_config_default(C.byref(cfg)))
+        cfg.X, cfg.Y, cfg.device = X, Y, device
+        cfg.dot_mode, cfg.precond, cfg.sweep_mode = dot_mode, precond, sweep_mode
+        cfg.max_iterations = max_iterations
+        if tol is not None:
+            cfg.tol = tol
+        cfg.pcg_poll_interval = pcg_poll_interval
+        self.cfg = cfg
+        self.X, self.Y = X, Y
+        self.h = C.c_void_p()
+        _check(self.L.euler_create(C.byref(cfg), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.euler_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- reference surface
+    def sim_init(self, scenario_file, upscale=False):
+        _check(self.L.euler_load_scenario_file(self.h, os.fsencode(scenario_file), int(upscale)))
+        return self
+
+    def load_text(self, text, upscale=False):
+        if isinstance(text, str):
+            text = text.encode()
+        _check(self.L.euler_load_scenario_mem(self.h, text, len(text), int(upscale)))
+        return self
+
+    def load_half_tank(self):
+        _check(self.L.euler_load_half_tank(self.h))
+        return self
+
+    def sim_step(self):
+        _check(self.L.euler_step(self.h))
+
+    step = sim_step
+
+    def draw(self, wx, wy):
+        n = C.c_int32(0)
+        _check(self.L.euler_render(self.h, wx, wy, None, 0, C.byref(n)))
+        buf = C.create_string_buffer(max(n.value, 1))
+        _check(self.L.euler_render(self.h, wx, wy, buf, n.value, C.byref(n)))
+        return buf.raw[: n.value]
+
+    # --- finer control
+    def timestep(self, frame_time_left=0.1):
+        dt = C.c_float(0)
+        _check(self.L.euler_timestep(self.h, frame_time_left, C.byref(dt)))
+        return dt.value
+
+    def substep(self, dt):
+        _check(self.L.euler_substep(self.h, dt))
+
+    def stage(self, stage, dt=0.0):
+        _check(self.L.euler_stage(self.h, stage, dt))
+
+    def pcg_op(self, op, dt=0.0, scalar=0.0):
+        out = C.c_double(0)
+        _check(self.L.euler_pcg_op(self.h, op, dt, scalar, C.byref(out)))
+        return out.value
+
+    # --- state
+    def get(self, field):
+        nbytes = self.L.euler_field_bytes(self.h, field)
+        dt = np.dtype(_FIELD_DTYPE[field])
+        a = np.empty(nbytes // dt.itemsize, dt)
+        if nbytes:
+            _check(self.L.euler_get_field(self.h, field, a.ctypes.data, nbytes))
+        return a.reshape(-1, 2) if field == F_MARKERS else a.reshape(self.Y, self.X)
+
+    def set(self, field, arr):
+        a = np.ascontiguousarray(arr, _FIELD_DTYPE[field])
+        _check(self.L.euler_set_field(self.h, field, a.ctypes.data, a.nbytes))
+
+    def set_markers(self, m):
+        a = np.ascontiguousarray(m, np.float32).reshape(-1, 2)
+        _check(self.L.euler_set_markers(self.h, a.ctypes.data, len(a)))
+
+    def set_rng(self, state, exhausted=0):
+        _check(self.L.euler_set_rng(self.h, int(state), int(exhausted)))
+
+    def stats(self):
+        s = Stats()
+        _check(self.L.euler_get_stats(self.h, C.byref(s)))
+        return s
+
+    # --- measurement
+    def profile_enable(self, classes):
+        names = profile_class_names()
+        mask = 0
+        for c in classes:
+            mask |= 1 << (names.index(c) if isinstance(c, str) else c)
+        _check(self.L.euler_profile_enable(self.h, mask))
+
+    def profile_reset(self):
+        _check(self.L.euler_profile_reset(self.h))
+
+    def profile(self):
+        out = {}
+        for i, n in enumerate(profile_class_names()):
+            ms, k = C.c_double(0), C.c_uint64(0)
+            _check(self.L.euler_profile_get(self.h, i, C.byref(ms), C.byref(k)))
+            if k.value:
+                out[n] = (ms.value, k.value)
+        return out
+
+    def copy_bandwidth(self, nbytes=1 << 30, reps=10):
+        g = C.c_double(0)
+        _check(self.L.euler_measure_copy_bandwidth(self.h, nbytes, reps, C.byref(g)))
+        return g.value
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        _check(self.L.euler_device_name(self.h, buf, 256))
+        return buf.value.decode()

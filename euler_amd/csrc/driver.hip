@@ -1,0 +1,572 @@
+// driver.hip — the C ABI of libeuler_hip.so (include/euler.h): handle life cycle, scenario upload,
+// the sim_step() driver (reference main.c:843-900), state access, render, measurement.
+#include "euler_dev.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+int eu_launch_build_system(euler_sim* S, float dt);
+int eu_launch_velocity_update(euler_sim* S, float dt);
+
+// ------------------------------------------------------------------------------------------
+// errors
+static thread_local char g_err[512] = "";
+
+void eu_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int eu_hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  eu_set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+  return EULER_EHIP;
+}
+
+extern "C" const char* euler_last_error(void) { return g_err; }
+extern "C" int euler_abi_version(void) { return EULER_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------------------
+// profiling: hipEvent pairs around the launches of the enabled kernel classes
+static const char* k_class_names[KC__COUNT] = {
+    "timestep", "marker_advect", "marker_events", "marker_bin", "marker_compact", "sources", "select",
+    "extrapolate", "advect_velocity", "build_system", "precon_factor", "forward_solve", "backward_solve",
+    "apply_a", "dot", "update_pr", "update_search", "reduce_final", "velocity_update", "jacobi", "misc"};
+
+void eu_prof_begin(euler_sim* S, int cls) {
+  if (!((S->prof_mask >> cls) & 1)) return;
+  if (S->ev_used + 2 > S->ev_cap) eu_prof_flush(S);
+  S->ev_cls[S->ev_used / 2] = cls;
+  (void)hipEventRecord(S->ev_pool[S->ev_used], S->stream);
+}
+void eu_prof_end(euler_sim* S, int cls) {
+  if (!((S->prof_mask >> cls) & 1)) return;
+  (void)hipEventRecord(S->ev_pool[S->ev_used + 1], S->stream);
+  S->ev_used += 2;
+}
+int eu_prof_flush(euler_sim* S) {
+  if (S->ev_used == 0) return EULER_OK;
+  HIPCHK(hipStreamSynchronize(S->stream));
+  for (int k = 0; k < S->ev_used; k += 2) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, S->ev_pool[k], S->ev_pool[k + 1]) == hipSuccess) {
+      S->prof_ms[S->ev_cls[k / 2]] += ms;
+      S->prof_launches[S->ev_cls[k / 2]] += 1;
+    }
+  }
+  S->ev_used = 0;
+  return EULER_OK;
+}
+
+extern "C" int euler_profile_class_count(void) { return KC__COUNT; }
+extern "C" const char* euler_profile_class_name(int32_t c) { return (c >= 0 && c < KC__COUNT) ? k_class_names[c] : ""; }
+extern "C" int euler_profile_enable(euler_sim* S, uint64_t mask) {
+  if (!S) return EULER_EINVAL;
+  int rc = eu_prof_flush(S);
+  S->prof_mask = mask;
+  return rc;
+}
+extern "C" int euler_profile_get(euler_sim* S, int32_t cls, double* ms, uint64_t* launches) {
+  if (!S || cls < 0 || cls >= KC__COUNT) return EULER_EINVAL;
+  int rc = eu_prof_flush(S);
+  if (ms) *ms = S->prof_ms[cls];
+  if (launches) *launches = S->prof_launches[cls];
+  return rc;
+}
+extern "C" int euler_profile_reset(euler_sim* S) {
+  if (!S) return EULER_EINVAL;
+  int rc = eu_prof_flush(S);
+  memset(S->prof_ms, 0, sizeof(S->prof_ms));
+  memset(S->prof_launches, 0, sizeof(S->prof_launches));
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// life cycle
+extern "C" int euler_config_default(euler_config* c) {
+  if (!c) return EULER_EINVAL;
+  memset(c, 0, sizeof(*c));
+  c->abi_version = EULER_ABI_VERSION;
+  c->X = 100; c->Y = 40;            // main.c:22-25
+  c->device = 0;
+  c->max_iterations = 100;          // main.c:735
+  c->tol = (double)1e-6f;           // main.c:736
+  c->dot_mode = EULER_DOT_AUTO;
+  c->precond = EULER_PRECOND_IC0;
+  c->sweep_mode = EULER_SWEEP_AUTO;
+  c->max_substeps = 8;              // main.c:851
+  c->frame_time = 0.1f;             // main.c:849
+  c->viscosity = 0.f;
+  c->pcg_poll_interval = 8;
+  return EULER_OK;
+}
+
+template <typename T>
+static int dalloc(T** p, size_t n) {
+  HIPCHK(hipMalloc((void**)p, n * sizeof(T)));
+  HIPCHK(hipMemset(*p, 0, n * sizeof(T)));
+  return EULER_OK;
+}
+#define DALLOC(p, n) do { int _rc = dalloc(&(p), (n)); if (_rc) { euler_destroy(S); return _rc; } } while (0)
+
+extern "C" void euler_destroy(euler_sim* S) {
+  if (!S) return;
+  if (S->stream) (void)hipStreamSynchronize(S->stream);
+  void* dev[] = {S->u, S->v, S->utmp, S->vtmp, S->solid, S->source, S->sink, S->count, S->prev_count, S->count32,
+                 S->markers[0], S->markers[1], S->ms, S->evmask, S->ev_theta, S->ev_delta, S->sel_idx, S->act_idx,
+                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->b, S->p, S->r, S->z, S->s, S->q, S->precon,
+                 S->cellmask, S->sc, S->partial, S->granules, S->ticket};
+  for (void* p : dev) if (p) (void)hipFree(p);
+  if (S->ms_host) (void)hipHostFree(S->ms_host);
+  if (S->sc_host) (void)hipHostFree(S->sc_host);
+  if (S->ev_pool) { for (int k = 0; k < S->ev_cap; ++k) (void)hipEventDestroy(S->ev_pool[k]); free(S->ev_pool); }
+  free(S->ev_cls);
+  if (S->stream) (void)hipStreamDestroy(S->stream);
+  free(S);
+}
+
+extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
+  if (!cfg || !out) { eu_set_error("euler_create: null argument"); return EULER_EINVAL; }
+  if (cfg->abi_version != EULER_ABI_VERSION) { eu_set_error("euler_create: ABI version %d != %d", cfg->abi_version, EULER_ABI_VERSION); return EULER_EINVAL; }
+  if (cfg->X < 8 || cfg->Y < 8 || (size_t)cfg->X * cfg->Y > (size_t)1 << 30) { eu_set_error("euler_create: grid %dx%d out of range", cfg->X, cfg->Y); return EULER_EINVAL; }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    eu_set_error("euler_create: no HIP device (%s); libeuler_hip has no CPU path", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return EULER_EHIP;
+  }
+  if (cfg->device < 0 || cfg->device >= ndev) { eu_set_error("euler_create: device %d of %d", cfg->device, ndev); return EULER_EINVAL; }
+  HIPCHK(hipSetDevice(cfg->device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    eu_set_error("euler_create: device is %s; this library carries gfx950 code only", prop.gcnArchName);
+    return EULER_EHIP;
+  }
+
+  euler_sim* S = (euler_sim*)calloc(1, sizeof(euler_sim));
+  if (!S) return EULER_ENOMEM;
+  S->cfg = *cfg;
+  if (S->cfg.max_iterations <= 0) S->cfg.max_iterations = 100;
+  if (S->cfg.max_substeps <= 0) S->cfg.max_substeps = 8;
+  if (S->cfg.frame_time <= 0.f) S->cfg.frame_time = 0.1f;
+  S->X = cfg->X; S->Y = cfg->Y;
+  const size_t C = S->C = (size_t)cfg->X * cfg->Y;
+  if (S->cfg.dot_mode == EULER_DOT_AUTO) S->cfg.dot_mode = C <= 65536 ? EULER_DOT_SEQUENTIAL : EULER_DOT_TREE;
+  if (S->cfg.sweep_mode == EULER_SWEEP_AUTO) S->cfg.sweep_mode = EULER_SWEEP_BAND;
+  HIPCHK(hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking));
+
+  DALLOC(S->u, C); DALLOC(S->v, C); DALLOC(S->utmp, C); DALLOC(S->vtmp, C);
+  DALLOC(S->solid, C); DALLOC(S->source, C); DALLOC(S->sink, C); DALLOC(S->count, C); DALLOC(S->prev_count, C);
+  DALLOC(S->count32, C);
+  S->max_markers = 4 * C;   // MAX_MARKER_COUNT, main.c:92
+  DALLOC(S->markers[0], S->max_markers); DALLOC(S->markers[1], S->max_markers);
+  DALLOC(S->ms, 1);
+  const size_t mwords = (S->max_markers + 63) / 64;
+  DALLOC(S->evmask, mwords);
+  DALLOC(S->ev_theta, S->max_markers); DALLOC(S->ev_delta, S->max_markers);
+  S->sel_cap = S->max_markers;
+  DALLOC(S->sel_idx, S->sel_cap);
+  DALLOC(S->act_idx, S->max_markers); DALLOC(S->act_dt, S->max_markers);
+  DALLOC(S->cellmask64, (C + 63) / 64);
+  S->sel.capacity_blocks = (mwords + 2047) / 2048 + 1;
+  DALLOC(S->sel.block_sums, S->sel.capacity_blocks);
+  DALLOC(S->b, C); DALLOC(S->p, C); DALLOC(S->r, C); DALLOC(S->z, C); DALLOC(S->s, C); DALLOC(S->q, C); DALLOC(S->precon, C);
+  DALLOC(S->cellmask, C);
+  DALLOC(S->sc, 1);
+  S->red_blocks = (int)eu_blocks(C, 256 * 16, 2048);
+  DALLOC(S->partial, (size_t)S->red_blocks);
+  S->nbands = (S->Y + 63) / 64;
+  DALLOC(S->granules, (size_t)S->nbands * S->X * 2);
+  DALLOC(S->ticket, 1);
+  S->ticket_base = 0; S->epoch = 0;
+  HIPCHK(hipHostMalloc((void**)&S->ms_host, sizeof(MarkerState), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&S->sc_host, sizeof(PcgScalars), hipHostMallocDefault));
+  memset(S->ms_host, 0, sizeof(MarkerState)); memset(S->sc_host, 0, sizeof(PcgScalars));
+
+  S->interp_lim[0] = nextafterf((float)(S->X - 2), 0.f);   // U extent (X-1, Y): size-1
+  S->interp_lim[1] = nextafterf((float)(S->Y - 1), 0.f);
+  S->interp_lim[2] = nextafterf((float)(S->X - 1), 0.f);   // V extent (X, Y-1)
+  S->interp_lim[3] = nextafterf((float)(S->Y - 2), 0.f);
+
+  S->ev_cap = 8192;
+  S->ev_pool = (hipEvent_t*)calloc((size_t)S->ev_cap, sizeof(hipEvent_t));
+  S->ev_cls = (int*)calloc((size_t)S->ev_cap / 2, sizeof(int));
+  if (!S->ev_pool || !S->ev_cls) { euler_destroy(S); return EULER_ENOMEM; }
+  for (int k = 0; k < S->ev_cap; ++k) HIPCHK(hipEventCreate(&S->ev_pool[k]));
+  HIPCHK(hipStreamSynchronize(S->stream));
+  *out = S;
+  return EULER_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// scenario upload = the device side of sim_init (main.c:209-274)
+static int upload_scenario(euler_sim* S, const uint8_t* solid, const uint8_t* source, const uint8_t* sink,
+                           const uint8_t* fluid) {
+  const size_t C = S->C;
+  std::vector<float> mk;
+  try { mk.resize(2 * S->max_markers); } catch (...) { return EULER_ENOMEM; }
+  uint64_t rng = EULER_RNG_SEED, n = 0;
+  int rc = euler_seed_markers(fluid, S->X, S->Y, &rng, mk.data(), &n);
+  if (rc) return rc;
+  size_t nsrc = 0;
+  for (size_t i = 0; i < C; ++i) nsrc += source[i] != 0;
+  S->n_source_cells = nsrc;
+  if (S->draws) { (void)hipFree(S->draws); S->draws = nullptr; }
+  if (nsrc) HIPCHK(hipMalloc((void**)&S->draws, 2 * nsrc * sizeof(float)));
+
+  hipStream_t st = S->stream;
+  HIPCHK(hipMemcpyAsync(S->solid, solid, C, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(S->source, source, C, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(S->sink, sink, C, hipMemcpyHostToDevice, st));
+  for (float* f : {S->u, S->v, S->utmp, S->vtmp}) HIPCHK(hipMemsetAsync(f, 0, C * sizeof(float), st));
+  for (double* d : {S->b, S->p, S->r, S->z, S->s, S->q, S->precon}) HIPCHK(hipMemsetAsync(d, 0, C * sizeof(double), st));
+  HIPCHK(hipMemsetAsync(S->count, 0, C, st));
+  HIPCHK(hipMemsetAsync(S->prev_count, 0, C, st));
+  HIPCHK(hipMemsetAsync(S->cellmask, 0, C, st));
+  S->cur = 0;
+  HIPCHK(hipMemcpyAsync(S->markers[0], mk.data(), n * sizeof(float2), hipMemcpyHostToDevice, st));
+  MarkerState m0;
+  memset(&m0, 0, sizeof(m0));
+  m0.n = n; m0.max_markers = S->max_markers; m0.rng_state = rng;
+  HIPCHK(hipMemcpyAsync(S->ms, &m0, sizeof(m0), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  S->n_markers_host = n;
+  // sim_init ends with refresh_marker_counts() (main.c:268): prev <- 0, counts <- bins
+  rc = eu_launch_refresh_counts(S);
+  if (rc) return rc;
+  rc = eu_sync_marker_state(S);
+  if (rc) return rc;
+  memset(&S->stats, 0, sizeof(S->stats));
+  S->loaded = 1;
+  return EULER_OK;
+}
+
+static int load_from_grids(euler_sim* S, int (*fill)(void*, uint8_t*, uint8_t*, uint8_t*, uint8_t*), void* ctx) {
+  const size_t C = S->C;
+  uint8_t* g = (uint8_t*)malloc(4 * C);
+  if (!g) return EULER_ENOMEM;
+  int rc = fill(ctx, g, g + C, g + 2 * C, g + 3 * C);
+  if (!rc) rc = upload_scenario(S, g, g + C, g + 2 * C, g + 3 * C);
+  free(g);
+  return rc;
+}
+
+struct TextCtx { const char* text; int len; int upscale; int X, Y; };
+static int fill_text(void* c, uint8_t* so, uint8_t* sr, uint8_t* si, uint8_t* fl) {
+  TextCtx* t = (TextCtx*)c;
+  return euler_parse_scenario(t->text, t->len, t->X, t->Y, t->upscale, so, sr, si, fl);
+}
+static int fill_tank(void* c, uint8_t* so, uint8_t* sr, uint8_t* si, uint8_t* fl) {
+  euler_sim* S = (euler_sim*)c;
+  return euler_half_tank_grids(S->X, S->Y, so, sr, si, fl);
+}
+
+extern "C" int euler_load_scenario_mem(euler_sim* S, const char* text, int32_t len, int32_t upscale) {
+  if (!S || !text || len < 0) { eu_set_error("euler_load_scenario_mem: bad argument"); return EULER_EINVAL; }
+  TextCtx t{text, len, upscale, S->X, S->Y};
+  return load_from_grids(S, fill_text, &t);
+}
+
+extern "C" int euler_load_scenario_file(euler_sim* S, const char* path, int32_t upscale) {
+  if (!S || !path) return EULER_EINVAL;
+  FILE* f = fopen(path, "rb");
+  if (!f) { eu_set_error("Could not load %s!", path); return EULER_EIO; }   // main.c:213
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  char* buf = (char*)malloc((size_t)n + 1);
+  if (!buf || (n > 0 && fread(buf, (size_t)n, 1, f) != 1)) { fclose(f); free(buf); eu_set_error("Could not load %s!", path); return EULER_EIO; }
+  fclose(f);
+  int rc = euler_load_scenario_mem(S, buf, (int32_t)n, upscale);
+  free(buf);
+  return rc;
+}
+
+extern "C" int euler_load_half_tank(euler_sim* S) {
+  if (!S) return EULER_EINVAL;
+  return load_from_grids(S, fill_tank, S);
+}
+
+// ------------------------------------------------------------------------------------------
+// stepping
+int eu_sync_marker_state(euler_sim* S) {
+  HIPCHK(hipMemcpyAsync(S->ms_host, S->ms, sizeof(MarkerState), hipMemcpyDeviceToHost, S->stream));
+  HIPCHK(hipStreamSynchronize(S->stream));
+  S->n_markers_host = S->ms_host->n;
+  if (S->ms_host->error) {
+    eu_set_error("device-side bounded wait expired (band pipeline), error=%d", S->ms_host->error);
+    return EULER_ETIMEOUT;
+  }
+  return EULER_OK;
+}
+
+extern "C" int euler_timestep(euler_sim* S, float frame_time_left, float* dt) {
+  if (!S || !S->loaded) { eu_set_error("euler_timestep: no scenario loaded"); return EULER_ESTATE; }
+  int rc = eu_launch_timestep(S, frame_time_left);
+  if (rc) return rc;
+  rc = eu_sync_marker_state(S);   // one host round trip per substep: dt, marker count, error flag
+  if (rc) return rc;
+  if (dt) *dt = S->ms_host->dt;
+  return EULER_OK;
+}
+
+static int run_stage(euler_sim* S, int stage, float dt) {
+  switch (stage) {
+    case EULER_STAGE_ADVECT_MARKERS: return eu_launch_advect_markers(S, dt);
+    case EULER_STAGE_REFRESH_COUNTS: return eu_launch_refresh_counts(S);
+    case EULER_STAGE_SOURCES: return eu_launch_sources(S);
+    case EULER_STAGE_EXTRAPOLATE: return eu_launch_extrapolate(S);
+    case EULER_STAGE_ADVECT_VELOCITY: return eu_launch_advect_velocity(S, dt);
+    case EULER_STAGE_PROJECT: return eu_launch_project(S, dt);
+    default: eu_set_error("unknown stage %d", stage); return EULER_EINVAL;
+  }
+}
+
+extern "C" int euler_stage(euler_sim* S, int32_t stage, float dt) {
+  if (!S || !S->loaded) { eu_set_error("euler_stage: no scenario loaded"); return EULER_ESTATE; }
+  int rc = run_stage(S, stage, dt);
+  if (rc) return rc;
+  return eu_sync_marker_state(S);
+}
+
+static int substep_async(euler_sim* S, float dt) {
+  for (int st = 0; st < EULER_STAGE__COUNT; ++st) {
+    int rc = run_stage(S, st, dt);
+    if (rc) return rc;
+  }
+  return EULER_OK;
+}
+
+static void account_substep(euler_sim* S, float dt) {
+  // sc_host was copied at the end of eu_launch_project and is valid after the next sync
+  S->stats.total_substeps += 1;
+  S->stats.last_dt = dt;
+}
+
+extern "C" int euler_substep(euler_sim* S, float dt) {
+  if (!S || !S->loaded) { eu_set_error("euler_substep: no scenario loaded"); return EULER_ESTATE; }
+  int rc = substep_async(S, dt);
+  if (rc) return rc;
+  rc = eu_sync_marker_state(S);
+  if (rc) return rc;
+  account_substep(S, dt);
+  S->stats.total_pcg_iterations += (uint64_t)S->sc_host->iters;
+  S->stats.last_pcg_iterations = S->sc_host->iters;
+  S->stats.last_residual = S->sc_host->rnorm;
+  return EULER_OK;
+}
+
+// sim_step (main.c:843-900): split the 0.1 s frame into <= 8 CFL-limited substeps
+extern "C" int euler_step(euler_sim* S) {
+  if (!S || !S->loaded) { eu_set_error("euler_step: no scenario loaded"); return EULER_ESTATE; }
+  float frame_time = S->cfg.frame_time;
+  int nsub = 0, iters = 0;
+  for (int step = 0; frame_time > 0.f && step < S->cfg.max_substeps; ++step) {
+    float dt = 0.f;
+    int rc = euler_timestep(S, frame_time, &dt);   // syncs: also finalises the previous substep's scalars
+    if (rc) return rc;
+    if (step > 0) { iters += S->sc_host->iters; S->stats.last_residual = S->sc_host->rnorm; }
+    frame_time -= dt;
+    rc = substep_async(S, dt);
+    if (rc) return rc;
+    account_substep(S, dt);
+    ++nsub;
+  }
+  int rc = eu_sync_marker_state(S);
+  if (rc) return rc;
+  if (nsub) { iters += S->sc_host->iters; S->stats.last_residual = S->sc_host->rnorm; }
+  S->stats.total_pcg_iterations += (uint64_t)iters;
+  S->stats.last_pcg_iterations = iters;
+  S->stats.last_substeps = nsub;
+  S->stats.frames += 1;
+  return EULER_OK;
+}
+
+extern "C" int euler_pcg_op(euler_sim* S, int32_t op, float dt, double a, double* out) {
+  if (!S || !S->loaded) { eu_set_error("euler_pcg_op: no scenario loaded"); return EULER_ESTATE; }
+  return eu_launch_pcg_op(S, op, dt, a, out);
+}
+
+// ------------------------------------------------------------------------------------------
+// state access
+static int field_ptr(euler_sim* S, int f, void** p, size_t* bytes) {
+  const size_t C = S->C;
+  switch (f) {
+    case EULER_F_U: *p = S->u; *bytes = C * 4; break;
+    case EULER_F_V: *p = S->v; *bytes = C * 4; break;
+    case EULER_F_UTMP: *p = S->utmp; *bytes = C * 4; break;
+    case EULER_F_VTMP: *p = S->vtmp; *bytes = C * 4; break;
+    case EULER_F_SOLID: *p = S->solid; *bytes = C; break;
+    case EULER_F_SOURCE: *p = S->source; *bytes = C; break;
+    case EULER_F_SINK: *p = S->sink; *bytes = C; break;
+    case EULER_F_COUNT: *p = S->count; *bytes = C; break;
+    case EULER_F_PREV_COUNT: *p = S->prev_count; *bytes = C; break;
+    case EULER_F_MARKERS: *p = S->markers[S->cur]; *bytes = (size_t)S->n_markers_host * 8; break;
+    case EULER_F_PRECON: *p = S->precon; *bytes = C * 8; break;
+    case EULER_F_PRESSURE: *p = S->p; *bytes = C * 8; break;
+    case EULER_F_PCG_B: *p = S->b; *bytes = C * 8; break;
+    case EULER_F_PCG_R: *p = S->r; *bytes = C * 8; break;
+    case EULER_F_PCG_Z: *p = S->z; *bytes = C * 8; break;
+    case EULER_F_PCG_S: *p = S->s; *bytes = C * 8; break;
+    case EULER_F_PCG_Q: *p = S->q; *bytes = C * 8; break;
+    case EULER_F_CELLMASK: *p = S->cellmask; *bytes = C; break;
+    default: eu_set_error("unknown field %d", f); return EULER_EINVAL;
+  }
+  return EULER_OK;
+}
+
+extern "C" size_t euler_field_bytes(const euler_sim* S, int32_t f) {
+  void* p; size_t b = 0;
+  if (!S || field_ptr((euler_sim*)S, f, &p, &b)) return 0;
+  return b;
+}
+
+extern "C" int euler_get_field(euler_sim* S, int32_t f, void* dst, size_t dst_bytes) {
+  if (!S || !dst) return EULER_EINVAL;
+  void* p; size_t b;
+  int rc = field_ptr(S, f, &p, &b);
+  if (rc) return rc;
+  if (dst_bytes < b) { eu_set_error("euler_get_field(%d): buffer %zu < %zu bytes", f, dst_bytes, b); return EULER_EINVAL; }
+  if (b == 0) return EULER_OK;
+  HIPCHK(hipMemcpyAsync(dst, p, b, hipMemcpyDeviceToHost, S->stream));
+  HIPCHK(hipStreamSynchronize(S->stream));
+  return EULER_OK;
+}
+
+extern "C" int euler_set_field(euler_sim* S, int32_t f, const void* src, size_t src_bytes) {
+  if (!S || !src) return EULER_EINVAL;
+  if (f == EULER_F_MARKERS) return euler_set_markers(S, (const float*)src, src_bytes / 8);
+  void* p; size_t b;
+  int rc = field_ptr(S, f, &p, &b);
+  if (rc) return rc;
+  if (src_bytes != b) { eu_set_error("euler_set_field(%d): %zu bytes given, %zu expected", f, src_bytes, b); return EULER_EINVAL; }
+  HIPCHK(hipMemcpyAsync(p, src, b, hipMemcpyHostToDevice, S->stream));
+  HIPCHK(hipStreamSynchronize(S->stream));
+  if (f == EULER_F_SOURCE) {
+    const uint8_t* s = (const uint8_t*)src;
+    size_t nsrc = 0;
+    for (size_t i = 0; i < S->C; ++i) nsrc += s[i] != 0;
+    S->n_source_cells = nsrc;
+    if (S->draws) { (void)hipFree(S->draws); S->draws = nullptr; }
+    if (nsrc) HIPCHK(hipMalloc((void**)&S->draws, 2 * nsrc * sizeof(float)));
+  }
+  S->loaded = 1;
+  return EULER_OK;
+}
+
+__global__ void k_set_marker_state(MarkerState* ms, unsigned long long n, unsigned long long maxm, int set_n,
+                                   unsigned long long rng, int exhausted, int set_rng) {
+  if (set_n) { ms->n = n; ms->max_markers = maxm; }
+  if (set_rng) { ms->rng_state = rng; ms->exhausted = exhausted; }
+}
+
+extern "C" int euler_set_markers(euler_sim* S, const float* xy, uint64_t n) {
+  if (!S || (!xy && n) || n > S->max_markers) return EULER_EINVAL;
+  if (n) HIPCHK(hipMemcpyAsync(S->markers[S->cur], xy, n * 8, hipMemcpyHostToDevice, S->stream));
+  hipLaunchKernelGGL(k_set_marker_state, dim3(1), dim3(1), 0, S->stream, S->ms, (unsigned long long)n,
+                     (unsigned long long)S->max_markers, 1, 0ull, 0, 0);
+  S->loaded = 1;
+  return eu_sync_marker_state(S);
+}
+
+extern "C" int euler_set_rng(euler_sim* S, uint64_t rng, int32_t exhausted) {
+  if (!S) return EULER_EINVAL;
+  hipLaunchKernelGGL(k_set_marker_state, dim3(1), dim3(1), 0, S->stream, S->ms, 0ull, 0ull, 0, (unsigned long long)rng,
+                     (int)exhausted, 1);
+  return eu_sync_marker_state(S);
+}
+
+__global__ __launch_bounds__(256) void k_count_fluid(const uint8_t* __restrict__ count, size_t C, unsigned long long* out) {
+  unsigned int c = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < C; i += (size_t)gridDim.x * blockDim.x) c += count[i] != 0;
+  c = (unsigned int)eu_wave_sum((double)c);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+
+extern "C" int euler_get_stats(euler_sim* S, euler_stats* out) {
+  if (!S || !out) return EULER_EINVAL;
+  int rc = eu_sync_marker_state(S);
+  if (rc) return rc;
+  // fluid-cell census reuses the (idle) select total word as a 64-bit scratch
+  unsigned long long* scratch = (unsigned long long*)S->partial;
+  HIPCHK(hipMemsetAsync(scratch, 0, 8, S->stream));
+  hipLaunchKernelGGL(k_count_fluid, dim3(eu_blocks(S->C, 256 * 8, 1024)), dim3(256), 0, S->stream, S->count, S->C, scratch);
+  unsigned long long nf = 0;
+  HIPCHK(hipMemcpyAsync(&nf, scratch, 8, hipMemcpyDeviceToHost, S->stream));
+  HIPCHK(hipStreamSynchronize(S->stream));
+  S->stats.n_markers = S->ms_host->n;
+  S->stats.source_exhausted = S->ms_host->exhausted;
+  S->stats.rng_state = S->ms_host->rng_state;
+  S->stats.marker_dt_events = S->ms_host->total_dt_events;
+  S->stats.marker_multi_events = S->ms_host->multi_events;
+  S->stats.fluid_cells = nf;
+  *out = S->stats;
+  return EULER_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// render: fetch only the visible window rows of the count grid (draw_rows reads y in
+// [max(Y-1-wy,1), Y-2] and x in [1, min(X-2, wx)], main.c:917-920)
+extern "C" int euler_render(euler_sim* S, int32_t wx, int32_t wy, char* out, int32_t cap, int32_t* len) {
+  if (!S || !len) return EULER_EINVAL;
+  if (!S->loaded) return EULER_ESTATE;
+  const int X = S->X, Y = S->Y;
+  int cutoff = Y - 1 - wy;
+  if (cutoff < 1) cutoff = 1;
+  const size_t C = S->C;
+  uint8_t* g = (uint8_t*)calloc(3, C);
+  if (!g) return EULER_ENOMEM;
+  const size_t off = (size_t)cutoff * X, bytes = (size_t)(Y - 1 - cutoff) * X;
+  hipError_t e = hipMemcpyAsync(g + off, S->solid + off, bytes, hipMemcpyDeviceToHost, S->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(g + C + off, S->sink + off, bytes, hipMemcpyDeviceToHost, S->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(g + 2 * C + off, S->count + off, bytes, hipMemcpyDeviceToHost, S->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(S->stream);
+  int rc = e == hipSuccess ? euler_render_grids(g, g + C, g + 2 * C, X, Y, wx, wy, out, cap, len)
+                           : eu_hip_fail(e, "render copy", __FILE__, __LINE__);
+  free(g);
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// measurement helpers
+__global__ __launch_bounds__(256) void k_copy16(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+extern "C" int euler_measure_copy_bandwidth(euler_sim* S, size_t bytes, int32_t reps, double* gbps) {
+  if (!S || !gbps || reps < 1) return EULER_EINVAL;
+  bytes &= ~(size_t)15;
+  float4 *a = nullptr, *b = nullptr;
+  HIPCHK(hipMalloc((void**)&a, bytes));
+  if (hipMalloc((void**)&b, bytes) != hipSuccess) { (void)hipFree(a); return EULER_ENOMEM; }
+  (void)hipMemsetAsync(a, 1, bytes, S->stream);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  const size_t n = bytes / 16;
+  hipLaunchKernelGGL(k_copy16, dim3(4096), dim3(256), 0, S->stream, a, b, n);   // warm-up
+  (void)hipEventRecord(e0, S->stream);
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_copy16, dim3(4096), dim3(256), 0, S->stream, a, b, n);
+  (void)hipEventRecord(e1, S->stream);
+  hipError_t e = hipStreamSynchronize(S->stream);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(a); (void)hipFree(b);
+  if (e != hipSuccess) return eu_hip_fail(e, "copy probe", __FILE__, __LINE__);
+  *gbps = 2.0 * (double)bytes * reps / ((double)ms * 1e-3) / 1e9;
+  return EULER_OK;
+}
+
+extern "C" int euler_device_name(euler_sim* S, char* out, int32_t cap) {
+  if (!S || !out || cap < 1) return EULER_EINVAL;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, S->cfg.device));
+  snprintf(out, (size_t)cap, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return EULER_OK;
+}

@@ -1,0 +1,229 @@
+// euler_dev.h — internal: device-resident state, launch plumbing and the device functions shared
+// by the kernel files of libeuler_hip.so.  gfx950 (MI355X, wave64) only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "euler.h"
+#include "euler_host.h"
+
+// ------------------------------------------------------------------------------------------
+// reference constants (main.c:58-60)
+#define EU_H 1.0f        // k_side_length
+#define EU_RHO 1.0f      // k_density
+#define EU_G (-10.0f)    // k_gravity
+
+// cell mask byte (EULER_F_CELLMASK)
+#define CM_FLUID 0x01
+#define CM_RIGHT 0x02   // fluid at (x+1,y)
+#define CM_UP    0x04   // fluid at (x,y+1)
+#define CM_LEFT  0x08   // fluid at (x-1,y)
+#define CM_DOWN  0x10   // fluid at (x,y-1)
+#define CM_DIAG_SHIFT 5 // a_diag = mask >> 5  (0..4)
+
+// kernel classes for euler_profile_*
+enum {
+  KC_TIMESTEP = 0, KC_MARKER_ADVECT, KC_MARKER_EVENTS, KC_MARKER_BIN, KC_MARKER_COMPACT, KC_SOURCES,
+  KC_SELECT, KC_EXTRAPOLATE, KC_ADVECT_VELOCITY, KC_BUILD_SYSTEM, KC_PRECON_FACTOR,
+  KC_FORWARD_SOLVE, KC_BACKWARD_SOLVE, KC_APPLY_A, KC_DOT, KC_UPDATE_PR, KC_UPDATE_SEARCH,
+  KC_REDUCE_FINAL, KC_VELOCITY_UPDATE, KC_JACOBI, KC_MISC, KC__COUNT
+};
+
+// Device-resident PCG scalars: no host round trip inside the iteration (reference: locals of
+// project(), main.c:748-765).
+struct PcgScalars {
+  double sigma, zs, sigma_new, alpha, beta, rnorm;
+  double tol;
+  int nonzero;   // !all_zero(r)  (main.c:742)
+  int done;      // inf_norm(r) <= tol reached (main.c:756)
+  int iters;     // apply_a calls so far (main.c:750)
+  int max_iters;
+};
+
+// Device-resident marker bookkeeping (reference: g_markers_length, g_source_exhausted, the
+// function-static rng_state; main.c:93-94,204).
+struct MarkerState {
+  unsigned long long n;            // g_markers_length
+  unsigned long long max_markers;  // MAX_MARKER_COUNT = 4*X*Y
+  unsigned long long rng_state;
+  int exhausted;
+  unsigned int n_events;      // candidate dt-shortening collisions found by the speculative pass
+  unsigned int n_actual;      // those that fire in array order
+  unsigned int n_deleted;     // markers removed by the last refresh
+  unsigned int n_append;      // markers appended by the last source update
+  unsigned long long n0_append;  // index of the first appended marker
+  unsigned long long total_dt_events, multi_events;
+  float dt_final;             // dt after the last marker (debug)
+  float dt;                   // calculate_timestep result
+  unsigned int max_u2_bits, max_v2_bits;
+  int error;                  // sticky device-side error (bounded waits)
+};
+
+struct SelectScratch {
+  unsigned int* block_sums;   // [nblocks]
+  unsigned int* total;        // [1]
+  size_t capacity_blocks;
+};
+
+struct euler_sim {
+  euler_config cfg;
+  int X, Y;
+  size_t C;
+  hipStream_t stream;
+  int loaded;
+
+  // fields (main.c:64-73,96-97)
+  float *u, *v, *utmp, *vtmp;
+  uint8_t *solid, *source, *sink, *count, *prev_count;
+  unsigned int* count32;
+  // markers, ping-pong (main.c:95)
+  float2* markers[2];
+  int cur;
+  size_t max_markers;
+  unsigned long long n_markers_host;   // exact at substep start
+  size_t n_source_cells;
+  MarkerState* ms;        // device
+  MarkerState* ms_host;   // pinned mirror
+  // marker scratch
+  unsigned long long* evmask;   // [ceil(max_markers/64)] also reused as delete mask
+  float* ev_theta;              // [max_markers] written only where an event exists
+  float* ev_delta;
+  unsigned int* sel_idx;        // ordered selection output (events / deletions / eligible cells)
+  size_t sel_cap;
+  unsigned int* act_idx; float* act_dt;   // actual events
+  unsigned long long* cellmask64;         // [ceil(C/64)] eligibility mask
+  float* draws;                           // [2*n_source_cells]
+  SelectScratch sel;
+
+  // pressure solve (main.c:552,577-578,716-745)
+  double *b, *p, *r, *z, *s, *q, *precon;
+  uint8_t* cellmask;
+  PcgScalars* sc;
+  PcgScalars* sc_host;    // pinned
+  double* partial;        // reduction partials
+  int red_blocks;
+  // band sweep
+  unsigned long long* granules;  // [nbands][X][2]
+  unsigned int* ticket;
+  unsigned int ticket_base;
+  unsigned int epoch;
+  int nbands;
+
+  float interp_lim[4];    // nextafterf(extent-1, 0) for U.x, U.y, V.x, V.y (main.c:339-340)
+
+  euler_stats stats;
+
+  // profiling
+  uint64_t prof_mask;
+  double prof_ms[KC__COUNT];
+  uint64_t prof_launches[KC__COUNT];
+  hipEvent_t* ev_pool; int* ev_cls; int ev_used, ev_cap;
+};
+
+// ------------------------------------------------------------------------------------------
+void eu_set_error(const char* fmt, ...);
+int eu_hip_fail(hipError_t e, const char* what, const char* file, int line);
+#define HIPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) return eu_hip_fail(_e, #call, __FILE__, __LINE__); } while (0)
+
+void eu_prof_begin(euler_sim* S, int cls);
+void eu_prof_end(euler_sim* S, int cls);
+int  eu_prof_flush(euler_sim* S);
+
+#define LAUNCH(S, CLS, KERNEL, GRID, BLOCK, ...)                                   \
+  do {                                                                             \
+    eu_prof_begin((S), (CLS));                                                     \
+    hipLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, (S)->stream, __VA_ARGS__);          \
+    eu_prof_end((S), (CLS));                                                       \
+  } while (0)
+
+static inline unsigned eu_blocks(size_t n, unsigned per_block, unsigned cap = 0x7fffffffu) {
+  size_t b = (n + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (unsigned)b;
+}
+
+// launch groups implemented in the kernel files
+int eu_launch_timestep(euler_sim* S, float frame_time_left);
+int eu_launch_advect_markers(euler_sim* S, float dt);
+int eu_launch_refresh_counts(euler_sim* S);
+int eu_launch_sources(euler_sim* S);
+int eu_launch_extrapolate(euler_sim* S);
+int eu_launch_advect_velocity(euler_sim* S, float dt);
+int eu_launch_project(euler_sim* S, float dt);
+int eu_launch_pcg_op(euler_sim* S, int op, float dt, double a, double* out);
+int eu_ordered_select(euler_sim* S, const unsigned long long* mask, size_t nwords, unsigned int* out_idx,
+                      unsigned int* out_total);
+int eu_sync_marker_state(euler_sim* S);
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+#ifdef __HIPCC__
+
+#define EU_WAVE 64
+
+struct GridRef {
+  int X, Y;
+  const uint8_t* count;   // g_fluid alias (main.c:99)
+  float ux_lim, uy_lim, vx_lim, vy_lim;
+};
+
+// typed cell property (p_property/u_property/v_property, main.c:119-138)
+__device__ __forceinline__ bool eu_prop_p(const uint8_t* g, size_t i) { return g[i] != 0; }
+__device__ __forceinline__ bool eu_prop_u(const uint8_t* g, size_t i) { return (g[i] != 0) | (g[i + 1] != 0); }
+__device__ __forceinline__ bool eu_prop_v(const uint8_t* g, size_t i, int X) { return (g[i] != 0) | (g[i + X] != 0); }
+
+__device__ __forceinline__ float eu_lerp(float x0, float x1, float f) { return (1.f - f) * x0 + f * x1; }   // main.c:311-313
+__device__ __forceinline__ float eu_frac(float f, bool start_ok, bool end_ok) {                            // main.c:301-309
+  return !start_ok ? 1.f : (!end_ok ? 0.f : f);
+}
+__device__ __forceinline__ float eu_clampf(float lo, float x, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// interpolate(), main.c:337-364.  TYPE 1 = U samples, 2 = V samples.
+template <int TYPE>
+__device__ __forceinline__ float eu_interp(const GridRef& g, const float* __restrict__ q, float ix, float iy) {
+  ix = eu_clampf(0.f, ix, TYPE == 1 ? g.ux_lim : g.vx_lim);
+  iy = eu_clampf(0.f, iy, TYPE == 1 ? g.uy_lim : g.vy_lim);
+  float wx, wy;
+  const float fx = modff(ix, &wx), fy = modff(iy, &wy);
+  const int bx = (int)wx, by = (int)wy;
+  const size_t i00 = (size_t)by * g.X + bx;
+  bool v00, v01, v10, v11;
+  if (TYPE == 1) {
+    const bool c0 = g.count[i00] != 0, c1 = g.count[i00 + 1] != 0, c2 = g.count[i00 + 2] != 0;
+    const bool d0 = g.count[i00 + g.X] != 0, d1 = g.count[i00 + g.X + 1] != 0, d2 = g.count[i00 + g.X + 2] != 0;
+    v00 = c0 | c1; v01 = c1 | c2; v10 = d0 | d1; v11 = d1 | d2;
+  } else {
+    const bool c0 = g.count[i00] != 0, c1 = g.count[i00 + 1] != 0;
+    const bool d0 = g.count[i00 + g.X] != 0, d1 = g.count[i00 + g.X + 1] != 0;
+    const bool e0 = g.count[i00 + 2 * (size_t)g.X] != 0, e1 = g.count[i00 + 2 * (size_t)g.X + 1] != 0;
+    v00 = c0 | d0; v01 = c1 | d1; v10 = d0 | e0; v11 = d1 | e1;
+  }
+  const float q00 = v00 ? q[i00] : 0.f, q01 = v01 ? q[i00 + 1] : 0.f;
+  const float q10 = v10 ? q[i00 + g.X] : 0.f, q11 = v11 ? q[i00 + g.X + 1] : 0.f;
+  const float lf = eu_frac(fy, v00, v10), rf = eu_frac(fy, v01, v11);
+  const float lv = eu_lerp(q00, q10, lf), rv = eu_lerp(q01, q11, rf);
+  const float hf = eu_frac(fx, v00 | v10, v01 | v11);
+  return eu_lerp(lv, rv, hf);
+}
+
+// wave64 reductions by shuffles
+__device__ __forceinline__ double eu_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double eu_wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { double w = __shfl_down(v, o, 64); v = w > v ? w : v; }
+  return v;
+}
+__device__ __forceinline__ float eu_wave_maxf(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { float w = __shfl_down(v, o, 64); v = w > v ? w : v; }
+  return v;
+}
+
+#endif  // __HIPCC__

@@ -1,0 +1,177 @@
+/*
+ * euler_host.c — host-only C parts of libeuler_hip.so: scenario text -> cell grids, the
+ * xorshift64* stream, initial marker seeding, and the ASCII frame formatter.
+ *
+ * These are the pieces of the reference's sim_init (main.c:209-274) and draw_rows
+ * (main.c:914-951) that never touch the hot path; they run once (init) or over a terminal-sized
+ * window (render), so they stay on the host.  Everything here is exported through include/euler.h
+ * and usable without a GPU.
+ */
+#include "euler_host.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- xorshift64* high half (misc/rng.c:5-20) and randf (main.c:203-207) ------------------- */
+
+uint32_t euler_rng_next_u32(uint64_t* state) {
+  uint64_t x = *state;
+  x ^= x >> 12;
+  x ^= x << 25;
+  x ^= x >> 27;
+  *state = x;
+  return (uint32_t)((x * 0x2545F4914F6CDD1Dull) >> 32);
+}
+
+float euler_rng_next_float(uint64_t* state) {
+  /* closed [0,1]: divide by UINT32_MAX in double, then narrow (main.c:206) */
+  return (float)(euler_rng_next_u32(state) / (double)UINT32_MAX);
+}
+
+/* ---- scenario text ---------------------------------------------------------------------- */
+
+static void classify(char c, size_t i, uint8_t* solid, uint8_t* source, uint8_t* sink, uint8_t* fluid) {
+  switch (c) { /* main.c:226-235; anything else is empty */
+    case 'X': solid[i] = 1; break;
+    case '0': fluid[i] = 1; break;
+    case '?': fluid[i] = 1; source[i] = 1; break;
+    case '=': sink[i] = 1; break;
+    default: break;
+  }
+}
+
+int euler_parse_scenario(const char* text, int32_t len, int32_t X, int32_t Y, int32_t upscale,
+                         uint8_t* solid, uint8_t* source, uint8_t* sink, uint8_t* fluid) {
+  if (!text || len < 0 || X < 4 || Y < 4 || !solid || !source || !sink || !fluid) return EULER_EINVAL;
+  const size_t C = (size_t)X * (size_t)Y;
+  memset(solid, 0, C); memset(source, 0, C); memset(sink, 0, C); memset(fluid, 0, C);
+
+  if (!upscale) {
+    /* The reference consumes the text as a stream (main.c:218-241): the first line fills row
+     * Y-2, each line fills x = 1..X-2; a line that reaches the width limit has its remainder
+     * (including its newline) discarded. */
+    int32_t pos = 0;
+    for (int32_t y = Y - 2; y > 0 && pos < len; --y) {
+      int32_t x = 1;
+      while (x < X - 1 && pos < len) {
+        char c = text[pos++];
+        if (c == '\n') break;
+        classify(c, (size_t)y * X + x, solid, source, sink, fluid);
+        ++x;
+      }
+      if (x == X - 1)
+        while (pos < len && text[pos++] != '\n') {}
+    }
+  } else {
+    /* Build extension: nearest-neighbour resample of a Wf x Hf picture onto the interior.
+     * ch(x,y) = line[(Y-2-y)*Hf/(Y-2)][(x-1)*Wf/(X-2)], missing characters are blanks. */
+    int32_t Hf = 0, Wf = 0;
+    for (int32_t i = 0, w = 0; i <= len; ++i) {
+      if (i == len || text[i] == '\n') {
+        if (i < len || w > 0) { ++Hf; if (w > Wf) Wf = w; }
+        w = 0;
+      } else ++w;
+    }
+    if (Hf == 0 || Wf == 0) return EULER_EINVAL;
+    int32_t* start = (int32_t*)malloc(sizeof(int32_t) * (size_t)Hf * 2);
+    if (!start) return EULER_ENOMEM;
+    int32_t* length = start + Hf;
+    int32_t k = 0, s0 = 0;
+    for (int32_t i = 0; i <= len; ++i)
+      if (i == len || text[i] == '\n') {
+        if (i < len || i > s0) { start[k] = s0; length[k] = i - s0; ++k; }
+        s0 = i + 1;
+      }
+    for (int32_t y = 1; y <= Y - 2; ++y) {
+      int64_t fr = ((int64_t)(Y - 2 - y) * Hf) / (Y - 2);
+      for (int32_t x = 1; x <= X - 2; ++x) {
+        int64_t fc = ((int64_t)(x - 1) * Wf) / (X - 2);
+        char c = fc < length[fr] ? text[start[fr] + fc] : ' ';
+        classify(c, (size_t)y * X + x, solid, source, sink, fluid);
+      }
+    }
+    free(start);
+  }
+  /* sink ring around the domain (main.c:244-252) */
+  for (int32_t y = 0; y < Y; ++y) { sink[(size_t)y * X] = 1; sink[(size_t)y * X + X - 1] = 1; }
+  for (int32_t x = 0; x < X; ++x) { sink[x] = 1; sink[(size_t)(Y - 1) * X + x] = 1; }
+  return EULER_OK;
+}
+
+int euler_half_tank_grids(int32_t X, int32_t Y, uint8_t* solid, uint8_t* source, uint8_t* sink, uint8_t* fluid) {
+  if (X < 6 || Y < 6) return EULER_EINVAL;
+  const size_t C = (size_t)X * (size_t)Y;
+  memset(solid, 0, C); memset(source, 0, C); memset(sink, 0, C); memset(fluid, 0, C);
+  for (int32_t y = 1; y <= Y - 2; ++y)
+    for (int32_t x = 1; x <= X - 2; ++x) {
+      size_t i = (size_t)y * X + x;
+      if (y == 1 || y == Y - 2 || x == 1 || x == X - 2) solid[i] = 1;
+      else if (y < Y / 2) fluid[i] = 1;
+    }
+  for (int32_t y = 0; y < Y; ++y) { sink[(size_t)y * X] = 1; sink[(size_t)y * X + X - 1] = 1; }
+  for (int32_t x = 0; x < X; ++x) { sink[x] = 1; sink[(size_t)(Y - 1) * X + x] = 1; }
+  return EULER_OK;
+}
+
+/* Four jittered markers per fluid cell (main.c:255-266): columns outer, rows inner, quadrant
+ * k = 0..3, the x jitter drawn before the y jitter, all arithmetic in float. */
+int euler_seed_markers(const uint8_t* fluid, int32_t X, int32_t Y, uint64_t* rng_state,
+                       float* markers_xy, uint64_t* n_markers) {
+  if (!fluid || !rng_state || !markers_xy || !n_markers) return EULER_EINVAL;
+  uint64_t n = 0;
+  for (int32_t cx = 0; cx < X; ++cx)
+    for (int32_t cy = 0; cy < Y; ++cy) {
+      if (!fluid[(size_t)cy * X + cx]) continue;
+      for (int k = 0; k < 4; ++k) {
+        float jx = euler_rng_next_float(rng_state) / 2;
+        float mx = cx + (k < 2 ? 0 : 0.5f) + jx;
+        float jy = euler_rng_next_float(rng_state) / 2;
+        float my = cy + (k % 2 ? 0 : 0.5f) + jy;
+        markers_xy[2 * n] = 1.f * mx;     /* k_side_length = 1 (main.c:58,262) */
+        markers_xy[2 * n + 1] = 1.f * my;
+        ++n;
+      }
+    }
+  *n_markers = n;
+  return EULER_OK;
+}
+
+/* ---- frame formatter (draw_rows, main.c:914-951; escape codes misc/terminal.h:36,53,60) ---- */
+
+int euler_render_grids(const uint8_t* solid, const uint8_t* sink, const uint8_t* count,
+                       int32_t X, int32_t Y, int32_t wx, int32_t wy, char* out, int32_t cap, int32_t* len) {
+  if (!solid || !sink || !count || !len) return EULER_EINVAL;
+  static const char glyph[4] = {' ', 'o', 'O', '0'};
+  static const char blue[] = "\x1B[34m", reset[] = "\x1B[0m", clear_line[] = "\x1b[K", crlf[] = "\r\n";
+  int64_t n = 0;
+#define EMIT(s, k) do { for (int _i = 0; _i < (int)(k); ++_i) { if (out && n < cap) out[n] = (s)[_i]; ++n; } } while (0)
+  int32_t cutoff = Y - 1 - wy;
+  if (cutoff < 1) cutoff = 1;
+  /* the reference's `for (y = Y-1; y-- > cutoff;)` visits y = Y-2 ... cutoff inclusive */
+  for (int32_t y = Y - 2; y >= cutoff; --y) {
+    int water_run = 0;
+    for (int32_t x = 1; x < X - 1 && x < wx + 1; ++x) {
+      size_t i = (size_t)y * X + x;
+      if (solid[i]) {
+        if (water_run) EMIT(reset, 4);
+        EMIT("X", 1);
+        water_run = 0;
+      } else if (sink[i]) {
+        if (water_run) EMIT(reset, 4);
+        EMIT("=", 1);           /* the run flag is deliberately left as is (main.c:927-931) */
+      } else {
+        int k = count[i] < 3 ? count[i] : 3;
+        if (!water_run && k) EMIT(blue, 5);
+        else if (water_run && !k) EMIT(reset, 4);
+        EMIT(&glyph[k], 1);
+        water_run = k != 0;
+      }
+    }
+    EMIT(reset, 4);
+    EMIT(clear_line, 3);
+    if (y > cutoff) EMIT(crlf, 2);
+  }
+#undef EMIT
+  *len = (int32_t)n;
+  return EULER_OK;
+}

@@ -1,0 +1,228 @@
+// k_grid.hip — grid-stage kernels of one substep: CFL timestep, extrapolation into new fluid,
+// boundary zeroing, semi-Lagrangian velocity advection (+ gravity + bounds), pressure-system
+// assembly and the post-solve velocity update.  All are embarrassingly parallel gathers with
+// coalesced row-major access; none has a floating-point reduction except the exact max.
+#include "euler_dev.h"
+
+// ------------------------------------------------------------------------------------------
+// calculate_timestep / maxsq (main.c:808-841): max over the typed extents, including zeros.
+__global__ __launch_bounds__(256) void k_maxsq(const float* __restrict__ u, const float* __restrict__ v,
+                                               int X, int Y, MarkerState* ms) {
+  const size_t C = (size_t)X * Y;
+  float mu = 0.f, mv = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < C; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % X), y = (int)(i / X);
+    if (x < X - 1) { const float s = u[i] * u[i]; if (s > mu) mu = s; }
+    if (y < Y - 1) { const float s = v[i] * v[i]; if (s > mv) mv = s; }
+  }
+  mu = eu_wave_maxf(mu);
+  mv = eu_wave_maxf(mv);
+  __shared__ float su[4], sv[4];
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (l == 0) { su[w] = mu; sv[w] = mv; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k) { if (su[k] > mu) mu = su[k]; if (sv[k] > mv) mv = sv[k]; }
+    // non-negative floats order like their bit patterns; NaN never gets here (s > m is false)
+    atomicMax(&ms->max_u2_bits, __float_as_uint(mu));
+    atomicMax(&ms->max_v2_bits, __float_as_uint(mv));
+  }
+}
+
+__global__ void k_dt(MarkerState* ms, float frame_time_left) {
+  const float mu = __uint_as_float(ms->max_u2_bits), mv = __uint_as_float(ms->max_v2_bits);
+  const float max_distance = 0.75f * EU_H;
+  const float max_velocity = sqrtf(mu + mv);
+  ms->dt = fminf(max_distance / max_velocity, frame_time_left);   // 0.75/0 = +inf -> frame time
+  ms->max_u2_bits = 0u;
+  ms->max_v2_bits = 0u;
+}
+
+int eu_launch_timestep(euler_sim* S, float frame_time_left) {
+  LAUNCH(S, KC_TIMESTEP, k_maxsq, dim3(eu_blocks(S->C, 256 * 8, 2048)), dim3(256), S->u, S->v, S->X, S->Y, S->ms);
+  LAUNCH(S, KC_TIMESTEP, k_dt, dim3(1), dim3(1), S->ms, frame_time_left);
+  return EULER_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// extrapolate (main.c:158-185) for U and V in one launch.  In place is race-free: only samples
+// WITHOUT the prev-fluid property are written, only samples WITH it are read.
+template <int TYPE>
+__device__ __forceinline__ bool typed_prop(const uint8_t* g, size_t i, int X) {
+  return TYPE == 1 ? eu_prop_u(g, i) : eu_prop_v(g, i, X);
+}
+
+template <int TYPE>
+__device__ __forceinline__ void extrapolate_sample(float* q, const uint8_t* prev, const uint8_t* cur,
+                                                   int x, int y, int X, int ex, int ey) {
+  const size_t i = (size_t)y * X + x;
+  if (typed_prop<TYPE>(prev, i, X) || !typed_prop<TYPE>(cur, i, X)) return;
+  const int x0 = x > 0 ? x - 1 : 0, x1 = x + 1 < ex ? x + 1 : ex - 1;
+  const int y0 = y > 0 ? y - 1 : 0, y1 = y + 1 < ey ? y + 1 : ey - 1;
+  float total = 0.f;
+  int n = 0;
+  for (int yy = y0; yy <= y1; ++yy)       // y outer, x inner, float adds in this order (main.c:161-168)
+    for (int xx = x0; xx <= x1; ++xx) {
+      const size_t j = (size_t)yy * X + xx;
+      if (typed_prop<TYPE>(prev, j, X)) { total += q[j]; ++n; }
+    }
+  q[i] = total / n;   // n == 0 -> 0/0 like the Release reference
+}
+
+__global__ __launch_bounds__(256) void k_extrapolate(float* u, float* v, const uint8_t* __restrict__ prev,
+                                                     const uint8_t* __restrict__ cur, int X, int Y) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= X || y >= Y) return;
+  if (x < X - 1) extrapolate_sample<1>(u, prev, cur, x, y, X, X - 1, Y);
+  if (y < Y - 1) extrapolate_sample<2>(v, prev, cur, x, y, X, X, Y - 1);
+}
+
+// zero_bounds (main.c:822-832) for U and V in one launch.
+__global__ __launch_bounds__(256) void k_zero_bounds(float* u, float* v, const uint8_t* __restrict__ cur,
+                                                     const uint8_t* __restrict__ solid, int X, int Y) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= X || y >= Y) return;
+  const size_t i = (size_t)y * X + x;
+  if (x < X - 1 && (!eu_prop_u(cur, i) || eu_prop_u(solid, i))) u[i] = 0.f;
+  if (y < Y - 1 && (!eu_prop_v(cur, i, X) || eu_prop_v(solid, i, X))) v[i] = 0.f;
+}
+
+int eu_launch_extrapolate(euler_sim* S) {
+  dim3 grid((S->X + 63) / 64, (S->Y + 3) / 4);
+  LAUNCH(S, KC_EXTRAPOLATE, k_extrapolate, grid, dim3(256), S->u, S->v, S->prev_count, S->count, S->X, S->Y);
+  LAUNCH(S, KC_EXTRAPOLATE, k_zero_bounds, grid, dim3(256), S->u, S->v, S->count, S->solid, S->X, S->Y);
+  return EULER_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// advect_u + advect_v (main.c:378-422) + apply_body_forces (main.c:539-545) + zero_bounds on the
+// outputs (main.c:888-889), fused: what reaches utmp/vtmp equals the reference's arrays after its
+// second zero_bounds pair (non-fluid or solid faces are 0, so the reference's stale entries and the
+// gravity it adds to non-fluid faces never survive).
+__global__ __launch_bounds__(256) void k_advect_velocity(const float* __restrict__ u, const float* __restrict__ v,
+                                                         float* __restrict__ uout, float* __restrict__ vout,
+                                                         const uint8_t* __restrict__ solid, GridRef g, float dt) {
+  const int X = g.X, Y = g.Y;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= X || y >= Y) return;
+  const size_t i = (size_t)y * X + x;
+  if (x < X - 1) {
+    float out = 0.f;
+    if (eu_prop_u(g.count, i) && !eu_prop_u(solid, i)) {
+      const float dx = u[i];
+      const float dy = eu_interp<2>(g, v, x + 0.5f, y - 0.5f);          // vidx_from_u, main.c:378-380
+      const float px = x - dx * dt / EU_H, py = y - dy * dt / EU_H;     // main.c:392-393
+      out = eu_interp<1>(g, u, px, py);
+    }
+    uout[i] = out;
+  }
+  if (y < Y - 1) {
+    float out = 0.f;
+    if (eu_prop_v(g.count, i, X) && !eu_prop_v(solid, i, X)) {
+      const float dy = v[i];
+      const float dx = eu_interp<1>(g, u, x - 0.5f, y + 0.5f);          // uidx_from_v, main.c:401-403
+      const float px = x - dx * dt / EU_H, py = y - dy * dt / EU_H;
+      out = eu_interp<2>(g, v, px, py);
+      out += EU_G * dt;                                                 // main.c:542
+    }
+    vout[i] = out;
+  }
+}
+
+int eu_launch_advect_velocity(euler_sim* S, float dt) {
+  GridRef g{S->X, S->Y, S->count, S->interp_lim[0], S->interp_lim[1], S->interp_lim[2], S->interp_lim[3]};
+  dim3 grid((S->X + 63) / 64, (S->Y + 3) / 4);
+  LAUNCH(S, KC_ADVECT_VELOCITY, k_advect_velocity, grid, dim3(256), S->u, S->v, S->utmp, S->vtmp, S->solid, g, dt);
+  return EULER_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// b, A and the initial PCG vectors (main.c:713-741).  One byte per cell carries everything the
+// solver needs to know about A: fluid flag, the four neighbour-fluid flags (the implicit -1
+// off-diagonals, main.c:561-575) and a_diag = 4 - #solid neighbours (main.c:554-559).
+__global__ __launch_bounds__(256) void k_build_system(const float* __restrict__ u, const float* __restrict__ v,
+                                                      const uint8_t* __restrict__ count, const uint8_t* __restrict__ solid,
+                                                      double* __restrict__ b, double* __restrict__ r, double* __restrict__ p,
+                                                      uint8_t* __restrict__ cellmask, PcgScalars* sc, int X, int Y, float dt) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  bool nz = false;
+  if (x < X && y < Y) {
+    const size_t i = (size_t)y * X + x;
+    uint8_t m = 0;
+    double bv = 0.0;
+    if (count[i] != 0) {   // never true on the border ring (sinks), so the +-1 / +-X reads are in range
+      m = CM_FLUID;
+      if (count[i + 1]) m |= CM_RIGHT;
+      if (count[i + X]) m |= CM_UP;
+      if (count[i - 1]) m |= CM_LEFT;
+      if (count[i - X]) m |= CM_DOWN;
+      const int diag = 4 - solid[i - 1] - solid[i + 1] - solid[i - X] - solid[i + X];
+      m |= (uint8_t)(diag << CM_DIAG_SHIFT);
+      const float k_inv_scale_f = (EU_H * EU_H) * EU_RHO / dt;                      // float expression, main.c:713
+      const float div_f = (u[i] - u[i - 1] + v[i] - v[i - X]) / EU_H;               // float expression, main.c:720
+      bv = -(double)div_f * (double)k_inv_scale_f;
+      nz = bv != 0.0;
+    }
+    cellmask[i] = m;
+    b[i] = bv;
+    r[i] = bv;
+    p[i] = 0.0;
+  }
+  if (__any(nz) && (threadIdx.x & 63) == 0) atomicOr(&sc->nonzero, 1);
+}
+
+// Pressure clamp (main.c:773-779) + velocity update (main.c:782-805), fused.  The clamp is
+// idempotent, so applying it on the fly to the neighbour reads races benignly with the write.
+__global__ __launch_bounds__(256) void k_velocity_update(const float* __restrict__ uin, const float* __restrict__ vin,
+                                                         float* __restrict__ uout, float* __restrict__ vout,
+                                                         double* p, const uint8_t* __restrict__ count,
+                                                         const uint8_t* __restrict__ solid, int X, int Y, float dt) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= X || y >= Y) return;
+  const size_t i = (size_t)y * X + x;
+  const bool f0 = count[i] != 0;
+  double p0 = p[i];
+  if (f0 && p0 < 0.0) { p0 = 0.0; p[i] = 0.0; }
+  const float neg_inv = -(1.f / (EU_RHO * EU_H));   // accel(), main.c:705-707
+  if (x < X - 1) {
+    const bool f1 = count[i + 1] != 0;
+    float o = 0.f;
+    if (solid[i] | solid[i + 1]) o = 0.f;
+    else if (f0 | f1) {
+      double p1 = p[i + 1];
+      if (f1 && p1 < 0.0) p1 = 0.0;
+      o = uin[i] + (neg_inv * (float)(p1 - p0)) * dt;
+    }
+    uout[i] = o;
+  }
+  if (y < Y - 1) {
+    const bool f1 = count[i + X] != 0;
+    float o = 0.f;
+    if (solid[i] | solid[i + X]) o = 0.f;
+    else if (f0 | f1) {
+      double p1 = p[i + X];
+      if (f1 && p1 < 0.0) p1 = 0.0;
+      o = vin[i] + (neg_inv * (float)(p1 - p0)) * dt;
+    }
+    vout[i] = o;
+  }
+}
+
+int eu_launch_build_system(euler_sim* S, float dt) {
+  dim3 grid((S->X + 63) / 64, (S->Y + 3) / 4);
+  LAUNCH(S, KC_BUILD_SYSTEM, k_build_system, grid, dim3(256), S->utmp, S->vtmp, S->count, S->solid, S->b, S->r, S->p,
+         S->cellmask, S->sc, S->X, S->Y, dt);
+  return EULER_OK;
+}
+
+int eu_launch_velocity_update(euler_sim* S, float dt) {
+  dim3 grid((S->X + 63) / 64, (S->Y + 3) / 4);
+  LAUNCH(S, KC_VELOCITY_UPDATE, k_velocity_update, grid, dim3(256), S->utmp, S->vtmp, S->u, S->v, S->p, S->count,
+         S->solid, S->X, S->Y, dt);
+  return EULER_OK;
+}

@@ -1,0 +1,389 @@
+// k_markers.hip — marker-particle kernels: advection with solid collision, binning into the
+// count grid, order-preserving compaction, fluid sources, and the ordered bit-select primitive
+// they share.
+//
+// The reference's marker array ORDER is observable (see advect below), so everything that
+// changes the array (swap-with-last deletion main.c:112, source appends main.c:288) reproduces
+// the reference's order exactly, in parallel.
+#include "euler_dev.h"
+
+#include <float.h>
+
+// ==========================================================================================
+// ordered select: indices of the set bits of a bit mask, ascending.  Three launches:
+// per-block popcount -> single-workgroup exclusive scan -> per-block emit.
+#define SEL_THREADS 256
+#define SEL_WPT 8                                 // mask words per thread
+#define SEL_WPB (SEL_THREADS * SEL_WPT)           // words per block (131072 items)
+
+__global__ __launch_bounds__(SEL_THREADS) void k_sel_count(const unsigned long long* __restrict__ mask, size_t nwords,
+                                                           unsigned int* __restrict__ block_sums) {
+  const size_t w0 = (size_t)blockIdx.x * SEL_WPB + (size_t)threadIdx.x * SEL_WPT;
+  unsigned int c = 0;
+#pragma unroll
+  for (int k = 0; k < SEL_WPT; ++k)
+    if (w0 + k < nwords) c += __popcll(mask[w0 + k]);
+  c = (unsigned int)eu_wave_sum((double)c);   // exact: counts << 2^53
+  __shared__ unsigned int sw[SEL_THREADS / 64];
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int t = 0;
+    for (int k = 0; k < SEL_THREADS / 64; ++k) t += sw[k];
+    block_sums[blockIdx.x] = t;
+  }
+}
+
+// exclusive scan of block_sums in place (single workgroup, 1024 threads), total -> *total
+__global__ __launch_bounds__(1024) void k_sel_scan(unsigned int* block_sums, size_t nblocks, unsigned int* total) {
+  __shared__ unsigned int buf[1024];
+  __shared__ unsigned int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (size_t base = 0; base < nblocks; base += 1024) {
+    const size_t i = base + threadIdx.x;
+    const unsigned int v = i < nblocks ? block_sums[i] : 0u;
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {   // Hillis-Steele inclusive scan
+      unsigned int t = threadIdx.x >= (unsigned)o ? buf[threadIdx.x - o] : 0u;
+      __syncthreads();
+      buf[threadIdx.x] += t;
+      __syncthreads();
+    }
+    const unsigned int incl = buf[threadIdx.x];
+    const unsigned int c = carry;
+    if (i < nblocks) block_sums[i] = c + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = c + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void k_sel_emit(const unsigned long long* __restrict__ mask, size_t nwords,
+                                                          const unsigned int* __restrict__ block_off,
+                                                          unsigned int* __restrict__ out, size_t out_cap) {
+  const size_t w0 = (size_t)blockIdx.x * SEL_WPB + (size_t)threadIdx.x * SEL_WPT;
+  unsigned long long w[SEL_WPT];
+  unsigned int c = 0;
+#pragma unroll
+  for (int k = 0; k < SEL_WPT; ++k) { w[k] = (w0 + k < nwords) ? mask[w0 + k] : 0ull; c += __popcll(w[k]); }
+  __shared__ unsigned int sc[SEL_THREADS];
+  sc[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 1; o < SEL_THREADS; o <<= 1) {
+    unsigned int t = threadIdx.x >= (unsigned)o ? sc[threadIdx.x - o] : 0u;
+    __syncthreads();
+    sc[threadIdx.x] += t;
+    __syncthreads();
+  }
+  size_t off = (size_t)block_off[blockIdx.x] + sc[threadIdx.x] - c;
+#pragma unroll
+  for (int k = 0; k < SEL_WPT; ++k) {
+    unsigned long long m = w[k];
+    while (m) {
+      const int bit = __ffsll((long long)m) - 1;
+      if (off < out_cap) out[off] = (unsigned int)((w0 + k) * 64 + bit);
+      ++off;
+      m &= m - 1;
+    }
+  }
+}
+
+int eu_ordered_select(euler_sim* S, const unsigned long long* mask, size_t nwords, unsigned int* out_idx,
+                      unsigned int* out_total) {
+  const size_t nblocks = (nwords + SEL_WPB - 1) / SEL_WPB;
+  if (nblocks > S->sel.capacity_blocks) { eu_set_error("ordered select: %zu blocks > capacity", nblocks); return EULER_EINVAL; }
+  const unsigned nb = nblocks ? (unsigned)nblocks : 1u;
+  LAUNCH(S, KC_SELECT, k_sel_count, dim3(nb), dim3(SEL_THREADS), mask, nwords, S->sel.block_sums);
+  LAUNCH(S, KC_SELECT, k_sel_scan, dim3(1), dim3(1024), S->sel.block_sums, nblocks ? nblocks : (size_t)1, out_total);
+  LAUNCH(S, KC_SELECT, k_sel_emit, dim3(nb), dim3(SEL_THREADS), mask, nwords, S->sel.block_sums, out_idx, S->sel_cap);
+  return EULER_OK;
+}
+
+// ==========================================================================================
+// advect_markers (main.c:464-537).
+//
+// The reference walks the marker array sequentially and, when a marker hits a solid after
+// having crossed a cell boundary, executes `dt -= t_prev` on the FUNCTION PARAMETER (main.c:501,
+// 518): every later marker in the array moves with the shortened dt.  Reproduced in parallel:
+//   pass A  every marker moves with the incoming dt (speculation); a marker that would shorten dt
+//           records (theta = time of the colliding crossing, delta = t_prev) and votes in a ballot;
+//   select  the voters' indices in array order;
+//   walk    one wave replays the chain in order: if (theta < dt) dt -= delta  -> list of
+//           (index, dt after it) for the collisions that really fire;
+//   pass B  markers behind the first firing collision are recomputed from their old position
+//           with the dt valid at their index.
+// Under the CFL bound (displacement <= 0.75 cell, main.c:838) a marker crosses at most one
+// boundary per axis, so it can shorten dt at most once; `multi_events` counts violations.
+struct AdvectOut { float px, py, theta, delta; int events; };
+
+__device__ __forceinline__ float time_to(float p0, float p1, float vel) {   // main.c:451-457
+  return fabsf(vel) > 0.f ? (p1 - p0) / vel : FLT_MAX;
+}
+
+__device__ __forceinline__ AdvectOut advect_one(const GridRef& g, const float* __restrict__ u, const float* __restrict__ v,
+                                                const uint8_t* __restrict__ solid, float px, float py, float dt) {
+  AdvectOut o;
+  o.events = 0; o.theta = 0.f; o.delta = 0.f;
+  // velocity_at (main.c:440-449)
+  float vx = eu_interp<1>(g, u, px / EU_H - 1.f, py / EU_H - 0.5f);
+  float vy = eu_interp<2>(g, v, px / EU_H - 0.5f, py / EU_H - 1.f);
+  int xi = (int)floorf(px / EU_H), yi = (int)floorf(py / EU_H);
+  const int xdir = vx > 0 ? 1 : -1;
+  int nxi = xi + (vx > 0 ? 1 : 0);
+  float npx = nxi * EU_H;
+  float tx = time_to(px, npx, vx);
+  const int xoff = vx < 0 ? -1 : 0;
+  const int ydir = vy > 0 ? 1 : -1;
+  int nyi = yi + (vy > 0 ? 1 : 0);
+  float npy = nyi * EU_H;
+  float ty = time_to(py, npy, vy);
+  const int yoff = vy < 0 ? -1 : 0;
+  float t_prev = 0.f, t_near = fminf(tx, ty);
+  int guard = 0;
+  while (t_near < dt && guard++ < 64) {
+    if (tx < ty) {
+      if (solid[(size_t)yi * g.X + (nxi + xoff)]) {
+        if (t_prev > 0.f) { if (o.events == 0) { o.theta = t_near; o.delta = t_prev; } o.events++; }
+        px = px + t_prev * vx; py = py + t_prev * vy;
+        dt -= t_prev; t_near = 0.f; vx = 0.f; tx = FLT_MAX;
+        ty = time_to(py, npy, vy);
+      } else {
+        xi = nxi; nxi = xi + xdir; npx = nxi * EU_H;
+        tx = time_to(px, npx, vx);
+      }
+    } else {
+      if (solid[(size_t)(nyi + yoff) * g.X + xi]) {
+        if (t_prev > 0.f) { if (o.events == 0) { o.theta = t_near; o.delta = t_prev; } o.events++; }
+        px = px + t_prev * vx; py = py + t_prev * vy;
+        dt -= t_prev; t_near = 0.f; vy = 0.f; ty = FLT_MAX;
+        tx = time_to(px, npx, vx);
+      } else {
+        yi = nyi; nyi = yi + ydir; npy = nyi * EU_H;
+        ty = time_to(py, npy, vy);
+      }
+    }
+    t_prev = t_near;
+    t_near = fminf(tx, ty);
+  }
+  const float t = (t_near < FLT_MAX) ? dt : t_prev;
+  o.px = px + t * vx;
+  o.py = py + t * vy;
+  return o;
+}
+
+__global__ __launch_bounds__(256) void k_advect_markers_a(const float2* __restrict__ in, float2* __restrict__ out,
+                                                          const float* __restrict__ u, const float* __restrict__ v,
+                                                          const uint8_t* __restrict__ solid, GridRef g, float dt,
+                                                          unsigned long long n, unsigned long long* __restrict__ evmask,
+                                                          float* __restrict__ ev_theta, float* __restrict__ ev_delta,
+                                                          MarkerState* ms) {
+  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  bool ev = false;
+  if (i < n) {
+    const float2 p = in[i];
+    const AdvectOut o = advect_one(g, u, v, solid, p.x, p.y, dt);
+    out[i] = make_float2(o.px, o.py);
+    if (o.events) {
+      ev = true;
+      ev_theta[i] = o.theta;
+      ev_delta[i] = o.delta;
+      if (o.events > 1) atomicAdd(&ms->multi_events, 1ull);
+    }
+  }
+  const unsigned long long b = __ballot(ev);
+  if ((threadIdx.x & 63) == 0 && (i >> 6) < ((n + 63) >> 6)) evmask[i >> 6] = b;
+}
+
+// one wave: replay the dt chain over the candidate collisions in array order
+__global__ __launch_bounds__(64) void k_marker_walk(const unsigned int* __restrict__ ev_idx, const float* __restrict__ ev_theta,
+                                                    const float* __restrict__ ev_delta, unsigned int* __restrict__ act_idx,
+                                                    float* __restrict__ act_dt, MarkerState* ms, float dt0) {
+  const unsigned int K = ms->n_events;
+  const int lane = threadIdx.x;
+  float dt = dt0;
+  unsigned int M = 0;
+  for (unsigned int base = 0; base < K; base += 64) {
+    unsigned int idx = 0; float th = 0.f, de = 0.f;
+    if (base + lane < K) { idx = ev_idx[base + lane]; th = ev_theta[idx]; de = ev_delta[idx]; }
+    const unsigned int cnt = K - base < 64u ? K - base : 64u;
+    for (unsigned int j = 0; j < cnt; ++j) {
+      const float thj = __shfl(th, (int)j, 64), dej = __shfl(de, (int)j, 64);
+      const unsigned int ij = __shfl(idx, (int)j, 64);
+      if (thj < dt) {
+        dt = dt - dej;
+        if (lane == 0) { act_idx[M] = ij; act_dt[M] = dt; }
+        ++M;
+      }
+    }
+  }
+  if (lane == 0) { ms->n_actual = M; ms->dt_final = dt; ms->total_dt_events += M; }
+}
+
+__global__ __launch_bounds__(256) void k_advect_markers_b(const float2* __restrict__ in, float2* __restrict__ out,
+                                                          const float* __restrict__ u, const float* __restrict__ v,
+                                                          const uint8_t* __restrict__ solid, GridRef g,
+                                                          unsigned long long n, const unsigned int* __restrict__ act_idx,
+                                                          const float* __restrict__ act_dt, const MarkerState* ms) {
+  const unsigned int M = ms->n_actual;
+  if (M == 0) return;
+  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || i <= act_idx[0]) return;
+  // number of firing collisions with index < i  (act_idx ascending)
+  unsigned int lo = 0, hi = M;
+  while (lo < hi) { const unsigned int mid = (lo + hi) >> 1; if (act_idx[mid] < i) lo = mid + 1; else hi = mid; }
+  const float dt = act_dt[lo - 1];
+  const float2 p = in[i];
+  const AdvectOut o = advect_one(g, u, v, solid, p.x, p.y, dt);
+  out[i] = make_float2(o.px, o.py);
+}
+
+int eu_launch_advect_markers(euler_sim* S, float dt) {
+  const unsigned long long n = S->n_markers_host;
+  GridRef g{S->X, S->Y, S->count, S->interp_lim[0], S->interp_lim[1], S->interp_lim[2], S->interp_lim[3]};
+  const float2* in = S->markers[S->cur];
+  float2* out = S->markers[S->cur ^ 1];
+  const unsigned nb = eu_blocks((size_t)n, 256);
+  LAUNCH(S, KC_MARKER_ADVECT, k_advect_markers_a, dim3(nb), dim3(256), in, out, S->u, S->v, S->solid, g, dt, n,
+         S->evmask, S->ev_theta, S->ev_delta, S->ms);
+  int rc = eu_ordered_select(S, S->evmask, (size_t)((n + 63) / 64), S->sel_idx, &S->ms->n_events);
+  if (rc) return rc;
+  LAUNCH(S, KC_MARKER_EVENTS, k_marker_walk, dim3(1), dim3(64), S->sel_idx, S->ev_theta, S->ev_delta, S->act_idx,
+         S->act_dt, S->ms, dt);
+  LAUNCH(S, KC_MARKER_ADVECT, k_advect_markers_b, dim3(nb), dim3(256), in, out, S->u, S->v, S->solid, g, n,
+         S->act_idx, S->act_dt, S->ms);
+  S->cur ^= 1;
+  return EULER_OK;
+}
+
+// ==========================================================================================
+// refresh_marker_counts (main.c:102-117)
+__global__ __launch_bounds__(256) void k_rotate_counts(uint8_t* __restrict__ prev, const uint8_t* __restrict__ cur,
+                                                       unsigned int* __restrict__ count32, size_t C) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < C; i += (size_t)gridDim.x * blockDim.x) {
+    prev[i] = cur[i];
+    count32[i] = 0u;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bin_markers(const float2* __restrict__ m, unsigned long long n,
+                                                     const uint8_t* __restrict__ sink, const uint8_t* __restrict__ solid,
+                                                     unsigned int* count32, unsigned long long* __restrict__ delmask, int X) {
+  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  bool del = false;
+  if (i < n) {
+    const float2 p = m[i];
+    const int x = (int)floorf(p.x / EU_H), y = (int)floorf(p.y / EU_H);
+    const size_t c = (size_t)y * X + x;
+    del = (sink[c] | solid[c]) != 0;
+    if (!del) atomicAdd(&count32[c], 1u);
+  }
+  const unsigned long long b = __ballot(del);
+  if ((threadIdx.x & 63) == 0 && (i >> 6) < ((n + 63) >> 6)) delmask[i >> 6] = b;
+}
+
+// Swap-with-last deletion (main.c:112), in parallel.  The sequential loop leaves survivors with
+// index < n' = n - D in place and fills the k-th hole (ascending) with the k-th survivor taken
+// from the back (descending).  del_idx is ascending, so the holes are its first entries and a
+// back survivor j finds its rank from the number of deletions above it.
+__global__ __launch_bounds__(256) void k_compact_markers(float2* m, const unsigned int* __restrict__ del_idx,
+                                                         const unsigned long long* __restrict__ delmask,
+                                                         const MarkerState* ms) {
+  const unsigned long long n = ms->n, D = ms->n_deleted;
+  if (D == 0) return;
+  const unsigned long long n1 = n - D;
+  for (unsigned long long j = n1 + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; j < n;
+       j += (unsigned long long)gridDim.x * blockDim.x) {
+    if ((delmask[j >> 6] >> (j & 63)) & 1ull) continue;   // deleted: dropped
+    // deletions with index <= j
+    unsigned long long lo = 0, hi = D;
+    while (lo < hi) { const unsigned long long mid = (lo + hi) >> 1; if (del_idx[mid] <= j) lo = mid + 1; else hi = mid; }
+    const unsigned long long del_above = D - lo;
+    const unsigned long long rank = (n - 1 - j) - del_above;   // survivors behind j
+    m[del_idx[rank]] = m[j];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_narrow_counts(uint8_t* __restrict__ count, const unsigned int* __restrict__ count32,
+                                                       size_t C, MarkerState* ms) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < C; i += (size_t)gridDim.x * blockDim.x)
+    count[i] = (uint8_t)count32[i];   // g_marker_count is uint8_t and wraps (main.c:96,114)
+  if (blockIdx.x == 0 && threadIdx.x == 0) ms->n -= ms->n_deleted;
+}
+
+int eu_launch_refresh_counts(euler_sim* S) {
+  const unsigned long long n = S->n_markers_host;
+  LAUNCH(S, KC_MARKER_BIN, k_rotate_counts, dim3(eu_blocks(S->C, 256 * 4, 4096)), dim3(256), S->prev_count, S->count,
+         S->count32, S->C);
+  LAUNCH(S, KC_MARKER_BIN, k_bin_markers, dim3(eu_blocks((size_t)n, 256)), dim3(256), S->markers[S->cur], n, S->sink,
+         S->solid, S->count32, S->evmask, S->X);
+  int rc = eu_ordered_select(S, S->evmask, (size_t)((n + 63) / 64), S->sel_idx, &S->ms->n_deleted);
+  if (rc) return rc;
+  LAUNCH(S, KC_MARKER_COMPACT, k_compact_markers, dim3(256), dim3(256), S->markers[S->cur], S->sel_idx, S->evmask, S->ms);
+  LAUNCH(S, KC_MARKER_BIN, k_narrow_counts, dim3(eu_blocks(S->C, 256 * 4, 4096)), dim3(256), S->count, S->count32, S->C,
+         S->ms);
+  return EULER_OK;
+}
+
+// ==========================================================================================
+// update_fluid_sources (main.c:276-298).  Eligible cells (source && count < 4) in row-major
+// order each append one marker until the array holds MAX-1 markers (the latch, main.c:281,290).
+// The k-th appended marker consumes draws 2k (y) and 2k+1 (x) of the xorshift64* stream: the
+// compiled reference evaluates v2f(x+randf(), y+randf()) right to left.
+__global__ __launch_bounds__(256) void k_source_mask(const uint8_t* __restrict__ source, const uint8_t* __restrict__ count,
+                                                     size_t C, unsigned long long* __restrict__ mask) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool e = i < C && source[i] && count[i] < 4;
+  const unsigned long long b = __ballot(e);
+  if ((threadIdx.x & 63) == 0 && (i >> 6) < ((C + 63) >> 6)) mask[i >> 6] = b;
+}
+
+__global__ void k_source_draws(MarkerState* ms, float* __restrict__ draws) {
+  unsigned long long n = ms->n;
+  const unsigned long long cap = ms->max_markers - 1;
+  int exhausted = ms->exhausted | (n == cap);
+  unsigned long long n_app = 0;
+  if (!exhausted) {
+    n_app = ms->n_events;   // number of eligible cells (select total lands here)
+    if (n_app > cap - n) n_app = cap - n;
+  }
+  unsigned long long st = ms->rng_state;
+  for (unsigned long long k = 0; k < 2 * n_app; ++k) {
+    st ^= st >> 12; st ^= st << 25; st ^= st >> 27;
+    const unsigned int hi = (unsigned int)((st * 0x2545F4914F6CDD1Dull) >> 32);
+    draws[k] = (float)(hi / (double)4294967295u);
+  }
+  ms->rng_state = st;
+  ms->n0_append = n;
+  ms->n_append = (unsigned int)n_app;
+  n += n_app;
+  ms->n = n;
+  ms->exhausted = exhausted | (n == cap && n_app > 0) | (n == cap);
+}
+
+__global__ __launch_bounds__(256) void k_source_place(float2* __restrict__ m, uint8_t* __restrict__ count,
+                                                      const unsigned int* __restrict__ elig, const float* __restrict__ draws,
+                                                      const MarkerState* ms, int X) {
+  const unsigned int n_app = ms->n_append;
+  const unsigned long long n0 = ms->n0_append;
+  for (unsigned int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_app; k += gridDim.x * blockDim.x) {
+    const unsigned int c = elig[k];
+    const int x = (int)(c % (unsigned)X), y = (int)(c / (unsigned)X);
+    const float ry = draws[2 * k], rx = draws[2 * k + 1];
+    m[n0 + k] = make_float2(EU_H * (x + rx), EU_H * (y + ry));
+    count[c] = (uint8_t)(count[c] + 1);
+  }
+}
+
+int eu_launch_sources(euler_sim* S) {
+  if (S->n_source_cells == 0) return EULER_OK;   // no '?' cells: the reference's loop body never runs
+  LAUNCH(S, KC_SOURCES, k_source_mask, dim3(eu_blocks(S->C, 256)), dim3(256), S->source, S->count, S->C, S->cellmask64);
+  int rc = eu_ordered_select(S, S->cellmask64, (S->C + 63) / 64, S->sel_idx, &S->ms->n_events);
+  if (rc) return rc;
+  LAUNCH(S, KC_SOURCES, k_source_draws, dim3(1), dim3(1), S->ms, S->draws);
+  LAUNCH(S, KC_SOURCES, k_source_place, dim3(eu_blocks(S->n_source_cells, 256, 2048)), dim3(256), S->markers[S->cur],
+         S->count, S->sel_idx, S->draws, S->ms, S->X);
+  return EULER_OK;
+}

@@ -1,0 +1,202 @@
+/*
+ * euler.h — C ABI of libeuler_hip.so: the MI355X-native replacement for the simulation path of
+ * cgmb/euler (reference main.c: sim_init :209, sim_step :843, draw :953 and the file-scope
+ * arrays g_u/g_v/g_marker_count/... :64-100 they communicate through).
+ *
+ * Plain C, plain pointers and sizes; no HIP or torch types.  Host code (the `euler` CLI, the
+ * reference's own main loop, bench.py, pytest via ctypes) sees only this file.
+ *
+ * Every function returns EULER_OK (0) or a negative EULER_E* code and never calls exit()
+ * (reference behaviour replaced: main.c:212-215 fprintf+exit(1)).  euler_last_error() returns
+ * a thread-local human-readable message for the last failure.
+ *
+ * A handle is single-caller (not re-entrant), like the reference's globals.
+ */
+#ifndef EULER_H
+#define EULER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EULER_ABI_VERSION 1
+
+enum {
+  EULER_OK = 0,
+  EULER_EINVAL = -1,     /* bad argument */
+  EULER_ENOMEM = -2,     /* host or device allocation failed */
+  EULER_EIO = -3,        /* scenario file unreadable (reference: "Could not load %s!", main.c:213) */
+  EULER_EHIP = -4,       /* a HIP runtime call failed / no gfx950 device */
+  EULER_ESTATE = -5,     /* call order violated (e.g. step before a scenario is loaded) */
+  EULER_ETIMEOUT = -6,   /* an in-kernel bounded wait expired (band pipeline) */
+  EULER_ECOMM = -7       /* multi-GPU communicator failure */
+};
+
+/* How dot(a,b) (reference main.c:629-639, a sequential row-major double sum) is evaluated. */
+enum {
+  EULER_DOT_AUTO = 0,        /* SEQUENTIAL when X*Y <= 65536, else TREE */
+  EULER_DOT_SEQUENTIAL = 1,  /* one thread adds in the reference's order: bit-identical results */
+  EULER_DOT_TREE = 2         /* fixed-shape parallel reduction: deterministic, differs in the last ulps */
+};
+
+/* Preconditioner of the pressure solve. */
+enum {
+  EULER_PRECOND_IC0 = 0,     /* the reference's incomplete Cholesky (main.c:580-627), evaluated as a
+                                dependency-ordered wavefront: bit-identical to the sequential sweep */
+  EULER_PRECOND_JACOBI = 1   /* z = r/diag: NOT the reference's iterates; for roofline comparison only */
+};
+
+/* IC(0) sweep implementation (same arithmetic, different schedule). */
+enum {
+  EULER_SWEEP_AUTO = 0,
+  EULER_SWEEP_BAND = 1,      /* 64-row bands, one wave each, pipelined through tagged granules */
+  EULER_SWEEP_SIMPLE = 2     /* one workgroup, one barrier per anti-diagonal (debug / cross-check) */
+};
+
+typedef struct euler_config {
+  int32_t abi_version;     /* EULER_ABI_VERSION */
+  int32_t X, Y;            /* grid size; reference: compile-time enum X=100, Y=40 (main.c:22-25) */
+  int32_t device;          /* HIP device ordinal */
+  int32_t max_iterations;  /* PCG cap, reference 100 (main.c:735) */
+  double  tol;             /* inf-norm tolerance, reference (double)1e-6f (main.c:736) */
+  int32_t dot_mode;        /* EULER_DOT_* */
+  int32_t precond;         /* EULER_PRECOND_* */
+  int32_t sweep_mode;      /* EULER_SWEEP_* */
+  int32_t max_substeps;    /* reference 8 (main.c:851) */
+  float   frame_time;      /* reference 0.1f (main.c:849) */
+  float   viscosity;       /* 0 = inviscid like the reference (no diffusion stage exists there) */
+  int32_t pcg_poll_interval; /* PCG iterations launched between convergence polls (default 8) */
+  int32_t reserved[8];
+} euler_config;
+
+typedef struct euler_sim euler_sim; /* opaque */
+
+/* Arrays readable/writable through euler_get_field/euler_set_field.  All grids are row-major
+ * [Y][X], full size even for the staggered U/V samples (main.c:62-67). */
+enum {
+  EULER_F_U = 0,          /* float  g_u     main.c:64 */
+  EULER_F_V,              /* float  g_v     main.c:65 */
+  EULER_F_UTMP,           /* float  g_utmp  main.c:66 */
+  EULER_F_VTMP,           /* float  g_vtmp  main.c:67 */
+  EULER_F_SOLID,          /* uint8  g_solid main.c:71 */
+  EULER_F_SOURCE,         /* uint8  g_source main.c:72 */
+  EULER_F_SINK,           /* uint8  g_sink  main.c:73 */
+  EULER_F_COUNT,          /* uint8  g_marker_count main.c:96 */
+  EULER_F_PREV_COUNT,     /* uint8  g_prev_marker_count main.c:97 */
+  EULER_F_MARKERS,        /* float2[n_markers] g_markers main.c:95, in the reference's array order */
+  EULER_F_PRECON,         /* double g_precon main.c:577 (persistent state) */
+  EULER_F_PRESSURE,       /* double p — a stack local of project(), main.c:739; exposed here */
+  EULER_F_PCG_B, EULER_F_PCG_R, EULER_F_PCG_Z, EULER_F_PCG_S, EULER_F_PCG_Q, /* double, main.c:716-745,578 */
+  EULER_F_CELLMASK,       /* uint8: bit0 fluid, bit1..4 fluid at x+1,y+1,x-1,y-1, bits5-7 a_diag (g_a, main.c:552) */
+  EULER_F__COUNT
+};
+
+/* Stages of one substep, in the reference's order (main.c:855-893).  Fused stages are listed
+ * as the reference stages they cover; the arrays they leave behind equal the reference's after
+ * the LAST covered stage. */
+enum {
+  EULER_STAGE_ADVECT_MARKERS = 0,   /* advect_markers            main.c:464-537 */
+  EULER_STAGE_REFRESH_COUNTS,       /* refresh_marker_counts     main.c:102-117 */
+  EULER_STAGE_SOURCES,              /* update_fluid_sources      main.c:276-298 */
+  EULER_STAGE_EXTRAPOLATE,          /* extrapolate(U), extrapolate(V), zero_bounds(U), zero_bounds(V)  main.c:865-868 */
+  EULER_STAGE_ADVECT_VELOCITY,      /* advect_u, advect_v, apply_body_forces, zero_bounds x2          main.c:871-889 */
+  EULER_STAGE_PROJECT,              /* project                   main.c:709-806 */
+  EULER_STAGE__COUNT
+};
+
+/* Single PCG building blocks on the handle's device vectors (kernel-level parity tests and
+ * micro-benchmarks).  Operands are the EULER_F_PCG_* arrays. */
+enum {
+  EULER_OP_BUILD_SYSTEM = 0, /* b, r=b, p=0, cell mask from UTMP/VTMP and dt      main.c:713-741 */
+  EULER_OP_PRECON_FACTOR,    /* E^-1 into PRECON                                  main.c:586-600 */
+  EULER_OP_FORWARD_SOLVE,    /* Q = L^-1 R                                        main.c:602-613 */
+  EULER_OP_BACKWARD_SOLVE,   /* Z = L^-T Q                                        main.c:615-626 */
+  EULER_OP_APPLY_A,          /* Z = A S                                           main.c:679-691 */
+  EULER_OP_DOT_ZR,           /* scalar <- dot(Z,R)                                main.c:629-639 */
+  EULER_OP_DOT_ZS,           /* scalar <- dot(Z,S) */
+  EULER_OP_INF_NORM_R,       /* scalar <- max |R|                                 main.c:654-667 */
+  EULER_OP_UPDATE_PR,        /* P += a S; R -= a Z (a = scalar argument)          main.c:753-754 */
+  EULER_OP_UPDATE_SEARCH,    /* S = Z + a S                                       main.c:669-677 */
+  EULER_OP__COUNT
+};
+
+typedef struct euler_stats {
+  uint64_t frames;              /* euler_step calls completed */
+  uint64_t total_substeps;
+  uint64_t total_pcg_iterations;
+  int32_t  last_substeps;       /* substeps of the last frame (1..8) */
+  int32_t  last_pcg_iterations; /* PCG iterations summed over the last frame */
+  double   last_residual;       /* inf-norm of r when the last solve stopped */
+  float    last_dt;             /* dt of the last substep */
+  uint64_t n_markers;
+  int32_t  source_exhausted;    /* g_source_exhausted, main.c:94 */
+  uint64_t rng_state;           /* xorshift64* state (function-static in the reference, main.c:204) */
+  uint64_t marker_dt_events;    /* collisions that shortened dt for later markers (main.c:501,518) */
+  uint64_t marker_multi_events; /* markers with more than one such collision (expected 0 under the CFL bound) */
+  uint64_t fluid_cells;
+} euler_stats;
+
+/* ---- life cycle ------------------------------------------------------------------------- */
+int  euler_config_default(euler_config* cfg);              /* reference constants, X=100, Y=40 */
+int  euler_create(const euler_config* cfg, euler_sim** out);   /* allocates HBM; needs a gfx950 GPU */
+void euler_destroy(euler_sim* sim);
+const char* euler_last_error(void);
+int  euler_abi_version(void);
+
+/* ---- scenario = sim_init (main.c:209-274) ----------------------------------------------- */
+/* upscale = 0: the reference's streaming parser at native resolution.
+ * upscale = 1: nearest-neighbour resample of the text onto the interior (this build's extension;
+ *              DESIGN.md "Scenario upscaling"). */
+int euler_load_scenario_mem(euler_sim* sim, const char* text, int32_t len, int32_t upscale);
+int euler_load_scenario_file(euler_sim* sim, const char* path, int32_t upscale);
+int euler_load_half_tank(euler_sim* sim);   /* synthetic config 3: solid ring, fluid in y < Y/2, at rest */
+
+/* Host-only pieces of sim_init, usable without a GPU (parser / marker seeding parity tests).
+ * Outputs are caller-owned; solid/source/sink/fluid are [Y][X] uint8, markers float2[4*X*Y]. */
+int euler_parse_scenario(const char* text, int32_t len, int32_t X, int32_t Y, int32_t upscale,
+                         uint8_t* solid, uint8_t* source, uint8_t* sink, uint8_t* fluid);
+int euler_seed_markers(const uint8_t* fluid, int32_t X, int32_t Y, uint64_t* rng_state,
+                       float* markers_xy, uint64_t* n_markers);
+
+/* ---- stepping = sim_step (main.c:843-900) ------------------------------------------------ */
+int euler_step(euler_sim* sim);                    /* one frame: <= max_substeps CFL substeps */
+int euler_timestep(euler_sim* sim, float frame_time_left, float* dt);   /* calculate_timestep, main.c:834-841 */
+int euler_substep(euler_sim* sim, float dt);       /* stages 2..11 of sim_step with a given dt */
+int euler_stage(euler_sim* sim, int32_t stage, float dt);   /* one EULER_STAGE_* (teacher-forced tests) */
+int euler_pcg_op(euler_sim* sim, int32_t op, float dt, double scalar_in, double* scalar_out);
+
+/* ---- state access ------------------------------------------------------------------------ */
+int euler_get_field(euler_sim* sim, int32_t field, void* dst, size_t dst_bytes);
+int euler_set_field(euler_sim* sim, int32_t field, const void* src, size_t src_bytes);
+int euler_set_markers(euler_sim* sim, const float* xy, uint64_t n);
+int euler_set_rng(euler_sim* sim, uint64_t rng_state, int32_t source_exhausted);
+int euler_get_stats(euler_sim* sim, euler_stats* out);
+size_t euler_field_bytes(const euler_sim* sim, int32_t field);   /* current size in bytes */
+
+/* ---- render = draw_rows (main.c:914-951) ------------------------------------------------- */
+/* Fetches only the visible window of the count grid from HBM.  Writes at most cap bytes into out
+ * and stores the full length in *len (call with cap=0 to size the buffer). */
+int euler_render(euler_sim* sim, int32_t wx, int32_t wy, char* out, int32_t cap, int32_t* len);
+/* The same formatter over caller-supplied host grids (no GPU needed). */
+int euler_render_grids(const uint8_t* solid, const uint8_t* sink, const uint8_t* count,
+                       int32_t X, int32_t Y, int32_t wx, int32_t wy, char* out, int32_t cap, int32_t* len);
+
+/* ---- measurement ------------------------------------------------------------------------- */
+/* Per-kernel-class timing with HIP events on the library's own stream.  class_mask bit i
+ * enables class i (see euler_profile_class_name); 0 disables. */
+int euler_profile_enable(euler_sim* sim, uint64_t class_mask);
+int euler_profile_class_count(void);
+const char* euler_profile_class_name(int32_t cls);
+int euler_profile_get(euler_sim* sim, int32_t cls, double* total_ms, uint64_t* launches);
+int euler_profile_reset(euler_sim* sim);
+/* Device-to-device copy bandwidth probe (float4 copy kernel), GB/s read+write. */
+int euler_measure_copy_bandwidth(euler_sim* sim, size_t bytes, int32_t reps, double* gbps);
+int euler_device_name(euler_sim* sim, char* out, int32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EULER_H */

@@ -54,10 +54,13 @@ def build_oracle(fast=False):
 _LIBS = {}
 
 
-def oracle_lib(fast=False):
-    if fast in _LIBS:
-        return _LIBS[fast]
-    lib = C.CDLL(build_oracle(fast))
+def oracle_lib(fast=False, lib_path=None):
+    """lib_path: load this exact build of oracle/euler_oracle.c (bench.py's cpu_baseline leg compiles
+    one for the host it runs on); otherwise the in-tree liboracle.so / liboracle_fast.so."""
+    key = lib_path or fast
+    if key in _LIBS:
+        return _LIBS[key]
+    lib = C.CDLL(lib_path or build_oracle(fast))
     sp = C.POINTER(EoSim)
     fp = C.POINTER(C.c_float)
     dp = C.POINTER(C.c_double)
@@ -93,7 +96,7 @@ def oracle_lib(fast=False):
     lib.eo_render_rows.restype = C.c_int
     lib.eo_fnv1a64.argtypes = [C.c_void_p, C.c_size_t]
     lib.eo_fnv1a64.restype = C.c_uint64
-    _LIBS[fast] = lib
+    _LIBS[key] = lib
     return lib
 
 
@@ -109,8 +112,8 @@ class Oracle:
     FIELDS_U8 = ("solid", "source", "sink", "count", "prev_count")
     FIELDS_F64 = ("precon", "q", "b", "p", "r", "z", "s")
 
-    def __init__(self, X, Y, fast=False):
-        self.lib = oracle_lib(fast)
+    def __init__(self, X, Y, fast=False, lib_path=None):
+        self.lib = oracle_lib(fast, lib_path)
         self.ptr = self.lib.eo_create(X, Y)
         if not self.ptr:
             raise MemoryError("eo_create failed")
