@@ -11,6 +11,8 @@
 
 int eu_launch_build_system(euler_sim* S, float dt);
 int eu_launch_velocity_update(euler_sim* S, float dt);
+int eu_unskew(euler_sim* S, const void* skew, void* rowmajor, int elem_bytes);
+int eu_skew(euler_sim* S, const void* rowmajor, void* skew, int elem_bytes);
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -41,7 +43,10 @@ static const char* k_class_names[KC__COUNT] = {
 void eu_prof_begin(euler_sim* S, int cls) {
   if (!((S->prof_mask >> cls) & 1)) return;
   if (S->ev_used + 2 > S->ev_cap) eu_prof_flush(S);
-  S->ev_cls[S->ev_used / 2] = cls;
+  const int k = S->ev_used / 2;
+  S->ev_cls[k] = cls;
+  S->ev_solve[k] = S->solve_seq;
+  S->ev_iter[k] = S->prof_iter;
   (void)hipEventRecord(S->ev_pool[S->ev_used], S->stream);
 }
 void eu_prof_end(euler_sim* S, int cls) {
@@ -49,15 +54,27 @@ void eu_prof_end(euler_sim* S, int cls) {
   (void)hipEventRecord(S->ev_pool[S->ev_used + 1], S->stream);
   S->ev_used += 2;
 }
+// Accumulate finished event pairs.  A PCG launch of solve q / iteration i did work iff the solve's
+// rhs was non-zero and i < the iteration count the DEVICE reached (launches enqueued beyond
+// convergence return at once and must not dilute the average launch time).
 int eu_prof_flush(euler_sim* S) {
   if (S->ev_used == 0) return EULER_OK;
+  HIPCHK(hipMemcpyAsync(S->sc_host, S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
   HIPCHK(hipStreamSynchronize(S->stream));
+  const int cur_iters = S->sc_host->nonzero ? S->sc_host->iters : -1;
   for (int k = 0; k < S->ev_used; k += 2) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, S->ev_pool[k], S->ev_pool[k + 1]) == hipSuccess) {
-      S->prof_ms[S->ev_cls[k / 2]] += ms;
-      S->prof_launches[S->ev_cls[k / 2]] += 1;
+    const int e = k / 2, cls = S->ev_cls[e];
+    bool active = true;
+    if (S->ev_iter[e] > -2) {
+      const int q = S->ev_solve[e];
+      const int iters = q == S->solve_seq ? cur_iters : (S->solve_seq - q < 256 ? S->solve_iters[q & 255] : 0);
+      active = iters >= 0 && S->ev_iter[e] < iters;
+      if (S->ev_iter[e] == -1) active = iters >= 0;
     }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, S->ev_pool[k], S->ev_pool[k + 1]) != hipSuccess) continue;
+    if (active) { S->prof_ms[cls] += ms; S->prof_launches[cls] += 1; }
+    else S->prof_idle[cls] += 1;
   }
   S->ev_used = 0;
   return EULER_OK;
@@ -83,6 +100,7 @@ extern "C" int euler_profile_reset(euler_sim* S) {
   int rc = eu_prof_flush(S);
   memset(S->prof_ms, 0, sizeof(S->prof_ms));
   memset(S->prof_launches, 0, sizeof(S->prof_launches));
+  memset(S->prof_idle, 0, sizeof(S->prof_idle));
   return rc;
 }
 
@@ -120,12 +138,12 @@ extern "C" void euler_destroy(euler_sim* S) {
   void* dev[] = {S->u, S->v, S->utmp, S->vtmp, S->solid, S->source, S->sink, S->count, S->prev_count, S->count32,
                  S->markers[0], S->markers[1], S->ms, S->evmask, S->ev_theta, S->ev_delta, S->sel_idx, S->act_idx,
                  S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->b, S->p, S->r, S->z, S->s, S->q, S->precon,
-                 S->cellmask, S->sc, S->partial, S->granules, S->ticket};
+                 S->cellmask, S->sc, S->partial, S->granules, S->ticket, S->rowmajor_tmp};
   for (void* p : dev) if (p) (void)hipFree(p);
   if (S->ms_host) (void)hipHostFree(S->ms_host);
   if (S->sc_host) (void)hipHostFree(S->sc_host);
   if (S->ev_pool) { for (int k = 0; k < S->ev_cap; ++k) (void)hipEventDestroy(S->ev_pool[k]); free(S->ev_pool); }
-  free(S->ev_cls);
+  free(S->ev_cls); free(S->ev_solve); free(S->ev_iter);
   if (S->stream) (void)hipStreamDestroy(S->stream);
   free(S);
 }
@@ -176,13 +194,18 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   DALLOC(S->cellmask64, (C + 63) / 64);
   S->sel.capacity_blocks = (mwords + 2047) / 2048 + 1;
   DALLOC(S->sel.block_sums, S->sel.capacity_blocks);
-  DALLOC(S->b, C); DALLOC(S->p, C); DALLOC(S->r, C); DALLOC(S->z, C); DALLOC(S->s, C); DALLOC(S->q, C); DALLOC(S->precon, C);
-  DALLOC(S->cellmask, C);
+  S->geom.X = S->X; S->geom.Y = S->Y;
+  S->geom.nbands = (S->Y + 63) / 64;
+  S->geom.T = S->X + 63;
+  S->geom.S = (size_t)S->geom.nbands * S->geom.T * 64;
+  const size_t SS = S->geom.S;
+  DALLOC(S->b, SS); DALLOC(S->p, SS); DALLOC(S->r, SS); DALLOC(S->z, SS); DALLOC(S->s, SS); DALLOC(S->q, SS); DALLOC(S->precon, SS);
+  DALLOC(S->cellmask, SS);
   DALLOC(S->sc, 1);
-  S->red_blocks = (int)eu_blocks(C, 256 * 16, 2048);
+  S->red_blocks = (int)eu_blocks(SS, 256 * 16, 2048);
   DALLOC(S->partial, (size_t)S->red_blocks);
-  S->nbands = (S->Y + 63) / 64;
-  DALLOC(S->granules, (size_t)S->nbands * S->X * 2);
+  S->gran_stride = (S->X + 31) / 32 * 32;
+  DALLOC(S->granules, (size_t)S->geom.nbands * S->gran_stride * 2);
   DALLOC(S->ticket, 1);
   S->ticket_base = 0; S->epoch = 0;
   HIPCHK(hipHostMalloc((void**)&S->ms_host, sizeof(MarkerState), hipHostMallocDefault));
@@ -194,10 +217,13 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   S->interp_lim[2] = nextafterf((float)(S->X - 1), 0.f);   // V extent (X, Y-1)
   S->interp_lim[3] = nextafterf((float)(S->Y - 2), 0.f);
 
-  S->ev_cap = 8192;
+  S->ev_cap = 16384;
   S->ev_pool = (hipEvent_t*)calloc((size_t)S->ev_cap, sizeof(hipEvent_t));
   S->ev_cls = (int*)calloc((size_t)S->ev_cap / 2, sizeof(int));
-  if (!S->ev_pool || !S->ev_cls) { euler_destroy(S); return EULER_ENOMEM; }
+  S->ev_solve = (int*)calloc((size_t)S->ev_cap / 2, sizeof(int));
+  S->ev_iter = (int*)calloc((size_t)S->ev_cap / 2, sizeof(int));
+  S->prof_iter = -2;
+  if (!S->ev_pool || !S->ev_cls || !S->ev_solve || !S->ev_iter) { euler_destroy(S); return EULER_ENOMEM; }
   for (int k = 0; k < S->ev_cap; ++k) HIPCHK(hipEventCreate(&S->ev_pool[k]));
   HIPCHK(hipStreamSynchronize(S->stream));
   *out = S;
@@ -225,10 +251,10 @@ static int upload_scenario(euler_sim* S, const uint8_t* solid, const uint8_t* so
   HIPCHK(hipMemcpyAsync(S->source, source, C, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(S->sink, sink, C, hipMemcpyHostToDevice, st));
   for (float* f : {S->u, S->v, S->utmp, S->vtmp}) HIPCHK(hipMemsetAsync(f, 0, C * sizeof(float), st));
-  for (double* d : {S->b, S->p, S->r, S->z, S->s, S->q, S->precon}) HIPCHK(hipMemsetAsync(d, 0, C * sizeof(double), st));
+  for (double* d : {S->b, S->p, S->r, S->z, S->s, S->q, S->precon}) HIPCHK(hipMemsetAsync(d, 0, S->geom.S * sizeof(double), st));
   HIPCHK(hipMemsetAsync(S->count, 0, C, st));
   HIPCHK(hipMemsetAsync(S->prev_count, 0, C, st));
-  HIPCHK(hipMemsetAsync(S->cellmask, 0, C, st));
+  HIPCHK(hipMemsetAsync(S->cellmask, 0, S->geom.S, st));
   S->cur = 0;
   HIPCHK(hipMemcpyAsync(S->markers[0], mk.data(), n * sizeof(float2), hipMemcpyHostToDevice, st));
   MarkerState m0;
@@ -427,6 +453,14 @@ extern "C" size_t euler_field_bytes(const euler_sim* S, int32_t f) {
   return b;
 }
 
+static bool field_is_skewed(int f) {
+  return f == EULER_F_PRECON || f == EULER_F_PRESSURE || (f >= EULER_F_PCG_B && f <= EULER_F_PCG_Q) || f == EULER_F_CELLMASK;
+}
+static int ensure_rowmajor_tmp(euler_sim* S) {
+  if (!S->rowmajor_tmp) HIPCHK(hipMalloc((void**)&S->rowmajor_tmp, S->C * sizeof(double)));
+  return EULER_OK;
+}
+
 extern "C" int euler_get_field(euler_sim* S, int32_t f, void* dst, size_t dst_bytes) {
   if (!S || !dst) return EULER_EINVAL;
   void* p; size_t b;
@@ -434,6 +468,12 @@ extern "C" int euler_get_field(euler_sim* S, int32_t f, void* dst, size_t dst_by
   if (rc) return rc;
   if (dst_bytes < b) { eu_set_error("euler_get_field(%d): buffer %zu < %zu bytes", f, dst_bytes, b); return EULER_EINVAL; }
   if (b == 0) return EULER_OK;
+  if (field_is_skewed(f)) {   // the solver's arrays are band-skewed in HBM: gather to row-major first
+    rc = ensure_rowmajor_tmp(S);
+    if (rc) return rc;
+    eu_unskew(S, p, S->rowmajor_tmp, f == EULER_F_CELLMASK ? 1 : 8);
+    p = S->rowmajor_tmp;
+  }
   HIPCHK(hipMemcpyAsync(dst, p, b, hipMemcpyDeviceToHost, S->stream));
   HIPCHK(hipStreamSynchronize(S->stream));
   return EULER_OK;
@@ -446,7 +486,14 @@ extern "C" int euler_set_field(euler_sim* S, int32_t f, const void* src, size_t 
   int rc = field_ptr(S, f, &p, &b);
   if (rc) return rc;
   if (src_bytes != b) { eu_set_error("euler_set_field(%d): %zu bytes given, %zu expected", f, src_bytes, b); return EULER_EINVAL; }
-  HIPCHK(hipMemcpyAsync(p, src, b, hipMemcpyHostToDevice, S->stream));
+  if (field_is_skewed(f)) {
+    rc = ensure_rowmajor_tmp(S);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(S->rowmajor_tmp, src, b, hipMemcpyHostToDevice, S->stream));
+    eu_skew(S, S->rowmajor_tmp, p, f == EULER_F_CELLMASK ? 1 : 8);
+  } else {
+    HIPCHK(hipMemcpyAsync(p, src, b, hipMemcpyHostToDevice, S->stream));
+  }
   HIPCHK(hipStreamSynchronize(S->stream));
   if (f == EULER_F_SOURCE) {
     const uint8_t* s = (const uint8_t*)src;

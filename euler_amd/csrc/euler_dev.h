@@ -61,6 +61,17 @@ struct MarkerState {
   int error;                  // sticky device-side error (bounded waits)
 };
 
+// Band-skewed layout of the solver's private arrays (k_pcg.hip header): element (x,y) lives at
+// ((y/64)*T + x + y%64)*64 + y%64 with T = X + 63; S elements in total, padding carries mask 0.
+struct SkewGeom {
+  int X, Y, nbands, T;
+  size_t S;
+};
+static inline __host__ __device__ size_t skew_index(const SkewGeom& g, int x, int y) {
+  const int l = y & 63;
+  return ((size_t)(y >> 6) * g.T + (size_t)(x + l)) * 64 + l;
+}
+
 struct SelectScratch {
   unsigned int* block_sums;   // [nblocks]
   unsigned int* total;        // [1]
@@ -97,29 +108,36 @@ struct euler_sim {
   float* draws;                           // [2*n_source_cells]
   SelectScratch sel;
 
-  // pressure solve (main.c:552,577-578,716-745)
+  // pressure solve (main.c:552,577-578,716-745): band-skewed arrays of geom.S elements
+  SkewGeom geom;
   double *b, *p, *r, *z, *s, *q, *precon;
   uint8_t* cellmask;
+  double* rowmajor_tmp;   // lazily allocated C doubles for euler_get/set_field of skewed arrays
   PcgScalars* sc;
   PcgScalars* sc_host;    // pinned
   double* partial;        // reduction partials
   int red_blocks;
   // band sweep
-  unsigned long long* granules;  // [nbands][X][2]
+  unsigned long long* granules;  // [nbands][gran_stride][2]
+  int gran_stride;
   unsigned int* ticket;
   unsigned int ticket_base;
   unsigned int epoch;
-  int nbands;
 
   float interp_lim[4];    // nextafterf(extent-1, 0) for U.x, U.y, V.x, V.y (main.c:339-340)
 
   euler_stats stats;
 
-  // profiling
+  // profiling: hipEvent pairs per launch; PCG launches carry (solve, iteration) so that launches
+  // that returned at once (after convergence / all-zero rhs) are NOT counted
   uint64_t prof_mask;
   double prof_ms[KC__COUNT];
   uint64_t prof_launches[KC__COUNT];
-  hipEvent_t* ev_pool; int* ev_cls; int ev_used, ev_cap;
+  uint64_t prof_idle[KC__COUNT];
+  hipEvent_t* ev_pool; int* ev_cls; int* ev_solve; int* ev_iter; int ev_used, ev_cap;
+  int solve_seq;          // index of the solve being enqueued
+  int prof_iter;          // iteration tag for the next launches: -2 = not a PCG launch, -1 = solve prologue
+  int solve_iters[256];   // final iteration count per finished solve (ring), -1 = rhs was all zero
 };
 
 // ------------------------------------------------------------------------------------------

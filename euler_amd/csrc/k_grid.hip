@@ -143,58 +143,70 @@ int eu_launch_advect_velocity(euler_sim* S, float dt) {
 // b, A and the initial PCG vectors (main.c:713-741).  One byte per cell carries everything the
 // solver needs to know about A: fluid flag, the four neighbour-fluid flags (the implicit -1
 // off-diagonals, main.c:561-575) and a_diag = 4 - #solid neighbours (main.c:554-559).
+// Threads run in the solver's band-skewed order (coalesced writes of b, r, p, mask; the row-major
+// velocity/count reads are a diagonal gather, once per substep).  Padding entries are skipped:
+// they keep mask 0 and value 0 from allocation.
 __global__ __launch_bounds__(256) void k_build_system(const float* __restrict__ u, const float* __restrict__ v,
                                                       const uint8_t* __restrict__ count, const uint8_t* __restrict__ solid,
                                                       double* __restrict__ b, double* __restrict__ r, double* __restrict__ p,
-                                                      uint8_t* __restrict__ cellmask, PcgScalars* sc, int X, int Y, float dt) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+                                                      uint8_t* __restrict__ cellmask, PcgScalars* sc, SkewGeom g, float dt) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool nz = false;
-  if (x < X && y < Y) {
-    const size_t i = (size_t)y * X + x;
-    uint8_t m = 0;
-    double bv = 0.0;
-    if (count[i] != 0) {   // never true on the border ring (sinks), so the +-1 / +-X reads are in range
-      m = CM_FLUID;
-      if (count[i + 1]) m |= CM_RIGHT;
-      if (count[i + X]) m |= CM_UP;
-      if (count[i - 1]) m |= CM_LEFT;
-      if (count[i - X]) m |= CM_DOWN;
-      const int diag = 4 - solid[i - 1] - solid[i + 1] - solid[i - X] - solid[i + X];
-      m |= (uint8_t)(diag << CM_DIAG_SHIFT);
-      const float k_inv_scale_f = (EU_H * EU_H) * EU_RHO / dt;                      // float expression, main.c:713
-      const float div_f = (u[i] - u[i - 1] + v[i] - v[i - X]) / EU_H;               // float expression, main.c:720
-      bv = -(double)div_f * (double)k_inv_scale_f;
-      nz = bv != 0.0;
+  if (e < g.S) {
+    const int X = g.X;
+    const int l = (int)(e & 63);
+    const size_t rec = e >> 6;
+    const int band = (int)(rec / g.T), t = (int)(rec % g.T);
+    const int x = t - l, y = band * 64 + l;
+    if (x >= 0 && x < X && y < g.Y) {
+      const size_t i = (size_t)y * X + x;
+      uint8_t m = 0;
+      double bv = 0.0;
+      if (count[i] != 0) {   // never true on the border ring (sinks), so the +-1 / +-X reads are in range
+        m = CM_FLUID;
+        if (count[i + 1]) m |= CM_RIGHT;
+        if (count[i + X]) m |= CM_UP;
+        if (count[i - 1]) m |= CM_LEFT;
+        if (count[i - X]) m |= CM_DOWN;
+        const int diag = 4 - solid[i - 1] - solid[i + 1] - solid[i - X] - solid[i + X];
+        m |= (uint8_t)(diag << CM_DIAG_SHIFT);
+        const float k_inv_scale_f = (EU_H * EU_H) * EU_RHO / dt;                      // float expression, main.c:713
+        const float div_f = (u[i] - u[i - 1] + v[i] - v[i - X]) / EU_H;               // float expression, main.c:720
+        bv = -(double)div_f * (double)k_inv_scale_f;
+        nz = bv != 0.0;
+      }
+      cellmask[e] = m;
+      b[e] = bv;
+      r[e] = bv;
+      p[e] = 0.0;
     }
-    cellmask[i] = m;
-    b[i] = bv;
-    r[i] = bv;
-    p[i] = 0.0;
   }
   if (__any(nz) && (threadIdx.x & 63) == 0) atomicOr(&sc->nonzero, 1);
 }
 
 // Pressure clamp (main.c:773-779) + velocity update (main.c:782-805), fused.  The clamp is
 // idempotent, so applying it on the fly to the neighbour reads races benignly with the write.
+// Row-major threads (coalesced velocity writes); p is gathered from the skewed layout.
 __global__ __launch_bounds__(256) void k_velocity_update(const float* __restrict__ uin, const float* __restrict__ vin,
                                                          float* __restrict__ uout, float* __restrict__ vout,
                                                          double* p, const uint8_t* __restrict__ count,
-                                                         const uint8_t* __restrict__ solid, int X, int Y, float dt) {
+                                                         const uint8_t* __restrict__ solid, SkewGeom g, float dt) {
+  const int X = g.X, Y = g.Y;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= X || y >= Y) return;
   const size_t i = (size_t)y * X + x;
+  const size_t e = skew_index(g, x, y);
   const bool f0 = count[i] != 0;
-  double p0 = p[i];
-  if (f0 && p0 < 0.0) { p0 = 0.0; p[i] = 0.0; }
+  double p0 = p[e];
+  if (f0 && p0 < 0.0) { p0 = 0.0; p[e] = 0.0; }
   const float neg_inv = -(1.f / (EU_RHO * EU_H));   // accel(), main.c:705-707
   if (x < X - 1) {
     const bool f1 = count[i + 1] != 0;
     float o = 0.f;
     if (solid[i] | solid[i + 1]) o = 0.f;
     else if (f0 | f1) {
-      double p1 = p[i + 1];
+      double p1 = p[e + 64];
       if (f1 && p1 < 0.0) p1 = 0.0;
       o = uin[i] + (neg_inv * (float)(p1 - p0)) * dt;
     }
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(256) void k_velocity_update(const float* __restrict
     float o = 0.f;
     if (solid[i] | solid[i + X]) o = 0.f;
     else if (f0 | f1) {
-      double p1 = p[i + X];
+      double p1 = p[skew_index(g, x, y + 1)];
       if (f1 && p1 < 0.0) p1 = 0.0;
       o = vin[i] + (neg_inv * (float)(p1 - p0)) * dt;
     }
@@ -214,15 +226,40 @@ __global__ __launch_bounds__(256) void k_velocity_update(const float* __restrict
 }
 
 int eu_launch_build_system(euler_sim* S, float dt) {
-  dim3 grid((S->X + 63) / 64, (S->Y + 3) / 4);
-  LAUNCH(S, KC_BUILD_SYSTEM, k_build_system, grid, dim3(256), S->utmp, S->vtmp, S->count, S->solid, S->b, S->r, S->p,
-         S->cellmask, S->sc, S->X, S->Y, dt);
+  LAUNCH(S, KC_BUILD_SYSTEM, k_build_system, dim3(eu_blocks(S->geom.S, 256)), dim3(256), S->utmp, S->vtmp, S->count,
+         S->solid, S->b, S->r, S->p, S->cellmask, S->sc, S->geom, dt);
   return EULER_OK;
 }
 
 int eu_launch_velocity_update(euler_sim* S, float dt) {
   dim3 grid((S->X + 63) / 64, (S->Y + 3) / 4);
   LAUNCH(S, KC_VELOCITY_UPDATE, k_velocity_update, grid, dim3(256), S->utmp, S->vtmp, S->u, S->v, S->p, S->count,
-         S->solid, S->X, S->Y, dt);
+         S->solid, S->geom, dt);
+  return EULER_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// skewed <-> row-major conversion for euler_get_field / euler_set_field (tests, render of p)
+template <typename T>
+__global__ __launch_bounds__(256) void k_unskew(const T* __restrict__ skew, T* __restrict__ rowmajor, SkewGeom g) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)g.X * g.Y) rowmajor[i] = skew[skew_index(g, (int)(i % g.X), (int)(i / g.X))];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_skew(const T* __restrict__ rowmajor, T* __restrict__ skew, SkewGeom g) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)g.X * g.Y) skew[skew_index(g, (int)(i % g.X), (int)(i / g.X))] = rowmajor[i];
+}
+
+int eu_unskew(euler_sim* S, const void* skew, void* rowmajor, int elem_bytes) {
+  const unsigned nb = eu_blocks(S->C, 256);
+  if (elem_bytes == 8) hipLaunchKernelGGL(k_unskew<double>, dim3(nb), dim3(256), 0, S->stream, (const double*)skew, (double*)rowmajor, S->geom);
+  else hipLaunchKernelGGL(k_unskew<uint8_t>, dim3(nb), dim3(256), 0, S->stream, (const uint8_t*)skew, (uint8_t*)rowmajor, S->geom);
+  return EULER_OK;
+}
+int eu_skew(euler_sim* S, const void* rowmajor, void* skew, int elem_bytes) {
+  const unsigned nb = eu_blocks(S->C, 256);
+  if (elem_bytes == 8) hipLaunchKernelGGL(k_skew<double>, dim3(nb), dim3(256), 0, S->stream, (const double*)rowmajor, (double*)skew, S->geom);
+  else hipLaunchKernelGGL(k_skew<uint8_t>, dim3(nb), dim3(256), 0, S->stream, (const uint8_t*)rowmajor, (uint8_t*)skew, S->geom);
   return EULER_OK;
 }

@@ -1,15 +1,27 @@
 // k_pcg.hip — the pressure solve: preconditioned conjugate gradient on the masked 5-point
 // Laplacian (reference project(), main.c:709-767, and its kernels main.c:580-702).
 //
+// HBM layout.  Every solver array (b, p, r, z, s, q, precon, cell mask) is private to the solver,
+// so it is stored BAND-SKEWED rather than row-major (struct SkewGeom, euler_dev.h):
+//     element (row y, column x)  ->  band b = y / 64, lane l = y % 64, record t = x + l
+//                                    index  = (b * T + t) * 64 + l,      T = X + 63.
+// A record (64 consecutive elements = 512 B of doubles) is exactly what one wave touches in one
+// step of the IC(0) wavefront sweeps (lane l at column t - l), so the sweeps stream contiguous
+// records: perfectly coalesced, no LDS transposition, pointer += 512 B per step.  The backward
+// sweep walks the same records downwards.  The 5-point neighbours sit at +-64 (left/right) and
+// +-65 (down/up) elements, still coalesced; band-crossing neighbours of lane 0 / lane 63 are one
+// strided access per record.  Padding entries (t - l outside [0,X), rows >= Y) carry mask 0 for
+// ever: every kernel treats them as non-fluid cells, which removes all edge predicates.
+//
 // Device-resident control: alpha, beta, sigma, the residual norm, the iteration count and the
-// `done` flag live in PcgScalars in HBM; every kernel starts by reading them and returns at once
-// after convergence, so the host enqueues iterations without a round trip and polls `done` every
-// few iterations.
+// `done` flag live in PcgScalars in HBM; every kernel reads them first and returns at once after
+// convergence, so the host enqueues iterations without a round trip and polls `done` every few
+// iterations.
 //
 // Bit-exactness: every element-wise kernel evaluates the reference's expression in the
-// reference's association order (compiled with -ffp-contract=off); the IC(0) triangular sweeps
-// have no reduction, so any dependency-respecting schedule gives the sequential sweep's bits;
-// dot() is either replayed sequentially (EULER_DOT_SEQUENTIAL) or reduced in a fixed tree.
+// reference's association order (-ffp-contract=off); the IC(0) sweeps have no reduction, so any
+// dependency-respecting schedule gives the sequential sweep's bits; dot() is either replayed in
+// the reference's row-major order (EULER_DOT_SEQUENTIAL) or reduced in a fixed tree.
 #include "euler_dev.h"
 
 #define RED_THREADS 256
@@ -30,7 +42,7 @@ __device__ __forceinline__ void pcg_scalar_step(PcgScalars* sc, int op, double v
   }
 }
 
-// fixed-shape block reduction; result valid in thread 0
+// fixed-shape block reductions; result valid in thread 0
 __device__ __forceinline__ double block_sum(double v) {
   __shared__ double sw[RED_THREADS / 64];
   v = eu_wave_sum(v);
@@ -66,13 +78,13 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_final(const double* __re
   if (threadIdx.x == 0) pcg_scalar_step(sc, op, v);
 }
 
-// dot(a,b) over fluid cells -> per-block partials (tree mode)
+// dot(a,b) over fluid cells -> per-block partials (tree mode); layout-agnostic
 __global__ __launch_bounds__(RED_THREADS) void k_dot_partial(const double* __restrict__ a, const double* __restrict__ b,
-                                                             const uint8_t* __restrict__ mask, size_t C,
+                                                             const uint8_t* __restrict__ mask, size_t S,
                                                              double* __restrict__ partial, const PcgScalars* sc, int force) {
   if (!force && pcg_idle(sc)) return;
-  const size_t chunk = (C + gridDim.x - 1) / gridDim.x;
-  const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < C ? lo + chunk : C;
+  const size_t chunk = (S + gridDim.x - 1) / gridDim.x;
+  const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < S ? lo + chunk : S;
   double t = 0.0;
   for (size_t i = lo + threadIdx.x; i < hi; i += RED_THREADS)
     if (mask[i] & CM_FLUID) t += a[i] * b[i];
@@ -80,22 +92,29 @@ __global__ __launch_bounds__(RED_THREADS) void k_dot_partial(const double* __res
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
-// dot(a,b) replayed in the reference's order (main.c:629-639): products are formed by the whole
-// workgroup, the running sum by one thread.  Bit-identical; meant for small grids.
+// dot(a,b) replayed in the reference's ROW-MAJOR order (main.c:629-639): products are gathered by
+// the whole workgroup, the running sum is formed by one thread.  Bit-identical; for small grids.
 #define SEQ_TILE 2048
 __global__ __launch_bounds__(256) void k_dot_sequential(const double* __restrict__ a, const double* __restrict__ b,
-                                                        const uint8_t* __restrict__ mask, size_t C, PcgScalars* sc,
+                                                        const uint8_t* __restrict__ mask, SkewGeom g, PcgScalars* sc,
                                                         int op, int force) {
   if (!force && pcg_idle(sc)) return;
   __shared__ double prod[SEQ_TILE];
   __shared__ uint8_t fl[SEQ_TILE];
+  const size_t C = (size_t)g.X * g.Y;
   double total = 0.0;   // `double total = 0.f`
   for (size_t base = 0; base < C; base += SEQ_TILE) {
     for (int k = threadIdx.x; k < SEQ_TILE; k += 256) {
-      const size_t i = base + k;
-      const bool f = i < C && (mask[i] & CM_FLUID);
+      const size_t c = base + k;
+      bool f = false;
+      double pr = 0.0;
+      if (c < C) {
+        const size_t i = skew_index(g, (int)(c % g.X), (int)(c / g.X));
+        f = (mask[i] & CM_FLUID) != 0;
+        if (f) pr = a[i] * b[i];
+      }
       fl[k] = f;
-      prod[k] = f ? a[i] * b[i] : 0.0;
+      prod[k] = pr;
     }
     __syncthreads();
     if (threadIdx.x == 0)
@@ -107,24 +126,27 @@ __global__ __launch_bounds__(256) void k_dot_sequential(const double* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
-// apply_a (main.c:679-691): z = A s on fluid cells (other entries of z are already 0).
+// apply_a (main.c:679-691): z = A s on fluid cells (other entries of z stay 0).
 // In tree mode the block also leaves its partial of dot(z,s).
 __global__ __launch_bounds__(RED_THREADS) void k_apply_a(const double* __restrict__ s, double* __restrict__ z,
-                                                         const uint8_t* __restrict__ mask, int X, size_t C,
+                                                         const uint8_t* __restrict__ mask, SkewGeom g,
                                                          double* __restrict__ partial, const PcgScalars* sc, int force) {
   if (!force && pcg_idle(sc)) return;
-  const size_t chunk = (C + gridDim.x - 1) / gridDim.x;
-  const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < C ? lo + chunk : C;
+  const size_t S = g.S;
+  const size_t chunk = (((S + gridDim.x - 1) / gridDim.x) + 63) & ~(size_t)63;   // whole records per block
+  const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < S ? lo + chunk : S;
+  const long long band_hop = 64ll * (g.T - 63);   // same column, adjacent band: see header
   double t = 0.0;
   for (size_t i = lo + threadIdx.x; i < hi; i += RED_THREADS) {
     const uint8_t m = mask[i];
     if (!(m & CM_FLUID)) continue;
+    const int l = (int)(i & 63);
     const double si = s[i];
     double o = (double)(int)(m >> CM_DIAG_SHIFT) * si;
-    o = o - ((m & CM_RIGHT) ? s[i + 1] : 0.0);
-    o = o - ((m & CM_UP) ? s[i + X] : 0.0);
-    o = o - ((m & CM_LEFT) ? s[i - 1] : 0.0);
-    o = o - ((m & CM_DOWN) ? s[i - X] : 0.0);
+    o = o - ((m & CM_RIGHT) ? s[i + 64] : 0.0);
+    o = o - ((m & CM_UP) ? s[l < 63 ? i + 65 : i + band_hop - 63] : 0.0);
+    o = o - ((m & CM_LEFT) ? s[i - 64] : 0.0);
+    o = o - ((m & CM_DOWN) ? s[l > 0 ? i - 65 : i - band_hop + 63] : 0.0);
     z[i] = o;
     t += o * si;
   }
@@ -135,14 +157,14 @@ __global__ __launch_bounds__(RED_THREADS) void k_apply_a(const double* __restric
 // p += alpha s ; r -= alpha z (fmadd x2, main.c:753-754) ; per-block max |r| (inf_norm, main.c:654-667)
 __global__ __launch_bounds__(RED_THREADS) void k_update_pr(double* __restrict__ p, double* __restrict__ r,
                                                            const double* __restrict__ s, const double* __restrict__ z,
-                                                           const uint8_t* __restrict__ mask, size_t C,
+                                                           const uint8_t* __restrict__ mask, size_t S,
                                                            double* __restrict__ partial, const PcgScalars* sc, int force,
                                                            double alpha_arg) {
   if (!force && pcg_idle(sc)) return;
   const double alpha = force ? alpha_arg : sc->alpha;
   const double nalpha = -alpha;
-  const size_t chunk = (C + gridDim.x - 1) / gridDim.x;
-  const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < C ? lo + chunk : C;
+  const size_t chunk = (S + gridDim.x - 1) / gridDim.x;
+  const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < S ? lo + chunk : S;
   double mx = 0.0;
   for (size_t i = lo + threadIdx.x; i < hi; i += RED_THREADS) {
     if (!(mask[i] & CM_FLUID)) continue;
@@ -158,9 +180,9 @@ __global__ __launch_bounds__(RED_THREADS) void k_update_pr(double* __restrict__ 
 
 // max |r| only (EULER_OP_INF_NORM_R)
 __global__ __launch_bounds__(RED_THREADS) void k_inf_norm(const double* __restrict__ r, const uint8_t* __restrict__ mask,
-                                                          size_t C, double* __restrict__ partial) {
-  const size_t chunk = (C + gridDim.x - 1) / gridDim.x;
-  const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < C ? lo + chunk : C;
+                                                          size_t S, double* __restrict__ partial) {
+  const size_t chunk = (S + gridDim.x - 1) / gridDim.x;
+  const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < S ? lo + chunk : S;
   double mx = 0.0;
   for (size_t i = lo + threadIdx.x; i < hi; i += RED_THREADS)
     if (mask[i] & CM_FLUID) { const double a = fabs(r[i]); if (a > mx) mx = a; }
@@ -171,11 +193,11 @@ __global__ __launch_bounds__(RED_THREADS) void k_inf_norm(const double* __restri
 // s = z + beta s (update_search, main.c:669-677); with COPY: s = z (the memcpy at main.c:746)
 template <bool COPY>
 __global__ __launch_bounds__(256) void k_update_search(double* __restrict__ s, const double* __restrict__ z,
-                                                       const uint8_t* __restrict__ mask, size_t C, const PcgScalars* sc,
+                                                       const uint8_t* __restrict__ mask, size_t S, const PcgScalars* sc,
                                                        int force, double beta_arg) {
   if (!force && pcg_idle(sc)) return;
   const double beta = force ? beta_arg : sc->beta;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < C; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (size_t)gridDim.x * blockDim.x) {
     if (COPY) s[i] = z[i];
     else if (mask[i] & CM_FLUID) s[i] = z[i] + beta * s[i];
   }
@@ -183,9 +205,9 @@ __global__ __launch_bounds__(256) void k_update_search(double* __restrict__ s, c
 
 // Jacobi stand-in preconditioner (not the reference's iterates; roofline comparison only)
 __global__ __launch_bounds__(256) void k_jacobi(const double* __restrict__ r, double* __restrict__ z,
-                                                const uint8_t* __restrict__ mask, size_t C, const PcgScalars* sc, int force) {
+                                                const uint8_t* __restrict__ mask, size_t S, const PcgScalars* sc, int force) {
   if (!force && pcg_idle(sc)) return;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < C; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (size_t)gridDim.x * blockDim.x) {
     const uint8_t m = mask[i];
     const int d = m >> CM_DIAG_SHIFT;
     z[i] = (m & CM_FLUID) ? r[i] / (double)(d ? d : 1) : 0.0;
@@ -208,12 +230,13 @@ __global__ __launch_bounds__(256) void k_jacobi(const double* __restrict__ r, do
 enum { SW_FACTOR = 0, SW_FORWARD = 1, SW_BACKWARD = 2 };
 
 struct SweepArgs {
-  int X, Y, nbands;
+  SkewGeom g;
   const uint8_t* mask;
   double* pre;            // precon: in/out for SW_FACTOR, in otherwise
   const double* in;       // r (forward) / q (backward); unused for factor
   double* out;            // q (forward) / z (backward); unused for factor
-  unsigned long long* granules;   // [nbands][X][2] tagged hand-off of a band's last row
+  unsigned long long* granules;   // [nbands][gran_stride][2] tagged hand-off of a band's edge row
+  int gran_stride;
   unsigned int* ticket;
   unsigned int ticket_base;
   unsigned int epoch;
@@ -251,7 +274,8 @@ __device__ __forceinline__ double sweep_cell(uint8_t m, double in, double pre_he
 template <int OP>
 __global__ __launch_bounds__(1024) void k_sweep_simple(SweepArgs a) {
   if (!a.force && pcg_idle(a.sc)) return;
-  const int X = a.X, Y = a.Y;
+  const SkewGeom g = a.g;
+  const int X = g.X, Y = g.Y;
   constexpr bool BWD = OP == SW_BACKWARD;
   double* dst = OP == SW_FACTOR ? a.pre : a.out;
   for (int d = 0; d < X + Y - 1; ++d) {
@@ -259,12 +283,12 @@ __global__ __launch_bounds__(1024) void k_sweep_simple(SweepArgs a) {
       const int xl = d - yl;
       if (xl < 0 || xl >= X) continue;
       const int x = BWD ? X - 1 - xl : xl, y = BWD ? Y - 1 - yl : yl;
-      const size_t i = (size_t)y * X + x;
+      const size_t i = skew_index(g, x, y);
       const uint8_t m = a.mask[i];
       if (OP == SW_FACTOR && !(m & CM_FLUID)) continue;
       double r = 0.0;
-      if (m & CM_FLUID) {
-        const size_t io = BWD ? i + 1 : i - 1, in_ = BWD ? i + X : i - X;   // fluid cells are interior
+      if (m & CM_FLUID) {   // fluid cells are interior: the neighbours exist
+        const size_t io = skew_index(g, BWD ? x + 1 : x - 1, y), in_ = skew_index(g, x, BWD ? y + 1 : y - 1);
         const double own_val = OP == SW_FACTOR ? a.pre[io] : dst[io];
         const double nb_val = OP == SW_FACTOR ? a.pre[in_] : dst[in_];
         const double own_pre = OP == SW_FORWARD ? a.pre[io] : 0.0, nb_pre = OP == SW_FORWARD ? a.pre[in_] : 0.0;
@@ -276,116 +300,161 @@ __global__ __launch_bounds__(1024) void k_sweep_simple(SweepArgs a) {
   }
 }
 
-// --- production schedule: 64-row bands, one wave each, skewed along the row -------------------
-// Lane l of band b owns row 64 b + l (in sweep order) and visits column tau - l at step tau, so
-// the value of the row below arrives from lane l-1 one step later by a wave shift, and the
-// previous column's value is the lane's own register.  Bands pipeline through HBM: the last lane
-// publishes each value as two 8-byte {epoch, half} granules (one write-through store each); the
-// next band's lane 0 polls them 16 columns at a time.  Bands take their index from a ticket, so a
-// band can only wait on a band that is already running: no residency assumption, no deadlock.
-#define SW_PF 8         // prefetch distance (steps) of the per-lane row streams
-#define SW_POLL 16      // boundary columns fetched per poll
+// --- production schedule: one wave per 64-row band, streaming the band's records ----------------
+// Lane l owns row 64 b + l.  Forward: records t = 0 .. T-1, lane l is at column t - l, the row
+// below arrives from lane l-1 (DPP wave_shr:1), the previous column is the lane's own register.
+// Backward: records T-1 .. 0, the row above arrives from lane l+1 (DPP wave_shl:1).
+// Bands pipeline through HBM: the edge lane (63 forward, 0 backward) stashes its results in LDS
+// and every 32 columns the wave publishes them as two 8-byte {epoch, half} granules per column
+// (agent-scope relaxed atomic stores = write-through); the next band's edge lane takes them 32
+// columns at a time, polled one block early.  Bands take their order from a ticket, so a band
+// only ever waits on a band that is already running: no residency assumption, no deadlock.
+#define SW_PF 8          // register prefetch distance in steps (5 VMEM ops/step, vmcnt holds 63)
+#define SW_BLK 32        // columns per publish/poll block
 #define SW_SPIN_LIMIT (1u << 22)
 
-__device__ __forceinline__ double wave_shift_up(double v) {   // lane l receives lane l-1's value
-  return __shfl_up(v, 1, 64);
+#define DPP_WAVE_SHL1 0x130
+#define DPP_WAVE_SHR1 0x138
+
+// lane l <- neighbouring lane's v; the lane without a source (0 for shr, 63 for shl) receives `edge`
+template <int CTRL>
+__device__ __forceinline__ double wave_shift_inject(double v, double edge) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane_uniform) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane_uniform),
+                          __builtin_amdgcn_readlane(__double2loint(v), lane_uniform));
 }
 
 template <int OP>
-__global__ __launch_bounds__(64) void k_sweep_band(SweepArgs a) {
+__global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
+  __shared__ double stash[64];   // the edge lane's last 64 results, by logical column & 63
   const int lane = threadIdx.x;
   unsigned int tk = 0;
   if (lane == 0) tk = atomicAdd(a.ticket, 1u);
-  tk = __shfl(tk, 0, 64);
-  const int band = (int)(tk - a.ticket_base);
+  tk = __builtin_amdgcn_readfirstlane(tk);
+  const int ord = (int)(tk - a.ticket_base);          // position in the band pipeline
   if (!a.force && pcg_idle(a.sc)) return;
   constexpr bool BWD = OP == SW_BACKWARD;
-  const int X = a.X, Y = a.Y;
-  const int yl = band * 64 + lane;
-  const bool row_ok = yl < Y;
-  const int y = BWD ? Y - 1 - yl : yl;
-  const size_t row = (size_t)(row_ok ? y : 0) * X;
-  const bool has_below = band > 0;                       // a previous band exists
-  const bool publish = band + 1 < a.nbands && lane == 63;
-  const size_t row_prev = has_below ? (size_t)(BWD ? y + 1 : y - 1) * X : 0;   // lane 0's neighbour row
-  unsigned long long* gr_out = a.granules + (size_t)band * X * 2;
-  const unsigned long long* gr_in = a.granules + (size_t)(has_below ? band - 1 : 0) * X * 2;
+  constexpr int CTRL = BWD ? DPP_WAVE_SHL1 : DPP_WAVE_SHR1;
+  const SkewGeom g = a.g;
+  const int X = g.X, T = g.T, nb = g.nbands;
+  const int band = BWD ? nb - 1 - ord : ord;
+  const bool has_prev = ord > 0;                      // a band before us in sweep order
+  const bool publish = ord + 1 < nb;
+  const int edge_out = BWD ? 0 : 63;                  // lane whose row the next band needs
+  const size_t base = (size_t)band * T * 64;
+  const uint8_t* mask = a.mask + base;
+  const double* pre = a.pre + base;
+  const double* in = (OP == SW_FACTOR ? a.pre : a.in) + base;
+  double* dst = (OP == SW_FACTOR ? a.pre : a.out) + base;
+  unsigned long long* gr_out = a.granules + (size_t)ord * a.gran_stride * 2;
+  const unsigned long long* gr_in = a.granules + (size_t)(has_prev ? ord - 1 : 0) * a.gran_stride * 2;
   const unsigned long long tag = (unsigned long long)a.epoch << 32;
-  double* dst = OP == SW_FACTOR ? a.pre : a.out;
 
-  // per-lane row streams, prefetched SW_PF steps ahead
-  double in_buf[SW_PF], pre_buf[SW_PF], npre_buf[SW_PF];
+  // forward only: precon of (row-1, same column) as a fourth stream.  For lane >= 1 that is record
+  // t-1, lane-1 of this band; for lane 0 it is lane 63 of band-1 at record t+63.  Both advance by
+  // one record per step, so it is one per-lane pointer.
+  const double* npre_ptr = pre;
+  if (OP == SW_FORWARD) {
+    if (lane > 0) npre_ptr = pre - 64 + (lane - 1);                                  // + t*64 -> (t-1)*64 + lane-1
+    else npre_ptr = band > 0 ? pre - (size_t)T * 64 + (size_t)63 * 64 + 63 : pre;    // + t*64 -> band-1, (t+63)*64 + 63
+  }
+
+  // ---- register prefetch ring ---------------------------------------------------------------
+  double in_buf[SW_PF], pre_buf[SW_PF], np_buf[SW_PF];
   uint8_t m_buf[SW_PF];
-  auto fetch = [&](int tau, int slot) {
-    const int xl = tau - lane;
-    const bool ok = row_ok && xl >= 0 && xl < X;
-    const int x = BWD ? X - 1 - xl : xl;
-    in_buf[slot] = (ok && OP != SW_FACTOR) ? a.in[row + x] : 0.0;
-    pre_buf[slot] = ok ? a.pre[row + x] : 0.0;
-    m_buf[slot] = ok ? a.mask[row + x] : (uint8_t)0;
-    // lane 0 also needs precon of the row below it, which is static data in forward solves
-    npre_buf[slot] = (OP == SW_FORWARD && ok && lane == 0 && has_below) ? a.pre[row_prev + x] : 0.0;
+  auto fetch = [&](int s, int slot) {
+    int sc_ = s < T ? s : T - 1;                       // clamp: steps >= T are never executed
+    const int t = BWD ? T - 1 - sc_ : sc_;
+    const size_t e = (size_t)t * 64 + lane;
+    in_buf[slot] = OP == SW_FACTOR ? 0.0 : in[e];
+    pre_buf[slot] = pre[e];
+    m_buf[slot] = mask[e];
+    if (OP == SW_FORWARD) {
+      const int tn = (lane > 0 && t == 0) ? 1 : t;     // record -1 does not exist (only lane 0 is live at t = 0)
+      np_buf[slot] = npre_ptr[(size_t)tn * 64];
+    } else np_buf[slot] = 0.0;
   };
 #pragma unroll
   for (int j = 0; j < SW_PF; ++j) fetch(j, j);
 
+  // ---- boundary row of the previous band: 32 columns per poll, issued one block early ---------
+  unsigned long long g0 = 0, g1 = 0;     // lanes 0..31: granule pair of logical column 32*k + lane
+  auto issue_poll = [&](int blk) {
+    const int xl = SW_BLK * blk + lane;
+    if (has_prev && lane < SW_BLK && xl < X) {
+      g0 = __hip_atomic_load(&gr_in[(size_t)xl * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      g1 = __hip_atomic_load(&gr_in[(size_t)xl * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  auto poll_ready = [&](int blk) {
+    const int xl = SW_BLK * blk + lane;
+    const bool want = has_prev && lane < SW_BLK && xl < X;
+    return !want || (((g0 >> 32) == a.epoch) && ((g1 >> 32) == a.epoch));
+  };
+  issue_poll(0);
+
   double own_val = 0.0, own_pre = 0.0;     // previous column of this row
-  double out_val = 0.0, out_pre = 0.0;     // this lane's result of the previous step (for lane+1)
-  double bnd = 0.0;                        // lane j: boundary value of column poll_base + j
-  const int nsteps = X + 63;
-  for (int t0 = 0; t0 < nsteps; t0 += SW_PF) {
+  double out_val = 0.0;                    // this lane's result of the previous step (for the next lane)
+  double bnd = 0.0;                        // lane j: previous band's edge value at logical column 32k + j
+  const int nblk = (X + SW_BLK - 1) / SW_BLK;
+
+  for (int s0 = 0; s0 < T; s0 += SW_PF) {
 #pragma unroll
     for (int j = 0; j < SW_PF; ++j) {
-      const int tau = t0 + j;
-      // ---- boundary row of the previous band (lane 0 consumes column tau at step tau)
-      if (has_below && (tau % SW_POLL) == 0 && tau < X) {
-        const int xl = tau + lane;
-        const bool want = lane < SW_POLL && xl < X;
-        const int x = BWD ? X - 1 - xl : xl;
-        unsigned long long g0 = 0, g1 = 0;
-        unsigned int spins = 0;
-        while (true) {
-          bool ready = true;
-          if (want) {
-            g0 = __hip_atomic_load(&gr_in[(size_t)x * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            g1 = __hip_atomic_load(&gr_in[(size_t)x * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ready = ((g0 >> 32) == a.epoch) && ((g1 >> 32) == a.epoch);
+      const int s = s0 + j;
+      if (s < T) {
+        // ---- every 32 steps: retire the poll of this block, start the next one
+        if ((s & (SW_BLK - 1)) == 0) {
+          const int blk = s / SW_BLK;
+          if (has_prev && blk < nblk) {
+            unsigned int spins = 0;
+            while (!__all(poll_ready(blk))) {
+              if (++spins > SW_SPIN_LIMIT) { if (lane == 0) atomicExch(a.error, 2); break; }
+              __builtin_amdgcn_s_sleep(1);
+              issue_poll(blk);
+            }
+            bnd = __longlong_as_double((long long)((g0 & 0xffffffffull) | (g1 << 32)));
+            issue_poll(blk + 1);
           }
-          if (__all(ready)) break;
-          if (++spins > SW_SPIN_LIMIT) { if (lane == 0) atomicExch(a.error, 1); break; }
-          __builtin_amdgcn_s_sleep(2);
         }
-        const unsigned long long bits = (g0 & 0xffffffffull) | (g1 << 32);
-        bnd = __longlong_as_double((long long)bits);
-      }
-      // ---- this step's operands
-      const double cin = in_buf[j], cpre = pre_buf[j], cnpre = npre_buf[j];
-      const uint8_t cm = m_buf[j];
-      fetch(tau + SW_PF, j);
-      const int xl = tau - lane;
-      const bool act = row_ok && xl >= 0 && xl < X;
-      const int x = BWD ? X - 1 - xl : xl;
-      double nb_val = wave_shift_up(out_val);
-      double nb_pre = OP == SW_FORWARD ? wave_shift_up(out_pre) : 0.0;
-      const double bsel = __shfl(bnd, tau % SW_POLL, 64);   // executed by the whole wave
-      if (lane == 0) {
-        nb_val = has_below ? bsel : 0.0;
-        nb_pre = cnpre;
-      }
-      double res = 0.0;
-      if (act) {
-        res = sweep_cell<OP>(cm, cin, cpre, own_val, own_pre, nb_val, nb_pre);
-        if (OP != SW_FACTOR || (cm & CM_FLUID)) dst[row + x] = res;
+        const double cin = in_buf[j], cpre = pre_buf[j], cnp = np_buf[j];
+        const uint8_t cm = m_buf[j];
+        fetch(s + SW_PF, j);
+        const int t = BWD ? T - 1 - s : s;
+        // the edge lane consumes logical column s of the previous band (lane s & 31 of bnd)
+        const double bsel = has_prev ? readlane_f64(bnd, s & (SW_BLK - 1)) : 0.0;
+        const double nb_val = wave_shift_inject<CTRL>(out_val, bsel);
+        const double res = sweep_cell<OP>(cm, cin, cpre, own_val, own_pre, nb_val, cnp);
+        dst[(size_t)t * 64 + lane] = res;
         own_val = res;
         own_pre = cpre;
+        out_val = res;
+        // ---- hand the edge row to the next band: logical column s - 63 is done
         if (publish) {
-          const unsigned long long bits = (unsigned long long)__double_as_longlong(res);
-          __hip_atomic_store(&gr_out[(size_t)x * 2], tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(&gr_out[(size_t)x * 2 + 1], tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int xl = s - 63;
+          if (lane == edge_out) stash[xl & 63] = res;
+          if (xl >= 0 && (xl & (SW_BLK - 1)) == SW_BLK - 1) {
+            const int col = xl - (SW_BLK - 1) + lane;
+            if (lane < SW_BLK && col < X) {
+              const unsigned long long bits = (unsigned long long)__double_as_longlong(stash[col & 63]);
+              __hip_atomic_store(&gr_out[(size_t)col * 2], tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(&gr_out[(size_t)col * 2 + 1], tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
         }
       }
-      out_val = res;
-      out_pre = cpre;
+    }
+  }
+  if (publish && (X & (SW_BLK - 1)) != 0) {   // last, partial block of columns
+    const int col = (X - 1) / SW_BLK * SW_BLK + lane;
+    if (lane < SW_BLK && col < X) {
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(stash[col & 63]);
+      __hip_atomic_store(&gr_out[(size_t)col * 2], tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&gr_out[(size_t)col * 2 + 1], tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -394,28 +463,23 @@ __global__ __launch_bounds__(64) void k_sweep_band(SweepArgs a) {
 // host-side launch helpers
 static SweepArgs make_sweep_args(euler_sim* S, int op, int force) {
   SweepArgs a;
-  a.X = S->X; a.Y = S->Y; a.nbands = S->nbands;
+  a.g = S->geom;
   a.mask = S->cellmask; a.pre = S->precon;
   a.in = op == SW_FORWARD ? S->r : S->q;
   a.out = op == SW_FORWARD ? S->q : S->z;
-  a.granules = S->granules; a.ticket = S->ticket;
+  a.granules = S->granules; a.gran_stride = S->gran_stride; a.ticket = S->ticket;
   a.ticket_base = S->ticket_base; a.epoch = S->epoch;
   a.sc = S->sc; a.force = force; a.error = &S->ms->error;
   return a;
 }
 
-static bool use_band(const euler_sim* S) {
-  if (S->cfg.sweep_mode == EULER_SWEEP_SIMPLE) return false;
-  return true;
-}
-
 template <int OP>
 static int launch_sweep(euler_sim* S, int cls, int force) {
-  if (use_band(S)) {
+  if (S->cfg.sweep_mode != EULER_SWEEP_SIMPLE) {
     S->epoch += 1;
     SweepArgs a = make_sweep_args(S, OP, force);
-    LAUNCH(S, cls, k_sweep_band<OP>, dim3(S->nbands), dim3(64), a);
-    S->ticket_base += (unsigned)S->nbands;
+    LAUNCH(S, cls, k_sweep_skew<OP>, dim3(S->geom.nbands), dim3(64), a);
+    S->ticket_base += (unsigned)S->geom.nbands;
   } else {
     SweepArgs a = make_sweep_args(S, OP, force);
     LAUNCH(S, cls, k_sweep_simple<OP>, dim3(1), dim3(1024), a);
@@ -424,11 +488,10 @@ static int launch_sweep(euler_sim* S, int cls, int force) {
 }
 
 static int launch_dot(euler_sim* S, const double* a, const double* b, int fin_op, int force) {
-  const bool seq = S->cfg.dot_mode == EULER_DOT_SEQUENTIAL;
-  if (seq) {
-    LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), a, b, S->cellmask, S->C, S->sc, fin_op, force);
+  if (S->cfg.dot_mode == EULER_DOT_SEQUENTIAL) {
+    LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), a, b, S->cellmask, S->geom, S->sc, fin_op, force);
   } else {
-    LAUNCH(S, KC_DOT, k_dot_partial, dim3(S->red_blocks), dim3(RED_THREADS), a, b, S->cellmask, S->C, S->partial, S->sc, force);
+    LAUNCH(S, KC_DOT, k_dot_partial, dim3(S->red_blocks), dim3(RED_THREADS), a, b, S->cellmask, S->geom.S, S->partial, S->sc, force);
     LAUNCH(S, KC_REDUCE_FINAL, k_reduce_final<false>, dim3(1), dim3(RED_THREADS), S->partial, S->red_blocks, S->sc, fin_op, force);
   }
   return EULER_OK;
@@ -436,7 +499,7 @@ static int launch_dot(euler_sim* S, const double* a, const double* b, int fin_op
 
 static int launch_precondition(euler_sim* S, int force) {   // z = M^-1 r
   if (S->cfg.precond == EULER_PRECOND_JACOBI) {
-    LAUNCH(S, KC_JACOBI, k_jacobi, dim3(eu_blocks(S->C, 256 * 4, 4096)), dim3(256), S->r, S->z, S->cellmask, S->C, S->sc, force);
+    LAUNCH(S, KC_JACOBI, k_jacobi, dim3(eu_blocks(S->geom.S, 256 * 4, 4096)), dim3(256), S->r, S->z, S->cellmask, S->geom.S, S->sc, force);
     return EULER_OK;
   }
   launch_sweep<SW_FORWARD>(S, KC_FORWARD_SOLVE, force);
@@ -445,11 +508,10 @@ static int launch_precondition(euler_sim* S, int force) {   // z = M^-1 r
 }
 
 static int launch_apply_a_and_alpha(euler_sim* S, int force) {
-  const bool seq = S->cfg.dot_mode == EULER_DOT_SEQUENTIAL;
-  LAUNCH(S, KC_APPLY_A, k_apply_a, dim3(S->red_blocks), dim3(RED_THREADS), S->s, S->z, S->cellmask, S->X, S->C, S->partial,
+  LAUNCH(S, KC_APPLY_A, k_apply_a, dim3(S->red_blocks), dim3(RED_THREADS), S->s, S->z, S->cellmask, S->geom, S->partial,
          S->sc, force);
-  if (seq) {
-    LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), S->z, S->s, S->cellmask, S->C, S->sc, (int)FIN_ALPHA, force);
+  if (S->cfg.dot_mode == EULER_DOT_SEQUENTIAL) {
+    LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), S->z, S->s, S->cellmask, S->geom, S->sc, (int)FIN_ALPHA, force);
   } else {
     LAUNCH(S, KC_REDUCE_FINAL, k_reduce_final<false>, dim3(1), dim3(RED_THREADS), S->partial, S->red_blocks, S->sc,
            (int)FIN_ALPHA, force);
@@ -467,39 +529,51 @@ __global__ void k_pcg_reset(PcgScalars* sc, double tol, int max_iters) {
 
 // project() (main.c:709-806)
 int eu_launch_project(euler_sim* S, float dt) {
+  // the previous solve's final scalars are in sc_host by now (copied at its end, synced since)
+  S->solve_iters[S->solve_seq & 255] = S->sc_host->nonzero ? S->sc_host->iters : -1;
+  S->solve_seq += 1;
+  S->prof_iter = -1;
+  const size_t SS = S->geom.S;
   LAUNCH(S, KC_MISC, k_pcg_reset, dim3(1), dim3(1), S->sc, S->cfg.tol, S->cfg.max_iterations);
   eu_launch_build_system(S, dt);
   // if (!all_zero(r)) { ... }: every kernel below is a no-op when sc->nonzero == 0
   if (S->cfg.precond == EULER_PRECOND_IC0) launch_sweep<SW_FACTOR>(S, KC_PRECON_FACTOR, 0);   // once per solve: A is fixed
   launch_precondition(S, 0);
-  LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<true>, dim3(eu_blocks(S->C, 256 * 4, 4096)), dim3(256), S->s, S->z,
-         S->cellmask, S->C, S->sc, 0, 0.0);
+  LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<true>, dim3(eu_blocks(SS, 256 * 4, 4096)), dim3(256), S->s, S->z,
+         S->cellmask, SS, S->sc, 0, 0.0);
   launch_dot(S, S->z, S->r, FIN_SIGMA_INIT, 0);
+  HIPCHK(hipMemcpyAsync(S->sc_host, S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
+  HIPCHK(hipStreamSynchronize(S->stream));
   const int poll = S->cfg.pcg_poll_interval > 0 ? S->cfg.pcg_poll_interval : 8;
   const int max_it = S->cfg.max_iterations;
   int it = 0;
-  bool stop = false;
+  bool stop = !S->sc_host->nonzero;   // all_zero(r): main.c:742
   while (it < max_it && !stop) {
     const int chunk_end = it + poll < max_it ? it + poll : max_it;
     for (; it < chunk_end; ++it) {
+      S->prof_iter = it;
       launch_apply_a_and_alpha(S, 0);
       LAUNCH(S, KC_UPDATE_PR, k_update_pr, dim3(S->red_blocks), dim3(RED_THREADS), S->p, S->r, S->s, S->z, S->cellmask,
-             S->C, S->partial, S->sc, 0, 0.0);
+             SS, S->partial, S->sc, 0, 0.0);
       LAUNCH(S, KC_REDUCE_FINAL, k_reduce_final<true>, dim3(1), dim3(RED_THREADS), S->partial, S->red_blocks, S->sc,
              (int)FIN_RNORM, 0);
       if (it + 1 < max_it) {   // the tail of the last iteration (main.c:760-765) is never consumed
+        // these belong to iteration `it` but only run if it did not converge: tag them it+1 so that
+        // they count as active only when the device went on to iteration it+1
+        S->prof_iter = it + 1;
         launch_precondition(S, 0);
         launch_dot(S, S->z, S->r, FIN_BETA, 0);
-        LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<false>, dim3(eu_blocks(S->C, 256 * 4, 4096)), dim3(256), S->s, S->z,
-               S->cellmask, S->C, S->sc, 0, 0.0);
+        LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<false>, dim3(eu_blocks(SS, 256 * 4, 4096)), dim3(256), S->s, S->z,
+               S->cellmask, SS, S->sc, 0, 0.0);
       }
     }
     if (it < max_it) {   // poll the device-side convergence flag
       HIPCHK(hipMemcpyAsync(S->sc_host, S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
       HIPCHK(hipStreamSynchronize(S->stream));
-      stop = S->sc_host->done || !S->sc_host->nonzero;
+      stop = S->sc_host->done != 0;
     }
   }
+  S->prof_iter = -2;
   eu_launch_velocity_update(S, dt);
   HIPCHK(hipMemcpyAsync(S->sc_host, S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
   return EULER_OK;
@@ -508,6 +582,7 @@ int eu_launch_project(euler_sim* S, float dt) {
 // single building blocks for kernel-level parity tests (euler_pcg_op)
 int eu_launch_pcg_op(euler_sim* S, int op, float dt, double a, double* out) {
   const bool want_scalar = op == EULER_OP_DOT_ZR || op == EULER_OP_DOT_ZS || op == EULER_OP_INF_NORM_R;
+  const size_t SS = S->geom.S;
   switch (op) {
     case EULER_OP_BUILD_SYSTEM:
       LAUNCH(S, KC_MISC, k_pcg_reset, dim3(1), dim3(1), S->sc, S->cfg.tol, S->cfg.max_iterations);
@@ -517,23 +592,23 @@ int eu_launch_pcg_op(euler_sim* S, int op, float dt, double a, double* out) {
     case EULER_OP_FORWARD_SOLVE: launch_sweep<SW_FORWARD>(S, KC_FORWARD_SOLVE, 1); break;
     case EULER_OP_BACKWARD_SOLVE: launch_sweep<SW_BACKWARD>(S, KC_BACKWARD_SOLVE, 1); break;
     case EULER_OP_APPLY_A:
-      LAUNCH(S, KC_APPLY_A, k_apply_a, dim3(S->red_blocks), dim3(RED_THREADS), S->s, S->z, S->cellmask, S->X, S->C,
+      LAUNCH(S, KC_APPLY_A, k_apply_a, dim3(S->red_blocks), dim3(RED_THREADS), S->s, S->z, S->cellmask, S->geom,
              S->partial, S->sc, 1);
       break;
     case EULER_OP_DOT_ZR: launch_dot(S, S->z, S->r, FIN_STORE_ONLY, 1); break;
     case EULER_OP_DOT_ZS: launch_dot(S, S->z, S->s, FIN_STORE_ONLY, 1); break;
     case EULER_OP_INF_NORM_R:
-      LAUNCH(S, KC_UPDATE_PR, k_inf_norm, dim3(S->red_blocks), dim3(RED_THREADS), S->r, S->cellmask, S->C, S->partial);
+      LAUNCH(S, KC_UPDATE_PR, k_inf_norm, dim3(S->red_blocks), dim3(RED_THREADS), S->r, S->cellmask, SS, S->partial);
       LAUNCH(S, KC_REDUCE_FINAL, k_reduce_final<true>, dim3(1), dim3(RED_THREADS), S->partial, S->red_blocks, S->sc,
              (int)FIN_STORE_ONLY, 1);
       break;
     case EULER_OP_UPDATE_PR:
       LAUNCH(S, KC_UPDATE_PR, k_update_pr, dim3(S->red_blocks), dim3(RED_THREADS), S->p, S->r, S->s, S->z, S->cellmask,
-             S->C, S->partial, S->sc, 1, a);
+             SS, S->partial, S->sc, 1, a);
       break;
     case EULER_OP_UPDATE_SEARCH:
-      LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<false>, dim3(eu_blocks(S->C, 256 * 4, 4096)), dim3(256), S->s, S->z,
-             S->cellmask, S->C, S->sc, 1, a);
+      LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<false>, dim3(eu_blocks(SS, 256 * 4, 4096)), dim3(256), S->s, S->z,
+             S->cellmask, SS, S->sc, 1, a);
       break;
     default: eu_set_error("unknown pcg op %d", op); return EULER_EINVAL;
   }

@@ -52,7 +52,8 @@ enum {
 /* IC(0) sweep implementation (same arithmetic, different schedule). */
 enum {
   EULER_SWEEP_AUTO = 0,
-  EULER_SWEEP_BAND = 1,      /* 64-row bands, one wave each, pipelined through tagged granules */
+  EULER_SWEEP_BAND = 1,      /* one wave per 64-row band streaming band-skewed records, bands pipelined
+                                through tagged granules (DESIGN.md "IC(0) sweeps") */
   EULER_SWEEP_SIMPLE = 2     /* one workgroup, one barrier per anti-diagonal (debug / cross-check) */
 };
 

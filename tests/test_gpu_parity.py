@@ -158,7 +158,8 @@ def compare_all(o, sim, what):
 
 
 @pytest.mark.parametrize("size,scn,frames", [((130, 70), "block", 12), ((257, 129), "filter", 8),
-                                             ((192, 200), "waterfall", 10), ((320, 192), "weird-edges", 6)])
+                                             ((192, 200), "waterfall", 10), ((320, 192), "weird-edges", 6),
+                                             ((112, 48), "filter", 40), ((144, 200), "block", 30)])
 def test_ragged_grids_bit_exact_vs_oracle(size, scn, frames):
     """Sizes that are not multiples of the 64-row band / 64-lane tiles, several bands deep."""
     o, sim = make_pair(size[0], size[1], scn, dot_mode=ea.DOT_SEQUENTIAL)
@@ -248,6 +249,56 @@ def test_pcg_kernels_vs_oracle():
     assert abs((x * Ay).sum() - (Ax * y).sum()) < 1e-9 * np.abs(x * Ay).sum()
 
 
+SWEEP_SHAPES = [(144, 100), (128, 70), (64, 300), (1024, 64), (208, 130), (96, 64), (100, 40), (333, 127)]
+
+
+@pytest.mark.parametrize("sweep", [ea.SWEEP_BAND, ea.SWEEP_SIMPLE])
+@pytest.mark.parametrize("shape", SWEEP_SHAPES)
+def test_ic0_sweeps_random_masks_bit_exact(shape, sweep):
+    """The three IC(0) sweeps (E^-1 factor incl. STALE entries of non-fluid neighbours, forward,
+    backward) on random fluid/solid patterns and random vectors, every schedule, bit-exact.
+    Shapes cover widths that are / are not multiples of the 32-column hand-off block, one band and
+    many bands, and a partial top band."""
+    X2, Y2 = shape
+    rng = np.random.default_rng(X2 * 1000 + Y2)
+    count = np.zeros((Y2, X2), np.uint8)
+    solid = np.zeros((Y2, X2), np.uint8)
+    inner = (slice(1, Y2 - 1), slice(1, X2 - 1))
+    count[inner] = (rng.random((Y2 - 2, X2 - 2)) < 0.7) * rng.integers(1, 5, (Y2 - 2, X2 - 2))
+    solid[inner] = rng.random((Y2 - 2, X2 - 2)) < 0.1
+    count[solid > 0] = 0
+    sink = np.zeros((Y2, X2), np.uint8)
+    sink[0, :] = sink[-1, :] = sink[:, 0] = sink[:, -1] = 1
+    stale = rng.random((Y2, X2)) * (rng.random((Y2, X2)) < 0.5)      # old precon values, some zero
+    fluid = count > 0
+    r = np.where(fluid, rng.standard_normal((Y2, X2)), 0.0)
+    zero_f = np.zeros((Y2, X2), np.float32)
+
+    o = Oracle(X2, Y2)
+    o.count[...] = count; o.solid[...] = solid; o.sink[...] = sink
+    o.precon[...] = stale
+    o.utmp[...] = 0; o.vtmp[...] = 0
+    o.lib.eo_build_system(o.ptr, np.float32(0.1), o.f32p(o.utmp), o.f32p(o.vtmp))
+    o.r[...] = r
+    o.lib.eo_apply_preconditioner(o.ptr, o.f64p(o.r), o.f64p(o.z))
+
+    sim = ea.Simulation(X2, Y2, dot_mode=ea.DOT_SEQUENTIAL, sweep_mode=sweep)
+    for f, a in ((ea.F_SOLID, solid), (ea.F_SOURCE, np.zeros_like(solid)), (ea.F_SINK, sink), (ea.F_COUNT, count),
+                 (ea.F_PREV_COUNT, count), (ea.F_UTMP, zero_f), (ea.F_VTMP, zero_f), (ea.F_PRECON, stale)):
+        sim.set(f, a)
+    sim.set_markers(np.zeros((0, 2), np.float32))
+    sim.pcg_op(ea.OP_BUILD_SYSTEM, 0.1)
+    sim.set(ea.F_PCG_R, r)
+    for rep in range(2):       # twice: the second factorisation starts from the first one's output, like the reference
+        sim.pcg_op(ea.OP_PRECON_FACTOR)
+        assert_bits(sim.get(ea.F_PRECON), o.precon, "precon %s rep %d" % (shape, rep))
+        sim.pcg_op(ea.OP_FORWARD_SOLVE)
+        assert_bits(sim.get(ea.F_PCG_Q), o.q, "q %s" % (shape,))
+        sim.pcg_op(ea.OP_BACKWARD_SOLVE)
+        assert_bits(sim.get(ea.F_PCG_Z), o.z, "z %s" % (shape,))
+        o.lib.eo_apply_preconditioner(o.ptr, o.f64p(o.r), o.f64p(o.z))
+
+
 def test_band_and_simple_sweeps_agree_bitwise():
     sims = []
     for mode in (ea.SWEEP_BAND, ea.SWEEP_SIMPLE):
@@ -260,13 +311,13 @@ def test_band_and_simple_sweeps_agree_bitwise():
 
 
 def test_post_projection_divergence_small_when_converged():
-    """Property check at a size the oracle is not consulted: whenever PCG converged (residual <= tol),
-    the projected field is divergence-free on fluid cells whose pressure was not clamped to 0
-    (main.c:773-779) and that have no air neighbour... restricted here to cells with p > 0."""
-    text = scenario_text(load("weird-edges_frames.npz"))
-    sim = ea.Simulation(200, 80).load_text(text, upscale=True)
+    """Property check: whenever the last solve of a frame converged (residual <= tol),
+    the projected field is divergence-free - checked on fluid cells whose own and four neighbours'
+    pressures are positive, i.e. untouched by the p >= 0 clamp (main.c:773-779).
+    div(u) = dt * residual <= 1e-7 in exact arithmetic; float velocities of magnitude ~10 add ~1e-5."""
+    sim = ea.Simulation(X, Y).load_text(scenario_text(load("block_frames.npz")))
     checked = 0
-    for _ in range(12):
+    for _ in range(60):
         sim.step()
         st = sim.stats()
         if st.last_pcg_iterations == 0 or st.last_residual > 1e-6:
@@ -275,14 +326,13 @@ def test_post_projection_divergence_small_when_converged():
         p = sim.get(ea.F_PRESSURE)
         div = np.zeros_like(u)
         div[1:, 1:] = u[1:, 1:] - u[1:, :-1] + v[1:, 1:] - v[:-1, 1:]
-        interior = (cnt > 0) & (p > 0)
-        interior[1:-1, 1:-1] &= (p[1:-1, 2:] > 0) & (p[1:-1, :-2] > 0) & (p[2:, 1:-1] > 0) & (p[:-2, 1:-1] > 0) | \
-            ~((cnt[1:-1, 2:] > 0) & (cnt[1:-1, :-2] > 0) & (cnt[2:, 1:-1] > 0) & (cnt[:-2, 1:-1] > 0)) & False
+        ok = (cnt > 0) & (p > 0)
+        interior = np.zeros_like(ok)
+        interior[1:-1, 1:-1] = ok[1:-1, 1:-1] & ok[1:-1, 2:] & ok[1:-1, :-2] & ok[2:, 1:-1] & ok[:-2, 1:-1]
         if interior.any():
-            # |A p - b| <= 1e-6 in the solver's scaling (b = -div * h^2 rho / dt): |div| <= 1e-6 * dt ... generous bound
             assert np.abs(div[interior]).max() < 1e-4, np.abs(div[interior]).max()
             checked += 1
-    assert checked > 0
+    assert checked > 10
 
 
 def test_half_tank_hydrostatic():
