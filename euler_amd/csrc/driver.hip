@@ -137,9 +137,11 @@ extern "C" void euler_destroy(euler_sim* S) {
   if (S->stream) (void)hipStreamSynchronize(S->stream);
   void* dev[] = {S->u, S->v, S->utmp, S->vtmp, S->solid, S->source, S->sink, S->count, S->prev_count, S->count32,
                  S->markers[0], S->markers[1], S->ms, S->evmask, S->ev_theta, S->ev_delta, S->sel_idx, S->act_idx,
-                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->b, S->p, S->r, S->z, S->s, S->q, S->precon,
-                 S->cellmask, S->sc, S->partial, S->granules, S->ticket, S->rowmajor_tmp};
+                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->granules, S->ticket,
+                 S->rowmajor_tmp};
   for (void* p : dev) if (p) (void)hipFree(p);
+  for (double* d : {S->b, S->p, S->r, S->z, S->s, S->q, S->precon}) if (d) (void)hipFree(d - EU_SKEW_SLACK);
+  if (S->cellmask) (void)hipFree(S->cellmask - EU_SKEW_SLACK);
   if (S->ms_host) (void)hipHostFree(S->ms_host);
   if (S->sc_host) (void)hipHostFree(S->sc_host);
   if (S->ev_pool) { for (int k = 0; k < S->ev_cap; ++k) (void)hipEventDestroy(S->ev_pool[k]); free(S->ev_pool); }
@@ -197,14 +199,17 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   S->geom.X = S->X; S->geom.Y = S->Y;
   S->geom.nbands = (S->Y + 63) / 64;
   S->geom.T = S->X + 63;
-  S->geom.S = (size_t)S->geom.nbands * S->geom.T * 64;
+  S->geom.TS = ((S->geom.T + 7) & ~7) + 32;   // the sweeps run whole pairs of 8-step blocks and prefetch 8 further
+  S->geom.S = (size_t)S->geom.nbands * S->geom.TS * 64;
   const size_t SS = S->geom.S;
-  DALLOC(S->b, SS); DALLOC(S->p, SS); DALLOC(S->r, SS); DALLOC(S->z, SS); DALLOC(S->s, SS); DALLOC(S->q, SS); DALLOC(S->precon, SS);
-  DALLOC(S->cellmask, SS);
+  if ((SS + EU_SKEW_SLACK) * 8 >= ((size_t)1 << 32)) { eu_set_error("grid too large for 32-bit record offsets"); euler_destroy(S); return EULER_EINVAL; }
+  // skewed arrays carry EU_SKEW_SLACK zeroed elements in front (the backward sweep prefetches below record 0)
+  for (double** d : {&S->b, &S->p, &S->r, &S->z, &S->s, &S->q, &S->precon}) { DALLOC(*d, SS + EU_SKEW_SLACK); *d += EU_SKEW_SLACK; }
+  DALLOC(S->cellmask, SS + EU_SKEW_SLACK); S->cellmask += EU_SKEW_SLACK;
   DALLOC(S->sc, 1);
   S->red_blocks = (int)eu_blocks(SS, 256 * 16, 2048);
   DALLOC(S->partial, (size_t)S->red_blocks);
-  S->gran_stride = (S->X + 31) / 32 * 32;
+  S->gran_stride = (S->X + 7) / 8 * 8;
   DALLOC(S->granules, (size_t)S->geom.nbands * S->gran_stride * 2);
   DALLOC(S->ticket, 1);
   S->ticket_base = 0; S->epoch = 0;

@@ -62,14 +62,17 @@ struct MarkerState {
 };
 
 // Band-skewed layout of the solver's private arrays (k_pcg.hip header): element (x,y) lives at
-// ((y/64)*T + x + y%64)*64 + y%64 with T = X + 63; S elements in total, padding carries mask 0.
+// ((y/64)*TS + x + y%64)*64 + y%64.  A band has T = X + 63 live records and a stride of
+// TS = roundup8(T) + 32 records; S = nbands*TS*64 elements in total; padding carries mask 0.
+// Every skewed array also has EU_SKEW_SLACK elements of zeroed slack in front of element 0.
+#define EU_SKEW_SLACK (32 * 64)
 struct SkewGeom {
-  int X, Y, nbands, T;
+  int X, Y, nbands, T, TS;
   size_t S;
 };
 static inline __host__ __device__ size_t skew_index(const SkewGeom& g, int x, int y) {
   const int l = y & 63;
-  return ((size_t)(y >> 6) * g.T + (size_t)(x + l)) * 64 + l;
+  return ((size_t)(y >> 6) * g.TS + (size_t)(x + l)) * 64 + l;
 }
 
 struct SelectScratch {

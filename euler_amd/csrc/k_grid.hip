@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void k_build_system(const float* __restrict__ 
     const int X = g.X;
     const int l = (int)(e & 63);
     const size_t rec = e >> 6;
-    const int band = (int)(rec / g.T), t = (int)(rec % g.T);
+    const int band = (int)(rec / g.TS), t = (int)(rec % g.TS);
     const int x = t - l, y = band * 64 + l;
     if (x >= 0 && x < X && y < g.Y) {
       const size_t i = (size_t)y * X + x;

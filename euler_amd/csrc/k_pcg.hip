@@ -4,7 +4,8 @@
 // HBM layout.  Every solver array (b, p, r, z, s, q, precon, cell mask) is private to the solver,
 // so it is stored BAND-SKEWED rather than row-major (struct SkewGeom, euler_dev.h):
 //     element (row y, column x)  ->  band b = y / 64, lane l = y % 64, record t = x + l
-//                                    index  = (b * T + t) * 64 + l,      T = X + 63.
+//                                    index  = (b * TS + t) * 64 + l
+// (T = X + 63 live records per band, band stride TS = roundup8(T) + 32 records).
 // A record (64 consecutive elements = 512 B of doubles) is exactly what one wave touches in one
 // step of the IC(0) wavefront sweeps (lane l at column t - l), so the sweeps stream contiguous
 // records: perfectly coalesced, no LDS transposition, pointer += 512 B per step.  The backward
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_apply_a(const double* __restric
   const size_t S = g.S;
   const size_t chunk = (((S + gridDim.x - 1) / gridDim.x) + 63) & ~(size_t)63;   // whole records per block
   const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < S ? lo + chunk : S;
-  const long long band_hop = 64ll * (g.T - 63);   // same column, adjacent band: see header
+  const long long band_hop = 64ll * (g.TS - 63);  // same column, adjacent band: see header
   double t = 0.0;
   for (size_t i = lo + threadIdx.x; i < hi; i += RED_THREADS) {
     const uint8_t m = mask[i];
@@ -301,18 +302,26 @@ __global__ __launch_bounds__(1024) void k_sweep_simple(SweepArgs a) {
 }
 
 // --- production schedule: one wave per 64-row band, streaming the band's records ----------------
-// Lane l owns row 64 b + l.  Forward: records t = 0 .. T-1, lane l is at column t - l, the row
+// Lane l owns row 64 b + l.  Forward: records t = 0, 1, ..., lane l is at column t - l, the row
 // below arrives from lane l-1 (DPP wave_shr:1), the previous column is the lane's own register.
-// Backward: records T-1 .. 0, the row above arrives from lane l+1 (DPP wave_shl:1).
-// Bands pipeline through HBM: the edge lane (63 forward, 0 backward) stashes its results in LDS
-// and every 32 columns the wave publishes them as two 8-byte {epoch, half} granules per column
-// (agent-scope relaxed atomic stores = write-through); the next band's edge lane takes them 32
-// columns at a time, polled one block early.  Bands take their order from a ticket, so a band
-// only ever waits on a band that is already running: no residency assumption, no deadlock.
-#define SW_PF 8          // register prefetch distance in steps (5 VMEM ops/step, vmcnt holds 63)
-#define SW_BLK 32        // columns per publish/poll block
+// Backward: records T-1, T-2, ..., the row above arrives from lane l+1 (DPP wave_shl:1).
+// The loop body is 8 steps = one hand-off block, fully unrolled, so every lane index below is a
+// compile-time constant:
+//   * operands of step s+8 are fetched while step s computes (4 coalesced 512-B record loads, one
+//     32-bit byte offset per stream from the uniform array base, += 512 per step);
+//   * the edge lane's result (lane 63 forward / 0 backward: logical column s-63) is moved with
+//     v_readlane + a lane-select into lane (s-63)&7 of one register pair; when 8 columns are complete,
+//     lanes 0..7 publish them as two 8-byte {epoch, half} granules each (agent-scope relaxed
+//     atomic stores = write-through);
+//   * the next band's edge lane takes its 8 boundary values from lanes 0..7 of a register pair
+//     fetched one block earlier (v_readlane -> the `old` operand of the DPP shift).
+// Bands take their order from a ticket, so a band only ever waits on a band that is already
+// running: no residency assumption, no deadlock.  No LDS is used.
+// Records t >= T of a band and the 32 records in front of each array are dead padding (mask 0):
+// the loop runs whole pairs of blocks and prefetches unconditionally.
+#define SW_BLK 8
+#define SW_CATCHUP 4
 #define SW_SPIN_LIMIT (1u << 22)
-
 #define DPP_WAVE_SHL1 0x130
 #define DPP_WAVE_SHR1 0x138
 
@@ -327,10 +336,13 @@ __device__ __forceinline__ double readlane_f64(double v, int lane_uniform) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane_uniform),
                           __builtin_amdgcn_readlane(__double2loint(v), lane_uniform));
 }
+template <typename T>
+__device__ __forceinline__ T ld_off(const T* base, unsigned byte_off) {   // uniform base + 32-bit offset
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 
 template <int OP>
 __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
-  __shared__ double stash[64];   // the edge lane's last 64 results, by logical column & 63
   const int lane = threadIdx.x;
   unsigned int tk = 0;
   if (lane == 0) tk = atomicAdd(a.ticket, 1u);
@@ -339,123 +351,140 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
   if (!a.force && pcg_idle(a.sc)) return;
   constexpr bool BWD = OP == SW_BACKWARD;
   constexpr int CTRL = BWD ? DPP_WAVE_SHL1 : DPP_WAVE_SHR1;
+  constexpr int EDGE_OUT = BWD ? 0 : 63;              // lane whose row the next band needs
   const SkewGeom g = a.g;
-  const int X = g.X, T = g.T, nb = g.nbands;
+  const int X = g.X, T = g.T, TS = g.TS, nb = g.nbands;
   const int band = BWD ? nb - 1 - ord : ord;
   const bool has_prev = ord > 0;                      // a band before us in sweep order
   const bool publish = ord + 1 < nb;
-  const int edge_out = BWD ? 0 : 63;                  // lane whose row the next band needs
-  const size_t base = (size_t)band * T * 64;
-  const uint8_t* mask = a.mask + base;
-  const double* pre = a.pre + base;
-  const double* in = (OP == SW_FACTOR ? a.pre : a.in) + base;
-  double* dst = (OP == SW_FACTOR ? a.pre : a.out) + base;
+  // all streams are addressed as (array - slack) + unsigned offset, so that the backward sweep's
+  // prefetch below record 0 of band 0 stays a non-negative 32-bit offset
+  const double* gpre = a.pre - EU_SKEW_SLACK;
+  const uint8_t* gmask = a.mask - EU_SKEW_SLACK;
+  const double* gin = (OP == SW_FACTOR ? a.pre : a.in) - EU_SKEW_SLACK;
+  double* gdst = (OP == SW_FACTOR ? a.pre : a.out) - EU_SKEW_SLACK;
   unsigned long long* gr_out = a.granules + (size_t)ord * a.gran_stride * 2;
   const unsigned long long* gr_in = a.granules + (size_t)(has_prev ? ord - 1 : 0) * a.gran_stride * 2;
   const unsigned long long tag = (unsigned long long)a.epoch << 32;
 
-  // forward only: precon of (row-1, same column) as a fourth stream.  For lane >= 1 that is record
-  // t-1, lane-1 of this band; for lane 0 it is lane 63 of band-1 at record t+63.  Both advance by
-  // one record per step, so it is one per-lane pointer.
-  const double* npre_ptr = pre;
-  if (OP == SW_FORWARD) {
-    if (lane > 0) npre_ptr = pre - 64 + (lane - 1);                                  // + t*64 -> (t-1)*64 + lane-1
-    else npre_ptr = band > 0 ? pre - (size_t)T * 64 + (size_t)63 * 64 + 63 : pre;    // + t*64 -> band-1, (t+63)*64 + 63
-  }
+  // element offset (from the array start) of (this band, record t, this lane); 32 bits suffice for
+  // byte offsets up to 16384^2 doubles.  Step s visits record t = s (forward) or T-1-s (backward).
+  const int step_elems = BWD ? -64 : 64;
+  const unsigned e0 = (unsigned)EU_SKEW_SLACK + (unsigned)((size_t)band * TS * 64) + (unsigned)((BWD ? T - 1 : 0) * 64 + lane);
+  // forward only: precon of (row-1, same column): lane >= 1 -> (record t-1, lane-1) = e - 65;
+  // lane 0 -> lane 63 of band-1 at record t+63 = e - 64*(TS-63) + 63.  (band 0: value unused.)
+  int npd = 0;
+  if (OP == SW_FORWARD) npd = lane > 0 ? -65 : (band > 0 ? -64 * (TS - 63) + 63 : 0);
 
-  // ---- register prefetch ring ---------------------------------------------------------------
-  double in_buf[SW_PF], pre_buf[SW_PF], np_buf[SW_PF];
-  uint8_t m_buf[SW_PF];
-  auto fetch = [&](int s, int slot) {
-    int sc_ = s < T ? s : T - 1;                       // clamp: steps >= T are never executed
-    const int t = BWD ? T - 1 - sc_ : sc_;
-    const size_t e = (size_t)t * 64 + lane;
-    in_buf[slot] = OP == SW_FACTOR ? 0.0 : in[e];
-    pre_buf[slot] = pre[e];
-    m_buf[slot] = mask[e];
-    if (OP == SW_FORWARD) {
-      const int tn = (lane > 0 && t == 0) ? 1 : t;     // record -1 does not exist (only lane 0 is live at t = 0)
-      np_buf[slot] = npre_ptr[(size_t)tn * 64];
-    } else np_buf[slot] = 0.0;
+  // Two operand sets, ping-ponged block by block: while block k computes from one set, the records
+  // of block k+1 are fetched into the other.  (With a single ring hipcc schedules a slot's refill
+  // ahead of the last use of its old value; the overlapping live ranges become ~35 v_mov phi-copies
+  // behind s_waitcnt vmcnt(1..4) on the loop back-edge, i.e. the "prefetch" drains every block.)
+  struct Operands { double in[SW_BLK], pre[SW_BLK], np[SW_BLK]; uint8_t m[SW_BLK]; };
+  Operands opA, opB;
+  unsigned e_pf = e0;   // element offset of the next record to prefetch
+  auto fetch = [&](Operands& o, int slot) {
+    o.in[slot] = OP == SW_FACTOR ? 0.0 : ld_off(gin, e_pf * 8u);
+    o.pre[slot] = ld_off(gpre, e_pf * 8u);
+    o.m[slot] = ld_off(gmask, e_pf);
+    o.np[slot] = OP == SW_FORWARD ? ld_off(gpre, (unsigned)((int)e_pf + npd) * 8u) : 0.0;
+    e_pf = (unsigned)((int)e_pf + step_elems);
   };
 #pragma unroll
-  for (int j = 0; j < SW_PF; ++j) fetch(j, j);
+  for (int j = 0; j < SW_BLK; ++j) fetch(opA, j);
 
-  // ---- boundary row of the previous band: 32 columns per poll, issued one block early ---------
-  unsigned long long g0 = 0, g1 = 0;     // lanes 0..31: granule pair of logical column 32*k + lane
-  auto issue_poll = [&](int blk) {
+  // ---- boundary values of the previous band: 8 logical columns per block ----------------------
+  // Lanes 0..7 fetch the granule pair of logical column 8*blk + lane with ONE 16-byte write-through
+  // (sc1) load.  The load for block blk+1 is issued at the start of block blk and retired at its
+  // end by a COUNTED s_waitcnt: at least 8 * VMEM_PER_STEP younger operations were issued behind
+  // it, so vmcnt(POLL_VMCNT) covers it while the newest prefetches stay in flight.  (Left to the
+  // compiler the result is waited for with vmcnt(0), which drains the prefetched block.)  The
+  // inline-asm load is invisible to hipcc's own counting; an extra outstanding operation only
+  // makes hipcc's waits stricter, never looser.
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const int ncolblk = (X + SW_BLK - 1) / SW_BLK;
+  constexpr int VMEM_PER_STEP = OP == SW_FORWARD ? 5 : (OP == SW_BACKWARD ? 4 : 3);
+  constexpr int POLL_VMCNT = 8 * VMEM_PER_STEP - 8;
+  auto poll_issue = [&](int blk, u32x4& gv) {
     const int xl = SW_BLK * blk + lane;
-    if (has_prev && lane < SW_BLK && xl < X) {
-      g0 = __hip_atomic_load(&gr_in[(size_t)xl * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      g1 = __hip_atomic_load(&gr_in[(size_t)xl * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane < SW_BLK && xl < X) {
+      const unsigned long long* p = &gr_in[(size_t)xl * 2];
+      asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(gv) : "v"(p) : "memory");
     }
   };
-  auto poll_ready = [&](int blk) {
+  auto poll_ready = [&](int blk, const u32x4& gv) {
     const int xl = SW_BLK * blk + lane;
-    const bool want = has_prev && lane < SW_BLK && xl < X;
-    return !want || (((g0 >> 32) == a.epoch) && ((g1 >> 32) == a.epoch));
+    const bool want = lane < SW_BLK && xl < X;
+    return !want || (gv[1] == a.epoch && gv[3] == a.epoch);
   };
-  issue_poll(0);
+  // slow path: the block is not there yet.  Wait until the producer is SW_CATCHUP blocks further
+  // (bands run at equal speed; resuming at the visibility edge would miss every later poll too).
+  auto poll_wait = [&](int blk, u32x4& gv) {
+    const int far = blk + SW_CATCHUP < ncolblk ? blk + SW_CATCHUP : ncolblk - 1;
+    unsigned int spins = 0;
+    for (int target = far;;) {
+      poll_issue(target, gv);
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(gv)::"memory");
+      if (__all(poll_ready(target, gv))) { if (target == blk) break; target = blk; continue; }
+      if (++spins > SW_SPIN_LIMIT) { if (lane == 0) atomicExch(a.error, 2); break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  };
 
   double own_val = 0.0, own_pre = 0.0;     // previous column of this row
   double out_val = 0.0;                    // this lane's result of the previous step (for the next lane)
-  double bnd = 0.0;                        // lane j: previous band's edge value at logical column 32k + j
-  const int nblk = (X + SW_BLK - 1) / SW_BLK;
+  double bnd = 0.0;                        // lanes 0..7: previous band's edge value at logical column 8*blk + lane
+  double pub = 0.0;                        // lanes 0..7: this band's edge results of the current column block
+  unsigned e = e0;
+  if (has_prev) {                          // block 0 synchronously
+    u32x4 gv = {0u, 0u, 0u, 0u};
+    poll_issue(0, gv);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(gv)::"memory");
+    if (!__all(poll_ready(0, gv))) poll_wait(0, gv);
+    bnd = __hiloint2double((int)gv[2], (int)gv[0]);
+  }
 
-  for (int s0 = 0; s0 < T; s0 += SW_PF) {
+  // one hand-off block = 8 steps: compute from `cur`, refill `nxt` with the block after it
+  auto run_block = [&](int blk, Operands& cur, Operands& nxt) {
+    const bool polling = has_prev && blk + 1 < ncolblk;
+    u32x4 gnext = {0u, 0u, 0u, 0u};
+    if (polling) poll_issue(blk + 1, gnext);
 #pragma unroll
-    for (int j = 0; j < SW_PF; ++j) {
-      const int s = s0 + j;
-      if (s < T) {
-        // ---- every 32 steps: retire the poll of this block, start the next one
-        if ((s & (SW_BLK - 1)) == 0) {
-          const int blk = s / SW_BLK;
-          if (has_prev && blk < nblk) {
-            unsigned int spins = 0;
-            while (!__all(poll_ready(blk))) {
-              if (++spins > SW_SPIN_LIMIT) { if (lane == 0) atomicExch(a.error, 2); break; }
-              __builtin_amdgcn_s_sleep(1);
-              issue_poll(blk);
-            }
-            bnd = __longlong_as_double((long long)((g0 & 0xffffffffull) | (g1 << 32)));
-            issue_poll(blk + 1);
-          }
-        }
-        const double cin = in_buf[j], cpre = pre_buf[j], cnp = np_buf[j];
-        const uint8_t cm = m_buf[j];
-        fetch(s + SW_PF, j);
-        const int t = BWD ? T - 1 - s : s;
-        // the edge lane consumes logical column s of the previous band (lane s & 31 of bnd)
-        const double bsel = has_prev ? readlane_f64(bnd, s & (SW_BLK - 1)) : 0.0;
-        const double nb_val = wave_shift_inject<CTRL>(out_val, bsel);
-        const double res = sweep_cell<OP>(cm, cin, cpre, own_val, own_pre, nb_val, cnp);
-        dst[(size_t)t * 64 + lane] = res;
-        own_val = res;
-        own_pre = cpre;
-        out_val = res;
-        // ---- hand the edge row to the next band: logical column s - 63 is done
-        if (publish) {
-          const int xl = s - 63;
-          if (lane == edge_out) stash[xl & 63] = res;
-          if (xl >= 0 && (xl & (SW_BLK - 1)) == SW_BLK - 1) {
-            const int col = xl - (SW_BLK - 1) + lane;
-            if (lane < SW_BLK && col < X) {
-              const unsigned long long bits = (unsigned long long)__double_as_longlong(stash[col & 63]);
-              __hip_atomic_store(&gr_out[(size_t)col * 2], tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              __hip_atomic_store(&gr_out[(size_t)col * 2 + 1], tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-          }
+    for (int j = 0; j < SW_BLK; ++j) {
+      fetch(nxt, j);
+      // the edge lane consumes logical column s = 8*blk + j of the previous band (lane j of bnd)
+      const double nb_val = wave_shift_inject<CTRL>(out_val, readlane_f64(bnd, j));
+      const double res = sweep_cell<OP>(cur.m[j], cur.in[j], cur.pre[j], own_val, own_pre, nb_val, cur.np[j]);
+      *reinterpret_cast<double*>(reinterpret_cast<char*>(gdst) + e * 8u) = res;
+      e = (unsigned)((int)e + step_elems);
+      own_val = res;
+      own_pre = cur.pre[j];
+      out_val = res;
+      // logical column s - 63 of the edge row is done: collect it in lane (s - 63) & 7 = (j + 1) & 7
+      {
+        const double edge_res = readlane_f64(res, EDGE_OUT);     // uniform
+        pub = lane == ((j + 1) & 7) ? edge_res : pub;            // lane masks are loop-invariant SGPR pairs
+      }
+      if (j == 6 && publish) {             // columns 8*blk - 64 ... 8*blk - 57 are complete
+        const int col = SW_BLK * blk - 64 + lane;
+        if (lane < SW_BLK && col >= 0 && col < X) {
+          const unsigned long long bits = (unsigned long long)__double_as_longlong(pub);
+          __hip_atomic_store(&gr_out[(size_t)col * 2], tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&gr_out[(size_t)col * 2 + 1], tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
     }
-  }
-  if (publish && (X & (SW_BLK - 1)) != 0) {   // last, partial block of columns
-    const int col = (X - 1) / SW_BLK * SW_BLK + lane;
-    if (lane < SW_BLK && col < X) {
-      const unsigned long long bits = (unsigned long long)__double_as_longlong(stash[col & 63]);
-      __hip_atomic_store(&gr_out[(size_t)col * 2], tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&gr_out[(size_t)col * 2 + 1], tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (polling) {                         // retire the poll issued 8 steps ago; its values serve block blk+1
+      asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gnext) : "n"(POLL_VMCNT) : "memory");
+      if (!__all(poll_ready(blk + 1, gnext))) poll_wait(blk + 1, gnext);
+      bnd = __hiloint2double((int)gnext[2], (int)gnext[0]);
     }
+  };
+
+  const int npairs = ((T + SW_BLK - 1) / SW_BLK + 1) / 2;   // whole pairs of blocks; the surplus runs over dead records
+  for (int pr = 0; pr < npairs; ++pr) {
+    run_block(2 * pr, opA, opB);
+    run_block(2 * pr + 1, opB, opA);
   }
 }
 
