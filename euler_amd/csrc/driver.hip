@@ -142,6 +142,7 @@ extern "C" void euler_destroy(euler_sim* S) {
   for (void* p : dev) if (p) (void)hipFree(p);
   for (double* d : {S->b, S->p, S->r, S->z, S->s, S->q, S->precon}) if (d) (void)hipFree(d - EU_SKEW_SLACK);
   if (S->cellmask) (void)hipFree(S->cellmask - EU_SKEW_SLACK);
+  if (S->fmask) (void)hipFree(S->fmask - EU_SKEW_SLACK);
   if (S->ms_host) (void)hipHostFree(S->ms_host);
   if (S->sc_host) (void)hipHostFree(S->sc_host);
   if (S->ev_pool) { for (int k = 0; k < S->ev_cap; ++k) (void)hipEventDestroy(S->ev_pool[k]); free(S->ev_pool); }
@@ -206,6 +207,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   // skewed arrays carry EU_SKEW_SLACK zeroed elements in front (the backward sweep prefetches below record 0)
   for (double** d : {&S->b, &S->p, &S->r, &S->z, &S->s, &S->q, &S->precon}) { DALLOC(*d, SS + EU_SKEW_SLACK); *d += EU_SKEW_SLACK; }
   DALLOC(S->cellmask, SS + EU_SKEW_SLACK); S->cellmask += EU_SKEW_SLACK;
+  DALLOC(S->fmask, SS + EU_SKEW_SLACK); S->fmask += EU_SKEW_SLACK;
   DALLOC(S->sc, 1);
   S->red_blocks = (int)eu_blocks(SS, 256 * 16, 2048);
   DALLOC(S->partial, (size_t)S->red_blocks);
@@ -213,6 +215,8 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   DALLOC(S->granules, (size_t)S->geom.nbands * S->gran_stride * 2);
   DALLOC(S->ticket, 1);
   S->ticket_base = 0; S->epoch = 0;
+  S->sweep_catchup = 0;
+  if (const char* e = getenv("EULER_SWEEP_CATCHUP")) S->sweep_catchup = atoi(e) < 0 ? 0 : atoi(e);
   HIPCHK(hipHostMalloc((void**)&S->ms_host, sizeof(MarkerState), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&S->sc_host, sizeof(PcgScalars), hipHostMallocDefault));
   memset(S->ms_host, 0, sizeof(MarkerState)); memset(S->sc_host, 0, sizeof(PcgScalars));
@@ -260,6 +264,7 @@ static int upload_scenario(euler_sim* S, const uint8_t* solid, const uint8_t* so
   HIPCHK(hipMemsetAsync(S->count, 0, C, st));
   HIPCHK(hipMemsetAsync(S->prev_count, 0, C, st));
   HIPCHK(hipMemsetAsync(S->cellmask, 0, S->geom.S, st));
+  HIPCHK(hipMemsetAsync(S->fmask, 0, S->geom.S, st));
   S->cur = 0;
   HIPCHK(hipMemcpyAsync(S->markers[0], mk.data(), n * sizeof(float2), hipMemcpyHostToDevice, st));
   MarkerState m0;

@@ -115,6 +115,7 @@ struct euler_sim {
   SkewGeom geom;
   double *b, *p, *r, *z, *s, *q, *precon;
   uint8_t* cellmask;
+  int8_t* fmask;          // skewed: -1 on fluid cells, 0 elsewhere
   double* rowmajor_tmp;   // lazily allocated C doubles for euler_get/set_field of skewed arrays
   PcgScalars* sc;
   PcgScalars* sc_host;    // pinned
@@ -126,6 +127,7 @@ struct euler_sim {
   unsigned int* ticket;
   unsigned int ticket_base;
   unsigned int epoch;
+  int sweep_catchup;      // tunable (EULER_SWEEP_CATCHUP), see k_sweep_skew
 
   float interp_lim[4];    // nextafterf(extent-1, 0) for U.x, U.y, V.x, V.y (main.c:339-340)
 

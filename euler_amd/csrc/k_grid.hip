@@ -149,7 +149,8 @@ int eu_launch_advect_velocity(euler_sim* S, float dt) {
 __global__ __launch_bounds__(256) void k_build_system(const float* __restrict__ u, const float* __restrict__ v,
                                                       const uint8_t* __restrict__ count, const uint8_t* __restrict__ solid,
                                                       double* __restrict__ b, double* __restrict__ r, double* __restrict__ p,
-                                                      uint8_t* __restrict__ cellmask, PcgScalars* sc, SkewGeom g, float dt) {
+                                                      uint8_t* __restrict__ cellmask, int8_t* __restrict__ fmask,
+                                                      PcgScalars* sc, SkewGeom g, float dt) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool nz = false;
   if (e < g.S) {
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(256) void k_build_system(const float* __restrict__ 
         nz = bv != 0.0;
       }
       cellmask[e] = m;
+      fmask[e] = (m & CM_FLUID) ? (int8_t)-1 : (int8_t)0;
       b[e] = bv;
       r[e] = bv;
       p[e] = 0.0;
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256) void k_velocity_update(const float* __restrict
 
 int eu_launch_build_system(euler_sim* S, float dt) {
   LAUNCH(S, KC_BUILD_SYSTEM, k_build_system, dim3(eu_blocks(S->geom.S, 256)), dim3(256), S->utmp, S->vtmp, S->count,
-         S->solid, S->b, S->r, S->p, S->cellmask, S->sc, S->geom, dt);
+         S->solid, S->b, S->r, S->p, S->cellmask, S->fmask, S->sc, S->geom, dt);
   return EULER_OK;
 }
 

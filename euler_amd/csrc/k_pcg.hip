@@ -233,11 +233,13 @@ enum { SW_FACTOR = 0, SW_FORWARD = 1, SW_BACKWARD = 2 };
 struct SweepArgs {
   SkewGeom g;
   const uint8_t* mask;
+  const int8_t* fmask;    // -1 on fluid cells, 0 elsewhere (sign-extended AND mask of the forward solve)
   double* pre;            // precon: in/out for SW_FACTOR, in otherwise
   const double* in;       // r (forward) / q (backward); unused for factor
   double* out;            // q (forward) / z (backward); unused for factor
   unsigned long long* granules;   // [nbands][gran_stride][2] tagged hand-off of a band's edge row
   int gran_stride;
+  int catchup;            // blocks the producer must lead by before a stalled consumer resumes
   unsigned int* ticket;
   unsigned int ticket_base;
   unsigned int epoch;
@@ -307,8 +309,8 @@ __global__ __launch_bounds__(1024) void k_sweep_simple(SweepArgs a) {
 // Backward: records T-1, T-2, ..., the row above arrives from lane l+1 (DPP wave_shl:1).
 // The loop body is 8 steps = one hand-off block, fully unrolled, so every lane index below is a
 // compile-time constant:
-//   * operands of step s+8 are fetched while step s computes (4 coalesced 512-B record loads, one
-//     32-bit byte offset per stream from the uniform array base, += 512 per step);
+//   * the operands of block k+1 (3 coalesced 512-B record loads per step, per-lane stream pointers
+//     with immediate offsets j*512) are fetched while block k computes;
 //   * the edge lane's result (lane 63 forward / 0 backward: logical column s-63) is moved with
 //     v_readlane + a lane-select into lane (s-63)&7 of one register pair; when 8 columns are complete,
 //     lanes 0..7 publish them as two 8-byte {epoch, half} granules each (agent-scope relaxed
@@ -320,7 +322,6 @@ __global__ __launch_bounds__(1024) void k_sweep_simple(SweepArgs a) {
 // Records t >= T of a band and the 32 records in front of each array are dead padding (mask 0):
 // the loop runs whole pairs of blocks and prefetches unconditionally.
 #define SW_BLK 8
-#define SW_CATCHUP 4
 #define SW_SPIN_LIMIT (1u << 22)
 #define DPP_WAVE_SHL1 0x130
 #define DPP_WAVE_SHR1 0x138
@@ -352,46 +353,44 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
   constexpr bool BWD = OP == SW_BACKWARD;
   constexpr int CTRL = BWD ? DPP_WAVE_SHL1 : DPP_WAVE_SHR1;
   constexpr int EDGE_OUT = BWD ? 0 : 63;              // lane whose row the next band needs
+  constexpr int STEP = BWD ? -64 : 64;                // elements per step
   const SkewGeom g = a.g;
   const int X = g.X, T = g.T, TS = g.TS, nb = g.nbands;
   const int band = BWD ? nb - 1 - ord : ord;
   const bool has_prev = ord > 0;                      // a band before us in sweep order
   const bool publish = ord + 1 < nb;
-  // all streams are addressed as (array - slack) + unsigned offset, so that the backward sweep's
-  // prefetch below record 0 of band 0 stays a non-negative 32-bit offset
-  const double* gpre = a.pre - EU_SKEW_SLACK;
-  const uint8_t* gmask = a.mask - EU_SKEW_SLACK;
-  const double* gin = (OP == SW_FACTOR ? a.pre : a.in) - EU_SKEW_SLACK;
-  double* gdst = (OP == SW_FACTOR ? a.pre : a.out) - EU_SKEW_SLACK;
   unsigned long long* gr_out = a.granules + (size_t)ord * a.gran_stride * 2;
   const unsigned long long* gr_in = a.granules + (size_t)(has_prev ? ord - 1 : 0) * a.gran_stride * 2;
   const unsigned long long tag = (unsigned long long)a.epoch << 32;
 
-  // element offset (from the array start) of (this band, record t, this lane); 32 bits suffice for
-  // byte offsets up to 16384^2 doubles.  Step s visits record t = s (forward) or T-1-s (backward).
-  const int step_elems = BWD ? -64 : 64;
-  const unsigned e0 = (unsigned)EU_SKEW_SLACK + (unsigned)((size_t)band * TS * 64) + (unsigned)((BWD ? T - 1 : 0) * 64 + lane);
-  // forward only: precon of (row-1, same column): lane >= 1 -> (record t-1, lane-1) = e - 65;
-  // lane 0 -> lane 63 of band-1 at record t+63 = e - 64*(TS-63) + 63.  (band 0: value unused.)
-  int npd = 0;
-  if (OP == SW_FORWARD) npd = lane > 0 ? -65 : (band > 0 ? -64 * (TS - 63) + 63 : 0);
+  // Per-lane stream pointers at (this band, first record, this lane).  They advance by 8 records
+  // per block, so the 8 steps of a block address their records with immediate offsets j*512 B.
+  const size_t e0 = (size_t)band * TS * 64 + (size_t)(BWD ? T - 1 : 0) * 64 + lane;
+  const double* p_in = (OP == SW_FACTOR ? a.pre : a.in) + e0;      // operands of the block being prefetched
+  const double* p_pre = a.pre + e0;
+  const uint8_t* p_msk = a.mask + e0;
+  const int8_t* p_fm = a.fmask + e0;
+  double* p_out = (OP == SW_FACTOR ? a.pre : a.out) + e0;          // results of the block being computed
 
   // Two operand sets, ping-ponged block by block: while block k computes from one set, the records
   // of block k+1 are fetched into the other.  (With a single ring hipcc schedules a slot's refill
   // ahead of the last use of its old value; the overlapping live ranges become ~35 v_mov phi-copies
-  // behind s_waitcnt vmcnt(1..4) on the loop back-edge, i.e. the "prefetch" drains every block.)
-  struct Operands { double in[SW_BLK], pre[SW_BLK], np[SW_BLK]; uint8_t m[SW_BLK]; };
+  // behind s_waitcnt vmcnt(1..4) on the loop back-edge, i.e. the "prefetch" drains every block.
+  // A third set = 16 steps of prefetch was measured: no gain at 8192^2, slower at 1024^2.)
+  struct Operands { double in[SW_BLK], pre[SW_BLK]; int m[SW_BLK]; };
   Operands opA, opB;
-  unsigned e_pf = e0;   // element offset of the next record to prefetch
-  auto fetch = [&](Operands& o, int slot) {
-    o.in[slot] = OP == SW_FACTOR ? 0.0 : ld_off(gin, e_pf * 8u);
-    o.pre[slot] = ld_off(gpre, e_pf * 8u);
-    o.m[slot] = ld_off(gmask, e_pf);
-    o.np[slot] = OP == SW_FORWARD ? ld_off(gpre, (unsigned)((int)e_pf + npd) * 8u) : 0.0;
-    e_pf = (unsigned)((int)e_pf + step_elems);
-  };
+  auto fetch_block = [&](Operands& o) {
 #pragma unroll
-  for (int j = 0; j < SW_BLK; ++j) fetch(opA, j);
+    for (int j = 0; j < SW_BLK; ++j) {
+      o.in[j] = OP == SW_FACTOR ? 0.0 : p_in[j * STEP];
+      o.pre[j] = p_pre[j * STEP];
+      // forward: sign-extended fluid flag (0 / -1) so that masking is two v_and;
+      // factor / backward: the full cell-mask byte (a_diag, right / up neighbour bits)
+      o.m[j] = OP == SW_FORWARD ? (int)p_fm[j * STEP] : (int)p_msk[j * STEP];
+    }
+    p_in += SW_BLK * STEP; p_pre += SW_BLK * STEP; p_msk += SW_BLK * STEP; p_fm += SW_BLK * STEP;
+  };
+  fetch_block(opA);
 
   // ---- boundary values of the previous band: 8 logical columns per block ----------------------
   // Lanes 0..7 fetch the granule pair of logical column 8*blk + lane with ONE 16-byte write-through
@@ -403,7 +402,7 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
   // makes hipcc's waits stricter, never looser.
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const int ncolblk = (X + SW_BLK - 1) / SW_BLK;
-  constexpr int VMEM_PER_STEP = OP == SW_FORWARD ? 5 : (OP == SW_BACKWARD ? 4 : 3);
+  constexpr int VMEM_PER_STEP = OP == SW_FACTOR ? 3 : 4;     // loads + the record store
   constexpr int POLL_VMCNT = 8 * VMEM_PER_STEP - 8;
   auto poll_issue = [&](int blk, u32x4& gv) {
     const int xl = SW_BLK * blk + lane;
@@ -417,10 +416,10 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
     const bool want = lane < SW_BLK && xl < X;
     return !want || (gv[1] == a.epoch && gv[3] == a.epoch);
   };
-  // slow path: the block is not there yet.  Wait until the producer is SW_CATCHUP blocks further
-  // (bands run at equal speed; resuming at the visibility edge would miss every later poll too).
+  // slow path: the block is not there yet (catchup > 0: resume only once the producer leads by that
+  // many further blocks; measured best at 0 with the counted waits)
   auto poll_wait = [&](int blk, u32x4& gv) {
-    const int far = blk + SW_CATCHUP < ncolblk ? blk + SW_CATCHUP : ncolblk - 1;
+    const int far = blk + a.catchup < ncolblk ? blk + a.catchup : ncolblk - 1;
     unsigned int spins = 0;
     for (int target = far;;) {
       poll_issue(target, gv);
@@ -431,11 +430,16 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
     }
   };
 
-  double own_val = 0.0, own_pre = 0.0;     // previous column of this row
-  double out_val = 0.0;                    // this lane's result of the previous step (for the next lane)
-  double bnd = 0.0;                        // lanes 0..7: previous band's edge value at logical column 8*blk + lane
-  double pub = 0.0;                        // lanes 0..7: this band's edge results of the current column block
-  unsigned e = e0;
+  // Loop-carried state.  What travels between cells is, per operation:
+  //   factor   : precon itself (left neighbour = own register, lower neighbour = lane-1)
+  //   forward  : m = (-1*precon)*q of a cell - exactly the term its right neighbour (same lane, next
+  //              step) AND its upper neighbour (lane+1, next step) subtract (main.c:607-609), so it
+  //              is formed once and shifted; the precon of the lower row is never loaded
+  //   backward : z (the coefficients belong to the consuming cell, main.c:620-622)
+  double own = 0.0;        // carried value of the previous column of this row
+  double out = 0.0;        // carried value this lane hands to the next lane
+  double bnd = 0.0;        // lanes 0..7: previous band's edge values at logical column 8*blk + lane
+  double pub = 0.0;        // lanes 0..7: this band's edge values of the current column block
   if (has_prev) {                          // block 0 synchronously
     u32x4 gv = {0u, 0u, 0u, 0u};
     poll_issue(0, gv);
@@ -449,21 +453,39 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
     const bool polling = has_prev && blk + 1 < ncolblk;
     u32x4 gnext = {0u, 0u, 0u, 0u};
     if (polling) poll_issue(blk + 1, gnext);
+    fetch_block(nxt);
 #pragma unroll
     for (int j = 0; j < SW_BLK; ++j) {
-      fetch(nxt, j);
       // the edge lane consumes logical column s = 8*blk + j of the previous band (lane j of bnd)
-      const double nb_val = wave_shift_inject<CTRL>(out_val, readlane_f64(bnd, j));
-      const double res = sweep_cell<OP>(cur.m[j], cur.in[j], cur.pre[j], own_val, own_pre, nb_val, cur.np[j]);
-      *reinterpret_cast<double*>(reinterpret_cast<char*>(gdst) + e * 8u) = res;
-      e = (unsigned)((int)e + step_elems);
-      own_val = res;
-      own_pre = cur.pre[j];
-      out_val = res;
+      const double nbv = wave_shift_inject<CTRL>(out, readlane_f64(bnd, j));
+      const double cin = cur.in[j], cpre = cur.pre[j];
+      const int cm = cur.m[j];
+      double res, carry;
+      if (OP == SW_FACTOR) {               // main.c:586-600; own / nbv are precon of the left / lower cell
+        const double aa = (double)(cm >> CM_DIAG_SHIFT);
+        const double cl = -1.0 * own, cb = -1.0 * nbv;
+        double e = aa - cl * cl - cb * cb;
+        if (e < 0.25 * aa) e = (aa != 0.0) ? aa : 1.0;
+        res = (cm & CM_FLUID) ? 1.0 / sqrt(e) : cpre;      // non-fluid: the stale entry stays
+        carry = res;
+      } else if (OP == SW_FORWARD) {       // main.c:602-613: t = r - (-1*pre_l)*q_l - (-1*pre_b)*q_b
+        const double t = cin - own - nbv;
+        const double qv = t * cpre;
+        res = __hiloint2double(__double2hiint(qv) & cm, __double2loint(qv) & cm);   // +0 on non-fluid cells
+        carry = -1.0 * cpre * res;         // this cell's term in its right and upper neighbours
+      } else {                             // main.c:615-626: t = q - (a_i*pre)*z_r - (a_j*pre)*z_u
+        const double cr = (cm & CM_RIGHT) ? -1.0 : 0.0, cu = (cm & CM_UP) ? -1.0 : 0.0;
+        const double t = cin - cr * cpre * own - cu * cpre * nbv;
+        res = (cm & CM_FLUID) ? t * cpre : 0.0;
+        carry = res;
+      }
+      p_out[j * STEP] = res;
+      own = carry;
+      out = carry;
       // logical column s - 63 of the edge row is done: collect it in lane (s - 63) & 7 = (j + 1) & 7
       {
-        const double edge_res = readlane_f64(res, EDGE_OUT);     // uniform
-        pub = lane == ((j + 1) & 7) ? edge_res : pub;            // lane masks are loop-invariant SGPR pairs
+        const double edge_val = readlane_f64(carry, EDGE_OUT);   // uniform
+        pub = lane == ((j + 1) & 7) ? edge_val : pub;            // lane masks are loop-invariant SGPR pairs
       }
       if (j == 6 && publish) {             // columns 8*blk - 64 ... 8*blk - 57 are complete
         const int col = SW_BLK * blk - 64 + lane;
@@ -474,6 +496,7 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
         }
       }
     }
+    p_out += SW_BLK * STEP;
     if (polling) {                         // retire the poll issued 8 steps ago; its values serve block blk+1
       asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gnext) : "n"(POLL_VMCNT) : "memory");
       if (!__all(poll_ready(blk + 1, gnext))) poll_wait(blk + 1, gnext);
@@ -493,10 +516,11 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
 static SweepArgs make_sweep_args(euler_sim* S, int op, int force) {
   SweepArgs a;
   a.g = S->geom;
-  a.mask = S->cellmask; a.pre = S->precon;
+  a.mask = S->cellmask; a.fmask = S->fmask; a.pre = S->precon;
   a.in = op == SW_FORWARD ? S->r : S->q;
   a.out = op == SW_FORWARD ? S->q : S->z;
   a.granules = S->granules; a.gran_stride = S->gran_stride; a.ticket = S->ticket;
+  a.catchup = S->sweep_catchup;
   a.ticket_base = S->ticket_base; a.epoch = S->epoch;
   a.sc = S->sc; a.force = force; a.error = &S->ms->error;
   return a;
