@@ -137,10 +137,10 @@ extern "C" void euler_destroy(euler_sim* S) {
   if (S->stream) (void)hipStreamSynchronize(S->stream);
   void* dev[] = {S->u, S->v, S->utmp, S->vtmp, S->solid, S->source, S->sink, S->count, S->prev_count, S->count32,
                  S->markers[0], S->markers[1], S->ms, S->evmask, S->ev_theta, S->ev_delta, S->sel_idx, S->act_idx,
-                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->granules, S->ticket,
+                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket,
                  S->rowmajor_tmp};
   for (void* p : dev) if (p) (void)hipFree(p);
-  for (double* d : {S->b, S->p, S->r, S->z, S->s, S->q, S->precon}) if (d) (void)hipFree(d - EU_SKEW_SLACK);
+  for (double* d : {S->b, S->p, S->r, S->z, S->s, S->q, S->precon, S->kr, S->ku}) if (d) (void)hipFree(d - EU_SKEW_SLACK);
   if (S->cellmask) (void)hipFree(S->cellmask - EU_SKEW_SLACK);
   if (S->fmask) (void)hipFree(S->fmask - EU_SKEW_SLACK);
   if (S->ms_host) (void)hipHostFree(S->ms_host);
@@ -205,12 +205,13 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   const size_t SS = S->geom.S;
   if ((SS + EU_SKEW_SLACK) * 8 >= ((size_t)1 << 32)) { eu_set_error("grid too large for 32-bit record offsets"); euler_destroy(S); return EULER_EINVAL; }
   // skewed arrays carry EU_SKEW_SLACK zeroed elements in front (the backward sweep prefetches below record 0)
-  for (double** d : {&S->b, &S->p, &S->r, &S->z, &S->s, &S->q, &S->precon}) { DALLOC(*d, SS + EU_SKEW_SLACK); *d += EU_SKEW_SLACK; }
+  for (double** d : {&S->b, &S->p, &S->r, &S->z, &S->s, &S->q, &S->precon, &S->kr, &S->ku}) { DALLOC(*d, SS + EU_SKEW_SLACK); *d += EU_SKEW_SLACK; }
   DALLOC(S->cellmask, SS + EU_SKEW_SLACK); S->cellmask += EU_SKEW_SLACK;
   DALLOC(S->fmask, SS + EU_SKEW_SLACK); S->fmask += EU_SKEW_SLACK;
   DALLOC(S->sc, 1);
   S->red_blocks = (int)eu_blocks(SS, 256 * 16, 2048);
   DALLOC(S->partial, (size_t)S->red_blocks);
+  DALLOC(S->red_counter, 1);
   S->gran_stride = (S->X + 7) / 8 * 8;
   DALLOC(S->granules, (size_t)S->geom.nbands * S->gran_stride * 2);
   DALLOC(S->ticket, 1);

@@ -114,12 +114,14 @@ struct euler_sim {
   // pressure solve (main.c:552,577-578,716-745): band-skewed arrays of geom.S elements
   SkewGeom geom;
   double *b, *p, *r, *z, *s, *q, *precon;
+  double *kr, *ku;        // a_i*precon, a_j*precon of the backward solve (per solve)
   uint8_t* cellmask;
   int8_t* fmask;          // skewed: -1 on fluid cells, 0 elsewhere
   double* rowmajor_tmp;   // lazily allocated C doubles for euler_get/set_field of skewed arrays
   PcgScalars* sc;
   PcgScalars* sc_host;    // pinned
   double* partial;        // reduction partials
+  unsigned int* red_counter;   // arrival ticket of the "last block reduces" epilogue (self-resetting)
   int red_blocks;
   // band sweep
   unsigned long long* granules;  // [nbands][gran_stride][2]

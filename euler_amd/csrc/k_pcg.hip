@@ -65,6 +65,36 @@ __device__ __forceinline__ double block_max(double v) {
   return t;
 }
 
+// "Last block reduces": each block publishes its partial (8-byte agent-scope atomic store =
+// write-through), drains, takes a ticket; the block that draws the last ticket folds ALL partials
+// in index order (so the result does not depend on arrival order: deterministic) and applies the
+// scalar epilogue.  Saves one launch + one kernel boundary per reduction (3 per PCG iteration).
+// Hand-off form: 8-byte agent atomics on both sides (MI355X_MICROARCH "valid forms").
+template <bool IS_MAX>
+__device__ __forceinline__ void block_finish(double v_block, double* partial, unsigned int* counter, PcgScalars* sc, int op) {
+  __shared__ int am_last;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(&partial[blockIdx.x]),
+                       (unsigned long long)__double_as_longlong(v_block), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    am_last = t == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!am_last) return;
+  double v = 0.0;
+  for (unsigned int i = threadIdx.x; i < gridDim.x; i += RED_THREADS) {
+    const double w = __longlong_as_double((long long)__hip_atomic_load(
+        reinterpret_cast<unsigned long long*>(&partial[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (IS_MAX) v = w > v ? w : v; else v += w;
+  }
+  v = IS_MAX ? block_max(v) : block_sum(v);
+  if (threadIdx.x == 0) {
+    pcg_scalar_step(sc, op, v);
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next reduction
+  }
+}
+
 // second stage: one workgroup folds the per-block partials in a fixed order
 template <bool IS_MAX>
 __global__ __launch_bounds__(RED_THREADS) void k_reduce_final(const double* __restrict__ partial, int n, PcgScalars* sc,
@@ -82,7 +112,8 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_final(const double* __re
 // dot(a,b) over fluid cells -> per-block partials (tree mode); layout-agnostic
 __global__ __launch_bounds__(RED_THREADS) void k_dot_partial(const double* __restrict__ a, const double* __restrict__ b,
                                                              const uint8_t* __restrict__ mask, size_t S,
-                                                             double* __restrict__ partial, const PcgScalars* sc, int force) {
+                                                             double* __restrict__ partial, PcgScalars* sc, int force,
+                                                             unsigned int* counter, int fin_op) {
   if (!force && pcg_idle(sc)) return;
   const size_t chunk = (S + gridDim.x - 1) / gridDim.x;
   const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < S ? lo + chunk : S;
@@ -90,7 +121,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_dot_partial(const double* __res
   for (size_t i = lo + threadIdx.x; i < hi; i += RED_THREADS)
     if (mask[i] & CM_FLUID) t += a[i] * b[i];
   t = block_sum(t);
-  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+  block_finish<false>(t, partial, counter, sc, fin_op);
 }
 
 // dot(a,b) replayed in the reference's ROW-MAJOR order (main.c:629-639): products are gathered by
@@ -131,7 +162,8 @@ __global__ __launch_bounds__(256) void k_dot_sequential(const double* __restrict
 // In tree mode the block also leaves its partial of dot(z,s).
 __global__ __launch_bounds__(RED_THREADS) void k_apply_a(const double* __restrict__ s, double* __restrict__ z,
                                                          const uint8_t* __restrict__ mask, SkewGeom g,
-                                                         double* __restrict__ partial, const PcgScalars* sc, int force) {
+                                                         double* __restrict__ partial, PcgScalars* sc, int force,
+                                                         unsigned int* counter, int fin_op) {
   if (!force && pcg_idle(sc)) return;
   const size_t S = g.S;
   const size_t chunk = (((S + gridDim.x - 1) / gridDim.x) + 63) & ~(size_t)63;   // whole records per block
@@ -152,15 +184,15 @@ __global__ __launch_bounds__(RED_THREADS) void k_apply_a(const double* __restric
     t += o * si;
   }
   t = block_sum(t);
-  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+  if (fin_op >= 0) block_finish<false>(t, partial, counter, sc, fin_op);   // fin_op < 0: dot(z,s) is replayed sequentially
 }
 
 // p += alpha s ; r -= alpha z (fmadd x2, main.c:753-754) ; per-block max |r| (inf_norm, main.c:654-667)
 __global__ __launch_bounds__(RED_THREADS) void k_update_pr(double* __restrict__ p, double* __restrict__ r,
                                                            const double* __restrict__ s, const double* __restrict__ z,
                                                            const uint8_t* __restrict__ mask, size_t S,
-                                                           double* __restrict__ partial, const PcgScalars* sc, int force,
-                                                           double alpha_arg) {
+                                                           double* __restrict__ partial, PcgScalars* sc, int force,
+                                                           double alpha_arg, unsigned int* counter, int fin_op) {
   if (!force && pcg_idle(sc)) return;
   const double alpha = force ? alpha_arg : sc->alpha;
   const double nalpha = -alpha;
@@ -176,7 +208,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_update_pr(double* __restrict__ 
     if (a > mx) mx = a;
   }
   mx = block_max(mx);
-  if (threadIdx.x == 0) partial[blockIdx.x] = mx;
+  if (fin_op >= 0) block_finish<true>(mx, partial, counter, sc, fin_op);
 }
 
 // max |r| only (EULER_OP_INF_NORM_R)
@@ -237,6 +269,8 @@ struct SweepArgs {
   double* pre;            // precon: in/out for SW_FACTOR, in otherwise
   const double* in;       // r (forward) / q (backward); unused for factor
   double* out;            // q (forward) / z (backward); unused for factor
+  double* kr; double* ku; // backward coefficients a_i*precon, a_j*precon (main.c:621-622): written by the
+                          // factor sweep once per solve, streamed by the backward sweep
   unsigned long long* granules;   // [nbands][gran_stride][2] tagged hand-off of a band's edge row
   int gran_stride;
   int catchup;            // blocks the producer must lead by before a stalled consumer resumes
@@ -370,6 +404,8 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
   const double* p_pre = a.pre + e0;
   const uint8_t* p_msk = a.mask + e0;
   const int8_t* p_fm = a.fmask + e0;
+  const double* p_kr = a.kr + e0; const double* p_ku = a.ku + e0;      // backward only
+  double* p_okr = a.kr + e0; double* p_oku = a.ku + e0;                // factor only
   double* p_out = (OP == SW_FACTOR ? a.pre : a.out) + e0;          // results of the block being computed
 
   // Two operand sets, ping-ponged block by block: while block k computes from one set, the records
@@ -377,18 +413,21 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
   // ahead of the last use of its old value; the overlapping live ranges become ~35 v_mov phi-copies
   // behind s_waitcnt vmcnt(1..4) on the loop back-edge, i.e. the "prefetch" drains every block.
   // A third set = 16 steps of prefetch was measured: no gain at 8192^2, slower at 1024^2.)
-  struct Operands { double in[SW_BLK], pre[SW_BLK]; int m[SW_BLK]; };
+  struct Operands { double in[SW_BLK], pre[SW_BLK], kr[SW_BLK], ku[SW_BLK]; int m[SW_BLK]; };
   Operands opA, opB;
   auto fetch_block = [&](Operands& o) {
 #pragma unroll
     for (int j = 0; j < SW_BLK; ++j) {
       o.in[j] = OP == SW_FACTOR ? 0.0 : p_in[j * STEP];
       o.pre[j] = p_pre[j * STEP];
-      // forward: sign-extended fluid flag (0 / -1) so that masking is two v_and;
-      // factor / backward: the full cell-mask byte (a_diag, right / up neighbour bits)
-      o.m[j] = OP == SW_FORWARD ? (int)p_fm[j * STEP] : (int)p_msk[j * STEP];
+      // forward / backward: sign-extended fluid flag (0 / -1) so that masking is two v_and;
+      // factor: the full cell-mask byte (a_diag, right / up neighbour bits)
+      o.m[j] = OP == SW_FACTOR ? (int)p_msk[j * STEP] : (int)p_fm[j * STEP];
+      o.kr[j] = OP == SW_BACKWARD ? p_kr[j * STEP] : 0.0;
+      o.ku[j] = OP == SW_BACKWARD ? p_ku[j * STEP] : 0.0;
     }
     p_in += SW_BLK * STEP; p_pre += SW_BLK * STEP; p_msk += SW_BLK * STEP; p_fm += SW_BLK * STEP;
+    p_kr += SW_BLK * STEP; p_ku += SW_BLK * STEP;
   };
   fetch_block(opA);
 
@@ -402,7 +441,7 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
   // makes hipcc's waits stricter, never looser.
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const int ncolblk = (X + SW_BLK - 1) / SW_BLK;
-  constexpr int VMEM_PER_STEP = OP == SW_FACTOR ? 3 : 4;     // loads + the record store
+  constexpr int VMEM_PER_STEP = OP == SW_FACTOR ? 5 : (OP == SW_FORWARD ? 4 : 6);   // loads + record stores
   constexpr int POLL_VMCNT = 8 * VMEM_PER_STEP - 8;
   auto poll_issue = [&](int blk, u32x4& gv) {
     const int xl = SW_BLK * blk + lane;
@@ -468,15 +507,18 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
         if (e < 0.25 * aa) e = (aa != 0.0) ? aa : 1.0;
         res = (cm & CM_FLUID) ? 1.0 / sqrt(e) : cpre;      // non-fluid: the stale entry stays
         carry = res;
+        // the backward solve's coefficients of this cell, fixed for the whole solve
+        p_okr[j * STEP] = ((cm & CM_RIGHT) ? -1.0 : 0.0) * res;
+        p_oku[j * STEP] = ((cm & CM_UP) ? -1.0 : 0.0) * res;
       } else if (OP == SW_FORWARD) {       // main.c:602-613: t = r - (-1*pre_l)*q_l - (-1*pre_b)*q_b
         const double t = cin - own - nbv;
         const double qv = t * cpre;
         res = __hiloint2double(__double2hiint(qv) & cm, __double2loint(qv) & cm);   // +0 on non-fluid cells
         carry = -1.0 * cpre * res;         // this cell's term in its right and upper neighbours
       } else {                             // main.c:615-626: t = q - (a_i*pre)*z_r - (a_j*pre)*z_u
-        const double cr = (cm & CM_RIGHT) ? -1.0 : 0.0, cu = (cm & CM_UP) ? -1.0 : 0.0;
-        const double t = cin - cr * cpre * own - cu * cpre * nbv;
-        res = (cm & CM_FLUID) ? t * cpre : 0.0;
+        const double t = cin - cur.kr[j] * own - cur.ku[j] * nbv;
+        const double zv = t * cpre;
+        res = __hiloint2double(__double2hiint(zv) & cm, __double2loint(zv) & cm);   // +0 on non-fluid cells
         carry = res;
       }
       p_out[j * STEP] = res;
@@ -496,7 +538,7 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
         }
       }
     }
-    p_out += SW_BLK * STEP;
+    p_out += SW_BLK * STEP; p_okr += SW_BLK * STEP; p_oku += SW_BLK * STEP;
     if (polling) {                         // retire the poll issued 8 steps ago; its values serve block blk+1
       asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gnext) : "n"(POLL_VMCNT) : "memory");
       if (!__all(poll_ready(blk + 1, gnext))) poll_wait(blk + 1, gnext);
@@ -519,6 +561,7 @@ static SweepArgs make_sweep_args(euler_sim* S, int op, int force) {
   a.mask = S->cellmask; a.fmask = S->fmask; a.pre = S->precon;
   a.in = op == SW_FORWARD ? S->r : S->q;
   a.out = op == SW_FORWARD ? S->q : S->z;
+  a.kr = S->kr; a.ku = S->ku;
   a.granules = S->granules; a.gran_stride = S->gran_stride; a.ticket = S->ticket;
   a.catchup = S->sweep_catchup;
   a.ticket_base = S->ticket_base; a.epoch = S->epoch;
@@ -544,8 +587,8 @@ static int launch_dot(euler_sim* S, const double* a, const double* b, int fin_op
   if (S->cfg.dot_mode == EULER_DOT_SEQUENTIAL) {
     LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), a, b, S->cellmask, S->geom, S->sc, fin_op, force);
   } else {
-    LAUNCH(S, KC_DOT, k_dot_partial, dim3(S->red_blocks), dim3(RED_THREADS), a, b, S->cellmask, S->geom.S, S->partial, S->sc, force);
-    LAUNCH(S, KC_REDUCE_FINAL, k_reduce_final<false>, dim3(1), dim3(RED_THREADS), S->partial, S->red_blocks, S->sc, fin_op, force);
+    LAUNCH(S, KC_DOT, k_dot_partial, dim3(S->red_blocks), dim3(RED_THREADS), a, b, S->cellmask, S->geom.S, S->partial, S->sc, force,
+           S->red_counter, fin_op);
   }
   return EULER_OK;
 }
@@ -561,14 +604,11 @@ static int launch_precondition(euler_sim* S, int force) {   // z = M^-1 r
 }
 
 static int launch_apply_a_and_alpha(euler_sim* S, int force) {
+  const bool seq = S->cfg.dot_mode == EULER_DOT_SEQUENTIAL;
   LAUNCH(S, KC_APPLY_A, k_apply_a, dim3(S->red_blocks), dim3(RED_THREADS), S->s, S->z, S->cellmask, S->geom, S->partial,
-         S->sc, force);
-  if (S->cfg.dot_mode == EULER_DOT_SEQUENTIAL) {
+         S->sc, force, S->red_counter, seq ? -1 : (int)FIN_ALPHA);
+  if (seq)
     LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), S->z, S->s, S->cellmask, S->geom, S->sc, (int)FIN_ALPHA, force);
-  } else {
-    LAUNCH(S, KC_REDUCE_FINAL, k_reduce_final<false>, dim3(1), dim3(RED_THREADS), S->partial, S->red_blocks, S->sc,
-           (int)FIN_ALPHA, force);
-  }
   return EULER_OK;
 }
 
@@ -607,9 +647,7 @@ int eu_launch_project(euler_sim* S, float dt) {
       S->prof_iter = it;
       launch_apply_a_and_alpha(S, 0);
       LAUNCH(S, KC_UPDATE_PR, k_update_pr, dim3(S->red_blocks), dim3(RED_THREADS), S->p, S->r, S->s, S->z, S->cellmask,
-             SS, S->partial, S->sc, 0, 0.0);
-      LAUNCH(S, KC_REDUCE_FINAL, k_reduce_final<true>, dim3(1), dim3(RED_THREADS), S->partial, S->red_blocks, S->sc,
-             (int)FIN_RNORM, 0);
+             SS, S->partial, S->sc, 0, 0.0, S->red_counter, (int)FIN_RNORM);
       if (it + 1 < max_it) {   // the tail of the last iteration (main.c:760-765) is never consumed
         // these belong to iteration `it` but only run if it did not converge: tag them it+1 so that
         // they count as active only when the device went on to iteration it+1
@@ -646,7 +684,7 @@ int eu_launch_pcg_op(euler_sim* S, int op, float dt, double a, double* out) {
     case EULER_OP_BACKWARD_SOLVE: launch_sweep<SW_BACKWARD>(S, KC_BACKWARD_SOLVE, 1); break;
     case EULER_OP_APPLY_A:
       LAUNCH(S, KC_APPLY_A, k_apply_a, dim3(S->red_blocks), dim3(RED_THREADS), S->s, S->z, S->cellmask, S->geom,
-             S->partial, S->sc, 1);
+             S->partial, S->sc, 1, S->red_counter, -1);
       break;
     case EULER_OP_DOT_ZR: launch_dot(S, S->z, S->r, FIN_STORE_ONLY, 1); break;
     case EULER_OP_DOT_ZS: launch_dot(S, S->z, S->s, FIN_STORE_ONLY, 1); break;
@@ -657,7 +695,7 @@ int eu_launch_pcg_op(euler_sim* S, int op, float dt, double a, double* out) {
       break;
     case EULER_OP_UPDATE_PR:
       LAUNCH(S, KC_UPDATE_PR, k_update_pr, dim3(S->red_blocks), dim3(RED_THREADS), S->p, S->r, S->s, S->z, S->cellmask,
-             SS, S->partial, S->sc, 1, a);
+             SS, S->partial, S->sc, 1, a, S->red_counter, -1);
       break;
     case EULER_OP_UPDATE_SEARCH:
       LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<false>, dim3(eu_blocks(SS, 256 * 4, 4096)), dim3(256), S->s, S->z,
