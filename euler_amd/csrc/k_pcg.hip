@@ -353,6 +353,9 @@ __global__ __launch_bounds__(1024) void k_sweep_simple(SweepArgs a) {
 //     fetched one block earlier (v_readlane -> the `old` operand of the DPP shift).
 // Bands take their order from a ticket, so a band only ever waits on a band that is already
 // running: no residency assumption, no deadlock.  No LDS is used.
+// One band per workgroup (= per CU) on purpose: a band streams ~16 B/cycle, so 4 waves saturate a
+// CU's ~64 B/clk vector-memory path.  (Measured: 4 / 8 bands per workgroup with an LDS-ring
+// hand-off run 1.4x / 2x SLOWER at 1024^2 and 8192^2 despite the shorter hand-off.)
 // Records t >= T of a band and the 32 records in front of each array are dead padding (mask 0):
 // the loop runs whole pairs of blocks and prefetches unconditionally.
 #define SW_BLK 8
@@ -550,6 +553,16 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
   for (int pr = 0; pr < npairs; ++pr) {
     run_block(2 * pr, opA, opB);
     run_block(2 * pr + 1, opB, opA);
+  }
+  // tail: the in-loop trigger fires at j == 6, so up to 8 finished columns of the edge row are still
+  // unannounced when the loop ends (all 8 when T is a multiple of 16)
+  if (publish) {
+    const int col = SW_BLK * (2 * npairs) - 64 + lane;
+    if (lane < SW_BLK && col >= 0 && col < X) {
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(pub);
+      __hip_atomic_store(&gr_out[(size_t)col * 2], tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&gr_out[(size_t)col * 2 + 1], tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 

@@ -20,10 +20,20 @@ def hashes(sim):
     return [fnv1a64(sim.get(ea.F_U)), fnv1a64(sim.get(ea.F_V)), fnv1a64(sim.get(ea.F_COUNT)), fnv1a64(sim.get(ea.F_MARKERS))]
 
 
-def assert_bits(got, want, what):
+def assert_bits(got, want, what, nan_class=False):
+    """nan_class: NaN payload/sign bits are implementation-defined (0*inf on x86 vs gfx950), so where
+    BOTH sides hold a NaN they count as equal; everything else stays bit-exact."""
     if bits_equal(got, want):
         return
     got, want = np.ascontiguousarray(got), np.ascontiguousarray(want)
+    if nan_class and got.shape == want.shape and got.dtype.kind == "f":
+        both = np.isnan(got) & np.isnan(want)
+        if both.any():
+            got, want = got.copy(), want.copy()
+            got[both] = 0
+            want[both] = 0
+            if bits_equal(got, want):
+                return
     if got.shape != want.shape or got.dtype != want.dtype:
         raise AssertionError("%s: %s%s != %s%s" % (what, got.dtype, got.shape, want.dtype, want.shape))
     ut = {1: np.uint8, 4: np.uint32, 8: np.uint64}[got.dtype.itemsize]
@@ -249,7 +259,8 @@ def test_pcg_kernels_vs_oracle():
     assert abs((x * Ay).sum() - (Ax * y).sum()) < 1e-9 * np.abs(x * Ay).sum()
 
 
-SWEEP_SHAPES = [(144, 100), (128, 70), (64, 300), (1024, 64), (208, 130), (96, 64), (100, 40), (333, 127)]
+SWEEP_SHAPES = [(144, 100), (128, 70), (64, 300), (1024, 64), (208, 130), (96, 64), (100, 40), (333, 127),
+                (257, 200), (65, 1100), (1025, 130), (80, 640)]   # X+63 multiple of 16; > 8 bands (two workgroups)
 
 
 @pytest.mark.parametrize("sweep", [ea.SWEEP_BAND, ea.SWEEP_SIMPLE])
@@ -291,11 +302,12 @@ def test_ic0_sweeps_random_masks_bit_exact(shape, sweep):
     sim.set(ea.F_PCG_R, r)
     for rep in range(2):       # twice: the second factorisation starts from the first one's output, like the reference
         sim.pcg_op(ea.OP_PRECON_FACTOR)
-        assert_bits(sim.get(ea.F_PRECON), o.precon, "precon %s rep %d" % (shape, rep))
+        # random masks can contain an isolated fluid cell (a = 0 -> precon = inf -> NaN, main.c:593-597)
+        assert_bits(sim.get(ea.F_PRECON), o.precon, "precon %s rep %d" % (shape, rep), nan_class=True)
         sim.pcg_op(ea.OP_FORWARD_SOLVE)
-        assert_bits(sim.get(ea.F_PCG_Q), o.q, "q %s" % (shape,))
+        assert_bits(sim.get(ea.F_PCG_Q), o.q, "q %s" % (shape,), nan_class=True)
         sim.pcg_op(ea.OP_BACKWARD_SOLVE)
-        assert_bits(sim.get(ea.F_PCG_Z), o.z, "z %s" % (shape,))
+        assert_bits(sim.get(ea.F_PCG_Z), o.z, "z %s" % (shape,), nan_class=True)
         o.lib.eo_apply_preconditioner(o.ptr, o.f64p(o.r), o.f64p(o.z))
 
 
