@@ -119,20 +119,12 @@ def cpu_model():
 
 def main():
     args = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
-
-    import torch
-    dist = None
+    from euler_amd.dist import Group, whole_job_rate
+    grp = Group()                      # one process per GPU; "nccl" (= RCCL) when N > 1
+    rank, local_rank, world = grp.rank, grp.local_rank, grp.world
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        args.gpus = world
+    import torch
 
     import euler_amd as ea
     from euler_amd import scenarios
@@ -186,20 +178,8 @@ def main():
         sim.profile_enable(timed_classes)
     st0 = sim.stats()
 
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sim.step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # timed region: barrier + device sync on both sides, MAX over ranks (euler_amd/dist.py)
+    elapsed = grp.timed(sim.step, args.steps)
 
     st1 = sim.stats()
     prof = sim.profile() if timed_classes else {}
@@ -208,9 +188,9 @@ def main():
     iters = st1.total_pcg_iterations - st0.total_pcg_iterations
     cells = N * N
 
+    job_rate = whole_job_rate(float(N * N), args.steps, elapsed, grp)
     if rank != 0:
-        if dist:
-            dist.destroy_process_group()
+        grp.close()
         return
 
     roof = None
@@ -242,7 +222,7 @@ def main():
 
     out = {
         "metric": "cells*steps/sec of sim_step() (dam-break frames incl. PCG pressure projection)",
-        "value": cells * args.steps * max(args.gpus, 1) / elapsed,
+        "value": job_rate,
         "unit": "cells*steps/s",
         "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
@@ -267,8 +247,7 @@ def main():
         "device": sim.device_name(),
     }
     print(json.dumps(out))
-    if dist:
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":

@@ -382,3 +382,25 @@ def test_error_conventions():
     assert e.value.code == -3 and "Could not load" in str(e.value)   # reference main.c:213
     with pytest.raises(ea.EulerError):
         ea.Simulation(4, 4)
+
+
+def test_cli_dump_matches_reference_frames(tmp_path):
+    """The C `euler` front end (scenario file -> step -> render loop, reference main.c:1016-1042):
+    frame k of `euler --dump` = the reference's draw_rows() bytes after k sim_step() calls."""
+    import os
+    import subprocess
+    g = load("block_frames.npz")
+    r = load("block_render.npz")
+    scn = tmp_path / "block.txt"
+    scn.write_text(scenario_text(g))
+    exe = os.path.join(os.path.dirname(ea.LIB_PATH), "..", "bin", "euler")
+    out = subprocess.run([exe, "--dump", "--frames", "2", "--window", "98x38", str(scn)], capture_output=True, timeout=120)
+    assert out.returncode == 0, out.stderr.decode()
+    frames = out.stdout.split(b"--- frame ")[1:]
+    assert len(frames) == 3
+    for k, key in ((1, "f0_w98x38"), (2, "f1_w98x38")):
+        header, body = frames[k].split(b"\n", 1)
+        n = int(header.split(b"(")[1].split()[0])
+        assert body[:n] == r[key].tobytes(), key
+    bad = subprocess.run([exe, "--dump", "/nonexistent.txt"], capture_output=True, timeout=60)
+    assert bad.returncode == 1 and b"Could not load" in bad.stderr
