@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--dot-mode", default="tree", choices=["tree", "sequential"])
     ap.add_argument("--precond", default="ic0", choices=["ic0", "jacobi"])
     ap.add_argument("--max-preroll", type=int, default=90)
+    ap.add_argument("--slab", default="local", choices=["local", "exact", "replicas"],
+                    help="N>1: slab-local IC(0) (scales; tolerance-only), exact coupling (the 1-GPU iterates; sweeps "
+                         "serialize across GPUs) or independent replicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the hipEvent per-kernel timing (used under rocprofv3)")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel class (diagnostics)")
@@ -132,7 +135,17 @@ def main():
     N = args.size
     dot_mode = ea.DOT_TREE if args.dot_mode == "tree" else ea.DOT_SEQUENTIAL
     precond = ea.PRECOND_IC0 if args.precond == "ic0" else ea.PRECOND_JACOBI
-    sim = ea.Simulation(N, N, device=local_rank, dot_mode=dot_mode, precond=precond)
+    # N > 1 (weak scaling): the grid grows to N x (N * gpus) rows; the pressure solve is split into one
+    # slab of N rows per GPU, the cheap stages run replicated (DESIGN.md "Multi-GPU")
+    sharded = world > 1 and args.slab != "replicas"
+    GX, GY = N, N * (world if sharded else 1)
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+    sim = ea.Simulation(GX, GY, device=local_rank, dot_mode=dot_mode, precond=precond)
+    comm = None
+    if sharded:
+        from euler_amd.slab import SLAB_EXACT, SLAB_LOCAL, TorchComm
+        comm = TorchComm(sim, SLAB_EXACT if args.slab == "exact" else SLAB_LOCAL)
     if args.workload == "dam_break":
         sim.load_text(scenarios.dam_break(), upscale=True)
     elif args.workload == "waterfall":
@@ -186,9 +199,13 @@ def main():
     sim.profile_enable([])
     substeps = st1.total_substeps - st0.total_substeps
     iters = st1.total_pcg_iterations - st0.total_pcg_iterations
-    cells = N * N
+    cells = GX * GY
+    cells_launch = cells // world if sharded else cells      # cells one kernel launch covers on one GPU
 
-    job_rate = whole_job_rate(float(N * N), args.steps, elapsed, grp)
+    if comm is not None and comm.error:
+        raise RuntimeError(comm.error)
+    # sharded: ONE job of GX*GY cells; replicas / single GPU: one job of N*N cells per rank
+    job_rate = (GX * GY * args.steps / elapsed) if sharded else whole_job_rate(float(N * N), args.steps, elapsed, grp)
     if rank != 0:
         grp.close()
         return
@@ -198,14 +215,14 @@ def main():
     for name, (ms, launches) in prof.items():
         entry = {"ms_total": round(ms, 3), "launches": int(launches), "avg_us": round(1e3 * ms / launches, 2)}
         if name in ALGO_BYTES:
-            entry["algo_GBps"] = round(ALGO_BYTES[name] * cells / (ms / launches * 1e-3) / 1e9, 1)
+            entry["algo_GBps"] = round(ALGO_BYTES[name] * cells_launch / (ms / launches * 1e-3) / 1e9, 1)
         kern[name] = entry
     if dominant in prof:
         ms, launches = prof[dominant]
-        achieved = ALGO_BYTES[dominant] * cells / (ms / launches * 1e-3) / 1e9
+        achieved = ALGO_BYTES[dominant] * cells_launch / (ms / launches * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
-                "algorithmic_bytes_per_launch": ALGO_BYTES[dominant] * cells,
+                "algorithmic_bytes_per_launch": ALGO_BYTES[dominant] * cells_launch,
                 "avg_launch_us": round(1e3 * ms / launches, 2), "launches": int(launches)}
     pcg_ms = sum(prof[k][0] for k in ALGO_BYTES if k in prof) + sum(prof[k][0] for k in ("reduce_final",) if k in prof)
     pcg_gbps = PCG_BYTES_PER_CELL_ITER * cells * iters / (pcg_ms * 1e-3) / 1e9 if pcg_ms and iters else None
@@ -231,10 +248,13 @@ def main():
         "vs_baseline": None,
         "dtype": "f32 fields, f64 PCG (the reference's mix)",
         "data": "synthetic",
-        "config": {"workload": "%dx%d %s, %s" % (N, N, args.workload, "block layout upscaled" if args.workload == "dam_break" else "synthetic"),
-                   "grid": [N, N], "preroll_frames": preroll, "precond": args.precond, "dot_mode": args.dot_mode,
+        "config": {"workload": "%dx%d %s, %s" % (GX, GY, args.workload, "block layout upscaled" if args.workload == "dam_break" else "synthetic"),
+                   "grid": [GX, GY], "preroll_frames": preroll, "precond": args.precond, "dot_mode": args.dot_mode,
                    "max_iterations": 100, "tol": 1e-6,
-                   "parallelism": "1 GPU" if args.gpus == 1 else "%d independent replicas (row-slab decomposition: see DESIGN.md)" % args.gpus},
+                   "parallelism": "1 GPU" if args.gpus == 1 else (
+                       "%d independent replicas" % args.gpus if not sharded else
+                       "%d row slabs of %d rows: distributed PCG (%s IC(0) coupling), replicated marker/advection stages; grid %dx%d"
+                       % (args.gpus, N, args.slab, GX, GY))},
         "substeps": int(substeps), "pcg_iterations": int(iters),
         "cells_substeps_per_s": cells * substeps / elapsed,
         "markers": int(st1.n_markers), "fluid_cells": int(st1.fluid_cells),

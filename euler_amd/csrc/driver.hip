@@ -137,7 +137,7 @@ extern "C" void euler_destroy(euler_sim* S) {
   if (S->stream) (void)hipStreamSynchronize(S->stream);
   void* dev[] = {S->u, S->v, S->utmp, S->vtmp, S->solid, S->source, S->sink, S->count, S->prev_count, S->count32,
                  S->markers[0], S->markers[1], S->ms, S->evmask, S->ev_theta, S->ev_delta, S->sel_idx, S->act_idx,
-                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket,
+                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->halo_buf,
                  S->rowmajor_tmp};
   for (void* p : dev) if (p) (void)hipFree(p);
   for (double* d : {S->b, S->p, S->r, S->z, S->s, S->q, S->precon, S->kr, S->ku}) if (d) (void)hipFree(d - EU_SKEW_SLACK);
@@ -147,7 +147,7 @@ extern "C" void euler_destroy(euler_sim* S) {
   if (S->sc_host) (void)hipHostFree(S->sc_host);
   if (S->ev_pool) { for (int k = 0; k < S->ev_cap; ++k) (void)hipEventDestroy(S->ev_pool[k]); free(S->ev_pool); }
   free(S->ev_cls); free(S->ev_solve); free(S->ev_iter);
-  if (S->stream) (void)hipStreamDestroy(S->stream);
+  if (S->stream && S->own_stream) (void)hipStreamDestroy(S->stream);
   free(S);
 }
 
@@ -181,6 +181,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   if (S->cfg.dot_mode == EULER_DOT_AUTO) S->cfg.dot_mode = C <= 65536 ? EULER_DOT_SEQUENTIAL : EULER_DOT_TREE;
   if (S->cfg.sweep_mode == EULER_SWEEP_AUTO) S->cfg.sweep_mode = EULER_SWEEP_BAND;
   HIPCHK(hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking));
+  S->own_stream = 1;
 
   DALLOC(S->u, C); DALLOC(S->v, C); DALLOC(S->utmp, C); DALLOC(S->vtmp, C);
   DALLOC(S->solid, C); DALLOC(S->source, C); DALLOC(S->sink, C); DALLOC(S->count, C); DALLOC(S->prev_count, C);
@@ -212,6 +213,8 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   S->red_blocks = (int)eu_blocks(SS, 256 * 16, 2048);
   DALLOC(S->partial, (size_t)S->red_blocks);
   DALLOC(S->red_counter, 1);
+  S->band_lo = 0; S->band_hi = S->geom.nbands; S->e_lo = 0; S->e_cnt = SS;
+  DALLOC(S->halo_buf, (size_t)4 * S->X);
   S->gran_stride = (S->X + 7) / 8 * 8;
   DALLOC(S->granules, (size_t)S->geom.nbands * S->gran_stride * 2);
   DALLOC(S->ticket, 1);
@@ -328,6 +331,48 @@ extern "C" int euler_load_scenario_file(euler_sim* S, const char* path, int32_t 
 extern "C" int euler_load_half_tank(euler_sim* S) {
   if (!S) return EULER_EINVAL;
   return load_from_grids(S, fill_tank, S);
+}
+
+// ------------------------------------------------------------------------------------------
+// multi-GPU plumbing
+extern "C" int euler_set_stream(euler_sim* S, void* hip_stream) {
+  if (!S) return EULER_EINVAL;
+  HIPCHK(hipStreamSynchronize(S->stream));
+  if (S->own_stream) (void)hipStreamDestroy(S->stream);
+  S->stream = (hipStream_t)hip_stream;
+  S->own_stream = 0;
+  return EULER_OK;
+}
+
+extern "C" int euler_set_comm(euler_sim* S, const euler_comm_ops* ops, int32_t coupling) {
+  if (!S) return EULER_EINVAL;
+  if (!ops || ops->nranks <= 1) {
+    S->has_comm = 0; S->band_lo = 0; S->band_hi = S->geom.nbands; S->e_lo = 0; S->e_cnt = S->geom.S;
+    return EULER_OK;
+  }
+  if (!ops->allreduce || !ops->halo || !ops->chain || !ops->allgather || ops->rank < 0 || ops->rank >= ops->nranks) {
+    eu_set_error("euler_set_comm: incomplete communicator"); return EULER_EINVAL;
+  }
+  const int nb = S->geom.nbands;
+  if (ops->nranks > nb) { eu_set_error("euler_set_comm: %d ranks for %d bands (64 rows each)", ops->nranks, nb); return EULER_EINVAL; }
+  if (S->cfg.sweep_mode == EULER_SWEEP_SIMPLE) { eu_set_error("euler_set_comm: EULER_SWEEP_SIMPLE is single-rank only"); return EULER_EINVAL; }
+  S->comm = *ops;
+  S->has_comm = 1;
+  S->couple = coupling == EULER_SLAB_EXACT;
+  S->band_lo = (int)((int64_t)nb * ops->rank / ops->nranks);
+  S->band_hi = (int)((int64_t)nb * (ops->rank + 1) / ops->nranks);
+  S->e_lo = (size_t)S->band_lo * S->geom.TS * 64;
+  S->e_cnt = (size_t)(S->band_hi - S->band_lo) * S->geom.TS * 64;
+  if (S->cfg.dot_mode == EULER_DOT_SEQUENTIAL) S->cfg.dot_mode = EULER_DOT_TREE;   // the replay order is a 1-rank notion
+  return EULER_OK;
+}
+
+extern "C" int euler_slab_info(euler_sim* S, int32_t* lo, int32_t* hi, int32_t* nb) {
+  if (!S) return EULER_EINVAL;
+  if (lo) *lo = S->band_lo;
+  if (hi) *hi = S->band_hi;
+  if (nb) *nb = S->geom.nbands;
+  return EULER_OK;
 }
 
 // ------------------------------------------------------------------------------------------

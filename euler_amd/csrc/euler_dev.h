@@ -36,6 +36,7 @@ enum {
 struct PcgScalars {
   double sigma, zs, sigma_new, alpha, beta, rnorm;
   double tol;
+  double comm_val;   // multi-rank: a rank-local reduction result on its way through the all-reduce
   int nonzero;   // !all_zero(r)  (main.c:742)
   int done;      // inf_norm(r) <= tol reached (main.c:756)
   int iters;     // apply_a calls so far (main.c:750)
@@ -134,6 +135,14 @@ struct euler_sim {
   float interp_lim[4];    // nextafterf(extent-1, 0) for U.x, U.y, V.x, V.y (main.c:339-340)
 
   euler_stats stats;
+
+  // multi-GPU slab decomposition of the pressure solve (include/euler.h euler_comm_ops)
+  euler_comm_ops comm;
+  int has_comm, couple;
+  int band_lo, band_hi;       // this rank's bands [lo, hi)
+  size_t e_lo, e_cnt;         // the same range in skewed elements
+  double* halo_buf;           // 4 rows of X doubles: send_lo, send_hi, recv_lo, recv_hi
+  int own_stream;
 
   // profiling: hipEvent pairs per launch; PCG launches carry (solve, iteration) so that launches
   // that returned at once (after convergence / all-zero rhs) are NOT counted

@@ -150,10 +150,10 @@ __global__ __launch_bounds__(256) void k_build_system(const float* __restrict__ 
                                                       const uint8_t* __restrict__ count, const uint8_t* __restrict__ solid,
                                                       double* __restrict__ b, double* __restrict__ r, double* __restrict__ p,
                                                       uint8_t* __restrict__ cellmask, int8_t* __restrict__ fmask,
-                                                      PcgScalars* sc, SkewGeom g, float dt) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                                      PcgScalars* sc, SkewGeom g, float dt, size_t e_lo, size_t e_cnt) {
+  const size_t e = e_lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // this rank's bands only
   bool nz = false;
-  if (e < g.S) {
+  if (e < e_lo + e_cnt) {
     const int X = g.X;
     const int l = (int)(e & 63);
     const size_t rec = e >> 6;
@@ -228,8 +228,8 @@ __global__ __launch_bounds__(256) void k_velocity_update(const float* __restrict
 }
 
 int eu_launch_build_system(euler_sim* S, float dt) {
-  LAUNCH(S, KC_BUILD_SYSTEM, k_build_system, dim3(eu_blocks(S->geom.S, 256)), dim3(256), S->utmp, S->vtmp, S->count,
-         S->solid, S->b, S->r, S->p, S->cellmask, S->fmask, S->sc, S->geom, dt);
+  LAUNCH(S, KC_BUILD_SYSTEM, k_build_system, dim3(eu_blocks(S->e_cnt, 256)), dim3(256), S->utmp, S->vtmp, S->count,
+         S->solid, S->b, S->r, S->p, S->cellmask, S->fmask, S->sc, S->geom, dt, S->e_lo, S->e_cnt);
   return EULER_OK;
 }
 

@@ -25,13 +25,15 @@
 // the reference's row-major order (EULER_DOT_SEQUENTIAL) or reduced in a fixed tree.
 #include "euler_dev.h"
 
+#include <vector>
+
 #define RED_THREADS 256
 
 __device__ __forceinline__ bool pcg_idle(const PcgScalars* sc) { return sc->done || !sc->nonzero; }
 
 // ------------------------------------------------------------------------------------------
 // scalar epilogues of the reductions
-enum { FIN_SIGMA_INIT = 0, FIN_ALPHA, FIN_RNORM, FIN_BETA, FIN_STORE_ONLY };
+enum { FIN_SIGMA_INIT = 0, FIN_ALPHA, FIN_RNORM, FIN_BETA, FIN_STORE_ONLY, FIN_TO_COMM };
 
 __device__ __forceinline__ void pcg_scalar_step(PcgScalars* sc, int op, double v) {
   switch (op) {
@@ -39,6 +41,7 @@ __device__ __forceinline__ void pcg_scalar_step(PcgScalars* sc, int op, double v
     case FIN_ALPHA: sc->zs = v; sc->alpha = sc->sigma / v; sc->iters += 1; break;     // main.c:750-752
     case FIN_RNORM: sc->rnorm = v; if (v <= sc->tol) sc->done = 1; break;             // main.c:756
     case FIN_BETA: sc->sigma_new = v; sc->beta = v / sc->sigma; sc->sigma = v; break; // main.c:762-765
+    case FIN_TO_COMM: sc->comm_val = v; break;   // multi-rank: the epilogue runs after the all-reduce
     default: sc->sigma_new = v; break;
   }
 }
@@ -274,6 +277,8 @@ struct SweepArgs {
   unsigned long long* granules;   // [nbands][gran_stride][2] tagged hand-off of a band's edge row
   int gran_stride;
   int catchup;            // blocks the producer must lead by before a stalled consumer resumes
+  int band_lo, nb_local;  // this rank's bands [band_lo, band_lo + nb_local)
+  int couple;             // 1: the first/last local band is coupled to the neighbouring rank's band
   unsigned int* ticket;
   unsigned int ticket_base;
   unsigned int epoch;
@@ -393,11 +398,14 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
   constexpr int STEP = BWD ? -64 : 64;                // elements per step
   const SkewGeom g = a.g;
   const int X = g.X, T = g.T, TS = g.TS, nb = g.nbands;
-  const int band = BWD ? nb - 1 - ord : ord;
-  const bool has_prev = ord > 0;                      // a band before us in sweep order
-  const bool publish = ord + 1 < nb;
-  unsigned long long* gr_out = a.granules + (size_t)ord * a.gran_stride * 2;
-  const unsigned long long* gr_in = a.granules + (size_t)(has_prev ? ord - 1 : 0) * a.gran_stride * 2;
+  // `ord` counts this launch's (= this rank's) bands in sweep order; gord is the position in the
+  // global band pipeline, which also names the hand-off rows (forwarded rank to rank when coupled)
+  const int band = BWD ? a.band_lo + a.nb_local - 1 - ord : a.band_lo + ord;
+  const int gord = BWD ? nb - 1 - band : band;
+  const bool has_prev = ord > 0 || (a.couple && gord > 0);            // a band before us in sweep order
+  const bool publish = ord + 1 < a.nb_local || (a.couple && gord + 1 < nb);
+  unsigned long long* gr_out = a.granules + (size_t)gord * a.gran_stride * 2;
+  const unsigned long long* gr_in = a.granules + (size_t)(has_prev ? gord - 1 : 0) * a.gran_stride * 2;
   const unsigned long long tag = (unsigned long long)a.epoch << 32;
 
   // Per-lane stream pointers at (this band, first record, this lane).  They advance by 8 records
@@ -577,18 +585,76 @@ static SweepArgs make_sweep_args(euler_sim* S, int op, int force) {
   a.kr = S->kr; a.ku = S->ku;
   a.granules = S->granules; a.gran_stride = S->gran_stride; a.ticket = S->ticket;
   a.catchup = S->sweep_catchup;
+  a.band_lo = S->band_lo; a.nb_local = S->band_hi - S->band_lo; a.couple = S->has_comm && S->couple;
   a.ticket_base = S->ticket_base; a.epoch = S->epoch;
   a.sc = S->sc; a.force = force; a.error = &S->ms->error;
   return a;
 }
 
+// ---- multi-rank helpers ---------------------------------------------------------------------
+__global__ void k_scalar_epilogue(PcgScalars* sc, int op, int force) {   // after the all-reduce of comm_val
+  if (!force && pcg_idle(sc)) return;
+  pcg_scalar_step(sc, op, sc->comm_val);
+}
+__global__ void k_nonzero_to_comm(PcgScalars* sc) { sc->comm_val = sc->nonzero ? 1.0 : 0.0; }
+__global__ void k_nonzero_from_comm(PcgScalars* sc) { sc->nonzero = sc->comm_val != 0.0; }
+
+// one grid row (band, lane) of a skewed array <-> a contiguous buffer of X doubles
+__global__ __launch_bounds__(256) void k_pack_row(const double* __restrict__ skew, double* __restrict__ row, SkewGeom g, int band, int lane) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x < g.X) row[x] = skew[((size_t)band * g.TS + x + lane) * 64 + lane];
+}
+__global__ __launch_bounds__(256) void k_unpack_row(double* __restrict__ skew, const double* __restrict__ row, SkewGeom g, int band, int lane) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x < g.X) skew[((size_t)band * g.TS + x + lane) * 64 + lane] = row[x];
+}
+
+#define COMM_CALL(expr) do { if ((expr) != 0) { eu_set_error("communicator callback failed: %s", #expr); return EULER_ECOMM; } } while (0)
+
+static int comm_allreduce_scalar(euler_sim* S, int is_max) {
+  COMM_CALL(S->comm.allreduce(S->comm.ctx, &S->sc->comm_val, 1, is_max));
+  return EULER_OK;
+}
+// rank-local reduction result (left in comm_val by FIN_TO_COMM) -> all-reduce -> scalar epilogue
+static int comm_finish(euler_sim* S, int fin_op, int is_max, int force) {
+  int rc = comm_allreduce_scalar(S, is_max);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_scalar_epilogue, dim3(1), dim3(1), 0, S->stream, S->sc, fin_op, force);
+  return EULER_OK;
+}
+static inline int fin_or_comm(const euler_sim* S, int fin_op) { return S->has_comm ? (int)FIN_TO_COMM : fin_op; }
+
+// ghost rows of the search vector s for apply_a: my lowest row goes to rank-1, my highest to rank+1
+static int comm_halo_s(euler_sim* S) {
+  const int X = S->X, nbk = (X + 255) / 256;
+  double *send_lo = S->halo_buf, *send_hi = S->halo_buf + X, *recv_lo = S->halo_buf + 2 * X, *recv_hi = S->halo_buf + 3 * X;
+  const bool has_lo = S->band_lo > 0, has_hi = S->band_hi < S->geom.nbands;
+  if (has_lo) hipLaunchKernelGGL(k_pack_row, dim3(nbk), dim3(256), 0, S->stream, S->s, send_lo, S->geom, S->band_lo, 0);
+  if (has_hi) hipLaunchKernelGGL(k_pack_row, dim3(nbk), dim3(256), 0, S->stream, S->s, send_hi, S->geom, S->band_hi - 1, 63);
+  COMM_CALL(S->comm.halo(S->comm.ctx, send_lo, send_hi, recv_lo, recv_hi, X));
+  if (has_lo) hipLaunchKernelGGL(k_unpack_row, dim3(nbk), dim3(256), 0, S->stream, S->s, recv_lo, S->geom, S->band_lo - 1, 63);
+  if (has_hi) hipLaunchKernelGGL(k_unpack_row, dim3(nbk), dim3(256), 0, S->stream, S->s, recv_hi, S->geom, S->band_hi, 0);
+  return EULER_OK;
+}
+
 template <int OP>
 static int launch_sweep(euler_sim* S, int cls, int force) {
   if (S->cfg.sweep_mode != EULER_SWEEP_SIMPLE) {
+    constexpr bool BWD = OP == SW_BACKWARD;
+    const int nb = S->geom.nbands, nbl = S->band_hi - S->band_lo;
+    const bool chain = S->has_comm && S->couple;
+    const int64_t row_bytes = (int64_t)S->gran_stride * 2 * 8;
+    // global pipeline positions of my first / last band in sweep order
+    const int g_first = BWD ? nb - S->band_hi : S->band_lo, g_last = g_first + nbl - 1;
+    const int r = S->comm.rank, prev_rank = BWD ? r + 1 : r - 1, next_rank = BWD ? r - 1 : r + 1;
     S->epoch += 1;
+    if (chain && g_first > 0)   // the edge row of the band before mine arrives from the previous slab
+      COMM_CALL(S->comm.chain(S->comm.ctx, S->granules + (size_t)(g_first - 1) * S->gran_stride * 2, row_bytes, prev_rank, r));
     SweepArgs a = make_sweep_args(S, OP, force);
-    LAUNCH(S, cls, k_sweep_skew<OP>, dim3(S->geom.nbands), dim3(64), a);
-    S->ticket_base += (unsigned)S->geom.nbands;
+    LAUNCH(S, cls, k_sweep_skew<OP>, dim3(nbl), dim3(64), a);
+    S->ticket_base += (unsigned)nbl;
+    if (chain && g_last + 1 < nb)
+      COMM_CALL(S->comm.chain(S->comm.ctx, S->granules + (size_t)g_last * S->gran_stride * 2, row_bytes, r, next_rank));
   } else {
     SweepArgs a = make_sweep_args(S, OP, force);
     LAUNCH(S, cls, k_sweep_simple<OP>, dim3(1), dim3(1024), a);
@@ -596,32 +662,42 @@ static int launch_sweep(euler_sim* S, int cls, int force) {
   return EULER_OK;
 }
 
+// element range of this rank (the whole array without a communicator)
+#define LOC(ptr) ((ptr) + S->e_lo)
+static inline int loc_red_blocks(const euler_sim* S) { return (int)eu_blocks(S->e_cnt, 256 * 16, 2048); }
+
 static int launch_dot(euler_sim* S, const double* a, const double* b, int fin_op, int force) {
-  if (S->cfg.dot_mode == EULER_DOT_SEQUENTIAL) {
+  if (S->cfg.dot_mode == EULER_DOT_SEQUENTIAL && !S->has_comm) {
     LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), a, b, S->cellmask, S->geom, S->sc, fin_op, force);
   } else {
-    LAUNCH(S, KC_DOT, k_dot_partial, dim3(S->red_blocks), dim3(RED_THREADS), a, b, S->cellmask, S->geom.S, S->partial, S->sc, force,
-           S->red_counter, fin_op);
+    LAUNCH(S, KC_DOT, k_dot_partial, dim3(loc_red_blocks(S)), dim3(RED_THREADS), LOC(a), LOC(b), LOC(S->cellmask), S->e_cnt,
+           S->partial, S->sc, force, S->red_counter, fin_or_comm(S, fin_op));
+    if (S->has_comm) return comm_finish(S, fin_op, 0, force);
   }
   return EULER_OK;
 }
 
 static int launch_precondition(euler_sim* S, int force) {   // z = M^-1 r
   if (S->cfg.precond == EULER_PRECOND_JACOBI) {
-    LAUNCH(S, KC_JACOBI, k_jacobi, dim3(eu_blocks(S->geom.S, 256 * 4, 4096)), dim3(256), S->r, S->z, S->cellmask, S->geom.S, S->sc, force);
+    LAUNCH(S, KC_JACOBI, k_jacobi, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->r), LOC(S->z), LOC(S->cellmask),
+           S->e_cnt, S->sc, force);
     return EULER_OK;
   }
-  launch_sweep<SW_FORWARD>(S, KC_FORWARD_SOLVE, force);
-  launch_sweep<SW_BACKWARD>(S, KC_BACKWARD_SOLVE, force);
-  return EULER_OK;
+  int rc = launch_sweep<SW_FORWARD>(S, KC_FORWARD_SOLVE, force);
+  if (rc) return rc;
+  return launch_sweep<SW_BACKWARD>(S, KC_BACKWARD_SOLVE, force);
 }
 
 static int launch_apply_a_and_alpha(euler_sim* S, int force) {
-  const bool seq = S->cfg.dot_mode == EULER_DOT_SEQUENTIAL;
-  LAUNCH(S, KC_APPLY_A, k_apply_a, dim3(S->red_blocks), dim3(RED_THREADS), S->s, S->z, S->cellmask, S->geom, S->partial,
-         S->sc, force, S->red_counter, seq ? -1 : (int)FIN_ALPHA);
+  const bool seq = S->cfg.dot_mode == EULER_DOT_SEQUENTIAL && !S->has_comm;
+  if (S->has_comm) { int rc = comm_halo_s(S); if (rc) return rc; }
+  SkewGeom gl = S->geom;
+  gl.S = S->e_cnt;
+  LAUNCH(S, KC_APPLY_A, k_apply_a, dim3(loc_red_blocks(S)), dim3(RED_THREADS), LOC(S->s), LOC(S->z), LOC(S->cellmask), gl,
+         S->partial, S->sc, force, S->red_counter, seq ? -1 : fin_or_comm(S, FIN_ALPHA));
   if (seq)
     LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), S->z, S->s, S->cellmask, S->geom, S->sc, (int)FIN_ALPHA, force);
+  if (S->has_comm) return comm_finish(S, FIN_ALPHA, 0, force);
   return EULER_OK;
 }
 
@@ -633,21 +709,29 @@ __global__ void k_pcg_reset(PcgScalars* sc, double tol, int max_iters) {
   sc->tol = tol; sc->nonzero = 0; sc->done = 0; sc->iters = 0; sc->max_iters = max_iters;
 }
 
-// project() (main.c:709-806)
+// project() (main.c:709-806).  With a communicator every launch below covers this rank's bands
+// only; the exchange points are: OR of all_zero(r), the band hand-off rows around each sweep
+// (exact coupling), the ghost rows of s before apply_a, one scalar all-reduce per reduction, and
+// the all-gather of p before the (replicated) velocity update.
 int eu_launch_project(euler_sim* S, float dt) {
   // the previous solve's final scalars are in sc_host by now (copied at its end, synced since)
   S->solve_iters[S->solve_seq & 255] = S->sc_host->nonzero ? S->sc_host->iters : -1;
   S->solve_seq += 1;
   S->prof_iter = -1;
-  const size_t SS = S->geom.S;
+  int rc;
   LAUNCH(S, KC_MISC, k_pcg_reset, dim3(1), dim3(1), S->sc, S->cfg.tol, S->cfg.max_iterations);
   eu_launch_build_system(S, dt);
+  if (S->has_comm) {   // all_zero(r) over the whole grid
+    hipLaunchKernelGGL(k_nonzero_to_comm, dim3(1), dim3(1), 0, S->stream, S->sc);
+    if ((rc = comm_allreduce_scalar(S, 1))) return rc;
+    hipLaunchKernelGGL(k_nonzero_from_comm, dim3(1), dim3(1), 0, S->stream, S->sc);
+  }
   // if (!all_zero(r)) { ... }: every kernel below is a no-op when sc->nonzero == 0
-  if (S->cfg.precond == EULER_PRECOND_IC0) launch_sweep<SW_FACTOR>(S, KC_PRECON_FACTOR, 0);   // once per solve: A is fixed
-  launch_precondition(S, 0);
-  LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<true>, dim3(eu_blocks(SS, 256 * 4, 4096)), dim3(256), S->s, S->z,
-         S->cellmask, SS, S->sc, 0, 0.0);
-  launch_dot(S, S->z, S->r, FIN_SIGMA_INIT, 0);
+  if (S->cfg.precond == EULER_PRECOND_IC0 && (rc = launch_sweep<SW_FACTOR>(S, KC_PRECON_FACTOR, 0))) return rc;   // once per solve
+  if ((rc = launch_precondition(S, 0))) return rc;
+  LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<true>, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->s), LOC(S->z),
+         LOC(S->cellmask), S->e_cnt, S->sc, 0, 0.0);
+  if ((rc = launch_dot(S, S->z, S->r, FIN_SIGMA_INIT, 0))) return rc;
   HIPCHK(hipMemcpyAsync(S->sc_host, S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
   HIPCHK(hipStreamSynchronize(S->stream));
   const int poll = S->cfg.pcg_poll_interval > 0 ? S->cfg.pcg_poll_interval : 8;
@@ -658,26 +742,37 @@ int eu_launch_project(euler_sim* S, float dt) {
     const int chunk_end = it + poll < max_it ? it + poll : max_it;
     for (; it < chunk_end; ++it) {
       S->prof_iter = it;
-      launch_apply_a_and_alpha(S, 0);
-      LAUNCH(S, KC_UPDATE_PR, k_update_pr, dim3(S->red_blocks), dim3(RED_THREADS), S->p, S->r, S->s, S->z, S->cellmask,
-             SS, S->partial, S->sc, 0, 0.0, S->red_counter, (int)FIN_RNORM);
+      if ((rc = launch_apply_a_and_alpha(S, 0))) return rc;
+      LAUNCH(S, KC_UPDATE_PR, k_update_pr, dim3(loc_red_blocks(S)), dim3(RED_THREADS), LOC(S->p), LOC(S->r), LOC(S->s), LOC(S->z),
+             LOC(S->cellmask), S->e_cnt, S->partial, S->sc, 0, 0.0, S->red_counter, fin_or_comm(S, FIN_RNORM));
+      if (S->has_comm && (rc = comm_finish(S, FIN_RNORM, 1, 0))) return rc;
       if (it + 1 < max_it) {   // the tail of the last iteration (main.c:760-765) is never consumed
         // these belong to iteration `it` but only run if it did not converge: tag them it+1 so that
         // they count as active only when the device went on to iteration it+1
         S->prof_iter = it + 1;
-        launch_precondition(S, 0);
-        launch_dot(S, S->z, S->r, FIN_BETA, 0);
-        LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<false>, dim3(eu_blocks(SS, 256 * 4, 4096)), dim3(256), S->s, S->z,
-               S->cellmask, SS, S->sc, 0, 0.0);
+        if ((rc = launch_precondition(S, 0))) return rc;
+        if ((rc = launch_dot(S, S->z, S->r, FIN_BETA, 0))) return rc;
+        LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<false>, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->s),
+               LOC(S->z), LOC(S->cellmask), S->e_cnt, S->sc, 0, 0.0);
       }
     }
-    if (it < max_it) {   // poll the device-side convergence flag
+    if (it < max_it) {   // poll the device-side convergence flag (identical on every rank)
       HIPCHK(hipMemcpyAsync(S->sc_host, S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
       HIPCHK(hipStreamSynchronize(S->stream));
       stop = S->sc_host->done != 0;
     }
   }
   S->prof_iter = -2;
+  if (S->has_comm) {   // every rank needs the whole pressure field for the replicated velocity update
+    const int n = S->comm.nranks, nb = S->geom.nbands;
+    std::vector<int64_t> off(n), cnt(n);
+    for (int k = 0; k < n; ++k) {
+      const int64_t lo = (int64_t)nb * k / n, hi = (int64_t)nb * (k + 1) / n;
+      off[k] = lo * S->geom.TS * 64 * 8;
+      cnt[k] = (hi - lo) * S->geom.TS * 64 * 8;
+    }
+    COMM_CALL(S->comm.allgather(S->comm.ctx, S->p, off.data(), cnt.data()));
+  }
   eu_launch_velocity_update(S, dt);
   HIPCHK(hipMemcpyAsync(S->sc_host, S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
   return EULER_OK;

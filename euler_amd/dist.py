@@ -20,13 +20,15 @@ class Group:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                backend = os.environ.get("EULER_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
                 self.device = torch.device("cuda", self.local_rank)
                 dist.init_process_group("nccl", device_id=self.device)
             else:
                 self.device = torch.device("cpu")
+                if os.environ.get("EULER_SHARE_GPU"):       # tests: several gloo ranks on one GPU
+                    self.local_rank = 0
                 dist.init_process_group("gloo")
             self.dist = dist
 

@@ -1,0 +1,150 @@
+"""Row-slab distribution of the pressure solve over torch.distributed (DESIGN.md "Multi-GPU").
+
+The C library drives the PCG loop and calls four exchange operations (include/euler.h
+`euler_comm_ops`); this module implements them: backend "nccl" (= RCCL over xGMI on an MI355X
+node) works on the device buffers in place; backend "gloo" (tests, incl. several ranks sharing
+one GPU) stages through host memory.  Device pointers of the handle are wrapped zero-copy as torch
+tensors through `__cuda_array_interface__`; the library is switched onto torch's current stream
+so that collectives and kernels are ordered by the stream.
+"""
+import ctypes as C
+import traceback
+
+SLAB_LOCAL, SLAB_EXACT = 0, 1
+
+_ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32)
+_HALO = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32)
+_CHAIN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32)
+_ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64))
+
+
+class CommOps(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int32), ("nranks", C.c_int32),
+                ("allreduce", _ALLREDUCE), ("halo", _HALO), ("chain", _CHAIN), ("allgather", _ALLGATHER)]
+
+
+class _DevMem:
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def slab_bands(nbands, rank, nranks):
+    """Bands [lo, hi) of a rank: the same even split the C library uses (euler_set_comm)."""
+    return nbands * rank // nranks, nbands * (rank + 1) // nranks
+
+
+class TorchComm:
+    """Attach a torch.distributed process group to one Simulation handle."""
+
+    def __init__(self, sim, coupling=SLAB_EXACT):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.sim = torch, dist, sim
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.stage = dist.get_backend() != "nccl"      # gloo: go through host memory
+        self.error = None
+        self._cache = {}
+        self.counts = {"allreduce": 0, "halo": 0, "chain": 0, "allgather": 0}
+        self._cb = (_ALLREDUCE(self._allreduce), _HALO(self._halo), _CHAIN(self._chain), _ALLGATHER(self._allgather))
+        self.ops = CommOps(None, self.rank, self.world, *self._cb)
+        L = sim.L
+        L.euler_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.euler_set_comm.argtypes = [C.c_void_p, C.POINTER(CommOps), C.c_int32]
+        L.euler_slab_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        rc = L.euler_set_stream(sim.h, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc == 0:
+            rc = L.euler_set_comm(sim.h, C.byref(self.ops), coupling)
+        if rc:
+            raise RuntimeError("euler_set_comm failed: %s" % L.euler_last_error().decode())
+        lo, hi, nb = C.c_int32(), C.c_int32(), C.c_int32()
+        L.euler_slab_info(sim.h, C.byref(lo), C.byref(hi), C.byref(nb))
+        self.band_lo, self.band_hi, self.nbands = lo.value, hi.value, nb.value
+        assert (self.band_lo, self.band_hi) == slab_bands(self.nbands, self.rank, self.world)
+        sim._comm = self       # keep the callbacks alive as long as the handle
+
+    # -- helpers
+    def _t(self, ptr, nbytes, dtype=None):
+        key = (ptr, nbytes, dtype)
+        t = self._cache.get(key)
+        if t is None:                  # the handle's buffers never move: wrap each one once
+            t = self.torch.as_tensor(_DevMem(ptr, nbytes), device="cuda")
+            if dtype is not None:
+                t = t.view(dtype)
+            self._cache[key] = t
+        return t
+
+    def _guard(self, name, fn):
+        try:
+            self.counts[name] += 1
+            fn()
+            return 0
+        except Exception:          # never let an exception cross the C boundary
+            self.error = traceback.format_exc()
+            return -1
+
+    # -- the four operations
+    def _allreduce(self, ctx, ptr, count, is_max):
+        def run():
+            t = self._t(ptr, 8 * count, self.torch.float64)
+            op = self.dist.ReduceOp.MAX if is_max else self.dist.ReduceOp.SUM
+            if self.stage:
+                c = t.cpu()
+                self.dist.all_reduce(c, op=op)
+                t.copy_(c)
+            else:
+                self.dist.all_reduce(t, op=op)
+        return self._guard("allreduce", run)
+
+    def _halo(self, ctx, send_lo, send_hi, recv_lo, recv_hi, count):
+        def run():
+            f64, n = self.torch.float64, 8 * count
+            pairs = []   # (send tensor, recv tensor, peer)
+            if self.rank > 0:
+                pairs.append((self._t(send_lo, n, f64), self._t(recv_lo, n, f64), self.rank - 1))
+            if self.rank + 1 < self.world:
+                pairs.append((self._t(send_hi, n, f64), self._t(recv_hi, n, f64), self.rank + 1))
+            if self.stage:
+                host = [(s.cpu(), self.torch.empty(count, dtype=f64), r, p) for s, r, p in pairs]
+                reqs = []
+                for s, tmp, r, p in host:
+                    reqs.append(self.dist.isend(s, p))
+                    reqs.append(self.dist.irecv(tmp, p))
+                for q in reqs:
+                    q.wait()
+                for s, tmp, r, p in host:
+                    r.copy_(tmp)
+            elif pairs:
+                ops = []
+                for s, r, p in pairs:
+                    ops.append(self.dist.P2POp(self.dist.isend, s, p))
+                    ops.append(self.dist.P2POp(self.dist.irecv, r, p))
+                for q in self.dist.batch_isend_irecv(ops):
+                    q.wait()
+        return self._guard("halo", run)
+
+    def _chain(self, ctx, ptr, nbytes, src, dst):
+        def run():
+            t = self._t(ptr, nbytes)
+            if self.rank == src:
+                self.dist.send(t.cpu() if self.stage else t, dst)
+            elif self.rank == dst:
+                if self.stage:
+                    tmp = self.torch.empty(nbytes, dtype=self.torch.uint8)
+                    self.dist.recv(tmp, src)
+                    t.copy_(tmp)
+                else:
+                    self.dist.recv(t, src)
+        return self._guard("chain", run)
+
+    def _allgather(self, ctx, base, off, cnt):
+        def run():
+            for r in range(self.world):
+                t = self._t(base + off[r], cnt[r])
+                if self.stage:
+                    c = t.cpu() if r == self.rank else self.torch.empty(cnt[r], dtype=self.torch.uint8)
+                    self.dist.broadcast(c, src=r)
+                    if r != self.rank:
+                        t.copy_(c)
+                else:
+                    self.dist.broadcast(t, src=r)
+        return self._guard("allgather", run)

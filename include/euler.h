@@ -185,6 +185,38 @@ int euler_render(euler_sim* sim, int32_t wx, int32_t wy, char* out, int32_t cap,
 int euler_render_grids(const uint8_t* solid, const uint8_t* sink, const uint8_t* count,
                        int32_t X, int32_t Y, int32_t wx, int32_t wy, char* out, int32_t cap, int32_t* len);
 
+/* ---- multi-GPU: the pressure solve distributed over row slabs (DESIGN.md "Multi-GPU") ------ */
+/* One process per GPU.  Every rank holds the whole grid and runs the cheap stages (markers,
+ * advection, extrapolation) redundantly and bit-identically; the pressure solve - project(),
+ * main.c:709-806, >= 97 % of the time - is partitioned into contiguous slabs of 64-row bands.
+ * The library keeps driving the PCG loop and calls these four operations at its exchange points;
+ * the host program implements them (euler_amd/slab.py: torch.distributed = RCCL on the node).
+ * All pointers are DEVICE pointers into the handle's buffers; operations must be ordered on the
+ * stream given to euler_set_stream.  Each returns 0 on success. */
+typedef struct euler_comm_ops {
+  void*   ctx;
+  int32_t rank, nranks;
+  /* in-place all-reduce of `count` doubles: sum (is_max = 0) or max (is_max = 1) */
+  int (*allreduce)(void* ctx, void* dev_f64, int32_t count, int32_t is_max);
+  /* ghost rows of the search vector: send_lo/recv_lo <-> rank-1, send_hi/recv_hi <-> rank+1
+   * (`count` doubles each; the ends of the chain skip the missing side) */
+  int (*halo)(void* ctx, void* send_lo, void* send_hi, void* recv_lo, void* recv_hi, int32_t count);
+  /* point-to-point: rank `src` sends nbytes at dev_ptr, rank `dst` receives into its own dev_ptr */
+  int (*chain)(void* ctx, void* dev_ptr, int64_t nbytes, int32_t src, int32_t dst);
+  /* all-gather: rank r contributes bytes [off[r], off[r]+cnt[r]) of the array at dev_base */
+  int (*allgather)(void* ctx, void* dev_base, const int64_t* off, const int64_t* cnt);
+} euler_comm_ops;
+
+enum {
+  EULER_SLAB_EXACT = 1,   /* band hand-off rows forwarded rank to rank: the reference's IC(0), the
+                             1-GPU iterates; the triangular sweeps then run one slab after another */
+  EULER_SLAB_LOCAL = 0    /* IC(0) restricted to each slab (block-Jacobi across slabs): slabs sweep
+                             concurrently; NOT the reference's iterates (tolerance only) */
+};
+int euler_set_comm(euler_sim* sim, const euler_comm_ops* ops, int32_t coupling);
+int euler_set_stream(euler_sim* sim, void* hip_stream);   /* run on the caller's HIP stream (e.g. torch's) */
+int euler_slab_info(euler_sim* sim, int32_t* band_lo, int32_t* band_hi, int32_t* nbands);
+
 /* ---- measurement ------------------------------------------------------------------------- */
 /* Per-kernel-class timing with HIP events on the library's own stream.  class_mask bit i
  * enables class i (see euler_profile_class_name); 0 disables. */
