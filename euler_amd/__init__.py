@@ -66,7 +66,7 @@ EXPORTS = [
     "euler_get_field", "euler_set_field", "euler_set_markers", "euler_set_rng", "euler_get_stats",
     "euler_field_bytes", "euler_render", "euler_render_grids", "euler_profile_enable",
     "euler_profile_class_count", "euler_profile_class_name", "euler_profile_get", "euler_profile_reset",
-    "euler_measure_copy_bandwidth", "euler_device_name",
+    "euler_measure_copy_bandwidth", "euler_device_name", "euler_set_comm", "euler_set_stream", "euler_slab_info",
 ]
 
 
@@ -112,6 +112,9 @@ def load_library():
         "euler_profile_reset": (C.c_int, [vp]),
         "euler_measure_copy_bandwidth": (C.c_int, [vp, C.c_size_t, i32, C.POINTER(f64)]),
         "euler_device_name": (C.c_int, [vp, C.c_char_p, i32]),
+        "euler_set_comm": (C.c_int, [vp, vp, i32]),                 # euler_amd/slab.py passes a CommOps struct
+        "euler_set_stream": (C.c_int, [vp, vp]),
+        "euler_slab_info": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)   # AttributeError here = a symbol include/euler.h declares is not exported

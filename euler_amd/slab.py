@@ -48,12 +48,9 @@ class TorchComm:
         self._cb = (_ALLREDUCE(self._allreduce), _HALO(self._halo), _CHAIN(self._chain), _ALLGATHER(self._allgather))
         self.ops = CommOps(None, self.rank, self.world, *self._cb)
         L = sim.L
-        L.euler_set_stream.argtypes = [C.c_void_p, C.c_void_p]
-        L.euler_set_comm.argtypes = [C.c_void_p, C.POINTER(CommOps), C.c_int32]
-        L.euler_slab_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         rc = L.euler_set_stream(sim.h, C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc == 0:
-            rc = L.euler_set_comm(sim.h, C.byref(self.ops), coupling)
+            rc = L.euler_set_comm(sim.h, C.cast(C.pointer(self.ops), C.c_void_p), coupling)
         if rc:
             raise RuntimeError("euler_set_comm failed: %s" % L.euler_last_error().decode())
         lo, hi, nb = C.c_int32(), C.c_int32(), C.c_int32()
