@@ -375,6 +375,33 @@ __device__ __forceinline__ double wave_shift_inject(double v, double edge) {
   const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
+// row-local DPP move of a double (row = 16 lanes); lanes without a source keep `old`
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double old, double v) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+#define DPP_ROW_SHL(n) (0x100 + (n))   // lane l <- lane l+n (within its row of 16)
+#define DPP_ROW_SHR(n) (0x110 + (n))   // lane l <- lane l-n
+// hand-off value of step j (0..7) -> the consuming edge lane.  The 8 boundary values of a block sit
+// in lanes IN_BASE..IN_BASE+7 (forward: 0..7, edge lane 0; backward: 56..63, edge lane 63).
+template <bool BWD, int J>
+__device__ __forceinline__ double edge_pick(double bnd) {
+  if (!BWD) { if (J == 0) return bnd; else return dpp_move<DPP_ROW_SHL(J == 0 ? 1 : J)>(0.0, bnd); }
+  else      { if (J == 7) return bnd; else return dpp_move<DPP_ROW_SHR(J == 7 ? 1 : 7 - J)>(0.0, bnd); }
+}
+
+template <bool BWD>
+__device__ __forceinline__ double edge_pick_j(double bnd, int j) {   // j is a constant after unrolling
+  switch (j) {
+    case 0: return edge_pick<BWD, 0>(bnd); case 1: return edge_pick<BWD, 1>(bnd);
+    case 2: return edge_pick<BWD, 2>(bnd); case 3: return edge_pick<BWD, 3>(bnd);
+    case 4: return edge_pick<BWD, 4>(bnd); case 5: return edge_pick<BWD, 5>(bnd);
+    case 6: return edge_pick<BWD, 6>(bnd); default: return edge_pick<BWD, 7>(bnd);
+  }
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int lane_uniform) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane_uniform),
                           __builtin_amdgcn_readlane(__double2loint(v), lane_uniform));
@@ -394,7 +421,9 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
   if (!a.force && pcg_idle(a.sc)) return;
   constexpr bool BWD = OP == SW_BACKWARD;
   constexpr int CTRL = BWD ? DPP_WAVE_SHL1 : DPP_WAVE_SHR1;
-  constexpr int EDGE_OUT = BWD ? 0 : 63;              // lane whose row the next band needs
+
+  constexpr int IN_BASE = BWD ? 56 : 0;               // lanes IN_BASE..+7 hold the 8 incoming boundary values of a block
+
   constexpr int STEP = BWD ? -64 : 64;                // elements per step
   const SkewGeom g = a.g;
   const int X = g.X, T = g.T, TS = g.TS, nb = g.nbands;
@@ -455,15 +484,15 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
   constexpr int VMEM_PER_STEP = OP == SW_FACTOR ? 5 : (OP == SW_FORWARD ? 4 : 6);   // loads + record stores
   constexpr int POLL_VMCNT = 8 * VMEM_PER_STEP - 8;
   auto poll_issue = [&](int blk, u32x4& gv) {
-    const int xl = SW_BLK * blk + lane;
-    if (lane < SW_BLK && xl < X) {
+    const int k = lane - IN_BASE, xl = SW_BLK * blk + k;
+    if (k >= 0 && k < SW_BLK && xl < X) {
       const unsigned long long* p = &gr_in[(size_t)xl * 2];
       asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(gv) : "v"(p) : "memory");
     }
   };
   auto poll_ready = [&](int blk, const u32x4& gv) {
-    const int xl = SW_BLK * blk + lane;
-    const bool want = lane < SW_BLK && xl < X;
+    const int k = lane - IN_BASE, xl = SW_BLK * blk + k;
+    const bool want = k >= 0 && k < SW_BLK && xl < X;
     return !want || (gv[1] == a.epoch && gv[3] == a.epoch);
   };
   // slow path: the block is not there yet (catchup > 0: resume only once the producer leads by that
@@ -488,8 +517,8 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
   //   backward : z (the coefficients belong to the consuming cell, main.c:620-622)
   double own = 0.0;        // carried value of the previous column of this row
   double out = 0.0;        // carried value this lane hands to the next lane
-  double bnd = 0.0;        // lanes 0..7: previous band's edge values at logical column 8*blk + lane
-  double pub = 0.0;        // lanes 0..7: this band's edge values of the current column block
+  double bnd = 0.0;        // lanes IN_BASE..+7: previous band's edge values at logical column 8*blk + (lane - IN_BASE)
+  double pub = 0.0;        // lanes OUT_BASE..+7: this band's most recent edge values (newest at the edge lane)
   if (has_prev) {                          // block 0 synchronously
     u32x4 gv = {0u, 0u, 0u, 0u};
     poll_issue(0, gv);
@@ -507,7 +536,7 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
 #pragma unroll
     for (int j = 0; j < SW_BLK; ++j) {
       // the edge lane consumes logical column s = 8*blk + j of the previous band (lane j of bnd)
-      const double nbv = wave_shift_inject<CTRL>(out, readlane_f64(bnd, j));
+      const double nbv = wave_shift_inject<CTRL>(out, edge_pick_j<BWD>(bnd, j));   // 2 + 2 DPP moves
       const double cin = cur.in[j], cpre = cur.pre[j];
       const int cm = cur.m[j];
       double res, carry;
@@ -535,14 +564,14 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
       p_out[j * STEP] = res;
       own = carry;
       out = carry;
-      // logical column s - 63 of the edge row is done: collect it in lane (s - 63) & 7 = (j + 1) & 7
-      {
-        const double edge_val = readlane_f64(carry, EDGE_OUT);   // uniform
-        pub = lane == ((j + 1) & 7) ? edge_val : pub;            // lane masks are loop-invariant SGPR pairs
-      }
+      // logical column s - 63 of the edge row is done: shift the outgoing-values register by one lane
+      // inside its row and drop the new value in at the edge lane (it is the lane without a source
+      // and keeps `old` = carry).  Newest value at the edge lane, the one from k steps ago k lanes away.
+      pub = BWD ? dpp_move<DPP_ROW_SHR(1)>(carry, pub) : dpp_move<DPP_ROW_SHL(1)>(carry, pub);
       if (j == 6 && publish) {             // columns 8*blk - 64 ... 8*blk - 57 are complete
-        const int col = SW_BLK * blk - 64 + lane;
-        if (lane < SW_BLK && col >= 0 && col < X) {
+        const int k = BWD ? lane : 63 - lane;                     // steps since the value was produced
+        const int col = SW_BLK * blk - 57 - k;
+        if (k >= 0 && k < SW_BLK && col >= 0 && col < X) {
           const unsigned long long bits = (unsigned long long)__double_as_longlong(pub);
           __hip_atomic_store(&gr_out[(size_t)col * 2], tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(&gr_out[(size_t)col * 2 + 1], tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -565,8 +594,9 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
   // tail: the in-loop trigger fires at j == 6, so up to 8 finished columns of the edge row are still
   // unannounced when the loop ends (all 8 when T is a multiple of 16)
   if (publish) {
-    const int col = SW_BLK * (2 * npairs) - 64 + lane;
-    if (lane < SW_BLK && col >= 0 && col < X) {
+    const int k = BWD ? lane : 63 - lane;
+    const int col = SW_BLK * (2 * npairs) - 64 - k;
+    if (k >= 0 && k < SW_BLK && col >= 0 && col < X) {
       const unsigned long long bits = (unsigned long long)__double_as_longlong(pub);
       __hip_atomic_store(&gr_out[(size_t)col * 2], tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&gr_out[(size_t)col * 2 + 1], tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -664,7 +694,7 @@ static int launch_sweep(euler_sim* S, int cls, int force) {
 
 // element range of this rank (the whole array without a communicator)
 #define LOC(ptr) ((ptr) + S->e_lo)
-static inline int loc_red_blocks(const euler_sim* S) { return (int)eu_blocks(S->e_cnt, 256 * 16, 2048); }
+static inline int loc_red_blocks(const euler_sim* S) { return (int)eu_blocks(S->e_cnt, 256 * 4, 4096); }
 
 static int launch_dot(euler_sim* S, const double* a, const double* b, int fin_op, int force) {
   if (S->cfg.dot_mode == EULER_DOT_SEQUENTIAL && !S->has_comm) {
