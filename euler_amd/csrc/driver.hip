@@ -210,7 +210,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   DALLOC(S->cellmask, SS + EU_SKEW_SLACK); S->cellmask += EU_SKEW_SLACK;
   DALLOC(S->fmask, SS + EU_SKEW_SLACK); S->fmask += EU_SKEW_SLACK;
   DALLOC(S->sc, 1);
-  S->red_blocks = (int)eu_blocks(SS, 256 * 4, 4096);
+  S->red_blocks = (int)eu_blocks(SS, 256 * 16, 2048);
   DALLOC(S->partial, (size_t)S->red_blocks);
   DALLOC(S->red_counter, 1);
   S->band_lo = 0; S->band_hi = S->geom.nbands; S->e_lo = 0; S->e_cnt = SS;

@@ -404,3 +404,84 @@ def test_cli_dump_matches_reference_frames(tmp_path):
         assert body[:n] == r[key].tobytes(), key
     bad = subprocess.run([exe, "--dump", "/nonexistent.txt"], capture_output=True, timeout=60)
     assert bad.returncode == 1 and b"Could not load" in bad.stderr
+
+
+# ----------------------------------------------------------------------------- randomized marker stress
+def _random_marker_state(X2, Y2, seed, n_markers, solid_frac, crowd=0):
+    """A synthetic state that stresses the marker stages far beyond the shipped scenarios: scattered
+    solid cells (many collisions after a cell crossing -> long dt chains, main.c:501), markers that
+    end up in sink/solid cells (mass deletion + swap-with-last order, main.c:112), optional crowding
+    of one cell beyond 255 markers (uint8 wrap, main.c:114)."""
+    rng = np.random.default_rng(seed)
+    solid = np.zeros((Y2, X2), np.uint8)
+    solid[2:-2, 2:-2] = rng.random((Y2 - 4, X2 - 4)) < solid_frac
+    sink = np.zeros((Y2, X2), np.uint8)
+    sink[0, :] = sink[-1, :] = sink[:, 0] = sink[:, -1] = 1
+    sink[3:-3, 3:-3] |= ((rng.random((Y2 - 6, X2 - 6)) < 0.02) & (solid[3:-3, 3:-3] == 0)).astype(np.uint8)
+    free = np.argwhere((solid == 0) & (sink == 0) & (np.indices((Y2, X2))[0] > 1) & (np.indices((Y2, X2))[0] < Y2 - 2)
+                       & (np.indices((Y2, X2))[1] > 1) & (np.indices((Y2, X2))[1] < X2 - 2))
+    cells = free[rng.integers(0, len(free), n_markers)]
+    if crowd:
+        cells[:crowd] = free[len(free) // 2]
+    m = np.empty((n_markers, 2), np.float32)
+    m[:, 0] = cells[:, 1] + rng.random(n_markers, dtype=np.float32) * np.float32(0.998) + np.float32(0.001)
+    m[:, 1] = cells[:, 0] + rng.random(n_markers, dtype=np.float32) * np.float32(0.998) + np.float32(0.001)
+    u = (rng.standard_normal((Y2, X2)) * 3).astype(np.float32)
+    v = (rng.standard_normal((Y2, X2)) * 3).astype(np.float32)
+    u[:, -1] = 0
+    v[-1, :] = 0
+    return solid, sink, m, u, v
+
+
+def _load_both(X2, Y2, solid, sink, m, u, v):
+    o = Oracle(X2, Y2)
+    o.solid[...] = solid; o.sink[...] = sink; o.u[...] = u; o.v[...] = v
+    o.set_markers(m)
+    o.lib.eo_refresh_marker_counts(o.ptr)            # establishes count / prev_count / deletes bad starts
+    o.lib.eo_refresh_marker_counts(o.ptr)
+    sim = ea.Simulation(X2, Y2, dot_mode=ea.DOT_SEQUENTIAL)
+    for f, a in ((ea.F_SOLID, solid), (ea.F_SOURCE, np.zeros_like(solid)), (ea.F_SINK, sink), (ea.F_U, u), (ea.F_V, v),
+                 (ea.F_COUNT, o.count), (ea.F_PREV_COUNT, o.prev_count)):
+        sim.set(f, a)
+    sim.set_markers(o.markers)
+    return o, sim
+
+
+@pytest.mark.parametrize("shape,seed,n,solid_frac", [((96, 72), 1, 6000, 0.25), ((200, 130), 2, 60000, 0.15),
+                                                      ((333, 257), 3, 200000, 0.30), ((64, 64), 4, 3000, 0.45)])
+def test_marker_stages_random_stress_bit_exact(shape, seed, n, solid_frac):
+    X2, Y2 = shape
+    solid, sink, m, u, v = _random_marker_state(X2, Y2, seed, n, solid_frac)
+    o, sim = _load_both(X2, Y2, solid, sink, m, u, v)
+    events = 0
+    for rep in range(3):
+        dt = sim.timestep(0.1)
+        assert dt == o.timestep(0.1)
+        sim.stage(ea.STAGE_ADVECT_MARKERS, dt)
+        o.lib.eo_advect_markers(o.ptr, np.float32(dt))
+        assert_bits(sim.get(ea.F_MARKERS), o.markers, "advect rep %d" % rep)
+        sim.stage(ea.STAGE_REFRESH_COUNTS)
+        o.lib.eo_refresh_marker_counts(o.ptr)
+        assert sim.stats().n_markers == o.n_markers
+        assert_bits(sim.get(ea.F_MARKERS), o.markers, "compaction order rep %d" % rep)
+        assert_bits(sim.get(ea.F_COUNT), o.count, "count rep %d" % rep)
+        assert_bits(sim.get(ea.F_PREV_COUNT), o.prev_count, "prev_count rep %d" % rep)
+    st = sim.stats()
+    assert st.marker_dt_events > 5, "the stress state should shorten dt many times (got %d)" % st.marker_dt_events
+    assert st.marker_multi_events == 0          # CFL bound: at most one shortening collision per marker
+    assert st.n_markers < n                     # deletions happened
+
+
+def test_marker_count_wraps_like_uint8():
+    """g_marker_count is uint8_t and simply wraps (main.c:96,114): 300 markers in one cell read 44."""
+    X2, Y2 = 64, 64
+    solid, sink, m, u, v = _random_marker_state(X2, Y2, 9, 2000, 0.0, crowd=300)
+    u[...] = 0
+    v[...] = 0
+    o, sim = _load_both(X2, Y2, solid, sink, m, u, v)
+    sim.stage(ea.STAGE_REFRESH_COUNTS)
+    o.lib.eo_refresh_marker_counts(o.ptr)
+    assert_bits(sim.get(ea.F_COUNT), o.count, "count")
+    cy, cx = np.unravel_index(np.argmax(np.bincount((np.floor(m[:, 1]).astype(int) * X2 + np.floor(m[:, 0]).astype(int)), minlength=X2 * Y2)), (Y2, X2))
+    true_count = int(((np.floor(m[:, 0]) == cx) & (np.floor(m[:, 1]) == cy)).sum())
+    assert true_count >= 300 and int(sim.get(ea.F_COUNT)[cy, cx]) == true_count % 256
