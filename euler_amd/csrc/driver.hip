@@ -137,7 +137,7 @@ extern "C" void euler_destroy(euler_sim* S) {
   if (S->stream) (void)hipStreamSynchronize(S->stream);
   void* dev[] = {S->u, S->v, S->utmp, S->vtmp, S->solid, S->source, S->sink, S->count, S->prev_count, S->count32,
                  S->markers[0], S->markers[1], S->ms, S->evmask, S->ev_theta, S->ev_delta, S->sel_idx, S->act_idx,
-                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->halo_buf,
+                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->halo_buf, S->band_ranges,
                  S->rowmajor_tmp};
   for (void* p : dev) if (p) (void)hipFree(p);
   for (double* d : {S->b, S->p, S->r, S->z, S->s, S->q, S->precon, S->kr, S->ku}) if (d) (void)hipFree(d - EU_SKEW_SLACK);
@@ -210,6 +210,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   DALLOC(S->cellmask, SS + EU_SKEW_SLACK); S->cellmask += EU_SKEW_SLACK;
   DALLOC(S->fmask, SS + EU_SKEW_SLACK); S->fmask += EU_SKEW_SLACK;
   DALLOC(S->sc, 1);
+  DALLOC(S->band_ranges, (size_t)S->geom.nbands);
   S->red_blocks = (int)eu_blocks(SS, 256 * 16, 2048);
   DALLOC(S->partial, (size_t)S->red_blocks);
   DALLOC(S->red_counter, 1);

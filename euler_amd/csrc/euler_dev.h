@@ -118,6 +118,7 @@ struct euler_sim {
   double *kr, *ku;        // a_i*precon, a_j*precon of the backward solve (per solve)
   uint8_t* cellmask;
   int8_t* fmask;          // skewed: -1 on fluid cells, 0 elsewhere
+  int4* band_ranges;      // per band: active block ranges of the forward / backward sweeps (per solve)
   double* rowmajor_tmp;   // lazily allocated C doubles for euler_get/set_field of skewed arrays
   PcgScalars* sc;
   PcgScalars* sc_host;    // pinned

@@ -149,6 +149,7 @@ int eu_launch_advect_velocity(euler_sim* S, float dt) {
 __global__ __launch_bounds__(256) void k_build_system(const float* __restrict__ u, const float* __restrict__ v,
                                                       const uint8_t* __restrict__ count, const uint8_t* __restrict__ solid,
                                                       double* __restrict__ b, double* __restrict__ r, double* __restrict__ p,
+                                                      double* __restrict__ q, double* __restrict__ z,
                                                       uint8_t* __restrict__ cellmask, int8_t* __restrict__ fmask,
                                                       PcgScalars* sc, SkewGeom g, float dt, size_t e_lo, size_t e_cnt) {
   const size_t e = e_lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // this rank's bands only
@@ -181,6 +182,8 @@ __global__ __launch_bounds__(256) void k_build_system(const float* __restrict__ 
       b[e] = bv;
       r[e] = bv;
       p[e] = 0.0;
+      q[e] = 0.0;   // the sweeps only visit the records that hold fluid (k_band_ranges): what they skip must be +0
+      z[e] = 0.0;
     }
   }
   if (__any(nz) && (threadIdx.x & 63) == 0) atomicOr(&sc->nonzero, 1);
@@ -227,10 +230,12 @@ __global__ __launch_bounds__(256) void k_velocity_update(const float* __restrict
   }
 }
 
+int eu_launch_band_ranges(euler_sim* S);
+
 int eu_launch_build_system(euler_sim* S, float dt) {
   LAUNCH(S, KC_BUILD_SYSTEM, k_build_system, dim3(eu_blocks(S->e_cnt, 256)), dim3(256), S->utmp, S->vtmp, S->count,
-         S->solid, S->b, S->r, S->p, S->cellmask, S->fmask, S->sc, S->geom, dt, S->e_lo, S->e_cnt);
-  return EULER_OK;
+         S->solid, S->b, S->r, S->p, S->q, S->z, S->cellmask, S->fmask, S->sc, S->geom, dt, S->e_lo, S->e_cnt);
+  return eu_launch_band_ranges(S);
 }
 
 int eu_launch_velocity_update(euler_sim* S, float dt) {

@@ -277,6 +277,7 @@ struct SweepArgs {
   unsigned long long* granules;   // [nbands][gran_stride][2] tagged hand-off of a band's edge row
   int gran_stride;
   int catchup;            // blocks the producer must lead by before a stalled consumer resumes
+  const int4* ranges;     // per band: active block ranges {fwd B0, fwd B1, bwd B0, bwd B1} (k_band_ranges)
   int band_lo, nb_local;  // this rank's bands [band_lo, band_lo + nb_local)
   int couple;             // 1: the first/last local band is coupled to the neighbouring rank's band
   unsigned int* ticket;
@@ -437,9 +438,34 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
   const unsigned long long* gr_in = a.granules + (size_t)(has_prev ? gord - 1 : 0) * a.gran_stride * 2;
   const unsigned long long tag = (unsigned long long)a.epoch << 32;
 
-  // Per-lane stream pointers at (this band, first record, this lane).  They advance by 8 records
-  // per block, so the 8 steps of a block address their records with immediate offsets j*512 B.
-  const size_t e0 = (size_t)band * TS * 64 + (size_t)(BWD ? T - 1 : 0) * 64 + lane;
+  // Active range (forward / backward solves only).  Outside the 16-step-aligned block range
+  // [B0, B1) every cell of the band is non-fluid, so its results are constants that are already in
+  // memory (q, z = +0, zeroed per solve) and the values it would hand on are CONST (z: +0; the
+  // forward carry m = (-1*precon)*(+0) = -0.0).  The band runs only [B0, B1); an empty band returns at
+  // once, and nobody waits for it.  The previous band's range tells which column blocks it
+  // publishes: [pB0 - 8, pB1 - 8); outside that window the consumer substitutes CONST and does
+  // not poll.  The factor sweep always runs the full range (a stale precon is not a constant).
+  constexpr bool RANGED = OP != SW_FACTOR;
+  constexpr double CONST = OP == SW_FORWARD ? -0.0 : 0.0;
+  const int full_blocks = 2 * (((T + SW_BLK - 1) / SW_BLK + 1) / 2);     // whole pairs of blocks
+  const int ncolblk = (X + SW_BLK - 1) / SW_BLK;
+  int B0 = 0, B1 = full_blocks, win_lo = 0, win_hi = ncolblk;
+  if (RANGED && a.ranges) {
+    const int4 mine = a.ranges[band];
+    B0 = BWD ? mine.z : mine.x; B1 = BWD ? mine.w : mine.y;
+    if (B0 >= B1) return;                              // no fluid in this band
+    if (has_prev) {
+      const int4 prv = a.ranges[BWD ? band + 1 : band - 1];
+      const int pB0 = BWD ? prv.z : prv.x, pB1 = BWD ? prv.w : prv.y;
+      win_lo = pB0 - 8 > 0 ? pB0 - 8 : 0;
+      win_hi = pB1 - 8 < ncolblk ? pB1 - 8 : ncolblk;   // empty producer: win_hi <= win_lo
+    }
+  }
+  auto in_window = [&](int blk) { return has_prev && blk >= win_lo && blk < win_hi; };
+
+  // Per-lane stream pointers at (this band, first record of the range, this lane).  They advance by 8
+  // records per block, so the 8 steps of a block address their records with immediate offsets j*512 B.
+  const size_t e0 = (size_t)band * TS * 64 + (size_t)(BWD ? T - 1 - SW_BLK * B0 : SW_BLK * B0) * 64 + lane;
   const double* p_in = (OP == SW_FACTOR ? a.pre : a.in) + e0;      // operands of the block being prefetched
   const double* p_pre = a.pre + e0;
   const uint8_t* p_msk = a.mask + e0;
@@ -480,7 +506,6 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
   // inline-asm load is invisible to hipcc's own counting; an extra outstanding operation only
   // makes hipcc's waits stricter, never looser.
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  const int ncolblk = (X + SW_BLK - 1) / SW_BLK;
   constexpr int VMEM_PER_STEP = OP == SW_FACTOR ? 5 : (OP == SW_FORWARD ? 4 : 6);   // loads + record stores
   constexpr int POLL_VMCNT = 8 * VMEM_PER_STEP - 8;
   auto poll_issue = [&](int blk, u32x4& gv) {
@@ -515,21 +540,21 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
   //              step) AND its upper neighbour (lane+1, next step) subtract (main.c:607-609), so it
   //              is formed once and shifted; the precon of the lower row is never loaded
   //   backward : z (the coefficients belong to the consuming cell, main.c:620-622)
-  double own = 0.0;        // carried value of the previous column of this row
-  double out = 0.0;        // carried value this lane hands to the next lane
-  double bnd = 0.0;        // lanes IN_BASE..+7: previous band's edge values at logical column 8*blk + (lane - IN_BASE)
-  double pub = 0.0;        // lanes OUT_BASE..+7: this band's most recent edge values (newest at the edge lane)
-  if (has_prev) {                          // block 0 synchronously
+  double own = CONST;      // carried value of the previous column of this row
+  double out = CONST;      // carried value this lane hands to the next lane
+  double bnd = CONST;      // lanes IN_BASE..+7: previous band's edge values at logical column 8*blk + (lane - IN_BASE)
+  double pub = CONST;      // lanes OUT_BASE..+7: this band's most recent edge values (newest at the edge lane)
+  if (in_window(B0)) {                     // first block synchronously
     u32x4 gv = {0u, 0u, 0u, 0u};
-    poll_issue(0, gv);
+    poll_issue(B0, gv);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(gv)::"memory");
-    if (!__all(poll_ready(0, gv))) poll_wait(0, gv);
+    if (!__all(poll_ready(B0, gv))) poll_wait(B0, gv);
     bnd = __hiloint2double((int)gv[2], (int)gv[0]);
   }
 
   // one hand-off block = 8 steps: compute from `cur`, refill `nxt` with the block after it
   auto run_block = [&](int blk, Operands& cur, Operands& nxt) {
-    const bool polling = has_prev && blk + 1 < ncolblk;
+    const bool polling = blk + 1 < B1 && in_window(blk + 1);
     u32x4 gnext = {0u, 0u, 0u, 0u};
     if (polling) poll_issue(blk + 1, gnext);
     fetch_block(nxt);
@@ -583,19 +608,20 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
       asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gnext) : "n"(POLL_VMCNT) : "memory");
       if (!__all(poll_ready(blk + 1, gnext))) poll_wait(blk + 1, gnext);
       bnd = __hiloint2double((int)gnext[2], (int)gnext[0]);
+    } else {
+      bnd = CONST;                         // the previous band publishes nothing for block blk+1: all non-fluid there
     }
   };
 
-  const int npairs = ((T + SW_BLK - 1) / SW_BLK + 1) / 2;   // whole pairs of blocks; the surplus runs over dead records
-  for (int pr = 0; pr < npairs; ++pr) {
-    run_block(2 * pr, opA, opB);
-    run_block(2 * pr + 1, opB, opA);
+  for (int blk = B0; blk < B1; blk += 2) {   // B0, B1 are even: whole pairs of blocks; a surplus runs over dead records
+    run_block(blk, opA, opB);
+    run_block(blk + 1, opB, opA);
   }
   // tail: the in-loop trigger fires at j == 6, so up to 8 finished columns of the edge row are still
   // unannounced when the loop ends (all 8 when T is a multiple of 16)
   if (publish) {
     const int k = BWD ? lane : 63 - lane;
-    const int col = SW_BLK * (2 * npairs) - 64 - k;
+    const int col = SW_BLK * B1 - 64 - k;
     if (k >= 0 && k < SW_BLK && col >= 0 && col < X) {
       const unsigned long long bits = (unsigned long long)__double_as_longlong(pub);
       __hip_atomic_store(&gr_out[(size_t)col * 2], tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -615,10 +641,45 @@ static SweepArgs make_sweep_args(euler_sim* S, int op, int force) {
   a.kr = S->kr; a.ku = S->ku;
   a.granules = S->granules; a.gran_stride = S->gran_stride; a.ticket = S->ticket;
   a.catchup = S->sweep_catchup;
+  a.ranges = S->band_ranges;
   a.band_lo = S->band_lo; a.nb_local = S->band_hi - S->band_lo; a.couple = S->has_comm && S->couple;
   a.ticket_base = S->ticket_base; a.epoch = S->epoch;
   a.sc = S->sc; a.force = force; a.error = &S->ms->error;
   return a;
+}
+
+// ---- active ranges of the bands (per solve) ---------------------------------------------------
+// For each 64-row band: the first / last record t = x + lane that holds a fluid cell, turned into
+// 16-step-aligned block ranges of the forward (step = t) and backward (step = T-1-t) sweeps; the
+// upper end leaves at least one all-non-fluid step inside the range (see k_sweep_skew).  Computed
+// from the row-major count grid, which every rank holds in full.
+__global__ __launch_bounds__(256) void k_band_ranges(const uint8_t* __restrict__ count, int X, int Y, int T, int4* __restrict__ ranges) {
+  __shared__ int s_lo, s_hi;
+  const int band = blockIdx.x;
+  if (threadIdx.x == 0) { s_lo = 0x7fffffff; s_hi = -1; }
+  __syncthreads();
+  int lo = 0x7fffffff, hi = -1;
+  for (int l = 0; l < 64; ++l) {
+    const int y = band * 64 + l;
+    if (y >= Y) break;
+    for (int x = threadIdx.x; x < X; x += 256)
+      if (count[(size_t)y * X + x]) { const int t = x + l; lo = t < lo ? t : lo; hi = t > hi ? t : hi; }
+  }
+  if (hi >= 0) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int4 r = make_int4(0, 0, 0, 0);
+    if (s_hi >= 0) {
+      const int f0 = s_lo & ~15, f1 = (s_hi + 2 + 15) & ~15;                       // forward steps [f0, f1)
+      const int b0 = (T - 1 - s_hi) & ~15, b1 = (T - 1 - s_lo + 2 + 15) & ~15;     // backward steps [b0, b1)
+      r = make_int4(f0 / 8, f1 / 8, b0 / 8, b1 / 8);
+    }
+    ranges[band] = r;
+  }
+}
+int eu_launch_band_ranges(euler_sim* S) {
+  LAUNCH(S, KC_BUILD_SYSTEM, k_band_ranges, dim3(S->geom.nbands), dim3(256), S->count, S->X, S->Y, S->geom.T, S->band_ranges);
+  return EULER_OK;
 }
 
 // ---- multi-rank helpers ---------------------------------------------------------------------
