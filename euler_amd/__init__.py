@@ -66,7 +66,7 @@ EXPORTS = [
     "euler_get_field", "euler_set_field", "euler_set_markers", "euler_set_rng", "euler_get_stats",
     "euler_field_bytes", "euler_render", "euler_render_grids", "euler_profile_enable",
     "euler_profile_class_count", "euler_profile_class_name", "euler_profile_get", "euler_profile_reset",
-    "euler_measure_copy_bandwidth", "euler_device_name", "euler_set_comm", "euler_set_stream", "euler_slab_info",
+    "euler_measure_copy_bandwidth", "euler_device_name", "euler_sweep_timeline", "euler_set_comm", "euler_set_stream", "euler_slab_info",
 ]
 
 
@@ -75,11 +75,12 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("EULER_HIP_LIB", LIB_PATH)   # development: an alternative build of the same library
+    if not os.path.exists(path):
         raise ImportError(
             "euler_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C euler_amd/csrc`. There is no CPU fallback." % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, i32, u64, f32, f64 = C.c_void_p, C.c_int32, C.c_uint64, C.c_float, C.c_double
     sig = {
         "euler_config_default": (C.c_int, [C.POINTER(Config)]),
@@ -112,6 +113,7 @@ def load_library():
         "euler_profile_reset": (C.c_int, [vp]),
         "euler_measure_copy_bandwidth": (C.c_int, [vp, C.c_size_t, i32, C.POINTER(f64)]),
         "euler_device_name": (C.c_int, [vp, C.c_char_p, i32]),
+        "euler_sweep_timeline": (C.c_int, [vp, C.POINTER(C.c_uint64), i32]),
         "euler_set_comm": (C.c_int, [vp, vp, i32]),                 # euler_amd/slab.py passes a CommOps struct
         "euler_set_stream": (C.c_int, [vp, vp]),
         "euler_slab_info": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
@@ -290,6 +292,18 @@ class Simulation:
         g = C.c_double(0)
         _check(self.L.euler_measure_copy_bandwidth(self.h, nbytes, reps, C.byref(g)))
         return g.value
+
+    def sweep_timeline(self):
+        """[(entry_us, first_ready_us, exit_us, blocks, stalled_blocks)] per band of the last sweep launch,
+        times relative to the first band's entry."""
+        nb = (self.Y + 63) // 64
+        buf = (C.c_uint64 * (4 * nb))()
+        n = self.L.euler_sweep_timeline(self.h, buf, nb)
+        if n < 0:
+            _check(n)
+        rows = [tuple(buf[4 * i + k] for k in range(4)) for i in range(n)]
+        t0 = min(r[0] for r in rows) if rows else 0
+        return [((r[0] - t0) / 100.0, (r[1] - t0) / 100.0, (r[2] - t0) / 100.0, r[3] >> 32, r[3] & 0xffffffff) for r in rows]
 
     def device_name(self):
         buf = C.create_string_buffer(256)

@@ -137,7 +137,7 @@ extern "C" void euler_destroy(euler_sim* S) {
   if (S->stream) (void)hipStreamSynchronize(S->stream);
   void* dev[] = {S->u, S->v, S->utmp, S->vtmp, S->solid, S->source, S->sink, S->count, S->prev_count, S->count32,
                  S->markers[0], S->markers[1], S->ms, S->evmask, S->ev_theta, S->ev_delta, S->sel_idx, S->act_idx,
-                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->halo_buf, S->band_ranges,
+                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->fbits_fwd, S->fbits_bwd, S->halo_buf, S->band_ranges,
                  S->rowmajor_tmp};
   for (void* p : dev) if (p) (void)hipFree(p);
   for (double* d : {S->b, S->p, S->r, S->z, S->s, S->q, S->precon, S->kr, S->ku}) if (d) (void)hipFree(d - EU_SKEW_SLACK);
@@ -209,6 +209,9 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   for (double** d : {&S->b, &S->p, &S->r, &S->z, &S->s, &S->q, &S->precon, &S->kr, &S->ku}) { DALLOC(*d, SS + EU_SKEW_SLACK); *d += EU_SKEW_SLACK; }
   DALLOC(S->cellmask, SS + EU_SKEW_SLACK); S->cellmask += EU_SKEW_SLACK;
   DALLOC(S->fmask, SS + EU_SKEW_SLACK); S->fmask += EU_SKEW_SLACK;
+  S->fb_stride = 2 * (((S->geom.T + 7) / 8 + 1) / 2) + 2;   // whole pairs of blocks + the block the prefetch runs ahead
+  DALLOC(S->fbits_fwd, (size_t)S->geom.nbands * S->fb_stride * 64);
+  DALLOC(S->fbits_bwd, (size_t)S->geom.nbands * S->fb_stride * 64);
   DALLOC(S->sc, 1);
   DALLOC(S->band_ranges, (size_t)S->geom.nbands);
   S->red_blocks = (int)eu_blocks(SS, 256 * 16, 2048);
@@ -219,6 +222,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   S->gran_stride = (S->X + 7) / 8 * 8;
   DALLOC(S->granules, (size_t)S->geom.nbands * S->gran_stride * 2);
   DALLOC(S->ticket, 1);
+  DALLOC(S->sweep_timeline, (size_t)S->geom.nbands * 4);
   S->ticket_base = 0; S->epoch = 0;
   S->sweep_catchup = 0;
   if (const char* e = getenv("EULER_SWEEP_CATCHUP")) S->sweep_catchup = atoi(e) < 0 ? 0 : atoi(e);
@@ -665,6 +669,14 @@ extern "C" int euler_measure_copy_bandwidth(euler_sim* S, size_t bytes, int32_t 
   if (e != hipSuccess) return eu_hip_fail(e, "copy probe", __FILE__, __LINE__);
   *gbps = 2.0 * (double)bytes * reps / ((double)ms * 1e-3) / 1e9;
   return EULER_OK;
+}
+
+extern "C" int euler_sweep_timeline(euler_sim* S, uint64_t* out, int32_t cap_bands) {
+  if (!S || !out || cap_bands < 0) return EULER_EINVAL;
+  const int n = S->band_hi - S->band_lo < cap_bands ? S->band_hi - S->band_lo : cap_bands;
+  HIPCHK(hipStreamSynchronize(S->stream));
+  HIPCHK(hipMemcpy(out, S->sweep_timeline, (size_t)n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return n;
 }
 
 extern "C" int euler_device_name(euler_sim* S, char* out, int32_t cap) {

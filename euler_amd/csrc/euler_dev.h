@@ -118,6 +118,8 @@ struct euler_sim {
   double *kr, *ku;        // a_i*precon, a_j*precon of the backward solve (per solve)
   uint8_t* cellmask;
   int8_t* fmask;          // skewed: -1 on fluid cells, 0 elsewhere
+  unsigned int* fbits_fwd; unsigned int* fbits_bwd;   // fluid flags of the sweeps, 8 steps to a dword (k_pack_fbits)
+  int fb_stride;          // words per band and lane
   int4* band_ranges;      // per band: active block ranges of the forward / backward sweeps (per solve)
   double* rowmajor_tmp;   // lazily allocated C doubles for euler_get/set_field of skewed arrays
   PcgScalars* sc;
@@ -131,6 +133,7 @@ struct euler_sim {
   unsigned int* ticket;
   unsigned int ticket_base;
   unsigned int epoch;
+  unsigned long long* sweep_timeline;   // [nbands][4], written by every band sweep (euler_sweep_timeline)
   int sweep_catchup;      // tunable (EULER_SWEEP_CATCHUP), see k_sweep_skew
 
   float interp_lim[4];    // nextafterf(extent-1, 0) for U.x, U.y, V.x, V.y (main.c:339-340)

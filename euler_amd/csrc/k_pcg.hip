@@ -25,6 +25,7 @@
 // the reference's row-major order (EULER_DOT_SEQUENTIAL) or reduced in a fixed tree.
 #include "euler_dev.h"
 
+#include <type_traits>
 #include <vector>
 
 #define RED_THREADS 1024
@@ -268,7 +269,9 @@ enum { SW_FACTOR = 0, SW_FORWARD = 1, SW_BACKWARD = 2 };
 struct SweepArgs {
   SkewGeom g;
   const uint8_t* mask;
-  const int8_t* fmask;    // -1 on fluid cells, 0 elsewhere (sign-extended AND mask of the forward solve)
+  const unsigned int* fbits_fwd;   // [nbands][fb_stride][64]: bit j of word (band, g, lane) = fluid flag of the lane's cell in
+  const unsigned int* fbits_bwd;   // step 8g+j of the forward / backward sweep (k_pack_fbits); one dword load per block
+  int fb_stride;
   double* pre;            // precon: in/out for SW_FACTOR, in otherwise
   const double* in;       // r (forward) / q (backward); unused for factor
   double* out;            // q (forward) / z (backward); unused for factor
@@ -286,6 +289,7 @@ struct SweepArgs {
   const PcgScalars* sc;
   int force;
   int* error;
+  unsigned long long* timeline;   // [nbands][4] {entry, first block ready, exit, stalled blocks} (euler_sweep_timeline)
 };
 
 template <int OP>
@@ -351,20 +355,22 @@ __global__ __launch_bounds__(1024) void k_sweep_simple(SweepArgs a) {
 // compile-time constant:
 //   * the operands of block k+1 (3 coalesced 512-B record loads per step, per-lane stream pointers
 //     with immediate offsets j*512) are fetched while block k computes;
-//   * the edge lane's result (lane 63 forward / 0 backward: logical column s-63) is moved with
-//     v_readlane + a lane-select into lane (s-63)&7 of one register pair; when 8 columns are complete,
-//     lanes 0..7 publish them as two 8-byte {epoch, half} granules each (agent-scope relaxed
-//     atomic stores = write-through);
-//   * the next band's edge lane takes its 8 boundary values from lanes 0..7 of a register pair
-//     fetched one block earlier (v_readlane -> the `old` operand of the DPP shift).
+//   * every step's carry row goes to an 8-slot LDS ring; once per block lanes 0..7 gather the edge
+//     lane's (63 forward / 0 backward: logical column s-63) last 8 values from it and publish them
+//     as two 8-byte {epoch, half} granules each (agent-scope relaxed atomic stores = write-through);
+//   * the previous band's 8 boundary values of a block are polled one block ahead (lane & 7 ->
+//     column), parked in LDS and read back as broadcasts: the `old` operand of the DPP shift.
 // Bands take their order from a ticket, so a band only ever waits on a band that is already
-// running: no residency assumption, no deadlock.  No LDS is used.
+// running: no residency assumption, no deadlock.  LDS is only the wave's own lane transposer.
 // One band per workgroup (= per CU) on purpose: a band streams ~16 B/cycle, so 4 waves saturate a
 // CU's ~64 B/clk vector-memory path.  (Measured: 4 / 8 bands per workgroup with an LDS-ring
 // hand-off run 1.4x / 2x SLOWER at 1024^2 and 8192^2 despite the shorter hand-off.)
 // Records t >= T of a band and the 32 records in front of each array are dead padding (mask 0):
 // the loop runs whole pairs of blocks and prefetches unconditionally.
 #define SW_BLK 8
+#ifndef SW_ABLATE
+#define SW_ABLATE 0   // development only (tools/micro/ablate.sh): knock out parts of the step to see what it costs
+#endif
 #define SW_SPIN_LIMIT (1u << 22)
 #define DPP_WAVE_SHL1 0x130
 #define DPP_WAVE_SHR1 0x138
@@ -376,33 +382,6 @@ __device__ __forceinline__ double wave_shift_inject(double v, double edge) {
   const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
-// row-local DPP move of a double (row = 16 lanes); lanes without a source keep `old`
-template <int CTRL>
-__device__ __forceinline__ double dpp_move(double old, double v) {
-  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-#define DPP_ROW_SHL(n) (0x100 + (n))   // lane l <- lane l+n (within its row of 16)
-#define DPP_ROW_SHR(n) (0x110 + (n))   // lane l <- lane l-n
-// hand-off value of step j (0..7) -> the consuming edge lane.  The 8 boundary values of a block sit
-// in lanes IN_BASE..IN_BASE+7 (forward: 0..7, edge lane 0; backward: 56..63, edge lane 63).
-template <bool BWD, int J>
-__device__ __forceinline__ double edge_pick(double bnd) {
-  if (!BWD) { if (J == 0) return bnd; else return dpp_move<DPP_ROW_SHL(J == 0 ? 1 : J)>(0.0, bnd); }
-  else      { if (J == 7) return bnd; else return dpp_move<DPP_ROW_SHR(J == 7 ? 1 : 7 - J)>(0.0, bnd); }
-}
-
-template <bool BWD>
-__device__ __forceinline__ double edge_pick_j(double bnd, int j) {   // j is a constant after unrolling
-  switch (j) {
-    case 0: return edge_pick<BWD, 0>(bnd); case 1: return edge_pick<BWD, 1>(bnd);
-    case 2: return edge_pick<BWD, 2>(bnd); case 3: return edge_pick<BWD, 3>(bnd);
-    case 4: return edge_pick<BWD, 4>(bnd); case 5: return edge_pick<BWD, 5>(bnd);
-    case 6: return edge_pick<BWD, 6>(bnd); default: return edge_pick<BWD, 7>(bnd);
-  }
-}
-
 __device__ __forceinline__ double readlane_f64(double v, int lane_uniform) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane_uniform),
                           __builtin_amdgcn_readlane(__double2loint(v), lane_uniform));
@@ -420,10 +399,10 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
   tk = __builtin_amdgcn_readfirstlane(tk);
   const int ord = (int)(tk - a.ticket_base);          // position in the band pipeline
   if (!a.force && pcg_idle(a.sc)) return;
+  const unsigned long long t_entry = wall_clock64();
+  unsigned int stalls = 0;
   constexpr bool BWD = OP == SW_BACKWARD;
   constexpr int CTRL = BWD ? DPP_WAVE_SHL1 : DPP_WAVE_SHR1;
-
-  constexpr int IN_BASE = BWD ? 56 : 0;               // lanes IN_BASE..+7 hold the 8 incoming boundary values of a block
 
   constexpr int STEP = BWD ? -64 : 64;                // elements per step
   const SkewGeom g = a.g;
@@ -469,7 +448,7 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
   const double* p_in = (OP == SW_FACTOR ? a.pre : a.in) + e0;      // operands of the block being prefetched
   const double* p_pre = a.pre + e0;
   const uint8_t* p_msk = a.mask + e0;
-  const int8_t* p_fm = a.fmask + e0;
+  const unsigned int* p_fb = (BWD ? a.fbits_bwd : a.fbits_fwd) + ((size_t)band * a.fb_stride + B0) * 64 + lane;
   const double* p_kr = a.kr + e0; const double* p_ku = a.ku + e0;      // backward only
   double* p_okr = a.kr + e0; double* p_oku = a.ku + e0;                // factor only
   double* p_out = (OP == SW_FACTOR ? a.pre : a.out) + e0;          // results of the block being computed
@@ -479,50 +458,92 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
   // ahead of the last use of its old value; the overlapping live ranges become ~35 v_mov phi-copies
   // behind s_waitcnt vmcnt(1..4) on the loop back-edge, i.e. the "prefetch" drains every block.
   // A third set = 16 steps of prefetch was measured: no gain at 8192^2, slower at 1024^2.)
-  struct Operands { double in[SW_BLK], pre[SW_BLK], kr[SW_BLK], ku[SW_BLK]; int m[SW_BLK]; };
+  struct Operands { double in[SW_BLK], pre[SW_BLK], kr[SW_BLK], ku[SW_BLK]; int m[SW_BLK]; unsigned int fb; };
   Operands opA, opB;
+  // forward / backward: the record loads are issued BY HAND (inline asm) and retired by counted
+  // s_waitcnt in front of each step.  hipcc's own wait insertion loses track of the issue order at
+  // the control-flow joins of the loop body (publish / poll branches) and then waits for every
+  // operation older than this block's loads - including the result stores issued a few cycles
+  // earlier, i.e. a full store round trip per block (measured: 1.5x per step).  Memory operations
+  // of a wave retire in issue order, and the order here is fixed by construction:
+  //     fetch(k):   fb, then per step j the LOADS_PER_STEP records      (LOADS = 8 * LOADS_PER_STEP + 1)
+  //     compute(k): one result store behind each step
+  //   => before step j of block k everything up to step j's last record is needed, and behind it were
+  //      issued (7 - j) * LOADS_PER_STEP loads of fetch(k), [8 stores of block k-1,] the LOADS of
+  //      fetch(k+1) and j stores: vmcnt((7 - j) * LOADS_PER_STEP + LOADS + j) is exact for the first
+  //      block and never waits for a load of fetch(k+1); the stores of block k-1 get a block of slack.
+  // Anything else in flight (poll loads, granule stores) only makes the wait stricter.
+  constexpr int LOADS_PER_STEP = OP == SW_BACKWARD ? 4 : 2;
+  constexpr int LOADS = SW_BLK * LOADS_PER_STEP + 1;
   auto fetch_block = [&](Operands& o) {
+    if constexpr (OP == SW_FACTOR) {
 #pragma unroll
-    for (int j = 0; j < SW_BLK; ++j) {
-      o.in[j] = OP == SW_FACTOR ? 0.0 : p_in[j * STEP];
-      o.pre[j] = p_pre[j * STEP];
-      // forward / backward: sign-extended fluid flag (0 / -1) so that masking is two v_and;
-      // factor: the full cell-mask byte (a_diag, right / up neighbour bits)
-      o.m[j] = OP == SW_FACTOR ? (int)p_msk[j * STEP] : (int)p_fm[j * STEP];
-      o.kr[j] = OP == SW_BACKWARD ? p_kr[j * STEP] : 0.0;
-      o.ku[j] = OP == SW_BACKWARD ? p_ku[j * STEP] : 0.0;
+      for (int j = 0; j < SW_BLK; ++j) {
+        o.in[j] = 0.0; o.kr[j] = 0.0; o.ku[j] = 0.0;
+        o.pre[j] = p_pre[j * STEP];
+        o.m[j] = (int)p_msk[j * STEP];   // the full cell-mask byte (a_diag, right / up neighbour bits)
+      }
+      o.fb = 0u;
+    } else {
+      // only the fluid flags, 8 steps to a dword - a byte load per step costs as much as the rest of the step
+      asm volatile("global_load_dword %0, %1, off" : "=&v"(o.fb) : "v"(p_fb) : "memory");
+#define SW_LOAD_STEP(J)                                                                                                    \
+      asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=&v"(o.in[J]) : "v"(p_in), "n"((J) * STEP * 8));        \
+      if (OP == SW_BACKWARD) {                                                                                             \
+        asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=&v"(o.kr[J]) : "v"(p_kr), "n"((J) * STEP * 8));      \
+        asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=&v"(o.ku[J]) : "v"(p_ku), "n"((J) * STEP * 8));      \
+      } else { o.kr[J] = 0.0; o.ku[J] = 0.0; }                                                                             \
+      asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=&v"(o.pre[J]) : "v"(p_pre), "n"((J) * STEP * 8));      \
+      o.m[J] = 0;
+      SW_LOAD_STEP(0) SW_LOAD_STEP(1) SW_LOAD_STEP(2) SW_LOAD_STEP(3) SW_LOAD_STEP(4) SW_LOAD_STEP(5) SW_LOAD_STEP(6) SW_LOAD_STEP(7)
+#undef SW_LOAD_STEP
+      asm volatile("" ::: "memory");
     }
-    p_in += SW_BLK * STEP; p_pre += SW_BLK * STEP; p_msk += SW_BLK * STEP; p_fm += SW_BLK * STEP;
+    p_in += SW_BLK * STEP; p_pre += SW_BLK * STEP; p_msk += SW_BLK * STEP; p_fb += 64;
     p_kr += SW_BLK * STEP; p_ku += SW_BLK * STEP;
   };
   fetch_block(opA);
+  if (SW_ABLATE & 2) fetch_block(opB);
 
   // ---- boundary values of the previous band: 8 logical columns per block ----------------------
-  // Lanes 0..7 fetch the granule pair of logical column 8*blk + lane with ONE 16-byte write-through
-  // (sc1) load.  The load for block blk+1 is issued at the start of block blk and retired at its
-  // end by a COUNTED s_waitcnt: at least 8 * VMEM_PER_STEP younger operations were issued behind
-  // it, so vmcnt(POLL_VMCNT) covers it while the newest prefetches stay in flight.  (Left to the
-  // compiler the result is waited for with vmcnt(0), which drains the prefetched block.)  The
-  // inline-asm load is invisible to hipcc's own counting; an extra outstanding operation only
-  // makes hipcc's waits stricter, never looser.
+  // Every lane fetches the granule pair of logical column 8*blk + (lane & 7) with ONE 16-byte
+  // write-through (sc1) load (8 distinct addresses per wave; column 0 on the lane that consumes it).  The load for block blk+1 is issued at
+  // the start of block blk and retired at its end by a COUNTED s_waitcnt: at least 8 * VMEM_PER_STEP
+  // younger operations were issued behind it, so vmcnt(POLL_VMCNT) covers it while the newest
+  // prefetches stay in flight.  (Left to the compiler the result is waited for with vmcnt(0), which
+  // drains the prefetched block.)  The inline-asm load is invisible to hipcc's own counting; an
+  // extra outstanding operation only makes hipcc's waits stricter, never looser.
+  //
+  // LDS as the lane transposer.  The wave is alone on its SIMD, so it is bound by instruction ISSUE
+  // (every instruction costs >= 4-5 cycles whatever its type): moving the 8 boundary values to the
+  // edge lane and collecting the edge lane's 8 results with DPP moves cost 8 instructions per step.
+  // Instead the validated boundary values are written once per block to s_bnd (lane & 7 -> slot) and
+  // read back as 8 broadcast values, which become the `old` operand of the wave shift (the lane
+  // without a source keeps it); every step's carry row is written to s_pub (one ds_write), from
+  // which 8 lanes gather the edge lane's last 8 values once per block.  A wave's LDS operations
+  // execute in order: no barrier.
+  __shared__ double s_bnd[SW_BLK];
+  __shared__ double s_pub[SW_BLK][64];
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  constexpr int VMEM_PER_STEP = OP == SW_FACTOR ? 5 : (OP == SW_FORWARD ? 4 : 6);   // loads + record stores
-  constexpr int POLL_VMCNT = 8 * VMEM_PER_STEP - 8;
+  // behind the poll load of a block come at least its record loads and its 8 result stores (factor: 16 + 32)
+  constexpr int POLL_VMCNT = OP == SW_FACTOR ? 32 : LOADS + SW_BLK;
+  constexpr int EDGE = BWD ? 0 : 63;      // the lane whose results the next band needs
+  const int k8 = BWD ? 7 - (lane & 7) : lane & 7;   // column of a block this lane polls / announces; 0 on the edge-consuming lane
   auto poll_issue = [&](int blk, u32x4& gv) {
-    const int k = lane - IN_BASE, xl = SW_BLK * blk + k;
-    if (k >= 0 && k < SW_BLK && xl < X) {
+    const int xl = SW_BLK * blk + k8;
+    if (xl < X) {
       const unsigned long long* p = &gr_in[(size_t)xl * 2];
       asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(gv) : "v"(p) : "memory");
     }
   };
   auto poll_ready = [&](int blk, const u32x4& gv) {
-    const int k = lane - IN_BASE, xl = SW_BLK * blk + k;
-    const bool want = k >= 0 && k < SW_BLK && xl < X;
-    return !want || (gv[1] == a.epoch && gv[3] == a.epoch);
+    const int xl = SW_BLK * blk + k8;
+    return xl >= X || (gv[1] == a.epoch && gv[3] == a.epoch);
   };
   // slow path: the block is not there yet (catchup > 0: resume only once the producer leads by that
   // many further blocks; measured best at 0 with the counted waits)
   auto poll_wait = [&](int blk, u32x4& gv) {
+    ++stalls;
     const int far = blk + a.catchup < ncolblk ? blk + a.catchup : ncolblk - 1;
     unsigned int spins = 0;
     for (int target = far;;) {
@@ -542,28 +563,66 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
   //   backward : z (the coefficients belong to the consuming cell, main.c:620-622)
   double own = CONST;      // carried value of the previous column of this row
   double out = CONST;      // carried value this lane hands to the next lane
-  double bnd = CONST;      // lanes IN_BASE..+7: previous band's edge values at logical column 8*blk + (lane - IN_BASE)
-  double pub = CONST;      // lanes OUT_BASE..+7: this band's most recent edge values (newest at the edge lane)
+  double bnd0 = CONST;     // lane 0: boundary value of the next block's first column (saves the LDS round trip for step 0)
+  s_pub[SW_BLK - 1][lane] = CONST;
   if (in_window(B0)) {                     // first block synchronously
     u32x4 gv = {0u, 0u, 0u, 0u};
     poll_issue(B0, gv);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(gv)::"memory");
     if (!__all(poll_ready(B0, gv))) poll_wait(B0, gv);
-    bnd = __hiloint2double((int)gv[2], (int)gv[0]);
+    bnd0 = __hiloint2double((int)gv[2], (int)gv[0]);
   }
+  // boundary values of the block about to run: parked in LDS by the lanes that polled them, read back
+  // as broadcasts one block ahead (the LDS round trip hides behind the next block's load issue)
+  double be[SW_BLK];
+  auto spread_boundary = [&]() {
+    s_bnd[k8] = bnd0;
+#pragma unroll
+    for (int j = 1; j < SW_BLK; ++j) be[j] = s_bnd[j];
+    be[0] = bnd0;                          // the lane without a shift source polled column 8*blk + 0 itself
+  };
+  spread_boundary();
+  const unsigned long long t_first = wall_clock64();
+
+  // lanes 0..7 announce logical columns col0 .. col0+7 of the edge row: gather (early) and store (late)
+  auto publish_gather = [&](int col0) {
+    // column c was produced at step c + 63, i.e. in ring slot (c + 63) & 7
+    return s_pub[(col0 + k8 + 63) & 7][EDGE];
+  };
+  auto publish_store = [&](int col0, double v) {
+    const int col = col0 + k8;
+    if (lane < SW_BLK && col >= 0 && col < X) {
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+      __hip_atomic_store(&gr_out[(size_t)col * 2], tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&gr_out[(size_t)col * 2 + 1], tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
 
   // one hand-off block = 8 steps: compute from `cur`, refill `nxt` with the block after it
   auto run_block = [&](int blk, Operands& cur, Operands& nxt) {
-    const bool polling = blk + 1 < B1 && in_window(blk + 1);
+    const bool polling = !(SW_ABLATE & 16) && blk + 1 < B1 && in_window(blk + 1);
     u32x4 gnext = {0u, 0u, 0u, 0u};
     if (polling) poll_issue(blk + 1, gnext);
-    fetch_block(nxt);
-#pragma unroll
-    for (int j = 0; j < SW_BLK; ++j) {
-      // the edge lane consumes logical column s = 8*blk + j of the previous band (lane j of bnd)
-      const double nbv = wave_shift_inject<CTRL>(out, edge_pick_j<BWD>(bnd, j));   // 2 + 2 DPP moves
+    if (!(SW_ABLATE & 2)) fetch_block(nxt);
+    // Pin the software pipeline: all loads of block blk+1 are issued here, ahead of the compute phase
+    // (left alone, hipcc's scheduler sinks them between the steps and waits for them a few
+    // instructions later; measured 1.4-2x slower per step).
+    __builtin_amdgcn_sched_barrier(0);
+    double pv = CONST;
+    auto step = [&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr (OP != SW_FACTOR) {     // retire this step's records (see fetch_block)
+        constexpr int N = (SW_BLK - 1 - j) * LOADS_PER_STEP + LOADS + j;
+        if (OP == SW_BACKWARD)
+          asm volatile("s_waitcnt vmcnt(%5)" : "+v"(cur.in[j]), "+v"(cur.pre[j]), "+v"(cur.kr[j]), "+v"(cur.ku[j]), "+v"(cur.fb) : "n"(N) : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(%3)" : "+v"(cur.in[j]), "+v"(cur.pre[j]), "+v"(cur.fb) : "n"(N) : "memory");
+      }
+      // the edge lane consumes logical column s = 8*blk + j of the previous band
+      const double nbv = (SW_ABLATE & 4) ? be[j] + out : wave_shift_inject<CTRL>(out, be[j]);   // 2 DPP moves
       const double cin = cur.in[j], cpre = cur.pre[j];
-      const int cm = cur.m[j];
+      // sign-extended fluid flag (0 / -1): masking is two v_and
+      const int cm = OP == SW_FACTOR ? cur.m[j] : ((int)(cur.fb << (31 - j)) >> 31);
       double res, carry;
       if (OP == SW_FACTOR) {               // main.c:586-600; own / nbv are precon of the left / lower cell
         const double aa = (double)(cm >> CM_DIAG_SHIFT);
@@ -586,47 +645,38 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
         res = __hiloint2double(__double2hiint(zv) & cm, __double2loint(zv) & cm);   // +0 on non-fluid cells
         carry = res;
       }
-      p_out[j * STEP] = res;
+      if (!(SW_ABLATE & 1)) p_out[j * STEP] = res;
       own = carry;
       out = carry;
-      // logical column s - 63 of the edge row is done: shift the outgoing-values register by one lane
-      // inside its row and drop the new value in at the edge lane (it is the lane without a source
-      // and keeps `old` = carry).  Newest value at the edge lane, the one from k steps ago k lanes away.
-      pub = BWD ? dpp_move<DPP_ROW_SHR(1)>(carry, pub) : dpp_move<DPP_ROW_SHL(1)>(carry, pub);
-      if (j == 6 && publish) {             // columns 8*blk - 64 ... 8*blk - 57 are complete
-        const int k = BWD ? lane : 63 - lane;                     // steps since the value was produced
-        const int col = SW_BLK * blk - 57 - k;
-        if (k >= 0 && k < SW_BLK && col >= 0 && col < X) {
-          const unsigned long long bits = (unsigned long long)__double_as_longlong(pub);
-          __hip_atomic_store(&gr_out[(size_t)col * 2], tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(&gr_out[(size_t)col * 2 + 1], tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-    }
+      if (!(SW_ABLATE & 8)) s_pub[j][lane] = carry;              // the edge lane's entry is gathered by publish_block
+      if (j == 6 && publish) pv = publish_gather(SW_BLK * blk - 64);   // columns 8*blk - 64 ... 8*blk - 57 are complete
+    };
+    step(std::integral_constant<int, 0>()); step(std::integral_constant<int, 1>()); step(std::integral_constant<int, 2>());
+    step(std::integral_constant<int, 3>()); step(std::integral_constant<int, 4>()); step(std::integral_constant<int, 5>());
+    step(std::integral_constant<int, 6>()); step(std::integral_constant<int, 7>());
+    __builtin_amdgcn_sched_barrier(0);
+    if (publish) publish_store(SW_BLK * blk - 64, pv);   // the gather's LDS latency hid behind step 7
     p_out += SW_BLK * STEP; p_okr += SW_BLK * STEP; p_oku += SW_BLK * STEP;
     if (polling) {                         // retire the poll issued 8 steps ago; its values serve block blk+1
       asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gnext) : "n"(POLL_VMCNT) : "memory");
       if (!__all(poll_ready(blk + 1, gnext))) poll_wait(blk + 1, gnext);
-      bnd = __hiloint2double((int)gnext[2], (int)gnext[0]);
+      bnd0 = __hiloint2double((int)gnext[2], (int)gnext[0]);
     } else {
-      bnd = CONST;                         // the previous band publishes nothing for block blk+1: all non-fluid there
+      bnd0 = CONST;                        // the previous band publishes nothing for block blk+1: all non-fluid there
     }
+    spread_boundary();
   };
 
   for (int blk = B0; blk < B1; blk += 2) {   // B0, B1 are even: whole pairs of blocks; a surplus runs over dead records
     run_block(blk, opA, opB);
     run_block(blk + 1, opB, opA);
   }
-  // tail: the in-loop trigger fires at j == 6, so up to 8 finished columns of the edge row are still
-  // unannounced when the loop ends (all 8 when T is a multiple of 16)
-  if (publish) {
-    const int k = BWD ? lane : 63 - lane;
-    const int col = SW_BLK * B1 - 64 - k;
-    if (k >= 0 && k < SW_BLK && col >= 0 && col < X) {
-      const unsigned long long bits = (unsigned long long)__double_as_longlong(pub);
-      __hip_atomic_store(&gr_out[(size_t)col * 2], tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&gr_out[(size_t)col * 2 + 1], tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+  // tail: the in-loop trigger fires at j == 6, so the edge row's column of the last step is still
+  // unannounced when the loop ends
+  if (publish) publish_store(SW_BLK * B1 - 71, publish_gather(SW_BLK * B1 - 71));
+  if (lane == 0) {
+    unsigned long long* tl = a.timeline + (size_t)ord * 4;
+    tl[0] = t_entry; tl[1] = t_first; tl[2] = wall_clock64(); tl[3] = ((unsigned long long)(B1 - B0) << 32) | stalls;
   }
 }
 
@@ -635,7 +685,7 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
 static SweepArgs make_sweep_args(euler_sim* S, int op, int force) {
   SweepArgs a;
   a.g = S->geom;
-  a.mask = S->cellmask; a.fmask = S->fmask; a.pre = S->precon;
+  a.mask = S->cellmask; a.fbits_fwd = S->fbits_fwd; a.fbits_bwd = S->fbits_bwd; a.fb_stride = S->fb_stride; a.pre = S->precon;
   a.in = op == SW_FORWARD ? S->r : S->q;
   a.out = op == SW_FORWARD ? S->q : S->z;
   a.kr = S->kr; a.ku = S->ku;
@@ -645,6 +695,7 @@ static SweepArgs make_sweep_args(euler_sim* S, int op, int force) {
   a.band_lo = S->band_lo; a.nb_local = S->band_hi - S->band_lo; a.couple = S->has_comm && S->couple;
   a.ticket_base = S->ticket_base; a.epoch = S->epoch;
   a.sc = S->sc; a.force = force; a.error = &S->ms->error;
+  a.timeline = S->sweep_timeline;
   return a;
 }
 
@@ -677,8 +728,31 @@ __global__ __launch_bounds__(256) void k_band_ranges(const uint8_t* __restrict__
     ranges[band] = r;
   }
 }
+// fluid flags of the sweeps, 8 steps to a dword: word (band, g, lane) bit j = the lane's cell in step 8g + j
+// of the forward sweep (record 8g + j) / of the backward sweep (record T-1 - 8g - j); 0 outside [0, T)
+__global__ __launch_bounds__(256) void k_pack_fbits(const int8_t* __restrict__ fmask, SkewGeom g, unsigned int* __restrict__ fwd,
+                                                    unsigned int* __restrict__ bwd, int fb_stride, int band_lo, int nb_local) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)nb_local * fb_stride * 64) return;
+  const int lane = (int)(i & 63);
+  const int gi = (int)((i >> 6) % fb_stride), band = band_lo + (int)((i >> 6) / fb_stride);
+  const int8_t* base = fmask + (size_t)band * g.TS * 64 + lane;
+  unsigned int wf = 0, wb = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int tf = 8 * gi + j, tb = g.T - 1 - 8 * gi - j;
+    if (tf < g.T && base[(size_t)tf * 64]) wf |= 1u << j;
+    if (tb >= 0 && base[(size_t)tb * 64]) wb |= 1u << j;
+  }
+  const size_t o = ((size_t)band * fb_stride + gi) * 64 + lane;
+  fwd[o] = wf; bwd[o] = wb;
+}
 int eu_launch_band_ranges(euler_sim* S) {
   LAUNCH(S, KC_BUILD_SYSTEM, k_band_ranges, dim3(S->geom.nbands), dim3(256), S->count, S->X, S->Y, S->geom.T, S->band_ranges);
+  const int nbl = S->band_hi - S->band_lo;
+  const size_t n = (size_t)nbl * S->fb_stride * 64;
+  LAUNCH(S, KC_BUILD_SYSTEM, k_pack_fbits, dim3((unsigned)((n + 255) / 256)), dim3(256), S->fmask, S->geom, S->fbits_fwd, S->fbits_bwd,
+         S->fb_stride, S->band_lo, nbl);
   return EULER_OK;
 }
 

@@ -228,6 +228,11 @@ int euler_profile_reset(euler_sim* sim);
 /* Device-to-device copy bandwidth probe (float4 copy kernel), GB/s read+write. */
 int euler_measure_copy_bandwidth(euler_sim* sim, size_t bytes, int32_t reps, double* gbps);
 int euler_device_name(euler_sim* sim, char* out, int32_t cap);
+/* Diagnostics: the band pipeline of the most recent IC(0) sweep launch.  For each of this rank's bands in
+ * sweep order, 4 words: wave entry, first block's boundary ready, wave exit (100 MHz constant clock
+ * ticks) and (blocks run << 32 | blocks that had to wait for the previous band).  Returns the number of
+ * bands written (<= cap_bands) or a negative error. */
+int euler_sweep_timeline(euler_sim* sim, uint64_t* out, int32_t cap_bands);
 
 #ifdef __cplusplus
 }
