@@ -368,8 +368,8 @@ __global__ __launch_bounds__(1024) void k_sweep_simple(SweepArgs a) {
 // Records t >= T of a band and the 32 records in front of each array are dead padding (mask 0):
 // the loop runs whole pairs of blocks and prefetches unconditionally.
 #define SW_BLK 8
-#ifndef SW_ABLATE
-#define SW_ABLATE 0   // development only (tools/micro/ablate.sh): knock out parts of the step to see what it costs
+#ifndef SW_EXPERIMENT
+#define SW_EXPERIMENT 0   // development only (timing experiments; results are wrong when set)
 #endif
 #define SW_SPIN_LIMIT (1u << 22)
 #define DPP_WAVE_SHL1 0x130
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
   // global band pipeline, which also names the hand-off rows (forwarded rank to rank when coupled)
   const int band = BWD ? a.band_lo + a.nb_local - 1 - ord : a.band_lo + ord;
   const int gord = BWD ? nb - 1 - band : band;
-  const bool has_prev = ord > 0 || (a.couple && gord > 0);            // a band before us in sweep order
+  const bool has_prev = !SW_EXPERIMENT && (ord > 0 || (a.couple && gord > 0));   // a band before us in sweep order
   const bool publish = ord + 1 < a.nb_local || (a.couple && gord + 1 < nb);
   unsigned long long* gr_out = a.granules + (size_t)gord * a.gran_stride * 2;
   const unsigned long long* gr_in = a.granules + (size_t)(has_prev ? gord - 1 : 0) * a.gran_stride * 2;
@@ -502,9 +502,6 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
     p_in += SW_BLK * STEP; p_pre += SW_BLK * STEP; p_msk += SW_BLK * STEP; p_fb += 64;
     p_kr += SW_BLK * STEP; p_ku += SW_BLK * STEP;
   };
-  fetch_block(opA);
-  if (SW_ABLATE & 2) fetch_block(opB);
-
   // ---- boundary values of the previous band: 8 logical columns per block ----------------------
   // Every lane fetches the granule pair of logical column 8*blk + (lane & 7) with ONE 16-byte
   // write-through (sc1) load (8 distinct addresses per wave; column 0 on the lane that consumes it).  The load for block blk+1 is issued at
@@ -529,12 +526,15 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
   constexpr int POLL_VMCNT = OP == SW_FACTOR ? 32 : LOADS + SW_BLK;
   constexpr int EDGE = BWD ? 0 : 63;      // the lane whose results the next band needs
   const int k8 = BWD ? 7 - (lane & 7) : lane & 7;   // column of a block this lane polls / announces; 0 on the edge-consuming lane
+  // Steady state is straight-line code: a lone wave pays ~30 cycles for every taken branch, so the
+  // per-band facts (is there a band before us / after us) select one of four instantiations of the
+  // loop up front, the poll is issued unconditionally (column clamped into the row; the result is
+  // ignored where the previous band publishes nothing) and only the rare "not there yet" path branches.
   auto poll_issue = [&](int blk, u32x4& gv) {
-    const int xl = SW_BLK * blk + k8;
-    if (xl < X) {
-      const unsigned long long* p = &gr_in[(size_t)xl * 2];
-      asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(gv) : "v"(p) : "memory");
-    }
+    int xl = SW_BLK * blk + k8;
+    xl = xl < X ? xl : X - 1;
+    const unsigned long long* p = &gr_in[(size_t)xl * 2];
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(gv) : "v"(p) : "memory");
   };
   auto poll_ready = [&](int blk, const u32x4& gv) {
     const int xl = SW_BLK * blk + k8;
@@ -561,119 +561,140 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
   //              step) AND its upper neighbour (lane+1, next step) subtract (main.c:607-609), so it
   //              is formed once and shifted; the precon of the lower row is never loaded
   //   backward : z (the coefficients belong to the consuming cell, main.c:620-622)
-  double own = CONST;      // carried value of the previous column of this row
-  double out = CONST;      // carried value this lane hands to the next lane
-  double bnd0 = CONST;     // lane 0: boundary value of the next block's first column (saves the LDS round trip for step 0)
-  s_pub[SW_BLK - 1][lane] = CONST;
-  if (in_window(B0)) {                     // first block synchronously
-    u32x4 gv = {0u, 0u, 0u, 0u};
-    poll_issue(B0, gv);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(gv)::"memory");
-    if (!__all(poll_ready(B0, gv))) poll_wait(B0, gv);
-    bnd0 = __hiloint2double((int)gv[2], (int)gv[0]);
-  }
-  // boundary values of the block about to run: parked in LDS by the lanes that polled them, read back
-  // as broadcasts one block ahead (the LDS round trip hides behind the next block's load issue)
-  double be[SW_BLK];
-  auto spread_boundary = [&]() {
-    s_bnd[k8] = bnd0;
-#pragma unroll
-    for (int j = 1; j < SW_BLK; ++j) be[j] = s_bnd[j];
-    be[0] = bnd0;                          // the lane without a shift source polled column 8*blk + 0 itself
-  };
-  spread_boundary();
-  const unsigned long long t_first = wall_clock64();
-
-  // lanes 0..7 announce logical columns col0 .. col0+7 of the edge row: gather (early) and store (late)
-  auto publish_gather = [&](int col0) {
-    // column c was produced at step c + 63, i.e. in ring slot (c + 63) & 7
-    return s_pub[(col0 + k8 + 63) & 7][EDGE];
-  };
-  auto publish_store = [&](int col0, double v) {
-    const int col = col0 + k8;
-    if (lane < SW_BLK && col >= 0 && col < X) {
-      const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-      __hip_atomic_store(&gr_out[(size_t)col * 2], tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&gr_out[(size_t)col * 2 + 1], tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long t_first = 0;
+  auto sweep = [&](auto hp_c, auto pb_c) {
+    constexpr bool HP = decltype(hp_c)::value;    // a band before us in sweep order: boundary values to poll
+    constexpr bool PB = decltype(pb_c)::value;    // a band after us: edge values to publish
+    fetch_block(opA);                             // (per instantiation: an in-flight operand must never be copied)
+    double own = CONST;      // carried value of the previous column of this row
+    double out = CONST;      // carried value this lane hands to the next lane
+    double bnd0 = CONST;     // lane 0: boundary value of the next block's first column (saves the LDS round trip for step 0)
+    s_pub[SW_BLK - 1][lane] = CONST;
+    if (HP && in_window(B0)) {               // first block synchronously
+      u32x4 gv = {0u, 0u, 0u, 0u};
+      poll_issue(B0, gv);
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(gv)::"memory");
+      if (!__all(poll_ready(B0, gv))) poll_wait(B0, gv);
+      bnd0 = __hiloint2double((int)gv[2], (int)gv[0]);
     }
-  };
-
-  // one hand-off block = 8 steps: compute from `cur`, refill `nxt` with the block after it
-  auto run_block = [&](int blk, Operands& cur, Operands& nxt) {
-    const bool polling = !(SW_ABLATE & 16) && blk + 1 < B1 && in_window(blk + 1);
-    u32x4 gnext = {0u, 0u, 0u, 0u};
-    if (polling) poll_issue(blk + 1, gnext);
-    if (!(SW_ABLATE & 2)) fetch_block(nxt);
-    // Pin the software pipeline: all loads of block blk+1 are issued here, ahead of the compute phase
-    // (left alone, hipcc's scheduler sinks them between the steps and waits for them a few
-    // instructions later; measured 1.4-2x slower per step).
-    __builtin_amdgcn_sched_barrier(0);
-    double pv = CONST;
-    auto step = [&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      if constexpr (OP != SW_FACTOR) {     // retire this step's records (see fetch_block)
-        constexpr int N = (SW_BLK - 1 - j) * LOADS_PER_STEP + LOADS + j;
-        if (OP == SW_BACKWARD)
-          asm volatile("s_waitcnt vmcnt(%5)" : "+v"(cur.in[j]), "+v"(cur.pre[j]), "+v"(cur.kr[j]), "+v"(cur.ku[j]), "+v"(cur.fb) : "n"(N) : "memory");
-        else
-          asm volatile("s_waitcnt vmcnt(%3)" : "+v"(cur.in[j]), "+v"(cur.pre[j]), "+v"(cur.fb) : "n"(N) : "memory");
-      }
-      // the edge lane consumes logical column s = 8*blk + j of the previous band
-      const double nbv = (SW_ABLATE & 4) ? be[j] + out : wave_shift_inject<CTRL>(out, be[j]);   // 2 DPP moves
-      const double cin = cur.in[j], cpre = cur.pre[j];
-      // sign-extended fluid flag (0 / -1): masking is two v_and
-      const int cm = OP == SW_FACTOR ? cur.m[j] : ((int)(cur.fb << (31 - j)) >> 31);
-      double res, carry;
-      if (OP == SW_FACTOR) {               // main.c:586-600; own / nbv are precon of the left / lower cell
-        const double aa = (double)(cm >> CM_DIAG_SHIFT);
-        const double cl = -1.0 * own, cb = -1.0 * nbv;
-        double e = aa - cl * cl - cb * cb;
-        if (e < 0.25 * aa) e = (aa != 0.0) ? aa : 1.0;
-        res = (cm & CM_FLUID) ? 1.0 / sqrt(e) : cpre;      // non-fluid: the stale entry stays
-        carry = res;
-        // the backward solve's coefficients of this cell, fixed for the whole solve
-        p_okr[j * STEP] = ((cm & CM_RIGHT) ? -1.0 : 0.0) * res;
-        p_oku[j * STEP] = ((cm & CM_UP) ? -1.0 : 0.0) * res;
-      } else if (OP == SW_FORWARD) {       // main.c:602-613: t = r - (-1*pre_l)*q_l - (-1*pre_b)*q_b
-        const double t = cin - own - nbv;
-        const double qv = t * cpre;
-        res = __hiloint2double(__double2hiint(qv) & cm, __double2loint(qv) & cm);   // +0 on non-fluid cells
-        carry = -1.0 * cpre * res;         // this cell's term in its right and upper neighbours
-      } else {                             // main.c:615-626: t = q - (a_i*pre)*z_r - (a_j*pre)*z_u
-        const double t = cin - cur.kr[j] * own - cur.ku[j] * nbv;
-        const double zv = t * cpre;
-        res = __hiloint2double(__double2hiint(zv) & cm, __double2loint(zv) & cm);   // +0 on non-fluid cells
-        carry = res;
-      }
-      if (!(SW_ABLATE & 1)) p_out[j * STEP] = res;
-      own = carry;
-      out = carry;
-      if (!(SW_ABLATE & 8)) s_pub[j][lane] = carry;              // the edge lane's entry is gathered by publish_block
-      if (j == 6 && publish) pv = publish_gather(SW_BLK * blk - 64);   // columns 8*blk - 64 ... 8*blk - 57 are complete
+    // boundary values of the block about to run: parked in LDS by the lanes that polled them, read back
+    // as broadcasts one block ahead (the LDS round trip hides behind the next block's load issue)
+    double be[SW_BLK];
+    auto spread_boundary = [&]() {
+      s_bnd[k8] = bnd0;
+  #pragma unroll
+      for (int j = 1; j < SW_BLK; ++j) be[j] = s_bnd[j];
+      be[0] = bnd0;                          // the lane without a shift source polled column 8*blk + 0 itself
     };
-    step(std::integral_constant<int, 0>()); step(std::integral_constant<int, 1>()); step(std::integral_constant<int, 2>());
-    step(std::integral_constant<int, 3>()); step(std::integral_constant<int, 4>()); step(std::integral_constant<int, 5>());
-    step(std::integral_constant<int, 6>()); step(std::integral_constant<int, 7>());
-    __builtin_amdgcn_sched_barrier(0);
-    if (publish) publish_store(SW_BLK * blk - 64, pv);   // the gather's LDS latency hid behind step 7
-    p_out += SW_BLK * STEP; p_okr += SW_BLK * STEP; p_oku += SW_BLK * STEP;
-    if (polling) {                         // retire the poll issued 8 steps ago; its values serve block blk+1
-      asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gnext) : "n"(POLL_VMCNT) : "memory");
-      if (!__all(poll_ready(blk + 1, gnext))) poll_wait(blk + 1, gnext);
-      bnd0 = __hiloint2double((int)gnext[2], (int)gnext[0]);
-    } else {
-      bnd0 = CONST;                        // the previous band publishes nothing for block blk+1: all non-fluid there
-    }
     spread_boundary();
-  };
+    t_first = wall_clock64();
 
-  for (int blk = B0; blk < B1; blk += 2) {   // B0, B1 are even: whole pairs of blocks; a surplus runs over dead records
-    run_block(blk, opA, opB);
-    run_block(blk + 1, opB, opA);
-  }
-  // tail: the in-loop trigger fires at j == 6, so the edge row's column of the last step is still
-  // unannounced when the loop ends
-  if (publish) publish_store(SW_BLK * B1 - 71, publish_gather(SW_BLK * B1 - 71));
+    // lanes 0..7 announce logical columns col0 .. col0+7 of the edge row: gather (early) and store (late)
+    auto publish_gather = [&](int col0) {
+      // column c was produced at step c + 63, i.e. in ring slot (c + 63) & 7
+      return s_pub[(col0 + k8 + 63) & 7][EDGE];
+    };
+    auto publish_store = [&](int col0, double v, bool on) {
+      const int col = col0 + k8;
+      if (on && lane < SW_BLK && col >= 0 && col < X) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+        if (SW_EXPERIMENT == 2) { gr_out[(size_t)col * 2] = tag | (bits & 0xffffffffull); gr_out[(size_t)col * 2 + 1] = tag | (bits >> 32); }
+        else if (SW_EXPERIMENT == 3) { }
+        else {
+        __hip_atomic_store(&gr_out[(size_t)col * 2], tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&gr_out[(size_t)col * 2 + 1], tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    };
+
+    double pv = CONST;       // lanes 0..7: the edge values gathered in the previous block, announced in this one
+    // one hand-off block = 8 steps: compute from `cur`, refill `nxt` with the block after it
+    auto run_block = [&](int blk, Operands& cur, Operands& nxt) {
+      // does block blk+1 take its boundary values from the previous band (else: CONST, all non-fluid there)?
+      const bool need = HP && blk + 1 < B1 && in_window(blk + 1);
+      u32x4 gnext = {0u, 0u, 0u, 0u};
+      if (HP) poll_issue(blk + 1, gnext);
+      fetch_block(nxt);
+      // Announce the previous block's edge values only now, BEHIND this block's record loads: memory
+      // operations retire in issue order and a write-through store takes about two block times to be
+      // acknowledged, so every load issued behind it is held up that long.  In this position the
+      // loads it can delay are those of the block after next.
+      if (PB) publish_store(SW_BLK * (blk - 1) - 64, pv, blk > B0);
+      // Pin the software pipeline: all loads of block blk+1 are issued here, ahead of the compute phase
+      // (left alone, hipcc's scheduler sinks them between the steps and waits for them a few
+      // instructions later; measured 1.4-2x slower per step).
+      __builtin_amdgcn_sched_barrier(0);
+      auto step = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (OP != SW_FACTOR) {     // retire this step's records (see fetch_block)
+          constexpr int N = (SW_BLK - 1 - j) * LOADS_PER_STEP + LOADS + j;
+          if (OP == SW_BACKWARD)
+            asm volatile("s_waitcnt vmcnt(%5)" : "+v"(cur.in[j]), "+v"(cur.pre[j]), "+v"(cur.kr[j]), "+v"(cur.ku[j]), "+v"(cur.fb) : "n"(N) : "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(%3)" : "+v"(cur.in[j]), "+v"(cur.pre[j]), "+v"(cur.fb) : "n"(N) : "memory");
+        }
+        // the edge lane consumes logical column s = 8*blk + j of the previous band
+        const double nbv = wave_shift_inject<CTRL>(out, be[j]);   // 2 DPP moves
+        const double cin = cur.in[j], cpre = cur.pre[j];
+        // sign-extended fluid flag (0 / -1): masking is two v_and
+        const int cm = OP == SW_FACTOR ? cur.m[j] : ((int)(cur.fb << (31 - j)) >> 31);
+        double res, carry;
+        if (OP == SW_FACTOR) {               // main.c:586-600; own / nbv are precon of the left / lower cell
+          const double aa = (double)(cm >> CM_DIAG_SHIFT);
+          const double cl = -1.0 * own, cb = -1.0 * nbv;
+          double e = aa - cl * cl - cb * cb;
+          if (e < 0.25 * aa) e = (aa != 0.0) ? aa : 1.0;
+          res = (cm & CM_FLUID) ? 1.0 / sqrt(e) : cpre;      // non-fluid: the stale entry stays
+          carry = res;
+          // the backward solve's coefficients of this cell, fixed for the whole solve
+          p_okr[j * STEP] = ((cm & CM_RIGHT) ? -1.0 : 0.0) * res;
+          p_oku[j * STEP] = ((cm & CM_UP) ? -1.0 : 0.0) * res;
+        } else if (OP == SW_FORWARD) {       // main.c:602-613: t = r - (-1*pre_l)*q_l - (-1*pre_b)*q_b
+          const double t = cin - own - nbv;
+          const double qv = t * cpre;
+          res = __hiloint2double(__double2hiint(qv) & cm, __double2loint(qv) & cm);   // +0 on non-fluid cells
+          carry = -1.0 * cpre * res;         // this cell's term in its right and upper neighbours
+        } else {                             // main.c:615-626: t = q - (a_i*pre)*z_r - (a_j*pre)*z_u
+          const double t = cin - cur.kr[j] * own - cur.ku[j] * nbv;
+          const double zv = t * cpre;
+          res = __hiloint2double(__double2hiint(zv) & cm, __double2loint(zv) & cm);   // +0 on non-fluid cells
+          carry = res;
+        }
+        p_out[j * STEP] = res;
+        own = carry;
+        out = carry;
+        if (PB) s_pub[j][lane] = carry;      // the edge lane's entry is gathered by publish_gather
+        if (j == 6 && PB) pv = publish_gather(SW_BLK * blk - 64);   // columns 8*blk - 64 ... 8*blk - 57 are complete
+      };
+      step(std::integral_constant<int, 0>()); step(std::integral_constant<int, 1>()); step(std::integral_constant<int, 2>());
+      step(std::integral_constant<int, 3>()); step(std::integral_constant<int, 4>()); step(std::integral_constant<int, 5>());
+      step(std::integral_constant<int, 6>()); step(std::integral_constant<int, 7>());
+      __builtin_amdgcn_sched_barrier(0);
+      p_out += SW_BLK * STEP; p_okr += SW_BLK * STEP; p_oku += SW_BLK * STEP;
+      if (HP) {                              // retire the poll issued 8 steps ago; its values serve block blk+1
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gnext) : "n"(POLL_VMCNT) : "memory");
+        if (__builtin_expect(need && !__all(poll_ready(blk + 1, gnext)), 0)) poll_wait(blk + 1, gnext);
+        const double v = __hiloint2double((int)gnext[2], (int)gnext[0]);
+        bnd0 = need ? v : CONST;
+        spread_boundary();
+      }
+    };
+
+    for (int blk = B0; blk < B1; blk += 2) {   // B0, B1 are even: whole pairs of blocks; a surplus runs over dead records
+      run_block(blk, opA, opB);
+      run_block(blk + 1, opB, opA);
+    }
+    // tail: the in-loop trigger fires at j == 6, so the edge row's column of the last step is still
+    // unannounced when the loop ends
+    if (PB) { publish_store(SW_BLK * (B1 - 1) - 64, pv, true); publish_store(SW_BLK * B1 - 71, publish_gather(SW_BLK * B1 - 71), true); }
+    // retire the prefetch that ran past the range before anything else reuses its registers (the kernel
+    // end would wait for it anyway; it also keeps tools/check_sweep_isa.py's path exploration exact)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  typedef std::integral_constant<bool, true> yes_t;
+  typedef std::integral_constant<bool, false> no_t;
+  if (has_prev) { if (publish) sweep(yes_t(), yes_t()); else sweep(yes_t(), no_t()); }
+  else          { if (publish) sweep(no_t(), yes_t()); else sweep(no_t(), no_t()); }
   if (lane == 0) {
     unsigned long long* tl = a.timeline + (size_t)ord * 4;
     tl[0] = t_entry; tl[1] = t_first; tl[2] = wall_clock64(); tl[3] = ((unsigned long long)(B1 - B0) << 32) | stalls;

@@ -7,9 +7,9 @@ set -eu
 cd "$(dirname "$0")/../.."
 OUT=tools/micro/lib_ablate
 mkdir -p $OUT
-for v in ${@:-1 2 3 4 8 16 31}; do
+for v in ${@:-1 2 3}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-function -Iinclude -Ieuler_amd/csrc \
-     -DSW_ABLATE=$v -c euler_amd/csrc/k_pcg.hip -o $OUT/k_pcg_$v.o
+     -DSW_EXPERIMENT=$v -c euler_amd/csrc/k_pcg.hip -o $OUT/k_pcg_$v.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libeuler_hip_$v.so euler_amd/csrc/obj/driver.o euler_amd/csrc/obj/k_grid.o \
      euler_amd/csrc/obj/k_markers.o $OUT/k_pcg_$v.o euler_amd/csrc/obj/euler_host.o
   rm $OUT/k_pcg_$v.o
