@@ -224,8 +224,6 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   DALLOC(S->ticket, 1);
   DALLOC(S->sweep_timeline, (size_t)S->geom.nbands * 4);
   S->ticket_base = 0; S->epoch = 0;
-  S->sweep_catchup = 0;
-  if (const char* e = getenv("EULER_SWEEP_CATCHUP")) S->sweep_catchup = atoi(e) < 0 ? 0 : atoi(e);
   HIPCHK(hipHostMalloc((void**)&S->ms_host, sizeof(MarkerState), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&S->sc_host, sizeof(PcgScalars), hipHostMallocDefault));
   memset(S->ms_host, 0, sizeof(MarkerState)); memset(S->sc_host, 0, sizeof(PcgScalars));

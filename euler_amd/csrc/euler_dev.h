@@ -134,7 +134,6 @@ struct euler_sim {
   unsigned int ticket_base;
   unsigned int epoch;
   unsigned long long* sweep_timeline;   // [nbands][4], written by every band sweep (euler_sweep_timeline)
-  int sweep_catchup;      // tunable (EULER_SWEEP_CATCHUP), see k_sweep_skew
 
   float interp_lim[4];    // nextafterf(extent-1, 0) for U.x, U.y, V.x, V.y (main.c:339-340)
 

@@ -279,7 +279,6 @@ struct SweepArgs {
                           // factor sweep once per solve, streamed by the backward sweep
   unsigned long long* granules;   // [nbands][gran_stride][2] tagged hand-off of a band's edge row
   int gran_stride;
-  int catchup;            // blocks the producer must lead by before a stalled consumer resumes
   const int4* ranges;     // per band: active block ranges {fwd B0, fwd B1, bwd B0, bwd B1} (k_band_ranges)
   int band_lo, nb_local;  // this rank's bands [band_lo, band_lo + nb_local)
   int couple;             // 1: the first/last local band is coupled to the neighbouring rank's band
@@ -347,30 +346,33 @@ __global__ __launch_bounds__(1024) void k_sweep_simple(SweepArgs a) {
   }
 }
 
-// --- production schedule: one wave per 64-row band, streaming the band's records ----------------
-// Lane l owns row 64 b + l.  Forward: records t = 0, 1, ..., lane l is at column t - l, the row
-// below arrives from lane l-1 (DPP wave_shr:1), the previous column is the lane's own register.
-// Backward: records T-1, T-2, ..., the row above arrives from lane l+1 (DPP wave_shl:1).
-// The loop body is 8 steps = one hand-off block, fully unrolled, so every lane index below is a
-// compile-time constant:
-//   * the operands of block k+1 (3 coalesced 512-B record loads per step, per-lane stream pointers
-//     with immediate offsets j*512) are fetched while block k computes;
-//   * every step's carry row goes to an 8-slot LDS ring; once per block lanes 0..7 gather the edge
-//     lane's (63 forward / 0 backward: logical column s-63) last 8 values from it and publish them
-//     as two 8-byte {epoch, half} granules each (agent-scope relaxed atomic stores = write-through);
-//   * the previous band's 8 boundary values of a block are polled one block ahead (lane & 7 ->
-//     column), parked in LDS and read back as broadcasts: the `old` operand of the DPP shift.
+// --- production schedule: one workgroup per 64-row band = a compute wave + two helper waves ---------
+// Compute wave.  Lane l owns row 64 b + l.  Forward: records t = 0, 1, ..., lane l is at column t - l,
+// the row below arrives from lane l-1 (DPP wave_shr:1), the previous column is the lane's own
+// register.  Backward: records T-1, T-2, ..., the row above arrives from lane l+1 (DPP wave_shl:1).
+// The loop body is 8 steps = one hand-off block, fully unrolled; the operands of block k+1 (coalesced
+// 512-B record loads, per-lane stream pointers with immediate offsets j*512, fluid flags 8 steps to a
+// dword) are fetched while block k computes.  A lone wave is bound by instruction ISSUE and by
+// the latency of whatever it waits for, so the compute wave touches global memory only for its
+// streams and everything about the band hand-off lives in the helper wave (own SIMD, own vmcnt):
+//   * every step's carry row goes to an LDS ring (one ds_write); the helper gathers the edge lane's
+//     (63 forward / 0 backward: logical column s-63) values block by block and publishes them to the
+//     next band as 16-byte granule pairs {lo, epoch, hi, epoch} (write-through stores);
+//   * the helper polls the previous band's granules up to 8 blocks ahead with ONE load per round
+//     trip and parks validated boundary values in a second LDS ring; the compute wave reads a
+//     block's 8 values as broadcasts - the `old` operand of the DPP shift, i.e. what the lane
+//     without a shift source receives.
+// The waves talk through three monotonic LDS counters (blocks computed / boundary blocks deposited /
+// groups announced); a wave's LDS operations execute in order, so "data, then counter" needs no fence.
 // Bands take their order from a ticket, so a band only ever waits on a band that is already
-// running: no residency assumption, no deadlock.  LDS is only the wave's own lane transposer.
-// One band per workgroup (= per CU) on purpose: a band streams ~16 B/cycle, so 4 waves saturate a
-// CU's ~64 B/clk vector-memory path.  (Measured: 4 / 8 bands per workgroup with an LDS-ring
-// hand-off run 1.4x / 2x SLOWER at 1024^2 and 8192^2 despite the shorter hand-off.)
+// running: no residency assumption, no deadlock; every spin is bounded (sticky error -> ETIMEOUT).
+// One band per workgroup (= per CU) on purpose: a band streams ~16 B/cycle, so 4 compute waves would
+// saturate a CU's ~64 B/clk vector-memory path (measured 1.4x / 2x slower with 4 / 8 bands per CU).
 // Records t >= T of a band and the 32 records in front of each array are dead padding (mask 0):
 // the loop runs whole pairs of blocks and prefetches unconditionally.
 #define SW_BLK 8
-#ifndef SW_EXPERIMENT
-#define SW_EXPERIMENT 0   // development only (timing experiments; results are wrong when set)
-#endif
+#define SW_RING 64            // carry rows kept in LDS (8 blocks)
+#define SW_BND_RING 16        // boundary blocks kept in LDS
 #define SW_SPIN_LIMIT (1u << 22)
 #define DPP_WAVE_SHL1 0x130
 #define DPP_WAVE_SHR1 0x138
@@ -382,47 +384,53 @@ __device__ __forceinline__ double wave_shift_inject(double v, double edge) {
   const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double readlane_f64(double v, int lane_uniform) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane_uniform),
-                          __builtin_amdgcn_readlane(__double2loint(v), lane_uniform));
-}
-template <typename T>
-__device__ __forceinline__ T ld_off(const T* base, unsigned byte_off) {   // uniform base + 32-bit offset
-  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
-}
+
+struct SweepShared {
+  double pub[SW_RING][64];            // carry rows of the last SW_RING steps (ring slot = step & 63)
+  double bnd[SW_BND_RING][SW_BLK];    // boundary values, ring slot = (block - B0) & 15
+  unsigned int dep_done, pub_done;    // helper -> compute: boundary blocks deposited, groups announced (one 8-byte read)
+  unsigned int comp_done;             // compute -> helper: blocks computed
+  unsigned int abort;
+  int ord;
+};
+__device__ __forceinline__ unsigned int lds_get(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_put(unsigned int* p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#define SW_COMPILER_FENCE() asm volatile("" ::: "memory")
 
 template <int OP>
-__global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
-  const int lane = threadIdx.x;
-  unsigned int tk = 0;
-  if (lane == 0) tk = atomicAdd(a.ticket, 1u);
-  tk = __builtin_amdgcn_readfirstlane(tk);
-  const int ord = (int)(tk - a.ticket_base);          // position in the band pipeline
+__global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
+  __shared__ SweepShared sh;
+  const int lane = threadIdx.x & 63;
+  const int role = threadIdx.x >> 6;                  // 0 compute, 1 announce, 2 fetch boundaries
+  if (threadIdx.x == 0) {
+    sh.ord = (int)(atomicAdd(a.ticket, 1u) - a.ticket_base);        // position in the band pipeline
+    sh.dep_done = 0; sh.pub_done = 0; sh.comp_done = 0; sh.abort = 0;
+  }
+  __syncthreads();
+  const int ord = __builtin_amdgcn_readfirstlane(sh.ord);
   if (!a.force && pcg_idle(a.sc)) return;
   const unsigned long long t_entry = wall_clock64();
-  unsigned int stalls = 0;
   constexpr bool BWD = OP == SW_BACKWARD;
   constexpr int CTRL = BWD ? DPP_WAVE_SHL1 : DPP_WAVE_SHR1;
-
   constexpr int STEP = BWD ? -64 : 64;                // elements per step
+  constexpr int EDGE = BWD ? 0 : 63;                  // the lane whose results the next band needs
   const SkewGeom g = a.g;
   const int X = g.X, T = g.T, TS = g.TS, nb = g.nbands;
   // `ord` counts this launch's (= this rank's) bands in sweep order; gord is the position in the
   // global band pipeline, which also names the hand-off rows (forwarded rank to rank when coupled)
   const int band = BWD ? a.band_lo + a.nb_local - 1 - ord : a.band_lo + ord;
   const int gord = BWD ? nb - 1 - band : band;
-  const bool has_prev = !SW_EXPERIMENT && (ord > 0 || (a.couple && gord > 0));   // a band before us in sweep order
+  const bool has_prev = ord > 0 || (a.couple && gord > 0);            // a band before us in sweep order
   const bool publish = ord + 1 < a.nb_local || (a.couple && gord + 1 < nb);
   unsigned long long* gr_out = a.granules + (size_t)gord * a.gran_stride * 2;
   const unsigned long long* gr_in = a.granules + (size_t)(has_prev ? gord - 1 : 0) * a.gran_stride * 2;
-  const unsigned long long tag = (unsigned long long)a.epoch << 32;
 
   // Active range (forward / backward solves only).  Outside the 16-step-aligned block range
   // [B0, B1) every cell of the band is non-fluid, so its results are constants that are already in
   // memory (q, z = +0, zeroed per solve) and the values it would hand on are CONST (z: +0; the
   // forward carry m = (-1*precon)*(+0) = -0.0).  The band runs only [B0, B1); an empty band returns at
   // once, and nobody waits for it.  The previous band's range tells which column blocks it
-  // publishes: [pB0 - 8, pB1 - 8); outside that window the consumer substitutes CONST and does
+  // announces: [pB0 - 8, pB1 - 8); outside that window the consumer substitutes CONST and does
   // not poll.  The factor sweep always runs the full range (a stale precon is not a constant).
   constexpr bool RANGED = OP != SW_FACTOR;
   constexpr double CONST = OP == SW_FORWARD ? -0.0 : 0.0;
@@ -440,8 +448,103 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
       win_hi = pB1 - 8 < ncolblk ? pB1 - 8 : ncolblk;   // empty producer: win_hi <= win_lo
     }
   }
-  auto in_window = [&](int blk) { return has_prev && blk >= win_lo && blk < win_hi; };
+  const int NBLK = B1 - B0;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+  // =========================== helper waves: the band hand-off ===================================
+  // wave 1 announces this band's edge values to the next band, wave 2 fetches the previous band's
+  if (role == 1) {
+    if (!publish) return;
+    const int t8 = lane >> 3, k8 = lane & 7;            // this lane serves group (next + t8), column k8 of it
+    auto announce = [&](int col, double v, bool on) {
+      if (on && col >= 0 && col < X) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+        const u32x4 gq = {(unsigned int)bits, a.epoch, (unsigned int)(bits >> 32), a.epoch};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(&gr_out[(size_t)col * 2]), "v"(gq) : "memory");
+      }
+    };
+    int next_pub = 0;                                   // groups announced so far (relative to B0)
+    unsigned int spins = 0;
+    while (next_pub < NBLK) {
+      const int cdone = (int)lds_get(&sh.comp_done);
+      SW_COMPILER_FENCE();
+      if (next_pub < cdone) {
+        // the group of block b = logical columns 8(b-8) .. 8(b-8)+7 of the edge row, produced in steps
+        // 8b-1 .. 8b+6, is complete once block b is (up to 8 groups per pass)
+        int n = cdone - next_pub; n = n < 8 ? n : 8;
+        const int b = B0 + next_pub + t8;
+        const double v = sh.pub[(SW_BLK * b - 1 + k8) & (SW_RING - 1)][EDGE];
+        announce(SW_BLK * (b - 8) + k8, v, t8 < n);
+        next_pub += n;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the ring rows are read: the compute wave may reuse them
+        lds_put(&sh.pub_done, (unsigned int)next_pub);
+        spins = 0;
+        continue;
+      }
+      if (lds_get(&sh.abort)) return;
+      if (++spins > (SW_SPIN_LIMIT << 3)) { if (lane == 0) atomicExch(a.error, 2); lds_put(&sh.abort, 1u); return; }
+    }
+    // The edge row's column of the very last step (8*B1 - 1) opens the group of a block that never runs.
+    // The next band reads it only when X + 63 is a multiple of 16 (factor sweep: full range, full window).
+    announce(SW_BLK * (B1 - 8), sh.pub[(SW_BLK * B1 - 1) & (SW_RING - 1)][EDGE], lane == 0);
+    return;
+  }
+  if (role == 2) {
+    if (!has_prev) return;
+    // Four polls are kept in flight (re-issued as they are retired, so they space themselves a quarter
+    // of a round trip apart): a granule is then seen about half a round trip after it lands instead
+    // of one and a half.  Each poll covers up to 8 blocks from the deposit front at its issue; every
+    // lane always loads (clamped address) so that the in-order vmcnt bookkeeping is exact.
+    const int t8 = lane >> 3, k8 = lane & 7;            // this lane serves block (base + t8), column k8 of it
+    int next_dep = 0;                                   // boundary blocks deposited so far (relative to B0)
+    unsigned int spins = 0;
+    struct Poll { u32x4 gv; int base, n; };
+    Poll q0, q1, q2, q3;
+    auto issue = [&](Poll& q) {
+      const int cdone = (int)lds_get(&sh.comp_done);
+      SW_COMPILER_FENCE();
+      int n = cdone + SW_BND_RING - 2 - next_dep;               // ring slots the compute wave is done with
+      n = n < NBLK - next_dep ? n : NBLK - next_dep;
+      q.n = n < 8 ? n : 8; q.base = next_dep;
+      const int blk = B0 + next_dep + t8, xl = SW_BLK * blk + k8;
+      const bool want = t8 < q.n && blk >= win_lo && blk < win_hi && xl < X;
+      const unsigned long long* p = &gr_in[want ? (size_t)xl * 2 : 0];
+      asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(q.gv) : "v"(p) : "memory");
+    };
+    auto retire = [&](Poll& q) {                        // the oldest of the four polls in flight
+      asm volatile("s_waitcnt vmcnt(3)" : "+v"(q.gv) :: "memory");
+      const int blk = B0 + q.base + t8, xl = SW_BLK * blk + k8;
+      const bool mine = t8 < q.n;
+      const bool want = mine && blk >= win_lo && blk < win_hi && xl < X;   // else: nothing is announced there, CONST
+      const bool ready = mine && (!want || (q.gv[1] == a.epoch && q.gv[3] == a.epoch));
+      const unsigned long long notready = ~__ballot(ready);
+      const int m = notready ? (__ffsll((long long)notready) - 1) >> 3 : 8;      // leading blocks whose 8 columns are all there
+      const int fresh0 = next_dep - q.base;                                        // blocks a younger poll's elder already deposited
+      if (m > fresh0) {
+        if (t8 >= fresh0 && t8 < m) sh.bnd[(q.base + t8) & (SW_BND_RING - 1)][k8] = want ? __hiloint2double((int)q.gv[2], (int)q.gv[0]) : CONST;
+        SW_COMPILER_FENCE();
+        next_dep = q.base + m;
+        lds_put(&sh.dep_done, (unsigned int)next_dep);
+        spins = 0;
+      } else {
+        ++spins;
+      }
+    };
+    issue(q0); issue(q1); issue(q2); issue(q3);
+    while (next_dep < NBLK) {
+      retire(q0); issue(q0);
+      retire(q1); issue(q1);
+      retire(q2); issue(q2);
+      retire(q3); issue(q3);
+      if (lds_get(&sh.abort) || spins > SW_SPIN_LIMIT) break;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0.gv), "+v"(q1.gv), "+v"(q2.gv), "+v"(q3.gv) :: "memory");   // before their registers are reused
+    if (spins > SW_SPIN_LIMIT) { if (lane == 0) atomicExch(a.error, 2); lds_put(&sh.abort, 1u); }
+    return;
+  }
+
+  // ====================================== compute wave ========================================
+  unsigned int stalls = 0;
   // Per-lane stream pointers at (this band, first record of the range, this lane).  They advance by 8
   // records per block, so the 8 steps of a block address their records with immediate offsets j*512 B.
   const size_t e0 = (size_t)band * TS * 64 + (size_t)(BWD ? T - 1 - SW_BLK * B0 : SW_BLK * B0) * 64 + lane;
@@ -454,25 +557,21 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
   double* p_out = (OP == SW_FACTOR ? a.pre : a.out) + e0;          // results of the block being computed
 
   // Two operand sets, ping-ponged block by block: while block k computes from one set, the records
-  // of block k+1 are fetched into the other.  (With a single ring hipcc schedules a slot's refill
-  // ahead of the last use of its old value; the overlapping live ranges become ~35 v_mov phi-copies
-  // behind s_waitcnt vmcnt(1..4) on the loop back-edge, i.e. the "prefetch" drains every block.
-  // A third set = 16 steps of prefetch was measured: no gain at 8192^2, slower at 1024^2.)
+  // of block k+1 are fetched into the other.
   struct Operands { double in[SW_BLK], pre[SW_BLK], kr[SW_BLK], ku[SW_BLK]; int m[SW_BLK]; unsigned int fb; };
   Operands opA, opB;
   // forward / backward: the record loads are issued BY HAND (inline asm) and retired by counted
   // s_waitcnt in front of each step.  hipcc's own wait insertion loses track of the issue order at
-  // the control-flow joins of the loop body (publish / poll branches) and then waits for every
-  // operation older than this block's loads - including the result stores issued a few cycles
-  // earlier, i.e. a full store round trip per block (measured: 1.5x per step).  Memory operations
-  // of a wave retire in issue order, and the order here is fixed by construction:
+  // control-flow joins and then waits for every operation older than this block's loads -
+  // including the result stores issued a few cycles earlier, i.e. a store round trip per block.
+  // Memory operations of a wave retire in issue order, and the order here is fixed by construction:
   //     fetch(k):   fb, then per step j the LOADS_PER_STEP records      (LOADS = 8 * LOADS_PER_STEP + 1)
   //     compute(k): one result store behind each step
   //   => before step j of block k everything up to step j's last record is needed, and behind it were
   //      issued (7 - j) * LOADS_PER_STEP loads of fetch(k), [8 stores of block k-1,] the LOADS of
   //      fetch(k+1) and j stores: vmcnt((7 - j) * LOADS_PER_STEP + LOADS + j) is exact for the first
   //      block and never waits for a load of fetch(k+1); the stores of block k-1 get a block of slack.
-  // Anything else in flight (poll loads, granule stores) only makes the wait stricter.
+  // tools/check_sweep_isa.py proves on the generated ISA that no in-flight operand is ever touched.
   constexpr int LOADS_PER_STEP = OP == SW_BACKWARD ? 4 : 2;
   constexpr int LOADS = SW_BLK * LOADS_PER_STEP + 1;
   auto fetch_block = [&](Operands& o) {
@@ -502,128 +601,58 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
     p_in += SW_BLK * STEP; p_pre += SW_BLK * STEP; p_msk += SW_BLK * STEP; p_fb += 64;
     p_kr += SW_BLK * STEP; p_ku += SW_BLK * STEP;
   };
-  // ---- boundary values of the previous band: 8 logical columns per block ----------------------
-  // Every lane fetches the granule pair of logical column 8*blk + (lane & 7) with ONE 16-byte
-  // write-through (sc1) load (8 distinct addresses per wave; column 0 on the lane that consumes it).  The load for block blk+1 is issued at
-  // the start of block blk and retired at its end by a COUNTED s_waitcnt: at least 8 * VMEM_PER_STEP
-  // younger operations were issued behind it, so vmcnt(POLL_VMCNT) covers it while the newest
-  // prefetches stay in flight.  (Left to the compiler the result is waited for with vmcnt(0), which
-  // drains the prefetched block.)  The inline-asm load is invisible to hipcc's own counting; an
-  // extra outstanding operation only makes hipcc's waits stricter, never looser.
-  //
-  // LDS as the lane transposer.  The wave is alone on its SIMD, so it is bound by instruction ISSUE
-  // (every instruction costs >= 4-5 cycles whatever its type): moving the 8 boundary values to the
-  // edge lane and collecting the edge lane's 8 results with DPP moves cost 8 instructions per step.
-  // Instead the validated boundary values are written once per block to s_bnd (lane & 7 -> slot) and
-  // read back as 8 broadcast values, which become the `old` operand of the wave shift (the lane
-  // without a source keeps it); every step's carry row is written to s_pub (one ds_write), from
-  // which 8 lanes gather the edge lane's last 8 values once per block.  A wave's LDS operations
-  // execute in order: no barrier.
-  __shared__ double s_bnd[SW_BLK];
-  __shared__ double s_pub[SW_BLK][64];
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  // behind the poll load of a block come at least its record loads and its 8 result stores (factor: 16 + 32)
-  constexpr int POLL_VMCNT = OP == SW_FACTOR ? 32 : LOADS + SW_BLK;
-  constexpr int EDGE = BWD ? 0 : 63;      // the lane whose results the next band needs
-  const int k8 = BWD ? 7 - (lane & 7) : lane & 7;   // column of a block this lane polls / announces; 0 on the edge-consuming lane
-  // Steady state is straight-line code: a lone wave pays ~30 cycles for every taken branch, so the
-  // per-band facts (is there a band before us / after us) select one of four instantiations of the
-  // loop up front, the poll is issued unconditionally (column clamped into the row; the result is
-  // ignored where the previous band publishes nothing) and only the rare "not there yet" path branches.
-  auto poll_issue = [&](int blk, u32x4& gv) {
-    int xl = SW_BLK * blk + k8;
-    xl = xl < X ? xl : X - 1;
-    const unsigned long long* p = &gr_in[(size_t)xl * 2];
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(gv) : "v"(p) : "memory");
-  };
-  auto poll_ready = [&](int blk, const u32x4& gv) {
-    const int xl = SW_BLK * blk + k8;
-    return xl >= X || (gv[1] == a.epoch && gv[3] == a.epoch);
-  };
-  // slow path: the block is not there yet (catchup > 0: resume only once the producer leads by that
-  // many further blocks; measured best at 0 with the counted waits)
-  auto poll_wait = [&](int blk, u32x4& gv) {
+
+  // wait (rarely) until the helper's counter reaches `target`
+  auto await = [&](const unsigned int* cnt, int target) {
     ++stalls;
-    const int far = blk + a.catchup < ncolblk ? blk + a.catchup : ncolblk - 1;
-    unsigned int spins = 0;
-    for (int target = far;;) {
-      poll_issue(target, gv);
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(gv)::"memory");
-      if (__all(poll_ready(target, gv))) { if (target == blk) break; target = blk; continue; }
-      if (++spins > SW_SPIN_LIMIT) { if (lane == 0) atomicExch(a.error, 2); break; }
-      __builtin_amdgcn_s_sleep(8);
+    for (unsigned int spins = 0; (int)lds_get(cnt) < target;) {
+      if (lds_get(&sh.abort)) break;
+      if (++spins > SW_SPIN_LIMIT) { if (lane == 0) atomicExch(a.error, 2); lds_put(&sh.abort, 1u); break; }
+      __builtin_amdgcn_s_sleep(1);
     }
+    SW_COMPILER_FENCE();
   };
 
-  // Loop-carried state.  What travels between cells is, per operation:
-  //   factor   : precon itself (left neighbour = own register, lower neighbour = lane-1)
-  //   forward  : m = (-1*precon)*q of a cell - exactly the term its right neighbour (same lane, next
-  //              step) AND its upper neighbour (lane+1, next step) subtract (main.c:607-609), so it
-  //              is formed once and shifted; the precon of the lower row is never loaded
-  //   backward : z (the coefficients belong to the consuming cell, main.c:620-622)
+  // Steady state is straight-line code: a lone wave pays ~30 cycles for every taken branch, so the
+  // per-band facts (is there a band before us / after us) select one of four instantiations of the loop.
   unsigned long long t_first = 0;
   auto sweep = [&](auto hp_c, auto pb_c) {
-    constexpr bool HP = decltype(hp_c)::value;    // a band before us in sweep order: boundary values to poll
-    constexpr bool PB = decltype(pb_c)::value;    // a band after us: edge values to publish
+    constexpr bool HP = decltype(hp_c)::value;    // a band before us in sweep order: boundary values from the helper
+    constexpr bool PB = decltype(pb_c)::value;    // a band after us: carry rows for the helper
     fetch_block(opA);                             // (per instantiation: an in-flight operand must never be copied)
+    // Loop-carried state.  What travels between cells is, per operation:
+    //   factor   : precon itself (left neighbour = own register, lower neighbour = lane-1)
+    //   forward  : m = (-1*precon)*q of a cell - exactly the term its right neighbour (same lane, next
+    //              step) AND its upper neighbour (lane+1, next step) subtract (main.c:607-609), so it
+    //              is formed once and shifted; the precon of the lower row is never loaded
+    //   backward : z (the coefficients belong to the consuming cell, main.c:620-622)
     double own = CONST;      // carried value of the previous column of this row
     double out = CONST;      // carried value this lane hands to the next lane
-    double bnd0 = CONST;     // lane 0: boundary value of the next block's first column (saves the LDS round trip for step 0)
-    s_pub[SW_BLK - 1][lane] = CONST;
-    if (HP && in_window(B0)) {               // first block synchronously
-      u32x4 gv = {0u, 0u, 0u, 0u};
-      poll_issue(B0, gv);
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(gv)::"memory");
-      if (!__all(poll_ready(B0, gv))) poll_wait(B0, gv);
-      bnd0 = __hiloint2double((int)gv[2], (int)gv[0]);
-    }
-    // boundary values of the block about to run: parked in LDS by the lanes that polled them, read back
-    // as broadcasts one block ahead (the LDS round trip hides behind the next block's load issue)
-    double be[SW_BLK];
-    auto spread_boundary = [&]() {
-      s_bnd[k8] = bnd0;
-  #pragma unroll
-      for (int j = 1; j < SW_BLK; ++j) be[j] = s_bnd[j];
-      be[0] = bnd0;                          // the lane without a shift source polled column 8*blk + 0 itself
+    // boundary values of the block about to run / of the one after it (what the lane without a shift source
+    // receives); two sets like the operands, so that the next block's are read half a block ahead
+    double beA[SW_BLK], beB[SW_BLK];
+    auto read_boundary = [&](int rel, double (&be)[SW_BLK]) {
+      const double* slot = sh.bnd[rel & (SW_BND_RING - 1)];
+#pragma unroll
+      for (int j = 0; j < SW_BLK; ++j) be[j] = HP ? slot[j] : CONST;
     };
-    spread_boundary();
+    if (PB) sh.pub[(SW_BLK * B0 - 1) & (SW_RING - 1)][lane] = CONST;   // "step B0*8 - 1": the band was all non-fluid before its range
+    if (HP) await(&sh.dep_done, 1);
+    read_boundary(0, beA);
     t_first = wall_clock64();
 
-    // lanes 0..7 announce logical columns col0 .. col0+7 of the edge row: gather (early) and store (late)
-    auto publish_gather = [&](int col0) {
-      // column c was produced at step c + 63, i.e. in ring slot (c + 63) & 7
-      return s_pub[(col0 + k8 + 63) & 7][EDGE];
-    };
-    auto publish_store = [&](int col0, double v, bool on) {
-      const int col = col0 + k8;
-      if (on && lane < SW_BLK && col >= 0 && col < X) {
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-        if (SW_EXPERIMENT == 2) { gr_out[(size_t)col * 2] = tag | (bits & 0xffffffffull); gr_out[(size_t)col * 2 + 1] = tag | (bits >> 32); }
-        else if (SW_EXPERIMENT == 3) { }
-        else {
-        __hip_atomic_store(&gr_out[(size_t)col * 2], tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&gr_out[(size_t)col * 2 + 1], tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-    };
-
-    double pv = CONST;       // lanes 0..7: the edge values gathered in the previous block, announced in this one
     // one hand-off block = 8 steps: compute from `cur`, refill `nxt` with the block after it
-    auto run_block = [&](int blk, Operands& cur, Operands& nxt) {
-      // does block blk+1 take its boundary values from the previous band (else: CONST, all non-fluid there)?
-      const bool need = HP && blk + 1 < B1 && in_window(blk + 1);
-      u32x4 gnext = {0u, 0u, 0u, 0u};
-      if (HP) poll_issue(blk + 1, gnext);
+    auto run_block = [&](int blk, Operands& cur, Operands& nxt, double (&be)[SW_BLK], double (&be_next)[SW_BLK]) {
+      const int rel = blk - B0;
       fetch_block(nxt);
-      // Announce the previous block's edge values only now, BEHIND this block's record loads: memory
-      // operations retire in issue order and a write-through store takes about two block times to be
-      // acknowledged, so every load issued behind it is held up that long.  In this position the
-      // loads it can delay are those of the block after next.
-      if (PB) publish_store(SW_BLK * (blk - 1) - 64, pv, blk > B0);
+      // the helpers' progress, read well ahead of its use: boundary blocks deposited, groups announced
+      unsigned long long prog = 0;
+      if (HP || PB) prog = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&sh.dep_done), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       // Pin the software pipeline: all loads of block blk+1 are issued here, ahead of the compute phase
       // (left alone, hipcc's scheduler sinks them between the steps and waits for them a few
       // instructions later; measured 1.4-2x slower per step).
       __builtin_amdgcn_sched_barrier(0);
+      double* ring = &sh.pub[(SW_BLK * blk) & (SW_RING - 1)][lane];
       auto step = [&](auto jc) {
         constexpr int j = decltype(jc)::value;
         if constexpr (OP != SW_FACTOR) {     // retire this step's records (see fetch_block)
@@ -663,30 +692,29 @@ __global__ __launch_bounds__(64) void k_sweep_skew(SweepArgs a) {
         p_out[j * STEP] = res;
         own = carry;
         out = carry;
-        if (PB) s_pub[j][lane] = carry;      // the edge lane's entry is gathered by publish_gather
-        if (j == 6 && PB) pv = publish_gather(SW_BLK * blk - 64);   // columns 8*blk - 64 ... 8*blk - 57 are complete
+        if (PB) ring[j * 64] = carry;        // the helper gathers the edge lane's entry
       };
       step(std::integral_constant<int, 0>()); step(std::integral_constant<int, 1>()); step(std::integral_constant<int, 2>());
-      step(std::integral_constant<int, 3>()); step(std::integral_constant<int, 4>()); step(std::integral_constant<int, 5>());
+      step(std::integral_constant<int, 3>());
+      if (HP) {
+        // half-way: the next block's boundary values (deposited once dep_done > rel+1; past the range: whatever is there)
+        if (__builtin_expect(rel + 1 < NBLK && (int)(unsigned int)prog < rel + 2, 0)) await(&sh.dep_done, rel + 2);
+        read_boundary(rel + 1, be_next);
+      }
+      step(std::integral_constant<int, 4>()); step(std::integral_constant<int, 5>());
       step(std::integral_constant<int, 6>()); step(std::integral_constant<int, 7>());
       __builtin_amdgcn_sched_barrier(0);
       p_out += SW_BLK * STEP; p_okr += SW_BLK * STEP; p_oku += SW_BLK * STEP;
-      if (HP) {                              // retire the poll issued 8 steps ago; its values serve block blk+1
-        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gnext) : "n"(POLL_VMCNT) : "memory");
-        if (__builtin_expect(need && !__all(poll_ready(blk + 1, gnext)), 0)) poll_wait(blk + 1, gnext);
-        const double v = __hiloint2double((int)gnext[2], (int)gnext[0]);
-        bnd0 = need ? v : CONST;
-        spread_boundary();
-      }
+      if (HP || PB) { SW_COMPILER_FENCE(); lds_put(&sh.comp_done, (unsigned int)(rel + 1)); }
+      // block blk+1 overwrites the ring rows of block blk-7, which the groups up to block blk-6 read
+      // (announced once pub_done >= rel-5)
+      if (PB && __builtin_expect(rel + 1 < NBLK && (int)(unsigned int)(prog >> 32) < rel - 5, 0)) await(&sh.pub_done, rel - 5);
     };
 
     for (int blk = B0; blk < B1; blk += 2) {   // B0, B1 are even: whole pairs of blocks; a surplus runs over dead records
-      run_block(blk, opA, opB);
-      run_block(blk + 1, opB, opA);
+      run_block(blk, opA, opB, beA, beB);
+      run_block(blk + 1, opB, opA, beB, beA);
     }
-    // tail: the in-loop trigger fires at j == 6, so the edge row's column of the last step is still
-    // unannounced when the loop ends
-    if (PB) { publish_store(SW_BLK * (B1 - 1) - 64, pv, true); publish_store(SW_BLK * B1 - 71, publish_gather(SW_BLK * B1 - 71), true); }
     // retire the prefetch that ran past the range before anything else reuses its registers (the kernel
     // end would wait for it anyway; it also keeps tools/check_sweep_isa.py's path exploration exact)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -711,7 +739,6 @@ static SweepArgs make_sweep_args(euler_sim* S, int op, int force) {
   a.out = op == SW_FORWARD ? S->q : S->z;
   a.kr = S->kr; a.ku = S->ku;
   a.granules = S->granules; a.gran_stride = S->gran_stride; a.ticket = S->ticket;
-  a.catchup = S->sweep_catchup;
   a.ranges = S->band_ranges;
   a.band_lo = S->band_lo; a.nb_local = S->band_hi - S->band_lo; a.couple = S->has_comm && S->couple;
   a.ticket_base = S->ticket_base; a.epoch = S->epoch;
@@ -837,7 +864,7 @@ static int launch_sweep(euler_sim* S, int cls, int force) {
     if (chain && g_first > 0)   // the edge row of the band before mine arrives from the previous slab
       COMM_CALL(S->comm.chain(S->comm.ctx, S->granules + (size_t)(g_first - 1) * S->gran_stride * 2, row_bytes, prev_rank, r));
     SweepArgs a = make_sweep_args(S, OP, force);
-    LAUNCH(S, cls, k_sweep_skew<OP>, dim3(nbl), dim3(64), a);
+    LAUNCH(S, cls, k_sweep_skew<OP>, dim3(nbl), dim3(192), a);
     S->ticket_base += (unsigned)nbl;
     if (chain && g_last + 1 < nb)
       COMM_CALL(S->comm.chain(S->comm.ctx, S->granules + (size_t)g_last * S->gran_stride * 2, row_bytes, r, next_rank));
