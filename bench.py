@@ -110,6 +110,22 @@ def cpu_baseline(sim, ea, steps_budget_s=12.0):
     return res
 
 
+PMC_KERNEL = {"forward_solve": "k_sweep_skew<1>", "backward_solve": "k_sweep_skew<2>", "precon_factor": "k_sweep_skew<0>",
+              "apply_a": "k_apply_a", "dot": "k_dot_partial", "update_pr": "k_update_pr", "update_search": "k_update_search<false>"}
+
+
+def pmc_traffic(size, workload, kernel_class):
+    """HBM bytes per launch of a kernel class from the committed PMC passes of the same workload
+    (profiles/pmc_traffic_<size>_<workload>.json, written by tools/summarize_profile.py from
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this very command); None if there is none."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic_%d_%s.json" % (size, workload))
+    try:
+        k = json.load(open(p))["kernels"].get(PMC_KERNEL.get(kernel_class, ""))
+        return int(k["hbm_bytes_per_launch"]) if k else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -221,7 +237,8 @@ def main():
         ms, launches = prof[dominant]
         achieved = ALGO_BYTES[dominant] * cells_launch / (ms / launches * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                "traffic": pmc_traffic(N, args.workload, dominant) if world == 1 else None,
                 "algorithmic_bytes_per_launch": ALGO_BYTES[dominant] * cells_launch,
                 "avg_launch_us": round(1e3 * ms / launches, 2), "launches": int(launches)}
     pcg_ms = sum(prof[k][0] for k in ALGO_BYTES if k in prof) + sum(prof[k][0] for k in ("reduce_final",) if k in prof)

@@ -65,6 +65,11 @@ if fetch and write:
         print("| %s | %d | %.0f | %.2f | %.0f | %.2f | %.2f |" % (k, f[k][0], fr, 2 * fr * 1024 / 1e6, wr, wr * 1024 / 1e6,
                                                               (2 * fr + wr) * 1024 / 1e6))
     print("\n(averages include idle early-exit launches, which move no data; active-launch traffic is slightly higher)")
+    # machine-readable copy for bench.py's roofline.traffic (bytes per launch, corrected as above)
+    traffic = {k: {"launches": f[k][0], "hbm_bytes_per_launch": round((2 * f[k][1] + w.get(k, (0, 0.0))[1]) * 1024)} for k in f}
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 on gfx950, KiB -> bytes",
+               "workload": os.path.basename(out.rstrip("/")).replace("prof_", ""), "kernels": traffic},
+              open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 
 for name in ("bench_trace.json", "bench_events.json"):
     p = os.path.join(out, name)
