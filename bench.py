@@ -199,12 +199,14 @@ def main():
         sim.step()
 
     dominant = "backward_solve" if precond == ea.PRECOND_IC0 else "update_pr"
-    timed_classes = list(ALGO_BYTES) if not args.no_kernel_timing else []
-    if args.profile_all:
-        timed_classes = ea.profile_class_names()
+    # Inside the timed region only the DOMINANT kernel is bracketed by HIP events (on the kernel's own
+    # stream): an event pair around every launch of all six PCG kernels costs ~20 % throughput at
+    # 1024^2 (measured), around the dominant one alone ~2 %.  The other classes are timed in a second,
+    # untimed pass of the same number of steps right after it (same phase: every substep runs the
+    # full iteration budget).
+    timed_classes = [dominant] if not args.no_kernel_timing else []
     sim.profile_reset()
-    if timed_classes:
-        sim.profile_enable(timed_classes)
+    sim.profile_enable(timed_classes)
     st0 = sim.stats()
 
     # timed region: barrier + device sync on both sides, MAX over ranks (euler_amd/dist.py)
@@ -213,6 +215,17 @@ def main():
     st1 = sim.stats()
     prof = sim.profile() if timed_classes else {}
     sim.profile_enable([])
+    iters_pass2 = 0
+    if not args.no_kernel_timing:
+        sim.profile_reset()
+        sim.profile_enable(ea.profile_class_names() if args.profile_all else [k for k in ALGO_BYTES if k != dominant])
+        for _ in range(args.steps):
+            sim.step()
+        iters_pass2 = sim.stats().total_pcg_iterations - st1.total_pcg_iterations
+        prof2 = sim.profile()
+        sim.profile_enable([])
+        for k, v in prof2.items():
+            prof.setdefault(k, v)
     substeps = st1.total_substeps - st0.total_substeps
     iters = st1.total_pcg_iterations - st0.total_pcg_iterations
     cells = GX * GY
@@ -241,8 +254,11 @@ def main():
                 "traffic": pmc_traffic(N, args.workload, dominant) if world == 1 else None,
                 "algorithmic_bytes_per_launch": ALGO_BYTES[dominant] * cells_launch,
                 "avg_launch_us": round(1e3 * ms / launches, 2), "launches": int(launches)}
-    pcg_ms = sum(prof[k][0] for k in ALGO_BYTES if k in prof) + sum(prof[k][0] for k in ("reduce_final",) if k in prof)
-    pcg_gbps = PCG_BYTES_PER_CELL_ITER * cells * iters / (pcg_ms * 1e-3) / 1e9 if pcg_ms and iters else None
+    # whole PCG iteration: per-launch averages summed over the six kernel classes (dominant: timed region;
+    # the others: second pass), against the 149 B per cell and iteration BASELINE.md prescribes
+    per_iter_ms = sum(prof[k][0] / prof[k][1] for k in ALGO_BYTES if k in prof and prof[k][1])
+    pcg_ms = per_iter_ms * iters
+    pcg_gbps = PCG_BYTES_PER_CELL_ITER * cells / (per_iter_ms * 1e-3) / 1e9 if per_iter_ms and len([k for k in ALGO_BYTES if k in prof]) == len(ALGO_BYTES) else None
 
     cpu_obj = None
     if cpu:
@@ -277,7 +293,8 @@ def main():
         "markers": int(st1.n_markers), "fluid_cells": int(st1.fluid_cells),
         "roofline": roof,
         "pcg_aggregate": {"algorithmic_GBps": round(pcg_gbps, 1) if pcg_gbps else None,
-                          "bytes_per_cell_iteration": PCG_BYTES_PER_CELL_ITER, "kernel_ms": round(pcg_ms, 2)},
+                          "bytes_per_cell_iteration": PCG_BYTES_PER_CELL_ITER, "kernel_us_per_iteration": round(1e3 * per_iter_ms, 2),
+                          "note": "dominant kernel timed inside the timed region, the other five in a second pass of the same length"},
         "kernels": kern,
         "cpu_baseline": cpu_obj,
         "parity_in_run": parity,

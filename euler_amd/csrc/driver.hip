@@ -145,6 +145,8 @@ extern "C" void euler_destroy(euler_sim* S) {
   if (S->fmask) (void)hipFree(S->fmask - EU_SKEW_SLACK);
   if (S->ms_host) (void)hipHostFree(S->ms_host);
   if (S->sc_host) (void)hipHostFree(S->sc_host);
+  if (S->poll_host) (void)hipHostFree(S->poll_host);
+  for (hipEvent_t e : S->poll_event) if (e) (void)hipEventDestroy(e);
   if (S->ev_pool) { for (int k = 0; k < S->ev_cap; ++k) (void)hipEventDestroy(S->ev_pool[k]); free(S->ev_pool); }
   free(S->ev_cls); free(S->ev_solve); free(S->ev_iter);
   if (S->stream && S->own_stream) (void)hipStreamDestroy(S->stream);
@@ -226,6 +228,9 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   S->ticket_base = 0; S->epoch = 0;
   HIPCHK(hipHostMalloc((void**)&S->ms_host, sizeof(MarkerState), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&S->sc_host, sizeof(PcgScalars), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&S->poll_host, 2 * sizeof(PcgScalars), hipHostMallocDefault));
+  memset(S->poll_host, 0, 2 * sizeof(PcgScalars));
+  for (hipEvent_t& e : S->poll_event) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   memset(S->ms_host, 0, sizeof(MarkerState)); memset(S->sc_host, 0, sizeof(PcgScalars));
 
   S->interp_lim[0] = nextafterf((float)(S->X - 2), 0.f);   // U extent (X-1, Y): size-1

@@ -124,6 +124,8 @@ struct euler_sim {
   double* rowmajor_tmp;   // lazily allocated C doubles for euler_get/set_field of skewed arrays
   PcgScalars* sc;
   PcgScalars* sc_host;    // pinned
+  PcgScalars* poll_host;  // pinned [2]: convergence polls taken one chunk late (eu_launch_project)
+  hipEvent_t poll_event[2];
   double* partial;        // reduction partials
   unsigned int* red_counter;   // arrival ticket of the "last block reduces" epilogue (self-resetting)
   int red_blocks;

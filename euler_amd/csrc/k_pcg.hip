@@ -930,6 +930,11 @@ int eu_launch_project(euler_sim* S, float dt) {
   // the previous solve's final scalars are in sc_host by now (copied at its end, synced since)
   S->solve_iters[S->solve_seq & 255] = S->sc_host->nonzero ? S->sc_host->iters : -1;
   S->solve_seq += 1;
+  // Did the previous solve use up its iteration budget without converging?  Then this one probably will too,
+  // and the convergence poll is taken one chunk late: the next chunk is already queued while the host
+  // waits, so the GPU never idles for the ~27 us round trip (at most one chunk of early-exit launches is
+  // wasted when the guess is wrong).  Converging solves keep the immediate poll.
+  const bool lookahead = !S->has_comm && S->sc_host->nonzero && !S->sc_host->done && S->sc_host->iters >= S->cfg.max_iterations;
   S->prof_iter = -1;
   int rc;
   LAUNCH(S, KC_MISC, k_pcg_reset, dim3(1), dim3(1), S->sc, S->cfg.tol, S->cfg.max_iterations);
@@ -949,7 +954,7 @@ int eu_launch_project(euler_sim* S, float dt) {
   HIPCHK(hipStreamSynchronize(S->stream));
   const int poll = S->cfg.pcg_poll_interval > 0 ? S->cfg.pcg_poll_interval : 8;
   const int max_it = S->cfg.max_iterations;
-  int it = 0;
+  int it = 0, chunk = 0;
   bool stop = !S->sc_host->nonzero;   // all_zero(r): main.c:742
   while (it < max_it && !stop) {
     const int chunk_end = it + poll < max_it ? it + poll : max_it;
@@ -970,9 +975,20 @@ int eu_launch_project(euler_sim* S, float dt) {
       }
     }
     if (it < max_it) {   // poll the device-side convergence flag (identical on every rank)
-      HIPCHK(hipMemcpyAsync(S->sc_host, S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
-      HIPCHK(hipStreamSynchronize(S->stream));
-      stop = S->sc_host->done != 0;
+      if (!lookahead) {
+        HIPCHK(hipMemcpyAsync(S->sc_host, S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
+        HIPCHK(hipStreamSynchronize(S->stream));
+        stop = S->sc_host->done != 0;
+      } else {
+        const int slot = chunk & 1;
+        if (chunk > 0) {                                      // the poll behind the previous chunk
+          HIPCHK(hipEventSynchronize(S->poll_event[slot ^ 1]));
+          stop = S->poll_host[slot ^ 1].done != 0;
+        }
+        HIPCHK(hipMemcpyAsync(&S->poll_host[slot], S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
+        HIPCHK(hipEventRecord(S->poll_event[slot], S->stream));
+        ++chunk;
+      }
     }
   }
   S->prof_iter = -2;
