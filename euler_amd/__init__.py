@@ -66,7 +66,7 @@ EXPORTS = [
     "euler_get_field", "euler_set_field", "euler_set_markers", "euler_set_rng", "euler_get_stats",
     "euler_field_bytes", "euler_render", "euler_render_grids", "euler_profile_enable",
     "euler_profile_class_count", "euler_profile_class_name", "euler_profile_get", "euler_profile_reset",
-    "euler_measure_copy_bandwidth", "euler_device_name", "euler_sweep_timeline", "euler_set_comm", "euler_set_stream", "euler_slab_info",
+    "euler_measure_copy_bandwidth", "euler_device_name", "euler_sweep_timeline", "euler_save_state", "euler_load_state", "euler_set_comm", "euler_set_stream", "euler_slab_info",
 ]
 
 
@@ -114,6 +114,8 @@ def load_library():
         "euler_measure_copy_bandwidth": (C.c_int, [vp, C.c_size_t, i32, C.POINTER(f64)]),
         "euler_device_name": (C.c_int, [vp, C.c_char_p, i32]),
         "euler_sweep_timeline": (C.c_int, [vp, C.POINTER(C.c_uint64), i32]),
+        "euler_save_state": (C.c_int, [vp, C.c_char_p]),
+        "euler_load_state": (C.c_int, [vp, C.c_char_p]),
         "euler_set_comm": (C.c_int, [vp, vp, i32]),                 # euler_amd/slab.py passes a CommOps struct
         "euler_set_stream": (C.c_int, [vp, vp]),
         "euler_slab_info": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
@@ -161,6 +163,57 @@ def render_grids(solid, sink, count, wx, wy):
     buf = C.create_string_buffer(max(n.value, 1))
     _check(L.euler_render_grids(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, X, Y, wx, wy, buf, n.value, C.byref(n)))
     return buf.raw[: n.value]
+
+
+SNAPSHOT_F32 = ("u", "v", "utmp", "vtmp")
+SNAPSHOT_U8 = ("solid", "source", "sink", "count", "prev_count")
+
+
+def _fnv1a64(data, h=14695981039346656037):
+    # vectorised FNV-1a is not possible (sequential dependence); snapshots of test size only
+    for b in memoryview(data).cast("B"):
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def read_snapshot(path, verify=True):
+    """Parse a state snapshot written by euler_save_state (layout: include/euler.h) into a dict of
+    numpy arrays + scalars.  verify=True recomputes the FNV-1a-64 checksum (pure Python: slow beyond a
+    few MB)."""
+    import struct
+    raw = open(path, "rb").read()
+    magic, version, X, Y, _, n, rng, exhausted, _, frames, substeps, iters = struct.unpack_from("<8sIiiIQQiiQQQ", raw, 0)
+    if magic != b"EULERSNP" or version != 1:
+        raise ValueError("%s is not an euler state snapshot (version 1)" % path)
+    out = {"X": X, "Y": Y, "n_markers": n, "rng_state": rng, "source_exhausted": exhausted, "frames": frames,
+           "total_substeps": substeps, "total_pcg_iterations": iters}
+    off, Cn = 72, X * Y
+    for name in SNAPSHOT_F32:
+        out[name] = np.frombuffer(raw, np.float32, Cn, off).reshape(Y, X).copy(); off += 4 * Cn
+    for name in SNAPSHOT_U8:
+        out[name] = np.frombuffer(raw, np.uint8, Cn, off).reshape(Y, X).copy(); off += Cn
+    out["precon"] = np.frombuffer(raw, np.float64, Cn, off).reshape(Y, X).copy(); off += 8 * Cn
+    out["markers"] = np.frombuffer(raw, np.float32, 2 * n, off).reshape(n, 2).copy(); off += 8 * n
+    (want,) = struct.unpack_from("<Q", raw, off)
+    if len(raw) != off + 8:
+        raise ValueError("%s: %d trailing bytes" % (path, len(raw) - off - 8))
+    if verify and _fnv1a64(raw[:off]) != want:
+        raise ValueError("%s: checksum mismatch" % path)
+    return out
+
+
+def write_snapshot(path, st):
+    """Inverse of read_snapshot (e.g. to turn a golden fixture into a resumable state)."""
+    import struct
+    Y, X = st["u"].shape
+    mk = np.ascontiguousarray(st["markers"], np.float32).reshape(-1, 2)
+    body = struct.pack("<8sIiiIQQiiQQQ", b"EULERSNP", 1, X, Y, 0, len(mk), int(st["rng_state"]), int(st.get("source_exhausted", 0)), 0,
+                       int(st.get("frames", 0)), int(st.get("total_substeps", 0)), int(st.get("total_pcg_iterations", 0)))
+    body += b"".join(np.ascontiguousarray(st[k], np.float32).tobytes() for k in SNAPSHOT_F32)
+    body += b"".join(np.ascontiguousarray(st[k], np.uint8).tobytes() for k in SNAPSHOT_U8)
+    body += np.ascontiguousarray(st["precon"], np.float64).tobytes() + mk.tobytes()
+    with open(path, "wb") as f:
+        f.write(body + struct.pack("<Q", _fnv1a64(body)))
 
 
 def profile_class_names():
@@ -292,6 +345,14 @@ class Simulation:
         g = C.c_double(0)
         _check(self.L.euler_measure_copy_bandwidth(self.h, nbytes, reps, C.byref(g)))
         return g.value
+
+    def save_state(self, path):
+        """Checkpoint (include/euler.h "state snapshots"): everything sim_step() depends on."""
+        _check(self.L.euler_save_state(self.h, os.fsencode(path)))
+
+    def load_state(self, path):
+        _check(self.L.euler_load_state(self.h, os.fsencode(path)))
+        return self
 
     def sweep_timeline(self):
         """[(entry_us, first_ready_us, exit_us, blocks, stalled_blocks)] per band of the last sweep launch,

@@ -6,7 +6,10 @@
  * of the reference (raw mode, key presses, SIGWINCH, misc/terminal.c) is out of scope; this front
  * end writes frames with plain ANSI codes, or dumps them for tests with --dump.
  *
- *   euler [--size XxY] [--upscale] [--frames N] [--window WxH] [--dump] [--no-pace] <scenario>
+ *   euler [--size XxY] [--upscale] [--frames N] [--window WxH] [--dump] [--no-pace]
+ *         [--resume FILE] [--checkpoint FILE] <scenario>
+ * --resume continues from a state snapshot (include/euler.h) instead of the scenario's initial state
+ * (the scenario argument may then be omitted); --checkpoint writes one after the last frame.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -16,7 +19,7 @@
 #include "euler.h"
 
 static void usage(const char* argv0) {
-  fprintf(stderr, "usage: %s [--size XxY] [--upscale] [--frames N] [--window WxH] [--dump] [--no-pace] <scenario>\n", argv0);
+  fprintf(stderr, "usage: %s [--size XxY] [--upscale] [--frames N] [--window WxH] [--dump] [--no-pace] [--resume FILE] [--checkpoint FILE] <scenario>\n", argv0);
 }
 
 int main(int argc, char** argv) {
@@ -24,6 +27,8 @@ int main(int argc, char** argv) {
   euler_config_default(&cfg);
   int upscale = 0, frames = -1, wx = 98, wy = 38, dump = 0, pace = 1;
   const char* scenario = NULL;
+  const char* resume = NULL;
+  const char* checkpoint = NULL;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--size") && i + 1 < argc) { if (sscanf(argv[++i], "%dx%d", &cfg.X, &cfg.Y) != 2) { usage(argv[0]); return 1; } }
     else if (!strcmp(argv[i], "--window") && i + 1 < argc) { if (sscanf(argv[++i], "%dx%d", &wx, &wy) != 2) { usage(argv[0]); return 1; } }
@@ -31,13 +36,16 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--upscale")) upscale = 1;
     else if (!strcmp(argv[i], "--dump")) dump = 1;
     else if (!strcmp(argv[i], "--no-pace")) pace = 0;
+    else if (!strcmp(argv[i], "--resume") && i + 1 < argc) resume = argv[++i];
+    else if (!strcmp(argv[i], "--checkpoint") && i + 1 < argc) checkpoint = argv[++i];
     else if (argv[i][0] == '-') { fprintf(stderr, "Unrecognized input: %s\n", argv[i]); return 1; }   /* main.c:995 */
     else scenario = argv[i];
   }
-  if (!scenario) { usage(argv[0]); return 1; }                                                       /* main.c:986-989 */
+  if (!scenario && !resume) { usage(argv[0]); return 1; }                                                       /* main.c:986-989 */
 
   euler_sim* sim = NULL;
-  if (euler_create(&cfg, &sim) != EULER_OK || euler_load_scenario_file(sim, scenario, upscale) != EULER_OK) {
+  if (euler_create(&cfg, &sim) != EULER_OK ||
+      (resume ? euler_load_state(sim, resume) : euler_load_scenario_file(sim, scenario, upscale)) != EULER_OK) {
     fprintf(stderr, "%s\n", euler_last_error());
     return 1;
   }
@@ -68,6 +76,7 @@ int main(int argc, char** argv) {
       clock_nanosleep(CLOCK_MONOTONIC, TIMER_ABSTIME, &next, NULL);
     }
   }
+  if (checkpoint && euler_save_state(sim, checkpoint) != EULER_OK) { fprintf(stderr, "%s\n", euler_last_error()); return 1; }
   euler_stats st;
   if (euler_get_stats(sim, &st) == EULER_OK)
     fprintf(stderr, "frames %llu substeps %llu pcg_iterations %llu markers %llu\n", (unsigned long long)st.frames,

@@ -674,6 +674,92 @@ extern "C" int euler_measure_copy_bandwidth(euler_sim* S, size_t bytes, int32_t 
   return EULER_OK;
 }
 
+// ---- state snapshots (checkpoint / resume) -----------------------------------
+// Everything the reference keeps in file-scope variables (main.c:64-100,204,577): the four velocity
+// fields, the five cell grids, g_precon, the marker array in order, the RNG state and the source
+// latch - plus this build's frame counters.  Little-endian; layout documented in include/euler.h.
+static uint64_t snap_fnv(uint64_t h, const void* p, size_t n) {
+  const unsigned char* b = (const unsigned char*)p;
+  for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+  return h;
+}
+struct SnapHeader {
+  char magic[8]; uint32_t version; int32_t X, Y; uint32_t reserved;
+  uint64_t n_markers, rng_state; int32_t source_exhausted; int32_t reserved2;
+  uint64_t frames, total_substeps, total_pcg_iterations;
+};
+static const int SNAP_F32[] = {EULER_F_U, EULER_F_V, EULER_F_UTMP, EULER_F_VTMP};
+static const int SNAP_U8[] = {EULER_F_SOLID, EULER_F_SOURCE, EULER_F_SINK, EULER_F_COUNT, EULER_F_PREV_COUNT};
+
+extern "C" int euler_save_state(euler_sim* S, const char* path) {
+  if (!S || !path) return EULER_EINVAL;
+  euler_stats st;
+  int rc = euler_get_stats(S, &st);
+  if (rc) return rc;
+  FILE* f = fopen(path, "wb");
+  if (!f) { eu_set_error("cannot open %s for writing", path); return EULER_EIO; }
+  SnapHeader h;
+  memset(&h, 0, sizeof h);
+  memcpy(h.magic, "EULERSNP", 8);
+  h.version = 1; h.X = S->X; h.Y = S->Y; h.n_markers = st.n_markers; h.rng_state = st.rng_state;
+  h.source_exhausted = st.source_exhausted; h.frames = st.frames; h.total_substeps = st.total_substeps;
+  h.total_pcg_iterations = st.total_pcg_iterations;
+  uint64_t sum = snap_fnv(14695981039346656037ull, &h, sizeof h);
+  bool ok = fwrite(&h, sizeof h, 1, f) == 1;
+  const size_t C = S->C;
+  std::vector<unsigned char> buf(C * 8 > st.n_markers * 8 ? C * 8 : (size_t)st.n_markers * 8);
+  auto put = [&](int field, size_t bytes) {
+    if (!ok || !bytes) return;
+    rc = euler_get_field(S, field, buf.data(), bytes);
+    if (rc) { ok = false; return; }
+    sum = snap_fnv(sum, buf.data(), bytes);
+    ok = fwrite(buf.data(), 1, bytes, f) == bytes;
+  };
+  for (int fd : SNAP_F32) put(fd, C * 4);
+  for (int fd : SNAP_U8) put(fd, C);
+  put(EULER_F_PRECON, C * 8);
+  put(EULER_F_MARKERS, (size_t)st.n_markers * 8);
+  ok = ok && fwrite(&sum, 8, 1, f) == 1;
+  ok = (fclose(f) == 0) && ok;
+  if (rc) return rc;
+  if (!ok) { eu_set_error("short write to %s", path); return EULER_EIO; }
+  return EULER_OK;
+}
+
+extern "C" int euler_load_state(euler_sim* S, const char* path) {
+  if (!S || !path) return EULER_EINVAL;
+  FILE* f = fopen(path, "rb");
+  if (!f) { eu_set_error("cannot open %s", path); return EULER_EIO; }
+  SnapHeader h;
+  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "EULERSNP", 8) != 0 || h.version != 1) {
+    fclose(f); eu_set_error("%s is not an euler state snapshot (version 1)", path); return EULER_EINVAL;
+  }
+  if (h.X != S->X || h.Y != S->Y || h.n_markers > S->max_markers) {
+    fclose(f); eu_set_error("snapshot grid %dx%d (%llu markers) does not fit this %dx%d handle", h.X, h.Y,
+                            (unsigned long long)h.n_markers, S->X, S->Y);
+    return EULER_EINVAL;
+  }
+  const size_t C = S->C;
+  const size_t body = C * 4 * 4 + C * 5 + C * 8 + (size_t)h.n_markers * 8;
+  std::vector<unsigned char> buf(body + 8);
+  const bool ok = fread(buf.data(), 1, body + 8, f) == body + 8;
+  fclose(f);
+  uint64_t sum = snap_fnv(snap_fnv(14695981039346656037ull, &h, sizeof h), buf.data(), body), want = 0;
+  memcpy(&want, buf.data() + body, 8);
+  if (!ok || sum != want) { eu_set_error("%s is truncated or corrupt (checksum)", path); return EULER_EIO; }
+  const unsigned char* p = buf.data();
+  int rc;
+  for (int fd : SNAP_F32) { if ((rc = euler_set_field(S, fd, p, C * 4))) return rc; p += C * 4; }
+  for (int fd : SNAP_U8) { if ((rc = euler_set_field(S, fd, p, C))) return rc; p += C; }
+  if ((rc = euler_set_field(S, EULER_F_PRECON, p, C * 8))) return rc;
+  p += C * 8;
+  if ((rc = euler_set_markers(S, (const float*)p, h.n_markers))) return rc;
+  if ((rc = euler_set_rng(S, h.rng_state, h.source_exhausted))) return rc;
+  S->stats.frames = h.frames; S->stats.total_substeps = h.total_substeps; S->stats.total_pcg_iterations = h.total_pcg_iterations;
+  S->loaded = 1;
+  return EULER_OK;
+}
+
 extern "C" int euler_sweep_timeline(euler_sim* S, uint64_t* out, int32_t cap_bands) {
   if (!S || !out || cap_bands < 0) return EULER_EINVAL;
   const int n = S->band_hi - S->band_lo < cap_bands ? S->band_hi - S->band_lo : cap_bands;

@@ -175,6 +175,18 @@ int euler_set_field(euler_sim* sim, int32_t field, const void* src, size_t src_b
 int euler_set_markers(euler_sim* sim, const float* xy, uint64_t n);
 int euler_set_rng(euler_sim* sim, uint64_t rng_state, int32_t source_exhausted);
 int euler_get_stats(euler_sim* sim, euler_stats* out);
+
+/* ---- state snapshots: checkpoint / resume --------------------------------
+ * Everything the reference keeps in file-scope variables (main.c:64-100, 204, 577), so that a resumed
+ * run continues bit for bit.  File layout, little-endian:
+ *   char[8] "EULERSNP"; u32 version = 1; i32 X, Y; u32 0; u64 n_markers; u64 rng_state;
+ *   i32 source_exhausted; i32 0; u64 frames, total_substeps, total_pcg_iterations;          (72 bytes)
+ *   f32[Y][X] u, v, utmp, vtmp;  u8[Y][X] solid, source, sink, count, prev_count;  f64[Y][X] precon;
+ *   f32[n_markers][2] markers in array order;  u64 FNV-1a-64 of all preceding bytes.
+ * euler_load_state needs a handle of the same X, Y.  (euler_amd.read_snapshot / write_snapshot mirror
+ * the format in numpy.) */
+int euler_save_state(euler_sim* sim, const char* path);
+int euler_load_state(euler_sim* sim, const char* path);
 size_t euler_field_bytes(const euler_sim* sim, int32_t field);   /* current size in bytes */
 
 /* ---- render = draw_rows (main.c:914-951) ------------------------------------------------- */
