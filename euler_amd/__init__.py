@@ -226,7 +226,7 @@ class Simulation:
     plus state access for parity tests."""
 
     def __init__(self, X=100, Y=40, device=0, dot_mode=DOT_AUTO, precond=PRECOND_IC0, sweep_mode=SWEEP_AUTO,
-                 max_iterations=100, tol=None, pcg_poll_interval=8):
+                 max_iterations=100, tol=None, pcg_poll_interval=8, viscosity=0.0):
         self.L = load_library()
         cfg = Config()
         _check(self.L.euler_config_default(C.byref(cfg)))
@@ -236,6 +236,7 @@ class Simulation:
         if tol is not None:
             cfg.tol = tol
         cfg.pcg_poll_interval = pcg_poll_interval
+        cfg.viscosity = viscosity            # extension: 0 = the inviscid reference
         self.cfg = cfg
         self.X, self.Y = X, Y
         self.h = C.c_void_p()

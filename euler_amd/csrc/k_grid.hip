@@ -132,10 +132,64 @@ __global__ __launch_bounds__(256) void k_advect_velocity(const float* __restrict
   }
 }
 
+// EXTENSION (the reference is inviscid): one explicit diffusion step of the advected
+// velocities over their live faces, out = q + nu*dt/h^2 * sum over live 4-neighbours (q_n - q), float,
+// neighbours visited left, right, down, up - the arithmetic of oracle eo_diffuse.  Jacobi from the old
+// values: reads utmp/vtmp, writes u/v, which are dead between advection and projection.
+__global__ __launch_bounds__(256) void k_diffuse_velocity(const float* __restrict__ uin, const float* __restrict__ vin,
+                                                          float* __restrict__ uout, float* __restrict__ vout,
+                                                          const uint8_t* __restrict__ count, const uint8_t* __restrict__ solid,
+                                                          int X, int Y, float c) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= X || y >= Y) return;
+  const size_t i = (size_t)y * X + x;
+  auto live_u = [&](size_t k) { return eu_prop_u(count, k) && !eu_prop_u(solid, k); };
+  auto live_v = [&](size_t k) { return eu_prop_v(count, k, X) && !eu_prop_v(solid, k, X); };
+  if (x < X - 1) {
+    float r = uin[i];
+    if (live_u(i)) {
+      float acc = 0.f;
+      if (x > 0 && live_u(i - 1)) acc += uin[i - 1] - uin[i];
+      if (x + 1 < X - 1 && live_u(i + 1)) acc += uin[i + 1] - uin[i];
+      if (y > 0 && live_u(i - X)) acc += uin[i - X] - uin[i];
+      if (y + 1 < Y && live_u(i + X)) acc += uin[i + X] - uin[i];
+      r = uin[i] + c * acc;
+    }
+    uout[i] = r;
+  }
+  if (y < Y - 1) {
+    float r = vin[i];
+    if (live_v(i)) {
+      float acc = 0.f;
+      if (x > 0 && live_v(i - 1)) acc += vin[i - 1] - vin[i];
+      if (x + 1 < X && live_v(i + 1)) acc += vin[i + 1] - vin[i];
+      if (y > 0 && live_v(i - X)) acc += vin[i - X] - vin[i];
+      if (y + 1 < Y - 1 && live_v(i + X)) acc += vin[i + X] - vin[i];
+      r = vin[i] + c * acc;
+    }
+    vout[i] = r;
+  }
+}
+__global__ __launch_bounds__(256) void k_copy_typed(const float* __restrict__ u, const float* __restrict__ v, float* __restrict__ uo,
+                                                    float* __restrict__ vo, int X, int Y) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= X || y >= Y) return;
+  const size_t i = (size_t)y * X + x;
+  if (x < X - 1) uo[i] = u[i];
+  if (y < Y - 1) vo[i] = v[i];
+}
+
 int eu_launch_advect_velocity(euler_sim* S, float dt) {
   GridRef g{S->X, S->Y, S->count, S->interp_lim[0], S->interp_lim[1], S->interp_lim[2], S->interp_lim[3]};
   dim3 grid((S->X + 63) / 64, (S->Y + 3) / 4);
   LAUNCH(S, KC_ADVECT_VELOCITY, k_advect_velocity, grid, dim3(256), S->u, S->v, S->utmp, S->vtmp, S->solid, g, dt);
+  if (S->cfg.viscosity > 0.f) {   // extension stage; absent (bit-identical to the reference) at viscosity 0
+    const float c = S->cfg.viscosity * dt / (EU_H * EU_H);
+    LAUNCH(S, KC_ADVECT_VELOCITY, k_diffuse_velocity, grid, dim3(256), S->utmp, S->vtmp, S->u, S->v, S->count, S->solid, S->X, S->Y, c);
+    LAUNCH(S, KC_ADVECT_VELOCITY, k_copy_typed, grid, dim3(256), S->u, S->v, S->utmp, S->vtmp, S->X, S->Y);
+  }
   return EULER_OK;
 }
 

@@ -529,6 +529,31 @@ int eo_project(eo_sim* s, float dt, const float* u, const float* v, float* uout,
   return iters;
 }
 
+/* ---------------------------------------------------------------- EXTENSION: velocity diffusion
+ * Not in the reference (it is inviscid); named by the north star only.  Defined by this
+ * build, restated here so that the GPU stage has something to be checked against: explicit Jacobi step
+ * from the old values, float arithmetic, neighbours visited left, right, down, up. */
+void eo_diffuse(const eo_sim* s, const float* q, int type, float dt, float* out) {
+  const int ex = ext_x(s, type), ey = ext_y(s, type);
+  const float c = s->viscosity * dt / (H_CELL * H_CELL);
+  for (int y = 0; y < ey; ++y)
+    for (int x = 0; x < ex; ++x) {
+      const size_t i = AT(s, y, x);
+      float r = q[i];
+      if (prop(s, s->count, x, y, type) && !prop(s, s->solid, x, y, type)) {
+        float acc = 0.f;
+        const int nx[4] = {x - 1, x + 1, x, x}, ny[4] = {y, y, y - 1, y + 1};
+        for (int k = 0; k < 4; ++k) {
+          if (nx[k] < 0 || nx[k] >= ex || ny[k] < 0 || ny[k] >= ey) continue;
+          if (!prop(s, s->count, nx[k], ny[k], type) || prop(s, s->solid, nx[k], ny[k], type)) continue;
+          acc += q[AT(s, ny[k], nx[k])] - q[i];
+        }
+        r = q[i] + c * acc;
+      }
+      out[i] = r;
+    }
+}
+
 /* ---------------------------------------------------------------- step driver (main.c:843-900) */
 
 int eo_substep(eo_sim* s, float dt) {
@@ -544,6 +569,17 @@ int eo_substep(eo_sim* s, float dt) {
   eo_apply_body_forces(s, s->vtmp, dt);
   eo_zero_bounds(s, s->utmp, EO_U);
   eo_zero_bounds(s, s->vtmp, EO_V);
+  if (s->viscosity > 0.f) {   /* extension; u, v are dead between advection and projection: scratch */
+    const size_t C = (size_t)s->X * s->Y;
+    eo_diffuse(s, s->utmp, EO_U, dt, s->u);
+    eo_diffuse(s, s->vtmp, EO_V, dt, s->v);
+    for (int y = 0; y < s->Y; ++y)
+      for (int x = 0; x < s->X; ++x) {
+        if (x < s->X - 1) s->utmp[AT(s, y, x)] = s->u[AT(s, y, x)];
+        if (y < s->Y - 1) s->vtmp[AT(s, y, x)] = s->v[AT(s, y, x)];
+      }
+    (void)C;
+  }
   int it = eo_project(s, dt, s->utmp, s->vtmp, s->u, s->v);
   s->total_substeps++;
   s->last_dt = dt;

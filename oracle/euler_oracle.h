@@ -40,6 +40,7 @@ typedef struct eo_sim {
   /* solver parameters (reference constants main.c:735-736, 849, 851, 838) */
   int max_iterations;                   /* 100 */
   double tol;                           /* (double)1e-6f */
+  float viscosity;                      /* EXTENSION, not in the reference: 0 = off = the reference */
   /* counters the reference does not keep */
   uint64_t total_substeps, total_pcg_iterations;
   int last_substeps, last_pcg_iterations;
@@ -74,6 +75,9 @@ void  eo_zero_bounds(const eo_sim* s, float* q, int type);             /* main.c
 void  eo_advect_u(const eo_sim* s, const float* u, const float* v, float dt, float* out);
 void  eo_advect_v(const eo_sim* s, const float* u, const float* v, float dt, float* out);
 void  eo_apply_body_forces(const eo_sim* s, float* v, float dt);       /* main.c:539-545 */
+/* EXTENSION (no reference counterpart): one explicit diffusion step of the typed field q
+ * over its live faces (fluid property and not solid), out = q + nu*dt/h^2 * sum over live 4-neighbours (q_n - q). */
+void  eo_diffuse(const eo_sim* s, const float* q, int type, float dt, float* out);
 int   eo_project(eo_sim* s, float dt, const float* u, const float* v, float* uout, float* vout);
 float eo_interpolate(const eo_sim* s, const float* q, float ix, float iy, int type);
 

@@ -35,7 +35,7 @@ class EoSim(C.Structure):
         ("precon", C.POINTER(C.c_double)), ("q", C.POINTER(C.c_double)),
         ("b", C.POINTER(C.c_double)), ("p", C.POINTER(C.c_double)),
         ("r", C.POINTER(C.c_double)), ("z", C.POINTER(C.c_double)), ("s", C.POINTER(C.c_double)),
-        ("max_iterations", C.c_int), ("tol", C.c_double),
+        ("max_iterations", C.c_int), ("tol", C.c_double), ("viscosity", C.c_float),
         ("total_substeps", C.c_uint64), ("total_pcg_iterations", C.c_uint64),
         ("last_substeps", C.c_int), ("last_pcg_iterations", C.c_int),
         ("last_residual", C.c_double), ("last_dt", C.c_float), ("frame_count", C.c_uint32),

@@ -485,3 +485,19 @@ def test_marker_count_wraps_like_uint8():
     cy, cx = np.unravel_index(np.argmax(np.bincount((np.floor(m[:, 1]).astype(int) * X2 + np.floor(m[:, 0]).astype(int)), minlength=X2 * Y2)), (Y2, X2))
     true_count = int(((np.floor(m[:, 0]) == cx) & (np.floor(m[:, 1]) == cy)).sum())
     assert true_count >= 300 and int(sim.get(ea.F_COUNT)[cy, cx]) == true_count % 256
+
+
+# ----------------------------------------------------------------------------- extension: velocity diffusion
+@pytest.mark.parametrize("size,scn,nu,frames", [((130, 70), "block", 0.05, 34), ((192, 200), "waterfall", 0.2, 10)])
+def test_velocity_diffusion_extension_bit_exact_vs_oracle(size, scn, nu, frames):
+    """The reference is inviscid; the diffusion stage is this build's extension (config.viscosity), defined
+    by oracle eo_diffuse.  viscosity = 0 leaves the stage out (every other test); > 0 must match the
+    oracle's restatement bit for bit and must actually change the flow."""
+    o, sim = make_pair(size[0], size[1], scn, dot_mode=ea.DOT_SEQUENTIAL, viscosity=nu)
+    o.c.viscosity = nu
+    _, inviscid = make_pair(size[0], size[1], scn, dot_mode=ea.DOT_SEQUENTIAL)
+    for f in range(frames):
+        o.step(); sim.step(); inviscid.step()
+        compare_all(o, sim, "nu=%g frame %d" % (nu, f))
+    assert max(np.abs(sim.get(ea.F_U) - inviscid.get(ea.F_U)).max(), np.abs(sim.get(ea.F_V) - inviscid.get(ea.F_V)).max()) > 1e-4
+    sim.close(); inviscid.close()
