@@ -140,7 +140,8 @@ extern "C" void euler_destroy(euler_sim* S) {
                  S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->fbits_fwd, S->fbits_bwd, S->halo_buf, S->band_ranges,
                  S->rowmajor_tmp};
   for (void* p : dev) if (p) (void)hipFree(p);
-  for (double* d : {S->b, S->p, S->r, S->z, S->s, S->q, S->precon, S->kr, S->ku}) if (d) (void)hipFree(d - EU_SKEW_SLACK);
+  for (double* d : {S->b, S->p, S->r, S->z, S->s, S->q, S->precon}) if (d) (void)hipFree(d - EU_SKEW_SLACK);
+  if (S->krku) (void)hipFree(S->krku - 2 * EU_SKEW_SLACK);
   if (S->cellmask) (void)hipFree(S->cellmask - EU_SKEW_SLACK);
   if (S->fmask) (void)hipFree(S->fmask - EU_SKEW_SLACK);
   if (S->ms_host) (void)hipHostFree(S->ms_host);
@@ -208,7 +209,8 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   const size_t SS = S->geom.S;
   if ((SS + EU_SKEW_SLACK) * 8 >= ((size_t)1 << 32)) { eu_set_error("grid too large for 32-bit record offsets"); euler_destroy(S); return EULER_EINVAL; }
   // skewed arrays carry EU_SKEW_SLACK zeroed elements in front (the backward sweep prefetches below record 0)
-  for (double** d : {&S->b, &S->p, &S->r, &S->z, &S->s, &S->q, &S->precon, &S->kr, &S->ku}) { DALLOC(*d, SS + EU_SKEW_SLACK); *d += EU_SKEW_SLACK; }
+  for (double** d : {&S->b, &S->p, &S->r, &S->z, &S->s, &S->q, &S->precon}) { DALLOC(*d, SS + EU_SKEW_SLACK); *d += EU_SKEW_SLACK; }
+  DALLOC(S->krku, 2 * (SS + EU_SKEW_SLACK)); S->krku += 2 * EU_SKEW_SLACK;
   DALLOC(S->cellmask, SS + EU_SKEW_SLACK); S->cellmask += EU_SKEW_SLACK;
   DALLOC(S->fmask, SS + EU_SKEW_SLACK); S->fmask += EU_SKEW_SLACK;
   S->fb_stride = 2 * (((S->geom.T + 7) / 8 + 1) / 2) + 2;   // whole pairs of blocks + the block the prefetch runs ahead

@@ -266,6 +266,7 @@ __global__ __launch_bounds__(256) void k_jacobi(const double* __restrict__ r, do
 // uses get_a_plus_i/j(y,x) = is_fluid of the right/upper neighbour.
 enum { SW_FACTOR = 0, SW_FORWARD = 1, SW_BACKWARD = 2 };
 
+typedef double sw_d2 __attribute__((ext_vector_type(2)));
 struct SweepArgs {
   SkewGeom g;
   const uint8_t* mask;
@@ -275,8 +276,8 @@ struct SweepArgs {
   double* pre;            // precon: in/out for SW_FACTOR, in otherwise
   const double* in;       // r (forward) / q (backward); unused for factor
   double* out;            // q (forward) / z (backward); unused for factor
-  double* kr; double* ku; // backward coefficients a_i*precon, a_j*precon (main.c:621-622): written by the
-                          // factor sweep once per solve, streamed by the backward sweep
+  sw_d2* krku;            // backward coefficients {a_i*precon, a_j*precon} (main.c:621-622) as one 16-byte stream:
+                          // written by the factor sweep once per solve, read by the backward sweep (one load, not two)
   unsigned long long* granules;   // [nbands][gran_stride][2] tagged hand-off of a band's edge row
   int gran_stride;
   const int4* ranges;     // per band: active block ranges {fwd B0, fwd B1, bwd B0, bwd B1} (k_band_ranges)
@@ -552,13 +553,14 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   const double* p_pre = a.pre + e0;
   const uint8_t* p_msk = a.mask + e0;
   const unsigned int* p_fb = (BWD ? a.fbits_bwd : a.fbits_fwd) + ((size_t)band * a.fb_stride + B0) * 64 + lane;
-  const double* p_kr = a.kr + e0; const double* p_ku = a.ku + e0;      // backward only
-  double* p_okr = a.kr + e0; double* p_oku = a.ku + e0;                // factor only
+  const sw_d2* p_kk = a.krku + e0;                                 // backward only; 16 B per step: the immediate offset (13 bits,
+  const sw_d2* p_kk4 = p_kk + 4 * STEP;                            // signed) reaches 4 steps, hence a second base for steps 4..7
+  sw_d2* p_okk = a.krku + e0;                                      // factor only
   double* p_out = (OP == SW_FACTOR ? a.pre : a.out) + e0;          // results of the block being computed
 
   // Two operand sets, ping-ponged block by block: while block k computes from one set, the records
   // of block k+1 are fetched into the other.
-  struct Operands { double in[SW_BLK], pre[SW_BLK], kr[SW_BLK], ku[SW_BLK]; int m[SW_BLK]; unsigned int fb; };
+  struct Operands { double in[SW_BLK], pre[SW_BLK]; sw_d2 kk[SW_BLK]; int m[SW_BLK]; unsigned int fb; };
   Operands opA, opB;
   // forward / backward: the record loads are issued BY HAND (inline asm) and retired by counted
   // s_waitcnt in front of each step.  hipcc's own wait insertion loses track of the issue order at
@@ -572,13 +574,13 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   //      fetch(k+1) and j stores: vmcnt((7 - j) * LOADS_PER_STEP + LOADS + j) is exact for the first
   //      block and never waits for a load of fetch(k+1); the stores of block k-1 get a block of slack.
   // tools/check_sweep_isa.py proves on the generated ISA that no in-flight operand is ever touched.
-  constexpr int LOADS_PER_STEP = OP == SW_BACKWARD ? 4 : 2;
+  constexpr int LOADS_PER_STEP = OP == SW_BACKWARD ? 3 : 2;
   constexpr int LOADS = SW_BLK * LOADS_PER_STEP + 1;
   auto fetch_block = [&](Operands& o) {
     if constexpr (OP == SW_FACTOR) {
 #pragma unroll
       for (int j = 0; j < SW_BLK; ++j) {
-        o.in[j] = 0.0; o.kr[j] = 0.0; o.ku[j] = 0.0;
+        o.in[j] = 0.0; o.kk[j] = sw_d2{0.0, 0.0};
         o.pre[j] = p_pre[j * STEP];
         o.m[j] = (int)p_msk[j * STEP];   // the full cell-mask byte (a_diag, right / up neighbour bits)
       }
@@ -589,9 +591,8 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
 #define SW_LOAD_STEP(J)                                                                                                    \
       asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=&v"(o.in[J]) : "v"(p_in), "n"((J) * STEP * 8));        \
       if (OP == SW_BACKWARD) {                                                                                             \
-        asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=&v"(o.kr[J]) : "v"(p_kr), "n"((J) * STEP * 8));      \
-        asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=&v"(o.ku[J]) : "v"(p_ku), "n"((J) * STEP * 8));      \
-      } else { o.kr[J] = 0.0; o.ku[J] = 0.0; }                                                                             \
+        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(o.kk[J]) : "v"((J) < 4 ? p_kk : p_kk4), "n"(((J) & 3) * STEP * 16)); \
+      } else { o.kk[J] = sw_d2{0.0, 0.0}; }                                                                                \
       asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=&v"(o.pre[J]) : "v"(p_pre), "n"((J) * STEP * 8));      \
       o.m[J] = 0;
       SW_LOAD_STEP(0) SW_LOAD_STEP(1) SW_LOAD_STEP(2) SW_LOAD_STEP(3) SW_LOAD_STEP(4) SW_LOAD_STEP(5) SW_LOAD_STEP(6) SW_LOAD_STEP(7)
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
       asm volatile("" ::: "memory");
     }
     p_in += SW_BLK * STEP; p_pre += SW_BLK * STEP; p_msk += SW_BLK * STEP; p_fb += 64;
-    p_kr += SW_BLK * STEP; p_ku += SW_BLK * STEP;
+    p_kk += SW_BLK * STEP; p_kk4 += SW_BLK * STEP;
   };
 
   // wait (rarely) until the helper's counter reaches `target`
@@ -653,12 +654,13 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
       // instructions later; measured 1.4-2x slower per step).
       __builtin_amdgcn_sched_barrier(0);
       double* ring = &sh.pub[(SW_BLK * blk) & (SW_RING - 1)][lane];
+      double prev_carry = CONST;
       auto step = [&](auto jc) {
         constexpr int j = decltype(jc)::value;
         if constexpr (OP != SW_FACTOR) {     // retire this step's records (see fetch_block)
           constexpr int N = (SW_BLK - 1 - j) * LOADS_PER_STEP + LOADS + j;
           if (OP == SW_BACKWARD)
-            asm volatile("s_waitcnt vmcnt(%5)" : "+v"(cur.in[j]), "+v"(cur.pre[j]), "+v"(cur.kr[j]), "+v"(cur.ku[j]), "+v"(cur.fb) : "n"(N) : "memory");
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(cur.in[j]), "+v"(cur.pre[j]), "+v"(cur.kk[j]), "+v"(cur.fb) : "n"(N) : "memory");
           else
             asm volatile("s_waitcnt vmcnt(%3)" : "+v"(cur.in[j]), "+v"(cur.pre[j]), "+v"(cur.fb) : "n"(N) : "memory");
         }
@@ -676,15 +678,14 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
           res = (cm & CM_FLUID) ? 1.0 / sqrt(e) : cpre;      // non-fluid: the stale entry stays
           carry = res;
           // the backward solve's coefficients of this cell, fixed for the whole solve
-          p_okr[j * STEP] = ((cm & CM_RIGHT) ? -1.0 : 0.0) * res;
-          p_oku[j * STEP] = ((cm & CM_UP) ? -1.0 : 0.0) * res;
+          p_okk[j * STEP] = sw_d2{((cm & CM_RIGHT) ? -1.0 : 0.0) * res, ((cm & CM_UP) ? -1.0 : 0.0) * res};
         } else if (OP == SW_FORWARD) {       // main.c:602-613: t = r - (-1*pre_l)*q_l - (-1*pre_b)*q_b
           const double t = cin - own - nbv;
           const double qv = t * cpre;
           res = __hiloint2double(__double2hiint(qv) & cm, __double2loint(qv) & cm);   // +0 on non-fluid cells
           carry = -1.0 * cpre * res;         // this cell's term in its right and upper neighbours
         } else {                             // main.c:615-626: t = q - (a_i*pre)*z_r - (a_j*pre)*z_u
-          const double t = cin - cur.kr[j] * own - cur.ku[j] * nbv;
+          const double t = cin - cur.kk[j].x * own - cur.kk[j].y * nbv;
           const double zv = t * cpre;
           res = __hiloint2double(__double2hiint(zv) & cm, __double2loint(zv) & cm);   // +0 on non-fluid cells
           carry = res;
@@ -692,7 +693,9 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
         p_out[j * STEP] = res;
         own = carry;
         out = carry;
-        if (PB) ring[j * 64] = carry;        // the helper gathers the edge lane's entry
+        // the announce wave gathers the edge lane's entry; two rows per LDS instruction (ds_write2st64_b64)
+        if (PB && (j & 1)) { ring[(j - 1) * 64] = prev_carry; ring[j * 64] = carry; }
+        prev_carry = carry;
       };
       step(std::integral_constant<int, 0>()); step(std::integral_constant<int, 1>()); step(std::integral_constant<int, 2>());
       step(std::integral_constant<int, 3>());
@@ -704,7 +707,7 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
       step(std::integral_constant<int, 4>()); step(std::integral_constant<int, 5>());
       step(std::integral_constant<int, 6>()); step(std::integral_constant<int, 7>());
       __builtin_amdgcn_sched_barrier(0);
-      p_out += SW_BLK * STEP; p_okr += SW_BLK * STEP; p_oku += SW_BLK * STEP;
+      p_out += SW_BLK * STEP; p_okk += SW_BLK * STEP;
       if (HP || PB) { SW_COMPILER_FENCE(); lds_put(&sh.comp_done, (unsigned int)(rel + 1)); }
       // block blk+1 overwrites the ring rows of block blk-7, which the groups up to block blk-6 read
       // (announced once pub_done >= rel-5)
@@ -737,7 +740,7 @@ static SweepArgs make_sweep_args(euler_sim* S, int op, int force) {
   a.mask = S->cellmask; a.fbits_fwd = S->fbits_fwd; a.fbits_bwd = S->fbits_bwd; a.fb_stride = S->fb_stride; a.pre = S->precon;
   a.in = op == SW_FORWARD ? S->r : S->q;
   a.out = op == SW_FORWARD ? S->q : S->z;
-  a.kr = S->kr; a.ku = S->ku;
+  a.krku = reinterpret_cast<sw_d2*>(S->krku);
   a.granules = S->granules; a.gran_stride = S->gran_stride; a.ticket = S->ticket;
   a.ranges = S->band_ranges;
   a.band_lo = S->band_lo; a.nb_local = S->band_hi - S->band_lo; a.couple = S->has_comm && S->couple;
