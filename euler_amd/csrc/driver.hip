@@ -204,7 +204,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   S->geom.X = S->X; S->geom.Y = S->Y;
   S->geom.nbands = (S->Y + 63) / 64;
   S->geom.T = S->X + 63;
-  S->geom.TS = ((S->geom.T + 7) & ~7) + 32;   // the sweeps run whole pairs of 8-step blocks and prefetch 8 further
+  S->geom.TS = ((S->geom.T + 31) & ~31) + 32;   // the sweeps run whole groups of four 8-step blocks and prefetch 16 steps further
   S->geom.S = (size_t)S->geom.nbands * S->geom.TS * 64;
   const size_t SS = S->geom.S;
   if ((SS + EU_SKEW_SLACK) * 8 >= ((size_t)1 << 32)) { eu_set_error("grid too large for 32-bit record offsets"); euler_destroy(S); return EULER_EINVAL; }
@@ -213,7 +213,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   DALLOC(S->krku, 2 * (SS + EU_SKEW_SLACK)); S->krku += 2 * EU_SKEW_SLACK;
   DALLOC(S->cellmask, SS + EU_SKEW_SLACK); S->cellmask += EU_SKEW_SLACK;
   DALLOC(S->fmask, SS + EU_SKEW_SLACK); S->fmask += EU_SKEW_SLACK;
-  S->fb_stride = 2 * (((S->geom.T + 7) / 8 + 1) / 2) + 2;   // whole pairs of blocks + the block the prefetch runs ahead
+  S->fb_stride = 4 * (((S->geom.T + 7) / 8 + 3) / 4) + 4;   // whole groups of 4 blocks + the two blocks the prefetch runs ahead
   DALLOC(S->fbits_fwd, (size_t)S->geom.nbands * S->fb_stride * 64);
   DALLOC(S->fbits_bwd, (size_t)S->geom.nbands * S->fb_stride * 64);
   DALLOC(S->sc, 1);

@@ -64,9 +64,9 @@ struct MarkerState {
 
 // Band-skewed layout of the solver's private arrays (k_pcg.hip header): element (x,y) lives at
 // ((y/64)*TS + x + y%64)*64 + y%64.  A band has T = X + 63 live records and a stride of
-// TS = roundup8(T) + 32 records; S = nbands*TS*64 elements in total; padding carries mask 0.
+// TS = roundup32(T) + 32 records; S = nbands*TS*64 elements in total; padding carries mask 0.
 // Every skewed array also has EU_SKEW_SLACK elements of zeroed slack in front of element 0.
-#define EU_SKEW_SLACK (32 * 64)
+#define EU_SKEW_SLACK (64 * 64)
 struct SkewGeom {
   int X, Y, nbands, T, TS;
   size_t S;

@@ -5,7 +5,7 @@
 // so it is stored BAND-SKEWED rather than row-major (struct SkewGeom, euler_dev.h):
 //     element (row y, column x)  ->  band b = y / 64, lane l = y % 64, record t = x + l
 //                                    index  = (b * TS + t) * 64 + l
-// (T = X + 63 live records per band, band stride TS = roundup8(T) + 32 records).
+// (T = X + 63 live records per band, band stride TS = roundup32(T) + 32 records).
 // A record (64 consecutive elements = 512 B of doubles) is exactly what one wave touches in one
 // step of the IC(0) wavefront sweeps (lane l at column t - l), so the sweeps stream contiguous
 // records: perfectly coalesced, no LDS transposition, pointer += 512 B per step.  The backward
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(1024) void k_sweep_simple(SweepArgs a) {
 // One band per workgroup (= per CU) on purpose: a band streams ~16 B/cycle, so 4 compute waves would
 // saturate a CU's ~64 B/clk vector-memory path (measured 1.4x / 2x slower with 4 / 8 bands per CU).
 // Records t >= T of a band and the 32 records in front of each array are dead padding (mask 0):
-// the loop runs whole pairs of blocks and prefetches unconditionally.
+// the loop runs whole groups of 4 blocks and prefetches unconditionally.
 #define SW_BLK 8
 #define SW_RING 64            // carry rows kept in LDS (8 blocks)
 #define SW_BND_RING 16        // boundary blocks kept in LDS
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   unsigned long long* gr_out = a.granules + (size_t)gord * a.gran_stride * 2;
   const unsigned long long* gr_in = a.granules + (size_t)(has_prev ? gord - 1 : 0) * a.gran_stride * 2;
 
-  // Active range (forward / backward solves only).  Outside the 16-step-aligned block range
+  // Active range (forward / backward solves only).  Outside the 32-step-aligned block range
   // [B0, B1) every cell of the band is non-fluid, so its results are constants that are already in
   // memory (q, z = +0, zeroed per solve) and the values it would hand on are CONST (z: +0; the
   // forward carry m = (-1*precon)*(+0) = -0.0).  The band runs only [B0, B1); an empty band returns at
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   // not poll.  The factor sweep always runs the full range (a stale precon is not a constant).
   constexpr bool RANGED = OP != SW_FACTOR;
   constexpr double CONST = OP == SW_FORWARD ? -0.0 : 0.0;
-  const int full_blocks = 2 * (((T + SW_BLK - 1) / SW_BLK + 1) / 2);     // whole pairs of blocks
+  const int full_blocks = 4 * (((T + SW_BLK - 1) / SW_BLK + 3) / 4);     // whole groups of 4 blocks (the loop's unroll)
   const int ncolblk = (X + SW_BLK - 1) / SW_BLK;
   int B0 = 0, B1 = full_blocks, win_lo = 0, win_hi = ncolblk;
   if (RANGED && a.ranges) {
@@ -558,10 +558,14 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   sw_d2* p_okk = a.krku + e0;                                      // factor only
   double* p_out = (OP == SW_FACTOR ? a.pre : a.out) + e0;          // results of the block being computed
 
-  // Two operand sets, ping-ponged block by block: while block k computes from one set, the records
-  // of block k+1 are fetched into the other.
+  // Operand sets in rotation.  Forward: four sets, prefetch distance 2 - while block k computes from one
+  // set, the records of blocks k+1 and k+2 are in flight into two others (HBM latency under load exceeds
+  // one block time).  Backward / factor: two sets, distance 1 - three backward sets (8 VGPRs per step)
+  // plus the rest exceed the 256 architectural VGPRs, and hipcc would then park in-flight operands in
+  // AGPRs, i.e. copy them before they have arrived (tools/check_sweep_isa.py catches exactly that).
+  constexpr int DIST = OP == SW_FORWARD ? 2 : 1;
   struct Operands { double in[SW_BLK], pre[SW_BLK]; sw_d2 kk[SW_BLK]; int m[SW_BLK]; unsigned int fb; };
-  Operands opA, opB;
+  Operands opA, opB, opC, opD;
   // forward / backward: the record loads are issued BY HAND (inline asm) and retired by counted
   // s_waitcnt in front of each step.  hipcc's own wait insertion loses track of the issue order at
   // control-flow joins and then waits for every operation older than this block's loads -
@@ -570,9 +574,9 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   //     fetch(k):   fb, then per step j the LOADS_PER_STEP records      (LOADS = 8 * LOADS_PER_STEP + 1)
   //     compute(k): one result store behind each step
   //   => before step j of block k everything up to step j's last record is needed, and behind it were
-  //      issued (7 - j) * LOADS_PER_STEP loads of fetch(k), [8 stores of block k-1,] the LOADS of
-  //      fetch(k+1) and j stores: vmcnt((7 - j) * LOADS_PER_STEP + LOADS + j) is exact for the first
-  //      block and never waits for a load of fetch(k+1); the stores of block k-1 get a block of slack.
+  //      issued (7 - j) * LOADS_PER_STEP loads of fetch(k), then per block of prefetch distance [8 older
+  //      stores and] one whole fetch, and j stores: vmcnt((7 - j) * LOADS_PER_STEP + DIST * LOADS + j) is exact
+  //      for the first blocks and never waits for a younger fetch.
   // tools/check_sweep_isa.py proves on the generated ISA that no in-flight operand is ever touched.
   constexpr int LOADS_PER_STEP = OP == SW_BACKWARD ? 3 : 2;
   constexpr int LOADS = SW_BLK * LOADS_PER_STEP + 1;
@@ -621,6 +625,7 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
     constexpr bool HP = decltype(hp_c)::value;    // a band before us in sweep order: boundary values from the helper
     constexpr bool PB = decltype(pb_c)::value;    // a band after us: carry rows for the helper
     fetch_block(opA);                             // (per instantiation: an in-flight operand must never be copied)
+    if (DIST == 2) fetch_block(opB);
     // Loop-carried state.  What travels between cells is, per operation:
     //   factor   : precon itself (left neighbour = own register, lower neighbour = lane-1)
     //   forward  : m = (-1*precon)*q of a cell - exactly the term its right neighbour (same lane, next
@@ -642,7 +647,7 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
     read_boundary(0, beA);
     t_first = wall_clock64();
 
-    // one hand-off block = 8 steps: compute from `cur`, refill `nxt` with the block after it
+    // one hand-off block = 8 steps: compute from `cur`, refill `nxt` with the block after the next
     auto run_block = [&](int blk, Operands& cur, Operands& nxt, double (&be)[SW_BLK], double (&be_next)[SW_BLK]) {
       const int rel = blk - B0;
       fetch_block(nxt);
@@ -658,7 +663,7 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
       auto step = [&](auto jc) {
         constexpr int j = decltype(jc)::value;
         if constexpr (OP != SW_FACTOR) {     // retire this step's records (see fetch_block)
-          constexpr int N = (SW_BLK - 1 - j) * LOADS_PER_STEP + LOADS + j;
+          constexpr int N0 = (SW_BLK - 1 - j) * LOADS_PER_STEP + DIST * LOADS + j, N = N0 < 63 ? N0 : 63;
           if (OP == SW_BACKWARD)
             asm volatile("s_waitcnt vmcnt(%4)" : "+v"(cur.in[j]), "+v"(cur.pre[j]), "+v"(cur.kk[j]), "+v"(cur.fb) : "n"(N) : "memory");
           else
@@ -714,9 +719,18 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
       if (PB && __builtin_expect(rel + 1 < NBLK && (int)(unsigned int)(prog >> 32) < rel - 5, 0)) await(&sh.pub_done, rel - 5);
     };
 
-    for (int blk = B0; blk < B1; blk += 2) {   // B0, B1 are even: whole pairs of blocks; a surplus runs over dead records
-      run_block(blk, opA, opB, beA, beB);
-      run_block(blk + 1, opB, opA, beB, beA);
+    for (int blk = B0; blk < B1; blk += 4) {   // B0, B1 are multiples of 4; a surplus runs over dead records
+      if (DIST == 2) {
+        run_block(blk, opA, opC, beA, beB);      // compute from the first set, fetch block blk+2 into the second
+        run_block(blk + 1, opB, opD, beB, beA);
+        run_block(blk + 2, opC, opA, beA, beB);
+        run_block(blk + 3, opD, opB, beB, beA);
+      } else {
+        run_block(blk, opA, opB, beA, beB);      // compute from the first set, fetch block blk+1 into the second
+        run_block(blk + 1, opB, opA, beB, beA);
+        run_block(blk + 2, opA, opB, beA, beB);
+        run_block(blk + 3, opB, opA, beB, beA);
+      }
     }
     // retire the prefetch that ran past the range before anything else reuses its registers (the kernel
     // end would wait for it anyway; it also keeps tools/check_sweep_isa.py's path exploration exact)
@@ -752,7 +766,7 @@ static SweepArgs make_sweep_args(euler_sim* S, int op, int force) {
 
 // ---- active ranges of the bands (per solve) ---------------------------------------------------
 // For each 64-row band: the first / last record t = x + lane that holds a fluid cell, turned into
-// 16-step-aligned block ranges of the forward (step = t) and backward (step = T-1-t) sweeps; the
+// 32-step-aligned block ranges of the forward (step = t) and backward (step = T-1-t) sweeps; the
 // upper end leaves at least one all-non-fluid step inside the range (see k_sweep_skew).  Computed
 // from the row-major count grid, which every rank holds in full.
 __global__ __launch_bounds__(256) void k_band_ranges(const uint8_t* __restrict__ count, int X, int Y, int T, int4* __restrict__ ranges) {
@@ -772,8 +786,8 @@ __global__ __launch_bounds__(256) void k_band_ranges(const uint8_t* __restrict__
   if (threadIdx.x == 0) {
     int4 r = make_int4(0, 0, 0, 0);
     if (s_hi >= 0) {
-      const int f0 = s_lo & ~15, f1 = (s_hi + 2 + 15) & ~15;                       // forward steps [f0, f1)
-      const int b0 = (T - 1 - s_hi) & ~15, b1 = (T - 1 - s_lo + 2 + 15) & ~15;     // backward steps [b0, b1)
+      const int f0 = s_lo & ~31, f1 = (s_hi + 2 + 31) & ~31;                       // forward steps [f0, f1)
+      const int b0 = (T - 1 - s_hi) & ~31, b1 = (T - 1 - s_lo + 2 + 31) & ~31;     // backward steps [b0, b1)
       r = make_int4(f0 / 8, f1 / 8, b0 / 8, b1 / 8);
     }
     ranges[band] = r;
