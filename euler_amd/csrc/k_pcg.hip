@@ -369,6 +369,10 @@ __global__ __launch_bounds__(1024) void k_sweep_simple(SweepArgs a) {
 // running: no residency assumption, no deadlock; every spin is bounded (sticky error -> ETIMEOUT).
 // One band per workgroup (= per CU) on purpose: a band streams ~16 B/cycle, so 4 compute waves would
 // saturate a CU's ~64 B/clk vector-memory path (measured 1.4x / 2x slower with 4 / 8 bands per CU).
+// Measured and rejected at 8192^2 (per-step time there is ~1.25x / 1.4x that of an L2-resident grid):
+// a fourth wave touching the coming records' cache lines 10 blocks ahead (L2 prefetch: no gain forward,
+// 1.2x slower backward - the touches cross the same per-CU memory path), and padding the band stride
+// against HBM channel aliasing (no effect).
 // Records t >= T of a band and the 32 records in front of each array are dead padding (mask 0):
 // the loop runs whole groups of 4 blocks and prefetches unconditionally.
 #define SW_BLK 8
