@@ -355,17 +355,24 @@ class Simulation:
         _check(self.L.euler_load_state(self.h, os.fsencode(path)))
         return self
 
-    def sweep_timeline(self):
+    def sweep_timeline(self, raw=False):
         """[(entry_us, first_ready_us, exit_us, blocks, stalled_blocks)] per band of the last sweep launch,
-        times relative to the first band's entry."""
+        times relative to the first band's entry.  raw=True: additionally the 4 development time stamps
+        (us, same origin; 0 unless the library was built with SW_TRACE_HANDOFF)."""
         nb = (self.Y + 63) // 64
-        buf = (C.c_uint64 * (4 * nb))()
+        buf = (C.c_uint64 * (8 * nb))()
         n = self.L.euler_sweep_timeline(self.h, buf, nb)
         if n < 0:
             _check(n)
-        rows = [tuple(buf[4 * i + k] for k in range(4)) for i in range(n)]
+        rows = [tuple(buf[8 * i + k] for k in range(8)) for i in range(n)]
         t0 = min(r[0] for r in rows) if rows else 0
-        return [((r[0] - t0) / 100.0, (r[1] - t0) / 100.0, (r[2] - t0) / 100.0, r[3] >> 32, r[3] & 0xffffffff) for r in rows]
+        out = []
+        for r in rows:
+            row = ((r[0] - t0) / 100.0, (r[1] - t0) / 100.0, (r[2] - t0) / 100.0, r[3] >> 32, r[3] & 0xffffffff)
+            if raw:
+                row += tuple((x - t0) / 100.0 if x else 0.0 for x in r[4:8])
+            out.append(row)
+        return out
 
     def device_name(self):
         buf = C.create_string_buffer(256)

@@ -226,7 +226,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   S->gran_stride = (S->X + 7) / 8 * 8;
   DALLOC(S->granules, (size_t)S->geom.nbands * S->gran_stride * 2);
   DALLOC(S->ticket, 1);
-  DALLOC(S->sweep_timeline, (size_t)S->geom.nbands * 4);
+  DALLOC(S->sweep_timeline, (size_t)S->geom.nbands * 8);
   S->ticket_base = 0; S->epoch = 0;
   HIPCHK(hipHostMalloc((void**)&S->ms_host, sizeof(MarkerState), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&S->sc_host, sizeof(PcgScalars), hipHostMallocDefault));
@@ -766,7 +766,7 @@ extern "C" int euler_sweep_timeline(euler_sim* S, uint64_t* out, int32_t cap_ban
   if (!S || !out || cap_bands < 0) return EULER_EINVAL;
   const int n = S->band_hi - S->band_lo < cap_bands ? S->band_hi - S->band_lo : cap_bands;
   HIPCHK(hipStreamSynchronize(S->stream));
-  HIPCHK(hipMemcpy(out, S->sweep_timeline, (size_t)n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out, S->sweep_timeline, (size_t)n * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return n;
 }
 

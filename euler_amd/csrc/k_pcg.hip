@@ -379,6 +379,10 @@ __global__ __launch_bounds__(1024) void k_sweep_simple(SweepArgs a) {
 #define SW_RING 64            // carry rows kept in LDS (8 blocks)
 #define SW_BND_RING 16        // boundary blocks kept in LDS
 #define SW_SPIN_LIMIT (1u << 22)
+#ifndef SW_TRACE_HANDOFF
+#define SW_TRACE_HANDOFF 0   // development build: time stamps of one hand-off (column block 40) in the timeline words 4..7
+#endif
+#define SW_TRACE_CB 40
 #define DPP_WAVE_SHL1 0x130
 #define DPP_WAVE_SHR1 0x138
 
@@ -480,6 +484,8 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
         const int b = B0 + next_pub + t8;
         const double v = sh.pub[(SW_BLK * b - 1 + k8) & (SW_RING - 1)][EDGE];
         announce(SW_BLK * (b - 8) + k8, v, t8 < n);
+        if (SW_TRACE_HANDOFF && lane == 0 && SW_TRACE_CB + 8 - B0 >= next_pub && SW_TRACE_CB + 8 - B0 < next_pub + n)
+          a.timeline[(size_t)ord * 8 + 5] = wall_clock64();
         next_pub += n;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the ring rows are read: the compute wave may reuse them
         lds_put(&sh.pub_done, (unsigned int)next_pub);
@@ -528,6 +534,8 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
       if (m > fresh0) {
         if (t8 >= fresh0 && t8 < m) sh.bnd[(q.base + t8) & (SW_BND_RING - 1)][k8] = want ? __hiloint2double((int)q.gv[2], (int)q.gv[0]) : CONST;
         SW_COMPILER_FENCE();
+        if (SW_TRACE_HANDOFF && lane == 0 && SW_TRACE_CB - B0 >= next_dep && SW_TRACE_CB - B0 < q.base + m)
+          a.timeline[(size_t)ord * 8 + 6] = wall_clock64();
         next_dep = q.base + m;
         lds_put(&sh.dep_done, (unsigned int)next_dep);
         spins = 0;
@@ -712,12 +720,14 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
         // half-way: the next block's boundary values (deposited once dep_done > rel+1; past the range: whatever is there)
         if (__builtin_expect(rel + 1 < NBLK && (int)(unsigned int)prog < rel + 2, 0)) await(&sh.dep_done, rel + 2);
         read_boundary(rel + 1, be_next);
+        if (SW_TRACE_HANDOFF && blk + 1 == SW_TRACE_CB && lane == 0) a.timeline[(size_t)ord * 8 + 7] = wall_clock64();
       }
       step(std::integral_constant<int, 4>()); step(std::integral_constant<int, 5>());
       step(std::integral_constant<int, 6>()); step(std::integral_constant<int, 7>());
       __builtin_amdgcn_sched_barrier(0);
       p_out += SW_BLK * STEP; p_okk += SW_BLK * STEP;
       if (HP || PB) { SW_COMPILER_FENCE(); lds_put(&sh.comp_done, (unsigned int)(rel + 1)); }
+      if (SW_TRACE_HANDOFF && blk == SW_TRACE_CB + 8 && lane == 0) a.timeline[(size_t)ord * 8 + 4] = wall_clock64();
       // block blk+1 overwrites the ring rows of block blk-7, which the groups up to block blk-6 read
       // (announced once pub_done >= rel-5)
       if (PB && __builtin_expect(rel + 1 < NBLK && (int)(unsigned int)(prog >> 32) < rel - 5, 0)) await(&sh.pub_done, rel - 5);
@@ -745,7 +755,7 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   if (has_prev) { if (publish) sweep(yes_t(), yes_t()); else sweep(yes_t(), no_t()); }
   else          { if (publish) sweep(no_t(), yes_t()); else sweep(no_t(), no_t()); }
   if (lane == 0) {
-    unsigned long long* tl = a.timeline + (size_t)ord * 4;
+    unsigned long long* tl = a.timeline + (size_t)ord * 8;
     tl[0] = t_entry; tl[1] = t_first; tl[2] = wall_clock64(); tl[3] = ((unsigned long long)(B1 - B0) << 32) | stalls;
   }
 }

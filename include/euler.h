@@ -241,9 +241,10 @@ int euler_profile_reset(euler_sim* sim);
 int euler_measure_copy_bandwidth(euler_sim* sim, size_t bytes, int32_t reps, double* gbps);
 int euler_device_name(euler_sim* sim, char* out, int32_t cap);
 /* Diagnostics: the band pipeline of the most recent IC(0) sweep launch.  For each of this rank's bands in
- * sweep order, 4 words: wave entry, first block's boundary ready, wave exit (100 MHz constant clock
- * ticks) and (blocks run << 32 | blocks that had to wait for the previous band).  Returns the number of
- * bands written (<= cap_bands) or a negative error. */
+ * sweep order, 8 words: wave entry, first block's boundary ready, wave exit (100 MHz constant clock
+ * ticks), (blocks run << 32 | blocks that had to wait for the previous band), and four hand-off time
+ * stamps that only a development build fills (k_pcg.hip SW_TRACE_HANDOFF; else 0).  `out` holds
+ * 8 * cap_bands words.  Returns the number of bands written (<= cap_bands) or a negative error. */
 int euler_sweep_timeline(euler_sim* sim, uint64_t* out, int32_t cap_bands);
 
 #ifdef __cplusplus
