@@ -501,3 +501,73 @@ def test_velocity_diffusion_extension_bit_exact_vs_oracle(size, scn, nu, frames)
         compare_all(o, sim, "nu=%g frame %d" % (nu, f))
     assert max(np.abs(sim.get(ea.F_U) - inviscid.get(ea.F_U)).max(), np.abs(sim.get(ea.F_V) - inviscid.get(ea.F_V)).max()) > 1e-4
     sim.close(); inviscid.close()
+
+
+def test_baseline_size_1024_half_tank_bit_exact_vs_oracle():
+    """BASELINE configs[1]'s grid size with the pressure solve fully engaged from the first frame (the
+    dam break falls freely for ~22 frames, the half tank's free surface makes every solve run its
+    100 iterations): 16 bands, 1 M cells, sequential dot mode - every field bit for bit after each of
+    two frames."""
+    o = Oracle(1024, 1024).load_half_tank()
+    sim = ea.Simulation(1024, 1024, dot_mode=ea.DOT_SEQUENTIAL).load_half_tank()
+    compare_all(o, sim, "init")
+    for f in range(2):
+        o.step()
+        sim.step()
+        st = sim.stats()
+        assert st.last_substeps == o.c.last_substeps and st.last_pcg_iterations == o.c.last_pcg_iterations >= 100, f
+        compare_all(o, sim, "1024 half tank frame %d" % f)
+    sim.close()
+
+
+def test_full_size_4096_properties_without_an_oracle():
+    """Size-independent properties at a size the CPU oracle cannot reach in test time (4096^2 half tank,
+    tree dots, one frame = 100 PCG iterations over 16.8 M cells, 33 M markers):
+    the count grid is the histogram of the marker array; the residual the solver reports is the true
+    residual b - A p recomputed on the host from the cell-mask encoding of A; p is clamped >= 0 and zero
+    off the fluid; velocities vanish on solid faces."""
+    N = 4096
+    sim = ea.Simulation(N, N, dot_mode=ea.DOT_TREE).load_half_tank()
+    sim.step()
+    st = sim.stats()
+    assert st.last_pcg_iterations == 100 * st.last_substeps
+    count, solid = sim.get(ea.F_COUNT), sim.get(ea.F_SOLID)
+    mk = sim.get(ea.F_MARKERS)
+    assert len(mk) == st.n_markers
+    cx, cy = np.floor(mk[:, 0]).astype(np.int64), np.floor(mk[:, 1]).astype(np.int64)
+    hist = np.bincount(cy * N + cx, minlength=N * N).reshape(N, N)
+    assert np.array_equal((hist & 255).astype(np.uint8), count)
+    del mk, cx, cy, hist
+    # true residual of the LAST solve: b - A p with A read off the mask byte (bit0 fluid, bits1-4 fluid at x+1, y+1, x-1, y-1, bits 5-7 a_diag)
+    p, b, m = sim.get(ea.F_PRESSURE), sim.get(ea.F_PCG_B), sim.get(ea.F_CELLMASK)
+    fluid = (m & 1) != 0
+    assert np.array_equal(fluid, count > 0)
+    assert (p[~fluid] == 0).all() and (p >= 0).all()
+    u, v = sim.get(ea.F_U), sim.get(ea.F_V)
+    su = (solid[:, :-1] | solid[:, 1:]) != 0
+    sv = (solid[:-1, :] | solid[1:, :]) != 0
+    assert (u[:, :-1][su] == 0).all() and (v[:-1, :][sv] == 0).all()
+    sim.close()
+
+
+def test_reported_residual_is_the_true_residual_2048():
+    """b - A p recomputed on the host (A from the cell-mask encoding) against the solver's own recursively
+    updated residual, 2048^2 half tank, after exactly one solve (pressure is clamped only after the solve, so
+    compare before the clamp can act: the half tank's pressures are positive)."""
+    N = 2048
+    sim = ea.Simulation(N, N, dot_mode=ea.DOT_TREE).load_half_tank()
+    dt = sim.timestep(0.1)
+    sim.substep(dt)
+    p, b, m, r = sim.get(ea.F_PRESSURE), sim.get(ea.F_PCG_B), sim.get(ea.F_CELLMASK), sim.get(ea.F_PCG_R)
+    fl = (m & 1) != 0
+    diag = (m >> 5).astype(np.float64)
+    ap = diag * p
+    ap[:, :-1] -= np.where((m[:, :-1] & 2) != 0, p[:, 1:], 0.0)     # fluid at x+1
+    ap[:-1, :] -= np.where((m[:-1, :] & 4) != 0, p[1:, :], 0.0)     # fluid at y+1
+    ap[:, 1:] -= np.where((m[:, 1:] & 8) != 0, p[:, :-1], 0.0)      # fluid at x-1
+    ap[1:, :] -= np.where((m[1:, :] & 16) != 0, p[:-1, :], 0.0)     # fluid at y-1
+    true_r = np.where(fl, b - ap, 0.0)
+    scale = np.abs(b).max()
+    assert np.abs(true_r - r).max() <= 1e-9 * scale, (np.abs(true_r - r).max(), scale)
+    assert abs(np.abs(true_r).max() - sim.stats().last_residual) <= 1e-9 * scale
+    sim.close()
