@@ -357,8 +357,8 @@ class Simulation:
 
     def sweep_timeline(self, raw=False):
         """[(entry_us, first_ready_us, exit_us, blocks, stalled_blocks)] per band of the last sweep launch,
-        times relative to the first band's entry.  raw=True: additionally the 4 development time stamps
-        (us, same origin; 0 unless the library was built with SW_TRACE_HANDOFF)."""
+        times relative to the first band's entry.  raw=True: additionally the 4 development words as integers
+        (stall counts per helper, or 100 MHz time stamps in an SW_TRACE_HANDOFF build) and the origin tick."""
         nb = (self.Y + 63) // 64
         buf = (C.c_uint64 * (8 * nb))()
         n = self.L.euler_sweep_timeline(self.h, buf, nb)
@@ -370,7 +370,7 @@ class Simulation:
         for r in rows:
             row = ((r[0] - t0) / 100.0, (r[1] - t0) / 100.0, (r[2] - t0) / 100.0, r[3] >> 32, r[3] & 0xffffffff)
             if raw:
-                row += tuple((x - t0) / 100.0 if x else 0.0 for x in r[4:8])
+                row += tuple(int(x) for x in r[4:8]) + (int(t0),)
             out.append(row)
         return out
 

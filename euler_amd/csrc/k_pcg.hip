@@ -369,6 +369,11 @@ __global__ __launch_bounds__(1024) void k_sweep_simple(SweepArgs a) {
 // running: no residency assumption, no deadlock; every spin is bounded (sticky error -> ETIMEOUT).
 // One band per workgroup (= per CU) on purpose: a band streams ~16 B/cycle, so 4 compute waves would
 // saturate a CU's ~64 B/clk vector-memory path (measured 1.4x / 2x slower with 4 / 8 bands per CU).
+// Measured and rejected: staging the compute wave's streams through LDS as well (a load wave feeding an
+// operand ring by LDS-DMA, a store wave draining a result ring; the compute wave without any global access).
+// A stand-alone model of the step promised 27 ns instead of 40; the real kernel, with its per-block
+// bookkeeping and five waves on the CU, ran 40 ns/step for a lone band and 50-55 ns with neighbours, and the
+// load wave could not keep the ring full from HBM at 8192^2 (1.6x slower sweeps).  Bit-exact, but not faster.
 // Measured and rejected at 8192^2 (per-step time there is ~1.25x / 1.4x that of an L2-resident grid):
 // a fourth wave touching the coming records' cache lines 10 blocks ahead (L2 prefetch: no gain forward,
 // 1.2x slower backward - the touches cross the same per-CU memory path), and padding the band stride

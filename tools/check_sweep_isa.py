@@ -62,7 +62,7 @@ def parse(body):
         mn = parts[0]
         ops = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
         ops = [o.split()[0] if o.split() else o for o in ops]          # drop modifiers such as "offset:512", "sc1"
-        if mn.startswith(NO_DEST) or not ops:
+        if mn.startswith(NO_DEST) or mn.startswith("global_load_lds") or not ops:   # (an LDS-DMA has no register destination)
             dest, srcs = frozenset(), ops
         else:
             dest, srcs = vregs(ops[0]), ops[1:]
@@ -124,8 +124,7 @@ def check(text, name):
 def main():
     text = isa_text()
     rc = 0
-    for op in (1, 2):
-        name = "_Z12k_sweep_skewILi%dEEv9SweepArgs" % op
+    for name in ["_Z12k_sweep_skewILi%dEEv9SweepArgs" % op for op in (1, 2)]:
         n, states, bad = check(text, name)
         print("%s: %d instructions, %d (pc, vmcnt queue) states explored, %d touches of an in-flight operand" % (name, n, states, len(bad)))
         for pc in sorted(bad):

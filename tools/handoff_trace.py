@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where does the band-to-band hand-off time go?  Needs the development build of the library
-(tools/micro/handoff_trace.sh; EULER_HIP_LIB=tools/micro/lib_ablate/libeuler_hip_trace.so).  For column
+(tools/micro/variant.sh trace -DSW_TRACE_HANDOFF=1; EULER_HIP_LIB=tools/micro/lib_ablate/libeuler_hip_trace.so).  For column
 block 40 of every band pair it prints: producer compute wave finished the block that completes those
 columns -> its announce wave issued the granule store -> the consumer's fetch wave deposited the block in
 LDS -> the consumer's compute wave picked it up."""
@@ -30,8 +30,8 @@ for op, name in ((ea.OP_FORWARD_SOLVE, "forward"), (ea.OP_BACKWARD_SOLVE, "backw
     print(name, "(us): compute done -> announced | announced -> deposited in the next band | deposited -> picked up | total")
     a, b, c = [], [], []
     for p, q in zip(tl, tl[1:]):
-        if p[5] and p[6] and q[7] and q[8]:
-            a.append(p[6] - p[5]); b.append(q[7] - p[6]); c.append(q[8] - q[7])
+        if p[5] and p[6] and q[7] and q[8]:      # raw 100 MHz ticks -> us
+            a.append((p[6] - p[5]) / 100.0); b.append((q[7] - p[6]) / 100.0); c.append((q[8] - q[7]) / 100.0)
     for k in range(len(a)):
         print("  band %2d -> %2d: %6.2f | %6.2f | %6.2f | %6.2f" % (k, k + 1, a[k], b[k], c[k], a[k] + b[k] + c[k]))
     if a:

@@ -30,7 +30,7 @@ for spec in shapes:
     for op, name in ((ea.OP_FORWARD_SOLVE, "forward"), (ea.OP_BACKWARD_SOLVE, "backward")):
         for _ in range(3):
             sim.pcg_op(op)
-        tl = [r for r in sim.sweep_timeline() if r[3] > 0]
+        tl = [r for r in sim.sweep_timeline(raw=True) if r[3] > 0]
         if not tl:
             continue
         t0 = min(r[0] for r in tl)
@@ -45,5 +45,5 @@ for spec in shapes:
                   int(np.median([r[4] for r in tl])), max(r[4] for r in tl), max(r[0] for r in tl) - t0))
         if os.environ.get("TIMELINE_DUMP"):
             for i, r in enumerate(tl):
-                print("   band %3d entry %9.2f first %9.2f exit %9.2f blocks %d stalls %d" % ((i,) + r))
+                print("   band %3d entry %9.2f first %9.2f exit %9.2f blocks %d stalls %d  (raw words 4..7: %s)" % ((i,) + r[:5] + (r[5:],)))
     sim.close()
