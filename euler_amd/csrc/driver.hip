@@ -143,7 +143,6 @@ extern "C" void euler_destroy(euler_sim* S) {
   for (double* d : {S->b, S->p, S->r, S->z, S->s, S->q, S->precon}) if (d) (void)hipFree(d - EU_SKEW_SLACK);
   if (S->krku) (void)hipFree(S->krku - 2 * EU_SKEW_SLACK);
   if (S->cellmask) (void)hipFree(S->cellmask - EU_SKEW_SLACK);
-  if (S->fmask) (void)hipFree(S->fmask - EU_SKEW_SLACK);
   if (S->ms_host) (void)hipHostFree(S->ms_host);
   if (S->sc_host) (void)hipHostFree(S->sc_host);
   if (S->poll_host) (void)hipHostFree(S->poll_host);
@@ -212,7 +211,6 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   for (double** d : {&S->b, &S->p, &S->r, &S->z, &S->s, &S->q, &S->precon}) { DALLOC(*d, SS + EU_SKEW_SLACK); *d += EU_SKEW_SLACK; }
   DALLOC(S->krku, 2 * (SS + EU_SKEW_SLACK)); S->krku += 2 * EU_SKEW_SLACK;
   DALLOC(S->cellmask, SS + EU_SKEW_SLACK); S->cellmask += EU_SKEW_SLACK;
-  DALLOC(S->fmask, SS + EU_SKEW_SLACK); S->fmask += EU_SKEW_SLACK;
   S->fb_stride = 4 * (((S->geom.T + 7) / 8 + 3) / 4) + 4;   // whole groups of 4 blocks + the two blocks the prefetch runs ahead
   DALLOC(S->fbits_fwd, (size_t)S->geom.nbands * S->fb_stride * 64);
   DALLOC(S->fbits_bwd, (size_t)S->geom.nbands * S->fb_stride * 64);
@@ -278,7 +276,6 @@ static int upload_scenario(euler_sim* S, const uint8_t* solid, const uint8_t* so
   HIPCHK(hipMemsetAsync(S->count, 0, C, st));
   HIPCHK(hipMemsetAsync(S->prev_count, 0, C, st));
   HIPCHK(hipMemsetAsync(S->cellmask, 0, S->geom.S, st));
-  HIPCHK(hipMemsetAsync(S->fmask, 0, S->geom.S, st));
   S->cur = 0;
   HIPCHK(hipMemcpyAsync(S->markers[0], mk.data(), n * sizeof(float2), hipMemcpyHostToDevice, st));
   MarkerState m0;

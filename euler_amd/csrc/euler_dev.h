@@ -117,7 +117,6 @@ struct euler_sim {
   double *b, *p, *r, *z, *s, *q, *precon;
   double* krku;           // {a_i*precon, a_j*precon} of the backward solve, 16 B per skewed element (per solve)
   uint8_t* cellmask;
-  int8_t* fmask;          // skewed: -1 on fluid cells, 0 elsewhere
   unsigned int* fbits_fwd; unsigned int* fbits_bwd;   // fluid flags of the sweeps, 8 steps to a dword (k_pack_fbits)
   int fb_stride;          // words per band and lane
   int4* band_ranges;      // per band: active block ranges of the forward / backward sweeps (per solve)

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void k_build_system(const float* __restrict__ 
                                                       const uint8_t* __restrict__ count, const uint8_t* __restrict__ solid,
                                                       double* __restrict__ b, double* __restrict__ r, double* __restrict__ p,
                                                       double* __restrict__ q, double* __restrict__ z,
-                                                      uint8_t* __restrict__ cellmask, int8_t* __restrict__ fmask,
+                                                      uint8_t* __restrict__ cellmask,
                                                       PcgScalars* sc, SkewGeom g, float dt, size_t e_lo, size_t e_cnt) {
   const size_t e = e_lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // this rank's bands only
   bool nz = false;
@@ -232,7 +232,6 @@ __global__ __launch_bounds__(256) void k_build_system(const float* __restrict__ 
         nz = bv != 0.0;
       }
       cellmask[e] = m;
-      fmask[e] = (m & CM_FLUID) ? (int8_t)-1 : (int8_t)0;
       b[e] = bv;
       r[e] = bv;
       p[e] = 0.0;
@@ -288,7 +287,7 @@ int eu_launch_band_ranges(euler_sim* S);
 
 int eu_launch_build_system(euler_sim* S, float dt) {
   LAUNCH(S, KC_BUILD_SYSTEM, k_build_system, dim3(eu_blocks(S->e_cnt, 256)), dim3(256), S->utmp, S->vtmp, S->count,
-         S->solid, S->b, S->r, S->p, S->q, S->z, S->cellmask, S->fmask, S->sc, S->geom, dt, S->e_lo, S->e_cnt);
+         S->solid, S->b, S->r, S->p, S->q, S->z, S->cellmask, S->sc, S->geom, dt, S->e_lo, S->e_cnt);
   return eu_launch_band_ranges(S);
 }
 

@@ -814,19 +814,19 @@ __global__ __launch_bounds__(256) void k_band_ranges(const uint8_t* __restrict__
 }
 // fluid flags of the sweeps, 8 steps to a dword: word (band, g, lane) bit j = the lane's cell in step 8g + j
 // of the forward sweep (record 8g + j) / of the backward sweep (record T-1 - 8g - j); 0 outside [0, T)
-__global__ __launch_bounds__(256) void k_pack_fbits(const int8_t* __restrict__ fmask, SkewGeom g, unsigned int* __restrict__ fwd,
+__global__ __launch_bounds__(256) void k_pack_fbits(const uint8_t* __restrict__ cellmask, SkewGeom g, unsigned int* __restrict__ fwd,
                                                     unsigned int* __restrict__ bwd, int fb_stride, int band_lo, int nb_local) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (size_t)nb_local * fb_stride * 64) return;
   const int lane = (int)(i & 63);
   const int gi = (int)((i >> 6) % fb_stride), band = band_lo + (int)((i >> 6) / fb_stride);
-  const int8_t* base = fmask + (size_t)band * g.TS * 64 + lane;
+  const uint8_t* base = cellmask + (size_t)band * g.TS * 64 + lane;
   unsigned int wf = 0, wb = 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int tf = 8 * gi + j, tb = g.T - 1 - 8 * gi - j;
-    if (tf < g.T && base[(size_t)tf * 64]) wf |= 1u << j;
-    if (tb >= 0 && base[(size_t)tb * 64]) wb |= 1u << j;
+    if (tf < g.T && (base[(size_t)tf * 64] & CM_FLUID)) wf |= 1u << j;
+    if (tb >= 0 && (base[(size_t)tb * 64] & CM_FLUID)) wb |= 1u << j;
   }
   const size_t o = ((size_t)band * fb_stride + gi) * 64 + lane;
   fwd[o] = wf; bwd[o] = wb;
@@ -835,7 +835,7 @@ int eu_launch_band_ranges(euler_sim* S) {
   LAUNCH(S, KC_BUILD_SYSTEM, k_band_ranges, dim3(S->geom.nbands), dim3(256), S->count, S->X, S->Y, S->geom.T, S->band_ranges);
   const int nbl = S->band_hi - S->band_lo;
   const size_t n = (size_t)nbl * S->fb_stride * 64;
-  LAUNCH(S, KC_BUILD_SYSTEM, k_pack_fbits, dim3((unsigned)((n + 255) / 256)), dim3(256), S->fmask, S->geom, S->fbits_fwd, S->fbits_bwd,
+  LAUNCH(S, KC_BUILD_SYSTEM, k_pack_fbits, dim3((unsigned)((n + 255) / 256)), dim3(256), S->cellmask, S->geom, S->fbits_fwd, S->fbits_bwd,
          S->fb_stride, S->band_lo, nbl);
   return EULER_OK;
 }
