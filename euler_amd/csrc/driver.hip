@@ -202,7 +202,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   DALLOC(S->sel.block_sums, S->sel.capacity_blocks);
   S->geom.X = S->X; S->geom.Y = S->Y;
   S->geom.nbands = (S->Y + 63) / 64;
-  S->geom.T = S->X + 63;
+  S->geom.T = (S->X + 63 + 1) & ~1;   // records per band, even: records are stored in pairs (euler_dev.h)
   S->geom.TS = ((S->geom.T + 31) & ~31) + 32;   // the sweeps run whole groups of four 8-step blocks and prefetch 16 steps further
   S->geom.S = (size_t)S->geom.nbands * S->geom.TS * 64;
   const size_t SS = S->geom.S;
@@ -221,7 +221,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   DALLOC(S->red_counter, 1);
   S->band_lo = 0; S->band_hi = S->geom.nbands; S->e_lo = 0; S->e_cnt = SS;
   DALLOC(S->halo_buf, (size_t)4 * S->X);
-  S->gran_stride = (S->X + 7) / 8 * 8;
+  S->gran_stride = (S->X + 1 + 7) / 8 * 8;   // hand-off columns [0, T - 63)
   DALLOC(S->granules, (size_t)S->geom.nbands * S->gran_stride * 2);
   DALLOC(S->ticket, 1);
   DALLOC(S->sweep_timeline, (size_t)S->geom.nbands * 8);

@@ -63,7 +63,9 @@ struct MarkerState {
 };
 
 // Band-skewed layout of the solver's private arrays (k_pcg.hip header): element (x,y) lives at
-// ((y/64)*TS + x + y%64)*64 + y%64.  A band has T = X + 63 live records and a stride of
+// record t = x + y%64 of band y/64, lane y%64; RECORDS COME IN PAIRS: the two elements (t even, t+1) of a lane
+// are adjacent, index = ((y/64)*TS + (t & ~1))*64 + 2*(y%64) + (t & 1), so that one 16-byte access per lane
+// serves two steps of the IC(0) sweeps (a lone wave pays per memory INSTRUCTION: tools/micro/step_bench2).  A band has T = X + 63 live records and a stride of
 // TS = roundup32(T) + 32 records; S = nbands*TS*64 elements in total; padding carries mask 0.
 // Every skewed array also has EU_SKEW_SLACK elements of zeroed slack in front of element 0.
 #define EU_SKEW_SLACK (64 * 64)
@@ -72,8 +74,16 @@ struct SkewGeom {
   size_t S;
 };
 static inline __host__ __device__ size_t skew_index(const SkewGeom& g, int x, int y) {
-  const int l = y & 63;
-  return ((size_t)(y >> 6) * g.TS + (size_t)(x + l)) * 64 + l;
+  const int l = y & 63, t = x + l;
+  return ((size_t)(y >> 6) * g.TS + (size_t)(t & ~1)) * 64 + 2 * l + (t & 1);
+}
+// inverse within the skewed arrays: element -> (band, record t, lane)
+static inline __host__ __device__ void skew_decode(const SkewGeom& g, size_t e, int& band, int& t, int& l) {
+  const size_t per_band = (size_t)g.TS * 64;
+  band = (int)(e / per_band);
+  const size_t r = e % per_band;
+  l = (int)((r & 127) >> 1);
+  t = (int)((r >> 7) << 1) + (int)(r & 1);
 }
 
 struct SelectScratch {

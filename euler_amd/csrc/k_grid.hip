@@ -210,9 +210,8 @@ __global__ __launch_bounds__(256) void k_build_system(const float* __restrict__ 
   bool nz = false;
   if (e < e_lo + e_cnt) {
     const int X = g.X;
-    const int l = (int)(e & 63);
-    const size_t rec = e >> 6;
-    const int band = (int)(rec / g.TS), t = (int)(rec % g.TS);
+    int band, t, l;
+    skew_decode(g, e, band, t, l);
     const int x = t - l, y = band * 64 + l;
     if (x >= 0 && x < X && y < g.Y) {
       const size_t i = (size_t)y * X + x;
@@ -264,7 +263,7 @@ __global__ __launch_bounds__(256) void k_velocity_update(const float* __restrict
     float o = 0.f;
     if (solid[i] | solid[i + 1]) o = 0.f;
     else if (f0 | f1) {
-      double p1 = p[e + 64];
+      double p1 = p[skew_index(g, x + 1, y)];
       if (f1 && p1 < 0.0) p1 = 0.0;
       o = uin[i] + (neg_inv * (float)(p1 - p0)) * dt;
     }

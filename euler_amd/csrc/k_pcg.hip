@@ -4,15 +4,17 @@
 // HBM layout.  Every solver array (b, p, r, z, s, q, precon, cell mask) is private to the solver,
 // so it is stored BAND-SKEWED rather than row-major (struct SkewGeom, euler_dev.h):
 //     element (row y, column x)  ->  band b = y / 64, lane l = y % 64, record t = x + l
-//                                    index  = (b * TS + t) * 64 + l
-// (T = X + 63 live records per band, band stride TS = roundup32(T) + 32 records).
-// A record (64 consecutive elements = 512 B of doubles) is exactly what one wave touches in one
-// step of the IC(0) wavefront sweeps (lane l at column t - l), so the sweeps stream contiguous
-// records: perfectly coalesced, no LDS transposition, pointer += 512 B per step.  The backward
-// sweep walks the same records downwards.  The 5-point neighbours sit at +-64 (left/right) and
-// +-65 (down/up) elements, still coalesced; band-crossing neighbours of lane 0 / lane 63 are one
-// strided access per record.  Padding entries (t - l outside [0,X), rows >= Y) carry mask 0 for
-// ever: every kernel treats them as non-fluid cells, which removes all edge predicates.
+//                                    index  = (b * TS + (t & ~1)) * 64 + 2 * l + (t & 1)
+// (T = X + 63 rounded up to even records per band, band stride TS = roundup32(T) + 32 records).
+// A record (the 64 elements of one t) is exactly what one wave touches in one step of the IC(0)
+// wavefront sweeps (lane l at column t - l).  Records are stored in PAIRS: a lane's elements of
+// records 2P and 2P+1 are adjacent, so one 16-byte access per lane serves two steps of a sweep
+// (1 KB per wave, perfectly coalesced, no LDS transposition; a lone wave pays per memory
+// instruction, not per byte).  The backward sweep walks the same pairs downwards.  The 5-point
+// neighbours are the pair partner / the facing element of the adjacent pair (left, right) and the
+// same of the neighbouring lane (down, up): still coalesced; band-crossing neighbours of lane 0 /
+// lane 63 go through the index function.  Padding entries (t - l outside [0,X), rows >= Y) carry
+// mask 0 for ever: every kernel treats them as non-fluid cells, which removes all edge predicates.
 //
 // Device-resident control: alpha, beta, sigma, the residual norm, the iteration count and the
 // `done` flag live in PcgScalars in HBM; every kernel reads them first and returns at once after
@@ -170,20 +172,35 @@ __global__ __launch_bounds__(RED_THREADS) void k_apply_a(const double* __restric
                                                          unsigned int* counter, int fin_op) {
   if (!force && pcg_idle(sc)) return;
   const size_t S = g.S;
-  const size_t chunk = (((S + gridDim.x - 1) / gridDim.x) + 63) & ~(size_t)63;   // whole records per block
+  const size_t chunk = (((S + gridDim.x - 1) / gridDim.x) + 127) & ~(size_t)127;   // whole record pairs per block
   const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < S ? lo + chunk : S;
-  const long long band_hop = 64ll * (g.TS - 63);  // same column, adjacent band: see header
   double t = 0.0;
   for (size_t i = lo + threadIdx.x; i < hi; i += RED_THREADS) {
     const uint8_t m = mask[i];
     if (!(m & CM_FLUID)) continue;
-    const int l = (int)(i & 63);
+    // neighbours in the paired-record layout (euler_dev.h): same lane, record t+-1 = the pair partner or the
+    // facing element of the adjacent pair; the row above / below = lane+-1 of record t+-1 (the adjacent band's
+    // lane 0 / 63 through the index function)
+    const int odd = (int)(i & 1), l = (int)((i & 127) >> 1);
+    const size_t right = odd ? i + 127 : i + 1, left = odd ? i - 1 : i - 127;
     const double si = s[i];
     double o = (double)(int)(m >> CM_DIAG_SHIFT) * si;
-    o = o - ((m & CM_RIGHT) ? s[i + 64] : 0.0);
-    o = o - ((m & CM_UP) ? s[l < 63 ? i + 65 : i + band_hop - 63] : 0.0);
-    o = o - ((m & CM_LEFT) ? s[i - 64] : 0.0);
-    o = o - ((m & CM_DOWN) ? s[l > 0 ? i - 65 : i - band_hop + 63] : 0.0);
+    o = o - ((m & CM_RIGHT) ? s[right] : 0.0);
+    if (m & CM_UP) {
+      size_t up = right + 2;
+      if (l == 63) { int band, tt, ll; skew_decode(g, i, band, tt, ll); up = skew_index(g, tt - 63, 64 * (band + 1)); }
+      o = o - s[up];
+    } else {
+      o = o - 0.0;
+    }
+    o = o - ((m & CM_LEFT) ? s[left] : 0.0);
+    if (m & CM_DOWN) {
+      size_t dn = left - 2;
+      if (l == 0) { int band, tt, ll; skew_decode(g, i, band, tt, ll); dn = skew_index(g, tt, 64 * band - 1); }
+      o = o - s[dn];
+    } else {
+      o = o - 0.0;
+    }
     z[i] = o;
     t += o * si;
   }
@@ -426,10 +443,9 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   const unsigned long long t_entry = wall_clock64();
   constexpr bool BWD = OP == SW_BACKWARD;
   constexpr int CTRL = BWD ? DPP_WAVE_SHL1 : DPP_WAVE_SHR1;
-  constexpr int STEP = BWD ? -64 : 64;                // elements per step
   constexpr int EDGE = BWD ? 0 : 63;                  // the lane whose results the next band needs
   const SkewGeom g = a.g;
-  const int X = g.X, T = g.T, TS = g.TS, nb = g.nbands;
+  const int X = g.T - 63, T = g.T, TS = g.TS, nb = g.nbands;   // X: hand-off columns live in step space, [0, T - 63) (T is even: g.X or g.X + 1)
   // `ord` counts this launch's (= this rank's) bands in sweep order; gord is the position in the
   // global band pipeline, which also names the hand-off rows (forwarded rank to rank when coupled)
   const int band = BWD ? a.band_lo + a.nb_local - 1 - ord : a.band_lo + ord;
@@ -563,17 +579,22 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
 
   // ====================================== compute wave ========================================
   unsigned int stalls = 0;
-  // Per-lane stream pointers at (this band, first record of the range, this lane).  They advance by 8
-  // records per block, so the 8 steps of a block address their records with immediate offsets j*512 B.
-  const size_t e0 = (size_t)band * TS * 64 + (size_t)(BWD ? T - 1 - SW_BLK * B0 : SW_BLK * B0) * 64 + lane;
-  const double* p_in = (OP == SW_FACTOR ? a.pre : a.in) + e0;      // operands of the block being prefetched
-  const double* p_pre = a.pre + e0;
-  const uint8_t* p_msk = a.mask + e0;
+  // Per-lane stream pointers at (this band, first record pair of the range, this lane).  Records come in
+  // pairs (euler_dev.h): a lane's elements of records 2P and 2P+1 are adjacent, so ONE 16-byte access per
+  // stream serves two steps - a lone wave pays per memory instruction (~16 cycles each whatever the width).
+  // A block = 8 steps = 4 pairs = 4 KB per 8-byte stream; pair p of the block is addressed with the
+  // immediate offset p * PSTEP (backward: descending).  T is even, so the backward sweep starts on the odd
+  // record of a pair: step 2p is the pair's odd element (.y), step 2p+1 its even one (.x).
+  constexpr int PSTEP = BWD ? -1024 : 1024;           // bytes from pair to pair for an 8-byte stream
+  const size_t pair0 = (size_t)band * TS * 64 + (size_t)(BWD ? T - 2 - SW_BLK * B0 : SW_BLK * B0) * 64 + 2 * lane;   // element index
+  const char* p_in = reinterpret_cast<const char*>((OP == SW_FACTOR ? a.pre : a.in) + pair0);   // operands of the block being prefetched
+  const char* p_pre = reinterpret_cast<const char*>(a.pre + pair0);
+  const char* p_msk = reinterpret_cast<const char*>(a.mask + pair0);      // factor: 2 mask bytes per pair
   const unsigned int* p_fb = (BWD ? a.fbits_bwd : a.fbits_fwd) + ((size_t)band * a.fb_stride + B0) * 64 + lane;
-  const sw_d2* p_kk = a.krku + e0;                                 // backward only; 16 B per step: the immediate offset (13 bits,
-  const sw_d2* p_kk4 = p_kk + 4 * STEP;                            // signed) reaches 4 steps, hence a second base for steps 4..7
-  sw_d2* p_okk = a.krku + e0;                                      // factor only
-  double* p_out = (OP == SW_FACTOR ? a.pre : a.out) + e0;          // results of the block being computed
+  const char* p_kk = reinterpret_cast<const char*>(a.krku + pair0);       // backward only; 32 B per pair: the immediate offset (13 bits,
+  const char* p_kk2 = p_kk + 2 * 2 * PSTEP;                               // signed) reaches 2 pairs, hence a second base for pairs 2, 3
+  char* p_okk = reinterpret_cast<char*>(a.krku + pair0);                  // factor only
+  char* p_out = reinterpret_cast<char*>((OP == SW_FACTOR ? a.pre : a.out) + pair0);   // results of the block being computed
 
   // Operand sets in rotation.  Forward: four sets, prefetch distance 2 - while block k computes from one
   // set, the records of blocks k+1 and k+2 are in flight into two others (HBM latency under load exceeds
@@ -581,47 +602,48 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   // plus the rest exceed the 256 architectural VGPRs, and hipcc would then park in-flight operands in
   // AGPRs, i.e. copy them before they have arrived (tools/check_sweep_isa.py catches exactly that).
   constexpr int DIST = OP == SW_FORWARD ? 2 : 1;
-  struct Operands { double in[SW_BLK], pre[SW_BLK]; sw_d2 kk[SW_BLK]; int m[SW_BLK]; unsigned int fb; };
+  struct Operands { sw_d2 in[4], pre[4], kk[4][2]; int m[4]; unsigned int fb; };    // per pair: .x = even record, .y = odd record
   Operands opA, opB, opC, opD;
   // forward / backward: the record loads are issued BY HAND (inline asm) and retired by counted
-  // s_waitcnt in front of each step.  hipcc's own wait insertion loses track of the issue order at
+  // s_waitcnt in front of each pair of steps.  hipcc's own wait insertion loses track of the issue order at
   // control-flow joins and then waits for every operation older than this block's loads -
   // including the result stores issued a few cycles earlier, i.e. a store round trip per block.
   // Memory operations of a wave retire in issue order, and the order here is fixed by construction:
-  //     fetch(k):   fb, then per step j the LOADS_PER_STEP records      (LOADS = 8 * LOADS_PER_STEP + 1)
-  //     compute(k): one result store behind each step
-  //   => before step j of block k everything up to step j's last record is needed, and behind it were
-  //      issued (7 - j) * LOADS_PER_STEP loads of fetch(k), then per block of prefetch distance [8 older
-  //      stores and] one whole fetch, and j stores: vmcnt((7 - j) * LOADS_PER_STEP + DIST * LOADS + j) is exact
-  //      for the first blocks and never waits for a younger fetch.
+  //     fetch(k):   fb, then per pair p the LOADS_PER_PAIR loads          (LOADS = 4 * LOADS_PER_PAIR + 1)
+  //     compute(k): one 16-byte result store behind each pair of steps
+  //   => before pair p of block k everything up to the pair's last load is needed, and behind it were issued
+  //      (3 - p) * LOADS_PER_PAIR loads of fetch(k), then per block of prefetch distance [4 older stores and] one
+  //      whole fetch, and p stores: vmcnt((3 - p) * LOADS_PER_PAIR + DIST * LOADS + p) is exact for the first
+  //      blocks and never waits for a younger fetch.
   // tools/check_sweep_isa.py proves on the generated ISA that no in-flight operand is ever touched.
-  constexpr int LOADS_PER_STEP = OP == SW_BACKWARD ? 3 : 2;
-  constexpr int LOADS = SW_BLK * LOADS_PER_STEP + 1;
+  constexpr int LOADS_PER_PAIR = OP == SW_BACKWARD ? 4 : 2;
+  constexpr int LOADS = 4 * LOADS_PER_PAIR + 1;
   auto fetch_block = [&](Operands& o) {
     if constexpr (OP == SW_FACTOR) {
 #pragma unroll
-      for (int j = 0; j < SW_BLK; ++j) {
-        o.in[j] = 0.0; o.kk[j] = sw_d2{0.0, 0.0};
-        o.pre[j] = p_pre[j * STEP];
-        o.m[j] = (int)p_msk[j * STEP];   // the full cell-mask byte (a_diag, right / up neighbour bits)
+      for (int pp = 0; pp < 4; ++pp) {
+        o.in[pp] = sw_d2{0.0, 0.0}; o.kk[pp][0] = sw_d2{0.0, 0.0}; o.kk[pp][1] = sw_d2{0.0, 0.0};
+        o.pre[pp] = *reinterpret_cast<const sw_d2*>(p_pre + pp * PSTEP);
+        o.m[pp] = (int)*reinterpret_cast<const unsigned short*>(p_msk + pp * (PSTEP / 8));   // the two cell-mask bytes of the pair
       }
       o.fb = 0u;
     } else {
       // only the fluid flags, 8 steps to a dword - a byte load per step costs as much as the rest of the step
       asm volatile("global_load_dword %0, %1, off" : "=&v"(o.fb) : "v"(p_fb) : "memory");
-#define SW_LOAD_STEP(J)                                                                                                    \
-      asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=&v"(o.in[J]) : "v"(p_in), "n"((J) * STEP * 8));        \
-      if (OP == SW_BACKWARD) {                                                                                             \
-        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(o.kk[J]) : "v"((J) < 4 ? p_kk : p_kk4), "n"(((J) & 3) * STEP * 16)); \
-      } else { o.kk[J] = sw_d2{0.0, 0.0}; }                                                                                \
-      asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=&v"(o.pre[J]) : "v"(p_pre), "n"((J) * STEP * 8));      \
-      o.m[J] = 0;
-      SW_LOAD_STEP(0) SW_LOAD_STEP(1) SW_LOAD_STEP(2) SW_LOAD_STEP(3) SW_LOAD_STEP(4) SW_LOAD_STEP(5) SW_LOAD_STEP(6) SW_LOAD_STEP(7)
-#undef SW_LOAD_STEP
+#define SW_LOAD_PAIR(P)                                                                                                     \
+      asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(o.in[P]) : "v"(p_in), "n"((P) * PSTEP));             \
+      if (OP == SW_BACKWARD) {                                                                                              \
+        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(o.kk[P][0]) : "v"((P) < 2 ? p_kk : p_kk2), "n"(((P) & 1) * 2 * PSTEP));      \
+        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(o.kk[P][1]) : "v"((P) < 2 ? p_kk : p_kk2), "n"(((P) & 1) * 2 * PSTEP + 16)); \
+      } else { o.kk[P][0] = sw_d2{0.0, 0.0}; o.kk[P][1] = sw_d2{0.0, 0.0}; }                                                \
+      asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(o.pre[P]) : "v"(p_pre), "n"((P) * PSTEP));           \
+      o.m[P] = 0;
+      SW_LOAD_PAIR(0) SW_LOAD_PAIR(1) SW_LOAD_PAIR(2) SW_LOAD_PAIR(3)
+#undef SW_LOAD_PAIR
       asm volatile("" ::: "memory");
     }
-    p_in += SW_BLK * STEP; p_pre += SW_BLK * STEP; p_msk += SW_BLK * STEP; p_fb += 64;
-    p_kk += SW_BLK * STEP; p_kk4 += SW_BLK * STEP;
+    p_in += 4 * PSTEP; p_pre += 4 * PSTEP; p_msk += 4 * (PSTEP / 8); p_fb += 64;
+    p_kk += 4 * 2 * PSTEP; p_kk2 += 4 * 2 * PSTEP;
   };
 
   // wait (rarely) until the helper's counter reaches `target`
@@ -676,21 +698,23 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
       // instructions later; measured 1.4-2x slower per step).
       __builtin_amdgcn_sched_barrier(0);
       double* ring = &sh.pub[(SW_BLK * blk) & (SW_RING - 1)][lane];
-      double prev_carry = CONST;
+      double prev_carry = CONST, prev_res = 0.0, prev_kr = 0.0, prev_ku = 0.0;
       auto step = [&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        if constexpr (OP != SW_FACTOR) {     // retire this step's records (see fetch_block)
-          constexpr int N0 = (SW_BLK - 1 - j) * LOADS_PER_STEP + DIST * LOADS + j, N = N0 < 63 ? N0 : 63;
+        constexpr int P = j >> 1;                         // the pair of records this step belongs to
+        constexpr bool ODD = ((j & 1) != 0) != BWD;       // does the step use the pair's odd record (.y)?
+        if constexpr (OP != SW_FACTOR && (j & 1) == 0) {  // retire this pair's records (see fetch_block)
+          constexpr int N0 = (3 - P) * LOADS_PER_PAIR + DIST * LOADS + P, N = N0 < 63 ? N0 : 63;
           if (OP == SW_BACKWARD)
-            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(cur.in[j]), "+v"(cur.pre[j]), "+v"(cur.kk[j]), "+v"(cur.fb) : "n"(N) : "memory");
+            asm volatile("s_waitcnt vmcnt(%5)" : "+v"(cur.in[P]), "+v"(cur.pre[P]), "+v"(cur.kk[P][0]), "+v"(cur.kk[P][1]), "+v"(cur.fb) : "n"(N) : "memory");
           else
-            asm volatile("s_waitcnt vmcnt(%3)" : "+v"(cur.in[j]), "+v"(cur.pre[j]), "+v"(cur.fb) : "n"(N) : "memory");
+            asm volatile("s_waitcnt vmcnt(%3)" : "+v"(cur.in[P]), "+v"(cur.pre[P]), "+v"(cur.fb) : "n"(N) : "memory");
         }
         // the edge lane consumes logical column s = 8*blk + j of the previous band
         const double nbv = wave_shift_inject<CTRL>(out, be[j]);   // 2 DPP moves
-        const double cin = cur.in[j], cpre = cur.pre[j];
+        const double cin = ODD ? cur.in[P].y : cur.in[P].x, cpre = ODD ? cur.pre[P].y : cur.pre[P].x;
         // sign-extended fluid flag (0 / -1): masking is two v_and
-        const int cm = OP == SW_FACTOR ? cur.m[j] : ((int)(cur.fb << (31 - j)) >> 31);
+        const int cm = OP == SW_FACTOR ? ((cur.m[P] >> (ODD ? 8 : 0)) & 0xff) : ((int)(cur.fb << (31 - j)) >> 31);
         double res, carry;
         if (OP == SW_FACTOR) {               // main.c:586-600; own / nbv are precon of the left / lower cell
           const double aa = (double)(cm >> CM_DIAG_SHIFT);
@@ -699,20 +723,28 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
           if (e < 0.25 * aa) e = (aa != 0.0) ? aa : 1.0;
           res = (cm & CM_FLUID) ? 1.0 / sqrt(e) : cpre;      // non-fluid: the stale entry stays
           carry = res;
-          // the backward solve's coefficients of this cell, fixed for the whole solve
-          p_okk[j * STEP] = sw_d2{((cm & CM_RIGHT) ? -1.0 : 0.0) * res, ((cm & CM_UP) ? -1.0 : 0.0) * res};
+          // the backward solve's coefficients of this cell, fixed for the whole solve (stored with the pair, below)
+          const double kr = ((cm & CM_RIGHT) ? -1.0 : 0.0) * res, ku = ((cm & CM_UP) ? -1.0 : 0.0) * res;
+          if (j & 1) {                       // factor runs forward: the odd step completes the pair {even, odd}
+            *reinterpret_cast<sw_d2*>(p_okk + P * 2 * PSTEP) = sw_d2{prev_kr, prev_ku};
+            *reinterpret_cast<sw_d2*>(p_okk + P * 2 * PSTEP + 16) = sw_d2{kr, ku};
+          }
+          prev_kr = kr; prev_ku = ku;
         } else if (OP == SW_FORWARD) {       // main.c:602-613: t = r - (-1*pre_l)*q_l - (-1*pre_b)*q_b
           const double t = cin - own - nbv;
           const double qv = t * cpre;
           res = __hiloint2double(__double2hiint(qv) & cm, __double2loint(qv) & cm);   // +0 on non-fluid cells
           carry = -1.0 * cpre * res;         // this cell's term in its right and upper neighbours
         } else {                             // main.c:615-626: t = q - (a_i*pre)*z_r - (a_j*pre)*z_u
-          const double t = cin - cur.kk[j].x * own - cur.kk[j].y * nbv;
+          const sw_d2 kk = cur.kk[P][ODD ? 1 : 0];
+          const double t = cin - kk.x * own - kk.y * nbv;
           const double zv = t * cpre;
           res = __hiloint2double(__double2hiint(zv) & cm, __double2loint(zv) & cm);   // +0 on non-fluid cells
           carry = res;
         }
-        p_out[j * STEP] = res;
+        // the pair's two results leave with one 16-byte store behind its second step ({even, odd} record order)
+        if (j & 1) *reinterpret_cast<sw_d2*>(p_out + P * PSTEP) = BWD ? sw_d2{res, prev_res} : sw_d2{prev_res, res};
+        prev_res = res;
         own = carry;
         out = carry;
         // the announce wave gathers the edge lane's entry; two rows per LDS instruction (ds_write2st64_b64)
@@ -730,7 +762,7 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
       step(std::integral_constant<int, 4>()); step(std::integral_constant<int, 5>());
       step(std::integral_constant<int, 6>()); step(std::integral_constant<int, 7>());
       __builtin_amdgcn_sched_barrier(0);
-      p_out += SW_BLK * STEP; p_okk += SW_BLK * STEP;
+      p_out += 4 * PSTEP; p_okk += 4 * 2 * PSTEP;
       if (HP || PB) { SW_COMPILER_FENCE(); lds_put(&sh.comp_done, (unsigned int)(rel + 1)); }
       if (SW_TRACE_HANDOFF && blk == SW_TRACE_CB + 8 && lane == 0) a.timeline[(size_t)ord * 8 + 4] = wall_clock64();
       // block blk+1 overwrites the ring rows of block blk-7, which the groups up to block blk-6 read
@@ -820,13 +852,13 @@ __global__ __launch_bounds__(256) void k_pack_fbits(const uint8_t* __restrict__ 
   if (i >= (size_t)nb_local * fb_stride * 64) return;
   const int lane = (int)(i & 63);
   const int gi = (int)((i >> 6) % fb_stride), band = band_lo + (int)((i >> 6) / fb_stride);
-  const uint8_t* base = cellmask + (size_t)band * g.TS * 64 + lane;
+  const uint8_t* base = cellmask + (size_t)band * g.TS * 64 + 2 * lane;   // paired records: (t & ~1) * 64 + 2 * lane + (t & 1)
   unsigned int wf = 0, wb = 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int tf = 8 * gi + j, tb = g.T - 1 - 8 * gi - j;
-    if (tf < g.T && (base[(size_t)tf * 64] & CM_FLUID)) wf |= 1u << j;
-    if (tb >= 0 && (base[(size_t)tb * 64] & CM_FLUID)) wb |= 1u << j;
+    if (tf < g.T && (base[(size_t)(tf & ~1) * 64 + (tf & 1)] & CM_FLUID)) wf |= 1u << j;
+    if (tb >= 0 && (base[(size_t)(tb & ~1) * 64 + (tb & 1)] & CM_FLUID)) wb |= 1u << j;
   }
   const size_t o = ((size_t)band * fb_stride + gi) * 64 + lane;
   fwd[o] = wf; bwd[o] = wb;
@@ -851,11 +883,11 @@ __global__ void k_nonzero_from_comm(PcgScalars* sc) { sc->nonzero = sc->comm_val
 // one grid row (band, lane) of a skewed array <-> a contiguous buffer of X doubles
 __global__ __launch_bounds__(256) void k_pack_row(const double* __restrict__ skew, double* __restrict__ row, SkewGeom g, int band, int lane) {
   const int x = blockIdx.x * 256 + threadIdx.x;
-  if (x < g.X) row[x] = skew[((size_t)band * g.TS + x + lane) * 64 + lane];
+  if (x < g.X) row[x] = skew[skew_index(g, x, band * 64 + lane)];
 }
 __global__ __launch_bounds__(256) void k_unpack_row(double* __restrict__ skew, const double* __restrict__ row, SkewGeom g, int band, int lane) {
   const int x = blockIdx.x * 256 + threadIdx.x;
-  if (x < g.X) skew[((size_t)band * g.TS + x + lane) * 64 + lane] = row[x];
+  if (x < g.X) skew[skew_index(g, x, band * 64 + lane)] = row[x];
 }
 
 #define COMM_CALL(expr) do { if ((expr) != 0) { eu_set_error("communicator callback failed: %s", #expr); return EULER_ECOMM; } } while (0)
