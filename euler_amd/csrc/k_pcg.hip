@@ -31,6 +31,7 @@
 #include <vector>
 
 #define RED_THREADS 1024
+typedef double sw_d2 __attribute__((ext_vector_type(2)));   // a lane's pair of records (16-byte accesses)
 
 __device__ __forceinline__ bool pcg_idle(const PcgScalars* sc) { return sc->done || !sc->nonzero; }
 
@@ -175,34 +176,64 @@ __global__ __launch_bounds__(RED_THREADS) void k_apply_a(const double* __restric
   const size_t chunk = (((S + gridDim.x - 1) / gridDim.x) + 127) & ~(size_t)127;   // whole record pairs per block
   const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < S ? lo + chunk : S;
   double t = 0.0;
-  for (size_t i = lo + threadIdx.x; i < hi; i += RED_THREADS) {
-    const uint8_t m = mask[i];
-    if (!(m & CM_FLUID)) continue;
-    // neighbours in the paired-record layout (euler_dev.h): same lane, record t+-1 = the pair partner or the
-    // facing element of the adjacent pair; the row above / below = lane+-1 of record t+-1 (the adjacent band's
-    // lane 0 / 63 through the index function)
-    const int odd = (int)(i & 1), l = (int)((i & 127) >> 1);
-    const size_t right = odd ? i + 127 : i + 1, left = odd ? i - 1 : i - 127;
-    const double si = s[i];
-    double o = (double)(int)(m >> CM_DIAG_SHIFT) * si;
-    o = o - ((m & CM_RIGHT) ? s[right] : 0.0);
-    if (m & CM_UP) {
-      size_t up = right + 2;
-      if (l == 63) { int band, tt, ll; skew_decode(g, i, band, tt, ll); up = skew_index(g, tt - 63, 64 * (band + 1)); }
-      o = o - s[up];
-    } else {
-      o = o - 0.0;
+  // One thread per PAIR of records of a lane (euler_dev.h): elements i = (t even, l) and i+1 = (t+1, l) come
+  // with one 16-byte load and are each other's right / left neighbour.  The others:
+  //   even element: left (t-1, l) = i-127, up (t+1, l+1) = i+3, down (t-1, l-1) = i-129
+  //   odd element : right (t+2, l) = i+128, up (t+2, l+1) = i+130, down (t, l-1) = i-2
+  // (the adjacent band's lane 0 / 63 through the index function when l = 63 / 0).
+  for (size_t i = lo + 2 * (size_t)threadIdx.x; i < hi; i += 2 * RED_THREADS) {
+    const unsigned int mm = *reinterpret_cast<const unsigned short*>(mask + i);
+    const unsigned int m0 = mm & 0xff, m1 = mm >> 8;
+    if (!((m0 | m1) & CM_FLUID)) continue;
+    const sw_d2 c = *reinterpret_cast<const sw_d2*>(s + i);
+    const int l = (int)((i & 127) >> 1);
+    sw_d2 o = {0.0, 0.0};
+    if (m0 & CM_FLUID) {
+      double v = (double)(int)(m0 >> CM_DIAG_SHIFT) * c.x;
+      v = v - ((m0 & CM_RIGHT) ? c.y : 0.0);
+      if (m0 & CM_UP) {
+        size_t up = i + 3;
+        if (l == 63) { int band, tt, ll; skew_decode(g, i, band, tt, ll); up = skew_index(g, tt - 63, 64 * (band + 1)); }
+        v = v - s[up];
+      } else {
+        v = v - 0.0;
+      }
+      v = v - ((m0 & CM_LEFT) ? s[i - 127] : 0.0);
+      if (m0 & CM_DOWN) {
+        size_t dn = i - 129;
+        if (l == 0) { int band, tt, ll; skew_decode(g, i, band, tt, ll); dn = skew_index(g, tt, 64 * band - 1); }
+        v = v - s[dn];
+      } else {
+        v = v - 0.0;
+      }
+      o.x = v;
+      t += v * c.x;
     }
-    o = o - ((m & CM_LEFT) ? s[left] : 0.0);
-    if (m & CM_DOWN) {
-      size_t dn = left - 2;
-      if (l == 0) { int band, tt, ll; skew_decode(g, i, band, tt, ll); dn = skew_index(g, tt, 64 * band - 1); }
-      o = o - s[dn];
-    } else {
-      o = o - 0.0;
+    if (m1 & CM_FLUID) {
+      double v = (double)(int)(m1 >> CM_DIAG_SHIFT) * c.y;
+      v = v - ((m1 & CM_RIGHT) ? s[i + 128] : 0.0);
+      if (m1 & CM_UP) {
+        size_t up = i + 130;
+        if (l == 63) { int band, tt, ll; skew_decode(g, i + 1, band, tt, ll); up = skew_index(g, tt - 63, 64 * (band + 1)); }
+        v = v - s[up];
+      } else {
+        v = v - 0.0;
+      }
+      v = v - ((m1 & CM_LEFT) ? c.x : 0.0);
+      if (m1 & CM_DOWN) {
+        size_t dn = i - 2;
+        if (l == 0) { int band, tt, ll; skew_decode(g, i + 1, band, tt, ll); dn = skew_index(g, tt, 64 * band - 1); }
+        v = v - s[dn];
+      } else {
+        v = v - 0.0;
+      }
+      o.y = v;
+      t += v * c.y;
     }
-    z[i] = o;
-    t += o * si;
+    // z of a non-fluid cell stays what it is (0): write the pair only where both are fluid, else element-wise
+    if ((m0 & m1) & CM_FLUID) *reinterpret_cast<sw_d2*>(z + i) = o;
+    else if (m0 & CM_FLUID) z[i] = o.x;
+    else z[i + 1] = o.y;
   }
   t = block_sum(t);
   if (fin_op >= 0) block_finish<false>(t, partial, counter, sc, fin_op);   // fin_op < 0: dot(z,s) is replayed sequentially
@@ -283,7 +314,6 @@ __global__ __launch_bounds__(256) void k_jacobi(const double* __restrict__ r, do
 // uses get_a_plus_i/j(y,x) = is_fluid of the right/upper neighbour.
 enum { SW_FACTOR = 0, SW_FORWARD = 1, SW_BACKWARD = 2 };
 
-typedef double sw_d2 __attribute__((ext_vector_type(2)));
 struct SweepArgs {
   SkewGeom g;
   const uint8_t* mask;
