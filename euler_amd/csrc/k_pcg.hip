@@ -122,11 +122,16 @@ __global__ __launch_bounds__(RED_THREADS) void k_dot_partial(const double* __res
                                                              double* __restrict__ partial, PcgScalars* sc, int force,
                                                              unsigned int* counter, int fin_op) {
   if (!force && pcg_idle(sc)) return;
-  const size_t chunk = (S + gridDim.x - 1) / gridDim.x;
+  const size_t chunk = (((S + gridDim.x - 1) / gridDim.x) + 1) & ~(size_t)1;   // S is even: whole 16-byte pairs per thread
   const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < S ? lo + chunk : S;
   double t = 0.0;
-  for (size_t i = lo + threadIdx.x; i < hi; i += RED_THREADS)
-    if (mask[i] & CM_FLUID) t += a[i] * b[i];
+  for (size_t i = lo + 2 * (size_t)threadIdx.x; i < hi; i += 2 * RED_THREADS) {
+    const unsigned int mm = *reinterpret_cast<const unsigned short*>(mask + i);
+    if (!((mm | (mm >> 8)) & CM_FLUID)) continue;
+    const sw_d2 av = *reinterpret_cast<const sw_d2*>(a + i), bv = *reinterpret_cast<const sw_d2*>(b + i);
+    if (mm & CM_FLUID) t += av.x * bv.x;
+    if ((mm >> 8) & CM_FLUID) t += av.y * bv.y;
+  }
   t = block_sum(t);
   block_finish<false>(t, partial, counter, sc, fin_op);
 }
@@ -248,16 +253,19 @@ __global__ __launch_bounds__(RED_THREADS) void k_update_pr(double* __restrict__ 
   if (!force && pcg_idle(sc)) return;
   const double alpha = force ? alpha_arg : sc->alpha;
   const double nalpha = -alpha;
-  const size_t chunk = (S + gridDim.x - 1) / gridDim.x;
+  const size_t chunk = (((S + gridDim.x - 1) / gridDim.x) + 1) & ~(size_t)1;   // whole 16-byte pairs per thread
   const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < S ? lo + chunk : S;
   double mx = 0.0;
-  for (size_t i = lo + threadIdx.x; i < hi; i += RED_THREADS) {
-    if (!(mask[i] & CM_FLUID)) continue;
-    p[i] = p[i] + s[i] * alpha;
-    const double rn = r[i] + z[i] * nalpha;
-    r[i] = rn;
-    const double a = fabs(rn);
-    if (a > mx) mx = a;
+  for (size_t i = lo + 2 * (size_t)threadIdx.x; i < hi; i += 2 * RED_THREADS) {
+    const unsigned int mm = *reinterpret_cast<const unsigned short*>(mask + i);
+    const bool f0 = (mm & CM_FLUID) != 0, f1 = ((mm >> 8) & CM_FLUID) != 0;
+    if (!(f0 | f1)) continue;
+    const sw_d2 sv = *reinterpret_cast<const sw_d2*>(s + i), zv = *reinterpret_cast<const sw_d2*>(z + i);
+    sw_d2 pv = *reinterpret_cast<const sw_d2*>(p + i), rv = *reinterpret_cast<const sw_d2*>(r + i);
+    if (f0) { pv.x = pv.x + sv.x * alpha; rv.x = rv.x + zv.x * nalpha; const double a = fabs(rv.x); if (a > mx) mx = a; }
+    if (f1) { pv.y = pv.y + sv.y * alpha; rv.y = rv.y + zv.y * nalpha; const double a = fabs(rv.y); if (a > mx) mx = a; }
+    *reinterpret_cast<sw_d2*>(p + i) = pv;      // a non-fluid partner is written back unchanged
+    *reinterpret_cast<sw_d2*>(r + i) = rv;
   }
   mx = block_max(mx);
   if (fin_op >= 0) block_finish<true>(mx, partial, counter, sc, fin_op);
@@ -282,9 +290,16 @@ __global__ __launch_bounds__(256) void k_update_search(double* __restrict__ s, c
                                                        int force, double beta_arg) {
   if (!force && pcg_idle(sc)) return;
   const double beta = force ? beta_arg : sc->beta;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (size_t)gridDim.x * blockDim.x) {
-    if (COPY) s[i] = z[i];
-    else if (mask[i] & CM_FLUID) s[i] = z[i] + beta * s[i];
+  for (size_t i = 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x); i < S; i += 2 * (size_t)gridDim.x * blockDim.x) {
+    const sw_d2 zv = *reinterpret_cast<const sw_d2*>(z + i);
+    if (COPY) { *reinterpret_cast<sw_d2*>(s + i) = zv; continue; }
+    const unsigned int mm = *reinterpret_cast<const unsigned short*>(mask + i);
+    const bool f0 = (mm & CM_FLUID) != 0, f1 = ((mm >> 8) & CM_FLUID) != 0;
+    if (!(f0 | f1)) continue;
+    sw_d2 sv = *reinterpret_cast<const sw_d2*>(s + i);
+    if (f0) sv.x = zv.x + beta * sv.x;
+    if (f1) sv.y = zv.y + beta * sv.y;
+    *reinterpret_cast<sw_d2*>(s + i) = sv;      // a non-fluid partner is written back unchanged
   }
 }
 
