@@ -871,11 +871,16 @@ __global__ __launch_bounds__(256) void k_band_ranges(const uint8_t* __restrict__
   if (threadIdx.x == 0) { s_lo = 0x7fffffff; s_hi = -1; }
   __syncthreads();
   int lo = 0x7fffffff, hi = -1;
-  for (int l = 0; l < 64; ++l) {
-    const int y = band * 64 + l;
-    if (y >= Y) break;
-    for (int x = threadIdx.x; x < X; x += 256)
-      if (count[(size_t)y * X + x]) { const int t = x + l; lo = t < lo ? t : lo; hi = t > hi ? t : hi; }
+  const int rows = Y - band * 64 < 64 ? Y - band * 64 : 64;
+  for (int x = threadIdx.x; x < X; x += 256) {
+    for (int l0 = 0; l0 < rows; l0 += 8) {          // 8 independent loads in flight per thread
+      uint8_t c[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) c[k] = l0 + k < rows ? count[(size_t)(band * 64 + l0 + k) * X + x] : (uint8_t)0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (c[k]) { const int t = x + l0 + k; lo = t < lo ? t : lo; hi = t > hi ? t : hi; }
+    }
   }
   if (hi >= 0) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
   __syncthreads();
