@@ -5,7 +5,7 @@
 // so it is stored BAND-SKEWED rather than row-major (struct SkewGeom, euler_dev.h):
 //     element (row y, column x)  ->  band b = y / 64, lane l = y % 64, record t = x + l
 //                                    index  = (b * TS + (t & ~1)) * 64 + 2 * l + (t & 1)
-// (T = X + 63 rounded up to even records per band, band stride TS = roundup32(T) + 32 records).
+// (T = X + 63 rounded up to even records per band, band stride TS = roundup24(T) + 32 records).
 // A record (the 64 elements of one t) is exactly what one wave touches in one step of the IC(0)
 // wavefront sweeps (lane l at column t - l).  Records are stored in PAIRS: a lane's elements of
 // records 2P and 2P+1 are adjacent, so one 16-byte access per lane serves two steps of a sweep
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(1024) void k_sweep_simple(SweepArgs a) {
 // 1.2x slower backward - the touches cross the same per-CU memory path), and padding the band stride
 // against HBM channel aliasing (no effect).
 // Records t >= T of a band and the 32 records in front of each array are dead padding (mask 0):
-// the loop runs whole groups of 4 blocks and prefetches unconditionally.
+// the loop runs whole groups of 3 blocks and prefetches unconditionally.
 #define SW_BLK 8
 #define SW_RING 64            // carry rows kept in LDS (8 blocks)
 #define SW_BND_RING 16        // boundary blocks kept in LDS
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   // not poll.  The factor sweep always runs the full range (a stale precon is not a constant).
   constexpr bool RANGED = OP != SW_FACTOR;
   constexpr double CONST = OP == SW_FORWARD ? -0.0 : 0.0;
-  const int full_blocks = 4 * (((T + SW_BLK - 1) / SW_BLK + 3) / 4);     // whole groups of 4 blocks (the loop's unroll)
+  const int full_blocks = 3 * (((T + SW_BLK - 1) / SW_BLK + 2) / 3);     // whole groups of 3 blocks (half of the loop's unroll)
   const int ncolblk = (X + SW_BLK - 1) / SW_BLK;
   int B0 = 0, B1 = full_blocks, win_lo = 0, win_hi = ncolblk;
   if (RANGED && a.ranges) {
@@ -641,14 +641,15 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   char* p_okk = reinterpret_cast<char*>(a.krku + pair0);                  // factor only
   char* p_out = reinterpret_cast<char*>((OP == SW_FACTOR ? a.pre : a.out) + pair0);   // results of the block being computed
 
-  // Operand sets in rotation.  Forward: four sets, prefetch distance 2 - while block k computes from one
-  // set, the records of blocks k+1 and k+2 are in flight into two others (HBM latency under load exceeds
-  // one block time).  Backward / factor: two sets, distance 1 - three backward sets (8 VGPRs per step)
-  // plus the rest exceed the 256 architectural VGPRs, and hipcc would then park in-flight operands in
-  // AGPRs, i.e. copy them before they have arrived (tools/check_sweep_isa.py catches exactly that).
-  constexpr int DIST = OP == SW_FORWARD ? 2 : 1;
+  // Operand sets in rotation.  Forward / backward: three sets, prefetch distance 2 - while block k computes
+  // from one set, the records of blocks k+1 and k+2 are in flight into the other two (HBM latency under load
+  // exceeds one block time); the loop is unrolled 6 blocks (3 operand sets x 2 boundary sets).  A fourth set
+  // would push the backward sweep past the 256 architectural VGPRs, and hipcc would then park in-flight
+  // operands in AGPRs, i.e. copy them before they have arrived (tools/check_sweep_isa.py catches exactly
+  // that).  Factor: two sets, distance 1 (compiler-managed loads).
+  constexpr int DIST = OP != SW_FACTOR ? 2 : 1;
   struct Operands { sw_d2 in[4], pre[4], kk[4][2]; int m[4]; unsigned int fb; };    // per pair: .x = even record, .y = odd record
-  Operands opA, opB, opC, opD;
+  Operands opA, opB, opC;
   // forward / backward: the record loads are issued BY HAND (inline asm) and retired by counted
   // s_waitcnt in front of each pair of steps.  hipcc's own wait insertion loses track of the issue order at
   // control-flow joins and then waits for every operation older than this block's loads -
@@ -815,17 +816,24 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
       if (PB && __builtin_expect(rel + 1 < NBLK && (int)(unsigned int)(prog >> 32) < rel - 5, 0)) await(&sh.pub_done, rel - 5);
     };
 
-    for (int blk = B0; blk < B1; blk += 4) {   // B0, B1 are multiples of 4; a surplus runs over dead records
+    // B0, B1 are multiples of 3 blocks; the body is 6 blocks (3 operand sets x 2 boundary sets) with an exit in the middle
+    for (int blk = B0; blk < B1; blk += 6) {
       if (DIST == 2) {
         run_block(blk, opA, opC, beA, beB);      // compute from the first set, fetch block blk+2 into the second
-        run_block(blk + 1, opB, opD, beB, beA);
-        run_block(blk + 2, opC, opA, beA, beB);
-        run_block(blk + 3, opD, opB, beB, beA);
+        run_block(blk + 1, opB, opA, beB, beA);
+        run_block(blk + 2, opC, opB, beA, beB);
+        if (blk + 3 >= B1) break;
+        run_block(blk + 3, opA, opC, beB, beA);
+        run_block(blk + 4, opB, opA, beA, beB);
+        run_block(blk + 5, opC, opB, beB, beA);
       } else {
         run_block(blk, opA, opB, beA, beB);      // compute from the first set, fetch block blk+1 into the second
         run_block(blk + 1, opB, opA, beB, beA);
         run_block(blk + 2, opA, opB, beA, beB);
+        if (blk + 3 >= B1) break;
         run_block(blk + 3, opB, opA, beB, beA);
+        run_block(blk + 4, opA, opB, beA, beB);
+        run_block(blk + 5, opB, opA, beB, beA);
       }
     }
     // retire the prefetch that ran past the range before anything else reuses its registers (the kernel
@@ -862,7 +870,7 @@ static SweepArgs make_sweep_args(euler_sim* S, int op, int force) {
 
 // ---- active ranges of the bands (per solve) ---------------------------------------------------
 // For each 64-row band: the first / last record t = x + lane that holds a fluid cell, turned into
-// 32-step-aligned block ranges of the forward (step = t) and backward (step = T-1-t) sweeps; the
+// 24-step-aligned block ranges of the forward (step = t) and backward (step = T-1-t) sweeps; the
 // upper end leaves at least one all-non-fluid step inside the range (see k_sweep_skew).  Computed
 // from the row-major count grid, which every rank holds in full.
 __global__ __launch_bounds__(256) void k_band_ranges(const uint8_t* __restrict__ count, int X, int Y, int T, int4* __restrict__ ranges) {
@@ -887,8 +895,8 @@ __global__ __launch_bounds__(256) void k_band_ranges(const uint8_t* __restrict__
   if (threadIdx.x == 0) {
     int4 r = make_int4(0, 0, 0, 0);
     if (s_hi >= 0) {
-      const int f0 = s_lo & ~31, f1 = (s_hi + 2 + 31) & ~31;                       // forward steps [f0, f1)
-      const int b0 = (T - 1 - s_hi) & ~31, b1 = (T - 1 - s_lo + 2 + 31) & ~31;     // backward steps [b0, b1)
+      const int f0 = s_lo / 24 * 24, f1 = (s_hi + 2 + 23) / 24 * 24;                       // forward steps [f0, f1)
+      const int b0 = (T - 1 - s_hi) / 24 * 24, b1 = (T - 1 - s_lo + 2 + 23) / 24 * 24;     // backward steps [b0, b1)
       r = make_int4(f0 / 8, f1 / 8, b0 / 8, b1 / 8);
     }
     ranges[band] = r;
