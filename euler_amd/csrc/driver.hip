@@ -203,7 +203,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   S->geom.X = S->X; S->geom.Y = S->Y;
   S->geom.nbands = (S->Y + 63) / 64;
   S->geom.T = (S->X + 63 + 1) & ~1;   // records per band, even: records are stored in pairs (euler_dev.h)
-  S->geom.TS = (S->geom.T + 23) / 24 * 24 + 32;   // the sweeps run whole groups of three 8-step blocks and prefetch 16 steps further
+  S->geom.TS = (S->geom.T + 31) / 32 * 32 + 64;   // the sweeps run whole groups of three / four 8-step blocks and prefetch up to 24 steps further
   S->geom.S = (size_t)S->geom.nbands * S->geom.TS * 64;
   const size_t SS = S->geom.S;
   if ((SS + EU_SKEW_SLACK) * 8 >= ((size_t)1 << 32)) { eu_set_error("grid too large for 32-bit record offsets"); euler_destroy(S); return EULER_EINVAL; }
@@ -211,7 +211,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   for (double** d : {&S->b, &S->p, &S->r, &S->z, &S->s, &S->q, &S->precon}) { DALLOC(*d, SS + EU_SKEW_SLACK); *d += EU_SKEW_SLACK; }
   DALLOC(S->krku, 2 * (SS + EU_SKEW_SLACK)); S->krku += 2 * EU_SKEW_SLACK;
   DALLOC(S->cellmask, SS + EU_SKEW_SLACK); S->cellmask += EU_SKEW_SLACK;
-  S->fb_stride = 3 * (((S->geom.T + 7) / 8 + 2) / 3) + 4;   // whole groups of 3 blocks + the two blocks the prefetch runs ahead
+  S->fb_stride = 12 * (((S->geom.T + 7) / 8 + 11) / 12) + 4;   // whole groups of 3 and of 4 blocks + the blocks the prefetch runs ahead
   DALLOC(S->fbits_fwd, (size_t)S->geom.nbands * S->fb_stride * 64);
   DALLOC(S->fbits_bwd, (size_t)S->geom.nbands * S->fb_stride * 64);
   DALLOC(S->sc, 1);

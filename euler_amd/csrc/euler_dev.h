@@ -66,7 +66,7 @@ struct MarkerState {
 // record t = x + y%64 of band y/64, lane y%64; RECORDS COME IN PAIRS: the two elements (t even, t+1) of a lane
 // are adjacent, index = ((y/64)*TS + (t & ~1))*64 + 2*(y%64) + (t & 1), so that one 16-byte access per lane
 // serves two steps of the IC(0) sweeps (a lone wave pays per memory INSTRUCTION: tools/micro/step_bench2).  A band has T = X + 63 live records and a stride of
-// TS = roundup24(T) + 32 records; S = nbands*TS*64 elements in total; padding carries mask 0.
+// TS = roundup32(T) + 64 records; S = nbands*TS*64 elements in total; padding carries mask 0.
 // Every skewed array also has EU_SKEW_SLACK elements of zeroed slack in front of element 0.
 #define EU_SKEW_SLACK (64 * 64)
 struct SkewGeom {

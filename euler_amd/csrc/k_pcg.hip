@@ -5,7 +5,7 @@
 // so it is stored BAND-SKEWED rather than row-major (struct SkewGeom, euler_dev.h):
 //     element (row y, column x)  ->  band b = y / 64, lane l = y % 64, record t = x + l
 //                                    index  = (b * TS + (t & ~1)) * 64 + 2 * l + (t & 1)
-// (T = X + 63 rounded up to even records per band, band stride TS = roundup24(T) + 32 records).
+// (T = X + 63 rounded up to even records per band, band stride TS = roundup32(T) + 64 records).
 // A record (the 64 elements of one t) is exactly what one wave touches in one step of the IC(0)
 // wavefront sweeps (lane l at column t - l).  Records are stored in PAIRS: a lane's elements of
 // records 2P and 2P+1 are adjacent, so one 16-byte access per lane serves two steps of a sweep
@@ -509,7 +509,8 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   // not poll.  The factor sweep always runs the full range (a stale precon is not a constant).
   constexpr bool RANGED = OP != SW_FACTOR;
   constexpr double CONST = OP == SW_FORWARD ? -0.0 : 0.0;
-  const int full_blocks = 3 * (((T + SW_BLK - 1) / SW_BLK + 2) / 3);     // whole groups of 3 blocks (half of the loop's unroll)
+  constexpr int BODY_HALF = OP == SW_BACKWARD ? 3 : 4;                  // blocks a range is a multiple of: half of the backward loop body (mid-body exit), the whole forward one
+  const int full_blocks = BODY_HALF * (((T + SW_BLK - 1) / SW_BLK + BODY_HALF - 1) / BODY_HALF);
   const int ncolblk = (X + SW_BLK - 1) / SW_BLK;
   int B0 = 0, B1 = full_blocks, win_lo = 0, win_hi = ncolblk;
   if (RANGED && a.ranges) {
@@ -641,15 +642,14 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   char* p_okk = reinterpret_cast<char*>(a.krku + pair0);                  // factor only
   char* p_out = reinterpret_cast<char*>((OP == SW_FACTOR ? a.pre : a.out) + pair0);   // results of the block being computed
 
-  // Operand sets in rotation.  Forward / backward: three sets, prefetch distance 2 - while block k computes
-  // from one set, the records of blocks k+1 and k+2 are in flight into the other two (HBM latency under load
-  // exceeds one block time); the loop is unrolled 6 blocks (3 operand sets x 2 boundary sets).  A fourth set
-  // would push the backward sweep past the 256 architectural VGPRs, and hipcc would then park in-flight
-  // operands in AGPRs, i.e. copy them before they have arrived (tools/check_sweep_isa.py catches exactly
-  // that).  Factor: two sets, distance 1 (compiler-managed loads).
-  constexpr int DIST = OP != SW_FACTOR ? 2 : 1;
+  // Operand sets in rotation: while block k computes from one set, the records of the next DIST blocks are in
+  // flight into the others (HBM latency under load exceeds one block time).  Forward: four sets, distance 3;
+  // backward: three sets, distance 2 - a fourth would push it past the 256 architectural VGPRs, and hipcc
+  // would then park in-flight operands in AGPRs, i.e. copy them before they have arrived
+  // (tools/check_sweep_isa.py catches exactly that).  Factor: two sets, distance 1 (compiler-managed loads).
+  constexpr int DIST = OP == SW_FORWARD ? 3 : (OP == SW_BACKWARD ? 2 : 1);
   struct Operands { sw_d2 in[4], pre[4], kk[4][2]; int m[4]; unsigned int fb; };    // per pair: .x = even record, .y = odd record
-  Operands opA, opB, opC;
+  Operands opA, opB, opC, opD;
   // forward / backward: the record loads are issued BY HAND (inline asm) and retired by counted
   // s_waitcnt in front of each pair of steps.  hipcc's own wait insertion loses track of the issue order at
   // control-flow joins and then waits for every operation older than this block's loads -
@@ -710,7 +710,8 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
     constexpr bool HP = decltype(hp_c)::value;    // a band before us in sweep order: boundary values from the helper
     constexpr bool PB = decltype(pb_c)::value;    // a band after us: carry rows for the helper
     fetch_block(opA);                             // (per instantiation: an in-flight operand must never be copied)
-    if (DIST == 2) fetch_block(opB);
+    if (DIST >= 2) fetch_block(opB);
+    if (DIST >= 3) fetch_block(opC);
     // Loop-carried state.  What travels between cells is, per operation:
     //   factor   : precon itself (left neighbour = own register, lower neighbour = lane-1)
     //   forward  : m = (-1*precon)*q of a cell - exactly the term its right neighbour (same lane, next
@@ -816,24 +817,30 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
       if (PB && __builtin_expect(rel + 1 < NBLK && (int)(unsigned int)(prog >> 32) < rel - 5, 0)) await(&sh.pub_done, rel - 5);
     };
 
-    // B0, B1 are multiples of 3 blocks; the body is 6 blocks (3 operand sets x 2 boundary sets) with an exit in the middle
-    for (int blk = B0; blk < B1; blk += 6) {
-      if (DIST == 2) {
-        run_block(blk, opA, opC, beA, beB);      // compute from the first set, fetch block blk+2 into the second
+    // At block k the wave computes from set k mod (DIST + 1) and refills the set of block k - 1.  Forward / factor: the
+    // body is 4 blocks and the ranges are multiples of 4; backward: 6 blocks (3 operand sets x 2 boundary sets) with
+    // an exit in the middle, ranges multiples of 3.  (A mid-body exit in the forward loop is correct too, but hipcc
+    // then merges the tails of the rare wait paths and tools/check_sweep_isa.py, which follows every branch both
+    // ways, can no longer prove it.)
+    for (int blk = B0; blk < B1; blk += (OP == SW_BACKWARD ? 6 : 4)) {
+      if (DIST == 3) {          // forward: four sets
+        run_block(blk, opA, opD, beA, beB);
+        run_block(blk + 1, opB, opA, beB, beA);
+        run_block(blk + 2, opC, opB, beA, beB);
+        run_block(blk + 3, opD, opC, beB, beA);
+      } else if (DIST == 2) {   // backward: three sets
+        run_block(blk, opA, opC, beA, beB);
         run_block(blk + 1, opB, opA, beB, beA);
         run_block(blk + 2, opC, opB, beA, beB);
         if (blk + 3 >= B1) break;
         run_block(blk + 3, opA, opC, beB, beA);
         run_block(blk + 4, opB, opA, beA, beB);
         run_block(blk + 5, opC, opB, beB, beA);
-      } else {
-        run_block(blk, opA, opB, beA, beB);      // compute from the first set, fetch block blk+1 into the second
+      } else {                  // factor: two sets
+        run_block(blk, opA, opB, beA, beB);
         run_block(blk + 1, opB, opA, beB, beA);
         run_block(blk + 2, opA, opB, beA, beB);
-        if (blk + 3 >= B1) break;
         run_block(blk + 3, opB, opA, beB, beA);
-        run_block(blk + 4, opA, opB, beA, beB);
-        run_block(blk + 5, opB, opA, beB, beA);
       }
     }
     // retire the prefetch that ran past the range before anything else reuses its registers (the kernel
@@ -870,7 +877,7 @@ static SweepArgs make_sweep_args(euler_sim* S, int op, int force) {
 
 // ---- active ranges of the bands (per solve) ---------------------------------------------------
 // For each 64-row band: the first / last record t = x + lane that holds a fluid cell, turned into
-// 24-step-aligned block ranges of the forward (step = t) and backward (step = T-1-t) sweeps; the
+// 32-step (forward) / 24-step (backward) aligned block ranges of the forward (step = t) and backward (step = T-1-t) sweeps; the
 // upper end leaves at least one all-non-fluid step inside the range (see k_sweep_skew).  Computed
 // from the row-major count grid, which every rank holds in full.
 __global__ __launch_bounds__(256) void k_band_ranges(const uint8_t* __restrict__ count, int X, int Y, int T, int4* __restrict__ ranges) {
@@ -895,7 +902,7 @@ __global__ __launch_bounds__(256) void k_band_ranges(const uint8_t* __restrict__
   if (threadIdx.x == 0) {
     int4 r = make_int4(0, 0, 0, 0);
     if (s_hi >= 0) {
-      const int f0 = s_lo / 24 * 24, f1 = (s_hi + 2 + 23) / 24 * 24;                       // forward steps [f0, f1)
+      const int f0 = s_lo / 32 * 32, f1 = (s_hi + 2 + 31) / 32 * 32;                       // forward steps [f0, f1): whole groups of 4 blocks
       const int b0 = (T - 1 - s_hi) / 24 * 24, b1 = (T - 1 - s_lo + 2 + 23) / 24 * 24;     // backward steps [b0, b1)
       r = make_int4(f0 / 8, f1 / 8, b0 / 8, b1 / 8);
     }
