@@ -436,6 +436,8 @@ __global__ __launch_bounds__(1024) void k_sweep_simple(SweepArgs a) {
 // A stand-alone model of the step promised 27 ns instead of 40; the real kernel, with its per-block
 // bookkeeping and five waves on the CU, ran 40 ns/step for a lone band and 50-55 ns with neighbours, and the
 // load wave could not keep the ring full from HBM at 8192^2 (1.6x slower sweeps).  Bit-exact, but not faster.
+// Measured and rejected: placing consecutive bands on one XCD (every 8th workgroup) with write-through or
+// with plain granule stores - the hand-off lag does not move (4.6-4.8 us per band either way).
 // Measured and rejected at 8192^2 (per-step time there is ~1.25x / 1.4x that of an L2-resident grid):
 // a fourth wave touching the coming records' cache lines 10 blocks ahead (L2 prefetch: no gain forward,
 // 1.2x slower backward - the touches cross the same per-CU memory path), and padding the band stride
