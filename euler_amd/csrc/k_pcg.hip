@@ -882,14 +882,14 @@ static SweepArgs make_sweep_args(euler_sim* S, int op, int force) {
 // 32-step (forward) / 24-step (backward) aligned block ranges of the forward (step = t) and backward (step = T-1-t) sweeps; the
 // upper end leaves at least one all-non-fluid step inside the range (see k_sweep_skew).  Computed
 // from the row-major count grid, which every rank holds in full.
-__global__ __launch_bounds__(256) void k_band_ranges(const uint8_t* __restrict__ count, int X, int Y, int T, int4* __restrict__ ranges) {
+__global__ __launch_bounds__(1024) void k_band_ranges(const uint8_t* __restrict__ count, int X, int Y, int T, int4* __restrict__ ranges) {
   __shared__ int s_lo, s_hi;
   const int band = blockIdx.x;
   if (threadIdx.x == 0) { s_lo = 0x7fffffff; s_hi = -1; }
   __syncthreads();
   int lo = 0x7fffffff, hi = -1;
   const int rows = Y - band * 64 < 64 ? Y - band * 64 : 64;
-  for (int x = threadIdx.x; x < X; x += 256) {
+  for (int x = threadIdx.x; x < X; x += 1024) {
     for (int l0 = 0; l0 < rows; l0 += 8) {          // 8 independent loads in flight per thread
       uint8_t c[8];
 #pragma unroll
@@ -931,7 +931,7 @@ __global__ __launch_bounds__(256) void k_pack_fbits(const uint8_t* __restrict__ 
   fwd[o] = wf; bwd[o] = wb;
 }
 int eu_launch_band_ranges(euler_sim* S) {
-  LAUNCH(S, KC_BUILD_SYSTEM, k_band_ranges, dim3(S->geom.nbands), dim3(256), S->count, S->X, S->Y, S->geom.T, S->band_ranges);
+  LAUNCH(S, KC_BUILD_SYSTEM, k_band_ranges, dim3(S->geom.nbands), dim3(1024), S->count, S->X, S->Y, S->geom.T, S->band_ranges);
   const int nbl = S->band_hi - S->band_lo;
   const size_t n = (size_t)nbl * S->fb_stride * 64;
   LAUNCH(S, KC_BUILD_SYSTEM, k_pack_fbits, dim3((unsigned)((n + 255) / 256)), dim3(256), S->cellmask, S->geom, S->fbits_fwd, S->fbits_bwd,
