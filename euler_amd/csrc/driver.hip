@@ -182,6 +182,18 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   const size_t C = S->C = (size_t)cfg->X * cfg->Y;
   if (S->cfg.dot_mode == EULER_DOT_AUTO) S->cfg.dot_mode = C <= 65536 ? EULER_DOT_SEQUENTIAL : EULER_DOT_TREE;
   if (S->cfg.sweep_mode == EULER_SWEEP_AUTO) S->cfg.sweep_mode = EULER_SWEEP_BAND;
+  S->geom.X = S->X; S->geom.Y = S->Y;
+  S->geom.nbands = (S->Y + 63) / 64;
+  S->geom.T = (S->X + 63 + 1) & ~1;   // records per band, even: records are stored in pairs (euler_dev.h)
+  S->geom.TS = (S->geom.T + 31) / 32 * 32 + 64;   // the sweeps run whole groups of three / four 8-step blocks and prefetch up to 24 steps further
+  S->geom.S = (size_t)S->geom.nbands * S->geom.TS * 64;
+  const size_t SS = S->geom.S;
+  // supported maximum = BASELINE's largest configuration, 16384^2 cells: marker indices (4 per cell) are 32-bit
+  if (C > ((size_t)1 << 28) || (SS + EU_SKEW_SLACK) * 8 >= ((size_t)1 << 32)) {
+    eu_set_error("grid %d x %d is larger than the supported maximum (2^28 cells)", cfg->X, cfg->Y);
+    free(S);
+    return EULER_EINVAL;
+  }
   HIPCHK(hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking));
   S->own_stream = 1;
 
@@ -200,13 +212,6 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   DALLOC(S->cellmask64, (C + 63) / 64);
   S->sel.capacity_blocks = (mwords + 2047) / 2048 + 1;
   DALLOC(S->sel.block_sums, S->sel.capacity_blocks);
-  S->geom.X = S->X; S->geom.Y = S->Y;
-  S->geom.nbands = (S->Y + 63) / 64;
-  S->geom.T = (S->X + 63 + 1) & ~1;   // records per band, even: records are stored in pairs (euler_dev.h)
-  S->geom.TS = (S->geom.T + 31) / 32 * 32 + 64;   // the sweeps run whole groups of three / four 8-step blocks and prefetch up to 24 steps further
-  S->geom.S = (size_t)S->geom.nbands * S->geom.TS * 64;
-  const size_t SS = S->geom.S;
-  if ((SS + EU_SKEW_SLACK) * 8 >= ((size_t)1 << 32)) { eu_set_error("grid too large for 32-bit record offsets"); euler_destroy(S); return EULER_EINVAL; }
   // skewed arrays carry EU_SKEW_SLACK zeroed elements in front (the backward sweep prefetches below record 0)
   for (double** d : {&S->b, &S->p, &S->r, &S->z, &S->s, &S->q, &S->precon}) { DALLOC(*d, SS + EU_SKEW_SLACK); *d += EU_SKEW_SLACK; }
   DALLOC(S->krku, 2 * (SS + EU_SKEW_SLACK)); S->krku += 2 * EU_SKEW_SLACK;

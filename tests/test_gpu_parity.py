@@ -382,6 +382,9 @@ def test_error_conventions():
     assert e.value.code == -3 and "Could not load" in str(e.value)   # reference main.c:213
     with pytest.raises(ea.EulerError):
         ea.Simulation(4, 4)
+    with pytest.raises(ea.EulerError) as e:
+        ea.Simulation(20000, 20000)         # beyond the supported maximum: refused before anything is allocated
+    assert e.value.code == -1 and "supported maximum" in str(e.value)
 
 
 def test_cli_dump_matches_reference_frames(tmp_path):
@@ -570,4 +573,29 @@ def test_reported_residual_is_the_true_residual_2048():
     scale = np.abs(b).max()
     assert np.abs(true_r - r).max() <= 1e-9 * scale, (np.abs(true_r - r).max(), scale)
     assert abs(np.abs(true_r).max() - sim.stats().last_residual) <= 1e-9 * scale
+    sim.close()
+
+
+# ----------------------------------------------------------------------------- degenerate inputs
+@pytest.mark.parametrize("size,text", [
+    ((100, 40), ""),                                  # empty file: nothing but the sink ring, no markers at all
+    ((100, 40), "X" * 98 + "\n" + "X" * 98 + "\n"),   # only walls
+    ((100, 40), "?\n"),                               # one source cell and nothing else: the fluid appears from nothing
+    ((8, 8), "00\n00\n"),                             # smallest useful grid, fluid against the sink ring
+    ((70, 9), "0" * 68 + "\n" + "0" * 68 + "\n"),     # one short band, very flat
+    ((9, 200), "\n".join(["0000000"] * 150) + "\n"),  # very narrow, 4 bands tall: T = 72, a band is mostly skew padding
+])
+def test_degenerate_scenarios_bit_exact_vs_oracle(size, text):
+    """Zero markers, no fluid, one cell, grids smaller than a band or narrower than the skew: every stage must cope
+    with empty launches and all-padding bands, and stay bit-identical to the oracle."""
+    o = Oracle(size[0], size[1]).load_text(text, upscale=False)
+    sim = ea.Simulation(size[0], size[1], dot_mode=ea.DOT_SEQUENTIAL).load_text(text, upscale=False)
+    compare_all(o, sim, "init")
+    for f in range(6):
+        o.step()
+        sim.step()
+        st = sim.stats()
+        assert st.n_markers == o.c.n_markers and st.last_substeps == o.c.last_substeps, f
+        compare_all(o, sim, "%s frame %d" % (size, f))
+    assert sim.draw(size[0] - 2, size[1] - 2) == o.render(size[0] - 2, size[1] - 2) if hasattr(o, "render") else True
     sim.close()
