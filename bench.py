@@ -256,9 +256,19 @@ def main():
                 "avg_launch_us": round(1e3 * ms / launches, 2), "launches": int(launches)}
     # whole PCG iteration: per-launch averages summed over the six kernel classes (dominant: timed region;
     # the others: second pass), against the 149 B per cell and iteration BASELINE.md prescribes
-    per_iter_ms = sum(prof[k][0] / prof[k][1] for k in ALGO_BYTES if k in prof and prof[k][1])
+    # total time of each class / PCG iterations of the pass it was timed in (dominant: the timed region; the others:
+    # the second pass) - a class may have fewer launches than iterations (the s = z copy at the start of a solve)
+    per_iter_ms = sum(prof[k][0] / (iters if k == dominant else iters_pass2) for k in ALGO_BYTES
+                      if k in prof and (iters if k == dominant else iters_pass2))
     pcg_ms = per_iter_ms * iters
-    pcg_gbps = PCG_BYTES_PER_CELL_ITER * cells / (per_iter_ms * 1e-3) / 1e9 if per_iter_ms and len([k for k in ALGO_BYTES if k in prof]) == len(ALGO_BYTES) else None
+    # single GPU: update_search (K5) runs fused into the next iteration's apply_a (K1) and has no launches of its own
+    fused_k5 = world == 1 and "apply_a" in prof
+    if fused_k5:
+        kern["apply_a"]["note"] = "update_search fused in: 42 algorithmic B/cell (2w+1 + 3w+1)"
+        kern["apply_a"]["algo_GBps"] = round((ALGO_BYTES["apply_a"] + ALGO_BYTES["update_search"]) * cells_launch
+                                              / (prof["apply_a"][0] / prof["apply_a"][1] * 1e-3) / 1e9, 1)
+    have = len([k for k in ALGO_BYTES if k in prof]) + (1 if fused_k5 else 0)
+    pcg_gbps = PCG_BYTES_PER_CELL_ITER * cells / (per_iter_ms * 1e-3) / 1e9 if per_iter_ms and have == len(ALGO_BYTES) else None
 
     cpu_obj = None
     if cpu:

@@ -140,7 +140,7 @@ extern "C" void euler_destroy(euler_sim* S) {
                  S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->fbits_fwd, S->fbits_bwd, S->halo_buf, S->band_ranges,
                  S->rowmajor_tmp};
   for (void* p : dev) if (p) (void)hipFree(p);
-  for (double* d : {S->b, S->p, S->r, S->z, S->s, S->q, S->precon}) if (d) (void)hipFree(d - EU_SKEW_SLACK);
+  for (double* d : {S->b, S->p, S->r, S->z, S->s, S->s2, S->q, S->precon}) if (d) (void)hipFree(d - EU_SKEW_SLACK);
   if (S->krku) (void)hipFree(S->krku - 2 * EU_SKEW_SLACK);
   if (S->cellmask) (void)hipFree(S->cellmask - EU_SKEW_SLACK);
   if (S->ms_host) (void)hipHostFree(S->ms_host);
@@ -213,7 +213,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   S->sel.capacity_blocks = (mwords + 2047) / 2048 + 1;
   DALLOC(S->sel.block_sums, S->sel.capacity_blocks);
   // skewed arrays carry EU_SKEW_SLACK zeroed elements in front (the backward sweep prefetches below record 0)
-  for (double** d : {&S->b, &S->p, &S->r, &S->z, &S->s, &S->q, &S->precon}) { DALLOC(*d, SS + EU_SKEW_SLACK); *d += EU_SKEW_SLACK; }
+  for (double** d : {&S->b, &S->p, &S->r, &S->z, &S->s, &S->s2, &S->q, &S->precon}) { DALLOC(*d, SS + EU_SKEW_SLACK); *d += EU_SKEW_SLACK; }
   DALLOC(S->krku, 2 * (SS + EU_SKEW_SLACK)); S->krku += 2 * EU_SKEW_SLACK;
   DALLOC(S->cellmask, SS + EU_SKEW_SLACK); S->cellmask += EU_SKEW_SLACK;
   S->fb_stride = 12 * (((S->geom.T + 7) / 8 + 11) / 12) + 4;   // whole groups of 3 and of 4 blocks + the blocks the prefetch runs ahead
@@ -277,7 +277,7 @@ static int upload_scenario(euler_sim* S, const uint8_t* solid, const uint8_t* so
   HIPCHK(hipMemcpyAsync(S->source, source, C, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(S->sink, sink, C, hipMemcpyHostToDevice, st));
   for (float* f : {S->u, S->v, S->utmp, S->vtmp}) HIPCHK(hipMemsetAsync(f, 0, C * sizeof(float), st));
-  for (double* d : {S->b, S->p, S->r, S->z, S->s, S->q, S->precon}) HIPCHK(hipMemsetAsync(d, 0, S->geom.S * sizeof(double), st));
+  for (double* d : {S->b, S->p, S->r, S->z, S->s, S->s2, S->q, S->precon}) HIPCHK(hipMemsetAsync(d, 0, S->geom.S * sizeof(double), st));
   HIPCHK(hipMemsetAsync(S->count, 0, C, st));
   HIPCHK(hipMemsetAsync(S->prev_count, 0, C, st));
   HIPCHK(hipMemsetAsync(S->cellmask, 0, S->geom.S, st));

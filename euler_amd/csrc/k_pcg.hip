@@ -244,6 +244,82 @@ __global__ __launch_bounds__(RED_THREADS) void k_apply_a(const double* __restric
   if (fin_op >= 0) block_finish<false>(t, partial, counter, sc, fin_op);   // fin_op < 0: dot(z,s) is replayed sequentially
 }
 
+// update_search (main.c:669-677) of one iteration fused into apply_a (main.c:679-691) of the next:
+//     s' = z + beta s   and   out = A s'   in one pass, out going to a scratch array (the forward solve's q, dead here).
+// A cell needs s' of its four neighbours, which it recomputes from z and the old s (the same expression its owner
+// evaluates: identical bits) - hence s' goes to a SECOND array, or a neighbour could read a half-updated s.
+// Saves a launch and 9 bytes per cell and iteration.  Same pair-per-thread structure as k_apply_a.
+__global__ __launch_bounds__(RED_THREADS) void k_search_apply(const double* __restrict__ s_old, const double* __restrict__ z,
+                                                              double* __restrict__ s_new, double* __restrict__ out,
+                                                              const uint8_t* __restrict__ mask, SkewGeom g,
+                                                              double* __restrict__ partial, PcgScalars* sc, int force,
+                                                              unsigned int* counter, int fin_op) {
+  if (!force && pcg_idle(sc)) return;
+  const double beta = sc->beta;
+  const size_t S = g.S;
+  const size_t chunk = (((S + gridDim.x - 1) / gridDim.x) + 127) & ~(size_t)127;   // whole record pairs per block
+  const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < S ? lo + chunk : S;
+  auto sn = [&](size_t k) { return z[k] + beta * s_old[k]; };                       // s' of a (fluid) neighbour
+  double t = 0.0;
+  for (size_t i = lo + 2 * (size_t)threadIdx.x; i < hi; i += 2 * RED_THREADS) {
+    const unsigned int mm = *reinterpret_cast<const unsigned short*>(mask + i);
+    const unsigned int m0 = mm & 0xff, m1 = mm >> 8;
+    if (!((m0 | m1) & CM_FLUID)) continue;
+    const sw_d2 so = *reinterpret_cast<const sw_d2*>(s_old + i), zc = *reinterpret_cast<const sw_d2*>(z + i);
+    const int l = (int)((i & 127) >> 1);
+    sw_d2 c = so, o = {0.0, 0.0};                     // c: the pair's s'
+    if (m0 & CM_FLUID) c.x = zc.x + beta * so.x;
+    if (m1 & CM_FLUID) c.y = zc.y + beta * so.y;
+    if (m0 & CM_FLUID) {
+      double v = (double)(int)(m0 >> CM_DIAG_SHIFT) * c.x;
+      v = v - ((m0 & CM_RIGHT) ? c.y : 0.0);
+      if (m0 & CM_UP) {
+        size_t up = i + 3;
+        if (l == 63) { int band, tt, ll; skew_decode(g, i, band, tt, ll); up = skew_index(g, tt - 63, 64 * (band + 1)); }
+        v = v - sn(up);
+      } else {
+        v = v - 0.0;
+      }
+      v = v - ((m0 & CM_LEFT) ? sn(i - 127) : 0.0);
+      if (m0 & CM_DOWN) {
+        size_t dn = i - 129;
+        if (l == 0) { int band, tt, ll; skew_decode(g, i, band, tt, ll); dn = skew_index(g, tt, 64 * band - 1); }
+        v = v - sn(dn);
+      } else {
+        v = v - 0.0;
+      }
+      o.x = v;
+      t += v * c.x;
+    }
+    if (m1 & CM_FLUID) {
+      double v = (double)(int)(m1 >> CM_DIAG_SHIFT) * c.y;
+      v = v - ((m1 & CM_RIGHT) ? sn(i + 128) : 0.0);
+      if (m1 & CM_UP) {
+        size_t up = i + 130;
+        if (l == 63) { int band, tt, ll; skew_decode(g, i + 1, band, tt, ll); up = skew_index(g, tt - 63, 64 * (band + 1)); }
+        v = v - sn(up);
+      } else {
+        v = v - 0.0;
+      }
+      v = v - ((m1 & CM_LEFT) ? c.x : 0.0);
+      if (m1 & CM_DOWN) {
+        size_t dn = i - 2;
+        if (l == 0) { int band, tt, ll; skew_decode(g, i + 1, band, tt, ll); dn = skew_index(g, tt, 64 * band - 1); }
+        v = v - sn(dn);
+      } else {
+        v = v - 0.0;
+      }
+      o.y = v;
+      t += v * c.y;
+    }
+    if ((m0 & m1) & CM_FLUID) { *reinterpret_cast<sw_d2*>(s_new + i) = c; *reinterpret_cast<sw_d2*>(out + i) = o; }
+    else if (m0 & CM_FLUID) { s_new[i] = c.x; out[i] = o.x; }
+    else { s_new[i + 1] = c.y; out[i + 1] = o.y; }
+  }
+  t = block_sum(t);
+  if (fin_op >= 0) block_finish<false>(t, partial, counter, sc, fin_op);   // fin_op < 0: dot(out, s') is replayed sequentially
+}
+
 // p += alpha s ; r -= alpha z (fmadd x2, main.c:753-754) ; per-block max |r| (inf_norm, main.c:654-667)
 __global__ __launch_bounds__(RED_THREADS) void k_update_pr(double* __restrict__ p, double* __restrict__ r,
                                                            const double* __restrict__ s, const double* __restrict__ z,
@@ -1049,6 +1125,17 @@ static int launch_apply_a_and_alpha(euler_sim* S, int force) {
   return EULER_OK;
 }
 
+// iterations >= 1 of a single-GPU solve: s' = z + beta s and A s' in one launch; returns with S->s = s' and A s' in S->q
+static int launch_search_apply_and_alpha(euler_sim* S) {
+  const bool seq = S->cfg.dot_mode == EULER_DOT_SEQUENTIAL;
+  LAUNCH(S, KC_APPLY_A, k_search_apply, dim3(S->red_blocks), dim3(RED_THREADS), S->s, S->z, S->s2, S->q, S->cellmask, S->geom,
+         S->partial, S->sc, 0, S->red_counter, seq ? -1 : (int)FIN_ALPHA);
+  double* t = S->s; S->s = S->s2; S->s2 = t;
+  if (seq)
+    LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), S->q, S->s, S->cellmask, S->geom, S->sc, (int)FIN_ALPHA, 0);
+  return EULER_OK;
+}
+
 int eu_launch_build_system(euler_sim* S, float dt);
 int eu_launch_velocity_update(euler_sim* S, float dt);
 
@@ -1085,6 +1172,7 @@ int eu_launch_project(euler_sim* S, float dt) {
   LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<true>, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->s), LOC(S->z),
          LOC(S->cellmask), S->e_cnt, S->sc, 0, 0.0);
   if ((rc = launch_dot(S, S->z, S->r, FIN_SIGMA_INIT, 0))) return rc;
+  if (!S->has_comm) HIPCHK(hipMemsetAsync(S->s2, 0, S->geom.S * sizeof(double), S->stream));   // s' of non-fluid cells is never written
   HIPCHK(hipMemcpyAsync(S->sc_host, S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
   HIPCHK(hipStreamSynchronize(S->stream));
   const int poll = S->cfg.pcg_poll_interval > 0 ? S->cfg.pcg_poll_interval : 8;
@@ -1095,9 +1183,10 @@ int eu_launch_project(euler_sim* S, float dt) {
     const int chunk_end = it + poll < max_it ? it + poll : max_it;
     for (; it < chunk_end; ++it) {
       S->prof_iter = it;
-      if ((rc = launch_apply_a_and_alpha(S, 0))) return rc;
-      LAUNCH(S, KC_UPDATE_PR, k_update_pr, dim3(loc_red_blocks(S)), dim3(RED_THREADS), LOC(S->p), LOC(S->r), LOC(S->s), LOC(S->z),
-             LOC(S->cellmask), S->e_cnt, S->partial, S->sc, 0, 0.0, S->red_counter, fin_or_comm(S, FIN_RNORM));
+      const bool fused = it > 0 && !S->has_comm;   // update_search of iteration it-1 rides along with this apply_a (A s' lands in q)
+      if ((rc = fused ? launch_search_apply_and_alpha(S) : launch_apply_a_and_alpha(S, 0))) return rc;
+      LAUNCH(S, KC_UPDATE_PR, k_update_pr, dim3(loc_red_blocks(S)), dim3(RED_THREADS), LOC(S->p), LOC(S->r), LOC(S->s),
+             LOC(fused ? S->q : S->z), LOC(S->cellmask), S->e_cnt, S->partial, S->sc, 0, 0.0, S->red_counter, fin_or_comm(S, FIN_RNORM));
       if (S->has_comm && (rc = comm_finish(S, FIN_RNORM, 1, 0))) return rc;
       if (it + 1 < max_it) {   // the tail of the last iteration (main.c:760-765) is never consumed
         // these belong to iteration `it` but only run if it did not converge: tag them it+1 so that
@@ -1105,8 +1194,9 @@ int eu_launch_project(euler_sim* S, float dt) {
         S->prof_iter = it + 1;
         if ((rc = launch_precondition(S, 0))) return rc;
         if ((rc = launch_dot(S, S->z, S->r, FIN_BETA, 0))) return rc;
-        LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<false>, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->s),
-               LOC(S->z), LOC(S->cellmask), S->e_cnt, S->sc, 0, 0.0);
+        if (S->has_comm)   // (single GPU: fused into the next iteration's apply_a)
+          LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<false>, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->s),
+                 LOC(S->z), LOC(S->cellmask), S->e_cnt, S->sc, 0, 0.0);
       }
     }
     if (it < max_it) {   // poll the device-side convergence flag (identical on every rank)
