@@ -267,8 +267,8 @@ def main():
         kern["apply_a"]["note"] = "update_search fused in: 42 algorithmic B/cell (2w+1 + 3w+1)"
         kern["apply_a"]["algo_GBps"] = round((ALGO_BYTES["apply_a"] + ALGO_BYTES["update_search"]) * cells_launch
                                               / (prof["apply_a"][0] / prof["apply_a"][1] * 1e-3) / 1e9, 1)
-    have = len([k for k in ALGO_BYTES if k in prof]) + (1 if fused_k5 else 0)
-    pcg_gbps = PCG_BYTES_PER_CELL_ITER * cells / (per_iter_ms * 1e-3) / 1e9 if per_iter_ms and have == len(ALGO_BYTES) else None
+    complete = all(k in prof for k in ALGO_BYTES if k != "update_search" or not fused_k5)
+    pcg_gbps = PCG_BYTES_PER_CELL_ITER * cells / (per_iter_ms * 1e-3) / 1e9 if per_iter_ms and complete else None
 
     cpu_obj = None
     if cpu:
