@@ -878,13 +878,14 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
       };
       step(std::integral_constant<int, 0>()); step(std::integral_constant<int, 1>()); step(std::integral_constant<int, 2>());
       step(std::integral_constant<int, 3>());
+      step(std::integral_constant<int, 4>()); step(std::integral_constant<int, 5>());
       if (HP) {
-        // half-way: the next block's boundary values (deposited once dep_done > rel+1; past the range: whatever is there)
+        // two steps before the block ends (an LDS round trip): the next block's boundary values (deposited once
+        // dep_done > rel+1; past the range: whatever is there).  A starved wave waits here, as late as possible.
         if (__builtin_expect(rel + 1 < NBLK && (int)(unsigned int)prog < rel + 2, 0)) await(&sh.dep_done, rel + 2);
         read_boundary(rel + 1, be_next);
         if (SW_TRACE_HANDOFF && blk + 1 == SW_TRACE_CB && lane == 0) a.timeline[(size_t)ord * 8 + 7] = wall_clock64();
       }
-      step(std::integral_constant<int, 4>()); step(std::integral_constant<int, 5>());
       step(std::integral_constant<int, 6>()); step(std::integral_constant<int, 7>());
       __builtin_amdgcn_sched_barrier(0);
       p_out += 4 * PSTEP; p_okk += 4 * 2 * PSTEP;
