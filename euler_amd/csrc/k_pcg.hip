@@ -427,7 +427,7 @@ struct SweepArgs {
   const PcgScalars* sc;
   int force;
   int* error;
-  unsigned long long* timeline;   // [nbands][4] {entry, first block ready, exit, stalled blocks} (euler_sweep_timeline)
+  unsigned long long* timeline;   // [nbands][8] {entry, first block ready, exit, blocks << 32 | stalled blocks, 4 development words} (euler_sweep_timeline)
 };
 
 template <int OP>
@@ -489,24 +489,26 @@ __global__ __launch_bounds__(1024) void k_sweep_simple(SweepArgs a) {
 // Compute wave.  Lane l owns row 64 b + l.  Forward: records t = 0, 1, ..., lane l is at column t - l,
 // the row below arrives from lane l-1 (DPP wave_shr:1), the previous column is the lane's own
 // register.  Backward: records T-1, T-2, ..., the row above arrives from lane l+1 (DPP wave_shl:1).
-// The loop body is 8 steps = one hand-off block, fully unrolled; the operands of block k+1 (coalesced
-// 512-B record loads, per-lane stream pointers with immediate offsets j*512, fluid flags 8 steps to a
-// dword) are fetched while block k computes.  A lone wave is bound by instruction ISSUE and by
-// the latency of whatever it waits for, so the compute wave touches global memory only for its
-// streams and everything about the band hand-off lives in the helper wave (own SIMD, own vmcnt):
-//   * every step's carry row goes to an LDS ring (one ds_write); the helper gathers the edge lane's
-//     (63 forward / 0 backward: logical column s-63) values block by block and publishes them to the
-//     next band as 16-byte granule pairs {lo, epoch, hi, epoch} (write-through stores);
-//   * the helper polls the previous band's granules up to 8 blocks ahead with ONE load per round
-//     trip and parks validated boundary values in a second LDS ring; the compute wave reads a
-//     block's 8 values as broadcasts - the `old` operand of the DPP shift, i.e. what the lane
-//     without a shift source receives.
+// The unit of work is 8 steps = one hand-off block, fully unrolled; records come in pairs (a lane's elements of
+// records 2P, 2P+1 are adjacent), so every stream moves two steps per 16-byte access, and the operands of the
+// next two or three blocks are in flight into rotating register sets while a block computes (fluid flags: 8
+// steps to a dword).  A lone wave is bound by instruction ISSUE and by the latency of whatever it waits
+// for, so the compute wave touches global memory only for its streams and everything about the band
+// hand-off lives in the helper waves (own SIMDs, own vmcnt):
+//   * the compute wave drops every step's carry row into an LDS ring (two rows per ds_write2st64_b64); the
+//     ANNOUNCE wave gathers the edge lane's (63 forward / 0 backward: logical column s-63) values block by
+//     block and publishes them to the next band as 16-byte granule pairs {lo, epoch, hi, epoch}
+//     (write-through stores), up to 8 groups per store;
+//   * the FETCH wave polls the previous band's granules with 4 loads in flight, each covering up to 8 blocks
+//     ahead of the compute wave, and parks validated boundary values in a second LDS ring; the compute wave
+//     reads a block's 8 values as broadcasts two steps before the previous block ends - they become the `old`
+//     operand of the DPP shift, i.e. what the lane without a shift source receives.
 // The waves talk through three monotonic LDS counters (blocks computed / boundary blocks deposited /
 // groups announced); a wave's LDS operations execute in order, so "data, then counter" needs no fence.
 // Bands take their order from a ticket, so a band only ever waits on a band that is already
 // running: no residency assumption, no deadlock; every spin is bounded (sticky error -> ETIMEOUT).
-// One band per workgroup (= per CU) on purpose: a band streams ~16 B/cycle, so 4 compute waves would
-// saturate a CU's ~64 B/clk vector-memory path (measured 1.4x / 2x slower with 4 / 8 bands per CU).
+// One band per workgroup (= per CU) on purpose: the CU's vector-memory path is shared - a second compute wave
+// on the CU costs each +18 % per step, four run 2.2x slower (tools/micro/step_bench2).
 // Measured and rejected: staging the compute wave's streams through LDS as well (a load wave feeding an
 // operand ring by LDS-DMA, a store wave draining a result ring; the compute wave without any global access).
 // A stand-alone model of the step promised 27 ns instead of 40; the real kernel, with its per-block
