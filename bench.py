@@ -55,6 +55,11 @@ def parse_args():
     ap.add_argument("--slab", default="local", choices=["local", "exact", "replicas"],
                     help="N>1: slab-local IC(0) (scales; tolerance-only), exact coupling (the 1-GPU iterates; sweeps "
                          "serialize across GPUs) or independent replicas")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
+                    help="N>1 exchange transport: the library's own RCCL communicator (C, no host code between kernels) "
+                         "or the torch.distributed callbacks of euler_amd/slab.py")
+    ap.add_argument("--force-slab", action="store_true",
+                    help="N=1 diagnostics: run the communicator code path with one rank (every exchange still goes through RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the hipEvent per-kernel timing (used under rocprofv3)")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel class (diagnostics)")
@@ -138,8 +143,18 @@ def cpu_model():
 
 def main():
     args = parse_args()
+    # stdout carries exactly ONE line, the JSON: whatever native libraries print on fd 1 while the job runs
+    # (RCCL writes its version banner there when a communicator is created) is diverted to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(line, flush=True)
     from euler_amd.dist import Group, whole_job_rate
-    grp = Group()                      # one process per GPU; "nccl" (= RCCL) when N > 1
+    grp = Group(force=args.force_slab)   # one process per GPU; "nccl" (= RCCL) when N > 1
     rank, local_rank, world = grp.rank, grp.local_rank, grp.world
     if world > 1:
         args.gpus = world
@@ -153,15 +168,15 @@ def main():
     precond = ea.PRECOND_IC0 if args.precond == "ic0" else ea.PRECOND_JACOBI
     # N > 1 (weak scaling): the grid grows to N x (N * gpus) rows; the pressure solve is split into one
     # slab of N rows per GPU, the cheap stages run replicated (DESIGN.md "Multi-GPU")
-    sharded = world > 1 and args.slab != "replicas"
+    sharded = (world > 1 or args.force_slab) and args.slab != "replicas"
     GX, GY = N, N * (world if sharded else 1)
     if world > 1:
         torch.cuda.set_device(local_rank)
     sim = ea.Simulation(GX, GY, device=local_rank, dot_mode=dot_mode, precond=precond)
     comm = None
     if sharded:
-        from euler_amd.slab import SLAB_EXACT, SLAB_LOCAL, TorchComm
-        comm = TorchComm(sim, SLAB_EXACT if args.slab == "exact" else SLAB_LOCAL)
+        from euler_amd.slab import SLAB_EXACT, SLAB_LOCAL, RcclComm, TorchComm
+        comm = (RcclComm if args.comm == "rccl" else TorchComm)(sim, SLAB_EXACT if args.slab == "exact" else SLAB_LOCAL)
     if args.workload == "dam_break":
         sim.load_text(scenarios.dam_break(), upscale=True)
     elif args.workload == "waterfall":
@@ -180,7 +195,7 @@ def main():
 
     # CPU baseline from the same state (rank 0, N=1 only)
     cpu = None
-    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline and not args.force_slab:
         cpu = cpu_baseline(sim, ea)
 
     # in-run parity note: advance the GPU by the same number of frames the strict-IEEE oracle ran
@@ -251,7 +266,7 @@ def main():
         achieved = ALGO_BYTES[dominant] * cells_launch / (ms / launches * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": pmc_traffic(N, args.workload, dominant) if world == 1 else None,
+                "traffic": pmc_traffic(N, args.workload, dominant) if not sharded else None,
                 "algorithmic_bytes_per_launch": ALGO_BYTES[dominant] * cells_launch,
                 "avg_launch_us": round(1e3 * ms / launches, 2), "launches": int(launches)}
     # whole PCG iteration: per-launch averages summed over the six kernel classes (dominant: timed region;
@@ -262,7 +277,7 @@ def main():
                       if k in prof and (iters if k == dominant else iters_pass2))
     pcg_ms = per_iter_ms * iters
     # single GPU: update_search (K5) runs fused into the next iteration's apply_a (K1) and has no launches of its own
-    fused_k5 = world == 1 and "apply_a" in prof
+    fused_k5 = not sharded and "apply_a" in prof
     if fused_k5:
         kern["apply_a"]["note"] = "update_search fused in: 42 algorithmic B/cell (2w+1 + 3w+1)"
         kern["apply_a"]["algo_GBps"] = round((ALGO_BYTES["apply_a"] + ALGO_BYTES["update_search"]) * cells_launch
@@ -294,10 +309,10 @@ def main():
         "config": {"workload": "%dx%d %s, %s" % (GX, GY, args.workload, "block layout upscaled" if args.workload == "dam_break" else "synthetic"),
                    "grid": [GX, GY], "preroll_frames": preroll, "precond": args.precond, "dot_mode": args.dot_mode,
                    "max_iterations": 100, "tol": 1e-6,
-                   "parallelism": "1 GPU" if args.gpus == 1 else (
+                   "parallelism": "1 GPU" if args.gpus == 1 and not sharded else (
                        "%d independent replicas" % args.gpus if not sharded else
-                       "%d row slabs of %d rows: distributed PCG (%s IC(0) coupling), replicated marker/advection stages; grid %dx%d"
-                       % (args.gpus, N, args.slab, GX, GY))},
+                       "%d row slabs of %d rows: distributed PCG (%s IC(0) coupling, exchanges by %s), replicated marker/advection stages; grid %dx%d"
+                       % (args.gpus, N, args.slab, "RCCL from the C library" if args.comm == "rccl" else "torch.distributed callbacks", GX, GY))},
         "substeps": int(substeps), "pcg_iterations": int(iters),
         "cells_substeps_per_s": cells * substeps / elapsed,
         "markers": int(st1.n_markers), "fluid_cells": int(st1.fluid_cells),
@@ -310,7 +325,8 @@ def main():
         "parity_in_run": parity,
         "device": sim.device_name(),
     }
-    print(json.dumps(out))
+    emit(json.dumps(out))
+    os.dup2(2, 1)
     grp.close()
 
 

@@ -67,6 +67,7 @@ EXPORTS = [
     "euler_field_bytes", "euler_render", "euler_render_grids", "euler_profile_enable",
     "euler_profile_class_count", "euler_profile_class_name", "euler_profile_get", "euler_profile_reset",
     "euler_measure_copy_bandwidth", "euler_device_name", "euler_sweep_timeline", "euler_save_state", "euler_load_state", "euler_set_comm", "euler_set_stream", "euler_slab_info",
+    "euler_rccl_unique_id", "euler_rccl_version", "euler_set_comm_rccl", "euler_comm_calls",
 ]
 
 
@@ -119,6 +120,10 @@ def load_library():
         "euler_set_comm": (C.c_int, [vp, vp, i32]),                 # euler_amd/slab.py passes a CommOps struct
         "euler_set_stream": (C.c_int, [vp, vp]),
         "euler_slab_info": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+        "euler_rccl_unique_id": (C.c_int, [vp, i32]),
+        "euler_rccl_version": (C.c_int, []),
+        "euler_set_comm_rccl": (C.c_int, [vp, vp, i32, i32, i32, i32]),
+        "euler_comm_calls": (C.c_int, [vp, C.POINTER(u64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)   # AttributeError here = a symbol include/euler.h declares is not exported

@@ -135,6 +135,7 @@ static int dalloc(T** p, size_t n) {
 extern "C" void euler_destroy(euler_sim* S) {
   if (!S) return;
   if (S->stream) (void)hipStreamSynchronize(S->stream);
+  eu_rccl_release(S);
   void* dev[] = {S->u, S->v, S->utmp, S->vtmp, S->solid, S->source, S->sink, S->count, S->prev_count, S->count32,
                  S->markers[0], S->markers[1], S->ms, S->evmask, S->ev_theta, S->ev_delta, S->sel_idx, S->act_idx,
                  S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->fbits_fwd, S->fbits_bwd, S->halo_buf, S->band_ranges,
@@ -356,9 +357,10 @@ extern "C" int euler_set_stream(euler_sim* S, void* hip_stream) {
   return EULER_OK;
 }
 
-extern "C" int euler_set_comm(euler_sim* S, const euler_comm_ops* ops, int32_t coupling) {
+// allow_single: keep the communicator code path with one rank (the RCCL self-test on a 1-GPU box)
+int eu_install_comm(euler_sim* S, const euler_comm_ops* ops, int32_t coupling, int allow_single) {
   if (!S) return EULER_EINVAL;
-  if (!ops || ops->nranks <= 1) {
+  if (!ops || ops->nranks < 1 || (ops->nranks == 1 && !allow_single)) {
     S->has_comm = 0; S->band_lo = 0; S->band_hi = S->geom.nbands; S->e_lo = 0; S->e_cnt = S->geom.S;
     return EULER_OK;
   }
@@ -377,6 +379,13 @@ extern "C" int euler_set_comm(euler_sim* S, const euler_comm_ops* ops, int32_t c
   S->e_cnt = (size_t)(S->band_hi - S->band_lo) * S->geom.TS * 64;
   if (S->cfg.dot_mode == EULER_DOT_SEQUENTIAL) S->cfg.dot_mode = EULER_DOT_TREE;   // the replay order is a 1-rank notion
   return EULER_OK;
+}
+
+extern "C" int euler_set_comm(euler_sim* S, const euler_comm_ops* ops, int32_t coupling) {
+  if (!S) return EULER_EINVAL;
+  HIPCHK(hipStreamSynchronize(S->stream));
+  eu_rccl_release(S);   // a caller-supplied communicator replaces the built-in one
+  return eu_install_comm(S, ops, coupling, 0);
 }
 
 extern "C" int euler_slab_info(euler_sim* S, int32_t* lo, int32_t* hi, int32_t* nb) {

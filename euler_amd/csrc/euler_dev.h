@@ -158,6 +158,7 @@ struct euler_sim {
   size_t e_lo, e_cnt;         // the same range in skewed elements
   double* halo_buf;           // 4 rows of X doubles: send_lo, send_hi, recv_lo, recv_hi
   int own_stream;
+  void* rccl;                 // the built-in RCCL communicator (comm_rccl.hip), if euler_set_comm_rccl installed one
 
   // profiling: hipEvent pairs per launch; PCG launches carry (solve, iteration) so that launches
   // that returned at once (after convergence / all-zero rhs) are NOT counted
@@ -206,6 +207,8 @@ int eu_launch_pcg_op(euler_sim* S, int op, float dt, double a, double* out);
 int eu_ordered_select(euler_sim* S, const unsigned long long* mask, size_t nwords, unsigned int* out_idx,
                       unsigned int* out_total);
 int eu_sync_marker_state(euler_sim* S);
+void eu_rccl_release(euler_sim* S);   // comm_rccl.hip
+int eu_install_comm(euler_sim* S, const euler_comm_ops* ops, int32_t coupling, int allow_single);
 
 // ------------------------------------------------------------------------------------------
 // device helpers

@@ -8,16 +8,19 @@ import time
 
 
 class Group:
-    def __init__(self, backend=None):
+    def __init__(self, backend=None, force=False):
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.dist = None
         self.device = None
-        if self.world > 1:
+        if self.world > 1 or force:   # force: a one-rank process group (transport self-test on a 1-GPU box)
             import torch
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if force and self.world == 1:
+                for k, v in (("MASTER_PORT", "29577"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
+                    os.environ.setdefault(k, v)
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             if backend is None:
                 backend = os.environ.get("EULER_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")

@@ -145,3 +145,42 @@ class TorchComm:
                 else:
                     self.dist.broadcast(t, src=r)
         return self._guard("allgather", run)
+
+
+class RcclComm:
+    """The library's own RCCL communicator (csrc/comm_rccl.hip): no Python between the kernels of a
+    PCG iteration.  torch.distributed is used once, to hand rank 0's ncclUniqueId to every rank."""
+
+    ID_BYTES = 128
+
+    def __init__(self, sim, coupling=SLAB_EXACT):
+        import torch
+        import torch.distributed as dist
+        self.sim = sim
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.error = None
+        L = sim.L
+        buf = (C.c_ubyte * self.ID_BYTES)()
+        if self.rank == 0:
+            rc = L.euler_rccl_unique_id(buf, self.ID_BYTES)
+            if rc:
+                raise RuntimeError("euler_rccl_unique_id failed: %s" % L.euler_last_error().decode())
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor(list(bytes(buf)), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=0)
+        ident = bytes(t.cpu().tolist())
+        rc = L.euler_set_comm_rccl(sim.h, ident, len(ident), self.rank, self.world, coupling)
+        if rc:
+            raise RuntimeError("euler_set_comm_rccl failed: %s" % L.euler_last_error().decode())
+        lo, hi, nb = C.c_int32(), C.c_int32(), C.c_int32()
+        L.euler_slab_info(sim.h, C.byref(lo), C.byref(hi), C.byref(nb))
+        self.band_lo, self.band_hi, self.nbands = lo.value, hi.value, nb.value
+        assert (self.band_lo, self.band_hi) == slab_bands(self.nbands, self.rank, self.world)
+        self.version = L.euler_rccl_version()
+        sim._comm = self
+
+    @property
+    def counts(self):
+        out = (C.c_uint64 * 4)()
+        self.sim.L.euler_comm_calls(self.sim.h, out)
+        return dict(zip(("allreduce", "halo", "chain", "allgather"), (int(v) for v in out)))

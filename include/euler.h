@@ -226,6 +226,20 @@ enum {
                              concurrently; NOT the reference's iterates (tolerance only) */
 };
 int euler_set_comm(euler_sim* sim, const euler_comm_ops* ops, int32_t coupling);
+
+/* The library's own communicator: the four operations above issued straight to RCCL (xGMI on an
+ * MI355X node) on the handle's stream - no host code between two kernels of a PCG iteration.
+ * Rank 0 creates an id (EULER_RCCL_ID_BYTES bytes = ncclUniqueId) and the launcher hands the same
+ * bytes to every rank over whatever host channel it has (torchrun's store, MPI, a file); then every
+ * rank calls euler_set_comm_rccl collectively, after hipSetDevice-equivalent euler_create on its own
+ * GPU.  RCCL is bound at run time (dlopen of librccl.so.1; a copy already in the process is reused);
+ * EULER_ECOMM if it is absent.  nranks = 1 is accepted and keeps the communicator code path (self-test). */
+#define EULER_RCCL_ID_BYTES 128
+int euler_rccl_unique_id(void* id_out, int32_t cap);
+int euler_rccl_version(void);                                  /* NCCL-style version code, -1 if unavailable */
+int euler_set_comm_rccl(euler_sim* sim, const void* unique_id, int32_t id_bytes, int32_t rank, int32_t nranks,
+                        int32_t coupling);
+int euler_comm_calls(euler_sim* sim, uint64_t out[4]);         /* built-in communicator: allreduce, halo, chain, allgather calls so far */
 int euler_set_stream(euler_sim* sim, void* hip_stream);   /* run on the caller's HIP stream (e.g. torch's) */
 int euler_slab_info(euler_sim* sim, int32_t* band_lo, int32_t* band_hi, int32_t* nbands);
 
