@@ -43,6 +43,8 @@ eo_sim* eo_create(int X, int Y) {
   s->b = calloc(C, sizeof(double)); s->p = calloc(C, sizeof(double));
   s->r = calloc(C, sizeof(double)); s->z = calloc(C, sizeof(double));
   s->s = calloc(C, sizeof(double));
+  s->cr = calloc(C, sizeof(float)); s->cg = calloc(C, sizeof(float)); s->cb = calloc(C, sizeof(float));
+  s->crtmp = calloc(C, sizeof(float)); s->cgtmp = calloc(C, sizeof(float)); s->cbtmp = calloc(C, sizeof(float));
   s->rng_state = 0x9bd185c449534b91ull; /* main.c:204 */
   s->max_iterations = 100;              /* main.c:735 */
   s->tol = (double)1e-6f;               /* main.c:736: a float literal widened */
@@ -55,6 +57,7 @@ void eo_destroy(eo_sim* s) {
   free(s->solid); free(s->source); free(s->sink); free(s->count); free(s->prev_count);
   free(s->markers); free(s->a_diag); free(s->precon); free(s->q);
   free(s->b); free(s->p); free(s->r); free(s->z); free(s->s);
+  free(s->cr); free(s->cg); free(s->cb); free(s->crtmp); free(s->cgtmp); free(s->cbtmp);
   free(s);
 }
 
@@ -122,6 +125,7 @@ static void finish_init(eo_sim* s, const uint8_t* fluid) {
         }
   s->n_markers = n;
   eo_refresh_marker_counts(s);
+  if (s->rainbow) eo_colorize(s);   /* main.c:270-273; set s->rainbow before loading */
 }
 
 static void set_cell(eo_sim* s, uint8_t* fluid, int x, int y, char c) {
@@ -209,14 +213,45 @@ int eo_load_half_tank(eo_sim* s) {
   return 0;
 }
 
+/* ---------------------------------------------------------------- dye colours (misc/color.h:16-34, main.c:187-201) */
+
+static float hsv_basis(float t) {   /* misc/color.h:16-34: period 6, values in [0,1] */
+  t -= 6.f * floorf(1.f / 6 * t);
+  if (t < 0.f) t += 6.f;
+  if (t < 1.f) return t;
+  if (t < 3.f) return 1.f;
+  if (t < 4.f) return 4.f - t;
+  return 0.f;
+}
+
+void eo_colorize(eo_sim* s) {   /* main.c:187-201; k_initial_color_period = 60 grid cells (main.c:83) */
+  for (int y = 0; y < s->Y; ++y)
+    for (int x = 0; x < s->X; ++x) {
+      size_t i = AT(s, y, x);
+      if (!s->count[i]) continue;
+      float t = 0.f;
+      if (!s->source[i]) t = (x + y) * 6.f / 60.f;
+      s->cr[i] = hsv_basis(t + 2.f);
+      s->cg[i] = hsv_basis(t);
+      s->cb[i] = hsv_basis(t - 2.f);
+    }
+}
+
 /* ---------------------------------------------------------------- sources (main.c:276-298) */
 
 void eo_update_fluid_sources(eo_sim* s) {
   int X = s->X, Y = s->Y;
   s->source_exhausted |= (s->n_markers == s->max_markers - 1);
+  /* main.c:283: k_source_color_period = 10 s (main.c:82); g_frame_count is a uint16_t (main.c:88) */
+  float t = 0.6f / 10.f * (uint16_t)s->frame_count;
   for (int y = 0; y < Y; ++y)
     for (int x = 0; x < X; ++x) {
       size_t i = AT(s, y, x);
+      if (s->source[i]) {   /* main.c:292-294: written whether or not the dye is shown */
+        s->cr[i] = hsv_basis(t + 2.f);
+        s->cg[i] = hsv_basis(t);
+        s->cb[i] = hsv_basis(t - 2.f);
+      }
       if (s->source[i] && !s->source_exhausted && s->count[i] < 4) {
         /* main.c:288 v2f(x+randf(), y+randf()): argument evaluation order is unspecified in C;
          * the compiled reference (gcc, x86-64) evaluates right-to-left, so y is drawn FIRST.
@@ -294,6 +329,18 @@ void eo_advect_v(const eo_sim* s, const float* u, const float* v, float dt, floa
       float dx = eo_interpolate(s, u, x - 0.5f, y + 0.5f, EO_U);
       float px = x - dx * dt / H_CELL, py = y - dy * dt / H_CELL;
       out[AT(s, y, x)] = eo_interpolate(s, v, px, py, EO_V);
+    }
+}
+
+/* advect_p (main.c:424-438): cell-centred quantity, fluid cells only, the rest of `out` keeps its old content */
+void eo_advect_p(const eo_sim* s, const float* q, const float* u, const float* v, float dt, float* out) {
+  for (int y = 0; y < s->Y; ++y)
+    for (int x = 0; x < s->X; ++x) {
+      if (!s->count[AT(s, y, x)]) continue;   /* never true on the border ring: it is all sink */
+      float dy = (v[AT(s, y, x)] + v[AT(s, y - 1, x)]) / 2;
+      float dx = (u[AT(s, y, x)] + u[AT(s, y, x - 1)]) / 2;
+      float px = x - dx * dt / H_CELL, py = y - dy * dt / H_CELL;
+      out[AT(s, y, x)] = eo_interpolate(s, q, px, py, EO_P);
     }
 }
 
@@ -559,6 +606,11 @@ void eo_diffuse(const eo_sim* s, const float* q, int type, float dt, float* out)
 int eo_substep(eo_sim* s, float dt) {
   eo_advect_markers(s, dt);
   eo_refresh_marker_counts(s);
+  if (s->rainbow) {   /* main.c:859-863 */
+    eo_extrapolate(s, s->cr, EO_P);
+    eo_extrapolate(s, s->cg, EO_P);
+    eo_extrapolate(s, s->cb, EO_P);
+  }
   eo_update_fluid_sources(s);
   eo_extrapolate(s, s->u, EO_U);
   eo_extrapolate(s, s->v, EO_V);
@@ -566,6 +618,12 @@ int eo_substep(eo_sim* s, float dt) {
   eo_zero_bounds(s, s->v, EO_V);
   eo_advect_u(s, s->u, s->v, dt, s->utmp);
   eo_advect_v(s, s->u, s->v, dt, s->vtmp);
+  if (s->rainbow) {   /* main.c:873-882: the memcpy moves the WHOLE tmp array, stale non-fluid entries included */
+    const size_t bytes = (size_t)s->X * s->Y * sizeof(float);
+    eo_advect_p(s, s->cr, s->u, s->v, dt, s->crtmp); memcpy(s->cr, s->crtmp, bytes);
+    eo_advect_p(s, s->cg, s->u, s->v, dt, s->cgtmp); memcpy(s->cg, s->cgtmp, bytes);
+    eo_advect_p(s, s->cb, s->u, s->v, dt, s->cbtmp); memcpy(s->cb, s->cbtmp, bytes);
+  }
   eo_apply_body_forces(s, s->vtmp, dt);
   eo_zero_bounds(s, s->utmp, EO_U);
   eo_zero_bounds(s, s->vtmp, EO_V);
@@ -623,8 +681,16 @@ int eo_render_rows(const eo_sim* s, int wx, int wy, char* out, int cap) {
       } else {
         int k = s->count[i] < 3 ? s->count[i] : 3;
         int has_water = k > 0;
-        if (!prev_water && has_water) PUT(BLUE);
-        else if (prev_water && !has_water) PUT(RESET);
+        if (!prev_water && has_water && !s->rainbow) PUT(BLUE);
+        else if (has_water && s->rainbow) {   /* buffer_append_color, main.c:902-912; misc/color.h:6-14 */
+          char tmp[32];
+          const float end = nextafterf(256.f, 0.f);
+          const float c3[3] = {s->cr[i], s->cg[i], s->cb[i]};
+          int o[3];
+          for (int k3 = 0; k3 < 3; ++k3) o[k3] = (int)clampf_(0.f, end * powf(c3[k3], 1 / 2.2f), end);
+          snprintf(tmp, sizeof tmp, "\x1B[38;2;%d;%d;%dm", o[0], o[1], o[2]);
+          PUT(tmp);
+        } else if (prev_water && !has_water) PUT(RESET);
         PUT(sym[k]);
         prev_water = has_water;
       }

@@ -47,6 +47,10 @@ typedef struct eo_sim {
   double last_residual;
   float last_dt;
   uint32_t frame_count;
+  /* --rainbow dye (main.c:75-83): g_r/g/b and their advection scratch; g_rainbow_enabled.  The arrays
+   * are always there (update_fluid_sources writes the source colour regardless, main.c:292-294). */
+  int rainbow;
+  float *cr, *cg, *cb, *crtmp, *cgtmp, *cbtmp;
 } eo_sim;
 
 eo_sim* eo_create(int X, int Y);
@@ -75,6 +79,8 @@ void  eo_zero_bounds(const eo_sim* s, float* q, int type);             /* main.c
 void  eo_advect_u(const eo_sim* s, const float* u, const float* v, float dt, float* out);
 void  eo_advect_v(const eo_sim* s, const float* u, const float* v, float dt, float* out);
 void  eo_apply_body_forces(const eo_sim* s, float* v, float dt);       /* main.c:539-545 */
+void  eo_colorize(eo_sim* s);                                          /* main.c:187-201 */
+void  eo_advect_p(const eo_sim* s, const float* q, const float* u, const float* v, float dt, float* out); /* main.c:424-438 */
 /* EXTENSION (no reference counterpart): one explicit diffusion step of the typed field q
  * over its live faces (fluid property and not solid), out = q + nu*dt/h^2 * sum over live 4-neighbours (q_n - q). */
 void  eo_diffuse(const eo_sim* s, const float* q, int type, float dt, float* out);

@@ -39,6 +39,9 @@ class EoSim(C.Structure):
         ("total_substeps", C.c_uint64), ("total_pcg_iterations", C.c_uint64),
         ("last_substeps", C.c_int), ("last_pcg_iterations", C.c_int),
         ("last_residual", C.c_double), ("last_dt", C.c_float), ("frame_count", C.c_uint32),
+        ("rainbow", C.c_int),
+        ("cr", C.POINTER(C.c_float)), ("cg", C.POINTER(C.c_float)), ("cb", C.POINTER(C.c_float)),
+        ("crtmp", C.POINTER(C.c_float)), ("cgtmp", C.POINTER(C.c_float)), ("cbtmp", C.POINTER(C.c_float)),
     ]
 
 
@@ -92,6 +95,8 @@ def oracle_lib(fast=False, lib_path=None):
     lib.eo_dot.restype = C.c_double
     lib.eo_inf_norm.argtypes = [sp, dp]
     lib.eo_inf_norm.restype = C.c_double
+    lib.eo_colorize.argtypes = [sp]
+    lib.eo_advect_p.argtypes = [sp, fp, fp, fp, C.c_float, fp]
     lib.eo_render_rows.argtypes = [sp, C.c_int, C.c_int, C.c_char_p, C.c_int]
     lib.eo_render_rows.restype = C.c_int
     lib.eo_fnv1a64.argtypes = [C.c_void_p, C.c_size_t]
@@ -108,15 +113,16 @@ def fnv1a64(arr):
 class Oracle:
     """Thin numpy view over one eo_sim. Arrays alias the C memory (no copies)."""
 
-    FIELDS_F32 = ("u", "v", "utmp", "vtmp")
+    FIELDS_F32 = ("u", "v", "utmp", "vtmp", "cr", "cg", "cb", "crtmp", "cgtmp", "cbtmp")
     FIELDS_U8 = ("solid", "source", "sink", "count", "prev_count")
     FIELDS_F64 = ("precon", "q", "b", "p", "r", "z", "s")
 
-    def __init__(self, X, Y, fast=False, lib_path=None):
+    def __init__(self, X, Y, fast=False, lib_path=None, rainbow=False):
         self.lib = oracle_lib(fast, lib_path)
         self.ptr = self.lib.eo_create(X, Y)
         if not self.ptr:
             raise MemoryError("eo_create failed")
+        self.ptr.contents.rainbow = int(rainbow)   # before loading: sim_init colours the initial fluid (main.c:270-273)
         self.X, self.Y = X, Y
         c = self.ptr.contents
         shape = (Y, X)
@@ -192,7 +198,7 @@ class Oracle:
         return a.ctypes.data_as(C.POINTER(C.c_double))
 
     def render(self, wx, wy):
-        cap = (self.X + 32) * (self.Y + 2) * 8
+        cap = (self.X + 32) * (self.Y + 2) * 24   # a coloured cell takes up to 20 bytes
         buf = C.create_string_buffer(cap)
         n = self.lib.eo_render_rows(self.ptr, wx, wy, buf, cap)
         return buf.raw[:n]
@@ -250,6 +256,10 @@ class Reference:
         self._markers = np.ctypeslib.as_array((C.c_float * (8 * REF_X * REF_Y)).in_dll(L, "g_markers")).reshape(-1, 2)
         self._len = C.c_size_t.in_dll(L, "g_markers_length")
         self._exhausted = C.c_bool.in_dll(L, "g_source_exhausted")
+        for n in ("g_r", "g_g", "g_b", "g_rtmp", "g_gtmp", "g_btmp"):
+            setattr(self, "c" + n[2:], arr(n, C.c_float))
+        self._rainbow = C.c_bool.in_dll(L, "g_rainbow_enabled")
+        self._frame_count = C.c_uint16.in_dll(L, "g_frame_count")
         self._wx = C.c_int.in_dll(L, "g_wx")
         self._wy = C.c_int.in_dll(L, "g_wy")
         L.sim_init.argtypes = [ArgsT]
@@ -282,9 +292,10 @@ class Reference:
     def sorted_markers(self):
         return sort_markers(self.markers)
 
-    def init(self, path):
+    def init(self, path, rainbow=False):
         self._path = path.encode()
-        self.lib.sim_init(ArgsT(self._path, False))
+        self._rainbow.value = bool(rainbow)     # main() sets the global before sim_init (main.c:1020)
+        self.lib.sim_init(ArgsT(self._path, bool(rainbow)))
         return self
 
     def step(self):

@@ -151,3 +151,31 @@ def test_render_rows_match_reference(scn):
         for n in ("count",):
             o.count[...] = g["f%d_count" % f]
         assert o.render(wx, wy) == r[key].tobytes(), key
+
+
+RAINBOW = ("block", "waterfall", "filter")
+
+
+@pytest.mark.parametrize("scn", RAINBOW)
+def test_rainbow_dye_bit_exact(scn):
+    """--rainbow: colorize at init, extrapolate(P) x3, the source colour, advect_p x3 with the
+    whole-array memcpy (main.c:187-201, 292-294, 859-863, 873-882) and the coloured draw_rows bytes
+    (main.c:902-951) against the compiled reference run with g_rainbow_enabled."""
+    g = load(scn + "_rainbow.npz")
+    o = Oracle(X, Y, rainbow=True).load_text(scenario_text(load(scn + "_frames.npz")))
+    for n, a in (("r", o.cr), ("g", o.cg), ("b", o.cb)):
+        assert bits_equal(a, g["init_" + n]), n
+    keep = set(int(f) for f in g["frames_full"])
+    for f in range(len(g["hashes"])):
+        o.step()
+        assert [fnv1a64(o.cr), fnv1a64(o.cg), fnv1a64(o.cb), fnv1a64(o.u), fnv1a64(o.count)] == [int(h) for h in g["hashes"][f]], (scn, f)
+        if f in keep:
+            for n, a in (("r", o.cr), ("g", o.cg), ("b", o.cb)):
+                assert bits_equal(a, g["f%d_%s" % (f, n)]), (scn, f, n)
+            for (wx, wy) in ((98, 38), (40, 10)):
+                assert o.render(wx, wy) == g["f%d_w%dx%d" % (f, wx, wy)].tobytes(), (scn, f, wx, wy)
+
+
+def test_rainbow_does_not_disturb_the_flow():
+    g, gr = load("block_frames.npz"), load("block_rainbow.npz")
+    assert [int(h) for h in gr["hashes"][:, 3]] == [int(h) for h in g["hashes"][:, 0]]
