@@ -18,7 +18,8 @@ DOT_AUTO, DOT_SEQUENTIAL, DOT_TREE = 0, 1, 2
 PRECOND_IC0, PRECOND_JACOBI = 0, 1
 SWEEP_AUTO, SWEEP_BAND, SWEEP_SIMPLE = 0, 1, 2
 (F_U, F_V, F_UTMP, F_VTMP, F_SOLID, F_SOURCE, F_SINK, F_COUNT, F_PREV_COUNT, F_MARKERS, F_PRECON,
- F_PRESSURE, F_PCG_B, F_PCG_R, F_PCG_Z, F_PCG_S, F_PCG_Q, F_CELLMASK) = range(18)
+ F_PRESSURE, F_PCG_B, F_PCG_R, F_PCG_Z, F_PCG_S, F_PCG_Q, F_CELLMASK,
+ F_DYE_R, F_DYE_G, F_DYE_B, F_DYE_RTMP, F_DYE_GTMP, F_DYE_BTMP) = range(24)
 (STAGE_ADVECT_MARKERS, STAGE_REFRESH_COUNTS, STAGE_SOURCES, STAGE_EXTRAPOLATE, STAGE_ADVECT_VELOCITY,
  STAGE_PROJECT) = range(6)
 (OP_BUILD_SYSTEM, OP_PRECON_FACTOR, OP_FORWARD_SOLVE, OP_BACKWARD_SOLVE, OP_APPLY_A, OP_DOT_ZR, OP_DOT_ZS,
@@ -29,6 +30,8 @@ _FIELD_DTYPE = {
     F_SOLID: np.uint8, F_SOURCE: np.uint8, F_SINK: np.uint8, F_COUNT: np.uint8, F_PREV_COUNT: np.uint8,
     F_MARKERS: np.float32, F_PRECON: np.float64, F_PRESSURE: np.float64, F_PCG_B: np.float64,
     F_PCG_R: np.float64, F_PCG_Z: np.float64, F_PCG_S: np.float64, F_PCG_Q: np.float64, F_CELLMASK: np.uint8,
+    F_DYE_R: np.float32, F_DYE_G: np.float32, F_DYE_B: np.float32,
+    F_DYE_RTMP: np.float32, F_DYE_GTMP: np.float32, F_DYE_BTMP: np.float32,
 }
 
 
@@ -43,7 +46,8 @@ class Config(C.Structure):
         ("abi_version", C.c_int32), ("X", C.c_int32), ("Y", C.c_int32), ("device", C.c_int32),
         ("max_iterations", C.c_int32), ("tol", C.c_double), ("dot_mode", C.c_int32), ("precond", C.c_int32),
         ("sweep_mode", C.c_int32), ("max_substeps", C.c_int32), ("frame_time", C.c_float),
-        ("viscosity", C.c_float), ("pcg_poll_interval", C.c_int32), ("reserved", C.c_int32 * 8),
+        ("viscosity", C.c_float), ("pcg_poll_interval", C.c_int32), ("rainbow", C.c_int32),
+        ("reserved", C.c_int32 * 7),
     ]
 
 
@@ -64,7 +68,7 @@ EXPORTS = [
     "euler_load_scenario_mem", "euler_load_scenario_file", "euler_load_half_tank", "euler_parse_scenario",
     "euler_seed_markers", "euler_step", "euler_timestep", "euler_substep", "euler_stage", "euler_pcg_op",
     "euler_get_field", "euler_set_field", "euler_set_markers", "euler_set_rng", "euler_get_stats",
-    "euler_field_bytes", "euler_render", "euler_render_grids", "euler_profile_enable",
+    "euler_field_bytes", "euler_render", "euler_render_grids", "euler_render_grids_rgb", "euler_colorize", "euler_profile_enable",
     "euler_profile_class_count", "euler_profile_class_name", "euler_profile_get", "euler_profile_reset",
     "euler_measure_copy_bandwidth", "euler_device_name", "euler_sweep_timeline", "euler_save_state", "euler_load_state", "euler_set_comm", "euler_set_stream", "euler_slab_info",
     "euler_rccl_unique_id", "euler_rccl_version", "euler_set_comm_rccl", "euler_comm_calls",
@@ -107,6 +111,8 @@ def load_library():
         "euler_field_bytes": (C.c_size_t, [vp, i32]),
         "euler_render": (C.c_int, [vp, i32, i32, C.c_char_p, i32, C.POINTER(i32)]),
         "euler_render_grids": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, C.c_char_p, i32, C.POINTER(i32)]),
+        "euler_render_grids_rgb": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_char_p, i32, C.POINTER(i32)]),
+        "euler_colorize": (C.c_int, [vp]),
         "euler_profile_enable": (C.c_int, [vp, u64]),
         "euler_profile_class_count": (C.c_int, []),
         "euler_profile_class_name": (C.c_char_p, [i32]),
@@ -158,20 +164,27 @@ def seed_markers(fluid, rng_state=0x9bd185c449534b91):
     return m[: n.value].copy(), st.value
 
 
-def render_grids(solid, sink, count, wx, wy):
-    """draw_rows() over host grids (reference main.c:914-951)."""
+def render_grids(solid, sink, count, wx, wy, rgb=None):
+    """draw_rows() over host grids (reference main.c:914-951); rgb = (r, g, b) float grids for --rainbow."""
     Y, X = count.shape
     L = load_library()
     n = C.c_int32(0)
     a = [np.ascontiguousarray(g, np.uint8) for g in (solid, sink, count)]
-    _check(L.euler_render_grids(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, X, Y, wx, wy, None, 0, C.byref(n)))
+    ptrs = [g.ctypes.data for g in a]
+    fn = L.euler_render_grids
+    if rgb is not None:
+        a += [np.ascontiguousarray(g, np.float32) for g in rgb]
+        ptrs = [g.ctypes.data for g in a]
+        fn = L.euler_render_grids_rgb
+    _check(fn(*ptrs, X, Y, wx, wy, None, 0, C.byref(n)))
     buf = C.create_string_buffer(max(n.value, 1))
-    _check(L.euler_render_grids(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, X, Y, wx, wy, buf, n.value, C.byref(n)))
+    _check(fn(*ptrs, X, Y, wx, wy, buf, n.value, C.byref(n)))
     return buf.raw[: n.value]
 
 
 SNAPSHOT_F32 = ("u", "v", "utmp", "vtmp")
 SNAPSHOT_U8 = ("solid", "source", "sink", "count", "prev_count")
+SNAPSHOT_DYE = ("dye_r", "dye_g", "dye_b", "dye_rtmp", "dye_gtmp", "dye_btmp")   # version 2 (euler_config.rainbow)
 
 
 def _fnv1a64(data, h=14695981039346656037):
@@ -188,8 +201,8 @@ def read_snapshot(path, verify=True):
     import struct
     raw = open(path, "rb").read()
     magic, version, X, Y, _, n, rng, exhausted, _, frames, substeps, iters = struct.unpack_from("<8sIiiIQQiiQQQ", raw, 0)
-    if magic != b"EULERSNP" or version != 1:
-        raise ValueError("%s is not an euler state snapshot (version 1)" % path)
+    if magic != b"EULERSNP" or version not in (1, 2):
+        raise ValueError("%s is not an euler state snapshot (version 1 or 2)" % path)
     out = {"X": X, "Y": Y, "n_markers": n, "rng_state": rng, "source_exhausted": exhausted, "frames": frames,
            "total_substeps": substeps, "total_pcg_iterations": iters}
     off, Cn = 72, X * Y
@@ -198,6 +211,9 @@ def read_snapshot(path, verify=True):
     for name in SNAPSHOT_U8:
         out[name] = np.frombuffer(raw, np.uint8, Cn, off).reshape(Y, X).copy(); off += Cn
     out["precon"] = np.frombuffer(raw, np.float64, Cn, off).reshape(Y, X).copy(); off += 8 * Cn
+    if version == 2:
+        for name in SNAPSHOT_DYE:
+            out[name] = np.frombuffer(raw, np.float32, Cn, off).reshape(Y, X).copy(); off += 4 * Cn
     out["markers"] = np.frombuffer(raw, np.float32, 2 * n, off).reshape(n, 2).copy(); off += 8 * n
     (want,) = struct.unpack_from("<Q", raw, off)
     if len(raw) != off + 8:
@@ -212,11 +228,15 @@ def write_snapshot(path, st):
     import struct
     Y, X = st["u"].shape
     mk = np.ascontiguousarray(st["markers"], np.float32).reshape(-1, 2)
-    body = struct.pack("<8sIiiIQQiiQQQ", b"EULERSNP", 1, X, Y, 0, len(mk), int(st["rng_state"]), int(st.get("source_exhausted", 0)), 0,
+    dye = "dye_r" in st
+    body = struct.pack("<8sIiiIQQiiQQQ", b"EULERSNP", 2 if dye else 1, X, Y, 0, len(mk), int(st["rng_state"]), int(st.get("source_exhausted", 0)), 0,
                        int(st.get("frames", 0)), int(st.get("total_substeps", 0)), int(st.get("total_pcg_iterations", 0)))
     body += b"".join(np.ascontiguousarray(st[k], np.float32).tobytes() for k in SNAPSHOT_F32)
     body += b"".join(np.ascontiguousarray(st[k], np.uint8).tobytes() for k in SNAPSHOT_U8)
-    body += np.ascontiguousarray(st["precon"], np.float64).tobytes() + mk.tobytes()
+    body += np.ascontiguousarray(st["precon"], np.float64).tobytes()
+    if dye:
+        body += b"".join(np.ascontiguousarray(st[k], np.float32).tobytes() for k in SNAPSHOT_DYE)
+    body += mk.tobytes()
     with open(path, "wb") as f:
         f.write(body + struct.pack("<Q", _fnv1a64(body)))
 
@@ -231,7 +251,7 @@ class Simulation:
     plus state access for parity tests."""
 
     def __init__(self, X=100, Y=40, device=0, dot_mode=DOT_AUTO, precond=PRECOND_IC0, sweep_mode=SWEEP_AUTO,
-                 max_iterations=100, tol=None, pcg_poll_interval=8, viscosity=0.0):
+                 max_iterations=100, tol=None, pcg_poll_interval=8, viscosity=0.0, rainbow=False):
         self.L = load_library()
         cfg = Config()
         _check(self.L.euler_config_default(C.byref(cfg)))
@@ -242,6 +262,7 @@ class Simulation:
             cfg.tol = tol
         cfg.pcg_poll_interval = pcg_poll_interval
         cfg.viscosity = viscosity            # extension: 0 = the inviscid reference
+        cfg.rainbow = int(rainbow)           # args_t.rainbow (main.c:54): carry and advect the dye fields
         self.cfg = cfg
         self.X, self.Y = X, Y
         self.h = C.c_void_p()
@@ -284,6 +305,10 @@ class Simulation:
         buf = C.create_string_buffer(max(n.value, 1))
         _check(self.L.euler_render(self.h, wx, wy, buf, n.value, C.byref(n)))
         return buf.raw[: n.value]
+
+    def colorize(self):
+        """The reference's 'r' key (main.c:970-973): colour the current fluid afresh."""
+        _check(self.L.euler_colorize(self.h))
 
     # --- finer control
     def timestep(self, frame_time_left=0.1):

@@ -141,6 +141,7 @@ extern "C" void euler_destroy(euler_sim* S) {
                  S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->fbits_fwd, S->fbits_bwd, S->halo_buf, S->band_ranges,
                  S->rowmajor_tmp};
   for (void* p : dev) if (p) (void)hipFree(p);
+  for (float* d : S->dye) if (d) (void)hipFree(d);
   for (double* d : {S->b, S->p, S->r, S->z, S->s, S->s2, S->q, S->precon}) if (d) (void)hipFree(d - EU_SKEW_SLACK);
   if (S->krku) (void)hipFree(S->krku - 2 * EU_SKEW_SLACK);
   if (S->cellmask) (void)hipFree(S->cellmask - EU_SKEW_SLACK);
@@ -201,6 +202,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   DALLOC(S->u, C); DALLOC(S->v, C); DALLOC(S->utmp, C); DALLOC(S->vtmp, C);
   DALLOC(S->solid, C); DALLOC(S->source, C); DALLOC(S->sink, C); DALLOC(S->count, C); DALLOC(S->prev_count, C);
   DALLOC(S->count32, C);
+  if (S->cfg.rainbow) for (float*& d : S->dye) DALLOC(d, C);
   S->max_markers = 4 * C;   // MAX_MARKER_COUNT, main.c:92
   DALLOC(S->markers[0], S->max_markers); DALLOC(S->markers[1], S->max_markers);
   DALLOC(S->ms, 1);
@@ -279,6 +281,7 @@ static int upload_scenario(euler_sim* S, const uint8_t* solid, const uint8_t* so
   HIPCHK(hipMemcpyAsync(S->sink, sink, C, hipMemcpyHostToDevice, st));
   for (float* f : {S->u, S->v, S->utmp, S->vtmp}) HIPCHK(hipMemsetAsync(f, 0, C * sizeof(float), st));
   for (double* d : {S->b, S->p, S->r, S->z, S->s, S->s2, S->q, S->precon}) HIPCHK(hipMemsetAsync(d, 0, S->geom.S * sizeof(double), st));
+  for (float* d : S->dye) if (d) HIPCHK(hipMemsetAsync(d, 0, C * sizeof(float), st));
   HIPCHK(hipMemsetAsync(S->count, 0, C, st));
   HIPCHK(hipMemsetAsync(S->prev_count, 0, C, st));
   HIPCHK(hipMemsetAsync(S->cellmask, 0, S->geom.S, st));
@@ -292,6 +295,8 @@ static int upload_scenario(euler_sim* S, const uint8_t* solid, const uint8_t* so
   S->n_markers_host = n;
   // sim_init ends with refresh_marker_counts() (main.c:268): prev <- 0, counts <- bins
   rc = eu_launch_refresh_counts(S);
+  if (rc) return rc;
+  rc = eu_launch_colorize(S);   // main.c:270-273 (only with cfg.rainbow)
   if (rc) return rc;
   rc = eu_sync_marker_state(S);
   if (rc) return rc;
@@ -423,9 +428,18 @@ static int run_stage(euler_sim* S, int stage, float dt) {
   switch (stage) {
     case EULER_STAGE_ADVECT_MARKERS: return eu_launch_advect_markers(S, dt);
     case EULER_STAGE_REFRESH_COUNTS: return eu_launch_refresh_counts(S);
-    case EULER_STAGE_SOURCES: return eu_launch_sources(S);
+    case EULER_STAGE_SOURCES: {   // with the dye: extrapolate(g_r/g/b, P) comes first (main.c:859-864)
+      int rc = eu_launch_dye_extrapolate(S);
+      if (!rc) rc = eu_launch_sources(S);
+      if (!rc) rc = eu_launch_dye_sources(S);
+      return rc;
+    }
     case EULER_STAGE_EXTRAPOLATE: return eu_launch_extrapolate(S);
-    case EULER_STAGE_ADVECT_VELOCITY: return eu_launch_advect_velocity(S, dt);
+    case EULER_STAGE_ADVECT_VELOCITY: {   // advect_p reads g_u, g_v before anything overwrites them (main.c:871-882)
+      int rc = eu_launch_dye_advect(S, dt);
+      if (!rc) rc = eu_launch_advect_velocity(S, dt);
+      return rc;
+    }
     case EULER_STAGE_PROJECT: return eu_launch_project(S, dt);
     default: eu_set_error("unknown stage %d", stage); return EULER_EINVAL;
   }
@@ -519,6 +533,9 @@ static int field_ptr(euler_sim* S, int f, void** p, size_t* bytes) {
     case EULER_F_PCG_S: *p = S->s; *bytes = C * 8; break;
     case EULER_F_PCG_Q: *p = S->q; *bytes = C * 8; break;
     case EULER_F_CELLMASK: *p = S->cellmask; *bytes = C; break;
+    case EULER_F_DYE_R: case EULER_F_DYE_G: case EULER_F_DYE_B: case EULER_F_DYE_RTMP: case EULER_F_DYE_GTMP: case EULER_F_DYE_BTMP:
+      if (!S->dye[0]) { eu_set_error("field %d needs euler_config.rainbow", f); return EULER_ESTATE; }
+      *p = S->dye[f - EULER_F_DYE_R]; *bytes = C * 4; break;
     default: eu_set_error("unknown field %d", f); return EULER_EINVAL;
   }
   return EULER_OK;
@@ -644,17 +661,33 @@ extern "C" int euler_render(euler_sim* S, int32_t wx, int32_t wy, char* out, int
   int cutoff = Y - 1 - wy;
   if (cutoff < 1) cutoff = 1;
   const size_t C = S->C;
+  const bool dye = S->dye[0] != nullptr;
   uint8_t* g = (uint8_t*)calloc(3, C);
-  if (!g) return EULER_ENOMEM;
+  float* col = dye ? (float*)calloc(3 * C, sizeof(float)) : nullptr;
+  if (!g || (dye && !col)) { free(g); free(col); return EULER_ENOMEM; }
   const size_t off = (size_t)cutoff * X, bytes = (size_t)(Y - 1 - cutoff) * X;
   hipError_t e = hipMemcpyAsync(g + off, S->solid + off, bytes, hipMemcpyDeviceToHost, S->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(g + C + off, S->sink + off, bytes, hipMemcpyDeviceToHost, S->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(g + 2 * C + off, S->count + off, bytes, hipMemcpyDeviceToHost, S->stream);
+  for (int k = 0; k < 3 && dye && e == hipSuccess; ++k)
+    e = hipMemcpyAsync(col + k * C + off, S->dye[k] + off, bytes * sizeof(float), hipMemcpyDeviceToHost, S->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(S->stream);
-  int rc = e == hipSuccess ? euler_render_grids(g, g + C, g + 2 * C, X, Y, wx, wy, out, cap, len)
-                           : eu_hip_fail(e, "render copy", __FILE__, __LINE__);
+  int rc = e != hipSuccess ? eu_hip_fail(e, "render copy", __FILE__, __LINE__)
+           : dye ? euler_render_grids_rgb(g, g + C, g + 2 * C, col, col + C, col + 2 * C, X, Y, wx, wy, out, cap, len)
+                 : euler_render_grids(g, g + C, g + 2 * C, X, Y, wx, wy, out, cap, len);
   free(g);
+  free(col);
   return rc;
+}
+
+// the 'r' key of the reference's main loop (main.c:970-973): colour the current fluid afresh
+extern "C" int euler_colorize(euler_sim* S) {
+  if (!S || !S->loaded) return EULER_ESTATE;
+  if (!S->dye[0]) { eu_set_error("euler_colorize needs euler_config.rainbow"); return EULER_ESTATE; }
+  int rc = eu_launch_colorize(S);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(S->stream));
+  return EULER_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -703,6 +736,7 @@ struct SnapHeader {
 };
 static const int SNAP_F32[] = {EULER_F_U, EULER_F_V, EULER_F_UTMP, EULER_F_VTMP};
 static const int SNAP_U8[] = {EULER_F_SOLID, EULER_F_SOURCE, EULER_F_SINK, EULER_F_COUNT, EULER_F_PREV_COUNT};
+static const int SNAP_DYE[] = {EULER_F_DYE_R, EULER_F_DYE_G, EULER_F_DYE_B, EULER_F_DYE_RTMP, EULER_F_DYE_GTMP, EULER_F_DYE_BTMP};   // version 2 only
 
 extern "C" int euler_save_state(euler_sim* S, const char* path) {
   if (!S || !path) return EULER_EINVAL;
@@ -714,7 +748,7 @@ extern "C" int euler_save_state(euler_sim* S, const char* path) {
   SnapHeader h;
   memset(&h, 0, sizeof h);
   memcpy(h.magic, "EULERSNP", 8);
-  h.version = 1; h.X = S->X; h.Y = S->Y; h.n_markers = st.n_markers; h.rng_state = st.rng_state;
+  h.version = S->dye[0] ? 2 : 1; h.X = S->X; h.Y = S->Y; h.n_markers = st.n_markers; h.rng_state = st.rng_state;
   h.source_exhausted = st.source_exhausted; h.frames = st.frames; h.total_substeps = st.total_substeps;
   h.total_pcg_iterations = st.total_pcg_iterations;
   uint64_t sum = snap_fnv(14695981039346656037ull, &h, sizeof h);
@@ -731,6 +765,7 @@ extern "C" int euler_save_state(euler_sim* S, const char* path) {
   for (int fd : SNAP_F32) put(fd, C * 4);
   for (int fd : SNAP_U8) put(fd, C);
   put(EULER_F_PRECON, C * 8);
+  if (S->dye[0]) for (int fd : SNAP_DYE) put(fd, C * 4);
   put(EULER_F_MARKERS, (size_t)st.n_markers * 8);
   ok = ok && fwrite(&sum, 8, 1, f) == 1;
   ok = (fclose(f) == 0) && ok;
@@ -744,8 +779,13 @@ extern "C" int euler_load_state(euler_sim* S, const char* path) {
   FILE* f = fopen(path, "rb");
   if (!f) { eu_set_error("cannot open %s", path); return EULER_EIO; }
   SnapHeader h;
-  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "EULERSNP", 8) != 0 || h.version != 1) {
-    fclose(f); eu_set_error("%s is not an euler state snapshot (version 1)", path); return EULER_EINVAL;
+  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "EULERSNP", 8) != 0 || (h.version != 1 && h.version != 2)) {
+    fclose(f); eu_set_error("%s is not an euler state snapshot (version 1 or 2)", path); return EULER_EINVAL;
+  }
+  if ((h.version == 2) != (S->dye[0] != nullptr)) {
+    fclose(f); eu_set_error("%s %s the dye fields but this handle was created %s euler_config.rainbow", path,
+                            h.version == 2 ? "carries" : "lacks", S->dye[0] ? "with" : "without");
+    return EULER_EINVAL;
   }
   if (h.X != S->X || h.Y != S->Y || h.n_markers > S->max_markers) {
     fclose(f); eu_set_error("snapshot grid %dx%d (%llu markers) does not fit this %dx%d handle", h.X, h.Y,
@@ -753,7 +793,7 @@ extern "C" int euler_load_state(euler_sim* S, const char* path) {
     return EULER_EINVAL;
   }
   const size_t C = S->C;
-  const size_t body = C * 4 * 4 + C * 5 + C * 8 + (size_t)h.n_markers * 8;
+  const size_t body = C * 4 * 4 + C * 5 + C * 8 + (h.version == 2 ? C * 4 * 6 : 0) + (size_t)h.n_markers * 8;
   std::vector<unsigned char> buf(body + 8);
   const bool ok = fread(buf.data(), 1, body + 8, f) == body + 8;
   fclose(f);
@@ -766,6 +806,7 @@ extern "C" int euler_load_state(euler_sim* S, const char* path) {
   for (int fd : SNAP_U8) { if ((rc = euler_set_field(S, fd, p, C))) return rc; p += C; }
   if ((rc = euler_set_field(S, EULER_F_PRECON, p, C * 8))) return rc;
   p += C * 8;
+  if (h.version == 2) for (int fd : SNAP_DYE) { if ((rc = euler_set_field(S, fd, p, C * 4))) return rc; p += C * 4; }
   if ((rc = euler_set_markers(S, (const float*)p, h.n_markers))) return rc;
   if ((rc = euler_set_rng(S, h.rng_state, h.source_exhausted))) return rc;
   S->stats.frames = h.frames; S->stats.total_substeps = h.total_substeps; S->stats.total_pcg_iterations = h.total_pcg_iterations;

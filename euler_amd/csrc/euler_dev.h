@@ -103,6 +103,7 @@ struct euler_sim {
   float *u, *v, *utmp, *vtmp;
   uint8_t *solid, *source, *sink, *count, *prev_count;
   unsigned int* count32;
+  float* dye[6];          // --rainbow only (cfg.rainbow): g_r, g_g, g_b, g_rtmp, g_gtmp, g_btmp (main.c:76-81)
   // markers, ping-pong (main.c:95)
   float2* markers[2];
   int cur;
@@ -203,6 +204,10 @@ int eu_launch_sources(euler_sim* S);
 int eu_launch_extrapolate(euler_sim* S);
 int eu_launch_advect_velocity(euler_sim* S, float dt);
 int eu_launch_project(euler_sim* S, float dt);
+int eu_launch_colorize(euler_sim* S);            // k_dye.hip: no-ops without cfg.rainbow
+int eu_launch_dye_extrapolate(euler_sim* S);
+int eu_launch_dye_sources(euler_sim* S);
+int eu_launch_dye_advect(euler_sim* S, float dt);
 int eu_launch_pcg_op(euler_sim* S, int op, float dt, double a, double* out);
 int eu_ordered_select(euler_sim* S, const unsigned long long* mask, size_t nwords, unsigned int* out_idx,
                       unsigned int* out_total);
@@ -233,17 +238,20 @@ __device__ __forceinline__ float eu_frac(float f, bool start_ok, bool end_ok) { 
 }
 __device__ __forceinline__ float eu_clampf(float lo, float x, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
-// interpolate(), main.c:337-364.  TYPE 1 = U samples, 2 = V samples.
+// interpolate(), main.c:337-364.  TYPE 0 = cell centres (P), 1 = U samples, 2 = V samples.
 template <int TYPE>
 __device__ __forceinline__ float eu_interp(const GridRef& g, const float* __restrict__ q, float ix, float iy) {
-  ix = eu_clampf(0.f, ix, TYPE == 1 ? g.ux_lim : g.vx_lim);
-  iy = eu_clampf(0.f, iy, TYPE == 1 ? g.uy_lim : g.vy_lim);
+  ix = eu_clampf(0.f, ix, TYPE == 1 ? g.ux_lim : g.vx_lim);   // P extent = (X, Y): x like V, y like U
+  iy = eu_clampf(0.f, iy, TYPE == 2 ? g.vy_lim : g.uy_lim);
   float wx, wy;
   const float fx = modff(ix, &wx), fy = modff(iy, &wy);
   const int bx = (int)wx, by = (int)wy;
   const size_t i00 = (size_t)by * g.X + bx;
   bool v00, v01, v10, v11;
-  if (TYPE == 1) {
+  if (TYPE == 0) {
+    v00 = g.count[i00] != 0; v01 = g.count[i00 + 1] != 0;
+    v10 = g.count[i00 + g.X] != 0; v11 = g.count[i00 + g.X + 1] != 0;
+  } else if (TYPE == 1) {
     const bool c0 = g.count[i00] != 0, c1 = g.count[i00 + 1] != 0, c2 = g.count[i00 + 2] != 0;
     const bool d0 = g.count[i00 + g.X] != 0, d1 = g.count[i00 + g.X + 1] != 0, d2 = g.count[i00 + g.X + 2] != 0;
     v00 = c0 | c1; v01 = c1 | c2; v10 = d0 | d1; v11 = d1 | d2;

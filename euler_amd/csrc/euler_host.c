@@ -9,6 +9,8 @@
  */
 #include "euler_host.h"
 
+#include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -138,11 +140,13 @@ int euler_seed_markers(const uint8_t* fluid, int32_t X, int32_t Y, uint64_t* rng
 
 /* ---- frame formatter (draw_rows, main.c:914-951; escape codes misc/terminal.h:36,53,60) ---- */
 
-int euler_render_grids(const uint8_t* solid, const uint8_t* sink, const uint8_t* count,
+static int render_rows(const uint8_t* solid, const uint8_t* sink, const uint8_t* count,
+                       const float* cr, const float* cg, const float* cb,
                        int32_t X, int32_t Y, int32_t wx, int32_t wy, char* out, int32_t cap, int32_t* len) {
   if (!solid || !sink || !count || !len) return EULER_EINVAL;
   static const char glyph[4] = {' ', 'o', 'O', '0'};
   static const char blue[] = "\x1B[34m", reset[] = "\x1B[0m", clear_line[] = "\x1b[K", crlf[] = "\r\n";
+  const int dye = cr && cg && cb;
   int64_t n = 0;
 #define EMIT(s, k) do { for (int _i = 0; _i < (int)(k); ++_i) { if (out && n < cap) out[n] = (s)[_i]; ++n; } } while (0)
   int32_t cutoff = Y - 1 - wy;
@@ -161,8 +165,19 @@ int euler_render_grids(const uint8_t* solid, const uint8_t* sink, const uint8_t*
         EMIT("=", 1);           /* the run flag is deliberately left as is (main.c:927-931) */
       } else {
         int k = count[i] < 3 ? count[i] : 3;
-        if (!water_run && k) EMIT(blue, 5);
-        else if (water_run && !k) EMIT(reset, 4);
+        if (!water_run && k && !dye) EMIT(blue, 5);
+        else if (k && dye) {    /* buffer_append_color (main.c:902-912): sRGB ~ x^(1/2.2), byte = (int)clamp(0, end*x, end) */
+          char esc[32];
+          const float end = nextafterf(256.f, 0.f);
+          const float lin[3] = {cr[i], cg[i], cb[i]};
+          int byte[3];
+          for (int c = 0; c < 3; ++c) {
+            float v = end * powf(lin[c], 1 / 2.2f);
+            byte[c] = (int)(v < 0.f ? 0.f : (v > end ? end : v));
+          }
+          int m = snprintf(esc, sizeof esc, "\x1B[38;2;%d;%d;%dm", byte[0], byte[1], byte[2]);
+          EMIT(esc, m);
+        } else if (water_run && !k) EMIT(reset, 4);
         EMIT(&glyph[k], 1);
         water_run = k != 0;
       }
@@ -174,4 +189,16 @@ int euler_render_grids(const uint8_t* solid, const uint8_t* sink, const uint8_t*
 #undef EMIT
   *len = (int32_t)n;
   return EULER_OK;
+}
+
+int euler_render_grids(const uint8_t* solid, const uint8_t* sink, const uint8_t* count,
+                       int32_t X, int32_t Y, int32_t wx, int32_t wy, char* out, int32_t cap, int32_t* len) {
+  return render_rows(solid, sink, count, NULL, NULL, NULL, X, Y, wx, wy, out, cap, len);
+}
+
+int euler_render_grids_rgb(const uint8_t* solid, const uint8_t* sink, const uint8_t* count,
+                           const float* r, const float* g, const float* b,
+                           int32_t X, int32_t Y, int32_t wx, int32_t wy, char* out, int32_t cap, int32_t* len) {
+  if (!r || !g || !b) return EULER_EINVAL;
+  return render_rows(solid, sink, count, r, g, b, X, Y, wx, wy, out, cap, len);
 }

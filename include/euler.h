@@ -70,7 +70,8 @@ typedef struct euler_config {
   float   frame_time;      /* reference 0.1f (main.c:849) */
   float   viscosity;       /* 0 = inviscid like the reference (no diffusion stage exists there) */
   int32_t pcg_poll_interval; /* PCG iterations launched between convergence polls (default 8) */
-  int32_t reserved[8];
+  int32_t rainbow;         /* args_t.rainbow / g_rainbow_enabled (main.c:54,75,1020): carry the dye fields */
+  int32_t reserved[7];
 } euler_config;
 
 typedef struct euler_sim euler_sim; /* opaque */
@@ -92,6 +93,9 @@ enum {
   EULER_F_PRESSURE,       /* double p — a stack local of project(), main.c:739; exposed here */
   EULER_F_PCG_B, EULER_F_PCG_R, EULER_F_PCG_Z, EULER_F_PCG_S, EULER_F_PCG_Q, /* double, main.c:716-745,578 */
   EULER_F_CELLMASK,       /* uint8: bit0 fluid, bit1..4 fluid at x+1,y+1,x-1,y-1, bits5-7 a_diag (g_a, main.c:552) */
+  EULER_F_DYE_R, EULER_F_DYE_G, EULER_F_DYE_B,             /* float g_r, g_g, g_b (main.c:76-78); euler_config.rainbow only */
+  EULER_F_DYE_RTMP, EULER_F_DYE_GTMP, EULER_F_DYE_BTMP,    /* float g_rtmp, g_gtmp, g_btmp (main.c:79-81): state, because the
+                                                              reference copies them back whole (main.c:875-881) */
   EULER_F__COUNT
 };
 
@@ -182,6 +186,7 @@ int euler_get_stats(euler_sim* sim, euler_stats* out);
  *   char[8] "EULERSNP"; u32 version = 1; i32 X, Y; u32 0; u64 n_markers; u64 rng_state;
  *   i32 source_exhausted; i32 0; u64 frames, total_substeps, total_pcg_iterations;          (72 bytes)
  *   f32[Y][X] u, v, utmp, vtmp;  u8[Y][X] solid, source, sink, count, prev_count;  f64[Y][X] precon;
+ *   [version = 2, handles created with euler_config.rainbow: f32[Y][X] g_r, g_g, g_b, g_rtmp, g_gtmp, g_btmp;]
  *   f32[n_markers][2] markers in array order;  u64 FNV-1a-64 of all preceding bytes.
  * euler_load_state needs a handle of the same X, Y.  (euler_amd.read_snapshot / write_snapshot mirror
  * the format in numpy.) */
@@ -196,6 +201,13 @@ int euler_render(euler_sim* sim, int32_t wx, int32_t wy, char* out, int32_t cap,
 /* The same formatter over caller-supplied host grids (no GPU needed). */
 int euler_render_grids(const uint8_t* solid, const uint8_t* sink, const uint8_t* count,
                        int32_t X, int32_t Y, int32_t wx, int32_t wy, char* out, int32_t cap, int32_t* len);
+/* --rainbow: every water glyph carries a 24-bit colour escape built from the dye (main.c:902-912, 936-937;
+ * misc/color.h:6-14).  euler_render uses it when the handle was created with euler_config.rainbow. */
+int euler_render_grids_rgb(const uint8_t* solid, const uint8_t* sink, const uint8_t* count,
+                           const float* r, const float* g, const float* b,
+                           int32_t X, int32_t Y, int32_t wx, int32_t wy, char* out, int32_t cap, int32_t* len);
+/* colorize() (main.c:187-201), the reference's 'r' key (main.c:970-973): recolour the current fluid. */
+int euler_colorize(euler_sim* sim);
 
 /* ---- multi-GPU: the pressure solve distributed over row slabs (DESIGN.md "Multi-GPU") ------ */
 /* One process per GPU.  Every rank holds the whole grid and runs the cheap stages (markers,

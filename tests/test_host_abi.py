@@ -99,3 +99,19 @@ def test_render_matches_reference(scn):
         wx, wy = (int(t) for t in w[1:].split("x"))
         got = ea.render_grids(g["solid"], g["sink"], g["%s_count" % f], wx, wy)
         assert got == r[key].tobytes(), key
+
+
+def test_coloured_frame_formatter_matches_reference_bytes():
+    """euler_render_grids_rgb (host C, no GPU) on the dye arrays the compiled reference produced
+    (tests/golden/*_rainbow.npz): the 24-bit colour escapes of main.c:902-912 byte for byte."""
+    import numpy as np
+    from golden_util import load
+    for scn in ("block", "waterfall"):
+        g, gr = load(scn + "_frames.npz"), load(scn + "_rainbow.npz")
+        f = int(gr["frames_full"][1])
+        if "f%d_count" % f not in g.files:
+            continue
+        rgb = tuple(gr["f%d_%s" % (f, c)] for c in "rgb")
+        for (wx, wy) in ((98, 38), (40, 10)):
+            got = ea.render_grids(g["solid"], g["sink"], g["f%d_count" % f], wx, wy, rgb=rgb)
+            assert got == gr["f%d_w%dx%d" % (f, wx, wy)].tobytes(), (scn, f, wx, wy)
