@@ -334,6 +334,8 @@ class Simulation:
         a = np.empty(nbytes // dt.itemsize, dt)
         if nbytes:
             _check(self.L.euler_get_field(self.h, field, a.ctypes.data, nbytes))
+        elif field != F_MARKERS:      # an unknown or unavailable field: let the library say why
+            _check(self.L.euler_get_field(self.h, field, np.empty(8, np.uint8).ctypes.data, 0) or -1)
         return a.reshape(-1, 2) if field == F_MARKERS else a.reshape(self.Y, self.X)
 
     def set(self, field, arr):

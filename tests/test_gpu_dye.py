@@ -44,7 +44,7 @@ def test_dye_vs_oracle_on_larger_grids(X_, Y_, workload, frames):
         sim.step()
         for fld, a in ((ea.F_DYE_R, o.cr), (ea.F_DYE_G, o.cg), (ea.F_DYE_B, o.cb), (ea.F_DYE_RTMP, o.crtmp), (ea.F_U, o.u)):
             assert_bits(sim.get(fld), a, "%s frame %d field %d" % (workload, f, fld), nan_class=True)
-        moved = moved or float(np.abs(o.u).max()) > 0
+        moved = moved or float(np.abs(o.v).max()) > 0
     assert moved
     assert sim.draw(X_, Y_) == o.render(X_, Y_)
 
