@@ -72,6 +72,7 @@ EXPORTS = [
     "euler_profile_class_count", "euler_profile_class_name", "euler_profile_get", "euler_profile_reset",
     "euler_measure_copy_bandwidth", "euler_device_name", "euler_sweep_timeline", "euler_save_state", "euler_load_state", "euler_set_comm", "euler_set_stream", "euler_slab_info",
     "euler_rccl_unique_id", "euler_rccl_version", "euler_set_comm_rccl", "euler_comm_calls",
+    "euler_p2p_export", "euler_p2p_connect", "euler_p2p_disconnect", "euler_p2p_calls",
 ]
 
 
@@ -130,6 +131,10 @@ def load_library():
         "euler_rccl_version": (C.c_int, []),
         "euler_set_comm_rccl": (C.c_int, [vp, vp, i32, i32, i32, i32]),
         "euler_comm_calls": (C.c_int, [vp, C.POINTER(u64)]),
+        "euler_p2p_export": (C.c_int, [vp, vp, i32]),
+        "euler_p2p_connect": (C.c_int, [vp, vp, i32]),
+        "euler_p2p_disconnect": (C.c_int, [vp]),
+        "euler_p2p_calls": (C.c_int, [vp, C.POINTER(u64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)   # AttributeError here = a symbol include/euler.h declares is not exported

@@ -1,0 +1,251 @@
+// comm_p2p.hip — the latency-bound exchanges of the row-slab pressure solve as direct peer-to-peer
+// mailbox writes (xGMI on an MI355X node), no collective library in the PCG loop.
+//
+// Every PCG iteration of the distributed solve needs three 8-byte all-reduces (dot(s,As), |r|_inf,
+// dot(z,r)) and one ghost-row exchange of the search vector with the two neighbouring slabs
+// (DESIGN.md "Multi-GPU").  All of them are pure latency.  Each rank owns a MAILBOX in fine-grained device
+// memory that its peers map through HIP IPC; an exchange is then
+//     all-reduce : one 1-block kernel - lane j stores {value, tag} into peer j's slot for this rank, polls its
+//                  own slot j, and lane order fixes the order of the sum (bit-identical on every rank);
+//     ghost rows : one 1-block kernel - the row is written into the neighbour's mailbox, then the own
+//                  mailbox is polled for the neighbour's row.
+// Every datum travels as a self-validating 16-byte granule {lo32, tag, hi32, tag} written with one
+// system-scope write-through store and read with system-scope loads - the same hand-off the IC(0) band
+// pipeline uses inside a GPU (k_pcg.hip; MI355X_MICROARCH "granule" hand-off) - so no fence, no
+// write-back of the L2 (which holds the solver's dirty vectors) and no assumption about the order in
+// which stores to a peer arrive.  The tag is the exchange's sequence number; two slot parities are enough
+// because an exchange k+2 cannot begin before every rank has finished reading exchange k (it needs their
+// contribution to exchange k+1, which they issue after k in stream order).  Waits are bounded (sticky
+// error -> EULER_ETIMEOUT).  The bulk transfers (band hand-off rows, all-gather of p: once per solve)
+// stay on the communicator that was installed first (RCCL).
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+
+#include "euler_dev.h"
+
+#define P2P_MAXR 16
+#define P2P_SPIN_LIMIT (1u << 23)   // x ~2 us per poll: a peer may lag by seconds, not for ever
+#define P2P_HDR_BYTES 4096
+
+typedef unsigned int p2p_u32x4 __attribute__((ext_vector_type(4)));
+
+struct P2PBoxHeader {
+  p2p_u32x4 scalar[2][P2P_MAXR];     // [parity][sending rank]
+};
+static_assert(sizeof(P2PBoxHeader) <= P2P_HDR_BYTES, "mailbox header");
+
+struct P2PState {
+  void* box;                          // own mailbox (fine-grained device memory)
+  size_t box_bytes;
+  void* peer[P2P_MAXR];               // host copy of the mapped mailboxes (own entry = box)
+  void** peer_dev;                    // the same table on the device
+  int rank, n, X;
+  unsigned int seq_scalar, seq_halo;  // exchange counters (identical on every rank by construction)
+  euler_comm_ops base;                // the communicator underneath (bulk transfers)
+  uint64_t calls[2];
+};
+
+__device__ __forceinline__ void p2p_store(void* p, double v, unsigned int tag) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+  const p2p_u32x4 g = {(unsigned int)bits, tag, (unsigned int)(bits >> 32), tag};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(g) : "memory");
+}
+__device__ __forceinline__ bool p2p_poll(const void* p, unsigned int tag, double* v) {
+  p2p_u32x4 g;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g) : "v"(p) : "memory");
+  *v = __hiloint2double((int)g[2], (int)g[0]);
+  return g[1] == tag && g[3] == tag;
+}
+
+// in-place all-reduce of ONE double per launch (sum in rank order, or max)
+__global__ __launch_bounds__(64) void k_p2p_allreduce(void** boxes, int rank, int n, unsigned int seq, double* val, int is_max, int* error) {
+  __shared__ double got[P2P_MAXR];
+  const int j = threadIdx.x;
+  const int par = seq & 1;
+  if (j < n) {
+    const double mine = *val;
+    P2PBoxHeader* theirs = static_cast<P2PBoxHeader*>(boxes[j]);
+    p2p_store(&theirs->scalar[par][rank], mine, seq);
+    const P2PBoxHeader* own = static_cast<const P2PBoxHeader*>(boxes[rank]);
+    double v = 0.0;
+    unsigned int spins = 0;
+    while (!p2p_poll(&own->scalar[par][j], seq, &v)) {
+      if (++spins > P2P_SPIN_LIMIT) { atomicExch(error, 3); v = mine; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    got[j] = v;
+  }
+  __syncthreads();
+  if (j == 0) {
+    double t = got[0];
+    for (int k = 1; k < n; ++k) t = is_max ? (got[k] > t ? got[k] : t) : t + got[k];
+    *val = t;
+  }
+}
+
+// ghost rows: rows travel as one granule per double.  Mailbox layout behind the header:
+// [parity][side: 0 = row arriving from rank-1, 1 = from rank+1][X] granules.
+__global__ __launch_bounds__(1024) void k_p2p_halo(void** boxes, int rank, int n, unsigned int seq, int X,
+                                                   const double* send_lo, const double* send_hi, double* recv_lo, double* recv_hi, int* error) {
+  const int par = seq & 1;
+  const size_t row = (size_t)X * 16, side_off = P2P_HDR_BYTES + (size_t)par * 2 * row;
+  // my lowest row is rank-1's "from rank+1" row, my highest row is rank+1's "from rank-1" row
+  if (rank > 0) {
+    char* dst = static_cast<char*>(boxes[rank - 1]) + side_off + row;
+    for (int x = threadIdx.x; x < X; x += 1024) p2p_store(dst + (size_t)x * 16, send_lo[x], seq);
+  }
+  if (rank + 1 < n) {
+    char* dst = static_cast<char*>(boxes[rank + 1]) + side_off;
+    for (int x = threadIdx.x; x < X; x += 1024) p2p_store(dst + (size_t)x * 16, send_hi[x], seq);
+  }
+  const char* own = static_cast<const char*>(boxes[rank]) + side_off;
+  for (int side = 0; side < 2; ++side) {
+    if (side == 0 ? rank == 0 : rank + 1 >= n) continue;
+    double* out = side == 0 ? recv_lo : recv_hi;
+    for (int x = threadIdx.x; x < X; x += 1024) {
+      double v = 0.0;
+      unsigned int spins = 0;
+      while (!p2p_poll(own + side * row + (size_t)x * 16, seq, &v)) {
+        if (++spins > P2P_SPIN_LIMIT) { atomicExch(error, 3); break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      out[x] = v;
+    }
+  }
+}
+
+static int p2p_allreduce(void* ctx, void* dev_f64, int32_t count, int32_t is_max) {
+  euler_sim* S = static_cast<euler_sim*>(ctx);
+  P2PState* p = static_cast<P2PState*>(S->p2p);
+  p->calls[0]++;
+  for (int k = 0; k < count; ++k) {
+    p->seq_scalar += 1;
+    hipLaunchKernelGGL(k_p2p_allreduce, dim3(1), dim3(64), 0, S->stream, p->peer_dev, p->rank, p->n, p->seq_scalar,
+                       static_cast<double*>(dev_f64) + k, (int)is_max, &S->ms->error);
+  }
+  return 0;
+}
+
+static int p2p_halo(void* ctx, void* send_lo, void* send_hi, void* recv_lo, void* recv_hi, int32_t count) {
+  euler_sim* S = static_cast<euler_sim*>(ctx);
+  P2PState* p = static_cast<P2PState*>(S->p2p);
+  p->calls[1]++;
+  if (count != p->X) { eu_set_error("p2p halo: row of %d doubles, mailbox sized for %d", (int)count, p->X); return -1; }
+  p->seq_halo += 1;
+  hipLaunchKernelGGL(k_p2p_halo, dim3(1), dim3(1024), 0, S->stream, p->peer_dev, p->rank, p->n, p->seq_halo, p->X,
+                     static_cast<const double*>(send_lo), static_cast<const double*>(send_hi), static_cast<double*>(recv_lo),
+                     static_cast<double*>(recv_hi), &S->ms->error);
+  return 0;
+}
+// bulk transfers: the communicator underneath, with its own context
+static int p2p_chain(void* ctx, void* dev_ptr, int64_t nbytes, int32_t src, int32_t dst) {
+  P2PState* p = static_cast<P2PState*>(static_cast<euler_sim*>(ctx)->p2p);
+  return p->base.chain(p->base.ctx, dev_ptr, nbytes, src, dst);
+}
+static int p2p_allgather(void* ctx, void* dev_base, const int64_t* off, const int64_t* cnt) {
+  P2PState* p = static_cast<P2PState*>(static_cast<euler_sim*>(ctx)->p2p);
+  return p->base.allgather(p->base.ctx, dev_base, off, cnt);
+}
+
+static size_t p2p_box_bytes(const euler_sim* S) { return P2P_HDR_BYTES + (size_t)2 * 2 * S->X * 16; }
+
+void eu_p2p_release(euler_sim* S) {
+  P2PState* p = static_cast<P2PState*>(S->p2p);
+  if (!p) return;
+  if (S->stream) (void)hipStreamSynchronize(S->stream);
+  for (int k = 0; k < p->n; ++k)
+    if (p->peer[k] && p->peer[k] != p->box) (void)hipIpcCloseMemHandle(p->peer[k]);
+  if (p->peer_dev) (void)hipFree(p->peer_dev);
+  if (p->box) (void)hipFree(p->box);
+  if (S->has_comm && S->comm.ctx == S && p->base.allreduce) S->comm = p->base;   // back to the communicator underneath
+  free(p);
+  S->p2p = nullptr;
+}
+
+// Step 1 (every rank): allocate the mailbox, hand out its IPC handle (EULER_P2P_HANDLE_BYTES bytes).
+extern "C" int euler_p2p_export(euler_sim* S, void* handle_out, int32_t cap) {
+  if (!S || !handle_out || cap < (int32_t)sizeof(hipIpcMemHandle_t)) { eu_set_error("euler_p2p_export: need %d bytes", (int)sizeof(hipIpcMemHandle_t)); return EULER_EINVAL; }
+  HIPCHK(hipSetDevice(S->cfg.device));
+  P2PState* p = static_cast<P2PState*>(S->p2p);
+  if (!p) {
+    p = static_cast<P2PState*>(calloc(1, sizeof(P2PState)));
+    if (!p) return EULER_ENOMEM;
+    p->box_bytes = p2p_box_bytes(S);
+    p->X = S->X;
+    hipError_t e = hipExtMallocWithFlags(&p->box, p->box_bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) { free(p); return eu_hip_fail(e, "hipExtMallocWithFlags(mailbox, fine-grained)", __FILE__, __LINE__); }
+    e = hipMemset(p->box, 0, p->box_bytes);   // tag 0 is never used by an exchange
+    if (e != hipSuccess) { (void)hipFree(p->box); free(p); return eu_hip_fail(e, "hipMemset(mailbox)", __FILE__, __LINE__); }
+    S->p2p = p;
+  }
+  hipIpcMemHandle_t h;
+  HIPCHK(hipIpcGetMemHandle(&h, p->box));
+  memcpy(handle_out, &h, sizeof h);
+  return EULER_OK;
+}
+
+// Step 2 (every rank, collectively, after a communicator has been installed): map the peers' mailboxes, prove
+// the path with one all-reduce of known values, then route the scalar all-reduces and the ghost rows over it.
+extern "C" int euler_p2p_connect(euler_sim* S, const void* handles, int32_t nranks) {
+  if (!S || !handles) return EULER_EINVAL;
+  P2PState* p = static_cast<P2PState*>(S->p2p);
+  if (!p) { eu_set_error("euler_p2p_connect: call euler_p2p_export first"); return EULER_ESTATE; }
+  if (!S->has_comm || S->comm.nranks != nranks || S->comm.ctx == S) { eu_set_error("euler_p2p_connect: install a communicator of %d ranks first", (int)nranks); return EULER_ESTATE; }
+  if (nranks > P2P_MAXR) { eu_set_error("euler_p2p_connect: at most %d ranks", P2P_MAXR); return EULER_EINVAL; }
+  HIPCHK(hipSetDevice(S->cfg.device));
+  p->rank = S->comm.rank; p->n = nranks;
+  const hipIpcMemHandle_t* hs = static_cast<const hipIpcMemHandle_t*>(handles);
+  for (int k = 0; k < nranks; ++k) {
+    if (k == p->rank) { p->peer[k] = p->box; continue; }
+    hipIpcMemHandle_t h;
+    memcpy(&h, &hs[k], sizeof h);
+    hipError_t e = hipIpcOpenMemHandle(&p->peer[k], h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) { p->peer[k] = nullptr; return eu_hip_fail(e, "hipIpcOpenMemHandle(peer mailbox)", __FILE__, __LINE__); }
+  }
+  HIPCHK(hipMalloc((void**)&p->peer_dev, sizeof(void*) * P2P_MAXR));
+  HIPCHK(hipMemcpy(p->peer_dev, p->peer, sizeof(void*) * P2P_MAXR, hipMemcpyHostToDevice));
+  // self-test on the real path: sum and max of rank + 1
+  double* probe = reinterpret_cast<double*>(S->halo_buf);
+  const double mine = (double)(p->rank + 1);
+  double got[2] = {0, 0};
+  for (int is_max = 0; is_max < 2; ++is_max) {
+    HIPCHK(hipMemcpyAsync(probe, &mine, 8, hipMemcpyHostToDevice, S->stream));
+    p->seq_scalar += 1;
+    hipLaunchKernelGGL(k_p2p_allreduce, dim3(1), dim3(64), 0, S->stream, p->peer_dev, p->rank, p->n, p->seq_scalar, probe, is_max, &S->ms->error);
+    HIPCHK(hipMemcpyAsync(&got[is_max], probe, 8, hipMemcpyDeviceToHost, S->stream));
+  }
+  int rc = eu_sync_marker_state(S);   // also picks up a timed-out wait
+  if (rc == EULER_ETIMEOUT) {         // a peer never showed up: not fatal for the handle, the caller falls back
+    (void)hipMemsetAsync(&S->ms->error, 0, sizeof(int), S->stream);
+    (void)eu_sync_marker_state(S);
+    eu_set_error("euler_p2p_connect: the self-test all-reduce timed out (a peer's mailbox never answered)");
+    return EULER_ECOMM;
+  }
+  if (rc) return rc;
+  if (got[0] != 0.5 * nranks * (nranks + 1) || got[1] != (double)nranks) {
+    eu_set_error("euler_p2p_connect: self-test all-reduce returned %g / %g, expected %g / %g", got[0], got[1], 0.5 * nranks * (nranks + 1), (double)nranks);
+    return EULER_ECOMM;
+  }
+  p->base = S->comm;
+  S->comm.ctx = S;
+  S->comm.allreduce = p2p_allreduce;
+  S->comm.halo = p2p_halo;
+  S->comm.chain = p2p_chain;
+  S->comm.allgather = p2p_allgather;
+  return EULER_OK;
+}
+
+extern "C" int euler_p2p_disconnect(euler_sim* S) {
+  if (!S) return EULER_EINVAL;
+  eu_p2p_release(S);
+  return EULER_OK;
+}
+
+extern "C" int euler_p2p_calls(euler_sim* S, uint64_t out[2]) {
+  if (!S || !out) return EULER_EINVAL;
+  P2PState* p = static_cast<P2PState*>(S->p2p);
+  out[0] = p ? p->calls[0] : 0; out[1] = p ? p->calls[1] : 0;
+  return EULER_OK;
+}

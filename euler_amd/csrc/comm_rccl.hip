@@ -170,6 +170,7 @@ extern "C" int euler_set_comm_rccl(euler_sim* S, const void* unique_id, int32_t 
   int rc = load_rccl();
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(S->stream));
+  eu_p2p_release(S);
   eu_rccl_release(S);
   RcclComm* c = static_cast<RcclComm*>(calloc(1, sizeof(RcclComm)));
   if (!c) return EULER_ENOMEM;

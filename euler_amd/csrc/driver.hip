@@ -135,6 +135,7 @@ static int dalloc(T** p, size_t n) {
 extern "C" void euler_destroy(euler_sim* S) {
   if (!S) return;
   if (S->stream) (void)hipStreamSynchronize(S->stream);
+  eu_p2p_release(S);
   eu_rccl_release(S);
   void* dev[] = {S->u, S->v, S->utmp, S->vtmp, S->solid, S->source, S->sink, S->count, S->prev_count, S->count32,
                  S->markers[0], S->markers[1], S->ms, S->evmask, S->ev_theta, S->ev_delta, S->sel_idx, S->act_idx,
@@ -389,6 +390,7 @@ int eu_install_comm(euler_sim* S, const euler_comm_ops* ops, int32_t coupling, i
 extern "C" int euler_set_comm(euler_sim* S, const euler_comm_ops* ops, int32_t coupling) {
   if (!S) return EULER_EINVAL;
   HIPCHK(hipStreamSynchronize(S->stream));
+  eu_p2p_release(S);
   eu_rccl_release(S);   // a caller-supplied communicator replaces the built-in one
   return eu_install_comm(S, ops, coupling, 0);
 }

@@ -160,6 +160,7 @@ struct euler_sim {
   double* halo_buf;           // 4 rows of X doubles: send_lo, send_hi, recv_lo, recv_hi
   int own_stream;
   void* rccl;                 // the built-in RCCL communicator (comm_rccl.hip), if euler_set_comm_rccl installed one
+  void* p2p;                  // peer-to-peer mailboxes for the scalar all-reduces and ghost rows (comm_p2p.hip)
 
   // profiling: hipEvent pairs per launch; PCG launches carry (solve, iteration) so that launches
   // that returned at once (after convergence / all-zero rhs) are NOT counted
@@ -213,6 +214,7 @@ int eu_ordered_select(euler_sim* S, const unsigned long long* mask, size_t nword
                       unsigned int* out_total);
 int eu_sync_marker_state(euler_sim* S);
 void eu_rccl_release(euler_sim* S);   // comm_rccl.hip
+void eu_p2p_release(euler_sim* S);    // comm_p2p.hip
 int eu_install_comm(euler_sim* S, const euler_comm_ops* ops, int32_t coupling, int allow_single);
 
 // ------------------------------------------------------------------------------------------

@@ -184,3 +184,46 @@ class RcclComm:
         out = (C.c_uint64 * 4)()
         self.sim.L.euler_comm_calls(self.sim.h, out)
         return dict(zip(("allreduce", "halo", "chain", "allgather"), (int(v) for v in out)))
+
+
+P2P_HANDLE_BYTES = 64
+
+
+def attach_p2p(sim):
+    """Route the per-iteration exchanges (three scalar all-reduces, the ghost rows) over peer-to-peer
+    mailboxes (csrc/comm_p2p.hip) on top of the communicator already installed on `sim`.
+    torch.distributed only carries the 64-byte IPC handles, once.  Returns True when the mailboxes are in
+    use on EVERY rank; on any failure all ranks stay on the installed communicator (the reason is in
+    sim._p2p_error)."""
+    import torch
+    import torch.distributed as dist
+    L = sim.L
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    buf = (C.c_ubyte * P2P_HANDLE_BYTES)()
+    rc = L.euler_p2p_export(sim.h, buf, P2P_HANDLE_BYTES)
+    sim._p2p_error = None if rc == 0 else L.euler_last_error().decode()
+    mine = torch.tensor(list(bytes(buf)) + [0 if rc == 0 else 1], dtype=torch.uint8, device=dev)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    every = [t.cpu() for t in every]
+    if any(int(t[-1]) for t in every):          # some rank could not export: nobody connects
+        return False
+    handles = b"".join(bytes(t[:-1].tolist()) for t in every)
+    rc = L.euler_p2p_connect(sim.h, handles, world)
+    if rc:
+        sim._p2p_error = L.euler_last_error().decode()
+    # connect is collective (its self-test is an all-reduce over the mailboxes): a rank that failed before it
+    # leaves the others to time out, so agree on the outcome and fall back together
+    ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0 and rc == 0:
+        sim._p2p_error = "another rank could not connect its mailboxes"
+        L.euler_p2p_disconnect(sim.h)
+    return int(ok.item()) == 1
+
+
+def p2p_counts(sim):
+    out = (C.c_uint64 * 2)()
+    sim.L.euler_p2p_calls(sim.h, out)
+    return {"allreduce": int(out[0]), "halo": int(out[1])}

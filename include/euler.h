@@ -252,6 +252,21 @@ int euler_rccl_version(void);                                  /* NCCL-style ver
 int euler_set_comm_rccl(euler_sim* sim, const void* unique_id, int32_t id_bytes, int32_t rank, int32_t nranks,
                         int32_t coupling);
 int euler_comm_calls(euler_sim* sim, uint64_t out[4]);         /* built-in communicator: allreduce, halo, chain, allgather calls so far */
+
+/* Peer-to-peer mailboxes for the latency-bound exchanges (csrc/comm_p2p.hip): the three 8-byte all-reduces
+ * and the ghost-row exchange of every PCG iteration become direct writes into the peers' mailboxes (HIP IPC
+ * mappings of fine-grained device memory; xGMI between the GPUs of a node) - one small kernel each, no
+ * collective library in the loop, sums formed in rank order (bit-identical on every rank).  The bulk
+ * transfers (band hand-off rows, all-gather of p) stay on the communicator installed before.
+ *   1. every rank:  euler_p2p_export(sim, handle)          -> EULER_P2P_HANDLE_BYTES bytes (a hipIpcMemHandle_t)
+ *   2. the launcher gathers the handles of all ranks, in rank order, on every rank (any host channel)
+ *   3. every rank:  euler_p2p_connect(sim, handles, nranks) after euler_set_comm[_rccl]; maps the mailboxes and
+ *      proves the path with an all-reduce of known values.  On failure the installed communicator stays as it is. */
+#define EULER_P2P_HANDLE_BYTES 64
+int euler_p2p_export(euler_sim* sim, void* handle_out, int32_t cap);
+int euler_p2p_connect(euler_sim* sim, const void* handles, int32_t nranks);
+int euler_p2p_disconnect(euler_sim* sim);                      /* back to the installed communicator; frees the mailbox */
+int euler_p2p_calls(euler_sim* sim, uint64_t out[2]);          /* all-reduces, ghost-row exchanges over the mailboxes so far */
 int euler_set_stream(euler_sim* sim, void* hip_stream);   /* run on the caller's HIP stream (e.g. torch's) */
 int euler_slab_info(euler_sim* sim, int32_t* band_lo, int32_t* band_hi, int32_t* nbands);
 

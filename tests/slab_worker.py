@@ -14,7 +14,7 @@ import torch.distributed as dist
 
 import euler_amd as ea
 from euler_amd import scenarios
-from euler_amd.slab import SLAB_EXACT, SLAB_LOCAL, TorchComm
+from euler_amd.slab import SLAB_EXACT, SLAB_LOCAL, TorchComm, attach_p2p, p2p_counts
 
 
 def build(X, Y, workload):
@@ -28,6 +28,7 @@ def build(X, Y, workload):
 
 def main():
     X, Y, workload, frames, coupling = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+    p2p = len(sys.argv) > 6 and sys.argv[6] == "p2p"
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
@@ -35,6 +36,9 @@ def main():
     sim = build(X, Y, workload)
     comm = TorchComm(sim, coupling)
     out = {"world": world, "bands": [comm.band_lo, comm.band_hi, comm.nbands], "frames": []}
+    if p2p:   # scalar all-reduces and ghost rows over IPC mailboxes (here: several processes on one GPU)
+        out["p2p_ok"] = attach_p2p(sim)
+        out["p2p_error"] = sim._p2p_error
     for f in range(frames):
         ref.step()
         sim.step()
@@ -52,6 +56,8 @@ def main():
                               "residual": [sr.last_residual, ss.last_residual],
                               "finite": bool(np.isfinite(sim.get(ea.F_U)).all() and np.isfinite(sim.get(ea.F_V)).all())})
     out["calls"] = comm.counts
+    if p2p:
+        out["p2p_calls"] = p2p_counts(sim)
     # every rank must hold the same replicated state
     h = torch.tensor([float(np.abs(sim.get(ea.F_U)).sum()), float(sim.stats().n_markers)], dtype=torch.float64)
     lo, hi = h.clone(), h.clone()
