@@ -58,6 +58,9 @@ def parse_args():
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
                     help="N>1 exchange transport: the library's own RCCL communicator (C, no host code between kernels) "
                          "or the torch.distributed callbacks of euler_amd/slab.py")
+    ap.add_argument("--no-p2p", action="store_true",
+                    help="N>1: keep the per-iteration exchanges (3 scalar all-reduces, ghost rows) on the communicator instead of "
+                         "the peer-to-peer mailboxes of csrc/comm_p2p.hip")
     ap.add_argument("--force-slab", action="store_true",
                     help="N=1 diagnostics: run the communicator code path with one rank (every exchange still goes through RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -174,9 +177,15 @@ def main():
         torch.cuda.set_device(local_rank)
     sim = ea.Simulation(GX, GY, device=local_rank, dot_mode=dot_mode, precond=precond)
     comm = None
+    p2p_on = False
     if sharded:
-        from euler_amd.slab import SLAB_EXACT, SLAB_LOCAL, RcclComm, TorchComm
+        from euler_amd.slab import SLAB_EXACT, SLAB_LOCAL, RcclComm, TorchComm, attach_p2p
         comm = (RcclComm if args.comm == "rccl" else TorchComm)(sim, SLAB_EXACT if args.slab == "exact" else SLAB_LOCAL)
+        # the latency-bound exchanges of every PCG iteration go peer to peer (xGMI); if the mailboxes cannot be set up
+        # on every rank the job stays on the communicator, and the JSON line says which one ran
+        p2p_on = (not args.no_p2p) and attach_p2p(sim)
+        if rank == 0 and not args.no_p2p and not p2p_on:
+            print("bench: peer-to-peer mailboxes unavailable (%s); exchanges stay on %s" % (sim._p2p_error, args.comm), file=sys.stderr)
     if args.workload == "dam_break":
         sim.load_text(scenarios.dam_break(), upscale=True)
     elif args.workload == "waterfall":
@@ -312,7 +321,9 @@ def main():
                    "parallelism": "1 GPU" if args.gpus == 1 and not sharded else (
                        "%d independent replicas" % args.gpus if not sharded else
                        "%d row slabs of %d rows: distributed PCG (%s IC(0) coupling, exchanges by %s), replicated marker/advection stages; grid %dx%d"
-                       % (args.gpus, N, args.slab, "RCCL from the C library" if args.comm == "rccl" else "torch.distributed callbacks", GX, GY))},
+                       % (args.gpus, N, args.slab,
+                          ("peer-to-peer mailboxes (scalars, ghost rows) + " if p2p_on else "")
+                          + ("RCCL from the C library" if args.comm == "rccl" else "torch.distributed callbacks"), GX, GY))},
         "substeps": int(substeps), "pcg_iterations": int(iters),
         "cells_substeps_per_s": cells * substeps / elapsed,
         "markers": int(st1.n_markers), "fluid_cells": int(st1.fluid_cells),

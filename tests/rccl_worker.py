@@ -15,7 +15,7 @@ import torch.distributed as dist
 
 import euler_amd as ea
 from euler_amd import scenarios
-from euler_amd.slab import RcclComm, TorchComm
+from euler_amd.slab import RcclComm, TorchComm, attach_p2p, p2p_counts
 
 
 def build(X, Y, workload, device):
@@ -69,6 +69,9 @@ def main():
     ref = build(X, Y, workload, local)
     sim = build(X, Y, workload, local)
     comm = RcclComm(sim, coupling)
+    p2p = len(sys.argv) > 6 and sys.argv[6] == "p2p"
+    if p2p:   # what bench.py runs on a node: mailboxes for the per-iteration exchanges, RCCL for the bulk transfers
+        out["p2p_ok"], out["p2p_error"] = attach_p2p(sim), sim._p2p_error
     out["rccl_version"] = comm.version
     out["bands"] = [comm.band_lo, comm.band_hi, comm.nbands]
     out["frames"] = []
@@ -85,6 +88,8 @@ def main():
             "iters": [sr.last_pcg_iterations, ss.last_pcg_iterations], "substeps": [sr.last_substeps, ss.last_substeps],
             "residual": [sr.last_residual, ss.last_residual]})
     out["calls"] = comm.counts
+    if p2p:
+        out["p2p_calls"] = p2p_counts(sim)
     h = torch.tensor([float(np.abs(sim.get(ea.F_U)).sum()), float(sim.stats().n_markers)], dtype=torch.float64, device="cuda")
     lo, hi = h.clone(), h.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)

@@ -90,10 +90,10 @@ def test_slab_local_preconditioner_converges_to_the_same_answer():
             assert f["dp"] <= 1e-4 * max(f["pmax"], 1.0), f
 
 
-def run_rccl_worker(nproc, X, Y, workload, frames, coupling, port):
+def run_rccl_worker(nproc, X, Y, workload, frames, coupling, port, extra=()):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc, "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "rccl_worker.py"), str(X), str(Y), workload, str(frames), str(coupling)]
+           "--master-port", str(port), os.path.join(ROOT, "tests", "rccl_worker.py"), str(X), str(Y), workload, str(frames), str(coupling)] + list(extra)
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
@@ -105,17 +105,22 @@ def gpu_count():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload,X,Y,frames", [("half_tank", 192, 256, 3), ("dam_break", 256, 256, 30)])
-def test_builtin_rccl_communicator(workload, X, Y, frames):
+@pytest.mark.parametrize("workload,X,Y,frames,p2p", [("half_tank", 192, 256, 3, False), ("dam_break", 256, 256, 30, True)])
+def test_builtin_rccl_communicator(workload, X, Y, frames, p2p):
     """The library's own RCCL communicator (csrc/comm_rccl.hip) over backend "nccl": as many ranks as the
     box has GPUs (1 on the test box: RCCL refuses two ranks on one device - the communicator code path of
     the PCG driver still runs, every exchange through RCCL on the handle's stream), compared with a plain
     single-GPU run.  The same worker also drives TorchComm's four operations on raw device pointers over RCCL."""
     n = max(1, min(gpu_count(), 4))
-    d = run_rccl_worker(n, X, Y, workload, frames, 1, 29541)
+    d = run_rccl_worker(n, X, Y, workload, frames, 1, 29541, extra=("p2p",) if p2p else ())
     assert d["world"] == n and d["rccl_version"] > 0
     assert d["torch_transport_ok"], d["torch_transport_error"]
-    assert d["ranks_agree"] and d["calls"]["allreduce"] > 0 and d["calls"]["allgather"] > 0 and d["calls"]["halo"] > 0
+    assert d["ranks_agree"] and d["calls"]["allgather"] > 0
+    if p2p:      # bench.py's configuration: mailboxes for the per-iteration exchanges, RCCL underneath for the bulk transfers
+        assert d["p2p_ok"], d["p2p_error"]
+        assert d["p2p_calls"]["allreduce"] > 0 and d["p2p_calls"]["halo"] > 0 and d["calls"]["allreduce"] == 0
+    else:
+        assert d["calls"]["allreduce"] > 0 and d["calls"]["halo"] > 0
     solved = 0
     for f in d["frames"]:
         assert f["cells_differing"] == 0 and f["markers_equal"], f
