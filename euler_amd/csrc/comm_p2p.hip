@@ -20,20 +20,12 @@
 // stay on the communicator that was installed first (RCCL).
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 
 #include "euler_dev.h"
 
-#define P2P_MAXR 16
-#define P2P_SPIN_LIMIT (1u << 23)   // x ~2 us per poll: a peer may lag by seconds, not for ever
-#define P2P_HDR_BYTES 4096
-
-typedef unsigned int p2p_u32x4 __attribute__((ext_vector_type(4)));
-
-struct P2PBoxHeader {
-  p2p_u32x4 scalar[2][P2P_MAXR];     // [parity][sending rank]
-};
 static_assert(sizeof(P2PBoxHeader) <= P2P_HDR_BYTES, "mailbox header");
 
 struct P2PState {
@@ -42,65 +34,69 @@ struct P2PState {
   void* peer[P2P_MAXR];               // host copy of the mapped mailboxes (own entry = box)
   void** peer_dev;                    // the same table on the device
   int rank, n, X;
-  unsigned int seq_scalar, seq_halo;  // exchange counters (identical on every rank by construction)
   euler_comm_ops base;                // the communicator underneath (bulk transfers)
   uint64_t calls[2];
 };
 
-__device__ __forceinline__ void p2p_store(void* p, double v, unsigned int tag) {
-  const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-  const p2p_u32x4 g = {(unsigned int)bits, tag, (unsigned int)(bits >> 32), tag};
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(g) : "memory");
-}
-__device__ __forceinline__ bool p2p_poll(const void* p, unsigned int tag, double* v) {
-  p2p_u32x4 g;
-  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g) : "v"(p) : "memory");
-  *v = __hiloint2double((int)g[2], (int)g[0]);
-  return g[1] == tag && g[3] == tag;
+// stand-alone in-place all-reduce of one double (the all_zero(r) flag, euler_comm_ops.allreduce, the self-test);
+// the reductions of the PCG loop do the same inside their own last block (k_pcg.hip block_finish)
+__global__ __launch_bounds__(64) void k_p2p_allreduce(PcgScalars* sc, double* val, int is_max) {
+  const double v = threadIdx.x == 0 ? *val : 0.0;
+  const double t = is_max ? p2p_allreduce_block<true>(sc, v) : p2p_allreduce_block<false>(sc, v);
+  if (threadIdx.x == 0) *val = t;
 }
 
-// in-place all-reduce of ONE double per launch (sum in rank order, or max)
-__global__ __launch_bounds__(64) void k_p2p_allreduce(void** boxes, int rank, int n, unsigned int seq, double* val, int is_max, int* error) {
-  __shared__ double got[P2P_MAXR];
-  const int j = threadIdx.x;
-  const int par = seq & 1;
-  if (j < n) {
-    const double mine = *val;
-    P2PBoxHeader* theirs = static_cast<P2PBoxHeader*>(boxes[j]);
-    p2p_store(&theirs->scalar[par][rank], mine, seq);
-    const P2PBoxHeader* own = static_cast<const P2PBoxHeader*>(boxes[rank]);
-    double v = 0.0;
-    unsigned int spins = 0;
-    while (!p2p_poll(&own->scalar[par][j], seq, &v)) {
-      if (++spins > P2P_SPIN_LIMIT) { atomicExch(error, 3); v = mine; break; }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    got[j] = v;
-  }
+// Ghost rows of a band-skewed vector: my lowest row becomes rank-1's ghost row above its slab, my highest row
+// rank+1's ghost row below its slab.  One granule per double.  Mailbox layout behind the header:
+// [parity][side: 0 = row arriving from rank-1, 1 = from rank+1][X] granules.  Rows are read from and written
+// into the skewed array directly (row (band, lane), element skew_index(g, x, 64 band + lane)).
+__global__ __launch_bounds__(1024) void k_p2p_halo(PcgScalars* sc, double* s, SkewGeom g, int band_lo, int band_hi) {
+  __shared__ unsigned int s_seq;
+  if (threadIdx.x == 0) s_seq = ++sc->p2p_halo_seq;
   __syncthreads();
-  if (j == 0) {
-    double t = got[0];
-    for (int k = 1; k < n; ++k) t = is_max ? (got[k] > t ? got[k] : t) : t + got[k];
-    *val = t;
+  const unsigned int seq = s_seq;
+  const int rank = sc->p2p_rank, n = sc->p2p_n, X = g.X, par = seq & 1;
+  const size_t row = (size_t)X * 16, side_off = P2P_HDR_BYTES + (size_t)par * 2 * row;
+  if (rank > 0) {
+    char* dst = static_cast<char*>(sc->p2p_boxes[rank - 1]) + side_off + row;          // their "from rank+1" row
+    for (int x = threadIdx.x; x < X; x += 1024) p2p_store(dst + (size_t)x * 16, s[skew_index(g, x, 64 * band_lo)], seq);
+  }
+  if (rank + 1 < n) {
+    char* dst = static_cast<char*>(sc->p2p_boxes[rank + 1]) + side_off;                // their "from rank-1" row
+    for (int x = threadIdx.x; x < X; x += 1024) p2p_store(dst + (size_t)x * 16, s[skew_index(g, x, 64 * band_hi - 1)], seq);
+  }
+  const char* own = static_cast<const char*>(sc->p2p_boxes[rank]) + side_off;
+  for (int side = 0; side < 2; ++side) {
+    if (side == 0 ? rank == 0 : rank + 1 >= n) continue;
+    const int y = side == 0 ? 64 * band_lo - 1 : 64 * band_hi;
+    for (int x = threadIdx.x; x < X; x += 1024) {
+      double v = 0.0;
+      unsigned int spins = 0;
+      while (!p2p_poll(own + side * row + (size_t)x * 16, seq, &v)) {
+        if (++spins > P2P_SPIN_LIMIT) { atomicExch(sc->p2p_error, 3); break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      s[skew_index(g, x, y)] = v;
+    }
   }
 }
-
-// ghost rows: rows travel as one granule per double.  Mailbox layout behind the header:
-// [parity][side: 0 = row arriving from rank-1, 1 = from rank+1][X] granules.
-__global__ __launch_bounds__(1024) void k_p2p_halo(void** boxes, int rank, int n, unsigned int seq, int X,
-                                                   const double* send_lo, const double* send_hi, double* recv_lo, double* recv_hi, int* error) {
-  const int par = seq & 1;
+// the same for the rows of euler_comm_ops.halo (contiguous buffers)
+__global__ __launch_bounds__(1024) void k_p2p_halo_rows(PcgScalars* sc, int X, const double* send_lo, const double* send_hi, double* recv_lo, double* recv_hi) {
+  __shared__ unsigned int s_seq;
+  if (threadIdx.x == 0) s_seq = ++sc->p2p_halo_seq;
+  __syncthreads();
+  const unsigned int seq = s_seq;
+  const int rank = sc->p2p_rank, n = sc->p2p_n, par = seq & 1;
   const size_t row = (size_t)X * 16, side_off = P2P_HDR_BYTES + (size_t)par * 2 * row;
-  // my lowest row is rank-1's "from rank+1" row, my highest row is rank+1's "from rank-1" row
   if (rank > 0) {
-    char* dst = static_cast<char*>(boxes[rank - 1]) + side_off + row;
+    char* dst = static_cast<char*>(sc->p2p_boxes[rank - 1]) + side_off + row;
     for (int x = threadIdx.x; x < X; x += 1024) p2p_store(dst + (size_t)x * 16, send_lo[x], seq);
   }
   if (rank + 1 < n) {
-    char* dst = static_cast<char*>(boxes[rank + 1]) + side_off;
+    char* dst = static_cast<char*>(sc->p2p_boxes[rank + 1]) + side_off;
     for (int x = threadIdx.x; x < X; x += 1024) p2p_store(dst + (size_t)x * 16, send_hi[x], seq);
   }
-  const char* own = static_cast<const char*>(boxes[rank]) + side_off;
+  const char* own = static_cast<const char*>(sc->p2p_boxes[rank]) + side_off;
   for (int side = 0; side < 2; ++side) {
     if (side == 0 ? rank == 0 : rank + 1 >= n) continue;
     double* out = side == 0 ? recv_lo : recv_hi;
@@ -108,7 +104,7 @@ __global__ __launch_bounds__(1024) void k_p2p_halo(void** boxes, int rank, int n
       double v = 0.0;
       unsigned int spins = 0;
       while (!p2p_poll(own + side * row + (size_t)x * 16, seq, &v)) {
-        if (++spins > P2P_SPIN_LIMIT) { atomicExch(error, 3); break; }
+        if (++spins > P2P_SPIN_LIMIT) { atomicExch(sc->p2p_error, 3); break; }
         __builtin_amdgcn_s_sleep(1);
       }
       out[x] = v;
@@ -120,11 +116,8 @@ static int p2p_allreduce(void* ctx, void* dev_f64, int32_t count, int32_t is_max
   euler_sim* S = static_cast<euler_sim*>(ctx);
   P2PState* p = static_cast<P2PState*>(S->p2p);
   p->calls[0]++;
-  for (int k = 0; k < count; ++k) {
-    p->seq_scalar += 1;
-    hipLaunchKernelGGL(k_p2p_allreduce, dim3(1), dim3(64), 0, S->stream, p->peer_dev, p->rank, p->n, p->seq_scalar,
-                       static_cast<double*>(dev_f64) + k, (int)is_max, &S->ms->error);
-  }
+  for (int k = 0; k < count; ++k)
+    hipLaunchKernelGGL(k_p2p_allreduce, dim3(1), dim3(64), 0, S->stream, S->sc, static_cast<double*>(dev_f64) + k, (int)is_max);
   return 0;
 }
 
@@ -133,11 +126,15 @@ static int p2p_halo(void* ctx, void* send_lo, void* send_hi, void* recv_lo, void
   P2PState* p = static_cast<P2PState*>(S->p2p);
   p->calls[1]++;
   if (count != p->X) { eu_set_error("p2p halo: row of %d doubles, mailbox sized for %d", (int)count, p->X); return -1; }
-  p->seq_halo += 1;
-  hipLaunchKernelGGL(k_p2p_halo, dim3(1), dim3(1024), 0, S->stream, p->peer_dev, p->rank, p->n, p->seq_halo, p->X,
-                     static_cast<const double*>(send_lo), static_cast<const double*>(send_hi), static_cast<double*>(recv_lo),
-                     static_cast<double*>(recv_hi), &S->ms->error);
+  hipLaunchKernelGGL(k_p2p_halo_rows, dim3(1), dim3(1024), 0, S->stream, S->sc, p->X, static_cast<const double*>(send_lo),
+                     static_cast<const double*>(send_hi), static_cast<double*>(recv_lo), static_cast<double*>(recv_hi));
   return 0;
+}
+int eu_p2p_halo_skewed(euler_sim* S, double* s_skewed) {
+  P2PState* p = static_cast<P2PState*>(S->p2p);
+  p->calls[1]++;
+  hipLaunchKernelGGL(k_p2p_halo, dim3(1), dim3(1024), 0, S->stream, S->sc, s_skewed, S->geom, S->band_lo, S->band_hi);
+  return EULER_OK;
 }
 // bulk transfers: the communicator underneath, with its own context
 static int p2p_chain(void* ctx, void* dev_ptr, int64_t nbytes, int32_t src, int32_t dst) {
@@ -160,6 +157,7 @@ void eu_p2p_release(euler_sim* S) {
   if (p->peer_dev) (void)hipFree(p->peer_dev);
   if (p->box) (void)hipFree(p->box);
   if (S->has_comm && S->comm.ctx == S && p->base.allreduce) S->comm = p->base;   // back to the communicator underneath
+  S->p2p_on = 0;
   free(p);
   S->p2p = nullptr;
 }
@@ -206,14 +204,17 @@ extern "C" int euler_p2p_connect(euler_sim* S, const void* handles, int32_t nran
   }
   HIPCHK(hipMalloc((void**)&p->peer_dev, sizeof(void*) * P2P_MAXR));
   HIPCHK(hipMemcpy(p->peer_dev, p->peer, sizeof(void*) * P2P_MAXR, hipMemcpyHostToDevice));
+  // the link lives in the device-resident PCG scalars (k_pcg_reset never touches these fields)
+  struct { void** boxes; int* error; int rank, n; unsigned int seq, hseq; } link = {p->peer_dev, &S->ms->error, p->rank, p->n, 0u, 0u};
+  static_assert(sizeof(link) == sizeof(PcgScalars) - offsetof(PcgScalars, p2p_boxes), "PcgScalars p2p tail");
+  HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(S->sc) + offsetof(PcgScalars, p2p_boxes), &link, sizeof link, hipMemcpyHostToDevice, S->stream));
   // self-test on the real path: sum and max of rank + 1
   double* probe = reinterpret_cast<double*>(S->halo_buf);
   const double mine = (double)(p->rank + 1);
   double got[2] = {0, 0};
   for (int is_max = 0; is_max < 2; ++is_max) {
     HIPCHK(hipMemcpyAsync(probe, &mine, 8, hipMemcpyHostToDevice, S->stream));
-    p->seq_scalar += 1;
-    hipLaunchKernelGGL(k_p2p_allreduce, dim3(1), dim3(64), 0, S->stream, p->peer_dev, p->rank, p->n, p->seq_scalar, probe, is_max, &S->ms->error);
+    hipLaunchKernelGGL(k_p2p_allreduce, dim3(1), dim3(64), 0, S->stream, S->sc, probe, is_max);
     HIPCHK(hipMemcpyAsync(&got[is_max], probe, 8, hipMemcpyDeviceToHost, S->stream));
   }
   int rc = eu_sync_marker_state(S);   // also picks up a timed-out wait
@@ -234,6 +235,7 @@ extern "C" int euler_p2p_connect(euler_sim* S, const void* handles, int32_t nran
   S->comm.halo = p2p_halo;
   S->comm.chain = p2p_chain;
   S->comm.allgather = p2p_allgather;
+  S->p2p_on = 1;
   return EULER_OK;
 }
 

@@ -41,6 +41,13 @@ struct PcgScalars {
   int done;      // inf_norm(r) <= tol reached (main.c:756)
   int iters;     // apply_a calls so far (main.c:750)
   int max_iters;
+  // peer-to-peer mailboxes (comm_p2p.hip), set once by euler_p2p_connect and never reset: the mapped mailboxes of all
+  // ranks, this rank, and the DEVICE-side exchange counters (only exchanges that really run count, so that the tags of
+  // all ranks stay in step although launches after convergence return at once)
+  void** p2p_boxes;
+  int* p2p_error;
+  int p2p_rank, p2p_n;
+  unsigned int p2p_seq, p2p_halo_seq;
 };
 
 // Device-resident marker bookkeeping (reference: g_markers_length, g_source_exhausted, the
@@ -161,6 +168,7 @@ struct euler_sim {
   int own_stream;
   void* rccl;                 // the built-in RCCL communicator (comm_rccl.hip), if euler_set_comm_rccl installed one
   void* p2p;                  // peer-to-peer mailboxes for the scalar all-reduces and ghost rows (comm_p2p.hip)
+  int p2p_on;                 // connected: reductions finish their all-reduce in their own last block, ghost rows go direct
 
   // profiling: hipEvent pairs per launch; PCG launches carry (solve, iteration) so that launches
   // that returned at once (after convergence / all-zero rhs) are NOT counted
@@ -215,6 +223,7 @@ int eu_ordered_select(euler_sim* S, const unsigned long long* mask, size_t nword
 int eu_sync_marker_state(euler_sim* S);
 void eu_rccl_release(euler_sim* S);   // comm_rccl.hip
 void eu_p2p_release(euler_sim* S);    // comm_p2p.hip
+int eu_p2p_halo_skewed(euler_sim* S, double* s_skewed);   // ghost rows of a band-skewed vector, straight from / into the array
 int eu_install_comm(euler_sim* S, const euler_comm_ops* ops, int32_t coupling, int allow_single);
 
 // ------------------------------------------------------------------------------------------
@@ -286,6 +295,60 @@ __device__ __forceinline__ float eu_wave_maxf(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { float w = __shfl_down(v, o, 64); v = w > v ? w : v; }
   return v;
+}
+
+// ---- peer-to-peer mailboxes (comm_p2p.hip): self-validating 16-byte granules {lo32, tag, hi32, tag}, one
+// system-scope write-through store / system-scope load each - the band pipeline's hand-off form across GPUs
+#define P2P_MAXR 16
+#define P2P_SPIN_LIMIT (1u << 23)   // x ~2 us per poll: a peer may lag by seconds, not for ever
+#define P2P_HDR_BYTES 4096
+typedef unsigned int p2p_u32x4 __attribute__((ext_vector_type(4)));
+struct P2PBoxHeader {
+  p2p_u32x4 scalar[2][P2P_MAXR];     // [parity][sending rank]
+};
+__device__ __forceinline__ void p2p_store(void* p, double v, unsigned int tag) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+  const p2p_u32x4 g = {(unsigned int)bits, tag, (unsigned int)(bits >> 32), tag};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(g) : "memory");
+}
+__device__ __forceinline__ bool p2p_poll(const void* p, unsigned int tag, double* v) {
+  p2p_u32x4 g;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g) : "v"(p) : "memory");
+  *v = __hiloint2double((int)g[2], (int)g[0]);
+  return g[1] == tag && g[3] == tag;
+}
+// All-reduce of one double across the ranks, called by EVERY thread of a block of >= P2P_MAXR threads; v is taken from
+// thread 0 and the result is valid in thread 0.  Lane j writes this rank's value into rank j's mailbox and polls the
+// own mailbox for rank j's; the fold runs in rank order, so every rank gets the same bits.
+template <bool IS_MAX>
+__device__ __forceinline__ double p2p_allreduce_block(PcgScalars* sc, double v) {
+  __shared__ double s_got[P2P_MAXR];
+  __shared__ double s_v;
+  __shared__ unsigned int s_seq;
+  if (threadIdx.x == 0) { s_v = v; s_seq = ++sc->p2p_seq; }
+  __syncthreads();
+  const int j = threadIdx.x, n = sc->p2p_n, rank = sc->p2p_rank;
+  if (j < n) {
+    const unsigned int seq = s_seq;
+    const int par = seq & 1;
+    const double mine = s_v;
+    p2p_store(&static_cast<P2PBoxHeader*>(sc->p2p_boxes[j])->scalar[par][rank], mine, seq);
+    const P2PBoxHeader* own = static_cast<const P2PBoxHeader*>(sc->p2p_boxes[rank]);
+    double got = 0.0;
+    unsigned int spins = 0;
+    while (!p2p_poll(&own->scalar[par][j], seq, &got)) {
+      if (++spins > P2P_SPIN_LIMIT) { atomicExch(sc->p2p_error, 3); got = mine; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    s_got[j] = got;
+  }
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) {
+    t = s_got[0];
+    for (int k = 1; k < n; ++k) t = IS_MAX ? (s_got[k] > t ? s_got[k] : t) : t + s_got[k];
+  }
+  return t;
 }
 
 #endif  // __HIPCC__

@@ -38,6 +38,7 @@ __device__ __forceinline__ bool pcg_idle(const PcgScalars* sc) { return sc->done
 // ------------------------------------------------------------------------------------------
 // scalar epilogues of the reductions
 enum { FIN_SIGMA_INIT = 0, FIN_ALPHA, FIN_RNORM, FIN_BETA, FIN_STORE_ONLY, FIN_TO_COMM };
+#define FIN_VIA_P2P 0x100   // multi-rank with mailboxes: the last block all-reduces its total peer to peer, then applies the epilogue
 
 __device__ __forceinline__ void pcg_scalar_step(PcgScalars* sc, int op, double v) {
   switch (op) {
@@ -96,6 +97,7 @@ __device__ __forceinline__ void block_finish(double v_block, double* partial, un
     if (IS_MAX) v = w > v ? w : v; else v += w;
   }
   v = IS_MAX ? block_max(v) : block_sum(v);
+  if (op & FIN_VIA_P2P) { v = p2p_allreduce_block<IS_MAX>(sc, v); op &= 0xff; }   // op is uniform: every thread of this block is here
   if (threadIdx.x == 0) {
     pcg_scalar_step(sc, op, v);
     __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next reduction
@@ -1044,15 +1046,19 @@ static int comm_allreduce_scalar(euler_sim* S, int is_max) {
 }
 // rank-local reduction result (left in comm_val by FIN_TO_COMM) -> all-reduce -> scalar epilogue
 static int comm_finish(euler_sim* S, int fin_op, int is_max, int force) {
+  if (S->p2p_on) return EULER_OK;   // the reduction's last block already exchanged the partials and applied the epilogue
   int rc = comm_allreduce_scalar(S, is_max);
   if (rc) return rc;
   hipLaunchKernelGGL(k_scalar_epilogue, dim3(1), dim3(1), 0, S->stream, S->sc, fin_op, force);
   return EULER_OK;
 }
-static inline int fin_or_comm(const euler_sim* S, int fin_op) { return S->has_comm ? (int)FIN_TO_COMM : fin_op; }
+static inline int fin_or_comm(const euler_sim* S, int fin_op) {
+  return S->has_comm ? (S->p2p_on ? (fin_op | FIN_VIA_P2P) : (int)FIN_TO_COMM) : fin_op;
+}
 
 // ghost rows of the search vector s for apply_a: my lowest row goes to rank-1, my highest to rank+1
 static int comm_halo_s(euler_sim* S) {
+  if (S->p2p_on) return eu_p2p_halo_skewed(S, S->s);   // one launch: rows leave from and land in the skewed array
   const int X = S->X, nbk = (X + 255) / 256;
   double *send_lo = S->halo_buf, *send_hi = S->halo_buf + X, *recv_lo = S->halo_buf + 2 * X, *recv_hi = S->halo_buf + 3 * X;
   const bool has_lo = S->band_lo > 0, has_hi = S->band_hi < S->geom.nbands;
