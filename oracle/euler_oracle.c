@@ -683,7 +683,7 @@ int eo_render_rows(const eo_sim* s, int wx, int wy, char* out, int cap) {
         int has_water = k > 0;
         if (!prev_water && has_water && !s->rainbow) PUT(BLUE);
         else if (has_water && s->rainbow) {   /* buffer_append_color, main.c:902-912; misc/color.h:6-14 */
-          char tmp[32];
+          char tmp[64];
           const float end = nextafterf(256.f, 0.f);
           const float c3[3] = {s->cr[i], s->cg[i], s->cb[i]};
           int o[3];
