@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument("--workload", default="dam_break", choices=["dam_break", "half_tank", "waterfall"])
     ap.add_argument("--dot-mode", default="tree", choices=["tree", "sequential"])
     ap.add_argument("--precond", default="ic0", choices=["ic0", "jacobi"])
-    ap.add_argument("--max-preroll", type=int, default=90)
+    ap.add_argument("--max-preroll", type=int, default=400)
     ap.add_argument("--slab", default="local", choices=["local", "exact", "replicas"],
                     help="N>1: slab-local IC(0) (scales; tolerance-only), exact coupling (the 1-GPU iterates; sweeps "
                          "serialize across GPUs) or independent replicas")
@@ -61,6 +61,9 @@ def parse_args():
     ap.add_argument("--no-p2p", action="store_true",
                     help="N>1: keep the per-iteration exchanges (3 scalar all-reduces, ghost rows) on the communicator instead of "
                          "the peer-to-peer mailboxes of csrc/comm_p2p.hip")
+    ap.add_argument("--grid-y-mult", type=int, default=0,
+                    help="diagnostics: run the N x (N*M) grid of an M-GPU weak-scaling job on the GPUs given (e.g. on one GPU: the "
+                         "single-GPU time of the 8-GPU job's grid)")
     ap.add_argument("--force-slab", action="store_true",
                     help="N=1 diagnostics: run the communicator code path with one rank (every exchange still goes through RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -172,7 +175,7 @@ def main():
     # N > 1 (weak scaling): the grid grows to N x (N * gpus) rows; the pressure solve is split into one
     # slab of N rows per GPU, the cheap stages run replicated (DESIGN.md "Multi-GPU")
     sharded = (world > 1 or args.force_slab) and args.slab != "replicas"
-    GX, GY = N, N * (world if sharded else 1)
+    GX, GY = N, N * (args.grid_y_mult if args.grid_y_mult > 0 else (world if sharded else 1))
     if world > 1:
         torch.cuda.set_device(local_rank)
     sim = ea.Simulation(GX, GY, device=local_rank, dot_mode=dot_mode, precond=precond)
@@ -186,10 +189,13 @@ def main():
         p2p_on = (not args.no_p2p) and attach_p2p(sim)
         if rank == 0 and not args.no_p2p and not p2p_on:
             print("bench: peer-to-peer mailboxes unavailable (%s); exchanges stay on %s" % (sim._p2p_error, args.comm), file=sys.stderr)
+    # weak scaling: the N x (N*M) grid holds M copies of the single-GPU picture on top of each other (closed tanks), so
+    # that every row slab does the work of the N = 1 job: same free-fall phase, same substeps, same iteration counts
+    tiles = GY // N
     if args.workload == "dam_break":
-        sim.load_text(scenarios.dam_break(), upscale=True)
+        sim.load_text(scenarios.stacked(scenarios.dam_break(), tiles), upscale=True)
     elif args.workload == "waterfall":
-        sim.load_text(scenarios.waterfall(), upscale=True)
+        sim.load_text(scenarios.stacked(scenarios.waterfall(), tiles), upscale=True)
     else:
         sim.load_half_tank()
 
@@ -258,7 +264,7 @@ def main():
     if comm is not None and comm.error:
         raise RuntimeError(comm.error)
     # sharded: ONE job of GX*GY cells; replicas / single GPU: one job of N*N cells per rank
-    job_rate = (GX * GY * args.steps / elapsed) if sharded else whole_job_rate(float(N * N), args.steps, elapsed, grp)
+    job_rate = (GX * GY * args.steps / elapsed) if sharded else whole_job_rate(float(GX * GY), args.steps, elapsed, grp)
     if rank != 0:
         grp.close()
         return
@@ -275,7 +281,7 @@ def main():
         achieved = ALGO_BYTES[dominant] * cells_launch / (ms / launches * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": pmc_traffic(N, args.workload, dominant) if not sharded else None,
+                "traffic": pmc_traffic(N, args.workload, dominant) if not sharded and GY == N else None,
                 "algorithmic_bytes_per_launch": ALGO_BYTES[dominant] * cells_launch,
                 "avg_launch_us": round(1e3 * ms / launches, 2), "launches": int(launches)}
     # whole PCG iteration: per-launch averages summed over the six kernel classes (dominant: timed region;
@@ -315,7 +321,8 @@ def main():
         "vs_baseline": None,
         "dtype": "f32 fields, f64 PCG (the reference's mix)",
         "data": "synthetic",
-        "config": {"workload": "%dx%d %s, %s" % (GX, GY, args.workload, "block layout upscaled" if args.workload == "dam_break" else "synthetic"),
+        "config": {"workload": "%dx%d %s, %s%s" % (GX, GY, args.workload, "block layout upscaled" if args.workload == "dam_break" else "synthetic",
+                                                   "" if tiles == 1 or args.workload == "half_tank" else ", %d tanks stacked (one per row slab)" % tiles),
                    "grid": [GX, GY], "preroll_frames": preroll, "precond": args.precond, "dot_mode": args.dot_mode,
                    "max_iterations": 100, "tol": 1e-6,
                    "parallelism": "1 GPU" if args.gpus == 1 and not sharded else (

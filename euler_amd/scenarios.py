@@ -55,5 +55,13 @@ def waterfall():
     return _text(g)
 
 
+def stacked(text, copies):
+    """`copies` pictures on top of each other (weak-scaling workloads: upscaled onto an X x (copies*Y) grid,
+    every row slab of a multi-GPU job gets one copy of the single-GPU scenario - closed tanks, walls in between)."""
+    if not text.endswith("\n"):
+        text += "\n"
+    return text * max(1, int(copies))
+
+
 def half_tank_note():
     return "config 3 (half-filled tank) is generated on the grid directly: euler_load_half_tank()"
