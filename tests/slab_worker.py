@@ -21,6 +21,8 @@ def build(X, Y, workload):
     sim = ea.Simulation(X, Y, dot_mode=ea.DOT_TREE)
     if workload == "half_tank":
         sim.load_half_tank()
+    elif workload.startswith("stacked_dam_break_"):      # bench.py's weak-scaling workload: one closed tank per row slab
+        sim.load_text(scenarios.stacked(scenarios.dam_break(), int(workload.rsplit("_", 1)[1])), upscale=True)
     else:
         sim.load_text(getattr(scenarios, workload)(), upscale=True)
     return sim

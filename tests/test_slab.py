@@ -130,3 +130,21 @@ def test_builtin_rccl_communicator(workload, X, Y, frames, p2p):
         assert abs(f["iters"][0] - f["iters"][1]) <= 1, f
         solved += f["iters"][1] > 0
     assert solved > 0
+
+
+@pytest.mark.gpu
+def test_weak_scaling_workload_local_coupling_is_the_reference_preconditioner():
+    """bench.py --gpus N stacks one closed dam-break tank per row slab; the slab cuts run through the solid walls
+    between the tanks, where IC(0) has no coupling to lose.  So EULER_SLAB_LOCAL (slabs sweep concurrently) produces
+    the 1-GPU iterates there: same tolerances as exact coupling, although no hand-off row is ever forwarded."""
+    d = run_workers(2, 256, 512, "stacked_dam_break_2", 30, 0, 29561, extra=("p2p",))
+    assert d["p2p_ok"] and d["ranks_agree"] and d["calls"]["chain"] == 0
+    solved = 0
+    for f in d["frames"]:
+        assert f["finite"] and f["cells_differing"] == 0 and f["markers_equal"], f
+        assert f["substeps"][0] == f["substeps"][1]
+        assert f["dp"] <= 1e-9 * max(f["pmax"], 1.0), f
+        assert f["du"] < 1e-6 and f["dv"] < 1e-6, f
+        assert abs(f["iters"][0] - f["iters"][1]) <= 1, f
+        solved += f["iters"][1] > 0
+    assert solved > 0
