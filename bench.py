@@ -283,6 +283,9 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": pmc_traffic(N, args.workload, dominant) if not sharded and GY == N else None,
                 "algorithmic_bytes_per_launch": ALGO_BYTES[dominant] * cells_launch,
+                "note": "algorithmic bytes count ALL X*Y cells of a launch (SURVEY 8d, like the reference's dense loops); the sweeps skip "
+                        "fluid-free blocks, so on sparse scenes the bytes really moved (traffic) are fewer and achieved can exceed what HBM delivered",
+                "fluid_fraction": round(float(st1.fluid_cells) / cells, 4),
                 "avg_launch_us": round(1e3 * ms / launches, 2), "launches": int(launches)}
     # whole PCG iteration: per-launch averages summed over the six kernel classes (dominant: timed region;
     # the others: second pass), against the 149 B per cell and iteration BASELINE.md prescribes
