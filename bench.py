@@ -131,7 +131,9 @@ def pmc_traffic(size, workload, kernel_class):
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this very command); None if there is none."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic_%d_%s.json" % (size, workload))
     try:
-        k = json.load(open(p))["kernels"].get(PMC_KERNEL.get(kernel_class, ""))
+        name = PMC_KERNEL.get(kernel_class, "")
+        kernels = json.load(open(p))["kernels"]
+        k = kernels.get(name) or kernels.get(name.replace(">", ", false>"))   # k_sweep_skew<OP, XG>: single-GPU build
         return int(k["hbm_bytes_per_launch"]) if k else None
     except (OSError, ValueError, KeyError):
         return None

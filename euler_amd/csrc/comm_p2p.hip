@@ -146,7 +146,23 @@ static int p2p_allgather(void* ctx, void* dev_base, const int64_t* off, const in
   return p->base.allgather(p->base.ctx, dev_base, off, cnt);
 }
 
-static size_t p2p_box_bytes(const euler_sim* S) { return P2P_HDR_BYTES + (size_t)2 * 2 * S->X * 16; }
+// mailbox: header | ghost rows [parity][side][X] granules | band hand-off rows [direction][epoch parity][gran_stride] granule pairs
+static size_t p2p_xgran_offset(const euler_sim* S, int backward, int parity) {
+  return P2P_HDR_BYTES + (size_t)2 * 2 * S->X * 16 + ((size_t)backward * 2 + parity) * S->gran_stride * 16;
+}
+static size_t p2p_box_bytes(const euler_sim* S) { return p2p_xgran_offset(S, 2, 0); }
+
+// Exact coupling: the forward / factor sweeps hand on upwards (rank -> rank + 1), the backward sweep downwards.  Rows
+// alternate with the sweep epoch: two sweeps of one direction in a row (factor, then forward) never share a row, and a
+// row comes round again only after a sweep of the other direction, which cannot finish on this rank before the
+// neighbour has finished reading (its own hand-off to us comes from the kernel behind that read).
+void eu_p2p_xgran(euler_sim* S, int backward, const unsigned long long** in, unsigned long long** out) {
+  P2PState* p = static_cast<P2PState*>(S->p2p);
+  const size_t off = p2p_xgran_offset(S, backward, (int)(S->epoch & 1u));
+  const int next = backward ? p->rank - 1 : p->rank + 1;
+  *in = reinterpret_cast<const unsigned long long*>(static_cast<char*>(p->box) + off);
+  *out = next >= 0 && next < p->n ? reinterpret_cast<unsigned long long*>(static_cast<char*>(p->peer[next]) + off) : nullptr;
+}
 
 void eu_p2p_release(euler_sim* S) {
   P2PState* p = static_cast<P2PState*>(S->p2p);

@@ -224,6 +224,8 @@ int eu_sync_marker_state(euler_sim* S);
 void eu_rccl_release(euler_sim* S);   // comm_rccl.hip
 void eu_p2p_release(euler_sim* S);    // comm_p2p.hip
 int eu_p2p_halo_skewed(euler_sim* S, double* s_skewed);   // ghost rows of a band-skewed vector, straight from / into the array
+// hand-off rows of the band pipeline across slabs (exact coupling): where this rank's first band reads, where its last band writes
+void eu_p2p_xgran(euler_sim* S, int backward, const unsigned long long** in, unsigned long long** out);
 int eu_install_comm(euler_sim* S, const euler_comm_ops* ops, int32_t coupling, int allow_single);
 
 // ------------------------------------------------------------------------------------------

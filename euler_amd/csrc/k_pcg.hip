@@ -420,6 +420,11 @@ struct SweepArgs {
                           // written by the factor sweep once per solve, read by the backward sweep (one load, not two)
   unsigned long long* granules;   // [nbands][gran_stride][2] tagged hand-off of a band's edge row
   int gran_stride;
+  // k_sweep_skew<OP, true> (exact coupling over the peer-to-peer mailboxes, comm_p2p.hip): the slab's first band takes
+  // its boundary row from the own mailbox (written by the previous slab's last band on ANOTHER GPU while both kernels
+  // run), the slab's last band announces into the next slab's mailbox; one row of gran_stride granule pairs each
+  const unsigned long long* xg_in;
+  unsigned long long* xg_out;
   const int4* ranges;     // per band: active block ranges {fwd B0, fwd B1, bwd B0, bwd B1} (k_band_ranges)
   int band_lo, nb_local;  // this rank's bands [band_lo, band_lo + nb_local)
   int couple;             // 1: the first/last local band is coupled to the neighbouring rank's band
@@ -555,7 +560,7 @@ __device__ __forceinline__ unsigned int lds_get(const unsigned int* p) { return 
 __device__ __forceinline__ void lds_put(unsigned int* p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #define SW_COMPILER_FENCE() asm volatile("" ::: "memory")
 
-template <int OP>
+template <int OP, bool XG = false>
 __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   __shared__ SweepShared sh;
   const int lane = threadIdx.x & 63;
@@ -581,6 +586,10 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   const bool publish = ord + 1 < a.nb_local || (a.couple && gord + 1 < nb);
   unsigned long long* gr_out = a.granules + (size_t)gord * a.gran_stride * 2;
   const unsigned long long* gr_in = a.granules + (size_t)(has_prev ? gord - 1 : 0) * a.gran_stride * 2;
+  if (XG) {   // the band pipeline continues across GPUs: same granules, same epochs, system-scope accesses (below)
+    if (ord + 1 == a.nb_local && gord + 1 < nb) gr_out = a.xg_out;
+    if (ord == 0 && gord > 0) gr_in = a.xg_in;
+  }
 
   // Active range (forward / backward solves only).  Outside the 32-step-aligned block range
   // [B0, B1) every cell of the band is non-fluid, so its results are constants that are already in
@@ -618,7 +627,8 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
       if (on && col >= 0 && col < X) {
         const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
         const u32x4 gq = {(unsigned int)bits, a.epoch, (unsigned int)(bits >> 32), a.epoch};
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(&gr_out[(size_t)col * 2]), "v"(gq) : "memory");
+        if (XG) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(&gr_out[(size_t)col * 2]), "v"(gq) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(&gr_out[(size_t)col * 2]), "v"(gq) : "memory");
       }
     };
     int next_pub = 0;                                   // groups announced so far (relative to B0)
@@ -669,7 +679,8 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
       const int blk = B0 + next_dep + t8, xl = SW_BLK * blk + k8;
       const bool want = t8 < q.n && blk >= win_lo && blk < win_hi && xl < X;
       const unsigned long long* p = &gr_in[want ? (size_t)xl * 2 : 0];
-      asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(q.gv) : "v"(p) : "memory");
+      if (XG) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(q.gv) : "v"(p) : "memory");
+      else asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(q.gv) : "v"(p) : "memory");
     };
     auto retire = [&](Poll& q) {                        // the oldest of the four polls in flight
       asm volatile("s_waitcnt vmcnt(3)" : "+v"(q.gv) :: "memory");
@@ -950,6 +961,7 @@ static SweepArgs make_sweep_args(euler_sim* S, int op, int force) {
   a.out = op == SW_FORWARD ? S->q : S->z;
   a.krku = reinterpret_cast<sw_d2*>(S->krku);
   a.granules = S->granules; a.gran_stride = S->gran_stride; a.ticket = S->ticket;
+  a.xg_in = nullptr; a.xg_out = nullptr;
   a.ranges = S->band_ranges;
   a.band_lo = S->band_lo; a.nb_local = S->band_hi - S->band_lo; a.couple = S->has_comm && S->couple;
   a.ticket_base = S->ticket_base; a.epoch = S->epoch;
@@ -1081,6 +1093,15 @@ static int launch_sweep(euler_sim* S, int cls, int force) {
     const int g_first = BWD ? nb - S->band_hi : S->band_lo, g_last = g_first + nbl - 1;
     const int r = S->comm.rank, prev_rank = BWD ? r + 1 : r - 1, next_rank = BWD ? r - 1 : r + 1;
     S->epoch += 1;
+    if (chain && S->p2p_on) {
+      // exact coupling over the mailboxes: all slabs launch at once and the band pipeline runs on across the GPUs -
+      // the previous slab's last band announces straight into this rank's mailbox while this kernel is running
+      SweepArgs a = make_sweep_args(S, OP, force);
+      eu_p2p_xgran(S, BWD ? 1 : 0, &a.xg_in, &a.xg_out);
+      LAUNCH(S, cls, (k_sweep_skew<OP, true>), dim3(nbl), dim3(192), a);
+      S->ticket_base += (unsigned)nbl;
+      return EULER_OK;
+    }
     if (chain && g_first > 0)   // the edge row of the band before mine arrives from the previous slab
       COMM_CALL(S->comm.chain(S->comm.ctx, S->granules + (size_t)(g_first - 1) * S->gran_stride * 2, row_bytes, prev_rank, r));
     SweepArgs a = make_sweep_args(S, OP, force);

@@ -47,6 +47,7 @@ def test_p2p_mailboxes_carry_the_iteration_exchanges(nproc, X, Y, workload, fram
     assert d["ranks_agree"]
     assert d["p2p_calls"]["allreduce"] > 0 and d["p2p_calls"]["halo"] > 0
     assert d["calls"]["allreduce"] == 0 and d["calls"]["halo"] == 0         # nothing per-iteration went through the host
+    assert d["calls"]["chain"] == 0       # exact coupling: the band pipeline runs on across the ranks through the mailboxes
     solved = 0
     for f in d["frames"]:
         assert f["finite"], f
