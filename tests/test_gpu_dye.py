@@ -33,7 +33,7 @@ def test_dye_free_running_bit_exact_vs_reference(scn):
         assert got == [int(h) for h in g["hashes"][f]], (scn, f)
 
 
-@pytest.mark.parametrize("X_,Y_,workload,frames", [(200, 150, "waterfall", 40), (320, 192, "dam_break", 45)])
+@pytest.mark.parametrize("X_,Y_,workload,frames", [(200, 150, "waterfall", 40), (256, 160, "dam_break", 30)])
 def test_dye_vs_oracle_on_larger_grids(X_, Y_, workload, frames):
     text = getattr(scenarios, workload)()
     o = Oracle(X_, Y_, rainbow=True).load_text(text, upscale=True)
