@@ -58,6 +58,9 @@ def parse_args():
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
                     help="N>1 exchange transport: the library's own RCCL communicator (C, no host code between kernels) "
                          "or the torch.distributed callbacks of euler_amd/slab.py")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1: weak = N x (N*gpus) grid, one tank per row slab (default; the driver's scaling run); strong = the "
+                         "N x N grid of --size split into row slabs (BASELINE configs[3]: --size 16384 --scaling strong)")
     ap.add_argument("--no-p2p", action="store_true",
                     help="N>1: keep the per-iteration exchanges (3 scalar all-reduces, ghost rows) on the communicator instead of "
                          "the peer-to-peer mailboxes of csrc/comm_p2p.hip")
@@ -177,7 +180,7 @@ def main():
     # N > 1 (weak scaling): the grid grows to N x (N * gpus) rows; the pressure solve is split into one
     # slab of N rows per GPU, the cheap stages run replicated (DESIGN.md "Multi-GPU")
     sharded = (world > 1 or args.force_slab) and args.slab != "replicas"
-    GX, GY = N, N * (args.grid_y_mult if args.grid_y_mult > 0 else (world if sharded else 1))
+    GX, GY = N, N * (args.grid_y_mult if args.grid_y_mult > 0 else (world if sharded and args.scaling == "weak" else 1))
     if world > 1:
         torch.cuda.set_device(local_rank)
     sim = ea.Simulation(GX, GY, device=local_rank, dot_mode=dot_mode, precond=precond)
@@ -322,7 +325,7 @@ def main():
         "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling if sharded else "weak",
         "vs_baseline": None,
         "dtype": "f32 fields, f64 PCG (the reference's mix)",
         "data": "synthetic",
@@ -333,7 +336,7 @@ def main():
                    "parallelism": "1 GPU" if args.gpus == 1 and not sharded else (
                        "%d independent replicas" % args.gpus if not sharded else
                        "%d row slabs of %d rows: distributed PCG (%s IC(0) coupling, exchanges by %s), replicated marker/advection stages; grid %dx%d"
-                       % (args.gpus, N, args.slab,
+                       % (args.gpus, GY // max(world, 1), args.slab,
                           ("peer-to-peer mailboxes (scalars, ghost rows) + " if p2p_on else "")
                           + ("RCCL from the C library" if args.comm == "rccl" else "torch.distributed callbacks"), GX, GY))},
         "substeps": int(substeps), "pcg_iterations": int(iters),
