@@ -35,7 +35,8 @@ def run_workers(nproc, X, Y, workload, frames, coupling, port, extra=()):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nproc,X,Y,workload,frames,coupling", [(2, 192, 256, "half_tank", 3, 1), (3, 200, 330, "waterfall", 12, 1), (4, 256, 512, "dam_break", 30, 0)])
+@pytest.mark.parametrize("nproc,X,Y,workload,frames,coupling", [(2, 192, 256, "half_tank", 3, 1), (3, 200, 330, "waterfall", 12, 1), (2, 256, 256, "dam_break", 30, 1),
+                                                               (4, 256, 512, "dam_break", 30, 0)])
 def test_p2p_mailboxes_carry_the_iteration_exchanges(nproc, X, Y, workload, frames, coupling):
     """csrc/comm_p2p.hip: the three scalar all-reduces and the ghost-row exchange of every PCG iteration as
     direct writes into the peers' IPC-mapped mailboxes (here: 2-4 processes sharing the box's one GPU; on a node
