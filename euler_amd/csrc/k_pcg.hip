@@ -537,9 +537,6 @@ __global__ __launch_bounds__(1024) void k_sweep_simple(SweepArgs a) {
 #define SW_TRACE_HANDOFF 0   // development build: time stamps of one hand-off (column block 40) in the timeline words 4..7
 #endif
 #define SW_TRACE_CB 40
-#ifndef SW_SCALAR_POLL
-#define SW_SCALAR_POLL 1     // single-GPU build: the fetch wave polls through the scalar memory path (see role 2)
-#endif
 #define DPP_WAVE_SHL1 0x130
 #define DPP_WAVE_SHR1 0x138
 
@@ -664,83 +661,6 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   }
   if (role == 2) {
     if (!has_prev) return;
-#if SW_SCALAR_POLL
-    if constexpr (!XG) {
-      // Polls go through the SCALAR memory path (s_load ... glc: past the scalar cache, coherent with the write-through
-      // granule stores on any XCD).  The CU's vector-memory queue is full of the compute wave's prefetches, and a vector
-      // poll returns behind them (~1 us in this kernel); a scalar poll has its own queue and takes ~0.45 us whatever the
-      // streams do (tools/micro/poll_bench).  One round = the granules of up to two blocks (2 x 128 B, 64 SGPRs): scalar
-      // loads return out of order, so a round is retired as a whole (lgkmcnt(0)).
-      typedef unsigned int s16 __attribute__((ext_vector_type(16)));
-      int next_dep = 0;
-      unsigned int spins = 0;
-      const unsigned int ep = a.epoch;
-      while (next_dep < NBLK) {
-        const int cdone = (int)lds_get(&sh.comp_done);
-        SW_COMPILER_FENCE();
-        int n = cdone + SW_BND_RING - 2 - next_dep;               // ring slots the compute wave is done with
-        n = n < NBLK - next_dep ? n : NBLK - next_dep;
-        n = n < 2 ? n : 2;
-        if (n <= 0) {
-          if (lds_get(&sh.abort)) break;
-          if (++spins > SW_SPIN_LIMIT) { if (lane == 0) atomicExch(a.error, 2); lds_put(&sh.abort, 1u); break; }
-          __builtin_amdgcn_s_sleep(1);
-          continue;
-        }
-        const int blk0 = B0 + next_dep, blk1 = blk0 + 1;
-        const bool want0 = blk0 >= win_lo && blk0 < win_hi, want1 = n > 1 && blk1 >= win_lo && blk1 < win_hi;
-        // wave-uniform addresses in SGPRs (128 B per block; an unwanted block re-reads block 0 of the row: in bounds, ignored)
-        const unsigned long long p0 = (unsigned long long)(gr_in + (size_t)(want0 ? SW_BLK * blk0 : 0) * 2);
-        const unsigned long long p1 = (unsigned long long)(gr_in + (size_t)(want1 ? SW_BLK * blk1 : 0) * 2);
-        const unsigned long long s0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned int)(p0 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned int)p0);
-        const unsigned long long s1 = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned int)(p1 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned int)p1);
-        s16 a0, a1, b0, b1;
-        asm volatile("s_load_dwordx16 %0, %4, 0x0 glc\n\ts_load_dwordx16 %1, %4, 0x40 glc\n\t"
-                     "s_load_dwordx16 %2, %5, 0x0 glc\n\ts_load_dwordx16 %3, %5, 0x40 glc\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(a0), "=&s"(a1), "=&s"(b0), "=&s"(b1) : "s"(s0), "s"(s1) : "memory");
-        // a granule = {lo32, tag, hi32, tag}; columns past the row's end are never announced and count as CONST
-        auto ready = [&](const s16& lo4, const s16& hi4, int blk, bool want) -> bool {
-          if (!want) return true;
-          bool ok = true;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            if (SW_BLK * blk + k < X) ok = ok && lo4[4 * k + 1] == ep && lo4[4 * k + 3] == ep;
-            if (SW_BLK * blk + 4 + k < X) ok = ok && hi4[4 * k + 1] == ep && hi4[4 * k + 3] == ep;
-          }
-          return ok;
-        };
-        const bool r0 = ready(a0, a1, blk0, want0), r1 = r0 && n > 1 && ready(b0, b1, blk1, want1);
-        auto deposit = [&](const s16& lo4, const s16& hi4, int blk, bool want, int rel) {
-          if (lane < SW_BLK) {
-            unsigned int vlo = lo4[0], vhi = lo4[2];
-            if (lane == 1) { vlo = lo4[4]; vhi = lo4[6]; }
-            if (lane == 2) { vlo = lo4[8]; vhi = lo4[10]; }
-            if (lane == 3) { vlo = lo4[12]; vhi = lo4[14]; }
-            if (lane == 4) { vlo = hi4[0]; vhi = hi4[2]; }
-            if (lane == 5) { vlo = hi4[4]; vhi = hi4[6]; }
-            if (lane == 6) { vlo = hi4[8]; vhi = hi4[10]; }
-            if (lane == 7) { vlo = hi4[12]; vhi = hi4[14]; }
-            const bool live = want && SW_BLK * blk + lane < X;
-            sh.bnd[rel & (SW_BND_RING - 1)][lane] = live ? __hiloint2double((int)vhi, (int)vlo) : CONST;
-          }
-        };
-        if (r0) {
-          deposit(a0, a1, blk0, want0, next_dep);
-          if (r1) deposit(b0, b1, blk1, want1, next_dep + 1);
-          SW_COMPILER_FENCE();
-          if (SW_TRACE_HANDOFF && lane == 0 && SW_TRACE_CB - B0 >= next_dep && SW_TRACE_CB - B0 < next_dep + (r1 ? 2 : 1))
-            a.timeline[(size_t)ord * 8 + 6] = wall_clock64();
-          next_dep += r1 ? 2 : 1;
-          lds_put(&sh.dep_done, (unsigned int)next_dep);
-          spins = 0;
-        } else {
-          if (lds_get(&sh.abort)) break;
-          if (++spins > SW_SPIN_LIMIT) { if (lane == 0) atomicExch(a.error, 2); lds_put(&sh.abort, 1u); break; }
-        }
-      }
-      return;
-    }
-#endif
     // Four polls are kept in flight (re-issued as they are retired, so they space themselves a quarter
     // of a round trip apart): a granule is then seen about half a round trip after it lands instead
     // of one and a half.  Each poll covers up to 8 blocks from the deposit front at its issue; every
