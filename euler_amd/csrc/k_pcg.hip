@@ -527,6 +527,13 @@ __global__ __launch_bounds__(1024) void k_sweep_simple(SweepArgs a) {
 // a fourth wave touching the coming records' cache lines 10 blocks ahead (L2 prefetch: no gain forward,
 // 1.2x slower backward - the touches cross the same per-CU memory path), and padding the band stride
 // against HBM channel aliasing (no effect).
+// Measured and rejected (round 1, last experiment): polling through the SCALAR memory path.  tools/micro/poll_bench: one hop
+// costs 480-640 ns with vector sc1 polls (more behind this kernel's deep prefetch queue: ~1.1 us), 450 ns with
+// `s_load_dwordx4 glc` polls whatever the CU's vector traffic does, same- or cross-XCD (sc1 stores; sc0 loads and plain
+// cross-XCD stores read stale).  But a scalar round trip carries at most ~256 B (64 SGPRs) = the granules of two blocks and
+// must be retired whole (out-of-order returns): a single scalar poller delivered a block every ~400 ns, the compute wave
+// needs one every 210-300 ns, and the sweeps ran 1.6x slower (72 -> 123 us).  What is left to try: two scalar pollers on
+// alternate blocks (a fourth wave), or tag-free compact rows behind a drained progress word.
 // Records t >= T of a band and the 32 records in front of each array are dead padding (mask 0):
 // the loop runs whole groups of 3 blocks and prefetches unconditionally.
 #define SW_BLK 8
