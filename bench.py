@@ -188,7 +188,17 @@ def main():
     p2p_on = False
     if sharded:
         from euler_amd.slab import SLAB_EXACT, SLAB_LOCAL, RcclComm, TorchComm, attach_p2p
-        comm = (RcclComm if args.comm == "rccl" else TorchComm)(sim, SLAB_EXACT if args.slab == "exact" else SLAB_LOCAL)
+        coupling = SLAB_EXACT if args.slab == "exact" else SLAB_LOCAL
+        if args.comm == "rccl":
+            from euler_amd.slab import RcclUnavailable
+            try:
+                comm = RcclComm(sim, coupling)
+            except RcclUnavailable as e:          # raised on every rank alike: the job goes on over torch.distributed, and says so
+                if rank == 0:
+                    print("bench: %s; exchanges fall back to torch.distributed callbacks" % e, file=sys.stderr)
+                args.comm = "torch"
+        if args.comm == "torch":
+            comm = TorchComm(sim, coupling)
         # the latency-bound exchanges of every PCG iteration go peer to peer (xGMI); if the mailboxes cannot be set up
         # on every rank the job stays on the communicator, and the JSON line says which one ran
         p2p_on = (not args.no_p2p) and attach_p2p(sim)

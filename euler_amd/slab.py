@@ -147,9 +147,16 @@ class TorchComm:
         return self._guard("allgather", run)
 
 
+class RcclUnavailable(RuntimeError):
+    pass
+
+
 class RcclComm:
     """The library's own RCCL communicator (csrc/comm_rccl.hip): no Python between the kernels of a
-    PCG iteration.  torch.distributed is used once, to hand rank 0's ncclUniqueId to every rank."""
+    PCG iteration.  torch.distributed is used once, to hand rank 0's ncclUniqueId to every rank.
+    Construction is collective and fails collectively: if RCCL cannot be bound on rank 0, or
+    ncclCommInitRank fails on any rank, every rank raises RcclUnavailable (and the handle is left without a
+    communicator), so that the caller can fall back on all ranks alike."""
 
     ID_BYTES = 128
 
@@ -160,18 +167,25 @@ class RcclComm:
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.error = None
         L = sim.L
-        buf = (C.c_ubyte * self.ID_BYTES)()
-        if self.rank == 0:
-            rc = L.euler_rccl_unique_id(buf, self.ID_BYTES)
-            if rc:
-                raise RuntimeError("euler_rccl_unique_id failed: %s" % L.euler_last_error().decode())
         dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        t = torch.tensor(list(bytes(buf)), dtype=torch.uint8, device=dev)
+        buf = (C.c_ubyte * self.ID_BYTES)()
+        status, why = 0, ""
+        if self.rank == 0:
+            status = L.euler_rccl_unique_id(buf, self.ID_BYTES)
+            why = L.euler_last_error().decode() if status else ""
+        t = torch.tensor(list(bytes(buf)) + [1 if status else 0], dtype=torch.uint8, device=dev)
         dist.broadcast(t, src=0)
-        ident = bytes(t.cpu().tolist())
+        t = t.cpu()
+        if int(t[-1]):
+            raise RcclUnavailable("euler_rccl_unique_id failed on rank 0: %s" % (why or "see rank 0"))
+        ident = bytes(t[:-1].tolist())
         rc = L.euler_set_comm_rccl(sim.h, ident, len(ident), self.rank, self.world, coupling)
-        if rc:
-            raise RuntimeError("euler_set_comm_rccl failed: %s" % L.euler_last_error().decode())
+        why = L.euler_last_error().decode() if rc else ""
+        ok = torch.tensor([0 if rc else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            L.euler_set_comm(sim.h, None, 0)      # drop whatever was installed
+            raise RcclUnavailable("euler_set_comm_rccl failed: %s" % (why or "on another rank"))
         lo, hi, nb = C.c_int32(), C.c_int32(), C.c_int32()
         L.euler_slab_info(sim.h, C.byref(lo), C.byref(hi), C.byref(nb))
         self.band_lo, self.band_hi, self.nbands = lo.value, hi.value, nb.value
