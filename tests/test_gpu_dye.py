@@ -116,3 +116,62 @@ def test_cli_keys_pause_gate_and_quit(tmp_path):
     assert frames[5] == f1                                   # '.': still paused
     assert frames[6] != f1                                   # 'p': resumed, third step taken
     assert "frames 3 " in err
+
+
+def test_cli_interactive_loop_on_a_pty(tmp_path):
+    """The reference's terminal loop (main.c:1016-1042, misc/terminal.c) for real: `euler --rainbow` on a
+    pseudo-terminal - window size from TIOCGWINSZ, raw mode, frames drawn with reposition / hide-cursor codes at
+    10 Hz, the keys p (pause), f (one frame), r (recolour), q (quit: screen cleared, cursor shown, exit 0)."""
+    import fcntl
+    import os
+    import pty
+    import select
+    import struct
+    import subprocess
+    import termios
+    import time
+    scn = tmp_path / "waterfall.txt"
+    scn.write_text(scenario_text(load("waterfall_frames.npz")))
+    exe = os.path.join(os.path.dirname(ea.LIB_PATH), "..", "bin", "euler")
+    master, slave = pty.openpty()
+    fcntl.ioctl(slave, termios.TIOCSWINSZ, struct.pack("HHHH", 30, 90, 0, 0))     # 30 rows x 90 columns
+    p = subprocess.Popen([exe, "--rainbow", str(scn)], stdin=slave, stdout=slave, stderr=subprocess.PIPE, close_fds=True)
+    os.close(slave)
+    out = b""
+
+    def pump(seconds):
+        nonlocal out
+        end = time.time() + seconds
+        while time.time() < end:
+            r, _, _ = select.select([master], [], [], 0.05)
+            if r:
+                try:
+                    out += os.read(master, 1 << 16)
+                except OSError:
+                    return
+
+    try:
+        pump(1.5)                      # a dozen frames
+        n_running = out.count(b"\x1b[H")
+        os.write(master, b"p")
+        pump(0.6)
+        os.write(master, b"f")
+        pump(0.4)
+        os.write(master, b"r")
+        pump(0.4)
+        os.write(master, b"q")
+        p.wait(timeout=20)
+    finally:
+        if p.poll() is None:
+            p.kill()
+        pump(0.2)
+        os.close(master)
+    err = p.stderr.read().decode()
+    assert p.returncode == 0, err
+    assert n_running >= 5                                   # frames were being drawn at ~10 Hz
+    assert b"\x1b[?25l" in out and b"\x1b[38;2;" in out     # cursor hidden, 24-bit colour escapes of the dye
+    assert out.rstrip().endswith(b"\x1b[?25h")              # quit: cursor shown again (after the final clear)
+    frames = int(err.split("frames ")[1].split()[0])
+    assert 5 <= frames < 60                                 # paused for a while: far fewer frames than wall time x 10 Hz would give
+    rows = [l for l in out.split(b"\x1b[H")[2].split(b"\r\n")]
+    assert len(rows) == 30 - 0 or len(rows) <= 38           # the window height bounds the rows drawn (Y - 2 = 38 at most)
