@@ -133,7 +133,10 @@ def test_cli_interactive_loop_on_a_pty(tmp_path):
     scn = tmp_path / "waterfall.txt"
     scn.write_text(scenario_text(load("waterfall_frames.npz")))
     exe = os.path.join(os.path.dirname(ea.LIB_PATH), "..", "bin", "euler")
-    master, slave = pty.openpty()
+    try:
+        master, slave = pty.openpty()
+    except OSError as e:                     # containers without /dev/ptmx: the key handler and the gate are covered by --keys above
+        pytest.skip("no pseudo-terminal available: %s" % e)
     fcntl.ioctl(slave, termios.TIOCSWINSZ, struct.pack("HHHH", 30, 90, 0, 0))     # 30 rows x 90 columns
     p = subprocess.Popen([exe, "--rainbow", str(scn)], stdin=slave, stdout=slave, stderr=subprocess.PIPE, close_fds=True)
     os.close(slave)
