@@ -62,9 +62,13 @@ def test_reference_names_drive_the_gpu(tmp_path, scn, rainbow):
     wx, wy = C.c_int.in_dll(L, "g_wx"), C.c_int.in_dll(L, "g_wy")
     wx.value, wy.value = 98, 38
     C.c_bool.in_dll(L, "g_rainbow_enabled").value = rainbow         # main() sets it before sim_init (main.c:1020)
+    # the library's state is process-global like the reference's (one dlopen per process): start from main()'s initial values
+    C.c_uint16.in_dll(L, "g_frame_count").value = 0
+    C.c_bool.in_dll(L, "g_pause").value = False
+    C.c_uint32.in_dll(L, "g_temp_unpause_counter").value = 0
     L.sim_init.argtypes = [ArgsT]
     L.euler_compat_handle.restype = C.c_void_p
-    L.sim_init(ArgsT(str(path).encode(), rainbow))
+    L.sim_init(ArgsT(str(path).encode(), rainbow))                   # a second sim_init replaces the handle
     assert L.euler_compat_handle()                                   # the three names sit on a libeuler_hip handle
 
     def frame():
