@@ -286,6 +286,10 @@ def main():
 
     roof = None
     kern = {}
+    try:      # the ceiling a plain device-to-device copy reaches on this very GPU (read + write), next to the 8 TB/s spec peak
+        copy_gbps = round(sim.copy_bandwidth(1 << 30, 10), 1)
+    except Exception:
+        copy_gbps = None
     for name, (ms, launches) in prof.items():
         entry = {"ms_total": round(ms, 3), "launches": int(launches), "avg_us": round(1e3 * ms / launches, 2)}
         if name in ALGO_BYTES:
@@ -296,6 +300,7 @@ def main():
         achieved = ALGO_BYTES[dominant] * cells_launch / (ms / launches * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                "measured_copy_GBps": copy_gbps,
                 "traffic": pmc_traffic(N, args.workload, dominant) if not sharded and GY == N else None,
                 "algorithmic_bytes_per_launch": ALGO_BYTES[dominant] * cells_launch,
                 "note": "algorithmic bytes count ALL X*Y cells of a launch (SURVEY 8d, like the reference's dense loops); the sweeps skip "
