@@ -121,6 +121,19 @@ def cpu_baseline(sim, ea, steps_budget_s=12.0):
         if name == "strict":
             res["_oracle_after"] = (o.u.copy(), o.v.copy(), (o.count > 0).copy(), nsteps)
         o.close()
+    # BASELINE configs[0]: the reference's own grid and scenario (block layout, 100 x 40, 100 frames), the oracle only
+    try:
+        from euler_amd import scenarios as _sc
+        o = oracle_lib.Oracle(100, 40, lib_path=libs["reference_flags"]).load_text(_sc.dam_break())
+        t0 = time.perf_counter()
+        for _ in range(100):
+            o.step()
+        dt = time.perf_counter() - t0
+        res["_native"] = dict(value=4000 * 100 / dt, seconds=round(dt, 3), steps=100, substeps=int(o.c.total_substeps),
+                              pcg_iterations=int(o.c.total_pcg_iterations))
+        o.close()
+    except Exception as e:      # never let the extra figure break the bench line
+        res["_native"] = {"error": str(e)}
     return res
 
 
@@ -331,6 +344,7 @@ def main():
                              "oracle/euler_oracle.c built -O3 -ffast-math -march=native (the reference's CMake flags), single thread"
                              % (ref["steps"], ref["substeps"], ref["pcg_iterations"], N, N, args.workload),
                    "strict_ieee_value": round(cpu["strict"]["value"], 1), "cpu_model": cpu_model(),
+                   "configs0_100x40_block_100_steps": cpu.get("_native"),
                    "host_cores_available": os.cpu_count()}
 
     out = {
