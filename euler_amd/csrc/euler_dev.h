@@ -302,7 +302,7 @@ __device__ __forceinline__ float eu_wave_maxf(float v) {
 // ---- peer-to-peer mailboxes (comm_p2p.hip): self-validating 16-byte granules {lo32, tag, hi32, tag}, one
 // system-scope write-through store / system-scope load each - the band pipeline's hand-off form across GPUs
 #define P2P_MAXR 16
-#define P2P_SPIN_LIMIT (1u << 23)   // x ~2 us per poll: a peer may lag by seconds, not for ever
+#define P2P_SPIN_LIMIT (1u << 25)   // x ~1.5 us per poll: a peer may lag by many seconds (start-up skew of a job), not for ever
 #define P2P_HDR_BYTES 4096
 typedef unsigned int p2p_u32x4 __attribute__((ext_vector_type(4)));
 struct P2PBoxHeader {
