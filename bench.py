@@ -311,10 +311,15 @@ def main():
     if dominant in prof:
         ms, launches = prof[dominant]
         achieved = ALGO_BYTES[dominant] * cells_launch / (ms / launches * 1e-3) / 1e9
+        traffic = pmc_traffic(N, args.workload, dominant) if not sharded and GY == N else None
         roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "measured_copy_GBps": copy_gbps,
-                "traffic": pmc_traffic(N, args.workload, dominant) if not sharded and GY == N else None,
+                "traffic": traffic,
+                # the HBM bytes rocprofv3 counted for this kernel (committed PMC passes of this very command) over the launch time
+                # measured here: what the memory system really delivered, next to the algorithmic figure above
+                "achieved_traffic": round(traffic / (ms / launches * 1e-3) / 1e9, 2) if traffic else None,
+                "frac_traffic": round(traffic / (ms / launches * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if traffic else None,
                 "algorithmic_bytes_per_launch": ALGO_BYTES[dominant] * cells_launch,
                 "note": "algorithmic bytes count ALL X*Y cells of a launch (SURVEY 8d, like the reference's dense loops); the sweeps skip "
                         "fluid-free blocks, so on sparse scenes the bytes really moved (traffic) are fewer and achieved can exceed what HBM delivered",
