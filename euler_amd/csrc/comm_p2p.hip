@@ -213,12 +213,13 @@ extern "C" int euler_p2p_connect(euler_sim* S, const void* handles, int32_t nran
   const hipIpcMemHandle_t* hs = static_cast<const hipIpcMemHandle_t*>(handles);
   for (int k = 0; k < nranks; ++k) {
     if (k == p->rank) { p->peer[k] = p->box; continue; }
+    if (p->peer[k]) { (void)hipIpcCloseMemHandle(p->peer[k]); p->peer[k] = nullptr; }   // a retry maps afresh
     hipIpcMemHandle_t h;
     memcpy(&h, &hs[k], sizeof h);
     hipError_t e = hipIpcOpenMemHandle(&p->peer[k], h, hipIpcMemLazyEnablePeerAccess);
     if (e != hipSuccess) { p->peer[k] = nullptr; return eu_hip_fail(e, "hipIpcOpenMemHandle(peer mailbox)", __FILE__, __LINE__); }
   }
-  HIPCHK(hipMalloc((void**)&p->peer_dev, sizeof(void*) * P2P_MAXR));
+  if (!p->peer_dev) HIPCHK(hipMalloc((void**)&p->peer_dev, sizeof(void*) * P2P_MAXR));   // (a failed earlier attempt may have left one)
   HIPCHK(hipMemcpy(p->peer_dev, p->peer, sizeof(void*) * P2P_MAXR, hipMemcpyHostToDevice));
   // the link lives in the device-resident PCG scalars (k_pcg_reset never touches these fields)
   struct { void** boxes; int* error; int rank, n; unsigned int seq, hseq; } link = {p->peer_dev, &S->ms->error, p->rank, p->n, 0u, 0u};
