@@ -150,3 +150,29 @@ def test_weak_scaling_workload_local_coupling_is_the_reference_preconditioner():
         assert abs(f["iters"][0] - f["iters"][1]) <= 1, f
         solved += f["iters"][1] > 0
     assert solved > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_multi_rank_contract(scaling):
+    """bench.py's N > 1 path end to end as the driver launches it (torch.distributed.run, one process per rank) - here two
+    gloo ranks sharing the box's GPU, exchanges over the mailboxes + torch callbacks: ONE JSON line on stdout (rank 0),
+    the contract's keys, whole-job value, the transports named, the workload of the chosen scaling."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", EULER_DIST_BACKEND="gloo", EULER_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "256",
+           "--comm", "torch", "--scaling", scaling, "--max-preroll", "60"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines                      # nothing but the JSON line reaches stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == scaling and d["value"] > 0 and d["higher_is_better"] is True
+    assert d["cpu_baseline"] is None and d["vs_baseline"] is None          # the CPU leg runs at N = 1 only
+    assert d["config"]["grid"] == ([256, 512] if scaling == "weak" else [256, 256])
+    assert "peer-to-peer mailboxes" in d["config"]["parallelism"] and "2 row slabs" in d["config"]["parallelism"]
+    assert abs(d["value"] - d["config"]["grid"][0] * d["config"]["grid"][1] * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0
