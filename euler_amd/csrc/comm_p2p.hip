@@ -36,7 +36,16 @@ struct P2PState {
   int rank, n, X;
   euler_comm_ops base;                // the communicator underneath (bulk transfers)
   uint64_t calls[2];
+  // the neighbouring slabs' z and search-direction arrays (k_search_apply reads across the slab boundary): [0] = rank-1,
+  // [1] = rank+1; sa / sb = the peer's arrays that were S->s / S->s2 at export time (the two swap roles every iteration,
+  // on every rank alike)
+  double *nb_z[2], *nb_sa[2], *nb_sb[2];
+  void* nb_base[2][3];                // the mapped allocations (to close)
+  double* orig_s;                     // this rank's S->s at export time
+  int have_arrays;
 };
+
+#define P2P_NHANDLES 4                 // mailbox, z, s, s2
 
 // stand-alone in-place all-reduce of one double (the all_zero(r) flag, euler_comm_ops.allreduce, the self-test);
 // the reductions of the PCG loop do the same inside their own last block (k_pcg.hip block_finish)
@@ -170,6 +179,9 @@ void eu_p2p_release(euler_sim* S) {
   if (S->stream) (void)hipStreamSynchronize(S->stream);
   for (int k = 0; k < p->n; ++k)
     if (p->peer[k] && p->peer[k] != p->box) (void)hipIpcCloseMemHandle(p->peer[k]);
+  for (int side = 0; side < 2; ++side)
+    for (int a = 0; a < 3; ++a)
+      if (p->nb_base[side][a]) (void)hipIpcCloseMemHandle(p->nb_base[side][a]);
   if (p->peer_dev) (void)hipFree(p->peer_dev);
   if (p->box) (void)hipFree(p->box);
   if (S->has_comm && S->comm.ctx == S && p->base.allreduce) S->comm = p->base;   // back to the communicator underneath
@@ -180,7 +192,7 @@ void eu_p2p_release(euler_sim* S) {
 
 // Step 1 (every rank): allocate the mailbox, hand out its IPC handle (EULER_P2P_HANDLE_BYTES bytes).
 extern "C" int euler_p2p_export(euler_sim* S, void* handle_out, int32_t cap) {
-  if (!S || !handle_out || cap < (int32_t)sizeof(hipIpcMemHandle_t)) { eu_set_error("euler_p2p_export: need %d bytes", (int)sizeof(hipIpcMemHandle_t)); return EULER_EINVAL; }
+  if (!S || !handle_out || cap < (int32_t)(P2P_NHANDLES * sizeof(hipIpcMemHandle_t))) { eu_set_error("euler_p2p_export: need %d bytes", (int)(P2P_NHANDLES * sizeof(hipIpcMemHandle_t))); return EULER_EINVAL; }
   HIPCHK(hipSetDevice(S->cfg.device));
   P2PState* p = static_cast<P2PState*>(S->p2p);
   if (!p) {
@@ -194,9 +206,14 @@ extern "C" int euler_p2p_export(euler_sim* S, void* handle_out, int32_t cap) {
     if (e != hipSuccess) { (void)hipFree(p->box); free(p); return eu_hip_fail(e, "hipMemset(mailbox)", __FILE__, __LINE__); }
     S->p2p = p;
   }
-  hipIpcMemHandle_t h;
-  HIPCHK(hipIpcGetMemHandle(&h, p->box));
-  memcpy(handle_out, &h, sizeof h);
+  hipIpcMemHandle_t h[P2P_NHANDLES];
+  HIPCHK(hipIpcGetMemHandle(&h[0], p->box));
+  // the solver arrays start EU_SKEW_SLACK elements into their allocations (driver.hip)
+  HIPCHK(hipIpcGetMemHandle(&h[1], S->z - EU_SKEW_SLACK));
+  HIPCHK(hipIpcGetMemHandle(&h[2], S->s - EU_SKEW_SLACK));
+  HIPCHK(hipIpcGetMemHandle(&h[3], S->s2 - EU_SKEW_SLACK));
+  p->orig_s = S->s;
+  memcpy(handle_out, h, sizeof h);
   return EULER_OK;
 }
 
@@ -210,12 +227,12 @@ extern "C" int euler_p2p_connect(euler_sim* S, const void* handles, int32_t nran
   if (nranks > P2P_MAXR) { eu_set_error("euler_p2p_connect: at most %d ranks", P2P_MAXR); return EULER_EINVAL; }
   HIPCHK(hipSetDevice(S->cfg.device));
   p->rank = S->comm.rank; p->n = nranks;
-  const hipIpcMemHandle_t* hs = static_cast<const hipIpcMemHandle_t*>(handles);
+  const hipIpcMemHandle_t* hs = static_cast<const hipIpcMemHandle_t*>(handles);   // P2P_NHANDLES per rank
   for (int k = 0; k < nranks; ++k) {
     if (k == p->rank) { p->peer[k] = p->box; continue; }
     if (p->peer[k]) { (void)hipIpcCloseMemHandle(p->peer[k]); p->peer[k] = nullptr; }   // a retry maps afresh
     hipIpcMemHandle_t h;
-    memcpy(&h, &hs[k], sizeof h);
+    memcpy(&h, &hs[(size_t)k * P2P_NHANDLES], sizeof h);
     hipError_t e = hipIpcOpenMemHandle(&p->peer[k], h, hipIpcMemLazyEnablePeerAccess);
     if (e != hipSuccess) { p->peer[k] = nullptr; return eu_hip_fail(e, "hipIpcOpenMemHandle(peer mailbox)", __FILE__, __LINE__); }
   }
@@ -246,6 +263,21 @@ extern "C" int euler_p2p_connect(euler_sim* S, const void* handles, int32_t nran
     eu_set_error("euler_p2p_connect: self-test all-reduce returned %g / %g, expected %g / %g", got[0], got[1], 0.5 * nranks * (nranks + 1), (double)nranks);
     return EULER_ECOMM;
   }
+  // the neighbouring slabs' z / s / s2 (fused search + apply_a across the slab boundary); failing here only costs the fusion
+  p->have_arrays = 1;
+  for (int side = 0; side < 2; ++side) {
+    const int nb = side == 0 ? p->rank - 1 : p->rank + 1;
+    if (nb < 0 || nb >= nranks) continue;
+    for (int a = 0; a < 3; ++a) {
+      if (p->nb_base[side][a]) { (void)hipIpcCloseMemHandle(p->nb_base[side][a]); p->nb_base[side][a] = nullptr; }
+      hipIpcMemHandle_t h;
+      memcpy(&h, &hs[(size_t)nb * P2P_NHANDLES + 1 + a], sizeof h);
+      if (hipIpcOpenMemHandle(&p->nb_base[side][a], h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { p->nb_base[side][a] = nullptr; p->have_arrays = 0; }
+    }
+    p->nb_z[side] = p->nb_base[side][0] ? static_cast<double*>(p->nb_base[side][0]) + EU_SKEW_SLACK : nullptr;
+    p->nb_sa[side] = p->nb_base[side][1] ? static_cast<double*>(p->nb_base[side][1]) + EU_SKEW_SLACK : nullptr;
+    p->nb_sb[side] = p->nb_base[side][2] ? static_cast<double*>(p->nb_base[side][2]) + EU_SKEW_SLACK : nullptr;
+  }
   p->base = S->comm;
   S->comm.ctx = S;
   S->comm.allreduce = p2p_allreduce;
@@ -254,6 +286,17 @@ extern "C" int euler_p2p_connect(euler_sim* S, const void* handles, int32_t nran
   S->comm.allgather = p2p_allgather;
   S->p2p_on = 1;
   return EULER_OK;
+}
+
+int eu_p2p_has_neighbour_arrays(const euler_sim* S) {
+  const P2PState* p = static_cast<const P2PState*>(S->p2p);
+  return S->p2p_on && p && p->have_arrays;
+}
+void eu_p2p_neighbour_arrays(euler_sim* S, const double** z_dn, const double** s_dn, const double** z_up, const double** s_up) {
+  P2PState* p = static_cast<P2PState*>(S->p2p);
+  const bool a_is_s = S->s == p->orig_s;          // which of the two search-direction arrays is "s" right now (all ranks alike)
+  *z_dn = p->nb_z[0]; *s_dn = a_is_s ? p->nb_sa[0] : p->nb_sb[0];
+  *z_up = p->nb_z[1]; *s_up = a_is_s ? p->nb_sa[1] : p->nb_sb[1];
 }
 
 extern "C" int euler_p2p_disconnect(euler_sim* S) {

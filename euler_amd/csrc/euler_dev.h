@@ -226,6 +226,9 @@ void eu_p2p_release(euler_sim* S);    // comm_p2p.hip
 int eu_p2p_halo_skewed(euler_sim* S, double* s_skewed);   // ghost rows of a band-skewed vector, straight from / into the array
 // hand-off rows of the band pipeline across slabs (exact coupling): where this rank's first band reads, where its last band writes
 void eu_p2p_xgran(euler_sim* S, int backward, const unsigned long long** in, unsigned long long** out);
+// the neighbouring ranks' z and (current) s arrays, IPC-mapped; null where there is no such rank / nothing is mapped
+int  eu_p2p_has_neighbour_arrays(const euler_sim* S);
+void eu_p2p_neighbour_arrays(euler_sim* S, const double** z_dn, const double** s_dn, const double** z_up, const double** s_up);
 int eu_install_comm(euler_sim* S, const euler_comm_ops* ops, int32_t coupling, int allow_single);
 
 // ------------------------------------------------------------------------------------------

@@ -251,11 +251,27 @@ __global__ __launch_bounds__(RED_THREADS) void k_apply_a(const double* __restric
 // A cell needs s' of its four neighbours, which it recomputes from z and the old s (the same expression its owner
 // evaluates: identical bits) - hence s' goes to a SECOND array, or a neighbour could read a half-updated s.
 // Saves a launch and 9 bytes per cell and iteration.  Same pair-per-thread structure as k_apply_a.
+// Several ranks (row slabs): the cells across a slab boundary belong to the neighbouring rank, and so do their z and s.
+// With the neighbours' arrays mapped (comm_p2p.hip) the kernel reads those two values where they live - a handful of
+// system-scope loads over xGMI for the lanes on the slab's edge rows - and forms the neighbour's s' with the owner's
+// expression.  No ghost-row exchange, no extra launch: every rank's z is final before anyone gets here (the all-reduce
+// behind dot(z,r) separates the backward sweeps from this kernel) and nobody overwrites z or the old s before the
+// all-reduce at the end of this kernel.
+struct SlabNeighbours {
+  const double *z_dn, *s_dn, *z_up, *s_up;   // the arrays of rank-1 / rank+1, offset like the local ones; null = no such rank
+  int nb_local;                              // bands of this slab
+};
+__device__ __forceinline__ double ld_system(const double* p) {
+  double v;
+  asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
 __global__ __launch_bounds__(RED_THREADS) void k_search_apply(const double* __restrict__ s_old, const double* __restrict__ z,
                                                               double* __restrict__ s_new, double* __restrict__ out,
                                                               const uint8_t* __restrict__ mask, SkewGeom g,
                                                               double* __restrict__ partial, PcgScalars* sc, int force,
-                                                              unsigned int* counter, int fin_op) {
+                                                              unsigned int* counter, int fin_op, SlabNeighbours nbr) {
   if (!force && pcg_idle(sc)) return;
   const double beta = sc->beta;
   const size_t S = g.S;
@@ -269,6 +285,23 @@ __global__ __launch_bounds__(RED_THREADS) void k_search_apply(const double* __re
     if (!((m0 | m1) & CM_FLUID)) continue;
     const sw_d2 so = *reinterpret_cast<const sw_d2*>(s_old + i), zc = *reinterpret_cast<const sw_d2*>(z + i);
     const int l = (int)((i & 127) >> 1);
+    // s' of the cell above / below element e (inside = its index when the neighbour sits in the same band)
+    auto sn_up = [&](size_t e, size_t inside) -> double {
+      if (l != 63) return sn(inside);
+      int band, tt, ll;
+      skew_decode(g, e, band, tt, ll);
+      const size_t k = skew_index(g, tt - 63, 64 * (band + 1));
+      if (nbr.z_up && band + 1 == nbr.nb_local) return ld_system(nbr.z_up + k) + beta * ld_system(nbr.s_up + k);
+      return sn(k);
+    };
+    auto sn_dn = [&](size_t e, size_t inside) -> double {
+      if (l != 0) return sn(inside);
+      int band, tt, ll;
+      skew_decode(g, e, band, tt, ll);
+      const size_t k = skew_index(g, tt, 64 * band - 1);
+      if (nbr.z_dn && band == 0) return ld_system(nbr.z_dn + k) + beta * ld_system(nbr.s_dn + k);
+      return sn(k);
+    };
     sw_d2 c = so, o = {0.0, 0.0};                     // c: the pair's s'
     if (m0 & CM_FLUID) c.x = zc.x + beta * so.x;
     if (m1 & CM_FLUID) c.y = zc.y + beta * so.y;
@@ -276,17 +309,13 @@ __global__ __launch_bounds__(RED_THREADS) void k_search_apply(const double* __re
       double v = (double)(int)(m0 >> CM_DIAG_SHIFT) * c.x;
       v = v - ((m0 & CM_RIGHT) ? c.y : 0.0);
       if (m0 & CM_UP) {
-        size_t up = i + 3;
-        if (l == 63) { int band, tt, ll; skew_decode(g, i, band, tt, ll); up = skew_index(g, tt - 63, 64 * (band + 1)); }
-        v = v - sn(up);
+        v = v - sn_up(i, i + 3);
       } else {
         v = v - 0.0;
       }
       v = v - ((m0 & CM_LEFT) ? sn(i - 127) : 0.0);
       if (m0 & CM_DOWN) {
-        size_t dn = i - 129;
-        if (l == 0) { int band, tt, ll; skew_decode(g, i, band, tt, ll); dn = skew_index(g, tt, 64 * band - 1); }
-        v = v - sn(dn);
+        v = v - sn_dn(i, i - 129);
       } else {
         v = v - 0.0;
       }
@@ -297,17 +326,13 @@ __global__ __launch_bounds__(RED_THREADS) void k_search_apply(const double* __re
       double v = (double)(int)(m1 >> CM_DIAG_SHIFT) * c.y;
       v = v - ((m1 & CM_RIGHT) ? sn(i + 128) : 0.0);
       if (m1 & CM_UP) {
-        size_t up = i + 130;
-        if (l == 63) { int band, tt, ll; skew_decode(g, i + 1, band, tt, ll); up = skew_index(g, tt - 63, 64 * (band + 1)); }
-        v = v - sn(up);
+        v = v - sn_up(i + 1, i + 130);
       } else {
         v = v - 0.0;
       }
       v = v - ((m1 & CM_LEFT) ? c.x : 0.0);
       if (m1 & CM_DOWN) {
-        size_t dn = i - 2;
-        if (l == 0) { int band, tt, ll; skew_decode(g, i + 1, band, tt, ll); dn = skew_index(g, tt, 64 * band - 1); }
-        v = v - sn(dn);
+        v = v - sn_dn(i + 1, i - 2);
       } else {
         v = v - 0.0;
       }
@@ -1164,12 +1189,21 @@ static int launch_apply_a_and_alpha(euler_sim* S, int force) {
 
 // iterations >= 1 of a single-GPU solve: s' = z + beta s and A s' in one launch; returns with S->s = s' and A s' in S->q
 static int launch_search_apply_and_alpha(euler_sim* S) {
-  const bool seq = S->cfg.dot_mode == EULER_DOT_SEQUENTIAL;
-  LAUNCH(S, KC_APPLY_A, k_search_apply, dim3(S->red_blocks), dim3(RED_THREADS), S->s, S->z, S->s2, S->q, S->cellmask, S->geom,
-         S->partial, S->sc, 0, S->red_counter, seq ? -1 : (int)FIN_ALPHA);
+  const bool seq = S->cfg.dot_mode == EULER_DOT_SEQUENTIAL && !S->has_comm;
+  SlabNeighbours nbr = {nullptr, nullptr, nullptr, nullptr, S->band_hi - S->band_lo};
+  if (S->has_comm) {   // the neighbouring slabs' z and s, addressed with this rank's offsets (the arrays are full-size everywhere)
+    eu_p2p_neighbour_arrays(S, &nbr.z_dn, &nbr.s_dn, &nbr.z_up, &nbr.s_up);
+    if (nbr.z_dn) { nbr.z_dn += S->e_lo; nbr.s_dn += S->e_lo; }
+    if (nbr.z_up) { nbr.z_up += S->e_lo; nbr.s_up += S->e_lo; }
+  }
+  SkewGeom gl = S->geom;
+  gl.S = S->e_cnt;
+  LAUNCH(S, KC_APPLY_A, k_search_apply, dim3(loc_red_blocks(S)), dim3(RED_THREADS), LOC(S->s), LOC(S->z), LOC(S->s2), LOC(S->q), LOC(S->cellmask), gl,
+         S->partial, S->sc, 0, S->red_counter, seq ? -1 : fin_or_comm(S, FIN_ALPHA), nbr);
   double* t = S->s; S->s = S->s2; S->s2 = t;
   if (seq)
     LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), S->q, S->s, S->cellmask, S->geom, S->sc, (int)FIN_ALPHA, 0);
+  if (S->has_comm) return comm_finish(S, FIN_ALPHA, 0, 0);
   return EULER_OK;
 }
 
@@ -1209,7 +1243,9 @@ int eu_launch_project(euler_sim* S, float dt) {
   LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<true>, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->s), LOC(S->z),
          LOC(S->cellmask), S->e_cnt, S->sc, 0, 0.0);
   if ((rc = launch_dot(S, S->z, S->r, FIN_SIGMA_INIT, 0))) return rc;
-  if (!S->has_comm) HIPCHK(hipMemsetAsync(S->s2, 0, S->geom.S * sizeof(double), S->stream));   // s' of non-fluid cells is never written
+  // ranks with their neighbours' z and s mapped run the fused kernel too (it reads across the slab boundary directly)
+  const bool fuse_search = !S->has_comm || eu_p2p_has_neighbour_arrays(S);
+  if (fuse_search) HIPCHK(hipMemsetAsync(LOC(S->s2), 0, S->e_cnt * sizeof(double), S->stream));   // s' of non-fluid cells is never written
   HIPCHK(hipMemcpyAsync(S->sc_host, S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
   HIPCHK(hipStreamSynchronize(S->stream));
   const int poll = S->cfg.pcg_poll_interval > 0 ? S->cfg.pcg_poll_interval : 8;
@@ -1220,7 +1256,7 @@ int eu_launch_project(euler_sim* S, float dt) {
     const int chunk_end = it + poll < max_it ? it + poll : max_it;
     for (; it < chunk_end; ++it) {
       S->prof_iter = it;
-      const bool fused = it > 0 && !S->has_comm;   // update_search of iteration it-1 rides along with this apply_a (A s' lands in q)
+      const bool fused = it > 0 && fuse_search;   // update_search of iteration it-1 rides along with this apply_a (A s' lands in q)
       if ((rc = fused ? launch_search_apply_and_alpha(S) : launch_apply_a_and_alpha(S, 0))) return rc;
       LAUNCH(S, KC_UPDATE_PR, k_update_pr, dim3(loc_red_blocks(S)), dim3(RED_THREADS), LOC(S->p), LOC(S->r), LOC(S->s),
              LOC(fused ? S->q : S->z), LOC(S->cellmask), S->e_cnt, S->partial, S->sc, 0, 0.0, S->red_counter, fin_or_comm(S, FIN_RNORM));
@@ -1231,7 +1267,7 @@ int eu_launch_project(euler_sim* S, float dt) {
         S->prof_iter = it + 1;
         if ((rc = launch_precondition(S, 0))) return rc;
         if ((rc = launch_dot(S, S->z, S->r, FIN_BETA, 0))) return rc;
-        if (S->has_comm)   // (single GPU: fused into the next iteration's apply_a)
+        if (!fuse_search)   // (otherwise fused into the next iteration's apply_a)
           LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<false>, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->s),
                  LOC(S->z), LOC(S->cellmask), S->e_cnt, S->sc, 0, 0.0);
       }

@@ -200,7 +200,7 @@ class RcclComm:
         return dict(zip(("allreduce", "halo", "chain", "allgather"), (int(v) for v in out)))
 
 
-P2P_HANDLE_BYTES = 64
+P2P_HANDLE_BYTES = 256     # EULER_P2P_HANDLE_BYTES: mailbox + the z / s / s2 arrays
 
 
 def attach_p2p(sim):

@@ -258,11 +258,11 @@ int euler_comm_calls(euler_sim* sim, uint64_t out[4]);         /* built-in commu
  * mappings of fine-grained device memory; xGMI between the GPUs of a node) - one small kernel each, no
  * collective library in the loop, sums formed in rank order (bit-identical on every rank).  The bulk
  * transfers (band hand-off rows, all-gather of p) stay on the communicator installed before.
- *   1. every rank:  euler_p2p_export(sim, handle)          -> EULER_P2P_HANDLE_BYTES bytes (a hipIpcMemHandle_t)
+ *   1. every rank:  euler_p2p_export(sim, handle)          -> EULER_P2P_HANDLE_BYTES bytes (IPC handles)
  *   2. the launcher gathers the handles of all ranks, in rank order, on every rank (any host channel)
  *   3. every rank:  euler_p2p_connect(sim, handles, nranks) after euler_set_comm[_rccl]; maps the mailboxes and
  *      proves the path with an all-reduce of known values.  On failure the installed communicator stays as it is. */
-#define EULER_P2P_HANDLE_BYTES 64
+#define EULER_P2P_HANDLE_BYTES 256   /* four hipIpcMemHandle_t: the mailbox and the z / s / s2 arrays (read across slab boundaries) */
 int euler_p2p_export(euler_sim* sim, void* handle_out, int32_t cap);
 int euler_p2p_connect(euler_sim* sim, const void* handles, int32_t nranks);
 int euler_p2p_disconnect(euler_sim* sim);                      /* back to the installed communicator; frees the mailbox */
