@@ -206,7 +206,7 @@ P2P_HANDLE_BYTES = 256     # EULER_P2P_HANDLE_BYTES: mailbox + the z / s / s2 ar
 def attach_p2p(sim):
     """Route the per-iteration exchanges (three scalar all-reduces, the ghost rows) over peer-to-peer
     mailboxes (csrc/comm_p2p.hip) on top of the communicator already installed on `sim`.
-    torch.distributed only carries the 64-byte IPC handles, once.  Returns True when the mailboxes are in
+    torch.distributed only carries the IPC handles (256 bytes per rank), once.  Returns True when the mailboxes are in
     use on EVERY rank; on any failure all ranks stay on the installed communicator (the reason is in
     sim._p2p_error)."""
     import torch
