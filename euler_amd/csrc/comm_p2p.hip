@@ -290,7 +290,11 @@ extern "C" int euler_p2p_connect(euler_sim* S, const void* handles, int32_t nran
 
 int eu_p2p_has_neighbour_arrays(const euler_sim* S) {
   const P2PState* p = static_cast<const P2PState*>(S->p2p);
-  return S->p2p_on && p && p->have_arrays;
+  // EULER_SLAB_FUSION=0 (environment, every rank alike): keep the ghost-row exchange + separate update_search instead of
+  // reading across the slab boundary - a switch for first contact with a node, where remote visibility cannot be
+  // tested on the one-GPU box (the reads rely on kernel-end release reaching the memory side, as it must between XCDs)
+  static const int allowed = []() { const char* e = getenv("EULER_SLAB_FUSION"); return !(e && e[0] == '0'); }();
+  return allowed && S->p2p_on && p && p->have_arrays;
 }
 void eu_p2p_neighbour_arrays(euler_sim* S, const double** z_dn, const double** s_dn, const double** z_up, const double** s_up) {
   P2PState* p = static_cast<P2PState*>(S->p2p);
