@@ -267,6 +267,7 @@ __device__ __forceinline__ double ld_system(const double* p) {
   return v;
 }
 
+template <bool SLAB>   // SLAB: several ranks, the neighbouring slabs' arrays are mapped (nbr); else nbr is ignored
 __global__ __launch_bounds__(RED_THREADS) void k_search_apply(const double* __restrict__ s_old, const double* __restrict__ z,
                                                               double* __restrict__ s_new, double* __restrict__ out,
                                                               const uint8_t* __restrict__ mask, SkewGeom g,
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_search_apply(const double* __re
       int band, tt, ll;
       skew_decode(g, e, band, tt, ll);
       const size_t k = skew_index(g, tt - 63, 64 * (band + 1));
-      if (nbr.z_up && band + 1 == nbr.nb_local) return ld_system(nbr.z_up + k) + beta * ld_system(nbr.s_up + k);
+      if (SLAB && nbr.z_up && band + 1 == nbr.nb_local) return ld_system(nbr.z_up + k) + beta * ld_system(nbr.s_up + k);
       return sn(k);
     };
     auto sn_dn = [&](size_t e, size_t inside) -> double {
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_search_apply(const double* __re
       int band, tt, ll;
       skew_decode(g, e, band, tt, ll);
       const size_t k = skew_index(g, tt, 64 * band - 1);
-      if (nbr.z_dn && band == 0) return ld_system(nbr.z_dn + k) + beta * ld_system(nbr.s_dn + k);
+      if (SLAB && nbr.z_dn && band == 0) return ld_system(nbr.z_dn + k) + beta * ld_system(nbr.s_dn + k);
       return sn(k);
     };
     sw_d2 c = so, o = {0.0, 0.0};                     // c: the pair's s'
@@ -1198,8 +1199,12 @@ static int launch_search_apply_and_alpha(euler_sim* S) {
   }
   SkewGeom gl = S->geom;
   gl.S = S->e_cnt;
-  LAUNCH(S, KC_APPLY_A, k_search_apply, dim3(loc_red_blocks(S)), dim3(RED_THREADS), LOC(S->s), LOC(S->z), LOC(S->s2), LOC(S->q), LOC(S->cellmask), gl,
-         S->partial, S->sc, 0, S->red_counter, seq ? -1 : fin_or_comm(S, FIN_ALPHA), nbr);
+  if (S->has_comm)
+    LAUNCH(S, KC_APPLY_A, k_search_apply<true>, dim3(loc_red_blocks(S)), dim3(RED_THREADS), LOC(S->s), LOC(S->z), LOC(S->s2), LOC(S->q), LOC(S->cellmask), gl,
+           S->partial, S->sc, 0, S->red_counter, fin_or_comm(S, FIN_ALPHA), nbr);
+  else
+    LAUNCH(S, KC_APPLY_A, k_search_apply<false>, dim3(S->red_blocks), dim3(RED_THREADS), S->s, S->z, S->s2, S->q, S->cellmask, S->geom,
+           S->partial, S->sc, 0, S->red_counter, seq ? -1 : (int)FIN_ALPHA, nbr);
   double* t = S->s; S->s = S->s2; S->s2 = t;
   if (seq)
     LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), S->q, S->s, S->cellmask, S->geom, S->sc, (int)FIN_ALPHA, 0);
