@@ -209,9 +209,11 @@ extern "C" int euler_p2p_export(euler_sim* S, void* handle_out, int32_t cap) {
   hipIpcMemHandle_t h[P2P_NHANDLES];
   HIPCHK(hipIpcGetMemHandle(&h[0], p->box));
   // the solver arrays start EU_SKEW_SLACK elements into their allocations (driver.hip)
-  HIPCHK(hipIpcGetMemHandle(&h[1], S->z - EU_SKEW_SLACK));
-  HIPCHK(hipIpcGetMemHandle(&h[2], S->s - EU_SKEW_SLACK));
-  HIPCHK(hipIpcGetMemHandle(&h[3], S->s2 - EU_SKEW_SLACK));
+  // (if an array cannot be exported its handle stays zero: the neighbours' open fails, and all ranks agree not to fuse)
+  memset(&h[1], 0, 3 * sizeof(hipIpcMemHandle_t));
+  (void)hipIpcGetMemHandle(&h[1], S->z - EU_SKEW_SLACK);
+  (void)hipIpcGetMemHandle(&h[2], S->s - EU_SKEW_SLACK);
+  (void)hipIpcGetMemHandle(&h[3], S->s2 - EU_SKEW_SLACK);
   p->orig_s = S->s;
   memcpy(handle_out, h, sizeof h);
   return EULER_OK;
@@ -278,6 +280,19 @@ extern "C" int euler_p2p_connect(euler_sim* S, const void* handles, int32_t nran
     p->nb_sa[side] = p->nb_base[side][1] ? static_cast<double*>(p->nb_base[side][1]) + EU_SKEW_SLACK : nullptr;
     p->nb_sb[side] = p->nb_base[side][2] ? static_cast<double*>(p->nb_base[side][2]) + EU_SKEW_SLACK : nullptr;
   }
+  // The fusion changes which exchanges a rank performs, so it must be all ranks or none: agree over the mailboxes
+  // (just proven) - and with EULER_SLAB_FUSION=0 in any rank's environment nobody fuses.
+  {
+    const char* e = getenv("EULER_SLAB_FUSION");
+    const double mine_ok = (p->have_arrays && !(e && e[0] == '0')) ? 1.0 : 0.0;
+    double sum = 0.0;
+    HIPCHK(hipMemcpyAsync(probe, &mine_ok, 8, hipMemcpyHostToDevice, S->stream));
+    hipLaunchKernelGGL(k_p2p_allreduce, dim3(1), dim3(64), 0, S->stream, S->sc, probe, 0);
+    HIPCHK(hipMemcpyAsync(&sum, probe, 8, hipMemcpyDeviceToHost, S->stream));
+    rc = eu_sync_marker_state(S);
+    if (rc) return rc;
+    p->have_arrays = sum == (double)nranks;
+  }
   p->base = S->comm;
   S->comm.ctx = S;
   S->comm.allreduce = p2p_allreduce;
@@ -290,11 +305,10 @@ extern "C" int euler_p2p_connect(euler_sim* S, const void* handles, int32_t nran
 
 int eu_p2p_has_neighbour_arrays(const euler_sim* S) {
   const P2PState* p = static_cast<const P2PState*>(S->p2p);
-  // EULER_SLAB_FUSION=0 (environment, every rank alike): keep the ghost-row exchange + separate update_search instead of
+  // EULER_SLAB_FUSION=0 (environment of any rank, evaluated in euler_p2p_connect): keep the ghost-row exchange + separate update_search instead of
   // reading across the slab boundary - a switch for first contact with a node, where remote visibility cannot be
   // tested on the one-GPU box (the reads rely on kernel-end release reaching the memory side, as it must between XCDs)
-  static const int allowed = []() { const char* e = getenv("EULER_SLAB_FUSION"); return !(e && e[0] == '0'); }();
-  return allowed && S->p2p_on && p && p->have_arrays;
+  return S->p2p_on && p && p->have_arrays;   // agreed by all ranks in euler_p2p_connect
 }
 void eu_p2p_neighbour_arrays(euler_sim* S, const double** z_dn, const double** s_dn, const double** z_up, const double** s_up) {
   P2PState* p = static_cast<P2PState*>(S->p2p);
