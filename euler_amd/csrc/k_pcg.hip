@@ -1008,9 +1008,9 @@ static SweepArgs make_sweep_args(euler_sim* S, int op, int force) {
 // 32-step (forward) / 24-step (backward) aligned block ranges of the forward (step = t) and backward (step = T-1-t) sweeps; the
 // upper end leaves at least one all-non-fluid step inside the range (see k_sweep_skew).  Computed
 // from the row-major count grid, which every rank holds in full.
-__global__ __launch_bounds__(1024) void k_band_ranges(const uint8_t* __restrict__ count, int X, int Y, int T, int4* __restrict__ ranges) {
+__global__ __launch_bounds__(1024) void k_band_ranges(const uint8_t* __restrict__ count, int X, int Y, int T, int4* __restrict__ ranges, int band0) {
   __shared__ int s_lo, s_hi;
-  const int band = blockIdx.x;
+  const int band = band0 + blockIdx.x;
   if (threadIdx.x == 0) { s_lo = 0x7fffffff; s_hi = -1; }
   __syncthreads();
   int lo = 0x7fffffff, hi = -1;
@@ -1057,7 +1057,9 @@ __global__ __launch_bounds__(256) void k_pack_fbits(const uint8_t* __restrict__ 
   fwd[o] = wf; bwd[o] = wb;
 }
 int eu_launch_band_ranges(euler_sim* S) {
-  LAUNCH(S, KC_BUILD_SYSTEM, k_band_ranges, dim3(S->geom.nbands), dim3(1024), S->count, S->X, S->Y, S->geom.T, S->band_ranges);
+  // a rank needs the ranges of its own bands and of the band before / after its slab (the hand-off windows)
+  const int b0 = S->band_lo > 0 ? S->band_lo - 1 : 0, b1 = S->band_hi < S->geom.nbands ? S->band_hi + 1 : S->geom.nbands;
+  LAUNCH(S, KC_BUILD_SYSTEM, k_band_ranges, dim3(b1 - b0), dim3(1024), S->count, S->X, S->Y, S->geom.T, S->band_ranges, b0);
   const int nbl = S->band_hi - S->band_lo;
   const size_t n = (size_t)nbl * S->fb_stride * 64;
   LAUNCH(S, KC_BUILD_SYSTEM, k_pack_fbits, dim3((unsigned)((n + 255) / 256)), dim3(256), S->cellmask, S->geom, S->fbits_fwd, S->fbits_bwd,
