@@ -225,7 +225,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   DALLOC(S->fbits_bwd, (size_t)S->geom.nbands * S->fb_stride * 64);
   DALLOC(S->sc, 1);
   DALLOC(S->band_ranges, (size_t)S->geom.nbands);
-  S->red_blocks = (int)eu_blocks(SS, 256 * 16, 2048);
+  S->red_blocks = (int)eu_blocks(SS, EU_RED_ELEMS, 2048);
   DALLOC(S->partial, (size_t)S->red_blocks);
   DALLOC(S->red_counter, 1);
   S->band_lo = 0; S->band_hi = S->geom.nbands; S->e_lo = 0; S->e_cnt = SS;

@@ -76,6 +76,10 @@ struct MarkerState {
 // TS = roundup32(T) + 64 records; S = nbands*TS*64 elements in total; padding carries mask 0.
 // Every skewed array also has EU_SKEW_SLACK elements of zeroed slack in front of element 0.
 #define EU_SKEW_SLACK (64 * 64)
+#ifndef EU_RED_ELEMS
+#define EU_RED_ELEMS (256 * 16)   // skewed elements per block of the reduction kernels (apply_a, update_pr, dot), at most 2048 blocks;
+                                  // 1024^2 frame: 2048 -> 79.8 ms, 4096 -> 77.0 ms, 8192 -> 79.5 ms
+#endif
 struct SkewGeom {
   int X, Y, nbands, T, TS;
   size_t S;

@@ -1153,7 +1153,7 @@ static int launch_sweep(euler_sim* S, int cls, int force) {
 
 // element range of this rank (the whole array without a communicator)
 #define LOC(ptr) ((ptr) + S->e_lo)
-static inline int loc_red_blocks(const euler_sim* S) { return (int)eu_blocks(S->e_cnt, 256 * 16, 2048); }
+static inline int loc_red_blocks(const euler_sim* S) { return (int)eu_blocks(S->e_cnt, EU_RED_ELEMS, 2048); }
 
 static int launch_dot(euler_sim* S, const double* a, const double* b, int fin_op, int force) {
   if (S->cfg.dot_mode == EULER_DOT_SEQUENTIAL && !S->has_comm) {
