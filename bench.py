@@ -167,6 +167,20 @@ def cpu_model():
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # asked for N GPUs but started as a plain process: start the N ranks the way the driver does (a child
+        # torch.distributed.run - nothing here has touched the GPU yet) and hand its one JSON line through
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        sys.stdout.write(r.stdout)
+        sys.stdout.flush()
+        sys.exit(r.returncode)
     # stdout carries exactly ONE line, the JSON: whatever native libraries print on fd 1 while the job runs
     # (RCCL writes its version banner there when a communicator is created) is diverted to stderr
     sys.stdout.flush()
