@@ -290,6 +290,12 @@ extern "C" int euler_p2p_connect(euler_sim* S, const void* handles, int32_t nran
     hipLaunchKernelGGL(k_p2p_allreduce, dim3(1), dim3(64), 0, S->stream, S->sc, probe, 0);
     HIPCHK(hipMemcpyAsync(&sum, probe, 8, hipMemcpyDeviceToHost, S->stream));
     rc = eu_sync_marker_state(S);
+    if (rc == EULER_ETIMEOUT) {       // a peer dropped out after the self-test: fall back like above, handle intact
+      (void)hipMemsetAsync(&S->ms->error, 0, sizeof(int), S->stream);
+      (void)eu_sync_marker_state(S);
+      eu_set_error("euler_p2p_connect: a peer left before the ranks could agree on the fused search kernel");
+      return EULER_ECOMM;
+    }
     if (rc) return rc;
     p->have_arrays = sum == (double)nranks;
   }
