@@ -149,7 +149,8 @@ def pmc_traffic(size, workload, kernel_class):
     try:
         name = PMC_KERNEL.get(kernel_class, "")
         kernels = json.load(open(p))["kernels"]
-        k = kernels.get(name) or kernels.get(name.replace(">", ", false>"))   # k_sweep_skew<OP, XG>: single-GPU build
+        # template arguments added since a PMC file was written: k_sweep_skew<OP, XG>, k_dot_partial<EDGES>, k_search_apply<SLAB>
+        k = kernels.get(name) or kernels.get(name.replace(">", ", false>")) or kernels.get(name + "<false>")
         return int(k["hbm_bytes_per_launch"]) if k else None
     except (OSError, ValueError, KeyError):
         return None

@@ -118,11 +118,25 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_final(const double* __re
   if (threadIdx.x == 0) pcg_scalar_step(sc, op, v);
 }
 
-// dot(a,b) over fluid cells -> per-block partials (tree mode); layout-agnostic
+// What a neighbouring RANK reads across a slab boundary (k_search_apply<true>: the edge rows of z and of the search
+// direction) is stored once more WRITE-THROUGH at system scope by the kernel that has it in registers anyway, and every
+// thread drains its stores before the block joins the reduction whose all-reduce releases the readers: the remote loads
+// then do not depend on what a kernel boundary flushes.  `edges` bit 0 / 1: this slab has a neighbour below / above.
+__device__ __forceinline__ void st_system(const double* p, double v) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ bool slab_edge_row(size_t e, int l, int TS, int nb_local, int edges) {
+  if (l != 0 && l != 63) return false;
+  const int band = (int)(e / ((size_t)TS * 64));
+  return l == 0 ? ((edges & 1) && band == 0) : ((edges & 2) && band == nb_local - 1);
+}
+
+// dot(a,b) over fluid cells -> per-block partials (tree mode); layout-agnostic.  EDGES: `a` is z of a slab (see above).
+template <bool EDGES>
 __global__ __launch_bounds__(RED_THREADS) void k_dot_partial(const double* __restrict__ a, const double* __restrict__ b,
                                                              const uint8_t* __restrict__ mask, size_t S,
                                                              double* __restrict__ partial, PcgScalars* sc, int force,
-                                                             unsigned int* counter, int fin_op) {
+                                                             unsigned int* counter, int fin_op, int TS, int nb_local, int edges) {
   if (!force && pcg_idle(sc)) return;
   const size_t chunk = (((S + gridDim.x - 1) / gridDim.x) + 1) & ~(size_t)1;   // S is even: whole 16-byte pairs per thread
   const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < S ? lo + chunk : S;
@@ -133,7 +147,12 @@ __global__ __launch_bounds__(RED_THREADS) void k_dot_partial(const double* __res
     const sw_d2 av = *reinterpret_cast<const sw_d2*>(a + i), bv = *reinterpret_cast<const sw_d2*>(b + i);
     if (mm & CM_FLUID) t += av.x * bv.x;
     if ((mm >> 8) & CM_FLUID) t += av.y * bv.y;
+    if (EDGES && slab_edge_row(i, (int)((i & 127) >> 1), TS, nb_local, edges)) {
+      if (mm & CM_FLUID) st_system(a + i, av.x);
+      if ((mm >> 8) & CM_FLUID) st_system(a + i + 1, av.y);
+    }
   }
+  if (EDGES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every thread's write-through stores have landed (block_sum syncs)
   t = block_sum(t);
   block_finish<false>(t, partial, counter, sc, fin_op);
 }
@@ -343,7 +362,12 @@ __global__ __launch_bounds__(RED_THREADS) void k_search_apply(const double* __re
     if ((m0 & m1) & CM_FLUID) { *reinterpret_cast<sw_d2*>(s_new + i) = c; *reinterpret_cast<sw_d2*>(out + i) = o; }
     else if (m0 & CM_FLUID) { s_new[i] = c.x; out[i] = o.x; }
     else { s_new[i + 1] = c.y; out[i + 1] = o.y; }
+    if (SLAB && slab_edge_row(i, l, g.TS, nbr.nb_local, (nbr.z_dn ? 1 : 0) | (nbr.z_up ? 2 : 0))) {   // the rows the neighbours will read
+      if (m0 & CM_FLUID) st_system(s_new + i, c.x);
+      if (m1 & CM_FLUID) st_system(s_new + i + 1, c.y);
+    }
   }
+  if (SLAB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // landed before this block joins the all-reduce (block_sum syncs)
   t = block_sum(t);
   if (fin_op >= 0) block_finish<false>(t, partial, counter, sc, fin_op);   // fin_op < 0: dot(out, s') is replayed sequentially
 }
@@ -405,6 +429,17 @@ __global__ __launch_bounds__(256) void k_update_search(double* __restrict__ s, c
     if (f1) sv.y = zv.y + beta * sv.y;
     *reinterpret_cast<sw_d2*>(s + i) = sv;      // a non-fluid partner is written back unchanged
   }
+}
+
+// the slab's edge rows of a skewed array once more, write-through at system scope (see st_system): row y0 and / or y1
+__global__ __launch_bounds__(256) void k_publish_edge_rows(double* arr, SkewGeom g, int y0, int y1, const PcgScalars* sc) {
+  if (pcg_idle(sc)) return;
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= g.X) return;
+  const int y = blockIdx.y == 0 ? y0 : y1;
+  if (y < 0) return;
+  double* p = arr + skew_index(g, x, y);
+  st_system(p, *p);
 }
 
 // Jacobi stand-in preconditioner (not the reference's iterates; roofline comparison only)
@@ -1159,8 +1194,13 @@ static int launch_dot(euler_sim* S, const double* a, const double* b, int fin_op
   if (S->cfg.dot_mode == EULER_DOT_SEQUENTIAL && !S->has_comm) {
     LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), a, b, S->cellmask, S->geom, S->sc, fin_op, force);
   } else {
-    LAUNCH(S, KC_DOT, k_dot_partial, dim3(loc_red_blocks(S)), dim3(RED_THREADS), LOC(a), LOC(b), LOC(S->cellmask), S->e_cnt,
-           S->partial, S->sc, force, S->red_counter, fin_or_comm(S, fin_op));
+    const int edges = (a == S->z && S->has_comm && eu_p2p_has_neighbour_arrays(S)) ? ((S->band_lo > 0 ? 1 : 0) | (S->band_hi < S->geom.nbands ? 2 : 0)) : 0;
+    if (edges)
+      LAUNCH(S, KC_DOT, k_dot_partial<true>, dim3(loc_red_blocks(S)), dim3(RED_THREADS), LOC(a), LOC(b), LOC(S->cellmask), S->e_cnt,
+             S->partial, S->sc, force, S->red_counter, fin_or_comm(S, fin_op), S->geom.TS, S->band_hi - S->band_lo, edges);
+    else
+      LAUNCH(S, KC_DOT, k_dot_partial<false>, dim3(loc_red_blocks(S)), dim3(RED_THREADS), LOC(a), LOC(b), LOC(S->cellmask), S->e_cnt,
+             S->partial, S->sc, force, S->red_counter, fin_or_comm(S, fin_op), 0, 0, 0);
     if (S->has_comm) return comm_finish(S, fin_op, 0, force);
   }
   return EULER_OK;
@@ -1249,6 +1289,10 @@ int eu_launch_project(euler_sim* S, float dt) {
   if ((rc = launch_precondition(S, 0))) return rc;
   LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<true>, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->s), LOC(S->z),
          LOC(S->cellmask), S->e_cnt, S->sc, 0, 0.0);
+  if (S->has_comm && eu_p2p_has_neighbour_arrays(S)) {   // the neighbours read these rows of s in the second iteration's k_search_apply
+    const int y0 = S->band_lo > 0 ? 64 * S->band_lo : -1, y1 = S->band_hi < S->geom.nbands ? 64 * S->band_hi - 1 : -1;
+    LAUNCH(S, KC_UPDATE_SEARCH, k_publish_edge_rows, dim3((S->X + 255) / 256, 2), dim3(256), S->s, S->geom, y0, y1, S->sc);
+  }
   if ((rc = launch_dot(S, S->z, S->r, FIN_SIGMA_INIT, 0))) return rc;
   // ranks with their neighbours' z and s mapped run the fused kernel too (it reads across the slab boundary directly)
   const bool fuse_search = !S->has_comm || eu_p2p_has_neighbour_arrays(S);
