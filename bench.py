@@ -50,7 +50,8 @@ def parse_args():
     ap.add_argument("--size", type=int, default=1024, help="N of the NxN grid (default: configs[1] = 1024)")
     ap.add_argument("--workload", default="dam_break", choices=["dam_break", "half_tank", "waterfall"])
     ap.add_argument("--dot-mode", default="tree", choices=["tree", "sequential"])
-    ap.add_argument("--precond", default="ic0", choices=["ic0", "jacobi"])
+    ap.add_argument("--precond", default="ic0", choices=["ic0", "jacobi", "ic0_tile"])
+    ap.add_argument("--tile-units", type=int, default=0)
     ap.add_argument("--max-preroll", type=int, default=400)
     ap.add_argument("--slab", default="local", choices=["local", "exact", "replicas"],
                     help="N>1: slab-local IC(0) (scales; tolerance-only), exact coupling (the 1-GPU iterates; sweeps "
@@ -204,14 +205,14 @@ def main():
 
     N = args.size
     dot_mode = ea.DOT_TREE if args.dot_mode == "tree" else ea.DOT_SEQUENTIAL
-    precond = ea.PRECOND_IC0 if args.precond == "ic0" else ea.PRECOND_JACOBI
+    precond = {"ic0": ea.PRECOND_IC0, "jacobi": ea.PRECOND_JACOBI, "ic0_tile": ea.PRECOND_IC0_TILE}[args.precond]
     # N > 1 (weak scaling): the grid grows to N x (N * gpus) rows; the pressure solve is split into one
     # slab of N rows per GPU, the cheap stages run replicated (DESIGN.md "Multi-GPU")
     sharded = (world > 1 or args.force_slab) and args.slab != "replicas"
     GX, GY = N, N * (args.grid_y_mult if args.grid_y_mult > 0 else (world if sharded and args.scaling == "weak" else 1))
     if world > 1:
         torch.cuda.set_device(local_rank)
-    sim = ea.Simulation(GX, GY, device=local_rank, dot_mode=dot_mode, precond=precond)
+    sim = ea.Simulation(GX, GY, device=local_rank, dot_mode=dot_mode, precond=precond, tile_units=args.tile_units)
     comm = None
     p2p_on = False
     if sharded:
@@ -271,7 +272,7 @@ def main():
     for _ in range(max(args.warmup - warm_done, 0)):
         sim.step()
 
-    dominant = "backward_solve" if precond == ea.PRECOND_IC0 else "update_pr"
+    dominant = "backward_solve" if precond != ea.PRECOND_JACOBI else "update_pr"
     # Inside the timed region only the DOMINANT kernel is bracketed by HIP events (on the kernel's own
     # stream): an event pair around every launch of all six PCG kernels costs ~20 % throughput at
     # 1024^2 (measured), around the dominant one alone ~2 %.  The other classes are timed in a second,

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libeuler_hip.so")
 
 # --- enums of include/euler.h ------------------------------------------------------------------
 DOT_AUTO, DOT_SEQUENTIAL, DOT_TREE = 0, 1, 2
-PRECOND_IC0, PRECOND_JACOBI = 0, 1
+PRECOND_IC0, PRECOND_JACOBI, PRECOND_IC0_TILE = 0, 1, 2
 SWEEP_AUTO, SWEEP_BAND, SWEEP_SIMPLE = 0, 1, 2
 (F_U, F_V, F_UTMP, F_VTMP, F_SOLID, F_SOURCE, F_SINK, F_COUNT, F_PREV_COUNT, F_MARKERS, F_PRECON,
  F_PRESSURE, F_PCG_B, F_PCG_R, F_PCG_Z, F_PCG_S, F_PCG_Q, F_CELLMASK,
@@ -47,7 +47,7 @@ class Config(C.Structure):
         ("max_iterations", C.c_int32), ("tol", C.c_double), ("dot_mode", C.c_int32), ("precond", C.c_int32),
         ("sweep_mode", C.c_int32), ("max_substeps", C.c_int32), ("frame_time", C.c_float),
         ("viscosity", C.c_float), ("pcg_poll_interval", C.c_int32), ("rainbow", C.c_int32),
-        ("reserved", C.c_int32 * 7),
+        ("precond_tile_units", C.c_int32), ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -66,7 +66,7 @@ _lib = None
 EXPORTS = [
     "euler_config_default", "euler_create", "euler_destroy", "euler_last_error", "euler_abi_version",
     "euler_load_scenario_mem", "euler_load_scenario_file", "euler_load_half_tank", "euler_parse_scenario",
-    "euler_seed_markers", "euler_step", "euler_timestep", "euler_substep", "euler_stage", "euler_pcg_op",
+    "euler_seed_markers", "euler_step", "euler_timestep", "euler_substep", "euler_stage", "euler_pcg_op", "euler_set_precond",
     "euler_get_field", "euler_set_field", "euler_set_markers", "euler_set_rng", "euler_get_stats",
     "euler_field_bytes", "euler_render", "euler_render_grids", "euler_render_grids_rgb", "euler_colorize", "euler_profile_enable",
     "euler_profile_class_count", "euler_profile_class_name", "euler_profile_get", "euler_profile_reset",
@@ -104,6 +104,7 @@ def load_library():
         "euler_substep": (C.c_int, [vp, f32]),
         "euler_stage": (C.c_int, [vp, i32, f32]),
         "euler_pcg_op": (C.c_int, [vp, i32, f32, f64, C.POINTER(f64)]),
+        "euler_set_precond": (C.c_int, [vp, i32, i32]),
         "euler_get_field": (C.c_int, [vp, i32, vp, C.c_size_t]),
         "euler_set_field": (C.c_int, [vp, i32, vp, C.c_size_t]),
         "euler_set_markers": (C.c_int, [vp, vp, u64]),
@@ -256,7 +257,7 @@ class Simulation:
     plus state access for parity tests."""
 
     def __init__(self, X=100, Y=40, device=0, dot_mode=DOT_AUTO, precond=PRECOND_IC0, sweep_mode=SWEEP_AUTO,
-                 max_iterations=100, tol=None, pcg_poll_interval=8, viscosity=0.0, rainbow=False):
+                 max_iterations=100, tol=None, pcg_poll_interval=8, viscosity=0.0, rainbow=False, tile_units=0):
         self.L = load_library()
         cfg = Config()
         _check(self.L.euler_config_default(C.byref(cfg)))
@@ -268,6 +269,7 @@ class Simulation:
         cfg.pcg_poll_interval = pcg_poll_interval
         cfg.viscosity = viscosity            # extension: 0 = the inviscid reference
         cfg.rainbow = int(rainbow)           # args_t.rainbow (main.c:54): carry and advect the dye fields
+        cfg.precond_tile_units = tile_units  # PRECOND_IC0_TILE: tile width in units of 96 records (0 = default)
         self.cfg = cfg
         self.X, self.Y = X, Y
         self.h = C.c_void_p()
@@ -326,6 +328,9 @@ class Simulation:
 
     def stage(self, stage, dt=0.0):
         _check(self.L.euler_stage(self.h, stage, dt))
+
+    def set_precond(self, precond, tile_units=0):
+        _check(self.L.euler_set_precond(self.h, precond, tile_units))
 
     def pcg_op(self, op, dt=0.0, scalar=0.0):
         out = C.c_double(0)

@@ -124,6 +124,25 @@ extern "C" int euler_config_default(euler_config* c) {
   return EULER_OK;
 }
 
+// tiles per band of the tile-local preconditioner (include/euler.h precond_tile_units; the oracle's eo_tile_start)
+static void eu_set_tiles(euler_sim* S, int tile_units) {
+  const int n_units = S->geom.T / 96;
+  if (tile_units <= 0) tile_units = 6;
+  int nt = (n_units + tile_units / 2) / tile_units;
+  if (nt < 1) nt = 1;
+  if (nt > n_units) nt = n_units;
+  S->cfg.precond_tile_units = tile_units;
+  S->tile_nt = nt;
+}
+
+extern "C" int euler_set_precond(euler_sim* S, int32_t precond, int32_t tile_units) {
+  if (!S || precond < EULER_PRECOND_IC0 || precond > EULER_PRECOND_IC0_TILE) { eu_set_error("euler_set_precond: bad argument"); return EULER_EINVAL; }
+  HIPCHK(hipStreamSynchronize(S->stream));
+  S->cfg.precond = precond;
+  eu_set_tiles(S, tile_units);
+  return EULER_OK;
+}
+
 template <typename T>
 static int dalloc(T** p, size_t n) {
   HIPCHK(hipMalloc((void**)p, n * sizeof(T)));
@@ -139,7 +158,7 @@ extern "C" void euler_destroy(euler_sim* S) {
   eu_rccl_release(S);
   void* dev[] = {S->u, S->v, S->utmp, S->vtmp, S->solid, S->source, S->sink, S->count, S->prev_count, S->count32,
                  S->markers[0], S->markers[1], S->ms, S->evmask, S->ev_theta, S->ev_delta, S->sel_idx, S->act_idx,
-                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->fbits_fwd, S->fbits_bwd, S->halo_buf, S->band_ranges,
+                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->fbits_fwd, S->fbits_bwd, S->halo_buf, S->band_ranges, S->tile_fluid,
                  S->rowmajor_tmp};
   for (void* p : dev) if (p) (void)hipFree(p);
   for (float* d : S->dye) if (d) (void)hipFree(d);
@@ -187,7 +206,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   if (S->cfg.sweep_mode == EULER_SWEEP_AUTO) S->cfg.sweep_mode = EULER_SWEEP_BAND;
   S->geom.X = S->X; S->geom.Y = S->Y;
   S->geom.nbands = (S->Y + 63) / 64;
-  S->geom.T = (S->X + 63 + 1) & ~1;   // records per band, even: records are stored in pairs (euler_dev.h)
+  S->geom.T = (S->X + 63 + 95) / 96 * 96;   // records per band in whole units of 96 (euler_dev.h); even: records are stored in pairs
   S->geom.TS = (S->geom.T + 31) / 32 * 32 + 64;   // the sweeps run whole groups of three / four 8-step blocks and prefetch up to 24 steps further
   S->geom.S = (size_t)S->geom.nbands * S->geom.TS * 64;
   const size_t SS = S->geom.S;
@@ -225,12 +244,14 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   DALLOC(S->fbits_bwd, (size_t)S->geom.nbands * S->fb_stride * 64);
   DALLOC(S->sc, 1);
   DALLOC(S->band_ranges, (size_t)S->geom.nbands);
+  DALLOC(S->tile_fluid, (size_t)S->geom.nbands * (S->geom.T / 96));
+  eu_set_tiles(S, S->cfg.precond_tile_units);
   S->red_blocks = (int)eu_blocks(SS, EU_RED_ELEMS, 2048);
   DALLOC(S->partial, (size_t)S->red_blocks);
   DALLOC(S->red_counter, 1);
   S->band_lo = 0; S->band_hi = S->geom.nbands; S->e_lo = 0; S->e_cnt = SS;
   DALLOC(S->halo_buf, (size_t)4 * S->X);
-  S->gran_stride = (S->X + 1 + 7) / 8 * 8;   // hand-off columns [0, T - 63)
+  S->gran_stride = (S->geom.T - 63 + 7) / 8 * 8;   // hand-off columns [0, T - 63)
   DALLOC(S->granules, (size_t)S->geom.nbands * S->gran_stride * 2);
   DALLOC(S->ticket, 1);
   DALLOC(S->sweep_timeline, (size_t)S->geom.nbands * 8);

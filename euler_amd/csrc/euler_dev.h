@@ -72,8 +72,10 @@ struct MarkerState {
 // Band-skewed layout of the solver's private arrays (k_pcg.hip header): element (x,y) lives at
 // record t = x + y%64 of band y/64, lane y%64; RECORDS COME IN PAIRS: the two elements (t even, t+1) of a lane
 // are adjacent, index = ((y/64)*TS + (t & ~1))*64 + 2*(y%64) + (t & 1), so that one 16-byte access per lane
-// serves two steps of the IC(0) sweeps (a lone wave pays per memory INSTRUCTION: tools/micro/step_bench2).  A band has T = X + 63 live records and a stride of
-// TS = roundup32(T) + 64 records; S = nbands*TS*64 elements in total; padding carries mask 0.
+// serves two steps of the IC(0) sweeps (a lone wave pays per memory INSTRUCTION: tools/micro/step_bench2).  A band has X + 63 live records,
+// T = that rounded up to whole units of 96 records (the unit of the tile-local preconditioner: a multiple of the sweeps' 32- and
+// 24-step loop bodies, so that a tile is a whole number of bodies in either direction) and a stride of
+// TS = T + 64 records; S = nbands*TS*64 elements in total; padding carries mask 0.
 // Every skewed array also has EU_SKEW_SLACK elements of zeroed slack in front of element 0.
 #define EU_SKEW_SLACK (64 * 64)
 #ifndef EU_RED_ELEMS
@@ -143,6 +145,8 @@ struct euler_sim {
   unsigned int* fbits_fwd; unsigned int* fbits_bwd;   // fluid flags of the sweeps, 8 steps to a dword (k_pack_fbits)
   int fb_stride;          // words per band and lane
   int4* band_ranges;      // per band: active block ranges of the forward / backward sweeps (per solve)
+  int tile_nt;            // EULER_PRECOND_IC0_TILE: tiles per band (include/euler.h precond_tile_units)
+  uint8_t* tile_fluid;    // [nbands][n_units]: tiles that hold fluid (per solve)
   double* rowmajor_tmp;   // lazily allocated C doubles for euler_get/set_field of skewed arrays
   PcgScalars* sc;
   PcgScalars* sc_host;    // pinned

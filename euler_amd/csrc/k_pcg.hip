@@ -496,7 +496,18 @@ struct SweepArgs {
   int force;
   int* error;
   unsigned long long* timeline;   // [nbands][8] {entry, first block ready, exit, blocks << 32 | stalled blocks, 4 development words} (euler_sweep_timeline)
+  // tile-local IC(0) (EULER_PRECOND_IC0_TILE; k_sweep_skew<OP, false, true>, k_sweep_simple): a band's n_units units of 96
+  // records are cut into tile_nt tiles, tile k = records [96 * (k * n_units / tile_nt), 96 * ((k + 1) * n_units / tile_nt))
+  int n_units, tile_nt;           // tile_nt = 0: the reference's IC(0)
+  const uint8_t* tile_fluid;      // [nbands][tile_nt]: does the tile hold a fluid cell (k_tile_flags, per solve)
 };
+// does record t start a tile (are the couplings arriving from record t - 1 cut)?
+__host__ __device__ __forceinline__ int tile_lo(int n_units, int nt, int k) { return 96 * (int)((long long)k * n_units / nt); }
+__device__ __forceinline__ bool tile_start(int n_units, int nt, int t) {
+  if (t % 96) return false;
+  const int u = t / 96, k = (int)(((long long)u * nt + n_units - 1) / n_units);
+  return (int)((long long)k * n_units / nt) == u;
+}
 
 template <int OP>
 __device__ __forceinline__ double sweep_cell(uint8_t m, double in, double pre_here, double own_val, double own_pre,
@@ -542,9 +553,15 @@ __global__ __launch_bounds__(1024) void k_sweep_simple(SweepArgs a) {
       double r = 0.0;
       if (m & CM_FLUID) {   // fluid cells are interior: the neighbours exist
         const size_t io = skew_index(g, BWD ? x + 1 : x - 1, y), in_ = skew_index(g, x, BWD ? y + 1 : y - 1);
-        const double own_val = OP == SW_FACTOR ? a.pre[io] : dst[io];
-        const double nb_val = OP == SW_FACTOR ? a.pre[in_] : dst[in_];
-        const double own_pre = OP == SW_FORWARD ? a.pre[io] : 0.0, nb_pre = OP == SW_FORWARD ? a.pre[in_] : 0.0;
+        double own_val = OP == SW_FACTOR ? a.pre[io] : dst[io];
+        double nb_val = OP == SW_FACTOR ? a.pre[in_] : dst[in_];
+        double own_pre = OP == SW_FORWARD ? a.pre[io] : 0.0, nb_pre = OP == SW_FORWARD ? a.pre[in_] : 0.0;
+        if (a.tile_nt > 0) {   // tile-local IC(0): a cut coupling carries what the wavefront carries into a tile
+          const int l = y & 63, t = x + l;
+          const bool cut = tile_start(a.n_units, a.tile_nt, BWD ? t + 1 : t);
+          if (cut) { own_val = 0.0; own_pre = 1.0; }                                   // forward: (-1 * 1) * (+0) = -0.0
+          if (cut || l == (BWD ? 63 : 0)) { nb_val = 0.0; nb_pre = 1.0; }
+        }
         r = sweep_cell<OP>(m, OP == SW_FACTOR ? 0.0 : a.in[i], a.pre[i], own_val, own_pre, nb_val, nb_pre);
       }
       dst[i] = r;
@@ -624,21 +641,34 @@ struct SweepShared {
   unsigned int abort;
   int ord;
 };
+struct SweepSharedTile {              // tile-local sweeps have no hand-off: the same members, never touched
+  double pub[1][64];
+  double bnd[1][SW_BLK];
+  unsigned int dep_done, pub_done, comp_done, abort;
+  int ord;
+};
 __device__ __forceinline__ unsigned int lds_get(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_put(unsigned int* p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #define SW_COMPILER_FENCE() asm volatile("" ::: "memory")
 
-template <int OP, bool XG = false>
-__global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
-  __shared__ SweepShared sh;
+// TILE (EULER_PRECOND_IC0_TILE): the same compute wave without any hand-off - one 64-thread workgroup per (tile, band),
+// grid (tile_nt, bands of this rank); the tile's records are the wave's range and it starts from the constants a band
+// starts from.  Every tile is independent: hundreds to thousands of waves stream at once and the sweeps are bound by HBM
+// bandwidth instead of by the dependency chain of a lone wave per band.
+template <int OP, bool XG = false, bool TILE = false>
+__global__ __launch_bounds__(TILE ? 64 : 192) void k_sweep_skew(SweepArgs a) {
+  __shared__ typename std::conditional<TILE, SweepSharedTile, SweepShared>::type sh;
   const int lane = threadIdx.x & 63;
   const int role = threadIdx.x >> 6;                  // 0 compute, 1 announce, 2 fetch boundaries
-  if (threadIdx.x == 0) {
-    sh.ord = (int)(atomicAdd(a.ticket, 1u) - a.ticket_base);        // position in the band pipeline
-    sh.dep_done = 0; sh.pub_done = 0; sh.comp_done = 0; sh.abort = 0;
+  int ord = 0;
+  if (!TILE) {
+    if (threadIdx.x == 0) {
+      sh.ord = (int)(atomicAdd(a.ticket, 1u) - a.ticket_base);        // position in the band pipeline
+      sh.dep_done = 0; sh.pub_done = 0; sh.comp_done = 0; sh.abort = 0;
+    }
+    __syncthreads();
+    ord = __builtin_amdgcn_readfirstlane(sh.ord);
   }
-  __syncthreads();
-  const int ord = __builtin_amdgcn_readfirstlane(sh.ord);
   if (!a.force && pcg_idle(a.sc)) return;
   const unsigned long long t_entry = wall_clock64();
   constexpr bool BWD = OP == SW_BACKWARD;
@@ -648,10 +678,10 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   const int X = g.T - 63, T = g.T, TS = g.TS, nb = g.nbands;   // X: hand-off columns live in step space, [0, T - 63) (T is even: g.X or g.X + 1)
   // `ord` counts this launch's (= this rank's) bands in sweep order; gord is the position in the
   // global band pipeline, which also names the hand-off rows (forwarded rank to rank when coupled)
-  const int band = BWD ? a.band_lo + a.nb_local - 1 - ord : a.band_lo + ord;
+  const int band = TILE ? a.band_lo + (int)blockIdx.y : (BWD ? a.band_lo + a.nb_local - 1 - ord : a.band_lo + ord);
   const int gord = BWD ? nb - 1 - band : band;
-  const bool has_prev = ord > 0 || (a.couple && gord > 0);            // a band before us in sweep order
-  const bool publish = ord + 1 < a.nb_local || (a.couple && gord + 1 < nb);
+  const bool has_prev = !TILE && (ord > 0 || (a.couple && gord > 0));            // a band before us in sweep order
+  const bool publish = !TILE && (ord + 1 < a.nb_local || (a.couple && gord + 1 < nb));
   unsigned long long* gr_out = a.granules + (size_t)gord * a.gran_stride * 2;
   const unsigned long long* gr_in = a.granules + (size_t)(has_prev ? gord - 1 : 0) * a.gran_stride * 2;
   if (XG) {   // the band pipeline continues across GPUs: same granules, same epochs, system-scope accesses (below)
@@ -672,7 +702,11 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   const int full_blocks = BODY_HALF * (((T + SW_BLK - 1) / SW_BLK + BODY_HALF - 1) / BODY_HALF);
   const int ncolblk = (X + SW_BLK - 1) / SW_BLK;
   int B0 = 0, B1 = full_blocks, win_lo = 0, win_hi = ncolblk;
-  if (RANGED && a.ranges) {
+  if (TILE) {   // the tile's records [t0, t1): whole groups of 96 steps in either direction (T is a multiple of 96)
+    if (a.tile_fluid && !a.tile_fluid[(size_t)band * a.tile_nt + blockIdx.x]) return;   // nothing to do: pre stays, q and z are +0 (zeroed per solve)
+    const int t0 = tile_lo(a.n_units, a.tile_nt, (int)blockIdx.x), t1 = tile_lo(a.n_units, a.tile_nt, (int)blockIdx.x + 1);
+    B0 = (BWD ? T - t1 : t0) / SW_BLK; B1 = (BWD ? T - t0 : t1) / SW_BLK;
+  } else if (RANGED && a.ranges) {
     const int4 mine = a.ranges[band];
     B0 = BWD ? mine.z : mine.x; B1 = BWD ? mine.w : mine.y;
     if (B0 >= B1) return;                              // no fluid in this band
@@ -688,7 +722,7 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
 
   // =========================== helper waves: the band hand-off ===================================
   // wave 1 announces this band's edge values to the next band, wave 2 fetches the previous band's
-  if (role == 1) {
+  if (!TILE && role == 1) {
     if (!publish) return;
     const int t8 = lane >> 3, k8 = lane & 7;            // this lane serves group (next + t8), column k8 of it
     auto announce = [&](int col, double v, bool on) {
@@ -727,7 +761,7 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
     announce(SW_BLK * (B1 - 8), sh.pub[(SW_BLK * B1 - 1) & (SW_RING - 1)][EDGE], lane == 0);
     return;
   }
-  if (role == 2) {
+  if (!TILE && role == 2) {
     if (!has_prev) return;
     // Four polls are kept in flight (re-issued as they are retired, so they space themselves a quarter
     // of a round trip apart): a granule is then seen about half a round trip after it lands instead
@@ -1011,9 +1045,10 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   };
   typedef std::integral_constant<bool, true> yes_t;
   typedef std::integral_constant<bool, false> no_t;
-  if (has_prev) { if (publish) sweep(yes_t(), yes_t()); else sweep(yes_t(), no_t()); }
+  if constexpr (TILE) sweep(no_t(), no_t());
+  else if (has_prev) { if (publish) sweep(yes_t(), yes_t()); else sweep(yes_t(), no_t()); }
   else          { if (publish) sweep(no_t(), yes_t()); else sweep(no_t(), no_t()); }
-  if (lane == 0) {
+  if (!TILE && lane == 0) {
     unsigned long long* tl = a.timeline + (size_t)ord * 8;
     tl[0] = t_entry; tl[1] = t_first; tl[2] = wall_clock64(); tl[3] = ((unsigned long long)(B1 - B0) << 32) | stalls;
   }
@@ -1035,6 +1070,9 @@ static SweepArgs make_sweep_args(euler_sim* S, int op, int force) {
   a.ticket_base = S->ticket_base; a.epoch = S->epoch;
   a.sc = S->sc; a.force = force; a.error = &S->ms->error;
   a.timeline = S->sweep_timeline;
+  a.n_units = S->geom.T / 96;
+  a.tile_nt = S->cfg.precond == EULER_PRECOND_IC0_TILE ? S->tile_nt : 0;
+  a.tile_fluid = S->tile_fluid;
   return a;
 }
 
@@ -1091,7 +1129,27 @@ __global__ __launch_bounds__(256) void k_pack_fbits(const uint8_t* __restrict__ 
   const size_t o = ((size_t)band * fb_stride + gi) * 64 + lane;
   fwd[o] = wf; bwd[o] = wb;
 }
+// tile-local IC(0): which tiles hold fluid at all (the others are skipped by all three sweeps)
+__global__ __launch_bounds__(64) void k_tile_flags(const unsigned int* __restrict__ fwd, int fb_stride, int n_units, int nt,
+                                                   uint8_t* __restrict__ flags, int band_lo) {
+  const int band = band_lo + blockIdx.y, k = blockIdx.x;
+  const int b0 = tile_lo(n_units, nt, k) / 8, b1 = tile_lo(n_units, nt, k + 1) / 8;
+  const unsigned int* p = fwd + ((size_t)band * fb_stride + b0) * 64 + threadIdx.x;
+  unsigned int w = 0;
+  for (int b = b0; b < b1; ++b, p += 64) w |= *p;
+  const bool any = __ballot(w != 0) != 0;
+  if (threadIdx.x == 0) flags[(size_t)band * nt + k] = any;
+}
 int eu_launch_band_ranges(euler_sim* S) {
+  if (S->cfg.precond == EULER_PRECOND_IC0_TILE) {   // no band pipeline: the packed fluid flags and the per-tile census
+    const int nbl = S->band_hi - S->band_lo;
+    const size_t n = (size_t)nbl * S->fb_stride * 64;
+    LAUNCH(S, KC_BUILD_SYSTEM, k_pack_fbits, dim3((unsigned)((n + 255) / 256)), dim3(256), S->cellmask, S->geom, S->fbits_fwd, S->fbits_bwd,
+           S->fb_stride, S->band_lo, nbl);
+    LAUNCH(S, KC_BUILD_SYSTEM, k_tile_flags, dim3(S->tile_nt, nbl), dim3(64), S->fbits_fwd, S->fb_stride, S->geom.T / 96, S->tile_nt,
+           S->tile_fluid, S->band_lo);
+    return EULER_OK;
+  }
   // a rank needs the ranges of its own bands and of the band before / after its slab (the hand-off windows)
   const int b0 = S->band_lo > 0 ? S->band_lo - 1 : 0, b1 = S->band_hi < S->geom.nbands ? S->band_hi + 1 : S->geom.nbands;
   LAUNCH(S, KC_BUILD_SYSTEM, k_band_ranges, dim3(b1 - b0), dim3(1024), S->count, S->X, S->Y, S->geom.T, S->band_ranges, b0);
@@ -1154,6 +1212,13 @@ static int comm_halo_s(euler_sim* S) {
 
 template <int OP>
 static int launch_sweep(euler_sim* S, int cls, int force) {
+  if (S->cfg.precond == EULER_PRECOND_IC0_TILE && S->cfg.sweep_mode != EULER_SWEEP_SIMPLE) {
+    // tile-local IC(0): every (tile, band) is an independent wavefront; nothing crosses a slab boundary either
+    SweepArgs a = make_sweep_args(S, OP, force);
+    if (force) a.tile_fluid = nullptr;   // single building blocks (euler_pcg_op) may run before the per-solve census
+    LAUNCH(S, cls, (k_sweep_skew<OP, false, true>), dim3(S->tile_nt, S->band_hi - S->band_lo), dim3(64), a);
+    return EULER_OK;
+  }
   if (S->cfg.sweep_mode != EULER_SWEEP_SIMPLE) {
     constexpr bool BWD = OP == SW_BACKWARD;
     const int nb = S->geom.nbands, nbl = S->band_hi - S->band_lo;
@@ -1285,7 +1350,7 @@ int eu_launch_project(euler_sim* S, float dt) {
     hipLaunchKernelGGL(k_nonzero_from_comm, dim3(1), dim3(1), 0, S->stream, S->sc);
   }
   // if (!all_zero(r)) { ... }: every kernel below is a no-op when sc->nonzero == 0
-  if (S->cfg.precond == EULER_PRECOND_IC0 && (rc = launch_sweep<SW_FACTOR>(S, KC_PRECON_FACTOR, 0))) return rc;   // once per solve
+  if (S->cfg.precond != EULER_PRECOND_JACOBI && (rc = launch_sweep<SW_FACTOR>(S, KC_PRECON_FACTOR, 0))) return rc;   // once per solve
   if ((rc = launch_precondition(S, 0))) return rc;
   LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<true>, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->s), LOC(S->z),
          LOC(S->cellmask), S->e_cnt, S->sc, 0, 0.0);

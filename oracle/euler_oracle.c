@@ -448,7 +448,67 @@ void eo_build_system(eo_sim* s, float dt, const float* u, const float* v) {
     }
 }
 
+/* EXTENSION (this build's, no reference counterpart): where the tile-local preconditioner cuts a band (euler_oracle.h) */
+int eo_tile_start(int X, int tile_units, int t) {
+  if (tile_units <= 0) return t == 0;
+  const int n_units = (X + 63 + 95) / 96;
+  int nt = (n_units + tile_units / 2) / tile_units;
+  if (nt < 1) nt = 1;
+  if (nt > n_units) nt = n_units;
+  if (t % 96) return 0;
+  const int unit = t / 96;
+  /* unit starts a tile iff unit == floor(k * n_units / nt) for some k */
+  for (int k = (int)((long long)unit * nt / n_units); k <= nt && (long long)k * n_units / nt <= unit; ++k)
+    if ((int)((long long)k * n_units / nt) == unit) return 1;
+  return 0;
+}
+
+/* Tile-local IC(0): the same three recurrences as below restricted to blocks.  A coupling that is cut contributes
+ * the value the product's wavefront carries into a tile: precon 0 in the factor, the term -0.0 in the forward solve
+ * (= (-1 * precon) * (+0)), z = +0 in the backward solve. */
+static void apply_preconditioner_tiled(eo_sim* s, const double* r, double* z) {
+  int X = s->X, Y = s->Y;
+  size_t C = (size_t)X * (size_t)Y;
+  double* pre = s->precon; double* q = s->q;
+  uint8_t* start = (uint8_t*)malloc((size_t)X + 64 + 1);   /* start[t]: record t begins a tile */
+  for (int t = 0; t <= X + 63; ++t) start[t] = (uint8_t)eo_tile_start(X, s->tile_units, t);
+  for (int y = 0; y < Y; ++y)
+    for (int x = 0; x < X; ++x) {
+      if (!FLUID(s, y, x)) continue;
+      size_t i = AT(s, y, x);
+      const int l = y & 63, t = x + l, cut = start[t];
+      double a = s->a_diag[i];
+      double cl = -1 * (cut ? 0.0 : pre[i - 1]);
+      double cb = -1 * ((cut || l == 0) ? 0.0 : pre[i - X]);
+      double e = a - cl * cl - cb * cb;
+      if (e < 0.25 * a) e = a != 0 ? a : 1;
+      pre[i] = 1 / sqrt(e);
+    }
+  memset(q, 0, C * sizeof(double));
+  for (int y = 0; y < Y; ++y)
+    for (int x = 0; x < X; ++x) {
+      if (!FLUID(s, y, x)) continue;
+      size_t i = AT(s, y, x);
+      const int l = y & 63, t = x + l, cut = start[t];
+      double t_ = r[i] - (cut ? -0.0 : -1 * pre[i - 1] * q[i - 1])
+                       - ((cut || l == 0) ? -0.0 : -1 * pre[i - X] * q[i - X]);
+      q[i] = t_ * pre[i];
+    }
+  memset(z, 0, C * sizeof(double));
+  for (int y = Y; y--;)
+    for (int x = X; x--;) {
+      if (!FLUID(s, y, x)) continue;
+      size_t i = AT(s, y, x);
+      const int l = y & 63, t = x + l, cut = start[t + 1];   /* the right / upper neighbour sits in record t + 1 */
+      double t_ = q[i] - (FLUID(s, y, x + 1) ? -1 : 0) * pre[i] * (cut ? 0.0 : z[i + 1])
+                       - (FLUID(s, y + 1, x) ? -1 : 0) * pre[i] * ((cut || l == 63) ? 0.0 : z[i + X]);
+      z[i] = t_ * pre[i];
+    }
+  free(start);
+}
+
 void eo_apply_preconditioner(eo_sim* s, const double* r, double* z) {
+  if (s->tile_units > 0) { apply_preconditioner_tiled(s, r, z); return; }
   int X = s->X, Y = s->Y;
   size_t C = (size_t)X * (size_t)Y;
   double* pre = s->precon; double* q = s->q;
