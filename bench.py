@@ -1,24 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py — BASELINE.json's metric on BASELINE.json's configuration.
+"""bench.py — BASELINE.json's metric on BASELINE.json's configurations.
 
-metric   cells*steps/s of the whole sim_step() path (one step = one 0.1 s frame = up to 8 CFL
-         substeps, each with a <=100-iteration PCG pressure projection), plus the achieved HBM
-         rate of the dominant pressure-solve kernel against the MI355X roofline.
-workload N=1: configs[1], the 1024x1024 dam break (block layout upscaled), synthetic.
-         The reference's precision mix is kept: float fields, double PCG vectors.
-         The dam first falls freely: for ~22 frames the divergence is exactly zero and the
-         reference's `all_zero(r)` test (main.c:742) skips the solve, so a frame costs < 1 ms.  From
-         then on float rounding of the growing velocities leaves a residual above the 1e-6 tolerance
-         and EVERY substep runs the full 100 PCG iterations (8 substeps/frame at peak).  The bench
-         "prerolls" untimed until a frame needs >= 100 PCG iterations, so the timed window always
-         lies in the expensive phase, never in the free-fall phase.
+metric    cells*steps/s of the whole sim_step() path (one step = one 0.1 s frame = up to 8 CFL substeps, each with a
+          PCG pressure projection), plus the achieved HBM rate of the pressure solve against the MI355X roofline.
 
-One JSON line on stdout (rank 0).  Inputs are resident in HBM when the timed region starts.
+headline  N=1: configs[2], the 8192x8192 half-filled tank, "pressure-solve roofline run" (SURVEY 8d config 3): tol = 0 and
+          max_iterations = 100, so every substep runs exactly 100 PCG iterations.  It runs in the ROOFLINE MODE SURVEY 7 (hard
+          part 1b) and 8d name: the tile-local IC(0) preconditioner (EULER_PRECOND_IC0_TILE, include/euler.h) - the reference's
+          recurrences restricted to 64-row x 16-column blocks, one pass over memory per iteration - which is NOT the reference's
+          sequence of iterates (same solution where PCG converges; tests/test_gpu_tile_precond.py).  The SAME workload in the
+          parity mode (the reference's own IC(0), bit-identical iterates) is measured right beside it ("exact_ic0"), and so
+          are configs[1] (1024^2 dam break, parity mode, checked in-run against the oracle), the 16384^2 projection and the
+          time both modes need to SOLVE a system to the reference's tolerance.  Every number carries its mode.
+
+roofline  bytes are counted three ways and named: `frac_traffic` = HBM bytes rocprofv3's FETCH_SIZE / WRITE_SIZE counters saw
+          for the kernel in a live PMC pass of this very workload (child processes of this run, calibrated on a copy of known
+          size in the same pass) / launch time; `frac_active` = SURVEY 8d's algorithmic bytes x FLUID cells (what the
+          kernels visit) / time; `frac_dense` = the same x ALL X*Y cells (the reference's dense loops; exceeds what HBM moved on
+          sparse scenes and is never the headline).  `roofline.frac` is the traffic-based one when the PMC pass ran.
+
+One JSON line on stdout (rank 0).  Inputs are resident in HBM when a timed region starts.
 """
 import argparse
-import ctypes as C
+import glob
 import json
 import os
+import shutil
+import sqlite3
 import subprocess
 import sys
 import tempfile
@@ -29,33 +37,46 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
-# algorithmic bytes per grid cell per launch (w = 8 for double vectors, 1 mask byte)
+# algorithmic bytes per grid cell per launch (w = 8 for double vectors, 1 mask byte per kernel)
 W = 8
 ALGO_BYTES = {
     "forward_solve": 3 * W + 1,    # read r, precon; write q
-    "backward_solve": 3 * W + 1,   # read q, precon; write z     (dot(z,r) is a separate launch here)
-    "apply_a": 2 * W + 1,          # read s; write z (+ in-register dot partial)
+    "backward_solve": 3 * W + 1,   # read q, precon; write z
+    "apply_a": 2 * W + 1,          # read s; write A s (+ in-register dot partial)
     "dot": 2 * W + 1,              # read z, r
     "update_pr": 6 * W + 1,        # read s, z, p, r; write p, r
     "update_search": 3 * W + 1,    # read z, s; write s
+    "precond_tile": 5 * W + 1,     # tile-local mode: read r, A s, precon; write r, z  (K2's r half, K3, K4 and dot in one pass)
 }
-PCG_BYTES_PER_CELL_ITER = 18 * W + 5   # 149 B, the figure BASELINE.md prescribes for IC(0) PCG
+APPLY_A_FUSED = {"ic0": 5 * W + 1,       # update_search fused in: read s, z; write s', A s'  (+ neighbours from cache)
+                 "ic0_tile": 6 * W + 1}  # ... and the previous iteration's p += alpha s: read + write p as well
+# whole PCG iteration per cell (SURVEY 8d "Algorithmic bytes"): the reference's IC(0) as five kernels 18w+5; the tile-local
+# variant as the two passes it runs, 11w+2 - "the figure for that variant ... never the larger one"
+PCG_BYTES = {"ic0": 18 * W + 5, "ic0_tile": 11 * W + 2, "jacobi": 11 * W + 3}
+PCG_CLASSES = ["forward_solve", "backward_solve", "apply_a", "dot", "update_pr", "update_search", "precond_tile"]
+KERNEL_OF_CLASS = {"forward_solve": "k_sweep_skew<1", "backward_solve": "k_sweep_skew<2", "precon_factor": "k_sweep_skew<0",
+                   "apply_a": "k_search_apply", "dot": "k_dot_partial", "update_pr": "k_update_pr", "precond_tile": "k_precond_tile"}
+MODE_NAME = {"ic0": "parity mode: the reference's IC(0), bit-identical iterates",
+             "ic0_tile": "roofline mode: tile-local IC(0) (64x%d-cell blocks), NOT the reference's iterates (tolerance parity where PCG converges)",
+             "jacobi": "Jacobi stand-in, NOT the reference's iterates"}
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=1024, help="N of the NxN grid (default: configs[1] = 1024)")
-    ap.add_argument("--workload", default="dam_break", choices=["dam_break", "half_tank", "waterfall"])
+    ap.add_argument("--size", type=int, default=0, help="N of the NxN grid (default: configs[2] = 8192)")
+    ap.add_argument("--workload", default="half_tank", choices=["dam_break", "half_tank", "waterfall"])
     ap.add_argument("--dot-mode", default="tree", choices=["tree", "sequential"])
-    ap.add_argument("--precond", default="ic0", choices=["ic0", "jacobi", "ic0_tile"])
-    ap.add_argument("--tile-units", type=int, default=0)
+    ap.add_argument("--precond", default="ic0_tile", choices=["ic0", "jacobi", "ic0_tile"],
+                    help="ic0_tile = roofline mode (default), ic0 = parity mode (the reference's preconditioner)")
+    ap.add_argument("--tile-records", type=int, default=0)
+    ap.add_argument("--tol", type=float, default=None, help="PCG tolerance (default: 0 for half_tank = the roofline run, else the reference's 1e-6)")
     ap.add_argument("--max-preroll", type=int, default=400)
     ap.add_argument("--slab", default="local", choices=["local", "exact", "replicas"],
-                    help="N>1: slab-local IC(0) (scales; tolerance-only), exact coupling (the 1-GPU iterates; sweeps "
-                         "serialize across GPUs) or independent replicas")
+                    help="N>1, parity mode only: slab-local IC(0) (scales; tolerance-only), exact coupling (the 1-GPU iterates; sweeps "
+                         "serialize across GPUs) or independent replicas.  The roofline mode has no coupling between slabs at all.")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
                     help="N>1 exchange transport: the library's own RCCL communicator (C, no host code between kernels) "
                          "or the torch.distributed callbacks of euler_amd/slab.py")
@@ -63,19 +84,23 @@ def parse_args():
                     help="N>1: weak = N x (N*gpus) grid, one tank per row slab (default; the driver's scaling run); strong = the "
                          "N x N grid of --size split into row slabs (BASELINE configs[3]: --size 16384 --scaling strong)")
     ap.add_argument("--no-p2p", action="store_true",
-                    help="N>1: keep the per-iteration exchanges (3 scalar all-reduces, ghost rows) on the communicator instead of "
+                    help="N>1: keep the per-iteration exchanges (scalar all-reduces, ghost rows) on the communicator instead of "
                          "the peer-to-peer mailboxes of csrc/comm_p2p.hip")
     ap.add_argument("--grid-y-mult", type=int, default=0,
-                    help="diagnostics: run the N x (N*M) grid of an M-GPU weak-scaling job on the GPUs given (e.g. on one GPU: the "
-                         "single-GPU time of the 8-GPU job's grid)")
+                    help="diagnostics: run the N x (N*M) grid of an M-GPU weak-scaling job on the GPUs given")
     ap.add_argument("--force-slab", action="store_true",
                     help="N=1 diagnostics: run the communicator code path with one rank (every exchange still goes through RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the hipEvent per-kernel timing (used under rocprofv3)")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel class (diagnostics)")
+    ap.add_argument("--no-secondary", action="store_true", help="headline case only (no parity-mode / 1024^2 / 16384^2 / time-to-solution blocks)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 PMC passes (roofline.traffic is then null)")
+    ap.add_argument("--no-16384", action="store_true", help="skip the 16384^2 projection block")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # this process runs under rocprofv3 --pmc
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------ CPU baseline
 def build_native_oracle():
     """cpu_baseline leg only: compile the oracle for THIS host (reference flags -O3 -ffast-math
     -march=native, CMakeLists.txt:11,18, and strict IEEE) into a temp dir."""
@@ -89,14 +114,53 @@ def build_native_oracle():
     return out
 
 
-def cpu_baseline(sim, ea, steps_budget_s=12.0):
-    """Time the CPU oracle (kind 'port': the from-scratch restatement proven bit-identical to the
-    compiled reference at 100x40) on this host, single thread like the reference, starting from the
-    SAME state the GPU timing starts from.  Bounded sample: one frame (<= 8 substeps)."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_roofline_run(libs, tol):
+    """The oracle ('port': the from-scratch restatement proven bit-identical to the compiled reference at 100x40), single
+    thread like the reference, on a BOUNDED sample of the headline workload: the half-filled tank at 2048^2 (1/16 of the
+    8192^2 grid, same fluid fraction, same tol = 0 / 100 iterations per substep), one frame; plus configs[0]."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy as np
     import oracle_lib
-    libs = build_native_oracle()
+    res = {}
+    N = 2048
+    for name, so in libs.items():
+        o = oracle_lib.Oracle(N, N, lib_path=so).load_half_tank()
+        o.c.tol = tol
+        t0 = time.perf_counter()
+        o.step()
+        dt = time.perf_counter() - t0
+        res[name] = dict(value=N * N / dt, seconds=round(dt, 3), steps=1, substeps=int(o.c.total_substeps),
+                         pcg_iterations=int(o.c.total_pcg_iterations))
+        o.close()
+    try:      # BASELINE configs[0]: the reference's own grid and scenario (block layout, 100 x 40, 100 frames)
+        from euler_amd import scenarios as _sc
+        o = oracle_lib.Oracle(100, 40, lib_path=libs["reference_flags"]).load_text(_sc.dam_break())
+        t0 = time.perf_counter()
+        for _ in range(100):
+            o.step()
+        dt = time.perf_counter() - t0
+        res["_native"] = dict(value=4000 * 100 / dt, seconds=round(dt, 3), steps=100, substeps=int(o.c.total_substeps),
+                              pcg_iterations=int(o.c.total_pcg_iterations))
+        o.close()
+    except Exception as e:      # never let the extra figure break the bench line
+        res["_native"] = {"error": str(e)}
+    return res
+
+
+def cpu_from_gpu_state(sim, ea, libs, budget_s=10.0, max_steps=2):
+    """configs[1] block: the oracle from the SAME state the GPU timing starts from (single thread); also returns the strict
+    build's state after its frames for the in-run parity note."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
     res = {}
     snap = {n: sim.get(f) for f, n in ((ea.F_U, "u"), (ea.F_V, "v"), (ea.F_SOLID, "solid"), (ea.F_SOURCE, "source"),
                                         (ea.F_SINK, "sink"), (ea.F_COUNT, "count"), (ea.F_PREV_COUNT, "prev_count"),
@@ -114,59 +178,210 @@ def cpu_baseline(sim, ea, steps_budget_s=12.0):
         while True:
             o.step()
             nsteps += 1
-            if time.perf_counter() - t0 > steps_budget_s or nsteps >= 3:
+            if time.perf_counter() - t0 > budget_s or nsteps >= max_steps:
                 break
         dt = time.perf_counter() - t0
-        res[name] = dict(value=sim.X * sim.Y * nsteps / dt, seconds=dt, steps=nsteps,
+        res[name] = dict(value=sim.X * sim.Y * nsteps / dt, seconds=round(dt, 3), steps=nsteps,
                          substeps=int(o.c.total_substeps), pcg_iterations=int(o.c.total_pcg_iterations))
         if name == "strict":
             res["_oracle_after"] = (o.u.copy(), o.v.copy(), (o.count > 0).copy(), nsteps)
         o.close()
-    # BASELINE configs[0]: the reference's own grid and scenario (block layout, 100 x 40, 100 frames), the oracle only
-    try:
-        from euler_amd import scenarios as _sc
-        o = oracle_lib.Oracle(100, 40, lib_path=libs["reference_flags"]).load_text(_sc.dam_break())
-        t0 = time.perf_counter()
-        for _ in range(100):
-            o.step()
-        dt = time.perf_counter() - t0
-        res["_native"] = dict(value=4000 * 100 / dt, seconds=round(dt, 3), steps=100, substeps=int(o.c.total_substeps),
-                              pcg_iterations=int(o.c.total_pcg_iterations))
-        o.close()
-    except Exception as e:      # never let the extra figure break the bench line
-        res["_native"] = {"error": str(e)}
     return res
 
 
-PMC_KERNEL = {"forward_solve": "k_sweep_skew<1>", "backward_solve": "k_sweep_skew<2>", "precon_factor": "k_sweep_skew<0>",
-              "apply_a": "k_apply_a", "dot": "k_dot_partial", "update_pr": "k_update_pr", "update_search": "k_update_search<false>"}
-
-
-def pmc_traffic(size, workload, kernel_class):
-    """HBM bytes per launch of a kernel class from the committed PMC passes of the same workload
-    (profiles/pmc_traffic_<size>_<workload>.json, written by tools/summarize_profile.py from
-    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this very command); None if there is none."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic_%d_%s.json" % (size, workload))
+# ------------------------------------------------------------------------------------------------ live PMC passes
+def pmc_live(child_args, timeout_s=420):
+    """HBM bytes per launch of every kernel of THIS workload from two rocprofv3 PMC passes run as child processes of this
+    run (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950; MI355X_MICROARCH.md 'rocprofv3 PMC slots').  The guide's
+    corrections are not assumed but CALIBRATED in the same pass: the child also runs the library's copy probe, whose
+    launches move a known number of bytes (k_copy16: 2^30 read + 2^30 written), and the KiB the counters report for it give
+    the factor for reads (the guide: x2 for wide coalesced reads on gfx950) and for writes.  -> (dict kernel -> bytes, note)."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    out = {}
+    base = tempfile.mkdtemp(prefix="euler_pmc_")
+    env = dict(os.environ, TMPDIR="/tmp")
     try:
-        name = PMC_KERNEL.get(kernel_class, "")
-        kernels = json.load(open(p))["kernels"]
-        # template arguments added since a PMC file was written: k_sweep_skew<OP, XG>, k_dot_partial<EDGES>, k_search_apply<SLAB>
-        k = kernels.get(name) or kernels.get(name.replace(">", ", false>")) or kernels.get(name + "<false>")
-        return int(k["hbm_bytes_per_launch"]) if k else None
-    except (OSError, ValueError, KeyError):
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(base, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__)] + child_args
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+            dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, (r.stderr or "")[-300:])
+            con = sqlite3.connect(dbs[0])
+            tables = [t[0] for t in con.execute("select name from sqlite_master where type in ('table','view')")]
+            if "counters_collection" not in tables:
+                return None, "no counters_collection view in %s" % os.path.basename(dbs[0])
+            rows = con.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name=? group by kernel_name",
+                               (counter,)).fetchall()
+            out[counter] = {k.split("(")[0].replace("void ", ""): (n, v) for k, n, v in rows}
+        cal = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            probe = [v for k, v in out[counter].items() if k.startswith("k_copy16")]
+            if not probe or probe[0][1] <= 0:
+                return None, "copy probe missing from the %s pass" % counter
+            cal[counter] = float(1 << 30) / (probe[0][1] * 1024.0)      # true bytes per reported byte
+        traffic = {}
+        for k, (n, v) in out["FETCH_SIZE"].items():
+            w = out["WRITE_SIZE"].get(k, (0, 0.0))[1]
+            traffic[k] = {"launches": int(n), "read_bytes": v * 1024.0 * cal["FETCH_SIZE"], "write_bytes": w * 1024.0 * cal["WRITE_SIZE"]}
+            traffic[k]["bytes"] = traffic[k]["read_bytes"] + traffic[k]["write_bytes"]
+        note = ("live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (separate child processes), KiB -> bytes, "
+                "calibrated on the copy probe of the same pass: reads x%.3f (guide: x2 on gfx950), writes x%.3f"
+                % (cal["FETCH_SIZE"], cal["WRITE_SIZE"]))
+        return traffic, note
+    except subprocess.TimeoutExpired:
+        return None, "rocprofv3 pass timed out after %d s" % timeout_s
+    except Exception as e:      # the bench line must survive a profiler problem
+        return None, "PMC pass failed: %r" % (e,)
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+
+
+def traffic_of(traffic, cls):
+    """bytes per launch of a kernel class from a pmc_live() table (kernel names carry template arguments)."""
+    if not traffic:
         return None
+    key = KERNEL_OF_CLASS.get(cls)
+    if not key:
+        return None
+    hits = [(k, v) for k, v in traffic.items() if k.startswith(key)]
+    if cls == "apply_a":      # iterations >= 1 run k_search_apply; the first of a solve k_apply_a (few launches)
+        hits = hits or [(k, v) for k, v in traffic.items() if k.startswith("k_apply_a")]
+    if not hits:
+        return None
+    return max(hits, key=lambda kv: kv[1]["launches"])[1]["bytes"]
 
 
-def cpu_model():
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                return line.split(":", 1)[1].strip()
-    except OSError:
-        pass
-    return "unknown"
+# ------------------------------------------------------------------------------------------------ one measured case
+def load_workload(sim, scenarios, workload, tiles=1):
+    if workload == "dam_break":
+        sim.load_text(scenarios.stacked(scenarios.dam_break(), tiles), upscale=True)
+    elif workload == "waterfall":
+        sim.load_text(scenarios.stacked(scenarios.waterfall(), tiles), upscale=True)
+    else:
+        sim.load_half_tank()
 
 
+def preroll_into_solves(sim, max_preroll):
+    """untimed: advance to the first frame whose substeps run PCG iterations at all (a dam break first falls freely for ~22
+    frames: zero divergence, the reference's all_zero(r) test skips the solve, main.c:742)"""
+    n = 0
+    while n < max_preroll:
+        sim.step()
+        n += 1
+        if sim.stats().last_pcg_iterations >= 100:
+            break
+    return n
+
+
+def kernel_rows(prof, precond, cells_fluid, traffic, fused_search):
+    """per kernel class: launch time and the byte counts -> GB/s"""
+    rows = {}
+    for name, (ms, launches) in prof.items():
+        e = {"ms_total": round(ms, 3), "launches": int(launches), "avg_us": round(1e3 * ms / launches, 2)}
+        b = ALGO_BYTES.get(name)
+        if name == "apply_a" and fused_search:
+            b = APPLY_A_FUSED.get(precond, b)
+            e["note"] = ("update_search fused in" + (" + the previous iteration's p += alpha s" if precond == "ic0_tile" else "")
+                         + ": %d algorithmic B/cell" % b)
+        if b:
+            sec = ms / launches * 1e-3
+            e["bytes_per_cell"] = b
+            e["GBps_active"] = round(b * cells_fluid / sec / 1e9, 1)
+            t = traffic_of(traffic, name)
+            if t:
+                e["traffic_bytes_per_launch"] = int(t)
+                e["GBps_traffic"] = round(t / sec / 1e9, 1)
+        rows[name] = e
+    return rows
+
+
+def time_frames(sim, ea, grp, args, precond, steps, warmup_done, warmup, big):
+    """the timed region + per-kernel HIP-event timing.  Large grids: every PCG class is bracketed inside the timed region
+    (an event pair costs microseconds, the kernels hundreds); small grids (launches of ~10 us): only the dominant class,
+    the others in a second pass of the same length."""
+    for _ in range(max(warmup - warmup_done, 0)):
+        sim.step()
+    dominant = {"ic0": "backward_solve", "ic0_tile": "apply_a", "jacobi": "update_pr"}[precond]
+    classes_all = ea.profile_class_names() if args.profile_all else PCG_CLASSES
+    timed = [] if args.no_kernel_timing else (classes_all if big else [dominant])
+    sim.profile_reset()
+    sim.profile_enable(timed)
+    st0 = sim.stats()
+    elapsed = grp.timed(sim.step, steps)
+    st1 = sim.stats()
+    prof = sim.profile() if timed else {}
+    sim.profile_enable([])
+    iters = st1.total_pcg_iterations - st0.total_pcg_iterations
+    iters2 = iters
+    if not args.no_kernel_timing and not big:
+        sim.profile_reset()
+        sim.profile_enable([k for k in classes_all if k != dominant])
+        for _ in range(steps):
+            sim.step()
+        iters2 = sim.stats().total_pcg_iterations - st1.total_pcg_iterations
+        for k, v in sim.profile().items():
+            prof.setdefault(k, v)
+        sim.profile_enable([])
+    per_iter_ms = sum(prof[k][0] / (iters if (big or k == dominant) else iters2) for k in PCG_CLASSES
+                      if k in prof and (iters if (big or k == dominant) else iters2))
+    return dict(elapsed=elapsed, st0=st0, st1=st1, prof=prof, iters=iters, per_iter_ms=per_iter_ms, dominant=dominant,
+                substeps=st1.total_substeps - st0.total_substeps)
+
+
+def summarize(t, size_x, size_y, precond, tile_w, traffic, traffic_note, steps, fused_search=True):
+    """value + per-kernel rows + roofline object (dominant kernel = the PCG class with the largest total time) + whole-iteration aggregate"""
+    cells = size_x * size_y
+    fluid = int(t["st1"].fluid_cells)
+    rows = kernel_rows(t["prof"], precond, fluid, traffic, fused_search)
+    pcg_rows = {k: v for k, v in rows.items() if k in PCG_CLASSES}
+    per_iter = [k for k in pcg_rows if rows[k]["launches"] >= 0.5 * max(t["iters"], 1)]
+    roof = None
+    if pcg_rows:
+        dom = max(pcg_rows, key=lambda k: pcg_rows[k]["ms_total"])
+        r = pcg_rows[dom]
+        sec = r["avg_us"] * 1e-6
+        b = r.get("bytes_per_cell", 0)
+        tr = r.get("traffic_bytes_per_launch")
+        active = b * fluid / sec / 1e9
+        achieved = (tr / sec / 1e9) if tr else active
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": int(tr) if tr else None,
+                "frac_traffic": round(tr / sec / 1e9 / HBM_PEAK_GBPS, 4) if tr else None,
+                "frac_active": round(active / HBM_PEAK_GBPS, 4),
+                "frac_dense": round(b * cells / sec / 1e9 / HBM_PEAK_GBPS, 4),
+                "achieved_is": "PMC traffic / launch time" if tr else "algorithmic bytes x fluid cells / launch time (no PMC pass)",
+                "algorithmic_bytes_per_cell": b, "algorithmic_bytes_per_launch_active": b * fluid,
+                "avg_launch_us": r["avg_us"], "launches": r["launches"], "fluid_fraction": round(fluid / cells, 4),
+                "traffic_source": traffic_note,
+                "note": "frac_dense counts ALL X*Y cells like the reference's dense loops and may exceed 1 on sparse scenes; the kernels "
+                        "visit fluid cells only, so frac_active / frac_traffic are what the memory system did"}
+    agg = None
+    if t["per_iter_ms"]:
+        sec = t["per_iter_ms"] * 1e-3
+        bpc = PCG_BYTES[precond]
+        tsum = None
+        if traffic:
+            parts = [rows[k].get("traffic_bytes_per_launch") for k in per_iter]
+            tsum = sum(parts) if parts and all(parts) else None
+        agg = {"us_per_iteration": round(1e3 * t["per_iter_ms"], 2), "bytes_per_cell_iteration": bpc,
+               "launches_per_iteration": len(per_iter),
+               "GBps_active": round(bpc * fluid / sec / 1e9, 1), "frac_active": round(bpc * fluid / sec / 1e9 / HBM_PEAK_GBPS, 4),
+               "GBps_traffic": round(tsum / sec / 1e9, 1) if tsum else None,
+               "frac_traffic": round(tsum / sec / 1e9 / HBM_PEAK_GBPS, 4) if tsum else None,
+               "frac_dense": round(bpc * cells / sec / 1e9 / HBM_PEAK_GBPS, 4)}
+    return {"mode": MODE_NAME[precond] % tile_w if precond == "ic0_tile" else MODE_NAME[precond],
+            "value": cells * steps / t["elapsed"], "unit": "cells*steps/s", "ms_per_step": 1e3 * t["elapsed"] / steps,
+            "substeps": int(t["substeps"]), "pcg_iterations": int(t["iters"]),
+            "cells_substeps_per_s": cells * t["substeps"] / t["elapsed"],
+            "fluid_cells": fluid, "markers": int(t["st1"].n_markers), "last_residual": float(t["st1"].last_residual),
+            "roofline": roof, "pcg_iteration": agg, "kernels": rows}
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -183,6 +398,25 @@ def main():
         sys.stdout.write(r.stdout)
         sys.stdout.flush()
         sys.exit(r.returncode)
+
+    N = args.size or 8192
+    tol = args.tol if args.tol is not None else (0.0 if args.workload == "half_tank" else None)
+    single = args.gpus == 1 and not args.force_slab and "RANK" not in os.environ
+    child_common = ["--size", str(N), "--workload", args.workload, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-kernel-timing",
+                    "--no-secondary", "--no-pmc", "--pmc-child", "--dot-mode", args.dot_mode, "--tile-records", str(args.tile_records)]
+    if args.tol is not None:
+        child_common += ["--tol", repr(args.tol)]
+
+    # ---- live PMC passes FIRST (child processes; this process has not touched the GPU yet and holds no HBM)
+    traffic = traffic_note = None
+    traffic_exact = traffic_exact_note = None
+    if single and not args.no_pmc and not args.pmc_child:
+        t0 = time.perf_counter()
+        traffic, traffic_note = pmc_live(child_common + ["--precond", args.precond])
+        if not args.no_secondary and args.precond != "ic0":
+            traffic_exact, traffic_exact_note = pmc_live(child_common + ["--precond", "ic0"])
+        print("bench: PMC passes took %.0f s (%s)" % (time.perf_counter() - t0, traffic_note), file=sys.stderr)
+
     # stdout carries exactly ONE line, the JSON: whatever native libraries print on fd 1 while the job runs
     # (RCCL writes its version banner there when a communicator is created) is diverted to stderr
     sys.stdout.flush()
@@ -203,16 +437,16 @@ def main():
     import euler_amd as ea
     from euler_amd import scenarios
 
-    N = args.size
     dot_mode = ea.DOT_TREE if args.dot_mode == "tree" else ea.DOT_SEQUENTIAL
-    precond = {"ic0": ea.PRECOND_IC0, "jacobi": ea.PRECOND_JACOBI, "ic0_tile": ea.PRECOND_IC0_TILE}[args.precond]
+    PC = {"ic0": ea.PRECOND_IC0, "jacobi": ea.PRECOND_JACOBI, "ic0_tile": ea.PRECOND_IC0_TILE}
+    tile_w = args.tile_records or 16
     # N > 1 (weak scaling): the grid grows to N x (N * gpus) rows; the pressure solve is split into one
     # slab of N rows per GPU, the cheap stages run replicated (DESIGN.md "Multi-GPU")
     sharded = (world > 1 or args.force_slab) and args.slab != "replicas"
     GX, GY = N, N * (args.grid_y_mult if args.grid_y_mult > 0 else (world if sharded and args.scaling == "weak" else 1))
     if world > 1:
         torch.cuda.set_device(local_rank)
-    sim = ea.Simulation(GX, GY, device=local_rank, dot_mode=dot_mode, precond=precond, tile_units=args.tile_units)
+    sim = ea.Simulation(GX, GY, device=local_rank, dot_mode=dot_mode, precond=PC[args.precond], tile_records=args.tile_records, tol=tol)
     comm = None
     p2p_on = False
     if sharded:
@@ -228,178 +462,185 @@ def main():
                 args.comm = "torch"
         if args.comm == "torch":
             comm = TorchComm(sim, coupling)
-        # the latency-bound exchanges of every PCG iteration go peer to peer (xGMI); if the mailboxes cannot be set up
-        # on every rank the job stays on the communicator, and the JSON line says which one ran
         p2p_on = (not args.no_p2p) and attach_p2p(sim)
         if rank == 0 and not args.no_p2p and not p2p_on:
             print("bench: peer-to-peer mailboxes unavailable (%s); exchanges stay on %s" % (sim._p2p_error, args.comm), file=sys.stderr)
-    # weak scaling: the N x (N*M) grid holds M copies of the single-GPU picture on top of each other (closed tanks), so
-    # that every row slab does the work of the N = 1 job: same free-fall phase, same substeps, same iteration counts
     tiles = GY // N
-    if args.workload == "dam_break":
-        sim.load_text(scenarios.stacked(scenarios.dam_break(), tiles), upscale=True)
-    elif args.workload == "waterfall":
-        sim.load_text(scenarios.stacked(scenarios.waterfall(), tiles), upscale=True)
-    else:
-        sim.load_half_tank()
+    load_workload(sim, scenarios, args.workload, tiles)
+    preroll = preroll_into_solves(sim, args.max_preroll)
+    if args.pmc_child:
+        sim.copy_bandwidth(1 << 30, 2)     # the calibration launches of pmc_live(): a known 2^30 bytes read and written each
 
-    # untimed preroll into the expensive phase: the first frame whose solves run the full
-    # iteration budget (>= 100 PCG iterations in the frame); see the module docstring
-    preroll = 0
-    while preroll < args.max_preroll:
-        sim.step()
-        preroll += 1
-        if sim.stats().last_pcg_iterations >= 100:
-            break
-
-    # CPU baseline from the same state (rank 0, N=1 only)
-    cpu = None
-    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline and not args.force_slab:
-        cpu = cpu_baseline(sim, ea)
-
-    # in-run parity note: advance the GPU by the same number of frames the strict-IEEE oracle ran
-    parity = None
-    warm_done = 0
-    if cpu and "_oracle_after" in cpu:
-        import numpy as np
-        ou, ov, ofl, k = cpu.pop("_oracle_after")
-        for _ in range(k):
-            sim.step()
-        warm_done = k
-        gu, gv, gfl = sim.get(ea.F_U), sim.get(ea.F_V), sim.get(ea.F_COUNT) > 0
-        parity = {"frames": k, "max_abs_du": float(np.abs(gu - ou).max()), "max_abs_dv": float(np.abs(gv - ov).max()),
-                  "fluid_cells_differing": int((gfl != ofl).sum()), "vs": "oracle (strict IEEE build) from the same state"}
-    for _ in range(max(args.warmup - warm_done, 0)):
-        sim.step()
-
-    dominant = "backward_solve" if precond != ea.PRECOND_JACOBI else "update_pr"
-    # Inside the timed region only the DOMINANT kernel is bracketed by HIP events (on the kernel's own
-    # stream): an event pair around every launch of all six PCG kernels costs ~20 % throughput at
-    # 1024^2 (measured), around the dominant one alone ~2 %.  The other classes are timed in a second,
-    # untimed pass of the same number of steps right after it (same phase: every substep runs the
-    # full iteration budget).
-    timed_classes = [dominant] if not args.no_kernel_timing else []
-    sim.profile_reset()
-    sim.profile_enable(timed_classes)
-    st0 = sim.stats()
-
-    # timed region: barrier + device sync on both sides, MAX over ranks (euler_amd/dist.py)
-    elapsed = grp.timed(sim.step, args.steps)
-
-    st1 = sim.stats()
-    prof = sim.profile() if timed_classes else {}
-    sim.profile_enable([])
-    iters_pass2 = 0
-    if not args.no_kernel_timing:
-        sim.profile_reset()
-        sim.profile_enable(ea.profile_class_names() if args.profile_all else [k for k in ALGO_BYTES if k != dominant])
-        for _ in range(args.steps):
-            sim.step()
-        iters_pass2 = sim.stats().total_pcg_iterations - st1.total_pcg_iterations
-        prof2 = sim.profile()
-        sim.profile_enable([])
-        for k, v in prof2.items():
-            prof.setdefault(k, v)
-    substeps = st1.total_substeps - st0.total_substeps
-    iters = st1.total_pcg_iterations - st0.total_pcg_iterations
-    cells = GX * GY
-    cells_launch = cells // world if sharded else cells      # cells one kernel launch covers on one GPU
-
+    big = GX * GY >= 4096 * 4096
+    t = time_frames(sim, ea, grp, args, args.precond, args.steps, 0, args.warmup, big)
     if comm is not None and comm.error:
         raise RuntimeError(comm.error)
-    # sharded: ONE job of GX*GY cells; replicas / single GPU: one job of N*N cells per rank
-    job_rate = (GX * GY * args.steps / elapsed) if sharded else whole_job_rate(float(GX * GY), args.steps, elapsed, grp)
+    cells = GX * GY
+    job_rate = (cells * args.steps / t["elapsed"]) if sharded else whole_job_rate(float(cells), args.steps, t["elapsed"], grp)
     if rank != 0:
         grp.close()
         return
-
-    roof = None
-    kern = {}
+    head = summarize(t, GX, GY, args.precond, tile_w, traffic, traffic_note, args.steps, fused_search=not sharded or p2p_on)
     try:      # the ceiling a plain device-to-device copy reaches on this very GPU (read + write), next to the 8 TB/s spec peak
         copy_gbps = round(sim.copy_bandwidth(1 << 30, 10), 1)
     except Exception:
         copy_gbps = None
-    for name, (ms, launches) in prof.items():
-        entry = {"ms_total": round(ms, 3), "launches": int(launches), "avg_us": round(1e3 * ms / launches, 2)}
-        if name in ALGO_BYTES:
-            entry["algo_GBps"] = round(ALGO_BYTES[name] * cells_launch / (ms / launches * 1e-3) / 1e9, 1)
-        kern[name] = entry
-    if dominant in prof:
-        ms, launches = prof[dominant]
-        achieved = ALGO_BYTES[dominant] * cells_launch / (ms / launches * 1e-3) / 1e9
-        traffic = pmc_traffic(N, args.workload, dominant) if not sharded and GY == N else None
-        roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "measured_copy_GBps": copy_gbps,
-                "traffic": traffic,
-                # the HBM bytes rocprofv3 counted for this kernel (committed PMC passes of this very command) over the launch time
-                # measured here: what the memory system really delivered, next to the algorithmic figure above
-                "achieved_traffic": round(traffic / (ms / launches * 1e-3) / 1e9, 2) if traffic else None,
-                "frac_traffic": round(traffic / (ms / launches * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if traffic else None,
-                "algorithmic_bytes_per_launch": ALGO_BYTES[dominant] * cells_launch,
-                "note": "algorithmic bytes count ALL X*Y cells of a launch (SURVEY 8d, like the reference's dense loops); the sweeps skip "
-                        "fluid-free blocks, so on sparse scenes the bytes really moved (traffic) are fewer and achieved can exceed what HBM delivered",
-                "fluid_fraction": round(float(st1.fluid_cells) / cells, 4),
-                "avg_launch_us": round(1e3 * ms / launches, 2), "launches": int(launches)}
-    # whole PCG iteration: per-launch averages summed over the six kernel classes (dominant: timed region;
-    # the others: second pass), against the 149 B per cell and iteration BASELINE.md prescribes
-    # total time of each class / PCG iterations of the pass it was timed in (dominant: the timed region; the others:
-    # the second pass) - a class may have fewer launches than iterations (the s = z copy at the start of a solve)
-    per_iter_ms = sum(prof[k][0] / (iters if k == dominant else iters_pass2) for k in ALGO_BYTES
-                      if k in prof and (iters if k == dominant else iters_pass2))
-    pcg_ms = per_iter_ms * iters
-    # single GPU: update_search (K5) runs fused into the next iteration's apply_a (K1) and has no launches of its own
-    fused_k5 = not sharded and "apply_a" in prof
-    if fused_k5:
-        kern["apply_a"]["note"] = "update_search fused in: 42 algorithmic B/cell (2w+1 + 3w+1)"
-        kern["apply_a"]["algo_GBps"] = round((ALGO_BYTES["apply_a"] + ALGO_BYTES["update_search"]) * cells_launch
-                                              / (prof["apply_a"][0] / prof["apply_a"][1] * 1e-3) / 1e9, 1)
-    complete = all(k in prof for k in ALGO_BYTES if k != "update_search" or not fused_k5)
-    pcg_gbps = PCG_BYTES_PER_CELL_ITER * cells / (per_iter_ms * 1e-3) / 1e9 if per_iter_ms and complete else None
+    if head["roofline"]:
+        head["roofline"]["measured_copy_GBps"] = copy_gbps
+    device = sim.device_name()
+    sim.close()
+    del sim
 
+    secondary = {}
     cpu_obj = None
-    if cpu:
-        ref = cpu["reference_flags"]
-        cpu_obj = {"value": round(ref["value"], 1), "unit": "cells*steps/s", "cores": 1, "kind": "port",
-                   "sample": "%d frame(s) (%d substeps, %d PCG iterations) of the same %dx%d %s state the GPU timing starts from; "
-                             "oracle/euler_oracle.c built -O3 -ffast-math -march=native (the reference's CMake flags), single thread"
-                             % (ref["steps"], ref["substeps"], ref["pcg_iterations"], N, N, args.workload),
-                   "strict_ieee_value": round(cpu["strict"]["value"], 1), "cpu_model": cpu_model(),
-                   "configs0_100x40_block_100_steps": cpu.get("_native"),
-                   "host_cores_available": os.cpu_count()}
+    if single and not args.no_secondary and not args.pmc_child:
+        libs = None if args.no_cpu_baseline else build_native_oracle()
+        # (1) the same workload in the parity mode: the reference's own IC(0)
+        if args.precond != "ic0":
+            try:
+                k2 = max(1, args.steps // 2)
+                s2 = ea.Simulation(GX, GY, device=local_rank, dot_mode=dot_mode, precond=ea.PRECOND_IC0, tol=tol)
+                load_workload(s2, scenarios, args.workload, 1)
+                preroll_into_solves(s2, args.max_preroll)
+                t2 = time_frames(s2, ea, grp, args, "ic0", k2, 0, args.warmup, big)
+                secondary["exact_ic0"] = summarize(t2, GX, GY, "ic0", tile_w, traffic_exact, traffic_exact_note, k2)
+                secondary["exact_ic0"]["workload"] = "%dx%d %s (the headline workload), %d frames" % (GX, GY, args.workload, k2)
+                s2.close()
+                del s2
+            except Exception as e:
+                secondary["exact_ic0"] = {"error": repr(e)}
+        # (2) time to SOLVE one system to the reference's tolerance, both modes (2048^2 half tank, first projection)
+        try:
+            tts = {}
+            for pc in ("ic0", "ic0_tile"):
+                s3 = ea.Simulation(2048, 2048, device=local_rank, dot_mode=dot_mode, precond=PC[pc], tile_records=args.tile_records,
+                                   max_iterations=20000, pcg_poll_interval=32).load_half_tank()
+                s3.step()                      # untimed: allocations, first launches
+                s3.load_half_tank()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                s3.step()
+                torch.cuda.synchronize()
+                st = s3.stats()
+                tts[pc] = {"ms": round(1e3 * (time.perf_counter() - t0), 2), "pcg_iterations": int(st.last_pcg_iterations),
+                           "residual": float(st.last_residual), "substeps": int(st.last_substeps)}
+                s3.close()
+                del s3
+            tts["workload"] = "2048x2048 half tank from rest, one frame, tol 1e-6 (the reference's), iteration cap lifted to 20000"
+            tts["speedup_tile_over_exact"] = round(tts["ic0"]["ms"] / tts["ic0_tile"]["ms"], 2)
+            secondary["time_to_solution"] = tts
+        except Exception as e:
+            secondary["time_to_solution"] = {"error": repr(e)}
+        # (3) BASELINE configs[1]: 1024^2 dam break in the expensive phase, parity mode, checked in-run against the oracle
+        try:
+            s4 = ea.Simulation(1024, 1024, device=local_rank, dot_mode=dot_mode, precond=ea.PRECOND_IC0)
+            load_workload(s4, scenarios, "dam_break", 1)
+            pre4 = preroll_into_solves(s4, args.max_preroll)
+            cpu1 = cpu_from_gpu_state(s4, ea, libs) if libs else None
+            parity = None
+            done = 0
+            if cpu1 and "_oracle_after" in cpu1:
+                import numpy as np
+                ou, ov, ofl, k = cpu1.pop("_oracle_after")
+                for _ in range(k):
+                    s4.step()
+                done = k
+                gu, gv, gfl = s4.get(ea.F_U), s4.get(ea.F_V), s4.get(ea.F_COUNT) > 0
+                parity = {"frames": k, "max_abs_du": float(np.abs(gu - ou).max()), "max_abs_dv": float(np.abs(gv - ov).max()),
+                          "fluid_cells_differing": int((gfl != ofl).sum()),
+                          "vs": "oracle (strict IEEE build) from the same state, EULER_DOT_TREE on the GPU"}
+            t4 = time_frames(s4, ea, grp, args, "ic0", 4, done, 1, False)
+            c1 = summarize(t4, 1024, 1024, "ic0", tile_w, None, "no PMC pass inside this block (profiles/ holds one)", 4)
+            c1.update({"workload": "1024x1024 dam break (block layout upscaled), preroll %d frames into the expensive phase" % pre4,
+                       "parity_in_run": parity,
+                       "cpu_same_state": {k: v for k, v in (cpu1 or {}).items() if not k.startswith("_")} or None})
+            s4.set_precond(ea.PRECOND_IC0_TILE, args.tile_records)
+            t4b = time_frames(s4, ea, grp, args, "ic0_tile", 4, 0, 1, False)
+            c1["roofline_mode_value"] = 1024 * 1024 * 4 / t4b["elapsed"]
+            c1["roofline_mode_us_per_iteration"] = round(1e3 * t4b["per_iter_ms"], 2)
+            secondary["configs1_1024_dam_break"] = c1
+            s4.close()
+            del s4
+        except Exception as e:
+            secondary["configs1_1024_dam_break"] = {"error": repr(e)}
+        # (4) the north star's target size: the pressure projection at 16384^2 (half tank, tol = 0: 100 iterations per substep)
+        if not args.no_16384 and N < 16384:
+            try:
+                t0 = time.perf_counter()
+                s5 = ea.Simulation(16384, 16384, device=local_rank, dot_mode=dot_mode, precond=PC[args.precond], tile_records=args.tile_records, tol=0.0)
+                s5.load_half_tank()
+                setup_s = time.perf_counter() - t0
+                preroll_into_solves(s5, 4)
+                t5 = time_frames(s5, ea, grp, args, args.precond, 1, 0, 0, True)
+                p16 = summarize(t5, 16384, 16384, args.precond, tile_w, None, None, 1)
+                # per-cell traffic of the same kernels as counted live at the headline size, scaled by fluid cells (labelled)
+                hp = head["pcg_iteration"]
+                if traffic and hp and hp.get("GBps_traffic") and p16["pcg_iteration"]:
+                    scale = p16["fluid_cells"] / max(head["fluid_cells"], 1)
+                    sec = p16["pcg_iteration"]["us_per_iteration"] * 1e-6
+                    hb = hp["GBps_traffic"] * 1e9 * hp["us_per_iteration"] * 1e-6
+                    p16["pcg_iteration"]["GBps_traffic_scaled"] = round(hb * scale / sec / 1e9, 1)
+                    p16["pcg_iteration"]["frac_traffic_scaled"] = round(hb * scale / sec / 1e9 / HBM_PEAK_GBPS, 4)
+                    p16["pcg_iteration"]["traffic_scaled_note"] = ("bytes per fluid cell as counted by the live PMC pass at the headline size "
+                                                                   "x this grid's fluid cells")
+                p16["workload"] = "16384x16384 half tank, tol 0, 100 iterations per substep, 1 frame"
+                p16["setup_seconds"] = round(setup_s, 1)
+                secondary["projection_16384"] = p16
+                s5.close()
+                del s5
+            except Exception as e:
+                secondary["projection_16384"] = {"error": repr(e)}
+        # (5) the CPU path beside it (rank 0, N = 1): single thread, bounded sample
+        if libs:
+            try:
+                cpu = cpu_baseline_roofline_run(libs, tol if tol is not None else 1e-6)
+                ref = cpu["reference_flags"]
+                per_cell_substep = ref["seconds"] / (2048 * 2048 * max(ref["substeps"], 1))
+                cpu_obj = {"value": round(ref["value"], 1), "unit": "cells*steps/s", "cores": 1, "kind": "port",
+                           "sample": "1 frame (%d substep(s), %d PCG iterations) of the 2048x2048 half tank - the headline workload at 1/16 of its "
+                                     "cells, same fluid fraction, same tol / iteration budget; oracle/euler_oracle.c built -O3 -ffast-math "
+                                     "-march=native (the reference's CMake flags), single thread like the reference" % (ref["substeps"], ref["pcg_iterations"]),
+                           "seconds": ref["seconds"], "strict_ieee_value": round(cpu["strict"]["value"], 1), "cpu_model": cpu_model(),
+                           "extrapolated_seconds_per_substep": {"8192x8192": round(per_cell_substep * 8192 * 8192, 1),
+                                                                "16384x16384": round(per_cell_substep * 16384 * 16384, 1),
+                                                                "note": "EXTRAPOLATED from the 2048^2 sample at constant time per cell and substep (100 iterations each)"},
+                           "configs0_100x40_block_100_steps": cpu.get("_native"),
+                           "configs1_1024_dam_break_same_state": (secondary.get("configs1_1024_dam_break") or {}).get("cpu_same_state"),
+                           "host_cores_available": os.cpu_count()}
+            except Exception as e:
+                cpu_obj = {"error": repr(e)}
 
+    parallelism = "1 GPU" if args.gpus == 1 and not sharded else (
+        "%d independent replicas" % args.gpus if not sharded else
+        "%d row slabs of %d rows: distributed PCG (%s, exchanges by %s), replicated marker/advection stages; grid %dx%d"
+        % (args.gpus, GY // max(world, 1), "tile-local IC(0): no coupling between slabs" if args.precond == "ic0_tile" else args.slab + " IC(0) coupling",
+           ("peer-to-peer mailboxes (scalars, ghost rows) + " if p2p_on else "")
+           + ("RCCL from the C library" if args.comm == "rccl" else "torch.distributed callbacks"), GX, GY))
     out = {
-        "metric": "cells*steps/sec of sim_step() (dam-break frames incl. PCG pressure projection)",
+        "metric": "cells*steps/sec of sim_step() (frames incl. the PCG pressure projection) + pressure-solve HBM GB/s vs roofline",
         "value": job_rate,
         "unit": "cells*steps/s",
         "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps,
+        "ms_per_step": 1e3 * t["elapsed"] / args.steps,
         "higher_is_better": True,
         "scaling": args.scaling if sharded else "weak",
         "vs_baseline": None,
         "dtype": "f32 fields, f64 PCG (the reference's mix)",
         "data": "synthetic",
-        "config": {"workload": "%dx%d %s, %s%s" % (GX, GY, args.workload, "block layout upscaled" if args.workload == "dam_break" else "synthetic",
-                                                   "" if tiles == 1 or args.workload == "half_tank" else ", %d tanks stacked (one per row slab)" % tiles),
-                   "grid": [GX, GY], "preroll_frames": preroll, "precond": args.precond, "dot_mode": args.dot_mode,
-                   "max_iterations": 100, "tol": 1e-6,
-                   "parallelism": "1 GPU" if args.gpus == 1 and not sharded else (
-                       "%d independent replicas" % args.gpus if not sharded else
-                       "%d row slabs of %d rows: distributed PCG (%s IC(0) coupling, exchanges by %s), replicated marker/advection stages; grid %dx%d"
-                       % (args.gpus, GY // max(world, 1), args.slab,
-                          ("peer-to-peer mailboxes (scalars, ghost rows) + " if p2p_on else "")
-                          + ("RCCL from the C library" if args.comm == "rccl" else "torch.distributed callbacks"), GX, GY))},
-        "substeps": int(substeps), "pcg_iterations": int(iters),
-        "cells_substeps_per_s": cells * substeps / elapsed,
-        "markers": int(st1.n_markers), "fluid_cells": int(st1.fluid_cells),
-        "roofline": roof,
-        "pcg_aggregate": {"algorithmic_GBps": round(pcg_gbps, 1) if pcg_gbps else None,
-                          "bytes_per_cell_iteration": PCG_BYTES_PER_CELL_ITER, "kernel_us_per_iteration": round(1e3 * per_iter_ms, 2),
-                          "note": "dominant kernel timed inside the timed region, the other five in a second pass of the same length"},
-        "kernels": kern,
+        "config": {"workload": "%dx%d %s%s, %s" % (GX, GY, args.workload,
+                                                   " (BASELINE configs[2], pressure-solve roofline run: tol 0, exactly 100 PCG iterations per substep)"
+                                                   if args.workload == "half_tank" and tol == 0.0 else "", head["mode"]),
+                   "grid": [GX, GY], "preroll_frames": preroll, "precond": args.precond, "tile_records": tile_w if args.precond == "ic0_tile" else None,
+                   "dot_mode": args.dot_mode, "max_iterations": 100, "tol": tol if tol is not None else 1e-6, "parallelism": parallelism},
+        "mode": head["mode"],
+        "substeps": head["substeps"], "pcg_iterations": head["pcg_iterations"], "cells_substeps_per_s": head["cells_substeps_per_s"],
+        "markers": head["markers"], "fluid_cells": head["fluid_cells"],
+        "roofline": head["roofline"],
+        "pcg_iteration": head["pcg_iteration"],
+        "kernels": head["kernels"],
         "cpu_baseline": cpu_obj,
-        "parity_in_run": parity,
-        "device": sim.device_name(),
+        "secondary": secondary or None,
+        "device": device,
     }
     emit(json.dumps(out))
     os.dup2(2, 1)

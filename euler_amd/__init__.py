@@ -47,7 +47,7 @@ class Config(C.Structure):
         ("max_iterations", C.c_int32), ("tol", C.c_double), ("dot_mode", C.c_int32), ("precond", C.c_int32),
         ("sweep_mode", C.c_int32), ("max_substeps", C.c_int32), ("frame_time", C.c_float),
         ("viscosity", C.c_float), ("pcg_poll_interval", C.c_int32), ("rainbow", C.c_int32),
-        ("precond_tile_units", C.c_int32), ("reserved", C.c_int32 * 6),
+        ("precond_tile_records", C.c_int32), ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -257,7 +257,7 @@ class Simulation:
     plus state access for parity tests."""
 
     def __init__(self, X=100, Y=40, device=0, dot_mode=DOT_AUTO, precond=PRECOND_IC0, sweep_mode=SWEEP_AUTO,
-                 max_iterations=100, tol=None, pcg_poll_interval=8, viscosity=0.0, rainbow=False, tile_units=0):
+                 max_iterations=100, tol=None, pcg_poll_interval=8, viscosity=0.0, rainbow=False, tile_records=0):
         self.L = load_library()
         cfg = Config()
         _check(self.L.euler_config_default(C.byref(cfg)))
@@ -269,7 +269,7 @@ class Simulation:
         cfg.pcg_poll_interval = pcg_poll_interval
         cfg.viscosity = viscosity            # extension: 0 = the inviscid reference
         cfg.rainbow = int(rainbow)           # args_t.rainbow (main.c:54): carry and advect the dye fields
-        cfg.precond_tile_units = tile_units  # PRECOND_IC0_TILE: tile width in units of 96 records (0 = default)
+        cfg.precond_tile_records = tile_records  # PRECOND_IC0_TILE: records per tile, 8 / 16 / 32 (0 = default 16)
         self.cfg = cfg
         self.X, self.Y = X, Y
         self.h = C.c_void_p()
@@ -329,8 +329,8 @@ class Simulation:
     def stage(self, stage, dt=0.0):
         _check(self.L.euler_stage(self.h, stage, dt))
 
-    def set_precond(self, precond, tile_units=0):
-        _check(self.L.euler_set_precond(self.h, precond, tile_units))
+    def set_precond(self, precond, tile_records=0):
+        _check(self.L.euler_set_precond(self.h, precond, tile_records))
 
     def pcg_op(self, op, dt=0.0, scalar=0.0):
         out = C.c_double(0)

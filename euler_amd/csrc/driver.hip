@@ -38,7 +38,7 @@ extern "C" int euler_abi_version(void) { return EULER_ABI_VERSION; }
 static const char* k_class_names[KC__COUNT] = {
     "timestep", "marker_advect", "marker_events", "marker_bin", "marker_compact", "sources", "select",
     "extrapolate", "advect_velocity", "build_system", "precon_factor", "forward_solve", "backward_solve",
-    "apply_a", "dot", "update_pr", "update_search", "reduce_final", "velocity_update", "jacobi", "misc"};
+    "apply_a", "dot", "update_pr", "update_search", "reduce_final", "velocity_update", "jacobi", "misc", "precond_tile"};
 
 void eu_prof_begin(euler_sim* S, int cls) {
   if (!((S->prof_mask >> cls) & 1)) return;
@@ -124,22 +124,21 @@ extern "C" int euler_config_default(euler_config* c) {
   return EULER_OK;
 }
 
-// tiles per band of the tile-local preconditioner (include/euler.h precond_tile_units; the oracle's eo_tile_start)
-static void eu_set_tiles(euler_sim* S, int tile_units) {
-  const int n_units = S->geom.T / 96;
-  if (tile_units <= 0) tile_units = 6;
-  int nt = (n_units + tile_units / 2) / tile_units;
-  if (nt < 1) nt = 1;
-  if (nt > n_units) nt = n_units;
-  S->cfg.precond_tile_units = tile_units;
-  S->tile_nt = nt;
+// records per tile of the tile-local preconditioner (include/euler.h precond_tile_records; the oracle's eo_tile_start)
+static int eu_set_tiles(euler_sim* S, int w) {
+  if (w <= 0) w = 16;
+  if (w != 8 && w != 16 && w != 32) { eu_set_error("precond_tile_records = %d: 8, 16 or 32 (0 = 16)", w); return EULER_EINVAL; }
+  S->cfg.precond_tile_records = w;
+  S->tile_w = w;
+  return EULER_OK;
 }
 
-extern "C" int euler_set_precond(euler_sim* S, int32_t precond, int32_t tile_units) {
+extern "C" int euler_set_precond(euler_sim* S, int32_t precond, int32_t tile_records) {
   if (!S || precond < EULER_PRECOND_IC0 || precond > EULER_PRECOND_IC0_TILE) { eu_set_error("euler_set_precond: bad argument"); return EULER_EINVAL; }
   HIPCHK(hipStreamSynchronize(S->stream));
+  int rc = eu_set_tiles(S, tile_records);
+  if (rc) return rc;
   S->cfg.precond = precond;
-  eu_set_tiles(S, tile_units);
   return EULER_OK;
 }
 
@@ -158,7 +157,7 @@ extern "C" void euler_destroy(euler_sim* S) {
   eu_rccl_release(S);
   void* dev[] = {S->u, S->v, S->utmp, S->vtmp, S->solid, S->source, S->sink, S->count, S->prev_count, S->count32,
                  S->markers[0], S->markers[1], S->ms, S->evmask, S->ev_theta, S->ev_delta, S->sel_idx, S->act_idx,
-                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->fbits_fwd, S->fbits_bwd, S->halo_buf, S->band_ranges, S->tile_fluid,
+                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->fbits_fwd, S->fbits_bwd, S->halo_buf, S->band_ranges, S->partial2,
                  S->rowmajor_tmp};
   for (void* p : dev) if (p) (void)hipFree(p);
   for (float* d : S->dye) if (d) (void)hipFree(d);
@@ -244,10 +243,10 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   DALLOC(S->fbits_bwd, (size_t)S->geom.nbands * S->fb_stride * 64);
   DALLOC(S->sc, 1);
   DALLOC(S->band_ranges, (size_t)S->geom.nbands);
-  DALLOC(S->tile_fluid, (size_t)S->geom.nbands * (S->geom.T / 96));
-  eu_set_tiles(S, S->cfg.precond_tile_units);
+  { int rc = eu_set_tiles(S, S->cfg.precond_tile_records); if (rc) { euler_destroy(S); return rc; } }
   S->red_blocks = (int)eu_blocks(SS, EU_RED_ELEMS, 2048);
-  DALLOC(S->partial, (size_t)S->red_blocks);
+  DALLOC(S->partial, (size_t)S->red_blocks > 2048 ? (size_t)S->red_blocks : 2048);
+  DALLOC(S->partial2, 2048);
   DALLOC(S->red_counter, 1);
   S->band_lo = 0; S->band_hi = S->geom.nbands; S->e_lo = 0; S->e_cnt = SS;
   DALLOC(S->halo_buf, (size_t)4 * S->X);
@@ -715,23 +714,35 @@ extern "C" int euler_colorize(euler_sim* S) {
 
 // ------------------------------------------------------------------------------------------
 // measurement helpers
-__global__ __launch_bounds__(256) void k_copy16(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+// the fastest plain copy of tools/micro/copy_bench on MI355X: 16 bytes per lane, 8 loads in flight per thread, non-temporal
+// (streaming) loads and stores, a grid-stride of 65536 blocks
+typedef float cp_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_copy16(const cp_f4* __restrict__ src, cp_f4* __restrict__ dst, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 7 * stride < n; i += 8 * stride) {
+    cp_f4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(&src[i + k * stride]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(v[k], &dst[i + k * stride]);
+  }
+  for (; i < n; i += stride) dst[i] = src[i];
 }
 
 extern "C" int euler_measure_copy_bandwidth(euler_sim* S, size_t bytes, int32_t reps, double* gbps) {
   if (!S || !gbps || reps < 1) return EULER_EINVAL;
   bytes &= ~(size_t)15;
-  float4 *a = nullptr, *b = nullptr;
+  cp_f4 *a = nullptr, *b = nullptr;
   HIPCHK(hipMalloc((void**)&a, bytes));
   if (hipMalloc((void**)&b, bytes) != hipSuccess) { (void)hipFree(a); return EULER_ENOMEM; }
   (void)hipMemsetAsync(a, 1, bytes, S->stream);
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   const size_t n = bytes / 16;
-  hipLaunchKernelGGL(k_copy16, dim3(4096), dim3(256), 0, S->stream, a, b, n);   // warm-up
+  hipLaunchKernelGGL(k_copy16, dim3(65536), dim3(256), 0, S->stream, a, b, n);   // warm-up
   (void)hipEventRecord(e0, S->stream);
-  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_copy16, dim3(4096), dim3(256), 0, S->stream, a, b, n);
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_copy16, dim3(65536), dim3(256), 0, S->stream, a, b, n);
   (void)hipEventRecord(e1, S->stream);
   hipError_t e = hipStreamSynchronize(S->stream);
   float ms = 0.f;

@@ -28,7 +28,7 @@ enum {
   KC_TIMESTEP = 0, KC_MARKER_ADVECT, KC_MARKER_EVENTS, KC_MARKER_BIN, KC_MARKER_COMPACT, KC_SOURCES,
   KC_SELECT, KC_EXTRAPOLATE, KC_ADVECT_VELOCITY, KC_BUILD_SYSTEM, KC_PRECON_FACTOR,
   KC_FORWARD_SOLVE, KC_BACKWARD_SOLVE, KC_APPLY_A, KC_DOT, KC_UPDATE_PR, KC_UPDATE_SEARCH,
-  KC_REDUCE_FINAL, KC_VELOCITY_UPDATE, KC_JACOBI, KC_MISC, KC__COUNT
+  KC_REDUCE_FINAL, KC_VELOCITY_UPDATE, KC_JACOBI, KC_MISC, KC_PRECOND_TILE, KC__COUNT
 };
 
 // Device-resident PCG scalars: no host round trip inside the iteration (reference: locals of
@@ -37,6 +37,9 @@ struct PcgScalars {
   double sigma, zs, sigma_new, alpha, beta, rnorm;
   double tol;
   double comm_val;   // multi-rank: a rank-local reduction result on its way through the all-reduce
+  double comm_val2;  // k_precond_tile leaves two: max |r| in comm_val, dot(z,r) here
+  double* s_last;    // tile-local mode: the search direction of the last iteration that ran (its p += alpha s is applied by
+                     // the next iteration's apply_a pass, or by k_finish_p when there is none)
   int nonzero;   // !all_zero(r)  (main.c:742)
   int done;      // inf_norm(r) <= tol reached (main.c:756)
   int iters;     // apply_a calls so far (main.c:750)
@@ -145,8 +148,8 @@ struct euler_sim {
   unsigned int* fbits_fwd; unsigned int* fbits_bwd;   // fluid flags of the sweeps, 8 steps to a dword (k_pack_fbits)
   int fb_stride;          // words per band and lane
   int4* band_ranges;      // per band: active block ranges of the forward / backward sweeps (per solve)
-  int tile_nt;            // EULER_PRECOND_IC0_TILE: tiles per band (include/euler.h precond_tile_units)
-  uint8_t* tile_fluid;    // [nbands][n_units]: tiles that hold fluid (per solve)
+  int tile_w;             // EULER_PRECOND_IC0_TILE: records per tile (include/euler.h precond_tile_records)
+  double* partial2;       // second set of reduction partials (k_precond_tile reduces max |r| and dot(z,r) at once)
   double* rowmajor_tmp;   // lazily allocated C doubles for euler_get/set_field of skewed arrays
   PcgScalars* sc;
   PcgScalars* sc_host;    // pinned

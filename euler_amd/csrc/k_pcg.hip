@@ -35,6 +35,17 @@ typedef double sw_d2 __attribute__((ext_vector_type(2)));   // a lane's pair of 
 
 __device__ __forceinline__ bool pcg_idle(const PcgScalars* sc) { return sc->done || !sc->nonzero; }
 
+#define DPP_WAVE_SHL1 0x130
+#define DPP_WAVE_SHR1 0x138
+
+// lane l <- neighbouring lane's v; the lane without a source (0 for shr, 63 for shl) receives `edge`
+template <int CTRL>
+__device__ __forceinline__ double wave_shift_inject(double v, double edge) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
 // ------------------------------------------------------------------------------------------
 // scalar epilogues of the reductions
 enum { FIN_SIGMA_INIT = 0, FIN_ALPHA, FIN_RNORM, FIN_BETA, FIN_STORE_ONLY, FIN_TO_COMM };
@@ -51,25 +62,27 @@ __device__ __forceinline__ void pcg_scalar_step(PcgScalars* sc, int op, double v
   }
 }
 
-// fixed-shape block reductions; result valid in thread 0
+// fixed-shape block reductions of an NT-thread block; result valid in thread 0
+template <int NT = RED_THREADS>
 __device__ __forceinline__ double block_sum(double v) {
-  __shared__ double sw[RED_THREADS / 64];
+  __shared__ double sw[NT / 64];
   v = eu_wave_sum(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = v;
   __syncthreads();
   double t = 0.0;
-  if (threadIdx.x == 0) for (int k = 0; k < RED_THREADS / 64; ++k) t += sw[k];
+  if (threadIdx.x == 0) for (int k = 0; k < NT / 64; ++k) t += sw[k];
   return t;
 }
+template <int NT = RED_THREADS>
 __device__ __forceinline__ double block_max(double v) {
-  __shared__ double sm[RED_THREADS / 64];
+  __shared__ double sm[NT / 64];
   v = eu_wave_max(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
   __syncthreads();
   double t = 0.0;
-  if (threadIdx.x == 0) for (int k = 0; k < RED_THREADS / 64; ++k) t = sm[k] > t ? sm[k] : t;
+  if (threadIdx.x == 0) for (int k = 0; k < NT / 64; ++k) t = sm[k] > t ? sm[k] : t;
   return t;
 }
 
@@ -78,7 +91,7 @@ __device__ __forceinline__ double block_max(double v) {
 // in index order (so the result does not depend on arrival order: deterministic) and applies the
 // scalar epilogue.  Saves one launch + one kernel boundary per reduction (3 per PCG iteration).
 // Hand-off form: 8-byte agent atomics on both sides (MI355X_MICROARCH "valid forms").
-template <bool IS_MAX>
+template <bool IS_MAX, int NT = RED_THREADS>
 __device__ __forceinline__ void block_finish(double v_block, double* partial, unsigned int* counter, PcgScalars* sc, int op) {
   __shared__ int am_last;
   if (threadIdx.x == 0) {
@@ -91,12 +104,12 @@ __device__ __forceinline__ void block_finish(double v_block, double* partial, un
   __syncthreads();
   if (!am_last) return;
   double v = 0.0;
-  for (unsigned int i = threadIdx.x; i < gridDim.x; i += RED_THREADS) {
+  for (unsigned int i = threadIdx.x; i < gridDim.x; i += NT) {
     const double w = __longlong_as_double((long long)__hip_atomic_load(
         reinterpret_cast<unsigned long long*>(&partial[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     if (IS_MAX) v = w > v ? w : v; else v += w;
   }
-  v = IS_MAX ? block_max(v) : block_sum(v);
+  v = IS_MAX ? block_max<NT>(v) : block_sum<NT>(v);
   if (op & FIN_VIA_P2P) { v = p2p_allreduce_block<IS_MAX>(sc, v); op &= 0xff; }   // op is uniform: every thread of this block is here
   if (threadIdx.x == 0) {
     pcg_scalar_step(sc, op, v);
@@ -196,8 +209,9 @@ __global__ __launch_bounds__(256) void k_dot_sequential(const double* __restrict
 __global__ __launch_bounds__(RED_THREADS) void k_apply_a(const double* __restrict__ s, double* __restrict__ z,
                                                          const uint8_t* __restrict__ mask, SkewGeom g,
                                                          double* __restrict__ partial, PcgScalars* sc, int force,
-                                                         unsigned int* counter, int fin_op) {
+                                                         unsigned int* counter, int fin_op, double* s_last) {
   if (!force && pcg_idle(sc)) return;
+  if (s_last && blockIdx.x == 0 && threadIdx.x == 0) sc->s_last = s_last;   // tile-local mode: whose p += alpha s is still due (k_finish_p)
   const size_t S = g.S;
   const size_t chunk = (((S + gridDim.x - 1) / gridDim.x) + 127) & ~(size_t)127;   // whole record pairs per block
   const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < S ? lo + chunk : S;
@@ -286,90 +300,141 @@ __device__ __forceinline__ double ld_system(const double* p) {
   return v;
 }
 
-template <bool SLAB>   // SLAB: several ranks, the neighbouring slabs' arrays are mapped (nbr); else nbr is ignored
-__global__ __launch_bounds__(RED_THREADS) void k_search_apply(const double* __restrict__ s_old, const double* __restrict__ z,
-                                                              double* __restrict__ s_new, double* __restrict__ out,
-                                                              const uint8_t* __restrict__ mask, SkewGeom g,
-                                                              double* __restrict__ partial, PcgScalars* sc, int force,
-                                                              unsigned int* counter, int fin_op, SlabNeighbours nbr) {
+// PUPD (tile-local mode): the pass also applies the previous iteration's p += alpha s_old (fmadd, main.c:753) - it reads s_old
+// anyway, and in that mode no other kernel of the iteration touches p (k_precond_tile does the rest of main.c:753-765).
+//
+// Schedule.  A wave walks a run of SA_RUN consecutive pair-records of one band (lane = row) with a three-deep window of s'
+// in registers - the pair before, the pair itself, the pair after - so every element of z and s is loaded ONCE, by one
+// 16-byte access per lane, and the four neighbours of a cell come out of the window: left / right are the lane's own
+// registers, down / up the neighbouring lane's by a DPP wave shift (the band-skewed layout puts the lower / upper row's
+// value of the same column one record earlier / later in the neighbouring lane).  Only lane 0 / lane 63 look outside
+// their band (two lanes of one 8-byte load each per element).  Against one thread per pair gathering six neighbours with
+// twelve strided 8-byte loads (round 1) that is 11 instead of 19 memory instructions per pair, and the HBM traffic drops
+// from 1.28x to the algorithmic bytes.
+#define SA_THREADS 256
+#define SA_RUN 32
+struct SaPair { sw_d2 z, so; double ez0, es0, ez1, es1; };   // one pair-record of a lane + the out-of-band vertical neighbours of its two elements
+
+template <bool SLAB, bool PUPD = false>   // SLAB: several ranks, the neighbouring slabs' arrays are mapped (nbr); else nbr is ignored
+__global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __restrict__ s_old, const double* __restrict__ z,
+                                                             double* __restrict__ s_new, double* __restrict__ out,
+                                                             const uint8_t* __restrict__ mask, SkewGeom g,
+                                                             double* __restrict__ partial, PcgScalars* sc, int force,
+                                                             unsigned int* counter, int fin_op, SlabNeighbours nbr,
+                                                             double* __restrict__ p, double* s_new_base) {
   if (!force && pcg_idle(sc)) return;
   const double beta = sc->beta;
-  const size_t S = g.S;
-  const size_t chunk = (((S + gridDim.x - 1) / gridDim.x) + 127) & ~(size_t)127;   // whole record pairs per block
-  const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < S ? lo + chunk : S;
-  auto sn = [&](size_t k) { return z[k] + beta * s_old[k]; };                       // s' of a (fluid) neighbour
+  const double alpha_prev = sc->alpha;     // of the previous iteration: this launch's own alpha is written by its LAST block
+  if (PUPD && blockIdx.x == 0 && threadIdx.x == 0) sc->s_last = s_new_base;
+  const int lane = threadIdx.x & 63;
+  const int TS = g.TS, npairs = TS / 2;
+  const int nb_local = (int)(g.S / ((size_t)TS * 64));
+  const int cpb = (npairs + SA_RUN - 1) / SA_RUN, total = nb_local * cpb;
+  const int n_waves = gridDim.x * (SA_THREADS / 64);
+  const bool edge_lane = lane == 0 || lane == 63;
   double t = 0.0;
-  for (size_t i = lo + 2 * (size_t)threadIdx.x; i < hi; i += 2 * RED_THREADS) {
-    const unsigned int mm = *reinterpret_cast<const unsigned short*>(mask + i);
-    const unsigned int m0 = mm & 0xff, m1 = mm >> 8;
-    if (!((m0 | m1) & CM_FLUID)) continue;
-    const sw_d2 so = *reinterpret_cast<const sw_d2*>(s_old + i), zc = *reinterpret_cast<const sw_d2*>(z + i);
-    const int l = (int)((i & 127) >> 1);
-    // s' of the cell above / below element e (inside = its index when the neighbour sits in the same band)
-    auto sn_up = [&](size_t e, size_t inside) -> double {
-      if (l != 63) return sn(inside);
-      int band, tt, ll;
-      skew_decode(g, e, band, tt, ll);
-      const size_t k = skew_index(g, tt - 63, 64 * (band + 1));
-      if (SLAB && nbr.z_up && band + 1 == nbr.nb_local) return ld_system(nbr.z_up + k) + beta * ld_system(nbr.s_up + k);
-      return sn(k);
-    };
-    auto sn_dn = [&](size_t e, size_t inside) -> double {
-      if (l != 0) return sn(inside);
-      int band, tt, ll;
-      skew_decode(g, e, band, tt, ll);
-      const size_t k = skew_index(g, tt, 64 * band - 1);
-      if (SLAB && nbr.z_dn && band == 0) return ld_system(nbr.z_dn + k) + beta * ld_system(nbr.s_dn + k);
-      return sn(k);
-    };
-    sw_d2 c = so, o = {0.0, 0.0};                     // c: the pair's s'
-    if (m0 & CM_FLUID) c.x = zc.x + beta * so.x;
-    if (m1 & CM_FLUID) c.y = zc.y + beta * so.y;
-    if (m0 & CM_FLUID) {
-      double v = (double)(int)(m0 >> CM_DIAG_SHIFT) * c.x;
-      v = v - ((m0 & CM_RIGHT) ? c.y : 0.0);
-      if (m0 & CM_UP) {
-        v = v - sn_up(i, i + 3);
-      } else {
-        v = v - 0.0;
-      }
-      v = v - ((m0 & CM_LEFT) ? sn(i - 127) : 0.0);
-      if (m0 & CM_DOWN) {
-        v = v - sn_dn(i, i - 129);
-      } else {
-        v = v - 0.0;
-      }
-      o.x = v;
-      t += v * c.x;
+  for (int c = blockIdx.x * (SA_THREADS / 64) + (threadIdx.x >> 6); c < total; c += n_waves) {
+    const int lb = c / cpb, P0 = (c % cpb) * SA_RUN, P1 = P0 + SA_RUN < npairs ? P0 + SA_RUN : npairs;
+    const size_t bbase = (size_t)lb * TS * 64 + 2 * lane;     // element (band, record 0, lane)
+    // the cell masks of the run; a run without fluid is skipped whole
+    unsigned int mm[SA_RUN];
+    unsigned int any = 0;
+#pragma unroll
+    for (int j = 0; j < SA_RUN; ++j) {
+      mm[j] = P0 + j < P1 ? (unsigned int)*reinterpret_cast<const unsigned short*>(mask + bbase + (size_t)(P0 + j) * 128) : 0u;
+      any |= mm[j];
     }
-    if (m1 & CM_FLUID) {
-      double v = (double)(int)(m1 >> CM_DIAG_SHIFT) * c.y;
-      v = v - ((m1 & CM_RIGHT) ? sn(i + 128) : 0.0);
-      if (m1 & CM_UP) {
-        v = v - sn_up(i + 1, i + 130);
-      } else {
-        v = v - 0.0;
+    if (!__ballot(((any | (any >> 8)) & CM_FLUID) != 0)) continue;
+    // where lane 0 / lane 63 find the row below / above their band (the adjacent band's lane 63 / lane 0), relative to pair 0:
+    // even element (record 2P):  below = record 2P + 63 of band - 1, above = record 2P - 63 of band + 1; odd element: + 1
+    const bool up_remote = SLAB && nbr.z_up && lb + 1 == nb_local, dn_remote = SLAB && nbr.z_dn && lb == 0;
+    const double* ez = lane == 0 ? (dn_remote ? nbr.z_dn : z) : (up_remote ? nbr.z_up : z);
+    const double* es = lane == 0 ? (dn_remote ? nbr.s_dn : s_old) : (up_remote ? nbr.s_up : s_old);
+    const bool remote = lane == 0 ? dn_remote : up_remote;
+    const long long e0_base = lane == 0 ? ((long long)(lb - 1) * TS + 62) * 64 + 127 : ((long long)(lb + 1) * TS - 64) * 64 + 1;
+    const long long e1_base = lane == 0 ? ((long long)(lb - 1) * TS + 64) * 64 + 126 : ((long long)(lb + 1) * TS - 62) * 64;
+    const unsigned int vbit = lane == 0 ? CM_DOWN : CM_UP;
+    auto load_pair = [&](int P, SaPair& d, unsigned int m) {
+      d.ez0 = d.es0 = d.ez1 = d.es1 = 0.0;
+      if (P < 0 || P >= npairs) { d.z = sw_d2{0.0, 0.0}; d.so = sw_d2{0.0, 0.0}; return; }   // outside the band: never a fluid cell's neighbour
+      d.z = *reinterpret_cast<const sw_d2*>(z + bbase + (size_t)P * 128);
+      d.so = *reinterpret_cast<const sw_d2*>(s_old + bbase + (size_t)P * 128);
+      if (edge_lane) {
+        if ((m & CM_FLUID) && (m & vbit)) {
+          const long long k = e0_base + (long long)P * 128;
+          if (SLAB && remote) { d.ez0 = ld_system(ez + k); d.es0 = ld_system(es + k); } else { d.ez0 = ez[k]; d.es0 = es[k]; }
+        }
+        if (((m >> 8) & CM_FLUID) && ((m >> 8) & vbit)) {
+          const long long k = e1_base + (long long)P * 128;
+          if (SLAB && remote) { d.ez1 = ld_system(ez + k); d.es1 = ld_system(es + k); } else { d.ez1 = ez[k]; d.es1 = es[k]; }
+        }
       }
-      v = v - ((m1 & CM_LEFT) ? c.x : 0.0);
-      if (m1 & CM_DOWN) {
-        v = v - sn_dn(i + 1, i - 2);
-      } else {
-        v = v - 0.0;
+    };
+    auto sprime = [&](const SaPair& d) { return sw_d2{d.z.x + beta * d.so.x, d.z.y + beta * d.so.y}; };   // s' = z + beta s (main.c:674)
+    SaPair A, B, Cn;
+    load_pair(P0 - 1, A, 0u);
+    load_pair(P0, B, mm[0]);
+    load_pair(P0 + 1, Cn, SA_RUN > 1 ? mm[1] : 0u);
+    double prev_y = sprime(A).y;
+    sw_d2 cur = sprime(B);
+#pragma unroll
+    for (int j = 0; j < SA_RUN; ++j) {
+      const int P = P0 + j;
+      if (P < P1) {                                       // (wave-uniform)
+        SaPair D;
+        load_pair(P + 2 <= P1 ? P + 2 : -1, D, j + 2 < SA_RUN ? mm[j + 2] : 0u);      // the pair after the next, in flight while this one computes
+        const unsigned int m0 = mm[j] & 0xff, m1 = mm[j] >> 8;
+        const sw_d2 nxt = sprime(Cn);
+        // the rows below / above: the neighbouring lane's registers (every lane takes part: a lane whose own pair holds no
+        // fluid still serves its neighbours); lane 0 / 63 inject what they fetched from the adjacent band
+        const double e0 = B.ez0 + beta * B.es0, e1 = B.ez1 + beta * B.es1;
+        const double dn0 = wave_shift_inject<DPP_WAVE_SHR1>(prev_y, e0), up0 = wave_shift_inject<DPP_WAVE_SHL1>(cur.y, e0);
+        const double dn1 = wave_shift_inject<DPP_WAVE_SHR1>(cur.x, e1), up1 = wave_shift_inject<DPP_WAVE_SHL1>(nxt.x, e1);
+        if ((m0 | m1) & CM_FLUID) {
+          const size_t i = bbase + (size_t)P * 128;
+          sw_d2 cc = B.so, o = {0.0, 0.0};                // cc: the pair's s' (a non-fluid element keeps its old value, +0)
+          if (PUPD) {
+            sw_d2 pv = *reinterpret_cast<const sw_d2*>(p + i);
+            if (m0 & CM_FLUID) pv.x = pv.x + B.so.x * alpha_prev;
+            if (m1 & CM_FLUID) pv.y = pv.y + B.so.y * alpha_prev;
+            *reinterpret_cast<sw_d2*>(p + i) = pv;        // a non-fluid partner is written back unchanged
+          }
+          if (m0 & CM_FLUID) cc.x = cur.x;
+          if (m1 & CM_FLUID) cc.y = cur.y;
+          if (m0 & CM_FLUID) {                            // apply_a (main.c:679-691): diag, right, up, left, down
+            double v = (double)(int)(m0 >> CM_DIAG_SHIFT) * cc.x;
+            v = v - ((m0 & CM_RIGHT) ? cc.y : 0.0);
+            v = v - ((m0 & CM_UP) ? up0 : 0.0);
+            v = v - ((m0 & CM_LEFT) ? prev_y : 0.0);
+            v = v - ((m0 & CM_DOWN) ? dn0 : 0.0);
+            o.x = v;
+            t += v * cc.x;
+          }
+          if (m1 & CM_FLUID) {
+            double v = (double)(int)(m1 >> CM_DIAG_SHIFT) * cc.y;
+            v = v - ((m1 & CM_RIGHT) ? nxt.x : 0.0);
+            v = v - ((m1 & CM_UP) ? up1 : 0.0);
+            v = v - ((m1 & CM_LEFT) ? cc.x : 0.0);
+            v = v - ((m1 & CM_DOWN) ? dn1 : 0.0);
+            o.y = v;
+            t += v * cc.y;
+          }
+          if ((m0 & m1) & CM_FLUID) { *reinterpret_cast<sw_d2*>(s_new + i) = cc; *reinterpret_cast<sw_d2*>(out + i) = o; }
+          else if (m0 & CM_FLUID) { s_new[i] = cc.x; out[i] = o.x; }
+          else { s_new[i + 1] = cc.y; out[i + 1] = o.y; }
+          if (SLAB && slab_edge_row(i, lane, TS, nb_local, (nbr.z_dn ? 1 : 0) | (nbr.z_up ? 2 : 0))) {   // the rows the neighbours will read
+            if (m0 & CM_FLUID) st_system(s_new + i, cc.x);
+            if (m1 & CM_FLUID) st_system(s_new + i + 1, cc.y);
+          }
+        }
+        prev_y = cur.y; cur = nxt;
+        B = Cn; Cn = D;
       }
-      o.y = v;
-      t += v * c.y;
-    }
-    if ((m0 & m1) & CM_FLUID) { *reinterpret_cast<sw_d2*>(s_new + i) = c; *reinterpret_cast<sw_d2*>(out + i) = o; }
-    else if (m0 & CM_FLUID) { s_new[i] = c.x; out[i] = o.x; }
-    else { s_new[i + 1] = c.y; out[i + 1] = o.y; }
-    if (SLAB && slab_edge_row(i, l, g.TS, nbr.nb_local, (nbr.z_dn ? 1 : 0) | (nbr.z_up ? 2 : 0))) {   // the rows the neighbours will read
-      if (m0 & CM_FLUID) st_system(s_new + i, c.x);
-      if (m1 & CM_FLUID) st_system(s_new + i + 1, c.y);
     }
   }
   if (SLAB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // landed before this block joins the all-reduce (block_sum syncs)
-  t = block_sum(t);
-  if (fin_op >= 0) block_finish<false>(t, partial, counter, sc, fin_op);   // fin_op < 0: dot(out, s') is replayed sequentially
+  t = block_sum<SA_THREADS>(t);
+  if (fin_op >= 0) block_finish<false, SA_THREADS>(t, partial, counter, sc, fin_op);   // fin_op < 0: dot(out, s') is replayed sequentially
 }
 
 // p += alpha s ; r -= alpha z (fmadd x2, main.c:753-754) ; per-block max |r| (inf_norm, main.c:654-667)
@@ -412,12 +477,14 @@ __global__ __launch_bounds__(RED_THREADS) void k_inf_norm(const double* __restri
 }
 
 // s = z + beta s (update_search, main.c:669-677); with COPY: s = z (the memcpy at main.c:746)
-template <bool COPY>
+// PUPD (tile-local mode without the fused k_search_apply): p += alpha s_old rides along (see k_search_apply)
+template <bool COPY, bool PUPD = false>
 __global__ __launch_bounds__(256) void k_update_search(double* __restrict__ s, const double* __restrict__ z,
                                                        const uint8_t* __restrict__ mask, size_t S, const PcgScalars* sc,
-                                                       int force, double beta_arg) {
+                                                       int force, double beta_arg, double* __restrict__ p = nullptr) {
   if (!force && pcg_idle(sc)) return;
   const double beta = force ? beta_arg : sc->beta;
+  const double alpha_prev = sc->alpha;
   for (size_t i = 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x); i < S; i += 2 * (size_t)gridDim.x * blockDim.x) {
     const sw_d2 zv = *reinterpret_cast<const sw_d2*>(z + i);
     if (COPY) { *reinterpret_cast<sw_d2*>(s + i) = zv; continue; }
@@ -425,6 +492,12 @@ __global__ __launch_bounds__(256) void k_update_search(double* __restrict__ s, c
     const bool f0 = (mm & CM_FLUID) != 0, f1 = ((mm >> 8) & CM_FLUID) != 0;
     if (!(f0 | f1)) continue;
     sw_d2 sv = *reinterpret_cast<const sw_d2*>(s + i);
+    if (PUPD) {
+      sw_d2 pv = *reinterpret_cast<const sw_d2*>(p + i);
+      if (f0) pv.x = pv.x + sv.x * alpha_prev;
+      if (f1) pv.y = pv.y + sv.y * alpha_prev;
+      *reinterpret_cast<sw_d2*>(p + i) = pv;
+    }
     if (f0) sv.x = zv.x + beta * sv.x;
     if (f1) sv.y = zv.y + beta * sv.y;
     *reinterpret_cast<sw_d2*>(s + i) = sv;      // a non-fluid partner is written back unchanged
@@ -496,18 +569,8 @@ struct SweepArgs {
   int force;
   int* error;
   unsigned long long* timeline;   // [nbands][8] {entry, first block ready, exit, blocks << 32 | stalled blocks, 4 development words} (euler_sweep_timeline)
-  // tile-local IC(0) (EULER_PRECOND_IC0_TILE; k_sweep_skew<OP, false, true>, k_sweep_simple): a band's n_units units of 96
-  // records are cut into tile_nt tiles, tile k = records [96 * (k * n_units / tile_nt), 96 * ((k + 1) * n_units / tile_nt))
-  int n_units, tile_nt;           // tile_nt = 0: the reference's IC(0)
-  const uint8_t* tile_fluid;      // [nbands][tile_nt]: does the tile hold a fluid cell (k_tile_flags, per solve)
+  int tile_w;                     // k_sweep_simple only: > 0 = tile-local IC(0) with tiles of tile_w records (the cross-check of k_precond_tile)
 };
-// does record t start a tile (are the couplings arriving from record t - 1 cut)?
-__host__ __device__ __forceinline__ int tile_lo(int n_units, int nt, int k) { return 96 * (int)((long long)k * n_units / nt); }
-__device__ __forceinline__ bool tile_start(int n_units, int nt, int t) {
-  if (t % 96) return false;
-  const int u = t / 96, k = (int)(((long long)u * nt + n_units - 1) / n_units);
-  return (int)((long long)k * n_units / nt) == u;
-}
 
 template <int OP>
 __device__ __forceinline__ double sweep_cell(uint8_t m, double in, double pre_here, double own_val, double own_pre,
@@ -556,9 +619,9 @@ __global__ __launch_bounds__(1024) void k_sweep_simple(SweepArgs a) {
         double own_val = OP == SW_FACTOR ? a.pre[io] : dst[io];
         double nb_val = OP == SW_FACTOR ? a.pre[in_] : dst[in_];
         double own_pre = OP == SW_FORWARD ? a.pre[io] : 0.0, nb_pre = OP == SW_FORWARD ? a.pre[in_] : 0.0;
-        if (a.tile_nt > 0) {   // tile-local IC(0): a cut coupling carries what the wavefront carries into a tile
+        if (a.tile_w > 0) {   // tile-local IC(0): a cut coupling carries what the wavefront carries into a tile
           const int l = y & 63, t = x + l;
-          const bool cut = tile_start(a.n_units, a.tile_nt, BWD ? t + 1 : t);
+          const bool cut = (BWD ? t + 1 : t) % a.tile_w == 0;
           if (cut) { own_val = 0.0; own_pre = 1.0; }                                   // forward: (-1 * 1) * (+0) = -0.0
           if (cut || l == (BWD ? 63 : 0)) { nb_val = 0.0; nb_pre = 1.0; }
         }
@@ -622,16 +685,6 @@ __global__ __launch_bounds__(1024) void k_sweep_simple(SweepArgs a) {
 #define SW_TRACE_HANDOFF 0   // development build: time stamps of one hand-off (column block 40) in the timeline words 4..7
 #endif
 #define SW_TRACE_CB 40
-#define DPP_WAVE_SHL1 0x130
-#define DPP_WAVE_SHR1 0x138
-
-// lane l <- neighbouring lane's v; the lane without a source (0 for shr, 63 for shl) receives `edge`
-template <int CTRL>
-__device__ __forceinline__ double wave_shift_inject(double v, double edge) {
-  const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), CTRL, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
 
 struct SweepShared {
   double pub[SW_RING][64];            // carry rows of the last SW_RING steps (ring slot = step & 63)
@@ -641,34 +694,21 @@ struct SweepShared {
   unsigned int abort;
   int ord;
 };
-struct SweepSharedTile {              // tile-local sweeps have no hand-off: the same members, never touched
-  double pub[1][64];
-  double bnd[1][SW_BLK];
-  unsigned int dep_done, pub_done, comp_done, abort;
-  int ord;
-};
 __device__ __forceinline__ unsigned int lds_get(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_put(unsigned int* p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #define SW_COMPILER_FENCE() asm volatile("" ::: "memory")
 
-// TILE (EULER_PRECOND_IC0_TILE): the same compute wave without any hand-off - one 64-thread workgroup per (tile, band),
-// grid (tile_nt, bands of this rank); the tile's records are the wave's range and it starts from the constants a band
-// starts from.  Every tile is independent: hundreds to thousands of waves stream at once and the sweeps are bound by HBM
-// bandwidth instead of by the dependency chain of a lone wave per band.
-template <int OP, bool XG = false, bool TILE = false>
-__global__ __launch_bounds__(TILE ? 64 : 192) void k_sweep_skew(SweepArgs a) {
-  __shared__ typename std::conditional<TILE, SweepSharedTile, SweepShared>::type sh;
+template <int OP, bool XG = false>
+__global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
+  __shared__ SweepShared sh;
   const int lane = threadIdx.x & 63;
   const int role = threadIdx.x >> 6;                  // 0 compute, 1 announce, 2 fetch boundaries
-  int ord = 0;
-  if (!TILE) {
-    if (threadIdx.x == 0) {
-      sh.ord = (int)(atomicAdd(a.ticket, 1u) - a.ticket_base);        // position in the band pipeline
-      sh.dep_done = 0; sh.pub_done = 0; sh.comp_done = 0; sh.abort = 0;
-    }
-    __syncthreads();
-    ord = __builtin_amdgcn_readfirstlane(sh.ord);
+  if (threadIdx.x == 0) {
+    sh.ord = (int)(atomicAdd(a.ticket, 1u) - a.ticket_base);        // position in the band pipeline
+    sh.dep_done = 0; sh.pub_done = 0; sh.comp_done = 0; sh.abort = 0;
   }
+  __syncthreads();
+  const int ord = __builtin_amdgcn_readfirstlane(sh.ord);
   if (!a.force && pcg_idle(a.sc)) return;
   const unsigned long long t_entry = wall_clock64();
   constexpr bool BWD = OP == SW_BACKWARD;
@@ -678,10 +718,10 @@ __global__ __launch_bounds__(TILE ? 64 : 192) void k_sweep_skew(SweepArgs a) {
   const int X = g.T - 63, T = g.T, TS = g.TS, nb = g.nbands;   // X: hand-off columns live in step space, [0, T - 63) (T is even: g.X or g.X + 1)
   // `ord` counts this launch's (= this rank's) bands in sweep order; gord is the position in the
   // global band pipeline, which also names the hand-off rows (forwarded rank to rank when coupled)
-  const int band = TILE ? a.band_lo + (int)blockIdx.y : (BWD ? a.band_lo + a.nb_local - 1 - ord : a.band_lo + ord);
+  const int band = BWD ? a.band_lo + a.nb_local - 1 - ord : a.band_lo + ord;
   const int gord = BWD ? nb - 1 - band : band;
-  const bool has_prev = !TILE && (ord > 0 || (a.couple && gord > 0));            // a band before us in sweep order
-  const bool publish = !TILE && (ord + 1 < a.nb_local || (a.couple && gord + 1 < nb));
+  const bool has_prev = ord > 0 || (a.couple && gord > 0);            // a band before us in sweep order
+  const bool publish = ord + 1 < a.nb_local || (a.couple && gord + 1 < nb);
   unsigned long long* gr_out = a.granules + (size_t)gord * a.gran_stride * 2;
   const unsigned long long* gr_in = a.granules + (size_t)(has_prev ? gord - 1 : 0) * a.gran_stride * 2;
   if (XG) {   // the band pipeline continues across GPUs: same granules, same epochs, system-scope accesses (below)
@@ -702,11 +742,7 @@ __global__ __launch_bounds__(TILE ? 64 : 192) void k_sweep_skew(SweepArgs a) {
   const int full_blocks = BODY_HALF * (((T + SW_BLK - 1) / SW_BLK + BODY_HALF - 1) / BODY_HALF);
   const int ncolblk = (X + SW_BLK - 1) / SW_BLK;
   int B0 = 0, B1 = full_blocks, win_lo = 0, win_hi = ncolblk;
-  if (TILE) {   // the tile's records [t0, t1): whole groups of 96 steps in either direction (T is a multiple of 96)
-    if (a.tile_fluid && !a.tile_fluid[(size_t)band * a.tile_nt + blockIdx.x]) return;   // nothing to do: pre stays, q and z are +0 (zeroed per solve)
-    const int t0 = tile_lo(a.n_units, a.tile_nt, (int)blockIdx.x), t1 = tile_lo(a.n_units, a.tile_nt, (int)blockIdx.x + 1);
-    B0 = (BWD ? T - t1 : t0) / SW_BLK; B1 = (BWD ? T - t0 : t1) / SW_BLK;
-  } else if (RANGED && a.ranges) {
+  if (RANGED && a.ranges) {
     const int4 mine = a.ranges[band];
     B0 = BWD ? mine.z : mine.x; B1 = BWD ? mine.w : mine.y;
     if (B0 >= B1) return;                              // no fluid in this band
@@ -722,7 +758,7 @@ __global__ __launch_bounds__(TILE ? 64 : 192) void k_sweep_skew(SweepArgs a) {
 
   // =========================== helper waves: the band hand-off ===================================
   // wave 1 announces this band's edge values to the next band, wave 2 fetches the previous band's
-  if (!TILE && role == 1) {
+  if (role == 1) {
     if (!publish) return;
     const int t8 = lane >> 3, k8 = lane & 7;            // this lane serves group (next + t8), column k8 of it
     auto announce = [&](int col, double v, bool on) {
@@ -761,7 +797,7 @@ __global__ __launch_bounds__(TILE ? 64 : 192) void k_sweep_skew(SweepArgs a) {
     announce(SW_BLK * (B1 - 8), sh.pub[(SW_BLK * B1 - 1) & (SW_RING - 1)][EDGE], lane == 0);
     return;
   }
-  if (!TILE && role == 2) {
+  if (role == 2) {
     if (!has_prev) return;
     // Four polls are kept in flight (re-issued as they are retired, so they space themselves a quarter
     // of a round trip apart): a granule is then seen about half a round trip after it lands instead
@@ -1045,12 +1081,213 @@ __global__ __launch_bounds__(TILE ? 64 : 192) void k_sweep_skew(SweepArgs a) {
   };
   typedef std::integral_constant<bool, true> yes_t;
   typedef std::integral_constant<bool, false> no_t;
-  if constexpr (TILE) sweep(no_t(), no_t());
-  else if (has_prev) { if (publish) sweep(yes_t(), yes_t()); else sweep(yes_t(), no_t()); }
+  if (has_prev) { if (publish) sweep(yes_t(), yes_t()); else sweep(yes_t(), no_t()); }
   else          { if (publish) sweep(no_t(), yes_t()); else sweep(no_t(), no_t()); }
-  if (!TILE && lane == 0) {
+  if (lane == 0) {
     unsigned long long* tl = a.timeline + (size_t)ord * 8;
     tl[0] = t_entry; tl[1] = t_first; tl[2] = wall_clock64(); tl[3] = ((unsigned long long)(B1 - B0) << 32) | stalls;
+  }
+}
+
+
+// ==========================================================================================
+// Tile-local IC(0) (EULER_PRECOND_IC0_TILE): the three recurrences above restricted to blocks - a block = the cells of one
+// band whose records fall into one tile [k W, (k+1) W), a parallelogram of 64 rows x W columns.  In the band-skewed layout
+// a tile is W consecutive records = one contiguous piece of every solver array, and it is small enough to live in the
+// REGISTERS of one wave (W = 16: 16 doubles per lane and vector).  So one wave loads a tile's r, A s and precon once, and
+// does everything the PCG iteration needs between two apply_a passes without another trip to memory:
+//     r -= alpha A s (fmadd, main.c:754) ; max |r| (inf_norm, main.c:756) ; q = L^-1 r ; z = L^-T q (main.c:602-626) ; dot(z, r)
+// = kernels K2, K3, K4 and dot() of SURVEY 8d in ONE pass: 5 w + 1 = 41 bytes per cell instead of 6w+1 + 3w+1 + 4w+1 + ... .
+// (p += alpha s rides along with the next apply_a pass, which reads s anyway: k_search_apply<.., true>.)
+// The wavefront inside the tile is the one of k_sweep_skew (lane l at record t, lower / upper row by DPP wave shifts), fully
+// unrolled with static register indices; tiles are independent, so thousands of waves stream at once and the kernel is
+// bound by HBM bandwidth, not by a dependency chain.  The compiler schedules it (nothing to hand-issue: occupancy hides
+// the latency).  Each wave walks tiles wave_id, wave_id + n_waves, ...; per-lane sums are folded in that fixed order,
+// then per wave, per block, and by the last block over all blocks in index order: deterministic.
+#define PT_THREADS 256
+struct TileArgs {
+  SkewGeom g;
+  const uint8_t* mask;
+  double* pre;            // factor: in/out; solve: in
+  double* r;              // solve: r (updated in place when rupd)
+  const double* as;       // A s of this iteration (rupd only)
+  double* z;
+  int band_lo, nb_local;
+  int rupd;               // 1: r -= alpha A s first and report max |r| (a PCG iteration); 0: z = M^-1 r only (start of a solve)
+  int sweeps;             // 0: the last iteration of the budget - only r and its norm are needed
+  int fin_dot;            // scalar epilogue of dot(z, r): FIN_SIGMA_INIT / FIN_BETA / FIN_STORE_ONLY, -1 = none (replayed sequentially)
+  int via;                // 0 single rank, FIN_VIA_P2P, or FIN_TO_COMM (multi-rank: how the two results reach the other ranks)
+  double* part_max; double* part_dot;
+  unsigned int* counter;
+  PcgScalars* sc;
+  int force;
+  double alpha_arg;       // force: alpha of the r update (single building block, tests)
+};
+
+// fixed-shape reductions of a PT_THREADS block; result valid in thread 0
+__device__ __forceinline__ void tile_block_reduce(double& mx, double& sm) {
+  __shared__ double s_mx[PT_THREADS / 64], s_sm[PT_THREADS / 64];
+  mx = eu_wave_max(mx);
+  sm = eu_wave_sum(sm);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { s_mx[threadIdx.x >> 6] = mx; s_sm[threadIdx.x >> 6] = sm; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = s_mx[0]; sm = s_sm[0];
+    for (int k = 1; k < PT_THREADS / 64; ++k) { mx = s_mx[k] > mx ? s_mx[k] : mx; sm += s_sm[k]; }
+  }
+}
+
+template <int W>
+__global__ __launch_bounds__(PT_THREADS) void k_factor_tile(TileArgs a) {
+  if (!a.force && pcg_idle(a.sc)) return;
+  const int lane = threadIdx.x & 63;
+  const int ntb = a.g.T / W, total = a.nb_local * ntb;
+  const int n_waves = gridDim.x * (PT_THREADS / 64);
+  for (int tile = blockIdx.x * (PT_THREADS / 64) + (threadIdx.x >> 6); tile < total; tile += n_waves) {
+    const int band = a.band_lo + tile / ntb, k = tile % ntb;
+    const size_t base = ((size_t)band * a.g.TS + (size_t)k * W) * 64 + 2 * lane;
+    unsigned int mm[W / 2];
+    unsigned int any = 0;
+#pragma unroll
+    for (int P = 0; P < W / 2; ++P) { mm[P] = *reinterpret_cast<const unsigned short*>(a.mask + base + P * 128); any |= mm[P]; }
+    if (!__ballot(((any | (any >> 8)) & CM_FLUID) != 0)) continue;     // no fluid in this tile: precon stays what it is
+    sw_d2 pp[W / 2];
+#pragma unroll
+    for (int P = 0; P < W / 2; ++P) pp[P] = *reinterpret_cast<const sw_d2*>(a.pre + base + P * 128);
+    double own = 0.0, out = 0.0;      // a tile starts where a band starts: precon 0 to the left and below
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const int cm = (int)((mm[j >> 1] >> ((j & 1) * 8)) & 0xff);
+      const double cpre = (j & 1) ? pp[j >> 1].y : pp[j >> 1].x;
+      const double nbv = wave_shift_inject<DPP_WAVE_SHR1>(out, 0.0);
+      const double aa = (double)(cm >> CM_DIAG_SHIFT);               // main.c:586-600
+      const double cl = -1.0 * own, cb = -1.0 * nbv;
+      double e = aa - cl * cl - cb * cb;
+      if (e < 0.25 * aa) e = (aa != 0.0) ? aa : 1.0;
+      const double res = (cm & CM_FLUID) ? 1.0 / sqrt(e) : cpre;     // non-fluid: the stale entry stays (and is what the neighbours read)
+      own = res; out = res;
+      if (j & 1) pp[j >> 1].y = res; else pp[j >> 1].x = res;
+    }
+#pragma unroll
+    for (int P = 0; P < W / 2; ++P) *reinterpret_cast<sw_d2*>(a.pre + base + P * 128) = pp[P];
+  }
+}
+
+template <int W>
+__global__ __launch_bounds__(PT_THREADS) void k_precond_tile(TileArgs a) {
+  if (!a.force && pcg_idle(a.sc)) return;
+  const int lane = threadIdx.x & 63;
+  const int ntb = a.g.T / W, total = a.nb_local * ntb;
+  const int n_waves = gridDim.x * (PT_THREADS / 64);
+  const double nalpha = -(a.force ? a.alpha_arg : a.sc->alpha);
+  double mx = 0.0, dsum = 0.0;
+  for (int tile = blockIdx.x * (PT_THREADS / 64) + (threadIdx.x >> 6); tile < total; tile += n_waves) {
+    const int band = a.band_lo + tile / ntb, k = tile % ntb;
+    const size_t base = ((size_t)band * a.g.TS + (size_t)k * W) * 64 + 2 * lane;
+    unsigned int mm[W / 2];
+    unsigned int any = 0;
+#pragma unroll
+    for (int P = 0; P < W / 2; ++P) { mm[P] = *reinterpret_cast<const unsigned short*>(a.mask + base + P * 128); any |= mm[P]; }
+    if (!__ballot(((any | (any >> 8)) & CM_FLUID) != 0)) continue;     // no fluid in this tile: r, z stay +0 there
+    sw_d2 rr[W / 2], qq[W / 2], pp[W / 2];
+#pragma unroll
+    for (int P = 0; P < W / 2; ++P) {
+      rr[P] = *reinterpret_cast<const sw_d2*>(a.r + base + P * 128);
+      pp[P] = *reinterpret_cast<const sw_d2*>(a.pre + base + P * 128);
+      if (a.rupd) qq[P] = *reinterpret_cast<const sw_d2*>(a.as + base + P * 128);
+    }
+    if (a.rupd) {      // r -= alpha z (fmadd, main.c:754, evaluated as r + z * (-alpha) like k_update_pr) and max |r| over fluid cells
+#pragma unroll
+      for (int P = 0; P < W / 2; ++P) {
+        if (mm[P] & CM_FLUID) { rr[P].x = rr[P].x + qq[P].x * nalpha; const double v = fabs(rr[P].x); if (v > mx) mx = v; }
+        if ((mm[P] >> 8) & CM_FLUID) { rr[P].y = rr[P].y + qq[P].y * nalpha; const double v = fabs(rr[P].y); if (v > mx) mx = v; }
+        *reinterpret_cast<sw_d2*>(a.r + base + P * 128) = rr[P];
+      }
+    }
+    if (!a.sweeps) continue;
+    // L q = r (main.c:602-613).  What travels from cell to cell is m = (-1 * precon) * q, the term both consumers subtract.
+    double own = -0.0, out = -0.0;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const int cm = (int)((mm[j >> 1] >> ((j & 1) * 8)) & 0xff);
+      const double cin = (j & 1) ? rr[j >> 1].y : rr[j >> 1].x, cpre = (j & 1) ? pp[j >> 1].y : pp[j >> 1].x;
+      const double nbv = wave_shift_inject<DPP_WAVE_SHR1>(out, -0.0);
+      const double t = cin - own - nbv;
+      const double qv = t * cpre;
+      const double res = (cm & CM_FLUID) ? qv : 0.0;
+      const double carry = -1.0 * cpre * res;
+      own = carry; out = carry;
+      if (j & 1) qq[j >> 1].y = res; else qq[j >> 1].x = res;
+    }
+    // L^T z = q (main.c:615-626), from the tile's last record down; dot(z, r) on the fly
+    own = 0.0; out = 0.0;
+#pragma unroll
+    for (int j = W - 1; j >= 0; --j) {
+      const int cm = (int)((mm[j >> 1] >> ((j & 1) * 8)) & 0xff);
+      const double cin = (j & 1) ? qq[j >> 1].y : qq[j >> 1].x, cpre = (j & 1) ? pp[j >> 1].y : pp[j >> 1].x;
+      const double crr = (j & 1) ? rr[j >> 1].y : rr[j >> 1].x;
+      const double nbv = wave_shift_inject<DPP_WAVE_SHL1>(out, 0.0);
+      const double kr = ((cm & CM_RIGHT) ? -1.0 : 0.0) * cpre, ku = ((cm & CM_UP) ? -1.0 : 0.0) * cpre;
+      const double t = cin - kr * own - ku * nbv;
+      const double zv = t * cpre;
+      const double res = (cm & CM_FLUID) ? zv : 0.0;
+      own = res; out = res;
+      if (cm & CM_FLUID) dsum += res * crr;
+      if (j & 1) qq[j >> 1].y = res; else qq[j >> 1].x = res;
+    }
+#pragma unroll
+    for (int P = 0; P < W / 2; ++P) *reinterpret_cast<sw_d2*>(a.z + base + P * 128) = qq[P];
+  }
+  // ---- the two reductions: block -> partials -> the last block folds them in index order and applies the scalar epilogues
+  tile_block_reduce(mx, dsum);
+  __shared__ int am_last;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(&a.part_max[blockIdx.x]), (unsigned long long)__double_as_longlong(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(&a.part_dot[blockIdx.x]), (unsigned long long)__double_as_longlong(dsum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int t = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    am_last = t == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!am_last) return;
+  double vmax = 0.0, vsum = 0.0;
+  for (unsigned int i = threadIdx.x; i < gridDim.x; i += PT_THREADS) {
+    const double m = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&a.part_max[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const double d = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&a.part_dot[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    vmax = m > vmax ? m : vmax; vsum += d;
+  }
+  tile_block_reduce(vmax, vsum);
+  if (a.via == FIN_VIA_P2P) {      // uniform: every thread of this block is here
+    if (a.rupd) vmax = p2p_allreduce_block<true>(a.sc, vmax);
+    if (a.fin_dot >= 0) vsum = p2p_allreduce_block<false>(a.sc, vsum);
+  }
+  if (threadIdx.x == 0) {
+    if (a.via == FIN_TO_COMM) { a.sc->comm_val = vmax; a.sc->comm_val2 = vsum; }   // the epilogues run after the host-driven all-reduces
+    else {
+      if (a.rupd) pcg_scalar_step(a.sc, FIN_RNORM, vmax);
+      if (a.fin_dot >= 0 && !(a.rupd && a.sc->done)) pcg_scalar_step(a.sc, a.fin_dot, vsum);
+    }
+    __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// tile-local mode: the p += alpha s (fmadd, main.c:753) of the last iteration that ran (the others rode along with the next
+// iteration's apply_a pass)
+__global__ __launch_bounds__(256) void k_finish_p(double* __restrict__ p, const uint8_t* __restrict__ mask, size_t e_lo, size_t S,
+                                                  const PcgScalars* sc) {
+  if (!sc->nonzero || sc->iters == 0) return;
+  const double alpha = sc->alpha;
+  const double* s = sc->s_last + e_lo;
+  for (size_t i = 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x); i < S; i += 2 * (size_t)gridDim.x * blockDim.x) {
+    const unsigned int mm = *reinterpret_cast<const unsigned short*>(mask + i);
+    const bool f0 = (mm & CM_FLUID) != 0, f1 = ((mm >> 8) & CM_FLUID) != 0;
+    if (!(f0 | f1)) continue;
+    const sw_d2 sv = *reinterpret_cast<const sw_d2*>(s + i);
+    sw_d2 pv = *reinterpret_cast<const sw_d2*>(p + i);
+    if (f0) pv.x = pv.x + sv.x * alpha;
+    if (f1) pv.y = pv.y + sv.y * alpha;
+    *reinterpret_cast<sw_d2*>(p + i) = pv;
   }
 }
 
@@ -1070,9 +1307,7 @@ static SweepArgs make_sweep_args(euler_sim* S, int op, int force) {
   a.ticket_base = S->ticket_base; a.epoch = S->epoch;
   a.sc = S->sc; a.force = force; a.error = &S->ms->error;
   a.timeline = S->sweep_timeline;
-  a.n_units = S->geom.T / 96;
-  a.tile_nt = S->cfg.precond == EULER_PRECOND_IC0_TILE ? S->tile_nt : 0;
-  a.tile_fluid = S->tile_fluid;
+  a.tile_w = S->cfg.precond == EULER_PRECOND_IC0_TILE ? S->tile_w : 0;
   return a;
 }
 
@@ -1129,27 +1364,8 @@ __global__ __launch_bounds__(256) void k_pack_fbits(const uint8_t* __restrict__ 
   const size_t o = ((size_t)band * fb_stride + gi) * 64 + lane;
   fwd[o] = wf; bwd[o] = wb;
 }
-// tile-local IC(0): which tiles hold fluid at all (the others are skipped by all three sweeps)
-__global__ __launch_bounds__(64) void k_tile_flags(const unsigned int* __restrict__ fwd, int fb_stride, int n_units, int nt,
-                                                   uint8_t* __restrict__ flags, int band_lo) {
-  const int band = band_lo + blockIdx.y, k = blockIdx.x;
-  const int b0 = tile_lo(n_units, nt, k) / 8, b1 = tile_lo(n_units, nt, k + 1) / 8;
-  const unsigned int* p = fwd + ((size_t)band * fb_stride + b0) * 64 + threadIdx.x;
-  unsigned int w = 0;
-  for (int b = b0; b < b1; ++b, p += 64) w |= *p;
-  const bool any = __ballot(w != 0) != 0;
-  if (threadIdx.x == 0) flags[(size_t)band * nt + k] = any;
-}
 int eu_launch_band_ranges(euler_sim* S) {
-  if (S->cfg.precond == EULER_PRECOND_IC0_TILE) {   // no band pipeline: the packed fluid flags and the per-tile census
-    const int nbl = S->band_hi - S->band_lo;
-    const size_t n = (size_t)nbl * S->fb_stride * 64;
-    LAUNCH(S, KC_BUILD_SYSTEM, k_pack_fbits, dim3((unsigned)((n + 255) / 256)), dim3(256), S->cellmask, S->geom, S->fbits_fwd, S->fbits_bwd,
-           S->fb_stride, S->band_lo, nbl);
-    LAUNCH(S, KC_BUILD_SYSTEM, k_tile_flags, dim3(S->tile_nt, nbl), dim3(64), S->fbits_fwd, S->fb_stride, S->geom.T / 96, S->tile_nt,
-           S->tile_fluid, S->band_lo);
-    return EULER_OK;
-  }
+  if (S->cfg.precond == EULER_PRECOND_IC0_TILE) return EULER_OK;   // no band pipeline, no packed flags: k_precond_tile reads the cell mask
   // a rank needs the ranges of its own bands and of the band before / after its slab (the hand-off windows)
   const int b0 = S->band_lo > 0 ? S->band_lo - 1 : 0, b1 = S->band_hi < S->geom.nbands ? S->band_hi + 1 : S->geom.nbands;
   LAUNCH(S, KC_BUILD_SYSTEM, k_band_ranges, dim3(b1 - b0), dim3(1024), S->count, S->X, S->Y, S->geom.T, S->band_ranges, b0);
@@ -1212,13 +1428,6 @@ static int comm_halo_s(euler_sim* S) {
 
 template <int OP>
 static int launch_sweep(euler_sim* S, int cls, int force) {
-  if (S->cfg.precond == EULER_PRECOND_IC0_TILE && S->cfg.sweep_mode != EULER_SWEEP_SIMPLE) {
-    // tile-local IC(0): every (tile, band) is an independent wavefront; nothing crosses a slab boundary either
-    SweepArgs a = make_sweep_args(S, OP, force);
-    if (force) a.tile_fluid = nullptr;   // single building blocks (euler_pcg_op) may run before the per-solve census
-    LAUNCH(S, cls, (k_sweep_skew<OP, false, true>), dim3(S->tile_nt, S->band_hi - S->band_lo), dim3(64), a);
-    return EULER_OK;
-  }
   if (S->cfg.sweep_mode != EULER_SWEEP_SIMPLE) {
     constexpr bool BWD = OP == SW_BACKWARD;
     const int nb = S->geom.nbands, nbl = S->band_hi - S->band_lo;
@@ -1271,6 +1480,59 @@ static int launch_dot(euler_sim* S, const double* a, const double* b, int fin_op
   return EULER_OK;
 }
 
+// tile-local IC(0) in its production form: everything between two apply_a passes in one kernel (k_precond_tile)
+static inline bool tile_fused(const euler_sim* S) { return S->cfg.precond == EULER_PRECOND_IC0_TILE && S->cfg.sweep_mode != EULER_SWEEP_SIMPLE; }
+__global__ void k_scalar_epilogue2(PcgScalars* sc, int op, int force) {   // after the all-reduce of comm_val2
+  if (!force && pcg_idle(sc)) return;
+  pcg_scalar_step(sc, op, sc->comm_val2);
+}
+static TileArgs make_tile_args(euler_sim* S, int force) {
+  TileArgs a;
+  a.g = S->geom; a.mask = S->cellmask; a.pre = S->precon; a.r = S->r; a.as = S->q; a.z = S->z;
+  a.band_lo = S->band_lo; a.nb_local = S->band_hi - S->band_lo;
+  a.rupd = 0; a.sweeps = 1; a.fin_dot = -1;
+  a.via = S->has_comm ? (S->p2p_on ? (int)FIN_VIA_P2P : (int)FIN_TO_COMM) : 0;
+  a.part_max = S->partial; a.part_dot = S->partial2; a.counter = S->red_counter; a.sc = S->sc; a.force = force; a.alpha_arg = 0.0;
+  return a;
+}
+static inline unsigned tile_blocks(const euler_sim* S) {
+  const size_t tiles = (size_t)(S->band_hi - S->band_lo) * (S->geom.T / S->tile_w);
+  return eu_blocks(tiles, PT_THREADS / 64, 2048);
+}
+static int launch_factor_tile(euler_sim* S, int force) {
+  const TileArgs a = make_tile_args(S, force);
+  switch (S->tile_w) {
+    case 8: LAUNCH(S, KC_PRECON_FACTOR, k_factor_tile<8>, dim3(tile_blocks(S)), dim3(PT_THREADS), a); break;
+    case 32: LAUNCH(S, KC_PRECON_FACTOR, k_factor_tile<32>, dim3(tile_blocks(S)), dim3(PT_THREADS), a); break;
+    default: LAUNCH(S, KC_PRECON_FACTOR, k_factor_tile<16>, dim3(tile_blocks(S)), dim3(PT_THREADS), a); break;
+  }
+  return EULER_OK;
+}
+// [r -= alpha A s, max |r|,] z = M^-1 r, dot(z, r) with its scalar epilogue fin_dot (FIN_SIGMA_INIT / FIN_BETA / FIN_STORE_ONLY)
+static int launch_precond_tile(euler_sim* S, int rupd, int sweeps, int fin_dot, int force, double alpha) {
+  const bool seq = S->cfg.dot_mode == EULER_DOT_SEQUENTIAL && !S->has_comm;
+  TileArgs a = make_tile_args(S, force);
+  a.rupd = rupd; a.sweeps = sweeps; a.fin_dot = (seq || !sweeps) ? -1 : fin_dot; a.alpha_arg = alpha;
+  switch (S->tile_w) {
+    case 8: LAUNCH(S, KC_PRECOND_TILE, k_precond_tile<8>, dim3(tile_blocks(S)), dim3(PT_THREADS), a); break;
+    case 32: LAUNCH(S, KC_PRECOND_TILE, k_precond_tile<32>, dim3(tile_blocks(S)), dim3(PT_THREADS), a); break;
+    default: LAUNCH(S, KC_PRECOND_TILE, k_precond_tile<16>, dim3(tile_blocks(S)), dim3(PT_THREADS), a); break;
+  }
+  if (seq && sweeps && fin_dot >= 0)   // the reference's row-major dot(z, r); a no-op once max |r| <= tol
+    LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), S->z, S->r, S->cellmask, S->geom, S->sc, fin_dot, force);
+  if (a.via == FIN_TO_COMM) {          // no mailboxes: the two results travel through the communicator, the epilogues follow
+    if (rupd) {
+      COMM_CALL(S->comm.allreduce(S->comm.ctx, &S->sc->comm_val, 1, 1));
+      hipLaunchKernelGGL(k_scalar_epilogue, dim3(1), dim3(1), 0, S->stream, S->sc, (int)FIN_RNORM, force);
+    }
+    if (a.fin_dot >= 0) {
+      COMM_CALL(S->comm.allreduce(S->comm.ctx, &S->sc->comm_val2, 1, 0));
+      hipLaunchKernelGGL(k_scalar_epilogue2, dim3(1), dim3(1), 0, S->stream, S->sc, fin_dot, force);
+    }
+  }
+  return EULER_OK;
+}
+
 static int launch_precondition(euler_sim* S, int force) {   // z = M^-1 r
   if (S->cfg.precond == EULER_PRECOND_JACOBI) {
     LAUNCH(S, KC_JACOBI, k_jacobi, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->r), LOC(S->z), LOC(S->cellmask),
@@ -1287,14 +1549,19 @@ static int launch_apply_a_and_alpha(euler_sim* S, int force) {
   if (S->has_comm) { int rc = comm_halo_s(S); if (rc) return rc; }
   SkewGeom gl = S->geom;
   gl.S = S->e_cnt;
-  LAUNCH(S, KC_APPLY_A, k_apply_a, dim3(loc_red_blocks(S)), dim3(RED_THREADS), LOC(S->s), LOC(S->z), LOC(S->cellmask), gl,
-         S->partial, S->sc, force, S->red_counter, seq ? -1 : fin_or_comm(S, FIN_ALPHA));
+  double* out = tile_fused(S) ? S->q : S->z;     // tile-local mode: A s always lands in q (k_precond_tile reads it there and writes z)
+  LAUNCH(S, KC_APPLY_A, k_apply_a, dim3(loc_red_blocks(S)), dim3(RED_THREADS), LOC(S->s), LOC(out), LOC(S->cellmask), gl,
+         S->partial, S->sc, force, S->red_counter, seq ? -1 : fin_or_comm(S, FIN_ALPHA), tile_fused(S) ? S->s : (double*)nullptr);
   if (seq)
-    LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), S->z, S->s, S->cellmask, S->geom, S->sc, (int)FIN_ALPHA, force);
+    LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), out, S->s, S->cellmask, S->geom, S->sc, (int)FIN_ALPHA, force);
   if (S->has_comm) return comm_finish(S, FIN_ALPHA, 0, force);
   return EULER_OK;
 }
 
+static inline unsigned sa_blocks(const euler_sim* S) {   // one wave per run of SA_RUN pair-records, at most 2048 blocks (the partials)
+  const size_t runs = (size_t)(S->band_hi - S->band_lo) * ((S->geom.TS / 2 + SA_RUN - 1) / SA_RUN);
+  return eu_blocks(runs, SA_THREADS / 64, 2048);
+}
 // iterations >= 1 of a single-GPU solve: s' = z + beta s and A s' in one launch; returns with S->s = s' and A s' in S->q
 static int launch_search_apply_and_alpha(euler_sim* S) {
   const bool seq = S->cfg.dot_mode == EULER_DOT_SEQUENTIAL && !S->has_comm;
@@ -1306,12 +1573,22 @@ static int launch_search_apply_and_alpha(euler_sim* S) {
   }
   SkewGeom gl = S->geom;
   gl.S = S->e_cnt;
-  if (S->has_comm)
-    LAUNCH(S, KC_APPLY_A, k_search_apply<true>, dim3(loc_red_blocks(S)), dim3(RED_THREADS), LOC(S->s), LOC(S->z), LOC(S->s2), LOC(S->q), LOC(S->cellmask), gl,
-           S->partial, S->sc, 0, S->red_counter, fin_or_comm(S, FIN_ALPHA), nbr);
-  else
-    LAUNCH(S, KC_APPLY_A, k_search_apply<false>, dim3(S->red_blocks), dim3(RED_THREADS), S->s, S->z, S->s2, S->q, S->cellmask, S->geom,
-           S->partial, S->sc, 0, S->red_counter, seq ? -1 : (int)FIN_ALPHA, nbr);
+  const bool pupd = tile_fused(S);   // tile-local mode: the previous iteration's p += alpha s rides along
+  if (S->has_comm) {
+    if (pupd)
+      LAUNCH(S, KC_APPLY_A, (k_search_apply<true, true>), dim3(sa_blocks(S)), dim3(SA_THREADS), LOC(S->s), LOC(S->z), LOC(S->s2), LOC(S->q), LOC(S->cellmask), gl,
+             S->partial, S->sc, 0, S->red_counter, fin_or_comm(S, FIN_ALPHA), nbr, LOC(S->p), S->s2);
+    else
+      LAUNCH(S, KC_APPLY_A, (k_search_apply<true, false>), dim3(sa_blocks(S)), dim3(SA_THREADS), LOC(S->s), LOC(S->z), LOC(S->s2), LOC(S->q), LOC(S->cellmask), gl,
+             S->partial, S->sc, 0, S->red_counter, fin_or_comm(S, FIN_ALPHA), nbr, (double*)nullptr, (double*)nullptr);
+  } else {
+    if (pupd)
+      LAUNCH(S, KC_APPLY_A, (k_search_apply<false, true>), dim3(sa_blocks(S)), dim3(SA_THREADS), S->s, S->z, S->s2, S->q, S->cellmask, S->geom,
+             S->partial, S->sc, 0, S->red_counter, seq ? -1 : (int)FIN_ALPHA, nbr, S->p, S->s2);
+    else
+      LAUNCH(S, KC_APPLY_A, (k_search_apply<false, false>), dim3(sa_blocks(S)), dim3(SA_THREADS), S->s, S->z, S->s2, S->q, S->cellmask, S->geom,
+             S->partial, S->sc, 0, S->red_counter, seq ? -1 : (int)FIN_ALPHA, nbr, (double*)nullptr, (double*)nullptr);
+  }
   double* t = S->s; S->s = S->s2; S->s2 = t;
   if (seq)
     LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), S->q, S->s, S->cellmask, S->geom, S->sc, (int)FIN_ALPHA, 0);
@@ -1350,15 +1627,21 @@ int eu_launch_project(euler_sim* S, float dt) {
     hipLaunchKernelGGL(k_nonzero_from_comm, dim3(1), dim3(1), 0, S->stream, S->sc);
   }
   // if (!all_zero(r)) { ... }: every kernel below is a no-op when sc->nonzero == 0
+  const bool tile = tile_fused(S);
+  if (tile) {                                                     // E^-1 per tile, then z = M^-1 r and sigma = dot(z, r) in one pass
+    if ((rc = launch_factor_tile(S, 0))) return rc;
+    if ((rc = launch_precond_tile(S, 0, 1, FIN_SIGMA_INIT, 0, 0.0))) return rc;
+  } else {
   if (S->cfg.precond != EULER_PRECOND_JACOBI && (rc = launch_sweep<SW_FACTOR>(S, KC_PRECON_FACTOR, 0))) return rc;   // once per solve
   if ((rc = launch_precondition(S, 0))) return rc;
+  }
   LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<true>, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->s), LOC(S->z),
          LOC(S->cellmask), S->e_cnt, S->sc, 0, 0.0);
   if (S->has_comm && eu_p2p_has_neighbour_arrays(S)) {   // the neighbours read these rows of s in the second iteration's k_search_apply
     const int y0 = S->band_lo > 0 ? 64 * S->band_lo : -1, y1 = S->band_hi < S->geom.nbands ? 64 * S->band_hi - 1 : -1;
     LAUNCH(S, KC_UPDATE_SEARCH, k_publish_edge_rows, dim3((S->X + 255) / 256, 2), dim3(256), S->s, S->geom, y0, y1, S->sc);
   }
-  if ((rc = launch_dot(S, S->z, S->r, FIN_SIGMA_INIT, 0))) return rc;
+  if (!tile && (rc = launch_dot(S, S->z, S->r, FIN_SIGMA_INIT, 0))) return rc;
   // ranks with their neighbours' z and s mapped run the fused kernel too (it reads across the slab boundary directly)
   const bool fuse_search = !S->has_comm || eu_p2p_has_neighbour_arrays(S);
   if (fuse_search) HIPCHK(hipMemsetAsync(LOC(S->s2), 0, S->e_cnt * sizeof(double), S->stream));   // s' of non-fluid cells is never written
@@ -1374,6 +1657,18 @@ int eu_launch_project(euler_sim* S, float dt) {
       S->prof_iter = it;
       const bool fused = it > 0 && fuse_search;   // update_search of iteration it-1 rides along with this apply_a (A s' lands in q)
       if ((rc = fused ? launch_search_apply_and_alpha(S) : launch_apply_a_and_alpha(S, 0))) return rc;
+      if (tile) {
+        // r -= alpha A s, max |r| (sets `done`), z = M^-1 r, beta = dot(z, r) / sigma: one pass; on the last iteration of the
+        // budget only r and its norm (main.c:760-765 would be computed and never consumed)
+        S->prof_iter = it;
+        if ((rc = launch_precond_tile(S, 1, it + 1 < max_it, FIN_BETA, 0, 0.0))) return rc;
+        if (it + 1 < max_it && !fuse_search) {   // s = z + beta s with the pending p += alpha s (else both ride along with the next apply_a)
+          S->prof_iter = it + 1;
+          LAUNCH(S, KC_UPDATE_SEARCH, (k_update_search<false, true>), dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->s),
+                 LOC(S->z), LOC(S->cellmask), S->e_cnt, S->sc, 0, 0.0, LOC(S->p));
+        }
+        continue;
+      }
       LAUNCH(S, KC_UPDATE_PR, k_update_pr, dim3(loc_red_blocks(S)), dim3(RED_THREADS), LOC(S->p), LOC(S->r), LOC(S->s),
              LOC(fused ? S->q : S->z), LOC(S->cellmask), S->e_cnt, S->partial, S->sc, 0, 0.0, S->red_counter, fin_or_comm(S, FIN_RNORM));
       if (S->has_comm && (rc = comm_finish(S, FIN_RNORM, 1, 0))) return rc;
@@ -1406,6 +1701,8 @@ int eu_launch_project(euler_sim* S, float dt) {
     }
   }
   S->prof_iter = -2;
+  if (tile)   // the last iteration's p += alpha s (every other one rode along with the following apply_a pass)
+    LAUNCH(S, KC_UPDATE_PR, k_finish_p, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->p), LOC(S->cellmask), S->e_lo, S->e_cnt, S->sc);
   if (S->has_comm) {   // every rank needs the whole pressure field for the replicated velocity update
     const int n = S->comm.nranks, nb = S->geom.nbands;
     std::vector<int64_t> off(n), cnt(n);
@@ -1430,12 +1727,15 @@ int eu_launch_pcg_op(euler_sim* S, int op, float dt, double a, double* out) {
       LAUNCH(S, KC_MISC, k_pcg_reset, dim3(1), dim3(1), S->sc, S->cfg.tol, S->cfg.max_iterations);
       eu_launch_build_system(S, dt);
       break;
-    case EULER_OP_PRECON_FACTOR: launch_sweep<SW_FACTOR>(S, KC_PRECON_FACTOR, 1); break;
-    case EULER_OP_FORWARD_SOLVE: launch_sweep<SW_FORWARD>(S, KC_FORWARD_SOLVE, 1); break;
-    case EULER_OP_BACKWARD_SOLVE: launch_sweep<SW_BACKWARD>(S, KC_BACKWARD_SOLVE, 1); break;
+    case EULER_OP_PRECON_FACTOR: if (tile_fused(S)) launch_factor_tile(S, 1); else launch_sweep<SW_FACTOR>(S, KC_PRECON_FACTOR, 1); break;
+    // tile-local mode has no forward solve of its own (q lives in registers): BACKWARD_SOLVE runs the whole Z = M^-1 R
+    case EULER_OP_FORWARD_SOLVE: if (!tile_fused(S)) launch_sweep<SW_FORWARD>(S, KC_FORWARD_SOLVE, 1); break;
+    case EULER_OP_BACKWARD_SOLVE:
+      if (tile_fused(S)) launch_precond_tile(S, 0, 1, FIN_STORE_ONLY, 1, 0.0); else launch_sweep<SW_BACKWARD>(S, KC_BACKWARD_SOLVE, 1);
+      break;
     case EULER_OP_APPLY_A:
       LAUNCH(S, KC_APPLY_A, k_apply_a, dim3(S->red_blocks), dim3(RED_THREADS), S->s, S->z, S->cellmask, S->geom,
-             S->partial, S->sc, 1, S->red_counter, -1);
+             S->partial, S->sc, 1, S->red_counter, -1, (double*)nullptr);
       break;
     case EULER_OP_DOT_ZR: launch_dot(S, S->z, S->r, FIN_STORE_ONLY, 1); break;
     case EULER_OP_DOT_ZS: launch_dot(S, S->z, S->s, FIN_STORE_ONLY, 1); break;

@@ -49,12 +49,13 @@ enum {
   EULER_PRECOND_JACOBI = 1,  /* z = r/diag: NOT the reference's iterates; for roofline comparison only */
   EULER_PRECOND_IC0_TILE = 2 /* tile-local IC(0) (SURVEY 7 hard part 1(b): "tile-local IC(0) = block-Jacobi-IC"): the reference's
                                 three recurrences (main.c:586-626) restricted to blocks - a block = the cells of one 64-row band
-                                whose skew records t = x + y % 64 fall into one tile of euler_config.precond_tile_units * 96 records
-                                (a parallelogram of 64 rows); couplings between blocks are dropped from the factor and from both
-                                triangular solves.  Every block is an independent wavefront: bandwidth-bound instead of
-                                latency-bound, and it shards without any coupling between row slabs.  NOT the reference's iterates:
-                                same solution where PCG converges (tolerance parity), ~20 % more iterations (tools/precond_study.py).
-                                Restated in the oracle (eo_sim.tile_units): GPU = oracle bit for bit in EULER_DOT_SEQUENTIAL. */
+                                whose skew records t = x + y % 64 fall into one tile of euler_config.precond_tile_records records
+                                (a parallelogram of 64 rows x W columns); couplings between blocks are dropped from the factor and
+                                from both triangular solves.  A block lives in the registers of one wave, so r -= alpha A s,
+                                max |r|, both solves and dot(z,r) are ONE pass over memory (k_precond_tile), bandwidth-bound
+                                instead of latency-bound, and nothing couples row slabs.  NOT the reference's iterates: the same
+                                solution where PCG converges (tolerance parity), ~25-35 % more iterations (tools/precond_study.py).
+                                Restated in the oracle (eo_sim.tile_records): GPU = oracle bit for bit in EULER_DOT_SEQUENTIAL. */
 };
 
 /* IC(0) sweep implementation (same arithmetic, different schedule). */
@@ -79,9 +80,8 @@ typedef struct euler_config {
   float   viscosity;       /* 0 = inviscid like the reference (no diffusion stage exists there) */
   int32_t pcg_poll_interval; /* PCG iterations launched between convergence polls (default 8) */
   int32_t rainbow;         /* args_t.rainbow / g_rainbow_enabled (main.c:54,75,1020): carry the dye fields */
-  int32_t precond_tile_units; /* EULER_PRECOND_IC0_TILE: target tile width in units of 96 records (0 = default 6, i.e. 576);
-                                 a band of n_units = ceil((X+63)/96) units is cut into nt = max(1, round(n_units / this)) tiles,
-                                 tile k starting at record 96 * floor(k * n_units / nt) */
+  int32_t precond_tile_records; /* EULER_PRECOND_IC0_TILE: records per tile, 8, 16 or 32 (0 = default 16); tile k of a band =
+                                   records [k * W, (k + 1) * W) */
   int32_t reserved[6];
 } euler_config;
 
@@ -183,9 +183,9 @@ int euler_timestep(euler_sim* sim, float frame_time_left, float* dt);   /* calcu
 int euler_substep(euler_sim* sim, float dt);       /* stages 2..11 of sim_step with a given dt */
 int euler_stage(euler_sim* sim, int32_t stage, float dt);   /* one EULER_STAGE_* (teacher-forced tests) */
 int euler_pcg_op(euler_sim* sim, int32_t op, float dt, double scalar_in, double* scalar_out);
-/* Switch the preconditioner of the following solves (EULER_PRECOND_*; tile_units as euler_config.precond_tile_units,
+/* Switch the preconditioner of the following solves (EULER_PRECOND_*; tile_records as euler_config.precond_tile_records,
  * 0 = default).  The solver's arrays do not depend on it; g_precon keeps whatever the last factorisation left. */
-int euler_set_precond(euler_sim* sim, int32_t precond, int32_t tile_units);
+int euler_set_precond(euler_sim* sim, int32_t precond, int32_t tile_records);
 
 /* ---- state access ------------------------------------------------------------------------ */
 int euler_get_field(euler_sim* sim, int32_t field, void* dst, size_t dst_bytes);

@@ -449,18 +449,8 @@ void eo_build_system(eo_sim* s, float dt, const float* u, const float* v) {
 }
 
 /* EXTENSION (this build's, no reference counterpart): where the tile-local preconditioner cuts a band (euler_oracle.h) */
-int eo_tile_start(int X, int tile_units, int t) {
-  if (tile_units <= 0) return t == 0;
-  const int n_units = (X + 63 + 95) / 96;
-  int nt = (n_units + tile_units / 2) / tile_units;
-  if (nt < 1) nt = 1;
-  if (nt > n_units) nt = n_units;
-  if (t % 96) return 0;
-  const int unit = t / 96;
-  /* unit starts a tile iff unit == floor(k * n_units / nt) for some k */
-  for (int k = (int)((long long)unit * nt / n_units); k <= nt && (long long)k * n_units / nt <= unit; ++k)
-    if ((int)((long long)k * n_units / nt) == unit) return 1;
-  return 0;
+int eo_tile_start(int tile_records, int t) {
+  return tile_records > 0 ? t % tile_records == 0 : t == 0;
 }
 
 /* Tile-local IC(0): the same three recurrences as below restricted to blocks.  A coupling that is cut contributes
@@ -471,7 +461,7 @@ static void apply_preconditioner_tiled(eo_sim* s, const double* r, double* z) {
   size_t C = (size_t)X * (size_t)Y;
   double* pre = s->precon; double* q = s->q;
   uint8_t* start = (uint8_t*)malloc((size_t)X + 64 + 1);   /* start[t]: record t begins a tile */
-  for (int t = 0; t <= X + 63; ++t) start[t] = (uint8_t)eo_tile_start(X, s->tile_units, t);
+  for (int t = 0; t <= X + 63; ++t) start[t] = (uint8_t)eo_tile_start(s->tile_records, t);
   for (int y = 0; y < Y; ++y)
     for (int x = 0; x < X; ++x) {
       if (!FLUID(s, y, x)) continue;
@@ -508,7 +498,7 @@ static void apply_preconditioner_tiled(eo_sim* s, const double* r, double* z) {
 }
 
 void eo_apply_preconditioner(eo_sim* s, const double* r, double* z) {
-  if (s->tile_units > 0) { apply_preconditioner_tiled(s, r, z); return; }
+  if (s->tile_records > 0) { apply_preconditioner_tiled(s, r, z); return; }
   int X = s->X, Y = s->Y;
   size_t C = (size_t)X * (size_t)Y;
   double* pre = s->precon; double* q = s->q;

@@ -52,8 +52,9 @@ typedef struct eo_sim {
   int rainbow;
   float *cr, *cg, *cb, *crtmp, *cgtmp, *cbtmp;
   /* EXTENSION (no reference counterpart; parity unpinned by the reference): tile-local IC(0), the block-Jacobi
-   * restriction of the reference's preconditioner.  0 = the reference's IC(0) (main.c:580-627).  See eo_tile_start. */
-  int tile_units;
+   * restriction of the reference's preconditioner.  0 = the reference's IC(0) (main.c:580-627); else the records per
+   * tile.  See eo_tile_start. */
+  int tile_records;
 } eo_sim;
 
 eo_sim* eo_create(int X, int Y);
@@ -97,13 +98,12 @@ void   eo_apply_a(const eo_sim* s, const double* in, double* out);
 double eo_dot(const eo_sim* s, const double* a, const double* b);
 double eo_inf_norm(const eo_sim* s, const double* r);
 /* EXTENSION: the blocks of the tile-local preconditioner.  The cells of a 64-row band are numbered by their
- * skew record t = x + y % 64 (0 <= t < X + 63); records are grouped into units of 96, n_units = ceil((X+63)/96),
- * and a band is cut into nt = max(1, round(n_units / tile_units)) tiles of whole units, tile k starting at record
- * 96 * floor(k * n_units / nt).  A block = the cells of one band whose records fall into one tile (a parallelogram
- * of 64 rows).  IC(0) is applied to the block-diagonal part of A: every coupling between cells of different blocks
- * is dropped from the factor and from both triangular solves (the diagonal of A stays whole).
+ * skew record t = x + y % 64; tile k of a band = the records [k * W, (k + 1) * W), W = tile_records.  A block = the cells
+ * of one band whose records fall into one tile (a parallelogram of 64 rows x W columns).  IC(0) is applied to the
+ * block-diagonal part of A: every coupling between cells of different blocks is dropped from the factor and from both
+ * triangular solves (the diagonal of A stays whole).
  * Returns 1 when record t starts a tile (couplings arriving from record t-1 are cut), else 0. */
-int    eo_tile_start(int X, int tile_units, int t);
+int    eo_tile_start(int tile_records, int t);
 
 /* ASCII frame as draw_rows() emits it (main.c:914-951), no cursor codes. Returns length. */
 int eo_render_rows(const eo_sim* s, int wx, int wy, char* out, int cap);

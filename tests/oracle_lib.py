@@ -42,7 +42,7 @@ class EoSim(C.Structure):
         ("rainbow", C.c_int),
         ("cr", C.POINTER(C.c_float)), ("cg", C.POINTER(C.c_float)), ("cb", C.POINTER(C.c_float)),
         ("crtmp", C.POINTER(C.c_float)), ("cgtmp", C.POINTER(C.c_float)), ("cbtmp", C.POINTER(C.c_float)),
-        ("tile_units", C.c_int),
+        ("tile_records", C.c_int),
     ]
 
 
@@ -96,7 +96,7 @@ def oracle_lib(fast=False, lib_path=None):
     lib.eo_dot.restype = C.c_double
     lib.eo_inf_norm.argtypes = [sp, dp]
     lib.eo_inf_norm.restype = C.c_double
-    lib.eo_tile_start.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.eo_tile_start.argtypes = [C.c_int, C.c_int]
     lib.eo_tile_start.restype = C.c_int
     lib.eo_colorize.argtypes = [sp]
     lib.eo_advect_p.argtypes = [sp, fp, fp, fp, C.c_float, fp]

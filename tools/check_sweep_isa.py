@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static check of the hand-scheduled IC(0) sweep kernels (k_sweep_skew<1|2, XG, TILE>).
+"""Static check of the hand-scheduled IC(0) sweep kernels (k_sweep_skew<1|2, false|true>).
 
 Their record loads are inline asm that hipcc does not track, retired by hand-counted
 `s_waitcnt vmcnt(N)`.  The scheme is only correct if no instruction touches a load's destination
@@ -124,8 +124,8 @@ def check(text, name):
 def main():
     text = isa_text()
     rc = 0
-    # forward / backward solve: single-GPU build, the cross-GPU (system-scope hand-off) build and the tile-local build
-    for name in ["_Z12k_sweep_skewILi%dELb%dELb%dEEv9SweepArgs" % (op, xg, tile) for op in (1, 2) for xg, tile in ((0, 0), (1, 0), (0, 1))]:
+    # forward / backward solve, single-GPU build and the cross-GPU (system-scope hand-off) build
+    for name in ["_Z12k_sweep_skewILi%dELb%dEEv9SweepArgs" % (op, xg) for op in (1, 2) for xg in (0, 1)]:
         n, states, bad = check(text, name)
         print("%s: %d instructions, %d (pc, vmcnt queue) states explored, %d touches of an in-flight operand" % (name, n, states, len(bad)))
         for pc in sorted(bad):

@@ -5,17 +5,18 @@
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-SIZE=${1:-1024}
+SIZE=${1:-8192}
 STEPS=${2:-2}
-WORKLOAD=${3:-dam_break}
-EXTRA=${4:-}
-OUT=gpurun_out/prof_${SIZE}_${WORKLOAD}
+WORKLOAD=${3:-half_tank}
+PRECOND=${4:-ic0_tile}
+EXTRA=${5:-}
+OUT=gpurun_out/prof_${SIZE}_${WORKLOAD}_${PRECOND}
 rm -rf "$OUT"; mkdir -p "$OUT"
-ARGS="bench.py --size $SIZE --workload $WORKLOAD --steps $STEPS --warmup 1 --no-cpu-baseline --no-kernel-timing $EXTRA"
+ARGS="bench.py --size $SIZE --workload $WORKLOAD --precond $PRECOND --steps $STEPS --warmup 1 --no-secondary --no-pmc --no-kernel-timing $EXTRA"
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- python3 $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.log"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o fetch -- python3 $ARGS > /dev/null 2> "$OUT/fetch.log"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o write -- python3 $ARGS > /dev/null 2> "$OUT/write.log"
-python3 bench.py --size $SIZE --workload $WORKLOAD --steps $STEPS --warmup 1 --no-cpu-baseline $EXTRA > "$OUT/bench_events.json" 2>> "$OUT/trace.log"
+python3 bench.py --size $SIZE --workload $WORKLOAD --precond $PRECOND --steps $STEPS --warmup 1 --no-secondary --no-pmc $EXTRA > "$OUT/bench_events.json" 2>> "$OUT/trace.log"
 python3 tools/summarize_profile.py "$OUT" > "$OUT/summary.md" 2>> "$OUT/trace.log"
 # keep only small artefacts for the merge back
 find "$OUT" -name "*.csv" -size +8M -delete

@@ -35,8 +35,8 @@ for name in ("bench_events.json", "bench_trace.json"):
             break
 
 print("# rocprofv3 summary: %s\n" % os.path.basename(out.rstrip("/")))
-print("command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --size N --steps K --warmup 1 --no-cpu-baseline "
-      "--no-kernel-timing` (+ one `--pmc FETCH_SIZE` and one `--pmc WRITE_SIZE` pass), see tools/profile_run.sh\n")
+print("command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --size N --workload W --precond P --steps K --warmup 1 --no-secondary "
+      "--no-pmc --no-kernel-timing` (+ one `--pmc FETCH_SIZE` and one `--pmc WRITE_SIZE` pass), see tools/profile_run.sh\n")
 con = db("trace/*_results.db")
 if con:
     print("## kernel trace (all launches, including the few idle early-exit launches after convergence)\n")
