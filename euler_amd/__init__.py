@@ -19,7 +19,7 @@ PRECOND_IC0, PRECOND_JACOBI, PRECOND_IC0_TILE = 0, 1, 2
 SWEEP_AUTO, SWEEP_BAND, SWEEP_SIMPLE = 0, 1, 2
 (F_U, F_V, F_UTMP, F_VTMP, F_SOLID, F_SOURCE, F_SINK, F_COUNT, F_PREV_COUNT, F_MARKERS, F_PRECON,
  F_PRESSURE, F_PCG_B, F_PCG_R, F_PCG_Z, F_PCG_S, F_PCG_Q, F_CELLMASK,
- F_DYE_R, F_DYE_G, F_DYE_B, F_DYE_RTMP, F_DYE_GTMP, F_DYE_BTMP) = range(24)
+ F_DYE_R, F_DYE_G, F_DYE_B, F_DYE_RTMP, F_DYE_GTMP, F_DYE_BTMP, F_MARKER_KEYS) = range(25)
 (STAGE_ADVECT_MARKERS, STAGE_REFRESH_COUNTS, STAGE_SOURCES, STAGE_EXTRAPOLATE, STAGE_ADVECT_VELOCITY,
  STAGE_PROJECT) = range(6)
 (OP_BUILD_SYSTEM, OP_PRECON_FACTOR, OP_FORWARD_SOLVE, OP_BACKWARD_SOLVE, OP_APPLY_A, OP_DOT_ZR, OP_DOT_ZS,
@@ -31,7 +31,7 @@ _FIELD_DTYPE = {
     F_MARKERS: np.float32, F_PRECON: np.float64, F_PRESSURE: np.float64, F_PCG_B: np.float64,
     F_PCG_R: np.float64, F_PCG_Z: np.float64, F_PCG_S: np.float64, F_PCG_Q: np.float64, F_CELLMASK: np.uint8,
     F_DYE_R: np.float32, F_DYE_G: np.float32, F_DYE_B: np.float32,
-    F_DYE_RTMP: np.float32, F_DYE_GTMP: np.float32, F_DYE_BTMP: np.float32,
+    F_DYE_RTMP: np.float32, F_DYE_GTMP: np.float32, F_DYE_BTMP: np.float32, F_MARKER_KEYS: np.uint32,
 }
 
 
@@ -47,7 +47,8 @@ class Config(C.Structure):
         ("max_iterations", C.c_int32), ("tol", C.c_double), ("dot_mode", C.c_int32), ("precond", C.c_int32),
         ("sweep_mode", C.c_int32), ("max_substeps", C.c_int32), ("frame_time", C.c_float),
         ("viscosity", C.c_float), ("pcg_poll_interval", C.c_int32), ("rainbow", C.c_int32),
-        ("precond_tile_records", C.c_int32), ("reserved", C.c_int32 * 6),
+        ("precond_tile_records", C.c_int32), ("slab_rank", C.c_int32), ("slab_nranks", C.c_int32),
+        ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -257,7 +258,7 @@ class Simulation:
     plus state access for parity tests."""
 
     def __init__(self, X=100, Y=40, device=0, dot_mode=DOT_AUTO, precond=PRECOND_IC0, sweep_mode=SWEEP_AUTO,
-                 max_iterations=100, tol=None, pcg_poll_interval=8, viscosity=0.0, rainbow=False, tile_records=0):
+                 max_iterations=100, tol=None, pcg_poll_interval=8, viscosity=0.0, rainbow=False, tile_records=0, slab=None):
         self.L = load_library()
         cfg = Config()
         _check(self.L.euler_config_default(C.byref(cfg)))
@@ -270,6 +271,9 @@ class Simulation:
         cfg.viscosity = viscosity            # extension: 0 = the inviscid reference
         cfg.rainbow = int(rainbow)           # args_t.rainbow (main.c:54): carry and advect the dye fields
         cfg.precond_tile_records = tile_records  # PRECOND_IC0_TILE: records per tile, 8 / 16 / 32 (0 = default 16)
+        if slab is not None:                 # (rank, nranks): row slabs for every stage, this process holds one slab only
+            cfg.slab_rank, cfg.slab_nranks = slab
+        self.slab = slab if slab is not None and slab[1] > 1 else None
         self.cfg = cfg
         self.X, self.Y = X, Y
         self.h = C.c_void_p()
@@ -346,11 +350,21 @@ class Simulation:
             _check(self.L.euler_get_field(self.h, field, a.ctypes.data, nbytes))
         elif field != F_MARKERS:      # an unknown or unavailable field: let the library say why
             _check(self.L.euler_get_field(self.h, field, np.empty(8, np.uint8).ctypes.data, 0) or -1)
-        return a.reshape(-1, 2) if field == F_MARKERS else a.reshape(self.Y, self.X)
+        if field == F_MARKERS:
+            return a.reshape(-1, 2)
+        if field == F_MARKER_KEYS:
+            return a
+        return a.reshape(-1, self.X)        # a row-slab handle returns its own rows (euler_slab_info)
 
     def set(self, field, arr):
         a = np.ascontiguousarray(arr, _FIELD_DTYPE[field])
         _check(self.L.euler_set_field(self.h, field, a.ctypes.data, a.nbytes))
+
+    def slab_rows(self):
+        """[row_lo, row_hi) this handle owns (the whole grid without slabs)."""
+        lo, hi, nb = C.c_int32(), C.c_int32(), C.c_int32()
+        _check(self.L.euler_slab_info(self.h, C.byref(lo), C.byref(hi), C.byref(nb)))
+        return (64 * lo.value, min(64 * hi.value, self.Y)) if self.slab else (0, self.Y)
 
     def set_markers(self, m):
         a = np.ascontiguousarray(m, np.float32).reshape(-1, 2)

@@ -230,13 +230,34 @@ extern "C" int euler_p2p_connect(euler_sim* S, const void* handles, int32_t nran
   HIPCHK(hipSetDevice(S->cfg.device));
   p->rank = S->comm.rank; p->n = nranks;
   const hipIpcMemHandle_t* hs = static_cast<const hipIpcMemHandle_t*>(handles);   // P2P_NHANDLES per rank
+  // Phase 1, map: a rank whose mapping fails does NOT leave - all ranks first agree on the outcome over the communicator
+  // installed before (a collective every rank reaches), so that nobody spins on a mailbox whose owner has given up.
+  int map_ok = 1;
+  hipError_t map_err = hipSuccess;
   for (int k = 0; k < nranks; ++k) {
     if (k == p->rank) { p->peer[k] = p->box; continue; }
     if (p->peer[k]) { (void)hipIpcCloseMemHandle(p->peer[k]); p->peer[k] = nullptr; }   // a retry maps afresh
     hipIpcMemHandle_t h;
     memcpy(&h, &hs[(size_t)k * P2P_NHANDLES], sizeof h);
     hipError_t e = hipIpcOpenMemHandle(&p->peer[k], h, hipIpcMemLazyEnablePeerAccess);
-    if (e != hipSuccess) { p->peer[k] = nullptr; return eu_hip_fail(e, "hipIpcOpenMemHandle(peer mailbox)", __FILE__, __LINE__); }
+    if (e != hipSuccess) { p->peer[k] = nullptr; map_ok = 0; map_err = e; }
+  }
+  // A retry must not be satisfied by the granules of a failed attempt (the sequence numbers start over): wipe the own
+  // mailbox; the all-reduce below is also the barrier behind which no peer of the OLD attempt can still be writing.
+  HIPCHK(hipMemsetAsync(p->box, 0, P2P_HDR_BYTES, S->stream));
+  {
+    double* flag = reinterpret_cast<double*>(S->halo_buf);
+    const double mine_ok = map_ok ? 0.0 : 1.0;      // max over ranks of "I failed"
+    double any_failed = 1.0;
+    HIPCHK(hipMemcpyAsync(flag, &mine_ok, 8, hipMemcpyHostToDevice, S->stream));
+    if (S->comm.allreduce(S->comm.ctx, flag, 1, 1) != 0) { eu_set_error("euler_p2p_connect: the communicator's all-reduce failed"); return EULER_ECOMM; }
+    HIPCHK(hipMemcpyAsync(&any_failed, flag, 8, hipMemcpyDeviceToHost, S->stream));
+    HIPCHK(hipStreamSynchronize(S->stream));
+    if (any_failed != 0.0) {
+      if (!map_ok) return eu_hip_fail(map_err, "hipIpcOpenMemHandle(peer mailbox)", __FILE__, __LINE__);
+      eu_set_error("euler_p2p_connect: a peer could not map the mailboxes; staying on the installed communicator");
+      return EULER_ECOMM;
+    }
   }
   if (!p->peer_dev) HIPCHK(hipMalloc((void**)&p->peer_dev, sizeof(void*) * P2P_MAXR));   // (a failed earlier attempt may have left one)
   HIPCHK(hipMemcpy(p->peer_dev, p->peer, sizeof(void*) * P2P_MAXR, hipMemcpyHostToDevice));
@@ -281,10 +302,12 @@ extern "C" int euler_p2p_connect(euler_sim* S, const void* handles, int32_t nran
     p->nb_sb[side] = p->nb_base[side][2] ? static_cast<double*>(p->nb_base[side][2]) + EU_SKEW_SLACK : nullptr;
   }
   // The fusion changes which exchanges a rank performs, so it must be all ranks or none: agree over the mailboxes
-  // (just proven) - and with EULER_SLAB_FUSION=0 in any rank's environment nobody fuses.
+  // (just proven).  OPT-IN: only with EULER_SLAB_FUSION=1 in every rank's environment.  The fused kernel reads the
+  // neighbours' coarse-grained arrays across GPUs (write-through stores + system-scope loads); that has only ever run with
+  // several processes on ONE device, so until a node run has validated it the ghost-row path is the default.
   {
     const char* e = getenv("EULER_SLAB_FUSION");
-    const double mine_ok = (p->have_arrays && !(e && e[0] == '0')) ? 1.0 : 0.0;
+    const double mine_ok = (p->have_arrays && e && e[0] == '1') ? 1.0 : 0.0;
     double sum = 0.0;
     HIPCHK(hipMemcpyAsync(probe, &mine_ok, 8, hipMemcpyHostToDevice, S->stream));
     hipLaunchKernelGGL(k_p2p_allreduce, dim3(1), dim3(64), 0, S->stream, S->sc, probe, 0);
@@ -311,10 +334,9 @@ extern "C" int euler_p2p_connect(euler_sim* S, const void* handles, int32_t nran
 
 int eu_p2p_has_neighbour_arrays(const euler_sim* S) {
   const P2PState* p = static_cast<const P2PState*>(S->p2p);
-  // EULER_SLAB_FUSION=0 (environment of any rank, evaluated in euler_p2p_connect): keep the ghost-row exchange + separate update_search instead of
-  // reading across the slab boundary - a switch for first contact with a node, where remote visibility cannot be
-  // tested on the one-GPU box (the reads rely on kernel-end release reaching the memory side, as it must between XCDs)
-  return S->p2p_on && p && p->have_arrays;   // agreed by all ranks in euler_p2p_connect
+  // only with EULER_SLAB_FUSION=1 in every rank's environment (evaluated in euler_p2p_connect); the default keeps the
+  // ghost-row exchange + separate update_search instead of reading across the slab boundary
+  return S->p2p_on && p && p->have_arrays && !S->slab_on;   // agreed by all ranks in euler_p2p_connect (row-slab handles: arrays are windows, no mapping)
 }
 void eu_p2p_neighbour_arrays(euler_sim* S, const double** z_dn, const double** s_dn, const double** z_up, const double** s_up) {
   P2PState* p = static_cast<P2PState*>(S->p2p);

@@ -155,20 +155,31 @@ extern "C" void euler_destroy(euler_sim* S) {
   if (S->stream) (void)hipStreamSynchronize(S->stream);
   eu_p2p_release(S);
   eu_rccl_release(S);
-  void* dev[] = {S->u, S->v, S->utmp, S->vtmp, S->solid, S->source, S->sink, S->count, S->prev_count, S->count32,
-                 S->markers[0], S->markers[1], S->ms, S->evmask, S->ev_theta, S->ev_delta, S->sel_idx, S->act_idx,
-                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->fbits_fwd, S->fbits_bwd, S->halo_buf, S->band_ranges, S->partial2,
+  eu_slab_release(S);
+  // row-major arrays are held by base pointers shifted to global (x, y) indexing: allocation = pointer + win_off
+  // (a handle that failed half-way through euler_create still holds the raw allocations: S->shifted)
+  const size_t wo = S->shifted ? S->win_off : 0;
+  for (float* f : {S->u, S->v, S->utmp, S->vtmp}) if (f) (void)hipFree(f + wo);
+  for (uint8_t* g : {S->solid, S->source, S->sink, S->count, S->prev_count}) if (g) (void)hipFree(g + wo);
+  if (S->count32) (void)hipFree(S->count32 + wo);
+  void* dev[] = {S->markers[0], S->markers[1], S->keys[0], S->keys[1], S->ms, S->evmask, S->ev_theta, S->ev_delta, S->sel_idx, S->act_idx,
+                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->halo_buf, S->band_ranges, S->partial2,
                  S->rowmajor_tmp};
   for (void* p : dev) if (p) (void)hipFree(p);
   for (float* d : S->dye) if (d) (void)hipFree(d);
-  for (double* d : {S->b, S->p, S->r, S->z, S->s, S->s2, S->q, S->precon}) if (d) (void)hipFree(d - EU_SKEW_SLACK);
-  if (S->krku) (void)hipFree(S->krku - 2 * EU_SKEW_SLACK);
-  if (S->cellmask) (void)hipFree(S->cellmask - EU_SKEW_SLACK);
+  // band-skewed arrays: shifted to global element indexing as well (skew_off), behind EU_SKEW_SLACK elements of slack
+  const size_t so = S->shifted ? S->skew_off : 0, sl = S->shifted ? (size_t)EU_SKEW_SLACK : 0;
+  for (double* d : {S->b, S->p, S->r, S->z, S->s, S->s2, S->q, S->precon}) if (d) (void)hipFree(d + so - sl);
+  if (S->krku) (void)hipFree(S->krku + 2 * so - 2 * sl);
+  if (S->cellmask) (void)hipFree(S->cellmask + so - sl);
+  const size_t fb_off = S->shifted ? (size_t)S->ab_lo * S->fb_stride * 64 : 0;
+  if (S->fbits_fwd) (void)hipFree(S->fbits_fwd + fb_off);
+  if (S->fbits_bwd) (void)hipFree(S->fbits_bwd + fb_off);
   if (S->ms_host) (void)hipHostFree(S->ms_host);
   if (S->sc_host) (void)hipHostFree(S->sc_host);
   if (S->poll_host) (void)hipHostFree(S->poll_host);
   for (hipEvent_t e : S->poll_event) if (e) (void)hipEventDestroy(e);
-  if (S->ev_pool) { for (int k = 0; k < S->ev_cap; ++k) (void)hipEventDestroy(S->ev_pool[k]); free(S->ev_pool); }
+  if (S->ev_pool) { for (int k = 0; k < S->ev_cap; ++k) if (S->ev_pool[k]) (void)hipEventDestroy(S->ev_pool[k]); free(S->ev_pool); }
   free(S->ev_cls); free(S->ev_solve); free(S->ev_iter);
   if (S->stream && S->own_stream) (void)hipStreamDestroy(S->stream);
   free(S);
@@ -208,22 +219,54 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   S->geom.T = (S->X + 63 + 95) / 96 * 96;   // records per band in whole units of 96 (euler_dev.h); even: records are stored in pairs
   S->geom.TS = (S->geom.T + 31) / 32 * 32 + 64;   // the sweeps run whole groups of three / four 8-step blocks and prefetch up to 24 steps further
   S->geom.S = (size_t)S->geom.nbands * S->geom.TS * 64;
-  const size_t SS = S->geom.S;
-  // supported maximum = BASELINE's largest configuration, 16384^2 cells: marker indices (4 per cell) are 32-bit
-  if (C > ((size_t)1 << 28) || (SS + EU_SKEW_SLACK) * 8 >= ((size_t)1 << 32)) {
-    eu_set_error("grid %d x %d is larger than the supported maximum (2^28 cells)", cfg->X, cfg->Y);
+  // row slabs: this handle holds the rows of its bands only (+ ghost rows); without slabs the window is the grid
+  const int nbands = S->geom.nbands;
+  S->slab_on = cfg->slab_nranks > 1;
+  if (S->slab_on) {
+    if (cfg->slab_rank < 0 || cfg->slab_rank >= cfg->slab_nranks || cfg->slab_nranks > nbands) {
+      eu_set_error("euler_create: slab rank %d of %d for %d bands of 64 rows", cfg->slab_rank, cfg->slab_nranks, nbands);
+      free(S); return EULER_EINVAL;
+    }
+    if (cfg->rainbow || cfg->viscosity > 0.f || S->cfg.sweep_mode == EULER_SWEEP_SIMPLE) {
+      eu_set_error("euler_create: row slabs do not carry the dye, the diffusion extension or EULER_SWEEP_SIMPLE");
+      free(S); return EULER_EINVAL;
+    }
+    S->band_lo = (int)((int64_t)nbands * cfg->slab_rank / cfg->slab_nranks);
+    S->band_hi = (int)((int64_t)nbands * (cfg->slab_rank + 1) / cfg->slab_nranks);
+    if (S->cfg.dot_mode == EULER_DOT_SEQUENTIAL) S->cfg.dot_mode = EULER_DOT_TREE;   // the replay order is a 1-rank notion
+  } else { S->band_lo = 0; S->band_hi = nbands; }
+  S->row_lo = 64 * S->band_lo; S->row_hi = 64 * S->band_hi < S->Y ? 64 * S->band_hi : S->Y;
+  S->win_lo = S->row_lo - EU_GHOST_LO > 0 ? S->row_lo - EU_GHOST_LO : 0;
+  S->win_hi = S->row_hi + EU_GHOST_HI < S->Y ? S->row_hi + EU_GHOST_HI : S->Y;
+  S->win_off = (size_t)S->win_lo * S->X;
+  S->Cw = (size_t)(S->win_hi - S->win_lo) * S->X;
+  S->ab_lo = S->band_lo > 0 ? S->band_lo - 1 : 0; S->ab_hi = S->band_hi < nbands ? S->band_hi + 1 : nbands;
+  S->skew_off = (size_t)S->ab_lo * S->geom.TS * 64;
+  S->Sw = (size_t)(S->ab_hi - S->ab_lo) * S->geom.TS * 64;
+  S->e_lo = (size_t)S->band_lo * S->geom.TS * 64; S->e_cnt = (size_t)(S->band_hi - S->band_lo) * S->geom.TS * 64;
+  const size_t SS = S->Sw;
+  const size_t Cw = S->Cw;
+  // supported maximum per handle = BASELINE's largest configuration, 16384^2 cells; marker indices (4 per cell, global) are 32-bit
+  if (C > ((size_t)1 << 29) || Cw > ((size_t)1 << 28) || (SS + EU_SKEW_SLACK) * 8 >= ((size_t)1 << 32)) {
+    eu_set_error("grid %d x %d is larger than the supported maximum (2^28 cells per GPU, 2^29 in all)", cfg->X, cfg->Y);
     free(S);
     return EULER_EINVAL;
   }
-  HIPCHK(hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking));
+  // from here on every failure releases what has been created so far (euler_destroy copes with a half-built handle)
+#define CREATECHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { int _rc = eu_hip_fail(_e, #call, __FILE__, __LINE__); euler_destroy(S); return _rc; } } while (0)
+  CREATECHK(hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking));
   S->own_stream = 1;
 
-  DALLOC(S->u, C); DALLOC(S->v, C); DALLOC(S->utmp, C); DALLOC(S->vtmp, C);
-  DALLOC(S->solid, C); DALLOC(S->source, C); DALLOC(S->sink, C); DALLOC(S->count, C); DALLOC(S->prev_count, C);
-  DALLOC(S->count32, C);
+  // (allocated un-shifted; all base pointers are shifted together once every allocation has succeeded: S->shifted)
+  DALLOC(S->u, Cw); DALLOC(S->v, Cw); DALLOC(S->utmp, Cw); DALLOC(S->vtmp, Cw);
+  DALLOC(S->solid, Cw); DALLOC(S->source, Cw); DALLOC(S->sink, Cw); DALLOC(S->count, Cw); DALLOC(S->prev_count, Cw);
+  DALLOC(S->count32, Cw);
   if (S->cfg.rainbow) for (float*& d : S->dye) DALLOC(d, C);
-  S->max_markers = 4 * C;   // MAX_MARKER_COUNT, main.c:92
+  // MAX_MARKER_COUNT = 4 X Y (main.c:92) is the GLOBAL cap; a slab holds the markers inside its rows: room for 6 per owned cell
+  S->max_markers = 4 * C;
+  if (S->slab_on) { const size_t cap = 6 * (size_t)(S->row_hi - S->row_lo) * S->X + 65536; if (cap < S->max_markers) S->max_markers = cap; }
   DALLOC(S->markers[0], S->max_markers); DALLOC(S->markers[1], S->max_markers);
+  if (S->slab_on) { DALLOC(S->keys[0], S->max_markers); DALLOC(S->keys[1], S->max_markers); }
   DALLOC(S->ms, 1);
   const size_t mwords = (S->max_markers + 63) / 64;
   DALLOC(S->evmask, mwords);
@@ -231,35 +274,43 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   S->sel_cap = S->max_markers;
   DALLOC(S->sel_idx, S->sel_cap);
   DALLOC(S->act_idx, S->max_markers); DALLOC(S->act_dt, S->max_markers);
-  DALLOC(S->cellmask64, (C + 63) / 64);
+  DALLOC(S->cellmask64, (Cw + 63) / 64 + 1);
   S->sel.capacity_blocks = (mwords + 2047) / 2048 + 1;
   DALLOC(S->sel.block_sums, S->sel.capacity_blocks);
   // skewed arrays carry EU_SKEW_SLACK zeroed elements in front (the backward sweep prefetches below record 0)
-  for (double** d : {&S->b, &S->p, &S->r, &S->z, &S->s, &S->s2, &S->q, &S->precon}) { DALLOC(*d, SS + EU_SKEW_SLACK); *d += EU_SKEW_SLACK; }
-  DALLOC(S->krku, 2 * (SS + EU_SKEW_SLACK)); S->krku += 2 * EU_SKEW_SLACK;
-  DALLOC(S->cellmask, SS + EU_SKEW_SLACK); S->cellmask += EU_SKEW_SLACK;
+  for (double** d : {&S->b, &S->p, &S->r, &S->z, &S->s, &S->s2, &S->q, &S->precon}) DALLOC(*d, SS + EU_SKEW_SLACK);
+  DALLOC(S->krku, 2 * (SS + EU_SKEW_SLACK));
+  DALLOC(S->cellmask, SS + EU_SKEW_SLACK);
   S->fb_stride = 12 * (((S->geom.T + 7) / 8 + 11) / 12) + 4;   // whole groups of 3 and of 4 blocks + the blocks the prefetch runs ahead
-  DALLOC(S->fbits_fwd, (size_t)S->geom.nbands * S->fb_stride * 64);
-  DALLOC(S->fbits_bwd, (size_t)S->geom.nbands * S->fb_stride * 64);
+  DALLOC(S->fbits_fwd, (size_t)(S->ab_hi - S->ab_lo) * S->fb_stride * 64);
+  DALLOC(S->fbits_bwd, (size_t)(S->ab_hi - S->ab_lo) * S->fb_stride * 64);
   DALLOC(S->sc, 1);
   DALLOC(S->band_ranges, (size_t)S->geom.nbands);
   { int rc = eu_set_tiles(S, S->cfg.precond_tile_records); if (rc) { euler_destroy(S); return rc; } }
-  S->red_blocks = (int)eu_blocks(SS, EU_RED_ELEMS, 2048);
+  S->red_blocks = (int)eu_blocks(S->e_cnt, EU_RED_ELEMS, 2048);
   DALLOC(S->partial, (size_t)S->red_blocks > 2048 ? (size_t)S->red_blocks : 2048);
   DALLOC(S->partial2, 2048);
   DALLOC(S->red_counter, 1);
-  S->band_lo = 0; S->band_hi = S->geom.nbands; S->e_lo = 0; S->e_cnt = SS;
   DALLOC(S->halo_buf, (size_t)4 * S->X);
   S->gran_stride = (S->geom.T - 63 + 7) / 8 * 8;   // hand-off columns [0, T - 63)
   DALLOC(S->granules, (size_t)S->geom.nbands * S->gran_stride * 2);
   DALLOC(S->ticket, 1);
   DALLOC(S->sweep_timeline, (size_t)S->geom.nbands * 8);
   S->ticket_base = 0; S->epoch = 0;
-  HIPCHK(hipHostMalloc((void**)&S->ms_host, sizeof(MarkerState), hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void**)&S->sc_host, sizeof(PcgScalars), hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void**)&S->poll_host, 2 * sizeof(PcgScalars), hipHostMallocDefault));
+  // every device allocation is in place: shift the base pointers to global indexing (euler_dev.h "Row slabs")
+  for (float** f : {&S->u, &S->v, &S->utmp, &S->vtmp}) *f -= S->win_off;
+  for (uint8_t** g : {&S->solid, &S->source, &S->sink, &S->count, &S->prev_count}) *g -= S->win_off;
+  S->count32 -= S->win_off;
+  for (double** d : {&S->b, &S->p, &S->r, &S->z, &S->s, &S->s2, &S->q, &S->precon}) *d += EU_SKEW_SLACK - S->skew_off;
+  S->krku += 2 * EU_SKEW_SLACK - 2 * S->skew_off;
+  S->cellmask += EU_SKEW_SLACK - S->skew_off;
+  S->fbits_fwd -= (size_t)S->ab_lo * S->fb_stride * 64; S->fbits_bwd -= (size_t)S->ab_lo * S->fb_stride * 64;
+  S->shifted = 1;
+  CREATECHK(hipHostMalloc((void**)&S->ms_host, sizeof(MarkerState), hipHostMallocDefault));
+  CREATECHK(hipHostMalloc((void**)&S->sc_host, sizeof(PcgScalars), hipHostMallocDefault));
+  CREATECHK(hipHostMalloc((void**)&S->poll_host, 2 * sizeof(PcgScalars), hipHostMallocDefault));
   memset(S->poll_host, 0, 2 * sizeof(PcgScalars));
-  for (hipEvent_t& e : S->poll_event) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (hipEvent_t& e : S->poll_event) CREATECHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   memset(S->ms_host, 0, sizeof(MarkerState)); memset(S->sc_host, 0, sizeof(PcgScalars));
 
   S->interp_lim[0] = nextafterf((float)(S->X - 2), 0.f);   // U extent (X-1, Y): size-1
@@ -274,8 +325,10 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   S->ev_iter = (int*)calloc((size_t)S->ev_cap / 2, sizeof(int));
   S->prof_iter = -2;
   if (!S->ev_pool || !S->ev_cls || !S->ev_solve || !S->ev_iter) { euler_destroy(S); return EULER_ENOMEM; }
-  for (int k = 0; k < S->ev_cap; ++k) HIPCHK(hipEventCreate(&S->ev_pool[k]));
-  HIPCHK(hipStreamSynchronize(S->stream));
+  for (int k = 0; k < S->ev_cap; ++k) CREATECHK(hipEventCreate(&S->ev_pool[k]));
+  if (S->slab_on) { int rc = eu_slab_alloc(S); if (rc) { euler_destroy(S); return rc; } }
+  CREATECHK(hipStreamSynchronize(S->stream));
+#undef CREATECHK
   *out = S;
   return EULER_OK;
 }
@@ -285,37 +338,55 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
 static int upload_scenario(euler_sim* S, const uint8_t* solid, const uint8_t* source, const uint8_t* sink,
                            const uint8_t* fluid) {
   const size_t C = S->C;
+  if (S->slab_on && !S->has_comm) { eu_set_error("row-slab handle: install the communicator (euler_set_comm / euler_set_comm_rccl) before loading a scenario"); return EULER_ESTATE; }
+  // every rank seeds the whole marker array on the host (one sequential RNG stream, main.c:255-266) and keeps its own rows
   std::vector<float> mk;
-  try { mk.resize(2 * S->max_markers); } catch (...) { return EULER_ENOMEM; }
+  try { mk.resize(2 * 4 * C); } catch (...) { return EULER_ENOMEM; }
   uint64_t rng = EULER_RNG_SEED, n = 0;
   int rc = euler_seed_markers(fluid, S->X, S->Y, &rng, mk.data(), &n);
   if (rc) return rc;
+  uint64_t n_loc = n;
+  std::vector<unsigned int> keys;
+  if (S->slab_on) {
+    try { keys.reserve((size_t)(n / (uint64_t)S->cfg.slab_nranks) + 1024); } catch (...) { return EULER_ENOMEM; }
+    n_loc = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+      const int y = (int)floorf(mk[2 * i + 1]);          // (positions are in cell units, h = 1)
+      if (y < S->row_lo || y >= S->row_hi) continue;
+      mk[2 * n_loc] = mk[2 * i]; mk[2 * n_loc + 1] = mk[2 * i + 1];
+      keys.push_back((unsigned int)i);
+      ++n_loc;
+    }
+    if (n_loc > S->max_markers) { eu_set_error("row slab %d holds %llu markers, more than its capacity %zu", S->cfg.slab_rank, (unsigned long long)n_loc, S->max_markers); return EULER_ENOMEM; }
+  }
   size_t nsrc = 0;
-  for (size_t i = 0; i < C; ++i) nsrc += source[i] != 0;
+  for (size_t i = (size_t)S->row_lo * S->X; i < (size_t)S->row_hi * S->X; ++i) nsrc += source[i] != 0;
   S->n_source_cells = nsrc;
   if (S->draws) { (void)hipFree(S->draws); S->draws = nullptr; }
   if (nsrc) HIPCHK(hipMalloc((void**)&S->draws, 2 * nsrc * sizeof(float)));
 
   hipStream_t st = S->stream;
-  HIPCHK(hipMemcpyAsync(S->solid, solid, C, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(S->source, source, C, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(S->sink, sink, C, hipMemcpyHostToDevice, st));
-  for (float* f : {S->u, S->v, S->utmp, S->vtmp}) HIPCHK(hipMemsetAsync(f, 0, C * sizeof(float), st));
-  for (double* d : {S->b, S->p, S->r, S->z, S->s, S->s2, S->q, S->precon}) HIPCHK(hipMemsetAsync(d, 0, S->geom.S * sizeof(double), st));
+  const size_t wo = S->win_off, Cw = S->Cw;            // the window's rows of the static grids
+  HIPCHK(hipMemcpyAsync(S->solid + wo, solid + wo, Cw, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(S->source + wo, source + wo, Cw, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(S->sink + wo, sink + wo, Cw, hipMemcpyHostToDevice, st));
+  for (float* f : {S->u, S->v, S->utmp, S->vtmp}) HIPCHK(hipMemsetAsync(f + wo, 0, Cw * sizeof(float), st));
+  for (double* d : {S->b, S->p, S->r, S->z, S->s, S->s2, S->q, S->precon}) HIPCHK(hipMemsetAsync(d + S->skew_off, 0, S->Sw * sizeof(double), st));
   for (float* d : S->dye) if (d) HIPCHK(hipMemsetAsync(d, 0, C * sizeof(float), st));
-  HIPCHK(hipMemsetAsync(S->count, 0, C, st));
-  HIPCHK(hipMemsetAsync(S->prev_count, 0, C, st));
-  HIPCHK(hipMemsetAsync(S->cellmask, 0, S->geom.S, st));
+  HIPCHK(hipMemsetAsync(S->count + wo, 0, Cw, st));
+  HIPCHK(hipMemsetAsync(S->prev_count + wo, 0, Cw, st));
+  HIPCHK(hipMemsetAsync(S->cellmask + S->skew_off, 0, S->Sw, st));
   S->cur = 0;
-  HIPCHK(hipMemcpyAsync(S->markers[0], mk.data(), n * sizeof(float2), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(S->markers[0], mk.data(), n_loc * sizeof(float2), hipMemcpyHostToDevice, st));
+  if (S->slab_on && n_loc) HIPCHK(hipMemcpyAsync(S->keys[0], keys.data(), n_loc * sizeof(unsigned int), hipMemcpyHostToDevice, st));
   MarkerState m0;
   memset(&m0, 0, sizeof(m0));
-  m0.n = n; m0.max_markers = S->max_markers; m0.rng_state = rng;
+  m0.n = n; m0.n_loc = n_loc; m0.max_markers = 4 * C; m0.rng_state = rng;     // n and the cap are the reference's GLOBAL ones
   HIPCHK(hipMemcpyAsync(S->ms, &m0, sizeof(m0), hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
-  S->n_markers_host = n;
+  S->n_markers_host = n_loc;
   // sim_init ends with refresh_marker_counts() (main.c:268): prev <- 0, counts <- bins
-  rc = eu_launch_refresh_counts(S);
+  rc = S->slab_on ? eu_slab_after_load(S) : eu_launch_refresh_counts(S);
   if (rc) return rc;
   rc = eu_launch_colorize(S);   // main.c:270-273 (only with cfg.rainbow)
   if (rc) return rc;
@@ -386,6 +457,21 @@ extern "C" int euler_set_stream(euler_sim* S, void* hip_stream) {
 // allow_single: keep the communicator code path with one rank (the RCCL self-test on a 1-GPU box)
 int eu_install_comm(euler_sim* S, const euler_comm_ops* ops, int32_t coupling, int allow_single) {
   if (!S) return EULER_EINVAL;
+  if (S->slab_on) {   // the handle IS one slab: the communicator must be the one it was created for; the partition stays
+    if (!ops) { S->has_comm = 0; return EULER_OK; }
+    if (!ops->allreduce || !ops->halo || !ops->chain || !ops->allgather || ops->rank != S->cfg.slab_rank || ops->nranks != S->cfg.slab_nranks) {
+      eu_set_error("euler_set_comm: this handle is slab %d of %d; the communicator says %d of %d", S->cfg.slab_rank, S->cfg.slab_nranks,
+                   ops->rank, ops->nranks);
+      return EULER_EINVAL;
+    }
+    if (coupling == EULER_SLAB_EXACT && S->cfg.precond == EULER_PRECOND_IC0) {
+      eu_set_error("euler_set_comm: row-slab handles run the tile-local preconditioner or slab-local IC(0) (the exact band pipeline "
+                   "needs the neighbours' rows)");
+      return EULER_EINVAL;
+    }
+    S->comm = *ops; S->bulk = *ops; S->has_comm = 1; S->couple = 0;
+    return EULER_OK;
+  }
   if (!ops || ops->nranks < 1 || (ops->nranks == 1 && !allow_single)) {
     S->has_comm = 0; S->band_lo = 0; S->band_hi = S->geom.nbands; S->e_lo = 0; S->e_cnt = S->geom.S;
     return EULER_OK;
@@ -396,7 +482,7 @@ int eu_install_comm(euler_sim* S, const euler_comm_ops* ops, int32_t coupling, i
   const int nb = S->geom.nbands;
   if (ops->nranks > nb) { eu_set_error("euler_set_comm: %d ranks for %d bands (64 rows each)", ops->nranks, nb); return EULER_EINVAL; }
   if (S->cfg.sweep_mode == EULER_SWEEP_SIMPLE) { eu_set_error("euler_set_comm: EULER_SWEEP_SIMPLE is single-rank only"); return EULER_EINVAL; }
-  S->comm = *ops;
+  S->comm = *ops; S->bulk = *ops;
   S->has_comm = 1;
   S->couple = coupling == EULER_SLAB_EXACT;
   S->band_lo = (int)((int64_t)nb * ops->rank / ops->nranks);
@@ -428,8 +514,9 @@ extern "C" int euler_slab_info(euler_sim* S, int32_t* lo, int32_t* hi, int32_t* 
 int eu_sync_marker_state(euler_sim* S) {
   HIPCHK(hipMemcpyAsync(S->ms_host, S->ms, sizeof(MarkerState), hipMemcpyDeviceToHost, S->stream));
   HIPCHK(hipStreamSynchronize(S->stream));
-  S->n_markers_host = S->ms_host->n;
+  S->n_markers_host = S->slab_on ? S->ms_host->n_loc : S->ms_host->n;
   if (S->ms_host->error) {
+    if (S->ms_host->error >= 16) { eu_set_error("row slab %d: exchange buffer overflow (code %d: 16 events, 17 migration, 18 deletions, 19 marker capacity)", S->cfg.slab_rank, S->ms_host->error); return EULER_ESTATE; }
     eu_set_error("device-side bounded wait expired (band pipeline), error=%d", S->ms_host->error);
     return EULER_ETIMEOUT;
   }
@@ -469,12 +556,14 @@ static int run_stage(euler_sim* S, int stage, float dt) {
 
 extern "C" int euler_stage(euler_sim* S, int32_t stage, float dt) {
   if (!S || !S->loaded) { eu_set_error("euler_stage: no scenario loaded"); return EULER_ESTATE; }
+  if (S->slab_on) { eu_set_error("euler_stage: single stages are not exposed on a row-slab handle (their ghost exchanges belong to the substep)"); return EULER_ESTATE; }
   int rc = run_stage(S, stage, dt);
   if (rc) return rc;
   return eu_sync_marker_state(S);
 }
 
 static int substep_async(euler_sim* S, float dt) {
+  if (S->slab_on) return eu_slab_substep(S, dt);       // the same stages over this rank's rows, with their exchanges in between
   for (int st = 0; st < EULER_STAGE__COUNT; ++st) {
     int rc = run_stage(S, st, dt);
     if (rc) return rc;
@@ -534,19 +623,23 @@ extern "C" int euler_pcg_op(euler_sim* S, int32_t op, float dt, double a, double
 
 // ------------------------------------------------------------------------------------------
 // state access
+// A field as the caller sees it: this handle's OWN rows [row_lo, row_hi) (the whole grid without slabs).
 static int field_ptr(euler_sim* S, int f, void** p, size_t* bytes) {
-  const size_t C = S->C;
+  const size_t C = (size_t)(S->row_hi - S->row_lo) * S->X, o = (size_t)S->row_lo * S->X;
   switch (f) {
-    case EULER_F_U: *p = S->u; *bytes = C * 4; break;
-    case EULER_F_V: *p = S->v; *bytes = C * 4; break;
-    case EULER_F_UTMP: *p = S->utmp; *bytes = C * 4; break;
-    case EULER_F_VTMP: *p = S->vtmp; *bytes = C * 4; break;
-    case EULER_F_SOLID: *p = S->solid; *bytes = C; break;
-    case EULER_F_SOURCE: *p = S->source; *bytes = C; break;
-    case EULER_F_SINK: *p = S->sink; *bytes = C; break;
-    case EULER_F_COUNT: *p = S->count; *bytes = C; break;
-    case EULER_F_PREV_COUNT: *p = S->prev_count; *bytes = C; break;
+    case EULER_F_U: *p = S->u + o; *bytes = C * 4; break;
+    case EULER_F_V: *p = S->v + o; *bytes = C * 4; break;
+    case EULER_F_UTMP: *p = S->utmp + o; *bytes = C * 4; break;
+    case EULER_F_VTMP: *p = S->vtmp + o; *bytes = C * 4; break;
+    case EULER_F_SOLID: *p = S->solid + o; *bytes = C; break;
+    case EULER_F_SOURCE: *p = S->source + o; *bytes = C; break;
+    case EULER_F_SINK: *p = S->sink + o; *bytes = C; break;
+    case EULER_F_COUNT: *p = S->count + o; *bytes = C; break;
+    case EULER_F_PREV_COUNT: *p = S->prev_count + o; *bytes = C; break;
     case EULER_F_MARKERS: *p = S->markers[S->cur]; *bytes = (size_t)S->n_markers_host * 8; break;
+    case EULER_F_MARKER_KEYS:
+      if (!S->slab_on) { eu_set_error("EULER_F_MARKER_KEYS: row-slab handles only (elsewhere a marker's key is its index)"); return EULER_ESTATE; }
+      *p = S->keys[S->cur]; *bytes = (size_t)S->n_markers_host * 4; break;
     case EULER_F_PRECON: *p = S->precon; *bytes = C * 8; break;
     case EULER_F_PRESSURE: *p = S->p; *bytes = C * 8; break;
     case EULER_F_PCG_B: *p = S->b; *bytes = C * 8; break;
@@ -573,7 +666,7 @@ static bool field_is_skewed(int f) {
   return f == EULER_F_PRECON || f == EULER_F_PRESSURE || (f >= EULER_F_PCG_B && f <= EULER_F_PCG_Q) || f == EULER_F_CELLMASK;
 }
 static int ensure_rowmajor_tmp(euler_sim* S) {
-  if (!S->rowmajor_tmp) HIPCHK(hipMalloc((void**)&S->rowmajor_tmp, S->C * sizeof(double)));
+  if (!S->rowmajor_tmp) HIPCHK(hipMalloc((void**)&S->rowmajor_tmp, (size_t)(S->row_hi - S->row_lo) * S->X * sizeof(double)));
   return EULER_OK;
 }
 
@@ -597,6 +690,9 @@ extern "C" int euler_get_field(euler_sim* S, int32_t f, void* dst, size_t dst_by
 
 extern "C" int euler_set_field(euler_sim* S, int32_t f, const void* src, size_t src_bytes) {
   if (!S || !src) return EULER_EINVAL;
+  if (S->slab_on && (f == EULER_F_MARKERS || f == EULER_F_MARKER_KEYS || f == EULER_F_COUNT || f == EULER_F_PREV_COUNT)) {
+    eu_set_error("euler_set_field(%d): a row-slab handle takes its markers and counts from euler_load_scenario_* only", f); return EULER_ESTATE;
+  }
   if (f == EULER_F_MARKERS) return euler_set_markers(S, (const float*)src, src_bytes / 8);
   void* p; size_t b;
   int rc = field_ptr(S, f, &p, &b);
@@ -614,7 +710,7 @@ extern "C" int euler_set_field(euler_sim* S, int32_t f, const void* src, size_t 
   if (f == EULER_F_SOURCE) {
     const uint8_t* s = (const uint8_t*)src;
     size_t nsrc = 0;
-    for (size_t i = 0; i < S->C; ++i) nsrc += s[i] != 0;
+    for (size_t i = 0; i < (size_t)(S->row_hi - S->row_lo) * S->X; ++i) nsrc += s[i] != 0;
     S->n_source_cells = nsrc;
     if (S->draws) { (void)hipFree(S->draws); S->draws = nullptr; }
     if (nsrc) HIPCHK(hipMalloc((void**)&S->draws, 2 * nsrc * sizeof(float)));
@@ -631,6 +727,7 @@ __global__ void k_set_marker_state(MarkerState* ms, unsigned long long n, unsign
 
 extern "C" int euler_set_markers(euler_sim* S, const float* xy, uint64_t n) {
   if (!S || (!xy && n) || n > S->max_markers) return EULER_EINVAL;
+  if (S->slab_on) { eu_set_error("euler_set_markers: not on a row-slab handle"); return EULER_ESTATE; }
   if (n) HIPCHK(hipMemcpyAsync(S->markers[S->cur], xy, n * 8, hipMemcpyHostToDevice, S->stream));
   hipLaunchKernelGGL(k_set_marker_state, dim3(1), dim3(1), 0, S->stream, S->ms, (unsigned long long)n,
                      (unsigned long long)S->max_markers, 1, 0ull, 0, 0);
@@ -659,7 +756,9 @@ extern "C" int euler_get_stats(euler_sim* S, euler_stats* out) {
   // fluid-cell census reuses the (idle) select total word as a 64-bit scratch
   unsigned long long* scratch = (unsigned long long*)S->partial;
   HIPCHK(hipMemsetAsync(scratch, 0, 8, S->stream));
-  hipLaunchKernelGGL(k_count_fluid, dim3(eu_blocks(S->C, 256 * 8, 1024)), dim3(256), 0, S->stream, S->count, S->C, scratch);
+  // (a row-slab handle counts its own rows; n_markers below is the job's total either way)
+  hipLaunchKernelGGL(k_count_fluid, dim3(eu_blocks((size_t)(S->row_hi - S->row_lo) * S->X, 256 * 8, 1024)), dim3(256), 0, S->stream,
+                     S->count + (size_t)S->row_lo * S->X, (size_t)(S->row_hi - S->row_lo) * S->X, scratch);
   unsigned long long nf = 0;
   HIPCHK(hipMemcpyAsync(&nf, scratch, 8, hipMemcpyDeviceToHost, S->stream));
   HIPCHK(hipStreamSynchronize(S->stream));
@@ -679,6 +778,7 @@ extern "C" int euler_get_stats(euler_sim* S, euler_stats* out) {
 extern "C" int euler_render(euler_sim* S, int32_t wx, int32_t wy, char* out, int32_t cap, int32_t* len) {
   if (!S || !len) return EULER_EINVAL;
   if (!S->loaded) return EULER_ESTATE;
+  if (S->slab_on) { eu_set_error("euler_render: not on a row-slab handle (render from the gathered count grid: euler_render_grids)"); return EULER_ESTATE; }
   const int X = S->X, Y = S->Y;
   int cutoff = Y - 1 - wy;
   if (cutoff < 1) cutoff = 1;
@@ -774,6 +874,7 @@ static const int SNAP_DYE[] = {EULER_F_DYE_R, EULER_F_DYE_G, EULER_F_DYE_B, EULE
 
 extern "C" int euler_save_state(euler_sim* S, const char* path) {
   if (!S || !path) return EULER_EINVAL;
+  if (S->slab_on) { eu_set_error("euler_save_state: not on a row-slab handle (gather the ranks' rows with euler_get_field)"); return EULER_ESTATE; }
   euler_stats st;
   int rc = euler_get_stats(S, &st);
   if (rc) return rc;
@@ -810,6 +911,7 @@ extern "C" int euler_save_state(euler_sim* S, const char* path) {
 
 extern "C" int euler_load_state(euler_sim* S, const char* path) {
   if (!S || !path) return EULER_EINVAL;
+  if (S->slab_on) { eu_set_error("euler_load_state: not on a row-slab handle"); return EULER_ESTATE; }
   FILE* f = fopen(path, "rb");
   if (!f) { eu_set_error("cannot open %s", path); return EULER_EIO; }
   SnapHeader h;

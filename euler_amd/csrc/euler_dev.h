@@ -70,6 +70,12 @@ struct MarkerState {
   float dt;                   // calculate_timestep result
   unsigned int max_u2_bits, max_v2_bits;
   int error;                  // sticky device-side error (bounded waits)
+  // row slabs (k_slab.hip): n above is the GLOBAL marker count (the reference's g_markers_length); this rank holds n_loc of them
+  unsigned long long n_loc;
+  unsigned int n_rm;          // local markers leaving the array in this refresh (deleted here + migrated away)
+  unsigned int n_del_glob;    // markers deleted on all ranks together in this refresh
+  unsigned int n_recv;        // markers received from the neighbouring slabs in this substep
+  unsigned int src_k_lo;      // sources: eligible cells on lower ranks (= this rank's first index into the substep's append order)
 };
 
 // Band-skewed layout of the solver's private arrays (k_pcg.hip header): element (x,y) lives at
@@ -177,6 +183,18 @@ struct euler_sim {
   size_t e_lo, e_cnt;         // the same range in skewed elements
   double* halo_buf;           // 4 rows of X doubles: send_lo, send_hi, recv_lo, recv_hi
   int own_stream;
+  // Row slabs for EVERY stage (euler_config.slab_nranks > 1; k_slab.hip): this rank owns the rows of its bands,
+  // [row_lo, row_hi).  Every row-major array holds only the window [win_lo, win_hi) = owned rows + EU_GHOST_LO rows below +
+  // EU_GHOST_HI above (clipped to the grid) and is addressed with GLOBAL (x, y): the base pointers are shifted by
+  // -win_lo * X (win_off).  The band-skewed arrays hold the own bands + one band either side, shifted likewise (skew_off).
+  // Without slabs the window is the whole grid and both offsets are 0.
+  int slab_on, shifted;
+  int row_lo, row_hi, win_lo, win_hi;
+  size_t win_off, Cw, skew_off, Sw;
+  int ab_lo, ab_hi;           // bands the skewed arrays hold
+  unsigned int* keys[2];      // slab mode: the GLOBAL array index (the reference's position in g_markers) of each local marker
+  euler_comm_ops bulk;        // the communicator the caller installed (the mailboxes replace S->comm's all-reduce / halo only)
+  struct SlabScratch* slab;   // exchange buffers (k_slab.hip)
   void* rccl;                 // the built-in RCCL communicator (comm_rccl.hip), if euler_set_comm_rccl installed one
   void* p2p;                  // peer-to-peer mailboxes for the scalar all-reduces and ghost rows (comm_p2p.hip)
   int p2p_on;                 // connected: reductions finish their all-reduce in their own last block, ghost rows go direct
@@ -216,6 +234,14 @@ static inline unsigned eu_blocks(size_t n, unsigned per_block, unsigned cap = 0x
   return (unsigned)b;
 }
 
+#define EU_GHOST_LO 1   // ghost rows below / above a slab: u, v need 1 / 1, the count grids 1 / 2, vtmp 1 / 0
+#define EU_GHOST_HI 2
+// slab mode (k_slab.hip)
+int  eu_slab_alloc(euler_sim* S);
+void eu_slab_release(euler_sim* S);
+int  eu_slab_substep(euler_sim* S, float dt);
+int  eu_slab_timestep(euler_sim* S, float frame_time_left);
+int  eu_slab_after_load(euler_sim* S);
 // launch groups implemented in the kernel files
 int eu_launch_timestep(euler_sim* S, float frame_time_left);
 int eu_launch_advect_markers(euler_sim* S, float dt);

@@ -7,10 +7,10 @@
 // ------------------------------------------------------------------------------------------
 // calculate_timestep / maxsq (main.c:808-841): max over the typed extents, including zeros.
 __global__ __launch_bounds__(256) void k_maxsq(const float* __restrict__ u, const float* __restrict__ v,
-                                               int X, int Y, MarkerState* ms) {
-  const size_t C = (size_t)X * Y;
+                                               int X, int Y, MarkerState* ms, int y0, int y1) {   // rows [y0, y1) of this rank
+  const size_t C = (size_t)X * y1;
   float mu = 0.f, mv = 0.f;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < C; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = (size_t)X * y0 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < C; i += (size_t)gridDim.x * blockDim.x) {
     const int x = (int)(i % X), y = (int)(i / X);
     if (x < X - 1) { const float s = u[i] * u[i]; if (s > mu) mu = s; }
     if (y < Y - 1) { const float s = v[i] * v[i]; if (s > mv) mv = s; }
@@ -38,8 +38,15 @@ __global__ void k_dt(MarkerState* ms, float frame_time_left) {
   ms->max_v2_bits = 0u;
 }
 
+int eu_launch_dt(euler_sim* S, float frame_time_left) {
+  LAUNCH(S, KC_TIMESTEP, k_dt, dim3(1), dim3(1), S->ms, frame_time_left);
+  return EULER_OK;
+}
+
 int eu_launch_timestep(euler_sim* S, float frame_time_left) {
-  LAUNCH(S, KC_TIMESTEP, k_maxsq, dim3(eu_blocks(S->C, 256 * 8, 2048)), dim3(256), S->u, S->v, S->X, S->Y, S->ms);
+  LAUNCH(S, KC_TIMESTEP, k_maxsq, dim3(eu_blocks((size_t)S->X * (S->row_hi - S->row_lo), 256 * 8, 2048)), dim3(256), S->u, S->v, S->X, S->Y, S->ms,
+         S->row_lo, S->row_hi);
+  if (S->slab_on) return eu_slab_timestep(S, frame_time_left);   // max over the slabs first
   LAUNCH(S, KC_TIMESTEP, k_dt, dim3(1), dim3(1), S->ms, frame_time_left);
   return EULER_OK;
 }
@@ -70,29 +77,29 @@ __device__ __forceinline__ void extrapolate_sample(float* q, const uint8_t* prev
 }
 
 __global__ __launch_bounds__(256) void k_extrapolate(float* u, float* v, const uint8_t* __restrict__ prev,
-                                                     const uint8_t* __restrict__ cur, int X, int Y) {
+                                                     const uint8_t* __restrict__ cur, int X, int Y, int y0, int y1) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= X || y >= Y) return;
+  const int y = y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= X || y >= y1) return;
   if (x < X - 1) extrapolate_sample<1>(u, prev, cur, x, y, X, X - 1, Y);
   if (y < Y - 1) extrapolate_sample<2>(v, prev, cur, x, y, X, X, Y - 1);
 }
 
 // zero_bounds (main.c:822-832) for U and V in one launch.
 __global__ __launch_bounds__(256) void k_zero_bounds(float* u, float* v, const uint8_t* __restrict__ cur,
-                                                     const uint8_t* __restrict__ solid, int X, int Y) {
+                                                     const uint8_t* __restrict__ solid, int X, int Y, int y0, int y1) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= X || y >= Y) return;
+  const int y = y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= X || y >= y1) return;
   const size_t i = (size_t)y * X + x;
   if (x < X - 1 && (!eu_prop_u(cur, i) || eu_prop_u(solid, i))) u[i] = 0.f;
   if (y < Y - 1 && (!eu_prop_v(cur, i, X) || eu_prop_v(solid, i, X))) v[i] = 0.f;
 }
 
 int eu_launch_extrapolate(euler_sim* S) {
-  dim3 grid((S->X + 63) / 64, (S->Y + 3) / 4);
-  LAUNCH(S, KC_EXTRAPOLATE, k_extrapolate, grid, dim3(256), S->u, S->v, S->prev_count, S->count, S->X, S->Y);
-  LAUNCH(S, KC_EXTRAPOLATE, k_zero_bounds, grid, dim3(256), S->u, S->v, S->count, S->solid, S->X, S->Y);
+  dim3 grid((S->X + 63) / 64, (S->row_hi - S->row_lo + 3) / 4);   // this rank's rows (all of them without slabs)
+  LAUNCH(S, KC_EXTRAPOLATE, k_extrapolate, grid, dim3(256), S->u, S->v, S->prev_count, S->count, S->X, S->Y, S->row_lo, S->row_hi);
+  LAUNCH(S, KC_EXTRAPOLATE, k_zero_bounds, grid, dim3(256), S->u, S->v, S->count, S->solid, S->X, S->Y, S->row_lo, S->row_hi);
   return EULER_OK;
 }
 
@@ -103,11 +110,11 @@ int eu_launch_extrapolate(euler_sim* S) {
 // gravity it adds to non-fluid faces never survive).
 __global__ __launch_bounds__(256) void k_advect_velocity(const float* __restrict__ u, const float* __restrict__ v,
                                                          float* __restrict__ uout, float* __restrict__ vout,
-                                                         const uint8_t* __restrict__ solid, GridRef g, float dt) {
+                                                         const uint8_t* __restrict__ solid, GridRef g, float dt, int y0, int y1) {
   const int X = g.X, Y = g.Y;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= X || y >= Y) return;
+  const int y = y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= X || y >= y1) return;
   const size_t i = (size_t)y * X + x;
   if (x < X - 1) {
     float out = 0.f;
@@ -139,10 +146,10 @@ __global__ __launch_bounds__(256) void k_advect_velocity(const float* __restrict
 __global__ __launch_bounds__(256) void k_diffuse_velocity(const float* __restrict__ uin, const float* __restrict__ vin,
                                                           float* __restrict__ uout, float* __restrict__ vout,
                                                           const uint8_t* __restrict__ count, const uint8_t* __restrict__ solid,
-                                                          int X, int Y, float c) {
+                                                          int X, int Y, float c, int y0, int y1) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= X || y >= Y) return;
+  const int y = y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= X || y >= y1) return;
   const size_t i = (size_t)y * X + x;
   auto live_u = [&](size_t k) { return eu_prop_u(count, k) && !eu_prop_u(solid, k); };
   auto live_v = [&](size_t k) { return eu_prop_v(count, k, X) && !eu_prop_v(solid, k, X); };
@@ -172,10 +179,10 @@ __global__ __launch_bounds__(256) void k_diffuse_velocity(const float* __restric
   }
 }
 __global__ __launch_bounds__(256) void k_copy_typed(const float* __restrict__ u, const float* __restrict__ v, float* __restrict__ uo,
-                                                    float* __restrict__ vo, int X, int Y) {
+                                                    float* __restrict__ vo, int X, int Y, int y0, int y1) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= X || y >= Y) return;
+  const int y = y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= X || y >= y1) return;
   const size_t i = (size_t)y * X + x;
   if (x < X - 1) uo[i] = u[i];
   if (y < Y - 1) vo[i] = v[i];
@@ -183,12 +190,12 @@ __global__ __launch_bounds__(256) void k_copy_typed(const float* __restrict__ u,
 
 int eu_launch_advect_velocity(euler_sim* S, float dt) {
   GridRef g{S->X, S->Y, S->count, S->interp_lim[0], S->interp_lim[1], S->interp_lim[2], S->interp_lim[3]};
-  dim3 grid((S->X + 63) / 64, (S->Y + 3) / 4);
-  LAUNCH(S, KC_ADVECT_VELOCITY, k_advect_velocity, grid, dim3(256), S->u, S->v, S->utmp, S->vtmp, S->solid, g, dt);
+  dim3 grid((S->X + 63) / 64, (S->row_hi - S->row_lo + 3) / 4);
+  LAUNCH(S, KC_ADVECT_VELOCITY, k_advect_velocity, grid, dim3(256), S->u, S->v, S->utmp, S->vtmp, S->solid, g, dt, S->row_lo, S->row_hi);
   if (S->cfg.viscosity > 0.f) {   // extension stage; absent (bit-identical to the reference) at viscosity 0
     const float c = S->cfg.viscosity * dt / (EU_H * EU_H);
-    LAUNCH(S, KC_ADVECT_VELOCITY, k_diffuse_velocity, grid, dim3(256), S->utmp, S->vtmp, S->u, S->v, S->count, S->solid, S->X, S->Y, c);
-    LAUNCH(S, KC_ADVECT_VELOCITY, k_copy_typed, grid, dim3(256), S->u, S->v, S->utmp, S->vtmp, S->X, S->Y);
+    LAUNCH(S, KC_ADVECT_VELOCITY, k_diffuse_velocity, grid, dim3(256), S->utmp, S->vtmp, S->u, S->v, S->count, S->solid, S->X, S->Y, c, S->row_lo, S->row_hi);
+    LAUNCH(S, KC_ADVECT_VELOCITY, k_copy_typed, grid, dim3(256), S->u, S->v, S->utmp, S->vtmp, S->X, S->Y, S->row_lo, S->row_hi);
   }
   return EULER_OK;
 }
@@ -247,11 +254,11 @@ __global__ __launch_bounds__(256) void k_build_system(const float* __restrict__ 
 __global__ __launch_bounds__(256) void k_velocity_update(const float* __restrict__ uin, const float* __restrict__ vin,
                                                          float* __restrict__ uout, float* __restrict__ vout,
                                                          double* p, const uint8_t* __restrict__ count,
-                                                         const uint8_t* __restrict__ solid, SkewGeom g, float dt) {
+                                                         const uint8_t* __restrict__ solid, SkewGeom g, float dt, int y0, int y1) {
   const int X = g.X, Y = g.Y;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= X || y >= Y) return;
+  const int y = y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= X || y >= y1) return;
   const size_t i = (size_t)y * X + x;
   const size_t e = skew_index(g, x, y);
   const bool f0 = count[i] != 0;
@@ -291,34 +298,35 @@ int eu_launch_build_system(euler_sim* S, float dt) {
 }
 
 int eu_launch_velocity_update(euler_sim* S, float dt) {
-  dim3 grid((S->X + 63) / 64, (S->Y + 3) / 4);
+  dim3 grid((S->X + 63) / 64, (S->row_hi - S->row_lo + 3) / 4);
   LAUNCH(S, KC_VELOCITY_UPDATE, k_velocity_update, grid, dim3(256), S->utmp, S->vtmp, S->u, S->v, S->p, S->count,
-         S->solid, S->geom, dt);
+         S->solid, S->geom, dt, S->row_lo, S->row_hi);
   return EULER_OK;
 }
 
 // ------------------------------------------------------------------------------------------
 // skewed <-> row-major conversion for euler_get_field / euler_set_field (tests, render of p)
+// (rowmajor holds this rank's rows only, starting at row y0)
 template <typename T>
-__global__ __launch_bounds__(256) void k_unskew(const T* __restrict__ skew, T* __restrict__ rowmajor, SkewGeom g) {
+__global__ __launch_bounds__(256) void k_unskew(const T* __restrict__ skew, T* __restrict__ rowmajor, SkewGeom g, int y0, int y1) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < (size_t)g.X * g.Y) rowmajor[i] = skew[skew_index(g, (int)(i % g.X), (int)(i / g.X))];
+  if (i < (size_t)g.X * (y1 - y0)) rowmajor[i] = skew[skew_index(g, (int)(i % g.X), y0 + (int)(i / g.X))];
 }
 template <typename T>
-__global__ __launch_bounds__(256) void k_skew(const T* __restrict__ rowmajor, T* __restrict__ skew, SkewGeom g) {
+__global__ __launch_bounds__(256) void k_skew(const T* __restrict__ rowmajor, T* __restrict__ skew, SkewGeom g, int y0, int y1) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < (size_t)g.X * g.Y) skew[skew_index(g, (int)(i % g.X), (int)(i / g.X))] = rowmajor[i];
+  if (i < (size_t)g.X * (y1 - y0)) skew[skew_index(g, (int)(i % g.X), y0 + (int)(i / g.X))] = rowmajor[i];
 }
 
 int eu_unskew(euler_sim* S, const void* skew, void* rowmajor, int elem_bytes) {
-  const unsigned nb = eu_blocks(S->C, 256);
-  if (elem_bytes == 8) hipLaunchKernelGGL(k_unskew<double>, dim3(nb), dim3(256), 0, S->stream, (const double*)skew, (double*)rowmajor, S->geom);
-  else hipLaunchKernelGGL(k_unskew<uint8_t>, dim3(nb), dim3(256), 0, S->stream, (const uint8_t*)skew, (uint8_t*)rowmajor, S->geom);
+  const unsigned nb = eu_blocks((size_t)S->X * (S->row_hi - S->row_lo), 256);
+  if (elem_bytes == 8) hipLaunchKernelGGL(k_unskew<double>, dim3(nb), dim3(256), 0, S->stream, (const double*)skew, (double*)rowmajor, S->geom, S->row_lo, S->row_hi);
+  else hipLaunchKernelGGL(k_unskew<uint8_t>, dim3(nb), dim3(256), 0, S->stream, (const uint8_t*)skew, (uint8_t*)rowmajor, S->geom, S->row_lo, S->row_hi);
   return EULER_OK;
 }
 int eu_skew(euler_sim* S, const void* rowmajor, void* skew, int elem_bytes) {
-  const unsigned nb = eu_blocks(S->C, 256);
-  if (elem_bytes == 8) hipLaunchKernelGGL(k_skew<double>, dim3(nb), dim3(256), 0, S->stream, (const double*)rowmajor, (double*)skew, S->geom);
-  else hipLaunchKernelGGL(k_skew<uint8_t>, dim3(nb), dim3(256), 0, S->stream, (const uint8_t*)rowmajor, (uint8_t*)skew, S->geom);
+  const unsigned nb = eu_blocks((size_t)S->X * (S->row_hi - S->row_lo), 256);
+  if (elem_bytes == 8) hipLaunchKernelGGL(k_skew<double>, dim3(nb), dim3(256), 0, S->stream, (const double*)rowmajor, (double*)skew, S->geom, S->row_lo, S->row_hi);
+  else hipLaunchKernelGGL(k_skew<uint8_t>, dim3(nb), dim3(256), 0, S->stream, (const uint8_t*)rowmajor, (uint8_t*)skew, S->geom, S->row_lo, S->row_hi);
   return EULER_OK;
 }

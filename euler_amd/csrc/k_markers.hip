@@ -226,14 +226,17 @@ __global__ __launch_bounds__(256) void k_advect_markers_b(const float2* __restri
                                                           const float* __restrict__ u, const float* __restrict__ v,
                                                           const uint8_t* __restrict__ solid, GridRef g,
                                                           unsigned long long n, const unsigned int* __restrict__ act_idx,
-                                                          const float* __restrict__ act_dt, const MarkerState* ms) {
+                                                          const float* __restrict__ act_dt, const MarkerState* ms,
+                                                          const unsigned int* __restrict__ keys) {   // keys: slab mode, the markers' GLOBAL array indices
   const unsigned int M = ms->n_actual;
   if (M == 0) return;
   const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || i <= act_idx[0]) return;
-  // number of firing collisions with index < i  (act_idx ascending)
+  if (i >= n) return;
+  const unsigned long long gi = keys ? keys[i] : i;      // the position in the reference's array decides which dt applies
+  if (gi <= act_idx[0]) return;
+  // number of firing collisions with index < gi  (act_idx ascending)
   unsigned int lo = 0, hi = M;
-  while (lo < hi) { const unsigned int mid = (lo + hi) >> 1; if (act_idx[mid] < i) lo = mid + 1; else hi = mid; }
+  while (lo < hi) { const unsigned int mid = (lo + hi) >> 1; if (act_idx[mid] < gi) lo = mid + 1; else hi = mid; }
   const float dt = act_dt[lo - 1];
   const float2 p = in[i];
   const AdvectOut o = advect_one(g, u, v, solid, p.x, p.y, dt);
@@ -253,7 +256,7 @@ int eu_launch_advect_markers(euler_sim* S, float dt) {
   LAUNCH(S, KC_MARKER_EVENTS, k_marker_walk, dim3(1), dim3(64), S->sel_idx, S->ev_theta, S->ev_delta, S->act_idx,
          S->act_dt, S->ms, dt);
   LAUNCH(S, KC_MARKER_ADVECT, k_advect_markers_b, dim3(nb), dim3(256), in, out, S->u, S->v, S->solid, g, n,
-         S->act_idx, S->act_dt, S->ms);
+         S->act_idx, S->act_dt, S->ms, (const unsigned int*)nullptr);
   S->cur ^= 1;
   return EULER_OK;
 }
@@ -261,8 +264,8 @@ int eu_launch_advect_markers(euler_sim* S, float dt) {
 // ==========================================================================================
 // refresh_marker_counts (main.c:102-117)
 __global__ __launch_bounds__(256) void k_rotate_counts(uint8_t* __restrict__ prev, const uint8_t* __restrict__ cur,
-                                                       unsigned int* __restrict__ count32, size_t C) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < C; i += (size_t)gridDim.x * blockDim.x) {
+                                                       unsigned int* __restrict__ count32, size_t i0, size_t C) {   // cells [i0, C): the window
+  for (size_t i = i0 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < C; i += (size_t)gridDim.x * blockDim.x) {
     prev[i] = cur[i];
     count32[i] = 0u;
   }
@@ -307,24 +310,48 @@ __global__ __launch_bounds__(256) void k_compact_markers(float2* m, const unsign
 }
 
 __global__ __launch_bounds__(256) void k_narrow_counts(uint8_t* __restrict__ count, const unsigned int* __restrict__ count32,
-                                                       size_t C, MarkerState* ms) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < C; i += (size_t)gridDim.x * blockDim.x)
+                                                       size_t i0, size_t C, MarkerState* ms, int slab) {
+  for (size_t i = i0 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < C; i += (size_t)gridDim.x * blockDim.x)
     count[i] = (uint8_t)count32[i];   // g_marker_count is uint8_t and wraps (main.c:96,114)
-  if (blockIdx.x == 0 && threadIdx.x == 0) ms->n -= ms->n_deleted;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (slab) { ms->n -= ms->n_del_glob; ms->n_loc -= ms->n_rm; }
+    else ms->n -= ms->n_deleted;
+  }
+}
+
+// pieces the row-slab substep (k_slab.hip) shares with the single-GPU stages: all over this rank's window of rows
+int eu_marker_rotate_counts(euler_sim* S) {
+  LAUNCH(S, KC_MARKER_BIN, k_rotate_counts, dim3(eu_blocks(S->Cw, 256 * 4, 4096)), dim3(256), S->prev_count, S->count,
+         S->count32, S->win_off, (size_t)S->win_hi * S->X);
+  return EULER_OK;
+}
+int eu_marker_narrow_counts(euler_sim* S) {
+  LAUNCH(S, KC_MARKER_BIN, k_narrow_counts, dim3(eu_blocks(S->Cw, 256 * 4, 4096)), dim3(256), S->count, S->count32, S->win_off,
+         (size_t)S->win_hi * S->X, S->ms, S->slab_on);
+  return EULER_OK;
+}
+int eu_marker_advect_a(euler_sim* S, float dt, unsigned long long n) {
+  GridRef g{S->X, S->Y, S->count, S->interp_lim[0], S->interp_lim[1], S->interp_lim[2], S->interp_lim[3]};
+  LAUNCH(S, KC_MARKER_ADVECT, k_advect_markers_a, dim3(eu_blocks((size_t)n, 256)), dim3(256), S->markers[S->cur], S->markers[S->cur ^ 1], S->u, S->v, S->solid, g, dt, n,
+         S->evmask, S->ev_theta, S->ev_delta, S->ms);
+  return eu_ordered_select(S, S->evmask, (size_t)((n + 63) / 64), S->sel_idx, &S->ms->n_events);
+}
+int eu_marker_advect_b(euler_sim* S, unsigned long long n, const unsigned int* keys) {
+  GridRef g{S->X, S->Y, S->count, S->interp_lim[0], S->interp_lim[1], S->interp_lim[2], S->interp_lim[3]};
+  LAUNCH(S, KC_MARKER_ADVECT, k_advect_markers_b, dim3(eu_blocks((size_t)n, 256)), dim3(256), S->markers[S->cur], S->markers[S->cur ^ 1], S->u, S->v, S->solid, g, n,
+         S->act_idx, S->act_dt, S->ms, keys);
+  return EULER_OK;
 }
 
 int eu_launch_refresh_counts(euler_sim* S) {
   const unsigned long long n = S->n_markers_host;
-  LAUNCH(S, KC_MARKER_BIN, k_rotate_counts, dim3(eu_blocks(S->C, 256 * 4, 4096)), dim3(256), S->prev_count, S->count,
-         S->count32, S->C);
+  eu_marker_rotate_counts(S);
   LAUNCH(S, KC_MARKER_BIN, k_bin_markers, dim3(eu_blocks((size_t)n, 256)), dim3(256), S->markers[S->cur], n, S->sink,
          S->solid, S->count32, S->evmask, S->X);
   int rc = eu_ordered_select(S, S->evmask, (size_t)((n + 63) / 64), S->sel_idx, &S->ms->n_deleted);
   if (rc) return rc;
   LAUNCH(S, KC_MARKER_COMPACT, k_compact_markers, dim3(256), dim3(256), S->markers[S->cur], S->sel_idx, S->evmask, S->ms);
-  LAUNCH(S, KC_MARKER_BIN, k_narrow_counts, dim3(eu_blocks(S->C, 256 * 4, 4096)), dim3(256), S->count, S->count32, S->C,
-         S->ms);
-  return EULER_OK;
+  return eu_marker_narrow_counts(S);
 }
 
 // ==========================================================================================

@@ -1367,7 +1367,8 @@ __global__ __launch_bounds__(256) void k_pack_fbits(const uint8_t* __restrict__ 
 int eu_launch_band_ranges(euler_sim* S) {
   if (S->cfg.precond == EULER_PRECOND_IC0_TILE) return EULER_OK;   // no band pipeline, no packed flags: k_precond_tile reads the cell mask
   // a rank needs the ranges of its own bands and of the band before / after its slab (the hand-off windows)
-  const int b0 = S->band_lo > 0 ? S->band_lo - 1 : 0, b1 = S->band_hi < S->geom.nbands ? S->band_hi + 1 : S->geom.nbands;
+  const bool nbrs = S->has_comm && S->couple && !S->slab_on;   // (a row-slab handle does not hold the neighbours' count rows)
+  const int b0 = nbrs && S->band_lo > 0 ? S->band_lo - 1 : S->band_lo, b1 = nbrs && S->band_hi < S->geom.nbands ? S->band_hi + 1 : S->band_hi;
   LAUNCH(S, KC_BUILD_SYSTEM, k_band_ranges, dim3(b1 - b0), dim3(1024), S->count, S->X, S->Y, S->geom.T, S->band_ranges, b0);
   const int nbl = S->band_hi - S->band_lo;
   const size_t n = (size_t)nbl * S->fb_stride * 64;
@@ -1703,7 +1704,14 @@ int eu_launch_project(euler_sim* S, float dt) {
   S->prof_iter = -2;
   if (tile)   // the last iteration's p += alpha s (every other one rode along with the following apply_a pass)
     LAUNCH(S, KC_UPDATE_PR, k_finish_p, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->p), LOC(S->cellmask), S->e_lo, S->e_cnt, S->sc);
-  if (S->has_comm) {   // every rank needs the whole pressure field for the replicated velocity update
+  if (S->has_comm && S->slab_on) {
+    // row slabs: the velocity update of the highest own row reads p one row up (main.c:800) - one ghost row from the rank above
+    const int X = S->X, nbk = (X + 255) / 256;
+    double *send_lo = S->halo_buf, *send_hi = S->halo_buf + X, *recv_lo = S->halo_buf + 2 * X, *recv_hi = S->halo_buf + 3 * X;
+    if (S->band_lo > 0) hipLaunchKernelGGL(k_pack_row, dim3(nbk), dim3(256), 0, S->stream, S->p, send_lo, S->geom, S->band_lo, 0);
+    COMM_CALL(S->bulk.halo(S->bulk.ctx, send_lo, send_hi, recv_lo, recv_hi, X));
+    if (S->band_hi < S->geom.nbands) hipLaunchKernelGGL(k_unpack_row, dim3(nbk), dim3(256), 0, S->stream, S->p, recv_hi, S->geom, S->band_hi, 0);
+  } else if (S->has_comm) {   // every rank needs the whole pressure field for the replicated velocity update
     const int n = S->comm.nranks, nb = S->geom.nbands;
     std::vector<int64_t> off(n), cnt(n);
     for (int k = 0; k < n; ++k) {

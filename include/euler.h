@@ -82,7 +82,14 @@ typedef struct euler_config {
   int32_t rainbow;         /* args_t.rainbow / g_rainbow_enabled (main.c:54,75,1020): carry the dye fields */
   int32_t precond_tile_records; /* EULER_PRECOND_IC0_TILE: records per tile, 8, 16 or 32 (0 = default 16); tile k of a band =
                                    records [k * W, (k + 1) * W) */
-  int32_t reserved[6];
+  int32_t slab_rank, slab_nranks; /* slab_nranks > 1: ROW SLABS FOR EVERY STAGE.  This handle is rank slab_rank of a job of
+                                   slab_nranks processes, one per GPU; it owns the rows of its 64-row bands (euler_slab_info) and
+                                   allocates ONLY those rows (+ 1 ghost row below, 2 above) of every grid and only the markers inside
+                                   them - per-rank memory ~ 1/slab_nranks.  Install a communicator of the same rank / size
+                                   (euler_set_comm / euler_set_comm_rccl) BEFORE loading a scenario.  Fields are then exchanged as the
+                                   owned rows (euler_get_field), markers as the local ones with their global array index
+                                   (EULER_F_MARKER_KEYS).  Needs EULER_PRECOND_IC0_TILE or slab-local IC(0) coupling. */
+  int32_t reserved[4];
 } euler_config;
 
 typedef struct euler_sim euler_sim; /* opaque */
@@ -107,6 +114,8 @@ enum {
   EULER_F_DYE_R, EULER_F_DYE_G, EULER_F_DYE_B,             /* float g_r, g_g, g_b (main.c:76-78); euler_config.rainbow only */
   EULER_F_DYE_RTMP, EULER_F_DYE_GTMP, EULER_F_DYE_BTMP,    /* float g_rtmp, g_gtmp, g_btmp (main.c:79-81): state, because the
                                                               reference copies them back whole (main.c:875-881) */
+  EULER_F_MARKER_KEYS,    /* uint32[n local markers]: row-slab handles only - the position of each local marker in the reference's
+                             g_markers array (EULER_F_MARKERS of all ranks, ordered by key, IS that array) */
   EULER_F__COUNT
 };
 
