@@ -348,7 +348,7 @@ class Simulation:
         a = np.empty(nbytes // dt.itemsize, dt)
         if nbytes:
             _check(self.L.euler_get_field(self.h, field, a.ctypes.data, nbytes))
-        elif field != F_MARKERS:      # an unknown or unavailable field: let the library say why
+        elif field not in (F_MARKERS, F_MARKER_KEYS):      # an unknown or unavailable field: let the library say why
             _check(self.L.euler_get_field(self.h, field, np.empty(8, np.uint8).ctypes.data, 0) or -1)
         if field == F_MARKERS:
             return a.reshape(-1, 2)

@@ -65,6 +65,7 @@ def main():
         dist.all_gather_object(keys_all, k.tolist())
         flat = np.sort(np.concatenate([np.asarray(x, np.int64) for x in keys_all])) if sum(len(x) for x in keys_all) else np.zeros(0, np.int64)
         d["keys_are_a_permutation"] = bool(len(flat) == len(rm) and np.array_equal(flat, np.arange(len(rm))))
+        d["keys_cover_own_count"] = bool(len(flat) == int(ss.n_markers) and np.array_equal(flat, np.arange(len(flat))))
         d["n_markers"] = [int(sr.n_markers), int(ss.n_markers), len(m)]
         d["iters"] = [sr.last_pcg_iterations, ss.last_pcg_iterations]
         d["substeps"] = [sr.last_substeps, ss.last_substeps]
@@ -77,7 +78,7 @@ def main():
         for o in agg[1:]:
             for key in ("du", "dv", "dp", "count_differ", "prev_count_differ"):
                 w[key] = max(w[key], o[key])
-            for key in ("markers_at_keys", "markers_in_rows", "keys_are_a_permutation"):
+            for key in ("markers_at_keys", "markers_in_rows", "keys_are_a_permutation", "keys_cover_own_count"):
                 w[key] = w[key] and o[key]
             w["rng"] = [w["rng"][0] and o["rng"][0], w["rng"][1] and o["rng"][1]]
             w.setdefault("local_markers", [agg[0]["n_markers"][2]]).append(o["n_markers"][2])

@@ -150,7 +150,7 @@ def test_switching_the_preconditioner_on_a_live_handle():
     text = scenario_text(load("block_frames.npz"))
     a = ea.Simulation(300, 200, dot_mode=ea.DOT_SEQUENTIAL).load_text(text, upscale=True)
     o = Oracle(300, 200).load_text(text, upscale=True)
-    for units in (0, 2, 0):
+    for units in (0, 16, 0):
         a.set_precond(ea.PRECOND_IC0_TILE if units else ea.PRECOND_IC0, units)
         o.c.tile_records = units
         for _ in range(3):

@@ -25,8 +25,10 @@ def test_slab_partition_covers_all_bands():
             assert min(sizes) >= 1 and max(sizes) - min(sizes) <= 1
 
 
-def run_workers(nproc, X, Y, workload, frames, coupling, port, extra=()):
+def run_workers(nproc, X, Y, workload, frames, coupling, port, extra=(), fusion=False):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if fusion:      # opt-in: k_search_apply reading the neighbouring slabs' z / s through IPC mappings
+        env["EULER_SLAB_FUSION"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc, "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "slab_worker.py"), str(X), str(Y), workload, str(frames), str(coupling)] + list(extra)
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
@@ -35,19 +37,20 @@ def run_workers(nproc, X, Y, workload, frames, coupling, port, extra=()):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fusion", [False, True])
 @pytest.mark.parametrize("nproc,X,Y,workload,frames,coupling", [(2, 192, 256, "half_tank", 3, 1), (3, 200, 330, "waterfall", 12, 1), (2, 256, 256, "dam_break", 30, 1),
                                                                (4, 256, 512, "dam_break", 30, 0)])
-def test_p2p_mailboxes_carry_the_iteration_exchanges(nproc, X, Y, workload, frames, coupling):
+def test_p2p_mailboxes_carry_the_iteration_exchanges(nproc, X, Y, workload, frames, coupling, fusion):
     """csrc/comm_p2p.hip: the three scalar all-reduces and the ghost-row exchange of every PCG iteration as
     direct writes into the peers' IPC-mapped mailboxes (here: 2-4 processes sharing the box's one GPU; on a node
     the same mappings cross xGMI).  The sums are formed in rank order, so every rank holds bit-identical scalars;
     against the 1-GPU run the same tolerances as the host-staged transport apply (exact coupling), and with
     slab-local coupling the replicated state must still agree on every rank."""
-    d = run_workers(nproc, X, Y, workload, frames, coupling, 29551, extra=("p2p",))
+    d = run_workers(nproc, X, Y, workload, frames, coupling, 29551, extra=("p2p",), fusion=fusion)
     assert d["p2p_ok"], d["p2p_error"]
     assert d["ranks_agree"]
     assert d["p2p_calls"]["allreduce"] > 0 and d["p2p_calls"]["halo"] > 0
-    assert d["calls"]["allreduce"] == 0 and d["calls"]["halo"] == 0         # nothing per-iteration went through the host
+    assert d["calls"]["allreduce"] <= 1 and d["calls"]["halo"] == 0         # nothing per-iteration went through the host (1 = euler_p2p_connect's agreement)
     assert d["calls"]["chain"] == 0       # exact coupling: the band pipeline runs on across the ranks through the mailboxes
     solved = 0
     for f in d["frames"]:
@@ -120,7 +123,7 @@ def test_builtin_rccl_communicator(workload, X, Y, frames, p2p):
     assert d["ranks_agree"] and d["calls"]["allgather"] > 0
     if p2p:      # bench.py's configuration: mailboxes for the per-iteration exchanges, RCCL underneath for the bulk transfers
         assert d["p2p_ok"], d["p2p_error"]
-        assert d["p2p_calls"]["allreduce"] > 0 and d["p2p_calls"]["halo"] > 0 and d["calls"]["allreduce"] == 0
+        assert d["p2p_calls"]["allreduce"] > 0 and d["p2p_calls"]["halo"] > 0 and d["calls"]["allreduce"] <= 1
     else:
         assert d["calls"]["allreduce"] > 0 and d["calls"]["halo"] > 0
     solved = 0
