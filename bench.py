@@ -74,9 +74,11 @@ def parse_args():
     ap.add_argument("--tile-records", type=int, default=0)
     ap.add_argument("--tol", type=float, default=None, help="PCG tolerance (default: 0 for half_tank = the roofline run, else the reference's 1e-6)")
     ap.add_argument("--max-preroll", type=int, default=400)
-    ap.add_argument("--slab", default="local", choices=["local", "exact", "replicas"],
-                    help="N>1, parity mode only: slab-local IC(0) (scales; tolerance-only), exact coupling (the 1-GPU iterates; sweeps "
-                         "serialize across GPUs) or independent replicas.  The roofline mode has no coupling between slabs at all.")
+    ap.add_argument("--slab", default="rows", choices=["rows", "local", "exact", "replicas"],
+                    help="N>1: rows = TRUE ROW SLABS for every stage (default; SURVEY 8e: each rank holds and steps only its rows and the "
+                         "markers in them, ghost rows / marker migration / dt all-reduce between neighbours); local / exact = round 1's layout "
+                         "(only the pressure solve is sharded, the cheap stages run replicated on the whole grid) with slab-local or exact IC(0) "
+                         "coupling; replicas = independent copies.  The roofline mode has no preconditioner coupling between slabs at all.")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
                     help="N>1 exchange transport: the library's own RCCL communicator (C, no host code between kernels) "
                          "or the torch.distributed callbacks of euler_amd/slab.py")
@@ -262,7 +264,7 @@ def load_workload(sim, scenarios, workload, tiles=1):
     elif workload == "waterfall":
         sim.load_text(scenarios.stacked(scenarios.waterfall(), tiles), upscale=True)
     else:
-        sim.load_half_tank()
+        sim.load_half_tank(tiles)      # `tiles` closed tanks on top of each other (weak scaling: one per row slab)
 
 
 def preroll_into_solves(sim, max_preroll):
@@ -446,7 +448,11 @@ def main():
     GX, GY = N, N * (args.grid_y_mult if args.grid_y_mult > 0 else (world if sharded and args.scaling == "weak" else 1))
     if world > 1:
         torch.cuda.set_device(local_rank)
-    sim = ea.Simulation(GX, GY, device=local_rank, dot_mode=dot_mode, precond=PC[args.precond], tile_records=args.tile_records, tol=tol)
+    rows = sharded and world > 1 and args.slab == "rows"      # true row slabs: this process holds its rows only
+    free_before = torch.cuda.mem_get_info()[0]
+    sim = ea.Simulation(GX, GY, device=local_rank, dot_mode=dot_mode, precond=PC[args.precond], tile_records=args.tile_records, tol=tol,
+                        slab=(rank, world) if rows else None)
+    hbm_per_rank = free_before - torch.cuda.mem_get_info()[0]
     comm = None
     p2p_on = False
     if sharded:
@@ -610,12 +616,16 @@ def main():
             except Exception as e:
                 cpu_obj = {"error": repr(e)}
 
+    transports = (("peer-to-peer mailboxes (PCG scalars, ghost rows of s) + " if p2p_on else "")
+                  + ("RCCL from the C library" if args.comm == "rccl" else "torch.distributed callbacks"))
+    pc_name = "tile-local IC(0): no coupling between slabs" if args.precond == "ic0_tile" else ("slab-local" if rows else args.slab) + " IC(0) coupling"
     parallelism = "1 GPU" if args.gpus == 1 and not sharded else (
         "%d independent replicas" % args.gpus if not sharded else
+        ("%d row slabs of %d rows, EVERY stage decomposed (each rank holds its rows + ghost rows and the markers inside them: %.2f GB of HBM "
+         "per rank; ghost rows, marker migration, dt all-reduce, distributed PCG with %s; exchanges by %s); grid %dx%d"
+         % (args.gpus, GY // max(world, 1), hbm_per_rank / 1e9, pc_name, transports, GX, GY)) if rows else
         "%d row slabs of %d rows: distributed PCG (%s, exchanges by %s), replicated marker/advection stages; grid %dx%d"
-        % (args.gpus, GY // max(world, 1), "tile-local IC(0): no coupling between slabs" if args.precond == "ic0_tile" else args.slab + " IC(0) coupling",
-           ("peer-to-peer mailboxes (scalars, ghost rows) + " if p2p_on else "")
-           + ("RCCL from the C library" if args.comm == "rccl" else "torch.distributed callbacks"), GX, GY))
+        % (args.gpus, GY // max(world, 1), pc_name, transports, GX, GY))
     out = {
         "metric": "cells*steps/sec of sim_step() (frames incl. the PCG pressure projection) + pressure-solve HBM GB/s vs roofline",
         "value": job_rate,
@@ -634,7 +644,7 @@ def main():
                    "dot_mode": args.dot_mode, "max_iterations": 100, "tol": tol if tol is not None else 1e-6, "parallelism": parallelism},
         "mode": head["mode"],
         "substeps": head["substeps"], "pcg_iterations": head["pcg_iterations"], "cells_substeps_per_s": head["cells_substeps_per_s"],
-        "markers": head["markers"], "fluid_cells": head["fluid_cells"],
+        "markers": head["markers"], "fluid_cells": head["fluid_cells"], "hbm_bytes_this_rank": int(hbm_per_rank),
         "roofline": head["roofline"],
         "pcg_iteration": head["pcg_iteration"],
         "kernels": head["kernels"],

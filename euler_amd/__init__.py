@@ -66,7 +66,7 @@ _lib = None
 
 EXPORTS = [
     "euler_config_default", "euler_create", "euler_destroy", "euler_last_error", "euler_abi_version",
-    "euler_load_scenario_mem", "euler_load_scenario_file", "euler_load_half_tank", "euler_parse_scenario",
+    "euler_load_scenario_mem", "euler_load_scenario_file", "euler_load_half_tank", "euler_load_half_tanks", "euler_parse_scenario",
     "euler_seed_markers", "euler_step", "euler_timestep", "euler_substep", "euler_stage", "euler_pcg_op", "euler_set_precond",
     "euler_get_field", "euler_set_field", "euler_set_markers", "euler_set_rng", "euler_get_stats",
     "euler_field_bytes", "euler_render", "euler_render_grids", "euler_render_grids_rgb", "euler_colorize", "euler_profile_enable",
@@ -98,6 +98,7 @@ def load_library():
         "euler_load_scenario_mem": (C.c_int, [vp, C.c_char_p, i32, i32]),
         "euler_load_scenario_file": (C.c_int, [vp, C.c_char_p, i32]),
         "euler_load_half_tank": (C.c_int, [vp]),
+        "euler_load_half_tanks": (C.c_int, [vp, i32]),
         "euler_parse_scenario": (C.c_int, [C.c_char_p, i32, i32, i32, i32, vp, vp, vp, vp]),
         "euler_seed_markers": (C.c_int, [vp, i32, i32, C.POINTER(u64), vp, C.POINTER(u64)]),
         "euler_step": (C.c_int, [vp]),
@@ -301,8 +302,8 @@ class Simulation:
         _check(self.L.euler_load_scenario_mem(self.h, text, len(text), int(upscale)))
         return self
 
-    def load_half_tank(self):
-        _check(self.L.euler_load_half_tank(self.h))
+    def load_half_tank(self, tanks=1):
+        _check(self.L.euler_load_half_tanks(self.h, tanks))
         return self
 
     def sim_step(self):

@@ -339,26 +339,25 @@ static int upload_scenario(euler_sim* S, const uint8_t* solid, const uint8_t* so
                            const uint8_t* fluid) {
   const size_t C = S->C;
   if (S->slab_on && !S->has_comm) { eu_set_error("row-slab handle: install the communicator (euler_set_comm / euler_set_comm_rccl) before loading a scenario"); return EULER_ESTATE; }
-  // every rank seeds the whole marker array on the host (one sequential RNG stream, main.c:255-266) and keeps its own rows
+  // The marker array comes from ONE sequential RNG stream (main.c:255-266).  A row-slab handle walks the whole stream and keeps
+  // the markers of its own rows with their positions in the array (keys); nobody stores the whole array.
   std::vector<float> mk;
-  try { mk.resize(2 * 4 * C); } catch (...) { return EULER_ENOMEM; }
-  uint64_t rng = EULER_RNG_SEED, n = 0;
-  int rc = euler_seed_markers(fluid, S->X, S->Y, &rng, mk.data(), &n);
-  if (rc) return rc;
-  uint64_t n_loc = n;
   std::vector<unsigned int> keys;
+  uint64_t rng = EULER_RNG_SEED, n = 0, n_loc = 0;
+  int rc;
   if (S->slab_on) {
-    try { keys.reserve((size_t)(n / (uint64_t)S->cfg.slab_nranks) + 1024); } catch (...) { return EULER_ENOMEM; }
-    n_loc = 0;
-    for (uint64_t i = 0; i < n; ++i) {
-      const int y = (int)floorf(mk[2 * i + 1]);          // (positions are in cell units, h = 1)
-      if (y < S->row_lo || y >= S->row_hi) continue;
-      mk[2 * n_loc] = mk[2 * i]; mk[2 * n_loc + 1] = mk[2 * i + 1];
-      keys.push_back((unsigned int)i);
-      ++n_loc;
-    }
+    uint64_t probe = EULER_RNG_SEED;
+    rc = euler_seed_markers_rows(fluid, S->X, S->Y, S->row_lo, S->row_hi, &probe, nullptr, nullptr, 0, &n, &n_loc);
+    if (rc) return rc;
     if (n_loc > S->max_markers) { eu_set_error("row slab %d holds %llu markers, more than its capacity %zu", S->cfg.slab_rank, (unsigned long long)n_loc, S->max_markers); return EULER_ENOMEM; }
+    try { mk.resize(2 * (size_t)n_loc + 2); keys.resize((size_t)n_loc + 1); } catch (...) { return EULER_ENOMEM; }
+    rc = euler_seed_markers_rows(fluid, S->X, S->Y, S->row_lo, S->row_hi, &rng, mk.data(), keys.data(), n_loc, &n, &n_loc);
+  } else {
+    try { mk.resize(2 * 4 * C); } catch (...) { return EULER_ENOMEM; }
+    rc = euler_seed_markers(fluid, S->X, S->Y, &rng, mk.data(), &n);
+    n_loc = n;
   }
+  if (rc) return rc;
   size_t nsrc = 0;
   for (size_t i = (size_t)S->row_lo * S->X; i < (size_t)S->row_hi * S->X; ++i) nsrc += source[i] != 0;
   S->n_source_cells = nsrc;
@@ -412,9 +411,12 @@ static int fill_text(void* c, uint8_t* so, uint8_t* sr, uint8_t* si, uint8_t* fl
   TextCtx* t = (TextCtx*)c;
   return euler_parse_scenario(t->text, t->len, t->X, t->Y, t->upscale, so, sr, si, fl);
 }
+struct TankCtx { euler_sim* S; int tanks; };
 static int fill_tank(void* c, uint8_t* so, uint8_t* sr, uint8_t* si, uint8_t* fl) {
-  euler_sim* S = (euler_sim*)c;
-  return euler_half_tank_grids(S->X, S->Y, so, sr, si, fl);
+  TankCtx* t = (TankCtx*)c;
+  int rc = euler_half_tanks_grids(t->S->X, t->S->Y, t->tanks, so, sr, si, fl);
+  if (rc) eu_set_error("half tanks: %d tanks do not fit a %d x %d grid (Y must be a multiple, each tank at least 6 rows)", t->tanks, t->S->X, t->S->Y);
+  return rc;
 }
 
 extern "C" int euler_load_scenario_mem(euler_sim* S, const char* text, int32_t len, int32_t upscale) {
@@ -438,10 +440,12 @@ extern "C" int euler_load_scenario_file(euler_sim* S, const char* path, int32_t 
   return rc;
 }
 
-extern "C" int euler_load_half_tank(euler_sim* S) {
+extern "C" int euler_load_half_tanks(euler_sim* S, int32_t tanks) {
   if (!S) return EULER_EINVAL;
-  return load_from_grids(S, fill_tank, S);
+  TankCtx t{S, tanks};
+  return load_from_grids(S, fill_tank, &t);
 }
+extern "C" int euler_load_half_tank(euler_sim* S) { return euler_load_half_tanks(S, 1); }
 
 // ------------------------------------------------------------------------------------------
 // multi-GPU plumbing

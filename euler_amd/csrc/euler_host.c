@@ -100,19 +100,29 @@ int euler_parse_scenario(const char* text, int32_t len, int32_t X, int32_t Y, in
   return EULER_OK;
 }
 
-int euler_half_tank_grids(int32_t X, int32_t Y, uint8_t* solid, uint8_t* source, uint8_t* sink, uint8_t* fluid) {
-  if (X < 6 || Y < 6) return EULER_EINVAL;
+/* `tanks` closed tanks on top of each other (1 = SURVEY 8d config 3): tank k takes the rows [k H, (k+1) H), H = Y / tanks,
+ * a solid ring one cell inside its border, fluid in its lower half; the rows where two tanks meet are solid as well, so that
+ * every tank is the single tank of an X x H grid (the weak-scaling workload: one tank per row slab). */
+int euler_half_tanks_grids(int32_t X, int32_t Y, int32_t tanks, uint8_t* solid, uint8_t* source, uint8_t* sink, uint8_t* fluid) {
+  if (tanks < 1 || Y % tanks) return EULER_EINVAL;
+  const int32_t H = Y / tanks;
+  if (X < 6 || H < 6) return EULER_EINVAL;
   const size_t C = (size_t)X * (size_t)Y;
   memset(solid, 0, C); memset(source, 0, C); memset(sink, 0, C); memset(fluid, 0, C);
-  for (int32_t y = 1; y <= Y - 2; ++y)
+  for (int32_t y = 1; y <= Y - 2; ++y) {
+    const int32_t ly = y % H;
     for (int32_t x = 1; x <= X - 2; ++x) {
       size_t i = (size_t)y * X + x;
-      if (y == 1 || y == Y - 2 || x == 1 || x == X - 2) solid[i] = 1;
-      else if (y < Y / 2) fluid[i] = 1;
+      if (ly == 0 || ly == H - 1 || ly == 1 || ly == H - 2 || x == 1 || x == X - 2) solid[i] = 1;
+      else if (ly < H / 2) fluid[i] = 1;
     }
+  }
   for (int32_t y = 0; y < Y; ++y) { sink[(size_t)y * X] = 1; sink[(size_t)y * X + X - 1] = 1; }
   for (int32_t x = 0; x < X; ++x) { sink[x] = 1; sink[(size_t)(Y - 1) * X + x] = 1; }
   return EULER_OK;
+}
+int euler_half_tank_grids(int32_t X, int32_t Y, uint8_t* solid, uint8_t* source, uint8_t* sink, uint8_t* fluid) {
+  return euler_half_tanks_grids(X, Y, 1, solid, source, sink, fluid);
 }
 
 /* Four jittered markers per fluid cell (main.c:255-266): columns outer, rows inner, quadrant
@@ -135,6 +145,37 @@ int euler_seed_markers(const uint8_t* fluid, int32_t X, int32_t Y, uint64_t* rng
       }
     }
   *n_markers = n;
+  return EULER_OK;
+}
+
+/* The same stream, keeping only the markers whose row floor(y) lies in [row_lo, row_hi) together with their index in the whole
+ * array (a row-slab handle: every rank walks the one sequential RNG stream, none stores the whole array).  Two passes by the
+ * caller: markers_xy == NULL counts (n_total, n_kept), the second call fills (the RNG state is only advanced by the caller's
+ * copy).  cap = room in markers_xy / keys. */
+int euler_seed_markers_rows(const uint8_t* fluid, int32_t X, int32_t Y, int32_t row_lo, int32_t row_hi, uint64_t* rng_state,
+                            float* markers_xy, uint32_t* keys, uint64_t cap, uint64_t* n_total, uint64_t* n_kept) {
+  if (!fluid || !rng_state || !n_total || !n_kept) return EULER_EINVAL;
+  uint64_t n = 0, kept = 0;
+  for (int32_t cx = 0; cx < X; ++cx)
+    for (int32_t cy = 0; cy < Y; ++cy) {
+      if (!fluid[(size_t)cy * X + cx]) continue;
+      for (int k = 0; k < 4; ++k) {
+        float jx = euler_rng_next_float(rng_state) / 2;
+        float mx = cx + (k < 2 ? 0 : 0.5f) + jx;
+        float jy = euler_rng_next_float(rng_state) / 2;
+        float my = cy + (k % 2 ? 0 : 0.5f) + jy;
+        const int32_t row = (int32_t)floorf(1.f * my);
+        if (row >= row_lo && row < row_hi) {
+          if (markers_xy) {
+            if (kept >= cap) return EULER_ENOMEM;
+            markers_xy[2 * kept] = 1.f * mx; markers_xy[2 * kept + 1] = 1.f * my; keys[kept] = (uint32_t)n;
+          }
+          ++kept;
+        }
+        ++n;
+      }
+    }
+  *n_total = n; *n_kept = kept;
   return EULER_OK;
 }
 

@@ -178,6 +178,9 @@ int  euler_abi_version(void);
 int euler_load_scenario_mem(euler_sim* sim, const char* text, int32_t len, int32_t upscale);
 int euler_load_scenario_file(euler_sim* sim, const char* path, int32_t upscale);
 int euler_load_half_tank(euler_sim* sim);   /* synthetic config 3: solid ring, fluid in y < Y/2, at rest */
+/* `tanks` such tanks on top of each other, each closed (solid where two meet): tank k is the single tank of an X x (Y / tanks) grid
+ * in rows [k Y / tanks, (k+1) Y / tanks).  The weak-scaling workload: one tank per row slab.  tanks = 1 is euler_load_half_tank. */
+int euler_load_half_tanks(euler_sim* sim, int32_t tanks);
 
 /* Host-only pieces of sim_init, usable without a GPU (parser / marker seeding parity tests).
  * Outputs are caller-owned; solid/source/sink/fluid are [Y][X] uint8, markers float2[4*X*Y]. */

@@ -57,7 +57,7 @@ def test_p2p_mailboxes_carry_the_iteration_exchanges(nproc, X, Y, workload, fram
         assert f["finite"], f
         if coupling == 1:
             assert f["cells_differing"] == 0 and f["markers_equal"] and f["substeps"][0] == f["substeps"][1], f
-            assert f["dp"] <= 1e-9 * max(f["pmax"], 1.0), f
+            assert f["dp"] <= 1e-8 * max(f["pmax"], 1.0), f
             assert f["du"] < 1e-6 and f["dv"] < 1e-6, f
             assert abs(f["iters"][0] - f["iters"][1]) <= 1, f
         solved += f["iters"][1] > 0
@@ -68,7 +68,7 @@ def test_p2p_mailboxes_carry_the_iteration_exchanges(nproc, X, Y, workload, fram
 @pytest.mark.parametrize("nproc,X,Y,workload,frames", [(2, 192, 256, "half_tank", 3), (3, 200, 330, "waterfall", 12), (2, 256, 256, "dam_break", 30)])
 def test_exact_coupling_matches_single_gpu(nproc, X, Y, workload, frames):
     """EULER_SLAB_EXACT: same preconditioner, same iterates; only the dot products are summed in a
-    different order (per-rank partials + all-reduce).  Tolerance: |dp| <= 1e-9 * max|p|, velocities
+    different order (per-rank partials + all-reduce).  Tolerance: |dp| <= 1e-8 * max|p|, velocities
     1e-6 absolute, identical cell grid, identical marker arrays, identical iteration counts."""
     d = run_workers(nproc, X, Y, workload, frames, 1, 29531)
     assert d["ranks_agree"] and d["calls"]["chain"] > 0 and d["calls"]["halo"] > 0
@@ -76,7 +76,7 @@ def test_exact_coupling_matches_single_gpu(nproc, X, Y, workload, frames):
     for f in d["frames"]:
         assert f["finite"] and f["cells_differing"] == 0 and f["markers_equal"], f
         assert f["substeps"][0] == f["substeps"][1]
-        assert f["dp"] <= 1e-9 * max(f["pmax"], 1.0), f
+        assert f["dp"] <= 1e-8 * max(f["pmax"], 1.0), f
         assert f["du"] < 1e-6 and f["dv"] < 1e-6, f
         assert abs(f["iters"][0] - f["iters"][1]) <= 1, f
         solved += f["iters"][1] > 0
@@ -130,7 +130,7 @@ def test_builtin_rccl_communicator(workload, X, Y, frames, p2p):
     for f in d["frames"]:
         assert f["cells_differing"] == 0 and f["markers_equal"], f
         assert f["substeps"][0] == f["substeps"][1]
-        assert f["dp"] <= 1e-9 * max(f["pmax"], 1.0), f
+        assert f["dp"] <= 1e-8 * max(f["pmax"], 1.0), f
         assert f["du"] < 1e-6 and f["dv"] < 1e-6, f
         assert abs(f["iters"][0] - f["iters"][1]) <= 1, f
         solved += f["iters"][1] > 0
@@ -148,7 +148,7 @@ def test_weak_scaling_workload_local_coupling_is_the_reference_preconditioner():
     for f in d["frames"]:
         assert f["finite"] and f["cells_differing"] == 0 and f["markers_equal"], f
         assert f["substeps"][0] == f["substeps"][1]
-        assert f["dp"] <= 1e-9 * max(f["pmax"], 1.0), f
+        assert f["dp"] <= 1e-8 * max(f["pmax"], 1.0), f
         assert f["du"] < 1e-6 and f["dv"] < 1e-6, f
         assert abs(f["iters"][0] - f["iters"][1]) <= 1, f
         solved += f["iters"][1] > 0
@@ -177,5 +177,6 @@ def test_bench_multi_rank_contract(scaling):
     assert d["cpu_baseline"] is None and d["vs_baseline"] is None          # the CPU leg runs at N = 1 only
     assert d["config"]["grid"] == ([256, 512] if scaling == "weak" else [256, 256])
     assert "peer-to-peer mailboxes" in d["config"]["parallelism"] and "2 row slabs" in d["config"]["parallelism"]
+    assert "EVERY stage decomposed" in d["config"]["parallelism"]        # true row slabs are the N > 1 default
     assert abs(d["value"] - d["config"]["grid"][0] * d["config"]["grid"][1] * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0

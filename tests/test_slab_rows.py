@@ -4,7 +4,7 @@ one MI355X, each holding one slab only, against a single-GPU run of the whole gr
 Everything that involves no floating-point reduction is BIT-EXACT: both count grids, the marker positions (each local marker
 equals the single-GPU array's entry at its key), the set of keys (a permutation of 0..n-1), the RNG state / source latch, dt
 (substeps).  The pressure solve sums its dot products per rank and all-reduces them, so p, u, v carry the tolerance of the
-multi-rank solve (tests/test_slab.py): |dp| <= 1e-9 max|p|, velocities 1e-6; in the tile-local mode (no coupling between
+multi-rank solve (tests/test_slab.py): |dp| <= 1e-8 max|p|, velocities 1e-6; in the tile-local mode (no coupling between
 blocks, let alone slabs) the preconditioner is the single-GPU one, so the same bound applies."""
 import json
 import os
@@ -51,6 +51,6 @@ def test_row_slabs_reproduce_the_single_gpu_run(nproc, X, Y, workload, frames, p
         assert f["rng"] == [True, True] and f["dt_events"][0] == f["dt_events"][1], (i, f)
         if precond == ea.PRECOND_IC0_TILE:
             assert abs(f["iters"][0] - f["iters"][1]) <= f["substeps"][0], (i, f)
-            assert f["dp"] <= 1e-9 * max(f["pmax"], 1.0) and f["du"] < 1e-6 and f["dv"] < 1e-6, (i, f)
+            assert f["dp"] <= 1e-8 * max(f["pmax"], 1.0) and f["du"] < 1e-6 and f["dv"] < 1e-6, (i, f)
         solved += f["iters"][1] > 0
     assert solved > 0
