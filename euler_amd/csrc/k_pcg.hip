@@ -312,10 +312,11 @@ __device__ __forceinline__ double ld_system(const double* p) {
 // twelve strided 8-byte loads (round 1) that is 11 instead of 19 memory instructions per pair, and the HBM traffic drops
 // from 1.28x to the algorithmic bytes.
 #define SA_THREADS 256
-#define SA_RUN 32
 struct SaPair { sw_d2 z, so; double ez0, es0, ez1, es1; };   // one pair-record of a lane + the out-of-band vertical neighbours of its two elements
 
-template <bool SLAB, bool PUPD = false>   // SLAB: several ranks, the neighbouring slabs' arrays are mapped (nbr); else nbr is ignored
+// SA_RUN pair-records per wave: 32 on large grids (the window's two extra pair loads per run cost 6 %), 8 on small ones (at 1024^2
+// runs of 32 leave 300 waves for 256 CUs: 30 us instead of 16)
+template <bool SLAB, bool PUPD, int SA_RUN>   // SLAB: several ranks, the neighbouring slabs' arrays are mapped (nbr); else nbr is ignored
 __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __restrict__ s_old, const double* __restrict__ z,
                                                              double* __restrict__ s_new, double* __restrict__ out,
                                                              const uint8_t* __restrict__ mask, SkewGeom g,
@@ -1559,9 +1560,12 @@ static int launch_apply_a_and_alpha(euler_sim* S, int force) {
   return EULER_OK;
 }
 
-static inline unsigned sa_blocks(const euler_sim* S) {   // one wave per run of SA_RUN pair-records, at most 2048 blocks (the partials)
-  const size_t runs = (size_t)(S->band_hi - S->band_lo) * ((S->geom.TS / 2 + SA_RUN - 1) / SA_RUN);
+static inline unsigned sa_blocks(const euler_sim* S, int run) {   // one wave per run of pair-records, at most 2048 blocks (the partials)
+  const size_t runs = (size_t)(S->band_hi - S->band_lo) * ((S->geom.TS / 2 + run - 1) / run);
   return eu_blocks(runs, SA_THREADS / 64, 2048);
+}
+static inline int sa_run(const euler_sim* S) {   // short runs while long ones would leave CUs without a wave
+  return (size_t)(S->band_hi - S->band_lo) * (S->geom.TS / 2 / 32) < 4096 ? 8 : 32;
 }
 // iterations >= 1 of a single-GPU solve: s' = z + beta s and A s' in one launch; returns with S->s = s' and A s' in S->q
 static int launch_search_apply_and_alpha(euler_sim* S) {
@@ -1575,21 +1579,21 @@ static int launch_search_apply_and_alpha(euler_sim* S) {
   SkewGeom gl = S->geom;
   gl.S = S->e_cnt;
   const bool pupd = tile_fused(S);   // tile-local mode: the previous iteration's p += alpha s rides along
+  const int run = sa_run(S);
+  const int fin = S->has_comm ? fin_or_comm(S, FIN_ALPHA) : (seq ? -1 : (int)FIN_ALPHA);
+  double* pp = pupd ? LOC(S->p) : (double*)nullptr;
+  double* sb = pupd ? S->s2 : (double*)nullptr;
+#define SA_LAUNCH(SLABF, PUPDF, RUNV)                                                                                                   \
+  LAUNCH(S, KC_APPLY_A, (k_search_apply<SLABF, PUPDF, RUNV>), dim3(sa_blocks(S, RUNV)), dim3(SA_THREADS), LOC(S->s), LOC(S->z), LOC(S->s2), \
+         LOC(S->q), LOC(S->cellmask), gl, S->partial, S->sc, 0, S->red_counter, fin, nbr, pp, sb)
   if (S->has_comm) {
-    if (pupd)
-      LAUNCH(S, KC_APPLY_A, (k_search_apply<true, true>), dim3(sa_blocks(S)), dim3(SA_THREADS), LOC(S->s), LOC(S->z), LOC(S->s2), LOC(S->q), LOC(S->cellmask), gl,
-             S->partial, S->sc, 0, S->red_counter, fin_or_comm(S, FIN_ALPHA), nbr, LOC(S->p), S->s2);
-    else
-      LAUNCH(S, KC_APPLY_A, (k_search_apply<true, false>), dim3(sa_blocks(S)), dim3(SA_THREADS), LOC(S->s), LOC(S->z), LOC(S->s2), LOC(S->q), LOC(S->cellmask), gl,
-             S->partial, S->sc, 0, S->red_counter, fin_or_comm(S, FIN_ALPHA), nbr, (double*)nullptr, (double*)nullptr);
+    if (pupd) { if (run == 8) SA_LAUNCH(true, true, 8); else SA_LAUNCH(true, true, 32); }
+    else { if (run == 8) SA_LAUNCH(true, false, 8); else SA_LAUNCH(true, false, 32); }
   } else {
-    if (pupd)
-      LAUNCH(S, KC_APPLY_A, (k_search_apply<false, true>), dim3(sa_blocks(S)), dim3(SA_THREADS), S->s, S->z, S->s2, S->q, S->cellmask, S->geom,
-             S->partial, S->sc, 0, S->red_counter, seq ? -1 : (int)FIN_ALPHA, nbr, S->p, S->s2);
-    else
-      LAUNCH(S, KC_APPLY_A, (k_search_apply<false, false>), dim3(sa_blocks(S)), dim3(SA_THREADS), S->s, S->z, S->s2, S->q, S->cellmask, S->geom,
-             S->partial, S->sc, 0, S->red_counter, seq ? -1 : (int)FIN_ALPHA, nbr, (double*)nullptr, (double*)nullptr);
+    if (pupd) { if (run == 8) SA_LAUNCH(false, true, 8); else SA_LAUNCH(false, true, 32); }
+    else { if (run == 8) SA_LAUNCH(false, false, 8); else SA_LAUNCH(false, false, 32); }
   }
+#undef SA_LAUNCH
   double* t = S->s; S->s = S->s2; S->s2 = t;
   if (seq)
     LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), S->q, S->s, S->cellmask, S->geom, S->sc, (int)FIN_ALPHA, 0);
