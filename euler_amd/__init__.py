@@ -274,7 +274,7 @@ class Simulation:
         cfg.precond_tile_records = tile_records  # PRECOND_IC0_TILE: records per tile, 8 / 16 / 32 (0 = default 16)
         if slab is not None:                 # (rank, nranks): row slabs for every stage, this process holds one slab only
             cfg.slab_rank, cfg.slab_nranks = slab
-        self.slab = slab if slab is not None and slab[1] > 1 else None
+        self.slab = slab if slab is not None and slab[1] >= 1 else None
         self.cfg = cfg
         self.X, self.Y = X, Y
         self.h = C.c_void_p()

@@ -221,7 +221,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   S->geom.S = (size_t)S->geom.nbands * S->geom.TS * 64;
   // row slabs: this handle holds the rows of its bands only (+ ghost rows); without slabs the window is the grid
   const int nbands = S->geom.nbands;
-  S->slab_on = cfg->slab_nranks > 1;
+  S->slab_on = cfg->slab_nranks >= 1;      // (1 rank: the same code path with nobody to exchange with - transport self-tests)
   if (S->slab_on) {
     if (cfg->slab_rank < 0 || cfg->slab_rank >= cfg->slab_nranks || cfg->slab_nranks > nbands) {
       eu_set_error("euler_create: slab rank %d of %d for %d bands of 64 rows", cfg->slab_rank, cfg->slab_nranks, nbands);

@@ -1,4 +1,4 @@
-// k_slab.hip — row slabs for EVERY stage of sim_step() (euler_config.slab_nranks > 1).
+// k_slab.hip — row slabs for EVERY stage of sim_step() (euler_config.slab_nranks >= 1).
 //
 // One process per GPU.  Rank g owns the rows of its 64-row bands, [row_lo, row_hi), of every field and the markers whose
 // floor(y) lies there; nothing of the rest of the grid exists on this GPU (per-rank memory ~ 1/G).  The stage kernels are

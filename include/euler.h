@@ -82,7 +82,7 @@ typedef struct euler_config {
   int32_t rainbow;         /* args_t.rainbow / g_rainbow_enabled (main.c:54,75,1020): carry the dye fields */
   int32_t precond_tile_records; /* EULER_PRECOND_IC0_TILE: records per tile, 8, 16 or 32 (0 = default 16); tile k of a band =
                                    records [k * W, (k + 1) * W) */
-  int32_t slab_rank, slab_nranks; /* slab_nranks > 1: ROW SLABS FOR EVERY STAGE.  This handle is rank slab_rank of a job of
+  int32_t slab_rank, slab_nranks; /* slab_nranks >= 1 (0 = off): ROW SLABS FOR EVERY STAGE.  This handle is rank slab_rank of a job of
                                    slab_nranks processes, one per GPU; it owns the rows of its 64-row bands (euler_slab_info) and
                                    allocates ONLY those rows (+ 1 ghost row below, 2 above) of every grid and only the markers inside
                                    them - per-rank memory ~ 1/slab_nranks.  Install a communicator of the same rank / size

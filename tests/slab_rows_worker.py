@@ -15,7 +15,7 @@ import torch.distributed as dist
 
 import euler_amd as ea
 from euler_amd import scenarios
-from euler_amd.slab import SLAB_LOCAL, TorchComm, attach_p2p
+from euler_amd.slab import SLAB_LOCAL, RcclComm, TorchComm, attach_p2p
 
 
 def load(sim, workload):
@@ -28,13 +28,20 @@ def load(sim, workload):
 
 def main():
     X, Y, workload, frames, precond = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
-    p2p = len(sys.argv) > 6 and sys.argv[6] == "p2p"
-    dist.init_process_group("gloo")
+    p2p = "p2p" in sys.argv[6:]
+    rccl = "rccl" in sys.argv[6:]       # one rank per GPU, the library's own RCCL communicator (1 rank on a 1-GPU box)
+    if rccl:
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        local = 0
+        dist.init_process_group("gloo")
+        torch.cuda.set_device(0)
     rank, world = dist.get_rank(), dist.get_world_size()
-    torch.cuda.set_device(0)
-    ref = load(ea.Simulation(X, Y, dot_mode=ea.DOT_TREE, precond=precond), workload)       # single GPU, the whole grid
-    sim = ea.Simulation(X, Y, dot_mode=ea.DOT_TREE, precond=precond, slab=(rank, world))   # one slab
-    comm = TorchComm(sim, SLAB_LOCAL)
+    ref = load(ea.Simulation(X, Y, device=local, dot_mode=ea.DOT_TREE, precond=precond), workload)       # single GPU, the whole grid
+    sim = ea.Simulation(X, Y, device=local, dot_mode=ea.DOT_TREE, precond=precond, slab=(rank, world))   # one slab
+    comm = RcclComm(sim, SLAB_LOCAL) if rccl else TorchComm(sim, SLAB_LOCAL)
     out = {"world": world, "frames": []}
     if p2p:
         out["p2p_ok"] = attach_p2p(sim)

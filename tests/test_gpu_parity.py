@@ -553,6 +553,100 @@ def test_full_size_4096_properties_without_an_oracle():
     sim.close()
 
 
+def _true_residual(sim):
+    """b - A p on the host from the cell-mask encoding of A (bit0 fluid, bits1-4 fluid at x+1, y+1, x-1, y-1, bits 5-7 a_diag)."""
+    p, b, m = sim.get(ea.F_PRESSURE), sim.get(ea.F_PCG_B), sim.get(ea.F_CELLMASK)
+    fl = (m & 1) != 0
+    ap = (m >> 5).astype(np.float64) * p
+    ap[:, :-1] -= np.where((m[:, :-1] & 2) != 0, p[:, 1:], 0.0)
+    ap[:-1, :] -= np.where((m[:-1, :] & 4) != 0, p[1:, :], 0.0)
+    ap[:, 1:] -= np.where((m[:, 1:] & 8) != 0, p[:, :-1], 0.0)
+    ap[1:, :] -= np.where((m[1:, :] & 16) != 0, p[:-1, :], 0.0)
+    return np.where(fl, b - ap, 0.0), fl
+
+
+@pytest.mark.parametrize("precond", [ea.PRECOND_IC0, ea.PRECOND_IC0_TILE])
+def test_full_size_8192_half_tank_properties(precond):
+    """BASELINE configs[2] at its full size (8192^2 half tank, 134 M markers), one substep = 100 PCG iterations, both
+    preconditioner modes, through the size-independent properties: the count grid is the histogram of the marker array
+    (checked on a 2048-row stripe to stay inside the test box's memory), the residual vector the solver carries IS b - A p
+    recomputed on the host (before the p >= 0 clamp can act: a tank at rest has positive pressures), p is 0 off the fluid,
+    velocities vanish on solid faces.  In the tile-local mode this also shows that p += alpha s riding one pass behind
+    (k_search_apply<.., PUPD>, k_finish_p) loses no update."""
+    N = 8192
+    sim = ea.Simulation(N, N, dot_mode=ea.DOT_TREE, precond=precond).load_half_tank()
+    dt = sim.timestep(0.1)
+    sim.substep(dt)
+    st = sim.stats()
+    assert st.last_pcg_iterations == 100
+    res, fl = _true_residual(sim)
+    r = sim.get(ea.F_PCG_R)
+    scale = np.abs(sim.get(ea.F_PCG_B)).max()
+    assert np.abs(np.where(fl, r, 0.0) - res).max() <= 1e-9 * scale
+    assert abs(np.abs(r[fl]).max() - st.last_residual) <= 1e-12 * scale
+    del res, r
+    p = sim.get(ea.F_PRESSURE)
+    assert (p[~fl] == 0).all() and (p >= 0).all()
+    del p
+    count, solid = sim.get(ea.F_COUNT), sim.get(ea.F_SOLID)
+    assert np.array_equal(fl, count > 0)
+    mk = sim.get(ea.F_MARKERS)
+    assert len(mk) == st.n_markers
+    cy = np.floor(mk[:, 1]).astype(np.int32)
+    sel = (cy >= 1024) & (cy < 3072)
+    cx = np.floor(mk[sel, 0]).astype(np.int64)
+    hist = np.bincount((cy[sel].astype(np.int64) - 1024) * N + cx, minlength=2048 * N).reshape(2048, N)
+    assert np.array_equal((hist & 255).astype(np.uint8), count[1024:3072])
+    del mk, cy, cx, hist, sel
+    u, v = sim.get(ea.F_U), sim.get(ea.F_V)
+    assert (u[:, :-1][(solid[:, :-1] | solid[:, 1:]) != 0] == 0).all() and (v[:-1, :][(solid[:-1, :] | solid[1:, :]) != 0] == 0).all()
+    sim.close()
+
+
+@pytest.mark.parametrize("precond", [ea.PRECOND_IC0, ea.PRECOND_IC0_TILE])
+def test_full_size_4096_waterfall_properties_with_sources_active(precond):
+    """BASELINE configs[4]'s grid and scenario (4096^2 waterfall: ~0.27 M source cells, a sink column), a few frames with the
+    sources running, both modes: every substep appends one marker per eligible source cell (the marker count grows by
+    their number), the count grid stays the histogram of the marker array, markers appended in the last substep lie
+    inside source cells, the RNG state moved, nothing is NaN, and the reported residual is the true one."""
+    N = 4096
+    sim = ea.Simulation(N, N, dot_mode=ea.DOT_TREE, precond=precond).load_text(scenarios_waterfall(), upscale=True)
+    source = sim.get(ea.F_SOURCE)
+    n_src = int((source != 0).sum())
+    assert n_src > 200000
+    st0 = sim.stats()
+    for _ in range(3):
+        sim.step()
+    st = sim.stats()
+    assert st.rng_state != st0.rng_state and not st.source_exhausted
+    assert st0.n_markers < st.n_markers <= st0.n_markers + st.total_substeps * n_src
+    mk = sim.get(ea.F_MARKERS)
+    assert len(mk) == st.n_markers and np.isfinite(mk).all()
+    cx, cy = np.floor(mk[:, 0]).astype(np.int64), np.floor(mk[:, 1]).astype(np.int64)
+    count = sim.get(ea.F_COUNT)
+    hist = np.bincount(cy * N + cx, minlength=N * N).reshape(N, N)
+    # The count grid is the histogram of the marker array EXCEPT for what the last update_fluid_sources did: it counts the new
+    # marker in its source cell (main.c:289-290) while x + randf() - float arithmetic at x ~ 4096, ulp 2^-11 - can round up to the
+    # next cell's edge.  So: same total, and every difference sits in a source cell or right next to one.
+    diff = hist.astype(np.int64) - count.astype(np.int64)
+    assert int(hist.sum()) == st.n_markers == int(count.astype(np.int64).sum())
+    near = source != 0
+    near[1:, :] |= source[:-1, :] != 0; near[:, 1:] |= source[:, :-1] != 0
+    assert (diff[~near] == 0).all() and np.abs(diff).max() <= 2 and (diff != 0).sum() < 1e-3 * n_src * st.last_substeps + 10
+    # the markers appended by the last substep's update_fluid_sources are the array's tail (no deletion happens after it)
+    tail = mk[-1000:]
+    assert near[np.floor(tail[:, 1]).astype(np.int64), np.floor(tail[:, 0]).astype(np.int64)].all()
+    del mk, cx, cy, hist
+    u, v = sim.get(ea.F_U), sim.get(ea.F_V)
+    assert np.isfinite(u).all() and np.isfinite(v).all()
+    sim.close()
+
+
+def scenarios_waterfall():
+    from euler_amd import scenarios
+    return scenarios.waterfall()
+
+
 def test_reported_residual_is_the_true_residual_2048():
     """b - A p recomputed on the host (A from the cell-mask encoding) against the solver's own recursively
     updated residual, 2048^2 half tank, after exactly one solve (pressure is clamped only after the solve, so

@@ -54,3 +54,25 @@ def test_row_slabs_reproduce_the_single_gpu_run(nproc, X, Y, workload, frames, p
             assert f["dp"] <= 1e-8 * max(f["pmax"], 1.0) and f["du"] < 1e-6 and f["dv"] < 1e-6, (i, f)
         solved += f["iters"][1] > 0
     assert solved > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,X,Y,frames,extra", [("waterfall", 200, 330, 30, ("rccl",)), ("dam_break", 256, 512, 36, ("rccl", "p2p"))])
+def test_row_slab_code_path_over_the_builtin_rccl_communicator(workload, X, Y, frames, extra):
+    """The slab substep with every exchange issued to RCCL from the C library (csrc/comm_rccl.hip) on the handle's stream: as
+    many ranks as the box has GPUs - ONE on the test box (RCCL refuses two ranks on a device), which still runs the whole
+    code path (ghost-row staging, all-gathers of the event / deletion blocks, all-reduces, migration buffers) through the
+    real transport; with more GPUs the same test is the multi-GPU parity check."""
+    import torch
+    n = max(1, min(torch.cuda.device_count(), 4))
+    d = run(n, X, Y, workload, frames, ea.PRECOND_IC0_TILE, 29591, extra)
+    assert d["world"] == n
+    solved = 0
+    for i, f in enumerate(d["frames"]):
+        assert f["substeps"][0] == f["substeps"][1], (i, f)
+        assert f["count_differ"] == 0 and f["prev_count_differ"] == 0, (i, f)
+        assert f["markers_at_keys"] and f["markers_in_rows"] and f["keys_are_a_permutation"], (i, f)
+        assert f["rng"] == [True, True] and f["dt_events"][0] == f["dt_events"][1], (i, f)
+        assert f["dp"] <= 1e-8 * max(f["pmax"], 1.0) and f["du"] < 1e-6 and f["dv"] < 1e-6, (i, f)
+        solved += f["iters"][1] > 0
+    assert solved > 0
