@@ -85,9 +85,11 @@ def parse_args():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N>1: weak = N x (N*gpus) grid, one tank per row slab (default; the driver's scaling run); strong = the "
                          "N x N grid of --size split into row slabs (BASELINE configs[3]: --size 16384 --scaling strong)")
-    ap.add_argument("--no-p2p", action="store_true",
-                    help="N>1: keep the per-iteration exchanges (scalar all-reduces, ghost rows) on the communicator instead of "
-                         "the peer-to-peer mailboxes of csrc/comm_p2p.hip")
+    ap.add_argument("--p2p", action="store_true",
+                    help="N>1: route the per-iteration PCG exchanges (scalar all-reduces, ghost rows of s) over the peer-to-peer IPC "
+                         "mailboxes of csrc/comm_p2p.hip instead of RCCL (the default, as the north star names it); falls back to RCCL on "
+                         "every rank if the mailboxes cannot be set up")
+    ap.add_argument("--no-p2p", action="store_true", help=argparse.SUPPRESS)   # (round 1's spelling of the default)
     ap.add_argument("--grid-y-mult", type=int, default=0,
                     help="diagnostics: run the N x (N*M) grid of an M-GPU weak-scaling job on the GPUs given")
     ap.add_argument("--force-slab", action="store_true",
@@ -468,8 +470,8 @@ def main():
                 args.comm = "torch"
         if args.comm == "torch":
             comm = TorchComm(sim, coupling)
-        p2p_on = (not args.no_p2p) and attach_p2p(sim)
-        if rank == 0 and not args.no_p2p and not p2p_on:
+        p2p_on = args.p2p and attach_p2p(sim)
+        if rank == 0 and args.p2p and not p2p_on:
             print("bench: peer-to-peer mailboxes unavailable (%s); exchanges stay on %s" % (sim._p2p_error, args.comm), file=sys.stderr)
     tiles = GY // N
     load_workload(sim, scenarios, args.workload, tiles)
@@ -617,7 +619,7 @@ def main():
                 cpu_obj = {"error": repr(e)}
 
     transports = (("peer-to-peer mailboxes (PCG scalars, ghost rows of s) + " if p2p_on else "")
-                  + ("RCCL from the C library" if args.comm == "rccl" else "torch.distributed callbacks"))
+                  + ("RCCL over xGMI, called from the C library on the kernels' stream" if args.comm == "rccl" else "torch.distributed callbacks"))
     pc_name = "tile-local IC(0): no coupling between slabs" if args.precond == "ic0_tile" else ("slab-local" if rows else args.slab) + " IC(0) coupling"
     parallelism = "1 GPU" if args.gpus == 1 and not sharded else (
         "%d independent replicas" % args.gpus if not sharded else

@@ -163,7 +163,7 @@ extern "C" void euler_destroy(euler_sim* S) {
   for (uint8_t* g : {S->solid, S->source, S->sink, S->count, S->prev_count}) if (g) (void)hipFree(g + wo);
   if (S->count32) (void)hipFree(S->count32 + wo);
   void* dev[] = {S->markers[0], S->markers[1], S->keys[0], S->keys[1], S->ms, S->evmask, S->ev_theta, S->ev_delta, S->sel_idx, S->act_idx,
-                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->halo_buf, S->band_ranges, S->partial2,
+                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->halo_buf, S->band_ranges, S->partial2, S->pair_buf,
                  S->rowmajor_tmp};
   for (void* p : dev) if (p) (void)hipFree(p);
   for (float* d : S->dye) if (d) (void)hipFree(d);
@@ -290,8 +290,9 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   S->red_blocks = (int)eu_blocks(S->e_cnt, EU_RED_ELEMS, 2048);
   DALLOC(S->partial, (size_t)S->red_blocks > 2048 ? (size_t)S->red_blocks : 2048);
   DALLOC(S->partial2, 2048);
+  DALLOC(S->pair_buf, 2 * 64);
   DALLOC(S->red_counter, 1);
-  DALLOC(S->halo_buf, (size_t)4 * S->X);
+  DALLOC(S->halo_buf, (size_t)8 * S->X);   // 4 buffers (send / recv, below / above) of up to two grid rows of doubles
   S->gran_stride = (S->geom.T - 63 + 7) / 8 * 8;   // hand-off columns [0, T - 63)
   DALLOC(S->granules, (size_t)S->geom.nbands * S->gran_stride * 2);
   DALLOC(S->ticket, 1);
@@ -346,12 +347,14 @@ static int upload_scenario(euler_sim* S, const uint8_t* solid, const uint8_t* so
   uint64_t rng = EULER_RNG_SEED, n = 0, n_loc = 0;
   int rc;
   if (S->slab_on) {
-    uint64_t probe = EULER_RNG_SEED;
-    rc = euler_seed_markers_rows(fluid, S->X, S->Y, S->row_lo, S->row_hi, &probe, nullptr, nullptr, 0, &n, &n_loc);
-    if (rc) return rc;
-    if (n_loc > S->max_markers) { eu_set_error("row slab %d holds %llu markers, more than its capacity %zu", S->cfg.slab_rank, (unsigned long long)n_loc, S->max_markers); return EULER_ENOMEM; }
-    try { mk.resize(2 * (size_t)n_loc + 2); keys.resize((size_t)n_loc + 1); } catch (...) { return EULER_ENOMEM; }
-    rc = euler_seed_markers_rows(fluid, S->X, S->Y, S->row_lo, S->row_hi, &rng, mk.data(), keys.data(), n_loc, &n, &n_loc);
+    // room: a cell's four markers land in its own row (or, when a jitter rounds up to the cell's edge, the next one)
+    uint64_t cells = 0;
+    for (int y = S->row_lo > 0 ? S->row_lo - 1 : 0; y < S->row_hi; ++y)
+      for (int x = 0; x < S->X; ++x) cells += fluid[(size_t)y * S->X + x] != 0;
+    const uint64_t room = 4 * cells;
+    if (room > S->max_markers) { eu_set_error("row slab %d holds up to %llu markers, more than its capacity %zu", S->cfg.slab_rank, (unsigned long long)room, S->max_markers); return EULER_ENOMEM; }
+    try { mk.resize(2 * (size_t)room + 2); keys.resize((size_t)room + 1); } catch (...) { return EULER_ENOMEM; }
+    rc = euler_seed_markers_rows(fluid, S->X, S->Y, S->row_lo, S->row_hi, &rng, mk.data(), keys.data(), room, &n, &n_loc);   // one walk over the stream
   } else {
     try { mk.resize(2 * 4 * C); } catch (...) { return EULER_ENOMEM; }
     rc = euler_seed_markers(fluid, S->X, S->Y, &rng, mk.data(), &n);

@@ -156,6 +156,7 @@ struct euler_sim {
   int4* band_ranges;      // per band: active block ranges of the forward / backward sweeps (per solve)
   int tile_w;             // EULER_PRECOND_IC0_TILE: records per tile (include/euler.h precond_tile_records)
   double* partial2;       // second set of reduction partials (k_precond_tile reduces max |r| and dot(z,r) at once)
+  double* pair_buf;       // [ranks][2]: every rank's {max |r|, dot(z,r)} of one iteration, exchanged by ONE all-gather (tile-local mode without mailboxes)
   double* rowmajor_tmp;   // lazily allocated C doubles for euler_get/set_field of skewed arrays
   PcgScalars* sc;
   PcgScalars* sc_host;    // pinned
@@ -338,6 +339,25 @@ __device__ __forceinline__ float eu_wave_maxf(float v) {
   for (int o = 32; o > 0; o >>= 1) { float w = __shfl_down(v, o, 64); v = w > v ? w : v; }
   return v;
 }
+
+// Markers are seeded four to a cell, consecutively (main.c:255-266), and mostly stay neighbours in the array: a lane that
+// opens a run of lanes binning into the same cell adds the run's length with ONE atomic (up to 4x fewer atomics, each a
+// 32-byte memory-side transaction in a column-ordered array: k_bin_markers at 8192^2: 5.1 ms with one atomic per marker).
+__device__ __forceinline__ void bin_aggregated(unsigned int* count32, bool live, size_t c) {
+  const unsigned int lo = (unsigned int)c, hi = (unsigned int)(c >> 32);
+  const int lane = threadIdx.x & 63;
+  const unsigned int plo = __shfl_up(lo, 1, 64), phi = __shfl_up(hi, 1, 64);
+  const bool plive = __shfl_up((int)live, 1, 64) != 0;
+  const bool head = live && (lane == 0 || !plive || plo != lo || phi != hi);     // first lane of a run of equal cells
+  const unsigned long long heads = __ballot(head), lives = __ballot(live);
+  if (head) {
+    // the run ends before the next head or the next dead lane
+    const unsigned long long above = lane == 63 ? 0ull : ((heads | ~lives) >> (lane + 1));
+    const int run = above ? __ffsll((long long)above) : 64 - lane;
+    atomicAdd(&count32[c], (unsigned int)run);
+  }
+}
+
 
 // ---- peer-to-peer mailboxes (comm_p2p.hip): self-validating 16-byte granules {lo32, tag, hi32, tag}, one
 // system-scope write-through store / system-scope load each - the band pipeline's hand-off form across GPUs

@@ -275,14 +275,16 @@ __global__ __launch_bounds__(256) void k_bin_markers(const float2* __restrict__ 
                                                      const uint8_t* __restrict__ sink, const uint8_t* __restrict__ solid,
                                                      unsigned int* count32, unsigned long long* __restrict__ delmask, int X) {
   const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  bool del = false;
+  bool del = false, live = false;
+  size_t c = 0;
   if (i < n) {
     const float2 p = m[i];
     const int x = (int)floorf(p.x / EU_H), y = (int)floorf(p.y / EU_H);
-    const size_t c = (size_t)y * X + x;
+    c = (size_t)y * X + x;
     del = (sink[c] | solid[c]) != 0;
-    if (!del) atomicAdd(&count32[c], 1u);
+    live = !del;
   }
+  bin_aggregated(count32, live, c);
   const unsigned long long b = __ballot(del);
   if ((threadIdx.x & 63) == 0 && (i >> 6) < ((n + 63) >> 6)) delmask[i >> 6] = b;
 }

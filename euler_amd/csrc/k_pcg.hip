@@ -1123,6 +1123,7 @@ struct TileArgs {
   PcgScalars* sc;
   int force;
   double alpha_arg;       // force: alpha of the r update (single building block, tests)
+  double* pair_slot;      // FIN_TO_COMM: where this rank's {max |r|, dot(z,r)} go (its slot of the all-gather buffer)
 };
 
 // fixed-shape reductions of a PT_THREADS block; result valid in thread 0
@@ -1264,7 +1265,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_precond_tile(TileArgs a) {
     if (a.fin_dot >= 0) vsum = p2p_allreduce_block<false>(a.sc, vsum);
   }
   if (threadIdx.x == 0) {
-    if (a.via == FIN_TO_COMM) { a.sc->comm_val = vmax; a.sc->comm_val2 = vsum; }   // the epilogues run after the host-driven all-reduces
+    if (a.via == FIN_TO_COMM) { a.pair_slot[0] = vmax; a.pair_slot[1] = vsum; }   // the epilogues run after the all-gather (k_pair_fold)
     else {
       if (a.rupd) pcg_scalar_step(a.sc, FIN_RNORM, vmax);
       if (a.fin_dot >= 0 && !(a.rupd && a.sc->done)) pcg_scalar_step(a.sc, a.fin_dot, vsum);
@@ -1484,9 +1485,14 @@ static int launch_dot(euler_sim* S, const double* a, const double* b, int fin_op
 
 // tile-local IC(0) in its production form: everything between two apply_a passes in one kernel (k_precond_tile)
 static inline bool tile_fused(const euler_sim* S) { return S->cfg.precond == EULER_PRECOND_IC0_TILE && S->cfg.sweep_mode != EULER_SWEEP_SIMPLE; }
-__global__ void k_scalar_epilogue2(PcgScalars* sc, int op, int force) {   // after the all-reduce of comm_val2
+// max |r| and dot(z,r) of all ranks after ONE exchange ("fuse the latter two into one ... message pair"): every rank
+// folds the gathered pairs in rank order - identical bits everywhere - and applies the two scalar epilogues
+__global__ void k_pair_fold(PcgScalars* sc, const double* __restrict__ pairs, int R, int rupd, int fin_dot, int force) {
   if (!force && pcg_idle(sc)) return;
-  pcg_scalar_step(sc, op, sc->comm_val2);
+  double vmax = 0.0, vsum = 0.0;
+  for (int r = 0; r < R; ++r) { vmax = pairs[2 * r] > vmax ? pairs[2 * r] : vmax; vsum += pairs[2 * r + 1]; }
+  if (rupd) pcg_scalar_step(sc, FIN_RNORM, vmax);
+  if (fin_dot >= 0 && !(rupd && sc->done)) pcg_scalar_step(sc, fin_dot, vsum);
 }
 static TileArgs make_tile_args(euler_sim* S, int force) {
   TileArgs a;
@@ -1495,6 +1501,7 @@ static TileArgs make_tile_args(euler_sim* S, int force) {
   a.rupd = 0; a.sweeps = 1; a.fin_dot = -1;
   a.via = S->has_comm ? (S->p2p_on ? (int)FIN_VIA_P2P : (int)FIN_TO_COMM) : 0;
   a.part_max = S->partial; a.part_dot = S->partial2; a.counter = S->red_counter; a.sc = S->sc; a.force = force; a.alpha_arg = 0.0;
+  a.pair_slot = S->pair_buf + 2 * (S->has_comm ? S->comm.rank : 0);
   return a;
 }
 static inline unsigned tile_blocks(const euler_sim* S) {
@@ -1522,15 +1529,32 @@ static int launch_precond_tile(euler_sim* S, int rupd, int sweeps, int fin_dot, 
   }
   if (seq && sweeps && fin_dot >= 0)   // the reference's row-major dot(z, r); a no-op once max |r| <= tol
     LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), S->z, S->r, S->cellmask, S->geom, S->sc, fin_dot, force);
-  if (a.via == FIN_TO_COMM) {          // no mailboxes: the two results travel through the communicator, the epilogues follow
-    if (rupd) {
-      COMM_CALL(S->comm.allreduce(S->comm.ctx, &S->sc->comm_val, 1, 1));
-      hipLaunchKernelGGL(k_scalar_epilogue, dim3(1), dim3(1), 0, S->stream, S->sc, (int)FIN_RNORM, force);
-    }
-    if (a.fin_dot >= 0) {
-      COMM_CALL(S->comm.allreduce(S->comm.ctx, &S->sc->comm_val2, 1, 0));
-      hipLaunchKernelGGL(k_scalar_epilogue2, dim3(1), dim3(1), 0, S->stream, S->sc, fin_dot, force);
-    }
+  if (a.via == FIN_TO_COMM) {          // no mailboxes: both results travel in ONE all-gather of 16 bytes per rank, then the epilogues
+    const int R = S->comm.nranks;
+    int64_t off[64], cnt[64];
+    for (int r = 0; r < R && r < 64; ++r) { off[r] = 16 * r; cnt[r] = 16; }
+    COMM_CALL(S->bulk.allgather(S->bulk.ctx, S->pair_buf, off, cnt));
+    hipLaunchKernelGGL(k_pair_fold, dim3(1), dim3(1), 0, S->stream, S->sc, S->pair_buf, R, rupd, a.fin_dot, force);
+  }
+  return EULER_OK;
+}
+
+// ghost rows of TWO skewed vectors in one exchange (z and s before the fused search + apply_a pass: the neighbouring
+// slabs' edge rows land in the adjacent bands' storage, where k_search_apply's lanes 0 / 63 look for them)
+static int comm_halo_two(euler_sim* S, double* a, double* b) {
+  if (S->p2p_on) { int rc = eu_p2p_halo_skewed(S, a); return rc ? rc : eu_p2p_halo_skewed(S, b); }
+  const int X = S->X, nbk = (X + 255) / 256;
+  double *send_lo = S->halo_buf, *send_hi = S->halo_buf + 2 * X, *recv_lo = S->halo_buf + 4 * X, *recv_hi = S->halo_buf + 6 * X;
+  const bool has_lo = S->band_lo > 0, has_hi = S->band_hi < S->geom.nbands;
+  double* arr[2] = {a, b};
+  for (int k = 0; k < 2; ++k) {
+    if (has_lo) hipLaunchKernelGGL(k_pack_row, dim3(nbk), dim3(256), 0, S->stream, arr[k], send_lo + k * X, S->geom, S->band_lo, 0);
+    if (has_hi) hipLaunchKernelGGL(k_pack_row, dim3(nbk), dim3(256), 0, S->stream, arr[k], send_hi + k * X, S->geom, S->band_hi - 1, 63);
+  }
+  COMM_CALL(S->comm.halo(S->comm.ctx, send_lo, send_hi, recv_lo, recv_hi, 2 * X));
+  for (int k = 0; k < 2; ++k) {
+    if (has_lo) hipLaunchKernelGGL(k_unpack_row, dim3(nbk), dim3(256), 0, S->stream, arr[k], recv_lo + k * X, S->geom, S->band_lo - 1, 63);
+    if (has_hi) hipLaunchKernelGGL(k_unpack_row, dim3(nbk), dim3(256), 0, S->stream, arr[k], recv_hi + k * X, S->geom, S->band_hi, 0);
   }
   return EULER_OK;
 }
@@ -1571,10 +1595,14 @@ static inline int sa_run(const euler_sim* S) {   // short runs while long ones w
 static int launch_search_apply_and_alpha(euler_sim* S) {
   const bool seq = S->cfg.dot_mode == EULER_DOT_SEQUENTIAL && !S->has_comm;
   SlabNeighbours nbr = {nullptr, nullptr, nullptr, nullptr, S->band_hi - S->band_lo};
-  if (S->has_comm) {   // the neighbouring slabs' z and s, addressed with this rank's offsets (the arrays are full-size everywhere)
+  const bool direct = S->has_comm && eu_p2p_has_neighbour_arrays(S);   // (opt-in) read the neighbouring slabs' z and s where they live
+  if (direct) {   // addressed with this rank's offsets (the arrays are full-size everywhere)
     eu_p2p_neighbour_arrays(S, &nbr.z_dn, &nbr.s_dn, &nbr.z_up, &nbr.s_up);
     if (nbr.z_dn) { nbr.z_dn += S->e_lo; nbr.s_dn += S->e_lo; }
     if (nbr.z_up) { nbr.z_up += S->e_lo; nbr.s_up += S->e_lo; }
+  } else if (S->has_comm) {   // the default: one exchange brings the neighbours' edge rows of z and s into the adjacent bands' storage
+    int rc = comm_halo_two(S, S->z, S->s);
+    if (rc) return rc;
   }
   SkewGeom gl = S->geom;
   gl.S = S->e_cnt;
@@ -1586,7 +1614,7 @@ static int launch_search_apply_and_alpha(euler_sim* S) {
 #define SA_LAUNCH(SLABF, PUPDF, RUNV)                                                                                                   \
   LAUNCH(S, KC_APPLY_A, (k_search_apply<SLABF, PUPDF, RUNV>), dim3(sa_blocks(S, RUNV)), dim3(SA_THREADS), LOC(S->s), LOC(S->z), LOC(S->s2), \
          LOC(S->q), LOC(S->cellmask), gl, S->partial, S->sc, 0, S->red_counter, fin, nbr, pp, sb)
-  if (S->has_comm) {
+  if (direct) {
     if (pupd) { if (run == 8) SA_LAUNCH(true, true, 8); else SA_LAUNCH(true, true, 32); }
     else { if (run == 8) SA_LAUNCH(true, false, 8); else SA_LAUNCH(true, false, 32); }
   } else {
@@ -1648,7 +1676,7 @@ int eu_launch_project(euler_sim* S, float dt) {
   }
   if (!tile && (rc = launch_dot(S, S->z, S->r, FIN_SIGMA_INIT, 0))) return rc;
   // ranks with their neighbours' z and s mapped run the fused kernel too (it reads across the slab boundary directly)
-  const bool fuse_search = !S->has_comm || eu_p2p_has_neighbour_arrays(S);
+  const bool fuse_search = true;   // every configuration runs the fused pass now (several ranks: ghost rows of z and s in front of it)
   if (fuse_search) HIPCHK(hipMemsetAsync(LOC(S->s2), 0, S->e_cnt * sizeof(double), S->stream));   // s' of non-fluid cells is never written
   HIPCHK(hipMemcpyAsync(S->sc_host, S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
   HIPCHK(hipStreamSynchronize(S->stream));

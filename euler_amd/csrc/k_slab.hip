@@ -274,21 +274,23 @@ __global__ __launch_bounds__(256) void k_bin_markers_slab(const float2* __restri
                                                           int row_lo, int row_hi, char* del_block) {
   const unsigned long long n = ms->n_loc;
   const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  bool rm = false;
+  bool rm = false, live = false;
+  size_t c = 0;
   if (i < n) {
     const float2 p = m[i];
     const int x = (int)floorf(p.x / EU_H), y = (int)floorf(p.y / EU_H);
     if (y < row_lo || y >= row_hi) rm = true;
     else {
-      const size_t c = (size_t)y * X + x;
+      c = (size_t)y * X + x;
       if ((sink[c] | solid[c]) != 0) {
         rm = true;
         const unsigned long long slot = atomicAdd(reinterpret_cast<unsigned long long*>(del_block), 1ull);
         if (slot < SL_DEL_CAP) reinterpret_cast<unsigned int*>(del_block + 8)[slot] = keys[i];
         else atomicExch(&ms->error, 18);
-      } else atomicAdd(&count32[c], 1u);
+      } else live = true;
     }
   }
+  bin_aggregated(count32, live, c);      // one atomic per run of lanes binning into the same cell
   const unsigned long long b = __ballot(rm);
   if ((threadIdx.x & 63) == 0 && (i >> 6) < mask_words) rmmask[i >> 6] = b;      // every word the launch covers: zero behind the last marker
 }

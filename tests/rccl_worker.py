@@ -85,6 +85,7 @@ def main():
             "dp": float(np.abs(sim.get(ea.F_PRESSURE) - pr).max()), "pmax": float(np.abs(pr).max()),
             "cells_differing": int(((sim.get(ea.F_COUNT) > 0) != (ref.get(ea.F_COUNT) > 0)).sum()),
             "markers_equal": bool(np.array_equal(sim.get(ea.F_MARKERS).view(np.uint32), ref.get(ea.F_MARKERS).view(np.uint32))),
+            "marker_diff": float(np.abs(sim.get(ea.F_MARKERS) - ref.get(ea.F_MARKERS)).max()) if sim.get(ea.F_MARKERS).shape == ref.get(ea.F_MARKERS).shape else 1e30,
             "iters": [sr.last_pcg_iterations, ss.last_pcg_iterations], "substeps": [sr.last_substeps, ss.last_substeps],
             "residual": [sr.last_residual, ss.last_residual]})
     out["calls"] = comm.counts

@@ -52,8 +52,10 @@ def main():
         dp = float(np.abs(sim.get(ea.F_PRESSURE) - ref.get(ea.F_PRESSURE)).max())
         pmax = float(np.abs(ref.get(ea.F_PRESSURE)).max())
         cells = int(((sim.get(ea.F_COUNT) > 0) != (ref.get(ea.F_COUNT) > 0)).sum())
-        same_markers = bool(np.array_equal(sim.get(ea.F_MARKERS).view(np.uint32), ref.get(ea.F_MARKERS).view(np.uint32)))
-        out["frames"].append({"du": du, "dv": dv, "dp": dp, "pmax": pmax, "cells_differing": cells, "markers_equal": same_markers,
+        ms_, mr_ = sim.get(ea.F_MARKERS), ref.get(ea.F_MARKERS)
+        same_markers = bool(np.array_equal(ms_.view(np.uint32), mr_.view(np.uint32)))
+        marker_diff = float(np.abs(ms_ - mr_).max()) if ms_.shape == mr_.shape and len(ms_) else (0.0 if ms_.shape == mr_.shape else 1e30)
+        out["frames"].append({"du": du, "dv": dv, "dp": dp, "pmax": pmax, "cells_differing": cells, "markers_equal": same_markers, "marker_diff": marker_diff,
                               "iters": [sr.last_pcg_iterations, ss.last_pcg_iterations], "substeps": [sr.last_substeps, ss.last_substeps],
                               "residual": [sr.last_residual, ss.last_residual],
                               "finite": bool(np.isfinite(sim.get(ea.F_U)).all() and np.isfinite(sim.get(ea.F_V)).all())})
