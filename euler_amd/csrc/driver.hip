@@ -170,7 +170,6 @@ extern "C" void euler_destroy(euler_sim* S) {
   // band-skewed arrays: shifted to global element indexing as well (skew_off), behind EU_SKEW_SLACK elements of slack
   const size_t so = S->shifted ? S->skew_off : 0, sl = S->shifted ? (size_t)EU_SKEW_SLACK : 0;
   for (double* d : {S->b, S->p, S->r, S->z, S->s, S->s2, S->q, S->precon}) if (d) (void)hipFree(d + so - sl);
-  if (S->krku) (void)hipFree(S->krku + 2 * so - 2 * sl);
   if (S->cellmask) (void)hipFree(S->cellmask + so - sl);
   const size_t fb_off = S->shifted ? (size_t)S->ab_lo * S->fb_stride * 64 : 0;
   if (S->fbits_fwd) (void)hipFree(S->fbits_fwd + fb_off);
@@ -279,7 +278,6 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   DALLOC(S->sel.block_sums, S->sel.capacity_blocks);
   // skewed arrays carry EU_SKEW_SLACK zeroed elements in front (the backward sweep prefetches below record 0)
   for (double** d : {&S->b, &S->p, &S->r, &S->z, &S->s, &S->s2, &S->q, &S->precon}) DALLOC(*d, SS + EU_SKEW_SLACK);
-  DALLOC(S->krku, 2 * (SS + EU_SKEW_SLACK));
   DALLOC(S->cellmask, SS + EU_SKEW_SLACK);
   S->fb_stride = 12 * (((S->geom.T + 7) / 8 + 11) / 12) + 4;   // whole groups of 3 and of 4 blocks + the blocks the prefetch runs ahead
   DALLOC(S->fbits_fwd, (size_t)(S->ab_hi - S->ab_lo) * S->fb_stride * 64);
@@ -303,7 +301,6 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   for (uint8_t** g : {&S->solid, &S->source, &S->sink, &S->count, &S->prev_count}) *g -= S->win_off;
   S->count32 -= S->win_off;
   for (double** d : {&S->b, &S->p, &S->r, &S->z, &S->s, &S->s2, &S->q, &S->precon}) *d += EU_SKEW_SLACK - S->skew_off;
-  S->krku += 2 * EU_SKEW_SLACK - 2 * S->skew_off;
   S->cellmask += EU_SKEW_SLACK - S->skew_off;
   S->fbits_fwd -= (size_t)S->ab_lo * S->fb_stride * 64; S->fbits_bwd -= (size_t)S->ab_lo * S->fb_stride * 64;
   S->shifted = 1;

@@ -149,7 +149,6 @@ struct euler_sim {
   SkewGeom geom;
   double *b, *p, *r, *z, *s, *q, *precon;
   double* s2;             // second search-direction array (k_search_apply ping-pongs s / s2)
-  double* krku;           // {a_i*precon, a_j*precon} of the backward solve, 16 B per skewed element (per solve)
   uint8_t* cellmask;
   unsigned int* fbits_fwd; unsigned int* fbits_bwd;   // fluid flags of the sweeps, 8 steps to a dword (k_pack_fbits)
   int fb_stride;          // words per band and lane

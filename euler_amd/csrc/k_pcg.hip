@@ -551,8 +551,6 @@ struct SweepArgs {
   double* pre;            // precon: in/out for SW_FACTOR, in otherwise
   const double* in;       // r (forward) / q (backward); unused for factor
   double* out;            // q (forward) / z (backward); unused for factor
-  sw_d2* krku;            // backward coefficients {a_i*precon, a_j*precon} (main.c:621-622) as one 16-byte stream:
-                          // written by the factor sweep once per solve, read by the backward sweep (one load, not two)
   unsigned long long* granules;   // [nbands][gran_stride][2] tagged hand-off of a band's edge row
   int gran_stride;
   // k_sweep_skew<OP, true> (exact coupling over the peer-to-peer mailboxes, comm_p2p.hip): the slab's first band takes
@@ -571,7 +569,37 @@ struct SweepArgs {
   int* error;
   unsigned long long* timeline;   // [nbands][8] {entry, first block ready, exit, blocks << 32 | stalled blocks, 4 development words} (euler_sweep_timeline)
   int tile_w;                     // k_sweep_simple only: > 0 = tile-local IC(0) with tiles of tile_w records (the cross-check of k_precond_tile)
+  // forward sweep, tree-dot mode, one rank: dot(z, r) of the preconditioner application this sweep starts, formed HERE as
+  // dot(q, q) - z = L^-T q and q = L^-1 r, so z.r = (L^-T q).(L q) = q.q exactly in real arithmetic (the backward solve applies
+  // the transpose of the forward solve's L: same precon, symmetric couplings), a sum of squares with no cancellation.  It
+  // replaces a launch that re-read z and r (17 B per cell); EULER_DOT_SEQUENTIAL keeps the reference's own dot(z, r).
+  int fin_qq;                     // scalar epilogue (FIN_SIGMA_INIT / FIN_BETA) or -1
+  double* qq_partial;             // [bands of the launch]
+  unsigned int* qq_counter;
+  PcgScalars* sc_w;
 };
+
+// one wave per band arrives with its partial; the last one folds all partials in band order (deterministic) and applies the epilogue
+__device__ __forceinline__ void sweep_qq_arrive(const SweepArgs& a, int ord, double lane_sum) {
+  const int lane = threadIdx.x & 63;
+  const double v = eu_wave_sum(lane_sum);
+  int last = 0;
+  if (lane == 0) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(&a.qq_partial[ord]), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last = __hip_atomic_fetch_add(a.qq_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)a.nb_local - 1;
+  }
+  last = __builtin_amdgcn_readfirstlane(last);
+  if (!last) return;
+  double t = 0.0;
+  for (int k = lane; k < a.nb_local; k += 64)
+    t += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&a.qq_partial[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  t = eu_wave_sum(t);
+  if (lane == 0) {
+    pcg_scalar_step(a.sc_w, a.fin_qq, t);
+    __hip_atomic_store(a.qq_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 
 template <int OP>
 __device__ __forceinline__ double sweep_cell(uint8_t m, double in, double pre_here, double own_val, double own_pre,
@@ -739,14 +767,17 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   // not poll.  The factor sweep always runs the full range (a stale precon is not a constant).
   constexpr bool RANGED = OP != SW_FACTOR;
   constexpr double CONST = OP == SW_FORWARD ? -0.0 : 0.0;
-  constexpr int BODY_HALF = OP == SW_BACKWARD ? 3 : 4;                  // blocks a range is a multiple of: half of the backward loop body (mid-body exit), the whole forward one
+  constexpr int BODY_HALF = 4;                                          // blocks a range is a multiple of: the loop body
   const int full_blocks = BODY_HALF * (((T + SW_BLK - 1) / SW_BLK + BODY_HALF - 1) / BODY_HALF);
   const int ncolblk = (X + SW_BLK - 1) / SW_BLK;
   int B0 = 0, B1 = full_blocks, win_lo = 0, win_hi = ncolblk;
   if (RANGED && a.ranges) {
     const int4 mine = a.ranges[band];
     B0 = BWD ? mine.z : mine.x; B1 = BWD ? mine.w : mine.y;
-    if (B0 >= B1) return;                              // no fluid in this band
+    if (B0 >= B1) {                                    // no fluid in this band
+      if (OP == SW_FORWARD && a.fin_qq >= 0 && role == 0) sweep_qq_arrive(a, ord, 0.0);
+      return;
+    }
     if (has_prev) {
       const int4 prv = a.ranges[BWD ? band + 1 : band - 1];
       const int pB0 = BWD ? prv.z : prv.x, pB1 = BWD ? prv.w : prv.y;
@@ -869,18 +900,15 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   const char* p_pre = reinterpret_cast<const char*>(a.pre + pair0);
   const char* p_msk = reinterpret_cast<const char*>(a.mask + pair0);      // factor: 2 mask bytes per pair
   const unsigned int* p_fb = (BWD ? a.fbits_bwd : a.fbits_fwd) + ((size_t)band * a.fb_stride + B0) * 64 + lane;
-  const char* p_kk = reinterpret_cast<const char*>(a.krku + pair0);       // backward only; 32 B per pair: the immediate offset (13 bits,
-  const char* p_kk2 = p_kk + 2 * 2 * PSTEP;                               // signed) reaches 2 pairs, hence a second base for pairs 2, 3
-  char* p_okk = reinterpret_cast<char*>(a.krku + pair0);                  // factor only
   char* p_out = reinterpret_cast<char*>((OP == SW_FACTOR ? a.pre : a.out) + pair0);   // results of the block being computed
 
   // Operand sets in rotation: while block k computes from one set, the records of the next DIST blocks are in
-  // flight into the others (HBM latency under load exceeds one block time).  Forward: four sets, distance 3;
-  // backward: three sets, distance 2 - a fourth would push it past the 256 architectural VGPRs, and hipcc
-  // would then park in-flight operands in AGPRs, i.e. copy them before they have arrived
-  // (tools/check_sweep_isa.py catches exactly that).  Factor: two sets, distance 1 (compiler-managed loads).
-  constexpr int DIST = OP == SW_FORWARD ? 3 : (OP == SW_BACKWARD ? 2 : 1);
-  struct Operands { sw_d2 in[4], pre[4], kk[4][2]; int m[4]; unsigned int fb; };    // per pair: .x = even record, .y = odd record
+  // flight into the others (HBM latency under load exceeds one block time).  Forward and backward: four sets, distance 3
+  // (round 1's backward sweep streamed its coefficients {a_i precon, a_j precon} as a third and fourth 16-byte load per pair
+  // and had registers for three sets only; round 2 rebuilds them from precon and two flag bits: 2 loads per pair like the
+  // forward sweep, 16 B per cell less traffic, and room for the fourth set).  Factor: two sets, distance 1 (compiler-managed loads).
+  constexpr int DIST = OP == SW_FACTOR ? 1 : 3;
+  struct Operands { sw_d2 in[4], pre[4]; int m[4]; unsigned int fb; };    // per pair: .x = even record, .y = odd record
   Operands opA, opB, opC, opD;
   // forward / backward: the record loads are issued BY HAND (inline asm) and retired by counted
   // s_waitcnt in front of each pair of steps.  hipcc's own wait insertion loses track of the issue order at
@@ -894,26 +922,23 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   //      whole fetch, and p stores: vmcnt((3 - p) * LOADS_PER_PAIR + DIST * LOADS + p) is exact for the first
   //      blocks and never waits for a younger fetch.
   // tools/check_sweep_isa.py proves on the generated ISA that no in-flight operand is ever touched.
-  constexpr int LOADS_PER_PAIR = OP == SW_BACKWARD ? 4 : 2;
+  constexpr int LOADS_PER_PAIR = 2;
   constexpr int LOADS = 4 * LOADS_PER_PAIR + 1;
   auto fetch_block = [&](Operands& o) {
     if constexpr (OP == SW_FACTOR) {
 #pragma unroll
       for (int pp = 0; pp < 4; ++pp) {
-        o.in[pp] = sw_d2{0.0, 0.0}; o.kk[pp][0] = sw_d2{0.0, 0.0}; o.kk[pp][1] = sw_d2{0.0, 0.0};
+        o.in[pp] = sw_d2{0.0, 0.0};
         o.pre[pp] = *reinterpret_cast<const sw_d2*>(p_pre + pp * PSTEP);
         o.m[pp] = (int)*reinterpret_cast<const unsigned short*>(p_msk + pp * (PSTEP / 8));   // the two cell-mask bytes of the pair
       }
       o.fb = 0u;
     } else {
-      // only the fluid flags, 8 steps to a dword - a byte load per step costs as much as the rest of the step
+      // only the flags, 8 steps to a dword (bits 0-7 fluid; backward: bits 8-15 fluid to the right, 16-23 fluid above) - a byte
+      // load per step costs as much as the rest of the step
       asm volatile("global_load_dword %0, %1, off" : "=&v"(o.fb) : "v"(p_fb) : "memory");
 #define SW_LOAD_PAIR(P)                                                                                                     \
       asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(o.in[P]) : "v"(p_in), "n"((P) * PSTEP));             \
-      if (OP == SW_BACKWARD) {                                                                                              \
-        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(o.kk[P][0]) : "v"((P) < 2 ? p_kk : p_kk2), "n"(((P) & 1) * 2 * PSTEP));      \
-        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(o.kk[P][1]) : "v"((P) < 2 ? p_kk : p_kk2), "n"(((P) & 1) * 2 * PSTEP + 16)); \
-      } else { o.kk[P][0] = sw_d2{0.0, 0.0}; o.kk[P][1] = sw_d2{0.0, 0.0}; }                                                \
       asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(o.pre[P]) : "v"(p_pre), "n"((P) * PSTEP));           \
       o.m[P] = 0;
       SW_LOAD_PAIR(0) SW_LOAD_PAIR(1) SW_LOAD_PAIR(2) SW_LOAD_PAIR(3)
@@ -921,7 +946,6 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
       asm volatile("" ::: "memory");
     }
     p_in += 4 * PSTEP; p_pre += 4 * PSTEP; p_msk += 4 * (PSTEP / 8); p_fb += 64;
-    p_kk += 4 * 2 * PSTEP; p_kk2 += 4 * 2 * PSTEP;
   };
 
   // wait (rarely) until the helper's counter reaches `target`
@@ -938,6 +962,7 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   // Steady state is straight-line code: a lone wave pays ~30 cycles for every taken branch, so the
   // per-band facts (is there a band before us / after us) select one of four instantiations of the loop.
   unsigned long long t_first = 0;
+  double qq = 0.0;           // forward: the lane's share of dot(q, q)
   auto sweep = [&](auto hp_c, auto pb_c) {
     constexpr bool HP = decltype(hp_c)::value;    // a band before us in sweep order: boundary values from the helper
     constexpr bool PB = decltype(pb_c)::value;    // a band after us: carry rows for the helper
@@ -951,6 +976,7 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
     //              is formed once and shifted; the precon of the lower row is never loaded
     //   backward : z (the coefficients belong to the consuming cell, main.c:620-622)
     double own = CONST;      // carried value of the previous column of this row
+    qq = 0.0;
     double out = CONST;      // carried value this lane hands to the next lane
     // boundary values of the block about to run / of the one after it (what the lane without a shift source
     // receives); two sets like the operands, so that the next block's are read half a block ahead
@@ -977,17 +1003,14 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
       // instructions later; measured 1.4-2x slower per step).
       __builtin_amdgcn_sched_barrier(0);
       double* ring = &sh.pub[(SW_BLK * blk) & (SW_RING - 1)][lane];
-      double prev_carry = CONST, prev_res = 0.0, prev_kr = 0.0, prev_ku = 0.0;
+      double prev_carry = CONST, prev_res = 0.0;
       auto step = [&](auto jc) {
         constexpr int j = decltype(jc)::value;
         constexpr int P = j >> 1;                         // the pair of records this step belongs to
         constexpr bool ODD = ((j & 1) != 0) != BWD;       // does the step use the pair's odd record (.y)?
         if constexpr (OP != SW_FACTOR && (j & 1) == 0) {  // retire this pair's records (see fetch_block)
           constexpr int N0 = (3 - P) * LOADS_PER_PAIR + DIST * LOADS + P, N = N0 < 63 ? N0 : 63;
-          if (OP == SW_BACKWARD)
-            asm volatile("s_waitcnt vmcnt(%5)" : "+v"(cur.in[P]), "+v"(cur.pre[P]), "+v"(cur.kk[P][0]), "+v"(cur.kk[P][1]), "+v"(cur.fb) : "n"(N) : "memory");
-          else
-            asm volatile("s_waitcnt vmcnt(%3)" : "+v"(cur.in[P]), "+v"(cur.pre[P]), "+v"(cur.fb) : "n"(N) : "memory");
+          asm volatile("s_waitcnt vmcnt(%3)" : "+v"(cur.in[P]), "+v"(cur.pre[P]), "+v"(cur.fb) : "n"(N) : "memory");
         }
         // the edge lane consumes logical column s = 8*blk + j of the previous band
         const double nbv = wave_shift_inject<CTRL>(out, be[j]);   // 2 DPP moves
@@ -1002,21 +1025,18 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
           if (e < 0.25 * aa) e = (aa != 0.0) ? aa : 1.0;
           res = (cm & CM_FLUID) ? 1.0 / sqrt(e) : cpre;      // non-fluid: the stale entry stays
           carry = res;
-          // the backward solve's coefficients of this cell, fixed for the whole solve (stored with the pair, below)
-          const double kr = ((cm & CM_RIGHT) ? -1.0 : 0.0) * res, ku = ((cm & CM_UP) ? -1.0 : 0.0) * res;
-          if (j & 1) {                       // factor runs forward: the odd step completes the pair {even, odd}
-            *reinterpret_cast<sw_d2*>(p_okk + P * 2 * PSTEP) = sw_d2{prev_kr, prev_ku};
-            *reinterpret_cast<sw_d2*>(p_okk + P * 2 * PSTEP + 16) = sw_d2{kr, ku};
-          }
-          prev_kr = kr; prev_ku = ku;
         } else if (OP == SW_FORWARD) {       // main.c:602-613: t = r - (-1*pre_l)*q_l - (-1*pre_b)*q_b
           const double t = cin - own - nbv;
           const double qv = t * cpre;
           res = __hiloint2double(__double2hiint(qv) & cm, __double2loint(qv) & cm);   // +0 on non-fluid cells
           carry = -1.0 * cpre * res;         // this cell's term in its right and upper neighbours
+          qq = __builtin_fma(res, res, qq);  // dot(q, q) = dot(z, r) (SweepArgs::fin_qq): one instruction, not part of the bit-exact arithmetic
         } else {                             // main.c:615-626: t = q - (a_i*pre)*z_r - (a_j*pre)*z_u
-          const sw_d2 kk = cur.kk[P][ODD ? 1 : 0];
-          const double t = cin - kk.x * own - kk.y * nbv;
+          // the cell's coefficients a_i precon, a_j precon (main.c:621-622), a = -1 / 0 by the fluid flag of the right / upper
+          // neighbour: (-1.0 or +0.0) * precon, the reference's product, from two sign-extended flag bits (off the carried chain)
+          const int fr = (int)(cur.fb << (23 - j)) >> 31, fu = (int)(cur.fb << (15 - j)) >> 31;
+          const double kr = __hiloint2double((int)0xBFF00000 & fr, 0) * cpre, ku = __hiloint2double((int)0xBFF00000 & fu, 0) * cpre;
+          const double t = cin - kr * own - ku * nbv;
           const double zv = t * cpre;
           res = __hiloint2double(__double2hiint(zv) & cm, __double2loint(zv) & cm);   // +0 on non-fluid cells
           carry = res;
@@ -1042,7 +1062,7 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
       }
       step(std::integral_constant<int, 6>()); step(std::integral_constant<int, 7>());
       __builtin_amdgcn_sched_barrier(0);
-      p_out += 4 * PSTEP; p_okk += 4 * 2 * PSTEP;
+      p_out += 4 * PSTEP;
       if (HP || PB) { SW_COMPILER_FENCE(); lds_put(&sh.comp_done, (unsigned int)(rel + 1)); }
       if (SW_TRACE_HANDOFF && blk == SW_TRACE_CB + 8 && lane == 0) a.timeline[(size_t)ord * 8 + 4] = wall_clock64();
       // block blk+1 overwrites the ring rows of block blk-7, which the groups up to block blk-6 read
@@ -1050,25 +1070,15 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
       if (PB && __builtin_expect(rel + 1 < NBLK && (int)(unsigned int)(prog >> 32) < rel - 5, 0)) await(&sh.pub_done, rel - 5);
     };
 
-    // At block k the wave computes from set k mod (DIST + 1) and refills the set of block k - 1.  Forward / factor: the
-    // body is 4 blocks and the ranges are multiples of 4; backward: 6 blocks (3 operand sets x 2 boundary sets) with
-    // an exit in the middle, ranges multiples of 3.  (A mid-body exit in the forward loop is correct too, but hipcc
-    // then merges the tails of the rare wait paths and tools/check_sweep_isa.py, which follows every branch both
-    // ways, can no longer prove it.)
-    for (int blk = B0; blk < B1; blk += (OP == SW_BACKWARD ? 6 : 4)) {
-      if (DIST == 3) {          // forward: four sets
+    // At block k the wave computes from set k mod (DIST + 1) and refills the set of block k - 1.  The body is 4 blocks
+    // and the ranges are multiples of 4 in every sweep.  (A mid-body exit is correct too, but hipcc then merges the tails of
+    // the rare wait paths and tools/check_sweep_isa.py, which follows every branch both ways, can no longer prove it.)
+    for (int blk = B0; blk < B1; blk += 4) {
+      if (DIST == 3) {          // forward, backward: four sets
         run_block(blk, opA, opD, beA, beB);
         run_block(blk + 1, opB, opA, beB, beA);
         run_block(blk + 2, opC, opB, beA, beB);
         run_block(blk + 3, opD, opC, beB, beA);
-      } else if (DIST == 2) {   // backward: three sets
-        run_block(blk, opA, opC, beA, beB);
-        run_block(blk + 1, opB, opA, beB, beA);
-        run_block(blk + 2, opC, opB, beA, beB);
-        if (blk + 3 >= B1) break;
-        run_block(blk + 3, opA, opC, beB, beA);
-        run_block(blk + 4, opB, opA, beA, beB);
-        run_block(blk + 5, opC, opB, beB, beA);
       } else {                  // factor: two sets
         run_block(blk, opA, opB, beA, beB);
         run_block(blk + 1, opB, opA, beB, beA);
@@ -1084,6 +1094,7 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   typedef std::integral_constant<bool, false> no_t;
   if (has_prev) { if (publish) sweep(yes_t(), yes_t()); else sweep(yes_t(), no_t()); }
   else          { if (publish) sweep(no_t(), yes_t()); else sweep(no_t(), no_t()); }
+  if (OP == SW_FORWARD && a.fin_qq >= 0) sweep_qq_arrive(a, ord, qq);
   if (lane == 0) {
     unsigned long long* tl = a.timeline + (size_t)ord * 8;
     tl[0] = t_entry; tl[1] = t_first; tl[2] = wall_clock64(); tl[3] = ((unsigned long long)(B1 - B0) << 32) | stalls;
@@ -1301,7 +1312,6 @@ static SweepArgs make_sweep_args(euler_sim* S, int op, int force) {
   a.mask = S->cellmask; a.fbits_fwd = S->fbits_fwd; a.fbits_bwd = S->fbits_bwd; a.fb_stride = S->fb_stride; a.pre = S->precon;
   a.in = op == SW_FORWARD ? S->r : S->q;
   a.out = op == SW_FORWARD ? S->q : S->z;
-  a.krku = reinterpret_cast<sw_d2*>(S->krku);
   a.granules = S->granules; a.gran_stride = S->gran_stride; a.ticket = S->ticket;
   a.xg_in = nullptr; a.xg_out = nullptr;
   a.ranges = S->band_ranges;
@@ -1310,12 +1320,13 @@ static SweepArgs make_sweep_args(euler_sim* S, int op, int force) {
   a.sc = S->sc; a.force = force; a.error = &S->ms->error;
   a.timeline = S->sweep_timeline;
   a.tile_w = S->cfg.precond == EULER_PRECOND_IC0_TILE ? S->tile_w : 0;
+  a.fin_qq = -1; a.qq_partial = S->partial; a.qq_counter = S->red_counter; a.sc_w = S->sc;
   return a;
 }
 
 // ---- active ranges of the bands (per solve) ---------------------------------------------------
 // For each 64-row band: the first / last record t = x + lane that holds a fluid cell, turned into
-// 32-step (forward) / 24-step (backward) aligned block ranges of the forward (step = t) and backward (step = T-1-t) sweeps; the
+// 32-step aligned block ranges of the forward (step = t) and backward (step = T-1-t) sweeps; the
 // upper end leaves at least one all-non-fluid step inside the range (see k_sweep_skew).  Computed
 // from the row-major count grid, which every rank holds in full.
 __global__ __launch_bounds__(1024) void k_band_ranges(const uint8_t* __restrict__ count, int X, int Y, int T, int4* __restrict__ ranges, int band0) {
@@ -1341,14 +1352,15 @@ __global__ __launch_bounds__(1024) void k_band_ranges(const uint8_t* __restrict_
     int4 r = make_int4(0, 0, 0, 0);
     if (s_hi >= 0) {
       const int f0 = s_lo / 32 * 32, f1 = (s_hi + 2 + 31) / 32 * 32;                       // forward steps [f0, f1): whole groups of 4 blocks
-      const int b0 = (T - 1 - s_hi) / 24 * 24, b1 = (T - 1 - s_lo + 2 + 23) / 24 * 24;     // backward steps [b0, b1)
+      const int b0 = (T - 1 - s_hi) / 32 * 32, b1 = (T - 1 - s_lo + 2 + 31) / 32 * 32;     // backward steps [b0, b1): whole groups of 4 blocks
       r = make_int4(f0 / 8, f1 / 8, b0 / 8, b1 / 8);
     }
     ranges[band] = r;
   }
 }
-// fluid flags of the sweeps, 8 steps to a dword: word (band, g, lane) bit j = the lane's cell in step 8g + j
-// of the forward sweep (record 8g + j) / of the backward sweep (record T-1 - 8g - j); 0 outside [0, T)
+// flags of the sweeps, 8 steps to a dword: word (band, g, lane) bit j = fluid flag of the lane's cell in step 8g + j
+// of the forward sweep (record 8g + j) / of the backward sweep (record T-1 - 8g - j); 0 outside [0, T).  The backward word
+// also carries the cell's CM_RIGHT (bits 8-15) and CM_UP (bits 16-23) flags
 __global__ __launch_bounds__(256) void k_pack_fbits(const uint8_t* __restrict__ cellmask, SkewGeom g, unsigned int* __restrict__ fwd,
                                                     unsigned int* __restrict__ bwd, int fb_stride, int band_lo, int nb_local) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -1361,7 +1373,12 @@ __global__ __launch_bounds__(256) void k_pack_fbits(const uint8_t* __restrict__ 
   for (int j = 0; j < 8; ++j) {
     const int tf = 8 * gi + j, tb = g.T - 1 - 8 * gi - j;
     if (tf < g.T && (base[(size_t)(tf & ~1) * 64 + (tf & 1)] & CM_FLUID)) wf |= 1u << j;
-    if (tb >= 0 && (base[(size_t)(tb & ~1) * 64 + (tb & 1)] & CM_FLUID)) wb |= 1u << j;
+    if (tb >= 0) {      // backward: the cell's fluid flag and the two neighbour flags its coefficients are built from
+      const unsigned int m = base[(size_t)(tb & ~1) * 64 + (tb & 1)];
+      if (m & CM_FLUID) wb |= 1u << j;
+      if (m & CM_RIGHT) wb |= 1u << (8 + j);
+      if (m & CM_UP) wb |= 1u << (16 + j);
+    }
   }
   const size_t o = ((size_t)band * fb_stride + gi) * 64 + lane;
   fwd[o] = wf; bwd[o] = wb;
@@ -1397,6 +1414,23 @@ __global__ __launch_bounds__(256) void k_unpack_row(double* __restrict__ skew, c
   if (x < g.X) skew[skew_index(g, x, band * 64 + lane)] = row[x];
 }
 
+// the edge rows of two skewed vectors <-> the neighbour buffers, one launch: blockIdx.y = 2 * side + vector.
+// PACK: lowest own row (band_lo, lane 0) -> lo buffer, highest (band_hi - 1, lane 63) -> hi buffer; else the rows that arrived
+// land in the adjacent bands' storage, (band_lo - 1, lane 63) and (band_hi, lane 0).
+template <bool PACK>
+__global__ __launch_bounds__(256) void k_halo_rows2(double* a, double* b, double* lo, double* hi, SkewGeom g, int band_lo, int band_hi,
+                                                    int has_lo, int has_hi) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= g.X) return;
+  const int side = blockIdx.y >> 1, vec = blockIdx.y & 1;
+  if (side == 0 ? !has_lo : !has_hi) return;
+  double* arr = vec ? b : a;
+  double* buf = (side ? hi : lo) + (size_t)vec * g.X;
+  const int y = PACK ? (side ? 64 * band_hi - 1 : 64 * band_lo) : (side ? 64 * band_hi : 64 * band_lo - 1);
+  double* e = arr + skew_index(g, x, y);
+  if (PACK) buf[x] = *e; else *e = buf[x];
+}
+
 #define COMM_CALL(expr) do { if ((expr) != 0) { eu_set_error("communicator callback failed: %s", #expr); return EULER_ECOMM; } } while (0)
 
 static int comm_allreduce_scalar(euler_sim* S, int is_max) {
@@ -1430,7 +1464,7 @@ static int comm_halo_s(euler_sim* S) {
 }
 
 template <int OP>
-static int launch_sweep(euler_sim* S, int cls, int force) {
+static int launch_sweep(euler_sim* S, int cls, int force, int fin_qq = -1) {
   if (S->cfg.sweep_mode != EULER_SWEEP_SIMPLE) {
     constexpr bool BWD = OP == SW_BACKWARD;
     const int nb = S->geom.nbands, nbl = S->band_hi - S->band_lo;
@@ -1452,6 +1486,7 @@ static int launch_sweep(euler_sim* S, int cls, int force) {
     if (chain && g_first > 0)   // the edge row of the band before mine arrives from the previous slab
       COMM_CALL(S->comm.chain(S->comm.ctx, S->granules + (size_t)(g_first - 1) * S->gran_stride * 2, row_bytes, prev_rank, r));
     SweepArgs a = make_sweep_args(S, OP, force);
+    a.fin_qq = fin_qq;
     LAUNCH(S, cls, k_sweep_skew<OP>, dim3(nbl), dim3(192), a);
     S->ticket_base += (unsigned)nbl;
     if (chain && g_last + 1 < nb)
@@ -1545,29 +1580,29 @@ static int comm_halo_two(euler_sim* S, double* a, double* b) {
   if (S->p2p_on) { int rc = eu_p2p_halo_skewed(S, a); return rc ? rc : eu_p2p_halo_skewed(S, b); }
   const int X = S->X, nbk = (X + 255) / 256;
   double *send_lo = S->halo_buf, *send_hi = S->halo_buf + 2 * X, *recv_lo = S->halo_buf + 4 * X, *recv_hi = S->halo_buf + 6 * X;
-  const bool has_lo = S->band_lo > 0, has_hi = S->band_hi < S->geom.nbands;
-  double* arr[2] = {a, b};
-  for (int k = 0; k < 2; ++k) {
-    if (has_lo) hipLaunchKernelGGL(k_pack_row, dim3(nbk), dim3(256), 0, S->stream, arr[k], send_lo + k * X, S->geom, S->band_lo, 0);
-    if (has_hi) hipLaunchKernelGGL(k_pack_row, dim3(nbk), dim3(256), 0, S->stream, arr[k], send_hi + k * X, S->geom, S->band_hi - 1, 63);
-  }
+  const int has_lo = S->band_lo > 0, has_hi = S->band_hi < S->geom.nbands;
+  // one launch packs the four rows (2 vectors x lowest / highest own row), one unpacks the four that arrived
+  hipLaunchKernelGGL(k_halo_rows2<true>, dim3(nbk, 4), dim3(256), 0, S->stream, a, b, send_lo, send_hi, S->geom, S->band_lo, S->band_hi, has_lo, has_hi);
   COMM_CALL(S->comm.halo(S->comm.ctx, send_lo, send_hi, recv_lo, recv_hi, 2 * X));
-  for (int k = 0; k < 2; ++k) {
-    if (has_lo) hipLaunchKernelGGL(k_unpack_row, dim3(nbk), dim3(256), 0, S->stream, arr[k], recv_lo + k * X, S->geom, S->band_lo - 1, 63);
-    if (has_hi) hipLaunchKernelGGL(k_unpack_row, dim3(nbk), dim3(256), 0, S->stream, arr[k], recv_hi + k * X, S->geom, S->band_hi, 0);
-  }
+  hipLaunchKernelGGL(k_halo_rows2<false>, dim3(nbk, 4), dim3(256), 0, S->stream, a, b, recv_lo, recv_hi, S->geom, S->band_lo, S->band_hi, has_lo, has_hi);
   return EULER_OK;
 }
 
-static int launch_precondition(euler_sim* S, int force) {   // z = M^-1 r
+// dot(z, r) rides in the forward sweep as dot(q, q) (SweepArgs::fin_qq): one rank, tree-dot mode, the band schedule
+static inline bool dot_rides_in_sweep(const euler_sim* S) {
+  return S->cfg.precond == EULER_PRECOND_IC0 && S->cfg.sweep_mode != EULER_SWEEP_SIMPLE && !S->has_comm && S->cfg.dot_mode != EULER_DOT_SEQUENTIAL;
+}
+static int launch_precondition(euler_sim* S, int force, int fin_dot = -1) {   // z = M^-1 r [and the scalar epilogue of dot(z, r)]
   if (S->cfg.precond == EULER_PRECOND_JACOBI) {
     LAUNCH(S, KC_JACOBI, k_jacobi, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->r), LOC(S->z), LOC(S->cellmask),
            S->e_cnt, S->sc, force);
-    return EULER_OK;
+    return fin_dot >= 0 ? launch_dot(S, S->z, S->r, fin_dot, force) : EULER_OK;
   }
-  int rc = launch_sweep<SW_FORWARD>(S, KC_FORWARD_SOLVE, force);
+  const bool ride = fin_dot >= 0 && dot_rides_in_sweep(S);
+  int rc = launch_sweep<SW_FORWARD>(S, KC_FORWARD_SOLVE, force, ride ? fin_dot : -1);
   if (rc) return rc;
-  return launch_sweep<SW_BACKWARD>(S, KC_BACKWARD_SOLVE, force);
+  if ((rc = launch_sweep<SW_BACKWARD>(S, KC_BACKWARD_SOLVE, force))) return rc;
+  return fin_dot >= 0 && !ride ? launch_dot(S, S->z, S->r, fin_dot, force) : EULER_OK;
 }
 
 static int launch_apply_a_and_alpha(euler_sim* S, int force) {
@@ -1666,7 +1701,7 @@ int eu_launch_project(euler_sim* S, float dt) {
     if ((rc = launch_precond_tile(S, 0, 1, FIN_SIGMA_INIT, 0, 0.0))) return rc;
   } else {
   if (S->cfg.precond != EULER_PRECOND_JACOBI && (rc = launch_sweep<SW_FACTOR>(S, KC_PRECON_FACTOR, 0))) return rc;   // once per solve
-  if ((rc = launch_precondition(S, 0))) return rc;
+  if ((rc = launch_precondition(S, 0, FIN_SIGMA_INIT))) return rc;
   }
   LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<true>, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->s), LOC(S->z),
          LOC(S->cellmask), S->e_cnt, S->sc, 0, 0.0);
@@ -1674,7 +1709,6 @@ int eu_launch_project(euler_sim* S, float dt) {
     const int y0 = S->band_lo > 0 ? 64 * S->band_lo : -1, y1 = S->band_hi < S->geom.nbands ? 64 * S->band_hi - 1 : -1;
     LAUNCH(S, KC_UPDATE_SEARCH, k_publish_edge_rows, dim3((S->X + 255) / 256, 2), dim3(256), S->s, S->geom, y0, y1, S->sc);
   }
-  if (!tile && (rc = launch_dot(S, S->z, S->r, FIN_SIGMA_INIT, 0))) return rc;
   // ranks with their neighbours' z and s mapped run the fused kernel too (it reads across the slab boundary directly)
   const bool fuse_search = true;   // every configuration runs the fused pass now (several ranks: ghost rows of z and s in front of it)
   if (fuse_search) HIPCHK(hipMemsetAsync(LOC(S->s2), 0, S->e_cnt * sizeof(double), S->stream));   // s' of non-fluid cells is never written
@@ -1709,8 +1743,7 @@ int eu_launch_project(euler_sim* S, float dt) {
         // these belong to iteration `it` but only run if it did not converge: tag them it+1 so that
         // they count as active only when the device went on to iteration it+1
         S->prof_iter = it + 1;
-        if ((rc = launch_precondition(S, 0))) return rc;
-        if ((rc = launch_dot(S, S->z, S->r, FIN_BETA, 0))) return rc;
+        if ((rc = launch_precondition(S, 0, FIN_BETA))) return rc;
         if (!fuse_search)   // (otherwise fused into the next iteration's apply_a)
           LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<false>, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->s),
                  LOC(S->z), LOC(S->cellmask), S->e_cnt, S->sc, 0, 0.0);
