@@ -478,14 +478,12 @@ __global__ __launch_bounds__(RED_THREADS) void k_inf_norm(const double* __restri
 }
 
 // s = z + beta s (update_search, main.c:669-677); with COPY: s = z (the memcpy at main.c:746)
-// PUPD (tile-local mode without the fused k_search_apply): p += alpha s_old rides along (see k_search_apply)
-template <bool COPY, bool PUPD = false>
+template <bool COPY>
 __global__ __launch_bounds__(256) void k_update_search(double* __restrict__ s, const double* __restrict__ z,
                                                        const uint8_t* __restrict__ mask, size_t S, const PcgScalars* sc,
-                                                       int force, double beta_arg, double* __restrict__ p = nullptr) {
+                                                       int force, double beta_arg) {
   if (!force && pcg_idle(sc)) return;
   const double beta = force ? beta_arg : sc->beta;
-  const double alpha_prev = sc->alpha;
   for (size_t i = 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x); i < S; i += 2 * (size_t)gridDim.x * blockDim.x) {
     const sw_d2 zv = *reinterpret_cast<const sw_d2*>(z + i);
     if (COPY) { *reinterpret_cast<sw_d2*>(s + i) = zv; continue; }
@@ -493,12 +491,6 @@ __global__ __launch_bounds__(256) void k_update_search(double* __restrict__ s, c
     const bool f0 = (mm & CM_FLUID) != 0, f1 = ((mm >> 8) & CM_FLUID) != 0;
     if (!(f0 | f1)) continue;
     sw_d2 sv = *reinterpret_cast<const sw_d2*>(s + i);
-    if (PUPD) {
-      sw_d2 pv = *reinterpret_cast<const sw_d2*>(p + i);
-      if (f0) pv.x = pv.x + sv.x * alpha_prev;
-      if (f1) pv.y = pv.y + sv.y * alpha_prev;
-      *reinterpret_cast<sw_d2*>(p + i) = pv;
-    }
     if (f0) sv.x = zv.x + beta * sv.x;
     if (f1) sv.y = zv.y + beta * sv.y;
     *reinterpret_cast<sw_d2*>(s + i) = sv;      // a non-fluid partner is written back unchanged
@@ -1710,8 +1702,9 @@ int eu_launch_project(euler_sim* S, float dt) {
     LAUNCH(S, KC_UPDATE_SEARCH, k_publish_edge_rows, dim3((S->X + 255) / 256, 2), dim3(256), S->s, S->geom, y0, y1, S->sc);
   }
   // ranks with their neighbours' z and s mapped run the fused kernel too (it reads across the slab boundary directly)
-  const bool fuse_search = true;   // every configuration runs the fused pass now (several ranks: ghost rows of z and s in front of it)
-  if (fuse_search) HIPCHK(hipMemsetAsync(LOC(S->s2), 0, S->e_cnt * sizeof(double), S->stream));   // s' of non-fluid cells is never written
+  // update_search of iteration k rides along with apply_a of iteration k + 1 in every configuration (several ranks: the ghost
+  // rows of z and s are exchanged in front of it)
+  HIPCHK(hipMemsetAsync(LOC(S->s2), 0, S->e_cnt * sizeof(double), S->stream));   // s' of non-fluid cells is never written
   HIPCHK(hipMemcpyAsync(S->sc_host, S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
   HIPCHK(hipStreamSynchronize(S->stream));
   const int poll = S->cfg.pcg_poll_interval > 0 ? S->cfg.pcg_poll_interval : 8;
@@ -1722,18 +1715,13 @@ int eu_launch_project(euler_sim* S, float dt) {
     const int chunk_end = it + poll < max_it ? it + poll : max_it;
     for (; it < chunk_end; ++it) {
       S->prof_iter = it;
-      const bool fused = it > 0 && fuse_search;   // update_search of iteration it-1 rides along with this apply_a (A s' lands in q)
+      const bool fused = it > 0;   // update_search of iteration it-1 rides along with this apply_a (A s' lands in q)
       if ((rc = fused ? launch_search_apply_and_alpha(S) : launch_apply_a_and_alpha(S, 0))) return rc;
       if (tile) {
         // r -= alpha A s, max |r| (sets `done`), z = M^-1 r, beta = dot(z, r) / sigma: one pass; on the last iteration of the
         // budget only r and its norm (main.c:760-765 would be computed and never consumed)
         S->prof_iter = it;
         if ((rc = launch_precond_tile(S, 1, it + 1 < max_it, FIN_BETA, 0, 0.0))) return rc;
-        if (it + 1 < max_it && !fuse_search) {   // s = z + beta s with the pending p += alpha s (else both ride along with the next apply_a)
-          S->prof_iter = it + 1;
-          LAUNCH(S, KC_UPDATE_SEARCH, (k_update_search<false, true>), dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->s),
-                 LOC(S->z), LOC(S->cellmask), S->e_cnt, S->sc, 0, 0.0, LOC(S->p));
-        }
         continue;
       }
       LAUNCH(S, KC_UPDATE_PR, k_update_pr, dim3(loc_red_blocks(S)), dim3(RED_THREADS), LOC(S->p), LOC(S->r), LOC(S->s),
@@ -1744,9 +1732,6 @@ int eu_launch_project(euler_sim* S, float dt) {
         // they count as active only when the device went on to iteration it+1
         S->prof_iter = it + 1;
         if ((rc = launch_precondition(S, 0, FIN_BETA))) return rc;
-        if (!fuse_search)   // (otherwise fused into the next iteration's apply_a)
-          LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<false>, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->s),
-                 LOC(S->z), LOC(S->cellmask), S->e_cnt, S->sc, 0, 0.0);
       }
     }
     if (it < max_it) {   // poll the device-side convergence flag (identical on every rank)

@@ -9,7 +9,7 @@ def _canvas(w, h):
 
 
 def _text(rows):
-    return "\n".join("".join(r).rstrip(" ") if False else "".join(r) for r in rows) + "\n"
+    return "\n".join("".join(r) for r in rows) + "\n"
 
 
 def dam_break():
@@ -62,6 +62,4 @@ def stacked(text, copies):
         text += "\n"
     return text * max(1, int(copies))
 
-
-def half_tank_note():
-    return "config 3 (half-filled tank) is generated on the grid directly: euler_load_half_tank()"
+# (config 3, the half-filled tank, is generated on the grid directly: euler_load_half_tank / euler_load_half_tanks)
