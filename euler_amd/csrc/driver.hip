@@ -163,7 +163,7 @@ extern "C" void euler_destroy(euler_sim* S) {
   for (uint8_t* g : {S->solid, S->source, S->sink, S->count, S->prev_count}) if (g) (void)hipFree(g + wo);
   if (S->count32) (void)hipFree(S->count32 + wo);
   void* dev[] = {S->markers[0], S->markers[1], S->keys[0], S->keys[1], S->ms, S->evmask, S->ev_theta, S->ev_delta, S->sel_idx, S->act_idx,
-                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->halo_buf, S->band_ranges, S->partial2, S->pair_buf,
+                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->halo_buf, S->band_ranges, S->partial2, S->pair_buf, S->rng_jump,
                  S->rowmajor_tmp};
   for (void* p : dev) if (p) (void)hipFree(p);
   for (float* d : S->dye) if (d) (void)hipFree(d);
@@ -289,6 +289,22 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   DALLOC(S->partial, (size_t)S->red_blocks > 2048 ? (size_t)S->red_blocks : 2048);
   DALLOC(S->partial2, 2048);
   DALLOC(S->pair_buf, 2 * 64);
+  {   // xorshift64* jump-ahead: M^(2^i) as the images of the 64 basis vectors, i < EU_RNG_JUMPS (euler_dev.h)
+    RngJump* J = (RngJump*)malloc(sizeof(RngJump));
+    if (!J) { euler_destroy(S); return EULER_ENOMEM; }
+    auto step = [](unsigned long long st) { st ^= st >> 12; st ^= st << 25; st ^= st >> 27; return st; };
+    for (int b = 0; b < 64; ++b) J->col[0][b] = step(1ull << b);
+    for (int i = 1; i < EU_RNG_JUMPS; ++i)
+      for (int b = 0; b < 64; ++b) {       // M^(2^i) e_b = M^(2^(i-1)) (M^(2^(i-1)) e_b)
+        unsigned long long x = J->col[i - 1][b], y = 0;
+        for (int k = 0; k < 64; ++k) if ((x >> k) & 1) y ^= J->col[i - 1][k];
+        J->col[i][b] = y;
+      }
+    int rc = dalloc(&S->rng_jump, 1);
+    if (!rc && hipMemcpy(S->rng_jump, J, sizeof(RngJump), hipMemcpyHostToDevice) != hipSuccess) rc = EULER_EHIP;
+    free(J);
+    if (rc) { euler_destroy(S); return rc; }
+  }
   DALLOC(S->red_counter, 1);
   DALLOC(S->halo_buf, (size_t)8 * S->X);   // 4 buffers (send / recv, below / above) of up to two grid rows of doubles
   S->gran_stride = (S->geom.T - 63 + 7) / 8 * 8;   // hand-off columns [0, T - 63)

@@ -76,6 +76,7 @@ struct MarkerState {
   unsigned int n_del_glob;    // markers deleted on all ranks together in this refresh
   unsigned int n_recv;        // markers received from the neighbouring slabs in this substep
   unsigned int src_k_lo;      // sources: eligible cells on lower ranks (= this rank's first index into the substep's append order)
+  unsigned long long rng0;    // sources: the generator's state at the start of the substep's draws (the parallel draw kernel jumps from it)
 };
 
 // Band-skewed layout of the solver's private arrays (k_pcg.hip header): element (x,y) lives at
@@ -155,6 +156,7 @@ struct euler_sim {
   int4* band_ranges;      // per band: active block ranges of the forward / backward sweeps (per solve)
   int tile_w;             // EULER_PRECOND_IC0_TILE: records per tile (include/euler.h precond_tile_records)
   double* partial2;       // second set of reduction partials (k_precond_tile reduces max |r| and dot(z,r) at once)
+  struct RngJump* rng_jump;   // xorshift64* jump-ahead matrices (device)
   double* pair_buf;       // [ranks][2]: every rank's {max |r|, dot(z,r)} of one iteration, exchanged by ONE all-gather (tile-local mode without mailboxes)
   double* rowmajor_tmp;   // lazily allocated C doubles for euler_get/set_field of skewed arrays
   PcgScalars* sc;
@@ -320,6 +322,31 @@ __device__ __forceinline__ float eu_interp(const GridRef& g, const float* __rest
   const float lv = eu_lerp(q00, q10, lf), rv = eu_lerp(q01, q11, rf);
   const float hf = eu_frac(fx, v00 | v10, v01 | v11);
   return eu_lerp(lv, rv, hf);
+}
+
+// xorshift64* (misc/rng.c:5-20) jump-ahead.  The state update x ^= x >> 12; x ^= x << 25; x ^= x >> 27 is linear over GF(2):
+// one step is a 64 x 64 bit matrix M, k steps are M^k.  jump[i][b] = M^(2^i) e_b (the image of bit b), filled once on the
+// host (driver.hip); a state is advanced k steps by applying M^(2^i) for the set bits of k - 64 conditional XORs each.  This
+// is what lets thousands of threads draw the substep's source positions (main.c:288) from ONE sequential stream.
+#define EU_RNG_JUMPS 40
+struct RngJump { unsigned long long col[EU_RNG_JUMPS][64]; };
+__device__ __forceinline__ unsigned long long eu_rng_step(unsigned long long st) {
+  st ^= st >> 12; st ^= st << 25; st ^= st >> 27;
+  return st;
+}
+__device__ __forceinline__ unsigned long long eu_rng_jump(const RngJump* __restrict__ J, unsigned long long st, unsigned long long k) {
+  for (int i = 0; k && i < EU_RNG_JUMPS; ++i, k >>= 1) {
+    if (!(k & 1)) continue;
+    unsigned long long y = 0, x = st;
+    const unsigned long long* c = J->col[i];
+    while (x) { const int b = __ffsll((long long)x) - 1; y ^= c[b]; x &= x - 1; }
+    st = y;
+  }
+  return st;
+}
+__device__ __forceinline__ float eu_rng_float(unsigned long long st) {   // randf(), main.c:203-207: closed [0, 1]
+  const unsigned int hi = (unsigned int)((st * 0x2545F4914F6CDD1Dull) >> 32);
+  return (float)(hi / (double)4294967295u);
 }
 
 // wave64 reductions by shuffles

@@ -369,7 +369,8 @@ __global__ __launch_bounds__(256) void k_source_mask(const uint8_t* __restrict__
   if ((threadIdx.x & 63) == 0 && (i >> 6) < ((C + 63) >> 6)) mask[i >> 6] = b;
 }
 
-__global__ void k_source_draws(MarkerState* ms, float* __restrict__ draws) {
+// the substep's bookkeeping (one thread): how many cells append (the latch, main.c:281,290), where the stream stands afterwards
+__global__ void k_source_draws(MarkerState* ms, const RngJump* __restrict__ J) {
   unsigned long long n = ms->n;
   const unsigned long long cap = ms->max_markers - 1;
   int exhausted = ms->exhausted | (n == cap);
@@ -378,18 +379,29 @@ __global__ void k_source_draws(MarkerState* ms, float* __restrict__ draws) {
     n_app = ms->n_events;   // number of eligible cells (select total lands here)
     if (n_app > cap - n) n_app = cap - n;
   }
-  unsigned long long st = ms->rng_state;
-  for (unsigned long long k = 0; k < 2 * n_app; ++k) {
-    st ^= st >> 12; st ^= st << 25; st ^= st >> 27;
-    const unsigned int hi = (unsigned int)((st * 0x2545F4914F6CDD1Dull) >> 32);
-    draws[k] = (float)(hi / (double)4294967295u);
-  }
-  ms->rng_state = st;
+  ms->rng0 = ms->rng_state;
+  ms->rng_state = eu_rng_jump(J, ms->rng_state, 2 * n_app);      // two draws per appended marker
   ms->n0_append = n;
   ms->n_append = (unsigned int)n_app;
+  ms->src_k_lo = 0;
   n += n_app;
   ms->n = n;
   ms->exhausted = exhausted | (n == cap && n_app > 0) | (n == cap);
+}
+// ... and the draws themselves, in parallel: a thread jumps to its chunk of the ONE sequential stream (draw d is the generator's
+// output after d + 1 steps from rng0) and walks SRC_CHUNK cells = 2 SRC_CHUNK draws.  Round 1 walked the stream with one
+// thread: 6.9 ms per substep at 4096^2 waterfall (0.27 M source cells), 39 % of the run.
+#define SRC_CHUNK 32
+__global__ __launch_bounds__(256) void k_source_fill(const MarkerState* ms, const RngJump* __restrict__ J, float* __restrict__ draws) {
+  const unsigned long long n_mine = ms->n_append, k_lo = ms->src_k_lo;        // this rank's cells are k_lo .. k_lo + n_mine of the substep's order
+  const unsigned long long c0 = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) * SRC_CHUNK;
+  if (c0 >= n_mine) return;
+  unsigned long long st = eu_rng_jump(J, ms->rng0, 2 * (k_lo + c0));
+  const unsigned long long c1 = c0 + SRC_CHUNK < n_mine ? c0 + SRC_CHUNK : n_mine;
+  for (unsigned long long c = c0; c < c1; ++c) {
+    st = eu_rng_step(st); draws[2 * c] = eu_rng_float(st);          // y first (main.c:288: right to left)
+    st = eu_rng_step(st); draws[2 * c + 1] = eu_rng_float(st);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_source_place(float2* __restrict__ m, uint8_t* __restrict__ count,
@@ -406,12 +418,18 @@ __global__ __launch_bounds__(256) void k_source_place(float2* __restrict__ m, ui
   }
 }
 
+int eu_source_fill(euler_sim* S) {   // the parallel draws of this rank's appended markers (k_slab.hip shares it)
+  LAUNCH(S, KC_SOURCES, k_source_fill, dim3(eu_blocks((S->n_source_cells + SRC_CHUNK - 1) / SRC_CHUNK, 256)), dim3(256), S->ms, S->rng_jump, S->draws);
+  return EULER_OK;
+}
+
 int eu_launch_sources(euler_sim* S) {
   if (S->n_source_cells == 0) return EULER_OK;   // no '?' cells: the reference's loop body never runs
   LAUNCH(S, KC_SOURCES, k_source_mask, dim3(eu_blocks(S->C, 256)), dim3(256), S->source, S->count, S->C, S->cellmask64);
   int rc = eu_ordered_select(S, S->cellmask64, (S->C + 63) / 64, S->sel_idx, &S->ms->n_events);
   if (rc) return rc;
-  LAUNCH(S, KC_SOURCES, k_source_draws, dim3(1), dim3(1), S->ms, S->draws);
+  LAUNCH(S, KC_SOURCES, k_source_draws, dim3(1), dim3(1), S->ms, S->rng_jump);
+  eu_source_fill(S);
   LAUNCH(S, KC_SOURCES, k_source_place, dim3(eu_blocks(S->n_source_cells, 256, 2048)), dim3(256), S->markers[S->cur],
          S->count, S->sel_idx, S->draws, S->ms, S->X);
   return EULER_OK;

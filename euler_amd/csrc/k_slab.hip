@@ -369,6 +369,7 @@ int eu_marker_rotate_counts(euler_sim* S);
 int eu_marker_narrow_counts(euler_sim* S);
 int eu_marker_advect_a(euler_sim* S, float dt, unsigned long long n);
 int eu_marker_advect_b(euler_sim* S, unsigned long long n, const unsigned int* keys);
+int eu_source_fill(euler_sim* S);
 
 static int slab_refresh(euler_sim* S, unsigned long long n_upper) {
   SlabScratch* s = S->slab;
@@ -397,8 +398,9 @@ __global__ __launch_bounds__(256) void k_source_mask_rows(const uint8_t* __restr
 __global__ void k_source_count_to_vec(const MarkerState* ms, double* vec, int R, int rank) {
   for (int r = 0; r < R; ++r) vec[r] = r == rank ? (double)ms->n_events : 0.0;
 }
-// the substep's draws (main.c:288, y first): every rank walks the whole stream - it is sequential - and keeps its own part
-__global__ void k_source_draws_slab(MarkerState* ms, float* __restrict__ draws, const double* __restrict__ vec, int R, int rank) {
+// the substep's bookkeeping on every rank alike (the latch and the stream position are global); the draws of the own cells are
+// then filled in parallel by k_source_fill (k_markers.hip), which jumps into the one sequential stream at this rank's offset
+__global__ void k_source_draws_slab(MarkerState* ms, const RngJump* __restrict__ J, const double* __restrict__ vec, int R, int rank) {
   unsigned long long n = ms->n;
   const unsigned long long cap = ms->max_markers - 1;
   const int exhausted = ms->exhausted | (n == cap);
@@ -407,14 +409,8 @@ __global__ void k_source_draws_slab(MarkerState* ms, float* __restrict__ draws, 
   const unsigned long long e_loc = (unsigned long long)vec[rank];
   unsigned long long n_app = 0;
   if (!exhausted) { n_app = e_tot; if (n_app > cap - n) n_app = cap - n; }
-  unsigned long long st = ms->rng_state;
-  for (unsigned long long k = 0; k < 2 * n_app; ++k) {
-    st ^= st >> 12; st ^= st << 25; st ^= st >> 27;
-    const unsigned int hi = (unsigned int)((st * 0x2545F4914F6CDD1Dull) >> 32);
-    const unsigned long long cell = k >> 1;
-    if (cell >= k_lo && cell < k_lo + e_loc) draws[k - 2 * k_lo] = (float)(hi / (double)4294967295u);
-  }
-  ms->rng_state = st;
+  ms->rng0 = ms->rng_state;
+  ms->rng_state = eu_rng_jump(J, ms->rng_state, 2 * n_app);
   ms->n0_append = n;
   unsigned long long mine = 0;
   if (n_app > k_lo) { mine = n_app - k_lo; if (mine > e_loc) mine = e_loc; }
@@ -450,8 +446,9 @@ static int slab_sources(euler_sim* S) {
   if (rc) return rc;
   hipLaunchKernelGGL(k_source_count_to_vec, dim3(1), dim3(1), 0, S->stream, S->ms, s->vec, s->R, s->rank);
   COMM_CALL(S->comm.allreduce(S->comm.ctx, s->vec, s->R, 0));
-  LAUNCH(S, KC_SOURCES, k_source_draws_slab, dim3(1), dim3(1), S->ms, S->draws, s->vec, s->R, s->rank);
+  LAUNCH(S, KC_SOURCES, k_source_draws_slab, dim3(1), dim3(1), S->ms, S->rng_jump, s->vec, s->R, s->rank);
   if (S->n_source_cells) {
+    eu_source_fill(S);
     LAUNCH(S, KC_SOURCES, k_source_place_slab, dim3(eu_blocks(S->n_source_cells, 256, 2048)), dim3(256), S->markers[S->cur], S->keys[S->cur],
            S->count, S->sel_idx, S->draws, S->ms, S->X, i0, (unsigned long long)S->max_markers);
     hipLaunchKernelGGL(k_source_done, dim3(1), dim3(1), 0, S->stream, S->ms);
