@@ -727,6 +727,11 @@ extern "C" int euler_set_field(euler_sim* S, int32_t f, const void* src, size_t 
     HIPCHK(hipMemcpyAsync(p, src, b, hipMemcpyHostToDevice, S->stream));
   }
   HIPCHK(hipStreamSynchronize(S->stream));
+  if (S->slab_on && (f == EULER_F_U || f == EULER_F_V)) {   // COLLECTIVE on a row-slab handle: the neighbours' ghost rows follow at once
+    rc = eu_slab_exchange_uv(S);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(S->stream));
+  }
   if (f == EULER_F_SOURCE) {
     const uint8_t* s = (const uint8_t*)src;
     size_t nsrc = 0;

@@ -133,6 +133,10 @@ static int exchange_uv(euler_sim* S) {
   const GhostField f[2] = {{S->u, 4, 1, 1}, {S->v, 4, 1, 1}};
   return exchange_rows(S, f, 2);
 }
+int eu_slab_exchange_uv(euler_sim* S) {
+  if (!S->has_comm) { eu_set_error("row-slab handle without a communicator"); return EULER_ESTATE; }
+  return exchange_uv(S);
+}
 static int exchange_counts(euler_sim* S) {
   const GhostField f[2] = {{S->count, 1, EU_GHOST_LO, EU_GHOST_HI}, {S->prev_count, 1, EU_GHOST_LO, EU_GHOST_HI}};
   return exchange_rows(S, f, 2);
@@ -376,6 +380,7 @@ static int slab_refresh(euler_sim* S, unsigned long long n_upper) {
   eu_marker_rotate_counts(S);
   const size_t mask_words = (S->max_markers + 63) / 64;
   char* my_block = s->xg + (size_t)s->rank * s->blk;
+  HIPCHK(hipMemsetAsync(my_block, 0, 8, S->stream));     // the deletion counter (the block carried this substep's dt-chain candidates before)
   LAUNCH(S, KC_MARKER_BIN, k_bin_markers_slab, dim3(eu_blocks((size_t)n_upper + 1, 256)), dim3(256), S->markers[S->cur], S->keys[S->cur], S->ms,
          S->sink, S->solid, S->count32, s->mask2, mask_words, S->X, S->row_lo, S->row_hi, my_block);
   COMM_CALL(S->bulk.allgather(S->bulk.ctx, s->xg, s->ag_off.data(), s->ag_cnt.data()));

@@ -88,7 +88,8 @@ typedef struct euler_config {
                                    them - per-rank memory ~ 1/slab_nranks.  Install a communicator of the same rank / size
                                    (euler_set_comm / euler_set_comm_rccl) BEFORE loading a scenario.  Fields are then exchanged as the
                                    owned rows (euler_get_field), markers as the local ones with their global array index
-                                   (EULER_F_MARKER_KEYS).  Needs EULER_PRECOND_IC0_TILE or slab-local IC(0) coupling. */
+                                   (EULER_F_MARKER_KEYS); euler_set_field(U / V) takes the own rows and is COLLECTIVE (it refreshes the
+                                   neighbours' ghost rows).  Needs EULER_PRECOND_IC0_TILE or slab-local IC(0) coupling. */
   int32_t reserved[4];
 } euler_config;
 

@@ -21,6 +21,9 @@ from euler_amd.slab import SLAB_LOCAL, RcclComm, TorchComm, attach_p2p
 def load(sim, workload):
     if workload == "half_tank":
         sim.load_half_tank()
+    elif workload.startswith("golden:"):      # one of the reference's five scenario texts, as stored with the golden fixtures
+        from golden_util import load as gload, scenario_text
+        sim.load_text(scenario_text(gload(workload[7:] + "_frames.npz")), upscale=True)
     else:
         sim.load_text(getattr(scenarios, workload)(), upscale=True)
     return sim
@@ -48,6 +51,37 @@ def main():
     load(sim, workload)
     lo, hi = sim.slab_rows()
     out["rows"] = [lo, hi]
+    if "events" in sys.argv[6:]:
+        # Drive the dt chain (main.c:497-501) across the ranks: a strong diagonal flow towards the walls inside two patches - one in the
+        # lowest slab, one straddling the first slab boundary - makes markers cross a cell edge and THEN hit a solid, which shortens dt
+        # for every LATER marker of the reference's array, wherever it lives.  One substep: the markers move before any dot product.
+        u = np.zeros((Y, X), np.float32); v = np.zeros((Y, X), np.float32)
+        from euler_amd.slab import slab_bands
+        edge = 64 * slab_bands((Y + 63) // 64, 0, world)[1]            # the first slab boundary
+        for (y0, y1) in ((2, 40), (edge - 20, edge + 20)):
+            u[y0:y1, 1:X // 3] = -7.0       # (from the face between the wall and the first water column on: the flow runs INTO the wall)
+            v[y0:y1, 1:X // 3] = -5.0
+        ref.set(ea.F_U, u); ref.set(ea.F_V, v)
+        sim.set(ea.F_U, u[lo:hi]); sim.set(ea.F_V, v[lo:hi])          # collective: ghost rows follow
+        dt_r, dt_s = ref.timestep(0.1), sim.timestep(0.1)
+        ref.substep(dt_r); sim.substep(dt_s)
+        m, k, rm = sim.get(ea.F_MARKERS), sim.get(ea.F_MARKER_KEYS), ref.get(ea.F_MARKERS)
+        ev = {"dt": [dt_r, dt_s], "dt_events": [int(ref.stats().marker_dt_events), int(sim.stats().marker_dt_events)],
+              "markers_at_keys": bool(np.array_equal(m.view(np.uint32), rm[k].view(np.uint32))),
+              "mismatch": [int((m.view(np.uint32) != rm[k].view(np.uint32)).any(axis=1).sum()), len(k),
+                           int(k[(m.view(np.uint32) != rm[k].view(np.uint32)).any(axis=1)].min()) if (m.view(np.uint32) != rm[k].view(np.uint32)).any() else -1,
+                           float(np.abs(m - rm[k]).max()) if len(k) else 0.0],
+              "count_differ": int((sim.get(ea.F_COUNT) != ref.get(ea.F_COUNT)[lo:hi]).sum())}
+        bad = np.nonzero((m.view(np.uint32) != rm[k].view(np.uint32)).any(axis=1))[0]
+        ev["bad_detail"] = [[int(i), int(k[i]), m[i].tolist(), rm[k[i]].tolist()] for i in bad[:6]] + [len(m), int(ref.stats().n_markers)]
+        agg = [None] * world
+        dist.all_gather_object(agg, ev)
+        ev["bad_detail_per_rank"] = [a["bad_detail"] for a in agg]
+        ev["markers_at_keys"] = all(a["markers_at_keys"] for a in agg)
+        ev["mismatch_per_rank"] = [a["mismatch"] for a in agg]
+        ev["count_differ"] = max(a["count_differ"] for a in agg)
+        out["events"] = ev
+        frames = 0
     free0, total = torch.cuda.mem_get_info()
     for f in range(frames):
         ref.step()
