@@ -63,10 +63,20 @@ def main():
             v[y0:y1, 1:X // 3] = -5.0
         ref.set(ea.F_U, u); ref.set(ea.F_V, v)
         sim.set(ea.F_U, u[lo:hi]); sim.set(ea.F_V, v[lo:hi])          # collective: ghost rows follow
+        if "deletions" in sys.argv[6:]:
+            # ... and a block of sink cells in the water, across the slab boundary: every marker inside is deleted by the next
+            # refresh_marker_counts (main.c:109-112), the swap-with-last order re-keys the survivors from the back of the array
+            sink = ref.get(ea.F_SINK).copy()
+            sink[edge - 6:edge + 6, X // 2:X // 2 + 12] = 1
+            sink[8:14, X - 30:X - 20] = 1
+            ref.set(ea.F_SINK, sink)
+            sim.set(ea.F_SINK, sink[lo:hi])
+        n0 = int(ref.stats().n_markers)
         dt_r, dt_s = ref.timestep(0.1), sim.timestep(0.1)
         ref.substep(dt_r); sim.substep(dt_s)
         m, k, rm = sim.get(ea.F_MARKERS), sim.get(ea.F_MARKER_KEYS), ref.get(ea.F_MARKERS)
         ev = {"dt": [dt_r, dt_s], "dt_events": [int(ref.stats().marker_dt_events), int(sim.stats().marker_dt_events)],
+              "n_markers": [int(ref.stats().n_markers), int(sim.stats().n_markers), n0],
               "markers_at_keys": bool(np.array_equal(m.view(np.uint32), rm[k].view(np.uint32))),
               "mismatch": [int((m.view(np.uint32) != rm[k].view(np.uint32)).any(axis=1).sum()), len(k),
                            int(k[(m.view(np.uint32) != rm[k].view(np.uint32)).any(axis=1)].min()) if (m.view(np.uint32) != rm[k].view(np.uint32)).any() else -1,
@@ -78,6 +88,10 @@ def main():
         dist.all_gather_object(agg, ev)
         ev["bad_detail_per_rank"] = [a["bad_detail"] for a in agg]
         ev["markers_at_keys"] = all(a["markers_at_keys"] for a in agg)
+        keys_all = [None] * world
+        dist.all_gather_object(keys_all, k.tolist())
+        flat = np.sort(np.concatenate([np.asarray(x, np.int64) for x in keys_all]))
+        ev["keys_are_a_permutation"] = bool(len(flat) == len(rm) and np.array_equal(flat, np.arange(len(rm))))
         ev["mismatch_per_rank"] = [a["mismatch"] for a in agg]
         ev["count_differ"] = max(a["count_differ"] for a in agg)
         out["events"] = ev

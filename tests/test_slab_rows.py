@@ -100,3 +100,18 @@ def test_dt_chain_across_ranks(nproc, X, Y, workload):
     assert ev["dt"][0] == ev["dt"][1]
     assert ev["dt_events"][0] == ev["dt_events"][1] > 0, ev
     assert ev["markers_at_keys"] and ev["count_differ"] == 0, ev
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,X,Y", [(3, 200, 192), (2, 256, 256)])
+def test_swap_with_last_deletion_across_ranks(nproc, X, Y):
+    """refresh_marker_counts deletes with g_markers[i--] = g_markers[--g_markers_length] (main.c:112): the survivors at the back
+    of the ARRAY fill the holes in order.  With row slabs that is a statement about keys (k_rekey): blocks of sink cells dropped
+    into the water - one across a slab boundary - delete a few hundred markers in one substep (while the dt chain fires as
+    well); afterwards the job holds n - D markers, their keys are a permutation of 0..n-D-1, and each sits bit for bit where
+    the single-GPU array has the marker of that index."""
+    d = run(nproc, X, Y, "half_tank", 0, ea.PRECOND_IC0_TILE, 29584, ("events", "deletions"))
+    ev = d["events"]
+    assert ev["n_markers"][0] == ev["n_markers"][1] < ev["n_markers"][2] - 100, ev["n_markers"]
+    assert ev["dt_events"][0] == ev["dt_events"][1]
+    assert ev["markers_at_keys"] and ev["keys_are_a_permutation"] and ev["count_differ"] == 0, ev
