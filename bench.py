@@ -291,6 +291,12 @@ def kernel_rows(prof, precond, cells_fluid, traffic, fused_search):
             b = APPLY_A_FUSED.get(precond, b)
             e["note"] = ("update_search fused in" + (" + the previous iteration's p += alpha s" if precond == "ic0_tile" else "")
                          + ": %d algorithmic B/cell" % b)
+        if name == "update_pr" and precond == "ic0_tile":
+            b = 3 * W + 1
+            e["note"] = "k_finish_p, once per solve: the last iteration's p += alpha s (read s, p; write p)"
+        if name == "update_search" and fused_search:
+            b = None
+            e["note"] = "once per solve: s = z over the whole padded array (every other update_search rides in apply_a)"
         if b:
             sec = ms / launches * 1e-3
             e["bytes_per_cell"] = b
@@ -488,7 +494,7 @@ def main():
     if rank != 0:
         grp.close()
         return
-    head = summarize(t, GX, GY, args.precond, tile_w, traffic, traffic_note, args.steps, fused_search=not sharded or p2p_on)
+    head = summarize(t, GX, GY, args.precond, tile_w, traffic, traffic_note, args.steps, fused_search=True)
     try:      # the ceiling a plain device-to-device copy reaches on this very GPU (read + write), next to the 8 TB/s spec peak
         copy_gbps = round(sim.copy_bandwidth(1 << 30, 10), 1)
     except Exception:
