@@ -161,7 +161,7 @@ extern "C" void euler_destroy(euler_sim* S) {
   const size_t wo = S->shifted ? S->win_off : 0;
   for (float* f : {S->u, S->v, S->utmp, S->vtmp}) if (f) (void)hipFree(f + wo);
   for (uint8_t* g : {S->solid, S->source, S->sink, S->count, S->prev_count}) if (g) (void)hipFree(g + wo);
-  if (S->count32) (void)hipFree(S->count32 + wo);
+  if (S->count32) (void)hipFree(S->count32);
   void* dev[] = {S->markers[0], S->markers[1], S->keys[0], S->keys[1], S->ms, S->evmask, S->ev_theta, S->ev_delta, S->sel_idx, S->act_idx,
                  S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->halo_buf, S->band_ranges, S->partial2, S->pair_buf, S->rng_jump,
                  S->rowmajor_tmp};
@@ -315,7 +315,6 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   // every device allocation is in place: shift the base pointers to global indexing (euler_dev.h "Row slabs")
   for (float** f : {&S->u, &S->v, &S->utmp, &S->vtmp}) *f -= S->win_off;
   for (uint8_t** g : {&S->solid, &S->source, &S->sink, &S->count, &S->prev_count}) *g -= S->win_off;
-  S->count32 -= S->win_off;
   for (double** d : {&S->b, &S->p, &S->r, &S->z, &S->s, &S->s2, &S->q, &S->precon}) *d += EU_SKEW_SLACK - S->skew_off;
   S->cellmask += EU_SKEW_SLACK - S->skew_off;
   S->fbits_fwd -= (size_t)S->ab_lo * S->fb_stride * 64; S->fbits_bwd -= (size_t)S->ab_lo * S->fb_stride * 64;

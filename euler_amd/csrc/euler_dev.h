@@ -125,7 +125,7 @@ struct euler_sim {
   // fields (main.c:64-73,96-97)
   float *u, *v, *utmp, *vtmp;
   uint8_t *solid, *source, *sink, *count, *prev_count;
-  unsigned int* count32;
+  unsigned int* count32;   // the binning counters of the window, COLUMN-major: [x][y - win_lo] (k_markers.hip), never shifted
   float* dye[6];          // --rainbow only (cfg.rainbow): g_r, g_g, g_b, g_rtmp, g_gtmp, g_btmp (main.c:76-81)
   // markers, ping-pong (main.c:95)
   float2* markers[2];
@@ -236,6 +236,14 @@ static inline unsigned eu_blocks(size_t n, unsigned per_block, unsigned cap = 0x
   return (unsigned)b;
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Kernels whose neighbouring blocks touch the same
+// cache lines of a row-major field (markers lie in the array roughly in spatial order; the solver's diagonal order crosses a
+// row's line 16 times) give each XCD one CONTIGUOUS eighth of the block range instead: a bijection of [0, gridDim.x).
+__device__ __forceinline__ size_t eu_xcd_block() {
+  const unsigned int b = blockIdx.x, full = gridDim.x & ~7u;
+  return b < full ? (size_t)(b & 7) * (full >> 3) + (b >> 3) : (size_t)b;
+}
+
 #define EU_GHOST_LO 1   // ghost rows below / above a slab: u, v need 1 / 1, the count grids 1 / 2, vtmp 1 / 0
 #define EU_GHOST_HI 2
 // slab mode (k_slab.hip)
@@ -303,6 +311,9 @@ __device__ __forceinline__ float eu_interp(const GridRef& g, const float* __rest
   const float fx = modff(ix, &wx), fy = modff(iy, &wy);
   const int bx = (int)wx, by = (int)wy;
   const size_t i00 = (size_t)by * g.X + bx;
+  // the four samples are loaded unconditionally and next to the mask bytes (the clamps keep all of them inside the arrays,
+  // ghost rows included): one memory round trip instead of two - the kernels that interpolate are latency-bound
+  const float r00 = q[i00], r01 = q[i00 + 1], r10 = q[i00 + g.X], r11 = q[i00 + g.X + 1];
   bool v00, v01, v10, v11;
   if (TYPE == 0) {
     v00 = g.count[i00] != 0; v01 = g.count[i00 + 1] != 0;
@@ -317,8 +328,8 @@ __device__ __forceinline__ float eu_interp(const GridRef& g, const float* __rest
     const bool e0 = g.count[i00 + 2 * (size_t)g.X] != 0, e1 = g.count[i00 + 2 * (size_t)g.X + 1] != 0;
     v00 = c0 | d0; v01 = c1 | d1; v10 = d0 | e0; v11 = d1 | e1;
   }
-  const float q00 = v00 ? q[i00] : 0.f, q01 = v01 ? q[i00 + 1] : 0.f;
-  const float q10 = v10 ? q[i00 + g.X] : 0.f, q11 = v11 ? q[i00 + g.X + 1] : 0.f;
+  const float q00 = v00 ? r00 : 0.f, q01 = v01 ? r01 : 0.f;
+  const float q10 = v10 ? r10 : 0.f, q11 = v11 ? r11 : 0.f;
   const float lf = eu_frac(fy, v00, v10), rf = eu_frac(fy, v01, v11);
   const float lv = eu_lerp(q00, q10, lf), rv = eu_lerp(q01, q11, rf);
   const float hf = eu_frac(fx, v00 | v10, v01 | v11);
@@ -371,6 +382,9 @@ __device__ __forceinline__ float eu_wave_maxf(float v) {
 // opens a run of lanes binning into the same cell adds the run's length with ONE atomic (up to 4x fewer atomics, each a
 // 32-byte memory-side transaction in a column-ordered array: k_bin_markers at 8192^2: 5.1 ms with one atomic per marker).
 __device__ __forceinline__ void bin_aggregated(unsigned int* count32, bool live, size_t c) {
+  // (the adds are executed at the memory side, ~11 G/s whatever their width: at 8192^2 they, not the marker reads, set the
+  // binning kernel's time - 3.4 ms against 0.5 ms without them.  The seeding order walks COLUMNS, main.c:243-266, so
+  // consecutive runs land X cells apart and cannot share a 64-bit add.)
   const unsigned int lo = (unsigned int)c, hi = (unsigned int)(c >> 32);
   const int lane = threadIdx.x & 63;
   const unsigned int plo = __shfl_up(lo, 1, 64), phi = __shfl_up(hi, 1, 64);

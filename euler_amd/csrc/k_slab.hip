@@ -275,17 +275,18 @@ __global__ void k_migrate_done(MarkerState* ms, const char* recv_lo, const char*
 __global__ __launch_bounds__(256) void k_bin_markers_slab(const float2* __restrict__ m, const unsigned int* __restrict__ keys, MarkerState* ms,
                                                           const uint8_t* __restrict__ sink, const uint8_t* __restrict__ solid,
                                                           unsigned int* count32, unsigned long long* __restrict__ rmmask, size_t mask_words, int X,
-                                                          int row_lo, int row_hi, char* del_block) {
+                                                          int row_lo, int row_hi, int win_lo, int win_h, char* del_block) {
   const unsigned long long n = ms->n_loc;
   const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   bool rm = false, live = false;
-  size_t c = 0;
+  size_t ct = 0;
   if (i < n) {
     const float2 p = m[i];
     const int x = (int)floorf(p.x / EU_H), y = (int)floorf(p.y / EU_H);
     if (y < row_lo || y >= row_hi) rm = true;
     else {
-      c = (size_t)y * X + x;
+      const size_t c = (size_t)y * X + x;
+      ct = (size_t)x * win_h + (y - win_lo);            // the column-major counters of the window (k_markers.hip)
       if ((sink[c] | solid[c]) != 0) {
         rm = true;
         const unsigned long long slot = atomicAdd(reinterpret_cast<unsigned long long*>(del_block), 1ull);
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256) void k_bin_markers_slab(const float2* __restri
       } else live = true;
     }
   }
-  bin_aggregated(count32, live, c);      // one atomic per run of lanes binning into the same cell
+  bin_aggregated(count32, live, ct);     // one atomic per run of lanes binning into the same cell
   const unsigned long long b = __ballot(rm);
   if ((threadIdx.x & 63) == 0 && (i >> 6) < mask_words) rmmask[i >> 6] = b;      // every word the launch covers: zero behind the last marker
 }
@@ -382,7 +383,7 @@ static int slab_refresh(euler_sim* S, unsigned long long n_upper) {
   char* my_block = s->xg + (size_t)s->rank * s->blk;
   HIPCHK(hipMemsetAsync(my_block, 0, 8, S->stream));     // the deletion counter (the block carried this substep's dt-chain candidates before)
   LAUNCH(S, KC_MARKER_BIN, k_bin_markers_slab, dim3(eu_blocks((size_t)n_upper + 1, 256)), dim3(256), S->markers[S->cur], S->keys[S->cur], S->ms,
-         S->sink, S->solid, S->count32, s->mask2, mask_words, S->X, S->row_lo, S->row_hi, my_block);
+         S->sink, S->solid, S->count32, s->mask2, mask_words, S->X, S->row_lo, S->row_hi, S->win_lo, S->win_hi - S->win_lo, my_block);
   COMM_CALL(S->bulk.allgather(S->bulk.ctx, s->xg, s->ag_off.data(), s->ag_cnt.data()));
   LAUNCH(S, KC_MARKER_COMPACT, k_merge_deleted, dim3(1), dim3(1024), s->xg, s->R, s->blk, s->rank, s->sortbuf, s->d_sorted, S->ms);
   LAUNCH(S, KC_MARKER_COMPACT, k_rekey, dim3(eu_blocks((size_t)n_upper + 1, 256, 4096)), dim3(256), S->keys[S->cur], s->mask2, s->d_sorted, S->ms);

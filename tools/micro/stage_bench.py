@@ -1,0 +1,25 @@
+"""Development aid: the marker stages of one 8192^2 half-tank substep, repeated, for `rocprofv3 --kernel-trace --stats`
+(EULER_HIP_LIB selects an experimental build of the library)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import euler_amd as ea
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+workload = sys.argv[2] if len(sys.argv) > 2 else "half_tank"
+sim = ea.Simulation(N, N, precond=ea.PRECOND_IC0_TILE, tol=0.0 if workload == "half_tank" else None, max_iterations=20)
+if workload == "half_tank":
+    sim.load_half_tank()
+else:
+    from euler_amd import scenarios
+    sim.load_text(getattr(scenarios, workload)(), upscale=True)
+for _ in range(3):
+    sim.step()
+for _ in range(8):
+    sim.stage(ea.STAGE_ADVECT_MARKERS, 0.004)
+    sim.stage(ea.STAGE_REFRESH_COUNTS)
+    sim.stage(ea.STAGE_EXTRAPOLATE)
+    sim.stage(ea.STAGE_ADVECT_VELOCITY, 0.004)
+sim.sync()
+print("markers", sim.stats().n_markers)
