@@ -203,6 +203,8 @@ def pmc_live(child_args, timeout_s=420):
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, "rocprofv3 not on PATH"
+    if "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ):
+        return None, "this run is itself being profiled: no nested PMC passes"
     out = {}
     base = tempfile.mkdtemp(prefix="euler_pmc_")
     env = dict(os.environ, TMPDIR="/tmp")
