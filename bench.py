@@ -5,7 +5,8 @@ metric    cells*steps/s of the whole sim_step() path (one step = one 0.1 s frame
           PCG pressure projection), plus the achieved HBM rate of the pressure solve against the MI355X roofline.
 
 headline  N=1: configs[2], the 8192x8192 half-filled tank, "pressure-solve roofline run" (SURVEY 8d config 3): tol = 0 and
-          max_iterations = 100, so every substep runs exactly 100 PCG iterations.  It runs in the ROOFLINE MODE SURVEY 7 (hard
+          max_iterations = 100, so every substep runs exactly 100 PCG iterations; the timed frames lie in the tank's saturated
+          phase (the reference's maximum of 8 CFL substeps per frame, preroll_into_solves).  It runs in the ROOFLINE MODE SURVEY 7 (hard
           part 1b) and 8d name: the tile-local IC(0) preconditioner (EULER_PRECOND_IC0_TILE, include/euler.h) - the reference's
           recurrences restricted to 64-row x 16-column blocks, one pass over memory per iteration - which is NOT the reference's
           sequence of iterates (same solution where PCG converges; tests/test_gpu_tile_precond.py).  The SAME workload in the
@@ -74,6 +75,8 @@ def parse_args():
     ap.add_argument("--tile-records", type=int, default=0)
     ap.add_argument("--tol", type=float, default=None, help="PCG tolerance (default: 0 for half_tank = the roofline run, else the reference's 1e-6)")
     ap.add_argument("--max-preroll", type=int, default=400)
+    ap.add_argument("--preroll", default="auto", choices=["auto", "solves"],
+                    help="auto: the half tank is advanced into its saturated phase (8 substeps per frame) before the timed frames; solves: only to the first solve")
     ap.add_argument("--slab", default="rows", choices=["rows", "local", "exact", "replicas"],
                     help="N>1: rows = TRUE ROW SLABS for every stage (default; SURVEY 8e: each rank holds and steps only its rows and the "
                          "markers in them, ghost rows / marker migration / dt all-reduce between neighbours); local / exact = round 1's layout "
@@ -271,15 +274,24 @@ def load_workload(sim, scenarios, workload, tiles=1):
         sim.load_half_tank(tiles)      # `tiles` closed tanks on top of each other (weak scaling: one per row slab)
 
 
-def preroll_into_solves(sim, max_preroll):
+def preroll_into_solves(sim, max_preroll, saturate=False):
     """untimed: advance to the first frame whose substeps run PCG iterations at all (a dam break first falls freely for ~22
-    frames: zero divergence, the reference's all_zero(r) test skips the solve, main.c:742)"""
+    frames: zero divergence, the reference's all_zero(r) test skips the solve, main.c:742).
+    saturate (the half tank, tol 0): go on until two frames in a row take the reference's maximum of 8 CFL substeps, at most 16
+    frames.  From rest the tank's velocities are the rounding noise of unconverged solves; it grows for ~7 frames, during which a
+    frame takes 1, 2, 3, 5, 7 ... substeps - a ramp whose shape depends on every summation order (mode, run length, number of
+    ranks).  Timing frames of the ramp would make cells*steps/s a lottery; in the saturated phase a frame is 8 substeps."""
     n = 0
     while n < max_preroll:
         sim.step()
         n += 1
         if sim.stats().last_pcg_iterations >= 100:
             break
+    full = 0
+    while saturate and n < min(max_preroll, 16) and full < 2:
+        sim.step()
+        n += 1
+        full = full + 1 if sim.stats().last_substeps >= 8 else 0
     return n
 
 
@@ -415,7 +427,7 @@ def main():
     tol = args.tol if args.tol is not None else (0.0 if args.workload == "half_tank" else None)
     single = args.gpus == 1 and not args.force_slab and "RANK" not in os.environ
     child_common = ["--size", str(N), "--workload", args.workload, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-kernel-timing",
-                    "--no-secondary", "--no-pmc", "--pmc-child", "--dot-mode", args.dot_mode, "--tile-records", str(args.tile_records)]
+                    "--no-secondary", "--no-pmc", "--pmc-child", "--preroll", "solves", "--dot-mode", args.dot_mode, "--tile-records", str(args.tile_records)]
     if args.tol is not None:
         child_common += ["--tol", repr(args.tol)]
 
@@ -483,7 +495,8 @@ def main():
             print("bench: peer-to-peer mailboxes unavailable (%s); exchanges stay on %s" % (sim._p2p_error, args.comm), file=sys.stderr)
     tiles = GY // N
     load_workload(sim, scenarios, args.workload, tiles)
-    preroll = preroll_into_solves(sim, args.max_preroll)
+    saturate = args.workload == "half_tank" and args.preroll == "auto"
+    preroll = preroll_into_solves(sim, args.max_preroll, saturate)
     if args.pmc_child:
         sim.copy_bandwidth(1 << 30, 2)     # the calibration launches of pmc_live(): a known 2^30 bytes read and written each
 
@@ -517,7 +530,7 @@ def main():
                 k2 = max(1, args.steps // 2)
                 s2 = ea.Simulation(GX, GY, device=local_rank, dot_mode=dot_mode, precond=ea.PRECOND_IC0, tol=tol)
                 load_workload(s2, scenarios, args.workload, 1)
-                preroll_into_solves(s2, args.max_preroll)
+                preroll_into_solves(s2, args.max_preroll, saturate)
                 t2 = time_frames(s2, ea, grp, args, "ic0", k2, 0, args.warmup, big)
                 secondary["exact_ic0"] = summarize(t2, GX, GY, "ic0", tile_w, traffic_exact, traffic_exact_note, k2)
                 secondary["exact_ic0"]["workload"] = "%dx%d %s (the headline workload), %d frames" % (GX, GY, args.workload, k2)
@@ -648,7 +661,8 @@ def main():
         "dtype": "f32 fields, f64 PCG (the reference's mix)",
         "data": "synthetic",
         "config": {"workload": "%dx%d %s%s, %s" % (GX, GY, args.workload,
-                                                   " (BASELINE configs[2], pressure-solve roofline run: tol 0, exactly 100 PCG iterations per substep)"
+                                                   " (BASELINE configs[2], pressure-solve roofline run: tol 0, exactly 100 PCG iterations per substep%s)"
+                                                   % ("; timed in the saturated phase: 8 CFL substeps per frame" if saturate else "")
                                                    if args.workload == "half_tank" and tol == 0.0 else "", head["mode"]),
                    "grid": [GX, GY], "preroll_frames": preroll, "precond": args.precond, "tile_records": tile_w if args.precond == "ic0_tile" else None,
                    "dot_mode": args.dot_mode, "max_iterations": 100, "tol": tol if tol is not None else 1e-6, "parallelism": parallelism},
