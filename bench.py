@@ -356,10 +356,13 @@ def time_frames(sim, ea, grp, args, precond, steps, warmup_done, warmup, big):
                 substeps=st1.total_substeps - st0.total_substeps)
 
 
-def summarize(t, size_x, size_y, precond, tile_w, traffic, traffic_note, steps, fused_search=True):
-    """value + per-kernel rows + roofline object (dominant kernel = the PCG class with the largest total time) + whole-iteration aggregate"""
-    cells = size_x * size_y
-    fluid = int(t["st1"].fluid_cells)
+def summarize(t, size_x, size_y, precond, tile_w, traffic, traffic_note, steps, fused_search=True, rank_cells=None, rank_fluid_share=1.0):
+    """value + per-kernel rows + roofline object (dominant kernel = the PCG class with the largest total time) + whole-iteration aggregate.
+    The byte rates are THIS rank's: its kernels cover rank_cells cells (row slabs: the own rows, whose fluid cells the handle counts
+    itself; band slabs of a replicated handle: 1 / world of the grid's fluid cells)."""
+    cells_job = size_x * size_y
+    cells = rank_cells if rank_cells else cells_job
+    fluid = int(t["st1"].fluid_cells * rank_fluid_share)
     rows = kernel_rows(t["prof"], precond, fluid, traffic, fused_search)
     pcg_rows = {k: v for k, v in rows.items() if k in PCG_CLASSES}
     per_iter = [k for k in pcg_rows if rows[k]["launches"] >= 0.5 * max(t["iters"], 1)]
@@ -398,9 +401,9 @@ def summarize(t, size_x, size_y, precond, tile_w, traffic, traffic_note, steps, 
                "frac_traffic": round(tsum / sec / 1e9 / HBM_PEAK_GBPS, 4) if tsum else None,
                "frac_dense": round(bpc * cells / sec / 1e9 / HBM_PEAK_GBPS, 4)}
     return {"mode": MODE_NAME[precond] % tile_w if precond == "ic0_tile" else MODE_NAME[precond],
-            "value": cells * steps / t["elapsed"], "unit": "cells*steps/s", "ms_per_step": 1e3 * t["elapsed"] / steps,
+            "value": cells_job * steps / t["elapsed"], "unit": "cells*steps/s", "ms_per_step": 1e3 * t["elapsed"] / steps,
             "substeps": int(t["substeps"]), "pcg_iterations": int(t["iters"]),
-            "cells_substeps_per_s": cells * t["substeps"] / t["elapsed"],
+            "cells_substeps_per_s": cells_job * t["substeps"] / t["elapsed"],
             "fluid_cells": fluid, "markers": int(t["st1"].n_markers), "last_residual": float(t["st1"].last_residual),
             "roofline": roof, "pcg_iteration": agg, "kernels": rows}
 
@@ -509,7 +512,14 @@ def main():
     if rank != 0:
         grp.close()
         return
-    head = summarize(t, GX, GY, args.precond, tile_w, traffic, traffic_note, args.steps, fused_search=True)
+    rank_cells, share = None, 1.0
+    if rows:
+        r0, r1 = sim.slab_rows()
+        rank_cells = GX * (r1 - r0)
+    elif sharded and world > 1:
+        rank_cells, share = GX * GY // world, 1.0 / world
+    head = summarize(t, GX, GY, args.precond, tile_w, traffic, traffic_note, args.steps, fused_search=True, rank_cells=rank_cells,
+                     rank_fluid_share=share)
     try:      # the ceiling a plain device-to-device copy reaches on this very GPU (read + write), next to the 8 TB/s spec peak
         copy_gbps = round(sim.copy_bandwidth(1 << 30, 10), 1)
     except Exception:
