@@ -75,6 +75,8 @@ def parse_args():
     ap.add_argument("--tile-records", type=int, default=0)
     ap.add_argument("--tol", type=float, default=None, help="PCG tolerance (default: 0 for half_tank = the roofline run, else the reference's 1e-6)")
     ap.add_argument("--max-preroll", type=int, default=400)
+    ap.add_argument("--partition", default="auto", choices=["auto", "even"],
+                    help="row slabs of a strong-scaling run: auto = band ranges that balance the fluid (found by a pilot pass with even slabs), even = equal rows")
     ap.add_argument("--preroll", default="auto", choices=["auto", "solves"],
                     help="auto: the half tank is advanced into its saturated phase (8 substeps per frame) before the timed frames; solves: only to the first solve")
     ap.add_argument("--slab", default="rows", choices=["rows", "local", "exact", "replicas"],
@@ -295,6 +297,21 @@ def preroll_into_solves(sim, max_preroll, saturate=False):
     return n
 
 
+def balanced_partition(weights, world):
+    """contiguous band ranges [lo, hi) per rank, at least one band each, whose weights are as even as a prefix split gets"""
+    nb, total = len(weights), float(sum(weights))
+    cuts, acc, b = [0], 0.0, 0
+    for r in range(1, world):
+        target = total * r / world
+        lo_min, hi_max = cuts[-1] + 1, nb - (world - r)
+        while b < hi_max and (b < lo_min or acc + 0.5 * weights[b] < target):
+            acc += weights[b]
+            b += 1
+        cuts.append(b)
+    cuts.append(nb)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
 def kernel_rows(prof, precond, cells_fluid, traffic, fused_search):
     """per kernel class: launch time and the byte counts -> GB/s"""
     rows = {}
@@ -474,32 +491,67 @@ def main():
     if world > 1:
         torch.cuda.set_device(local_rank)
     rows = sharded and world > 1 and args.slab == "rows"      # true row slabs: this process holds its rows only
-    free_before = torch.cuda.mem_get_info()[0]
-    sim = ea.Simulation(GX, GY, device=local_rank, dot_mode=dot_mode, precond=PC[args.precond], tile_records=args.tile_records, tol=tol,
-                        slab=(rank, world) if rows else None)
-    hbm_per_rank = free_before - torch.cuda.mem_get_info()[0]
-    comm = None
-    p2p_on = False
-    if sharded:
-        from euler_amd.slab import SLAB_EXACT, SLAB_LOCAL, RcclComm, TorchComm, attach_p2p
-        coupling = SLAB_EXACT if args.slab == "exact" else SLAB_LOCAL
-        if args.comm == "rccl":
-            from euler_amd.slab import RcclUnavailable
-            try:
-                comm = RcclComm(sim, coupling)
-            except RcclUnavailable as e:          # raised on every rank alike: the job goes on over torch.distributed, and says so
-                if rank == 0:
-                    print("bench: %s; exchanges fall back to torch.distributed callbacks" % e, file=sys.stderr)
-                args.comm = "torch"
-        if args.comm == "torch":
-            comm = TorchComm(sim, coupling)
-        p2p_on = args.p2p and attach_p2p(sim)
-        if rank == 0 and args.p2p and not p2p_on:
-            print("bench: peer-to-peer mailboxes unavailable (%s); exchanges stay on %s" % (sim._p2p_error, args.comm), file=sys.stderr)
     tiles = GY // N
-    load_workload(sim, scenarios, args.workload, tiles)
     saturate = args.workload == "half_tank" and args.preroll == "auto"
-    preroll = preroll_into_solves(sim, args.max_preroll, saturate)
+    comm_note = []
+
+    def make_sim(slab_arg):
+        """create a handle (the whole grid, or this rank's slab), attach the exchanges, load the workload"""
+        free_before = torch.cuda.mem_get_info()[0]
+        sm = ea.Simulation(GX, GY, device=local_rank, dot_mode=dot_mode, precond=PC[args.precond], tile_records=args.tile_records, tol=tol,
+                           slab=slab_arg)
+        hbm = free_before - torch.cuda.mem_get_info()[0]
+        cm, p2p = None, False
+        if sharded:
+            from euler_amd.slab import SLAB_EXACT, SLAB_LOCAL, RcclComm, TorchComm, attach_p2p
+            coupling = SLAB_EXACT if args.slab == "exact" else SLAB_LOCAL
+            if args.comm == "rccl":
+                from euler_amd.slab import RcclUnavailable
+                try:
+                    cm = RcclComm(sm, coupling)
+                except RcclUnavailable as e:          # raised on every rank alike: the job goes on over torch.distributed, and says so
+                    if rank == 0:
+                        print("bench: %s; exchanges fall back to torch.distributed callbacks" % e, file=sys.stderr)
+                    args.comm = "torch"
+            if args.comm == "torch":
+                cm = TorchComm(sm, coupling)
+            p2p = args.p2p and attach_p2p(sm)
+            if rank == 0 and args.p2p and not p2p and not comm_note:
+                comm_note.append(1)
+                print("bench: peer-to-peer mailboxes unavailable (%s); exchanges stay on %s" % (sm._p2p_error, args.comm), file=sys.stderr)
+        load_workload(sm, scenarios, args.workload, tiles)
+        return sm, cm, p2p, hbm
+
+    slab_arg, partition, preroll = ((rank, world) if rows else None), None, None
+    if rows and args.scaling == "strong" and args.partition == "auto":
+        # ONE picture over all ranks: even row slabs leave the ranks above (or below) the water with air.  A pilot pass with even
+        # slabs runs the untimed preroll, every rank reports the fluid cells of its bands, and the timed pass is created with
+        # band ranges that balance them (euler_config.slab_band_lo / hi) and pre-rolled by the same number of frames.
+        import numpy as np
+        pilot, pcomm, _, _ = make_sim(slab_arg)
+        preroll = preroll_into_solves(pilot, args.max_preroll, saturate)
+        r0, r1 = pilot.slab_rows()
+        fl_rows = (pilot.get(ea.F_COUNT) > 0).sum(axis=1)                # own rows
+        mine = [[(r0 + k) // 64, int(fl_rows[k:k + 64].sum())] for k in range(0, r1 - r0, 64)]
+        if pcomm is not None and pcomm.error:
+            raise RuntimeError(pcomm.error)
+        pilot.close()
+        del pilot, pcomm
+        allb = [None] * world
+        grp.dist.all_gather_object(allb, mine)
+        nb = (GY + 63) // 64
+        weights = [0.02 * 64 * GX] * nb                                  # an air cell costs a few dozen bytes per substep, a fluid cell ~9 KB
+        for lst in allb:
+            for bnd, cnt in lst:
+                weights[bnd] += cnt
+        partition = balanced_partition(weights, world)
+        slab_arg = (rank, world, partition[rank][0], partition[rank][1])
+    sim, comm, p2p_on, hbm_per_rank = make_sim(slab_arg)
+    if preroll is None:
+        preroll = preroll_into_solves(sim, args.max_preroll, saturate)
+    else:
+        for _ in range(preroll):
+            sim.step()
     if args.pmc_child:
         sim.copy_bandwidth(1 << 30, 2)     # the calibration launches of pmc_live(): a known 2^30 bytes read and written each
 
@@ -509,6 +561,14 @@ def main():
         raise RuntimeError(comm.error)
     cells = GX * GY
     job_rate = (cells * args.steps / t["elapsed"]) if sharded else whole_job_rate(float(cells), args.steps, t["elapsed"], grp)
+    balance = None
+    if rows:
+        per_rank = [None] * world
+        grp.dist.all_gather_object(per_rank, [int(sim.stats().fluid_cells), list(sim.slab_rows())])
+        fl = [p[0] for p in per_rank]
+        balance = {"partition": "fluid-balanced band ranges (from a pilot pass with even slabs)" if partition else "even rows",
+                   "rows_per_rank": [p[1] for p in per_rank], "fluid_cells_per_rank": fl,
+                   "max_over_mean": round(max(fl) / max(sum(fl) / len(fl), 1.0), 3)}
     if rank != 0:
         grp.close()
         return
@@ -654,9 +714,9 @@ def main():
     pc_name = "tile-local IC(0): no coupling between slabs" if args.precond == "ic0_tile" else ("slab-local" if rows else args.slab) + " IC(0) coupling"
     parallelism = "1 GPU" if args.gpus == 1 and not sharded else (
         "%d independent replicas" % args.gpus if not sharded else
-        ("%d row slabs of %d rows, EVERY stage decomposed (each rank holds its rows + ghost rows and the markers inside them: %.2f GB of HBM "
+        ("%d row slabs of %s rows, EVERY stage decomposed (each rank holds its rows + ghost rows and the markers inside them: %.2f GB of HBM "
          "per rank; ghost rows, marker migration, dt all-reduce, distributed PCG with %s; exchanges by %s); grid %dx%d"
-         % (args.gpus, GY // max(world, 1), hbm_per_rank / 1e9, pc_name, transports, GX, GY)) if rows else
+         % (args.gpus, ("fluid-balanced numbers of" if partition else str(GY // max(world, 1))), hbm_per_rank / 1e9, pc_name, transports, GX, GY)) if rows else
         "%d row slabs of %d rows: distributed PCG (%s, exchanges by %s), replicated marker/advection stages; grid %dx%d"
         % (args.gpus, GY // max(world, 1), pc_name, transports, GX, GY))
     out = {
@@ -681,6 +741,7 @@ def main():
         "markers": head["markers"], "fluid_cells": head["fluid_cells"], "hbm_bytes_this_rank": int(hbm_per_rank),
         "roofline": head["roofline"],
         "pcg_iteration": head["pcg_iteration"],
+        "balance": balance,
         "kernels": head["kernels"],
         "cpu_baseline": cpu_obj,
         "secondary": secondary or None,

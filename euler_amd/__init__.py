@@ -48,7 +48,7 @@ class Config(C.Structure):
         ("sweep_mode", C.c_int32), ("max_substeps", C.c_int32), ("frame_time", C.c_float),
         ("viscosity", C.c_float), ("pcg_poll_interval", C.c_int32), ("rainbow", C.c_int32),
         ("precond_tile_records", C.c_int32), ("slab_rank", C.c_int32), ("slab_nranks", C.c_int32),
-        ("reserved", C.c_int32 * 4),
+        ("slab_band_lo", C.c_int32), ("slab_band_hi", C.c_int32), ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -272,8 +272,10 @@ class Simulation:
         cfg.viscosity = viscosity            # extension: 0 = the inviscid reference
         cfg.rainbow = int(rainbow)           # args_t.rainbow (main.c:54): carry and advect the dye fields
         cfg.precond_tile_records = tile_records  # PRECOND_IC0_TILE: records per tile, 8 / 16 / 32 (0 = default 16)
-        if slab is not None:                 # (rank, nranks): row slabs for every stage, this process holds one slab only
-            cfg.slab_rank, cfg.slab_nranks = slab
+        if slab is not None:                 # (rank, nranks[, band_lo, band_hi]): row slabs for every stage, this process holds one slab only
+            cfg.slab_rank, cfg.slab_nranks = slab[0], slab[1]
+            if len(slab) == 4:               # an explicit (fluid-balanced) partition instead of the even split
+                cfg.slab_band_lo, cfg.slab_band_hi = slab[2], slab[3]
         self.slab = slab if slab is not None and slab[1] >= 1 else None
         self.cfg = cfg
         self.X, self.Y = X, Y

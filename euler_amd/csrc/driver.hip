@@ -232,6 +232,17 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
     }
     S->band_lo = (int)((int64_t)nbands * cfg->slab_rank / cfg->slab_nranks);
     S->band_hi = (int)((int64_t)nbands * (cfg->slab_rank + 1) / cfg->slab_nranks);
+    if (cfg->slab_band_hi > cfg->slab_band_lo || cfg->slab_band_lo != 0) {      // an explicit partition (include/euler.h)
+      const int lo = cfg->slab_band_lo, hi = cfg->slab_band_hi;
+      const bool first = cfg->slab_rank == 0, last = cfg->slab_rank + 1 == cfg->slab_nranks;
+      if (lo < 0 || hi <= lo || hi > nbands || (first && lo != 0) || (last && hi != nbands) || (!first && lo < cfg->slab_rank) ||
+          (!last && nbands - hi < cfg->slab_nranks - 1 - cfg->slab_rank)) {
+        eu_set_error("euler_create: slab rank %d of %d cannot own bands [%d, %d) of %d (every rank needs a band; the ranges tile the grid in rank order)",
+                     cfg->slab_rank, cfg->slab_nranks, lo, hi, nbands);
+        free(S); return EULER_EINVAL;
+      }
+      S->band_lo = lo; S->band_hi = hi;
+    }
     if (S->cfg.dot_mode == EULER_DOT_SEQUENTIAL) S->cfg.dot_mode = EULER_DOT_TREE;   // the replay order is a 1-rank notion
   } else { S->band_lo = 0; S->band_hi = nbands; }
   S->row_lo = 64 * S->band_lo; S->row_hi = 64 * S->band_hi < S->Y ? 64 * S->band_hi : S->Y;
@@ -489,7 +500,7 @@ int eu_install_comm(euler_sim* S, const euler_comm_ops* ops, int32_t coupling, i
       return EULER_EINVAL;
     }
     S->comm = *ops; S->bulk = *ops; S->has_comm = 1; S->couple = 0;
-    return EULER_OK;
+    return eu_slab_check_partition(S);      // the ranks' band ranges tile the grid (explicit partitions: euler_config.slab_band_lo / hi)
   }
   if (!ops || ops->nranks < 1 || (ops->nranks == 1 && !allow_single)) {
     S->has_comm = 0; S->band_lo = 0; S->band_hi = S->geom.nbands; S->e_lo = 0; S->e_cnt = S->geom.S;

@@ -252,6 +252,7 @@ void eu_slab_release(euler_sim* S);
 int  eu_slab_substep(euler_sim* S, float dt);
 int  eu_slab_timestep(euler_sim* S, float frame_time_left);
 int  eu_slab_after_load(euler_sim* S);
+int  eu_slab_check_partition(euler_sim* S);   // collective: the ranks' band ranges tile the grid
 int  eu_slab_exchange_uv(euler_sim* S);     // ghost rows of u, v (euler_set_field on a slab handle)
 // launch groups implemented in the kernel files
 int eu_launch_timestep(euler_sim* S, float frame_time_left);

@@ -28,6 +28,7 @@
 // raises a sticky device error (EULER_ESTATE at the next sync) instead of corrupting anything.
 #include "euler_dev.h"
 
+#include <cstdio>
 #include <vector>
 
 #define SL_EV_CAP 1024        // dt-chain candidates per rank and substep (they are rare: a marker must hit a solid after crossing a cell)
@@ -47,6 +48,7 @@ struct SlabScratch {
   size_t mig_cap, buf_doubles;    // migrants per direction; size of each of the four neighbour buffers in doubles
   double *send_lo, *send_hi, *recv_lo, *recv_hi;
   double* vec;                    // [R + 8] small all-reduce vector
+  double* vec2;                   // [2 R] the partition check
   unsigned long long* mask2;      // second marker bit mask (local removals)
   std::vector<int64_t> ag_off, ag_cnt;
   unsigned long long global_sources;   // source cells of all ranks (fixed by the scenario)
@@ -80,6 +82,7 @@ int eu_slab_alloc(euler_sim* S) {
     HIPCHK(hipMemset(*b, 0, s->buf_doubles * 8));
   }
   HIPCHK(hipMalloc((void**)&s->vec, (SL_MAXR + 8) * 8));
+  HIPCHK(hipMalloc((void**)&s->vec2, 2 * SL_MAXR * 8));
   HIPCHK(hipMalloc((void**)&s->mask2, ((S->max_markers + 63) / 64) * 8));
   s->ag_off.resize(s->R); s->ag_cnt.resize(s->R);
   for (int r = 0; r < s->R; ++r) { s->ag_off[r] = (int64_t)r * (int64_t)s->blk; s->ag_cnt[r] = (int64_t)s->blk; }
@@ -89,10 +92,39 @@ int eu_slab_alloc(euler_sim* S) {
 void eu_slab_release(euler_sim* S) {
   SlabScratch* s = S->slab;
   if (!s) return;
-  void* dev[] = {s->xg, s->sortbuf, s->ev_th, s->ev_de, s->d_sorted, s->send_lo, s->send_hi, s->recv_lo, s->recv_hi, s->vec, s->mask2};
+  void* dev[] = {s->xg, s->sortbuf, s->ev_th, s->ev_de, s->d_sorted, s->send_lo, s->send_hi, s->recv_lo, s->recv_hi, s->vec, s->vec2, s->mask2};
   for (void* p : dev) if (p) (void)hipFree(p);
   delete s;
   S->slab = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------ the partition
+// Collective, at communicator install: every rank deposits its band range in an all-reduced vector and checks that the ranges tile
+// [0, nbands) in rank order - an explicit partition (euler_config.slab_band_lo / hi) is the caller's, and a gap or an overlap
+// would silently lose rows.
+__global__ void k_partition_fill(double* v, int R, int rank, int lo, int hi) {
+  for (int k = threadIdx.x; k < 2 * R; k += blockDim.x) v[k] = 0.0;
+  __syncthreads();
+  if (threadIdx.x == 0) { v[rank] = (double)lo; v[R + rank] = (double)hi; }
+}
+int eu_slab_check_partition(euler_sim* S) {
+  SlabScratch* s = S->slab;
+  if (!s || s->R < 2) return EULER_OK;
+  hipLaunchKernelGGL(k_partition_fill, dim3(1), dim3(64), 0, S->stream, s->vec2, s->R, s->rank, S->band_lo, S->band_hi);
+  COMM_CALL(S->comm.allreduce(S->comm.ctx, s->vec2, 2 * s->R, 0));
+  double h[2 * SL_MAXR];
+  HIPCHK(hipMemcpyAsync(h, s->vec2, sizeof(double) * 2 * s->R, hipMemcpyDeviceToHost, S->stream));
+  HIPCHK(hipStreamSynchronize(S->stream));
+  bool ok = h[0] == 0.0 && h[2 * s->R - 1] == (double)S->geom.nbands;
+  for (int r = 0; r < s->R; ++r) ok = ok && h[s->R + r] > h[r] && (r == 0 || h[r] == h[s->R + r - 1]);
+  if (!ok) {
+    char txt[256]; int n = 0;
+    for (int r = 0; r < s->R && n < 230; ++r) n += snprintf(txt + n, sizeof txt - n, " [%d,%d)", (int)h[r], (int)h[s->R + r]);
+    eu_set_error("row slabs: the ranks' band ranges do not tile the %d bands in rank order:%s", S->geom.nbands, txt);
+    S->has_comm = 0;
+    return EULER_EINVAL;
+  }
+  return EULER_OK;
 }
 
 // ------------------------------------------------------------------------------------------ ghost rows

@@ -90,7 +90,11 @@ typedef struct euler_config {
                                    owned rows (euler_get_field), markers as the local ones with their global array index
                                    (EULER_F_MARKER_KEYS); euler_set_field(U / V) takes the own rows and is COLLECTIVE (it refreshes the
                                    neighbours' ghost rows).  Needs EULER_PRECOND_IC0_TILE or slab-local IC(0) coupling. */
-  int32_t reserved[4];
+  int32_t slab_band_lo, slab_band_hi; /* row slabs: this rank's 64-row bands [lo, hi) given explicitly (hi > lo) instead of the even split
+                                   nbands * rank / nranks - for partitions that balance the FLUID (a dam break settles into the
+                                   lowest third of the tank: even row slabs leave most ranks with air).  The ranks' ranges must tile
+                                   [0, nbands) in rank order; euler_set_comm* checks it against the neighbours.  0, 0 = even split. */
+  int32_t reserved[2];
 } euler_config;
 
 typedef struct euler_sim euler_sim; /* opaque */

@@ -43,7 +43,12 @@ def main():
         torch.cuda.set_device(0)
     rank, world = dist.get_rank(), dist.get_world_size()
     ref = load(ea.Simulation(X, Y, device=local, dot_mode=ea.DOT_TREE, precond=precond), workload)       # single GPU, the whole grid
-    sim = ea.Simulation(X, Y, device=local, dot_mode=ea.DOT_TREE, precond=precond, slab=(rank, world))   # one slab
+    slab = (rank, world)
+    for a in sys.argv[6:]:
+        if a.startswith("bands="):            # an explicit partition, "0-1,1-3,3-8": band ranges per rank (euler_config.slab_band_lo / hi)
+            lo, hi = a[6:].split(",")[rank].split("-")
+            slab = (rank, world, int(lo), int(hi))
+    sim = ea.Simulation(X, Y, device=local, dot_mode=ea.DOT_TREE, precond=precond, slab=slab)   # one slab
     comm = RcclComm(sim, SLAB_LOCAL) if rccl else TorchComm(sim, SLAB_LOCAL)
     out = {"world": world, "frames": []}
     if p2p:

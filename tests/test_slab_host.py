@@ -66,3 +66,28 @@ def test_stacked_half_tanks_are_copies_of_the_single_tank():
         assert np.array_equal(sink, ring)                                        # sinks only on the grid's border (main.c:244-252)
         assert (solid[[k * H for k in range(1, tanks)], 1:-1] == 1).all()        # closed where two tanks meet
     assert L.euler_half_tanks_grids(X, 100, 3, *[a.ctypes.data for a in one]) != 0  # rows must divide
+
+
+def test_fluid_balanced_partition_tiles_the_grid():
+    """bench.py's band ranges for a strong-scaling run: contiguous, in rank order, at least one band each, and as even in weight as a
+    prefix split over whole bands gets (euler_config.slab_band_lo / hi take them; euler_set_comm* verifies the tiling again)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rng = np.random.default_rng(11)
+    for nb, world in ((4, 4), (16, 4), (256, 8), (100, 7), (9, 8)):
+        for trial in range(20):
+            settled = rng.integers(1, nb + 1)                       # water in the lowest `settled` bands, air above
+            w = [1.02 if b < settled else 0.02 for b in range(nb)]
+            if trial % 3 == 0:
+                w = list(rng.random(nb) + 0.02)
+            part = bench.balanced_partition(w, world)
+            assert len(part) == world and part[0][0] == 0 and part[-1][1] == nb
+            assert all(hi > lo for lo, hi in part) and all(part[r][1] == part[r + 1][0] for r in range(world - 1))
+            loads = [sum(w[lo:hi]) for lo, hi in part]
+            # no rank carries more than the ideal share plus one band's worth (a band cannot be split)
+            assert max(loads) <= sum(w) / world + max(w) + 1e-9 or nb - world < 2, (nb, world, part, loads)
+    even = bench.balanced_partition([1.0] * 256, 8)
+    assert even == [(32 * r, 32 * r + 32) for r in range(8)]

@@ -34,6 +34,7 @@ def run(nproc, X, Y, workload, frames, precond, port, extra=()):
     (3, 200, 330, "waterfall", 30, ea.PRECOND_IC0_TILE, ()),          # sources (RNG stream split over ranks), sinks (deletions re-key)
     (2, 320, 256, "golden:weird-edges", 30, ea.PRECOND_IC0_TILE, ()),
     (2, 256, 256, "waterfall", 20, ea.PRECOND_IC0, ()),               # slab-local IC(0): another preconditioner than 1 GPU (tolerance where converged)
+    (3, 256, 512, "dam_break", 40, ea.PRECOND_IC0_TILE, ("bands=0-1,1-3,3-8",)),   # an explicit, uneven partition (fluid-balanced slabs)
 ])
 def test_row_slabs_reproduce_the_single_gpu_run(nproc, X, Y, workload, frames, precond, extra):
     d = run(nproc, X, Y, workload, frames, precond, 29581, extra)
@@ -115,3 +116,14 @@ def test_swap_with_last_deletion_across_ranks(nproc, X, Y):
     assert ev["n_markers"][0] == ev["n_markers"][1] < ev["n_markers"][2] - 100, ev["n_markers"]
     assert ev["dt_events"][0] == ev["dt_events"][1]
     assert ev["markers_at_keys"] and ev["keys_are_a_permutation"] and ev["count_differ"] == 0, ev
+
+
+@pytest.mark.gpu
+def test_a_partition_with_a_gap_is_refused():
+    """explicit band ranges that do not tile the grid are caught collectively when the communicator is installed"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29587",
+           os.path.join(ROOT, "tests", "slab_rows_worker.py"), "256", "512", "dam_break", "1", str(ea.PRECOND_IC0_TILE), "bands=0-3,4-8"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode != 0
+    assert "do not tile" in out.stderr, out.stderr[-2000:]
