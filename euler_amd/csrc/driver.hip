@@ -163,7 +163,7 @@ extern "C" void euler_destroy(euler_sim* S) {
   for (uint8_t* g : {S->solid, S->source, S->sink, S->count, S->prev_count}) if (g) (void)hipFree(g + wo);
   if (S->count32) (void)hipFree(S->count32);
   void* dev[] = {S->markers[0], S->markers[1], S->keys[0], S->keys[1], S->ms, S->evmask, S->ev_theta, S->ev_delta, S->sel_idx, S->act_idx,
-                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->halo_buf, S->band_ranges, S->partial2, S->pair_buf, S->rng_jump,
+                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->halo_buf, S->band_ranges, S->partial2, S->pair_buf, S->rng_jump, S->chunk_flag, S->chunk_bits, S->chunk_list,
                  S->rowmajor_tmp};
   for (void* p : dev) if (p) (void)hipFree(p);
   for (float* d : S->dye) if (d) (void)hipFree(d);
@@ -300,6 +300,11 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   DALLOC(S->partial, (size_t)S->red_blocks > 2048 ? (size_t)S->red_blocks : 2048);
   DALLOC(S->partial2, 2048);
   DALLOC(S->pair_buf, 2 * 64);
+  S->chunk_cap = (size_t)(S->band_hi - S->band_lo) * (S->geom.T / 16);
+  S->chunk_words = (S->chunk_cap + 63) / 64;
+  DALLOC(S->chunk_flag, S->chunk_cap + 64);
+  DALLOC(S->chunk_bits, S->chunk_words + 1);
+  DALLOC(S->chunk_list, S->chunk_cap + 64);
   {   // xorshift64* jump-ahead: M^(2^i) as the images of the 64 basis vectors, i < EU_RNG_JUMPS (euler_dev.h)
     RngJump* J = (RngJump*)malloc(sizeof(RngJump));
     if (!J) { euler_destroy(S); return EULER_ENOMEM; }

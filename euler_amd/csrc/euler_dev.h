@@ -44,6 +44,7 @@ struct PcgScalars {
   int done;      // inf_norm(r) <= tol reached (main.c:756)
   int iters;     // apply_a calls so far (main.c:750)
   int max_iters;
+  unsigned int n_chunks, pad_;   // active 16-record chunks of this solve (euler_sim.chunk_list)
   // peer-to-peer mailboxes (comm_p2p.hip), set once by euler_p2p_connect and never reset: the mapped mailboxes of all
   // ranks, this rank, and the DEVICE-side exchange counters (only exchanges that really run count, so that the tags of
   // all ranks stay in step although launches after convergence return at once)
@@ -157,6 +158,13 @@ struct euler_sim {
   int tile_w;             // EULER_PRECOND_IC0_TILE: records per tile (include/euler.h precond_tile_records)
   double* partial2;       // second set of reduction partials (k_precond_tile reduces max |r| and dot(z,r) at once)
   struct RngJump* rng_jump;   // xorshift64* jump-ahead matrices (device)
+  // Active chunks of a solve: a chunk = 16 consecutive records of a band = one tile of the tile-local preconditioner (W = 16) = one
+  // run of k_search_apply (8 pair-records).  k_build_system flags every chunk that holds fluid (a byte each, packed to bits), an ordered select turns the bits
+  // into the ascending list both kernels walk - no wave reads the masks of an empty chunk, and a listed chunk's masks travel with its data.
+  uint8_t* chunk_flag;
+  unsigned long long* chunk_bits;
+  unsigned int* chunk_list;
+  size_t chunk_words, chunk_cap;
   double* pair_buf;       // [ranks][2]: every rank's {max |r|, dot(z,r)} of one iteration, exchanged by ONE all-gather (tile-local mode without mailboxes)
   double* rowmajor_tmp;   // lazily allocated C doubles for euler_get/set_field of skewed arrays
   PcgScalars* sc;

@@ -212,10 +212,11 @@ __global__ __launch_bounds__(256) void k_build_system(const float* __restrict__ 
                                                       double* __restrict__ b, double* __restrict__ r, double* __restrict__ p,
                                                       double* __restrict__ q, double* __restrict__ z,
                                                       uint8_t* __restrict__ cellmask,
-                                                      PcgScalars* sc, SkewGeom g, float dt, size_t e_lo, size_t e_cnt) {
+                                                      PcgScalars* sc, SkewGeom g, float dt, size_t e_lo, size_t e_cnt,
+                                                      uint8_t* __restrict__ chunk_flag) {
   // eu_xcd_block: the 16 diagonal steps that share a 64-byte line of a row-major field meet in ONE L2 instead of in all eight
   const size_t e = e_lo + eu_xcd_block() * blockDim.x + threadIdx.x;   // this rank's bands only
-  bool nz = false;
+  bool nz = false, fl = false;
   if (e < e_lo + e_cnt) {
     const int X = g.X;
     int band, t, l;
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(256) void k_build_system(const float* __restrict__ 
       double bv = 0.0;
       if (count[i] != 0) {   // never true on the border ring (sinks), so the +-1 / +-X reads are in range
         m = CM_FLUID;
+        fl = true;
         if (count[i + 1]) m |= CM_RIGHT;
         if (count[i + X]) m |= CM_UP;
         if (count[i - 1]) m |= CM_LEFT;
@@ -246,7 +248,29 @@ __global__ __launch_bounds__(256) void k_build_system(const float* __restrict__ 
       z[e] = 0.0;
     }
   }
-  if (__any(nz) && (threadIdx.x & 63) == 0) atomicOr(&sc->nonzero, 1);
+  // !all_zero(r), main.c:742.  Once the flag is up nobody has to raise it again: in a moving fluid EVERY wave finds a nonzero b, and
+  // half a million atomic ORs on one address took 3.4 of the kernel's 5.1 ms at 8192^2 (at rest, where b is mostly zero, none)
+  if (__any(nz) && (threadIdx.x & 63) == 0 && __hip_atomic_load(&sc->nonzero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+    atomicOr(&sc->nonzero, 1);
+  // the wave's 64 elements are two records of one 16-record chunk (euler_dev.h "Active chunks"): one bit says it holds fluid
+  if (__any(fl) && (threadIdx.x & 63) == 0) {
+    const size_t we = e_lo + eu_xcd_block() * blockDim.x + (threadIdx.x & ~63u);      // the wave's first element
+    const size_t per_band = (size_t)g.TS * 64;
+    const size_t chunk = ((we - e_lo) / per_band) * (size_t)(g.T / 16) + ((we % per_band) / 64) / 16;
+    chunk_flag[chunk] = 1;      // (a plain store: every wave of the chunk writes the same byte; an atomic OR into shared words cost 3 ms)
+  }
+}
+
+// one bit per chunk from the bytes k_build_system left (the ordered select wants bits)
+__global__ __launch_bounds__(256) void k_pack_chunk_bits(const uint8_t* __restrict__ flag, unsigned long long* __restrict__ bits, size_t nwords, size_t nchunks) {
+  const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nwords) return;
+  unsigned long long v = 0;
+  for (int k = 0; k < 64; ++k) {
+    const size_t c = w * 64 + k;
+    if (c < nchunks && flag[c]) v |= 1ull << k;
+  }
+  bits[w] = v;
 }
 
 // Pressure clamp (main.c:773-779) + velocity update (main.c:782-805), fused.  The clamp is
@@ -293,8 +317,13 @@ __global__ __launch_bounds__(256) void k_velocity_update(const float* __restrict
 int eu_launch_band_ranges(euler_sim* S);
 
 int eu_launch_build_system(euler_sim* S, float dt) {
+  HIPCHK(hipMemsetAsync(S->chunk_flag, 0, S->chunk_cap + 64, S->stream));
   LAUNCH(S, KC_BUILD_SYSTEM, k_build_system, dim3(eu_blocks(S->e_cnt, 256)), dim3(256), S->utmp, S->vtmp, S->count,
-         S->solid, S->b, S->r, S->p, S->q, S->z, S->cellmask, S->sc, S->geom, dt, S->e_lo, S->e_cnt);
+         S->solid, S->b, S->r, S->p, S->q, S->z, S->cellmask, S->sc, S->geom, dt, S->e_lo, S->e_cnt, S->chunk_flag);
+  LAUNCH(S, KC_BUILD_SYSTEM, k_pack_chunk_bits, dim3(eu_blocks(S->chunk_words, 256)), dim3(256), S->chunk_flag, S->chunk_bits, S->chunk_words, S->chunk_cap);
+  // the ascending list of this solve's active chunks (k_search_apply, k_precond_tile)
+  int rc = eu_ordered_select(S, S->chunk_bits, S->chunk_words, S->chunk_list, &S->sc->n_chunks);
+  if (rc) return rc;
   return eu_launch_band_ranges(S);
 }
 

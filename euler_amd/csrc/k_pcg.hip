@@ -323,7 +323,8 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
                                                              const uint8_t* __restrict__ mask, SkewGeom g,
                                                              double* __restrict__ partial, PcgScalars* sc, int force,
                                                              unsigned int* counter, int fin_op, SlabNeighbours nbr,
-                                                             double* __restrict__ p, double* s_new_base) {
+                                                             double* __restrict__ p, double* s_new_base,
+                                                             const unsigned int* __restrict__ chunk_list) {   // SA_RUN == 8 only: the solve's active runs
   if (!force && pcg_idle(sc)) return;
   const double beta = sc->beta;
   const double alpha_prev = sc->alpha;     // of the previous iteration: this launch's own alpha is written by its LAST block
@@ -335,8 +336,14 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
   const int n_waves = gridDim.x * (SA_THREADS / 64);
   const bool edge_lane = lane == 0 || lane == 63;
   double t = 0.0;
-  for (int c = blockIdx.x * (SA_THREADS / 64) + (threadIdx.x >> 6); c < total; c += n_waves) {
-    const int lb = c / cpb, P0 = (c % cpb) * SA_RUN, P1 = P0 + SA_RUN < npairs ? P0 + SA_RUN : npairs;
+  // with the list of active chunks (euler_dev.h) a wave never visits an empty run, and a run's masks are loaded with its data
+  const bool listed = chunk_list != nullptr;
+  const int ntb16 = g.T / 16;
+  const int todo = listed ? (int)sc->n_chunks : total;
+  for (int i = blockIdx.x * (SA_THREADS / 64) + (threadIdx.x >> 6); i < todo; i += n_waves) {
+    int c = i, per = cpb;
+    if (listed) { c = (int)chunk_list[i]; per = ntb16; }
+    const int lb = c / per, P0 = (c % per) * SA_RUN, P1 = P0 + SA_RUN < npairs ? P0 + SA_RUN : npairs;
     const size_t bbase = (size_t)lb * TS * 64 + 2 * lane;     // element (band, record 0, lane)
     // the cell masks of the run; a run without fluid is skipped whole
     unsigned int mm[SA_RUN];
@@ -346,7 +353,7 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
       mm[j] = P0 + j < P1 ? (unsigned int)*reinterpret_cast<const unsigned short*>(mask + bbase + (size_t)(P0 + j) * 128) : 0u;
       any |= mm[j];
     }
-    if (!__ballot(((any | (any >> 8)) & CM_FLUID) != 0)) continue;
+    if (!listed && !__ballot(((any | (any >> 8)) & CM_FLUID) != 0)) continue;
     // where lane 0 / lane 63 find the row below / above their band (the adjacent band's lane 63 / lane 0), relative to pair 0:
     // even element (record 2P):  below = record 2P + 63 of band - 1, above = record 2P - 63 of band + 1; odd element: + 1
     const bool up_remote = SLAB && nbr.z_up && lb + 1 == nb_local, dn_remote = SLAB && nbr.z_dn && lb == 0;
@@ -1124,6 +1131,7 @@ struct TileArgs {
   int via;                // 0 single rank, FIN_VIA_P2P, or FIN_TO_COMM (multi-rank: how the two results reach the other ranks)
   double* part_max; double* part_dot;
   unsigned int* counter;
+  const unsigned int* list;   // W == 16 inside a solve: the ascending list of active tiles (euler_dev.h "Active chunks"), else null
   PcgScalars* sc;
   int force;
   double alpha_arg;       // force: alpha of the r update (single building block, tests)
@@ -1188,14 +1196,17 @@ __global__ __launch_bounds__(PT_THREADS) void k_precond_tile(TileArgs a) {
   const int n_waves = gridDim.x * (PT_THREADS / 64);
   const double nalpha = -(a.force ? a.alpha_arg : a.sc->alpha);
   double mx = 0.0, dsum = 0.0;
-  for (int tile = blockIdx.x * (PT_THREADS / 64) + (threadIdx.x >> 6); tile < total; tile += n_waves) {
+  const bool listed = W == 16 && a.list != nullptr;
+  const int todo = listed ? (int)a.sc->n_chunks : total;
+  for (int i = blockIdx.x * (PT_THREADS / 64) + (threadIdx.x >> 6); i < todo; i += n_waves) {
+    const int tile = listed ? (int)a.list[i] : i;
     const int band = a.band_lo + tile / ntb, k = tile % ntb;
     const size_t base = ((size_t)band * a.g.TS + (size_t)k * W) * 64 + 2 * lane;
     unsigned int mm[W / 2];
     unsigned int any = 0;
 #pragma unroll
     for (int P = 0; P < W / 2; ++P) { mm[P] = *reinterpret_cast<const unsigned short*>(a.mask + base + P * 128); any |= mm[P]; }
-    if (!__ballot(((any | (any >> 8)) & CM_FLUID) != 0)) continue;     // no fluid in this tile: r, z stay +0 there
+    if (!listed && !__ballot(((any | (any >> 8)) & CM_FLUID) != 0)) continue;     // no fluid in this tile: r, z stay +0 there
     sw_d2 rr[W / 2], qq[W / 2], pp[W / 2];
 #pragma unroll
     for (int P = 0; P < W / 2; ++P) {
@@ -1530,6 +1541,7 @@ static TileArgs make_tile_args(euler_sim* S, int force) {
   a.via = S->has_comm ? (S->p2p_on ? (int)FIN_VIA_P2P : (int)FIN_TO_COMM) : 0;
   a.part_max = S->partial; a.part_dot = S->partial2; a.counter = S->red_counter; a.sc = S->sc; a.force = force; a.alpha_arg = 0.0;
   a.pair_slot = S->pair_buf + 2 * (S->has_comm ? S->comm.rank : 0);
+  a.list = (!force && S->tile_w == 16) ? S->chunk_list : nullptr;      // (forced single operations may run on masks no solve has listed)
   return a;
 }
 static inline unsigned tile_blocks(const euler_sim* S) {
@@ -1645,7 +1657,7 @@ static int launch_search_apply_and_alpha(euler_sim* S) {
   double* sb = pupd ? S->s2 : (double*)nullptr;
 #define SA_LAUNCH(SLABF, PUPDF, RUNV)                                                                                                   \
   LAUNCH(S, KC_APPLY_A, (k_search_apply<SLABF, PUPDF, RUNV>), dim3(sa_blocks(S, RUNV)), dim3(SA_THREADS), LOC(S->s), LOC(S->z), LOC(S->s2), \
-         LOC(S->q), LOC(S->cellmask), gl, S->partial, S->sc, 0, S->red_counter, fin, nbr, pp, sb)
+         LOC(S->q), LOC(S->cellmask), gl, S->partial, S->sc, 0, S->red_counter, fin, nbr, pp, sb, (RUNV) == 8 ? S->chunk_list : (const unsigned int*)nullptr)
   if (direct) {
     if (pupd) { if (run == 8) SA_LAUNCH(true, true, 8); else SA_LAUNCH(true, true, 32); }
     else { if (run == 8) SA_LAUNCH(true, false, 8); else SA_LAUNCH(true, false, 32); }
