@@ -315,8 +315,8 @@ __device__ __forceinline__ double ld_system(const double* p) {
 #define SA_THREADS 256
 struct SaPair { sw_d2 z, so; double ez0, es0, ez1, es1; };   // one pair-record of a lane + the out-of-band vertical neighbours of its two elements
 
-// SA_RUN pair-records per wave: 8 up to 8192^2 (more waves in flight; at 1024^2 runs of 32 would leave 300 waves for 256 CUs),
-// 32 beyond (sa_run)
+// SA_RUN pair-records per wave: 8 (more waves in flight - at 1024^2 runs of 32 would leave 300 waves for 256 CUs - and the granularity
+// of the active-chunk list); 16 / 32 remain for experiments (sa_run)
 template <bool SLAB, bool PUPD, int SA_RUN>   // SLAB: several ranks, the neighbouring slabs' arrays are mapped (nbr); else nbr is ignored
 __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __restrict__ s_old, const double* __restrict__ z,
                                                              double* __restrict__ s_new, double* __restrict__ out,
@@ -1632,8 +1632,9 @@ static inline int sa_run(const euler_sim* S) {   // short runs while long ones w
   static const char* e = getenv("EULER_SA_RUN");      // (experiments)
   if (e && !S->has_comm) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16 || v == 32) return v; }
   // measured (same box, tile-local mode): 8192^2 - 8: 346 us, 16: 358, 32: 376 (113 / 134 / 185 VGPRs: occupancy beats the window's
-  // two extra pair loads per run, which hit L2); 16384^2 - 8: 1412 us, 32: 1389
-  return (size_t)(S->band_hi - S->band_lo) * (S->geom.TS / 2 / 32) < 32768 ? 8 : 32;
+  // two extra pair loads per run, which hit L2); 16384^2, scanning every run's masks - 8: 1412 us, 32: 1389; with the list of active
+  // chunks (runs of 8 only) - 8: 1177 us, 32: 1401
+  return 8;
 }
 // iterations >= 1 of a single-GPU solve: s' = z + beta s and A s' in one launch; returns with S->s = s' and A s' in S->q
 static int launch_search_apply_and_alpha(euler_sim* S) {
