@@ -30,6 +30,30 @@ float euler_rng_next_float(uint64_t* state) {
   return (float)(euler_rng_next_u32(state) / (double)UINT32_MAX);
 }
 
+/* Jump-ahead: the state update is linear over GF(2), so k steps are the 64 x 64 bit matrix M^k; col[i][b] = M^(2^i) e_b.  A row-slab
+ * handle uses it to skip the cells of other ranks' rows while it walks the ONE seeding stream (below). */
+#define RNG_JUMPS 48
+static uint64_t g_jump[RNG_JUMPS][64];
+static int g_jump_ready = 0;
+static uint64_t jump_apply(const uint64_t* col, uint64_t x) {
+  uint64_t y = 0;
+  while (x) { y ^= col[__builtin_ctzll(x)]; x &= x - 1; }
+  return y;
+}
+static void jump_init(void) {
+  if (g_jump_ready) return;
+  for (int b = 0; b < 64; ++b) { uint64_t x = 1ull << b; x ^= x >> 12; x ^= x << 25; x ^= x >> 27; g_jump[0][b] = x; }
+  for (int i = 1; i < RNG_JUMPS; ++i)
+    for (int b = 0; b < 64; ++b) g_jump[i][b] = jump_apply(g_jump[i - 1], g_jump[i - 1][b]);
+  g_jump_ready = 1;
+}
+uint64_t euler_rng_jump(uint64_t state, uint64_t steps) {
+  jump_init();
+  for (int i = 0; steps && i < RNG_JUMPS; ++i, steps >>= 1)
+    if (steps & 1) state = jump_apply(g_jump[i], state);
+  return state;
+}
+
 /* ---- scenario text ---------------------------------------------------------------------- */
 
 static void classify(char c, size_t i, uint8_t* solid, uint8_t* source, uint8_t* sink, uint8_t* fluid) {
@@ -155,9 +179,22 @@ int euler_seed_markers(const uint8_t* fluid, int32_t X, int32_t Y, uint64_t* rng
 int euler_seed_markers_rows(const uint8_t* fluid, int32_t X, int32_t Y, int32_t row_lo, int32_t row_hi, uint64_t* rng_state,
                             float* markers_xy, uint32_t* keys, uint64_t cap, uint64_t* n_total, uint64_t* n_kept) {
   if (!fluid || !rng_state || !n_total || !n_kept) return EULER_EINVAL;
+  /* A cell's markers land in its own row or (a jitter of exactly 0.5) the next one: only the cells of rows [lo2, row_hi) can give
+   * this rank a marker.  The cells below and above them in a column are skipped - 4 keys and 8 draws each - with a jump. */
+  const int32_t lo2 = row_lo > 0 ? row_lo - 1 : 0, hi2 = row_hi < Y ? row_hi : Y;
+  uint32_t* below = (uint32_t*)calloc((size_t)X, sizeof(uint32_t));
+  uint32_t* above = (uint32_t*)calloc((size_t)X, sizeof(uint32_t));
+  if (!below || !above) { free(below); free(above); return EULER_ENOMEM; }
+  for (int32_t cy = 0; cy < lo2; ++cy)
+    for (int32_t cx = 0; cx < X; ++cx) below[cx] += fluid[(size_t)cy * X + cx] != 0;
+  for (int32_t cy = hi2; cy < Y; ++cy)
+    for (int32_t cx = 0; cx < X; ++cx) above[cx] += fluid[(size_t)cy * X + cx] != 0;
   uint64_t n = 0, kept = 0;
-  for (int32_t cx = 0; cx < X; ++cx)
-    for (int32_t cy = 0; cy < Y; ++cy) {
+  int rc = EULER_OK;
+  for (int32_t cx = 0; cx < X && rc == EULER_OK; ++cx) {
+    n += 4ull * below[cx];
+    *rng_state = euler_rng_jump(*rng_state, 8ull * below[cx]);
+    for (int32_t cy = lo2; cy < hi2; ++cy) {
       if (!fluid[(size_t)cy * X + cx]) continue;
       for (int k = 0; k < 4; ++k) {
         float jx = euler_rng_next_float(rng_state) / 2;
@@ -167,14 +204,20 @@ int euler_seed_markers_rows(const uint8_t* fluid, int32_t X, int32_t Y, int32_t 
         const int32_t row = (int32_t)floorf(1.f * my);
         if (row >= row_lo && row < row_hi) {
           if (markers_xy) {
-            if (kept >= cap) return EULER_ENOMEM;
+            if (kept >= cap) { rc = EULER_ENOMEM; break; }
             markers_xy[2 * kept] = 1.f * mx; markers_xy[2 * kept + 1] = 1.f * my; keys[kept] = (uint32_t)n;
           }
           ++kept;
         }
         ++n;
       }
+      if (rc != EULER_OK) break;
     }
+    n += 4ull * above[cx];
+    *rng_state = euler_rng_jump(*rng_state, 8ull * above[cx]);
+  }
+  free(below); free(above);
+  if (rc != EULER_OK) return rc;
   *n_total = n; *n_kept = kept;
   return EULER_OK;
 }
