@@ -395,6 +395,7 @@ def summarize(t, size_x, size_y, precond, tile_w, traffic, traffic_note, steps, 
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": int(tr) if tr else None,
                 "frac_traffic": round(tr / sec / 1e9 / HBM_PEAK_GBPS, 4) if tr else None,
+                "achieved_algorithmic": round(active, 1),      # SURVEY 8d bytes x the fluid cells one launch processes / launch time
                 "frac_active": round(active / HBM_PEAK_GBPS, 4),
                 "frac_dense": round(b * cells / sec / 1e9 / HBM_PEAK_GBPS, 4),
                 "achieved_is": "PMC traffic / launch time" if tr else "algorithmic bytes x fluid cells / launch time (no PMC pass)",
