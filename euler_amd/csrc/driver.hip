@@ -12,6 +12,7 @@
 int eu_launch_build_system(euler_sim* S, float dt);
 int eu_launch_velocity_update(euler_sim* S, float dt);
 int eu_unskew(euler_sim* S, const void* skew, void* rowmajor, int elem_bytes);
+int eu_launch_tile_table(euler_sim* S);
 int eu_skew(euler_sim* S, const void* rowmajor, void* skew, int elem_bytes);
 
 // ------------------------------------------------------------------------------------------
@@ -139,6 +140,7 @@ extern "C" int euler_set_precond(euler_sim* S, int32_t precond, int32_t tile_rec
   int rc = eu_set_tiles(S, tile_records);
   if (rc) return rc;
   S->cfg.precond = precond;
+  S->lean_ok = 0;      // the next assembly writes the solver arrays whole (k_build_system)
   return EULER_OK;
 }
 
@@ -163,7 +165,7 @@ extern "C" void euler_destroy(euler_sim* S) {
   for (uint8_t* g : {S->solid, S->source, S->sink, S->count, S->prev_count}) if (g) (void)hipFree(g + wo);
   if (S->count32) (void)hipFree(S->count32);
   void* dev[] = {S->markers[0], S->markers[1], S->keys[0], S->keys[1], S->ms, S->evmask, S->ev_theta, S->ev_delta, S->sel_idx, S->act_idx,
-                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->halo_buf, S->band_ranges, S->partial2, S->pair_buf, S->rng_jump, S->chunk_flag, S->chunk_bits, S->chunk_list,
+                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->halo_buf, S->band_ranges, S->partial2, S->pair_buf, S->rng_jump, S->chunk_flag, S->chunk_prev, S->chunk_part, S->tile_table, S->chunk_bits, S->chunk_list,
                  S->rowmajor_tmp};
   for (void* p : dev) if (p) (void)hipFree(p);
   for (float* d : S->dye) if (d) (void)hipFree(d);
@@ -303,6 +305,9 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   S->chunk_cap = (size_t)(S->band_hi - S->band_lo) * (S->geom.T / 16);
   S->chunk_words = (S->chunk_cap + 63) / 64;
   DALLOC(S->chunk_flag, S->chunk_cap + 64);
+  DALLOC(S->chunk_prev, S->chunk_cap + 64);
+  DALLOC(S->chunk_part, S->chunk_cap + 64);
+  DALLOC(S->tile_table, 8 * 64 * 2);
   DALLOC(S->chunk_bits, S->chunk_words + 1);
   DALLOC(S->chunk_list, S->chunk_cap + 64);
   {   // xorshift64* jump-ahead: M^(2^i) as the images of the 64 basis vectors, i < EU_RNG_JUMPS (euler_dev.h)
@@ -356,6 +361,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   if (!S->ev_pool || !S->ev_cls || !S->ev_solve || !S->ev_iter) { euler_destroy(S); return EULER_ENOMEM; }
   for (int k = 0; k < S->ev_cap; ++k) CREATECHK(hipEventCreate(&S->ev_pool[k]));
   if (S->slab_on) { int rc = eu_slab_alloc(S); if (rc) { euler_destroy(S); return rc; } }
+  eu_launch_tile_table(S);      // E^-1 of an interior tile (k_pcg.hip), once per handle
   CREATECHK(hipStreamSynchronize(S->stream));
 #undef CREATECHK
   *out = S;
@@ -551,7 +557,7 @@ int eu_sync_marker_state(euler_sim* S) {
   HIPCHK(hipStreamSynchronize(S->stream));
   S->n_markers_host = S->slab_on ? S->ms_host->n_loc : S->ms_host->n;
   if (S->ms_host->error) {
-    if (S->ms_host->error >= 16) { eu_set_error("row slab %d: exchange buffer overflow (code %d: 16 events, 17 migration, 18 deletions, 19 marker capacity)", S->cfg.slab_rank, S->ms_host->error); return EULER_ESTATE; }
+    if (S->ms_host->error >= 16) { eu_set_error("row slabs (seen on rank %d): exchange buffer overflow on some rank (code %d: 16 dt-chain candidates, 17 migration, 18 deletions, 19 marker capacity)", S->cfg.slab_rank, S->ms_host->error); return EULER_ESTATE; }
     eu_set_error("device-side bounded wait expired (band pipeline), error=%d", S->ms_host->error);
     return EULER_ETIMEOUT;
   }
@@ -616,6 +622,7 @@ extern "C" int euler_substep(euler_sim* S, float dt) {
   if (!S || !S->loaded) { eu_set_error("euler_substep: no scenario loaded"); return EULER_ESTATE; }
   int rc = substep_async(S, dt);
   if (rc) return rc;
+  if (S->slab_on && (rc = eu_slab_error_sync(S))) return rc;
   rc = eu_sync_marker_state(S);
   if (rc) return rc;
   account_substep(S, dt);
@@ -641,7 +648,9 @@ extern "C" int euler_step(euler_sim* S) {
     account_substep(S, dt);
     ++nsub;
   }
-  int rc = eu_sync_marker_state(S);
+  int rc = S->slab_on ? eu_slab_error_sync(S) : EULER_OK;      // an overflow on one rank fails the frame on every rank
+  if (rc) return rc;
+  rc = eu_sync_marker_state(S);
   if (rc) return rc;
   if (nsub) { iters += S->sc_host->iters; S->stats.last_residual = S->sc_host->rnorm; }
   S->stats.total_pcg_iterations += (uint64_t)iters;
@@ -653,6 +662,8 @@ extern "C" int euler_step(euler_sim* S) {
 
 extern "C" int euler_pcg_op(euler_sim* S, int32_t op, float dt, double a, double* out) {
   if (!S || !S->loaded) { eu_set_error("euler_pcg_op: no scenario loaded"); return EULER_ESTATE; }
+  // (the single building blocks address the whole grid; a row-slab handle holds a window of it)
+  if (S->slab_on) { eu_set_error("euler_pcg_op: single PCG operations are not exposed on a row-slab handle"); return EULER_ESTATE; }
   return eu_launch_pcg_op(S, op, dt, a, out);
 }
 
@@ -725,8 +736,10 @@ extern "C" int euler_get_field(euler_sim* S, int32_t f, void* dst, size_t dst_by
 
 extern "C" int euler_set_field(euler_sim* S, int32_t f, const void* src, size_t src_bytes) {
   if (!S || !src) return EULER_EINVAL;
-  if (S->slab_on && (f == EULER_F_MARKERS || f == EULER_F_MARKER_KEYS || f == EULER_F_COUNT || f == EULER_F_PREV_COUNT)) {
-    eu_set_error("euler_set_field(%d): a row-slab handle takes its markers and counts from euler_load_scenario_* only", f); return EULER_ESTATE;
+  if (S->slab_on && (f == EULER_F_MARKERS || f == EULER_F_MARKER_KEYS || f == EULER_F_COUNT || f == EULER_F_PREV_COUNT ||
+                     f == EULER_F_SOLID || f == EULER_F_SOURCE || f == EULER_F_SINK)) {
+    // (static grids carry ghost rows and job-wide facts - the number of source cells of all ranks - that only a scenario load sets up)
+    eu_set_error("euler_set_field(%d): a row-slab handle takes its markers, counts and static grids from euler_load_scenario_* / euler_load_state only", f); return EULER_ESTATE;
   }
   if (f == EULER_F_MARKERS) return euler_set_markers(S, (const float*)src, src_bytes / 8);
   void* p; size_t b;
@@ -734,6 +747,7 @@ extern "C" int euler_set_field(euler_sim* S, int32_t f, const void* src, size_t 
   if (rc) return rc;
   if (src_bytes != b) { eu_set_error("euler_set_field(%d): %zu bytes given, %zu expected", f, src_bytes, b); return EULER_EINVAL; }
   if (field_is_skewed(f)) {
+    S->lean_ok = 0;      // a caller's values in the solver arrays: the next assembly writes them whole
     rc = ensure_rowmajor_tmp(S);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(S->rowmajor_tmp, src, b, hipMemcpyHostToDevice, S->stream));

@@ -22,6 +22,8 @@
 #define CM_LEFT  0x08   // fluid at (x-1,y)
 #define CM_DOWN  0x10   // fluid at (x,y-1)
 #define CM_DIAG_SHIFT 5 // a_diag = mask >> 5  (0..4)
+#define CM_INTERIOR 0x9F   // fluid, four fluid neighbours, a_diag 4: the mask of a cell deep inside the water
+#define EU_CHUNK_INTERIOR 0x80000000u   // chunk_list entry: every cell of the chunk is CM_INTERIOR (euler_sim.chunk_list)
 
 // kernel classes for euler_profile_*
 enum {
@@ -38,8 +40,10 @@ struct PcgScalars {
   double tol;
   double comm_val;   // multi-rank: a rank-local reduction result on its way through the all-reduce
   double comm_val2;  // k_precond_tile leaves two: max |r| in comm_val, dot(z,r) here
-  double* s_last;    // tile-local mode: the search direction of the last iteration that ran (its p += alpha s is applied by
-                     // the next iteration's apply_a pass, or by k_finish_p when there is none)
+  double alpha_prev; // alpha of the iteration before the last one that ran (tile-local mode: p is updated every SECOND iteration)
+  double* s_last;    // tile-local mode: the search direction of the last iteration that ran, and of the one before it (s_prev).
+  double* s_prev;    // p += alpha s of iterations k, k + 1 (k even) is applied by the apply_a pass of iteration k + 2, which finds
+                     // s_k in the array it is about to overwrite and reads s_(k+1) anyway; k_finish_p applies what is left at the end
   int nonzero;   // !all_zero(r)  (main.c:742)
   int done;      // inf_norm(r) <= tol reached (main.c:756)
   int iters;     // apply_a calls so far (main.c:750)
@@ -161,7 +165,11 @@ struct euler_sim {
   // Active chunks of a solve: a chunk = 16 consecutive records of a band = one tile of the tile-local preconditioner (W = 16) = one
   // run of k_search_apply (8 pair-records).  k_build_system flags every chunk that holds fluid (a byte each, packed to bits), an ordered select turns the bits
   // into the ascending list both kernels walk - no wave reads the masks of an empty chunk, and a listed chunk's masks travel with its data.
-  uint8_t* chunk_flag;
+  uint8_t* chunk_flag;    // this solve: the chunk holds fluid
+  uint8_t* chunk_prev;    // the previous solve's flags (k_build_system<true>: where stale masks / p / r may sit)
+  uint8_t* chunk_part;    // this solve: some cell of the chunk is not CM_INTERIOR (the listed entry of an interior chunk carries EU_CHUNK_INTERIOR)
+  int lean_ok;            // the solver arrays have only been written by solves since chunk_prev was current (else k_build_system writes them whole)
+  double* tile_table;     // [8][64][2]: E^-1 of an interior tile of 16 records (k_tile_table) - the same for every interior tile, so k_precond_tile never streams it
   unsigned long long* chunk_bits;
   unsigned int* chunk_list;
   size_t chunk_words, chunk_cap;
@@ -262,6 +270,7 @@ int  eu_slab_timestep(euler_sim* S, float frame_time_left);
 int  eu_slab_after_load(euler_sim* S);
 int  eu_slab_check_partition(euler_sim* S);   // collective: the ranks' band ranges tile the grid
 int  eu_slab_exchange_uv(euler_sim* S);     // ghost rows of u, v (euler_set_field on a slab handle)
+int  eu_slab_error_sync(euler_sim* S);      // collective: the ranks' sticky error words -> their maximum on every rank
 // launch groups implemented in the kernel files
 int eu_launch_timestep(euler_sim* S, float frame_time_left);
 int eu_launch_advect_markers(euler_sim* S, float dt);

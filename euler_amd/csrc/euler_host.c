@@ -9,6 +9,7 @@
  */
 #include "euler_host.h"
 
+#include <pthread.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -34,19 +35,18 @@ float euler_rng_next_float(uint64_t* state) {
  * handle uses it to skip the cells of other ranks' rows while it walks the ONE seeding stream (below). */
 #define RNG_JUMPS 48
 static uint64_t g_jump[RNG_JUMPS][64];
-static int g_jump_ready = 0;
+static pthread_once_t g_jump_once = PTHREAD_ONCE_INIT;   /* handles may load scenarios from several threads at once */
 static uint64_t jump_apply(const uint64_t* col, uint64_t x) {
   uint64_t y = 0;
   while (x) { y ^= col[__builtin_ctzll(x)]; x &= x - 1; }
   return y;
 }
-static void jump_init(void) {
-  if (g_jump_ready) return;
+static void jump_fill(void) {
   for (int b = 0; b < 64; ++b) { uint64_t x = 1ull << b; x ^= x >> 12; x ^= x << 25; x ^= x >> 27; g_jump[0][b] = x; }
   for (int i = 1; i < RNG_JUMPS; ++i)
     for (int b = 0; b < 64; ++b) g_jump[i][b] = jump_apply(g_jump[i - 1], g_jump[i - 1][b]);
-  g_jump_ready = 1;
 }
+static void jump_init(void) { pthread_once(&g_jump_once, jump_fill); }
 uint64_t euler_rng_jump(uint64_t state, uint64_t steps) {
   jump_init();
   for (int i = 0; steps && i < RNG_JUMPS; ++i, steps >>= 1)

@@ -4,6 +4,8 @@
 // coalesced row-major access; none has a floating-point reduction except the exact max.
 #include "euler_dev.h"
 
+#include <stdlib.h>
+
 // ------------------------------------------------------------------------------------------
 // calculate_timestep / maxsq (main.c:808-841): max over the typed extents, including zeros.
 __global__ __launch_bounds__(256) void k_maxsq(const float* __restrict__ u, const float* __restrict__ v,
@@ -207,25 +209,37 @@ int eu_launch_advect_velocity(euler_sim* S, float dt) {
 // Threads run in the solver's band-skewed order (coalesced writes of b, r, p, mask; the row-major
 // velocity/count reads are a diagonal gather, once per substep).  Padding entries are skipped:
 // they keep mask 0 and value 0 from allocation.
+// TILE (the tile-local preconditioner): q and z need no zeroing (k_precond_tile writes z over whole active tiles and reads A s = q
+// on fluid cells only), and a wave without fluid in a chunk that held none in the previous solve either has nothing to write at
+// all - its masks, p and r are still the zeros the last solve that touched them (or the allocation) left.  8192^2 half tank:
+// 41 B x all cells -> 25 B x the cells of active chunks.
+template <bool TILE>
 __global__ __launch_bounds__(256) void k_build_system(const float* __restrict__ u, const float* __restrict__ v,
                                                       const uint8_t* __restrict__ count, const uint8_t* __restrict__ solid,
                                                       double* __restrict__ b, double* __restrict__ r, double* __restrict__ p,
                                                       double* __restrict__ q, double* __restrict__ z,
                                                       uint8_t* __restrict__ cellmask,
                                                       PcgScalars* sc, SkewGeom g, float dt, size_t e_lo, size_t e_cnt,
-                                                      uint8_t* __restrict__ chunk_flag) {
+                                                      uint8_t* __restrict__ chunk_flag, uint8_t* __restrict__ chunk_part,
+                                                      const uint8_t* __restrict__ chunk_prev) {
   // eu_xcd_block: the 16 diagonal steps that share a 64-byte line of a row-major field meet in ONE L2 instead of in all eight
   const size_t e = e_lo + eu_xcd_block() * blockDim.x + threadIdx.x;   // this rank's bands only
-  bool nz = false, fl = false;
+  // the wave's 64 elements are two half records of one 16-record chunk (euler_dev.h "Active chunks")
+  const size_t we = e_lo + eu_xcd_block() * blockDim.x + (threadIdx.x & ~63u);      // the wave's first element
+  const size_t per_band = (size_t)g.TS * 64;
+  const size_t chunk = ((we - e_lo) / per_band) * (size_t)(g.T / 16) + ((we % per_band) / 64) / 16;
+  const bool in_chunks = (we % per_band) / 64 < (size_t)g.T;      // (the TS - T records behind a band's last chunk are padding)
+  bool nz = false, fl = false, inside = false;
+  uint8_t m = 0;
+  double bv = 0.0;
   if (e < e_lo + e_cnt) {
     const int X = g.X;
     int band, t, l;
     skew_decode(g, e, band, t, l);
     const int x = t - l, y = band * 64 + l;
     if (x >= 0 && x < X && y < g.Y) {
+      inside = true;
       const size_t i = (size_t)y * X + x;
-      uint8_t m = 0;
-      double bv = 0.0;
       if (count[i] != 0) {   // never true on the border ring (sinks), so the +-1 / +-X reads are in range
         m = CM_FLUID;
         fl = true;
@@ -240,10 +254,16 @@ __global__ __launch_bounds__(256) void k_build_system(const float* __restrict__ 
         bv = -(double)div_f * (double)k_inv_scale_f;
         nz = bv != 0.0;
       }
-      cellmask[e] = m;
-      b[e] = bv;
-      r[e] = bv;
-      p[e] = 0.0;
+    }
+  }
+  const bool wave_fluid = __any(fl);
+  const bool touch = !TILE || wave_fluid || (in_chunks && chunk_prev[chunk] != 0);
+  if (inside && touch) {
+    cellmask[e] = m;
+    b[e] = bv;
+    r[e] = bv;
+    p[e] = 0.0;
+    if (!TILE) {
       q[e] = 0.0;   // the sweeps only visit the records that hold fluid (k_band_ranges): what they skip must be +0
       z[e] = 0.0;
     }
@@ -252,13 +272,13 @@ __global__ __launch_bounds__(256) void k_build_system(const float* __restrict__ 
   // half a million atomic ORs on one address took 3.4 of the kernel's 5.1 ms at 8192^2 (at rest, where b is mostly zero, none)
   if (__any(nz) && (threadIdx.x & 63) == 0 && __hip_atomic_load(&sc->nonzero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
     atomicOr(&sc->nonzero, 1);
-  // the wave's 64 elements are two records of one 16-record chunk (euler_dev.h "Active chunks"): one bit says it holds fluid
-  if (__any(fl) && (threadIdx.x & 63) == 0) {
-    const size_t we = e_lo + eu_xcd_block() * blockDim.x + (threadIdx.x & ~63u);      // the wave's first element
-    const size_t per_band = (size_t)g.TS * 64;
-    const size_t chunk = ((we - e_lo) / per_band) * (size_t)(g.T / 16) + ((we % per_band) / 64) / 16;
-    chunk_flag[chunk] = 1;      // (a plain store: every wave of the chunk writes the same byte; an atomic OR into shared words cost 3 ms)
+  // one byte says the chunk holds fluid, a second one that it is not an INTERIOR chunk (euler_dev.h: every cell fluid with four
+  // fluid neighbours and a_diag 4, mask CM_INTERIOR).  Plain stores: every wave writes the same value; an atomic OR into shared
+  // words cost 3 ms
+  if ((threadIdx.x & 63) == 0 && in_chunks) {
+    if (wave_fluid) chunk_flag[chunk] = 1;
   }
+  if (in_chunks && __any(m != CM_INTERIOR) && (threadIdx.x & 63) == 0) chunk_part[chunk] = 1;
 }
 
 // one bit per chunk from the bytes k_build_system left (the ordered select wants bits)
@@ -316,14 +336,35 @@ __global__ __launch_bounds__(256) void k_velocity_update(const float* __restrict
 
 int eu_launch_band_ranges(euler_sim* S);
 
+// the top bit of a listed chunk says INTERIOR (k_search_apply / k_precond_tile: no mask loads, constant coefficients, E^-1 from the table)
+__global__ __launch_bounds__(256) void k_mark_interior(unsigned int* __restrict__ list, const PcgScalars* sc, const uint8_t* __restrict__ part) {
+  const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= sc->n_chunks) return;
+  const unsigned int c = list[i];
+  if (!part[c]) list[i] = c | EU_CHUNK_INTERIOR;
+}
+
 int eu_launch_build_system(euler_sim* S, float dt) {
+  // the flags of the previous solve stay readable (which chunks may hold stale masks / p / r): two sets, swapped per solve
+  uint8_t* t = S->chunk_flag; S->chunk_flag = S->chunk_prev; S->chunk_prev = t;
   HIPCHK(hipMemsetAsync(S->chunk_flag, 0, S->chunk_cap + 64, S->stream));
-  LAUNCH(S, KC_BUILD_SYSTEM, k_build_system, dim3(eu_blocks(S->e_cnt, 256)), dim3(256), S->utmp, S->vtmp, S->count,
-         S->solid, S->b, S->r, S->p, S->q, S->z, S->cellmask, S->sc, S->geom, dt, S->e_lo, S->e_cnt, S->chunk_flag);
+  HIPCHK(hipMemsetAsync(S->chunk_part, 0, S->chunk_cap + 64, S->stream));
+  // the lean assembly needs every solve since the arrays were last written whole to have been a tile-mode solve of this handle
+  const bool lean = S->cfg.precond == EULER_PRECOND_IC0_TILE && S->cfg.sweep_mode != EULER_SWEEP_SIMPLE && S->lean_ok;
+  if (lean)
+    LAUNCH(S, KC_BUILD_SYSTEM, k_build_system<true>, dim3(eu_blocks(S->e_cnt, 256)), dim3(256), S->utmp, S->vtmp, S->count,
+           S->solid, S->b, S->r, S->p, S->q, S->z, S->cellmask, S->sc, S->geom, dt, S->e_lo, S->e_cnt, S->chunk_flag, S->chunk_part, S->chunk_prev);
+  else
+    LAUNCH(S, KC_BUILD_SYSTEM, k_build_system<false>, dim3(eu_blocks(S->e_cnt, 256)), dim3(256), S->utmp, S->vtmp, S->count,
+           S->solid, S->b, S->r, S->p, S->q, S->z, S->cellmask, S->sc, S->geom, dt, S->e_lo, S->e_cnt, S->chunk_flag, S->chunk_part, S->chunk_prev);
+  S->lean_ok = 1;      // this solve's flags describe everything that is non-zero from here on
   LAUNCH(S, KC_BUILD_SYSTEM, k_pack_chunk_bits, dim3(eu_blocks(S->chunk_words, 256)), dim3(256), S->chunk_flag, S->chunk_bits, S->chunk_words, S->chunk_cap);
   // the ascending list of this solve's active chunks (k_search_apply, k_precond_tile)
   int rc = eu_ordered_select(S, S->chunk_bits, S->chunk_words, S->chunk_list, &S->sc->n_chunks);
   if (rc) return rc;
+  static const bool no_interior = getenv("EULER_NO_INTERIOR") != nullptr;      // (experiments: every chunk takes the general path)
+  if (!no_interior)
+    LAUNCH(S, KC_BUILD_SYSTEM, k_mark_interior, dim3(eu_blocks(S->chunk_cap, 256)), dim3(256), S->chunk_list, S->sc, S->chunk_part);
   return eu_launch_band_ranges(S);
 }
 

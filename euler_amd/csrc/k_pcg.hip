@@ -55,7 +55,7 @@ enum { FIN_SIGMA_INIT = 0, FIN_ALPHA, FIN_RNORM, FIN_BETA, FIN_STORE_ONLY, FIN_T
 __device__ __forceinline__ void pcg_scalar_step(PcgScalars* sc, int op, double v) {
   switch (op) {
     case FIN_SIGMA_INIT: sc->sigma = v; break;                                        // main.c:748
-    case FIN_ALPHA: sc->zs = v; sc->alpha = sc->sigma / v; sc->iters += 1; break;     // main.c:750-752
+    case FIN_ALPHA: sc->zs = v; sc->alpha_prev = sc->alpha; sc->alpha = sc->sigma / v; sc->iters += 1; break;     // main.c:750-752
     case FIN_RNORM: sc->rnorm = v; if (v <= sc->tol) sc->done = 1; break;             // main.c:756
     case FIN_BETA: sc->sigma_new = v; sc->beta = v / sc->sigma; sc->sigma = v; break; // main.c:762-765
     case FIN_TO_COMM: sc->comm_val = v; break;   // multi-rank: the epilogue runs after the all-reduce
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_apply_a(const double* __restric
                                                          double* __restrict__ partial, PcgScalars* sc, int force,
                                                          unsigned int* counter, int fin_op, double* s_last) {
   if (!force && pcg_idle(sc)) return;
-  if (s_last && blockIdx.x == 0 && threadIdx.x == 0) sc->s_last = s_last;   // tile-local mode: whose p += alpha s is still due (k_finish_p)
+  if (s_last && blockIdx.x == 0 && threadIdx.x == 0) { sc->s_last = s_last; sc->s_prev = nullptr; }   // tile-local mode: whose p += alpha s is still due (k_finish_p)
   const size_t S = g.S;
   const size_t chunk = (((S + gridDim.x - 1) / gridDim.x) + 127) & ~(size_t)127;   // whole record pairs per block
   const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < S ? lo + chunk : S;
@@ -301,8 +301,13 @@ __device__ __forceinline__ double ld_system(const double* p) {
   return v;
 }
 
-// PUPD (tile-local mode): the pass also applies the previous iteration's p += alpha s_old (fmadd, main.c:753) - it reads s_old
-// anyway, and in that mode no other kernel of the iteration touches p (k_precond_tile does the rest of main.c:753-765).
+// PMODE (tile-local mode, where no other kernel of the iteration touches p - k_precond_tile does the rest of main.c:753-765):
+//   0  the reference's structure (k_update_pr applies p += alpha s)
+//   1  tile-local mode, an odd iteration: p is left alone
+//   2  tile-local mode, an even iteration k >= 2: p = (p + alpha_(k-2) s_(k-2)) + alpha_(k-1) s_(k-1) - the two fmadds of main.c:753
+//      that are due, in their order, hence the reference's bits.  s_(k-1) is this pass's s_old; s_(k-2) sits in the array the
+//      pass is about to overwrite with s_k (the two search arrays ping-pong), read by the thread that overwrites it.  p is read
+//      and written every second iteration: 12 instead of 16 bytes per cell and iteration.
 //
 // Schedule.  A wave walks a run of SA_RUN consecutive pair-records of one band (lane = row) with a three-deep window of s'
 // in registers - the pair before, the pair itself, the pair after - so every element of z and s is loaded ONCE, by one
@@ -312,23 +317,27 @@ __device__ __forceinline__ double ld_system(const double* p) {
 // their band (two lanes of one 8-byte load each per element).  Against one thread per pair gathering six neighbours with
 // twelve strided 8-byte loads (round 1) that is 11 instead of 19 memory instructions per pair, and the HBM traffic drops
 // from 1.28x to the algorithmic bytes.
+//
+// INTERIOR chunks (EU_CHUNK_INTERIOR in the list entry: every cell fluid, four fluid neighbours, a_diag 4 - most of a deep tank)
+// take a second instantiation of the run body with the masks as compile-time constants: no mask loads, no selects.
 #define SA_THREADS 256
 struct SaPair { sw_d2 z, so; double ez0, es0, ez1, es1; };   // one pair-record of a lane + the out-of-band vertical neighbours of its two elements
 
 // SA_RUN pair-records per wave: 8 (more waves in flight - at 1024^2 runs of 32 would leave 300 waves for 256 CUs - and the granularity
 // of the active-chunk list); 16 / 32 remain for experiments (sa_run)
-template <bool SLAB, bool PUPD, int SA_RUN>   // SLAB: several ranks, the neighbouring slabs' arrays are mapped (nbr); else nbr is ignored
+template <bool SLAB, int PMODE, int SA_RUN>   // SLAB: several ranks, the neighbouring slabs' arrays are mapped (nbr); else nbr is ignored
 __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __restrict__ s_old, const double* __restrict__ z,
                                                              double* __restrict__ s_new, double* __restrict__ out,
                                                              const uint8_t* __restrict__ mask, SkewGeom g,
                                                              double* __restrict__ partial, PcgScalars* sc, int force,
                                                              unsigned int* counter, int fin_op, SlabNeighbours nbr,
-                                                             double* __restrict__ p, double* s_new_base,
+                                                             double* __restrict__ p, double* s_new_base, double* s_old_base,
                                                              const unsigned int* __restrict__ chunk_list) {   // SA_RUN == 8 only: the solve's active runs
   if (!force && pcg_idle(sc)) return;
   const double beta = sc->beta;
   const double alpha_prev = sc->alpha;     // of the previous iteration: this launch's own alpha is written by its LAST block
-  if (PUPD && blockIdx.x == 0 && threadIdx.x == 0) sc->s_last = s_new_base;
+  const double alpha_pp = sc->alpha_prev;  // of the one before
+  if (PMODE && blockIdx.x == 0 && threadIdx.x == 0) { sc->s_last = s_new_base; sc->s_prev = s_old_base; }
   const int lane = threadIdx.x & 63;
   const int TS = g.TS, npairs = TS / 2;
   const int nb_local = (int)(g.S / ((size_t)TS * 64));
@@ -340,106 +349,115 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
   const bool listed = chunk_list != nullptr;
   const int ntb16 = g.T / 16;
   const int todo = listed ? (int)sc->n_chunks : total;
+  typedef std::integral_constant<bool, true> yes_t;
+  typedef std::integral_constant<bool, false> no_t;
   for (int i = blockIdx.x * (SA_THREADS / 64) + (threadIdx.x >> 6); i < todo; i += n_waves) {
     int c = i, per = cpb;
-    if (listed) { c = (int)chunk_list[i]; per = ntb16; }
+    bool interior = false;
+    if (listed) { const unsigned int ent = chunk_list[i]; interior = (ent & EU_CHUNK_INTERIOR) != 0; c = (int)(ent & ~EU_CHUNK_INTERIOR); per = ntb16; }
     const int lb = c / per, P0 = (c % per) * SA_RUN, P1 = P0 + SA_RUN < npairs ? P0 + SA_RUN : npairs;
     const size_t bbase = (size_t)lb * TS * 64 + 2 * lane;     // element (band, record 0, lane)
-    // the cell masks of the run; a run without fluid is skipped whole
-    unsigned int mm[SA_RUN];
-    unsigned int any = 0;
+    auto run = [&](auto full_tag) {
+      constexpr bool FULL = decltype(full_tag)::value;
+      // the cell masks of the run; a run without fluid is skipped whole
+      unsigned int mm[SA_RUN];
+      unsigned int any = 0;
 #pragma unroll
-    for (int j = 0; j < SA_RUN; ++j) {
-      mm[j] = P0 + j < P1 ? (unsigned int)*reinterpret_cast<const unsigned short*>(mask + bbase + (size_t)(P0 + j) * 128) : 0u;
-      any |= mm[j];
-    }
-    if (!listed && !__ballot(((any | (any >> 8)) & CM_FLUID) != 0)) continue;
-    // where lane 0 / lane 63 find the row below / above their band (the adjacent band's lane 63 / lane 0), relative to pair 0:
-    // even element (record 2P):  below = record 2P + 63 of band - 1, above = record 2P - 63 of band + 1; odd element: + 1
-    const bool up_remote = SLAB && nbr.z_up && lb + 1 == nb_local, dn_remote = SLAB && nbr.z_dn && lb == 0;
-    const double* ez = lane == 0 ? (dn_remote ? nbr.z_dn : z) : (up_remote ? nbr.z_up : z);
-    const double* es = lane == 0 ? (dn_remote ? nbr.s_dn : s_old) : (up_remote ? nbr.s_up : s_old);
-    const bool remote = lane == 0 ? dn_remote : up_remote;
-    const long long e0_base = lane == 0 ? ((long long)(lb - 1) * TS + 62) * 64 + 127 : ((long long)(lb + 1) * TS - 64) * 64 + 1;
-    const long long e1_base = lane == 0 ? ((long long)(lb - 1) * TS + 64) * 64 + 126 : ((long long)(lb + 1) * TS - 62) * 64;
-    const unsigned int vbit = lane == 0 ? CM_DOWN : CM_UP;
-    auto load_pair = [&](int P, SaPair& d, unsigned int m) {
-      d.ez0 = d.es0 = d.ez1 = d.es1 = 0.0;
-      if (P < 0 || P >= npairs) { d.z = sw_d2{0.0, 0.0}; d.so = sw_d2{0.0, 0.0}; return; }   // outside the band: never a fluid cell's neighbour
-      d.z = *reinterpret_cast<const sw_d2*>(z + bbase + (size_t)P * 128);
-      d.so = *reinterpret_cast<const sw_d2*>(s_old + bbase + (size_t)P * 128);
-      if (edge_lane) {
-        if ((m & CM_FLUID) && (m & vbit)) {
-          const long long k = e0_base + (long long)P * 128;
-          if (SLAB && remote) { d.ez0 = ld_system(ez + k); d.es0 = ld_system(es + k); } else { d.ez0 = ez[k]; d.es0 = es[k]; }
+      for (int j = 0; j < SA_RUN; ++j) {
+        if (FULL) mm[j] = CM_INTERIOR | (CM_INTERIOR << 8);
+        else mm[j] = P0 + j < P1 ? (unsigned int)*reinterpret_cast<const unsigned short*>(mask + bbase + (size_t)(P0 + j) * 128) : 0u;
+        any |= mm[j];
+      }
+      if (!FULL && !listed && !__ballot(((any | (any >> 8)) & CM_FLUID) != 0)) return;
+      // where lane 0 / lane 63 find the row below / above their band (the adjacent band's lane 63 / lane 0), relative to pair 0:
+      // even element (record 2P):  below = record 2P + 63 of band - 1, above = record 2P - 63 of band + 1; odd element: + 1
+      const bool up_remote = SLAB && nbr.z_up && lb + 1 == nb_local, dn_remote = SLAB && nbr.z_dn && lb == 0;
+      const double* ez = lane == 0 ? (dn_remote ? nbr.z_dn : z) : (up_remote ? nbr.z_up : z);
+      const double* es = lane == 0 ? (dn_remote ? nbr.s_dn : s_old) : (up_remote ? nbr.s_up : s_old);
+      const bool remote = lane == 0 ? dn_remote : up_remote;
+      const long long e0_base = lane == 0 ? ((long long)(lb - 1) * TS + 62) * 64 + 127 : ((long long)(lb + 1) * TS - 64) * 64 + 1;
+      const long long e1_base = lane == 0 ? ((long long)(lb - 1) * TS + 64) * 64 + 126 : ((long long)(lb + 1) * TS - 62) * 64;
+      const unsigned int vbit = lane == 0 ? CM_DOWN : CM_UP;
+      auto load_pair = [&](int P, SaPair& d, unsigned int m) {
+        d.ez0 = d.es0 = d.ez1 = d.es1 = 0.0;
+        if (P < 0 || P >= npairs) { d.z = sw_d2{0.0, 0.0}; d.so = sw_d2{0.0, 0.0}; return; }   // outside the band: never a fluid cell's neighbour
+        d.z = *reinterpret_cast<const sw_d2*>(z + bbase + (size_t)P * 128);
+        d.so = *reinterpret_cast<const sw_d2*>(s_old + bbase + (size_t)P * 128);
+        if (edge_lane) {
+          if ((m & CM_FLUID) && (m & vbit)) {
+            const long long k = e0_base + (long long)P * 128;
+            if (SLAB && remote) { d.ez0 = ld_system(ez + k); d.es0 = ld_system(es + k); } else { d.ez0 = ez[k]; d.es0 = es[k]; }
+          }
+          if (((m >> 8) & CM_FLUID) && ((m >> 8) & vbit)) {
+            const long long k = e1_base + (long long)P * 128;
+            if (SLAB && remote) { d.ez1 = ld_system(ez + k); d.es1 = ld_system(es + k); } else { d.ez1 = ez[k]; d.es1 = es[k]; }
+          }
         }
-        if (((m >> 8) & CM_FLUID) && ((m >> 8) & vbit)) {
-          const long long k = e1_base + (long long)P * 128;
-          if (SLAB && remote) { d.ez1 = ld_system(ez + k); d.es1 = ld_system(es + k); } else { d.ez1 = ez[k]; d.es1 = es[k]; }
+      };
+      auto sprime = [&](const SaPair& d) { return sw_d2{d.z.x + beta * d.so.x, d.z.y + beta * d.so.y}; };   // s' = z + beta s (main.c:674)
+      SaPair A, B, Cn;
+      load_pair(P0 - 1, A, 0u);
+      load_pair(P0, B, mm[0]);
+      load_pair(P0 + 1, Cn, SA_RUN > 1 ? mm[1] : 0u);
+      double prev_y = sprime(A).y;
+      sw_d2 cur = sprime(B);
+#pragma unroll
+      for (int j = 0; j < SA_RUN; ++j) {
+        const int P = P0 + j;
+        if (P < P1) {                                       // (wave-uniform)
+          SaPair D;
+          load_pair(P + 2 <= P1 ? P + 2 : -1, D, j + 2 < SA_RUN ? mm[j + 2] : 0u);      // the pair after the next, in flight while this one computes
+          const unsigned int m0 = mm[j] & 0xff, m1 = mm[j] >> 8;
+          const sw_d2 nxt = sprime(Cn);
+          // the rows below / above: the neighbouring lane's registers (every lane takes part: a lane whose own pair holds no
+          // fluid still serves its neighbours); lane 0 / 63 inject what they fetched from the adjacent band
+          const double e0 = B.ez0 + beta * B.es0, e1 = B.ez1 + beta * B.es1;
+          const double dn0 = wave_shift_inject<DPP_WAVE_SHR1>(prev_y, e0), up0 = wave_shift_inject<DPP_WAVE_SHL1>(cur.y, e0);
+          const double dn1 = wave_shift_inject<DPP_WAVE_SHR1>(cur.x, e1), up1 = wave_shift_inject<DPP_WAVE_SHL1>(nxt.x, e1);
+          if ((m0 | m1) & CM_FLUID) {
+            const size_t i = bbase + (size_t)P * 128;
+            sw_d2 cc = B.so, o = {0.0, 0.0};                // cc: the pair's s' (a non-fluid element keeps its old value, +0)
+            if (PMODE == 2) {
+              sw_d2 pv = *reinterpret_cast<const sw_d2*>(p + i);
+              const sw_d2 s2v = *reinterpret_cast<const sw_d2*>(s_new + i);      // s of two iterations ago, about to be overwritten
+              if (m0 & CM_FLUID) { pv.x = pv.x + s2v.x * alpha_pp; pv.x = pv.x + B.so.x * alpha_prev; }
+              if (m1 & CM_FLUID) { pv.y = pv.y + s2v.y * alpha_pp; pv.y = pv.y + B.so.y * alpha_prev; }
+              *reinterpret_cast<sw_d2*>(p + i) = pv;        // a non-fluid partner is written back unchanged
+            }
+            if (m0 & CM_FLUID) cc.x = cur.x;
+            if (m1 & CM_FLUID) cc.y = cur.y;
+            if (m0 & CM_FLUID) {                            // apply_a (main.c:679-691): diag, right, up, left, down
+              double v = (double)(int)(m0 >> CM_DIAG_SHIFT) * cc.x;
+              v = v - ((m0 & CM_RIGHT) ? cc.y : 0.0);
+              v = v - ((m0 & CM_UP) ? up0 : 0.0);
+              v = v - ((m0 & CM_LEFT) ? prev_y : 0.0);
+              v = v - ((m0 & CM_DOWN) ? dn0 : 0.0);
+              o.x = v;
+              t += v * cc.x;
+            }
+            if (m1 & CM_FLUID) {
+              double v = (double)(int)(m1 >> CM_DIAG_SHIFT) * cc.y;
+              v = v - ((m1 & CM_RIGHT) ? nxt.x : 0.0);
+              v = v - ((m1 & CM_UP) ? up1 : 0.0);
+              v = v - ((m1 & CM_LEFT) ? cc.x : 0.0);
+              v = v - ((m1 & CM_DOWN) ? dn1 : 0.0);
+              o.y = v;
+              t += v * cc.y;
+            }
+            if ((m0 & m1) & CM_FLUID) { *reinterpret_cast<sw_d2*>(s_new + i) = cc; *reinterpret_cast<sw_d2*>(out + i) = o; }
+            else if (m0 & CM_FLUID) { s_new[i] = cc.x; out[i] = o.x; }
+            else { s_new[i + 1] = cc.y; out[i + 1] = o.y; }
+            if (SLAB && slab_edge_row(i, lane, TS, nb_local, (nbr.z_dn ? 1 : 0) | (nbr.z_up ? 2 : 0))) {   // the rows the neighbours will read
+              if (m0 & CM_FLUID) st_system(s_new + i, cc.x);
+              if (m1 & CM_FLUID) st_system(s_new + i + 1, cc.y);
+            }
+          }
+          prev_y = cur.y; cur = nxt;
+          B = Cn; Cn = D;
         }
       }
     };
-    auto sprime = [&](const SaPair& d) { return sw_d2{d.z.x + beta * d.so.x, d.z.y + beta * d.so.y}; };   // s' = z + beta s (main.c:674)
-    SaPair A, B, Cn;
-    load_pair(P0 - 1, A, 0u);
-    load_pair(P0, B, mm[0]);
-    load_pair(P0 + 1, Cn, SA_RUN > 1 ? mm[1] : 0u);
-    double prev_y = sprime(A).y;
-    sw_d2 cur = sprime(B);
-#pragma unroll
-    for (int j = 0; j < SA_RUN; ++j) {
-      const int P = P0 + j;
-      if (P < P1) {                                       // (wave-uniform)
-        SaPair D;
-        load_pair(P + 2 <= P1 ? P + 2 : -1, D, j + 2 < SA_RUN ? mm[j + 2] : 0u);      // the pair after the next, in flight while this one computes
-        const unsigned int m0 = mm[j] & 0xff, m1 = mm[j] >> 8;
-        const sw_d2 nxt = sprime(Cn);
-        // the rows below / above: the neighbouring lane's registers (every lane takes part: a lane whose own pair holds no
-        // fluid still serves its neighbours); lane 0 / 63 inject what they fetched from the adjacent band
-        const double e0 = B.ez0 + beta * B.es0, e1 = B.ez1 + beta * B.es1;
-        const double dn0 = wave_shift_inject<DPP_WAVE_SHR1>(prev_y, e0), up0 = wave_shift_inject<DPP_WAVE_SHL1>(cur.y, e0);
-        const double dn1 = wave_shift_inject<DPP_WAVE_SHR1>(cur.x, e1), up1 = wave_shift_inject<DPP_WAVE_SHL1>(nxt.x, e1);
-        if ((m0 | m1) & CM_FLUID) {
-          const size_t i = bbase + (size_t)P * 128;
-          sw_d2 cc = B.so, o = {0.0, 0.0};                // cc: the pair's s' (a non-fluid element keeps its old value, +0)
-          if (PUPD) {
-            sw_d2 pv = *reinterpret_cast<const sw_d2*>(p + i);
-            if (m0 & CM_FLUID) pv.x = pv.x + B.so.x * alpha_prev;
-            if (m1 & CM_FLUID) pv.y = pv.y + B.so.y * alpha_prev;
-            *reinterpret_cast<sw_d2*>(p + i) = pv;        // a non-fluid partner is written back unchanged
-          }
-          if (m0 & CM_FLUID) cc.x = cur.x;
-          if (m1 & CM_FLUID) cc.y = cur.y;
-          if (m0 & CM_FLUID) {                            // apply_a (main.c:679-691): diag, right, up, left, down
-            double v = (double)(int)(m0 >> CM_DIAG_SHIFT) * cc.x;
-            v = v - ((m0 & CM_RIGHT) ? cc.y : 0.0);
-            v = v - ((m0 & CM_UP) ? up0 : 0.0);
-            v = v - ((m0 & CM_LEFT) ? prev_y : 0.0);
-            v = v - ((m0 & CM_DOWN) ? dn0 : 0.0);
-            o.x = v;
-            t += v * cc.x;
-          }
-          if (m1 & CM_FLUID) {
-            double v = (double)(int)(m1 >> CM_DIAG_SHIFT) * cc.y;
-            v = v - ((m1 & CM_RIGHT) ? nxt.x : 0.0);
-            v = v - ((m1 & CM_UP) ? up1 : 0.0);
-            v = v - ((m1 & CM_LEFT) ? cc.x : 0.0);
-            v = v - ((m1 & CM_DOWN) ? dn1 : 0.0);
-            o.y = v;
-            t += v * cc.y;
-          }
-          if ((m0 & m1) & CM_FLUID) { *reinterpret_cast<sw_d2*>(s_new + i) = cc; *reinterpret_cast<sw_d2*>(out + i) = o; }
-          else if (m0 & CM_FLUID) { s_new[i] = cc.x; out[i] = o.x; }
-          else { s_new[i + 1] = cc.y; out[i + 1] = o.y; }
-          if (SLAB && slab_edge_row(i, lane, TS, nb_local, (nbr.z_dn ? 1 : 0) | (nbr.z_up ? 2 : 0))) {   // the rows the neighbours will read
-            if (m0 & CM_FLUID) st_system(s_new + i, cc.x);
-            if (m1 & CM_FLUID) st_system(s_new + i + 1, cc.y);
-          }
-        }
-        prev_y = cur.y; cur = nxt;
-        B = Cn; Cn = D;
-      }
-    }
+    if (SA_RUN == 8 && interior) run(yes_t()); else run(no_t());
   }
   if (SLAB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // landed before this block joins the all-reduce (block_sum syncs)
   t = block_sum<SA_THREADS>(t);
@@ -1132,6 +1150,7 @@ struct TileArgs {
   double* part_max; double* part_dot;
   unsigned int* counter;
   const unsigned int* list;   // W == 16 inside a solve: the ascending list of active tiles (euler_dev.h "Active chunks"), else null
+  const double* table;        // W == 16: E^-1 of an interior tile (k_tile_table); with it, listed interior tiles skip masks and precon
   PcgScalars* sc;
   int force;
   double alpha_arg;       // force: alpha of the r update (single building block, tests)
@@ -1150,6 +1169,37 @@ __device__ __forceinline__ void tile_block_reduce(double& mx, double& sm) {
     mx = s_mx[0]; sm = s_sm[0];
     for (int k = 1; k < PT_THREADS / 64; ++k) { mx = s_mx[k] > mx ? s_mx[k] : mx; sm += s_sm[k]; }
   }
+}
+
+// one cell of the E^-1 recurrence (main.c:586-600): own / nbv = precon of the left / lower neighbour
+__device__ __forceinline__ double factor_step(double aa, double own, double nbv) {
+  const double cl = -1.0 * own, cb = -1.0 * nbv;
+  double e = aa - cl * cl - cb * cb;
+  if (e < 0.25 * aa) e = (aa != 0.0) ? aa : 1.0;
+  return 1.0 / sqrt(e);
+}
+
+// E^-1 of an INTERIOR tile of 16 records (every cell fluid with a_diag 4): the recurrence starts from precon 0 on the tile's left
+// edge and below lane 0 and sees the same coefficients everywhere, so its 16 x 64 values are the same for every interior tile of
+// every solve.  Computed once per handle by the arithmetic of k_factor_tile (same bits); k_precond_tile keeps it in LDS instead of
+// streaming 8 bytes per cell of precon from HBM.  One wave.  tab[P][lane] = {record 2P, record 2P + 1}.
+__global__ __launch_bounds__(64) void k_tile_table(double* __restrict__ tab) {
+  const int lane = threadIdx.x & 63;
+  double own = 0.0, out = 0.0;
+  sw_d2 pp[8];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const double nbv = wave_shift_inject<DPP_WAVE_SHR1>(out, 0.0);
+    const double res = factor_step(4.0, own, nbv);
+    own = res; out = res;
+    if (j & 1) pp[j >> 1].y = res; else pp[j >> 1].x = res;
+  }
+#pragma unroll
+  for (int P = 0; P < 8; ++P) reinterpret_cast<sw_d2*>(tab)[P * 64 + lane] = pp[P];
+}
+int eu_launch_tile_table(euler_sim* S) {
+  hipLaunchKernelGGL(k_tile_table, dim3(1), dim3(64), 0, S->stream, S->tile_table);
+  return EULER_OK;
 }
 
 template <int W>
@@ -1176,10 +1226,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_factor_tile(TileArgs a) {
       const double cpre = (j & 1) ? pp[j >> 1].y : pp[j >> 1].x;
       const double nbv = wave_shift_inject<DPP_WAVE_SHR1>(out, 0.0);
       const double aa = (double)(cm >> CM_DIAG_SHIFT);               // main.c:586-600
-      const double cl = -1.0 * own, cb = -1.0 * nbv;
-      double e = aa - cl * cl - cb * cb;
-      if (e < 0.25 * aa) e = (aa != 0.0) ? aa : 1.0;
-      const double res = (cm & CM_FLUID) ? 1.0 / sqrt(e) : cpre;     // non-fluid: the stale entry stays (and is what the neighbours read)
+      const double res = (cm & CM_FLUID) ? factor_step(aa, own, nbv) : cpre;     // non-fluid: the stale entry stays (and is what the neighbours read)
       own = res; out = res;
       if (j & 1) pp[j >> 1].y = res; else pp[j >> 1].x = res;
     }
@@ -1198,63 +1245,83 @@ __global__ __launch_bounds__(PT_THREADS) void k_precond_tile(TileArgs a) {
   double mx = 0.0, dsum = 0.0;
   const bool listed = W == 16 && a.list != nullptr;
   const int todo = listed ? (int)a.sc->n_chunks : total;
+  // E^-1 of an interior tile, the same for all of them (k_tile_table): in LDS for the whole launch
+  constexpr int TABP = W == 16 ? 8 : 1;
+  __shared__ sw_d2 s_tab[TABP][64];
+  const bool have_tab = W == 16 && listed && a.table != nullptr;
+  if (have_tab) {
+    for (int k = threadIdx.x; k < TABP * 64; k += PT_THREADS) (&s_tab[0][0])[k] = reinterpret_cast<const sw_d2*>(a.table)[k];
+    __syncthreads();
+  }
+  typedef std::integral_constant<bool, true> yes_t;
+  typedef std::integral_constant<bool, false> no_t;
   for (int i = blockIdx.x * (PT_THREADS / 64) + (threadIdx.x >> 6); i < todo; i += n_waves) {
-    const int tile = listed ? (int)a.list[i] : i;
+    const unsigned int ent = listed ? a.list[i] : (unsigned int)i;
+    const bool interior = have_tab && (ent & EU_CHUNK_INTERIOR) != 0;
+    const int tile = (int)(listed ? ent & ~EU_CHUNK_INTERIOR : ent);
     const int band = a.band_lo + tile / ntb, k = tile % ntb;
     const size_t base = ((size_t)band * a.g.TS + (size_t)k * W) * 64 + 2 * lane;
-    unsigned int mm[W / 2];
-    unsigned int any = 0;
-#pragma unroll
-    for (int P = 0; P < W / 2; ++P) { mm[P] = *reinterpret_cast<const unsigned short*>(a.mask + base + P * 128); any |= mm[P]; }
-    if (!listed && !__ballot(((any | (any >> 8)) & CM_FLUID) != 0)) continue;     // no fluid in this tile: r, z stay +0 there
-    sw_d2 rr[W / 2], qq[W / 2], pp[W / 2];
-#pragma unroll
-    for (int P = 0; P < W / 2; ++P) {
-      rr[P] = *reinterpret_cast<const sw_d2*>(a.r + base + P * 128);
-      pp[P] = *reinterpret_cast<const sw_d2*>(a.pre + base + P * 128);
-      if (a.rupd) qq[P] = *reinterpret_cast<const sw_d2*>(a.as + base + P * 128);
-    }
-    if (a.rupd) {      // r -= alpha z (fmadd, main.c:754, evaluated as r + z * (-alpha) like k_update_pr) and max |r| over fluid cells
+    auto run = [&](auto full_tag) {
+      constexpr bool FULL = decltype(full_tag)::value;      // interior tile: masks are constants, precon comes from the table
+      unsigned int mm[W / 2];
+      unsigned int any = 0;
 #pragma unroll
       for (int P = 0; P < W / 2; ++P) {
-        if (mm[P] & CM_FLUID) { rr[P].x = rr[P].x + qq[P].x * nalpha; const double v = fabs(rr[P].x); if (v > mx) mx = v; }
-        if ((mm[P] >> 8) & CM_FLUID) { rr[P].y = rr[P].y + qq[P].y * nalpha; const double v = fabs(rr[P].y); if (v > mx) mx = v; }
-        *reinterpret_cast<sw_d2*>(a.r + base + P * 128) = rr[P];
+        mm[P] = FULL ? (unsigned int)(CM_INTERIOR | (CM_INTERIOR << 8)) : (unsigned int)*reinterpret_cast<const unsigned short*>(a.mask + base + P * 128);
+        any |= mm[P];
       }
-    }
-    if (!a.sweeps) continue;
-    // L q = r (main.c:602-613).  What travels from cell to cell is m = (-1 * precon) * q, the term both consumers subtract.
-    double own = -0.0, out = -0.0;
+      if (!FULL && !listed && !__ballot(((any | (any >> 8)) & CM_FLUID) != 0)) return;     // no fluid in this tile: r, z stay +0 there
+      sw_d2 rr[W / 2], qq[W / 2], pp[W / 2];
 #pragma unroll
-    for (int j = 0; j < W; ++j) {
-      const int cm = (int)((mm[j >> 1] >> ((j & 1) * 8)) & 0xff);
-      const double cin = (j & 1) ? rr[j >> 1].y : rr[j >> 1].x, cpre = (j & 1) ? pp[j >> 1].y : pp[j >> 1].x;
-      const double nbv = wave_shift_inject<DPP_WAVE_SHR1>(out, -0.0);
-      const double t = cin - own - nbv;
-      const double qv = t * cpre;
-      const double res = (cm & CM_FLUID) ? qv : 0.0;
-      const double carry = -1.0 * cpre * res;
-      own = carry; out = carry;
-      if (j & 1) qq[j >> 1].y = res; else qq[j >> 1].x = res;
-    }
-    // L^T z = q (main.c:615-626), from the tile's last record down; dot(z, r) on the fly
-    own = 0.0; out = 0.0;
+      for (int P = 0; P < W / 2; ++P) {
+        rr[P] = *reinterpret_cast<const sw_d2*>(a.r + base + P * 128);
+        if (FULL) pp[P] = s_tab[P < TABP ? P : 0][lane];
+        else pp[P] = *reinterpret_cast<const sw_d2*>(a.pre + base + P * 128);
+        if (a.rupd) qq[P] = *reinterpret_cast<const sw_d2*>(a.as + base + P * 128);
+      }
+      if (a.rupd) {      // r -= alpha z (fmadd, main.c:754, evaluated as r + z * (-alpha) like k_update_pr) and max |r| over fluid cells
 #pragma unroll
-    for (int j = W - 1; j >= 0; --j) {
-      const int cm = (int)((mm[j >> 1] >> ((j & 1) * 8)) & 0xff);
-      const double cin = (j & 1) ? qq[j >> 1].y : qq[j >> 1].x, cpre = (j & 1) ? pp[j >> 1].y : pp[j >> 1].x;
-      const double crr = (j & 1) ? rr[j >> 1].y : rr[j >> 1].x;
-      const double nbv = wave_shift_inject<DPP_WAVE_SHL1>(out, 0.0);
-      const double kr = ((cm & CM_RIGHT) ? -1.0 : 0.0) * cpre, ku = ((cm & CM_UP) ? -1.0 : 0.0) * cpre;
-      const double t = cin - kr * own - ku * nbv;
-      const double zv = t * cpre;
-      const double res = (cm & CM_FLUID) ? zv : 0.0;
-      own = res; out = res;
-      if (cm & CM_FLUID) dsum += res * crr;
-      if (j & 1) qq[j >> 1].y = res; else qq[j >> 1].x = res;
-    }
+        for (int P = 0; P < W / 2; ++P) {
+          if (mm[P] & CM_FLUID) { rr[P].x = rr[P].x + qq[P].x * nalpha; const double v = fabs(rr[P].x); if (v > mx) mx = v; }
+          if ((mm[P] >> 8) & CM_FLUID) { rr[P].y = rr[P].y + qq[P].y * nalpha; const double v = fabs(rr[P].y); if (v > mx) mx = v; }
+          *reinterpret_cast<sw_d2*>(a.r + base + P * 128) = rr[P];
+        }
+      }
+      if (!a.sweeps) return;
+      // L q = r (main.c:602-613).  What travels from cell to cell is m = (-1 * precon) * q, the term both consumers subtract.
+      double own = -0.0, out = -0.0;
 #pragma unroll
-    for (int P = 0; P < W / 2; ++P) *reinterpret_cast<sw_d2*>(a.z + base + P * 128) = qq[P];
+      for (int j = 0; j < W; ++j) {
+        const int cm = (int)((mm[j >> 1] >> ((j & 1) * 8)) & 0xff);
+        const double cin = (j & 1) ? rr[j >> 1].y : rr[j >> 1].x, cpre = (j & 1) ? pp[j >> 1].y : pp[j >> 1].x;
+        const double nbv = wave_shift_inject<DPP_WAVE_SHR1>(out, -0.0);
+        const double t = cin - own - nbv;
+        const double qv = t * cpre;
+        const double res = (cm & CM_FLUID) ? qv : 0.0;
+        const double carry = -1.0 * cpre * res;
+        own = carry; out = carry;
+        if (j & 1) qq[j >> 1].y = res; else qq[j >> 1].x = res;
+      }
+      // L^T z = q (main.c:615-626), from the tile's last record down; dot(z, r) on the fly
+      own = 0.0; out = 0.0;
+#pragma unroll
+      for (int j = W - 1; j >= 0; --j) {
+        const int cm = (int)((mm[j >> 1] >> ((j & 1) * 8)) & 0xff);
+        const double cin = (j & 1) ? qq[j >> 1].y : qq[j >> 1].x, cpre = (j & 1) ? pp[j >> 1].y : pp[j >> 1].x;
+        const double crr = (j & 1) ? rr[j >> 1].y : rr[j >> 1].x;
+        const double nbv = wave_shift_inject<DPP_WAVE_SHL1>(out, 0.0);
+        const double kr = ((cm & CM_RIGHT) ? -1.0 : 0.0) * cpre, ku = ((cm & CM_UP) ? -1.0 : 0.0) * cpre;
+        const double t = cin - kr * own - ku * nbv;
+        const double zv = t * cpre;
+        const double res = (cm & CM_FLUID) ? zv : 0.0;
+        own = res; out = res;
+        if (cm & CM_FLUID) dsum += res * crr;
+        if (j & 1) qq[j >> 1].y = res; else qq[j >> 1].x = res;
+      }
+#pragma unroll
+      for (int P = 0; P < W / 2; ++P) *reinterpret_cast<sw_d2*>(a.z + base + P * 128) = qq[P];
+    };
+    if (W == 16 && interior) run(yes_t()); else run(no_t());
   }
   // ---- the two reductions: block -> partials -> the last block folds them in index order and applies the scalar epilogues
   tile_block_reduce(mx, dsum);
@@ -1289,19 +1356,26 @@ __global__ __launch_bounds__(PT_THREADS) void k_precond_tile(TileArgs a) {
   }
 }
 
-// tile-local mode: the p += alpha s (fmadd, main.c:753) of the last iteration that ran (the others rode along with the next
-// iteration's apply_a pass)
+// tile-local mode: the p += alpha s (fmadd, main.c:753) that are still due when a solve ends - of the last iteration alone when
+// an odd number ran, of the last two (in their order) when an even number did (k_search_apply PMODE 2 applied the others)
 __global__ __launch_bounds__(256) void k_finish_p(double* __restrict__ p, const uint8_t* __restrict__ mask, size_t e_lo, size_t S,
                                                   const PcgScalars* sc) {
   if (!sc->nonzero || sc->iters == 0) return;
-  const double alpha = sc->alpha;
+  const double alpha = sc->alpha, alpha_pp = sc->alpha_prev;
   const double* s = sc->s_last + e_lo;
+  const bool two = (sc->iters & 1) == 0;
+  const double* sp = two ? sc->s_prev + e_lo : s;
   for (size_t i = 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x); i < S; i += 2 * (size_t)gridDim.x * blockDim.x) {
     const unsigned int mm = *reinterpret_cast<const unsigned short*>(mask + i);
     const bool f0 = (mm & CM_FLUID) != 0, f1 = ((mm >> 8) & CM_FLUID) != 0;
     if (!(f0 | f1)) continue;
     const sw_d2 sv = *reinterpret_cast<const sw_d2*>(s + i);
     sw_d2 pv = *reinterpret_cast<const sw_d2*>(p + i);
+    if (two) {
+      const sw_d2 s2v = *reinterpret_cast<const sw_d2*>(sp + i);
+      if (f0) pv.x = pv.x + s2v.x * alpha_pp;
+      if (f1) pv.y = pv.y + s2v.y * alpha_pp;
+    }
     if (f0) pv.x = pv.x + sv.x * alpha;
     if (f1) pv.y = pv.y + sv.y * alpha;
     *reinterpret_cast<sw_d2*>(p + i) = pv;
@@ -1542,6 +1616,7 @@ static TileArgs make_tile_args(euler_sim* S, int force) {
   a.part_max = S->partial; a.part_dot = S->partial2; a.counter = S->red_counter; a.sc = S->sc; a.force = force; a.alpha_arg = 0.0;
   a.pair_slot = S->pair_buf + 2 * (S->has_comm ? S->comm.rank : 0);
   a.list = (!force && S->tile_w == 16) ? S->chunk_list : nullptr;      // (forced single operations may run on masks no solve has listed)
+  a.table = S->tile_table;
   return a;
 }
 static inline unsigned tile_blocks(const euler_sim* S) {
@@ -1630,14 +1705,14 @@ static inline unsigned sa_blocks(const euler_sim* S, int run) {   // one wave pe
 }
 static inline int sa_run(const euler_sim* S) {   // short runs while long ones would leave CUs without a wave
   static const char* e = getenv("EULER_SA_RUN");      // (experiments)
-  if (e && !S->has_comm) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16 || v == 32) return v; }
+  if (e && !S->has_comm) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32) return v; }
   // measured (same box, tile-local mode): 8192^2 - 8: 346 us, 16: 358, 32: 376 (113 / 134 / 185 VGPRs: occupancy beats the window's
   // two extra pair loads per run, which hit L2); 16384^2, scanning every run's masks - 8: 1412 us, 32: 1389; with the list of active
   // chunks (runs of 8 only) - 8: 1177 us, 32: 1401
   return 8;
 }
 // iterations >= 1 of a single-GPU solve: s' = z + beta s and A s' in one launch; returns with S->s = s' and A s' in S->q
-static int launch_search_apply_and_alpha(euler_sim* S) {
+static int launch_search_apply_and_alpha(euler_sim* S, int it) {
   const bool seq = S->cfg.dot_mode == EULER_DOT_SEQUENTIAL && !S->has_comm;
   SlabNeighbours nbr = {nullptr, nullptr, nullptr, nullptr, S->band_hi - S->band_lo};
   const bool direct = S->has_comm && eu_p2p_has_neighbour_arrays(S);   // (opt-in) read the neighbouring slabs' z and s where they live
@@ -1651,21 +1726,23 @@ static int launch_search_apply_and_alpha(euler_sim* S) {
   }
   SkewGeom gl = S->geom;
   gl.S = S->e_cnt;
-  const bool pupd = tile_fused(S);   // tile-local mode: the previous iteration's p += alpha s rides along
+  // tile-local mode: p += alpha s rides along, two iterations' worth on every even iteration (k_search_apply PMODE)
+  const int pmode = tile_fused(S) ? ((it >= 2 && (it & 1) == 0) ? 2 : 1) : 0;
   const int run = sa_run(S);
   const int fin = S->has_comm ? fin_or_comm(S, FIN_ALPHA) : (seq ? -1 : (int)FIN_ALPHA);
-  double* pp = pupd ? LOC(S->p) : (double*)nullptr;
-  double* sb = pupd ? S->s2 : (double*)nullptr;
-#define SA_LAUNCH(SLABF, PUPDF, RUNV)                                                                                                   \
-  LAUNCH(S, KC_APPLY_A, (k_search_apply<SLABF, PUPDF, RUNV>), dim3(sa_blocks(S, RUNV)), dim3(SA_THREADS), LOC(S->s), LOC(S->z), LOC(S->s2), \
-         LOC(S->q), LOC(S->cellmask), gl, S->partial, S->sc, 0, S->red_counter, fin, nbr, pp, sb, (RUNV) == 8 ? S->chunk_list : (const unsigned int*)nullptr)
+  double* pp = pmode ? LOC(S->p) : (double*)nullptr;
+#define SA_LAUNCH(SLABF, PM, RUNV)                                                                                                      \
+  LAUNCH(S, KC_APPLY_A, (k_search_apply<SLABF, PM, RUNV>), dim3(sa_blocks(S, RUNV)), dim3(SA_THREADS), LOC(S->s), LOC(S->z), LOC(S->s2), \
+         LOC(S->q), LOC(S->cellmask), gl, S->partial, S->sc, 0, S->red_counter, fin, nbr, pp, S->s2, S->s, (RUNV) == 8 ? S->chunk_list : (const unsigned int*)nullptr)
+#define SA_RUNS(SLABF, PM) do { if (run == 8) SA_LAUNCH(SLABF, PM, 8); else if (run == 16) SA_LAUNCH(SLABF, PM, 16); else SA_LAUNCH(SLABF, PM, 32); } while (0)
   if (direct) {
-    if (pupd) { if (run == 8) SA_LAUNCH(true, true, 8); else SA_LAUNCH(true, true, 32); }
-    else { if (run == 8) SA_LAUNCH(true, false, 8); else SA_LAUNCH(true, false, 32); }
+    if (pmode == 2) { if (run == 8) SA_LAUNCH(true, 2, 8); else SA_LAUNCH(true, 2, 32); }
+    else if (pmode == 1) { if (run == 8) SA_LAUNCH(true, 1, 8); else SA_LAUNCH(true, 1, 32); }
+    else { if (run == 8) SA_LAUNCH(true, 0, 8); else SA_LAUNCH(true, 0, 32); }
   } else {
-    if (pupd) { if (run == 4) SA_LAUNCH(false, true, 4); else if (run == 8) SA_LAUNCH(false, true, 8); else if (run == 16) SA_LAUNCH(false, true, 16); else SA_LAUNCH(false, true, 32); }
-    else { if (run == 8) SA_LAUNCH(false, false, 8); else if (run == 16) SA_LAUNCH(false, false, 16); else SA_LAUNCH(false, false, 32); }
+    if (pmode == 2) SA_RUNS(false, 2); else if (pmode == 1) SA_RUNS(false, 1); else SA_RUNS(false, 0);
   }
+#undef SA_RUNS
 #undef SA_LAUNCH
   double* t = S->s; S->s = S->s2; S->s2 = t;
   if (seq)
@@ -1678,7 +1755,8 @@ int eu_launch_build_system(euler_sim* S, float dt);
 int eu_launch_velocity_update(euler_sim* S, float dt);
 
 __global__ void k_pcg_reset(PcgScalars* sc, double tol, int max_iters) {
-  sc->sigma = sc->zs = sc->sigma_new = sc->alpha = sc->beta = sc->rnorm = 0.0;
+  sc->sigma = sc->zs = sc->sigma_new = sc->alpha = sc->alpha_prev = sc->beta = sc->rnorm = 0.0;
+  sc->s_last = sc->s_prev = nullptr;
   sc->tol = tol; sc->nonzero = 0; sc->done = 0; sc->iters = 0; sc->max_iters = max_iters;
 }
 
@@ -1734,7 +1812,7 @@ int eu_launch_project(euler_sim* S, float dt) {
     for (; it < chunk_end; ++it) {
       S->prof_iter = it;
       const bool fused = it > 0;   // update_search of iteration it-1 rides along with this apply_a (A s' lands in q)
-      if ((rc = fused ? launch_search_apply_and_alpha(S) : launch_apply_a_and_alpha(S, 0))) return rc;
+      if ((rc = fused ? launch_search_apply_and_alpha(S, it) : launch_apply_a_and_alpha(S, 0))) return rc;
       if (tile) {
         // r -= alpha A s, max |r| (sets `done`), z = M^-1 r, beta = dot(z, r) / sigma: one pass; on the last iteration of the
         // budget only r and its norm (main.c:760-765 would be computed and never consumed)

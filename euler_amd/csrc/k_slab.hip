@@ -29,17 +29,23 @@
 #include "euler_dev.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
-#define SL_EV_CAP 1024        // dt-chain candidates per rank and substep (they are rare: a marker must hit a solid after crossing a cell)
-#define SL_DEL_CAP 4096       // markers deleted per rank and substep (sinks / solids)
-#define SL_SORT_CAP 65536     // merged list of all ranks (16 ranks x SL_DEL_CAP)
+// Exchange capacities per rank and substep grow with the grid (SlabScratch::ev_cap / del_cap): what can hit a wall or
+// fall into a sink in one substep is a front of <= 0.75 cell times a length of the order of X, four markers to a cell.
+//   dt-chain candidates: 1024 + X / 2   (rare: a marker must hit a solid after crossing a cell)
+//   deletions:           4096 + 8 X     (sinks / solids)
+// An overflow anywhere is raised on EVERY rank - all ranks read the same counters in the gathered blocks, and local
+// overflows (migration, marker capacity) travel with the next exchange of the error word (slab_error_sync) - so the job
+// fails collectively instead of hanging in the next exchange.
 #define SL_MAXR 16
 
 struct SlMigrant { float x, y; unsigned int key; };
 
 struct SlabScratch {
   int R, rank;
+  unsigned int ev_cap, del_cap, sort_cap;   // per-rank capacities (above); sort_cap = power of two >= R * max(ev_cap, del_cap)
   size_t blk;                     // bytes of one rank's block in the all-gather buffer
   char* xg;                       // [R][blk]: {u64 count; payload}
   unsigned long long* sortbuf;    // [SL_SORT_CAP]
@@ -66,17 +72,25 @@ int eu_slab_alloc(euler_sim* S) {
   S->slab = s;
   s->R = S->cfg.slab_nranks; s->rank = S->cfg.slab_rank;
   if (s->R > SL_MAXR) { eu_set_error("row slabs: at most %d ranks", SL_MAXR); return EULER_EINVAL; }
-  const size_t ev_blk = 8 + (size_t)16 * SL_EV_CAP, del_blk = 8 + (size_t)4 * SL_DEL_CAP;
-  s->blk = ev_blk > del_blk ? ev_blk : del_blk;
+  s->ev_cap = 1024u + (unsigned int)S->X / 2u;
+  s->del_cap = 4096u + 8u * (unsigned int)S->X;
+  if (const char* e = getenv("EULER_SLAB_CAPS")) {      // tests: tiny capacities to drive the overflow path
+    unsigned int a = 0, b = 0;
+    if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1 && b >= 1) { s->ev_cap = a; s->del_cap = b; }
+  }
+  const size_t merged = (size_t)s->R * (s->ev_cap > s->del_cap ? s->ev_cap : s->del_cap);
+  s->sort_cap = 1; while (s->sort_cap < merged) s->sort_cap <<= 1;
+  const size_t ev_blk = 8 + (size_t)16 * s->ev_cap, del_blk = 8 + (size_t)4 * s->del_cap;
+  s->blk = ((ev_blk > del_blk ? ev_blk : del_blk) + 15) & ~(size_t)15;
   s->mig_cap = (size_t)16 * S->X + 4096;
   const size_t mig_bytes = 8 + s->mig_cap * sizeof(SlMigrant), row_bytes = (size_t)S->X * 4 * 2 * 2 + 64;   // ghost rows: <= 2 fields x 2 rows of floats
   s->buf_doubles = ((mig_bytes > row_bytes ? mig_bytes : row_bytes) + 7) / 8;
   HIPCHK(hipMalloc((void**)&s->xg, s->blk * s->R));
   HIPCHK(hipMemset(s->xg, 0, s->blk * s->R));
-  HIPCHK(hipMalloc((void**)&s->sortbuf, SL_SORT_CAP * 8));
-  HIPCHK(hipMalloc((void**)&s->ev_th, SL_SORT_CAP * 4));
-  HIPCHK(hipMalloc((void**)&s->ev_de, SL_SORT_CAP * 4));
-  HIPCHK(hipMalloc((void**)&s->d_sorted, SL_SORT_CAP * 4));
+  HIPCHK(hipMalloc((void**)&s->sortbuf, (size_t)s->sort_cap * 8));
+  HIPCHK(hipMalloc((void**)&s->ev_th, (size_t)s->sort_cap * 4));
+  HIPCHK(hipMalloc((void**)&s->ev_de, (size_t)s->sort_cap * 4));
+  HIPCHK(hipMalloc((void**)&s->d_sorted, (size_t)s->sort_cap * 4));
   for (double** b : {&s->send_lo, &s->send_hi, &s->recv_lo, &s->recv_hi}) {
     HIPCHK(hipMalloc((void**)b, s->buf_doubles * 8));
     HIPCHK(hipMemset(*b, 0, s->buf_doubles * 8));
@@ -141,8 +155,18 @@ static int exchange_rows(euler_sim* S, const GhostField* f, int nf) {
   for (int k = 0; k < nf; ++k) {
     char* b = static_cast<char*>(f[k].base);
     const size_t rb = X * f[k].elem;
-    if (has_lo && f[k].hi) HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(s->send_lo) + o_dn, b + (size_t)S->row_lo * rb, f[k].hi * rb, hipMemcpyDeviceToDevice, st));
-    if (has_hi && f[k].lo) HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(s->send_hi) + o_up, b + (size_t)(S->row_hi - f[k].lo) * rb, f[k].lo * rb, hipMemcpyDeviceToDevice, st));
+    // (a slab may own fewer rows than the neighbour has ghost rows - the grid's last band can be a single row: send what exists,
+    // the rest of the slot as zeros; the receiver drops rows beyond the grid anyway)
+    const int own = S->row_hi - S->row_lo;
+    const int n_dn = f[k].hi < own ? f[k].hi : own, n_up = f[k].lo < own ? f[k].lo : own;
+    if (has_lo && f[k].hi) {
+      if (n_dn < f[k].hi) HIPCHK(hipMemsetAsync(reinterpret_cast<char*>(s->send_lo) + o_dn, 0, f[k].hi * rb, st));
+      HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(s->send_lo) + o_dn, b + (size_t)S->row_lo * rb, n_dn * rb, hipMemcpyDeviceToDevice, st));
+    }
+    if (has_hi && f[k].lo) {
+      if (n_up < f[k].lo) HIPCHK(hipMemsetAsync(reinterpret_cast<char*>(s->send_hi) + o_up, 0, f[k].lo * rb, st));
+      HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(s->send_hi) + o_up, b + (size_t)(S->row_hi - n_up) * rb, n_up * rb, hipMemcpyDeviceToDevice, st));
+    }
     o_dn += f[k].hi * rb; o_up += f[k].lo * rb;
   }
   const size_t bytes = o_dn > o_up ? o_dn : o_up;
@@ -179,16 +203,29 @@ static int exchange_vtmp(euler_sim* S) {
 }
 
 // ------------------------------------------------------------------------------------------ timestep
+// (the sticky error word of every rank rides along: an overflow on one rank becomes every rank's error before the substep starts)
 __global__ void k_maxsq_to_vec(const MarkerState* ms, double* v) {
-  v[0] = (double)__uint_as_float(ms->max_u2_bits); v[1] = (double)__uint_as_float(ms->max_v2_bits);
+  v[0] = (double)__uint_as_float(ms->max_u2_bits); v[1] = (double)__uint_as_float(ms->max_v2_bits); v[2] = (double)ms->error;
 }
 __global__ void k_maxsq_from_vec(MarkerState* ms, const double* v) {
   ms->max_u2_bits = __float_as_uint((float)v[0]); ms->max_v2_bits = __float_as_uint((float)v[1]);
+  if (!ms->error && v[2] != 0.0) ms->error = (int)v[2];
+}
+__global__ void k_error_to_vec(const MarkerState* ms, double* v) { v[0] = (double)ms->error; }
+__global__ void k_error_from_vec(MarkerState* ms, const double* v) { if (!ms->error && v[0] != 0.0) ms->error = (int)v[0]; }
+// end of a frame: one more exchange of the error word, so that the final sync of euler_step fails (or passes) on all ranks alike
+int eu_slab_error_sync(euler_sim* S) {
+  SlabScratch* s = S->slab;
+  if (!S->has_comm) return EULER_OK;
+  hipLaunchKernelGGL(k_error_to_vec, dim3(1), dim3(1), 0, S->stream, S->ms, s->vec);
+  COMM_CALL(S->comm.allreduce(S->comm.ctx, s->vec, 1, 1));
+  hipLaunchKernelGGL(k_error_from_vec, dim3(1), dim3(1), 0, S->stream, S->ms, s->vec);
+  return EULER_OK;
 }
 int eu_slab_timestep(euler_sim* S, float frame_time_left) {   // k_maxsq over the own rows has been launched
   SlabScratch* s = S->slab;
   hipLaunchKernelGGL(k_maxsq_to_vec, dim3(1), dim3(1), 0, S->stream, S->ms, s->vec);
-  COMM_CALL(S->comm.allreduce(S->comm.ctx, s->vec, 2, 1));
+  COMM_CALL(S->comm.allreduce(S->comm.ctx, s->vec, 3, 1));
   hipLaunchKernelGGL(k_maxsq_from_vec, dim3(1), dim3(1), 0, S->stream, S->ms, s->vec);
   return eu_launch_dt(S, frame_time_left);
 }
@@ -216,10 +253,11 @@ struct SlEvent { unsigned int key, pad; float theta, delta; };
 
 __global__ __launch_bounds__(256) void k_pack_events(const unsigned int* __restrict__ ev_idx, const float* __restrict__ theta,
                                                      const float* __restrict__ delta, const unsigned int* __restrict__ keys,
-                                                     MarkerState* ms, char* block) {
-  unsigned int n = ms->n_events;
-  if (n > SL_EV_CAP) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicExch(&ms->error, 16); n = SL_EV_CAP; }
-  if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<unsigned long long*>(block) = n;
+                                                     MarkerState* ms, char* block, unsigned int cap) {
+  const unsigned int n_all = ms->n_events;
+  const unsigned int n = n_all > cap ? cap : n_all;
+  // the header carries the TRUE count: every rank sees the overflow in the gathered blocks (k_event_chain) and fails with it
+  if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<unsigned long long*>(block) = n_all;
   SlEvent* e = reinterpret_cast<SlEvent*>(block + 8);
   for (unsigned int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
     const unsigned int i = ev_idx[k];
@@ -231,11 +269,16 @@ __global__ __launch_bounds__(256) void k_pack_events(const unsigned int* __restr
 // that order -> (key, dt after it) of the collisions that fire, exactly k_marker_walk's output on the reference's array
 __global__ __launch_bounds__(1024) void k_event_chain(const char* __restrict__ xg, int R, size_t blk, unsigned long long* sortbuf,
                                                       float* __restrict__ th, float* __restrict__ de, unsigned int* __restrict__ act_key,
-                                                      float* __restrict__ act_dt, MarkerState* ms, float dt0) {
+                                                      float* __restrict__ act_dt, MarkerState* ms, float dt0, unsigned int cap) {
   __shared__ unsigned int base[SL_MAXR + 1];
   if (threadIdx.x == 0) {
     unsigned int t = 0;
-    for (int r = 0; r < R; ++r) { base[r] = t; t += (unsigned int)*reinterpret_cast<const unsigned long long*>(xg + (size_t)r * blk); }
+    for (int r = 0; r < R; ++r) {
+      base[r] = t;
+      const unsigned long long c = *reinterpret_cast<const unsigned long long*>(xg + (size_t)r * blk);
+      if (c > cap) atomicExch(&ms->error, 16);      // some rank had more candidates than fit: every rank reads this and stops
+      t += (unsigned int)(c < cap ? c : cap);
+    }
     base[R] = t;
   }
   __syncthreads();
@@ -307,7 +350,7 @@ __global__ void k_migrate_done(MarkerState* ms, const char* recv_lo, const char*
 __global__ __launch_bounds__(256) void k_bin_markers_slab(const float2* __restrict__ m, const unsigned int* __restrict__ keys, MarkerState* ms,
                                                           const uint8_t* __restrict__ sink, const uint8_t* __restrict__ solid,
                                                           unsigned int* count32, unsigned long long* __restrict__ rmmask, size_t mask_words, int X,
-                                                          int row_lo, int row_hi, int win_lo, int win_h, char* del_block) {
+                                                          int row_lo, int row_hi, int win_lo, int win_h, char* del_block, unsigned int del_cap) {
   const unsigned long long n = ms->n_loc;
   const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   bool rm = false, live = false;
@@ -322,8 +365,7 @@ __global__ __launch_bounds__(256) void k_bin_markers_slab(const float2* __restri
       if ((sink[c] | solid[c]) != 0) {
         rm = true;
         const unsigned long long slot = atomicAdd(reinterpret_cast<unsigned long long*>(del_block), 1ull);
-        if (slot < SL_DEL_CAP) reinterpret_cast<unsigned int*>(del_block + 8)[slot] = keys[i];
-        else atomicExch(&ms->error, 18);
+        if (slot < del_cap) reinterpret_cast<unsigned int*>(del_block + 8)[slot] = keys[i];      // (the counter keeps the true number: k_merge_deleted raises the overflow on every rank)
       } else live = true;
     }
   }
@@ -334,14 +376,15 @@ __global__ __launch_bounds__(256) void k_bin_markers_slab(const float2* __restri
 
 // every rank: the deleted keys of all ranks, ascending
 __global__ __launch_bounds__(1024) void k_merge_deleted(char* xg, int R, size_t blk, int my_rank, unsigned long long* sortbuf,
-                                                        unsigned int* __restrict__ d_sorted, MarkerState* ms) {
+                                                        unsigned int* __restrict__ d_sorted, MarkerState* ms, unsigned int del_cap) {
   __shared__ unsigned int base[SL_MAXR + 1];
   if (threadIdx.x == 0) {
     unsigned int t = 0;
     for (int r = 0; r < R; ++r) {
       base[r] = t;
       unsigned long long c = *reinterpret_cast<const unsigned long long*>(xg + (size_t)r * blk);
-      t += (unsigned int)(c < SL_DEL_CAP ? c : SL_DEL_CAP);
+      if (c > del_cap) atomicExch(&ms->error, 18);      // every rank reads the same counters: the job fails as one
+      t += (unsigned int)(c < del_cap ? c : del_cap);
     }
     base[R] = t;
     ms->n_del_glob = t;
@@ -415,9 +458,9 @@ static int slab_refresh(euler_sim* S, unsigned long long n_upper) {
   char* my_block = s->xg + (size_t)s->rank * s->blk;
   HIPCHK(hipMemsetAsync(my_block, 0, 8, S->stream));     // the deletion counter (the block carried this substep's dt-chain candidates before)
   LAUNCH(S, KC_MARKER_BIN, k_bin_markers_slab, dim3(eu_blocks((size_t)n_upper + 1, 256)), dim3(256), S->markers[S->cur], S->keys[S->cur], S->ms,
-         S->sink, S->solid, S->count32, s->mask2, mask_words, S->X, S->row_lo, S->row_hi, S->win_lo, S->win_hi - S->win_lo, my_block);
+         S->sink, S->solid, S->count32, s->mask2, mask_words, S->X, S->row_lo, S->row_hi, S->win_lo, S->win_hi - S->win_lo, my_block, s->del_cap);
   COMM_CALL(S->bulk.allgather(S->bulk.ctx, s->xg, s->ag_off.data(), s->ag_cnt.data()));
-  LAUNCH(S, KC_MARKER_COMPACT, k_merge_deleted, dim3(1), dim3(1024), s->xg, s->R, s->blk, s->rank, s->sortbuf, s->d_sorted, S->ms);
+  LAUNCH(S, KC_MARKER_COMPACT, k_merge_deleted, dim3(1), dim3(1024), s->xg, s->R, s->blk, s->rank, s->sortbuf, s->d_sorted, S->ms, s->del_cap);
   LAUNCH(S, KC_MARKER_COMPACT, k_rekey, dim3(eu_blocks((size_t)n_upper + 1, 256, 4096)), dim3(256), S->keys[S->cur], s->mask2, s->d_sorted, S->ms);
   int rc = eu_ordered_select(S, s->mask2, (size_t)((n_upper + 63) / 64), S->sel_idx, &S->ms->n_rm);
   if (rc) return rc;
@@ -501,9 +544,9 @@ static int slab_advect_markers(euler_sim* S, float dt) {
   int rc = eu_marker_advect_a(S, dt, n);                 // every local marker with the incoming dt; candidates -> sel_idx
   if (rc) return rc;
   LAUNCH(S, KC_MARKER_EVENTS, k_pack_events, dim3(4), dim3(256), S->sel_idx, S->ev_theta, S->ev_delta, S->keys[S->cur], S->ms,
-         s->xg + (size_t)s->rank * s->blk);
+         s->xg + (size_t)s->rank * s->blk, s->ev_cap);
   COMM_CALL(S->bulk.allgather(S->bulk.ctx, s->xg, s->ag_off.data(), s->ag_cnt.data()));
-  LAUNCH(S, KC_MARKER_EVENTS, k_event_chain, dim3(1), dim3(1024), s->xg, s->R, s->blk, s->sortbuf, s->ev_th, s->ev_de, S->act_idx, S->act_dt, S->ms, dt);
+  LAUNCH(S, KC_MARKER_EVENTS, k_event_chain, dim3(1), dim3(1024), s->xg, s->R, s->blk, s->sortbuf, s->ev_th, s->ev_de, S->act_idx, S->act_dt, S->ms, dt, s->ev_cap);
   if ((rc = eu_marker_advect_b(S, n, S->keys[S->cur]))) return rc;
   HIPCHK(hipMemcpyAsync(S->keys[S->cur ^ 1], S->keys[S->cur], (size_t)n * sizeof(unsigned int), hipMemcpyDeviceToDevice, S->stream));
   S->cur ^= 1;

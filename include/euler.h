@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define EULER_ABI_VERSION 1
+#define EULER_ABI_VERSION 2   /* 2: euler_comm_ops.exchange, row-slab snapshots */
 
 enum {
   EULER_OK = 0,
@@ -240,12 +240,16 @@ int euler_render_grids_rgb(const uint8_t* solid, const uint8_t* sink, const uint
 /* colorize() (main.c:187-201), the reference's 'r' key (main.c:970-973): recolour the current fluid. */
 int euler_colorize(euler_sim* sim);
 
-/* ---- multi-GPU: the pressure solve distributed over row slabs (DESIGN.md "Multi-GPU") ------ */
-/* One process per GPU.  Every rank holds the whole grid and runs the cheap stages (markers,
- * advection, extrapolation) redundantly and bit-identically; the pressure solve - project(),
- * main.c:709-806, >= 97 % of the time - is partitioned into contiguous slabs of 64-row bands.
- * The library keeps driving the PCG loop and calls these four operations at its exchange points;
- * the host program implements them (euler_amd/slab.py: torch.distributed = RCCL on the node).
+/* ---- multi-GPU: 1-D row slabs (DESIGN.md "Multi-GPU") ------------------------------ */
+/* One process per GPU.  Two layouts share the communicator interface below:
+ *   row slabs for EVERY stage (euler_config.slab_nranks >= 1; the default of bench.py --gpus N): a handle holds only the rows of
+ *     its 64-row bands (+ ghost rows) of every field and the markers inside them; ghost rows of u / v / counts, marker migration,
+ *     the dt all-reduce and the distributed PCG all go through these operations;
+ *   round 1's layout (euler_set_comm on a full-size handle): only the pressure solve - project(), main.c:709-806 - is partitioned
+ *     into slabs of bands, the cheap stages run replicated on the whole grid.  Kept because its exact IC(0) coupling
+ *     (EULER_SLAB_EXACT) is the one multi-rank mode that reproduces the single-GPU ITERATES.
+ * The library drives the substep and calls these operations at its exchange points; the host program implements them
+ * (euler_amd/slab.py: torch.distributed) or installs the library's own RCCL communicator (euler_set_comm_rccl).
  * All pointers are DEVICE pointers into the handle's buffers; operations must be ordered on the
  * stream given to euler_set_stream.  Each returns 0 on success. */
 typedef struct euler_comm_ops {
@@ -260,6 +264,12 @@ typedef struct euler_comm_ops {
   int (*chain)(void* ctx, void* dev_ptr, int64_t nbytes, int32_t src, int32_t dst);
   /* all-gather: rank r contributes bytes [off[r], off[r]+cnt[r]) of the array at dev_base */
   int (*allgather)(void* ctx, void* dev_base, const int64_t* off, const int64_t* cnt);
+  /* ONE exchange for a PCG iteration's latency-bound traffic (SURVEY 8e "fuse ... into one message pair"; optional - null: the
+   * library issues halo + allgather instead): `count` doubles to / from each neighbour exactly like halo (count = 0: none), AND
+   * an all-gather of `nsmall` doubles per rank: rank r's contribution sits at small[r * nsmall] (in place), every rank ends up
+   * with all of them, which it folds in rank order - the same bits everywhere.  The built-in RCCL communicator issues all of it
+   * as one group of sends and receives. */
+  int (*exchange)(void* ctx, void* send_lo, void* send_hi, void* recv_lo, void* recv_hi, int32_t count, void* small, int32_t nsmall);
 } euler_comm_ops;
 
 enum {

@@ -157,3 +157,42 @@ def test_switching_the_preconditioner_on_a_live_handle():
             a.step()
             o.step()
         compare_all(o, a, "units %d" % units)
+
+
+@pytest.mark.parametrize("max_it", [100, 37, 2, 1])
+def test_interior_chunks_and_two_step_pressure_update_bit_exact(max_it):
+    """Chunks deep inside the water (every cell fluid, four fluid neighbours, a_diag 4) take the constant-mask instantiations of
+    k_search_apply / k_precond_tile with E^-1 from the per-handle table (k_tile_table) instead of the precon array, and p is
+    updated every second iteration with the two fmadds that are due (k_search_apply PMODE 2, k_finish_p): budgets that end on an
+    even and on an odd iteration, one and two iterations, against the oracle's plain restatement - every bit of p, u, v."""
+    X, Y = 260, 300      # band 1 (rows 64..127) lies whole inside the half tank's water: interior tiles at records 80..255
+    o = Oracle(X, Y).load_half_tank()
+    o.c.tile_records = 16
+    o.c.max_iterations = max_it
+    sim = ea.Simulation(X, Y, dot_mode=ea.DOT_SEQUENTIAL, precond=ea.PRECOND_IC0_TILE, tile_records=16, max_iterations=max_it).load_half_tank()
+    for f in range(3):
+        o.step()
+        sim.step()
+        st = sim.stats()
+        assert st.last_substeps == o.c.last_substeps and st.last_pcg_iterations == o.c.last_pcg_iterations, f
+        compare_all(o, sim, "half tank %dx%d, budget %d, frame %d" % (X, Y, max_it, f))
+    m = sim.get(ea.F_CELLMASK)
+    assert (m[64:128, 3:257] == 0x9F).all()      # the band really is interior
+
+
+def test_tile_mode_moving_water_lean_assembly_bit_exact():
+    """A dam break several bands deep, 30 frames in tile-local mode: chunks turn from interior to partial to empty and back while
+    the assembly (k_build_system<true>) only rewrites the chunks that hold or held fluid - against the oracle every frame, and
+    the solver's own arrays must carry no stale entry: masks and p are +0 wherever the cell grid says air."""
+    text = scenario_text(load("block_frames.npz"))
+    X, Y = 384, 448
+    o = Oracle(X, Y).load_text(text, upscale=True)
+    o.c.tile_records = 16
+    sim = ea.Simulation(X, Y, dot_mode=ea.DOT_SEQUENTIAL, precond=ea.PRECOND_IC0_TILE, tile_records=16).load_text(text, upscale=True)
+    for f in range(30):
+        o.step()
+        sim.step()
+        compare_all(o, sim, "dam break %dx%d frame %d" % (X, Y, f))
+        air = sim.get(ea.F_COUNT) == 0
+        assert (sim.get(ea.F_CELLMASK)[air] == 0).all(), f
+        assert (sim.get(ea.F_PRESSURE)[air] == 0).all(), f

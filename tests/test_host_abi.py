@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), "include/euler.h declares %s but libeuler_hip.so does not export it" % name
     assert declared == set(ea.EXPORTS)
-    assert L.euler_abi_version() == 1
+    assert L.euler_abi_version() == 2
 
 
 def test_no_cpu_fallback():
