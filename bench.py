@@ -47,13 +47,15 @@ ALGO_BYTES = {
     "dot": 2 * W + 1,              # read z, r
     "update_pr": 6 * W + 1,        # read s, z, p, r; write p, r
     "update_search": 3 * W + 1,    # read z, s; write s
-    "precond_tile": 5 * W + 1,     # tile-local mode: read r, A s, precon; write r, z  (K2's r half, K3, K4 and dot in one pass)
+    "precond_tile": 4 * W + 1,     # tile-local mode: read r, A s; write r, z  (K2's r half, K3, K4 and dot in one pass; E^-1 of an interior
+                                   # tile is the per-handle table, round 3 - boundary tiles still stream 8 B more)
 }
 APPLY_A_FUSED = {"ic0": 5 * W + 1,       # update_search fused in: read s, z; write s', A s'  (+ neighbours from cache)
-                 "ic0_tile": 6 * W + 1}  # ... and the previous iteration's p += alpha s: read + write p as well
+                 "ic0_tile": 5.5 * W + 1}  # ... and p += alpha s of two iterations on every second one: read s, z (+ s of two iterations ago
+                                           # and p every second iteration); write s', A s' (+ p every second iteration): 4w + 1.5w
 # whole PCG iteration per cell (SURVEY 8d "Algorithmic bytes"): the reference's IC(0) as five kernels 18w+5; the tile-local
 # variant as the two passes it runs, 11w+2 - "the figure for that variant ... never the larger one"
-PCG_BYTES = {"ic0": 18 * W + 5, "ic0_tile": 11 * W + 2, "jacobi": 11 * W + 3}
+PCG_BYTES = {"ic0": 18 * W + 5, "ic0_tile": 9.5 * W + 2, "jacobi": 11 * W + 3}   # tile-local: 5.5w+1 + 4w+1 = 78 (round 2: 11w+2 = 90)
 PCG_CLASSES = ["forward_solve", "backward_solve", "apply_a", "dot", "update_pr", "update_search", "precond_tile"]
 KERNEL_OF_CLASS = {"forward_solve": "k_sweep_skew<1", "backward_solve": "k_sweep_skew<2", "precon_factor": "k_sweep_skew<0",
                    "apply_a": "k_search_apply", "dot": "k_dot_partial", "update_pr": "k_update_pr", "precond_tile": "k_precond_tile"}
@@ -105,6 +107,7 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true", help="headline case only (no parity-mode / 1024^2 / 16384^2 / time-to-solution blocks)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 PMC passes (roofline.traffic is then null)")
     ap.add_argument("--no-16384", action="store_true", help="skip the 16384^2 projection block")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong_16384_dam_break block (BASELINE configs[3]; N = 1: its denominator)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # this process runs under rocprofv3 --pmc
     return ap.parse_args()
 
@@ -312,6 +315,114 @@ def balanced_partition(weights, world):
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
+def make_handle(ctx, GX, GY, workload, tiles, slab_arg, precond, tol):
+    """create a handle (the whole grid, or this rank's slab), attach the exchanges, load the workload -> (sim, comm, p2p, HBM bytes)"""
+    import torch
+    args, ea, rank = ctx["args"], ctx["ea"], ctx["rank"]
+    free_before = torch.cuda.mem_get_info()[0]
+    sm = ea.Simulation(GX, GY, device=ctx["local_rank"], dot_mode=ctx["dot_mode"], precond=ctx["PC"][precond], tile_records=args.tile_records, tol=tol,
+                       slab=slab_arg)
+    hbm = free_before - torch.cuda.mem_get_info()[0]
+    cm, p2p = None, False
+    if ctx["sharded"]:
+        from euler_amd.slab import SLAB_EXACT, SLAB_LOCAL, RcclComm, TorchComm, attach_p2p
+        coupling = SLAB_EXACT if args.slab == "exact" else SLAB_LOCAL
+        if args.comm == "rccl":
+            from euler_amd.slab import RcclUnavailable
+            try:
+                cm = RcclComm(sm, coupling)
+            except RcclUnavailable as e:          # raised on every rank alike: the job goes on over torch.distributed, and says so
+                if rank == 0:
+                    print("bench: %s; exchanges fall back to torch.distributed callbacks" % e, file=sys.stderr)
+                args.comm = "torch"
+        if args.comm == "torch":
+            cm = TorchComm(sm, coupling)
+        p2p = args.p2p and attach_p2p(sm)
+        if rank == 0 and args.p2p and not p2p and not ctx["comm_note"]:
+            ctx["comm_note"].append(1)
+            print("bench: peer-to-peer mailboxes unavailable (%s); exchanges stay on %s" % (sm._p2p_error, args.comm), file=sys.stderr)
+    load_workload(sm, ctx["scenarios"], workload, tiles)
+    return sm, cm, p2p, hbm
+
+
+def pilot_partition(ctx, GX, GY, workload, tiles, saturate):
+    """ONE picture over all ranks: even row slabs leave the ranks above (or below) the water with air.  A pilot pass with even
+    slabs runs the untimed preroll, every rank reports the fluid cells of its bands, and the timed pass is created with band
+    ranges that balance them (euler_config.slab_band_lo / hi) and pre-rolled by the same number of frames.
+    -> (band ranges per rank, preroll frames)"""
+    args, ea, grp, rank, world = ctx["args"], ctx["ea"], ctx["grp"], ctx["rank"], ctx["world"]
+    pilot, pcomm, _, _ = make_handle(ctx, GX, GY, workload, tiles, (rank, world), args.precond, ctx["tol"] if workload == args.workload else None)
+    preroll = preroll_into_solves(pilot, args.max_preroll, saturate)
+    r0, r1 = pilot.slab_rows()
+    fl_rows = (pilot.get(ea.F_COUNT) > 0).sum(axis=1)                # own rows
+    mine = [[(r0 + k) // 64, int(fl_rows[k:k + 64].sum())] for k in range(0, r1 - r0, 64)]
+    if pcomm is not None and getattr(pcomm, "error", None):
+        raise RuntimeError(pcomm.error)
+    pilot.close()
+    del pilot, pcomm
+    allb = [None] * world
+    grp.dist.all_gather_object(allb, mine)
+    nb = (GY + 63) // 64
+    weights = [0.02 * 64 * GX] * nb                                  # an air cell costs a few dozen bytes per substep, a fluid cell ~9 KB
+    for lst in allb:
+        for bnd, cnt in lst:
+            weights[bnd] += cnt
+    return balanced_partition(weights, world), preroll
+
+
+def rank_balance(ctx, sim, partition):
+    import numpy as np  # noqa: F401
+    grp, world = ctx["grp"], ctx["world"]
+    per_rank = [None] * world
+    grp.dist.all_gather_object(per_rank, [int(sim.stats().fluid_cells), list(sim.slab_rows())])
+    fl = [p[0] for p in per_rank]
+    return {"partition": "fluid-balanced band ranges (from a pilot pass with even slabs)" if partition else "even rows",
+            "rows_per_rank": [p[1] for p in per_rank], "fluid_cells_per_rank": fl,
+            "max_over_mean": round(max(fl) / max(sum(fl) / len(fl), 1.0), 3)}
+
+
+def strong_block(ctx, size, steps, tile_w):
+    """BASELINE configs[3] (SURVEY 8d Config 4): ONE size x size dam break, main.c:843-900 per substep, the unit of the north star's
+    strong-scaling target.  N > 1: split into fluid-balanced row slabs (collective: every rank calls this); N = 1: the same scenario
+    on one GPU, the curve's denominator.  Timed like the headline (barrier + sync on both sides, MAX over ranks).  Rank 0 gets the
+    block, the others None."""
+    args, ea, grp, rank, world = ctx["args"], ctx["ea"], ctx["grp"], ctx["rank"], ctx["world"]
+    multi = ctx["sharded"] and world > 1
+    t_setup = time.perf_counter()
+    if multi:
+        partition, preroll = pilot_partition(ctx, size, size, "dam_break", 1, False)
+        sim, comm, p2p_on, hbm = make_handle(ctx, size, size, "dam_break", 1, (rank, world, partition[rank][0], partition[rank][1]), args.precond, None)
+        for _ in range(preroll):
+            sim.step()
+    else:
+        partition = None
+        sim, comm, p2p_on, hbm = make_handle(dict(ctx, sharded=False), size, size, "dam_break", 1, None, args.precond, None)
+        preroll = preroll_into_solves(sim, args.max_preroll, False)
+    setup_s = time.perf_counter() - t_setup
+    t = time_frames(sim, ea, grp, args, args.precond, steps, 0, 1, True)
+    if comm is not None and getattr(comm, "error", None):
+        raise RuntimeError(comm.error)
+    balance = rank_balance(ctx, sim, partition) if multi else None
+    out = None
+    if rank == 0:
+        rank_cells = None
+        if multi:
+            r0, r1 = sim.slab_rows()
+            rank_cells = size * (r1 - r0)
+        blk = summarize(t, size, size, args.precond, tile_w, None, None, steps, rank_cells=rank_cells)
+        out = {k: blk[k] for k in ("mode", "value", "unit", "ms_per_step", "substeps", "pcg_iterations", "cells_substeps_per_s", "fluid_cells",
+                                   "markers", "last_residual", "roofline", "pcg_iteration")}
+        out.update({"workload": "%dx%d dam break (block layout upscaled; BASELINE configs[3]), %d timed frames after %d preroll frames "
+                                "(into the phase where every substep runs PCG to the iteration cap)" % (size, size, steps, preroll),
+                    "n_gpus": world if multi else 1, "scaling": "strong", "balance": balance, "hbm_bytes_this_rank": int(hbm),
+                    "setup_and_preroll_seconds": round(setup_s, 1),
+                    "note": ("rank 0's kernels cover its slab; `value` is the whole job" if multi else
+                             "one GPU: the denominator of the strong-scaling curve (run `bench.py --gpus N` for the N-GPU points of the same scenario)")})
+    sim.close()
+    del sim
+    return out
+
+
 def kernel_rows(prof, precond, cells_fluid, traffic, fused_search):
     """per kernel class: launch time and the byte counts -> GB/s"""
     rows = {}
@@ -391,15 +502,17 @@ def summarize(t, size_x, size_y, precond, tile_w, traffic, traffic_note, steps, 
         b = r.get("bytes_per_cell", 0)
         tr = r.get("traffic_bytes_per_launch")
         active = b * fluid / sec / 1e9
-        achieved = (tr / sec / 1e9) if tr else active
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": int(tr) if tr else None,
+        # `achieved` / `frac` = ALGORITHMIC bytes (SURVEY 8d's per-cell figure for this variant x the fluid cells one launch processes)
+        # / average launch time; the PMC traffic (FETCH_SIZE counts Infinity-Cache hits too) stays beside it as traffic / frac_traffic
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(active, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(active / HBM_PEAK_GBPS, 4), "traffic": int(tr) if tr else None,
                 "frac_traffic": round(tr / sec / 1e9 / HBM_PEAK_GBPS, 4) if tr else None,
-                "achieved_algorithmic": round(active, 1),      # SURVEY 8d bytes x the fluid cells one launch processes / launch time
+                "traffic_over_algorithmic": round(tr / (b * fluid), 3) if tr else None,
+                "achieved_algorithmic": round(active, 1),
                 "frac_active": round(active / HBM_PEAK_GBPS, 4),
                 "frac_dense": round(b * cells / sec / 1e9 / HBM_PEAK_GBPS, 4),
-                "achieved_is": "PMC traffic / launch time" if tr else "algorithmic bytes x fluid cells / launch time (no PMC pass)",
-                "algorithmic_bytes_per_cell": b, "algorithmic_bytes_per_launch_active": b * fluid,
+                "achieved_is": "algorithmic bytes per cell x fluid cells of one launch / average launch time (HIP events in the timed region)",
+                "algorithmic_bytes_per_cell": b, "algorithmic_bytes_per_launch_active": int(b * fluid),
                 "avg_launch_us": r["avg_us"], "launches": r["launches"], "fluid_fraction": round(fluid / cells, 4),
                 "traffic_source": traffic_note,
                 "note": "frac_dense counts ALL X*Y cells like the reference's dense loops and may exceed 1 on sparse scenes; the kernels "
@@ -424,6 +537,116 @@ def summarize(t, size_x, size_y, precond, tile_w, traffic, traffic_note, steps, 
             "cells_substeps_per_s": cells_job * t["substeps"] / t["elapsed"],
             "fluid_cells": fluid, "markers": int(t["st1"].n_markers), "last_residual": float(t["st1"].last_residual),
             "roofline": roof, "pcg_iteration": agg, "kernels": rows}
+
+
+def equal_residual(sim, ea, grp, args, GX, GY, tile_w):
+    """Reference-quality throughput of the roofline mode.  On the state the timed frames left (the saturated tank), ONE pressure
+    system - the stages of a substep up to project(), main.c:855-889, run once; project() reads utmp / vtmp / the cell grid and
+    can be repeated - is solved with the reference's IC(0) and the reference's budget of 100 iterations (main.c:735): its residual
+    is the bar.  Then the tile-local mode gets the smallest budget (steps of 4) whose residual on the SAME system is at or below
+    that bar, and frames are timed with that budget: cells*steps/s at equal residual."""
+    import torch
+    dt = sim.timestep(0.1)
+    for st in (ea.STAGE_ADVECT_MARKERS, ea.STAGE_REFRESH_COUNTS, ea.STAGE_SOURCES, ea.STAGE_EXTRAPOLATE, ea.STAGE_ADVECT_VELOCITY):
+        sim.stage(st, dt)
+
+    def solve(precond, budget):
+        sim.set_precond(precond, args.tile_records)
+        sim.set_solver(budget)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sim.stage(ea.STAGE_PROJECT, dt)
+        torch.cuda.synchronize()
+        st = sim.stats()
+        return {"ms": round(1e3 * (time.perf_counter() - t0), 2), "iterations": int(st.last_pcg_iterations), "residual": float(st.last_residual)}
+
+    solve(ea.PRECOND_IC0, 100)                      # (untimed: first launches of the sweep kernels on this handle)
+    exact = solve(ea.PRECOND_IC0, 100)
+    tile100 = solve(ea.PRECOND_IC0_TILE, 100)
+    budget, tile = 100, tile100
+    scan = [[100, tile100["residual"]]]
+    while tile["residual"] > exact["residual"] and budget < 400:
+        budget += 4
+        tile = solve(ea.PRECOND_IC0_TILE, budget)
+        scan.append([budget, tile["residual"]])
+    out = {"system": "%dx%d %s, the state behind the timed frames, one substep's pressure system (dt %.3g)" % (GX, GY, args.workload, dt),
+           "reference_ic0_100_iterations": exact, "tile_100_iterations": tile100,
+           "tile_budget_for_equal_residual": budget if tile["residual"] <= exact["residual"] else None, "tile_at_that_budget": tile,
+           "solve_speedup_at_equal_residual": round(exact["ms"] / tile["ms"], 2), "residual_scan": scan[-12:]}
+    if tile["residual"] <= exact["residual"]:
+        # frames with that budget in the roofline mode: the one number for "reference-quality throughput"
+        sim.set_precond(ea.PRECOND_IC0_TILE, args.tile_records)
+        sim.set_solver(budget)
+        sim.step()
+        k = max(1, args.steps // 2)
+        st0 = sim.stats()
+        el = grp.timed(sim.step, k)
+        st1 = sim.stats()
+        out["frames_at_that_budget"] = {"value": GX * GY * k / el, "unit": "cells*steps/s", "ms_per_step": 1e3 * el / k, "steps": k,
+                                        "substeps": int(st1.total_substeps - st0.total_substeps),
+                                        "pcg_iterations": int(st1.total_pcg_iterations - st0.total_pcg_iterations),
+                                        "cells_substeps_per_s": GX * GY * (st1.total_substeps - st0.total_substeps) / el}
+    sim.set_solver(100)
+    return out
+
+
+def oracle_from_sim(sim, ea, so, tile_records=0):
+    """an oracle (test infrastructure, checker only) holding exactly the state of a GPU handle"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    o = oracle_lib.Oracle(sim.X, sim.Y, lib_path=so)
+    o.c.tile_records = tile_records
+    for f, n in ((ea.F_U, "u"), (ea.F_V, "v"), (ea.F_UTMP, "utmp"), (ea.F_VTMP, "vtmp"), (ea.F_SOLID, "solid"), (ea.F_SOURCE, "source"),
+                 (ea.F_SINK, "sink"), (ea.F_COUNT, "count"), (ea.F_PREV_COUNT, "prev_count"), (ea.F_PRECON, "precon")):
+        getattr(o, n)[...] = sim.get(f)
+    o.set_markers(sim.get(ea.F_MARKERS))
+    st = sim.stats()
+    o.c.rng_state = st.rng_state
+    o.c.source_exhausted = st.source_exhausted
+    return o
+
+
+PARITY_CASES = (("1024x1024 dam break, expensive phase (BASELINE configs[1])", 1024, "dam_break", 400),
+                ("2048x2048 half tank from rest (configs[2] at 1/16 of its cells)", 2048, "half_tank", 0),
+                ("1024x1024 waterfall (configs[4] at 1/16 of its cells)", 1024, "waterfall", 30))
+
+
+def parity_vs_reference(ea, scenarios, so, device, dot_mode, tile_records, cases=PARITY_CASES):
+    """What the roofline mode's fields are worth against the REFERENCE's preconditioner: from ONE state per BASELINE workload, one
+    frame in the tile-local mode on the GPU and one frame with the reference's IC(0) on the oracle (CPU restatement, pinned to
+    the compiled reference).  Where the solves converge the two agree to solver tolerance; where they run into the reference's
+    100-iteration cap (main.c:735) both are unconverged and differ by what the last iterations would still have moved."""
+    import numpy as np
+    out = []
+    for name, n, workload, preroll in cases:
+        sim = ea.Simulation(n, n, device=device, dot_mode=dot_mode, precond=ea.PRECOND_IC0)
+        load_workload(sim, scenarios, workload, 1)
+        pre = preroll_into_solves(sim, preroll) if preroll else 0
+        o = oracle_from_sim(sim, ea, so)
+        t0 = time.perf_counter()
+        o.step()
+        cpu_s = time.perf_counter() - t0
+        sim.set_precond(ea.PRECOND_IC0_TILE, tile_records)
+        sim.step()
+        st = sim.stats()
+        pr = o.p
+        pmax = float(np.abs(pr).max())
+        gfl, ofl = sim.get(ea.F_COUNT) > 0, o.count > 0
+        e = {"state": "%s, %d preroll frames in the parity mode" % (name, pre),
+             "substeps": [int(st.last_substeps), int(o.c.last_substeps)], "pcg_iterations": [int(st.last_pcg_iterations), int(o.c.last_pcg_iterations)],
+             "capped": bool(o.c.last_pcg_iterations >= 100 * o.c.last_substeps),
+             "residual_last_solve": [float(st.last_residual), float(o.c.last_residual)],
+             "max_abs_du": float(np.abs(sim.get(ea.F_U) - o.u).max()), "max_abs_dv": float(np.abs(sim.get(ea.F_V) - o.v).max()),
+             "max_abs_velocity": float(max(np.abs(o.u).max(), np.abs(o.v).max())),
+             "dp_over_max_p": float(np.abs(sim.get(ea.F_PRESSURE) - pr).max() / pmax) if pmax > 0 else 0.0,
+             "fluid_cells": int(ofl.sum()), "fluid_cells_differing": int((gfl != ofl).sum()),
+             "markers": [int(st.n_markers), int(o.n_markers)], "oracle_seconds": round(cpu_s, 2),
+             "order": "[GPU tile-local mode, oracle with the reference's IC(0)]"}
+        out.append(e)
+        o.close()
+        sim.close()
+        del sim
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -496,58 +719,13 @@ def main():
     saturate = args.workload == "half_tank" and args.preroll == "auto"
     comm_note = []
 
-    def make_sim(slab_arg):
-        """create a handle (the whole grid, or this rank's slab), attach the exchanges, load the workload"""
-        free_before = torch.cuda.mem_get_info()[0]
-        sm = ea.Simulation(GX, GY, device=local_rank, dot_mode=dot_mode, precond=PC[args.precond], tile_records=args.tile_records, tol=tol,
-                           slab=slab_arg)
-        hbm = free_before - torch.cuda.mem_get_info()[0]
-        cm, p2p = None, False
-        if sharded:
-            from euler_amd.slab import SLAB_EXACT, SLAB_LOCAL, RcclComm, TorchComm, attach_p2p
-            coupling = SLAB_EXACT if args.slab == "exact" else SLAB_LOCAL
-            if args.comm == "rccl":
-                from euler_amd.slab import RcclUnavailable
-                try:
-                    cm = RcclComm(sm, coupling)
-                except RcclUnavailable as e:          # raised on every rank alike: the job goes on over torch.distributed, and says so
-                    if rank == 0:
-                        print("bench: %s; exchanges fall back to torch.distributed callbacks" % e, file=sys.stderr)
-                    args.comm = "torch"
-            if args.comm == "torch":
-                cm = TorchComm(sm, coupling)
-            p2p = args.p2p and attach_p2p(sm)
-            if rank == 0 and args.p2p and not p2p and not comm_note:
-                comm_note.append(1)
-                print("bench: peer-to-peer mailboxes unavailable (%s); exchanges stay on %s" % (sm._p2p_error, args.comm), file=sys.stderr)
-        load_workload(sm, scenarios, args.workload, tiles)
-        return sm, cm, p2p, hbm
-
+    ctx = dict(args=args, ea=ea, scenarios=scenarios, grp=grp, rank=rank, world=world, local_rank=local_rank, dot_mode=dot_mode, PC=PC,
+               sharded=sharded, comm_note=comm_note, tol=tol)
     slab_arg, partition, preroll = ((rank, world) if rows else None), None, None
     if rows and args.scaling == "strong" and args.partition == "auto":
-        # ONE picture over all ranks: even row slabs leave the ranks above (or below) the water with air.  A pilot pass with even
-        # slabs runs the untimed preroll, every rank reports the fluid cells of its bands, and the timed pass is created with
-        # band ranges that balance them (euler_config.slab_band_lo / hi) and pre-rolled by the same number of frames.
-        import numpy as np
-        pilot, pcomm, _, _ = make_sim(slab_arg)
-        preroll = preroll_into_solves(pilot, args.max_preroll, saturate)
-        r0, r1 = pilot.slab_rows()
-        fl_rows = (pilot.get(ea.F_COUNT) > 0).sum(axis=1)                # own rows
-        mine = [[(r0 + k) // 64, int(fl_rows[k:k + 64].sum())] for k in range(0, r1 - r0, 64)]
-        if pcomm is not None and pcomm.error:
-            raise RuntimeError(pcomm.error)
-        pilot.close()
-        del pilot, pcomm
-        allb = [None] * world
-        grp.dist.all_gather_object(allb, mine)
-        nb = (GY + 63) // 64
-        weights = [0.02 * 64 * GX] * nb                                  # an air cell costs a few dozen bytes per substep, a fluid cell ~9 KB
-        for lst in allb:
-            for bnd, cnt in lst:
-                weights[bnd] += cnt
-        partition = balanced_partition(weights, world)
+        partition, preroll = pilot_partition(ctx, GX, GY, args.workload, tiles, saturate)
         slab_arg = (rank, world, partition[rank][0], partition[rank][1])
-    sim, comm, p2p_on, hbm_per_rank = make_sim(slab_arg)
+    sim, comm, p2p_on, hbm_per_rank = make_handle(ctx, GX, GY, args.workload, tiles, slab_arg, args.precond, tol)
     if preroll is None:
         preroll = preroll_into_solves(sim, args.max_preroll, saturate)
     else:
@@ -562,34 +740,44 @@ def main():
         raise RuntimeError(comm.error)
     cells = GX * GY
     job_rate = (cells * args.steps / t["elapsed"]) if sharded else whole_job_rate(float(cells), args.steps, t["elapsed"], grp)
-    balance = None
-    if rows:
-        per_rank = [None] * world
-        grp.dist.all_gather_object(per_rank, [int(sim.stats().fluid_cells), list(sim.slab_rows())])
-        fl = [p[0] for p in per_rank]
-        balance = {"partition": "fluid-balanced band ranges (from a pilot pass with even slabs)" if partition else "even rows",
-                   "rows_per_rank": [p[1] for p in per_rank], "fluid_cells_per_rank": fl,
-                   "max_over_mean": round(max(fl) / max(sum(fl) / len(fl), 1.0), 3)}
+    balance = rank_balance(ctx, sim, partition) if rows else None
+    head = copy_gbps = device = equal = None
+    tile_w_run = tile_w
+    if rank == 0:
+        rank_cells, share = None, 1.0
+        if rows:
+            r0, r1 = sim.slab_rows()
+            rank_cells = GX * (r1 - r0)
+        elif sharded and world > 1:
+            rank_cells, share = GX * GY // world, 1.0 / world
+        head = summarize(t, GX, GY, args.precond, tile_w, traffic, traffic_note, args.steps, fused_search=True, rank_cells=rank_cells,
+                         rank_fluid_share=share)
+        try:      # the ceiling a plain device-to-device copy reaches on this very GPU (read + write), next to the 8 TB/s spec peak
+            copy_gbps = round(sim.copy_bandwidth(1 << 30, 10), 1)
+        except Exception:
+            copy_gbps = None
+        if head["roofline"]:
+            head["roofline"]["measured_copy_GBps"] = copy_gbps
+        device = sim.device_name()
+    if single and not args.no_secondary and not args.pmc_child and args.precond == "ic0_tile":
+        try:      # what the roofline mode is worth at the REFERENCE's residual (same systems, both preconditioners, on this very state)
+            equal = equal_residual(sim, ea, grp, args, GX, GY, tile_w)
+        except Exception as e:
+            equal = {"error": repr(e)}
+    sim.close()
+    del sim
+    # BASELINE configs[3], the strong-scaling unit: N > 1 (the driver's scaling run) measures it beside the weak line, N = 1 its denominator
+    strong = None
+    want_strong = not args.no_strong and not args.pmc_child and not args.force_slab and args.scaling == "weak" and N < 16384 and \
+        ((rows and world > 1) or (single and not args.no_secondary))
+    if want_strong:
+        try:
+            strong = strong_block(ctx, 16384, 2, tile_w)
+        except Exception as e:      # (collective: a failure here is every rank's)
+            strong = {"error": repr(e)}
     if rank != 0:
         grp.close()
         return
-    rank_cells, share = None, 1.0
-    if rows:
-        r0, r1 = sim.slab_rows()
-        rank_cells = GX * (r1 - r0)
-    elif sharded and world > 1:
-        rank_cells, share = GX * GY // world, 1.0 / world
-    head = summarize(t, GX, GY, args.precond, tile_w, traffic, traffic_note, args.steps, fused_search=True, rank_cells=rank_cells,
-                     rank_fluid_share=share)
-    try:      # the ceiling a plain device-to-device copy reaches on this very GPU (read + write), next to the 8 TB/s spec peak
-        copy_gbps = round(sim.copy_bandwidth(1 << 30, 10), 1)
-    except Exception:
-        copy_gbps = None
-    if head["roofline"]:
-        head["roofline"]["measured_copy_GBps"] = copy_gbps
-    device = sim.device_name()
-    sim.close()
-    del sim
 
     secondary = {}
     cpu_obj = None
@@ -663,6 +851,12 @@ def main():
             del s4
         except Exception as e:
             secondary["configs1_1024_dam_break"] = {"error": repr(e)}
+        # (3b) the roofline mode's fields against the reference's preconditioner, one state per BASELINE workload
+        if libs:
+            try:
+                secondary["parity_vs_reference_ic0"] = parity_vs_reference(ea, scenarios, libs["strict"], local_rank, dot_mode, args.tile_records)
+            except Exception as e:
+                secondary["parity_vs_reference_ic0"] = {"error": repr(e)}
         # (4) the north star's target size: the pressure projection at 16384^2 (half tank, tol = 0: 100 iterations per substep)
         if not args.no_16384 and N < 16384:
             try:
@@ -690,7 +884,10 @@ def main():
                 del s5
             except Exception as e:
                 secondary["projection_16384"] = {"error": repr(e)}
-        # (5) the CPU path beside it (rank 0, N = 1): single thread, bounded sample
+    if (single and not args.no_secondary and not args.pmc_child) or (world > 1 and not args.no_cpu_baseline):
+        if not single:
+            libs = build_native_oracle()
+        # (5) the CPU path beside it (rank 0): single thread, bounded sample
         if libs:
             try:
                 cpu = cpu_baseline_roofline_run(libs, tol if tol is not None else 1e-6)
@@ -745,6 +942,8 @@ def main():
         "balance": balance,
         "kernels": head["kernels"],
         "cpu_baseline": cpu_obj,
+        "equal_residual": equal,
+        "strong_16384_dam_break": strong,
         "secondary": secondary or None,
         "device": device,
     }

@@ -67,7 +67,7 @@ _lib = None
 EXPORTS = [
     "euler_config_default", "euler_create", "euler_destroy", "euler_last_error", "euler_abi_version",
     "euler_load_scenario_mem", "euler_load_scenario_file", "euler_load_half_tank", "euler_load_half_tanks", "euler_parse_scenario",
-    "euler_seed_markers", "euler_step", "euler_timestep", "euler_substep", "euler_stage", "euler_pcg_op", "euler_set_precond",
+    "euler_seed_markers", "euler_step", "euler_timestep", "euler_substep", "euler_stage", "euler_pcg_op", "euler_set_precond", "euler_set_solver",
     "euler_get_field", "euler_set_field", "euler_set_markers", "euler_set_rng", "euler_get_stats",
     "euler_field_bytes", "euler_render", "euler_render_grids", "euler_render_grids_rgb", "euler_colorize", "euler_profile_enable",
     "euler_profile_class_count", "euler_profile_class_name", "euler_profile_get", "euler_profile_reset",
@@ -107,6 +107,7 @@ def load_library():
         "euler_stage": (C.c_int, [vp, i32, f32]),
         "euler_pcg_op": (C.c_int, [vp, i32, f32, f64, C.POINTER(f64)]),
         "euler_set_precond": (C.c_int, [vp, i32, i32]),
+        "euler_set_solver": (C.c_int, [vp, i32, f64]),
         "euler_get_field": (C.c_int, [vp, i32, vp, C.c_size_t]),
         "euler_set_field": (C.c_int, [vp, i32, vp, C.c_size_t]),
         "euler_set_markers": (C.c_int, [vp, vp, u64]),
@@ -338,6 +339,10 @@ class Simulation:
 
     def set_precond(self, precond, tile_records=0):
         _check(self.L.euler_set_precond(self.h, precond, tile_records))
+
+    def set_solver(self, max_iterations=0, tol=-1.0):
+        """iteration budget / tolerance of the following solves (<= 0 / < 0: unchanged)"""
+        _check(self.L.euler_set_solver(self.h, max_iterations, tol))
 
     def pcg_op(self, op, dt=0.0, scalar=0.0):
         out = C.c_double(0)

@@ -328,6 +328,7 @@ extern "C" int euler_p2p_connect(euler_sim* S, const void* handles, int32_t nran
   S->comm.halo = p2p_halo;
   S->comm.chain = p2p_chain;
   S->comm.allgather = p2p_allgather;
+  S->comm.exchange = nullptr;   // (the mailboxes carry the per-iteration traffic inside the kernels)
   S->p2p_on = 1;
   return EULER_OK;
 }

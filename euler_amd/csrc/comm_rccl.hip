@@ -72,7 +72,8 @@ struct RcclComm {
   ncclComm_t comm;
   euler_sim* S;
   int rank, n;
-  uint64_t calls[4];   // allreduce, halo, chain, allgather
+  uint64_t calls[5];   // allreduce, halo, chain, allgather, exchange
+  int small_by_allgather;   // EULER_RCCL_SMALL=allgather: the small part of an exchange as ncclAllGather instead of sends / receives
 };
 
 #define NCHK(call)                                                                              \
@@ -134,6 +135,42 @@ int op_allgather(void* ctx, void* base, const int64_t* off, const int64_t* cnt) 
   return 0;
 }
 
+// ONE group for a PCG iteration's exchange point (include/euler.h euler_comm_ops.exchange): the edge rows to / from the two
+// neighbours and `nsmall` doubles of every rank to every rank, all as sends and receives that progress together - the
+// per-iteration traffic of the distributed PCG is latency-bound (8 B ... 131 KB), so what counts is the number of
+// serial RCCL operations, two per iteration this way.
+int op_exchange(void* ctx, void* send_lo, void* send_hi, void* recv_lo, void* recv_hi, int32_t count, void* small, int32_t nsmall) {
+  RcclComm* c = static_cast<RcclComm*>(ctx);
+  c->calls[4]++;
+  if (c->n < 2) return 0;
+  hipStream_t st = c->S->stream;
+  double* sm = static_cast<double*>(small);
+  NCHK(g_api.GroupStart());
+  if (count > 0) {
+    if (c->rank > 0) {
+      NCHK(g_api.Send(send_lo, (size_t)count, ncclDouble, c->rank - 1, c->comm, st));
+      NCHK(g_api.Recv(recv_lo, (size_t)count, ncclDouble, c->rank - 1, c->comm, st));
+    }
+    if (c->rank + 1 < c->n) {
+      NCHK(g_api.Send(send_hi, (size_t)count, ncclDouble, c->rank + 1, c->comm, st));
+      NCHK(g_api.Recv(recv_hi, (size_t)count, ncclDouble, c->rank + 1, c->comm, st));
+    }
+  }
+  if (nsmall > 0) {
+    if (c->small_by_allgather) {
+      NCHK(g_api.AllGather(sm + (size_t)c->rank * nsmall, sm, (size_t)nsmall, ncclDouble, c->comm, st));
+    } else {
+      for (int r = 0; r < c->n; ++r) {
+        if (r == c->rank) continue;
+        NCHK(g_api.Send(sm + (size_t)c->rank * nsmall, (size_t)nsmall, ncclDouble, r, c->comm, st));
+        NCHK(g_api.Recv(sm + (size_t)r * nsmall, (size_t)nsmall, ncclDouble, r, c->comm, st));
+      }
+    }
+  }
+  NCHK(g_api.GroupEnd());
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int euler_rccl_unique_id(void* id_out, int32_t cap) {
@@ -175,6 +212,7 @@ extern "C" int euler_set_comm_rccl(euler_sim* S, const void* unique_id, int32_t 
   RcclComm* c = static_cast<RcclComm*>(calloc(1, sizeof(RcclComm)));
   if (!c) return EULER_ENOMEM;
   c->S = S; c->rank = rank; c->n = nranks;
+  { const char* e = getenv("EULER_RCCL_SMALL"); c->small_by_allgather = e && strcmp(e, "allgather") == 0; }
   ncclUniqueId id;
   memcpy(&id, unique_id, sizeof id);
   HIPCHK(hipSetDevice(S->cfg.device));
@@ -184,14 +222,15 @@ extern "C" int euler_set_comm_rccl(euler_sim* S, const void* unique_id, int32_t 
   euler_comm_ops ops;
   ops.ctx = c; ops.rank = rank; ops.nranks = nranks;
   ops.allreduce = op_allreduce; ops.halo = op_halo; ops.chain = op_chain; ops.allgather = op_allgather;
+  ops.exchange = getenv("EULER_RCCL_NO_EXCHANGE") ? nullptr : op_exchange;   // (experiments: the same traffic as halo + all-gather)
   rc = eu_install_comm(S, &ops, coupling, /*allow_single=*/1);
   if (rc) eu_rccl_release(S);
   return rc;
 }
 
-extern "C" int euler_comm_calls(euler_sim* S, uint64_t out[4]) {
+extern "C" int euler_comm_calls(euler_sim* S, uint64_t out[5]) {
   if (!S || !out) return EULER_EINVAL;
   RcclComm* c = static_cast<RcclComm*>(S->rccl);
-  for (int k = 0; k < 4; ++k) out[k] = c ? c->calls[k] : 0;
+  for (int k = 0; k < 5; ++k) out[k] = c ? c->calls[k] : 0;
   return EULER_OK;
 }

@@ -144,6 +144,14 @@ extern "C" int euler_set_precond(euler_sim* S, int32_t precond, int32_t tile_rec
   return EULER_OK;
 }
 
+extern "C" int euler_set_solver(euler_sim* S, int32_t max_iterations, double tol) {
+  if (!S) return EULER_EINVAL;
+  HIPCHK(hipStreamSynchronize(S->stream));
+  if (max_iterations > 0) S->cfg.max_iterations = max_iterations;
+  if (tol >= 0.0) S->cfg.tol = tol;
+  return EULER_OK;
+}
+
 template <typename T>
 static int dalloc(T** p, size_t n) {
   HIPCHK(hipMalloc((void**)p, n * sizeof(T)));
@@ -165,7 +173,7 @@ extern "C" void euler_destroy(euler_sim* S) {
   for (uint8_t* g : {S->solid, S->source, S->sink, S->count, S->prev_count}) if (g) (void)hipFree(g + wo);
   if (S->count32) (void)hipFree(S->count32);
   void* dev[] = {S->markers[0], S->markers[1], S->keys[0], S->keys[1], S->ms, S->evmask, S->ev_theta, S->ev_delta, S->sel_idx, S->act_idx,
-                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->halo_buf, S->band_ranges, S->partial2, S->pair_buf, S->rng_jump, S->chunk_flag, S->chunk_prev, S->chunk_part, S->tile_table, S->chunk_bits, S->chunk_list,
+                 S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->halo_buf, S->band_ranges, S->partial2, S->pair_buf, S->xrows, S->alpha_buf, S->rng_jump, S->chunk_flag, S->chunk_prev, S->chunk_part, S->tile_table, S->chunk_bits, S->chunk_list,
                  S->rowmajor_tmp};
   for (void* p : dev) if (p) (void)hipFree(p);
   for (float* d : S->dye) if (d) (void)hipFree(d);
@@ -302,6 +310,9 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   DALLOC(S->partial, (size_t)S->red_blocks > 2048 ? (size_t)S->red_blocks : 2048);
   DALLOC(S->partial2, 2048);
   DALLOC(S->pair_buf, 2 * 64);
+  DALLOC(S->alpha_buf, 64);
+  S->xrow_len = ((size_t)S->X + 15) / 16 * 16 + 64;
+  DALLOC(S->xrows, 8 * S->xrow_len);
   S->chunk_cap = (size_t)(S->band_hi - S->band_lo) * (S->geom.T / 16);
   S->chunk_words = (S->chunk_cap + 63) / 64;
   DALLOC(S->chunk_flag, S->chunk_cap + 64);
@@ -495,6 +506,15 @@ extern "C" int euler_set_stream(euler_sim* S, void* hip_stream) {
   return EULER_OK;
 }
 
+// where the reductions' FIN_TO_COMM epilogue leaves this rank's value for the small all-gather (k_pcg.hip "ghost rows")
+static int eu_set_comm_slot(euler_sim* S) {
+  if (S->comm.nranks > 64) { eu_set_error("euler_set_comm: at most 64 ranks"); return EULER_EINVAL; }
+  double* slot = S->alpha_buf + S->comm.rank;
+  HIPCHK(hipMemcpyAsync(&S->sc->comm_slot, &slot, sizeof slot, hipMemcpyHostToDevice, S->stream));
+  HIPCHK(hipStreamSynchronize(S->stream));
+  return EULER_OK;
+}
+
 // allow_single: keep the communicator code path with one rank (the RCCL self-test on a 1-GPU box)
 int eu_install_comm(euler_sim* S, const euler_comm_ops* ops, int32_t coupling, int allow_single) {
   if (!S) return EULER_EINVAL;
@@ -511,6 +531,7 @@ int eu_install_comm(euler_sim* S, const euler_comm_ops* ops, int32_t coupling, i
       return EULER_EINVAL;
     }
     S->comm = *ops; S->bulk = *ops; S->has_comm = 1; S->couple = 0;
+    { int rc = eu_set_comm_slot(S); if (rc) return rc; }
     return eu_slab_check_partition(S);      // the ranks' band ranges tile the grid (explicit partitions: euler_config.slab_band_lo / hi)
   }
   if (!ops || ops->nranks < 1 || (ops->nranks == 1 && !allow_single)) {
@@ -531,7 +552,7 @@ int eu_install_comm(euler_sim* S, const euler_comm_ops* ops, int32_t coupling, i
   S->e_lo = (size_t)S->band_lo * S->geom.TS * 64;
   S->e_cnt = (size_t)(S->band_hi - S->band_lo) * S->geom.TS * 64;
   if (S->cfg.dot_mode == EULER_DOT_SEQUENTIAL) S->cfg.dot_mode = EULER_DOT_TREE;   // the replay order is a 1-rank notion
-  return EULER_OK;
+  return eu_set_comm_slot(S);
 }
 
 extern "C" int euler_set_comm(euler_sim* S, const euler_comm_ops* ops, int32_t coupling) {
@@ -600,7 +621,12 @@ extern "C" int euler_stage(euler_sim* S, int32_t stage, float dt) {
   if (S->slab_on) { eu_set_error("euler_stage: single stages are not exposed on a row-slab handle (their ghost exchanges belong to the substep)"); return EULER_ESTATE; }
   int rc = run_stage(S, stage, dt);
   if (rc) return rc;
-  return eu_sync_marker_state(S);
+  rc = eu_sync_marker_state(S);
+  if (!rc && stage == EULER_STAGE_PROJECT) {      // the solve's outcome (not the totals: a stage is not a substep)
+    S->stats.last_pcg_iterations = S->sc_host->nonzero ? S->sc_host->iters : 0;
+    S->stats.last_residual = S->sc_host->rnorm;
+  }
+  return rc;
 }
 
 static int substep_async(euler_sim* S, float dt) {
@@ -737,9 +763,10 @@ extern "C" int euler_get_field(euler_sim* S, int32_t f, void* dst, size_t dst_by
 extern "C" int euler_set_field(euler_sim* S, int32_t f, const void* src, size_t src_bytes) {
   if (!S || !src) return EULER_EINVAL;
   if (S->slab_on && (f == EULER_F_MARKERS || f == EULER_F_MARKER_KEYS || f == EULER_F_COUNT || f == EULER_F_PREV_COUNT ||
-                     f == EULER_F_SOLID || f == EULER_F_SOURCE || f == EULER_F_SINK)) {
-    // (static grids carry ghost rows and job-wide facts - the number of source cells of all ranks - that only a scenario load sets up)
-    eu_set_error("euler_set_field(%d): a row-slab handle takes its markers, counts and static grids from euler_load_scenario_* / euler_load_state only", f); return EULER_ESTATE;
+                     f == EULER_F_SOLID || f == EULER_F_SOURCE)) {
+    // (solid cells are read through ghost rows, the source cells of ALL ranks decide whether the source stage runs at all: facts
+    // that only a scenario / snapshot load sets up; the sink grid is read on own rows only and may be edited)
+    eu_set_error("euler_set_field(%d): a row-slab handle takes its markers, counts, solid and source cells from euler_load_scenario_* / euler_load_state only", f); return EULER_ESTATE;
   }
   if (f == EULER_F_MARKERS) return euler_set_markers(S, (const float*)src, src_bytes / 8);
   void* p; size_t b;

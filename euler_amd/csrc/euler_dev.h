@@ -40,6 +40,7 @@ struct PcgScalars {
   double tol;
   double comm_val;   // multi-rank: a rank-local reduction result on its way through the all-reduce
   double comm_val2;  // k_precond_tile leaves two: max |r| in comm_val, dot(z,r) here
+  double* comm_slot; // several ranks: this rank's slot of the small all-gather buffer (euler_comm_ops.exchange), set with the communicator
   double alpha_prev; // alpha of the iteration before the last one that ran (tile-local mode: p is updated every SECOND iteration)
   double* s_last;    // tile-local mode: the search direction of the last iteration that ran, and of the one before it (s_prev).
   double* s_prev;    // p += alpha s of iterations k, k + 1 (k even) is applied by the apply_a pass of iteration k + 2, which finds
@@ -173,6 +174,11 @@ struct euler_sim {
   unsigned long long* chunk_bits;
   unsigned int* chunk_list;
   size_t chunk_words, chunk_cap;
+  // several ranks, tile-local mode without mailboxes ("ghost rows", k_pcg.hip): compact edge rows of X doubles each
+  double* xrows;          // one allocation: z send lo / hi, z recv lo / hi, the ghost rows of s below / above (two generations each)
+  size_t xrow_len;        // doubles per row (X rounded up)
+  int gs_cur;             // which generation of the ghost rows of s holds the current search direction
+  double* alpha_buf;      // [ranks]: every rank's partial of dot(s, A s), exchanged and folded in rank order
   double* pair_buf;       // [ranks][2]: every rank's {max |r|, dot(z,r)} of one iteration, exchanged by ONE all-gather (tile-local mode without mailboxes)
   double* rowmajor_tmp;   // lazily allocated C doubles for euler_get/set_field of skewed arrays
   PcgScalars* sc;

@@ -58,7 +58,7 @@ __device__ __forceinline__ void pcg_scalar_step(PcgScalars* sc, int op, double v
     case FIN_ALPHA: sc->zs = v; sc->alpha_prev = sc->alpha; sc->alpha = sc->sigma / v; sc->iters += 1; break;     // main.c:750-752
     case FIN_RNORM: sc->rnorm = v; if (v <= sc->tol) sc->done = 1; break;             // main.c:756
     case FIN_BETA: sc->sigma_new = v; sc->beta = v / sc->sigma; sc->sigma = v; break; // main.c:762-765
-    case FIN_TO_COMM: sc->comm_val = v; break;   // multi-rank: the epilogue runs after the all-reduce
+    case FIN_TO_COMM: sc->comm_val = v; if (sc->comm_slot) *sc->comm_slot = v; break;   // multi-rank: the epilogue runs after the exchange
     default: sc->sigma_new = v; break;
   }
 }
@@ -292,8 +292,14 @@ __global__ __launch_bounds__(RED_THREADS) void k_apply_a(const double* __restric
 // behind dot(z,r) separates the backward sweeps from this kernel) and nobody overwrites z or the old s before the
 // all-reduce at the end of this kernel.
 struct SlabNeighbours {
-  const double *z_dn, *s_dn, *z_up, *s_up;   // the arrays of rank-1 / rank+1, offset like the local ones; null = no such rank
+  const double *z_dn, *s_dn, *z_up, *s_up;   // SLAB 1: the arrays of rank-1 / rank+1, offset like the local ones; null = no such rank
   int nb_local;                              // bands of this slab
+  // SLAB 2 (the default with several ranks in tile-local mode): the neighbouring slabs' edge rows as COMPACT rows of X doubles
+  // indexed by the column - z as it arrived with the iteration's one exchange, s as this rank keeps it up to date ITSELF: the
+  // ghost cell's s' = z + beta s is formed here with the owner's expression (identical bits) and stored for the next iteration,
+  // so only z ever travels.  null = no such rank.
+  const double *zrow_dn, *srow_dn, *zrow_up, *srow_up;
+  double *snew_dn, *snew_up;
 };
 __device__ __forceinline__ double ld_system(const double* p) {
   double v;
@@ -325,7 +331,7 @@ struct SaPair { sw_d2 z, so; double ez0, es0, ez1, es1; };   // one pair-record 
 
 // SA_RUN pair-records per wave: 8 (more waves in flight - at 1024^2 runs of 32 would leave 300 waves for 256 CUs - and the granularity
 // of the active-chunk list); 16 / 32 remain for experiments (sa_run)
-template <bool SLAB, int PMODE, int SA_RUN>   // SLAB: several ranks, the neighbouring slabs' arrays are mapped (nbr); else nbr is ignored
+template <int SLAB, int PMODE, int SA_RUN>   // SLAB 1: several ranks, the neighbouring slabs' arrays are mapped; 2: their edge rows as compact rows (nbr); 0: nbr is ignored
 __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __restrict__ s_old, const double* __restrict__ z,
                                                              double* __restrict__ s_new, double* __restrict__ out,
                                                              const uint8_t* __restrict__ mask, SkewGeom g,
@@ -371,13 +377,20 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
       if (!FULL && !listed && !__ballot(((any | (any >> 8)) & CM_FLUID) != 0)) return;
       // where lane 0 / lane 63 find the row below / above their band (the adjacent band's lane 63 / lane 0), relative to pair 0:
       // even element (record 2P):  below = record 2P + 63 of band - 1, above = record 2P - 63 of band + 1; odd element: + 1
-      const bool up_remote = SLAB && nbr.z_up && lb + 1 == nb_local, dn_remote = SLAB && nbr.z_dn && lb == 0;
+      const bool up_remote = SLAB == 1 && nbr.z_up && lb + 1 == nb_local, dn_remote = SLAB == 1 && nbr.z_dn && lb == 0;
       const double* ez = lane == 0 ? (dn_remote ? nbr.z_dn : z) : (up_remote ? nbr.z_up : z);
       const double* es = lane == 0 ? (dn_remote ? nbr.s_dn : s_old) : (up_remote ? nbr.s_up : s_old);
       const bool remote = lane == 0 ? dn_remote : up_remote;
       const long long e0_base = lane == 0 ? ((long long)(lb - 1) * TS + 62) * 64 + 127 : ((long long)(lb + 1) * TS - 64) * 64 + 1;
       const long long e1_base = lane == 0 ? ((long long)(lb - 1) * TS + 64) * 64 + 126 : ((long long)(lb + 1) * TS - 62) * 64;
       const unsigned int vbit = lane == 0 ? CM_DOWN : CM_UP;
+      // SLAB 2: lane 0 of the slab's first band / lane 63 of its last one find the row across the slab boundary in the compact
+      // rows, at the cell's column: even element (record 2P) of lane 0 sits in column 2P, of lane 63 in column 2P - 63
+      const bool ghost = SLAB == 2 && (lane == 0 ? (nbr.zrow_dn != nullptr && lb == 0) : (nbr.zrow_up != nullptr && lb + 1 == nb_local));
+      const double* gz = lane == 0 ? nbr.zrow_dn : nbr.zrow_up;
+      const double* gs = lane == 0 ? nbr.srow_dn : nbr.srow_up;
+      double* gsn = lane == 0 ? nbr.snew_dn : nbr.snew_up;
+      const int gcol = lane == 0 ? 0 : -63;
       auto load_pair = [&](int P, SaPair& d, unsigned int m) {
         d.ez0 = d.es0 = d.ez1 = d.es1 = 0.0;
         if (P < 0 || P >= npairs) { d.z = sw_d2{0.0, 0.0}; d.so = sw_d2{0.0, 0.0}; return; }   // outside the band: never a fluid cell's neighbour
@@ -386,11 +399,13 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
         if (edge_lane) {
           if ((m & CM_FLUID) && (m & vbit)) {
             const long long k = e0_base + (long long)P * 128;
-            if (SLAB && remote) { d.ez0 = ld_system(ez + k); d.es0 = ld_system(es + k); } else { d.ez0 = ez[k]; d.es0 = es[k]; }
+            if (SLAB == 2 && ghost) { d.ez0 = gz[2 * P + gcol]; d.es0 = gs[2 * P + gcol]; }
+            else if (SLAB == 1 && remote) { d.ez0 = ld_system(ez + k); d.es0 = ld_system(es + k); } else { d.ez0 = ez[k]; d.es0 = es[k]; }
           }
           if (((m >> 8) & CM_FLUID) && ((m >> 8) & vbit)) {
             const long long k = e1_base + (long long)P * 128;
-            if (SLAB && remote) { d.ez1 = ld_system(ez + k); d.es1 = ld_system(es + k); } else { d.ez1 = ez[k]; d.es1 = es[k]; }
+            if (SLAB == 2 && ghost) { d.ez1 = gz[2 * P + 1 + gcol]; d.es1 = gs[2 * P + 1 + gcol]; }
+            else if (SLAB == 1 && remote) { d.ez1 = ld_system(ez + k); d.es1 = ld_system(es + k); } else { d.ez1 = ez[k]; d.es1 = es[k]; }
           }
         }
       };
@@ -412,6 +427,10 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
           // the rows below / above: the neighbouring lane's registers (every lane takes part: a lane whose own pair holds no
           // fluid still serves its neighbours); lane 0 / 63 inject what they fetched from the adjacent band
           const double e0 = B.ez0 + beta * B.es0, e1 = B.ez1 + beta * B.es1;
+          if (SLAB == 2 && ghost && edge_lane) {            // the ghost cells' s' for the next iteration (the owner forms the same bits)
+            if ((mm[j] & CM_FLUID) && (mm[j] & vbit)) gsn[2 * P + gcol] = e0;
+            if (((mm[j] >> 8) & CM_FLUID) && ((mm[j] >> 8) & vbit)) gsn[2 * P + 1 + gcol] = e1;
+          }
           const double dn0 = wave_shift_inject<DPP_WAVE_SHR1>(prev_y, e0), up0 = wave_shift_inject<DPP_WAVE_SHL1>(cur.y, e0);
           const double dn1 = wave_shift_inject<DPP_WAVE_SHR1>(cur.x, e1), up1 = wave_shift_inject<DPP_WAVE_SHL1>(nxt.x, e1);
           if ((m0 | m1) & CM_FLUID) {
@@ -447,7 +466,7 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
             if ((m0 & m1) & CM_FLUID) { *reinterpret_cast<sw_d2*>(s_new + i) = cc; *reinterpret_cast<sw_d2*>(out + i) = o; }
             else if (m0 & CM_FLUID) { s_new[i] = cc.x; out[i] = o.x; }
             else { s_new[i + 1] = cc.y; out[i + 1] = o.y; }
-            if (SLAB && slab_edge_row(i, lane, TS, nb_local, (nbr.z_dn ? 1 : 0) | (nbr.z_up ? 2 : 0))) {   // the rows the neighbours will read
+            if (SLAB == 1 && slab_edge_row(i, lane, TS, nb_local, (nbr.z_dn ? 1 : 0) | (nbr.z_up ? 2 : 0))) {   // the rows the neighbours will read
               if (m0 & CM_FLUID) st_system(s_new + i, cc.x);
               if (m1 & CM_FLUID) st_system(s_new + i + 1, cc.y);
             }
@@ -459,7 +478,7 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
     };
     if (SA_RUN == 8 && interior) run(yes_t()); else run(no_t());
   }
-  if (SLAB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // landed before this block joins the all-reduce (block_sum syncs)
+  if (SLAB == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // landed before this block joins the all-reduce (block_sum syncs)
   t = block_sum<SA_THREADS>(t);
   if (fin_op >= 0) block_finish<false, SA_THREADS>(t, partial, counter, sc, fin_op);   // fin_op < 0: dot(out, s') is replayed sequentially
 }
@@ -1155,6 +1174,11 @@ struct TileArgs {
   int force;
   double alpha_arg;       // force: alpha of the r update (single building block, tests)
   double* pair_slot;      // FIN_TO_COMM: where this rank's {max |r|, dot(z,r)} go (its slot of the all-gather buffer)
+  // several ranks, compact ghost rows (k_search_apply SLAB 2): the slab's lowest / highest row of z goes out as a row of X doubles,
+  // written by the lanes that hold it (lane 0 of band edge_lo, lane 63 of band edge_hi); null / -1 = no neighbour on that side
+  double *zsend_lo, *zsend_hi;
+  int edge_lo, edge_hi;
+  int reverse;            // walk the tiles in descending order
 };
 
 // fixed-shape reductions of a PT_THREADS block; result valid in thread 0
@@ -1256,7 +1280,9 @@ __global__ __launch_bounds__(PT_THREADS) void k_precond_tile(TileArgs a) {
   typedef std::integral_constant<bool, true> yes_t;
   typedef std::integral_constant<bool, false> no_t;
   for (int i = blockIdx.x * (PT_THREADS / 64) + (threadIdx.x >> 6); i < todo; i += n_waves) {
-    const unsigned int ent = listed ? a.list[i] : (unsigned int)i;
+    // (reverse: start where the previous pass - k_search_apply, ascending - ended, i.e. on what the Infinity Cache still holds)
+    const int ii = a.reverse ? todo - 1 - i : i;
+    const unsigned int ent = listed ? a.list[ii] : (unsigned int)ii;
     const bool interior = have_tab && (ent & EU_CHUNK_INTERIOR) != 0;
     const int tile = (int)(listed ? ent & ~EU_CHUNK_INTERIOR : ent);
     const int band = a.band_lo + tile / ntb, k = tile % ntb;
@@ -1320,6 +1346,16 @@ __global__ __launch_bounds__(PT_THREADS) void k_precond_tile(TileArgs a) {
       }
 #pragma unroll
       for (int P = 0; P < W / 2; ++P) *reinterpret_cast<sw_d2*>(a.z + base + P * 128) = qq[P];
+      if (band == a.edge_lo || band == a.edge_hi) {      // (wave-uniform) the rows the neighbouring slabs need, as compact rows
+        const bool lo = band == a.edge_lo && lane == 0, hi = band == a.edge_hi && lane == 63;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          const double zv = (j & 1) ? qq[j >> 1].y : qq[j >> 1].x;
+          const int x_lo = k * W + j, x_hi = k * W + j - 63;      // the column of lane 0 / lane 63 in record k W + j
+          if (lo && x_lo < a.g.X) a.zsend_lo[x_lo] = zv;
+          if (hi && x_hi >= 0 && x_hi < a.g.X) a.zsend_hi[x_hi] = zv;
+        }
+      }
     };
     if (W == 16 && interior) run(yes_t()); else run(no_t());
   }
@@ -1511,6 +1547,39 @@ __global__ __launch_bounds__(256) void k_halo_rows2(double* a, double* b, double
 
 #define COMM_CALL(expr) do { if ((expr) != 0) { eu_set_error("communicator callback failed: %s", #expr); return EULER_ECOMM; } } while (0)
 
+// ---- "ghost rows": the default with several ranks in tile-local mode (no mailboxes) ------------------------------------------
+// A PCG iteration has TWO exchange points, each ONE call of euler_comm_ops.exchange (RCCL: one group of sends / receives):
+//   G1  behind k_precond_tile:  the slab's edge rows of z to the two neighbours + {max |r|, dot(z,r)} of every rank to every rank
+//   G2  behind k_search_apply:  the partial of dot(s, A s) of every rank to every rank
+// and every rank folds what arrived in rank order (identical bits everywhere: alpha, beta and `done` stay in step without a
+// broadcast).  Against round 2 (halo(z, s) - all-reduce(alpha) - all-gather{max |r|, dot}: three exchanges, two pack / unpack
+// launches): the edge rows leave k_precond_tile as compact rows and are read by k_search_apply as compact rows (no pack, no
+// unpack), and s does not travel at all - a rank keeps its ghost rows of s current by itself (k_search_apply SLAB 2).
+static inline bool tile_fused(const euler_sim* S);
+static inline bool ghost_mode(const euler_sim* S) { return S->has_comm && !S->p2p_on && tile_fused(S); }
+enum { XR_ZSEND_LO = 0, XR_ZSEND_HI, XR_ZRECV_LO, XR_ZRECV_HI, XR_GS_LO0, XR_GS_LO1, XR_GS_HI0, XR_GS_HI1 };
+static inline double* xrow(const euler_sim* S, int k) { return S->xrows + (size_t)k * S->xrow_len; }
+static int comm_exchange(euler_sim* S, double* send_lo, double* send_hi, double* recv_lo, double* recv_hi, int count, double* small, int nsmall) {
+  if (S->bulk.exchange) {
+    COMM_CALL(S->bulk.exchange(S->bulk.ctx, send_lo, send_hi, recv_lo, recv_hi, count, small, nsmall));
+    return EULER_OK;
+  }
+  // a communicator without the fused operation: the same traffic as a neighbour exchange and an all-gather
+  if (count > 0) COMM_CALL(S->bulk.halo(S->bulk.ctx, send_lo, send_hi, recv_lo, recv_hi, count));
+  if (nsmall > 0) {
+    int64_t off[64], cnt[64];
+    for (int r = 0; r < S->bulk.nranks && r < 64; ++r) { off[r] = (int64_t)8 * nsmall * r; cnt[r] = (int64_t)8 * nsmall; }
+    COMM_CALL(S->bulk.allgather(S->bulk.ctx, small, off, cnt));
+  }
+  return EULER_OK;
+}
+__global__ void k_alpha_fold(PcgScalars* sc, const double* __restrict__ vals, int R, int force) {   // G2: dot(s, A s) = sum over ranks, in rank order
+  if (!force && pcg_idle(sc)) return;
+  double v = 0.0;
+  for (int r = 0; r < R; ++r) v += vals[r];
+  pcg_scalar_step(sc, FIN_ALPHA, v);
+}
+
 static int comm_allreduce_scalar(euler_sim* S, int is_max) {
   COMM_CALL(S->comm.allreduce(S->comm.ctx, &S->sc->comm_val, 1, is_max));
   return EULER_OK;
@@ -1518,6 +1587,12 @@ static int comm_allreduce_scalar(euler_sim* S, int is_max) {
 // rank-local reduction result (left in comm_val by FIN_TO_COMM) -> all-reduce -> scalar epilogue
 static int comm_finish(euler_sim* S, int fin_op, int is_max, int force) {
   if (S->p2p_on) return EULER_OK;   // the reduction's last block already exchanged the partials and applied the epilogue
+  if (fin_op == FIN_ALPHA && ghost_mode(S)) {      // G2
+    int rc = comm_exchange(S, nullptr, nullptr, nullptr, nullptr, 0, S->alpha_buf, 1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_alpha_fold, dim3(1), dim3(1), 0, S->stream, S->sc, S->alpha_buf, S->comm.nranks, force);
+    return EULER_OK;
+  }
   int rc = comm_allreduce_scalar(S, is_max);
   if (rc) return rc;
   hipLaunchKernelGGL(k_scalar_epilogue, dim3(1), dim3(1), 0, S->stream, S->sc, fin_op, force);
@@ -1617,6 +1692,12 @@ static TileArgs make_tile_args(euler_sim* S, int force) {
   a.pair_slot = S->pair_buf + 2 * (S->has_comm ? S->comm.rank : 0);
   a.list = (!force && S->tile_w == 16) ? S->chunk_list : nullptr;      // (forced single operations may run on masks no solve has listed)
   a.table = S->tile_table;
+  a.zsend_lo = a.zsend_hi = nullptr; a.edge_lo = a.edge_hi = -1;
+  { static const int rev = getenv("EULER_TILE_REVERSE") ? atoi(getenv("EULER_TILE_REVERSE")) : 0; a.reverse = rev; }      // (experiment)
+  if (ghost_mode(S)) {
+    if (S->band_lo > 0) { a.zsend_lo = xrow(S, XR_ZSEND_LO); a.edge_lo = S->band_lo; }
+    if (S->band_hi < S->geom.nbands) { a.zsend_hi = xrow(S, XR_ZSEND_HI); a.edge_hi = S->band_hi - 1; }
+  }
   return a;
 }
 static inline unsigned tile_blocks(const euler_sim* S) {
@@ -1644,11 +1725,11 @@ static int launch_precond_tile(euler_sim* S, int rupd, int sweeps, int fin_dot, 
   }
   if (seq && sweeps && fin_dot >= 0)   // the reference's row-major dot(z, r); a no-op once max |r| <= tol
     LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), S->z, S->r, S->cellmask, S->geom, S->sc, fin_dot, force);
-  if (a.via == FIN_TO_COMM) {          // no mailboxes: both results travel in ONE all-gather of 16 bytes per rank, then the epilogues
+  if (a.via == FIN_TO_COMM) {          // no mailboxes: G1 - both results (and, in the solve, the edge rows of the new z) in ONE exchange, then the epilogues
     const int R = S->comm.nranks;
-    int64_t off[64], cnt[64];
-    for (int r = 0; r < R && r < 64; ++r) { off[r] = 16 * r; cnt[r] = 16; }
-    COMM_CALL(S->bulk.allgather(S->bulk.ctx, S->pair_buf, off, cnt));
+    const bool rows = ghost_mode(S) && !force;
+    int rc = comm_exchange(S, xrow(S, XR_ZSEND_LO), xrow(S, XR_ZSEND_HI), xrow(S, XR_ZRECV_LO), xrow(S, XR_ZRECV_HI), rows ? S->X : 0, S->pair_buf, 2);
+    if (rc) return rc;
     hipLaunchKernelGGL(k_pair_fold, dim3(1), dim3(1), 0, S->stream, S->sc, S->pair_buf, R, rupd, a.fin_dot, force);
   }
   return EULER_OK;
@@ -1687,7 +1768,21 @@ static int launch_precondition(euler_sim* S, int force, int fin_dot = -1) {   //
 
 static int launch_apply_a_and_alpha(euler_sim* S, int force) {
   const bool seq = S->cfg.dot_mode == EULER_DOT_SEQUENTIAL && !S->has_comm;
-  if (S->has_comm) { int rc = comm_halo_s(S); if (rc) return rc; }
+  if (S->has_comm && ghost_mode(S) && !force) {
+    // the first search direction is z_0, whose edge rows arrived with the exchange behind the solve's first k_precond_tile: they
+    // become the ghost rows of s - in the adjacent bands' storage for this one pass (k_apply_a looks there), and generation 0 of
+    // the compact rows k_search_apply keeps current from here on
+    const int X = S->X, nbk = (X + 255) / 256;
+    if (S->band_lo > 0) {
+      hipLaunchKernelGGL(k_unpack_row, dim3(nbk), dim3(256), 0, S->stream, S->s, xrow(S, XR_ZRECV_LO), S->geom, S->band_lo - 1, 63);
+      HIPCHK(hipMemcpyAsync(xrow(S, XR_GS_LO0), xrow(S, XR_ZRECV_LO), (size_t)X * 8, hipMemcpyDeviceToDevice, S->stream));
+    }
+    if (S->band_hi < S->geom.nbands) {
+      hipLaunchKernelGGL(k_unpack_row, dim3(nbk), dim3(256), 0, S->stream, S->s, xrow(S, XR_ZRECV_HI), S->geom, S->band_hi, 0);
+      HIPCHK(hipMemcpyAsync(xrow(S, XR_GS_HI0), xrow(S, XR_ZRECV_HI), (size_t)X * 8, hipMemcpyDeviceToDevice, S->stream));
+    }
+    S->gs_cur = 0;
+  } else if (S->has_comm) { int rc = comm_halo_s(S); if (rc) return rc; }
   SkewGeom gl = S->geom;
   gl.S = S->e_cnt;
   double* out = tile_fused(S) ? S->q : S->z;     // tile-local mode: A s always lands in q (k_precond_tile reads it there and writes z)
@@ -1714,9 +1809,15 @@ static inline int sa_run(const euler_sim* S) {   // short runs while long ones w
 // iterations >= 1 of a single-GPU solve: s' = z + beta s and A s' in one launch; returns with S->s = s' and A s' in S->q
 static int launch_search_apply_and_alpha(euler_sim* S, int it) {
   const bool seq = S->cfg.dot_mode == EULER_DOT_SEQUENTIAL && !S->has_comm;
-  SlabNeighbours nbr = {nullptr, nullptr, nullptr, nullptr, S->band_hi - S->band_lo};
+  SlabNeighbours nbr = {nullptr, nullptr, nullptr, nullptr, S->band_hi - S->band_lo, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   const bool direct = S->has_comm && eu_p2p_has_neighbour_arrays(S);   // (opt-in) read the neighbouring slabs' z and s where they live
-  if (direct) {   // addressed with this rank's offsets (the arrays are full-size everywhere)
+  const bool ghost = ghost_mode(S);
+  if (ghost) {      // the neighbours' z rows came with G1; the ghost rows of s are kept here (two generations, like s / s2)
+    const int c = S->gs_cur;
+    if (S->band_lo > 0) { nbr.zrow_dn = xrow(S, XR_ZRECV_LO); nbr.srow_dn = xrow(S, XR_GS_LO0 + c); nbr.snew_dn = xrow(S, XR_GS_LO0 + (c ^ 1)); }
+    if (S->band_hi < S->geom.nbands) { nbr.zrow_up = xrow(S, XR_ZRECV_HI); nbr.srow_up = xrow(S, XR_GS_HI0 + c); nbr.snew_up = xrow(S, XR_GS_HI0 + (c ^ 1)); }
+    S->gs_cur = c ^ 1;
+  } else if (direct) {   // addressed with this rank's offsets (the arrays are full-size everywhere)
     eu_p2p_neighbour_arrays(S, &nbr.z_dn, &nbr.s_dn, &nbr.z_up, &nbr.s_up);
     if (nbr.z_dn) { nbr.z_dn += S->e_lo; nbr.s_dn += S->e_lo; }
     if (nbr.z_up) { nbr.z_up += S->e_lo; nbr.s_up += S->e_lo; }
@@ -1735,12 +1836,14 @@ static int launch_search_apply_and_alpha(euler_sim* S, int it) {
   LAUNCH(S, KC_APPLY_A, (k_search_apply<SLABF, PM, RUNV>), dim3(sa_blocks(S, RUNV)), dim3(SA_THREADS), LOC(S->s), LOC(S->z), LOC(S->s2), \
          LOC(S->q), LOC(S->cellmask), gl, S->partial, S->sc, 0, S->red_counter, fin, nbr, pp, S->s2, S->s, (RUNV) == 8 ? S->chunk_list : (const unsigned int*)nullptr)
 #define SA_RUNS(SLABF, PM) do { if (run == 8) SA_LAUNCH(SLABF, PM, 8); else if (run == 16) SA_LAUNCH(SLABF, PM, 16); else SA_LAUNCH(SLABF, PM, 32); } while (0)
-  if (direct) {
-    if (pmode == 2) { if (run == 8) SA_LAUNCH(true, 2, 8); else SA_LAUNCH(true, 2, 32); }
-    else if (pmode == 1) { if (run == 8) SA_LAUNCH(true, 1, 8); else SA_LAUNCH(true, 1, 32); }
-    else { if (run == 8) SA_LAUNCH(true, 0, 8); else SA_LAUNCH(true, 0, 32); }
+  if (ghost) {      // (tile-local mode: pmode 1 or 2; several ranks: runs of 8)
+    if (pmode == 2) SA_LAUNCH(2, 2, 8); else SA_LAUNCH(2, 1, 8);
+  } else if (direct) {
+    if (pmode == 2) { if (run == 8) SA_LAUNCH(1, 2, 8); else SA_LAUNCH(1, 2, 32); }
+    else if (pmode == 1) { if (run == 8) SA_LAUNCH(1, 1, 8); else SA_LAUNCH(1, 1, 32); }
+    else { if (run == 8) SA_LAUNCH(1, 0, 8); else SA_LAUNCH(1, 0, 32); }
   } else {
-    if (pmode == 2) SA_RUNS(false, 2); else if (pmode == 1) SA_RUNS(false, 1); else SA_RUNS(false, 0);
+    if (pmode == 2) SA_RUNS(0, 2); else if (pmode == 1) SA_RUNS(0, 1); else SA_RUNS(0, 0);
   }
 #undef SA_RUNS
 #undef SA_LAUNCH
@@ -1772,7 +1875,8 @@ int eu_launch_project(euler_sim* S, float dt) {
   // and the convergence poll is taken one chunk late: the next chunk is already queued while the host
   // waits, so the GPU never idles for the ~27 us round trip (at most one chunk of early-exit launches is
   // wasted when the guess is wrong).  Converging solves keep the immediate poll.
-  const bool lookahead = !S->has_comm && S->sc_host->nonzero && !S->sc_host->done && S->sc_host->iters >= S->cfg.max_iterations;
+  // (several ranks: nonzero / done / iters are the same on every rank, so all ranks take the same decision)
+  const bool lookahead = S->sc_host->nonzero && !S->sc_host->done && S->sc_host->iters >= S->cfg.max_iterations;
   S->prof_iter = -1;
   int rc;
   LAUNCH(S, KC_MISC, k_pcg_reset, dim3(1), dim3(1), S->sc, S->cfg.tol, S->cfg.max_iterations);

@@ -16,11 +16,12 @@ _ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32)
 _HALO = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32)
 _CHAIN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32)
 _ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64))
+_EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32)
 
 
 class CommOps(C.Structure):
     _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int32), ("nranks", C.c_int32),
-                ("allreduce", _ALLREDUCE), ("halo", _HALO), ("chain", _CHAIN), ("allgather", _ALLGATHER)]
+                ("allreduce", _ALLREDUCE), ("halo", _HALO), ("chain", _CHAIN), ("allgather", _ALLGATHER), ("exchange", _EXCHANGE)]
 
 
 class _DevMem:
@@ -44,8 +45,11 @@ class TorchComm:
         self.stage = dist.get_backend() != "nccl"      # gloo: go through host memory
         self.error = None
         self._cache = {}
-        self.counts = {"allreduce": 0, "halo": 0, "chain": 0, "allgather": 0}
-        self._cb = (_ALLREDUCE(self._allreduce), _HALO(self._halo), _CHAIN(self._chain), _ALLGATHER(self._allgather))
+        self.counts = {"allreduce": 0, "halo": 0, "chain": 0, "allgather": 0, "exchange": 0}
+        # EULER_TORCH_NO_EXCHANGE: leave the fused operation out (the library then issues halo + allgather: the fallback path)
+        import os
+        fused = _EXCHANGE(self._exchange) if not os.environ.get("EULER_TORCH_NO_EXCHANGE") else _EXCHANGE()
+        self._cb = (_ALLREDUCE(self._allreduce), _HALO(self._halo), _CHAIN(self._chain), _ALLGATHER(self._allgather), fused)
         self.ops = CommOps(None, self.rank, self.world, *self._cb)
         L = sim.L
         rc = L.euler_set_stream(sim.h, C.c_void_p(torch.cuda.current_stream().cuda_stream))
@@ -118,6 +122,46 @@ class TorchComm:
                 for q in self.dist.batch_isend_irecv(ops):
                     q.wait()
         return self._guard("halo", run)
+
+    def _exchange(self, ctx, send_lo, send_hi, recv_lo, recv_hi, count, small, nsmall):
+        """euler_comm_ops.exchange: neighbour rows + an all-gather of nsmall doubles per rank (in place), as one operation."""
+        def run():
+            f64 = self.torch.float64
+            pairs = []
+            if count > 0:
+                n = 8 * count
+                if self.rank > 0:
+                    pairs.append((self._t(send_lo, n, f64), self._t(recv_lo, n, f64), self.rank - 1))
+                if self.rank + 1 < self.world:
+                    pairs.append((self._t(send_hi, n, f64), self._t(recv_hi, n, f64), self.rank + 1))
+            sm = self._t(small, 8 * nsmall * self.world, f64) if nsmall > 0 else None
+            if self.stage:
+                host = [(s.cpu(), self.torch.empty(count, dtype=f64), r, p) for s, r, p in pairs]
+                reqs = []
+                for s, tmp, r, p in host:
+                    reqs.append(self.dist.isend(s, p))
+                    reqs.append(self.dist.irecv(tmp, p))
+                if sm is not None:
+                    mine = sm[self.rank * nsmall:(self.rank + 1) * nsmall].cpu()
+                    every = [self.torch.empty(nsmall, dtype=f64) for _ in range(self.world)]
+                    self.dist.all_gather(every, mine)
+                for q in reqs:
+                    q.wait()
+                for s, tmp, r, p in host:
+                    r.copy_(tmp)
+                if sm is not None:
+                    sm.copy_(self.torch.cat(every))
+            else:
+                ops = []
+                for s, r, p in pairs:
+                    ops.append(self.dist.P2POp(self.dist.isend, s, p))
+                    ops.append(self.dist.P2POp(self.dist.irecv, r, p))
+                reqs = self.dist.batch_isend_irecv(ops) if ops else []
+                if sm is not None:
+                    self.dist.all_gather_into_tensor(sm, sm[self.rank * nsmall:(self.rank + 1) * nsmall].clone())
+                for q in reqs:
+                    q.wait()
+        return self._guard("exchange", run)
 
     def _chain(self, ctx, ptr, nbytes, src, dst):
         def run():
@@ -195,9 +239,9 @@ class RcclComm:
 
     @property
     def counts(self):
-        out = (C.c_uint64 * 4)()
+        out = (C.c_uint64 * 5)()
         self.sim.L.euler_comm_calls(self.sim.h, out)
-        return dict(zip(("allreduce", "halo", "chain", "allgather"), (int(v) for v in out)))
+        return dict(zip(("allreduce", "halo", "chain", "allgather", "exchange"), (int(v) for v in out)))
 
 
 P2P_HANDLE_BYTES = 256     # EULER_P2P_HANDLE_BYTES: mailbox + the z / s / s2 arrays

@@ -203,6 +203,9 @@ int euler_pcg_op(euler_sim* sim, int32_t op, float dt, double scalar_in, double*
 /* Switch the preconditioner of the following solves (EULER_PRECOND_*; tile_records as euler_config.precond_tile_records,
  * 0 = default).  The solver's arrays do not depend on it; g_precon keeps whatever the last factorisation left. */
 int euler_set_precond(euler_sim* sim, int32_t precond, int32_t tile_records);
+/* The iteration budget and tolerance of the following solves (euler_config.max_iterations / tol; reference: 100 and 1e-6f,
+ * main.c:735-736).  max_iterations <= 0 or tol < 0 leave the respective value as it is. */
+int euler_set_solver(euler_sim* sim, int32_t max_iterations, double tol);
 
 /* ---- state access ------------------------------------------------------------------------ */
 int euler_get_field(euler_sim* sim, int32_t field, void* dst, size_t dst_bytes);
@@ -292,7 +295,7 @@ int euler_rccl_unique_id(void* id_out, int32_t cap);
 int euler_rccl_version(void);                                  /* NCCL-style version code, -1 if unavailable */
 int euler_set_comm_rccl(euler_sim* sim, const void* unique_id, int32_t id_bytes, int32_t rank, int32_t nranks,
                         int32_t coupling);
-int euler_comm_calls(euler_sim* sim, uint64_t out[4]);         /* built-in communicator: allreduce, halo, chain, allgather calls so far */
+int euler_comm_calls(euler_sim* sim, uint64_t out[5]);         /* built-in communicator: allreduce, halo, chain, allgather, exchange calls so far */
 
 /* Peer-to-peer mailboxes for the latency-bound exchanges (csrc/comm_p2p.hip): the three 8-byte all-reduces
  * and the ghost-row exchange of every PCG iteration become direct writes into the peers' mailboxes (HIP IPC

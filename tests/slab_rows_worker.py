@@ -48,6 +48,11 @@ def main():
         if a.startswith("bands="):            # an explicit partition, "0-1,1-3,3-8": band ranges per rank (euler_config.slab_band_lo / hi)
             lo, hi = a[6:].split(",")[rank].split("-")
             slab = (rank, world, int(lo), int(hi))
+    if "noexchange" in sys.argv[6:]:
+        os.environ["EULER_TORCH_NO_EXCHANGE"] = "1"      # the communicator without the fused operation: the library's halo + all-gather fallback
+    for a in sys.argv[6:]:
+        if a.startswith("caps="):             # tiny exchange capacities (dt-chain candidates, deletions) to drive the overflow path
+            os.environ["EULER_SLAB_CAPS"] = a[5:]
     sim = ea.Simulation(X, Y, device=local, dot_mode=ea.DOT_TREE, precond=precond, slab=slab)   # one slab
     comm = RcclComm(sim, SLAB_LOCAL) if rccl else TorchComm(sim, SLAB_LOCAL)
     out = {"world": world, "frames": []}
@@ -76,6 +81,22 @@ def main():
             sink[8:14, X - 30:X - 20] = 1
             ref.set(ea.F_SINK, sink)
             sim.set(ea.F_SINK, sink[lo:hi])
+        if "overflow" in sys.argv[6:]:
+            # more deletions than the (shrunken) exchange capacity: EVERY rank must come back with the error - nobody hangs in the next
+            # exchange, nobody carries on with a truncated list
+            failed, msg = False, ""
+            try:
+                sim.substep(sim.timestep(0.1))
+                sim.substep(sim.timestep(0.1))
+            except ea.EulerError as e:
+                failed, msg = True, str(e)
+            agg = [None] * world
+            dist.all_gather_object(agg, [failed, msg])
+            if rank == 0:
+                print(json.dumps({"world": world, "overflow": {"failed": [a[0] for a in agg], "msg": [a[1] for a in agg]}}))
+            dist.barrier()
+            dist.destroy_process_group()
+            return
         n0 = int(ref.stats().n_markers)
         dt_r, dt_s = ref.timestep(0.1), sim.timestep(0.1)
         ref.substep(dt_r); sim.substep(dt_s)

@@ -603,6 +603,75 @@ def test_full_size_8192_half_tank_properties(precond):
     sim.close()
 
 
+def test_full_size_16384_dam_break_properties_both_modes():
+    """BASELINE configs[3] at its full size on one GPU (16384^2 dam break: 83 M fluid cells, 334 M markers, ~48 GB of HBM),
+    rolled into the expensive phase (every substep runs PCG into the iteration cap, main.c:735), then one frame in the tile-local
+    mode and one in the reference's IC(0), each through the size-independent properties: the count grid is the histogram of the
+    marker array (on a 2048-row stripe through the water), the residual the solver reports is max |r| of the vector it carries,
+    and that vector IS b - A p recomputed on the host from the mask encoding of A - on every row of the system none of whose
+    five pressures was clamped afterwards (main.c:773-779: the clamp acts after the solve and only ever writes an exact 0) -
+    p >= 0 and 0 off the fluid, velocities vanish on solid faces, nothing is NaN."""
+    from euler_amd import scenarios
+    N = 16384
+    sim = ea.Simulation(N, N, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE).load_text(scenarios.dam_break(), upscale=True)
+    st = sim.stats()
+    assert st.n_markers > 300e6
+    for _ in range(60):
+        sim.step()
+        if sim.stats().last_pcg_iterations >= 100:
+            break
+    assert sim.stats().last_pcg_iterations >= 100
+    solid = sim.get(ea.F_SOLID)
+    su = (solid[:, :-1] | solid[:, 1:]) != 0
+    sv = (solid[:-1, :] | solid[1:, :]) != 0
+    del solid
+    for precond in (ea.PRECOND_IC0_TILE, ea.PRECOND_IC0):
+        sim.set_precond(precond)
+        sim.step()
+        st = sim.stats()
+        assert st.last_pcg_iterations >= 100 * st.last_substeps - 8 * st.last_substeps, (precond, st.last_pcg_iterations, st.last_substeps)
+        p, b, m = sim.get(ea.F_PRESSURE), sim.get(ea.F_PCG_B), sim.get(ea.F_CELLMASK)
+        fl = (m & 1) != 0
+        assert (p[~fl] == 0).all() and (p >= 0).all() and np.isfinite(p).all()
+        # rows of the system that the clamp did not touch: the cell and its four neighbours all kept their solved pressure
+        zero = fl & (p == 0)
+        touched = zero.copy()
+        touched[:, 1:] |= zero[:, :-1]; touched[:, :-1] |= zero[:, 1:]; touched[1:, :] |= zero[:-1, :]; touched[:-1, :] |= zero[1:, :]
+        ok = fl & ~touched
+        del zero, touched
+        assert ok.sum() > 0.9 * fl.sum()
+        ap = (m >> 5).astype(np.float64) * p
+        ap[:, :-1] -= np.where((m[:, :-1] & 2) != 0, p[:, 1:], 0.0)
+        ap[:-1, :] -= np.where((m[:-1, :] & 4) != 0, p[1:, :], 0.0)
+        ap[:, 1:] -= np.where((m[:, 1:] & 8) != 0, p[:, :-1], 0.0)
+        ap[1:, :] -= np.where((m[1:, :] & 16) != 0, p[:-1, :], 0.0)
+        scale = np.abs(b).max()
+        np.subtract(b, ap, out=ap)                      # b - A p
+        del p, b
+        r = sim.get(ea.F_PCG_R)
+        assert np.abs(r[fl]).max() == st.last_residual or abs(np.abs(r[fl]).max() - st.last_residual) <= 1e-12 * scale
+        assert np.abs((r - ap)[ok]).max() <= 1e-9 * scale, precond
+        del r, ap, ok
+        count = sim.get(ea.F_COUNT)
+        assert np.array_equal(fl, count > 0)
+        del m
+        mk = sim.get(ea.F_MARKERS)
+        assert len(mk) == st.n_markers and np.isfinite(mk).all()
+        rows = np.nonzero(fl.any(axis=1))[0]
+        y0 = int(rows[len(rows) // 2]) - 1024            # a 2048-row stripe through the middle of the water
+        cy = np.floor(mk[:, 1]).astype(np.int32)
+        sel = (cy >= y0) & (cy < y0 + 2048)
+        cx = np.floor(mk[sel, 0]).astype(np.int64)
+        hist = np.bincount((cy[sel].astype(np.int64) - y0) * N + cx, minlength=2048 * N).reshape(2048, N)
+        assert np.array_equal((hist & 255).astype(np.uint8), count[y0:y0 + 2048])
+        del mk, cy, cx, hist, sel, count, fl
+        u, v = sim.get(ea.F_U), sim.get(ea.F_V)
+        assert np.isfinite(u).all() and np.isfinite(v).all()
+        assert (u[:, :-1][su] == 0).all() and (v[:-1, :][sv] == 0).all()
+        del u, v
+    sim.close()
+
+
 @pytest.mark.parametrize("precond", [ea.PRECOND_IC0, ea.PRECOND_IC0_TILE])
 def test_full_size_4096_waterfall_properties_with_sources_active(precond):
     """BASELINE configs[4]'s grid and scenario (4096^2 waterfall: ~0.27 M source cells, a sink column), a few frames with the

@@ -35,6 +35,7 @@ def run(nproc, X, Y, workload, frames, precond, port, extra=()):
     (2, 320, 256, "golden:weird-edges", 30, ea.PRECOND_IC0_TILE, ()),
     (2, 256, 256, "waterfall", 20, ea.PRECOND_IC0, ()),               # slab-local IC(0): another preconditioner than 1 GPU (tolerance where converged)
     (3, 256, 512, "dam_break", 40, ea.PRECOND_IC0_TILE, ("bands=0-1,1-3,3-8",)),   # an explicit, uneven partition (fluid-balanced slabs)
+    (3, 256, 512, "dam_break", 40, ea.PRECOND_IC0_TILE, ("noexchange",)),          # a communicator without euler_comm_ops.exchange: halo + all-gather
 ])
 def test_row_slabs_reproduce_the_single_gpu_run(nproc, X, Y, workload, frames, precond, extra):
     d = run(nproc, X, Y, workload, frames, precond, 29581, extra)
@@ -116,6 +117,52 @@ def test_swap_with_last_deletion_across_ranks(nproc, X, Y):
     assert ev["n_markers"][0] == ev["n_markers"][1] < ev["n_markers"][2] - 100, ev["n_markers"]
     assert ev["dt_events"][0] == ev["dt_events"][1]
     assert ev["markers_at_keys"] and ev["keys_are_a_permutation"] and ev["count_differ"] == 0, ev
+
+
+@pytest.mark.gpu
+def test_configs3_shape_four_fluid_balanced_slabs_2048x4096():
+    """BASELINE configs[3]'s scenario and decomposition at a size four ranks can share one GPU with: the dam break on a 2048 x 4096
+    grid (8.4 M cells, ~10 M markers) as 4 row slabs whose band ranges balance the FLUID (bench.py --scaling strong: prefix split
+    over fluid cells per band - here of the initial picture), 22 frames: free fall through three slab boundaries into the phase
+    where the solves run into the iteration cap.  Against the single-GPU run: cell grids, every marker at its key, RNG, dt chain
+    bit-exact and p / u / v within the multi-rank solve's tolerance up to the first capped frame, the structural invariants
+    (markers inside their slab's rows, keys a permutation) throughout."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from bench import balanced_partition
+    from euler_amd import scenarios
+    X, Y, world = 2048, 4096, 4
+    _, _, _, fluid = ea.parse_scenario(scenarios.dam_break(), X, Y, upscale=True)
+    nb = (Y + 63) // 64
+    weights = [0.02 * 64 * X + float(fluid[64 * b:64 * b + 64].sum()) for b in range(nb)]
+    part = balanced_partition(weights, world)
+    fl = [sum(weights[lo:hi]) for lo, hi in part]
+    assert max(fl) / (sum(fl) / world) < 1.15 and part[0][1] - part[0][0] > part[1][1] - part[1][0]      # balanced, and not the even split
+    d = run(world, X, Y, "dam_break", 22, ea.PRECOND_IC0_TILE, 29588, ("bands=" + ",".join("%d-%d" % p for p in part),))
+    capped, checked = False, 0
+    for i, f in enumerate(d["frames"]):
+        assert f["markers_in_rows"] and f["keys_cover_own_count"], (i, f)
+        capped = capped or (f["iters"][0] >= 100 * f["substeps"][0] and f["pmax"] > 0)
+        if capped:
+            continue
+        checked += 1
+        assert f["substeps"][0] == f["substeps"][1] and f["count_differ"] == 0 and f["prev_count_differ"] == 0, (i, f)
+        assert f["markers_at_keys"] and f["keys_are_a_permutation"] and f["n_markers"][0] == f["n_markers"][1], (i, f)
+        assert f["rng"] == [True, True] and f["dt_events"][0] == f["dt_events"][1], (i, f)
+        assert f["dp"] <= 1e-8 * f["pmax"] + 2e-6 and f["du"] < 1e-6 and f["dv"] < 1e-6, (i, f)
+    assert checked >= 10 and d["frames"][-1]["n_markers"][1] > 9e6
+
+
+@pytest.mark.gpu
+def test_exchange_overflow_fails_on_every_rank():
+    """the per-substep exchange buffers are bounded (they scale with X: k_slab.hip); when a substep deletes more markers
+    than fit - here the capacity is shrunk to 64 by EULER_SLAB_CAPS and blocks of sink cells delete hundreds - every rank must
+    return EULER_ESTATE from the same call: the overflowing rank's counter travels in the gathered block, the sticky error word in
+    the next exchange (eu_slab_error_sync)."""
+    d = run(3, 200, 192, "half_tank", 0, ea.PRECOND_IC0_TILE, 29585, ("events", "deletions", "overflow", "caps=8,64"))
+    ov = d["overflow"]
+    assert ov["failed"] == [True, True, True], ov
+    assert all("overflow" in m for m in ov["msg"]), ov
 
 
 @pytest.mark.gpu
