@@ -123,13 +123,14 @@ int op_allgather(void* ctx, void* base, const int64_t* off, const int64_t* cnt) 
   c->calls[3]++;
   char* b = static_cast<char*>(base);
   hipStream_t st = c->S->stream;
-  bool even = true;
+  bool even = cnt[0] > 0;
   for (int r = 0; r < c->n; ++r) even = even && cnt[r] == cnt[0] && off[r] == off[0] + (int64_t)r * cnt[0];
   if (even) {
     NCHK(g_api.AllGather(b + off[c->rank], b + off[0], (size_t)cnt[0], ncclUint8, c->comm, st));
   } else {
     NCHK(g_api.GroupStart());
-    for (int r = 0; r < c->n; ++r) NCHK(g_api.Broadcast(b + off[r], b + off[r], (size_t)cnt[r], ncclUint8, r, c->comm, st));
+    for (int r = 0; r < c->n; ++r)
+      if (cnt[r] > 0) NCHK(g_api.Broadcast(b + off[r], b + off[r], (size_t)cnt[r], ncclUint8, r, c->comm, st));      // (a rank may have nothing to contribute)
     NCHK(g_api.GroupEnd());
   }
   return 0;

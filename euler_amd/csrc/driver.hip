@@ -760,6 +760,14 @@ extern "C" int euler_get_field(euler_sim* S, int32_t f, void* dst, size_t dst_by
   return EULER_OK;
 }
 
+// the source cells of the own rows changed: the buffer of their random draws follows (k_source_fill)
+int eu_set_source_count(euler_sim* S, size_t nsrc) {
+  S->n_source_cells = nsrc;
+  if (S->draws) { (void)hipFree(S->draws); S->draws = nullptr; }
+  if (nsrc) HIPCHK(hipMalloc((void**)&S->draws, 2 * nsrc * sizeof(float)));
+  return EULER_OK;
+}
+
 extern "C" int euler_set_field(euler_sim* S, int32_t f, const void* src, size_t src_bytes) {
   if (!S || !src) return EULER_EINVAL;
   if (S->slab_on && (f == EULER_F_MARKERS || f == EULER_F_MARKER_KEYS || f == EULER_F_COUNT || f == EULER_F_PREV_COUNT ||
@@ -792,9 +800,7 @@ extern "C" int euler_set_field(euler_sim* S, int32_t f, const void* src, size_t 
     const uint8_t* s = (const uint8_t*)src;
     size_t nsrc = 0;
     for (size_t i = 0; i < (size_t)(S->row_hi - S->row_lo) * S->X; ++i) nsrc += s[i] != 0;
-    S->n_source_cells = nsrc;
-    if (S->draws) { (void)hipFree(S->draws); S->draws = nullptr; }
-    if (nsrc) HIPCHK(hipMalloc((void**)&S->draws, 2 * nsrc * sizeof(float)));
+    if ((rc = eu_set_source_count(S, nsrc))) return rc;
   }
   S->loaded = 1;
   return EULER_OK;
@@ -859,7 +865,7 @@ extern "C" int euler_get_stats(euler_sim* S, euler_stats* out) {
 extern "C" int euler_render(euler_sim* S, int32_t wx, int32_t wy, char* out, int32_t cap, int32_t* len) {
   if (!S || !len) return EULER_EINVAL;
   if (!S->loaded) return EULER_ESTATE;
-  if (S->slab_on) { eu_set_error("euler_render: not on a row-slab handle (render from the gathered count grid: euler_render_grids)"); return EULER_ESTATE; }
+  if (S->slab_on) return eu_slab_render(S, wx, wy, out, cap, len);      // collective: the visible rows are gathered from the ranks that own them
   const int X = S->X, Y = S->Y;
   int cutoff = Y - 1 - wy;
   if (cutoff < 1) cutoff = 1;
@@ -932,102 +938,6 @@ extern "C" int euler_measure_copy_bandwidth(euler_sim* S, size_t bytes, int32_t 
   (void)hipFree(a); (void)hipFree(b);
   if (e != hipSuccess) return eu_hip_fail(e, "copy probe", __FILE__, __LINE__);
   *gbps = 2.0 * (double)bytes * reps / ((double)ms * 1e-3) / 1e9;
-  return EULER_OK;
-}
-
-// ---- state snapshots (checkpoint / resume) -----------------------------------
-// Everything the reference keeps in file-scope variables (main.c:64-100,204,577): the four velocity
-// fields, the five cell grids, g_precon, the marker array in order, the RNG state and the source
-// latch - plus this build's frame counters.  Little-endian; layout documented in include/euler.h.
-static uint64_t snap_fnv(uint64_t h, const void* p, size_t n) {
-  const unsigned char* b = (const unsigned char*)p;
-  for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
-  return h;
-}
-struct SnapHeader {
-  char magic[8]; uint32_t version; int32_t X, Y; uint32_t reserved;
-  uint64_t n_markers, rng_state; int32_t source_exhausted; int32_t reserved2;
-  uint64_t frames, total_substeps, total_pcg_iterations;
-};
-static const int SNAP_F32[] = {EULER_F_U, EULER_F_V, EULER_F_UTMP, EULER_F_VTMP};
-static const int SNAP_U8[] = {EULER_F_SOLID, EULER_F_SOURCE, EULER_F_SINK, EULER_F_COUNT, EULER_F_PREV_COUNT};
-static const int SNAP_DYE[] = {EULER_F_DYE_R, EULER_F_DYE_G, EULER_F_DYE_B, EULER_F_DYE_RTMP, EULER_F_DYE_GTMP, EULER_F_DYE_BTMP};   // version 2 only
-
-extern "C" int euler_save_state(euler_sim* S, const char* path) {
-  if (!S || !path) return EULER_EINVAL;
-  if (S->slab_on) { eu_set_error("euler_save_state: not on a row-slab handle (gather the ranks' rows with euler_get_field)"); return EULER_ESTATE; }
-  euler_stats st;
-  int rc = euler_get_stats(S, &st);
-  if (rc) return rc;
-  FILE* f = fopen(path, "wb");
-  if (!f) { eu_set_error("cannot open %s for writing", path); return EULER_EIO; }
-  SnapHeader h;
-  memset(&h, 0, sizeof h);
-  memcpy(h.magic, "EULERSNP", 8);
-  h.version = S->dye[0] ? 2 : 1; h.X = S->X; h.Y = S->Y; h.n_markers = st.n_markers; h.rng_state = st.rng_state;
-  h.source_exhausted = st.source_exhausted; h.frames = st.frames; h.total_substeps = st.total_substeps;
-  h.total_pcg_iterations = st.total_pcg_iterations;
-  uint64_t sum = snap_fnv(14695981039346656037ull, &h, sizeof h);
-  bool ok = fwrite(&h, sizeof h, 1, f) == 1;
-  const size_t C = S->C;
-  std::vector<unsigned char> buf(C * 8 > st.n_markers * 8 ? C * 8 : (size_t)st.n_markers * 8);
-  auto put = [&](int field, size_t bytes) {
-    if (!ok || !bytes) return;
-    rc = euler_get_field(S, field, buf.data(), bytes);
-    if (rc) { ok = false; return; }
-    sum = snap_fnv(sum, buf.data(), bytes);
-    ok = fwrite(buf.data(), 1, bytes, f) == bytes;
-  };
-  for (int fd : SNAP_F32) put(fd, C * 4);
-  for (int fd : SNAP_U8) put(fd, C);
-  put(EULER_F_PRECON, C * 8);
-  if (S->dye[0]) for (int fd : SNAP_DYE) put(fd, C * 4);
-  put(EULER_F_MARKERS, (size_t)st.n_markers * 8);
-  ok = ok && fwrite(&sum, 8, 1, f) == 1;
-  ok = (fclose(f) == 0) && ok;
-  if (rc) return rc;
-  if (!ok) { eu_set_error("short write to %s", path); return EULER_EIO; }
-  return EULER_OK;
-}
-
-extern "C" int euler_load_state(euler_sim* S, const char* path) {
-  if (!S || !path) return EULER_EINVAL;
-  if (S->slab_on) { eu_set_error("euler_load_state: not on a row-slab handle"); return EULER_ESTATE; }
-  FILE* f = fopen(path, "rb");
-  if (!f) { eu_set_error("cannot open %s", path); return EULER_EIO; }
-  SnapHeader h;
-  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "EULERSNP", 8) != 0 || (h.version != 1 && h.version != 2)) {
-    fclose(f); eu_set_error("%s is not an euler state snapshot (version 1 or 2)", path); return EULER_EINVAL;
-  }
-  if ((h.version == 2) != (S->dye[0] != nullptr)) {
-    fclose(f); eu_set_error("%s %s the dye fields but this handle was created %s euler_config.rainbow", path,
-                            h.version == 2 ? "carries" : "lacks", S->dye[0] ? "with" : "without");
-    return EULER_EINVAL;
-  }
-  if (h.X != S->X || h.Y != S->Y || h.n_markers > S->max_markers) {
-    fclose(f); eu_set_error("snapshot grid %dx%d (%llu markers) does not fit this %dx%d handle", h.X, h.Y,
-                            (unsigned long long)h.n_markers, S->X, S->Y);
-    return EULER_EINVAL;
-  }
-  const size_t C = S->C;
-  const size_t body = C * 4 * 4 + C * 5 + C * 8 + (h.version == 2 ? C * 4 * 6 : 0) + (size_t)h.n_markers * 8;
-  std::vector<unsigned char> buf(body + 8);
-  const bool ok = fread(buf.data(), 1, body + 8, f) == body + 8;
-  fclose(f);
-  uint64_t sum = snap_fnv(snap_fnv(14695981039346656037ull, &h, sizeof h), buf.data(), body), want = 0;
-  memcpy(&want, buf.data() + body, 8);
-  if (!ok || sum != want) { eu_set_error("%s is truncated or corrupt (checksum)", path); return EULER_EIO; }
-  const unsigned char* p = buf.data();
-  int rc;
-  for (int fd : SNAP_F32) { if ((rc = euler_set_field(S, fd, p, C * 4))) return rc; p += C * 4; }
-  for (int fd : SNAP_U8) { if ((rc = euler_set_field(S, fd, p, C))) return rc; p += C; }
-  if ((rc = euler_set_field(S, EULER_F_PRECON, p, C * 8))) return rc;
-  p += C * 8;
-  if (h.version == 2) for (int fd : SNAP_DYE) { if ((rc = euler_set_field(S, fd, p, C * 4))) return rc; p += C * 4; }
-  if ((rc = euler_set_markers(S, (const float*)p, h.n_markers))) return rc;
-  if ((rc = euler_set_rng(S, h.rng_state, h.source_exhausted))) return rc;
-  S->stats.frames = h.frames; S->stats.total_substeps = h.total_substeps; S->stats.total_pcg_iterations = h.total_pcg_iterations;
-  S->loaded = 1;
   return EULER_OK;
 }
 

@@ -219,6 +219,7 @@ struct euler_sim {
   unsigned int* keys[2];      // slab mode: the GLOBAL array index (the reference's position in g_markers) of each local marker
   euler_comm_ops bulk;        // the communicator the caller installed (the mailboxes replace S->comm's all-reduce / halo only)
   struct SlabScratch* slab;   // exchange buffers (k_slab.hip)
+  int part_lo[64], part_hi[64];   // every rank's band range (eu_slab_check_partition), for the snapshot manifest and the render gather
   void* rccl;                 // the built-in RCCL communicator (comm_rccl.hip), if euler_set_comm_rccl installed one
   void* p2p;                  // peer-to-peer mailboxes for the scalar all-reduces and ghost rows (comm_p2p.hip)
   int p2p_on;                 // connected: reductions finish their all-reduce in their own last block, ghost rows go direct
@@ -276,6 +277,8 @@ int  eu_slab_timestep(euler_sim* S, float frame_time_left);
 int  eu_slab_after_load(euler_sim* S);
 int  eu_slab_check_partition(euler_sim* S);   // collective: the ranks' band ranges tile the grid
 int  eu_slab_exchange_uv(euler_sim* S);     // ghost rows of u, v (euler_set_field on a slab handle)
+int  eu_slab_render(euler_sim* S, int wx, int wy, char* out, int cap, int* len);   // snapshot.hip: euler_render on a row-slab handle (collective)
+int  eu_slab_after_restore(euler_sim* S);   // collective: the job-wide facts a scenario load sets up (source cells of all ranks)
 int  eu_slab_error_sync(euler_sim* S);      // collective: the ranks' sticky error words -> their maximum on every rank
 // launch groups implemented in the kernel files
 int eu_launch_timestep(euler_sim* S, float frame_time_left);

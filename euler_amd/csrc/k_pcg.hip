@@ -394,9 +394,16 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
       auto load_pair = [&](int P, SaPair& d, unsigned int m) {
         d.ez0 = d.es0 = d.ez1 = d.es1 = 0.0;
         if (P < 0 || P >= npairs) { d.z = sw_d2{0.0, 0.0}; d.so = sw_d2{0.0, 0.0}; return; }   // outside the band: never a fluid cell's neighbour
+#ifdef SA_ABL_NO_WINDOW       // timing experiment (WRONG results): the pairs before / after the run are not loaded
+        if (P < P0 || P >= P1) { d.z = sw_d2{0.0, 0.0}; d.so = sw_d2{0.0, 0.0}; return; }
+#endif
         d.z = *reinterpret_cast<const sw_d2*>(z + bbase + (size_t)P * 128);
         d.so = *reinterpret_cast<const sw_d2*>(s_old + bbase + (size_t)P * 128);
+#ifdef SA_ABL_NO_EDGE         // timing experiment (WRONG results): lanes 0 / 63 do not fetch the rows across the band boundary
+        if (false) {
+#else
         if (edge_lane) {
+#endif
           if ((m & CM_FLUID) && (m & vbit)) {
             const long long k = e0_base + (long long)P * 128;
             if (SLAB == 2 && ghost) { d.ez0 = gz[2 * P + gcol]; d.es0 = gs[2 * P + gcol]; }
@@ -786,8 +793,12 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   // global band pipeline, which also names the hand-off rows (forwarded rank to rank when coupled)
   const int band = BWD ? a.band_lo + a.nb_local - 1 - ord : a.band_lo + ord;
   const int gord = BWD ? nb - 1 - band : band;
+#ifdef SW_ABL_FORCE_LONE      // timing experiment (WRONG results): every band runs as if it were alone - no hand-off, no helper waves
+  const bool has_prev = false, publish = false;
+#else
   const bool has_prev = ord > 0 || (a.couple && gord > 0);            // a band before us in sweep order
   const bool publish = ord + 1 < a.nb_local || (a.couple && gord + 1 < nb);
+#endif
   unsigned long long* gr_out = a.granules + (size_t)gord * a.gran_stride * 2;
   const unsigned long long* gr_in = a.granules + (size_t)(has_prev ? gord - 1 : 0) * a.gran_stride * 2;
   if (XG) {   // the band pipeline continues across GPUs: same granules, same epochs, system-scope accesses (below)
@@ -860,6 +871,9 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
       }
       if (lds_get(&sh.abort)) return;
       if (++spins > (SW_SPIN_LIMIT << 3)) { if (lane == 0) atomicExch(a.error, 2); lds_put(&sh.abort, 1u); return; }
+#ifdef SW_ANNOUNCE_SLEEP       // the announce wave yields while it has nothing to announce (tools/r03: sweep ablations)
+      __builtin_amdgcn_s_sleep(SW_ANNOUNCE_SLEEP);
+#endif
     }
     // The edge row's column of the very last step (8*B1 - 1) opens the group of a block that never runs.
     // The next band reads it only when X + 63 is a multiple of 16 (factor sweep: full range, full window).
@@ -916,6 +930,9 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
       retire(q1); issue(q1);
       retire(q2); issue(q2);
       retire(q3); issue(q3);
+#ifdef SW_FETCH_SLEEP          // fewer polls per microsecond (tools/r03: sweep ablations)
+      __builtin_amdgcn_s_sleep(SW_FETCH_SLEEP);
+#endif
       if (lds_get(&sh.abort) || spins > SW_SPIN_LIMIT) break;
     }
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0.gv), "+v"(q1.gv), "+v"(q2.gv), "+v"(q3.gv) :: "memory");   // before their registers are reused
@@ -1084,7 +1101,9 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
         own = carry;
         out = carry;
         // the announce wave gathers the edge lane's entry; two rows per LDS instruction (ds_write2st64_b64)
+#ifndef SW_ABL_NO_RING         // experiment (WRONG results downstream): the compute wave does not feed the announce wave
         if (PB && (j & 1)) { ring[(j - 1) * 64] = prev_carry; ring[j * 64] = carry; }
+#endif
         prev_carry = carry;
       };
       step(std::integral_constant<int, 0>()); step(std::integral_constant<int, 1>()); step(std::integral_constant<int, 2>());
@@ -1693,7 +1712,9 @@ static TileArgs make_tile_args(euler_sim* S, int force) {
   a.list = (!force && S->tile_w == 16) ? S->chunk_list : nullptr;      // (forced single operations may run on masks no solve has listed)
   a.table = S->tile_table;
   a.zsend_lo = a.zsend_hi = nullptr; a.edge_lo = a.edge_hi = -1;
-  { static const int rev = getenv("EULER_TILE_REVERSE") ? atoi(getenv("EULER_TILE_REVERSE")) : 0; a.reverse = rev; }      // (experiment)
+  // descending: k_search_apply walks the chunks upwards, so this pass starts on what the Infinity Cache still holds of it - and ends
+  // where the next k_search_apply starts.  8192^2: 548 -> 536 us per iteration (EULER_TILE_REVERSE=0 restores the ascending order)
+  { static const int rev = getenv("EULER_TILE_REVERSE") ? atoi(getenv("EULER_TILE_REVERSE")) : 1; a.reverse = rev; }
   if (ghost_mode(S)) {
     if (S->band_lo > 0) { a.zsend_lo = xrow(S, XR_ZSEND_LO); a.edge_lo = S->band_lo; }
     if (S->band_hi < S->geom.nbands) { a.zsend_hi = xrow(S, XR_ZSEND_HI); a.edge_hi = S->band_hi - 1; }

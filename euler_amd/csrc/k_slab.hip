@@ -123,6 +123,7 @@ __global__ void k_partition_fill(double* v, int R, int rank, int lo, int hi) {
 }
 int eu_slab_check_partition(euler_sim* S) {
   SlabScratch* s = S->slab;
+  S->part_lo[0] = S->band_lo; S->part_hi[0] = S->band_hi;
   if (!s || s->R < 2) return EULER_OK;
   hipLaunchKernelGGL(k_partition_fill, dim3(1), dim3(64), 0, S->stream, s->vec2, s->R, s->rank, S->band_lo, S->band_hi);
   COMM_CALL(S->comm.allreduce(S->comm.ctx, s->vec2, 2 * s->R, 0));
@@ -138,6 +139,7 @@ int eu_slab_check_partition(euler_sim* S) {
     S->has_comm = 0;
     return EULER_EINVAL;
   }
+  for (int r = 0; r < s->R && r < 64; ++r) { S->part_lo[r] = (int)h[r]; S->part_hi[r] = (int)h[s->R + r]; }
   return EULER_OK;
 }
 
@@ -585,8 +587,21 @@ int eu_slab_substep(euler_sim* S, float dt) {
   return exchange_uv(S);
 }
 
-// sim_init's refresh_marker_counts (main.c:268) + the ghost rows the first substep reads
 __global__ void k_set_vec0(double* v, double x) { v[0] = x; }
+// after a snapshot has been loaded into a slab handle (snapshot.hip): what a scenario load agrees on collectively
+int eu_slab_after_restore(euler_sim* S) {
+  SlabScratch* s = S->slab;
+  if (!S->has_comm) { eu_set_error("row-slab handle: install the communicator before loading a snapshot"); return EULER_ESTATE; }
+  hipLaunchKernelGGL(k_set_vec0, dim3(1), dim3(1), 0, S->stream, s->vec, (double)S->n_source_cells);
+  COMM_CALL(S->comm.allreduce(S->comm.ctx, s->vec, 1, 0));
+  double tot = 0.0;
+  HIPCHK(hipMemcpyAsync(&tot, s->vec, 8, hipMemcpyDeviceToHost, S->stream));
+  HIPCHK(hipStreamSynchronize(S->stream));
+  s->global_sources = (unsigned long long)tot;
+  return EULER_OK;
+}
+
+// sim_init's refresh_marker_counts (main.c:268) + the ghost rows the first substep reads
 int eu_slab_after_load(euler_sim* S) {
   SlabScratch* s = S->slab;
   hipLaunchKernelGGL(k_set_vec0, dim3(1), dim3(1), 0, S->stream, s->vec, (double)S->n_source_cells);

@@ -1,0 +1,348 @@
+// snapshot.hip — state snapshots (checkpoint / resume) for whole-grid AND row-slab handles, and euler_render on
+// a row-slab handle.
+//
+// A snapshot is everything the reference keeps in file-scope variables (main.c:64-100, 204, 577): the four velocity fields, the
+// five cell grids, g_precon, the marker array in order, the RNG state and the source latch - plus this build's frame counters.
+// Little-endian; layouts documented in include/euler.h.
+//   * a whole-grid handle writes ONE file (version 1, version 2 with the dye);
+//   * a job of row slabs writes one PART file per rank (version 3: the rank's own rows, its markers WITH their keys = their
+//     positions in the reference's array) and, rank 0, a small manifest under the given name listing the ranks' band ranges.
+// Loading is independent of how the state was written: any handle - whole grid, or a slab of ANY partition - takes its rows
+// (ghost rows included: the files of a job hold every row) and the markers inside its rows from whichever files hold them.  So a
+// 3-rank job can be resumed on 2 ranks, or on one GPU, or with another (fluid-balanced) partition: the re-partitioning of a run
+// whose water has moved is save + load.
+#include "euler_dev.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+int eu_set_source_count(euler_sim* S, size_t nsrc);   // driver.hip
+
+static uint64_t snap_fnv(uint64_t h, const void* p, size_t n) {
+  const unsigned char* b = (const unsigned char*)p;
+  for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+  return h;
+}
+struct SnapHeader {
+  char magic[8]; uint32_t version; int32_t X, Y; uint32_t reserved;
+  uint64_t n_markers, rng_state; int32_t source_exhausted; int32_t reserved2;
+  uint64_t frames, total_substeps, total_pcg_iterations;
+};
+struct SlabHeader {      // follows SnapHeader in a version 3 part file
+  int32_t nranks, rank, band_lo, band_hi, row_lo, row_hi;
+  uint64_t n_loc;
+};
+struct ManifestHeader { char magic[8]; uint32_t version; int32_t X, Y, nranks; };   // then nranks x {int32 band_lo, band_hi}
+static const int SNAP_F32[] = {EULER_F_U, EULER_F_V, EULER_F_UTMP, EULER_F_VTMP};
+static const int SNAP_U8[] = {EULER_F_SOLID, EULER_F_SOURCE, EULER_F_SINK, EULER_F_COUNT, EULER_F_PREV_COUNT};
+static const int SNAP_DYE[] = {EULER_F_DYE_R, EULER_F_DYE_G, EULER_F_DYE_B, EULER_F_DYE_RTMP, EULER_F_DYE_GTMP, EULER_F_DYE_BTMP};   // version 2 only
+
+static std::string part_name(const char* path, int rank, int nranks) {
+  char suffix[64];
+  snprintf(suffix, sizeof suffix, ".%dof%d", rank, nranks);
+  return std::string(path) + suffix;
+}
+
+// ------------------------------------------------------------------------------------------ save
+extern "C" int euler_save_state(euler_sim* S, const char* path) {
+  if (!S || !path) return EULER_EINVAL;
+  euler_stats st;
+  int rc = euler_get_stats(S, &st);
+  if (rc) return rc;
+  const bool slab = S->slab_on != 0;
+  const int nranks = slab ? S->cfg.slab_nranks : 1, rank = slab ? S->cfg.slab_rank : 0;
+  const std::string file = slab ? part_name(path, rank, nranks) : std::string(path);
+  FILE* f = fopen(file.c_str(), "wb");
+  if (!f) { eu_set_error("cannot open %s for writing", file.c_str()); return EULER_EIO; }
+  SnapHeader h;
+  memset(&h, 0, sizeof h);
+  memcpy(h.magic, "EULERSNP", 8);
+  h.version = slab ? 3 : (S->dye[0] ? 2 : 1); h.X = S->X; h.Y = S->Y; h.n_markers = st.n_markers; h.rng_state = st.rng_state;
+  h.source_exhausted = st.source_exhausted; h.frames = st.frames; h.total_substeps = st.total_substeps;
+  h.total_pcg_iterations = st.total_pcg_iterations;
+  uint64_t sum = snap_fnv(14695981039346656037ull, &h, sizeof h);
+  bool ok = fwrite(&h, sizeof h, 1, f) == 1;
+  const uint64_t n_loc = S->n_markers_host;      // exact: euler_get_stats synced the marker state
+  if (slab) {
+    SlabHeader sh;
+    memset(&sh, 0, sizeof sh);
+    sh.nranks = nranks; sh.rank = rank; sh.band_lo = S->band_lo; sh.band_hi = S->band_hi; sh.row_lo = S->row_lo; sh.row_hi = S->row_hi; sh.n_loc = n_loc;
+    sum = snap_fnv(sum, &sh, sizeof sh);
+    ok = ok && fwrite(&sh, sizeof sh, 1, f) == 1;
+  }
+  const size_t Cr = (size_t)(S->row_hi - S->row_lo) * S->X;      // cells of the own rows (the whole grid without slabs)
+  std::vector<unsigned char> buf(Cr * 8 > n_loc * 8 ? Cr * 8 : (size_t)n_loc * 8);
+  auto put = [&](int field, size_t bytes) {
+    if (!ok || !bytes) return;
+    rc = euler_get_field(S, field, buf.data(), bytes);
+    if (rc) { ok = false; return; }
+    sum = snap_fnv(sum, buf.data(), bytes);
+    ok = fwrite(buf.data(), 1, bytes, f) == bytes;
+  };
+  for (int fd : SNAP_F32) put(fd, Cr * 4);
+  for (int fd : SNAP_U8) put(fd, Cr);
+  put(EULER_F_PRECON, Cr * 8);
+  if (S->dye[0]) for (int fd : SNAP_DYE) put(fd, Cr * 4);
+  put(EULER_F_MARKERS, (size_t)n_loc * 8);
+  if (slab) put(EULER_F_MARKER_KEYS, (size_t)n_loc * 4);
+  ok = ok && fwrite(&sum, 8, 1, f) == 1;
+  ok = (fclose(f) == 0) && ok;
+  if (rc) return rc;
+  if (!ok) { eu_set_error("short write to %s", file.c_str()); return EULER_EIO; }
+  if (slab && rank == 0) {      // the manifest: which part holds which bands
+    FILE* m = fopen(path, "wb");
+    if (!m) { eu_set_error("cannot open %s for writing", path); return EULER_EIO; }
+    ManifestHeader mh;
+    memset(&mh, 0, sizeof mh);
+    memcpy(mh.magic, "EULERMAN", 8);
+    mh.version = 3; mh.X = S->X; mh.Y = S->Y; mh.nranks = nranks;
+    bool mok = fwrite(&mh, sizeof mh, 1, m) == 1;
+    for (int r = 0; r < nranks && mok; ++r) { const int32_t b[2] = {S->part_lo[r], S->part_hi[r]}; mok = fwrite(b, sizeof b, 1, m) == 1; }
+    mok = (fclose(m) == 0) && mok;
+    if (!mok) { eu_set_error("short write to %s", path); return EULER_EIO; }
+  }
+  return EULER_OK;
+}
+
+// ------------------------------------------------------------------------------------------ load
+namespace {
+struct Part {
+  std::string file;
+  SnapHeader h;
+  int row_lo, row_hi;
+  uint64_t n_loc;
+  bool keyed;                       // version 3: markers carry keys; else a marker's key is its index
+  std::vector<unsigned char> data;  // the whole file once loaded
+  size_t body;                      // offset of the first field
+  size_t cells() const { return (size_t)(row_hi - row_lo) * h.X; }
+  const unsigned char* section(int k) const {      // 0..3 f32 fields, 4..8 u8 grids, 9 precon, 10..15 dye (v2), 16 markers, 17 keys
+    const size_t C = cells();
+    size_t off = body;
+    if (k <= 3) return data.data() + off + (size_t)k * 4 * C;
+    off += 16 * C;
+    if (k <= 8) return data.data() + off + (size_t)(k - 4) * C;
+    off += 5 * C;
+    if (k == 9) return data.data() + off;
+    off += 8 * C;
+    if (h.version == 2) { if (k <= 15) return data.data() + off + (size_t)(k - 10) * 4 * C; off += 24 * C; }
+    if (k == 16) return data.data() + off;
+    return data.data() + off + (size_t)n_loc * 8;
+  }
+};
+
+int read_part(Part& p) {
+  FILE* f = fopen(p.file.c_str(), "rb");
+  if (!f) { eu_set_error("cannot open %s", p.file.c_str()); return EULER_EIO; }
+  fseek(f, 0, SEEK_END);
+  const long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  if (n < (long)(sizeof(SnapHeader) + 8)) { fclose(f); eu_set_error("%s is not an euler state snapshot", p.file.c_str()); return EULER_EINVAL; }
+  try { p.data.resize((size_t)n); } catch (...) { fclose(f); return EULER_ENOMEM; }
+  const bool ok = fread(p.data.data(), 1, (size_t)n, f) == (size_t)n;
+  fclose(f);
+  memcpy(&p.h, p.data.data(), sizeof p.h);
+  if (!ok || memcmp(p.h.magic, "EULERSNP", 8) != 0 || p.h.version < 1 || p.h.version > 3) {
+    eu_set_error("%s is not an euler state snapshot (version 1, 2 or 3)", p.file.c_str()); return EULER_EINVAL;
+  }
+  p.body = sizeof(SnapHeader);
+  p.row_lo = 0; p.row_hi = p.h.Y; p.n_loc = p.h.n_markers; p.keyed = false;
+  if (p.h.version == 3) {
+    SlabHeader sh;
+    memcpy(&sh, p.data.data() + sizeof(SnapHeader), sizeof sh);
+    p.body += sizeof sh;
+    p.row_lo = sh.row_lo; p.row_hi = sh.row_hi; p.n_loc = sh.n_loc; p.keyed = true;
+  }
+  const size_t C = p.cells();
+  const size_t want = p.body + C * 29 + (p.h.version == 2 ? C * 24 : 0) + (size_t)p.n_loc * (p.keyed ? 12 : 8) + 8;
+  uint64_t sum = 0, stored = 0;
+  if ((size_t)n == want) { sum = snap_fnv(14695981039346656037ull, p.data.data(), want - 8); memcpy(&stored, p.data.data() + want - 8, 8); }
+  if ((size_t)n != want || sum != stored) { eu_set_error("%s is truncated or corrupt (checksum)", p.file.c_str()); return EULER_EIO; }
+  return EULER_OK;
+}
+}  // namespace
+
+extern "C" int euler_load_state(euler_sim* S, const char* path) {
+  if (!S || !path) return EULER_EINVAL;
+  if (S->slab_on && !S->has_comm) { eu_set_error("row-slab handle: install the communicator before loading a snapshot"); return EULER_ESTATE; }
+  // what is there: one whole-grid file, or a manifest naming the part files of a job
+  std::vector<Part> parts;
+  {
+    FILE* f = fopen(path, "rb");
+    if (!f) { eu_set_error("cannot open %s", path); return EULER_EIO; }
+    char magic[8] = {0};
+    const bool got = fread(magic, 8, 1, f) == 1;
+    if (got && memcmp(magic, "EULERMAN", 8) == 0) {
+      ManifestHeader mh;
+      fseek(f, 0, SEEK_SET);
+      if (fread(&mh, sizeof mh, 1, f) != 1 || mh.version != 3 || mh.nranks < 1 || mh.nranks > 64) { fclose(f); eu_set_error("%s: bad manifest", path); return EULER_EINVAL; }
+      for (int r = 0; r < mh.nranks; ++r) {
+        int32_t b[2];
+        if (fread(b, sizeof b, 1, f) != 1) { fclose(f); eu_set_error("%s: bad manifest", path); return EULER_EINVAL; }
+        Part p;
+        p.file = part_name(path, r, mh.nranks);
+        p.row_lo = 64 * b[0]; p.row_hi = 64 * b[1] < mh.Y ? 64 * b[1] : mh.Y;      // (confirmed by the part's own header when it is read)
+        parts.push_back(p);
+      }
+    } else {
+      Part p;
+      p.file = path; p.row_lo = 0; p.row_hi = S->Y;
+      parts.push_back(p);
+    }
+    fclose(f);
+  }
+  // a handle needs the rows of its window (ghost rows included) and the markers inside its own rows: only the parts that overlap
+  const int X = S->X, Y = S->Y;
+  const int need_lo = S->slab_on ? S->win_lo : 0, need_hi = S->slab_on ? S->win_hi : Y;
+  std::vector<Part*> use;
+  for (Part& p : parts) {
+    if (p.row_hi <= need_lo || p.row_lo >= need_hi) continue;
+    int rc = read_part(p);
+    if (rc) return rc;
+    if (p.h.X != X || p.h.Y != Y) { eu_set_error("snapshot grid %dx%d does not fit this %dx%d handle", p.h.X, p.h.Y, X, Y); return EULER_EINVAL; }
+    use.push_back(&p);
+  }
+  if (use.empty()) { eu_set_error("%s holds no rows of this handle", path); return EULER_EINVAL; }
+  const SnapHeader& h0 = use[0]->h;
+  const bool dye = h0.version == 2;
+  if (dye != (S->dye[0] != nullptr)) {
+    eu_set_error("%s %s the dye fields but this handle was created %s euler_config.rainbow", path, dye ? "carries" : "lacks", S->dye[0] ? "with" : "without");
+    return EULER_EINVAL;
+  }
+  for (Part* p : use)
+    if (p->h.n_markers != h0.n_markers || p->h.rng_state != h0.rng_state || p->h.frames != h0.frames) { eu_set_error("%s: the part files belong to different states", path); return EULER_EINVAL; }
+
+  // ---- rows [need_lo, need_hi) of a field section from the parts
+  const int rows = need_hi - need_lo;
+  std::vector<unsigned char> buf((size_t)rows * X * 8);
+  std::vector<char> have((size_t)rows);
+  auto gather = [&](int section, int elem, int y0, int y1) -> bool {      // rows [y0, y1) -> buf
+    std::fill(have.begin(), have.end(), 0);
+    for (Part* p : use) {
+      const int a = p->row_lo > y0 ? p->row_lo : y0, b = p->row_hi < y1 ? p->row_hi : y1;
+      if (b <= a) continue;
+      memcpy(buf.data() + (size_t)(a - y0) * X * elem, p->section(section) + (size_t)(a - p->row_lo) * X * elem, (size_t)(b - a) * X * elem);
+      for (int y = a; y < b; ++y) have[(size_t)(y - y0)] = 1;
+    }
+    for (int y = y0; y < y1; ++y) if (!have[(size_t)(y - y0)]) { eu_set_error("%s: row %d is in none of the part files", path, y); return false; }
+    return true;
+  };
+  HIPCHK(hipStreamSynchronize(S->stream));
+  float* f32[4] = {S->u, S->v, S->utmp, S->vtmp};
+  uint8_t* u8[5] = {S->solid, S->source, S->sink, S->count, S->prev_count};
+  for (int k = 0; k < 4; ++k) {
+    if (!gather(k, 4, need_lo, need_hi)) return EULER_EINVAL;
+    HIPCHK(hipMemcpy(f32[k] + (size_t)need_lo * X, buf.data(), (size_t)rows * X * 4, hipMemcpyHostToDevice));
+  }
+  size_t nsrc = 0;
+  for (int k = 0; k < 5; ++k) {
+    if (!gather(4 + k, 1, need_lo, need_hi)) return EULER_EINVAL;
+    HIPCHK(hipMemcpy(u8[k] + (size_t)need_lo * X, buf.data(), (size_t)rows * X, hipMemcpyHostToDevice));
+    if (k == 1) for (size_t i = (size_t)(S->row_lo - need_lo) * X; i < (size_t)(S->row_hi - need_lo) * X; ++i) nsrc += buf[i] != 0;
+  }
+  int rc = eu_set_source_count(S, nsrc);
+  if (rc) return rc;
+  if (!gather(9, 8, S->row_lo, S->row_hi)) return EULER_EINVAL;      // g_precon: the own rows, into the band-skewed array
+  if ((rc = euler_set_field(S, EULER_F_PRECON, buf.data(), (size_t)(S->row_hi - S->row_lo) * X * 8))) return rc;
+  if (dye)
+    for (int k = 0; k < 6; ++k) {
+      if (!gather(10 + k, 4, 0, Y)) return EULER_EINVAL;
+      if ((rc = euler_set_field(S, SNAP_DYE[k], buf.data(), (size_t)Y * X * 4))) return rc;
+    }
+
+  // ---- markers: those inside the own rows, with their keys (a whole-grid handle: all of them, ordered by key)
+  std::vector<float> mk;
+  std::vector<unsigned int> keys;
+  uint64_t n_loc = 0;
+  if (!S->slab_on) {
+    if (h0.n_markers > S->max_markers) { eu_set_error("snapshot holds %llu markers, more than this handle's capacity", (unsigned long long)h0.n_markers); return EULER_EINVAL; }
+    try { mk.resize(2 * (size_t)h0.n_markers + 2); } catch (...) { return EULER_ENOMEM; }
+    std::vector<char> seen;
+    uint64_t placed = 0;
+    for (Part* p : use) {
+      const float* m = reinterpret_cast<const float*>(p->section(16));
+      const unsigned int* kk = reinterpret_cast<const unsigned int*>(p->section(17));
+      for (uint64_t i = 0; i < p->n_loc; ++i) {
+        const uint64_t key = p->keyed ? kk[i] : i;
+        if (key >= h0.n_markers) { eu_set_error("%s: marker key %llu out of range", path, (unsigned long long)key); return EULER_EINVAL; }
+        mk[2 * key] = m[2 * i]; mk[2 * key + 1] = m[2 * i + 1];
+        ++placed;
+      }
+    }
+    if (placed != h0.n_markers) { eu_set_error("%s: the part files hold %llu of %llu markers", path, (unsigned long long)placed, (unsigned long long)h0.n_markers); return EULER_EINVAL; }
+    if ((rc = euler_set_markers(S, mk.data(), h0.n_markers))) return rc;
+    if ((rc = euler_set_rng(S, h0.rng_state, h0.source_exhausted))) return rc;
+  } else {
+    for (Part* p : use) {
+      const float* m = reinterpret_cast<const float*>(p->section(16));
+      const unsigned int* kk = reinterpret_cast<const unsigned int*>(p->section(17));
+      for (uint64_t i = 0; i < p->n_loc; ++i) {
+        const int y = (int)floorf(m[2 * i + 1] / EU_H);
+        if (y < S->row_lo || y >= S->row_hi) continue;
+        mk.push_back(m[2 * i]); mk.push_back(m[2 * i + 1]);
+        keys.push_back(p->keyed ? kk[i] : (unsigned int)i);
+      }
+    }
+    n_loc = keys.size();
+    if (n_loc > S->max_markers) { eu_set_error("row slab %d: %llu markers in its rows, more than its capacity %zu", S->cfg.slab_rank, (unsigned long long)n_loc, S->max_markers); return EULER_ENOMEM; }
+    if (n_loc) {
+      HIPCHK(hipMemcpy(S->markers[S->cur], mk.data(), (size_t)n_loc * 8, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(S->keys[S->cur], keys.data(), (size_t)n_loc * 4, hipMemcpyHostToDevice));
+    }
+    MarkerState m0;
+    memset(&m0, 0, sizeof m0);
+    m0.n = h0.n_markers; m0.n_loc = n_loc; m0.max_markers = 4 * S->C; m0.rng_state = h0.rng_state; m0.exhausted = h0.source_exhausted;
+    HIPCHK(hipMemcpy(S->ms, &m0, sizeof m0, hipMemcpyHostToDevice));
+    S->n_markers_host = n_loc;
+    if ((rc = eu_slab_after_restore(S))) return rc;      // collective: the source cells of all ranks
+    if ((rc = eu_sync_marker_state(S))) return rc;
+  }
+  S->lean_ok = 0;      // the solver arrays may hold another state's pressure and masks: the next assembly writes them whole
+  memset(&S->stats, 0, sizeof S->stats);
+  S->stats.frames = h0.frames; S->stats.total_substeps = h0.total_substeps; S->stats.total_pcg_iterations = h0.total_pcg_iterations;
+  S->loaded = 1;
+  return EULER_OK;
+}
+
+// ------------------------------------------------------------------------------------------ render on a row-slab handle
+// draw_rows (main.c:914-951) reads g_solid, g_sink, g_marker_count in the visible rows [max(Y-1-wy, 1), Y-1).  Collective: every
+// rank contributes the visible rows it owns (an all-gather per grid, in place in a staging buffer), and every rank formats the same
+// frame.  A terminal-sized window is a few dozen rows of the top slab; the call works for any window.
+int eu_slab_render(euler_sim* S, int wx, int wy, char* out, int cap, int* len) {
+  if (!S->has_comm) { eu_set_error("row-slab handle without a communicator"); return EULER_ESTATE; }
+  const int X = S->X, Y = S->Y, R = S->cfg.slab_nranks;
+  int cutoff = Y - 1 - wy;
+  if (cutoff < 1) cutoff = 1;
+  const int vis_lo = cutoff, vis_hi = Y - 1 > cutoff ? Y - 1 : cutoff, vrows = vis_hi - vis_lo;
+  const size_t plane = (size_t)vrows * X;
+  uint8_t* stage = nullptr;
+  HIPCHK(hipMalloc((void**)&stage, 3 * plane + 16));
+  const uint8_t* grids[3] = {S->solid, S->sink, S->count};
+  std::vector<int64_t> off(R), cnt(R);
+  int rc = EULER_OK;
+  for (int k = 0; k < 3 && !rc && vrows > 0; ++k) {
+    for (int r = 0; r < R; ++r) {
+      const int lo = 64 * S->part_lo[r], hi = 64 * S->part_hi[r] < Y ? 64 * S->part_hi[r] : Y;
+      const int a = lo > vis_lo ? lo : vis_lo, b = hi < vis_hi ? hi : vis_hi;
+      off[r] = (int64_t)(k * plane) + (b > a ? (int64_t)(a - vis_lo) * X : 0);
+      cnt[r] = b > a ? (int64_t)(b - a) * X : 0;
+      if (r == S->cfg.slab_rank && b > a)
+        (void)hipMemcpyAsync(stage + off[r], grids[k] + (size_t)a * X, (size_t)cnt[r], hipMemcpyDeviceToDevice, S->stream);
+    }
+    if (S->bulk.allgather(S->bulk.ctx, stage, off.data(), cnt.data()) != 0) { eu_set_error("communicator callback failed: render all-gather"); rc = EULER_ECOMM; }
+  }
+  uint8_t* g = rc ? nullptr : (uint8_t*)calloc(3, S->C);      // (untouched pages of the full-size planes are never committed)
+  if (!rc && !g) rc = EULER_ENOMEM;
+  if (!rc) {
+    for (int k = 0; k < 3 && plane; ++k)
+      if (hipMemcpyAsync(g + (size_t)k * S->C + (size_t)vis_lo * X, stage + k * plane, plane, hipMemcpyDeviceToHost, S->stream) != hipSuccess) rc = EULER_EHIP;
+    if (hipStreamSynchronize(S->stream) != hipSuccess) rc = EULER_EHIP;
+  }
+  if (!rc) rc = euler_render_grids(g, g + S->C, g + 2 * S->C, X, Y, wx, wy, out, cap, len);
+  free(g);
+  (void)hipFree(stage);
+  return rc;
+}

@@ -180,6 +180,8 @@ class TorchComm:
     def _allgather(self, ctx, base, off, cnt):
         def run():
             for r in range(self.world):
+                if cnt[r] == 0:           # (a rank may have nothing to contribute: the same on every rank)
+                    continue
                 t = self._t(base + off[r], cnt[r])
                 if self.stage:
                     c = t.cpu() if r == self.rank else self.torch.empty(cnt[r], dtype=self.torch.uint8)

@@ -223,14 +223,24 @@ int euler_get_stats(euler_sim* sim, euler_stats* out);
  *   [version = 2, handles created with euler_config.rainbow: f32[Y][X] g_r, g_g, g_b, g_rtmp, g_gtmp, g_btmp;]
  *   f32[n_markers][2] markers in array order;  u64 FNV-1a-64 of all preceding bytes.
  * euler_load_state needs a handle of the same X, Y.  (euler_amd.read_snapshot / write_snapshot mirror
- * the format in numpy.) */
+ * the format in numpy.)
+ * ROW SLABS (version 3): every rank of a job calls euler_save_state with the SAME path and writes its own part file
+ * "<path>.<rank>of<nranks>": the 72-byte header above with version = 3, then i32 nranks, rank, band_lo, band_hi, row_lo, row_hi,
+ * u64 n_local_markers; the arrays above restricted to the rank's OWN rows [row_lo, row_hi); f32[n_local][2] markers,
+ * u32[n_local] their keys (positions in the reference's g_markers); FNV-1a-64.  Rank 0 also writes the manifest at <path>:
+ * char[8] "EULERMAN"; u32 3; i32 X, Y, nranks; nranks x {i32 band_lo, band_hi}.
+ * euler_load_state is independent of how a state was written: a whole-grid handle or a slab of ANY partition loads from a single
+ * file or from a manifest, taking its rows (ghost rows included) and the markers inside its rows from the parts that hold them.
+ * Resuming a 3-rank job on 2 ranks, on one GPU, or on a re-balanced partition is save + load.  On a row-slab handle the call is
+ * collective (communicator installed first, like euler_load_scenario_*). */
 int euler_save_state(euler_sim* sim, const char* path);
 int euler_load_state(euler_sim* sim, const char* path);
 size_t euler_field_bytes(const euler_sim* sim, int32_t field);   /* current size in bytes */
 
 /* ---- render = draw_rows (main.c:914-951) ------------------------------------------------- */
 /* Fetches only the visible window of the count grid from HBM.  Writes at most cap bytes into out
- * and stores the full length in *len (call with cap=0 to size the buffer). */
+ * and stores the full length in *len (call with cap=0 to size the buffer).  On a row-slab handle the call is COLLECTIVE: the
+ * visible rows are gathered from the ranks that own them and every rank returns the same frame. */
 int euler_render(euler_sim* sim, int32_t wx, int32_t wy, char* out, int32_t cap, int32_t* len);
 /* The same formatter over caller-supplied host grids (no GPU needed). */
 int euler_render_grids(const uint8_t* solid, const uint8_t* sink, const uint8_t* count,

@@ -58,7 +58,17 @@ def main():
     out = {"world": world, "frames": []}
     if p2p:
         out["p2p_ok"] = attach_p2p(sim)
-    load(sim, workload)
+    snap_save = snap_load = None
+    for a in sys.argv[6:]:
+        if a.startswith("save="):
+            snap_save = a[5:]
+        if a.startswith("load="):
+            snap_load = a[5:]
+    if snap_load:                             # resume a job that another set of ranks (another partition) saved; the single-GPU run resumes its own file
+        sim.load_state(snap_load)
+        ref.load_state(snap_load + ".ref")
+    else:
+        load(sim, workload)
     lo, hi = sim.slab_rows()
     out["rows"] = [lo, hi]
     if "events" in sys.argv[6:]:
@@ -152,6 +162,8 @@ def main():
         d["substeps"] = [sr.last_substeps, ss.last_substeps]
         d["rng"] = [int(sr.rng_state) == int(ss.rng_state), sr.source_exhausted == ss.source_exhausted]
         d["dt_events"] = [int(sr.marker_dt_events), int(ss.marker_dt_events)]
+        if "render" in sys.argv[6:]:          # euler_render on a slab handle is collective and returns the single-GPU frame on every rank
+            d["render_equal"] = bool(sim.draw(120, 50) == ref.draw(120, 50) and sim.draw(X, Y) == ref.draw(X, Y))
         # worst over the ranks
         agg = [None] * world
         dist.all_gather_object(agg, d)
@@ -159,11 +171,15 @@ def main():
         for o in agg[1:]:
             for key in ("du", "dv", "dp", "count_differ", "prev_count_differ"):
                 w[key] = max(w[key], o[key])
-            for key in ("markers_at_keys", "markers_in_rows", "keys_are_a_permutation", "keys_cover_own_count"):
+            for key in ("markers_at_keys", "markers_in_rows", "keys_are_a_permutation", "keys_cover_own_count") + (("render_equal",) if "render_equal" in w else ()):
                 w[key] = w[key] and o[key]
             w["rng"] = [w["rng"][0] and o["rng"][0], w["rng"][1] and o["rng"][1]]
             w.setdefault("local_markers", [agg[0]["n_markers"][2]]).append(o["n_markers"][2])
         out["frames"].append(w)
+    if snap_save:
+        sim.save_state(snap_save)             # every rank: its part file; rank 0: the manifest too
+        if rank == 0:
+            ref.save_state(snap_save + ".ref")
     free1, _ = torch.cuda.mem_get_info()
     out["calls"] = comm.counts
     if rank == 0:

@@ -154,6 +154,43 @@ def test_configs3_shape_four_fluid_balanced_slabs_2048x4096():
 
 
 @pytest.mark.gpu
+def test_snapshot_of_three_slabs_resumes_on_two_and_on_one_gpu(tmp_path):
+    """a 3-rank job saves (one part file per rank + the manifest), a 2-rank job - another partition, so rows and
+    markers change hands, ghost rows come out of the files - loads it and continues; so does a plain single-GPU handle.  Both must
+    continue exactly like the uninterrupted single-GPU run: cell grids, every marker at its key, RNG, dt chain bit-exact, p / u / v
+    within the multi-rank solve's tolerance up to the first capped frame.  euler_render on the slab handles (collective) returns the
+    single-GPU frame, byte for byte, for a terminal-sized window and for the whole grid."""
+    import numpy as np
+    snap = str(tmp_path / "job.snap")
+    d1 = run(3, 256, 512, "dam_break", 12, ea.PRECOND_IC0_TILE, 29589, ("save=" + snap, "render"))
+    assert all(f["render_equal"] for f in d1["frames"])
+    assert os.path.exists(snap) and all(os.path.exists("%s.%dof3" % (snap, r)) for r in range(3))
+    d2 = run(2, 256, 512, "dam_break", 20, ea.PRECOND_IC0_TILE, 29590, ("load=" + snap, "render"))
+    capped, checked = False, 0
+    for i, f in enumerate(d2["frames"]):
+        assert f["markers_in_rows"] and f["keys_cover_own_count"] and f["render_equal"], (i, f)
+        capped = capped or (f["iters"][0] >= 100 * f["substeps"][0] and f["pmax"] > 0)
+        if capped:
+            continue
+        checked += 1
+        assert f["substeps"][0] == f["substeps"][1] and f["count_differ"] == 0 and f["prev_count_differ"] == 0, (i, f)
+        assert f["markers_at_keys"] and f["keys_are_a_permutation"] and f["n_markers"][0] == f["n_markers"][1], (i, f)
+        assert f["rng"] == [True, True], (i, f)
+        assert f["dp"] <= 1e-8 * f["pmax"] + 2e-6 and f["du"] < 1e-6 and f["dv"] < 1e-6, (i, f)
+    assert checked >= 8
+    # ... and on one GPU: the parts merge into the whole grid, the markers go to their keys - the state IS the single-GPU run's
+    one = ea.Simulation(256, 512, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE).load_state(snap)
+    ref = ea.Simulation(256, 512, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE).load_state(snap + ".ref")
+    for fld in (ea.F_COUNT, ea.F_PREV_COUNT, ea.F_SOLID, ea.F_SINK, ea.F_SOURCE):
+        assert np.array_equal(one.get(fld), ref.get(fld)), fld
+    exact = d1["frames"][-1]["du"] == 0.0 and d1["frames"][-1]["dv"] == 0.0      # (no solve has rounded differently yet: then every bit)
+    for fld in (ea.F_U, ea.F_V, ea.F_MARKERS):
+        a, b = one.get(fld), ref.get(fld)
+        assert a.shape == b.shape and (np.array_equal(a.view(np.uint32), b.view(np.uint32)) if exact else np.abs(a - b).max() < 1e-6), fld
+    assert one.stats().rng_state == ref.stats().rng_state and one.stats().n_markers == ref.stats().n_markers
+
+
+@pytest.mark.gpu
 def test_exchange_overflow_fails_on_every_rank():
     """the per-substep exchange buffers are bounded (they scale with X: k_slab.hip); when a substep deletes more markers
     than fit - here the capacity is shrunk to 64 by EULER_SLAB_CAPS and blocks of sink cells delete hundreds - every rank must

@@ -8,6 +8,5 @@ mkdir -p $OUT
 NAME=$1; shift
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-function -Iinclude -Ieuler_amd/csrc "$@" \
    -c euler_amd/csrc/k_pcg.hip -o $OUT/k_pcg_$NAME.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libeuler_hip_$NAME.so euler_amd/csrc/obj/driver.o euler_amd/csrc/obj/k_grid.o \
-   euler_amd/csrc/obj/k_markers.o $OUT/k_pcg_$NAME.o euler_amd/csrc/obj/euler_host.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libeuler_hip_$NAME.so $(ls euler_amd/csrc/obj/*.o | grep -v k_pcg.o) $OUT/k_pcg_$NAME.o
 rm $OUT/k_pcg_$NAME.o
