@@ -322,10 +322,9 @@ def make_handle(ctx, GX, GY, workload, tiles, slab_arg, precond, tol):
     """create a handle (the whole grid, or this rank's slab), attach the exchanges, load the workload -> (sim, comm, p2p, HBM bytes)"""
     import torch
     args, ea, rank = ctx["args"], ctx["ea"], ctx["rank"]
-    free_before = torch.cuda.mem_get_info()[0]
     sm = ea.Simulation(GX, GY, device=ctx["local_rank"], dot_mode=ctx["dot_mode"], precond=ctx["PC"][precond], tile_records=args.tile_records, tol=tol,
                        slab=slab_arg)
-    hbm = free_before - torch.cuda.mem_get_info()[0]
+    hbm = sm.hbm_bytes()      # what THIS handle allocated (free-memory differences are confounded when ranks share a device)
     cm, p2p = None, False
     if ctx["sharded"]:
         from euler_amd.slab import SLAB_EXACT, SLAB_LOCAL, RcclComm, TorchComm, attach_p2p
@@ -542,24 +541,20 @@ def summarize(t, size_x, size_y, precond, tile_w, traffic, traffic_note, steps, 
             "roofline": roof, "pcg_iteration": agg, "kernels": rows}
 
 
-def equal_residual(sim, ea, grp, args, GX, GY, tile_w):
-    """Reference-quality throughput of the roofline mode.  On the state the timed frames left (the saturated tank), ONE pressure
-    system - the stages of a substep up to project(), main.c:855-889, run once; project() reads utmp / vtmp / the cell grid and
-    can be repeated - is solved with the reference's IC(0) and the reference's budget of 100 iterations (main.c:735): its residual
-    is the bar.  Then the tile-local mode gets the smallest budget (steps of 4) whose residual on the SAME system is at or below
-    that bar, and frames are timed with that budget: cells*steps/s at equal residual."""
-    import torch
+def equal_residual_scan(sim, ea, tile_records, limit=1200):
+    """ONE pressure system - the stages of a substep up to project(), main.c:855-889, run once; project() reads utmp / vtmp / the
+    cell grid and can be repeated - solved with the reference's IC(0) and the reference's budget of 100 iterations (main.c:735):
+    its residual is the bar.  Then the tile-local mode gets the smallest budget (steps of 4) whose residual on the SAME system is at
+    or below that bar.  Leaves the handle mid-substep (the caller goes on with whole frames), in the tile-local mode, budget 100."""
     dt = sim.timestep(0.1)
     for st in (ea.STAGE_ADVECT_MARKERS, ea.STAGE_REFRESH_COUNTS, ea.STAGE_SOURCES, ea.STAGE_EXTRAPOLATE, ea.STAGE_ADVECT_VELOCITY):
         sim.stage(st, dt)
 
     def solve(precond, budget):
-        sim.set_precond(precond, args.tile_records)
-        sim.set_solver(budget)
-        torch.cuda.synchronize()
+        sim.set_precond(precond, tile_records)
+        sim.set_solver(budget)              # (synchronises the handle's stream; euler_stage returns with its work done)
         t0 = time.perf_counter()
         sim.stage(ea.STAGE_PROJECT, dt)
-        torch.cuda.synchronize()
         st = sim.stats()
         return {"ms": round(1e3 * (time.perf_counter() - t0), 2), "iterations": int(st.last_pcg_iterations), "residual": float(st.last_residual)}
 
@@ -568,15 +563,24 @@ def equal_residual(sim, ea, grp, args, GX, GY, tile_w):
     tile100 = solve(ea.PRECOND_IC0_TILE, 100)
     budget, tile = 100, tile100
     scan = [[100, tile100["residual"]]]
-    while tile["residual"] > exact["residual"] and budget < 400:
-        budget += 4
+    while tile["residual"] > exact["residual"] and budget < limit and exact["iterations"] >= 100:
+        budget = budget + 4 if budget < 160 else int(budget * 1.06) // 4 * 4 + 4      # (the inf-norm residual of CG is not monotone: a scan, not a bisection)
         tile = solve(ea.PRECOND_IC0_TILE, budget)
         scan.append([budget, tile["residual"]])
-    out = {"system": "%dx%d %s, the state behind the timed frames, one substep's pressure system (dt %.3g)" % (GX, GY, args.workload, dt),
-           "reference_ic0_100_iterations": exact, "tile_100_iterations": tile100,
-           "tile_budget_for_equal_residual": budget if tile["residual"] <= exact["residual"] else None, "tile_at_that_budget": tile,
-           "solve_speedup_at_equal_residual": round(exact["ms"] / tile["ms"], 2), "residual_scan": scan[-12:]}
-    if tile["residual"] <= exact["residual"]:
+    sim.set_solver(100)
+    reached = tile["residual"] <= exact["residual"]
+    return {"dt": dt, "reference_ic0_100_iterations": exact, "tile_100_iterations": tile100,
+            "tile_budget_for_equal_residual": budget if reached else None, "tile_at_that_budget": tile,
+            "solve_speedup_at_equal_residual": round(exact["ms"] / tile["ms"], 2) if reached else None, "residual_scan": scan[::max(1, len(scan) // 16)] + scan[-1:]}
+
+
+def equal_residual(sim, ea, grp, args, GX, GY, tile_w):
+    """Reference-quality throughput of the roofline mode on the headline workload: equal_residual_scan on the state the timed frames
+    left (the saturated tank), then frames timed with the budget it found: cells*steps/s at equal residual."""
+    out = equal_residual_scan(sim, ea, args.tile_records)
+    out["system"] = "%dx%d %s, the state behind the timed frames, one substep's pressure system (dt %.3g)" % (GX, GY, args.workload, out.pop("dt"))
+    budget = out["tile_budget_for_equal_residual"]
+    if budget:
         # frames with that budget in the roofline mode: the one number for "reference-quality throughput"
         sim.set_precond(ea.PRECOND_IC0_TILE, args.tile_records)
         sim.set_solver(budget)
@@ -651,6 +655,16 @@ def parity_vs_reference(ea, scenarios, so, device, dot_mode, tile_records, cases
              "fluid_cells": int(ofl.sum()), "fluid_cells_differing": int((gfl != ofl).sum()),
              "markers": [int(st.n_markers), int(o.n_markers)], "oracle_seconds": round(cpu_s, 2),
              "order": "[GPU tile-local mode, oracle with the reference's IC(0)]"}
+        try:      # ... and what the tile-local mode needs to match the reference's residual on the NEXT substep's system of this state
+            sc = equal_residual_scan(sim, ea, tile_records)
+            e["next_system"] = {"residual_reference_ic0_100": sc["reference_ic0_100_iterations"]["residual"],
+                                "residual_tile_100": sc["tile_100_iterations"]["residual"],
+                                "tile_budget_for_equal_residual": sc["tile_budget_for_equal_residual"],
+                                "residual_scan": sc["residual_scan"],
+                                "solve_ms": [sc["reference_ic0_100_iterations"]["ms"], sc["tile_at_that_budget"]["ms"]],
+                                "solve_speedup_at_equal_residual": sc["solve_speedup_at_equal_residual"]}
+        except Exception as ex:
+            e["next_system"] = {"error": repr(ex)}
         out.append(e)
         o.close()
         sim.close()

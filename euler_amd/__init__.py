@@ -71,7 +71,7 @@ EXPORTS = [
     "euler_get_field", "euler_set_field", "euler_set_markers", "euler_set_rng", "euler_get_stats",
     "euler_field_bytes", "euler_render", "euler_render_grids", "euler_render_grids_rgb", "euler_colorize", "euler_profile_enable",
     "euler_profile_class_count", "euler_profile_class_name", "euler_profile_get", "euler_profile_reset",
-    "euler_measure_copy_bandwidth", "euler_device_name", "euler_sweep_timeline", "euler_save_state", "euler_load_state", "euler_set_comm", "euler_set_stream", "euler_slab_info",
+    "euler_measure_copy_bandwidth", "euler_device_name", "euler_hbm_bytes", "euler_sweep_timeline", "euler_save_state", "euler_load_state", "euler_set_comm", "euler_set_stream", "euler_slab_info",
     "euler_rccl_unique_id", "euler_rccl_version", "euler_set_comm_rccl", "euler_comm_calls",
     "euler_p2p_export", "euler_p2p_connect", "euler_p2p_disconnect", "euler_p2p_calls",
 ]
@@ -125,6 +125,7 @@ def load_library():
         "euler_profile_reset": (C.c_int, [vp]),
         "euler_measure_copy_bandwidth": (C.c_int, [vp, C.c_size_t, i32, C.POINTER(f64)]),
         "euler_device_name": (C.c_int, [vp, C.c_char_p, i32]),
+        "euler_hbm_bytes": (u64, [vp]),
         "euler_sweep_timeline": (C.c_int, [vp, C.POINTER(C.c_uint64), i32]),
         "euler_save_state": (C.c_int, [vp, C.c_char_p]),
         "euler_load_state": (C.c_int, [vp, C.c_char_p]),
@@ -437,6 +438,10 @@ class Simulation:
                 row += tuple(int(x) for x in r[4:8]) + (int(t0),)
             out.append(row)
         return out
+
+    def hbm_bytes(self):
+        """device memory this handle allocated (a row-slab handle: its slab only)"""
+        return int(self.L.euler_hbm_bytes(self.h))
 
     def device_name(self):
         buf = C.create_string_buffer(256)

@@ -152,9 +152,11 @@ extern "C" int euler_set_solver(euler_sim* S, int32_t max_iterations, double tol
   return EULER_OK;
 }
 
+static thread_local size_t g_alloc_bytes = 0;      // what the handle under construction has allocated (euler_hbm_bytes)
 template <typename T>
 static int dalloc(T** p, size_t n) {
   HIPCHK(hipMalloc((void**)p, n * sizeof(T)));
+  g_alloc_bytes += n * sizeof(T);
   HIPCHK(hipMemset(*p, 0, n * sizeof(T)));
   return EULER_OK;
 }
@@ -215,6 +217,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
 
   euler_sim* S = (euler_sim*)calloc(1, sizeof(euler_sim));
   if (!S) return EULER_ENOMEM;
+  g_alloc_bytes = 0;
   S->cfg = *cfg;
   if (S->cfg.max_iterations <= 0) S->cfg.max_iterations = 100;
   if (S->cfg.max_substeps <= 0) S->cfg.max_substeps = 8;
@@ -372,6 +375,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   if (!S->ev_pool || !S->ev_cls || !S->ev_solve || !S->ev_iter) { euler_destroy(S); return EULER_ENOMEM; }
   for (int k = 0; k < S->ev_cap; ++k) CREATECHK(hipEventCreate(&S->ev_pool[k]));
   if (S->slab_on) { int rc = eu_slab_alloc(S); if (rc) { euler_destroy(S); return rc; } }
+  S->hbm_bytes = g_alloc_bytes + (S->slab_on ? eu_slab_bytes(S) : 0);
   eu_launch_tile_table(S);      // E^-1 of an interior tile (k_pcg.hip), once per handle
   CREATECHK(hipStreamSynchronize(S->stream));
 #undef CREATECHK
@@ -948,6 +952,8 @@ extern "C" int euler_sweep_timeline(euler_sim* S, uint64_t* out, int32_t cap_ban
   HIPCHK(hipMemcpy(out, S->sweep_timeline, (size_t)n * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return n;
 }
+
+extern "C" uint64_t euler_hbm_bytes(const euler_sim* S) { return S ? (uint64_t)S->hbm_bytes : 0; }
 
 extern "C" int euler_device_name(euler_sim* S, char* out, int32_t cap) {
   if (!S || !out || cap < 1) return EULER_EINVAL;

@@ -169,6 +169,7 @@ struct euler_sim {
   uint8_t* chunk_flag;    // this solve: the chunk holds fluid
   uint8_t* chunk_prev;    // the previous solve's flags (k_build_system<true>: where stale masks / p / r may sit)
   uint8_t* chunk_part;    // this solve: some cell of the chunk is not CM_INTERIOR (the listed entry of an interior chunk carries EU_CHUNK_INTERIOR)
+  size_t hbm_bytes;       // device memory this handle allocated at creation (euler_hbm_bytes)
   int lean_ok;            // the solver arrays have only been written by solves since chunk_prev was current (else k_build_system writes them whole)
   double* tile_table;     // [8][64][2]: E^-1 of an interior tile of 16 records (k_tile_table) - the same for every interior tile, so k_precond_tile never streams it
   unsigned long long* chunk_bits;
@@ -271,6 +272,7 @@ __device__ __forceinline__ size_t eu_xcd_block() {
 #define EU_GHOST_HI 2
 // slab mode (k_slab.hip)
 int  eu_slab_alloc(euler_sim* S);
+size_t eu_slab_bytes(const euler_sim* S);   // device memory of the slab exchange buffers
 void eu_slab_release(euler_sim* S);
 int  eu_slab_substep(euler_sim* S, float dt);
 int  eu_slab_timestep(euler_sim* S, float frame_time_left);

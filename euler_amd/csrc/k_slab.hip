@@ -103,6 +103,12 @@ int eu_slab_alloc(euler_sim* S) {
   return EULER_OK;
 }
 
+size_t eu_slab_bytes(const euler_sim* S) {
+  const SlabScratch* s = S->slab;
+  if (!s) return 0;
+  return s->blk * s->R + (size_t)s->sort_cap * 20 + 4 * s->buf_doubles * 8 + ((S->max_markers + 63) / 64) * 8 + (3 * SL_MAXR + 8) * 8;
+}
+
 void eu_slab_release(euler_sim* S) {
   SlabScratch* s = S->slab;
   if (!s) return;

@@ -335,6 +335,7 @@ int euler_profile_reset(euler_sim* sim);
 /* Device-to-device copy bandwidth probe (float4 copy kernel), GB/s read+write. */
 int euler_measure_copy_bandwidth(euler_sim* sim, size_t bytes, int32_t reps, double* gbps);
 int euler_device_name(euler_sim* sim, char* out, int32_t cap);
+uint64_t euler_hbm_bytes(const euler_sim* sim);   /* device memory the handle allocated (a row-slab handle: its slab only) */
 /* Diagnostics: the band pipeline of the most recent IC(0) sweep launch.  For each of this rank's bands in
  * sweep order, 8 words: wave entry, first block's boundary ready, wave exit (100 MHz constant clock
  * ticks), (blocks run << 32 | blocks that had to wait for the previous band), and four hand-off time

@@ -196,3 +196,43 @@ def test_tile_mode_moving_water_lean_assembly_bit_exact():
         air = sim.get(ea.F_COUNT) == 0
         assert (sim.get(ea.F_CELLMASK)[air] == 0).all(), f
         assert (sim.get(ea.F_PRESSURE)[air] == 0).all(), f
+
+
+def test_tile_mode_fields_against_the_reference_preconditioner_per_baseline_workload():
+    """What the roofline mode's FIELDS are worth against the reference's IC(0), from one state per BASELINE
+    workload, one frame each: tile-local mode on the GPU, the reference's preconditioner on the oracle (bench.py's
+    parity_vs_reference block, the same code).
+
+    * Where the solves converge inside the reference's budget of 100 iterations (main.c:735) the two agree to solver tolerance:
+      first solving frame of the 1024^2 dam break - |du|, |dv| <= 1e-5, identical cell grid and marker count.
+    * Where the cap cuts the solves short - every BASELINE workload at its size once real pressures build up - both answers are
+      unconverged and they differ by what the missing iterations would still have moved: parity with the reference's fields
+      does NOT hold there, by design of the cap, and this test says so explicitly: it records the deviation, checks that it is an
+      unconverged-solve effect (the structural state - cell grid, marker count - still agrees to 1e-4 of the fluid cells after the
+      frame), and that the reference's residual is within reach of the tile-local mode at a profit: on the next system of the
+      same state a scan finds the iteration budget at which the tile-local solve is at or below the residual the reference's
+      IC(0) reaches in 100 (measured: 144 ... 484, the inf-norm residual of CG oscillates), and the solve with that budget still
+      ends sooner than the reference's 100 iterations (measured 1.6x ... 3.4x)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from euler_amd import scenarios
+    from oracle_lib import build_oracle
+    res = bench.parity_vs_reference(ea, scenarios, build_oracle(), 0, ea.DOT_TREE, 0)
+    assert len(res) == 4
+    converged = [e for e in res if not e["capped"]]
+    capped = [e for e in res if e["capped"]]
+    assert converged and capped
+    for e in res:
+        print(e)
+        assert e["markers"][0] == e["markers"][1]
+        assert e["fluid_cells_differing"] <= 1e-4 * e["fluid_cells"] + 2
+    for e in converged:
+        assert e["max_abs_du"] <= 1e-5 and e["max_abs_dv"] <= 1e-5 and e["fluid_cells_differing"] == 0, e
+    for e in capped:
+        ns = e["next_system"]
+        assert "error" not in ns, ns
+        if ns["residual_reference_ic0_100"] > 0 and e["max_p"] > 0:
+            assert ns["tile_budget_for_equal_residual"] is not None and ns["tile_budget_for_equal_residual"] <= 1200, ns
+            assert ns["solve_speedup_at_equal_residual"] >= 1.2, ns
