@@ -181,8 +181,8 @@ extern "C" void euler_destroy(euler_sim* S) {
   for (float* d : S->dye) if (d) (void)hipFree(d);
   // band-skewed arrays: shifted to global element indexing as well (skew_off), behind EU_SKEW_SLACK elements of slack
   const size_t so = S->shifted ? S->skew_off : 0, sl = S->shifted ? (size_t)EU_SKEW_SLACK : 0;
-  for (double* d : {S->b, S->p, S->r, S->z, S->s, S->s2, S->q, S->precon}) if (d) (void)hipFree(d + so - sl);
-  if (S->cellmask) (void)hipFree(S->cellmask + so - sl);
+  (void)so; (void)sl;
+  for (void* d : S->skew_alloc) if (d) (void)hipFree(d);      // (the raw allocations: s / s2 swap during solves, and each array has its own stagger)
   const size_t fb_off = S->shifted ? (size_t)S->ab_lo * S->fb_stride * 64 : 0;
   if (S->fbits_fwd) (void)hipFree(S->fbits_fwd + fb_off);
   if (S->fbits_bwd) (void)hipFree(S->fbits_bwd + fb_off);
@@ -301,8 +301,22 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   S->sel.capacity_blocks = (mwords + 2047) / 2048 + 1;
   DALLOC(S->sel.block_sums, S->sel.capacity_blocks);
   // skewed arrays carry EU_SKEW_SLACK zeroed elements in front (the backward sweep prefetches below record 0)
-  for (double** d : {&S->b, &S->p, &S->r, &S->z, &S->s, &S->s2, &S->q, &S->precon}) DALLOC(*d, SS + EU_SKEW_SLACK);
-  DALLOC(S->cellmask, SS + EU_SKEW_SLACK);
+  // Every array starts EU_ARRAY_STAGGER bytes further into its allocation than the one before: eight arrays of the same size, allocated back to
+  // back, otherwise sit at the same offset modulo every power of two, and the four to six streams a PCG pass reads and writes at the same
+  // element index land in the same HBM channel at the same time (EULER_ARRAY_STAGGER overrides, in bytes; 0 = round 2's placement)
+  {
+    static const char* e = getenv("EULER_ARRAY_STAGGER");
+    const size_t stagger = (e ? (size_t)atol(e) : (size_t)EU_ARRAY_STAGGER) / 8 * 8;
+    int k = 0;
+    for (double** d : {&S->b, &S->p, &S->r, &S->z, &S->s, &S->s2, &S->q, &S->precon}) {
+      DALLOC(*d, SS + EU_SKEW_SLACK + 8 * stagger / 8);
+      S->skew_alloc[k] = *d;
+      *d += (size_t)k * stagger / 8;
+      ++k;
+    }
+    DALLOC(S->cellmask, SS + EU_SKEW_SLACK);
+    S->skew_alloc[8] = S->cellmask;
+  }
   S->fb_stride = 12 * (((S->geom.T + 7) / 8 + 11) / 12) + 4;   // whole groups of 3 and of 4 blocks + the blocks the prefetch runs ahead
   DALLOC(S->fbits_fwd, (size_t)(S->ab_hi - S->ab_lo) * S->fb_stride * 64);
   DALLOC(S->fbits_bwd, (size_t)(S->ab_hi - S->ab_lo) * S->fb_stride * 64);

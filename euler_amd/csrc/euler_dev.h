@@ -94,6 +94,9 @@ struct MarkerState {
 // TS = T + 64 records; S = nbands*TS*64 elements in total; padding carries mask 0.
 // Every skewed array also has EU_SKEW_SLACK elements of zeroed slack in front of element 0.
 #define EU_SKEW_SLACK (64 * 64)
+#ifndef EU_ARRAY_STAGGER
+#define EU_ARRAY_STAGGER 0   // bytes (driver.hip: euler_create)
+#endif
 #ifndef EU_RED_ELEMS
 #define EU_RED_ELEMS (256 * 16)   // skewed elements per block of the reduction kernels (apply_a, update_pr, dot), at most 2048 blocks;
                                   // 1024^2 frame: 2048 -> 79.8 ms, 4096 -> 77.0 ms, 8192 -> 79.5 ms
@@ -156,6 +159,7 @@ struct euler_sim {
   SkewGeom geom;
   double *b, *p, *r, *z, *s, *q, *precon;
   double* s2;             // second search-direction array (k_search_apply ping-pongs s / s2)
+  void* skew_alloc[9];    // the raw allocations behind b p r z s s2 q precon cellmask (each array is staggered inside its own)
   uint8_t* cellmask;
   unsigned int* fbits_fwd; unsigned int* fbits_bwd;   // fluid flags of the sweeps, 8 steps to a dword (k_pack_fbits)
   int fb_stride;          // words per band and lane
