@@ -108,6 +108,7 @@ def parse_args():
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 PMC passes (roofline.traffic is then null)")
     ap.add_argument("--no-16384", action="store_true", help="skip the 16384^2 projection block")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong_16384_dam_break block (BASELINE configs[3]; N = 1: its denominator)")
+    ap.add_argument("--strong-size", type=int, default=16384, help="N of the strong block's N x N dam break (tests use a small one)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # this process runs under rocprofv3 --pmc
     return ap.parse_args()
 
@@ -791,11 +792,11 @@ def main():
     del sim
     # BASELINE configs[3], the strong-scaling unit: N > 1 (the driver's scaling run) measures it beside the weak line, N = 1 its denominator
     strong = None
-    want_strong = not args.no_strong and not args.pmc_child and not args.force_slab and args.scaling == "weak" and N < 16384 and \
+    want_strong = not args.no_strong and not args.pmc_child and not args.force_slab and args.scaling == "weak" and N < args.strong_size and \
         ((rows and world > 1) or (single and not args.no_secondary))
     if want_strong:
         try:
-            strong = strong_block(ctx, 16384, 2, tile_w)
+            strong = strong_block(ctx, args.strong_size, 2, tile_w)
         except Exception as e:      # (collective: a failure here is every rank's)
             strong = {"error": repr(e)}
     if rank != 0:
@@ -966,7 +967,7 @@ def main():
         "kernels": head["kernels"],
         "cpu_baseline": cpu_obj,
         "equal_residual": equal,
-        "strong_16384_dam_break": strong,
+        "strong_%d_dam_break" % args.strong_size: strong,
         "secondary": secondary or None,
         "device": device,
     }

@@ -178,7 +178,7 @@ extern "C" void euler_destroy(euler_sim* S) {
                  S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->halo_buf, S->band_ranges, S->partial2, S->pair_buf, S->xrows, S->alpha_buf, S->rng_jump, S->chunk_flag, S->chunk_prev, S->chunk_part, S->tile_table, S->chunk_bits, S->chunk_list,
                  S->rowmajor_tmp};
   for (void* p : dev) if (p) (void)hipFree(p);
-  for (float* d : S->dye) if (d) (void)hipFree(d);
+  for (float* d : S->dye) if (d) (void)hipFree(d + wo);
   // band-skewed arrays: shifted to global element indexing as well (skew_off), behind EU_SKEW_SLACK elements of slack
   const size_t so = S->shifted ? S->skew_off : 0, sl = S->shifted ? (size_t)EU_SKEW_SLACK : 0;
   (void)so; (void)sl;
@@ -239,8 +239,8 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
       eu_set_error("euler_create: slab rank %d of %d for %d bands of 64 rows", cfg->slab_rank, cfg->slab_nranks, nbands);
       free(S); return EULER_EINVAL;
     }
-    if (cfg->rainbow || cfg->viscosity > 0.f || S->cfg.sweep_mode == EULER_SWEEP_SIMPLE) {
-      eu_set_error("euler_create: row slabs do not carry the dye, the diffusion extension or EULER_SWEEP_SIMPLE");
+    if (cfg->viscosity > 0.f || S->cfg.sweep_mode == EULER_SWEEP_SIMPLE) {
+      eu_set_error("euler_create: row slabs do not carry the diffusion extension or EULER_SWEEP_SIMPLE");
       free(S); return EULER_EINVAL;
     }
     S->band_lo = (int)((int64_t)nbands * cfg->slab_rank / cfg->slab_nranks);
@@ -284,7 +284,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   DALLOC(S->u, Cw); DALLOC(S->v, Cw); DALLOC(S->utmp, Cw); DALLOC(S->vtmp, Cw);
   DALLOC(S->solid, Cw); DALLOC(S->source, Cw); DALLOC(S->sink, Cw); DALLOC(S->count, Cw); DALLOC(S->prev_count, Cw);
   DALLOC(S->count32, Cw);
-  if (S->cfg.rainbow) for (float*& d : S->dye) DALLOC(d, C);
+  if (S->cfg.rainbow) for (float*& d : S->dye) DALLOC(d, Cw);      // (the window like every row-major field; the whole grid without slabs)
   // MAX_MARKER_COUNT = 4 X Y (main.c:92) is the GLOBAL cap; a slab holds the markers inside its rows: room for 6 per owned cell
   S->max_markers = 4 * C;
   if (S->slab_on) { const size_t cap = 6 * (size_t)(S->row_hi - S->row_lo) * S->X + 65536; if (cap < S->max_markers) S->max_markers = cap; }
@@ -363,6 +363,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   S->ticket_base = 0; S->epoch = 0;
   // every device allocation is in place: shift the base pointers to global indexing (euler_dev.h "Row slabs")
   for (float** f : {&S->u, &S->v, &S->utmp, &S->vtmp}) *f -= S->win_off;
+  for (float*& d : S->dye) if (d) d -= S->win_off;
   for (uint8_t** g : {&S->solid, &S->source, &S->sink, &S->count, &S->prev_count}) *g -= S->win_off;
   for (double** d : {&S->b, &S->p, &S->r, &S->z, &S->s, &S->s2, &S->q, &S->precon}) *d += EU_SKEW_SLACK - S->skew_off;
   S->cellmask += EU_SKEW_SLACK - S->skew_off;
@@ -437,7 +438,7 @@ static int upload_scenario(euler_sim* S, const uint8_t* solid, const uint8_t* so
   HIPCHK(hipMemcpyAsync(S->sink + wo, sink + wo, Cw, hipMemcpyHostToDevice, st));
   for (float* f : {S->u, S->v, S->utmp, S->vtmp}) HIPCHK(hipMemsetAsync(f + wo, 0, Cw * sizeof(float), st));
   for (double* d : {S->b, S->p, S->r, S->z, S->s, S->s2, S->q, S->precon}) HIPCHK(hipMemsetAsync(d + S->skew_off, 0, S->Sw * sizeof(double), st));
-  for (float* d : S->dye) if (d) HIPCHK(hipMemsetAsync(d, 0, C * sizeof(float), st));
+  for (float* d : S->dye) if (d) HIPCHK(hipMemsetAsync(d + wo, 0, Cw * sizeof(float), st));
   HIPCHK(hipMemsetAsync(S->count + wo, 0, Cw, st));
   HIPCHK(hipMemsetAsync(S->prev_count + wo, 0, Cw, st));
   HIPCHK(hipMemsetAsync(S->cellmask + S->skew_off, 0, S->Sw, st));
@@ -455,6 +456,7 @@ static int upload_scenario(euler_sim* S, const uint8_t* solid, const uint8_t* so
   if (rc) return rc;
   rc = eu_launch_colorize(S);   // main.c:270-273 (only with cfg.rainbow)
   if (rc) return rc;
+  if (S->slab_on && S->dye[0] && (rc = eu_slab_exchange_dye(S))) return rc;
   rc = eu_sync_marker_state(S);
   if (rc) return rc;
   memset(&S->stats, 0, sizeof(S->stats));
@@ -740,7 +742,7 @@ static int field_ptr(euler_sim* S, int f, void** p, size_t* bytes) {
     case EULER_F_CELLMASK: *p = S->cellmask; *bytes = C; break;
     case EULER_F_DYE_R: case EULER_F_DYE_G: case EULER_F_DYE_B: case EULER_F_DYE_RTMP: case EULER_F_DYE_GTMP: case EULER_F_DYE_BTMP:
       if (!S->dye[0]) { eu_set_error("field %d needs euler_config.rainbow", f); return EULER_ESTATE; }
-      *p = S->dye[f - EULER_F_DYE_R]; *bytes = C * 4; break;
+      *p = S->dye[f - EULER_F_DYE_R] + o; *bytes = C * 4; break;
     default: eu_set_error("unknown field %d", f); return EULER_EINVAL;
   }
   return EULER_OK;
@@ -913,6 +915,7 @@ extern "C" int euler_colorize(euler_sim* S) {
   if (!S->dye[0]) { eu_set_error("euler_colorize needs euler_config.rainbow"); return EULER_ESTATE; }
   int rc = eu_launch_colorize(S);
   if (rc) return rc;
+  if (S->slab_on && (rc = eu_slab_exchange_dye(S))) return rc;      // (collective on a row-slab handle: the neighbours' ghost rows follow)
   HIPCHK(hipStreamSynchronize(S->stream));
   return EULER_OK;
 }

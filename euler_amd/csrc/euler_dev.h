@@ -283,6 +283,7 @@ int  eu_slab_timestep(euler_sim* S, float frame_time_left);
 int  eu_slab_after_load(euler_sim* S);
 int  eu_slab_check_partition(euler_sim* S);   // collective: the ranks' band ranges tile the grid
 int  eu_slab_exchange_uv(euler_sim* S);     // ghost rows of u, v (euler_set_field on a slab handle)
+int  eu_slab_exchange_dye(euler_sim* S);    // ghost rows of g_r, g_g, g_b (--rainbow)
 int  eu_slab_render(euler_sim* S, int wx, int wy, char* out, int cap, int* len);   // snapshot.hip: euler_render on a row-slab handle (collective)
 int  eu_slab_after_restore(euler_sim* S);   // collective: the job-wide facts a scenario load sets up (source cells of all ranks)
 int  eu_slab_error_sync(euler_sim* S);      // collective: the ranks' sticky error words -> their maximum on every rank

@@ -17,10 +17,10 @@ __device__ __forceinline__ float hsv_basis(float t) {
 
 // colorize (main.c:187-201): fluid cells only; k_initial_color_period = 60 cells (main.c:83)
 __global__ __launch_bounds__(256) void k_colorize(float* r, float* g, float* b, const uint8_t* __restrict__ count,
-                                                  const uint8_t* __restrict__ source, int X, int Y) {
+                                                  const uint8_t* __restrict__ source, int X, int y0, int y1) {   // rows [y0, y1) of this rank
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= X || y >= Y) return;
+  const int y = y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= X || y >= y1) return;
   const size_t i = (size_t)y * X + x;
   if (!count[i]) return;
   float t = 0.f;
@@ -34,10 +34,10 @@ __global__ __launch_bounds__(256) void k_colorize(float* r, float* g, float* b, 
 // of its previously-fluid 3x3 neighbours, summed y-major then x.  In place is race-free (writes go to cells
 // without the prev-fluid property, reads to cells with it).
 __global__ __launch_bounds__(256) void k_extrapolate_dye(float* r, float* g, float* b, const uint8_t* __restrict__ prev,
-                                                         const uint8_t* __restrict__ cur, int X, int Y) {
+                                                         const uint8_t* __restrict__ cur, int X, int Y, int ry0, int ry1) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= X || y >= Y) return;
+  const int y = ry0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= X || y >= ry1) return;
   const size_t i = (size_t)y * X + x;
   if (prev[i] || !cur[i]) return;
   const int x0 = x > 0 ? x - 1 : 0, x1 = x + 1 < X ? x + 1 : X - 1;
@@ -54,9 +54,9 @@ __global__ __launch_bounds__(256) void k_extrapolate_dye(float* r, float* g, flo
 
 // the source colour (main.c:283,292-294): every source cell, every substep
 __global__ __launch_bounds__(256) void k_dye_sources(float* r, float* g, float* b, const uint8_t* __restrict__ source,
-                                                     size_t C, float t) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= C || !source[i]) return;
+                                                     size_t i0, size_t C, float t) {   // cells [i0, i0 + C): this rank's rows
+  const size_t i = i0 + (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= i0 + C || !source[i]) return;
   r[i] = hsv_basis(t + 2.f);
   g[i] = hsv_basis(t);
   b[i] = hsv_basis(t - 2.f);
@@ -66,11 +66,11 @@ __global__ __launch_bounds__(256) void k_dye_sources(float* r, float* g, float* 
 __global__ __launch_bounds__(256) void k_advect_dye(const float* __restrict__ r, const float* __restrict__ g,
                                                     const float* __restrict__ b, float* __restrict__ rout,
                                                     float* __restrict__ gout, float* __restrict__ bout,
-                                                    const float* __restrict__ u, const float* __restrict__ v, GridRef gr, float dt) {
-  const int X = gr.X, Y = gr.Y;
+                                                    const float* __restrict__ u, const float* __restrict__ v, GridRef gr, float dt, int y0, int y1) {
+  const int X = gr.X;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= X || y >= Y) return;
+  const int y = y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= X || y >= y1) return;
   const size_t i = (size_t)y * X + x;
   if (!gr.count[i]) return;                     // never fluid on the border ring (all sink): i - X, i - 1 exist
   const float dy = (v[i] + v[i - X]) / 2;
@@ -81,17 +81,17 @@ __global__ __launch_bounds__(256) void k_advect_dye(const float* __restrict__ r,
   bout[i] = eu_interp<0>(gr, b, px, py);
 }
 
-static inline dim3 cell_grid(const euler_sim* S) { return dim3((S->X + 63) / 64, (S->Y + 3) / 4); }
+static inline dim3 cell_grid(const euler_sim* S) { return dim3((S->X + 63) / 64, (S->row_hi - S->row_lo + 3) / 4); }   // this rank's rows (all of them without slabs)
 
 int eu_launch_colorize(euler_sim* S) {
   if (!S->dye[0]) return EULER_OK;
-  LAUNCH(S, KC_MISC, k_colorize, cell_grid(S), dim3(256), S->dye[0], S->dye[1], S->dye[2], S->count, S->source, S->X, S->Y);
+  LAUNCH(S, KC_MISC, k_colorize, cell_grid(S), dim3(256), S->dye[0], S->dye[1], S->dye[2], S->count, S->source, S->X, S->row_lo, S->row_hi);
   return EULER_OK;
 }
 
 int eu_launch_dye_extrapolate(euler_sim* S) {
   if (!S->dye[0]) return EULER_OK;
-  LAUNCH(S, KC_EXTRAPOLATE, k_extrapolate_dye, cell_grid(S), dim3(256), S->dye[0], S->dye[1], S->dye[2], S->prev_count, S->count, S->X, S->Y);
+  LAUNCH(S, KC_EXTRAPOLATE, k_extrapolate_dye, cell_grid(S), dim3(256), S->dye[0], S->dye[1], S->dye[2], S->prev_count, S->count, S->X, S->Y, S->row_lo, S->row_hi);
   return EULER_OK;
 }
 
@@ -99,7 +99,8 @@ int eu_launch_dye_sources(euler_sim* S) {
   if (!S->dye[0] || S->n_source_cells == 0) return EULER_OK;
   // k_source_color_period = 10 s (main.c:82); g_frame_count is a uint16_t (main.c:88) = frames completed so far
   const float t = 0.6f / 10.f * (uint16_t)S->stats.frames;
-  LAUNCH(S, KC_SOURCES, k_dye_sources, dim3(eu_blocks(S->C, 256)), dim3(256), S->dye[0], S->dye[1], S->dye[2], S->source, S->C, t);
+  const size_t i0 = (size_t)S->row_lo * S->X, n = (size_t)(S->row_hi - S->row_lo) * S->X;
+  LAUNCH(S, KC_SOURCES, k_dye_sources, dim3(eu_blocks(n, 256)), dim3(256), S->dye[0], S->dye[1], S->dye[2], S->source, i0, n, t);
   return EULER_OK;
 }
 
@@ -107,8 +108,9 @@ int eu_launch_dye_advect(euler_sim* S, float dt) {
   if (!S->dye[0]) return EULER_OK;
   GridRef g{S->X, S->Y, S->count, S->interp_lim[0], S->interp_lim[1], S->interp_lim[2], S->interp_lim[3]};
   LAUNCH(S, KC_ADVECT_VELOCITY, k_advect_dye, cell_grid(S), dim3(256), S->dye[0], S->dye[1], S->dye[2], S->dye[3], S->dye[4], S->dye[5],
-         S->u, S->v, g, dt);
-  // memcpy(g_r, g_rtmp, sizeof(g_r)) x3 (main.c:875,878,881): the WHOLE scratch array, stale non-fluid entries included
-  for (int k = 0; k < 3; ++k) HIPCHK(hipMemcpyAsync(S->dye[k], S->dye[3 + k], S->C * sizeof(float), hipMemcpyDeviceToDevice, S->stream));
+         S->u, S->v, g, dt, S->row_lo, S->row_hi);
+  // memcpy(g_r, g_rtmp, sizeof(g_r)) x3 (main.c:875,878,881): the WHOLE scratch array, stale non-fluid entries included (a row slab: its own rows)
+  const size_t o = (size_t)S->row_lo * S->X, n = (size_t)(S->row_hi - S->row_lo) * S->X;
+  for (int k = 0; k < 3; ++k) HIPCHK(hipMemcpyAsync(S->dye[k] + o, S->dye[3 + k] + o, n * sizeof(float), hipMemcpyDeviceToDevice, S->stream));
   return EULER_OK;
 }

@@ -205,6 +205,13 @@ static int exchange_counts(euler_sim* S) {
   const GhostField f[2] = {{S->count, 1, EU_GHOST_LO, EU_GHOST_HI}, {S->prev_count, 1, EU_GHOST_LO, EU_GHOST_HI}};
   return exchange_rows(S, f, 2);
 }
+// the dye (--rainbow): one ghost row of g_r, g_g, g_b either side (extrapolate(.., P) reads the 3x3, advect_p back-traces <= 0.75 cell)
+int eu_slab_exchange_dye(euler_sim* S) {
+  if (!S->dye[0]) return EULER_OK;
+  if (!S->has_comm) { eu_set_error("row-slab handle without a communicator"); return EULER_ESTATE; }
+  const GhostField f[3] = {{S->dye[0], 4, 1, 1}, {S->dye[1], 4, 1, 1}, {S->dye[2], 4, 1, 1}};
+  return exchange_rows(S, f, 3);
+}
 static int exchange_vtmp(euler_sim* S) {
   const GhostField f[1] = {{S->vtmp, 4, 1, 0}};
   return exchange_rows(S, f, 1);
@@ -580,11 +587,24 @@ int eu_slab_substep(euler_sim* S, float dt) {
   if ((rc = slab_advect_markers(S, dt))) return rc;
   const unsigned long long n_upper = S->n_markers_host + 2 * s->mig_cap;      // local markers after migration: an upper bound for the launches
   if ((rc = slab_refresh(S, n_upper < S->max_markers ? n_upper : S->max_markers))) return rc;
+  // --rainbow: extrapolate(g_r / g / b, P) sits between the refresh and the sources (main.c:859-864).  It reads the count grids' ghost
+  // rows of THIS refresh, so with the dye those travel first (and once more behind the sources, which add to the counts)
+  if (S->dye[0]) {
+    if ((rc = exchange_counts(S))) return rc;
+    if ((rc = eu_launch_dye_extrapolate(S))) return rc;
+  }
   if ((rc = slab_sources(S))) return rc;
+  if ((rc = eu_launch_dye_sources(S))) return rc;
   if ((rc = exchange_counts(S))) return rc;
+  if ((rc = eu_slab_exchange_dye(S))) return rc;
   // extrapolate, zero_bounds (main.c:865-868): u, v of the own rows; then their ghost rows
   if ((rc = eu_launch_extrapolate(S))) return rc;
   if ((rc = exchange_uv(S))) return rc;
+  // --rainbow: advect_p reads g_u, g_v before anything overwrites them (main.c:871-882); the copied-back rows' ghosts follow
+  if (S->dye[0]) {
+    if ((rc = eu_launch_dye_advect(S, dt))) return rc;
+    if ((rc = eu_slab_exchange_dye(S))) return rc;
+  }
   // advect_u / advect_v / body forces / zero_bounds (main.c:871-889) -> utmp, vtmp of the own rows
   if ((rc = eu_launch_advect_velocity(S, dt))) return rc;
   if ((rc = exchange_vtmp(S))) return rc;

@@ -61,7 +61,8 @@ extern "C" int euler_save_state(euler_sim* S, const char* path) {
   SnapHeader h;
   memset(&h, 0, sizeof h);
   memcpy(h.magic, "EULERSNP", 8);
-  h.version = slab ? 3 : (S->dye[0] ? 2 : 1); h.X = S->X; h.Y = S->Y; h.n_markers = st.n_markers; h.rng_state = st.rng_state;
+  h.version = slab ? 3 : (S->dye[0] ? 2 : 1); h.reserved = (slab && S->dye[0]) ? 1 : 0;      // (version 3 with the dye: reserved = 1)
+  h.X = S->X; h.Y = S->Y; h.n_markers = st.n_markers; h.rng_state = st.rng_state;
   h.source_exhausted = st.source_exhausted; h.frames = st.frames; h.total_substeps = st.total_substeps;
   h.total_pcg_iterations = st.total_pcg_iterations;
   uint64_t sum = snap_fnv(14695981039346656037ull, &h, sizeof h);
@@ -119,6 +120,7 @@ struct Part {
   std::vector<unsigned char> data;  // the whole file once loaded
   size_t body;                      // offset of the first field
   size_t cells() const { return (size_t)(row_hi - row_lo) * h.X; }
+  bool has_dye() const { return h.version == 2 || (h.version == 3 && h.reserved == 1); }
   const unsigned char* section(int k) const {      // 0..3 f32 fields, 4..8 u8 grids, 9 precon, 10..15 dye (v2), 16 markers, 17 keys
     const size_t C = cells();
     size_t off = body;
@@ -128,7 +130,7 @@ struct Part {
     off += 5 * C;
     if (k == 9) return data.data() + off;
     off += 8 * C;
-    if (h.version == 2) { if (k <= 15) return data.data() + off + (size_t)(k - 10) * 4 * C; off += 24 * C; }
+    if (has_dye()) { if (k <= 15) return data.data() + off + (size_t)(k - 10) * 4 * C; off += 24 * C; }
     if (k == 16) return data.data() + off;
     return data.data() + off + (size_t)n_loc * 8;
   }
@@ -157,7 +159,7 @@ int read_part(Part& p) {
     p.row_lo = sh.row_lo; p.row_hi = sh.row_hi; p.n_loc = sh.n_loc; p.keyed = true;
   }
   const size_t C = p.cells();
-  const size_t want = p.body + C * 29 + (p.h.version == 2 ? C * 24 : 0) + (size_t)p.n_loc * (p.keyed ? 12 : 8) + 8;
+  const size_t want = p.body + C * 29 + (p.has_dye() ? C * 24 : 0) + (size_t)p.n_loc * (p.keyed ? 12 : 8) + 8;
   uint64_t sum = 0, stored = 0;
   if ((size_t)n == want) { sum = snap_fnv(14695981039346656037ull, p.data.data(), want - 8); memcpy(&stored, p.data.data() + want - 8, 8); }
   if ((size_t)n != want || sum != stored) { eu_set_error("%s is truncated or corrupt (checksum)", p.file.c_str()); return EULER_EIO; }
@@ -207,7 +209,7 @@ extern "C" int euler_load_state(euler_sim* S, const char* path) {
   }
   if (use.empty()) { eu_set_error("%s holds no rows of this handle", path); return EULER_EINVAL; }
   const SnapHeader& h0 = use[0]->h;
-  const bool dye = h0.version == 2;
+  const bool dye = use[0]->has_dye();
   if (dye != (S->dye[0] != nullptr)) {
     eu_set_error("%s %s the dye fields but this handle was created %s euler_config.rainbow", path, dye ? "carries" : "lacks", S->dye[0] ? "with" : "without");
     return EULER_EINVAL;
@@ -247,10 +249,10 @@ extern "C" int euler_load_state(euler_sim* S, const char* path) {
   if (rc) return rc;
   if (!gather(9, 8, S->row_lo, S->row_hi)) return EULER_EINVAL;      // g_precon: the own rows, into the band-skewed array
   if ((rc = euler_set_field(S, EULER_F_PRECON, buf.data(), (size_t)(S->row_hi - S->row_lo) * X * 8))) return rc;
-  if (dye)
+  if (dye)      // the window's rows (ghost rows included), like u and v
     for (int k = 0; k < 6; ++k) {
-      if (!gather(10 + k, 4, 0, Y)) return EULER_EINVAL;
-      if ((rc = euler_set_field(S, SNAP_DYE[k], buf.data(), (size_t)Y * X * 4))) return rc;
+      if (!gather(10 + k, 4, need_lo, need_hi)) return EULER_EINVAL;
+      HIPCHK(hipMemcpy(S->dye[k] + (size_t)need_lo * X, buf.data(), (size_t)rows * X * 4, hipMemcpyHostToDevice));
     }
 
   // ---- markers: those inside the own rows, with their keys (a whole-grid handle: all of them, ordered by key)
@@ -317,32 +319,43 @@ int eu_slab_render(euler_sim* S, int wx, int wy, char* out, int cap, int* len) {
   int cutoff = Y - 1 - wy;
   if (cutoff < 1) cutoff = 1;
   const int vis_lo = cutoff, vis_hi = Y - 1 > cutoff ? Y - 1 : cutoff, vrows = vis_hi - vis_lo;
-  const size_t plane = (size_t)vrows * X;
+  const bool dye = S->dye[0] != nullptr;
+  // planes: solid, sink, count (bytes) and, with --rainbow, g_r, g_g, g_b (floats)
+  const int nplanes = dye ? 6 : 3;
+  const void* grids[6] = {S->solid, S->sink, S->count, S->dye[0], S->dye[1], S->dye[2]};
+  const size_t elem[6] = {1, 1, 1, 4, 4, 4};
+  size_t poff[7] = {0};
+  for (int k = 0; k < nplanes; ++k) poff[k + 1] = poff[k] + (size_t)vrows * X * elem[k];
   uint8_t* stage = nullptr;
-  HIPCHK(hipMalloc((void**)&stage, 3 * plane + 16));
-  const uint8_t* grids[3] = {S->solid, S->sink, S->count};
+  HIPCHK(hipMalloc((void**)&stage, poff[nplanes] + 16));
   std::vector<int64_t> off(R), cnt(R);
   int rc = EULER_OK;
-  for (int k = 0; k < 3 && !rc && vrows > 0; ++k) {
+  for (int k = 0; k < nplanes && !rc && vrows > 0; ++k) {
     for (int r = 0; r < R; ++r) {
       const int lo = 64 * S->part_lo[r], hi = 64 * S->part_hi[r] < Y ? 64 * S->part_hi[r] : Y;
       const int a = lo > vis_lo ? lo : vis_lo, b = hi < vis_hi ? hi : vis_hi;
-      off[r] = (int64_t)(k * plane) + (b > a ? (int64_t)(a - vis_lo) * X : 0);
-      cnt[r] = b > a ? (int64_t)(b - a) * X : 0;
+      off[r] = (int64_t)poff[k] + (b > a ? (int64_t)(a - vis_lo) * X * (int64_t)elem[k] : 0);
+      cnt[r] = b > a ? (int64_t)(b - a) * X * (int64_t)elem[k] : 0;
       if (r == S->cfg.slab_rank && b > a)
-        (void)hipMemcpyAsync(stage + off[r], grids[k] + (size_t)a * X, (size_t)cnt[r], hipMemcpyDeviceToDevice, S->stream);
+        (void)hipMemcpyAsync(stage + off[r], static_cast<const char*>(grids[k]) + (size_t)a * X * elem[k], (size_t)cnt[r], hipMemcpyDeviceToDevice, S->stream);
     }
     if (S->bulk.allgather(S->bulk.ctx, stage, off.data(), cnt.data()) != 0) { eu_set_error("communicator callback failed: render all-gather"); rc = EULER_ECOMM; }
   }
-  uint8_t* g = rc ? nullptr : (uint8_t*)calloc(3, S->C);      // (untouched pages of the full-size planes are never committed)
-  if (!rc && !g) rc = EULER_ENOMEM;
+  const size_t C = S->C;
+  uint8_t* g = rc ? nullptr : (uint8_t*)calloc(3, C);      // (untouched pages of the full-size planes are never committed)
+  float* col = (rc || !dye) ? nullptr : (float*)calloc(3 * C, sizeof(float));
+  if (!rc && (!g || (dye && !col))) rc = EULER_ENOMEM;
   if (!rc) {
-    for (int k = 0; k < 3 && plane; ++k)
-      if (hipMemcpyAsync(g + (size_t)k * S->C + (size_t)vis_lo * X, stage + k * plane, plane, hipMemcpyDeviceToHost, S->stream) != hipSuccess) rc = EULER_EHIP;
+    for (int k = 0; k < nplanes && vrows > 0; ++k) {
+      void* dst = k < 3 ? (void*)(g + (size_t)k * C + (size_t)vis_lo * X) : (void*)(col + (size_t)(k - 3) * C + (size_t)vis_lo * X);
+      if (hipMemcpyAsync(dst, stage + poff[k], poff[k + 1] - poff[k], hipMemcpyDeviceToHost, S->stream) != hipSuccess) rc = EULER_EHIP;
+    }
     if (hipStreamSynchronize(S->stream) != hipSuccess) rc = EULER_EHIP;
   }
-  if (!rc) rc = euler_render_grids(g, g + S->C, g + 2 * S->C, X, Y, wx, wy, out, cap, len);
+  if (!rc) rc = dye ? euler_render_grids_rgb(g, g + C, g + 2 * C, col, col + C, col + 2 * C, X, Y, wx, wy, out, cap, len)
+                    : euler_render_grids(g, g + C, g + 2 * C, X, Y, wx, wy, out, cap, len);
   free(g);
+  free(col);
   (void)hipFree(stage);
   return rc;
 }

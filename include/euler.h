@@ -227,7 +227,8 @@ int euler_get_stats(euler_sim* sim, euler_stats* out);
  * ROW SLABS (version 3): every rank of a job calls euler_save_state with the SAME path and writes its own part file
  * "<path>.<rank>of<nranks>": the 72-byte header above with version = 3, then i32 nranks, rank, band_lo, band_hi, row_lo, row_hi,
  * u64 n_local_markers; the arrays above restricted to the rank's OWN rows [row_lo, row_hi); f32[n_local][2] markers,
- * u32[n_local] their keys (positions in the reference's g_markers); FNV-1a-64.  Rank 0 also writes the manifest at <path>:
+ * u32[n_local] their keys (positions in the reference's g_markers); FNV-1a-64.  (Handles created with euler_config.rainbow: the
+ * header's reserved word is 1 and the six dye arrays follow precon, as in version 2.)  Rank 0 also writes the manifest at <path>:
  * char[8] "EULERMAN"; u32 3; i32 X, Y, nranks; nranks x {i32 band_lo, band_hi}.
  * euler_load_state is independent of how a state was written: a whole-grid handle or a slab of ANY partition loads from a single
  * file or from a manifest, taking its rows (ghost rows included) and the markers inside its rows from the parts that hold them.

@@ -42,7 +42,10 @@ def main():
         dist.init_process_group("gloo")
         torch.cuda.set_device(0)
     rank, world = dist.get_rank(), dist.get_world_size()
-    ref = load(ea.Simulation(X, Y, device=local, dot_mode=ea.DOT_TREE, precond=precond), workload)       # single GPU, the whole grid
+    rainbow = "rainbow" in sys.argv[6:]       # --rainbow: the dye fields on row slabs (ghost rows of g_r / g_g / g_b, coloured frames)
+    ref = ea.Simulation(X, Y, device=local, dot_mode=ea.DOT_TREE, precond=precond, rainbow=rainbow)       # single GPU, the whole grid
+    if not any(a.startswith("load=") for a in sys.argv[6:]):
+        load(ref, workload)
     slab = (rank, world)
     for a in sys.argv[6:]:
         if a.startswith("bands="):            # an explicit partition, "0-1,1-3,3-8": band ranges per rank (euler_config.slab_band_lo / hi)
@@ -53,7 +56,7 @@ def main():
     for a in sys.argv[6:]:
         if a.startswith("caps="):             # tiny exchange capacities (dt-chain candidates, deletions) to drive the overflow path
             os.environ["EULER_SLAB_CAPS"] = a[5:]
-    sim = ea.Simulation(X, Y, device=local, dot_mode=ea.DOT_TREE, precond=precond, slab=slab)   # one slab
+    sim = ea.Simulation(X, Y, device=local, dot_mode=ea.DOT_TREE, precond=precond, slab=slab, rainbow=rainbow)   # one slab
     comm = RcclComm(sim, SLAB_LOCAL) if rccl else TorchComm(sim, SLAB_LOCAL)
     out = {"world": world, "frames": []}
     if p2p:
@@ -162,6 +165,13 @@ def main():
         d["substeps"] = [sr.last_substeps, ss.last_substeps]
         d["rng"] = [int(sr.rng_state) == int(ss.rng_state), sr.source_exhausted == ss.source_exhausted]
         d["dt_events"] = [int(sr.marker_dt_events), int(ss.marker_dt_events)]
+        if rainbow:                            # the dye: bit-exact while u, v are (no reduction of its own), else within their tolerance
+            dd = 0.0
+            for fld in (ea.F_DYE_R, ea.F_DYE_G, ea.F_DYE_B):
+                a, b = sim.get(fld), ref.get(fld)[lo:hi]
+                fl = ref.get(ea.F_COUNT)[lo:hi] > 0
+                dd = max(dd, float(np.abs(a - b)[fl].max()) if fl.any() else 0.0)
+            d["ddye"] = dd
         if "render" in sys.argv[6:]:          # euler_render on a slab handle is collective and returns the single-GPU frame on every rank
             d["render_equal"] = bool(sim.draw(120, 50) == ref.draw(120, 50) and sim.draw(X, Y) == ref.draw(X, Y))
         # worst over the ranks
@@ -169,7 +179,7 @@ def main():
         dist.all_gather_object(agg, d)
         w = dict(agg[0])
         for o in agg[1:]:
-            for key in ("du", "dv", "dp", "count_differ", "prev_count_differ"):
+            for key in ("du", "dv", "dp", "count_differ", "prev_count_differ") + (("ddye",) if "ddye" in w else ()):
                 w[key] = max(w[key], o[key])
             for key in ("markers_at_keys", "markers_in_rows", "keys_are_a_permutation", "keys_cover_own_count") + (("render_equal",) if "render_equal" in w else ()):
                 w[key] = w[key] and o[key]

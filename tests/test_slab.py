@@ -165,7 +165,7 @@ def test_bench_multi_rank_contract(scaling):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", EULER_DIST_BACKEND="gloo", EULER_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "256",
-           "--comm", "torch", "--p2p", "--scaling", scaling, "--max-preroll", "60"]
+           "--comm", "torch", "--p2p", "--scaling", scaling, "--max-preroll", "60", "--strong-size", "512"]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -175,7 +175,12 @@ def test_bench_multi_rank_contract(scaling):
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == scaling and d["value"] > 0 and d["higher_is_better"] is True
-    assert d["cpu_baseline"] is None and d["vs_baseline"] is None          # the CPU leg runs at N = 1 only
+    assert d["vs_baseline"] is None
+    assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0          # rank 0 times the CPU path beside it at every N
+    if scaling == "weak":          # the default N > 1 run also measures the strong-scaling unit (BASELINE configs[3]'s scenario; here at 512^2)
+        st = d["strong_512_dam_break"]
+        assert st["scaling"] == "strong" and st["n_gpus"] == 2 and st["value"] > 0 and st["pcg_iterations"] > 0, st
+        assert st["balance"]["partition"].startswith("fluid-balanced") and len(st["balance"]["rows_per_rank"]) == 2, st["balance"]
     assert d["config"]["grid"] == ([256, 512] if scaling == "weak" else [256, 256])
     assert "peer-to-peer mailboxes" in d["config"]["parallelism"] and "2 row slabs" in d["config"]["parallelism"]
     assert "EVERY stage decomposed" in d["config"]["parallelism"]        # true row slabs are the N > 1 default

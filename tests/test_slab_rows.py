@@ -191,6 +191,34 @@ def test_snapshot_of_three_slabs_resumes_on_two_and_on_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nproc,X,Y,workload,frames", [(2, 256, 512, "dam_break", 30), (3, 200, 330, "waterfall", 25)])
+def test_rainbow_dye_on_row_slabs(nproc, X, Y, workload, frames, tmp_path):
+    """--rainbow on row slabs (SURVEY 8f-3 on the multi-GPU layout): colorize at load, extrapolate(g_r / g / b, P), the source colour, advect_p
+    and its whole-array copy over each rank's rows with one ghost row of the three channels either side.  The dye has no reduction of
+    its own: while u, v equal the single-GPU run's bit for bit (free fall, no solve yet) so does the dye; afterwards it follows their
+    tolerance.  The coloured frame (euler_render, collective) is the single-GPU frame byte for byte as long as the fields are; a
+    snapshot with the dye resumes on one GPU."""
+    snap = str(tmp_path / "dye.snap")
+    d = run(nproc, X, Y, workload, frames, ea.PRECOND_IC0_TILE, 29592, ("rainbow", "render", "save=" + snap))
+    exact = 0
+    for i, f in enumerate(d["frames"]):
+        assert f["markers_in_rows"] and f["keys_cover_own_count"], (i, f)
+        if f["du"] == 0.0 and f["dv"] == 0.0 and f["count_differ"] == 0:
+            assert f["ddye"] == 0.0 and f["render_equal"], (i, f)
+            exact += 1
+        else:
+            assert f["ddye"] < 1e-3, (i, f)
+    assert exact >= 5
+    import numpy as np
+    one = ea.Simulation(X, Y, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE, rainbow=True).load_state(snap)
+    ref = ea.Simulation(X, Y, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE, rainbow=True).load_state(snap + ".ref")
+    fl = ref.get(ea.F_COUNT) > 0
+    for fld in (ea.F_DYE_R, ea.F_DYE_G, ea.F_DYE_B):
+        assert np.abs(one.get(fld) - ref.get(fld))[fl].max() < 1e-3, fld
+    assert np.array_equal(one.get(ea.F_COUNT), ref.get(ea.F_COUNT))
+
+
+@pytest.mark.gpu
 def test_exchange_overflow_fails_on_every_rank():
     """the per-substep exchange buffers are bounded (they scale with X: k_slab.hip); when a substep deletes more markers
     than fit - here the capacity is shrunk to 64 by EULER_SLAB_CAPS and blocks of sink cells delete hundreds - every rank must
