@@ -45,17 +45,19 @@ ALGO_BYTES = {
     "backward_solve": 3 * W + 1,   # read q, precon; write z
     "apply_a": 2 * W + 1,          # read s; write A s (+ in-register dot partial)
     "dot": 2 * W + 1,              # read z, r
-    "update_pr": 6 * W + 1,        # read s, z, p, r; write p, r
+    "update_pr": 3 * W + 1,        # parity mode since round 3: read r, A s; write r (+ max |r|) - the first half of the tile pass; p rides in apply_a
     "update_search": 3 * W + 1,    # read z, s; write s
     "precond_tile": 4 * W + 1,     # tile-local mode: read r, A s; write r, z  (K2's r half, K3, K4 and dot in one pass; E^-1 of an interior
                                    # tile is the per-handle table, round 3 - boundary tiles still stream 8 B more)
 }
-APPLY_A_FUSED = {"ic0": 5 * W + 1,       # update_search fused in: read s, z; write s', A s'  (+ neighbours from cache)
+APPLY_A_FUSED = {"ic0": 5.5 * W + 1,     # update_search fused in: read s, z; write s', A s'; since round 3 also p += alpha s as below
+                 "jacobi": 5.5 * W + 1,
                  "ic0_tile": 5.5 * W + 1}  # ... and p += alpha s of two iterations on every second one: read s, z (+ s of two iterations ago
                                            # and p every second iteration); write s', A s' (+ p every second iteration): 4w + 1.5w
 # whole PCG iteration per cell (SURVEY 8d "Algorithmic bytes"): the reference's IC(0) as five kernels 18w+5; the tile-local
 # variant as the two passes it runs, 11w+2 - "the figure for that variant ... never the larger one"
-PCG_BYTES = {"ic0": 18 * W + 5, "ic0_tile": 9.5 * W + 2, "jacobi": 11 * W + 3}   # tile-local: 5.5w+1 + 4w+1 = 78 (round 2: 11w+2 = 90)
+PCG_BYTES = {"ic0": 17.5 * W + 5, "ic0_tile": 9.5 * W + 2, "jacobi": 10.5 * W + 3}   # tile-local: 5.5w+1 + 4w+1 = 78 (round 2: 11w+2 = 90); the reference's
+# structure 18w+5 = 149 minus the half p update saved since round 3 (p is read and written every second iteration): 145
 PCG_CLASSES = ["forward_solve", "backward_solve", "apply_a", "dot", "update_pr", "update_search", "precond_tile"]
 KERNEL_OF_CLASS = {"forward_solve": "k_sweep_skew<1", "backward_solve": "k_sweep_skew<2", "precon_factor": "k_sweep_skew<0",
                    "apply_a": "k_search_apply", "dot": "k_dot_partial", "update_pr": "k_update_pr", "precond_tile": "k_precond_tile"}
@@ -438,7 +440,9 @@ def kernel_rows(prof, precond, cells_fluid, traffic, fused_search):
                          + ": %d algorithmic B/cell" % b)
         if name == "update_pr" and precond == "ic0_tile":
             b = 3 * W + 1
-            e["note"] = "k_finish_p, once per solve: the last iteration's p += alpha s (read s, p; write p)"
+            e["note"] = "k_finish_p, once per solve: the last one or two p += alpha s (read s, p; write p)"
+        elif name == "update_pr":
+            e["note"] = "r -= alpha A s and max |r| (the first half of k_precond_tile) + k_finish_p once per solve"
         if name == "update_search" and fused_search:
             b = None
             e["note"] = "once per solve: s = z over the whole padded array (every other update_search rides in apply_a)"

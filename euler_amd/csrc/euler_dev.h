@@ -165,6 +165,7 @@ struct euler_sim {
   int fb_stride;          // words per band and lane
   int4* band_ranges;      // per band: active block ranges of the forward / backward sweeps (per solve)
   int tile_w;             // EULER_PRECOND_IC0_TILE: records per tile (include/euler.h precond_tile_records)
+  const double* tile_as_override;   // where A s sits for the r update of the non-tile modes (z behind the first apply_a of a solve, else q)
   double* partial2;       // second set of reduction partials (k_precond_tile reduces max |r| and dot(z,r) at once)
   struct RngJump* rng_jump;   // xorshift64* jump-ahead matrices (device)
   // Active chunks of a solve: a chunk = 16 consecutive records of a band = one tile of the tile-local preconditioner (W = 16) = one

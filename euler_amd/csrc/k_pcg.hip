@@ -1320,7 +1320,8 @@ __global__ __launch_bounds__(PT_THREADS) void k_precond_tile(TileArgs a) {
 #pragma unroll
       for (int P = 0; P < W / 2; ++P) {
         rr[P] = *reinterpret_cast<const sw_d2*>(a.r + base + P * 128);
-        if (FULL) pp[P] = s_tab[P < TABP ? P : 0][lane];
+        if (!a.sweeps) pp[P] = sw_d2{0.0, 0.0};      // (the r update alone - the parity mode's use of this kernel - needs no E^-1)
+        else if (FULL) pp[P] = s_tab[P < TABP ? P : 0][lane];
         else pp[P] = *reinterpret_cast<const sw_d2*>(a.pre + base + P * 128);
         if (a.rupd) qq[P] = *reinterpret_cast<const sw_d2*>(a.as + base + P * 128);
       }
@@ -1703,13 +1704,13 @@ __global__ void k_pair_fold(PcgScalars* sc, const double* __restrict__ pairs, in
 }
 static TileArgs make_tile_args(euler_sim* S, int force) {
   TileArgs a;
-  a.g = S->geom; a.mask = S->cellmask; a.pre = S->precon; a.r = S->r; a.as = S->q; a.z = S->z;
+  a.g = S->geom; a.mask = S->cellmask; a.pre = S->precon; a.r = S->r; a.as = S->tile_as_override ? S->tile_as_override : S->q; a.z = S->z;
   a.band_lo = S->band_lo; a.nb_local = S->band_hi - S->band_lo;
   a.rupd = 0; a.sweeps = 1; a.fin_dot = -1;
   a.via = S->has_comm ? (S->p2p_on ? (int)FIN_VIA_P2P : (int)FIN_TO_COMM) : 0;
   a.part_max = S->partial; a.part_dot = S->partial2; a.counter = S->red_counter; a.sc = S->sc; a.force = force; a.alpha_arg = 0.0;
   a.pair_slot = S->pair_buf + 2 * (S->has_comm ? S->comm.rank : 0);
-  a.list = (!force && S->tile_w == 16) ? S->chunk_list : nullptr;      // (forced single operations may run on masks no solve has listed)
+  a.list = !force ? S->chunk_list : nullptr;      // (tiles of 16 records only; forced single operations may run on masks no solve has listed)
   a.table = S->tile_table;
   a.zsend_lo = a.zsend_hi = nullptr; a.edge_lo = a.edge_hi = -1;
   // descending: k_search_apply walks the chunks upwards, so this pass starts on what the Infinity Cache still holds of it - and ends
@@ -1735,14 +1736,18 @@ static int launch_factor_tile(euler_sim* S, int force) {
   return EULER_OK;
 }
 // [r -= alpha A s, max |r|,] z = M^-1 r, dot(z, r) with its scalar epilogue fin_dot (FIN_SIGMA_INIT / FIN_BETA / FIN_STORE_ONLY)
-static int launch_precond_tile(euler_sim* S, int rupd, int sweeps, int fin_dot, int force, double alpha) {
+// r_only: the kernel's first half alone - r -= alpha A s and max |r| with its epilogue (`done`) - over 16-record chunks whatever the
+// handle's tile width: how EVERY non-tile configuration (the reference's IC(0), Jacobi) updates r since round 3 (p rides in k_search_apply)
+static int launch_precond_tile(euler_sim* S, int rupd, int sweeps, int fin_dot, int force, double alpha, bool r_only = false) {
   const bool seq = S->cfg.dot_mode == EULER_DOT_SEQUENTIAL && !S->has_comm;
   TileArgs a = make_tile_args(S, force);
   a.rupd = rupd; a.sweeps = sweeps; a.fin_dot = (seq || !sweeps) ? -1 : fin_dot; a.alpha_arg = alpha;
-  switch (S->tile_w) {
-    case 8: LAUNCH(S, KC_PRECOND_TILE, k_precond_tile<8>, dim3(tile_blocks(S)), dim3(PT_THREADS), a); break;
-    case 32: LAUNCH(S, KC_PRECOND_TILE, k_precond_tile<32>, dim3(tile_blocks(S)), dim3(PT_THREADS), a); break;
-    default: LAUNCH(S, KC_PRECOND_TILE, k_precond_tile<16>, dim3(tile_blocks(S)), dim3(PT_THREADS), a); break;
+  const int w = r_only ? 16 : S->tile_w, cls = r_only ? KC_UPDATE_PR : KC_PRECOND_TILE;
+  const unsigned nblk = eu_blocks((size_t)(S->band_hi - S->band_lo) * (S->geom.T / w), PT_THREADS / 64, 2048);
+  switch (w) {
+    case 8: LAUNCH(S, cls, k_precond_tile<8>, dim3(nblk), dim3(PT_THREADS), a); break;
+    case 32: LAUNCH(S, cls, k_precond_tile<32>, dim3(nblk), dim3(PT_THREADS), a); break;
+    default: LAUNCH(S, cls, k_precond_tile<16>, dim3(nblk), dim3(PT_THREADS), a); break;
   }
   if (seq && sweeps && fin_dot >= 0)   // the reference's row-major dot(z, r); a no-op once max |r| <= tol
     LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), S->z, S->r, S->cellmask, S->geom, S->sc, fin_dot, force);
@@ -1808,7 +1813,7 @@ static int launch_apply_a_and_alpha(euler_sim* S, int force) {
   gl.S = S->e_cnt;
   double* out = tile_fused(S) ? S->q : S->z;     // tile-local mode: A s always lands in q (k_precond_tile reads it there and writes z)
   LAUNCH(S, KC_APPLY_A, k_apply_a, dim3(loc_red_blocks(S)), dim3(RED_THREADS), LOC(S->s), LOC(out), LOC(S->cellmask), gl,
-         S->partial, S->sc, force, S->red_counter, seq ? -1 : fin_or_comm(S, FIN_ALPHA), tile_fused(S) ? S->s : (double*)nullptr);
+         S->partial, S->sc, force, S->red_counter, seq ? -1 : fin_or_comm(S, FIN_ALPHA), force ? (double*)nullptr : S->s);      // (s_last: whose p += alpha s is due)
   if (seq)
     LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), out, S->s, S->cellmask, S->geom, S->sc, (int)FIN_ALPHA, force);
   if (S->has_comm) return comm_finish(S, FIN_ALPHA, 0, force);
@@ -1848,11 +1853,12 @@ static int launch_search_apply_and_alpha(euler_sim* S, int it) {
   }
   SkewGeom gl = S->geom;
   gl.S = S->e_cnt;
-  // tile-local mode: p += alpha s rides along, two iterations' worth on every even iteration (k_search_apply PMODE)
-  const int pmode = tile_fused(S) ? ((it >= 2 && (it & 1) == 0) ? 2 : 1) : 0;
+  // p += alpha s rides along, two iterations' worth on every even iteration (k_search_apply PMODE) - in every configuration since
+  // round 3: the parity mode's k_update_pr read and wrote p on every iteration for nothing but this
+  const int pmode = (it >= 2 && (it & 1) == 0) ? 2 : 1;
   const int run = sa_run(S);
   const int fin = S->has_comm ? fin_or_comm(S, FIN_ALPHA) : (seq ? -1 : (int)FIN_ALPHA);
-  double* pp = pmode ? LOC(S->p) : (double*)nullptr;
+  double* pp = LOC(S->p);
 #define SA_LAUNCH(SLABF, PM, RUNV)                                                                                                      \
   LAUNCH(S, KC_APPLY_A, (k_search_apply<SLABF, PM, RUNV>), dim3(sa_blocks(S, RUNV)), dim3(SA_THREADS), LOC(S->s), LOC(S->z), LOC(S->s2), \
          LOC(S->q), LOC(S->cellmask), gl, S->partial, S->sc, 0, S->red_counter, fin, nbr, pp, S->s2, S->s, (RUNV) == 8 ? S->chunk_list : (const unsigned int*)nullptr)
@@ -1945,9 +1951,12 @@ int eu_launch_project(euler_sim* S, float dt) {
         if ((rc = launch_precond_tile(S, 1, it + 1 < max_it, FIN_BETA, 0, 0.0))) return rc;
         continue;
       }
-      LAUNCH(S, KC_UPDATE_PR, k_update_pr, dim3(loc_red_blocks(S)), dim3(RED_THREADS), LOC(S->p), LOC(S->r), LOC(S->s),
-             LOC(fused ? S->q : S->z), LOC(S->cellmask), S->e_cnt, S->partial, S->sc, 0, 0.0, S->red_counter, fin_or_comm(S, FIN_RNORM));
-      if (S->has_comm && (rc = comm_finish(S, FIN_RNORM, 1, 0))) return rc;
+      // r -= alpha A s, max |r| (sets `done`): the first half of the tile pass, over the solve's active chunks (A s sits in q, or in z
+      // behind the first apply_a); p += alpha s rides in k_search_apply / k_finish_p
+      S->tile_as_override = fused ? S->q : S->z;
+      rc = launch_precond_tile(S, 1, 0, -1, 0, 0.0, true);
+      S->tile_as_override = nullptr;
+      if (rc) return rc;
       if (it + 1 < max_it) {   // the tail of the last iteration (main.c:760-765) is never consumed
         // these belong to iteration `it` but only run if it did not converge: tag them it+1 so that
         // they count as active only when the device went on to iteration it+1
@@ -1973,8 +1982,8 @@ int eu_launch_project(euler_sim* S, float dt) {
     }
   }
   S->prof_iter = -2;
-  if (tile)   // the last iteration's p += alpha s (every other one rode along with the following apply_a pass)
-    LAUNCH(S, KC_UPDATE_PR, k_finish_p, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->p), LOC(S->cellmask), S->e_lo, S->e_cnt, S->sc);
+  // the last one or two p += alpha s (the others rode along with the apply_a passes)
+  LAUNCH(S, KC_UPDATE_PR, k_finish_p, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->p), LOC(S->cellmask), S->e_lo, S->e_cnt, S->sc);
   if (S->has_comm && S->slab_on) {
     // row slabs: the velocity update of the highest own row reads p one row up (main.c:800) - one ghost row from the rank above
     const int X = S->X, nbk = (X + 255) / 256;
