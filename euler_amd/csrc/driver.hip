@@ -139,6 +139,8 @@ extern "C" int euler_set_precond(euler_sim* S, int32_t precond, int32_t tile_rec
   HIPCHK(hipStreamSynchronize(S->stream));
   int rc = eu_set_tiles(S, tile_records);
   if (rc) return rc;
+  // (a row-slab handle runs whatever preconditioner it is given WITHOUT coupling between the slabs - eu_install_comm forced S->couple = 0 and
+  // refuses EULER_SLAB_EXACT for it - so EULER_PRECOND_IC0 here means slab-local IC(0): valid, and not the single-GPU iterates)
   S->cfg.precond = precond;
   S->lean_ok = 0;      // the next assembly writes the solver arrays whole (k_build_system)
   return EULER_OK;
