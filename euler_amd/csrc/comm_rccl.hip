@@ -81,6 +81,13 @@ struct RcclComm {
     ncclResult_t _r = (call);                                                                   \
     if (_r != ncclSuccess) { eu_set_error("RCCL: %s -> %s", #call, g_api.GetErrorString(_r)); return -1; } \
   } while (0)
+// inside ncclGroupStart ... ncclGroupEnd: remember the first failure and keep going, so that the group is always closed
+// (an open group would swallow every later call of this process)
+#define GCHK(call)                                                                              \
+  do {                                                                                          \
+    ncclResult_t _r = (call);                                                                   \
+    if (_r != ncclSuccess && !group_failed) { eu_set_error("RCCL: %s -> %s", #call, g_api.GetErrorString(_r)); group_failed = true; } \
+  } while (0)
 
 int op_allreduce(void* ctx, void* dev, int32_t count, int32_t is_max) {
   RcclComm* c = static_cast<RcclComm*>(ctx);
@@ -95,17 +102,18 @@ int op_halo(void* ctx, void* send_lo, void* send_hi, void* recv_lo, void* recv_h
   c->calls[1]++;
   if (c->n < 2) return 0;
   hipStream_t st = c->S->stream;
+  bool group_failed = false;
   NCHK(g_api.GroupStart());
   if (c->rank > 0) {
-    NCHK(g_api.Send(send_lo, (size_t)count, ncclDouble, c->rank - 1, c->comm, st));
-    NCHK(g_api.Recv(recv_lo, (size_t)count, ncclDouble, c->rank - 1, c->comm, st));
+    GCHK(g_api.Send(send_lo, (size_t)count, ncclDouble, c->rank - 1, c->comm, st));
+    GCHK(g_api.Recv(recv_lo, (size_t)count, ncclDouble, c->rank - 1, c->comm, st));
   }
   if (c->rank + 1 < c->n) {
-    NCHK(g_api.Send(send_hi, (size_t)count, ncclDouble, c->rank + 1, c->comm, st));
-    NCHK(g_api.Recv(recv_hi, (size_t)count, ncclDouble, c->rank + 1, c->comm, st));
+    GCHK(g_api.Send(send_hi, (size_t)count, ncclDouble, c->rank + 1, c->comm, st));
+    GCHK(g_api.Recv(recv_hi, (size_t)count, ncclDouble, c->rank + 1, c->comm, st));
   }
-  NCHK(g_api.GroupEnd());
-  return 0;
+  GCHK(g_api.GroupEnd());
+  return group_failed ? -1 : 0;
 }
 
 int op_chain(void* ctx, void* dev, int64_t nbytes, int32_t src, int32_t dst) {
@@ -128,10 +136,12 @@ int op_allgather(void* ctx, void* base, const int64_t* off, const int64_t* cnt) 
   if (even) {
     NCHK(g_api.AllGather(b + off[c->rank], b + off[0], (size_t)cnt[0], ncclUint8, c->comm, st));
   } else {
+    bool group_failed = false;
     NCHK(g_api.GroupStart());
     for (int r = 0; r < c->n; ++r)
-      if (cnt[r] > 0) NCHK(g_api.Broadcast(b + off[r], b + off[r], (size_t)cnt[r], ncclUint8, r, c->comm, st));      // (a rank may have nothing to contribute)
-    NCHK(g_api.GroupEnd());
+      if (cnt[r] > 0) GCHK(g_api.Broadcast(b + off[r], b + off[r], (size_t)cnt[r], ncclUint8, r, c->comm, st));      // (a rank may have nothing to contribute)
+    GCHK(g_api.GroupEnd());
+    if (group_failed) return -1;
   }
   return 0;
 }
@@ -146,30 +156,31 @@ int op_exchange(void* ctx, void* send_lo, void* send_hi, void* recv_lo, void* re
   if (c->n < 2) return 0;
   hipStream_t st = c->S->stream;
   double* sm = static_cast<double*>(small);
+  bool group_failed = false;
   NCHK(g_api.GroupStart());
   if (count > 0) {
     if (c->rank > 0) {
-      NCHK(g_api.Send(send_lo, (size_t)count, ncclDouble, c->rank - 1, c->comm, st));
-      NCHK(g_api.Recv(recv_lo, (size_t)count, ncclDouble, c->rank - 1, c->comm, st));
+      GCHK(g_api.Send(send_lo, (size_t)count, ncclDouble, c->rank - 1, c->comm, st));
+      GCHK(g_api.Recv(recv_lo, (size_t)count, ncclDouble, c->rank - 1, c->comm, st));
     }
     if (c->rank + 1 < c->n) {
-      NCHK(g_api.Send(send_hi, (size_t)count, ncclDouble, c->rank + 1, c->comm, st));
-      NCHK(g_api.Recv(recv_hi, (size_t)count, ncclDouble, c->rank + 1, c->comm, st));
+      GCHK(g_api.Send(send_hi, (size_t)count, ncclDouble, c->rank + 1, c->comm, st));
+      GCHK(g_api.Recv(recv_hi, (size_t)count, ncclDouble, c->rank + 1, c->comm, st));
     }
   }
   if (nsmall > 0) {
     if (c->small_by_allgather) {
-      NCHK(g_api.AllGather(sm + (size_t)c->rank * nsmall, sm, (size_t)nsmall, ncclDouble, c->comm, st));
+      GCHK(g_api.AllGather(sm + (size_t)c->rank * nsmall, sm, (size_t)nsmall, ncclDouble, c->comm, st));
     } else {
       for (int r = 0; r < c->n; ++r) {
         if (r == c->rank) continue;
-        NCHK(g_api.Send(sm + (size_t)c->rank * nsmall, (size_t)nsmall, ncclDouble, r, c->comm, st));
-        NCHK(g_api.Recv(sm + (size_t)r * nsmall, (size_t)nsmall, ncclDouble, r, c->comm, st));
+        GCHK(g_api.Send(sm + (size_t)c->rank * nsmall, (size_t)nsmall, ncclDouble, r, c->comm, st));
+        GCHK(g_api.Recv(sm + (size_t)r * nsmall, (size_t)nsmall, ncclDouble, r, c->comm, st));
       }
     }
   }
-  NCHK(g_api.GroupEnd());
-  return 0;
+  GCHK(g_api.GroupEnd());
+  return group_failed ? -1 : 0;
 }
 
 }  // namespace
