@@ -769,6 +769,13 @@ def main():
     cells = GX * GY
     job_rate = (cells * args.steps / t["elapsed"]) if sharded else whole_job_rate(float(cells), args.steps, t["elapsed"], grp)
     balance = rank_balance(ctx, sim, partition) if rows else None
+    comm_calls = None
+    if comm is not None:
+        try:      # how many operations of each kind the communicator carried so far (preroll + warm-up + timed frames): with the fused
+            # exchange a PCG iteration costs two `exchange` calls and nothing else
+            comm_calls = dict(comm.counts)
+        except Exception:
+            comm_calls = None
     head = copy_gbps = device = equal = None
     tile_w_run = tile_w
     if rank == 0:
@@ -968,6 +975,7 @@ def main():
         "roofline": head["roofline"],
         "pcg_iteration": head["pcg_iteration"],
         "balance": balance,
+        "comm_calls_rank0": comm_calls,
         "kernels": head["kernels"],
         "cpu_baseline": cpu_obj,
         "equal_residual": equal,
