@@ -52,18 +52,21 @@ ALGO_BYTES = {
 }
 APPLY_A_FUSED = {"ic0": 5.5 * W + 1,     # update_search fused in: read s, z; write s', A s'; since round 3 also p += alpha s as below
                  "jacobi": 5.5 * W + 1,
+                 "ic0_tile2": 5.5 * W + 1, # (two-level mode: + one 8-byte coarse value per 64-cell run - the table of <= 256 values sits in L2)
                  "ic0_tile": 5.5 * W + 1}  # ... and p += alpha s of two iterations on every second one: read s, z (+ s of two iterations ago
                                            # and p every second iteration); write s', A s' (+ p every second iteration): 4w + 1.5w
 # whole PCG iteration per cell (SURVEY 8d "Algorithmic bytes"): the reference's IC(0) as five kernels 18w+5; the tile-local
 # variant as the two passes it runs, 11w+2 - "the figure for that variant ... never the larger one"
-PCG_BYTES = {"ic0": 17.5 * W + 5, "ic0_tile": 9.5 * W + 2, "jacobi": 10.5 * W + 3}   # tile-local: 5.5w+1 + 4w+1 = 78 (round 2: 11w+2 = 90); the reference's
+PCG_BYTES = {"ic0": 17.5 * W + 5, "ic0_tile": 9.5 * W + 2, "ic0_tile2": 9.5 * W + 2, "jacobi": 10.5 * W + 3}   # tile-local: 5.5w+1 + 4w+1 = 78 (round 2: 11w+2 = 90); the reference's
 # structure 18w+5 = 149 minus the half p update saved since round 3 (p is read and written every second iteration): 145
 PCG_CLASSES = ["forward_solve", "backward_solve", "apply_a", "dot", "update_pr", "update_search", "precond_tile"]
 KERNEL_OF_CLASS = {"forward_solve": "k_sweep_skew<1", "backward_solve": "k_sweep_skew<2", "precon_factor": "k_sweep_skew<0",
                    "apply_a": "k_search_apply", "dot": "k_dot_partial", "update_pr": "k_update_pr", "precond_tile": "k_precond_tile"}
 MODE_NAME = {"ic0": "parity mode: the reference's IC(0), bit-identical iterates",
              "ic0_tile": "roofline mode: tile-local IC(0) (64x%d-cell blocks), NOT the reference's iterates (tolerance parity where PCG converges)",
+             "ic0_tile2": "two-level mode: tile-local IC(0) (64x%d-cell blocks) + a coarse correction (<= 256 aggregates, dense inverse), NOT the reference's iterates",
              "jacobi": "Jacobi stand-in, NOT the reference's iterates"}
+TILE_MODES = ("ic0_tile", "ic0_tile2")
 
 
 def parse_args():
@@ -74,8 +77,9 @@ def parse_args():
     ap.add_argument("--size", type=int, default=0, help="N of the NxN grid (default: configs[2] = 8192)")
     ap.add_argument("--workload", default="half_tank", choices=["dam_break", "half_tank", "waterfall"])
     ap.add_argument("--dot-mode", default="tree", choices=["tree", "sequential"])
-    ap.add_argument("--precond", default="ic0_tile", choices=["ic0", "jacobi", "ic0_tile"],
-                    help="ic0_tile = roofline mode (default), ic0 = parity mode (the reference's preconditioner)")
+    ap.add_argument("--precond", default="ic0_tile", choices=["ic0", "jacobi", "ic0_tile", "ic0_tile2"],
+                    help="ic0_tile = roofline mode (default), ic0 = parity mode (the reference's preconditioner), ic0_tile2 = roofline mode + coarse "
+                         "correction (one GPU; fewer iterations to a given residual, DESIGN.md 5c)")
     ap.add_argument("--tile-records", type=int, default=0)
     ap.add_argument("--tol", type=float, default=None, help="PCG tolerance (default: 0 for half_tank = the roofline run, else the reference's 1e-6)")
     ap.add_argument("--max-preroll", type=int, default=400)
@@ -436,9 +440,9 @@ def kernel_rows(prof, precond, cells_fluid, traffic, fused_search):
         b = ALGO_BYTES.get(name)
         if name == "apply_a" and fused_search:
             b = APPLY_A_FUSED.get(precond, b)
-            e["note"] = ("update_search fused in" + (" + the previous iteration's p += alpha s" if precond == "ic0_tile" else "")
+            e["note"] = ("update_search fused in" + (" + the previous iteration's p += alpha s" if precond in TILE_MODES else "")
                          + ": %d algorithmic B/cell" % b)
-        if name == "update_pr" and precond == "ic0_tile":
+        if name == "update_pr" and precond in TILE_MODES:
             b = 3 * W + 1
             e["note"] = "k_finish_p, once per solve: the last one or two p += alpha s (read s, p; write p)"
         elif name == "update_pr":
@@ -464,7 +468,7 @@ def time_frames(sim, ea, grp, args, precond, steps, warmup_done, warmup, big):
     the others in a second pass of the same length."""
     for _ in range(max(warmup - warmup_done, 0)):
         sim.step()
-    dominant = {"ic0": "backward_solve", "ic0_tile": "apply_a", "jacobi": "update_pr"}[precond]
+    dominant = {"ic0": "backward_solve", "ic0_tile": "apply_a", "ic0_tile2": "apply_a", "jacobi": "update_pr"}[precond]
     classes_all = ea.profile_class_names() if args.profile_all else PCG_CLASSES
     timed = [] if args.no_kernel_timing else (classes_all if big else [dominant])
     sim.profile_reset()
@@ -533,12 +537,12 @@ def summarize(t, size_x, size_y, precond, tile_w, traffic, traffic_note, steps, 
             parts = [rows[k].get("traffic_bytes_per_launch") for k in per_iter]
             tsum = sum(parts) if parts and all(parts) else None
         agg = {"us_per_iteration": round(1e3 * t["per_iter_ms"], 2), "bytes_per_cell_iteration": bpc,
-               "launches_per_iteration": len(per_iter),
+               "launches_per_iteration": len(per_iter) + (1 if precond == "ic0_tile2" else 0),      # + k_coarse_solve (timed in the precond_tile class)
                "GBps_active": round(bpc * fluid / sec / 1e9, 1), "frac_active": round(bpc * fluid / sec / 1e9 / HBM_PEAK_GBPS, 4),
                "GBps_traffic": round(tsum / sec / 1e9, 1) if tsum else None,
                "frac_traffic": round(tsum / sec / 1e9 / HBM_PEAK_GBPS, 4) if tsum else None,
                "frac_dense": round(bpc * cells / sec / 1e9 / HBM_PEAK_GBPS, 4)}
-    return {"mode": MODE_NAME[precond] % tile_w if precond == "ic0_tile" else MODE_NAME[precond],
+    return {"mode": MODE_NAME[precond] % tile_w if precond in TILE_MODES else MODE_NAME[precond],
             "value": cells_job * steps / t["elapsed"], "unit": "cells*steps/s", "ms_per_step": 1e3 * t["elapsed"] / steps,
             "substeps": int(t["substeps"]), "pcg_iterations": int(t["iters"]),
             "cells_substeps_per_s": cells_job * t["substeps"] / t["elapsed"],
@@ -546,7 +550,7 @@ def summarize(t, size_x, size_y, precond, tile_w, traffic, traffic_note, steps, 
             "roofline": roof, "pcg_iteration": agg, "kernels": rows}
 
 
-def equal_residual_scan(sim, ea, tile_records, limit=1200):
+def equal_residual_scan(sim, ea, tile_records, limit=1200, two_level=False):
     """ONE pressure system - the stages of a substep up to project(), main.c:855-889, run once; project() reads utmp / vtmp / the
     cell grid and can be repeated - solved with the reference's IC(0) and the reference's budget of 100 iterations (main.c:735):
     its residual is the bar.  Then the tile-local mode gets the smallest budget (steps of 4) whose residual on the SAME system is at
@@ -572,9 +576,24 @@ def equal_residual_scan(sim, ea, tile_records, limit=1200):
         budget = budget + 4 if budget < 160 else int(budget * 1.06) // 4 * 4 + 4      # (the inf-norm residual of CG is not monotone: a scan, not a bisection)
         tile = solve(ea.PRECOND_IC0_TILE, budget)
         scan.append([budget, tile["residual"]])
+    two = None
+    if two_level:      # the same bar for the two-level mode: budgets from 20 up in steps of 4 (it needs fewer than the reference's 100)
+        two = {"scan": []}
+        b2 = 16
+        while True:
+            b2 += 4 if b2 < 160 else 16
+            t2 = solve(ea.PRECOND_IC0_TILE2, b2)
+            two["scan"].append([b2, t2["residual"]])
+            if t2["residual"] <= exact["residual"] or b2 >= limit or exact["iterations"] < 100:
+                break
+        ok2 = t2["residual"] <= exact["residual"]
+        two.update({"budget_for_equal_residual": b2 if ok2 else None, "at_that_budget": t2, "at_100_iterations": solve(ea.PRECOND_IC0_TILE2, 100),
+                    "solve_speedup_at_equal_residual": round(exact["ms"] / t2["ms"], 2) if ok2 else None})
+        two["scan"] = two["scan"][::max(1, len(two["scan"]) // 16)] + two["scan"][-1:]
+        sim.set_precond(ea.PRECOND_IC0_TILE, tile_records)
     sim.set_solver(100)
     reached = tile["residual"] <= exact["residual"]
-    return {"dt": dt, "reference_ic0_100_iterations": exact, "tile_100_iterations": tile100,
+    return {"dt": dt, "reference_ic0_100_iterations": exact, "tile_100_iterations": tile100, "two_level": two,
             "tile_budget_for_equal_residual": budget if reached else None, "tile_at_that_budget": tile,
             "solve_speedup_at_equal_residual": round(exact["ms"] / tile["ms"], 2) if reached else None, "residual_scan": scan[::max(1, len(scan) // 16)] + scan[-1:]}
 
@@ -582,22 +601,29 @@ def equal_residual_scan(sim, ea, tile_records, limit=1200):
 def equal_residual(sim, ea, grp, args, GX, GY, tile_w):
     """Reference-quality throughput of the roofline mode on the headline workload: equal_residual_scan on the state the timed frames
     left (the saturated tank), then frames timed with the budget it found: cells*steps/s at equal residual."""
-    out = equal_residual_scan(sim, ea, args.tile_records)
+    out = equal_residual_scan(sim, ea, args.tile_records, two_level=True)
     out["system"] = "%dx%d %s, the state behind the timed frames, one substep's pressure system (dt %.3g)" % (GX, GY, args.workload, out.pop("dt"))
-    budget = out["tile_budget_for_equal_residual"]
-    if budget:
-        # frames with that budget in the roofline mode: the one number for "reference-quality throughput"
-        sim.set_precond(ea.PRECOND_IC0_TILE, args.tile_records)
+
+    def frames(precond, budget):
+        sim.set_precond(precond, args.tile_records)
         sim.set_solver(budget)
         sim.step()
         k = max(1, args.steps // 2)
         st0 = sim.stats()
         el = grp.timed(sim.step, k)
         st1 = sim.stats()
-        out["frames_at_that_budget"] = {"value": GX * GY * k / el, "unit": "cells*steps/s", "ms_per_step": 1e3 * el / k, "steps": k,
-                                        "substeps": int(st1.total_substeps - st0.total_substeps),
-                                        "pcg_iterations": int(st1.total_pcg_iterations - st0.total_pcg_iterations),
-                                        "cells_substeps_per_s": GX * GY * (st1.total_substeps - st0.total_substeps) / el}
+        return {"value": GX * GY * k / el, "unit": "cells*steps/s", "ms_per_step": 1e3 * el / k, "steps": k,
+                "substeps": int(st1.total_substeps - st0.total_substeps),
+                "pcg_iterations": int(st1.total_pcg_iterations - st0.total_pcg_iterations),
+                "cells_substeps_per_s": GX * GY * (st1.total_substeps - st0.total_substeps) / el}
+
+    # frames with that budget: the one number for "reference-quality throughput", per mode
+    if out["tile_budget_for_equal_residual"]:
+        out["frames_at_that_budget"] = frames(ea.PRECOND_IC0_TILE, out["tile_budget_for_equal_residual"])
+    two = out.get("two_level")
+    if two and two.get("budget_for_equal_residual"):
+        two["frames_at_that_budget"] = frames(ea.PRECOND_IC0_TILE2, two["budget_for_equal_residual"])
+        sim.set_precond(ea.PRECOND_IC0_TILE, args.tile_records)
     sim.set_solver(100)
     return out
 
@@ -734,7 +760,7 @@ def main():
     from euler_amd import scenarios
 
     dot_mode = ea.DOT_TREE if args.dot_mode == "tree" else ea.DOT_SEQUENTIAL
-    PC = {"ic0": ea.PRECOND_IC0, "jacobi": ea.PRECOND_JACOBI, "ic0_tile": ea.PRECOND_IC0_TILE}
+    PC = {"ic0": ea.PRECOND_IC0, "jacobi": ea.PRECOND_JACOBI, "ic0_tile": ea.PRECOND_IC0_TILE, "ic0_tile2": ea.PRECOND_IC0_TILE2}
     tile_w = args.tile_records or 16
     # N > 1 (weak scaling): the grid grows to N x (N * gpus) rows; the pressure solve is split into one
     # slab of N rows per GPU, the cheap stages run replicated (DESIGN.md "Multi-GPU")
@@ -835,7 +861,7 @@ def main():
         # (2) time to SOLVE one system to the reference's tolerance, both modes (2048^2 half tank, first projection)
         try:
             tts = {}
-            for pc in ("ic0", "ic0_tile"):
+            for pc in ("ic0", "ic0_tile", "ic0_tile2"):
                 s3 = ea.Simulation(2048, 2048, device=local_rank, dot_mode=dot_mode, precond=PC[pc], tile_records=args.tile_records,
                                    max_iterations=20000, pcg_poll_interval=32).load_half_tank()
                 s3.step()                      # untimed: allocations, first launches
@@ -851,6 +877,7 @@ def main():
                 del s3
             tts["workload"] = "2048x2048 half tank from rest, one frame, tol 1e-6 (the reference's), iteration cap lifted to 20000"
             tts["speedup_tile_over_exact"] = round(tts["ic0"]["ms"] / tts["ic0_tile"]["ms"], 2)
+            tts["speedup_two_level_over_exact"] = round(tts["ic0"]["ms"] / tts["ic0_tile2"]["ms"], 2)
             secondary["time_to_solution"] = tts
         except Exception as e:
             secondary["time_to_solution"] = {"error": repr(e)}
@@ -944,7 +971,7 @@ def main():
 
     transports = (("peer-to-peer mailboxes (PCG scalars, ghost rows of s) + " if p2p_on else "")
                   + ("RCCL over xGMI, called from the C library on the kernels' stream" if args.comm == "rccl" else "torch.distributed callbacks"))
-    pc_name = "tile-local IC(0): no coupling between slabs" if args.precond == "ic0_tile" else ("slab-local" if rows else args.slab) + " IC(0) coupling"
+    pc_name = "tile-local IC(0): no coupling between slabs" if args.precond in TILE_MODES else ("slab-local" if rows else args.slab) + " IC(0) coupling"
     parallelism = "1 GPU" if args.gpus == 1 and not sharded else (
         "%d independent replicas" % args.gpus if not sharded else
         ("%d row slabs of %s rows, EVERY stage decomposed (each rank holds its rows + ghost rows and the markers inside them: %.2f GB of HBM "
@@ -967,7 +994,7 @@ def main():
                                                    " (BASELINE configs[2], pressure-solve roofline run: tol 0, exactly 100 PCG iterations per substep%s)"
                                                    % ("; timed in the saturated phase: 8 CFL substeps per frame" if saturate else "")
                                                    if args.workload == "half_tank" and tol == 0.0 else "", head["mode"]),
-                   "grid": [GX, GY], "preroll_frames": preroll, "precond": args.precond, "tile_records": tile_w if args.precond == "ic0_tile" else None,
+                   "grid": [GX, GY], "preroll_frames": preroll, "precond": args.precond, "tile_records": tile_w if args.precond in TILE_MODES else None,
                    "dot_mode": args.dot_mode, "max_iterations": 100, "tol": tol if tol is not None else 1e-6, "parallelism": parallelism},
         "mode": head["mode"],
         "substeps": head["substeps"], "pcg_iterations": head["pcg_iterations"], "cells_substeps_per_s": head["cells_substeps_per_s"],

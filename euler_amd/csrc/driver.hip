@@ -135,10 +135,17 @@ static int eu_set_tiles(euler_sim* S, int w) {
 }
 
 extern "C" int euler_set_precond(euler_sim* S, int32_t precond, int32_t tile_records) {
-  if (!S || precond < EULER_PRECOND_IC0 || precond > EULER_PRECOND_IC0_TILE) { eu_set_error("euler_set_precond: bad argument"); return EULER_EINVAL; }
+  if (!S || precond < EULER_PRECOND_IC0 || precond > EULER_PRECOND_IC0_TILE2) { eu_set_error("euler_set_precond: bad argument"); return EULER_EINVAL; }
   HIPCHK(hipStreamSynchronize(S->stream));
   int rc = eu_set_tiles(S, tile_records);
   if (rc) return rc;
+  if (precond == EULER_PRECOND_IC0_TILE2) {      // the two-level mode: tiles of 16 records, one GPU, tree dots; its arrays come with the first use
+    if (S->has_comm || S->slab_on || S->tile_w != 16 || S->cfg.sweep_mode == EULER_SWEEP_SIMPLE) {
+      eu_set_error("EULER_PRECOND_IC0_TILE2: one GPU, tiles of 16 records, the band schedule"); return EULER_EINVAL;
+    }
+    S->cfg.dot_mode = EULER_DOT_TREE;
+    if ((rc = eu_coarse_alloc(S))) return rc;
+  }
   // (a row-slab handle runs whatever preconditioner it is given WITHOUT coupling between the slabs - eu_install_comm forced S->couple = 0 and
   // refuses EULER_SLAB_EXACT for it - so EULER_PRECOND_IC0 here means slab-local IC(0): valid, and not the single-GPU iterates)
   S->cfg.precond = precond;
@@ -170,6 +177,7 @@ extern "C" void euler_destroy(euler_sim* S) {
   eu_p2p_release(S);
   eu_rccl_release(S);
   eu_slab_release(S);
+  eu_coarse_release(S);
   // row-major arrays are held by base pointers shifted to global (x, y) indexing: allocation = pointer + win_off
   // (a handle that failed half-way through euler_create still holds the raw allocations: S->shifted)
   const size_t wo = S->shifted ? S->win_off : 0;
@@ -392,6 +400,14 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   if (!S->ev_pool || !S->ev_cls || !S->ev_solve || !S->ev_iter) { euler_destroy(S); return EULER_ENOMEM; }
   for (int k = 0; k < S->ev_cap; ++k) CREATECHK(hipEventCreate(&S->ev_pool[k]));
   if (S->slab_on) { int rc = eu_slab_alloc(S); if (rc) { euler_destroy(S); return rc; } }
+  if (S->cfg.precond == EULER_PRECOND_IC0_TILE2) {
+    if (S->slab_on || S->tile_w != 16 || S->cfg.sweep_mode == EULER_SWEEP_SIMPLE) {
+      eu_set_error("EULER_PRECOND_IC0_TILE2: one GPU, tiles of 16 records, the band schedule"); euler_destroy(S); return EULER_EINVAL;
+    }
+    S->cfg.dot_mode = EULER_DOT_TREE;
+    int rc = eu_coarse_alloc(S);
+    if (rc) { euler_destroy(S); return rc; }
+  }
   S->hbm_bytes = g_alloc_bytes + (S->slab_on ? eu_slab_bytes(S) : 0);
   eu_launch_tile_table(S);      // E^-1 of an interior tile (k_pcg.hip), once per handle
   CREATECHK(hipStreamSynchronize(S->stream));

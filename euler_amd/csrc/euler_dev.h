@@ -164,6 +164,13 @@ struct euler_sim {
   unsigned int* fbits_fwd; unsigned int* fbits_bwd;   // fluid flags of the sweeps, 8 steps to a dword (k_pack_fbits)
   int fb_stride;          // words per band and lane
   int4* band_ranges;      // per band: active block ranges of the forward / backward sweeps (per solve)
+  // EULER_PRECOND_IC0_TILE2 (two-level; k_coarse.hip): coarse cells of g x g grid cells, g = 64 m = 1 << coarse_shift, nx x ny of them (<= 256)
+  int coarse_m, coarse_shift, coarse_nx, coarse_ny, coarse_n;
+  int *cc_diag, *cc_right, *cc_up;   // P^T A P as a 5-point stencil over the coarse grid: integer sums of A's entries (exact, order-free)
+  double* cc_fac;                    // [n][n]: the dense (banded) Cholesky factor of P^T A P, per solve
+  double* cc_inv;                    // [n][n]: its inverse, per solve
+  double* cc_part;                   // [chunks][3]: per tile, the sums of r over its fluid cells by coarse column (k_precond_tile)
+  double* cc_y;                      // [n]: the coarse correction of the iteration (k_coarse_solve)
   int tile_w;             // EULER_PRECOND_IC0_TILE: records per tile (include/euler.h precond_tile_records)
   const double* tile_as_override;   // where A s sits for the r update of the non-tile modes (z behind the first apply_a of a solve, else q)
   double* partial2;       // second set of reduction partials (k_precond_tile reduces max |r| and dot(z,r) at once)
@@ -313,6 +320,14 @@ void eu_p2p_xgran(euler_sim* S, int backward, const unsigned long long** in, uns
 int  eu_p2p_has_neighbour_arrays(const euler_sim* S);
 void eu_p2p_neighbour_arrays(euler_sim* S, const double** z_dn, const double** s_dn, const double** z_up, const double** s_up);
 int eu_install_comm(euler_sim* S, const euler_comm_ops* ops, int32_t coupling, int allow_single);
+static inline bool eu_is_tile(const euler_sim* S) { return S->cfg.precond == EULER_PRECOND_IC0_TILE || S->cfg.precond == EULER_PRECOND_IC0_TILE2; }
+static inline bool eu_is_two_level(const euler_sim* S) { return S->cfg.precond == EULER_PRECOND_IC0_TILE2; }
+// two-level preconditioner (k_coarse.hip)
+int  eu_coarse_alloc(euler_sim* S);           // lazily, when the mode is first selected
+void eu_coarse_release(euler_sim* S);
+int  eu_launch_coarse_setup(euler_sim* S);    // per solve: P^T A P, its factor and inverse
+int  eu_launch_coarse_solve(euler_sim* S, int fin_op, int force);   // per iteration: y = (P^T A P)^-1 P^T r, dot(z,r) += y . r_c, the scalar epilogue
+int  eu_launch_coarse_search_init(euler_sim* S);   // s = z + P y (the first search direction of a solve)
 
 // ------------------------------------------------------------------------------------------
 // device helpers

@@ -1,0 +1,328 @@
+// k_coarse.hip — the coarse level of the TWO-LEVEL preconditioner (EULER_PRECOND_IC0_TILE2, include/euler.h; round 3):
+//
+//     z = M_tile^-1 r + P (P^T A P)^-1 P^T r
+//
+// M_tile = the tile-local IC(0) of k_pcg.hip (64-row x 16-record blocks, one pass over memory); P = piecewise constants over coarse
+// cells of g x g grid cells (g = 64 m, a power of two; at most 256 coarse cells, 16 x 16 on a square grid) restricted to the fluid.
+// No reference counterpart (the reference has ONE preconditioner, main.c:580-627): this is an extension of the roofline mode, restated
+// in the oracle (eo_sim.coarse_m, coarse_correction) and compared with it to rounding.  Why: a block-local factor has no coupling
+// beyond its block, and the first hundred iterations of a large solve - all the reference's cap ever allows, main.c:735 - live on the
+// long-range part of A^-1 (the hydrostatic mode of a tank).  The coarse space has that part: DESIGN.md 5c.
+//
+// What runs where:
+//   per solve      k_coarse_assemble  P^T A P as integer sums of A's entries per pair of coarse cells (a 5-point stencil over the coarse
+//                                     grid; integers: exact whatever the order of the atomics), walked tile by tile like k_factor_tile
+//                  k_coarse_factor    its dense Cholesky factor, banded (half-bandwidth nx), one workgroup
+//                  k_coarse_inverse   the explicit inverse, one thread per column, columns in LDS (n <= 256: 0.5 MB) - applying the
+//                                     preconditioner is then a 256 x 256 matrix-vector product instead of two triangular solves on the critical path
+//   per iteration  k_precond_tile     (k_pcg.hip) leaves, per tile, the sums of the new r over its fluid cells by coarse column: 3 doubles
+//                  k_coarse_solve     a workgroup per coarse cell: r_c = sums of those partials in a fixed order; the last one to finish:
+//                                     y = (P^T A P)^-1 r_c, dot(z, r) += y . r_c, and the scalar epilogue (sigma / beta) k_precond_tile leaves to it
+//                  k_search_apply     (k_pcg.hip, COARSE) adds y of a cell's coarse cell to z wherever it forms s' = z + beta s
+#include "euler_dev.h"
+
+#include <stdlib.h>
+
+#define CC_MAX 256          // coarse cells
+#define CC_THREADS 1024
+
+// the scalar epilogues of k_pcg.hip (same codes)
+enum { CFIN_SIGMA_INIT = 0, CFIN_BETA = 3 };
+
+int eu_coarse_alloc(euler_sim* S) {
+  if (S->cc_inv) return EULER_OK;
+  int m = 1, shift = 6;
+  while (((S->X + 64 * m - 1) / (64 * m)) * ((S->geom.nbands + m - 1) / m) > CC_MAX) { m *= 2; shift += 1; }
+  S->coarse_m = m; S->coarse_shift = shift;
+  S->coarse_nx = (S->X + 64 * m - 1) / (64 * m);
+  S->coarse_ny = (S->geom.nbands + m - 1) / m;
+  S->coarse_n = S->coarse_nx * S->coarse_ny;
+  const size_t n = (size_t)S->coarse_n;
+  HIPCHK(hipMalloc((void**)&S->cc_diag, 3 * n * sizeof(int)));
+  S->cc_right = S->cc_diag + n; S->cc_up = S->cc_diag + 2 * n;
+  HIPCHK(hipMalloc((void**)&S->cc_fac, n * n * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&S->cc_inv, n * n * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&S->cc_part, (S->chunk_cap + 64) * 3 * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&S->cc_y, (2 * CC_MAX + 1) * sizeof(double)));      // y [CC_MAX], r_c [CC_MAX], the ticket counter of k_coarse_solve
+  HIPCHK(hipMemset(S->cc_part, 0, (S->chunk_cap + 64) * 3 * sizeof(double)));
+  HIPCHK(hipMemset(S->cc_y, 0, (2 * CC_MAX + 1) * sizeof(double)));
+  return EULER_OK;
+}
+
+void eu_coarse_release(euler_sim* S) {
+  if (S->cc_diag) (void)hipFree(S->cc_diag);
+  for (double* d : {S->cc_fac, S->cc_inv, S->cc_part, S->cc_y}) if (d) (void)hipFree(d);
+  S->cc_diag = S->cc_right = S->cc_up = nullptr;
+  S->cc_fac = S->cc_inv = S->cc_part = S->cc_y = nullptr;
+}
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// ---- P^T A P.  A tile = 16 records x 64 lanes of one band: cell (lane l, record t) sits in column x = t - l, row 64 band + l.  Its
+// columns span at most three coarse columns (79 columns, g >= 64), counted from J0 = the coarse column of the tile's leftmost column.
+// Per coarse cell c:  diag += a_diag of every fluid cell, - 2 per fluid-fluid edge inside c;  right[c] -= 1 per edge to coarse cell c + 1;
+// up[c] -= 1 per edge to c + nx.  Every edge is visited once, from its left / lower cell (CM_RIGHT, CM_UP of the mask byte).
+__global__ __launch_bounds__(256) void k_coarse_assemble(const uint8_t* __restrict__ mask, SkewGeom g, const unsigned int* __restrict__ list,
+                                                         const PcgScalars* sc, int band_lo, int shift, int m, int nx, int* cd, int* cr, int* cu) {
+  const int lane = threadIdx.x & 63;
+  const int ntb = g.T / 16, todo = (int)sc->n_chunks;
+  const int n_waves = gridDim.x * 4;
+  for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < todo; i += n_waves) {
+    const int tile = (int)(list[i] & ~EU_CHUNK_INTERIOR);
+    const int band = band_lo + tile / ntb, k = tile % ntb;
+    const size_t base = ((size_t)band * g.TS + (size_t)k * 16) * 64 + 2 * lane;
+    const int xl = k * 16 - 63;
+    const int J0 = (xl > 0 ? xl : 0) >> shift;
+    const int I = band / m;
+    const bool top_of_coarse_row = lane == 63 && (band + 1) % m == 0;      // the cell above lies in the next coarse row
+    int d[3] = {0, 0, 0}, r[3] = {0, 0, 0}, u[3] = {0, 0, 0};
+#pragma unroll
+    for (int P = 0; P < 8; ++P) {
+      const unsigned int mm = *reinterpret_cast<const unsigned short*>(mask + base + P * 128);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const unsigned int cm = (mm >> (8 * h)) & 0xff;
+        if (!(cm & CM_FLUID)) continue;
+        const int x = k * 16 + 2 * P + h - lane;      // >= 1 for a fluid cell
+        const int b = (x >> shift) - J0;
+        int dd = (int)(cm >> CM_DIAG_SHIFT), rr = 0, uu = 0;
+        if (cm & CM_RIGHT) { if (((x + 1) >> shift) - J0 == b) dd -= 2; else rr -= 1; }
+        if (cm & CM_UP) { if (!top_of_coarse_row) dd -= 2; else uu -= 1; }
+        if (b == 0) { d[0] += dd; r[0] += rr; u[0] += uu; }
+        else if (b == 1) { d[1] += dd; r[1] += rr; u[1] += uu; }
+        else { d[2] += dd; r[2] += rr; u[2] += uu; }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const int sd = wave_sum_i(d[b]), sr = wave_sum_i(r[b]), su = wave_sum_i(u[b]);
+      if (lane == 0 && J0 + b < nx) {
+        const int c = I * nx + J0 + b;
+        if (sd) atomicAdd(&cd[c], sd);
+        if (sr) atomicAdd(&cr[c], sr);
+        if (su) atomicAdd(&cu[c], su);
+      }
+    }
+  }
+}
+
+// ---- the dense matrix from the stencil and its banded Cholesky factor (lower triangle), one workgroup.
+// Column k: d = sqrt(a_kk); the bw entries below it are divided by d; the bw x bw window behind it takes the rank-1 update -
+// an element per thread and pass (bw = nx = 16 on a square grid: one pass of 1024 threads).  An empty coarse cell gets a unit diagonal
+// (its right-hand side is 0).  The band is worked on in LDS when it fits (element (i, j) at i * bw + j + bw: n (bw + 1) doubles, 34 KB for
+// 16 x 16) and copied out to the dense array the inverse reads; a wide band (a flat grid with few coarse rows) is factored in place in
+// global memory instead - same arithmetic, same order.
+#define CC_LDS_BAND 8192      // doubles
+__global__ __launch_bounds__(CC_THREADS) void k_coarse_factor(const int* __restrict__ cd, const int* __restrict__ cr, const int* __restrict__ cu,
+                                                              int n, int nx, int bw, double* __restrict__ A, const PcgScalars* sc) {
+  if (!sc->nonzero) return;
+  __shared__ double s_band[CC_LDS_BAND];
+  __shared__ double s_d;
+  const int tid = threadIdx.x;
+  const bool in_lds = n * (bw + 1) + bw <= CC_LDS_BAND;
+  double* M = in_lds ? s_band : A;
+  const int rs = in_lds ? bw : n, off = in_lds ? bw : 0;      // element (i, j), i - bw <= j <= i, at M[i * rs + j + off]
+  for (int e = tid; e < n * n; e += CC_THREADS) A[e] = 0.0;
+  if (in_lds) for (int e = tid; e < CC_LDS_BAND; e += CC_THREADS) s_band[e] = 0.0;
+  __syncthreads();
+  for (int c = tid; c < n; c += CC_THREADS) {
+    M[c * rs + c + off] = cd[c] != 0 ? (double)cd[c] : 1.0;
+    if ((c + 1) % nx != 0 && c + 1 < n) M[(c + 1) * rs + c + off] = (double)cr[c];
+    if (c + nx < n) M[(c + nx) * rs + c + off] = (double)cu[c];
+  }
+  __syncthreads();
+  for (int k = 0; k < n; ++k) {
+    const int w = k + bw < n - 1 ? bw : n - 1 - k;      // rows below the diagonal inside the band
+    if (tid == 0) { const double d = sqrt(M[k * rs + k + off]); M[k * rs + k + off] = d; s_d = d; }
+    __syncthreads();
+    if (tid < w) M[(k + 1 + tid) * rs + k + off] /= s_d;
+    __syncthreads();
+    for (int idx = tid; idx < w * w; idx += CC_THREADS) {
+      const int ti = idx / w, tj = idx % w;
+      if (tj <= ti) M[(k + 1 + ti) * rs + (k + 1 + tj) + off] -= M[(k + 1 + ti) * rs + k + off] * M[(k + 1 + tj) * rs + k + off];
+    }
+    __syncthreads();
+  }
+  if (in_lds)
+    for (int e = tid; e < n * (bw + 1); e += CC_THREADS) {
+      const int i = e / (bw + 1), j = i - bw + e % (bw + 1);
+      if (j >= 0) A[(size_t)i * n + j] = s_band[i * rs + j + off];
+    }
+}
+
+// ---- the explicit inverse: wave c solves L L^T x = e_c by two banded substitutions - lanes over the band (one product per lane and
+// step for bw <= 64), a shuffle fold, x in LDS - and leaves it as row c of inv (coalesced; the inverse is symmetric).  Four columns per
+// workgroup; the factor's band is staged in LDS first when it fits (as in k_coarse_factor: 34 KB for 16 x 16 coarse cells), so a step
+// of the dependent chain costs LDS latency, not L2's (measured: 1110 us as a thread per column out of global memory -> ~60 us).
+#define CC_INV_BAND 6144      // doubles
+__device__ __forceinline__ double wave_sum_all(double v) {      // the same value in every lane (butterfly)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__global__ __launch_bounds__(256) void k_coarse_inverse(const double* __restrict__ L, int n, int bw, double* __restrict__ inv, const PcgScalars* sc) {
+  if (!sc->nonzero) return;
+  __shared__ double s_band[CC_INV_BAND];
+  __shared__ double s_x[4][CC_MAX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = blockIdx.x * 4 + wave;
+  const bool in_lds = n * (bw + 1) + bw <= CC_INV_BAND;
+  if (in_lds) {
+    for (int e = tid; e < n * (bw + 1); e += 256) {
+      const int i = e / (bw + 1), j = i - bw + e % (bw + 1);
+      s_band[i * bw + j + bw] = j >= 0 ? L[(size_t)i * n + j] : 0.0;
+    }
+    __syncthreads();
+  }
+  if (c >= n) return;      // (no workgroup barrier below)
+  const double* M = in_lds ? s_band : L;
+  const int rs = in_lds ? bw : n, off = in_lds ? bw : 0;      // element (i, j), i - bw <= j <= i, at M[i * rs + j + off]
+  double* x = s_x[wave];
+  for (int i = lane; i < c; i += 64) x[i] = 0.0;
+  __builtin_amdgcn_wave_barrier();
+  for (int i = c; i < n; ++i) {      // L w = e_c  (w_i = 0 for i < c)
+    const int j0 = i - bw > c ? i - bw : c;
+    double t = 0.0;
+    for (int j = j0 + lane; j < i; j += 64) t += M[i * rs + j + off] * x[j];
+    t = wave_sum_all(t);
+    const double xi = ((i == c ? 1.0 : 0.0) - t) / M[i * rs + i + off];
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) x[i] = xi;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int i = n - 1; i >= 0; --i) {      // L^T x = w
+    const int j1 = i + bw < n - 1 ? i + bw : n - 1;
+    double t = 0.0;
+    for (int j = i + 1 + lane; j <= j1; j += 64) t += M[j * rs + i + off] * x[j];
+    t = wave_sum_all(t);
+    const double xi = (x[i] - t) / M[i * rs + i + off];
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) x[i] = xi;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int i = lane; i < n; i += 64) inv[(size_t)c * n + i] = x[i];
+}
+
+int eu_launch_coarse_setup(euler_sim* S) {
+  const int n = S->coarse_n;
+  HIPCHK(hipMemsetAsync(S->cc_diag, 0, 3 * (size_t)n * sizeof(int), S->stream));
+  HIPCHK(hipMemsetAsync(S->cc_part, 0, (S->chunk_cap + 64) * 3 * sizeof(double), S->stream));      // (tiles outside this solve's list contribute nothing)
+  const unsigned nblk = eu_blocks(S->chunk_cap, 4, 2048);
+  LAUNCH(S, KC_PRECON_FACTOR, k_coarse_assemble, dim3(nblk), dim3(256), S->cellmask, S->geom, S->chunk_list, S->sc, S->band_lo, S->coarse_shift,
+         S->coarse_m, S->coarse_nx, S->cc_diag, S->cc_right, S->cc_up);
+  const int bw = S->coarse_ny > 1 ? S->coarse_nx : 1;      // half-bandwidth of P^T A P in row-major order of the coarse cells
+  LAUNCH(S, KC_PRECON_FACTOR, k_coarse_factor, dim3(1), dim3(CC_THREADS), S->cc_diag, S->cc_right, S->cc_up, n, S->coarse_nx, bw, S->cc_fac, S->sc);
+  LAUNCH(S, KC_PRECON_FACTOR, k_coarse_inverse, dim3((n + 3) / 4), dim3(256), S->cc_fac, n, bw, S->cc_inv, S->sc);
+  return EULER_OK;
+}
+
+// ---- per iteration: y = (P^T A P)^-1 P^T r and the epilogue of dot(z, r).  One workgroup per coarse cell gathers the tiles' partial
+// sums of its cell (the bands of the coarse row x the tiles whose 79 columns touch the coarse column: ~300 entries for 16 x 16 coarse
+// cells on 8192^2, 1.5 MB over all - one workgroup alone took 99 us for that) in a fixed assignment of entries to threads and a fixed
+// fold, publishes r_c[c] and takes a ticket; the workgroup that draws the last ticket forms y = inv r_c (four threads per row, 0.5 MB
+// out of L2), dot(z, r) += y . r_c and the scalar epilogue.  The hand-off is the one of block_finish (k_pcg.hip): 8-byte agent-scope
+// atomics on both sides.  Nothing depends on which workgroup is last.
+__device__ __forceinline__ double cc_block_sum(double v, double* s_red) {      // valid in thread 0; fixed order
+  v = eu_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) for (int k = 0; k < CC_THREADS / 64; ++k) t += s_red[k];
+  return t;
+}
+
+__global__ __launch_bounds__(CC_THREADS) void k_coarse_solve(const double* __restrict__ part, const double* __restrict__ inv, double* __restrict__ y,
+                                                             double* rc, unsigned int* counter, PcgScalars* sc, int fin_op, int force, int n, int nx,
+                                                             int m, int shift, int ntb, int band_lo, int band_hi) {
+  if (!force && (sc->done || !sc->nonzero)) return;      // (`done` may have been raised by this very iteration's max |r|)
+  __shared__ double s_rc[CC_MAX], s_q[4][CC_MAX], s_red[CC_THREADS / 64];
+  __shared__ int am_last;
+  const int tid = threadIdx.x, c = blockIdx.x;
+  {
+    const int I = c / nx, J = c % nx, g = 1 << shift;
+    const int klo = (J * g) >> 4;
+    int khi = ((J + 1) * g - 1 + 63) >> 4;
+    if (khi > ntb - 1) khi = ntb - 1;
+    const int nk = khi - klo + 1;
+    const int b0 = I * m > band_lo ? I * m : band_lo, b1 = (I + 1) * m < band_hi ? (I + 1) * m : band_hi;
+    const int total = b1 > b0 ? (b1 - b0) * nk : 0;
+    double sum = 0.0;
+    for (int e = tid; e < total; e += CC_THREADS) {
+      const int band = b0 + e / nk, k = klo + e % nk;
+      const int xl = k * 16 - 63;
+      const int b = J - ((xl > 0 ? xl : 0) >> shift);
+      if (b >= 0 && b < 3) sum += part[((size_t)(band - band_lo) * ntb + k) * 3 + b];
+    }
+    sum = cc_block_sum(sum, s_red);
+    if (tid == 0) {
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(&rc[c]), (unsigned long long)__double_as_longlong(sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      am_last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!am_last) return;
+  }
+  if (tid < CC_MAX)
+    s_rc[tid] = tid < n ? __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&rc[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
+  __syncthreads();
+  const int row = tid & (CC_MAX - 1), q = tid >> 8;      // rows of the (symmetric) inverse by columns: coalesced over `row`; j = q, q + 4, ...
+  double acc = 0.0;
+  if (row < n)      // (16 loads in flight per thread: this workgroup alone pulls the 0.5 MB, latency-bound unless the loads overlap)
+    for (int j = q; j < n; j += 64) {
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = j + 4 * u < n ? inv[(size_t)(j + 4 * u) * n + row] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc += v[u] * s_rc[(j + 4 * u) & (CC_MAX - 1)];
+    }
+  s_q[q][row] = acc;
+  __syncthreads();
+  double dv = 0.0;
+  if (tid < n) {
+    const double yv = (s_q[0][tid] + s_q[1][tid]) + (s_q[2][tid] + s_q[3][tid]);
+    y[tid] = yv;
+    dv = yv * s_rc[tid];
+  }
+  const double t = cc_block_sum(dv, s_red);
+  if (tid == 0) {
+    const double v = sc->sigma_new + t;      // k_precond_tile left dot(z_tile, r) there (FIN_STORE_ONLY)
+    if (fin_op == CFIN_SIGMA_INIT) sc->sigma = v;                                                     // main.c:748
+    else if (fin_op == CFIN_BETA) { sc->sigma_new = v; sc->beta = v / sc->sigma; sc->sigma = v; }     // main.c:762-765
+    else sc->sigma_new = v;
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next iteration
+  }
+}
+
+int eu_launch_coarse_solve(euler_sim* S, int fin_op, int force) {
+  LAUNCH(S, KC_PRECOND_TILE, k_coarse_solve, dim3(S->coarse_n), dim3(CC_THREADS), S->cc_part, S->cc_inv, S->cc_y, S->cc_y + CC_MAX,
+         reinterpret_cast<unsigned int*>(S->cc_y + 2 * CC_MAX), S->sc, fin_op, force, S->coarse_n, S->coarse_nx, S->coarse_m, S->coarse_shift,
+         S->geom.T / 16, S->band_lo, S->band_hi);
+  return EULER_OK;
+}
+
+// ---- the first search direction of a solve: s = z + P y (the memcpy at main.c:746, with the coarse part of z added on fluid cells)
+__global__ __launch_bounds__(256) void k_coarse_search_init(double* __restrict__ s, const double* __restrict__ z, const uint8_t* __restrict__ mask,
+                                                            const double* __restrict__ y, SkewGeom g, int shift, int m, int nx, const PcgScalars* sc) {
+  if (sc->done || !sc->nonzero) return;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < g.S; e += (size_t)gridDim.x * blockDim.x) {
+    double v = z[e];
+    if (mask[e] & CM_FLUID) {
+      int band, t, l;
+      skew_decode(g, e, band, t, l);
+      v = v + y[(band / m) * nx + ((t - l) >> shift)];
+    }
+    s[e] = v;
+  }
+}
+
+int eu_launch_coarse_search_init(euler_sim* S) {
+  LAUNCH(S, KC_UPDATE_SEARCH, k_coarse_search_init, dim3(eu_blocks(S->geom.S, 256 * 4, 4096)), dim3(256), S->s, S->z, S->cellmask, S->cc_y, S->geom,
+         S->coarse_shift, S->coarse_m, S->coarse_nx, S->sc);
+  return EULER_OK;
+}

@@ -350,7 +350,7 @@ int eu_launch_build_system(euler_sim* S, float dt) {
   HIPCHK(hipMemsetAsync(S->chunk_flag, 0, S->chunk_cap + 64, S->stream));
   HIPCHK(hipMemsetAsync(S->chunk_part, 0, S->chunk_cap + 64, S->stream));
   // the lean assembly needs every solve since the arrays were last written whole to have been a tile-mode solve of this handle
-  const bool lean = S->cfg.precond == EULER_PRECOND_IC0_TILE && S->cfg.sweep_mode != EULER_SWEEP_SIMPLE && S->lean_ok;
+  const bool lean = eu_is_tile(S) && S->cfg.sweep_mode != EULER_SWEEP_SIMPLE && S->lean_ok;
   if (lean)
     LAUNCH(S, KC_BUILD_SYSTEM, k_build_system<true>, dim3(eu_blocks(S->e_cnt, 256)), dim3(256), S->utmp, S->vtmp, S->count,
            S->solid, S->b, S->r, S->p, S->q, S->z, S->cellmask, S->sc, S->geom, dt, S->e_lo, S->e_cnt, S->chunk_flag, S->chunk_part, S->chunk_prev);

@@ -331,14 +331,18 @@ struct SaPair { sw_d2 z, so; double ez0, es0, ez1, es1; };   // one pair-record 
 
 // SA_RUN pair-records per wave: 8 (more waves in flight - at 1024^2 runs of 32 would leave 300 waves for 256 CUs - and the granularity
 // of the active-chunk list); 16 / 32 remain for experiments (sa_run)
-template <int SLAB, int PMODE, int SA_RUN>   // SLAB 1: several ranks, the neighbouring slabs' arrays are mapped; 2: their edge rows as compact rows (nbr); 0: nbr is ignored
+// COARSE (two-level preconditioner, k_coarse.hip): z stands for z + P y wherever s' = z + beta s is formed - y of the cell's coarse
+// cell is looked up (a lane's columns of one run cross at most one coarse column boundary) and added first, like the oracle's z += P y.
+struct CoarseRef { const double* y; int shift, m, nx, band0; };   // band0: the global index of the arrays' band 0
+template <int SLAB, int PMODE, int SA_RUN, bool COARSE = false>   // SLAB 1: several ranks, the neighbouring slabs' arrays are mapped; 2: their edge rows as compact rows (nbr); 0: nbr is ignored
 __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __restrict__ s_old, const double* __restrict__ z,
                                                              double* __restrict__ s_new, double* __restrict__ out,
                                                              const uint8_t* __restrict__ mask, SkewGeom g,
                                                              double* __restrict__ partial, PcgScalars* sc, int force,
                                                              unsigned int* counter, int fin_op, SlabNeighbours nbr,
                                                              double* __restrict__ p, double* s_new_base, double* s_old_base,
-                                                             const unsigned int* __restrict__ chunk_list) {   // SA_RUN == 8 only: the solve's active runs
+                                                             const unsigned int* __restrict__ chunk_list,      // SA_RUN == 8 only: the solve's active runs
+                                                             CoarseRef cref) {
   if (!force && pcg_idle(sc)) return;
   const double beta = sc->beta;
   const double alpha_prev = sc->alpha;     // of the previous iteration: this launch's own alpha is written by its LAST block
@@ -391,6 +395,22 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
       const double* gs = lane == 0 ? nbr.srow_dn : nbr.srow_up;
       double* gsn = lane == 0 ? nbr.snew_dn : nbr.snew_up;
       const int gcol = lane == 0 ? 0 : -63;
+      // COARSE: this lane's columns in the run (pairs P0 - 1 .. P1: 20 records at most) start in coarse column Ja and reach Ja + 1 at record tb
+      double cya = 0.0, cyb = 0.0, cea = 0.0, ceb = 0.0;
+      int ctb = 0x7fffffff;
+      if (COARSE) {
+        const int xa = 2 * (P0 - 1) - lane, Ja = (xa > 0 ? xa : 0) >> cref.shift;
+        const int I = (cref.band0 + lb) / cref.m;
+        ctb = ((Ja + 1) << cref.shift) + lane;
+        cya = cref.y[I * cref.nx + Ja];
+        cyb = Ja + 1 < cref.nx ? cref.y[I * cref.nx + Ja + 1] : 0.0;
+        if (edge_lane) {      // the row across the band boundary may belong to the neighbouring coarse row (same columns)
+          const int Ie = (cref.band0 + lb + (lane == 0 ? -1 : 1)) / cref.m;
+          const bool inside = cref.band0 + lb + (lane == 0 ? -1 : 1) >= 0;
+          cea = inside ? cref.y[Ie * cref.nx + Ja] : 0.0;
+          ceb = (inside && Ja + 1 < cref.nx) ? cref.y[Ie * cref.nx + Ja + 1] : 0.0;
+        }
+      }
       auto load_pair = [&](int P, SaPair& d, unsigned int m) {
         d.ez0 = d.es0 = d.ez1 = d.es1 = 0.0;
         if (P < 0 || P >= npairs) { d.z = sw_d2{0.0, 0.0}; d.so = sw_d2{0.0, 0.0}; return; }   // outside the band: never a fluid cell's neighbour
@@ -414,6 +434,14 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
             if (SLAB == 2 && ghost) { d.ez1 = gz[2 * P + 1 + gcol]; d.es1 = gs[2 * P + 1 + gcol]; }
             else if (SLAB == 1 && remote) { d.ez1 = ld_system(ez + k); d.es1 = ld_system(es + k); } else { d.ez1 = ez[k]; d.es1 = es[k]; }
           }
+          if (COARSE) {      // (harmless where nothing was loaded: the value is then never selected)
+            d.ez0 = d.ez0 + (2 * P >= ctb ? ceb : cea);
+            d.ez1 = d.ez1 + (2 * P + 1 >= ctb ? ceb : cea);
+          }
+        }
+        if (COARSE) {        // z + P y of the lane's own two cells (records 2P, 2P + 1)
+          d.z.x = d.z.x + (2 * P >= ctb ? cyb : cya);
+          d.z.y = d.z.y + (2 * P + 1 >= ctb ? cyb : cya);
         }
       };
       auto sprime = [&](const SaPair& d) { return sw_d2{d.z.x + beta * d.so.x, d.z.y + beta * d.so.y}; };   // s' = z + beta s (main.c:674)
@@ -1198,6 +1226,8 @@ struct TileArgs {
   double *zsend_lo, *zsend_hi;
   int edge_lo, edge_hi;
   int reverse;            // walk the tiles in descending order
+  double* cpart;          // two-level mode (k_coarse.hip): per tile, the sums of the (updated) r over its fluid cells by coarse column: [tile][3]
+  int cshift;             // log2 of the coarse cell width in grid cells
 };
 
 // fixed-shape reductions of a PT_THREADS block; result valid in thread 0
@@ -1334,6 +1364,20 @@ __global__ __launch_bounds__(PT_THREADS) void k_precond_tile(TileArgs a) {
         }
       }
       if (!a.sweeps) return;
+      if (W == 16 && a.cpart) {      // P^T r of this tile: cell (lane, record k W + j) sits in column k W + j - lane; at most three coarse columns per tile
+        const int xl = k * W - 63, J0 = (xl > 0 ? xl : 0) >> a.cshift;
+        double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          const int cm = (int)((mm[j >> 1] >> ((j & 1) * 8)) & 0xff);
+          const double rv = (cm & CM_FLUID) ? ((j & 1) ? rr[j >> 1].y : rr[j >> 1].x) : 0.0;
+          const int x = k * W + j - lane;
+          const int b = ((x > 0 ? x : 0) >> a.cshift) - J0;
+          c0 += b == 0 ? rv : 0.0; c1 += b == 1 ? rv : 0.0; c2 += b == 2 ? rv : 0.0;
+        }
+        c0 = eu_wave_sum(c0); c1 = eu_wave_sum(c1); c2 = eu_wave_sum(c2);
+        if (lane == 0) { double* cp = a.cpart + (size_t)tile * 3; cp[0] = c0; cp[1] = c1; cp[2] = c2; }
+      }
       // L q = r (main.c:602-613).  What travels from cell to cell is m = (-1 * precon) * q, the term both consumers subtract.
       double own = -0.0, out = -0.0;
 #pragma unroll
@@ -1453,7 +1497,7 @@ static SweepArgs make_sweep_args(euler_sim* S, int op, int force) {
   a.ticket_base = S->ticket_base; a.epoch = S->epoch;
   a.sc = S->sc; a.force = force; a.error = &S->ms->error;
   a.timeline = S->sweep_timeline;
-  a.tile_w = S->cfg.precond == EULER_PRECOND_IC0_TILE ? S->tile_w : 0;
+  a.tile_w = eu_is_tile(S) ? S->tile_w : 0;
   a.fin_qq = -1; a.qq_partial = S->partial; a.qq_counter = S->red_counter; a.sc_w = S->sc;
   return a;
 }
@@ -1518,7 +1562,7 @@ __global__ __launch_bounds__(256) void k_pack_fbits(const uint8_t* __restrict__ 
   fwd[o] = wf; bwd[o] = wb;
 }
 int eu_launch_band_ranges(euler_sim* S) {
-  if (S->cfg.precond == EULER_PRECOND_IC0_TILE) return EULER_OK;   // no band pipeline, no packed flags: k_precond_tile reads the cell mask
+  if (eu_is_tile(S)) return EULER_OK;   // no band pipeline, no packed flags: k_precond_tile reads the cell mask
   // a rank needs the ranges of its own bands and of the band before / after its slab (the hand-off windows)
   const bool nbrs = S->has_comm && S->couple && !S->slab_on;   // (a row-slab handle does not hold the neighbours' count rows)
   const int b0 = nbrs && S->band_lo > 0 ? S->band_lo - 1 : S->band_lo, b1 = nbrs && S->band_hi < S->geom.nbands ? S->band_hi + 1 : S->band_hi;
@@ -1692,7 +1736,7 @@ static int launch_dot(euler_sim* S, const double* a, const double* b, int fin_op
 }
 
 // tile-local IC(0) in its production form: everything between two apply_a passes in one kernel (k_precond_tile)
-static inline bool tile_fused(const euler_sim* S) { return S->cfg.precond == EULER_PRECOND_IC0_TILE && S->cfg.sweep_mode != EULER_SWEEP_SIMPLE; }
+static inline bool tile_fused(const euler_sim* S) { return eu_is_tile(S) && S->cfg.sweep_mode != EULER_SWEEP_SIMPLE; }
 // max |r| and dot(z,r) of all ranks after ONE exchange ("fuse the latter two into one ... message pair"): every rank
 // folds the gathered pairs in rank order - identical bits everywhere - and applies the two scalar epilogues
 __global__ void k_pair_fold(PcgScalars* sc, const double* __restrict__ pairs, int R, int rupd, int fin_dot, int force) {
@@ -1716,6 +1760,7 @@ static TileArgs make_tile_args(euler_sim* S, int force) {
   // descending: k_search_apply walks the chunks upwards, so this pass starts on what the Infinity Cache still holds of it - and ends
   // where the next k_search_apply starts.  8192^2: 548 -> 536 us per iteration (EULER_TILE_REVERSE=0 restores the ascending order)
   { static const int rev = getenv("EULER_TILE_REVERSE") ? atoi(getenv("EULER_TILE_REVERSE")) : 1; a.reverse = rev; }
+  a.cpart = nullptr; a.cshift = 0;
   if (ghost_mode(S)) {
     if (S->band_lo > 0) { a.zsend_lo = xrow(S, XR_ZSEND_LO); a.edge_lo = S->band_lo; }
     if (S->band_hi < S->geom.nbands) { a.zsend_hi = xrow(S, XR_ZSEND_HI); a.edge_hi = S->band_hi - 1; }
@@ -1742,6 +1787,11 @@ static int launch_precond_tile(euler_sim* S, int rupd, int sweeps, int fin_dot, 
   const bool seq = S->cfg.dot_mode == EULER_DOT_SEQUENTIAL && !S->has_comm;
   TileArgs a = make_tile_args(S, force);
   a.rupd = rupd; a.sweeps = sweeps; a.fin_dot = (seq || !sweeps) ? -1 : fin_dot; a.alpha_arg = alpha;
+  // two-level mode: the tile pass also leaves P^T r per tile and only STORES its share of dot(z, r); k_coarse_solve adds the coarse
+  // share and applies the epilogue
+  const bool two_level = eu_is_two_level(S) && sweeps && !r_only && !force && a.list != nullptr;
+  const int fin_real = a.fin_dot;
+  if (two_level) { a.cpart = S->cc_part; a.cshift = S->coarse_shift; if (a.fin_dot >= 0) a.fin_dot = FIN_STORE_ONLY; }
   const int w = r_only ? 16 : S->tile_w, cls = r_only ? KC_UPDATE_PR : KC_PRECOND_TILE;
   const unsigned nblk = eu_blocks((size_t)(S->band_hi - S->band_lo) * (S->geom.T / w), PT_THREADS / 64, 2048);
   switch (w) {
@@ -1749,6 +1799,7 @@ static int launch_precond_tile(euler_sim* S, int rupd, int sweeps, int fin_dot, 
     case 32: LAUNCH(S, cls, k_precond_tile<32>, dim3(nblk), dim3(PT_THREADS), a); break;
     default: LAUNCH(S, cls, k_precond_tile<16>, dim3(nblk), dim3(PT_THREADS), a); break;
   }
+  if (two_level) { int rc = eu_launch_coarse_solve(S, fin_real, force); if (rc) return rc; }
   if (seq && sweeps && fin_dot >= 0)   // the reference's row-major dot(z, r); a no-op once max |r| <= tol
     LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), S->z, S->r, S->cellmask, S->geom, S->sc, fin_dot, force);
   if (a.via == FIN_TO_COMM) {          // no mailboxes: G1 - both results (and, in the solve, the edge rows of the new z) in ONE exchange, then the epilogues
@@ -1826,7 +1877,7 @@ static inline unsigned sa_blocks(const euler_sim* S, int run) {   // one wave pe
 }
 static inline int sa_run(const euler_sim* S) {   // short runs while long ones would leave CUs without a wave
   static const char* e = getenv("EULER_SA_RUN");      // (experiments)
-  if (e && !S->has_comm) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32) return v; }
+  if (e && !S->has_comm && !eu_is_two_level(S)) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32) return v; }
   // measured (same box, tile-local mode): 8192^2 - 8: 346 us, 16: 358, 32: 376 (113 / 134 / 185 VGPRs: occupancy beats the window's
   // two extra pair loads per run, which hit L2); 16384^2, scanning every run's masks - 8: 1412 us, 32: 1389; with the list of active
   // chunks (runs of 8 only) - 8: 1177 us, 32: 1401
@@ -1859,11 +1910,15 @@ static int launch_search_apply_and_alpha(euler_sim* S, int it) {
   const int run = sa_run(S);
   const int fin = S->has_comm ? fin_or_comm(S, FIN_ALPHA) : (seq ? -1 : (int)FIN_ALPHA);
   double* pp = LOC(S->p);
-#define SA_LAUNCH(SLABF, PM, RUNV)                                                                                                      \
-  LAUNCH(S, KC_APPLY_A, (k_search_apply<SLABF, PM, RUNV>), dim3(sa_blocks(S, RUNV)), dim3(SA_THREADS), LOC(S->s), LOC(S->z), LOC(S->s2), \
-         LOC(S->q), LOC(S->cellmask), gl, S->partial, S->sc, 0, S->red_counter, fin, nbr, pp, S->s2, S->s, (RUNV) == 8 ? S->chunk_list : (const unsigned int*)nullptr)
+  const CoarseRef cref = {S->cc_y, S->coarse_shift, S->coarse_m, S->coarse_nx, S->band_lo};
+#define SA_LAUNCH_C(SLABF, PM, RUNV, CF)                                                                                                \
+  LAUNCH(S, KC_APPLY_A, (k_search_apply<SLABF, PM, RUNV, CF>), dim3(sa_blocks(S, RUNV)), dim3(SA_THREADS), LOC(S->s), LOC(S->z), LOC(S->s2), \
+         LOC(S->q), LOC(S->cellmask), gl, S->partial, S->sc, 0, S->red_counter, fin, nbr, pp, S->s2, S->s, (RUNV) == 8 ? S->chunk_list : (const unsigned int*)nullptr, cref)
+#define SA_LAUNCH(SLABF, PM, RUNV) SA_LAUNCH_C(SLABF, PM, RUNV, false)
 #define SA_RUNS(SLABF, PM) do { if (run == 8) SA_LAUNCH(SLABF, PM, 8); else if (run == 16) SA_LAUNCH(SLABF, PM, 16); else SA_LAUNCH(SLABF, PM, 32); } while (0)
-  if (ghost) {      // (tile-local mode: pmode 1 or 2; several ranks: runs of 8)
+  if (eu_is_two_level(S) && tile_fused(S)) {      // two-level preconditioner: one GPU, runs of 8 (the list), z + P y
+    if (pmode == 2) SA_LAUNCH_C(0, 2, 8, true); else SA_LAUNCH_C(0, 1, 8, true);
+  } else if (ghost) {      // (tile-local mode: pmode 1 or 2; several ranks: runs of 8)
     if (pmode == 2) SA_LAUNCH(2, 2, 8); else SA_LAUNCH(2, 1, 8);
   } else if (direct) {
     if (pmode == 2) { if (run == 8) SA_LAUNCH(1, 2, 8); else SA_LAUNCH(1, 2, 32); }
@@ -1874,6 +1929,7 @@ static int launch_search_apply_and_alpha(euler_sim* S, int it) {
   }
 #undef SA_RUNS
 #undef SA_LAUNCH
+#undef SA_LAUNCH_C
   double* t = S->s; S->s = S->s2; S->s2 = t;
   if (seq)
     LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), S->q, S->s, S->cellmask, S->geom, S->sc, (int)FIN_ALPHA, 0);
@@ -1915,6 +1971,8 @@ int eu_launch_project(euler_sim* S, float dt) {
   }
   // if (!all_zero(r)) { ... }: every kernel below is a no-op when sc->nonzero == 0
   const bool tile = tile_fused(S);
+  const bool two_level = tile && eu_is_two_level(S);
+  if (two_level && (rc = eu_launch_coarse_setup(S))) return rc;   // P^T A P of this system, its factor and inverse (k_coarse.hip)
   if (tile) {                                                     // E^-1 per tile, then z = M^-1 r and sigma = dot(z, r) in one pass
     if ((rc = launch_factor_tile(S, 0))) return rc;
     if ((rc = launch_precond_tile(S, 0, 1, FIN_SIGMA_INIT, 0, 0.0))) return rc;
@@ -1922,6 +1980,8 @@ int eu_launch_project(euler_sim* S, float dt) {
   if (S->cfg.precond != EULER_PRECOND_JACOBI && (rc = launch_sweep<SW_FACTOR>(S, KC_PRECON_FACTOR, 0))) return rc;   // once per solve
   if ((rc = launch_precondition(S, 0, FIN_SIGMA_INIT))) return rc;
   }
+  if (two_level) { if ((rc = eu_launch_coarse_search_init(S))) return rc; }      // s = z + P y
+  else
   LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<true>, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->s), LOC(S->z),
          LOC(S->cellmask), S->e_cnt, S->sc, 0, 0.0);
   if (S->has_comm && eu_p2p_has_neighbour_arrays(S)) {   // the neighbours read these rows of s in the second iteration's k_search_apply

@@ -47,7 +47,7 @@ enum {
   EULER_PRECOND_IC0 = 0,     /* the reference's incomplete Cholesky (main.c:580-627), evaluated as a
                                 dependency-ordered wavefront: bit-identical to the sequential sweep */
   EULER_PRECOND_JACOBI = 1,  /* z = r/diag: NOT the reference's iterates; for roofline comparison only */
-  EULER_PRECOND_IC0_TILE = 2 /* tile-local IC(0) (SURVEY 7 hard part 1(b): "tile-local IC(0) = block-Jacobi-IC"): the reference's
+  EULER_PRECOND_IC0_TILE = 2, /* tile-local IC(0) (SURVEY 7 hard part 1(b): "tile-local IC(0) = block-Jacobi-IC"): the reference's
                                 three recurrences (main.c:586-626) restricted to blocks - a block = the cells of one 64-row band
                                 whose skew records t = x + y % 64 fall into one tile of euler_config.precond_tile_records records
                                 (a parallelogram of 64 rows x W columns); couplings between blocks are dropped from the factor and
@@ -56,6 +56,18 @@ enum {
                                 instead of latency-bound, and nothing couples row slabs.  NOT the reference's iterates: the same
                                 solution where PCG converges (tolerance parity), ~25-35 % more iterations (tools/precond_study.py).
                                 Restated in the oracle (eo_sim.tile_records): GPU = oracle bit for bit in EULER_DOT_SEQUENTIAL. */
+  EULER_PRECOND_IC0_TILE2 = 3 /* TWO-LEVEL (round 3): the tile-local IC(0) above (64 x 16 blocks) plus a coarse correction,
+                                    z = M_tile^-1 r + P (P^T A P)^-1 P^T r,
+                                P = piecewise constants over coarse cells of (64 m)^2 grid cells restricted to the fluid, m the smallest
+                                power of two that leaves at most 256 coarse cells (16 x 16 of them on a square grid).  The block-local
+                                factor has no coupling beyond a block; the coarse space restores the long-range part of the inverse, which is
+                                what the first hundred iterations of a large solve live on: 2-4x fewer iterations than the REFERENCE's IC(0)
+                                to the reference's tolerance (2048^2 tank: 402 vs 1726), the reference's residual-after-100 in ~44 iterations
+                                on the saturated 8192^2 tank.  Same traffic
+                                per iteration as the tile-local mode (the coarse part is 3 doubles per tile out, one double per coarse cell
+                                in) + one small launch.  NOT the reference's iterates; symmetric positive definite, so PCG converges to the same
+                                solution.  Restated in the oracle (eo_sim.coarse_m): GPU = oracle to rounding (tolerance, not bits: the
+                                coarse sums are formed in another order).  One GPU only; EULER_DOT_TREE. */
 };
 
 /* IC(0) sweep implementation (same arithmetic, different schedule). */

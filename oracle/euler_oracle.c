@@ -58,6 +58,7 @@ void eo_destroy(eo_sim* s) {
   free(s->markers); free(s->a_diag); free(s->precon); free(s->q);
   free(s->b); free(s->p); free(s->r); free(s->z); free(s->s);
   free(s->cr); free(s->cg); free(s->cb); free(s->crtmp); free(s->cgtmp); free(s->cbtmp);
+  free(s->coarse_chol);
   free(s);
 }
 
@@ -434,6 +435,7 @@ float eo_calculate_timestep(const eo_sim* s, float frame_time) {
 #define FLUID(s, y, x) ((s)->count[AT(s, y, x)] != 0)
 
 void eo_build_system(eo_sim* s, float dt, const float* u, const float* v) {
+  free(s->coarse_chol); s->coarse_chol = NULL;      /* a new system: the coarse factor (two-level extension) is recomputed on demand */
   int X = s->X, Y = s->Y;
   size_t C = (size_t)X * (size_t)Y;
   const double k_inv_scale = (H_CELL * H_CELL) * DENSITY / dt; /* float expr widened, main.c:713 */
@@ -497,8 +499,64 @@ static void apply_preconditioner_tiled(eo_sim* s, const double* r, double* z) {
   free(start);
 }
 
+/* EXTENSION (two-level, euler_oracle.h coarse_m): z += P (P^T A P)^-1 P^T r. */
+int eo_coarse_m(int X, int Y) {
+  int m = 1;
+  while (((X + 64 * m - 1) / (64 * m)) * ((Y + 64 * m - 1) / (64 * m)) > 256) m *= 2;
+  return m;
+}
+static void coarse_correction(eo_sim* s, const double* r, double* z) {
+  const int X = s->X, Y = s->Y, g = 64 * s->coarse_m;
+  const int nx = (X + g - 1) / g, ny = (Y + g - 1) / g, n = nx * ny;
+  if (!s->coarse_chol) {      /* A_c = P^T A P: sums of A's entries over pairs of coarse cells, then its Cholesky factor */
+    double* A = (double*)calloc((size_t)n * n, sizeof(double));
+    for (int y = 0; y < Y; ++y)
+      for (int x = 0; x < X; ++x) {
+        if (!FLUID(s, y, x)) continue;
+        const int c = (y / g) * nx + x / g;
+        A[(size_t)c * n + c] += s->a_diag[AT(s, y, x)];
+        if (FLUID(s, y, x + 1)) { const int d = (y / g) * nx + (x + 1) / g; A[(size_t)c * n + d] -= 1; A[(size_t)d * n + c] -= 1; }
+        if (FLUID(s, y + 1, x)) { const int d = ((y + 1) / g) * nx + x / g; A[(size_t)c * n + d] -= 1; A[(size_t)d * n + c] -= 1; }
+      }
+    for (int c = 0; c < n; ++c) if (A[(size_t)c * n + c] == 0.0) A[(size_t)c * n + c] = 1.0;      /* a coarse cell without fluid */
+    for (int k = 0; k < n; ++k) {      /* in place, lower triangle (banded: entries beyond column distance nx stay 0) */
+      const double d = sqrt(A[(size_t)k * n + k]);
+      A[(size_t)k * n + k] = d;
+      const int hi = k + nx < n - 1 ? k + nx : n - 1;
+      for (int i = k + 1; i <= hi; ++i) A[(size_t)i * n + k] /= d;
+      for (int j = k + 1; j <= hi; ++j)
+        for (int i = j; i <= hi; ++i) A[(size_t)i * n + j] -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+    }
+    s->coarse_chol = A; s->coarse_n = n; s->coarse_nx = nx;
+  }
+  const double* L = s->coarse_chol;
+  double* rc = (double*)calloc((size_t)n, sizeof(double));
+  for (int y = 0; y < Y; ++y)
+    for (int x = 0; x < X; ++x)
+      if (FLUID(s, y, x)) rc[(y / g) * nx + x / g] += r[AT(s, y, x)];
+  for (int i = 0; i < n; ++i) {      /* L w = r_c */
+    double t = rc[i];
+    for (int j = i - nx > 0 ? i - nx : 0; j < i; ++j) t -= L[(size_t)i * n + j] * rc[j];
+    rc[i] = t / L[(size_t)i * n + i];
+  }
+  for (int i = n; i--;) {            /* L^T y = w */
+    double t = rc[i];
+    const int hi = i + nx < n - 1 ? i + nx : n - 1;
+    for (int j = i + 1; j <= hi; ++j) t -= L[(size_t)j * n + i] * rc[j];
+    rc[i] = t / L[(size_t)i * n + i];
+  }
+  for (int y = 0; y < Y; ++y)
+    for (int x = 0; x < X; ++x)
+      if (FLUID(s, y, x)) z[AT(s, y, x)] += rc[(y / g) * nx + x / g];
+  free(rc);
+}
+
 void eo_apply_preconditioner(eo_sim* s, const double* r, double* z) {
-  if (s->tile_records > 0) { apply_preconditioner_tiled(s, r, z); return; }
+  if (s->tile_records > 0) {
+    apply_preconditioner_tiled(s, r, z);
+    if (s->coarse_m > 0) coarse_correction(s, r, z);
+    return;
+  }
   int X = s->X, Y = s->Y;
   size_t C = (size_t)X * (size_t)Y;
   double* pre = s->precon; double* q = s->q;

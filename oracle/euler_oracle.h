@@ -55,6 +55,16 @@ typedef struct eo_sim {
    * restriction of the reference's preconditioner.  0 = the reference's IC(0) (main.c:580-627); else the records per
    * tile.  See eo_tile_start. */
   int tile_records;
+  /* EXTENSION on top of it (round 3): a coarse correction - the "two-level" preconditioner
+   *     z = M_tile^-1 r + P (P^T A P)^-1 P^T r,
+   * P = piecewise constants over coarse cells of (64 m) x (64 m) grid cells restricted to the fluid (coarse_m = m > 0; 0 = off).
+   * The block-local IC(0) has no coupling beyond a 64 x 16 block; the coarse space restores the long-range part of the inverse
+   * (the hydrostatic mode of a tank, say), which is what the first hundred iterations of a solve live on.  Still symmetric positive
+   * definite: PCG converges to the same solution.  The coarse matrix (at most 256 x 256) is factored once per system
+   * (eo_build_system invalidates it). */
+  int coarse_m;
+  int coarse_n, coarse_nx;      /* filled by the first application: number of coarse cells, coarse cells per row */
+  double* coarse_chol;          /* dense lower Cholesky factor of P^T A P (coarse_n^2), NULL = not factored yet */
 } eo_sim;
 
 eo_sim* eo_create(int X, int Y);
@@ -104,6 +114,8 @@ double eo_inf_norm(const eo_sim* s, const double* r);
  * triangular solves (the diagonal of A stays whole).
  * Returns 1 when record t starts a tile (couplings arriving from record t-1 are cut), else 0. */
 int    eo_tile_start(int tile_records, int t);
+/* the coarse-cell width the product picks for a grid: the smallest power of two m with ceil(X / 64m) * ceil(Y / 64m) <= 256 */
+int    eo_coarse_m(int X, int Y);
 
 /* ASCII frame as draw_rows() emits it (main.c:914-951), no cursor codes. Returns length. */
 int eo_render_rows(const eo_sim* s, int wx, int wy, char* out, int cap);

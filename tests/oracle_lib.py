@@ -43,6 +43,7 @@ class EoSim(C.Structure):
         ("cr", C.POINTER(C.c_float)), ("cg", C.POINTER(C.c_float)), ("cb", C.POINTER(C.c_float)),
         ("crtmp", C.POINTER(C.c_float)), ("cgtmp", C.POINTER(C.c_float)), ("cbtmp", C.POINTER(C.c_float)),
         ("tile_records", C.c_int),
+        ("coarse_m", C.c_int), ("coarse_n", C.c_int), ("coarse_nx", C.c_int), ("coarse_chol", C.POINTER(C.c_double)),
     ]
 
 
@@ -98,6 +99,8 @@ def oracle_lib(fast=False, lib_path=None):
     lib.eo_inf_norm.restype = C.c_double
     lib.eo_tile_start.argtypes = [C.c_int, C.c_int]
     lib.eo_tile_start.restype = C.c_int
+    lib.eo_coarse_m.argtypes = [C.c_int, C.c_int]
+    lib.eo_coarse_m.restype = C.c_int
     lib.eo_colorize.argtypes = [sp]
     lib.eo_advect_p.argtypes = [sp, fp, fp, fp, C.c_float, fp]
     lib.eo_render_rows.argtypes = [sp, C.c_int, C.c_int, C.c_char_p, C.c_int]

@@ -70,3 +70,49 @@ def test_pcg_with_tile_preconditioner_reaches_the_same_pressure():
     assert r0 <= 1e-6 and r1 <= 1e-6
     assert np.abs(p1 - p0).max() <= 1e-5 * np.abs(p0).max()
     assert it0 < it1 <= 1.6 * it0, (it0, it1)
+
+
+# ---- the two-level EXTENSION (oracle/euler_oracle.h eo_sim.coarse_m; include/euler.h EULER_PRECOND_IC0_TILE2)
+def test_coarse_grid_size_rule():
+    """coarse cells of (64 m)^2 grid cells, m the smallest power of two leaving at most 256 of them"""
+    L = oracle_lib()
+    assert L.eo_coarse_m(512, 512) == 1 and L.eo_coarse_m(1024, 1024) == 1      # 8 x 8, 16 x 16 coarse cells
+    assert L.eo_coarse_m(2048, 2048) == 2 and L.eo_coarse_m(8192, 8192) == 8 and L.eo_coarse_m(16384, 16384) == 16
+    assert L.eo_coarse_m(1100, 200) == 1 and L.eo_coarse_m(16384, 64) == 1      # 18 x 4; 256 x 1
+
+
+def test_two_level_preconditioner_is_symmetric_positive():
+    o = _system(300, 200)
+    rng = np.random.default_rng(11)
+    fluid = o.count > 0
+    a = np.where(fluid, rng.standard_normal(fluid.shape), 0.0)
+    b = np.where(fluid, rng.standard_normal(fluid.shape), 0.0)
+    o.c.coarse_m = o.lib.eo_coarse_m(300, 200)
+    Ma, Mb = _apply(o, 16, a), _apply(o, 16, b)
+    assert abs((Ma * b).sum() - (a * Mb).sum()) < 1e-10 * np.abs(Ma * b).sum()
+    assert (Ma * a).sum() > 0 and (Mb * b).sum() > 0
+    o.c.coarse_m = 0
+    Mt = _apply(o, 16, a)
+    assert not np.array_equal(Ma, Mt)
+    # the correction is constant over the fluid cells of a coarse cell (64 x 64 cells here: rows y // 64, columns x // 64)
+    d = Ma - Mt
+    for I in range(0, 200, 64):
+        for J in range(0, 300, 64):
+            vals = d[I:I + 64, J:J + 64][fluid[I:I + 64, J:J + 64]]
+            if vals.size:
+                assert np.ptp(vals) <= 1e-12 * max(1.0, np.abs(vals).max()), (I, J)
+
+
+def test_pcg_with_two_level_preconditioner_reaches_the_same_pressure_in_fewer_iterations():
+    """256^2 half tank from rest, tolerance parity: |dp| <= 1e-5 max |p| against the reference's IC(0), in fewer iterations than it."""
+    res = {}
+    for name, units, cm in (("ic0", 0, 0), ("tile", 16, 0), ("two_level", 16, 1)):
+        o = Oracle(256, 256).load_half_tank()
+        o.c.tile_records = units
+        o.c.coarse_m = cm and o.lib.eo_coarse_m(256, 256)
+        o.c.max_iterations = 3000
+        o.step()
+        res[name] = (o.p.copy(), int(o.c.total_pcg_iterations), o.c.last_residual)
+    assert all(r[2] <= 1e-6 for r in res.values())
+    assert np.abs(res["two_level"][0] - res["ic0"][0]).max() <= 1e-5 * np.abs(res["ic0"][0]).max()
+    assert res["two_level"][1] < res["ic0"][1] < res["tile"][1], {k: v[1] for k, v in res.items()}
