@@ -2070,6 +2070,11 @@ int eu_launch_project(euler_sim* S, float dt) {
 int eu_launch_pcg_op(euler_sim* S, int op, float dt, double a, double* out) {
   const bool want_scalar = op == EULER_OP_DOT_ZR || op == EULER_OP_DOT_ZS || op == EULER_OP_INF_NORM_R;
   const size_t SS = S->geom.S;
+  if (eu_is_two_level(S) && (op == EULER_OP_PRECON_FACTOR || op == EULER_OP_FORWARD_SOLVE || op == EULER_OP_BACKWARD_SOLVE)) {
+    // the coarse level is assembled over a solve's chunk list and lives in the solve: a single forced operation would return the tile level alone
+    eu_set_error("euler_pcg_op: the preconditioner of EULER_PRECOND_IC0_TILE2 is not available as a single operation (select EULER_PRECOND_IC0_TILE for its tile level)");
+    return EULER_EINVAL;
+  }
   switch (op) {
     case EULER_OP_BUILD_SYSTEM:
       LAUNCH(S, KC_MISC, k_pcg_reset, dim3(1), dim3(1), S->sc, S->cfg.tol, S->cfg.max_iterations);

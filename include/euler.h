@@ -211,7 +211,8 @@ int euler_step(euler_sim* sim);                    /* one frame: <= max_substeps
 int euler_timestep(euler_sim* sim, float frame_time_left, float* dt);   /* calculate_timestep, main.c:834-841 */
 int euler_substep(euler_sim* sim, float dt);       /* stages 2..11 of sim_step with a given dt */
 int euler_stage(euler_sim* sim, int32_t stage, float dt);   /* one EULER_STAGE_* (teacher-forced tests) */
-int euler_pcg_op(euler_sim* sim, int32_t op, float dt, double scalar_in, double* scalar_out);
+int euler_pcg_op(euler_sim* sim, int32_t op, float dt, double scalar_in, double* scalar_out);   /* one EULER_OP_* (kernel-level parity tests);
+ * EULER_EINVAL for the preconditioner operations of a handle in EULER_PRECOND_IC0_TILE2 (its coarse level exists inside a solve only) */
 /* Switch the preconditioner of the following solves (EULER_PRECOND_*; tile_records as euler_config.precond_tile_records,
  * 0 = default).  The solver's arrays do not depend on it; g_precon keeps whatever the last factorisation left. */
 int euler_set_precond(euler_sim* sim, int32_t precond, int32_t tile_records);

@@ -318,3 +318,17 @@ def test_two_level_mode_moving_water_against_the_oracle():
     o.step(); sim.step()
     assert_bits(sim.get(ea.F_COUNT), o.count, "count after switching back")
     assert np.abs(sim.get(ea.F_U) - o.u).max() < 1e-4
+
+
+def test_two_level_mode_refuses_what_it_cannot_do():
+    """single preconditioner operations (the coarse level lives inside a solve), tile widths other than 16"""
+    sim = ea.Simulation(260, 300, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE2).load_half_tank()
+    sim.pcg_op(ea.OP_BUILD_SYSTEM, dt=0.05)
+    with pytest.raises(ea.EulerError):
+        sim.pcg_op(ea.OP_BACKWARD_SOLVE)
+    with pytest.raises(ea.EulerError):
+        sim.set_precond(ea.PRECOND_IC0_TILE2, 8)
+    sim.set_precond(ea.PRECOND_IC0_TILE, 8)       # the tile level alone takes any width
+    sim.pcg_op(ea.OP_BACKWARD_SOLVE)
+    sim.step()
+    assert sim.stats().last_residual <= 1e-6 or sim.stats().last_pcg_iterations == 100
