@@ -52,12 +52,13 @@ ALGO_BYTES = {
 }
 APPLY_A_FUSED = {"ic0": 5.5 * W + 1,     # update_search fused in: read s, z; write s', A s'; since round 3 also p += alpha s as below
                  "jacobi": 5.5 * W + 1,
+                 "ic0_tile_mg": 5.5 * W + 1,
                  "ic0_tile2": 5.5 * W + 1, # (two-level mode: + one 8-byte coarse value per 64-cell run - the table of <= 256 values sits in L2)
                  "ic0_tile": 5.5 * W + 1}  # ... and p += alpha s of two iterations on every second one: read s, z (+ s of two iterations ago
                                            # and p every second iteration); write s', A s' (+ p every second iteration): 4w + 1.5w
 # whole PCG iteration per cell (SURVEY 8d "Algorithmic bytes"): the reference's IC(0) as five kernels 18w+5; the tile-local
 # variant as the two passes it runs, 11w+2 - "the figure for that variant ... never the larger one"
-PCG_BYTES = {"ic0": 17.5 * W + 5, "ic0_tile": 9.5 * W + 2, "ic0_tile2": 9.5 * W + 2, "jacobi": 10.5 * W + 3}   # tile-local: 5.5w+1 + 4w+1 = 78 (round 2: 11w+2 = 90); the reference's
+PCG_BYTES = {"ic0": 17.5 * W + 5, "ic0_tile": 9.5 * W + 2, "ic0_tile2": 9.5 * W + 2, "ic0_tile_mg": 9.5 * W + 2, "jacobi": 10.5 * W + 3}   # tile-local: 5.5w+1 + 4w+1 = 78 (round 2: 11w+2 = 90); the reference's
 # structure 18w+5 = 149 minus the half p update saved since round 3 (p is read and written every second iteration): 145
 PCG_CLASSES = ["forward_solve", "backward_solve", "apply_a", "dot", "update_pr", "update_search", "precond_tile"]
 KERNEL_OF_CLASS = {"forward_solve": "k_sweep_skew<1", "backward_solve": "k_sweep_skew<2", "precon_factor": "k_sweep_skew<0",
@@ -65,8 +66,9 @@ KERNEL_OF_CLASS = {"forward_solve": "k_sweep_skew<1", "backward_solve": "k_sweep
 MODE_NAME = {"ic0": "parity mode: the reference's IC(0), bit-identical iterates",
              "ic0_tile": "roofline mode: tile-local IC(0) (64x%d-cell blocks), NOT the reference's iterates (tolerance parity where PCG converges)",
              "ic0_tile2": "two-level mode: tile-local IC(0) (64x%d-cell blocks) + a coarse correction (<= 256 aggregates, dense inverse), NOT the reference's iterates",
+             "ic0_tile_mg": "multilevel mode: tile-local IC(0) (64x%d-cell blocks) + one V-cycle over aggregates of 16, 32, ... cells with a dense top level, NOT the reference's iterates",
              "jacobi": "Jacobi stand-in, NOT the reference's iterates"}
-TILE_MODES = ("ic0_tile", "ic0_tile2")
+TILE_MODES = ("ic0_tile", "ic0_tile2", "ic0_tile_mg")
 
 
 def parse_args():
@@ -77,7 +79,7 @@ def parse_args():
     ap.add_argument("--size", type=int, default=0, help="N of the NxN grid (default: configs[2] = 8192)")
     ap.add_argument("--workload", default="half_tank", choices=["dam_break", "half_tank", "waterfall"])
     ap.add_argument("--dot-mode", default="tree", choices=["tree", "sequential"])
-    ap.add_argument("--precond", default="ic0_tile", choices=["ic0", "jacobi", "ic0_tile", "ic0_tile2"],
+    ap.add_argument("--precond", default="ic0_tile", choices=["ic0", "jacobi", "ic0_tile", "ic0_tile2", "ic0_tile_mg"],
                     help="ic0_tile = roofline mode (default), ic0 = parity mode (the reference's preconditioner), ic0_tile2 = roofline mode + coarse "
                          "correction (one GPU; fewer iterations to a given residual, DESIGN.md 5c)")
     ap.add_argument("--tile-records", type=int, default=0)
@@ -468,7 +470,7 @@ def time_frames(sim, ea, grp, args, precond, steps, warmup_done, warmup, big):
     the others in a second pass of the same length."""
     for _ in range(max(warmup - warmup_done, 0)):
         sim.step()
-    dominant = {"ic0": "backward_solve", "ic0_tile": "apply_a", "ic0_tile2": "apply_a", "jacobi": "update_pr"}[precond]
+    dominant = {"ic0": "backward_solve", "ic0_tile": "apply_a", "ic0_tile2": "apply_a", "ic0_tile_mg": "apply_a", "jacobi": "update_pr"}[precond]
     classes_all = ea.profile_class_names() if args.profile_all else PCG_CLASSES
     timed = [] if args.no_kernel_timing else (classes_all if big else [dominant])
     sim.profile_reset()
@@ -537,7 +539,7 @@ def summarize(t, size_x, size_y, precond, tile_w, traffic, traffic_note, steps, 
             parts = [rows[k].get("traffic_bytes_per_launch") for k in per_iter]
             tsum = sum(parts) if parts and all(parts) else None
         agg = {"us_per_iteration": round(1e3 * t["per_iter_ms"], 2), "bytes_per_cell_iteration": bpc,
-               "launches_per_iteration": len(per_iter) + (1 if precond == "ic0_tile2" else 0),      # + k_coarse_solve (timed in the precond_tile class)
+               "launches_per_iteration": len(per_iter) + (1 if precond == "ic0_tile2" else 0),      # + k_coarse_solve (timed in the precond_tile class; the multilevel mode: + a dozen small launches)
                "GBps_active": round(bpc * fluid / sec / 1e9, 1), "frac_active": round(bpc * fluid / sec / 1e9 / HBM_PEAK_GBPS, 4),
                "GBps_traffic": round(tsum / sec / 1e9, 1) if tsum else None,
                "frac_traffic": round(tsum / sec / 1e9 / HBM_PEAK_GBPS, 4) if tsum else None,
@@ -577,19 +579,26 @@ def equal_residual_scan(sim, ea, tile_records, limit=1200, two_level=False, solv
         tile = solve(ea.PRECOND_IC0_TILE, budget)
         scan.append([budget, tile["residual"]])
     two = None
-    if two_level:      # the same bar for the two-level mode: budgets from 20 up in steps of 4 (it needs fewer than the reference's 100)
-        two = {"scan": []}
-        b2 = 16
+    multi = None
+
+    def coarse_scan(precond):      # the same bar for a mode with a coarse correction: budgets from 8 up (it needs fewer than the reference's 100)
+        out = {"scan": []}
+        b2 = 4
         while True:
             b2 += 4 if b2 < 160 else 16
-            t2 = solve(ea.PRECOND_IC0_TILE2, b2)
-            two["scan"].append([b2, t2["residual"]])
+            t2 = solve(precond, b2)
+            out["scan"].append([b2, t2["residual"]])
             if t2["residual"] <= exact["residual"] or b2 >= limit or exact["iterations"] < 100:
                 break
         ok2 = t2["residual"] <= exact["residual"]
-        two.update({"budget_for_equal_residual": b2 if ok2 else None, "at_that_budget": t2, "at_100_iterations": solve(ea.PRECOND_IC0_TILE2, 100),
+        out.update({"budget_for_equal_residual": b2 if ok2 else None, "at_that_budget": t2, "at_100_iterations": solve(precond, 100),
                     "solve_speedup_at_equal_residual": round(exact["ms"] / t2["ms"], 2) if ok2 else None})
-        two["scan"] = two["scan"][::max(1, len(two["scan"]) // 16)] + two["scan"][-1:]
+        out["scan"] = out["scan"][::max(1, len(out["scan"]) // 16)] + out["scan"][-1:]
+        return out
+
+    if two_level:
+        two = coarse_scan(ea.PRECOND_IC0_TILE2)
+        multi = coarse_scan(ea.PRECOND_IC0_TILE_MG)
         sim.set_precond(ea.PRECOND_IC0_TILE, tile_records)
     errors = None
     if two_level and two is not None:
@@ -597,7 +606,7 @@ def equal_residual_scan(sim, ea, tile_records, limit=1200, two_level=False, solv
         # of this system (two-level mode to the reference's tolerance 1e-6, cap lifted): ||p_k - p*||_2 / ||p*||_2
         try:
             import numpy as np
-            sim.set_precond(ea.PRECOND_IC0_TILE2, tile_records)
+            sim.set_precond(ea.PRECOND_IC0_TILE_MG, tile_records)
             sim.set_solver(20000, 1e-6)
             sim.stage(ea.STAGE_PROJECT, dt)
             st = sim.stats()
@@ -628,13 +637,17 @@ def equal_residual_scan(sim, ea, tile_records, limit=1200, two_level=False, solv
                 k += 4 if k < 64 else 16
             errors["two_level_budget_for_equal_error"] = k if ek is not None and ek <= errors["reference_ic0_100"] else None
             errors["two_level_at_that_budget"] = ek
+            errors["multilevel_100"] = err(ea.PRECOND_IC0_TILE_MG, 100)
+            bm = multi.get("budget_for_equal_residual") if multi else None
+            if bm and bm != 100:
+                errors["multilevel_%d" % bm] = err(ea.PRECOND_IC0_TILE_MG, bm)
             del pstar
         except Exception as e:
             errors = {"error": repr(e)}
         sim.set_precond(ea.PRECOND_IC0_TILE, tile_records)
     sim.set_solver(100, solver_tol)
     reached = tile["residual"] <= exact["residual"]
-    return {"dt": dt, "reference_ic0_100_iterations": exact, "tile_100_iterations": tile100, "two_level": two, "pressure_error_vs_converged": errors,
+    return {"dt": dt, "reference_ic0_100_iterations": exact, "tile_100_iterations": tile100, "two_level": two, "multilevel": multi, "pressure_error_vs_converged": errors,
             "tile_budget_for_equal_residual": budget if reached else None, "tile_at_that_budget": tile,
             "solve_speedup_at_equal_residual": round(exact["ms"] / tile["ms"], 2) if reached else None, "residual_scan": scan[::max(1, len(scan) // 16)] + scan[-1:]}
 
@@ -661,10 +674,27 @@ def equal_residual(sim, ea, grp, args, GX, GY, tile_w, solver_tol):
     # frames with that budget: the one number for "reference-quality throughput", per mode
     if out["tile_budget_for_equal_residual"]:
         out["frames_at_that_budget"] = frames(ea.PRECOND_IC0_TILE, out["tile_budget_for_equal_residual"])
-    two = out.get("two_level")
-    if two and two.get("budget_for_equal_residual"):
-        two["frames_at_that_budget"] = frames(ea.PRECOND_IC0_TILE2, two["budget_for_equal_residual"])
-        sim.set_precond(ea.PRECOND_IC0_TILE, args.tile_records)
+    for key, pc in (("two_level", ea.PRECOND_IC0_TILE2), ("multilevel", ea.PRECOND_IC0_TILE_MG)):
+        blk = out.get(key)
+        if blk and blk.get("budget_for_equal_residual"):
+            blk["frames_at_that_budget"] = frames(pc, blk["budget_for_equal_residual"])
+    mg = out.get("multilevel")
+    if mg is not None:      # and the thing the reference cannot do at this size at all: frames whose solves reach its tolerance 1e-6
+        try:
+            sim.set_precond(ea.PRECOND_IC0_TILE_MG, args.tile_records)
+            sim.set_solver(20000, 1e-6)
+            sim.step()
+            st0 = sim.stats()
+            el = grp.timed(sim.step, 1)
+            st1 = sim.stats()
+            mg["converged_frames"] = {"value": GX * GY / el, "unit": "cells*steps/s", "ms_per_step": 1e3 * el, "steps": 1, "tol": 1e-6,
+                                      "substeps": int(st1.total_substeps - st0.total_substeps),
+                                      "pcg_iterations": int(st1.total_pcg_iterations - st0.total_pcg_iterations),
+                                      "last_residual": float(st1.last_residual)}
+        except Exception as e:
+            mg["converged_frames"] = {"error": repr(e)}
+        sim.set_solver(100, solver_tol)
+    sim.set_precond(ea.PRECOND_IC0_TILE, args.tile_records)
     sim.set_solver(100)
     return out
 
@@ -801,7 +831,7 @@ def main():
     from euler_amd import scenarios
 
     dot_mode = ea.DOT_TREE if args.dot_mode == "tree" else ea.DOT_SEQUENTIAL
-    PC = {"ic0": ea.PRECOND_IC0, "jacobi": ea.PRECOND_JACOBI, "ic0_tile": ea.PRECOND_IC0_TILE, "ic0_tile2": ea.PRECOND_IC0_TILE2}
+    PC = {"ic0": ea.PRECOND_IC0, "jacobi": ea.PRECOND_JACOBI, "ic0_tile": ea.PRECOND_IC0_TILE, "ic0_tile2": ea.PRECOND_IC0_TILE2, "ic0_tile_mg": ea.PRECOND_IC0_TILE_MG}
     tile_w = args.tile_records or 16
     # N > 1 (weak scaling): the grid grows to N x (N * gpus) rows; the pressure solve is split into one
     # slab of N rows per GPU, the cheap stages run replicated (DESIGN.md "Multi-GPU")
@@ -902,7 +932,7 @@ def main():
         # (2) time to SOLVE one system to the reference's tolerance, both modes (2048^2 half tank, first projection)
         try:
             tts = {}
-            for pc in ("ic0", "ic0_tile", "ic0_tile2"):
+            for pc in ("ic0", "ic0_tile", "ic0_tile2", "ic0_tile_mg"):
                 s3 = ea.Simulation(2048, 2048, device=local_rank, dot_mode=dot_mode, precond=PC[pc], tile_records=args.tile_records,
                                    max_iterations=20000, pcg_poll_interval=32).load_half_tank()
                 s3.step()                      # untimed: allocations, first launches
@@ -919,6 +949,7 @@ def main():
             tts["workload"] = "2048x2048 half tank from rest, one frame, tol 1e-6 (the reference's), iteration cap lifted to 20000"
             tts["speedup_tile_over_exact"] = round(tts["ic0"]["ms"] / tts["ic0_tile"]["ms"], 2)
             tts["speedup_two_level_over_exact"] = round(tts["ic0"]["ms"] / tts["ic0_tile2"]["ms"], 2)
+            tts["speedup_multilevel_over_exact"] = round(tts["ic0"]["ms"] / tts["ic0_tile_mg"]["ms"], 2)
             secondary["time_to_solution"] = tts
         except Exception as e:
             secondary["time_to_solution"] = {"error": repr(e)}

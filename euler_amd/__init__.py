@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libeuler_hip.so")
 
 # --- enums of include/euler.h ------------------------------------------------------------------
 DOT_AUTO, DOT_SEQUENTIAL, DOT_TREE = 0, 1, 2
-PRECOND_IC0, PRECOND_JACOBI, PRECOND_IC0_TILE, PRECOND_IC0_TILE2 = 0, 1, 2, 3
+PRECOND_IC0, PRECOND_JACOBI, PRECOND_IC0_TILE, PRECOND_IC0_TILE2, PRECOND_IC0_TILE_MG = 0, 1, 2, 3, 4
 SWEEP_AUTO, SWEEP_BAND, SWEEP_SIMPLE = 0, 1, 2
 (F_U, F_V, F_UTMP, F_VTMP, F_SOLID, F_SOURCE, F_SINK, F_COUNT, F_PREV_COUNT, F_MARKERS, F_PRECON,
  F_PRESSURE, F_PCG_B, F_PCG_R, F_PCG_Z, F_PCG_S, F_PCG_Q, F_CELLMASK,

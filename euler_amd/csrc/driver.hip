@@ -135,13 +135,13 @@ static int eu_set_tiles(euler_sim* S, int w) {
 }
 
 extern "C" int euler_set_precond(euler_sim* S, int32_t precond, int32_t tile_records) {
-  if (!S || precond < EULER_PRECOND_IC0 || precond > EULER_PRECOND_IC0_TILE2) { eu_set_error("euler_set_precond: bad argument"); return EULER_EINVAL; }
+  if (!S || precond < EULER_PRECOND_IC0 || precond > EULER_PRECOND_IC0_TILE_MG) { eu_set_error("euler_set_precond: bad argument"); return EULER_EINVAL; }
   HIPCHK(hipStreamSynchronize(S->stream));
   int rc = eu_set_tiles(S, tile_records);
   if (rc) return rc;
-  if (precond == EULER_PRECOND_IC0_TILE2) {      // the two-level mode: tiles of 16 records, one GPU, tree dots; its arrays come with the first use
+  if (precond == EULER_PRECOND_IC0_TILE2 || precond == EULER_PRECOND_IC0_TILE_MG) {      // the two-level / multilevel modes: tiles of 16 records, one GPU, tree dots; their arrays come with the first use
     if (S->has_comm || S->slab_on || S->tile_w != 16 || S->cfg.sweep_mode == EULER_SWEEP_SIMPLE) {
-      eu_set_error("EULER_PRECOND_IC0_TILE2: one GPU, tiles of 16 records, the band schedule"); return EULER_EINVAL;
+      eu_set_error("EULER_PRECOND_IC0_TILE2 / _MG: one GPU, tiles of 16 records, the band schedule"); return EULER_EINVAL;
     }
     S->cfg.dot_mode = EULER_DOT_TREE;
     if ((rc = eu_coarse_alloc(S))) return rc;
@@ -400,9 +400,9 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   if (!S->ev_pool || !S->ev_cls || !S->ev_solve || !S->ev_iter) { euler_destroy(S); return EULER_ENOMEM; }
   for (int k = 0; k < S->ev_cap; ++k) CREATECHK(hipEventCreate(&S->ev_pool[k]));
   if (S->slab_on) { int rc = eu_slab_alloc(S); if (rc) { euler_destroy(S); return rc; } }
-  if (S->cfg.precond == EULER_PRECOND_IC0_TILE2) {
+  if (S->cfg.precond == EULER_PRECOND_IC0_TILE2 || S->cfg.precond == EULER_PRECOND_IC0_TILE_MG) {
     if (S->slab_on || S->tile_w != 16 || S->cfg.sweep_mode == EULER_SWEEP_SIMPLE) {
-      eu_set_error("EULER_PRECOND_IC0_TILE2: one GPU, tiles of 16 records, the band schedule"); euler_destroy(S); return EULER_EINVAL;
+      eu_set_error("EULER_PRECOND_IC0_TILE2 / _MG: one GPU, tiles of 16 records, the band schedule"); euler_destroy(S); return EULER_EINVAL;
     }
     S->cfg.dot_mode = EULER_DOT_TREE;
     int rc = eu_coarse_alloc(S);

@@ -171,6 +171,14 @@ struct euler_sim {
   double* cc_inv;                    // [n][n]: its inverse, per solve
   double* cc_part;                   // [chunks][3]: per tile, the sums of r over its fluid cells by coarse column (k_precond_tile)
   double* cc_y;                      // [n]: the coarse correction of the iteration (k_coarse_solve)
+  // EULER_PRECOND_IC0_TILE_MG (multilevel; k_coarse.hip): levels 0 .. mg_levels - 1 of aggregates of (16 << l)^2 grid cells, mg_nx[l] x mg_ny[l]
+  // of them, pooled arrays with level l at offset mg_off[l]; the level above the last one is the dense top level (cc_*: 64 m cells wide)
+  int mg_levels, mg_nx[12], mg_ny[12];
+  size_t mg_off[12], mg_cells;
+  int *mg_d, *mg_rt, *mg_up;         // A_l = P^T A_(l-1) P as 5-point stencils with integer entries: diagonal, coupling to the right, upwards
+  double *mg_rhs, *mg_x;             // right-hand side and result of the V-cycle per level (level 0's result is what k_search_apply adds to z)
+  double* mg_part;                   // [chunks][4][2]: per tile and group of 16 lanes, the sums of r over the fluid cells left / right of the aggregate boundary
+  double* mg_dot;                    // per-block partials of x_0 . rhs_0 (+ the ticket counter behind them)
   int tile_w;             // EULER_PRECOND_IC0_TILE: records per tile (include/euler.h precond_tile_records)
   const double* tile_as_override;   // where A s sits for the r update of the non-tile modes (z behind the first apply_a of a solve, else q)
   double* partial2;       // second set of reduction partials (k_precond_tile reduces max |r| and dot(z,r) at once)
@@ -320,8 +328,9 @@ void eu_p2p_xgran(euler_sim* S, int backward, const unsigned long long** in, uns
 int  eu_p2p_has_neighbour_arrays(const euler_sim* S);
 void eu_p2p_neighbour_arrays(euler_sim* S, const double** z_dn, const double** s_dn, const double** z_up, const double** s_up);
 int eu_install_comm(euler_sim* S, const euler_comm_ops* ops, int32_t coupling, int allow_single);
-static inline bool eu_is_tile(const euler_sim* S) { return S->cfg.precond == EULER_PRECOND_IC0_TILE || S->cfg.precond == EULER_PRECOND_IC0_TILE2; }
-static inline bool eu_is_two_level(const euler_sim* S) { return S->cfg.precond == EULER_PRECOND_IC0_TILE2; }
+static inline bool eu_is_tile(const euler_sim* S) { return S->cfg.precond == EULER_PRECOND_IC0_TILE || S->cfg.precond == EULER_PRECOND_IC0_TILE2 || S->cfg.precond == EULER_PRECOND_IC0_TILE_MG; }
+static inline bool eu_is_two_level(const euler_sim* S) { return S->cfg.precond == EULER_PRECOND_IC0_TILE2 || S->cfg.precond == EULER_PRECOND_IC0_TILE_MG; }   // "has a coarse correction"
+static inline bool eu_is_mg(const euler_sim* S) { return S->cfg.precond == EULER_PRECOND_IC0_TILE_MG; }
 // two-level preconditioner (k_coarse.hip)
 int  eu_coarse_alloc(euler_sim* S);           // lazily, when the mode is first selected
 void eu_coarse_release(euler_sim* S);

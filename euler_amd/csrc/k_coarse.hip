@@ -25,6 +25,9 @@
 
 #define CC_MAX 256          // coarse cells
 #define CC_THREADS 1024
+#define MG_DOT_BLOCKS 1024   // most blocks of the level-0 kernel that closes the V-cycle (its dot partials)
+#define MG_OMEGA 0.8         // damped Jacobi
+#define MG_KAPPA 1.5         // scaling of the coarse-grid correction (plain aggregation under-corrects)
 
 // the scalar epilogues of k_pcg.hip (same codes)
 enum { CFIN_SIGMA_INIT = 0, CFIN_BETA = 3 };
@@ -46,14 +49,32 @@ int eu_coarse_alloc(euler_sim* S) {
   HIPCHK(hipMalloc((void**)&S->cc_y, (2 * CC_MAX + 1) * sizeof(double)));      // y [CC_MAX], r_c [CC_MAX], the ticket counter of k_coarse_solve
   HIPCHK(hipMemset(S->cc_part, 0, (S->chunk_cap + 64) * 3 * sizeof(double)));
   HIPCHK(hipMemset(S->cc_y, 0, (2 * CC_MAX + 1) * sizeof(double)));
+  // the multilevel hierarchy below the dense level: aggregates of 16, 32, ... , 32 m grid cells (k_mg_* below)
+  S->mg_levels = 0; S->mg_cells = 0;
+  for (int g = 16; g < 64 * m; g *= 2) {
+    const int l = S->mg_levels++;
+    S->mg_nx[l] = (S->X + g - 1) / g; S->mg_ny[l] = (S->geom.nbands * 64 + g - 1) / g;      // (rows up to the last band's end: aggregates above Y stay empty)
+    S->mg_off[l] = S->mg_cells; S->mg_cells += (size_t)S->mg_nx[l] * S->mg_ny[l];
+  }
+  HIPCHK(hipMalloc((void**)&S->mg_d, 3 * S->mg_cells * sizeof(int)));
+  S->mg_rt = S->mg_d + S->mg_cells; S->mg_up = S->mg_d + 2 * S->mg_cells;
+  HIPCHK(hipMalloc((void**)&S->mg_rhs, 2 * S->mg_cells * sizeof(double)));
+  S->mg_x = S->mg_rhs + S->mg_cells;
+  HIPCHK(hipMalloc((void**)&S->mg_part, (S->chunk_cap + 64) * 8 * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&S->mg_dot, (MG_DOT_BLOCKS + 1) * sizeof(double)));
+  HIPCHK(hipMemset(S->mg_rhs, 0, 2 * S->mg_cells * sizeof(double)));
+  HIPCHK(hipMemset(S->mg_part, 0, (S->chunk_cap + 64) * 8 * sizeof(double)));
+  HIPCHK(hipMemset(S->mg_dot, 0, (MG_DOT_BLOCKS + 1) * sizeof(double)));
   return EULER_OK;
 }
 
 void eu_coarse_release(euler_sim* S) {
   if (S->cc_diag) (void)hipFree(S->cc_diag);
-  for (double* d : {S->cc_fac, S->cc_inv, S->cc_part, S->cc_y}) if (d) (void)hipFree(d);
+  for (double* d : {S->cc_fac, S->cc_inv, S->cc_part, S->cc_y, S->mg_rhs, S->mg_part, S->mg_dot}) if (d) (void)hipFree(d);
+  if (S->mg_d) (void)hipFree(S->mg_d);
   S->cc_diag = S->cc_right = S->cc_up = nullptr;
   S->cc_fac = S->cc_inv = S->cc_part = S->cc_y = nullptr;
+  S->mg_d = S->mg_rt = S->mg_up = nullptr; S->mg_rhs = S->mg_x = S->mg_part = S->mg_dot = nullptr;
 }
 
 __device__ __forceinline__ int wave_sum_i(int v) {
@@ -208,13 +229,254 @@ __global__ __launch_bounds__(256) void k_coarse_inverse(const double* __restrict
   for (int i = lane; i < n; i += 64) inv[(size_t)c * n + i] = x[i];
 }
 
+// ==========================================================================================
+// Multilevel mode (EULER_PRECOND_IC0_TILE_MG): z = M_tile^-1 r + P_0 V(P_0^T r).  Level l = aggregates of (16 << l)^2 grid cells; A_l as a
+// 5-point stencil with integer entries (d, rt = coupling to the aggregate on the right, up = to the one above); the level above the last is
+// the dense level of the two-level mode.  The oracle's restatement: mg_build / mg_vcycle (oracle/euler_oracle.c), same formulas in the same order.
+//
+// A tile against the aggregates of 16: lane l = 16 j + i sits in aggregate row 4 band + j; its 16 records are the columns 16 (k - j) - i .. + 15:
+// the first i of them lie in aggregate column k - j - 1 ("left"), the other 16 - i in column k - j ("right") - for all 16 lanes of the group alike,
+// so a tile contributes to 4 x 2 aggregates and an aggregate (I, J) collects the right part of tile k = J + j and the left part of tile k = J + j + 1
+// (j = I & 3) of its band.
+__device__ __forceinline__ int group_sum_i(int v) {      // over the 16 lanes of a group
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__global__ __launch_bounds__(256) void k_mg_assemble0(const uint8_t* __restrict__ mask, SkewGeom g, const unsigned int* __restrict__ list, const PcgScalars* sc,
+                                                      int band_lo, int nx0, int* cd, int* cr, int* cu) {
+  const int lane = threadIdx.x & 63, j = lane >> 4, i = lane & 15;
+  const int ntb = g.T / 16, todo = (int)sc->n_chunks;
+  const int n_waves = gridDim.x * 4;
+  for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < todo; w += n_waves) {
+    const int tile = (int)(list[w] & ~EU_CHUNK_INTERIOR);
+    const int band = band_lo + tile / ntb, k = tile % ntb;
+    const size_t base = ((size_t)band * g.TS + (size_t)k * 16) * 64 + 2 * lane;
+    int d[2] = {0, 0}, r[2] = {0, 0}, u[2] = {0, 0};
+#pragma unroll
+    for (int P = 0; P < 8; ++P) {
+      const unsigned int mm = *reinterpret_cast<const unsigned short*>(mask + base + P * 128);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const unsigned int cm = (mm >> (8 * h)) & 0xff;
+        if (!(cm & CM_FLUID)) continue;
+        const int jj = 2 * P + h;                 // column 16 (k - j) + jj - i
+        const int side = jj >= i;
+        int dd = (int)(cm >> CM_DIAG_SHIFT), rr = 0, uu = 0;
+        if (cm & CM_RIGHT) { if (((jj - i + 1) & 15) != 0) dd -= 2; else rr -= 1; }      // the cell to the right opens the next aggregate column
+        if (cm & CM_UP) { if (i != 15) dd -= 2; else uu -= 1; }                             // the cell above opens the next aggregate row
+        d[side] += dd; r[side] += rr; u[side] += uu;
+      }
+    }
+#pragma unroll
+    for (int sd = 0; sd < 2; ++sd) {
+      const int td = group_sum_i(d[sd]), tr = group_sum_i(r[sd]), tu = group_sum_i(u[sd]);
+      const int J = k - j - 1 + sd;
+      if (i == 0 && J >= 0 && J < nx0) {
+        const size_t c = (size_t)(4 * band + j) * nx0 + J;
+        if (td) atomicAdd(&cd[c], td);
+        if (tr) atomicAdd(&cr[c], tr);
+        if (tu) atomicAdd(&cu[c], tu);
+      }
+    }
+  }
+}
+
+// A_(l+1) = P^T A_l P for 2 x 2 aggregation: the couplings inside a parent count twice on its diagonal, those leaving it add up
+__global__ __launch_bounds__(256) void k_mg_coarsen(const int* __restrict__ fd, const int* __restrict__ fr, const int* __restrict__ fu, int fnx, int fny,
+                                                    int* __restrict__ cd, int* __restrict__ cr, int* __restrict__ cu, int cnx, int cny, const PcgScalars* sc) {
+  if (!sc->nonzero) return;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= cnx * cny) return;
+  const int I = p / cnx, J = p % cnx;
+  int d = 0, r = 0, u = 0;
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) {
+      const int ci = 2 * I + a, cj = 2 * J + b;
+      if (ci >= fny || cj >= fnx) continue;
+      const size_t c = (size_t)ci * fnx + cj;
+      d += fd[c];
+      if (b) r += fr[c]; else d += 2 * fr[c];
+      if (a) u += fu[c]; else d += 2 * fu[c];
+    }
+  cd[p] = d; cr[p] = r; cu[p] = u;
+}
+
+struct MgLevel { const int *d, *rt, *up; const double* rhs; int nx, ny; };
+// (A_l v)[c] with v = the Jacobi step from zero, omega rhs / d, optionally + kappa e[parent]: diagonal, right, left, up, down - the oracle's order
+template <bool WITH_E>
+__device__ __forceinline__ double mg_val(const MgLevel& L, const double* __restrict__ e, int enx, int I, int J) {
+  const size_t c = (size_t)I * L.nx + J;
+  const int d = L.d[c];
+  if (!d) return 0.0;
+  double v = MG_OMEGA * L.rhs[c] / (double)d;
+  if (WITH_E) v = v + MG_KAPPA * e[(size_t)(I >> 1) * enx + (J >> 1)];
+  return v;
+}
+template <bool WITH_E>
+__device__ __forceinline__ double mg_apply(const MgLevel& L, const double* __restrict__ e, int enx, int I, int J, double vc) {
+  const size_t c = (size_t)I * L.nx + J;
+  double t = (double)L.d[c] * vc;
+  if (J + 1 < L.nx) t = t + (double)L.rt[c] * mg_val<WITH_E>(L, e, enx, I, J + 1);
+  if (J > 0) t = t + (double)L.rt[c - 1] * mg_val<WITH_E>(L, e, enx, I, J - 1);
+  if (I + 1 < L.ny) t = t + (double)L.up[c] * mg_val<WITH_E>(L, e, enx, I + 1, J);
+  if (I > 0) t = t + (double)L.up[c - L.nx] * mg_val<WITH_E>(L, e, enx, I - 1, J);
+  return t;
+}
+
+// level-0 right-hand side from the tiles' partial sums (right part of tile J + j, then left part of tile J + j + 1)
+__global__ __launch_bounds__(256) void k_mg_gather0(const double* __restrict__ part, double* __restrict__ rhs0, int nx0, int ny0, int ntb, int band_lo, int band_hi,
+                                                    const PcgScalars* sc, int force) {
+  if (!force && (sc->done || !sc->nonzero)) return;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= nx0 * ny0) return;
+  const int I = c / nx0, J = c % nx0, band = I >> 2, j = I & 3;
+  double t = 0.0;
+  if (band >= band_lo && band < band_hi) {
+    const size_t row = (size_t)(band - band_lo) * ntb;
+    const int k0 = J + j, k1 = J + j + 1;
+    if (k0 < ntb) t = part[(row + k0) * 8 + j * 2 + 1];
+    if (k1 < ntb) t = t + part[(row + k1) * 8 + j * 2];
+  }
+  rhs0[c] = t;
+}
+
+// down: the right-hand side of level l + 1 = the restricted residual of level l after its first Jacobi step (children in the order
+// (2I, 2J), (2I, 2J + 1), (2I + 1, 2J), (2I + 1, 2J + 1)); a thread per parent
+__global__ __launch_bounds__(256) void k_mg_down(MgLevel L, double* __restrict__ crhs, int cnx, int cny, const PcgScalars* sc, int force) {
+  if (!force && (sc->done || !sc->nonzero)) return;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= cnx * cny) return;
+  const int I = p / cnx, J = p % cnx;
+  double t = 0.0;
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) {
+      const int ci = 2 * I + a, cj = 2 * J + b;
+      if (ci >= L.ny || cj >= L.nx) continue;
+      const size_t c = (size_t)ci * L.nx + cj;
+      double res = 0.0;
+      if (L.d[c]) res = L.rhs[c] - mg_apply<false>(L, nullptr, 0, ci, cj, mg_val<false>(L, nullptr, 0, ci, cj));
+      t = t + res;
+    }
+  crhs[p] = t;
+}
+
+// the dense level: y = (P^T A P)^-1 rhs, one workgroup (the matrix-vector product of k_coarse_solve)
+__global__ __launch_bounds__(CC_THREADS) void k_mg_top(const double* __restrict__ rhs, const double* __restrict__ inv, double* __restrict__ y, int n,
+                                                       const PcgScalars* sc, int force) {
+  if (!force && (sc->done || !sc->nonzero)) return;
+  __shared__ double s_rc[CC_MAX], s_q[4][CC_MAX];
+  const int tid = threadIdx.x;
+  if (tid < CC_MAX) s_rc[tid] = tid < n ? rhs[tid] : 0.0;
+  __syncthreads();
+  const int row = tid & (CC_MAX - 1), q = tid >> 8;
+  double acc = 0.0;
+  if (row < n)
+    for (int j = q; j < n; j += 64) {
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = j + 4 * u < n ? inv[(size_t)(j + 4 * u) * n + row] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc += v[u] * s_rc[(j + 4 * u) & (CC_MAX - 1)];
+    }
+  s_q[q][row] = acc;
+  __syncthreads();
+  if (tid < n) y[tid] = (s_q[0][tid] + s_q[1][tid]) + (s_q[2][tid] + s_q[3][tid]);
+}
+
+// up: x = x2 + omega (rhs - A x2) / d with x2 = the first Jacobi step + kappa e[parent], e = the level above's result; a thread per cell.
+// LAST (level 0): also the share of dot(z, r) the correction adds, x . rhs, folded per block and by the block that draws the last ticket
+// (block_finish's hand-off), with the scalar epilogue k_precond_tile left open.
+template <bool LAST>
+__global__ __launch_bounds__(256) void k_mg_up(MgLevel L, const double* __restrict__ e, int enx, double* __restrict__ x, PcgScalars* sc, int fin_op, int force,
+                                               double* dot_part, unsigned int* counter) {
+  if (!force && (sc->done || !sc->nonzero)) return;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  double dv = 0.0;
+  if (c < L.nx * L.ny) {
+    const int I = c / L.nx, J = c % L.nx;
+    double xv = 0.0;
+    const int d = L.d[c];
+    if (d) {
+      const double x2 = mg_val<true>(L, e, enx, I, J);
+      xv = x2 + MG_OMEGA * (L.rhs[c] - mg_apply<true>(L, e, enx, I, J, x2)) / (double)d;
+    }
+    x[c] = xv;
+    if (LAST) dv = xv * L.rhs[c];
+  }
+  if (!LAST) return;
+  __shared__ double s_red[4];
+  __shared__ int am_last;
+  dv = eu_wave_sum(dv);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = dv;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(&dot_part[blockIdx.x]), (unsigned long long)__double_as_longlong(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    am_last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!am_last) return;
+  double t = 0.0;
+  for (unsigned int k = threadIdx.x; k < gridDim.x; k += 256)
+    t += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&dot_part[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  t = eu_wave_sum(t);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double v = sc->sigma_new + ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));      // k_precond_tile left dot(z_tile, r) there (FIN_STORE_ONLY)
+    if (fin_op == CFIN_SIGMA_INIT) sc->sigma = v;                                                     // main.c:748
+    else if (fin_op == CFIN_BETA) { sc->sigma_new = v; sc->beta = v / sc->sigma; sc->sigma = v; }     // main.c:762-765
+    else sc->sigma_new = v;
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+static int launch_mg_cycle(euler_sim* S, int fin_op, int force) {
+  const int nl = S->mg_levels;
+  auto level = [&](int l) { const size_t o = S->mg_off[l]; return MgLevel{S->mg_d + o, S->mg_rt + o, S->mg_up + o, S->mg_rhs + o, S->mg_nx[l], S->mg_ny[l]}; };
+  const int n0 = S->mg_nx[0] * S->mg_ny[0];
+  LAUNCH(S, KC_PRECOND_TILE, k_mg_gather0, dim3((n0 + 255) / 256), dim3(256), S->mg_part, S->mg_rhs, S->mg_nx[0], S->mg_ny[0], S->geom.T / 16, S->band_lo, S->band_hi, S->sc, force);
+  double* top_rhs = S->cc_y + CC_MAX;
+  for (int l = 0; l < nl; ++l) {
+    const bool top = l + 1 == nl;
+    const int cnx = top ? S->coarse_nx : S->mg_nx[l + 1], cny = top ? S->coarse_ny : S->mg_ny[l + 1];
+    LAUNCH(S, KC_PRECOND_TILE, k_mg_down, dim3(((size_t)cnx * cny + 255) / 256), dim3(256), level(l), top ? top_rhs : S->mg_rhs + S->mg_off[l + 1], cnx, cny, S->sc, force);
+  }
+  LAUNCH(S, KC_PRECOND_TILE, k_mg_top, dim3(1), dim3(CC_THREADS), top_rhs, S->cc_inv, S->cc_y, S->coarse_n, S->sc, force);
+  for (int l = nl - 1; l >= 0; --l) {
+    const bool top = l + 1 == nl;
+    const double* e = top ? S->cc_y : S->mg_x + S->mg_off[l + 1];
+    const int enx = top ? S->coarse_nx : S->mg_nx[l + 1];
+    const unsigned nb = (unsigned)(((size_t)S->mg_nx[l] * S->mg_ny[l] + 255) / 256);
+    if (l > 0) LAUNCH(S, KC_PRECOND_TILE, k_mg_up<false>, dim3(nb), dim3(256), level(l), e, enx, S->mg_x + S->mg_off[l], S->sc, fin_op, force, (double*)nullptr, (unsigned int*)nullptr);
+    else LAUNCH(S, KC_PRECOND_TILE, k_mg_up<true>, dim3(nb), dim3(256), level(l), e, enx, S->mg_x, S->sc, fin_op, force, S->mg_dot, reinterpret_cast<unsigned int*>(S->mg_dot + MG_DOT_BLOCKS));
+  }
+  return EULER_OK;
+}
+
 int eu_launch_coarse_setup(euler_sim* S) {
   const int n = S->coarse_n;
   HIPCHK(hipMemsetAsync(S->cc_diag, 0, 3 * (size_t)n * sizeof(int), S->stream));
-  HIPCHK(hipMemsetAsync(S->cc_part, 0, (S->chunk_cap + 64) * 3 * sizeof(double), S->stream));      // (tiles outside this solve's list contribute nothing)
   const unsigned nblk = eu_blocks(S->chunk_cap, 4, 2048);
+  if (eu_is_mg(S) && S->mg_levels > 0) {      // level 0 from the cells, every further level (and the dense one) from the level below
+    HIPCHK(hipMemsetAsync(S->mg_d, 0, 3 * S->mg_cells * sizeof(int), S->stream));
+    HIPCHK(hipMemsetAsync(S->mg_part, 0, (S->chunk_cap + 64) * 8 * sizeof(double), S->stream));      // (tiles outside this solve's list contribute nothing)
+    LAUNCH(S, KC_PRECON_FACTOR, k_mg_assemble0, dim3(nblk), dim3(256), S->cellmask, S->geom, S->chunk_list, S->sc, S->band_lo, S->mg_nx[0], S->mg_d, S->mg_rt, S->mg_up);
+    for (int l = 1; l <= S->mg_levels; ++l) {
+      const bool top = l == S->mg_levels;
+      const int cnx = top ? S->coarse_nx : S->mg_nx[l], cny = top ? S->coarse_ny : S->mg_ny[l];
+      const size_t fo = S->mg_off[l - 1], co = top ? 0 : S->mg_off[l];
+      LAUNCH(S, KC_PRECON_FACTOR, k_mg_coarsen, dim3(((size_t)cnx * cny + 255) / 256), dim3(256), S->mg_d + fo, S->mg_rt + fo, S->mg_up + fo, S->mg_nx[l - 1], S->mg_ny[l - 1],
+             top ? S->cc_diag : S->mg_d + co, top ? S->cc_right : S->mg_rt + co, top ? S->cc_up : S->mg_up + co, cnx, cny, S->sc);
+    }
+  } else {
+  HIPCHK(hipMemsetAsync(S->cc_part, 0, (S->chunk_cap + 64) * 3 * sizeof(double), S->stream));      // (tiles outside this solve's list contribute nothing)
   LAUNCH(S, KC_PRECON_FACTOR, k_coarse_assemble, dim3(nblk), dim3(256), S->cellmask, S->geom, S->chunk_list, S->sc, S->band_lo, S->coarse_shift,
          S->coarse_m, S->coarse_nx, S->cc_diag, S->cc_right, S->cc_up);
+  }
   const int bw = S->coarse_ny > 1 ? S->coarse_nx : 1;      // half-bandwidth of P^T A P in row-major order of the coarse cells
   LAUNCH(S, KC_PRECON_FACTOR, k_coarse_factor, dim3(1), dim3(CC_THREADS), S->cc_diag, S->cc_right, S->cc_up, n, S->coarse_nx, bw, S->cc_fac, S->sc);
   LAUNCH(S, KC_PRECON_FACTOR, k_coarse_inverse, dim3((n + 3) / 4), dim3(256), S->cc_fac, n, bw, S->cc_inv, S->sc);
@@ -300,6 +562,7 @@ __global__ __launch_bounds__(CC_THREADS) void k_coarse_solve(const double* __res
 }
 
 int eu_launch_coarse_solve(euler_sim* S, int fin_op, int force) {
+  if (eu_is_mg(S) && S->mg_levels > 0) return launch_mg_cycle(S, fin_op, force);
   LAUNCH(S, KC_PRECOND_TILE, k_coarse_solve, dim3(S->coarse_n), dim3(CC_THREADS), S->cc_part, S->cc_inv, S->cc_y, S->cc_y + CC_MAX,
          reinterpret_cast<unsigned int*>(S->cc_y + 2 * CC_MAX), S->sc, fin_op, force, S->coarse_n, S->coarse_nx, S->coarse_m, S->coarse_shift,
          S->geom.T / 16, S->band_lo, S->band_hi);
@@ -308,21 +571,22 @@ int eu_launch_coarse_solve(euler_sim* S, int fin_op, int force) {
 
 // ---- the first search direction of a solve: s = z + P y (the memcpy at main.c:746, with the coarse part of z added on fluid cells)
 __global__ __launch_bounds__(256) void k_coarse_search_init(double* __restrict__ s, const double* __restrict__ z, const uint8_t* __restrict__ mask,
-                                                            const double* __restrict__ y, SkewGeom g, int shift, int m, int nx, const PcgScalars* sc) {
+                                                            const double* __restrict__ y, SkewGeom g, int shift, int nx, const PcgScalars* sc) {
   if (sc->done || !sc->nonzero) return;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < g.S; e += (size_t)gridDim.x * blockDim.x) {
     double v = z[e];
     if (mask[e] & CM_FLUID) {
       int band, t, l;
       skew_decode(g, e, band, t, l);
-      v = v + y[(band / m) * nx + ((t - l) >> shift)];
+      v = v + y[(size_t)((band * 64 + l) >> shift) * nx + ((t - l) >> shift)];
     }
     s[e] = v;
   }
 }
 
 int eu_launch_coarse_search_init(euler_sim* S) {
-  LAUNCH(S, KC_UPDATE_SEARCH, k_coarse_search_init, dim3(eu_blocks(S->geom.S, 256 * 4, 4096)), dim3(256), S->s, S->z, S->cellmask, S->cc_y, S->geom,
-         S->coarse_shift, S->coarse_m, S->coarse_nx, S->sc);
+  const bool mg = eu_is_mg(S) && S->mg_levels > 0;
+  LAUNCH(S, KC_UPDATE_SEARCH, k_coarse_search_init, dim3(eu_blocks(S->geom.S, 256 * 4, 4096)), dim3(256), S->s, S->z, S->cellmask, mg ? S->mg_x : S->cc_y, S->geom,
+         mg ? 4 : S->coarse_shift, mg ? S->mg_nx[0] : S->coarse_nx, S->sc);
   return EULER_OK;
 }

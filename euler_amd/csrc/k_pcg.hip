@@ -333,7 +333,13 @@ struct SaPair { sw_d2 z, so; double ez0, es0, ez1, es1; };   // one pair-record 
 // of the active-chunk list); 16 / 32 remain for experiments (sa_run)
 // COARSE (two-level preconditioner, k_coarse.hip): z stands for z + P y wherever s' = z + beta s is formed - y of the cell's coarse
 // cell is looked up (a lane's columns of one run cross at most one coarse column boundary) and added first, like the oracle's z += P y.
-struct CoarseRef { const double* y; int shift, m, nx, band0; };   // band0: the global index of the arrays' band 0
+__device__ __forceinline__ double pick3(int t, int tb1, int tb2, double v0, double v1, double v2) {
+  double v = v0;
+  v = t >= tb1 ? v1 : v;
+  v = t >= tb2 ? v2 : v;
+  return v;
+}
+struct CoarseRef { const double* y; int shift, nx, ny, band0; };   // y[ny][nx] over aggregates of (1 << shift)^2 grid cells; band0: the global index of the arrays' band 0
 template <int SLAB, int PMODE, int SA_RUN, bool COARSE = false>   // SLAB 1: several ranks, the neighbouring slabs' arrays are mapped; 2: their edge rows as compact rows (nbr); 0: nbr is ignored
 __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __restrict__ s_old, const double* __restrict__ z,
                                                              double* __restrict__ s_new, double* __restrict__ out,
@@ -395,23 +401,29 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
       const double* gs = lane == 0 ? nbr.srow_dn : nbr.srow_up;
       double* gsn = lane == 0 ? nbr.snew_dn : nbr.snew_up;
       const int gcol = lane == 0 ? 0 : -63;
-      // COARSE: this lane's columns in the run (pairs P0 - 1 .. P1: 20 records at most) start in coarse column Ja and reach Ja + 1 at record tb
-      double cya = 0.0, cyb = 0.0, cea = 0.0, ceb = 0.0;
-      int ctb = 0x7fffffff;
+      // COARSE: this lane's columns in the run (pairs P0 - 1 .. P1: 20 records at most) start in aggregate column Ja, reach Ja + 1 at record
+      // tb1 and Ja + 2 at record tb2 (aggregates of 16: three columns; of 64 and more: two); the lane's row decides the aggregate row
+      double cy0 = 0.0, cy1 = 0.0, cy2 = 0.0, ce0 = 0.0, ce1 = 0.0, ce2 = 0.0;
+      int ctb1 = 0x7fffffff, ctb2 = 0x7fffffff;
       if (COARSE) {
         const int xa = 2 * (P0 - 1) - lane, Ja = (xa > 0 ? xa : 0) >> cref.shift;
-        const int I = (cref.band0 + lb) / cref.m;
-        ctb = ((Ja + 1) << cref.shift) + lane;
-        cya = cref.y[I * cref.nx + Ja];
-        cyb = Ja + 1 < cref.nx ? cref.y[I * cref.nx + Ja + 1] : 0.0;
-        if (edge_lane) {      // the row across the band boundary may belong to the neighbouring coarse row (same columns)
-          const int Ie = (cref.band0 + lb + (lane == 0 ? -1 : 1)) / cref.m;
-          const bool inside = cref.band0 + lb + (lane == 0 ? -1 : 1) >= 0;
-          cea = inside ? cref.y[Ie * cref.nx + Ja] : 0.0;
-          ceb = (inside && Ja + 1 < cref.nx) ? cref.y[Ie * cref.nx + Ja + 1] : 0.0;
+        const int row = (cref.band0 + lb) * 64 + lane;
+        const size_t I = (size_t)(row >> cref.shift) * cref.nx;
+        ctb1 = ((Ja + 1) << cref.shift) + lane;
+        ctb2 = ((Ja + 2) << cref.shift) + lane;
+        cy0 = Ja < cref.nx ? cref.y[I + Ja] : 0.0;
+        cy1 = Ja + 1 < cref.nx ? cref.y[I + Ja + 1] : 0.0;
+        cy2 = Ja + 2 < cref.nx ? cref.y[I + Ja + 2] : 0.0;
+        if (edge_lane) {      // the row across the band boundary may belong to the neighbouring aggregate row (same columns)
+          const int re = row + (lane == 0 ? -1 : 1);
+          const bool inside = re >= 0 && (re >> cref.shift) < cref.ny;
+          const size_t Ie = (size_t)((inside ? re : row) >> cref.shift) * cref.nx;
+          ce0 = (inside && Ja < cref.nx) ? cref.y[Ie + Ja] : 0.0;
+          ce1 = (inside && Ja + 1 < cref.nx) ? cref.y[Ie + Ja + 1] : 0.0;
+          ce2 = (inside && Ja + 2 < cref.nx) ? cref.y[Ie + Ja + 2] : 0.0;
         }
       }
-      auto load_pair = [&](int P, SaPair& d, unsigned int m) {
+      auto load_pair = [&](int P, SaPair& d, unsigned int m) __attribute__((always_inline)) {
         d.ez0 = d.es0 = d.ez1 = d.es1 = 0.0;
         if (P < 0 || P >= npairs) { d.z = sw_d2{0.0, 0.0}; d.so = sw_d2{0.0, 0.0}; return; }   // outside the band: never a fluid cell's neighbour
 #ifdef SA_ABL_NO_WINDOW       // timing experiment (WRONG results): the pairs before / after the run are not loaded
@@ -435,16 +447,16 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
             else if (SLAB == 1 && remote) { d.ez1 = ld_system(ez + k); d.es1 = ld_system(es + k); } else { d.ez1 = ez[k]; d.es1 = es[k]; }
           }
           if (COARSE) {      // (harmless where nothing was loaded: the value is then never selected)
-            d.ez0 = d.ez0 + (2 * P >= ctb ? ceb : cea);
-            d.ez1 = d.ez1 + (2 * P + 1 >= ctb ? ceb : cea);
+            d.ez0 = d.ez0 + pick3(2 * P, ctb1, ctb2, ce0, ce1, ce2);
+            d.ez1 = d.ez1 + pick3(2 * P + 1, ctb1, ctb2, ce0, ce1, ce2);
           }
         }
         if (COARSE) {        // z + P y of the lane's own two cells (records 2P, 2P + 1)
-          d.z.x = d.z.x + (2 * P >= ctb ? cyb : cya);
-          d.z.y = d.z.y + (2 * P + 1 >= ctb ? cyb : cya);
+          d.z.x = d.z.x + pick3(2 * P, ctb1, ctb2, cy0, cy1, cy2);
+          d.z.y = d.z.y + pick3(2 * P + 1, ctb1, ctb2, cy0, cy1, cy2);
         }
       };
-      auto sprime = [&](const SaPair& d) { return sw_d2{d.z.x + beta * d.so.x, d.z.y + beta * d.so.y}; };   // s' = z + beta s (main.c:674)
+      auto sprime = [&](const SaPair& d) __attribute__((always_inline)) { return sw_d2{d.z.x + beta * d.so.x, d.z.y + beta * d.so.y}; };   // s' = z + beta s (main.c:674)
       SaPair A, B, Cn;
       load_pair(P0 - 1, A, 0u);
       load_pair(P0, B, mm[0]);
@@ -1364,7 +1376,19 @@ __global__ __launch_bounds__(PT_THREADS) void k_precond_tile(TileArgs a) {
         }
       }
       if (!a.sweeps) return;
-      if (W == 16 && a.cpart) {      // P^T r of this tile: cell (lane, record k W + j) sits in column k W + j - lane; at most three coarse columns per tile
+      if (W == 16 && a.cpart && a.cshift == 4) {      // multilevel mode: aggregates of 16 - per group of 16 lanes, the cells left / right of the group's aggregate boundary (k_coarse.hip)
+        const int i16 = lane & 15;
+        double sl = 0.0, sr = 0.0;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          const int cm = (int)((mm[j >> 1] >> ((j & 1) * 8)) & 0xff);
+          const double rv = (cm & CM_FLUID) ? ((j & 1) ? rr[j >> 1].y : rr[j >> 1].x) : 0.0;
+          if (j < i16) sl += rv; else sr += rv;
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { sl += __shfl_xor(sl, o, 64); sr += __shfl_xor(sr, o, 64); }
+        if (i16 == 0) { double* cp = a.cpart + (size_t)tile * 8 + (lane >> 4) * 2; cp[0] = sl; cp[1] = sr; }
+      } else if (W == 16 && a.cpart) {      // P^T r of this tile: cell (lane, record k W + j) sits in column k W + j - lane; at most three coarse columns per tile
         const int xl = k * W - 63, J0 = (xl > 0 ? xl : 0) >> a.cshift;
         double c0 = 0.0, c1 = 0.0, c2 = 0.0;
 #pragma unroll
@@ -1791,7 +1815,11 @@ static int launch_precond_tile(euler_sim* S, int rupd, int sweeps, int fin_dot, 
   // share and applies the epilogue
   const bool two_level = eu_is_two_level(S) && sweeps && !r_only && !force && a.list != nullptr;
   const int fin_real = a.fin_dot;
-  if (two_level) { a.cpart = S->cc_part; a.cshift = S->coarse_shift; if (a.fin_dot >= 0) a.fin_dot = FIN_STORE_ONLY; }
+  if (two_level) {
+    const bool mg = eu_is_mg(S) && S->mg_levels > 0;
+    a.cpart = mg ? S->mg_part : S->cc_part; a.cshift = mg ? 4 : S->coarse_shift;
+    if (a.fin_dot >= 0) a.fin_dot = FIN_STORE_ONLY;
+  }
   const int w = r_only ? 16 : S->tile_w, cls = r_only ? KC_UPDATE_PR : KC_PRECOND_TILE;
   const unsigned nblk = eu_blocks((size_t)(S->band_hi - S->band_lo) * (S->geom.T / w), PT_THREADS / 64, 2048);
   switch (w) {
@@ -1910,7 +1938,8 @@ static int launch_search_apply_and_alpha(euler_sim* S, int it) {
   const int run = sa_run(S);
   const int fin = S->has_comm ? fin_or_comm(S, FIN_ALPHA) : (seq ? -1 : (int)FIN_ALPHA);
   double* pp = LOC(S->p);
-  const CoarseRef cref = {S->cc_y, S->coarse_shift, S->coarse_m, S->coarse_nx, S->band_lo};
+  const bool mg = eu_is_mg(S) && S->mg_levels > 0;
+  const CoarseRef cref = {mg ? S->mg_x : S->cc_y, mg ? 4 : S->coarse_shift, mg ? S->mg_nx[0] : S->coarse_nx, mg ? S->mg_ny[0] : S->coarse_ny, S->band_lo};
 #define SA_LAUNCH_C(SLABF, PM, RUNV, CF)                                                                                                \
   LAUNCH(S, KC_APPLY_A, (k_search_apply<SLABF, PM, RUNV, CF>), dim3(sa_blocks(S, RUNV)), dim3(SA_THREADS), LOC(S->s), LOC(S->z), LOC(S->s2), \
          LOC(S->q), LOC(S->cellmask), gl, S->partial, S->sc, 0, S->red_counter, fin, nbr, pp, S->s2, S->s, (RUNV) == 8 ? S->chunk_list : (const unsigned int*)nullptr, cref)
@@ -2072,7 +2101,7 @@ int eu_launch_pcg_op(euler_sim* S, int op, float dt, double a, double* out) {
   const size_t SS = S->geom.S;
   if (eu_is_two_level(S) && (op == EULER_OP_PRECON_FACTOR || op == EULER_OP_FORWARD_SOLVE || op == EULER_OP_BACKWARD_SOLVE)) {
     // the coarse level is assembled over a solve's chunk list and lives in the solve: a single forced operation would return the tile level alone
-    eu_set_error("euler_pcg_op: the preconditioner of EULER_PRECOND_IC0_TILE2 is not available as a single operation (select EULER_PRECOND_IC0_TILE for its tile level)");
+    eu_set_error("euler_pcg_op: the preconditioner of EULER_PRECOND_IC0_TILE2 / _MG is not available as a single operation (select EULER_PRECOND_IC0_TILE for its tile level)");
     return EULER_EINVAL;
   }
   switch (op) {

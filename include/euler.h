@@ -56,7 +56,7 @@ enum {
                                 instead of latency-bound, and nothing couples row slabs.  NOT the reference's iterates: the same
                                 solution where PCG converges (tolerance parity), ~25-35 % more iterations (tools/precond_study.py).
                                 Restated in the oracle (eo_sim.tile_records): GPU = oracle bit for bit in EULER_DOT_SEQUENTIAL. */
-  EULER_PRECOND_IC0_TILE2 = 3 /* TWO-LEVEL (round 3): the tile-local IC(0) above (64 x 16 blocks) plus a coarse correction,
+  EULER_PRECOND_IC0_TILE2 = 3,/* TWO-LEVEL (round 3): the tile-local IC(0) above (64 x 16 blocks) plus a coarse correction,
                                     z = M_tile^-1 r + P (P^T A P)^-1 P^T r,
                                 P = piecewise constants over coarse cells of (64 m)^2 grid cells restricted to the fluid, m the smallest
                                 power of two that leaves at most 256 coarse cells (16 x 16 of them on a square grid).  The block-local
@@ -68,6 +68,15 @@ enum {
                                 in) + one small launch.  NOT the reference's iterates; symmetric positive definite, so PCG converges to the same
                                 solution.  Restated in the oracle (eo_sim.coarse_m): GPU = oracle to rounding (tolerance, not bits: the
                                 coarse sums are formed in another order).  One GPU only; EULER_DOT_TREE. */
+  EULER_PRECOND_IC0_TILE_MG = 4 /* MULTILEVEL (round 3): the same, with the coarse correction taken from a hierarchy instead of one level,
+                                    z = M_tile^-1 r + P_0 V(P_0^T r),
+                                P_0 = piecewise constants over aggregates of 16 x 16 grid cells (the tile width) restricted to the fluid, V = one
+                                symmetric V-cycle over 2 x 2 aggregations 16 -> 32 -> ... -> 64 m (Galerkin 5-point stencils with integer
+                                entries; damped Jacobi 0.8 before and after, correction scaled by 1.5), the top level (<= 256 cells) solved
+                                with the dense inverse of the two-level mode.  The number of iterations to the reference's tolerance no longer
+                                grows with the grid: ~100-130 where the reference's IC(0) needs 231 (256^2), 880 (1024^2), thousands (8192^2).
+                                Cost per iteration: the tile-local mode's two passes + a dozen launches over arrays 256 times smaller than
+                                the grid.  Restated in the oracle (eo_sim.coarse_mg): GPU = oracle to rounding.  One GPU only; EULER_DOT_TREE. */
 };
 
 /* IC(0) sweep implementation (same arithmetic, different schedule). */

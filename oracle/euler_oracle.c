@@ -51,6 +51,7 @@ eo_sim* eo_create(int X, int Y) {
   return s;
 }
 
+static void mg_free(eo_sim* s);
 void eo_destroy(eo_sim* s) {
   if (!s) return;
   free(s->u); free(s->v); free(s->utmp); free(s->vtmp);
@@ -59,6 +60,7 @@ void eo_destroy(eo_sim* s) {
   free(s->b); free(s->p); free(s->r); free(s->z); free(s->s);
   free(s->cr); free(s->cg); free(s->cb); free(s->crtmp); free(s->cgtmp); free(s->cbtmp);
   free(s->coarse_chol);
+  mg_free(s);
   free(s);
 }
 
@@ -436,6 +438,7 @@ float eo_calculate_timestep(const eo_sim* s, float frame_time) {
 
 void eo_build_system(eo_sim* s, float dt, const float* u, const float* v) {
   free(s->coarse_chol); s->coarse_chol = NULL;      /* a new system: the coarse factor (two-level extension) is recomputed on demand */
+  mg_free(s);
   int X = s->X, Y = s->Y;
   size_t C = (size_t)X * (size_t)Y;
   const double k_inv_scale = (H_CELL * H_CELL) * DENSITY / dt; /* float expr widened, main.c:713 */
@@ -505,35 +508,32 @@ int eo_coarse_m(int X, int Y) {
   while (((X + 64 * m - 1) / (64 * m)) * ((Y + 64 * m - 1) / (64 * m)) > 256) m *= 2;
   return m;
 }
-static void coarse_correction(eo_sim* s, const double* r, double* z) {
+static void coarse_factor(eo_sim* s) {      /* A_c = P^T A P: sums of A's entries over pairs of coarse cells, then its Cholesky factor */
   const int X = s->X, Y = s->Y, g = 64 * s->coarse_m;
   const int nx = (X + g - 1) / g, ny = (Y + g - 1) / g, n = nx * ny;
-  if (!s->coarse_chol) {      /* A_c = P^T A P: sums of A's entries over pairs of coarse cells, then its Cholesky factor */
-    double* A = (double*)calloc((size_t)n * n, sizeof(double));
-    for (int y = 0; y < Y; ++y)
-      for (int x = 0; x < X; ++x) {
-        if (!FLUID(s, y, x)) continue;
-        const int c = (y / g) * nx + x / g;
-        A[(size_t)c * n + c] += s->a_diag[AT(s, y, x)];
-        if (FLUID(s, y, x + 1)) { const int d = (y / g) * nx + (x + 1) / g; A[(size_t)c * n + d] -= 1; A[(size_t)d * n + c] -= 1; }
-        if (FLUID(s, y + 1, x)) { const int d = ((y + 1) / g) * nx + x / g; A[(size_t)c * n + d] -= 1; A[(size_t)d * n + c] -= 1; }
-      }
-    for (int c = 0; c < n; ++c) if (A[(size_t)c * n + c] == 0.0) A[(size_t)c * n + c] = 1.0;      /* a coarse cell without fluid */
-    for (int k = 0; k < n; ++k) {      /* in place, lower triangle (banded: entries beyond column distance nx stay 0) */
-      const double d = sqrt(A[(size_t)k * n + k]);
-      A[(size_t)k * n + k] = d;
-      const int hi = k + nx < n - 1 ? k + nx : n - 1;
-      for (int i = k + 1; i <= hi; ++i) A[(size_t)i * n + k] /= d;
-      for (int j = k + 1; j <= hi; ++j)
-        for (int i = j; i <= hi; ++i) A[(size_t)i * n + j] -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
-    }
-    s->coarse_chol = A; s->coarse_n = n; s->coarse_nx = nx;
-  }
-  const double* L = s->coarse_chol;
-  double* rc = (double*)calloc((size_t)n, sizeof(double));
+  double* A = (double*)calloc((size_t)n * n, sizeof(double));
   for (int y = 0; y < Y; ++y)
-    for (int x = 0; x < X; ++x)
-      if (FLUID(s, y, x)) rc[(y / g) * nx + x / g] += r[AT(s, y, x)];
+    for (int x = 0; x < X; ++x) {
+      if (!FLUID(s, y, x)) continue;
+      const int c = (y / g) * nx + x / g;
+      A[(size_t)c * n + c] += s->a_diag[AT(s, y, x)];
+      if (FLUID(s, y, x + 1)) { const int d = (y / g) * nx + (x + 1) / g; A[(size_t)c * n + d] -= 1; A[(size_t)d * n + c] -= 1; }
+      if (FLUID(s, y + 1, x)) { const int d = ((y + 1) / g) * nx + x / g; A[(size_t)c * n + d] -= 1; A[(size_t)d * n + c] -= 1; }
+    }
+  for (int c = 0; c < n; ++c) if (A[(size_t)c * n + c] == 0.0) A[(size_t)c * n + c] = 1.0;      /* a coarse cell without fluid */
+  for (int k = 0; k < n; ++k) {      /* in place, lower triangle (banded: entries beyond column distance nx stay 0) */
+    const double d = sqrt(A[(size_t)k * n + k]);
+    A[(size_t)k * n + k] = d;
+    const int hi = k + nx < n - 1 ? k + nx : n - 1;
+    for (int i = k + 1; i <= hi; ++i) A[(size_t)i * n + k] /= d;
+    for (int j = k + 1; j <= hi; ++j)
+      for (int i = j; i <= hi; ++i) A[(size_t)i * n + j] -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+  }
+  s->coarse_chol = A; s->coarse_n = n; s->coarse_nx = nx;
+}
+static void coarse_top_solve(eo_sim* s, double* rc) {      /* rc <- (P^T A P)^-1 rc by the two banded substitutions */
+  const int n = s->coarse_n, nx = s->coarse_nx;
+  const double* L = s->coarse_chol;
   for (int i = 0; i < n; ++i) {      /* L w = r_c */
     double t = rc[i];
     for (int j = i - nx > 0 ? i - nx : 0; j < i; ++j) t -= L[(size_t)i * n + j] * rc[j];
@@ -545,16 +545,130 @@ static void coarse_correction(eo_sim* s, const double* r, double* z) {
     for (int j = i + 1; j <= hi; ++j) t -= L[(size_t)j * n + i] * rc[j];
     rc[i] = t / L[(size_t)i * n + i];
   }
+}
+static void coarse_correction(eo_sim* s, const double* r, double* z) {
+  const int X = s->X, Y = s->Y, g = 64 * s->coarse_m;
+  if (!s->coarse_chol) coarse_factor(s);
+  const int nx = s->coarse_nx, n = s->coarse_n;
+  double* rc = (double*)calloc((size_t)n, sizeof(double));
+  for (int y = 0; y < Y; ++y)
+    for (int x = 0; x < X; ++x)
+      if (FLUID(s, y, x)) rc[(y / g) * nx + x / g] += r[AT(s, y, x)];
+  coarse_top_solve(s, rc);
   for (int y = 0; y < Y; ++y)
     for (int x = 0; x < X; ++x)
       if (FLUID(s, y, x)) z[AT(s, y, x)] += rc[(y / g) * nx + x / g];
   free(rc);
 }
 
+/* EXTENSION (multilevel, euler_oracle.h coarse_mg): z += P_0 V(P_0^T r).  Level l: aggregates of (16 << l)^2 grid cells, nx x ny of them;
+ * A_l as a 5-point stencil: d (diagonal), rt (coupling to the aggregate on the right, <= 0), up (to the one above). */
+typedef struct { int nx, ny; int *d, *rt, *up; double *rhs, *x, *t; } mg_level;
+typedef struct { int nlev; mg_level lv[16]; } mg_hierarchy;
+#define MG_OMEGA 0.8
+#define MG_KAPPA 1.5
+static void mg_free(eo_sim* s) {
+  mg_hierarchy* h = (mg_hierarchy*)s->mg;
+  if (!h) return;
+  for (int l = 0; l < h->nlev; ++l) { free(h->lv[l].d); free(h->lv[l].rhs); }
+  free(h); s->mg = NULL;
+}
+static void mg_alloc_level(mg_level* L, int nx, int ny) {
+  const size_t n = (size_t)nx * ny;
+  L->nx = nx; L->ny = ny;
+  L->d = (int*)calloc(3 * n, sizeof(int)); L->rt = L->d + n; L->up = L->d + 2 * n;
+  L->rhs = (double*)calloc(3 * n, sizeof(double)); L->x = L->rhs + n; L->t = L->rhs + 2 * n;
+}
+static void mg_build(eo_sim* s) {
+  const int X = s->X, Y = s->Y, gtop = 64 * s->coarse_m;
+  mg_hierarchy* h = (mg_hierarchy*)calloc(1, sizeof(mg_hierarchy));
+  int g = 16, l = 0;
+  for (;; g *= 2, ++l) { mg_alloc_level(&h->lv[l], (X + g - 1) / g, (Y + g - 1) / g); if (g >= gtop) break; }
+  h->nlev = l + 1;
+  mg_level* L0 = &h->lv[0];
+  for (int y = 0; y < Y; ++y)      /* A_0 = P_0^T A P_0: sums of A's entries over pairs of aggregates */
+    for (int x = 0; x < X; ++x) {
+      if (!FLUID(s, y, x)) continue;
+      const int c = (y >> 4) * L0->nx + (x >> 4);
+      L0->d[c] += s->a_diag[AT(s, y, x)];
+      if (FLUID(s, y, x + 1)) { if (((x + 1) >> 4) == (x >> 4)) L0->d[c] -= 2; else L0->rt[c] -= 1; }
+      if (FLUID(s, y + 1, x)) { if (((y + 1) >> 4) == (y >> 4)) L0->d[c] -= 2; else L0->up[c] -= 1; }
+    }
+  for (int k = 1; k < h->nlev; ++k) {      /* A_k = P^T A_(k-1) P, 2 x 2 aggregation */
+    const mg_level* F = &h->lv[k - 1]; mg_level* C = &h->lv[k];
+    for (int I = 0; I < F->ny; ++I)
+      for (int J = 0; J < F->nx; ++J) {
+        const int c = I * F->nx + J, p = (I >> 1) * C->nx + (J >> 1);
+        C->d[p] += F->d[c];
+        if (J & 1) C->rt[p] += F->rt[c]; else C->d[p] += 2 * F->rt[c];      /* (rt of the last column is 0) */
+        if (I & 1) C->up[p] += F->up[c]; else C->d[p] += 2 * F->up[c];
+      }
+  }
+  s->mg = h;
+}
+/* (A_l v)[c] in this order: diagonal, right, left, up, down */
+static double mg_apply(const mg_level* L, const double* v, int I, int J) {
+  const int c = I * L->nx + J;
+  double t = (double)L->d[c] * v[c];
+  if (J + 1 < L->nx) t = t + (double)L->rt[c] * v[c + 1];
+  if (J > 0) t = t + (double)L->rt[c - 1] * v[c - 1];
+  if (I + 1 < L->ny) t = t + (double)L->up[c] * v[c + L->nx];
+  if (I > 0) t = t + (double)L->up[c - L->nx] * v[c - L->nx];
+  return t;
+}
+static void coarse_top_solve(eo_sim* s, double* rc);
+static void mg_vcycle(eo_sim* s, mg_hierarchy* h, int l) {      /* lv[l].x = V_l lv[l].rhs */
+  mg_level* L = &h->lv[l];
+  const int n = L->nx * L->ny;
+  if (l == h->nlev - 1) { memcpy(L->x, L->rhs, (size_t)n * sizeof(double)); coarse_top_solve(s, L->x); return; }
+  mg_level* C = &h->lv[l + 1];
+  for (int c = 0; c < n; ++c) L->x[c] = L->d[c] ? MG_OMEGA * L->rhs[c] / (double)L->d[c] : 0.0;      /* Jacobi from a zero guess */
+  memset(C->rhs, 0, (size_t)C->nx * C->ny * sizeof(double));
+  for (int I = 0; I < L->ny; ++I)      /* restricted residual; children in the order (2I, 2J), (2I, 2J+1), (2I+1, 2J), (2I+1, 2J+1) */
+    for (int J = 0; J < L->nx; ++J) L->t[I * L->nx + J] = L->d[I * L->nx + J] ? L->rhs[I * L->nx + J] - mg_apply(L, L->x, I, J) : 0.0;
+  for (int I = 0; I < C->ny; ++I)
+    for (int J = 0; J < C->nx; ++J) {
+      double t = 0.0;
+      for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b)
+          if (2 * I + a < L->ny && 2 * J + b < L->nx) t = t + L->t[(2 * I + a) * L->nx + 2 * J + b];
+      C->rhs[I * C->nx + J] = t;
+    }
+  mg_vcycle(s, h, l + 1);
+  for (int I = 0; I < L->ny; ++I)      /* the correction, scaled */
+    for (int J = 0; J < L->nx; ++J) {
+      const int c = I * L->nx + J;
+      L->x[c] = L->d[c] ? L->x[c] + MG_KAPPA * C->x[(I >> 1) * C->nx + (J >> 1)] : 0.0;
+    }
+  for (int I = 0; I < L->ny; ++I)      /* Jacobi again */
+    for (int J = 0; J < L->nx; ++J) {
+      const int c = I * L->nx + J;
+      L->t[c] = L->d[c] ? L->x[c] + MG_OMEGA * (L->rhs[c] - mg_apply(L, L->x, I, J)) / (double)L->d[c] : 0.0;
+    }
+  memcpy(L->x, L->t, (size_t)n * sizeof(double));
+}
+static void coarse_factor(eo_sim* s);
+static void mg_correction(eo_sim* s, const double* r, double* z) {
+  const int X = s->X, Y = s->Y;
+  if (!s->coarse_chol) coarse_factor(s);
+  if (!s->mg) mg_build(s);
+  mg_hierarchy* h = (mg_hierarchy*)s->mg;
+  mg_level* L0 = &h->lv[0];
+  memset(L0->rhs, 0, (size_t)L0->nx * L0->ny * sizeof(double));
+  for (int y = 0; y < Y; ++y)
+    for (int x = 0; x < X; ++x)
+      if (FLUID(s, y, x)) L0->rhs[(y >> 4) * L0->nx + (x >> 4)] += r[AT(s, y, x)];
+  mg_vcycle(s, h, 0);
+  for (int y = 0; y < Y; ++y)
+    for (int x = 0; x < X; ++x)
+      if (FLUID(s, y, x)) z[AT(s, y, x)] += L0->x[(y >> 4) * L0->nx + (x >> 4)];
+}
+
 void eo_apply_preconditioner(eo_sim* s, const double* r, double* z) {
   if (s->tile_records > 0) {
     apply_preconditioner_tiled(s, r, z);
-    if (s->coarse_m > 0) coarse_correction(s, r, z);
+    if (s->coarse_m > 0 && s->coarse_mg) mg_correction(s, r, z);
+    else if (s->coarse_m > 0) coarse_correction(s, r, z);
     return;
   }
   int X = s->X, Y = s->Y;

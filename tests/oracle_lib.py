@@ -44,6 +44,7 @@ class EoSim(C.Structure):
         ("crtmp", C.POINTER(C.c_float)), ("cgtmp", C.POINTER(C.c_float)), ("cbtmp", C.POINTER(C.c_float)),
         ("tile_records", C.c_int),
         ("coarse_m", C.c_int), ("coarse_n", C.c_int), ("coarse_nx", C.c_int), ("coarse_chol", C.POINTER(C.c_double)),
+        ("coarse_mg", C.c_int), ("mg", C.c_void_p),
     ]
 
 

@@ -239,15 +239,16 @@ def test_tile_mode_fields_against_the_reference_preconditioner_per_baseline_work
 
 
 # ----------------------------------------------------------------------------- two-level preconditioner (EULER_PRECOND_IC0_TILE2)
-def _two_level_pair(X, Y, max_it, text=None):
+def _two_level_pair(X, Y, max_it, text=None, mg=False):
     o = Oracle(X, Y)
-    sim = ea.Simulation(X, Y, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE2, tile_records=16, max_iterations=max_it)
+    sim = ea.Simulation(X, Y, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE_MG if mg else ea.PRECOND_IC0_TILE2, tile_records=16, max_iterations=max_it)
     if text is None:
         o.load_half_tank(); sim.load_half_tank()
     else:
         o.load_text(text, upscale=True); sim.load_text(text, upscale=True)
     o.c.tile_records = 16
     o.c.coarse_m = o.lib.eo_coarse_m(X, Y)
+    o.c.coarse_mg = int(mg)
     o.c.max_iterations = max_it
     return o, sim
 
@@ -332,3 +333,74 @@ def test_two_level_mode_refuses_what_it_cannot_do():
     sim.pcg_op(ea.OP_BACKWARD_SOLVE)
     sim.step()
     assert sim.stats().last_residual <= 1e-6 or sim.stats().last_pcg_iterations == 100
+
+
+# ----------------------------------------------------------------------------- multilevel preconditioner (EULER_PRECOND_IC0_TILE_MG)
+@pytest.mark.parametrize("X,Y", [(260, 300), (1100, 200), (130, 1030), (1536, 1280)])
+def test_multilevel_preconditioner_matches_the_oracle_restatement(X, Y):
+    """z = M_tile^-1 r + P_0 V(P_0^T r) (k_coarse.hip: k_mg_*) against the oracle's restatement (eo_sim.coarse_mg, mg_build / mg_vcycle): the
+    hierarchy's stencils are integer sums (exact), the V-cycle uses the oracle's formulas in the oracle's order, the level-0 sums of r fold in
+    another order - agreement to rounding.  (a) budget capped at 5: pressures of the first substep to 1e-11 of max |p| (measured 2e-15..4e-13),
+    residuals to 1e-9; (b) to the reference's tolerance: the same iteration counts within 3 % (measured: identical), pressures within 1e-6 of
+    max |p|, identical cell grids.  Square, flat, tall; 1536 x 1280 has coarse_m = 2, i.e. three levels below the dense one."""
+    o, sim = _two_level_pair(X, Y, 5, mg=True)
+    dt = sim.timestep(0.1)
+    assert dt == o.timestep(0.1)
+    sim.substep(dt); o.substep(dt)
+    st = sim.stats()
+    assert st.last_pcg_iterations == o.c.last_pcg_iterations == 5
+    pr = o.p
+    assert np.abs(sim.get(ea.F_PRESSURE) - pr).max() <= 1e-11 * np.abs(pr).max()
+    assert abs(st.last_residual - o.c.last_residual) <= 1e-9 * o.c.last_residual
+    sim.close(); o.close()
+    o, sim = _two_level_pair(X, Y, 4000, mg=True)
+    o.step(); sim.step()
+    st = sim.stats()
+    assert st.last_residual <= 1e-6 and o.c.last_residual <= 1e-6
+    assert abs(st.total_pcg_iterations - o.c.total_pcg_iterations) <= 0.03 * o.c.total_pcg_iterations + 2, (st.total_pcg_iterations, o.c.total_pcg_iterations)
+    p, pr = sim.get(ea.F_PRESSURE), o.p
+    assert np.abs(p - pr).max() <= 1e-6 * np.abs(pr).max()
+    assert_bits(sim.get(ea.F_COUNT), o.count, "cell grid")
+    assert np.abs(sim.get(ea.F_U) - o.u).max() < 1e-5 and np.abs(sim.get(ea.F_V) - o.v).max() < 1e-5
+
+
+def test_multilevel_iteration_counts_do_not_grow_with_the_grid():
+    """Half tank from rest to the reference's tolerance at 512^2, 1024^2, 2048^2: the multilevel mode needs 100-125 iterations at every size
+    (measured 107 / 108 / 118) where the reference's IC(0) needs 445 / 880 / 1726, and reaches the reference's pressure (1e-5 of max |p|,
+    checked at 512^2 against the parity mode)."""
+    its = {}
+    for n in (512, 1024, 2048):
+        sim = ea.Simulation(n, n, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE_MG, max_iterations=5000).load_half_tank()
+        dt = sim.timestep(0.1)
+        sim.substep(dt)
+        st = sim.stats()
+        assert st.last_residual <= 1e-6
+        its[n] = st.last_pcg_iterations
+        if n == 512:
+            ref = ea.Simulation(n, n, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0, max_iterations=5000).load_half_tank()
+            ref.substep(dt)
+            pr = ref.get(ea.F_PRESSURE)
+            assert np.abs(sim.get(ea.F_PRESSURE) - pr).max() <= 1e-5 * np.abs(pr).max()
+            its["ic0_512"] = ref.stats().last_pcg_iterations
+            ref.close()
+        sim.close()
+    print(its)
+    assert all(90 <= its[n] <= 135 for n in (512, 1024, 2048)), its
+    assert its[512] < 0.3 * its["ic0_512"]
+
+
+def test_multilevel_mode_moving_water_against_the_oracle():
+    """A dam break several bands deep, solves run to tolerance: free-running against the oracle's restatement for 10 frames - cell grids and
+    marker counts identical, velocities within 1e-4; then back to the reference's preconditioner on the same handle."""
+    text = scenario_text(load("block_frames.npz"))
+    o, sim = _two_level_pair(384, 448, 4000, text, mg=True)
+    for f in range(10):
+        o.step(); sim.step()
+        assert_bits(sim.get(ea.F_COUNT), o.count, "count frame %d" % f)
+        assert sim.stats().n_markers == o.n_markers
+        assert np.abs(sim.get(ea.F_U) - o.u).max() < 1e-4 and np.abs(sim.get(ea.F_V) - o.v).max() < 1e-4, f
+    sim.set_precond(ea.PRECOND_IC0)
+    o.c.tile_records = 0; o.c.coarse_m = 0; o.c.coarse_mg = 0
+    o.step(); sim.step()
+    assert_bits(sim.get(ea.F_COUNT), o.count, "count after switching back")
+    assert np.abs(sim.get(ea.F_U) - o.u).max() < 1e-4
