@@ -25,7 +25,7 @@
 
 #define CC_MAX 256          // coarse cells
 #define CC_THREADS 1024
-#define MG_DOT_BLOCKS 1024   // most blocks of the level-0 kernel that closes the V-cycle (its dot partials)
+#define MG_DOT_BLOCKS 512    // most blocks of the level-0 kernel that closes the V-cycle (its dot partials)
 #define MG_OMEGA 0.8         // damped Jacobi
 #define MG_KAPPA 1.5         // scaling of the coarse-grid correction (plain aggregation under-corrects)
 
@@ -58,11 +58,11 @@ int eu_coarse_alloc(euler_sim* S) {
   }
   HIPCHK(hipMalloc((void**)&S->mg_d, 3 * S->mg_cells * sizeof(int)));
   S->mg_rt = S->mg_d + S->mg_cells; S->mg_up = S->mg_d + 2 * S->mg_cells;
-  HIPCHK(hipMalloc((void**)&S->mg_rhs, 2 * S->mg_cells * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&S->mg_rhs, 3 * S->mg_cells * sizeof(double)));      // rhs, x, x1 (the Jacobi step) per level
   S->mg_x = S->mg_rhs + S->mg_cells;
   HIPCHK(hipMalloc((void**)&S->mg_part, (S->chunk_cap + 64) * 8 * sizeof(double)));
   HIPCHK(hipMalloc((void**)&S->mg_dot, (MG_DOT_BLOCKS + 1) * sizeof(double)));
-  HIPCHK(hipMemset(S->mg_rhs, 0, 2 * S->mg_cells * sizeof(double)));
+  HIPCHK(hipMemset(S->mg_rhs, 0, 3 * S->mg_cells * sizeof(double)));
   HIPCHK(hipMemset(S->mg_part, 0, (S->chunk_cap + 64) * 8 * sizeof(double)));
   HIPCHK(hipMemset(S->mg_dot, 0, (MG_DOT_BLOCKS + 1) * sizeof(double)));
   return EULER_OK;
@@ -302,17 +302,15 @@ __global__ __launch_bounds__(256) void k_mg_coarsen(const int* __restrict__ fd, 
   cd[p] = d; cr[p] = r; cu[p] = u;
 }
 
-struct MgLevel { const int *d, *rt, *up; const double* rhs; int nx, ny; };
-// (A_l v)[c] with v = the Jacobi step from zero, omega rhs / d, optionally + kappa e[parent]: diagonal, right, left, up, down - the oracle's order
+struct MgLevel { const int *d, *rt, *up; const double *rhs, *x1; int nx, ny; };      // x1 = the Jacobi step from zero, omega rhs / d (0 on empty aggregates), left by the kernel that wrote rhs
+// v of a cell: x1, optionally + kappa e[parent] (0 on empty aggregates)
 template <bool WITH_E>
 __device__ __forceinline__ double mg_val(const MgLevel& L, const double* __restrict__ e, int enx, int I, int J) {
   const size_t c = (size_t)I * L.nx + J;
-  const int d = L.d[c];
-  if (!d) return 0.0;
-  double v = MG_OMEGA * L.rhs[c] / (double)d;
-  if (WITH_E) v = v + MG_KAPPA * e[(size_t)(I >> 1) * enx + (J >> 1)];
-  return v;
+  if (!WITH_E) return L.x1[c];
+  return L.d[c] ? L.x1[c] + MG_KAPPA * e[(size_t)(I >> 1) * enx + (J >> 1)] : 0.0;
 }
+// (A_l v)[c]: diagonal, right, left, up, down - the oracle's order (mg_apply)
 template <bool WITH_E>
 __device__ __forceinline__ double mg_apply(const MgLevel& L, const double* __restrict__ e, int enx, int I, int J, double vc) {
   const size_t c = (size_t)I * L.nx + J;
@@ -324,9 +322,9 @@ __device__ __forceinline__ double mg_apply(const MgLevel& L, const double* __res
   return t;
 }
 
-// level-0 right-hand side from the tiles' partial sums (right part of tile J + j, then left part of tile J + j + 1)
-__global__ __launch_bounds__(256) void k_mg_gather0(const double* __restrict__ part, double* __restrict__ rhs0, int nx0, int ny0, int ntb, int band_lo, int band_hi,
-                                                    const PcgScalars* sc, int force) {
+// level-0 right-hand side from the tiles' partial sums (right part of tile J + j, then left part of tile J + j + 1), and its Jacobi step
+__global__ __launch_bounds__(256) void k_mg_gather0(const double* __restrict__ part, const int* __restrict__ d0, double* __restrict__ rhs0, double* __restrict__ x10,
+                                                    int nx0, int ny0, int ntb, int band_lo, int band_hi, const PcgScalars* sc, int force) {
   if (!force && (sc->done || !sc->nonzero)) return;
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= nx0 * ny0) return;
@@ -339,61 +337,59 @@ __global__ __launch_bounds__(256) void k_mg_gather0(const double* __restrict__ p
     if (k1 < ntb) t = t + part[(row + k1) * 8 + j * 2];
   }
   rhs0[c] = t;
+  const int d = d0[c];
+  x10[c] = d ? MG_OMEGA * t / (double)d : 0.0;
 }
 
-// down: the right-hand side of level l + 1 = the restricted residual of level l after its first Jacobi step (children in the order
-// (2I, 2J), (2I, 2J + 1), (2I + 1, 2J), (2I + 1, 2J + 1)); a thread per parent
-__global__ __launch_bounds__(256) void k_mg_down(MgLevel L, double* __restrict__ crhs, int cnx, int cny, const PcgScalars* sc, int force) {
+// down: the right-hand side of level l + 1 = the restricted residual of level l after its Jacobi step, children in the order (2I, 2J),
+// (2I, 2J + 1), (2I + 1, 2J), (2I + 1, 2J + 1).  A thread per CHILD (four neighbouring lanes per parent; a thread per parent left one wave
+// per SIMD with 40 dependent loads each: 25 us at level 0 of 8192^2); the first of the four adds them up in that order and leaves the
+// parent's Jacobi step as well.
+__global__ __launch_bounds__(256) void k_mg_down(MgLevel L, double* __restrict__ crhs, double* __restrict__ cx1, const int* __restrict__ cd, int cnx, int cny,
+                                                 const PcgScalars* sc, int force) {
   if (!force && (sc->done || !sc->nonzero)) return;
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= cnx * cny) return;
-  const int I = p / cnx, J = p % cnx;
-  double t = 0.0;
-  for (int a = 0; a < 2; ++a)
-    for (int b = 0; b < 2; ++b) {
-      const int ci = 2 * I + a, cj = 2 * J + b;
-      if (ci >= L.ny || cj >= L.nx) continue;
+  const int tid = blockIdx.x * 256 + threadIdx.x;
+  const int p = tid >> 2, q = tid & 3;
+  double res = 0.0;
+  if (p < cnx * cny) {
+    const int ci = 2 * (p / cnx) + (q >> 1), cj = 2 * (p % cnx) + (q & 1);
+    if (ci < L.ny && cj < L.nx) {
       const size_t c = (size_t)ci * L.nx + cj;
-      double res = 0.0;
-      if (L.d[c]) res = L.rhs[c] - mg_apply<false>(L, nullptr, 0, ci, cj, mg_val<false>(L, nullptr, 0, ci, cj));
-      t = t + res;
+      if (L.d[c]) res = L.rhs[c] - mg_apply<false>(L, nullptr, 0, ci, cj, L.x1[c]);
     }
-  crhs[p] = t;
+  }
+  const int base = (threadIdx.x & 63) & ~3;
+  const double r0 = __shfl(res, base, 64), r1 = __shfl(res, base + 1, 64), r2 = __shfl(res, base + 2, 64), r3 = __shfl(res, base + 3, 64);
+  if (q == 0 && p < cnx * cny) {
+    double t = 0.0;
+    t = t + r0; t = t + r1; t = t + r2; t = t + r3;
+    crhs[p] = t;
+    if (cx1) { const int d = cd[p]; cx1[p] = d ? MG_OMEGA * t / (double)d : 0.0; }
+  }
 }
 
-// the dense level: y = (P^T A P)^-1 rhs, one workgroup (the matrix-vector product of k_coarse_solve)
-__global__ __launch_bounds__(CC_THREADS) void k_mg_top(const double* __restrict__ rhs, const double* __restrict__ inv, double* __restrict__ y, int n,
-                                                       const PcgScalars* sc, int force) {
+// the dense level: y = (P^T A P)^-1 rhs, a workgroup per row (one workgroup alone took 15 us for the 0.5 MB)
+__global__ __launch_bounds__(256) void k_mg_top(const double* __restrict__ rhs, const double* __restrict__ inv, double* __restrict__ y, int n,
+                                                const PcgScalars* sc, int force) {
   if (!force && (sc->done || !sc->nonzero)) return;
-  __shared__ double s_rc[CC_MAX], s_q[4][CC_MAX];
-  const int tid = threadIdx.x;
-  if (tid < CC_MAX) s_rc[tid] = tid < n ? rhs[tid] : 0.0;
+  __shared__ double s_red[4];
+  const int row = blockIdx.x, j = threadIdx.x;
+  double v = j < n ? inv[(size_t)row * n + j] * rhs[j] : 0.0;      // (the inverse is symmetric: row = column)
+  v = eu_wave_sum(v);
+  if ((j & 63) == 0) s_red[j >> 6] = v;
   __syncthreads();
-  const int row = tid & (CC_MAX - 1), q = tid >> 8;
-  double acc = 0.0;
-  if (row < n)
-    for (int j = q; j < n; j += 64) {
-      double v[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = j + 4 * u < n ? inv[(size_t)(j + 4 * u) * n + row] : 0.0;
-#pragma unroll
-      for (int u = 0; u < 16; ++u) acc += v[u] * s_rc[(j + 4 * u) & (CC_MAX - 1)];
-    }
-  s_q[q][row] = acc;
-  __syncthreads();
-  if (tid < n) y[tid] = (s_q[0][tid] + s_q[1][tid]) + (s_q[2][tid] + s_q[3][tid]);
+  if (j == 0) y[row] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
-// up: x = x2 + omega (rhs - A x2) / d with x2 = the first Jacobi step + kappa e[parent], e = the level above's result; a thread per cell.
+// up: x = x2 + omega (rhs - A x2) / d with x2 = the Jacobi step + kappa e[parent], e = the level above's result; a thread per cell.
 // LAST (level 0): also the share of dot(z, r) the correction adds, x . rhs, folded per block and by the block that draws the last ticket
 // (block_finish's hand-off), with the scalar epilogue k_precond_tile left open.
 template <bool LAST>
 __global__ __launch_bounds__(256) void k_mg_up(MgLevel L, const double* __restrict__ e, int enx, double* __restrict__ x, PcgScalars* sc, int fin_op, int force,
                                                double* dot_part, unsigned int* counter) {
   if (!force && (sc->done || !sc->nonzero)) return;
-  const int c = blockIdx.x * 256 + threadIdx.x;
   double dv = 0.0;
-  if (c < L.nx * L.ny) {
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < L.nx * L.ny; c += gridDim.x * 256) {
     const int I = c / L.nx, J = c % L.nx;
     double xv = 0.0;
     const int d = L.d[c];
@@ -402,7 +398,7 @@ __global__ __launch_bounds__(256) void k_mg_up(MgLevel L, const double* __restri
       xv = x2 + MG_OMEGA * (L.rhs[c] - mg_apply<true>(L, e, enx, I, J, x2)) / (double)d;
     }
     x[c] = xv;
-    if (LAST) dv = xv * L.rhs[c];
+    if (LAST) dv += xv * L.rhs[c];
   }
   if (!LAST) return;
   __shared__ double s_red[4];
@@ -436,23 +432,30 @@ __global__ __launch_bounds__(256) void k_mg_up(MgLevel L, const double* __restri
 
 static int launch_mg_cycle(euler_sim* S, int fin_op, int force) {
   const int nl = S->mg_levels;
-  auto level = [&](int l) { const size_t o = S->mg_off[l]; return MgLevel{S->mg_d + o, S->mg_rt + o, S->mg_up + o, S->mg_rhs + o, S->mg_nx[l], S->mg_ny[l]}; };
+  double* x1 = S->mg_x + S->mg_cells;      // the third pool
+  auto level = [&](int l) { const size_t o = S->mg_off[l]; return MgLevel{S->mg_d + o, S->mg_rt + o, S->mg_up + o, S->mg_rhs + o, x1 + o, S->mg_nx[l], S->mg_ny[l]}; };
   const int n0 = S->mg_nx[0] * S->mg_ny[0];
-  LAUNCH(S, KC_PRECOND_TILE, k_mg_gather0, dim3((n0 + 255) / 256), dim3(256), S->mg_part, S->mg_rhs, S->mg_nx[0], S->mg_ny[0], S->geom.T / 16, S->band_lo, S->band_hi, S->sc, force);
+  LAUNCH(S, KC_PRECOND_TILE, k_mg_gather0, dim3((n0 + 255) / 256), dim3(256), S->mg_part, S->mg_d, S->mg_rhs, x1, S->mg_nx[0], S->mg_ny[0], S->geom.T / 16,
+         S->band_lo, S->band_hi, S->sc, force);
   double* top_rhs = S->cc_y + CC_MAX;
   for (int l = 0; l < nl; ++l) {
     const bool top = l + 1 == nl;
     const int cnx = top ? S->coarse_nx : S->mg_nx[l + 1], cny = top ? S->coarse_ny : S->mg_ny[l + 1];
-    LAUNCH(S, KC_PRECOND_TILE, k_mg_down, dim3(((size_t)cnx * cny + 255) / 256), dim3(256), level(l), top ? top_rhs : S->mg_rhs + S->mg_off[l + 1], cnx, cny, S->sc, force);
+    const size_t co = top ? 0 : S->mg_off[l + 1];
+    LAUNCH(S, KC_PRECOND_TILE, k_mg_down, dim3(((size_t)cnx * cny * 4 + 255) / 256), dim3(256), level(l), top ? top_rhs : S->mg_rhs + co, top ? (double*)nullptr : x1 + co,
+           top ? (const int*)nullptr : S->mg_d + co, cnx, cny, S->sc, force);
   }
-  LAUNCH(S, KC_PRECOND_TILE, k_mg_top, dim3(1), dim3(CC_THREADS), top_rhs, S->cc_inv, S->cc_y, S->coarse_n, S->sc, force);
+  LAUNCH(S, KC_PRECOND_TILE, k_mg_top, dim3(S->coarse_n), dim3(256), top_rhs, S->cc_inv, S->cc_y, S->coarse_n, S->sc, force);
   for (int l = nl - 1; l >= 0; --l) {
     const bool top = l + 1 == nl;
     const double* e = top ? S->cc_y : S->mg_x + S->mg_off[l + 1];
     const int enx = top ? S->coarse_nx : S->mg_nx[l + 1];
-    const unsigned nb = (unsigned)(((size_t)S->mg_nx[l] * S->mg_ny[l] + 255) / 256);
-    if (l > 0) LAUNCH(S, KC_PRECOND_TILE, k_mg_up<false>, dim3(nb), dim3(256), level(l), e, enx, S->mg_x + S->mg_off[l], S->sc, fin_op, force, (double*)nullptr, (unsigned int*)nullptr);
-    else LAUNCH(S, KC_PRECOND_TILE, k_mg_up<true>, dim3(nb), dim3(256), level(l), e, enx, S->mg_x, S->sc, fin_op, force, S->mg_dot, reinterpret_cast<unsigned int*>(S->mg_dot + MG_DOT_BLOCKS));
+    const size_t cells = (size_t)S->mg_nx[l] * S->mg_ny[l];
+    if (l > 0) LAUNCH(S, KC_PRECOND_TILE, k_mg_up<false>, dim3((unsigned)((cells + 255) / 256)), dim3(256), level(l), e, enx, S->mg_x + S->mg_off[l], S->sc, fin_op, force, (double*)nullptr, (unsigned int*)nullptr);
+    else {
+      const unsigned nb = (unsigned)((cells + 255) / 256) < MG_DOT_BLOCKS ? (unsigned)((cells + 255) / 256) : MG_DOT_BLOCKS;
+      LAUNCH(S, KC_PRECOND_TILE, k_mg_up<true>, dim3(nb), dim3(256), level(l), e, enx, S->mg_x, S->sc, fin_op, force, S->mg_dot, reinterpret_cast<unsigned int*>(S->mg_dot + MG_DOT_BLOCKS));
+    }
   }
   return EULER_OK;
 }

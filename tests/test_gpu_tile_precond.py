@@ -336,7 +336,7 @@ def test_two_level_mode_refuses_what_it_cannot_do():
 
 
 # ----------------------------------------------------------------------------- multilevel preconditioner (EULER_PRECOND_IC0_TILE_MG)
-@pytest.mark.parametrize("X,Y", [(260, 300), (1100, 200), (130, 1030), (1536, 1280)])
+@pytest.mark.parametrize("X,Y", [(100, 40), (260, 300), (1100, 200), (130, 1030), (1536, 1280)])
 def test_multilevel_preconditioner_matches_the_oracle_restatement(X, Y):
     """z = M_tile^-1 r + P_0 V(P_0^T r) (k_coarse.hip: k_mg_*) against the oracle's restatement (eo_sim.coarse_mg, mg_build / mg_vcycle): the
     hierarchy's stencils are integer sums (exact), the V-cycle uses the oracle's formulas in the oracle's order, the level-0 sums of r fold in
