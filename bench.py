@@ -83,6 +83,8 @@ def parse_args():
                     help="ic0_tile = roofline mode (default), ic0 = parity mode (the reference's preconditioner), ic0_tile2 = roofline mode + coarse "
                          "correction (one GPU; fewer iterations to a given residual, DESIGN.md 5c)")
     ap.add_argument("--tile-records", type=int, default=0)
+    ap.add_argument("--max-iterations", type=int, default=100, help="PCG iteration cap per solve (the reference's: 100, main.c:735); lift it together with --tol 1e-6 "
+                                                                    "to time frames whose solves converge (e.g. --precond ic0_tile_mg)")
     ap.add_argument("--tol", type=float, default=None, help="PCG tolerance (default: 0 for half_tank = the roofline run, else the reference's 1e-6)")
     ap.add_argument("--max-preroll", type=int, default=400)
     ap.add_argument("--partition", default="auto", choices=["auto", "even"],
@@ -332,7 +334,7 @@ def make_handle(ctx, GX, GY, workload, tiles, slab_arg, precond, tol):
     import torch
     args, ea, rank = ctx["args"], ctx["ea"], ctx["rank"]
     sm = ea.Simulation(GX, GY, device=ctx["local_rank"], dot_mode=ctx["dot_mode"], precond=ctx["PC"][precond], tile_records=args.tile_records, tol=tol,
-                       slab=slab_arg)
+                       slab=slab_arg, max_iterations=args.max_iterations, pcg_poll_interval=8 if args.max_iterations <= 100 else 32)
     hbm = sm.hbm_bytes()      # what THIS handle allocated (free-memory differences are confounded when ranks share a device)
     cm, p2p = None, False
     if ctx["sharded"]:
@@ -1067,7 +1069,7 @@ def main():
                                                    % ("; timed in the saturated phase: 8 CFL substeps per frame" if saturate else "")
                                                    if args.workload == "half_tank" and tol == 0.0 else "", head["mode"]),
                    "grid": [GX, GY], "preroll_frames": preroll, "precond": args.precond, "tile_records": tile_w if args.precond in TILE_MODES else None,
-                   "dot_mode": args.dot_mode, "max_iterations": 100, "tol": tol if tol is not None else 1e-6, "parallelism": parallelism},
+                   "dot_mode": args.dot_mode, "max_iterations": args.max_iterations, "tol": tol if tol is not None else 1e-6, "parallelism": parallelism},
         "mode": head["mode"],
         "substeps": head["substeps"], "pcg_iterations": head["pcg_iterations"], "cells_substeps_per_s": head["cells_substeps_per_s"],
         "markers": head["markers"], "fluid_cells": head["fluid_cells"], "hbm_bytes_this_rank": int(hbm_per_rank),
