@@ -12,8 +12,11 @@ from euler_amd import scenarios
 print("| grid | scenario | mode | iteration cap | frames | substeps | PCG iterations | solves that hit the cap | markers | fluid cells | max abs u | wall |")
 print("|---|---|---|---|---|---|---|---|---|---|---|---|")
 for size, wl, frames in ((2048, "waterfall", 120), (1024, "dam", 300)):
-    for pc, name, cap in ((ea.PRECOND_IC0, "parity", 100), (ea.PRECOND_IC0_TILE, "roofline", 100), (ea.PRECOND_IC0_TILE2, "two-level", 100),
-                          (ea.PRECOND_IC0_TILE2, "two-level", 20000), (ea.PRECOND_IC0, "parity", 20000)):
+    rows = ((ea.PRECOND_IC0, "parity", 100), (ea.PRECOND_IC0_TILE, "roofline", 100), (ea.PRECOND_IC0_TILE2, "two-level", 100),
+            (ea.PRECOND_IC0_TILE2, "two-level", 20000), (ea.PRECOND_IC0, "parity", 20000), (ea.PRECOND_IC0_TILE_MG, "multilevel", 100), (ea.PRECOND_IC0_TILE_MG, "multilevel", 20000))
+    if len(sys.argv) > 1:
+        rows = [r for r in rows if r[1] in sys.argv[1:]]
+    for pc, name, cap in rows:
         sim = ea.Simulation(size, size, dot_mode=ea.DOT_TREE, precond=pc, tile_records=16, max_iterations=cap, pcg_poll_interval=8 if cap == 100 else 32)
         sim.load_text(scenarios.dam_break() if wl == "dam" else scenarios.waterfall(), upscale=True)
         t0 = time.time()
