@@ -404,3 +404,38 @@ def test_multilevel_mode_moving_water_against_the_oracle():
     o.step(); sim.step()
     assert_bits(sim.get(ea.F_COUNT), o.count, "count after switching back")
     assert np.abs(sim.get(ea.F_U) - o.u).max() < 1e-4
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("mg", [False, True])
+def test_coarse_modes_on_random_scenes(seed, mg):
+    """Random walls, pools and air pockets (a 44 x 36 character scene upscaled to 300 x 260: aggregates without fluid, aggregates cut by walls,
+    fluid in single cells): two-level and multilevel modes against the oracle's restatements - iterates capped at 5 to 1e-10 of max |p| for
+    three substeps of moving water, then a frame solved to tolerance with the same cell grid and iteration counts within 5 %."""
+    rng = np.random.default_rng(seed)
+    H, W = 36, 44
+    rows = []
+    for y in range(H):
+        r = rng.random(W)
+        row = "".join("X" if v < 0.10 else ("0" if v < 0.62 else " ") for v in r)
+        rows.append("X" + row[1:-1] + "X")
+    rows[0] = rows[-1] = "X" * W
+    text = "\n".join(rows) + "\n"
+    o, sim = _two_level_pair(300, 260, 5, text, mg=mg)
+    for k in range(3):
+        dt = sim.timestep(0.1)
+        assert dt == o.timestep(0.1)
+        sim.substep(dt); o.substep(dt)
+        st = sim.stats()
+        assert st.last_pcg_iterations == o.c.last_pcg_iterations
+        pr = o.p
+        if k == 0:      # (later substeps inherit float32 velocities that may round apart)
+            assert np.abs(sim.get(ea.F_PRESSURE) - pr).max() <= 1e-10 * max(np.abs(pr).max(), 1e-30), k
+        assert_bits(sim.get(ea.F_COUNT), o.count, "cell grid, substep %d" % k)
+    sim.close(); o.close()
+    o, sim = _two_level_pair(300, 260, 4000, text, mg=mg)
+    o.step(); sim.step()
+    assert sim.stats().last_residual <= 1e-6 and o.c.last_residual <= 1e-6
+    assert abs(sim.stats().total_pcg_iterations - o.c.total_pcg_iterations) <= 0.05 * o.c.total_pcg_iterations + 3, (sim.stats().total_pcg_iterations, o.c.total_pcg_iterations)
+    assert_bits(sim.get(ea.F_COUNT), o.count, "cell grid")
+    assert np.abs(sim.get(ea.F_U) - o.u).max() < 1e-4 and np.abs(sim.get(ea.F_V) - o.v).max() < 1e-4
