@@ -140,8 +140,8 @@ extern "C" int euler_set_precond(euler_sim* S, int32_t precond, int32_t tile_rec
   int rc = eu_set_tiles(S, tile_records);
   if (rc) return rc;
   if (precond == EULER_PRECOND_IC0_TILE2 || precond == EULER_PRECOND_IC0_TILE_MG) {      // the two-level / multilevel modes: tiles of 16 records, one GPU, tree dots; their arrays come with the first use
-    if (S->has_comm || S->slab_on || S->tile_w != 16 || S->cfg.sweep_mode == EULER_SWEEP_SIMPLE) {
-      eu_set_error("EULER_PRECOND_IC0_TILE2 / _MG: one GPU, tiles of 16 records, the band schedule"); return EULER_EINVAL;
+    if (((S->has_comm || S->slab_on) && precond != EULER_PRECOND_IC0_TILE_MG) || S->tile_w != 16 || S->cfg.sweep_mode == EULER_SWEEP_SIMPLE) {
+      eu_set_error("EULER_PRECOND_IC0_TILE2: one GPU; _MG: one GPU or row slabs; both: tiles of 16 records, the band schedule"); return EULER_EINVAL;
     }
     S->cfg.dot_mode = EULER_DOT_TREE;
     if ((rc = eu_coarse_alloc(S))) return rc;
@@ -401,8 +401,8 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   for (int k = 0; k < S->ev_cap; ++k) CREATECHK(hipEventCreate(&S->ev_pool[k]));
   if (S->slab_on) { int rc = eu_slab_alloc(S); if (rc) { euler_destroy(S); return rc; } }
   if (S->cfg.precond == EULER_PRECOND_IC0_TILE2 || S->cfg.precond == EULER_PRECOND_IC0_TILE_MG) {
-    if (S->slab_on || S->tile_w != 16 || S->cfg.sweep_mode == EULER_SWEEP_SIMPLE) {
-      eu_set_error("EULER_PRECOND_IC0_TILE2 / _MG: one GPU, tiles of 16 records, the band schedule"); euler_destroy(S); return EULER_EINVAL;
+    if ((S->slab_on && S->cfg.precond != EULER_PRECOND_IC0_TILE_MG) || S->tile_w != 16 || S->cfg.sweep_mode == EULER_SWEEP_SIMPLE) {
+      eu_set_error("EULER_PRECOND_IC0_TILE2: one GPU; _MG: one GPU or row slabs; both: tiles of 16 records, the band schedule"); euler_destroy(S); return EULER_EINVAL;
     }
     S->cfg.dot_mode = EULER_DOT_TREE;
     int rc = eu_coarse_alloc(S);

@@ -337,6 +337,7 @@ void eu_coarse_release(euler_sim* S);
 int  eu_launch_coarse_setup(euler_sim* S);    // per solve: P^T A P, its factor and inverse
 int  eu_launch_coarse_solve(euler_sim* S, int fin_op, int force);   // per iteration: y = (P^T A P)^-1 P^T r, dot(z,r) += y . r_c, the scalar epilogue
 int  eu_launch_coarse_search_init(euler_sim* S);   // s = z + P y (the first search direction of a solve)
+int  eu_launch_coarse_add_row(euler_sim* S, double* row, int yrow);   // row slabs: + P y on a compact ghost row (grid row yrow)
 
 // ------------------------------------------------------------------------------------------
 // device helpers

@@ -29,6 +29,8 @@
 #define MG_OMEGA 0.8         // damped Jacobi
 #define MG_KAPPA 1.5         // scaling of the coarse-grid correction (plain aggregation under-corrects)
 
+#define COMM_CALL(expr) do { if ((expr) != 0) { eu_set_error("communicator callback failed: %s", #expr); return EULER_ECOMM; } } while (0)
+
 // the scalar epilogues of k_pcg.hip (same codes)
 enum { CFIN_SIGMA_INIT = 0, CFIN_BETA = 3 };
 
@@ -341,6 +343,15 @@ __global__ __launch_bounds__(256) void k_mg_gather0(const double* __restrict__ p
   x10[c] = d ? MG_OMEGA * t / (double)d : 0.0;
 }
 
+// (row slabs: the other ranks' rows of rhs_0 arrive by all-gather; their Jacobi step is formed here)
+__global__ __launch_bounds__(256) void k_mg_jacobi0(const int* __restrict__ d0, const double* __restrict__ rhs0, double* __restrict__ x10, int n0, const PcgScalars* sc, int force) {
+  if (!force && (sc->done || !sc->nonzero)) return;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= n0) return;
+  const int d = d0[c];
+  x10[c] = d ? MG_OMEGA * rhs0[c] / (double)d : 0.0;
+}
+
 // down: the right-hand side of level l + 1 = the restricted residual of level l after its Jacobi step, children in the order (2I, 2J),
 // (2I, 2J + 1), (2I + 1, 2J), (2I + 1, 2J + 1).  A thread per CHILD (four neighbouring lanes per parent; a thread per parent left one wave
 // per SIMD with 40 dependent loads each: 25 us at level 0 of 8192^2); the first of the four adds them up in that order and leaves the
@@ -437,6 +448,12 @@ static int launch_mg_cycle(euler_sim* S, int fin_op, int force) {
   const int n0 = S->mg_nx[0] * S->mg_ny[0];
   LAUNCH(S, KC_PRECOND_TILE, k_mg_gather0, dim3((n0 + 255) / 256), dim3(256), S->mg_part, S->mg_d, S->mg_rhs, x1, S->mg_nx[0], S->mg_ny[0], S->geom.T / 16,
          S->band_lo, S->band_hi, S->sc, force);
+  if (S->has_comm) {      // row slabs: every rank's rows of the level-0 right-hand side to every rank; the V-cycle itself runs replicated (identical bits everywhere)
+    int64_t off[64], cnt[64];
+    for (int r = 0; r < S->bulk.nranks && r < 64; ++r) { off[r] = (int64_t)4 * S->part_lo[r] * S->mg_nx[0] * sizeof(double); cnt[r] = (int64_t)4 * (S->part_hi[r] - S->part_lo[r]) * S->mg_nx[0] * sizeof(double); }
+    COMM_CALL(S->bulk.allgather(S->bulk.ctx, S->mg_rhs, off, cnt));
+    LAUNCH(S, KC_PRECOND_TILE, k_mg_jacobi0, dim3((n0 + 255) / 256), dim3(256), S->mg_d, S->mg_rhs, x1, n0, S->sc, force);
+  }
   double* top_rhs = S->cc_y + CC_MAX;
   for (int l = 0; l < nl; ++l) {
     const bool top = l + 1 == nl;
@@ -468,6 +485,13 @@ int eu_launch_coarse_setup(euler_sim* S) {
     HIPCHK(hipMemsetAsync(S->mg_d, 0, 3 * S->mg_cells * sizeof(int), S->stream));
     HIPCHK(hipMemsetAsync(S->mg_part, 0, (S->chunk_cap + 64) * 8 * sizeof(double), S->stream));      // (tiles outside this solve's list contribute nothing)
     LAUNCH(S, KC_PRECON_FACTOR, k_mg_assemble0, dim3(nblk), dim3(256), S->cellmask, S->geom, S->chunk_list, S->sc, S->band_lo, S->mg_nx[0], S->mg_d, S->mg_rt, S->mg_up);
+    if (S->has_comm) {      // row slabs: an aggregate of 16 rows belongs to one rank (slabs are cut at band boundaries) - every rank contributes its rows of A_0, then all of them build the same hierarchy
+      int64_t off[64], cnt[64];
+      for (int r = 0; r < S->bulk.nranks && r < 64; ++r) { off[r] = (int64_t)4 * S->part_lo[r] * S->mg_nx[0] * sizeof(int); cnt[r] = (int64_t)4 * (S->part_hi[r] - S->part_lo[r]) * S->mg_nx[0] * sizeof(int); }
+      COMM_CALL(S->bulk.allgather(S->bulk.ctx, S->mg_d, off, cnt));
+      COMM_CALL(S->bulk.allgather(S->bulk.ctx, S->mg_rt, off, cnt));
+      COMM_CALL(S->bulk.allgather(S->bulk.ctx, S->mg_up, off, cnt));
+    }
     for (int l = 1; l <= S->mg_levels; ++l) {
       const bool top = l == S->mg_levels;
       const int cnx = top ? S->coarse_nx : S->mg_nx[l], cny = top ? S->coarse_ny : S->mg_ny[l];
@@ -572,11 +596,12 @@ int eu_launch_coarse_solve(euler_sim* S, int fin_op, int force) {
   return EULER_OK;
 }
 
-// ---- the first search direction of a solve: s = z + P y (the memcpy at main.c:746, with the coarse part of z added on fluid cells)
+// ---- the first search direction of a solve: s = z + P y (the memcpy at main.c:746, with the coarse part of z added on fluid cells), this rank's bands
 __global__ __launch_bounds__(256) void k_coarse_search_init(double* __restrict__ s, const double* __restrict__ z, const uint8_t* __restrict__ mask,
-                                                            const double* __restrict__ y, SkewGeom g, int shift, int nx, const PcgScalars* sc) {
+                                                            const double* __restrict__ y, SkewGeom g, int shift, int nx, size_t e_lo, size_t e_cnt, const PcgScalars* sc) {
   if (sc->done || !sc->nonzero) return;
-  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < g.S; e += (size_t)gridDim.x * blockDim.x) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < e_cnt; k += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = e_lo + k;
     double v = z[e];
     if (mask[e] & CM_FLUID) {
       int band, t, l;
@@ -589,7 +614,19 @@ __global__ __launch_bounds__(256) void k_coarse_search_init(double* __restrict__
 
 int eu_launch_coarse_search_init(euler_sim* S) {
   const bool mg = eu_is_mg(S) && S->mg_levels > 0;
-  LAUNCH(S, KC_UPDATE_SEARCH, k_coarse_search_init, dim3(eu_blocks(S->geom.S, 256 * 4, 4096)), dim3(256), S->s, S->z, S->cellmask, mg ? S->mg_x : S->cc_y, S->geom,
-         mg ? 4 : S->coarse_shift, mg ? S->mg_nx[0] : S->coarse_nx, S->sc);
+  LAUNCH(S, KC_UPDATE_SEARCH, k_coarse_search_init, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), S->s, S->z, S->cellmask, mg ? S->mg_x : S->cc_y, S->geom,
+         mg ? 4 : S->coarse_shift, mg ? S->mg_nx[0] : S->coarse_nx, S->e_lo, S->e_cnt, S->sc);
+  return EULER_OK;
+}
+
+// ---- row slabs: a neighbour's edge row of z_0 (a compact row, one value per column) becomes a ghost row of the first search direction: + P y of its cells
+__global__ __launch_bounds__(256) void k_coarse_add_row(double* __restrict__ row, const double* __restrict__ y, int X, int yrow, int shift, int nx, const PcgScalars* sc) {
+  if (sc->done || !sc->nonzero) return;
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x < X) row[x] = row[x] + y[(size_t)(yrow >> shift) * nx + (x >> shift)];
+}
+int eu_launch_coarse_add_row(euler_sim* S, double* row, int yrow) {
+  const bool mg = eu_is_mg(S) && S->mg_levels > 0;
+  LAUNCH(S, KC_UPDATE_SEARCH, k_coarse_add_row, dim3((S->X + 255) / 256), dim3(256), row, mg ? S->mg_x : S->cc_y, S->X, yrow, mg ? 4 : S->coarse_shift, mg ? S->mg_nx[0] : S->coarse_nx, S->sc);
   return EULER_OK;
 }

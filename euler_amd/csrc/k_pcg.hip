@@ -1827,7 +1827,7 @@ static int launch_precond_tile(euler_sim* S, int rupd, int sweeps, int fin_dot, 
     case 32: LAUNCH(S, cls, k_precond_tile<32>, dim3(nblk), dim3(PT_THREADS), a); break;
     default: LAUNCH(S, cls, k_precond_tile<16>, dim3(nblk), dim3(PT_THREADS), a); break;
   }
-  if (two_level) { int rc = eu_launch_coarse_solve(S, fin_real, force); if (rc) return rc; }
+  if (two_level && a.via != FIN_TO_COMM) { int rc = eu_launch_coarse_solve(S, fin_real, force); if (rc) return rc; }
   if (seq && sweeps && fin_dot >= 0)   // the reference's row-major dot(z, r); a no-op once max |r| <= tol
     LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), S->z, S->r, S->cellmask, S->geom, S->sc, fin_dot, force);
   if (a.via == FIN_TO_COMM) {          // no mailboxes: G1 - both results (and, in the solve, the edge rows of the new z) in ONE exchange, then the epilogues
@@ -1836,6 +1836,9 @@ static int launch_precond_tile(euler_sim* S, int rupd, int sweeps, int fin_dot, 
     int rc = comm_exchange(S, xrow(S, XR_ZSEND_LO), xrow(S, XR_ZSEND_HI), xrow(S, XR_ZRECV_LO), xrow(S, XR_ZRECV_HI), rows ? S->X : 0, S->pair_buf, 2);
     if (rc) return rc;
     hipLaunchKernelGGL(k_pair_fold, dim3(1), dim3(1), 0, S->stream, S->sc, S->pair_buf, R, rupd, a.fin_dot, force);
+    // coarse correction on row slabs: the tiles' shares of dot(z, r) are folded (stored, not applied); the V-cycle - its level-0 right-hand
+    // side all-gathered, the rest replicated - adds its share and applies the epilogue, the same bits on every rank
+    if (two_level) { rc = eu_launch_coarse_solve(S, fin_real, force); if (rc) return rc; }
   }
   return EULER_OK;
 }
@@ -1878,13 +1881,16 @@ static int launch_apply_a_and_alpha(euler_sim* S, int force) {
     // become the ghost rows of s - in the adjacent bands' storage for this one pass (k_apply_a looks there), and generation 0 of
     // the compact rows k_search_apply keeps current from here on
     const int X = S->X, nbk = (X + 255) / 256;
+    const bool coarse = eu_is_two_level(S);      // (the first search direction is z_0 + P y then: the ghost rows take the P y of their own cells)
     if (S->band_lo > 0) {
-      hipLaunchKernelGGL(k_unpack_row, dim3(nbk), dim3(256), 0, S->stream, S->s, xrow(S, XR_ZRECV_LO), S->geom, S->band_lo - 1, 63);
       HIPCHK(hipMemcpyAsync(xrow(S, XR_GS_LO0), xrow(S, XR_ZRECV_LO), (size_t)X * 8, hipMemcpyDeviceToDevice, S->stream));
+      if (coarse) { int rc = eu_launch_coarse_add_row(S, xrow(S, XR_GS_LO0), 64 * S->band_lo - 1); if (rc) return rc; }
+      hipLaunchKernelGGL(k_unpack_row, dim3(nbk), dim3(256), 0, S->stream, S->s, xrow(S, XR_GS_LO0), S->geom, S->band_lo - 1, 63);
     }
     if (S->band_hi < S->geom.nbands) {
-      hipLaunchKernelGGL(k_unpack_row, dim3(nbk), dim3(256), 0, S->stream, S->s, xrow(S, XR_ZRECV_HI), S->geom, S->band_hi, 0);
       HIPCHK(hipMemcpyAsync(xrow(S, XR_GS_HI0), xrow(S, XR_ZRECV_HI), (size_t)X * 8, hipMemcpyDeviceToDevice, S->stream));
+      if (coarse) { int rc = eu_launch_coarse_add_row(S, xrow(S, XR_GS_HI0), 64 * S->band_hi); if (rc) return rc; }
+      hipLaunchKernelGGL(k_unpack_row, dim3(nbk), dim3(256), 0, S->stream, S->s, xrow(S, XR_GS_HI0), S->geom, S->band_hi, 0);
     }
     S->gs_cur = 0;
   } else if (S->has_comm) { int rc = comm_halo_s(S); if (rc) return rc; }
@@ -1945,7 +1951,9 @@ static int launch_search_apply_and_alpha(euler_sim* S, int it) {
          LOC(S->q), LOC(S->cellmask), gl, S->partial, S->sc, 0, S->red_counter, fin, nbr, pp, S->s2, S->s, (RUNV) == 8 ? S->chunk_list : (const unsigned int*)nullptr, cref)
 #define SA_LAUNCH(SLABF, PM, RUNV) SA_LAUNCH_C(SLABF, PM, RUNV, false)
 #define SA_RUNS(SLABF, PM) do { if (run == 8) SA_LAUNCH(SLABF, PM, 8); else if (run == 16) SA_LAUNCH(SLABF, PM, 16); else SA_LAUNCH(SLABF, PM, 32); } while (0)
-  if (eu_is_two_level(S) && tile_fused(S)) {      // two-level preconditioner: one GPU, runs of 8 (the list), z + P y
+  if (eu_is_two_level(S) && tile_fused(S) && ghost) {      // coarse correction on row slabs (multilevel mode): the ghost rows of z get their P y here as well
+    if (pmode == 2) SA_LAUNCH_C(2, 2, 8, true); else SA_LAUNCH_C(2, 1, 8, true);
+  } else if (eu_is_two_level(S) && tile_fused(S)) {      // two-level / multilevel preconditioner on one GPU: runs of 8 (the list), z + P y
     if (pmode == 2) SA_LAUNCH_C(0, 2, 8, true); else SA_LAUNCH_C(0, 1, 8, true);
   } else if (ghost) {      // (tile-local mode: pmode 1 or 2; several ranks: runs of 8)
     if (pmode == 2) SA_LAUNCH(2, 2, 8); else SA_LAUNCH(2, 1, 8);
@@ -2001,6 +2009,10 @@ int eu_launch_project(euler_sim* S, float dt) {
   // if (!all_zero(r)) { ... }: every kernel below is a no-op when sc->nonzero == 0
   const bool tile = tile_fused(S);
   const bool two_level = tile && eu_is_two_level(S);
+  if (two_level && S->has_comm && !(eu_is_mg(S) && ghost_mode(S) && S->slab_on)) {
+    eu_set_error("coarse-correction preconditioners with several ranks: EULER_PRECOND_IC0_TILE_MG on row slabs without mailboxes only");
+    return EULER_EINVAL;
+  }
   if (two_level && (rc = eu_launch_coarse_setup(S))) return rc;   // P^T A P of this system, its factor and inverse (k_coarse.hip)
   if (tile) {                                                     // E^-1 per tile, then z = M^-1 r and sigma = dot(z, r) in one pass
     if ((rc = launch_factor_tile(S, 0))) return rc;

@@ -76,7 +76,10 @@ enum {
                                 with the dense inverse of the two-level mode.  The number of iterations to the reference's tolerance no longer
                                 grows with the grid: ~100-130 where the reference's IC(0) needs 231 (256^2), 880 (1024^2), thousands (8192^2).
                                 Cost per iteration: the tile-local mode's two passes + a dozen launches over arrays 256 times smaller than
-                                the grid.  Restated in the oracle (eo_sim.coarse_mg): GPU = oracle to rounding.  One GPU only; EULER_DOT_TREE. */
+                                the grid.  Restated in the oracle (eo_sim.coarse_mg): GPU = oracle to rounding.  EULER_DOT_TREE.  One GPU, or row slabs without
+                                mailboxes (euler_config.slab_*): an aggregate of 16 rows belongs to one rank, so every rank contributes its rows of the
+                                level-0 operator (per solve) and of the level-0 right-hand side (per iteration, one all-gather behind the G1 exchange)
+                                and all ranks run the same V-cycle - the same bits everywhere; the iteration counts are the single GPU's. */
 };
 
 /* IC(0) sweep implementation (same arithmetic, different schedule). */

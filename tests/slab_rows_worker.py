@@ -43,7 +43,11 @@ def main():
         torch.cuda.set_device(0)
     rank, world = dist.get_rank(), dist.get_world_size()
     rainbow = "rainbow" in sys.argv[6:]       # --rainbow: the dye fields on row slabs (ghost rows of g_r / g_g / g_b, coloured frames)
-    ref = ea.Simulation(X, Y, device=local, dot_mode=ea.DOT_TREE, precond=precond, rainbow=rainbow)       # single GPU, the whole grid
+    maxit = 100
+    for a in sys.argv[6:]:
+        if a.startswith("maxit="):            # lift the reference's iteration cap: solves run to tolerance (the coarse-correction modes: tolerance parity between 1 and N ranks)
+            maxit = int(a[6:])
+    ref = ea.Simulation(X, Y, device=local, dot_mode=ea.DOT_TREE, precond=precond, rainbow=rainbow, max_iterations=maxit)       # single GPU, the whole grid
     if not any(a.startswith("load=") for a in sys.argv[6:]):
         load(ref, workload)
     slab = (rank, world)
@@ -56,7 +60,7 @@ def main():
     for a in sys.argv[6:]:
         if a.startswith("caps="):             # tiny exchange capacities (dt-chain candidates, deletions) to drive the overflow path
             os.environ["EULER_SLAB_CAPS"] = a[5:]
-    sim = ea.Simulation(X, Y, device=local, dot_mode=ea.DOT_TREE, precond=precond, slab=slab, rainbow=rainbow)   # one slab
+    sim = ea.Simulation(X, Y, device=local, dot_mode=ea.DOT_TREE, precond=precond, slab=slab, rainbow=rainbow, max_iterations=maxit)   # one slab
     comm = RcclComm(sim, SLAB_LOCAL) if rccl else TorchComm(sim, SLAB_LOCAL)
     out = {"world": world, "frames": []}
     if p2p:
@@ -162,6 +166,7 @@ def main():
         d["keys_cover_own_count"] = bool(len(flat) == int(ss.n_markers) and np.array_equal(flat, np.arange(len(flat))))
         d["n_markers"] = [int(sr.n_markers), int(ss.n_markers), len(m)]
         d["iters"] = [sr.last_pcg_iterations, ss.last_pcg_iterations]
+        d["residual"] = [float(sr.last_residual), float(ss.last_residual)]
         d["substeps"] = [sr.last_substeps, ss.last_substeps]
         d["rng"] = [int(sr.rng_state) == int(ss.rng_state), sr.source_exhausted == ss.source_exhausted]
         d["dt_events"] = [int(sr.marker_dt_events), int(ss.marker_dt_events)]

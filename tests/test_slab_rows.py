@@ -239,3 +239,29 @@ def test_a_partition_with_a_gap_is_refused():
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode != 0
     assert "do not tile" in out.stderr, out.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,X,Y,workload,frames,extra", [
+    (2, 256, 512, "dam_break", 30, ()),
+    (3, 320, 448, "half_tank", 6, ("bands=0-2,2-3,3-7",)),      # an uneven partition; a tank at rest (long solves from the first frame on)
+    (4, 256, 512, "waterfall", 20, ()),
+])
+def test_multilevel_mode_on_row_slabs(nproc, X, Y, workload, frames, extra):
+    """EULER_PRECOND_IC0_TILE_MG on row slabs: every rank assembles its rows of the level-0 operator (an aggregate of 16 rows belongs to
+    one rank), the operator and, per iteration, the level-0 right-hand side are all-gathered, the V-cycle runs replicated - the same bits on
+    every rank - and k_search_apply adds P y to the ghost rows of z as well.  Against the single-GPU run of the same mode with the cap lifted
+    (solves to the reference's tolerance): identical cell grids and markers while the runs are in step, the same iteration counts to a few
+    (the level-0 sums fold per rank), pressures within 1e-6 of max |p| + 2e-6, velocities within 1e-5."""
+    d = run(nproc, X, Y, workload, frames, ea.PRECOND_IC0_TILE_MG, 29641, tuple(extra) + ("maxit=4000",))
+    solved = 0
+    for i, f in enumerate(d["frames"]):
+        assert f["markers_in_rows"] and f["keys_cover_own_count"], (i, f)
+        assert f["residual"][0] <= 1e-6 and f["residual"][1] <= 1e-6, (i, f)
+        assert f["substeps"][0] == f["substeps"][1], (i, f)
+        assert abs(f["iters"][0] - f["iters"][1]) <= 0.05 * f["iters"][0] + 3, (i, f)
+        assert f["count_differ"] == 0 and f["prev_count_differ"] == 0, (i, f)
+        assert f["keys_are_a_permutation"], (i, f)
+        assert f["dp"] <= 1e-6 * f["pmax"] + 2e-6 and f["du"] <= 1e-5 and f["dv"] <= 1e-5, (i, f)
+        solved += f["iters"][1] > 0
+    assert solved >= 3
