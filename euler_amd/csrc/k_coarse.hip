@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void k_coarse_inverse(const double* __restrict
 // ==========================================================================================
 // Multilevel mode (EULER_PRECOND_IC0_TILE_MG): z = M_tile^-1 r + P_0 V(P_0^T r).  Level l = aggregates of (16 << l)^2 grid cells; A_l as a
 // 5-point stencil with integer entries (d, rt = coupling to the aggregate on the right, up = to the one above); the level above the last is
-// the dense level of the two-level mode.  The oracle's restatement: mg_build / mg_vcycle (oracle/euler_oracle.c), same formulas in the same order.
+// the dense level of the two-level mode.  The CPU restatement the tests check it against (mg_build / mg_vcycle) uses the same formulas in the same order.
 //
 // A tile against the aggregates of 16: lane l = 16 j + i sits in aggregate row 4 band + j; its 16 records are the columns 16 (k - j) - i .. + 15:
 // the first i of them lie in aggregate column k - j - 1 ("left"), the other 16 - i in column k - j ("right") - for all 16 lanes of the group alike,
