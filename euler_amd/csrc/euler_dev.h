@@ -179,6 +179,7 @@ struct euler_sim {
   double *mg_rhs, *mg_x;             // right-hand side and result of the V-cycle per level (level 0's result is what k_search_apply adds to z)
   double* mg_part;                   // [chunks][4][2]: per tile and group of 16 lanes, the sums of r over the fluid cells left / right of the aggregate boundary
   double* mg_dot;                    // per-block partials of x_0 . rhs_0 (+ the ticket counter behind them)
+  double* mg_xbuf; int mg_xslot;     // row slabs: [ranks][mg_xslot] - every rank's {max |r|, dot(z,r), its rows of the level-0 right-hand side}, ONE all-gather inside the G1 exchange
   int tile_w;             // EULER_PRECOND_IC0_TILE: records per tile (include/euler.h precond_tile_records)
   const double* tile_as_override;   // where A s sits for the r update of the non-tile modes (z behind the first apply_a of a solve, else q)
   double* partial2;       // second set of reduction partials (k_precond_tile reduces max |r| and dot(z,r) at once)
@@ -337,6 +338,8 @@ void eu_coarse_release(euler_sim* S);
 int  eu_launch_coarse_setup(euler_sim* S);    // per solve: P^T A P, its factor and inverse
 int  eu_launch_coarse_solve(euler_sim* S, int fin_op, int force);   // per iteration: y = (P^T A P)^-1 P^T r, dot(z,r) += y . r_c, the scalar epilogue
 int  eu_launch_coarse_search_init(euler_sim* S);   // s = z + P y (the first search direction of a solve)
+int  eu_coarse_comm_slots(euler_sim* S);      // row slabs: doubles per rank in S->mg_xbuf (allocated on demand), < 0 on error
+int  eu_launch_coarse_pre(euler_sim* S, int force);   // row slabs: this rank's rows of the level-0 right-hand side into its slot, before the exchange
 int  eu_launch_coarse_add_row(euler_sim* S, double* row, int yrow);   // row slabs: + P y on a compact ghost row (grid row yrow)
 
 // ------------------------------------------------------------------------------------------

@@ -72,7 +72,8 @@ int eu_coarse_alloc(euler_sim* S) {
 
 void eu_coarse_release(euler_sim* S) {
   if (S->cc_diag) (void)hipFree(S->cc_diag);
-  for (double* d : {S->cc_fac, S->cc_inv, S->cc_part, S->cc_y, S->mg_rhs, S->mg_part, S->mg_dot}) if (d) (void)hipFree(d);
+  for (double* d : {S->cc_fac, S->cc_inv, S->cc_part, S->cc_y, S->mg_rhs, S->mg_part, S->mg_dot, S->mg_xbuf}) if (d) (void)hipFree(d);
+  S->mg_xbuf = nullptr; S->mg_xslot = 0;
   if (S->mg_d) (void)hipFree(S->mg_d);
   S->cc_diag = S->cc_right = S->cc_up = nullptr;
   S->cc_fac = S->cc_inv = S->cc_part = S->cc_y = nullptr;
@@ -324,13 +325,14 @@ __device__ __forceinline__ double mg_apply(const MgLevel& L, const double* __res
   return t;
 }
 
-// level-0 right-hand side from the tiles' partial sums (right part of tile J + j, then left part of tile J + j + 1), and its Jacobi step
-__global__ __launch_bounds__(256) void k_mg_gather0(const double* __restrict__ part, const int* __restrict__ d0, double* __restrict__ rhs0, double* __restrict__ x10,
-                                                    int nx0, int ny0, int ntb, int band_lo, int band_hi, const PcgScalars* sc, int force) {
+// level-0 right-hand side from the tiles' partial sums (right part of tile J + j, then left part of tile J + j + 1), and its Jacobi step.
+// Row slabs: rows [row0, row1) only, into this rank's slot of the exchange buffer (x10 null: k_mg_scatter0 forms the Jacobi step once every rank's rows are there)
+__global__ __launch_bounds__(256) void k_mg_gather0(const double* __restrict__ part, const int* __restrict__ d0, double* __restrict__ dst, double* __restrict__ x10,
+                                                    int nx0, int row0, int row1, int ntb, int band_lo, int band_hi, const PcgScalars* sc, int force) {
   if (!force && (sc->done || !sc->nonzero)) return;
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= nx0 * ny0) return;
-  const int I = c / nx0, J = c % nx0, band = I >> 2, j = I & 3;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= nx0 * (row1 - row0)) return;
+  const int I = row0 + k / nx0, J = k % nx0, band = I >> 2, j = I & 3;
   double t = 0.0;
   if (band >= band_lo && band < band_hi) {
     const size_t row = (size_t)(band - band_lo) * ntb;
@@ -338,18 +340,24 @@ __global__ __launch_bounds__(256) void k_mg_gather0(const double* __restrict__ p
     if (k0 < ntb) t = part[(row + k0) * 8 + j * 2 + 1];
     if (k1 < ntb) t = t + part[(row + k1) * 8 + j * 2];
   }
-  rhs0[c] = t;
-  const int d = d0[c];
-  x10[c] = d ? MG_OMEGA * t / (double)d : 0.0;
+  dst[k] = t;
+  if (x10) { const int d = d0[(size_t)I * nx0 + J]; x10[k] = d ? MG_OMEGA * t / (double)d : 0.0; }
 }
 
-// (row slabs: the other ranks' rows of rhs_0 arrive by all-gather; their Jacobi step is formed here)
-__global__ __launch_bounds__(256) void k_mg_jacobi0(const int* __restrict__ d0, const double* __restrict__ rhs0, double* __restrict__ x10, int n0, const PcgScalars* sc, int force) {
+// row slabs: every rank's rows of rhs_0 arrived in its slot of the exchange buffer ({max |r|, dot} first); rhs_0 whole, and its Jacobi step
+struct MgParts { int n; int lo[64], hi[64]; };      // aggregate rows [lo, hi) per rank
+__global__ __launch_bounds__(256) void k_mg_scatter0(const double* __restrict__ xbuf, int slot, MgParts P, const int* __restrict__ d0, double* __restrict__ rhs0, double* __restrict__ x10,
+                                                     int nx0, int n0, const PcgScalars* sc, int force) {
   if (!force && (sc->done || !sc->nonzero)) return;
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= n0) return;
+  const int I = c / nx0, J = c % nx0;
+  double t = 0.0;
+  for (int r = 0; r < P.n; ++r)
+    if (I >= P.lo[r] && I < P.hi[r]) { t = xbuf[(size_t)r * slot + 2 + (size_t)(I - P.lo[r]) * nx0 + J]; break; }
+  rhs0[c] = t;
   const int d = d0[c];
-  x10[c] = d ? MG_OMEGA * rhs0[c] / (double)d : 0.0;
+  x10[c] = d ? MG_OMEGA * t / (double)d : 0.0;
 }
 
 // down: the right-hand side of level l + 1 = the restricted residual of level l after its Jacobi step, children in the order (2I, 2J),
@@ -446,14 +454,14 @@ static int launch_mg_cycle(euler_sim* S, int fin_op, int force) {
   double* x1 = S->mg_x + S->mg_cells;      // the third pool
   auto level = [&](int l) { const size_t o = S->mg_off[l]; return MgLevel{S->mg_d + o, S->mg_rt + o, S->mg_up + o, S->mg_rhs + o, x1 + o, S->mg_nx[l], S->mg_ny[l]}; };
   const int n0 = S->mg_nx[0] * S->mg_ny[0];
-  LAUNCH(S, KC_PRECOND_TILE, k_mg_gather0, dim3((n0 + 255) / 256), dim3(256), S->mg_part, S->mg_d, S->mg_rhs, x1, S->mg_nx[0], S->mg_ny[0], S->geom.T / 16,
-         S->band_lo, S->band_hi, S->sc, force);
-  if (S->has_comm) {      // row slabs: every rank's rows of the level-0 right-hand side to every rank; the V-cycle itself runs replicated (identical bits everywhere)
-    int64_t off[64], cnt[64];
-    for (int r = 0; r < S->bulk.nranks && r < 64; ++r) { off[r] = (int64_t)4 * S->part_lo[r] * S->mg_nx[0] * sizeof(double); cnt[r] = (int64_t)4 * (S->part_hi[r] - S->part_lo[r]) * S->mg_nx[0] * sizeof(double); }
-    COMM_CALL(S->bulk.allgather(S->bulk.ctx, S->mg_rhs, off, cnt));
-    LAUNCH(S, KC_PRECOND_TILE, k_mg_jacobi0, dim3((n0 + 255) / 256), dim3(256), S->mg_d, S->mg_rhs, x1, n0, S->sc, force);
-  }
+  if (S->has_comm) {      // row slabs: the rows travelled inside the G1 exchange (eu_launch_coarse_pre); the V-cycle itself runs replicated (identical bits everywhere)
+    MgParts P;
+    P.n = S->bulk.nranks < 64 ? S->bulk.nranks : 64;
+    for (int r = 0; r < P.n; ++r) { P.lo[r] = 4 * S->part_lo[r]; P.hi[r] = 4 * S->part_hi[r]; }
+    LAUNCH(S, KC_PRECOND_TILE, k_mg_scatter0, dim3((n0 + 255) / 256), dim3(256), S->mg_xbuf, S->mg_xslot, P, S->mg_d, S->mg_rhs, x1, S->mg_nx[0], n0, S->sc, force);
+  } else
+    LAUNCH(S, KC_PRECOND_TILE, k_mg_gather0, dim3((n0 + 255) / 256), dim3(256), S->mg_part, S->mg_d, S->mg_rhs, x1, S->mg_nx[0], 0, S->mg_ny[0], S->geom.T / 16,
+           S->band_lo, S->band_hi, S->sc, force);
   double* top_rhs = S->cc_y + CC_MAX;
   for (int l = 0; l < nl; ++l) {
     const bool top = l + 1 == nl;
@@ -474,6 +482,27 @@ static int launch_mg_cycle(euler_sim* S, int fin_op, int force) {
       LAUNCH(S, KC_PRECOND_TILE, k_mg_up<true>, dim3(nb), dim3(256), level(l), e, enx, S->mg_x, S->sc, fin_op, force, S->mg_dot, reinterpret_cast<unsigned int*>(S->mg_dot + MG_DOT_BLOCKS));
     }
   }
+  return EULER_OK;
+}
+
+int eu_coarse_comm_slots(euler_sim* S) {
+  int rows = 0;
+  for (int r = 0; r < S->bulk.nranks && r < 64; ++r) rows = 4 * (S->part_hi[r] - S->part_lo[r]) > rows ? 4 * (S->part_hi[r] - S->part_lo[r]) : rows;
+  const int slot = 2 + rows * S->mg_nx[0];
+  if (slot != S->mg_xslot || !S->mg_xbuf) {
+    if (S->mg_xbuf) { if (hipStreamSynchronize(S->stream) != hipSuccess || hipFree(S->mg_xbuf) != hipSuccess) return -1; S->mg_xbuf = nullptr; }
+    if (hipMalloc((void**)&S->mg_xbuf, (size_t)slot * S->bulk.nranks * sizeof(double)) != hipSuccess) { eu_set_error("hipMalloc of the multilevel exchange buffer failed"); return -1; }
+    if (hipMemsetAsync(S->mg_xbuf, 0, (size_t)slot * S->bulk.nranks * sizeof(double), S->stream) != hipSuccess) return -1;
+    S->mg_xslot = slot;
+  }
+  return slot;
+}
+int eu_launch_coarse_pre(euler_sim* S, int force) {
+  const int row0 = 4 * S->band_lo, row1 = 4 * S->band_hi;
+  const int cells = (row1 - row0) * S->mg_nx[0];
+  if (cells > 0)
+    LAUNCH(S, KC_PRECOND_TILE, k_mg_gather0, dim3((cells + 255) / 256), dim3(256), S->mg_part, S->mg_d, S->mg_xbuf + (size_t)S->bulk.rank * S->mg_xslot + 2, (double*)nullptr,
+           S->mg_nx[0], row0, row1, S->geom.T / 16, S->band_lo, S->band_hi, S->sc, force);
   return EULER_OK;
 }
 

@@ -1763,10 +1763,10 @@ static int launch_dot(euler_sim* S, const double* a, const double* b, int fin_op
 static inline bool tile_fused(const euler_sim* S) { return eu_is_tile(S) && S->cfg.sweep_mode != EULER_SWEEP_SIMPLE; }
 // max |r| and dot(z,r) of all ranks after ONE exchange ("fuse the latter two into one ... message pair"): every rank
 // folds the gathered pairs in rank order - identical bits everywhere - and applies the two scalar epilogues
-__global__ void k_pair_fold(PcgScalars* sc, const double* __restrict__ pairs, int R, int rupd, int fin_dot, int force) {
+__global__ void k_pair_fold(PcgScalars* sc, const double* __restrict__ pairs, int stride, int R, int rupd, int fin_dot, int force) {
   if (!force && pcg_idle(sc)) return;
   double vmax = 0.0, vsum = 0.0;
-  for (int r = 0; r < R; ++r) { vmax = pairs[2 * r] > vmax ? pairs[2 * r] : vmax; vsum += pairs[2 * r + 1]; }
+  for (int r = 0; r < R; ++r) { vmax = pairs[(size_t)stride * r] > vmax ? pairs[(size_t)stride * r] : vmax; vsum += pairs[(size_t)stride * r + 1]; }
   if (rupd) pcg_scalar_step(sc, FIN_RNORM, vmax);
   if (fin_dot >= 0 && !(rupd && sc->done)) pcg_scalar_step(sc, fin_dot, vsum);
 }
@@ -1820,6 +1820,15 @@ static int launch_precond_tile(euler_sim* S, int rupd, int sweeps, int fin_dot, 
     a.cpart = mg ? S->mg_part : S->cc_part; a.cshift = mg ? 4 : S->coarse_shift;
     if (a.fin_dot >= 0) a.fin_dot = FIN_STORE_ONLY;
   }
+  // row slabs + coarse correction: the pair and this rank's rows of the level-0 right-hand side travel in ONE slot of ONE all-gather inside the G1 exchange
+  double* xsmall = S->pair_buf;
+  int nsmall = 2;
+  if (two_level && a.via == FIN_TO_COMM) {
+    nsmall = eu_coarse_comm_slots(S);
+    if (nsmall < 0) return EULER_ENOMEM;
+    xsmall = S->mg_xbuf;
+    a.pair_slot = xsmall + (size_t)S->comm.rank * nsmall;
+  }
   const int w = r_only ? 16 : S->tile_w, cls = r_only ? KC_UPDATE_PR : KC_PRECOND_TILE;
   const unsigned nblk = eu_blocks((size_t)(S->band_hi - S->band_lo) * (S->geom.T / w), PT_THREADS / 64, 2048);
   switch (w) {
@@ -1833,9 +1842,11 @@ static int launch_precond_tile(euler_sim* S, int rupd, int sweeps, int fin_dot, 
   if (a.via == FIN_TO_COMM) {          // no mailboxes: G1 - both results (and, in the solve, the edge rows of the new z) in ONE exchange, then the epilogues
     const int R = S->comm.nranks;
     const bool rows = ghost_mode(S) && !force;
-    int rc = comm_exchange(S, xrow(S, XR_ZSEND_LO), xrow(S, XR_ZSEND_HI), xrow(S, XR_ZRECV_LO), xrow(S, XR_ZRECV_HI), rows ? S->X : 0, S->pair_buf, 2);
+    int rc = two_level ? eu_launch_coarse_pre(S, force) : EULER_OK;
     if (rc) return rc;
-    hipLaunchKernelGGL(k_pair_fold, dim3(1), dim3(1), 0, S->stream, S->sc, S->pair_buf, R, rupd, a.fin_dot, force);
+    rc = comm_exchange(S, xrow(S, XR_ZSEND_LO), xrow(S, XR_ZSEND_HI), xrow(S, XR_ZRECV_LO), xrow(S, XR_ZRECV_HI), rows ? S->X : 0, xsmall, nsmall);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pair_fold, dim3(1), dim3(1), 0, S->stream, S->sc, xsmall, nsmall, R, rupd, a.fin_dot, force);
     // coarse correction on row slabs: the tiles' shares of dot(z, r) are folded (stored, not applied); the V-cycle - its level-0 right-hand
     // side all-gathered, the rest replicated - adds its share and applies the epilogue, the same bits on every rank
     if (two_level) { rc = eu_launch_coarse_solve(S, fin_real, force); if (rc) return rc; }

@@ -78,7 +78,7 @@ enum {
                                 Cost per iteration: the tile-local mode's two passes + a dozen launches over arrays 256 times smaller than
                                 the grid.  Restated in the oracle (eo_sim.coarse_mg): GPU = oracle to rounding.  EULER_DOT_TREE.  One GPU, or row slabs without
                                 mailboxes (euler_config.slab_*): an aggregate of 16 rows belongs to one rank, so every rank contributes its rows of the
-                                level-0 operator (per solve) and of the level-0 right-hand side (per iteration, one all-gather behind the G1 exchange)
+                                level-0 operator (per solve) and of the level-0 right-hand side (per iteration, inside the G1 exchange's all-gather)
                                 and all ranks run the same V-cycle - the same bits everywhere; the iteration counts are the single GPU's. */
 };
 
