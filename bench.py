@@ -416,6 +416,21 @@ def strong_block(ctx, size, steps, tile_w):
     if comm is not None and getattr(comm, "error", None):
         raise RuntimeError(comm.error)
     balance = rank_balance(ctx, sim, partition) if multi else None
+    # the same job with every solve run to the reference's tolerance (multilevel mode, cap lifted): what "a 16384^2 dam break, simulated" costs per frame
+    conv = None
+    if args.precond in ("ic0_tile", "ic0_tile_mg") and not getattr(args, "no_converged", False):
+        try:
+            sim.set_precond(ea.PRECOND_IC0_TILE_MG, args.tile_records)
+            sim.set_solver(20000, 1e-6)
+            sim.step()
+            st0 = sim.stats()
+            el = grp.timed(sim.step, 1)
+            st1 = sim.stats()
+            conv = {"mode": MODE_NAME["ic0_tile_mg"] % tile_w, "value": size * size / el, "unit": "cells*steps/s", "ms_per_step": 1e3 * el, "steps": 1, "tol": 1e-6,
+                    "substeps": int(st1.total_substeps - st0.total_substeps), "pcg_iterations": int(st1.total_pcg_iterations - st0.total_pcg_iterations),
+                    "last_residual": float(st1.last_residual)}
+        except Exception as e:      # (collective: a failure here is every rank's)
+            conv = {"error": repr(e)}
     out = None
     if rank == 0:
         rank_cells = None
@@ -428,7 +443,7 @@ def strong_block(ctx, size, steps, tile_w):
         out.update({"workload": "%dx%d dam break (block layout upscaled; BASELINE configs[3]), %d timed frames after %d preroll frames "
                                 "(into the phase where every substep runs PCG to the iteration cap)" % (size, size, steps, preroll),
                     "n_gpus": world if multi else 1, "scaling": "strong", "balance": balance, "hbm_bytes_this_rank": int(hbm),
-                    "setup_and_preroll_seconds": round(setup_s, 1),
+                    "setup_and_preroll_seconds": round(setup_s, 1), "converged_frames_multilevel": conv,
                     "note": ("rank 0's kernels cover its slab; `value` is the whole job" if multi else
                              "one GPU: the denominator of the strong-scaling curve (run `bench.py --gpus N` for the N-GPU points of the same scenario)")})
     sim.close()
