@@ -418,7 +418,7 @@ def strong_block(ctx, size, steps, tile_w):
     balance = rank_balance(ctx, sim, partition) if multi else None
     # the same job with every solve run to the reference's tolerance (multilevel mode, cap lifted): what "a 16384^2 dam break, simulated" costs per frame
     conv = None
-    if args.precond in ("ic0_tile", "ic0_tile_mg") and not getattr(args, "no_converged", False):
+    if args.precond in ("ic0_tile", "ic0_tile_mg") and not p2p_on:      # (the multilevel mode runs on the default transport, not over the mailboxes)
         try:
             sim.set_precond(ea.PRECOND_IC0_TILE_MG, args.tile_records)
             sim.set_solver(20000, 1e-6)

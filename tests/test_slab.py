@@ -181,6 +181,7 @@ def test_bench_multi_rank_contract(scaling):
         st = d["strong_512_dam_break"]
         assert st["scaling"] == "strong" and st["n_gpus"] == 2 and st["value"] > 0 and st["pcg_iterations"] > 0, st
         assert st["balance"]["partition"].startswith("fluid-balanced") and len(st["balance"]["rows_per_rank"]) == 2, st["balance"]
+        assert st["converged_frames_multilevel"] is None      # (--p2p here: the multilevel mode's converged frames need the default transport, test_slab_rows.py)
     assert d["config"]["grid"] == ([256, 512] if scaling == "weak" else [256, 256])
     assert "peer-to-peer mailboxes" in d["config"]["parallelism"] and "2 row slabs" in d["config"]["parallelism"]
     assert "EVERY stage decomposed" in d["config"]["parallelism"]        # true row slabs are the N > 1 default
