@@ -28,7 +28,7 @@
 
 static void usage(const char* argv0) {
   fprintf(stderr, "usage: %s [--rainbow] [--size XxY] [--upscale] [--frames N] [--window WxH] [--dump] [--no-pace] [--keys STRING] "
-                  "[--resume FILE] [--checkpoint FILE] <scenario>\n", argv0);
+                  "[--resume FILE] [--checkpoint FILE] [--solver reference|tile|two-level|multilevel] [--max-iterations N] <scenario>\n", argv0);
 }
 
 /* ---- terminal (misc/terminal.c) ------------------------------------------------------------ */
@@ -115,6 +115,18 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--keys") && i + 1 < argc) keys = argv[++i];
     else if (!strcmp(argv[i], "--resume") && i + 1 < argc) resume = argv[++i];
     else if (!strcmp(argv[i], "--checkpoint") && i + 1 < argc) checkpoint = argv[++i];
+    /* the pressure solver's preconditioner (include/euler.h EULER_PRECOND_*): `reference` (default) = main.c:577-627, bit-identical iterates;
+     * the others reach the same pressure where the solve converges - `multilevel` in ~110 iterations whatever the grid size, so with
+     * --max-iterations lifted above the reference's 100 (main.c:735) a large grid is actually SOLVED each substep */
+    else if (!strcmp(argv[i], "--solver") && i + 1 < argc) {
+      const char* v = argv[++i];
+      if (!strcmp(v, "reference")) cfg.precond = EULER_PRECOND_IC0;
+      else if (!strcmp(v, "tile")) cfg.precond = EULER_PRECOND_IC0_TILE;
+      else if (!strcmp(v, "two-level")) cfg.precond = EULER_PRECOND_IC0_TILE2;
+      else if (!strcmp(v, "multilevel")) cfg.precond = EULER_PRECOND_IC0_TILE_MG;
+      else { usage(argv[0]); return 1; }
+    }
+    else if (!strcmp(argv[i], "--max-iterations") && i + 1 < argc) { cfg.max_iterations = atoi(argv[++i]); if (cfg.max_iterations < 1) { usage(argv[0]); return 1; } }
     else if (argv[i][0] == '-') { fprintf(stderr, "Unrecognized input: %s\n", argv[i]); return 1; }   /* main.c:995 */
     else scenario = argv[i];
   }

@@ -407,6 +407,12 @@ def test_cli_dump_matches_reference_frames(tmp_path):
         assert body[:n] == r[key].tobytes(), key
     bad = subprocess.run([exe, "--dump", "/nonexistent.txt"], capture_output=True, timeout=60)
     assert bad.returncode == 1 and b"Could not load" in bad.stderr
+    # --solver: the other preconditioners draw the same frames where the solves converge (block.txt at rest: the first frames do)
+    for solver in ("tile", "two-level", "multilevel"):
+        alt = subprocess.run([exe, "--dump", "--frames", "2", "--window", "98x38", "--solver", solver, "--max-iterations", "500", str(scn)], capture_output=True, timeout=120)
+        assert alt.returncode == 0, alt.stderr.decode()
+        assert alt.stdout == out.stdout, solver
+    assert subprocess.run([exe, "--dump", "--solver", "nonsense", str(scn)], capture_output=True, timeout=60).returncode == 1
 
 
 # ----------------------------------------------------------------------------- randomized marker stress
