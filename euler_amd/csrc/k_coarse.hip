@@ -1,6 +1,8 @@
-// k_coarse.hip — the coarse level of the TWO-LEVEL preconditioner (EULER_PRECOND_IC0_TILE2, include/euler.h; round 3):
+// k_coarse.hip — the coarse levels of the TWO-LEVEL and the MULTILEVEL preconditioner (EULER_PRECOND_IC0_TILE2 / _TILE_MG, include/euler.h; round 3):
 //
-//     z = M_tile^-1 r + P (P^T A P)^-1 P^T r
+//     z = M_tile^-1 r + P (P^T A P)^-1 P^T r            (two-level; the first part of this file)
+//     z = M_tile^-1 r + P_0 V(P_0^T r)                  (multilevel: "Multilevel mode" below - a V-cycle over aggregates of 16, 32, ... cells whose top level is the
+//                                                        dense level of the two-level mode; also on row slabs)
 //
 // M_tile = the tile-local IC(0) of k_pcg.hip (64-row x 16-record blocks, one pass over memory); P = piecewise constants over coarse
 // cells of g x g grid cells (g = 64 m, a power of two; at most 256 coarse cells, 16 x 16 on a square grid) restricted to the fluid.
@@ -34,8 +36,10 @@
 // the scalar epilogues of k_pcg.hip (same codes)
 enum { CFIN_SIGMA_INIT = 0, CFIN_BETA = 3 };
 
+void eu_coarse_release(euler_sim* S);
 int eu_coarse_alloc(euler_sim* S) {
-  if (S->cc_inv) return EULER_OK;
+  if (S->mg_dot) return EULER_OK;      // (the last allocation below: everything is there)
+  eu_coarse_release(S);                // (a failed earlier attempt may have left some of it)
   int m = 1, shift = 6;
   while (((S->X + 64 * m - 1) / (64 * m)) * ((S->geom.nbands + m - 1) / m) > CC_MAX) { m *= 2; shift += 1; }
   S->coarse_m = m; S->coarse_shift = shift;
