@@ -754,6 +754,8 @@ def parity_vs_reference(ea, scenarios, so, device, dot_mode, tile_records, cases
         for _ in range(more):
             sim.step()
         pre += more
+        snap = os.path.join(tempfile.mkdtemp(prefix="euler_bench_"), "state.bin")
+        sim.save_state(snap)      # (the same state again below, for the frames in other modes)
         o = oracle_from_sim(sim, ea, so)
         t0 = time.perf_counter()
         o.step()
@@ -761,6 +763,7 @@ def parity_vs_reference(ea, scenarios, so, device, dot_mode, tile_records, cases
         sim.set_precond(ea.PRECOND_IC0_TILE, tile_records)
         sim.step()
         st = sim.stats()
+        tile_uv = (sim.get(ea.F_U), sim.get(ea.F_V), sim.get(ea.F_COUNT) > 0)
         pr = o.p
         pmax = float(np.abs(pr).max())
         gfl, ofl = sim.get(ea.F_COUNT) > 0, o.count > 0
@@ -784,6 +787,30 @@ def parity_vs_reference(ea, scenarios, so, device, dot_mode, tile_records, cases
                                 "solve_speedup_at_equal_residual": sc["solve_speedup_at_equal_residual"]}
         except Exception as ex:
             e["next_system"] = {"error": repr(ex)}
+        try:      # ... and all three against the CONVERGED frame of the same state (multilevel mode, cap lifted: every solve to the reference's tolerance)
+            def frame(precond, cap):
+                sim.load_state(snap)
+                sim.set_precond(precond, tile_records)
+                sim.set_solver(cap, 1e-6)
+                t0 = time.perf_counter()
+                sim.step()
+                s2 = sim.stats()
+                return sim.get(ea.F_U), sim.get(ea.F_V), sim.get(ea.F_COUNT) > 0, s2, time.perf_counter() - t0
+            us, vs, fs, sst, secs = frame(ea.PRECOND_IC0_TILE_MG, 20000)
+            um, vm, fm, mst, msecs = frame(ea.PRECOND_IC0_TILE_MG, 100)
+
+            def dist(u, v, f):
+                return {"max_abs_du": float(np.abs(u - us).max()), "max_abs_dv": float(np.abs(v - vs).max()), "fluid_cells_differing": int((f != fs).sum())}
+            e["against_converged"] = {"converged": {"substeps": int(sst.last_substeps), "pcg_iterations": int(sst.last_pcg_iterations), "residual_last_solve": float(sst.last_residual),
+                                                    "frame_seconds": round(secs, 3)},
+                                      "reference_ic0_cap_100": dist(o.u, o.v, ofl), "tile_local_cap_100": dist(*tile_uv),
+                                      "multilevel_cap_100": dict(dist(um, vm, fm), frame_seconds=round(msecs, 3), pcg_iterations=int(mst.last_pcg_iterations))}
+        except Exception as ex:
+            e["against_converged"] = {"error": repr(ex)}
+        try:
+            os.remove(snap); os.rmdir(os.path.dirname(snap))
+        except OSError:
+            pass
         out.append(e)
         o.close()
         sim.close()

@@ -236,6 +236,21 @@ def test_tile_mode_fields_against_the_reference_preconditioner_per_baseline_work
         if ns["residual_reference_ic0_100"] > 0 and e["max_p"] > 0:
             assert ns["tile_budget_for_equal_residual"] is not None and ns["tile_budget_for_equal_residual"] <= 1200, ns
             assert ns["solve_speedup_at_equal_residual"] >= 1.2, ns
+    # ... and against the CONVERGED frame of the same state (multilevel mode, cap lifted): the recorded distances of the three capped runs
+    for e in res:
+        ac = e["against_converged"]
+        assert "error" not in ac, ac
+        assert ac["converged"]["residual_last_solve"] <= 1e-6
+        print(e["state"], {k: v for k, v in ac.items()})
+    for e in converged:      # where the reference's cap does not bind, everybody sits on the converged frame
+        ac = e["against_converged"]
+        for k in ("reference_ic0_cap_100", "tile_local_cap_100", "multilevel_cap_100"):
+            assert ac[k]["max_abs_du"] <= 1e-4 and ac[k]["max_abs_dv"] <= 1e-4, (k, ac)
+    for e in capped:         # where it binds, the multilevel mode at the same cap is the nearest of the three (the half tank: by orders of magnitude)
+        ac = e["against_converged"]
+        if e["max_p"] > 0 and e["max_abs_velocity"] > 0:
+            m, r, t = (max(ac[k]["max_abs_du"], ac[k]["max_abs_dv"]) for k in ("multilevel_cap_100", "reference_ic0_cap_100", "tile_local_cap_100"))
+            assert m <= r * 1.05 + 1e-6 and m <= t * 1.05 + 1e-6, ac
 
 
 # ----------------------------------------------------------------------------- two-level preconditioner (EULER_PRECOND_IC0_TILE2)
