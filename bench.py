@@ -1122,6 +1122,9 @@ def main():
         "kernels": head["kernels"],
         "cpu_baseline": cpu_obj,
         "equal_residual": equal,
+        # the same workload with EVERY solve run to the reference's tolerance 1e-6 (multilevel mode, cap lifted) - not the headline (whose work is fixed at 100 iterations per
+        # substep by BASELINE configs[2]), the figure for "this grid, actually solved"; a copy of equal_residual.multilevel.converged_frames
+        "converged_frames_multilevel": (equal or {}).get("multilevel", {}).get("converged_frames") if isinstance(equal, dict) and isinstance(equal.get("multilevel"), dict) else None,
         "strong_%d_dam_break" % args.strong_size: strong,
         "secondary": secondary or None,
         "device": device,
