@@ -184,6 +184,8 @@ extern "C" void euler_destroy(euler_sim* S) {
   for (float* f : {S->u, S->v, S->utmp, S->vtmp}) if (f) (void)hipFree(f + wo);
   for (uint8_t* g : {S->solid, S->source, S->sink, S->count, S->prev_count}) if (g) (void)hipFree(g + wo);
   if (S->count32) (void)hipFree(S->count32);
+  if (S->sys_m) (void)hipFree(S->sys_m);
+  if (S->sys_div) (void)hipFree(S->sys_div);
   void* dev[] = {S->markers[0], S->markers[1], S->keys[0], S->keys[1], S->ms, S->evmask, S->ev_theta, S->ev_delta, S->sel_idx, S->act_idx,
                  S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->halo_buf, S->band_ranges, S->partial2, S->pair_buf, S->xrows, S->alpha_buf, S->rng_jump, S->chunk_flag, S->chunk_prev, S->chunk_part, S->tile_table, S->chunk_bits, S->chunk_list,
                  S->rowmajor_tmp};
@@ -294,6 +296,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   DALLOC(S->u, Cw); DALLOC(S->v, Cw); DALLOC(S->utmp, Cw); DALLOC(S->vtmp, Cw);
   DALLOC(S->solid, Cw); DALLOC(S->source, Cw); DALLOC(S->sink, Cw); DALLOC(S->count, Cw); DALLOC(S->prev_count, Cw);
   DALLOC(S->count32, Cw);
+  DALLOC(S->sys_m, Cw); DALLOC(S->sys_div, Cw);
   if (S->cfg.rainbow) for (float*& d : S->dye) DALLOC(d, Cw);      // (the window like every row-major field; the whole grid without slabs)
   // MAX_MARKER_COUNT = 4 X Y (main.c:92) is the GLOBAL cap; a slab holds the markers inside its rows: room for 6 per owned cell
   S->max_markers = 4 * C;

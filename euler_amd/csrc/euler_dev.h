@@ -161,6 +161,7 @@ struct euler_sim {
   double* s2;             // second search-direction array (k_search_apply ping-pongs s / s2)
   void* skew_alloc[9];    // the raw allocations behind b p r z s s2 q precon cellmask (each array is staggered inside its own)
   uint8_t* cellmask;
+  uint8_t* sys_m; float* sys_div;   // row-major scratch of the assembly (k_cell_system -> k_build_system): mask byte and float divergence per cell of the window, indexed i - win_off
   unsigned int* fbits_fwd; unsigned int* fbits_bwd;   // fluid flags of the sweeps, 8 steps to a dword (k_pack_fbits)
   int fb_stride;          // words per band and lane
   int4* band_ranges;      // per band: active block ranges of the forward / backward sweeps (per solve)

@@ -281,6 +281,87 @@ __global__ __launch_bounds__(256) void k_build_system(const float* __restrict__ 
   if (in_chunks && __any(m != CM_INTERIOR) && (threadIdx.x & 63) == 0) chunk_part[chunk] = 1;
 }
 
+// The assembly in two steps (round 3).  k_build_system above gathers along the diagonal: a wave's 64 lanes sit in 64 different rows, so
+// each of the 13 loads of a fluid cell touches 64 cache lines - the texture path, not HBM, set its 1.27 ms at 8192^2 (1.2 GB of traffic).
+// Here the neighbourhood work runs where it coalesces - k_cell_system, a thread per cell of the row-major grids, leaves the mask byte and
+// the float divergence (main.c:720) per cell - and the skewed pass gathers just those two (one for a cell without fluid): same bits.
+// (Measured and rejected: staging the row-major fields of a chunk's parallelogram through LDS - 81 columns for 16 records, 52 KB per 1024
+// cells: 3.1 ms.)
+__global__ __launch_bounds__(256) void k_cell_system(const float* __restrict__ u, const float* __restrict__ v, const uint8_t* __restrict__ count,
+                                                     const uint8_t* __restrict__ solid, uint8_t* __restrict__ sys_m, float* __restrict__ sys_div,
+                                                     int X, int y0, int y1, size_t win_off) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= (size_t)X * (y1 - y0)) return;
+  const size_t i = (size_t)y0 * X + k;
+  uint8_t m = 0;
+  float div_f = 0.f;
+  if (count[i] != 0) {   // never true on the border ring (sinks), so the +-1 / +-X reads are in range
+    m = CM_FLUID;
+    if (count[i + 1]) m |= CM_RIGHT;
+    if (count[i + X]) m |= CM_UP;
+    if (count[i - 1]) m |= CM_LEFT;
+    if (count[i - X]) m |= CM_DOWN;
+    const int diag = 4 - solid[i - 1] - solid[i + 1] - solid[i - X] - solid[i + X];
+    m |= (uint8_t)(diag << CM_DIAG_SHIFT);
+    div_f = (u[i] - u[i - 1] + v[i] - v[i - X]) / EU_H;               // float expression, main.c:720
+  }
+  sys_m[i - win_off] = m;
+  sys_div[i - win_off] = div_f;
+}
+
+template <bool TILE>
+__global__ __launch_bounds__(256) void k_build_system2(const uint8_t* __restrict__ sys_m, const float* __restrict__ sys_div, size_t win_off,
+                                                       double* __restrict__ b, double* __restrict__ r, double* __restrict__ p,
+                                                       double* __restrict__ q, double* __restrict__ z,
+                                                       uint8_t* __restrict__ cellmask,
+                                                       PcgScalars* sc, SkewGeom g, float dt, size_t e_lo, size_t e_cnt,
+                                                       uint8_t* __restrict__ chunk_flag, uint8_t* __restrict__ chunk_part,
+                                                       const uint8_t* __restrict__ chunk_prev) {
+  const size_t e = e_lo + eu_xcd_block() * blockDim.x + threadIdx.x;   // this rank's bands only
+  const size_t we = e_lo + eu_xcd_block() * blockDim.x + (threadIdx.x & ~63u);      // the wave's first element
+  const size_t per_band = (size_t)g.TS * 64;
+  const size_t chunk = ((we - e_lo) / per_band) * (size_t)(g.T / 16) + ((we % per_band) / 64) / 16;
+  const bool in_chunks = (we % per_band) / 64 < (size_t)g.T;      // (the TS - T records behind a band's last chunk are padding)
+  bool nz = false, fl = false, inside = false;
+  uint8_t m = 0;
+  double bv = 0.0;
+  if (e < e_lo + e_cnt) {
+    const int X = g.X;
+    int band, t, l;
+    skew_decode(g, e, band, t, l);
+    const int x = t - l, y = band * 64 + l;
+    if (x >= 0 && x < X && y < g.Y) {
+      inside = true;
+      const size_t il = (size_t)y * X + x - win_off;
+      m = sys_m[il];
+      if (m) {
+        fl = true;
+        const float k_inv_scale_f = (EU_H * EU_H) * EU_RHO / dt;                      // float expression, main.c:713
+        bv = -(double)sys_div[il] * (double)k_inv_scale_f;
+        nz = bv != 0.0;
+      }
+    }
+  }
+  const bool wave_fluid = __any(fl);
+  const bool touch = !TILE || wave_fluid || (in_chunks && chunk_prev[chunk] != 0);
+  if (inside && touch) {
+    cellmask[e] = m;
+    b[e] = bv;
+    r[e] = bv;
+    p[e] = 0.0;
+    if (!TILE) {
+      q[e] = 0.0;   // the sweeps only visit the records that hold fluid (k_band_ranges): what they skip must be +0
+      z[e] = 0.0;
+    }
+  }
+  if (__any(nz) && (threadIdx.x & 63) == 0 && __hip_atomic_load(&sc->nonzero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+    atomicOr(&sc->nonzero, 1);
+  if ((threadIdx.x & 63) == 0 && in_chunks) {
+    if (wave_fluid) chunk_flag[chunk] = 1;
+  }
+  if (in_chunks && __any(m != CM_INTERIOR) && (threadIdx.x & 63) == 0) chunk_part[chunk] = 1;
+}
+
 // one bit per chunk from the bytes k_build_system left (the ordered select wants bits)
 __global__ __launch_bounds__(256) void k_pack_chunk_bits(const uint8_t* __restrict__ flag, unsigned long long* __restrict__ bits, size_t nwords, size_t nchunks) {
   const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -351,7 +432,18 @@ int eu_launch_build_system(euler_sim* S, float dt) {
   HIPCHK(hipMemsetAsync(S->chunk_part, 0, S->chunk_cap + 64, S->stream));
   // the lean assembly needs every solve since the arrays were last written whole to have been a tile-mode solve of this handle
   const bool lean = eu_is_tile(S) && S->cfg.sweep_mode != EULER_SWEEP_SIMPLE && S->lean_ok;
-  if (lean)
+  static const bool gather = getenv("EULER_BUILD_GATHER") != nullptr;      // (experiments: the one-kernel diagonal gather of rounds 1-2)
+  if (!gather) {
+    const size_t win_off = (size_t)S->win_lo * S->X;
+    LAUNCH(S, KC_BUILD_SYSTEM, k_cell_system, dim3(eu_blocks((size_t)S->X * (S->row_hi - S->row_lo), 256)), dim3(256), S->utmp, S->vtmp, S->count, S->solid, S->sys_m, S->sys_div,
+           S->X, S->row_lo, S->row_hi, win_off);
+    if (lean)
+      LAUNCH(S, KC_BUILD_SYSTEM, k_build_system2<true>, dim3(eu_blocks(S->e_cnt, 256)), dim3(256), S->sys_m, S->sys_div, win_off, S->b, S->r, S->p, S->q, S->z, S->cellmask, S->sc,
+             S->geom, dt, S->e_lo, S->e_cnt, S->chunk_flag, S->chunk_part, S->chunk_prev);
+    else
+      LAUNCH(S, KC_BUILD_SYSTEM, k_build_system2<false>, dim3(eu_blocks(S->e_cnt, 256)), dim3(256), S->sys_m, S->sys_div, win_off, S->b, S->r, S->p, S->q, S->z, S->cellmask, S->sc,
+             S->geom, dt, S->e_lo, S->e_cnt, S->chunk_flag, S->chunk_part, S->chunk_prev);
+  } else if (lean)
     LAUNCH(S, KC_BUILD_SYSTEM, k_build_system<true>, dim3(eu_blocks(S->e_cnt, 256)), dim3(256), S->utmp, S->vtmp, S->count,
            S->solid, S->b, S->r, S->p, S->q, S->z, S->cellmask, S->sc, S->geom, dt, S->e_lo, S->e_cnt, S->chunk_flag, S->chunk_part, S->chunk_prev);
   else
