@@ -30,9 +30,13 @@ emit("| config | mode | steps | substeps | PCG iterations | markers (start -> en
 emit("|---|---|---|---|---|---|---|---|---|---|---|")
 for label, size, text, steps in (("configs[1] 1024^2 dam break", 1024, scenarios.dam_break(), 500),
                                  ("configs[4] 4096^2 waterfall", 4096, scenarios.waterfall(), 2000)):
-    for pc, budget, name in ((ea.PRECOND_IC0, 100, "parity (reference IC(0), 100)"), (ea.PRECOND_IC0_TILE, 100, "roofline (tile-local, 100)"),
-                             (ea.PRECOND_IC0_TILE, BUDGET, "roofline (tile-local, %d)" % BUDGET)):
-        sim = ea.Simulation(size, size, dot_mode=ea.DOT_TREE, precond=pc, max_iterations=budget).load_text(text, upscale=True)
+    modes = ((ea.PRECOND_IC0, 100, "parity (reference IC(0), 100)"), (ea.PRECOND_IC0_TILE, 100, "roofline (tile-local, 100)"),
+             (ea.PRECOND_IC0_TILE, BUDGET, "roofline (tile-local, %d)" % BUDGET),
+             (ea.PRECOND_IC0_TILE_MG, 100, "multilevel (100)"), (ea.PRECOND_IC0_TILE_MG, 20000, "multilevel, every solve to 1e-6"))
+    if os.environ.get("EULER_LONG_RUN_MODES"):      # e.g. "multilevel": only the modes whose name starts like that
+        modes = [m for m in modes if m[2].startswith(os.environ["EULER_LONG_RUN_MODES"])]
+    for pc, budget, name in modes:
+        sim = ea.Simulation(size, size, dot_mode=ea.DOT_TREE, precond=pc, max_iterations=budget, pcg_poll_interval=8 if budget <= 200 else 32).load_text(text, upscale=True)
         n0 = sim.stats().n_markers
         latch = None
         t0 = time.time()
