@@ -47,7 +47,7 @@ int eu_coarse_alloc(euler_sim* S) {
   S->coarse_ny = (S->geom.nbands + m - 1) / m;
   S->coarse_n = S->coarse_nx * S->coarse_ny;
   const size_t n = (size_t)S->coarse_n;
-  HIPCHK(hipMalloc((void**)&S->cc_diag, 3 * n * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&S->cc_diag, 4 * n * sizeof(int)));      // diagonal, right, up; pinned[n] (k_coarse_factor)
   S->cc_right = S->cc_diag + n; S->cc_up = S->cc_diag + 2 * n;
   HIPCHK(hipMalloc((void**)&S->cc_fac, n * n * sizeof(double)));
   HIPCHK(hipMalloc((void**)&S->cc_inv, n * n * sizeof(double)));
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_coarse_assemble(const uint8_t* __restri
 // global memory instead - same arithmetic, same order.
 #define CC_LDS_BAND 8192      // doubles
 __global__ __launch_bounds__(CC_THREADS) void k_coarse_factor(const int* __restrict__ cd, const int* __restrict__ cr, const int* __restrict__ cu,
-                                                              int n, int nx, int bw, double* __restrict__ A, const PcgScalars* sc) {
+                                                              int n, int nx, int bw, double* __restrict__ A, const PcgScalars* sc, int* __restrict__ pinned) {
   if (!sc->nonzero) return;
   __shared__ double s_band[CC_LDS_BAND];
   __shared__ double s_d;
@@ -165,7 +165,14 @@ __global__ __launch_bounds__(CC_THREADS) void k_coarse_factor(const int* __restr
   __syncthreads();
   for (int k = 0; k < n; ++k) {
     const int w = k + bw < n - 1 ? bw : n - 1 - k;      // rows below the diagonal inside the band
-    if (tid == 0) { const double d = sqrt(M[k * rs + k + off]); M[k * rs + k + off] = d; s_d = d; }
+    if (tid == 0) {
+      // a fluid region cut off from the air (closed box, enclosed pool) makes A - and P^T A P - singular: the last pivot of such a component is rounding noise instead
+      // of 0.  Like the reference's own factor (main.c:595) the pivot falls back to the matrix' diagonal then: that coarse cell is pinned, the operator stays positive definite
+      double piv = M[k * rs + k + off];
+      const double a_kk = cd[k] != 0 ? (double)cd[k] : 1.0;
+      if (!(piv > 1e-8 * a_kk)) { piv = a_kk; if (cd[k] != 0) pinned[k] = 1; }      // (k_coarse_nullfix takes the pinned cell's component out of the inverse again)
+      const double d = sqrt(piv); M[k * rs + k + off] = d; s_d = d;
+    }
     __syncthreads();
     if (tid < w) M[(k + 1 + tid) * rs + k + off] /= s_d;
     __syncthreads();
@@ -489,6 +496,46 @@ static int launch_mg_cycle(euler_sim* S, int fin_op, int force) {
   return EULER_OK;
 }
 
+// ---- fluid cut off from the air: P^T A P has the indicator n of every such component in its null space, the factor pinned one cell of it (k_coarse_factor) and the inverse
+// S of the pinned matrix treats the component lopsidedly - PCG then stalls on the part of r along n that no A s can touch.  With n = a_kk S e_k (the pinned system's answer
+// to the pin itself: exactly the indicator) the inverse becomes (I - n n^T / n.n) S (I - n n^T / n.n): the pseudo-inverse of P^T A P - zero along n, S elsewhere.
+__global__ __launch_bounds__(CC_THREADS) void k_coarse_nullfix(double* __restrict__ inv, const int* __restrict__ cd, const int* __restrict__ pinned, int n, const PcgScalars* sc) {
+  if (!sc->nonzero) return;
+  __shared__ double s_n[CC_MAX], s_w[CC_MAX], s_red[CC_THREADS / 64];
+  __shared__ double s_nn, s_nw;
+  const int tid = threadIdx.x;
+  for (int k = 0; k < n; ++k) {
+    if (!pinned[k]) continue;      // (uniform)
+    const double a_kk = (double)cd[k];
+    if (tid < n) s_n[tid] = a_kk * inv[(size_t)tid * n + k];
+    __syncthreads();
+    double v = tid < n ? s_n[tid] * s_n[tid] : 0.0;
+    v = eu_wave_sum(v);
+    if ((tid & 63) == 0) s_red[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) { double t = 0.0; for (int q = 0; q < CC_THREADS / 64; ++q) t += s_red[q]; s_nn = t; }
+    __syncthreads();
+    if (tid < n) {      // w = S n
+      double t = 0.0;
+      for (int j = 0; j < n; ++j) t += inv[(size_t)j * n + tid] * s_n[j];
+      s_w[tid] = t;
+    }
+    __syncthreads();
+    v = tid < n ? s_n[tid] * s_w[tid] : 0.0;
+    v = eu_wave_sum(v);
+    if ((tid & 63) == 0) s_red[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) { double t = 0.0; for (int q = 0; q < CC_THREADS / 64; ++q) t += s_red[q]; s_nw = t; }
+    __syncthreads();
+    const double nn = s_nn, c = s_nw / (nn * nn);
+    for (int e = tid; e < n * n; e += CC_THREADS) {
+      const int i = e / n, j = e % n;
+      inv[e] = inv[e] - (s_n[i] * s_w[j] + s_w[i] * s_n[j]) / nn + s_n[i] * s_n[j] * c;
+    }
+    __syncthreads();
+  }
+}
+
 int eu_coarse_comm_slots(euler_sim* S) {
   int rows = 0;
   for (int r = 0; r < S->bulk.nranks && r < 64; ++r) rows = 4 * (S->part_hi[r] - S->part_lo[r]) > rows ? 4 * (S->part_hi[r] - S->part_lo[r]) : rows;
@@ -512,7 +559,7 @@ int eu_launch_coarse_pre(euler_sim* S, int force) {
 
 int eu_launch_coarse_setup(euler_sim* S) {
   const int n = S->coarse_n;
-  HIPCHK(hipMemsetAsync(S->cc_diag, 0, 3 * (size_t)n * sizeof(int), S->stream));
+  HIPCHK(hipMemsetAsync(S->cc_diag, 0, 4 * (size_t)n * sizeof(int), S->stream));
   const unsigned nblk = eu_blocks(S->chunk_cap, 4, 2048);
   if (eu_is_mg(S) && S->mg_levels > 0) {      // level 0 from the cells, every further level (and the dense one) from the level below
     HIPCHK(hipMemsetAsync(S->mg_d, 0, 3 * S->mg_cells * sizeof(int), S->stream));
@@ -538,8 +585,9 @@ int eu_launch_coarse_setup(euler_sim* S) {
          S->coarse_m, S->coarse_nx, S->cc_diag, S->cc_right, S->cc_up);
   }
   const int bw = S->coarse_ny > 1 ? S->coarse_nx : 1;      // half-bandwidth of P^T A P in row-major order of the coarse cells
-  LAUNCH(S, KC_PRECON_FACTOR, k_coarse_factor, dim3(1), dim3(CC_THREADS), S->cc_diag, S->cc_right, S->cc_up, n, S->coarse_nx, bw, S->cc_fac, S->sc);
+  LAUNCH(S, KC_PRECON_FACTOR, k_coarse_factor, dim3(1), dim3(CC_THREADS), S->cc_diag, S->cc_right, S->cc_up, n, S->coarse_nx, bw, S->cc_fac, S->sc, S->cc_diag + 3 * (size_t)n);
   LAUNCH(S, KC_PRECON_FACTOR, k_coarse_inverse, dim3((n + 3) / 4), dim3(256), S->cc_fac, n, bw, S->cc_inv, S->sc);
+  LAUNCH(S, KC_PRECON_FACTOR, k_coarse_nullfix, dim3(1), dim3(CC_THREADS), S->cc_inv, S->cc_diag, S->cc_diag + 3 * (size_t)n, n, S->sc);
   return EULER_OK;
 }
 

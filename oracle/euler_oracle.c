@@ -59,7 +59,7 @@ void eo_destroy(eo_sim* s) {
   free(s->markers); free(s->a_diag); free(s->precon); free(s->q);
   free(s->b); free(s->p); free(s->r); free(s->z); free(s->s);
   free(s->cr); free(s->cg); free(s->cb); free(s->crtmp); free(s->cgtmp); free(s->cbtmp);
-  free(s->coarse_chol);
+  free(s->coarse_chol); free(s->coarse_null);
   mg_free(s);
   free(s);
 }
@@ -508,10 +508,12 @@ int eo_coarse_m(int X, int Y) {
   while (((X + 64 * m - 1) / (64 * m)) * ((Y + 64 * m - 1) / (64 * m)) > 256) m *= 2;
   return m;
 }
+static void coarse_top_solve(eo_sim* s, double* rc);
 static void coarse_factor(eo_sim* s) {      /* A_c = P^T A P: sums of A's entries over pairs of coarse cells, then its Cholesky factor */
   const int X = s->X, Y = s->Y, g = 64 * s->coarse_m;
   const int nx = (X + g - 1) / g, ny = (Y + g - 1) / g, n = nx * ny;
   double* A = (double*)calloc((size_t)n * n, sizeof(double));
+  s->coarse_npinned = 0;
   for (int y = 0; y < Y; ++y)
     for (int x = 0; x < X; ++x) {
       if (!FLUID(s, y, x)) continue;
@@ -521,7 +523,11 @@ static void coarse_factor(eo_sim* s) {      /* A_c = P^T A P: sums of A's entrie
       if (FLUID(s, y + 1, x)) { const int d = ((y + 1) / g) * nx + x / g; A[(size_t)c * n + d] -= 1; A[(size_t)d * n + c] -= 1; }
     }
   for (int c = 0; c < n; ++c) if (A[(size_t)c * n + c] == 0.0) A[(size_t)c * n + c] = 1.0;      /* a coarse cell without fluid */
+  double* a_kk = (double*)malloc((size_t)n * sizeof(double));
+  for (int c = 0; c < n; ++c) a_kk[c] = A[(size_t)c * n + c];
   for (int k = 0; k < n; ++k) {      /* in place, lower triangle (banded: entries beyond column distance nx stay 0) */
+    /* fluid cut off from the air makes A and P^T A P singular: the last pivot of such a component is rounding noise - it falls back to the diagonal (that coarse cell is pinned) */
+    if (!(A[(size_t)k * n + k] > 1e-8 * a_kk[k])) { A[(size_t)k * n + k] = a_kk[k]; if (s->coarse_npinned < 16 && a_kk[k] != 1.0) s->coarse_pinned[s->coarse_npinned++] = k; }
     const double d = sqrt(A[(size_t)k * n + k]);
     A[(size_t)k * n + k] = d;
     const int hi = k + nx < n - 1 ? k + nx : n - 1;
@@ -530,8 +536,35 @@ static void coarse_factor(eo_sim* s) {      /* A_c = P^T A P: sums of A's entrie
       for (int i = j; i <= hi; ++i) A[(size_t)i * n + j] -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
   }
   s->coarse_chol = A; s->coarse_n = n; s->coarse_nx = nx;
+  /* the indicator of every cut-off component: the pinned system's answer to its own pin, n = a_kk S e_k (coarse_top_solve projects it out on both sides) */
+  free(s->coarse_null);
+  s->coarse_null = s->coarse_npinned ? (double*)calloc((size_t)s->coarse_npinned * n, sizeof(double)) : NULL;
+  const int np = s->coarse_npinned;
+  s->coarse_npinned = 0;      /* (plain pinned solves while the indicators are formed, one after the other as the product does) */
+  for (int q = 0; q < np; ++q) {
+    double* nv = s->coarse_null + (size_t)q * n;
+    nv[s->coarse_pinned[q]] = a_kk[s->coarse_pinned[q]];
+    coarse_top_solve(s, nv);
+    s->coarse_npinned = q + 1;
+  }
+  free(a_kk);
 }
-static void coarse_top_solve(eo_sim* s, double* rc) {      /* rc <- (P^T A P)^-1 rc by the two banded substitutions */
+static void coarse_project_null(const eo_sim* s, double* v) {      /* v <- (I - n n^T / n.n) v for the indicator n of every cut-off component */
+  const int n = s->coarse_n;
+  for (int q = 0; q < s->coarse_npinned; ++q) {
+    const double* nv = s->coarse_null + (size_t)q * n;
+    double nn = 0.0, nvv = 0.0;
+    for (int i = 0; i < n; ++i) { nn += nv[i] * nv[i]; nvv += nv[i] * v[i]; }
+    for (int i = 0; i < n; ++i) v[i] -= nv[i] * (nvv / nn);
+  }
+}
+static void coarse_top_solve_pinned(eo_sim* s, double* rc);
+static void coarse_top_solve(eo_sim* s, double* rc) {      /* rc <- pseudo-inverse of P^T A P applied to rc */
+  coarse_project_null(s, rc);
+  coarse_top_solve_pinned(s, rc);
+  coarse_project_null(s, rc);
+}
+static void coarse_top_solve_pinned(eo_sim* s, double* rc) {      /* rc <- S rc, S = the inverse of the (pinned) factored matrix, by the two banded substitutions */
   const int n = s->coarse_n, nx = s->coarse_nx;
   const double* L = s->coarse_chol;
   for (int i = 0; i < n; ++i) {      /* L w = r_c */

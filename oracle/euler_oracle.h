@@ -76,6 +76,10 @@ typedef struct eo_sim {
    * same top level, 121 multilevel).  The hierarchy is rebuilt per system (eo_build_system invalidates it). */
   int coarse_mg;
   void* mg;                     /* the hierarchy (euler_oracle.c: mg_hierarchy), NULL = not built yet */
+  /* fluid cut off from the air (a closed box full of water): P^T A P is singular along the indicator of such a component; the factor pins one of its cells
+   * (the pivot falls back to the diagonal, like main.c:595) and the solve projects the indicators out on both sides - the pseudo-inverse */
+  int coarse_npinned, coarse_pinned[16];
+  double* coarse_null;          /* [coarse_npinned][coarse_n] */
 } eo_sim;
 
 eo_sim* eo_create(int X, int Y);
