@@ -172,6 +172,7 @@ struct euler_sim {
   double* cc_inv;                    // [n][n]: its inverse, per solve
   double* cc_part;                   // [chunks][3]: per tile, the sums of r over its fluid cells by coarse column (k_precond_tile)
   double* cc_y;                      // [n]: the coarse correction of the iteration (k_coarse_solve)
+  double* cc_null;                   // [4][CC_MAX] + 1: the indicators of up to four fluid regions cut off from the air (null vectors of P^T A P) and, last, how many (k_coarse_nullfix)
   // EULER_PRECOND_IC0_TILE_MG (multilevel; k_coarse.hip): levels 0 .. mg_levels - 1 of aggregates of (16 << l)^2 grid cells, mg_nx[l] x mg_ny[l]
   // of them, pooled arrays with level l at offset mg_off[l]; the level above the last one is the dense top level (cc_*: 64 m cells wide)
   int mg_levels, mg_nx[12], mg_ny[12];
@@ -337,6 +338,7 @@ static inline bool eu_is_mg(const euler_sim* S) { return S->cfg.precond == EULER
 int  eu_coarse_alloc(euler_sim* S);           // lazily, when the mode is first selected
 void eu_coarse_release(euler_sim* S);
 int  eu_launch_coarse_setup(euler_sim* S);    // per solve: P^T A P, its factor and inverse
+int  eu_launch_coarse_consistent(euler_sim* S);   // per solve: if water is cut off from the air, take the part of r = b along that region's indicator out (host sync for the count)
 int  eu_launch_coarse_solve(euler_sim* S, int fin_op, int force);   // per iteration: y = (P^T A P)^-1 P^T r, dot(z,r) += y . r_c, the scalar epilogue
 int  eu_launch_coarse_search_init(euler_sim* S);   // s = z + P y (the first search direction of a solve)
 int  eu_coarse_comm_slots(euler_sim* S);      // row slabs: doubles per rank in S->mg_xbuf (allocated on demand), < 0 on error

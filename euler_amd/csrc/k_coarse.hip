@@ -27,6 +27,7 @@
 
 #define CC_MAX 256          // coarse cells
 #define CC_THREADS 1024
+#define CC_NULL_MAX 4       // fluid regions cut off from the air whose indicators are kept (k_coarse_nullfix)
 #define MG_DOT_BLOCKS 512    // most blocks of the level-0 kernel that closes the V-cycle (its dot partials)
 #define MG_OMEGA 0.8         // damped Jacobi
 #define MG_KAPPA 1.5         // scaling of the coarse-grid correction (plain aggregation under-corrects)
@@ -55,6 +56,8 @@ int eu_coarse_alloc(euler_sim* S) {
   HIPCHK(hipMalloc((void**)&S->cc_y, (2 * CC_MAX + 1) * sizeof(double)));      // y [CC_MAX], r_c [CC_MAX], the ticket counter of k_coarse_solve
   HIPCHK(hipMemset(S->cc_part, 0, (S->chunk_cap + 64) * 3 * sizeof(double)));
   HIPCHK(hipMemset(S->cc_y, 0, (2 * CC_MAX + 1) * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&S->cc_null, (CC_NULL_MAX * CC_MAX + 1) * sizeof(double)));
+  HIPCHK(hipMemset(S->cc_null, 0, (CC_NULL_MAX * CC_MAX + 1) * sizeof(double)));
   // the multilevel hierarchy below the dense level: aggregates of 16, 32, ... , 32 m grid cells (k_mg_* below)
   S->mg_levels = 0; S->mg_cells = 0;
   for (int g = 16; g < 64 * m; g *= 2) {
@@ -76,7 +79,8 @@ int eu_coarse_alloc(euler_sim* S) {
 
 void eu_coarse_release(euler_sim* S) {
   if (S->cc_diag) (void)hipFree(S->cc_diag);
-  for (double* d : {S->cc_fac, S->cc_inv, S->cc_part, S->cc_y, S->mg_rhs, S->mg_part, S->mg_dot, S->mg_xbuf}) if (d) (void)hipFree(d);
+  for (double* d : {S->cc_fac, S->cc_inv, S->cc_part, S->cc_y, S->mg_rhs, S->mg_part, S->mg_dot, S->mg_xbuf, S->cc_null}) if (d) (void)hipFree(d);
+  S->cc_null = nullptr;
   S->mg_xbuf = nullptr; S->mg_xslot = 0;
   if (S->mg_d) (void)hipFree(S->mg_d);
   S->cc_diag = S->cc_right = S->cc_up = nullptr;
@@ -499,16 +503,24 @@ static int launch_mg_cycle(euler_sim* S, int fin_op, int force) {
 // ---- fluid cut off from the air: P^T A P has the indicator n of every such component in its null space, the factor pinned one cell of it (k_coarse_factor) and the inverse
 // S of the pinned matrix treats the component lopsidedly - PCG then stalls on the part of r along n that no A s can touch.  With n = a_kk S e_k (the pinned system's answer
 // to the pin itself: exactly the indicator) the inverse becomes (I - n n^T / n.n) S (I - n n^T / n.n): the pseudo-inverse of P^T A P - zero along n, S elsewhere.
-__global__ __launch_bounds__(CC_THREADS) void k_coarse_nullfix(double* __restrict__ inv, const int* __restrict__ cd, const int* __restrict__ pinned, int n, const PcgScalars* sc) {
+__global__ __launch_bounds__(CC_THREADS) void k_coarse_nullfix(double* __restrict__ inv, const int* __restrict__ cd, const int* __restrict__ pinned, int n, const PcgScalars* sc,
+                                                               double* __restrict__ nullv) {
+  const int tid = threadIdx.x;
+  if (tid == 0) nullv[CC_NULL_MAX * CC_MAX] = 0.0;
   if (!sc->nonzero) return;
   __shared__ double s_n[CC_MAX], s_w[CC_MAX], s_red[CC_THREADS / 64];
   __shared__ double s_nn, s_nw;
-  const int tid = threadIdx.x;
+  int found = 0;
   for (int k = 0; k < n; ++k) {
     if (!pinned[k]) continue;      // (uniform)
     const double a_kk = (double)cd[k];
     if (tid < n) s_n[tid] = a_kk * inv[(size_t)tid * n + k];
     __syncthreads();
+    if (found < CC_NULL_MAX) {      // kept for eu_launch_coarse_consistent
+      if (tid < CC_MAX) nullv[found * CC_MAX + tid] = tid < n ? s_n[tid] : 0.0;
+      if (tid == 0) nullv[CC_NULL_MAX * CC_MAX] = (double)(found + 1);
+    }
+    ++found;
     double v = tid < n ? s_n[tid] * s_n[tid] : 0.0;
     v = eu_wave_sum(v);
     if ((tid & 63) == 0) s_red[tid >> 6] = v;
@@ -534,6 +546,54 @@ __global__ __launch_bounds__(CC_THREADS) void k_coarse_nullfix(double* __restric
     }
     __syncthreads();
   }
+}
+
+// ---- water cut off from the air, continued: b - float divergences - is compatible with the singular A only to rounding (n.b ~ 1e-4 over such a region, not 0), and CG on a
+// singular, slightly inconsistent system wanders once it gets close (seen: 2000 iterations instead of 100).  The part of r = b along the region's indicator - a few 1e-9 per cell,
+// far below the tolerance, and nothing any A s could touch - is taken out before the solve starts.  Rare, so simple: one workgroup, fixed order; one GPU only.
+__global__ __launch_bounds__(CC_THREADS) void k_null_project(double* __restrict__ r, const uint8_t* __restrict__ mask, SkewGeom g, size_t e_lo, size_t e_cnt,
+                                                             const double* __restrict__ nullv, int shift, int nx, const PcgScalars* sc) {
+  if (!sc->nonzero) return;
+  __shared__ double s_red[2][CC_THREADS / 64];
+  __shared__ double s_eps, s_nn;
+  const int tid = threadIdx.x, count = (int)nullv[CC_NULL_MAX * CC_MAX];
+  for (int q = 0; q < count; ++q) {
+    const double* nv = nullv + q * CC_MAX;
+    double eps = 0.0, nn = 0.0;
+    for (size_t k = tid; k < e_cnt; k += CC_THREADS) {
+      const size_t e = e_lo + k;
+      if (!(mask[e] & CM_FLUID)) continue;
+      int band, t, l;
+      skew_decode(g, e, band, t, l);
+      const double w = nv[(size_t)((band * 64 + l) >> shift) * nx + ((t - l) >> shift)];
+      eps += r[e] * w; nn += w * w;
+    }
+    eps = eu_wave_sum(eps); nn = eu_wave_sum(nn);
+    if ((tid & 63) == 0) { s_red[0][tid >> 6] = eps; s_red[1][tid >> 6] = nn; }
+    __syncthreads();
+    if (tid == 0) { double a = 0.0, b = 0.0; for (int w = 0; w < CC_THREADS / 64; ++w) { a += s_red[0][w]; b += s_red[1][w]; } s_eps = a; s_nn = b; }
+    __syncthreads();
+    if (s_nn > 0.0) {
+      const double f = s_eps / s_nn;
+      for (size_t k = tid; k < e_cnt; k += CC_THREADS) {
+        const size_t e = e_lo + k;
+        if (!(mask[e] & CM_FLUID)) continue;
+        int band, t, l;
+        skew_decode(g, e, band, t, l);
+        r[e] = r[e] - nv[(size_t)((band * 64 + l) >> shift) * nx + ((t - l) >> shift)] * f;
+      }
+    }
+    __syncthreads();
+  }
+}
+int eu_launch_coarse_consistent(euler_sim* S) {
+  if (S->has_comm) return EULER_OK;      // (row slabs: the sums would have to be global - not built; the pseudo-inverse alone keeps such solves converging, mostly)
+  double count = 0.0;
+  HIPCHK(hipMemcpyAsync(&count, S->cc_null + CC_NULL_MAX * CC_MAX, sizeof(double), hipMemcpyDeviceToHost, S->stream));
+  HIPCHK(hipStreamSynchronize(S->stream));
+  if (count > 0.0)
+    LAUNCH(S, KC_PRECON_FACTOR, k_null_project, dim3(1), dim3(CC_THREADS), S->r, S->cellmask, S->geom, S->e_lo, S->e_cnt, S->cc_null, S->coarse_shift, S->coarse_nx, S->sc);
+  return EULER_OK;
 }
 
 int eu_coarse_comm_slots(euler_sim* S) {
@@ -587,7 +647,7 @@ int eu_launch_coarse_setup(euler_sim* S) {
   const int bw = S->coarse_ny > 1 ? S->coarse_nx : 1;      // half-bandwidth of P^T A P in row-major order of the coarse cells
   LAUNCH(S, KC_PRECON_FACTOR, k_coarse_factor, dim3(1), dim3(CC_THREADS), S->cc_diag, S->cc_right, S->cc_up, n, S->coarse_nx, bw, S->cc_fac, S->sc, S->cc_diag + 3 * (size_t)n);
   LAUNCH(S, KC_PRECON_FACTOR, k_coarse_inverse, dim3((n + 3) / 4), dim3(256), S->cc_fac, n, bw, S->cc_inv, S->sc);
-  LAUNCH(S, KC_PRECON_FACTOR, k_coarse_nullfix, dim3(1), dim3(CC_THREADS), S->cc_inv, S->cc_diag, S->cc_diag + 3 * (size_t)n, n, S->sc);
+  LAUNCH(S, KC_PRECON_FACTOR, k_coarse_nullfix, dim3(1), dim3(CC_THREADS), S->cc_inv, S->cc_diag, S->cc_diag + 3 * (size_t)n, n, S->sc, S->cc_null);
   return EULER_OK;
 }
 

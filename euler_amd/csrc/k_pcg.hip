@@ -2025,6 +2025,7 @@ int eu_launch_project(euler_sim* S, float dt) {
     return EULER_EINVAL;
   }
   if (two_level && (rc = eu_launch_coarse_setup(S))) return rc;   // P^T A P of this system, its factor and inverse (k_coarse.hip)
+  if (two_level && (rc = eu_launch_coarse_consistent(S))) return rc;   // (water cut off from the air: r = b made compatible with the singular A)
   if (tile) {                                                     // E^-1 per tile, then z = M^-1 r and sigma = dot(z, r) in one pass
     if ((rc = launch_factor_tile(S, 0))) return rc;
     if ((rc = launch_precond_tile(S, 0, 1, FIN_SIGMA_INIT, 0, 0.0))) return rc;

@@ -789,6 +789,24 @@ int eo_project(eo_sim* s, float dt, const float* u, const float* v, float* uout,
   int iters = 0;
   int nonzero = 0;
   for (size_t i = 0; i < C && !nonzero; ++i) if (s->count[i] && r[i] != 0.f) nonzero = 1;
+  if (nonzero && s->tile_records > 0 && s->coarse_m > 0) {
+    /* EXTENSION (coarse modes): water cut off from the air makes A singular along the indicator n of that region, and b - float divergences - is compatible
+     * with that only to rounding (n.b ~ 1e-4, not 0).  CG on a singular, slightly inconsistent system wanders once it gets close; the part of b along n
+     * (a few 1e-9 per cell, far below the tolerance, and no A s can touch it anyway) is taken out before the solve starts. */
+    if (!s->coarse_chol) coarse_factor(s);
+    const int g = 64 * s->coarse_m;
+    for (int q = 0; q < s->coarse_npinned; ++q) {
+      const double* nv = s->coarse_null + (size_t)q * s->coarse_n;
+      double eps = 0.0, nn = 0.0;
+      for (int y = 0; y < Y; ++y)
+        for (int x = 0; x < X; ++x)
+          if (FLUID(s, y, x)) { const double w = nv[(y / g) * s->coarse_nx + x / g]; eps += r[AT(s, y, x)] * w; nn += w * w; }
+      if (nn > 0.0)
+        for (int y = 0; y < Y; ++y)
+          for (int x = 0; x < X; ++x)
+            if (FLUID(s, y, x)) r[AT(s, y, x)] -= nv[(y / g) * s->coarse_nx + x / g] * (eps / nn);
+    }
+  }
   s->last_residual = 0;
   if (nonzero) {
     eo_apply_preconditioner(s, r, z);

@@ -489,3 +489,17 @@ def test_coarse_modes_on_fluid_cut_off_from_the_air(case, mg):
     # the same cells hold water as with the reference's IC(0) (the counts inside them are marker positions to 1e-6: they may differ by one), the same flow
     assert np.array_equal(sim.get(ea.F_COUNT) > 0, ref.get(ea.F_COUNT) > 0)
     assert np.abs(sim.get(ea.F_U) - ref.get(ea.F_U)).max() < 1e-3 and np.abs(sim.get(ea.F_V) - ref.get(ea.F_V)).max() < 1e-3
+
+
+def test_closed_box_right_hand_side_is_made_compatible():
+    """b of a closed box (float divergences) is compatible with the singular A only to rounding; before eu_launch_coarse_consistent took the part of b along the
+    region's indicator out, one solve in six of this run wandered for 2000 iterations after missing the tolerance narrowly (oracle and GPU alike).  Now: ~100 each,
+    in step with the oracle."""
+    text = _closed_boxes()["closed full box"]
+    o, sim = _two_level_pair(160, 128, 2000, text, mg=True)
+    for f in range(8):
+        sim.step(); o.step()
+        st = sim.stats()
+        assert st.last_residual <= 1e-6 and o.c.last_residual <= 1e-6
+        assert st.last_pcg_iterations <= 160 and o.c.last_pcg_iterations <= 160, (f, st.last_pcg_iterations, o.c.last_pcg_iterations)
+        assert abs(st.last_pcg_iterations - o.c.last_pcg_iterations) <= 12, (f, st.last_pcg_iterations, o.c.last_pcg_iterations)
