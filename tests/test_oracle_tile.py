@@ -166,9 +166,8 @@ def test_pcg_with_multilevel_preconditioner_iteration_counts():
 
 def test_coarse_modes_on_a_closed_box_full_of_water():
     """fluid cut off from the air: A and the coarse matrix are singular; the pinned factor + projected solve (pseudo-inverse) keep PCG converging,
-    in fewer iterations than the reference's IC(0), to the same cells.  (b is not exactly compatible - its sum over the component is ~1e-4, rounding of the
-    float divergences - and CG on a singular, slightly inconsistent system is only conditionally stable whatever the preconditioner: a solve that misses
-    the tolerance narrowly can wander for a few hundred iterations before it gets there)"""
+    in fewer iterations than the reference's IC(0), to the same cells.  (b is compatible with the singular A only to rounding - its sum over the component is
+    ~1e-4 - and CG on a singular, slightly inconsistent system wanders once it gets close: eo_project takes that part of b out first in the coarse modes)"""
     W, H = 40, 30
     rows = ["X" * W] + ["X" + "0" * (W - 2) + "X" for _ in range(H - 2)] + ["X" * W]
     text = "\n".join(rows) + "\n"
@@ -180,11 +179,13 @@ def test_coarse_modes_on_a_closed_box_full_of_water():
         o.c.coarse_mg = mg
         o.c.max_iterations = 2000
         its = 0
-        for f in range(4):
+        for f in range(8):
             o.step()
             assert o.c.last_residual <= 1e-6, (name, f, o.c.last_residual)
-            if cm:
+            if cm and f < 4:
                 assert o.c.coarse_npinned == 1      # (frames later the settling markers open air cells under the lid: regular again)
+            if mg:
+                assert o.c.last_pcg_iterations <= 160, (f, o.c.last_pcg_iterations)      # (before b was made compatible: 2000 in frame 4)
         res[name] = (int(o.c.total_pcg_iterations), o.count.copy())
     assert res["mg"][0] < 0.7 * res["ic0"][0] and res["two"][0] < 1.2 * res["ic0"][0], {k: v[0] for k, v in res.items()}      # (3 x 2 coarse cells only: the two-level mode gains nothing here)
     # the same cells hold water (the counts inside them are marker positions to 1e-6: they may differ by one)
