@@ -480,7 +480,7 @@ def test_coarse_modes_on_fluid_cut_off_from_the_air(case, mg):
     text = _closed_boxes()[case]
     ref = ea.Simulation(320, 256, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0, max_iterations=3000).load_text(text, upscale=True)
     o, sim = _two_level_pair(320, 256, 3000, text, mg=mg)
-    for f in range(12):
+    for f in range(8):
         ref.step(); sim.step(); o.step()
         st = sim.stats()
         assert st.last_residual <= 1e-6 and ref.stats().last_residual <= 1e-6 and o.c.last_residual <= 1e-6, (f, st.last_residual, o.c.last_residual)
