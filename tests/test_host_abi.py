@@ -26,6 +26,18 @@ def test_library_exports_every_declared_symbol():
     assert L.euler_abi_version() == 2
 
 
+def test_python_constants_mirror_the_header_enums():
+    """the ctypes wrapper's EULER_* values are the header's (preconditioner modes, dot modes, sweep modes, error codes)"""
+    hdr = open(os.path.join(ROOT, "include", "euler.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    values = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(EULER_[A-Z0-9_]+)\s*=\s*(-?\d+)", hdr)}
+    for py, c in (("PRECOND_IC0", "EULER_PRECOND_IC0"), ("PRECOND_JACOBI", "EULER_PRECOND_JACOBI"), ("PRECOND_IC0_TILE", "EULER_PRECOND_IC0_TILE"),
+                  ("PRECOND_IC0_TILE2", "EULER_PRECOND_IC0_TILE2"), ("PRECOND_IC0_TILE_MG", "EULER_PRECOND_IC0_TILE_MG"),
+                  ("DOT_TREE", "EULER_DOT_TREE"), ("DOT_SEQUENTIAL", "EULER_DOT_SEQUENTIAL")):
+        assert c in values, c
+        assert getattr(ea, py) == values[c], (py, getattr(ea, py), values[c])
+
+
 def test_no_cpu_fallback():
     """Without a GPU the handle cannot be created: the product has no CPU path."""
     import torch
