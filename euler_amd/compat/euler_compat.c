@@ -20,6 +20,7 @@
 #include <stdbool.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 #include <stdlib.h>
 
 #include "euler.h"
@@ -57,6 +58,18 @@ void sim_init(args_t in) {
   }
   const char* up = getenv("EULER_COMPAT_UPSCALE");
   if (up && up[0] == '1') upscale = 1;
+  /* the preconditioner of the pressure solve (include/euler.h EULER_PRECOND_*): "reference" (default) = main.c:577-627 with bit-identical iterates; "multilevel" with
+   * EULER_COMPAT_MAX_ITERATIONS above the reference's 100 lets a large grid's solves converge (~110 iterations whatever the size) */
+  const char* solver = getenv("EULER_COMPAT_SOLVER");
+  if (solver) {
+    if (!strcmp(solver, "reference")) cfg.precond = EULER_PRECOND_IC0;
+    else if (!strcmp(solver, "tile")) cfg.precond = EULER_PRECOND_IC0_TILE;
+    else if (!strcmp(solver, "two-level")) cfg.precond = EULER_PRECOND_IC0_TILE2;
+    else if (!strcmp(solver, "multilevel")) cfg.precond = EULER_PRECOND_IC0_TILE_MG;
+    else { fprintf(stderr, "EULER_COMPAT_SOLVER=%s: expected reference, tile, two-level or multilevel\n", solver); exit(1); }
+  }
+  const char* maxit = getenv("EULER_COMPAT_MAX_ITERATIONS");
+  if (maxit && (cfg.max_iterations = atoi(maxit)) < 1) { fprintf(stderr, "EULER_COMPAT_MAX_ITERATIONS=%s: expected a positive count\n", maxit); exit(1); }
   cfg.rainbow = g_rainbow_enabled;                 /* main() sets the global before sim_init (main.c:1020) */
   if (g_sim) { euler_destroy(g_sim); g_sim = NULL; }
   if (euler_create(&cfg, &g_sim) != EULER_OK || euler_load_scenario_file(g_sim, in.scenario_file, upscale) != EULER_OK) {

@@ -96,3 +96,13 @@ def test_reference_names_drive_the_gpu(tmp_path, scn, rainbow):
     if rainbow:
         L.colorize()                                                  # the 'r' key (main.c:970-973)
         assert frame() != want["f10_w98x38"].tobytes()
+    else:
+        # the same names over another preconditioner (EULER_COMPAT_SOLVER): block.txt's solves converge within the cap in the first frames, so the frames are the same
+        os.environ["EULER_COMPAT_SOLVER"], os.environ["EULER_COMPAT_MAX_ITERATIONS"] = "multilevel", "400"
+        try:
+            frames.value = 0
+            L.sim_init(ArgsT(str(path).encode(), rainbow))
+            L.sim_step()
+            assert frames.value == 1 and frame() == want["f0_w98x38"].tobytes()
+        finally:
+            del os.environ["EULER_COMPAT_SOLVER"], os.environ["EULER_COMPAT_MAX_ITERATIONS"]
