@@ -18,7 +18,15 @@ roofline  bytes are counted three ways and named: `frac_traffic` = HBM bytes roc
           for the kernel in a live PMC pass of this very workload (child processes of this run, calibrated on a copy of known
           size in the same pass) / launch time; `frac_active` = SURVEY 8d's algorithmic bytes x FLUID cells (what the
           kernels visit) / time; `frac_dense` = the same x ALL X*Y cells (the reference's dense loops; exceeds what HBM moved on
-          sparse scenes and is never the headline).  `roofline.frac` is the traffic-based one when the PMC pass ran.
+          sparse scenes and is never the headline).  `roofline.frac` is the ALGORITHMIC one (frac_active) since round 3; the traffic-based
+          figure stays beside it as `frac_traffic` / `traffic_over_algorithmic`.
+
+quality   what the headline's speed is worth against the reference (none of it is the headline): `equal_residual` - the budget at which the tile-local,
+          two-level and multilevel modes reach the residual the reference's IC(0) reaches in its 100 iterations, frames at that budget, the pressure
+          error of each against the converged solution; `converged_frames_multilevel` - the headline workload with EVERY solve run to the reference's
+          tolerance (EULER_PRECOND_IC0_TILE_MG, cap lifted); `secondary.parity_vs_reference_ic0` - one frame per BASELINE workload state in every
+          mode against the reference's IC(0) on the oracle and against the converged frame; `secondary.time_to_solution`; `strong_16384_dam_break`
+          - configs[3] on this many GPUs (N = 1: the strong-scaling denominator), roofline mode and converged frames.
 
 One JSON line on stdout (rank 0).  Inputs are resident in HBM when a timed region starts.
 """
