@@ -46,29 +46,26 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
-# algorithmic bytes per grid cell per launch (w = 8 for double vectors, 1 mask byte per kernel)
+# Algorithmic bytes per FLUID cell and launch (w = 8 for double vectors, one mask byte per kernel), per mode, for the launches of ONE
+# PCG iteration as this build runs it.  ITER_BYTES is the single table: a class's `bytes_per_cell`, the iteration's `bytes_per_cell_iteration`
+# (= the sum over the per-iteration classes, checked in summarize()) and `roofline.achieved` all come from it - "never the larger one".
 W = 8
-ALGO_BYTES = {
-    "forward_solve": 3 * W + 1,    # read r, precon; write q
-    "backward_solve": 3 * W + 1,   # read q, precon; write z
-    "apply_a": 2 * W + 1,          # read s; write A s (+ in-register dot partial)
-    "dot": 2 * W + 1,              # read z, r
-    "update_pr": 3 * W + 1,        # parity mode since round 3: read r, A s; write r (+ max |r|) - the first half of the tile pass; p rides in apply_a
-    "update_search": 3 * W + 1,    # read z, s; write s
-    "precond_tile": 4 * W + 1,     # tile-local mode: read r, A s; write r, z  (K2's r half, K3, K4 and dot in one pass; E^-1 of an interior
-                                   # tile is the per-handle table, round 3 - boundary tiles still stream 8 B more)
+_APPLY = 5.5 * W + 1      # k_search_apply: s' = z + beta s and A s' in one pass (read s, z; write s', A s') 4w+1, + p += alpha s of TWO iterations on
+#                           every second pass (read s of two iterations ago and p, write p) 1.5w  -> 45
+_TILE = 4 * W + 1         # k_precond_tile: r -= alpha A s, max |r|, z = M_tile^-1 r, dot(z, r): read r, A s; write r, z (E^-1 of an interior tile is a table in LDS) -> 33
+_RUPD = 3 * W + 1         # parity mode: the first half of that pass alone (read r, A s; write r; max |r|) -> 25
+_SWEEP = 3 * W + 1        # one IC(0) sweep of the reference's factor: read rhs, precon; write the result -> 25 each way
+ITER_BYTES = {
+    "ic0": {"forward_solve": _SWEEP, "backward_solve": _SWEEP, "apply_a": _APPLY, "update_pr": _RUPD},      # 120 (the reference's five loops: 18w+5 = 149; main.c as written: 212)
+    "ic0_tile": {"apply_a": _APPLY, "precond_tile": _TILE},                                                   # 78
+    "ic0_tile2": {"apply_a": _APPLY, "precond_tile": _TILE, "coarse_cycle": 0.0},
+    # multilevel: + the V-cycle: 8 doubles of partial sums per 16x64 tile written and read (0.125 B/cell) and the level arrays, 1/256 of a solver array each (~0.2 B/cell)
+    "ic0_tile_mg": {"apply_a": _APPLY, "precond_tile": _TILE, "coarse_cycle": 0.33},
+    "jacobi": {"apply_a": _APPLY, "update_pr": _RUPD, "jacobi": 2 * W + 1, "dot": 2 * W + 1},
 }
-APPLY_A_FUSED = {"ic0": 5.5 * W + 1,     # update_search fused in: read s, z; write s', A s'; since round 3 also p += alpha s as below
-                 "jacobi": 5.5 * W + 1,
-                 "ic0_tile_mg": 5.5 * W + 1,
-                 "ic0_tile2": 5.5 * W + 1, # (two-level mode: + one 8-byte coarse value per 64-cell run - the table of <= 256 values sits in L2)
-                 "ic0_tile": 5.5 * W + 1}  # ... and p += alpha s of two iterations on every second one: read s, z (+ s of two iterations ago
-                                           # and p every second iteration); write s', A s' (+ p every second iteration): 4w + 1.5w
-# whole PCG iteration per cell (SURVEY 8d "Algorithmic bytes"): the reference's IC(0) as five kernels 18w+5; the tile-local
-# variant as the two passes it runs, 11w+2 - "the figure for that variant ... never the larger one"
-PCG_BYTES = {"ic0": 17.5 * W + 5, "ic0_tile": 9.5 * W + 2, "ic0_tile2": 9.5 * W + 2, "ic0_tile_mg": 9.5 * W + 2, "jacobi": 10.5 * W + 3}   # tile-local: 5.5w+1 + 4w+1 = 78 (round 2: 11w+2 = 90); the reference's
-# structure 18w+5 = 149 minus the half p update saved since round 3 (p is read and written every second iteration): 145
-PCG_CLASSES = ["forward_solve", "backward_solve", "apply_a", "dot", "update_pr", "update_search", "precond_tile"]
+PCG_BYTES = {m: sum(c.values()) for m, c in ITER_BYTES.items()}
+ONCE_PER_SOLVE_BYTES = {"update_pr": 3 * W + 1}      # k_finish_p in the tile modes: the last one or two p += alpha s (read s, p; write p)
+PCG_CLASSES = ["forward_solve", "backward_solve", "apply_a", "dot", "update_pr", "update_search", "precond_tile", "coarse_cycle", "jacobi"]
 KERNEL_OF_CLASS = {"forward_solve": "k_sweep_skew<1", "backward_solve": "k_sweep_skew<2", "precon_factor": "k_sweep_skew<0",
                    "apply_a": "k_search_apply", "dot": "k_dot_partial", "update_pr": "k_update_pr", "precond_tile": "k_precond_tile"}
 MODE_NAME = {"ic0": "parity mode: the reference's IC(0), bit-identical iterates",
@@ -125,6 +122,8 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true", help="headline case only (no parity-mode / 1024^2 / 16384^2 / time-to-solution blocks)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 PMC passes (roofline.traffic is then null)")
     ap.add_argument("--no-16384", action="store_true", help="skip the 16384^2 projection block")
+    ap.add_argument("--quality", action="store_true", help="also run the long quality studies (equal-residual budget scans, one frame per BASELINE workload against the "
+                                                           "reference's IC(0) on the oracle); their results go to bench_full.json")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong_16384_dam_break block (BASELINE configs[3]; N = 1: its denominator)")
     ap.add_argument("--strong-size", type=int, default=16384, help="N of the strong block's N x N dam break (tests use a small one)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # this process runs under rocprofv3 --pmc
@@ -273,11 +272,13 @@ def pmc_live(child_args, timeout_s=420):
         shutil.rmtree(base, ignore_errors=True)
 
 
-def traffic_of(traffic, cls):
+def traffic_of(traffic, cls, precond=None):
     """bytes per launch of a kernel class from a pmc_live() table (kernel names carry template arguments)."""
     if not traffic:
         return None
     key = KERNEL_OF_CLASS.get(cls)
+    if cls == "update_pr" and precond is not None and precond not in TILE_MODES:
+        key = "k_precond_tile"      # (r -= alpha A s, max |r| = the first half of the tile pass, r_only)
     if not key:
         return None
     hits = [(k, v) for k, v in traffic.items() if k.startswith(key)]
@@ -459,29 +460,21 @@ def strong_block(ctx, size, steps, tile_w):
     return out
 
 
-def kernel_rows(prof, precond, cells_fluid, traffic, fused_search):
-    """per kernel class: launch time and the byte counts -> GB/s"""
+def kernel_rows(prof, precond, cells_fluid, traffic, iters):
+    """per kernel class: launch time and the byte counts -> GB/s.  A class that runs once per iteration takes its bytes from ITER_BYTES[precond]."""
     rows = {}
     for name, (ms, launches) in prof.items():
+        if not launches:
+            continue
         e = {"ms_total": round(ms, 3), "launches": int(launches), "avg_us": round(1e3 * ms / launches, 2)}
-        b = ALGO_BYTES.get(name)
-        if name == "apply_a" and fused_search:
-            b = APPLY_A_FUSED.get(precond, b)
-            e["note"] = ("update_search fused in" + (" + the previous iteration's p += alpha s" if precond in TILE_MODES else "")
-                         + ": %d algorithmic B/cell" % b)
-        if name == "update_pr" and precond in TILE_MODES:
-            b = 3 * W + 1
-            e["note"] = "k_finish_p, once per solve: the last one or two p += alpha s (read s, p; write p)"
-        elif name == "update_pr":
-            e["note"] = "r -= alpha A s and max |r| (the first half of k_precond_tile) + k_finish_p once per solve"
-        if name == "update_search" and fused_search:
-            b = None
-            e["note"] = "once per solve: s = z over the whole padded array (every other update_search rides in apply_a)"
-        if b:
+        per_iteration = launches >= 0.5 * max(iters, 1)
+        b = ITER_BYTES[precond].get(name) if per_iteration else ONCE_PER_SOLVE_BYTES.get(name)
+        e["per_iteration"] = bool(per_iteration)
+        if b is not None:
             sec = ms / launches * 1e-3
             e["bytes_per_cell"] = b
             e["GBps_active"] = round(b * cells_fluid / sec / 1e9, 1)
-            t = traffic_of(traffic, name)
+            t = traffic_of(traffic, name, precond)
             if t:
                 e["traffic_bytes_per_launch"] = int(t)
                 e["GBps_traffic"] = round(t / sec / 1e9, 1)
@@ -516,28 +509,28 @@ def time_frames(sim, ea, grp, args, precond, steps, warmup_done, warmup, big):
         for k, v in sim.profile().items():
             prof.setdefault(k, v)
         sim.profile_enable([])
-    per_iter_ms = sum(prof[k][0] / (iters if (big or k == dominant) else iters2) for k in PCG_CLASSES
-                      if k in prof and (iters if (big or k == dominant) else iters2))
+    # one iteration = the mode's per-iteration classes (ITER_BYTES); once-per-solve launches (s = z, k_finish_p, the factor) are not in it
+    per_iter_ms = sum(prof[k][0] / prof[k][1] for k in ITER_BYTES[precond]
+                      if k in prof and prof[k][1] >= 0.5 * max(iters if (big or k == dominant) else iters2, 1))
     return dict(elapsed=elapsed, st0=st0, st1=st1, prof=prof, iters=iters, per_iter_ms=per_iter_ms, dominant=dominant,
                 substeps=st1.total_substeps - st0.total_substeps)
 
 
 def summarize(t, size_x, size_y, precond, tile_w, traffic, traffic_note, steps, fused_search=True, rank_cells=None, rank_fluid_share=1.0):
-    """value + per-kernel rows + roofline object (dominant kernel = the PCG class with the largest total time) + whole-iteration aggregate.
+    """value + per-kernel rows + roofline object (dominant kernel = the per-iteration PCG class with the largest total time) + whole-iteration aggregate.
     The byte rates are THIS rank's: its kernels cover rank_cells cells (row slabs: the own rows, whose fluid cells the handle counts
     itself; band slabs of a replicated handle: 1 / world of the grid's fluid cells)."""
     cells_job = size_x * size_y
     cells = rank_cells if rank_cells else cells_job
     fluid = int(t["st1"].fluid_cells * rank_fluid_share)
-    rows = kernel_rows(t["prof"], precond, fluid, traffic, fused_search)
-    pcg_rows = {k: v for k, v in rows.items() if k in PCG_CLASSES}
-    per_iter = [k for k in pcg_rows if rows[k]["launches"] >= 0.5 * max(t["iters"], 1)]
+    rows = kernel_rows(t["prof"], precond, fluid, traffic, t["iters"])
+    per_iter = [k for k in rows if rows[k]["per_iteration"] and k in ITER_BYTES[precond]]
     roof = None
-    if pcg_rows:
-        dom = max(pcg_rows, key=lambda k: pcg_rows[k]["ms_total"])
-        r = pcg_rows[dom]
+    if per_iter:
+        dom = max(per_iter, key=lambda k: rows[k]["ms_total"])
+        r = rows[dom]
         sec = r["avg_us"] * 1e-6
-        b = r.get("bytes_per_cell", 0)
+        b = r["bytes_per_cell"]
         tr = r.get("traffic_bytes_per_launch")
         active = b * fluid / sec / 1e9
         # `achieved` / `frac` = ALGORITHMIC bytes (SURVEY 8d's per-cell figure for this variant x the fluid cells one launch processes)
@@ -546,25 +539,27 @@ def summarize(t, size_x, size_y, precond, tile_w, traffic, traffic_note, steps, 
                 "frac": round(active / HBM_PEAK_GBPS, 4), "traffic": int(tr) if tr else None,
                 "frac_traffic": round(tr / sec / 1e9 / HBM_PEAK_GBPS, 4) if tr else None,
                 "traffic_over_algorithmic": round(tr / (b * fluid), 3) if tr else None,
-                "achieved_algorithmic": round(active, 1),
-                "frac_active": round(active / HBM_PEAK_GBPS, 4),
                 "frac_dense": round(b * cells / sec / 1e9 / HBM_PEAK_GBPS, 4),
                 "achieved_is": "algorithmic bytes per cell x fluid cells of one launch / average launch time (HIP events in the timed region)",
-                "algorithmic_bytes_per_cell": b, "algorithmic_bytes_per_launch_active": int(b * fluid),
+                "algorithmic_bytes_per_cell": b, "algorithmic_bytes_per_launch": int(b * fluid),
                 "avg_launch_us": r["avg_us"], "launches": r["launches"], "fluid_fraction": round(fluid / cells, 4),
                 "traffic_source": traffic_note,
                 "note": "frac_dense counts ALL X*Y cells like the reference's dense loops and may exceed 1 on sparse scenes; the kernels "
-                        "visit fluid cells only, so frac_active / frac_traffic are what the memory system did"}
+                        "visit fluid cells only, so frac / frac_traffic are what the memory system did"}
     agg = None
-    if t["per_iter_ms"]:
+    if t["per_iter_ms"] and per_iter:
         sec = t["per_iter_ms"] * 1e-3
-        bpc = PCG_BYTES[precond]
+        bpc = sum(rows[k]["bytes_per_cell"] for k in per_iter)
+        # the accounting follows the kernels: the iteration's bytes are the sum over the classes that were timed once per iteration - and that is the mode's table
+        assert abs(bpc - PCG_BYTES[precond]) < 1e-9 or set(per_iter) != set(ITER_BYTES[precond]), (bpc, PCG_BYTES[precond], per_iter)
         tsum = None
         if traffic:
-            parts = [rows[k].get("traffic_bytes_per_launch") for k in per_iter]
+            parts = [rows[k].get("traffic_bytes_per_launch") for k in per_iter if rows[k]["bytes_per_cell"] >= 1]
             tsum = sum(parts) if parts and all(parts) else None
-        agg = {"us_per_iteration": round(1e3 * t["per_iter_ms"], 2), "bytes_per_cell_iteration": bpc,
-               "launches_per_iteration": len(per_iter) + (1 if precond == "ic0_tile2" else 0),      # + k_coarse_solve (timed in the precond_tile class; the multilevel mode: + a dozen small launches)
+        agg = {"us_per_iteration": round(1e3 * t["per_iter_ms"], 2), "bytes_per_cell_iteration": round(bpc, 2),
+               "classes": {k: rows[k]["bytes_per_cell"] for k in per_iter},
+               "complete": set(per_iter) == set(ITER_BYTES[precond]),      # every per-iteration class of the mode was timed
+               "launches_per_iteration": len(per_iter),      # (coarse_cycle: one class, 12 small launches in the multilevel mode)
                "GBps_active": round(bpc * fluid / sec / 1e9, 1), "frac_active": round(bpc * fluid / sec / 1e9 / HBM_PEAK_GBPS, 4),
                "GBps_traffic": round(tsum / sec / 1e9, 1) if tsum else None,
                "frac_traffic": round(tsum / sec / 1e9 / HBM_PEAK_GBPS, 4) if tsum else None,
@@ -826,6 +821,265 @@ def parity_vs_reference(ea, scenarios, so, device, dot_mode, tile_records, cases
     return out
 
 
+# ------------------------------------------------------------------------------------------------ quality of the headline's speed (default run: summaries)
+def quality_summary(sim, ea, tile_records, solver_tol):
+    """ONE pressure system - the state behind the timed frames, the stages of a substep up to project() (main.c:855-889) run once; project()
+    reads utmp / vtmp / the cell grid and can be repeated - solved with each preconditioner under the reference's budget of 100 iterations
+    (main.c:735): residual, time, and the ERROR of the pressure against the converged solution of the same system (multilevel mode to the
+    reference's tolerance 1e-6, cap lifted).  Leaves the handle mid-substep (the caller goes on with whole frames)."""
+    import numpy as np
+    dt = sim.timestep(0.1)
+    for st in (ea.STAGE_ADVECT_MARKERS, ea.STAGE_REFRESH_COUNTS, ea.STAGE_SOURCES, ea.STAGE_EXTRAPOLATE, ea.STAGE_ADVECT_VELOCITY):
+        sim.stage(st, dt)
+
+    def solve(precond, budget, tol=solver_tol):
+        sim.set_precond(precond, tile_records)
+        sim.set_solver(budget, tol)
+        t0 = time.perf_counter()
+        sim.stage(ea.STAGE_PROJECT, dt)
+        st = sim.stats()
+        return {"ms": round(1e3 * (time.perf_counter() - t0), 2), "iterations": int(st.last_pcg_iterations), "residual": float(st.last_residual)}
+
+    solve(ea.PRECOND_IC0_TILE_MG, 8)      # (untimed: first launches / allocations of the coarse levels on this handle)
+    conv = solve(ea.PRECOND_IC0_TILE_MG, 20000, 1e-6)
+    pstar = sim.get(ea.F_PRESSURE).astype(np.float64)
+    nstar = float(np.sqrt((pstar * pstar).sum())) or 1.0
+    out = {"system": "one substep's pressure system of the state behind the timed frames (dt %.3g)" % dt, "budget": 100,
+           "converged": dict(conv, mode="ic0_tile_mg", tol=1e-6), "error_unit": "||p - p*||_2 / ||p*||_2 against the converged solution p*", "modes": {}}
+    solve(ea.PRECOND_IC0, 4)              # (untimed: first launches of the sweep kernels)
+    for name, pc in (("ic0", ea.PRECOND_IC0), ("ic0_tile", ea.PRECOND_IC0_TILE), ("ic0_tile2", ea.PRECOND_IC0_TILE2), ("ic0_tile_mg", ea.PRECOND_IC0_TILE_MG)):
+        r = solve(pc, 100)
+        d = sim.get(ea.F_PRESSURE).astype(np.float64) - pstar
+        r["pressure_error"] = float(np.sqrt((d * d).sum()) / nstar)
+        out["modes"][name] = r
+    del pstar
+    sim.set_precond(ea.PRECOND_IC0_TILE, tile_records)
+    sim.set_solver(100, solver_tol)
+    return out
+
+
+def converged_block(sim, ea, grp, args, GX, GY, tile_w, steps, solver_tol):
+    """The headline workload with EVERY solve run to the reference's tolerance 1e-6 (main.c:736) - the multilevel mode, iteration cap lifted: what
+    "this grid, actually solved" costs.  Timed like the headline, per-kernel HIP events in the timed region, its own roofline object."""
+    sim.set_precond(ea.PRECOND_IC0_TILE_MG, args.tile_records)
+    sim.set_solver(20000, 1e-6)
+    sim.step()      # (untimed: the tank calms down from the capped frames' noise; allocations of the coarse levels)
+    t = time_frames(sim, ea, grp, args, "ic0_tile_mg", steps, 0, 1, True)
+    blk = summarize(t, GX, GY, "ic0_tile_mg", tile_w, None, None, steps)
+    out = {k: blk[k] for k in ("mode", "value", "unit", "ms_per_step", "substeps", "pcg_iterations", "cells_substeps_per_s", "fluid_cells", "last_residual",
+                               "roofline", "pcg_iteration", "kernels")}
+    out.update({"steps": steps, "tol": 1e-6, "max_iterations": 20000,
+                "iterations_per_solve": round(blk["pcg_iterations"] / max(blk["substeps"], 1), 1),
+                "workload": "%dx%d %s, the frames behind the headline's, every solve converged" % (GX, GY, args.workload)})
+    sim.set_precond(ea.PRECOND_IC0_TILE, args.tile_records)
+    sim.set_solver(args.max_iterations, solver_tol)
+    return out
+
+
+def converged_deviation(ea, scenarios, so, device, dot_mode, tile_records, n=512, more=40):
+    """How far the converged multilevel frame on the GPU is from the REFERENCE's algorithm run to convergence: from one state of the n x n dam
+    break at impact, one frame on the GPU (multilevel mode, tol 1e-6, cap lifted) and one on the oracle with the reference's own IC(0), same
+    tolerance, cap lifted (main.c:735 raised; nothing else changed).  Both converge to the same pressure, so the fields agree to solver tolerance."""
+    import numpy as np
+    sim = ea.Simulation(n, n, device=device, dot_mode=dot_mode, precond=ea.PRECOND_IC0_TILE_MG, tile_records=tile_records, max_iterations=20000, pcg_poll_interval=32)
+    load_workload(sim, scenarios, "dam_break", 1)
+    pre = preroll_into_solves(sim, 400)
+    for _ in range(more):
+        sim.step()
+    o = oracle_from_sim(sim, ea, so)
+    o.c.max_iterations = 20000
+    t0 = time.perf_counter()
+    o.step()
+    cpu_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    sim.step()
+    gpu_s = time.perf_counter() - t0
+    st = sim.stats()
+    gfl, ofl = sim.get(ea.F_COUNT) > 0, o.count > 0
+    pmax = float(np.abs(o.p).max()) or 1.0
+    out = {"state": "%dx%d dam break after %d frames (the water has hit the floor)" % (n, n, pre + more),
+           "vs": "oracle with the reference's IC(0), tol 1e-6, cap lifted, from the same state",
+           "substeps": [int(st.last_substeps), int(o.c.last_substeps)], "pcg_iterations": [int(st.last_pcg_iterations), int(o.c.last_pcg_iterations)],
+           "max_abs_du": float(np.abs(sim.get(ea.F_U) - o.u).max()), "max_abs_dv": float(np.abs(sim.get(ea.F_V) - o.v).max()),
+           "max_abs_velocity": float(max(np.abs(o.u).max(), np.abs(o.v).max())),
+           "dp_over_max_p": float(np.abs(sim.get(ea.F_PRESSURE) - o.p).max() / pmax),
+           "fluid_cells": int(ofl.sum()), "fluid_cells_differing": int((gfl != ofl).sum()),
+           "frame_seconds": [round(gpu_s, 3), round(cpu_s, 2)], "order": "[GPU multilevel mode, oracle]"}
+    o.close()
+    sim.close()
+    return out
+
+
+def cpu_converged_baseline(libs, n=1024):
+    """cpu_baseline at EQUAL TOLERANCE: the oracle with the reference's IC(0), single thread, tol 1e-6, cap lifted, one frame of the n x n half tank from rest"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    o = oracle_lib.Oracle(n, n, lib_path=libs["reference_flags"]).load_half_tank()
+    o.c.max_iterations = 20000
+    t0 = time.perf_counter()
+    o.step()
+    dt = time.perf_counter() - t0
+    out = {"value": round(n * n / dt, 1), "unit": "cells*steps/s", "cores": 1, "kind": "port", "seconds": round(dt, 2),
+           "substeps": int(o.c.total_substeps), "pcg_iterations": int(o.c.total_pcg_iterations), "last_residual": float(o.c.last_residual),
+           "sample": "1 frame of the %dx%d half tank from rest, the reference's IC(0) run to tol 1e-6 (cap lifted), -O3 -ffast-math -march=native, single thread; "
+                     "its iteration count grows with N (445 / 880 / 1726 at 512 / 1024 / 2048), so the rate at 8192 is ~8x lower" % (n, n)}
+    o.close()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ the ONE line
+LINE_LIMIT = 8000      # bytes; the driver keeps a bounded tail of stdout (round 3's 25.7 KB line came back unparsed)
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _r(x, nd=4):
+    if isinstance(x, float):
+        return float("%.*g" % (nd + 2, x)) if abs(x) >= 1 else round(x, nd + 2)
+    return x
+
+
+def _short(x):
+    """numbers to 6 significant digits, recursively"""
+    if isinstance(x, dict):
+        return {k: _short(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_short(v) for v in x]
+    if isinstance(x, float):
+        return float("%.6g" % x)
+    return x
+
+
+ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic", "traffic_over_algorithmic", "algorithmic_bytes_per_cell",
+             "algorithmic_bytes_per_launch", "avg_launch_us", "launches", "measured_copy_GBps")
+ITER_KEYS = ("us_per_iteration", "bytes_per_cell_iteration", "classes", "launches_per_iteration", "GBps_active", "frac_active", "GBps_traffic", "frac_traffic")
+
+
+def _block(b, extra=()):
+    """the compact form of a summarize() block"""
+    if not isinstance(b, dict):
+        return None
+    if "error" in b:
+        return {"error": str(b["error"])[:160]}
+    out = _pick(b, ("value", "ms_per_step", "steps", "substeps", "pcg_iterations", "fluid_cells", "tol", "iterations_per_solve", "n_gpus") + tuple(extra))
+    if isinstance(b.get("roofline"), dict):
+        out["roofline"] = _pick(b["roofline"], ("kernel", "frac", "achieved", "avg_launch_us", "algorithmic_bytes_per_cell", "traffic", "traffic_over_algorithmic"))
+    if isinstance(b.get("pcg_iteration"), dict):
+        out["pcg_iteration"] = _pick(b["pcg_iteration"], ("us_per_iteration", "bytes_per_cell_iteration", "frac_active", "frac_traffic"))
+    return out
+
+
+def compact_line(full, limit=LINE_LIMIT):
+    """The driver-facing line: the contract's keys, `roofline`, `cpu_baseline`, `pcg_iteration`, `kernels`, the converged block and one-number summaries of the
+    secondary blocks - under `limit` bytes whatever the full object holds (which goes to bench_full.json).  Pure function of `full` (tests/test_bench_line.py)."""
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data"))
+    line["vs_baseline"] = full.get("vs_baseline")
+    cfg = dict(full.get("config") or {})
+    cfg.pop("parallelism_detail", None)
+    for k in ("workload", "parallelism"):
+        if isinstance(cfg.get(k), str) and len(cfg[k]) > 200:
+            cfg[k] = cfg[k][:197] + "..."
+    line["config"] = cfg
+    line.update(_pick(full, ("substeps", "pcg_iterations", "cells_substeps_per_s", "fluid_cells", "markers")))
+    roof = full.get("roofline")
+    line["roofline"] = _pick(roof, ROOF_KEYS) if isinstance(roof, dict) else None
+    if isinstance(roof, dict) and "traffic" not in line["roofline"]:
+        line["roofline"]["traffic"] = None
+    line["pcg_iteration"] = _pick(full.get("pcg_iteration"), ITER_KEYS) or None
+    line["kernels"] = {k: _pick(v, ("avg_us", "launches", "bytes_per_cell", "GBps_active", "GBps_traffic"))
+                       for k, v in (full.get("kernels") or {}).items() if isinstance(v, dict) and v.get("bytes_per_cell") is not None}
+    cpu = full.get("cpu_baseline")
+    if isinstance(cpu, dict):
+        c = _pick(cpu, ("value", "unit", "cores", "kind", "sample", "seconds", "strict_ieee_value", "cpu_model", "host_cores_available", "error"))
+        if isinstance(c.get("sample"), str) and len(c["sample"]) > 240:
+            c["sample"] = c["sample"][:237] + "..."
+        if isinstance(cpu.get("equal_tolerance"), dict):
+            c["equal_tolerance"] = _pick(cpu["equal_tolerance"], ("value", "seconds", "pcg_iterations", "substeps", "error"))
+        if isinstance(cpu.get("configs0_100x40_block_100_steps"), dict):
+            c["configs0_value"] = cpu["configs0_100x40_block_100_steps"].get("value")
+        line["cpu_baseline"] = c
+    else:
+        line["cpu_baseline"] = None
+    conv = full.get("converged")
+    if isinstance(conv, dict):
+        c = _block(conv, ("last_residual", "cells_substeps_per_s"))
+        if isinstance(conv.get("roofline"), dict):
+            c["roofline"] = _pick(conv["roofline"], ROOF_KEYS)
+        if isinstance(conv.get("pcg_iteration"), dict):
+            c["pcg_iteration"] = _pick(conv["pcg_iteration"], ITER_KEYS)
+        if isinstance(conv.get("deviation_vs_reference_converged"), dict):
+            c["deviation_vs_reference_converged"] = _pick(conv["deviation_vs_reference_converged"],
+                                                          ("state", "max_abs_du", "max_abs_dv", "max_abs_velocity", "dp_over_max_p", "fluid_cells_differing", "pcg_iterations", "error"))
+        if isinstance(conv.get("cpu_baseline_equal_tolerance"), dict):
+            c["cpu_baseline_equal_tolerance"] = _pick(conv["cpu_baseline_equal_tolerance"], ("value", "unit", "cores", "kind", "seconds", "pcg_iterations", "error"))
+        line["converged"] = c
+    summary = {}
+    q = full.get("quality")
+    if isinstance(q, dict) and isinstance(q.get("modes"), dict):
+        summary["quality_100_iterations"] = {"pressure_error_vs_converged": {m: v.get("pressure_error") for m, v in q["modes"].items()},
+                                             "solve_ms": {m: v.get("ms") for m, v in q["modes"].items()},
+                                             "converged_iterations": (q.get("converged") or {}).get("iterations")}
+    elif isinstance(q, dict) and "error" in q:
+        summary["quality_100_iterations"] = {"error": str(q["error"])[:160]}
+    sec = full.get("secondary") or {}
+    if isinstance(sec.get("exact_ic0"), dict):
+        summary["exact_ic0"] = _block(sec["exact_ic0"])
+    if isinstance(sec.get("projection_16384"), dict):
+        summary["projection_16384"] = _block(sec["projection_16384"])
+    c1 = sec.get("configs1_1024_dam_break")
+    if isinstance(c1, dict):
+        b = _block(c1, ("roofline_mode_value", "roofline_mode_us_per_iteration", "persistent_value", "f32_value", "steps_500_seconds"))
+        if isinstance(c1.get("parity_in_run"), dict):
+            b["parity_in_run"] = _pick(c1["parity_in_run"], ("frames", "max_abs_du", "max_abs_dv", "fluid_cells_differing"))
+        summary["configs1_1024_dam_break"] = b
+    tts = sec.get("time_to_solution")
+    if isinstance(tts, dict):
+        summary["time_to_solution_2048_ms"] = {k: v.get("ms") for k, v in tts.items() if isinstance(v, dict) and "ms" in v} or _pick(tts, ("error",))
+    for k, v in full.items():
+        if k.startswith("strong_") and isinstance(v, dict):
+            b = _block(v, ("scaling", "setup_and_preroll_seconds"))
+            if isinstance(v.get("converged_frames_multilevel"), dict):
+                b["converged"] = _pick(v["converged_frames_multilevel"], ("value", "ms_per_step", "substeps", "pcg_iterations", "error"))
+            if isinstance(v.get("balance"), dict):
+                b["balance_max_over_mean"] = v["balance"].get("max_over_mean")
+            summary[k] = b
+    line["summary"] = summary
+    line.update(_pick(full, ("balance", "comm_calls_rank0", "device", "full", "timings_s")))
+    if isinstance(line.get("balance"), dict):
+        line["balance"] = _pick(line["balance"], ("partition", "max_over_mean"))
+    line = _short(line)
+    for k in ("value", "ms_per_step"):      # (the contract's two numbers at full precision: value x ms_per_step is checkable)
+        if k in full:
+            line[k] = full[k]
+    # the size guard: drop the least important parts until the line fits
+    for drop in (("timings_s",), ("kernels",), ("summary", "time_to_solution_2048_ms"), ("summary", "configs1_1024_dam_break"), ("summary", "exact_ic0"),
+                 ("summary", "projection_16384"), ("summary",), ("comm_calls_rank0",), ("balance",)):
+        if len(json.dumps(line)) < limit:
+            break
+        d = line
+        for k in drop[:-1]:
+            d = d.get(k) or {}
+        d.pop(drop[-1], None)
+    return line
+
+
+def write_full(full):
+    """the full object beside the line: bench_full.json at the repo root and (the GPU box's scratch that travels back) under gpurun_out/"""
+    where = None
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "bench_full.json"), "w") as f:
+                json.dump(full, f)
+                f.write("\n")
+            where = where or os.path.join(os.path.relpath(d, ROOT), "bench_full.json").replace("./", "")
+        except OSError:
+            pass
+    return where
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     args = parse_args()
@@ -855,12 +1109,14 @@ def main():
     # ---- live PMC passes FIRST (child processes; this process has not touched the GPU yet and holds no HBM)
     traffic = traffic_note = None
     traffic_exact = traffic_exact_note = None
+    t_start, t_pmc = time.perf_counter(), 0.0
     if single and not args.no_pmc and not args.pmc_child:
         t0 = time.perf_counter()
         traffic, traffic_note = pmc_live(child_common + ["--precond", args.precond])
         if not args.no_secondary and args.precond != "ic0":
             traffic_exact, traffic_exact_note = pmc_live(child_common + ["--precond", "ic0"])
-        print("bench: PMC passes took %.0f s (%s)" % (time.perf_counter() - t0, traffic_note), file=sys.stderr)
+        t_pmc = time.perf_counter() - t0
+        print("bench: PMC passes took %.0f s (%s)" % (t_pmc, traffic_note), file=sys.stderr)
 
     # stdout carries exactly ONE line, the JSON: whatever native libraries print on fd 1 while the job runs
     # (RCCL writes its version banner there when a communicator is created) is diverted to stderr
@@ -925,8 +1181,17 @@ def main():
             comm_calls = dict(comm.counts)
         except Exception:
             comm_calls = None
-    head = copy_gbps = device = equal = None
+    head = copy_gbps = device = quality = converged = exact = None
     tile_w_run = tile_w
+    timings = {"pmc_passes": round(t_pmc, 1)}
+    clock = [t_start + t_pmc]
+
+    def lap(name):
+        now = time.perf_counter()
+        timings[name] = round(now - clock[0], 1)
+        clock[0] = now
+    lap("setup_preroll_headline_frames")
+    solver_tol = 1e-6 if tol is None else tol
     if rank == 0:
         rank_cells, share = None, 1.0
         if rows:
@@ -943,11 +1208,36 @@ def main():
         if head["roofline"]:
             head["roofline"]["measured_copy_GBps"] = copy_gbps
         device = sim.device_name()
-    if single and not args.no_secondary and not args.pmc_child and args.precond == "ic0_tile":
-        try:      # what the roofline mode is worth at the REFERENCE's residual (same systems, both preconditioners, on this very state)
-            equal = equal_residual(sim, ea, grp, args, GX, GY, tile_w, 1e-6 if tol is None else tol)
+    secondary = {}
+    extras = single and not args.no_secondary and not args.pmc_child
+    big_head = GX * GY >= 4096 * 4096
+    if extras and args.precond == "ic0_tile":
+        # the SAME handle goes on (no second preroll): the parity mode on the same frames, what 100 iterations are worth per mode, then the converged frames
+        try:      # (1) the same workload in the parity mode: the reference's own IC(0), bit-identical iterates
+            k2 = max(1, min(4, args.steps // 2))
+            sim.set_precond(ea.PRECOND_IC0, args.tile_records)
+            sim.step()
+            t2 = time_frames(sim, ea, grp, args, "ic0", k2, 0, 0, big_head)
+            exact = summarize(t2, GX, GY, "ic0", tile_w, traffic_exact, traffic_exact_note, k2)
+            exact["workload"] = "%dx%d %s (the headline workload, the frames behind the headline's), %d frames" % (GX, GY, args.workload, k2)
+            exact["steps"] = k2
         except Exception as e:
-            equal = {"error": repr(e)}
+            exact = {"error": repr(e)}
+        secondary["exact_ic0"] = exact
+        sim.set_precond(ea.PRECOND_IC0_TILE, args.tile_records)
+        lap("exact_ic0")
+        try:      # (2) what the budget of 100 iterations is worth in every mode, against the converged solution of the same system
+            quality = quality_summary(sim, ea, args.tile_records, solver_tol)
+            if args.quality:
+                quality["equal_residual"] = equal_residual(sim, ea, grp, args, GX, GY, tile_w, solver_tol)
+        except Exception as e:
+            quality = {"error": repr(e)}
+        lap("quality")
+        try:      # (3) every solve converged to the reference's tolerance
+            converged = converged_block(sim, ea, grp, args, GX, GY, tile_w, max(2, min(6, args.steps // 3)), solver_tol)
+        except Exception as e:
+            converged = {"error": repr(e)}
+        lap("converged")
     sim.close()
     del sim
     # BASELINE configs[3], the strong-scaling unit: N > 1 (the driver's scaling run) measures it beside the weak line, N = 1 its denominator
@@ -959,29 +1249,16 @@ def main():
             strong = strong_block(ctx, args.strong_size, 2, tile_w)
         except Exception as e:      # (collective: a failure here is every rank's)
             strong = {"error": repr(e)}
+        lap("strong_block")
     if rank != 0:
         grp.close()
         return
 
-    secondary = {}
     cpu_obj = None
-    if single and not args.no_secondary and not args.pmc_child:
+    libs = None
+    if extras:
         libs = None if args.no_cpu_baseline else build_native_oracle()
-        # (1) the same workload in the parity mode: the reference's own IC(0)
-        if args.precond != "ic0":
-            try:
-                k2 = max(1, args.steps // 2)
-                s2 = ea.Simulation(GX, GY, device=local_rank, dot_mode=dot_mode, precond=ea.PRECOND_IC0, tol=tol)
-                load_workload(s2, scenarios, args.workload, 1)
-                preroll_into_solves(s2, args.max_preroll, saturate)
-                t2 = time_frames(s2, ea, grp, args, "ic0", k2, 0, args.warmup, big)
-                secondary["exact_ic0"] = summarize(t2, GX, GY, "ic0", tile_w, traffic_exact, traffic_exact_note, k2)
-                secondary["exact_ic0"]["workload"] = "%dx%d %s (the headline workload), %d frames" % (GX, GY, args.workload, k2)
-                s2.close()
-                del s2
-            except Exception as e:
-                secondary["exact_ic0"] = {"error": repr(e)}
-        # (2) time to SOLVE one system to the reference's tolerance, both modes (2048^2 half tank, first projection)
+        # (4) time to SOLVE one system to the reference's tolerance, every mode (2048^2 half tank, first projection)
         try:
             tts = {}
             for pc in ("ic0", "ic0_tile", "ic0_tile2", "ic0_tile_mg"):
@@ -999,13 +1276,11 @@ def main():
                 s3.close()
                 del s3
             tts["workload"] = "2048x2048 half tank from rest, one frame, tol 1e-6 (the reference's), iteration cap lifted to 20000"
-            tts["speedup_tile_over_exact"] = round(tts["ic0"]["ms"] / tts["ic0_tile"]["ms"], 2)
-            tts["speedup_two_level_over_exact"] = round(tts["ic0"]["ms"] / tts["ic0_tile2"]["ms"], 2)
-            tts["speedup_multilevel_over_exact"] = round(tts["ic0"]["ms"] / tts["ic0_tile_mg"]["ms"], 2)
             secondary["time_to_solution"] = tts
         except Exception as e:
             secondary["time_to_solution"] = {"error": repr(e)}
-        # (3) BASELINE configs[1]: 1024^2 dam break in the expensive phase, parity mode, checked in-run against the oracle
+        lap("time_to_solution")
+        # (5) BASELINE configs[1]: 1024^2 dam break in the expensive phase, parity mode, checked in-run against the oracle
         try:
             s4 = ea.Simulation(1024, 1024, device=local_rank, dot_mode=dot_mode, precond=ea.PRECOND_IC0)
             load_workload(s4, scenarios, "dam_break", 1)
@@ -1025,7 +1300,7 @@ def main():
                           "vs": "oracle (strict IEEE build) from the same state, EULER_DOT_TREE on the GPU"}
             t4 = time_frames(s4, ea, grp, args, "ic0", 4, done, 1, False)
             c1 = summarize(t4, 1024, 1024, "ic0", tile_w, None, "no PMC pass inside this block (profiles/ holds one)", 4)
-            c1.update({"workload": "1024x1024 dam break (block layout upscaled), preroll %d frames into the expensive phase" % pre4,
+            c1.update({"workload": "1024x1024 dam break (block layout upscaled), preroll %d frames into the expensive phase" % pre4, "steps": 4,
                        "parity_in_run": parity,
                        "cpu_same_state": {k: v for k, v in (cpu1 or {}).items() if not k.startswith("_")} or None})
             s4.set_precond(ea.PRECOND_IC0_TILE, args.tile_records)
@@ -1037,13 +1312,22 @@ def main():
             del s4
         except Exception as e:
             secondary["configs1_1024_dam_break"] = {"error": repr(e)}
-        # (3b) the roofline mode's fields against the reference's preconditioner, one state per BASELINE workload
-        if libs:
+        lap("configs1")
+        # (5b, --quality) the roofline mode's fields against the reference's preconditioner, one state per BASELINE workload
+        if libs and args.quality:
             try:
                 secondary["parity_vs_reference_ic0"] = parity_vs_reference(ea, scenarios, libs["strict"], local_rank, dot_mode, args.tile_records)
             except Exception as e:
                 secondary["parity_vs_reference_ic0"] = {"error": repr(e)}
-        # (4) the north star's target size: the pressure projection at 16384^2 (half tank, tol = 0: 100 iterations per substep)
+            lap("parity_vs_reference")
+        # (6) the converged frame against the reference's algorithm run to convergence
+        if libs and isinstance(converged, dict) and "error" not in converged:
+            try:
+                converged["deviation_vs_reference_converged"] = converged_deviation(ea, scenarios, libs["strict"], local_rank, dot_mode, args.tile_records)
+            except Exception as e:
+                converged["deviation_vs_reference_converged"] = {"error": repr(e)}
+            lap("converged_deviation")
+        # (7) the north star's target size: the pressure projection at 16384^2 (half tank, tol = 0: 100 iterations per substep), with its own PMC pass
         if not args.no_16384 and N < 16384:
             try:
                 t0 = time.perf_counter()
@@ -1052,28 +1336,26 @@ def main():
                 setup_s = time.perf_counter() - t0
                 preroll_into_solves(s5, 4)
                 t5 = time_frames(s5, ea, grp, args, args.precond, 1, 0, 0, True)
-                p16 = summarize(t5, 16384, 16384, args.precond, tile_w, None, None, 1)
-                # per-cell traffic of the same kernels as counted live at the headline size, scaled by fluid cells (labelled)
-                hp = head["pcg_iteration"]
-                if traffic and hp and hp.get("GBps_traffic") and p16["pcg_iteration"]:
-                    scale = p16["fluid_cells"] / max(head["fluid_cells"], 1)
-                    sec = p16["pcg_iteration"]["us_per_iteration"] * 1e-6
-                    hb = hp["GBps_traffic"] * 1e9 * hp["us_per_iteration"] * 1e-6
-                    p16["pcg_iteration"]["GBps_traffic_scaled"] = round(hb * scale / sec / 1e9, 1)
-                    p16["pcg_iteration"]["frac_traffic_scaled"] = round(hb * scale / sec / 1e9 / HBM_PEAK_GBPS, 4)
-                    p16["pcg_iteration"]["traffic_scaled_note"] = ("bytes per fluid cell as counted by the live PMC pass at the headline size "
-                                                                   "x this grid's fluid cells")
-                p16["workload"] = "16384x16384 half tank, tol 0, 100 iterations per substep, 1 frame"
-                p16["setup_seconds"] = round(setup_s, 1)
-                secondary["projection_16384"] = p16
+                st5 = t5
                 s5.close()
                 del s5
+                traffic16 = note16 = None
+                if not args.no_pmc:      # (after the handle is gone: the child processes need the HBM)
+                    child16 = list(child_common)
+                    child16[child16.index("--size") + 1] = "16384"
+                    traffic16, note16 = pmc_live(child16 + ["--precond", args.precond, "--max-preroll", "4"])
+                p16 = summarize(st5, 16384, 16384, args.precond, tile_w, traffic16, note16, 1)
+                p16["workload"] = "16384x16384 half tank, tol 0, 100 iterations per substep, 1 frame"
+                p16["steps"] = 1
+                p16["setup_seconds"] = round(setup_s, 1)
+                secondary["projection_16384"] = p16
             except Exception as e:
                 secondary["projection_16384"] = {"error": repr(e)}
-    if (single and not args.no_secondary and not args.pmc_child) or (world > 1 and not args.no_cpu_baseline):
+            lap("projection_16384")
+    if extras or (world > 1 and not args.no_cpu_baseline):
         if not single:
             libs = build_native_oracle()
-        # (5) the CPU path beside it (rank 0): single thread, bounded sample
+        # (8) the CPU path beside it (rank 0): single thread, bounded sample
         if libs:
             try:
                 cpu = cpu_baseline_roofline_run(libs, tol if tol is not None else 1e-6)
@@ -1092,18 +1374,29 @@ def main():
                            "host_cores_available": os.cpu_count()}
             except Exception as e:
                 cpu_obj = {"error": repr(e)}
+            if single and isinstance(converged, dict) and "error" not in converged:
+                try:
+                    converged["cpu_baseline_equal_tolerance"] = cpu_converged_baseline(libs)
+                    if isinstance(cpu_obj, dict):
+                        cpu_obj["equal_tolerance"] = converged["cpu_baseline_equal_tolerance"]
+                except Exception as e:
+                    converged["cpu_baseline_equal_tolerance"] = {"error": repr(e)}
+            lap("cpu_baseline")
 
     transports = (("peer-to-peer mailboxes (PCG scalars, ghost rows of s) + " if p2p_on else "")
                   + ("RCCL over xGMI, called from the C library on the kernels' stream" if args.comm == "rccl" else "torch.distributed callbacks"))
     pc_name = "tile-local IC(0): no coupling between slabs" if args.precond in TILE_MODES else ("slab-local" if rows else args.slab) + " IC(0) coupling"
     parallelism = "1 GPU" if args.gpus == 1 and not sharded else (
         "%d independent replicas" % args.gpus if not sharded else
-        ("%d row slabs of %s rows, EVERY stage decomposed (each rank holds its rows + ghost rows and the markers inside them: %.2f GB of HBM "
-         "per rank; ghost rows, marker migration, dt all-reduce, distributed PCG with %s; exchanges by %s); grid %dx%d"
+        ("%d row slabs of %s rows, every stage decomposed (%.2f GB of HBM per rank; ghost rows, marker migration, dt all-reduce, distributed PCG with %s; exchanges by %s); grid %dx%d"
          % (args.gpus, ("fluid-balanced numbers of" if partition else str(GY // max(world, 1))), hbm_per_rank / 1e9, pc_name, transports, GX, GY)) if rows else
         "%d row slabs of %d rows: distributed PCG (%s, exchanges by %s), replicated marker/advection stages; grid %dx%d"
         % (args.gpus, GY // max(world, 1), pc_name, transports, GX, GY))
-    out = {
+    parallelism_short = "1 GPU" if args.gpus == 1 and not sharded else (
+        "%d independent replicas" % args.gpus if not sharded else
+        "%d row slabs%s; %s; exchanges: %s%s" % (args.gpus, (" (%s rows each), EVERY stage decomposed" % ("fluid-balanced" if partition else str(GY // max(world, 1)))) if rows else
+                                               " of the pressure solve only", pc_name, "peer-to-peer mailboxes + " if p2p_on else "", "RCCL" if args.comm == "rccl" else "torch.distributed callbacks"))
+    full = {
         "metric": "cells*steps/sec of sim_step() (frames incl. the PCG pressure projection) + pressure-solve HBM GB/s vs roofline",
         "value": job_rate,
         "unit": "cells*steps/s",
@@ -1112,14 +1405,14 @@ def main():
         "higher_is_better": True,
         "scaling": args.scaling if sharded else "weak",
         "vs_baseline": None,
-        "dtype": "f32 fields, f64 PCG (the reference's mix)",
+        "dtype": "f64 PCG vectors, f32 fields (the reference's mix, main.c:64-67,577-578,716)",
         "data": "synthetic",
         "config": {"workload": "%dx%d %s%s, %s" % (GX, GY, args.workload,
                                                    " (BASELINE configs[2], pressure-solve roofline run: tol 0, exactly 100 PCG iterations per substep%s)"
                                                    % ("; timed in the saturated phase: 8 CFL substeps per frame" if saturate else "")
-                                                   if args.workload == "half_tank" and tol == 0.0 else "", head["mode"]),
+                                                   if args.workload == "half_tank" and tol == 0.0 else "", args.precond),
                    "grid": [GX, GY], "preroll_frames": preroll, "precond": args.precond, "tile_records": tile_w if args.precond in TILE_MODES else None,
-                   "dot_mode": args.dot_mode, "max_iterations": args.max_iterations, "tol": tol if tol is not None else 1e-6, "parallelism": parallelism},
+                   "dot_mode": args.dot_mode, "max_iterations": args.max_iterations, "tol": tol if tol is not None else 1e-6, "parallelism": parallelism_short, "parallelism_detail": parallelism},
         "mode": head["mode"],
         "substeps": head["substeps"], "pcg_iterations": head["pcg_iterations"], "cells_substeps_per_s": head["cells_substeps_per_s"],
         "markers": head["markers"], "fluid_cells": head["fluid_cells"], "hbm_bytes_this_rank": int(hbm_per_rank),
@@ -1129,15 +1422,18 @@ def main():
         "comm_calls_rank0": comm_calls,
         "kernels": head["kernels"],
         "cpu_baseline": cpu_obj,
-        "equal_residual": equal,
         # the same workload with EVERY solve run to the reference's tolerance 1e-6 (multilevel mode, cap lifted) - not the headline (whose work is fixed at 100 iterations per
-        # substep by BASELINE configs[2]), the figure for "this grid, actually solved"; a copy of equal_residual.multilevel.converged_frames
-        "converged_frames_multilevel": (equal or {}).get("multilevel", {}).get("converged_frames") if isinstance(equal, dict) and isinstance(equal.get("multilevel"), dict) else None,
+        # substep by BASELINE configs[2]), the figure for "this grid, actually solved", with its own roofline object, the CPU at equal tolerance and the deviation from the
+        # reference's algorithm run to convergence
+        "converged": converged,
+        "quality": quality,
         "strong_%d_dam_break" % args.strong_size: strong,
         "secondary": secondary or None,
         "device": device,
+        "timings_s": timings,
     }
-    emit(json.dumps(out))
+    full["full"] = write_full(full)
+    emit(json.dumps(compact_line(full)))
     os.dup2(2, 1)
     grp.close()
 

@@ -227,6 +227,9 @@ extern "C" int euler_p2p_connect(euler_sim* S, const void* handles, int32_t nran
   if (!p) { eu_set_error("euler_p2p_connect: call euler_p2p_export first"); return EULER_ESTATE; }
   if (!S->has_comm || S->comm.nranks != nranks || S->comm.ctx == S) { eu_set_error("euler_p2p_connect: install a communicator of %d ranks first", (int)nranks); return EULER_ESTATE; }
   if (nranks > P2P_MAXR) { eu_set_error("euler_p2p_connect: at most %d ranks", P2P_MAXR); return EULER_EINVAL; }
+  if (S->cfg.precond == EULER_PRECOND_IC0_TILE2 || S->cfg.precond == EULER_PRECOND_IC0_TILE_MG) {      // (the same configuration on every rank: everybody returns here)
+    eu_set_error("euler_p2p_connect: the coarse-correction preconditioners run on the default transport, not over the mailboxes"); return EULER_EINVAL;
+  }
   HIPCHK(hipSetDevice(S->cfg.device));
   p->rank = S->comm.rank; p->n = nranks;
   const hipIpcMemHandle_t* hs = static_cast<const hipIpcMemHandle_t*>(handles);   // P2P_NHANDLES per rank

@@ -73,7 +73,7 @@ struct RcclComm {
   euler_sim* S;
   int rank, n;
   uint64_t calls[5];   // allreduce, halo, chain, allgather, exchange
-  int small_by_allgather;   // EULER_RCCL_SMALL=allgather: the small part of an exchange as ncclAllGather instead of sends / receives
+  int small_by_allgather;   // the all-to-all part of an exchange as ncclAllGather instead of sends / receives: 0 = when the slot exceeds 64 doubles (default), 1 = always (EULER_RCCL_SMALL=allgather), -1 = never
 };
 
 #define NCHK(call)                                                                              \
@@ -168,18 +168,19 @@ int op_exchange(void* ctx, void* send_lo, void* send_hi, void* recv_lo, void* re
       GCHK(g_api.Recv(recv_hi, (size_t)count, ncclDouble, c->rank + 1, c->comm, st));
     }
   }
-  if (nsmall > 0) {
-    if (c->small_by_allgather) {
-      GCHK(g_api.AllGather(sm + (size_t)c->rank * nsmall, sm, (size_t)nsmall, ncclDouble, c->comm, st));
-    } else {
-      for (int r = 0; r < c->n; ++r) {
-        if (r == c->rank) continue;
-        GCHK(g_api.Send(sm + (size_t)c->rank * nsmall, (size_t)nsmall, ncclDouble, r, c->comm, st));
-        GCHK(g_api.Recv(sm + (size_t)r * nsmall, (size_t)nsmall, ncclDouble, r, c->comm, st));
-      }
+  // the all-to-all part: a few doubles per rank ride in the same group as sends / receives (latency-bound: one serial RCCL operation); a large slot
+  // (the multilevel mode's level-0 rows: cells / 256 doubles over all ranks, 8 MB at 16384^2) goes as ONE in-place ncclAllGather behind the group
+  // instead of N - 1 send / receive pairs per rank - it is bandwidth-bound, and the ring spreads it over the links
+  const bool by_allgather = nsmall > 0 && (c->small_by_allgather > 0 || (c->small_by_allgather == 0 && nsmall > 64));
+  if (nsmall > 0 && !by_allgather) {
+    for (int r = 0; r < c->n; ++r) {
+      if (r == c->rank) continue;
+      GCHK(g_api.Send(sm + (size_t)c->rank * nsmall, (size_t)nsmall, ncclDouble, r, c->comm, st));
+      GCHK(g_api.Recv(sm + (size_t)r * nsmall, (size_t)nsmall, ncclDouble, r, c->comm, st));
     }
   }
   GCHK(g_api.GroupEnd());
+  if (by_allgather && !group_failed) NCHK(g_api.AllGather(sm + (size_t)c->rank * nsmall, sm, (size_t)nsmall, ncclDouble, c->comm, st));
   return group_failed ? -1 : 0;
 }
 
@@ -224,7 +225,7 @@ extern "C" int euler_set_comm_rccl(euler_sim* S, const void* unique_id, int32_t 
   RcclComm* c = static_cast<RcclComm*>(calloc(1, sizeof(RcclComm)));
   if (!c) return EULER_ENOMEM;
   c->S = S; c->rank = rank; c->n = nranks;
-  { const char* e = getenv("EULER_RCCL_SMALL"); c->small_by_allgather = e && strcmp(e, "allgather") == 0; }
+  { const char* e = getenv("EULER_RCCL_SMALL"); c->small_by_allgather = !e ? 0 : (strcmp(e, "allgather") == 0 ? 1 : -1); }      // default: by size; "allgather" / anything else: always / never
   ncclUniqueId id;
   memcpy(&id, unique_id, sizeof id);
   HIPCHK(hipSetDevice(S->cfg.device));

@@ -39,7 +39,7 @@ extern "C" int euler_abi_version(void) { return EULER_ABI_VERSION; }
 static const char* k_class_names[KC__COUNT] = {
     "timestep", "marker_advect", "marker_events", "marker_bin", "marker_compact", "sources", "select",
     "extrapolate", "advect_velocity", "build_system", "precon_factor", "forward_solve", "backward_solve",
-    "apply_a", "dot", "update_pr", "update_search", "reduce_final", "velocity_update", "jacobi", "misc", "precond_tile"};
+    "apply_a", "dot", "update_pr", "update_search", "reduce_final", "velocity_update", "jacobi", "misc", "precond_tile", "coarse_cycle"};
 
 void eu_prof_begin(euler_sim* S, int cls) {
   if (!((S->prof_mask >> cls) & 1)) return;
@@ -134,18 +134,30 @@ static int eu_set_tiles(euler_sim* S, int w) {
   return EULER_OK;
 }
 
+// which preconditioner / communicator combinations a solve can run (k_pcg.hip eu_launch_project): checked where the combination is made, not in the middle of a solve
+static const char* eu_precond_combination(const euler_sim* S, int precond, int tile_w, int has_comm, int slab_on, int p2p_on) {
+  const bool coarse = precond == EULER_PRECOND_IC0_TILE2 || precond == EULER_PRECOND_IC0_TILE_MG;
+  if (!coarse) return nullptr;
+  if (tile_w != 16 || S->cfg.sweep_mode == EULER_SWEEP_SIMPLE) return "the coarse-correction preconditioners run on tiles of 16 records with the band schedule";
+  if (precond == EULER_PRECOND_IC0_TILE2 && (has_comm || slab_on)) return "EULER_PRECOND_IC0_TILE2 runs on one GPU (row slabs: EULER_PRECOND_IC0_TILE_MG)";
+  if (precond == EULER_PRECOND_IC0_TILE_MG && has_comm && (!slab_on || p2p_on)) return "EULER_PRECOND_IC0_TILE_MG with several ranks: row-slab handles without mailboxes only";
+  return nullptr;
+}
+
 extern "C" int euler_set_precond(euler_sim* S, int32_t precond, int32_t tile_records) {
   if (!S || precond < EULER_PRECOND_IC0 || precond > EULER_PRECOND_IC0_TILE_MG) { eu_set_error("euler_set_precond: bad argument"); return EULER_EINVAL; }
+  // validate first: a refused call leaves the handle exactly as it was
+  const int w = tile_records <= 0 ? 16 : tile_records;
+  if (w != 8 && w != 16 && w != 32) { eu_set_error("precond_tile_records = %d: 8, 16 or 32 (0 = 16)", tile_records); return EULER_EINVAL; }
+  if (const char* why = eu_precond_combination(S, precond, w, S->has_comm, S->slab_on, S->p2p_on)) { eu_set_error("euler_set_precond: %s", why); return EULER_EINVAL; }
   HIPCHK(hipStreamSynchronize(S->stream));
-  int rc = eu_set_tiles(S, tile_records);
-  if (rc) return rc;
-  if (precond == EULER_PRECOND_IC0_TILE2 || precond == EULER_PRECOND_IC0_TILE_MG) {      // the two-level / multilevel modes: tiles of 16 records, one GPU, tree dots; their arrays come with the first use
-    if (((S->has_comm || S->slab_on) && precond != EULER_PRECOND_IC0_TILE_MG) || S->tile_w != 16 || S->cfg.sweep_mode == EULER_SWEEP_SIMPLE) {
-      eu_set_error("EULER_PRECOND_IC0_TILE2: one GPU; _MG: one GPU or row slabs; both: tiles of 16 records, the band schedule"); return EULER_EINVAL;
-    }
-    S->cfg.dot_mode = EULER_DOT_TREE;
-    if ((rc = eu_coarse_alloc(S))) return rc;
-  }
+  const bool coarse = precond == EULER_PRECOND_IC0_TILE2 || precond == EULER_PRECOND_IC0_TILE_MG;
+  if (coarse) { int rc = eu_coarse_alloc(S); if (rc) return rc; }      // their arrays come with the first use
+  (void)eu_set_tiles(S, w);
+  // the coarse modes fold their sums as trees: EULER_DOT_TREE while one of them is selected, the caller's own mode (EULER_DOT_SEQUENTIAL: the
+  // reference's order of the dot products, the bit-identical parity mode) again afterwards
+  S->cfg.dot_mode = coarse ? EULER_DOT_TREE : S->dot_mode_user;
+  if (S->has_comm && S->cfg.dot_mode == EULER_DOT_SEQUENTIAL) S->cfg.dot_mode = EULER_DOT_TREE;
   // (a row-slab handle runs whatever preconditioner it is given WITHOUT coupling between the slabs - eu_install_comm forced S->couple = 0 and
   // refuses EULER_SLAB_EXACT for it - so EULER_PRECOND_IC0 here means slab-local IC(0): valid, and not the single-GPU iterates)
   S->cfg.precond = precond;
@@ -237,6 +249,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   S->X = cfg->X; S->Y = cfg->Y;
   const size_t C = S->C = (size_t)cfg->X * cfg->Y;
   if (S->cfg.dot_mode == EULER_DOT_AUTO) S->cfg.dot_mode = C <= 65536 ? EULER_DOT_SEQUENTIAL : EULER_DOT_TREE;
+  S->dot_mode_user = S->cfg.dot_mode;
   if (S->cfg.sweep_mode == EULER_SWEEP_AUTO) S->cfg.sweep_mode = EULER_SWEEP_BAND;
   S->geom.X = S->X; S->geom.Y = S->Y;
   S->geom.nbands = (S->Y + 63) / 64;
@@ -559,6 +572,8 @@ static int eu_set_comm_slot(euler_sim* S) {
 // allow_single: keep the communicator code path with one rank (the RCCL self-test on a 1-GPU box)
 int eu_install_comm(euler_sim* S, const euler_comm_ops* ops, int32_t coupling, int allow_single) {
   if (!S) return EULER_EINVAL;
+  if (ops && ops->nranks >= 1 && !(ops->nranks == 1 && !allow_single && !S->slab_on))
+    if (const char* why = eu_precond_combination(S, S->cfg.precond, S->tile_w, 1, S->slab_on, 0)) { eu_set_error("euler_set_comm: %s", why); return EULER_EINVAL; }
   if (S->slab_on) {   // the handle IS one slab: the communicator must be the one it was created for; the partition stays
     if (!ops) { S->has_comm = 0; return EULER_OK; }
     if (!ops->allreduce || !ops->halo || !ops->chain || !ops->allgather || ops->rank != S->cfg.slab_rank || ops->nranks != S->cfg.slab_nranks) {

@@ -30,7 +30,7 @@ enum {
   KC_TIMESTEP = 0, KC_MARKER_ADVECT, KC_MARKER_EVENTS, KC_MARKER_BIN, KC_MARKER_COMPACT, KC_SOURCES,
   KC_SELECT, KC_EXTRAPOLATE, KC_ADVECT_VELOCITY, KC_BUILD_SYSTEM, KC_PRECON_FACTOR,
   KC_FORWARD_SOLVE, KC_BACKWARD_SOLVE, KC_APPLY_A, KC_DOT, KC_UPDATE_PR, KC_UPDATE_SEARCH,
-  KC_REDUCE_FINAL, KC_VELOCITY_UPDATE, KC_JACOBI, KC_MISC, KC_PRECOND_TILE, KC__COUNT
+  KC_REDUCE_FINAL, KC_VELOCITY_UPDATE, KC_JACOBI, KC_MISC, KC_PRECOND_TILE, KC_COARSE_CYCLE, KC__COUNT
 };
 
 // Device-resident PCG scalars: no host round trip inside the iteration (reference: locals of
@@ -130,6 +130,7 @@ struct euler_sim {
   size_t C;
   hipStream_t stream;
   int loaded;
+  int dot_mode_user;      // the dot mode the caller's configuration resolved to (the coarse modes force EULER_DOT_TREE while they are selected; leaving them restores this)
 
   // fields (main.c:64-73,96-97)
   float *u, *v, *utmp, *vtmp;
@@ -306,6 +307,7 @@ int  eu_slab_exchange_dye(euler_sim* S);    // ghost rows of g_r, g_g, g_b (--ra
 int  eu_slab_render(euler_sim* S, int wx, int wy, char* out, int cap, int* len);   // snapshot.hip: euler_render on a row-slab handle (collective)
 int  eu_slab_after_restore(euler_sim* S);   // collective: the job-wide facts a scenario load sets up (source cells of all ranks)
 int  eu_slab_error_sync(euler_sim* S);      // collective: the ranks' sticky error words -> their maximum on every rank
+int  eu_slab_status_sync(euler_sim* S, int local_rc, int* worst);   // collective: a host-side status code -> non-zero on every rank if any rank failed
 // launch groups implemented in the kernel files
 int eu_launch_timestep(euler_sim* S, float frame_time_left);
 int eu_launch_advect_markers(euler_sim* S, float dt);

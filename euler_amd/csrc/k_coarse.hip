@@ -28,6 +28,7 @@
 #define CC_MAX 256          // coarse cells
 #define CC_THREADS 1024
 #define CC_NULL_MAX 4       // fluid regions cut off from the air whose indicators are kept (k_coarse_nullfix)
+#define CC_NULL_TOTAL (CC_NULL_MAX * CC_MAX + 1 + 2 * CC_NULL_MAX + 512 * 2 * CC_NULL_MAX + 1)      // = NS_TOTAL below
 #define MG_DOT_BLOCKS 512    // most blocks of the level-0 kernel that closes the V-cycle (its dot partials)
 #define MG_OMEGA 0.8         // damped Jacobi
 #define MG_KAPPA 1.5         // scaling of the coarse-grid correction (plain aggregation under-corrects)
@@ -56,8 +57,8 @@ int eu_coarse_alloc(euler_sim* S) {
   HIPCHK(hipMalloc((void**)&S->cc_y, (2 * CC_MAX + 1) * sizeof(double)));      // y [CC_MAX], r_c [CC_MAX], the ticket counter of k_coarse_solve
   HIPCHK(hipMemset(S->cc_part, 0, (S->chunk_cap + 64) * 3 * sizeof(double)));
   HIPCHK(hipMemset(S->cc_y, 0, (2 * CC_MAX + 1) * sizeof(double)));
-  HIPCHK(hipMalloc((void**)&S->cc_null, (CC_NULL_MAX * CC_MAX + 1) * sizeof(double)));
-  HIPCHK(hipMemset(S->cc_null, 0, (CC_NULL_MAX * CC_MAX + 1) * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&S->cc_null, CC_NULL_TOTAL * sizeof(double)));      // indicators, their number, the sums / partials / ticket of k_null_sums
+  HIPCHK(hipMemset(S->cc_null, 0, CC_NULL_TOTAL * sizeof(double)));
   // the multilevel hierarchy below the dense level: aggregates of 16, 32, ... , 32 m grid cells (k_mg_* below)
   S->mg_levels = 0; S->mg_cells = 0;
   for (int g = 16; g < 64 * m; g *= 2) {
@@ -464,8 +465,10 @@ __global__ __launch_bounds__(256) void k_mg_up(MgLevel L, const double* __restri
   }
 }
 
+#define CLAUNCH(S, KERNEL, GRID, BLOCK, ...) hipLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, (S)->stream, __VA_ARGS__)
 static int launch_mg_cycle(euler_sim* S, int fin_op, int force) {
   const int nl = S->mg_levels;
+  eu_prof_begin(S, KC_COARSE_CYCLE);      // ONE event pair around the whole cycle (a pair per 5 us launch would time the events)
   double* x1 = S->mg_x + S->mg_cells;      // the third pool
   auto level = [&](int l) { const size_t o = S->mg_off[l]; return MgLevel{S->mg_d + o, S->mg_rt + o, S->mg_up + o, S->mg_rhs + o, x1 + o, S->mg_nx[l], S->mg_ny[l]}; };
   const int n0 = S->mg_nx[0] * S->mg_ny[0];
@@ -473,30 +476,31 @@ static int launch_mg_cycle(euler_sim* S, int fin_op, int force) {
     MgParts P;
     P.n = S->bulk.nranks < 64 ? S->bulk.nranks : 64;
     for (int r = 0; r < P.n; ++r) { P.lo[r] = 4 * S->part_lo[r]; P.hi[r] = 4 * S->part_hi[r]; }
-    LAUNCH(S, KC_PRECOND_TILE, k_mg_scatter0, dim3((n0 + 255) / 256), dim3(256), S->mg_xbuf, S->mg_xslot, P, S->mg_d, S->mg_rhs, x1, S->mg_nx[0], n0, S->sc, force);
+    CLAUNCH(S, k_mg_scatter0, dim3((n0 + 255) / 256), dim3(256), S->mg_xbuf, S->mg_xslot, P, S->mg_d, S->mg_rhs, x1, S->mg_nx[0], n0, S->sc, force);
   } else
-    LAUNCH(S, KC_PRECOND_TILE, k_mg_gather0, dim3((n0 + 255) / 256), dim3(256), S->mg_part, S->mg_d, S->mg_rhs, x1, S->mg_nx[0], 0, S->mg_ny[0], S->geom.T / 16,
+    CLAUNCH(S, k_mg_gather0, dim3((n0 + 255) / 256), dim3(256), S->mg_part, S->mg_d, S->mg_rhs, x1, S->mg_nx[0], 0, S->mg_ny[0], S->geom.T / 16,
            S->band_lo, S->band_hi, S->sc, force);
   double* top_rhs = S->cc_y + CC_MAX;
   for (int l = 0; l < nl; ++l) {
     const bool top = l + 1 == nl;
     const int cnx = top ? S->coarse_nx : S->mg_nx[l + 1], cny = top ? S->coarse_ny : S->mg_ny[l + 1];
     const size_t co = top ? 0 : S->mg_off[l + 1];
-    LAUNCH(S, KC_PRECOND_TILE, k_mg_down, dim3(((size_t)cnx * cny * 4 + 255) / 256), dim3(256), level(l), top ? top_rhs : S->mg_rhs + co, top ? (double*)nullptr : x1 + co,
+    CLAUNCH(S, k_mg_down, dim3(((size_t)cnx * cny * 4 + 255) / 256), dim3(256), level(l), top ? top_rhs : S->mg_rhs + co, top ? (double*)nullptr : x1 + co,
            top ? (const int*)nullptr : S->mg_d + co, cnx, cny, S->sc, force);
   }
-  LAUNCH(S, KC_PRECOND_TILE, k_mg_top, dim3(S->coarse_n), dim3(256), top_rhs, S->cc_inv, S->cc_y, S->coarse_n, S->sc, force);
+  CLAUNCH(S, k_mg_top, dim3(S->coarse_n), dim3(256), top_rhs, S->cc_inv, S->cc_y, S->coarse_n, S->sc, force);
   for (int l = nl - 1; l >= 0; --l) {
     const bool top = l + 1 == nl;
     const double* e = top ? S->cc_y : S->mg_x + S->mg_off[l + 1];
     const int enx = top ? S->coarse_nx : S->mg_nx[l + 1];
     const size_t cells = (size_t)S->mg_nx[l] * S->mg_ny[l];
-    if (l > 0) LAUNCH(S, KC_PRECOND_TILE, k_mg_up<false>, dim3((unsigned)((cells + 255) / 256)), dim3(256), level(l), e, enx, S->mg_x + S->mg_off[l], S->sc, fin_op, force, (double*)nullptr, (unsigned int*)nullptr);
+    if (l > 0) CLAUNCH(S, k_mg_up<false>, dim3((unsigned)((cells + 255) / 256)), dim3(256), level(l), e, enx, S->mg_x + S->mg_off[l], S->sc, fin_op, force, (double*)nullptr, (unsigned int*)nullptr);
     else {
       const unsigned nb = (unsigned)((cells + 255) / 256) < MG_DOT_BLOCKS ? (unsigned)((cells + 255) / 256) : MG_DOT_BLOCKS;
-      LAUNCH(S, KC_PRECOND_TILE, k_mg_up<true>, dim3(nb), dim3(256), level(l), e, enx, S->mg_x, S->sc, fin_op, force, S->mg_dot, reinterpret_cast<unsigned int*>(S->mg_dot + MG_DOT_BLOCKS));
+      CLAUNCH(S, k_mg_up<true>, dim3(nb), dim3(256), level(l), e, enx, S->mg_x, S->sc, fin_op, force, S->mg_dot, reinterpret_cast<unsigned int*>(S->mg_dot + MG_DOT_BLOCKS));
     }
   }
+  eu_prof_end(S, KC_COARSE_CYCLE);
   return EULER_OK;
 }
 
@@ -549,50 +553,94 @@ __global__ __launch_bounds__(CC_THREADS) void k_coarse_nullfix(double* __restric
 }
 
 // ---- water cut off from the air, continued: b - float divergences - is compatible with the singular A only to rounding (n.b ~ 1e-4 over such a region, not 0), and CG on a
-// singular, slightly inconsistent system wanders once it gets close (seen: 2000 iterations instead of 100).  The part of r = b along the region's indicator - a few 1e-9 per cell,
-// far below the tolerance, and nothing any A s could touch - is taken out before the solve starts.  Rare, so simple: one workgroup, fixed order; one GPU only.
-__global__ __launch_bounds__(CC_THREADS) void k_null_project(double* __restrict__ r, const uint8_t* __restrict__ mask, SkewGeom g, size_t e_lo, size_t e_cnt,
-                                                             const double* __restrict__ nullv, int shift, int nx, const PcgScalars* sc) {
-  if (!sc->nonzero) return;
-  __shared__ double s_red[2][CC_THREADS / 64];
-  __shared__ double s_eps, s_nn;
-  const int tid = threadIdx.x, count = (int)nullv[CC_NULL_MAX * CC_MAX];
-  for (int q = 0; q < count; ++q) {
-    const double* nv = nullv + q * CC_MAX;
-    double eps = 0.0, nn = 0.0;
-    for (size_t k = tid; k < e_cnt; k += CC_THREADS) {
-      const size_t e = e_lo + k;
-      if (!(mask[e] & CM_FLUID)) continue;
-      int band, t, l;
-      skew_decode(g, e, band, t, l);
-      const double w = nv[(size_t)((band * 64 + l) >> shift) * nx + ((t - l) >> shift)];
-      eps += r[e] * w; nn += w * w;
-    }
-    eps = eu_wave_sum(eps); nn = eu_wave_sum(nn);
-    if ((tid & 63) == 0) { s_red[0][tid >> 6] = eps; s_red[1][tid >> 6] = nn; }
-    __syncthreads();
-    if (tid == 0) { double a = 0.0, b = 0.0; for (int w = 0; w < CC_THREADS / 64; ++w) { a += s_red[0][w]; b += s_red[1][w]; } s_eps = a; s_nn = b; }
-    __syncthreads();
-    if (s_nn > 0.0) {
-      const double f = s_eps / s_nn;
-      for (size_t k = tid; k < e_cnt; k += CC_THREADS) {
-        const size_t e = e_lo + k;
-        if (!(mask[e] & CM_FLUID)) continue;
-        int band, t, l;
-        skew_decode(g, e, band, t, l);
-        r[e] = r[e] - nv[(size_t)((band * 64 + l) >> shift) * nx + ((t - l) >> shift)] * f;
-      }
-    }
-    __syncthreads();
+// singular, slightly inconsistent system wanders once it gets close (seen: 2000 iterations instead of 100).  The part of r = b along every region's indicator - a few 1e-9 per cell,
+// far below the tolerance, and nothing any A s could touch - is taken out before the solve starts: eps_q = n_q . r and n_q . n_q for all (up to four) indicators in one pass over
+// this rank's cells (per-block partials, the last block folds them in block order), on row slabs the sums of all ranks (ONE all-reduce of 8 doubles: the indicators, like the whole
+// dense level, are the same on every rank), then r -= sum_q n_q eps_q / nn_q.  Both launches are unconditional and return at once on the device when no region is cut off
+// (the usual case): no host round trip per solve (round 3: a one-workgroup kernel behind a hipStreamSynchronize, one GPU only).
+#define NULL_BLOCKS 512
+// cc_null layout: [CC_NULL_MAX][CC_MAX] indicators, [CC_NULL_MAX * CC_MAX] their number, then NS_SUMS: 8 sums {eps_q, nn_q}, NS_PART: per-block partials, NS_TICKET
+#define NS_SUMS (CC_NULL_MAX * CC_MAX + 1)
+#define NS_PART (NS_SUMS + 2 * CC_NULL_MAX)
+#define NS_TICKET (NS_PART + NULL_BLOCKS * 2 * CC_NULL_MAX)
+#define NS_TOTAL (NS_TICKET + 1)
+static_assert(NS_TOTAL == CC_NULL_TOTAL, "cc_null layout");
+__global__ __launch_bounds__(256) void k_null_sums(const double* __restrict__ r, const uint8_t* __restrict__ mask, SkewGeom g, size_t e_lo, size_t e_cnt,
+                                                   double* __restrict__ nullv, int shift, int nx, const PcgScalars* sc) {
+  const int count = (int)nullv[CC_NULL_MAX * CC_MAX];
+  if (!sc->nonzero || count <= 0) {      // (row slabs all-reduce the sums whatever they hold: keep them finite)
+    if (blockIdx.x == 0 && threadIdx.x < 2 * CC_NULL_MAX) nullv[NS_SUMS + threadIdx.x] = 0.0;
+    return;
+  }
+  double acc[2 * CC_NULL_MAX];
+#pragma unroll
+  for (int k = 0; k < 2 * CC_NULL_MAX; ++k) acc[k] = 0.0;
+  for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < e_cnt; k += (size_t)gridDim.x * 256) {
+    const size_t e = e_lo + k;
+    if (!(mask[e] & CM_FLUID)) continue;
+    int band, t, l;
+    skew_decode(g, e, band, t, l);
+    const size_t c = (size_t)((band * 64 + l) >> shift) * nx + ((t - l) >> shift);
+    const double rv = r[e];
+#pragma unroll
+    for (int q = 0; q < CC_NULL_MAX; ++q)
+      if (q < count) { const double w = nullv[q * CC_MAX + c]; acc[2 * q] += rv * w; acc[2 * q + 1] += w * w; }
+  }
+  __shared__ double s_red[4][2 * CC_NULL_MAX];
+  __shared__ int am_last;
+#pragma unroll
+  for (int k = 0; k < 2 * CC_NULL_MAX; ++k) {
+    const double v = eu_wave_sum(acc[k]);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  double* part = nullv + NS_PART;
+  unsigned int* ticket = reinterpret_cast<unsigned int*>(nullv + NS_TICKET);
+  if (threadIdx.x < 2 * CC_NULL_MAX) {
+    const int k = threadIdx.x;
+    const double t = (s_red[0][k] + s_red[1][k]) + (s_red[2][k] + s_red[3][k]);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(&part[(size_t)blockIdx.x * 2 * CC_NULL_MAX + k]), (unsigned long long)__double_as_longlong(t), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) am_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  __syncthreads();
+  if (!am_last) return;
+  if (threadIdx.x < 2 * CC_NULL_MAX) {      // block order: the same bits whichever block comes last
+    double t = 0.0;
+    for (unsigned int b2 = 0; b2 < gridDim.x; ++b2)
+      t += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&part[(size_t)b2 * 2 * CC_NULL_MAX + threadIdx.x]), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+    nullv[NS_SUMS + threadIdx.x] = t;
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(256) void k_null_apply(double* __restrict__ r, const uint8_t* __restrict__ mask, SkewGeom g, size_t e_lo, size_t e_cnt,
+                                                    const double* __restrict__ nullv, int shift, int nx, const PcgScalars* sc) {
+  const int count = (int)nullv[CC_NULL_MAX * CC_MAX];
+  if (!sc->nonzero || count <= 0) return;
+  double f[CC_NULL_MAX];
+#pragma unroll
+  for (int q = 0; q < CC_NULL_MAX; ++q) { const double nn = nullv[NS_SUMS + 2 * q + 1]; f[q] = (q < count && nn > 0.0) ? nullv[NS_SUMS + 2 * q] / nn : 0.0; }
+  for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < e_cnt; k += (size_t)gridDim.x * 256) {
+    const size_t e = e_lo + k;
+    if (!(mask[e] & CM_FLUID)) continue;
+    int band, t, l;
+    skew_decode(g, e, band, t, l);
+    const size_t c = (size_t)((band * 64 + l) >> shift) * nx + ((t - l) >> shift);
+    double v = r[e];
+#pragma unroll
+    for (int q = 0; q < CC_NULL_MAX; ++q)
+      if (q < count) v = v - nullv[q * CC_MAX + c] * f[q];
+    r[e] = v;
   }
 }
 int eu_launch_coarse_consistent(euler_sim* S) {
-  if (S->has_comm) return EULER_OK;      // (row slabs: the sums would have to be global - not built; the pseudo-inverse alone keeps such solves converging, mostly)
-  double count = 0.0;
-  HIPCHK(hipMemcpyAsync(&count, S->cc_null + CC_NULL_MAX * CC_MAX, sizeof(double), hipMemcpyDeviceToHost, S->stream));
-  HIPCHK(hipStreamSynchronize(S->stream));
-  if (count > 0.0)
-    LAUNCH(S, KC_PRECON_FACTOR, k_null_project, dim3(1), dim3(CC_THREADS), S->r, S->cellmask, S->geom, S->e_lo, S->e_cnt, S->cc_null, S->coarse_shift, S->coarse_nx, S->sc);
+  const unsigned nblk = eu_blocks(S->e_cnt, 256 * 8, NULL_BLOCKS);
+  LAUNCH(S, KC_PRECON_FACTOR, k_null_sums, dim3(nblk), dim3(256), S->r, S->cellmask, S->geom, S->e_lo, S->e_cnt, S->cc_null, S->coarse_shift, S->coarse_nx, S->sc);
+  if (S->has_comm) COMM_CALL(S->bulk.allreduce(S->bulk.ctx, S->cc_null + NS_SUMS, 2 * CC_NULL_MAX, 0));      // (zeros when nothing is cut off: every rank calls it, every solve)
+  LAUNCH(S, KC_PRECON_FACTOR, k_null_apply, dim3(nblk), dim3(256), S->r, S->cellmask, S->geom, S->e_lo, S->e_cnt, S->cc_null, S->coarse_shift, S->coarse_nx, S->sc);
   return EULER_OK;
 }
 
@@ -612,7 +660,7 @@ int eu_launch_coarse_pre(euler_sim* S, int force) {
   const int row0 = 4 * S->band_lo, row1 = 4 * S->band_hi;
   const int cells = (row1 - row0) * S->mg_nx[0];
   if (cells > 0)
-    LAUNCH(S, KC_PRECOND_TILE, k_mg_gather0, dim3((cells + 255) / 256), dim3(256), S->mg_part, S->mg_d, S->mg_xbuf + (size_t)S->bulk.rank * S->mg_xslot + 2, (double*)nullptr,
+    LAUNCH(S, KC_COARSE_CYCLE, k_mg_gather0, dim3((cells + 255) / 256), dim3(256), S->mg_part, S->mg_d, S->mg_xbuf + (size_t)S->bulk.rank * S->mg_xslot + 2, (double*)nullptr,
            S->mg_nx[0], row0, row1, S->geom.T / 16, S->band_lo, S->band_hi, S->sc, force);
   return EULER_OK;
 }
@@ -731,7 +779,7 @@ __global__ __launch_bounds__(CC_THREADS) void k_coarse_solve(const double* __res
 
 int eu_launch_coarse_solve(euler_sim* S, int fin_op, int force) {
   if (eu_is_mg(S) && S->mg_levels > 0) return launch_mg_cycle(S, fin_op, force);
-  LAUNCH(S, KC_PRECOND_TILE, k_coarse_solve, dim3(S->coarse_n), dim3(CC_THREADS), S->cc_part, S->cc_inv, S->cc_y, S->cc_y + CC_MAX,
+  LAUNCH(S, KC_COARSE_CYCLE, k_coarse_solve, dim3(S->coarse_n), dim3(CC_THREADS), S->cc_part, S->cc_inv, S->cc_y, S->cc_y + CC_MAX,
          reinterpret_cast<unsigned int*>(S->cc_y + 2 * CC_MAX), S->sc, fin_op, force, S->coarse_n, S->coarse_nx, S->coarse_m, S->coarse_shift,
          S->geom.T / 16, S->band_lo, S->band_hi);
   return EULER_OK;

@@ -171,34 +171,54 @@ __global__ __launch_bounds__(RED_THREADS) void k_dot_partial(const double* __res
   block_finish<false>(t, partial, counter, sc, fin_op);
 }
 
-// dot(a,b) replayed in the reference's ROW-MAJOR order (main.c:629-639): products are gathered by
-// the whole workgroup, the running sum is formed by one thread.  Bit-identical; for small grids.
-#define SEQ_TILE 2048
+// dot(a,b) replayed in the reference's ROW-MAJOR order (main.c:629-639): bit-identical; for small grids (and every bit-exact test).
+// The running sum is ONE dependent chain of additions - nothing can split it - so the kernel is built around keeping that chain fed: wave 0's first lane
+// adds while waves 1..3 gather the NEXT tile's products (a[i] b[i] of fluid cells, +0.0 elsewhere) into the other half of a double buffer, one
+// barrier per tile.  Two things shorten the chain itself, both exact: a group of 64 consecutive cells without fluid is skipped (its ballot is 0), and inside a
+// group every entry is added, fluid or not - x + (+0.0) = x for every x except -0.0, and the sum is never -0.0 (it starts as +0.0, and +0.0 + -0.0 = +0.0) -
+// which makes the inner loop branch-free: 64 LDS reads in flight, 64 dependent v_add_f64.  Round 3's form (a branch and an LDS round trip per cell, the
+// gather not overlapped) took ~1.5 ms per dot at 384 x 448 and was most of the GPU suite's wall time.
+#define SEQ_TILE 4096
 __global__ __launch_bounds__(256) void k_dot_sequential(const double* __restrict__ a, const double* __restrict__ b,
                                                         const uint8_t* __restrict__ mask, SkewGeom g, PcgScalars* sc,
                                                         int op, int force) {
   if (!force && pcg_idle(sc)) return;
-  __shared__ double prod[SEQ_TILE];
-  __shared__ uint8_t fl[SEQ_TILE];
+  __shared__ double prod[2][SEQ_TILE];
+  __shared__ unsigned long long any[2][SEQ_TILE / 64];
   const size_t C = (size_t)g.X * g.Y;
+  const int ntiles = (int)((C + SEQ_TILE - 1) / SEQ_TILE);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double total = 0.0;   // `double total = 0.f`
-  for (size_t base = 0; base < C; base += SEQ_TILE) {
-    for (int k = threadIdx.x; k < SEQ_TILE; k += 256) {
-      const size_t c = base + k;
-      bool f = false;
-      double pr = 0.0;
-      if (c < C) {
-        const size_t i = skew_index(g, (int)(c % g.X), (int)(c / g.X));
-        f = (mask[i] & CM_FLUID) != 0;
-        if (f) pr = a[i] * b[i];
+  for (int tile = -1; tile < ntiles; ++tile) {
+    if (wave > 0 && tile + 1 < ntiles) {            // gather tile + 1
+      const int buf = (tile + 1) & 1;
+      const size_t base = (size_t)(tile + 1) * SEQ_TILE;
+      for (int grp = wave - 1; grp < SEQ_TILE / 64; grp += 3) {
+        const size_t c = base + (size_t)grp * 64 + lane;
+        bool f = false;
+        double pr = 0.0;
+        if (c < C) {
+          const size_t i = skew_index(g, (int)(c % g.X), (int)(c / g.X));
+          f = (mask[i] & CM_FLUID) != 0;
+          if (f) pr = a[i] * b[i];
+        }
+        prod[buf][grp * 64 + lane] = pr;
+        const unsigned long long bal = __ballot(f);
+        if (lane == 0) any[buf][grp] = bal;
       }
-      fl[k] = f;
-      prod[k] = pr;
     }
-    __syncthreads();
-    if (threadIdx.x == 0)
-      for (int k = 0; k < SEQ_TILE; ++k)
-        if (fl[k]) total += prod[k];
+    if (threadIdx.x == 0 && tile >= 0) {            // the chain over tile
+      const int buf = tile & 1;
+      for (int grp = 0; grp < SEQ_TILE / 64; ++grp) {
+        if (any[buf][grp] == 0ull) continue;
+        const double* pp = &prod[buf][grp * 64];
+        double v[64];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) v[k] = pp[k];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) total += v[k];
+      }
+    }
     __syncthreads();
   }
   if (threadIdx.x == 0) pcg_scalar_step(sc, op, total);

@@ -237,6 +237,21 @@ int eu_slab_error_sync(euler_sim* S) {
   hipLaunchKernelGGL(k_error_from_vec, dim3(1), dim3(1), 0, S->stream, S->ms, s->vec);
   return EULER_OK;
 }
+// collective: the ranks' local status codes of a host-side step (file I/O of a snapshot) -> `*worst` = the largest on every rank, so that a
+// failure on ONE rank (a missing part file, a full disk) is a failure everywhere instead of a hang in the next collective
+int eu_slab_status_sync(euler_sim* S, int local_rc, int* worst) {
+  *worst = local_rc;
+  if (!S->has_comm || !S->slab) return EULER_OK;
+  SlabScratch* s = S->slab;
+  const double mine = local_rc != 0 ? 1.0 : 0.0;
+  HIPCHK(hipMemcpyAsync(s->vec, &mine, sizeof mine, hipMemcpyHostToDevice, S->stream));
+  COMM_CALL(S->bulk.allreduce(S->bulk.ctx, s->vec, 1, 1));
+  double any = 0.0;
+  HIPCHK(hipMemcpyAsync(&any, s->vec, sizeof any, hipMemcpyDeviceToHost, S->stream));
+  HIPCHK(hipStreamSynchronize(S->stream));
+  if (any != 0.0 && local_rc == 0) *worst = EULER_EIO;
+  return EULER_OK;
+}
 int eu_slab_timestep(euler_sim* S, float frame_time_left) {   // k_maxsq over the own rows has been launched
   SlabScratch* s = S->slab;
   hipLaunchKernelGGL(k_maxsq_to_vec, dim3(1), dim3(1), 0, S->stream, S->ms, s->vec);

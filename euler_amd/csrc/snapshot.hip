@@ -48,16 +48,14 @@ static std::string part_name(const char* path, int rank, int nranks) {
 }
 
 // ------------------------------------------------------------------------------------------ save
-extern "C" int euler_save_state(euler_sim* S, const char* path) {
-  if (!S || !path) return EULER_EINVAL;
-  euler_stats st;
-  int rc = euler_get_stats(S, &st);
-  if (rc) return rc;
-  const bool slab = S->slab_on != 0;
-  const int nranks = slab ? S->cfg.slab_nranks : 1, rank = slab ? S->cfg.slab_rank : 0;
-  const std::string file = slab ? part_name(path, rank, nranks) : std::string(path);
-  FILE* f = fopen(file.c_str(), "wb");
-  if (!f) { eu_set_error("cannot open %s for writing", file.c_str()); return EULER_EIO; }
+// Files appear under their final names only when complete: every file is written under "<name>.tmp" and renamed.  Row slabs (collective): the ranks
+// agree (one all-reduce of the status) that every part file was written and closed before any of them is renamed, and again that every rename
+// succeeded before rank 0 puts the manifest in place - a manifest never names a part that is missing or belongs to an older state, and a rank
+// that fails makes the call fail on every rank.
+static int write_part_file(euler_sim* S, const euler_stats& st, const std::string& tmp, bool slab, int nranks, int rank) {
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f) { eu_set_error("cannot open %s for writing", tmp.c_str()); return EULER_EIO; }
+  int rc = EULER_OK;
   SnapHeader h;
   memset(&h, 0, sizeof h);
   memcpy(h.magic, "EULERSNP", 8);
@@ -76,7 +74,8 @@ extern "C" int euler_save_state(euler_sim* S, const char* path) {
     ok = ok && fwrite(&sh, sizeof sh, 1, f) == 1;
   }
   const size_t Cr = (size_t)(S->row_hi - S->row_lo) * S->X;      // cells of the own rows (the whole grid without slabs)
-  std::vector<unsigned char> buf(Cr * 8 > n_loc * 8 ? Cr * 8 : (size_t)n_loc * 8);
+  std::vector<unsigned char> buf;
+  try { buf.resize(Cr * 8 > n_loc * 8 ? Cr * 8 : (size_t)n_loc * 8); } catch (...) { fclose(f); return EULER_ENOMEM; }
   auto put = [&](int field, size_t bytes) {
     if (!ok || !bytes) return;
     rc = euler_get_field(S, field, buf.data(), bytes);
@@ -93,20 +92,48 @@ extern "C" int euler_save_state(euler_sim* S, const char* path) {
   ok = ok && fwrite(&sum, 8, 1, f) == 1;
   ok = (fclose(f) == 0) && ok;
   if (rc) return rc;
-  if (!ok) { eu_set_error("short write to %s", file.c_str()); return EULER_EIO; }
-  if (slab && rank == 0) {      // the manifest: which part holds which bands
-    FILE* m = fopen(path, "wb");
-    if (!m) { eu_set_error("cannot open %s for writing", path); return EULER_EIO; }
-    ManifestHeader mh;
-    memset(&mh, 0, sizeof mh);
-    memcpy(mh.magic, "EULERMAN", 8);
-    mh.version = 3; mh.X = S->X; mh.Y = S->Y; mh.nranks = nranks;
-    bool mok = fwrite(&mh, sizeof mh, 1, m) == 1;
-    for (int r = 0; r < nranks && mok; ++r) { const int32_t b[2] = {S->part_lo[r], S->part_hi[r]}; mok = fwrite(b, sizeof b, 1, m) == 1; }
-    mok = (fclose(m) == 0) && mok;
-    if (!mok) { eu_set_error("short write to %s", path); return EULER_EIO; }
-  }
+  if (!ok) { eu_set_error("short write to %s", tmp.c_str()); return EULER_EIO; }
   return EULER_OK;
+}
+
+extern "C" int euler_save_state(euler_sim* S, const char* path) {
+  if (!S || !path) return EULER_EINVAL;
+  euler_stats st;
+  int rc = euler_get_stats(S, &st);
+  const bool slab = S->slab_on != 0;
+  if (rc && !slab) return rc;
+  const int nranks = slab ? S->cfg.slab_nranks : 1, rank = slab ? S->cfg.slab_rank : 0;
+  const std::string file = slab ? part_name(path, rank, nranks) : std::string(path);
+  const std::string tmp = file + ".tmp";
+  if (!rc) rc = write_part_file(S, st, tmp, slab, nranks, rank);
+  auto agree = [&](int local, const char* what) -> int {      // row slabs: non-zero on every rank if any rank failed
+    if (!slab || !S->has_comm) return local;
+    int worst = local;
+    const int rc2 = eu_slab_status_sync(S, local, &worst);
+    if (rc2) return rc2;
+    if (worst && !local) eu_set_error("euler_save_state(%s): another rank failed to %s", path, what);
+    return worst;
+  };
+  if ((rc = agree(rc, "write its part file"))) { remove(tmp.c_str()); return rc; }
+  if (rename(tmp.c_str(), file.c_str()) != 0) { eu_set_error("cannot rename %s to %s", tmp.c_str(), file.c_str()); rc = EULER_EIO; }
+  if ((rc = agree(rc, "put its part file in place"))) return rc;
+  if (slab && rank == 0) {      // the manifest: which part holds which bands - last, and complete when it appears
+    const std::string mtmp = std::string(path) + ".tmp";
+    FILE* m = fopen(mtmp.c_str(), "wb");
+    bool mok = m != nullptr;
+    if (mok) {
+      ManifestHeader mh;
+      memset(&mh, 0, sizeof mh);
+      memcpy(mh.magic, "EULERMAN", 8);
+      mh.version = 3; mh.X = S->X; mh.Y = S->Y; mh.nranks = nranks;
+      mok = fwrite(&mh, sizeof mh, 1, m) == 1;
+      for (int r = 0; r < nranks && mok; ++r) { const int32_t b[2] = {S->part_lo[r], S->part_hi[r]}; mok = fwrite(b, sizeof b, 1, m) == 1; }
+      mok = (fclose(m) == 0) && mok;
+      mok = mok && rename(mtmp.c_str(), path) == 0;
+    }
+    if (!mok) { eu_set_error("cannot write the manifest %s", path); rc = EULER_EIO; }
+  }
+  return agree(rc, "write the manifest");
 }
 
 // ------------------------------------------------------------------------------------------ load
@@ -154,6 +181,7 @@ int read_part(Part& p) {
   p.row_lo = 0; p.row_hi = p.h.Y; p.n_loc = p.h.n_markers; p.keyed = false;
   if (p.h.version == 3) {
     SlabHeader sh;
+    if ((size_t)n < sizeof(SnapHeader) + sizeof sh + 8) { eu_set_error("%s is truncated (slab header)", p.file.c_str()); return EULER_EIO; }
     memcpy(&sh, p.data.data() + sizeof(SnapHeader), sizeof sh);
     p.body += sizeof sh;
     p.row_lo = sh.row_lo; p.row_hi = sh.row_hi; p.n_loc = sh.n_loc; p.keyed = true;
@@ -167,9 +195,8 @@ int read_part(Part& p) {
 }
 }  // namespace
 
-extern "C" int euler_load_state(euler_sim* S, const char* path) {
-  if (!S || !path) return EULER_EINVAL;
-  if (S->slab_on && !S->has_comm) { eu_set_error("row-slab handle: install the communicator before loading a snapshot"); return EULER_ESTATE; }
+// everything of a load that is this rank's own business (files, host buffers, uploads): NO collective in here, so a failure leaves no other rank waiting
+static int load_state_local(euler_sim* S, const char* path, SnapHeader* h_out) {
   // what is there: one whole-grid file, or a manifest naming the part files of a job
   std::vector<Part> parts;
   {
@@ -263,6 +290,7 @@ extern "C" int euler_load_state(euler_sim* S, const char* path) {
     if (h0.n_markers > S->max_markers) { eu_set_error("snapshot holds %llu markers, more than this handle's capacity", (unsigned long long)h0.n_markers); return EULER_EINVAL; }
     try { mk.resize(2 * (size_t)h0.n_markers + 2); } catch (...) { return EULER_ENOMEM; }
     std::vector<char> seen;
+    try { seen.assign((size_t)h0.n_markers, 0); } catch (...) { return EULER_ENOMEM; }
     uint64_t placed = 0;
     for (Part* p : use) {
       const float* m = reinterpret_cast<const float*>(p->section(16));
@@ -270,6 +298,8 @@ extern "C" int euler_load_state(euler_sim* S, const char* path) {
       for (uint64_t i = 0; i < p->n_loc; ++i) {
         const uint64_t key = p->keyed ? kk[i] : i;
         if (key >= h0.n_markers) { eu_set_error("%s: marker key %llu out of range", path, (unsigned long long)key); return EULER_EINVAL; }
+        if (seen[(size_t)key]) { eu_set_error("%s: marker key %llu appears twice", path, (unsigned long long)key); return EULER_EINVAL; }
+        seen[(size_t)key] = 1;
         mk[2 * key] = m[2 * i]; mk[2 * key + 1] = m[2 * i + 1];
         ++placed;
       }
@@ -299,9 +329,32 @@ extern "C" int euler_load_state(euler_sim* S, const char* path) {
     m0.n = h0.n_markers; m0.n_loc = n_loc; m0.max_markers = 4 * S->C; m0.rng_state = h0.rng_state; m0.exhausted = h0.source_exhausted;
     HIPCHK(hipMemcpy(S->ms, &m0, sizeof m0, hipMemcpyHostToDevice));
     S->n_markers_host = n_loc;
+  }
+  *h_out = h0;
+  return EULER_OK;
+}
+
+// Collective on a row-slab handle: every rank loads its rows and markers on its own, then the ranks AGREE on the outcome (one all-reduce of the
+// status) before the first collective of the restore - a missing or corrupt part file, a row no file holds, more markers than a slab's capacity or
+// an allocation failure on ONE rank fails the call on EVERY rank (the handle is then unloaded everywhere) instead of leaving the others waiting.
+extern "C" int euler_load_state(euler_sim* S, const char* path) {
+  if (!S || !path) return EULER_EINVAL;
+  if (S->slab_on && !S->has_comm) { eu_set_error("row-slab handle: install the communicator before loading a snapshot"); return EULER_ESTATE; }
+  SnapHeader h0;
+  memset(&h0, 0, sizeof h0);
+  int rc = load_state_local(S, path, &h0);
+  if (S->slab_on) {
+    int worst = rc;
+    const int rc2 = eu_slab_status_sync(S, rc, &worst);
+    if (rc2) return rc2;
+    if (worst) {
+      if (!rc) eu_set_error("euler_load_state(%s): another rank could not load its part of the state", path);
+      S->loaded = 0;
+      return rc ? rc : worst;
+    }
     if ((rc = eu_slab_after_restore(S))) return rc;      // collective: the source cells of all ranks
     if ((rc = eu_sync_marker_state(S))) return rc;
-  }
+  } else if (rc) return rc;
   S->lean_ok = 0;      // the solver arrays may hold another state's pressure and masks: the next assembly writes them whole
   memset(&S->stats, 0, sizeof S->stats);
   S->stats.frames = h0.frames; S->stats.total_substeps = h0.total_substeps; S->stats.total_pcg_iterations = h0.total_pcg_iterations;

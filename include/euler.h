@@ -79,7 +79,10 @@ enum {
                                 the grid.  Restated in the oracle (eo_sim.coarse_mg): GPU = oracle to rounding.  EULER_DOT_TREE.  One GPU, or row slabs without
                                 mailboxes (euler_config.slab_*): an aggregate of 16 rows belongs to one rank, so every rank contributes its rows of the
                                 level-0 operator (per solve) and of the level-0 right-hand side (per iteration, inside the G1 exchange's all-gather)
-                                and all ranks run the same V-cycle - the same bits everywhere; the iteration counts are the single GPU's. */
+                                and all ranks run the same V-cycle - the same bits everywhere; the operator is the single GPU's, so the iteration counts are
+                                too up to the rounding of the per-rank dot products.  Water cut off from the air (a singular system): the right-hand
+                                side is made compatible with the region's indicator on one GPU and on row slabs alike (the sums are all-reduced).
+                                Per iteration the ranks all-gather cells / 256 doubles (8 MB at 16384^2, one ncclAllGather) besides the edge rows. */
 };
 
 /* IC(0) sweep implementation (same arithmetic, different schedule). */

@@ -795,16 +795,22 @@ int eo_project(eo_sim* s, float dt, const float* u, const float* v, float* uout,
      * (a few 1e-9 per cell, far below the tolerance, and no A s can touch it anyway) is taken out before the solve starts. */
     if (!s->coarse_chol) coarse_factor(s);
     const int g = 64 * s->coarse_m;
-    for (int q = 0; q < s->coarse_npinned; ++q) {
+    /* (all the sums from the r the solve starts with, then all the corrections - the indicators of distinct regions do not overlap - as the product's two launches do;
+     * the product keeps at most four indicators) */
+    double eps[4] = {0, 0, 0, 0}, nn[4] = {0, 0, 0, 0};
+    const int np = s->coarse_npinned < 4 ? s->coarse_npinned : 4;
+    for (int q = 0; q < np; ++q) {
       const double* nv = s->coarse_null + (size_t)q * s->coarse_n;
-      double eps = 0.0, nn = 0.0;
       for (int y = 0; y < Y; ++y)
         for (int x = 0; x < X; ++x)
-          if (FLUID(s, y, x)) { const double w = nv[(y / g) * s->coarse_nx + x / g]; eps += r[AT(s, y, x)] * w; nn += w * w; }
-      if (nn > 0.0)
+          if (FLUID(s, y, x)) { const double w = nv[(y / g) * s->coarse_nx + x / g]; eps[q] += r[AT(s, y, x)] * w; nn[q] += w * w; }
+    }
+    for (int q = 0; q < np; ++q) {
+      const double* nv = s->coarse_null + (size_t)q * s->coarse_n;
+      if (nn[q] > 0.0)
         for (int y = 0; y < Y; ++y)
           for (int x = 0; x < X; ++x)
-            if (FLUID(s, y, x)) r[AT(s, y, x)] -= nv[(y / g) * s->coarse_nx + x / g] * (eps / nn);
+            if (FLUID(s, y, x)) r[AT(s, y, x)] -= nv[(y / g) * s->coarse_nx + x / g] * (eps[q] / nn[q]);
     }
   }
   s->last_residual = 0;

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/trajectories.json: the pinned oracle stepped through every trajectory of tests/trajectories.py, per frame the SHA-1 of
+each array the GPU tests compare (+ counters).  Run in the build container (a minute of CPU):  python tests/golden/make_trajectories.py [name ...]
+The oracle itself is pinned to the compiled reference by tests/test_oracle_vs_ref.py and the golden fixtures; tests/test_trajectories.py re-checks
+the cheap trajectories of this file against a live oracle on every CPU run."""
+import hashlib
+import json
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import trajectories as T  # noqa: E402
+
+
+def record(name):
+    spec = T.SPECS[name]
+    o = T.make_oracle(spec)
+    rec = {"frames": []}
+    if spec.get("init"):
+        rec["init"] = T.snapshot(o, spec)
+    for _ in range(spec["frames"]):
+        o.step()
+        rec["frames"].append(T.snapshot(o, spec))
+    if spec.get("render"):
+        rec["render"] = hashlib.sha1(o.render(spec["X"], spec["Y"])).hexdigest()[:20]
+    o.close()
+    return rec
+
+
+def main():
+    names = sys.argv[1:] or sorted(T.SPECS)
+    try:
+        with open(T.PATH) as f:
+            out = json.load(f)
+    except OSError:
+        out = {}
+    for n in names:
+        t0 = time.perf_counter()
+        out[n] = record(n)
+        print("%-34s %3d frames  %.1f s" % (n, len(out[n]["frames"]), time.perf_counter() - t0))
+    with open(T.PATH, "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+        f.write("\n")
+
+
+if __name__ == "__main__":
+    main()

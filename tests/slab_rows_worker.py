@@ -21,6 +21,10 @@ from euler_amd.slab import SLAB_LOCAL, RcclComm, TorchComm, attach_p2p
 def load(sim, workload):
     if workload == "half_tank":
         sim.load_half_tank()
+    elif workload == "closed_box":            # a closed box full of water: no contact with the air, A singular along the region's indicator (coarse modes: k_null_sums / k_null_apply)
+        W, H = 40, 30
+        rows = ["X" * W] + ["X" + "0" * (W - 2) + "X" for _ in range(H - 2)] + ["X" * W]
+        sim.load_text("\n".join(rows) + "\n", upscale=True)
     elif workload.startswith("golden:"):      # one of the reference's five scenario texts, as stored with the golden fixtures
         from golden_util import load as gload, scenario_text
         sim.load_text(scenario_text(gload(workload[7:] + "_frames.npz")), upscale=True)
@@ -71,6 +75,21 @@ def main():
             snap_save = a[5:]
         if a.startswith("load="):
             snap_load = a[5:]
+    if snap_load and "loadfail" in sys.argv[6:]:
+        # a part file is missing / corrupt for ONE rank: euler_load_state (collective) must come back with an error on EVERY rank - nobody waits
+        # in the restore's all-reduce for a rank that has already left
+        failed, msg = False, ""
+        try:
+            sim.load_state(snap_load)
+        except ea.EulerError as e:
+            failed, msg = True, str(e)
+        agg = [None] * world
+        dist.all_gather_object(agg, [failed, msg])
+        if rank == 0:
+            print(json.dumps({"world": world, "loadfail": {"failed": [a[0] for a in agg], "msg": [a[1] for a in agg]}}))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if snap_load:                             # resume a job that another set of ranks (another partition) saved; the single-GPU run resumes its own file
         sim.load_state(snap_load)
         ref.load_state(snap_load + ".ref")

@@ -150,21 +150,23 @@ def test_filter_substep_exercises_dt_chain():
 
 
 # ----------------------------------------------------------------------------- vs the oracle, ragged / larger grids
-def make_pair(X2, Y2, scn="block", **kw):
+def make_pair(X2, Y2, scn="block", oracle=True, **kw):
     text = scenario_text(load(scn + "_frames.npz"))
-    o = Oracle(X2, Y2).load_text(text, upscale=True)
+    o = Oracle(X2, Y2).load_text(text, upscale=True) if oracle else None
     sim = ea.Simulation(X2, Y2, **kw).load_text(text, upscale=True)
     return o, sim
 
 
 def compare_all(o, sim, what):
-    assert_bits(sim.get(ea.F_COUNT), o.count, what + " count")
-    assert_bits(sim.get(ea.F_PREV_COUNT), o.prev_count, what + " prev_count")
-    assert_bits(sim.get(ea.F_MARKERS), o.markers, what + " markers")
-    assert_bits(sim.get(ea.F_U), o.u, what + " u")
-    assert_bits(sim.get(ea.F_V), o.v, what + " v")
-    assert_bits(sim.get(ea.F_PRECON), o.precon, what + " precon")
-    assert_bits(sim.get(ea.F_PRESSURE), o.p, what + " p")
+    """every observable bit for bit; `o` is a live Oracle or the Recorded stand-in of a trajectory (tests/trajectories.py: digests, live replay on a mismatch)"""
+    from trajectories import same
+    same(sim.get(ea.F_COUNT), o, "count", what + " count")
+    same(sim.get(ea.F_PREV_COUNT), o, "prev_count", what + " prev_count")
+    same(sim.get(ea.F_MARKERS), o, "markers", what + " markers")
+    same(sim.get(ea.F_U), o, "u", what + " u")
+    same(sim.get(ea.F_V), o, "v", what + " v")
+    same(sim.get(ea.F_PRECON), o, "precon", what + " precon")
+    same(sim.get(ea.F_PRESSURE), o, "p", what + " p")
 
 
 @pytest.mark.parametrize("size,scn,frames", [((130, 70), "block", 12), ((257, 129), "filter", 8),
@@ -172,7 +174,9 @@ def compare_all(o, sim, what):
                                              ((112, 48), "filter", 40), ((144, 200), "block", 30)])
 def test_ragged_grids_bit_exact_vs_oracle(size, scn, frames):
     """Sizes that are not multiples of the 64-row band / 64-lane tiles, several bands deep."""
-    o, sim = make_pair(size[0], size[1], scn, dot_mode=ea.DOT_SEQUENTIAL)
+    from trajectories import oracle_for
+    _, sim = make_pair(size[0], size[1], scn, dot_mode=ea.DOT_SEQUENTIAL, oracle=False)
+    o = oracle_for("ragged_%dx%d_%s" % (size[0], size[1], scn))
     compare_all(o, sim, "init")
     for f in range(frames):
         o.step()
@@ -502,9 +506,10 @@ def test_velocity_diffusion_extension_bit_exact_vs_oracle(size, scn, nu, frames)
     """The reference is inviscid; the diffusion stage is this build's extension (config.viscosity), defined
     by oracle eo_diffuse.  viscosity = 0 leaves the stage out (every other test); > 0 must match the
     oracle's restatement bit for bit and must actually change the flow."""
-    o, sim = make_pair(size[0], size[1], scn, dot_mode=ea.DOT_SEQUENTIAL, viscosity=nu)
-    o.c.viscosity = nu
-    _, inviscid = make_pair(size[0], size[1], scn, dot_mode=ea.DOT_SEQUENTIAL)
+    from trajectories import oracle_for
+    _, sim = make_pair(size[0], size[1], scn, oracle=False, dot_mode=ea.DOT_SEQUENTIAL, viscosity=nu)
+    o = oracle_for("diffusion_%dx%d_%s" % (size[0], size[1], scn))      # (the oracle with eo_sim.viscosity = nu; recorded: tests/trajectories.py)
+    _, inviscid = make_pair(size[0], size[1], scn, oracle=False, dot_mode=ea.DOT_SEQUENTIAL)
     for f in range(frames):
         o.step(); sim.step(); inviscid.step()
         compare_all(o, sim, "nu=%g frame %d" % (nu, f))
@@ -517,7 +522,8 @@ def test_baseline_size_1024_half_tank_bit_exact_vs_oracle():
     dam break falls freely for ~22 frames, the half tank's free surface makes every solve run its
     100 iterations): 16 bands, 1 M cells, sequential dot mode - every field bit for bit after each of
     two frames."""
-    o = Oracle(1024, 1024).load_half_tank()
+    from trajectories import oracle_for
+    o = oracle_for("half_tank_1024")
     sim = ea.Simulation(1024, 1024, dot_mode=ea.DOT_SEQUENTIAL).load_half_tank()
     compare_all(o, sim, "init")
     for f in range(2):

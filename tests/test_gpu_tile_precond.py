@@ -186,8 +186,8 @@ def test_tile_mode_moving_water_lean_assembly_bit_exact():
     the solver's own arrays must carry no stale entry: masks and p are +0 wherever the cell grid says air."""
     text = scenario_text(load("block_frames.npz"))
     X, Y = 384, 448
-    o = Oracle(X, Y).load_text(text, upscale=True)
-    o.c.tile_records = 16
+    from trajectories import oracle_for
+    o = oracle_for("lean_384x448")      # (the oracle with tile_records = 16 on this scenario; recorded: tests/trajectories.py)
     sim = ea.Simulation(X, Y, dot_mode=ea.DOT_SEQUENTIAL, precond=ea.PRECOND_IC0_TILE, tile_records=16).load_text(text, upscale=True)
     for f in range(30):
         o.step()
@@ -503,3 +503,24 @@ def test_closed_box_right_hand_side_is_made_compatible():
         assert st.last_residual <= 1e-6 and o.c.last_residual <= 1e-6
         assert st.last_pcg_iterations <= 160 and o.c.last_pcg_iterations <= 160, (f, st.last_pcg_iterations, o.c.last_pcg_iterations)
         assert abs(st.last_pcg_iterations - o.c.last_pcg_iterations) <= 12, (f, st.last_pcg_iterations, o.c.last_pcg_iterations)
+
+
+def test_set_precond_validates_before_it_changes_anything_and_restores_the_dot_mode():
+    """a refused euler_set_precond leaves the handle as it was (the tile width used to change before the mode was checked), and a handle created with
+    EULER_DOT_SEQUENTIAL - the reference's order of the dot products, the bit-identical parity mode - gets that mode back when it leaves a coarse mode (which
+    folds trees): after IC0 -> multilevel -> IC0 the run continues bit for bit with the oracle."""
+    sim = ea.Simulation(130, 70, dot_mode=ea.DOT_SEQUENTIAL, precond=ea.PRECOND_IC0_TILE, tile_records=8).load_half_tank()
+    o = Oracle(130, 70).load_half_tank()
+    o.c.tile_records = 8
+    with pytest.raises(ea.EulerError):
+        sim.set_precond(ea.PRECOND_IC0_TILE2, 32)          # the coarse modes run on tiles of 16: refused ...
+    with pytest.raises(ea.EulerError):
+        sim.set_precond(ea.PRECOND_IC0_TILE, 12)
+    sim.step(); o.step()                                   # ... and the tiles are still 8 records wide
+    compare_all(o, sim, "tile 8 after a refused call")
+    sim.set_precond(ea.PRECOND_IC0_TILE_MG, 16)
+    sim.set_precond(ea.PRECOND_IC0, 0)                     # back in the parity mode: sequential dots again
+    o.c.tile_records = 0
+    for f in range(2):
+        sim.step(); o.step()
+        compare_all(o, sim, "parity mode after a detour through the multilevel mode, frame %d" % f)

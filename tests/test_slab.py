@@ -177,9 +177,15 @@ def test_bench_multi_rank_contract(scaling):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == scaling and d["value"] > 0 and d["higher_is_better"] is True
     assert d["vs_baseline"] is None
     assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0          # rank 0 times the CPU path beside it at every N
+    assert len(lines[0]) < 8192                                                          # the driver keeps a bounded tail of stdout (round 3: 25.7 KB came back unparsed)
+    with open(os.path.join(ROOT, d["full"])) as f:                                       # everything else: the full object beside the line
+        full = json.load(f)
+    assert full["value"] == pytest.approx(d["value"], rel=1e-5) and full["n_gpus"] == 2
     if scaling == "weak":          # the default N > 1 run also measures the strong-scaling unit (BASELINE configs[3]'s scenario; here at 512^2)
-        st = d["strong_512_dam_break"]
+        st = d["summary"]["strong_512_dam_break"]
         assert st["scaling"] == "strong" and st["n_gpus"] == 2 and st["value"] > 0 and st["pcg_iterations"] > 0, st
+        assert st["balance_max_over_mean"] >= 1.0
+        st = full["strong_512_dam_break"]
         assert st["balance"]["partition"].startswith("fluid-balanced") and len(st["balance"]["rows_per_rank"]) == 2, st["balance"]
         assert st["converged_frames_multilevel"] is None      # (--p2p here: the multilevel mode's converged frames need the default transport, test_slab_rows.py)
     assert d["config"]["grid"] == ([256, 512] if scaling == "weak" else [256, 256])

@@ -178,6 +178,7 @@ def test_snapshot_of_three_slabs_resumes_on_two_and_on_one_gpu(tmp_path):
         assert f["rng"] == [True, True], (i, f)
         assert f["dp"] <= 1e-8 * f["pmax"] + 2e-6 and f["du"] < 1e-6 and f["dv"] < 1e-6, (i, f)
     assert checked >= 8
+    assert not [f for f in os.listdir(str(tmp_path)) if f.endswith(".tmp")]      # (files appear under their final names only: written as .tmp, renamed)
     # ... and on one GPU: the parts merge into the whole grid, the markers go to their keys - the state IS the single-GPU run's
     one = ea.Simulation(256, 512, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE).load_state(snap)
     ref = ea.Simulation(256, 512, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE).load_state(snap + ".ref")
@@ -188,6 +189,24 @@ def test_snapshot_of_three_slabs_resumes_on_two_and_on_one_gpu(tmp_path):
         a, b = one.get(fld), ref.get(fld)
         assert a.shape == b.shape and (np.array_equal(a.view(np.uint32), b.view(np.uint32)) if exact else np.abs(a - b).max() < 1e-6), fld
     assert one.stats().rng_state == ref.stats().rng_state and one.stats().n_markers == ref.stats().n_markers
+
+
+@pytest.mark.gpu
+def test_a_part_file_one_rank_cannot_read_fails_the_load_on_every_rank(tmp_path):
+    """euler_load_state on row slabs is collective, and every rank-local failure used to return BEFORE its only collective - the healthy
+    ranks then waited in the restore's all-reduce forever.  A 3-rank job saves; the top part file is then truncated (only the upper rank of a 2-rank
+    job reads it; the checksum catches it) or removed: the 2-rank load returns an error on BOTH ranks, the failing one with its own message."""
+    snap = str(tmp_path / "job.snap")
+    run(3, 256, 512, "dam_break", 2, ea.PRECOND_IC0_TILE, 29601, ("save=" + snap,))
+    top = snap + ".2of3"
+    with open(top, "r+b") as f:
+        f.truncate(os.path.getsize(top) - 100)
+    d = run(2, 256, 512, "dam_break", 0, ea.PRECOND_IC0_TILE, 29602, ("load=" + snap, "loadfail"))
+    assert d["loadfail"]["failed"] == [True, True], d
+    assert "another rank" in d["loadfail"]["msg"][0] and "truncated or corrupt" in d["loadfail"]["msg"][1], d
+    os.remove(top)
+    d = run(2, 256, 512, "dam_break", 0, ea.PRECOND_IC0_TILE, 29603, ("load=" + snap, "loadfail"))
+    assert d["loadfail"]["failed"] == [True, True] and "cannot open" in d["loadfail"]["msg"][1], d
 
 
 @pytest.mark.gpu
@@ -246,6 +265,7 @@ def test_a_partition_with_a_gap_is_refused():
     (2, 256, 512, "dam_break", 30, ()),
     (3, 300, 440, "half_tank", 6, ("bands=0-2,2-3,3-7",)),      # an uneven partition, X and Y no multiples of 16; a tank at rest (long solves from the first frame on)
     (4, 256, 512, "waterfall", 20, ()),
+    (2, 320, 256, "closed_box", 6, ()),       # water cut off from the air: the right-hand side is made compatible on the slabs as on one GPU (all-reduced sums)
 ])
 def test_multilevel_mode_on_row_slabs(nproc, X, Y, workload, frames, extra):
     """EULER_PRECOND_IC0_TILE_MG on row slabs: every rank assembles its rows of the level-0 operator (an aggregate of 16 rows belongs to

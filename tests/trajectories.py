@@ -1,0 +1,166 @@
+"""Recorded oracle trajectories (test infrastructure): the CPU-heavy oracle legs of the `-m gpu` parity tests, run ONCE in the build container.
+
+The bit-exact GPU tests used to step the pinned CPU oracle beside the GPU inside the test (1024^2 frames, 30 frames of a 384x448 dam break ...): most of the
+GPU suite's wall time was the single-threaded oracle (VERDICT r3 "what's weak" 9: 662 s on the driver's box, 1098 s on a slower one, against a 1200 s limit).
+Bit-exactness needs no arrays, only their digests: tests/golden/make_trajectories.py steps the oracle (pinned to the compiled reference by
+tests/test_oracle_vs_ref.py, and re-checked against these very records on the CPU by tests/test_trajectories.py) through every trajectory below and
+stores, per frame, the SHA-1 of each compared array and the counters, in tests/golden/trajectories.json.  A test then gets a `Recorded` stand-in for
+its Oracle: `same()` compares the digest of the GPU's array with the record; ON A MISMATCH it replays the live oracle up to that frame and hands both
+arrays to assert_bits - the same assertion, with the same diagnostics (first differing entry), as before.  A trajectory missing from the file (or
+EULER_LIVE_ORACLE=1) runs live, unchanged."""
+import hashlib
+import json
+import os
+import types
+
+import numpy as np
+
+from golden_util import GOLDEN, load, scenario_text
+from oracle_lib import Oracle
+
+PATH = os.path.join(GOLDEN, "trajectories.json")
+STATE = ("count", "prev_count", "markers", "u", "v", "precon", "p")
+DYE = ("cr", "cg", "cb", "crtmp", "u")
+
+# name -> how the oracle of that test is set up, how many frames it runs, which arrays the test compares
+SPECS = {
+    "lean_384x448": dict(X=384, Y=448, golden="block", tile_records=16, frames=30, fields=STATE),
+    "half_tank_1024": dict(X=1024, Y=1024, half_tank=True, frames=2, fields=STATE, init=True),
+    "diffusion_130x70_block": dict(X=130, Y=70, golden="block", viscosity=0.05, frames=34, fields=STATE),
+    "diffusion_192x200_waterfall": dict(X=192, Y=200, golden="waterfall", viscosity=0.2, frames=10, fields=STATE),
+    "dye_200x150_waterfall": dict(X=200, Y=150, scenario="waterfall", rainbow=True, frames=40, fields=DYE, nan_class=True, render=True),
+    "dye_256x160_dam_break": dict(X=256, Y=160, scenario="dam_break", rainbow=True, frames=30, fields=DYE, nan_class=True, render=True),
+}
+for _size, _scn, _frames in (((130, 70), "block", 12), ((257, 129), "filter", 8), ((192, 200), "waterfall", 10), ((320, 192), "weird-edges", 6),
+                             ((112, 48), "filter", 40), ((144, 200), "block", 30)):
+    SPECS["ragged_%dx%d_%s" % (_size[0], _size[1], _scn)] = dict(X=_size[0], Y=_size[1], golden=_scn, frames=_frames, fields=STATE, init=True)
+
+
+def spec_text(spec):
+    if "golden" in spec:
+        return scenario_text(load(spec["golden"] + "_frames.npz"))
+    if "scenario" in spec:
+        from euler_amd import scenarios
+        return getattr(scenarios, spec["scenario"])()
+    return None
+
+
+def make_oracle(spec):
+    """the live oracle of a trajectory, in its initial state"""
+    o = Oracle(spec["X"], spec["Y"], rainbow=bool(spec.get("rainbow")))
+    if spec.get("half_tank"):
+        o.load_half_tank()
+    else:
+        o.load_text(spec_text(spec), upscale=True)
+    o.c.tile_records = int(spec.get("tile_records", 0))
+    if spec.get("viscosity"):
+        o.c.viscosity = spec["viscosity"]
+    return o
+
+
+def digest(a, nan_class=False):
+    a = np.ascontiguousarray(a)
+    if nan_class and a.dtype.kind == "f":      # NaN payload / sign bits are implementation-defined (assert_bits nan_class): one canonical NaN
+        nan = np.isnan(a)
+        if nan.any():
+            a = a.copy()
+            a[nan] = np.nan
+    h = hashlib.sha1()
+    h.update(("%s%s" % (a.dtype.str, a.shape)).encode())
+    h.update(a.tobytes())
+    return h.hexdigest()[:20]
+
+
+def snapshot(o, spec):
+    """what is recorded of one frame"""
+    nc = bool(spec.get("nan_class"))
+    rec = {n: digest(getattr(o, n), nc) for n in spec["fields"]}
+    rec["last_substeps"] = int(o.c.last_substeps)
+    rec["last_pcg_iterations"] = int(o.c.last_pcg_iterations)
+    rec["n_markers"] = int(o.n_markers)
+    rec["vmax"] = float(np.abs(o.v).max())
+    return rec
+
+
+_cache = {}
+
+
+def records():
+    if "r" not in _cache:
+        try:
+            with open(PATH) as f:
+                _cache["r"] = json.load(f)
+        except OSError:
+            _cache["r"] = {}
+    return _cache["r"]
+
+
+class Recorded:
+    """Stands in for the Oracle of a recorded trajectory: step() moves to the next recorded frame, `c` carries that frame's counters, same()
+    compares digests; live() replays the real oracle up to the current frame (the slow path: diagnostics after a mismatch)."""
+
+    def __init__(self, name):
+        self.name, self.spec = name, SPECS[name]
+        self.rec = records()[name]
+        self.frame = -1                      # -1: the initial state (recorded when spec["init"])
+        self._live, self._live_frame = None, -1
+        self.X, self.Y = self.spec["X"], self.spec["Y"]
+
+    def step(self):
+        self.frame += 1
+        if self.frame >= len(self.rec["frames"]):
+            raise IndexError("trajectory %s holds %d frames" % (self.name, len(self.rec["frames"])))
+
+    @property
+    def cur(self):
+        return self.rec["init"] if self.frame < 0 else self.rec["frames"][self.frame]
+
+    @property
+    def c(self):
+        return types.SimpleNamespace(last_substeps=self.cur["last_substeps"], last_pcg_iterations=self.cur["last_pcg_iterations"])
+
+    @property
+    def n_markers(self):
+        return self.cur["n_markers"]
+
+    @property
+    def vmax(self):
+        return self.cur["vmax"]
+
+    def live(self):
+        if self._live is None:
+            self._live = make_oracle(self.spec)
+        while self._live_frame < self.frame:
+            self._live.step()
+            self._live_frame += 1
+        assert self._live_frame == self.frame, "live replay cannot go back"
+        return self._live
+
+    def render_digest(self):
+        return self.rec["render"]
+
+    def close(self):
+        if self._live is not None:
+            self._live.close()
+
+
+def oracle_for(name):
+    """the test's oracle: the recorded stand-in when the trajectory is on file, the live oracle otherwise (or with EULER_LIVE_ORACLE=1)"""
+    if os.environ.get("EULER_LIVE_ORACLE") or name not in records():
+        return make_oracle(SPECS[name])
+    return Recorded(name)
+
+
+def same(got, o, attr, what, nan_class=False):
+    """assert_bits(got, o.<attr>) - through the recorded digest when `o` is a Recorded trajectory"""
+    from test_gpu_parity import assert_bits
+    if isinstance(o, Recorded):
+        if digest(got, nan_class) == o.cur[attr]:
+            return
+        assert_bits(got, getattr(o.live(), attr), what + " [recorded digest differs; live replay]", nan_class=nan_class)
+        raise AssertionError("%s: the GPU's array matches the live oracle but not the recorded digest - regenerate tests/golden/trajectories.json" % what)
+    assert_bits(got, getattr(o, attr), what, nan_class=nan_class)
+
+
+def vmax(o):
+    return o.vmax if isinstance(o, Recorded) else float(np.abs(o.v).max())
