@@ -65,7 +65,7 @@ ITER_BYTES = {
 }
 PCG_BYTES = {m: sum(c.values()) for m, c in ITER_BYTES.items()}
 ONCE_PER_SOLVE_BYTES = {"update_pr": 3 * W + 1}      # k_finish_p in the tile modes: the last one or two p += alpha s (read s, p; write p)
-PCG_CLASSES = ["forward_solve", "backward_solve", "apply_a", "dot", "update_pr", "update_search", "precond_tile", "coarse_cycle", "jacobi"]
+PCG_CLASSES = ["forward_solve", "backward_solve", "apply_a", "dot", "update_pr", "update_search", "precond_tile", "coarse_cycle", "jacobi", "resident_pcg"]
 KERNEL_OF_CLASS = {"forward_solve": "k_sweep_skew<1", "backward_solve": "k_sweep_skew<2", "precon_factor": "k_sweep_skew<0",
                    "apply_a": "k_search_apply", "dot": "k_dot_partial", "update_pr": "k_update_pr", "precond_tile": "k_precond_tile"}
 MODE_NAME = {"ic0": "parity mode: the reference's IC(0), bit-identical iterates",
@@ -490,6 +490,8 @@ def time_frames(sim, ea, grp, args, precond, steps, warmup_done, warmup, big):
         sim.step()
     dominant = {"ic0": "backward_solve", "ic0_tile": "apply_a", "ic0_tile2": "apply_a", "ic0_tile_mg": "apply_a", "jacobi": "update_pr"}[precond]
     classes_all = ea.profile_class_names() if args.profile_all else PCG_CLASSES
+    if not big and precond == "ic0_tile" and sim.resident_info()[0]:
+        dominant = "resident_pcg"
     timed = [] if args.no_kernel_timing else (classes_all if big else [dominant])
     sim.profile_reset()
     sim.profile_enable(timed)
@@ -512,8 +514,14 @@ def time_frames(sim, ea, grp, args, precond, steps, warmup_done, warmup, big):
     # one iteration = the mode's per-iteration classes (ITER_BYTES); once-per-solve launches (s = z, k_finish_p, the factor) are not in it
     per_iter_ms = sum(prof[k][0] / prof[k][1] for k in ITER_BYTES[precond]
                       if k in prof and prof[k][1] >= 0.5 * max(iters if (big or k == dominant) else iters2, 1))
+    resident = None
+    if "resident_pcg" in prof and prof["resident_pcg"][1]:      # the solves ran as ONE persistent launch each (csrc/k_resident.hip): its time / the iterations it ran
+        resident = dict(ms_total=prof["resident_pcg"][0], solves=int(prof["resident_pcg"][1]), iters=iters if (big or dominant == "resident_pcg") else iters2,
+                        f32=bool(sim.cfg.pcg_precision))
+        if "apply_a" not in prof:
+            per_iter_ms = prof["resident_pcg"][0] / max(resident["iters"], 1)
     return dict(elapsed=elapsed, st0=st0, st1=st1, prof=prof, iters=iters, per_iter_ms=per_iter_ms, dominant=dominant,
-                substeps=st1.total_substeps - st0.total_substeps)
+                substeps=st1.total_substeps - st0.total_substeps, resident=resident)
 
 
 def summarize(t, size_x, size_y, precond, tile_w, traffic, traffic_note, steps, fused_search=True, rank_cells=None, rank_fluid_share=1.0):
@@ -564,6 +572,21 @@ def summarize(t, size_x, size_y, precond, tile_w, traffic, traffic_note, steps, 
                "GBps_traffic": round(tsum / sec / 1e9, 1) if tsum else None,
                "frac_traffic": round(tsum / sec / 1e9 / HBM_PEAK_GBPS, 4) if tsum else None,
                "frac_dense": round(bpc * cells / sec / 1e9 / HBM_PEAK_GBPS, 4)}
+    if t.get("resident") and not per_iter:
+        # the resident solver: r, s, p, E^-1 stay in registers / LDS for the whole solve - no HBM traffic inside it.  For comparison the figure the multi-kernel
+        # form would need for the same time: its algorithmic bytes (78 B per cell and iteration in double, 40 in float) / this time
+        rs = t["resident"]
+        sec = rs["ms_total"] / max(rs["iters"], 1) * 1e-3
+        w = 4 if rs.get("f32") else W
+        bpc = 9.5 * w + 2
+        agg = {"us_per_iteration": round(1e6 * sec, 2), "resident": True, "solves": rs["solves"], "launches_per_iteration": 0,
+               "hbm_bytes_inside_the_solve": 0, "equivalent_bytes_per_cell_iteration": bpc,
+               "GBps_active": round(bpc * fluid / sec / 1e9, 1), "frac_active": round(bpc * fluid / sec / 1e9 / HBM_PEAK_GBPS, 4),
+               "note": "one persistent launch per solve, vectors in registers: bound by two grid-wide synchronisations per iteration, not by bytes; frac_active = what the "
+                       "multi-kernel form's algorithmic bytes would need at this speed"}
+        roof = {"bound": "hbm", "kernel": "resident_pcg", "achieved": agg["GBps_active"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": agg["frac_active"], "traffic": 0,
+                "algorithmic_bytes_per_cell": bpc, "avg_launch_us": round(1e3 * rs["ms_total"] / max(rs["solves"], 1), 2), "launches": rs["solves"],
+                "note": agg["note"]}
     return {"mode": MODE_NAME[precond] % tile_w if precond in TILE_MODES else MODE_NAME[precond],
             "value": cells_job * steps / t["elapsed"], "unit": "cells*steps/s", "ms_per_step": 1e3 * t["elapsed"] / steps,
             "substeps": int(t["substeps"]), "pcg_iterations": int(t["iters"]),
@@ -1030,7 +1053,7 @@ def compact_line(full, limit=LINE_LIMIT):
         summary["projection_16384"] = _block(sec["projection_16384"])
     c1 = sec.get("configs1_1024_dam_break")
     if isinstance(c1, dict):
-        b = _block(c1, ("roofline_mode_value", "roofline_mode_us_per_iteration", "persistent_value", "f32_value", "steps_500_seconds"))
+        b = _block(c1, ("roofline_mode_value", "roofline_mode_us_per_iteration", "f32_value", "f32_us_per_iteration", "multi_kernel_us_per_iteration"))
         if isinstance(c1.get("parity_in_run"), dict):
             b["parity_in_run"] = _pick(c1["parity_in_run"], ("frames", "max_abs_du", "max_abs_dv", "fluid_cells_differing"))
         summary["configs1_1024_dam_break"] = b
@@ -1303,13 +1326,32 @@ def main():
             c1.update({"workload": "1024x1024 dam break (block layout upscaled), preroll %d frames into the expensive phase" % pre4, "steps": 4,
                        "parity_in_run": parity,
                        "cpu_same_state": {k: v for k, v in (cpu1 or {}).items() if not k.startswith("_")} or None})
-            s4.set_precond(ea.PRECOND_IC0_TILE, args.tile_records)
-            t4b = time_frames(s4, ea, grp, args, "ic0_tile", 4, 0, 1, False)
-            c1["roofline_mode_value"] = 1024 * 1024 * 4 / t4b["elapsed"]
-            c1["roofline_mode_us_per_iteration"] = round(1e3 * t4b["per_iter_ms"], 2)
-            secondary["configs1_1024_dam_break"] = c1
+            # the roofline mode at this size: the resident solver (one persistent launch per solve, vectors in registers), its float variant (configs[1] "fp32": a labelled
+            # secondary, narrower than the reference's double PCG) and the multi-kernel form, all from the state the parity-mode frames left
+            state = {f: s4.get(f) for f in (ea.F_SOLID, ea.F_SOURCE, ea.F_SINK, ea.F_COUNT, ea.F_PREV_COUNT, ea.F_U, ea.F_V, ea.F_UTMP, ea.F_VTMP, ea.F_PRECON)}
+            state_m, state_st = s4.get(ea.F_MARKERS), s4.stats()
             s4.close()
             del s4
+            variants = {}
+            for name, kw in (("resident_f64", {}), ("resident_f32", dict(pcg_precision=ea.PCG_F32)), ("multi_kernel_f64", dict(resident=ea.RESIDENT_OFF))):
+                sv = ea.Simulation(1024, 1024, device=local_rank, dot_mode=dot_mode, precond=ea.PRECOND_IC0_TILE, tile_records=args.tile_records, **kw)
+                for f, a in state.items():
+                    sv.set(f, a)
+                sv.set_markers(state_m)
+                sv.set_rng(state_st.rng_state, state_st.source_exhausted)
+                tv = time_frames(sv, ea, grp, args, "ic0_tile", 8, 0, 1, False)
+                bv = summarize(tv, 1024, 1024, "ic0_tile", tile_w, None, None, 8)
+                variants[name] = {"value": bv["value"], "ms_per_step": bv["ms_per_step"], "substeps": bv["substeps"], "pcg_iterations": bv["pcg_iterations"],
+                                  "us_per_iteration": (bv["pcg_iteration"] or {}).get("us_per_iteration"), "resident_info": list(sv.resident_info())}
+                sv.close()
+                del sv
+            c1["roofline_mode"] = variants
+            c1["roofline_mode_value"] = variants["resident_f64"]["value"]
+            c1["roofline_mode_us_per_iteration"] = variants["resident_f64"]["us_per_iteration"]
+            c1["f32_value"] = variants["resident_f32"]["value"]
+            c1["f32_us_per_iteration"] = variants["resident_f32"]["us_per_iteration"]
+            c1["multi_kernel_us_per_iteration"] = variants["multi_kernel_f64"]["us_per_iteration"]
+            secondary["configs1_1024_dam_break"] = c1
         except Exception as e:
             secondary["configs1_1024_dam_break"] = {"error": repr(e)}
         lap("configs1")

@@ -17,6 +17,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libeuler_hip.so")
 DOT_AUTO, DOT_SEQUENTIAL, DOT_TREE = 0, 1, 2
 PRECOND_IC0, PRECOND_JACOBI, PRECOND_IC0_TILE, PRECOND_IC0_TILE2, PRECOND_IC0_TILE_MG = 0, 1, 2, 3, 4
 SWEEP_AUTO, SWEEP_BAND, SWEEP_SIMPLE = 0, 1, 2
+PCG_F64, PCG_F32 = 0, 1
+RESIDENT_AUTO, RESIDENT_OFF = 0, 1
 (F_U, F_V, F_UTMP, F_VTMP, F_SOLID, F_SOURCE, F_SINK, F_COUNT, F_PREV_COUNT, F_MARKERS, F_PRECON,
  F_PRESSURE, F_PCG_B, F_PCG_R, F_PCG_Z, F_PCG_S, F_PCG_Q, F_CELLMASK,
  F_DYE_R, F_DYE_G, F_DYE_B, F_DYE_RTMP, F_DYE_GTMP, F_DYE_BTMP, F_MARKER_KEYS) = range(25)
@@ -48,7 +50,7 @@ class Config(C.Structure):
         ("sweep_mode", C.c_int32), ("max_substeps", C.c_int32), ("frame_time", C.c_float),
         ("viscosity", C.c_float), ("pcg_poll_interval", C.c_int32), ("rainbow", C.c_int32),
         ("precond_tile_records", C.c_int32), ("slab_rank", C.c_int32), ("slab_nranks", C.c_int32),
-        ("slab_band_lo", C.c_int32), ("slab_band_hi", C.c_int32), ("reserved", C.c_int32 * 2),
+        ("slab_band_lo", C.c_int32), ("slab_band_hi", C.c_int32), ("pcg_precision", C.c_int32), ("resident", C.c_int32),
     ]
 
 
@@ -73,7 +75,7 @@ EXPORTS = [
     "euler_profile_class_count", "euler_profile_class_name", "euler_profile_get", "euler_profile_reset",
     "euler_measure_copy_bandwidth", "euler_device_name", "euler_hbm_bytes", "euler_sweep_timeline", "euler_save_state", "euler_load_state", "euler_set_comm", "euler_set_stream", "euler_slab_info",
     "euler_rccl_unique_id", "euler_rccl_version", "euler_set_comm_rccl", "euler_comm_calls",
-    "euler_p2p_export", "euler_p2p_connect", "euler_p2p_disconnect", "euler_p2p_calls",
+    "euler_p2p_export", "euler_p2p_connect", "euler_p2p_disconnect", "euler_p2p_calls", "euler_resident_info",
 ]
 
 
@@ -123,6 +125,7 @@ def load_library():
         "euler_profile_class_name": (C.c_char_p, [i32]),
         "euler_profile_get": (C.c_int, [vp, i32, C.POINTER(f64), C.POINTER(u64)]),
         "euler_profile_reset": (C.c_int, [vp]),
+        "euler_resident_info": (C.c_int, [vp, C.POINTER(u64)]),
         "euler_measure_copy_bandwidth": (C.c_int, [vp, C.c_size_t, i32, C.POINTER(f64)]),
         "euler_device_name": (C.c_int, [vp, C.c_char_p, i32]),
         "euler_hbm_bytes": (u64, [vp]),
@@ -261,7 +264,8 @@ class Simulation:
     plus state access for parity tests."""
 
     def __init__(self, X=100, Y=40, device=0, dot_mode=DOT_AUTO, precond=PRECOND_IC0, sweep_mode=SWEEP_AUTO,
-                 max_iterations=100, tol=None, pcg_poll_interval=8, viscosity=0.0, rainbow=False, tile_records=0, slab=None):
+                 max_iterations=100, tol=None, pcg_poll_interval=8, viscosity=0.0, rainbow=False, tile_records=0, slab=None,
+                 pcg_precision=0, resident=0):
         self.L = load_library()
         cfg = Config()
         _check(self.L.euler_config_default(C.byref(cfg)))
@@ -279,6 +283,8 @@ class Simulation:
             if len(slab) == 4:               # an explicit (fluid-balanced) partition instead of the even split
                 cfg.slab_band_lo, cfg.slab_band_hi = slab[2], slab[3]
         self.slab = slab if slab is not None and slab[1] >= 1 else None
+        cfg.pcg_precision = pcg_precision    # PCG_F32: solver vectors in float (BASELINE configs[1]'s "fp32"; resident solver only)
+        cfg.resident = resident              # RESIDENT_OFF: never the one-launch resident solver (k_resident.hip)
         self.cfg = cfg
         self.X, self.Y = X, Y
         self.h = C.c_void_p()
@@ -381,6 +387,12 @@ class Simulation:
 
     def set_rng(self, state, exhausted=0):
         _check(self.L.euler_set_rng(self.h, int(state), int(exhausted)))
+
+    def resident_info(self):
+        """(eligible, solves run by the resident solver, solves that fell back to the multi-kernel path)"""
+        out = (C.c_uint64 * 3)()
+        _check(self.L.euler_resident_info(self.h, out))
+        return bool(out[0]), int(out[1]), int(out[2])
 
     def stats(self):
         s = Stats()

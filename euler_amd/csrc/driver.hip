@@ -39,7 +39,7 @@ extern "C" int euler_abi_version(void) { return EULER_ABI_VERSION; }
 static const char* k_class_names[KC__COUNT] = {
     "timestep", "marker_advect", "marker_events", "marker_bin", "marker_compact", "sources", "select",
     "extrapolate", "advect_velocity", "build_system", "precon_factor", "forward_solve", "backward_solve",
-    "apply_a", "dot", "update_pr", "update_search", "reduce_final", "velocity_update", "jacobi", "misc", "precond_tile", "coarse_cycle"};
+    "apply_a", "dot", "update_pr", "update_search", "reduce_final", "velocity_update", "jacobi", "misc", "precond_tile", "coarse_cycle", "resident_pcg"};
 
 void eu_prof_begin(euler_sim* S, int cls) {
   if (!((S->prof_mask >> cls) & 1)) return;
@@ -134,6 +134,25 @@ static int eu_set_tiles(euler_sim* S, int w) {
   return EULER_OK;
 }
 
+// the resident solver (k_resident.hip) can run this handle's solves: plain tile-local preconditioner, one GPU, tree dots, and EVERY chunk of the grid
+// finds a wave on the chip at once (so that no scene ever outgrows it)
+bool eu_resident_eligible(const euler_sim* S) {
+  static const bool env_off = getenv("EULER_RESIDENT") && atoi(getenv("EULER_RESIDENT")) == 0;      // (experiments / A-B timing)
+  if (env_off || S->res_disabled || S->cfg.resident == EULER_RESIDENT_OFF) return false;
+  if (S->cfg.precond != EULER_PRECOND_IC0_TILE || S->tile_w != 16 || S->cfg.sweep_mode == EULER_SWEEP_SIMPLE || S->cfg.dot_mode != EULER_DOT_TREE) return false;
+  if (S->has_comm || S->slab_on || S->p2p_on) return false;
+  // double: a solve whose active chunks do not all fit takes the multi-kernel path (decided per solve, eu_launch_project); float has no other path, so
+  // the whole grid must fit
+  const int cap = eu_resident_capacity(const_cast<euler_sim*>(S), S->cfg.pcg_precision == EULER_PCG_F32);
+  if (S->cfg.pcg_precision == EULER_PCG_F32) return cap > 0 && S->geom.nbands * (S->geom.T / 16) <= 4 * cap;
+  return cap > 0 && S->geom.nbands * (S->geom.T / 16) <= 16 * cap;      // (grids far beyond the capacity do not even ask: the two host round trips per solve buy nothing there)
+}
+extern "C" int euler_resident_info(euler_sim* S, uint64_t out[3]) {
+  if (!S || !out) return EULER_EINVAL;
+  out[0] = eu_resident_eligible(S) ? 1 : 0; out[1] = S->res_solves; out[2] = S->res_fallbacks;
+  return EULER_OK;
+}
+
 // which preconditioner / communicator combinations a solve can run (k_pcg.hip eu_launch_project): checked where the combination is made, not in the middle of a solve
 static const char* eu_precond_combination(const euler_sim* S, int precond, int tile_w, int has_comm, int slab_on, int p2p_on) {
   const bool coarse = precond == EULER_PRECOND_IC0_TILE2 || precond == EULER_PRECOND_IC0_TILE_MG;
@@ -150,6 +169,7 @@ extern "C" int euler_set_precond(euler_sim* S, int32_t precond, int32_t tile_rec
   const int w = tile_records <= 0 ? 16 : tile_records;
   if (w != 8 && w != 16 && w != 32) { eu_set_error("precond_tile_records = %d: 8, 16 or 32 (0 = 16)", tile_records); return EULER_EINVAL; }
   if (const char* why = eu_precond_combination(S, precond, w, S->has_comm, S->slab_on, S->p2p_on)) { eu_set_error("euler_set_precond: %s", why); return EULER_EINVAL; }
+  if (S->cfg.pcg_precision == EULER_PCG_F32 && (precond != EULER_PRECOND_IC0_TILE || w != 16)) { eu_set_error("euler_set_precond: an EULER_PCG_F32 handle runs EULER_PRECOND_IC0_TILE with tiles of 16 records only"); return EULER_EINVAL; }
   HIPCHK(hipStreamSynchronize(S->stream));
   const bool coarse = precond == EULER_PRECOND_IC0_TILE2 || precond == EULER_PRECOND_IC0_TILE_MG;
   if (coarse) { int rc = eu_coarse_alloc(S); if (rc) return rc; }      // their arrays come with the first use
@@ -213,6 +233,8 @@ extern "C" void euler_destroy(euler_sim* S) {
   if (S->ms_host) (void)hipHostFree(S->ms_host);
   if (S->sc_host) (void)hipHostFree(S->sc_host);
   if (S->poll_host) (void)hipHostFree(S->poll_host);
+  if (S->res_err) (void)hipHostFree(S->res_err);
+  if (S->res_gran) (void)hipFree(S->res_gran);
   for (hipEvent_t e : S->poll_event) if (e) (void)hipEventDestroy(e);
   if (S->ev_pool) { for (int k = 0; k < S->ev_cap; ++k) if (S->ev_pool[k]) (void)hipEventDestroy(S->ev_pool[k]); free(S->ev_pool); }
   free(S->ev_cls); free(S->ev_solve); free(S->ev_iter);
@@ -398,6 +420,10 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   CREATECHK(hipHostMalloc((void**)&S->ms_host, sizeof(MarkerState), hipHostMallocDefault));
   CREATECHK(hipHostMalloc((void**)&S->sc_host, sizeof(PcgScalars), hipHostMallocDefault));
   CREATECHK(hipHostMalloc((void**)&S->poll_host, 2 * sizeof(PcgScalars), hipHostMallocDefault));
+  CREATECHK(hipHostMalloc((void**)&S->res_err, sizeof(int), hipHostMallocDefault));      // (the resident solver raises it from the device: k_resident.hip)
+  *S->res_err = 0;
+  DALLOC(S->res_gran, 2 * 3 * 512 * 2);
+  S->res_tag = 1;
   memset(S->poll_host, 0, 2 * sizeof(PcgScalars));
   for (hipEvent_t& e : S->poll_event) CREATECHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   memset(S->ms_host, 0, sizeof(MarkerState)); memset(S->sc_host, 0, sizeof(PcgScalars));
@@ -426,6 +452,12 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   }
   S->hbm_bytes = g_alloc_bytes + (S->slab_on ? eu_slab_bytes(S) : 0);
   eu_launch_tile_table(S);      // E^-1 of an interior tile (k_pcg.hip), once per handle
+  if (S->cfg.pcg_precision != EULER_PCG_F64 && S->cfg.pcg_precision != EULER_PCG_F32) { eu_set_error("euler_create: pcg_precision %d", S->cfg.pcg_precision); euler_destroy(S); return EULER_EINVAL; }
+  if (S->cfg.pcg_precision == EULER_PCG_F32 && !eu_resident_eligible(S)) {
+    eu_set_error("euler_create: EULER_PCG_F32 runs in the resident solver: one GPU, EULER_PRECOND_IC0_TILE with tiles of 16 records, EULER_DOT_TREE, "
+                 "EULER_RESIDENT_AUTO, and a grid of at most %d 16-record chunks (this one: %d)", 4 * eu_resident_capacity(S, 1), S->geom.nbands * (S->geom.T / 16));
+    euler_destroy(S); return EULER_EINVAL;
+  }
   CREATECHK(hipStreamSynchronize(S->stream));
 #undef CREATECHK
   *out = S;

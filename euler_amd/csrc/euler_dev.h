@@ -30,7 +30,7 @@ enum {
   KC_TIMESTEP = 0, KC_MARKER_ADVECT, KC_MARKER_EVENTS, KC_MARKER_BIN, KC_MARKER_COMPACT, KC_SOURCES,
   KC_SELECT, KC_EXTRAPOLATE, KC_ADVECT_VELOCITY, KC_BUILD_SYSTEM, KC_PRECON_FACTOR,
   KC_FORWARD_SOLVE, KC_BACKWARD_SOLVE, KC_APPLY_A, KC_DOT, KC_UPDATE_PR, KC_UPDATE_SEARCH,
-  KC_REDUCE_FINAL, KC_VELOCITY_UPDATE, KC_JACOBI, KC_MISC, KC_PRECOND_TILE, KC_COARSE_CYCLE, KC__COUNT
+  KC_REDUCE_FINAL, KC_VELOCITY_UPDATE, KC_JACOBI, KC_MISC, KC_PRECOND_TILE, KC_COARSE_CYCLE, KC_RESIDENT, KC__COUNT
 };
 
 // Device-resident PCG scalars: no host round trip inside the iteration (reference: locals of
@@ -183,6 +183,12 @@ struct euler_sim {
   double* mg_part;                   // [chunks][4][2]: per tile and group of 16 lanes, the sums of r over the fluid cells left / right of the aggregate boundary
   double* mg_dot;                    // per-block partials of x_0 . rhs_0 (+ the ticket counter behind them)
   double* mg_xbuf; int mg_xslot;     // row slabs: [ranks][mg_xslot] - every rank's {max |r|, dot(z,r), its rows of the level-0 right-hand side}, ONE all-gather inside the G1 exchange
+  // the resident solver (k_resident.hip): the tile-local PCG of a grid whose chunks all find a wave on the chip at once, in ONE persistent launch
+  unsigned long long* res_gran;   // [2][3][512] 16-byte {value, generation} granules of its grid-wide reductions
+  unsigned long long res_tag;     // generation of the next launch's first reduction (never reset: stale granules never match)
+  int* res_err;                   // pinned host word the kernel raises when a wait ran out; the host then solves with the multi-kernel path
+  int res_disabled;               // ... and stops using the kernel on this handle
+  unsigned long long res_solves, res_fallbacks;
   int tile_w;             // EULER_PRECOND_IC0_TILE: records per tile (include/euler.h precond_tile_records)
   const double* tile_as_override;   // where A s sits for the r update of the non-tile modes (z behind the first apply_a of a solve, else q)
   double* partial2;       // second set of reduction partials (k_precond_tile reduces max |r| and dot(z,r) at once)
@@ -316,6 +322,9 @@ int eu_launch_sources(euler_sim* S);
 int eu_launch_extrapolate(euler_sim* S);
 int eu_launch_advect_velocity(euler_sim* S, float dt);
 int eu_launch_project(euler_sim* S, float dt);
+int eu_resident_capacity(euler_sim* S, int f32);            // k_resident.hip: workgroups of the resident PCG kernel the device holds at once
+int eu_launch_resident(euler_sim* S, unsigned int n_chunks);
+bool eu_resident_eligible(const euler_sim* S);               // driver.hip: this handle's configuration and grid allow the resident solver
 int eu_launch_colorize(euler_sim* S);            // k_dye.hip: no-ops without cfg.rainbow
 int eu_launch_dye_extrapolate(euler_sim* S);
 int eu_launch_dye_sources(euler_sim* S);

@@ -2037,6 +2037,37 @@ int eu_launch_project(euler_sim* S, float dt) {
     if ((rc = comm_allreduce_scalar(S, 1))) return rc;
     hipLaunchKernelGGL(k_nonzero_from_comm, dim3(1), dim3(1), 0, S->stream, S->sc);
   }
+  // Small grids (every chunk finds a wave on the chip at once): the whole solve as ONE persistent launch (k_resident.hip).  Two host round trips per solve -
+  // the number of active chunks before the launch, its error word behind it - instead of one per eight iterations.
+  if (eu_resident_eligible(S)) {
+    HIPCHK(hipMemcpyAsync(S->sc_host, S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
+    HIPCHK(hipStreamSynchronize(S->stream));
+    const unsigned int nch = S->sc_host->n_chunks;
+    const bool fits = nch <= 4u * (unsigned int)eu_resident_capacity(S, S->cfg.pcg_precision == EULER_PCG_F32);
+    if (S->sc_host->nonzero && nch > 0 && fits) {
+      S->prof_iter = -2;
+      if ((rc = eu_launch_resident(S, nch))) return rc;
+      HIPCHK(hipMemcpyAsync(S->sc_host, S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
+      HIPCHK(hipStreamSynchronize(S->stream));
+      if (*S->res_err == 0) {
+        S->res_solves += 1;
+        eu_launch_velocity_update(S, dt);
+        return EULER_OK;      // (sc_host is current)
+      }
+      // a wait ran out (the workgroups were not all resident - another process on the device?): this system again with the multi-kernel path, which the handle keeps from here on
+      S->res_fallbacks += 1; S->res_disabled = 1; *S->res_err = 0;
+      if (S->cfg.pcg_precision == EULER_PCG_F32) { eu_set_error("the resident solver timed out and EULER_PCG_F32 has no other path"); return EULER_EHIP; }
+      S->solve_seq -= 1;
+      S->lean_ok = 0;      // (the assembly runs a second time: it writes the solver arrays whole)
+      return eu_launch_project(S, dt);
+    }
+    if (!S->sc_host->nonzero || nch == 0) {      // all_zero(r), main.c:742: p = 0
+      S->prof_iter = -2;
+      eu_launch_velocity_update(S, dt);
+      return EULER_OK;
+    }
+    // (more active chunks than find a wave at once: this solve takes the multi-kernel path below)
+  }
   // if (!all_zero(r)) { ... }: every kernel below is a no-op when sc->nonzero == 0
   const bool tile = tile_fused(S);
   const bool two_level = tile && eu_is_two_level(S);

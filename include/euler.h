@@ -121,8 +121,17 @@ typedef struct euler_config {
                                    nbands * rank / nranks - for partitions that balance the FLUID (a dam break settles into the
                                    lowest third of the tank: even row slabs leave most ranks with air).  The ranks' ranges must tile
                                    [0, nbands) in rank order; euler_set_comm* checks it against the neighbours.  0, 0 = even split. */
-  int32_t reserved[2];
+  int32_t pcg_precision;   /* EULER_PCG_F64 (0, default: the reference's double vectors, main.c:577-578,716) or EULER_PCG_F32: every solver vector in float, sums and
+                              scalars in double - BASELINE configs[1]'s "fp32".  NOT the reference's iterates (tolerance parity only, restated in the oracle:
+                              eo_sim.pcg_f32); runs in the resident solver, so it needs what that needs (below) and euler_create refuses it otherwise. */
+  int32_t resident;        /* EULER_RESIDENT_AUTO (0): a grid of at most 4 x (resident workgroups) 16-record chunks - up to ~1400^2 on an MI355X, BASELINE
+                              configs[1] included - runs the tile-local PCG (EULER_PRECOND_IC0_TILE, one GPU, EULER_DOT_TREE, tiles of 16 records) as ONE
+                              persistent launch whose vectors stay in registers (csrc/k_resident.hip): same arithmetic, sums folded per workgroup, so the
+                              iterates agree with the multi-kernel form to rounding.  EULER_RESIDENT_OFF (1): always the multi-kernel form. */
 } euler_config;
+
+enum { EULER_PCG_F64 = 0, EULER_PCG_F32 = 1 };
+enum { EULER_RESIDENT_AUTO = 0, EULER_RESIDENT_OFF = 1 };
 
 typedef struct euler_sim euler_sim; /* opaque */
 
@@ -202,6 +211,7 @@ int  euler_create(const euler_config* cfg, euler_sim** out);   /* allocates HBM;
 void euler_destroy(euler_sim* sim);
 const char* euler_last_error(void);
 int  euler_abi_version(void);
+int  euler_resident_info(euler_sim* sim, uint64_t out[3]); /* {this handle's solves may use the resident solver (euler_config.resident), solves it ran, solves that fell back to the multi-kernel path} */
 
 /* ---- scenario = sim_init (main.c:209-274) ----------------------------------------------- */
 /* upscale = 0: the reference's streaming parser at native resolution.

@@ -502,6 +502,90 @@ static void apply_preconditioner_tiled(eo_sim* s, const double* r, double* z) {
   free(start);
 }
 
+/* EXTENSION (euler_oracle.h pcg_f32): the same three recurrences in FLOAT arithmetic - every operation's result is rounded to float (a double operation on
+ * float operands rounded once more to float IS the float operation: +, -, *, /, sqrt are innocuous under double rounding at these widths). */
+static double F32(double x) { return (double)(float)x; }
+static void apply_preconditioner_tiled_f32(eo_sim* s, const double* r, double* z) {
+  int X = s->X, Y = s->Y;
+  size_t C = (size_t)X * (size_t)Y;
+  double* pre = s->precon; double* q = s->q;
+  uint8_t* start = (uint8_t*)malloc((size_t)X + 64 + 1);
+  for (int t = 0; t <= X + 63; ++t) start[t] = (uint8_t)eo_tile_start(s->tile_records, t);
+  for (int y = 0; y < Y; ++y)
+    for (int x = 0; x < X; ++x) {
+      if (!FLUID(s, y, x)) continue;
+      size_t i = AT(s, y, x);
+      const int l = y & 63, t = x + l, cut = start[t];
+      double a = s->a_diag[i];
+      double cl = -1 * (cut ? 0.0 : F32(pre[i - 1]));      /* (a stale entry of a double solve is read as float) */
+      double cb = -1 * ((cut || l == 0) ? 0.0 : F32(pre[i - X]));
+      double e = F32(F32(a - F32(cl * cl)) - F32(cb * cb));
+      if (e < F32(0.25 * a)) e = a != 0 ? a : 1;
+      pre[i] = F32(1 / F32(sqrt(e)));
+    }
+  memset(q, 0, C * sizeof(double));
+  for (int y = 0; y < Y; ++y)
+    for (int x = 0; x < X; ++x) {
+      if (!FLUID(s, y, x)) continue;
+      size_t i = AT(s, y, x);
+      const int l = y & 63, t = x + l, cut = start[t];
+      double t_ = F32(F32(r[i] - (cut ? -0.0 : F32(-1 * pre[i - 1] * q[i - 1])))
+                           - ((cut || l == 0) ? -0.0 : F32(-1 * pre[i - X] * q[i - X])));
+      q[i] = F32(t_ * pre[i]);
+    }
+  memset(z, 0, C * sizeof(double));
+  for (int y = Y; y--;)
+    for (int x = X; x--;) {
+      if (!FLUID(s, y, x)) continue;
+      size_t i = AT(s, y, x);
+      const int l = y & 63, t = x + l, cut = start[t + 1];
+      double t_ = F32(F32(q[i] - F32((FLUID(s, y, x + 1) ? -1 : 0) * pre[i] * (cut ? 0.0 : z[i + 1])))
+                              - F32((FLUID(s, y + 1, x) ? -1 : 0) * pre[i] * ((cut || l == 63) ? 0.0 : z[i + X])));
+      z[i] = F32(t_ * pre[i]);
+    }
+  free(start);
+}
+static void apply_a_f32(const eo_sim* s, const double* in, double* out) {
+  int X = s->X, Y = s->Y;
+  for (int y = 0; y < Y; ++y)
+    for (int x = 0; x < X; ++x) {
+      if (!FLUID(s, y, x)) continue;
+      size_t i = AT(s, y, x);
+      double v = F32(s->a_diag[i] * in[i]);
+      v = F32(v - (FLUID(s, y, x + 1) ? in[i + 1] : 0));
+      v = F32(v - (FLUID(s, y + 1, x) ? in[i + X] : 0));
+      v = F32(v - (FLUID(s, y, x - 1) ? in[i - 1] : 0));
+      v = F32(v - (FLUID(s, y - 1, x) ? in[i - X] : 0));
+      out[i] = v;
+    }
+}
+/* the PCG loop of project() (main.c:742-766) on float vectors; returns the iteration count */
+static int pcg_f32(eo_sim* s) {
+  size_t C = (size_t)s->X * (size_t)s->Y;
+  double *p = s->p, *r = s->r, *z = s->z, *sv = s->s;
+  for (size_t i = 0; i < C; ++i) r[i] = F32(r[i]);
+  int iters = 0;
+  apply_preconditioner_tiled_f32(s, r, z);
+  memcpy(sv, z, C * sizeof(double));
+  double sigma = eo_dot(s, z, r);
+  for (int it = 0; it < s->max_iterations; ++it) {
+    apply_a_f32(s, sv, z);
+    iters++;
+    const double alpha = sigma / eo_dot(s, z, sv);
+    const double at = F32(alpha), nat = F32(-alpha);
+    for (size_t i = 0; i < C; ++i) if (s->count[i]) { p[i] = F32(p[i] + F32(sv[i] * at)); r[i] = F32(r[i] + F32(z[i] * nat)); }
+    s->last_residual = eo_inf_norm(s, r);
+    if (s->last_residual <= s->tol) break;
+    if (it + 1 == s->max_iterations) break;      /* (the budget's last preconditioner application is never consumed) */
+    apply_preconditioner_tiled_f32(s, r, z);
+    const double sigma_new = eo_dot(s, z, r);
+    const double bt = F32(sigma_new / sigma);
+    for (size_t i = 0; i < C; ++i) if (s->count[i]) sv[i] = F32(z[i] + F32(bt * sv[i]));
+    sigma = sigma_new;
+  }
+  return iters;
+}
+
 /* EXTENSION (two-level, euler_oracle.h coarse_m): z += P (P^T A P)^-1 P^T r. */
 int eo_coarse_m(int X, int Y) {
   int m = 1;
@@ -814,7 +898,8 @@ int eo_project(eo_sim* s, float dt, const float* u, const float* v, float* uout,
     }
   }
   s->last_residual = 0;
-  if (nonzero) {
+  if (nonzero && s->pcg_f32 && s->tile_records > 0 && s->coarse_m == 0) iters = pcg_f32(s);
+  else if (nonzero) {
     eo_apply_preconditioner(s, r, z);
     memcpy(sv, z, C * sizeof(double));
     double sigma = eo_dot(s, z, r);

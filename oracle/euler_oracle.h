@@ -80,6 +80,11 @@ typedef struct eo_sim {
    * (the pivot falls back to the diagonal, like main.c:595) and the solve projects the indicators out on both sides - the pseudo-inverse */
   int coarse_npinned, coarse_pinned[16];
   double* coarse_null;          /* [coarse_npinned][coarse_n] */
+  /* EXTENSION (round 4; BASELINE configs[1] "fp32"): the tile-local PCG with every solver vector in FLOAT - r, z, s, p, A s and E^-1 are rounded to float after
+   * every operation, the dot products and the scalars alpha, beta, sigma stay double (products of two floats are exact in double).  Not the reference's iterates
+   * (its PCG is double, main.c:577-578,716): tolerance parity only.  Needs tile_records > 0 and no coarse correction.  The arrays keep their double storage and
+   * hold float values. */
+  int pcg_f32;
 } eo_sim;
 
 eo_sim* eo_create(int X, int Y);

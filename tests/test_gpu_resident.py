@@ -1,0 +1,147 @@
+"""The resident solver (csrc/k_resident.hip): the tile-local PCG of a small grid as ONE persistent launch whose vectors stay in registers, and its
+float variant (euler_config.pcg_precision = EULER_PCG_F32: BASELINE configs[1]'s "fp32").
+
+* f64: the multi-kernel tile mode's arithmetic expression for expression; only the dot products fold in another order (per workgroup instead of per
+  block), so the two agree like any two tree shapes: the same iteration counts to a few, the same pressure to solver tolerance where the solves
+  converge, identical cell grids - and both agree with the oracle's restatement of the tile-local mode within the bar of the tree mode
+  (test_gpu_tile_precond.py::test_tree_dot_1024_dam_break_expensive_phase_vs_oracle).
+* f32: NOT the reference's iterates (its PCG is double, main.c:577-578,716) - tolerance parity: against the oracle's f64 solve of the same systems and against
+  the oracle's own float restatement (eo_sim.pcg_f32)."""
+import numpy as np
+import pytest
+
+import euler_amd as ea
+from euler_amd import scenarios
+from oracle_lib import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def pair(X, Y, text=None, **kw):
+    a = ea.Simulation(X, Y, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE, **kw)
+    b = ea.Simulation(X, Y, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE, resident=ea.RESIDENT_OFF, **{k: v for k, v in kw.items() if k != "pcg_precision"})
+    for s in (a, b):
+        if text is None:
+            s.load_half_tank()
+        else:
+            s.load_text(text, upscale=True)
+    return a, b
+
+
+@pytest.mark.parametrize("X,Y,workload,frames", [(512, 512, "dam_break", 40), (300, 200, "waterfall", 30), (1024, 1024, "half_tank", 2), (130, 70, "half_tank", 3)])
+def test_resident_f64_against_the_multi_kernel_tile_mode(X, Y, workload, frames):
+    text = None if workload == "half_tank" else getattr(scenarios, workload)()
+    a, b = pair(X, Y, text, max_iterations=2000)      # cap lifted: converged solves compare to tolerance
+    assert a.resident_info()[0] and not b.resident_info()[0]
+    solved = 0
+    for f in range(frames):
+        a.step(); b.step()
+        sa, sb = a.stats(), b.stats()
+        assert sa.last_substeps == sb.last_substeps, f
+        assert abs(sa.last_pcg_iterations - sb.last_pcg_iterations) <= 0.02 * sb.last_pcg_iterations + 2 * sb.last_substeps, (f, sa.last_pcg_iterations, sb.last_pcg_iterations)
+        assert sa.last_residual <= 1e-6 and sb.last_residual <= 1e-6
+        pa, pb = a.get(ea.F_PRESSURE), b.get(ea.F_PRESSURE)
+        assert np.abs(pa - pb).max() <= 1e-6 * max(np.abs(pb).max(), 1.0) + 1e-6, (f, np.abs(pa - pb).max(), np.abs(pb).max())
+        assert np.array_equal(a.get(ea.F_COUNT), b.get(ea.F_COUNT)), f
+        assert np.abs(a.get(ea.F_U) - b.get(ea.F_U)).max() < 1e-4 and np.abs(a.get(ea.F_V) - b.get(ea.F_V)).max() < 1e-4
+        solved += sa.last_pcg_iterations > 0
+    assert solved >= 2
+    info = a.resident_info()
+    assert info[1] >= solved and info[2] == 0      # every solve with a right-hand side ran resident, none fell back
+
+
+def test_resident_capped_solves_take_the_reference_budget():
+    """the reference's cap (main.c:735): exactly 100 iterations per substep with tol 0, counters and the last residual in step with the multi-kernel form"""
+    a, b = pair(512, 512, None, tol=0.0)
+    for f in range(3):
+        a.step(); b.step()
+        sa, sb = a.stats(), b.stats()
+        assert sa.last_substeps == sb.last_substeps and sa.last_pcg_iterations == sb.last_pcg_iterations == 100 * sa.last_substeps
+    # a tank at rest, 100 unconverged iterations: the dot products' rounding is amplified; the fields agree loosely, the cell grid exactly
+    assert np.array_equal(a.get(ea.F_COUNT) > 0, b.get(ea.F_COUNT) > 0)
+
+
+def test_resident_against_the_oracle_tile_mode():
+    """one frame of a 384 x 320 dam break in the expensive phase, teacher-forced from the GPU's state: resident solver (tree sums) against the oracle's tile-local mode (sequential sums)"""
+    sim = ea.Simulation(384, 320, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE, max_iterations=3000).load_text(scenarios.dam_break(), upscale=True)
+    for _ in range(60):
+        sim.step()
+        if sim.stats().last_pcg_iterations > 200:
+            break
+    o = Oracle(384, 320)
+    o.c.tile_records = 16
+    o.c.max_iterations = 3000
+    for f, n in ((ea.F_U, "u"), (ea.F_V, "v"), (ea.F_UTMP, "utmp"), (ea.F_VTMP, "vtmp"), (ea.F_SOLID, "solid"), (ea.F_SOURCE, "source"), (ea.F_SINK, "sink"),
+                 (ea.F_COUNT, "count"), (ea.F_PREV_COUNT, "prev_count"), (ea.F_PRECON, "precon")):
+        getattr(o, n)[...] = sim.get(f)
+    o.set_markers(sim.get(ea.F_MARKERS))
+    o.c.rng_state = sim.stats().rng_state
+    sim.step(); o.step()
+    st = sim.stats()
+    assert st.last_substeps == o.c.last_substeps and abs(st.last_pcg_iterations - o.c.last_pcg_iterations) <= 0.02 * o.c.last_pcg_iterations + 8
+    assert np.array_equal(sim.get(ea.F_COUNT), o.count)
+    assert np.abs(sim.get(ea.F_U) - o.u).max() <= 1e-5 and np.abs(sim.get(ea.F_V) - o.v).max() <= 1e-5
+    assert np.abs(sim.get(ea.F_PRESSURE) - o.p).max() <= 1e-6 * np.abs(o.p).max() + 1e-6
+    assert np.array_equal(sim.get(ea.F_PRECON), o.precon)      # E^-1 is element-wise: bit for bit (g_precon persists, main.c:577)
+
+
+def test_f32_pcg_variant_tolerance_parity():
+    """BASELINE configs[1] "fp32": solver vectors in float.  One frame of the 1024^2 dam break in its solving phase under the reference's cap of 100: against the f64
+    resident run from the same state - the cell grid is identical, velocities agree to 1e-3 of their magnitude; the stated tolerance of the variant."""
+    N = 1024
+    f64 = ea.Simulation(N, N, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE).load_text(scenarios.dam_break(), upscale=True)
+    for _ in range(60):
+        f64.step()
+        if f64.stats().last_pcg_iterations >= 100:
+            break
+    f32 = ea.Simulation(N, N, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE, pcg_precision=ea.PCG_F32)
+    for f in (ea.F_SOLID, ea.F_SOURCE, ea.F_SINK, ea.F_COUNT, ea.F_PREV_COUNT, ea.F_U, ea.F_V, ea.F_UTMP, ea.F_VTMP, ea.F_PRECON):
+        f32.set(f, f64.get(f))
+    f32.set_markers(f64.get(ea.F_MARKERS))
+    f32.set_rng(f64.stats().rng_state, f64.stats().source_exhausted)
+    for k in range(10):
+        f64.step(); f32.step()
+        assert f32.stats().last_substeps == f64.stats().last_substeps
+        vmax = max(np.abs(f64.get(ea.F_U)).max(), np.abs(f64.get(ea.F_V)).max())
+        du = max(np.abs(f32.get(ea.F_U) - f64.get(ea.F_U)).max(), np.abs(f32.get(ea.F_V) - f64.get(ea.F_V)).max())
+        assert du <= 1e-3 * vmax + 1e-3, (k, du, vmax)
+        assert np.array_equal(f32.get(ea.F_COUNT) > 0, f64.get(ea.F_COUNT) > 0), k
+    assert f32.resident_info()[1] > 0 and f32.resident_info()[2] == 0
+
+
+def test_f32_gpu_against_the_oracle_float_restatement():
+    """the float variant on the GPU against the oracle's restatement of it (eo_sim.pcg_f32: every operation rounded to float, sums in double), one frame of a 384 x 320
+    dam break in its solving phase under the reference's cap, teacher-forced from the GPU's state.  The two differ in the order of the dot products only; a float
+    solve amplifies that more than a double one: pressures to 1e-3 of max |p|, velocities to 1e-3 of their magnitude, the same cell grid, E^-1 bit for bit."""
+    sim = ea.Simulation(384, 320, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE, pcg_precision=ea.PCG_F32).load_text(scenarios.dam_break(), upscale=True)
+    for _ in range(60):
+        sim.step()
+        if sim.stats().last_pcg_iterations >= 100:
+            break
+    o = Oracle(384, 320)
+    o.c.tile_records = 16
+    o.c.pcg_f32 = 1
+    for f, n in ((ea.F_U, "u"), (ea.F_V, "v"), (ea.F_UTMP, "utmp"), (ea.F_VTMP, "vtmp"), (ea.F_SOLID, "solid"), (ea.F_SOURCE, "source"), (ea.F_SINK, "sink"),
+                 (ea.F_COUNT, "count"), (ea.F_PREV_COUNT, "prev_count"), (ea.F_PRECON, "precon")):
+        getattr(o, n)[...] = sim.get(f)
+    o.set_markers(sim.get(ea.F_MARKERS))
+    o.c.rng_state = sim.stats().rng_state
+    sim.step(); o.step()
+    st = sim.stats()
+    assert st.last_substeps == o.c.last_substeps and st.last_pcg_iterations == o.c.last_pcg_iterations
+    assert np.array_equal(sim.get(ea.F_COUNT), o.count)
+    vmax = max(np.abs(o.u).max(), np.abs(o.v).max())
+    assert max(np.abs(sim.get(ea.F_U) - o.u).max(), np.abs(sim.get(ea.F_V) - o.v).max()) <= 1e-3 * vmax + 1e-4
+    assert np.abs(sim.get(ea.F_PRESSURE) - o.p).max() <= 1e-3 * np.abs(o.p).max() + 1e-5
+    assert np.array_equal(sim.get(ea.F_PRECON), o.precon)
+    assert np.array_equal(sim.get(ea.F_PRESSURE), sim.get(ea.F_PRESSURE).astype(np.float32).astype(np.float64))      # p holds float values
+
+
+def test_f32_needs_the_resident_solver():
+    with pytest.raises(ea.EulerError):
+        ea.Simulation(4096, 4096, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE, pcg_precision=ea.PCG_F32)      # too many chunks
+    with pytest.raises(ea.EulerError):
+        ea.Simulation(512, 512, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0, pcg_precision=ea.PCG_F32)             # the reference's IC(0) is a double path
+    s = ea.Simulation(512, 512, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE, pcg_precision=ea.PCG_F32)
+    with pytest.raises(ea.EulerError):
+        s.set_precond(ea.PRECOND_IC0_TILE_MG, 16)
