@@ -345,7 +345,7 @@ __device__ __forceinline__ double mg_apply(const MgLevel& L, const double* __res
 // Row slabs: rows [row0, row1) only, into this rank's slot of the exchange buffer (x10 null: k_mg_scatter0 forms the Jacobi step once every rank's rows are there)
 __global__ __launch_bounds__(256) void k_mg_gather0(const double* __restrict__ part, const int* __restrict__ d0, double* __restrict__ dst, double* __restrict__ x10,
                                                     int nx0, int row0, int row1, int ntb, int band_lo, int band_hi, const PcgScalars* sc, int force) {
-  if (!force && (sc->done || !sc->nonzero)) return;
+  (void)force; (void)sc;      // (no early exit on `done`: see launch_mg_cycle)
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= nx0 * (row1 - row0)) return;
   const int I = row0 + k / nx0, J = k % nx0, band = I >> 2, j = I & 3;
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void k_mg_gather0(const double* __restrict__ p
 struct MgParts { int n; int lo[64], hi[64]; };      // aggregate rows [lo, hi) per rank
 __global__ __launch_bounds__(256) void k_mg_scatter0(const double* __restrict__ xbuf, int slot, MgParts P, const int* __restrict__ d0, double* __restrict__ rhs0, double* __restrict__ x10,
                                                      int nx0, int n0, const PcgScalars* sc, int force) {
-  if (!force && (sc->done || !sc->nonzero)) return;
+  (void)force; (void)sc;      // (no early exit on `done`: see launch_mg_cycle)
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= n0) return;
   const int I = c / nx0, J = c % nx0;
@@ -382,15 +382,17 @@ __global__ __launch_bounds__(256) void k_mg_scatter0(const double* __restrict__ 
 // parent's Jacobi step as well.
 __global__ __launch_bounds__(256) void k_mg_down(MgLevel L, double* __restrict__ crhs, double* __restrict__ cx1, const int* __restrict__ cd, int cnx, int cny,
                                                  const PcgScalars* sc, int force) {
-  if (!force && (sc->done || !sc->nonzero)) return;
+  (void)force; (void)sc;      // (no early exit on `done`: see launch_mg_cycle)
   const int tid = blockIdx.x * 256 + threadIdx.x;
   const int p = tid >> 2, q = tid & 3;
   double res = 0.0;
   if (p < cnx * cny) {
     const int ci = 2 * (p / cnx) + (q >> 1), cj = 2 * (p % cnx) + (q & 1);
-    if (ci < L.ny && cj < L.nx) {
+    if (ci < L.ny && cj < L.nx) {      // (every load below is issued before the first result is needed: no load waits for another's value)
       const size_t c = (size_t)ci * L.nx + cj;
-      if (L.d[c]) res = L.rhs[c] - mg_apply<false>(L, nullptr, 0, ci, cj, L.x1[c]);
+      const int dc = L.d[c];
+      const double t = L.rhs[c] - mg_apply<false>(L, nullptr, 0, ci, cj, L.x1[c]);
+      res = dc ? t : 0.0;
     }
   }
   const int base = (threadIdx.x & 63) & ~3;
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(256) void k_mg_down(MgLevel L, double* __restrict__
 // the dense level: y = (P^T A P)^-1 rhs, a workgroup per row (one workgroup alone took 15 us for the 0.5 MB)
 __global__ __launch_bounds__(256) void k_mg_top(const double* __restrict__ rhs, const double* __restrict__ inv, double* __restrict__ y, int n,
                                                 const PcgScalars* sc, int force) {
-  if (!force && (sc->done || !sc->nonzero)) return;
+  (void)force; (void)sc;      // (no early exit on `done`: see launch_mg_cycle)
   __shared__ double s_red[4];
   const int row = blockIdx.x, j = threadIdx.x;
   double v = j < n ? inv[(size_t)row * n + j] * rhs[j] : 0.0;      // (the inverse is symmetric: row = column)
@@ -422,20 +424,18 @@ __global__ __launch_bounds__(256) void k_mg_top(const double* __restrict__ rhs, 
 template <bool LAST>
 __global__ __launch_bounds__(256) void k_mg_up(MgLevel L, const double* __restrict__ e, int enx, double* __restrict__ x, PcgScalars* sc, int fin_op, int force,
                                                double* dot_part, unsigned int* counter) {
-  if (!force && (sc->done || !sc->nonzero)) return;
+  const bool idle = !force && (sc->done || !sc->nonzero);      // read first, consulted last: the load overlaps the level's own loads
   double dv = 0.0;
   for (int c = blockIdx.x * 256 + threadIdx.x; c < L.nx * L.ny; c += gridDim.x * 256) {
     const int I = c / L.nx, J = c % L.nx;
-    double xv = 0.0;
     const int d = L.d[c];
-    if (d) {
-      const double x2 = mg_val<true>(L, e, enx, I, J);
-      xv = x2 + MG_OMEGA * (L.rhs[c] - mg_apply<true>(L, e, enx, I, J, x2)) / (double)d;
-    }
+    const double x2 = mg_val<true>(L, e, enx, I, J);
+    const double t = x2 + MG_OMEGA * (L.rhs[c] - mg_apply<true>(L, e, enx, I, J, x2)) / (double)(d ? d : 1);      // (loads issued together; an empty aggregate selects 0)
+    const double xv = d ? t : 0.0;
     x[c] = xv;
     if (LAST) dv += xv * L.rhs[c];
   }
-  if (!LAST) return;
+  if (!LAST || idle) return;      // (after convergence the level arrays are dead; the scalar epilogue below must not run)
   __shared__ double s_red[4];
   __shared__ int am_last;
   dv = eu_wave_sum(dv);
@@ -466,6 +466,9 @@ __global__ __launch_bounds__(256) void k_mg_up(MgLevel L, const double* __restri
 }
 
 #define CLAUNCH(S, KERNEL, GRID, BLOCK, ...) hipLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, (S)->stream, __VA_ARGS__)
+// The kernels of the cycle do NOT start with the usual `if (done) return`: that test is a memory round trip (~1.5 us) in front of launches that take ~3 us
+// themselves.  Past convergence they recompute level arrays nobody reads again (the fine-grid kernels do return at once, and k_mg_up<true> keeps its
+// scalar epilogue behind the flag, which it loads first and consults last).
 static int launch_mg_cycle(euler_sim* S, int fin_op, int force) {
   const int nl = S->mg_levels;
   eu_prof_begin(S, KC_COARSE_CYCLE);      // ONE event pair around the whole cycle (a pair per 5 us launch would time the events)
