@@ -73,7 +73,7 @@ EXPORTS = [
     "euler_get_field", "euler_set_field", "euler_set_markers", "euler_set_rng", "euler_get_stats",
     "euler_field_bytes", "euler_render", "euler_render_grids", "euler_render_grids_rgb", "euler_colorize", "euler_profile_enable",
     "euler_profile_class_count", "euler_profile_class_name", "euler_profile_get", "euler_profile_reset",
-    "euler_measure_copy_bandwidth", "euler_device_name", "euler_hbm_bytes", "euler_sweep_timeline", "euler_save_state", "euler_load_state", "euler_set_comm", "euler_set_stream", "euler_slab_info",
+    "euler_measure_copy_bandwidth", "euler_measure_exchange", "euler_device_name", "euler_hbm_bytes", "euler_sweep_timeline", "euler_save_state", "euler_load_state", "euler_set_comm", "euler_set_stream", "euler_slab_info",
     "euler_rccl_unique_id", "euler_rccl_version", "euler_set_comm_rccl", "euler_comm_calls",
     "euler_p2p_export", "euler_p2p_connect", "euler_p2p_disconnect", "euler_p2p_calls", "euler_resident_info",
 ]
@@ -127,6 +127,7 @@ def load_library():
         "euler_profile_reset": (C.c_int, [vp]),
         "euler_resident_info": (C.c_int, [vp, C.POINTER(u64)]),
         "euler_measure_copy_bandwidth": (C.c_int, [vp, C.c_size_t, i32, C.POINTER(f64)]),
+        "euler_measure_exchange": (C.c_int, [vp, i32, i32, i32, C.POINTER(f64)]),
         "euler_device_name": (C.c_int, [vp, C.c_char_p, i32]),
         "euler_hbm_bytes": (u64, [vp]),
         "euler_sweep_timeline": (C.c_int, [vp, C.POINTER(C.c_uint64), i32]),
@@ -422,6 +423,12 @@ class Simulation:
     def copy_bandwidth(self, nbytes=1 << 30, reps=10):
         g = C.c_double(0)
         _check(self.L.euler_measure_copy_bandwidth(self.h, nbytes, reps, C.byref(g)))
+        return g.value
+
+    def exchange_latency(self, reps=200, row_doubles=0, nsmall=2):
+        """collective: microseconds per exchange point of a distributed PCG iteration over the installed communicator"""
+        g = C.c_double(0)
+        _check(self.L.euler_measure_exchange(self.h, reps, row_doubles, nsmall, C.byref(g)))
         return g.value
 
     def save_state(self, path):

@@ -1030,6 +1030,46 @@ extern "C" int euler_measure_copy_bandwidth(euler_sim* S, size_t bytes, int32_t 
   return EULER_OK;
 }
 
+// The latency of ONE exchange point of a distributed PCG iteration over the installed communicator - `row_doubles` doubles to / from each neighbour and `nsmall` doubles
+// of every rank to every rank, euler_comm_ops.exchange (or halo + all-gather where the communicator has no fused operation) - measured with HIP events on the handle's stream
+// over `reps` back-to-back calls.  Collective.  The model of DESIGN 7a has this one unknown (L); tools/node_first_contact.sh measures it before anything else on a node.
+extern "C" int euler_measure_exchange(euler_sim* S, int32_t reps, int32_t row_doubles, int32_t nsmall, double* us_per_exchange) {
+  if (!S || !us_per_exchange || reps < 1 || row_doubles < 0 || nsmall < 0) return EULER_EINVAL;
+  if (!S->has_comm) { eu_set_error("euler_measure_exchange: install a communicator first"); return EULER_ESTATE; }
+  const int R = S->bulk.nranks;
+  double* buf = nullptr;
+  const size_t n = 4 * (size_t)(row_doubles > 0 ? row_doubles : 1) + (size_t)R * (nsmall > 0 ? nsmall : 1);
+  HIPCHK(hipMalloc((void**)&buf, n * sizeof(double)));
+  (void)hipMemsetAsync(buf, 0, n * sizeof(double), S->stream);
+  double *slo = buf, *shi = buf + row_doubles, *rlo = buf + 2 * (size_t)row_doubles, *rhi = buf + 3 * (size_t)row_doubles, *small = buf + 4 * (size_t)(row_doubles > 0 ? row_doubles : 1);
+  auto once = [&]() -> int {
+    if (S->bulk.exchange) return S->bulk.exchange(S->bulk.ctx, slo, shi, rlo, rhi, row_doubles, small, nsmall);
+    int rc = row_doubles > 0 ? S->bulk.halo(S->bulk.ctx, slo, shi, rlo, rhi, row_doubles) : 0;
+    if (!rc && nsmall > 0) {
+      int64_t off[64], cnt[64];
+      for (int r = 0; r < R && r < 64; ++r) { off[r] = (int64_t)8 * nsmall * r; cnt[r] = (int64_t)8 * nsmall; }
+      rc = S->bulk.allgather(S->bulk.ctx, small, off, cnt);
+    }
+    return rc;
+  };
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  int rc = 0;
+  for (int r = 0; r < 3 && !rc; ++r) rc = once();      // warm-up (connections, proxies)
+  (void)hipEventRecord(e0, S->stream);
+  for (int r = 0; r < reps && !rc; ++r) rc = once();
+  (void)hipEventRecord(e1, S->stream);
+  hipError_t e = hipStreamSynchronize(S->stream);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(buf);
+  if (rc) { eu_set_error("euler_measure_exchange: the communicator's exchange failed"); return EULER_ECOMM; }
+  if (e != hipSuccess) return eu_hip_fail(e, "exchange probe", __FILE__, __LINE__);
+  *us_per_exchange = 1e3 * (double)ms / reps;
+  return EULER_OK;
+}
+
 extern "C" int euler_sweep_timeline(euler_sim* S, uint64_t* out, int32_t cap_bands) {
   if (!S || !out || cap_bands < 0) return EULER_EINVAL;
   const int n = S->band_hi - S->band_lo < cap_bands ? S->band_hi - S->band_lo : cap_bands;

@@ -373,6 +373,7 @@ int euler_profile_get(euler_sim* sim, int32_t cls, double* total_ms, uint64_t* l
 int euler_profile_reset(euler_sim* sim);
 /* Device-to-device copy bandwidth probe (float4 copy kernel), GB/s read+write. */
 int euler_measure_copy_bandwidth(euler_sim* sim, size_t bytes, int32_t reps, double* gbps);
+int euler_measure_exchange(euler_sim* sim, int32_t reps, int32_t row_doubles, int32_t nsmall, double* us_per_exchange);   /* collective: one exchange point of a distributed PCG iteration over the installed communicator, HIP-event time per call */
 int euler_device_name(euler_sim* sim, char* out, int32_t cap);
 uint64_t euler_hbm_bytes(const euler_sim* sim);   /* device memory the handle allocated (a row-slab handle: its slab only) */
 /* Diagnostics: the band pipeline of the most recent IC(0) sweep launch.  For each of this rank's bands in

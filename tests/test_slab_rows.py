@@ -285,3 +285,15 @@ def test_multilevel_mode_on_row_slabs(nproc, X, Y, workload, frames, extra):
         assert f["dp"] <= 1e-6 * f["pmax"] + 2e-6 and f["du"] <= 1e-5 and f["dv"] <= 1e-5, (i, f)
         solved += f["iters"][1] > 0
     assert solved >= 3
+
+
+@pytest.mark.gpu
+def test_node_first_contact_kit_runs_on_whatever_is_there(tmp_path):
+    """tools/node_first_contact.sh: the exchange-latency probe over the library's RCCL communicator with min(devices, 8) ranks - one on this box -
+    prints its JSON line; the scaling runs are skipped on a single GPU."""
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "node_first_contact.sh"), str(tmp_path)], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    d = json.loads(open(os.path.join(str(tmp_path), "exchange_latency.json")).read().strip().splitlines()[-1])
+    assert d["world"] >= 1 and d["rccl_version"] > 0 and len(d["us_per_exchange"]) == 4 and all(v >= 0 for v in d["us_per_exchange"].values())
+    assert d["model_16384"]["strong_scaling_speedup_estimate"] > 0
