@@ -141,56 +141,112 @@ namespace {
 struct Part {
   std::string file;
   SnapHeader h;
-  int row_lo, row_hi;
-  uint64_t n_loc;
+  int row_lo, row_hi;               // rows the FILE holds
+  int keep_lo, keep_hi;             // rows of it kept in memory: those the handle's window needs
+  uint64_t n_loc;                   // markers in the file
   bool keyed;                       // version 3: markers carry keys; else a marker's key is its index
-  std::vector<unsigned char> data;  // the whole file once loaded
-  size_t body;                      // offset of the first field
-  size_t cells() const { return (size_t)(row_hi - row_lo) * h.X; }
+  // kept in memory: the rows [keep_lo, keep_hi) of every field section, and the markers whose row lies in [mark_lo, mark_hi) with their keys
+  std::vector<unsigned char> sec[16];
+  std::vector<float> mk;
+  std::vector<unsigned int> keys;
   bool has_dye() const { return h.version == 2 || (h.version == 3 && h.reserved == 1); }
-  const unsigned char* section(int k) const {      // 0..3 f32 fields, 4..8 u8 grids, 9 precon, 10..15 dye (v2), 16 markers, 17 keys
-    const size_t C = cells();
-    size_t off = body;
-    if (k <= 3) return data.data() + off + (size_t)k * 4 * C;
-    off += 16 * C;
-    if (k <= 8) return data.data() + off + (size_t)(k - 4) * C;
-    off += 5 * C;
-    if (k == 9) return data.data() + off;
-    off += 8 * C;
-    if (has_dye()) { if (k <= 15) return data.data() + off + (size_t)(k - 10) * 4 * C; off += 24 * C; }
-    if (k == 16) return data.data() + off;
-    return data.data() + off + (size_t)n_loc * 8;
-  }
+  const unsigned char* rows(int k, int y) const { return sec[k].data() + (size_t)(y - keep_lo) * h.X * elem(k); }      // row y (kept) of section k
+  static size_t elem(int k) { return k <= 3 ? 4 : (k <= 8 ? 1 : (k == 9 ? 8 : 4)); }      // 0..3 f32 fields, 4..8 u8 grids, 9 precon, 10..15 dye
 };
 
-int read_part(Part& p) {
+// One pass over the file in 4 MB pieces: the checksum covers every byte, memory holds only what the handle needs - the rows of its window and the markers
+// inside [mark_lo, mark_hi) - so a whole-grid snapshot of 16384^2 (7.8 GB + 2.7 GB of markers) loaded into eight row slabs costs each rank its own eighth,
+// not the whole file.
+int read_part(Part& p, int need_lo, int need_hi, int mark_lo, int mark_hi) {
   FILE* f = fopen(p.file.c_str(), "rb");
   if (!f) { eu_set_error("cannot open %s", p.file.c_str()); return EULER_EIO; }
+  struct Closer { FILE* f; ~Closer() { fclose(f); } } closer{f};
   fseek(f, 0, SEEK_END);
   const long n = ftell(f);
   fseek(f, 0, SEEK_SET);
-  if (n < (long)(sizeof(SnapHeader) + 8)) { fclose(f); eu_set_error("%s is not an euler state snapshot", p.file.c_str()); return EULER_EINVAL; }
-  try { p.data.resize((size_t)n); } catch (...) { fclose(f); return EULER_ENOMEM; }
-  const bool ok = fread(p.data.data(), 1, (size_t)n, f) == (size_t)n;
-  fclose(f);
-  memcpy(&p.h, p.data.data(), sizeof p.h);
-  if (!ok || memcmp(p.h.magic, "EULERSNP", 8) != 0 || p.h.version < 1 || p.h.version > 3) {
+  if (n < (long)(sizeof(SnapHeader) + 8) || fread(&p.h, sizeof p.h, 1, f) != 1 || memcmp(p.h.magic, "EULERSNP", 8) != 0 || p.h.version < 1 || p.h.version > 3) {
     eu_set_error("%s is not an euler state snapshot (version 1, 2 or 3)", p.file.c_str()); return EULER_EINVAL;
   }
-  p.body = sizeof(SnapHeader);
+  uint64_t sum = snap_fnv(14695981039346656037ull, &p.h, sizeof p.h);
+  size_t body = sizeof(SnapHeader);
   p.row_lo = 0; p.row_hi = p.h.Y; p.n_loc = p.h.n_markers; p.keyed = false;
   if (p.h.version == 3) {
     SlabHeader sh;
-    if ((size_t)n < sizeof(SnapHeader) + sizeof sh + 8) { eu_set_error("%s is truncated (slab header)", p.file.c_str()); return EULER_EIO; }
-    memcpy(&sh, p.data.data() + sizeof(SnapHeader), sizeof sh);
-    p.body += sizeof sh;
+    if ((size_t)n < sizeof(SnapHeader) + sizeof sh + 8 || fread(&sh, sizeof sh, 1, f) != 1) { eu_set_error("%s is truncated (slab header)", p.file.c_str()); return EULER_EIO; }
+    sum = snap_fnv(sum, &sh, sizeof sh);
+    body += sizeof sh;
     p.row_lo = sh.row_lo; p.row_hi = sh.row_hi; p.n_loc = sh.n_loc; p.keyed = true;
   }
-  const size_t C = p.cells();
-  const size_t want = p.body + C * 29 + (p.has_dye() ? C * 24 : 0) + (size_t)p.n_loc * (p.keyed ? 12 : 8) + 8;
-  uint64_t sum = 0, stored = 0;
-  if ((size_t)n == want) { sum = snap_fnv(14695981039346656037ull, p.data.data(), want - 8); memcpy(&stored, p.data.data() + want - 8, 8); }
-  if ((size_t)n != want || sum != stored) { eu_set_error("%s is truncated or corrupt (checksum)", p.file.c_str()); return EULER_EIO; }
+  if (p.h.X <= 0 || p.row_hi < p.row_lo) { eu_set_error("%s: bad header", p.file.c_str()); return EULER_EINVAL; }
+  const size_t X = (size_t)p.h.X, C = (size_t)(p.row_hi - p.row_lo) * X;
+  const size_t want = body + C * 29 + (p.has_dye() ? C * 24 : 0) + (size_t)p.n_loc * (p.keyed ? 12 : 8) + 8;
+  if ((size_t)n != want) { eu_set_error("%s is truncated or corrupt (size)", p.file.c_str()); return EULER_EIO; }
+  p.keep_lo = need_lo > p.row_lo ? need_lo : p.row_lo; p.keep_hi = need_hi < p.row_hi ? need_hi : p.row_hi;
+  if (p.keep_hi < p.keep_lo) p.keep_hi = p.keep_lo;
+  std::vector<unsigned char> chunk;
+  try { chunk.resize((size_t)4 << 20); } catch (...) { return EULER_ENOMEM; }
+  // a stretch of `bytes` bytes of the file; `sink(offset in the stretch, data, length)` sees every piece in order
+  auto stream = [&](size_t bytes, auto&& sink) -> bool {
+    for (size_t done = 0; done < bytes;) {
+      const size_t len = bytes - done < chunk.size() ? bytes - done : chunk.size();
+      if (fread(chunk.data(), 1, len, f) != len) return false;
+      sum = snap_fnv(sum, chunk.data(), len);
+      sink(done, chunk.data(), len);
+      done += len;
+    }
+    return true;
+  };
+  const int nsec = p.has_dye() ? 16 : 10;
+  for (int k = 0; k < nsec; ++k) {
+    const size_t e = Part::elem(k), lo = (size_t)(p.keep_lo - p.row_lo) * X * e, hi = (size_t)(p.keep_hi - p.row_lo) * X * e;      // kept bytes of the section
+    try { p.sec[k].resize(hi - lo); } catch (...) { return EULER_ENOMEM; }
+    unsigned char* dst = p.sec[k].data();
+    const bool ok = stream(C * e, [&](size_t off, const unsigned char* d, size_t len) {
+      const size_t a = off > lo ? off : lo, b2 = off + len < hi ? off + len : hi;
+      if (b2 > a) memcpy(dst + (a - lo), d + (a - off), b2 - a);
+    });
+    if (!ok) { eu_set_error("%s: short read", p.file.c_str()); return EULER_EIO; }
+  }
+  // markers: those whose row lies in [mark_lo, mark_hi); the indices kept decide which keys are kept from the stretch behind them
+  std::vector<uint64_t> kept;
+  unsigned char carry[8];
+  size_t ncarry = 0;
+  uint64_t mi = 0;
+  bool oom = false;
+  bool ok = stream((size_t)p.n_loc * 8, [&](size_t, const unsigned char* d, size_t len) {
+    size_t pos = 0;
+    while (pos < len && !oom) {
+      float m[2];
+      if (ncarry || len - pos < 8) {      // a marker split across two pieces
+        const size_t take = 8 - ncarry < len - pos ? 8 - ncarry : len - pos;
+        memcpy(carry + ncarry, d + pos, take); ncarry += take; pos += take;
+        if (ncarry < 8) break;
+        memcpy(m, carry, 8); ncarry = 0;
+      } else { memcpy(m, d + pos, 8); pos += 8; }
+      const int y = (int)floorf(m[1] / EU_H);
+      if (y >= mark_lo && y < mark_hi) {
+        try { p.mk.push_back(m[0]); p.mk.push_back(m[1]); kept.push_back(mi); } catch (...) { oom = true; }
+      }
+      ++mi;
+    }
+  });
+  if (oom) return EULER_ENOMEM;
+  if (!ok) { eu_set_error("%s: short read", p.file.c_str()); return EULER_EIO; }
+  if (p.keyed) {
+    size_t next = 0;
+    try { p.keys.resize(kept.size()); } catch (...) { return EULER_ENOMEM; }
+    ncarry = 0; mi = 0;
+    ok = stream((size_t)p.n_loc * 4, [&](size_t, const unsigned char* d, size_t len) {      // (4 MB pieces are whole multiples of 4 bytes)
+      for (size_t pos = 0; pos + 4 <= len; pos += 4, ++mi)
+        if (next < kept.size() && kept[next] == mi) { memcpy(&p.keys[next], d + pos, 4); ++next; }
+    });
+    if (!ok) { eu_set_error("%s: short read", p.file.c_str()); return EULER_EIO; }
+  } else {
+    try { p.keys.resize(kept.size()); } catch (...) { return EULER_ENOMEM; }
+    for (size_t i = 0; i < kept.size(); ++i) p.keys[i] = (unsigned int)kept[i];
+  }
+  uint64_t stored = 0;
+  if (fread(&stored, 8, 1, f) != 1 || stored != sum) { eu_set_error("%s is truncated or corrupt (checksum)", p.file.c_str()); return EULER_EIO; }
   return EULER_OK;
 }
 }  // namespace
@@ -229,7 +285,7 @@ static int load_state_local(euler_sim* S, const char* path, SnapHeader* h_out) {
   std::vector<Part*> use;
   for (Part& p : parts) {
     if (p.row_hi <= need_lo || p.row_lo >= need_hi) continue;
-    int rc = read_part(p);
+    int rc = read_part(p, need_lo, need_hi, S->slab_on ? S->row_lo : 0, S->slab_on ? S->row_hi : Y);
     if (rc) return rc;
     if (p.h.X != X || p.h.Y != Y) { eu_set_error("snapshot grid %dx%d does not fit this %dx%d handle", p.h.X, p.h.Y, X, Y); return EULER_EINVAL; }
     use.push_back(&p);
@@ -253,7 +309,7 @@ static int load_state_local(euler_sim* S, const char* path, SnapHeader* h_out) {
     for (Part* p : use) {
       const int a = p->row_lo > y0 ? p->row_lo : y0, b = p->row_hi < y1 ? p->row_hi : y1;
       if (b <= a) continue;
-      memcpy(buf.data() + (size_t)(a - y0) * X * elem, p->section(section) + (size_t)(a - p->row_lo) * X * elem, (size_t)(b - a) * X * elem);
+      memcpy(buf.data() + (size_t)(a - y0) * X * elem, p->rows(section, a), (size_t)(b - a) * X * elem);
       for (int y = a; y < b; ++y) have[(size_t)(y - y0)] = 1;
     }
     for (int y = y0; y < y1; ++y) if (!have[(size_t)(y - y0)]) { eu_set_error("%s: row %d is in none of the part files", path, y); return false; }
@@ -293,10 +349,10 @@ static int load_state_local(euler_sim* S, const char* path, SnapHeader* h_out) {
     try { seen.assign((size_t)h0.n_markers, 0); } catch (...) { return EULER_ENOMEM; }
     uint64_t placed = 0;
     for (Part* p : use) {
-      const float* m = reinterpret_cast<const float*>(p->section(16));
-      const unsigned int* kk = reinterpret_cast<const unsigned int*>(p->section(17));
-      for (uint64_t i = 0; i < p->n_loc; ++i) {
-        const uint64_t key = p->keyed ? kk[i] : i;
+      const float* m = p->mk.data();
+      const unsigned int* kk = p->keys.data();
+      for (uint64_t i = 0; i < p->keys.size(); ++i) {
+        const uint64_t key = kk[i];
         if (key >= h0.n_markers) { eu_set_error("%s: marker key %llu out of range", path, (unsigned long long)key); return EULER_EINVAL; }
         if (seen[(size_t)key]) { eu_set_error("%s: marker key %llu appears twice", path, (unsigned long long)key); return EULER_EINVAL; }
         seen[(size_t)key] = 1;
@@ -308,15 +364,9 @@ static int load_state_local(euler_sim* S, const char* path, SnapHeader* h_out) {
     if ((rc = euler_set_markers(S, mk.data(), h0.n_markers))) return rc;
     if ((rc = euler_set_rng(S, h0.rng_state, h0.source_exhausted))) return rc;
   } else {
-    for (Part* p : use) {
-      const float* m = reinterpret_cast<const float*>(p->section(16));
-      const unsigned int* kk = reinterpret_cast<const unsigned int*>(p->section(17));
-      for (uint64_t i = 0; i < p->n_loc; ++i) {
-        const int y = (int)floorf(m[2 * i + 1] / EU_H);
-        if (y < S->row_lo || y >= S->row_hi) continue;
-        mk.push_back(m[2 * i]); mk.push_back(m[2 * i + 1]);
-        keys.push_back(p->keyed ? kk[i] : (unsigned int)i);
-      }
+    for (Part* p : use) {      // (read_part kept exactly the markers inside the own rows)
+      mk.insert(mk.end(), p->mk.begin(), p->mk.end());
+      keys.insert(keys.end(), p->keys.begin(), p->keys.end());
     }
     n_loc = keys.size();
     if (n_loc > S->max_markers) { eu_set_error("row slab %d: %llu markers in its rows, more than its capacity %zu", S->cfg.slab_rank, (unsigned long long)n_loc, S->max_markers); return EULER_ENOMEM; }

@@ -179,6 +179,15 @@ def test_snapshot_of_three_slabs_resumes_on_two_and_on_one_gpu(tmp_path):
         assert f["dp"] <= 1e-8 * f["pmax"] + 2e-6 and f["du"] < 1e-6 and f["dv"] < 1e-6, (i, f)
     assert checked >= 8
     assert not [f for f in os.listdir(str(tmp_path)) if f.endswith(".tmp")]      # (files appear under their final names only: written as .tmp, renamed)
+    # ... and the other way round: the single-GPU run's whole-grid file (version 1) resumed on two slabs - each rank streams the file once and keeps its own rows and markers only
+    import shutil
+    whole = str(tmp_path / "whole.snap")
+    shutil.copyfile(snap + ".ref", whole)
+    shutil.copyfile(snap + ".ref", whole + ".ref")
+    d3 = run(2, 256, 512, "dam_break", 6, ea.PRECOND_IC0_TILE, 29591, ("load=" + whole,))
+    for i, f in enumerate(d3["frames"]):
+        assert f["markers_in_rows"] and f["keys_cover_own_count"] and f["keys_are_a_permutation"], (i, f)
+        assert f["count_differ"] == 0 and f["n_markers"][0] == f["n_markers"][1], (i, f)
     # ... and on one GPU: the parts merge into the whole grid, the markers go to their keys - the state IS the single-GPU run's
     one = ea.Simulation(256, 512, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE).load_state(snap)
     ref = ea.Simulation(256, 512, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE).load_state(snap + ".ref")
