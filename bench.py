@@ -117,6 +117,7 @@ def parse_args():
     ap.add_argument("--force-slab", action="store_true",
                     help="N=1 diagnostics: run the communicator code path with one rank (every exchange still goes through RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-size", type=int, default=2048, help="N of the N x N half tank the cpu_baseline leg times (tests use a small one)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the hipEvent per-kernel timing (used under rocprofv3)")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel class (diagnostics)")
     ap.add_argument("--no-secondary", action="store_true", help="headline case only (no parity-mode / 1024^2 / 16384^2 / time-to-solution blocks)")
@@ -154,14 +155,13 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline_roofline_run(libs, tol):
+def cpu_baseline_roofline_run(libs, tol, N=2048):
     """The oracle ('port': the from-scratch restatement proven bit-identical to the compiled reference at 100x40), single
     thread like the reference, on a BOUNDED sample of the headline workload: the half-filled tank at 2048^2 (1/16 of the
     8192^2 grid, same fluid fraction, same tol = 0 / 100 iterations per substep), one frame; plus configs[0]."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     res = {}
-    N = 2048
     for name, so in libs.items():
         o = oracle_lib.Oracle(N, N, lib_path=so).load_half_tank()
         o.c.tol = tol
@@ -1400,17 +1400,18 @@ def main():
         # (8) the CPU path beside it (rank 0): single thread, bounded sample
         if libs:
             try:
-                cpu = cpu_baseline_roofline_run(libs, tol if tol is not None else 1e-6)
+                NS = args.cpu_sample_size
+                cpu = cpu_baseline_roofline_run(libs, tol if tol is not None else 1e-6, NS)
                 ref = cpu["reference_flags"]
-                per_cell_substep = ref["seconds"] / (2048 * 2048 * max(ref["substeps"], 1))
+                per_cell_substep = ref["seconds"] / (NS * NS * max(ref["substeps"], 1))
                 cpu_obj = {"value": round(ref["value"], 1), "unit": "cells*steps/s", "cores": 1, "kind": "port",
-                           "sample": "1 frame (%d substep(s), %d PCG iterations) of the 2048x2048 half tank - the headline workload at 1/16 of its "
+                           "sample": "1 frame (%d substep(s), %d PCG iterations) of the %dx%d half tank - the headline workload at 1/%d of its "
                                      "cells, same fluid fraction, same tol / iteration budget; oracle/euler_oracle.c built -O3 -ffast-math "
-                                     "-march=native (the reference's CMake flags), single thread like the reference" % (ref["substeps"], ref["pcg_iterations"]),
+                                     "-march=native (the reference's CMake flags), single thread like the reference" % (ref["substeps"], ref["pcg_iterations"], NS, NS, max(1, (8192 // NS) ** 2)),
                            "seconds": ref["seconds"], "strict_ieee_value": round(cpu["strict"]["value"], 1), "cpu_model": cpu_model(),
                            "extrapolated_seconds_per_substep": {"8192x8192": round(per_cell_substep * 8192 * 8192, 1),
                                                                 "16384x16384": round(per_cell_substep * 16384 * 16384, 1),
-                                                                "note": "EXTRAPOLATED from the 2048^2 sample at constant time per cell and substep (100 iterations each)"},
+                                                                "note": "EXTRAPOLATED from the %d^2 sample at constant time per cell and substep (100 iterations each)" % NS},
                            "configs0_100x40_block_100_steps": cpu.get("_native"),
                            "configs1_1024_dam_break_same_state": (secondary.get("configs1_1024_dam_break") or {}).get("cpu_same_state"),
                            "host_cores_available": os.cpu_count()}

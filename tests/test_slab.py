@@ -165,7 +165,7 @@ def test_bench_multi_rank_contract(scaling):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", EULER_DIST_BACKEND="gloo", EULER_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "256",
-           "--comm", "torch", "--p2p", "--scaling", scaling, "--max-preroll", "60", "--strong-size", "512"]
+           "--comm", "torch", "--p2p", "--scaling", scaling, "--max-preroll", "60", "--strong-size", "512", "--cpu-sample-size", "512"]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     lines = [l for l in out.stdout.splitlines() if l.strip()]
