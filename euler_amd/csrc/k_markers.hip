@@ -128,8 +128,13 @@ __device__ __forceinline__ AdvectOut advect_one(const GridRef& g, const float* _
   AdvectOut o;
   o.events = 0; o.theta = 0.f; o.delta = 0.f;
   // velocity_at (main.c:440-449)
+#ifdef EU_EXP_TR      // timing experiment (WRONG results): the gathers walk the arrays as if they were stored column-major
+  float vx = eu_interp<1>(g, u, py / EU_H - 0.5f, px / EU_H - 1.f);
+  float vy = eu_interp<2>(g, v, py / EU_H - 1.f, px / EU_H - 0.5f);
+#else
   float vx = eu_interp<1>(g, u, px / EU_H - 1.f, py / EU_H - 0.5f);
   float vy = eu_interp<2>(g, v, px / EU_H - 0.5f, py / EU_H - 1.f);
+#endif
   int xi = (int)floorf(px / EU_H), yi = (int)floorf(py / EU_H);
   const int xdir = vx > 0 ? 1 : -1;
   int nxi = xi + (vx > 0 ? 1 : 0);
