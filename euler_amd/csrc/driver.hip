@@ -145,7 +145,7 @@ bool eu_resident_eligible(const euler_sim* S) {
   // the whole grid must fit
   const int cap = eu_resident_capacity(const_cast<euler_sim*>(S), S->cfg.pcg_precision == EULER_PCG_F32);
   if (S->cfg.pcg_precision == EULER_PCG_F32) return cap > 0 && S->geom.nbands * (S->geom.T / 16) <= 4 * cap;
-  return cap > 0 && S->geom.nbands * (S->geom.T / 16) <= 16 * cap;      // (grids far beyond the capacity do not even ask: the two host round trips per solve buy nothing there)
+  return cap > 0;      // (any grid: what counts is the ACTIVE chunks of a solve - BASELINE configs[4], the 4096^2 waterfall, starts at 1.6 % water: 71 -> 11.7 us per iteration until it has grown past a million cells; where a solve does not fit, the extra host round trip is ~30 us against milliseconds of solve)
 }
 extern "C" int euler_resident_info(euler_sim* S, uint64_t out[3]) {
   if (!S || !out) return EULER_EINVAL;

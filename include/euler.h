@@ -124,10 +124,12 @@ typedef struct euler_config {
   int32_t pcg_precision;   /* EULER_PCG_F64 (0, default: the reference's double vectors, main.c:577-578,716) or EULER_PCG_F32: every solver vector in float, sums and
                               scalars in double - BASELINE configs[1]'s "fp32".  NOT the reference's iterates (tolerance parity only, restated in the oracle:
                               eo_sim.pcg_f32); runs in the resident solver, so it needs what that needs (below) and euler_create refuses it otherwise. */
-  int32_t resident;        /* EULER_RESIDENT_AUTO (0): a grid of at most 4 x (resident workgroups) 16-record chunks - up to ~1400^2 on an MI355X, BASELINE
-                              configs[1] included - runs the tile-local PCG (EULER_PRECOND_IC0_TILE, one GPU, EULER_DOT_TREE, tiles of 16 records) as ONE
-                              persistent launch whose vectors stay in registers (csrc/k_resident.hip): same arithmetic, sums folded per workgroup, so the
-                              iterates agree with the multi-kernel form to rounding.  EULER_RESIDENT_OFF (1): always the multi-kernel form. */
+  int32_t resident;        /* EULER_RESIDENT_AUTO (0): a solve whose ACTIVE 16-record chunks (those holding fluid) all find a wave on the chip at once - at most
+                              4 x (resident workgroups): 1024 chunks = 1 M cells of water in double, 2048 in float on an MI355X; BASELINE configs[1] (1024^2 dam break)
+                              always, configs[4] (4096^2 waterfall) while its water is below that - runs the tile-local PCG (EULER_PRECOND_IC0_TILE, one GPU, EULER_DOT_TREE,
+                              tiles of 16 records) as ONE persistent launch whose vectors stay in registers (csrc/k_resident.hip): same arithmetic, sums folded per
+                              workgroup, so the iterates agree with the multi-kernel form to rounding; decided per solve.  EULER_RESIDENT_OFF (1): always the
+                              multi-kernel form. */
 } euler_config;
 
 enum { EULER_PCG_F64 = 0, EULER_PCG_F32 = 1 };

@@ -28,7 +28,9 @@ def pair(X, Y, text=None, **kw):
     return a, b
 
 
-@pytest.mark.parametrize("X,Y,workload,frames", [(512, 512, "dam_break", 40), (300, 200, "waterfall", 30), (1024, 1024, "half_tank", 2), (130, 70, "half_tank", 3)])
+@pytest.mark.parametrize("X,Y,workload,frames", [(512, 512, "dam_break", 40), (300, 200, "waterfall", 30), (1024, 1024, "half_tank", 2), (130, 70, "half_tank", 3),
+                                                 # ragged: widths that are no multiple of a chunk, heights that end inside a band, one band, one chunk column
+                                                 (257, 129, "waterfall", 20), (333, 200, "dam_break", 30), (65, 300, "dam_break", 30), (1000, 900, "dam_break", 26), (40, 64, "half_tank", 3)])
 def test_resident_f64_against_the_multi_kernel_tile_mode(X, Y, workload, frames):
     text = None if workload == "half_tank" else getattr(scenarios, workload)()
     a, b = pair(X, Y, text, max_iterations=2000)      # cap lifted: converged solves compare to tolerance
