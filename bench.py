@@ -881,14 +881,14 @@ def quality_summary(sim, ea, tile_records, solver_tol):
     return out
 
 
-def converged_block(sim, ea, grp, args, GX, GY, tile_w, steps, solver_tol):
+def converged_block(sim, ea, grp, args, GX, GY, tile_w, steps, solver_tol, traffic=None, traffic_note=None):
     """The headline workload with EVERY solve run to the reference's tolerance 1e-6 (main.c:736) - the multilevel mode, iteration cap lifted: what
     "this grid, actually solved" costs.  Timed like the headline, per-kernel HIP events in the timed region, its own roofline object."""
     sim.set_precond(ea.PRECOND_IC0_TILE_MG, args.tile_records)
     sim.set_solver(20000, 1e-6)
     sim.step()      # (untimed: the tank calms down from the capped frames' noise; allocations of the coarse levels)
     t = time_frames(sim, ea, grp, args, "ic0_tile_mg", steps, 0, 1, True)
-    blk = summarize(t, GX, GY, "ic0_tile_mg", tile_w, None, None, steps)
+    blk = summarize(t, GX, GY, "ic0_tile_mg", tile_w, traffic, traffic_note, steps)
     out = {k: blk[k] for k in ("mode", "value", "unit", "ms_per_step", "substeps", "pcg_iterations", "cells_substeps_per_s", "fluid_cells", "last_residual",
                                "roofline", "pcg_iteration", "kernels")}
     out.update({"steps": steps, "tol": 1e-6, "max_iterations": 20000,
@@ -1132,12 +1132,18 @@ def main():
     # ---- live PMC passes FIRST (child processes; this process has not touched the GPU yet and holds no HBM)
     traffic = traffic_note = None
     traffic_exact = traffic_exact_note = None
+    traffic_mg = traffic_mg_note = None
     t_start, t_pmc = time.perf_counter(), 0.0
     if single and not args.no_pmc and not args.pmc_child:
         t0 = time.perf_counter()
         traffic, traffic_note = pmc_live(child_common + ["--precond", args.precond])
         if not args.no_secondary and args.precond != "ic0":
             traffic_exact, traffic_exact_note = pmc_live(child_common + ["--precond", "ic0"])
+        if not args.no_secondary and args.precond == "ic0_tile":      # the converged block's kernels (multilevel mode, every solve to 1e-6)
+            mg_child = [a for a in child_common]
+            if "--tol" in mg_child:
+                del mg_child[mg_child.index("--tol"):mg_child.index("--tol") + 2]
+            traffic_mg, traffic_mg_note = pmc_live(mg_child + ["--precond", "ic0_tile_mg", "--tol", "1e-6", "--max-iterations", "20000"])
         t_pmc = time.perf_counter() - t0
         print("bench: PMC passes took %.0f s (%s)" % (t_pmc, traffic_note), file=sys.stderr)
 
@@ -1257,7 +1263,7 @@ def main():
             quality = {"error": repr(e)}
         lap("quality")
         try:      # (3) every solve converged to the reference's tolerance
-            converged = converged_block(sim, ea, grp, args, GX, GY, tile_w, max(2, min(6, args.steps // 3)), solver_tol)
+            converged = converged_block(sim, ea, grp, args, GX, GY, tile_w, max(2, min(6, args.steps // 3)), solver_tol, traffic_mg, traffic_mg_note)
         except Exception as e:
             converged = {"error": repr(e)}
         lap("converged")

@@ -28,7 +28,7 @@
 
 static void usage(const char* argv0) {
   fprintf(stderr, "usage: %s [--rainbow] [--size XxY] [--upscale] [--frames N] [--window WxH] [--dump] [--no-pace] [--keys STRING] "
-                  "[--resume FILE] [--checkpoint FILE] [--solver reference|tile|two-level|multilevel] [--max-iterations N] <scenario>\n", argv0);
+                  "[--resume FILE] [--checkpoint FILE] [--solver reference|tile|tile-fp32|two-level|multilevel] [--max-iterations N] <scenario>\n", argv0);
 }
 
 /* ---- terminal (misc/terminal.c) ------------------------------------------------------------ */
@@ -122,6 +122,7 @@ int main(int argc, char** argv) {
       const char* v = argv[++i];
       if (!strcmp(v, "reference")) cfg.precond = EULER_PRECOND_IC0;
       else if (!strcmp(v, "tile")) cfg.precond = EULER_PRECOND_IC0_TILE;
+      else if (!strcmp(v, "tile-fp32")) { cfg.precond = EULER_PRECOND_IC0_TILE; cfg.pcg_precision = EULER_PCG_F32; cfg.dot_mode = EULER_DOT_TREE; }   /* solver vectors in float (resident solver: small grids) */
       else if (!strcmp(v, "two-level")) cfg.precond = EULER_PRECOND_IC0_TILE2;
       else if (!strcmp(v, "multilevel")) cfg.precond = EULER_PRECOND_IC0_TILE_MG;
       else { usage(argv[0]); return 1; }

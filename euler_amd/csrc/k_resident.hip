@@ -49,7 +49,7 @@ struct ResArgs {
   int* err;
 };
 
-namespace {
+namespace eu_resident {
 typedef unsigned int rs_u4 __attribute__((ext_vector_type(4)));
 
 template <int CTRL> __device__ __forceinline__ double rs_shift(double v, double edge) {
@@ -390,7 +390,8 @@ __global__ __launch_bounds__(RS_THREADS, sizeof(T) == 8 ? 1 : 2) void k_pcg_resi
 }
 
 int g_res_capacity[2] = {-1, -1};      // workgroups resident at once, per precision (one device kind per process)
-}  // namespace
+}  // namespace eu_resident
+using namespace eu_resident;
 
 // how many workgroups of the resident kernel the device holds at once (0: cannot be used)
 int eu_resident_capacity(euler_sim* S, int f32) {

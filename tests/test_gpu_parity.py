@@ -417,6 +417,14 @@ def test_cli_dump_matches_reference_frames(tmp_path):
         assert alt.returncode == 0, alt.stderr.decode()
         assert alt.stdout == out.stdout, solver
     assert subprocess.run([exe, "--dump", "--solver", "nonsense", str(scn)], capture_output=True, timeout=60).returncode == 1
+    # --solver tile-fp32 (euler_config.pcg_precision: solver vectors in float, the resident solver): the same frames on an upscaled grid as the double tile-local
+    # solver while the block falls freely and lands (the picture is the cell grid)
+    big = [exe, "--dump", "--frames", "30", "--size", "400x160", "--upscale", "--window", "98x38"]
+    a = subprocess.run(big + ["--solver", "tile", str(scn)], capture_output=True, timeout=120)
+    b = subprocess.run(big + ["--solver", "tile-fp32", str(scn)], capture_output=True, timeout=120)
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr.decode(), b.stderr.decode())
+    fa, fb = a.stdout.split(b"--- frame ")[1:], b.stdout.split(b"--- frame ")[1:]
+    assert len(fa) == len(fb) == 31 and fa[:26] == fb[:26]
 
 
 # ----------------------------------------------------------------------------- randomized marker stress

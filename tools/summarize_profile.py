@@ -22,6 +22,7 @@ def db(pattern):
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("eu_resident::", "")
     return name.split("(")[0].replace("void ", "")[:64]
 
 
