@@ -1069,7 +1069,7 @@ def compact_line(full, limit=LINE_LIMIT):
                 b["balance_max_over_mean"] = v["balance"].get("max_over_mean")
             summary[k] = b
     line["summary"] = summary
-    line.update(_pick(full, ("balance", "comm_calls_rank0", "device", "full", "timings_s")))
+    line.update(_pick(full, ("balance", "comm_calls_rank0", "device", "full", "timings_s", "dtype_note")))
     if isinstance(line.get("balance"), dict):
         line["balance"] = _pick(line["balance"], ("partition", "max_over_mean"))
     line = _short(line)
@@ -1454,7 +1454,8 @@ def main():
         "higher_is_better": True,
         "scaling": args.scaling if sharded else "weak",
         "vs_baseline": None,
-        "dtype": "f64 PCG vectors, f32 fields (the reference's mix, main.c:64-67,577-578,716)",
+        "dtype": "f64",      # the pressure solve computes in double on float fields: the reference's mix (main.c:64-67,577-578,716); the f32 variant is a labelled secondary
+        "dtype_note": "f64 PCG vectors, f32 velocity / marker fields (the reference's mix, main.c:64-67,577-578,716)",
         "data": "synthetic",
         "config": {"workload": "%dx%d %s%s, %s" % (GX, GY, args.workload,
                                                    " (BASELINE configs[2], pressure-solve roofline run: tol 0, exactly 100 PCG iterations per substep%s)"
