@@ -184,7 +184,7 @@ struct euler_sim {
   double* mg_dot;                    // per-block partials of x_0 . rhs_0 (+ the ticket counter behind them)
   double* mg_xbuf; int mg_xslot;     // row slabs: [ranks][mg_xslot] - every rank's {max |r|, dot(z,r), its rows of the level-0 right-hand side}, ONE all-gather inside the G1 exchange
   // the resident solver (k_resident.hip): the tile-local PCG of a grid whose chunks all find a wave on the chip at once, in ONE persistent launch
-  unsigned long long* res_gran;   // [2][3][512] 16-byte {value, generation} granules of its grid-wide reductions
+  unsigned long long* res_gran;   // [2][3][768] 16-byte {value, generation} granules of its grid-wide reductions
   unsigned long long res_tag;     // generation of the next launch's first reduction (never reset: stale granules never match)
   int* res_err;                   // pinned host word the kernel raises when a wait ran out; the host then solves with the multi-kernel path
   int res_disabled;               // ... and stops using the kernel on this handle

@@ -4,7 +4,7 @@
 // bytes: 1024^2 ran 31.6 us per iteration for 25 MB of algorithmic traffic (0.10 of the roofline), two launches whose waves each wait
 // for a scalar, for their operands, for the reduction's ticket and for the next launch.  Here:
 //
-//   * one WAVE per active chunk (the solve's chunk list, k_build_system), 4 waves per workgroup, every workgroup resident at once;
+//   * one WAVE per active chunk (the solve's chunk list, k_build_system), 4 waves per workgroup, every workgroup resident at once (two per CU in double, three in float);
 //     r, s, p and E^-1 of the chunk's 16 x 64 cells live in the wave's registers from the first iteration to the last (64 values per lane);
 //   * A s needs the chunk's halo - the record before and after it (64 cells each), the row below lane 0 and above lane 63 (16 each): every
 //     wave publishes those cells of z and s (write-through) before the iteration's second reduction; behind it the neighbours form the halo's
@@ -29,7 +29,7 @@
 
 #define RS_THREADS 256
 #define RS_WAVES 4
-#define RS_MAX_WG 512          // granules per kind; 2 workgroups per CU
+#define RS_MAX_WG 768          // granules per kind; up to 3 workgroups per CU
 #define RS_SHL1 0x130          // DPP wave shifts (k_pcg.hip): lane l <- lane l + 1, lane 63 <- the injected value
 #define RS_SHR1 0x138          // lane l <- lane l - 1, lane 0 <- the injected value
 #define RS_TIMEOUT_TICKS 200000000ull   // of the 100 MHz wall clock
@@ -42,7 +42,7 @@ struct ResArgs {
   void *zx, *sx;               // the cells other waves read: z and s at their band-skewed element index, as T (storage: the handle's z and s arrays)
   const unsigned int* list;
   PcgScalars* sc;
-  unsigned long long* gran;    // [2][3][RS_MAX_WG] granules of 16 bytes
+  unsigned long long* gran;    // [2][3][RS_MAX_WG] granules of 16 bytes (driver.hip allocates 2 * 3 * 768 * 2 words)
   unsigned long long tag0;     // generation of this launch's first reduction (monotonic over the handle's life: nothing is ever cleared)
   int band_lo, max_iters;
   double tol;
@@ -206,7 +206,7 @@ __device__ __forceinline__ void rs_tile_solve(const T (&rr)[16], const T* ee_l, 
 }
 
 template <typename T>
-__global__ __launch_bounds__(RS_THREADS, sizeof(T) == 8 ? 1 : 2) void k_pcg_resident(ResArgs a) {      // (double: one wave per SIMD and all 512 registers - at 256 the chunk's state spilled)
+__global__ __launch_bounds__(RS_THREADS, 2) void k_pcg_resident(ResArgs a) {      // (<= 256 registers: double 254, float 168)      // (double: one wave per SIMD and all 512 registers - at 256 the chunk's state spilled)
   typedef double d2 __attribute__((ext_vector_type(2)));
   PcgScalars* sc = a.sc;
   if (!sc->nonzero) return;      // all_zero(r), main.c:742 (every thread of the grid reads the same word)
@@ -225,6 +225,7 @@ __global__ __launch_bounds__(RS_THREADS, sizeof(T) == 8 ? 1 : 2) void k_pcg_resi
   const int tile = (int)(ent & ~EU_CHUNK_INTERIOR);
   const int band = a.band_lo + tile / ntb, k = tile % ntb;
   const size_t base = ((size_t)band * TS + (size_t)k * 16) * 64 + 2 * lane;      // element (band, record 16 k, lane)
+  size_t vbase = base;      // (the copy the iteration loop uses: see there)
   T* zx = static_cast<T*>(a.zx);
   T* sx = static_cast<T*>(a.sx);
 
@@ -265,21 +266,23 @@ __global__ __launch_bounds__(RS_THREADS, sizeof(T) == 8 ? 1 : 2) void k_pcg_resi
   // what lane 0 needs from the band below - (band - 1, lane 63, record 16 k + j + 63) - lanes 16..31 what lane 63 needs from the band above -
   // (band + 1, lane 0, record 16 k + j - 63).  Addresses that do not exist (or are never selected by a mask bit) fall back to the wave's own cell.
   const bool hasL = act && k > 0;
-  const size_t iL = hasL ? base - 127 : base, iR = act ? base + 1024 : base;
-  size_t iE = base;
+  const long long dL = hasL ? -127 : 0, dR = act ? 1024 : 0;      // (offsets from the chunk's own element: the addresses are formed inside the loop)
+  long long dE = 0;
   bool hasE = false;
-  if (act && lane < 16 && band > 0) { const int t2 = 16 * k + lane + 63; iE = ((size_t)(band - 1) * TS + (size_t)(t2 & ~1)) * 64 + 126 + (t2 & 1); hasE = true; }
+  if (act && lane < 16 && band > 0) { const int t2 = 16 * k + lane + 63; dE = (long long)(((size_t)(band - 1) * TS + (size_t)(t2 & ~1)) * 64 + 126 + (t2 & 1)) - (long long)base; hasE = true; }
   if (act && lane >= 16 && lane < 32 && band + 1 < nbands) {
     const int t2 = 16 * k + (lane - 16) - 63;
-    if (t2 >= 0) { iE = ((size_t)(band + 1) * TS + (size_t)(t2 & ~1)) * 64 + (t2 & 1); hasE = true; }
+    if (t2 >= 0) { dE = (long long)(((size_t)(band + 1) * TS + (size_t)(t2 & ~1)) * 64 + (t2 & 1)) - (long long)base; hasE = true; }
   }
   auto publish = [&](const T (&zv)[16], const T (&sv)[16]) {      // the cells other waves read: first and last record, lane 0 and lane 63
     if (!act) return;
-    rs_st(zx + base, zv[0]); rs_st(sx + base, sv[0]);
-    rs_st(zx + base + 7 * 128 + 1, zv[15]); rs_st(sx + base + 7 * 128 + 1, sv[15]);
+    T* zb = zx + vbase;
+    T* sb = sx + vbase;
+    rs_st(zb, zv[0]); rs_st(sb, sv[0]);
+    rs_st(zb + 7 * 128 + 1, zv[15]); rs_st(sb + 7 * 128 + 1, sv[15]);
     if (lane == 0 || lane == 63) {
 #pragma unroll
-      for (int j = 1; j < 15; ++j) { rs_st(zx + base + (j >> 1) * 128 + (j & 1), zv[j]); rs_st(sx + base + (j >> 1) * 128 + (j & 1), sv[j]); }
+      for (int j = 1; j < 15; ++j) { rs_st(zb + (j >> 1) * 128 + (j & 1), zv[j]); rs_st(sb + (j >> 1) * 128 + (j & 1), sv[j]); }
     }
   };
 
@@ -303,8 +306,14 @@ __global__ __launch_bounds__(RS_THREADS, sizeof(T) == 8 ? 1 : 2) void k_pcg_resi
     // ---- s' = z + beta s (main.c:669-677; the first search direction is z_0 itself, main.c:746) on the chunk and on its halo, then A s' (main.c:679-691)
     const bool first = it == 0;
     const T bt = (T)beta;
+    // Everything derived from the masks and the chunk's address is loop-invariant, and the compiler hoists ALL of it out of the iteration loop - 16 diagonals as
+    // doubles, 64-bit addresses of every halo cell ... - ~100 registers of values that cost one or two instructions to recompute.  Opaque copies keep them in the loop:
+    // the double kernel then fits 256 registers (two workgroups per CU: twice the chunks) without spilling.
+#pragma unroll
+    for (int P = 0; P < 8; ++P) asm volatile("" : "+v"(mm[P]));
+    asm volatile("" : "+v"(vbase));
     T zL, sL, zR, sR, zE, sE;
-    rs_ld6(zx + iL, sx + iL, zx + iR, sx + iR, zx + iE, sx + iE, zL, sL, zR, sR, zE, sE);
+    rs_ld6(zx + vbase + dL, sx + vbase + dL, zx + vbase + dR, sx + vbase + dR, zx + vbase + dE, sx + vbase + dE, zL, sL, zR, sR, zE, sE);
     T spL = first ? zL : zL + bt * sL, spR = first ? zR : zR + bt * sR, spE = first ? zE : zE + bt * sE;
     if (!hasL) spL = (T)0;
     if (!hasE) spE = (T)0;
@@ -358,6 +367,7 @@ __global__ __launch_bounds__(RS_THREADS, sizeof(T) == 8 ? 1 : 2) void k_pcg_resi
       }
     }
     // ---- z = M^-1 r and dot(z, r) (main.c:760-762) - not on the budget's last iteration, whose result nobody would read
+    asm volatile("" ::: "memory");      // (phase boundary: keeps the scheduler from hoisting the next phase's LDS loads into this one - register pressure)
     double dsum = 0.0;
     const bool sweeps = it < max_it;
     if (sweeps) {
@@ -401,7 +411,7 @@ int eu_resident_capacity(euler_sim* S, int f32) {
   hipError_t e = f32 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_resident<float>, RS_THREADS, 0)
                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_resident<double>, RS_THREADS, 0);
   if (e != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, S->cfg.device) != hipSuccess) { cap = 0; return 0; }
-  if (per_cu > (f32 ? 2 : 1)) per_cu = f32 ? 2 : 1;
+  if (per_cu > 3) per_cu = 3;      // (double: 2 by registers and LDS, float: 3)
   cap = per_cu * cus;
   if (cap > RS_MAX_WG) cap = RS_MAX_WG;
   return cap;
