@@ -125,7 +125,7 @@ typedef struct euler_config {
                               scalars in double - BASELINE configs[1]'s "fp32".  NOT the reference's iterates (tolerance parity only, restated in the oracle:
                               eo_sim.pcg_f32); runs in the resident solver, so it needs what that needs (below) and euler_create refuses it otherwise. */
   int32_t resident;        /* EULER_RESIDENT_AUTO (0): a solve whose ACTIVE 16-record chunks (those holding fluid) all find a wave on the chip at once - at most
-                              4 x (resident workgroups): 1024 chunks = 1 M cells of water in double, 2048 in float on an MI355X; BASELINE configs[1] (1024^2 dam break)
+                              4 x (resident workgroups): 2048 chunks = 2 M cells of water in double, 3072 in float on an MI355X; BASELINE configs[1] (1024^2 dam break)
                               always, configs[4] (4096^2 waterfall) while its water is below that - runs the tile-local PCG (EULER_PRECOND_IC0_TILE, one GPU, EULER_DOT_TREE,
                               tiles of 16 records) as ONE persistent launch whose vectors stay in registers (csrc/k_resident.hip): same arithmetic, sums folded per
                               workgroup, so the iterates agree with the multi-kernel form to rounding; decided per solve.  EULER_RESIDENT_OFF (1): always the
