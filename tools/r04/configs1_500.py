@@ -2,7 +2,7 @@
 """BASELINE configs[1] as named: the 1024 x 1024 dam break, 500 steps (frames), on one MI355X - wall time per mode.
 parity = the reference's IC(0), bit-identical iterates (cap 100); tile = tile-local IC(0), resident solver (f64 / f32), cap 100; converged = multilevel mode, every solve to 1e-6."""
 import sys, os, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import euler_amd as ea

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE configs[4] as named: the 4096 x 4096 waterfall (sources and sinks active), 2000 steps, one MI355X - wall time per mode."""
 import sys, os, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import euler_amd as ea

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """marker stages at 8192^2 (half tank at rest, first frames): HIP-event time per launch of every non-PCG class"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import euler_amd as ea
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 s = ea.Simulation(N, N, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE, tol=0.0).load_half_tank()

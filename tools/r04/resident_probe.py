@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """round 4: the resident solver at BASELINE configs[1] (1024^2 dam break in its solving phase): ms per frame and us per iteration, resident f64 / f32 against the multi-kernel tile mode"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import euler_amd as ea
 from euler_amd import scenarios
