@@ -286,8 +286,8 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
       eu_set_error("euler_create: slab rank %d of %d for %d bands of 64 rows", cfg->slab_rank, cfg->slab_nranks, nbands);
       free(S); return EULER_EINVAL;
     }
-    if (cfg->viscosity > 0.f || S->cfg.sweep_mode == EULER_SWEEP_SIMPLE) {
-      eu_set_error("euler_create: row slabs do not carry the diffusion extension or EULER_SWEEP_SIMPLE");
+    if (S->cfg.sweep_mode == EULER_SWEEP_SIMPLE) {
+      eu_set_error("euler_create: row slabs do not run EULER_SWEEP_SIMPLE");
       free(S); return EULER_EINVAL;
     }
     S->band_lo = (int)((int64_t)nbands * cfg->slab_rank / cfg->slab_nranks);
@@ -706,9 +706,9 @@ static int run_stage(euler_sim* S, int stage, float dt) {
 
 extern "C" int euler_stage(euler_sim* S, int32_t stage, float dt) {
   if (!S || !S->loaded) { eu_set_error("euler_stage: no scenario loaded"); return EULER_ESTATE; }
-  if (S->slab_on) { eu_set_error("euler_stage: single stages are not exposed on a row-slab handle (their ghost exchanges belong to the substep)"); return EULER_ESTATE; }
-  int rc = run_stage(S, stage, dt);
+  int rc = S->slab_on ? eu_slab_stage(S, stage, dt) : run_stage(S, stage, dt);      // (row slabs: collective - the stage and the exchanges that belong to it)
   if (rc) return rc;
+  if (S->slab_on && (rc = eu_slab_error_sync(S))) return rc;
   rc = eu_sync_marker_state(S);
   if (!rc && stage == EULER_STAGE_PROJECT) {      // the solve's outcome (not the totals: a stage is not a substep)
     S->stats.last_pcg_iterations = S->sc_host->nonzero ? S->sc_host->iters : 0;

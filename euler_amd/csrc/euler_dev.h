@@ -305,6 +305,7 @@ int  eu_slab_alloc(euler_sim* S);
 size_t eu_slab_bytes(const euler_sim* S);   // device memory of the slab exchange buffers
 void eu_slab_release(euler_sim* S);
 int  eu_slab_substep(euler_sim* S, float dt);
+int  eu_slab_stage(euler_sim* S, int stage, float dt);   // euler_stage on a row-slab handle (collective): the stage with its exchanges
 int  eu_slab_timestep(euler_sim* S, float frame_time_left);
 int  eu_slab_after_load(euler_sim* S);
 int  eu_slab_check_partition(euler_sim* S);   // collective: the ranks' band ranges tile the grid
@@ -321,6 +322,7 @@ int eu_launch_refresh_counts(euler_sim* S);
 int eu_launch_sources(euler_sim* S);
 int eu_launch_extrapolate(euler_sim* S);
 int eu_launch_advect_velocity(euler_sim* S, float dt);
+int eu_launch_diffuse(euler_sim* S, float dt);     // the diffusion extension alone (row slabs: behind the ghost rows of utmp / vtmp)
 int eu_launch_project(euler_sim* S, float dt);
 int eu_resident_capacity(euler_sim* S, int f32);            // k_resident.hip: workgroups of the resident PCG kernel the device holds at once
 int eu_launch_resident(euler_sim* S, unsigned int n_chunks);

@@ -190,15 +190,21 @@ __global__ __launch_bounds__(256) void k_copy_typed(const float* __restrict__ u,
   if (y < Y - 1) vo[i] = v[i];
 }
 
+int eu_launch_diffuse(euler_sim* S, float dt);
 int eu_launch_advect_velocity(euler_sim* S, float dt) {
   GridRef g{S->X, S->Y, S->count, S->interp_lim[0], S->interp_lim[1], S->interp_lim[2], S->interp_lim[3]};
   dim3 grid((S->X + 63) / 64, (S->row_hi - S->row_lo + 3) / 4);
   LAUNCH(S, KC_ADVECT_VELOCITY, k_advect_velocity, grid, dim3(256), S->u, S->v, S->utmp, S->vtmp, S->solid, g, dt, S->row_lo, S->row_hi);
-  if (S->cfg.viscosity > 0.f) {   // extension stage; absent (bit-identical to the reference) at viscosity 0
-    const float c = S->cfg.viscosity * dt / (EU_H * EU_H);
-    LAUNCH(S, KC_ADVECT_VELOCITY, k_diffuse_velocity, grid, dim3(256), S->utmp, S->vtmp, S->u, S->v, S->count, S->solid, S->X, S->Y, c, S->row_lo, S->row_hi);
-    LAUNCH(S, KC_ADVECT_VELOCITY, k_copy_typed, grid, dim3(256), S->u, S->v, S->utmp, S->vtmp, S->X, S->Y, S->row_lo, S->row_hi);
-  }
+  // (a row-slab handle exchanges the ghost rows of utmp / vtmp between the two: eu_slab_substep calls eu_launch_diffuse itself)
+  return S->slab_on ? EULER_OK : eu_launch_diffuse(S, dt);
+}
+// the diffusion extension over the own rows: reads utmp / vtmp one row below and above them
+int eu_launch_diffuse(euler_sim* S, float dt) {
+  if (!(S->cfg.viscosity > 0.f)) return EULER_OK;   // extension stage; absent (bit-identical to the reference) at viscosity 0
+  dim3 grid((S->X + 63) / 64, (S->row_hi - S->row_lo + 3) / 4);
+  const float c = S->cfg.viscosity * dt / (EU_H * EU_H);
+  LAUNCH(S, KC_ADVECT_VELOCITY, k_diffuse_velocity, grid, dim3(256), S->utmp, S->vtmp, S->u, S->v, S->count, S->solid, S->X, S->Y, c, S->row_lo, S->row_hi);
+  LAUNCH(S, KC_ADVECT_VELOCITY, k_copy_typed, grid, dim3(256), S->u, S->v, S->utmp, S->vtmp, S->X, S->Y, S->row_lo, S->row_hi);
   return EULER_OK;
 }
 

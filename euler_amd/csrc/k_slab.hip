@@ -622,10 +622,43 @@ int eu_slab_substep(euler_sim* S, float dt) {
   }
   // advect_u / advect_v / body forces / zero_bounds (main.c:871-889) -> utmp, vtmp of the own rows
   if ((rc = eu_launch_advect_velocity(S, dt))) return rc;
+  if (S->cfg.viscosity > 0.f) {      // the diffusion extension reads the advected velocities one row below and above the own rows
+    const GhostField f[2] = {{S->utmp, 4, 1, 1}, {S->vtmp, 4, 1, 1}};
+    if ((rc = exchange_rows(S, f, 2))) return rc;
+    if ((rc = eu_launch_diffuse(S, dt))) return rc;
+  }
   if ((rc = exchange_vtmp(S))) return rc;
   // project (main.c:893): distributed PCG over the band slabs; p's ghost row inside; u, v of the own rows
   if ((rc = eu_launch_project(S, dt))) return rc;
   return exchange_uv(S);
+}
+
+// euler_stage on a row-slab handle (collective): ONE stage of the substep over this rank's rows together with the exchanges that belong to it - the slices of
+// eu_slab_substep above, in its order, so that the stages called 0 .. 5 with one dt ARE a substep.  Without the dye (its steps interleave with the stages).
+int eu_slab_stage(euler_sim* S, int stage, float dt) {
+  if (!S->has_comm) { eu_set_error("row-slab handle without a communicator"); return EULER_ESTATE; }
+  if (S->dye[0]) { eu_set_error("euler_stage on a row-slab handle: not with euler_config.rainbow (the dye's steps sit between the stages)"); return EULER_ESTATE; }
+  SlabScratch* s = S->slab;
+  int rc;
+  switch (stage) {
+    case EULER_STAGE_ADVECT_MARKERS: return slab_advect_markers(S, dt);
+    case EULER_STAGE_REFRESH_COUNTS: {
+      const unsigned long long n_upper = S->n_markers_host + 2 * s->mig_cap;
+      return slab_refresh(S, n_upper < S->max_markers ? n_upper : S->max_markers);
+    }
+    case EULER_STAGE_SOURCES: if ((rc = slab_sources(S))) return rc; return exchange_counts(S);
+    case EULER_STAGE_EXTRAPOLATE: if ((rc = eu_launch_extrapolate(S))) return rc; return exchange_uv(S);
+    case EULER_STAGE_ADVECT_VELOCITY:
+      if ((rc = eu_launch_advect_velocity(S, dt))) return rc;
+      if (S->cfg.viscosity > 0.f) {
+        const GhostField f[2] = {{S->utmp, 4, 1, 1}, {S->vtmp, 4, 1, 1}};
+        if ((rc = exchange_rows(S, f, 2))) return rc;
+        if ((rc = eu_launch_diffuse(S, dt))) return rc;
+      }
+      return exchange_vtmp(S);
+    case EULER_STAGE_PROJECT: if ((rc = eu_launch_project(S, dt))) return rc; return exchange_uv(S);
+    default: eu_set_error("unknown stage %d", stage); return EULER_EINVAL;
+  }
 }
 
 __global__ void k_set_vec0(double* v, double x) { v[0] = x; }

@@ -237,7 +237,8 @@ int euler_seed_markers(const uint8_t* fluid, int32_t X, int32_t Y, uint64_t* rng
 int euler_step(euler_sim* sim);                    /* one frame: <= max_substeps CFL substeps */
 int euler_timestep(euler_sim* sim, float frame_time_left, float* dt);   /* calculate_timestep, main.c:834-841 */
 int euler_substep(euler_sim* sim, float dt);       /* stages 2..11 of sim_step with a given dt */
-int euler_stage(euler_sim* sim, int32_t stage, float dt);   /* one EULER_STAGE_* (teacher-forced tests) */
+int euler_stage(euler_sim* sim, int32_t stage, float dt);   /* one EULER_STAGE_* (teacher-forced tests).  Row-slab handles: COLLECTIVE - the stage over the own rows with the
+                                                                exchanges that belong to it (stages 0 .. 5 with one dt are a substep); not with euler_config.rainbow */
 int euler_pcg_op(euler_sim* sim, int32_t op, float dt, double scalar_in, double* scalar_out);   /* one EULER_OP_* (kernel-level parity tests);
  * EULER_EINVAL for the preconditioner operations of a handle in EULER_PRECOND_IC0_TILE2 (its coarse level exists inside a solve only) */
 /* Switch the preconditioner of the following solves (EULER_PRECOND_*; tile_records as euler_config.precond_tile_records,

@@ -48,10 +48,14 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     rainbow = "rainbow" in sys.argv[6:]       # --rainbow: the dye fields on row slabs (ghost rows of g_r / g_g / g_b, coloured frames)
     maxit = 100
+    nu = 0.0
+    for a in sys.argv[6:]:
+        if a.startswith("nu="):               # the velocity-diffusion extension (euler_config.viscosity) on row slabs
+            nu = float(a[3:])
     for a in sys.argv[6:]:
         if a.startswith("maxit="):            # lift the reference's iteration cap: solves run to tolerance (the coarse-correction modes: tolerance parity between 1 and N ranks)
             maxit = int(a[6:])
-    ref = ea.Simulation(X, Y, device=local, dot_mode=ea.DOT_TREE, precond=precond, rainbow=rainbow, max_iterations=maxit)       # single GPU, the whole grid
+    ref = ea.Simulation(X, Y, device=local, dot_mode=ea.DOT_TREE, precond=precond, rainbow=rainbow, max_iterations=maxit, viscosity=nu)       # single GPU, the whole grid
     if not any(a.startswith("load=") for a in sys.argv[6:]):
         load(ref, workload)
     slab = (rank, world)
@@ -64,7 +68,7 @@ def main():
     for a in sys.argv[6:]:
         if a.startswith("caps="):             # tiny exchange capacities (dt-chain candidates, deletions) to drive the overflow path
             os.environ["EULER_SLAB_CAPS"] = a[5:]
-    sim = ea.Simulation(X, Y, device=local, dot_mode=ea.DOT_TREE, precond=precond, slab=slab, rainbow=rainbow, max_iterations=maxit)   # one slab
+    sim = ea.Simulation(X, Y, device=local, dot_mode=ea.DOT_TREE, precond=precond, slab=slab, rainbow=rainbow, max_iterations=maxit, viscosity=nu)   # one slab
     comm = RcclComm(sim, SLAB_LOCAL) if rccl else TorchComm(sim, SLAB_LOCAL)
     out = {"world": world, "frames": []}
     if p2p:
@@ -159,9 +163,17 @@ def main():
         out["events"] = ev
         frames = 0
     free0, total = torch.cuda.mem_get_info()
+    stages = "stages" in sys.argv[6:]         # euler_stage on the slab handle (collective): the six stages of a substep one by one against the single GPU's substep
     for f in range(frames):
-        ref.step()
-        sim.step()
+        if stages:
+            dt_r, dt_s = ref.timestep(0.1), sim.timestep(0.1)
+            assert dt_r == dt_s, (dt_r, dt_s)
+            ref.substep(dt_r)
+            for st in range(6):
+                sim.stage(st, dt_s)
+        else:
+            ref.step()
+            sim.step()
         if comm.error:
             raise RuntimeError(comm.error)
         sr, ss = ref.stats(), sim.stats()
@@ -186,7 +198,7 @@ def main():
         d["n_markers"] = [int(sr.n_markers), int(ss.n_markers), len(m)]
         d["iters"] = [sr.last_pcg_iterations, ss.last_pcg_iterations]
         d["residual"] = [float(sr.last_residual), float(ss.last_residual)]
-        d["substeps"] = [sr.last_substeps, ss.last_substeps]
+        d["substeps"] = [1, 1] if stages else [sr.last_substeps, ss.last_substeps]
         d["rng"] = [int(sr.rng_state) == int(ss.rng_state), sr.source_exhausted == ss.source_exhausted]
         d["dt_events"] = [int(sr.marker_dt_events), int(ss.marker_dt_events)]
         if rainbow:                            # the dye: bit-exact while u, v are (no reduction of its own), else within their tolerance

@@ -36,6 +36,8 @@ def run(nproc, X, Y, workload, frames, precond, port, extra=()):
     (2, 256, 256, "waterfall", 20, ea.PRECOND_IC0, ()),               # slab-local IC(0): another preconditioner than 1 GPU (tolerance where converged)
     (3, 256, 512, "dam_break", 40, ea.PRECOND_IC0_TILE, ("bands=0-1,1-3,3-8",)),   # an explicit, uneven partition (fluid-balanced slabs)
     (3, 256, 512, "dam_break", 40, ea.PRECOND_IC0_TILE, ("noexchange",)),          # a communicator without euler_comm_ops.exchange: halo + all-gather
+    (2, 256, 512, "dam_break", 30, ea.PRECOND_IC0_TILE, ("nu=0.05",)),             # the velocity-diffusion extension on row slabs (ghost rows of utmp / vtmp in front of it)
+    (3, 256, 512, "dam_break", 60, ea.PRECOND_IC0_TILE, ("stages",)),              # euler_stage on slab handles: 60 substeps taken stage by stage (each with its exchanges)
 ])
 def test_row_slabs_reproduce_the_single_gpu_run(nproc, X, Y, workload, frames, precond, extra):
     d = run(nproc, X, Y, workload, frames, precond, 29581, extra)
