@@ -188,6 +188,8 @@ struct euler_sim {
   unsigned long long res_tag;     // generation of the next launch's first reduction (never reset: stale granules never match)
   int* res_err;                   // pinned host word the kernel raises when a wait ran out; the host then solves with the multi-kernel path
   int res_disabled;               // ... and stops using the kernel on this handle
+  unsigned int res_last_chunks;   // active chunks of the previous solve (from sc_host): decides whether the next one is launched resident without asking the device
+  int res_have_last, res_skip_once;
   unsigned long long res_solves, res_fallbacks;
   int tile_w;             // EULER_PRECOND_IC0_TILE: records per tile (include/euler.h precond_tile_records)
   const double* tile_as_override;   // where A s sits for the r update of the non-tile modes (z behind the first apply_a of a solve, else q)

@@ -2021,6 +2021,7 @@ __global__ void k_pcg_reset(PcgScalars* sc, double tol, int max_iters) {
 int eu_launch_project(euler_sim* S, float dt) {
   // the previous solve's final scalars are in sc_host by now (copied at its end, synced since)
   S->solve_iters[S->solve_seq & 255] = S->sc_host->nonzero ? S->sc_host->iters : -1;
+  if (S->solve_seq > 0) { S->res_last_chunks = S->sc_host->n_chunks; S->res_have_last = 1; }      // (the resident solver's guess for this solve, below)
   S->solve_seq += 1;
   // Did the previous solve use up its iteration budget without converging?  Then this one probably will too,
   // and the convergence poll is taken one chunk late: the next chunk is already queued while the host
@@ -2039,34 +2040,41 @@ int eu_launch_project(euler_sim* S, float dt) {
   }
   // Small grids (every chunk finds a wave on the chip at once): the whole solve as ONE persistent launch (k_resident.hip).  Two host round trips per solve -
   // the number of active chunks before the launch, its error word behind it - instead of one per eight iterations.
-  if (eu_resident_eligible(S)) {
-    HIPCHK(hipMemcpyAsync(S->sc_host, S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
-    HIPCHK(hipStreamSynchronize(S->stream));
-    const unsigned int nch = S->sc_host->n_chunks;
-    const bool fits = nch <= 4u * (unsigned int)eu_resident_capacity(S, S->cfg.pcg_precision == EULER_PCG_F32);
-    if (S->sc_host->nonzero && nch > 0 && fits) {
-      S->prof_iter = -2;
-      if ((rc = eu_launch_resident(S, nch))) return rc;
+  const bool res_skip = S->res_skip_once != 0;
+  S->res_skip_once = 0;
+  if (!res_skip && eu_resident_eligible(S)) {
+    // Whether this solve's active chunks fit is decided from the PREVIOUS solve's count (scenes change slowly; sc_host holds it: copied at the end of every solve) - no host
+    // round trip in front of the launch: the kernel is launched over the device's whole capacity, the workgroups beyond (n_chunks + 3) / 4 leave at once, and a solve that
+    // does not fit after all says so itself (error word 2) and is redone below.  The first solve of a handle asks the device.
+    const unsigned int cap_chunks = 4u * (unsigned int)eu_resident_capacity(S, S->cfg.pcg_precision == EULER_PCG_F32);
+    unsigned int guess = S->res_last_chunks;
+    if (!S->res_have_last) {
       HIPCHK(hipMemcpyAsync(S->sc_host, S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
       HIPCHK(hipStreamSynchronize(S->stream));
-      if (*S->res_err == 0) {
-        S->res_solves += 1;
+      guess = S->sc_host->n_chunks;
+    }
+    if (guess + guess / 16 + 8 <= cap_chunks || S->cfg.pcg_precision == EULER_PCG_F32) {
+      S->prof_iter = -2;
+      if ((rc = eu_launch_resident(S, cap_chunks))) return rc;      // (a no-op on the device when the right-hand side is all zero: main.c:742, p = 0 from the assembly)
+      HIPCHK(hipMemcpyAsync(S->sc_host, S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
+      HIPCHK(hipStreamSynchronize(S->stream));
+      S->res_last_chunks = S->sc_host->n_chunks; S->res_have_last = 1;
+      const int err = *S->res_err;
+      if (err == 0) {
+        if (S->sc_host->nonzero) S->res_solves += 1;
         eu_launch_velocity_update(S, dt);
         return EULER_OK;      // (sc_host is current)
       }
-      // a wait ran out (the workgroups were not all resident - another process on the device?): this system again with the multi-kernel path, which the handle keeps from here on
-      S->res_fallbacks += 1; S->res_disabled = 1; *S->res_err = 0;
-      if (S->cfg.pcg_precision == EULER_PCG_F32) { eu_set_error("the resident solver timed out and EULER_PCG_F32 has no other path"); return EULER_EHIP; }
+      *S->res_err = 0;
+      if (S->cfg.pcg_precision == EULER_PCG_F32) { eu_set_error(err == 2 ? "EULER_PCG_F32: the solve's active chunks do not fit the resident solver" : "the resident solver timed out and EULER_PCG_F32 has no other path"); return EULER_EHIP; }
+      if (err != 2) { S->res_fallbacks += 1; S->res_disabled = 1; }      // a wait ran out (the workgroups were not all resident - another process on the device?): the handle keeps to the multi-kernel path from here on
+      // (error 2: more active chunks than fit - the scene grew; this system with the multi-kernel path: k_pcg_reset + the assembly again, written whole)
       S->solve_seq -= 1;
-      S->lean_ok = 0;      // (the assembly runs a second time: it writes the solver arrays whole)
+      S->lean_ok = 0;
+      S->res_skip_once = 1;
       return eu_launch_project(S, dt);
     }
-    if (!S->sc_host->nonzero || nch == 0) {      // all_zero(r), main.c:742: p = 0
-      S->prof_iter = -2;
-      eu_launch_velocity_update(S, dt);
-      return EULER_OK;
-    }
-    // (more active chunks than find a wave at once: this solve takes the multi-kernel path below)
+    // (too many active chunks last time: the multi-kernel path below; its final copy of the scalars keeps the count current)
   }
   // if (!all_zero(r)) { ... }: every kernel below is a no-op when sc->nonzero == 0
   const bool tile = tile_fused(S);

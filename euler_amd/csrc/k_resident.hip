@@ -105,7 +105,7 @@ template <typename T> __device__ __forceinline__ T rs_factor_step(T aa, T own, T
 // Grid-wide reductions of NV values (kind k: sum if !is_max[k]) in ONE sweep: every workgroup's partial goes out as a granule, every
 // workgroup's first wave gathers all of them.  Returns false on a timeout.
 template <int NV>
-__device__ __forceinline__ bool rs_reduce(const ResArgs& a, double (&v)[NV], const bool (&is_max)[NV], int kind0, unsigned long long tag, double (*s_red)[3], double* s_tot, int* s_fail) {
+__device__ __forceinline__ bool rs_reduce(const ResArgs& a, int nwg, double (&v)[NV], const bool (&is_max)[NV], int kind0, unsigned long long tag, double (*s_red)[3], double* s_tot, int* s_fail) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int n = 0; n < NV; ++n) {
@@ -124,7 +124,6 @@ __device__ __forceinline__ bool rs_reduce(const ResArgs& a, double (&v)[NV], con
     }
   }
   if (wave == 0) {
-    const int nwg = (int)gridDim.x;
     const unsigned long long t_start = wall_clock64();
     bool failed = false;
 #pragma unroll
@@ -218,6 +217,11 @@ __global__ __launch_bounds__(RS_THREADS, 2) void k_pcg_resident(ResArgs a) {    
   __shared__ T s_edge[RS_WAVES][32];        // the halo's s' of lane 0 (entries 0..15: the row below the band) and of lane 63 (16..31: the row above), per record
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = (int)sc->n_chunks;
+  // The host launches as many workgroups as the device holds at once WITHOUT knowing this solve's number of active chunks (that would be a host round trip per solve):
+  // the first (nch + 3) / 4 take part, the others leave at once; a solve that needs more than were launched raises error 2 ("does not fit") and nobody starts.
+  const int nwg = (nch + RS_WAVES - 1) / RS_WAVES;
+  if (nwg > (int)gridDim.x) { if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+  if ((int)blockIdx.x >= nwg) return;
   const int ci = blockIdx.x * RS_WAVES + wave;
   const bool act = ci < nch;
   const int TS = a.g.TS, ntb = a.g.T / 16, nbands = a.g.nbands;
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(RS_THREADS, 2) void k_pcg_resident(ResArgs a) {    
     publish(zz, ss);
     double v[1] = {dsum};
     const bool mx[1] = {false};
-    if (!rs_reduce<1>(a, v, mx, 0, tag, s_red, &s_tot[0], &s_fail)) return;
+    if (!rs_reduce<1>(a, nwg, v, mx, 0, tag, s_red, &s_tot[0], &s_fail)) return;
     ++tag;
     sigma = v[0];
   }
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(RS_THREADS, 2) void k_pcg_resident(ResArgs a) {    
     {
       double v[1] = {dsa};
       const bool mx[1] = {false};
-      if (!rs_reduce<1>(a, v, mx, 0, tag, s_red, &s_tot[0], &s_fail)) return;
+      if (!rs_reduce<1>(a, nwg, v, mx, 0, tag, s_red, &s_tot[0], &s_fail)) return;
       ++tag;
       zs = v[0];
     }
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(RS_THREADS, 2) void k_pcg_resident(ResArgs a) {    
     {
       double v[2] = {mxr, dsum};
       const bool mx[2] = {true, false};
-      if (!rs_reduce<2>(a, v, mx, 1, tag, s_red, &s_tot[0], &s_fail)) return;
+      if (!rs_reduce<2>(a, nwg, v, mx, 1, tag, s_red, &s_tot[0], &s_fail)) return;
       ++tag;
       rnorm = v[0];
       if (rnorm <= a.tol) done = 1;                                               // main.c:756
@@ -414,11 +418,12 @@ int eu_resident_capacity(euler_sim* S, int f32) {
   if (per_cu > 3) per_cu = 3;      // (double: 2 by registers and LDS, float: 3)
   cap = per_cu * cus;
   if (cap > RS_MAX_WG) cap = RS_MAX_WG;
+  if (const char* e = getenv("EULER_RESIDENT_CAP")) { const int v = atoi(e); if (v > 0 && v < cap) cap = v; }      // (tests: a small capacity, so that a scene outgrows it)
   return cap;
 }
 
 // launch the whole solve; the caller has run k_pcg_reset + the assembly and knows n_chunks (> 0) and that the right-hand side is not all zero
-int eu_launch_resident(euler_sim* S, unsigned int n_chunks) {
+int eu_launch_resident(euler_sim* S, unsigned int n_chunks) {      // n_chunks: how many workgroups' worth of chunks to launch for (the exact count, or the device's capacity)
   ResArgs a;
   a.g = S->geom; a.mask = S->cellmask; a.b = S->b; a.p = S->p; a.r = S->r; a.pre = S->precon; a.zx = S->z; a.sx = S->s; a.list = S->chunk_list; a.sc = S->sc;
   a.gran = S->res_gran; a.tag0 = S->res_tag; a.band_lo = S->band_lo; a.max_iters = S->cfg.max_iterations; a.tol = S->cfg.tol; a.err = S->res_err;

@@ -139,6 +139,41 @@ def test_f32_gpu_against_the_oracle_float_restatement():
     assert np.array_equal(sim.get(ea.F_PRESSURE), sim.get(ea.F_PRESSURE).astype(np.float32).astype(np.float64))      # p holds float values
 
 
+def test_a_scene_that_outgrows_the_chip_moves_to_the_multi_kernel_path():
+    """The resident launch is sized from the PREVIOUS solve's active chunks (no host round trip in front of it); a solve that does not fit after all says so on the
+    device (error word 2), is redone with the multi-kernel path, and the following ones go there directly.  Driven here by a capacity of 8 workgroups (32 chunks,
+    EULER_RESIDENT_CAP) under a waterfall whose water keeps growing: the run equals the multi-kernel run to the tree mode's tolerance, nothing timed out."""
+    import os
+    import subprocess
+    import sys
+    code = """
+import sys, json
+import numpy as np
+import euler_amd as ea
+from euler_amd import scenarios
+a = ea.Simulation(300, 200, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE, max_iterations=2000).load_text(scenarios.waterfall(), upscale=True)
+b = ea.Simulation(300, 200, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE, max_iterations=2000, resident=ea.RESIDENT_OFF).load_text(scenarios.waterfall(), upscale=True)
+solves = 0
+worst = 0.0
+for f in range(70):
+    a.step(); b.step()
+    solves += a.stats().last_substeps if a.stats().last_pcg_iterations else 0
+    assert a.stats().last_substeps == b.stats().last_substeps
+    assert np.array_equal(a.get(ea.F_COUNT), b.get(ea.F_COUNT)), f
+    pa, pb = a.get(ea.F_PRESSURE), b.get(ea.F_PRESSURE)
+    worst = max(worst, float(np.abs(pa - pb).max() / max(np.abs(pb).max(), 1.0)))
+print(json.dumps({"info": list(a.resident_info()), "solves": solves, "worst_dp": worst, "fluid": int((a.get(ea.F_COUNT) > 0).sum())}))
+"""
+    env = dict(os.environ, EULER_RESIDENT_CAP="8", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["info"][0] and d["info"][2] == 0                 # still eligible, no time-out
+    assert 0 < d["info"][1] < d["solves"], d                  # the early solves ran resident, the later ones did not fit
+    assert d["worst_dp"] <= 1e-6, d
+
+
 def test_f32_needs_the_resident_solver():
     with pytest.raises(ea.EulerError):
         ea.Simulation(4096, 4096, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE, pcg_precision=ea.PCG_F32)      # too many chunks
