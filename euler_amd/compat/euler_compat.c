@@ -64,9 +64,10 @@ void sim_init(args_t in) {
   if (solver) {
     if (!strcmp(solver, "reference")) cfg.precond = EULER_PRECOND_IC0;
     else if (!strcmp(solver, "tile")) cfg.precond = EULER_PRECOND_IC0_TILE;
+    else if (!strcmp(solver, "tile-fp32")) { cfg.precond = EULER_PRECOND_IC0_TILE; cfg.pcg_precision = EULER_PCG_F32; cfg.dot_mode = EULER_DOT_TREE; }   /* solver vectors in float (small grids: the resident solver) */
     else if (!strcmp(solver, "two-level")) cfg.precond = EULER_PRECOND_IC0_TILE2;
     else if (!strcmp(solver, "multilevel")) cfg.precond = EULER_PRECOND_IC0_TILE_MG;
-    else { fprintf(stderr, "EULER_COMPAT_SOLVER=%s: expected reference, tile, two-level or multilevel\n", solver); exit(1); }
+    else { fprintf(stderr, "EULER_COMPAT_SOLVER=%s: expected reference, tile, tile-fp32, two-level or multilevel\n", solver); exit(1); }
   }
   const char* maxit = getenv("EULER_COMPAT_MAX_ITERATIONS");
   if (maxit && (cfg.max_iterations = atoi(maxit)) < 1) { fprintf(stderr, "EULER_COMPAT_MAX_ITERATIONS=%s: expected a positive count\n", maxit); exit(1); }
