@@ -183,6 +183,21 @@ def cpu_baseline_roofline_run(libs, tol, N=2048):
         o.close()
     except Exception as e:      # never let the extra figure break the bench line
         res["_native"] = {"error": str(e)}
+    try:      # ... and the COMPILED REFERENCE itself (oracle/_ref: the unmodified main.c, built -O3 -ffp-contract=off in the build container) on the only grid it has
+        if oracle_lib.have_ref():
+            from golden_util import load as gload, scenario_text
+            path = os.path.join(tempfile.mkdtemp(prefix="euler_ref_"), "block.txt")
+            with open(path, "w") as f:
+                f.write(scenario_text(gload("block_frames.npz")))
+            r = oracle_lib.Reference().init(path)
+            t0 = time.perf_counter()
+            for _ in range(100):
+                r.step()
+            dt = time.perf_counter() - t0
+            res["_reference"] = dict(value=4000 * 100 / dt, seconds=round(dt, 3), steps=100, kind="reference",
+                                     what="oracle/_ref/libeuler_ref.so: the unmodified reference main.c (gcc -O3 -ffp-contract=off), scenarios/block.txt on its compile-time 100x40 grid, 100 sim_step calls, single thread")
+    except Exception as e:
+        res["_reference"] = {"error": str(e)}
     return res
 
 
@@ -1022,6 +1037,8 @@ def compact_line(full, limit=LINE_LIMIT):
             c["equal_tolerance"] = _pick(cpu["equal_tolerance"], ("value", "seconds", "pcg_iterations", "substeps", "error"))
         if isinstance(cpu.get("configs0_100x40_block_100_steps"), dict):
             c["configs0_value"] = cpu["configs0_100x40_block_100_steps"].get("value")
+        if isinstance(cpu.get("reference_main_c_100x40_block_100_steps"), dict) and "value" in cpu["reference_main_c_100x40_block_100_steps"]:
+            c["reference_main_c_100x40_value"] = cpu["reference_main_c_100x40_block_100_steps"]["value"]      # (the compiled reference itself: kind "reference")
         line["cpu_baseline"] = c
     else:
         line["cpu_baseline"] = None
@@ -1419,6 +1436,7 @@ def main():
                                                                 "16384x16384": round(per_cell_substep * 16384 * 16384, 1),
                                                                 "note": "EXTRAPOLATED from the %d^2 sample at constant time per cell and substep (100 iterations each)" % NS},
                            "configs0_100x40_block_100_steps": cpu.get("_native"),
+                           "reference_main_c_100x40_block_100_steps": cpu.get("_reference"),
                            "configs1_1024_dam_break_same_state": (secondary.get("configs1_1024_dam_break") or {}).get("cpu_same_state"),
                            "host_cores_available": os.cpu_count()}
             except Exception as e:
