@@ -4,31 +4,29 @@
 metric    cells*steps/s of the whole sim_step() path (one step = one 0.1 s frame = up to 8 CFL substeps, each with a
           PCG pressure projection), plus the achieved HBM rate of the pressure solve against the MI355X roofline.
 
+output    ONE compact JSON line on stdout (rank 0; < 8 KB: compact_line, tests/test_bench_line.py - round 3's 25.7 KB line came back unparsed from the driver):
+          the contract's keys, `roofline`, `pcg_iteration`, `kernels`, `cpu_baseline`, the `converged` block and one-number summaries of the secondary blocks.
+          The whole object goes to bench_full.json beside it (and under gpurun_out/).  Inputs are resident in HBM when a timed region starts.
+
 headline  N=1: configs[2], the 8192x8192 half-filled tank, "pressure-solve roofline run" (SURVEY 8d config 3): tol = 0 and
           max_iterations = 100, so every substep runs exactly 100 PCG iterations; the timed frames lie in the tank's saturated
           phase (the reference's maximum of 8 CFL substeps per frame, preroll_into_solves).  It runs in the ROOFLINE MODE SURVEY 7 (hard
           part 1b) and 8d name: the tile-local IC(0) preconditioner (EULER_PRECOND_IC0_TILE, include/euler.h) - the reference's
           recurrences restricted to 64-row x 16-column blocks, one pass over memory per iteration - which is NOT the reference's
-          sequence of iterates (same solution where PCG converges; tests/test_gpu_tile_precond.py).  The SAME workload in the
-          parity mode (the reference's own IC(0), bit-identical iterates) is measured right beside it ("exact_ic0"), and so
-          are configs[1] (1024^2 dam break, parity mode, checked in-run against the oracle), the 16384^2 projection and the
-          time both modes need to SOLVE a system to the reference's tolerance.  Every number carries its mode.
+          sequence of iterates (same solution where PCG converges; tests/test_gpu_tile_precond.py).  Every number carries its mode.
 
-roofline  bytes are counted three ways and named: `frac_traffic` = HBM bytes rocprofv3's FETCH_SIZE / WRITE_SIZE counters saw
-          for the kernel in a live PMC pass of this very workload (child processes of this run, calibrated on a copy of known
-          size in the same pass) / launch time; `frac_active` = SURVEY 8d's algorithmic bytes x FLUID cells (what the
-          kernels visit) / time; `frac_dense` = the same x ALL X*Y cells (the reference's dense loops; exceeds what HBM moved on
-          sparse scenes and is never the headline).  `roofline.frac` is the ALGORITHMIC one (frac_active) since round 3; the traffic-based
-          figure stays beside it as `frac_traffic` / `traffic_over_algorithmic`.
+roofline  `roofline.frac` / `achieved` = ALGORITHMIC bytes of the dominant launch (ITER_BYTES: bytes per fluid cell of every launch of an iteration, per mode) x the
+          fluid cells it processes / its average launch time (HIP events inside the timed region).  `traffic` = HBM bytes rocprofv3's FETCH_SIZE / WRITE_SIZE
+          counters saw for the kernel in a live PMC pass of this very workload (child processes of this run, calibrated on a copy of known size in the same
+          pass), with `frac_traffic` / `traffic_over_algorithmic` beside it.  An iteration's bytes are the SUM of its launches' bytes (asserted in summarize()).
 
-quality   what the headline's speed is worth against the reference (none of it is the headline): `equal_residual` - the budget at which the tile-local,
-          two-level and multilevel modes reach the residual the reference's IC(0) reaches in its 100 iterations, frames at that budget, the pressure
-          error of each against the converged solution; `converged_frames_multilevel` - the headline workload with EVERY solve run to the reference's
-          tolerance (EULER_PRECOND_IC0_TILE_MG, cap lifted); `secondary.parity_vs_reference_ic0` - one frame per BASELINE workload state in every
-          mode against the reference's IC(0) on the oracle and against the converged frame; `secondary.time_to_solution`; `strong_16384_dam_break`
-          - configs[3] on this many GPUs (N = 1: the strong-scaling denominator), roofline mode and converged frames.
-
-One JSON line on stdout (rank 0).  Inputs are resident in HBM when a timed region starts.
+beside it `converged` - the same workload with EVERY solve run to the reference's tolerance (multilevel mode, cap lifted): its own roofline, the CPU at equal tolerance
+          (the oracle's IC(0) to 1e-6), the deviation from the reference's algorithm run to convergence; `summary.exact_ic0` - the same frames in the parity mode (the
+          reference's own IC(0), bit-identical iterates); `summary.quality_100_iterations` - what the reference's budget is worth in every mode against the converged
+          solution; `summary.configs1_1024_dam_break` - BASELINE configs[1]: parity mode checked in-run against the oracle, the resident solver (one persistent launch
+          per solve), its float variant ("fp32") and the multi-kernel form; `summary.projection_16384` with its own PMC pass; `summary.time_to_solution_2048_ms`;
+          `summary.strong_16384_dam_break` - configs[3] on this many GPUs (N = 1: the strong-scaling denominator).  `--quality` adds the long studies (equal-residual
+          budget scans, one frame per BASELINE workload against the reference's IC(0) on the oracle) to bench_full.json.
 """
 import argparse
 import glob
