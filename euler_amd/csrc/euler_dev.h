@@ -136,6 +136,8 @@ struct euler_sim {
   float *u, *v, *utmp, *vtmp;
   uint8_t *solid, *source, *sink, *count, *prev_count;
   unsigned int* count32;   // the binning counters of the window, COLUMN-major: [x][y - win_lo] (k_markers.hip), never shifted
+  uint8_t* blockedT;       // sink | solid per cell, COLUMN-major like count32 (whole-grid handles; k_bin_markers); rebuilt when blocked_dirty
+  int blocked_dirty;
   float* dye[6];          // --rainbow only (cfg.rainbow): g_r, g_g, g_b, g_rtmp, g_gtmp, g_btmp (main.c:76-81)
   // markers, ping-pong (main.c:95)
   float2* markers[2];

@@ -282,8 +282,25 @@ __global__ __launch_bounds__(256) void k_rotate_counts(uint8_t* __restrict__ pre
   }
 }
 
+// sink | solid per cell, COLUMN-major like count32 (static between scenario edits: rebuilt when euler_sim.blocked_dirty says so).  The marker array walks the grid column by
+// column, so a wave's 64 markers sit in ~16 cells of one column: in the row-major grids that is 16-17 cache lines per gather and two gathers per marker (1.37 ms at 8192^2,
+// bound by lines per gather like k_advect_markers_a: profiles/r04_marker_gather_experiment.md); here it is one gather out of one or two lines, next to the counters' own line.
+__global__ __launch_bounds__(256) void k_blocked_transpose(const uint8_t* __restrict__ sink, const uint8_t* __restrict__ solid, uint8_t* __restrict__ blockedT, int X, int Y) {
+  __shared__ uint8_t tile[64][65];
+  const int xb = blockIdx.x * 64, yb = blockIdx.y * 64, l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int k = w; k < 64; k += 4) {                       // row yb + k, columns xb + l
+    const int x = xb + l, y = yb + k;
+    tile[k][l] = (x < X && y < Y) ? (uint8_t)((sink[(size_t)y * X + x] | solid[(size_t)y * X + x]) != 0) : (uint8_t)0;
+  }
+  __syncthreads();
+  for (int k = w; k < 64; k += 4) {                       // column xb + k, rows yb + l
+    const int x = xb + k, y = yb + l;
+    if (x < X && y < Y) blockedT[(size_t)x * Y + y] = tile[l][k];
+  }
+}
+
 __global__ __launch_bounds__(256) void k_bin_markers(const float2* __restrict__ m, unsigned long long n,
-                                                     const uint8_t* __restrict__ sink, const uint8_t* __restrict__ solid,
+                                                     const uint8_t* __restrict__ blockedT,
                                                      unsigned int* count32, unsigned long long* __restrict__ delmask, int X, int H) {
   const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   bool del = false, live = false;
@@ -291,9 +308,8 @@ __global__ __launch_bounds__(256) void k_bin_markers(const float2* __restrict__ 
   if (i < n) {
     const float2 p = m[i];
     const int x = (int)floorf(p.x / EU_H), y = (int)floorf(p.y / EU_H);
-    const size_t c = (size_t)y * X + x;
     ct = (size_t)x * H + y;
-    del = (sink[c] | solid[c]) != 0;
+    del = blockedT[ct] != 0;      // refresh_marker_counts drops markers in sink or solid cells (main.c:109-112)
     live = !del;
   }
   bin_aggregated(count32, live, ct);
@@ -372,8 +388,12 @@ int eu_marker_advect_b(euler_sim* S, unsigned long long n, const unsigned int* k
 int eu_launch_refresh_counts(euler_sim* S) {
   const unsigned long long n = S->n_markers_host;
   eu_marker_rotate_counts(S);
-  LAUNCH(S, KC_MARKER_BIN, k_bin_markers, dim3(eu_blocks((size_t)n, 256)), dim3(256), S->markers[S->cur], n, S->sink,
-         S->solid, S->count32, S->evmask, S->X, S->Y);
+  if (S->blocked_dirty) {      // (the solid / sink grids changed: scenario load, euler_set_field, a snapshot)
+    LAUNCH(S, KC_MARKER_BIN, k_blocked_transpose, dim3((S->X + 63) / 64, (S->Y + 63) / 64), dim3(256), S->sink, S->solid, S->blockedT, S->X, S->Y);
+    S->blocked_dirty = 0;
+  }
+  LAUNCH(S, KC_MARKER_BIN, k_bin_markers, dim3(eu_blocks((size_t)n, 256)), dim3(256), S->markers[S->cur], n, S->blockedT,
+         S->count32, S->evmask, S->X, S->Y);
   int rc = eu_ordered_select(S, S->evmask, (size_t)((n + 63) / 64), S->sel_idx, &S->ms->n_deleted);
   if (rc) return rc;
   LAUNCH(S, KC_MARKER_COMPACT, k_compact_markers, dim3(256), dim3(256), S->markers[S->cur], S->sel_idx, S->evmask, S->ms);
