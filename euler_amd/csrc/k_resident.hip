@@ -205,7 +205,7 @@ __device__ __forceinline__ void rs_tile_solve(const T (&rr)[16], const T* ee_l, 
 }
 
 template <typename T>
-__global__ __launch_bounds__(RS_THREADS, 2) void k_pcg_resident(ResArgs a) {      // (<= 256 registers: double 254, float 168)      // (double: one wave per SIMD and all 512 registers - at 256 the chunk's state spilled)
+__global__ __launch_bounds__(RS_THREADS, 2) void k_pcg_resident(ResArgs a) {      // (<= 256 registers: double 254, float 168 - see the opaque copies in the iteration loop)
   typedef double d2 __attribute__((ext_vector_type(2)));
   PcgScalars* sc = a.sc;
   if (!sc->nonzero) return;      // all_zero(r), main.c:742 (every thread of the grid reads the same word)
