@@ -425,7 +425,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   CREATECHK(hipHostMalloc((void**)&S->poll_host, 2 * sizeof(PcgScalars), hipHostMallocDefault));
   CREATECHK(hipHostMalloc((void**)&S->res_err, sizeof(int), hipHostMallocDefault));      // (the resident solver raises it from the device: k_resident.hip)
   *S->res_err = 0;
-  DALLOC(S->res_gran, 2 * 3 * 768 * 2);      // (k_resident.hip RS_MAX_WG)
+  DALLOC(S->res_gran, 2 * 2 * (2 * 768) * 2);      // (k_resident.hip: [2 generations][2 groups][2 RS_MAX_WG granules] x 2 words)
   S->res_tag = 1;
   memset(S->poll_host, 0, 2 * sizeof(PcgScalars));
   for (hipEvent_t& e : S->poll_event) CREATECHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));

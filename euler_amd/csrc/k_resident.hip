@@ -42,7 +42,7 @@ struct ResArgs {
   void *zx, *sx;               // the cells other waves read: z and s at their band-skewed element index, as T (storage: the handle's z and s arrays)
   const unsigned int* list;
   PcgScalars* sc;
-  unsigned long long* gran;    // [2][3][RS_MAX_WG] granules of 16 bytes (driver.hip allocates 2 * 3 * 768 * 2 words)
+  unsigned long long* gran;    // [2 generations][2 groups][2 RS_MAX_WG] granules of 16 bytes (driver.hip allocates them)
   unsigned long long tag0;     // generation of this launch's first reduction (monotonic over the handle's life: nothing is ever cleared)
   int band_lo, max_iters;
   double tol;
@@ -102,10 +102,13 @@ template <typename T> __device__ __forceinline__ T rs_factor_step(T aa, T own, T
   return (T)1 / (std::is_same<T, float>::value ? (T)sqrtf((float)e) : (T)sqrt((double)e));
 }
 
-// Grid-wide reductions of NV values (kind k: sum if !is_max[k]) in ONE sweep: every workgroup's partial goes out as a granule, every
-// workgroup's first wave gathers all of them.  Returns false on a timeout.
+// Grid-wide reductions of NV values (value n: a maximum if is_max[n], else a sum) in ONE sweep: every workgroup's partials go out as NV adjacent granules (index
+// wg * NV + n), every workgroup's first wave gathers all nwg * NV of them - lane l takes the granules l, l + 64, ...: with NV = 2 the even lanes see only value 0, the
+// odd lanes only value 1, so both values cost one round trip - and folds them in a fixed order (a lane its own in index order, then a butterfly over the lanes of
+// the same parity).  Returns false on a timeout.  `group` 0 / 1 = the iteration's first / second reduction (separate granule arrays, two generations each).
 template <int NV>
-__device__ __forceinline__ bool rs_reduce(const ResArgs& a, int nwg, double (&v)[NV], const bool (&is_max)[NV], int kind0, unsigned long long tag, double (*s_red)[3], double* s_tot, int* s_fail) {
+__device__ __forceinline__ bool rs_reduce(const ResArgs& a, int nwg, double (&v)[NV], const bool (&is_max)[NV], int group, unsigned long long tag, double (*s_red)[3], double* s_tot, int* s_fail) {
+  static_assert(NV == 1 || NV == 2, "one or two values");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int n = 0; n < NV; ++n) {
@@ -114,49 +117,46 @@ __device__ __forceinline__ bool rs_reduce(const ResArgs& a, int nwg, double (&v)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's halo cells have landed before the granule that vouches for them
   __syncthreads();
-  const int par = (int)(tag & 1);
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int n = 0; n < NV; ++n) {
-      double t = s_red[0][n];
-      for (int k = 1; k < RS_WAVES; ++k) t = is_max[n] ? (s_red[k][n] > t ? s_red[k][n] : t) : t + s_red[k][n];
-      rs_st_gran(a.gran + ((size_t)(par * 3 + kind0 + n) * RS_MAX_WG + blockIdx.x) * 2, t, tag);
-    }
+  unsigned long long* gbase = a.gran + (size_t)((int)(tag & 1) * 2 + group) * (RS_MAX_WG * 2) * 2;      // [generation parity][group][RS_MAX_WG * 2 granules] x 2 words
+  if (threadIdx.x < NV) {
+    const int n = threadIdx.x;
+    double t = s_red[0][n];
+    for (int k = 1; k < RS_WAVES; ++k) t = is_max[n] ? (s_red[k][n] > t ? s_red[k][n] : t) : t + s_red[k][n];
+    rs_st_gran(gbase + ((size_t)blockIdx.x * NV + n) * 2, t, tag);
   }
   if (wave == 0) {
     const unsigned long long t_start = wall_clock64();
+    const int total = nwg * NV;
+    const bool mine_max = is_max[NV == 2 ? (lane & 1) : 0];      // (the kind of every granule this lane sees)
     bool failed = false;
-#pragma unroll
-    for (int n = 0; n < NV; ++n) {
-      const unsigned long long* base = a.gran + (size_t)(par * 3 + kind0 + n) * RS_MAX_WG * 2;
-      double acc = 0.0;
-      for (int q = 0; q < (RS_MAX_WG / 64) / 4; ++q) {      // 4 granules per lane and pass: lane, lane + 64, ...
-        const int i0 = lane + 64 * (4 * q);
-        if (64 * (4 * q) >= nwg) break;                     // (wave-uniform)
-        rs_u4 w0, w1, w2, w3;
-        const bool h0 = i0 < nwg, h1 = i0 + 64 < nwg, h2 = i0 + 128 < nwg, h3 = i0 + 192 < nwg;
-        const unsigned long long *p0 = base + (size_t)(h0 ? i0 : 0) * 2, *p1 = base + (size_t)(h1 ? i0 + 64 : 0) * 2,
-                                 *p2 = base + (size_t)(h2 ? i0 + 128 : 0) * 2, *p3 = base + (size_t)(h3 ? i0 + 192 : 0) * 2;
-        for (unsigned int spins = 1;; ++spins) {
-          rs_ld_gran4(p0, p1, p2, p3, w0, w1, w2, w3);
-          const bool ok = (!h0 || rs_gran_tag(w0) == tag) && (!h1 || rs_gran_tag(w1) == tag) && (!h2 || rs_gran_tag(w2) == tag) && (!h3 || rs_gran_tag(w3) == tag);
-          if (__all(ok)) break;
-          if ((spins & 4095u) == 0) {      // (rarely: the clock is a scalar memory read, the error word lives in host memory)
-            const bool give_up = wall_clock64() - t_start > RS_TIMEOUT_TICKS || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
-            if (__any(give_up)) { failed = true; break; }      // (wave-uniform)
-          }
-          __builtin_amdgcn_s_sleep(1);
+    double acc = 0.0;
+    for (int q = 0; 256 * q < total && !failed; ++q) {      // 4 granules per lane and pass
+      const int i0 = lane + 256 * q;
+      rs_u4 w0, w1, w2, w3;
+      const bool h0 = i0 < total, h1 = i0 + 64 < total, h2 = i0 + 128 < total, h3 = i0 + 192 < total;
+      const unsigned long long *p0 = gbase + (size_t)(h0 ? i0 : 0) * 2, *p1 = gbase + (size_t)(h1 ? i0 + 64 : 0) * 2,
+                               *p2 = gbase + (size_t)(h2 ? i0 + 128 : 0) * 2, *p3 = gbase + (size_t)(h3 ? i0 + 192 : 0) * 2;
+      for (unsigned int spins = 1;; ++spins) {
+        rs_ld_gran4(p0, p1, p2, p3, w0, w1, w2, w3);
+        const bool ok = (!h0 || rs_gran_tag(w0) == tag) && (!h1 || rs_gran_tag(w1) == tag) && (!h2 || rs_gran_tag(w2) == tag) && (!h3 || rs_gran_tag(w3) == tag);
+        if (__all(ok)) break;
+        if ((spins & 4095u) == 0) {      // (rarely: the clock is a scalar memory read, the error word lives in host memory)
+          const bool give_up = wall_clock64() - t_start > RS_TIMEOUT_TICKS || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+          if (__any(give_up)) { failed = true; break; }      // (wave-uniform)
         }
-        if (failed) break;
-        // fixed order: a lane folds its granules in index order, the lanes fold as a butterfly
-        const double g0 = h0 ? rs_gran_val(w0) : 0.0, g1 = h1 ? rs_gran_val(w1) : 0.0, g2 = h2 ? rs_gran_val(w2) : 0.0, g3 = h3 ? rs_gran_val(w3) : 0.0;
-        if (is_max[n]) { acc = g0 > acc ? g0 : acc; acc = g1 > acc ? g1 : acc; acc = g2 > acc ? g2 : acc; acc = g3 > acc ? g3 : acc; }
-        else { acc += g0; acc += g1; acc += g2; acc += g3; }
+#ifdef RS_POLL_SLEEP      // (measured: 11.0 us per iteration with the nap, 10.7 without - one wave per workgroup polls, the others wait at the barrier)
+        __builtin_amdgcn_s_sleep(1);
+#endif
       }
       if (failed) break;
+      const double g0 = h0 ? rs_gran_val(w0) : 0.0, g1 = h1 ? rs_gran_val(w1) : 0.0, g2 = h2 ? rs_gran_val(w2) : 0.0, g3 = h3 ? rs_gran_val(w3) : 0.0;
+      if (mine_max) { acc = g0 > acc ? g0 : acc; acc = g1 > acc ? g1 : acc; acc = g2 > acc ? g2 : acc; acc = g3 > acc ? g3 : acc; }
+      else { acc += g0; acc += g1; acc += g2; acc += g3; }
+    }
+    if (!failed) {
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { const double w = __shfl_xor(acc, o, 64); acc = is_max[n] ? (w > acc ? w : acc) : acc + w; }
-      if (lane == 0) s_tot[n] = acc;
+      for (int o = 32; o >= NV; o >>= 1) { const double w = __shfl_xor(acc, o, 64); acc = mine_max ? (w > acc ? w : acc) : acc + w; }      // (NV = 2: the lanes of one parity)
+      if (lane < NV) s_tot[lane] = acc;
     }
     if (lane == 0) {
       *s_fail = failed ? 1 : 0;
