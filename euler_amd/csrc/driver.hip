@@ -217,6 +217,10 @@ extern "C" void euler_destroy(euler_sim* S) {
   for (uint8_t* g : {S->solid, S->source, S->sink, S->count, S->prev_count}) if (g) (void)hipFree(g + wo);
   if (S->count32) (void)hipFree(S->count32);
   if (S->blockedT) (void)hipFree(S->blockedT);
+  if (S->uT) (void)hipFree(S->uT);
+  if (S->vT) (void)hipFree(S->vT);
+  if (S->countT) (void)hipFree(S->countT);
+  if (S->solidT) (void)hipFree(S->solidT);
   if (S->sys_m) (void)hipFree(S->sys_m);
   if (S->sys_div) (void)hipFree(S->sys_div);
   void* dev[] = {S->markers[0], S->markers[1], S->keys[0], S->keys[1], S->ms, S->evmask, S->ev_theta, S->ev_delta, S->sel_idx, S->act_idx,
@@ -332,8 +336,8 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   DALLOC(S->u, Cw); DALLOC(S->v, Cw); DALLOC(S->utmp, Cw); DALLOC(S->vtmp, Cw);
   DALLOC(S->solid, Cw); DALLOC(S->source, Cw); DALLOC(S->sink, Cw); DALLOC(S->count, Cw); DALLOC(S->prev_count, Cw);
   DALLOC(S->count32, Cw);
-  if (!S->slab_on) DALLOC(S->blockedT, Cw);
-  S->blocked_dirty = 1;
+  if (!S->slab_on) { DALLOC(S->blockedT, Cw); DALLOC(S->uT, Cw); DALLOC(S->vT, Cw); DALLOC(S->countT, Cw); DALLOC(S->solidT, Cw); }      // (the marker stage's column-major copies)
+  S->blocked_dirty = 1; S->solidT_dirty = 1;
   DALLOC(S->sys_m, Cw); DALLOC(S->sys_div, Cw);
   if (S->cfg.rainbow) for (float*& d : S->dye) DALLOC(d, Cw);      // (the window like every row-major field; the whole grid without slabs)
   // MAX_MARKER_COUNT = 4 X Y (main.c:92) is the GLOBAL cap; a slab holds the markers inside its rows: room for 6 per owned cell
@@ -505,7 +509,7 @@ static int upload_scenario(euler_sim* S, const uint8_t* solid, const uint8_t* so
   HIPCHK(hipMemcpyAsync(S->solid + wo, solid + wo, Cw, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(S->source + wo, source + wo, Cw, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(S->sink + wo, sink + wo, Cw, hipMemcpyHostToDevice, st));
-  S->blocked_dirty = 1;
+  S->blocked_dirty = 1; S->solidT_dirty = 1;
   for (float* f : {S->u, S->v, S->utmp, S->vtmp}) HIPCHK(hipMemsetAsync(f + wo, 0, Cw * sizeof(float), st));
   for (double* d : {S->b, S->p, S->r, S->z, S->s, S->s2, S->q, S->precon}) HIPCHK(hipMemsetAsync(d + S->skew_off, 0, S->Sw * sizeof(double), st));
   for (float* d : S->dye) if (d) HIPCHK(hipMemsetAsync(d + wo, 0, Cw * sizeof(float), st));
@@ -888,7 +892,7 @@ extern "C" int euler_set_field(euler_sim* S, int32_t f, const void* src, size_t 
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(S->stream));
   }
-  if (f == EULER_F_SOLID || f == EULER_F_SINK) S->blocked_dirty = 1;      // (k_bin_markers' column-major copy follows at the next refresh)
+  if (f == EULER_F_SOLID || f == EULER_F_SINK) { S->blocked_dirty = 1; S->solidT_dirty = 1; }      // (the marker stage's column-major copies follow at their next use)
   if (f == EULER_F_SOURCE) {
     const uint8_t* s = (const uint8_t*)src;
     size_t nsrc = 0;

@@ -138,6 +138,8 @@ struct euler_sim {
   unsigned int* count32;   // the binning counters of the window, COLUMN-major: [x][y - win_lo] (k_markers.hip), never shifted
   uint8_t* blockedT;       // sink | solid per cell, COLUMN-major like count32 (whole-grid handles; k_bin_markers); rebuilt when blocked_dirty
   int blocked_dirty;
+  float *uT, *vT; uint8_t *countT, *solidT;   // COLUMN-major copies of u, v, the count grid (made in front of every marker advection) and of the solid grid (when blocked_dirty): whole-grid handles only
+  int solidT_dirty;
   float* dye[6];          // --rainbow only (cfg.rainbow): g_r, g_g, g_b, g_rtmp, g_gtmp, g_btmp (main.c:76-81)
   // markers, ping-pong (main.c:95)
   float2* markers[2];
@@ -386,29 +388,31 @@ __device__ __forceinline__ float eu_frac(float f, bool start_ok, bool end_ok) { 
 __device__ __forceinline__ float eu_clampf(float lo, float x, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 // interpolate(), main.c:337-364.  TYPE 0 = cell centres (P), 1 = U samples, 2 = V samples.
-template <int TYPE>
+// TR: q and g.count are stored COLUMN-major, [x][y] (the marker stage's copies: k_markers.hip) - the same values, the strides swapped
+template <int TYPE, bool TR = false>
 __device__ __forceinline__ float eu_interp(const GridRef& g, const float* __restrict__ q, float ix, float iy) {
   ix = eu_clampf(0.f, ix, TYPE == 1 ? g.ux_lim : g.vx_lim);   // P extent = (X, Y): x like V, y like U
   iy = eu_clampf(0.f, iy, TYPE == 2 ? g.vy_lim : g.uy_lim);
   float wx, wy;
   const float fx = modff(ix, &wx), fy = modff(iy, &wy);
   const int bx = (int)wx, by = (int)wy;
-  const size_t i00 = (size_t)by * g.X + bx;
+  const size_t sx = TR ? (size_t)g.Y : (size_t)1, sy = TR ? (size_t)1 : (size_t)g.X;      // one step in x / in y
+  const size_t i00 = (size_t)by * sy + (size_t)bx * sx;
   // the four samples are loaded unconditionally and next to the mask bytes (the clamps keep all of them inside the arrays,
   // ghost rows included): one memory round trip instead of two - the kernels that interpolate are latency-bound
-  const float r00 = q[i00], r01 = q[i00 + 1], r10 = q[i00 + g.X], r11 = q[i00 + g.X + 1];
+  const float r00 = q[i00], r01 = q[i00 + sx], r10 = q[i00 + sy], r11 = q[i00 + sy + sx];
   bool v00, v01, v10, v11;
   if (TYPE == 0) {
-    v00 = g.count[i00] != 0; v01 = g.count[i00 + 1] != 0;
-    v10 = g.count[i00 + g.X] != 0; v11 = g.count[i00 + g.X + 1] != 0;
+    v00 = g.count[i00] != 0; v01 = g.count[i00 + sx] != 0;
+    v10 = g.count[i00 + sy] != 0; v11 = g.count[i00 + sy + sx] != 0;
   } else if (TYPE == 1) {
-    const bool c0 = g.count[i00] != 0, c1 = g.count[i00 + 1] != 0, c2 = g.count[i00 + 2] != 0;
-    const bool d0 = g.count[i00 + g.X] != 0, d1 = g.count[i00 + g.X + 1] != 0, d2 = g.count[i00 + g.X + 2] != 0;
+    const bool c0 = g.count[i00] != 0, c1 = g.count[i00 + sx] != 0, c2 = g.count[i00 + 2 * sx] != 0;
+    const bool d0 = g.count[i00 + sy] != 0, d1 = g.count[i00 + sy + sx] != 0, d2 = g.count[i00 + sy + 2 * sx] != 0;
     v00 = c0 | c1; v01 = c1 | c2; v10 = d0 | d1; v11 = d1 | d2;
   } else {
-    const bool c0 = g.count[i00] != 0, c1 = g.count[i00 + 1] != 0;
-    const bool d0 = g.count[i00 + g.X] != 0, d1 = g.count[i00 + g.X + 1] != 0;
-    const bool e0 = g.count[i00 + 2 * (size_t)g.X] != 0, e1 = g.count[i00 + 2 * (size_t)g.X + 1] != 0;
+    const bool c0 = g.count[i00] != 0, c1 = g.count[i00 + sx] != 0;
+    const bool d0 = g.count[i00 + sy] != 0, d1 = g.count[i00 + sy + sx] != 0;
+    const bool e0 = g.count[i00 + 2 * sy] != 0, e1 = g.count[i00 + 2 * sy + sx] != 0;
     v00 = c0 | d0; v01 = c1 | d1; v10 = d0 | e0; v11 = d1 | e1;
   }
   const float q00 = v00 ? r00 : 0.f, q01 = v01 ? r01 : 0.f;

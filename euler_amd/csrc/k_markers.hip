@@ -7,6 +7,8 @@
 // the reference's order exactly, in parallel.
 #include "euler_dev.h"
 
+#include <stdlib.h>
+
 #include <float.h>
 
 // ==========================================================================================
@@ -123,18 +125,17 @@ __device__ __forceinline__ float time_to(float p0, float p1, float vel) {   // m
   return fabsf(vel) > 0.f ? (p1 - p0) / vel : FLT_MAX;
 }
 
+// TR: u, v, g.count and solid are the COLUMN-major copies (k_transpose_for_markers): the marker array walks the grid column by column (main.c:243-266), so a wave's
+// 64 markers sit in ~16 cells of one column - 16-17 cache lines per gather in the row-major fields, one or two in the column-major ones.  The same values: the same bits.
+template <bool TR>
 __device__ __forceinline__ AdvectOut advect_one(const GridRef& g, const float* __restrict__ u, const float* __restrict__ v,
                                                 const uint8_t* __restrict__ solid, float px, float py, float dt) {
   AdvectOut o;
   o.events = 0; o.theta = 0.f; o.delta = 0.f;
   // velocity_at (main.c:440-449)
-#ifdef EU_EXP_TR      // timing experiment (WRONG results): the gathers walk the arrays as if they were stored column-major
-  float vx = eu_interp<1>(g, u, py / EU_H - 0.5f, px / EU_H - 1.f);
-  float vy = eu_interp<2>(g, v, py / EU_H - 1.f, px / EU_H - 0.5f);
-#else
-  float vx = eu_interp<1>(g, u, px / EU_H - 1.f, py / EU_H - 0.5f);
-  float vy = eu_interp<2>(g, v, px / EU_H - 0.5f, py / EU_H - 1.f);
-#endif
+  float vx = eu_interp<1, TR>(g, u, px / EU_H - 1.f, py / EU_H - 0.5f);
+  float vy = eu_interp<2, TR>(g, v, px / EU_H - 0.5f, py / EU_H - 1.f);
+  auto is_solid = [&](int sy_, int sx_) -> bool { return solid[TR ? (size_t)sx_ * g.Y + sy_ : (size_t)sy_ * g.X + sx_] != 0; };
   int xi = (int)floorf(px / EU_H), yi = (int)floorf(py / EU_H);
   const int xdir = vx > 0 ? 1 : -1;
   int nxi = xi + (vx > 0 ? 1 : 0);
@@ -150,7 +151,7 @@ __device__ __forceinline__ AdvectOut advect_one(const GridRef& g, const float* _
   int guard = 0;
   while (t_near < dt && guard++ < 64) {
     if (tx < ty) {
-      if (solid[(size_t)yi * g.X + (nxi + xoff)]) {
+      if (is_solid(yi, nxi + xoff)) {
         if (t_prev > 0.f) { if (o.events == 0) { o.theta = t_near; o.delta = t_prev; } o.events++; }
         px = px + t_prev * vx; py = py + t_prev * vy;
         dt -= t_prev; t_near = 0.f; vx = 0.f; tx = FLT_MAX;
@@ -160,7 +161,7 @@ __device__ __forceinline__ AdvectOut advect_one(const GridRef& g, const float* _
         tx = time_to(px, npx, vx);
       }
     } else {
-      if (solid[(size_t)(nyi + yoff) * g.X + xi]) {
+      if (is_solid(nyi + yoff, xi)) {
         if (t_prev > 0.f) { if (o.events == 0) { o.theta = t_near; o.delta = t_prev; } o.events++; }
         px = px + t_prev * vx; py = py + t_prev * vy;
         dt -= t_prev; t_near = 0.f; vy = 0.f; ty = FLT_MAX;
@@ -179,6 +180,7 @@ __device__ __forceinline__ AdvectOut advect_one(const GridRef& g, const float* _
   return o;
 }
 
+template <bool TR>
 __global__ __launch_bounds__(256) void k_advect_markers_a(const float2* __restrict__ in, float2* __restrict__ out,
                                                           const float* __restrict__ u, const float* __restrict__ v,
                                                           const uint8_t* __restrict__ solid, GridRef g, float dt,
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256) void k_advect_markers_a(const float2* __restri
   bool ev = false;
   if (i < n) {
     const float2 p = in[i];
-    const AdvectOut o = advect_one(g, u, v, solid, p.x, p.y, dt);
+    const AdvectOut o = advect_one<TR>(g, u, v, solid, p.x, p.y, dt);
     out[i] = make_float2(o.px, o.py);
     if (o.events) {
       ev = true;
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(64) void k_marker_walk(const unsigned int* __restri
   if (lane == 0) { ms->n_actual = M; ms->dt_final = dt; ms->total_dt_events += M; }
 }
 
+template <bool TR>
 __global__ __launch_bounds__(256) void k_advect_markers_b(const float2* __restrict__ in, float2* __restrict__ out,
                                                           const float* __restrict__ u, const float* __restrict__ v,
                                                           const uint8_t* __restrict__ solid, GridRef g,
@@ -244,8 +247,43 @@ __global__ __launch_bounds__(256) void k_advect_markers_b(const float2* __restri
   while (lo < hi) { const unsigned int mid = (lo + hi) >> 1; if (act_idx[mid] < gi) lo = mid + 1; else hi = mid; }
   const float dt = act_dt[lo - 1];
   const float2 p = in[i];
-  const AdvectOut o = advect_one(g, u, v, solid, p.x, p.y, dt);
+  const AdvectOut o = advect_one<TR>(g, u, v, solid, p.x, p.y, dt);
   out[i] = make_float2(o.px, o.py);
+}
+
+// the marker stage's column-major copies: u, v and the count grid as they stand in front of advect_markers (main.c:855), the solid grid when it changed.  A workgroup moves
+// a 64 x 64 tile through LDS: 256-byte rows in, 256-byte columns out.  9 bytes per cell read and written per substep - a quarter of a millisecond at 8192^2 against the
+// millisecond the advection saves.
+__global__ __launch_bounds__(256) void k_transpose_for_markers(const float* __restrict__ u, const float* __restrict__ v, const uint8_t* __restrict__ count, const uint8_t* __restrict__ solid,
+                                                               float* __restrict__ uT, float* __restrict__ vT, uint8_t* __restrict__ countT, uint8_t* __restrict__ solidT,
+                                                               int X, int Y, int with_solid) {
+  __shared__ float tu[64][65], tv[64][65];
+  __shared__ uint8_t tc[64][65], ts[64][65];
+  const int xb = blockIdx.x * 64, yb = blockIdx.y * 64, l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int k = w; k < 64; k += 4) {                       // row yb + k, columns xb + l
+    const int x = xb + l, y = yb + k;
+    const bool in = x < X && y < Y;
+    const size_t i = (size_t)y * X + x;
+    tu[k][l] = in ? u[i] : 0.f; tv[k][l] = in ? v[i] : 0.f; tc[k][l] = in ? count[i] : (uint8_t)0;
+    if (with_solid) ts[k][l] = in ? solid[i] : (uint8_t)0;
+  }
+  __syncthreads();
+  for (int k = w; k < 64; k += 4) {                       // column xb + k, rows yb + l
+    const int x = xb + k, y = yb + l;
+    if (x < X && y < Y) {
+      const size_t i = (size_t)x * Y + y;
+      uT[i] = tu[l][k]; vT[i] = tv[l][k]; countT[i] = tc[l][k];
+      if (with_solid) solidT[i] = ts[l][k];
+    }
+  }
+}
+static bool eu_markers_column_major(euler_sim* S) {      // (whole-grid handles; EULER_MARKERS_ROWMAJOR=1: the row-major kernels, for A-B timing)
+  static const bool off = getenv("EULER_MARKERS_ROWMAJOR") != nullptr;
+  if (off || S->slab_on || !S->uT) return false;
+  LAUNCH(S, KC_MARKER_ADVECT, k_transpose_for_markers, dim3((S->X + 63) / 64, (S->Y + 63) / 64), dim3(256), S->u, S->v, S->count, S->solid, S->uT, S->vT, S->countT, S->solidT,
+         S->X, S->Y, S->solidT_dirty);
+  S->solidT_dirty = 0;
+  return true;
 }
 
 int eu_launch_advect_markers(euler_sim* S, float dt) {
@@ -254,13 +292,24 @@ int eu_launch_advect_markers(euler_sim* S, float dt) {
   const float2* in = S->markers[S->cur];
   float2* out = S->markers[S->cur ^ 1];
   const unsigned nb = eu_blocks((size_t)n, 256);
-  LAUNCH(S, KC_MARKER_ADVECT, k_advect_markers_a, dim3(nb), dim3(256), in, out, S->u, S->v, S->solid, g, dt, n,
+  if (eu_markers_column_major(S)) {
+    GridRef gt = g;
+    gt.count = S->countT;
+    LAUNCH(S, KC_MARKER_ADVECT, k_advect_markers_a<true>, dim3(nb), dim3(256), in, out, S->uT, S->vT, S->solidT, gt, dt, n, S->evmask, S->ev_theta, S->ev_delta, S->ms);
+    int rc = eu_ordered_select(S, S->evmask, (size_t)((n + 63) / 64), S->sel_idx, &S->ms->n_events);
+    if (rc) return rc;
+    LAUNCH(S, KC_MARKER_EVENTS, k_marker_walk, dim3(1), dim3(64), S->sel_idx, S->ev_theta, S->ev_delta, S->act_idx, S->act_dt, S->ms, dt);
+    LAUNCH(S, KC_MARKER_ADVECT, k_advect_markers_b<true>, dim3(nb), dim3(256), in, out, S->uT, S->vT, S->solidT, gt, n, S->act_idx, S->act_dt, S->ms, (const unsigned int*)nullptr);
+    S->cur ^= 1;
+    return EULER_OK;
+  }
+  LAUNCH(S, KC_MARKER_ADVECT, k_advect_markers_a<false>, dim3(nb), dim3(256), in, out, S->u, S->v, S->solid, g, dt, n,
          S->evmask, S->ev_theta, S->ev_delta, S->ms);
   int rc = eu_ordered_select(S, S->evmask, (size_t)((n + 63) / 64), S->sel_idx, &S->ms->n_events);
   if (rc) return rc;
   LAUNCH(S, KC_MARKER_EVENTS, k_marker_walk, dim3(1), dim3(64), S->sel_idx, S->ev_theta, S->ev_delta, S->act_idx,
          S->act_dt, S->ms, dt);
-  LAUNCH(S, KC_MARKER_ADVECT, k_advect_markers_b, dim3(nb), dim3(256), in, out, S->u, S->v, S->solid, g, n,
+  LAUNCH(S, KC_MARKER_ADVECT, k_advect_markers_b<false>, dim3(nb), dim3(256), in, out, S->u, S->v, S->solid, g, n,
          S->act_idx, S->act_dt, S->ms, (const unsigned int*)nullptr);
   S->cur ^= 1;
   return EULER_OK;
@@ -374,13 +423,13 @@ int eu_marker_narrow_counts(euler_sim* S) {
 }
 int eu_marker_advect_a(euler_sim* S, float dt, unsigned long long n) {
   GridRef g{S->X, S->Y, S->count, S->interp_lim[0], S->interp_lim[1], S->interp_lim[2], S->interp_lim[3]};
-  LAUNCH(S, KC_MARKER_ADVECT, k_advect_markers_a, dim3(eu_blocks((size_t)n, 256)), dim3(256), S->markers[S->cur], S->markers[S->cur ^ 1], S->u, S->v, S->solid, g, dt, n,
+  LAUNCH(S, KC_MARKER_ADVECT, k_advect_markers_a<false>, dim3(eu_blocks((size_t)n, 256)), dim3(256), S->markers[S->cur], S->markers[S->cur ^ 1], S->u, S->v, S->solid, g, dt, n,
          S->evmask, S->ev_theta, S->ev_delta, S->ms);
   return eu_ordered_select(S, S->evmask, (size_t)((n + 63) / 64), S->sel_idx, &S->ms->n_events);
 }
 int eu_marker_advect_b(euler_sim* S, unsigned long long n, const unsigned int* keys) {
   GridRef g{S->X, S->Y, S->count, S->interp_lim[0], S->interp_lim[1], S->interp_lim[2], S->interp_lim[3]};
-  LAUNCH(S, KC_MARKER_ADVECT, k_advect_markers_b, dim3(eu_blocks((size_t)n, 256)), dim3(256), S->markers[S->cur], S->markers[S->cur ^ 1], S->u, S->v, S->solid, g, n,
+  LAUNCH(S, KC_MARKER_ADVECT, k_advect_markers_b<false>, dim3(eu_blocks((size_t)n, 256)), dim3(256), S->markers[S->cur], S->markers[S->cur ^ 1], S->u, S->v, S->solid, g, n,
          S->act_idx, S->act_dt, S->ms, keys);
   return EULER_OK;
 }
