@@ -482,7 +482,11 @@ __device__ __forceinline__ void bin_aggregated(unsigned int* count32, bool live,
     // the run ends before the next head or the next dead lane
     const unsigned long long above = lane == 63 ? 0ull : ((heads | ~lives) >> (lane + 1));
     const int run = above ? __ffsll((long long)above) : 64 - lane;
+#ifndef EU_EXP_BIN_NOATOMIC      // (timing experiment, WRONG results)
     atomicAdd(&count32[c], (unsigned int)run);
+#else
+    if (run == 12345) count32[c] = 1;
+#endif
   }
 }
 
