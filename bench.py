@@ -48,20 +48,31 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MIC
 # PCG iteration as this build runs it.  ITER_BYTES is the single table: a class's `bytes_per_cell`, the iteration's `bytes_per_cell_iteration`
 # (= the sum over the per-iteration classes, checked in summarize()) and `roofline.achieved` all come from it - "never the larger one".
 W = 8
-_APPLY = 5.5 * W + 1      # k_search_apply: s' = z + beta s and A s' in one pass (read s, z; write s', A s') 4w+1, + p += alpha s of TWO iterations on
-#                           every second pass (read s of two iterations ago and p, write p) 1.5w  -> 45
-_TILE = 4 * W + 1         # k_precond_tile: r -= alpha A s, max |r|, z = M_tile^-1 r, dot(z, r): read r, A s; write r, z (E^-1 of an interior tile is a table in LDS) -> 33
-_RUPD = 3 * W + 1         # parity mode: the first half of that pass alone (read r, A s; write r; max |r|) -> 25
+_TILE = 4 * W + 1         # k_precond_tile: r -= alpha A s', max |r|, z = M_tile^-1 r, dot(z, r): read r and s' (A s' is formed again from s', not read back); write r, z (E^-1 of an interior tile is a table in LDS) -> 33
+_RUPD = 3 * W + 1         # parity mode: the first half of that pass alone (read r, s'; write r; max |r|) -> 25
 _SWEEP = 3 * W + 1        # one IC(0) sweep of the reference's factor: read rhs, precon; write the result -> 25 each way
-ITER_BYTES = {
-    "ic0": {"forward_solve": _SWEEP, "backward_solve": _SWEEP, "apply_a": _APPLY, "update_pr": _RUPD},      # 120 (the reference's five loops: 18w+5 = 149; main.c as written: 212)
-    "ic0_tile": {"apply_a": _APPLY, "precond_tile": _TILE},                                                   # 78
-    "ic0_tile2": {"apply_a": _APPLY, "precond_tile": _TILE, "coarse_cycle": 0.0},
-    # multilevel: + the V-cycle: 8 doubles of partial sums per 16x64 tile written and read (0.125 B/cell) and the level arrays, 1/256 of a solver array each (~0.2 B/cell)
-    "ic0_tile_mg": {"apply_a": _APPLY, "precond_tile": _TILE, "coarse_cycle": 0.33},
-    "jacobi": {"apply_a": _APPLY, "update_pr": _RUPD, "jacobi": 2 * W + 1, "dot": 2 * W + 1},
-}
-PCG_BYTES = {m: sum(c.values()) for m, c in ITER_BYTES.items()}
+ITER_BYTES, PCG_BYTES = {}, {}
+
+
+def set_as_stored(stored):
+    """The byte table of the build's launches.  stored False (the default wherever this bench runs: tree dots, one GPU or compact ghost rows): A s' never goes to
+    memory - k_search_apply reads s, z and writes s' (3w+1), plus p += alpha s of TWO iterations on every second pass (read s of two iterations ago and p, write p:
+    1.5w) -> 37.  stored True (sequential dots, mailboxes, EULER_TILE_STORE_AS=1): it also writes A s' -> 45, and the r update reads that instead of s'."""
+    apply_ = (5.5 if stored else 4.5) * W + 1
+    ITER_BYTES.clear()
+    ITER_BYTES.update({
+        "ic0": {"forward_solve": _SWEEP, "backward_solve": _SWEEP, "apply_a": apply_, "update_pr": _RUPD},      # 112 (the reference's five loops: 18w+5 = 149; main.c as written: 212)
+        "ic0_tile": {"apply_a": apply_, "precond_tile": _TILE},                                                   # 70
+        "ic0_tile2": {"apply_a": apply_, "precond_tile": _TILE, "coarse_cycle": 0.0},
+        # multilevel: + the V-cycle: 8 doubles of partial sums per 16x64 tile written and read (0.125 B/cell) and the level arrays, 1/256 of a solver array each (~0.2 B/cell)
+        "ic0_tile_mg": {"apply_a": apply_, "precond_tile": _TILE, "coarse_cycle": 0.33},
+        "jacobi": {"apply_a": apply_, "update_pr": _RUPD, "jacobi": 2 * W + 1, "dot": 2 * W + 1},
+    })
+    PCG_BYTES.clear()
+    PCG_BYTES.update({m: sum(c.values()) for m, c in ITER_BYTES.items()})
+
+
+set_as_stored(False)
 ONCE_PER_SOLVE_BYTES = {"update_pr": 3 * W + 1}      # k_finish_p in the tile modes: the last one or two p += alpha s (read s, p; write p)
 PCG_CLASSES = ["forward_solve", "backward_solve", "apply_a", "dot", "update_pr", "update_search", "precond_tile", "coarse_cycle", "jacobi", "resident_pcg"]
 KERNEL_OF_CLASS = {"forward_solve": "k_sweep_skew<1", "backward_solve": "k_sweep_skew<2", "precon_factor": "k_sweep_skew<0",
@@ -587,11 +598,11 @@ def summarize(t, size_x, size_y, precond, tile_w, traffic, traffic_note, steps, 
                "frac_dense": round(bpc * cells / sec / 1e9 / HBM_PEAK_GBPS, 4)}
     if t.get("resident") and not per_iter:
         # the resident solver: r, s, p, E^-1 stay in registers / LDS for the whole solve - no HBM traffic inside it.  For comparison the figure the multi-kernel
-        # form would need for the same time: its algorithmic bytes (78 B per cell and iteration in double, 40 in float) / this time
+        # form would need for the same time: its algorithmic bytes (70 B per cell and iteration in double, 36 in float) / this time
         rs = t["resident"]
         sec = rs["ms_total"] / max(rs["iters"], 1) * 1e-3
         w = 4 if rs.get("f32") else W
-        bpc = 9.5 * w + 2
+        bpc = 8.5 * w + 2
         agg = {"us_per_iteration": round(1e6 * sec, 2), "resident": True, "solves": rs["solves"], "launches_per_iteration": 0,
                "hbm_bytes_inside_the_solve": 0, "equivalent_bytes_per_cell_iteration": bpc,
                "GBps_active": round(bpc * fluid / sec / 1e9, 1), "frac_active": round(bpc * fluid / sec / 1e9 / HBM_PEAK_GBPS, 4),
@@ -1183,6 +1194,7 @@ def main():
     from euler_amd import scenarios
 
     dot_mode = ea.DOT_TREE if args.dot_mode == "tree" else ea.DOT_SEQUENTIAL
+    set_as_stored(args.dot_mode != "tree" or bool(args.p2p) or os.environ.get("EULER_TILE_STORE_AS", "0") not in ("", "0"))      # which launches this run makes (k_pcg.hip tile_recompute)
     PC = {"ic0": ea.PRECOND_IC0, "jacobi": ea.PRECOND_JACOBI, "ic0_tile": ea.PRECOND_IC0_TILE, "ic0_tile2": ea.PRECOND_IC0_TILE2, "ic0_tile_mg": ea.PRECOND_IC0_TILE_MG}
     tile_w = args.tile_records or 16
     # N > 1 (weak scaling): the grid grows to N x (N * gpus) rows; the pressure solve is split into one

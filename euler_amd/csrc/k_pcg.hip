@@ -360,7 +360,8 @@ __device__ __forceinline__ double pick3(int t, int tb1, int tb2, double v0, doub
   return v;
 }
 struct CoarseRef { const double* y; int shift, nx, ny, band0; };   // y[ny][nx] over aggregates of (1 << shift)^2 grid cells; band0: the global index of the arrays' band 0
-template <int SLAB, int PMODE, int SA_RUN, bool COARSE = false>   // SLAB 1: several ranks, the neighbouring slabs' arrays are mapped; 2: their edge rows as compact rows (nbr); 0: nbr is ignored
+// STORE false: A s' is not stored (`out` is ignored) - k_precond_tile<16, true> forms it again from s' instead of reading it back
+template <int SLAB, int PMODE, int SA_RUN, bool COARSE = false, bool STORE = true>   // SLAB 1: several ranks, the neighbouring slabs' arrays are mapped; 2: their edge rows as compact rows (nbr); 0: nbr is ignored
 __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __restrict__ s_old, const double* __restrict__ z,
                                                              double* __restrict__ s_new, double* __restrict__ out,
                                                              const uint8_t* __restrict__ mask, SkewGeom g,
@@ -530,9 +531,14 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
               o.y = v;
               t += v * cc.y;
             }
-            if ((m0 & m1) & CM_FLUID) { *reinterpret_cast<sw_d2*>(s_new + i) = cc; *reinterpret_cast<sw_d2*>(out + i) = o; }
-            else if (m0 & CM_FLUID) { s_new[i] = cc.x; out[i] = o.x; }
-            else { s_new[i + 1] = cc.y; out[i + 1] = o.y; }
+            if ((m0 & m1) & CM_FLUID) *reinterpret_cast<sw_d2*>(s_new + i) = cc;
+            else if (m0 & CM_FLUID) s_new[i] = cc.x;
+            else s_new[i + 1] = cc.y;
+            if (STORE) {
+              if ((m0 & m1) & CM_FLUID) *reinterpret_cast<sw_d2*>(out + i) = o;
+              else if (m0 & CM_FLUID) out[i] = o.x;
+              else out[i + 1] = o.y;
+            }
             if (SLAB == 1 && slab_edge_row(i, lane, TS, nb_local, (nbr.z_dn ? 1 : 0) | (nbr.z_up ? 2 : 0))) {   // the rows the neighbours will read
               if (m0 & CM_FLUID) st_system(s_new + i, cc.x);
               if (m1 & CM_FLUID) st_system(s_new + i + 1, cc.y);
@@ -1260,6 +1266,9 @@ struct TileArgs {
   int reverse;            // walk the tiles in descending order
   double* cpart;          // two-level mode (k_coarse.hip): per tile, the sums of the (updated) r over its fluid cells by coarse column: [tile][3]
   int cshift;             // log2 of the coarse cell width in grid cells
+  // RECOMP (k_precond_tile<16, true>): `as` is the search direction s' itself and the pass forms A s' from it.  On row slabs the rows across
+  // the slab boundary are the compact ghost rows of s' that k_search_apply SLAB 2 keeps (indexed by the column); null = no neighbouring slab
+  const double *gs_lo, *gs_hi;
 };
 
 // fixed-shape reductions of a PT_THREADS block; result valid in thread 0
@@ -1340,8 +1349,16 @@ __global__ __launch_bounds__(PT_THREADS) void k_factor_tile(TileArgs a) {
   }
 }
 
-template <int W>
-__global__ __launch_bounds__(PT_THREADS) void k_precond_tile(TileArgs a) {
+// RECOMP (W == 16, inside a solve): the r update's A s' is not read back from memory - k_search_apply did not store it - but formed
+// again from s' with the expression of k_search_apply / k_apply_a (main.c:679-691: diag, right, up, left, down; identical bits): the
+// tile's 16 records of s' plus the pair-record before and after it, the rows below lane 0 / above lane 63 by ONE load (lanes 0-15 fetch
+// the 16 values below, lanes 48-63 the 16 above; v_readlane hands them to the DPP shifts).  8 bytes per cell and iteration that are
+// neither written nor read: 8192^2, k_search_apply 296-314 -> 232-239 us, this kernel 210-214 -> 209-223 us.
+#ifndef PT_RECOMP_BLOCKS
+#define PT_RECOMP_BLOCKS 1
+#endif
+template <int W, bool RECOMP = false>
+__global__ __launch_bounds__(PT_THREADS, RECOMP ? PT_RECOMP_BLOCKS : 1) void k_precond_tile(TileArgs a) {
   if (!a.force && pcg_idle(a.sc)) return;
   const int lane = threadIdx.x & 63;
   const int ntb = a.g.T / W, total = a.nb_local * ntb;
@@ -1382,12 +1399,63 @@ __global__ __launch_bounds__(PT_THREADS) void k_precond_tile(TileArgs a) {
 #pragma unroll
       for (int P = 0; P < W / 2; ++P) {
         rr[P] = *reinterpret_cast<const sw_d2*>(a.r + base + P * 128);
+        if (RECOMP && a.rupd) continue;              // (E^-1 is fetched behind the r update: PT_RECOMP_LATE)
         if (!a.sweeps) pp[P] = sw_d2{0.0, 0.0};      // (the r update alone - the parity mode's use of this kernel - needs no E^-1)
         else if (FULL) pp[P] = s_tab[P < TABP ? P : 0][lane];
         else pp[P] = *reinterpret_cast<const sw_d2*>(a.pre + base + P * 128);
-        if (a.rupd) qq[P] = *reinterpret_cast<const sw_d2*>(a.as + base + P * 128);
+        if (!RECOMP && a.rupd) qq[P] = *reinterpret_cast<const sw_d2*>(a.as + base + P * 128);
       }
-      if (a.rupd) {      // r -= alpha z (fmadd, main.c:754, evaluated as r + z * (-alpha) like k_update_pr) and max |r| over fluid cells
+      if (RECOMP && a.rupd) {
+        const int npairs = a.g.TS / 2, P0 = k * (W / 2);
+        sw_d2 ss[W / 2 + 2];
+#pragma unroll
+        for (int P = -1; P <= W / 2; ++P)
+          ss[P + 1] = (P0 + P >= 0 && P0 + P < npairs) ? *reinterpret_cast<const sw_d2*>(a.as + base + (long long)P * 128) : sw_d2{0.0, 0.0};
+        // lane L < 16: s' of the cell below lane 0's cell of record k W + L (column k W + L, row 64 band - 1);
+        // lane L >= 48: of the cell above lane 63's cell of record k W + L - 48 (column k W + L - 48 - 63, row 64 (band + 1))
+        double ev = 0.0;
+        if (lane < 16) {
+          const int x = k * W + lane;
+          if (x < a.g.X) {
+            if (a.gs_lo && band == a.band_lo) ev = a.gs_lo[x];
+            else if (band > 0) ev = a.as[skew_index(a.g, x, 64 * band - 1)];
+          }
+        } else if (lane >= 48) {
+          const int x = k * W + lane - 48 - 63;
+          if (x >= 0 && x < a.g.X) {
+            if (a.gs_hi && band == a.band_lo + a.nb_local - 1) ev = a.gs_hi[x];
+            else if (band + 1 < a.g.nbands) ev = a.as[skew_index(a.g, x, 64 * (band + 1))];
+          }
+        }
+        const int ev_lo = __double2loint(ev), ev_hi = __double2hiint(ev);
+#pragma unroll
+        for (int P = 0; P < W / 2; ++P) {
+          const unsigned int m0 = mm[P] & 0xff, m1 = mm[P] >> 8;
+          const sw_d2 cc = ss[P + 1];
+          const double prev_y = ss[P].y, nxt_x = ss[P + 2].x;
+          const double d0 = __hiloint2double(__builtin_amdgcn_readlane(ev_hi, 2 * P), __builtin_amdgcn_readlane(ev_lo, 2 * P));
+          const double d1 = __hiloint2double(__builtin_amdgcn_readlane(ev_hi, 2 * P + 1), __builtin_amdgcn_readlane(ev_lo, 2 * P + 1));
+          const double u0 = __hiloint2double(__builtin_amdgcn_readlane(ev_hi, 48 + 2 * P), __builtin_amdgcn_readlane(ev_lo, 48 + 2 * P));
+          const double u1 = __hiloint2double(__builtin_amdgcn_readlane(ev_hi, 49 + 2 * P), __builtin_amdgcn_readlane(ev_lo, 49 + 2 * P));
+          const double dn0 = wave_shift_inject<DPP_WAVE_SHR1>(prev_y, d0), up0 = wave_shift_inject<DPP_WAVE_SHL1>(cc.y, u0);
+          const double dn1 = wave_shift_inject<DPP_WAVE_SHR1>(cc.x, d1), up1 = wave_shift_inject<DPP_WAVE_SHL1>(nxt_x, u1);
+          double v = (double)(int)(m0 >> CM_DIAG_SHIFT) * cc.x;      // apply_a (main.c:679-691): diag, right, up, left, down
+          v = v - ((m0 & CM_RIGHT) ? cc.y : 0.0);
+          v = v - ((m0 & CM_UP) ? up0 : 0.0);
+          v = v - ((m0 & CM_LEFT) ? prev_y : 0.0);
+          v = v - ((m0 & CM_DOWN) ? dn0 : 0.0);
+          // r -= alpha A s' (fmadd, main.c:754) and max |r| over fluid cells, as below
+          if (m0 & CM_FLUID) { rr[P].x = rr[P].x + v * nalpha; const double w = fabs(rr[P].x); if (w > mx) mx = w; }
+          v = (double)(int)(m1 >> CM_DIAG_SHIFT) * cc.y;
+          v = v - ((m1 & CM_RIGHT) ? nxt_x : 0.0);
+          v = v - ((m1 & CM_UP) ? up1 : 0.0);
+          v = v - ((m1 & CM_LEFT) ? cc.x : 0.0);
+          v = v - ((m1 & CM_DOWN) ? dn1 : 0.0);
+          if (m1 & CM_FLUID) { rr[P].y = rr[P].y + v * nalpha; const double w = fabs(rr[P].y); if (w > mx) mx = w; }
+          *reinterpret_cast<sw_d2*>(a.r + base + P * 128) = rr[P];
+        }
+      }
+      if (!RECOMP && a.rupd) {      // r -= alpha z (fmadd, main.c:754, evaluated as r + z * (-alpha) like k_update_pr) and max |r| over fluid cells
 #pragma unroll
         for (int P = 0; P < W / 2; ++P) {
           if (mm[P] & CM_FLUID) { rr[P].x = rr[P].x + qq[P].x * nalpha; const double v = fabs(rr[P].x); if (v > mx) mx = v; }
@@ -1396,6 +1464,11 @@ __global__ __launch_bounds__(PT_THREADS) void k_precond_tile(TileArgs a) {
         }
       }
       if (!a.sweeps) return;
+      if (RECOMP && a.rupd) {      // the window of s' is dead: E^-1 takes its registers (the barrier keeps the compiler from hoisting these loads above the r update)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int P = 0; P < W / 2; ++P) pp[P] = FULL ? s_tab[P < TABP ? P : 0][lane] : *reinterpret_cast<const sw_d2*>(a.pre + base + P * 128);
+      }
       if (W == 16 && a.cpart && a.cshift == 4) {      // multilevel mode: aggregates of 16 - per group of 16 lanes, the cells left / right of the group's aggregate boundary (k_coarse.hip)
         const int i16 = lane & 15;
         double sl = 0.0, sr = 0.0;
@@ -1781,6 +1854,18 @@ static int launch_dot(euler_sim* S, const double* a, const double* b, int fin_op
 
 // tile-local IC(0) in its production form: everything between two apply_a passes in one kernel (k_precond_tile)
 static inline bool tile_fused(const euler_sim* S) { return eu_is_tile(S) && S->cfg.sweep_mode != EULER_SWEEP_SIMPLE; }
+// A s' never goes to memory: k_search_apply leaves it out and the r update (k_precond_tile<16, true>) forms it again from s' (the same bits).
+// Not where somebody else reads the array - the sequential replay of dot(s, A s) - nor where the rows across a slab boundary are not at hand:
+// the mailbox configurations (comm_p2p.hip) and the reference's IC(0) on several ranks.  EULER_TILE_STORE_AS=1 restores the stored form.
+static inline int sa_run(const euler_sim* S);
+static inline bool tile_recompute(const euler_sim* S) {
+  static const int stored = getenv("EULER_TILE_STORE_AS") ? atoi(getenv("EULER_TILE_STORE_AS")) : 0;
+  if (stored || sa_run(S) != 8) return false;
+  if (!tile_fused(S)) return !S->has_comm && S->cfg.dot_mode != EULER_DOT_SEQUENTIAL;      // (the r update of the other modes is this kernel's first half)
+  if (S->tile_w != 16) return false;
+  if (S->has_comm) return ghost_mode(S);
+  return S->cfg.dot_mode != EULER_DOT_SEQUENTIAL;
+}
 // max |r| and dot(z,r) of all ranks after ONE exchange ("fuse the latter two into one ... message pair"): every rank
 // folds the gathered pairs in rank order - identical bits everywhere - and applies the two scalar epilogues
 __global__ void k_pair_fold(PcgScalars* sc, const double* __restrict__ pairs, int stride, int R, int rupd, int fin_dot, int force) {
@@ -1805,6 +1890,7 @@ static TileArgs make_tile_args(euler_sim* S, int force) {
   // where the next k_search_apply starts.  8192^2: 548 -> 536 us per iteration (EULER_TILE_REVERSE=0 restores the ascending order)
   { static const int rev = getenv("EULER_TILE_REVERSE") ? atoi(getenv("EULER_TILE_REVERSE")) : 1; a.reverse = rev; }
   a.cpart = nullptr; a.cshift = 0;
+  a.gs_lo = a.gs_hi = nullptr;
   if (ghost_mode(S)) {
     if (S->band_lo > 0) { a.zsend_lo = xrow(S, XR_ZSEND_LO); a.edge_lo = S->band_lo; }
     if (S->band_hi < S->geom.nbands) { a.zsend_hi = xrow(S, XR_ZSEND_HI); a.edge_hi = S->band_hi - 1; }
@@ -1851,10 +1937,22 @@ static int launch_precond_tile(euler_sim* S, int rupd, int sweeps, int fin_dot, 
   }
   const int w = r_only ? 16 : S->tile_w, cls = r_only ? KC_UPDATE_PR : KC_PRECOND_TILE;
   const unsigned nblk = eu_blocks((size_t)(S->band_hi - S->band_lo) * (S->geom.T / w), PT_THREADS / 64, 2048);
+  // (r_only: the other modes' r update - A s' would sit in q behind k_search_apply, in z behind the solve's first k_apply_a, which stores it)
+  const bool recomp = rupd && !force && tile_recompute(S) && (r_only ? S->tile_as_override == S->q : !S->tile_as_override);
+  if (recomp) {      // A s' is formed from the search direction (S->s behind k_search_apply's swap, or s_0 behind k_apply_a) and, on row slabs, the ghost rows of s' of its generation
+    a.as = S->s;
+    if (ghost_mode(S)) {
+      if (S->band_lo > 0) a.gs_lo = xrow(S, XR_GS_LO0 + S->gs_cur);
+      if (S->band_hi < S->geom.nbands) a.gs_hi = xrow(S, XR_GS_HI0 + S->gs_cur);
+    }
+  }
   switch (w) {
     case 8: LAUNCH(S, cls, k_precond_tile<8>, dim3(nblk), dim3(PT_THREADS), a); break;
     case 32: LAUNCH(S, cls, k_precond_tile<32>, dim3(nblk), dim3(PT_THREADS), a); break;
-    default: LAUNCH(S, cls, k_precond_tile<16>, dim3(nblk), dim3(PT_THREADS), a); break;
+    default:
+      if (recomp) LAUNCH(S, cls, (k_precond_tile<16, true>), dim3(nblk), dim3(PT_THREADS), a);
+      else LAUNCH(S, cls, k_precond_tile<16>, dim3(nblk), dim3(PT_THREADS), a);
+      break;
   }
   if (two_level && a.via != FIN_TO_COMM) { int rc = eu_launch_coarse_solve(S, fin_real, force); if (rc) return rc; }
   if (seq && sweeps && fin_dot >= 0)   // the reference's row-major dot(z, r); a no-op once max |r| <= tol
@@ -1975,11 +2073,13 @@ static int launch_search_apply_and_alpha(euler_sim* S, int it) {
   const int run = sa_run(S);
   const int fin = S->has_comm ? fin_or_comm(S, FIN_ALPHA) : (seq ? -1 : (int)FIN_ALPHA);
   double* pp = LOC(S->p);
+  const bool store = !tile_recompute(S);      // false: A s' is not stored (k_precond_tile<16, true> forms it again)
   const bool mg = eu_is_mg(S) && S->mg_levels > 0;
   const CoarseRef cref = {mg ? S->mg_x : S->cc_y, mg ? 4 : S->coarse_shift, mg ? S->mg_nx[0] : S->coarse_nx, mg ? S->mg_ny[0] : S->coarse_ny, S->band_lo};
-#define SA_LAUNCH_C(SLABF, PM, RUNV, CF)                                                                                                \
-  LAUNCH(S, KC_APPLY_A, (k_search_apply<SLABF, PM, RUNV, CF>), dim3(sa_blocks(S, RUNV)), dim3(SA_THREADS), LOC(S->s), LOC(S->z), LOC(S->s2), \
+#define SA_LAUNCH_CS(SLABF, PM, RUNV, CF, ST)                                                                                                \
+  LAUNCH(S, KC_APPLY_A, (k_search_apply<SLABF, PM, RUNV, CF, ST>), dim3(sa_blocks(S, RUNV)), dim3(SA_THREADS), LOC(S->s), LOC(S->z), LOC(S->s2), \
          LOC(S->q), LOC(S->cellmask), gl, S->partial, S->sc, 0, S->red_counter, fin, nbr, pp, S->s2, S->s, (RUNV) == 8 ? S->chunk_list : (const unsigned int*)nullptr, cref)
+#define SA_LAUNCH_C(SLABF, PM, RUNV, CF) do { if ((RUNV) == 8 && !store) SA_LAUNCH_CS(SLABF, PM, RUNV, CF, ((RUNV) != 8)); else SA_LAUNCH_CS(SLABF, PM, RUNV, CF, true); } while (0)
 #define SA_LAUNCH(SLABF, PM, RUNV) SA_LAUNCH_C(SLABF, PM, RUNV, false)
 #define SA_RUNS(SLABF, PM) do { if (run == 8) SA_LAUNCH(SLABF, PM, 8); else if (run == 16) SA_LAUNCH(SLABF, PM, 16); else SA_LAUNCH(SLABF, PM, 32); } while (0)
   if (eu_is_two_level(S) && tile_fused(S) && ghost) {      // coarse correction on row slabs (multilevel mode): the ghost rows of z get their P y here as well
@@ -1998,6 +2098,7 @@ static int launch_search_apply_and_alpha(euler_sim* S, int it) {
 #undef SA_RUNS
 #undef SA_LAUNCH
 #undef SA_LAUNCH_C
+#undef SA_LAUNCH_CS
   double* t = S->s; S->s = S->s2; S->s2 = t;
   if (seq)
     LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), S->q, S->s, S->cellmask, S->geom, S->sc, (int)FIN_ALPHA, 0);
