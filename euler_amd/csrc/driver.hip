@@ -12,6 +12,8 @@
 int eu_launch_build_system(euler_sim* S, float dt);
 int eu_launch_velocity_update(euler_sim* S, float dt);
 int eu_unskew(euler_sim* S, const void* skew, void* rowmajor, int elem_bytes);
+int eu_unskew_fluid(euler_sim* S, const double* skew, double* rowmajor);
+double* eu_current_search_direction(euler_sim* S);
 int eu_launch_tile_table(euler_sim* S);
 int eu_skew(euler_sim* S, const void* rowmajor, void* skew, int elem_bytes);
 
@@ -231,6 +233,7 @@ extern "C" void euler_destroy(euler_sim* S) {
   // band-skewed arrays: shifted to global element indexing as well (skew_off), behind EU_SKEW_SLACK elements of slack
   const size_t so = S->shifted ? S->skew_off : 0, sl = S->shifted ? (size_t)EU_SKEW_SLACK : 0;
   (void)so; (void)sl;
+  for (void* d : S->s_ring_alloc) if (d) (void)hipFree(d);
   for (void* d : S->skew_alloc) if (d) (void)hipFree(d);      // (the raw allocations: s / s2 swap during solves, and each array has its own stagger)
   const size_t fb_off = S->shifted ? (size_t)S->ab_lo * S->fb_stride * 64 : 0;
   if (S->fbits_fwd) (void)hipFree(S->fbits_fwd + fb_off);
@@ -813,7 +816,7 @@ static int field_ptr(euler_sim* S, int f, void** p, size_t* bytes) {
     case EULER_F_PCG_B: *p = S->b; *bytes = C * 8; break;
     case EULER_F_PCG_R: *p = S->r; *bytes = C * 8; break;
     case EULER_F_PCG_Z: *p = S->z; *bytes = C * 8; break;
-    case EULER_F_PCG_S: *p = S->s; *bytes = C * 8; break;
+    case EULER_F_PCG_S: *p = eu_current_search_direction(S); *bytes = C * 8; break;
     case EULER_F_PCG_Q: *p = S->q; *bytes = C * 8; break;
     case EULER_F_CELLMASK: *p = S->cellmask; *bytes = C; break;
     case EULER_F_DYE_R: case EULER_F_DYE_G: case EULER_F_DYE_B: case EULER_F_DYE_RTMP: case EULER_F_DYE_GTMP: case EULER_F_DYE_BTMP:
@@ -848,7 +851,9 @@ extern "C" int euler_get_field(euler_sim* S, int32_t f, void* dst, size_t dst_by
   if (field_is_skewed(f)) {   // the solver's arrays are band-skewed in HBM: gather to row-major first
     rc = ensure_rowmajor_tmp(S);
     if (rc) return rc;
-    eu_unskew(S, p, S->rowmajor_tmp, f == EULER_F_CELLMASK ? 1 : 8);
+    if (f == EULER_F_PCG_S && S->s_none) HIPCHK(hipMemsetAsync(S->rowmajor_tmp, 0, b, S->stream));
+    else if (f == EULER_F_PCG_S && S->s_stale) eu_unskew_fluid(S, (const double*)p, (double*)S->rowmajor_tmp);
+    else eu_unskew(S, p, S->rowmajor_tmp, f == EULER_F_CELLMASK ? 1 : 8);
     p = S->rowmajor_tmp;
   }
   HIPCHK(hipMemcpyAsync(dst, p, b, hipMemcpyDeviceToHost, S->stream));
@@ -879,6 +884,7 @@ extern "C" int euler_set_field(euler_sim* S, int32_t f, const void* src, size_t 
   if (src_bytes != b) { eu_set_error("euler_set_field(%d): %zu bytes given, %zu expected", f, src_bytes, b); return EULER_EINVAL; }
   if (field_is_skewed(f)) {
     S->lean_ok = 0;      // a caller's values in the solver arrays: the next assembly writes them whole
+    if (f == EULER_F_PCG_S) { S->s_stale = 0; S->s_launched = 0; S->s_none = 0; }      // (every element of S->s is the caller's now)
     rc = ensure_rowmajor_tmp(S);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(S->rowmajor_tmp, src, b, hipMemcpyHostToDevice, S->stream));

@@ -41,10 +41,10 @@ struct PcgScalars {
   double comm_val;   // multi-rank: a rank-local reduction result on its way through the all-reduce
   double comm_val2;  // k_precond_tile leaves two: max |r| in comm_val, dot(z,r) here
   double* comm_slot; // several ranks: this rank's slot of the small all-gather buffer (euler_comm_ops.exchange), set with the communicator
-  double alpha_prev; // alpha of the iteration before the last one that ran (tile-local mode: p is updated every SECOND iteration)
-  double* s_last;    // tile-local mode: the search direction of the last iteration that ran, and of the one before it (s_prev).
-  double* s_prev;    // p += alpha s of iterations k, k + 1 (k even) is applied by the apply_a pass of iteration k + 2, which finds
-                     // s_k in the array it is about to overwrite and reads s_(k+1) anyway; k_finish_p applies what is left at the end
+  double alpha_prev; // alpha of the iteration before the last one that ran
+  double alpha_hist[8];   // alpha of iteration k at [k & 7]: p += alpha s is applied N iterations at a time (N = 2, 4 or 8 fmadds of main.c:753, in their order) by the
+                          // k_search_apply pass of every N-th iteration, which reads s_(k-1) anyway, finds s_(k-N) in the array it is about to overwrite (the search
+                          // directions live in a ring of N arrays) and fetches the N - 2 in between; k_finish_p applies what is left when a solve ends
   int nonzero;   // !all_zero(r)  (main.c:742)
   int done;      // inf_norm(r) <= tol reached (main.c:756)
   int iters;     // apply_a calls so far (main.c:750)
@@ -196,6 +196,13 @@ struct euler_sim {
   int res_have_last, res_skip_once;
   unsigned long long res_solves, res_fallbacks;
   int tile_w;             // EULER_PRECOND_IC0_TILE: records per tile (include/euler.h precond_tile_records)
+  double* s_ring[8];                // the search directions' ring (k_pcg.hip p_steps): [0], [1] = s, s2 as the solve found them, the others allocated when first needed
+  void* s_ring_alloc[8];            // raw allocations of [2..]
+  double* s_base[2];                // the handle's own two search arrays (S->s / S->s2 point into the ring while a solve runs)
+  int s_ring_n;                     // arrays of the current / last solve's ring
+  int s_launched;                   // iterations the last solve LAUNCHED (launches behind convergence return at once but still turn the ring)
+  int s_none;                       // the last solve's right-hand side was all zero (main.c:742): no search direction exists, EULER_F_PCG_S reads as +0
+  int s_stale;                      // non-fluid elements of the search arrays hold values of earlier solves (nothing reads them unmasked): EULER_F_PCG_S shows them as +0
   const double* tile_as_override;   // where A s sits for the r update of the non-tile modes (z behind the first apply_a of a solve, else q)
   double* partial2;       // second set of reduction partials (k_precond_tile reduces max |r| and dot(z,r) at once)
   struct RngJump* rng_jump;   // xorshift64* jump-ahead matrices (device)

@@ -487,6 +487,18 @@ __global__ __launch_bounds__(256) void k_skew(const T* __restrict__ rowmajor, T*
   if (i < (size_t)g.X * (y1 - y0)) skew[skew_index(g, (int)(i % g.X), y0 + (int)(i / g.X))] = rowmajor[i];
 }
 
+// a solver vector whose non-fluid elements are not maintained (k_pcg.hip: the search directions' ring): they read as +0
+__global__ __launch_bounds__(256) void k_unskew_fluid(const double* __restrict__ skew, const uint8_t* __restrict__ mask, double* __restrict__ rowmajor, SkewGeom g, int y0, int y1) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)g.X * (y1 - y0)) return;
+  const size_t e = skew_index(g, (int)(i % g.X), y0 + (int)(i / g.X));
+  rowmajor[i] = (mask[e] & CM_FLUID) ? skew[e] : 0.0;
+}
+int eu_unskew_fluid(euler_sim* S, const double* skew, double* rowmajor) {
+  const unsigned nb = eu_blocks((size_t)S->X * (S->row_hi - S->row_lo), 256);
+  hipLaunchKernelGGL(k_unskew_fluid, dim3(nb), dim3(256), 0, S->stream, skew, S->cellmask, rowmajor, S->geom, S->row_lo, S->row_hi);
+  return EULER_OK;
+}
 int eu_unskew(euler_sim* S, const void* skew, void* rowmajor, int elem_bytes) {
   const unsigned nb = eu_blocks((size_t)S->X * (S->row_hi - S->row_lo), 256);
   if (elem_bytes == 8) hipLaunchKernelGGL(k_unskew<double>, dim3(nb), dim3(256), 0, S->stream, (const double*)skew, (double*)rowmajor, S->geom, S->row_lo, S->row_hi);

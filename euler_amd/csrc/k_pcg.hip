@@ -55,7 +55,7 @@ enum { FIN_SIGMA_INIT = 0, FIN_ALPHA, FIN_RNORM, FIN_BETA, FIN_STORE_ONLY, FIN_T
 __device__ __forceinline__ void pcg_scalar_step(PcgScalars* sc, int op, double v) {
   switch (op) {
     case FIN_SIGMA_INIT: sc->sigma = v; break;                                        // main.c:748
-    case FIN_ALPHA: sc->zs = v; sc->alpha_prev = sc->alpha; sc->alpha = sc->sigma / v; sc->iters += 1; break;     // main.c:750-752
+    case FIN_ALPHA: sc->zs = v; sc->alpha_prev = sc->alpha; sc->alpha = sc->sigma / v; sc->alpha_hist[sc->iters & 7] = sc->alpha; sc->iters += 1; break;     // main.c:750-752
     case FIN_RNORM: sc->rnorm = v; if (v <= sc->tol) sc->done = 1; break;             // main.c:756
     case FIN_BETA: sc->sigma_new = v; sc->beta = v / sc->sigma; sc->sigma = v; break; // main.c:762-765
     case FIN_TO_COMM: sc->comm_val = v; if (sc->comm_slot) *sc->comm_slot = v; break;   // multi-rank: the epilogue runs after the exchange
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_apply_a(const double* __restric
                                                          double* __restrict__ partial, PcgScalars* sc, int force,
                                                          unsigned int* counter, int fin_op, double* s_last) {
   if (!force && pcg_idle(sc)) return;
-  if (s_last && blockIdx.x == 0 && threadIdx.x == 0) { sc->s_last = s_last; sc->s_prev = nullptr; }   // tile-local mode: whose p += alpha s is still due (k_finish_p)
+  (void)s_last;
   const size_t S = g.S;
   const size_t chunk = (((S + gridDim.x - 1) / gridDim.x) + 127) & ~(size_t)127;   // whole record pairs per block
   const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < S ? lo + chunk : S;
@@ -330,10 +330,11 @@ __device__ __forceinline__ double ld_system(const double* p) {
 // PMODE (tile-local mode, where no other kernel of the iteration touches p - k_precond_tile does the rest of main.c:753-765):
 //   0  the reference's structure (k_update_pr applies p += alpha s)
 //   1  tile-local mode, an odd iteration: p is left alone
-//   2  tile-local mode, an even iteration k >= 2: p = (p + alpha_(k-2) s_(k-2)) + alpha_(k-1) s_(k-1) - the two fmadds of main.c:753
-//      that are due, in their order, hence the reference's bits.  s_(k-1) is this pass's s_old; s_(k-2) sits in the array the
-//      pass is about to overwrite with s_k (the two search arrays ping-pong), read by the thread that overwrites it.  p is read
-//      and written every second iteration: 12 instead of 16 bytes per cell and iteration.
+//   N = 2, 4, 8  an iteration k >= N, k a multiple of N: p = (..(p + alpha_(k-N) s_(k-N)) + ..) + alpha_(k-1) s_(k-1) - the N fmadds of
+//      main.c:753 that are due, in their order, hence the reference's bits.  s_(k-1) is this pass's s_old; s_(k-N) sits in the array the
+//      pass is about to overwrite with s_k (the search directions turn through a ring of N arrays), read by the thread that overwrites
+//      it; the N - 2 in between come from `hist`.  p is read and written every N-th iteration: (2 w + (N - 1) w) / N bytes per cell and
+//      iteration - 12 (N = 2, rounds 3-4), 10 (N = 4), 9 (N = 8) instead of 16.
 //
 // Schedule.  A wave walks a run of SA_RUN consecutive pair-records of one band (lane = row) with a three-deep window of s'
 // in registers - the pair before, the pair itself, the pair after - so every element of z and s is loaded ONCE, by one
@@ -360,6 +361,7 @@ __device__ __forceinline__ double pick3(int t, int tb1, int tb2, double v0, doub
   return v;
 }
 struct CoarseRef { const double* y; int shift, nx, ny, band0; };   // y[ny][nx] over aggregates of (1 << shift)^2 grid cells; band0: the global index of the arrays' band 0
+struct SaHist { const double* s[6]; };   // PMODE N: the arrays of s_(k-N+1) .. s_(k-2) (N - 2 of them), offset like s_old
 // STORE false: A s' is not stored (`out` is ignored) - k_precond_tile<16, true> forms it again from s' instead of reading it back
 template <int SLAB, int PMODE, int SA_RUN, bool COARSE = false, bool STORE = true>   // SLAB 1: several ranks, the neighbouring slabs' arrays are mapped; 2: their edge rows as compact rows (nbr); 0: nbr is ignored
 __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __restrict__ s_old, const double* __restrict__ z,
@@ -369,12 +371,18 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
                                                              unsigned int* counter, int fin_op, SlabNeighbours nbr,
                                                              double* __restrict__ p, double* s_new_base, double* s_old_base,
                                                              const unsigned int* __restrict__ chunk_list,      // SA_RUN == 8 only: the solve's active runs
-                                                             CoarseRef cref) {
+                                                             CoarseRef cref, SaHist hist) {
   if (!force && pcg_idle(sc)) return;
   const double beta = sc->beta;
-  const double alpha_prev = sc->alpha;     // of the previous iteration: this launch's own alpha is written by its LAST block
-  const double alpha_pp = sc->alpha_prev;  // of the one before
-  if (PMODE && blockIdx.x == 0 && threadIdx.x == 0) { sc->s_last = s_new_base; sc->s_prev = s_old_base; }
+  (void)s_new_base; (void)s_old_base;
+  // PMODE N: alpha of the iterations k - N .. k - 1 (k = the iterations counted so far: this launch's own alpha is written by its LAST block)
+  constexpr int NPA = PMODE >= 2 ? PMODE : 2;
+  double al[NPA] = {};
+  if (PMODE >= 2) {
+    const int k = sc->iters;
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) al[j] = sc->alpha_hist[(k - NPA + j) & 7];
+  }
   const int lane = threadIdx.x & 63;
   const int TS = g.TS, npairs = TS / 2;
   const int nb_local = (int)(g.S / ((size_t)TS * 64));
@@ -504,11 +512,19 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
           if ((m0 | m1) & CM_FLUID) {
             const size_t i = bbase + (size_t)P * 128;
             sw_d2 cc = B.so, o = {0.0, 0.0};                // cc: the pair's s' (a non-fluid element keeps its old value, +0)
-            if (PMODE == 2) {
+            if (PMODE >= 2) {
               sw_d2 pv = *reinterpret_cast<const sw_d2*>(p + i);
-              const sw_d2 s2v = *reinterpret_cast<const sw_d2*>(s_new + i);      // s of two iterations ago, about to be overwritten
-              if (m0 & CM_FLUID) { pv.x = pv.x + s2v.x * alpha_pp; pv.x = pv.x + B.so.x * alpha_prev; }
-              if (m1 & CM_FLUID) { pv.y = pv.y + s2v.y * alpha_pp; pv.y = pv.y + B.so.y * alpha_prev; }
+              constexpr int NP = PMODE >= 2 ? PMODE : 2;
+              sw_d2 sv[NP];
+              sv[0] = *reinterpret_cast<const sw_d2*>(s_new + i);      // s of N iterations ago, about to be overwritten
+#pragma unroll
+              for (int j = 1; j < NP - 1; ++j) sv[j] = *reinterpret_cast<const sw_d2*>(hist.s[j - 1] + i);
+              sv[NP - 1] = B.so;
+#pragma unroll
+              for (int j = 0; j < NP; ++j) {
+                if (m0 & CM_FLUID) pv.x = pv.x + sv[j].x * al[j];
+                if (m1 & CM_FLUID) pv.y = pv.y + sv[j].y * al[j];
+              }
               *reinterpret_cast<sw_d2*>(p + i) = pv;        // a non-fluid partner is written back unchanged
             }
             if (m0 & CM_FLUID) cc.x = cur.x;
@@ -1573,28 +1589,32 @@ __global__ __launch_bounds__(PT_THREADS, RECOMP ? PT_RECOMP_BLOCKS : 1) void k_p
   }
 }
 
-// tile-local mode: the p += alpha s (fmadd, main.c:753) that are still due when a solve ends - of the last iteration alone when
-// an odd number ran, of the last two (in their order) when an even number did (k_search_apply PMODE 2 applied the others)
+// the p += alpha s (fmadd, main.c:753) that are still due when a solve ends: with `iters` iterations counted and N at a time applied by the
+// k_search_apply pass of every N-th iteration k >= N (the terms below k), those from the last such k (or from 0) to iters - 1, in their order
+struct SRing { const double* s[8]; int n, steps; };      // the ring: s_j sits in s[j % n]
 __global__ __launch_bounds__(256) void k_finish_p(double* __restrict__ p, const uint8_t* __restrict__ mask, size_t e_lo, size_t S,
-                                                  const PcgScalars* sc) {
+                                                  const PcgScalars* sc, SRing ring) {
   if (!sc->nonzero || sc->iters == 0) return;
-  const double alpha = sc->alpha, alpha_pp = sc->alpha_prev;
-  const double* s = sc->s_last + e_lo;
-  const bool two = (sc->iters & 1) == 0;
-  const double* sp = two ? sc->s_prev + e_lo : s;
+  const int n_it = sc->iters;
+  const int from = n_it - 1 >= ring.steps ? (n_it - 1) / ring.steps * ring.steps : 0;
+  const int cnt = n_it - from;      // 1 .. steps
+  double al[8];
+  const double* sp[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const int it = from + (j < cnt ? j : 0); al[j] = sc->alpha_hist[it & 7]; sp[j] = ring.s[it % ring.n] + e_lo; }
   for (size_t i = 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x); i < S; i += 2 * (size_t)gridDim.x * blockDim.x) {
     const unsigned int mm = *reinterpret_cast<const unsigned short*>(mask + i);
     const bool f0 = (mm & CM_FLUID) != 0, f1 = ((mm >> 8) & CM_FLUID) != 0;
     if (!(f0 | f1)) continue;
-    const sw_d2 sv = *reinterpret_cast<const sw_d2*>(s + i);
     sw_d2 pv = *reinterpret_cast<const sw_d2*>(p + i);
-    if (two) {
-      const sw_d2 s2v = *reinterpret_cast<const sw_d2*>(sp + i);
-      if (f0) pv.x = pv.x + s2v.x * alpha_pp;
-      if (f1) pv.y = pv.y + s2v.y * alpha_pp;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < cnt) {      // (uniform)
+        const sw_d2 sv = *reinterpret_cast<const sw_d2*>(sp[j] + i);
+        if (f0) pv.x = pv.x + sv.x * al[j];
+        if (f1) pv.y = pv.y + sv.y * al[j];
+      }
     }
-    if (f0) pv.x = pv.x + sv.x * alpha;
-    if (f1) pv.y = pv.y + sv.y * alpha;
     *reinterpret_cast<sw_d2*>(p + i) = pv;
   }
 }
@@ -2046,6 +2066,42 @@ static inline int sa_run(const euler_sim* S) {   // short runs while long ones w
   // chunks (runs of 8 only) - 8: 1177 us, 32: 1401
   return 8;
 }
+// p += alpha s, N iterations at a time (k_search_apply PMODE N): 4 - the search directions turn through a ring of four arrays, two of them allocated when the
+// first solve needs them; 2 (rounds 3-4: s and s2 alone) with the mailboxes, whose peers map exactly those two, and with the experimental run lengths.
+// EULER_P_STEPS=2 restores the two-array form everywhere (the same bits: the fmadds of main.c:753 are applied in their order either way).
+static inline int p_steps(const euler_sim* S) {
+  static const int env = getenv("EULER_P_STEPS") ? atoi(getenv("EULER_P_STEPS")) : 0;
+  if (S->p2p_on || sa_run(S) != 8) return 2;
+  return env == 2 ? 2 : 4;
+}
+// the ring of this solve: [0], [1] = s, s2 as the solve finds them, then the extra arrays (zeroed once; like s and s2 they are only ever written on fluid cells)
+static int ring_begin(euler_sim* S) {
+  const int n = p_steps(S);
+  if (!S->s_base[0]) { S->s_base[0] = S->s; S->s_base[1] = S->s2; }      // the two arrays of the handle (whichever way round the solves so far left them)
+  if (n > 2) { S->s = S->s_base[0]; S->s2 = S->s_base[1]; }             // (the last solve may have ended on one of the extra arrays)
+  else if (S->s != S->s_base[0] && S->s != S->s_base[1]) { S->s = S->s_base[0]; S->s2 = S->s_base[1]; }
+  else if (S->s2 != S->s_base[0] && S->s2 != S->s_base[1]) S->s2 = S->s == S->s_base[0] ? S->s_base[1] : S->s_base[0];
+  S->s_ring[0] = S->s; S->s_ring[1] = S->s2;
+  for (int k = 2; k < n; ++k) {
+    if (!S->s_ring_alloc[k]) {
+      const size_t elems = S->Sw + EU_SKEW_SLACK;
+      HIPCHK(hipMalloc(&S->s_ring_alloc[k], elems * sizeof(double)));
+      HIPCHK(hipMemsetAsync(S->s_ring_alloc[k], 0, elems * sizeof(double), S->stream));
+    }
+    S->s_ring[k] = static_cast<double*>(S->s_ring_alloc[k]) + EU_SKEW_SLACK - S->skew_off;
+  }
+  S->s_ring_n = n;
+  S->s_launched = 0;
+  return EULER_OK;
+}
+// EULER_F_PCG_S: the search direction of the last iteration that RAN (launches behind convergence return at once but still turn the ring)
+double* eu_current_search_direction(euler_sim* S) {
+  if (S->s_ring_n < 2 || S->s_launched <= 0) return S->s;
+  (void)hipStreamSynchronize(S->stream);      // sc_host: copied at the end of the solve
+  const int ran = S->sc_host->nonzero ? S->sc_host->iters : 0;
+  if (ran <= 0 || ran > S->s_launched) return S->s;
+  return S->s_ring[(ran - 1) % S->s_ring_n];
+}
 // iterations >= 1 of a single-GPU solve: s' = z + beta s and A s' in one launch; returns with S->s = s' and A s' in S->q
 static int launch_search_apply_and_alpha(euler_sim* S, int it) {
   const bool seq = S->cfg.dot_mode == EULER_DOT_SEQUENTIAL && !S->has_comm;
@@ -2069,7 +2125,10 @@ static int launch_search_apply_and_alpha(euler_sim* S, int it) {
   gl.S = S->e_cnt;
   // p += alpha s rides along, two iterations' worth on every even iteration (k_search_apply PMODE) - in every configuration since
   // round 3: the parity mode's k_update_pr read and wrote p on every iteration for nothing but this
-  const int pmode = (it >= 2 && (it & 1) == 0) ? 2 : 1;
+  const int steps = S->s_ring_n;
+  const int pmode = (it >= steps && it % steps == 0) ? steps : 1;
+  SaHist hist = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
+  for (int j = 1; j + 1 < steps; ++j) hist.s[j - 1] = LOC(S->s_ring[j]);      // PMODE N (it a multiple of N): s_(it-N+j) sits in ring[j]
   const int run = sa_run(S);
   const int fin = S->has_comm ? fin_or_comm(S, FIN_ALPHA) : (seq ? -1 : (int)FIN_ALPHA);
   double* pp = LOC(S->p);
@@ -2078,28 +2137,29 @@ static int launch_search_apply_and_alpha(euler_sim* S, int it) {
   const CoarseRef cref = {mg ? S->mg_x : S->cc_y, mg ? 4 : S->coarse_shift, mg ? S->mg_nx[0] : S->coarse_nx, mg ? S->mg_ny[0] : S->coarse_ny, S->band_lo};
 #define SA_LAUNCH_CS(SLABF, PM, RUNV, CF, ST)                                                                                                \
   LAUNCH(S, KC_APPLY_A, (k_search_apply<SLABF, PM, RUNV, CF, ST>), dim3(sa_blocks(S, RUNV)), dim3(SA_THREADS), LOC(S->s), LOC(S->z), LOC(S->s2), \
-         LOC(S->q), LOC(S->cellmask), gl, S->partial, S->sc, 0, S->red_counter, fin, nbr, pp, S->s2, S->s, (RUNV) == 8 ? S->chunk_list : (const unsigned int*)nullptr, cref)
+         LOC(S->q), LOC(S->cellmask), gl, S->partial, S->sc, 0, S->red_counter, fin, nbr, pp, S->s2, S->s, (RUNV) == 8 ? S->chunk_list : (const unsigned int*)nullptr, cref, hist)
 #define SA_LAUNCH_C(SLABF, PM, RUNV, CF) do { if ((RUNV) == 8 && !store) SA_LAUNCH_CS(SLABF, PM, RUNV, CF, ((RUNV) != 8)); else SA_LAUNCH_CS(SLABF, PM, RUNV, CF, true); } while (0)
 #define SA_LAUNCH(SLABF, PM, RUNV) SA_LAUNCH_C(SLABF, PM, RUNV, false)
 #define SA_RUNS(SLABF, PM) do { if (run == 8) SA_LAUNCH(SLABF, PM, 8); else if (run == 16) SA_LAUNCH(SLABF, PM, 16); else SA_LAUNCH(SLABF, PM, 32); } while (0)
   if (eu_is_two_level(S) && tile_fused(S) && ghost) {      // coarse correction on row slabs (multilevel mode): the ghost rows of z get their P y here as well
-    if (pmode == 2) SA_LAUNCH_C(2, 2, 8, true); else SA_LAUNCH_C(2, 1, 8, true);
+    if (pmode == 4) SA_LAUNCH_C(2, 4, 8, true); else if (pmode == 2) SA_LAUNCH_C(2, 2, 8, true); else SA_LAUNCH_C(2, 1, 8, true);
   } else if (eu_is_two_level(S) && tile_fused(S)) {      // two-level / multilevel preconditioner on one GPU: runs of 8 (the list), z + P y
-    if (pmode == 2) SA_LAUNCH_C(0, 2, 8, true); else SA_LAUNCH_C(0, 1, 8, true);
-  } else if (ghost) {      // (tile-local mode: pmode 1 or 2; several ranks: runs of 8)
-    if (pmode == 2) SA_LAUNCH(2, 2, 8); else SA_LAUNCH(2, 1, 8);
+    if (pmode == 4) SA_LAUNCH_C(0, 4, 8, true); else if (pmode == 2) SA_LAUNCH_C(0, 2, 8, true); else SA_LAUNCH_C(0, 1, 8, true);
+  } else if (ghost) {      // (tile-local mode; several ranks: runs of 8)
+    if (pmode == 4) SA_LAUNCH(2, 4, 8); else if (pmode == 2) SA_LAUNCH(2, 2, 8); else SA_LAUNCH(2, 1, 8);
   } else if (direct) {
     if (pmode == 2) { if (run == 8) SA_LAUNCH(1, 2, 8); else SA_LAUNCH(1, 2, 32); }
     else if (pmode == 1) { if (run == 8) SA_LAUNCH(1, 1, 8); else SA_LAUNCH(1, 1, 32); }
     else { if (run == 8) SA_LAUNCH(1, 0, 8); else SA_LAUNCH(1, 0, 32); }
   } else {
-    if (pmode == 2) SA_RUNS(0, 2); else if (pmode == 1) SA_RUNS(0, 1); else SA_RUNS(0, 0);
+    if (pmode == 4) SA_LAUNCH(0, 4, 8); else if (pmode == 2) SA_RUNS(0, 2); else if (pmode == 1) SA_RUNS(0, 1); else SA_RUNS(0, 0);
   }
 #undef SA_RUNS
 #undef SA_LAUNCH
 #undef SA_LAUNCH_C
 #undef SA_LAUNCH_CS
-  double* t = S->s; S->s = S->s2; S->s2 = t;
+  S->s = S->s_ring[it % steps]; S->s2 = S->s_ring[(it + 1) % steps];      // (two arrays: the swap of rounds 1-4)
+  S->s_launched = it + 1;
   if (seq)
     LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), S->q, S->s, S->cellmask, S->geom, S->sc, (int)FIN_ALPHA, 0);
   if (S->has_comm) return comm_finish(S, FIN_ALPHA, 0, 0);
@@ -2111,7 +2171,6 @@ int eu_launch_velocity_update(euler_sim* S, float dt);
 
 __global__ void k_pcg_reset(PcgScalars* sc, double tol, int max_iters) {
   sc->sigma = sc->zs = sc->sigma_new = sc->alpha = sc->alpha_prev = sc->beta = sc->rnorm = 0.0;
-  sc->s_last = sc->s_prev = nullptr;
   sc->tol = tol; sc->nonzero = 0; sc->done = 0; sc->iters = 0; sc->max_iters = max_iters;
 }
 
@@ -2120,6 +2179,7 @@ __global__ void k_pcg_reset(PcgScalars* sc, double tol, int max_iters) {
 // (exact coupling), the ghost rows of s before apply_a, one scalar all-reduce per reduction, and
 // the all-gather of p before the (replicated) velocity update.
 int eu_launch_project(euler_sim* S, float dt) {
+  S->s_launched = 0;      // (EULER_F_PCG_S: no multi-kernel iteration of this solve has run yet)
   // the previous solve's final scalars are in sc_host by now (copied at its end, synced since)
   S->solve_iters[S->solve_seq & 255] = S->sc_host->nonzero ? S->sc_host->iters : -1;
   if (S->solve_seq > 0) { S->res_last_chunks = S->sc_host->n_chunks; S->res_have_last = 1; }      // (the resident solver's guess for this solve, below)
@@ -2193,6 +2253,7 @@ int eu_launch_project(euler_sim* S, float dt) {
   if (S->cfg.precond != EULER_PRECOND_JACOBI && (rc = launch_sweep<SW_FACTOR>(S, KC_PRECON_FACTOR, 0))) return rc;   // once per solve
   if ((rc = launch_precondition(S, 0, FIN_SIGMA_INIT))) return rc;
   }
+  if ((rc = ring_begin(S))) return rc;      // (S->s = ring[0] takes the first search direction)
   if (two_level) { if ((rc = eu_launch_coarse_search_init(S))) return rc; }      // s = z + P y
   else
   LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<true>, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->s), LOC(S->z),
@@ -2204,13 +2265,18 @@ int eu_launch_project(euler_sim* S, float dt) {
   // ranks with their neighbours' z and s mapped run the fused kernel too (it reads across the slab boundary directly)
   // update_search of iteration k rides along with apply_a of iteration k + 1 in every configuration (several ranks: the ghost
   // rows of z and s are exchanged in front of it)
-  HIPCHK(hipMemsetAsync(LOC(S->s2), 0, S->e_cnt * sizeof(double), S->stream));   // s' of non-fluid cells is never written
+  // s' of non-fluid cells is never written: with two arrays the second one is cleared per solve as ever; a ring of four keeps what earlier solves left
+  // off the fluid - nothing reads those elements unmasked, EULER_F_PCG_S shows them as +0 (s_stale) - rather than clear three arrays per solve
+  // (s_stale with two arrays as well: the copy s = z above carries what z holds in tiles that are no longer active)
+  if (S->s_ring_n == 2) HIPCHK(hipMemsetAsync(LOC(S->s2), 0, S->e_cnt * sizeof(double), S->stream));
+  S->s_stale = 1;
   HIPCHK(hipMemcpyAsync(S->sc_host, S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
   HIPCHK(hipStreamSynchronize(S->stream));
   const int poll = S->cfg.pcg_poll_interval > 0 ? S->cfg.pcg_poll_interval : 8;
   const int max_it = S->cfg.max_iterations;
   int it = 0, chunk = 0;
   bool stop = !S->sc_host->nonzero;   // all_zero(r): main.c:742
+  S->s_none = stop ? 1 : 0;           // (no search direction exists: EULER_F_PCG_S reads as +0)
   while (it < max_it && !stop) {
     const int chunk_end = it + poll < max_it ? it + poll : max_it;
     for (; it < chunk_end; ++it) {
@@ -2256,7 +2322,13 @@ int eu_launch_project(euler_sim* S, float dt) {
   }
   S->prof_iter = -2;
   // the last one or two p += alpha s (the others rode along with the apply_a passes)
-  LAUNCH(S, KC_UPDATE_PR, k_finish_p, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->p), LOC(S->cellmask), S->e_lo, S->e_cnt, S->sc);
+  {
+    SRing ring;
+    for (int k = 0; k < 8; ++k) ring.s[k] = S->s_ring[k < S->s_ring_n ? k : 0];
+    ring.n = S->s_ring_n; ring.steps = S->s_ring_n;
+    LAUNCH(S, KC_UPDATE_PR, k_finish_p, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->p), LOC(S->cellmask), S->e_lo, S->e_cnt, S->sc, ring);
+    if (S->s_ring_n > 2) { S->s = S->s_base[0]; S->s2 = S->s_base[1]; }      // between solves S->s / S->s2 are the handle's own two arrays (EULER_F_PCG_S finds the last direction in the ring)
+  }
   if (S->has_comm && S->slab_on) {
     // row slabs: the velocity update of the highest own row reads p one row up (main.c:800) - one ghost row from the rank above
     const int X = S->X, nbk = (X + 255) / 256;
@@ -2281,6 +2353,8 @@ int eu_launch_project(euler_sim* S, float dt) {
 
 // single building blocks for kernel-level parity tests (euler_pcg_op)
 int eu_launch_pcg_op(euler_sim* S, int op, float dt, double a, double* out) {
+  S->s_none = 0;
+  S->s_launched = 0;      // (a single operation works on S->s as it stands)
   const bool want_scalar = op == EULER_OP_DOT_ZR || op == EULER_OP_DOT_ZS || op == EULER_OP_INF_NORM_R;
   const size_t SS = S->geom.S;
   if (eu_is_two_level(S) && (op == EULER_OP_PRECON_FACTOR || op == EULER_OP_FORWARD_SOLVE || op == EULER_OP_BACKWARD_SOLVE)) {
