@@ -54,16 +54,16 @@ _SWEEP = 3 * W + 1        # one IC(0) sweep of the reference's factor: read rhs,
 ITER_BYTES, PCG_BYTES = {}, {}
 
 
-def set_as_stored(stored, p_steps=4):
+def set_as_stored(stored, p_steps=8):
     """The byte table of the build's launches.  stored False (the default wherever this bench runs: tree dots, one GPU or compact ghost rows): A s' never goes to
-    memory - k_search_apply reads s, z and writes s' (3w+1), plus p += alpha s of FOUR iterations on every fourth pass (read p and the s of four, three and two
-    iterations ago, write p: 5w / 4 = 1.25w) -> 35.  stored True (sequential dots, mailboxes, EULER_TILE_STORE_AS=1): it also writes A s' -> 43, and the r update reads
-    that instead of s'.  p_steps 2 (mailboxes, EULER_P_STEPS=2): p on every second pass, 1.5w -> 37 / 45."""
-    apply_ = (4 if stored else 3) * W + 1 + (1.25 if p_steps == 4 else 1.5) * W
+    memory - k_search_apply reads s, z and writes s' (3w+1), plus p += alpha s of EIGHT iterations on every eighth pass (read p and the s of eight .. two
+    iterations ago, write p: 9w / 8 = 1.125w) -> 34.  stored True (sequential dots, mailboxes, EULER_TILE_STORE_AS=1): it also writes A s' -> 42, and the r update reads
+    that instead of s'.  p_steps N (mailboxes: 2; EULER_P_STEPS): p on every N-th pass, (N + 1) w / N -> 35 (4), 37 (2)."""
+    apply_ = (4 if stored else 3) * W + 1 + (p_steps + 1.0) / p_steps * W
     ITER_BYTES.clear()
     ITER_BYTES.update({
-        "ic0": {"forward_solve": _SWEEP, "backward_solve": _SWEEP, "apply_a": apply_, "update_pr": _RUPD},      # 110 (the reference's five loops: 18w+5 = 149; main.c as written: 212)
-        "ic0_tile": {"apply_a": apply_, "precond_tile": _TILE},                                                   # 68
+        "ic0": {"forward_solve": _SWEEP, "backward_solve": _SWEEP, "apply_a": apply_, "update_pr": _RUPD},      # 109 (the reference's five loops: 18w+5 = 149; main.c as written: 212)
+        "ic0_tile": {"apply_a": apply_, "precond_tile": _TILE},                                                   # 67
         "ic0_tile2": {"apply_a": apply_, "precond_tile": _TILE, "coarse_cycle": 0.0},
         # multilevel: + the V-cycle: 8 doubles of partial sums per 16x64 tile written and read (0.125 B/cell) and the level arrays, 1/256 of a solver array each (~0.2 B/cell)
         "ic0_tile_mg": {"apply_a": apply_, "precond_tile": _TILE, "coarse_cycle": 0.33},
@@ -599,11 +599,11 @@ def summarize(t, size_x, size_y, precond, tile_w, traffic, traffic_note, steps, 
                "frac_dense": round(bpc * cells / sec / 1e9 / HBM_PEAK_GBPS, 4)}
     if t.get("resident") and not per_iter:
         # the resident solver: r, s, p, E^-1 stay in registers / LDS for the whole solve - no HBM traffic inside it.  For comparison the figure the multi-kernel
-        # form would need for the same time: its algorithmic bytes (68 B per cell and iteration in double, 35 in float) / this time
+        # form would need for the same time: its algorithmic bytes (67 B per cell and iteration in double, 34.5 in float) / this time
         rs = t["resident"]
         sec = rs["ms_total"] / max(rs["iters"], 1) * 1e-3
         w = 4 if rs.get("f32") else W
-        bpc = 8.25 * w + 2
+        bpc = 8.125 * w + 2
         agg = {"us_per_iteration": round(1e6 * sec, 2), "resident": True, "solves": rs["solves"], "launches_per_iteration": 0,
                "hbm_bytes_inside_the_solve": 0, "equivalent_bytes_per_cell_iteration": bpc,
                "GBps_active": round(bpc * fluid / sec / 1e9, 1), "frac_active": round(bpc * fluid / sec / 1e9 / HBM_PEAK_GBPS, 4),
@@ -1196,7 +1196,7 @@ def main():
 
     dot_mode = ea.DOT_TREE if args.dot_mode == "tree" else ea.DOT_SEQUENTIAL
     set_as_stored(args.dot_mode != "tree" or bool(args.p2p) or os.environ.get("EULER_TILE_STORE_AS", "0") not in ("", "0"),
-                  2 if (args.p2p or os.environ.get("EULER_P_STEPS") == "2") else 4)      # which launches this run makes (k_pcg.hip tile_recompute, p_steps)
+                  2 if (args.p2p or os.environ.get("EULER_P_STEPS") == "2") else 4 if os.environ.get("EULER_P_STEPS") == "4" else 8)      # which launches this run makes (k_pcg.hip tile_recompute, p_steps)
     PC = {"ic0": ea.PRECOND_IC0, "jacobi": ea.PRECOND_JACOBI, "ic0_tile": ea.PRECOND_IC0_TILE, "ic0_tile2": ea.PRECOND_IC0_TILE2, "ic0_tile_mg": ea.PRECOND_IC0_TILE_MG}
     tile_w = args.tile_records or 16
     # N > 1 (weak scaling): the grid grows to N x (N * gpus) rows; the pressure solve is split into one

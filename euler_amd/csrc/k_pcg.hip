@@ -2066,13 +2066,14 @@ static inline int sa_run(const euler_sim* S) {   // short runs while long ones w
   // chunks (runs of 8 only) - 8: 1177 us, 32: 1401
   return 8;
 }
-// p += alpha s, N iterations at a time (k_search_apply PMODE N): 4 - the search directions turn through a ring of four arrays, two of them allocated when the
-// first solve needs them; 2 (rounds 3-4: s and s2 alone) with the mailboxes, whose peers map exactly those two, and with the experimental run lengths.
-// EULER_P_STEPS=2 restores the two-array form everywhere (the same bits: the fmadds of main.c:753 are applied in their order either way).
+// p += alpha s, N iterations at a time (k_search_apply PMODE N): 8 - the search directions turn through a ring of eight arrays, six of them allocated when the
+// first solve needs them (8192^2: 431 -> 421 us per iteration against 4, 473 -> 450 for 4 against 2); 2 (rounds 3-4: s and s2 alone) with the mailboxes, whose
+// peers map exactly those two, and with the experimental run lengths.  EULER_P_STEPS=2 / 4 select the shorter rings (the same bits: the fmadds of main.c:753
+// are applied in their order either way).
 static inline int p_steps(const euler_sim* S) {
   static const int env = getenv("EULER_P_STEPS") ? atoi(getenv("EULER_P_STEPS")) : 0;
   if (S->p2p_on || sa_run(S) != 8) return 2;
-  return env == 2 ? 2 : 4;
+  return env == 2 ? 2 : env == 4 ? 4 : 8;
 }
 // the ring of this solve: [0], [1] = s, s2 as the solve finds them, then the extra arrays (zeroed once; like s and s2 they are only ever written on fluid cells)
 static int ring_begin(euler_sim* S) {
@@ -2142,17 +2143,17 @@ static int launch_search_apply_and_alpha(euler_sim* S, int it) {
 #define SA_LAUNCH(SLABF, PM, RUNV) SA_LAUNCH_C(SLABF, PM, RUNV, false)
 #define SA_RUNS(SLABF, PM) do { if (run == 8) SA_LAUNCH(SLABF, PM, 8); else if (run == 16) SA_LAUNCH(SLABF, PM, 16); else SA_LAUNCH(SLABF, PM, 32); } while (0)
   if (eu_is_two_level(S) && tile_fused(S) && ghost) {      // coarse correction on row slabs (multilevel mode): the ghost rows of z get their P y here as well
-    if (pmode == 4) SA_LAUNCH_C(2, 4, 8, true); else if (pmode == 2) SA_LAUNCH_C(2, 2, 8, true); else SA_LAUNCH_C(2, 1, 8, true);
+    if (pmode == 8) SA_LAUNCH_C(2, 8, 8, true); else if (pmode == 4) SA_LAUNCH_C(2, 4, 8, true); else if (pmode == 2) SA_LAUNCH_C(2, 2, 8, true); else SA_LAUNCH_C(2, 1, 8, true);
   } else if (eu_is_two_level(S) && tile_fused(S)) {      // two-level / multilevel preconditioner on one GPU: runs of 8 (the list), z + P y
-    if (pmode == 4) SA_LAUNCH_C(0, 4, 8, true); else if (pmode == 2) SA_LAUNCH_C(0, 2, 8, true); else SA_LAUNCH_C(0, 1, 8, true);
+    if (pmode == 8) SA_LAUNCH_C(0, 8, 8, true); else if (pmode == 4) SA_LAUNCH_C(0, 4, 8, true); else if (pmode == 2) SA_LAUNCH_C(0, 2, 8, true); else SA_LAUNCH_C(0, 1, 8, true);
   } else if (ghost) {      // (tile-local mode; several ranks: runs of 8)
-    if (pmode == 4) SA_LAUNCH(2, 4, 8); else if (pmode == 2) SA_LAUNCH(2, 2, 8); else SA_LAUNCH(2, 1, 8);
+    if (pmode == 8) SA_LAUNCH(2, 8, 8); else if (pmode == 4) SA_LAUNCH(2, 4, 8); else if (pmode == 2) SA_LAUNCH(2, 2, 8); else SA_LAUNCH(2, 1, 8);
   } else if (direct) {
     if (pmode == 2) { if (run == 8) SA_LAUNCH(1, 2, 8); else SA_LAUNCH(1, 2, 32); }
     else if (pmode == 1) { if (run == 8) SA_LAUNCH(1, 1, 8); else SA_LAUNCH(1, 1, 32); }
     else { if (run == 8) SA_LAUNCH(1, 0, 8); else SA_LAUNCH(1, 0, 32); }
   } else {
-    if (pmode == 4) SA_LAUNCH(0, 4, 8); else if (pmode == 2) SA_RUNS(0, 2); else if (pmode == 1) SA_RUNS(0, 1); else SA_RUNS(0, 0);
+    if (pmode == 8) SA_LAUNCH(0, 8, 8); else if (pmode == 4) SA_LAUNCH(0, 4, 8); else if (pmode == 2) SA_RUNS(0, 2); else if (pmode == 1) SA_RUNS(0, 1); else SA_RUNS(0, 0);
   }
 #undef SA_RUNS
 #undef SA_LAUNCH

@@ -90,8 +90,8 @@ def test_the_guard_drops_parts_rather_than_overflow():
 def test_iteration_bytes_are_the_sum_of_the_launches():
     # the byte accounting follows the kernels (round 3 credited the parity mode 145 B for launches that declared 120); since k_search_apply no longer
     # stores A s' the launches declare 8 B less - except in the configurations that keep the stored form (sequential dots, mailboxes)
-    assert bench.PCG_BYTES["ic0"] == 25 + 25 + 35 + 25 == 110      # (p += alpha s on every FOURTH pass: 1.25 w instead of 1.5 w)
-    assert bench.PCG_BYTES["ic0_tile"] == 35 + 33 == 68
+    assert bench.PCG_BYTES["ic0"] == 25 + 25 + 34 + 25 == 109      # (p += alpha s on every EIGHTH pass: 1.125 w instead of 1.5 w)
+    assert bench.PCG_BYTES["ic0_tile"] == 34 + 33 == 67
     for mode, classes in bench.ITER_BYTES.items():
         assert abs(bench.PCG_BYTES[mode] - sum(classes.values())) < 1e-12
     try:
