@@ -554,16 +554,16 @@ def test_a_s_formed_again_in_the_r_update_has_the_stored_forms_bits():
     and as the other modes' r update - forms it again from s' with the same expression (main.c:679-691).  EULER_TILE_STORE_AS=1 restores the stored form.  Likewise
     p += alpha s is applied eight iterations at a time out of a ring of eight search arrays (the fmadds of main.c:753 in their order); EULER_P_STEPS=2 restores the
     two-array form, 4 a ring of four.  A few frames of four modes (resident solver off, so that the kernels in question run) leave the same bits in every field and
-    solver vector in all four forms."""
+    solver vector in all of them (run: the default; stored A s' with a ring of four; recomputed A s' with the two arrays)."""
     import json
     import os
     import subprocess
     import sys
     runs = []
-    for extra in ({}, {"EULER_TILE_STORE_AS": "1"}, {"EULER_P_STEPS": "2"}, {"EULER_P_STEPS": "4"}):
+    for extra in ({}, {"EULER_TILE_STORE_AS": "1", "EULER_P_STEPS": "4"}, {"EULER_P_STEPS": "2"}):
         env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), **extra)
         out = subprocess.run([sys.executable, "-c", _AS_FORMS_CODE], capture_output=True, text=True, env=env, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         runs.append(json.loads(out.stdout.strip().splitlines()[-1]))
-    assert runs[0] == runs[1] == runs[2] == runs[3], runs
+    assert runs[0] == runs[1] == runs[2], runs
     assert all(v[1] > 50 for v in runs[0].values()), runs[0]      # the solves iterated

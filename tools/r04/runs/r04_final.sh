@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4, last GPU call of a batch: the full -m gpu suite with durations and the driver's bench command at HEAD
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -q --durations=25 > gpurun_out/r04_suite_final.txt 2>&1
+python -m pytest tests -m gpu -q --durations=0 > gpurun_out/r04_suite_final.txt 2>&1
 tail -4 gpurun_out/r04_suite_final.txt
 ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r04_bench_default.json 2> gpurun_out/r04_bench_default.log ) 2> gpurun_out/r04_bench_default.time
 wc -c gpurun_out/r04_bench_default.json; tail -2 gpurun_out/r04_bench_default.log; cat gpurun_out/r04_bench_default.time
