@@ -212,7 +212,7 @@ struct euler_sim {
   uint8_t* chunk_flag;    // this solve: the chunk holds fluid
   uint8_t* chunk_prev;    // the previous solve's flags (k_build_system<true>: where stale masks / p / r may sit)
   uint8_t* chunk_part;    // this solve: some cell of the chunk is not CM_INTERIOR (the listed entry of an interior chunk carries EU_CHUNK_INTERIOR)
-  size_t hbm_bytes;       // device memory this handle allocated at creation (euler_hbm_bytes)
+  size_t hbm_bytes;       // device memory this handle allocated: at creation, plus the search directions' ring when the first multi-kernel solve needs it (euler_hbm_bytes)
   int lean_ok;            // the solver arrays have only been written by solves since chunk_prev was current (else k_build_system writes them whole)
   double* tile_table;     // [8][64][2]: E^-1 of an interior tile of 16 records (k_tile_table) - the same for every interior tile, so k_precond_tile never streams it
   unsigned long long* chunk_bits;

@@ -2087,6 +2087,7 @@ static int ring_begin(euler_sim* S) {
     if (!S->s_ring_alloc[k]) {
       const size_t elems = S->Sw + EU_SKEW_SLACK;
       HIPCHK(hipMalloc(&S->s_ring_alloc[k], elems * sizeof(double)));
+      S->hbm_bytes += elems * sizeof(double);      // (euler_hbm_bytes: what the handle holds)
       HIPCHK(hipMemsetAsync(S->s_ring_alloc[k], 0, elems * sizeof(double), S->stream));
     }
     S->s_ring[k] = static_cast<double*>(S->s_ring_alloc[k]) + EU_SKEW_SLACK - S->skew_off;

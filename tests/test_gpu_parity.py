@@ -624,7 +624,7 @@ def test_full_size_8192_half_tank_properties(precond):
 
 
 def test_full_size_16384_dam_break_properties_both_modes():
-    """BASELINE configs[3] at its full size on one GPU (16384^2 dam break: 83 M fluid cells, 334 M markers, ~48 GB of HBM),
+    """BASELINE configs[3] at its full size on one GPU (16384^2 dam break: 83 M fluid cells, 334 M markers, ~61 GB of HBM with the ring of search directions),
     rolled into the expensive phase (every substep runs PCG into the iteration cap, main.c:735), then one frame in the tile-local
     mode and one in the reference's IC(0), each through the size-independent properties: the count grid is the histogram of the
     marker array (on a 2048-row stripe through the water), the residual the solver reports is max |r| of the vector it carries,
