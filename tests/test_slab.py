@@ -8,6 +8,8 @@ import sys
 
 import pytest
 
+import ranks
+
 from euler_amd.slab import slab_bands
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,14 +42,13 @@ def check_same_iterates(f, workload):
 
 
 def run_workers(nproc, X, Y, workload, frames, coupling, port, extra=(), fusion=False):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ)
     if fusion:      # opt-in: k_search_apply reading the neighbouring slabs' z / s through IPC mappings
         env["EULER_SLAB_FUSION"] = "1"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc, "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "slab_worker.py"), str(X), str(Y), workload, str(frames), str(coupling)] + list(extra)
-    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
-    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
-    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    # (ranks started directly, tests/ranks.py: the environment torch.distributed.run gives them, without the launcher's two seconds per case)
+    rc, out, err = ranks.launch(nproc, os.path.join(ROOT, "tests", "slab_worker.py"), [X, Y, workload, frames, coupling] + list(extra), port, env=env)
+    assert rc == 0, (out[-1500:], err[-3000:])
+    return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
 
 
 @pytest.mark.gpu
@@ -104,12 +105,9 @@ def test_slab_local_preconditioner_converges_to_the_same_answer():
 
 
 def run_rccl_worker(nproc, X, Y, workload, frames, coupling, port, extra=()):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc, "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "rccl_worker.py"), str(X), str(Y), workload, str(frames), str(coupling)] + list(extra)
-    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
-    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
-    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    rc, out, err = ranks.launch(nproc, os.path.join(ROOT, "tests", "rccl_worker.py"), [X, Y, workload, frames, coupling] + list(extra), port)
+    assert rc == 0, (out[-1500:], err[-3000:])
+    return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
 
 
 def gpu_count():

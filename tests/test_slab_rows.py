@@ -14,17 +14,16 @@ import sys
 import pytest
 
 import euler_amd as ea
+import ranks
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def run(nproc, X, Y, workload, frames, precond, port, extra=()):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc, "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "slab_rows_worker.py"), str(X), str(Y), workload, str(frames), str(precond)] + list(extra)
-    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1200)
-    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
-    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    # (ranks started directly, tests/ranks.py: the same environment torch.distributed.run gives them, without the launcher's two seconds per case)
+    rc, out, err = ranks.launch(nproc, os.path.join(ROOT, "tests", "slab_rows_worker.py"), [X, Y, workload, frames, precond] + list(extra), port, timeout=1200)
+    assert rc == 0, (out[-1500:], err[-3000:])
+    return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
 
 
 @pytest.mark.gpu
@@ -263,12 +262,9 @@ def test_exchange_overflow_fails_on_every_rank():
 @pytest.mark.gpu
 def test_a_partition_with_a_gap_is_refused():
     """explicit band ranges that do not tile the grid are caught collectively when the communicator is installed"""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29587",
-           os.path.join(ROOT, "tests", "slab_rows_worker.py"), "256", "512", "dam_break", "1", str(ea.PRECOND_IC0_TILE), "bands=0-3,4-8"]
-    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
-    assert out.returncode != 0
-    assert "do not tile" in out.stderr, out.stderr[-2000:]
+    rc, out, err = ranks.launch(2, os.path.join(ROOT, "tests", "slab_rows_worker.py"), [256, 512, "dam_break", 1, ea.PRECOND_IC0_TILE, "bands=0-3,4-8"], 29587, timeout=600)
+    assert rc != 0
+    assert "do not tile" in err, err[-2000:]
 
 
 @pytest.mark.gpu
