@@ -75,6 +75,7 @@ struct MarkerState {
   float dt_final;             // dt after the last marker (debug)
   float dt;                   // calculate_timestep result
   unsigned int max_u2_bits, max_v2_bits;
+  unsigned int dt_ticket;     // k_maxsq: blocks that have delivered their maxima (the last one forms dt on a whole-grid handle)
   int error;                  // sticky device-side error (bounded waits)
   // row slabs (k_slab.hip): n above is the GLOBAL marker count (the reference's g_markers_length); this rank holds n_loc of them
   unsigned long long n_loc;

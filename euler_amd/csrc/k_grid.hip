@@ -8,14 +8,46 @@
 
 // ------------------------------------------------------------------------------------------
 // calculate_timestep / maxsq (main.c:808-841): max over the typed extents, including zeros.
+// A block walks whole rows (no division per element; float4 loads where the rows are 16-byte aligned), the maxima are exact and order-independent.  FUSE_DT
+// (whole-grid handles): the block that delivers last forms dt as well - k_dt's arithmetic - instead of a second launch.
+__device__ __forceinline__ void dt_from_maxima(MarkerState* ms, float frame_time_left, unsigned int mu_bits, unsigned int mv_bits) {
+  const float mu = __uint_as_float(mu_bits), mv = __uint_as_float(mv_bits);
+  const float max_distance = 0.75f * EU_H;
+  const float max_velocity = sqrtf(mu + mv);
+  ms->dt = fminf(max_distance / max_velocity, frame_time_left);   // 0.75/0 = +inf -> frame time
+  ms->max_u2_bits = 0u;
+  ms->max_v2_bits = 0u;
+}
+template <bool FUSE_DT>
 __global__ __launch_bounds__(256) void k_maxsq(const float* __restrict__ u, const float* __restrict__ v,
-                                               int X, int Y, MarkerState* ms, int y0, int y1) {   // rows [y0, y1) of this rank
-  const size_t C = (size_t)X * y1;
+                                               int X, int Y, MarkerState* ms, int y0, int y1, float frame_time_left) {   // rows [y0, y1) of this rank
   float mu = 0.f, mv = 0.f;
-  for (size_t i = (size_t)X * y0 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < C; i += (size_t)gridDim.x * blockDim.x) {
-    const int x = (int)(i % X), y = (int)(i / X);
-    if (x < X - 1) { const float s = u[i] * u[i]; if (s > mu) mu = s; }
-    if (y < Y - 1) { const float s = v[i] * v[i]; if (s > mv) mv = s; }
+  const bool vec = (X & 3) == 0;
+  for (int y = y0 + (int)blockIdx.x; y < y1; y += (int)gridDim.x) {
+    const float* ur = u + (size_t)y * X;
+    const float* vr = v + (size_t)y * X;
+    const bool vrow = y < Y - 1;
+    if (vec) {
+      for (int x = 4 * (int)threadIdx.x; x < X; x += 4 * 256) {
+        const float4 a = *reinterpret_cast<const float4*>(ur + x);
+        float s = a.x * a.x; if (s > mu) mu = s;
+        s = a.y * a.y; if (s > mu) mu = s;
+        s = a.z * a.z; if (s > mu) mu = s;
+        if (x + 3 < X - 1) { s = a.w * a.w; if (s > mu) mu = s; }
+        if (vrow) {
+          const float4 b = *reinterpret_cast<const float4*>(vr + x);
+          s = b.x * b.x; if (s > mv) mv = s;
+          s = b.y * b.y; if (s > mv) mv = s;
+          s = b.z * b.z; if (s > mv) mv = s;
+          s = b.w * b.w; if (s > mv) mv = s;
+        }
+      }
+    } else {
+      for (int x = (int)threadIdx.x; x < X; x += 256) {
+        if (x < X - 1) { const float s = ur[x] * ur[x]; if (s > mu) mu = s; }
+        if (vrow) { const float s = vr[x] * vr[x]; if (s > mv) mv = s; }
+      }
+    }
   }
   mu = eu_wave_maxf(mu);
   mv = eu_wave_maxf(mv);
@@ -28,17 +60,19 @@ __global__ __launch_bounds__(256) void k_maxsq(const float* __restrict__ u, cons
     // non-negative floats order like their bit patterns; NaN never gets here (s > m is false)
     atomicMax(&ms->max_u2_bits, __float_as_uint(mu));
     atomicMax(&ms->max_v2_bits, __float_as_uint(mv));
+    if (FUSE_DT) {
+      __threadfence();
+      if (atomicAdd(&ms->dt_ticket, 1u) == gridDim.x - 1) {      // every block's maxima are in
+        __threadfence();
+        dt_from_maxima(ms, frame_time_left, __hip_atomic_load(&ms->max_u2_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       __hip_atomic_load(&ms->max_v2_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        __hip_atomic_store(&ms->dt_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 }
 
-__global__ void k_dt(MarkerState* ms, float frame_time_left) {
-  const float mu = __uint_as_float(ms->max_u2_bits), mv = __uint_as_float(ms->max_v2_bits);
-  const float max_distance = 0.75f * EU_H;
-  const float max_velocity = sqrtf(mu + mv);
-  ms->dt = fminf(max_distance / max_velocity, frame_time_left);   // 0.75/0 = +inf -> frame time
-  ms->max_u2_bits = 0u;
-  ms->max_v2_bits = 0u;
-}
+__global__ void k_dt(MarkerState* ms, float frame_time_left) { dt_from_maxima(ms, frame_time_left, ms->max_u2_bits, ms->max_v2_bits); }
 
 int eu_launch_dt(euler_sim* S, float frame_time_left) {
   LAUNCH(S, KC_TIMESTEP, k_dt, dim3(1), dim3(1), S->ms, frame_time_left);
@@ -46,10 +80,13 @@ int eu_launch_dt(euler_sim* S, float frame_time_left) {
 }
 
 int eu_launch_timestep(euler_sim* S, float frame_time_left) {
-  LAUNCH(S, KC_TIMESTEP, k_maxsq, dim3(eu_blocks((size_t)S->X * (S->row_hi - S->row_lo), 256 * 8, 2048)), dim3(256), S->u, S->v, S->X, S->Y, S->ms,
-         S->row_lo, S->row_hi);
-  if (S->slab_on) return eu_slab_timestep(S, frame_time_left);   // max over the slabs first
-  LAUNCH(S, KC_TIMESTEP, k_dt, dim3(1), dim3(1), S->ms, frame_time_left);
+  const int rows = S->row_hi - S->row_lo;
+  const unsigned nb = (unsigned)(rows < 2048 ? rows : 2048);
+  if (S->slab_on) {      // max over the slabs first
+    LAUNCH(S, KC_TIMESTEP, k_maxsq<false>, dim3(nb), dim3(256), S->u, S->v, S->X, S->Y, S->ms, S->row_lo, S->row_hi, frame_time_left);
+    return eu_slab_timestep(S, frame_time_left);
+  }
+  LAUNCH(S, KC_TIMESTEP, k_maxsq<true>, dim3(nb), dim3(256), S->u, S->v, S->X, S->Y, S->ms, S->row_lo, S->row_hi, frame_time_left);
   return EULER_OK;
 }
 
