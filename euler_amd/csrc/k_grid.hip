@@ -23,29 +23,40 @@ __global__ __launch_bounds__(256) void k_maxsq(const float* __restrict__ u, cons
                                                int X, int Y, MarkerState* ms, int y0, int y1, float frame_time_left) {   // rows [y0, y1) of this rank
   float mu = 0.f, mv = 0.f;
   const bool vec = (X & 3) == 0;
-  for (int y = y0 + (int)blockIdx.x; y < y1; y += (int)gridDim.x) {
-    const float* ur = u + (size_t)y * X;
-    const float* vr = v + (size_t)y * X;
-    const bool vrow = y < Y - 1;
+  for (int yq = y0 + 4 * (int)blockIdx.x; yq < y1; yq += 4 * (int)gridDim.x) {      // four rows at a time: eight independent loads in flight per thread
     if (vec) {
       for (int x = 4 * (int)threadIdx.x; x < X; x += 4 * 256) {
-        const float4 a = *reinterpret_cast<const float4*>(ur + x);
-        float s = a.x * a.x; if (s > mu) mu = s;
-        s = a.y * a.y; if (s > mu) mu = s;
-        s = a.z * a.z; if (s > mu) mu = s;
-        if (x + 3 < X - 1) { s = a.w * a.w; if (s > mu) mu = s; }
-        if (vrow) {
-          const float4 b = *reinterpret_cast<const float4*>(vr + x);
-          s = b.x * b.x; if (s > mv) mv = s;
-          s = b.y * b.y; if (s > mv) mv = s;
-          s = b.z * b.z; if (s > mv) mv = s;
-          s = b.w * b.w; if (s > mv) mv = s;
+        float4 a[4], b[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int y = yq + r < y1 ? yq + r : y1 - 1;      // (a row counted twice changes no maximum)
+          a[r] = *reinterpret_cast<const float4*>(u + (size_t)y * X + x);
+          b[r] = *reinterpret_cast<const float4*>(v + (size_t)y * X + x);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int y = yq + r < y1 ? yq + r : y1 - 1;
+          float s = a[r].x * a[r].x; if (s > mu) mu = s;
+          s = a[r].y * a[r].y; if (s > mu) mu = s;
+          s = a[r].z * a[r].z; if (s > mu) mu = s;
+          if (x + 3 < X - 1) { s = a[r].w * a[r].w; if (s > mu) mu = s; }
+          if (y < Y - 1) {
+            s = b[r].x * b[r].x; if (s > mv) mv = s;
+            s = b[r].y * b[r].y; if (s > mv) mv = s;
+            s = b[r].z * b[r].z; if (s > mv) mv = s;
+            s = b[r].w * b[r].w; if (s > mv) mv = s;
+          }
         }
       }
     } else {
-      for (int x = (int)threadIdx.x; x < X; x += 256) {
-        if (x < X - 1) { const float s = ur[x] * ur[x]; if (s > mu) mu = s; }
-        if (vrow) { const float s = vr[x] * vr[x]; if (s > mv) mv = s; }
+      for (int r = 0; r < 4 && yq + r < y1; ++r) {
+        const int y = yq + r;
+        const float* ur = u + (size_t)y * X;
+        const float* vr = v + (size_t)y * X;
+        for (int x = (int)threadIdx.x; x < X; x += 256) {
+          if (x < X - 1) { const float s = ur[x] * ur[x]; if (s > mu) mu = s; }
+          if (y < Y - 1) { const float s = vr[x] * vr[x]; if (s > mv) mv = s; }
+        }
       }
     }
   }
@@ -80,8 +91,8 @@ int eu_launch_dt(euler_sim* S, float frame_time_left) {
 }
 
 int eu_launch_timestep(euler_sim* S, float frame_time_left) {
-  const int rows = S->row_hi - S->row_lo;
-  const unsigned nb = (unsigned)(rows < 2048 ? rows : 2048);
+  const int quads = (S->row_hi - S->row_lo + 3) / 4;      // a block walks four rows at a time
+  const unsigned nb = (unsigned)(quads < 1024 ? quads : 1024);
   if (S->slab_on) {      // max over the slabs first
     LAUNCH(S, KC_TIMESTEP, k_maxsq<false>, dim3(nb), dim3(256), S->u, S->v, S->X, S->Y, S->ms, S->row_lo, S->row_hi, frame_time_left);
     return eu_slab_timestep(S, frame_time_left);

@@ -12,7 +12,7 @@ con = sqlite3.connect(glob.glob("gpurun_out/prof_gap/*_results.db")[0])
 rows = con.execute("select name, start, end from kernels order by start").fetchall()
 # the timed frames are the tail: take the last `frames` frames = from the (frames*?)-th k_maxsq from the end... use the last 40% of the k_dt launches' region
 names = [r[0].split("(")[0].replace("void ", "") for r in rows]
-dts = [i for i, n in enumerate(names) if n.startswith("k_dt")]
+dts = [i for i, n in enumerate(names) if n.startswith("k_maxsq")]
 # substeps of the timed region: count back substeps until ~frames*4.. just take the last 20 substeps
 first = dts[-21]
 last = dts[-1]
@@ -31,7 +31,7 @@ print("-- largest gaps (us per substep)")
 for k, v in sorted(gap_after.items(), key=lambda x: -x[1])[:24]:
     print("%-90s %8.1f  (%d per substep, %.1f us each)" % (k[:90], v / 20e3, cnt[k] / 20, v / cnt[k] / 1e3))
 print("-- kernel time (us per substep)")
-for k, v in sorted(dur.items(), key=lambda x: -x[1])[:16]:
+for k, v in sorted(dur.items(), key=lambda x: -x[1])[:40]:
     print("%-60s %8.1f" % (k[:60], v / 20e3))
 P
 rm -rf gpurun_out/prof_gap
