@@ -152,7 +152,9 @@ enum {
   EULER_F_MARKERS,        /* float2[n_markers] g_markers main.c:95, in the reference's array order */
   EULER_F_PRECON,         /* double g_precon main.c:577 (persistent state) */
   EULER_F_PRESSURE,       /* double p — a stack local of project(), main.c:739; exposed here */
-  EULER_F_PCG_B, EULER_F_PCG_R, EULER_F_PCG_Z, EULER_F_PCG_S, EULER_F_PCG_Q, /* double, main.c:716-745,578 */
+  EULER_F_PCG_B, EULER_F_PCG_R, EULER_F_PCG_Z, EULER_F_PCG_S, EULER_F_PCG_Q, /* double, main.c:716-745,578.  Test surface: after a solve S is the search
+                                                              direction of the last iteration that ran (+0 off the fluid and when the right-hand side was
+                                                              all zero); Q holds A s only where a solve stores it (most do not any more) */
   EULER_F_CELLMASK,       /* uint8: bit0 fluid, bit1..4 fluid at x+1,y+1,x-1,y-1, bits5-7 a_diag (g_a, main.c:552) */
   EULER_F_DYE_R, EULER_F_DYE_G, EULER_F_DYE_B,             /* float g_r, g_g, g_b (main.c:76-78); euler_config.rainbow only */
   EULER_F_DYE_RTMP, EULER_F_DYE_GTMP, EULER_F_DYE_BTMP,    /* float g_rtmp, g_gtmp, g_btmp (main.c:79-81): state, because the
