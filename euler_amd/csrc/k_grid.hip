@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256) void k_extrapolate4(float* u, float* v, const 
 int eu_launch_extrapolate(euler_sim* S) {
   // (a small grid has too few waves to hide the longer thread: 1024^2 extrapolates in 5.7 us a cell per thread, in 11.4 four per thread; 8192^2: 186 -> 79 us,
   // zero_bounds 217 -> 149 us)
-  if ((S->X & 3) == 0 && (size_t)S->X * (S->row_hi - S->row_lo) >= ((size_t)1 << 22)) {
+  static const size_t min_cells = getenv("EULER_GRID4_MIN_CELLS") ? (size_t)atoll(getenv("EULER_GRID4_MIN_CELLS")) : ((size_t)1 << 22);      // (tests: 0 selects the four-cell kernels on any grid)
+  if ((S->X & 3) == 0 && (size_t)S->X * (S->row_hi - S->row_lo) >= min_cells) {
     dim3 grid4((S->X / 4 + 63) / 64, (S->row_hi - S->row_lo + 3) / 4);
     LAUNCH(S, KC_EXTRAPOLATE, k_extrapolate4, grid4, dim3(256), S->u, S->v, S->prev_count, S->count, S->X, S->Y, S->row_lo, S->row_hi);
     LAUNCH(S, KC_EXTRAPOLATE, k_zero_bounds4, grid4, dim3(256), S->u, S->v, S->count, S->solid, S->X, S->Y, S->row_lo, S->row_hi);
