@@ -30,15 +30,16 @@
 #define CC_NULL_MAX 4       // fluid regions cut off from the air whose indicators are kept (k_coarse_nullfix)
 #define CC_NULL_TOTAL (CC_NULL_MAX * CC_MAX + 1 + 2 * CC_NULL_MAX + 512 * 2 * CC_NULL_MAX + 1)      // = NS_TOTAL below
 #define MG_DOT_BLOCKS 512    // most blocks of the level-0 kernel that closes the V-cycle (its dot partials)
-// Round 4 scanned both on the GPU (tools/r04/mg_scan.py; iterations per solve to 1e-6 at 0.8 / 1.5, the values of round 3, and at 1.0 / 1.8: 8192^2 half tank 155 -> 127,
-// 2048^2 dam break 43.2 -> 39.9, 2048^2 waterfall 129.5 -> 120.7).  omega = 1 is the largest admissible value: the cycle is symmetric positive SEMI-definite for
+// Round 4 scanned both on the GPU (tools/r04/mg_scan.py, mg_scan16k.py; iterations per solve to 1e-6 at 0.8 / 1.5, the values of round 3, and at 1.0 / 1.7: 8192^2 half
+// tank 155 -> 128, 2048^2 dam break 43.2 -> 40.3, 2048^2 waterfall 129.5 -> 121.7; 1.8 - 2.0 are a little better still on deep water (4096^2 waterfall 165 -> 147 at
+// 1.8) and worse on the thin sheet of a dam break's first frames after impact (16384^2: 90 -> 101 iterations over those frames): 1.7 sits between.  omega = 1 is the largest admissible value: the cycle is symmetric positive SEMI-definite for
 // omega <= 2 / lambda_max(D^-1 A) (-> 1 on a large grid), and the tile-local part of the preconditioner is positive definite, so the sum stays SPD; at 1.1 PCG needs
 // four times the iterations and at 1.2 it does not converge any more.
 #ifndef MG_OMEGA
 #define MG_OMEGA 1.0         // Jacobi (undamped)
 #endif
 #ifndef MG_KAPPA
-#define MG_KAPPA 1.8         // scaling of the coarse-grid correction (plain aggregation under-corrects)
+#define MG_KAPPA 1.7         // scaling of the coarse-grid correction (plain aggregation under-corrects)
 #endif
 
 #define COMM_CALL(expr) do { if ((expr) != 0) { eu_set_error("communicator callback failed: %s", #expr); return EULER_ECOMM; } } while (0)

@@ -683,7 +683,7 @@ static void coarse_correction(eo_sim* s, const double* r, double* z) {
 typedef struct { int nx, ny; int *d, *rt, *up; double *rhs, *x, *t; } mg_level;
 typedef struct { int nlev; mg_level lv[16]; } mg_hierarchy;
 #define MG_OMEGA 1.0      /* (round 4: 0.8 / 1.5 before; k_coarse.hip says why) */
-#define MG_KAPPA 1.8
+#define MG_KAPPA 1.7
 static void mg_free(eo_sim* s) {
   mg_hierarchy* h = (mg_hierarchy*)s->mg;
   if (!h) return;
