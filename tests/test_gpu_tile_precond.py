@@ -534,7 +534,7 @@ import numpy as np
 import euler_amd as ea
 from euler_amd import scenarios
 out = {}
-for name, pc, size, scn, frames in (("tile", ea.PRECOND_IC0_TILE, (448, 320), "dam_break", 45), ("mg", ea.PRECOND_IC0_TILE_MG, (640, 384), "waterfall", 10),
+for name, pc, size, scn, frames in (("tile", ea.PRECOND_IC0_TILE, (448, 320), "dam_break", 45), ("mg", ea.PRECOND_IC0_TILE_MG, (384, 320), "dam_break", 45),
                                     ("ic0", ea.PRECOND_IC0, (320, 448), "waterfall", 6), ("jacobi", ea.PRECOND_JACOBI, (257, 193), "waterfall", 6)):
     s = ea.Simulation(size[0], size[1], dot_mode=ea.DOT_TREE, precond=pc, resident=ea.RESIDENT_OFF).load_text(getattr(scenarios, scn)(), upscale=True)
     h = hashlib.sha1()
