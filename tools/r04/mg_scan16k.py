@@ -14,7 +14,7 @@ for name, N, scn, pre, frames in (("dam16384", 16384, "dam_break", None, 8), ("d
     if pre is None:
         while n < 80:
             s.step(); n += 1
-            if s.stats().last_pcg_iterations > 0:
+            if s.stats().last_pcg_iterations >= 15 * s.stats().last_substeps:      # (the impact, not the first trickle of iterations in free fall)
                 break
     else:
         for _ in range(pre):
