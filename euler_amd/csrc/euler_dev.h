@@ -478,20 +478,36 @@ __device__ __forceinline__ float eu_wave_maxf(float v) {
 // 32-byte memory-side transaction in a column-ordered array: k_bin_markers at 8192^2: 5.1 ms with one atomic per marker).
 __device__ __forceinline__ void bin_aggregated(unsigned int* count32, bool live, size_t c) {
   // (the adds are executed at the memory side, ~11 G/s whatever their width: at 8192^2 they, not the marker reads, set the
-  // binning kernel's time - 3.4 ms against 0.5 ms without them.  The seeding order walks COLUMNS, main.c:243-266, so
-  // consecutive runs land X cells apart and cannot share a 64-bit add.)
+  // binning kernel's time - 3.4 ms against 0.5 ms without them.)  One add per RUN of lanes binning into the same cell - and, since the
+  // counters are column-major like the seeding order (main.c:243-266: consecutive runs are consecutive cells of one column), ONE 64-bit add
+  // for two runs whose cells are an even / odd pair of neighbouring counters: the low word takes the even cell's run, the high word the odd
+  // cell's (no carry: a counter stays far below 2^32).
   const unsigned int lo = (unsigned int)c, hi = (unsigned int)(c >> 32);
   const int lane = threadIdx.x & 63;
   const unsigned int plo = __shfl_up(lo, 1, 64), phi = __shfl_up(hi, 1, 64);
   const bool plive = __shfl_up((int)live, 1, 64) != 0;
   const bool head = live && (lane == 0 || !plive || plo != lo || phi != hi);     // first lane of a run of equal cells
   const unsigned long long heads = __ballot(head), lives = __ballot(live);
-  if (head) {
-    // the run ends before the next head or the next dead lane
-    const unsigned long long above = lane == 63 ? 0ull : ((heads | ~lives) >> (lane + 1));
-    const int run = above ? __ffsll((long long)above) : 64 - lane;
+  // the run ends before the next head or the next dead lane
+  const unsigned long long above = lane == 63 ? 0ull : ((heads | ~lives) >> (lane + 1));
+  const int run = above ? __ffsll((long long)above) : 64 - lane;
+  // the run behind this one: starts at lane + run if that lane is a head (i.e. no dead lane in between)
+  const int nl = lane + run;
+  const bool has_next = head && nl < 64 && ((heads >> nl) & 1ull);
+  const int src = has_next ? nl : lane;
+  const unsigned int nlo = __shfl(lo, src, 64), nhi = __shfl(hi, src, 64);
+  const int nrun = __shfl(run, src, 64);
+  const bool pairs = has_next && !(lo & 1u) && nlo == lo + 1u && nhi == hi;      // (c even: the 64-bit add is aligned)
+  // is this head the second of such a pair?  The head below it is the highest head bit under this lane
+  const unsigned long long below = heads & ((1ull << lane) - 1ull);
+  const int pl = below ? 63 - __clzll((long long)below) : lane;
+  const unsigned int qlo = __shfl(lo, pl, 64), qhi = __shfl(hi, pl, 64);
+  const int qrun = __shfl(run, pl, 64);
+  const bool absorbed = head && below && (lo & 1u) && qlo + 1u == lo && qhi == hi && pl + qrun == lane;
+  if (head && !absorbed) {
 #ifndef EU_EXP_BIN_NOATOMIC      // (timing experiment, WRONG results)
-    atomicAdd(&count32[c], (unsigned int)run);
+    if (pairs) atomicAdd(reinterpret_cast<unsigned long long*>(&count32[c]), (unsigned long long)(unsigned int)run | ((unsigned long long)(unsigned int)nrun << 32));
+    else atomicAdd(&count32[c], (unsigned int)run);
 #else
     if (run == 12345) count32[c] = 1;
 #endif
