@@ -12,8 +12,11 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 sim = ea.Simulation(N, N, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE_MG, tol=1e-6, max_iterations=2000).load_text(scenarios.dam_break(), upscale=True)
 t0 = time.time()
-while sim.stats().last_pcg_iterations == 0 and time.time() - t0 < 120:
+while time.time() - t0 < 120:
     sim.step()
+    st = sim.stats()
+    if st.last_pcg_iterations >= 15 * st.last_substeps:      # (the impact, not the trickle of iterations in free fall)
+        break
 for _ in range(2):
     sim.step()
 
