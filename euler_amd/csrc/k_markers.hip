@@ -93,8 +93,53 @@ __global__ __launch_bounds__(SEL_THREADS) void k_sel_emit(const unsigned long lo
   }
 }
 
+// The same select as ONE workgroup for a short mask (a small grid's markers, any grid's chunk flags): a thread counts a contiguous slice of words, the 1024
+// counts are scanned in LDS, the thread emits its slice's indices behind its offset - the same ascending list, one launch instead of three (1024^2: 19 -> 7 us,
+// three times per substep).
+#define SEL1_MAX_WORDS (1u << 15)
+__device__ __forceinline__ unsigned int sel_wave_excl(unsigned int c, unsigned int* total) {      // exclusive prefix of c over the wave's lanes, and the wave's sum
+  unsigned int v = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const unsigned int t = __shfl_up(v, o, 64); if ((int)(threadIdx.x & 63) >= o) v += t; }
+  *total = __shfl(v, 63, 64);
+  return v - c;
+}
+// wave w takes the words [w seg, (w + 1) seg), 64 at a time with lane l on word base + l (coalesced); the list stays ascending: groups of 64 words in order, lanes in order
+__global__ __launch_bounds__(1024) void k_sel_small(const unsigned long long* __restrict__ mask, unsigned int nwords, unsigned int* __restrict__ out, size_t out_cap,
+                                                    unsigned int* total) {
+  __shared__ unsigned int wsum[16];
+  const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const unsigned int seg = ((nwords + 15u) / 16u + 63u) & ~63u, w0 = wave * seg, w1 = w0 + seg < nwords ? w0 + seg : nwords;
+  unsigned int c = 0;
+  for (unsigned int w = w0 + lane; w < w1; w += 64) c += __popcll(mask[w]);
+  unsigned int tot;
+  (void)sel_wave_excl(c, &tot);
+  if (lane == 0) wsum[wave] = tot;
+  __syncthreads();
+  size_t off = 0;
+  for (unsigned int k = 0; k < wave; ++k) off += wsum[k];
+  if (threadIdx.x == 0) { unsigned int t = 0; for (int k = 0; k < 16; ++k) t += wsum[k]; *total = t; }
+  for (unsigned int base = w0; base < w1; base += 64) {      // (uniform per wave)
+    const unsigned int w = base + lane;
+    unsigned long long m = w < w1 ? mask[w] : 0ull;
+    unsigned int gt;
+    size_t o = off + sel_wave_excl((unsigned int)__popcll(m), &gt);
+    while (m) {
+      const int bit = __ffsll((long long)m) - 1;
+      if (o < out_cap) out[o] = w * 64u + (unsigned int)bit;
+      ++o;
+      m &= m - 1;
+    }
+    off += gt;
+  }
+}
+
 int eu_ordered_select(euler_sim* S, const unsigned long long* mask, size_t nwords, unsigned int* out_idx,
                       unsigned int* out_total) {
+  if (nwords <= SEL1_MAX_WORDS) {
+    LAUNCH(S, KC_SELECT, k_sel_small, dim3(1), dim3(1024), mask, (unsigned int)nwords, out_idx, S->sel_cap, out_total);
+    return EULER_OK;
+  }
   const size_t nblocks = (nwords + SEL_WPB - 1) / SEL_WPB;
   if (nblocks > S->sel.capacity_blocks) { eu_set_error("ordered select: %zu blocks > capacity", nblocks); return EULER_EINVAL; }
   const unsigned nb = nblocks ? (unsigned)nblocks : 1u;
