@@ -230,9 +230,8 @@ __global__ __launch_bounds__(256) void k_dot_sequential(const double* __restrict
 __global__ __launch_bounds__(RED_THREADS) void k_apply_a(const double* __restrict__ s, double* __restrict__ z,
                                                          const uint8_t* __restrict__ mask, SkewGeom g,
                                                          double* __restrict__ partial, PcgScalars* sc, int force,
-                                                         unsigned int* counter, int fin_op, double* s_last) {
+                                                         unsigned int* counter, int fin_op) {
   if (!force && pcg_idle(sc)) return;
-  (void)s_last;
   const size_t S = g.S;
   const size_t chunk = (((S + gridDim.x - 1) / gridDim.x) + 127) & ~(size_t)127;   // whole record pairs per block
   const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < S ? lo + chunk : S;
@@ -2047,7 +2046,7 @@ static int launch_apply_a_and_alpha(euler_sim* S, int force) {
   gl.S = S->e_cnt;
   double* out = tile_fused(S) ? S->q : S->z;     // tile-local mode: A s always lands in q (k_precond_tile reads it there and writes z)
   LAUNCH(S, KC_APPLY_A, k_apply_a, dim3(loc_red_blocks(S)), dim3(RED_THREADS), LOC(S->s), LOC(out), LOC(S->cellmask), gl,
-         S->partial, S->sc, force, S->red_counter, seq ? -1 : fin_or_comm(S, FIN_ALPHA), force ? (double*)nullptr : S->s);      // (s_last: whose p += alpha s is due)
+         S->partial, S->sc, force, S->red_counter, seq ? -1 : fin_or_comm(S, FIN_ALPHA));
   if (seq)
     LAUNCH(S, KC_DOT, k_dot_sequential, dim3(1), dim3(256), out, S->s, S->cellmask, S->geom, S->sc, (int)FIN_ALPHA, force);
   if (S->has_comm) return comm_finish(S, FIN_ALPHA, 0, force);
@@ -2377,7 +2376,7 @@ int eu_launch_pcg_op(euler_sim* S, int op, float dt, double a, double* out) {
       break;
     case EULER_OP_APPLY_A:
       LAUNCH(S, KC_APPLY_A, k_apply_a, dim3(S->red_blocks), dim3(RED_THREADS), S->s, S->z, S->cellmask, S->geom,
-             S->partial, S->sc, 1, S->red_counter, -1, (double*)nullptr);
+             S->partial, S->sc, 1, S->red_counter, -1);
       break;
     case EULER_OP_DOT_ZR: launch_dot(S, S->z, S->r, FIN_STORE_ONLY, 1); break;
     case EULER_OP_DOT_ZS: launch_dot(S, S->z, S->s, FIN_STORE_ONLY, 1); break;
