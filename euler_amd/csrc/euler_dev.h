@@ -174,20 +174,25 @@ struct euler_sim {
   // EULER_PRECOND_IC0_TILE2 (two-level; k_coarse.hip): coarse cells of g x g grid cells, g = 64 m = 1 << coarse_shift, nx x ny of them (<= 256)
   int coarse_m, coarse_shift, coarse_nx, coarse_ny, coarse_n;
   int *cc_diag, *cc_right, *cc_up;   // P^T A P as a 5-point stencil over the coarse grid: integer sums of A's entries (exact, order-free)
-  double* cc_fac;                    // [n][n]: the dense (banded) Cholesky factor of P^T A P, per solve
+  int* cc_pinned;                    // [n]: dense-level cells the factor pinned (water cut off from the air)
+  double* cc_sten;                   // [5][n]: that stencil as doubles (d, e, n, ne, nw): what k_coarse_factor reads
+  int cc_n;                          // size of the dense level of the current solve (two-level: coarse_n; multilevel: the top level's nodes)
+  double* cc_fac;                    // [n][n]: the dense (banded) Cholesky factor of the dense level's matrix, per solve
   double* cc_inv;                    // [n][n]: its inverse, per solve
   double* cc_part;                   // [chunks][3]: per tile, the sums of r over its fluid cells by coarse column (k_precond_tile)
   double* cc_y;                      // [n]: the coarse correction of the iteration (k_coarse_solve)
-  double* cc_null;                   // [4][CC_MAX] + 1: the indicators of up to four fluid regions cut off from the air (null vectors of P^T A P) and, last, how many (k_coarse_nullfix)
-  // EULER_PRECOND_IC0_TILE_MG (multilevel; k_coarse.hip): levels 0 .. mg_levels - 1 of aggregates of (16 << l)^2 grid cells, mg_nx[l] x mg_ny[l]
-  // of them, pooled arrays with level l at offset mg_off[l]; the level above the last one is the dense top level (cc_*: 64 m cells wide)
+  double* cc_null;                   // [4][CC_MAX] + 1: the indicators of up to four fluid regions cut off from the air (null vectors of the dense level) and, last, how many (k_coarse_nullfix)
+  // EULER_PRECOND_IC0_TILE_MG (multilevel; k_mg.hip): levels 0 .. mg_levels - 1 of node grids, mg_nx[l] x mg_ny[l] nodes (level 0: a node per 16 x 16 cells, each level
+  // above every other node of the one below; the last level is the dense one), pooled arrays with level l at offset mg_off[l]
   int mg_levels, mg_nx[12], mg_ny[12];
   size_t mg_off[12], mg_cells;
-  int *mg_d, *mg_rt, *mg_up;         // A_l = P^T A_(l-1) P as 5-point stencils with integer entries: diagonal, coupling to the right, upwards
-  double *mg_rhs, *mg_x;             // right-hand side and result of the V-cycle per level (level 0's result is what k_search_apply adds to z)
-  double* mg_part;                   // [chunks][4][2]: per tile and group of 16 lanes, the sums of r over the fluid cells left / right of the aggregate boundary
-  double* mg_dot;                    // per-block partials of x_0 . rhs_0 (+ the ticket counter behind them)
-  double* mg_xbuf; int mg_xslot;     // row slabs: [ranks][mg_xslot] - every rank's {max |r|, dot(z,r), its rows of the level-0 right-hand side}, ONE all-gather inside the G1 exchange
+  double* mg_a;                      // [9][nodes] per level (level l at 9 * mg_off[l]): the Galerkin operators as nine-point stencils
+  unsigned long long* mg_a0i;        // [9][nodes of level 0]: A_0 in units of 2^-16, summed by integer atomics per solve
+  double *mg_rhs, *mg_x;             // right-hand side and result of the V-cycle per level (level 0's result is what k_search_apply adds to z through P_0)
+  double* mg_part;                   // [chunks][48]: per tile and half-group of 8 lanes, the weighted sums of r for 2 node rows x 3 node columns (k_precond_tile)
+  double* mg_dot;                    // per-workgroup partials of x_0 . rhs_0 (+ the ticket counters behind them)
+  double* mg_null0;                  // [4][mg_cells]: the indicators of cut-off regions on every level (k_mg_null_prolong)
+  double* mg_xbuf; int mg_xslot;     // row slabs: [ranks][mg_xslot] - every rank's {max |r|, dot(z,r), its share of the level-0 right-hand side}, ONE all-gather inside the G1 exchange
   // the resident solver (k_resident.hip): the tile-local PCG of a grid whose chunks all find a wave on the chip at once, in ONE persistent launch
   unsigned long long* res_gran;   // [2][3][768] 16-byte {value, generation} granules of its grid-wide reductions
   unsigned long long res_tag;     // generation of the next launch's first reduction (never reset: stale granules never match)
@@ -369,7 +374,8 @@ int  eu_launch_coarse_consistent(euler_sim* S);   // per solve: if water is cut 
 int  eu_launch_coarse_solve(euler_sim* S, int fin_op, int force);   // per iteration: y = (P^T A P)^-1 P^T r, dot(z,r) += y . r_c, the scalar epilogue
 int  eu_launch_coarse_search_init(euler_sim* S);   // s = z + P y (the first search direction of a solve)
 int  eu_coarse_comm_slots(euler_sim* S);      // row slabs: doubles per rank in S->mg_xbuf (allocated on demand), < 0 on error
-int  eu_launch_coarse_pre(euler_sim* S, int force);   // row slabs: this rank's rows of the level-0 right-hand side into its slot, before the exchange
+int  eu_launch_coarse_pre(euler_sim* S, int force);   // row slabs: this rank's share of the level-0 right-hand side into its slot, before the exchange
+int  eu_launch_coarse_scatter(euler_sim* S);          // row slabs: behind the exchange, the ranks' shares added up: the level-0 right-hand side whole on every rank
 int  eu_launch_coarse_add_row(euler_sim* S, double* row, int yrow);   // row slabs: + P y on a compact ghost row (grid row yrow)
 
 // ------------------------------------------------------------------------------------------

@@ -1,0 +1,47 @@
+// k_mg.h — internal: what the multilevel preconditioner's coarse part (k_mg.hip) shares with the fine-grid passes of k_pcg.hip and with k_coarse.hip.
+#pragma once
+
+#include "euler_dev.h"
+
+#define MG_OMEGA 0.8         // damped Jacobi on every level below the dense one (tools/r05/mg_proto.py: 0.7 - 1.0 are within two iterations of each other, 1.1 costs 40 %)
+#define MG_TOP_MAX 64        // nodes of the dense top level at most (its inverse lives in LDS: 32 KB)
+#define MG_MAXLEV 12
+#define MG_PART 48           // doubles k_precond_tile leaves per tile: 8 half-groups of 8 lanes x (2 node rows x 3 node columns)
+#define MG_NULL_MAX 4        // indicators of fluid regions cut off from the air that are kept (k_coarse.hip CC_NULL_MAX)
+#define MG_DOT_BLOCKS 1024   // workgroups of k_mg_up at most (tiles of 32 x 32 nodes of level 0: 16384^2 has 1024)
+#define MG_FIN_SLOT 7        // k_mg_up's epilogue on row slabs with a split cycle: x_0 . rhs_0 of the own rows is ADDED to the rank's slot instead of applied
+
+int  eu_mg_alloc(euler_sim* S);
+void eu_mg_release(euler_sim* S);
+int  eu_mg_setup(euler_sim* S);                                   // per solve: the operators of every level (the dense top level's stencil is S->mg_a + 9 * S->mg_off[top])
+int  eu_mg_solve(euler_sim* S, int fin_op, int force);            // per iteration: the V-cycle, x_0 . rhs_0 into dot(z, r), the scalar epilogue
+int  eu_mg_search_init(euler_sim* S);                             // s = z + P_0 x_0
+int  eu_mg_add_row(euler_sim* S, double* row, int yrow);          // + P_0 x_0 on a compact row of cells
+int  eu_mg_slab_rows(euler_sim* S, int force);                   // row slabs: this rank's share of level 0's right-hand side into its slot of the exchange buffer
+
+#ifdef __HIPCC__
+// A cell's column c (or row) against n nodes, node j AT the centre of cell 16 j + 8: the node left of / at the cell and the weight f (in sixteenths) of the next one;
+// beyond the outermost nodes the interpolant is constant (weight clamps, oracle: mg_w0)
+__device__ __forceinline__ void mg_cell_w(int c, int n, int& j0, int& j1, double& f) {
+  const int u = c - 8;
+  int j = u >> 4;
+  double w = (double)(u & 15) * (1.0 / 16.0);
+  if (j < 0) { j = 0; w = 0.0; }
+  int k = j + 1;
+  if (k > n - 1) { k = n - 1; w = 0.0; }
+  j0 = j; j1 = k; f = w;
+}
+// the two values a row of cells sees at a node column: rows combined first (oracle mg_interp0: lo / hi), then mg_lerp_x along the row
+__device__ __forceinline__ double mg_rows(double v0, double v1, double fy) { return (1.0 - fy) * v0 + fy * v1; }
+__device__ __forceinline__ double mg_lerp_x(double lo, double hi, double fx) { return (1.0 - fx) * lo + fx * hi; }
+// (P_0 y) at cell (x, yrow)
+__device__ __forceinline__ double mg_interp0(const double* __restrict__ y, int nx0, int ny0, int x, int yrow) {
+  int jx0, jx1, jy0, jy1;
+  double fx, fy;
+  mg_cell_w(x, nx0, jx0, jx1, fx);
+  mg_cell_w(yrow, ny0, jy0, jy1, fy);
+  const double lo = mg_rows(y[(size_t)jy0 * nx0 + jx0], y[(size_t)jy1 * nx0 + jx0], fy);
+  const double hi = mg_rows(y[(size_t)jy0 * nx0 + jx1], y[(size_t)jy1 * nx0 + jx1], fy);
+  return mg_lerp_x(lo, hi, fx);
+}
+#endif

@@ -1,0 +1,787 @@
+// k_mg.hip — the coarse part of the MULTILEVEL preconditioner (EULER_PRECOND_IC0_TILE_MG, include/euler.h; round 5):
+//
+//     z = M_tile^-1 r + P_0 V(P_0^T r)
+//
+// M_tile = the tile-local IC(0) of k_pcg.hip.  Level 0 = a grid of NODES, node (I, J) at the centre of grid cell (16 J + 8, 16 I + 8) - one per tile width in x and
+// per quarter band in y; P_0 = bilinear interpolation from the four nodes around a cell (weights in sixteenths), restricted to the fluid, constant beyond the outermost
+// nodes.  Level l + 1 = every other node of level l in both directions (its node J sits ON node 2 J), bilinear again: weights 1, 1/2 - full weighting.  Because nodes
+// sit AT cell centres / on finer nodes, a hat is 0 at the neighbouring nodes and the Galerkin operators A_0 = P_0^T A P_0, A_(l+1) = P^T A_l P are exact NINE-POINT
+// stencils (a[k][c]: the entry that couples node c = (I, J) to node (I + k / 3 - 1, J + k % 3 - 1); A_0's entries are multiples of 2^-16: integer sums, exact in any order).
+// V = one symmetric V-cycle: damped Jacobi (omega) from a zero guess, restricted residual, recursion, correction, Jacobi again; the top level (<= 64 nodes) is the
+// dense pseudo-inverse of k_coarse.hip (factor, inverse, null-space fix for water cut off from the air).
+//
+// Rounds 3-4 used piecewise constants over the same 16 x 16 blocks (aggregation: 5-point stencils with integer entries, the correction scaled by 1.7) and ONE launch per
+// level and direction (12 launches, 63 us per iteration at 8192^2).  The bilinear spaces halve the iteration count (tank at rest to 1e-6, 1024^2 / 2048^2: 104 / 108 -> 52 / 52;
+// 512^2 dam break at impact 109 -> 64; 1024^2 waterfall 124 -> 62: tools/r05/mg_proto.py), and the cycle now runs in THREE launches whatever the depth of the hierarchy:
+//
+//   k_mg_down<true>   gathers the level-0 right-hand side from the tiles' partial sums (k_precond_tile leaves 48 doubles per tile: per half-group of 8 lanes, 2 node rows
+//                     x 3 node columns) and takes it down one level; every workgroup owns a tile of the OUTPUT level and recomputes the halo it needs of the levels
+//                     below in LDS (Jacobi step, residual, restriction: a level transition is three LDS phases, no launch)
+//   k_mg_down<false>  the next (up to three) level transitions the same way; the workgroup that draws the last ticket then runs every level of <= 1024 nodes - down, the
+//                     dense top, up again - alone, out of LDS and registers (stencils preloaded, 4 barriers per level)
+//   k_mg_up           from that level's result back to level 0: every workgroup owns a 32 x 32 tile of level 0 and recomputes the halos of the coarser levels it
+//                     needs (they shrink by two per level); its last workgroup folds x_0 . rhs_0 into dot(z, r) and applies the scalar epilogue
+//
+// The CPU restatement the tests check all of this against: oracle/euler_oracle.c mg_build / mg_vcycle (same formulas; sums in another order: agreement to rounding).
+// No reference counterpart (the reference has ONE preconditioner, main.c:580-627).
+#include "euler_dev.h"
+#include "k_mg.h"
+
+#define COMM_CALL(expr) do { if ((expr) != 0) { eu_set_error("communicator callback failed: %s", #expr); return EULER_ECOMM; } } while (0)
+
+enum { MFIN_SIGMA_INIT = 0, MFIN_BETA = 3 };      // the scalar epilogues of k_pcg.hip (same codes)
+
+// ------------------------------------------------------------------------------------------ hierarchy
+struct MgHier {
+  int nl;                          // levels, the dense top included
+  int nx[MG_MAXLEV], ny[MG_MAXLEV];
+  unsigned int off[MG_MAXLEV];     // first node of level l in the pooled arrays
+  const double* a;                 // stencils: level l at a + 9 * off[l], entry k of node c at [k * n_l + c]
+  double* rhs;
+  double* x;
+};
+static MgHier mg_hier(const euler_sim* S) {
+  MgHier H;
+  H.nl = S->mg_levels;
+  for (int l = 0; l < MG_MAXLEV; ++l) { H.nx[l] = l < H.nl ? S->mg_nx[l] : 0; H.ny[l] = l < H.nl ? S->mg_ny[l] : 0; H.off[l] = l < H.nl ? (unsigned int)S->mg_off[l] : 0u; }
+  H.a = S->mg_a; H.rhs = S->mg_rhs; H.x = S->mg_x;
+  return H;
+}
+__device__ __forceinline__ const double* mg_sten(const MgHier& H, int l) { return H.a + 9 * (size_t)H.off[l]; }
+
+int eu_mg_alloc(euler_sim* S) {
+  if (S->mg_dot) return EULER_OK;
+  int nx = (S->X + 15) / 16, ny = 4 * S->geom.nbands, l = 0;
+  S->mg_cells = 0;
+  for (;; ++l) {
+    if (l >= MG_MAXLEV) { eu_set_error("multilevel preconditioner: more than %d levels", MG_MAXLEV); return EULER_EINVAL; }
+    S->mg_nx[l] = nx; S->mg_ny[l] = ny; S->mg_off[l] = S->mg_cells; S->mg_cells += (size_t)nx * ny;
+    if (nx * ny <= MG_TOP_MAX) break;
+    nx = (nx + 1) / 2; ny = (ny + 1) / 2;
+  }
+  S->mg_levels = l + 1;
+  const size_t n0 = (size_t)S->mg_nx[0] * S->mg_ny[0];
+  HIPCHK(hipMalloc((void**)&S->mg_a, 9 * S->mg_cells * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&S->mg_a0i, 9 * n0 * sizeof(unsigned long long)));
+  HIPCHK(hipMalloc((void**)&S->mg_rhs, 2 * S->mg_cells * sizeof(double)));
+  S->mg_x = S->mg_rhs + S->mg_cells;
+  HIPCHK(hipMalloc((void**)&S->mg_part, (S->chunk_cap + 64) * MG_PART * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&S->mg_null0, (size_t)MG_NULL_MAX * S->mg_cells * sizeof(double)));      // the indicators of cut-off regions on every level (k_mg_null_prolong)
+  HIPCHK(hipMemset(S->mg_a, 0, 9 * S->mg_cells * sizeof(double)));
+  HIPCHK(hipMemset(S->mg_rhs, 0, 2 * S->mg_cells * sizeof(double)));
+  HIPCHK(hipMemset(S->mg_part, 0, (S->chunk_cap + 64) * MG_PART * sizeof(double)));
+  HIPCHK(hipMemset(S->mg_null0, 0, (size_t)MG_NULL_MAX * S->mg_cells * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&S->mg_dot, (MG_DOT_BLOCKS + 2) * sizeof(double)));      // per-workgroup partials of x_0 . rhs_0, then the tickets of k_mg_up and k_mg_down
+  HIPCHK(hipMemset(S->mg_dot, 0, (MG_DOT_BLOCKS + 2) * sizeof(double)));
+  S->hbm_bytes += (9 * S->mg_cells + 2 * S->mg_cells + (size_t)MG_NULL_MAX * S->mg_cells) * sizeof(double) + 9 * n0 * 8 + (S->chunk_cap + 64) * MG_PART * sizeof(double);
+  return EULER_OK;
+}
+void eu_mg_release(euler_sim* S) {
+  for (double* d : {S->mg_a, S->mg_rhs, S->mg_part, S->mg_dot, S->mg_xbuf, S->mg_null0}) if (d) (void)hipFree(d);
+  if (S->mg_a0i) (void)hipFree(S->mg_a0i);
+  S->mg_a = S->mg_rhs = S->mg_x = S->mg_part = S->mg_dot = S->mg_xbuf = S->mg_null0 = nullptr;
+  S->mg_a0i = nullptr; S->mg_xslot = 0;
+}
+
+// ------------------------------------------------------------------------------------------ per solve: the operators
+// A_0 = P_0^T A P_0 from the tiles' masks.  With c' = a_diag - (fluid neighbours) (the air neighbours of a cell) and p_i = P_0^T e_i (a cell's four weights),
+//     A = sum_i c'_i e_i e_i^T + sum_edges (e_i - e_j)(e_i - e_j)^T      =>      A_0 = sum_i c'_i p_i p_i^T + sum_edges (p_i - p_j)(p_i - p_j)^T
+// and since the weights are linear between two nodes, p_i - p_j of a horizontal edge is (1/16)(e_J - e_(J+1)) in x times the row weights wy - the same for every
+// edge of that row between the nodes J and J + 1 (0 beyond the outermost nodes) - and likewise for vertical edges.  So a lane (one row, 16 consecutive columns: at
+// most two node intervals) only counts: per interval, its horizontal edges H, sum c' wx wx^T and sum over its vertical edges of wx wx^T (three integers each, in
+// 1/256), and adds row weights x those to the stencil entries - 64 integer adds per lane into a window in LDS, flushed by 64-bit atomics (units of 2^-16: exact).
+#define MG_WIN (6 * 8 * 9)
+__global__ __launch_bounds__(256) void k_mg_assemble0(const uint8_t* __restrict__ mask, SkewGeom g, const unsigned int* __restrict__ list, const PcgScalars* sc,
+                                                      int band_lo, int nx0, int ny0, unsigned long long* __restrict__ a0i) {
+  __shared__ int s_win[4][MG_WIN];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int* win = s_win[wv];
+  for (int e = lane; e < MG_WIN; e += 64) win[e] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int ntb = g.T / 16, todo = (int)sc->n_chunks;
+  const int n_waves = gridDim.x * 4;
+  const size_t n0 = (size_t)nx0 * ny0;
+  for (int w = blockIdx.x * 4 + wv; w < todo; w += n_waves) {
+    const int tile = (int)(list[w] & ~EU_CHUNK_INTERIOR);
+    const int band = band_lo + tile / ntb, k = tile % ntb;
+    const size_t base = ((size_t)band * g.TS + (size_t)k * 16) * 64 + 2 * lane;
+    // the lane's row against the node rows
+    const int uy = 64 * band + lane - 8, I0 = uy >> 4;
+    int wy0 = 16 - (uy & 15), wy1 = uy & 15;
+    if (I0 < 0) { wy0 = 0; wy1 = 16; }
+    if (I0 >= ny0 - 1) { wy0 = 16; wy1 = 0; }
+    const bool vert_ok = I0 >= 0 && I0 <= ny0 - 2;
+    const int Jb = (16 * k - lane - 8) >> 4;      // node interval of the lane's first column
+    int H[2] = {0, 0}, C[2][3] = {{0, 0, 0}, {0, 0, 0}}, V[2][3] = {{0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+    for (int P = 0; P < 8; ++P) {
+      const unsigned int mm = *reinterpret_cast<const unsigned short*>(mask + base + P * 128);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const unsigned int cm = (mm >> (8 * h)) & 0xff;
+        if (!(cm & CM_FLUID)) continue;
+        const int ux = 16 * k + 2 * P + h - lane - 8, J0 = ux >> 4;
+        int w0 = 16 - (ux & 15), w1 = ux & 15;
+        if (J0 < 0) { w0 = 0; w1 = 16; }
+        if (J0 >= nx0 - 1) { w0 = 16; w1 = 0; }
+        const int cp = (int)(cm >> CM_DIAG_SHIFT) - __popc(cm & (CM_RIGHT | CM_UP | CM_LEFT | CM_DOWN));
+        const int hh = ((cm & CM_RIGHT) && J0 >= 0 && J0 <= nx0 - 2) ? 1 : 0;
+        const int vv = (cm & CM_UP) ? 1 : 0;
+        const int q00 = w0 * w0, q01 = w0 * w1, q11 = w1 * w1;
+        if (J0 == Jb) { H[0] += hh; C[0][0] += cp * q00; C[0][1] += cp * q01; C[0][2] += cp * q11; V[0][0] += vv * q00; V[0][1] += vv * q01; V[0][2] += vv * q11; }
+        else          { H[1] += hh; C[1][0] += cp * q00; C[1][1] += cp * q01; C[1][2] += cp * q11; V[1][0] += vv * q00; V[1][1] += vv * q01; V[1][2] += vv * q11; }
+      }
+    }
+    const int rI0 = I0 - (4 * band - 1);      // 0 .. 4
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+      const int cJ0 = Jb + sg - (k - 5);      // 0 .. 5
+      const int Mx[2][2] = {{C[sg][0] + H[sg], C[sg][1] - H[sg]}, {C[sg][1] - H[sg], C[sg][2] + H[sg]}};
+      const int Vx[2][2] = {{V[sg][0], V[sg][1]}, {V[sg][1], V[sg][2]}};
+      const int wy[2] = {wy0, wy1};
+#pragma unroll
+      for (int ra = 0; ra < 2; ++ra)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int ca = 0; ca < 2; ++ca)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+              int val = wy[ra] * wy[rb] * Mx[ca][cb];
+              if (vert_ok) val += (ra == rb ? 1 : -1) * Vx[ca][cb];
+              if (val != 0) atomicAdd(&win[((rI0 + ra) * 8 + cJ0 + ca) * 9 + (rb - ra + 1) * 3 + (cb - ca + 1)], val);
+            }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < MG_WIN; e += 64) {
+      const int v = win[e];
+      if (v == 0) continue;
+      win[e] = 0;
+      const int kk = e % 9, cJ = (e / 9) & 7, rI = e / 72;
+      const int I = 4 * band - 1 + rI, J = k - 5 + cJ;
+      if (I >= 0 && I < ny0 && J >= 0 && J < nx0) atomicAdd(&a0i[(size_t)kk * n0 + (size_t)I * nx0 + J], (unsigned long long)(long long)v);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+__global__ __launch_bounds__(256) void k_mg_convert0(const unsigned long long* __restrict__ a0i, double* __restrict__ a, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) a[i] = (double)(long long)a0i[i] * (1.0 / 65536.0);
+}
+
+// weight of node j of a finer level (fn nodes) on node Jc of the next one (cn nodes), whose node Jc sits on the finer level's node 2 Jc
+__device__ __forceinline__ double mg_w1(int Jc, int j, int fn, int cn) {
+  if (j < 0 || j >= fn || Jc < 0 || Jc >= cn) return 0.0;
+  if (j == 2 * Jc) return 1.0;
+  if (j == 2 * Jc - 1) return 0.5;
+  if (j == 2 * Jc + 1) return Jc + 1 <= cn - 1 ? 0.5 : 1.0;      // (the last fine node, odd, without a node to its right: constant)
+  return 0.0;
+}
+// A_(l+1) = P^T A_l P, a thread per node of level l + 1
+__global__ __launch_bounds__(256) void k_mg_coarsen(const double* __restrict__ af, int fnx, int fny, double* __restrict__ ac, int cnx, int cny, const PcgScalars* sc) {
+  if (!sc->nonzero) return;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= cnx * cny) return;
+  const int I = p / cnx, J = p % cnx;
+  const size_t fn = (size_t)fnx * fny, cn = (size_t)cnx * cny;
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int dy = -1; dy <= 1; ++dy)
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int mi = 2 * I + dy, mj = 2 * J + dx;
+      const double wM = mg_w1(I, mi, fny, cny) * mg_w1(J, mj, fnx, cnx);
+      if (wM == 0.0) continue;
+      const size_t m = (size_t)mi * fnx + mj;
+      for (int e = 0; e < 9; ++e) {
+        const double av = af[(size_t)e * fn + m];
+        if (av == 0.0) continue;
+        const int ni = mi + e / 3 - 1, nj = mj + e % 3 - 1;
+        for (int q = 0; q < 9; ++q) {
+          const double wN = mg_w1(I + q / 3 - 1, ni, fny, cny) * mg_w1(J + q % 3 - 1, nj, fnx, cnx);
+          if (wN != 0.0) acc[q] += wM * av * wN;
+        }
+      }
+    }
+  for (int q = 0; q < 9; ++q) ac[(size_t)q * cn + p] = acc[q];
+}
+
+// ------------------------------------------------------------------------------------------ per iteration: the cycle
+struct MgRect { int i0, i1, j0, j1; };      // rows [i0, i1) x columns [j0, j1)
+__device__ __forceinline__ int mg_rw(const MgRect& r) { return r.j1 - r.j0; }
+__device__ __forceinline__ int mg_rn(const MgRect& r) { return (r.i1 - r.i0) * (r.j1 - r.j0); }
+__device__ __forceinline__ MgRect mg_grow(const MgRect& r, int ny, int nx) {
+  return MgRect{r.i0 > 0 ? r.i0 - 1 : 0, r.i1 < ny ? r.i1 + 1 : ny, r.j0 > 0 ? r.j0 - 1 : 0, r.j1 < nx ? r.j1 + 1 : nx};
+}
+// the nodes of level l whose residual feeds the nodes `c` of level l + 1
+__device__ __forceinline__ MgRect mg_fine_of(const MgRect& c, int ny, int nx) {
+  MgRect f = {2 * c.i0 - 1, 2 * c.i1, 2 * c.j0 - 1, 2 * c.j1};
+  if (f.i0 < 0) f.i0 = 0;
+  if (f.j0 < 0) f.j0 = 0;
+  if (f.i1 > ny) f.i1 = ny;
+  if (f.j1 > nx) f.j1 = nx;
+  return f;
+}
+// the nodes of level l that the owner of the nodes `c` of level l + 1 writes (a partition of level l)
+__device__ __forceinline__ MgRect mg_owned_of(const MgRect& c, int cny, int cnx, int ny, int nx) {
+  return MgRect{2 * c.i0, c.i1 == cny ? ny : 2 * c.i1, 2 * c.j0, c.j1 == cnx ? nx : 2 * c.j1};
+}
+__device__ __forceinline__ bool mg_in(const MgRect& r, int i, int j) { return i >= r.i0 && i < r.i1 && j >= r.j0 && j < r.j1; }
+
+// level-0 right-hand side of node (I, J) from the tiles' partial sums (k_precond_tile): half-group (group G' = 4 band + j', half h) holds 2 node rows x 3 node columns,
+// rows (G' - 1, G') for h = 0, (G', G' + 1) for h = 1; columns from k - j' - 1 - h for tile k.  Twelve terms, in this order.
+__device__ __forceinline__ double mg_gather0(const double* __restrict__ part, int I, int J, int ntb, int band_lo, int band_hi) {
+  double t = 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int Gp = q == 0 ? I + 1 : (q == 3 ? I - 1 : I), h = q >> 1, rs = q & 1 ? 1 : 0;      // (I+1, low, 0), (I, low, 1), (I, high, 0), (I-1, high, 1)
+    if (Gp < 4 * band_lo || Gp >= 4 * band_hi) continue;
+    const int b = Gp >> 2, jp = Gp & 3;
+    const double* row = part + (size_t)(b - band_lo) * ntb * MG_PART + (2 * jp + h) * 6 + rs * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int k = J - c + jp + 1 + h;
+      if (k >= 0 && k < ntb) t = t + row[(size_t)k * MG_PART + c];
+    }
+  }
+  return t;
+}
+
+struct MgDownArgs {
+  MgHier H;
+  int lA, lB;                 // from the right-hand side of level lA to that of level lB (lA <= lB)
+  int tile;                   // edge of a workgroup's tile of level lB
+  int cap0, cap1;             // doubles per LDS patch of the levels lA, lA + 2 / lA + 1, lA + 3
+  int tail;                   // the workgroup that draws the last ticket goes on with the levels >= lB (all of <= 1024 nodes), the dense top and the way back up to lB
+  const double* part;         // GATHER: the tiles' partial sums
+  int ntb, band_lo, band_hi;
+  const double* inv;          // the dense top level's inverse [n_top][n_top]
+  unsigned int* ticket;
+  const PcgScalars* sc;
+};
+
+#define MG_DOWN_THREADS 1024
+#define MG_TAIL_MAX 1024      // nodes of the first level the tail takes
+#define MG_TAIL_LEVELS 4      // stencil levels of the tail at most (1024 -> 272 -> 72 -> top would be 3)
+
+__device__ __forceinline__ void mg_st_agent(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double mg_ld_agent(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// (A_l v)[c] over a patch of v in LDS: entries k = 0 .. 8 in this order, neighbours outside the grid skipped
+__device__ __forceinline__ double mg_apply_patch(const double* __restrict__ a, size_t n, size_t c, int i, int j, int ny, int nx, const double* v, const MgRect& R) {
+  const int w = mg_rw(R);
+  double t = 0.0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int i2 = i + k / 3 - 1, j2 = j + k % 3 - 1;
+    if (i2 < 0 || i2 >= ny || j2 < 0 || j2 >= nx) continue;
+    t = t + a[(size_t)k * n + c] * v[(i2 - R.i0) * w + (j2 - R.j0)];
+  }
+  return t;
+}
+
+// the tail: levels lB .. top by ONE workgroup of 1024 threads, a thread per node (tid < n_l); vectors in LDS, stencils in registers
+__device__ void mg_tail(const MgDownArgs& A, double* lds) {
+  const MgHier& H = A.H;
+  const int tid = threadIdx.x, top = H.nl - 1, nt = top - A.lB;      // nt stencil levels, then the dense one
+  const int ntop = H.nx[top] * H.ny[top];
+  // LDS: per stencil level of the tail two vectors (x1 -> x, t / x2), then the dense level's right-hand side and result, then its inverse
+  double* vec[MG_TAIL_LEVELS];
+  double* p = lds;
+#pragma unroll
+  for (int q = 0; q < MG_TAIL_LEVELS; ++q) { vec[q] = p; if (q < nt) p += 2 * (size_t)H.nx[A.lB + q] * H.ny[A.lB + q]; }
+  double* top_rhs = p;
+  double* top_y = p + ntop;
+  double* s_inv = p + 2 * ntop;
+  // everything this workgroup needs from memory, in one batch: the entry level's right-hand side (published by all workgroups), the stencils, the inverse
+  double rhs[MG_TAIL_LEVELS], a[MG_TAIL_LEVELS][9];
+#pragma unroll
+  for (int q = 0; q < MG_TAIL_LEVELS; ++q) {
+    rhs[q] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a[q][k] = 0.0;
+    if (q < nt) {
+      const int l = A.lB + q;
+      const size_t n = (size_t)H.nx[l] * H.ny[l];
+      if ((size_t)tid < n) {
+        const double* st = mg_sten(H, l);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a[q][k] = st[(size_t)k * n + tid];
+      }
+    }
+  }
+  {
+    const size_t n = (size_t)H.nx[A.lB] * H.ny[A.lB];
+    if ((size_t)tid < n) rhs[0] = mg_ld_agent(H.rhs + H.off[A.lB] + tid);
+  }
+  for (int e = tid; e < ntop * ntop; e += MG_DOWN_THREADS) s_inv[e] = A.inv[e];
+  // ---- down
+#pragma unroll
+  for (int q = 0; q < MG_TAIL_LEVELS; ++q) {
+    if (q >= nt) break;
+    const int l = A.lB + q, nx = H.nx[l], ny = H.ny[l], n = nx * ny;
+    const int cnx = H.nx[l + 1], cny = H.ny[l + 1], cn = cnx * cny;
+    double* x1 = vec[q];
+    double* tt = vec[q] + n;
+    const double d = a[q][4];
+    if (tid < n) x1[tid] = d != 0.0 ? MG_OMEGA * rhs[q] / d : 0.0;
+    __syncthreads();
+    if (tid < n) {
+      const int i = tid / nx, j = tid % nx;
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int i2 = i + k / 3 - 1, j2 = j + k % 3 - 1;
+        if (i2 < 0 || i2 >= ny || j2 < 0 || j2 >= nx) continue;
+        t = t + a[q][k] * x1[i2 * nx + j2];
+      }
+      tt[tid] = d != 0.0 ? rhs[q] - t : 0.0;
+    }
+    __syncthreads();
+    if (tid < cn) {      // full weighting: rows outer, columns inner
+      const int I = tid / cnx, J = tid % cnx;
+      double t = 0.0;
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          const double w = mg_w1(I, 2 * I + dy, ny, cny) * mg_w1(J, 2 * J + dx, nx, cnx);
+          if (w != 0.0) t = t + w * tt[(2 * I + dy) * nx + 2 * J + dx];
+        }
+      if (q + 1 < MG_TAIL_LEVELS && q + 1 < nt) rhs[q + 1] = t;
+      if (q + 1 == nt) top_rhs[tid] = t;      // the dense level's right-hand side
+    }
+  }
+  if (nt == 0 && tid < ntop) top_rhs[tid] = rhs[0];      // (the entry level IS the dense level)
+  __syncthreads();
+  // ---- the dense level: y = inv rhs, 16 threads per row
+  {
+    double* rt = top_rhs;
+    double* yt = top_y;
+    const int row = tid >> 4, part = tid & 15;
+    double v = 0.0;
+    if (row < ntop) for (int c = part; c < ntop; c += 16) v += s_inv[row * ntop + c] * rt[c];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (row < ntop && part == 0) yt[row] = v;
+    __syncthreads();
+    if (nt == 0 && tid < ntop) H.x[H.off[top] + tid] = yt[tid];
+  }
+  // ---- up
+#pragma unroll
+  for (int q = MG_TAIL_LEVELS - 1; q >= 0; --q) {
+    if (q >= nt) continue;
+    const int l = A.lB + q, nx = H.nx[l], ny = H.ny[l], n = nx * ny;
+    const int cnx = H.nx[l + 1], cny = H.ny[l + 1];
+    double* x1 = vec[q];            // becomes x
+    double* x2 = vec[q] + n;
+    const double* e = q + 1 == nt ? top_y : vec[q + 1 < MG_TAIL_LEVELS ? q + 1 : q];
+    const double d = a[q][4];
+    if (tid < n) {
+      const int i = tid / nx, j = tid % nx;
+      const int I = i >> 1, J = j >> 1;
+      const int I1 = (i & 1) && I + 1 <= cny - 1 ? I + 1 : I, J1 = (j & 1) && J + 1 <= cnx - 1 ? J + 1 : J;
+      const double fy = (i & 1) && I + 1 <= cny - 1 ? 0.5 : 0.0, fx = (j & 1) && J + 1 <= cnx - 1 ? 0.5 : 0.0;
+      const double lo = (1.0 - fx) * e[I * cnx + J] + fx * e[I * cnx + J1];
+      const double hi = (1.0 - fx) * e[I1 * cnx + J] + fx * e[I1 * cnx + J1];
+      x2[tid] = d != 0.0 ? x1[tid] + ((1.0 - fy) * lo + fy * hi) : 0.0;
+    }
+    __syncthreads();
+    double xv = 0.0;
+    if (tid < n) {
+      const int i = tid / nx, j = tid % nx;
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int i2 = i + k / 3 - 1, j2 = j + k % 3 - 1;
+        if (i2 < 0 || i2 >= ny || j2 < 0 || j2 >= nx) continue;
+        t = t + a[q][k] * x2[i2 * nx + j2];
+      }
+      xv = d != 0.0 ? x2[tid] + MG_OMEGA * (rhs[q] - t) / d : 0.0;
+    }
+    __syncthreads();
+    if (tid < n) { x1[tid] = xv; if (q == 0) H.x[H.off[l] + tid] = xv; }
+    __syncthreads();
+  }
+}
+
+template <bool GATHER>
+__global__ __launch_bounds__(MG_DOWN_THREADS) void k_mg_down(MgDownArgs A) {
+  extern __shared__ double lds[];
+  __shared__ int s_last;
+  const MgHier& H = A.H;
+  const int tid = threadIdx.x;
+  const int tiles_x = (H.nx[A.lB] + A.tile - 1) / A.tile;
+  const int ti = blockIdx.x / tiles_x, tj = blockIdx.x % tiles_x;
+  MgRect own = {ti * A.tile, (ti + 1) * A.tile, tj * A.tile, (tj + 1) * A.tile};
+  if (own.i1 > H.ny[A.lB]) own.i1 = H.ny[A.lB];
+  if (own.j1 > H.nx[A.lB]) own.j1 = H.nx[A.lB];
+  // the rectangles of level l: R = the right-hand side this workgroup needs, T = where it needs the residual, O = what it writes out
+  auto rects = [&](int l, MgRect& R, MgRect& T, MgRect& O) {
+    MgRect r = own, o = own, t = own;
+    for (int k = A.lB - 1; k >= l; --k) {
+      o = mg_owned_of(o, H.ny[k + 1], H.nx[k + 1], H.ny[k], H.nx[k]);
+      t = mg_fine_of(r, H.ny[k], H.nx[k]);
+      r = mg_grow(t, H.ny[k], H.nx[k]);
+    }
+    R = r; T = t; O = o;
+  };
+  double* buf[2] = {lds, lds + 2 * (size_t)A.cap0};
+  int cap[2] = {A.cap0, A.cap1};
+  // ---- the entry level's right-hand side and Jacobi step
+  {
+    MgRect R, T, O;
+    rects(A.lA, R, T, O);
+    const int l = A.lA, nx = H.nx[l], n = nx * H.ny[l];
+    const double* st = mg_sten(H, l);
+    double* prhs = buf[0];
+    double* px1 = buf[0] + cap[0];
+    const int w = mg_rw(R);
+    for (int e = tid; e < mg_rn(R); e += MG_DOWN_THREADS) {
+      const int i = R.i0 + e / w, j = R.j0 + e % w;
+      const size_t c = (size_t)i * nx + j;
+      double v;
+      if (GATHER) {
+        v = mg_gather0(A.part, i, j, A.ntb, A.band_lo, A.band_hi);
+        if (mg_in(O, i, j)) {
+          if (A.tail && A.lA == A.lB) mg_st_agent(H.rhs + H.off[l] + c, v);
+          else H.rhs[H.off[l] + c] = v;
+        }
+      } else v = H.rhs[H.off[l] + c];
+      const double d = st[(size_t)4 * n + c];
+      prhs[e] = v;
+      px1[e] = d != 0.0 ? MG_OMEGA * v / d : 0.0;
+    }
+  }
+  __syncthreads();
+  // ---- level transitions lA -> lA + 1 -> ... -> lB
+  for (int l = A.lA; l < A.lB; ++l) {
+    const int cur = (l - A.lA) & 1;
+    MgRect R, T, O, Rc, Tc, Oc;
+    rects(l, R, T, O);
+    rects(l + 1, Rc, Tc, Oc);
+    const int nx = H.nx[l], ny = H.ny[l];
+    const size_t n = (size_t)nx * ny;
+    const int cnx = H.nx[l + 1], cny = H.ny[l + 1];
+    const size_t cn = (size_t)cnx * cny;
+    const double* st = mg_sten(H, l);
+    const double* stc = mg_sten(H, l + 1);
+    double* prhs = buf[cur];
+    double* px1 = buf[cur] + cap[cur];
+    double* crhs = buf[cur ^ 1];
+    double* cx1 = buf[cur ^ 1] + cap[cur ^ 1];
+    const int w = mg_rw(R), tw = mg_rw(T);
+    // residual behind the Jacobi step, in place of the right-hand side
+    for (int e = tid; e < mg_rn(T); e += MG_DOWN_THREADS) {
+      const int i = T.i0 + e / tw, j = T.j0 + e % tw;
+      const size_t c = (size_t)i * nx + j;
+      const int pe = (i - R.i0) * w + (j - R.j0);
+      const double d = st[(size_t)4 * n + c];
+      const double t = mg_apply_patch(st, n, c, i, j, ny, nx, px1, R);
+      prhs[pe] = d != 0.0 ? prhs[pe] - t : 0.0;
+    }
+    __syncthreads();
+    // full weighting -> the next level's right-hand side (and its Jacobi step)
+    const int cw = mg_rw(Rc);
+    for (int e = tid; e < mg_rn(Rc); e += MG_DOWN_THREADS) {
+      const int I = Rc.i0 + e / cw, J = Rc.j0 + e % cw;
+      const size_t c = (size_t)I * cnx + J;
+      double t = 0.0;
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          const double wgt = mg_w1(I, 2 * I + dy, ny, cny) * mg_w1(J, 2 * J + dx, nx, cnx);
+          if (wgt != 0.0) t = t + wgt * prhs[(2 * I + dy - R.i0) * w + (2 * J + dx - R.j0)];
+        }
+      if (mg_in(Oc, I, J)) {
+        if (A.tail && l + 1 == A.lB) mg_st_agent(H.rhs + H.off[l + 1] + c, t);
+        else H.rhs[H.off[l + 1] + c] = t;
+      }
+      if (l + 1 < A.lB) {
+        const double d = stc[(size_t)4 * cn + c];
+        crhs[e] = t;
+        cx1[e] = d != 0.0 ? MG_OMEGA * t / d : 0.0;
+      }
+    }
+    __syncthreads();
+  }
+  if (!A.tail) return;
+  // ---- the last workgroup to get here takes the small levels
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned int t = __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == gridDim.x - 1;
+    if (s_last) __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  mg_tail(A, lds);
+}
+
+// up: x_l = x2 + omega (rhs - A x2) / d with x2 = the Jacobi step + P x_(l+1), for the levels below the tail's entry level down to 0.  A workgroup owns a tile of
+// level 0 and recomputes what it needs of the coarser levels: x_l on `X_l`, x2 on X_l grown by one, x_(l+1) on the nodes around that.
+struct MgUpArgs {
+  MgHier H;
+  int lC;                     // the level whose result the tail left in H.x (0: nothing to do but the dot product)
+  int tile, cap;              // edge of a workgroup's tile of level 0; doubles per LDS patch
+  int row_lo, row_hi;         // node rows of level 0 whose x . rhs this rank adds to dot(z, r) (row slabs: the own rows)
+  PcgScalars* sc;
+  int fin_op, force;
+  double* dot_part;
+  unsigned int* ticket;
+};
+#define MG_UP_THREADS 1024
+__device__ __forceinline__ MgRect mg_coarse_around(const MgRect& f, int cny, int cnx) {
+  MgRect c = {f.i0 >> 1, ((f.i1 - 1) >> 1) + 2, f.j0 >> 1, ((f.j1 - 1) >> 1) + 2};
+  if (c.i1 > cny) c.i1 = cny;
+  if (c.j1 > cnx) c.j1 = cnx;
+  return c;
+}
+__global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
+  extern __shared__ double lds[];
+  __shared__ double s_red[MG_UP_THREADS / 64];
+  __shared__ int s_last;
+  const MgHier& H = A.H;
+  const int tid = threadIdx.x;
+  const bool idle = !A.force && (A.sc->done || !A.sc->nonzero);      // read first, consulted last
+  const int tiles_x = (H.nx[0] + A.tile - 1) / A.tile;
+  const int ti = blockIdx.x / tiles_x, tj = blockIdx.x % tiles_x;
+  MgRect own = {ti * A.tile, (ti + 1) * A.tile, tj * A.tile, (tj + 1) * A.tile};
+  if (own.i1 > H.ny[0]) own.i1 = H.ny[0];
+  if (own.j1 > H.nx[0]) own.j1 = H.nx[0];
+  auto rects = [&](int l, MgRect& X, MgRect& X2) {      // X_l: where x_l is needed; X2_l = X_l grown by one
+    MgRect x = own, x2 = mg_grow(own, H.ny[0], H.nx[0]);
+    for (int k = 1; k <= l; ++k) { x = mg_coarse_around(x2, H.ny[k], H.nx[k]); x2 = mg_grow(x, H.ny[k], H.nx[k]); }
+    X = x; X2 = x2;
+  };
+  double* bx[2] = {lds, lds + A.cap};      // x of the level above / of this level, alternating
+  double* b2 = lds + 2 * (size_t)A.cap;    // x2 of this level
+  if (A.lC > 0) {
+    MgRect X, X2;
+    rects(A.lC, X, X2);
+    const int w = mg_rw(X), nx = H.nx[A.lC];
+    double* dst = bx[A.lC & 1];
+    for (int e = tid; e < mg_rn(X); e += MG_UP_THREADS) dst[e] = H.x[H.off[A.lC] + (size_t)(X.i0 + e / w) * nx + X.j0 + e % w];
+    __syncthreads();
+  }
+  double dv = 0.0;
+  for (int l = A.lC - 1; l >= 0; --l) {
+    MgRect X, X2, Xc, X2c;
+    rects(l, X, X2);
+    rects(l + 1, Xc, X2c);
+    const int nx = H.nx[l], ny = H.ny[l];
+    const size_t n = (size_t)nx * ny;
+    const int cnx = H.nx[l + 1], cny = H.ny[l + 1];
+    const double* st = mg_sten(H, l);
+    const double* e_ = bx[(l + 1) & 1];
+    double* xo = bx[l & 1];
+    const int w2 = mg_rw(X2), cw = mg_rw(Xc), w = mg_rw(X);
+    for (int e = tid; e < mg_rn(X2); e += MG_UP_THREADS) {
+      const int i = X2.i0 + e / w2, j = X2.j0 + e % w2;
+      const size_t c = (size_t)i * nx + j;
+      const double d = st[(size_t)4 * n + c], rv = H.rhs[H.off[l] + c];
+      const int I = i >> 1, J = j >> 1;
+      const bool oy = (i & 1) && I + 1 <= cny - 1, ox = (j & 1) && J + 1 <= cnx - 1;
+      const int I1 = oy ? I + 1 : I, J1 = ox ? J + 1 : J;
+      const double fy = oy ? 0.5 : 0.0, fx = ox ? 0.5 : 0.0;
+      const double lo = (1.0 - fx) * e_[(I - Xc.i0) * cw + (J - Xc.j0)] + fx * e_[(I - Xc.i0) * cw + (J1 - Xc.j0)];
+      const double hi = (1.0 - fx) * e_[(I1 - Xc.i0) * cw + (J - Xc.j0)] + fx * e_[(I1 - Xc.i0) * cw + (J1 - Xc.j0)];
+      b2[e] = d != 0.0 ? MG_OMEGA * rv / d + ((1.0 - fy) * lo + fy * hi) : 0.0;
+    }
+    __syncthreads();
+    for (int e = tid; e < mg_rn(X); e += MG_UP_THREADS) {
+      const int i = X.i0 + e / w, j = X.j0 + e % w;
+      const size_t c = (size_t)i * nx + j;
+      const double d = st[(size_t)4 * n + c], rv = H.rhs[H.off[l] + c];
+      const double t = mg_apply_patch(st, n, c, i, j, ny, nx, b2, X2);
+      const double x2c = b2[(i - X2.i0) * w2 + (j - X2.j0)];
+      const double xv = d != 0.0 ? x2c + MG_OMEGA * (rv - t) / d : 0.0;
+      xo[e] = xv;
+      if (l == 0) { H.x[c] = xv; if (i >= A.row_lo && i < A.row_hi) dv += xv * rv; }
+    }
+    __syncthreads();
+  }
+  if (A.lC == 0) {      // level 0 is the tail's own level: only the dot product is left
+    const int w = mg_rw(own), nx = H.nx[0];
+    for (int e = tid; e < mg_rn(own); e += MG_UP_THREADS) {
+      const int i = own.i0 + e / w, j = own.j0 + e % w;
+      const size_t c = (size_t)i * nx + j;
+      if (i >= A.row_lo && i < A.row_hi) dv += H.x[c] * H.rhs[c];
+    }
+  }
+  if (idle) return;      // (after convergence the level arrays are dead; the scalar epilogue below must not run)
+  dv = eu_wave_sum(dv);
+  if ((tid & 63) == 0) s_red[tid >> 6] = dv;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int k = 0; k < MG_UP_THREADS / 64; ++k) t += s_red[k];
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(&A.dot_part[blockIdx.x]), (unsigned long long)__double_as_longlong(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  double t = 0.0;
+  for (unsigned int k = tid; k < gridDim.x; k += MG_UP_THREADS)
+    t += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&A.dot_part[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  t = eu_wave_sum(t);
+  __syncthreads();
+  if ((tid & 63) == 0) s_red[tid >> 6] = t;
+  __syncthreads();
+  if (tid == 0) {
+    double v = 0.0;
+    for (int k = 0; k < MG_UP_THREADS / 64; ++k) v += s_red[k];
+    if (A.fin_op == MG_FIN_SLOT) { A.sc->comm_val2 = v; if (A.sc->comm_slot) A.sc->comm_slot[1] += v; }      // (row slabs, split cycle: this rank's share travels with the pair)
+    else {
+      v = A.sc->sigma_new + v;      // k_precond_tile left dot(z_tile, r) there (FIN_STORE_ONLY)
+      if (A.fin_op == MFIN_SIGMA_INIT) A.sc->sigma = v;                                                       // main.c:748
+      else if (A.fin_op == MFIN_BETA) { A.sc->sigma_new = v; A.sc->beta = v / A.sc->sigma; A.sc->sigma = v; }   // main.c:762-765
+      else A.sc->sigma_new = v;
+    }
+    __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+static inline int mg_entry_level(const euler_sim* S) {      // the first level of <= MG_TAIL_MAX nodes: where the one-workgroup tail takes over
+  int l = 0;
+  while (l < S->mg_levels - 1 && (size_t)S->mg_nx[l] * S->mg_ny[l] > MG_TAIL_MAX) ++l;
+  return l;
+}
+static size_t mg_tail_lds(const euler_sim* S, int lB) {
+  size_t d = 0;
+  for (int l = lB; l < S->mg_levels; ++l) d += 2 * (size_t)S->mg_nx[l] * S->mg_ny[l];      // (the dense level: its right-hand side and result)
+  const size_t ntop = (size_t)S->mg_nx[S->mg_levels - 1] * S->mg_ny[S->mg_levels - 1];
+  return (d + ntop * ntop) * sizeof(double);
+}
+static int mg_set_lds(const void* fn, size_t bytes) {
+  if (bytes > 48 * 1024) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return EULER_OK;
+}
+
+// the cycle: H.rhs[level 0] -> H.x[level 0]; `gather`: level 0's right-hand side comes from the tiles' partial sums (else it is in H.rhs already)
+static int launch_mg_cycle(euler_sim* S, int fin_op, int force, bool gather) {
+  eu_prof_begin(S, KC_COARSE_CYCLE);      // ONE event pair around the whole cycle
+  const MgHier H = mg_hier(S);
+  const int lC = mg_entry_level(S);
+  if (S->mg_levels - 1 - lC > MG_TAIL_LEVELS) { eu_set_error("multilevel preconditioner: %d levels behind the entry level (at most %d)", S->mg_levels - 1 - lC, MG_TAIL_LEVELS); return EULER_EINVAL; }
+  unsigned int* tick_down = reinterpret_cast<unsigned int*>(S->mg_dot + MG_DOT_BLOCKS + 1);
+  unsigned int* tick_up = reinterpret_cast<unsigned int*>(S->mg_dot + MG_DOT_BLOCKS);
+  int lA = 0;
+  bool first = true;
+  do {
+    MgDownArgs A;
+    A.H = H; A.lA = lA;
+    A.lB = first ? (lC < 1 ? lC : 1) : (lA + 3 < lC ? lA + 3 : lC);
+    const int steps = A.lB - A.lA;
+    A.tile = steps == 3 ? 4 : steps == 2 ? 8 : steps == 1 ? 16 : 32;
+    int e = A.tile, c[4] = {0, 0, 0, 0};
+    c[steps] = e * e;
+    for (int k = steps - 1; k >= 0; --k) { e = 2 * e + 3; c[k] = e * e; }
+    A.cap0 = c[0] > c[2] ? c[0] : c[2]; A.cap1 = c[1] > c[3] ? c[1] : c[3];
+    A.tail = A.lB == lC;
+    A.part = S->mg_part; A.ntb = S->geom.T / 16; A.band_lo = S->band_lo; A.band_hi = S->band_hi;
+    A.inv = S->cc_inv; A.ticket = tick_down; A.sc = S->sc;
+    size_t lds = 2 * ((size_t)A.cap0 + A.cap1) * sizeof(double);
+    if (A.tail) { const size_t t = mg_tail_lds(S, A.lB); if (t > lds) lds = t; }
+    const unsigned nblk = (unsigned)(((S->mg_nx[A.lB] + A.tile - 1) / A.tile) * ((S->mg_ny[A.lB] + A.tile - 1) / A.tile));
+    if (first && gather) {
+      int rc = mg_set_lds(reinterpret_cast<const void*>(&k_mg_down<true>), lds); if (rc) return rc;
+      hipLaunchKernelGGL(k_mg_down<true>, dim3(nblk), dim3(MG_DOWN_THREADS), lds, S->stream, A);
+    } else {
+      int rc = mg_set_lds(reinterpret_cast<const void*>(&k_mg_down<false>), lds); if (rc) return rc;
+      hipLaunchKernelGGL(k_mg_down<false>, dim3(nblk), dim3(MG_DOWN_THREADS), lds, S->stream, A);
+    }
+    lA = A.lB;
+    first = false;
+  } while (lA < lC);
+  {
+    MgUpArgs U;
+    U.H = H; U.lC = lC; U.tile = 32; U.cap = 36 * 36;
+    U.row_lo = 0; U.row_hi = S->mg_ny[0];
+    U.sc = S->sc; U.fin_op = fin_op; U.force = force; U.dot_part = S->mg_dot; U.ticket = tick_up;
+    const unsigned nblk = (unsigned)(((S->mg_nx[0] + 31) / 32) * ((S->mg_ny[0] + 31) / 32));
+    if (nblk > MG_DOT_BLOCKS) { eu_set_error("multilevel preconditioner: %u tiles of level 0 (at most %d)", nblk, MG_DOT_BLOCKS); return EULER_EINVAL; }
+    const size_t lds = 3 * (size_t)U.cap * sizeof(double);
+    hipLaunchKernelGGL(k_mg_up, dim3(nblk), dim3(MG_UP_THREADS), lds, S->stream, U);
+  }
+  eu_prof_end(S, KC_COARSE_CYCLE);
+  return EULER_OK;
+}
+
+int eu_mg_solve(euler_sim* S, int fin_op, int force) { return launch_mg_cycle(S, fin_op, force, !S->has_comm); }
+
+// row slabs: from this rank's tiles, the node rows [4 band_lo - 1, 4 band_hi + 1) of level 0's right-hand side (clipped to the grid) into `dst`
+__global__ __launch_bounds__(256) void k_mg_gather_rows(const double* __restrict__ part, double* __restrict__ dst, int nx0, int row0, int row1, int ntb, int band_lo, int band_hi) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= nx0 * (row1 - row0)) return;
+  dst[k] = mg_gather0(part, row0 + k / nx0, k % nx0, ntb, band_lo, band_hi);
+}
+int eu_mg_slab_rows(euler_sim* S, int force) {
+  (void)force;
+  const int ny0 = S->mg_ny[0];
+  const int row0 = 4 * S->band_lo - 1 < 0 ? 0 : 4 * S->band_lo - 1, row1 = 4 * S->band_hi + 1 > ny0 ? ny0 : 4 * S->band_hi + 1;
+  const int cells = (row1 - row0) * S->mg_nx[0];
+  if (cells > 0)
+    LAUNCH(S, KC_COARSE_CYCLE, k_mg_gather_rows, dim3((cells + 255) / 256), dim3(256), S->mg_part, S->mg_xbuf + (size_t)S->bulk.rank * S->mg_xslot + 2, S->mg_nx[0], row0, row1, S->geom.T / 16,
+           S->band_lo, S->band_hi);
+  return EULER_OK;
+}
+
+// per solve: A_0 from the tiles, the coarser operators, the dense top level's stencil as five arrays for k_coarse_factor
+__global__ __launch_bounds__(256) void k_mg_top_stencil(const double* __restrict__ at, int n, double* __restrict__ out) {      // out: [9][n] -> the factor kernel reads d, e, n, ne, nw = entries 4, 5, 7, 8, 6
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 9 * n) out[i] = at[i];
+}
+int eu_mg_setup(euler_sim* S) {
+  const size_t n0 = (size_t)S->mg_nx[0] * S->mg_ny[0];
+  HIPCHK(hipMemsetAsync(S->mg_a0i, 0, 9 * n0 * sizeof(unsigned long long), S->stream));
+  HIPCHK(hipMemsetAsync(S->mg_part, 0, (S->chunk_cap + 64) * MG_PART * sizeof(double), S->stream));      // (tiles outside this solve's list contribute nothing)
+  const unsigned nblk = eu_blocks(S->chunk_cap, 4, 2048);
+  LAUNCH(S, KC_PRECON_FACTOR, k_mg_assemble0, dim3(nblk), dim3(256), S->cellmask, S->geom, S->chunk_list, S->sc, S->band_lo, S->mg_nx[0], S->mg_ny[0], S->mg_a0i);
+  LAUNCH(S, KC_PRECON_FACTOR, k_mg_convert0, dim3((unsigned)((9 * n0 + 255) / 256)), dim3(256), S->mg_a0i, S->mg_a, 9 * n0);
+  // row slabs: a node row collects cells of the ranks either side of a slab boundary.  The entries are multiples of 2^-16 far below 2^37: their sums are exact in
+  // any order, so ONE all-reduce makes A_0 whole and bit-identical everywhere (per solve; only the rows at slab boundaries actually overlap)
+  if (S->has_comm) COMM_CALL(S->bulk.allreduce(S->bulk.ctx, S->mg_a, (int32_t)(9 * n0), 0));
+  for (int l = 1; l < S->mg_levels; ++l)
+    LAUNCH(S, KC_PRECON_FACTOR, k_mg_coarsen, dim3((unsigned)(((size_t)S->mg_nx[l] * S->mg_ny[l] + 255) / 256)), dim3(256), S->mg_a + 9 * S->mg_off[l - 1], S->mg_nx[l - 1], S->mg_ny[l - 1],
+           S->mg_a + 9 * S->mg_off[l], S->mg_nx[l], S->mg_ny[l], S->sc);
+  return EULER_OK;
+}
+
+// ------------------------------------------------------------------------------------------ P_0 at single cells (the first search direction, ghost rows, the null-space fix)
+__global__ __launch_bounds__(256) void k_mg_search_init(double* __restrict__ s, const double* __restrict__ z, const uint8_t* __restrict__ mask, const double* __restrict__ y,
+                                                        SkewGeom g, int nx0, int ny0, size_t e_lo, size_t e_cnt, const PcgScalars* sc) {
+  if (sc->done || !sc->nonzero) return;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < e_cnt; k += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = e_lo + k;
+    double v = z[e];
+    if (mask[e] & CM_FLUID) {
+      int band, t, l;
+      skew_decode(g, e, band, t, l);
+      v = v + mg_interp0(y, nx0, ny0, t - l, band * 64 + l);
+    }
+    s[e] = v;
+  }
+}
+int eu_mg_search_init(euler_sim* S) {
+  LAUNCH(S, KC_UPDATE_SEARCH, k_mg_search_init, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), S->s, S->z, S->cellmask, S->mg_x, S->geom, S->mg_nx[0], S->mg_ny[0], S->e_lo, S->e_cnt, S->sc);
+  return EULER_OK;
+}
+__global__ __launch_bounds__(256) void k_mg_add_row(double* __restrict__ row, const double* __restrict__ y, int X, int yrow, int nx0, int ny0, const PcgScalars* sc) {
+  if (sc->done || !sc->nonzero) return;
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x < X) row[x] = row[x] + mg_interp0(y, nx0, ny0, x, yrow);
+}
+int eu_mg_add_row(euler_sim* S, double* row, int yrow) {
+  LAUNCH(S, KC_UPDATE_SEARCH, k_mg_add_row, dim3((S->X + 255) / 256), dim3(256), row, S->mg_x, S->X, yrow, S->mg_nx[0], S->mg_ny[0], S->sc);
+  return EULER_OK;
+}

@@ -26,6 +26,7 @@
 // dependency-respecting schedule gives the sequential sweep's bits; dot() is either replayed in
 // the reference's row-major order (EULER_DOT_SEQUENTIAL) or reduced in a fixed tree.
 #include "euler_dev.h"
+#include "k_mg.h"
 
 #include <stdlib.h>
 #include <type_traits>
@@ -359,10 +360,19 @@ __device__ __forceinline__ double pick3(int t, int tb1, int tb2, double v0, doub
   v = t >= tb2 ? v2 : v;
   return v;
 }
-struct CoarseRef { const double* y; int shift, nx, ny, band0; };   // y[ny][nx] over aggregates of (1 << shift)^2 grid cells; band0: the global index of the arrays' band 0
+struct CoarseRef { const double* y; int shift, nx, ny, band0; };   // y[ny][nx] over coarse cells of (1 << shift)^2 grid cells (COARSE 1) / over the multilevel mode's level-0 nodes (COARSE 2); band0: the global index of the arrays' band 0
+__device__ __forceinline__ double pick4(int q, double v0, double v1, double v2, double v3) {
+  double v = v0;
+  v = q >= 1 ? v1 : v;
+  v = q >= 2 ? v2 : v;
+  v = q >= 3 ? v3 : v;
+  return v;
+}
 struct SaHist { const double* s[6]; };   // PMODE N: the arrays of s_(k-N+1) .. s_(k-2) (N - 2 of them), offset like s_old
 // STORE false: A s' is not stored (`out` is ignored) - k_precond_tile<16, true> forms it again from s' instead of reading it back
-template <int SLAB, int PMODE, int SA_RUN, bool COARSE = false, bool STORE = true>   // SLAB 1: several ranks, the neighbouring slabs' arrays are mapped; 2: their edge rows as compact rows (nbr); 0: nbr is ignored
+// COARSE 2 (multilevel preconditioner, k_mg.hip): z + P_0 x_0 with P_0 bilinear from the level-0 nodes - the lane combines its two node rows once per run (four node columns
+// cover the run and its window), every cell then interpolates along its row; the expression is mg_interp0's, so a cell gets the same bits whoever forms its s'.
+template <int SLAB, int PMODE, int SA_RUN, int COARSE = 0, bool STORE = true>   // SLAB 1: several ranks, the neighbouring slabs' arrays are mapped; 2: their edge rows as compact rows (nbr); 0: nbr is ignored
 __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __restrict__ s_old, const double* __restrict__ z,
                                                              double* __restrict__ s_new, double* __restrict__ out,
                                                              const uint8_t* __restrict__ mask, SkewGeom g,
@@ -431,9 +441,35 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
       const int gcol = lane == 0 ? 0 : -63;
       // COARSE: this lane's columns in the run (pairs P0 - 1 .. P1: 20 records at most) start in aggregate column Ja, reach Ja + 1 at record
       // tb1 and Ja + 2 at record tb2 (aggregates of 16: three columns; of 64 and more: two); the lane's row decides the aggregate row
-      double cy0 = 0.0, cy1 = 0.0, cy2 = 0.0, ce0 = 0.0, ce1 = 0.0, ce2 = 0.0;
-      int ctb1 = 0x7fffffff, ctb2 = 0x7fffffff;
-      if (COARSE) {
+      double cy0 = 0.0, cy1 = 0.0, cy2 = 0.0, cy3 = 0.0, ce0 = 0.0, ce1 = 0.0, ce2 = 0.0, ce3 = 0.0;
+      int ctb1 = 0x7fffffff, ctb2 = 0x7fffffff, cJb = 0;
+      if (COARSE == 2) {
+        const int Ja = (2 * (P0 - 1) - lane - 8) >> 4;
+        cJb = Ja < 0 ? 0 : Ja;
+        const int row = (cref.band0 + lb) * 64 + lane;
+        const int c0 = cJb < cref.nx ? cJb : cref.nx - 1, c1 = cJb + 1 < cref.nx ? cJb + 1 : cref.nx - 1, c2 = cJb + 2 < cref.nx ? cJb + 2 : cref.nx - 1, c3 = cJb + 3 < cref.nx ? cJb + 3 : cref.nx - 1;
+        int i0, i1;
+        double fy;
+        mg_cell_w(row, cref.ny, i0, i1, fy);
+        const double* y0 = cref.y + (size_t)i0 * cref.nx;
+        const double* y1 = cref.y + (size_t)i1 * cref.nx;
+        cy0 = mg_rows(y0[c0], y1[c0], fy); cy1 = mg_rows(y0[c1], y1[c1], fy); cy2 = mg_rows(y0[c2], y1[c2], fy); cy3 = mg_rows(y0[c3], y1[c3], fy);
+        if (edge_lane) {      // the row across the band boundary
+          const int re = row + (lane == 0 ? -1 : 1);
+          if (re >= 0 && re < 16 * cref.ny) {
+            mg_cell_w(re, cref.ny, i0, i1, fy);
+            y0 = cref.y + (size_t)i0 * cref.nx; y1 = cref.y + (size_t)i1 * cref.nx;
+            ce0 = mg_rows(y0[c0], y1[c0], fy); ce1 = mg_rows(y0[c1], y1[c1], fy); ce2 = mg_rows(y0[c2], y1[c2], fy); ce3 = mg_rows(y0[c3], y1[c3], fy);
+          }
+        }
+      }
+      auto p0y = [&](int t, double a0, double a1, double a2, double a3) __attribute__((always_inline)) {      // (P_0 x_0) at the lane's column of record t, from a row's four node values
+        int j0, j1;
+        double f;
+        mg_cell_w(t - lane, cref.nx, j0, j1, f);
+        return mg_lerp_x(pick4(j0 - cJb, a0, a1, a2, a3), pick4(j1 - cJb, a0, a1, a2, a3), f);
+      };
+      if (COARSE == 1) {
         const int xa = 2 * (P0 - 1) - lane, Ja = (xa > 0 ? xa : 0) >> cref.shift;
         const int row = (cref.band0 + lb) * 64 + lane;
         const size_t I = (size_t)(row >> cref.shift) * cref.nx;
@@ -474,14 +510,22 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
             if (SLAB == 2 && ghost) { d.ez1 = gz[2 * P + 1 + gcol]; d.es1 = gs[2 * P + 1 + gcol]; }
             else if (SLAB == 1 && remote) { d.ez1 = ld_system(ez + k); d.es1 = ld_system(es + k); } else { d.ez1 = ez[k]; d.es1 = es[k]; }
           }
-          if (COARSE) {      // (harmless where nothing was loaded: the value is then never selected)
+          if (COARSE == 1) {      // (harmless where nothing was loaded: the value is then never selected)
             d.ez0 = d.ez0 + pick3(2 * P, ctb1, ctb2, ce0, ce1, ce2);
             d.ez1 = d.ez1 + pick3(2 * P + 1, ctb1, ctb2, ce0, ce1, ce2);
           }
+          if (COARSE == 2) {
+            d.ez0 = d.ez0 + p0y(2 * P, ce0, ce1, ce2, ce3);
+            d.ez1 = d.ez1 + p0y(2 * P + 1, ce0, ce1, ce2, ce3);
+          }
         }
-        if (COARSE) {        // z + P y of the lane's own two cells (records 2P, 2P + 1)
+        if (COARSE == 1) {        // z + P y of the lane's own two cells (records 2P, 2P + 1)
           d.z.x = d.z.x + pick3(2 * P, ctb1, ctb2, cy0, cy1, cy2);
           d.z.y = d.z.y + pick3(2 * P + 1, ctb1, ctb2, cy0, cy1, cy2);
+        }
+        if (COARSE == 2) {
+          d.z.x = d.z.x + p0y(2 * P, cy0, cy1, cy2, cy3);
+          d.z.y = d.z.y + p0y(2 * P + 1, cy0, cy1, cy2, cy3);
         }
       };
       auto sprime = [&](const SaPair& d) __attribute__((always_inline)) { return sw_d2{d.z.x + beta * d.so.x, d.z.y + beta * d.so.y}; };   // s' = z + beta s (main.c:674)
@@ -1279,8 +1323,9 @@ struct TileArgs {
   double *zsend_lo, *zsend_hi;
   int edge_lo, edge_hi;
   int reverse;            // walk the tiles in descending order
-  double* cpart;          // two-level mode (k_coarse.hip): per tile, the sums of the (updated) r over its fluid cells by coarse column: [tile][3]
+  double* cpart;          // two-level mode (k_coarse.hip): per tile, the sums of the (updated) r over its fluid cells by coarse column: [tile][3]; multilevel mode (k_mg.hip): [tile][48]
   int cshift;             // log2 of the coarse cell width in grid cells
+  int cmode, cnx, cny;    // cmode 2: the multilevel mode's bilinear restriction onto cnx x cny nodes of level 0
   // RECOMP (k_precond_tile<16, true>): `as` is the search direction s' itself and the pass forms A s' from it.  On row slabs the rows across
   // the slab boundary are the compact ghost rows of s' that k_search_apply SLAB 2 keeps (indexed by the column); null = no neighbouring slab
   const double *gs_lo, *gs_hi;
@@ -1331,6 +1376,20 @@ int eu_launch_tile_table(euler_sim* S) {
   return EULER_OK;
 }
 
+// the sum over a half-group of 8 lanes, in every lane of it: two quad permutes and the mirror of the half row (fixed order)
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double half_group_sum(double v) {
+  v = v + dpp_move<0xB1>(v);       // quad_perm [1, 0, 3, 2]
+  v = v + dpp_move<0x4E>(v);       // quad_perm [2, 3, 0, 1]
+  v = v + dpp_move<0x141>(v);      // row_half_mirror
+  return v;
+}
+
 template <int W>
 __global__ __launch_bounds__(PT_THREADS) void k_factor_tile(TileArgs a) {
   if (!a.force && pcg_idle(a.sc)) return;
@@ -1372,7 +1431,9 @@ __global__ __launch_bounds__(PT_THREADS) void k_factor_tile(TileArgs a) {
 #ifndef PT_RECOMP_BLOCKS
 #define PT_RECOMP_BLOCKS 1
 #endif
-template <int W, bool RECOMP = false>
+// CMODE: 0 no coarse part, 1 two-level mode (three sums per tile), 2 multilevel mode (the bilinear restriction: 48 sums per tile) - a template parameter so that the
+// tile-local mode's own instantiation keeps its registers (151: three waves per SIMD)
+template <int W, bool RECOMP = false, int CMODE = 0>
 __global__ __launch_bounds__(PT_THREADS, RECOMP ? PT_RECOMP_BLOCKS : 1) void k_precond_tile(TileArgs a) {
   if (!a.force && pcg_idle(a.sc)) return;
   const int lane = threadIdx.x & 63;
@@ -1479,24 +1540,46 @@ __global__ __launch_bounds__(PT_THREADS, RECOMP ? PT_RECOMP_BLOCKS : 1) void k_p
         }
       }
       if (!a.sweeps) return;
-      if (RECOMP && a.rupd) {      // the window of s' is dead: E^-1 takes its registers (the barrier keeps the compiler from hoisting these loads above the r update)
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int P = 0; P < W / 2; ++P) pp[P] = FULL ? s_tab[P < TABP ? P : 0][lane] : *reinterpret_cast<const sw_d2*>(a.pre + base + P * 128);
-      }
-      if (W == 16 && a.cpart && a.cshift == 4) {      // multilevel mode: aggregates of 16 - per group of 16 lanes, the cells left / right of the group's aggregate boundary (k_coarse.hip)
-        const int i16 = lane & 15;
-        double sl = 0.0, sr = 0.0;
+      if (W == 16 && CMODE == 2) {
+        // multilevel mode (k_mg.hip): P_0^T r of this tile, P_0 bilinear from the nodes at the cells (16 J + 8, 16 I + 8).  Lane 16 jg + i sits in row 16 G + i (G = 4 band + jg):
+        // the lanes i < 8 of a group lie between the node rows G - 1 and G, the lanes i >= 8 between G and G + 1 - a HALF-GROUP of 8 lanes is homogeneous - and a lane's 16
+        // columns between at most three node columns, starting at nb = k - jg - 1 (i < 8) / k - jg - 2 (i >= 8).  So a lane forms three column sums, multiplies them by its two
+        // row weights, and three DPP steps add the six products over the half-group: 2 node rows x 3 node columns per half-group, 48 doubles per tile (weights in sixteenths)
+        const int i16 = lane & 15, jg = lane >> 4;
+        const bool low = i16 < 8;
+        const int I0 = 4 * band + jg - (low ? 1 : 0);
+        double wy1 = (double)(low ? i16 + 8 : i16 - 8), wy0 = 16.0 - wy1;
+        if (I0 < 0) { wy0 = 0.0; wy1 = 16.0; }
+        if (I0 >= a.cny - 1) { wy0 = 16.0; wy1 = 0.0; }
+        const int nb = k - jg - (low ? 1 : 2), tb = low ? i16 + 8 : i16 - 8;      // records < tb lie between the node columns nb, nb + 1, the others between nb + 1, nb + 2
+        const bool lft0 = nb < 0, rgt0 = nb >= a.cnx - 1, lft1 = nb + 1 < 0, rgt1 = nb + 1 >= a.cnx - 1;      // beyond the outermost nodes: constant
+        // a record's weight of the right-hand node is (j - i16 + 8) & 15 = j + b with b constant over a segment: only sum rv and sum j rv per segment are accumulated
+        double s1 = 0.0, t1 = 0.0, s2 = 0.0, t2 = 0.0;
 #pragma unroll
         for (int j = 0; j < W; ++j) {
           const int cm = (int)((mm[j >> 1] >> ((j & 1) * 8)) & 0xff);
           const double rv = (cm & CM_FLUID) ? ((j & 1) ? rr[j >> 1].y : rr[j >> 1].x) : 0.0;
-          if (j < i16) sl += rv; else sr += rv;
+          const double jv = rv * (double)j;
+          const bool second = j >= tb;
+          s1 += second ? 0.0 : rv; t1 += second ? 0.0 : jv;
+          s2 += second ? rv : 0.0; t2 += second ? jv : 0.0;
         }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { sl += __shfl_xor(sl, o, 64); sr += __shfl_xor(sr, o, 64); }
-        if (i16 == 0) { double* cp = a.cpart + (size_t)tile * 8 + (lane >> 4) * 2; cp[0] = sl; cp[1] = sr; }
-      } else if (W == 16 && a.cpart) {      // P^T r of this tile: cell (lane, record k W + j) sits in column k W + j - lane; at most three coarse columns per tile
+        const double b1 = (double)(low ? 8 - i16 : 24 - i16), b2 = (double)(low ? -8 - i16 : 8 - i16);
+        double u1a = t1 + b1 * s1, u0a = 16.0 * s1 - u1a;      // first segment: weights of the nodes nb + 1 / nb
+        double u1b = t2 + b2 * s2, u0b = 16.0 * s2 - u1b;      // second segment: nb + 2 / nb + 1
+        if (lft0) { u0a = 0.0; u1a = 16.0 * s1; }
+        if (rgt0) { u0a = 16.0 * s1; u1a = 0.0; }
+        if (lft1) { u0b = 0.0; u1b = 16.0 * s2; }
+        if (rgt1) { u0b = 16.0 * s2; u1b = 0.0; }
+        const double c0 = u0a, c1 = u1a + u0b, c2 = u1b;
+        wy0 *= 1.0 / 256.0; wy1 *= 1.0 / 256.0;
+        const double p00 = half_group_sum(wy0 * c0), p01 = half_group_sum(wy0 * c1), p02 = half_group_sum(wy0 * c2);
+        const double p10 = half_group_sum(wy1 * c0), p11 = half_group_sum(wy1 * c1), p12 = half_group_sum(wy1 * c2);
+        if ((lane & 7) == 0) {
+          double* cp = a.cpart + (size_t)tile * 48 + (lane >> 3) * 6;
+          cp[0] = p00; cp[1] = p01; cp[2] = p02; cp[3] = p10; cp[4] = p11; cp[5] = p12;
+        }
+      } else if (W == 16 && CMODE == 1) {      // P^T r of this tile: cell (lane, record k W + j) sits in column k W + j - lane; at most three coarse columns per tile
         const int xl = k * W - 63, J0 = (xl > 0 ? xl : 0) >> a.cshift;
         double c0 = 0.0, c1 = 0.0, c2 = 0.0;
 #pragma unroll
@@ -1509,6 +1592,11 @@ __global__ __launch_bounds__(PT_THREADS, RECOMP ? PT_RECOMP_BLOCKS : 1) void k_p
         }
         c0 = eu_wave_sum(c0); c1 = eu_wave_sum(c1); c2 = eu_wave_sum(c2);
         if (lane == 0) { double* cp = a.cpart + (size_t)tile * 3; cp[0] = c0; cp[1] = c1; cp[2] = c2; }
+      }
+      if (RECOMP && a.rupd) {      // the window of s' is dead: E^-1 takes its registers (the barrier keeps the compiler from hoisting these loads above the r update)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int P = 0; P < W / 2; ++P) pp[P] = FULL ? s_tab[P < TABP ? P : 0][lane] : *reinterpret_cast<const sw_d2*>(a.pre + base + P * 128);
       }
       // L q = r (main.c:602-613).  What travels from cell to cell is m = (-1 * precon) * q, the term both consumers subtract.
       double own = -0.0, out = -0.0;
@@ -1908,7 +1996,7 @@ static TileArgs make_tile_args(euler_sim* S, int force) {
   // descending: k_search_apply walks the chunks upwards, so this pass starts on what the Infinity Cache still holds of it - and ends
   // where the next k_search_apply starts.  8192^2: 548 -> 536 us per iteration (EULER_TILE_REVERSE=0 restores the ascending order)
   { static const int rev = getenv("EULER_TILE_REVERSE") ? atoi(getenv("EULER_TILE_REVERSE")) : 1; a.reverse = rev; }
-  a.cpart = nullptr; a.cshift = 0;
+  a.cpart = nullptr; a.cshift = 0; a.cmode = 0; a.cnx = a.cny = 0;
   a.gs_lo = a.gs_hi = nullptr;
   if (ghost_mode(S)) {
     if (S->band_lo > 0) { a.zsend_lo = xrow(S, XR_ZSEND_LO); a.edge_lo = S->band_lo; }
@@ -1941,8 +2029,9 @@ static int launch_precond_tile(euler_sim* S, int rupd, int sweeps, int fin_dot, 
   const bool two_level = eu_is_two_level(S) && sweeps && !r_only && !force && a.list != nullptr;
   const int fin_real = a.fin_dot;
   if (two_level) {
-    const bool mg = eu_is_mg(S) && S->mg_levels > 0;
+    const bool mg = eu_is_mg(S);
     a.cpart = mg ? S->mg_part : S->cc_part; a.cshift = mg ? 4 : S->coarse_shift;
+    a.cmode = mg ? 2 : 1; a.cnx = mg ? S->mg_nx[0] : 0; a.cny = mg ? S->mg_ny[0] : 0;
     if (a.fin_dot >= 0) a.fin_dot = FIN_STORE_ONLY;
   }
   // row slabs + coarse correction: the pair and this rank's rows of the level-0 right-hand side travel in ONE slot of ONE all-gather inside the G1 exchange
@@ -1969,7 +2058,9 @@ static int launch_precond_tile(euler_sim* S, int rupd, int sweeps, int fin_dot, 
     case 8: LAUNCH(S, cls, k_precond_tile<8>, dim3(nblk), dim3(PT_THREADS), a); break;
     case 32: LAUNCH(S, cls, k_precond_tile<32>, dim3(nblk), dim3(PT_THREADS), a); break;
     default:
-      if (recomp) LAUNCH(S, cls, (k_precond_tile<16, true>), dim3(nblk), dim3(PT_THREADS), a);
+      if (a.cmode == 2) { if (recomp) LAUNCH(S, cls, (k_precond_tile<16, true, 2>), dim3(nblk), dim3(PT_THREADS), a); else LAUNCH(S, cls, (k_precond_tile<16, false, 2>), dim3(nblk), dim3(PT_THREADS), a); }
+      else if (a.cmode == 1) { if (recomp) LAUNCH(S, cls, (k_precond_tile<16, true, 1>), dim3(nblk), dim3(PT_THREADS), a); else LAUNCH(S, cls, (k_precond_tile<16, false, 1>), dim3(nblk), dim3(PT_THREADS), a); }
+      else if (recomp) LAUNCH(S, cls, (k_precond_tile<16, true>), dim3(nblk), dim3(PT_THREADS), a);
       else LAUNCH(S, cls, k_precond_tile<16>, dim3(nblk), dim3(PT_THREADS), a);
       break;
   }
@@ -1985,8 +2076,8 @@ static int launch_precond_tile(euler_sim* S, int rupd, int sweeps, int fin_dot, 
     if (rc) return rc;
     hipLaunchKernelGGL(k_pair_fold, dim3(1), dim3(1), 0, S->stream, S->sc, xsmall, nsmall, R, rupd, a.fin_dot, force);
     // coarse correction on row slabs: the tiles' shares of dot(z, r) are folded (stored, not applied); the V-cycle - its level-0 right-hand
-    // side all-gathered, the rest replicated - adds its share and applies the epilogue, the same bits on every rank
-    if (two_level) { rc = eu_launch_coarse_solve(S, fin_real, force); if (rc) return rc; }
+    // side the sum of the ranks' shares, the rest replicated - adds its share and applies the epilogue, the same bits on every rank
+    if (two_level) { rc = eu_launch_coarse_scatter(S); if (rc) return rc; rc = eu_launch_coarse_solve(S, fin_real, force); if (rc) return rc; }
   }
   return EULER_OK;
 }
@@ -2134,18 +2225,19 @@ static int launch_search_apply_and_alpha(euler_sim* S, int it) {
   const int fin = S->has_comm ? fin_or_comm(S, FIN_ALPHA) : (seq ? -1 : (int)FIN_ALPHA);
   double* pp = LOC(S->p);
   const bool store = !tile_recompute(S);      // false: A s' is not stored (k_precond_tile<16, true> forms it again)
-  const bool mg = eu_is_mg(S) && S->mg_levels > 0;
+  const bool mg = eu_is_mg(S);
   const CoarseRef cref = {mg ? S->mg_x : S->cc_y, mg ? 4 : S->coarse_shift, mg ? S->mg_nx[0] : S->coarse_nx, mg ? S->mg_ny[0] : S->coarse_ny, S->band_lo};
 #define SA_LAUNCH_CS(SLABF, PM, RUNV, CF, ST)                                                                                                \
   LAUNCH(S, KC_APPLY_A, (k_search_apply<SLABF, PM, RUNV, CF, ST>), dim3(sa_blocks(S, RUNV)), dim3(SA_THREADS), LOC(S->s), LOC(S->z), LOC(S->s2), \
          LOC(S->q), LOC(S->cellmask), gl, S->partial, S->sc, 0, S->red_counter, fin, nbr, pp, S->s2, S->s, (RUNV) == 8 ? S->chunk_list : (const unsigned int*)nullptr, cref, hist)
 #define SA_LAUNCH_C(SLABF, PM, RUNV, CF) do { if ((RUNV) == 8 && !store) SA_LAUNCH_CS(SLABF, PM, RUNV, CF, ((RUNV) != 8)); else SA_LAUNCH_CS(SLABF, PM, RUNV, CF, true); } while (0)
-#define SA_LAUNCH(SLABF, PM, RUNV) SA_LAUNCH_C(SLABF, PM, RUNV, false)
+#define SA_LAUNCH(SLABF, PM, RUNV) SA_LAUNCH_C(SLABF, PM, RUNV, 0)
 #define SA_RUNS(SLABF, PM) do { if (run == 8) SA_LAUNCH(SLABF, PM, 8); else if (run == 16) SA_LAUNCH(SLABF, PM, 16); else SA_LAUNCH(SLABF, PM, 32); } while (0)
   if (eu_is_two_level(S) && tile_fused(S) && ghost) {      // coarse correction on row slabs (multilevel mode): the ghost rows of z get their P y here as well
-    if (pmode == 8) SA_LAUNCH_C(2, 8, 8, true); else if (pmode == 4) SA_LAUNCH_C(2, 4, 8, true); else if (pmode == 2) SA_LAUNCH_C(2, 2, 8, true); else SA_LAUNCH_C(2, 1, 8, true);
+    if (pmode == 8) SA_LAUNCH_C(2, 8, 8, 2); else if (pmode == 4) SA_LAUNCH_C(2, 4, 8, 2); else if (pmode == 2) SA_LAUNCH_C(2, 2, 8, 2); else SA_LAUNCH_C(2, 1, 8, 2);
   } else if (eu_is_two_level(S) && tile_fused(S)) {      // two-level / multilevel preconditioner on one GPU: runs of 8 (the list), z + P y
-    if (pmode == 8) SA_LAUNCH_C(0, 8, 8, true); else if (pmode == 4) SA_LAUNCH_C(0, 4, 8, true); else if (pmode == 2) SA_LAUNCH_C(0, 2, 8, true); else SA_LAUNCH_C(0, 1, 8, true);
+    if (mg) { if (pmode == 8) SA_LAUNCH_C(0, 8, 8, 2); else if (pmode == 4) SA_LAUNCH_C(0, 4, 8, 2); else if (pmode == 2) SA_LAUNCH_C(0, 2, 8, 2); else SA_LAUNCH_C(0, 1, 8, 2); }
+    else { if (pmode == 8) SA_LAUNCH_C(0, 8, 8, 1); else if (pmode == 4) SA_LAUNCH_C(0, 4, 8, 1); else if (pmode == 2) SA_LAUNCH_C(0, 2, 8, 1); else SA_LAUNCH_C(0, 1, 8, 1); }
   } else if (ghost) {      // (tile-local mode; several ranks: runs of 8)
     if (pmode == 8) SA_LAUNCH(2, 8, 8); else if (pmode == 4) SA_LAUNCH(2, 4, 8); else if (pmode == 2) SA_LAUNCH(2, 2, 8); else SA_LAUNCH(2, 1, 8);
   } else if (direct) {

@@ -593,33 +593,24 @@ int eo_coarse_m(int X, int Y) {
   return m;
 }
 static void coarse_top_solve(eo_sim* s, double* rc);
-static void coarse_factor(eo_sim* s) {      /* A_c = P^T A P: sums of A's entries over pairs of coarse cells, then its Cholesky factor */
-  const int X = s->X, Y = s->Y, g = 64 * s->coarse_m;
-  const int nx = (X + g - 1) / g, ny = (Y + g - 1) / g, n = nx * ny;
-  double* A = (double*)calloc((size_t)n * n, sizeof(double));
+static void mg_build(eo_sim* s, double** A_top, int* n_top, int* nx_top);
+/* the dense level: A (n x n, symmetric, banded with half-bandwidth bw) -> its Cholesky factor in place, with the pin rule for cut-off fluid and the indicators of such components */
+static void dense_factor(eo_sim* s, double* A, int n, int nx, int bw) {
   s->coarse_npinned = 0;
-  for (int y = 0; y < Y; ++y)
-    for (int x = 0; x < X; ++x) {
-      if (!FLUID(s, y, x)) continue;
-      const int c = (y / g) * nx + x / g;
-      A[(size_t)c * n + c] += s->a_diag[AT(s, y, x)];
-      if (FLUID(s, y, x + 1)) { const int d = (y / g) * nx + (x + 1) / g; A[(size_t)c * n + d] -= 1; A[(size_t)d * n + c] -= 1; }
-      if (FLUID(s, y + 1, x)) { const int d = ((y + 1) / g) * nx + x / g; A[(size_t)c * n + d] -= 1; A[(size_t)d * n + c] -= 1; }
-    }
   for (int c = 0; c < n; ++c) if (A[(size_t)c * n + c] == 0.0) A[(size_t)c * n + c] = 1.0;      /* a coarse cell without fluid */
   double* a_kk = (double*)malloc((size_t)n * sizeof(double));
   for (int c = 0; c < n; ++c) a_kk[c] = A[(size_t)c * n + c];
-  for (int k = 0; k < n; ++k) {      /* in place, lower triangle (banded: entries beyond column distance nx stay 0) */
+  for (int k = 0; k < n; ++k) {      /* in place, lower triangle (banded: entries beyond column distance bw stay 0) */
     /* fluid cut off from the air makes A and P^T A P singular: the last pivot of such a component is rounding noise - it falls back to the diagonal (that coarse cell is pinned) */
     if (!(A[(size_t)k * n + k] > 1e-8 * a_kk[k])) { A[(size_t)k * n + k] = a_kk[k]; if (s->coarse_npinned < 16 && a_kk[k] != 1.0) s->coarse_pinned[s->coarse_npinned++] = k; }
     const double d = sqrt(A[(size_t)k * n + k]);
     A[(size_t)k * n + k] = d;
-    const int hi = k + nx < n - 1 ? k + nx : n - 1;
+    const int hi = k + bw < n - 1 ? k + bw : n - 1;
     for (int i = k + 1; i <= hi; ++i) A[(size_t)i * n + k] /= d;
     for (int j = k + 1; j <= hi; ++j)
       for (int i = j; i <= hi; ++i) A[(size_t)i * n + j] -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
   }
-  s->coarse_chol = A; s->coarse_n = n; s->coarse_nx = nx;
+  s->coarse_chol = A; s->coarse_n = n; s->coarse_nx = nx; s->coarse_bw = bw;
   /* the indicator of every cut-off component: the pinned system's answer to its own pin, n = a_kk S e_k (coarse_top_solve projects it out on both sides) */
   free(s->coarse_null);
   s->coarse_null = s->coarse_npinned ? (double*)calloc((size_t)s->coarse_npinned * n, sizeof(double)) : NULL;
@@ -632,6 +623,26 @@ static void coarse_factor(eo_sim* s) {      /* A_c = P^T A P: sums of A's entrie
     s->coarse_npinned = q + 1;
   }
   free(a_kk);
+}
+static void coarse_factor(eo_sim* s) {      /* A_c = P^T A P: sums of A's entries over pairs of coarse cells, then its Cholesky factor */
+  if (s->coarse_mg) {      /* multilevel mode: the dense level is the top of the hierarchy (mg_build) */
+    double* A; int n, nx;
+    mg_build(s, &A, &n, &nx);
+    dense_factor(s, A, n, nx, n > nx ? nx + 1 : n - 1 > 0 ? n - 1 : 1);
+    return;
+  }
+  const int X = s->X, Y = s->Y, g = 64 * s->coarse_m;
+  const int nx = (X + g - 1) / g, ny = (Y + g - 1) / g, n = nx * ny;
+  double* A = (double*)calloc((size_t)n * n, sizeof(double));
+  for (int y = 0; y < Y; ++y)
+    for (int x = 0; x < X; ++x) {
+      if (!FLUID(s, y, x)) continue;
+      const int c = (y / g) * nx + x / g;
+      A[(size_t)c * n + c] += s->a_diag[AT(s, y, x)];
+      if (FLUID(s, y, x + 1)) { const int d = (y / g) * nx + (x + 1) / g; A[(size_t)c * n + d] -= 1; A[(size_t)d * n + c] -= 1; }
+      if (FLUID(s, y + 1, x)) { const int d = ((y + 1) / g) * nx + x / g; A[(size_t)c * n + d] -= 1; A[(size_t)d * n + c] -= 1; }
+    }
+  dense_factor(s, A, n, nx, nx);
 }
 static void coarse_project_null(const eo_sim* s, double* v) {      /* v <- (I - n n^T / n.n) v for the indicator n of every cut-off component */
   const int n = s->coarse_n;
@@ -649,7 +660,7 @@ static void coarse_top_solve(eo_sim* s, double* rc) {      /* rc <- pseudo-inver
   coarse_project_null(s, rc);
 }
 static void coarse_top_solve_pinned(eo_sim* s, double* rc) {      /* rc <- S rc, S = the inverse of the (pinned) factored matrix, by the two banded substitutions */
-  const int n = s->coarse_n, nx = s->coarse_nx;
+  const int n = s->coarse_n, nx = s->coarse_bw;
   const double* L = s->coarse_chol;
   for (int i = 0; i < n; ++i) {      /* L w = r_c */
     double t = rc[i];
@@ -678,107 +689,212 @@ static void coarse_correction(eo_sim* s, const double* r, double* z) {
   free(rc);
 }
 
-/* EXTENSION (multilevel, euler_oracle.h coarse_mg): z += P_0 V(P_0^T r).  Level l: aggregates of (16 << l)^2 grid cells, nx x ny of them;
- * A_l as a 5-point stencil: d (diagonal), rt (coupling to the aggregate on the right, <= 0), up (to the one above). */
-typedef struct { int nx, ny; int *d, *rt, *up; double *rhs, *x, *t; } mg_level;
-typedef struct { int nlev; mg_level lv[16]; } mg_hierarchy;
-#define MG_OMEGA 1.0      /* (round 4: 0.8 / 1.5 before; k_coarse.hip says why) */
-#define MG_KAPPA 1.7
+/* EXTENSION (multilevel, euler_oracle.h coarse_mg; round 5: bilinear coarse spaces): z += P_0 V(P_0^T r).
+ * Level 0: a node per 16 x 16 grid cells, at the centre of cell (16 J + 8, 16 I + 8) (nx0 = ceil(X / 16), ny0 = 4 ceil(Y / 64): the product's bands); P_0 = BILINEAR interpolation
+ * from the four nodes around a cell (weights in sixteenths), restricted to the fluid, constant beyond the outermost nodes.  Level l + 1: every other node of level l in both
+ * directions (its node J sits on node 2 J), bilinear again (weights 1, 1/2: full weighting).  Nodes sit AT cell centres so that a hat is 0 at the neighbouring nodes.  A_0 = P_0^T A P_0, A_(l+1) = P^T A_l P: nine-point stencils, a[k][c] = the entry that couples node c = (I, J) to node (I + k / 3 - 1, J + k % 3 - 1).
+ * One symmetric V-cycle: damped Jacobi (omega) from a zero guess, restricted residual, recursion, correction, Jacobi again; the top level (at most MG_TOP_MAX nodes) is
+ * solved exactly (dense_factor).  Round 3-4 used piecewise constants over the same blocks (aggregation, 5-point stencils with integer entries, correction scaled by 1.7):
+ * 104 / 108 PCG iterations to 1e-6 on the 1024^2 / 2048^2 tank at rest, 109 on a 512^2 dam break at impact - the bilinear spaces need 52 / 52 / 64 (tools/r05/mg_proto.py). */
+typedef struct { int nx, ny; double* a[9]; double *rhs, *x, *t, *x1; } mg_level;
+typedef struct { int nlev; mg_level lv[20]; } mg_hierarchy;
+#define MG_OMEGA 0.8
+#define MG_TOP_MAX 64
 static void mg_free(eo_sim* s) {
   mg_hierarchy* h = (mg_hierarchy*)s->mg;
   if (!h) return;
-  for (int l = 0; l < h->nlev; ++l) { free(h->lv[l].d); free(h->lv[l].rhs); }
+  for (int l = 0; l < h->nlev; ++l) { free(h->lv[l].a[0]); free(h->lv[l].rhs); }
   free(h); s->mg = NULL;
 }
 static void mg_alloc_level(mg_level* L, int nx, int ny) {
   const size_t n = (size_t)nx * ny;
   L->nx = nx; L->ny = ny;
-  L->d = (int*)calloc(3 * n, sizeof(int)); L->rt = L->d + n; L->up = L->d + 2 * n;
-  L->rhs = (double*)calloc(3 * n, sizeof(double)); L->x = L->rhs + n; L->t = L->rhs + 2 * n;
+  L->a[0] = (double*)calloc(9 * n, sizeof(double));
+  for (int k = 1; k < 9; ++k) L->a[k] = L->a[0] + k * n;
+  L->rhs = (double*)calloc(4 * n, sizeof(double)); L->x = L->rhs + n; L->t = L->rhs + 2 * n; L->x1 = L->rhs + 3 * n;
 }
-static void mg_build(eo_sim* s) {
-  const int X = s->X, Y = s->Y, gtop = 64 * s->coarse_m;
+/* cell c of a row / column of cells against n nodes, node j AT the centre of cell 16 j + 8 (so a node's hat is 0 at the neighbouring nodes and the Galerkin operators are
+ * exact nine-point stencils): the two nodes j0, j1 around the cell and the weight f of j1 (1 - f of j0), a multiple of 1 / 16; constant beyond the outermost nodes */
+static inline void mg_w0(int c, int n, int* j0, int* j1, double* f) {
+  const int u = c - 8;
+  int j = u >= 0 ? u >> 4 : -1;
+  double w = (double)(u - 16 * j) / 16.0;
+  if (j < 0) { j = 0; w = 0.0; }                  /* left of the first node */
+  int k = j + 1;
+  if (k > n - 1) { k = n - 1; w = 0.0; }          /* right of the last node */
+  *j0 = j; *j1 = k; *f = w;
+}
+/* node c of a finer level against the n nodes of the next one, whose node j sits ON the finer level's node 2 j: weights 1 or 1/2, 1/2 */
+static inline void mg_w1(int c, int n, int* j0, int* j1, double* f) {
+  int j = c >> 1;
+  double w = (c & 1) ? 0.5 : 0.0;
+  int k = j + 1;
+  if (k > n - 1) { k = n - 1; w = 0.0; }
+  *j0 = j; *j1 = k; *f = w;
+}
+static inline void mg_add(mg_level* L, int I, int J, int I2, int J2, double v) {      /* A[(I, J), (I2, J2)] += v */
+  if (v == 0.0) return;
+  L->a[(I2 - I + 1) * 3 + (J2 - J + 1)][(size_t)I * L->nx + J] += v;
+}
+static void mg_build(eo_sim* s, double** A_top, int* n_top, int* nx_top) {
+  const int X = s->X, Y = s->Y;
+  mg_free(s);
   mg_hierarchy* h = (mg_hierarchy*)calloc(1, sizeof(mg_hierarchy));
-  int g = 16, l = 0;
-  for (;; g *= 2, ++l) { mg_alloc_level(&h->lv[l], (X + g - 1) / g, (Y + g - 1) / g); if (g >= gtop) break; }
+  int nx = (X + 15) / 16, ny = 4 * ((Y + 63) / 64), l = 0;
+  for (;; ++l) { mg_alloc_level(&h->lv[l], nx, ny); if (nx * ny <= MG_TOP_MAX) break; nx = (nx + 1) / 2; ny = (ny + 1) / 2; }
   h->nlev = l + 1;
   mg_level* L0 = &h->lv[0];
-  for (int y = 0; y < Y; ++y)      /* A_0 = P_0^T A P_0: sums of A's entries over pairs of aggregates */
+  /* A_0 = P_0^T A P_0: x^T A x = sum_cells a_diag x_i^2 - 2 sum_edges x_i x_j with x = P_0 X; every entry is a multiple of 2^-20 - exact in any order */
+  for (int y = 0; y < Y; ++y)
     for (int x = 0; x < X; ++x) {
       if (!FLUID(s, y, x)) continue;
-      const int c = (y >> 4) * L0->nx + (x >> 4);
-      L0->d[c] += s->a_diag[AT(s, y, x)];
-      if (FLUID(s, y, x + 1)) { if (((x + 1) >> 4) == (x >> 4)) L0->d[c] -= 2; else L0->rt[c] -= 1; }
-      if (FLUID(s, y + 1, x)) { if (((y + 1) >> 4) == (y >> 4)) L0->d[c] -= 2; else L0->up[c] -= 1; }
+      int jx[2], jy[2]; double wx[2], wy[2], f;
+      mg_w0(x, L0->nx, &jx[0], &jx[1], &f); wx[0] = 1.0 - f; wx[1] = f;
+      mg_w0(y, L0->ny, &jy[0], &jy[1], &f); wy[0] = 1.0 - f; wy[1] = f;
+      const double ad = (double)s->a_diag[AT(s, y, x)];
+      for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b)
+          mg_add(L0, jy[a >> 1], jx[a & 1], jy[b >> 1], jx[b & 1], ad * (wy[a >> 1] * wx[a & 1]) * (wy[b >> 1] * wx[b & 1]));
+      for (int e = 0; e < 2; ++e) {      /* the edge to the right (e = 0) / upper (e = 1) neighbour, both directions */
+        const int x2 = x + (e == 0), y2 = y + (e == 1);
+        if (!FLUID(s, y2, x2)) continue;
+        int kx[2], ky[2]; double vx[2], vy[2];
+        mg_w0(x2, L0->nx, &kx[0], &kx[1], &f); vx[0] = 1.0 - f; vx[1] = f;
+        mg_w0(y2, L0->ny, &ky[0], &ky[1], &f); vy[0] = 1.0 - f; vy[1] = f;
+        for (int a = 0; a < 4; ++a)
+          for (int b = 0; b < 4; ++b) {
+            const double v = -((wy[a >> 1] * wx[a & 1]) * (vy[b >> 1] * vx[b & 1]));
+            mg_add(L0, jy[a >> 1], jx[a & 1], ky[b >> 1], kx[b & 1], v);
+            mg_add(L0, ky[b >> 1], kx[b & 1], jy[a >> 1], jx[a & 1], v);
+          }
+      }
     }
-  for (int k = 1; k < h->nlev; ++k) {      /* A_k = P^T A_(k-1) P, 2 x 2 aggregation */
+  for (int k = 1; k < h->nlev; ++k) {      /* A_k = P^T A_(k-1) P */
     const mg_level* F = &h->lv[k - 1]; mg_level* C = &h->lv[k];
     for (int I = 0; I < F->ny; ++I)
       for (int J = 0; J < F->nx; ++J) {
-        const int c = I * F->nx + J, p = (I >> 1) * C->nx + (J >> 1);
-        C->d[p] += F->d[c];
-        if (J & 1) C->rt[p] += F->rt[c]; else C->d[p] += 2 * F->rt[c];      /* (rt of the last column is 0) */
-        if (I & 1) C->up[p] += F->up[c]; else C->d[p] += 2 * F->up[c];
+        const size_t c = (size_t)I * F->nx + J;
+        int jx[2], jy[2]; double wx[2], wy[2], f;
+        mg_w1(J, C->nx, &jx[0], &jx[1], &f); wx[0] = 1.0 - f; wx[1] = f;
+        mg_w1(I, C->ny, &jy[0], &jy[1], &f); wy[0] = 1.0 - f; wy[1] = f;
+        for (int e = 0; e < 9; ++e) {
+          const double av = F->a[e][c];
+          if (av == 0.0) continue;
+          const int I2 = I + e / 3 - 1, J2 = J + e % 3 - 1;
+          int kx[2], ky[2]; double vx[2], vy[2];
+          mg_w1(J2, C->nx, &kx[0], &kx[1], &f); vx[0] = 1.0 - f; vx[1] = f;
+          mg_w1(I2, C->ny, &ky[0], &ky[1], &f); vy[0] = 1.0 - f; vy[1] = f;
+          for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b)
+              mg_add(C, jy[a >> 1], jx[a & 1], ky[b >> 1], kx[b & 1], (wy[a >> 1] * wx[a & 1]) * av * (vy[b >> 1] * vx[b & 1]));
+        }
       }
   }
   s->mg = h;
+  const mg_level* T = &h->lv[h->nlev - 1];
+  const int n = T->nx * T->ny;
+  double* A = (double*)calloc((size_t)n * n, sizeof(double));
+  for (int I = 0; I < T->ny; ++I)
+    for (int J = 0; J < T->nx; ++J)
+      for (int e = 0; e < 9; ++e) {
+        const int I2 = I + e / 3 - 1, J2 = J + e % 3 - 1;
+        if (I2 < 0 || I2 >= T->ny || J2 < 0 || J2 >= T->nx) continue;
+        A[(size_t)(I * T->nx + J) * n + I2 * T->nx + J2] = T->a[e][(size_t)I * T->nx + J];
+      }
+  *A_top = A; *n_top = n; *nx_top = T->nx;
 }
-/* (A_l v)[c] in this order: diagonal, right, left, up, down */
+/* (A_l v)[c] in the order of the stencil: k = 0 .. 8 */
 static double mg_apply(const mg_level* L, const double* v, int I, int J) {
-  const int c = I * L->nx + J;
-  double t = (double)L->d[c] * v[c];
-  if (J + 1 < L->nx) t = t + (double)L->rt[c] * v[c + 1];
-  if (J > 0) t = t + (double)L->rt[c - 1] * v[c - 1];
-  if (I + 1 < L->ny) t = t + (double)L->up[c] * v[c + L->nx];
-  if (I > 0) t = t + (double)L->up[c - L->nx] * v[c - L->nx];
+  const size_t c = (size_t)I * L->nx + J;
+  double t = 0.0;
+  for (int e = 0; e < 9; ++e) {
+    const int I2 = I + e / 3 - 1, J2 = J + e % 3 - 1;
+    if (I2 < 0 || I2 >= L->ny || J2 < 0 || J2 >= L->nx) continue;
+    t = t + L->a[e][c] * v[(size_t)I2 * L->nx + J2];
+  }
   return t;
 }
-static void coarse_top_solve(eo_sim* s, double* rc);
+static void mg_restrict(const mg_level* F, const double* t, mg_level* C, double* out) {      /* out = P^T t */
+  memset(out, 0, (size_t)C->nx * C->ny * sizeof(double));
+  for (int I = 0; I < F->ny; ++I)
+    for (int J = 0; J < F->nx; ++J) {
+      int jx[2], jy[2]; double wx[2], wy[2], f;
+      mg_w1(J, C->nx, &jx[0], &jx[1], &f); wx[0] = 1.0 - f; wx[1] = f;
+      mg_w1(I, C->ny, &jy[0], &jy[1], &f); wy[0] = 1.0 - f; wy[1] = f;
+      const double v = t[(size_t)I * F->nx + J];
+      for (int a = 0; a < 4; ++a) out[(size_t)jy[a >> 1] * C->nx + jx[a & 1]] += (wy[a >> 1] * wx[a & 1]) * v;
+    }
+}
+static double mg_interp1(const mg_level* F, const mg_level* C, const double* e, int I, int J) {      /* (P e) at node (I, J) of the finer level */
+  int jx[2], jy[2]; double fx, fy;
+  mg_w1(J, C->nx, &jx[0], &jx[1], &fx);
+  mg_w1(I, C->ny, &jy[0], &jy[1], &fy);
+  (void)F;
+  const double lo = (1.0 - fx) * e[(size_t)jy[0] * C->nx + jx[0]] + fx * e[(size_t)jy[0] * C->nx + jx[1]];
+  const double hi = (1.0 - fx) * e[(size_t)jy[1] * C->nx + jx[0]] + fx * e[(size_t)jy[1] * C->nx + jx[1]];
+  return (1.0 - fy) * lo + fy * hi;
+}
+static double mg_interp0(const mg_level* L0, const double* e, int x, int y) {      /* (P_0 e) at cell (x, y) */
+  int jx[2], jy[2]; double fx, fy;
+  mg_w0(x, L0->nx, &jx[0], &jx[1], &fx);
+  mg_w0(y, L0->ny, &jy[0], &jy[1], &fy);
+  const double lo = (1.0 - fy) * e[(size_t)jy[0] * L0->nx + jx[0]] + fy * e[(size_t)jy[1] * L0->nx + jx[0]];
+  const double hi = (1.0 - fy) * e[(size_t)jy[0] * L0->nx + jx[1]] + fy * e[(size_t)jy[1] * L0->nx + jx[1]];
+  return (1.0 - fx) * lo + fx * hi;
+}
 static void mg_vcycle(eo_sim* s, mg_hierarchy* h, int l) {      /* lv[l].x = V_l lv[l].rhs */
   mg_level* L = &h->lv[l];
-  const int n = L->nx * L->ny;
-  if (l == h->nlev - 1) { memcpy(L->x, L->rhs, (size_t)n * sizeof(double)); coarse_top_solve(s, L->x); return; }
+  const size_t n = (size_t)L->nx * L->ny;
+  if (l == h->nlev - 1) { memcpy(L->x, L->rhs, n * sizeof(double)); coarse_top_solve(s, L->x); return; }
   mg_level* C = &h->lv[l + 1];
-  for (int c = 0; c < n; ++c) L->x[c] = L->d[c] ? MG_OMEGA * L->rhs[c] / (double)L->d[c] : 0.0;      /* Jacobi from a zero guess */
-  memset(C->rhs, 0, (size_t)C->nx * C->ny * sizeof(double));
-  for (int I = 0; I < L->ny; ++I)      /* restricted residual; children in the order (2I, 2J), (2I, 2J+1), (2I+1, 2J), (2I+1, 2J+1) */
-    for (int J = 0; J < L->nx; ++J) L->t[I * L->nx + J] = L->d[I * L->nx + J] ? L->rhs[I * L->nx + J] - mg_apply(L, L->x, I, J) : 0.0;
-  for (int I = 0; I < C->ny; ++I)
-    for (int J = 0; J < C->nx; ++J) {
-      double t = 0.0;
-      for (int a = 0; a < 2; ++a)
-        for (int b = 0; b < 2; ++b)
-          if (2 * I + a < L->ny && 2 * J + b < L->nx) t = t + L->t[(2 * I + a) * L->nx + 2 * J + b];
-      C->rhs[I * C->nx + J] = t;
-    }
+  const double* d = L->a[4];
+  for (size_t c = 0; c < n; ++c) L->x1[c] = d[c] != 0.0 ? MG_OMEGA * L->rhs[c] / d[c] : 0.0;      /* Jacobi from a zero guess */
+  for (int I = 0; I < L->ny; ++I)
+    for (int J = 0; J < L->nx; ++J) { const size_t c = (size_t)I * L->nx + J; L->t[c] = d[c] != 0.0 ? L->rhs[c] - mg_apply(L, L->x1, I, J) : 0.0; }
+  mg_restrict(L, L->t, C, C->rhs);
   mg_vcycle(s, h, l + 1);
-  for (int I = 0; I < L->ny; ++I)      /* the correction, scaled */
-    for (int J = 0; J < L->nx; ++J) {
-      const int c = I * L->nx + J;
-      L->x[c] = L->d[c] ? L->x[c] + MG_KAPPA * C->x[(I >> 1) * C->nx + (J >> 1)] : 0.0;
-    }
+  for (int I = 0; I < L->ny; ++I)      /* the correction */
+    for (int J = 0; J < L->nx; ++J) { const size_t c = (size_t)I * L->nx + J; L->t[c] = d[c] != 0.0 ? L->x1[c] + mg_interp1(L, C, C->x, I, J) : 0.0; }
   for (int I = 0; I < L->ny; ++I)      /* Jacobi again */
-    for (int J = 0; J < L->nx; ++J) {
-      const int c = I * L->nx + J;
-      L->t[c] = L->d[c] ? L->x[c] + MG_OMEGA * (L->rhs[c] - mg_apply(L, L->x, I, J)) / (double)L->d[c] : 0.0;
-    }
-  memcpy(L->x, L->t, (size_t)n * sizeof(double));
+    for (int J = 0; J < L->nx; ++J) { const size_t c = (size_t)I * L->nx + J; L->x[c] = d[c] != 0.0 ? L->t[c] + MG_OMEGA * (L->rhs[c] - mg_apply(L, L->t, I, J)) / d[c] : 0.0; }
 }
-static void coarse_factor(eo_sim* s);
 static void mg_correction(eo_sim* s, const double* r, double* z) {
   const int X = s->X, Y = s->Y;
   if (!s->coarse_chol) coarse_factor(s);
-  if (!s->mg) mg_build(s);
   mg_hierarchy* h = (mg_hierarchy*)s->mg;
   mg_level* L0 = &h->lv[0];
   memset(L0->rhs, 0, (size_t)L0->nx * L0->ny * sizeof(double));
   for (int y = 0; y < Y; ++y)
-    for (int x = 0; x < X; ++x)
-      if (FLUID(s, y, x)) L0->rhs[(y >> 4) * L0->nx + (x >> 4)] += r[AT(s, y, x)];
+    for (int x = 0; x < X; ++x) {
+      if (!FLUID(s, y, x)) continue;
+      int jx[2], jy[2]; double fx, fy;
+      mg_w0(x, L0->nx, &jx[0], &jx[1], &fx);
+      mg_w0(y, L0->ny, &jy[0], &jy[1], &fy);
+      const double rv = r[AT(s, y, x)];
+      L0->rhs[(size_t)jy[0] * L0->nx + jx[0]] += ((1.0 - fy) * (1.0 - fx)) * rv;
+      L0->rhs[(size_t)jy[0] * L0->nx + jx[1]] += ((1.0 - fy) * fx) * rv;
+      L0->rhs[(size_t)jy[1] * L0->nx + jx[0]] += (fy * (1.0 - fx)) * rv;
+      L0->rhs[(size_t)jy[1] * L0->nx + jx[1]] += (fy * fx) * rv;
+    }
   mg_vcycle(s, h, 0);
   for (int y = 0; y < Y; ++y)
     for (int x = 0; x < X; ++x)
-      if (FLUID(s, y, x)) z[AT(s, y, x)] += L0->x[(y >> 4) * L0->nx + (x >> 4)];
+      if (FLUID(s, y, x)) z[AT(s, y, x)] += mg_interp0(L0, L0->x, x, y);
+}
+/* the indicator of a cut-off component, known on the top level (coarse_null), at the cells: prolonged down the hierarchy, then P_0 */
+static double* mg_null_level0(eo_sim* s, const double* nv) {
+  mg_hierarchy* h = (mg_hierarchy*)s->mg;
+  const int top = h->nlev - 1;
+  double* cur = (double*)malloc((size_t)h->lv[top].nx * h->lv[top].ny * sizeof(double));
+  memcpy(cur, nv, (size_t)h->lv[top].nx * h->lv[top].ny * sizeof(double));
+  for (int l = top - 1; l >= 0; --l) {
+    const mg_level* L = &h->lv[l]; const mg_level* C = &h->lv[l + 1];
+    double* nxt = (double*)malloc((size_t)L->nx * L->ny * sizeof(double));
+    for (int I = 0; I < L->ny; ++I)
+      for (int J = 0; J < L->nx; ++J) nxt[(size_t)I * L->nx + J] = L->a[4][(size_t)I * L->nx + J] != 0.0 ? mg_interp1(L, C, cur, I, J) : 0.0;
+    free(cur); cur = nxt;
+  }
+  return cur;
 }
 
 void eo_apply_preconditioner(eo_sim* s, const double* r, double* z) {
@@ -883,19 +999,23 @@ int eo_project(eo_sim* s, float dt, const float* u, const float* v, float* uout,
      * the product keeps at most four indicators) */
     double eps[4] = {0, 0, 0, 0}, nn[4] = {0, 0, 0, 0};
     const int np = s->coarse_npinned < 4 ? s->coarse_npinned : 4;
+    double* n0[4] = {NULL, NULL, NULL, NULL};      /* multilevel mode: the indicators on level 0 (the cells sample them through P_0) */
+    const mg_level* L0 = s->coarse_mg ? &((mg_hierarchy*)s->mg)->lv[0] : NULL;
+    for (int q = 0; q < np && s->coarse_mg; ++q) n0[q] = mg_null_level0(s, s->coarse_null + (size_t)q * s->coarse_n);
+#define NULL_AT(q, y, x) (s->coarse_mg ? mg_interp0(L0, n0[q], x, y) : (s->coarse_null + (size_t)(q) * s->coarse_n)[((y) / g) * s->coarse_nx + (x) / g])
     for (int q = 0; q < np; ++q) {
-      const double* nv = s->coarse_null + (size_t)q * s->coarse_n;
       for (int y = 0; y < Y; ++y)
         for (int x = 0; x < X; ++x)
-          if (FLUID(s, y, x)) { const double w = nv[(y / g) * s->coarse_nx + x / g]; eps[q] += r[AT(s, y, x)] * w; nn[q] += w * w; }
+          if (FLUID(s, y, x)) { const double w = NULL_AT(q, y, x); eps[q] += r[AT(s, y, x)] * w; nn[q] += w * w; }
     }
     for (int q = 0; q < np; ++q) {
-      const double* nv = s->coarse_null + (size_t)q * s->coarse_n;
       if (nn[q] > 0.0)
         for (int y = 0; y < Y; ++y)
           for (int x = 0; x < X; ++x)
-            if (FLUID(s, y, x)) r[AT(s, y, x)] -= nv[(y / g) * s->coarse_nx + x / g] * (eps[q] / nn[q]);
+            if (FLUID(s, y, x)) r[AT(s, y, x)] -= NULL_AT(q, y, x) * (eps[q] / nn[q]);
     }
+#undef NULL_AT
+    for (int q = 0; q < 4; ++q) free(n0[q]);
   }
   s->last_residual = 0;
   if (nonzero && s->pcg_f32 && s->tile_records > 0 && s->coarse_m == 0) iters = pcg_f32(s);

@@ -65,15 +65,14 @@ typedef struct eo_sim {
   int coarse_m;
   int coarse_n, coarse_nx;      /* filled by the first application: number of coarse cells, coarse cells per row */
   double* coarse_chol;          /* dense lower Cholesky factor of P^T A P (coarse_n^2), NULL = not factored yet */
-  /* EXTENSION on top of that (round 3): the MULTILEVEL form of the coarse correction (coarse_mg != 0, with coarse_m > 0):
+  /* EXTENSION on top of that (round 3; round 5: bilinear coarse spaces): the MULTILEVEL form of the coarse correction (coarse_mg != 0, with coarse_m > 0):
    *     z = M_tile^-1 r + P_0 V(P_0^T r)
-   * P_0 = piecewise constants over aggregates of 16 x 16 grid cells restricted to the fluid; V = one symmetric V-cycle for
-   * A_0 = P_0^T A P_0 over the hierarchy of 2 x 2 aggregations 16 -> 32 -> ... -> 64 m (Galerkin operators: 5-point stencils with
-   * integer entries), damped Jacobi (omega = 0.8) once before and once after the coarse-grid correction, the correction scaled
-   * by kappa = 1.5 (plain aggregation under-corrects), the top level (at most 256 cells) solved exactly with coarse_chol.
-   * A fixed symmetric positive definite operator: PCG converges to the same solution; the aggregates of 16 cells match the tile
-   * width, so the iteration count no longer grows with the grid (1024^2 tank at rest: 880 reference IC(0), 627 two-level with the
-   * same top level, 121 multilevel).  The hierarchy is rebuilt per system (eo_build_system invalidates it). */
+   * P_0 = bilinear interpolation from a grid of nodes, one per 16 x 16 grid cells at the block's centre, restricted to the fluid; V = one symmetric V-cycle for
+   * A_0 = P_0^T A P_0 over a hierarchy of node grids, each with a node per 2 x 2 nodes of the one below and bilinear interpolation again (Galerkin operators:
+   * nine-point stencils), damped Jacobi (omega = 0.8) once before and once after the coarse-grid correction, the top level (at most 64 nodes) solved exactly
+   * with coarse_chol.  A fixed symmetric positive definite operator: PCG converges to the same solution, and the iteration count does not grow with the grid
+   * (tank at rest to 1e-6: 880 iterations with the reference's IC(0) at 1024^2, 104 with round 4's piecewise-constant aggregates, 52 with these).
+   * The hierarchy is rebuilt per system (eo_build_system invalidates it). */
   int coarse_mg;
   void* mg;                     /* the hierarchy (euler_oracle.c: mg_hierarchy), NULL = not built yet */
   /* fluid cut off from the air (a closed box full of water): P^T A P is singular along the indicator of such a component; the factor pins one of its cells
@@ -85,6 +84,7 @@ typedef struct eo_sim {
    * (its PCG is double, main.c:577-578,716): tolerance parity only.  Needs tile_records > 0 and no coarse correction.  The arrays keep their double storage and
    * hold float values. */
   int pcg_f32;
+  int coarse_bw;                /* half-bandwidth of coarse_chol */
 } eo_sim;
 
 eo_sim* eo_create(int X, int Y);

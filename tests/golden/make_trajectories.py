@@ -21,9 +21,16 @@ def record(name):
     rec = {"frames": []}
     if spec.get("init"):
         rec["init"] = T.snapshot(o, spec)
-    for _ in range(spec["frames"]):
-        o.step()
-        rec["frames"].append(T.snapshot(o, spec))
+    n = spec.get("substeps") or spec["frames"]
+    every = spec.get("every", 1)
+    for f in range(n):
+        t0 = time.perf_counter()
+        T.advance(o, spec)
+        full = (f + 1) % every == 0 or f == n - 1
+        snap = T.snapshot(o, spec if full else dict(spec, fields=()))
+        rec["frames"].append(snap)
+        if spec.get("big"):
+            print("  %s %d: %d substeps, %d iterations, %d markers, %.1f s" % (name, f, snap["last_substeps"], snap["last_pcg_iterations"], snap["n_markers"], time.perf_counter() - t0), flush=True)
     if spec.get("render"):
         rec["render"] = hashlib.sha1(o.render(spec["X"], spec["Y"])).hexdigest()[:20]
     o.close()
@@ -40,7 +47,12 @@ def main():
     for n in names:
         t0 = time.perf_counter()
         out[n] = record(n)
-        print("%-34s %3d frames  %.1f s" % (n, len(out[n]["frames"]), time.perf_counter() - t0))
+        print("%-34s %3d frames  %.1f s" % (n, len(out[n]["frames"]), time.perf_counter() - t0), flush=True)
+        if os.environ.get("EULER_TRAJ_OUT"):      # (several big recordings side by side: each writes its own file, merged afterwards)
+            with open(os.environ["EULER_TRAJ_OUT"] + n + ".json", "w") as f:
+                json.dump({n: out[n]}, f, indent=0, sort_keys=True)
+    if os.environ.get("EULER_TRAJ_OUT"):
+        return
     with open(T.PATH, "w") as f:
         json.dump(out, f, indent=0, sort_keys=True)
         f.write("\n")

@@ -120,7 +120,7 @@ def test_pcg_with_two_level_preconditioner_reaches_the_same_pressure_in_fewer_it
 
 # ---- the multilevel EXTENSION (oracle/euler_oracle.h eo_sim.coarse_mg; include/euler.h EULER_PRECOND_IC0_TILE_MG)
 def test_multilevel_preconditioner_is_symmetric_positive():
-    """one V-cycle with Jacobi before and after and a scaled correction is a fixed symmetric positive definite operator - what PCG needs"""
+    """one V-cycle with Jacobi before and after is a fixed symmetric positive definite operator - what PCG needs"""
     o = _system(300, 200)
     rng = np.random.default_rng(12)
     fluid = o.count > 0
@@ -136,16 +136,23 @@ def test_multilevel_preconditioner_is_symmetric_positive():
         assert (_apply(o, 16, c) * c).sum() > 0
     o.c.coarse_mg = 0; o.c.coarse_m = 0
     d = Ma - _apply(o, 16, a)
-    for I in range(0, 200, 16):      # the correction is constant over the fluid cells of an aggregate of 16 x 16
-        for J in range(0, 300, 16):
-            vals = d[I:I + 16, J:J + 16][fluid[I:I + 16, J:J + 16]]
-            if vals.size:
-                assert np.ptp(vals) <= 1e-12 * max(1.0, np.abs(vals).max()), (I, J)
+    # the correction lies in the coarse space: bilinear between the nodes at the cells (16 J + 8, 16 I + 8) - inside a node interval its second differences vanish
+    scale = np.abs(d).max()
+    assert scale > 0
+    x = np.arange(1, 299)
+    same_x = ((x - 1 - 8) // 16 == (x + 1 - 8) // 16) & (x - 1 >= 8) & (x + 1 < 16 * ((300 + 15) // 16 - 1) + 8)
+    trip = fluid[:, 2:] & fluid[:, 1:-1] & fluid[:, :-2] & same_x[None, :]
+    assert trip.sum() > 1000
+    assert np.abs((d[:, 2:] - 2 * d[:, 1:-1] + d[:, :-2])[trip]).max() <= 1e-11 * scale
+    y = np.arange(1, 199)
+    same_y = ((y - 1 - 8) // 16 == (y + 1 - 8) // 16) & (y - 1 >= 8)
+    trip = fluid[2:, :] & fluid[1:-1, :] & fluid[:-2, :] & same_y[:, None]
+    assert np.abs((d[2:, :] - 2 * d[1:-1, :] + d[:-2, :])[trip]).max() <= 1e-11 * scale
 
 
 def test_pcg_with_multilevel_preconditioner_iteration_counts():
     """256^2 and 512^2 half tank from rest, tolerance parity with the reference's IC(0) (1e-5 max |p|); the iteration count stays put
-    when the grid doubles (measured 96 / 107; the reference's IC(0): 231 / 445)."""
+    when the grid doubles (measured 50 / 52 with the bilinear coarse spaces of round 5, 96 / 107 with round 4's aggregates; the reference's IC(0): 231 / 445)."""
     its = {}
     for n in (256, 512):
         res = {}
@@ -160,8 +167,8 @@ def test_pcg_with_multilevel_preconditioner_iteration_counts():
             res[name] = (o.p.copy(), int(o.c.last_pcg_iterations))
         assert np.abs(res["mg"][0] - res["ic0"][0]).max() <= 1e-5 * np.abs(res["ic0"][0]).max()
         its[n] = (res["ic0"][1], res["mg"][1])
-    assert its[256][1] < 0.5 * its[256][0] and its[512][1] < 0.3 * its[512][0], its
-    assert its[512][1] <= its[256][1] + 20, its
+    assert its[256][1] < 0.3 * its[256][0] and its[512][1] < 0.15 * its[512][0], its
+    assert its[512][1] <= its[256][1] + 6, its
 
 
 def test_coarse_modes_on_a_closed_box_full_of_water():

@@ -31,6 +31,14 @@ SPECS = {
     "dye_200x150_waterfall": dict(X=200, Y=150, scenario="waterfall", rainbow=True, frames=40, fields=DYE, nan_class=True, render=True),
     "dye_256x160_dam_break": dict(X=256, Y=160, scenario="dam_break", rainbow=True, frames=30, fields=DYE, nan_class=True, render=True),
 }
+# BASELINE.json's own sizes (VERDICT r4 "next" 2): the oracle's leg is minutes of CPU and gigabytes of memory, run once in the build container; `substeps`: the
+# trajectory is single substeps (dt = calculate_timestep(0.1), then one substep) instead of whole frames; `big`: tests/test_trajectories.py never replays it live
+SPECS.update({
+    "half_tank_8192_ic0_substep": dict(X=8192, Y=8192, half_tank=True, substeps=1, fields=STATE, big=True),                       # configs[2], the reference's IC(0)
+    "half_tank_4096_tile_substep": dict(X=4096, Y=4096, half_tank=True, tile_records=16, substeps=1, fields=STATE, big=True),     # the roofline mode's preconditioner
+    "waterfall_4096": dict(X=4096, Y=4096, scenario="waterfall", frames=6, fields=STATE, big=True),                               # configs[4]: sources firing
+    "dam_break_2048": dict(X=2048, Y=2048, scenario="dam_break", frames=36, fields=STATE, big=True, every=6),                     # configs[1]/[3]'s scenario into the capped phase
+})
 for _size, _scn, _frames in (((130, 70), "block", 12), ((257, 129), "filter", 8), ((192, 200), "waterfall", 10), ((320, 192), "weird-edges", 6),
                              ((112, 48), "filter", 40), ((144, 200), "block", 30)):
     SPECS["ragged_%dx%d_%s" % (_size[0], _size[1], _scn)] = dict(X=_size[0], Y=_size[1], golden=_scn, frames=_frames, fields=STATE, init=True)
@@ -79,7 +87,18 @@ def snapshot(o, spec):
     rec["last_pcg_iterations"] = int(o.c.last_pcg_iterations)
     rec["n_markers"] = int(o.n_markers)
     rec["vmax"] = float(np.abs(o.v).max())
+    if spec.get("big"):
+        rec["last_dt"] = float(o.c.last_dt)
+        rec["rng_state"] = int(o.c.rng_state)
     return rec
+
+
+def advance(o, spec):
+    """one recorded unit of a trajectory on a LIVE oracle: a frame, or - `substeps` - calculate_timestep(0.1) and one substep"""
+    if spec.get("substeps"):
+        o.substep(o.timestep(0.1))
+    else:
+        o.step()
 
 
 _cache = {}
@@ -127,11 +146,20 @@ class Recorded:
     def vmax(self):
         return self.cur["vmax"]
 
+    def substep(self, dt):
+        assert self.spec.get("substeps"), self.name
+        self.step()
+        assert np.float32(dt) == np.float32(self.cur["last_dt"]), ("dt", dt, self.cur["last_dt"])
+
+    def has(self, attr):
+        """frames of a trajectory recorded with `every` = n hold the arrays' digests on every n-th frame (and the last) only; the counters on all"""
+        return attr in self.cur
+
     def live(self):
         if self._live is None:
             self._live = make_oracle(self.spec)
         while self._live_frame < self.frame:
-            self._live.step()
+            advance(self._live, self.spec)
             self._live_frame += 1
         assert self._live_frame == self.frame, "live replay cannot go back"
         return self._live
