@@ -174,7 +174,7 @@ extern "C" int euler_set_precond(euler_sim* S, int32_t precond, int32_t tile_rec
   if (S->cfg.pcg_precision == EULER_PCG_F32 && (precond != EULER_PRECOND_IC0_TILE || w != 16)) { eu_set_error("euler_set_precond: an EULER_PCG_F32 handle runs EULER_PRECOND_IC0_TILE with tiles of 16 records only"); return EULER_EINVAL; }
   HIPCHK(hipStreamSynchronize(S->stream));
   const bool coarse = precond == EULER_PRECOND_IC0_TILE2 || precond == EULER_PRECOND_IC0_TILE_MG;
-  if (coarse) { int rc = eu_coarse_alloc(S); if (rc) return rc; }      // their arrays come with the first use
+  if (coarse) { int rc = eu_coarse_alloc(S, precond == EULER_PRECOND_IC0_TILE_MG); if (rc) return rc; }      // their arrays come with the first use
   (void)eu_set_tiles(S, w);
   // the coarse modes fold their sums as trees: EULER_DOT_TREE while one of them is selected, the caller's own mode (EULER_DOT_SEQUENTIAL: the
   // reference's order of the dot products, the bit-identical parity mode) again afterwards
@@ -457,7 +457,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
       eu_set_error("EULER_PRECOND_IC0_TILE2: one GPU; _MG: one GPU or row slabs; both: tiles of 16 records, the band schedule"); euler_destroy(S); return EULER_EINVAL;
     }
     S->cfg.dot_mode = EULER_DOT_TREE;
-    int rc = eu_coarse_alloc(S);
+    int rc = eu_coarse_alloc(S, S->cfg.precond == EULER_PRECOND_IC0_TILE_MG);
     if (rc) { euler_destroy(S); return rc; }
   }
   S->hbm_bytes = g_alloc_bytes + (S->slab_on ? eu_slab_bytes(S) : 0);

@@ -192,6 +192,7 @@ struct euler_sim {
   double* mg_part;                   // [chunks][48]: per tile and half-group of 8 lanes, the weighted sums of r for 2 node rows x 3 node columns (k_precond_tile)
   double* mg_dot;                    // per-workgroup partials of x_0 . rhs_0 (+ the ticket counters behind them)
   double* mg_null0;                  // [4][mg_cells]: the indicators of cut-off regions on every level (k_mg_null_prolong)
+  double* mg_m0;                     // [4][nodes of level 0] + [4]: P_0^T of those indicators on the cells, and m_0 . n_0 (the gauge of k_mg_up)
   double* mg_xbuf; int mg_xslot;     // row slabs: [ranks][mg_xslot] - every rank's {max |r|, dot(z,r), its share of the level-0 right-hand side}, ONE all-gather inside the G1 exchange
   // the resident solver (k_resident.hip): the tile-local PCG of a grid whose chunks all find a wave on the chip at once, in ONE persistent launch
   unsigned long long* res_gran;   // [2][3][768] 16-byte {value, generation} granules of its grid-wide reductions
@@ -367,7 +368,7 @@ static inline bool eu_is_tile(const euler_sim* S) { return S->cfg.precond == EUL
 static inline bool eu_is_two_level(const euler_sim* S) { return S->cfg.precond == EULER_PRECOND_IC0_TILE2 || S->cfg.precond == EULER_PRECOND_IC0_TILE_MG; }   // "has a coarse correction"
 static inline bool eu_is_mg(const euler_sim* S) { return S->cfg.precond == EULER_PRECOND_IC0_TILE_MG; }
 // two-level preconditioner (k_coarse.hip)
-int  eu_coarse_alloc(euler_sim* S);           // lazily, when the mode is first selected
+int  eu_coarse_alloc(euler_sim* S, bool mg);  // lazily, when the mode is first selected (mg: the multilevel mode's hierarchy as well)
 void eu_coarse_release(euler_sim* S);
 int  eu_launch_coarse_setup(euler_sim* S);    // per solve: P^T A P, its factor and inverse
 int  eu_launch_coarse_consistent(euler_sim* S);   // per solve: if water is cut off from the air, take the part of r = b along that region's indicator out (host sync for the count)

@@ -36,8 +36,8 @@
 enum { CFIN_SIGMA_INIT = 0, CFIN_BETA = 3 };
 
 void eu_coarse_release(euler_sim* S);
-int eu_coarse_alloc(euler_sim* S) {
-  if (S->cc_null) return eu_is_mg(S) ? eu_mg_alloc(S) : EULER_OK;      // (the last allocation below: everything of the dense level is there)
+int eu_coarse_alloc(euler_sim* S, bool mg) {
+  if (S->cc_null) return mg ? eu_mg_alloc(S) : EULER_OK;      // (the last allocation below: everything of the dense level is there)
   eu_coarse_release(S);                // (a failed earlier attempt may have left some of it)
   int m = 1, shift = 6;
   while (((S->X + 64 * m - 1) / (64 * m)) * ((S->geom.nbands + m - 1) / m) > CC_MAX) { m *= 2; shift += 1; }
@@ -57,7 +57,7 @@ int eu_coarse_alloc(euler_sim* S) {
   HIPCHK(hipMemset(S->cc_y, 0, (2 * CC_MAX + 1) * sizeof(double)));
   HIPCHK(hipMalloc((void**)&S->cc_null, CC_NULL_TOTAL * sizeof(double)));      // indicators, their number, the sums / partials / ticket of k_null_sums
   HIPCHK(hipMemset(S->cc_null, 0, CC_NULL_TOTAL * sizeof(double)));
-  if (eu_is_mg(S)) return eu_mg_alloc(S);
+  if (mg) return eu_mg_alloc(S);
   return EULER_OK;
 }
 
@@ -408,6 +408,8 @@ int eu_launch_coarse_consistent(euler_sim* S) {
       LAUNCH(S, KC_PRECON_FACTOR, k_mg_null_prolong, dim3((S->mg_nx[l] * S->mg_ny[l] + 255) / 256), dim3(256), S->cc_null, S->mg_null0, S->mg_cells, S->mg_a + 9 * S->mg_off[l] + 4 * (size_t)S->mg_nx[l] * S->mg_ny[l],
              S->mg_off[l], S->mg_nx[l], S->mg_ny[l], S->mg_off[l + 1], S->mg_nx[l + 1], S->mg_ny[l + 1], l + 1 == top ? 1 : 0, S->sc);
     M = MgNull{S->mg_null0, S->mg_cells, S->mg_nx[0], S->mg_ny[0]};
+    int rc = eu_mg_null_setup(S);
+    if (rc) return rc;
   }
   LAUNCH(S, KC_PRECON_FACTOR, k_null_sums, dim3(nblk), dim3(256), S->r, S->cellmask, S->geom, S->e_lo, S->e_cnt, S->cc_null, S->coarse_shift, S->coarse_nx, S->sc, M);
   if (S->has_comm) COMM_CALL(S->bulk.allreduce(S->bulk.ctx, S->cc_null + NS_SUMS, 2 * CC_NULL_MAX, 0));      // (zeros when nothing is cut off: every rank calls it, every solve)

@@ -17,6 +17,7 @@ int  eu_mg_setup(euler_sim* S);                                   // per solve: 
 int  eu_mg_solve(euler_sim* S, int fin_op, int force);            // per iteration: the V-cycle, x_0 . rhs_0 into dot(z, r), the scalar epilogue
 int  eu_mg_search_init(euler_sim* S);                             // s = z + P_0 x_0
 int  eu_mg_add_row(euler_sim* S, double* row, int yrow);          // + P_0 x_0 on a compact row of cells
+int  eu_mg_null_setup(euler_sim* S);                              // per solve, behind the indicators' way down the levels: what the gauge of a cut-off region needs
 int  eu_mg_slab_rows(euler_sim* S, int force);                   // row slabs: this rank's share of level 0's right-hand side into its slot of the exchange buffer
 
 #ifdef __HIPCC__

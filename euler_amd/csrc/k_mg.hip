@@ -71,15 +71,17 @@ int eu_mg_alloc(euler_sim* S) {
   HIPCHK(hipMemset(S->mg_rhs, 0, 2 * S->mg_cells * sizeof(double)));
   HIPCHK(hipMemset(S->mg_part, 0, (S->chunk_cap + 64) * MG_PART * sizeof(double)));
   HIPCHK(hipMemset(S->mg_null0, 0, (size_t)MG_NULL_MAX * S->mg_cells * sizeof(double)));
-  HIPCHK(hipMalloc((void**)&S->mg_dot, (MG_DOT_BLOCKS + 2) * sizeof(double)));      // per-workgroup partials of x_0 . rhs_0, then the tickets of k_mg_up and k_mg_down
-  HIPCHK(hipMemset(S->mg_dot, 0, (MG_DOT_BLOCKS + 2) * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&S->mg_m0, (MG_NULL_MAX * n0 + MG_NULL_MAX) * sizeof(double)));
+  HIPCHK(hipMemset(S->mg_m0, 0, (MG_NULL_MAX * n0 + MG_NULL_MAX) * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&S->mg_dot, ((1 + MG_NULL_MAX) * MG_DOT_BLOCKS + 2) * sizeof(double)));      // per-workgroup partials of x_0 . rhs_0 and of the gauge sums, then the tickets of k_mg_up and k_mg_down
+  HIPCHK(hipMemset(S->mg_dot, 0, ((1 + MG_NULL_MAX) * MG_DOT_BLOCKS + 2) * sizeof(double)));
   S->hbm_bytes += (9 * S->mg_cells + 2 * S->mg_cells + (size_t)MG_NULL_MAX * S->mg_cells) * sizeof(double) + 9 * n0 * 8 + (S->chunk_cap + 64) * MG_PART * sizeof(double);
   return EULER_OK;
 }
 void eu_mg_release(euler_sim* S) {
-  for (double* d : {S->mg_a, S->mg_rhs, S->mg_part, S->mg_dot, S->mg_xbuf, S->mg_null0}) if (d) (void)hipFree(d);
+  for (double* d : {S->mg_a, S->mg_rhs, S->mg_part, S->mg_dot, S->mg_xbuf, S->mg_null0, S->mg_m0}) if (d) (void)hipFree(d);
   if (S->mg_a0i) (void)hipFree(S->mg_a0i);
-  S->mg_a = S->mg_rhs = S->mg_x = S->mg_part = S->mg_dot = S->mg_xbuf = S->mg_null0 = nullptr;
+  S->mg_a = S->mg_rhs = S->mg_x = S->mg_part = S->mg_dot = S->mg_xbuf = S->mg_null0 = S->mg_m0 = nullptr;
   S->mg_a0i = nullptr; S->mg_xslot = 0;
 }
 
@@ -534,8 +536,12 @@ struct MgUpArgs {
   int row_lo, row_hi;         // node rows of level 0 whose x . rhs this rank adds to dot(z, r) (row slabs: the own rows)
   PcgScalars* sc;
   int fin_op, force;
-  double* dot_part;
+  double* dot_part;           // [MG_DOT_BLOCKS] partials of x_0 . rhs_0, then [MG_NULL_MAX][MG_DOT_BLOCKS] partials of m_0 . x_0 (the gauge, below)
   unsigned int* ticket;
+  const double* nullv;        // k_coarse.hip's cc_null: [.. + MG_NULL_MAX * 256] = the number of fluid regions cut off from the air
+  const double* n0;           // [MG_NULL_MAX][nstride]: their indicators on the levels (level 0 first)
+  const double* m0;           // [MG_NULL_MAX][n_0]: P_0^T of their indicators on the cells; [MG_NULL_MAX * n_0 + q] = m_0 . n_0
+  size_t nstride;
 };
 #define MG_UP_THREADS 1024
 __device__ __forceinline__ MgRect mg_coarse_around(const MgRect& f, int cny, int cnx) {
@@ -551,6 +557,13 @@ __global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
   const MgHier& H = A.H;
   const int tid = threadIdx.x;
   const bool idle = !A.force && (A.sc->done || !A.sc->nonzero);      // read first, consulted last
+  // Water cut off from the air (rare): its pressure is determined up to a constant, PCG delivers the one with n . M p = 0 (M the preconditioner, n the region's indicator)
+  // and the reference's clamp (main.c:773-779) makes that constant observable.  The tile-local factor alone gives, like the reference's own, very nearly "mean 0 over the
+  // region"; the dense level's pseudo-inverse keeps that, the Jacobi steps of the levels in between do not - so the correction is made mean-free over the CELLS of every
+  // such region: x_0 -= n_0 (m_0 . x_0) / (m_0 . n_0).  The workgroups leave partials of m_0 . x_0, the last one folds them and corrects x_0 (oracle: mg_gauge).
+  const int n_null = (int)A.nullv[MG_NULL_MAX * 256];
+  const size_t n0n = (size_t)H.nx[0] * H.ny[0];
+  double gv[MG_NULL_MAX] = {0.0, 0.0, 0.0, 0.0};
   const int tiles_x = (H.nx[0] + A.tile - 1) / A.tile;
   const int ti = blockIdx.x / tiles_x, tj = blockIdx.x % tiles_x;
   MgRect own = {ti * A.tile, (ti + 1) * A.tile, tj * A.tile, (tj + 1) * A.tile};
@@ -604,7 +617,14 @@ __global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
       const double x2c = b2[(i - X2.i0) * w2 + (j - X2.j0)];
       const double xv = d != 0.0 ? x2c + MG_OMEGA * (rv - t) / d : 0.0;
       xo[e] = xv;
-      if (l == 0) { H.x[c] = xv; if (i >= A.row_lo && i < A.row_hi) dv += xv * rv; }
+      if (l == 0) {
+        if (n_null > 0) {
+          mg_st_agent(H.x + c, xv);
+#pragma unroll
+          for (int q = 0; q < MG_NULL_MAX; ++q) if (q < n_null) gv[q] += A.m0[(size_t)q * n0n + c] * xv;
+        } else H.x[c] = xv;
+        if (i >= A.row_lo && i < A.row_hi) dv += xv * rv;
+      }
     }
     __syncthreads();
   }
@@ -613,11 +633,27 @@ __global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
     for (int e = tid; e < mg_rn(own); e += MG_UP_THREADS) {
       const int i = own.i0 + e / w, j = own.j0 + e % w;
       const size_t c = (size_t)i * nx + j;
-      if (i >= A.row_lo && i < A.row_hi) dv += H.x[c] * H.rhs[c];
+      const double xv = n_null > 0 ? mg_ld_agent(H.x + c) : H.x[c];      // (written by the tail workgroup of the launch before)
+      if (i >= A.row_lo && i < A.row_hi) dv += xv * H.rhs[c];
+#pragma unroll
+      for (int q = 0; q < MG_NULL_MAX; ++q) if (q < n_null) gv[q] += A.m0[(size_t)q * n0n + c] * xv;
     }
   }
   if (idle) return;      // (after convergence the level arrays are dead; the scalar epilogue below must not run)
+  for (int q = 0; q < n_null && q < MG_NULL_MAX; ++q) {
+    double g = q == 0 ? gv[0] : q == 1 ? gv[1] : q == 2 ? gv[2] : gv[3];
+    g = eu_wave_sum(g);
+    __syncthreads();
+    if ((tid & 63) == 0) s_red[tid >> 6] = g;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int k = 0; k < MG_UP_THREADS / 64; ++k) t += s_red[k];
+      mg_st_agent(A.dot_part + (size_t)(1 + q) * MG_DOT_BLOCKS + blockIdx.x, t);
+    }
+  }
   dv = eu_wave_sum(dv);
+  __syncthreads();
   if ((tid & 63) == 0) s_red[tid >> 6] = dv;
   __syncthreads();
   if (tid == 0) {
@@ -629,6 +665,26 @@ __global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
   }
   __syncthreads();
   if (!s_last) return;
+  for (int q = 0; q < n_null && q < MG_NULL_MAX; ++q) {      // the gauge: every workgroup's x_0 is in memory (agent-scope stores, drained before the tickets)
+    double g = 0.0;
+    for (unsigned int k = tid; k < gridDim.x; k += MG_UP_THREADS) g += mg_ld_agent(A.dot_part + (size_t)(1 + q) * MG_DOT_BLOCKS + k);
+    g = eu_wave_sum(g);
+    __syncthreads();
+    if ((tid & 63) == 0) s_red[tid >> 6] = g;
+    __syncthreads();
+    double tot = 0.0;
+    for (int k = 0; k < MG_UP_THREADS / 64; ++k) tot += s_red[k];
+    const double mn = A.m0[(size_t)MG_NULL_MAX * n0n + q];
+    if (mn > 0.0) {
+      const double cq = tot / mn;
+      for (size_t c = tid; c < n0n; c += MG_UP_THREADS) {
+        const double nv = A.n0[(size_t)q * A.nstride + c];
+        if (nv != 0.0) mg_st_agent(H.x + c, mg_ld_agent(H.x + c) - nv * cq);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   double t = 0.0;
   for (unsigned int k = tid; k < gridDim.x; k += MG_UP_THREADS)
     t += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&A.dot_part[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -673,8 +729,8 @@ static int launch_mg_cycle(euler_sim* S, int fin_op, int force, bool gather) {
   const MgHier H = mg_hier(S);
   const int lC = mg_entry_level(S);
   if (S->mg_levels - 1 - lC > MG_TAIL_LEVELS) { eu_set_error("multilevel preconditioner: %d levels behind the entry level (at most %d)", S->mg_levels - 1 - lC, MG_TAIL_LEVELS); return EULER_EINVAL; }
-  unsigned int* tick_down = reinterpret_cast<unsigned int*>(S->mg_dot + MG_DOT_BLOCKS + 1);
-  unsigned int* tick_up = reinterpret_cast<unsigned int*>(S->mg_dot + MG_DOT_BLOCKS);
+  unsigned int* tick_down = reinterpret_cast<unsigned int*>(S->mg_dot + (1 + MG_NULL_MAX) * MG_DOT_BLOCKS + 1);
+  unsigned int* tick_up = reinterpret_cast<unsigned int*>(S->mg_dot + (1 + MG_NULL_MAX) * MG_DOT_BLOCKS);
   int lA = 0;
   bool first = true;
   do {
@@ -708,6 +764,7 @@ static int launch_mg_cycle(euler_sim* S, int fin_op, int force, bool gather) {
     U.H = H; U.lC = lC; U.tile = 32; U.cap = 36 * 36;
     U.row_lo = 0; U.row_hi = S->mg_ny[0];
     U.sc = S->sc; U.fin_op = fin_op; U.force = force; U.dot_part = S->mg_dot; U.ticket = tick_up;
+    U.nullv = S->cc_null; U.n0 = S->mg_null0; U.m0 = S->mg_m0; U.nstride = S->mg_cells;
     const unsigned nblk = (unsigned)(((S->mg_nx[0] + 31) / 32) * ((S->mg_ny[0] + 31) / 32));
     if (nblk > MG_DOT_BLOCKS) { eu_set_error("multilevel preconditioner: %u tiles of level 0 (at most %d)", nblk, MG_DOT_BLOCKS); return EULER_EINVAL; }
     const size_t lds = 3 * (size_t)U.cap * sizeof(double);
@@ -783,5 +840,62 @@ __global__ __launch_bounds__(256) void k_mg_add_row(double* __restrict__ row, co
 }
 int eu_mg_add_row(euler_sim* S, double* row, int yrow) {
   LAUNCH(S, KC_UPDATE_SEARCH, k_mg_add_row, dim3((S->X + 255) / 256), dim3(256), row, S->mg_x, S->X, yrow, S->mg_nx[0], S->mg_ny[0], S->sc);
+  return EULER_OK;
+}
+
+// ------------------------------------------------------------------------------------------ water cut off from the air: what the gauge of k_mg_up needs, per solve
+// m_0[q] = P_0^T (the indicator of region q on the cells): a cell's four weights (multiples of 1 / 256: integer atomics, exact) where the level-0 indicator, sampled
+// through P_0, says "inside"; then m_0 . n_0.  Both kernels return at once when no region is cut off (the usual case).
+__global__ __launch_bounds__(256) void k_mg_null_mass(const uint8_t* __restrict__ mask, SkewGeom g, size_t e_lo, size_t e_cnt, const double* __restrict__ nullv, const double* __restrict__ n0,
+                                                      size_t nstride, int nx0, int ny0, unsigned long long* __restrict__ acc, const PcgScalars* sc) {
+  const int count = (int)nullv[MG_NULL_MAX * 256];
+  if (!sc->nonzero || count <= 0) return;
+  const size_t n0n = (size_t)nx0 * ny0;
+  for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < e_cnt; k += (size_t)gridDim.x * 256) {
+    const size_t e = e_lo + k;
+    if (!(mask[e] & CM_FLUID)) continue;
+    int band, t, l;
+    skew_decode(g, e, band, t, l);
+    const int x = t - l, y = band * 64 + l;
+    int jx0, jx1, jy0, jy1;
+    double fx, fy;
+    mg_cell_w(x, nx0, jx0, jx1, fx);
+    mg_cell_w(y, ny0, jy0, jy1, fy);
+    const int wx1 = (int)(fx * 16.0), wx0 = 16 - wx1, wy1 = (int)(fy * 16.0), wy0 = 16 - wy1;
+    for (int q = 0; q < MG_NULL_MAX && q < count; ++q) {
+      if (!(mg_interp0(n0 + (size_t)q * nstride, nx0, ny0, x, y) > 0.5)) continue;
+      unsigned long long* a = acc + (size_t)q * n0n;
+      if (wy0 * wx0) atomicAdd(&a[(size_t)jy0 * nx0 + jx0], (unsigned long long)(wy0 * wx0));
+      if (wy0 * wx1) atomicAdd(&a[(size_t)jy0 * nx0 + jx1], (unsigned long long)(wy0 * wx1));
+      if (wy1 * wx0) atomicAdd(&a[(size_t)jy1 * nx0 + jx0], (unsigned long long)(wy1 * wx0));
+      if (wy1 * wx1) atomicAdd(&a[(size_t)jy1 * nx0 + jx1], (unsigned long long)(wy1 * wx1));
+    }
+  }
+}
+__global__ __launch_bounds__(1024) void k_mg_null_finish(const unsigned long long* __restrict__ acc, const double* __restrict__ nullv, const double* __restrict__ n0, size_t nstride, size_t n0n,
+                                                         double* __restrict__ m0, const PcgScalars* sc) {
+  const int count = (int)nullv[MG_NULL_MAX * 256];
+  if (!sc->nonzero || count <= 0) return;
+  __shared__ double s_red[16];
+  const int q = blockIdx.x;
+  if (q >= count) { if (threadIdx.x == 0) m0[(size_t)MG_NULL_MAX * n0n + q] = 0.0; return; }
+  double t = 0.0;
+  for (size_t c = threadIdx.x; c < n0n; c += 1024) {
+    const double v = (double)acc[(size_t)q * n0n + c] * (1.0 / 256.0);
+    m0[(size_t)q * n0n + c] = v;
+    t += v * n0[(size_t)q * nstride + c];
+  }
+  t = eu_wave_sum(t);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) { double v = 0.0; for (int k = 0; k < 16; ++k) v += s_red[k]; m0[(size_t)MG_NULL_MAX * n0n + q] = v; }
+}
+int eu_mg_null_setup(euler_sim* S) {      // behind k_mg_null_prolong (k_coarse.hip: eu_launch_coarse_consistent)
+  if (S->has_comm) return EULER_OK;       // (row slabs: the regions' masses would have to be summed over the ranks - the gauge is left to PCG there)
+  const size_t n0n = (size_t)S->mg_nx[0] * S->mg_ny[0];
+  HIPCHK(hipMemsetAsync(S->mg_a0i, 0, MG_NULL_MAX * n0n * sizeof(unsigned long long), S->stream));      // (A_0's integer sums are converted by now: the array is scratch)
+  LAUNCH(S, KC_PRECON_FACTOR, k_mg_null_mass, dim3(eu_blocks(S->e_cnt, 256 * 8, 512)), dim3(256), S->cellmask, S->geom, S->e_lo, S->e_cnt, S->cc_null, S->mg_null0, S->mg_cells,
+         S->mg_nx[0], S->mg_ny[0], S->mg_a0i, S->sc);
+  LAUNCH(S, KC_PRECON_FACTOR, k_mg_null_finish, dim3(MG_NULL_MAX), dim3(1024), S->mg_a0i, S->cc_null, S->mg_null0, S->mg_cells, n0n, S->mg_m0, S->sc);
   return EULER_OK;
 }

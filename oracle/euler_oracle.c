@@ -697,13 +697,14 @@ static void coarse_correction(eo_sim* s, const double* r, double* z) {
  * solved exactly (dense_factor).  Round 3-4 used piecewise constants over the same blocks (aggregation, 5-point stencils with integer entries, correction scaled by 1.7):
  * 104 / 108 PCG iterations to 1e-6 on the 1024^2 / 2048^2 tank at rest, 109 on a 512^2 dam break at impact - the bilinear spaces need 52 / 52 / 64 (tools/r05/mg_proto.py). */
 typedef struct { int nx, ny; double* a[9]; double *rhs, *x, *t, *x1; } mg_level;
-typedef struct { int nlev; mg_level lv[20]; } mg_hierarchy;
+typedef struct { int nlev; mg_level lv[20]; int nnull; double* n0[4]; double* m0[4]; } mg_hierarchy;      /* n0 / m0: see mg_gauge */
 #define MG_OMEGA 0.8
 #define MG_TOP_MAX 64
 static void mg_free(eo_sim* s) {
   mg_hierarchy* h = (mg_hierarchy*)s->mg;
   if (!h) return;
   for (int l = 0; l < h->nlev; ++l) { free(h->lv[l].a[0]); free(h->lv[l].rhs); }
+  for (int q = 0; q < 4; ++q) { free(h->n0[q]); free(h->m0[q]); }
   free(h); s->mg = NULL;
 }
 static void mg_alloc_level(mg_level* L, int nx, int ny) {
@@ -858,6 +859,41 @@ static void mg_vcycle(eo_sim* s, mg_hierarchy* h, int l) {      /* lv[l].x = V_l
   for (int I = 0; I < L->ny; ++I)      /* Jacobi again */
     for (int J = 0; J < L->nx; ++J) { const size_t c = (size_t)I * L->nx + J; L->x[c] = d[c] != 0.0 ? L->t[c] + MG_OMEGA * (L->rhs[c] - mg_apply(L, L->t, I, J)) / d[c] : 0.0; }
 }
+static double* mg_null_level0(eo_sim* s, const double* nv);
+/* Water cut off from the air: its pressure is determined up to a constant, PCG delivers the one with n . M p = 0 (M the preconditioner, n the region's indicator) and the
+ * reference's clamp (main.c:773-779) makes that constant observable.  With the tile-local factor alone that is, like the reference's own, very nearly "p has mean 0 over the
+ * region"; the dense level's pseudo-inverse keeps it so, the Jacobi steps of the levels in between do not.  So the correction is made mean-free over the CELLS of every such
+ * region before it is added: x_0 -= n_0 (m_0 . x_0) / (m_0 . n_0), n_0 = the indicator on level 0, m_0 = P_0^T (the indicator on the cells). */
+static void mg_gauge(eo_sim* s, mg_hierarchy* h) {
+  const int np = s->coarse_npinned < 4 ? s->coarse_npinned : 4;
+  if (np == 0) return;
+  mg_level* L0 = &h->lv[0];
+  const size_t n = (size_t)L0->nx * L0->ny;
+  if (h->nnull != np || !h->n0[0]) {
+    for (int q = 0; q < 4; ++q) { free(h->n0[q]); free(h->m0[q]); h->n0[q] = h->m0[q] = NULL; }
+    for (int q = 0; q < np; ++q) {
+      h->n0[q] = mg_null_level0(s, s->coarse_null + (size_t)q * s->coarse_n);
+      h->m0[q] = (double*)calloc(n, sizeof(double));
+      for (int y = 0; y < s->Y; ++y)
+        for (int x = 0; x < s->X; ++x) {
+          if (!FLUID(s, y, x) || !(mg_interp0(L0, h->n0[q], x, y) > 0.5)) continue;
+          int jx[2], jy[2]; double fx, fy;
+          mg_w0(x, L0->nx, &jx[0], &jx[1], &fx);
+          mg_w0(y, L0->ny, &jy[0], &jy[1], &fy);
+          h->m0[q][(size_t)jy[0] * L0->nx + jx[0]] += (1.0 - fy) * (1.0 - fx);
+          h->m0[q][(size_t)jy[0] * L0->nx + jx[1]] += (1.0 - fy) * fx;
+          h->m0[q][(size_t)jy[1] * L0->nx + jx[0]] += fy * (1.0 - fx);
+          h->m0[q][(size_t)jy[1] * L0->nx + jx[1]] += fy * fx;
+        }
+    }
+    h->nnull = np;
+  }
+  for (int q = 0; q < np; ++q) {
+    double mx = 0.0, mn = 0.0;
+    for (size_t c = 0; c < n; ++c) { mx += h->m0[q][c] * L0->x[c]; mn += h->m0[q][c] * h->n0[q][c]; }
+    if (mn > 0.0) for (size_t c = 0; c < n; ++c) L0->x[c] -= h->n0[q][c] * (mx / mn);
+  }
+}
 static void mg_correction(eo_sim* s, const double* r, double* z) {
   const int X = s->X, Y = s->Y;
   if (!s->coarse_chol) coarse_factor(s);
@@ -877,6 +913,7 @@ static void mg_correction(eo_sim* s, const double* r, double* z) {
       L0->rhs[(size_t)jy[1] * L0->nx + jx[1]] += (fy * fx) * rv;
     }
   mg_vcycle(s, h, 0);
+  mg_gauge(s, h);
   for (int y = 0; y < Y; ++y)
     for (int x = 0; x < X; ++x)
       if (FLUID(s, y, x)) z[AT(s, y, x)] += mg_interp0(L0, L0->x, x, y);

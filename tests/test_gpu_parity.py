@@ -543,6 +543,84 @@ def test_baseline_size_1024_half_tank_bit_exact_vs_oracle():
     sim.close()
 
 
+def _compare_recorded(o, sim, what):
+    """compare_all for a trajectory whose frames may hold the arrays' digests only now and then (`every`): the counters always, the arrays where they are on file"""
+    from trajectories import same
+    for f, attr in ((ea.F_COUNT, "count"), (ea.F_PREV_COUNT, "prev_count"), (ea.F_MARKERS, "markers"), (ea.F_U, "u"), (ea.F_V, "v"), (ea.F_PRECON, "precon"), (ea.F_PRESSURE, "p")):
+        if o.has(attr):
+            a = sim.get(f)
+            same(a, o, attr, what + " " + attr)
+            del a
+    st = sim.stats()
+    assert st.n_markers == o.n_markers, what
+    assert st.rng_state == o.cur["rng_state"], what
+
+
+def test_configs2_8192_half_tank_one_substep_bit_exact_vs_recorded_oracle():
+    """BASELINE configs[2] AT ITS FULL SIZE against the pinned oracle, not through properties: 8192^2 half tank (67 M cells, 134 M markers), the reference's IC(0), the
+    reference's order of every sum (EULER_DOT_SEQUENTIAL), one substep = calculate_timestep + the whole of main.c:853-892 with 100 PCG iterations - count grids, the marker
+    array in order, u, v, g_precon and the pressure bit for bit.  The oracle's leg (19 minutes of one core, 7.5 GB) was run once in the build container and is on file as
+    digests (tests/golden/trajectories.json: half_tank_8192_ic0_substep; tests/golden/make_trajectories.py regenerates it)."""
+    from trajectories import oracle_for
+    o = oracle_for("half_tank_8192_ic0_substep")
+    sim = ea.Simulation(8192, 8192, dot_mode=ea.DOT_SEQUENTIAL, precond=ea.PRECOND_IC0).load_half_tank()
+    dt = sim.timestep(0.1)
+    sim.substep(dt)
+    o.substep(dt)
+    assert sim.stats().last_pcg_iterations == o.c.last_pcg_iterations == 100
+    _compare_recorded(o, sim, "8192^2 half tank, one substep")
+    sim.close()
+
+
+def test_roofline_mode_4096_half_tank_one_substep_bit_exact_vs_recorded_oracle():
+    """The roofline mode's preconditioner (tile-local IC(0), tiles of 16 records) at 4096^2, sequential sums, one substep of 100 iterations against the oracle's
+    restatement of it, bit for bit (trajectory half_tank_4096_tile_substep) - what the headline's kernels compute, pinned at a BASELINE size."""
+    from trajectories import oracle_for
+    o = oracle_for("half_tank_4096_tile_substep")
+    sim = ea.Simulation(4096, 4096, dot_mode=ea.DOT_SEQUENTIAL, precond=ea.PRECOND_IC0_TILE, tile_records=16).load_half_tank()
+    dt = sim.timestep(0.1)
+    sim.substep(dt)
+    o.substep(dt)
+    assert sim.stats().last_pcg_iterations == o.c.last_pcg_iterations == 100
+    _compare_recorded(o, sim, "4096^2 half tank, tile-local mode, one substep")
+    sim.close()
+
+
+def test_configs4_4096_waterfall_sources_firing_bit_exact_vs_recorded_oracle():
+    """BASELINE configs[4] at its full size: 4096^2 waterfall, the first six frames - 0.27 M source cells each appending a marker per substep (main.c:276-298: the RNG
+    stream, the append order), the sink column, every solve into the cap - free-running against the recorded oracle, every array bit for bit after every frame."""
+    from trajectories import oracle_for
+    o = oracle_for("waterfall_4096")
+    sim = ea.Simulation(4096, 4096, dot_mode=ea.DOT_SEQUENTIAL, precond=ea.PRECOND_IC0).load_text(scenarios_waterfall(), upscale=True)
+    n_before = sim.stats().n_markers
+    for f in range(6):
+        sim.step()
+        o.step()
+        st = sim.stats()
+        assert st.last_substeps == o.c.last_substeps and st.last_pcg_iterations == o.c.last_pcg_iterations, f
+        _compare_recorded(o, sim, "4096^2 waterfall frame %d" % f)
+    assert sim.stats().n_markers > n_before + 100000 and not sim.stats().source_exhausted
+    sim.close()
+
+
+def test_dam_break_2048_into_the_capped_phase_bit_exact_vs_recorded_oracle():
+    """configs[1] / [3]'s scenario at 2048^2 (5.2 M markers), 30 frames free-running: free fall with solves that converge in a few iterations or not at all, then six frames whose
+    solves all run into the reference's cap (4 substeps of 100 iterations) - counters every frame, every array on every sixth frame, bit for bit.  (The trajectory on file
+    holds 36 frames; the last six - five substeps each, all capped - add a minute of sequential-sum kernels and nothing new.)"""
+    from euler_amd import scenarios
+    from trajectories import oracle_for
+    o = oracle_for("dam_break_2048")
+    sim = ea.Simulation(2048, 2048, dot_mode=ea.DOT_SEQUENTIAL, precond=ea.PRECOND_IC0).load_text(scenarios.dam_break(), upscale=True)
+    for f in range(30):
+        sim.step()
+        o.step()
+        st = sim.stats()
+        assert st.last_substeps == o.c.last_substeps and st.last_pcg_iterations == o.c.last_pcg_iterations, (f, st.last_substeps, st.last_pcg_iterations)
+        _compare_recorded(o, sim, "2048^2 dam break frame %d" % f)
+    assert sim.stats().last_pcg_iterations == 400
+    sim.close()
+
+
 def test_full_size_4096_properties_without_an_oracle():
     """Size-independent properties at a size the CPU oracle cannot reach in test time (4096^2 half tank,
     tree dots, one frame = 100 PCG iterations over 16.8 M cells, 33 M markers):

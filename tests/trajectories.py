@@ -185,6 +185,9 @@ def same(got, o, attr, what, nan_class=False):
     if isinstance(o, Recorded):
         if digest(got, nan_class) == o.cur[attr]:
             return
+        if o.spec.get("big") and not os.environ.get("EULER_REPLAY_BIG"):      # (the live leg of these is minutes of CPU and gigabytes: not inside a test run)
+            raise AssertionError("%s: the GPU's array differs from the recorded oracle digest of trajectory %s, frame %d (EULER_REPLAY_BIG=1 replays the oracle live for the first differing entry)"
+                                 % (what, o.name, o.frame))
         assert_bits(got, getattr(o.live(), attr), what + " [recorded digest differs; live replay]", nan_class=nan_class)
         raise AssertionError("%s: the GPU's array matches the live oracle but not the recorded digest - regenerate tests/golden/trajectories.json" % what)
     assert_bits(got, getattr(o, attr), what, nan_class=nan_class)
