@@ -57,16 +57,17 @@ ITER_BYTES, PCG_BYTES = {}, {}
 def set_as_stored(stored, p_steps=8):
     """The byte table of the build's launches.  stored False (the default wherever this bench runs: tree dots, one GPU or compact ghost rows): A s' never goes to
     memory - k_search_apply reads s, z and writes s' (3w+1), plus p += alpha s of EIGHT iterations on every eighth pass (read p and the s of eight .. two
-    iterations ago, write p: 9w / 8 = 1.125w) -> 34.  stored True (sequential dots, mailboxes, EULER_TILE_STORE_AS=1): it also writes A s' -> 42, and the r update reads
-    that instead of s'.  p_steps N (mailboxes: 2; EULER_P_STEPS): p on every N-th pass, (N + 1) w / N -> 35 (4), 37 (2)."""
+    iterations ago, write p: 9w / 8 = 1.125w) -> 34.  stored True (sequential dots, mailboxes, EULER_OPT_TILE_STORE_AS): it also writes A s' -> 42, and the r update reads
+    that instead of s'.  p_steps N (mailboxes: 2; EULER_OPT_P_STEPS): p on every N-th pass, (N + 1) w / N -> 35 (4), 37 (2)."""
     apply_ = (4 if stored else 3) * W + 1 + (p_steps + 1.0) / p_steps * W
     ITER_BYTES.clear()
     ITER_BYTES.update({
         "ic0": {"forward_solve": _SWEEP, "backward_solve": _SWEEP, "apply_a": apply_, "update_pr": _RUPD},      # 109 (the reference's five loops: 18w+5 = 149; main.c as written: 212)
         "ic0_tile": {"apply_a": apply_, "precond_tile": _TILE},                                                   # 67
         "ic0_tile2": {"apply_a": apply_, "precond_tile": _TILE, "coarse_cycle": 0.0},
-        # multilevel: + the V-cycle: 8 doubles of partial sums per 16x64 tile written and read (0.125 B/cell) and the level arrays, 1/256 of a solver array each (~0.2 B/cell)
-        "ic0_tile_mg": {"apply_a": apply_, "precond_tile": _TILE, "coarse_cycle": 0.33},
+        # multilevel: + the V-cycle: 48 doubles of partial sums per 16x64 tile written and read (0.75 B/cell) and the node grids - a node per 256 cells, per node nine stencil
+        # entries read on the way down and again on the way up + right-hand side / result (~190 B per node of level 0, a third more for the levels above: ~1.0 B/cell)
+        "ic0_tile_mg": {"apply_a": apply_, "precond_tile": _TILE, "coarse_cycle": 1.75},
         "jacobi": {"apply_a": apply_, "update_pr": _RUPD, "jacobi": 2 * W + 1, "dot": 2 * W + 1},
     })
     PCG_BYTES.clear()
@@ -81,7 +82,7 @@ KERNEL_OF_CLASS = {"forward_solve": "k_sweep_skew<1", "backward_solve": "k_sweep
 MODE_NAME = {"ic0": "parity mode: the reference's IC(0), bit-identical iterates",
              "ic0_tile": "roofline mode: tile-local IC(0) (64x%d-cell blocks), NOT the reference's iterates (tolerance parity where PCG converges)",
              "ic0_tile2": "two-level mode: tile-local IC(0) (64x%d-cell blocks) + a coarse correction (<= 256 aggregates, dense inverse), NOT the reference's iterates",
-             "ic0_tile_mg": "multilevel mode: tile-local IC(0) (64x%d-cell blocks) + one V-cycle over aggregates of 16, 32, ... cells with a dense top level, NOT the reference's iterates",
+             "ic0_tile_mg": "multilevel mode: tile-local IC(0) (64x%d-cell blocks) + one V-cycle over node grids of 16, 32, ... cells spacing (bilinear interpolation, nine-point Galerkin stencils, dense top level), NOT the reference's iterates",
              "jacobi": "Jacobi stand-in, NOT the reference's iterates"}
 TILE_MODES = ("ic0_tile", "ic0_tile2", "ic0_tile_mg")
 
@@ -592,7 +593,7 @@ def summarize(t, size_x, size_y, precond, tile_w, traffic, traffic_note, steps, 
         agg = {"us_per_iteration": round(1e3 * t["per_iter_ms"], 2), "bytes_per_cell_iteration": round(bpc, 2),
                "classes": {k: rows[k]["bytes_per_cell"] for k in per_iter},
                "complete": set(per_iter) == set(ITER_BYTES[precond]),      # every per-iteration class of the mode was timed
-               "launches_per_iteration": len(per_iter),      # (coarse_cycle: one class, 12 small launches in the multilevel mode)
+               "launches_per_iteration": len(per_iter),      # (coarse_cycle: one class, three launches in the multilevel mode)
                "GBps_active": round(bpc * fluid / sec / 1e9, 1), "frac_active": round(bpc * fluid / sec / 1e9 / HBM_PEAK_GBPS, 4),
                "GBps_traffic": round(tsum / sec / 1e9, 1) if tsum else None,
                "frac_traffic": round(tsum / sec / 1e9 / HBM_PEAK_GBPS, 4) if tsum else None,
@@ -1195,8 +1196,7 @@ def main():
     from euler_amd import scenarios
 
     dot_mode = ea.DOT_TREE if args.dot_mode == "tree" else ea.DOT_SEQUENTIAL
-    set_as_stored(args.dot_mode != "tree" or bool(args.p2p) or os.environ.get("EULER_TILE_STORE_AS", "0") not in ("", "0"),
-                  2 if (args.p2p or os.environ.get("EULER_P_STEPS") == "2") else 4 if os.environ.get("EULER_P_STEPS") == "4" else 8)      # which launches this run makes (k_pcg.hip tile_recompute, p_steps)
+    set_as_stored(args.dot_mode != "tree" or bool(args.p2p), 2 if args.p2p else 8)      # which launches this run makes (k_pcg.hip tile_recompute, p_steps; the handles keep euler_set_option's defaults)
     PC = {"ic0": ea.PRECOND_IC0, "jacobi": ea.PRECOND_JACOBI, "ic0_tile": ea.PRECOND_IC0_TILE, "ic0_tile2": ea.PRECOND_IC0_TILE2, "ic0_tile_mg": ea.PRECOND_IC0_TILE_MG}
     tile_w = args.tile_records or 16
     # N > 1 (weak scaling): the grid grows to N x (N * gpus) rows; the pressure solve is split into one

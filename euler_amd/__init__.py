@@ -16,6 +16,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libeuler_hip.so")
 # --- enums of include/euler.h ------------------------------------------------------------------
 DOT_AUTO, DOT_SEQUENTIAL, DOT_TREE = 0, 1, 2
 PRECOND_IC0, PRECOND_JACOBI, PRECOND_IC0_TILE, PRECOND_IC0_TILE2, PRECOND_IC0_TILE_MG = 0, 1, 2, 3, 4
+(OPT_P_STEPS, OPT_TILE_STORE_AS, OPT_TILE_REVERSE, OPT_RESIDENT_CAP, OPT_GRID4_MIN_CELLS, OPT_SLAB_FUSION, OPT_RCCL_SMALL, OPT_RCCL_NO_EXCHANGE, OPT_MARKERS_ROWMAJOR,
+ OPT_SA_RUN, OPT_NO_INTERIOR, OPT_BUILD_GATHER, OPT_RESIDENT_FORCE_TIMEOUT, OPT_ONE_EXCHANGE) = range(1, 15)      # include/euler.h EULER_OPT_*
 SWEEP_AUTO, SWEEP_BAND, SWEEP_SIMPLE = 0, 1, 2
 PCG_F64, PCG_F32 = 0, 1
 RESIDENT_AUTO, RESIDENT_OFF = 0, 1
@@ -76,6 +78,7 @@ EXPORTS = [
     "euler_measure_copy_bandwidth", "euler_measure_exchange", "euler_device_name", "euler_hbm_bytes", "euler_sweep_timeline", "euler_save_state", "euler_load_state", "euler_set_comm", "euler_set_stream", "euler_slab_info",
     "euler_rccl_unique_id", "euler_rccl_version", "euler_set_comm_rccl", "euler_comm_calls",
     "euler_p2p_export", "euler_p2p_connect", "euler_p2p_disconnect", "euler_p2p_calls", "euler_resident_info",
+    "euler_set_option", "euler_get_option",
 ]
 
 
@@ -144,6 +147,8 @@ def load_library():
         "euler_p2p_connect": (C.c_int, [vp, vp, i32]),
         "euler_p2p_disconnect": (C.c_int, [vp]),
         "euler_p2p_calls": (C.c_int, [vp, C.POINTER(u64)]),
+        "euler_set_option": (C.c_int, [vp, i32, C.c_int64]),
+        "euler_get_option": (C.c_int, [vp, i32, C.POINTER(C.c_int64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)   # AttributeError here = a symbol include/euler.h declares is not exported
@@ -388,6 +393,16 @@ class Simulation:
 
     def set_rng(self, state, exhausted=0):
         _check(self.L.euler_set_rng(self.h, int(state), int(exhausted)))
+
+    def set_option(self, key, value):
+        """include/euler.h EULER_OPT_*: a per-handle option (what used to be an EULER_* environment variable)"""
+        _check(self.L.euler_set_option(self.h, int(key), C.c_int64(int(value))))
+        return self
+
+    def get_option(self, key):
+        v = C.c_int64(0)
+        _check(self.L.euler_get_option(self.h, int(key), C.byref(v)))
+        return int(v.value)
 
     def resident_info(self):
         """(eligible, solves run by the resident solver, solves that fell back to the multi-kernel path)"""

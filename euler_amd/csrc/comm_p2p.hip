@@ -305,12 +305,11 @@ extern "C" int euler_p2p_connect(euler_sim* S, const void* handles, int32_t nran
     p->nb_sb[side] = p->nb_base[side][2] ? static_cast<double*>(p->nb_base[side][2]) + EU_SKEW_SLACK : nullptr;
   }
   // The fusion changes which exchanges a rank performs, so it must be all ranks or none: agree over the mailboxes
-  // (just proven).  OPT-IN: only with EULER_SLAB_FUSION=1 in every rank's environment.  The fused kernel reads the
+  // (just proven).  OPT-IN: only with EULER_OPT_SLAB_FUSION set on every rank's handle.  The fused kernel reads the
   // neighbours' coarse-grained arrays across GPUs (write-through stores + system-scope loads); that has only ever run with
   // several processes on ONE device, so until a node run has validated it the ghost-row path is the default.
   {
-    const char* e = getenv("EULER_SLAB_FUSION");
-    const double mine_ok = (p->have_arrays && e && e[0] == '1') ? 1.0 : 0.0;
+    const double mine_ok = (p->have_arrays && S->opt[EULER_OPT_SLAB_FUSION] == 1) ? 1.0 : 0.0;
     double sum = 0.0;
     HIPCHK(hipMemcpyAsync(probe, &mine_ok, 8, hipMemcpyHostToDevice, S->stream));
     hipLaunchKernelGGL(k_p2p_allreduce, dim3(1), dim3(64), 0, S->stream, S->sc, probe, 0);

@@ -225,7 +225,7 @@ extern "C" int euler_set_comm_rccl(euler_sim* S, const void* unique_id, int32_t 
   RcclComm* c = static_cast<RcclComm*>(calloc(1, sizeof(RcclComm)));
   if (!c) return EULER_ENOMEM;
   c->S = S; c->rank = rank; c->n = nranks;
-  { const char* e = getenv("EULER_RCCL_SMALL"); c->small_by_allgather = !e ? 0 : (strcmp(e, "allgather") == 0 ? 1 : -1); }      // default: by size; "allgather" / anything else: always / never
+  c->small_by_allgather = S->opt[EULER_OPT_RCCL_SMALL] == 1 ? 1 : S->opt[EULER_OPT_RCCL_SMALL] == 2 ? -1 : 0;      // EULER_OPT_RCCL_SMALL: by size (default) / always ncclAllGather / never
   ncclUniqueId id;
   memcpy(&id, unique_id, sizeof id);
   HIPCHK(hipSetDevice(S->cfg.device));
@@ -235,7 +235,7 @@ extern "C" int euler_set_comm_rccl(euler_sim* S, const void* unique_id, int32_t 
   euler_comm_ops ops;
   ops.ctx = c; ops.rank = rank; ops.nranks = nranks;
   ops.allreduce = op_allreduce; ops.halo = op_halo; ops.chain = op_chain; ops.allgather = op_allgather;
-  ops.exchange = getenv("EULER_RCCL_NO_EXCHANGE") ? nullptr : op_exchange;   // (experiments: the same traffic as halo + all-gather)
+  ops.exchange = S->opt[EULER_OPT_RCCL_NO_EXCHANGE] ? nullptr : op_exchange;   // (experiments: the same traffic as halo + all-gather)
   rc = eu_install_comm(S, &ops, coupling, /*allow_single=*/1);
   if (rc) eu_rccl_release(S);
   return rc;

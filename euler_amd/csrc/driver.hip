@@ -139,8 +139,7 @@ static int eu_set_tiles(euler_sim* S, int w) {
 // the resident solver (k_resident.hip) can run this handle's solves: plain tile-local preconditioner, one GPU, tree dots, and EVERY chunk of the grid
 // finds a wave on the chip at once (so that no scene ever outgrows it)
 bool eu_resident_eligible(const euler_sim* S) {
-  static const bool env_off = getenv("EULER_RESIDENT") && atoi(getenv("EULER_RESIDENT")) == 0;      // (experiments / A-B timing)
-  if (env_off || S->res_disabled || S->cfg.resident == EULER_RESIDENT_OFF) return false;
+  if (S->res_disabled || S->cfg.resident == EULER_RESIDENT_OFF) return false;
   if (S->cfg.precond != EULER_PRECOND_IC0_TILE || S->tile_w != 16 || S->cfg.sweep_mode == EULER_SWEEP_SIMPLE || S->cfg.dot_mode != EULER_DOT_TREE) return false;
   if (S->has_comm || S->slab_on || S->p2p_on) return false;
   // double: a solve whose active chunks do not all fit takes the multi-kernel path (decided per solve, eu_launch_project); float has no other path, so
@@ -152,6 +151,34 @@ bool eu_resident_eligible(const euler_sim* S) {
 extern "C" int euler_resident_info(euler_sim* S, uint64_t out[3]) {
   if (!S || !out) return EULER_EINVAL;
   out[0] = eu_resident_eligible(S) ? 1 : 0; out[1] = S->res_solves; out[2] = S->res_fallbacks;
+  return EULER_OK;
+}
+
+// Per-handle options (include/euler.h EULER_OPT_*): validated here, read where they act.  A refused call changes nothing.
+extern "C" int euler_set_option(euler_sim* S, int32_t key, int64_t value) {
+  if (!S || key <= 0 || key >= EULER_OPT__COUNT) { eu_set_error("euler_set_option: unknown key %d", (int)key); return EULER_EINVAL; }
+  bool ok = true;
+  const char* when = nullptr;
+  switch (key) {
+    case EULER_OPT_P_STEPS: ok = value == 2 || value == 4 || value == 8; break;
+    case EULER_OPT_SA_RUN: ok = value == 8 || value == 16 || value == 32; break;
+    case EULER_OPT_RCCL_SMALL: ok = value >= 0 && value <= 2; if (S->rccl) when = "before euler_set_comm_rccl"; break;
+    case EULER_OPT_RCCL_NO_EXCHANGE: ok = value == 0 || value == 1; if (S->rccl) when = "before euler_set_comm_rccl"; break;
+    case EULER_OPT_SLAB_FUSION: ok = value == 0 || value == 1; if (S->p2p_on) when = "before euler_p2p_connect"; break;
+    case EULER_OPT_ONE_EXCHANGE: ok = value == 0 || value == 1; break;
+    case EULER_OPT_RESIDENT_CAP: case EULER_OPT_GRID4_MIN_CELLS: case EULER_OPT_RESIDENT_FORCE_TIMEOUT: ok = value >= 0; break;
+    default: ok = value == 0 || value == 1; break;
+  }
+  if (!ok) { eu_set_error("euler_set_option: key %d does not take the value %lld", (int)key, (long long)value); return EULER_EINVAL; }
+  if (when) { eu_set_error("euler_set_option: key %d must be set %s", (int)key, when); return EULER_ESTATE; }
+  HIPCHK(hipStreamSynchronize(S->stream));
+  S->opt[key] = value;
+  if (key == EULER_OPT_P_STEPS || key == EULER_OPT_SA_RUN) S->s_ring_n = 0;      // (the next solve sets its ring up afresh)
+  return EULER_OK;
+}
+extern "C" int euler_get_option(euler_sim* S, int32_t key, int64_t* value) {
+  if (!S || !value || key <= 0 || key >= EULER_OPT__COUNT) { eu_set_error("euler_get_option: unknown key %d", (int)key); return EULER_EINVAL; }
+  *value = S->opt[key];
   return EULER_OK;
 }
 
@@ -270,6 +297,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   }
 
   euler_sim* S = (euler_sim*)calloc(1, sizeof(euler_sim));
+  if (S) { S->opt[EULER_OPT_P_STEPS] = 8; S->opt[EULER_OPT_TILE_REVERSE] = 1; S->opt[EULER_OPT_GRID4_MIN_CELLS] = 1ll << 22; S->opt[EULER_OPT_SA_RUN] = 8; }      // (euler_set_option's defaults)
   if (!S) return EULER_ENOMEM;
   g_alloc_bytes = 0;
   S->cfg = *cfg;
@@ -361,10 +389,9 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   // skewed arrays carry EU_SKEW_SLACK zeroed elements in front (the backward sweep prefetches below record 0)
   // Every array starts EU_ARRAY_STAGGER bytes further into its allocation than the one before: eight arrays of the same size, allocated back to
   // back, otherwise sit at the same offset modulo every power of two, and the four to six streams a PCG pass reads and writes at the same
-  // element index land in the same HBM channel at the same time (EULER_ARRAY_STAGGER overrides, in bytes; 0 = round 2's placement)
+  // element index land in the same HBM channel at the same time (EU_ARRAY_STAGGER, bytes; measured in rounds 2-4: 0 .. 1 MB make no difference on this chip)
   {
-    static const char* e = getenv("EULER_ARRAY_STAGGER");
-    const size_t stagger = (e ? (size_t)atol(e) : (size_t)EU_ARRAY_STAGGER) / 8 * 8;
+    const size_t stagger = (size_t)EU_ARRAY_STAGGER / 8 * 8;
     int k = 0;
     for (double** d : {&S->b, &S->p, &S->r, &S->z, &S->s, &S->s2, &S->q, &S->precon}) {
       DALLOC(*d, SS + EU_SKEW_SLACK + 8 * stagger / 8);

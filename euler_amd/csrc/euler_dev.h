@@ -131,6 +131,7 @@ struct euler_sim {
   size_t C;
   hipStream_t stream;
   int loaded;
+  long long opt[16];      // euler_set_option (include/euler.h EULER_OPT_*), defaults set by euler_create
   int dot_mode_user;      // the dot mode the caller's configuration resolved to (the coarse modes force EULER_DOT_TREE while they are selected; leaving them restores this)
 
   // fields (main.c:64-73,96-97)

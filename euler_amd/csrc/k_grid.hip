@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void k_extrapolate4(float* u, float* v, const 
 int eu_launch_extrapolate(euler_sim* S) {
   // (a small grid has too few waves to hide the longer thread: 1024^2 extrapolates in 5.7 us a cell per thread, in 11.4 four per thread; 8192^2: 186 -> 79 us,
   // zero_bounds 217 -> 149 us)
-  static const size_t min_cells = getenv("EULER_GRID4_MIN_CELLS") ? (size_t)atoll(getenv("EULER_GRID4_MIN_CELLS")) : ((size_t)1 << 22);      // (tests: 0 selects the four-cell kernels on any grid)
+  const size_t min_cells = (size_t)S->opt[EULER_OPT_GRID4_MIN_CELLS];      // (EULER_OPT_GRID4_MIN_CELLS; tests: 0 selects the four-cell kernels on any grid)
   if ((S->X & 3) == 0 && (size_t)S->X * (S->row_hi - S->row_lo) >= min_cells) {
     dim3 grid4((S->X / 4 + 63) / 64, (S->row_hi - S->row_lo + 3) / 4);
     LAUNCH(S, KC_EXTRAPOLATE, k_extrapolate4, grid4, dim3(256), S->u, S->v, S->prev_count, S->count, S->X, S->Y, S->row_lo, S->row_hi);
@@ -540,7 +540,7 @@ int eu_launch_build_system(euler_sim* S, float dt) {
   HIPCHK(hipMemsetAsync(S->chunk_part, 0, S->chunk_cap + 64, S->stream));
   // the lean assembly needs every solve since the arrays were last written whole to have been a tile-mode solve of this handle
   const bool lean = eu_is_tile(S) && S->cfg.sweep_mode != EULER_SWEEP_SIMPLE && S->lean_ok;
-  static const bool gather = getenv("EULER_BUILD_GATHER") != nullptr;      // (experiments: the one-kernel diagonal gather of rounds 1-2)
+  const bool gather = S->opt[EULER_OPT_BUILD_GATHER] != 0;      // (experiments: the one-kernel diagonal gather of rounds 1-2)
   if (!gather) {
     const size_t win_off = (size_t)S->win_lo * S->X;
     LAUNCH(S, KC_BUILD_SYSTEM, k_cell_system, dim3(eu_blocks((size_t)S->X * (S->row_hi - S->row_lo), 256)), dim3(256), S->utmp, S->vtmp, S->count, S->solid, S->sys_m, S->sys_div,
@@ -562,7 +562,7 @@ int eu_launch_build_system(euler_sim* S, float dt) {
   // the ascending list of this solve's active chunks (k_search_apply, k_precond_tile)
   int rc = eu_ordered_select(S, S->chunk_bits, S->chunk_words, S->chunk_list, &S->sc->n_chunks);
   if (rc) return rc;
-  static const bool no_interior = getenv("EULER_NO_INTERIOR") != nullptr;      // (experiments: every chunk takes the general path)
+  const bool no_interior = S->opt[EULER_OPT_NO_INTERIOR] != 0;      // (experiments: every chunk takes the general path)
   if (!no_interior)
     LAUNCH(S, KC_BUILD_SYSTEM, k_mark_interior, dim3(eu_blocks(S->chunk_cap, 256)), dim3(256), S->chunk_list, S->sc, S->chunk_part);
   return eu_launch_band_ranges(S);

@@ -322,8 +322,8 @@ __global__ __launch_bounds__(256) void k_transpose_for_markers(const float* __re
     }
   }
 }
-static bool eu_markers_column_major(euler_sim* S) {      // (whole-grid handles; EULER_MARKERS_ROWMAJOR=1: the row-major kernels, for A-B timing)
-  static const bool off = getenv("EULER_MARKERS_ROWMAJOR") != nullptr;
+static bool eu_markers_column_major(euler_sim* S) {      // (whole-grid handles; EULER_OPT_MARKERS_ROWMAJOR: the row-major kernels, for A-B timing)
+  const bool off = S->opt[EULER_OPT_MARKERS_ROWMAJOR] != 0;
   if (off || S->slab_on || !S->uT) return false;
   LAUNCH(S, KC_MARKER_ADVECT, k_transpose_for_markers, dim3((S->X + 63) / 64, (S->Y + 63) / 64), dim3(256), S->u, S->v, S->count, S->solid, S->uT, S->vT, S->countT, S->solidT,
          S->X, S->Y, S->solidT_dirty);

@@ -22,7 +22,7 @@
 //   k_mg_up           from that level's result back to level 0: every workgroup owns a 32 x 32 tile of level 0 and recomputes the halos of the coarser levels it
 //                     needs (they shrink by two per level); its last workgroup folds x_0 . rhs_0 into dot(z, r) and applies the scalar epilogue
 //
-// The CPU restatement the tests check all of this against: oracle/euler_oracle.c mg_build / mg_vcycle (same formulas; sums in another order: agreement to rounding).
+// The CPU restatement the tests check all of this against: the test oracle's mg_build / mg_vcycle (same formulas; sums in another order: agreement to rounding).
 // No reference counterpart (the reference has ONE preconditioner, main.c:580-627).
 #include "euler_dev.h"
 #include "k_mg.h"
@@ -872,30 +872,40 @@ __global__ __launch_bounds__(256) void k_mg_null_mass(const uint8_t* __restrict_
     }
   }
 }
-__global__ __launch_bounds__(1024) void k_mg_null_finish(const unsigned long long* __restrict__ acc, const double* __restrict__ nullv, const double* __restrict__ n0, size_t nstride, size_t n0n,
-                                                         double* __restrict__ m0, const PcgScalars* sc) {
+__global__ __launch_bounds__(256) void k_mg_null_convert(const unsigned long long* __restrict__ acc, const double* __restrict__ nullv, size_t n, double* __restrict__ m0, const PcgScalars* sc) {
+  const int count = (int)nullv[MG_NULL_MAX * 256];
+  if (!sc->nonzero || count <= 0) return;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) m0[i] = (double)acc[i] * (1.0 / 256.0);
+}
+__global__ __launch_bounds__(1024) void k_mg_null_finish(const double* __restrict__ nullv, const double* __restrict__ n0, size_t nstride, size_t n0n, double* __restrict__ m0, const PcgScalars* sc) {
   const int count = (int)nullv[MG_NULL_MAX * 256];
   if (!sc->nonzero || count <= 0) return;
   __shared__ double s_red[16];
   const int q = blockIdx.x;
   if (q >= count) { if (threadIdx.x == 0) m0[(size_t)MG_NULL_MAX * n0n + q] = 0.0; return; }
   double t = 0.0;
-  for (size_t c = threadIdx.x; c < n0n; c += 1024) {
-    const double v = (double)acc[(size_t)q * n0n + c] * (1.0 / 256.0);
-    m0[(size_t)q * n0n + c] = v;
-    t += v * n0[(size_t)q * nstride + c];
-  }
+  for (size_t c = threadIdx.x; c < n0n; c += 1024) t += m0[(size_t)q * n0n + c] * n0[(size_t)q * nstride + c];
   t = eu_wave_sum(t);
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = t;
   __syncthreads();
   if (threadIdx.x == 0) { double v = 0.0; for (int k = 0; k < 16; ++k) v += s_red[k]; m0[(size_t)MG_NULL_MAX * n0n + q] = v; }
 }
 int eu_mg_null_setup(euler_sim* S) {      // behind k_mg_null_prolong (k_coarse.hip: eu_launch_coarse_consistent)
-  if (S->has_comm) return EULER_OK;       // (row slabs: the regions' masses would have to be summed over the ranks - the gauge is left to PCG there)
   const size_t n0n = (size_t)S->mg_nx[0] * S->mg_ny[0];
+  if (S->has_comm) {
+    // row slabs: a region's cells lie on several ranks, so m_0 is a sum over the ranks - an all-reduce of 4 n_0 doubles that only a job with a cut-off region needs.  Whether
+    // there is one is the same on every rank (the dense level is replicated): one host round trip per solve decides (row-slab handles only)
+    double cnt = 0.0;
+    HIPCHK(hipMemcpyAsync(&cnt, S->cc_null + MG_NULL_MAX * 256, sizeof(double), hipMemcpyDeviceToHost, S->stream));
+    HIPCHK(hipStreamSynchronize(S->stream));
+    if (!(cnt > 0.0)) return EULER_OK;
+  }
   HIPCHK(hipMemsetAsync(S->mg_a0i, 0, MG_NULL_MAX * n0n * sizeof(unsigned long long), S->stream));      // (A_0's integer sums are converted by now: the array is scratch)
   LAUNCH(S, KC_PRECON_FACTOR, k_mg_null_mass, dim3(eu_blocks(S->e_cnt, 256 * 8, 512)), dim3(256), S->cellmask, S->geom, S->e_lo, S->e_cnt, S->cc_null, S->mg_null0, S->mg_cells,
          S->mg_nx[0], S->mg_ny[0], S->mg_a0i, S->sc);
-  LAUNCH(S, KC_PRECON_FACTOR, k_mg_null_finish, dim3(MG_NULL_MAX), dim3(1024), S->mg_a0i, S->cc_null, S->mg_null0, S->mg_cells, n0n, S->mg_m0, S->sc);
+  LAUNCH(S, KC_PRECON_FACTOR, k_mg_null_convert, dim3((unsigned)((MG_NULL_MAX * n0n + 255) / 256)), dim3(256), S->mg_a0i, S->cc_null, MG_NULL_MAX * n0n, S->mg_m0, S->sc);
+  if (S->has_comm) COMM_CALL(S->bulk.allreduce(S->bulk.ctx, S->mg_m0, (int32_t)(MG_NULL_MAX * n0n), 0));      // (multiples of 1 / 256: exact in any order)
+  LAUNCH(S, KC_PRECON_FACTOR, k_mg_null_finish, dim3(MG_NULL_MAX), dim3(1024), S->cc_null, S->mg_null0, S->mg_cells, n0n, S->mg_m0, S->sc);
   return EULER_OK;
 }

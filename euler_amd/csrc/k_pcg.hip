@@ -1963,11 +1963,10 @@ static int launch_dot(euler_sim* S, const double* a, const double* b, int fin_op
 static inline bool tile_fused(const euler_sim* S) { return eu_is_tile(S) && S->cfg.sweep_mode != EULER_SWEEP_SIMPLE; }
 // A s' never goes to memory: k_search_apply leaves it out and the r update (k_precond_tile<16, true>) forms it again from s' (the same bits).
 // Not where somebody else reads the array - the sequential replay of dot(s, A s) - nor where the rows across a slab boundary are not at hand:
-// the mailbox configurations (comm_p2p.hip) and the reference's IC(0) on several ranks.  EULER_TILE_STORE_AS=1 restores the stored form.
+// the mailbox configurations (comm_p2p.hip) and the reference's IC(0) on several ranks.  EULER_OPT_TILE_STORE_AS restores the stored form.
 static inline int sa_run(const euler_sim* S);
 static inline bool tile_recompute(const euler_sim* S) {
-  static const int stored = getenv("EULER_TILE_STORE_AS") ? atoi(getenv("EULER_TILE_STORE_AS")) : 0;
-  if (stored || sa_run(S) != 8) return false;
+  if (S->opt[EULER_OPT_TILE_STORE_AS] || sa_run(S) != 8) return false;
   if (!tile_fused(S)) return !S->has_comm && S->cfg.dot_mode != EULER_DOT_SEQUENTIAL;      // (the r update of the other modes is this kernel's first half)
   if (S->tile_w != 16) return false;
   if (S->has_comm) return ghost_mode(S);
@@ -1994,8 +1993,8 @@ static TileArgs make_tile_args(euler_sim* S, int force) {
   a.table = S->tile_table;
   a.zsend_lo = a.zsend_hi = nullptr; a.edge_lo = a.edge_hi = -1;
   // descending: k_search_apply walks the chunks upwards, so this pass starts on what the Infinity Cache still holds of it - and ends
-  // where the next k_search_apply starts.  8192^2: 548 -> 536 us per iteration (EULER_TILE_REVERSE=0 restores the ascending order)
-  { static const int rev = getenv("EULER_TILE_REVERSE") ? atoi(getenv("EULER_TILE_REVERSE")) : 1; a.reverse = rev; }
+  // where the next k_search_apply starts.  8192^2: 548 -> 536 us per iteration (EULER_OPT_TILE_REVERSE 0 restores the ascending order)
+  a.reverse = S->opt[EULER_OPT_TILE_REVERSE] != 0;
   a.cpart = nullptr; a.cshift = 0; a.cmode = 0; a.cnx = a.cny = 0;
   a.gs_lo = a.gs_hi = nullptr;
   if (ghost_mode(S)) {
@@ -2149,8 +2148,7 @@ static inline unsigned sa_blocks(const euler_sim* S, int run) {   // one wave pe
   return eu_blocks(runs, SA_THREADS / 64, 2048);
 }
 static inline int sa_run(const euler_sim* S) {   // short runs while long ones would leave CUs without a wave
-  static const char* e = getenv("EULER_SA_RUN");      // (experiments)
-  if (e && !S->has_comm && !eu_is_two_level(S)) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32) return v; }
+  if (S->opt[EULER_OPT_SA_RUN] != 8 && !S->has_comm && !eu_is_two_level(S)) return (int)S->opt[EULER_OPT_SA_RUN];      // (experiments: 16, 32)
   // measured (same box, tile-local mode): 8192^2 - 8: 346 us, 16: 358, 32: 376 (113 / 134 / 185 VGPRs: occupancy beats the window's
   // two extra pair loads per run, which hit L2); 16384^2, scanning every run's masks - 8: 1412 us, 32: 1389; with the list of active
   // chunks (runs of 8 only) - 8: 1177 us, 32: 1401
@@ -2158,12 +2156,11 @@ static inline int sa_run(const euler_sim* S) {   // short runs while long ones w
 }
 // p += alpha s, N iterations at a time (k_search_apply PMODE N): 8 - the search directions turn through a ring of eight arrays, six of them allocated when the
 // first solve needs them (8192^2: 431 -> 421 us per iteration against 4, 473 -> 450 for 4 against 2); 2 (rounds 3-4: s and s2 alone) with the mailboxes, whose
-// peers map exactly those two, and with the experimental run lengths.  EULER_P_STEPS=2 / 4 select the shorter rings (the same bits: the fmadds of main.c:753
+// peers map exactly those two, and with the experimental run lengths.  EULER_OPT_P_STEPS 2 / 4 select the shorter rings (the same bits: the fmadds of main.c:753
 // are applied in their order either way).
 static inline int p_steps(const euler_sim* S) {
-  static const int env = getenv("EULER_P_STEPS") ? atoi(getenv("EULER_P_STEPS")) : 0;
   if (S->p2p_on || sa_run(S) != 8) return 2;
-  return env == 2 ? 2 : env == 4 ? 4 : 8;
+  return (int)S->opt[EULER_OPT_P_STEPS];
 }
 // the ring of this solve: [0], [1] = s, s2 as the solve finds them, then the extra arrays (zeroed once; like s and s2 they are only ever written on fluid cells)
 static int ring_begin(euler_sim* S) {
@@ -2273,6 +2270,7 @@ __global__ void k_pcg_reset(PcgScalars* sc, double tol, int max_iters) {
 // the all-gather of p before the (replicated) velocity update.
 int eu_launch_project(euler_sim* S, float dt) {
   S->s_launched = 0;      // (EULER_F_PCG_S: no multi-kernel iteration of this solve has run yet)
+  const PcgScalars prev_solve = *S->sc_host;      // (the previous solve's final scalars: a resident launch that has to be redone must not leave its own in their place)
   // the previous solve's final scalars are in sc_host by now (copied at its end, synced since)
   S->solve_iters[S->solve_seq & 255] = S->sc_host->nonzero ? S->sc_host->iters : -1;
   if (S->solve_seq > 0) { S->res_last_chunks = S->sc_host->n_chunks; S->res_have_last = 1; }      // (the resident solver's guess for this solve, below)
@@ -2320,12 +2318,15 @@ int eu_launch_project(euler_sim* S, float dt) {
         return EULER_OK;      // (sc_host is current)
       }
       *S->res_err = 0;
-      if (S->cfg.pcg_precision == EULER_PCG_F32) { eu_set_error(err == 2 ? "EULER_PCG_F32: the solve's active chunks do not fit the resident solver" : "the resident solver timed out and EULER_PCG_F32 has no other path"); return EULER_EHIP; }
+      if (S->cfg.pcg_precision == EULER_PCG_F32 && err == 2) { eu_set_error("EULER_PCG_F32: the solve's active chunks do not fit the resident solver"); return EULER_EHIP; }
+      // (a time-out on an EULER_PCG_F32 handle: this system and every later one are solved in DOUBLE by the multi-kernel path - the substep's markers have moved already,
+      // so failing here would leave the handle between two stages; euler_resident_info reports the fallback)
       if (err != 2) { S->res_fallbacks += 1; S->res_disabled = 1; }      // a wait ran out (the workgroups were not all resident - another process on the device?): the handle keeps to the multi-kernel path from here on
       // (error 2: more active chunks than fit - the scene grew; this system with the multi-kernel path: k_pcg_reset + the assembly again, written whole)
       S->solve_seq -= 1;
       S->lean_ok = 0;
       S->res_skip_once = 1;
+      *S->sc_host = prev_solve;      // (solve_iters[] and the look-ahead of the redo are the previous SOLVE's, not the aborted launch's)
       return eu_launch_project(S, dt);
     }
     // (too many active chunks last time: the multi-kernel path below; its final copy of the scalars keeps the count current)

@@ -47,6 +47,7 @@ struct ResArgs {
   int band_lo, max_iters;
   double tol;
   int* err;
+  int force_fail;              // test hook (EULER_OPT_RESIDENT_FORCE_TIMEOUT): give up at once with error word 1, as if a wait had run out
 };
 
 namespace eu_resident {
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(RS_THREADS, 2) void k_pcg_resident(ResArgs a) {    
   // the first (nch + 3) / 4 take part, the others leave at once; a solve that needs more than were launched raises error 2 ("does not fit") and nobody starts.
   const int nwg = (nch + RS_WAVES - 1) / RS_WAVES;
   if (nwg > (int)gridDim.x) { if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+  if (a.force_fail) { if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
   if ((int)blockIdx.x >= nwg) return;
   const int ci = blockIdx.x * RS_WAVES + wave;
   const bool act = ci < nch;
@@ -403,23 +405,24 @@ __global__ __launch_bounds__(RS_THREADS, 2) void k_pcg_resident(ResArgs a) {    
   }
 }
 
-int g_res_capacity[2] = {-1, -1};      // workgroups resident at once, per precision (one device kind per process)
+int g_res_capacity[16][2];             // workgroups resident at once, per device and precision (0 = not asked yet, -1 = cannot be used)
 }  // namespace eu_resident
 using namespace eu_resident;
 
 // how many workgroups of the resident kernel the device holds at once (0: cannot be used)
 int eu_resident_capacity(euler_sim* S, int f32) {
-  int& cap = g_res_capacity[f32 ? 1 : 0];
-  if (cap >= 0) return cap;
+  static int dummy[2];
+  int& cap = (S->cfg.device >= 0 && S->cfg.device < 16) ? g_res_capacity[S->cfg.device][f32 ? 1 : 0] : dummy[f32 ? 1 : 0];
+  const long long lim = S->opt[EULER_OPT_RESIDENT_CAP];      // (tests: a small capacity, so that a scene outgrows it)
+  if (cap != 0) { const int c = cap < 0 ? 0 : cap; return lim > 0 && lim < c ? (int)lim : c; }
   int per_cu = 0, cus = 0;
   hipError_t e = f32 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_resident<float>, RS_THREADS, 0)
                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_resident<double>, RS_THREADS, 0);
-  if (e != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, S->cfg.device) != hipSuccess) { cap = 0; return 0; }
+  if (e != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, S->cfg.device) != hipSuccess || per_cu * cus <= 0) { cap = -1; return 0; }
   if (per_cu > 3) per_cu = 3;      // (double: 2 by registers and LDS, float: 3)
   cap = per_cu * cus;
   if (cap > RS_MAX_WG) cap = RS_MAX_WG;
-  if (const char* e = getenv("EULER_RESIDENT_CAP")) { const int v = atoi(e); if (v > 0 && v < cap) cap = v; }      // (tests: a small capacity, so that a scene outgrows it)
-  return cap;
+  return lim > 0 && lim < cap ? (int)lim : cap;
 }
 
 // launch the whole solve; the caller has run k_pcg_reset + the assembly and knows n_chunks (> 0) and that the right-hand side is not all zero
@@ -428,6 +431,8 @@ int eu_launch_resident(euler_sim* S, unsigned int n_chunks) {      // n_chunks: 
   a.g = S->geom; a.mask = S->cellmask; a.b = S->b; a.p = S->p; a.r = S->r; a.pre = S->precon; a.zx = S->z; a.sx = S->s; a.list = S->chunk_list; a.sc = S->sc;
   a.gran = S->res_gran; a.tag0 = S->res_tag; a.band_lo = S->band_lo; a.max_iters = S->cfg.max_iterations; a.tol = S->cfg.tol; a.err = S->res_err;
   S->res_tag += 2ull * (unsigned long long)S->cfg.max_iterations + 4ull;
+  a.force_fail = 0;
+  if (S->opt[EULER_OPT_RESIDENT_FORCE_TIMEOUT] > 0) { a.force_fail = 1; S->opt[EULER_OPT_RESIDENT_FORCE_TIMEOUT] -= 1; }
   const unsigned nwg = (n_chunks + RS_WAVES - 1) / RS_WAVES;
   if (S->cfg.pcg_precision == EULER_PCG_F32) LAUNCH(S, KC_RESIDENT, k_pcg_resident<float>, dim3(nwg), dim3(RS_THREADS), a);
   else LAUNCH(S, KC_RESIDENT, k_pcg_resident<double>, dim3(nwg), dim3(RS_THREADS), a);

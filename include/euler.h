@@ -349,6 +349,29 @@ int euler_rccl_unique_id(void* id_out, int32_t cap);
 int euler_rccl_version(void);                                  /* NCCL-style version code, -1 if unavailable */
 int euler_set_comm_rccl(euler_sim* sim, const void* unique_id, int32_t id_bytes, int32_t rank, int32_t nranks,
                         int32_t coupling);
+/* Per-handle options (round 5): the forms and test hooks that used to be EULER_* environment variables read once per process.  Two handles of one process may
+ * differ.  euler_set_option validates the value and the moment (a key that shapes allocations or a communicator must be set before what it shapes exists) and leaves
+ * the handle untouched when it refuses; none of the keys changes a result's bits unless its line says so. */
+enum {
+  EULER_OPT_P_STEPS = 1,            /* 2, 4 or 8 (default): p += alpha s is applied N iterations at a time out of a ring of N search arrays (the fmadds of main.c:753 in their order: the same bits) */
+  EULER_OPT_TILE_STORE_AS = 2,      /* 1: k_search_apply stores A s' and the r update reads it back (round 3's form; the same bits); 0 (default): formed twice */
+  EULER_OPT_TILE_REVERSE = 3,       /* 0: k_precond_tile walks the chunk list upwards; 1 (default): downwards */
+  EULER_OPT_RESIDENT_CAP = 4,       /* > 0: the resident solver's capacity in workgroups, at most the device's own (tests: a scene that outgrows the chip); 0: the device's */
+  EULER_OPT_GRID4_MIN_CELLS = 5,    /* grids of at least this many cells run extrapolate / zero_bounds four cells per thread (default 2^22; the same bits) */
+  EULER_OPT_SLAB_FUSION = 6,        /* 1: with the mailboxes connected, read the neighbouring slabs' edge rows where they live (set on every rank, before euler_p2p_connect) */
+  EULER_OPT_RCCL_SMALL = 7,         /* the small all-gather inside the RCCL exchange: 0 by size (default), 1 always ncclAllGather, 2 always sends / receives (before euler_set_comm_rccl) */
+  EULER_OPT_RCCL_NO_EXCHANGE = 8,   /* 1: the built-in communicator without the fused exchange (halo + allgather instead: the same traffic; before euler_set_comm_rccl) */
+  EULER_OPT_MARKERS_ROWMAJOR = 9,   /* 1: the marker stages read the row-major grids (A-B timing; the same bits) */
+  EULER_OPT_SA_RUN = 10,            /* 8 (default), 16, 32: pair-records per wave of k_search_apply (experiments; plain tile-local / parity modes on one GPU only) */
+  EULER_OPT_NO_INTERIOR = 11,       /* 1: no constant-mask instantiation for interior chunks (experiments; the same bits) */
+  EULER_OPT_BUILD_GATHER = 12,      /* 1: the assembly as one diagonal gather (rounds 1-2; the same bits) */
+  EULER_OPT_RESIDENT_FORCE_TIMEOUT = 13, /* test hook: the next n resident launches give up at once as if a wait had run out (error word 1): the time-out path */
+  EULER_OPT_ONE_EXCHANGE = 14,      /* row slabs, tile-local mode: 1 = the Chronopoulos-Gear form of PCG - ONE exchange point per iteration instead of two (changes the bits: tolerance parity) */
+  EULER_OPT__COUNT
+};
+int euler_set_option(euler_sim* sim, int32_t key, int64_t value);
+int euler_get_option(euler_sim* sim, int32_t key, int64_t* value);
+
 int euler_comm_calls(euler_sim* sim, uint64_t out[5]);         /* built-in communicator: allreduce, halo, chain, allgather, exchange calls so far */
 
 /* Peer-to-peer mailboxes for the latency-bound exchanges (csrc/comm_p2p.hip): the three 8-byte all-reduces

@@ -31,6 +31,7 @@ def build(X, Y, workload):
 def main():
     X, Y, workload, frames, coupling = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
     p2p = len(sys.argv) > 6 and sys.argv[6] == "p2p"
+    fusion = "fusion" in sys.argv[6:]      # opt-in (euler_set_option EULER_OPT_SLAB_FUSION, on every rank's handle): read the neighbouring slabs' edge rows where they live
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
@@ -38,6 +39,8 @@ def main():
     sim = build(X, Y, workload)
     comm = TorchComm(sim, coupling)
     out = {"world": world, "bands": [comm.band_lo, comm.band_hi, comm.nbands], "frames": []}
+    if fusion:
+        sim.set_option(ea.OPT_SLAB_FUSION, 1)
     if p2p:   # scalar all-reduces and ghost rows over IPC mailboxes (here: several processes on one GPU)
         out["p2p_ok"] = attach_p2p(sim)
         out["p2p_error"] = sim._p2p_error

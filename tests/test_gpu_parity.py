@@ -884,40 +884,22 @@ def test_jacobi_stand_in_preconditioner_converges_to_the_same_pressure():
         sim.close()
 
 
-_GRID4_CODE = """
-import sys, json, hashlib
-import numpy as np
-import euler_amd as ea
-from euler_amd import scenarios
-out = {}
-for name, size, scn, frames, kw in (("waterfall", (320, 256), "waterfall", 40, {}), ("dam_break", (256, 384), "dam_break", 40, {}), ("rainbow", (192, 128), "waterfall", 25, dict(rainbow=True))):
-    s = ea.Simulation(size[0], size[1], **kw).load_text(getattr(scenarios, scn)(), upscale=True)
-    h = hashlib.sha1()
-    for f in range(frames):
-        s.step()
-        for fld in (ea.F_U, ea.F_V, ea.F_PRESSURE, ea.F_COUNT, ea.F_PREV_COUNT):
-            h.update(np.ascontiguousarray(s.get(fld)).tobytes())
-    h.update(np.ascontiguousarray(s.get(ea.F_MARKERS)).tobytes())
-    out[name] = [h.hexdigest(), int(s.stats().total_pcg_iterations)]
-print(json.dumps(out))
-"""
-
-
 @pytest.mark.gpu
 def test_four_cells_per_thread_stage_kernels_leave_the_same_bits():
     """extrapolate / zero_bounds (main.c:158-185, 822-832) run four cells per thread on large grids (k_extrapolate4 / k_zero_bounds4: word loads of the byte grids);
-    the bit-exact tests above run grids below that threshold, i.e. the cell-per-thread kernels.  EULER_GRID4_MIN_CELLS=0 selects the four-cell kernels on any grid
-    whose width is a multiple of 4: the same frames, the same bits in every field and the marker array (default dot mode: the reference's sequential order)."""
-    import json
-    import os
-    import subprocess
-    import sys
-    runs = []
-    for extra in ({}, {"EULER_GRID4_MIN_CELLS": "0"}):
-        env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), **extra)
-        out = subprocess.run([sys.executable, "-c", _GRID4_CODE], capture_output=True, text=True, env=env, timeout=600)
-        assert out.returncode == 0, out.stderr[-2000:]
-        runs.append(json.loads(out.stdout.strip().splitlines()[-1]))
-    assert runs[0] == runs[1], runs
-    assert all(v[1] > 100 for v in runs[0].values()), runs[0]
+    the bit-exact tests above run grids below that threshold, i.e. the cell-per-thread kernels.  EULER_OPT_GRID4_MIN_CELLS = 0 selects the four-cell kernels on any grid
+    whose width is a multiple of 4.  TWO HANDLES OF ONE PROCESS, one with the option and one without, step side by side: the same bits in every field and the marker
+    array after every frame (default dot mode: the reference's sequential order)."""
+    from euler_amd import scenarios
+    for name, size, scn, frames, kw in (("waterfall", (320, 256), "waterfall", 40, {}), ("dam_break", (256, 384), "dam_break", 40, {}), ("rainbow", (192, 128), "waterfall", 25, dict(rainbow=True))):
+        a = ea.Simulation(size[0], size[1], **kw).load_text(getattr(scenarios, scn)(), upscale=True)
+        b = ea.Simulation(size[0], size[1], **kw).load_text(getattr(scenarios, scn)(), upscale=True)
+        b.set_option(ea.OPT_GRID4_MIN_CELLS, 0)
+        assert a.get_option(ea.OPT_GRID4_MIN_CELLS) == 1 << 22 and b.get_option(ea.OPT_GRID4_MIN_CELLS) == 0
+        for f in range(frames):
+            a.step(); b.step()
+            for fld in (ea.F_U, ea.F_V, ea.F_PRESSURE, ea.F_COUNT, ea.F_PREV_COUNT, ea.F_MARKERS):
+                assert_bits(b.get(fld), a.get(fld), "%s frame %d field %d" % (name, f, fld))
+        assert a.stats().total_pcg_iterations == b.stats().total_pcg_iterations > 100
+        a.close(); b.close()
 

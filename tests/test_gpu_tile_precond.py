@@ -527,42 +527,31 @@ def test_set_precond_validates_before_it_changes_anything_and_restores_the_dot_m
         compare_all(o, sim, "parity mode after a detour through the multilevel mode, frame %d" % f)
 
 
-_AS_FORMS_CODE = """
-import sys, json, hashlib
-import numpy as np
-import euler_amd as ea
-from euler_amd import scenarios
-out = {}
-for name, pc, size, scn, frames in (("tile", ea.PRECOND_IC0_TILE, (448, 320), "dam_break", 45), ("mg", ea.PRECOND_IC0_TILE_MG, (384, 320), "dam_break", 45),
-                                    ("ic0", ea.PRECOND_IC0, (320, 448), "waterfall", 6), ("jacobi", ea.PRECOND_JACOBI, (257, 193), "waterfall", 6)):
-    s = ea.Simulation(size[0], size[1], dot_mode=ea.DOT_TREE, precond=pc, resident=ea.RESIDENT_OFF).load_text(getattr(scenarios, scn)(), upscale=True)
-    h = hashlib.sha1()
-    its = 0
-    for f in range(frames):
-        s.step()
-        its += s.stats().last_pcg_iterations
-        for fld in (ea.F_U, ea.F_V, ea.F_PRESSURE, ea.F_PCG_R, ea.F_PCG_Z, ea.F_PCG_S, ea.F_COUNT):
-            h.update(np.ascontiguousarray(s.get(fld)).tobytes())
-    out[name] = [h.hexdigest(), its]
-print(json.dumps(out))
-"""
-
-
 def test_a_s_formed_again_in_the_r_update_has_the_stored_forms_bits():
     """k_search_apply does not store A s' (one GPU, tree dots; row slabs with compact ghost rows): the r update - k_precond_tile<16, true>, in the tile-local modes
-    and as the other modes' r update - forms it again from s' with the same expression (main.c:679-691).  EULER_TILE_STORE_AS=1 restores the stored form.  Likewise
-    p += alpha s is applied eight iterations at a time out of a ring of eight search arrays (the fmadds of main.c:753 in their order); EULER_P_STEPS=2 restores the
-    two-array form, 4 a ring of four.  A few frames of four modes (resident solver off, so that the kernels in question run) leave the same bits in every field and
-    solver vector in all of them (run: the default; stored A s' with a ring of four; recomputed A s' with the two arrays)."""
-    import json
-    import os
-    import subprocess
-    import sys
-    runs = []
-    for extra in ({}, {"EULER_TILE_STORE_AS": "1", "EULER_P_STEPS": "4"}, {"EULER_P_STEPS": "2"}):
-        env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), **extra)
-        out = subprocess.run([sys.executable, "-c", _AS_FORMS_CODE], capture_output=True, text=True, env=env, timeout=600)
-        assert out.returncode == 0, out.stderr[-2000:]
-        runs.append(json.loads(out.stdout.strip().splitlines()[-1]))
-    assert runs[0] == runs[1] == runs[2], runs
-    assert all(v[1] > 50 for v in runs[0].values()), runs[0]      # the solves iterated
+    and as the other modes' r update - forms it again from s' with the same expression (main.c:679-691).  EULER_OPT_TILE_STORE_AS restores the stored form.  Likewise
+    p += alpha s is applied eight iterations at a time out of a ring of eight search arrays (the fmadds of main.c:753 in their order); EULER_OPT_P_STEPS = 2 restores the
+    two-array form, 4 a ring of four.  THREE HANDLES OF ONE PROCESS with different options (the default; stored A s' with a ring of four; recomputed A s' with the two
+    arrays) step side by side through a few frames of four modes (resident solver off, so that the kernels in question run): the same bits in every field and solver
+    vector after every frame."""
+    from euler_amd import scenarios
+    for name, pc, size, scn, frames in (("tile", ea.PRECOND_IC0_TILE, (448, 320), "dam_break", 45), ("mg", ea.PRECOND_IC0_TILE_MG, (384, 320), "dam_break", 45),
+                                        ("ic0", ea.PRECOND_IC0, (320, 448), "waterfall", 6), ("jacobi", ea.PRECOND_JACOBI, (257, 193), "waterfall", 6)):
+        sims = [ea.Simulation(size[0], size[1], dot_mode=ea.DOT_TREE, precond=pc, resident=ea.RESIDENT_OFF).load_text(getattr(scenarios, scn)(), upscale=True) for _ in range(3)]
+        sims[1].set_option(ea.OPT_TILE_STORE_AS, 1).set_option(ea.OPT_P_STEPS, 4)
+        sims[2].set_option(ea.OPT_P_STEPS, 2)
+        assert [s.get_option(ea.OPT_P_STEPS) for s in sims] == [8, 4, 2]
+        its = 0
+        for f in range(frames):
+            for s in sims:
+                s.step()
+            its += sims[0].stats().last_pcg_iterations
+            for fld in (ea.F_U, ea.F_V, ea.F_PRESSURE, ea.F_PCG_R, ea.F_PCG_Z, ea.F_PCG_S, ea.F_COUNT):
+                a = sims[0].get(fld)
+                assert_bits(sims[1].get(fld), a, "%s frame %d field %d: stored A s', ring of four" % (name, f, fld))
+                assert_bits(sims[2].get(fld), a, "%s frame %d field %d: two search arrays" % (name, f, fld))
+        assert its > 50, (name, its)      # the solves iterated
+        for s in sims:
+            s.close()
+    with pytest.raises(ea.EulerError):      # a refused option leaves the handle as it was
+        ea.Simulation(64, 64).set_option(ea.OPT_P_STEPS, 3)

@@ -43,8 +43,8 @@ def check_same_iterates(f, workload):
 
 def run_workers(nproc, X, Y, workload, frames, coupling, port, extra=(), fusion=False):
     env = dict(os.environ)
-    if fusion:      # opt-in: k_search_apply reading the neighbouring slabs' z / s through IPC mappings
-        env["EULER_SLAB_FUSION"] = "1"
+    if fusion:      # opt-in: k_search_apply reading the neighbouring slabs' z / s through IPC mappings - a per-handle option the worker sets on every rank
+        extra = list(extra) + ["fusion"]
     # (ranks started directly, tests/ranks.py: the environment torch.distributed.run gives them, without the launcher's two seconds per case)
     rc, out, err = ranks.launch(nproc, os.path.join(ROOT, "tests", "slab_worker.py"), [X, Y, workload, frames, coupling] + list(extra), port, env=env)
     assert rc == 0, (out[-1500:], err[-3000:])
