@@ -182,31 +182,34 @@ __device__ __forceinline__ double mg_w1(int Jc, int j, int fn, int cn) {
   if (j == 2 * Jc + 1) return Jc + 1 <= cn - 1 ? 0.5 : 1.0;      // (the last fine node, odd, without a node to its right: constant)
   return 0.0;
 }
-// A_(l+1) = P^T A_l P, a thread per node of level l + 1
+// A_(l+1) = P^T A_l P, a thread per node of level l + 1 and stencil entry: entry q of node (I, J) = sum over the fine nodes m under (I, J) and the fine nodes n under the
+// coarse neighbour (I, J) + q of w(m) A_l[m, n] w(n) - at most 3 x 3 x 3 x 3 terms, walked in a fixed order
 __global__ __launch_bounds__(256) void k_mg_coarsen(const double* __restrict__ af, int fnx, int fny, double* __restrict__ ac, int cnx, int cny, const PcgScalars* sc) {
   if (!sc->nonzero) return;
-  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int tid = blockIdx.x * 256 + threadIdx.x;
+  const int p = tid / 9, q = tid % 9;
   if (p >= cnx * cny) return;
-  const int I = p / cnx, J = p % cnx;
+  const int I = p / cnx, J = p % cnx, I2 = I + q / 3 - 1, J2 = J + q % 3 - 1;
   const size_t fn = (size_t)fnx * fny, cn = (size_t)cnx * cny;
-  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int dy = -1; dy <= 1; ++dy)
-    for (int dx = -1; dx <= 1; ++dx) {
-      const int mi = 2 * I + dy, mj = 2 * J + dx;
-      const double wM = mg_w1(I, mi, fny, cny) * mg_w1(J, mj, fnx, cnx);
-      if (wM == 0.0) continue;
-      const size_t m = (size_t)mi * fnx + mj;
-      for (int e = 0; e < 9; ++e) {
-        const double av = af[(size_t)e * fn + m];
-        if (av == 0.0) continue;
-        const int ni = mi + e / 3 - 1, nj = mj + e % 3 - 1;
-        for (int q = 0; q < 9; ++q) {
-          const double wN = mg_w1(I + q / 3 - 1, ni, fny, cny) * mg_w1(J + q % 3 - 1, nj, fnx, cnx);
-          if (wN != 0.0) acc[q] += wM * av * wN;
+  double acc = 0.0;
+  if (I2 >= 0 && I2 < cny && J2 >= 0 && J2 < cnx) {
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int mi = 2 * I + dy, mj = 2 * J + dx;
+        const double wM = mg_w1(I, mi, fny, cny) * mg_w1(J, mj, fnx, cnx);
+        if (wM == 0.0) continue;
+        const size_t m = (size_t)mi * fnx + mj;
+        for (int ey = -1; ey <= 1; ++ey) {
+          const double wy = mg_w1(I2, mi + ey, fny, cny);
+          if (wy == 0.0) continue;
+          for (int ex = -1; ex <= 1; ++ex) {
+            const double wN = wy * mg_w1(J2, mj + ex, fnx, cnx);
+            if (wN != 0.0) acc += wM * af[(size_t)((ey + 1) * 3 + ex + 1) * fn + m] * wN;
+          }
         }
       }
-    }
-  for (int q = 0; q < 9; ++q) ac[(size_t)q * cn + p] = acc[q];
+  }
+  ac[(size_t)q * cn + p] = acc;
 }
 
 // ------------------------------------------------------------------------------------------ per iteration: the cycle
@@ -240,11 +243,11 @@ __device__ __forceinline__ double mg_gather0(const double* __restrict__ part, in
     const int Gp = q == 0 ? I + 1 : (q == 3 ? I - 1 : I), h = q >> 1, rs = q & 1 ? 1 : 0;      // (I+1, low, 0), (I, low, 1), (I, high, 0), (I-1, high, 1)
     if (Gp < 4 * band_lo || Gp >= 4 * band_hi) continue;
     const int b = Gp >> 2, jp = Gp & 3;
-    const double* row = part + (size_t)(b - band_lo) * ntb * MG_PART + (2 * jp + h) * 6 + rs * 3;
+    const double* row = part + ((size_t)(b - band_lo) * MG_PART + (2 * jp + h) * 6 + rs * 3) * ntb;      // [band][slot][tile]
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const int k = J - c + jp + 1 + h;
-      if (k >= 0 && k < ntb) t = t + row[(size_t)k * MG_PART + c];
+      if (k >= 0 && k < ntb) t = t + row[(size_t)c * ntb + k];
     }
   }
   return t;
@@ -462,7 +465,11 @@ __global__ __launch_bounds__(MG_DOWN_THREADS) void k_mg_down(MgDownArgs A) {
   }
   __syncthreads();
   // ---- level transitions lA -> lA + 1 -> ... -> lB
+#ifdef MG_ABL_NO_TRANS
+  for (int l = A.lA; l < A.lA; ++l) {
+#else
   for (int l = A.lA; l < A.lB; ++l) {
+#endif
     const int cur = (l - A.lA) & 1;
     MgRect R, T, O, Rc, Tc, Oc;
     rects(l, R, T, O);
@@ -524,7 +531,9 @@ __global__ __launch_bounds__(MG_DOWN_THREADS) void k_mg_down(MgDownArgs A) {
   }
   __syncthreads();
   if (!s_last) return;
+#ifndef MG_ABL_NO_TAIL      // (timing experiments, WRONG results: tools/micro/variant_file.sh)
   mg_tail(A, lds);
+#endif
 }
 
 // up: x_l = x2 + omega (rhs - A x2) / d with x2 = the Jacobi step + P x_(l+1), for the levels below the tail's entry level down to 0.  A workgroup owns a tile of
@@ -543,7 +552,9 @@ struct MgUpArgs {
   const double* m0;           // [MG_NULL_MAX][n_0]: P_0^T of their indicators on the cells; [MG_NULL_MAX * n_0 + q] = m_0 . n_0
   size_t nstride;
 };
+#ifndef MG_UP_THREADS
 #define MG_UP_THREADS 1024
+#endif
 __device__ __forceinline__ MgRect mg_coarse_around(const MgRect& f, int cny, int cnx) {
   MgRect c = {f.i0 >> 1, ((f.i1 - 1) >> 1) + 2, f.j0 >> 1, ((f.j1 - 1) >> 1) + 2};
   if (c.i1 > cny) c.i1 = cny;
@@ -585,7 +596,11 @@ __global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
     __syncthreads();
   }
   double dv = 0.0;
+#ifdef MG_ABL_NO_UP
+  for (int l = -1; l >= 0; --l) {
+#else
   for (int l = A.lC - 1; l >= 0; --l) {
+#endif
     MgRect X, X2, Xc, X2c;
     rects(l, X, X2);
     rects(l + 1, Xc, X2c);
@@ -809,7 +824,7 @@ int eu_mg_setup(euler_sim* S) {
   // any order, so ONE all-reduce makes A_0 whole and bit-identical everywhere (per solve; only the rows at slab boundaries actually overlap)
   if (S->has_comm) COMM_CALL(S->bulk.allreduce(S->bulk.ctx, S->mg_a, (int32_t)(9 * n0), 0));
   for (int l = 1; l < S->mg_levels; ++l)
-    LAUNCH(S, KC_PRECON_FACTOR, k_mg_coarsen, dim3((unsigned)(((size_t)S->mg_nx[l] * S->mg_ny[l] + 255) / 256)), dim3(256), S->mg_a + 9 * S->mg_off[l - 1], S->mg_nx[l - 1], S->mg_ny[l - 1],
+    LAUNCH(S, KC_PRECON_FACTOR, k_mg_coarsen, dim3((unsigned)((9 * (size_t)S->mg_nx[l] * S->mg_ny[l] + 255) / 256)), dim3(256), S->mg_a + 9 * S->mg_off[l - 1], S->mg_nx[l - 1], S->mg_ny[l - 1],
            S->mg_a + 9 * S->mg_off[l], S->mg_nx[l], S->mg_ny[l], S->sc);
   return EULER_OK;
 }

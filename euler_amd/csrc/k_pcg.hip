@@ -443,11 +443,16 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
       // tb1 and Ja + 2 at record tb2 (aggregates of 16: three columns; of 64 and more: two); the lane's row decides the aggregate row
       double cy0 = 0.0, cy1 = 0.0, cy2 = 0.0, cy3 = 0.0, ce0 = 0.0, ce1 = 0.0, ce2 = 0.0, ce3 = 0.0;
       int ctb1 = 0x7fffffff, ctb2 = 0x7fffffff, cJb = 0;
+      (void)cJb;
       if (COARSE == 2) {
-        const int Ja = (2 * (P0 - 1) - lane - 8) >> 4;
-        cJb = Ja < 0 ? 0 : Ja;
+        // the lane's columns in the run and its window (records 2 (P0 - 1) .. 2 P1 + 1: 20 at most) lie between the node columns Jb .. Jb + 3; the column of record t lies between
+        // Jb and Jb + 1 up to record ctb1, between Jb + 1 and Jb + 2 up to ctb2, then between Jb + 2 and Jb + 3.  Nodes beyond the grid repeat the outermost one (constant there)
+        cJb = (2 * (P0 - 1) - lane - 8) >> 4;
+        ctb1 = 16 * (cJb + 1) + lane + 8; ctb2 = ctb1 + 16;
         const int row = (cref.band0 + lb) * 64 + lane;
-        const int c0 = cJb < cref.nx ? cJb : cref.nx - 1, c1 = cJb + 1 < cref.nx ? cJb + 1 : cref.nx - 1, c2 = cJb + 2 < cref.nx ? cJb + 2 : cref.nx - 1, c3 = cJb + 3 < cref.nx ? cJb + 3 : cref.nx - 1;
+        const int hi_ = cref.nx - 1;
+        const int c0 = cJb < 0 ? 0 : (cJb < hi_ ? cJb : hi_), c1 = cJb + 1 < 0 ? 0 : (cJb + 1 < hi_ ? cJb + 1 : hi_), c2 = cJb + 2 < 0 ? 0 : (cJb + 2 < hi_ ? cJb + 2 : hi_),
+                  c3 = cJb + 3 < 0 ? 0 : (cJb + 3 < hi_ ? cJb + 3 : hi_);
         int i0, i1;
         double fy;
         mg_cell_w(row, cref.ny, i0, i1, fy);
@@ -464,10 +469,8 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
         }
       }
       auto p0y = [&](int t, double a0, double a1, double a2, double a3) __attribute__((always_inline)) {      // (P_0 x_0) at the lane's column of record t, from a row's four node values
-        int j0, j1;
-        double f;
-        mg_cell_w(t - lane, cref.nx, j0, j1, f);
-        return mg_lerp_x(pick4(j0 - cJb, a0, a1, a2, a3), pick4(j1 - cJb, a0, a1, a2, a3), f);
+        const double f = (double)((t - lane - 8) & 15) * (1.0 / 16.0);
+        return mg_lerp_x(pick3(t, ctb1, ctb2, a0, a1, a2), pick3(t, ctb1, ctb2, a1, a2, a3), f);
       };
       if (COARSE == 1) {
         const int xa = 2 * (P0 - 1) - lane, Ja = (xa > 0 ? xa : 0) >> cref.shift;
@@ -1575,9 +1578,9 @@ __global__ __launch_bounds__(PT_THREADS, RECOMP ? PT_RECOMP_BLOCKS : 1) void k_p
         wy0 *= 1.0 / 256.0; wy1 *= 1.0 / 256.0;
         const double p00 = half_group_sum(wy0 * c0), p01 = half_group_sum(wy0 * c1), p02 = half_group_sum(wy0 * c2);
         const double p10 = half_group_sum(wy1 * c0), p11 = half_group_sum(wy1 * c1), p12 = half_group_sum(wy1 * c2);
-        if ((lane & 7) == 0) {
-          double* cp = a.cpart + (size_t)tile * 48 + (lane >> 3) * 6;
-          cp[0] = p00; cp[1] = p01; cp[2] = p02; cp[3] = p10; cp[4] = p11; cp[5] = p12;
+        if ((lane & 7) == 0) {      // slot-major per band, [band][slot][tile]: the gather of a node row reads consecutive tiles of one slot (coalesced), k_mg.hip mg_gather0
+          double* cp = a.cpart + ((size_t)(tile / ntb) * 48 + (lane >> 3) * 6) * ntb + k;
+          cp[0] = p00; cp[ntb] = p01; cp[2 * ntb] = p02; cp[3 * ntb] = p10; cp[4 * ntb] = p11; cp[5 * ntb] = p12;
         }
       } else if (W == 16 && CMODE == 1) {      // P^T r of this tile: cell (lane, record k W + j) sits in column k W + j - lane; at most three coarse columns per tile
         const int xl = k * W - 63, J0 = (xl > 0 ? xl : 0) >> a.cshift;
