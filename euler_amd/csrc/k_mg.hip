@@ -39,12 +39,13 @@ struct MgHier {
   const double* a;                 // stencils: level l at a + 9 * off[l], entry k of node c at [k * n_l + c]
   double* rhs;
   double* x;
+  const double* wd;                // omega / diagonal per node (0 where the node carries no fluid): the Jacobi steps multiply
 };
 static MgHier mg_hier(const euler_sim* S) {
   MgHier H;
   H.nl = S->mg_levels;
   for (int l = 0; l < MG_MAXLEV; ++l) { H.nx[l] = l < H.nl ? S->mg_nx[l] : 0; H.ny[l] = l < H.nl ? S->mg_ny[l] : 0; H.off[l] = l < H.nl ? (unsigned int)S->mg_off[l] : 0u; }
-  H.a = S->mg_a; H.rhs = S->mg_rhs; H.x = S->mg_x;
+  H.a = S->mg_a; H.rhs = S->mg_rhs; H.x = S->mg_x; H.wd = S->mg_wd;
   return H;
 }
 __device__ __forceinline__ const double* mg_sten(const MgHier& H, int l) { return H.a + 9 * (size_t)H.off[l]; }
@@ -63,24 +64,25 @@ int eu_mg_alloc(euler_sim* S) {
   const size_t n0 = (size_t)S->mg_nx[0] * S->mg_ny[0];
   HIPCHK(hipMalloc((void**)&S->mg_a, 9 * S->mg_cells * sizeof(double)));
   HIPCHK(hipMalloc((void**)&S->mg_a0i, 9 * n0 * sizeof(unsigned long long)));
-  HIPCHK(hipMalloc((void**)&S->mg_rhs, 2 * S->mg_cells * sizeof(double)));
-  S->mg_x = S->mg_rhs + S->mg_cells;
+  HIPCHK(hipMalloc((void**)&S->mg_rhs, 3 * S->mg_cells * sizeof(double)));
+  S->mg_x = S->mg_rhs + S->mg_cells; S->mg_wd = S->mg_rhs + 2 * S->mg_cells;
   HIPCHK(hipMalloc((void**)&S->mg_part, (S->chunk_cap + 64) * MG_PART * sizeof(double)));
   HIPCHK(hipMalloc((void**)&S->mg_null0, (size_t)MG_NULL_MAX * S->mg_cells * sizeof(double)));      // the indicators of cut-off regions on every level (k_mg_null_prolong)
   HIPCHK(hipMemset(S->mg_a, 0, 9 * S->mg_cells * sizeof(double)));
-  HIPCHK(hipMemset(S->mg_rhs, 0, 2 * S->mg_cells * sizeof(double)));
+  HIPCHK(hipMemset(S->mg_rhs, 0, 3 * S->mg_cells * sizeof(double)));
   HIPCHK(hipMemset(S->mg_part, 0, (S->chunk_cap + 64) * MG_PART * sizeof(double)));
   HIPCHK(hipMemset(S->mg_null0, 0, (size_t)MG_NULL_MAX * S->mg_cells * sizeof(double)));
   HIPCHK(hipMalloc((void**)&S->mg_m0, (MG_NULL_MAX * n0 + MG_NULL_MAX) * sizeof(double)));
   HIPCHK(hipMemset(S->mg_m0, 0, (MG_NULL_MAX * n0 + MG_NULL_MAX) * sizeof(double)));
   HIPCHK(hipMalloc((void**)&S->mg_dot, ((1 + MG_NULL_MAX) * MG_DOT_BLOCKS + 2) * sizeof(double)));      // per-workgroup partials of x_0 . rhs_0 and of the gauge sums, then the tickets of k_mg_up and k_mg_down
   HIPCHK(hipMemset(S->mg_dot, 0, ((1 + MG_NULL_MAX) * MG_DOT_BLOCKS + 2) * sizeof(double)));
-  S->hbm_bytes += (9 * S->mg_cells + 2 * S->mg_cells + (size_t)MG_NULL_MAX * S->mg_cells) * sizeof(double) + 9 * n0 * 8 + (S->chunk_cap + 64) * MG_PART * sizeof(double);
+  S->hbm_bytes += (9 * S->mg_cells + 3 * S->mg_cells + (size_t)MG_NULL_MAX * S->mg_cells) * sizeof(double) + 9 * n0 * 8 + (S->chunk_cap + 64) * MG_PART * sizeof(double);
   return EULER_OK;
 }
 void eu_mg_release(euler_sim* S) {
   for (double* d : {S->mg_a, S->mg_rhs, S->mg_part, S->mg_dot, S->mg_xbuf, S->mg_null0, S->mg_m0}) if (d) (void)hipFree(d);
   if (S->mg_a0i) (void)hipFree(S->mg_a0i);
+  S->mg_wd = nullptr;
   S->mg_a = S->mg_rhs = S->mg_x = S->mg_part = S->mg_dot = S->mg_xbuf = S->mg_null0 = S->mg_m0 = nullptr;
   S->mg_a0i = nullptr; S->mg_xslot = 0;
 }
@@ -267,6 +269,7 @@ struct MgDownArgs {
 };
 
 #define MG_DOWN_THREADS 1024
+#define MG_SPLIT 704          // threads [0, MG_SPLIT) serve a launch's second level (<= 25 x 25 nodes + a row of slack), the others its third (<= 11 x 11)
 #define MG_TAIL_MAX 1024      // nodes of the first level the tail takes
 #define MG_TAIL_LEVELS 4      // stencil levels of the tail at most (1024 -> 272 -> 72 -> top would be 3)
 
@@ -304,10 +307,10 @@ __device__ void mg_tail(const MgDownArgs& A, double* lds) {
   double* top_y = p + ntop;
   double* s_inv = p + 2 * ntop;
   // everything this workgroup needs from memory, in one batch: the entry level's right-hand side (published by all workgroups), the stencils, the inverse
-  double rhs[MG_TAIL_LEVELS], a[MG_TAIL_LEVELS][9];
+  double rhs[MG_TAIL_LEVELS], a[MG_TAIL_LEVELS][9], wd[MG_TAIL_LEVELS];
 #pragma unroll
   for (int q = 0; q < MG_TAIL_LEVELS; ++q) {
-    rhs[q] = 0.0;
+    rhs[q] = 0.0; wd[q] = 0.0;
 #pragma unroll
     for (int k = 0; k < 9; ++k) a[q][k] = 0.0;
     if (q < nt) {
@@ -317,6 +320,7 @@ __device__ void mg_tail(const MgDownArgs& A, double* lds) {
         const double* st = mg_sten(H, l);
 #pragma unroll
         for (int k = 0; k < 9; ++k) a[q][k] = st[(size_t)k * n + tid];
+        wd[q] = H.wd[H.off[l] + tid];
       }
     }
   }
@@ -333,8 +337,7 @@ __device__ void mg_tail(const MgDownArgs& A, double* lds) {
     const int cnx = H.nx[l + 1], cny = H.ny[l + 1], cn = cnx * cny;
     double* x1 = vec[q];
     double* tt = vec[q] + n;
-    const double d = a[q][4];
-    if (tid < n) x1[tid] = d != 0.0 ? MG_OMEGA * rhs[q] / d : 0.0;
+    if (tid < n) x1[tid] = wd[q] * rhs[q];
     __syncthreads();
     if (tid < n) {
       const int i = tid / nx, j = tid % nx;
@@ -345,7 +348,7 @@ __device__ void mg_tail(const MgDownArgs& A, double* lds) {
         if (i2 < 0 || i2 >= ny || j2 < 0 || j2 >= nx) continue;
         t = t + a[q][k] * x1[i2 * nx + j2];
       }
-      tt[tid] = d != 0.0 ? rhs[q] - t : 0.0;
+      tt[tid] = wd[q] != 0.0 ? rhs[q] - t : 0.0;
     }
     __syncthreads();
     if (tid < cn) {      // full weighting: rows outer, columns inner
@@ -386,7 +389,6 @@ __device__ void mg_tail(const MgDownArgs& A, double* lds) {
     double* x1 = vec[q];            // becomes x
     double* x2 = vec[q] + n;
     const double* e = q + 1 == nt ? top_y : vec[q + 1 < MG_TAIL_LEVELS ? q + 1 : q];
-    const double d = a[q][4];
     if (tid < n) {
       const int i = tid / nx, j = tid % nx;
       const int I = i >> 1, J = j >> 1;
@@ -394,7 +396,7 @@ __device__ void mg_tail(const MgDownArgs& A, double* lds) {
       const double fy = (i & 1) && I + 1 <= cny - 1 ? 0.5 : 0.0, fx = (j & 1) && J + 1 <= cnx - 1 ? 0.5 : 0.0;
       const double lo = (1.0 - fx) * e[I * cnx + J] + fx * e[I * cnx + J1];
       const double hi = (1.0 - fx) * e[I1 * cnx + J] + fx * e[I1 * cnx + J1];
-      x2[tid] = d != 0.0 ? x1[tid] + ((1.0 - fy) * lo + fy * hi) : 0.0;
+      x2[tid] = wd[q] != 0.0 ? x1[tid] + ((1.0 - fy) * lo + fy * hi) : 0.0;
     }
     __syncthreads();
     double xv = 0.0;
@@ -407,11 +409,49 @@ __device__ void mg_tail(const MgDownArgs& A, double* lds) {
         if (i2 < 0 || i2 >= ny || j2 < 0 || j2 >= nx) continue;
         t = t + a[q][k] * x2[i2 * nx + j2];
       }
-      xv = d != 0.0 ? x2[tid] + MG_OMEGA * (rhs[q] - t) / d : 0.0;
+      xv = wd[q] != 0.0 ? x2[tid] + wd[q] * (rhs[q] - t) : 0.0;
     }
     __syncthreads();
     if (tid < n) { x1[tid] = xv; if (q == 0) H.x[H.off[l] + tid] = xv; }
     __syncthreads();
+  }
+}
+
+// One level of the way down inside a workgroup: the residual behind the Jacobi step (in place of the right-hand side patch), then full weighting into the next level's
+// patch.  The stencils of the NS nodes a thread handles sit in registers (loaded when the kernel starts, together with everything else that does not depend on the
+// level above: the phases wait for LDS only); the threads [toff, toff + ...) do the work (the small levels of a launch use disjoint thread ranges, so a thread holds the
+// first level's slots and at most one more).
+template <int NS>
+__device__ __forceinline__ void mg_prefetch_sten(const MgHier& H, int l, const MgRect& T, int toff, double (&a)[NS][9]) {
+  const int tid = (int)threadIdx.x - toff, nx = H.nx[l], tw = mg_rw(T), tn = mg_rn(T);
+  const size_t n = (size_t)nx * H.ny[l];
+  const double* st = mg_sten(H, l);
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    const int e = tid + u * MG_DOWN_THREADS;
+    const bool on = tid >= 0 && e < tn;
+    const size_t c = on ? (size_t)(T.i0 + e / tw) * nx + T.j0 + e % tw : 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a[u][k] = on ? st[(size_t)k * n + c] : 0.0;
+  }
+}
+template <int NS>
+__device__ __forceinline__ void mg_residual_patch(const MgHier& H, int l, const MgRect& R, const MgRect& T, int toff, const double (&a)[NS][9], double* prhs, const double* px1) {
+  const int tid = (int)threadIdx.x - toff, nx = H.nx[l], ny = H.ny[l], w = mg_rw(R), tw = mg_rw(T), tn = mg_rn(T);
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    const int e = tid + u * MG_DOWN_THREADS;
+    if (tid < 0 || e >= tn) continue;
+    const int i = T.i0 + e / tw, j = T.j0 + e % tw;
+    const int pe = (i - R.i0) * w + (j - R.j0);
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int i2 = i + k / 3 - 1, j2 = j + k % 3 - 1;
+      if (i2 < 0 || i2 >= ny || j2 < 0 || j2 >= nx) continue;
+      t = t + a[u][k] * px1[pe + (k / 3 - 1) * w + (k % 3 - 1)];
+    }
+    prhs[pe] = a[u][4] != 0.0 ? prhs[pe] - t : 0.0;
   }
 }
 
@@ -436,31 +476,50 @@ __global__ __launch_bounds__(MG_DOWN_THREADS) void k_mg_down(MgDownArgs A) {
     }
     R = r; T = t; O = o;
   };
+  const int nt = A.lB - A.lA;      // transitions of this launch: 0 .. 3
   double* buf[2] = {lds, lds + 2 * (size_t)A.cap0};
   int cap[2] = {A.cap0, A.cap1};
-  // ---- the entry level's right-hand side and Jacobi step
+  // ---- everything that does not depend on another level, in one batch: the stencils of the nodes this thread handles (level lA: up to three per thread; lA + 1 and lA + 2:
+  // one, on the threads below / from MG_SPLIT), omega / diagonal of the right-hand-side nodes, the entry level's right-hand side itself
+  double a0[3][9], an[1][9], w0[3], wn = 0.0;      // (an: level lA + 1's stencil on the threads below MG_SPLIT, level lA + 2's on the others)
+  MgRect R0, T0, O0;
+  rects(A.lA, R0, T0, O0);
+  if (nt >= 1) mg_prefetch_sten<3>(H, A.lA, T0, 0, a0);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) an[0][k] = 0.0;
+  if (nt >= 2 && tid < MG_SPLIT) { MgRect R, T, O; rects(A.lA + 1, R, T, O); mg_prefetch_sten<1>(H, A.lA + 1, T, 0, an); }
+  if (nt >= 3 && tid >= MG_SPLIT) { MgRect R, T, O; rects(A.lA + 2, R, T, O); mg_prefetch_sten<1>(H, A.lA + 2, T, MG_SPLIT, an); }
+  {      // omega / diagonal of the level this thread writes a right-hand side of in the restriction phases: lA + 1 on the threads below MG_SPLIT, lA + 2 from there
+    if (nt >= 2 && tid < MG_SPLIT) { MgRect R, T, O; rects(A.lA + 1, R, T, O); if (tid < mg_rn(R)) wn = H.wd[H.off[A.lA + 1] + (size_t)(R.i0 + tid / mg_rw(R)) * H.nx[A.lA + 1] + R.j0 + tid % mg_rw(R)]; }
+    if (nt >= 3 && tid >= MG_SPLIT) { MgRect R, T, O; rects(A.lA + 2, R, T, O); const int e = tid - MG_SPLIT; if (e < mg_rn(R)) wn = H.wd[H.off[A.lA + 2] + (size_t)(R.i0 + e / mg_rw(R)) * H.nx[A.lA + 2] + R.j0 + e % mg_rw(R)]; }
+  }
   {
-    MgRect R, T, O;
-    rects(A.lA, R, T, O);
-    const int l = A.lA, nx = H.nx[l], n = nx * H.ny[l];
-    const double* st = mg_sten(H, l);
+    const int l = A.lA, nx = H.nx[l], w = mg_rw(R0), rn = mg_rn(R0);
+    double v0[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int e = tid + u * MG_DOWN_THREADS;
+      v0[u] = 0.0; w0[u] = 0.0;
+      if (e >= rn) continue;
+      const int i = R0.i0 + e / w, j = R0.j0 + e % w;
+      const size_t c = (size_t)i * nx + j;
+      w0[u] = H.wd[H.off[l] + c];
+      v0[u] = GATHER ? mg_gather0(A.part, i, j, A.ntb, A.band_lo, A.band_hi) : H.rhs[H.off[l] + c];
+    }
     double* prhs = buf[0];
     double* px1 = buf[0] + cap[0];
-    const int w = mg_rw(R);
-    for (int e = tid; e < mg_rn(R); e += MG_DOWN_THREADS) {
-      const int i = R.i0 + e / w, j = R.j0 + e % w;
-      const size_t c = (size_t)i * nx + j;
-      double v;
-      if (GATHER) {
-        v = mg_gather0(A.part, i, j, A.ntb, A.band_lo, A.band_hi);
-        if (mg_in(O, i, j)) {
-          if (A.tail && A.lA == A.lB) mg_st_agent(H.rhs + H.off[l] + c, v);
-          else H.rhs[H.off[l] + c] = v;
-        }
-      } else v = H.rhs[H.off[l] + c];
-      const double d = st[(size_t)4 * n + c];
-      prhs[e] = v;
-      px1[e] = d != 0.0 ? MG_OMEGA * v / d : 0.0;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int e = tid + u * MG_DOWN_THREADS;
+      if (e >= rn) continue;
+      const int i = R0.i0 + e / w, j = R0.j0 + e % w;
+      if (GATHER && mg_in(O0, i, j)) {
+        const size_t c = (size_t)i * nx + j;
+        if (A.tail && nt == 0) mg_st_agent(H.rhs + H.off[l] + c, v0[u]);
+        else H.rhs[H.off[l] + c] = v0[u];
+      }
+      prhs[e] = v0[u];
+      px1[e] = w0[u] * v0[u];
     }
   }
   __syncthreads();
@@ -470,34 +529,26 @@ __global__ __launch_bounds__(MG_DOWN_THREADS) void k_mg_down(MgDownArgs A) {
 #else
   for (int l = A.lA; l < A.lB; ++l) {
 #endif
-    const int cur = (l - A.lA) & 1;
+    const int rel = l - A.lA, cur = rel & 1;
     MgRect R, T, O, Rc, Tc, Oc;
     rects(l, R, T, O);
     rects(l + 1, Rc, Tc, Oc);
     const int nx = H.nx[l], ny = H.ny[l];
-    const size_t n = (size_t)nx * ny;
     const int cnx = H.nx[l + 1], cny = H.ny[l + 1];
-    const size_t cn = (size_t)cnx * cny;
-    const double* st = mg_sten(H, l);
-    const double* stc = mg_sten(H, l + 1);
     double* prhs = buf[cur];
     double* px1 = buf[cur] + cap[cur];
     double* crhs = buf[cur ^ 1];
     double* cx1 = buf[cur ^ 1] + cap[cur ^ 1];
-    const int w = mg_rw(R), tw = mg_rw(T);
+    const int w = mg_rw(R);
     // residual behind the Jacobi step, in place of the right-hand side
-    for (int e = tid; e < mg_rn(T); e += MG_DOWN_THREADS) {
-      const int i = T.i0 + e / tw, j = T.j0 + e % tw;
-      const size_t c = (size_t)i * nx + j;
-      const int pe = (i - R.i0) * w + (j - R.j0);
-      const double d = st[(size_t)4 * n + c];
-      const double t = mg_apply_patch(st, n, c, i, j, ny, nx, px1, R);
-      prhs[pe] = d != 0.0 ? prhs[pe] - t : 0.0;
-    }
+    if (rel == 0) mg_residual_patch<3>(H, l, R, T, 0, a0, prhs, px1);
+    else if (rel == 1) mg_residual_patch<1>(H, l, R, T, 0, an, prhs, px1);
+    else mg_residual_patch<1>(H, l, R, T, MG_SPLIT, an, prhs, px1);
     __syncthreads();
-    // full weighting -> the next level's right-hand side (and its Jacobi step)
-    const int cw = mg_rw(Rc);
-    for (int e = tid; e < mg_rn(Rc); e += MG_DOWN_THREADS) {
+    // full weighting -> the next level's right-hand side (and its Jacobi step): the threads below MG_SPLIT for lA + 1 (and for a launch's last level), from MG_SPLIT for lA + 2
+    const int toff = rel == 1 && l + 1 < A.lB ? MG_SPLIT : 0;
+    const int cw = mg_rw(Rc), cn = mg_rn(Rc);
+    for (int e = tid - toff; e >= 0 && e < cn; e += MG_DOWN_THREADS) {
       const int I = Rc.i0 + e / cw, J = Rc.j0 + e % cw;
       const size_t c = (size_t)I * cnx + J;
       double t = 0.0;
@@ -512,11 +563,7 @@ __global__ __launch_bounds__(MG_DOWN_THREADS) void k_mg_down(MgDownArgs A) {
         if (A.tail && l + 1 == A.lB) mg_st_agent(H.rhs + H.off[l + 1] + c, t);
         else H.rhs[H.off[l + 1] + c] = t;
       }
-      if (l + 1 < A.lB) {
-        const double d = stc[(size_t)4 * cn + c];
-        crhs[e] = t;
-        cx1[e] = d != 0.0 ? MG_OMEGA * t / d : 0.0;
-      }
+      if (l + 1 < A.lB) { crhs[e] = t; cx1[e] = wn * t; }      // (one node per thread on these levels: wn is this node's omega / diagonal)
     }
     __syncthreads();
   }
@@ -587,12 +634,56 @@ __global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
   };
   double* bx[2] = {lds, lds + A.cap};      // x of the level above / of this level, alternating
   double* b2 = lds + 2 * (size_t)A.cap;    // x2 of this level
+  // ---- everything that does not depend on the level above, in one batch.  Level 0: two nodes of X2 and one of X per thread; the coarser levels are small - the thread
+  // ranges [off_l, off_l + |X2_l|) are disjoint, so a thread serves level 0 and at most one more (`myl`)
+  double w2a[2] = {0.0, 0.0}, r2a[2] = {0.0, 0.0}, a0[9], w0 = 0.0, r0 = 0.0;      // level 0
+  double w2m = 0.0, r2m = 0.0, am[9], wm = 0.0, rm = 0.0;                              // level myl
+  int myl = -1, mye = 0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { a0[k] = 0.0; am[k] = 0.0; }
   if (A.lC > 0) {
     MgRect X, X2;
+    rects(0, X, X2);
+    const int nx = H.nx[0];
+    const size_t n = (size_t)nx * H.ny[0];
+    const int w2 = mg_rw(X2), w = mg_rw(X);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + u * MG_UP_THREADS;
+      if (e < mg_rn(X2)) { const size_t c = (size_t)(X2.i0 + e / w2) * nx + X2.j0 + e % w2; w2a[u] = H.wd[c]; r2a[u] = H.rhs[c]; }
+    }
+    if (tid < mg_rn(X)) {
+      const size_t c = (size_t)(X.i0 + tid / w) * nx + X.j0 + tid % w;
+      const double* st = mg_sten(H, 0);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) a0[k] = st[(size_t)k * n + c];
+      w0 = H.wd[c]; r0 = H.rhs[c];
+    }
+    int off = 0;
+    for (int l = 1; l < A.lC; ++l) {
+      rects(l, X, X2);
+      const int e = tid - off, n2 = mg_rn(X2);
+      if (e >= 0 && e < n2) {
+        myl = l; mye = e;
+        const int lnx = H.nx[l];
+        const size_t ln = (size_t)lnx * H.ny[l];
+        const int lw2 = mg_rw(X2), lw = mg_rw(X);
+        const size_t c2 = (size_t)(X2.i0 + e / lw2) * lnx + X2.j0 + e % lw2;
+        w2m = H.wd[H.off[l] + c2]; r2m = H.rhs[H.off[l] + c2];
+        if (e < mg_rn(X)) {
+          const size_t c = (size_t)(X.i0 + e / lw) * lnx + X.j0 + e % lw;
+          const double* st = mg_sten(H, l);
+#pragma unroll
+          for (int k = 0; k < 9; ++k) am[k] = st[(size_t)k * ln + c];
+          wm = H.wd[H.off[l] + c]; rm = H.rhs[H.off[l] + c];
+        }
+      }
+      off += n2;
+    }
     rects(A.lC, X, X2);
-    const int w = mg_rw(X), nx = H.nx[A.lC];
+    const int cw = mg_rw(X), cnx = H.nx[A.lC];
     double* dst = bx[A.lC & 1];
-    for (int e = tid; e < mg_rn(X); e += MG_UP_THREADS) dst[e] = H.x[H.off[A.lC] + (size_t)(X.i0 + e / w) * nx + X.j0 + e % w];
+    for (int e = tid; e < mg_rn(X); e += MG_UP_THREADS) dst[e] = H.x[H.off[A.lC] + (size_t)(X.i0 + e / cw) * cnx + X.j0 + e % cw];
     __syncthreads();
   }
   double dv = 0.0;
@@ -605,34 +696,41 @@ __global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
     rects(l, X, X2);
     rects(l + 1, Xc, X2c);
     const int nx = H.nx[l], ny = H.ny[l];
-    const size_t n = (size_t)nx * ny;
     const int cnx = H.nx[l + 1], cny = H.ny[l + 1];
-    const double* st = mg_sten(H, l);
     const double* e_ = bx[(l + 1) & 1];
     double* xo = bx[l & 1];
     const int w2 = mg_rw(X2), cw = mg_rw(Xc), w = mg_rw(X);
-    for (int e = tid; e < mg_rn(X2); e += MG_UP_THREADS) {
+    // x2 = the Jacobi step + P x_(l+1) on X2
+    auto x2_at = [&](int e, double wdv, double rv) __attribute__((always_inline)) {
       const int i = X2.i0 + e / w2, j = X2.j0 + e % w2;
-      const size_t c = (size_t)i * nx + j;
-      const double d = st[(size_t)4 * n + c], rv = H.rhs[H.off[l] + c];
       const int I = i >> 1, J = j >> 1;
       const bool oy = (i & 1) && I + 1 <= cny - 1, ox = (j & 1) && J + 1 <= cnx - 1;
       const int I1 = oy ? I + 1 : I, J1 = ox ? J + 1 : J;
       const double fy = oy ? 0.5 : 0.0, fx = ox ? 0.5 : 0.0;
       const double lo = (1.0 - fx) * e_[(I - Xc.i0) * cw + (J - Xc.j0)] + fx * e_[(I - Xc.i0) * cw + (J1 - Xc.j0)];
       const double hi = (1.0 - fx) * e_[(I1 - Xc.i0) * cw + (J - Xc.j0)] + fx * e_[(I1 - Xc.i0) * cw + (J1 - Xc.j0)];
-      b2[e] = d != 0.0 ? MG_OMEGA * rv / d + ((1.0 - fy) * lo + fy * hi) : 0.0;
-    }
+      b2[e] = wdv != 0.0 ? wdv * rv + ((1.0 - fy) * lo + fy * hi) : 0.0;
+    };
+    if (l == 0) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) { const int e = tid + u * MG_UP_THREADS; if (e < mg_rn(X2)) x2_at(e, w2a[u], r2a[u]); }
+    } else if (l == myl) x2_at(mye, w2m, r2m);
     __syncthreads();
-    for (int e = tid; e < mg_rn(X); e += MG_UP_THREADS) {
+    // x = x2 + (omega / d) (rhs - A x2) on X
+    auto x_at = [&](int e, const double (&a)[9], double wdv, double rv) __attribute__((always_inline)) {
       const int i = X.i0 + e / w, j = X.j0 + e % w;
-      const size_t c = (size_t)i * nx + j;
-      const double d = st[(size_t)4 * n + c], rv = H.rhs[H.off[l] + c];
-      const double t = mg_apply_patch(st, n, c, i, j, ny, nx, b2, X2);
-      const double x2c = b2[(i - X2.i0) * w2 + (j - X2.j0)];
-      const double xv = d != 0.0 ? x2c + MG_OMEGA * (rv - t) / d : 0.0;
+      const int pe = (i - X2.i0) * w2 + (j - X2.j0);
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int i2 = i + k / 3 - 1, j2 = j + k % 3 - 1;
+        if (i2 < 0 || i2 >= ny || j2 < 0 || j2 >= nx) continue;
+        t = t + a[k] * b2[pe + (k / 3 - 1) * w2 + (k % 3 - 1)];
+      }
+      const double xv = wdv != 0.0 ? b2[pe] + wdv * (rv - t) : 0.0;
       xo[e] = xv;
       if (l == 0) {
+        const size_t c = (size_t)i * nx + j;
         if (n_null > 0) {
           mg_st_agent(H.x + c, xv);
 #pragma unroll
@@ -640,7 +738,9 @@ __global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
         } else H.x[c] = xv;
         if (i >= A.row_lo && i < A.row_hi) dv += xv * rv;
       }
-    }
+    };
+    if (l == 0) { if (tid < mg_rn(X)) x_at(tid, a0, w0, r0); }
+    else if (l == myl && mye < mg_rn(X)) x_at(mye, am, wm, rm);
     __syncthreads();
   }
   if (A.lC == 0) {      // level 0 is the tail's own level: only the dot product is left
@@ -813,6 +913,15 @@ __global__ __launch_bounds__(256) void k_mg_top_stencil(const double* __restrict
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < 9 * n) out[i] = at[i];
 }
+__global__ __launch_bounds__(256) void k_mg_wd(const double* __restrict__ a, const unsigned int* offs, int nl, MgHier H, double* __restrict__ wd) {
+  (void)a; (void)offs; (void)nl;
+  const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int l = blockIdx.y;
+  const size_t n = (size_t)H.nx[l] * H.ny[l];
+  if (c >= n) return;
+  const double d = mg_sten(H, l)[4 * n + c];
+  wd[H.off[l] + c] = d != 0.0 ? MG_OMEGA / d : 0.0;
+}
 int eu_mg_setup(euler_sim* S) {
   const size_t n0 = (size_t)S->mg_nx[0] * S->mg_ny[0];
   HIPCHK(hipMemsetAsync(S->mg_a0i, 0, 9 * n0 * sizeof(unsigned long long), S->stream));
@@ -826,6 +935,8 @@ int eu_mg_setup(euler_sim* S) {
   for (int l = 1; l < S->mg_levels; ++l)
     LAUNCH(S, KC_PRECON_FACTOR, k_mg_coarsen, dim3((unsigned)((9 * (size_t)S->mg_nx[l] * S->mg_ny[l] + 255) / 256)), dim3(256), S->mg_a + 9 * S->mg_off[l - 1], S->mg_nx[l - 1], S->mg_ny[l - 1],
            S->mg_a + 9 * S->mg_off[l], S->mg_nx[l], S->mg_ny[l], S->sc);
+  // omega / diagonal per node of every level below the dense one: the cycle's Jacobi steps multiply
+  hipLaunchKernelGGL(k_mg_wd, dim3((unsigned)(((size_t)S->mg_nx[0] * S->mg_ny[0] + 255) / 256), (unsigned)S->mg_levels), dim3(256), 0, S->stream, (const double*)nullptr, (const unsigned int*)nullptr, 0, mg_hier(S), S->mg_wd);
   return EULER_OK;
 }
 

@@ -849,7 +849,7 @@ static void mg_vcycle(eo_sim* s, mg_hierarchy* h, int l) {      /* lv[l].x = V_l
   if (l == h->nlev - 1) { memcpy(L->x, L->rhs, n * sizeof(double)); coarse_top_solve(s, L->x); return; }
   mg_level* C = &h->lv[l + 1];
   const double* d = L->a[4];
-  for (size_t c = 0; c < n; ++c) L->x1[c] = d[c] != 0.0 ? MG_OMEGA * L->rhs[c] / d[c] : 0.0;      /* Jacobi from a zero guess */
+  for (size_t c = 0; c < n; ++c) L->x1[c] = d[c] != 0.0 ? (MG_OMEGA / d[c]) * L->rhs[c] : 0.0;      /* Jacobi from a zero guess (the product keeps omega / d per node) */
   for (int I = 0; I < L->ny; ++I)
     for (int J = 0; J < L->nx; ++J) { const size_t c = (size_t)I * L->nx + J; L->t[c] = d[c] != 0.0 ? L->rhs[c] - mg_apply(L, L->x1, I, J) : 0.0; }
   mg_restrict(L, L->t, C, C->rhs);
@@ -857,7 +857,7 @@ static void mg_vcycle(eo_sim* s, mg_hierarchy* h, int l) {      /* lv[l].x = V_l
   for (int I = 0; I < L->ny; ++I)      /* the correction */
     for (int J = 0; J < L->nx; ++J) { const size_t c = (size_t)I * L->nx + J; L->t[c] = d[c] != 0.0 ? L->x1[c] + mg_interp1(L, C, C->x, I, J) : 0.0; }
   for (int I = 0; I < L->ny; ++I)      /* Jacobi again */
-    for (int J = 0; J < L->nx; ++J) { const size_t c = (size_t)I * L->nx + J; L->x[c] = d[c] != 0.0 ? L->t[c] + MG_OMEGA * (L->rhs[c] - mg_apply(L, L->t, I, J)) / d[c] : 0.0; }
+    for (int J = 0; J < L->nx; ++J) { const size_t c = (size_t)I * L->nx + J; L->x[c] = d[c] != 0.0 ? L->t[c] + (MG_OMEGA / d[c]) * (L->rhs[c] - mg_apply(L, L->t, I, J)) : 0.0; }
 }
 static double* mg_null_level0(eo_sim* s, const double* nv);
 /* Water cut off from the air: its pressure is determined up to a constant, PCG delivers the one with n . M p = 0 (M the preconditioner, n the region's indicator) and the
