@@ -1097,7 +1097,7 @@ def compact_line(full, limit=LINE_LIMIT):
                 b["balance_max_over_mean"] = v["balance"].get("max_over_mean")
             summary[k] = b
     line["summary"] = summary
-    line.update(_pick(full, ("balance", "comm_calls_rank0", "device", "full", "timings_s", "dtype_note")))
+    line.update(_pick(full, ("balance", "comm_calls_rank0", "comm", "device", "full", "timings_s", "dtype_note")))
     if isinstance(line.get("balance"), dict):
         line["balance"] = _pick(line["balance"], ("partition", "max_over_mean"))
     line = _short(line)
@@ -1239,6 +1239,19 @@ def main():
             comm_calls = dict(comm.counts)
         except Exception:
             comm_calls = None
+    # the communicator as the job saw it: how many ranks the transport really connected, and the one unknown of the scaling model - the latency L of an
+    # exchange point of the distributed PCG iteration, measured over THIS communicator (collective: every rank calls it; HIP-event time per call on rank 0's stream):
+    # G1 = the slab's edge rows of z to the two neighbours + {max |r|, dot(z, r)} of every rank to every rank, G2 = the dot partial of every rank to every rank
+    comm_info = None
+    if comm is not None:
+        comm_info = {"ranks": int(getattr(comm, "world", world)), "transport": "rccl" if args.comm == "rccl" else "torch.distributed", "rccl_version": getattr(comm, "version", None),
+                     "p2p_mailboxes": bool(p2p_on)}
+        try:
+            comm_info["exchange_us"] = {"g1_edge_rows_and_pair": round(sim.exchange_latency(100, GX, 2), 2), "g2_scalar": round(sim.exchange_latency(100, 0, 1), 2)}
+            l = sum(comm_info["exchange_us"].values())
+            comm_info["exchange_us"]["per_iteration"] = round(l, 2)
+        except Exception as e:
+            comm_info["exchange_us"] = {"error": repr(e)}
     head = copy_gbps = device = quality = converged = exact = None
     tile_w_run = tile_w
     timings = {"pmc_passes": round(t_pmc, 1)}
@@ -1500,6 +1513,7 @@ def main():
         "pcg_iteration": head["pcg_iteration"],
         "balance": balance,
         "comm_calls_rank0": comm_calls,
+        "comm": comm_info,
         "kernels": head["kernels"],
         "cpu_baseline": cpu_obj,
         # the same workload with EVERY solve run to the reference's tolerance 1e-6 (multilevel mode, cap lifted) - not the headline (whose work is fixed at 100 iterations per

@@ -165,7 +165,6 @@ extern "C" int euler_set_option(euler_sim* S, int32_t key, int64_t value) {
     case EULER_OPT_RCCL_SMALL: ok = value >= 0 && value <= 2; if (S->rccl) when = "before euler_set_comm_rccl"; break;
     case EULER_OPT_RCCL_NO_EXCHANGE: ok = value == 0 || value == 1; if (S->rccl) when = "before euler_set_comm_rccl"; break;
     case EULER_OPT_SLAB_FUSION: ok = value == 0 || value == 1; if (S->p2p_on) when = "before euler_p2p_connect"; break;
-    case EULER_OPT_ONE_EXCHANGE: ok = value == 0 || value == 1; break;
     case EULER_OPT_RESIDENT_CAP: case EULER_OPT_GRID4_MIN_CELLS: case EULER_OPT_RESIDENT_FORCE_TIMEOUT: ok = value >= 0; break;
     default: ok = value == 0 || value == 1; break;
   }

@@ -366,7 +366,6 @@ enum {
   EULER_OPT_NO_INTERIOR = 11,       /* 1: no constant-mask instantiation for interior chunks (experiments; the same bits) */
   EULER_OPT_BUILD_GATHER = 12,      /* 1: the assembly as one diagonal gather (rounds 1-2; the same bits) */
   EULER_OPT_RESIDENT_FORCE_TIMEOUT = 13, /* test hook: the next n resident launches give up at once as if a wait had run out (error word 1): the time-out path */
-  EULER_OPT_ONE_EXCHANGE = 14,      /* row slabs, tile-local mode: 1 = the Chronopoulos-Gear form of PCG - ONE exchange point per iteration instead of two (changes the bits: tolerance parity) */
   EULER_OPT__COUNT
 };
 int euler_set_option(euler_sim* sim, int32_t key, int64_t value);

@@ -68,6 +68,28 @@ def test_compact_line_is_small_and_carries_the_contract():
         assert d["summary"]["quality_100_iterations"]["pressure_error_vs_converged"]["ic0"] == 0.98
 
 
+def test_compact_line_of_an_eight_gpu_job_carries_the_communicator():
+    """N = 8: the line of a row-slab job also holds what the transport connected (`comm.ranks`) and the measured latency of the two exchange
+    points of a distributed PCG iteration (`comm.exchange_us`: the one unknown of the scaling model), the fluid balance and the call counters - and still fits."""
+    full = canned_full(50)
+    full.update({"n_gpus": 8, "scaling": "weak",
+                 "balance": {"partition": [[0, 128], [128, 256], [256, 384], [384, 512], [512, 640], [640, 768], [768, 896], [896, 1024]],
+                             "fluid_cells_per_rank": [33460285] * 8, "max_over_mean": 1.0, "note": "b" * 300},
+                 "comm_calls_rank0": {"allreduce": 1621, "halo": 3362, "chain": 0, "allgather": 480, "exchange": 32320},
+                 "comm": {"ranks": 8, "transport": "rccl", "rccl_version": 22703, "p2p_mailboxes": False,
+                          "exchange_us": {"g1_edge_rows_and_pair": 14.82, "g2_scalar": 9.31, "per_iteration": 24.13}}})
+    full["config"]["parallelism"] = "8 row slabs (8192 rows each), EVERY stage decomposed; tile-local IC(0): no coupling between slabs; exchanges: RCCL"
+    full["config"]["parallelism_detail"] = "p" * 600
+    full["strong_16384_dam_break"] = dict(full["strong_16384_dam_break"], n_gpus=8, balance={"partition": [[i, i + 32] for i in range(0, 256, 32)], "max_over_mean": 1.08, "x": "y" * 200})
+    line = json.dumps(bench.compact_line(full))
+    assert len(line) < 8192, len(line)
+    d = json.loads(line)
+    assert d["n_gpus"] == 8 and d["comm"]["ranks"] == 8 and d["comm"]["transport"] == "rccl"
+    assert d["comm"]["exchange_us"]["per_iteration"] == 24.13
+    assert d["comm_calls_rank0"]["exchange"] == 32320 and d["balance"]["max_over_mean"] == 1.0
+    assert d["summary"]["strong_16384_dam_break"]["balance_max_over_mean"] == 1.08
+
+
 def test_compact_line_survives_missing_and_failed_blocks():
     full = canned_full()
     full["converged"] = {"error": "RuntimeError('boom')"}
