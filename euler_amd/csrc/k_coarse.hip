@@ -418,11 +418,11 @@ int eu_launch_coarse_consistent(euler_sim* S) {
 }
 
 // ---- row slabs, multilevel mode.  The level-0 right-hand side of a node row collects tiles of the bands either side of it, so a rank forms, from ITS tiles, the node rows
-// [4 band_lo - 1, 4 band_hi + 1) - its own and one either side - into its slot of the G1 exchange's all-gather (behind {max |r|, dot(z, r)}); k_mg_scatter0 then adds, in rank
+// [RPB band_lo - 1, RPB band_hi + 1) - its own and one either side - into its slot of the G1 exchange's all-gather (behind {max |r|, dot(z, r)}); k_mg_scatter0 then adds, in rank
 // order, what the ranks hold of every row: the same bits on every rank, and the V-cycle runs replicated from there.
 int eu_coarse_comm_slots(euler_sim* S) {
   int rows = 0;
-  for (int r = 0; r < S->bulk.nranks && r < 64; ++r) rows = 4 * (S->part_hi[r] - S->part_lo[r]) + 2 > rows ? 4 * (S->part_hi[r] - S->part_lo[r]) + 2 : rows;
+  for (int r = 0; r < S->bulk.nranks && r < 64; ++r) rows = MG_RPB * (S->part_hi[r] - S->part_lo[r]) + 2 > rows ? MG_RPB * (S->part_hi[r] - S->part_lo[r]) + 2 : rows;
   const int slot = 2 + rows * S->mg_nx[0];
   if (slot != S->mg_xslot || !S->mg_xbuf) {
     if (S->mg_xbuf) { if (hipStreamSynchronize(S->stream) != hipSuccess || hipFree(S->mg_xbuf) != hipSuccess) return -1; S->mg_xbuf = nullptr; }
@@ -447,7 +447,7 @@ int eu_launch_coarse_scatter(euler_sim* S) {
   MgParts P;
   P.n = S->bulk.nranks < 64 ? S->bulk.nranks : 64;
   const int ny0 = S->mg_ny[0];
-  for (int r = 0; r < P.n; ++r) { P.lo[r] = 4 * S->part_lo[r] - 1 < 0 ? 0 : 4 * S->part_lo[r] - 1; P.hi[r] = 4 * S->part_hi[r] + 1 > ny0 ? ny0 : 4 * S->part_hi[r] + 1; }
+  for (int r = 0; r < P.n; ++r) { P.lo[r] = MG_RPB * S->part_lo[r] - 1 < 0 ? 0 : MG_RPB * S->part_lo[r] - 1; P.hi[r] = MG_RPB * S->part_hi[r] + 1 > ny0 ? ny0 : MG_RPB * S->part_hi[r] + 1; }
   const int n0 = S->mg_nx[0] * ny0;
   hipLaunchKernelGGL(k_mg_scatter0, dim3((n0 + 255) / 256), dim3(256), 0, S->stream, S->mg_xbuf, S->mg_xslot, P, S->mg_rhs, S->mg_nx[0], n0);
   return EULER_OK;

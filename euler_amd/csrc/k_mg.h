@@ -6,9 +6,24 @@
 #define MG_OMEGA 0.8         // damped Jacobi on every level below the dense one (tools/r05/mg_proto.py: 0.7 - 1.0 are within two iterations of each other, 1.1 costs 40 %)
 #define MG_TOP_MAX 64        // nodes of the dense top level at most (its inverse lives in LDS: 32 KB)
 #define MG_MAXLEV 12
-#define MG_PART 48           // doubles k_precond_tile leaves per tile: 8 half-groups of 8 lanes x (2 node rows x 3 node columns)
+// Level 0's node spacing in grid cells: node (I, J) sits AT the centre of cell (G0 J + G0 / 2, G0 I + G0 / 2).  8 (round 5): a tank at rest needs 30 PCG iterations to 1e-6 where
+// 16 - the tile width - needs 52 and round 4's aggregates of 16 needed 104 (tools/r05/mg_proto.py; dam break at impact 39 / 65 / 109, waterfall 37 / 63 / 124), for a level 0 of
+// four times the nodes.  Everything below follows from it: a band of 64 rows holds MG_RPB node rows; the lanes of a tile between the same two node rows form groups of
+// MG_LG = G0 / 2 (aligned: a DPP quad or half row); a lane's 16 columns lie between at most MG_NSEG + 1 node columns, a group's between MG_NSLOT.
+#ifndef MG_G0
+#define MG_G0 8
+#endif
+#define MG_LOG (MG_G0 == 8 ? 3 : 4)
+#define MG_RPB (64 / MG_G0)
+#define MG_LG (MG_G0 / 2)
+#define MG_NGRP (64 / MG_LG)
+#define MG_NSEG (16 / MG_G0 + 1)
+#define MG_NSLOT (MG_NSEG + 2)
+#define MG_PART (MG_NGRP * 2 * MG_NSLOT)      // doubles k_precond_tile leaves per tile: per group of MG_LG lanes, 2 node rows x MG_NSLOT node columns (160 for G0 = 8)
+#define MG_NI ((19 + MG_G0 - 1) / MG_G0 + 1)  // node intervals the 20 records of a k_search_apply run and its window can touch
+static_assert(MG_G0 == 8 || MG_G0 == 16, "MG_G0");
 #define MG_NULL_MAX 4        // indicators of fluid regions cut off from the air that are kept (k_coarse.hip CC_NULL_MAX)
-#define MG_DOT_BLOCKS 1024   // workgroups of k_mg_up at most (tiles of 32 x 32 nodes of level 0: 16384^2 has 1024)
+#define MG_DOT_BLOCKS 4096   // workgroups of k_mg_up at most (tiles of 32 x 32 nodes of level 0: 16384^2 has 4096 with G0 = 8)
 #define MG_FIN_SLOT 7        // k_mg_up's epilogue on row slabs with a split cycle: x_0 . rhs_0 of the own rows is ADDED to the rank's slot instead of applied
 
 int  eu_mg_alloc(euler_sim* S);
@@ -21,12 +36,12 @@ int  eu_mg_null_setup(euler_sim* S);                              // per solve, 
 int  eu_mg_slab_rows(euler_sim* S, int force);                   // row slabs: this rank's share of level 0's right-hand side into its slot of the exchange buffer
 
 #ifdef __HIPCC__
-// A cell's column c (or row) against n nodes, node j AT the centre of cell 16 j + 8: the node left of / at the cell and the weight f (in sixteenths) of the next one;
+// A cell's column c (or row) against n nodes, node j AT the centre of cell G0 j + G0 / 2: the node left of / at the cell and the weight f (a multiple of 1 / G0) of the next one;
 // beyond the outermost nodes the interpolant is constant (weight clamps, oracle: mg_w0)
 __device__ __forceinline__ void mg_cell_w(int c, int n, int& j0, int& j1, double& f) {
-  const int u = c - 8;
-  int j = u >> 4;
-  double w = (double)(u & 15) * (1.0 / 16.0);
+  const int u = c - MG_G0 / 2;
+  int j = u >> MG_LOG;
+  double w = (double)(u & (MG_G0 - 1)) * (1.0 / MG_G0);
   if (j < 0) { j = 0; w = 0.0; }
   int k = j + 1;
   if (k > n - 1) { k = n - 1; w = 0.0; }

@@ -52,7 +52,7 @@ __device__ __forceinline__ const double* mg_sten(const MgHier& H, int l) { retur
 
 int eu_mg_alloc(euler_sim* S) {
   if (S->mg_dot) return EULER_OK;
-  int nx = (S->X + 15) / 16, ny = 4 * S->geom.nbands, l = 0;
+  int nx = (S->X + MG_G0 - 1) / MG_G0, ny = MG_RPB * S->geom.nbands, l = 0;
   S->mg_cells = 0;
   for (;; ++l) {
     if (l >= MG_MAXLEV) { eu_set_error("multilevel preconditioner: more than %d levels", MG_MAXLEV); return EULER_EINVAL; }
@@ -94,7 +94,9 @@ void eu_mg_release(euler_sim* S) {
 // edge of that row between the nodes J and J + 1 (0 beyond the outermost nodes) - and likewise for vertical edges.  So a lane (one row, 16 consecutive columns: at
 // most two node intervals) only counts: per interval, its horizontal edges H, sum c' wx wx^T and sum over its vertical edges of wx wx^T (three integers each, in
 // 1/256), and adds row weights x those to the stencil entries - 64 integer adds per lane into a window in LDS, flushed by 64-bit atomics (units of 2^-16: exact).
-#define MG_WIN (6 * 8 * 9)
+#define MG_WIN_R (MG_RPB + 2)                 // node rows a band's 64 rows touch
+#define MG_WIN_C (80 / MG_G0 + 2)             // node columns a tile's 79 columns touch (8: 12, 16: 7)
+#define MG_WIN (MG_WIN_R * MG_WIN_C * 9)
 __global__ __launch_bounds__(256) void k_mg_assemble0(const uint8_t* __restrict__ mask, SkewGeom g, const unsigned int* __restrict__ list, const PcgScalars* sc,
                                                       int band_lo, int nx0, int ny0, unsigned long long* __restrict__ a0i) {
   __shared__ int s_win[4][MG_WIN];
@@ -110,14 +112,16 @@ __global__ __launch_bounds__(256) void k_mg_assemble0(const uint8_t* __restrict_
     const int tile = (int)(list[w] & ~EU_CHUNK_INTERIOR);
     const int band = band_lo + tile / ntb, k = tile % ntb;
     const size_t base = ((size_t)band * g.TS + (size_t)k * 16) * 64 + 2 * lane;
-    // the lane's row against the node rows
-    const int uy = 64 * band + lane - 8, I0 = uy >> 4;
-    int wy0 = 16 - (uy & 15), wy1 = uy & 15;
-    if (I0 < 0) { wy0 = 0; wy1 = 16; }
-    if (I0 >= ny0 - 1) { wy0 = 16; wy1 = 0; }
+    // the lane's row against the node rows (weights in 1 / G0)
+    const int uy = 64 * band + lane - MG_G0 / 2, I0 = uy >> MG_LOG;
+    int wy0 = MG_G0 - (uy & (MG_G0 - 1)), wy1 = uy & (MG_G0 - 1);
+    if (I0 < 0) { wy0 = 0; wy1 = MG_G0; }
+    if (I0 >= ny0 - 1) { wy0 = MG_G0; wy1 = 0; }
     const bool vert_ok = I0 >= 0 && I0 <= ny0 - 2;
-    const int Jb = (16 * k - lane - 8) >> 4;      // node interval of the lane's first column
-    int H[2] = {0, 0}, C[2][3] = {{0, 0, 0}, {0, 0, 0}}, V[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    const int Jb = (16 * k - lane - MG_G0 / 2) >> MG_LOG;      // node interval of the lane's first column
+    int H[MG_NSEG], C[MG_NSEG][3], V[MG_NSEG][3];
+#pragma unroll
+    for (int m = 0; m < MG_NSEG; ++m) { H[m] = 0; C[m][0] = C[m][1] = C[m][2] = 0; V[m][0] = V[m][1] = V[m][2] = 0; }
 #pragma unroll
     for (int P = 0; P < 8; ++P) {
       const unsigned int mm = *reinterpret_cast<const unsigned short*>(mask + base + P * 128);
@@ -125,22 +129,24 @@ __global__ __launch_bounds__(256) void k_mg_assemble0(const uint8_t* __restrict_
       for (int h = 0; h < 2; ++h) {
         const unsigned int cm = (mm >> (8 * h)) & 0xff;
         if (!(cm & CM_FLUID)) continue;
-        const int ux = 16 * k + 2 * P + h - lane - 8, J0 = ux >> 4;
-        int w0 = 16 - (ux & 15), w1 = ux & 15;
-        if (J0 < 0) { w0 = 0; w1 = 16; }
-        if (J0 >= nx0 - 1) { w0 = 16; w1 = 0; }
+        const int ux = 16 * k + 2 * P + h - lane - MG_G0 / 2, J0 = ux >> MG_LOG;
+        int w0 = MG_G0 - (ux & (MG_G0 - 1)), w1 = ux & (MG_G0 - 1);
+        if (J0 < 0) { w0 = 0; w1 = MG_G0; }
+        if (J0 >= nx0 - 1) { w0 = MG_G0; w1 = 0; }
         const int cp = (int)(cm >> CM_DIAG_SHIFT) - __popc(cm & (CM_RIGHT | CM_UP | CM_LEFT | CM_DOWN));
         const int hh = ((cm & CM_RIGHT) && J0 >= 0 && J0 <= nx0 - 2) ? 1 : 0;
         const int vv = (cm & CM_UP) ? 1 : 0;
         const int q00 = w0 * w0, q01 = w0 * w1, q11 = w1 * w1;
-        if (J0 == Jb) { H[0] += hh; C[0][0] += cp * q00; C[0][1] += cp * q01; C[0][2] += cp * q11; V[0][0] += vv * q00; V[0][1] += vv * q01; V[0][2] += vv * q11; }
-        else          { H[1] += hh; C[1][0] += cp * q00; C[1][1] += cp * q01; C[1][2] += cp * q11; V[1][0] += vv * q00; V[1][1] += vv * q01; V[1][2] += vv * q11; }
+#pragma unroll
+        for (int m = 0; m < MG_NSEG; ++m)
+          if (J0 - Jb == m) { H[m] += hh; C[m][0] += cp * q00; C[m][1] += cp * q01; C[m][2] += cp * q11; V[m][0] += vv * q00; V[m][1] += vv * q01; V[m][2] += vv * q11; }
       }
     }
-    const int rI0 = I0 - (4 * band - 1);      // 0 .. 4
+    const int rI0 = I0 - (MG_RPB * band - 1);
+    const int cbase = (16 * k - 63 - MG_G0 / 2) >> MG_LOG;      // the window's first node column
 #pragma unroll
-    for (int sg = 0; sg < 2; ++sg) {
-      const int cJ0 = Jb + sg - (k - 5);      // 0 .. 5
+    for (int sg = 0; sg < MG_NSEG; ++sg) {
+      const int cJ0 = Jb + sg - cbase;
       const int Mx[2][2] = {{C[sg][0] + H[sg], C[sg][1] - H[sg]}, {C[sg][1] - H[sg], C[sg][2] + H[sg]}};
       const int Vx[2][2] = {{V[sg][0], V[sg][1]}, {V[sg][1], V[sg][2]}};
       const int wy[2] = {wy0, wy1};
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(256) void k_mg_assemble0(const uint8_t* __restrict_
             for (int cb = 0; cb < 2; ++cb) {
               int val = wy[ra] * wy[rb] * Mx[ca][cb];
               if (vert_ok) val += (ra == rb ? 1 : -1) * Vx[ca][cb];
-              if (val != 0) atomicAdd(&win[((rI0 + ra) * 8 + cJ0 + ca) * 9 + (rb - ra + 1) * 3 + (cb - ca + 1)], val);
+              if (val != 0) atomicAdd(&win[((rI0 + ra) * MG_WIN_C + cJ0 + ca) * 9 + (rb - ra + 1) * 3 + (cb - ca + 1)], val);
             }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -163,8 +169,8 @@ __global__ __launch_bounds__(256) void k_mg_assemble0(const uint8_t* __restrict_
       const int v = win[e];
       if (v == 0) continue;
       win[e] = 0;
-      const int kk = e % 9, cJ = (e / 9) & 7, rI = e / 72;
-      const int I = 4 * band - 1 + rI, J = k - 5 + cJ;
+      const int kk = e % 9, cJ = (e / 9) % MG_WIN_C, rI = e / (9 * MG_WIN_C);
+      const int I = MG_RPB * band - 1 + rI, J = cbase + cJ;
       if (I >= 0 && I < ny0 && J >= 0 && J < nx0) atomicAdd(&a0i[(size_t)kk * n0 + (size_t)I * nx0 + J], (unsigned long long)(long long)v);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(256) void k_mg_assemble0(const uint8_t* __restrict_
 }
 __global__ __launch_bounds__(256) void k_mg_convert0(const unsigned long long* __restrict__ a0i, double* __restrict__ a, size_t n) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) a[i] = (double)(long long)a0i[i] * (1.0 / 65536.0);
+  if (i < n) a[i] = (double)(long long)a0i[i] * (1.0 / ((double)MG_G0 * MG_G0 * MG_G0 * MG_G0));
 }
 
 // weight of node j of a finer level (fn nodes) on node Jc of the next one (cn nodes), whose node Jc sits on the finer level's node 2 Jc
@@ -236,20 +242,29 @@ __device__ __forceinline__ MgRect mg_owned_of(const MgRect& c, int cny, int cnx,
 }
 __device__ __forceinline__ bool mg_in(const MgRect& r, int i, int j) { return i >= r.i0 && i < r.i1 && j >= r.j0 && j < r.j1; }
 
-// level-0 right-hand side of node (I, J) from the tiles' partial sums (k_precond_tile): half-group (group G' = 4 band + j', half h) holds 2 node rows x 3 node columns,
-// rows (G' - 1, G') for h = 0, (G', G' + 1) for h = 1; columns from k - j' - 1 - h for tile k.  Twelve terms, in this order.
+// level-0 right-hand side of node (I, J) from the tiles' partial sums (k_precond_tile): a group of MG_LG lanes (global lane index L = 64 band + MG_LG g, all of its rows between
+// the node rows v = (L - G0 / 2) >> LOG and v + 1) holds, per tile k, 2 node rows x MG_NSLOT node columns starting at column Jq(k, g) - [band][group][row slot][column slot][tile].
+// Node row I collects row slot 0 of the two groups with v = I and row slot 1 of the two with v = I - 1; per group the tiles whose column slots reach J.  Fixed order.
 __device__ __forceinline__ double mg_gather0(const double* __restrict__ part, int I, int J, int ntb, int band_lo, int band_hi) {
   double t = 0.0;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int Gp = q == 0 ? I + 1 : (q == 3 ? I - 1 : I), h = q >> 1, rs = q & 1 ? 1 : 0;      // (I+1, low, 0), (I, low, 1), (I, high, 0), (I-1, high, 1)
-    if (Gp < 4 * band_lo || Gp >= 4 * band_hi) continue;
-    const int b = Gp >> 2, jp = Gp & 3;
-    const double* row = part + ((size_t)(b - band_lo) * MG_PART + (2 * jp + h) * 6 + rs * 3) * ntb;      // [band][slot][tile]
+  for (int rs = 0; rs < 2; ++rs) {
+    const int v = I - rs;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const int k = J - c + jp + 1 + h;
-      if (k >= 0 && k < ntb) t = t + row[(size_t)c * ntb + k];
+    for (int h = 0; h < 2; ++h) {
+      const int L = MG_G0 * v + MG_G0 / 2 + h * MG_LG;      // first lane of the group, counted over all bands
+      if (L < 0) continue;
+      const int b = L >> 6, gq = (L & 63) / MG_LG;
+      if (b < band_lo || b >= band_hi) continue;
+      const int c0 = MG_LG * gq + MG_LG - 1 + MG_G0 / 2;      // Jq(k) = (16 k - c0) >> LOG
+      int k0 = (MG_G0 * (J - MG_NSLOT + 1) + c0 + 15) >> 4, k1 = ((MG_G0 * (J + 1) + c0 + 15) >> 4) - 1;
+      if (k0 < 0) k0 = 0;
+      if (k1 > ntb - 1) k1 = ntb - 1;
+      const double* row = part + ((size_t)(b - band_lo) * MG_PART + (size_t)(gq * 2 + rs) * MG_NSLOT) * ntb;
+      for (int k = k0; k <= k1; ++k) {
+        const int q = J - ((16 * k - c0) >> MG_LOG);
+        if (q >= 0 && q < MG_NSLOT) t = t + row[(size_t)q * ntb + k];
+      }
     }
   }
   return t;
@@ -891,7 +906,7 @@ static int launch_mg_cycle(euler_sim* S, int fin_op, int force, bool gather) {
 
 int eu_mg_solve(euler_sim* S, int fin_op, int force) { return launch_mg_cycle(S, fin_op, force, !S->has_comm); }
 
-// row slabs: from this rank's tiles, the node rows [4 band_lo - 1, 4 band_hi + 1) of level 0's right-hand side (clipped to the grid) into `dst`
+// row slabs: from this rank's tiles, the node rows [RPB band_lo - 1, RPB band_hi + 1) of level 0's right-hand side (clipped to the grid) into `dst`
 __global__ __launch_bounds__(256) void k_mg_gather_rows(const double* __restrict__ part, double* __restrict__ dst, int nx0, int row0, int row1, int ntb, int band_lo, int band_hi) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= nx0 * (row1 - row0)) return;
@@ -900,7 +915,7 @@ __global__ __launch_bounds__(256) void k_mg_gather_rows(const double* __restrict
 int eu_mg_slab_rows(euler_sim* S, int force) {
   (void)force;
   const int ny0 = S->mg_ny[0];
-  const int row0 = 4 * S->band_lo - 1 < 0 ? 0 : 4 * S->band_lo - 1, row1 = 4 * S->band_hi + 1 > ny0 ? ny0 : 4 * S->band_hi + 1;
+  const int row0 = MG_RPB * S->band_lo - 1 < 0 ? 0 : MG_RPB * S->band_lo - 1, row1 = MG_RPB * S->band_hi + 1 > ny0 ? ny0 : MG_RPB * S->band_hi + 1;
   const int cells = (row1 - row0) * S->mg_nx[0];
   if (cells > 0)
     LAUNCH(S, KC_COARSE_CYCLE, k_mg_gather_rows, dim3((cells + 255) / 256), dim3(256), S->mg_part, S->mg_xbuf + (size_t)S->bulk.rank * S->mg_xslot + 2, S->mg_nx[0], row0, row1, S->geom.T / 16,
@@ -987,7 +1002,7 @@ __global__ __launch_bounds__(256) void k_mg_null_mass(const uint8_t* __restrict_
     double fx, fy;
     mg_cell_w(x, nx0, jx0, jx1, fx);
     mg_cell_w(y, ny0, jy0, jy1, fy);
-    const int wx1 = (int)(fx * 16.0), wx0 = 16 - wx1, wy1 = (int)(fy * 16.0), wy0 = 16 - wy1;
+    const int wx1 = (int)(fx * MG_G0), wx0 = MG_G0 - wx1, wy1 = (int)(fy * MG_G0), wy0 = MG_G0 - wy1;
     for (int q = 0; q < MG_NULL_MAX && q < count; ++q) {
       if (!(mg_interp0(n0 + (size_t)q * nstride, nx0, ny0, x, y) > 0.5)) continue;
       unsigned long long* a = acc + (size_t)q * n0n;
@@ -1002,7 +1017,7 @@ __global__ __launch_bounds__(256) void k_mg_null_convert(const unsigned long lon
   const int count = (int)nullv[MG_NULL_MAX * 256];
   if (!sc->nonzero || count <= 0) return;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) m0[i] = (double)acc[i] * (1.0 / 256.0);
+  if (i < n) m0[i] = (double)acc[i] * (1.0 / ((double)MG_G0 * MG_G0));
 }
 __global__ __launch_bounds__(1024) void k_mg_null_finish(const double* __restrict__ nullv, const double* __restrict__ n0, size_t nstride, size_t n0n, double* __restrict__ m0, const PcgScalars* sc) {
   const int count = (int)nullv[MG_NULL_MAX * 256];

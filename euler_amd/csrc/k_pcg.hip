@@ -441,36 +441,42 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
       const int gcol = lane == 0 ? 0 : -63;
       // COARSE: this lane's columns in the run (pairs P0 - 1 .. P1: 20 records at most) start in aggregate column Ja, reach Ja + 1 at record
       // tb1 and Ja + 2 at record tb2 (aggregates of 16: three columns; of 64 and more: two); the lane's row decides the aggregate row
-      double cy0 = 0.0, cy1 = 0.0, cy2 = 0.0, cy3 = 0.0, ce0 = 0.0, ce1 = 0.0, ce2 = 0.0, ce3 = 0.0;
+      double cy0 = 0.0, cy1 = 0.0, cy2 = 0.0, ce0 = 0.0, ce1 = 0.0, ce2 = 0.0;
+      double cyv[MG_NI + 1], cev[MG_NI + 1];
+#pragma unroll
+      for (int q = 0; q <= MG_NI; ++q) { cyv[q] = 0.0; cev[q] = 0.0; }
       int ctb1 = 0x7fffffff, ctb2 = 0x7fffffff, cJb = 0;
       (void)cJb;
       if (COARSE == 2) {
-        // the lane's columns in the run and its window (records 2 (P0 - 1) .. 2 P1 + 1: 20 at most) lie between the node columns Jb .. Jb + 3; the column of record t lies between
-        // Jb and Jb + 1 up to record ctb1, between Jb + 1 and Jb + 2 up to ctb2, then between Jb + 2 and Jb + 3.  Nodes beyond the grid repeat the outermost one (constant there)
-        cJb = (2 * (P0 - 1) - lane - 8) >> 4;
-        ctb1 = 16 * (cJb + 1) + lane + 8; ctb2 = ctb1 + 16;
+        // the lane's columns in the run and its window (records 2 (P0 - 1) .. 2 P1 + 1: 20 at most) lie between the node columns Jb .. Jb + MG_NI (spacing MG_G0); the column of
+        // record t lies between Jb + m and Jb + m + 1 from record ctb[m] on.  Nodes beyond the grid repeat the outermost one (constant there)
+        cJb = (2 * (P0 - 1) - lane - MG_G0 / 2) >> MG_LOG;
+        ctb1 = MG_G0 * (cJb + 1) + lane + MG_G0 / 2;
         const int row = (cref.band0 + lb) * 64 + lane;
         const int hi_ = cref.nx - 1;
-        const int c0 = cJb < 0 ? 0 : (cJb < hi_ ? cJb : hi_), c1 = cJb + 1 < 0 ? 0 : (cJb + 1 < hi_ ? cJb + 1 : hi_), c2 = cJb + 2 < 0 ? 0 : (cJb + 2 < hi_ ? cJb + 2 : hi_),
-                  c3 = cJb + 3 < 0 ? 0 : (cJb + 3 < hi_ ? cJb + 3 : hi_);
         int i0, i1;
         double fy;
         mg_cell_w(row, cref.ny, i0, i1, fy);
         const double* y0 = cref.y + (size_t)i0 * cref.nx;
         const double* y1 = cref.y + (size_t)i1 * cref.nx;
-        cy0 = mg_rows(y0[c0], y1[c0], fy); cy1 = mg_rows(y0[c1], y1[c1], fy); cy2 = mg_rows(y0[c2], y1[c2], fy); cy3 = mg_rows(y0[c3], y1[c3], fy);
+#pragma unroll
+        for (int q = 0; q <= MG_NI; ++q) { const int c = cJb + q < 0 ? 0 : (cJb + q < hi_ ? cJb + q : hi_); cyv[q] = mg_rows(y0[c], y1[c], fy); }
         if (edge_lane) {      // the row across the band boundary
           const int re = row + (lane == 0 ? -1 : 1);
-          if (re >= 0 && re < 16 * cref.ny) {
+          if (re >= 0 && re < MG_G0 * cref.ny) {
             mg_cell_w(re, cref.ny, i0, i1, fy);
             y0 = cref.y + (size_t)i0 * cref.nx; y1 = cref.y + (size_t)i1 * cref.nx;
-            ce0 = mg_rows(y0[c0], y1[c0], fy); ce1 = mg_rows(y0[c1], y1[c1], fy); ce2 = mg_rows(y0[c2], y1[c2], fy); ce3 = mg_rows(y0[c3], y1[c3], fy);
+#pragma unroll
+            for (int q = 0; q <= MG_NI; ++q) { const int c = cJb + q < 0 ? 0 : (cJb + q < hi_ ? cJb + q : hi_); cev[q] = mg_rows(y0[c], y1[c], fy); }
           }
         }
       }
-      auto p0y = [&](int t, double a0, double a1, double a2, double a3) __attribute__((always_inline)) {      // (P_0 x_0) at the lane's column of record t, from a row's four node values
-        const double f = (double)((t - lane - 8) & 15) * (1.0 / 16.0);
-        return mg_lerp_x(pick3(t, ctb1, ctb2, a0, a1, a2), pick3(t, ctb1, ctb2, a1, a2, a3), f);
+      auto p0y = [&](int t, const double (&av)[MG_NI + 1]) __attribute__((always_inline)) {      // (P_0 x_0) at the lane's column of record t, from a row's node values
+        const double f = (double)((t - lane - MG_G0 / 2) & (MG_G0 - 1)) * (1.0 / MG_G0);
+        double lo = av[0], hi = av[1];
+#pragma unroll
+        for (int m = 1; m < MG_NI; ++m) { const bool in = t >= ctb1 + MG_G0 * (m - 1); lo = in ? av[m] : lo; hi = in ? av[m + 1] : hi; }
+        return mg_lerp_x(lo, hi, f);
       };
       if (COARSE == 1) {
         const int xa = 2 * (P0 - 1) - lane, Ja = (xa > 0 ? xa : 0) >> cref.shift;
@@ -518,8 +524,8 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
             d.ez1 = d.ez1 + pick3(2 * P + 1, ctb1, ctb2, ce0, ce1, ce2);
           }
           if (COARSE == 2) {
-            d.ez0 = d.ez0 + p0y(2 * P, ce0, ce1, ce2, ce3);
-            d.ez1 = d.ez1 + p0y(2 * P + 1, ce0, ce1, ce2, ce3);
+            d.ez0 = d.ez0 + p0y(2 * P, cev);
+            d.ez1 = d.ez1 + p0y(2 * P + 1, cev);
           }
         }
         if (COARSE == 1) {        // z + P y of the lane's own two cells (records 2P, 2P + 1)
@@ -527,8 +533,8 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
           d.z.y = d.z.y + pick3(2 * P + 1, ctb1, ctb2, cy0, cy1, cy2);
         }
         if (COARSE == 2) {
-          d.z.x = d.z.x + p0y(2 * P, cy0, cy1, cy2, cy3);
-          d.z.y = d.z.y + p0y(2 * P + 1, cy0, cy1, cy2, cy3);
+          d.z.x = d.z.x + p0y(2 * P, cyv);
+          d.z.y = d.z.y + p0y(2 * P + 1, cyv);
         }
       };
       auto sprime = [&](const SaPair& d) __attribute__((always_inline)) { return sw_d2{d.z.x + beta * d.so.x, d.z.y + beta * d.so.y}; };   // s' = z + beta s (main.c:674)
@@ -1379,17 +1385,17 @@ int eu_launch_tile_table(euler_sim* S) {
   return EULER_OK;
 }
 
-// the sum over a half-group of 8 lanes, in every lane of it: two quad permutes and the mirror of the half row (fixed order)
+// sums over aligned groups of lanes: two quad permutes (and the mirror of the half row), fixed order
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {
   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double half_group_sum(double v) {
+__device__ __forceinline__ double group_sum(double v) {      // over an aligned group of MG_LG lanes (k_mg.h), in every lane of it
   v = v + dpp_move<0xB1>(v);       // quad_perm [1, 0, 3, 2]
   v = v + dpp_move<0x4E>(v);       // quad_perm [2, 3, 0, 1]
-  v = v + dpp_move<0x141>(v);      // row_half_mirror
+  if (MG_LG == 8) v = v + dpp_move<0x141>(v);      // row_half_mirror
   return v;
 }
 
@@ -1544,43 +1550,51 @@ __global__ __launch_bounds__(PT_THREADS, RECOMP ? PT_RECOMP_BLOCKS : 1) void k_p
       }
       if (!a.sweeps) return;
       if (W == 16 && CMODE == 2) {
-        // multilevel mode (k_mg.hip): P_0^T r of this tile, P_0 bilinear from the nodes at the cells (16 J + 8, 16 I + 8).  Lane 16 jg + i sits in row 16 G + i (G = 4 band + jg):
-        // the lanes i < 8 of a group lie between the node rows G - 1 and G, the lanes i >= 8 between G and G + 1 - a HALF-GROUP of 8 lanes is homogeneous - and a lane's 16
-        // columns between at most three node columns, starting at nb = k - jg - 1 (i < 8) / k - jg - 2 (i >= 8).  So a lane forms three column sums, multiplies them by its two
-        // row weights, and three DPP steps add the six products over the half-group: 2 node rows x 3 node columns per half-group, 48 doubles per tile (weights in sixteenths)
-        const int i16 = lane & 15, jg = lane >> 4;
-        const bool low = i16 < 8;
-        const int I0 = 4 * band + jg - (low ? 1 : 0);
-        double wy1 = (double)(low ? i16 + 8 : i16 - 8), wy0 = 16.0 - wy1;
-        if (I0 < 0) { wy0 = 0.0; wy1 = 16.0; }
-        if (I0 >= a.cny - 1) { wy0 = 16.0; wy1 = 0.0; }
-        const int nb = k - jg - (low ? 1 : 2), tb = low ? i16 + 8 : i16 - 8;      // records < tb lie between the node columns nb, nb + 1, the others between nb + 1, nb + 2
-        const bool lft0 = nb < 0, rgt0 = nb >= a.cnx - 1, lft1 = nb + 1 < 0, rgt1 = nb + 1 >= a.cnx - 1;      // beyond the outermost nodes: constant
-        // a record's weight of the right-hand node is (j - i16 + 8) & 15 = j + b with b constant over a segment: only sum rv and sum j rv per segment are accumulated
-        double s1 = 0.0, t1 = 0.0, s2 = 0.0, t2 = 0.0;
+        // multilevel mode (k_mg.hip): P_0^T r of this tile, P_0 bilinear from the nodes at the cells (G0 J + G0 / 2, G0 I + G0 / 2), G0 = MG_G0.  The lanes of a GROUP of
+        // MG_LG = G0 / 2 (aligned: a DPP quad for G0 = 8, a half row for 16) lie between the same two node rows I0, I0 + 1; a lane's 16 columns between at most MG_NSEG + 1 node
+        // columns starting at Jb (its own), a group's between MG_NSLOT starting at Jq (the group's last lane's).  A record's weight of the right-hand node is rec + b with b
+        // constant over a segment, so a lane accumulates sum rv and sum rec rv per segment, turns them into its node-column sums, shifts them to the group's slots, multiplies
+        // by its two row weights, and log2(MG_LG) DPP steps add the products over the group: 2 node rows x MG_NSLOT node columns per group (weights in 1 / G0)
+        const int gq = lane / MG_LG;
+        const int uy = 64 * band + lane - MG_G0 / 2, I0 = uy >> MG_LOG;
+        double wy1 = (double)(uy & (MG_G0 - 1)), wy0 = (double)MG_G0 - wy1;
+        if (I0 < 0) { wy0 = 0.0; wy1 = (double)MG_G0; }
+        if (I0 >= a.cny - 1) { wy0 = (double)MG_G0; wy1 = 0.0; }
+        const int x0 = 16 * k - lane - MG_G0 / 2, Jb = x0 >> MG_LOG, tbase = MG_G0 * Jb - x0;      // tbase in (-G0, 0]: records >= tbase + G0 m lie in segment m
+        const int Jq = (16 * k - (MG_LG * gq + MG_LG - 1) - MG_G0 / 2) >> MG_LOG;
+        double sg_s[MG_NSEG], sg_t[MG_NSEG];
+#pragma unroll
+        for (int m = 0; m < MG_NSEG; ++m) { sg_s[m] = 0.0; sg_t[m] = 0.0; }
 #pragma unroll
         for (int j = 0; j < W; ++j) {
           const int cm = (int)((mm[j >> 1] >> ((j & 1) * 8)) & 0xff);
           const double rv = (cm & CM_FLUID) ? ((j & 1) ? rr[j >> 1].y : rr[j >> 1].x) : 0.0;
           const double jv = rv * (double)j;
-          const bool second = j >= tb;
-          s1 += second ? 0.0 : rv; t1 += second ? 0.0 : jv;
-          s2 += second ? rv : 0.0; t2 += second ? jv : 0.0;
+#pragma unroll
+          for (int m = 0; m < MG_NSEG; ++m) {
+            const bool in = (m == 0 || j >= tbase + MG_G0 * m) && (m == MG_NSEG - 1 || j < tbase + MG_G0 * (m + 1));
+            sg_s[m] += in ? rv : 0.0; sg_t[m] += in ? jv : 0.0;
+          }
         }
-        const double b1 = (double)(low ? 8 - i16 : 24 - i16), b2 = (double)(low ? -8 - i16 : 8 - i16);
-        double u1a = t1 + b1 * s1, u0a = 16.0 * s1 - u1a;      // first segment: weights of the nodes nb + 1 / nb
-        double u1b = t2 + b2 * s2, u0b = 16.0 * s2 - u1b;      // second segment: nb + 2 / nb + 1
-        if (lft0) { u0a = 0.0; u1a = 16.0 * s1; }
-        if (rgt0) { u0a = 16.0 * s1; u1a = 0.0; }
-        if (lft1) { u0b = 0.0; u1b = 16.0 * s2; }
-        if (rgt1) { u0b = 16.0 * s2; u1b = 0.0; }
-        const double c0 = u0a, c1 = u1a + u0b, c2 = u1b;
-        wy0 *= 1.0 / 256.0; wy1 *= 1.0 / 256.0;
-        const double p00 = half_group_sum(wy0 * c0), p01 = half_group_sum(wy0 * c1), p02 = half_group_sum(wy0 * c2);
-        const double p10 = half_group_sum(wy1 * c0), p11 = half_group_sum(wy1 * c1), p12 = half_group_sum(wy1 * c2);
-        if ((lane & 7) == 0) {      // slot-major per band, [band][slot][tile]: the gather of a node row reads consecutive tiles of one slot (coalesced), k_mg.hip mg_gather0
-          double* cp = a.cpart + ((size_t)(tile / ntb) * 48 + (lane >> 3) * 6) * ntb + k;
-          cp[0] = p00; cp[ntb] = p01; cp[2 * ntb] = p02; cp[3 * ntb] = p10; cp[4 * ntb] = p11; cp[5 * ntb] = p12;
+        double cn[MG_NSEG + 1];
+#pragma unroll
+        for (int m = 0; m <= MG_NSEG; ++m) cn[m] = 0.0;
+#pragma unroll
+        for (int m = 0; m < MG_NSEG; ++m) {
+          double u1 = sg_t[m] + (double)(-tbase - MG_G0 * m) * sg_s[m], u0 = (double)MG_G0 * sg_s[m] - u1;      // weights of the nodes Jb + m + 1 / Jb + m
+          if (Jb + m < 0) { u0 = 0.0; u1 = (double)MG_G0 * sg_s[m]; }                                             // beyond the outermost nodes: constant
+          if (Jb + m >= a.cnx - 1) { u0 = (double)MG_G0 * sg_s[m]; u1 = 0.0; }
+          cn[m] += u0; cn[m + 1] += u1;
+        }
+        const bool shifted = Jb != Jq;      // (Jb - Jq is 0 or 1)
+        wy0 *= 1.0 / (MG_G0 * MG_G0); wy1 *= 1.0 / (MG_G0 * MG_G0);
+        double* cp = a.cpart + ((size_t)(tile / ntb) * MG_PART + (size_t)gq * 2 * MG_NSLOT) * ntb + k;      // [band][group][row slot][column slot][tile]: the gather reads consecutive tiles of a slot
+#pragma unroll
+        for (int q = 0; q < MG_NSLOT; ++q) {
+          const double lo = q <= MG_NSEG ? cn[q] : 0.0, hi = q >= 1 ? cn[q - 1] : 0.0;
+          const double cs = shifted ? hi : lo;
+          const double p0 = group_sum(wy0 * cs), p1 = group_sum(wy1 * cs);
+          if (lane % MG_LG == 0) { cp[(size_t)q * ntb] = p0; cp[(size_t)(MG_NSLOT + q) * ntb] = p1; }
         }
       } else if (W == 16 && CMODE == 1) {      // P^T r of this tile: cell (lane, record k W + j) sits in column k W + j - lane; at most three coarse columns per tile
         const int xl = k * W - 63, J0 = (xl > 0 ? xl : 0) >> a.cshift;

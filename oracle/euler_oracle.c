@@ -690,16 +690,19 @@ static void coarse_correction(eo_sim* s, const double* r, double* z) {
 }
 
 /* EXTENSION (multilevel, euler_oracle.h coarse_mg; round 5: bilinear coarse spaces): z += P_0 V(P_0^T r).
- * Level 0: a node per 16 x 16 grid cells, at the centre of cell (16 J + 8, 16 I + 8) (nx0 = ceil(X / 16), ny0 = 4 ceil(Y / 64): the product's bands); P_0 = BILINEAR interpolation
- * from the four nodes around a cell (weights in sixteenths), restricted to the fluid, constant beyond the outermost nodes.  Level l + 1: every other node of level l in both
+ * Level 0: a node per G0 x G0 grid cells (G0 = 8), at the centre of cell (G0 J + G0 / 2, G0 I + G0 / 2) (nx0 = ceil(X / G0), ny0 = (64 / G0) ceil(Y / 64): the product's bands);
+ * P_0 = BILINEAR interpolation from the four nodes around a cell (weights in 1 / G0), restricted to the fluid, constant beyond the outermost nodes.  Level l + 1: every other node of level l in both
  * directions (its node J sits on node 2 J), bilinear again (weights 1, 1/2: full weighting).  Nodes sit AT cell centres so that a hat is 0 at the neighbouring nodes.  A_0 = P_0^T A P_0, A_(l+1) = P^T A_l P: nine-point stencils, a[k][c] = the entry that couples node c = (I, J) to node (I + k / 3 - 1, J + k % 3 - 1).
  * One symmetric V-cycle: damped Jacobi (omega) from a zero guess, restricted residual, recursion, correction, Jacobi again; the top level (at most MG_TOP_MAX nodes) is
  * solved exactly (dense_factor).  Round 3-4 used piecewise constants over the same blocks (aggregation, 5-point stencils with integer entries, correction scaled by 1.7):
- * 104 / 108 PCG iterations to 1e-6 on the 1024^2 / 2048^2 tank at rest, 109 on a 512^2 dam break at impact - the bilinear spaces need 52 / 52 / 64 (tools/r05/mg_proto.py). */
+ * 104 / 108 PCG iterations to 1e-6 on the 1024^2 / 2048^2 tank at rest, 109 on a 512^2 dam break at impact - the bilinear spaces need 52 / 52 / 64 with nodes 16 cells
+ * apart and 30 / - / 39 with 8 (tools/r05/mg_proto.py). */
 typedef struct { int nx, ny; double* a[9]; double *rhs, *x, *t, *x1; } mg_level;
 typedef struct { int nlev; mg_level lv[20]; int nnull; double* n0[4]; double* m0[4]; } mg_hierarchy;      /* n0 / m0: see mg_gauge */
 #define MG_OMEGA 0.8
 #define MG_TOP_MAX 64
+#define MG_G0 8       /* level 0's node spacing in grid cells (the product: k_mg.h MG_G0) */
+#define MG_LOG 3
 static void mg_free(eo_sim* s) {
   mg_hierarchy* h = (mg_hierarchy*)s->mg;
   if (!h) return;
@@ -714,12 +717,12 @@ static void mg_alloc_level(mg_level* L, int nx, int ny) {
   for (int k = 1; k < 9; ++k) L->a[k] = L->a[0] + k * n;
   L->rhs = (double*)calloc(4 * n, sizeof(double)); L->x = L->rhs + n; L->t = L->rhs + 2 * n; L->x1 = L->rhs + 3 * n;
 }
-/* cell c of a row / column of cells against n nodes, node j AT the centre of cell 16 j + 8 (so a node's hat is 0 at the neighbouring nodes and the Galerkin operators are
- * exact nine-point stencils): the two nodes j0, j1 around the cell and the weight f of j1 (1 - f of j0), a multiple of 1 / 16; constant beyond the outermost nodes */
+/* cell c of a row / column of cells against n nodes, node j AT the centre of cell G0 j + G0 / 2 (so a node's hat is 0 at the neighbouring nodes and the Galerkin operators are
+ * exact nine-point stencils): the two nodes j0, j1 around the cell and the weight f of j1 (1 - f of j0), a multiple of 1 / G0; constant beyond the outermost nodes */
 static inline void mg_w0(int c, int n, int* j0, int* j1, double* f) {
-  const int u = c - 8;
-  int j = u >= 0 ? u >> 4 : -1;
-  double w = (double)(u - 16 * j) / 16.0;
+  const int u = c - MG_G0 / 2;
+  int j = u >= 0 ? u >> MG_LOG : -1;
+  double w = (double)(u - MG_G0 * j) / (double)MG_G0;
   if (j < 0) { j = 0; w = 0.0; }                  /* left of the first node */
   int k = j + 1;
   if (k > n - 1) { k = n - 1; w = 0.0; }          /* right of the last node */
@@ -741,11 +744,11 @@ static void mg_build(eo_sim* s, double** A_top, int* n_top, int* nx_top) {
   const int X = s->X, Y = s->Y;
   mg_free(s);
   mg_hierarchy* h = (mg_hierarchy*)calloc(1, sizeof(mg_hierarchy));
-  int nx = (X + 15) / 16, ny = 4 * ((Y + 63) / 64), l = 0;
+  int nx = (X + MG_G0 - 1) / MG_G0, ny = (64 / MG_G0) * ((Y + 63) / 64), l = 0;
   for (;; ++l) { mg_alloc_level(&h->lv[l], nx, ny); if (nx * ny <= MG_TOP_MAX) break; nx = (nx + 1) / 2; ny = (ny + 1) / 2; }
   h->nlev = l + 1;
   mg_level* L0 = &h->lv[0];
-  /* A_0 = P_0^T A P_0: x^T A x = sum_cells a_diag x_i^2 - 2 sum_edges x_i x_j with x = P_0 X; every entry is a multiple of 2^-20 - exact in any order */
+  /* A_0 = P_0^T A P_0: x^T A x = sum_cells a_diag x_i^2 - 2 sum_edges x_i x_j with x = P_0 X; every entry is a multiple of 1 / G0^4 - exact in any order */
   for (int y = 0; y < Y; ++y)
     for (int x = 0; x < X; ++x) {
       if (!FLUID(s, y, x)) continue;

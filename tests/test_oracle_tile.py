@@ -136,23 +136,24 @@ def test_multilevel_preconditioner_is_symmetric_positive():
         assert (_apply(o, 16, c) * c).sum() > 0
     o.c.coarse_mg = 0; o.c.coarse_m = 0
     d = Ma - _apply(o, 16, a)
-    # the correction lies in the coarse space: bilinear between the nodes at the cells (16 J + 8, 16 I + 8) - inside a node interval its second differences vanish
+    # the correction lies in the coarse space: bilinear between the nodes at the cells (G0 J + G0 / 2, G0 I + G0 / 2), G0 = 8 - inside a node interval its second differences vanish
+    G0 = 8
     scale = np.abs(d).max()
     assert scale > 0
     x = np.arange(1, 299)
-    same_x = ((x - 1 - 8) // 16 == (x + 1 - 8) // 16) & (x - 1 >= 8) & (x + 1 < 16 * ((300 + 15) // 16 - 1) + 8)
+    same_x = ((x - 1 - G0 // 2) // G0 == (x + 1 - G0 // 2) // G0) & (x - 1 >= G0 // 2) & (x + 1 < G0 * ((300 + G0 - 1) // G0 - 1) + G0 // 2)
     trip = fluid[:, 2:] & fluid[:, 1:-1] & fluid[:, :-2] & same_x[None, :]
     assert trip.sum() > 1000
     assert np.abs((d[:, 2:] - 2 * d[:, 1:-1] + d[:, :-2])[trip]).max() <= 1e-11 * scale
     y = np.arange(1, 199)
-    same_y = ((y - 1 - 8) // 16 == (y + 1 - 8) // 16) & (y - 1 >= 8)
+    same_y = ((y - 1 - G0 // 2) // G0 == (y + 1 - G0 // 2) // G0) & (y - 1 >= G0 // 2)
     trip = fluid[2:, :] & fluid[1:-1, :] & fluid[:-2, :] & same_y[:, None]
     assert np.abs((d[2:, :] - 2 * d[1:-1, :] + d[:-2, :])[trip]).max() <= 1e-11 * scale
 
 
 def test_pcg_with_multilevel_preconditioner_iteration_counts():
     """256^2 and 512^2 half tank from rest, tolerance parity with the reference's IC(0) (1e-5 max |p|); the iteration count stays put
-    when the grid doubles (measured 50 / 52 with the bilinear coarse spaces of round 5, 96 / 107 with round 4's aggregates; the reference's IC(0): 231 / 445)."""
+    when the grid doubles (measured 29 / 30 with the bilinear coarse spaces of round 5 on nodes 8 cells apart, 96 / 107 with round 4's aggregates; the reference's IC(0): 231 / 445)."""
     its = {}
     for n in (256, 512):
         res = {}
@@ -167,7 +168,7 @@ def test_pcg_with_multilevel_preconditioner_iteration_counts():
             res[name] = (o.p.copy(), int(o.c.last_pcg_iterations))
         assert np.abs(res["mg"][0] - res["ic0"][0]).max() <= 1e-5 * np.abs(res["ic0"][0]).max()
         its[n] = (res["ic0"][1], res["mg"][1])
-    assert its[256][1] < 0.3 * its[256][0] and its[512][1] < 0.15 * its[512][0], its
+    assert its[256][1] < 0.2 * its[256][0] and its[512][1] < 0.1 * its[512][0], its
     assert its[512][1] <= its[256][1] + 6, its
 
 
