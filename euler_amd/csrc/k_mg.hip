@@ -245,6 +245,7 @@ __device__ __forceinline__ bool mg_in(const MgRect& r, int i, int j) { return i 
 // level-0 right-hand side of node (I, J) from the tiles' partial sums (k_precond_tile): a group of MG_LG lanes (global lane index L = 64 band + MG_LG g, all of its rows between
 // the node rows v = (L - G0 / 2) >> LOG and v + 1) holds, per tile k, 2 node rows x MG_NSLOT node columns starting at column Jq(k, g) - [band][group][row slot][column slot][tile].
 // Node row I collects row slot 0 of the two groups with v = I and row slot 1 of the two with v = I - 1; per group the tiles whose column slots reach J.  Fixed order.
+#define MG_GK ((MG_G0 * MG_NSLOT + 15) / 16 + 1)
 __device__ __forceinline__ double mg_gather0(const double* __restrict__ part, int I, int J, int ntb, int band_lo, int band_hi) {
   double t = 0.0;
 #pragma unroll
@@ -257,14 +258,17 @@ __device__ __forceinline__ double mg_gather0(const double* __restrict__ part, in
       const int b = L >> 6, gq = (L & 63) / MG_LG;
       if (b < band_lo || b >= band_hi) continue;
       const int c0 = MG_LG * gq + MG_LG - 1 + MG_G0 / 2;      // Jq(k) = (16 k - c0) >> LOG
-      int k0 = (MG_G0 * (J - MG_NSLOT + 1) + c0 + 15) >> 4, k1 = ((MG_G0 * (J + 1) + c0 + 15) >> 4) - 1;
-      if (k0 < 0) k0 = 0;
-      if (k1 > ntb - 1) k1 = ntb - 1;
+      const int k0 = (MG_G0 * (J - MG_NSLOT + 1) + c0 + 15) >> 4, k1 = ((MG_G0 * (J + 1) + c0 + 15) >> 4) - 1;      // the tiles whose column slots reach J: at most MG_GK of them
       const double* row = part + ((size_t)(b - band_lo) * MG_PART + (size_t)(gq * 2 + rs) * MG_NSLOT) * ntb;
-      for (int k = k0; k <= k1; ++k) {
-        const int q = J - ((16 * k - c0) >> MG_LOG);
-        if (q >= 0 && q < MG_NSLOT) t = t + row[(size_t)q * ntb + k];
+      double v[MG_GK];
+#pragma unroll
+      for (int u = 0; u < MG_GK; ++u) {      // (every load is issued before the first sum needs one: a node's sixteen loads are in flight together)
+        const int k = k0 + u, q = J - ((16 * k - c0) >> MG_LOG);
+        const bool ok = k >= 0 && k <= k1 && k < ntb && q >= 0 && q < MG_NSLOT;
+        v[u] = ok ? row[(size_t)q * ntb + k] : 0.0;
       }
+#pragma unroll
+      for (int u = 0; u < MG_GK; ++u) t = t + v[u];
     }
   }
   return t;
@@ -602,8 +606,9 @@ __global__ __launch_bounds__(MG_DOWN_THREADS) void k_mg_down(MgDownArgs A) {
 // level 0 and recomputes what it needs of the coarser levels: x_l on `X_l`, x2 on X_l grown by one, x_(l+1) on the nodes around that.
 struct MgUpArgs {
   MgHier H;
-  int lC;                     // the level whose result the tail left in H.x (0: nothing to do but the dot product)
-  int tile, cap;              // edge of a workgroup's tile of level 0; doubles per LDS patch
+  int lC;                     // the level whose result is in H.x already (the tail's entry level; 0: nothing to do but the dot product)
+  int l0;                     // the finest level this launch computes (k_mg_up: > 0 when level 0 is left to k_mg_up0; then no dot product, no epilogue)
+  int tile, cap;              // edge of a workgroup's tile of level l0; doubles per LDS patch
   int row_lo, row_hi;         // node rows of level 0 whose x . rhs this rank adds to dot(z, r) (row slabs: the own rows)
   PcgScalars* sc;
   int fin_op, force;
@@ -637,14 +642,15 @@ __global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
   const int n_null = (int)A.nullv[MG_NULL_MAX * 256];
   const size_t n0n = (size_t)H.nx[0] * H.ny[0];
   double gv[MG_NULL_MAX] = {0.0, 0.0, 0.0, 0.0};
-  const int tiles_x = (H.nx[0] + A.tile - 1) / A.tile;
+  const int L0 = A.l0;
+  const int tiles_x = (H.nx[L0] + A.tile - 1) / A.tile;
   const int ti = blockIdx.x / tiles_x, tj = blockIdx.x % tiles_x;
   MgRect own = {ti * A.tile, (ti + 1) * A.tile, tj * A.tile, (tj + 1) * A.tile};
-  if (own.i1 > H.ny[0]) own.i1 = H.ny[0];
-  if (own.j1 > H.nx[0]) own.j1 = H.nx[0];
+  if (own.i1 > H.ny[L0]) own.i1 = H.ny[L0];
+  if (own.j1 > H.nx[L0]) own.j1 = H.nx[L0];
   auto rects = [&](int l, MgRect& X, MgRect& X2) {      // X_l: where x_l is needed; X2_l = X_l grown by one
-    MgRect x = own, x2 = mg_grow(own, H.ny[0], H.nx[0]);
-    for (int k = 1; k <= l; ++k) { x = mg_coarse_around(x2, H.ny[k], H.nx[k]); x2 = mg_grow(x, H.ny[k], H.nx[k]); }
+    MgRect x = own, x2 = mg_grow(own, H.ny[L0], H.nx[L0]);
+    for (int k = L0 + 1; k <= l; ++k) { x = mg_coarse_around(x2, H.ny[k], H.nx[k]); x2 = mg_grow(x, H.ny[k], H.nx[k]); }
     X = x; X2 = x2;
   };
   double* bx[2] = {lds, lds + A.cap};      // x of the level above / of this level, alternating
@@ -656,26 +662,26 @@ __global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
   int myl = -1, mye = 0;
 #pragma unroll
   for (int k = 0; k < 9; ++k) { a0[k] = 0.0; am[k] = 0.0; }
-  if (A.lC > 0) {
+  if (A.lC > L0) {
     MgRect X, X2;
-    rects(0, X, X2);
-    const int nx = H.nx[0];
-    const size_t n = (size_t)nx * H.ny[0];
+    rects(L0, X, X2);
+    const int nx = H.nx[L0];
+    const size_t n = (size_t)nx * H.ny[L0];
     const int w2 = mg_rw(X2), w = mg_rw(X);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int e = tid + u * MG_UP_THREADS;
-      if (e < mg_rn(X2)) { const size_t c = (size_t)(X2.i0 + e / w2) * nx + X2.j0 + e % w2; w2a[u] = H.wd[c]; r2a[u] = H.rhs[c]; }
+      if (e < mg_rn(X2)) { const size_t c = H.off[L0] + (size_t)(X2.i0 + e / w2) * nx + X2.j0 + e % w2; w2a[u] = H.wd[c]; r2a[u] = H.rhs[c]; }
     }
     if (tid < mg_rn(X)) {
       const size_t c = (size_t)(X.i0 + tid / w) * nx + X.j0 + tid % w;
-      const double* st = mg_sten(H, 0);
+      const double* st = mg_sten(H, L0);
 #pragma unroll
       for (int k = 0; k < 9; ++k) a0[k] = st[(size_t)k * n + c];
-      w0 = H.wd[c]; r0 = H.rhs[c];
+      w0 = H.wd[H.off[L0] + c]; r0 = H.rhs[H.off[L0] + c];
     }
     int off = 0;
-    for (int l = 1; l < A.lC; ++l) {
+    for (int l = L0 + 1; l < A.lC; ++l) {
       rects(l, X, X2);
       const int e = tid - off, n2 = mg_rn(X2);
       if (e >= 0 && e < n2) {
@@ -705,7 +711,7 @@ __global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
 #ifdef MG_ABL_NO_UP
   for (int l = -1; l >= 0; --l) {
 #else
-  for (int l = A.lC - 1; l >= 0; --l) {
+  for (int l = A.lC - 1; l >= L0; --l) {
 #endif
     MgRect X, X2, Xc, X2c;
     rects(l, X, X2);
@@ -726,7 +732,7 @@ __global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
       const double hi = (1.0 - fx) * e_[(I1 - Xc.i0) * cw + (J - Xc.j0)] + fx * e_[(I1 - Xc.i0) * cw + (J1 - Xc.j0)];
       b2[e] = wdv != 0.0 ? wdv * rv + ((1.0 - fy) * lo + fy * hi) : 0.0;
     };
-    if (l == 0) {
+    if (l == L0) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) { const int e = tid + u * MG_UP_THREADS; if (e < mg_rn(X2)) x2_at(e, w2a[u], r2a[u]); }
     } else if (l == myl) x2_at(mye, w2m, r2m);
@@ -744,6 +750,7 @@ __global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
       }
       const double xv = wdv != 0.0 ? b2[pe] + wdv * (rv - t) : 0.0;
       xo[e] = xv;
+      if (l == L0 && L0 > 0) { if (mg_in(own, i, j)) H.x[H.off[L0] + (size_t)i * nx + j] = xv; }      // (level 0 follows in k_mg_up0)
       if (l == 0) {
         const size_t c = (size_t)i * nx + j;
         if (n_null > 0) {
@@ -754,7 +761,7 @@ __global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
         if (i >= A.row_lo && i < A.row_hi) dv += xv * rv;
       }
     };
-    if (l == 0) { if (tid < mg_rn(X)) x_at(tid, a0, w0, r0); }
+    if (l == L0) { if (tid < mg_rn(X)) x_at(tid, a0, w0, r0); }
     else if (l == myl && mye < mg_rn(X)) x_at(mye, am, wm, rm);
     __syncthreads();
   }
@@ -769,7 +776,7 @@ __global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
       for (int q = 0; q < MG_NULL_MAX; ++q) if (q < n_null) gv[q] += A.m0[(size_t)q * n0n + c] * xv;
     }
   }
-  if (idle) return;      // (after convergence the level arrays are dead; the scalar epilogue below must not run)
+  if (idle || L0 > 0) return;      // (after convergence the level arrays are dead; the scalar epilogue below must not run.  L0 > 0: level 0, the dot product and the epilogue are k_mg_up0's)
   for (int q = 0; q < n_null && q < MG_NULL_MAX; ++q) {
     double g = q == 0 ? gv[0] : q == 1 ? gv[1] : q == 2 ? gv[2] : gv[3];
     g = eu_wave_sum(g);
@@ -836,6 +843,180 @@ __global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
   }
 }
 
+// ------------------------------------------------------------------------------------------ the big level: level 0 <-> level 1 on small workgroups
+// Level 0 holds most of the hierarchy's nodes (1024^2 of them on an 8192^2 grid).  The kernels above give a workgroup of 1024 threads one tile and hide nothing behind
+// anything - right for the small levels, whose cost is the chain of phases.  Level 0 is the opposite case: many tiles, little work in each.  These two kernels take it with
+// workgroups of 256 threads, several nodes per thread, loads issued where they are needed: five or six workgroups share a CU and one's phase waits behind another's loads
+// (8192^2: 101 + 87 us for the two ends of the cycle as 1024-thread workgroups -> see DESIGN.md).
+#define MG_FINE_THREADS 256
+// k_mg_down1: level 0's right-hand side from the tiles' partial sums (GATHER) or from H.rhs (row slabs: summed over the ranks before), its residual behind the Jacobi step,
+// full weighting -> level 1's right-hand side.  A workgroup owns tile x tile nodes of level 1.
+template <bool GATHER>
+__global__ __launch_bounds__(MG_FINE_THREADS) void k_mg_down1(MgDownArgs A) {
+  extern __shared__ double lds[];
+  const MgHier& H = A.H;
+  const int tid = threadIdx.x;
+  const int nx = H.nx[0], ny = H.ny[0], cnx = H.nx[1], cny = H.ny[1];
+  const size_t n = (size_t)nx * ny;
+  const int tiles_x = (cnx + A.tile - 1) / A.tile;
+  const int ti = blockIdx.x / tiles_x, tj = blockIdx.x % tiles_x;
+  MgRect own = {ti * A.tile, (ti + 1) * A.tile, tj * A.tile, (tj + 1) * A.tile};
+  if (own.i1 > cny) own.i1 = cny;
+  if (own.j1 > cnx) own.j1 = cnx;
+  const MgRect O = mg_owned_of(own, cny, cnx, ny, nx), T = mg_fine_of(own, ny, nx), R = mg_grow(T, ny, nx);
+  double* prhs = lds;
+  double* px1 = lds + A.cap0;
+  const double* st = mg_sten(H, 0);
+  const int w = mg_rw(R), tw = mg_rw(T);
+  for (int e = tid; e < mg_rn(R); e += MG_FINE_THREADS) {
+    const int i = R.i0 + e / w, j = R.j0 + e % w;
+    const size_t c = (size_t)i * nx + j;
+    const double v = GATHER ? mg_gather0(A.part, i, j, A.ntb, A.band_lo, A.band_hi) : H.rhs[c];
+    if (GATHER && mg_in(O, i, j)) H.rhs[c] = v;
+    prhs[e] = v;
+    px1[e] = H.wd[c] * v;
+  }
+  __syncthreads();
+  for (int e = tid; e < mg_rn(T); e += MG_FINE_THREADS) {
+    const int i = T.i0 + e / tw, j = T.j0 + e % tw;
+    const size_t c = (size_t)i * nx + j;
+    const int pe = (i - R.i0) * w + (j - R.j0);
+    const double d = st[(size_t)4 * n + c];
+    const double t = mg_apply_patch(st, n, c, i, j, ny, nx, px1, R);
+    prhs[pe] = d != 0.0 ? prhs[pe] - t : 0.0;
+  }
+  __syncthreads();
+  const int ow = mg_rw(own);
+  for (int e = tid; e < mg_rn(own); e += MG_FINE_THREADS) {
+    const int I = own.i0 + e / ow, J = own.j0 + e % ow;
+    double t = 0.0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const double wgt = mg_w1(I, 2 * I + dy, ny, cny) * mg_w1(J, 2 * J + dx, nx, cnx);
+        if (wgt != 0.0) t = t + wgt * prhs[(2 * I + dy - R.i0) * w + (2 * J + dx - R.j0)];
+      }
+    H.rhs[H.off[1] + (size_t)I * cnx + J] = t;
+  }
+}
+
+// k_mg_up0: level 0's result from level 1's (H.x), x_0 . rhs_0 into dot(z, r), the scalar epilogue, the gauge of cut-off regions (k_mg_up's last part, for level 0).
+// A workgroup owns tile x tile nodes of level 0.
+__global__ __launch_bounds__(MG_FINE_THREADS) void k_mg_up0(MgUpArgs A) {
+  extern __shared__ double lds[];
+  __shared__ double s_red[MG_FINE_THREADS / 64];
+  __shared__ int s_last;
+  const MgHier& H = A.H;
+  const int tid = threadIdx.x;
+  const bool idle = !A.force && (A.sc->done || !A.sc->nonzero);      // read first, consulted last
+  const int n_null = (int)A.nullv[MG_NULL_MAX * 256];
+  const int nx = H.nx[0], ny = H.ny[0], cnx = H.nx[1], cny = H.ny[1];
+  const size_t n0n = (size_t)nx * ny;
+  double gv[MG_NULL_MAX] = {0.0, 0.0, 0.0, 0.0};
+  const int tiles_x = (nx + A.tile - 1) / A.tile;
+  const int ti = blockIdx.x / tiles_x, tj = blockIdx.x % tiles_x;
+  MgRect X = {ti * A.tile, (ti + 1) * A.tile, tj * A.tile, (tj + 1) * A.tile};
+  if (X.i1 > ny) X.i1 = ny;
+  if (X.j1 > nx) X.j1 = nx;
+  const MgRect X2 = mg_grow(X, ny, nx), Xc = mg_coarse_around(X2, cny, cnx);
+  double* e_ = lds;                  // level 1's result on Xc
+  double* b2 = lds + A.cap;          // x2 on X2
+  const double* st = mg_sten(H, 0);
+  const int w2 = mg_rw(X2), cw = mg_rw(Xc), w = mg_rw(X);
+  for (int e = tid; e < mg_rn(Xc); e += MG_FINE_THREADS) e_[e] = H.x[H.off[1] + (size_t)(Xc.i0 + e / cw) * cnx + Xc.j0 + e % cw];
+  __syncthreads();
+  for (int e = tid; e < mg_rn(X2); e += MG_FINE_THREADS) {
+    const int i = X2.i0 + e / w2, j = X2.j0 + e % w2;
+    const size_t c = (size_t)i * nx + j;
+    const double wdv = H.wd[c], rv = H.rhs[c];
+    const int I = i >> 1, J = j >> 1;
+    const bool oy = (i & 1) && I + 1 <= cny - 1, ox = (j & 1) && J + 1 <= cnx - 1;
+    const int I1 = oy ? I + 1 : I, J1 = ox ? J + 1 : J;
+    const double fy = oy ? 0.5 : 0.0, fx = ox ? 0.5 : 0.0;
+    const double lo = (1.0 - fx) * e_[(I - Xc.i0) * cw + (J - Xc.j0)] + fx * e_[(I - Xc.i0) * cw + (J1 - Xc.j0)];
+    const double hi = (1.0 - fx) * e_[(I1 - Xc.i0) * cw + (J - Xc.j0)] + fx * e_[(I1 - Xc.i0) * cw + (J1 - Xc.j0)];
+    b2[e] = wdv != 0.0 ? wdv * rv + ((1.0 - fy) * lo + fy * hi) : 0.0;
+  }
+  __syncthreads();
+  double dv = 0.0;
+  for (int e = tid; e < mg_rn(X); e += MG_FINE_THREADS) {
+    const int i = X.i0 + e / w, j = X.j0 + e % w;
+    const size_t c = (size_t)i * nx + j;
+    const double wdv = H.wd[c], rv = H.rhs[c];
+    const double t = mg_apply_patch(st, n0n, c, i, j, ny, nx, b2, X2);
+    const double xv = wdv != 0.0 ? b2[(i - X2.i0) * w2 + (j - X2.j0)] + wdv * (rv - t) : 0.0;
+    if (n_null > 0) {
+      mg_st_agent(H.x + c, xv);
+#pragma unroll
+      for (int q = 0; q < MG_NULL_MAX; ++q) if (q < n_null) gv[q] += A.m0[(size_t)q * n0n + c] * xv;
+    } else H.x[c] = xv;
+    if (i >= A.row_lo && i < A.row_hi) dv += xv * rv;
+  }
+  if (idle) return;      // (after convergence the level arrays are dead; the scalar epilogue below must not run)
+  for (int q = 0; q < n_null && q < MG_NULL_MAX; ++q) {
+    double g = q == 0 ? gv[0] : q == 1 ? gv[1] : q == 2 ? gv[2] : gv[3];
+    g = eu_wave_sum(g);
+    __syncthreads();
+    if ((tid & 63) == 0) s_red[tid >> 6] = g;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int k = 0; k < MG_FINE_THREADS / 64; ++k) t += s_red[k];
+      mg_st_agent(A.dot_part + (size_t)(1 + q) * MG_DOT_BLOCKS + blockIdx.x, t);
+    }
+  }
+  dv = eu_wave_sum(dv);
+  __syncthreads();
+  if ((tid & 63) == 0) s_red[tid >> 6] = dv;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int k = 0; k < MG_FINE_THREADS / 64; ++k) t += s_red[k];
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(&A.dot_part[blockIdx.x]), (unsigned long long)__double_as_longlong(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  for (int q = 0; q < n_null && q < MG_NULL_MAX; ++q) {      // the gauge: every workgroup's x_0 is in memory (agent-scope stores, drained before the tickets)
+    double g = 0.0;
+    for (unsigned int k = tid; k < gridDim.x; k += MG_FINE_THREADS) g += mg_ld_agent(A.dot_part + (size_t)(1 + q) * MG_DOT_BLOCKS + k);
+    g = eu_wave_sum(g);
+    __syncthreads();
+    if ((tid & 63) == 0) s_red[tid >> 6] = g;
+    __syncthreads();
+    double tot = 0.0;
+    for (int k = 0; k < MG_FINE_THREADS / 64; ++k) tot += s_red[k];
+    const double mn = A.m0[(size_t)MG_NULL_MAX * n0n + q];
+    if (mn > 0.0) {
+      const double cq = tot / mn;
+      for (size_t c = tid; c < n0n; c += MG_FINE_THREADS) {
+        const double nv = A.n0[(size_t)q * A.nstride + c];
+        if (nv != 0.0) mg_st_agent(H.x + c, mg_ld_agent(H.x + c) - nv * cq);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  double t = 0.0;
+  for (unsigned int k = tid; k < gridDim.x; k += MG_FINE_THREADS)
+    t += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&A.dot_part[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  t = eu_wave_sum(t);
+  __syncthreads();
+  if ((tid & 63) == 0) s_red[tid >> 6] = t;
+  __syncthreads();
+  if (tid == 0) {
+    double v = 0.0;
+    for (int k = 0; k < MG_FINE_THREADS / 64; ++k) v += s_red[k];
+    v = A.sc->sigma_new + v;      // k_precond_tile left dot(z_tile, r) there (FIN_STORE_ONLY)
+    if (A.fin_op == MFIN_SIGMA_INIT) A.sc->sigma = v;                                                       // main.c:748
+    else if (A.fin_op == MFIN_BETA) { A.sc->sigma_new = v; A.sc->beta = v / A.sc->sigma; A.sc->sigma = v; }   // main.c:762-765
+    else A.sc->sigma_new = v;
+    __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ host side
 static inline int mg_entry_level(const euler_sim* S) {      // the first level of <= MG_TAIL_MAX nodes: where the one-workgroup tail takes over
   int l = 0;
@@ -853,7 +1034,9 @@ static int mg_set_lds(const void* fn, size_t bytes) {
   return EULER_OK;
 }
 
-// the cycle: H.rhs[level 0] -> H.x[level 0]; `gather`: level 0's right-hand side comes from the tiles' partial sums (else it is in H.rhs already)
+// the cycle: H.rhs[level 0] -> H.x[level 0]; `gather`: level 0's right-hand side comes from the tiles' partial sums (else it is in H.rhs already).
+// Level 0 of more than MG_TAIL_MAX nodes: k_mg_down1, k_mg_down<false> x 1 .. 2 (the last one with the tail), k_mg_up for the levels between, k_mg_up0.  A small level 0 (grids up
+// to 256^2): k_mg_down<gather> with the tail, then k_mg_up for the dot product alone.
 static int launch_mg_cycle(euler_sim* S, int fin_op, int force, bool gather) {
   eu_prof_begin(S, KC_COARSE_CYCLE);      // ONE event pair around the whole cycle
   const MgHier H = mg_hier(S);
@@ -861,44 +1044,62 @@ static int launch_mg_cycle(euler_sim* S, int fin_op, int force, bool gather) {
   if (S->mg_levels - 1 - lC > MG_TAIL_LEVELS) { eu_set_error("multilevel preconditioner: %d levels behind the entry level (at most %d)", S->mg_levels - 1 - lC, MG_TAIL_LEVELS); return EULER_EINVAL; }
   unsigned int* tick_down = reinterpret_cast<unsigned int*>(S->mg_dot + (1 + MG_NULL_MAX) * MG_DOT_BLOCKS + 1);
   unsigned int* tick_up = reinterpret_cast<unsigned int*>(S->mg_dot + (1 + MG_NULL_MAX) * MG_DOT_BLOCKS);
-  int lA = 0;
-  bool first = true;
-  do {
+  auto down_args = [&](int lA, int lB) {
     MgDownArgs A;
-    A.H = H; A.lA = lA;
-    A.lB = first ? (lC < 1 ? lC : 1) : (lA + 3 < lC ? lA + 3 : lC);
-    const int steps = A.lB - A.lA;
+    A.H = H; A.lA = lA; A.lB = lB;
+    const int steps = lB - lA;
     A.tile = steps == 3 ? 4 : steps == 2 ? 8 : steps == 1 ? 16 : 32;
     int e = A.tile, c[4] = {0, 0, 0, 0};
     c[steps] = e * e;
     for (int k = steps - 1; k >= 0; --k) { e = 2 * e + 3; c[k] = e * e; }
     A.cap0 = c[0] > c[2] ? c[0] : c[2]; A.cap1 = c[1] > c[3] ? c[1] : c[3];
-    A.tail = A.lB == lC;
+    A.tail = lB == lC;
     A.part = S->mg_part; A.ntb = S->geom.T / 16; A.band_lo = S->band_lo; A.band_hi = S->band_hi;
     A.inv = S->cc_inv; A.ticket = tick_down; A.sc = S->sc;
+    return A;
+  };
+  auto launch_down = [&](const MgDownArgs& A, bool g) -> int {
     size_t lds = 2 * ((size_t)A.cap0 + A.cap1) * sizeof(double);
     if (A.tail) { const size_t t = mg_tail_lds(S, A.lB); if (t > lds) lds = t; }
     const unsigned nblk = (unsigned)(((S->mg_nx[A.lB] + A.tile - 1) / A.tile) * ((S->mg_ny[A.lB] + A.tile - 1) / A.tile));
-    if (first && gather) {
-      int rc = mg_set_lds(reinterpret_cast<const void*>(&k_mg_down<true>), lds); if (rc) return rc;
-      hipLaunchKernelGGL(k_mg_down<true>, dim3(nblk), dim3(MG_DOWN_THREADS), lds, S->stream, A);
-    } else {
-      int rc = mg_set_lds(reinterpret_cast<const void*>(&k_mg_down<false>), lds); if (rc) return rc;
-      hipLaunchKernelGGL(k_mg_down<false>, dim3(nblk), dim3(MG_DOWN_THREADS), lds, S->stream, A);
+    if (g) { int rc = mg_set_lds(reinterpret_cast<const void*>(&k_mg_down<true>), lds); if (rc) return rc; hipLaunchKernelGGL(k_mg_down<true>, dim3(nblk), dim3(MG_DOWN_THREADS), lds, S->stream, A); }
+    else { int rc = mg_set_lds(reinterpret_cast<const void*>(&k_mg_down<false>), lds); if (rc) return rc; hipLaunchKernelGGL(k_mg_down<false>, dim3(nblk), dim3(MG_DOWN_THREADS), lds, S->stream, A); }
+    return EULER_OK;
+  };
+  MgUpArgs U;
+  U.H = H; U.lC = lC; U.l0 = 0; U.tile = 32; U.cap = 36 * 36;
+  U.row_lo = 0; U.row_hi = S->mg_ny[0];
+  U.sc = S->sc; U.fin_op = fin_op; U.force = force; U.dot_part = S->mg_dot; U.ticket = tick_up;
+  U.nullv = S->cc_null; U.n0 = S->mg_null0; U.m0 = S->mg_m0; U.nstride = S->mg_cells;
+  const unsigned nblk0 = (unsigned)(((S->mg_nx[0] + 31) / 32) * ((S->mg_ny[0] + 31) / 32));
+  if (nblk0 > MG_DOT_BLOCKS) { eu_set_error("multilevel preconditioner: %u tiles of level 0 (at most %d)", nblk0, MG_DOT_BLOCKS); return EULER_EINVAL; }
+  if (lC == 0) {      // level 0 is small: one launch down (its last workgroup runs everything), one for the dot product
+    int rc = launch_down(down_args(0, 0), gather);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_mg_up, dim3(nblk0), dim3(MG_UP_THREADS), 3 * (size_t)U.cap * sizeof(double), S->stream, U);
+  } else {
+    {      // level 0 -> 1 on small workgroups
+      MgDownArgs A = down_args(0, 1);
+      A.tail = 0;
+      const size_t lds = 2 * (size_t)A.cap0 * sizeof(double);
+      const unsigned nblk = (unsigned)(((S->mg_nx[1] + A.tile - 1) / A.tile) * ((S->mg_ny[1] + A.tile - 1) / A.tile));
+      if (gather) hipLaunchKernelGGL(k_mg_down1<true>, dim3(nblk), dim3(MG_FINE_THREADS), lds, S->stream, A);
+      else hipLaunchKernelGGL(k_mg_down1<false>, dim3(nblk), dim3(MG_FINE_THREADS), lds, S->stream, A);
     }
-    lA = A.lB;
-    first = false;
-  } while (lA < lC);
-  {
-    MgUpArgs U;
-    U.H = H; U.lC = lC; U.tile = 32; U.cap = 36 * 36;
-    U.row_lo = 0; U.row_hi = S->mg_ny[0];
-    U.sc = S->sc; U.fin_op = fin_op; U.force = force; U.dot_part = S->mg_dot; U.ticket = tick_up;
-    U.nullv = S->cc_null; U.n0 = S->mg_null0; U.m0 = S->mg_m0; U.nstride = S->mg_cells;
-    const unsigned nblk = (unsigned)(((S->mg_nx[0] + 31) / 32) * ((S->mg_ny[0] + 31) / 32));
-    if (nblk > MG_DOT_BLOCKS) { eu_set_error("multilevel preconditioner: %u tiles of level 0 (at most %d)", nblk, MG_DOT_BLOCKS); return EULER_EINVAL; }
-    const size_t lds = 3 * (size_t)U.cap * sizeof(double);
-    hipLaunchKernelGGL(k_mg_up, dim3(nblk), dim3(MG_UP_THREADS), lds, S->stream, U);
+    int lA = 1;
+    do {      // levels 1 .. lC, three transitions per launch; the one that reaches lC goes on with the tail (lC == 1: the tail alone)
+      const int lB = lA + 3 < lC ? lA + 3 : lC;
+      int rc = launch_down(down_args(lA, lB), false);
+      if (rc) return rc;
+      lA = lB;
+    } while (lA < lC);
+    if (lC > 1) {      // back up to level 1
+      MgUpArgs V = U;
+      V.l0 = 1;
+      const unsigned nblk = (unsigned)(((S->mg_nx[1] + 31) / 32) * ((S->mg_ny[1] + 31) / 32));
+      hipLaunchKernelGGL(k_mg_up, dim3(nblk), dim3(MG_UP_THREADS), 3 * (size_t)V.cap * sizeof(double), S->stream, V);
+    }
+    hipLaunchKernelGGL(k_mg_up0, dim3(nblk0), dim3(MG_FINE_THREADS), 2 * (size_t)U.cap * sizeof(double), S->stream, U);
   }
   eu_prof_end(S, KC_COARSE_CYCLE);
   return EULER_OK;
