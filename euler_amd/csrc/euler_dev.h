@@ -191,6 +191,7 @@ struct euler_sim {
   unsigned long long* mg_a0i;        // [9][nodes of level 0]: A_0 in units of 2^-16, summed by integer atomics per solve
   double *mg_rhs, *mg_x;             // right-hand side and result of the V-cycle per level (level 0's result is what k_search_apply adds to z through P_0)
   double* mg_wd;                     // omega / diagonal per node (0: no fluid under the node), per solve
+  uint8_t* mg_inner0; double mg_ic[9];   // level 0: nodes whose stencil is deep water's (mg_ic, a constant of the node spacing), per solve
   double* mg_part;                   // [chunks][48]: per tile and half-group of 8 lanes, the weighted sums of r for 2 node rows x 3 node columns (k_precond_tile)
   double* mg_dot;                    // per-workgroup partials of x_0 . rhs_0 (+ the ticket counters behind them)
   double* mg_null0;                  // [4][mg_cells]: the indicators of cut-off regions on every level (k_mg_null_prolong)

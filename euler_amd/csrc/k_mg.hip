@@ -40,12 +40,17 @@ struct MgHier {
   double* rhs;
   double* x;
   const double* wd;                // omega / diagonal per node (0 where the node carries no fluid): the Jacobi steps multiply
+  const uint8_t* inner0;           // level 0: 1 where a node's stencil is the one of deep water (`ic`): the two level-0 kernels then load a byte instead of nine doubles
+  double ic[9], icwd;
 };
 static MgHier mg_hier(const euler_sim* S) {
   MgHier H;
   H.nl = S->mg_levels;
   for (int l = 0; l < MG_MAXLEV; ++l) { H.nx[l] = l < H.nl ? S->mg_nx[l] : 0; H.ny[l] = l < H.nl ? S->mg_ny[l] : 0; H.off[l] = l < H.nl ? (unsigned int)S->mg_off[l] : 0u; }
   H.a = S->mg_a; H.rhs = S->mg_rhs; H.x = S->mg_x; H.wd = S->mg_wd;
+  H.inner0 = S->mg_inner0;
+  for (int k = 0; k < 9; ++k) H.ic[k] = S->mg_ic[k];
+  H.icwd = MG_OMEGA / S->mg_ic[4];
   return H;
 }
 __device__ __forceinline__ const double* mg_sten(const MgHier& H, int l) { return H.a + 9 * (size_t)H.off[l]; }
@@ -72,6 +77,15 @@ int eu_mg_alloc(euler_sim* S) {
   HIPCHK(hipMemset(S->mg_rhs, 0, 3 * S->mg_cells * sizeof(double)));
   HIPCHK(hipMemset(S->mg_part, 0, (S->chunk_cap + 64) * MG_PART * sizeof(double)));
   HIPCHK(hipMemset(S->mg_null0, 0, (size_t)MG_NULL_MAX * S->mg_cells * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&S->mg_inner0, n0));
+  HIPCHK(hipMemset(S->mg_inner0, 0, n0));
+  {      // level 0's stencil under deep water: A_0 = K (x) M + M (x) K with the 1-D mass and stiffness sums of the hats (multiples of 1 / G0^2: exact)
+    double M[3] = {0, 0, 0}, K[3] = {-1.0 / MG_G0, 2.0 / MG_G0, -1.0 / MG_G0};
+    for (int k = -(MG_G0 - 1); k <= MG_G0 - 1; ++k) { const double w = 1.0 - (k < 0 ? -k : k) / (double)MG_G0; M[1] += w * w; }
+    for (int k = 0; k < MG_G0; ++k) M[0] += (1.0 - k / (double)MG_G0) * (k / (double)MG_G0);
+    M[2] = M[0];
+    for (int q = 0; q < 9; ++q) S->mg_ic[q] = K[q % 3] * M[q / 3] + M[q % 3] * K[q / 3];
+  }
   HIPCHK(hipMalloc((void**)&S->mg_m0, (MG_NULL_MAX * n0 + MG_NULL_MAX) * sizeof(double)));
   HIPCHK(hipMemset(S->mg_m0, 0, (MG_NULL_MAX * n0 + MG_NULL_MAX) * sizeof(double)));
   HIPCHK(hipMalloc((void**)&S->mg_dot, ((1 + MG_NULL_MAX) * MG_DOT_BLOCKS + 2) * sizeof(double)));      // per-workgroup partials of x_0 . rhs_0 and of the gauge sums, then the tickets of k_mg_up and k_mg_down
@@ -82,6 +96,8 @@ int eu_mg_alloc(euler_sim* S) {
 void eu_mg_release(euler_sim* S) {
   for (double* d : {S->mg_a, S->mg_rhs, S->mg_part, S->mg_dot, S->mg_xbuf, S->mg_null0, S->mg_m0}) if (d) (void)hipFree(d);
   if (S->mg_a0i) (void)hipFree(S->mg_a0i);
+  if (S->mg_inner0) (void)hipFree(S->mg_inner0);
+  S->mg_inner0 = nullptr;
   S->mg_wd = nullptr;
   S->mg_a = S->mg_rhs = S->mg_x = S->mg_part = S->mg_dot = S->mg_xbuf = S->mg_null0 = S->mg_m0 = nullptr;
   S->mg_a0i = nullptr; S->mg_xslot = 0;
@@ -243,7 +259,7 @@ __device__ __forceinline__ MgRect mg_owned_of(const MgRect& c, int cny, int cnx,
 __device__ __forceinline__ bool mg_in(const MgRect& r, int i, int j) { return i >= r.i0 && i < r.i1 && j >= r.j0 && j < r.j1; }
 
 // level-0 right-hand side of node (I, J) from the tiles' partial sums (k_precond_tile): a group of MG_LG lanes (global lane index L = 64 band + MG_LG g, all of its rows between
-// the node rows v = (L - G0 / 2) >> LOG and v + 1) holds, per tile k, 2 node rows x MG_NSLOT node columns starting at column Jq(k, g) - [band][group][row slot][column slot][tile].
+// the node rows v = (L - G0 / 2) >> LOG and v + 1) holds, per tile k, 2 node rows x MG_NSLOT node columns starting at column Jq(k, g) - [band][tile][group][row slot][column slot].
 // Node row I collects row slot 0 of the two groups with v = I and row slot 1 of the two with v = I - 1; per group the tiles whose column slots reach J.  Fixed order.
 #define MG_GK ((MG_G0 * MG_NSLOT + 15) / 16 + 1)
 __device__ __forceinline__ double mg_gather0(const double* __restrict__ part, int I, int J, int ntb, int band_lo, int band_hi) {
@@ -259,13 +275,13 @@ __device__ __forceinline__ double mg_gather0(const double* __restrict__ part, in
       if (b < band_lo || b >= band_hi) continue;
       const int c0 = MG_LG * gq + MG_LG - 1 + MG_G0 / 2;      // Jq(k) = (16 k - c0) >> LOG
       const int k0 = (MG_G0 * (J - MG_NSLOT + 1) + c0 + 15) >> 4, k1 = ((MG_G0 * (J + 1) + c0 + 15) >> 4) - 1;      // the tiles whose column slots reach J: at most MG_GK of them
-      const double* row = part + ((size_t)(b - band_lo) * MG_PART + (size_t)(gq * 2 + rs) * MG_NSLOT) * ntb;
+      const double* row = part + (size_t)(b - band_lo) * ntb * MG_PART + (size_t)(gq * 2 + rs) * MG_NSLOT;      // [band][tile][group][row slot][column slot]
       double v[MG_GK];
 #pragma unroll
       for (int u = 0; u < MG_GK; ++u) {      // (every load is issued before the first sum needs one: a node's sixteen loads are in flight together)
         const int k = k0 + u, q = J - ((16 * k - c0) >> MG_LOG);
         const bool ok = k >= 0 && k <= k1 && k < ntb && q >= 0 && q < MG_NSLOT;
-        v[u] = ok ? row[(size_t)q * ntb + k] : 0.0;
+        v[u] = ok ? row[(size_t)k * MG_PART + q] : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < MG_GK; ++u) t = t + v[u];
@@ -871,19 +887,26 @@ __global__ __launch_bounds__(MG_FINE_THREADS) void k_mg_down1(MgDownArgs A) {
   for (int e = tid; e < mg_rn(R); e += MG_FINE_THREADS) {
     const int i = R.i0 + e / w, j = R.j0 + e % w;
     const size_t c = (size_t)i * nx + j;
-    const double v = GATHER ? mg_gather0(A.part, i, j, A.ntb, A.band_lo, A.band_hi) : H.rhs[c];
+    const double v = GATHER ? mg_gather0(A.part, i, j, A.ntb, A.band_lo, A.band_hi) : H.rhs[c];      // (a staged, band-by-band gather out of LDS was built and measured: 167 us against 90)
     if (GATHER && mg_in(O, i, j)) H.rhs[c] = v;
     prhs[e] = v;
-    px1[e] = H.wd[c] * v;
+    px1[e] = (H.inner0[c] ? H.icwd : H.wd[c]) * v;
   }
   __syncthreads();
   for (int e = tid; e < mg_rn(T); e += MG_FINE_THREADS) {
     const int i = T.i0 + e / tw, j = T.j0 + e % tw;
     const size_t c = (size_t)i * nx + j;
     const int pe = (i - R.i0) * w + (j - R.j0);
-    const double d = st[(size_t)4 * n + c];
-    const double t = mg_apply_patch(st, n, c, i, j, ny, nx, px1, R);
-    prhs[pe] = d != 0.0 ? prhs[pe] - t : 0.0;
+    if (H.inner0[c]) {      // deep water: the stencil is a constant (an interior node has all eight neighbours inside the grid)
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) t = t + H.ic[k] * px1[pe + (k / 3 - 1) * w + (k % 3 - 1)];
+      prhs[pe] = prhs[pe] - t;
+    } else {
+      const double d = st[(size_t)4 * n + c];
+      const double t = mg_apply_patch(st, n, c, i, j, ny, nx, px1, R);
+      prhs[pe] = d != 0.0 ? prhs[pe] - t : 0.0;
+    }
   }
   __syncthreads();
   const int ow = mg_rw(own);
@@ -929,7 +952,7 @@ __global__ __launch_bounds__(MG_FINE_THREADS) void k_mg_up0(MgUpArgs A) {
   for (int e = tid; e < mg_rn(X2); e += MG_FINE_THREADS) {
     const int i = X2.i0 + e / w2, j = X2.j0 + e % w2;
     const size_t c = (size_t)i * nx + j;
-    const double wdv = H.wd[c], rv = H.rhs[c];
+    const double wdv = H.inner0[c] ? H.icwd : H.wd[c], rv = H.rhs[c];
     const int I = i >> 1, J = j >> 1;
     const bool oy = (i & 1) && I + 1 <= cny - 1, ox = (j & 1) && J + 1 <= cnx - 1;
     const int I1 = oy ? I + 1 : I, J1 = ox ? J + 1 : J;
@@ -943,9 +966,15 @@ __global__ __launch_bounds__(MG_FINE_THREADS) void k_mg_up0(MgUpArgs A) {
   for (int e = tid; e < mg_rn(X); e += MG_FINE_THREADS) {
     const int i = X.i0 + e / w, j = X.j0 + e % w;
     const size_t c = (size_t)i * nx + j;
-    const double wdv = H.wd[c], rv = H.rhs[c];
-    const double t = mg_apply_patch(st, n0n, c, i, j, ny, nx, b2, X2);
-    const double xv = wdv != 0.0 ? b2[(i - X2.i0) * w2 + (j - X2.j0)] + wdv * (rv - t) : 0.0;
+    const bool inner = H.inner0[c] != 0;
+    const double wdv = inner ? H.icwd : H.wd[c], rv = H.rhs[c];
+    const int pe2 = (i - X2.i0) * w2 + (j - X2.j0);
+    double t = 0.0;
+    if (inner) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) t = t + H.ic[k] * b2[pe2 + (k / 3 - 1) * w2 + (k % 3 - 1)];
+    } else t = mg_apply_patch(st, n0n, c, i, j, ny, nx, b2, X2);
+    const double xv = wdv != 0.0 ? b2[pe2] + wdv * (rv - t) : 0.0;
     if (n_null > 0) {
       mg_st_agent(H.x + c, xv);
 #pragma unroll
@@ -1129,6 +1158,14 @@ __global__ __launch_bounds__(256) void k_mg_top_stencil(const double* __restrict
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < 9 * n) out[i] = at[i];
 }
+__global__ __launch_bounds__(256) void k_mg_inner0(MgHier H, uint8_t* __restrict__ inner) {      // a node whose nine entries are deep water's (bit for bit: both sides are exact)
+  const size_t n = (size_t)H.nx[0] * H.ny[0], c = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= n) return;
+  bool same = true;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) same = same && H.a[(size_t)k * n + c] == H.ic[k];
+  inner[c] = same ? 1 : 0;
+}
 __global__ __launch_bounds__(256) void k_mg_wd(const double* __restrict__ a, const unsigned int* offs, int nl, MgHier H, double* __restrict__ wd) {
   (void)a; (void)offs; (void)nl;
   const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -1151,6 +1188,7 @@ int eu_mg_setup(euler_sim* S) {
   for (int l = 1; l < S->mg_levels; ++l)
     LAUNCH(S, KC_PRECON_FACTOR, k_mg_coarsen, dim3((unsigned)((9 * (size_t)S->mg_nx[l] * S->mg_ny[l] + 255) / 256)), dim3(256), S->mg_a + 9 * S->mg_off[l - 1], S->mg_nx[l - 1], S->mg_ny[l - 1],
            S->mg_a + 9 * S->mg_off[l], S->mg_nx[l], S->mg_ny[l], S->sc);
+  hipLaunchKernelGGL(k_mg_inner0, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, S->stream, mg_hier(S), S->mg_inner0);
   // omega / diagonal per node of every level below the dense one: the cycle's Jacobi steps multiply
   hipLaunchKernelGGL(k_mg_wd, dim3((unsigned)(((size_t)S->mg_nx[0] * S->mg_ny[0] + 255) / 256), (unsigned)S->mg_levels), dim3(256), 0, S->stream, (const double*)nullptr, (const unsigned int*)nullptr, 0, mg_hier(S), S->mg_wd);
   return EULER_OK;

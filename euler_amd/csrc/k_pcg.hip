@@ -1455,6 +1455,8 @@ __global__ __launch_bounds__(PT_THREADS, RECOMP ? PT_RECOMP_BLOCKS : 1) void k_p
   // E^-1 of an interior tile, the same for all of them (k_tile_table): in LDS for the whole launch
   constexpr int TABP = W == 16 ? 8 : 1;
   __shared__ sw_d2 s_tab[TABP][64];
+  __shared__ double s_cpart[CMODE == 2 ? PT_THREADS / 64 : 1][CMODE == 2 ? MG_PART : 1];      // multilevel mode: a wave's partial sums on their way out
+  (void)s_cpart;
   const bool have_tab = W == 16 && listed && a.table != nullptr;
   if (have_tab) {
     for (int k = threadIdx.x; k < TABP * 64; k += PT_THREADS) (&s_tab[0][0])[k] = reinterpret_cast<const sw_d2*>(a.table)[k];
@@ -1588,14 +1590,25 @@ __global__ __launch_bounds__(PT_THREADS, RECOMP ? PT_RECOMP_BLOCKS : 1) void k_p
         }
         const bool shifted = Jb != Jq;      // (Jb - Jq is 0 or 1)
         wy0 *= 1.0 / (MG_G0 * MG_G0); wy1 *= 1.0 / (MG_G0 * MG_G0);
-        double* cp = a.cpart + ((size_t)(tile / ntb) * MG_PART + (size_t)gq * 2 * MG_NSLOT) * ntb + k;      // [band][group][row slot][column slot][tile]: the gather reads consecutive tiles of a slot
+        // the tile's MG_PART sums go out as ONE contiguous piece, [tile][group][row slot][column slot], through a row of LDS: three coalesced stores per wave instead of ten
+        // instructions of sixteen scattered doubles (8192^2: 251 -> ~210 us for the pass; the gather of k_mg.hip reads two or three neighbouring doubles per tile either way)
+        double* sp = s_cpart[threadIdx.x >> 6];
 #pragma unroll
         for (int q = 0; q < MG_NSLOT; ++q) {
           const double lo = q <= MG_NSEG ? cn[q] : 0.0, hi = q >= 1 ? cn[q - 1] : 0.0;
           const double cs = shifted ? hi : lo;
           const double p0 = group_sum(wy0 * cs), p1 = group_sum(wy1 * cs);
-          if (lane % MG_LG == 0) { cp[(size_t)q * ntb] = p0; cp[(size_t)(MG_NSLOT + q) * ntb] = p1; }
+          if (lane % MG_LG == 0) { sp[gq * 2 * MG_NSLOT + q] = p0; sp[gq * 2 * MG_NSLOT + MG_NSLOT + q] = p1; }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        {
+          double* cp = a.cpart + (size_t)tile * MG_PART;
+#pragma unroll
+          for (int u = 0; u < (MG_PART + 63) / 64; ++u) { const int e = lane + 64 * u; if (e < MG_PART) cp[e] = sp[e]; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
       } else if (W == 16 && CMODE == 1) {      // P^T r of this tile: cell (lane, record k W + j) sits in column k W + j - lane; at most three coarse columns per tile
         const int xl = k * W - 63, J0 = (xl > 0 ? xl : 0) >> a.cshift;
         double c0 = 0.0, c1 = 0.0, c2 = 0.0;
