@@ -865,6 +865,7 @@ __global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
 // workgroups of 256 threads, several nodes per thread, loads issued where they are needed: five or six workgroups share a CU and one's phase waits behind another's loads
 // (8192^2: 101 + 87 us for the two ends of the cycle as 1024-thread workgroups -> see DESIGN.md).
 #define MG_FINE_THREADS 256
+#define MG_SMALL_LEVEL0 16384      // nodes of level 0 up to which the cycle runs as two launches of the general kernels (launch_mg_cycle)
 // k_mg_down1: level 0's right-hand side from the tiles' partial sums (GATHER) or from H.rhs (row slabs: summed over the ranks before), its residual behind the Jacobi step,
 // full weighting -> level 1's right-hand side.  A workgroup owns tile x tile nodes of level 1.
 template <bool GATHER>
@@ -1102,9 +1103,18 @@ static int launch_mg_cycle(euler_sim* S, int fin_op, int force, bool gather) {
   U.nullv = S->cc_null; U.n0 = S->mg_null0; U.m0 = S->mg_m0; U.nstride = S->mg_cells;
   const unsigned nblk0 = (unsigned)(((S->mg_nx[0] + 31) / 32) * ((S->mg_ny[0] + 31) / 32));
   if (nblk0 > MG_DOT_BLOCKS) { eu_set_error("multilevel preconditioner: %u tiles of level 0 (at most %d)", nblk0, MG_DOT_BLOCKS); return EULER_EINVAL; }
-  if (lC == 0) {      // level 0 is small: one launch down (its last workgroup runs everything), one for the dot product
-    int rc = launch_down(down_args(0, 0), gather);
-    if (rc) return rc;
+  if ((size_t)S->mg_nx[0] * S->mg_ny[0] <= MG_SMALL_LEVEL0) {
+    // a small level 0 (grids up to 1024^2): the launches are the cost, not the nodes - ONE launch down (gather, every transition, its last workgroup the small levels), ONE back up
+    // with the dot product (1024^2: 6 launches per iteration -> 4)
+    int lA = 0;
+    bool first = true;
+    do {
+      const int lB = lA + 3 < lC ? lA + 3 : lC;
+      int rc = launch_down(down_args(lA, lB), first && gather);
+      if (rc) return rc;
+      lA = lB;
+      first = false;
+    } while (lA < lC);
     hipLaunchKernelGGL(k_mg_up, dim3(nblk0), dim3(MG_UP_THREADS), 3 * (size_t)U.cap * sizeof(double), S->stream, U);
   } else {
     {      // level 0 -> 1 on small workgroups

@@ -68,21 +68,21 @@ enum {
                                 in) + one small launch.  NOT the reference's iterates; symmetric positive definite, so PCG converges to the same
                                 solution.  Restated in the oracle (eo_sim.coarse_m): GPU = oracle to rounding (tolerance, not bits: the
                                 coarse sums are formed in another order).  One GPU only; EULER_DOT_TREE. */
-  EULER_PRECOND_IC0_TILE_MG = 4 /* MULTILEVEL (round 3): the same, with the coarse correction taken from a hierarchy instead of one level,
+  EULER_PRECOND_IC0_TILE_MG = 4 /* MULTILEVEL (round 3; round 5: bilinear node grids): the same, with the coarse correction taken from a hierarchy instead of one level,
                                     z = M_tile^-1 r + P_0 V(P_0^T r),
-                                P_0 = piecewise constants over aggregates of 16 x 16 grid cells (the tile width) restricted to the fluid, V = one
-                                symmetric V-cycle over 2 x 2 aggregations 16 -> 32 -> ... -> 64 m (Galerkin 5-point stencils with integer
-                                entries; damped Jacobi 0.8 before and after, correction scaled by 1.5), the top level (<= 256 cells) solved
-                                with the dense inverse of the two-level mode.  The number of iterations to the reference's tolerance no longer
-                                grows with the grid: ~100-130 where the reference's IC(0) needs 231 (256^2), 880 (1024^2), thousands (8192^2).
-                                Cost per iteration: the tile-local mode's two passes + a dozen launches over arrays 256 times smaller than
-                                the grid.  Restated in the oracle (eo_sim.coarse_mg): GPU = oracle to rounding.  EULER_DOT_TREE.  One GPU, or row slabs without
-                                mailboxes (euler_config.slab_*): an aggregate of 16 rows belongs to one rank, so every rank contributes its rows of the
-                                level-0 operator (per solve) and of the level-0 right-hand side (per iteration, inside the G1 exchange's all-gather)
-                                and all ranks run the same V-cycle - the same bits everywhere; the operator is the single GPU's, so the iteration counts are
-                                too up to the rounding of the per-rank dot products.  Water cut off from the air (a singular system): the right-hand
-                                side is made compatible with the region's indicator on one GPU and on row slabs alike (the sums are all-reduced).
-                                Per iteration the ranks all-gather cells / 256 doubles (8 MB at 16384^2, one ncclAllGather) besides the edge rows. */
+                                level 0 = a grid of nodes 8 cells apart (node (I, J) at the centre of cell (8 J + 4, 8 I + 4)), P_0 = bilinear interpolation from the four nodes
+                                around a cell, restricted to the fluid; every further level = every other node of the one below, bilinear again (full weighting); Galerkin
+                                operators (exact nine-point stencils), one symmetric V-cycle (damped Jacobi 0.8 before and after), the top level (<= 64 nodes) solved
+                                with the dense pseudo-inverse of the two-level mode.  The number of iterations to the reference's tolerance does not grow with the grid:
+                                ~30 on a tank at rest at any size, 40-50 on moving water, where the reference's IC(0) needs 231 (256^2), 880 (1024^2), thousands (8192^2)
+                                and rounds 3-4's piecewise-constant aggregates of 16 cells needed 105-150.  Cost per iteration: the tile-local mode's two passes (+ 160
+                                doubles of partial sums per 1024-cell tile) + five launches over node grids 1/64 the size of the grid and less.  Restated in the oracle
+                                (eo_sim.coarse_mg): GPU = oracle to rounding.  EULER_DOT_TREE.  One GPU, or row slabs without mailboxes (euler_config.slab_*): per solve one
+                                all-reduce makes the level-0 operator whole (exact sums: the same bits on every rank); per iteration every rank contributes, inside the G1
+                                exchange's all-gather, what ITS tiles add to its node rows and one row either side (cells / 64 doubles over all ranks: 32 MB at 16384^2),
+                                the shares are added in rank order and all ranks run the same V-cycle - the same bits everywhere.  Water cut off from the air (a singular
+                                system): the right-hand side is made compatible with the region's indicator, and the correction is kept mean-free over the region so that
+                                the pressure's constant - which the reference's clamp p >= 0 makes observable - is the tile-local factor's, i.e. very nearly the reference's. */
 };
 
 /* IC(0) sweep implementation (same arithmetic, different schedule). */
