@@ -515,12 +515,8 @@ __device__ __forceinline__ void bin_aggregated(unsigned int* count32, bool live,
   const int qrun = __shfl(run, pl, 64);
   const bool absorbed = head && below && (lo & 1u) && qlo + 1u == lo && qhi == hi && pl + qrun == lane;
   if (head && !absorbed) {
-#ifndef EU_EXP_BIN_NOATOMIC      // (timing experiment, WRONG results)
     if (pairs) atomicAdd(reinterpret_cast<unsigned long long*>(&count32[c]), (unsigned long long)(unsigned int)run | ((unsigned long long)(unsigned int)nrun << 32));
     else atomicAdd(&count32[c], (unsigned int)run);
-#else
-    if (run == 12345) count32[c] = 1;
-#endif
   }
 }
 

@@ -559,11 +559,7 @@ __global__ __launch_bounds__(MG_DOWN_THREADS) void k_mg_down(MgDownArgs A) {
   }
   __syncthreads();
   // ---- level transitions lA -> lA + 1 -> ... -> lB
-#ifdef MG_ABL_NO_TRANS
-  for (int l = A.lA; l < A.lA; ++l) {
-#else
   for (int l = A.lA; l < A.lB; ++l) {
-#endif
     const int rel = l - A.lA, cur = rel & 1;
     MgRect R, T, O, Rc, Tc, Oc;
     rects(l, R, T, O);
@@ -613,9 +609,7 @@ __global__ __launch_bounds__(MG_DOWN_THREADS) void k_mg_down(MgDownArgs A) {
   }
   __syncthreads();
   if (!s_last) return;
-#ifndef MG_ABL_NO_TAIL      // (timing experiments, WRONG results: tools/micro/variant_file.sh)
   mg_tail(A, lds);
-#endif
 }
 
 // up: x_l = x2 + omega (rhs - A x2) / d with x2 = the Jacobi step + P x_(l+1), for the levels below the tail's entry level down to 0.  A workgroup owns a tile of
@@ -724,11 +718,7 @@ __global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
     __syncthreads();
   }
   double dv = 0.0;
-#ifdef MG_ABL_NO_UP
-  for (int l = -1; l >= 0; --l) {
-#else
   for (int l = A.lC - 1; l >= L0; --l) {
-#endif
     MgRect X, X2, Xc, X2c;
     rects(l, X, X2);
     rects(l + 1, Xc, X2c);

@@ -499,16 +499,9 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
       auto load_pair = [&](int P, SaPair& d, unsigned int m) __attribute__((always_inline)) {
         d.ez0 = d.es0 = d.ez1 = d.es1 = 0.0;
         if (P < 0 || P >= npairs) { d.z = sw_d2{0.0, 0.0}; d.so = sw_d2{0.0, 0.0}; return; }   // outside the band: never a fluid cell's neighbour
-#ifdef SA_ABL_NO_WINDOW       // timing experiment (WRONG results): the pairs before / after the run are not loaded
-        if (P < P0 || P >= P1) { d.z = sw_d2{0.0, 0.0}; d.so = sw_d2{0.0, 0.0}; return; }
-#endif
         d.z = *reinterpret_cast<const sw_d2*>(z + bbase + (size_t)P * 128);
         d.so = *reinterpret_cast<const sw_d2*>(s_old + bbase + (size_t)P * 128);
-#ifdef SA_ABL_NO_EDGE         // timing experiment (WRONG results): lanes 0 / 63 do not fetch the rows across the band boundary
-        if (false) {
-#else
         if (edge_lane) {
-#endif
           if ((m & CM_FLUID) && (m & vbit)) {
             const long long k = e0_base + (long long)P * 128;
             if (SLAB == 2 && ghost) { d.ez0 = gz[2 * P + gcol]; d.es0 = gs[2 * P + gcol]; }
@@ -927,12 +920,8 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
   // global band pipeline, which also names the hand-off rows (forwarded rank to rank when coupled)
   const int band = BWD ? a.band_lo + a.nb_local - 1 - ord : a.band_lo + ord;
   const int gord = BWD ? nb - 1 - band : band;
-#ifdef SW_ABL_FORCE_LONE      // timing experiment (WRONG results): every band runs as if it were alone - no hand-off, no helper waves
-  const bool has_prev = false, publish = false;
-#else
   const bool has_prev = ord > 0 || (a.couple && gord > 0);            // a band before us in sweep order
   const bool publish = ord + 1 < a.nb_local || (a.couple && gord + 1 < nb);
-#endif
   unsigned long long* gr_out = a.granules + (size_t)gord * a.gran_stride * 2;
   const unsigned long long* gr_in = a.granules + (size_t)(has_prev ? gord - 1 : 0) * a.gran_stride * 2;
   if (XG) {   // the band pipeline continues across GPUs: same granules, same epochs, system-scope accesses (below)
@@ -1235,9 +1224,7 @@ __global__ __launch_bounds__(192) void k_sweep_skew(SweepArgs a) {
         own = carry;
         out = carry;
         // the announce wave gathers the edge lane's entry; two rows per LDS instruction (ds_write2st64_b64)
-#ifndef SW_ABL_NO_RING         // experiment (WRONG results downstream): the compute wave does not feed the announce wave
         if (PB && (j & 1)) { ring[(j - 1) * 64] = prev_carry; ring[j * 64] = carry; }
-#endif
         prev_carry = carry;
       };
       step(std::integral_constant<int, 0>()); step(std::integral_constant<int, 1>()); step(std::integral_constant<int, 2>());

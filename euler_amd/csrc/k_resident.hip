@@ -145,9 +145,7 @@ __device__ __forceinline__ bool rs_reduce(const ResArgs& a, int nwg, double (&v)
           const bool give_up = wall_clock64() - t_start > RS_TIMEOUT_TICKS || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
           if (__any(give_up)) { failed = true; break; }      // (wave-uniform)
         }
-#ifdef RS_POLL_SLEEP      // (measured: 11.0 us per iteration with the nap, 10.7 without - one wave per workgroup polls, the others wait at the barrier)
-        __builtin_amdgcn_s_sleep(1);
-#endif
+        // (a nap between polls - __builtin_amdgcn_s_sleep(1) - measured 11.0 us per iteration against 10.7 without: one wave per workgroup polls, the others wait at the barrier)
       }
       if (failed) break;
       const double g0 = h0 ? rs_gran_val(w0) : 0.0, g1 = h1 ? rs_gran_val(w1) : 0.0, g2 = h2 ? rs_gran_val(w2) : 0.0, g3 = h3 ? rs_gran_val(w3) : 0.0;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where does the band-to-band hand-off time go?  Needs the development build of the library
-(tools/micro/variant.sh trace -DSW_TRACE_HANDOFF=1; EULER_HIP_LIB=tools/micro/lib_ablate/libeuler_hip_trace.so).  For column
+(tools/micro/variant_file.sh k_pcg trace -DSW_TRACE_HANDOFF=1; EULER_HIP_LIB=tools/micro/lib_ablate/libeuler_hip_trace.so).  For column
 block 40 of every band pair it prints: producer compute wave finished the block that completes those
 columns -> its announce wave issued the granule store -> the consumer's fetch wave deposited the block in
 LDS -> the consumer's compute wave picked it up."""
