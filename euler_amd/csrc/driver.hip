@@ -1,6 +1,7 @@
 // driver.hip — the C ABI of libeuler_hip.so (include/euler.h): handle life cycle, scenario upload,
 // the sim_step() driver (reference main.c:843-900), state access, render, measurement.
 #include "euler_dev.h"
+#include "k_mg.h"
 
 #include <math.h>
 #include <stdarg.h>
@@ -166,6 +167,8 @@ extern "C" int euler_set_option(euler_sim* S, int32_t key, int64_t value) {
     case EULER_OPT_RCCL_NO_EXCHANGE: ok = value == 0 || value == 1; if (S->rccl) when = "before euler_set_comm_rccl"; break;
     case EULER_OPT_SLAB_FUSION: ok = value == 0 || value == 1; if (S->p2p_on) when = "before euler_p2p_connect"; break;
     case EULER_OPT_RESIDENT_CAP: case EULER_OPT_GRID4_MIN_CELLS: case EULER_OPT_RESIDENT_FORCE_TIMEOUT: ok = value >= 0; break;
+    case EULER_OPT_MG_SPLIT_LEVEL: ok = value >= -1 && value < 12; break;
+    case EULER_OPT_MG_SPLIT_ACTIVE: ok = false; break;
     default: ok = value == 0 || value == 1; break;
   }
   if (!ok) { eu_set_error("euler_set_option: key %d does not take the value %lld", (int)key, (long long)value); return EULER_EINVAL; }
@@ -173,6 +176,7 @@ extern "C" int euler_set_option(euler_sim* S, int32_t key, int64_t value) {
   HIPCHK(hipStreamSynchronize(S->stream));
   S->opt[key] = value;
   if (key == EULER_OPT_P_STEPS || key == EULER_OPT_SA_RUN) S->s_ring_n = 0;      // (the next solve sets its ring up afresh)
+  if (key == EULER_OPT_MG_SPLIT_LEVEL) { eu_mg_split_release(S); S->opt[EULER_OPT_MG_SPLIT_ACTIVE] = 0; }      // (... plans its cycle afresh)
   return EULER_OK;
 }
 extern "C" int euler_get_option(euler_sim* S, int32_t key, int64_t* value) {

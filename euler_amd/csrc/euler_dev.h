@@ -196,6 +196,7 @@ struct euler_sim {
   double* mg_dot;                    // per-workgroup partials of x_0 . rhs_0 (+ the ticket counters behind them)
   double* mg_null0;                  // [4][mg_cells]: the indicators of cut-off regions on every level (k_mg_null_prolong)
   double* mg_m0;                     // [4][nodes of level 0] + [4]: P_0^T of those indicators on the cells, and m_0 . n_0 (the gauge of k_mg_up)
+  void* mg_split;                    // row slabs: the plan and buffers of the split cycle (k_mg.hip MgSplitState), built on first use
   double* mg_xbuf; int mg_xslot;     // row slabs: [ranks][mg_xslot] - every rank's {max |r|, dot(z,r), its share of the level-0 right-hand side}, ONE all-gather inside the G1 exchange
   // the resident solver (k_resident.hip): the tile-local PCG of a grid whose chunks all find a wave on the chip at once, in ONE persistent launch
   unsigned long long* res_gran;   // [2][3][768] 16-byte {value, generation} granules of its grid-wide reductions

@@ -423,7 +423,7 @@ int eu_launch_coarse_consistent(euler_sim* S) {
 int eu_coarse_comm_slots(euler_sim* S) {
   int rows = 0;
   for (int r = 0; r < S->bulk.nranks && r < 64; ++r) rows = MG_RPB * (S->part_hi[r] - S->part_lo[r]) + 2 > rows ? MG_RPB * (S->part_hi[r] - S->part_lo[r]) + 2 : rows;
-  const int slot = 2 + rows * S->mg_nx[0];
+  const int slot = eu_mg_split(S) ? eu_mg_split_nsmall(S) : 2 + rows * S->mg_nx[0];      // (the split cycle: a window of the gather level instead of level 0's rows)
   if (slot != S->mg_xslot || !S->mg_xbuf) {
     if (S->mg_xbuf) { if (hipStreamSynchronize(S->stream) != hipSuccess || hipFree(S->mg_xbuf) != hipSuccess) return -1; S->mg_xbuf = nullptr; }
     if (hipMalloc((void**)&S->mg_xbuf, (size_t)slot * S->bulk.nranks * sizeof(double)) != hipSuccess) { eu_set_error("hipMalloc of the multilevel exchange buffer failed"); return -1; }

@@ -34,6 +34,17 @@ int  eu_mg_search_init(euler_sim* S);                             // s = z + P_0
 int  eu_mg_add_row(euler_sim* S, double* row, int yrow);          // + P_0 x_0 on a compact row of cells
 int  eu_mg_null_setup(euler_sim* S);                              // per solve, behind the indicators' way down the levels: what the gauge of a cut-off region needs
 int  eu_mg_slab_rows(euler_sim* S, int force);                   // row slabs: this rank's share of level 0's right-hand side into its slot of the exchange buffer
+// row slabs, the cycle split by rows (k_mg.hip "row slabs: the cycle split by rows"): whether this handle runs it, the all-gather's doubles per rank, the neighbour messages
+// (k = 0, 1 send to the rank below / above, 2, 3 what arrived from them; doubles each: eu_mg_split_count), the ranks' {x_0 . rhs_0, gauge sums}
+bool eu_mg_split(euler_sim* S);
+int  eu_mg_split_nsmall(euler_sim* S);
+int  eu_mg_split_count(euler_sim* S);
+double* eu_mg_split_msg(euler_sim* S, int k);
+double* eu_mg_split_gc(euler_sim* S);
+int  eu_mg_split_pre(euler_sim* S);
+int  eu_mg_split_mid(euler_sim* S, int fin_op, int force, double* zrecv_lo, double* zrecv_hi);
+int  eu_mg_split_fold(euler_sim* S, int fin_op, int force);
+void eu_mg_split_release(euler_sim* S);
 
 #ifdef __HIPCC__
 // A cell's column c (or row) against n nodes, node j AT the centre of cell G0 j + G0 / 2: the node left of / at the cell and the weight f (a multiple of 1 / G0) of the next one;

@@ -94,6 +94,7 @@ int eu_mg_alloc(euler_sim* S) {
   return EULER_OK;
 }
 void eu_mg_release(euler_sim* S) {
+  eu_mg_split_release(S);
   for (double* d : {S->mg_a, S->mg_rhs, S->mg_part, S->mg_dot, S->mg_xbuf, S->mg_null0, S->mg_m0}) if (d) (void)hipFree(d);
   if (S->mg_a0i) (void)hipFree(S->mg_a0i);
   if (S->mg_inner0) (void)hipFree(S->mg_inner0);
@@ -301,6 +302,9 @@ struct MgDownArgs {
   const double* inv;          // the dense top level's inverse [n_top][n_top]
   unsigned int* ticket;
   const PcgScalars* sc;
+  // row slabs, split cycle (eu_mg_split_*): the launch covers the tile rows [tile_row0, tile_row0 + gridDim.x / tiles_x) of the output level only, and the entry level's
+  // right-hand side counts as 0 outside the rows [clip_lo, clip_hi) - this rank's share lives there, the memory beyond holds other iterations' leftovers
+  int tile_row0, clip_lo, clip_hi;
 };
 
 #define MG_DOWN_THREADS 1024
@@ -497,7 +501,7 @@ __global__ __launch_bounds__(MG_DOWN_THREADS) void k_mg_down(MgDownArgs A) {
   const MgHier& H = A.H;
   const int tid = threadIdx.x;
   const int tiles_x = (H.nx[A.lB] + A.tile - 1) / A.tile;
-  const int ti = blockIdx.x / tiles_x, tj = blockIdx.x % tiles_x;
+  const int ti = A.tile_row0 + blockIdx.x / tiles_x, tj = blockIdx.x % tiles_x;
   MgRect own = {ti * A.tile, (ti + 1) * A.tile, tj * A.tile, (tj + 1) * A.tile};
   if (own.i1 > H.ny[A.lB]) own.i1 = H.ny[A.lB];
   if (own.j1 > H.nx[A.lB]) own.j1 = H.nx[A.lB];
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(MG_DOWN_THREADS) void k_mg_down(MgDownArgs A) {
       const int i = R0.i0 + e / w, j = R0.j0 + e % w;
       const size_t c = (size_t)i * nx + j;
       w0[u] = H.wd[H.off[l] + c];
-      v0[u] = GATHER ? mg_gather0(A.part, i, j, A.ntb, A.band_lo, A.band_hi) : H.rhs[H.off[l] + c];
+      v0[u] = GATHER ? mg_gather0(A.part, i, j, A.ntb, A.band_lo, A.band_hi) : ((i >= A.clip_lo && i < A.clip_hi) ? H.rhs[H.off[l] + c] : 0.0);
     }
     double* prhs = buf[0];
     double* px1 = buf[0] + cap[0];
@@ -628,6 +632,8 @@ struct MgUpArgs {
   const double* n0;           // [MG_NULL_MAX][nstride]: their indicators on the levels (level 0 first)
   const double* m0;           // [MG_NULL_MAX][n_0]: P_0^T of their indicators on the cells; [MG_NULL_MAX * n_0 + q] = m_0 . n_0
   size_t nstride;
+  int tile_row0;              // row slabs, split cycle: the launch covers the tile rows from here on (of level l0)
+  double* slot;               // ... and k_mg_up0 leaves {x_0 . rhs_0 over the own rows, the gauge sums} HERE instead of applying them: they are summed over the ranks first (k_mg_split_fold)
 };
 #ifndef MG_UP_THREADS
 #define MG_UP_THREADS 1024
@@ -654,7 +660,7 @@ __global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
   double gv[MG_NULL_MAX] = {0.0, 0.0, 0.0, 0.0};
   const int L0 = A.l0;
   const int tiles_x = (H.nx[L0] + A.tile - 1) / A.tile;
-  const int ti = blockIdx.x / tiles_x, tj = blockIdx.x % tiles_x;
+  const int ti = A.tile_row0 + blockIdx.x / tiles_x, tj = blockIdx.x % tiles_x;
   MgRect own = {ti * A.tile, (ti + 1) * A.tile, tj * A.tile, (tj + 1) * A.tile};
   if (own.i1 > H.ny[L0]) own.i1 = H.ny[L0];
   if (own.j1 > H.nx[L0]) own.j1 = H.nx[L0];
@@ -866,7 +872,7 @@ __global__ __launch_bounds__(MG_FINE_THREADS) void k_mg_down1(MgDownArgs A) {
   const int nx = H.nx[0], ny = H.ny[0], cnx = H.nx[1], cny = H.ny[1];
   const size_t n = (size_t)nx * ny;
   const int tiles_x = (cnx + A.tile - 1) / A.tile;
-  const int ti = blockIdx.x / tiles_x, tj = blockIdx.x % tiles_x;
+  const int ti = A.tile_row0 + blockIdx.x / tiles_x, tj = blockIdx.x % tiles_x;
   MgRect own = {ti * A.tile, (ti + 1) * A.tile, tj * A.tile, (tj + 1) * A.tile};
   if (own.i1 > cny) own.i1 = cny;
   if (own.j1 > cnx) own.j1 = cnx;
@@ -878,7 +884,7 @@ __global__ __launch_bounds__(MG_FINE_THREADS) void k_mg_down1(MgDownArgs A) {
   for (int e = tid; e < mg_rn(R); e += MG_FINE_THREADS) {
     const int i = R.i0 + e / w, j = R.j0 + e % w;
     const size_t c = (size_t)i * nx + j;
-    const double v = GATHER ? mg_gather0(A.part, i, j, A.ntb, A.band_lo, A.band_hi) : H.rhs[c];      // (a staged, band-by-band gather out of LDS was built and measured: 167 us against 90)
+    const double v = GATHER ? mg_gather0(A.part, i, j, A.ntb, A.band_lo, A.band_hi) : ((i >= A.clip_lo && i < A.clip_hi) ? H.rhs[c] : 0.0);      // (a staged, band-by-band gather out of LDS was built and measured: 167 us against 90)
     if (GATHER && mg_in(O, i, j)) H.rhs[c] = v;
     prhs[e] = v;
     px1[e] = (H.inner0[c] ? H.icwd : H.wd[c]) * v;
@@ -929,7 +935,7 @@ __global__ __launch_bounds__(MG_FINE_THREADS) void k_mg_up0(MgUpArgs A) {
   const size_t n0n = (size_t)nx * ny;
   double gv[MG_NULL_MAX] = {0.0, 0.0, 0.0, 0.0};
   const int tiles_x = (nx + A.tile - 1) / A.tile;
-  const int ti = blockIdx.x / tiles_x, tj = blockIdx.x % tiles_x;
+  const int ti = A.tile_row0 + blockIdx.x / tiles_x, tj = blockIdx.x % tiles_x;
   MgRect X = {ti * A.tile, (ti + 1) * A.tile, tj * A.tile, (tj + 1) * A.tile};
   if (X.i1 > ny) X.i1 = ny;
   if (X.j1 > nx) X.j1 = nx;
@@ -969,7 +975,7 @@ __global__ __launch_bounds__(MG_FINE_THREADS) void k_mg_up0(MgUpArgs A) {
     if (n_null > 0) {
       mg_st_agent(H.x + c, xv);
 #pragma unroll
-      for (int q = 0; q < MG_NULL_MAX; ++q) if (q < n_null) gv[q] += A.m0[(size_t)q * n0n + c] * xv;
+      for (int q = 0; q < MG_NULL_MAX; ++q) if (q < n_null && i >= A.row_lo && i < A.row_hi) gv[q] += A.m0[(size_t)q * n0n + c] * xv;
     } else H.x[c] = xv;
     if (i >= A.row_lo && i < A.row_hi) dv += xv * rv;
   }
@@ -999,6 +1005,8 @@ __global__ __launch_bounds__(MG_FINE_THREADS) void k_mg_up0(MgUpArgs A) {
   }
   __syncthreads();
   if (!s_last) return;
+  if (A.slot && tid < MG_NULL_MAX) A.slot[1 + tid] = 0.0;
+  __syncthreads();
   for (int q = 0; q < n_null && q < MG_NULL_MAX; ++q) {      // the gauge: every workgroup's x_0 is in memory (agent-scope stores, drained before the tickets)
     double g = 0.0;
     for (unsigned int k = tid; k < gridDim.x; k += MG_FINE_THREADS) g += mg_ld_agent(A.dot_part + (size_t)(1 + q) * MG_DOT_BLOCKS + k);
@@ -1009,7 +1017,8 @@ __global__ __launch_bounds__(MG_FINE_THREADS) void k_mg_up0(MgUpArgs A) {
     double tot = 0.0;
     for (int k = 0; k < MG_FINE_THREADS / 64; ++k) tot += s_red[k];
     const double mn = A.m0[(size_t)MG_NULL_MAX * n0n + q];
-    if (mn > 0.0) {
+    if (A.slot) { if (tid == 0) A.slot[1 + q] = tot; }
+    else if (mn > 0.0) {
       const double cq = tot / mn;
       for (size_t c = tid; c < n0n; c += MG_FINE_THREADS) {
         const double nv = A.n0[(size_t)q * A.nstride + c];
@@ -1029,6 +1038,7 @@ __global__ __launch_bounds__(MG_FINE_THREADS) void k_mg_up0(MgUpArgs A) {
   if (tid == 0) {
     double v = 0.0;
     for (int k = 0; k < MG_FINE_THREADS / 64; ++k) v += s_red[k];
+    if (A.slot) { A.slot[0] = v; __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }      // (split cycle: the ranks' shares are summed first)
     v = A.sc->sigma_new + v;      // k_precond_tile left dot(z_tile, r) there (FIN_STORE_ONLY)
     if (A.fin_op == MFIN_SIGMA_INIT) A.sc->sigma = v;                                                       // main.c:748
     else if (A.fin_op == MFIN_BETA) { A.sc->sigma_new = v; A.sc->beta = v / A.sc->sigma; A.sc->sigma = v; }   // main.c:762-765
@@ -1057,40 +1067,51 @@ static int mg_set_lds(const void* fn, size_t bytes) {
 // the cycle: H.rhs[level 0] -> H.x[level 0]; `gather`: level 0's right-hand side comes from the tiles' partial sums (else it is in H.rhs already).
 // Level 0 of more than MG_TAIL_MAX nodes: k_mg_down1, k_mg_down<false> x 1 .. 2 (the last one with the tail), k_mg_up for the levels between, k_mg_up0.  A small level 0 (grids up
 // to 256^2): k_mg_down<gather> with the tail, then k_mg_up for the dot product alone.
+static inline unsigned int* mg_tick_down(const euler_sim* S) { return reinterpret_cast<unsigned int*>(S->mg_dot + (1 + MG_NULL_MAX) * MG_DOT_BLOCKS + 1); }
+static inline unsigned int* mg_tick_up(const euler_sim* S) { return reinterpret_cast<unsigned int*>(S->mg_dot + (1 + MG_NULL_MAX) * MG_DOT_BLOCKS); }
+static MgDownArgs mg_down_args(const euler_sim* S, const MgHier& H, int lA, int lB, int lC) {
+  MgDownArgs A;
+  A.H = H; A.lA = lA; A.lB = lB;
+  const int steps = lB - lA;
+  A.tile = steps == 3 ? 4 : steps == 2 ? 8 : steps == 1 ? 16 : 32;
+  int e = A.tile, c[4] = {0, 0, 0, 0};
+  c[steps] = e * e;
+  for (int k = steps - 1; k >= 0; --k) { e = 2 * e + 3; c[k] = e * e; }
+  A.cap0 = c[0] > c[2] ? c[0] : c[2]; A.cap1 = c[1] > c[3] ? c[1] : c[3];
+  A.tail = lB == lC;
+  A.part = S->mg_part; A.ntb = S->geom.T / 16; A.band_lo = S->band_lo; A.band_hi = S->band_hi;
+  A.inv = S->cc_inv; A.ticket = mg_tick_down(S); A.sc = S->sc;
+  A.tile_row0 = 0; A.clip_lo = 0; A.clip_hi = 0x7fffffff;
+  return A;
+}
+// rows [r0, r1) of the output level: the tile rows that cover them (split cycle); r1 < 0: the whole level
+static int mg_launch_down(euler_sim* S, MgDownArgs A, bool g, int r0 = 0, int r1 = -1) {
+  size_t lds = 2 * ((size_t)A.cap0 + A.cap1) * sizeof(double);
+  if (A.tail) { const size_t t = mg_tail_lds(S, A.lB); if (t > lds) lds = t; }
+  int trows = (S->mg_ny[A.lB] + A.tile - 1) / A.tile;
+  if (r1 >= 0) { A.tile_row0 = r0 / A.tile; trows = (r1 + A.tile - 1) / A.tile - A.tile_row0; if (trows <= 0) return EULER_OK; }
+  const unsigned nblk = (unsigned)(((S->mg_nx[A.lB] + A.tile - 1) / A.tile) * trows);
+  if (g) { int rc = mg_set_lds(reinterpret_cast<const void*>(&k_mg_down<true>), lds); if (rc) return rc; hipLaunchKernelGGL(k_mg_down<true>, dim3(nblk), dim3(MG_DOWN_THREADS), lds, S->stream, A); }
+  else { int rc = mg_set_lds(reinterpret_cast<const void*>(&k_mg_down<false>), lds); if (rc) return rc; hipLaunchKernelGGL(k_mg_down<false>, dim3(nblk), dim3(MG_DOWN_THREADS), lds, S->stream, A); }
+  return EULER_OK;
+}
+static MgUpArgs mg_up_args(const euler_sim* S, const MgHier& H, int lC, int fin_op, int force) {
+  MgUpArgs U;
+  U.H = H; U.lC = lC; U.l0 = 0; U.tile = 32; U.cap = 36 * 36;
+  U.row_lo = 0; U.row_hi = S->mg_ny[0];
+  U.sc = S->sc; U.fin_op = fin_op; U.force = force; U.dot_part = S->mg_dot; U.ticket = mg_tick_up(S);
+  U.nullv = S->cc_null; U.n0 = S->mg_null0; U.m0 = S->mg_m0; U.nstride = S->mg_cells;
+  U.tile_row0 = 0; U.slot = nullptr;
+  return U;
+}
 static int launch_mg_cycle(euler_sim* S, int fin_op, int force, bool gather) {
   eu_prof_begin(S, KC_COARSE_CYCLE);      // ONE event pair around the whole cycle
   const MgHier H = mg_hier(S);
   const int lC = mg_entry_level(S);
   if (S->mg_levels - 1 - lC > MG_TAIL_LEVELS) { eu_set_error("multilevel preconditioner: %d levels behind the entry level (at most %d)", S->mg_levels - 1 - lC, MG_TAIL_LEVELS); return EULER_EINVAL; }
-  unsigned int* tick_down = reinterpret_cast<unsigned int*>(S->mg_dot + (1 + MG_NULL_MAX) * MG_DOT_BLOCKS + 1);
-  unsigned int* tick_up = reinterpret_cast<unsigned int*>(S->mg_dot + (1 + MG_NULL_MAX) * MG_DOT_BLOCKS);
-  auto down_args = [&](int lA, int lB) {
-    MgDownArgs A;
-    A.H = H; A.lA = lA; A.lB = lB;
-    const int steps = lB - lA;
-    A.tile = steps == 3 ? 4 : steps == 2 ? 8 : steps == 1 ? 16 : 32;
-    int e = A.tile, c[4] = {0, 0, 0, 0};
-    c[steps] = e * e;
-    for (int k = steps - 1; k >= 0; --k) { e = 2 * e + 3; c[k] = e * e; }
-    A.cap0 = c[0] > c[2] ? c[0] : c[2]; A.cap1 = c[1] > c[3] ? c[1] : c[3];
-    A.tail = lB == lC;
-    A.part = S->mg_part; A.ntb = S->geom.T / 16; A.band_lo = S->band_lo; A.band_hi = S->band_hi;
-    A.inv = S->cc_inv; A.ticket = tick_down; A.sc = S->sc;
-    return A;
-  };
-  auto launch_down = [&](const MgDownArgs& A, bool g) -> int {
-    size_t lds = 2 * ((size_t)A.cap0 + A.cap1) * sizeof(double);
-    if (A.tail) { const size_t t = mg_tail_lds(S, A.lB); if (t > lds) lds = t; }
-    const unsigned nblk = (unsigned)(((S->mg_nx[A.lB] + A.tile - 1) / A.tile) * ((S->mg_ny[A.lB] + A.tile - 1) / A.tile));
-    if (g) { int rc = mg_set_lds(reinterpret_cast<const void*>(&k_mg_down<true>), lds); if (rc) return rc; hipLaunchKernelGGL(k_mg_down<true>, dim3(nblk), dim3(MG_DOWN_THREADS), lds, S->stream, A); }
-    else { int rc = mg_set_lds(reinterpret_cast<const void*>(&k_mg_down<false>), lds); if (rc) return rc; hipLaunchKernelGGL(k_mg_down<false>, dim3(nblk), dim3(MG_DOWN_THREADS), lds, S->stream, A); }
-    return EULER_OK;
-  };
-  MgUpArgs U;
-  U.H = H; U.lC = lC; U.l0 = 0; U.tile = 32; U.cap = 36 * 36;
-  U.row_lo = 0; U.row_hi = S->mg_ny[0];
-  U.sc = S->sc; U.fin_op = fin_op; U.force = force; U.dot_part = S->mg_dot; U.ticket = tick_up;
-  U.nullv = S->cc_null; U.n0 = S->mg_null0; U.m0 = S->mg_m0; U.nstride = S->mg_cells;
+  auto down_args = [&](int lA, int lB) { return mg_down_args(S, H, lA, lB, lC); };
+  auto launch_down = [&](const MgDownArgs& A, bool g) -> int { return mg_launch_down(S, A, g); };
+  const MgUpArgs U = mg_up_args(S, H, lC, fin_op, force);
   const unsigned nblk0 = (unsigned)(((S->mg_nx[0] + 31) / 32) * ((S->mg_ny[0] + 31) / 32));
   if (nblk0 > MG_DOT_BLOCKS) { eu_set_error("multilevel preconditioner: %u tiles of level 0 (at most %d)", nblk0, MG_DOT_BLOCKS); return EULER_EINVAL; }
   if ((size_t)S->mg_nx[0] * S->mg_ny[0] <= MG_SMALL_LEVEL0) {
@@ -1131,6 +1152,339 @@ static int launch_mg_cycle(euler_sim* S, int fin_op, int force, bool gather) {
     hipLaunchKernelGGL(k_mg_up0, dim3(nblk0), dim3(MG_FINE_THREADS), 2 * (size_t)U.cap * sizeof(double), S->stream, U);
   }
   eu_prof_end(S, KC_COARSE_CYCLE);
+  return EULER_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------ row slabs: the cycle split by rows (round 5)
+// Replicated, the cycle costs every rank the whole of it and an all-gather of level 0's right-hand side (cells / 64 doubles: 32 MB at 16384^2) per iteration.  Split:
+//   * the way DOWN is linear, so a rank takes what ITS tiles contribute (zero elsewhere) down to the gather level Lg (the first of <= MG_GATHER_MAX nodes) on the rows that
+//     share can reach, and the ranks all-gather WINDOWS of that level (own rows + a few): k_mg_split_unpack adds them up in rank order - the same bits everywhere;
+//   * from Lg to the dense level and back to Lg everything runs replicated as before (small);
+//   * the way back UP below Lg needs the TRUE right-hand sides on a rank's rows and their halo: the neighbours' shares on those rows (ZONES) travel with the edge rows of z
+//     in the same neighbour exchange, and every rank computes levels Lg - 1 .. 0 for its own rows (+ 1) only;
+//   * the correction's share of dot(z, r), x_0 . rhs_0, then lives on the ranks' own rows: ONE more 5-double all-gather behind the cycle (beta cannot wait for the next
+//     exchange point) - three exchange points per iteration instead of two, for a level 0 of 1 / ranks the work and an all-gather of kilobytes.
+// Needs every zone to reach into the NEXT rank only (slabs of a few bands); else - and on small grids, where level 0 is the gather level - the replicated form runs.
+#define MG_GATHER_MAX 16384
+struct MgSplitPlan {
+  int valid, Lg, ranks, rank;
+  int I[MG_MAXLEV][64][2];        // [level][rank]: the node rows a rank's own tiles can contribute to (its share's support)
+  int NR[MG_MAXLEV][2];           // this rank: the node rows whose TRUE right-hand side its way up needs
+  int NX[MG_MAXLEV][2];           // ... and the rows of x_l it computes
+  int zs[2][MG_MAXLEV][2];        // [side 0 lo / 1 hi][level]: rows of this rank's share the neighbour on that side needs
+  int zr[2][MG_MAXLEV][2];        // rows of that neighbour's share this rank needs
+  int zoff_s[2][MG_MAXLEV], zoff_r[2][MG_MAXLEV], zone_doubles;      // offsets inside a zone message, the (uniform) message length
+  int win_rows, nsmall;           // window rows per rank at level Lg (max over ranks), doubles per all-gather slot: 2 + win_rows * nx_Lg
+};
+struct MgSplitSeg { int level, row0, row1, off; };      // behind the exchange: rows of a level's right-hand side that change (a neighbour's share arrives, or leftovers must go)
+struct MgSplitDst {
+  int nseg, total, X;
+  MgSplitSeg seg[4 * MG_MAXLEV];
+  int own[MG_MAXLEV][2], zr[2][MG_MAXLEV][2], zoff[2][MG_MAXLEV];
+};
+struct MgSplitMsg { int rows[2][MG_MAXLEV][2], off[2][MG_MAXLEV]; int Lg, X, zone; };
+struct MgSplitWin { int n; int lo[64], hi[64]; };
+struct MgSplitState {
+  MgSplitPlan P;
+  MgSplitDst D;
+  MgSplitMsg M;
+  MgSplitWin W;
+  double* msg;      // [4][X + zone]: send lo / hi, receive lo / hi
+  double* gc;       // [ranks][1 + MG_NULL_MAX]: {x_0 . rhs_0 over the own rows, gauge sums}
+};
+static inline MgSplitState* mg_split_state(const euler_sim* S) { return static_cast<MgSplitState*>(S->mg_split); }
+
+static inline void mg_clip(int* r, int n) { if (r[0] < 0) r[0] = 0; if (r[1] > n) r[1] = n; if (r[1] < r[0]) r[1] = r[0]; }
+static int mg_gather_level(const euler_sim* S) {
+  const long long forced = S->opt[EULER_OPT_MG_SPLIT_LEVEL];
+  const int lC = mg_entry_level(S);
+  if (forced < 0) return 0;
+  if (forced > 0) return (int)(forced < lC ? forced : lC);
+  if ((size_t)S->mg_nx[0] * S->mg_ny[0] <= MG_SMALL_LEVEL0) return 0;
+  int l = 0;
+  while (l < lC && (size_t)S->mg_nx[l] * S->mg_ny[l] > MG_GATHER_MAX) ++l;
+  return l;
+}
+static const MgSplitPlan* mg_split_plan(euler_sim* S) {
+  if (S->mg_split) return mg_split_state(S)->P.valid ? &mg_split_state(S)->P : nullptr;
+  MgSplitState* st = new (std::nothrow) MgSplitState();
+  if (!st) return nullptr;
+  S->mg_split = st;
+  MgSplitPlan& P = st->P;
+  const int R = S->bulk.nranks, me = S->bulk.rank, Lg = mg_gather_level(S);
+  if (!S->has_comm || !S->slab_on || R > 64 || R < 2 || Lg < 1 || !S->mg_a) return nullptr;
+  P.Lg = Lg; P.ranks = R; P.rank = me;
+  for (int r = 0; r < R; ++r) {      // supports of the ranks' shares, level by level
+    int a = MG_RPB * S->part_lo[r] - 1, b = MG_RPB * S->part_hi[r] + 1;
+    for (int l = 0; l <= Lg; ++l) {
+      P.I[l][r][0] = a; P.I[l][r][1] = b;
+      mg_clip(P.I[l][r], S->mg_ny[l]);
+      a = P.I[l][r][0]; b = P.I[l][r][1];
+      const int na = (a - 2 >= 0 ? (a - 2 + 1) / 2 : 0), nb = (b + 1) / 2 + 1;      // ceil((a - 2) / 2) .. floor((b + 1) / 2)
+      a = na; b = nb;
+    }
+  }
+  {      // what this rank's way up needs
+    int x0 = MG_RPB * S->part_lo[me] - 1, x1 = MG_RPB * S->part_hi[me] + 1;
+    for (int l = 0; l < Lg; ++l) {
+      P.NX[l][0] = x0; P.NX[l][1] = x1; mg_clip(P.NX[l], S->mg_ny[l]);
+      P.NR[l][0] = P.NX[l][0] - 1; P.NR[l][1] = P.NX[l][1] + 1; mg_clip(P.NR[l], S->mg_ny[l]);
+      x0 = P.NR[l][0] >> 1; x1 = ((P.NR[l][1] - 1) >> 1) + 2;      // mg_coarse_around
+    }
+  }
+  // zones: side 0 = the rank below (me - 1), side 1 = the rank above.  What I need of a neighbour's share, what it needs of mine (its need is computed like mine)
+  int zone = 0;
+  for (int side = 0; side < 2; ++side) {
+    const int nb = side == 0 ? me - 1 : me + 1;
+    int offs = 0, offr = 0;
+    for (int l = 0; l < Lg; ++l) {
+      P.zs[side][l][0] = P.zs[side][l][1] = P.zr[side][l][0] = P.zr[side][l][1] = 0;
+      P.zoff_s[side][l] = offs; P.zoff_r[side][l] = offr;
+      if (nb < 0 || nb >= R) continue;
+      // the neighbour's need at level l
+      int x0 = MG_RPB * S->part_lo[nb] - 1, x1 = MG_RPB * S->part_hi[nb] + 1, nr[2] = {0, 0};
+      for (int k = 0; k <= l; ++k) {
+        int nx_[2] = {x0, x1}; mg_clip(nx_, S->mg_ny[k]);
+        nr[0] = nx_[0] - 1; nr[1] = nx_[1] + 1; mg_clip(nr, S->mg_ny[k]);
+        x0 = nr[0] >> 1; x1 = ((nr[1] - 1) >> 1) + 2;
+      }
+      const int s0 = P.I[l][me][0] > nr[0] ? P.I[l][me][0] : nr[0], s1 = P.I[l][me][1] < nr[1] ? P.I[l][me][1] : nr[1];
+      if (s1 > s0) { P.zs[side][l][0] = s0; P.zs[side][l][1] = s1; offs += (s1 - s0) * S->mg_nx[l]; }
+      const int r0 = P.I[l][nb][0] > P.NR[l][0] ? P.I[l][nb][0] : P.NR[l][0], r1 = P.I[l][nb][1] < P.NR[l][1] ? P.I[l][nb][1] : P.NR[l][1];
+      if (r1 > r0) { P.zr[side][l][0] = r0; P.zr[side][l][1] = r1; offr += (r1 - r0) * S->mg_nx[l]; }
+      // a zone may reach into the next rank only: the rank beyond must not contribute to what I need
+      const int far = side == 0 ? me - 2 : me + 2;
+      if (far >= 0 && far < R) {
+        const int f0 = P.I[l][far][0] > P.NR[l][0] ? P.I[l][far][0] : P.NR[l][0], f1 = P.I[l][far][1] < P.NR[l][1] ? P.I[l][far][1] : P.NR[l][1];
+        if (f1 > f0) P.valid = -1;
+      }
+    }
+    zone = offs > zone ? offs : zone; zone = offr > zone ? offr : zone;
+  }
+  int win = 0;
+  for (int r = 0; r < R; ++r) win = P.I[Lg][r][1] - P.I[Lg][r][0] > win ? P.I[Lg][r][1] - P.I[Lg][r][0] : win;
+  P.win_rows = win; P.nsmall = 2 + win * S->mg_nx[Lg];
+  // every rank must come to the same verdict and the same message length: the plan's inputs are the partition (the same everywhere), so one all-reduce of {failed, zone} settles both
+  double v[2] = {P.valid < 0 ? 1.0 : 0.0, (double)zone};
+  double* dv = S->mg_dot;      // (scratch: the partials are rewritten by the next cycle)
+  if (hipMemcpyAsync(dv, v, sizeof v, hipMemcpyHostToDevice, S->stream) != hipSuccess || S->bulk.allreduce(S->bulk.ctx, dv, 2, 1) != 0 ||
+      hipMemcpyAsync(v, dv, sizeof v, hipMemcpyDeviceToHost, S->stream) != hipSuccess || hipStreamSynchronize(S->stream) != hipSuccess) { P.valid = 0; return nullptr; }
+  if (v[0] != 0.0) { P.valid = 0; return nullptr; }
+  P.zone_doubles = (int)v[1];
+  // what the kernels either side of the exchange need of the plan
+  const int X = S->X;
+  MgSplitMsg& M = st->M;
+  M.Lg = Lg; M.X = X; M.zone = P.zone_doubles;
+  for (int side = 0; side < 2; ++side) for (int l = 0; l < MG_MAXLEV; ++l) { M.rows[side][l][0] = P.zs[side][l][0]; M.rows[side][l][1] = P.zs[side][l][1]; M.off[side][l] = P.zoff_s[side][l]; }
+  MgSplitDst& D = st->D;
+  D.nseg = 0; D.total = 0; D.X = X;
+  for (int l = 0; l < Lg; ++l) {
+    D.own[l][0] = P.I[l][me][0]; D.own[l][1] = P.I[l][me][1];
+    for (int side = 0; side < 2; ++side) { D.zr[side][l][0] = P.zr[side][l][0]; D.zr[side][l][1] = P.zr[side][l][1]; D.zoff[side][l] = P.zoff_r[side][l]; }
+    int run0 = -1;
+    for (int row = P.NR[l][0]; row <= P.NR[l][1]; ++row) {
+      const bool in = row < P.NR[l][1];
+      const bool touched = in && (!(row >= D.own[l][0] && row < D.own[l][1]) || (row >= D.zr[0][l][0] && row < D.zr[0][l][1]) || (row >= D.zr[1][l][0] && row < D.zr[1][l][1]));
+      if (touched && run0 < 0) run0 = row;
+      if (!touched && run0 >= 0) {
+        if (D.nseg >= 4 * MG_MAXLEV) { P.valid = 0; return nullptr; }
+        D.seg[D.nseg++] = MgSplitSeg{l, run0, row, D.total};
+        D.total += (row - run0) * S->mg_nx[l];
+        run0 = -1;
+      }
+    }
+  }
+  MgSplitWin& W = st->W;
+  W.n = R;
+  for (int r = 0; r < R; ++r) { W.lo[r] = P.I[Lg][r][0]; W.hi[r] = P.I[Lg][r][1]; }
+  const size_t mlen = (size_t)X + P.zone_doubles;
+  if (hipMalloc((void**)&st->msg, 4 * mlen * sizeof(double)) != hipSuccess || hipMalloc((void**)&st->gc, (size_t)R * (1 + MG_NULL_MAX) * sizeof(double)) != hipSuccess ||
+      hipMemsetAsync(st->msg, 0, 4 * mlen * sizeof(double), S->stream) != hipSuccess || hipMemsetAsync(st->gc, 0, (size_t)R * (1 + MG_NULL_MAX) * sizeof(double), S->stream) != hipSuccess) {
+    eu_set_error("hipMalloc of the split cycle's message buffers failed");
+    return nullptr;
+  }
+  P.valid = 1;
+  S->opt[EULER_OPT_MG_SPLIT_ACTIVE] = Lg;
+  return &P;
+}
+bool eu_mg_split(euler_sim* S) { return eu_is_mg(S) && mg_split_plan(S) != nullptr; }
+int eu_mg_split_nsmall(euler_sim* S) { return mg_split_state(S)->P.nsmall; }
+int eu_mg_split_count(euler_sim* S) { return S->X + mg_split_state(S)->P.zone_doubles; }
+double* eu_mg_split_msg(euler_sim* S, int k) { return mg_split_state(S)->msg + (size_t)k * ((size_t)S->X + mg_split_state(S)->P.zone_doubles); }
+double* eu_mg_split_gc(euler_sim* S) { return mg_split_state(S)->gc; }
+void eu_mg_split_release(euler_sim* S) {
+  MgSplitState* st = mg_split_state(S);
+  if (!st) return;
+  if (st->msg) (void)hipFree(st->msg);
+  if (st->gc) (void)hipFree(st->gc);
+  delete st;
+  S->mg_split = nullptr;
+}
+
+// pack: this rank's share on the rows a neighbour needs (ZONES) behind the edge row of z that k_precond_tile wrote into the message; its window of the gather level into
+// its slot of the all-gather
+__global__ __launch_bounds__(256) void k_mg_split_pack(MgHier H, MgSplitMsg M, double* __restrict__ msg_lo, double* __restrict__ msg_hi, double* __restrict__ slot, int w0, int w1, int win_rows) {
+  const int side = blockIdx.y;      // 0 / 1: the messages; 2: the window
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (side == 2) {
+    const int nx = H.nx[M.Lg];
+    if (i >= (size_t)win_rows * nx) return;
+    const int row = w0 + (int)(i / nx);
+    slot[2 + i] = row < w1 ? H.rhs[H.off[M.Lg] + (size_t)row * nx + i % nx] : 0.0;
+    return;
+  }
+  double* msg = side == 0 ? msg_lo : msg_hi;
+  const size_t e = i;
+  if (e >= (size_t)M.zone) return;
+  double v = 0.0;
+  for (int l = 0; l < M.Lg; ++l) {
+    const size_t n = (size_t)(M.rows[side][l][1] - M.rows[side][l][0]) * H.nx[l];
+    if (e >= (size_t)M.off[side][l] && e < (size_t)M.off[side][l] + n) { v = H.rhs[H.off[l] + (size_t)M.rows[side][l][0] * H.nx[l] + (e - M.off[side][l])]; break; }
+  }
+  msg[M.X + e] = v;
+}
+// unpack: (y = 0) the rows of D's segments become TRUE right-hand sides: this rank's share where its tiles reach (elsewhere the memory holds leftovers), + the lower neighbour's,
+// + the upper one's - in that order; (y = 1, 2) the neighbours' edge rows of z into the compact rows k_search_apply reads; (y = 3) the gather level, whole, from the ranks'
+// windows in rank order
+__global__ __launch_bounds__(256) void k_mg_split_unpack(MgHier H, MgSplitDst D, int Lg, const double* __restrict__ msg_lo, const double* __restrict__ msg_hi, double* __restrict__ zlo,
+                                                         double* __restrict__ zhi, const double* __restrict__ xbuf, int slotlen, MgSplitWin W) {
+  const int what = blockIdx.y;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (what == 3) {
+    const int nx = H.nx[Lg];
+    if (i >= (size_t)nx * H.ny[Lg]) return;
+    const int row = (int)(i / nx);
+    double t = 0.0;
+    for (int r = 0; r < W.n; ++r)
+      if (row >= W.lo[r] && row < W.hi[r]) t = t + xbuf[(size_t)r * slotlen + 2 + (size_t)(row - W.lo[r]) * nx + i % nx];
+    H.rhs[H.off[Lg] + i] = t;
+    return;
+  }
+  if (what == 1) { if (zlo && i < (size_t)D.X) zlo[i] = msg_lo[i]; return; }
+  if (what == 2) { if (zhi && i < (size_t)D.X) zhi[i] = msg_hi[i]; return; }
+  if (i >= (size_t)D.total) return;
+  for (int k = 0; k < D.nseg; ++k) {
+    const MgSplitSeg& s = D.seg[k];
+    const int l = s.level, nx = H.nx[l];
+    const size_t n = (size_t)(s.row1 - s.row0) * nx;
+    if (i < (size_t)s.off || i >= (size_t)s.off + n) continue;
+    const size_t e = i - s.off;
+    const int row = s.row0 + (int)(e / nx), col = (int)(e % nx);
+    double* dst = H.rhs + H.off[l] + (size_t)row * nx + col;
+    double v = (row >= D.own[l][0] && row < D.own[l][1]) ? *dst : 0.0;
+    if (row >= D.zr[0][l][0] && row < D.zr[0][l][1]) v = v + msg_lo[D.X + D.zoff[0][l] + (size_t)(row - D.zr[0][l][0]) * nx + col];
+    if (row >= D.zr[1][l][0] && row < D.zr[1][l][1]) v = v + msg_hi[D.X + D.zoff[1][l] + (size_t)(row - D.zr[1][l][0]) * nx + col];
+    *dst = v;
+    return;
+  }
+}
+// behind the cycle: the ranks' {x_0 . rhs_0 over their own rows, gauge sums} -> dot(z, r) with its epilogue; the gauge of cut-off regions on this rank's rows
+__global__ __launch_bounds__(256) void k_mg_split_fold(PcgScalars* sc, const double* __restrict__ vals, int R, int fin_op, int force, MgHier H, const double* __restrict__ nullv, const double* __restrict__ n0,
+                                                       size_t nstride, const double* __restrict__ m0, int row0, int row1) {
+  const bool idle = !force && (sc->done || !sc->nonzero);
+  if (idle) return;
+  const int n_null = (int)nullv[MG_NULL_MAX * 256];
+  const size_t n0n = (size_t)H.nx[0] * H.ny[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double v = 0.0;
+    for (int r = 0; r < R; ++r) v += vals[(size_t)r * (1 + MG_NULL_MAX)];
+    v = sc->sigma_new + v;
+    if (fin_op == MFIN_SIGMA_INIT) sc->sigma = v;
+    else if (fin_op == MFIN_BETA) { sc->sigma_new = v; sc->beta = v / sc->sigma; sc->sigma = v; }
+    else sc->sigma_new = v;
+  }
+  for (int q = 0; q < n_null && q < MG_NULL_MAX; ++q) {
+    double tot = 0.0;
+    for (int r = 0; r < R; ++r) tot += vals[(size_t)r * (1 + MG_NULL_MAX) + 1 + q];
+    const double mn = m0[(size_t)MG_NULL_MAX * n0n + q];
+    if (!(mn > 0.0)) continue;
+    const double cq = tot / mn;
+    const size_t lo = (size_t)row0 * H.nx[0], hi = (size_t)row1 * H.nx[0];
+    for (size_t c = lo + (size_t)blockIdx.x * 256 + threadIdx.x; c < hi; c += (size_t)gridDim.x * 256) {
+      const double nv = n0[(size_t)q * nstride + c];
+      if (nv != 0.0) H.x[c] = H.x[c] - nv * cq;
+    }
+  }
+}
+
+
+// the split cycle's launches.  pre: before the G1 exchange (k_precond_tile has left the tiles' partial sums and, in the messages, the edge rows of z)
+int eu_mg_split_pre(euler_sim* S) {
+  MgSplitState* st = mg_split_state(S);
+  const MgSplitPlan& P = st->P;
+  const MgHier H = mg_hier(S);
+  const int me = P.rank, Lg = P.Lg;
+  eu_prof_begin(S, KC_COARSE_CYCLE);
+  {      // level 0 -> 1 from this rank's tiles
+    MgDownArgs A = mg_down_args(S, H, 0, 1, -1);
+    A.tile_row0 = P.I[1][me][0] / A.tile;
+    const int trows = (P.I[1][me][1] + A.tile - 1) / A.tile - A.tile_row0;
+    const unsigned nblk = (unsigned)(((S->mg_nx[1] + A.tile - 1) / A.tile) * trows);
+    hipLaunchKernelGGL(k_mg_down1<true>, dim3(nblk), dim3(MG_FINE_THREADS), 2 * (size_t)A.cap0 * sizeof(double), S->stream, A);
+  }
+  for (int lA = 1; lA < Lg;) {
+    const int lB = lA + 3 < Lg ? lA + 3 : Lg;
+    MgDownArgs A = mg_down_args(S, H, lA, lB, -1);
+    A.clip_lo = P.I[lA][me][0]; A.clip_hi = P.I[lA][me][1];
+    int rc = mg_launch_down(S, A, false, P.I[lB][me][0], P.I[lB][me][1]);
+    if (rc) return rc;
+    lA = lB;
+  }
+  const size_t win = (size_t)P.win_rows * S->mg_nx[Lg], most = win > (size_t)P.zone_doubles ? win : (size_t)P.zone_doubles;
+  const size_t mlen = (size_t)S->X + P.zone_doubles;
+  hipLaunchKernelGGL(k_mg_split_pack, dim3((unsigned)((most + 255) / 256), 3), dim3(256), 0, S->stream, H, st->M, st->msg, st->msg + mlen, S->mg_xbuf + (size_t)me * P.nsmall,
+                     P.I[Lg][me][0], P.I[Lg][me][1], P.win_rows);
+  eu_prof_end(S, KC_COARSE_CYCLE);
+  return EULER_OK;
+}
+// mid: behind the exchange - the true right-hand sides, the replicated middle, the way up on the own rows; leaves {x_0 . rhs_0, gauge sums} of the own rows in this rank's slot of gc
+int eu_mg_split_mid(euler_sim* S, int fin_op, int force, double* zrecv_lo, double* zrecv_hi) {
+  MgSplitState* st = mg_split_state(S);
+  const MgSplitPlan& P = st->P;
+  const MgHier H = mg_hier(S);
+  const int me = P.rank, Lg = P.Lg, lC = mg_entry_level(S);
+  if (S->mg_levels - 1 - lC > MG_TAIL_LEVELS) { eu_set_error("multilevel preconditioner: %d levels behind the entry level (at most %d)", S->mg_levels - 1 - lC, MG_TAIL_LEVELS); return EULER_EINVAL; }
+  eu_prof_begin(S, KC_COARSE_CYCLE);
+  const size_t mlen = (size_t)S->X + P.zone_doubles, ng = (size_t)S->mg_nx[Lg] * S->mg_ny[Lg];
+  size_t most = ng > (size_t)st->D.total ? ng : (size_t)st->D.total;
+  if ((size_t)S->X > most) most = S->X;
+  hipLaunchKernelGGL(k_mg_split_unpack, dim3((unsigned)((most + 255) / 256), 4), dim3(256), 0, S->stream, H, st->D, Lg, st->msg + 2 * mlen, st->msg + 3 * mlen, S->band_lo > 0 ? zrecv_lo : nullptr,
+                     S->band_hi < S->geom.nbands ? zrecv_hi : nullptr, S->mg_xbuf, P.nsmall, st->W);
+  int lA = Lg;
+  do {      // replicated: the gather level down to the entry level, the tail, back up to the entry level
+    const int lB = lA + 3 < lC ? lA + 3 : lC;
+    int rc = mg_launch_down(S, mg_down_args(S, H, lA, lB, lC), false);
+    if (rc) return rc;
+    lA = lB;
+  } while (lA < lC);
+  MgUpArgs U = mg_up_args(S, H, lC, fin_op, force);
+  if (lC > Lg) {      // ... and to the gather level
+    MgUpArgs V = U;
+    V.l0 = Lg;
+    const unsigned nblk = (unsigned)(((S->mg_nx[Lg] + 31) / 32) * ((S->mg_ny[Lg] + 31) / 32));
+    hipLaunchKernelGGL(k_mg_up, dim3(nblk), dim3(MG_UP_THREADS), 3 * (size_t)V.cap * sizeof(double), S->stream, V);
+  }
+  if (Lg > 1) {      // the own rows: levels Lg - 1 .. 1
+    MgUpArgs V = U;
+    V.l0 = 1; V.lC = Lg;
+    V.tile_row0 = P.NX[1][0] / 32;
+    const int trows = (P.NX[1][1] + 31) / 32 - V.tile_row0;
+    hipLaunchKernelGGL(k_mg_up, dim3((unsigned)(((S->mg_nx[1] + 31) / 32) * trows)), dim3(MG_UP_THREADS), 3 * (size_t)V.cap * sizeof(double), S->stream, V);
+  }
+  U.tile_row0 = P.NX[0][0] / 32;
+  const int trows = (P.NX[0][1] + 31) / 32 - U.tile_row0;
+  U.row_lo = MG_RPB * S->part_lo[me]; U.row_hi = MG_RPB * S->part_hi[me];
+  U.slot = st->gc + (size_t)me * (1 + MG_NULL_MAX);
+  hipLaunchKernelGGL(k_mg_up0, dim3((unsigned)(((S->mg_nx[0] + 31) / 32) * trows)), dim3(MG_FINE_THREADS), 2 * (size_t)U.cap * sizeof(double), S->stream, U);
+  eu_prof_end(S, KC_COARSE_CYCLE);
+  return EULER_OK;
+}
+// fold: behind the all-gather of gc
+int eu_mg_split_fold(euler_sim* S, int fin_op, int force) {
+  MgSplitState* st = mg_split_state(S);
+  const MgSplitPlan& P = st->P;
+  hipLaunchKernelGGL(k_mg_split_fold, dim3(64), dim3(256), 0, S->stream, S->sc, st->gc, P.ranks, fin_op, force, mg_hier(S), S->cc_null, S->mg_null0, (size_t)S->mg_cells, S->mg_m0, P.NX[0][0], P.NX[0][1]);
   return EULER_OK;
 }
 

@@ -2053,11 +2053,17 @@ static int launch_precond_tile(euler_sim* S, int rupd, int sweeps, int fin_dot, 
   // row slabs + coarse correction: the pair and this rank's rows of the level-0 right-hand side travel in ONE slot of ONE all-gather inside the G1 exchange
   double* xsmall = S->pair_buf;
   int nsmall = 2;
+  bool split = false;      // multilevel mode: the cycle split by rows (k_mg.hip) - the edge rows of z go straight into its messages
   if (two_level && a.via == FIN_TO_COMM) {
+    split = eu_is_mg(S) && ghost_mode(S) && eu_mg_split(S);
     nsmall = eu_coarse_comm_slots(S);
     if (nsmall < 0) return EULER_ENOMEM;
     xsmall = S->mg_xbuf;
     a.pair_slot = xsmall + (size_t)S->comm.rank * nsmall;
+    if (split) {
+      if (a.zsend_lo) a.zsend_lo = eu_mg_split_msg(S, 0);
+      if (a.zsend_hi) a.zsend_hi = eu_mg_split_msg(S, 1);
+    }
   }
   const int w = r_only ? 16 : S->tile_w, cls = r_only ? KC_UPDATE_PR : KC_PRECOND_TILE;
   const unsigned nblk = eu_blocks((size_t)(S->band_hi - S->band_lo) * (S->geom.T / w), PT_THREADS / 64, 2048);
@@ -2086,11 +2092,19 @@ static int launch_precond_tile(euler_sim* S, int rupd, int sweeps, int fin_dot, 
   if (a.via == FIN_TO_COMM) {          // no mailboxes: G1 - both results (and, in the solve, the edge rows of the new z) in ONE exchange, then the epilogues
     const int R = S->comm.nranks;
     const bool rows = ghost_mode(S) && !force;
-    int rc = two_level ? eu_launch_coarse_pre(S, force) : EULER_OK;
+    int rc = !two_level ? EULER_OK : split ? eu_mg_split_pre(S) : eu_launch_coarse_pre(S, force);
     if (rc) return rc;
-    rc = comm_exchange(S, xrow(S, XR_ZSEND_LO), xrow(S, XR_ZSEND_HI), xrow(S, XR_ZRECV_LO), xrow(S, XR_ZRECV_HI), rows ? S->X : 0, xsmall, nsmall);
+    if (split) rc = comm_exchange(S, eu_mg_split_msg(S, 0), eu_mg_split_msg(S, 1), eu_mg_split_msg(S, 2), eu_mg_split_msg(S, 3), eu_mg_split_count(S), xsmall, nsmall);
+    else rc = comm_exchange(S, xrow(S, XR_ZSEND_LO), xrow(S, XR_ZSEND_HI), xrow(S, XR_ZRECV_LO), xrow(S, XR_ZRECV_HI), rows ? S->X : 0, xsmall, nsmall);
     if (rc) return rc;
     hipLaunchKernelGGL(k_pair_fold, dim3(1), dim3(1), 0, S->stream, S->sc, xsmall, nsmall, R, rupd, a.fin_dot, force);
+    if (split) {      // a third exchange point: the ranks' shares of the correction's dot product (and of the gauge sums) live on their own rows
+      if ((rc = eu_mg_split_mid(S, fin_real, force, xrow(S, XR_ZRECV_LO), xrow(S, XR_ZRECV_HI)))) return rc;
+      int64_t off[64], cnt[64];
+      for (int r = 0; r < R && r < 64; ++r) { off[r] = (int64_t)8 * (1 + MG_NULL_MAX) * r; cnt[r] = (int64_t)8 * (1 + MG_NULL_MAX); }
+      COMM_CALL(S->bulk.allgather(S->bulk.ctx, eu_mg_split_gc(S), off, cnt));
+      return eu_mg_split_fold(S, fin_real, force);
+    }
     // coarse correction on row slabs: the tiles' shares of dot(z, r) are folded (stored, not applied); the V-cycle - its level-0 right-hand
     // side the sum of the ranks' shares, the rest replicated - adds its share and applies the epilogue, the same bits on every rank
     if (two_level) { rc = eu_launch_coarse_scatter(S); if (rc) return rc; rc = eu_launch_coarse_solve(S, fin_real, force); if (rc) return rc; }

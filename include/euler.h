@@ -366,6 +366,9 @@ enum {
   EULER_OPT_NO_INTERIOR = 11,       /* 1: no constant-mask instantiation for interior chunks (experiments; the same bits) */
   EULER_OPT_BUILD_GATHER = 12,      /* 1: the assembly as one diagonal gather (rounds 1-2; the same bits) */
   EULER_OPT_RESIDENT_FORCE_TIMEOUT = 13, /* test hook: the next n resident launches give up at once as if a wait had run out (error word 1): the time-out path */
+  EULER_OPT_MG_SPLIT_LEVEL = 14,    /* multilevel mode on row slabs: the level whose right-hand side the ranks all-gather (below it every rank works on its own rows): 0 (default) by size,
+                                       n > 0 that level (tests: the split on small grids), -1 never (the cycle replicated from level 0 on).  The same value on every rank */
+  EULER_OPT_MG_SPLIT_ACTIVE = 15,   /* read only: the gather level the last multilevel solve on row slabs ran with, 0 while the cycle runs replicated */
   EULER_OPT__COUNT
 };
 int euler_set_option(euler_sim* sim, int32_t key, int64_t value);

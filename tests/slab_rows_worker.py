@@ -69,6 +69,9 @@ def main():
         if a.startswith("caps="):             # tiny exchange capacities (dt-chain candidates, deletions) to drive the overflow path
             os.environ["EULER_SLAB_CAPS"] = a[5:]
     sim = ea.Simulation(X, Y, device=local, dot_mode=ea.DOT_TREE, precond=precond, slab=slab, rainbow=rainbow, max_iterations=maxit, viscosity=nu)   # one slab
+    for a in sys.argv[6:]:
+        if a.startswith("split="):            # multilevel mode: the level the ranks all-gather (EULER_OPT_MG_SPLIT_LEVEL: the split cycle on grids this small)
+            sim.set_option(ea.OPT_MG_SPLIT_LEVEL, int(a[6:]))
     comm = RcclComm(sim, SLAB_LOCAL) if rccl else TorchComm(sim, SLAB_LOCAL)
     out = {"world": world, "frames": []}
     if p2p:
@@ -228,6 +231,7 @@ def main():
             ref.save_state(snap_save + ".ref")
     free1, _ = torch.cuda.mem_get_info()
     out["calls"] = comm.counts
+    out["split_active"] = sim.get_option(ea.OPT_MG_SPLIT_ACTIVE)
     if rank == 0:
         print(json.dumps(out))
     dist.barrier()

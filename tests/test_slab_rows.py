@@ -273,6 +273,12 @@ def test_a_partition_with_a_gap_is_refused():
     (3, 300, 440, "half_tank", 6, ("bands=0-2,2-3,3-7",)),      # an uneven partition, X and Y no multiples of 16; a tank at rest (long solves from the first frame on)
     (4, 256, 512, "waterfall", 20, ()),
     (2, 320, 256, "closed_box", 6, ()),       # water cut off from the air: the right-hand side is made compatible on the slabs as on one GPU (all-reduced sums)
+    # the cycle split by rows on grids this small: the ranks all-gather windows of level 1 / 2, everything below runs on the own rows
+    (2, 1024, 1024, "half_tank", 3, ("split=1",)),
+    (2, 1024, 1024, "dam_break", 40, ("split=2",)),
+    (3, 1000, 1100, "waterfall", 12, ("split=2", "bands=0-5,5-11,11-18")),
+    (4, 512, 2048, "half_tank", 3, ("split=1",)),
+    (2, 640, 1024, "closed_box", 4, ("split=2",)),      # ... with the gauge of a cut-off region summed over the ranks
 ])
 def test_multilevel_mode_on_row_slabs(nproc, X, Y, workload, frames, extra):
     """EULER_PRECOND_IC0_TILE_MG on row slabs: every rank assembles its rows of the level-0 operator (an aggregate of 16 rows belongs to
@@ -292,6 +298,8 @@ def test_multilevel_mode_on_row_slabs(nproc, X, Y, workload, frames, extra):
         assert f["dp"] <= 1e-6 * f["pmax"] + 2e-6 and f["du"] <= 1e-5 and f["dv"] <= 1e-5, (i, f)
         solved += f["iters"][1] > 0
     assert solved >= 3
+    want = [int(a[6:]) for a in extra if a.startswith("split=")]
+    assert d["split_active"] == (want[0] if want else 0), d["split_active"]
 
 
 @pytest.mark.gpu
