@@ -2100,9 +2100,7 @@ static int launch_precond_tile(euler_sim* S, int rupd, int sweeps, int fin_dot, 
     hipLaunchKernelGGL(k_pair_fold, dim3(1), dim3(1), 0, S->stream, S->sc, xsmall, nsmall, R, rupd, a.fin_dot, force);
     if (split) {      // a third exchange point: the ranks' shares of the correction's dot product (and of the gauge sums) live on their own rows
       if ((rc = eu_mg_split_mid(S, fin_real, force, xrow(S, XR_ZRECV_LO), xrow(S, XR_ZRECV_HI)))) return rc;
-      int64_t off[64], cnt[64];
-      for (int r = 0; r < R && r < 64; ++r) { off[r] = (int64_t)8 * (1 + MG_NULL_MAX) * r; cnt[r] = (int64_t)8 * (1 + MG_NULL_MAX); }
-      COMM_CALL(S->bulk.allgather(S->bulk.ctx, eu_mg_split_gc(S), off, cnt));
+      if ((rc = comm_exchange(S, nullptr, nullptr, nullptr, nullptr, 0, eu_mg_split_gc(S), 1 + MG_NULL_MAX))) return rc;
       return eu_mg_split_fold(S, fin_real, force);
     }
     // coarse correction on row slabs: the tiles' shares of dot(z, r) are folded (stored, not applied); the V-cycle - its level-0 right-hand

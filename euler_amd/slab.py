@@ -46,6 +46,7 @@ class TorchComm:
         self.error = None
         self._cache = {}
         self.counts = {"allreduce": 0, "halo": 0, "chain": 0, "allgather": 0, "exchange": 0}
+        self.bytes = {"rows": 0, "gathered": 0, "allreduce": 0}      # what this rank sent to neighbours / received of all-gathers (the whole buffer) / all-reduced
         # EULER_TORCH_NO_EXCHANGE: leave the fused operation out (the library then issues halo + allgather: the fallback path)
         import os
         fused = _EXCHANGE(self._exchange) if not os.environ.get("EULER_TORCH_NO_EXCHANGE") else _EXCHANGE()
@@ -86,6 +87,7 @@ class TorchComm:
     # -- the four operations
     def _allreduce(self, ctx, ptr, count, is_max):
         def run():
+            self.bytes["allreduce"] += 8 * count
             t = self._t(ptr, 8 * count, self.torch.float64)
             op = self.dist.ReduceOp.MAX if is_max else self.dist.ReduceOp.SUM
             if self.stage:
@@ -135,6 +137,8 @@ class TorchComm:
                 if self.rank + 1 < self.world:
                     pairs.append((self._t(send_hi, n, f64), self._t(recv_hi, n, f64), self.rank + 1))
             sm = self._t(small, 8 * nsmall * self.world, f64) if nsmall > 0 else None
+            self.bytes["rows"] += 8 * count * len(pairs)
+            self.bytes["gathered"] += 8 * nsmall * self.world
             if self.stage:
                 host = [(s.cpu(), self.torch.empty(count, dtype=f64), r, p) for s, r, p in pairs]
                 reqs = []
