@@ -194,9 +194,12 @@ __global__ __launch_bounds__(256) void k_mg_assemble0(const uint8_t* __restrict_
     __builtin_amdgcn_wave_barrier();
   }
 }
-__global__ __launch_bounds__(256) void k_mg_convert0(const unsigned long long* __restrict__ a0i, double* __restrict__ a, size_t n) {
+// (the nine planes' entries [first, first + count) each: a rank of a split cycle converts the rows its tiles reach)
+__global__ __launch_bounds__(256) void k_mg_convert0(const unsigned long long* __restrict__ a0i, double* __restrict__ a, size_t n0, size_t first, size_t count) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) a[i] = (double)(long long)a0i[i] * (1.0 / ((double)MG_G0 * MG_G0 * MG_G0 * MG_G0));
+  if (i >= 9 * count) return;
+  const size_t e = (i / count) * n0 + first + i % count;
+  a[e] = (double)(long long)a0i[e] * (1.0 / ((double)MG_G0 * MG_G0 * MG_G0 * MG_G0));
 }
 
 // weight of node j of a finer level (fn nodes) on node Jc of the next one (cn nodes), whose node Jc sits on the finer level's node 2 Jc
@@ -209,11 +212,12 @@ __device__ __forceinline__ double mg_w1(int Jc, int j, int fn, int cn) {
 }
 // A_(l+1) = P^T A_l P, a thread per node of level l + 1 and stencil entry: entry q of node (I, J) = sum over the fine nodes m under (I, J) and the fine nodes n under the
 // coarse neighbour (I, J) + q of w(m) A_l[m, n] w(n) - at most 3 x 3 x 3 x 3 terms, walked in a fixed order
-__global__ __launch_bounds__(256) void k_mg_coarsen(const double* __restrict__ af, int fnx, int fny, double* __restrict__ ac, int cnx, int cny, const PcgScalars* sc) {
+// (rows [r0, r1) of the coarse level)
+__global__ __launch_bounds__(256) void k_mg_coarsen(const double* __restrict__ af, int fnx, int fny, double* __restrict__ ac, int cnx, int cny, const PcgScalars* sc, int r0, int r1) {
   if (!sc->nonzero) return;
   const int tid = blockIdx.x * 256 + threadIdx.x;
-  const int p = tid / 9, q = tid % 9;
-  if (p >= cnx * cny) return;
+  const int p = r0 * cnx + tid / 9, q = tid % 9;
+  if (p >= r1 * cnx) return;
   const int I = p / cnx, J = p % cnx, I2 = I + q / 3 - 1, J2 = J + q % 3 - 1;
   const size_t fn = (size_t)fnx * fny, cn = (size_t)cnx * cny;
   double acc = 0.0;
@@ -1192,7 +1196,15 @@ struct MgSplitState {
   MgSplitWin W;
   double* msg;      // [4][X + zone]: send lo / hi, receive lo / hi
   double* gc;       // [ranks][1 + MG_NULL_MAX]: {x_0 . rhs_0 over the own rows, gauge sums}
+  // the operators, per solve (eu_mg_setup): every level below the gather level is formed where it is OWNED (level 0: the rank's node rows; a coarser node row belongs to the
+  // owner of the fine row under it) and MG_SETUP_HALO rows travel to either neighbour, level by level; the gather level's owned rows are all-gathered
+  int setup_ok;
+  int O[MG_MAXLEV][64][2];
+  double* sbuf;     // [4][9 (MG_SETUP_HALO + 1) nx_0]
+  double* abuf;     // [ranks][aslot]
+  int aslot;
 };
+#define MG_SETUP_HALO 6
 static inline MgSplitState* mg_split_state(const euler_sim* S) { return static_cast<MgSplitState*>(S->mg_split); }
 
 static inline void mg_clip(int* r, int n) { if (r[0] < 0) r[0] = 0; if (r[1] > n) r[1] = n; if (r[1] < r[0]) r[1] = r[0]; }
@@ -1213,7 +1225,7 @@ static const MgSplitPlan* mg_split_plan(euler_sim* S) {
   S->mg_split = st;
   MgSplitPlan& P = st->P;
   const int R = S->bulk.nranks, me = S->bulk.rank, Lg = mg_gather_level(S);
-  if (!S->has_comm || !S->slab_on || R > 64 || R < 2 || Lg < 1 || !S->mg_a) return nullptr;
+  if (!S->has_comm || !S->slab_on || S->p2p_on || R > 64 || R < 2 || Lg < 1 || !S->mg_a) return nullptr;
   P.Lg = Lg; P.ranks = R; P.rank = me;
   for (int r = 0; r < R; ++r) {      // supports of the ranks' shares, level by level
     int a = MG_RPB * S->part_lo[r] - 1, b = MG_RPB * S->part_hi[r] + 1;
@@ -1262,16 +1274,39 @@ static const MgSplitPlan* mg_split_plan(euler_sim* S) {
     }
     zone = offs > zone ? offs : zone; zone = offr > zone ? offr : zone;
   }
+  // the setup by owners: every rank's owned rows of every level below the gather level at least a halo thick, and what a rank reads of a level within its owned rows + halo
+  int setup_bad = 0, maxo = 0;
+  for (int r = 0; r < R; ++r) {
+    int a = MG_RPB * S->part_lo[r], b = MG_RPB * S->part_hi[r];
+    for (int l = 0; l <= Lg; ++l) {
+      st->O[l][r][0] = a; st->O[l][r][1] = b;
+      if (l < Lg && b - a < MG_SETUP_HALO) setup_bad = 1;
+      a = (a + 1) / 2; b = (b + 1) / 2;
+    }
+    maxo = st->O[Lg][r][1] - st->O[Lg][r][0] > maxo ? st->O[Lg][r][1] - st->O[Lg][r][0] : maxo;
+  }
+  for (int l = 0; l < Lg; ++l) {
+    const int o0 = st->O[l][me][0], o1 = st->O[l][me][1], ny = S->mg_ny[l];
+    int lo = P.I[l][me][0] - 1, hi = P.I[l][me][1] + 1;                                     // the way down: the residual one row beyond the share's support
+    lo = P.NR[l][0] < lo ? P.NR[l][0] : lo; hi = P.NR[l][1] > hi ? P.NR[l][1] : hi;         // the way up
+    const int c0 = 2 * st->O[l + 1][me][0] - 1, c1 = 2 * st->O[l + 1][me][1];               // the next level's owned rows are formed from these
+    lo = c0 < lo ? c0 : lo; hi = c1 > hi ? c1 : hi;
+    if (lo < 0) lo = 0;
+    if (hi > ny) hi = ny;
+    if (lo < o0 - MG_SETUP_HALO || hi > o1 + MG_SETUP_HALO) setup_bad = 1;
+  }
+  st->aslot = 9 * maxo * S->mg_nx[Lg];
   int win = 0;
   for (int r = 0; r < R; ++r) win = P.I[Lg][r][1] - P.I[Lg][r][0] > win ? P.I[Lg][r][1] - P.I[Lg][r][0] : win;
   P.win_rows = win; P.nsmall = 2 + win * S->mg_nx[Lg];
   // every rank must come to the same verdict and the same message length: the plan's inputs are the partition (the same everywhere), so one all-reduce of {failed, zone} settles both
-  double v[2] = {P.valid < 0 ? 1.0 : 0.0, (double)zone};
+  double v[3] = {P.valid < 0 ? 1.0 : 0.0, (double)zone, (double)setup_bad};
   double* dv = S->mg_dot;      // (scratch: the partials are rewritten by the next cycle)
-  if (hipMemcpyAsync(dv, v, sizeof v, hipMemcpyHostToDevice, S->stream) != hipSuccess || S->bulk.allreduce(S->bulk.ctx, dv, 2, 1) != 0 ||
+  if (hipMemcpyAsync(dv, v, sizeof v, hipMemcpyHostToDevice, S->stream) != hipSuccess || S->bulk.allreduce(S->bulk.ctx, dv, 3, 1) != 0 ||
       hipMemcpyAsync(v, dv, sizeof v, hipMemcpyDeviceToHost, S->stream) != hipSuccess || hipStreamSynchronize(S->stream) != hipSuccess) { P.valid = 0; return nullptr; }
   if (v[0] != 0.0) { P.valid = 0; return nullptr; }
   P.zone_doubles = (int)v[1];
+  st->setup_ok = v[2] == 0.0;
   // what the kernels either side of the exchange need of the plan
   const int X = S->X;
   MgSplitMsg& M = st->M;
@@ -1300,7 +1335,11 @@ static const MgSplitPlan* mg_split_plan(euler_sim* S) {
   for (int r = 0; r < R; ++r) { W.lo[r] = P.I[Lg][r][0]; W.hi[r] = P.I[Lg][r][1]; }
   const size_t mlen = (size_t)X + P.zone_doubles;
   if (hipMalloc((void**)&st->msg, 4 * mlen * sizeof(double)) != hipSuccess || hipMalloc((void**)&st->gc, (size_t)R * (1 + MG_NULL_MAX) * sizeof(double)) != hipSuccess ||
-      hipMemsetAsync(st->msg, 0, 4 * mlen * sizeof(double), S->stream) != hipSuccess || hipMemsetAsync(st->gc, 0, (size_t)R * (1 + MG_NULL_MAX) * sizeof(double), S->stream) != hipSuccess) {
+      hipMemsetAsync(st->msg, 0, 4 * mlen * sizeof(double), S->stream) != hipSuccess || hipMemsetAsync(st->gc, 0, (size_t)R * (1 + MG_NULL_MAX) * sizeof(double), S->stream) != hipSuccess ||
+      (st->setup_ok && (hipMalloc((void**)&st->sbuf, 4 * (size_t)9 * (MG_SETUP_HALO + 1) * S->mg_nx[0] * sizeof(double)) != hipSuccess ||
+                        hipMalloc((void**)&st->abuf, (size_t)R * st->aslot * sizeof(double)) != hipSuccess ||
+                        hipMemsetAsync(st->sbuf, 0, 4 * (size_t)9 * (MG_SETUP_HALO + 1) * S->mg_nx[0] * sizeof(double), S->stream) != hipSuccess ||
+                        hipMemsetAsync(st->abuf, 0, (size_t)R * st->aslot * sizeof(double), S->stream) != hipSuccess))) {
     eu_set_error("hipMalloc of the split cycle's message buffers failed");
     return nullptr;
   }
@@ -1318,6 +1357,8 @@ void eu_mg_split_release(euler_sim* S) {
   if (!st) return;
   if (st->msg) (void)hipFree(st->msg);
   if (st->gc) (void)hipFree(st->gc);
+  if (st->sbuf) (void)hipFree(st->sbuf);
+  if (st->abuf) (void)hipFree(st->abuf);
   delete st;
   S->mg_split = nullptr;
 }
@@ -1512,9 +1553,9 @@ __global__ __launch_bounds__(256) void k_mg_top_stencil(const double* __restrict
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < 9 * n) out[i] = at[i];
 }
-__global__ __launch_bounds__(256) void k_mg_inner0(MgHier H, uint8_t* __restrict__ inner) {      // a node whose nine entries are deep water's (bit for bit: both sides are exact)
-  const size_t n = (size_t)H.nx[0] * H.ny[0], c = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (c >= n) return;
+__global__ __launch_bounds__(256) void k_mg_inner0(MgHier H, uint8_t* __restrict__ inner, size_t first, size_t count) {      // a node whose nine entries are deep water's (bit for bit: both sides are exact)
+  const size_t n = (size_t)H.nx[0] * H.ny[0], c = first + (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= first + count) return;
   bool same = true;
 #pragma unroll
   for (int k = 0; k < 9; ++k) same = same && H.a[(size_t)k * n + c] == H.ic[k];
@@ -1529,20 +1570,98 @@ __global__ __launch_bounds__(256) void k_mg_wd(const double* __restrict__ a, con
   const double d = mg_sten(H, l)[4 * n + c];
   wd[H.off[l] + c] = d != 0.0 ? MG_OMEGA / d : 0.0;
 }
+// rows of a level's nine planes <-> a message (plane-major there too); mode 0: pack, 1: unpack (replace), 2: unpack, adding on the rows [add0, add1) (level 0: both ranks'
+// cells reach the node rows at a slab boundary; the entries are small multiples of 2^-12, their sums exact)
+__global__ __launch_bounds__(256) void k_mg_sten_rows(double* __restrict__ a, size_t n, int nx, int row0, int rows, double* __restrict__ msg, int mode, int add0, int add1) {
+  const size_t per = (size_t)rows * nx, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= 9 * per) return;
+  const size_t k = i / per, e = i % per;
+  double* cell = a + k * n + (size_t)row0 * nx + e;
+  if (mode == 0) msg[i] = *cell;
+  else {
+    const int row = row0 + (int)(e / nx);
+    *cell = (mode == 2 && row >= add0 && row < add1) ? *cell + msg[i] : msg[i];
+  }
+}
+// the gather level's operator, whole, from the owners' rows
+struct MgOwners { int n; int lo[64], hi[64]; };
+__global__ __launch_bounds__(256) void k_mg_sten_gathered(double* __restrict__ a, size_t n, int nx, const double* __restrict__ abuf, int aslot, MgOwners W) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= 9 * n) return;
+  const size_t k = i / n, c = i % n;
+  const int row = (int)(c / nx);
+  for (int r = 0; r < W.n; ++r)
+    if (row >= W.lo[r] && row < W.hi[r]) { a[i] = abuf[(size_t)r * aslot + k * (size_t)(W.hi[r] - W.lo[r]) * nx + (size_t)(row - W.lo[r]) * nx + c % nx]; return; }
+}
+static int mg_setup_split(euler_sim* S, MgSplitState* st) {
+  const MgSplitPlan& P = st->P;
+  const int me = P.rank, R = P.ranks, Lg = P.Lg, nx0 = S->mg_nx[0];
+  const size_t n0 = (size_t)nx0 * S->mg_ny[0];
+  const int s0 = P.I[0][me][0], s1 = P.I[0][me][1];      // the rows this rank's tiles reach
+  HIPCHK(hipMemset2DAsync(S->mg_a0i + (size_t)s0 * nx0, n0 * sizeof(unsigned long long), 0, (size_t)(s1 - s0) * nx0 * sizeof(unsigned long long), 9, S->stream));
+  HIPCHK(hipMemsetAsync(S->mg_part, 0, (S->chunk_cap + 64) * MG_PART * sizeof(double), S->stream));
+  LAUNCH(S, KC_PRECON_FACTOR, k_mg_assemble0, dim3(eu_blocks(S->chunk_cap, 4, 2048)), dim3(256), S->cellmask, S->geom, S->chunk_list, S->sc, S->band_lo, nx0, S->mg_ny[0], S->mg_a0i);
+  const size_t cnt0 = (size_t)(s1 - s0) * nx0;
+  LAUNCH(S, KC_PRECON_FACTOR, k_mg_convert0, dim3((unsigned)((9 * cnt0 + 255) / 256)), dim3(256), S->mg_a0i, S->mg_a, n0, (size_t)s0 * nx0, cnt0);
+  const size_t blen = (size_t)9 * (MG_SETUP_HALO + 1) * nx0;
+  double *send_lo = st->sbuf, *send_hi = st->sbuf + blen, *recv_lo = st->sbuf + 2 * blen, *recv_hi = st->sbuf + 3 * blen;
+  const bool has_lo = me > 0, has_hi = me + 1 < R;
+  for (int l = 0; l <= Lg; ++l) {
+    const int nx = S->mg_nx[l], ny = S->mg_ny[l], o0 = st->O[l][me][0], o1 = st->O[l][me][1];
+    double* a = S->mg_a + 9 * S->mg_off[l];
+    const size_t n = (size_t)nx * ny;
+    if (l > 0) {
+      const size_t cnt = (size_t)9 * (o1 - o0) * nx;
+      if (cnt) LAUNCH(S, KC_PRECON_FACTOR, k_mg_coarsen, dim3((unsigned)((cnt + 255) / 256)), dim3(256), S->mg_a + 9 * S->mg_off[l - 1], S->mg_nx[l - 1], S->mg_ny[l - 1], a, nx, ny, S->sc, o0, o1);
+    }
+    if (l == Lg) break;
+    // the rows either neighbour needs of this rank / this rank of them: MG_SETUP_HALO owned rows; level 0 one more - the shared row across the boundary, as a share
+    const int extra = l == 0 ? 1 : 0, rows = MG_SETUP_HALO + extra;
+    const unsigned nb = (unsigned)(((size_t)9 * rows * nx + 255) / 256);
+    if (has_lo) hipLaunchKernelGGL(k_mg_sten_rows, dim3(nb), dim3(256), 0, S->stream, a, n, nx, o0 - extra, rows, send_lo, 0, 0, 0);
+    if (has_hi) hipLaunchKernelGGL(k_mg_sten_rows, dim3(nb), dim3(256), 0, S->stream, a, n, nx, o1 - MG_SETUP_HALO, rows, send_hi, 0, 0, 0);
+    COMM_CALL(S->bulk.halo(S->bulk.ctx, send_lo, send_hi, recv_lo, recv_hi, 9 * rows * nx));
+    if (has_lo) hipLaunchKernelGGL(k_mg_sten_rows, dim3(nb), dim3(256), 0, S->stream, a, n, nx, o0 - MG_SETUP_HALO, rows, recv_lo, l == 0 ? 2 : 1, s0, s1);
+    if (has_hi) hipLaunchKernelGGL(k_mg_sten_rows, dim3(nb), dim3(256), 0, S->stream, a, n, nx, o1 - extra, rows, recv_hi, l == 0 ? 2 : 1, s0, s1);
+  }
+  {      // the gather level: the owners' rows to everybody
+    const int nx = S->mg_nx[Lg], o0 = st->O[Lg][me][0], o1 = st->O[Lg][me][1];
+    const size_t n = (size_t)nx * S->mg_ny[Lg];
+    double* a = S->mg_a + 9 * S->mg_off[Lg];
+    if (o1 > o0) hipLaunchKernelGGL(k_mg_sten_rows, dim3((unsigned)(((size_t)9 * (o1 - o0) * nx + 255) / 256)), dim3(256), 0, S->stream, a, n, nx, o0, o1 - o0, st->abuf + (size_t)me * st->aslot, 0, 0, 0);
+    int64_t off[64], cnt[64];
+    for (int r = 0; r < R; ++r) { off[r] = (int64_t)8 * st->aslot * r; cnt[r] = (int64_t)8 * st->aslot; }
+    COMM_CALL(S->bulk.allgather(S->bulk.ctx, st->abuf, off, cnt));
+    MgOwners W;
+    W.n = R;
+    for (int r = 0; r < R; ++r) { W.lo[r] = st->O[Lg][r][0]; W.hi[r] = st->O[Lg][r][1]; }
+    hipLaunchKernelGGL(k_mg_sten_gathered, dim3((unsigned)((9 * n + 255) / 256)), dim3(256), 0, S->stream, a, n, nx, st->abuf, st->aslot, W);
+  }
+  for (int l = Lg + 1; l < S->mg_levels; ++l)
+    LAUNCH(S, KC_PRECON_FACTOR, k_mg_coarsen, dim3((unsigned)((9 * (size_t)S->mg_nx[l] * S->mg_ny[l] + 255) / 256)), dim3(256), S->mg_a + 9 * S->mg_off[l - 1], S->mg_nx[l - 1], S->mg_ny[l - 1],
+           S->mg_a + 9 * S->mg_off[l], S->mg_nx[l], S->mg_ny[l], S->sc, 0, S->mg_ny[l]);
+  int i0 = st->O[0][me][0] - MG_SETUP_HALO, i1 = st->O[0][me][1] + MG_SETUP_HALO;
+  if (i0 < 0) i0 = 0;
+  if (i1 > S->mg_ny[0]) i1 = S->mg_ny[0];
+  hipLaunchKernelGGL(k_mg_inner0, dim3((unsigned)(((size_t)(i1 - i0) * nx0 + 255) / 256)), dim3(256), 0, S->stream, mg_hier(S), S->mg_inner0, (size_t)i0 * nx0, (size_t)(i1 - i0) * nx0);
+  hipLaunchKernelGGL(k_mg_wd, dim3((unsigned)((n0 + 255) / 256), (unsigned)S->mg_levels), dim3(256), 0, S->stream, (const double*)nullptr, (const unsigned int*)nullptr, 0, mg_hier(S), S->mg_wd);
+  return EULER_OK;
+}
 int eu_mg_setup(euler_sim* S) {
   const size_t n0 = (size_t)S->mg_nx[0] * S->mg_ny[0];
+  if (S->has_comm && mg_split_plan(S) && mg_split_state(S)->setup_ok) return mg_setup_split(S, mg_split_state(S));
   HIPCHK(hipMemsetAsync(S->mg_a0i, 0, 9 * n0 * sizeof(unsigned long long), S->stream));
   HIPCHK(hipMemsetAsync(S->mg_part, 0, (S->chunk_cap + 64) * MG_PART * sizeof(double), S->stream));      // (tiles outside this solve's list contribute nothing)
   const unsigned nblk = eu_blocks(S->chunk_cap, 4, 2048);
   LAUNCH(S, KC_PRECON_FACTOR, k_mg_assemble0, dim3(nblk), dim3(256), S->cellmask, S->geom, S->chunk_list, S->sc, S->band_lo, S->mg_nx[0], S->mg_ny[0], S->mg_a0i);
-  LAUNCH(S, KC_PRECON_FACTOR, k_mg_convert0, dim3((unsigned)((9 * n0 + 255) / 256)), dim3(256), S->mg_a0i, S->mg_a, 9 * n0);
-  // row slabs: a node row collects cells of the ranks either side of a slab boundary.  The entries are multiples of 2^-16 far below 2^37: their sums are exact in
-  // any order, so ONE all-reduce makes A_0 whole and bit-identical everywhere (per solve; only the rows at slab boundaries actually overlap)
+  LAUNCH(S, KC_PRECON_FACTOR, k_mg_convert0, dim3((unsigned)((9 * n0 + 255) / 256)), dim3(256), S->mg_a0i, S->mg_a, n0, (size_t)0, n0);
+  // row slabs, the cycle replicated: a node row collects cells of the ranks either side of a slab boundary.  The entries are multiples of 2^-12 far below 2^37: their sums are
+  // exact in any order, so ONE all-reduce makes A_0 whole and bit-identical everywhere (the split cycle, above, exchanges rows with the neighbours instead)
   if (S->has_comm) COMM_CALL(S->bulk.allreduce(S->bulk.ctx, S->mg_a, (int32_t)(9 * n0), 0));
   for (int l = 1; l < S->mg_levels; ++l)
     LAUNCH(S, KC_PRECON_FACTOR, k_mg_coarsen, dim3((unsigned)((9 * (size_t)S->mg_nx[l] * S->mg_ny[l] + 255) / 256)), dim3(256), S->mg_a + 9 * S->mg_off[l - 1], S->mg_nx[l - 1], S->mg_ny[l - 1],
-           S->mg_a + 9 * S->mg_off[l], S->mg_nx[l], S->mg_ny[l], S->sc);
-  hipLaunchKernelGGL(k_mg_inner0, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, S->stream, mg_hier(S), S->mg_inner0);
+           S->mg_a + 9 * S->mg_off[l], S->mg_nx[l], S->mg_ny[l], S->sc, 0, S->mg_ny[l]);
+  hipLaunchKernelGGL(k_mg_inner0, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, S->stream, mg_hier(S), S->mg_inner0, (size_t)0, n0);
   // omega / diagonal per node of every level below the dense one: the cycle's Jacobi steps multiply
   hipLaunchKernelGGL(k_mg_wd, dim3((unsigned)(((size_t)S->mg_nx[0] * S->mg_ny[0] + 255) / 256), (unsigned)S->mg_levels), dim3(256), 0, S->stream, (const double*)nullptr, (const unsigned int*)nullptr, 0, mg_hier(S), S->mg_wd);
   return EULER_OK;
@@ -1639,7 +1758,9 @@ int eu_mg_null_setup(euler_sim* S) {      // behind k_mg_null_prolong (k_coarse.
   LAUNCH(S, KC_PRECON_FACTOR, k_mg_null_mass, dim3(eu_blocks(S->e_cnt, 256 * 8, 512)), dim3(256), S->cellmask, S->geom, S->e_lo, S->e_cnt, S->cc_null, S->mg_null0, S->mg_cells,
          S->mg_nx[0], S->mg_ny[0], S->mg_a0i, S->sc);
   LAUNCH(S, KC_PRECON_FACTOR, k_mg_null_convert, dim3((unsigned)((MG_NULL_MAX * n0n + 255) / 256)), dim3(256), S->mg_a0i, S->cc_null, MG_NULL_MAX * n0n, S->mg_m0, S->sc);
-  if (S->has_comm) COMM_CALL(S->bulk.allreduce(S->bulk.ctx, S->mg_m0, (int32_t)(MG_NULL_MAX * n0n), 0));      // (multiples of 1 / 256: exact in any order)
+  // m_0 . n_0 from this rank's share of m_0 - it lies on the rows its cells reach, where the rank holds the indicator whatever the cycle's form (a split cycle prolongs it on
+  // the own rows only) - then shares and scalars are summed over the ranks together (the shares: multiples of 1 / 64, exact in any order)
   LAUNCH(S, KC_PRECON_FACTOR, k_mg_null_finish, dim3(MG_NULL_MAX), dim3(1024), S->cc_null, S->mg_null0, S->mg_cells, n0n, S->mg_m0, S->sc);
+  if (S->has_comm) COMM_CALL(S->bulk.allreduce(S->bulk.ctx, S->mg_m0, (int32_t)(MG_NULL_MAX * n0n + MG_NULL_MAX), 0));
   return EULER_OK;
 }

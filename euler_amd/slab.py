@@ -46,7 +46,9 @@ class TorchComm:
         self.error = None
         self._cache = {}
         self.counts = {"allreduce": 0, "halo": 0, "chain": 0, "allgather": 0, "exchange": 0}
-        self.bytes = {"rows": 0, "gathered": 0, "allreduce": 0}      # what this rank sent to neighbours / received of all-gathers (the whole buffer) / all-reduced
+        # what this rank sent to neighbours / received of all-gathers (the whole buffer) / all-reduced; halo_* and allgather: the stand-alone operations (per solve: the
+        # multilevel mode's operators), rows / gathered: the fused exchange points of the PCG iterations
+        self.bytes = {"rows": 0, "gathered": 0, "allreduce": 0, "halo_rows": 0, "allgather": 0}
         # EULER_TORCH_NO_EXCHANGE: leave the fused operation out (the library then issues halo + allgather: the fallback path)
         import os
         fused = _EXCHANGE(self._exchange) if not os.environ.get("EULER_TORCH_NO_EXCHANGE") else _EXCHANGE()
@@ -106,6 +108,7 @@ class TorchComm:
                 pairs.append((self._t(send_lo, n, f64), self._t(recv_lo, n, f64), self.rank - 1))
             if self.rank + 1 < self.world:
                 pairs.append((self._t(send_hi, n, f64), self._t(recv_hi, n, f64), self.rank + 1))
+            self.bytes["halo_rows"] += n * len(pairs)
             if self.stage:
                 host = [(s.cpu(), self.torch.empty(count, dtype=f64), r, p) for s, r, p in pairs]
                 reqs = []
@@ -183,6 +186,7 @@ class TorchComm:
 
     def _allgather(self, ctx, base, off, cnt):
         def run():
+            self.bytes["allgather"] += sum(cnt[r] for r in range(self.world))
             for r in range(self.world):
                 if cnt[r] == 0:           # (a rank may have nothing to contribute: the same on every rank)
                     continue

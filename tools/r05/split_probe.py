@@ -43,6 +43,7 @@ def worker():
            "exchange_points_per_iteration": round((comm.counts["exchange"] - c0["exchange"] + comm.counts["allreduce"] - c0["allreduce"]) / max(its, 1), 2),
            "bytes_gathered_per_iteration": round((comm.bytes["gathered"] - b0["gathered"]) / max(its, 1)),
            "bytes_to_neighbours_per_iteration": round((comm.bytes["rows"] - b0["rows"]) / max(its, 1)),
+           "per_solve_bytes": {k: round((comm.bytes[k] - b0[k]) / substeps) for k in ("allreduce", "halo_rows", "allgather")},
            "rank0_kernel_us_per_iteration": {k: round(v[0] * 1e3 / max(its, 1), 1) for k, v in prof.items() if v[0] > 0}}
     if rank == 0:
         print(json.dumps(out))
