@@ -1073,11 +1073,16 @@ static int mg_set_lds(const void* fn, size_t bytes) {
 // to 256^2): k_mg_down<gather> with the tail, then k_mg_up for the dot product alone.
 static inline unsigned int* mg_tick_down(const euler_sim* S) { return reinterpret_cast<unsigned int*>(S->mg_dot + (1 + MG_NULL_MAX) * MG_DOT_BLOCKS + 1); }
 static inline unsigned int* mg_tick_up(const euler_sim* S) { return reinterpret_cast<unsigned int*>(S->mg_dot + (1 + MG_NULL_MAX) * MG_DOT_BLOCKS); }
+#ifndef MG_MIN_BLOCKS
+#define MG_MIN_BLOCKS 64
+#endif
 static MgDownArgs mg_down_args(const euler_sim* S, const MgHier& H, int lA, int lB, int lC) {
   MgDownArgs A;
   A.H = H; A.lA = lA; A.lB = lB;
   const int steps = lB - lA;
   A.tile = steps == 3 ? 4 : steps == 2 ? 8 : steps == 1 ? 16 : 32;
+  // a small level (grids up to 1024^2): the launch is latency, not work - smaller tiles until MG_MIN_BLOCKS workgroups share it (1024^2: 16 workgroups -> 64)
+  while (steps > 0 && A.tile > 4 && (size_t)((S->mg_nx[lB] + A.tile - 1) / A.tile) * ((S->mg_ny[lB] + A.tile - 1) / A.tile) < MG_MIN_BLOCKS) A.tile /= 2;
   int e = A.tile, c[4] = {0, 0, 0, 0};
   c[steps] = e * e;
   for (int k = steps - 1; k >= 0; --k) { e = 2 * e + 3; c[k] = e * e; }
@@ -1130,7 +1135,11 @@ static int launch_mg_cycle(euler_sim* S, int fin_op, int force, bool gather) {
       lA = lB;
       first = false;
     } while (lA < lC);
-    hipLaunchKernelGGL(k_mg_up, dim3(nblk0), dim3(MG_UP_THREADS), 3 * (size_t)U.cap * sizeof(double), S->stream, U);
+    MgUpArgs V = U;
+    while (V.tile > 8 && (size_t)((S->mg_nx[0] + V.tile - 1) / V.tile) * ((S->mg_ny[0] + V.tile - 1) / V.tile) < MG_MIN_BLOCKS) V.tile /= 2;
+    V.cap = (V.tile + 4) * (V.tile + 4);
+    const unsigned nb = (unsigned)(((S->mg_nx[0] + V.tile - 1) / V.tile) * ((S->mg_ny[0] + V.tile - 1) / V.tile));
+    hipLaunchKernelGGL(k_mg_up, dim3(nb), dim3(MG_UP_THREADS), 3 * (size_t)V.cap * sizeof(double), S->stream, V);
   } else {
     {      // level 0 -> 1 on small workgroups
       MgDownArgs A = down_args(0, 1);

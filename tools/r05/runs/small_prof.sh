@@ -15,4 +15,4 @@ st = s.stats(); print("iterations", st.total_pcg_iterations, "substeps", st.tota
 PY
 rm -rf /tmp/sp; timeout 200 rocprofv3 --kernel-trace -d /tmp/sp -o t -- python3 /tmp/small_probe.py > /tmp/sp.log 2>&1 < /dev/null
 tail -1 /tmp/sp.log
-timeout 60 python3 $ROOT/tools/r05/kstats.py /tmp/sp < /dev/null | head -24
+timeout 60 python3 $ROOT/tools/r05/kstats.py /tmp/sp < /dev/null | head -${2:-24}
