@@ -819,6 +819,7 @@ extern "C" int euler_pcg_op(euler_sim* S, int32_t op, float dt, double a, double
   if (!S || !S->loaded) { eu_set_error("euler_pcg_op: no scenario loaded"); return EULER_ESTATE; }
   // (the single building blocks address the whole grid; a row-slab handle holds a window of it)
   if (S->slab_on) { eu_set_error("euler_pcg_op: single PCG operations are not exposed on a row-slab handle"); return EULER_ESTATE; }
+  S->pcg_fields_resident = 0;      // (single operations run the multi-kernel path: z, s, q are in memory again)
   return eu_launch_pcg_op(S, op, dt, a, out);
 }
 
@@ -878,6 +879,10 @@ extern "C" int euler_get_field(euler_sim* S, int32_t f, void* dst, size_t dst_by
   if (rc) return rc;
   if (dst_bytes < b) { eu_set_error("euler_get_field(%d): buffer %zu < %zu bytes", f, dst_bytes, b); return EULER_EINVAL; }
   if (b == 0) return EULER_OK;
+  if ((f == EULER_F_PCG_Z || f == EULER_F_PCG_S || f == EULER_F_PCG_Q) && S->pcg_fields_resident) {
+    eu_set_error("euler_get_field(%d): the last solve ran in the resident kernel, which keeps z, s and A s in registers (euler_config.resident = EULER_RESIDENT_OFF shows them)", f);
+    return EULER_ESTATE;
+  }
   if (field_is_skewed(f)) {   // the solver's arrays are band-skewed in HBM: gather to row-major first
     rc = ensure_rowmajor_tmp(S);
     if (rc) return rc;

@@ -206,6 +206,7 @@ struct euler_sim {
   unsigned int res_last_chunks;   // active chunks of the previous solve (from sc_host): decides whether the next one is launched resident without asking the device
   int res_have_last, res_skip_once;
   unsigned long long res_solves, res_fallbacks;
+  int pcg_fields_resident;        // the last solve ran in the resident kernel: S->z / S->s / S->q hold published halo cells only (euler_get_field refuses them)
   int tile_w;             // EULER_PRECOND_IC0_TILE: records per tile (include/euler.h precond_tile_records)
   double* s_ring[8];                // the search directions' ring (k_pcg.hip p_steps): [0], [1] = s, s2 as the solve found them, the others allocated when first needed
   void* s_ring_alloc[8];            // raw allocations of [2..]
@@ -338,6 +339,7 @@ int  eu_slab_exchange_dye(euler_sim* S);    // ghost rows of g_r, g_g, g_b (--ra
 int  eu_slab_render(euler_sim* S, int wx, int wy, char* out, int cap, int* len);   // snapshot.hip: euler_render on a row-slab handle (collective)
 int  eu_slab_after_restore(euler_sim* S);   // collective: the job-wide facts a scenario load sets up (source cells of all ranks)
 int  eu_slab_error_sync(euler_sim* S);      // collective: the ranks' sticky error words -> their maximum on every rank
+int  eu_slab_same_everywhere(euler_sim* S, const double* vals, int n, int* same);   // collective: do these host-side values agree on every rank?
 int  eu_slab_status_sync(euler_sim* S, int local_rc, int* worst);   // collective: a host-side status code -> non-zero on every rank if any rank failed
 // launch groups implemented in the kernel files
 int eu_launch_timestep(euler_sim* S, float frame_time_left);

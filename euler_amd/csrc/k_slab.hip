@@ -252,6 +252,20 @@ int eu_slab_status_sync(euler_sim* S, int local_rc, int* worst) {
   if (any != 0.0 && local_rc == 0) *worst = EULER_EIO;
   return EULER_OK;
 }
+// collective: do n <= 4 host-side values (integers below 2^53) agree on every rank?  max(v) and max(-v) in one all-reduce
+int eu_slab_same_everywhere(euler_sim* S, const double* vals, int n, int* same) {
+  *same = 1;
+  if (!S->has_comm || !S->slab || n > 4) return EULER_OK;
+  SlabScratch* s = S->slab;
+  double v[8];
+  for (int k = 0; k < n; ++k) { v[2 * k] = vals[k]; v[2 * k + 1] = -vals[k]; }
+  HIPCHK(hipMemcpyAsync(s->vec, v, sizeof(double) * 2 * n, hipMemcpyHostToDevice, S->stream));
+  COMM_CALL(S->bulk.allreduce(S->bulk.ctx, s->vec, 2 * n, 1));
+  HIPCHK(hipMemcpyAsync(v, s->vec, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, S->stream));
+  HIPCHK(hipStreamSynchronize(S->stream));
+  for (int k = 0; k < n; ++k) if (v[2 * k] != -v[2 * k + 1]) *same = 0;
+  return EULER_OK;
+}
 int eu_slab_timestep(euler_sim* S, float frame_time_left) {   // k_maxsq over the own rows has been launched
   SlabScratch* s = S->slab;
   hipLaunchKernelGGL(k_maxsq_to_vec, dim3(1), dim3(1), 0, S->stream, S->ms, s->vec);

@@ -402,6 +402,12 @@ extern "C" int euler_load_state(euler_sim* S, const char* path) {
       S->loaded = 0;
       return rc ? rc : worst;
     }
+    // every rank compared the headers of the part files IT read; ranks whose rows lie in different files must have seen the same state too (an overwrite that died between
+    // the renames of the parts leaves old and new files side by side)
+    const double id[4] = {(double)h0.frames, (double)(h0.rng_state & 0xffffffffull), (double)(h0.rng_state >> 32), (double)h0.n_markers};
+    int same = 1;
+    if ((rc = eu_slab_same_everywhere(S, id, 4, &same))) return rc;
+    if (!same) { eu_set_error("euler_load_state(%s): the ranks read part files of different states (an interrupted overwrite?)", path); S->loaded = 0; return EULER_EINVAL; }
     if ((rc = eu_slab_after_restore(S))) return rc;      // collective: the source cells of all ranks
     if ((rc = eu_sync_marker_state(S))) return rc;
   } else if (rc) return rc;

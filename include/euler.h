@@ -154,7 +154,9 @@ enum {
   EULER_F_PRESSURE,       /* double p — a stack local of project(), main.c:739; exposed here */
   EULER_F_PCG_B, EULER_F_PCG_R, EULER_F_PCG_Z, EULER_F_PCG_S, EULER_F_PCG_Q, /* double, main.c:716-745,578.  Test surface: after a solve S is the search
                                                               direction of the last iteration that ran (+0 off the fluid and when the right-hand side was
-                                                              all zero); Q holds A s only where a solve stores it (most do not any more) */
+                                                              all zero); Q holds A s only where a solve stores it (most do not any more).
+                                                              After a solve that ran in the resident kernel (euler_resident_info) Z, S and Q do not exist in
+                                                              memory: euler_get_field returns EULER_ESTATE for them until a multi-kernel solve has run */
   EULER_F_CELLMASK,       /* uint8: bit0 fluid, bit1..4 fluid at x+1,y+1,x-1,y-1, bits5-7 a_diag (g_a, main.c:552) */
   EULER_F_DYE_R, EULER_F_DYE_G, EULER_F_DYE_B,             /* float g_r, g_g, g_b (main.c:76-78); euler_config.rainbow only */
   EULER_F_DYE_RTMP, EULER_F_DYE_GTMP, EULER_F_DYE_BTMP,    /* float g_rtmp, g_gtmp, g_btmp (main.c:79-81): state, because the

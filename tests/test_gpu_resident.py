@@ -61,6 +61,13 @@ def test_resident_capped_solves_take_the_reference_budget():
         assert sa.last_substeps == sb.last_substeps and sa.last_pcg_iterations == sb.last_pcg_iterations == 100 * sa.last_substeps
     # a tank at rest, 100 unconverged iterations: the dot products' rounding is amplified; the fields agree loosely, the cell grid exactly
     assert np.array_equal(a.get(ea.F_COUNT) > 0, b.get(ea.F_COUNT) > 0)
+    # z, s and A s of a resident solve never leave the registers: the test surface says so instead of showing the arrays' leftovers; p, r, b are there
+    for f in (ea.F_PCG_Z, ea.F_PCG_S, ea.F_PCG_Q):
+        with pytest.raises(ea.EulerError) as e:
+            a.get(f)
+        assert e.value.code == -5 and "resident" in str(e.value)      # EULER_ESTATE
+        assert b.get(f).shape == (512, 512)
+    assert np.isfinite(a.get(ea.F_PCG_R)).all() and np.abs(a.get(ea.F_PRESSURE)).max() > 0
 
 
 def test_resident_against_the_oracle_tile_mode():

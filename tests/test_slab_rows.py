@@ -217,6 +217,15 @@ def test_a_part_file_one_rank_cannot_read_fails_the_load_on_every_rank(tmp_path)
     os.remove(top)
     d = run(2, 256, 512, "dam_break", 0, ea.PRECOND_IC0_TILE, 29603, ("load=" + snap, "loadfail"))
     assert d["loadfail"]["failed"] == [True, True] and "cannot open" in d["loadfail"]["msg"][1], d
+    # an overwrite that died between the renames of the part files leaves parts of two states under one manifest.  Ranks that read different files compare
+    # what they saw (one all-reduce) before anything is restored: the load fails on both
+    a, b = str(tmp_path / "a.snap"), str(tmp_path / "b.snap")
+    run(2, 256, 512, "dam_break", 2, ea.PRECOND_IC0_TILE, 29604, ("save=" + a,))
+    run(2, 256, 512, "dam_break", 4, ea.PRECOND_IC0_TILE, 29605, ("save=" + b,))
+    import shutil
+    shutil.copyfile(b + ".1of2", a + ".1of2")
+    d = run(2, 256, 512, "dam_break", 0, ea.PRECOND_IC0_TILE, 29606, ("load=" + a, "loadfail"))
+    assert d["loadfail"]["failed"] == [True, True] and any("different states" in m for m in d["loadfail"]["msg"]), d
 
 
 @pytest.mark.gpu

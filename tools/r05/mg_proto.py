@@ -283,6 +283,7 @@ def main():
             add("scan_om%.1f_ka%.1f" % (om, ka), v_bil(16, 1.0, exact=False, omega=om, kappa=ka, inter="bil"))
     add("bil8_vcycle_bil", v_bil(8, 1.0, exact=False, omega=0.8, kappa=1.0, inter="bil"))
     add("bil4_vcycle_bil", v_bil(4, 1.0, exact=False, omega=0.8, kappa=1.0, inter="bil"))
+    add("bil8_vcycle_bil_s2", v_bil(8, 1.0, exact=False, omega=0.8, kappa=1.0, inter="bil", nsmooth=2))
     add("mult_const16_exact_k1.0", v_const(16, 1.0))
     add("mult_bil16_exact_k1.0", v_bil(16, 1.0))
     for name, make in variants.items():
