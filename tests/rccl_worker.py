@@ -32,6 +32,7 @@ def torch_transport_selfcheck(rank, world):
     tc = object.__new__(TorchComm)
     tc.torch, tc.dist, tc.rank, tc.world, tc.stage, tc.error, tc._cache = torch, dist, rank, world, False, None, {}
     tc.counts = {"allreduce": 0, "halo": 0, "chain": 0, "allgather": 0}
+    tc.bytes = {"rows": 0, "gathered": 0, "allreduce": 0, "halo_rows": 0, "allgather": 0}
     x = torch.full((4,), float(rank + 1), dtype=torch.float64, device="cuda")
     rc = tc._allreduce(None, x.data_ptr(), 4, 0)
     want_sum = world * (world + 1) / 2
