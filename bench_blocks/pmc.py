@@ -33,7 +33,7 @@ def pmc_live(child_args, timeout_s=420):
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(base, counter)
-            cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__)] + child_args
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "bench.py")] + child_args
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
             dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
             if r.returncode != 0 or not dbs:

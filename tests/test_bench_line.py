@@ -123,3 +123,25 @@ def test_iteration_bytes_are_the_sum_of_the_launches():
         assert bench.PCG_BYTES["ic0_tile"] == 70
     finally:
         bench.set_as_stored(False)
+
+
+def test_the_pmc_passes_run_bench_py_itself(monkeypatch):
+    """The live PMC passes are child processes of the bench run: `rocprofv3 --pmc ... -- python bench.py <args> --pmc-child`.  The script they name must be bench.py (after the
+    split into bench_blocks/ it was the module's own file for a while, and `roofline.traffic` came back null)."""
+    import bench_blocks.pmc as pmc
+    seen = []
+
+    class Done:
+        returncode, stderr, stdout = 1, "stop here", ""
+
+    monkeypatch.setattr(pmc.shutil, "which", lambda name: "/opt/rocm/bin/rocprofv3")
+    monkeypatch.setattr(pmc.subprocess, "run", lambda cmd, **kw: (seen.append(cmd), Done())[1])
+    for k in [k for k in os.environ if k.startswith(("ROCPROF", "ROCP_TOOL"))] + ["LD_PRELOAD"]:
+        monkeypatch.delenv(k, raising=False)
+    traffic, note = pmc.pmc_live(["--size", "64", "--pmc-child"])
+    assert traffic is None and "failed" in note
+    cmd = seen[0]
+    i = cmd.index("--")
+    assert cmd[:3] == ["/opt/rocm/bin/rocprofv3", "--pmc", "FETCH_SIZE"] and not any(a in cmd for a in ("--sys-trace", "-s", "--hip-trace", "--runtime-trace"))
+    assert os.path.basename(cmd[i + 2]) == "bench.py" and os.path.samefile(cmd[i + 2], os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    assert cmd[i + 3:] == ["--size", "64", "--pmc-child"]

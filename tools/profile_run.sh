@@ -19,6 +19,6 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o write -- python
 python3 bench.py --size $SIZE --workload $WORKLOAD --precond $PRECOND --steps $STEPS --warmup 1 --no-secondary --no-pmc $EXTRA > "$OUT/bench_events.json" 2>> "$OUT/trace.log"
 python3 tools/summarize_profile.py "$OUT" > "$OUT/summary.md" 2>> "$OUT/trace.log"
 # keep only small artefacts for the merge back
-find "$OUT" -name "*.csv" -size +8M -delete
+find "$OUT" -type f -size +4M -delete
 tail -5 "$OUT/trace.log"
 cat "$OUT/summary.md" | head -60
