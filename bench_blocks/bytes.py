@@ -46,9 +46,10 @@ def set_as_stored(stored, p_steps=8):
         "ic0": {"forward_solve": _SWEEP, "backward_solve": _SWEEP, "apply_a": apply_, "update_pr": _RUPD},      # 109 (the reference's five loops: 18w+5 = 149; main.c as written: 212)
         "ic0_tile": {"apply_a": apply_, "precond_tile": _TILE},                                                   # 67
         "ic0_tile2": {"apply_a": apply_, "precond_tile": _TILE, "coarse_cycle": 0.0},
-        # multilevel: + the V-cycle: 48 doubles of partial sums per 16x64 tile written and read (0.75 B/cell) and the node grids - a node per 256 cells, per node nine stencil
-        # entries read on the way down and again on the way up + right-hand side / result (~190 B per node of level 0, a third more for the levels above: ~1.0 B/cell)
-        "ic0_tile_mg": {"apply_a": apply_, "precond_tile": _TILE, "coarse_cycle": 1.75},
+        # multilevel: + the V-cycle: 72 doubles of partial sums per 16 x 64 tile written and read (1.1 B/cell) and the node grids - a node per 64 cells, per node of level 0 the
+        # right-hand side written and read, omega / d and the "deep water" byte read on the way down and again on the way up, the result written and read by k_search_apply
+        # (~58 B per node: nine stencil entries only where the byte says so), a third more for the levels above: ~1.2 B/cell
+        "ic0_tile_mg": {"apply_a": apply_, "precond_tile": _TILE, "coarse_cycle": 2.3},
         "jacobi": {"apply_a": apply_, "update_pr": _RUPD, "jacobi": 2 * W + 1, "dot": 2 * W + 1},
     })
     PCG_BYTES.clear()

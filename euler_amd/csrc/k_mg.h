@@ -4,24 +4,30 @@
 #include "euler_dev.h"
 
 #define MG_OMEGA 0.8         // damped Jacobi on every level below the dense one (tools/r05/mg_proto.py: 0.7 - 1.0 are within two iterations of each other, 1.1 costs 40 %)
+// The Jacobi steps damp per node, omega_i = min(MG_OMEGA, MG_THETA / (1 + sum |off-diagonals| / d)): Gershgorin then keeps D~^-1 A below MG_THETA < 2 everywhere.  A regular node's
+// off-diagonals add up to its diagonal (0.8 either way); a drop of spray - one fluid cell between four nodes - is a rank-one block of eigenvalue 4 d that plain omega = 0.8 amplifies
+// by 2.2 per step: the cycle turned indefinite as the waterfall filled with spray and PCG fell back to the tile-local mode's iteration counts (oracle: mg_damping)
+#define MG_THETA 1.6
 #define MG_TOP_MAX 64        // nodes of the dense top level at most (its inverse lives in LDS: 32 KB)
 #define MG_MAXLEV 12
 // Level 0's node spacing in grid cells: node (I, J) sits AT the centre of cell (G0 J + G0 / 2, G0 I + G0 / 2).  8 (round 5): a tank at rest needs 30 PCG iterations to 1e-6 where
 // 16 - the tile width - needs 52 and round 4's aggregates of 16 needed 104 (tools/r05/mg_proto.py; dam break at impact 39 / 65 / 109, waterfall 37 / 63 / 124), for a level 0 of
-// four times the nodes.  Everything below follows from it: a band of 64 rows holds MG_RPB node rows; the lanes of a tile between the same two node rows form groups of
-// MG_LG = G0 / 2 (aligned: a DPP quad or half row); a lane's 16 columns lie between at most MG_NSEG + 1 node columns, a group's between MG_NSLOT.
+// four times the nodes.  Everything below follows from it: a band of 64 rows holds MG_RPB node rows; the lanes 8 G - 4 .. 8 G + 3 of a tile (GROUP G = (lane + 4) >> 3: 0 .. 8,
+// the first and the last half groups) lie between the same two node rows I0 = 8 band + G - 1 and I0 + 1, and their 16 + 7 columns between the four node columns
+// Jq .. Jq + 3, Jq = 2 k - G - 1 (k: the tile's index in its band): a tile leaves 9 groups x 2 node rows x 4 node columns = 72 sums (160 per tile with groups of four lanes,
+// until the two quads between the same node rows were merged: the gather of k_mg.hip then takes 4 loads per node instead of 16).
 #ifndef MG_G0
 #define MG_G0 8
 #endif
-#define MG_LOG (MG_G0 == 8 ? 3 : 4)
+#define MG_LOG 3
 #define MG_RPB (64 / MG_G0)
-#define MG_LG (MG_G0 / 2)
-#define MG_NGRP (64 / MG_LG)
-#define MG_NSEG (16 / MG_G0 + 1)
-#define MG_NSLOT (MG_NSEG + 2)
-#define MG_PART (MG_NGRP * 2 * MG_NSLOT)      // doubles k_precond_tile leaves per tile: per group of MG_LG lanes, 2 node rows x MG_NSLOT node columns (160 for G0 = 8)
+#define MG_LG 4                                // the quad: what a DPP butterfly adds in registers; the two quads of a group meet in LDS
+#define MG_NGRP 9
+#define MG_NSEG (16 / MG_G0 + 1)               // node intervals a lane's 16 columns can touch
+#define MG_NSLOT 4
+#define MG_PART (MG_NGRP * 2 * MG_NSLOT)       // doubles k_precond_tile leaves per tile: [group][row slot][column slot]
 #define MG_NI ((19 + MG_G0 - 1) / MG_G0 + 1)  // node intervals the 20 records of a k_search_apply run and its window can touch
-static_assert(MG_G0 == 8 || MG_G0 == 16, "MG_G0");
+static_assert(MG_G0 == 8, "MG_G0: the tiles' partial sums (k_precond_tile, mg_gather0) are laid out for nodes 8 cells apart");
 #define MG_NULL_MAX 4        // indicators of fluid regions cut off from the air that are kept (k_coarse.hip CC_NULL_MAX)
 #define MG_DOT_BLOCKS 4096   // workgroups of k_mg_up at most (tiles of 32 x 32 nodes of level 0: 16384^2 has 4096 with G0 = 8)
 #define MG_FIN_SLOT 7        // k_mg_up's epilogue on row slabs with a split cycle: x_0 . rhs_0 of the own rows is ADDED to the rank's slot instead of applied

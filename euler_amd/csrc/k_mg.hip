@@ -50,7 +50,14 @@ static MgHier mg_hier(const euler_sim* S) {
   H.a = S->mg_a; H.rhs = S->mg_rhs; H.x = S->mg_x; H.wd = S->mg_wd;
   H.inner0 = S->mg_inner0;
   for (int k = 0; k < 9; ++k) H.ic[k] = S->mg_ic[k];
-  H.icwd = MG_OMEGA / S->mg_ic[4];
+  {      // deep water's omega_i / d (k_mg_wd's expressions: a node flagged "inner" must get the bits its own entries would give)
+    const double d = S->mg_ic[4];
+    double off = 0.0;
+    for (int k = 0; k < 9; ++k) if (k != 4) off = off + fabs(S->mg_ic[k]);
+    double om = d != 0.0 ? MG_THETA / (1.0 + off / d) : 0.0;
+    if (om > MG_OMEGA) om = MG_OMEGA;
+    H.icwd = d != 0.0 ? om / d : 0.0;
+  }
   return H;
 }
 __device__ __forceinline__ const double* mg_sten(const MgHier& H, int l) { return H.a + 9 * (size_t)H.off[l]; }
@@ -263,35 +270,33 @@ __device__ __forceinline__ MgRect mg_owned_of(const MgRect& c, int cny, int cnx,
 }
 __device__ __forceinline__ bool mg_in(const MgRect& r, int i, int j) { return i >= r.i0 && i < r.i1 && j >= r.j0 && j < r.j1; }
 
-// level-0 right-hand side of node (I, J) from the tiles' partial sums (k_precond_tile): a group of MG_LG lanes (global lane index L = 64 band + MG_LG g, all of its rows between
-// the node rows v = (L - G0 / 2) >> LOG and v + 1) holds, per tile k, 2 node rows x MG_NSLOT node columns starting at column Jq(k, g) - [band][tile][group][row slot][column slot].
-// Node row I collects row slot 0 of the two groups with v = I and row slot 1 of the two with v = I - 1; per group the tiles whose column slots reach J.  Fixed order.
-#define MG_GK ((MG_G0 * MG_NSLOT + 15) / 16 + 1)
+// Level 0's right-hand side from the tiles' sums (k_precond_tile: [band][tile][group][row slot][column slot], k_mg.h).  Node row I collects row slot 0 of the groups with
+// I0 = I and row slot 1 of those with I0 = I - 1; I0 = 8 b + G - 1, so one group per node row - two HALF groups (G = 8 of band b - 1, G = 0 of band b) where the row lies
+// across a band boundary; node column J lies in the slots of exactly two tiles of a group, k = (J + G - 1) >> 1 (slot 2 or 3) and k + 1 (slot 0 or 1).  Four loads per node
+// (eight across a band boundary), every one issued before the first add; a fixed order.
 __device__ __forceinline__ double mg_gather0(const double* __restrict__ part, int I, int J, int ntb, int band_lo, int band_hi) {
-  double t = 0.0;
+  double v[8];
 #pragma unroll
   for (int rs = 0; rs < 2; ++rs) {
-    const int v = I - rs;
+    const int I0 = I - rs;
+    const int b1 = (I0 + 1) >> MG_LOG, G1 = I0 + 1 - MG_RPB * b1;      // (I0 >= -1)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int L = MG_G0 * v + MG_G0 / 2 + h * MG_LG;      // first lane of the group, counted over all bands
-      if (L < 0) continue;
-      const int b = L >> 6, gq = (L & 63) / MG_LG;
-      if (b < band_lo || b >= band_hi) continue;
-      const int c0 = MG_LG * gq + MG_LG - 1 + MG_G0 / 2;      // Jq(k) = (16 k - c0) >> LOG
-      const int k0 = (MG_G0 * (J - MG_NSLOT + 1) + c0 + 15) >> 4, k1 = ((MG_G0 * (J + 1) + c0 + 15) >> 4) - 1;      // the tiles whose column slots reach J: at most MG_GK of them
-      const double* row = part + (size_t)(b - band_lo) * ntb * MG_PART + (size_t)(gq * 2 + rs) * MG_NSLOT;      // [band][tile][group][row slot][column slot]
-      double v[MG_GK];
+      const int b = h == 0 ? b1 : b1 - 1, G = h == 0 ? G1 : 8;
+      const bool grp = (h == 0 || G1 == 0) && b >= band_lo && b < band_hi;
+      const int ka = (J + G - 1) >> 1;
+      const double* row = part + ((size_t)(grp ? b - band_lo : 0) * ntb) * MG_PART + (size_t)(G * 2 + rs) * MG_NSLOT;
 #pragma unroll
-      for (int u = 0; u < MG_GK; ++u) {      // (every load is issued before the first sum needs one: a node's sixteen loads are in flight together)
-        const int k = k0 + u, q = J - ((16 * k - c0) >> MG_LOG);
-        const bool ok = k >= 0 && k <= k1 && k < ntb && q >= 0 && q < MG_NSLOT;
-        v[u] = ok ? row[(size_t)k * MG_PART + q] : 0.0;
+      for (int u = 0; u < 2; ++u) {
+        const int k = ka + u, q = J - (2 * k - G - 1);      // u = 0: slot 2 or 3; u = 1: slot 0 or 1
+        const bool ok = grp && k >= 0 && k < ntb;
+        v[rs * 4 + h * 2 + u] = ok ? row[(size_t)k * MG_PART + q] : 0.0;
       }
-#pragma unroll
-      for (int u = 0; u < MG_GK; ++u) t = t + v[u];
     }
   }
+  double t = 0.0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) t = t + v[u];
   return t;
 }
 
@@ -1576,8 +1581,14 @@ __global__ __launch_bounds__(256) void k_mg_wd(const double* __restrict__ a, con
   const int l = blockIdx.y;
   const size_t n = (size_t)H.nx[l] * H.ny[l];
   if (c >= n) return;
-  const double d = mg_sten(H, l)[4 * n + c];
-  wd[H.off[l] + c] = d != 0.0 ? MG_OMEGA / d : 0.0;
+  const double* st = mg_sten(H, l);
+  const double d = st[4 * n + c];
+  double off = 0.0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) if (k != 4) off = off + fabs(st[(size_t)k * n + c]);
+  double om = d != 0.0 ? MG_THETA / (1.0 + off / d) : 0.0;      // (k_mg.h MG_THETA; oracle: mg_damping - the same expressions)
+  if (om > MG_OMEGA) om = MG_OMEGA;
+  wd[H.off[l] + c] = d != 0.0 ? om / d : 0.0;
 }
 // rows of a level's nine planes <-> a message (plane-major there too); mode 0: pack, 1: unpack (replace), 2: unpack, adding on the rows [add0, add1) (level 0: both ranks'
 // cells reach the node rows at a slab boundary; the entries are small multiples of 2^-12, their sums exact)

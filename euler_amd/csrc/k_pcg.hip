@@ -1442,7 +1442,7 @@ __global__ __launch_bounds__(PT_THREADS, RECOMP ? PT_RECOMP_BLOCKS : 1) void k_p
   // E^-1 of an interior tile, the same for all of them (k_tile_table): in LDS for the whole launch
   constexpr int TABP = W == 16 ? 8 : 1;
   __shared__ sw_d2 s_tab[TABP][64];
-  __shared__ double s_cpart[CMODE == 2 ? PT_THREADS / 64 : 1][CMODE == 2 ? MG_PART : 1];      // multilevel mode: a wave's partial sums on their way out
+  __shared__ double s_cpart[CMODE == 2 ? PT_THREADS / 64 : 1][CMODE == 2 ? 16 * 2 * MG_NSLOT : 1];      // multilevel mode: a wave's partial sums on their way out
   (void)s_cpart;
   const bool have_tab = W == 16 && listed && a.table != nullptr;
   if (have_tab) {
@@ -1539,18 +1539,17 @@ __global__ __launch_bounds__(PT_THREADS, RECOMP ? PT_RECOMP_BLOCKS : 1) void k_p
       }
       if (!a.sweeps) return;
       if (W == 16 && CMODE == 2) {
-        // multilevel mode (k_mg.hip): P_0^T r of this tile, P_0 bilinear from the nodes at the cells (G0 J + G0 / 2, G0 I + G0 / 2), G0 = MG_G0.  The lanes of a GROUP of
-        // MG_LG = G0 / 2 (aligned: a DPP quad for G0 = 8, a half row for 16) lie between the same two node rows I0, I0 + 1; a lane's 16 columns between at most MG_NSEG + 1 node
-        // columns starting at Jb (its own), a group's between MG_NSLOT starting at Jq (the group's last lane's).  A record's weight of the right-hand node is rec + b with b
-        // constant over a segment, so a lane accumulates sum rv and sum rec rv per segment, turns them into its node-column sums, shifts them to the group's slots, multiplies
-        // by its two row weights, and log2(MG_LG) DPP steps add the products over the group: 2 node rows x MG_NSLOT node columns per group (weights in 1 / G0)
-        const int gq = lane / MG_LG;
+        // multilevel mode (k_mg.hip): P_0^T r of this tile, P_0 bilinear from the nodes at the cells (G0 J + G0 / 2, G0 I + G0 / 2), G0 = MG_G0 = 8.  The eight lanes of a GROUP
+        // (k_mg.h) lie between the same two node rows I0, I0 + 1; a lane's 16 columns between at most MG_NSEG + 1 node columns starting at Jb (its own), the group's between
+        // MG_NSLOT = 4 starting at Jq.  A record's weight of the right-hand node is rec + b with b constant over a segment, so a lane accumulates sum rv and sum rec rv per
+        // segment, turns them into its node-column sums, shifts them to the group's slots and multiplies by its two row weights (weights in 1 / G0)
+        const int quad = lane >> 2, G = (lane + 4) >> 3;      // the group: lanes 8 G - 4 .. 8 G + 3 (k_mg.h)
         const int uy = 64 * band + lane - MG_G0 / 2, I0 = uy >> MG_LOG;
         double wy1 = (double)(uy & (MG_G0 - 1)), wy0 = (double)MG_G0 - wy1;
         if (I0 < 0) { wy0 = 0.0; wy1 = (double)MG_G0; }
         if (I0 >= a.cny - 1) { wy0 = (double)MG_G0; wy1 = 0.0; }
         const int x0 = 16 * k - lane - MG_G0 / 2, Jb = x0 >> MG_LOG, tbase = MG_G0 * Jb - x0;      // tbase in (-G0, 0]: records >= tbase + G0 m lie in segment m
-        const int Jq = (16 * k - (MG_LG * gq + MG_LG - 1) - MG_G0 / 2) >> MG_LOG;
+        const int Jq = 2 * k - G - 1;      // the group's first node column: Jb - Jq is 1 for the group's first lane (whose third segment is empty), 0 for the others
         double sg_s[MG_NSEG], sg_t[MG_NSEG];
 #pragma unroll
         for (int m = 0; m < MG_NSEG; ++m) { sg_s[m] = 0.0; sg_t[m] = 0.0; }
@@ -1575,24 +1574,31 @@ __global__ __launch_bounds__(PT_THREADS, RECOMP ? PT_RECOMP_BLOCKS : 1) void k_p
           if (Jb + m >= a.cnx - 1) { u0 = (double)MG_G0 * sg_s[m]; u1 = 0.0; }
           cn[m] += u0; cn[m + 1] += u1;
         }
-        const bool shifted = Jb != Jq;      // (Jb - Jq is 0 or 1)
+        const bool shifted = Jb != Jq;
         wy0 *= 1.0 / (MG_G0 * MG_G0); wy1 *= 1.0 / (MG_G0 * MG_G0);
-        // the tile's MG_PART sums go out as ONE contiguous piece, [tile][group][row slot][column slot], through a row of LDS: three coalesced stores per wave instead of ten
-        // instructions of sixteen scattered doubles (8192^2: 251 -> ~210 us for the pass; the gather of k_mg.hip reads two or three neighbouring doubles per tile either way)
+        // Two DPP steps add the products over a quad; the two quads of a group meet in a row of LDS on the way out, and the tile's MG_PART sums leave as ONE contiguous
+        // piece, [tile][group][row slot][column slot]: two coalesced stores per wave (scattered doubles cost 44 us per pass at 8192^2)
         double* sp = s_cpart[threadIdx.x >> 6];
 #pragma unroll
         for (int q = 0; q < MG_NSLOT; ++q) {
-          const double lo = q <= MG_NSEG ? cn[q] : 0.0, hi = q >= 1 ? cn[q - 1] : 0.0;
+          const double lo = cn[q], hi = q >= 1 ? cn[q - 1] : 0.0;
           const double cs = shifted ? hi : lo;
           const double p0 = group_sum(wy0 * cs), p1 = group_sum(wy1 * cs);
-          if (lane % MG_LG == 0) { sp[gq * 2 * MG_NSLOT + q] = p0; sp[gq * 2 * MG_NSLOT + MG_NSLOT + q] = p1; }
+          if ((lane & 3) == 0) { sp[quad * 2 * MG_NSLOT + q] = p0; sp[quad * 2 * MG_NSLOT + MG_NSLOT + q] = p1; }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         {
           double* cp = a.cpart + (size_t)tile * MG_PART;
 #pragma unroll
-          for (int u = 0; u < (MG_PART + 63) / 64; ++u) { const int e = lane + 64 * u; if (e < MG_PART) cp[e] = sp[e]; }
+          for (int u = 0; u < (MG_PART + 63) / 64; ++u) {
+            const int e = lane + 64 * u;
+            if (e < MG_PART) {
+              const int g = e / (2 * MG_NSLOT), w = e % (2 * MG_NSLOT);      // group g = quads 2 g - 1 and 2 g (the half groups: quad 0 / quad 15 alone)
+              const double va = g > 0 ? sp[(2 * g - 1) * 2 * MG_NSLOT + w] : 0.0, vb = g < 8 ? sp[(2 * g) * 2 * MG_NSLOT + w] : 0.0;
+              cp[e] = va + vb;
+            }
+          }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -697,9 +697,10 @@ static void coarse_correction(eo_sim* s, const double* r, double* z) {
  * solved exactly (dense_factor).  Round 3-4 used piecewise constants over the same blocks (aggregation, 5-point stencils with integer entries, correction scaled by 1.7):
  * 104 / 108 PCG iterations to 1e-6 on the 1024^2 / 2048^2 tank at rest, 109 on a 512^2 dam break at impact - the bilinear spaces need 52 / 52 / 64 with nodes 16 cells
  * apart and 30 / - / 39 with 8 (tools/r05/mg_proto.py). */
-typedef struct { int nx, ny; double* a[9]; double *rhs, *x, *t, *x1; } mg_level;
+typedef struct { int nx, ny; double* a[9]; double *rhs, *x, *t, *x1, *wd; } mg_level;      /* wd: the Jacobi steps' omega_i / d_i (mg_damping) */
 typedef struct { int nlev; mg_level lv[20]; int nnull; double* n0[4]; double* m0[4]; } mg_hierarchy;      /* n0 / m0: see mg_gauge */
 #define MG_OMEGA 0.8
+#define MG_THETA 1.6     /* the Jacobi steps stay below this Gershgorin bound of D~^-1 A (the product: k_mg.h MG_THETA) */
 #define MG_TOP_MAX 64
 #define MG_G0 8       /* level 0's node spacing in grid cells (the product: k_mg.h MG_G0) */
 #define MG_LOG 3
@@ -715,7 +716,7 @@ static void mg_alloc_level(mg_level* L, int nx, int ny) {
   L->nx = nx; L->ny = ny;
   L->a[0] = (double*)calloc(9 * n, sizeof(double));
   for (int k = 1; k < 9; ++k) L->a[k] = L->a[0] + k * n;
-  L->rhs = (double*)calloc(4 * n, sizeof(double)); L->x = L->rhs + n; L->t = L->rhs + 2 * n; L->x1 = L->rhs + 3 * n;
+  L->rhs = (double*)calloc(5 * n, sizeof(double)); L->x = L->rhs + n; L->t = L->rhs + 2 * n; L->x1 = L->rhs + 3 * n; L->wd = L->rhs + 4 * n;
 }
 /* cell c of a row / column of cells against n nodes, node j AT the centre of cell G0 j + G0 / 2 (so a node's hat is 0 at the neighbouring nodes and the Galerkin operators are
  * exact nine-point stencils): the two nodes j0, j1 around the cell and the weight f of j1 (1 - f of j0), a multiple of 1 / G0; constant beyond the outermost nodes */
@@ -739,6 +740,22 @@ static inline void mg_w1(int c, int n, int* j0, int* j1, double* f) {
 static inline void mg_add(mg_level* L, int I, int J, int I2, int J2, double v) {      /* A[(I, J), (I2, J2)] += v */
   if (v == 0.0) return;
   L->a[(I2 - I + 1) * 3 + (J2 - J + 1)][(size_t)I * L->nx + J] += v;
+}
+/* Damped Jacobi, x += (omega_i / d_i) (rhs - A x)_i, converges iff the eigenvalues of D~^-1 A stay below 2.  On a regular node of these nine-point operators the off-diagonal
+ * entries add up to the diagonal and omega = 0.8 gives 1.6; but a drop of spray - ONE fluid cell seen by its four nodes - is a rank-one block whose eigenvalue is 4 d, and the
+ * step then amplifies that mode by |1 - 3.2|: the cycle turns indefinite, and with a few hundred drops on the grid (the waterfall after 100 s) PCG needs as many iterations as
+ * without a coarse correction.  So every node damps by omega_i = min(omega, theta / (1 + sum |off-diagonals| / d)): Gershgorin keeps D~^-1 A below theta = 1.6 < 2 everywhere,
+ * regular nodes keep 0.8, and the cycle stays symmetric (the same D~ before and behind the correction) and positive. */
+static void mg_damping(mg_level* L) {
+  const size_t n = (size_t)L->nx * L->ny;
+  for (size_t c = 0; c < n; ++c) {
+    const double d = L->a[4][c];
+    double off = 0.0;
+    for (int k = 0; k < 9; ++k) if (k != 4) off = off + fabs(L->a[k][c]);
+    double om = d != 0.0 ? MG_THETA / (1.0 + off / d) : 0.0;
+    if (om > MG_OMEGA) om = MG_OMEGA;
+    L->wd[c] = d != 0.0 ? om / d : 0.0;
+  }
 }
 static void mg_build(eo_sim* s, double** A_top, int* n_top, int* nx_top) {
   const int X = s->X, Y = s->Y;
@@ -794,6 +811,7 @@ static void mg_build(eo_sim* s, double** A_top, int* n_top, int* nx_top) {
         }
       }
   }
+  for (int k = 0; k < h->nlev; ++k) mg_damping(&h->lv[k]);
   s->mg = h;
   const mg_level* T = &h->lv[h->nlev - 1];
   const int n = T->nx * T->ny;
@@ -852,7 +870,7 @@ static void mg_vcycle(eo_sim* s, mg_hierarchy* h, int l) {      /* lv[l].x = V_l
   if (l == h->nlev - 1) { memcpy(L->x, L->rhs, n * sizeof(double)); coarse_top_solve(s, L->x); return; }
   mg_level* C = &h->lv[l + 1];
   const double* d = L->a[4];
-  for (size_t c = 0; c < n; ++c) L->x1[c] = d[c] != 0.0 ? (MG_OMEGA / d[c]) * L->rhs[c] : 0.0;      /* Jacobi from a zero guess (the product keeps omega / d per node) */
+  for (size_t c = 0; c < n; ++c) L->x1[c] = d[c] != 0.0 ? L->wd[c] * L->rhs[c] : 0.0;      /* Jacobi from a zero guess (the product keeps omega / d per node) */
   for (int I = 0; I < L->ny; ++I)
     for (int J = 0; J < L->nx; ++J) { const size_t c = (size_t)I * L->nx + J; L->t[c] = d[c] != 0.0 ? L->rhs[c] - mg_apply(L, L->x1, I, J) : 0.0; }
   mg_restrict(L, L->t, C, C->rhs);
@@ -860,7 +878,7 @@ static void mg_vcycle(eo_sim* s, mg_hierarchy* h, int l) {      /* lv[l].x = V_l
   for (int I = 0; I < L->ny; ++I)      /* the correction */
     for (int J = 0; J < L->nx; ++J) { const size_t c = (size_t)I * L->nx + J; L->t[c] = d[c] != 0.0 ? L->x1[c] + mg_interp1(L, C, C->x, I, J) : 0.0; }
   for (int I = 0; I < L->ny; ++I)      /* Jacobi again */
-    for (int J = 0; J < L->nx; ++J) { const size_t c = (size_t)I * L->nx + J; L->x[c] = d[c] != 0.0 ? L->t[c] + (MG_OMEGA / d[c]) * (L->rhs[c] - mg_apply(L, L->t, I, J)) : 0.0; }
+    for (int J = 0; J < L->nx; ++J) { const size_t c = (size_t)I * L->nx + J; L->x[c] = d[c] != 0.0 ? L->t[c] + L->wd[c] * (L->rhs[c] - mg_apply(L, L->t, I, J)) : 0.0; }
 }
 static double* mg_null_level0(eo_sim* s, const double* nv);
 /* Water cut off from the air: its pressure is determined up to a constant, PCG delivers the one with n . M p = 0 (M the preconditioner, n the region's indicator) and the

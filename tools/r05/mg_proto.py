@@ -155,7 +155,7 @@ def bil2(nx):
     return P, cx
 
 
-def vcycle_solver(A0, nx0, top=256, omega=1.0, kappa=1.7, inter="agg", nsmooth=1, smoother="jacobi"):
+def vcycle_solver(A0, nx0, top=256, omega=1.0, kappa=1.7, inter="agg", nsmooth=1, smoother="jacobi", theta=1.6):
     """the product's cycle: Jacobi from zero, restricted residual, recursion, scaled correction, Jacobi; dense top level"""
     levels = []
     A, nx = A0, nx0
@@ -185,6 +185,10 @@ def vcycle_solver(A0, nx0, top=256, omega=1.0, kappa=1.7, inter="agg", nsmooth=1
         if smoother == "l1":
             l1 = np.asarray(abs(A).sum(axis=1)).ravel()
             dinv = np.where(d > 0, 1.0 / np.where(l1 > 0, l1, 1), 0.0)
+        if smoother == "gersh":      # per-node damping: omega_i = min(omega, theta / (1 + s_i)), s_i = sum |off-diagonals| / diagonal: the Gershgorin bound of D~^-1 A stays below theta < 2
+            l1 = np.asarray(abs(A).sum(axis=1)).ravel()
+            sden = np.where(d > 0, l1 / np.where(d > 0, d, 1), 1.0)      # 1 + s_i
+            dinv = dinv * np.minimum(omega, theta / sden) / omega
         x = smooth(A, dinv, None, rhs, True)
         xc = cyc(l + 1, P.T @ (rhs - A @ x))
         x = x + kappa * (P @ xc)
@@ -283,6 +287,9 @@ def main():
             add("scan_om%.1f_ka%.1f" % (om, ka), v_bil(16, 1.0, exact=False, omega=om, kappa=ka, inter="bil"))
     add("bil8_vcycle_bil", v_bil(8, 1.0, exact=False, omega=0.8, kappa=1.0, inter="bil"))
     add("bil4_vcycle_bil", v_bil(4, 1.0, exact=False, omega=0.8, kappa=1.0, inter="bil"))
+    add("bil8_vcycle_gersh16", v_bil(8, 1.0, exact=False, omega=0.8, kappa=1.0, inter="bil", smoother="gersh", theta=1.6))
+    add("bil8_vcycle_gersh18", v_bil(8, 1.0, exact=False, omega=0.8, kappa=1.0, inter="bil", smoother="gersh", theta=1.8))
+    add("bil8_vcycle_l1", v_bil(8, 1.0, exact=False, omega=1.0, kappa=1.0, inter="bil", smoother="l1"))
     add("bil8_vcycle_bil_s2", v_bil(8, 1.0, exact=False, omega=0.8, kappa=1.0, inter="bil", nsmooth=2))
     add("mult_const16_exact_k1.0", v_const(16, 1.0))
     add("mult_bil16_exact_k1.0", v_bil(16, 1.0))
