@@ -5,8 +5,8 @@
 
 #define MG_OMEGA 0.8         // damped Jacobi on every level below the dense one (tools/r05/mg_proto.py: 0.7 - 1.0 are within two iterations of each other, 1.1 costs 40 %)
 // The Jacobi steps damp per node, omega_i = min(MG_OMEGA, MG_THETA / (1 + sum |off-diagonals| / d)): Gershgorin then keeps D~^-1 A below MG_THETA < 2 everywhere.  A regular node's
-// off-diagonals add up to its diagonal (0.8 either way); a drop of spray - one fluid cell between four nodes - is a rank-one block of eigenvalue 4 d that plain omega = 0.8 amplifies
-// by 2.2 per step: the cycle turned indefinite as the waterfall filled with spray and PCG fell back to the tile-local mode's iteration counts (oracle: mg_damping)
+// off-diagonals add up to its diagonal (0.8 either way); a drop of spray - one fluid cell between four nodes - is a rank-one block of eigenvalue 4 d that plain omega = 0.8 multiplies
+// by 1 - 3.2 per step: as the waterfall filled with spray the cycle stopped approximating the coarse solve and PCG fell back to the tile-local mode's iteration counts (oracle: mg_damping)
 #define MG_THETA 1.6
 #define MG_TOP_MAX 64        // nodes of the dense top level at most (its inverse lives in LDS: 32 KB)
 #define MG_MAXLEV 12

@@ -743,16 +743,16 @@ static inline void mg_add(mg_level* L, int I, int J, int I2, int J2, double v) {
 }
 /* Damped Jacobi, x += (omega_i / d_i) (rhs - A x)_i, converges iff the eigenvalues of D~^-1 A stay below 2.  On a regular node of these nine-point operators the off-diagonal
  * entries add up to the diagonal and omega = 0.8 gives 1.6; but a drop of spray - ONE fluid cell seen by its four nodes - is a rank-one block whose eigenvalue is 4 d, and the
- * step then amplifies that mode by |1 - 3.2|: the cycle turns indefinite, and with a few hundred drops on the grid (the waterfall after 100 s) PCG needs as many iterations as
- * without a coarse correction.  So every node damps by omega_i = min(omega, theta / (1 + sum |off-diagonals| / d)): Gershgorin keeps D~^-1 A below theta = 1.6 < 2 everywhere,
+ * step then multiplies that mode by 1 - 3.2 instead of damping it: the cycle stops approximating the coarse solve, and with a few hundred drops on the grid (the waterfall after
+ * 100 s) PCG needs as many iterations as without a coarse correction.  So every node damps by omega_i = min(omega, theta / (1 + sum |off-diagonals| / d)): Gershgorin keeps D~^-1 A below theta = 1.6 < 2 everywhere,
  * regular nodes keep 0.8, and the cycle stays symmetric (the same D~ before and behind the correction) and positive. */
-static void mg_damping(mg_level* L) {
+static void mg_damping(mg_level* L, double theta) {
   const size_t n = (size_t)L->nx * L->ny;
   for (size_t c = 0; c < n; ++c) {
     const double d = L->a[4][c];
     double off = 0.0;
     for (int k = 0; k < 9; ++k) if (k != 4) off = off + fabs(L->a[k][c]);
-    double om = d != 0.0 ? MG_THETA / (1.0 + off / d) : 0.0;
+    double om = d != 0.0 ? theta / (1.0 + off / d) : 0.0;
     if (om > MG_OMEGA) om = MG_OMEGA;
     L->wd[c] = d != 0.0 ? om / d : 0.0;
   }
@@ -811,7 +811,7 @@ static void mg_build(eo_sim* s, double** A_top, int* n_top, int* nx_top) {
         }
       }
   }
-  for (int k = 0; k < h->nlev; ++k) mg_damping(&h->lv[k]);
+  for (int k = 0; k < h->nlev; ++k) mg_damping(&h->lv[k], s->mg_theta > 0.0 ? s->mg_theta : MG_THETA);
   s->mg = h;
   const mg_level* T = &h->lv[h->nlev - 1];
   const int n = T->nx * T->ny;

@@ -85,6 +85,7 @@ typedef struct eo_sim {
    * hold float values. */
   int pcg_f32;
   int coarse_bw;                /* half-bandwidth of coarse_chol */
+  double mg_theta;              /* tests: the bound of the cycle's per-node Jacobi damping (mg_damping); 0 = the product's MG_THETA, 1e30 = plain omega on every node */
 } eo_sim;
 
 eo_sim* eo_create(int X, int Y);

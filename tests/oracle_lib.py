@@ -46,7 +46,7 @@ class EoSim(C.Structure):
         ("coarse_m", C.c_int), ("coarse_n", C.c_int), ("coarse_nx", C.c_int), ("coarse_chol", C.POINTER(C.c_double)),
         ("coarse_mg", C.c_int), ("mg", C.c_void_p),
         ("coarse_npinned", C.c_int), ("coarse_pinned", C.c_int * 16), ("coarse_null", C.POINTER(C.c_double)),
-        ("pcg_f32", C.c_int), ("coarse_bw", C.c_int),
+        ("pcg_f32", C.c_int), ("coarse_bw", C.c_int), ("mg_theta", C.c_double),
     ]
 
 

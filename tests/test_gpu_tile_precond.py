@@ -380,6 +380,30 @@ def test_multilevel_preconditioner_matches_the_oracle_restatement(X, Y):
     assert np.abs(sim.get(ea.F_U) - o.u).max() < 1e-5 and np.abs(sim.get(ea.F_V) - o.v).max() < 1e-5
 
 
+def test_multilevel_mode_with_spray_above_the_pool_matches_the_oracle():
+    """The per-node damping of the cycle's Jacobi steps (k_mg_wd; oracle: mg_damping; tests/test_oracle_tile.py has the story): a pool with 200 single-cell drops above it
+    solves in the iterations of a pool without them, on the GPU as in the oracle, and five capped iterations agree to rounding."""
+    from test_oracle_tile import _spray_text
+    X, Y = 256, 192
+    text = _spray_text(X - 5, Y - 2, 200)
+    for maxit in (5, 4000):
+        o = Oracle(X, Y).load_text(text, upscale=False)
+        o.c.tile_records = 16; o.c.coarse_m = o.lib.eo_coarse_m(X, Y); o.c.coarse_mg = 1; o.c.max_iterations = maxit
+        sim = ea.Simulation(X, Y, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE_MG, max_iterations=maxit).load_text(text, upscale=False)
+        o.step(); sim.step()
+        st = sim.stats()
+        pr = o.p
+        if maxit == 5:
+            assert st.last_pcg_iterations == o.c.last_pcg_iterations == 5
+            assert np.abs(sim.get(ea.F_PRESSURE) - pr).max() <= 1e-11 * np.abs(pr).max()
+        else:
+            assert st.last_residual <= 1e-6 and o.c.last_residual <= 1e-6
+            assert abs(st.last_pcg_iterations - o.c.last_pcg_iterations) <= 2 and st.last_pcg_iterations <= 36, (st.last_pcg_iterations, o.c.last_pcg_iterations)
+            assert np.abs(sim.get(ea.F_PRESSURE) - pr).max() <= 1e-6 * np.abs(pr).max()
+        assert_bits(sim.get(ea.F_COUNT), o.count, "cell grid")
+        sim.close(); o.close()
+
+
 def test_multilevel_iteration_counts_do_not_grow_with_the_grid():
     """Half tank from rest to the reference's tolerance at 512^2, 1024^2, 2048^2: the multilevel mode needs ~30 iterations at every size (bilinear
     coarse spaces on nodes 8 cells apart, round 5; rounds 3-4's piecewise-constant aggregates of 16: 107 / 108 / 118) where the reference's IC(0) needs 445 / 880 / 1726, and

@@ -198,3 +198,60 @@ def test_coarse_modes_on_a_closed_box_full_of_water():
     assert res["mg"][0] < 0.7 * res["ic0"][0] and res["two"][0] < 1.2 * res["ic0"][0], {k: v[0] for k, v in res.items()}      # (3 x 2 coarse cells only: the two-level mode gains nothing here)
     # the same cells hold water (the counts inside them are marker positions to 1e-6: they may differ by one)
     assert np.array_equal(res["mg"][1] > 0, res["ic0"][1] > 0) and np.array_equal(res["two"][1] > 0, res["ic0"][1] > 0)
+
+
+def _spray_text(W, H, drops, seed=5):
+    """a pool at the bottom of a walled box and `drops` single fluid cells above it, none touching another (the reference's format: first line = top row)"""
+    rng = np.random.default_rng(seed)
+    g = [[" "] * W for _ in range(H)]
+    for x in range(W):
+        g[0][x] = g[H - 1][x] = "X"
+    for y in range(H):
+        g[y][0] = g[y][W - 1] = "X"
+    for y in range(H - 1 - H // 4, H - 1):
+        for x in range(1, W - 1):
+            g[y][x] = "0"
+    k = 0
+    while k < drops:
+        x, y = int(rng.integers(3, W - 3)), int(rng.integers(3, H - 3 - H // 4))
+        if all(g[y + dy][x + dx] == " " for dy in (-1, 0, 1) for dx in (-1, 0, 1)):
+            g[y][x] = "0"
+            k += 1
+    return "\n".join("".join(r) for r in g) + "\n"
+
+
+def test_multilevel_cycle_with_spray_above_the_pool():
+    """Round 5, found by configs[4]'s 2000 steps: a drop of spray - ONE fluid cell between its four level-0 nodes - is a rank-one block of the Galerkin operator whose Jacobi
+    eigenvalue is 4; plain omega = 0.8 multiplies that mode by 1 - 3.2 per step instead of damping it, the cycle stops approximating the coarse solve, and a waterfall full of
+    spray needed ~1200 iterations per solve where it needs 57.  The per-node damping (mg_damping: Gershgorin bound 1.6) repairs it: a pool with 200 drops above it solves in the
+    iterations of a pool without drops; with the damping switched off (eo_sim.mg_theta = 1e30) the same solve takes half as many again (32 against 54 when this was written)."""
+    X, Y = 256, 192
+    text = _spray_text(X - 5, Y - 2, 200)
+    res = {}
+    for name, mg, theta in (("tile", 0, 0.0), ("damped", 1, 0.0), ("plain", 1, 1e30)):
+        o = Oracle(X, Y, fast=True).load_text(text, upscale=False)
+        o.c.tile_records = 16
+        o.c.coarse_m = mg and o.lib.eo_coarse_m(X, Y)
+        o.c.coarse_mg = mg
+        o.c.mg_theta = theta
+        o.c.max_iterations = 3000
+        o.step()
+        assert o.c.last_residual <= 1e-6
+        res[name] = (o.p.copy(), int(o.c.last_pcg_iterations))
+    assert res["damped"][1] <= 36 < 45 <= res["plain"][1] < res["tile"][1], {k: v[1] for k, v in res.items()}
+    assert np.abs(res["damped"][0] - res["tile"][0]).max() <= 1e-5 * np.abs(res["tile"][0]).max()
+    # still symmetric and positive, on right-hand sides that live on the drops too
+    o = Oracle(X, Y).load_text(text, upscale=False)
+    o.c.coarse_m = o.lib.eo_coarse_m(X, Y)
+    o.c.coarse_mg = 1
+    o.utmp[...] = o.u; o.vtmp[...] = o.v
+    o.lib.eo_build_system(o.ptr, np.float32(0.05), o.f32p(o.utmp), o.f32p(o.vtmp))
+    fluid = o.count > 0
+    drops = fluid & ~(fluid.sum(axis=1) > 100)[:, None]
+    assert 150 <= drops.sum() <= 210
+    rng = np.random.default_rng(8)
+    a = np.where(drops, rng.standard_normal(fluid.shape), 0.0)
+    b = np.where(fluid, rng.standard_normal(fluid.shape), 0.0)
+    Ma, Mb = _apply(o, 16, a), _apply(o, 16, b)
+    assert abs((Ma * b).sum() - (a * Mb).sum()) < 1e-10 * np.abs(Ma * b).sum()
+    assert (Ma * a).sum() > 0 and (Mb * b).sum() > 0
