@@ -1375,6 +1375,7 @@ void eu_mg_split_release(euler_sim* S) {
   if (st->abuf) (void)hipFree(st->abuf);
   delete st;
   S->mg_split = nullptr;
+  S->opt[EULER_OPT_MG_SPLIT_ACTIVE] = 0;
 }
 
 // pack: this rank's share on the rows a neighbour needs (ZONES) behind the edge row of z that k_precond_tile wrote into the message; its window of the gather level into

@@ -72,15 +72,19 @@ enum {
                                     z = M_tile^-1 r + P_0 V(P_0^T r),
                                 level 0 = a grid of nodes 8 cells apart (node (I, J) at the centre of cell (8 J + 4, 8 I + 4)), P_0 = bilinear interpolation from the four nodes
                                 around a cell, restricted to the fluid; every further level = every other node of the one below, bilinear again (full weighting); Galerkin
-                                operators (exact nine-point stencils), one symmetric V-cycle (damped Jacobi 0.8 before and after), the top level (<= 64 nodes) solved
+                                operators (exact nine-point stencils), one symmetric V-cycle (damped Jacobi before and after: 0.8, per node less where a Gershgorin bound of 1.6
+                                demands it - spray drops), the top level (<= 64 nodes) solved
                                 with the dense pseudo-inverse of the two-level mode.  The number of iterations to the reference's tolerance does not grow with the grid:
                                 ~30 on a tank at rest at any size, 40-50 on moving water, where the reference's IC(0) needs 231 (256^2), 880 (1024^2), thousands (8192^2)
-                                and rounds 3-4's piecewise-constant aggregates of 16 cells needed 105-150.  Cost per iteration: the tile-local mode's two passes (+ 160
+                                and rounds 3-4's piecewise-constant aggregates of 16 cells needed 105-150.  Cost per iteration: the tile-local mode's two passes (+ 72
                                 doubles of partial sums per 1024-cell tile) + five launches over node grids 1/64 the size of the grid and less.  Restated in the oracle
-                                (eo_sim.coarse_mg): GPU = oracle to rounding.  EULER_DOT_TREE.  One GPU, or row slabs without mailboxes (euler_config.slab_*): per solve one
-                                all-reduce makes the level-0 operator whole (exact sums: the same bits on every rank); per iteration every rank contributes, inside the G1
-                                exchange's all-gather, what ITS tiles add to its node rows and one row either side (cells / 64 doubles over all ranks: 32 MB at 16384^2),
-                                the shares are added in rank order and all ranks run the same V-cycle - the same bits everywhere.  Water cut off from the air (a singular
+                                (eo_sim.coarse_mg): GPU = oracle to rounding.  EULER_DOT_TREE.  One GPU, or row slabs without mailboxes (euler_config.slab_*).  On slabs the cycle is SPLIT BY ROWS
+                                wherever a level of <= 16384 nodes lies above level 0 and the slabs are a few bands thick (EULER_OPT_MG_SPLIT_LEVEL): a rank takes
+                                its own tiles' share down to that level, windows of it are all-gathered inside the G1 exchange (0.16 MB per iteration at 16384^2 on 8 ranks), the
+                                neighbours' shares on a rank's halo rows travel with the edge rows of z, the coarse levels run replicated, the fine levels on the own node rows, and
+                                one more 40-byte exchange sums the correction's share of dot(z, r); per solve the operators are formed by their owners.  Otherwise (small grids,
+                                thin slabs, EULER_OPT_MG_SPLIT_LEVEL = -1) the cycle runs replicated: one all-reduce per solve makes the level-0 operator whole, every rank
+                                contributes its node rows to the G1 all-gather (cells / 64 doubles over all ranks: 32 MB at 16384^2).  Either way every rank computes the same bits.  Water cut off from the air (a singular
                                 system): the right-hand side is made compatible with the region's indicator, and the correction is kept mean-free over the region so that
                                 the pressure's constant - which the reference's clamp p >= 0 makes observable - is the tile-local factor's, i.e. very nearly the reference's. */
 };
