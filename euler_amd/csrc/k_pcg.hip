@@ -373,7 +373,9 @@ struct SaHist { const double* s[6]; };   // PMODE N: the arrays of s_(k-N+1) .. 
 // COARSE 2 (multilevel preconditioner, k_mg.hip): z + P_0 x_0 with P_0 bilinear from the level-0 nodes - the lane combines its two node rows once per run (four node columns
 // cover the run and its window), every cell then interpolates along its row; the expression is mg_interp0's, so a cell gets the same bits whoever forms its s'.
 template <int SLAB, int PMODE, int SA_RUN, int COARSE = 0, bool STORE = true>   // SLAB 1: several ranks, the neighbouring slabs' arrays are mapped; 2: their edge rows as compact rows (nbr); 0: nbr is ignored
-__global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __restrict__ s_old, const double* __restrict__ z,
+// (multilevel mode, one GPU, seven of eight passes: four waves per SIMD - 128 registers, one of them spilled - since the lanes' level-0 node values live in LDS: 212 -> 197 us at 8192^2;
+// forced onto the 150 registers of the select-chain form the same bound cost 100 bytes of scratch and 288 us)
+__global__ __launch_bounds__(SA_THREADS, (COARSE == 2 && PMODE == 1 && SLAB == 0) ? 4 : 1) void k_search_apply(const double* __restrict__ s_old, const double* __restrict__ z,
                                                              double* __restrict__ s_new, double* __restrict__ out,
                                                              const uint8_t* __restrict__ mask, SkewGeom g,
                                                              double* __restrict__ partial, PcgScalars* sc, int force,
@@ -381,6 +383,8 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
                                                              double* __restrict__ p, double* s_new_base, double* s_old_base,
                                                              const unsigned int* __restrict__ chunk_list,      // SA_RUN == 8 only: the solve's active runs
                                                              CoarseRef cref, SaHist hist) {
+  __shared__ double s_cy[COARSE == 2 ? SA_THREADS / 64 : 1][COARSE == 2 ? MG_NI + 1 : 1][64];      // multilevel mode: a lane's node values of the run (own row / the row across the band boundary)
+  __shared__ double s_ce[COARSE == 2 ? SA_THREADS / 64 : 1][COARSE == 2 ? MG_NI + 1 : 1][64];
   if (!force && pcg_idle(sc)) return;
   const double beta = sc->beta;
   (void)s_new_base; (void)s_old_base;
@@ -442,9 +446,8 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
       // COARSE: this lane's columns in the run (pairs P0 - 1 .. P1: 20 records at most) start in aggregate column Ja, reach Ja + 1 at record
       // tb1 and Ja + 2 at record tb2 (aggregates of 16: three columns; of 64 and more: two); the lane's row decides the aggregate row
       double cy0 = 0.0, cy1 = 0.0, cy2 = 0.0, ce0 = 0.0, ce1 = 0.0, ce2 = 0.0;
-      double cyv[MG_NI + 1], cev[MG_NI + 1];
-#pragma unroll
-      for (int q = 0; q <= MG_NI; ++q) { cyv[q] = 0.0; cev[q] = 0.0; }
+      double (*cyv)[64] = s_cy[COARSE == 2 ? threadIdx.x >> 6 : 0];
+      double (*cev)[64] = s_ce[COARSE == 2 ? threadIdx.x >> 6 : 0];
       int ctb1 = 0x7fffffff, ctb2 = 0x7fffffff, cJb = 0;
       (void)cJb;
       if (COARSE == 2) {
@@ -460,23 +463,26 @@ __global__ __launch_bounds__(SA_THREADS) void k_search_apply(const double* __res
         const double* y0 = cref.y + (size_t)i0 * cref.nx;
         const double* y1 = cref.y + (size_t)i1 * cref.nx;
 #pragma unroll
-        for (int q = 0; q <= MG_NI; ++q) { const int c = cJb + q < 0 ? 0 : (cJb + q < hi_ ? cJb + q : hi_); cyv[q] = mg_rows(y0[c], y1[c], fy); }
+        for (int q = 0; q <= MG_NI; ++q) { const int c = cJb + q < 0 ? 0 : (cJb + q < hi_ ? cJb + q : hi_); cyv[q][lane] = mg_rows(y0[c], y1[c], fy); }
+#pragma unroll
+        for (int q = 0; q <= MG_NI; ++q) cev[q][lane] = 0.0;
         if (edge_lane) {      // the row across the band boundary
           const int re = row + (lane == 0 ? -1 : 1);
           if (re >= 0 && re < MG_G0 * cref.ny) {
             mg_cell_w(re, cref.ny, i0, i1, fy);
             y0 = cref.y + (size_t)i0 * cref.nx; y1 = cref.y + (size_t)i1 * cref.nx;
 #pragma unroll
-            for (int q = 0; q <= MG_NI; ++q) { const int c = cJb + q < 0 ? 0 : (cJb + q < hi_ ? cJb + q : hi_); cev[q] = mg_rows(y0[c], y1[c], fy); }
+            for (int q = 0; q <= MG_NI; ++q) { const int c = cJb + q < 0 ? 0 : (cJb + q < hi_ ? cJb + q : hi_); cev[q][lane] = mg_rows(y0[c], y1[c], fy); }
           }
         }
       }
-      auto p0y = [&](int t, const double (&av)[MG_NI + 1]) __attribute__((always_inline)) {      // (P_0 x_0) at the lane's column of record t, from a row's node values
+      // (the node values sit in LDS, [node column][lane]: a record picks its interval by arithmetic and reads two of them - conflict-free, and twenty registers fewer than arrays
+      // with a chain of selects per record)
+      auto p0y = [&](int t, double (*av)[64]) __attribute__((always_inline)) {      // (P_0 x_0) at the lane's column of record t, from a row's node values
         const double f = (double)((t - lane - MG_G0 / 2) & (MG_G0 - 1)) * (1.0 / MG_G0);
-        double lo = av[0], hi = av[1];
-#pragma unroll
-        for (int m = 1; m < MG_NI; ++m) { const bool in = t >= ctb1 + MG_G0 * (m - 1); lo = in ? av[m] : lo; hi = in ? av[m + 1] : hi; }
-        return mg_lerp_x(lo, hi, f);
+        int m = t >= ctb1 ? ((t - ctb1) >> MG_LOG) + 1 : 0;
+        m = m < MG_NI - 1 ? m : MG_NI - 1;
+        return mg_lerp_x(av[m][lane], av[m + 1][lane], f);
       };
       if (COARSE == 1) {
         const int xa = 2 * (P0 - 1) - lane, Ja = (xa > 0 ? xa : 0) >> cref.shift;
