@@ -375,6 +375,7 @@ struct SaHist { const double* s[6]; };   // PMODE N: the arrays of s_(k-N+1) .. 
 template <int SLAB, int PMODE, int SA_RUN, int COARSE = 0, bool STORE = true>   // SLAB 1: several ranks, the neighbouring slabs' arrays are mapped; 2: their edge rows as compact rows (nbr); 0: nbr is ignored
 // (multilevel mode, one GPU, seven of eight passes: four waves per SIMD - 128 registers, one of them spilled - since the lanes' level-0 node values live in LDS: 212 -> 197 us at 8192^2;
 // forced onto the 150 registers of the select-chain form the same bound cost 100 bytes of scratch and 288 us)
+// (the tile-local mode's pass has 98 registers, four waves; squeezed to 96 for five - 12 bytes of scratch - it takes 180 us instead of 169)
 __global__ __launch_bounds__(SA_THREADS, (COARSE == 2 && PMODE == 1 && SLAB == 0) ? 4 : 1) void k_search_apply(const double* __restrict__ s_old, const double* __restrict__ z,
                                                              double* __restrict__ s_new, double* __restrict__ out,
                                                              const uint8_t* __restrict__ mask, SkewGeom g,
