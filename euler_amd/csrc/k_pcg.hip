@@ -2399,7 +2399,11 @@ int eu_launch_project(euler_sim* S, float dt) {
   if ((rc = launch_precondition(S, 0, FIN_SIGMA_INIT))) return rc;
   }
   if ((rc = ring_begin(S))) return rc;      // (S->s = ring[0] takes the first search direction)
-  if (two_level) { if ((rc = eu_launch_coarse_search_init(S))) return rc; }      // s = z + P y
+  // multilevel mode on one GPU: the first search direction s = z + P y is formed by the first k_search_apply itself (beta is 0 behind k_pcg_reset, and 0 times what an earlier
+  // solve left in the ring is 0) - a copy pass and a k_apply_a less per solve.  Only there: no recorded digest pins this mode's zeros' signs (z = -0 comes out as +0)
+  const bool fold0 = two_level && eu_is_mg(S) && !S->has_comm && S->cfg.dot_mode != EULER_DOT_SEQUENTIAL && sa_run(S) == 8;
+  if (fold0) { /* (below) */ }
+  else if (two_level) { if ((rc = eu_launch_coarse_search_init(S))) return rc; }      // s = z + P y
   else
   LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<true>, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->s), LOC(S->z),
          LOC(S->cellmask), S->e_cnt, S->sc, 0, 0.0);
@@ -2426,7 +2430,8 @@ int eu_launch_project(euler_sim* S, float dt) {
     const int chunk_end = it + poll < max_it ? it + poll : max_it;
     for (; it < chunk_end; ++it) {
       S->prof_iter = it;
-      const bool fused = it > 0;   // update_search of iteration it-1 rides along with this apply_a (A s' lands in q)
+      const bool fused = it > 0 || fold0;   // update_search of iteration it-1 rides along with this apply_a (A s' lands in q)
+      if (it == 0 && fold0) { S->s = S->s_ring[S->s_ring_n - 1]; S->s2 = S->s_ring[0]; }      // (the pass writes ring[0], the first direction's place; what it reads of s counts 0 times)
       if ((rc = fused ? launch_search_apply_and_alpha(S, it) : launch_apply_a_and_alpha(S, 0))) return rc;
       if (tile) {
         // r -= alpha A s, max |r| (sets `done`), z = M^-1 r, beta = dot(z, r) / sigma: one pass; on the last iteration of the
