@@ -288,6 +288,7 @@ def test_a_partition_with_a_gap_is_refused():
     (3, 1000, 1100, "waterfall", 12, ("split=2", "bands=0-5,5-11,11-18")),
     (4, 512, 2048, "half_tank", 3, ("split=1",)),
     (2, 640, 1024, "closed_box", 4, ("split=2",)),      # ... with the gauge of a cut-off region summed over the ranks
+    (3, 640, 1024, "closed_box", 4, ("split=1", "bands=0-6,6-10,10-16")),      # ... a region that spans three uneven slabs
     # a slab of ONE band between two thick ones: at gather level 1 the zones still come from the next rank only (the operators' halo of 6 rows too); at level 3 the
     # lowest rank's way up would need rows of the rank beyond its neighbour - the ranks agree on that in the plan's all-reduce and run the replicated cycle
     (3, 512, 1024, "half_tank", 3, ("split=1", "bands=0-7,7-8,8-16")),
