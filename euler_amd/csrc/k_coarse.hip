@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void k_null_apply(double* __restrict__ r, cons
   if (!sc->nonzero || count <= 0) return;
   double f[CC_NULL_MAX];
 #pragma unroll
-  for (int q = 0; q < CC_NULL_MAX; ++q) { const double nn = nullv[NS_SUMS + 2 * q + 1]; f[q] = (q < count && nn > 0.0) ? nullv[NS_SUMS + 2 * q] / nn : 0.0; }
+  for (int q = 0; q < CC_NULL_MAX; ++q) { const double nn = nullv[NS_SUMS + 2 * q + 1]; f[q] = (q < count && nn > 1e-12) ? nullv[NS_SUMS + 2 * q] / nn : 0.0; }      // (1e-12: a dependent node's "indicator" is rounding noise on the cells - oracle: eo_project)
   for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < e_cnt; k += (size_t)gridDim.x * 256) {
     const size_t e = e_lo + k;
     if (!(mask[e] & CM_FLUID)) continue;

@@ -1067,7 +1067,9 @@ int eo_project(eo_sim* s, float dt, const float* u, const float* v, float* uout,
           if (FLUID(s, y, x)) { const double w = NULL_AT(q, y, x); eps[q] += r[AT(s, y, x)] * w; nn[q] += w * w; }
     }
     for (int q = 0; q < np; ++q) {
-      if (nn[q] > 0.0)
+      /* (> 1e-12, not > 0: a pinned node can also be a dependent one - two nodes that see the same lone drop - whose "indicator" is rounding noise on the cells, 1e-17 on one
+       * cell; normalised, that would take the WHOLE right-hand side of the cell out.  A real region has cells with indicator ~1) */
+      if (nn[q] > 1e-12)
         for (int y = 0; y < Y; ++y)
           for (int x = 0; x < X; ++x)
             if (FLUID(s, y, x)) r[AT(s, y, x)] -= NULL_AT(q, y, x) * (eps[q] / nn[q]);
