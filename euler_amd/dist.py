@@ -24,6 +24,14 @@ class Group:
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             if backend is None:
                 backend = os.environ.get("EULER_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(self.world)))
+            if backend == "nccl" and torch.cuda.device_count() < local_world and not os.environ.get("EULER_DIST_BACKEND"):
+                # more ranks than devices on this node (a 1-GPU box asked for --gpus 4): the ranks share the devices over gloo - a functional run, not a scaling measurement
+                import sys
+                if self.rank == 0:
+                    print("bench: %d local ranks on %d device(s): the ranks share them (gloo); not a scaling measurement" % (local_world, torch.cuda.device_count()), file=sys.stderr)
+                backend = "gloo"
+                os.environ["EULER_SHARE_GPU"] = "1"
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
                 self.device = torch.device("cuda", self.local_rank)
