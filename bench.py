@@ -223,6 +223,8 @@ def main():
     if comm is not None:
         comm_info = {"ranks": int(getattr(comm, "world", world)), "transport": "rccl" if args.comm == "rccl" else "torch.distributed", "rccl_version": getattr(comm, "version", None),
                      "p2p_mailboxes": bool(p2p_on)}
+        if os.environ.get("EULER_SHARE_GPU"):      # (euler_amd/dist.py: more local ranks than devices, or a test that asked for it)
+            comm_info["ranks_share_devices"] = True
         try:
             comm_info["exchange_us"] = {"g1_edge_rows_and_pair": round(sim.exchange_latency(100, GX, 2), 2), "g2_scalar": round(sim.exchange_latency(100, 0, 1), 2)}
             l = sum(comm_info["exchange_us"].values())
