@@ -869,7 +869,9 @@ __global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
 // anything - right for the small levels, whose cost is the chain of phases.  Level 0 is the opposite case: many tiles, little work in each.  These two kernels take it with
 // workgroups of 256 threads, several nodes per thread, loads issued where they are needed: five or six workgroups share a CU and one's phase waits behind another's loads
 // (8192^2: 101 + 87 us for the two ends of the cycle as 1024-thread workgroups -> see DESIGN.md).
+#ifndef MG_FINE_THREADS
 #define MG_FINE_THREADS 256
+#endif
 #define MG_SMALL_LEVEL0 16384      // nodes of level 0 up to which the cycle runs as two launches of the general kernels (launch_mg_cycle)
 // k_mg_down1: level 0's right-hand side from the tiles' partial sums (GATHER) or from H.rhs (row slabs: summed over the ranks before), its residual behind the Jacobi step,
 // full weighting -> level 1's right-hand side.  A workgroup owns tile x tile nodes of level 1.
