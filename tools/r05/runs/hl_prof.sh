@@ -13,4 +13,4 @@ print("ok", sim.stats().total_pcg_iterations)
 PY
 rm -rf /tmp/hlp; timeout 200 rocprofv3 --kernel-trace -d /tmp/hlp -o t -- python3 /tmp/hl_probe.py > /tmp/hlp.log 2>&1 < /dev/null
 tail -1 /tmp/hlp.log
-timeout 60 python3 $ROOT/tools/r05/kstats.py /tmp/hlp k_search_apply k_precond_tile < /dev/null | head -4
+timeout 60 python3 $ROOT/tools/r05/kstats.py /tmp/hlp ${1:-k_search_apply k_precond_tile} < /dev/null | head -6
