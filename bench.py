@@ -313,7 +313,7 @@ def main():
             tts = {}
             for pc in ("ic0", "ic0_tile", "ic0_tile2", "ic0_tile_mg"):
                 s3 = ea.Simulation(2048, 2048, device=local_rank, dot_mode=dot_mode, precond=PC[pc], tile_records=args.tile_records,
-                                   max_iterations=20000, pcg_poll_interval=32).load_half_tank()
+                                   max_iterations=20000, pcg_poll_interval=8).load_half_tank()
                 s3.step()                      # untimed: allocations, first launches
                 s3.load_half_tank()
                 torch.cuda.synchronize()

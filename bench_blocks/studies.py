@@ -368,7 +368,7 @@ def converged_deviation(ea, scenarios, so, device, dot_mode, tile_records, n=512
     break at impact, one frame on the GPU (multilevel mode, tol 1e-6, cap lifted) and one on the oracle with the reference's own IC(0), same
     tolerance, cap lifted (main.c:735 raised; nothing else changed).  Both converge to the same pressure, so the fields agree to solver tolerance."""
     import numpy as np
-    sim = ea.Simulation(n, n, device=device, dot_mode=dot_mode, precond=ea.PRECOND_IC0_TILE_MG, tile_records=tile_records, max_iterations=20000, pcg_poll_interval=32)
+    sim = ea.Simulation(n, n, device=device, dot_mode=dot_mode, precond=ea.PRECOND_IC0_TILE_MG, tile_records=tile_records, max_iterations=20000, pcg_poll_interval=8)
     load_workload(sim, scenarios, "dam_break", 1)
     pre = preroll_into_solves(sim, 400)
     for _ in range(more):

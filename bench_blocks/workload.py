@@ -65,7 +65,7 @@ def make_handle(ctx, GX, GY, workload, tiles, slab_arg, precond, tol):
     import torch
     args, ea, rank = ctx["args"], ctx["ea"], ctx["rank"]
     sm = ea.Simulation(GX, GY, device=ctx["local_rank"], dot_mode=ctx["dot_mode"], precond=ctx["PC"][precond], tile_records=args.tile_records, tol=tol,
-                       slab=slab_arg, max_iterations=args.max_iterations, pcg_poll_interval=8 if args.max_iterations <= 100 else 32)
+                       slab=slab_arg, max_iterations=args.max_iterations, pcg_poll_interval=8)
     hbm = sm.hbm_bytes()      # what THIS handle allocated (free-memory differences are confounded when ranks share a device)
     cm, p2p = None, False
     if ctx["sharded"]:

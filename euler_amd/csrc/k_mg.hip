@@ -314,6 +314,7 @@ struct MgDownArgs {
   // row slabs, split cycle (eu_mg_split_*): the launch covers the tile rows [tile_row0, tile_row0 + gridDim.x / tiles_x) of the output level only, and the entry level's
   // right-hand side counts as 0 outside the rows [clip_lo, clip_hi) - this rank's share lives there, the memory beyond holds other iterations' leftovers
   int tile_row0, clip_lo, clip_hi;
+  int force;                  // 0: a launch behind convergence (sc->done) or of a solve that never started (!sc->nonzero) returns at once - every workgroup alike, no ticket is drawn
 };
 
 #define MG_DOWN_THREADS 1024
@@ -507,6 +508,7 @@ template <bool GATHER>
 __global__ __launch_bounds__(MG_DOWN_THREADS) void k_mg_down(MgDownArgs A) {
   extern __shared__ double lds[];
   __shared__ int s_last;
+  if (!A.force && (A.sc->done || !A.sc->nonzero)) return;      // (the host polls late: launches queued behind convergence do no work - main.c:757 has left the loop)
   const MgHier& H = A.H;
   const int tid = threadIdx.x;
   const int tiles_x = (H.nx[A.lB] + A.tile - 1) / A.tile;
@@ -659,7 +661,7 @@ __global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
   __shared__ int s_last;
   const MgHier& H = A.H;
   const int tid = threadIdx.x;
-  const bool idle = !A.force && (A.sc->done || !A.sc->nonzero);      // read first, consulted last
+  if (!A.force && (A.sc->done || !A.sc->nonzero)) return;      // behind convergence the level arrays are dead and the scalar epilogue must not run: every workgroup leaves at once (round 6; rounds 3-5 did the whole pass and skipped the epilogue)
   // Water cut off from the air (rare): its pressure is determined up to a constant, PCG delivers the one with n . M p = 0 (M the preconditioner, n the region's indicator)
   // and the reference's clamp (main.c:773-779) makes that constant observable.  The tile-local factor alone gives, like the reference's own, very nearly "mean 0 over the
   // region"; the dense level's pseudo-inverse keeps that, the Jacobi steps of the levels in between do not - so the correction is made mean-free over the CELLS of every
@@ -797,7 +799,7 @@ __global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
       for (int q = 0; q < MG_NULL_MAX; ++q) if (q < n_null) gv[q] += A.m0[(size_t)q * n0n + c] * xv;
     }
   }
-  if (idle || L0 > 0) return;      // (after convergence the level arrays are dead; the scalar epilogue below must not run.  L0 > 0: level 0, the dot product and the epilogue are k_mg_up0's)
+  if (L0 > 0) return;      // (L0 > 0: level 0, the dot product and the epilogue are k_mg_up0's)
   for (int q = 0; q < n_null && q < MG_NULL_MAX; ++q) {
     double g = q == 0 ? gv[0] : q == 1 ? gv[1] : q == 2 ? gv[2] : gv[3];
     g = eu_wave_sum(g);
@@ -813,6 +815,7 @@ __global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
   dv = eu_wave_sum(dv);
   __syncthreads();
   if ((tid & 63) == 0) s_red[tid >> 6] = dv;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY thread's x_0 stores have left before the workgroup's ticket is drawn (as in k_mg_down): the gauge pass of the last workgroup reads them
   __syncthreads();
   if (tid == 0) {
     double t = 0.0;
@@ -878,6 +881,7 @@ __global__ __launch_bounds__(MG_UP_THREADS) void k_mg_up(MgUpArgs A) {
 template <bool GATHER>
 __global__ __launch_bounds__(MG_FINE_THREADS) void k_mg_down1(MgDownArgs A) {
   extern __shared__ double lds[];
+  if (!A.force && (A.sc->done || !A.sc->nonzero)) return;      // (as k_mg_down: nothing behind convergence)
   const MgHier& H = A.H;
   const int tid = threadIdx.x;
   const int nx = H.nx[0], ny = H.ny[0], cnx = H.nx[1], cny = H.ny[1];
@@ -940,7 +944,7 @@ __global__ __launch_bounds__(MG_FINE_THREADS) void k_mg_up0(MgUpArgs A) {
   __shared__ int s_last;
   const MgHier& H = A.H;
   const int tid = threadIdx.x;
-  const bool idle = !A.force && (A.sc->done || !A.sc->nonzero);      // read first, consulted last
+  if (!A.force && (A.sc->done || !A.sc->nonzero)) return;      // (as k_mg_up)
   const int n_null = (int)A.nullv[MG_NULL_MAX * 256];
   const int nx = H.nx[0], ny = H.ny[0], cnx = H.nx[1], cny = H.ny[1];
   const size_t n0n = (size_t)nx * ny;
@@ -990,7 +994,6 @@ __global__ __launch_bounds__(MG_FINE_THREADS) void k_mg_up0(MgUpArgs A) {
     } else H.x[c] = xv;
     if (i >= A.row_lo && i < A.row_hi) dv += xv * rv;
   }
-  if (idle) return;      // (after convergence the level arrays are dead; the scalar epilogue below must not run)
   for (int q = 0; q < n_null && q < MG_NULL_MAX; ++q) {
     double g = q == 0 ? gv[0] : q == 1 ? gv[1] : q == 2 ? gv[2] : gv[3];
     g = eu_wave_sum(g);
@@ -1006,6 +1009,7 @@ __global__ __launch_bounds__(MG_FINE_THREADS) void k_mg_up0(MgUpArgs A) {
   dv = eu_wave_sum(dv);
   __syncthreads();
   if ((tid & 63) == 0) s_red[tid >> 6] = dv;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every thread's x_0 stores have left before the ticket (see k_mg_up)
   __syncthreads();
   if (tid == 0) {
     double t = 0.0;
@@ -1097,7 +1101,7 @@ static MgDownArgs mg_down_args(const euler_sim* S, const MgHier& H, int lA, int 
   A.tail = lB == lC;
   A.part = S->mg_part; A.ntb = S->geom.T / 16; A.band_lo = S->band_lo; A.band_hi = S->band_hi;
   A.inv = S->cc_inv; A.ticket = mg_tick_down(S); A.sc = S->sc;
-  A.tile_row0 = 0; A.clip_lo = 0; A.clip_hi = 0x7fffffff;
+  A.tile_row0 = 0; A.clip_lo = 0; A.clip_hi = 0x7fffffff; A.force = 0;
   return A;
 }
 // rows [r0, r1) of the output level: the tile rows that cover them (split cycle); r1 < 0: the whole level
@@ -1125,7 +1129,7 @@ static int launch_mg_cycle(euler_sim* S, int fin_op, int force, bool gather) {
   const MgHier H = mg_hier(S);
   const int lC = mg_entry_level(S);
   if (S->mg_levels - 1 - lC > MG_TAIL_LEVELS) { eu_set_error("multilevel preconditioner: %d levels behind the entry level (at most %d)", S->mg_levels - 1 - lC, MG_TAIL_LEVELS); return EULER_EINVAL; }
-  auto down_args = [&](int lA, int lB) { return mg_down_args(S, H, lA, lB, lC); };
+  auto down_args = [&](int lA, int lB) { MgDownArgs A = mg_down_args(S, H, lA, lB, lC); A.force = force; return A; };
   auto launch_down = [&](const MgDownArgs& A, bool g) -> int { return mg_launch_down(S, A, g); };
   const MgUpArgs U = mg_up_args(S, H, lC, fin_op, force);
   const unsigned nblk0 = (unsigned)(((S->mg_nx[0] + 31) / 32) * ((S->mg_ny[0] + 31) / 32));
@@ -1329,6 +1333,7 @@ static const MgSplitPlan* mg_split_plan(euler_sim* S) {
   M.Lg = Lg; M.X = X; M.zone = P.zone_doubles;
   for (int side = 0; side < 2; ++side) for (int l = 0; l < MG_MAXLEV; ++l) { M.rows[side][l][0] = P.zs[side][l][0]; M.rows[side][l][1] = P.zs[side][l][1]; M.off[side][l] = P.zoff_s[side][l]; }
   MgSplitDst& D = st->D;
+  int local_fail = 0;      // what can fail on ONE rank (the segment table, the allocations): settled by a second all-reduce, so that every rank runs the same cycle
   D.nseg = 0; D.total = 0; D.X = X;
   for (int l = 0; l < Lg; ++l) {
     D.own[l][0] = P.I[l][me][0]; D.own[l][1] = P.I[l][me][1];
@@ -1339,7 +1344,7 @@ static const MgSplitPlan* mg_split_plan(euler_sim* S) {
       const bool touched = in && (!(row >= D.own[l][0] && row < D.own[l][1]) || (row >= D.zr[0][l][0] && row < D.zr[0][l][1]) || (row >= D.zr[1][l][0] && row < D.zr[1][l][1]));
       if (touched && run0 < 0) run0 = row;
       if (!touched && run0 >= 0) {
-        if (D.nseg >= 4 * MG_MAXLEV) { P.valid = 0; return nullptr; }
+        if (D.nseg >= 4 * MG_MAXLEV) { local_fail = 1; run0 = -1; continue; }      // (agreed on below: no rank leaves the plan alone)
         D.seg[D.nseg++] = MgSplitSeg{l, run0, row, D.total};
         D.total += (row - run0) * S->mg_nx[l];
         run0 = -1;
@@ -1356,7 +1361,20 @@ static const MgSplitPlan* mg_split_plan(euler_sim* S) {
                         hipMalloc((void**)&st->abuf, (size_t)R * st->aslot * sizeof(double)) != hipSuccess ||
                         hipMemsetAsync(st->sbuf, 0, 4 * (size_t)9 * (MG_SETUP_HALO + 1) * S->mg_nx[0] * sizeof(double), S->stream) != hipSuccess ||
                         hipMemsetAsync(st->abuf, 0, (size_t)R * st->aslot * sizeof(double), S->stream) != hipSuccess))) {
-    eu_set_error("hipMalloc of the split cycle's message buffers failed");
+    local_fail = 1;
+  }
+  // A rank that failed here alone would run the replicated cycle (two exchange points, an all-reduce of A_0) against the others' split cycle (three, halo + all-gather):
+  // mismatched collectives, a hang.  One more all-reduce (once per plan): every rank takes the split cycle or none does.
+  double lf = (double)local_fail;
+  if (hipMemcpyAsync(dv, &lf, sizeof lf, hipMemcpyHostToDevice, S->stream) != hipSuccess || S->bulk.allreduce(S->bulk.ctx, dv, 1, 1) != 0 ||
+      hipMemcpyAsync(&lf, dv, sizeof lf, hipMemcpyDeviceToHost, S->stream) != hipSuccess || hipStreamSynchronize(S->stream) != hipSuccess) lf = 1.0;
+  if (lf != 0.0) {
+    if (local_fail) eu_set_error("the split cycle's segment table or message buffers could not be set up on this rank; every rank falls back to the replicated cycle");
+    if (st->msg) { (void)hipFree(st->msg); st->msg = nullptr; }
+    if (st->gc) { (void)hipFree(st->gc); st->gc = nullptr; }
+    if (st->sbuf) { (void)hipFree(st->sbuf); st->sbuf = nullptr; }
+    if (st->abuf) { (void)hipFree(st->abuf); st->abuf = nullptr; }
+    P.valid = 0;
     return nullptr;
   }
   P.valid = 1;
@@ -1512,7 +1530,9 @@ int eu_mg_split_mid(euler_sim* S, int fin_op, int force, double* zrecv_lo, doubl
   int lA = Lg;
   do {      // replicated: the gather level down to the entry level, the tail, back up to the entry level
     const int lB = lA + 3 < lC ? lA + 3 : lC;
-    int rc = mg_launch_down(S, mg_down_args(S, H, lA, lB, lC), false);
+    MgDownArgs A = mg_down_args(S, H, lA, lB, lC);
+    A.force = force;
+    int rc = mg_launch_down(S, A, false);
     if (rc) return rc;
     lA = lB;
   } while (lA < lC);

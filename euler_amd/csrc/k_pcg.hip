@@ -2326,12 +2326,14 @@ int eu_launch_project(euler_sim* S, float dt) {
   S->solve_iters[S->solve_seq & 255] = S->sc_host->nonzero ? S->sc_host->iters : -1;
   if (S->solve_seq > 0) { S->res_last_chunks = S->sc_host->n_chunks; S->res_have_last = 1; }      // (the resident solver's guess for this solve, below)
   S->solve_seq += 1;
-  // Did the previous solve use up its iteration budget without converging?  Then this one probably will too,
-  // and the convergence poll is taken one chunk late: the next chunk is already queued while the host
-  // waits, so the GPU never idles for the ~27 us round trip (at most one chunk of early-exit launches is
-  // wasted when the guess is wrong).  Converging solves keep the immediate poll.
-  // (several ranks: nonzero / done / iters are the same on every rank, so all ranks take the same decision)
-  const bool lookahead = S->sc_host->nonzero && !S->sc_host->done && S->sc_host->iters >= S->cfg.max_iterations;
+  // Convergence polls never drain the queue (round 6): the host enqueues a chunk of iterations, a 48-byte copy of the scalars and an event, and then waits for the
+  // copy behind the PREVIOUS chunk - the GPU always has the next chunk queued behind the one whose outcome the host is waiting for.  What is queued behind
+  // convergence returns at once (every per-iteration kernel reads sc->done first), so a late poll costs launches, not work.  The chunk length follows a
+  // prediction: a solve that converged in k iterations is followed by one that needs about k (scenes change slowly) - chunks of pcg_poll_interval up to k - 2,
+  // chunks of 2 from there on (rounds 1-5: a blocking poll every pcg_poll_interval iterations for converging solves: ~27 us of idle GPU each, and up to
+  // pcg_poll_interval - 1 launches behind convergence that, in the multilevel mode's cycle, did their whole work).
+  // (several ranks: nonzero / done / iters are the same on every rank, so all ranks cut the same chunks and stop behind the same one)
+  const int pred_iters = (S->sc_host->nonzero && S->sc_host->done && S->sc_host->iters < S->cfg.max_iterations) ? S->sc_host->iters : 0;
   S->prof_iter = -1;
   int rc;
   LAUNCH(S, KC_MISC, k_pcg_reset, dim3(1), dim3(1), S->sc, S->cfg.tol, S->cfg.max_iterations);
@@ -2427,7 +2429,12 @@ int eu_launch_project(euler_sim* S, float dt) {
   bool stop = !S->sc_host->nonzero;   // all_zero(r): main.c:742
   S->s_none = stop ? 1 : 0;           // (no search direction exists: EULER_F_PCG_S reads as +0)
   while (it < max_it && !stop) {
-    const int chunk_end = it + poll < max_it ? it + poll : max_it;
+    int chunk_end = it + poll;
+    if (pred_iters > 0 && it < pred_iters + poll && chunk_end > pred_iters - 2) {      // around the predicted end: short chunks (the first of them ends at pred - 2)
+      const int lo = pred_iters - 2 < chunk_end ? pred_iters - 2 : chunk_end;
+      chunk_end = lo > it + 2 ? lo : it + 2;
+    }
+    if (chunk_end > max_it) chunk_end = max_it;
     for (; it < chunk_end; ++it) {
       S->prof_iter = it;
       const bool fused = it > 0 || fold0;   // update_search of iteration it-1 rides along with this apply_a (A s' lands in q)
@@ -2453,21 +2460,15 @@ int eu_launch_project(euler_sim* S, float dt) {
         if ((rc = launch_precondition(S, 0, FIN_BETA))) return rc;
       }
     }
-    if (it < max_it) {   // poll the device-side convergence flag (identical on every rank)
-      if (!lookahead) {
-        HIPCHK(hipMemcpyAsync(S->sc_host, S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
-        HIPCHK(hipStreamSynchronize(S->stream));
-        stop = S->sc_host->done != 0;
-      } else {
-        const int slot = chunk & 1;
-        if (chunk > 0) {                                      // the poll behind the previous chunk
-          HIPCHK(hipEventSynchronize(S->poll_event[slot ^ 1]));
-          stop = S->poll_host[slot ^ 1].done != 0;
-        }
-        HIPCHK(hipMemcpyAsync(&S->poll_host[slot], S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
-        HIPCHK(hipEventRecord(S->poll_event[slot], S->stream));
-        ++chunk;
+    if (it < max_it) {   // poll the device-side convergence flag (identical on every rank): one chunk late, see above
+      const int slot = chunk & 1;
+      if (chunk > 0) {                                      // the poll behind the previous chunk
+        HIPCHK(hipEventSynchronize(S->poll_event[slot ^ 1]));
+        stop = S->poll_host[slot ^ 1].done != 0;
       }
+      HIPCHK(hipMemcpyAsync(&S->poll_host[slot], S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
+      HIPCHK(hipEventRecord(S->poll_event[slot], S->stream));
+      ++chunk;
     }
   }
   S->prof_iter = -2;
