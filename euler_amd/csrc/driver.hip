@@ -11,7 +11,8 @@
 #include <vector>
 
 int eu_launch_build_system(euler_sim* S, float dt);
-int eu_launch_velocity_update(euler_sim* S, float dt);
+int eu_launch_velocity_update(euler_sim* S, float dt, int finish);
+int eu_pressure_current(euler_sim* S);      // k_grid.hip
 int eu_unskew(euler_sim* S, const void* skew, void* rowmajor, int elem_bytes);
 int eu_unskew_fluid(euler_sim* S, const double* skew, double* rowmajor);
 double* eu_current_search_direction(euler_sim* S);
@@ -255,7 +256,7 @@ extern "C" void euler_destroy(euler_sim* S) {
   if (S->solidT) (void)hipFree(S->solidT);
   if (S->sys_m) (void)hipFree(S->sys_m);
   if (S->sys_div) (void)hipFree(S->sys_div);
-  void* dev[] = {S->markers[0], S->markers[1], S->keys[0], S->keys[1], S->ms, S->evmask, S->ev_theta, S->ev_delta, S->sel_idx, S->act_idx,
+  void* dev[] = {S->markers[0], S->markers[1], S->keys[0], S->keys[1], S->ms, S->evmask, S->delmask, S->ev_theta, S->ev_delta, S->sel_idx, S->act_idx,
                  S->act_dt, S->cellmask64, S->draws, S->sel.block_sums, S->sc, S->partial, S->red_counter, S->granules, S->ticket, S->sweep_timeline, S->halo_buf, S->band_ranges, S->partial2, S->pair_buf, S->xrows, S->alpha_buf, S->rng_jump, S->chunk_flag, S->chunk_prev, S->chunk_part, S->tile_table, S->chunk_bits, S->chunk_list,
                  S->rowmajor_tmp};
   for (void* p : dev) if (p) (void)hipFree(p);
@@ -371,7 +372,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   DALLOC(S->solid, Cw); DALLOC(S->source, Cw); DALLOC(S->sink, Cw); DALLOC(S->count, Cw); DALLOC(S->prev_count, Cw);
   DALLOC(S->count32, Cw);
   if (!S->slab_on) { DALLOC(S->blockedT, Cw); DALLOC(S->uT, Cw); DALLOC(S->vT, Cw); DALLOC(S->countT, Cw); DALLOC(S->solidT, Cw); }      // (the marker stage's column-major copies)
-  S->blocked_dirty = 1; S->solidT_dirty = 1;
+  S->blocked_dirty = 1; S->solidT_dirty = 1; S->prebin_valid = 0; if (S->maxsq_state == 2) S->maxsq_state = 1; S->p_pending = 0;
   DALLOC(S->sys_m, Cw); DALLOC(S->sys_div, Cw);
   if (S->cfg.rainbow) for (float*& d : S->dye) DALLOC(d, Cw);      // (the window like every row-major field; the whole grid without slabs)
   // MAX_MARKER_COUNT = 4 X Y (main.c:92) is the GLOBAL cap; a slab holds the markers inside its rows: room for 6 per owned cell
@@ -382,6 +383,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   DALLOC(S->ms, 1);
   const size_t mwords = (S->max_markers + 63) / 64;
   DALLOC(S->evmask, mwords);
+  if (!S->slab_on) DALLOC(S->delmask, mwords);      // (the advection pass that bins as well keeps the delete ballot apart from the collision ballot)
   DALLOC(S->ev_theta, S->max_markers); DALLOC(S->ev_delta, S->max_markers);
   S->sel_cap = S->max_markers;
   DALLOC(S->sel_idx, S->sel_cap);
@@ -542,7 +544,7 @@ static int upload_scenario(euler_sim* S, const uint8_t* solid, const uint8_t* so
   HIPCHK(hipMemcpyAsync(S->solid + wo, solid + wo, Cw, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(S->source + wo, source + wo, Cw, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(S->sink + wo, sink + wo, Cw, hipMemcpyHostToDevice, st));
-  S->blocked_dirty = 1; S->solidT_dirty = 1;
+  S->blocked_dirty = 1; S->solidT_dirty = 1; S->prebin_valid = 0; if (S->maxsq_state == 2) S->maxsq_state = 1; S->p_pending = 0;
   for (float* f : {S->u, S->v, S->utmp, S->vtmp}) HIPCHK(hipMemsetAsync(f + wo, 0, Cw * sizeof(float), st));
   for (double* d : {S->b, S->p, S->r, S->z, S->s, S->s2, S->q, S->precon}) HIPCHK(hipMemsetAsync(d + S->skew_off, 0, S->Sw * sizeof(double), st));
   for (float* d : S->dye) if (d) HIPCHK(hipMemsetAsync(d + wo, 0, Cw * sizeof(float), st));
@@ -724,7 +726,14 @@ extern "C" int euler_timestep(euler_sim* S, float frame_time_left, float* dt) {
   return EULER_OK;
 }
 
+// somebody other than the substep's own sequence is about to write the state: what one stage prepared for the next no longer describes it
+static void eu_state_edited(euler_sim* S) {
+  S->prebin_valid = 0;                               // (k_advect_bin_a2's counts and delete ballot)
+  if (S->maxsq_state == 2) S->maxsq_state = 1;       // (k_velocity_update_para's maxima of u, v: stale, cleared before the next accumulation)
+}
 static int run_stage(euler_sim* S, int stage, float dt) {
+  if (stage != EULER_STAGE_REFRESH_COUNTS) S->prebin_valid = 0;      // (what k_advect_bin_a2 binned belongs to the refresh that follows it DIRECTLY)
+  if (stage == EULER_STAGE_EXTRAPOLATE && S->maxsq_state == 2) S->maxsq_state = 1;      // (writes u, v; inside a substep the timestep has consumed the maxima long before)
   switch (stage) {
     case EULER_STAGE_ADVECT_MARKERS: return eu_launch_advect_markers(S, dt);
     case EULER_STAGE_REFRESH_COUNTS: return eu_launch_refresh_counts(S);
@@ -820,6 +829,8 @@ extern "C" int euler_pcg_op(euler_sim* S, int32_t op, float dt, double a, double
   // (the single building blocks address the whole grid; a row-slab handle holds a window of it)
   if (S->slab_on) { eu_set_error("euler_pcg_op: single PCG operations are not exposed on a row-slab handle"); return EULER_ESTATE; }
   S->pcg_fields_resident = 0;      // (single operations run the multi-kernel path: z, s, q are in memory again)
+  int rcp = eu_pressure_current(S);
+  if (rcp) return rcp;
   return eu_launch_pcg_op(S, op, dt, a, out);
 }
 
@@ -883,6 +894,7 @@ extern "C" int euler_get_field(euler_sim* S, int32_t f, void* dst, size_t dst_by
     eu_set_error("euler_get_field(%d): the last solve ran in the resident kernel, which keeps z, s and A s in registers (euler_config.resident = EULER_RESIDENT_OFF shows them)", f);
     return EULER_ESTATE;
   }
+  if (f == EULER_F_PRESSURE && (rc = eu_pressure_current(S))) return rc;      // (k_velocity_update_para leaves the last fmadds and the clamp to whoever looks)
   if (field_is_skewed(f)) {   // the solver's arrays are band-skewed in HBM: gather to row-major first
     rc = ensure_rowmajor_tmp(S);
     if (rc) return rc;
@@ -906,6 +918,8 @@ int eu_set_source_count(euler_sim* S, size_t nsrc) {
 
 extern "C" int euler_set_field(euler_sim* S, int32_t f, const void* src, size_t src_bytes) {
   if (!S || !src) return EULER_EINVAL;
+  if (field_is_skewed(f)) { int rcp = eu_pressure_current(S); if (rcp) return rcp; }      // (the pressure is finished from the solver's arrays before a caller overwrites any of them)
+  eu_state_edited(S);
   if (S->slab_on && (f == EULER_F_MARKERS || f == EULER_F_MARKER_KEYS || f == EULER_F_COUNT || f == EULER_F_PREV_COUNT ||
                      f == EULER_F_SOLID || f == EULER_F_SOURCE)) {
     // (solid cells are read through ghost rows, the source cells of ALL ranks decide whether the source stage runs at all: facts
@@ -953,6 +967,7 @@ __global__ void k_set_marker_state(MarkerState* ms, unsigned long long n, unsign
 extern "C" int euler_set_markers(euler_sim* S, const float* xy, uint64_t n) {
   if (!S || (!xy && n) || n > S->max_markers) return EULER_EINVAL;
   if (S->slab_on) { eu_set_error("euler_set_markers: not on a row-slab handle"); return EULER_ESTATE; }
+  eu_state_edited(S);
   if (n) HIPCHK(hipMemcpyAsync(S->markers[S->cur], xy, n * 8, hipMemcpyHostToDevice, S->stream));
   hipLaunchKernelGGL(k_set_marker_state, dim3(1), dim3(1), 0, S->stream, S->ms, (unsigned long long)n,
                      (unsigned long long)S->max_markers, 1, 0ull, 0, 0);

@@ -131,13 +131,18 @@ struct euler_sim {
   size_t C;
   hipStream_t stream;
   int loaded;
-  long long opt[16];      // euler_set_option (include/euler.h EULER_OPT_*), defaults set by euler_create
+  long long opt[32];      // euler_set_option (include/euler.h EULER_OPT_*), defaults set by euler_create
   int dot_mode_user;      // the dot mode the caller's configuration resolved to (the coarse modes force EULER_DOT_TREE while they are selected; leaving them restores this)
 
   // fields (main.c:64-73,96-97)
   float *u, *v, *utmp, *vtmp;
   uint8_t *solid, *source, *sink, *count, *prev_count;
   unsigned int* count32;   // the binning counters of the window, COLUMN-major: [x][y - win_lo] (k_markers.hip), never shifted
+  int p_pending;           // k_velocity_update_para finished and clamped the pressure in LDS only: 1 - memory still lacks the last fmadds and the clamp, 2 - the clamp (eu_pressure_current)
+  int maxsq_state;         // ms->max_u2_bits / max_v2_bits: 0 - zero, 2 - the maxima of u, v as they stand (k_velocity_update_para), 1 - maxima of a state that has been edited since
+  int count32_dirty;       // the counters hold something (between a binning launch and the k_narrow_counts<true> that clears them; whole-grid handles)
+  int prebin_valid;        // the advection stage in front binned its own output (k_advect_bin_a2): the next refresh keeps the counters and the delete ballot
+  unsigned long long* delmask;   // [ceil(max_markers/64)] that pass's delete ballot (whole-grid handles)
   uint8_t* blockedT;       // sink | solid per cell, COLUMN-major like count32 (whole-grid handles; k_bin_markers); rebuilt when blocked_dirty
   int blocked_dirty;
   float *uT, *vT; uint8_t *countT, *solidT;   // COLUMN-major copies of u, v, the count grid (made in front of every marker advection) and of the solid grid (when blocked_dirty): whole-grid handles only

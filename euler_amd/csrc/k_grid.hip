@@ -97,6 +97,11 @@ int eu_launch_timestep(euler_sim* S, float frame_time_left) {
     LAUNCH(S, KC_TIMESTEP, k_maxsq<false>, dim3(nb), dim3(256), S->u, S->v, S->X, S->Y, S->ms, S->row_lo, S->row_hi, frame_time_left);
     return eu_slab_timestep(S, frame_time_left);
   }
+  if (S->maxsq_state == 2) {      // k_velocity_update_para left the maxima of exactly these u, v (nothing has written them since: driver.hip drops the state otherwise)
+    S->maxsq_state = 0;
+    return eu_launch_dt(S, frame_time_left);
+  }
+  if (S->maxsq_state == 1) { HIPCHK(hipMemsetAsync(&S->ms->max_u2_bits, 0, 2 * sizeof(unsigned int), S->stream)); S->maxsq_state = 0; }      // (maxima of a state edited since)
   LAUNCH(S, KC_TIMESTEP, k_maxsq<true>, dim3(nb), dim3(256), S->u, S->v, S->X, S->Y, S->ms, S->row_lo, S->row_hi, frame_time_left);
   return EULER_OK;
 }
@@ -470,6 +475,80 @@ __global__ __launch_bounds__(256) void k_build_system2(const uint8_t* __restrict
   if (in_chunks && __any(m != CM_INTERIOR) && (threadIdx.x & 63) == 0) chunk_part[chunk] = 1;
 }
 
+// The assembly in ONE pass (round 6).  The two-step form above writes 5 bytes per cell of scratch and gathers them back along the diagonal (0.22 + 0.60 ms at 8192^2).  A run of
+// W consecutive records of a band is a PARALLELOGRAM of the grid: row l of the band holds its cells x = t0 - l .. t0 - l + W - 1 - W consecutive cells of a row-major row.  A
+// workgroup takes the 96 records of one unit (six chunks; T is a whole number of units): it walks the 64 row segments with consecutive threads on consecutive cells (coalesced
+// 384-byte reads of count, solid, utmp, vtmp; the four neighbours come out of the same lines), leaves mask byte and float divergence (main.c:720) in LDS, and writes the skewed
+// arrays from there with consecutive threads on consecutive elements.  The same arithmetic per cell: the same bits; the chunk flags as before.
+#define BS_W 96
+template <bool TILE>
+__global__ __launch_bounds__(256) void k_build_system_para(const float* __restrict__ u, const float* __restrict__ v, const uint8_t* __restrict__ count, const uint8_t* __restrict__ solid,
+                                                           double* __restrict__ b, double* __restrict__ r, double* __restrict__ p, double* __restrict__ q, double* __restrict__ z,
+                                                           uint8_t* __restrict__ cellmask, PcgScalars* sc, SkewGeom g, float dt, int band_lo,
+                                                           uint8_t* __restrict__ chunk_flag, uint8_t* __restrict__ chunk_part, const uint8_t* __restrict__ chunk_prev) {
+  __shared__ float sd[64][BS_W + 1];
+  __shared__ uint8_t sm[64][BS_W + 4];
+  __shared__ int s_fl[BS_W / 16], s_part[BS_W / 16], s_prev[BS_W / 16], s_nz;
+  const int units = g.T / BS_W;
+  const size_t blk = eu_xcd_block();      // neighbouring units share the lines their slanted edges cut: one L2 for a run of them
+  const int band = band_lo + (int)(blk / units), t0 = (int)(blk % units) * BS_W;
+  const int X = g.X, Y = g.Y, tid = threadIdx.x;
+  const size_t chunk0 = (size_t)(band - band_lo) * (size_t)(g.T / 16) + (size_t)(t0 / 16);
+  if (tid < BS_W / 16) { s_fl[tid] = 0; s_part[tid] = 0; s_prev[tid] = TILE ? (chunk_prev[chunk0 + tid] != 0) : 1; }
+  if (tid == 0) s_nz = 0;
+  __syncthreads();
+  for (int c = tid; c < 64 * BS_W; c += 256) {
+    const int l = c / BS_W, j = c % BS_W;
+    const int x = t0 - l + j, y = band * 64 + l;
+    uint8_t m = 0;
+    float div_f = 0.f;
+    if (x >= 0 && x < X && y < Y) {
+      const size_t i = (size_t)y * X + x;
+      if (count[i] != 0) {   // never true on the border ring (sinks), so the +-1 / +-X reads are in range
+        m = CM_FLUID;
+        if (count[i + 1]) m |= CM_RIGHT;
+        if (count[i + X]) m |= CM_UP;
+        if (count[i - 1]) m |= CM_LEFT;
+        if (count[i - X]) m |= CM_DOWN;
+        const int diag = 4 - solid[i - 1] - solid[i + 1] - solid[i - X] - solid[i + X];
+        m |= (uint8_t)(diag << CM_DIAG_SHIFT);
+        div_f = (u[i] - u[i - 1] + v[i] - v[i - X]) / EU_H;               // float expression, main.c:720
+      }
+    }
+    sm[l][j] = m;
+    sd[l][j] = div_f;
+    if (m & CM_FLUID) s_fl[j / 16] = 1;                 // (plain stores of the same value)
+    if (m != CM_INTERIOR) s_part[j / 16] = 1;
+  }
+  __syncthreads();
+  const float k_inv_scale_f = (EU_H * EU_H) * EU_RHO / dt;                      // float expression, main.c:713
+  bool nz = false;
+  for (int c = tid; c < 64 * BS_W; c += 256) {          // element c of the unit: pair-record c / 128, lane (c % 128) / 2, parity c % 2
+    const int pr = c >> 7, l = (c & 127) >> 1, j = 2 * pr + (c & 1);
+    const int ch = j / 16;
+    const bool touch = s_fl[ch] || s_prev[ch];      // (TILE: a chunk without fluid now and in the previous solve still holds the zeros that solve's assembly left)
+    const int x = t0 + j - l, y = band * 64 + l;
+    if (!touch || x < 0 || x >= X || y >= Y) continue;  // (padding entries keep mask 0 and value 0 from allocation)
+    const uint8_t m = sm[l][j];
+    const double bv = m ? -(double)sd[l][j] * (double)k_inv_scale_f : 0.0;
+    nz = nz || bv != 0.0;
+    const size_t e = ((size_t)band * g.TS + (size_t)(t0 + 2 * pr)) * 64 + (size_t)(c & 127);
+    cellmask[e] = m;
+    b[e] = bv;
+    r[e] = bv;
+    p[e] = 0.0;
+    if (!TILE) { q[e] = 0.0; z[e] = 0.0; }
+  }
+  if (nz) s_nz = 1;
+  __syncthreads();
+  if (tid < BS_W / 16) {
+    if (s_fl[tid]) chunk_flag[chunk0 + tid] = 1;
+    if (s_part[tid]) chunk_part[chunk0 + tid] = 1;
+  }
+  // !all_zero(r), main.c:742 (once the flag is up nobody has to raise it again)
+  if (tid == 0 && s_nz && __hip_atomic_load(&sc->nonzero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(&sc->nonzero, 1);
+}
+
 // one bit per chunk from the bytes k_build_system left (the ordered select wants bits)
 __global__ __launch_bounds__(256) void k_pack_chunk_bits(const uint8_t* __restrict__ flag, unsigned long long* __restrict__ bits, size_t nwords, size_t nchunks) {
   const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -523,6 +602,98 @@ __global__ __launch_bounds__(256) void k_velocity_update(const float* __restrict
   }
 }
 
+// Round 6: the end of project() in ONE pass over parallelograms (k_build_system_para's geometry) - the p += alpha s that are still due (k_finish_p's arithmetic, main.c:753),
+// the clamp (main.c:773-779), both velocity updates (main.c:782-805) and the maxima calculate_timestep wants next (main.c:808-841).  A workgroup finishes the pressure of its
+// 96 records in skewed order (coalesced reads of p, the mask and the pending search directions) into LDS - plus the record to its right and the row above its band, formed
+// the same way from the same inputs - and walks the 64 row segments with consecutive threads on consecutive cells: what rounds 1-5 gathered from the skewed array (three
+// pressures per cell) comes out of LDS.  The pass READS p and WRITES none of it (no workgroup sees another's result): the finished, clamped pressure is formed in memory
+// only when somebody asks for it (eu_pressure_current: EULER_F_PRESSURE, euler_pcg_op), from the same ring - most substeps nobody does, and 8 bytes per fluid cell stay unwritten.
+struct VuRing { const double* s[8]; int n, steps, use; };      // use 0: p is final as it stands (the resident solver wrote it; a right-hand side of zeros)
+#define VU_W 96
+__global__ __launch_bounds__(256) void k_velocity_update_para(const float* __restrict__ uin, const float* __restrict__ vin, float* __restrict__ uout, float* __restrict__ vout,
+                                                              const double* __restrict__ p, const uint8_t* __restrict__ mask, const uint8_t* __restrict__ count,
+                                                              const uint8_t* __restrict__ solid, SkewGeom g, float dt, const PcgScalars* sc, VuRing ring, MarkerState* ms) {
+  __shared__ double sp[65][VU_W + 1];
+  __shared__ float s_mu[4], s_mv[4];
+  const int units = g.T / VU_W;
+  const size_t blk = eu_xcd_block();
+  const int band = (int)(blk / units), t0 = (int)(blk % units) * VU_W;
+  const int X = g.X, Y = g.Y, tid = threadIdx.x;
+  // the fmadds that are due: iterations from .. n_it - 1 (k_finish_p)
+  int cnt = 0, from = 0;
+  if (ring.use && sc->nonzero && sc->iters > 0) {
+    const int n_it = sc->iters;
+    from = n_it - 1 >= ring.steps ? (n_it - 1) / ring.steps * ring.steps : 0;
+    cnt = n_it - from;
+  }
+  double al[8];
+  const double* sq[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const int it = from + (j < cnt ? j : 0); al[j] = sc->alpha_hist[it & 7]; sq[j] = ring.s[it % ring.n]; }
+  auto finished = [&](size_t e) -> double {      // the clamped, finished pressure of element e; +0 off the fluid (main.c:739: p starts as zeros and only fluid cells are ever written)
+    if (!(mask[e] & CM_FLUID)) return 0.0;
+    double pv = p[e];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (j < cnt) pv = pv + sq[j][e] * al[j];      // (uniform)
+    return pv < 0.0 ? 0.0 : pv;
+  };
+  const size_t ebase = ((size_t)band * g.TS + (size_t)t0) * 64;
+  for (int c = tid; c < 64 * VU_W; c += 256) {          // element c of the unit: pair-record c / 128, lane (c % 128) / 2, parity c % 2
+    const int l = (c & 127) >> 1, j = 2 * (c >> 7) + (c & 1);
+    sp[l][j] = finished(ebase + (size_t)c);
+  }
+  if (tid < 64) {                                        // the record to the right (t0 + 96 <= T: a padding record at worst, mask 0)
+    sp[tid][VU_W] = finished(ebase + (size_t)VU_W * 64 + 2 * (size_t)tid);
+  } else if (tid < 64 + VU_W) {                          // the row above the band: lane 0 of band + 1, records t0 - 64 + j (j = 1 .. 96)
+    const int j = tid - 64 + 1, x = t0 - 64 + j;
+    double pv = 0.0;
+    if (x >= 0 && x < X && band + 1 < g.nbands) pv = finished(((size_t)(band + 1) * g.TS + (size_t)(x & ~1)) * 64 + (size_t)(x & 1));
+    sp[64][j] = pv;
+  }
+  __syncthreads();
+  const float neg_inv = -(1.f / (EU_RHO * EU_H));   // accel(), main.c:705-707
+  float mu = 0.f, mv = 0.f;
+  for (int c = tid; c < 64 * VU_W; c += 256) {
+    const int l = c / VU_W, j = c % VU_W;
+    const int x = t0 - l + j, y = band * 64 + l;
+    if (x < 0 || x >= X || y >= Y) continue;
+    const size_t i = (size_t)y * X + x;
+    const bool f0 = count[i] != 0;
+    const double p0 = sp[l][j];
+    if (x < X - 1) {
+      const bool f1 = count[i + 1] != 0;
+      float o = 0.f;
+      if (solid[i] | solid[i + 1]) o = 0.f;
+      else if (f0 | f1) o = uin[i] + (neg_inv * (float)(sp[l][j + 1] - p0)) * dt;
+      uout[i] = o;
+      const float sqv = o * o; if (sqv > mu) mu = sqv;
+    }
+    if (y < Y - 1) {
+      const bool f1 = count[i + X] != 0;
+      float o = 0.f;
+      if (solid[i] | solid[i + X]) o = 0.f;
+      else if (f0 | f1) o = vin[i] + (neg_inv * (float)(sp[l + 1][j + 1] - p0)) * dt;
+      vout[i] = o;
+      const float sqv = o * o; if (sqv > mv) mv = sqv;
+    }
+  }
+  // maxsq (main.c:808-820) of what was just written: exact, order-free maxima; k_dt forms dt from them at the next timestep
+  mu = eu_wave_maxf(mu);
+  mv = eu_wave_maxf(mv);
+  if ((tid & 63) == 0) { s_mu[tid >> 6] = mu; s_mv[tid >> 6] = mv; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int k = 1; k < 4; ++k) { if (s_mu[k] > mu) mu = s_mu[k]; if (s_mv[k] > mv) mv = s_mv[k]; }
+    if (mu > 0.f) atomicMax(&ms->max_u2_bits, __float_as_uint(mu));      // (non-negative floats order like their bit patterns; a NaN never wins: s > m is false)
+    if (mv > 0.f) atomicMax(&ms->max_v2_bits, __float_as_uint(mv));
+  }
+}
+// the clamp alone, in memory (eu_pressure_current)
+__global__ __launch_bounds__(256) void k_clamp_p(double* __restrict__ p, const uint8_t* __restrict__ mask, size_t e_lo, size_t S) {
+  for (size_t i = e_lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < e_lo + S; i += (size_t)gridDim.x * blockDim.x)
+    if ((mask[i] & CM_FLUID) && p[i] < 0.0) p[i] = 0.0;
+}
+
 int eu_launch_band_ranges(euler_sim* S);
 
 // the top bit of a listed chunk says INTERIOR (k_search_apply / k_precond_tile: no mask loads, constant coefficients, E^-1 from the table)
@@ -541,7 +712,16 @@ int eu_launch_build_system(euler_sim* S, float dt) {
   // the lean assembly needs every solve since the arrays were last written whole to have been a tile-mode solve of this handle
   const bool lean = eu_is_tile(S) && S->cfg.sweep_mode != EULER_SWEEP_SIMPLE && S->lean_ok;
   const bool gather = S->opt[EULER_OPT_BUILD_GATHER] != 0;      // (experiments: the one-kernel diagonal gather of rounds 1-2)
-  if (!gather) {
+  const bool two_pass = S->opt[EULER_OPT_BUILD_TWO_PASS] != 0;  // (rounds 3-5: a row-major pass and a skewed gather)
+  if (!gather && !two_pass) {
+    const unsigned nblk = (unsigned)((size_t)(S->band_hi - S->band_lo) * (S->geom.T / BS_W));
+    if (lean)
+      LAUNCH(S, KC_BUILD_SYSTEM, k_build_system_para<true>, dim3(nblk), dim3(256), S->utmp, S->vtmp, S->count, S->solid, S->b, S->r, S->p, S->q, S->z, S->cellmask, S->sc, S->geom, dt, S->band_lo,
+             S->chunk_flag, S->chunk_part, S->chunk_prev);
+    else
+      LAUNCH(S, KC_BUILD_SYSTEM, k_build_system_para<false>, dim3(nblk), dim3(256), S->utmp, S->vtmp, S->count, S->solid, S->b, S->r, S->p, S->q, S->z, S->cellmask, S->sc, S->geom, dt, S->band_lo,
+             S->chunk_flag, S->chunk_part, S->chunk_prev);
+  } else if (!gather) {
     const size_t win_off = (size_t)S->win_lo * S->X;
     LAUNCH(S, KC_BUILD_SYSTEM, k_cell_system, dim3(eu_blocks((size_t)S->X * (S->row_hi - S->row_lo), 256)), dim3(256), S->utmp, S->vtmp, S->count, S->solid, S->sys_m, S->sys_div,
            S->X, S->row_lo, S->row_hi, win_off);
@@ -568,7 +748,32 @@ int eu_launch_build_system(euler_sim* S, float dt) {
   return eu_launch_band_ranges(S);
 }
 
-int eu_launch_velocity_update(euler_sim* S, float dt) {
+int eu_launch_finish_p(euler_sim* S);      // k_pcg.hip: the p += alpha s still due, in memory
+// The finished, clamped pressure in memory: k_velocity_update_para forms it in LDS only.  Whoever reads S->p between two solves comes through here first.
+int eu_pressure_current(euler_sim* S) {
+  if (!S->p_pending) return EULER_OK;
+  const int mode = S->p_pending;
+  S->p_pending = 0;
+  if (mode == 1) { int rc = eu_launch_finish_p(S); if (rc) return rc; }
+  LAUNCH(S, KC_VELOCITY_UPDATE, k_clamp_p, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), S->p, S->cellmask, S->e_lo, S->e_cnt);
+  return EULER_OK;
+}
+// finish: 1 - the multi-kernel solve left its last p += alpha s undone (the ring of eu_launch_project is current); 0 - p is final (resident solver)
+int eu_launch_velocity_update(euler_sim* S, float dt, int finish) {
+  const bool one_pass = !S->has_comm && !S->slab_on && S->opt[EULER_OPT_VELOCITY_TWO_PASS] == 0;
+  if (one_pass) {
+    VuRing ring;
+    for (int k = 0; k < 8; ++k) ring.s[k] = S->s_ring[k < S->s_ring_n ? k : 0];
+    ring.n = S->s_ring_n > 0 ? S->s_ring_n : 1; ring.steps = ring.n; ring.use = finish && S->s_ring_n > 0;
+    if (!ring.use) for (int k = 0; k < 8; ++k) ring.s[k] = S->p;      // (never read)
+    if (S->maxsq_state != 0) HIPCHK(hipMemsetAsync(&S->ms->max_u2_bits, 0, 2 * sizeof(unsigned int), S->stream));      // (maxima no timestep consumed)
+    LAUNCH(S, KC_VELOCITY_UPDATE, k_velocity_update_para, dim3((unsigned)((size_t)S->geom.nbands * (S->geom.T / VU_W))), dim3(256), S->utmp, S->vtmp, S->u, S->v, S->p, S->cellmask,
+           S->count, S->solid, S->geom, dt, S->sc, ring, S->ms);
+    S->p_pending = ring.use ? 1 : 2;
+    S->maxsq_state = 2;      // the maxima of u, v as they stand are in ms (eu_launch_timestep: k_dt alone)
+    return EULER_OK;
+  }
+  if (finish) { int rc = eu_launch_finish_p(S); if (rc) return rc; }
   dim3 grid((S->X + 63) / 64, (S->row_hi - S->row_lo + 3) / 4);
   LAUNCH(S, KC_VELOCITY_UPDATE, k_velocity_update, grid, dim3(256), S->utmp, S->vtmp, S->u, S->v, S->p, S->count,
          S->solid, S->geom, dt, S->row_lo, S->row_hi);

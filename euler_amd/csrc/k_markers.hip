@@ -288,6 +288,85 @@ __global__ __launch_bounds__(256) void k_advect_markers_a2(const float2* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------ round 6: advection and binning in ONE pass
+// refresh_marker_counts (main.c:102-117) bins the positions advect_markers (main.c:464-537) has just written.  As two kernels that is 8 B per marker read a second time and a
+// pass whose time is the memory-side adds of the counters, while the advection pass is bound by its arithmetic and gathers: the two do not compete.  Here the speculative pass
+// bins what it has computed - cell, sink | solid test (the delete ballot), the run-aggregated adds - and pass B, which recomputes the markers behind a firing dt collision,
+// moves the counts of those whose cell changed (k_advect_markers_b<TR, true>).  Integer adds: the counters come out the same whatever the order.
+// A thread holds TWO markers: their cells mostly coincide (markers are seeded four to a cell, consecutively), so the thread's item is (cell, weight 1 or 2) and a run of lanes
+// adds the sum of its weights; the rare thread with two different cells bins the second one in a second, wave-uniform round.
+__device__ __forceinline__ void bin_aggregated_w(unsigned int* count32, bool live, size_t c, unsigned int w) {      // bin_aggregated (euler_dev.h) with a weight of 1 or 2 per lane
+  const unsigned int lo = (unsigned int)c, hi = (unsigned int)(c >> 32);
+  const int lane = threadIdx.x & 63;
+  const unsigned int plo = __shfl_up(lo, 1, 64), phi = __shfl_up(hi, 1, 64);
+  const bool plive = __shfl_up((int)live, 1, 64) != 0;
+  const bool head = live && (lane == 0 || !plive || plo != lo || phi != hi);     // first lane of a run of equal cells
+  const unsigned long long heads = __ballot(head), lives = __ballot(live), twos = __ballot(live && w == 2u);
+  const unsigned long long above = lane == 63 ? 0ull : ((heads | ~lives) >> (lane + 1));
+  const int run = above ? __ffsll((long long)above) : 64 - lane;                 // lanes in the run
+  const unsigned long long rmask = (run >= 64 ? ~0ull : ((1ull << run) - 1ull)) << lane;
+  const int wsum = run + __popcll(twos & rmask);                                 // markers in the run
+  const int nl = lane + run;
+  const bool has_next = head && nl < 64 && ((heads >> nl) & 1ull);
+  const int src = has_next ? nl : lane;
+  const unsigned int nlo = __shfl(lo, src, 64), nhi = __shfl(hi, src, 64);
+  const int nsum = __shfl(wsum, src, 64);
+  const bool pairs = has_next && !(lo & 1u) && nlo == lo + 1u && nhi == hi;      // (c even: the 64-bit add is aligned)
+  const unsigned long long below = heads & ((1ull << lane) - 1ull);
+  const int pl = below ? 63 - __clzll((long long)below) : lane;
+  const unsigned int qlo = __shfl(lo, pl, 64), qhi = __shfl(hi, pl, 64);
+  const int qrun = __shfl(run, pl, 64);
+  const bool absorbed = head && below && (lo & 1u) && qlo + 1u == lo && qhi == hi && pl + qrun == lane;
+  if (head && !absorbed) {
+    if (pairs) atomicAdd(reinterpret_cast<unsigned long long*>(&count32[c]), (unsigned long long)(unsigned int)wsum | ((unsigned long long)(unsigned int)nsum << 32));
+    else atomicAdd(&count32[c], (unsigned int)wsum);
+  }
+}
+__device__ __forceinline__ size_t mk_cell_colmajor(float px, float py, int H) {      // the counters' (and blockedT's) index of the cell a position lies in
+  return (size_t)(int)floorf(px / EU_H) * H + (int)floorf(py / EU_H);
+}
+template <bool TR>
+__global__ __launch_bounds__(256) void k_advect_bin_a2(const float2* __restrict__ in, float2* __restrict__ out,
+                                                       const float* __restrict__ u, const float* __restrict__ v,
+                                                       const uint8_t* __restrict__ solid, GridRef g, float dt,
+                                                       unsigned long long n, unsigned long long* __restrict__ evmask,
+                                                       float* __restrict__ ev_theta, float* __restrict__ ev_delta,
+                                                       MarkerState* ms, const uint8_t* __restrict__ blockedT, unsigned int* count32,
+                                                       unsigned long long* __restrict__ delmask, int H) {
+  const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, i = 2 * t;
+  bool ev0 = false, ev1 = false, del0 = false, del1 = false, live0 = false, live1 = false;
+  size_t c0 = 0, c1 = 0;
+  if (i + 1 < n) {
+    const float4 p = *reinterpret_cast<const float4*>(in + i);
+    const AdvectOut o0 = advect_one<TR>(g, u, v, solid, p.x, p.y, dt);
+    const AdvectOut o1 = advect_one<TR>(g, u, v, solid, p.z, p.w, dt);
+    *reinterpret_cast<float4*>(out + i) = make_float4(o0.px, o0.py, o1.px, o1.py);
+    if (o0.events) { ev0 = true; ev_theta[i] = o0.theta; ev_delta[i] = o0.delta; if (o0.events > 1) atomicAdd(&ms->multi_events, 1ull); }
+    if (o1.events) { ev1 = true; ev_theta[i + 1] = o1.theta; ev_delta[i + 1] = o1.delta; if (o1.events > 1) atomicAdd(&ms->multi_events, 1ull); }
+    c0 = mk_cell_colmajor(o0.px, o0.py, H); c1 = mk_cell_colmajor(o1.px, o1.py, H);
+    del0 = blockedT[c0] != 0; del1 = blockedT[c1] != 0;      // refresh_marker_counts drops markers in sink or solid cells (main.c:109-112)
+    live0 = !del0; live1 = !del1;
+  } else if (i < n) {
+    const float2 p = in[i];
+    const AdvectOut o0 = advect_one<TR>(g, u, v, solid, p.x, p.y, dt);
+    out[i] = make_float2(o0.px, o0.py);
+    if (o0.events) { ev0 = true; ev_theta[i] = o0.theta; ev_delta[i] = o0.delta; if (o0.events > 1) atomicAdd(&ms->multi_events, 1ull); }
+    c0 = mk_cell_colmajor(o0.px, o0.py, H);
+    del0 = blockedT[c0] != 0;
+    live0 = !del0;
+  }
+  const bool same = live0 && live1 && c0 == c1;
+  bin_aggregated_w(count32, live0 || live1, live0 ? c0 : c1, same ? 2u : 1u);
+  const bool second = live0 && live1 && c0 != c1;
+  if (__any(second)) bin_aggregated(count32, second, c1);
+  const unsigned long long b0 = __ballot(ev0), b1 = __ballot(ev1), d0 = __ballot(del0), d1 = __ballot(del1);
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned long long w = i >> 6, nwords = (n + 63) >> 6;      // (i = the wave's first marker: a multiple of 128)
+    if (w < nwords) { evmask[w] = mk_spread32(b0) | (mk_spread32(b1) << 1); delmask[w] = mk_spread32(d0) | (mk_spread32(d1) << 1); }
+    if (w + 1 < nwords) { evmask[w + 1] = mk_spread32(b0 >> 32) | (mk_spread32(b1 >> 32) << 1); delmask[w + 1] = mk_spread32(d0 >> 32) | (mk_spread32(d1 >> 32) << 1); }
+  }
+}
+
 // one wave: replay the dt chain over the candidate collisions in array order
 __global__ __launch_bounds__(64) void k_marker_walk(const unsigned int* __restrict__ ev_idx, const float* __restrict__ ev_theta,
                                                     const float* __restrict__ ev_delta, unsigned int* __restrict__ act_idx,
@@ -313,26 +392,49 @@ __global__ __launch_bounds__(64) void k_marker_walk(const unsigned int* __restri
   if (lane == 0) { ms->n_actual = M; ms->dt_final = dt; ms->total_dt_events += M; }
 }
 
-template <bool TR>
+// FIX (behind k_advect_bin_a2): a recomputed marker whose cell changed takes its count along, and the delete ballot of its word is made current.
+// A workgroup walks the array with a stride (the launch leaves at once when no collision fired: half a million workgroups took 110 us to do so at 8192^2).
+template <bool TR, bool FIX>
 __global__ __launch_bounds__(256) void k_advect_markers_b(const float2* __restrict__ in, float2* __restrict__ out,
                                                           const float* __restrict__ u, const float* __restrict__ v,
                                                           const uint8_t* __restrict__ solid, GridRef g,
                                                           unsigned long long n, const unsigned int* __restrict__ act_idx,
                                                           const float* __restrict__ act_dt, const MarkerState* ms,
-                                                          const unsigned int* __restrict__ keys) {   // keys: slab mode, the markers' GLOBAL array indices
+                                                          const unsigned int* __restrict__ keys,      // keys: slab mode, the markers' GLOBAL array indices
+                                                          const uint8_t* __restrict__ blockedT, unsigned int* count32, unsigned long long* delmask, int H) {
   const unsigned int M = ms->n_actual;
   if (M == 0) return;
-  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const unsigned long long gi = keys ? keys[i] : i;      // the position in the reference's array decides which dt applies
-  if (gi <= act_idx[0]) return;
-  // number of firing collisions with index < gi  (act_idx ascending)
-  unsigned int lo = 0, hi = M;
-  while (lo < hi) { const unsigned int mid = (lo + hi) >> 1; if (act_idx[mid] < gi) lo = mid + 1; else hi = mid; }
-  const float dt = act_dt[lo - 1];
-  const float2 p = in[i];
-  const AdvectOut o = advect_one<TR>(g, u, v, solid, p.x, p.y, dt);
-  out[i] = make_float2(o.px, o.py);
+  const unsigned int first = act_idx[0];
+  for (unsigned long long base = (unsigned long long)blockIdx.x * blockDim.x; base < n; base += (unsigned long long)gridDim.x * blockDim.x) {      // (uniform per workgroup)
+    const unsigned long long i = base + threadIdx.x;
+    bool redo = false, ndel = false;
+    if (i < n) {
+      const unsigned long long gi = keys ? keys[i] : i;      // the position in the reference's array decides which dt applies
+      if (gi > first) {
+        // number of firing collisions with index < gi  (act_idx ascending)
+        unsigned int lo = 0, hi = M;
+        while (lo < hi) { const unsigned int mid = (lo + hi) >> 1; if (act_idx[mid] < gi) lo = mid + 1; else hi = mid; }
+        const float dt = act_dt[lo - 1];
+        const float2 p = in[i];
+        const AdvectOut o = advect_one<TR>(g, u, v, solid, p.x, p.y, dt);
+        if (FIX) {
+          const float2 was = out[i];      // pass A's result: binned already
+          const size_t oc = mk_cell_colmajor(was.x, was.y, H), nc = mk_cell_colmajor(o.px, o.py, H);
+          redo = true;
+          ndel = blockedT[nc] != 0;
+          if (oc != nc) {
+            if (blockedT[oc] == 0) atomicSub(&count32[oc], 1u);
+            if (!ndel) atomicAdd(&count32[nc], 1u);
+          }
+        }
+        out[i] = make_float2(o.px, o.py);
+      }
+    }
+    if (FIX) {
+      const unsigned long long rb = __ballot(redo), nb = __ballot(redo && ndel);
+      if ((threadIdx.x & 63) == 0 && rb) { const unsigned long long w = i >> 6; delmask[w] = (delmask[w] & ~rb) | nb; }      // (i: the wave's first marker)
+    }
+  }
 }
 
 // the marker stage's column-major copies: u, v and the count grid as they stand in front of advect_markers (main.c:855), the solid grid when it changed.  A workgroup moves
@@ -343,20 +445,41 @@ __global__ __launch_bounds__(256) void k_transpose_for_markers(const float* __re
                                                                int X, int Y, int with_solid) {
   __shared__ float tu[64][65], tv[64][65];
   __shared__ uint8_t tc[64][65], ts[64][65];
+  __shared__ int s_any;
   const int xb = blockIdx.x * 64, yb = blockIdx.y * 64, l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_any = 0;
+  __syncthreads();
+  // Round 6: a sample of u or v is only ever USED where its typed fluid property holds (eu_interp selects the others away: main.c:348-362) - a U sample next to a cell
+  // with markers, a V sample below or above one.  A tile whose cells, the column to its right and the row above it hold no marker has no such sample: its u and v are
+  // not moved (the copies keep what an earlier substep left; nothing reads it).  The half tank's air, most of a dam break's grid.
+  bool any = false;
   for (int k = w; k < 64; k += 4) {                       // row yb + k, columns xb + l
     const int x = xb + l, y = yb + k;
     const bool in = x < X && y < Y;
-    const size_t i = (size_t)y * X + x;
-    tu[k][l] = in ? u[i] : 0.f; tv[k][l] = in ? v[i] : 0.f; tc[k][l] = in ? count[i] : (uint8_t)0;
-    if (with_solid) ts[k][l] = in ? solid[i] : (uint8_t)0;
+    const uint8_t c = in ? count[(size_t)y * X + x] : (uint8_t)0;
+    tc[k][l] = c;
+    any = any || c != 0;
+    if (with_solid) ts[k][l] = in ? solid[(size_t)y * X + x] : (uint8_t)0;
   }
+  if (w == 0) { const int x = xb + 64, y = yb + l; any = any || (x < X && y < Y && count[(size_t)y * X + x] != 0); }      // the column to the right
+  if (w == 1) { const int x = xb + l, y = yb + 64; any = any || (x < X && y < Y && count[(size_t)y * X + x] != 0); }      // the row above
+  if (__any(any) && l == 0) s_any = 1;
+  __syncthreads();
+  const bool move = s_any != 0;
+  if (move)
+    for (int k = w; k < 64; k += 4) {
+      const int x = xb + l, y = yb + k;
+      const bool in = x < X && y < Y;
+      const size_t i = (size_t)y * X + x;
+      tu[k][l] = in ? u[i] : 0.f; tv[k][l] = in ? v[i] : 0.f;
+    }
   __syncthreads();
   for (int k = w; k < 64; k += 4) {                       // column xb + k, rows yb + l
     const int x = xb + k, y = yb + l;
     if (x < X && y < Y) {
       const size_t i = (size_t)x * Y + y;
-      uT[i] = tu[l][k]; vT[i] = tv[l][k]; countT[i] = tc[l][k];
+      if (move) { uT[i] = tu[l][k]; vT[i] = tv[l][k]; }
+      countT[i] = tc[l][k];
       if (with_solid) solidT[i] = ts[l][k];
     }
   }
@@ -370,20 +493,50 @@ static bool eu_markers_column_major(euler_sim* S) {      // (whole-grid handles;
   return true;
 }
 
+__global__ void k_blocked_transpose(const uint8_t* __restrict__ sink, const uint8_t* __restrict__ solid, uint8_t* __restrict__ blockedT, int X, int Y);
+static int eu_blocked_current(euler_sim* S) {      // sink | solid, column-major (the solid / sink grids changed: scenario load, euler_set_field, a snapshot)
+  if (S->blocked_dirty) {
+    LAUNCH(S, KC_MARKER_BIN, k_blocked_transpose, dim3((S->X + 63) / 64, (S->Y + 63) / 64), dim3(256), S->sink, S->solid, S->blockedT, S->X, S->Y);
+    S->blocked_dirty = 0;
+  }
+  return EULER_OK;
+}
+// the binning counters are all zero between two refreshes (k_narrow_counts<true> clears what it reads); a refresh that did not get that far leaves them marked
+static int eu_count32_clean(euler_sim* S) {
+  if (S->count32_dirty) HIPCHK(hipMemsetAsync(S->count32, 0, S->Cw * sizeof(unsigned int), S->stream));
+  S->count32_dirty = 1;      // (from here until the next k_narrow_counts<true>)
+  return EULER_OK;
+}
+
 int eu_launch_advect_markers(euler_sim* S, float dt) {
   const unsigned long long n = S->n_markers_host;
   GridRef g{S->X, S->Y, S->count, S->interp_lim[0], S->interp_lim[1], S->interp_lim[2], S->interp_lim[3]};
   const float2* in = S->markers[S->cur];
   float2* out = S->markers[S->cur ^ 1];
-  const unsigned nb = eu_blocks((size_t)n, 256);
+  const unsigned nb = eu_blocks((size_t)n, 256), nb_b = eu_blocks((size_t)n, 256, 4096);
+  S->prebin_valid = 0;
   if (eu_markers_column_major(S)) {
     GridRef gt = g;
     gt.count = S->countT;
-    LAUNCH(S, KC_MARKER_ADVECT, k_advect_markers_a2<true>, dim3(eu_blocks((size_t)((n + 1) / 2), 256)), dim3(256), in, out, S->uT, S->vT, S->solidT, gt, dt, n, S->evmask, S->ev_theta, S->ev_delta, S->ms);
+    const bool fuse = S->opt[EULER_OPT_MARKERS_TWO_PASS] == 0 && S->delmask != nullptr;      // (round 6: the speculative pass bins as well; EULER_OPT_MARKERS_TWO_PASS: rounds 4-5's form)
+    if (fuse) {
+      int rc = eu_blocked_current(S);
+      if (!rc) rc = eu_count32_clean(S);
+      if (rc) return rc;
+      LAUNCH(S, KC_MARKER_ADVECT, k_advect_bin_a2<true>, dim3(eu_blocks((size_t)((n + 1) / 2), 256)), dim3(256), in, out, S->uT, S->vT, S->solidT, gt, dt, n, S->evmask, S->ev_theta, S->ev_delta, S->ms,
+             S->blockedT, S->count32, S->delmask, S->Y);
+    } else
+      LAUNCH(S, KC_MARKER_ADVECT, k_advect_markers_a2<true>, dim3(eu_blocks((size_t)((n + 1) / 2), 256)), dim3(256), in, out, S->uT, S->vT, S->solidT, gt, dt, n, S->evmask, S->ev_theta, S->ev_delta, S->ms);
     int rc = eu_ordered_select(S, S->evmask, (size_t)((n + 63) / 64), S->sel_idx, &S->ms->n_events);
     if (rc) return rc;
     LAUNCH(S, KC_MARKER_EVENTS, k_marker_walk, dim3(1), dim3(64), S->sel_idx, S->ev_theta, S->ev_delta, S->act_idx, S->act_dt, S->ms, dt);
-    LAUNCH(S, KC_MARKER_ADVECT, k_advect_markers_b<true>, dim3(nb), dim3(256), in, out, S->uT, S->vT, S->solidT, gt, n, S->act_idx, S->act_dt, S->ms, (const unsigned int*)nullptr);
+    if (fuse) {
+      LAUNCH(S, KC_MARKER_ADVECT, (k_advect_markers_b<true, true>), dim3(nb_b), dim3(256), in, out, S->uT, S->vT, S->solidT, gt, n, S->act_idx, S->act_dt, S->ms, (const unsigned int*)nullptr,
+             S->blockedT, S->count32, S->delmask, S->Y);
+      S->prebin_valid = 1;      // (consumed by the refresh that follows; anything else in between drops it: driver.hip)
+    } else
+      LAUNCH(S, KC_MARKER_ADVECT, (k_advect_markers_b<true, false>), dim3(nb_b), dim3(256), in, out, S->uT, S->vT, S->solidT, gt, n, S->act_idx, S->act_dt, S->ms, (const unsigned int*)nullptr,
+             (const uint8_t*)nullptr, (unsigned int*)nullptr, (unsigned long long*)nullptr, 0);
     S->cur ^= 1;
     return EULER_OK;
   }
@@ -393,8 +546,8 @@ int eu_launch_advect_markers(euler_sim* S, float dt) {
   if (rc) return rc;
   LAUNCH(S, KC_MARKER_EVENTS, k_marker_walk, dim3(1), dim3(64), S->sel_idx, S->ev_theta, S->ev_delta, S->act_idx,
          S->act_dt, S->ms, dt);
-  LAUNCH(S, KC_MARKER_ADVECT, k_advect_markers_b<false>, dim3(nb), dim3(256), in, out, S->u, S->v, S->solid, g, n,
-         S->act_idx, S->act_dt, S->ms, (const unsigned int*)nullptr);
+  LAUNCH(S, KC_MARKER_ADVECT, (k_advect_markers_b<false, false>), dim3(nb_b), dim3(256), in, out, S->u, S->v, S->solid, g, n,
+         S->act_idx, S->act_dt, S->ms, (const unsigned int*)nullptr, (const uint8_t*)nullptr, (unsigned int*)nullptr, (unsigned long long*)nullptr, 0);
   S->cur ^= 1;
   return EULER_OK;
 }
@@ -473,20 +626,31 @@ __global__ __launch_bounds__(256) void k_compact_markers(float2* m, const unsign
 }
 
 // count = (uint8_t)count32, transposed back to row-major through LDS: a workgroup takes 64 columns x 64 rows; it reads 64
-// consecutive rows of a column with one wave (256 bytes) and writes 64 consecutive cells of a row with one wave (64 bytes)
-__global__ __launch_bounds__(256) void k_narrow_counts(uint8_t* __restrict__ count, const unsigned int* __restrict__ count32,
-                                                       int X, int y0, int y1, MarkerState* ms, int slab) {
+// consecutive rows of a column with one wave (256 bytes) and writes 64 consecutive cells of a row with one wave (64 bytes).
+// FOLD (whole-grid handles, round 6): the pass also does what k_rotate_counts did in front of the binning - prev <- cur (main.c:103) from the count grid it is
+// about to overwrite, and cur <- 0 (main.c:104) for the counters it has just read: they are all zero again when the next refresh (or the advection pass that
+// bins for it) starts.  One pass over the cells instead of two.
+template <bool FOLD>
+__global__ __launch_bounds__(256) void k_narrow_counts(uint8_t* __restrict__ count, unsigned int* __restrict__ count32,
+                                                       int X, int y0, int y1, MarkerState* ms, int slab, uint8_t* __restrict__ prev) {
   __shared__ uint8_t tile[64][65];
   const int H = y1 - y0, xb = blockIdx.x * 64, yb = blockIdx.y * 64;
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int k = w; k < 64; k += 4) {                       // column xb + k, rows yb + l
     const int x = xb + k, yr = yb + l;
-    tile[k][l] = (x < X && yr < H) ? (uint8_t)count32[(size_t)x * H + yr] : (uint8_t)0;   // g_marker_count is uint8_t and wraps (main.c:96,114)
+    const bool in = x < X && yr < H;
+    const unsigned int c = in ? count32[(size_t)x * H + yr] : 0u;
+    tile[k][l] = (uint8_t)c;   // g_marker_count is uint8_t and wraps (main.c:96,114)
+    if (FOLD && c != 0u) count32[(size_t)x * H + yr] = 0u;
   }
   __syncthreads();
   for (int k = w; k < 64; k += 4) {                       // row yb + k, columns xb + l
     const int x = xb + l, yr = yb + k;
-    if (x < X && yr < H) count[(size_t)(y0 + yr) * X + x] = tile[l][k];
+    if (x < X && yr < H) {
+      const size_t i = (size_t)(y0 + yr) * X + x;
+      if (FOLD) prev[i] = count[i];
+      count[i] = tile[l][k];
+    }
   }
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     if (slab) { ms->n -= ms->n_del_glob; ms->n_loc -= ms->n_rm; }
@@ -501,8 +665,8 @@ int eu_marker_rotate_counts(euler_sim* S) {
   return EULER_OK;
 }
 int eu_marker_narrow_counts(euler_sim* S) {
-  LAUNCH(S, KC_MARKER_BIN, k_narrow_counts, dim3((S->X + 63) / 64, (S->win_hi - S->win_lo + 63) / 64), dim3(256), S->count, S->count32, S->X,
-         S->win_lo, S->win_hi, S->ms, S->slab_on);
+  LAUNCH(S, KC_MARKER_BIN, k_narrow_counts<false>, dim3((S->X + 63) / 64, (S->win_hi - S->win_lo + 63) / 64), dim3(256), S->count, S->count32, S->X,
+         S->win_lo, S->win_hi, S->ms, S->slab_on, (uint8_t*)nullptr);
   return EULER_OK;
 }
 int eu_marker_advect_a(euler_sim* S, float dt, unsigned long long n) {
@@ -513,24 +677,30 @@ int eu_marker_advect_a(euler_sim* S, float dt, unsigned long long n) {
 }
 int eu_marker_advect_b(euler_sim* S, unsigned long long n, const unsigned int* keys) {
   GridRef g{S->X, S->Y, S->count, S->interp_lim[0], S->interp_lim[1], S->interp_lim[2], S->interp_lim[3]};
-  LAUNCH(S, KC_MARKER_ADVECT, k_advect_markers_b<false>, dim3(eu_blocks((size_t)n, 256)), dim3(256), S->markers[S->cur], S->markers[S->cur ^ 1], S->u, S->v, S->solid, g, n,
-         S->act_idx, S->act_dt, S->ms, keys);
+  LAUNCH(S, KC_MARKER_ADVECT, (k_advect_markers_b<false, false>), dim3(eu_blocks((size_t)n, 256, 4096)), dim3(256), S->markers[S->cur], S->markers[S->cur ^ 1], S->u, S->v, S->solid, g, n,
+         S->act_idx, S->act_dt, S->ms, keys, (const uint8_t*)nullptr, (unsigned int*)nullptr, (unsigned long long*)nullptr, 0);
   return EULER_OK;
 }
 
-int eu_launch_refresh_counts(euler_sim* S) {
+int eu_launch_refresh_counts(euler_sim* S) {      // (whole-grid handles; row slabs: k_slab.hip)
   const unsigned long long n = S->n_markers_host;
-  eu_marker_rotate_counts(S);
-  if (S->blocked_dirty) {      // (the solid / sink grids changed: scenario load, euler_set_field, a snapshot)
-    LAUNCH(S, KC_MARKER_BIN, k_blocked_transpose, dim3((S->X + 63) / 64, (S->Y + 63) / 64), dim3(256), S->sink, S->solid, S->blockedT, S->X, S->Y);
-    S->blocked_dirty = 0;
+  unsigned long long* delmask = S->evmask;
+  int rc;
+  if (S->prebin_valid) delmask = S->delmask;      // the advection pass in front binned what it wrote (k_advect_bin_a2): the counters and the delete ballot stand
+  else {
+    if ((rc = eu_blocked_current(S)) || (rc = eu_count32_clean(S))) return rc;
+    LAUNCH(S, KC_MARKER_BIN, k_bin_markers, dim3(eu_blocks((size_t)n, 256)), dim3(256), S->markers[S->cur], n, S->blockedT,
+           S->count32, S->evmask, S->X, S->Y);
   }
-  LAUNCH(S, KC_MARKER_BIN, k_bin_markers, dim3(eu_blocks((size_t)n, 256)), dim3(256), S->markers[S->cur], n, S->blockedT,
-         S->count32, S->evmask, S->X, S->Y);
-  int rc = eu_ordered_select(S, S->evmask, (size_t)((n + 63) / 64), S->sel_idx, &S->ms->n_deleted);
+  S->prebin_valid = 0;
+  rc = eu_ordered_select(S, delmask, (size_t)((n + 63) / 64), S->sel_idx, &S->ms->n_deleted);
   if (rc) return rc;
-  LAUNCH(S, KC_MARKER_COMPACT, k_compact_markers, dim3(256), dim3(256), S->markers[S->cur], S->sel_idx, S->evmask, S->ms);
-  return eu_marker_narrow_counts(S);
+  LAUNCH(S, KC_MARKER_COMPACT, k_compact_markers, dim3(256), dim3(256), S->markers[S->cur], S->sel_idx, delmask, S->ms);
+  // prev <- cur, cur <- the counters, the counters <- 0
+  LAUNCH(S, KC_MARKER_BIN, k_narrow_counts<true>, dim3((S->X + 63) / 64, (S->win_hi - S->win_lo + 63) / 64), dim3(256), S->count, S->count32, S->X,
+         S->win_lo, S->win_hi, S->ms, 0, S->prev_count);
+  S->count32_dirty = 0;
+  return EULER_OK;
 }
 
 // ==========================================================================================

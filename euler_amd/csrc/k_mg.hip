@@ -62,6 +62,9 @@ static MgHier mg_hier(const euler_sim* S) {
 }
 __device__ __forceinline__ const double* mg_sten(const MgHier& H, int l) { return H.a + 9 * (size_t)H.off[l]; }
 
+void eu_mg_release(euler_sim* S);
+// (a failed allocation gives back what the attempt already holds: the next attempt starts from nothing - ADVICE r5)
+#define MGCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { eu_mg_release(S); return eu_hip_fail(_e, #call, __FILE__, __LINE__); } } while (0)
 int eu_mg_alloc(euler_sim* S) {
   if (S->mg_dot) return EULER_OK;
   int nx = (S->X + MG_G0 - 1) / MG_G0, ny = MG_RPB * S->geom.nbands, l = 0;
@@ -74,18 +77,25 @@ int eu_mg_alloc(euler_sim* S) {
   }
   S->mg_levels = l + 1;
   const size_t n0 = (size_t)S->mg_nx[0] * S->mg_ny[0];
-  HIPCHK(hipMalloc((void**)&S->mg_a, 9 * S->mg_cells * sizeof(double)));
-  HIPCHK(hipMalloc((void**)&S->mg_a0i, 9 * n0 * sizeof(unsigned long long)));
-  HIPCHK(hipMalloc((void**)&S->mg_rhs, 3 * S->mg_cells * sizeof(double)));
+  {      // the limits of the cycle's launches, checked where the mode is SELECTED (euler_create, euler_set_precond) - not inside a solve, behind the substep's marker stages
+    int lC = 0;      // (mg_entry_level)
+    while (lC < S->mg_levels - 1 && (size_t)S->mg_nx[lC] * S->mg_ny[lC] > 1024 /* MG_TAIL_MAX */) ++lC;
+    const size_t tiles0 = (size_t)((S->mg_nx[0] + 31) / 32) * ((S->mg_ny[0] + 31) / 32);
+    if (S->mg_levels - 1 - lC > 4 /* MG_TAIL_LEVELS */) { eu_set_error("multilevel preconditioner: %d levels behind the entry level (at most 4): the grid is too large for this mode", S->mg_levels - 1 - lC); S->mg_levels = 0; return EULER_EINVAL; }
+    if (tiles0 > MG_DOT_BLOCKS) { eu_set_error("multilevel preconditioner: %zu tiles of level 0 (at most %d): the grid is too large for this mode", tiles0, MG_DOT_BLOCKS); S->mg_levels = 0; return EULER_EINVAL; }
+  }
+  MGCHK(hipMalloc((void**)&S->mg_a, 9 * S->mg_cells * sizeof(double)));
+  MGCHK(hipMalloc((void**)&S->mg_a0i, 9 * n0 * sizeof(unsigned long long)));
+  MGCHK(hipMalloc((void**)&S->mg_rhs, 3 * S->mg_cells * sizeof(double)));
   S->mg_x = S->mg_rhs + S->mg_cells; S->mg_wd = S->mg_rhs + 2 * S->mg_cells;
-  HIPCHK(hipMalloc((void**)&S->mg_part, (S->chunk_cap + 64) * MG_PART * sizeof(double)));
-  HIPCHK(hipMalloc((void**)&S->mg_null0, (size_t)MG_NULL_MAX * S->mg_cells * sizeof(double)));      // the indicators of cut-off regions on every level (k_mg_null_prolong)
-  HIPCHK(hipMemset(S->mg_a, 0, 9 * S->mg_cells * sizeof(double)));
-  HIPCHK(hipMemset(S->mg_rhs, 0, 3 * S->mg_cells * sizeof(double)));
-  HIPCHK(hipMemset(S->mg_part, 0, (S->chunk_cap + 64) * MG_PART * sizeof(double)));
-  HIPCHK(hipMemset(S->mg_null0, 0, (size_t)MG_NULL_MAX * S->mg_cells * sizeof(double)));
-  HIPCHK(hipMalloc((void**)&S->mg_inner0, n0));
-  HIPCHK(hipMemset(S->mg_inner0, 0, n0));
+  MGCHK(hipMalloc((void**)&S->mg_part, (S->chunk_cap + 64) * MG_PART * sizeof(double)));
+  MGCHK(hipMalloc((void**)&S->mg_null0, (size_t)MG_NULL_MAX * S->mg_cells * sizeof(double)));      // the indicators of cut-off regions on every level (k_mg_null_prolong)
+  MGCHK(hipMemset(S->mg_a, 0, 9 * S->mg_cells * sizeof(double)));
+  MGCHK(hipMemset(S->mg_rhs, 0, 3 * S->mg_cells * sizeof(double)));
+  MGCHK(hipMemset(S->mg_part, 0, (S->chunk_cap + 64) * MG_PART * sizeof(double)));
+  MGCHK(hipMemset(S->mg_null0, 0, (size_t)MG_NULL_MAX * S->mg_cells * sizeof(double)));
+  MGCHK(hipMalloc((void**)&S->mg_inner0, n0));
+  MGCHK(hipMemset(S->mg_inner0, 0, n0));
   {      // level 0's stencil under deep water: A_0 = K (x) M + M (x) K with the 1-D mass and stiffness sums of the hats (multiples of 1 / G0^2: exact)
     double M[3] = {0, 0, 0}, K[3] = {-1.0 / MG_G0, 2.0 / MG_G0, -1.0 / MG_G0};
     for (int k = -(MG_G0 - 1); k <= MG_G0 - 1; ++k) { const double w = 1.0 - (k < 0 ? -k : k) / (double)MG_G0; M[1] += w * w; }
@@ -93,13 +103,14 @@ int eu_mg_alloc(euler_sim* S) {
     M[2] = M[0];
     for (int q = 0; q < 9; ++q) S->mg_ic[q] = K[q % 3] * M[q / 3] + M[q % 3] * K[q / 3];
   }
-  HIPCHK(hipMalloc((void**)&S->mg_m0, (MG_NULL_MAX * n0 + MG_NULL_MAX) * sizeof(double)));
-  HIPCHK(hipMemset(S->mg_m0, 0, (MG_NULL_MAX * n0 + MG_NULL_MAX) * sizeof(double)));
-  HIPCHK(hipMalloc((void**)&S->mg_dot, ((1 + MG_NULL_MAX) * MG_DOT_BLOCKS + 2) * sizeof(double)));      // per-workgroup partials of x_0 . rhs_0 and of the gauge sums, then the tickets of k_mg_up and k_mg_down
-  HIPCHK(hipMemset(S->mg_dot, 0, ((1 + MG_NULL_MAX) * MG_DOT_BLOCKS + 2) * sizeof(double)));
+  MGCHK(hipMalloc((void**)&S->mg_m0, (MG_NULL_MAX * n0 + MG_NULL_MAX) * sizeof(double)));
+  MGCHK(hipMemset(S->mg_m0, 0, (MG_NULL_MAX * n0 + MG_NULL_MAX) * sizeof(double)));
+  MGCHK(hipMalloc((void**)&S->mg_dot, ((1 + MG_NULL_MAX) * MG_DOT_BLOCKS + 2) * sizeof(double)));      // per-workgroup partials of x_0 . rhs_0 and of the gauge sums, then the tickets of k_mg_up and k_mg_down
+  MGCHK(hipMemset(S->mg_dot, 0, ((1 + MG_NULL_MAX) * MG_DOT_BLOCKS + 2) * sizeof(double)));
   S->hbm_bytes += (9 * S->mg_cells + 3 * S->mg_cells + (size_t)MG_NULL_MAX * S->mg_cells) * sizeof(double) + 9 * n0 * 8 + (S->chunk_cap + 64) * MG_PART * sizeof(double);
   return EULER_OK;
 }
+#undef MGCHK
 void eu_mg_release(euler_sim* S) {
   eu_mg_split_release(S);
   for (double* d : {S->mg_a, S->mg_rhs, S->mg_part, S->mg_dot, S->mg_xbuf, S->mg_null0, S->mg_m0}) if (d) (void)hipFree(d);
@@ -321,6 +332,7 @@ struct MgDownArgs {
 #define MG_SPLIT 704          // threads [0, MG_SPLIT) serve a launch's second level (<= 25 x 25 nodes + a row of slack), the others its third (<= 11 x 11)
 #define MG_TAIL_MAX 1024      // nodes of the first level the tail takes
 #define MG_TAIL_LEVELS 4      // stencil levels of the tail at most (1024 -> 272 -> 72 -> top would be 3)
+static_assert(MG_TAIL_MAX == 1024 && MG_TAIL_LEVELS == 4, "eu_mg_alloc checks these limits with literals");
 
 __device__ __forceinline__ void mg_st_agent(double* p, double v) {
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

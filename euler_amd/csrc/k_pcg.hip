@@ -29,6 +29,7 @@
 #include "k_mg.h"
 
 #include <stdlib.h>
+#include <cmath>
 #include <type_traits>
 #include <vector>
 
@@ -1736,6 +1737,16 @@ __global__ __launch_bounds__(256) void k_finish_p(double* __restrict__ p, const 
   }
 }
 
+// (of the last multi-kernel solve: its ring and scalars stand until the next solve starts)
+int eu_launch_finish_p(euler_sim* S) {
+  if (S->s_ring_n <= 0) return EULER_OK;
+  SRing ring;
+  for (int k = 0; k < 8; ++k) ring.s[k] = S->s_ring[k < S->s_ring_n ? k : 0];
+  ring.n = S->s_ring_n; ring.steps = S->s_ring_n;
+  LAUNCH(S, KC_UPDATE_PR, k_finish_p, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), S->p + S->e_lo, S->cellmask + S->e_lo, S->e_lo, S->e_cnt, S->sc, ring);
+  return EULER_OK;
+}
+
 // ==========================================================================================
 // host-side launch helpers
 static SweepArgs make_sweep_args(euler_sim* S, int op, int force) {
@@ -2307,7 +2318,7 @@ static int launch_search_apply_and_alpha(euler_sim* S, int it) {
 }
 
 int eu_launch_build_system(euler_sim* S, float dt);
-int eu_launch_velocity_update(euler_sim* S, float dt);
+int eu_launch_velocity_update(euler_sim* S, float dt, int finish);
 
 __global__ void k_pcg_reset(PcgScalars* sc, double tol, int max_iters) {
   sc->sigma = sc->zs = sc->sigma_new = sc->alpha = sc->alpha_prev = sc->beta = sc->rnorm = 0.0;
@@ -2320,6 +2331,7 @@ __global__ void k_pcg_reset(PcgScalars* sc, double tol, int max_iters) {
 // the all-gather of p before the (replicated) velocity update.
 int eu_launch_project(euler_sim* S, float dt) {
   S->s_launched = 0;      // (EULER_F_PCG_S: no multi-kernel iteration of this solve has run yet)
+  S->p_pending = 0;       // (the assembly writes p afresh: whatever the last solve left unfinished in memory is gone with it)
   S->pcg_fields_resident = 0;
   const PcgScalars prev_solve = *S->sc_host;      // (the previous solve's final scalars: a resident launch that has to be redone must not leave its own in their place)
   // the previous solve's final scalars are in sc_host by now (copied at its end, synced since)
@@ -2367,7 +2379,7 @@ int eu_launch_project(euler_sim* S, float dt) {
       const int err = *S->res_err;
       if (err == 0) {
         if (S->sc_host->nonzero) { S->res_solves += 1; S->pcg_fields_resident = 1; }      // (z, s, q never left the registers: EULER_F_PCG_Z / _S / _Q have nothing to show)
-        eu_launch_velocity_update(S, dt);
+        if ((rc = eu_launch_velocity_update(S, dt, 0))) return rc;      // (the resident kernel wrote the final p)
         return EULER_OK;      // (sc_host is current)
       }
       *S->res_err = 0;
@@ -2404,7 +2416,13 @@ int eu_launch_project(euler_sim* S, float dt) {
   // multilevel mode on one GPU: the first search direction s = z + P y is formed by the first k_search_apply itself (beta is 0 behind k_pcg_reset, and 0 times what an earlier
   // solve left in the ring is 0) - a copy pass and a k_apply_a less per solve.  Only there: no recorded digest pins this mode's zeros' signs (z = -0 comes out as +0)
   const bool fold0 = two_level && eu_is_mg(S) && !S->has_comm && S->cfg.dot_mode != EULER_DOT_SEQUENTIAL && sa_run(S) == 8;
-  if (fold0) { /* (below) */ }
+  if (fold0) {
+    // (below) - beta = 0 times what an earlier solve left in ring[n - 1].  That product is only 0 while the array is finite: a solve that broke down (tol = 0 runs where
+    // z . s reaches 0: alpha = 0 / 0) leaves Inf / NaN there, and 0 x Inf = NaN would poison every later solve - such a solve's ring is cleared first
+    const PcgScalars& ps = prev_solve;
+    if (ps.nonzero && !(std::isfinite(ps.alpha) && std::isfinite(ps.beta) && std::isfinite(ps.rnorm) && std::isfinite(ps.sigma) && std::isfinite(ps.zs)))
+      for (int k = 0; k < S->s_ring_n; ++k) HIPCHK(hipMemsetAsync(S->s_ring[k] + S->skew_off, 0, S->Sw * sizeof(double), S->stream));
+  }
   else if (two_level) { if ((rc = eu_launch_coarse_search_init(S))) return rc; }      // s = z + P y
   else
   LAUNCH(S, KC_UPDATE_SEARCH, k_update_search<true>, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->s), LOC(S->z),
@@ -2472,14 +2490,11 @@ int eu_launch_project(euler_sim* S, float dt) {
     }
   }
   S->prof_iter = -2;
-  // the last one or two p += alpha s (the others rode along with the apply_a passes)
-  {
-    SRing ring;
-    for (int k = 0; k < 8; ++k) ring.s[k] = S->s_ring[k < S->s_ring_n ? k : 0];
-    ring.n = S->s_ring_n; ring.steps = S->s_ring_n;
-    LAUNCH(S, KC_UPDATE_PR, k_finish_p, dim3(eu_blocks(S->e_cnt, 256 * 4, 4096)), dim3(256), LOC(S->p), LOC(S->cellmask), S->e_lo, S->e_cnt, S->sc, ring);
-    if (S->s_ring_n > 2) { S->s = S->s_base[0]; S->s2 = S->s_base[1]; }      // between solves S->s / S->s2 are the handle's own two arrays (EULER_F_PCG_S finds the last direction in the ring)
-  }
+  // the last p += alpha s (the others rode along with the apply_a passes): in memory where a communicator needs the finished rows (and in the two-pass form), else inside the
+  // velocity update's pass (k_grid.hip k_velocity_update_para)
+  const bool finish_in_update = !S->has_comm && !S->slab_on && S->opt[EULER_OPT_VELOCITY_TWO_PASS] == 0;
+  if (!finish_in_update) { if ((rc = eu_launch_finish_p(S))) return rc; }
+  if (S->s_ring_n > 2) { S->s = S->s_base[0]; S->s2 = S->s_base[1]; }      // between solves S->s / S->s2 are the handle's own two arrays (EULER_F_PCG_S finds the last direction in the ring)
   if (S->has_comm && S->slab_on) {
     // row slabs: the velocity update of the highest own row reads p one row up (main.c:800) - one ghost row from the rank above
     const int X = S->X, nbk = (X + 255) / 256;
@@ -2497,7 +2512,7 @@ int eu_launch_project(euler_sim* S, float dt) {
     }
     COMM_CALL(S->comm.allgather(S->comm.ctx, S->p, off.data(), cnt.data()));
   }
-  eu_launch_velocity_update(S, dt);
+  if ((rc = eu_launch_velocity_update(S, dt, finish_in_update ? 1 : 0))) return rc;
   HIPCHK(hipMemcpyAsync(S->sc_host, S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
   return EULER_OK;
 }

@@ -375,6 +375,9 @@ enum {
   EULER_OPT_MG_SPLIT_LEVEL = 14,    /* multilevel mode on row slabs: the level whose right-hand side the ranks all-gather (below it every rank works on its own rows): 0 (default) by size,
                                        n > 0 that level (tests: the split on small grids), -1 never (the cycle replicated from level 0 on).  The same value on every rank */
   EULER_OPT_MG_SPLIT_ACTIVE = 15,   /* read only: the gather level the last multilevel solve on row slabs ran with, 0 while the cycle runs replicated */
+  EULER_OPT_MARKERS_TWO_PASS = 16,  /* 1: advect_markers and refresh_marker_counts as separate passes over the marker array (rounds 1-5; A-B timing; the same bits); 0 (default): the advection pass bins what it writes */
+  EULER_OPT_BUILD_TWO_PASS = 17,    /* 1: the assembly as a row-major pass + a skewed gather (rounds 3-5; A-B timing; the same bits); 0 (default): one pass over parallelograms of the band-skewed layout */
+  EULER_OPT_VELOCITY_TWO_PASS = 18, /* 1: k_finish_p + k_velocity_update as in rounds 1-5 (A-B timing; the same bits); 0 (default): one pass */
   EULER_OPT__COUNT
 };
 int euler_set_option(euler_sim* sim, int32_t key, int64_t value);

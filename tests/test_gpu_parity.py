@@ -470,10 +470,16 @@ def _load_both(X2, Y2, solid, sink, m, u, v):
 
 @pytest.mark.parametrize("shape,seed,n,solid_frac", [((96, 72), 1, 6000, 0.25), ((200, 130), 2, 60000, 0.15),
                                                       ((333, 257), 3, 200000, 0.30), ((64, 64), 4, 3000, 0.45)])
-def test_marker_stages_random_stress_bit_exact(shape, seed, n, solid_frac):
+@pytest.mark.parametrize("form", ["one_pass", "two_pass", "edited"])
+def test_marker_stages_random_stress_bit_exact(shape, seed, n, solid_frac, form):
+    """form: one_pass - the advection pass bins what it writes and pass B moves the counts of the markers it recomputes (round 6, the default: the dt chains
+    of this state recompute most of the array); two_pass - rounds 1-5's separate binning pass (EULER_OPT_MARKERS_TWO_PASS); edited - the caller writes the
+    marker array between the two stages, so what the advection pass binned must be dropped."""
     X2, Y2 = shape
     solid, sink, m, u, v = _random_marker_state(X2, Y2, seed, n, solid_frac)
     o, sim = _load_both(X2, Y2, solid, sink, m, u, v)
+    if form == "two_pass":
+        sim.set_option(ea.OPT_MARKERS_TWO_PASS, 1)
     events = 0
     for rep in range(3):
         dt = sim.timestep(0.1)
@@ -481,6 +487,10 @@ def test_marker_stages_random_stress_bit_exact(shape, seed, n, solid_frac):
         sim.stage(ea.STAGE_ADVECT_MARKERS, dt)
         o.lib.eo_advect_markers(o.ptr, np.float32(dt))
         assert_bits(sim.get(ea.F_MARKERS), o.markers, "advect rep %d" % rep)
+        if form == "edited":      # the same markers, back to front: the counts must come from THIS array, the deletions in ITS order
+            rev = np.ascontiguousarray(o.markers[::-1])
+            o.set_markers(rev)
+            sim.set_markers(rev)
         sim.stage(ea.STAGE_REFRESH_COUNTS)
         o.lib.eo_refresh_marker_counts(o.ptr)
         assert sim.stats().n_markers == o.n_markers
