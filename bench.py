@@ -432,7 +432,9 @@ def main():
                 ref = cpu["reference_flags"]
                 per_cell_substep = ref["seconds"] / (NS * NS * max(ref["substeps"], 1))
                 cpu_obj = {"value": round(ref["value"], 1), "unit": "cells*steps/s", "cores": 1, "kind": "port",
-                           "sample": "1 frame (%d substep(s), %d PCG iterations) of the %dx%d half tank - the headline workload at 1/%d of its "
+                           # like for like with the GPU line's cells_substeps_per_s: a CPU sample frame from rest is ONE substep, a GPU headline step is eight
+                           "cells_substeps_per_s": round(ref["value"] * max(ref["substeps"], 1), 1), "substeps_per_step": int(ref["substeps"]),
+                           "sample": "1 frame = %d substep(s) (the GPU headline step: 8 substeps - compare cells_substeps_per_s), %d PCG iterations, of the %dx%d half tank - the headline workload at 1/%d of its "
                                      "cells, same fluid fraction, same tol / iteration budget; oracle/euler_oracle.c built -O3 -ffast-math "
                                      "-march=native (the reference's CMake flags), single thread like the reference" % (ref["substeps"], ref["pcg_iterations"], NS, NS, max(1, (8192 // NS) ** 2)),
                            "seconds": ref["seconds"], "strict_ieee_value": round(cpu["strict"]["value"], 1), "cpu_model": cpu_model(),

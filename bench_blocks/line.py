@@ -81,7 +81,7 @@ def compact_line(full, limit=LINE_LIMIT):
                        for k, v in (full.get("kernels") or {}).items() if isinstance(v, dict) and v.get("bytes_per_cell") is not None}
     cpu = full.get("cpu_baseline")
     if isinstance(cpu, dict):
-        c = _pick(cpu, ("value", "unit", "cores", "kind", "sample", "seconds", "strict_ieee_value", "cpu_model", "host_cores_available", "error"))
+        c = _pick(cpu, ("value", "unit", "cores", "kind", "cells_substeps_per_s", "substeps_per_step", "sample", "seconds", "strict_ieee_value", "cpu_model", "host_cores_available", "error"))
         if isinstance(c.get("sample"), str) and len(c["sample"]) > 240:
             c["sample"] = c["sample"][:237] + "..."
         if isinstance(cpu.get("equal_tolerance"), dict):
@@ -97,7 +97,8 @@ def compact_line(full, limit=LINE_LIMIT):
     if isinstance(conv, dict):
         c = _block(conv, ("last_residual", "cells_substeps_per_s"))
         if isinstance(conv.get("roofline"), dict):
-            c["roofline"] = _pick(conv["roofline"], ROOF_KEYS)
+            # (no PMC figures here: the counters' per-launch averages of a converging run include the launches queued behind convergence, which move no data - VERDICT r5)
+            c["roofline"] = _pick(conv["roofline"], tuple(k for k in ROOF_KEYS if "traffic" not in k))
         if isinstance(conv.get("pcg_iteration"), dict):
             c["pcg_iteration"] = _pick(conv["pcg_iteration"], ITER_KEYS)
         if isinstance(conv.get("deviation_vs_reference_converged"), dict):

@@ -116,7 +116,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--resume") && i + 1 < argc) resume = argv[++i];
     else if (!strcmp(argv[i], "--checkpoint") && i + 1 < argc) checkpoint = argv[++i];
     /* the pressure solver's preconditioner (include/euler.h EULER_PRECOND_*): `reference` (default) = main.c:577-627, bit-identical iterates;
-     * the others reach the same pressure where the solve converges - `multilevel` in ~110 iterations whatever the grid size, so with
+     * the others reach the same pressure where the solve converges - `multilevel` in 30-60 iterations whatever the grid size, so with
      * --max-iterations lifted above the reference's 100 (main.c:735) a large grid is actually SOLVED each substep */
     else if (!strcmp(argv[i], "--solver") && i + 1 < argc) {
       const char* v = argv[++i];

@@ -59,7 +59,7 @@ void sim_init(args_t in) {
   const char* up = getenv("EULER_COMPAT_UPSCALE");
   if (up && up[0] == '1') upscale = 1;
   /* the preconditioner of the pressure solve (include/euler.h EULER_PRECOND_*): "reference" (default) = main.c:577-627 with bit-identical iterates; "multilevel" with
-   * EULER_COMPAT_MAX_ITERATIONS above the reference's 100 lets a large grid's solves converge (~110 iterations whatever the size) */
+   * EULER_COMPAT_MAX_ITERATIONS above the reference's 100 lets a large grid's solves converge (30-60 iterations whatever the size) */
   const char* solver = getenv("EULER_COMPAT_SOLVER");
   if (solver) {
     if (!strcmp(solver, "reference")) cfg.precond = EULER_PRECOND_IC0;

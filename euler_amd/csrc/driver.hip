@@ -163,7 +163,9 @@ extern "C" int euler_set_option(euler_sim* S, int32_t key, int64_t value) {
   const char* when = nullptr;
   switch (key) {
     case EULER_OPT_P_STEPS: ok = value == 2 || value == 4 || value == 8; break;
-    case EULER_OPT_SA_RUN: ok = value == 8 || value == 16 || value == 32; break;
+    case EULER_OPT_SA_RUN: ok = value == 8 || value == 16 || value == 32;
+      if (ok && value != 8 && (S->has_comm || eu_is_two_level(S))) when = "on a handle without a communicator, in the parity or the plain tile-local mode (the others run runs of 8)";
+      break;
     case EULER_OPT_RCCL_SMALL: ok = value >= 0 && value <= 2; if (S->rccl) when = "before euler_set_comm_rccl"; break;
     case EULER_OPT_RCCL_NO_EXCHANGE: ok = value == 0 || value == 1; if (S->rccl) when = "before euler_set_comm_rccl"; break;
     case EULER_OPT_SLAB_FUSION: ok = value == 0 || value == 1; if (S->p2p_on) when = "before euler_p2p_connect"; break;

@@ -188,16 +188,16 @@ struct euler_sim {
   double* cc_part;                   // [chunks][3]: per tile, the sums of r over its fluid cells by coarse column (k_precond_tile)
   double* cc_y;                      // [n]: the coarse correction of the iteration (k_coarse_solve)
   double* cc_null;                   // [4][CC_MAX] + 1: the indicators of up to four fluid regions cut off from the air (null vectors of the dense level) and, last, how many (k_coarse_nullfix)
-  // EULER_PRECOND_IC0_TILE_MG (multilevel; k_mg.hip): levels 0 .. mg_levels - 1 of node grids, mg_nx[l] x mg_ny[l] nodes (level 0: a node per 16 x 16 cells, each level
+  // EULER_PRECOND_IC0_TILE_MG (multilevel; k_mg.hip): levels 0 .. mg_levels - 1 of node grids, mg_nx[l] x mg_ny[l] nodes (level 0: a node per MG_G0 x MG_G0 = 8 x 8 cells, AT the centre of cell (8 J + 4, 8 I + 4) - k_mg.h; each level
   // above every other node of the one below; the last level is the dense one), pooled arrays with level l at offset mg_off[l]
   int mg_levels, mg_nx[12], mg_ny[12];
   size_t mg_off[12], mg_cells;
   double* mg_a;                      // [9][nodes] per level (level l at 9 * mg_off[l]): the Galerkin operators as nine-point stencils
-  unsigned long long* mg_a0i;        // [9][nodes of level 0]: A_0 in units of 2^-16, summed by integer atomics per solve
+  unsigned long long* mg_a0i;        // [9][nodes of level 0]: A_0 in units of 1 / MG_G0^4 = 2^-12, summed by integer atomics per solve
   double *mg_rhs, *mg_x;             // right-hand side and result of the V-cycle per level (level 0's result is what k_search_apply adds to z through P_0)
   double* mg_wd;                     // omega / diagonal per node (0: no fluid under the node), per solve
   uint8_t* mg_inner0; double mg_ic[9];   // level 0: nodes whose stencil is deep water's (mg_ic, a constant of the node spacing), per solve
-  double* mg_part;                   // [chunks][48]: per tile and half-group of 8 lanes, the weighted sums of r for 2 node rows x 3 node columns (k_precond_tile)
+  double* mg_part;                   // [chunks][MG_PART = 72]: per tile, [group of 8 lanes (9: the first and the last are half groups)][row slot (2)][column slot (4)] - the weighted sums of r (k_precond_tile writes, mg_gather0 reads; k_mg.h)
   double* mg_dot;                    // per-workgroup partials of x_0 . rhs_0 (+ the ticket counters behind them)
   double* mg_null0;                  // [4][mg_cells]: the indicators of cut-off regions on every level (k_mg_null_prolong)
   double* mg_m0;                     // [4][nodes of level 0] + [4]: P_0^T of those indicators on the cells, and m_0 . n_0 (the gauge of k_mg_up)

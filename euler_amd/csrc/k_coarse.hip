@@ -1,7 +1,7 @@
 // k_coarse.hip — the coarse levels of the TWO-LEVEL and the MULTILEVEL preconditioner (EULER_PRECOND_IC0_TILE2 / _TILE_MG, include/euler.h; round 3):
 //
 //     z = M_tile^-1 r + P (P^T A P)^-1 P^T r            (two-level; the first part of this file)
-//     z = M_tile^-1 r + P_0 V(P_0^T r)                  (multilevel: "Multilevel mode" below - a V-cycle over aggregates of 16, 32, ... cells whose top level is the
+//     z = M_tile^-1 r + P_0 V(P_0^T r)                  (multilevel: "Multilevel mode" below - a V-cycle over bilinear node grids 8, 16, 32, ... cells apart (k_mg.hip) whose top level is the
 //                                                        dense level of the two-level mode; also on row slabs)
 //
 // M_tile = the tile-local IC(0) of k_pcg.hip (64-row x 16-record blocks, one pass over memory); P = piecewise constants over coarse

@@ -477,10 +477,10 @@ __global__ __launch_bounds__(256) void k_build_system2(const uint8_t* __restrict
 
 // The assembly in ONE pass (round 6).  The two-step form above writes 5 bytes per cell of scratch and gathers them back along the diagonal (0.22 + 0.60 ms at 8192^2).  A run of
 // W consecutive records of a band is a PARALLELOGRAM of the grid: row l of the band holds its cells x = t0 - l .. t0 - l + W - 1 - W consecutive cells of a row-major row.  A
-// workgroup takes the 96 records of one unit (six chunks; T is a whole number of units): it walks the 64 row segments with consecutive threads on consecutive cells (coalesced
-// 384-byte reads of count, solid, utmp, vtmp; the four neighbours come out of the same lines), leaves mask byte and float divergence (main.c:720) in LDS, and writes the skewed
+// workgroup takes BS_W = 48 records (three chunks; T is a whole number of 96): it walks the 64 row segments with consecutive threads on consecutive cells (coalesced
+// 192-byte reads of count, solid, utmp, vtmp; the four neighbours come out of the same lines), leaves mask byte and float divergence (main.c:720) in LDS, and writes the skewed
 // arrays from there with consecutive threads on consecutive elements.  The same arithmetic per cell: the same bits; the chunk flags as before.
-#define BS_W 96
+#define BS_W 48            // records per workgroup (T is a whole number of 96): 15 KB of LDS, ten workgroups per CU
 template <bool TILE>
 __global__ __launch_bounds__(256) void k_build_system_para(const float* __restrict__ u, const float* __restrict__ v, const uint8_t* __restrict__ count, const uint8_t* __restrict__ solid,
                                                            double* __restrict__ b, double* __restrict__ r, double* __restrict__ p, double* __restrict__ q, double* __restrict__ z,
@@ -497,28 +497,57 @@ __global__ __launch_bounds__(256) void k_build_system_para(const float* __restri
   if (tid < BS_W / 16) { s_fl[tid] = 0; s_part[tid] = 0; s_prev[tid] = TILE ? (chunk_prev[chunk0 + tid] != 0) : 1; }
   if (tid == 0) s_nz = 0;
   __syncthreads();
-  for (int c = tid; c < 64 * BS_W; c += 256) {
-    const int l = c / BS_W, j = c % BS_W;
-    const int x = t0 - l + j, y = band * 64 + l;
-    uint8_t m = 0;
-    float div_f = 0.f;
-    if (x >= 0 && x < X && y < Y) {
-      const size_t i = (size_t)y * X + x;
-      if (count[i] != 0) {   // never true on the border ring (sinks), so the +-1 / +-X reads are in range
-        m = CM_FLUID;
-        if (count[i + 1]) m |= CM_RIGHT;
-        if (count[i + X]) m |= CM_UP;
-        if (count[i - 1]) m |= CM_LEFT;
-        if (count[i - X]) m |= CM_DOWN;
-        const int diag = 4 - solid[i - 1] - solid[i + 1] - solid[i - X] - solid[i + X];
+  static_assert((64 * BS_W) % (256 * 4) == 0, "whole rounds of four cells per thread");
+  for (int c0 = tid; c0 < 64 * BS_W; c0 += 256 * 4) {
+    // four cells per thread; a wave whose cells hold no fluid is done after the count bytes, any other issues every load of the round before the first use
+    // (the neighbours of a cell that cannot be fluid - the border ring, beyond the grid - are read at the cell itself: in range, unused)
+    size_t ii[4]; int ll[4], jj[4]; uint8_t cc[4]; size_t dx[4], dy[4];
+    bool any = false;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + 256 * u;
+      ll[u] = c / BS_W; jj[u] = c % BS_W;
+      const int x = t0 - ll[u] + jj[u], y = band * 64 + ll[u];
+      const bool in = x >= 0 && x < X && y < Y;
+      const bool inner = x > 0 && x < X - 1 && y > 0 && y < Y - 1;
+      ii[u] = in ? (size_t)y * X + x : (size_t)0;
+      dx[u] = inner ? (size_t)1 : (size_t)0; dy[u] = inner ? (size_t)X : (size_t)0;
+      cc[u] = in ? count[ii[u]] : (uint8_t)0;      // never non-zero on the border ring (sinks)
+      any = any || cc[u] != 0;
+    }
+    uint8_t mm[4] = {0, 0, 0, 0};
+    float dv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (__any(any)) {
+      uint8_t cr[4], cu[4], cl[4], cd[4], sr[4], su[4], sl[4], sdn[4];
+      float u0[4], u1[4], v0[4], v1[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const size_t i = ii[k];
+        cr[k] = count[i + dx[k]]; cu[k] = count[i + dy[k]]; cl[k] = count[i - dx[k]]; cd[k] = count[i - dy[k]];
+        sr[k] = solid[i + dx[k]]; su[k] = solid[i + dy[k]]; sl[k] = solid[i - dx[k]]; sdn[k] = solid[i - dy[k]];
+        u0[k] = u[i]; u1[k] = u[i - dx[k]]; v0[k] = v[i]; v1[k] = v[i - dy[k]];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (cc[k] == 0) continue;
+        uint8_t m = CM_FLUID;
+        if (cr[k]) m |= CM_RIGHT;
+        if (cu[k]) m |= CM_UP;
+        if (cl[k]) m |= CM_LEFT;
+        if (cd[k]) m |= CM_DOWN;
+        const int diag = 4 - sl[k] - sr[k] - sdn[k] - su[k];
         m |= (uint8_t)(diag << CM_DIAG_SHIFT);
-        div_f = (u[i] - u[i - 1] + v[i] - v[i - X]) / EU_H;               // float expression, main.c:720
+        mm[k] = m;
+        dv[k] = (u0[k] - u1[k] + v0[k] - v1[k]) / EU_H;               // float expression, main.c:720
       }
     }
-    sm[l][j] = m;
-    sd[l][j] = div_f;
-    if (m & CM_FLUID) s_fl[j / 16] = 1;                 // (plain stores of the same value)
-    if (m != CM_INTERIOR) s_part[j / 16] = 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sm[ll[k]][jj[k]] = mm[k];
+      sd[ll[k]][jj[k]] = dv[k];
+      if (mm[k] & CM_FLUID) s_fl[jj[k] / 16] = 1;                 // (plain stores of the same value)
+      if (mm[k] != CM_INTERIOR) s_part[jj[k] / 16] = 1;
+    }
   }
   __syncthreads();
   const float k_inv_scale_f = (EU_H * EU_H) * EU_RHO / dt;                      // float expression, main.c:713
@@ -604,12 +633,13 @@ __global__ __launch_bounds__(256) void k_velocity_update(const float* __restrict
 
 // Round 6: the end of project() in ONE pass over parallelograms (k_build_system_para's geometry) - the p += alpha s that are still due (k_finish_p's arithmetic, main.c:753),
 // the clamp (main.c:773-779), both velocity updates (main.c:782-805) and the maxima calculate_timestep wants next (main.c:808-841).  A workgroup finishes the pressure of its
-// 96 records in skewed order (coalesced reads of p, the mask and the pending search directions) into LDS - plus the record to its right and the row above its band, formed
+// VU_W = 48 records in skewed order (coalesced reads of p, the mask and the pending search directions) into LDS - plus the record to its right and the row above its band, formed
 // the same way from the same inputs - and walks the 64 row segments with consecutive threads on consecutive cells: what rounds 1-5 gathered from the skewed array (three
 // pressures per cell) comes out of LDS.  The pass READS p and WRITES none of it (no workgroup sees another's result): the finished, clamped pressure is formed in memory
 // only when somebody asks for it (eu_pressure_current: EULER_F_PRESSURE, euler_pcg_op), from the same ring - most substeps nobody does, and 8 bytes per fluid cell stay unwritten.
 struct VuRing { const double* s[8]; int n, steps, use; };      // use 0: p is final as it stands (the resident solver wrote it; a right-hand side of zeros)
-#define VU_W 96
+#define VU_W 48           // records per workgroup (T is a whole number of 96): 25 KB of LDS, six workgroups per CU
+#define VU_ILP 4          // elements per thread whose loads are in flight together (the pass is a chain mask -> p, ring -> LDS per element: latency, not bytes, at one)
 __global__ __launch_bounds__(256) void k_velocity_update_para(const float* __restrict__ uin, const float* __restrict__ vin, float* __restrict__ uout, float* __restrict__ vout,
                                                               const double* __restrict__ p, const uint8_t* __restrict__ mask, const uint8_t* __restrict__ count,
                                                               const uint8_t* __restrict__ solid, SkewGeom g, float dt, const PcgScalars* sc, VuRing ring, MarkerState* ms) {
@@ -630,51 +660,112 @@ __global__ __launch_bounds__(256) void k_velocity_update_para(const float* __res
   const double* sq[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { const int it = from + (j < cnt ? j : 0); al[j] = sc->alpha_hist[it & 7]; sq[j] = ring.s[it % ring.n]; }
-  auto finished = [&](size_t e) -> double {      // the clamped, finished pressure of element e; +0 off the fluid (main.c:739: p starts as zeros and only fluid cells are ever written)
-    if (!(mask[e] & CM_FLUID)) return 0.0;
-    double pv = p[e];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) if (j < cnt) pv = pv + sq[j][e] * al[j];      // (uniform)
-    return pv < 0.0 ? 0.0 : pv;
-  };
+  // the clamped, finished pressure of element e; +0 off the fluid (main.c:739: p starts as zeros and only fluid cells are ever written)
   const size_t ebase = ((size_t)band * g.TS + (size_t)t0) * 64;
-  for (int c = tid; c < 64 * VU_W; c += 256) {          // element c of the unit: pair-record c / 128, lane (c % 128) / 2, parity c % 2
-    const int l = (c & 127) >> 1, j = 2 * (c >> 7) + (c & 1);
-    sp[l][j] = finished(ebase + (size_t)c);
+  static_assert((64 * VU_W) % (256 * VU_ILP) == 0, "whole rounds of VU_ILP elements per thread");
+  for (int c0 = tid; c0 < 64 * VU_W; c0 += 256 * VU_ILP) {      // element c of the unit: pair-record c / 128, lane (c % 128) / 2, parity c % 2
+    uint8_t m[VU_ILP];
+    double pv[VU_ILP];
+    bool any = false;
+#pragma unroll
+    for (int u = 0; u < VU_ILP; ++u) { m[u] = mask[ebase + (size_t)(c0 + 256 * u)]; any = any || (m[u] & CM_FLUID); }
+    if (__any(any)) {      // (uniform: a wave whose elements hold no fluid loads nothing else - the air above a tank)
+#pragma unroll
+      for (int u = 0; u < VU_ILP; ++u) pv[u] = p[ebase + (size_t)(c0 + 256 * u)];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < cnt) {      // (uniform) the fmadds in their order (main.c:753), per element
+          double sv[VU_ILP];
+#pragma unroll
+          for (int u = 0; u < VU_ILP; ++u) sv[u] = sq[j][ebase + (size_t)(c0 + 256 * u)];
+#pragma unroll
+          for (int u = 0; u < VU_ILP; ++u) pv[u] = pv[u] + sv[u] * al[j];
+        }
+    } else {
+#pragma unroll
+      for (int u = 0; u < VU_ILP; ++u) pv[u] = 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < VU_ILP; ++u) {
+      const int c = c0 + 256 * u;
+      const double v = (m[u] & CM_FLUID) ? (pv[u] < 0.0 ? 0.0 : pv[u]) : 0.0;
+      sp[(c & 127) >> 1][2 * (c >> 7) + (c & 1)] = v;
+    }
   }
-  if (tid < 64) {                                        // the record to the right (t0 + 96 <= T: a padding record at worst, mask 0)
-    sp[tid][VU_W] = finished(ebase + (size_t)VU_W * 64 + 2 * (size_t)tid);
-  } else if (tid < 64 + VU_W) {                          // the row above the band: lane 0 of band + 1, records t0 - 64 + j (j = 1 .. 96)
-    const int j = tid - 64 + 1, x = t0 - 64 + j;
-    double pv = 0.0;
-    if (x >= 0 && x < X && band + 1 < g.nbands) pv = finished(((size_t)(band + 1) * g.TS + (size_t)(x & ~1)) * 64 + (size_t)(x & 1));
-    sp[64][j] = pv;
+  {      // the record to the right (t0 + W <= T: a padding record at worst, mask 0) and the row above the band: lane 0 of band + 1, records t0 - 64 + j (j = 1 .. W)
+    size_t e = 0;
+    bool want = false;
+    int hl = 0, hj = 0;
+    if (tid < 64) { e = ebase + (size_t)VU_W * 64 + 2 * (size_t)tid; want = true; hl = tid; hj = VU_W; }
+    else if (tid < 64 + VU_W) {
+      const int j = tid - 64 + 1, x = t0 - 64 + j;
+      hl = 64; hj = j;
+      if (x >= 0 && x < X && band + 1 < g.nbands) { e = ((size_t)(band + 1) * g.TS + (size_t)(x & ~1)) * 64 + (size_t)(x & 1); want = true; }
+    }
+    if (tid < 64 + VU_W) {
+      double pv = 0.0;
+      if (want && (mask[e] & CM_FLUID)) {
+        pv = p[e];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (j < cnt) pv = pv + sq[j][e] * al[j];
+        pv = pv < 0.0 ? 0.0 : pv;
+      }
+      sp[hl][hj] = pv;
+    }
   }
   __syncthreads();
   const float neg_inv = -(1.f / (EU_RHO * EU_H));   // accel(), main.c:705-707
   float mu = 0.f, mv = 0.f;
-  for (int c = tid; c < 64 * VU_W; c += 256) {
-    const int l = c / VU_W, j = c % VU_W;
-    const int x = t0 - l + j, y = band * 64 + l;
-    if (x < 0 || x >= X || y >= Y) continue;
-    const size_t i = (size_t)y * X + x;
-    const bool f0 = count[i] != 0;
-    const double p0 = sp[l][j];
-    if (x < X - 1) {
-      const bool f1 = count[i + 1] != 0;
-      float o = 0.f;
-      if (solid[i] | solid[i + 1]) o = 0.f;
-      else if (f0 | f1) o = uin[i] + (neg_inv * (float)(sp[l][j + 1] - p0)) * dt;
-      uout[i] = o;
-      const float sqv = o * o; if (sqv > mu) mu = sqv;
+  static_assert((64 * VU_W) % (256 * 4) == 0, "whole rounds of four cells per thread");
+  for (int c0 = tid; c0 < 64 * VU_W; c0 += 256 * 4) {
+    // four cells per thread, every load of the round issued before the first use (cells beyond the grid's edge read cell 0 and write nothing)
+    size_t ii[4]; bool in[4]; int ll[4], jj[4], xx[4], yy[4];
+    uint8_t c_0[4], c_r[4], c_u[4], s_0[4], s_r[4], s_u[4];
+    float ui[4], vi[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + 256 * u;
+      ll[u] = c / VU_W; jj[u] = c % VU_W;
+      xx[u] = t0 - ll[u] + jj[u]; yy[u] = band * 64 + ll[u];
+      in[u] = xx[u] >= 0 && xx[u] < X && yy[u] < Y;
+      ii[u] = in[u] ? (size_t)yy[u] * X + xx[u] : (size_t)0;
+      const bool hr = in[u] && xx[u] < X - 1, hu = in[u] && yy[u] < Y - 1;
+      c_0[u] = count[ii[u]]; s_0[u] = solid[ii[u]];
+      c_r[u] = count[ii[u] + (hr ? 1 : 0)]; s_r[u] = solid[ii[u] + (hr ? 1 : 0)];
+      c_u[u] = count[ii[u] + (hu ? (size_t)X : (size_t)0)]; s_u[u] = solid[ii[u] + (hu ? (size_t)X : (size_t)0)];
     }
-    if (y < Y - 1) {
-      const bool f1 = count[i + X] != 0;
-      float o = 0.f;
-      if (solid[i] | solid[i + X]) o = 0.f;
-      else if (f0 | f1) o = vin[i] + (neg_inv * (float)(sp[l + 1][j + 1] - p0)) * dt;
-      vout[i] = o;
-      const float sqv = o * o; if (sqv > mv) mv = sqv;
+    bool wet = false;      // some face of these cells has fluid on a side: only then is an old velocity read (main.c:786-789, 799-802: the air's faces are set to 0)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wet = wet || ((c_0[u] | c_r[u] | c_u[u]) != 0);
+    if (__any(wet)) {      // (uniform per wave)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { ui[u] = uin[ii[u]]; vi[u] = vin[ii[u]]; }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { ui[u] = 0.f; vi[u] = 0.f; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!in[u]) continue;
+      const int l = ll[u], j = jj[u];
+      const bool f0 = c_0[u] != 0;
+      const double p0 = sp[l][j];
+      if (xx[u] < X - 1) {
+        const bool f1 = c_r[u] != 0;
+        float o = 0.f;
+        if (s_0[u] | s_r[u]) o = 0.f;
+        else if (f0 | f1) o = ui[u] + (neg_inv * (float)(sp[l][j + 1] - p0)) * dt;
+        uout[ii[u]] = o;
+        const float sqv = o * o; if (sqv > mu) mu = sqv;
+      }
+      if (yy[u] < Y - 1) {
+        const bool f1 = c_u[u] != 0;
+        float o = 0.f;
+        if (s_0[u] | s_u[u]) o = 0.f;
+        else if (f0 | f1) o = vi[u] + (neg_inv * (float)(sp[l + 1][j + 1] - p0)) * dt;
+        vout[ii[u]] = o;
+        const float sqv = o * o; if (sqv > mv) mv = sqv;
+      }
     }
   }
   // maxsq (main.c:808-820) of what was just written: exact, order-free maxima; k_dt forms dt from them at the next timestep

@@ -440,20 +440,21 @@ __global__ __launch_bounds__(256) void k_advect_markers_b(const float2* __restri
 // the marker stage's column-major copies: u, v and the count grid as they stand in front of advect_markers (main.c:855), the solid grid when it changed.  A workgroup moves
 // a 64 x 64 tile through LDS: 256-byte rows in, 256-byte columns out.  9 bytes per cell read and written per substep - a quarter of a millisecond at 8192^2 against the
 // millisecond the advection saves.
+#define TM_ROWS 32      // a workgroup's tile: 64 columns x TM_ROWS rows - 21 KB of LDS, seven workgroups per CU (64 x 64: 42 KB, three: the pass was latency-bound)
 __global__ __launch_bounds__(256) void k_transpose_for_markers(const float* __restrict__ u, const float* __restrict__ v, const uint8_t* __restrict__ count, const uint8_t* __restrict__ solid,
                                                                float* __restrict__ uT, float* __restrict__ vT, uint8_t* __restrict__ countT, uint8_t* __restrict__ solidT,
                                                                int X, int Y, int with_solid) {
-  __shared__ float tu[64][65], tv[64][65];
-  __shared__ uint8_t tc[64][65], ts[64][65];
+  __shared__ float tu[TM_ROWS][65], tv[TM_ROWS][65];
+  __shared__ uint8_t tc[TM_ROWS][65], ts[TM_ROWS][65];
   __shared__ int s_any;
-  const int xb = blockIdx.x * 64, yb = blockIdx.y * 64, l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int xb = blockIdx.x * 64, yb = blockIdx.y * TM_ROWS, l = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (threadIdx.x == 0) s_any = 0;
   __syncthreads();
   // Round 6: a sample of u or v is only ever USED where its typed fluid property holds (eu_interp selects the others away: main.c:348-362) - a U sample next to a cell
   // with markers, a V sample below or above one.  A tile whose cells, the column to its right and the row above it hold no marker has no such sample: its u and v are
   // not moved (the copies keep what an earlier substep left; nothing reads it).  The half tank's air, most of a dam break's grid.
   bool any = false;
-  for (int k = w; k < 64; k += 4) {                       // row yb + k, columns xb + l
+  for (int k = w; k < TM_ROWS; k += 4) {                  // row yb + k, columns xb + l
     const int x = xb + l, y = yb + k;
     const bool in = x < X && y < Y;
     const uint8_t c = in ? count[(size_t)y * X + x] : (uint8_t)0;
@@ -461,33 +462,34 @@ __global__ __launch_bounds__(256) void k_transpose_for_markers(const float* __re
     any = any || c != 0;
     if (with_solid) ts[k][l] = in ? solid[(size_t)y * X + x] : (uint8_t)0;
   }
-  if (w == 0) { const int x = xb + 64, y = yb + l; any = any || (x < X && y < Y && count[(size_t)y * X + x] != 0); }      // the column to the right
-  if (w == 1) { const int x = xb + l, y = yb + 64; any = any || (x < X && y < Y && count[(size_t)y * X + x] != 0); }      // the row above
+  if (w == 0 && l < TM_ROWS) { const int x = xb + 64, y = yb + l; any = any || (x < X && y < Y && count[(size_t)y * X + x] != 0); }      // the column to the right
+  if (w == 1) { const int x = xb + l, y = yb + TM_ROWS; any = any || (x < X && y < Y && count[(size_t)y * X + x] != 0); }                // the row above
   if (__any(any) && l == 0) s_any = 1;
   __syncthreads();
   const bool move = s_any != 0;
   if (move)
-    for (int k = w; k < 64; k += 4) {
+    for (int k = w; k < TM_ROWS; k += 4) {
       const int x = xb + l, y = yb + k;
       const bool in = x < X && y < Y;
       const size_t i = (size_t)y * X + x;
       tu[k][l] = in ? u[i] : 0.f; tv[k][l] = in ? v[i] : 0.f;
     }
   __syncthreads();
-  for (int k = w; k < 64; k += 4) {                       // column xb + k, rows yb + l
-    const int x = xb + k, y = yb + l;
+  const int r = l % TM_ROWS, h = l / TM_ROWS;              // a wave writes 64 / TM_ROWS columns at a time, TM_ROWS consecutive rows of each
+  for (int k = w * (64 / TM_ROWS) + h; k < 64; k += 4 * (64 / TM_ROWS)) {      // column xb + k, rows yb + r
+    const int x = xb + k, y = yb + r;
     if (x < X && y < Y) {
       const size_t i = (size_t)x * Y + y;
-      if (move) { uT[i] = tu[l][k]; vT[i] = tv[l][k]; }
-      countT[i] = tc[l][k];
-      if (with_solid) solidT[i] = ts[l][k];
+      if (move) { uT[i] = tu[r][k]; vT[i] = tv[r][k]; }
+      countT[i] = tc[r][k];
+      if (with_solid) solidT[i] = ts[r][k];
     }
   }
 }
 static bool eu_markers_column_major(euler_sim* S) {      // (whole-grid handles; EULER_OPT_MARKERS_ROWMAJOR: the row-major kernels, for A-B timing)
   const bool off = S->opt[EULER_OPT_MARKERS_ROWMAJOR] != 0;
   if (off || S->slab_on || !S->uT) return false;
-  LAUNCH(S, KC_MARKER_ADVECT, k_transpose_for_markers, dim3((S->X + 63) / 64, (S->Y + 63) / 64), dim3(256), S->u, S->v, S->count, S->solid, S->uT, S->vT, S->countT, S->solidT,
+  LAUNCH(S, KC_MARKER_ADVECT, k_transpose_for_markers, dim3((S->X + 63) / 64, (S->Y + TM_ROWS - 1) / TM_ROWS), dim3(256), S->u, S->v, S->count, S->solid, S->uT, S->vT, S->countT, S->solidT,
          S->X, S->Y, S->solidT_dirty);
   S->solidT_dirty = 0;
   return true;

@@ -2,25 +2,26 @@
 //
 //     z = M_tile^-1 r + P_0 V(P_0^T r)
 //
-// M_tile = the tile-local IC(0) of k_pcg.hip.  Level 0 = a grid of NODES, node (I, J) at the centre of grid cell (16 J + 8, 16 I + 8) - one per tile width in x and
-// per quarter band in y; P_0 = bilinear interpolation from the four nodes around a cell (weights in sixteenths), restricted to the fluid, constant beyond the outermost
-// nodes.  Level l + 1 = every other node of level l in both directions (its node J sits ON node 2 J), bilinear again: weights 1, 1/2 - full weighting.  Because nodes
+// M_tile = the tile-local IC(0) of k_pcg.hip.  Level 0 = a grid of NODES, node (I, J) at the centre of grid cell (8 J + 4, 8 I + 4) (MG_G0 = 8, k_mg.h: two node columns per
+// tile width, eight node rows per band); P_0 = bilinear interpolation from the four nodes around a cell (weights in eighths), restricted to the fluid, constant beyond the
+// outermost nodes.  Level l + 1 = every other node of level l in both directions (its node J sits ON node 2 J), bilinear again: weights 1, 1/2 - full weighting.  Because nodes
 // sit AT cell centres / on finer nodes, a hat is 0 at the neighbouring nodes and the Galerkin operators A_0 = P_0^T A P_0, A_(l+1) = P^T A_l P are exact NINE-POINT
-// stencils (a[k][c]: the entry that couples node c = (I, J) to node (I + k / 3 - 1, J + k % 3 - 1); A_0's entries are multiples of 2^-16: integer sums, exact in any order).
-// V = one symmetric V-cycle: damped Jacobi (omega) from a zero guess, restricted residual, recursion, correction, Jacobi again; the top level (<= 64 nodes) is the
-// dense pseudo-inverse of k_coarse.hip (factor, inverse, null-space fix for water cut off from the air).
+// stencils (a[k][c]: the entry that couples node c = (I, J) to node (I + k / 3 - 1, J + k % 3 - 1); A_0's entries are multiples of 2^-12: integer sums, exact in any order).
+// V = one symmetric V-cycle: damped Jacobi (per-node omega, k_mg.h) from a zero guess, restricted residual, recursion, correction, Jacobi again; the top level (<= 64 nodes) is
+// the dense pseudo-inverse of k_coarse.hip (factor, inverse, null-space fix for water cut off from the air).
 //
-// Rounds 3-4 used piecewise constants over the same 16 x 16 blocks (aggregation: 5-point stencils with integer entries, the correction scaled by 1.7) and ONE launch per
-// level and direction (12 launches, 63 us per iteration at 8192^2).  The bilinear spaces halve the iteration count (tank at rest to 1e-6, 1024^2 / 2048^2: 104 / 108 -> 52 / 52;
-// 512^2 dam break at impact 109 -> 64; 1024^2 waterfall 124 -> 62: tools/r05/mg_proto.py), and the cycle now runs in THREE launches whatever the depth of the hierarchy:
+// History: rounds 3-4 used piecewise constants over 16 x 16 blocks (aggregation: 5-point stencils with integer entries, the correction scaled by 1.7) and ONE launch per
+// level and direction (12 launches, 63 us per iteration at 8192^2).  Bilinear spaces on nodes 16 cells apart halved the iteration count, nodes 8 cells apart nearly halved it
+// again (tank at rest to 1e-6: 104 -> 52 -> 30; tools/r05/mg_proto.py) for a level 0 of four times the nodes.  The cycle runs in FOUR to SIX launches whatever the depth:
 //
-//   k_mg_down<true>   gathers the level-0 right-hand side from the tiles' partial sums (k_precond_tile leaves 48 doubles per tile: per half-group of 8 lanes, 2 node rows
-//                     x 3 node columns) and takes it down one level; every workgroup owns a tile of the OUTPUT level and recomputes the halo it needs of the levels
-//                     below in LDS (Jacobi step, residual, restriction: a level transition is three LDS phases, no launch)
-//   k_mg_down<false>  the next (up to three) level transitions the same way; the workgroup that draws the last ticket then runs every level of <= 1024 nodes - down, the
-//                     dense top, up again - alone, out of LDS and registers (stencils preloaded, 4 barriers per level)
-//   k_mg_up           from that level's result back to level 0: every workgroup owns a 32 x 32 tile of level 0 and recomputes the halos of the coarser levels it
-//                     needs (they shrink by two per level); its last workgroup folds x_0 . rhs_0 into dot(z, r) and applies the scalar epilogue
+//   k_mg_down1<true>  (level 0 of more than MG_SMALL_LEVEL0 nodes) gathers the level-0 right-hand side from the tiles' partial sums (k_precond_tile leaves MG_PART = 72
+//                     doubles per tile: [group of 8 lanes][row slot][column slot], k_mg.h) and takes it down ONE level on workgroups of 256 threads
+//   k_mg_down<..>     the next (up to three) level transitions per launch; every workgroup owns a tile of the OUTPUT level and recomputes the halo it needs of the levels
+//                     below in LDS (Jacobi step, residual, restriction: a level transition is three LDS phases, no launch); the workgroup that draws the last ticket of the
+//                     launch that reaches the entry level then runs every level of <= 1024 nodes - down, the dense top, up again - alone, out of LDS and registers
+//   k_mg_up           from that level's result back to level 1 (level 0 on small grids): every workgroup owns a 32 x 32 tile and recomputes the halos of the coarser levels
+//   k_mg_up0          level 1 -> level 0 on small workgroups; its last workgroup folds x_0 . rhs_0 into dot(z, r) and applies the scalar epilogue
+// Every one of them leaves at once behind convergence (sc->done; round 6).
 //
 // The CPU restatement the tests check all of this against: the test oracle's mg_build / mg_vcycle (same formulas; sums in another order: agreement to rounding).
 // No reference counterpart (the reference has ONE preconditioner, main.c:580-627).
@@ -125,10 +126,10 @@ void eu_mg_release(euler_sim* S) {
 // ------------------------------------------------------------------------------------------ per solve: the operators
 // A_0 = P_0^T A P_0 from the tiles' masks.  With c' = a_diag - (fluid neighbours) (the air neighbours of a cell) and p_i = P_0^T e_i (a cell's four weights),
 //     A = sum_i c'_i e_i e_i^T + sum_edges (e_i - e_j)(e_i - e_j)^T      =>      A_0 = sum_i c'_i p_i p_i^T + sum_edges (p_i - p_j)(p_i - p_j)^T
-// and since the weights are linear between two nodes, p_i - p_j of a horizontal edge is (1/16)(e_J - e_(J+1)) in x times the row weights wy - the same for every
+// and since the weights are linear between two nodes, p_i - p_j of a horizontal edge is (1 / MG_G0)(e_J - e_(J+1)) in x times the row weights wy - the same for every
 // edge of that row between the nodes J and J + 1 (0 beyond the outermost nodes) - and likewise for vertical edges.  So a lane (one row, 16 consecutive columns: at
-// most two node intervals) only counts: per interval, its horizontal edges H, sum c' wx wx^T and sum over its vertical edges of wx wx^T (three integers each, in
-// 1/256), and adds row weights x those to the stencil entries - 64 integer adds per lane into a window in LDS, flushed by 64-bit atomics (units of 2^-16: exact).
+// most MG_NSEG = three node intervals) only counts: per interval, its horizontal edges H, sum c' wx wx^T and sum over its vertical edges of wx wx^T (three integers each, in
+// 1 / MG_G0^2), and adds row weights x those to the stencil entries - 64 integer adds per lane into a window in LDS, flushed by 64-bit atomics (units of 1 / MG_G0^4 = 2^-12: exact).
 #define MG_WIN_R (MG_RPB + 2)                 // node rows a band's 64 rows touch
 #define MG_WIN_C (80 / MG_G0 + 2)             // node columns a tile's 79 columns touch (8: 12, 16: 7)
 #define MG_WIN (MG_WIN_R * MG_WIN_C * 9)

@@ -1327,8 +1327,8 @@ struct TileArgs {
   double *zsend_lo, *zsend_hi;
   int edge_lo, edge_hi;
   int reverse;            // walk the tiles in descending order
-  double* cpart;          // two-level mode (k_coarse.hip): per tile, the sums of the (updated) r over its fluid cells by coarse column: [tile][3]; multilevel mode (k_mg.hip): [tile][48]
-  int cshift;             // log2 of the coarse cell width in grid cells
+  double* cpart;          // two-level mode (k_coarse.hip): per tile, the sums of the (updated) r over its fluid cells by coarse column: [tile][3]; multilevel mode (k_mg.hip): [tile][MG_PART = 72] = [group][row slot][column slot] (k_mg.h)
+  int cshift;             // two-level mode: log2 of the coarse cell width in grid cells (the multilevel mode's node spacing is the constant MG_G0: nothing reads this there)
   int cmode, cnx, cny;    // cmode 2: the multilevel mode's bilinear restriction onto cnx x cny nodes of level 0
   // RECOMP (k_precond_tile<16, true>): `as` is the search direction s' itself and the pass forms A s' from it.  On row slabs the rows across
   // the slab boundary are the compact ghost rows of s' that k_search_apply SLAB 2 keeps (indexed by the column); null = no neighbouring slab
@@ -2070,7 +2070,7 @@ static int launch_precond_tile(euler_sim* S, int rupd, int sweeps, int fin_dot, 
   const int fin_real = a.fin_dot;
   if (two_level) {
     const bool mg = eu_is_mg(S);
-    a.cpart = mg ? S->mg_part : S->cc_part; a.cshift = mg ? 4 : S->coarse_shift;
+    a.cpart = mg ? S->mg_part : S->cc_part; a.cshift = mg ? 0 : S->coarse_shift;
     a.cmode = mg ? 2 : 1; a.cnx = mg ? S->mg_nx[0] : 0; a.cny = mg ? S->mg_ny[0] : 0;
     if (a.fin_dot >= 0) a.fin_dot = FIN_STORE_ONLY;
   }
@@ -2284,7 +2284,7 @@ static int launch_search_apply_and_alpha(euler_sim* S, int it) {
   double* pp = LOC(S->p);
   const bool store = !tile_recompute(S);      // false: A s' is not stored (k_precond_tile<16, true> forms it again)
   const bool mg = eu_is_mg(S);
-  const CoarseRef cref = {mg ? S->mg_x : S->cc_y, mg ? 4 : S->coarse_shift, mg ? S->mg_nx[0] : S->coarse_nx, mg ? S->mg_ny[0] : S->coarse_ny, S->band_lo};
+  const CoarseRef cref = {mg ? S->mg_x : S->cc_y, mg ? 0 : S->coarse_shift, mg ? S->mg_nx[0] : S->coarse_nx, mg ? S->mg_ny[0] : S->coarse_ny, S->band_lo};
 #define SA_LAUNCH_CS(SLABF, PM, RUNV, CF, ST)                                                                                                \
   LAUNCH(S, KC_APPLY_A, (k_search_apply<SLABF, PM, RUNV, CF, ST>), dim3(sa_blocks(S, RUNV)), dim3(SA_THREADS), LOC(S->s), LOC(S->z), LOC(S->s2), \
          LOC(S->q), LOC(S->cellmask), gl, S->partial, S->sc, 0, S->red_counter, fin, nbr, pp, S->s2, S->s, (RUNV) == 8 ? S->chunk_list : (const unsigned int*)nullptr, cref, hist)

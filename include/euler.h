@@ -368,7 +368,7 @@ enum {
   EULER_OPT_RCCL_SMALL = 7,         /* the small all-gather inside the RCCL exchange: 0 by size (default), 1 always ncclAllGather, 2 always sends / receives (before euler_set_comm_rccl) */
   EULER_OPT_RCCL_NO_EXCHANGE = 8,   /* 1: the built-in communicator without the fused exchange (halo + allgather instead: the same traffic; before euler_set_comm_rccl) */
   EULER_OPT_MARKERS_ROWMAJOR = 9,   /* 1: the marker stages read the row-major grids (A-B timing; the same bits) */
-  EULER_OPT_SA_RUN = 10,            /* 8 (default), 16, 32: pair-records per wave of k_search_apply (experiments; plain tile-local / parity modes on one GPU only) */
+  EULER_OPT_SA_RUN = 10,            /* 8 (default), 16, 32: pair-records per wave of k_search_apply (experiments).  16 / 32: the parity and the plain tile-local mode on one GPU only - refused (EULER_ESTATE) while a communicator or a coarse-correction mode is installed, and a handle that gets one later runs runs of 8 whatever the value */
   EULER_OPT_NO_INTERIOR = 11,       /* 1: no constant-mask instantiation for interior chunks (experiments; the same bits) */
   EULER_OPT_BUILD_GATHER = 12,      /* 1: the assembly as one diagonal gather (rounds 1-2; the same bits) */
   EULER_OPT_RESIDENT_FORCE_TIMEOUT = 13, /* test hook: the next n resident launches give up at once as if a wait had run out (error word 1): the time-out path */

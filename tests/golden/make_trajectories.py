@@ -37,7 +37,26 @@ def record(name):
     return rec
 
 
+def stamp():
+    """MANIFEST.json <- the SHA-1 of oracle/euler_oracle.c the records stand for (tests/test_trajectories.py checks it on every CPU run): call this after the
+    big records have been replayed against the current source (EULER_REPLAY_BIG=1) or regenerated"""
+    root = os.path.dirname(os.path.dirname(HERE))
+    with open(os.path.join(root, "oracle", "euler_oracle.c"), "rb") as f:
+        sha = hashlib.sha1(f.read()).hexdigest()
+    path = os.path.join(HERE, "MANIFEST.json")
+    with open(path) as f:
+        man = json.load(f)
+    man["oracle_source"] = {"file": "oracle/euler_oracle.c", "sha1": sha, "big_records_replayed": sorted(n for n, s in T.SPECS.items() if s.get("big")),
+                            "how": "EULER_REPLAY_BIG=1 python -m pytest tests/test_trajectories.py -k big, then make_trajectories.py --stamp"}
+    with open(path, "w") as f:
+        json.dump(man, f, indent=1)
+        f.write("\n")
+    print("stamped", sha)
+
+
 def main():
+    if sys.argv[1:] == ["--stamp"]:
+        return stamp()
     names = sys.argv[1:] or sorted(T.SPECS)
     try:
         with open(T.PATH) as f:

@@ -673,28 +673,53 @@ def _true_residual(sim):
     return np.where(fl, b - ap, 0.0), fl
 
 
-@pytest.mark.parametrize("precond", [ea.PRECOND_IC0, ea.PRECOND_IC0_TILE])
+def mg_record(name):
+    """tests/golden/mg_records.npz (make_mg_records.py): the oracle's restatement of the multilevel mode run to tolerance at BASELINE-sized grids -> (scalars, sampled p)"""
+    import os
+    from golden_util import GOLDEN
+    with np.load(os.path.join(GOLDEN, "mg_records.npz")) as z:
+        return z[name + ".scalars"], z[name + ".p"]
+
+
+def mg_sample(p, n=64):
+    Y, X = p.shape
+    return p[np.ix_((np.arange(n) * (Y - 1)) // (n - 1), (np.arange(n) * (X - 1)) // (n - 1))]
+
+
+@pytest.mark.parametrize("precond", [ea.PRECOND_IC0, ea.PRECOND_IC0_TILE, ea.PRECOND_IC0_TILE_MG])
 def test_full_size_8192_half_tank_properties(precond):
-    """BASELINE configs[2] at its full size (8192^2 half tank, 134 M markers), one substep = 100 PCG iterations, both
-    preconditioner modes, through the size-independent properties: the count grid is the histogram of the marker array
-    (checked on a 2048-row stripe to stay inside the test box's memory), the residual vector the solver carries IS b - A p
-    recomputed on the host (before the p >= 0 clamp can act: a tank at rest has positive pressures), p is 0 off the fluid,
-    velocities vanish on solid faces.  In the tile-local mode this also shows that p += alpha s riding one pass behind
-    (k_search_apply<.., PUPD>, k_finish_p) loses no update."""
+    """BASELINE configs[2] at its full size (8192^2 half tank, 134 M markers), one substep, through the size-independent properties: the count grid is the histogram
+    of the marker array (checked on a 2048-row stripe to stay inside the test box's memory), the residual vector the solver carries IS b - A p recomputed on the host
+    (before the p >= 0 clamp can act: a tank at rest has positive pressures), p is 0 off the fluid, velocities vanish on solid faces.
+    The reference's IC(0) and the tile-local mode run the reference's 100 iterations (in the tile-local mode this also shows that p += alpha s riding one pass
+    behind - k_search_apply<.., PUPD>, the fmadds left to k_velocity_update_para / k_finish_p - loses no update).
+    The MULTILEVEL mode (round 6: the mode whose solves converge had no test above 1536 x 1280) runs with the cap lifted: it reaches the reference's tolerance, the
+    TRUE residual on the host is <= 1e-6, in <= 60 iterations - and iteration count, max |p| and the pressure on a 64 x 64 sample grid are those of the oracle's
+    restatement (mg_build / mg_vcycle) recorded in the build container (tests/golden/mg_records.npz)."""
     N = 8192
-    sim = ea.Simulation(N, N, dot_mode=ea.DOT_TREE, precond=precond).load_half_tank()
+    mg = precond == ea.PRECOND_IC0_TILE_MG
+    sim = ea.Simulation(N, N, dot_mode=ea.DOT_TREE, precond=precond, max_iterations=4000 if mg else 100).load_half_tank()
     dt = sim.timestep(0.1)
     sim.substep(dt)
     st = sim.stats()
-    assert st.last_pcg_iterations == 100
     res, fl = _true_residual(sim)
     r = sim.get(ea.F_PCG_R)
     scale = np.abs(sim.get(ea.F_PCG_B)).max()
     assert np.abs(np.where(fl, r, 0.0) - res).max() <= 1e-9 * scale
     assert abs(np.abs(r[fl]).max() - st.last_residual) <= 1e-12 * scale
+    if mg:
+        sc, ps = mg_record("half_tank_8192_mg")
+        assert dt == np.float32(sc[3]) and st.n_markers == int(sc[4])
+        assert st.last_residual <= 1e-6 and np.abs(res).max() <= 1e-6 + 1e-9 * scale
+        assert st.last_pcg_iterations <= 60 and abs(st.last_pcg_iterations - sc[0]) <= 0.03 * sc[0] + 2, (st.last_pcg_iterations, sc[0])
+    else:
+        assert st.last_pcg_iterations == 100
     del res, r
     p = sim.get(ea.F_PRESSURE)
     assert (p[~fl] == 0).all() and (p >= 0).all()
+    if mg:
+        assert abs(np.abs(p).max() - sc[2]) <= 1e-6 * sc[2]
+        assert np.abs(mg_sample(p) - ps).max() <= 1e-6 * sc[2]
     del p
     count, solid = sim.get(ea.F_COUNT), sim.get(ea.F_SOLID)
     assert np.array_equal(fl, count > 0)
@@ -733,11 +758,16 @@ def test_full_size_16384_dam_break_properties_both_modes():
     su = (solid[:, :-1] | solid[:, 1:]) != 0
     sv = (solid[:-1, :] | solid[1:, :]) != 0
     del solid
-    for precond in (ea.PRECOND_IC0_TILE, ea.PRECOND_IC0):
+    for precond in (ea.PRECOND_IC0_TILE, ea.PRECOND_IC0, ea.PRECOND_IC0_TILE_MG):
         sim.set_precond(precond)
+        if precond == ea.PRECOND_IC0_TILE_MG:      # round 6: the multilevel mode at configs[3]'s full size, the cap lifted - every substep's solve reaches the reference's tolerance
+            sim.set_solver(max_iterations=4000)
         sim.step()
         st = sim.stats()
-        assert st.last_pcg_iterations >= 10 * st.last_substeps, (precond, st.last_pcg_iterations, st.last_substeps)      # the solves are engaged (some converge, some run into the cap)
+        if precond == ea.PRECOND_IC0_TILE_MG:
+            assert st.last_residual <= 1e-6 and 0 < st.last_pcg_iterations <= 60 * st.last_substeps, (st.last_pcg_iterations, st.last_substeps, st.last_residual)
+        else:
+            assert st.last_pcg_iterations >= 10 * st.last_substeps, (precond, st.last_pcg_iterations, st.last_substeps)      # the solves are engaged (some converge, some run into the cap)
         p, b, m = sim.get(ea.F_PRESSURE), sim.get(ea.F_PCG_B), sim.get(ea.F_CELLMASK)
         fl = (m & 1) != 0
         assert (p[~fl] == 0).all() and (p >= 0).all() and np.isfinite(p).all()
@@ -749,7 +779,9 @@ def test_full_size_16384_dam_break_properties_both_modes():
         del zero, touched
         # (at this size the block of water is still falling when the solves start to run into the cap: nearly all of it is at p = 0 after
         # the clamp, and the rows the check can use are the ~2e5 along the walls and the floor)
-        assert ok.sum() > 1e4, (int(ok.sum()), int(fl.sum()))
+        # (the multilevel leg SOLVES the system: the block is in free fall, its true pressure is zero but for rounding - nearly every cell is clamped and hardly a row is left;
+        # the unconverged modes' pressures are the noise of 100 iterations, positive on millions of cells)
+        assert ok.sum() > 1e4 or precond == ea.PRECOND_IC0_TILE_MG, (int(ok.sum()), int(fl.sum()))
         ap = (m >> 5).astype(np.float64) * p
         ap[:, :-1] -= np.where((m[:, :-1] & 2) != 0, p[:, 1:], 0.0)
         ap[:-1, :] -= np.where((m[:-1, :] & 4) != 0, p[1:, :], 0.0)
@@ -760,7 +792,7 @@ def test_full_size_16384_dam_break_properties_both_modes():
         del p, b
         r = sim.get(ea.F_PCG_R)
         assert np.abs(r[fl]).max() == st.last_residual or abs(np.abs(r[fl]).max() - st.last_residual) <= 1e-12 * scale
-        assert np.abs((r - ap)[ok]).max() <= 1e-9 * scale, precond
+        assert not ok.any() or np.abs((r - ap)[ok]).max() <= 1e-9 * scale, precond
         del r, ap, ok
         count = sim.get(ea.F_COUNT)
         assert np.array_equal(fl, count > 0)
@@ -782,21 +814,35 @@ def test_full_size_16384_dam_break_properties_both_modes():
     sim.close()
 
 
-@pytest.mark.parametrize("precond", [ea.PRECOND_IC0, ea.PRECOND_IC0_TILE])
+@pytest.mark.parametrize("precond", [ea.PRECOND_IC0, ea.PRECOND_IC0_TILE, ea.PRECOND_IC0_TILE_MG])
 def test_full_size_4096_waterfall_properties_with_sources_active(precond):
     """BASELINE configs[4]'s grid and scenario (4096^2 waterfall: ~0.27 M source cells, a sink column), a few frames with the
     sources running, both modes: every substep appends one marker per eligible source cell (the marker count grows by
     their number), the count grid stays the histogram of the marker array, markers appended in the last substep lie
     inside source cells, the RNG state moved, nothing is NaN, and the reported residual is the true one."""
     N = 4096
-    sim = ea.Simulation(N, N, dot_mode=ea.DOT_TREE, precond=precond).load_text(scenarios_waterfall(), upscale=True)
+    mg = precond == ea.PRECOND_IC0_TILE_MG      # (round 6: the multilevel mode with the cap lifted - every solve to the reference's tolerance, at most 60 iterations per substep)
+    sim = ea.Simulation(N, N, dot_mode=ea.DOT_TREE, precond=precond, max_iterations=4000 if mg else 100).load_text(scenarios_waterfall(), upscale=True)
     source = sim.get(ea.F_SOURCE)
     n_src = int((source != 0).sum())
     assert n_src > 200000
     st0 = sim.stats()
     for _ in range(3):
         sim.step()
+        if mg:
+            stf = sim.stats()
+            assert stf.last_residual <= 1e-6 and stf.last_pcg_iterations <= 60 * stf.last_substeps, (stf.last_pcg_iterations, stf.last_substeps, stf.last_residual)
     st = sim.stats()
+    if mg:      # the last solve's TRUE residual on the rows the clamp (main.c:773-779) left alone
+        p, b, m = sim.get(ea.F_PRESSURE), sim.get(ea.F_PCG_B), sim.get(ea.F_CELLMASK)
+        res, fl = _true_residual(sim)
+        zero = fl & (p == 0)
+        touched = zero.copy()
+        touched[:, 1:] |= zero[:, :-1]; touched[:, :-1] |= zero[:, 1:]; touched[1:, :] |= zero[:-1, :]; touched[:-1, :] |= zero[1:, :]
+        ok = fl & ~touched
+        assert ok.sum() > 1000 and np.abs(res[ok]).max() <= 1e-6 + 1e-9 * np.abs(b).max()
+        assert (p[~fl] == 0).all() and (p >= 0).all()
+        del p, b, m, res, fl, zero, touched, ok
     assert st.rng_state != st0.rng_state and not st.source_exhausted
     assert st0.n_markers < st.n_markers <= st0.n_markers + st.total_substeps * n_src
     mk = sim.get(ea.F_MARKERS)
@@ -913,3 +959,28 @@ def test_four_cells_per_thread_stage_kernels_leave_the_same_bits():
         assert a.stats().total_pcg_iterations == b.stats().total_pcg_iterations > 100
         a.close(); b.close()
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precond", [ea.PRECOND_IC0, ea.PRECOND_IC0_TILE, ea.PRECOND_IC0_TILE_MG])
+def test_round_6_stage_forms_leave_the_same_bits_as_rounds_1_to_5(precond):
+    """Round 6 fused stages on whole-grid handles: the advection pass bins what it writes (k_advect_bin_a2, pass B moving the counts of recomputed markers), the
+    assembly is one pass over parallelograms (k_build_system_para), the end of project() is one pass that finishes and clamps the pressure in LDS and leaves the
+    maxima for the next timestep (k_velocity_update_para; the pressure is finished in memory only when asked for).  EULER_OPT_MARKERS_TWO_PASS / _BUILD_TWO_PASS /
+    _VELOCITY_TWO_PASS select rounds 1-5's kernels.  Two handles of one process, one with the three options, step side by side: the same bits in every field, the
+    pressure included, after every frame - in the parity mode (sequential dots), the tile-local mode (the resident solver on this size) and the multilevel mode."""
+    from euler_amd import scenarios
+    kw = dict(precond=precond, dot_mode=ea.DOT_SEQUENTIAL if precond == ea.PRECOND_IC0 else ea.DOT_TREE, max_iterations=4000 if precond == ea.PRECOND_IC0_TILE_MG else 100)
+    for name, size, scn, frames in (("waterfall", (320, 256), "waterfall", 30), ("dam_break", (256, 384), "dam_break", 40)):
+        a = ea.Simulation(size[0], size[1], **kw).load_text(getattr(scenarios, scn)(), upscale=True)
+        b = ea.Simulation(size[0], size[1], **kw).load_text(getattr(scenarios, scn)(), upscale=True)
+        for key in (ea.OPT_MARKERS_TWO_PASS, ea.OPT_BUILD_TWO_PASS, ea.OPT_VELOCITY_TWO_PASS):
+            b.set_option(key, 1)
+        for f in range(frames):
+            a.step(); b.step()
+            assert a.stats().last_substeps == b.stats().last_substeps and a.stats().last_pcg_iterations == b.stats().last_pcg_iterations, (name, f)
+            look = (ea.F_U, ea.F_V, ea.F_COUNT, ea.F_PREV_COUNT, ea.F_MARKERS) + ((ea.F_PRESSURE,) if f % 3 == 0 else ())      # (most frames nobody looks at the pressure: the lazy path stays lazy)
+            for fld in look:
+                assert_bits(a.get(fld), b.get(fld), "%s frame %d field %d" % (name, f, fld))
+        assert a.stats().total_pcg_iterations == b.stats().total_pcg_iterations > 100
+        a.close(); b.close()

@@ -380,6 +380,59 @@ def test_multilevel_preconditioner_matches_the_oracle_restatement(X, Y):
     assert np.abs(sim.get(ea.F_U) - o.u).max() < 1e-5 and np.abs(sim.get(ea.F_V) - o.v).max() < 1e-5
 
 
+def test_multilevel_mode_4096_half_tank_against_the_recorded_oracle():
+    """The oracle's restatement of the multilevel mode at 4096^2 (tests/golden/mg_records.npz, make_mg_records.py: 20 s of one core in the build container; the 8192^2
+    record is checked in test_gpu_parity.py::test_full_size_8192_half_tank_properties): the same dt and marker count, the iteration count within 3 %, max |p| and the
+    pressure on a 64 x 64 sample grid within 1e-6 max |p|."""
+    from test_gpu_parity import mg_record, mg_sample
+    sc, ps = mg_record("half_tank_4096_mg")
+    N = 4096
+    sim = ea.Simulation(N, N, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE_MG, max_iterations=4000).load_half_tank()
+    dt = sim.timestep(0.1)
+    assert dt == np.float32(sc[3])
+    sim.substep(dt)
+    st = sim.stats()
+    assert st.n_markers == int(sc[4]) and st.last_residual <= 1e-6
+    assert abs(st.last_pcg_iterations - sc[0]) <= 0.03 * sc[0] + 2, (st.last_pcg_iterations, sc[0])
+    p = sim.get(ea.F_PRESSURE)
+    assert abs(np.abs(p).max() - sc[2]) <= 1e-6 * sc[2] and np.abs(mg_sample(p) - ps).max() <= 1e-6 * sc[2]
+    sim.close()
+
+
+def test_multilevel_mode_2048_dam_break_against_the_recorded_oracle():
+    """configs[1] / [3]'s scenario at 2048^2 in the multilevel mode, free-running from frame 0 against the oracle's restatement recorded in the build container
+    (tests/golden/mg_records.npz): the water falls freely (no solves: the GPU's frames are the oracle's) except for a first contact in frames 15 and 16, then frames 23 to 32
+    run into the impact, every substep solved to the reference's tolerance - the twelve recorded frames.  Per recorded frame: the same substep count and marker count, the same number of fluid cells, the
+    iteration count within 3 % (+ 2), max |p| and the pressure on a 64 x 64 sample grid within a tolerance that starts at 1e-6 max |p| and is allowed to grow with the
+    frames (two tolerance-converged trajectories of a splash drift apart; the bound below is ten times what was measured)."""
+    from euler_amd import scenarios
+    from test_gpu_parity import mg_record, mg_sample
+    sc, ps = mg_record("dam_break_2048_mg")
+    N = 2048
+    sim = ea.Simulation(N, N, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE_MG, max_iterations=4000).load_text(scenarios.dam_break(), upscale=True)
+    k, dev = 0, []
+    for frame in range(1, int(sc[-1][0]) + 1):
+        sim.step()
+        if frame != int(sc[k][0]):      # (free fall: the oracle's right-hand sides were all zero, main.c:742)
+            continue
+        st = sim.stats()
+        fr, nsub, its, res, pmax, nmark, nfluid, umax, vmax = sc[k]
+        p = sim.get(ea.F_PRESSURE)
+        d = np.abs(mg_sample(p) - ps[k]).max() / pmax
+        dev.append((frame, st.last_substeps, st.last_pcg_iterations, int(its), float(d)))
+        assert st.last_substeps == int(nsub) and st.n_markers == int(nmark), dev
+        assert st.last_residual <= 1e-6 and abs(st.last_pcg_iterations - its) <= 0.03 * its + 2, dev
+        assert int((sim.get(ea.F_COUNT) > 0).sum()) == int(nfluid), dev
+        assert abs(np.abs(p).max() - pmax) <= MG_DAM_TOL[min(k, len(MG_DAM_TOL) - 1)] * pmax and d <= MG_DAM_TOL[min(k, len(MG_DAM_TOL) - 1)], dev
+        k += 1
+    print(dev)
+    assert k == len(sc)
+    sim.close()
+
+
+MG_DAM_TOL = [1e-6, 1e-6, 1e-5, 1e-5, 1e-4, 1e-4, 1e-3, 1e-3, 1e-3, 1e-3, 1e-3, 1e-3]
+
+
 def test_multilevel_mode_with_spray_above_the_pool_matches_the_oracle():
     """The per-node damping of the cycle's Jacobi steps (k_mg_wd; oracle: mg_damping; tests/test_oracle_tile.py has the story): a pool with 200 single-cell drops above it
     solves in the iterations of a pool without them, on the GPU as in the oracle, and five capped iterations agree to rounding."""
@@ -544,7 +597,12 @@ def test_set_precond_validates_before_it_changes_anything_and_restores_the_dot_m
     sim.step(); o.step()                                   # ... and the tiles are still 8 records wide
     compare_all(o, sim, "tile 8 after a refused call")
     sim.set_precond(ea.PRECOND_IC0_TILE_MG, 16)
+    with pytest.raises(ea.EulerError):                     # EULER_OPT_SA_RUN 16 / 32: the parity and the plain tile-local mode only (include/euler.h) ...
+        sim.set_option(ea.OPT_SA_RUN, 16)
+    assert sim.get_option(ea.OPT_SA_RUN) == 8
     sim.set_precond(ea.PRECOND_IC0, 0)                     # back in the parity mode: sequential dots again
+    sim.set_option(ea.OPT_SA_RUN, 16)                      # ... where it is taken
+    sim.set_option(ea.OPT_SA_RUN, 8)
     o.c.tile_records = 0
     for f in range(2):
         sim.step(); o.step()

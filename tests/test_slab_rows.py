@@ -1,4 +1,4 @@
-"""Row slabs for EVERY stage (euler_config.slab_nranks, csrc/k_slab.hip): 2-4 gloo ranks sharing the test box's
+"""Row slabs for EVERY stage (euler_config.slab_nranks, csrc/k_slab.hip): 2-4 (one case: 8) gloo ranks sharing the test box's
 one MI355X, each holding one slab only, against a single-GPU run of the whole grid in the same process.
 
 Everything that involves no floating-point reduction is BIT-EXACT: both count grids, the marker positions (each local marker
@@ -294,6 +294,8 @@ def test_a_partition_with_a_gap_is_refused():
     (3, 512, 1024, "half_tank", 3, ("split=1", "bands=0-7,7-8,8-16")),
     (3, 512, 1024, "half_tank", 3, ("split=2", "bands=0-7,7-8,8-16")),      # (... still so at level 2; the operators' halo no longer: they are all-reduced, the iterations split)
     (3, 1024, 2048, "half_tank", 3, ("split=3", "bands=0-15,15-16,16-32", "expect_active=0")),
+    # EIGHT ranks (the node's count; round 6): 1024 x 8192, the tank's water balanced over seven slabs and the air above it on the eighth, the split cycle forced
+    (8, 1024, 8192, "half_tank", 3, ("split=1", "bands=0-10,10-20,20-29,29-38,38-47,47-56,56-66,66-128")),
 ])
 def test_multilevel_mode_on_row_slabs(nproc, X, Y, workload, frames, extra):
     """EULER_PRECOND_IC0_TILE_MG on row slabs: every rank assembles its rows of the level-0 operator (an aggregate of 16 rows belongs to
