@@ -197,7 +197,7 @@ struct euler_sim {
   double *mg_rhs, *mg_x;             // right-hand side and result of the V-cycle per level (level 0's result is what k_search_apply adds to z through P_0)
   double* mg_wd;                     // omega / diagonal per node (0: no fluid under the node), per solve
   uint8_t* mg_inner0; double mg_ic[9];   // level 0: nodes whose stencil is deep water's (mg_ic, a constant of the node spacing), per solve
-  double* mg_part;                   // [chunks][MG_PART = 72]: per tile, [group of 8 lanes (9: the first and the last are half groups)][row slot (2)][column slot (4)] - the weighted sums of r (k_precond_tile writes, mg_gather0 reads; k_mg.h)
+  double* mg_part;                   // MG_PART = 72 doubles per tile, stored [band][group of 8 lanes (9: the first and the last are half groups)][tile][row slot (2)][column slot (4)] - the weighted sums of r (k_precond_tile writes, mg_gather0 reads; k_mg.h)
   double* mg_dot;                    // per-workgroup partials of x_0 . rhs_0 (+ the ticket counters behind them)
   double* mg_null0;                  // [4][mg_cells]: the indicators of cut-off regions on every level (k_mg_null_prolong)
   double* mg_m0;                     // [4][nodes of level 0] + [4]: P_0^T of those indicators on the cells, and m_0 . n_0 (the gauge of k_mg_up)

@@ -510,8 +510,9 @@ __global__ __launch_bounds__(256) void k_build_system_para(const float* __restri
       const int x = t0 - ll[u] + jj[u], y = band * 64 + ll[u];
       const bool in = x >= 0 && x < X && y < Y;
       const bool inner = x > 0 && x < X - 1 && y > 0 && y < Y - 1;
-      ii[u] = in ? (size_t)y * X + x : (size_t)0;
-      dx[u] = inner ? (size_t)1 : (size_t)0; dy[u] = inner ? (size_t)X : (size_t)0;
+      // (a cell beyond the grid's edge reads the nearest cell of its own row instead - never cell 0: a row-slab handle's arrays hold its window of rows only)
+      ii[u] = (size_t)(y < Y ? y : Y - 1) * X + (size_t)(x < 0 ? 0 : x >= X ? X - 1 : x);
+      dx[u] = inner && in ? (size_t)1 : (size_t)0; dy[u] = inner && in ? (size_t)X : (size_t)0;
       cc[u] = in ? count[ii[u]] : (uint8_t)0;      // never non-zero on the border ring (sinks)
       any = any || cc[u] != 0;
     }

@@ -25,7 +25,7 @@
 #define MG_NGRP 9
 #define MG_NSEG (16 / MG_G0 + 1)               // node intervals a lane's 16 columns can touch
 #define MG_NSLOT 4
-#define MG_PART (MG_NGRP * 2 * MG_NSLOT)       // doubles k_precond_tile leaves per tile: [group][row slot][column slot]
+#define MG_PART (MG_NGRP * 2 * MG_NSLOT)       // doubles k_precond_tile leaves per tile: group x row slot x column slot, stored [band][group][tile][row slot][column slot] (mg_gather0)
 #define MG_NI ((19 + MG_G0 - 1) / MG_G0 + 1)  // node intervals the 20 records of a k_search_apply run and its window can touch
 static_assert(MG_G0 == 8, "MG_G0: the tiles' partial sums (k_precond_tile, mg_gather0) are laid out for nodes 8 cells apart");
 #define MG_NULL_MAX 4        // indicators of fluid regions cut off from the air that are kept (k_coarse.hip CC_NULL_MAX)

@@ -41,7 +41,7 @@ struct MgHier {
   double* rhs;
   double* x;
   const double* wd;                // omega / diagonal per node (0 where the node carries no fluid): the Jacobi steps multiply
-  const uint8_t* inner0;           // level 0: 1 where a node's stencil is the one of deep water (`ic`): the two level-0 kernels then load a byte instead of nine doubles
+  const uint8_t* inner0;           // level 0: 1 where a node's stencil is the one of deep water (`ic`), 2 where it is all zeros (no fluid under the node): the two level-0 kernels then load a byte instead of nine doubles
   double ic[9], icwd;
 };
 static MgHier mg_hier(const euler_sim* S) {
@@ -282,7 +282,7 @@ __device__ __forceinline__ MgRect mg_owned_of(const MgRect& c, int cny, int cnx,
 }
 __device__ __forceinline__ bool mg_in(const MgRect& r, int i, int j) { return i >= r.i0 && i < r.i1 && j >= r.j0 && j < r.j1; }
 
-// Level 0's right-hand side from the tiles' sums (k_precond_tile: [band][tile][group][row slot][column slot], k_mg.h).  Node row I collects row slot 0 of the groups with
+// Level 0's right-hand side from the tiles' sums (k_precond_tile: [band][group][tile][row slot][column slot], k_mg.h).  Node row I collects row slot 0 of the groups with
 // I0 = I and row slot 1 of those with I0 = I - 1; I0 = 8 b + G - 1, so one group per node row - two HALF groups (G = 8 of band b - 1, G = 0 of band b) where the row lies
 // across a band boundary; node column J lies in the slots of exactly two tiles of a group, k = (J + G - 1) >> 1 (slot 2 or 3) and k + 1 (slot 0 or 1).  Four loads per node
 // (eight across a band boundary), every one issued before the first add; a fixed order.
@@ -297,12 +297,12 @@ __device__ __forceinline__ double mg_gather0(const double* __restrict__ part, in
       const int b = h == 0 ? b1 : b1 - 1, G = h == 0 ? G1 : 8;
       const bool grp = (h == 0 || G1 == 0) && b >= band_lo && b < band_hi;
       const int ka = (J + G - 1) >> 1;
-      const double* row = part + ((size_t)(grp ? b - band_lo : 0) * ntb) * MG_PART + (size_t)(G * 2 + rs) * MG_NSLOT;
+      const double* row = part + (((size_t)(grp ? b - band_lo : 0) * MG_NGRP + (size_t)G) * ntb) * (2 * MG_NSLOT) + rs * MG_NSLOT;      // [band][group][tile][row slot][column slot]
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int k = ka + u, q = J - (2 * k - G - 1);      // u = 0: slot 2 or 3; u = 1: slot 0 or 1
         const bool ok = grp && k >= 0 && k < ntb;
-        v[rs * 4 + h * 2 + u] = ok ? row[(size_t)k * MG_PART + q] : 0.0;
+        v[rs * 4 + h * 2 + u] = ok ? row[(size_t)k * (2 * MG_NSLOT) + q] : 0.0;
       }
     }
   }
@@ -915,19 +915,22 @@ __global__ __launch_bounds__(MG_FINE_THREADS) void k_mg_down1(MgDownArgs A) {
     const double v = GATHER ? mg_gather0(A.part, i, j, A.ntb, A.band_lo, A.band_hi) : ((i >= A.clip_lo && i < A.clip_hi) ? H.rhs[c] : 0.0);      // (a staged, band-by-band gather out of LDS was built and measured: 167 us against 90)
     if (GATHER && mg_in(O, i, j)) H.rhs[c] = v;
     prhs[e] = v;
-    px1[e] = (H.inner0[c] ? H.icwd : H.wd[c]) * v;
+    const uint8_t in0 = H.inner0[c];      // 1: deep water (constants), 2: no fluid under the node (every entry 0, omega / d = 0: nothing else is loaded), 0: its own nine entries
+    px1[e] = (in0 == 1 ? H.icwd : in0 == 2 ? 0.0 : H.wd[c]) * v;
   }
   __syncthreads();
   for (int e = tid; e < mg_rn(T); e += MG_FINE_THREADS) {
     const int i = T.i0 + e / tw, j = T.j0 + e % tw;
     const size_t c = (size_t)i * nx + j;
     const int pe = (i - R.i0) * w + (j - R.j0);
-    if (H.inner0[c]) {      // deep water: the stencil is a constant (an interior node has all eight neighbours inside the grid)
+    const uint8_t in0 = H.inner0[c];
+    if (in0 == 1) {      // deep water: the stencil is a constant (an interior node has all eight neighbours inside the grid)
       double t = 0.0;
 #pragma unroll
       for (int k = 0; k < 9; ++k) t = t + H.ic[k] * px1[pe + (k / 3 - 1) * w + (k % 3 - 1)];
       prhs[pe] = prhs[pe] - t;
-    } else {
+    } else if (in0 == 2) prhs[pe] = 0.0;      // (d == 0 below, without the loads)
+    else {
       const double d = st[(size_t)4 * n + c];
       const double t = mg_apply_patch(st, n, c, i, j, ny, nx, px1, R);
       prhs[pe] = d != 0.0 ? prhs[pe] - t : 0.0;
@@ -977,7 +980,9 @@ __global__ __launch_bounds__(MG_FINE_THREADS) void k_mg_up0(MgUpArgs A) {
   for (int e = tid; e < mg_rn(X2); e += MG_FINE_THREADS) {
     const int i = X2.i0 + e / w2, j = X2.j0 + e % w2;
     const size_t c = (size_t)i * nx + j;
-    const double wdv = H.inner0[c] ? H.icwd : H.wd[c], rv = H.rhs[c];
+    const uint8_t in0 = H.inner0[c];
+    if (in0 == 2) { b2[e] = 0.0; continue; }      // (omega / d == 0 below, without the loads: the air above a tank, most of a dam break's grid)
+    const double wdv = in0 == 1 ? H.icwd : H.wd[c], rv = H.rhs[c];
     const int I = i >> 1, J = j >> 1;
     const bool oy = (i & 1) && I + 1 <= cny - 1, ox = (j & 1) && J + 1 <= cnx - 1;
     const int I1 = oy ? I + 1 : I, J1 = ox ? J + 1 : J;
@@ -991,14 +996,15 @@ __global__ __launch_bounds__(MG_FINE_THREADS) void k_mg_up0(MgUpArgs A) {
   for (int e = tid; e < mg_rn(X); e += MG_FINE_THREADS) {
     const int i = X.i0 + e / w, j = X.j0 + e % w;
     const size_t c = (size_t)i * nx + j;
-    const bool inner = H.inner0[c] != 0;
-    const double wdv = inner ? H.icwd : H.wd[c], rv = H.rhs[c];
+    const uint8_t in0 = H.inner0[c];
+    const bool inner = in0 == 1, empty = in0 == 2;
+    const double wdv = inner ? H.icwd : empty ? 0.0 : H.wd[c], rv = empty ? 0.0 : H.rhs[c];      // (an empty node's x_0 is 0 and adds 0 to x_0 . rhs_0)
     const int pe2 = (i - X2.i0) * w2 + (j - X2.j0);
     double t = 0.0;
     if (inner) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) t = t + H.ic[k] * b2[pe2 + (k / 3 - 1) * w2 + (k % 3 - 1)];
-    } else t = mg_apply_patch(st, n0n, c, i, j, ny, nx, b2, X2);
+    } else if (!empty) t = mg_apply_patch(st, n0n, c, i, j, ny, nx, b2, X2);
     const double xv = wdv != 0.0 ? b2[pe2] + wdv * (rv - t) : 0.0;
     if (n_null > 0) {
       mg_st_agent(H.x + c, xv);
@@ -1606,10 +1612,10 @@ __global__ __launch_bounds__(256) void k_mg_top_stencil(const double* __restrict
 __global__ __launch_bounds__(256) void k_mg_inner0(MgHier H, uint8_t* __restrict__ inner, size_t first, size_t count) {      // a node whose nine entries are deep water's (bit for bit: both sides are exact)
   const size_t n = (size_t)H.nx[0] * H.ny[0], c = first + (size_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= first + count) return;
-  bool same = true;
+  bool same = true, none = true;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) same = same && H.a[(size_t)k * n + c] == H.ic[k];
-  inner[c] = same ? 1 : 0;
+  for (int k = 0; k < 9; ++k) { const double v = H.a[(size_t)k * n + c]; same = same && v == H.ic[k]; none = none && v == 0.0; }
+  inner[c] = same ? 1 : none ? 2 : 0;      // 2 (round 6): no fluid under the node's hat - the level-0 kernels load neither its entries nor omega / d nor its right-hand side
 }
 __global__ __launch_bounds__(256) void k_mg_wd(const double* __restrict__ a, const unsigned int* offs, int nl, MgHier H, double* __restrict__ wd) {
   (void)a; (void)offs; (void)nl;

