@@ -231,6 +231,13 @@ def main():
             comm_info["exchange_us"]["per_iteration"] = round(l, 2)
         except Exception as e:
             comm_info["exchange_us"] = {"error": repr(e)}
+        if args.precond == "ic0_tile_mg":      # the multilevel cycle on row slabs: split by rows (a third exchange point) or replicated - and by which rule
+            try:
+                comm_info["mg_split_active"] = int(sim.get_option(ea.OPT_MG_SPLIT_ACTIVE))      # the gather level of the last solve, 0 = the cycle ran replicated
+                comm_info["mg_split_rule"] = ("by size (EULER_OPT_MG_SPLIT_LEVEL = 0): split wherever a level of <= 16384 nodes lies above level 0 and every rank's zones reach "
+                                              "into the next rank only; it trades the replicated level 0 and its all-gather for one more exchange point (exchange_us is the measured L)")
+            except Exception as e:
+                comm_info["mg_split_active"] = {"error": repr(e)}
     head = copy_gbps = device = quality = converged = exact = None
     tile_w_run = tile_w
     timings = {"pmc_passes": round(t_pmc, 1)}

@@ -643,12 +643,13 @@ struct VuRing { const double* s[8]; int n, steps, use; };      // use 0: p is fi
 #define VU_ILP 4          // elements per thread whose loads are in flight together (the pass is a chain mask -> p, ring -> LDS per element: latency, not bytes, at one)
 __global__ __launch_bounds__(256) void k_velocity_update_para(const float* __restrict__ uin, const float* __restrict__ vin, float* __restrict__ uout, float* __restrict__ vout,
                                                               const double* __restrict__ p, const uint8_t* __restrict__ mask, const uint8_t* __restrict__ count,
-                                                              const uint8_t* __restrict__ solid, SkewGeom g, float dt, const PcgScalars* sc, VuRing ring, MarkerState* ms) {
+                                                              const uint8_t* __restrict__ solid, SkewGeom g, float dt, const PcgScalars* sc, VuRing ring, MarkerState* ms,
+                                                              int band_lo, int do_max) {      // this rank's bands start at band_lo; do_max 0: a row slab's maxima are k_maxsq's (all-reduced)
   __shared__ double sp[65][VU_W + 1];
   __shared__ float s_mu[4], s_mv[4];
   const int units = g.T / VU_W;
   const size_t blk = eu_xcd_block();
-  const int band = (int)(blk / units), t0 = (int)(blk % units) * VU_W;
+  const int band = band_lo + (int)(blk / units), t0 = (int)(blk % units) * VU_W;
   const int X = g.X, Y = g.Y, tid = threadIdx.x;
   // the fmadds that are due: iterations from .. n_it - 1 (k_finish_p)
   int cnt = 0, from = 0;
@@ -695,17 +696,18 @@ __global__ __launch_bounds__(256) void k_velocity_update_para(const float* __res
   }
   {      // the record to the right (t0 + W <= T: a padding record at worst, mask 0) and the row above the band: lane 0 of band + 1, records t0 - 64 + j (j = 1 .. W)
     size_t e = 0;
-    bool want = false;
+    bool want = false, above = false;
     int hl = 0, hj = 0;
     if (tid < 64) { e = ebase + (size_t)VU_W * 64 + 2 * (size_t)tid; want = true; hl = tid; hj = VU_W; }
     else if (tid < 64 + VU_W) {
       const int j = tid - 64 + 1, x = t0 - 64 + j;
       hl = 64; hj = j;
-      if (x >= 0 && x < X && band + 1 < g.nbands) { e = ((size_t)(band + 1) * g.TS + (size_t)(x & ~1)) * 64 + (size_t)(x & 1); want = true; }
+      // (fluid or not is read off the count grid here: on a row slab that row belongs to the rank above - its pressures arrived as a ghost row, its mask bytes did not)
+      if (x >= 0 && x < X && band + 1 < g.nbands && count[(size_t)(band + 1) * 64 * X + x] != 0) { e = ((size_t)(band + 1) * g.TS + (size_t)(x & ~1)) * 64 + (size_t)(x & 1); want = true; above = true; }
     }
     if (tid < 64 + VU_W) {
       double pv = 0.0;
-      if (want && (mask[e] & CM_FLUID)) {
+      if (want && (above || (mask[e] & CM_FLUID))) {
         pv = p[e];
 #pragma unroll
         for (int j = 0; j < 8; ++j) if (j < cnt) pv = pv + sq[j][e] * al[j];
@@ -729,7 +731,7 @@ __global__ __launch_bounds__(256) void k_velocity_update_para(const float* __res
       ll[u] = c / VU_W; jj[u] = c % VU_W;
       xx[u] = t0 - ll[u] + jj[u]; yy[u] = band * 64 + ll[u];
       in[u] = xx[u] >= 0 && xx[u] < X && yy[u] < Y;
-      ii[u] = in[u] ? (size_t)yy[u] * X + xx[u] : (size_t)0;
+      ii[u] = (size_t)(yy[u] < Y ? yy[u] : Y - 1) * X + (size_t)(xx[u] < 0 ? 0 : xx[u] >= X ? X - 1 : xx[u]);      // (beyond the edge: a cell of the own row, read and not used)
       const bool hr = in[u] && xx[u] < X - 1, hu = in[u] && yy[u] < Y - 1;
       c_0[u] = count[ii[u]]; s_0[u] = solid[ii[u]];
       c_r[u] = count[ii[u] + (hr ? 1 : 0)]; s_r[u] = solid[ii[u] + (hr ? 1 : 0)];
@@ -774,7 +776,7 @@ __global__ __launch_bounds__(256) void k_velocity_update_para(const float* __res
   mv = eu_wave_maxf(mv);
   if ((tid & 63) == 0) { s_mu[tid >> 6] = mu; s_mv[tid >> 6] = mv; }
   __syncthreads();
-  if (tid == 0) {
+  if (tid == 0 && do_max) {
     for (int k = 1; k < 4; ++k) { if (s_mu[k] > mu) mu = s_mu[k]; if (s_mv[k] > mv) mv = s_mv[k]; }
     if (mu > 0.f) atomicMax(&ms->max_u2_bits, __float_as_uint(mu));      // (non-negative floats order like their bit patterns; a NaN never wins: s > m is false)
     if (mv > 0.f) atomicMax(&ms->max_v2_bits, __float_as_uint(mv));
@@ -852,17 +854,20 @@ int eu_pressure_current(euler_sim* S) {
 }
 // finish: 1 - the multi-kernel solve left its last p += alpha s undone (the ring of eu_launch_project is current); 0 - p is final (resident solver)
 int eu_launch_velocity_update(euler_sim* S, float dt, int finish) {
-  const bool one_pass = !S->has_comm && !S->slab_on && S->opt[EULER_OPT_VELOCITY_TWO_PASS] == 0;
+  // (row slabs: the finished pressure is in memory - the ghost row of the rank above came out of it - so the pass has nothing to finish, only to clamp; the round-1 layout,
+  // a communicator without row slabs, keeps the old kernel: its ranks hold the whole grid's p but only their own bands' masks)
+  const bool one_pass = (!S->has_comm || S->slab_on) && S->opt[EULER_OPT_VELOCITY_TWO_PASS] == 0 && (!S->slab_on || !finish);
   if (one_pass) {
     VuRing ring;
     for (int k = 0; k < 8; ++k) ring.s[k] = S->s_ring[k < S->s_ring_n ? k : 0];
     ring.n = S->s_ring_n > 0 ? S->s_ring_n : 1; ring.steps = ring.n; ring.use = finish && S->s_ring_n > 0;
     if (!ring.use) for (int k = 0; k < 8; ++k) ring.s[k] = S->p;      // (never read)
-    if (S->maxsq_state != 0) HIPCHK(hipMemsetAsync(&S->ms->max_u2_bits, 0, 2 * sizeof(unsigned int), S->stream));      // (maxima no timestep consumed)
-    LAUNCH(S, KC_VELOCITY_UPDATE, k_velocity_update_para, dim3((unsigned)((size_t)S->geom.nbands * (S->geom.T / VU_W))), dim3(256), S->utmp, S->vtmp, S->u, S->v, S->p, S->cellmask,
-           S->count, S->solid, S->geom, dt, S->sc, ring, S->ms);
+    const int do_max = S->slab_on ? 0 : 1;
+    if (do_max && S->maxsq_state != 0) HIPCHK(hipMemsetAsync(&S->ms->max_u2_bits, 0, 2 * sizeof(unsigned int), S->stream));      // (maxima no timestep consumed)
+    LAUNCH(S, KC_VELOCITY_UPDATE, k_velocity_update_para, dim3((unsigned)((size_t)(S->band_hi - S->band_lo) * (S->geom.T / VU_W))), dim3(256), S->utmp, S->vtmp, S->u, S->v, S->p, S->cellmask,
+           S->count, S->solid, S->geom, dt, S->sc, ring, S->ms, S->band_lo, do_max);
     S->p_pending = ring.use ? 1 : 2;
-    S->maxsq_state = 2;      // the maxima of u, v as they stand are in ms (eu_launch_timestep: k_dt alone)
+    if (do_max) S->maxsq_state = 2;      // the maxima of u, v as they stand are in ms (eu_launch_timestep: k_dt alone)
     return EULER_OK;
   }
   if (finish) { int rc = eu_launch_finish_p(S); if (rc) return rc; }
