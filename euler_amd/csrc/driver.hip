@@ -374,7 +374,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   DALLOC(S->solid, Cw); DALLOC(S->source, Cw); DALLOC(S->sink, Cw); DALLOC(S->count, Cw); DALLOC(S->prev_count, Cw);
   DALLOC(S->count32, Cw);
   if (!S->slab_on) { DALLOC(S->blockedT, Cw); DALLOC(S->uT, Cw); DALLOC(S->vT, Cw); DALLOC(S->countT, Cw); DALLOC(S->solidT, Cw); }      // (the marker stage's column-major copies)
-  S->blocked_dirty = 1; S->solidT_dirty = 1; S->prebin_valid = 0; if (S->maxsq_state == 2) S->maxsq_state = 1; S->p_pending = 0;
+  S->blocked_dirty = 1; S->solidT_dirty = 1; S->prebin_valid = 0; if (S->maxsq_state == 2) S->maxsq_state = 1; S->p_pending = 0; S->uv_clean = 0; S->uv_zb = 0;
   DALLOC(S->sys_m, Cw); DALLOC(S->sys_div, Cw);
   if (S->cfg.rainbow) for (float*& d : S->dye) DALLOC(d, Cw);      // (the window like every row-major field; the whole grid without slabs)
   // MAX_MARKER_COUNT = 4 X Y (main.c:92) is the GLOBAL cap; a slab holds the markers inside its rows: room for 6 per owned cell
@@ -546,7 +546,7 @@ static int upload_scenario(euler_sim* S, const uint8_t* solid, const uint8_t* so
   HIPCHK(hipMemcpyAsync(S->solid + wo, solid + wo, Cw, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(S->source + wo, source + wo, Cw, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(S->sink + wo, sink + wo, Cw, hipMemcpyHostToDevice, st));
-  S->blocked_dirty = 1; S->solidT_dirty = 1; S->prebin_valid = 0; if (S->maxsq_state == 2) S->maxsq_state = 1; S->p_pending = 0;
+  S->blocked_dirty = 1; S->solidT_dirty = 1; S->prebin_valid = 0; if (S->maxsq_state == 2) S->maxsq_state = 1; S->p_pending = 0; S->uv_clean = 0; S->uv_zb = 0;
   for (float* f : {S->u, S->v, S->utmp, S->vtmp}) HIPCHK(hipMemsetAsync(f + wo, 0, Cw * sizeof(float), st));
   for (double* d : {S->b, S->p, S->r, S->z, S->s, S->s2, S->q, S->precon}) HIPCHK(hipMemsetAsync(d + S->skew_off, 0, S->Sw * sizeof(double), st));
   for (float* d : S->dye) if (d) HIPCHK(hipMemsetAsync(d + wo, 0, Cw * sizeof(float), st));
@@ -732,10 +732,13 @@ extern "C" int euler_timestep(euler_sim* S, float frame_time_left, float* dt) {
 static void eu_state_edited(euler_sim* S) {
   S->prebin_valid = 0;                               // (k_advect_bin_a2's counts and delete ballot)
   if (S->maxsq_state == 2) S->maxsq_state = 1;       // (k_velocity_update_para's maxima of u, v: stale, cleared before the next accumulation)
+  S->uv_clean = 0; S->uv_zb = 0;                     // (what the lean zero_bounds / the velocity update's skipped zero stores rely on)
 }
 static int run_stage(euler_sim* S, int stage, float dt) {
   if (stage != EULER_STAGE_REFRESH_COUNTS) S->prebin_valid = 0;      // (what k_advect_bin_a2 binned belongs to the refresh that follows it DIRECTLY)
   if (stage == EULER_STAGE_EXTRAPOLATE && S->maxsq_state == 2) S->maxsq_state = 1;      // (writes u, v; inside a substep the timestep has consumed the maxima long before)
+  if (stage == EULER_STAGE_REFRESH_COUNTS) { S->uv_clean = S->uv_clean == 1 ? 2 : 0; S->uv_zb = 0; }      // (prev <- cur: once is what k_zero_bounds4<true> expects)
+  if (stage == EULER_STAGE_SOURCES) S->uv_zb = 0;                                                        // (the count grid changes)
   switch (stage) {
     case EULER_STAGE_ADVECT_MARKERS: return eu_launch_advect_markers(S, dt);
     case EULER_STAGE_REFRESH_COUNTS: return eu_launch_refresh_counts(S);

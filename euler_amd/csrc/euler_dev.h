@@ -140,6 +140,8 @@ struct euler_sim {
   unsigned int* count32;   // the binning counters of the window, COLUMN-major: [x][y - win_lo] (k_markers.hip), never shifted
   int p_pending;           // k_velocity_update_para finished and clamped the pressure in LDS only: 1 - memory still lacks the last fmadds and the clamp, 2 - the clamp (eu_pressure_current)
   int maxsq_state;         // ms->max_u2_bits / max_v2_bits: 0 - zero, 2 - the maxima of u, v as they stand (k_velocity_update_para), 1 - maxima of a state that has been edited since
+  int uv_clean;            // 1: the last velocity update left every sample without the fluid property / with the solid property zero; 2: ... and exactly one refresh_marker_counts has run since (k_zero_bounds4<true>); 0: unknown
+  int uv_zb;               // zero_bounds has run with the count grid as it stands (k_velocity_update_para need not store the zeros of the air and the walls again)
   int count32_dirty;       // the counters hold something (between a binning launch and the k_narrow_counts<true> that clears them; whole-grid handles)
   int prebin_valid;        // the advection stage in front binned its own output (k_advect_bin_a2): the next refresh keeps the counters and the delete ballot
   unsigned long long* delmask;   // [ceil(max_markers/64)] that pass's delete ballot (whole-grid handles)

@@ -165,14 +165,25 @@ __device__ __forceinline__ uint2 eu_props4(const uint8_t* __restrict__ g, size_t
   const unsigned int up = y + 1 < Y ? eu_nonzero_bytes(*reinterpret_cast<const unsigned int*>(g + i + X)) : 0u;
   return make_uint2(c | (c >> 1) | (right << 3), c | up);
 }
+// LEAN (round 6, whole-grid handles): the air is not zeroed again.  At the end of a substep every sample without the typed fluid property, and every one with the typed solid
+// property, IS zero (the velocity update sets the air's and the walls' faces to 0, main.c:784-790, 797-803; in the first substep u = v = 0).  Of the samples zero_bounds has to
+// zero now - no fluid property in the NEW count grid, or solid - only two kinds can hold anything else: those that had the fluid property in the previous grid and no wall
+// (a velocity that the water has left), and walls' samples that extrapolate has just written (fluid now, not before).  16384^2 dam break: 1.5 GB of zeros per substep not written.
+// (Valid while exactly one refresh_marker_counts lies between the last velocity update and this call and nobody edited the state: euler_sim.uv_clean.)
+template <bool LEAN>
 __global__ __launch_bounds__(256) void k_zero_bounds4(float* u, float* v, const uint8_t* __restrict__ cur,
-                                                      const uint8_t* __restrict__ solid, int X, int Y, int y0, int y1) {
+                                                      const uint8_t* __restrict__ solid, int X, int Y, int y0, int y1, const uint8_t* __restrict__ prev) {
   const int x = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
   const int y = y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= X || y >= y1) return;
   const size_t i = (size_t)y * X + x;
   const uint2 pc = eu_props4(cur, i, x, y, X, Y), ps = eu_props4(solid, i, x, y, X, Y);
   unsigned int zu = (~pc.x | ps.x) & 0xfu, zv = (~pc.y | ps.y) & 0xfu;      // samples that go to zero
+  if (LEAN) {
+    const uint2 pp = eu_props4(prev, i, x, y, X, Y);
+    zu &= (pp.x & ~ps.x) | (pc.x & ~pp.x);
+    zv &= (pp.y & ~ps.y) | (pc.y & ~pp.y);
+  }
   if (x + 4 >= X) zu &= 0x7u;                                               // (the grid's last column holds no U sample)
   if (y >= Y - 1) zv = 0u;                                                  // (nor its last row a V sample)
   if (zu == 0xfu) *reinterpret_cast<float4*>(u + i) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -203,12 +214,17 @@ int eu_launch_extrapolate(euler_sim* S) {
   if ((S->X & 3) == 0 && (size_t)S->X * (S->row_hi - S->row_lo) >= min_cells) {
     dim3 grid4((S->X / 4 + 63) / 64, (S->row_hi - S->row_lo + 3) / 4);
     LAUNCH(S, KC_EXTRAPOLATE, k_extrapolate4, grid4, dim3(256), S->u, S->v, S->prev_count, S->count, S->X, S->Y, S->row_lo, S->row_hi);
-    LAUNCH(S, KC_EXTRAPOLATE, k_zero_bounds4, grid4, dim3(256), S->u, S->v, S->count, S->solid, S->X, S->Y, S->row_lo, S->row_hi);
+    if (!S->slab_on && S->uv_clean == 2 && S->opt[EULER_OPT_VELOCITY_TWO_PASS] == 0)
+      LAUNCH(S, KC_EXTRAPOLATE, k_zero_bounds4<true>, grid4, dim3(256), S->u, S->v, S->count, S->solid, S->X, S->Y, S->row_lo, S->row_hi, S->prev_count);
+    else
+      LAUNCH(S, KC_EXTRAPOLATE, k_zero_bounds4<false>, grid4, dim3(256), S->u, S->v, S->count, S->solid, S->X, S->Y, S->row_lo, S->row_hi, (const uint8_t*)nullptr);
+    S->uv_zb = 1;      // (zero_bounds has run with the count grid as it stands)
     return EULER_OK;
   }
   dim3 grid((S->X + 63) / 64, (S->row_hi - S->row_lo + 3) / 4);   // this rank's rows (all of them without slabs)
   LAUNCH(S, KC_EXTRAPOLATE, k_extrapolate, grid, dim3(256), S->u, S->v, S->prev_count, S->count, S->X, S->Y, S->row_lo, S->row_hi);
   LAUNCH(S, KC_EXTRAPOLATE, k_zero_bounds, grid, dim3(256), S->u, S->v, S->count, S->solid, S->X, S->Y, S->row_lo, S->row_hi);
+  S->uv_zb = 1;
   return EULER_OK;
 }
 
@@ -644,7 +660,9 @@ struct VuRing { const double* s[8]; int n, steps, use; };      // use 0: p is fi
 __global__ __launch_bounds__(256) void k_velocity_update_para(const float* __restrict__ uin, const float* __restrict__ vin, float* __restrict__ uout, float* __restrict__ vout,
                                                               const double* __restrict__ p, const uint8_t* __restrict__ mask, const uint8_t* __restrict__ count,
                                                               const uint8_t* __restrict__ solid, SkewGeom g, float dt, const PcgScalars* sc, VuRing ring, MarkerState* ms,
-                                                              int band_lo, int do_max) {      // this rank's bands start at band_lo; do_max 0: a row slab's maxima are k_maxsq's (all-reduced)
+                                                              int band_lo, int do_max, int skip_zero) {      // this rank's bands start at band_lo; do_max 0: a row slab's maxima are k_maxsq's (all-reduced)
+  // skip_zero: the faces this pass sets to 0 - the air's, the walls' (main.c:784-790, 797-803) - are not stored: zero_bounds zeroed exactly those samples of u, v earlier in
+  // this substep, with the same count grid (euler_sim.uv_zb), and nothing has written them since
   __shared__ double sp[65][VU_W + 1];
   __shared__ float s_mu[4], s_mv[4];
   const int units = g.T / VU_W;
@@ -756,17 +774,19 @@ __global__ __launch_bounds__(256) void k_velocity_update_para(const float* __res
       if (xx[u] < X - 1) {
         const bool f1 = c_r[u] != 0;
         float o = 0.f;
+        bool live = false;
         if (s_0[u] | s_r[u]) o = 0.f;
-        else if (f0 | f1) o = ui[u] + (neg_inv * (float)(sp[l][j + 1] - p0)) * dt;
-        uout[ii[u]] = o;
+        else if (f0 | f1) { o = ui[u] + (neg_inv * (float)(sp[l][j + 1] - p0)) * dt; live = true; }
+        if (live || !skip_zero) uout[ii[u]] = o;
         const float sqv = o * o; if (sqv > mu) mu = sqv;
       }
       if (yy[u] < Y - 1) {
         const bool f1 = c_u[u] != 0;
         float o = 0.f;
+        bool live = false;
         if (s_0[u] | s_u[u]) o = 0.f;
-        else if (f0 | f1) o = vi[u] + (neg_inv * (float)(sp[l + 1][j + 1] - p0)) * dt;
-        vout[ii[u]] = o;
+        else if (f0 | f1) { o = vi[u] + (neg_inv * (float)(sp[l + 1][j + 1] - p0)) * dt; live = true; }
+        if (live || !skip_zero) vout[ii[u]] = o;
         const float sqv = o * o; if (sqv > mv) mv = sqv;
       }
     }
@@ -865,7 +885,8 @@ int eu_launch_velocity_update(euler_sim* S, float dt, int finish) {
     const int do_max = S->slab_on ? 0 : 1;
     if (do_max && S->maxsq_state != 0) HIPCHK(hipMemsetAsync(&S->ms->max_u2_bits, 0, 2 * sizeof(unsigned int), S->stream));      // (maxima no timestep consumed)
     LAUNCH(S, KC_VELOCITY_UPDATE, k_velocity_update_para, dim3((unsigned)((size_t)(S->band_hi - S->band_lo) * (S->geom.T / VU_W))), dim3(256), S->utmp, S->vtmp, S->u, S->v, S->p, S->cellmask,
-           S->count, S->solid, S->geom, dt, S->sc, ring, S->ms, S->band_lo, do_max);
+           S->count, S->solid, S->geom, dt, S->sc, ring, S->ms, S->band_lo, do_max, (!S->slab_on && S->uv_zb) ? 1 : 0);
+    S->uv_clean = 1;      // every sample without the fluid property, every wall's sample is zero now (k_zero_bounds4<true> of the next substep relies on it)
     S->p_pending = ring.use ? 1 : 2;
     if (do_max) S->maxsq_state = 2;      // the maxima of u, v as they stand are in ms (eu_launch_timestep: k_dt alone)
     return EULER_OK;
