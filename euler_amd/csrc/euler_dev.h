@@ -147,7 +147,7 @@ struct euler_sim {
   unsigned long long* delmask;   // [ceil(max_markers/64)] that pass's delete ballot (whole-grid handles)
   uint8_t* blockedT;       // sink | solid per cell, COLUMN-major like count32 (whole-grid handles; k_bin_markers); rebuilt when blocked_dirty
   int blocked_dirty;
-  float *uT, *vT; uint8_t *countT, *solidT;   // COLUMN-major copies of u, v, the count grid (made in front of every marker advection) and of the solid grid (when blocked_dirty): whole-grid handles only
+  float *uT, *vT; uint8_t *countT, *solidT;   // COLUMN-major copies of u, v (made in front of every marker advection), per cell the typed fluid properties of an interpolation's four corners (countT: k_transpose_for_markers) and of the solid grid (when blocked_dirty): whole-grid handles only
   int solidT_dirty;
   float* dye[6];          // --rainbow only (cfg.rainbow): g_r, g_g, g_b, g_rtmp, g_gtmp, g_btmp (main.c:76-81)
   // markers, ping-pong (main.c:95)
@@ -417,7 +417,9 @@ __device__ __forceinline__ float eu_clampf(float lo, float x, float hi) { return
 
 // interpolate(), main.c:337-364.  TYPE 0 = cell centres (P), 1 = U samples, 2 = V samples.
 // TR: q and g.count are stored COLUMN-major, [x][y] (the marker stage's copies: k_markers.hip) - the same values, the strides swapped
-template <int TYPE, bool TR = false>
+// PROPS: g.count does not hold counts but, per cell, the typed fluid properties of the four corners of an interpolation whose BASE cell it is (bits 0-3 U-typed, 4-7 V-typed,
+// corner order v00 v01 v10 v11; k_transpose_for_markers): one byte gather instead of six
+template <int TYPE, bool TR = false, bool PROPS = TR>
 __device__ __forceinline__ float eu_interp(const GridRef& g, const float* __restrict__ q, float ix, float iy) {
   ix = eu_clampf(0.f, ix, TYPE == 1 ? g.ux_lim : g.vx_lim);   // P extent = (X, Y): x like V, y like U
   iy = eu_clampf(0.f, iy, TYPE == 2 ? g.vy_lim : g.uy_lim);
@@ -430,6 +432,11 @@ __device__ __forceinline__ float eu_interp(const GridRef& g, const float* __rest
   // ghost rows included): one memory round trip instead of two - the kernels that interpolate are latency-bound
   const float r00 = q[i00], r01 = q[i00 + sx], r10 = q[i00 + sy], r11 = q[i00 + sy + sx];
   bool v00, v01, v10, v11;
+  if (PROPS && TYPE != 0) {
+    // ONE byte instead of six counts - the passes that interpolate are bound by their gather instructions and the lines each touches
+    const unsigned int nb = g.count[i00] >> (TYPE == 1 ? 0 : 4);
+    v00 = (nb & 1u) != 0; v01 = (nb & 2u) != 0; v10 = (nb & 4u) != 0; v11 = (nb & 8u) != 0;
+  } else
   if (TYPE == 0) {
     v00 = g.count[i00] != 0; v01 = g.count[i00 + sx] != 0;
     v10 = g.count[i00 + sy] != 0; v11 = g.count[i00 + sy + sx] != 0;

@@ -185,11 +185,11 @@ __device__ __forceinline__ AdvectOut advect_one(const GridRef& g, const float* _
   const int xdir = vx > 0 ? 1 : -1;
   int nxi = xi + (vx > 0 ? 1 : 0);
   float npx = nxi * EU_H;
-  float tx = time_to(px, npx, vx);
-  const int xoff = vx < 0 ? -1 : 0;
   const int ydir = vy > 0 ? 1 : -1;
   int nyi = yi + (vy > 0 ? 1 : 0);
   float npy = nyi * EU_H;
+  float tx = time_to(px, npx, vx);
+  const int xoff = vx < 0 ? -1 : 0;
   float ty = time_to(py, npy, vy);
   const int yoff = vy < 0 ? -1 : 0;
   float t_prev = 0.f, t_near = fminf(tx, ty);
@@ -441,11 +441,18 @@ __global__ __launch_bounds__(256) void k_advect_markers_b(const float2* __restri
 // a 64 x 64 tile through LDS: 256-byte rows in, 256-byte columns out.  9 bytes per cell read and written per substep - a quarter of a millisecond at 8192^2 against the
 // millisecond the advection saves.
 #define TM_ROWS 32      // a workgroup's tile: 64 columns x TM_ROWS rows - 21 KB of LDS, seven workgroups per CU (64 x 64: 42 KB, three: the pass was latency-bound)
+// countT does not hold counts (round 6): per cell, the typed fluid properties of the FOUR CORNERS of an interpolation whose base cell it is (eu_interp<.., TR>) -
+// bits 0-3 for a U-typed field (v00 = c(x,y) | c(x+1,y), v01 = c(x+1,y) | c(x+2,y), v10, v11 the same one row up), bits 4-7 for a V-typed one
+// (v00 = c(x,y) | c(x,y+1), v01 = c(x+1,y) | c(x+1,y+1), v10 = c(x,y+1) | c(x,y+2), v11 = c(x+1,y+1) | c(x+1,y+2)); counts beyond the grid read as 0 (the
+// interpolation's clamps never look there).  One byte gather per interpolation instead of six: the advection pass is bound by the number of its gather
+// instructions and the lines each touches (timing experiments, profiles/r06_marker_gather_experiment.md: 1078 -> 683 us without the twelve count loads of a thread).
 __global__ __launch_bounds__(256) void k_transpose_for_markers(const float* __restrict__ u, const float* __restrict__ v, const uint8_t* __restrict__ count, const uint8_t* __restrict__ solid,
                                                                float* __restrict__ uT, float* __restrict__ vT, uint8_t* __restrict__ countT, uint8_t* __restrict__ solidT,
                                                                int X, int Y, int with_solid) {
   __shared__ float tu[TM_ROWS][65], tv[TM_ROWS][65];
-  __shared__ uint8_t tc[TM_ROWS][65], ts[TM_ROWS][65];
+  __shared__ uint8_t ts[TM_ROWS][65];
+  __shared__ uint8_t tw[TM_ROWS + 2][68];      // per cell of the tile and of the two rows above it: bits 0-2 = "cell x / x + 1 / x + 2 of this row holds markers" (columns of the tile only)
+  __shared__ uint8_t e_hi[TM_ROWS + 2][2];     // ... and the same for the two columns to the right of the tile (xb + 64, xb + 65)
   __shared__ int s_any;
   const int xb = blockIdx.x * 64, yb = blockIdx.y * TM_ROWS, l = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (threadIdx.x == 0) s_any = 0;
@@ -454,17 +461,36 @@ __global__ __launch_bounds__(256) void k_transpose_for_markers(const float* __re
   // with markers, a V sample below or above one.  A tile whose cells, the column to its right and the row above it hold no marker has no such sample: its u and v are
   // not moved (the copies keep what an earlier substep left; nothing reads it).  The half tank's air, most of a dam break's grid.
   bool any = false;
-  for (int k = w; k < TM_ROWS; k += 4) {                  // row yb + k, columns xb + l
-    const int x = xb + l, y = yb + k;
-    const bool in = x < X && y < Y;
-    const uint8_t c = in ? count[(size_t)y * X + x] : (uint8_t)0;
-    tc[k][l] = c;
-    any = any || c != 0;
-    if (with_solid) ts[k][l] = in ? solid[(size_t)y * X + x] : (uint8_t)0;
+  {
+    // rows yb + k, k = w, w + 4, ...: the wave's lanes on columns xb + l; every load first, then a ballot per row (uniform over the wave: a lane's three bits are a shift away).
+    // The two columns to the right: ONE load by the first 2 (TM_ROWS + 2) threads (a masked load per row and wave cost 56 us at 8192^2: the pass is bound by its memory instructions)
+    constexpr int NIT = (TM_ROWS + 2 + 3) / 4;
+    uint8_t cv[NIT], sv[NIT];
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) {
+      const int k = w + 4 * q, y = yb + k, x = xb + l;
+      const bool row = k < TM_ROWS + 2 && y < Y;
+      cv[q] = (row && x < X) ? count[(size_t)y * X + x] : (uint8_t)0;
+      sv[q] = (with_solid && k < TM_ROWS && row && x < X) ? solid[(size_t)y * X + x] : (uint8_t)0;
+    }
+    if (threadIdx.x < 2 * (TM_ROWS + 2)) {
+      const int k = threadIdx.x >> 1, j = threadIdx.x & 1, x = xb + 64 + j, y = yb + k;
+      const bool c = x < X && y < Y && count[(size_t)y * X + x] != 0;
+      e_hi[k][j] = c ? 1 : 0;
+      if (c && j == 0 && k < TM_ROWS) s_any = 1;      // the column to the right of the tile
+    }
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) {
+      const int k = w + 4 * q;
+      const unsigned long long b = __ballot(cv[q] != 0);
+      if (k < TM_ROWS + 2) {      // (uniform)
+        tw[k][l] = (uint8_t)((b >> l) & 7ull);
+        any = any || (k <= TM_ROWS && b != 0ull);      // the tile and the row above it
+        if (with_solid && k < TM_ROWS) ts[k][l] = sv[q];
+      }
+    }
   }
-  if (w == 0 && l < TM_ROWS) { const int x = xb + 64, y = yb + l; any = any || (x < X && y < Y && count[(size_t)y * X + x] != 0); }      // the column to the right
-  if (w == 1) { const int x = xb + l, y = yb + TM_ROWS; any = any || (x < X && y < Y && count[(size_t)y * X + x] != 0); }                // the row above
-  if (__any(any) && l == 0) s_any = 1;
+  if (any && l == 0) s_any = 1;
   __syncthreads();
   const bool move = s_any != 0;
   if (move)
@@ -481,7 +507,15 @@ __global__ __launch_bounds__(256) void k_transpose_for_markers(const float* __re
     if (x < X && y < Y) {
       const size_t i = (size_t)x * Y + y;
       if (move) { uT[i] = tu[r][k]; vT[i] = tv[r][k]; }
-      countT[i] = tc[r][k];
+      // the cells (x .. x + 2) of the rows y, y + 1, y + 2 as three bits each (the last two columns of the tile look beyond it)
+      auto win = [&](int row) -> unsigned int {
+        unsigned int t = tw[row][k];
+        if (k >= 62) t |= k == 62 ? (unsigned int)e_hi[row][0] << 2 : ((unsigned int)e_hi[row][0] << 1) | ((unsigned int)e_hi[row][1] << 2);
+        return t;
+      };
+      const unsigned int A = win(r), B = win(r + 1), C = win(r + 2);
+      // U-typed corners: v00 = c(x,y) | c(x+1,y), v01 = c(x+1,y) | c(x+2,y), v10 / v11 one row up; V-typed: v00 = c(x,y) | c(x,y+1), v01 = c(x+1,y) | c(x+1,y+1), v10 / v11 one row up
+      countT[i] = (uint8_t)(((A | (A >> 1)) & 3u) | (((B | (B >> 1)) & 3u) << 2) | (((A | B) & 3u) << 4) | (((B | C) & 3u) << 6));
       if (with_solid) solidT[i] = ts[r][k];
     }
   }

@@ -14,6 +14,8 @@ if workload == "half_tank":
 else:
     from euler_amd import scenarios
     sim.load_text(getattr(scenarios, workload)(), upscale=True)
+if os.environ.get("EU_TWO_PASS"):      # (rounds 1-5's separate advection and binning passes)
+    sim.set_option(ea.OPT_MARKERS_TWO_PASS, 1)
 for _ in range(3):
     sim.step()
 for _ in range(8):
