@@ -2348,6 +2348,10 @@ int eu_launch_project(euler_sim* S, float dt) {
   // pcg_poll_interval - 1 launches behind convergence that, in the multilevel mode's cycle, did their whole work).
   // (several ranks: nonzero / done / iters are the same on every rank, so all ranks cut the same chunks and stop behind the same one)
   const int pred_iters = (S->sc_host->nonzero && S->sc_host->done && S->sc_host->iters < S->cfg.max_iterations) ? S->sc_host->iters : 0;
+  // With the peer-to-peer mailboxes a rank's kernels WAIT inside the kernel for their peers' (comm_p2p.hip).  Ranks that share one GPU (the tests) then need the queue to run
+  // dry now and then - a process whose kernels spin while the other's are queued behind them makes a 2 s test take 200 - so converging solves keep rounds 1-5's blocking
+  // poll there (solves that ran into the cap polled one chunk late before, and still do).
+  const bool drain_poll = S->p2p_on && !(S->sc_host->nonzero && !S->sc_host->done && S->sc_host->iters >= S->cfg.max_iterations);
   S->prof_iter = -1;
   int rc;
   LAUNCH(S, KC_MISC, k_pcg_reset, dim3(1), dim3(1), S->sc, S->cfg.tol, S->cfg.max_iterations);
@@ -2450,7 +2454,7 @@ int eu_launch_project(euler_sim* S, float dt) {
   S->s_none = stop ? 1 : 0;           // (no search direction exists: EULER_F_PCG_S reads as +0)
   while (it < max_it && !stop) {
     int chunk_end = it + poll;
-    if (pred_iters > 0 && it < pred_iters + poll && chunk_end > pred_iters - 2) {      // around the predicted end: short chunks (the first of them ends at pred - 2)
+    if (!drain_poll && pred_iters > 0 && it < pred_iters + poll && chunk_end > pred_iters - 2) {      // around the predicted end: short chunks (the first of them ends at pred - 2)
       const int lo = pred_iters - 2 < chunk_end ? pred_iters - 2 : chunk_end;
       chunk_end = lo > it + 2 ? lo : it + 2;
     }
@@ -2480,6 +2484,11 @@ int eu_launch_project(euler_sim* S, float dt) {
         if ((rc = launch_precondition(S, 0, FIN_BETA))) return rc;
       }
     }
+    if (it < max_it && drain_poll) {
+      HIPCHK(hipMemcpyAsync(S->sc_host, S->sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, S->stream));
+      HIPCHK(hipStreamSynchronize(S->stream));
+      stop = S->sc_host->done != 0;
+    } else
     if (it < max_it) {   // poll the device-side convergence flag (identical on every rank): one chunk late, see above
       const int slot = chunk & 1;
       if (chunk > 0) {                                      // the poll behind the previous chunk
