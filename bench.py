@@ -63,7 +63,7 @@ def parse_args():
     ap.add_argument("--dot-mode", default="tree", choices=["tree", "sequential"])
     ap.add_argument("--precond", default="ic0_tile", choices=["ic0", "jacobi", "ic0_tile", "ic0_tile2", "ic0_tile_mg"],
                     help="ic0_tile = roofline mode (default), ic0 = parity mode (the reference's preconditioner), ic0_tile2 = roofline mode + coarse "
-                         "correction (one GPU; fewer iterations to a given residual, DESIGN.md 5c)")
+                         "correction (one GPU; fewer iterations to a given residual, docs/solver_two_level.md)")
     ap.add_argument("--tile-records", type=int, default=0)
     ap.add_argument("--max-iterations", type=int, default=100, help="PCG iteration cap per solve (the reference's: 100, main.c:735); lift it together with --tol 1e-6 "
                                                                     "to time frames whose solves converge (e.g. --precond ic0_tile_mg)")

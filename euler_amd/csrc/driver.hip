@@ -1102,7 +1102,7 @@ extern "C" int euler_measure_copy_bandwidth(euler_sim* S, size_t bytes, int32_t 
 
 // The latency of ONE exchange point of a distributed PCG iteration over the installed communicator - `row_doubles` doubles to / from each neighbour and `nsmall` doubles
 // of every rank to every rank, euler_comm_ops.exchange (or halo + all-gather where the communicator has no fused operation) - measured with HIP events on the handle's stream
-// over `reps` back-to-back calls.  Collective.  The model of DESIGN 7a has this one unknown (L); tools/node_first_contact.sh measures it before anything else on a node.
+// over `reps` back-to-back calls.  Collective.  The model of DESIGN.md section 7 has this one unknown (L); tools/node_first_contact.sh measures it before anything else on a node.
 extern "C" int euler_measure_exchange(euler_sim* S, int32_t reps, int32_t row_doubles, int32_t nsmall, double* us_per_exchange) {
   if (!S || !us_per_exchange || reps < 1 || row_doubles < 0 || nsmall < 0) return EULER_EINVAL;
   if (!S->has_comm) { eu_set_error("euler_measure_exchange: install a communicator first"); return EULER_ESTATE; }

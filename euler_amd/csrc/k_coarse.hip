@@ -9,7 +9,7 @@
 // No reference counterpart (the reference has ONE preconditioner, main.c:580-627): this is an extension of the roofline mode, restated
 // in the oracle (eo_sim.coarse_m, coarse_correction) and compared with it to rounding.  Why: a block-local factor has no coupling
 // beyond its block, and the first hundred iterations of a large solve - all the reference's cap ever allows, main.c:735 - live on the
-// long-range part of A^-1 (the hydrostatic mode of a tank).  The coarse space has that part: DESIGN.md 5c.
+// long-range part of A^-1 (the hydrostatic mode of a tank).  The coarse space has that part: docs/solver_two_level.md.
 //
 // What runs where:
 //   per solve      k_coarse_assemble  P^T A P as integer sums of A's entries per pair of coarse cells (a 5-point stencil over the coarse

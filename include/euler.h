@@ -63,7 +63,7 @@ enum {
                                 factor has no coupling beyond a block; the coarse space restores the long-range part of the inverse, which is
                                 what the first hundred iterations of a large solve live on: 2-4x fewer iterations than the REFERENCE's IC(0)
                                 to the reference's tolerance (2048^2 tank: 402 vs 1726), the reference's residual-after-100 in ~44 iterations
-                                on the saturated 8192^2 tank.  Same traffic
+                                on the saturated 8192^2 tank (docs/solver_two_level.md).  Same traffic
                                 per iteration as the tile-local mode (the coarse part is 3 doubles per tile out, one double per coarse cell
                                 in) + one small launch.  NOT the reference's iterates; symmetric positive definite, so PCG converges to the same
                                 solution.  Restated in the oracle (eo_sim.coarse_m): GPU = oracle to rounding (tolerance, not bits: the
@@ -79,7 +79,7 @@ enum {
                                 and rounds 3-4's piecewise-constant aggregates of 16 cells needed 105-150.  Cost per iteration: the tile-local mode's two passes (+ 72
                                 doubles of partial sums per 1024-cell tile) + five launches over node grids 1/64 the size of the grid and less.  Restated in the oracle
                                 (eo_sim.coarse_mg): GPU = oracle to rounding.  EULER_DOT_TREE.  One GPU, or row slabs without mailboxes (euler_config.slab_*).  On slabs the cycle is SPLIT BY ROWS
-                                wherever a level of <= 16384 nodes lies above level 0 and the slabs are a few bands thick (EULER_OPT_MG_SPLIT_LEVEL): a rank takes
+                                wherever a level of <= 16384 nodes lies above level 0 and the slabs are a few bands thick (docs/solver_multilevel.md; EULER_OPT_MG_SPLIT_LEVEL): a rank takes
                                 its own tiles' share down to that level, windows of it are all-gathered inside the G1 exchange (0.16 MB per iteration at 16384^2 on 8 ranks), the
                                 neighbours' shares on a rank's halo rows travel with the edge rows of z, the coarse levels run replicated, the fine levels on the own node rows, and
                                 one more 40-byte exchange sums the correction's share of dot(z, r); per solve the operators are formed by their owners.  Otherwise (small grids,
@@ -155,10 +155,11 @@ enum {
   EULER_F_PREV_COUNT,     /* uint8  g_prev_marker_count main.c:97 */
   EULER_F_MARKERS,        /* float2[n_markers] g_markers main.c:95, in the reference's array order */
   EULER_F_PRECON,         /* double g_precon main.c:577 (persistent state) */
-  EULER_F_PRESSURE,       /* double p — a stack local of project(), main.c:739; exposed here */
+  EULER_F_PRESSURE,       /* double p — a stack local of project(), main.c:739; exposed here.  Whole-grid handles form the finished, clamped pressure in device memory only when
+                             it is asked for (the velocity update keeps it in LDS): the call costs one pass over the solver arrays the first time after a substep */
   EULER_F_PCG_B, EULER_F_PCG_R, EULER_F_PCG_Z, EULER_F_PCG_S, EULER_F_PCG_Q, /* double, main.c:716-745,578.  Test surface: after a solve S is the search
                                                               direction of the last iteration that ran (+0 off the fluid and when the right-hand side was
-                                                              all zero); Q holds A s only where a solve stores it (most do not any more).
+                                                              all zero); Q holds A s only where a solve stores it (docs/solver_tile_local.md: most do not any more).
                                                               After a solve that ran in the resident kernel (euler_resident_info) Z, S and Q do not exist in
                                                               memory: euler_get_field returns EULER_ESTATE for them until a multi-kernel solve has run */
   EULER_F_CELLMASK,       /* uint8: bit0 fluid, bit1..4 fluid at x+1,y+1,x-1,y-1, bits5-7 a_diag (g_a, main.c:552) */
@@ -372,7 +373,7 @@ enum {
   EULER_OPT_NO_INTERIOR = 11,       /* 1: no constant-mask instantiation for interior chunks (experiments; the same bits) */
   EULER_OPT_BUILD_GATHER = 12,      /* 1: the assembly as one diagonal gather (rounds 1-2; the same bits) */
   EULER_OPT_RESIDENT_FORCE_TIMEOUT = 13, /* test hook: the next n resident launches give up at once as if a wait had run out (error word 1): the time-out path */
-  EULER_OPT_MG_SPLIT_LEVEL = 14,    /* multilevel mode on row slabs: the level whose right-hand side the ranks all-gather (below it every rank works on its own rows): 0 (default) by size,
+  EULER_OPT_MG_SPLIT_LEVEL = 14,    /* multilevel mode on row slabs: the level whose right-hand side the ranks all-gather (below it every rank works on its own rows, docs/solver_multilevel.md): 0 (default) by size,
                                        n > 0 that level (tests: the split on small grids), -1 never (the cycle replicated from level 0 on).  The same value on every rank */
   EULER_OPT_MG_SPLIT_ACTIVE = 15,   /* read only: the gather level the last multilevel solve on row slabs ran with, 0 while the cycle runs replicated */
   EULER_OPT_MARKERS_TWO_PASS = 16,  /* 1: advect_markers and refresh_marker_counts as separate passes over the marker array (rounds 1-5; A-B timing; the same bits); 0 (default): the advection pass bins what it writes */

@@ -282,7 +282,7 @@ def test_a_partition_with_a_gap_is_refused():
     (3, 300, 440, "half_tank", 6, ("bands=0-2,2-3,3-7",)),      # an uneven partition, X and Y no multiples of 16; a tank at rest (long solves from the first frame on)
     (4, 256, 512, "waterfall", 20, ()),
     (2, 320, 256, "closed_box", 6, ()),       # water cut off from the air: the right-hand side is made compatible on the slabs as on one GPU (all-reduced sums)
-    # the cycle split by rows on grids this small: the ranks all-gather windows of level 1 / 2, everything below runs on the own rows
+    # the cycle split by rows (docs/solver_multilevel_row_slabs.md) on grids this small: the ranks all-gather windows of level 1 / 2, everything below runs on the own rows
     (2, 1024, 1024, "half_tank", 3, ("split=1",)),
     (2, 1024, 1024, "dam_break", 40, ("split=2",)),
     (3, 1000, 1100, "waterfall", 12, ("split=2", "bands=0-5,5-11,11-18")),
