@@ -177,6 +177,10 @@ extern "C" int euler_set_option(euler_sim* S, int32_t key, int64_t value) {
   if (!ok) { eu_set_error("euler_set_option: key %d does not take the value %lld", (int)key, (long long)value); return EULER_EINVAL; }
   if (when) { eu_set_error("euler_set_option: key %d must be set %s", (int)key, when); return EULER_ESTATE; }
   HIPCHK(hipStreamSynchronize(S->stream));
+  if (key == EULER_OPT_P_STEPS || key == EULER_OPT_SA_RUN) {      // the ring is about to be forgotten: the pressure the last velocity update left unfinished in memory is finished from it first
+    int rcp = eu_pressure_current(S);
+    if (rcp) return rcp;
+  }
   S->opt[key] = value;
   if (key == EULER_OPT_P_STEPS || key == EULER_OPT_SA_RUN) S->s_ring_n = 0;      // (the next solve sets its ring up afresh)
   if (key == EULER_OPT_MG_SPLIT_LEVEL) { eu_mg_split_release(S); S->opt[EULER_OPT_MG_SPLIT_ACTIVE] = 0; }      // (... plans its cycle afresh)

@@ -985,3 +985,26 @@ def test_round_6_stage_forms_leave_the_same_bits_as_rounds_1_to_5(precond):
                 assert_bits(a.get(fld), b.get(fld), "%s frame %d field %d" % (name, f, fld))
         assert a.stats().total_pcg_iterations == b.stats().total_pcg_iterations > 100
         a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_the_lazily_finished_pressure_survives_an_option_that_forgets_the_ring():
+    """k_velocity_update_para leaves the last p += alpha s and the clamp to whoever asks for EULER_F_PRESSURE (eu_pressure_current: from the search directions' ring of the
+    last solve).  EULER_OPT_P_STEPS / _SA_RUN make the next solve set its ring up afresh: the pressure is finished BEFORE the ring is forgotten - two handles, one reads
+    the pressure directly, one after such an option call: the same bits."""
+    from euler_amd import scenarios
+    sims = [ea.Simulation(256, 384, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0).load_text(scenarios.dam_break(), upscale=True) for _ in range(2)]
+    for f in range(34):
+        for s in sims:
+            s.step()
+    assert sims[0].stats().last_pcg_iterations > 50
+    p0 = sims[0].get(ea.F_PRESSURE)
+    sims[1].set_option(ea.OPT_P_STEPS, 4)
+    p1 = sims[1].get(ea.F_PRESSURE)
+    assert np.abs(p0).max() > 0
+    assert_bits(p1, p0, "pressure behind euler_set_option(EULER_OPT_P_STEPS)")
+    for s in sims:      # ... and both go on in step (p += alpha s four at a time leaves the same bits as eight)
+        s.step()
+    assert_bits(sims[1].get(ea.F_U), sims[0].get(ea.F_U), "u one frame later")
+    for s in sims:
+        s.close()
