@@ -503,6 +503,7 @@ def main():
         "comm_calls_rank0": comm_calls,
         "comm": comm_info,
         "kernels": head["kernels"],
+        "stages": head.get("stages"),      # round 6: kernel time per substep of the stages AROUND the iterations (marker advection + binning, assembly, velocity update ...)
         "cpu_baseline": cpu_obj,
         # the same workload with EVERY solve run to the reference's tolerance 1e-6 (multilevel mode, cap lifted) - not the headline (whose work is fixed at 100 iterations per
         # substep by BASELINE configs[2]), the figure for "this grid, actually solved", with its own roofline object, the CPU at equal tolerance and the deviation from the

@@ -79,6 +79,10 @@ def compact_line(full, limit=LINE_LIMIT):
     line["pcg_iteration"] = _pick(full.get("pcg_iteration"), ITER_KEYS) or None
     line["kernels"] = {k: _pick(v, ("avg_us", "launches", "bytes_per_cell", "GBps_active", "GBps_traffic"))
                        for k, v in (full.get("kernels") or {}).items() if isinstance(v, dict) and v.get("bytes_per_cell") is not None}
+    st = full.get("stages")
+    if isinstance(st, dict) and isinstance(st.get("ms_per_substep"), dict):      # the stages around the iterations: the six largest classes and the sums
+        top = dict(list(st["ms_per_substep"].items())[:6])
+        line["stages"] = {"ms_per_substep": top, "non_pcg_ms_per_substep": st.get("non_pcg_ms_per_substep"), "pcg_ms_per_substep": st.get("pcg_ms_per_substep")}
     cpu = full.get("cpu_baseline")
     if isinstance(cpu, dict):
         c = _pick(cpu, ("value", "unit", "cores", "kind", "cells_substeps_per_s", "substeps_per_step", "sample", "seconds", "strict_ieee_value", "cpu_model", "host_cores_available", "error"))
@@ -101,6 +105,8 @@ def compact_line(full, limit=LINE_LIMIT):
             c["roofline"] = _pick(conv["roofline"], tuple(k for k in ROOF_KEYS if "traffic" not in k))
         if isinstance(conv.get("pcg_iteration"), dict):
             c["pcg_iteration"] = _pick(conv["pcg_iteration"], ITER_KEYS)
+        if isinstance(conv.get("stages"), dict):
+            c["stages"] = _pick(conv["stages"], ("non_pcg_ms_per_substep", "pcg_ms_per_substep"))
         if isinstance(conv.get("deviation_vs_reference_converged"), dict):
             c["deviation_vs_reference_converged"] = _pick(conv["deviation_vs_reference_converged"],
                                                           ("state", "max_abs_du", "max_abs_dv", "max_abs_velocity", "dp_over_max_p", "fluid_cells_differing", "pcg_iterations", "error"))
@@ -134,6 +140,9 @@ def compact_line(full, limit=LINE_LIMIT):
             b = _block(v, ("scaling", "setup_and_preroll_seconds"))
             if isinstance(v.get("converged_frames_multilevel"), dict):
                 b["converged"] = _pick(v["converged_frames_multilevel"], ("value", "ms_per_step", "substeps", "pcg_iterations", "error"))
+                cs = v["converged_frames_multilevel"].get("stages")
+                if isinstance(cs, dict):      # how the converged frame's kernel time divides: iterations / the stages around them
+                    b["converged"]["stages"] = _pick(cs, ("pcg_ms_per_substep", "non_pcg_ms_per_substep", "non_pcg_share_of_kernel_time"))
             if isinstance(v.get("balance"), dict):
                 b["balance_max_over_mean"] = v["balance"].get("max_over_mean")
             summary[k] = b

@@ -12,7 +12,7 @@ import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-from bench_blocks.bytes import MODE_NAME  # noqa: F401
+from bench_blocks.bytes import ITER_BYTES, MODE_NAME  # noqa: F401
 from bench_blocks.cpu import oracle_from_sim  # noqa: F401
 from bench_blocks.timing import summarize, time_frames  # noqa: F401
 from bench_blocks.workload import load_workload, make_handle, pilot_partition, preroll_into_solves, rank_balance  # noqa: F401
@@ -48,11 +48,23 @@ def strong_block(ctx, size, steps, tile_w):
             sim.set_solver(20000, 1e-6)
             sim.step()
             st0 = sim.stats()
+            if not args.no_kernel_timing:      # every kernel class bracketed: how the converged frame divides into iterations and the stages around them
+                sim.profile_reset()
+                sim.profile_enable(ea.profile_class_names())
             el = grp.timed(sim.step, 1)
             st1 = sim.stats()
+            prof = {} if args.no_kernel_timing else sim.profile()
+            sim.profile_enable([])
+            nsub = int(st1.total_substeps - st0.total_substeps)
             conv = {"mode": MODE_NAME["ic0_tile_mg"] % tile_w, "value": size * size / el, "unit": "cells*steps/s", "ms_per_step": 1e3 * el, "steps": 1, "tol": 1e-6,
-                    "substeps": int(st1.total_substeps - st0.total_substeps), "pcg_iterations": int(st1.total_pcg_iterations - st0.total_pcg_iterations),
+                    "substeps": nsub, "pcg_iterations": int(st1.total_pcg_iterations - st0.total_pcg_iterations),
                     "last_residual": float(st1.last_residual)}
+            if prof and nsub:
+                pcg = sum(ms for k, (ms, n) in prof.items() if k in ITER_BYTES["ic0_tile_mg"] and n)
+                rest = {k: round(ms / nsub, 3) for k, (ms, n) in prof.items() if k not in ITER_BYTES["ic0_tile_mg"] and n}
+                conv["stages"] = {"pcg_ms_per_substep": round(pcg / nsub, 3), "non_pcg_ms_per_substep": round(sum(rest.values()), 3),
+                                  "non_pcg_share_of_kernel_time": round(sum(rest.values()) / max(sum(rest.values()) + pcg / nsub, 1e-9), 3),
+                                  "ms_per_substep": dict(sorted(rest.items(), key=lambda kv: -kv[1])[:8])}
         except Exception as e:      # (collective: a failure here is every rank's)
             conv = {"error": repr(e)}
     out = None
@@ -63,7 +75,7 @@ def strong_block(ctx, size, steps, tile_w):
             rank_cells = size * (r1 - r0)
         blk = summarize(t, size, size, args.precond, tile_w, None, None, steps, rank_cells=rank_cells)
         out = {k: blk[k] for k in ("mode", "value", "unit", "ms_per_step", "substeps", "pcg_iterations", "cells_substeps_per_s", "fluid_cells",
-                                   "markers", "last_residual", "roofline", "pcg_iteration")}
+                                   "markers", "last_residual", "roofline", "pcg_iteration", "stages")}
         out.update({"workload": "%dx%d dam break (block layout upscaled; BASELINE configs[3]), %d timed frames after %d preroll frames "
                                 "(into the phase where every substep runs PCG to the iteration cap)" % (size, size, steps, preroll),
                     "n_gpus": world if multi else 1, "scaling": "strong", "balance": balance, "hbm_bytes_this_rank": int(hbm),
@@ -354,7 +366,7 @@ def converged_block(sim, ea, grp, args, GX, GY, tile_w, steps, solver_tol, traff
     t = time_frames(sim, ea, grp, args, "ic0_tile_mg", steps, 0, 1, True)
     blk = summarize(t, GX, GY, "ic0_tile_mg", tile_w, traffic, traffic_note, steps)
     out = {k: blk[k] for k in ("mode", "value", "unit", "ms_per_step", "substeps", "pcg_iterations", "cells_substeps_per_s", "fluid_cells", "last_residual",
-                               "roofline", "pcg_iteration", "kernels")}
+                               "roofline", "pcg_iteration", "kernels", "stages")}
     out.update({"steps": steps, "tol": 1e-6, "max_iterations": 20000,
                 "iterations_per_solve": round(blk["pcg_iterations"] / max(blk["substeps"], 1), 1),
                 "workload": "%dx%d %s, the frames behind the headline's, every solve converged" % (GX, GY, args.workload)})

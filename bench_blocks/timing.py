@@ -45,7 +45,9 @@ def time_frames(sim, ea, grp, args, precond, steps, warmup_done, warmup, big):
     for _ in range(max(warmup - warmup_done, 0)):
         sim.step()
     dominant = {"ic0": "backward_solve", "ic0_tile": "apply_a", "ic0_tile2": "apply_a", "ic0_tile_mg": "apply_a", "jacobi": "update_pr"}[precond]
-    classes_all = ea.profile_class_names() if args.profile_all else PCG_CLASSES
+    # round 6: on large grids EVERY kernel class is bracketed (the ~30 launches per substep outside the iterations cost their event pairs microseconds beside kernels of
+    # hundreds): the line then carries the stages around the solve as well (`stages`), not only the iteration's classes
+    classes_all = ea.profile_class_names() if (args.profile_all or big) else PCG_CLASSES
     if not big and precond == "ic0_tile" and sim.resident_info()[0]:
         dominant = "resident_pcg"
     timed = [] if args.no_kernel_timing else (classes_all if big else [dominant])
@@ -143,7 +145,14 @@ def summarize(t, size_x, size_y, precond, tile_w, traffic, traffic_note, steps, 
         roof = {"bound": "hbm", "kernel": "resident_pcg", "achieved": agg["GBps_active"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": agg["frac_active"], "traffic": 0,
                 "algorithmic_bytes_per_cell": bpc, "avg_launch_us": round(1e3 * rs["ms_total"] / max(rs["solves"], 1), 2), "launches": rs["solves"],
                 "note": agg["note"]}
+    stages = None
+    if t["substeps"] and len(rows) > len(per_iter) + 2:      # every class was timed: the time per substep of the stages around the iterations
+        ms = {k: round(rows[k]["ms_total"] / t["substeps"], 3) for k in rows if k not in ITER_BYTES[precond] and k != "resident_pcg"}
+        stages = {"ms_per_substep": dict(sorted(ms.items(), key=lambda kv: -kv[1])), "non_pcg_ms_per_substep": round(sum(ms.values()), 3),
+                  "pcg_ms_per_substep": round(sum(rows[k]["ms_total"] for k in per_iter) / t["substeps"], 3),
+                  "note": "kernel time by class (HIP events in the timed region) / substeps; a solve's first k_apply_a and first k_precond_tile launch sit inside their per-iteration classes"}
     return {"mode": MODE_NAME[precond] % tile_w if precond in TILE_MODES else MODE_NAME[precond],
+            "stages": stages,
             "value": cells_job * steps / t["elapsed"], "unit": "cells*steps/s", "ms_per_step": 1e3 * t["elapsed"] / steps,
             "substeps": int(t["substeps"]), "pcg_iterations": int(t["iters"]),
             "cells_substeps_per_s": cells_job * t["substeps"] / t["elapsed"],
