@@ -46,6 +46,12 @@ def canned_full(noise=0):
                           "time_to_solution": {m: {"ms": 12.5, "pcg_iterations": 118} for m in ("ic0", "ic0_tile", "ic0_tile2", "ic0_tile_mg")},
                           "parity_vs_reference_ic0": [{"residual_scan": [[i, 0.123456789 * i] for i in range(noise)]} for _ in range(4)]},
             "device": "AMD Instinct MI355X", "timings_s": {"a": 1.0, "b": 2.0}, "full": "bench_full.json"}
+    # round 6: kernel time by class per substep (the stages around the iterations are half of the converged frame)
+    full["stages"] = {"ms_per_substep": {"apply_a": 3.17, "precond_tile": 2.15, "advect_bin": 1.04, "build_system": 0.48, "velocity_update": 0.66, "transpose": 0.28,
+                                         "narrow_counts": 0.05, "dt": 0.01}, "non_pcg_ms_per_substep": 4.0, "pcg_ms_per_substep": 45.9}
+    full["converged"]["stages"] = dict(full["stages"])
+    full["strong_16384_dam_break"]["converged_frames_multilevel"]["stages"] = {"pcg_ms_per_substep": 18.2, "non_pcg_ms_per_substep": 12.1, "non_pcg_share_of_kernel_time": 0.399,
+                                                                               "ms_per_substep": {"advect_bin": 4.1}}
     return full
 
 
@@ -66,6 +72,9 @@ def test_compact_line_is_small_and_carries_the_contract():
         assert d["converged"]["deviation_vs_reference_converged"]["fluid_cells_differing"] == 0
         assert d["pcg_iteration"]["bytes_per_cell_iteration"] == 78.0
         assert d["summary"]["quality_100_iterations"]["pressure_error_vs_converged"]["ic0"] == 0.98
+        assert d["stages"]["non_pcg_ms_per_substep"] == 4.0 and len(d["stages"]["ms_per_substep"]) == 6 and "dt" not in d["stages"]["ms_per_substep"]
+        assert d["converged"]["stages"]["non_pcg_ms_per_substep"] == 4.0
+        assert d["summary"]["strong_16384_dam_break"]["converged"]["stages"]["non_pcg_share_of_kernel_time"] == 0.399
 
 
 def test_compact_line_of_an_eight_gpu_job_carries_the_communicator():
