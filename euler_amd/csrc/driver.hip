@@ -256,6 +256,7 @@ extern "C" void euler_destroy(euler_sim* S) {
   for (uint8_t* g : {S->solid, S->source, S->sink, S->count, S->prev_count}) if (g) (void)hipFree(g + wo);
   if (S->count32) (void)hipFree(S->count32);
   if (S->blockedT) (void)hipFree(S->blockedT);
+  if (S->tmap) (void)hipFree(S->tmap);
   if (S->uT) (void)hipFree(S->uT);
   if (S->vT) (void)hipFree(S->vT);
   if (S->countT) (void)hipFree(S->countT);
@@ -378,7 +379,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   DALLOC(S->solid, Cw); DALLOC(S->source, Cw); DALLOC(S->sink, Cw); DALLOC(S->count, Cw); DALLOC(S->prev_count, Cw);
   DALLOC(S->count32, Cw);
   if (!S->slab_on) { DALLOC(S->blockedT, Cw); DALLOC(S->uT, Cw); DALLOC(S->vT, Cw); DALLOC(S->countT, Cw); DALLOC(S->solidT, Cw); }      // (the marker stage's column-major copies)
-  S->blocked_dirty = 1; S->solidT_dirty = 1; S->prebin_valid = 0; if (S->maxsq_state == 2) S->maxsq_state = 1; S->p_pending = 0; S->uv_clean = 0; S->uv_zb = 0;
+  S->blocked_dirty = 1; S->solidT_dirty = 1; S->prebin_valid = 0; if (S->maxsq_state == 2) S->maxsq_state = 1; S->p_pending = 0; S->uv_clean = 0; S->uv_zb = 0; S->tmap_valid = 0; S->utmp_clean = 0; S->countT_clean = 0;
   DALLOC(S->sys_m, Cw); DALLOC(S->sys_div, Cw);
   if (S->cfg.rainbow) for (float*& d : S->dye) DALLOC(d, Cw);      // (the window like every row-major field; the whole grid without slabs)
   // MAX_MARKER_COUNT = 4 X Y (main.c:92) is the GLOBAL cap; a slab holds the markers inside its rows: room for 6 per owned cell
@@ -390,6 +391,10 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   const size_t mwords = (S->max_markers + 63) / 64;
   DALLOC(S->evmask, mwords);
   if (!S->slab_on) DALLOC(S->delmask, mwords);      // (the advection pass that bins as well keeps the delete ballot apart from the collision ballot)
+  if (!S->slab_on) {      // the tile map (euler_dev.h): flags of the count grid, then of the previous one, a ring of one tile around each (the passes look right of and above a tile without asking where the grid ends)
+    S->tmap_nx = (S->X + 63) / 64 + 1; S->tmap_n = S->tmap_nx * ((S->Y + 63) / 64 + 2);
+    DALLOC(S->tmap, 3 * (size_t)S->tmap_n);      // (+ "a marker entered the tile since the last refresh": k_markers.hip mk_touch)
+  }
   DALLOC(S->ev_theta, S->max_markers); DALLOC(S->ev_delta, S->max_markers);
   S->sel_cap = S->max_markers;
   DALLOC(S->sel_idx, S->sel_cap);
@@ -550,7 +555,7 @@ static int upload_scenario(euler_sim* S, const uint8_t* solid, const uint8_t* so
   HIPCHK(hipMemcpyAsync(S->solid + wo, solid + wo, Cw, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(S->source + wo, source + wo, Cw, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(S->sink + wo, sink + wo, Cw, hipMemcpyHostToDevice, st));
-  S->blocked_dirty = 1; S->solidT_dirty = 1; S->prebin_valid = 0; if (S->maxsq_state == 2) S->maxsq_state = 1; S->p_pending = 0; S->uv_clean = 0; S->uv_zb = 0;
+  S->blocked_dirty = 1; S->solidT_dirty = 1; S->prebin_valid = 0; if (S->maxsq_state == 2) S->maxsq_state = 1; S->p_pending = 0; S->uv_clean = 0; S->uv_zb = 0; S->tmap_valid = 0; S->utmp_clean = 0; S->countT_clean = 0;
   for (float* f : {S->u, S->v, S->utmp, S->vtmp}) HIPCHK(hipMemsetAsync(f + wo, 0, Cw * sizeof(float), st));
   for (double* d : {S->b, S->p, S->r, S->z, S->s, S->s2, S->q, S->precon}) HIPCHK(hipMemsetAsync(d + S->skew_off, 0, S->Sw * sizeof(double), st));
   for (float* d : S->dye) if (d) HIPCHK(hipMemsetAsync(d + wo, 0, Cw * sizeof(float), st));
@@ -736,12 +741,13 @@ extern "C" int euler_timestep(euler_sim* S, float frame_time_left, float* dt) {
 static void eu_state_edited(euler_sim* S) {
   S->prebin_valid = 0;                               // (k_advect_bin_a2's counts and delete ballot)
   if (S->maxsq_state == 2) S->maxsq_state = 1;       // (k_velocity_update_para's maxima of u, v: stale, cleared before the next accumulation)
-  S->uv_clean = 0; S->uv_zb = 0;                     // (what the lean zero_bounds / the velocity update's skipped zero stores rely on)
+  S->uv_clean = 0; S->uv_zb = 0; S->tmap_valid = 0; S->utmp_clean = 0; S->countT_clean = 0;                     // (what the lean zero_bounds / the velocity update's skipped zero stores rely on)
 }
 static int run_stage(euler_sim* S, int stage, float dt) {
   if (stage != EULER_STAGE_REFRESH_COUNTS) S->prebin_valid = 0;      // (what k_advect_bin_a2 binned belongs to the refresh that follows it DIRECTLY)
   if (stage == EULER_STAGE_EXTRAPOLATE && S->maxsq_state == 2) S->maxsq_state = 1;      // (writes u, v; inside a substep the timestep has consumed the maxima long before)
   if (stage == EULER_STAGE_REFRESH_COUNTS) { S->uv_clean = S->uv_clean == 1 ? 2 : 0; S->uv_zb = 0; }      // (prev <- cur: once is what k_zero_bounds4<true> expects)
+  if (stage == EULER_STAGE_REFRESH_COUNTS) { S->utmp_clean = S->utmp_clean == 1 ? 2 : 0; S->countT_clean = S->countT_clean == 1 ? 2 : 0; }      // (the same for what the tile map's readers left)
   if (stage == EULER_STAGE_SOURCES) S->uv_zb = 0;                                                        // (the count grid changes)
   switch (stage) {
     case EULER_STAGE_ADVECT_MARKERS: return eu_launch_advect_markers(S, dt);

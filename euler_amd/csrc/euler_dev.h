@@ -145,6 +145,15 @@ struct euler_sim {
   int count32_dirty;       // the counters hold something (between a binning launch and the k_narrow_counts<true> that clears them; whole-grid handles)
   int prebin_valid;        // the advection stage in front binned its own output (k_advect_bin_a2): the next refresh keeps the counters and the delete ballot
   unsigned long long* delmask;   // [ceil(max_markers/64)] that pass's delete ballot (whole-grid handles)
+  // Round 6, the TILE MAP (whole-grid handles): per 64 x 64 cells, "some cell of the tile holds markers" for the count grid as it stands (tmap) and for the previous one
+  // (tmap + tmap_n) - a superset: a set flag over an empty tile is harmless.  k_narrow_counts<true> writes both at every refresh, k_source_place sets what it fills; the
+  // grid passes whose output over a tile with no water in or next to it in EITHER grid is the zeros already there leave at once (k_advect_velocity, k_zero_bounds4<true>,
+  // k_extrapolate4, k_transpose_for_markers): most of a dam break's grid.
+  uint8_t* tmap;
+  int tmap_nx, tmap_n;     // tiles per row; tiles in all (the previous grid's flags start at tmap + tmap_n; at tmap + 2 tmap_n: a marker has entered the tile since the last refresh)
+  int tmap_valid;          // both maps describe count / prev_count (0: somebody else wrote the grids since the last refresh)
+  int utmp_clean;          // 1: utmp / vtmp are zero wherever the typed fluid property of the count grid does not hold (k_advect_velocity wrote them); 2: ... of prev_count (one refresh since); 0: unknown
+  int countT_clean;        // the same for countT (k_transpose_for_markers)
   uint8_t* blockedT;       // sink | solid per cell, COLUMN-major like count32 (whole-grid handles; k_bin_markers); rebuilt when blocked_dirty
   int blocked_dirty;
   float *uT, *vT; uint8_t *countT, *solidT;   // COLUMN-major copies of u, v (made in front of every marker advection), per cell the typed fluid properties of an interpolation's four corners (countT: k_transpose_for_markers) and of the solid grid (when blocked_dirty): whole-grid handles only
@@ -348,6 +357,8 @@ int  eu_slab_after_restore(euler_sim* S);   // collective: the job-wide facts a 
 int  eu_slab_error_sync(euler_sim* S);      // collective: the ranks' sticky error words -> their maximum on every rank
 int  eu_slab_same_everywhere(euler_sim* S, const double* vals, int n, int* same);   // collective: do these host-side values agree on every rank?
 int  eu_slab_status_sync(euler_sim* S, int local_rc, int* worst);   // collective: a host-side status code -> non-zero on every rank if any rank failed
+// the tile map describes both count grids and this handle's passes may use it (EULER_OPT_NO_TILE_MAP: rounds 1-5's forms)
+static inline bool eu_tile_map_on(const euler_sim* S) { return S->tmap && S->tmap_valid && !S->slab_on && S->opt[EULER_OPT_NO_TILE_MAP] == 0; }
 // launch groups implemented in the kernel files
 int eu_launch_timestep(euler_sim* S, float frame_time_left);
 int eu_launch_advect_markers(euler_sim* S, float dt);
@@ -406,6 +417,26 @@ struct GridRef {
 
 // typed cell property (p_property/u_property/v_property, main.c:119-138)
 __device__ __forceinline__ bool eu_prop_p(const uint8_t* g, size_t i) { return g[i] != 0; }
+// the tile map (euler_sim.tmap): no water in the tiles (ty, tx0 .. tx0 + ntx - 1), the tile to their right and the row of tiles above them - in the count grid and in the
+// previous one.  Uniform over a workgroup when its arguments are (scalar loads).  Column tnx - 1 and the rows behind the grid's last tile row are a ring of zeros.
+__device__ __forceinline__ bool eu_tiles_idle(const uint8_t* __restrict__ tmap, int tnx, int tn, int ty, int tx0, int ntx) {
+  unsigned int a = 0;
+  for (int k = 0; k <= ntx; ++k) {
+    const int tx = tx0 + k < tnx ? tx0 + k : tnx - 1;
+    const int t = ty * tnx + tx;
+    a |= (unsigned int)tmap[t] | tmap[t + tnx] | tmap[tn + t] | tmap[tn + t + tnx];
+  }
+  return a == 0;
+}
+// ... in the count grid as it stands only, the tile columns tx0 .. tx1 and one more to the right, the tile row ty and (up) the one above
+__device__ __forceinline__ bool eu_tiles_idle_cur(const uint8_t* __restrict__ tmap, int tnx, int ty, int tx0, int tx1, bool up) {
+  unsigned int a = 0;
+  for (int tx = tx0; tx <= tx1 + 1; ++tx) {
+    const int t = ty * tnx + (tx < tnx ? tx : tnx - 1);
+    a |= (unsigned int)tmap[t] | (up ? (unsigned int)tmap[t + tnx] : 0u);
+  }
+  return a == 0;
+}
 __device__ __forceinline__ bool eu_prop_u(const uint8_t* g, size_t i) { return (g[i] != 0) | (g[i + 1] != 0); }
 __device__ __forceinline__ bool eu_prop_v(const uint8_t* g, size_t i, int X) { return (g[i] != 0) | (g[i + X] != 0); }
 

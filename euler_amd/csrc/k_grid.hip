@@ -172,38 +172,49 @@ __device__ __forceinline__ uint2 eu_props4(const uint8_t* __restrict__ g, size_t
 // (Valid while exactly one refresh_marker_counts lies between the last velocity update and this call and nobody edited the state: euler_sim.uv_clean.)
 template <bool LEAN>
 __global__ __launch_bounds__(256) void k_zero_bounds4(float* u, float* v, const uint8_t* __restrict__ cur,
-                                                      const uint8_t* __restrict__ solid, int X, int Y, int y0, int y1, const uint8_t* __restrict__ prev) {
+                                                      const uint8_t* __restrict__ solid, int X, int Y, int y0, int y1, const uint8_t* __restrict__ prev,
+                                                      const uint8_t* __restrict__ tmap, int tnx, int tn, int rep) {
+  // (a workgroup: 256 columns x 4 rep rows inside one row of tiles; no fluid property now or before - nothing to zero)
+  if (LEAN && tmap && eu_tiles_idle(tmap, tnx, tn, (y0 + (int)blockIdx.y * 4 * rep) >> 6, (int)blockIdx.x * 4, 4)) return;
   const int x = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
-  const int y = y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= X || y >= y1) return;
-  const size_t i = (size_t)y * X + x;
-  const uint2 pc = eu_props4(cur, i, x, y, X, Y), ps = eu_props4(solid, i, x, y, X, Y);
-  unsigned int zu = (~pc.x | ps.x) & 0xfu, zv = (~pc.y | ps.y) & 0xfu;      // samples that go to zero
-  if (LEAN) {
-    const uint2 pp = eu_props4(prev, i, x, y, X, Y);
-    zu &= (pp.x & ~ps.x) | (pc.x & ~pp.x);
-    zv &= (pp.y & ~ps.y) | (pc.y & ~pp.y);
+  if (x >= X) return;
+  for (int r = 0; r < rep; ++r) {
+    const int y = y0 + ((int)blockIdx.y * rep + r) * 4 + (int)(threadIdx.x >> 6);
+    if (y >= y1) return;
+    const size_t i = (size_t)y * X + x;
+    const uint2 pc = eu_props4(cur, i, x, y, X, Y), ps = eu_props4(solid, i, x, y, X, Y);
+    unsigned int zu = (~pc.x | ps.x) & 0xfu, zv = (~pc.y | ps.y) & 0xfu;      // samples that go to zero
+    if (LEAN) {
+      const uint2 pp = eu_props4(prev, i, x, y, X, Y);
+      zu &= (pp.x & ~ps.x) | (pc.x & ~pp.x);
+      zv &= (pp.y & ~ps.y) | (pc.y & ~pp.y);
+    }
+    if (x + 4 >= X) zu &= 0x7u;                                               // (the grid's last column holds no U sample)
+    if (y >= Y - 1) zv = 0u;                                                  // (nor its last row a V sample)
+    if (zu == 0xfu) *reinterpret_cast<float4*>(u + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    else { for (int k = 0; k < 4; ++k) if (zu & (1u << k)) u[i + k] = 0.f; }
+    if (zv == 0xfu) *reinterpret_cast<float4*>(v + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    else { for (int k = 0; k < 4; ++k) if (zv & (1u << k)) v[i + k] = 0.f; }
   }
-  if (x + 4 >= X) zu &= 0x7u;                                               // (the grid's last column holds no U sample)
-  if (y >= Y - 1) zv = 0u;                                                  // (nor its last row a V sample)
-  if (zu == 0xfu) *reinterpret_cast<float4*>(u + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-  else { for (int k = 0; k < 4; ++k) if (zu & (1u << k)) u[i + k] = 0.f; }
-  if (zv == 0xfu) *reinterpret_cast<float4*>(v + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-  else { for (int k = 0; k < 4; ++k) if (zv & (1u << k)) v[i + k] = 0.f; }
 }
 __global__ __launch_bounds__(256) void k_extrapolate4(float* u, float* v, const uint8_t* __restrict__ prev,
-                                                      const uint8_t* __restrict__ cur, int X, int Y, int y0, int y1) {
+                                                      const uint8_t* __restrict__ cur, int X, int Y, int y0, int y1,
+                                                      const uint8_t* __restrict__ tmap, int tnx, int tn, int rep) {
+  if (tmap && eu_tiles_idle(tmap, tnx, tn, (y0 + (int)blockIdx.y * 4 * rep) >> 6, (int)blockIdx.x * 4, 4)) return;      // (no sample has just become fluid where there is no water)
   const int x = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
-  const int y = y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= X || y >= y1) return;
-  const size_t i = (size_t)y * X + x;
-  const uint2 pp = eu_props4(prev, i, x, y, X, Y), pc = eu_props4(cur, i, x, y, X, Y);
-  unsigned int eu = ~pp.x & pc.x & 0xfu, ev = ~pp.y & pc.y & 0xfu;          // samples that have just become fluid (main.c:158-160)
-  if (x + 4 >= X) eu &= 0x7u;
-  if (y >= Y - 1) ev = 0u;
-  for (int k = 0; k < 4; ++k) {
-    if (eu & (1u << k)) extrapolate_sample<1>(u, prev, cur, x + k, y, X, X - 1, Y);
-    if (ev & (1u << k)) extrapolate_sample<2>(v, prev, cur, x + k, y, X, X, Y - 1);
+  if (x >= X) return;
+  for (int r = 0; r < rep; ++r) {
+    const int y = y0 + ((int)blockIdx.y * rep + r) * 4 + (int)(threadIdx.x >> 6);
+    if (y >= y1) return;
+    const size_t i = (size_t)y * X + x;
+    const uint2 pp = eu_props4(prev, i, x, y, X, Y), pc = eu_props4(cur, i, x, y, X, Y);
+    unsigned int eu = ~pp.x & pc.x & 0xfu, ev = ~pp.y & pc.y & 0xfu;          // samples that have just become fluid (main.c:158-160)
+    if (x + 4 >= X) eu &= 0x7u;
+    if (y >= Y - 1) ev = 0u;
+    for (int k = 0; k < 4; ++k) {
+      if (eu & (1u << k)) extrapolate_sample<1>(u, prev, cur, x + k, y, X, X - 1, Y);
+      if (ev & (1u << k)) extrapolate_sample<2>(v, prev, cur, x + k, y, X, X, Y - 1);
+    }
   }
 }
 
@@ -213,11 +224,16 @@ int eu_launch_extrapolate(euler_sim* S) {
   const size_t min_cells = (size_t)S->opt[EULER_OPT_GRID4_MIN_CELLS];      // (EULER_OPT_GRID4_MIN_CELLS; tests: 0 selects the four-cell kernels on any grid)
   if ((S->X & 3) == 0 && (size_t)S->X * (S->row_hi - S->row_lo) >= min_cells) {
     dim3 grid4((S->X / 4 + 63) / 64, (S->row_hi - S->row_lo + 3) / 4);
-    LAUNCH(S, KC_EXTRAPOLATE, k_extrapolate4, grid4, dim3(256), S->u, S->v, S->prev_count, S->count, S->X, S->Y, S->row_lo, S->row_hi);
+    const uint8_t* tm = eu_tile_map_on(S) ? S->tmap : nullptr;
+    int rep = 1;
+    if (tm) while (rep < 16 && ((size_t)S->X * S->Y >> 24) >= (size_t)(2 * rep)) rep *= 2;      // (8192^2: 4, 16384^2: 16 - at least 4 K workgroups)
+    grid4.y = (unsigned)((S->row_hi - S->row_lo + 4 * rep - 1) / (4 * rep));
+    LAUNCH(S, KC_EXTRAPOLATE, k_extrapolate4, grid4, dim3(256), S->u, S->v, S->prev_count, S->count, S->X, S->Y, S->row_lo, S->row_hi, tm, S->tmap_nx, S->tmap_n, rep);
     if (!S->slab_on && S->uv_clean == 2 && S->opt[EULER_OPT_VELOCITY_TWO_PASS] == 0)
-      LAUNCH(S, KC_EXTRAPOLATE, k_zero_bounds4<true>, grid4, dim3(256), S->u, S->v, S->count, S->solid, S->X, S->Y, S->row_lo, S->row_hi, S->prev_count);
+      LAUNCH(S, KC_EXTRAPOLATE, k_zero_bounds4<true>, grid4, dim3(256), S->u, S->v, S->count, S->solid, S->X, S->Y, S->row_lo, S->row_hi, S->prev_count, tm, S->tmap_nx, S->tmap_n, rep);
     else
-      LAUNCH(S, KC_EXTRAPOLATE, k_zero_bounds4<false>, grid4, dim3(256), S->u, S->v, S->count, S->solid, S->X, S->Y, S->row_lo, S->row_hi, (const uint8_t*)nullptr);
+      LAUNCH(S, KC_EXTRAPOLATE, k_zero_bounds4<false>, grid4, dim3(256), S->u, S->v, S->count, S->solid, S->X, S->Y, S->row_lo, S->row_hi, (const uint8_t*)nullptr,
+             (const uint8_t*)nullptr, 0, 0, rep);
     S->uv_zb = 1;      // (zero_bounds has run with the count grid as it stands)
     return EULER_OK;
   }
@@ -235,32 +251,39 @@ int eu_launch_extrapolate(euler_sim* S) {
 // gravity it adds to non-fluid faces never survive).
 __global__ __launch_bounds__(256) void k_advect_velocity(const float* __restrict__ u, const float* __restrict__ v,
                                                          float* __restrict__ uout, float* __restrict__ vout,
-                                                         const uint8_t* __restrict__ solid, GridRef g, float dt, int y0, int y1) {
+                                                         const uint8_t* __restrict__ solid, GridRef g, float dt, int y0, int y1,
+                                                         const uint8_t* __restrict__ tmap, int tnx, int tn, int rep) {
   const int X = g.X, Y = g.Y;
+  // round 6 (tmap: whole-grid handles whose utmp / vtmp this kernel wrote one refresh ago): a tile with no water in or next to it now and then holds the zeros it would get.
+  // A workgroup takes 64 columns x 4 rep rows (rep = 16 on large grids: the tile; a wave that only looks at the map and leaves still costs its microsecond - 16384^2: 2.9 M of them)
+  if (tmap && eu_tiles_idle(tmap, tnx, tn, (y0 + (int)blockIdx.y * 4 * rep) >> 6, (int)blockIdx.x, 1)) return;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= X || y >= y1) return;
-  const size_t i = (size_t)y * X + x;
-  if (x < X - 1) {
-    float out = 0.f;
-    if (eu_prop_u(g.count, i) && !eu_prop_u(solid, i)) {
-      const float dx = u[i];
-      const float dy = eu_interp<2>(g, v, x + 0.5f, y - 0.5f);          // vidx_from_u, main.c:378-380
-      const float px = x - dx * dt / EU_H, py = y - dy * dt / EU_H;     // main.c:392-393
-      out = eu_interp<1>(g, u, px, py);
+  if (x >= X) return;
+  for (int r = 0; r < rep; ++r) {
+    const int y = y0 + ((int)blockIdx.y * rep + r) * 4 + (int)(threadIdx.x >> 6);
+    if (y >= y1) return;
+    const size_t i = (size_t)y * X + x;
+    if (x < X - 1) {
+      float out = 0.f;
+      if (eu_prop_u(g.count, i) && !eu_prop_u(solid, i)) {
+        const float dx = u[i];
+        const float dy = eu_interp<2>(g, v, x + 0.5f, y - 0.5f);          // vidx_from_u, main.c:378-380
+        const float px = x - dx * dt / EU_H, py = y - dy * dt / EU_H;     // main.c:392-393
+        out = eu_interp<1>(g, u, px, py);
+      }
+      uout[i] = out;
     }
-    uout[i] = out;
-  }
-  if (y < Y - 1) {
-    float out = 0.f;
-    if (eu_prop_v(g.count, i, X) && !eu_prop_v(solid, i, X)) {
-      const float dy = v[i];
-      const float dx = eu_interp<1>(g, u, x - 0.5f, y + 0.5f);          // uidx_from_v, main.c:401-403
-      const float px = x - dx * dt / EU_H, py = y - dy * dt / EU_H;
-      out = eu_interp<2>(g, v, px, py);
-      out += EU_G * dt;                                                 // main.c:542
+    if (y < Y - 1) {
+      float out = 0.f;
+      if (eu_prop_v(g.count, i, X) && !eu_prop_v(solid, i, X)) {
+        const float dy = v[i];
+        const float dx = eu_interp<1>(g, u, x - 0.5f, y + 0.5f);          // uidx_from_v, main.c:401-403
+        const float px = x - dx * dt / EU_H, py = y - dy * dt / EU_H;
+        out = eu_interp<2>(g, v, px, py);
+        out += EU_G * dt;                                                 // main.c:542
+      }
+      vout[i] = out;
     }
-    vout[i] = out;
   }
 }
 
@@ -317,7 +340,14 @@ int eu_launch_diffuse(euler_sim* S, float dt);
 int eu_launch_advect_velocity(euler_sim* S, float dt) {
   GridRef g{S->X, S->Y, S->count, S->interp_lim[0], S->interp_lim[1], S->interp_lim[2], S->interp_lim[3]};
   dim3 grid((S->X + 63) / 64, (S->row_hi - S->row_lo + 3) / 4);
-  LAUNCH(S, KC_ADVECT_VELOCITY, k_advect_velocity, grid, dim3(256), S->u, S->v, S->utmp, S->vtmp, S->solid, g, dt, S->row_lo, S->row_hi);
+  // (the tile map: utmp / vtmp must be what this kernel left one refresh ago, and nothing but the refresh may have touched the count grids since)
+  const bool lean = eu_tile_map_on(S) && S->utmp_clean == 2 && !(S->cfg.viscosity > 0.f);
+  int rep = 1;
+  if (lean) while (rep < 16 && ((size_t)S->X * S->Y >> 22) >= (size_t)(2 * rep)) rep *= 2;      // (2048^2: 1, 4096^2: 4, 8192^2 and beyond: 16 - at least 16 K workgroups)
+  grid.y = (unsigned)((S->row_hi - S->row_lo + 4 * rep - 1) / (4 * rep));
+  LAUNCH(S, KC_ADVECT_VELOCITY, k_advect_velocity, grid, dim3(256), S->u, S->v, S->utmp, S->vtmp, S->solid, g, dt, S->row_lo, S->row_hi,
+         lean ? (const uint8_t*)S->tmap : (const uint8_t*)nullptr, S->tmap_nx, S->tmap_n, rep);
+  S->utmp_clean = (S->cfg.viscosity > 0.f) ? 0 : 1;      // (the diffusion extension writes utmp / vtmp behind this)
   // (a row-slab handle exchanges the ghost rows of utmp / vtmp between the two: eu_slab_substep calls eu_launch_diffuse itself)
   return S->slab_on ? EULER_OK : eu_launch_diffuse(S, dt);
 }
@@ -501,7 +531,8 @@ template <bool TILE>
 __global__ __launch_bounds__(256) void k_build_system_para(const float* __restrict__ u, const float* __restrict__ v, const uint8_t* __restrict__ count, const uint8_t* __restrict__ solid,
                                                            double* __restrict__ b, double* __restrict__ r, double* __restrict__ p, double* __restrict__ q, double* __restrict__ z,
                                                            uint8_t* __restrict__ cellmask, PcgScalars* sc, SkewGeom g, float dt, int band_lo,
-                                                           uint8_t* __restrict__ chunk_flag, uint8_t* __restrict__ chunk_part, const uint8_t* __restrict__ chunk_prev) {
+                                                           uint8_t* __restrict__ chunk_flag, uint8_t* __restrict__ chunk_part, const uint8_t* __restrict__ chunk_prev,
+                                                           const uint8_t* __restrict__ tmap, int tnx) {
   __shared__ float sd[64][BS_W + 1];
   __shared__ uint8_t sm[64][BS_W + 4];
   __shared__ int s_fl[BS_W / 16], s_part[BS_W / 16], s_prev[BS_W / 16], s_nz;
@@ -513,6 +544,14 @@ __global__ __launch_bounds__(256) void k_build_system_para(const float* __restri
   if (tid < BS_W / 16) { s_fl[tid] = 0; s_part[tid] = 0; s_prev[tid] = TILE ? (chunk_prev[chunk0 + tid] != 0) : 1; }
   if (tid == 0) s_nz = 0;
   __syncthreads();
+  if (TILE && tmap) {      // the tile map (euler_dev.h): no water in the tiles the parallelogram lies in, none in its chunks at the previous solve - masks, b, r, p are the zeros they would get
+    bool prev_any = false;
+    for (int k = 0; k < BS_W / 16; ++k) prev_any = prev_any || s_prev[k] != 0;
+    if (!prev_any && eu_tiles_idle_cur(tmap, tnx, band, t0 > 63 ? (t0 - 63) >> 6 : 0, ((t0 + BS_W - 1) >> 6) - 1, false)) {
+      if (tid < BS_W / 16) chunk_part[chunk0 + tid] = 1;      // (what the pass leaves for chunks of air: not INTERIOR)
+      return;
+    }
+  }
   static_assert((64 * BS_W) % (256 * 4) == 0, "whole rounds of four cells per thread");
   for (int c0 = tid; c0 < 64 * BS_W; c0 += 256 * 4) {
     // four cells per thread; a wave whose cells hold no fluid is done after the count bytes, any other issues every load of the round before the first use
@@ -660,7 +699,8 @@ struct VuRing { const double* s[8]; int n, steps, use; };      // use 0: p is fi
 __global__ __launch_bounds__(256) void k_velocity_update_para(const float* __restrict__ uin, const float* __restrict__ vin, float* __restrict__ uout, float* __restrict__ vout,
                                                               const double* __restrict__ p, const uint8_t* __restrict__ mask, const uint8_t* __restrict__ count,
                                                               const uint8_t* __restrict__ solid, SkewGeom g, float dt, const PcgScalars* sc, VuRing ring, MarkerState* ms,
-                                                              int band_lo, int do_max, int skip_zero) {      // this rank's bands start at band_lo; do_max 0: a row slab's maxima are k_maxsq's (all-reduced)
+                                                              int band_lo, int do_max, int skip_zero,      // this rank's bands start at band_lo; do_max 0: a row slab's maxima are k_maxsq's (all-reduced)
+                                                              const uint8_t* __restrict__ tmap, int tnx) {
   // skip_zero: the faces this pass sets to 0 - the air's, the walls' (main.c:784-790, 797-803) - are not stored: zero_bounds zeroed exactly those samples of u, v earlier in
   // this substep, with the same count grid (euler_sim.uv_zb), and nothing has written them since
   __shared__ double sp[65][VU_W + 1];
@@ -669,6 +709,8 @@ __global__ __launch_bounds__(256) void k_velocity_update_para(const float* __res
   const size_t blk = eu_xcd_block();
   const int band = band_lo + (int)(blk / units), t0 = (int)(blk % units) * VU_W;
   const int X = g.X, Y = g.Y, tid = threadIdx.x;
+  // the tile map (euler_dev.h; with skip_zero): no water in the tiles the parallelogram lies in, to their right or above - every face is the air's, zero already, and no maximum
+  if (skip_zero && tmap && eu_tiles_idle_cur(tmap, tnx, band, t0 > 63 ? (t0 - 63) >> 6 : 0, (t0 + VU_W - 1) >> 6, true)) return;
   // the fmadds that are due: iterations from .. n_it - 1 (k_finish_p)
   int cnt = 0, from = 0;
   if (ring.use && sc->nonzero && sc->iters > 0) {
@@ -831,10 +873,10 @@ int eu_launch_build_system(euler_sim* S, float dt) {
     const unsigned nblk = (unsigned)((size_t)(S->band_hi - S->band_lo) * (S->geom.T / BS_W));
     if (lean)
       LAUNCH(S, KC_BUILD_SYSTEM, k_build_system_para<true>, dim3(nblk), dim3(256), S->utmp, S->vtmp, S->count, S->solid, S->b, S->r, S->p, S->q, S->z, S->cellmask, S->sc, S->geom, dt, S->band_lo,
-             S->chunk_flag, S->chunk_part, S->chunk_prev);
+             S->chunk_flag, S->chunk_part, S->chunk_prev, eu_tile_map_on(S) ? (const uint8_t*)S->tmap : (const uint8_t*)nullptr, S->tmap_nx);
     else
       LAUNCH(S, KC_BUILD_SYSTEM, k_build_system_para<false>, dim3(nblk), dim3(256), S->utmp, S->vtmp, S->count, S->solid, S->b, S->r, S->p, S->q, S->z, S->cellmask, S->sc, S->geom, dt, S->band_lo,
-             S->chunk_flag, S->chunk_part, S->chunk_prev);
+             S->chunk_flag, S->chunk_part, S->chunk_prev, (const uint8_t*)nullptr, 0);
   } else if (!gather) {
     const size_t win_off = (size_t)S->win_lo * S->X;
     LAUNCH(S, KC_BUILD_SYSTEM, k_cell_system, dim3(eu_blocks((size_t)S->X * (S->row_hi - S->row_lo), 256)), dim3(256), S->utmp, S->vtmp, S->count, S->solid, S->sys_m, S->sys_div,
@@ -885,7 +927,8 @@ int eu_launch_velocity_update(euler_sim* S, float dt, int finish) {
     const int do_max = S->slab_on ? 0 : 1;
     if (do_max && S->maxsq_state != 0) HIPCHK(hipMemsetAsync(&S->ms->max_u2_bits, 0, 2 * sizeof(unsigned int), S->stream));      // (maxima no timestep consumed)
     LAUNCH(S, KC_VELOCITY_UPDATE, k_velocity_update_para, dim3((unsigned)((size_t)(S->band_hi - S->band_lo) * (S->geom.T / VU_W))), dim3(256), S->utmp, S->vtmp, S->u, S->v, S->p, S->cellmask,
-           S->count, S->solid, S->geom, dt, S->sc, ring, S->ms, S->band_lo, do_max, (!S->slab_on && S->uv_zb) ? 1 : 0);
+           S->count, S->solid, S->geom, dt, S->sc, ring, S->ms, S->band_lo, do_max, (!S->slab_on && S->uv_zb) ? 1 : 0,
+           eu_tile_map_on(S) ? (const uint8_t*)S->tmap : (const uint8_t*)nullptr, S->tmap_nx);
     S->uv_clean = 1;      // every sample without the fluid property, every wall's sample is zero now (k_zero_bounds4<true> of the next substep relies on it)
     S->p_pending = ring.use ? 1 : 2;
     if (do_max) S->maxsq_state = 2;      // the maxima of u, v as they stand are in ms (eu_launch_timestep: k_dt alone)

@@ -325,6 +325,16 @@ __device__ __forceinline__ void bin_aggregated_w(unsigned int* count32, bool liv
 __device__ __forceinline__ size_t mk_cell_colmajor(float px, float py, int H) {      // the counters' (and blockedT's) index of the cell a position lies in
   return (size_t)(int)floorf(px / EU_H) * H + (int)floorf(py / EU_H);
 }
+// the tile map's third array (euler_sim.tmap + 2 tmap_n): "a marker ENTERED this tile since the last refresh".  A marker that stays inside its tile needs no mark - the tile
+// held it at the last refresh, so the count grid's flag is up - and k_narrow_counts<true> reads the counters of a tile only if one of the two says so.
+__device__ __forceinline__ int mk_tile(float px, float py, int tnx) { return ((int)floorf(py / EU_H) >> 6) * tnx + ((int)floorf(px / EU_H) >> 6); }
+// the counters' index of the cell the NEW position lies in (mk_cell_colmajor), marking its tile when the OLD position lay in another one (positions are never negative:
+// truncation is floor; EU_H = 1)
+__device__ __forceinline__ size_t mk_cell_touch(float ox, float oy, float px, float py, int H, bool live, uint8_t* touch, int tnx) {
+  const int nx = (int)floorf(px / EU_H), ny = (int)floorf(py / EU_H);
+  if (live && (((nx ^ (int)ox) | (ny ^ (int)oy)) >> 6) != 0) touch[(ny >> 6) * tnx + (nx >> 6)] = 1;      // (16384^2 dam break: + 55 us here, - 170 us in k_narrow_counts)
+  return (size_t)nx * H + ny;
+}
 template <bool TR>
 __global__ __launch_bounds__(256) void k_advect_bin_a2(const float2* __restrict__ in, float2* __restrict__ out,
                                                        const float* __restrict__ u, const float* __restrict__ v,
@@ -332,7 +342,7 @@ __global__ __launch_bounds__(256) void k_advect_bin_a2(const float2* __restrict_
                                                        unsigned long long n, unsigned long long* __restrict__ evmask,
                                                        float* __restrict__ ev_theta, float* __restrict__ ev_delta,
                                                        MarkerState* ms, const uint8_t* __restrict__ blockedT, unsigned int* count32,
-                                                       unsigned long long* __restrict__ delmask, int H) {
+                                                       unsigned long long* __restrict__ delmask, int H, uint8_t* touch, int tnx) {
   const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, i = 2 * t;
   bool ev0 = false, ev1 = false, del0 = false, del1 = false, live0 = false, live1 = false;
   size_t c0 = 0, c1 = 0;
@@ -343,7 +353,7 @@ __global__ __launch_bounds__(256) void k_advect_bin_a2(const float2* __restrict_
     *reinterpret_cast<float4*>(out + i) = make_float4(o0.px, o0.py, o1.px, o1.py);
     if (o0.events) { ev0 = true; ev_theta[i] = o0.theta; ev_delta[i] = o0.delta; if (o0.events > 1) atomicAdd(&ms->multi_events, 1ull); }
     if (o1.events) { ev1 = true; ev_theta[i + 1] = o1.theta; ev_delta[i + 1] = o1.delta; if (o1.events > 1) atomicAdd(&ms->multi_events, 1ull); }
-    c0 = mk_cell_colmajor(o0.px, o0.py, H); c1 = mk_cell_colmajor(o1.px, o1.py, H);
+    c0 = mk_cell_touch(p.x, p.y, o0.px, o0.py, H, true, touch, tnx); c1 = mk_cell_touch(p.z, p.w, o1.px, o1.py, H, true, touch, tnx);      // (a marker about to be deleted marks too: a superset)
     del0 = blockedT[c0] != 0; del1 = blockedT[c1] != 0;      // refresh_marker_counts drops markers in sink or solid cells (main.c:109-112)
     live0 = !del0; live1 = !del1;
   } else if (i < n) {
@@ -351,7 +361,7 @@ __global__ __launch_bounds__(256) void k_advect_bin_a2(const float2* __restrict_
     const AdvectOut o0 = advect_one<TR>(g, u, v, solid, p.x, p.y, dt);
     out[i] = make_float2(o0.px, o0.py);
     if (o0.events) { ev0 = true; ev_theta[i] = o0.theta; ev_delta[i] = o0.delta; if (o0.events > 1) atomicAdd(&ms->multi_events, 1ull); }
-    c0 = mk_cell_colmajor(o0.px, o0.py, H);
+    c0 = mk_cell_touch(p.x, p.y, o0.px, o0.py, H, true, touch, tnx);
     del0 = blockedT[c0] != 0;
     live0 = !del0;
   }
@@ -401,7 +411,8 @@ __global__ __launch_bounds__(256) void k_advect_markers_b(const float2* __restri
                                                           unsigned long long n, const unsigned int* __restrict__ act_idx,
                                                           const float* __restrict__ act_dt, const MarkerState* ms,
                                                           const unsigned int* __restrict__ keys,      // keys: slab mode, the markers' GLOBAL array indices
-                                                          const uint8_t* __restrict__ blockedT, unsigned int* count32, unsigned long long* delmask, int H) {
+                                                          const uint8_t* __restrict__ blockedT, unsigned int* count32, unsigned long long* delmask, int H,
+                                                          uint8_t* touch, int tnx) {
   const unsigned int M = ms->n_actual;
   if (M == 0) return;
   const unsigned int first = act_idx[0];
@@ -424,7 +435,7 @@ __global__ __launch_bounds__(256) void k_advect_markers_b(const float2* __restri
           ndel = blockedT[nc] != 0;
           if (oc != nc) {
             if (blockedT[oc] == 0) atomicSub(&count32[oc], 1u);
-            if (!ndel) atomicAdd(&count32[nc], 1u);
+            if (!ndel) { atomicAdd(&count32[nc], 1u); touch[mk_tile(o.px, o.py, tnx)] = 1; }      // (the tile map: the marker may have entered the tile)
           }
         }
         out[i] = make_float2(o.px, o.py);
@@ -448,13 +459,16 @@ __global__ __launch_bounds__(256) void k_advect_markers_b(const float2* __restri
 // instructions and the lines each touches (timing experiments, profiles/r06_marker_gather_experiment.md: 1078 -> 683 us without the twelve count loads of a thread).
 __global__ __launch_bounds__(256) void k_transpose_for_markers(const float* __restrict__ u, const float* __restrict__ v, const uint8_t* __restrict__ count, const uint8_t* __restrict__ solid,
                                                                float* __restrict__ uT, float* __restrict__ vT, uint8_t* __restrict__ countT, uint8_t* __restrict__ solidT,
-                                                               int X, int Y, int with_solid) {
+                                                               int X, int Y, int with_solid, const uint8_t* __restrict__ tmap, int tnx, int tn) {
+  // round 6 (tmap: countT is what this kernel left one refresh ago): no water in or next to the tile in either count grid - countT holds the zeros it would get, u and v stay
+  const int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+  if (tmap && eu_tiles_idle(tmap, tnx, tn, (by * TM_ROWS) >> 6, bx, 1)) return;
   __shared__ float tu[TM_ROWS][65], tv[TM_ROWS][65];
   __shared__ uint8_t ts[TM_ROWS][65];
   __shared__ uint8_t tw[TM_ROWS + 2][68];      // per cell of the tile and of the two rows above it: bits 0-2 = "cell x / x + 1 / x + 2 of this row holds markers" (columns of the tile only)
   __shared__ uint8_t e_hi[TM_ROWS + 2][2];     // ... and the same for the two columns to the right of the tile (xb + 64, xb + 65)
   __shared__ int s_any;
-  const int xb = blockIdx.x * 64, yb = blockIdx.y * TM_ROWS, l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int xb = bx * 64, yb = by * TM_ROWS, l = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (threadIdx.x == 0) s_any = 0;
   __syncthreads();
   // Round 6: a sample of u or v is only ever USED where its typed fluid property holds (eu_interp selects the others away: main.c:348-362) - a U sample next to a cell
@@ -523,9 +537,11 @@ __global__ __launch_bounds__(256) void k_transpose_for_markers(const float* __re
 static bool eu_markers_column_major(euler_sim* S) {      // (whole-grid handles; EULER_OPT_MARKERS_ROWMAJOR: the row-major kernels, for A-B timing)
   const bool off = S->opt[EULER_OPT_MARKERS_ROWMAJOR] != 0;
   if (off || S->slab_on || !S->uT) return false;
+  const bool lean = eu_tile_map_on(S) && S->countT_clean == 2 && !S->solidT_dirty;
   LAUNCH(S, KC_MARKER_ADVECT, k_transpose_for_markers, dim3((S->X + 63) / 64, (S->Y + TM_ROWS - 1) / TM_ROWS), dim3(256), S->u, S->v, S->count, S->solid, S->uT, S->vT, S->countT, S->solidT,
-         S->X, S->Y, S->solidT_dirty);
+         S->X, S->Y, S->solidT_dirty, lean ? (const uint8_t*)S->tmap : (const uint8_t*)nullptr, S->tmap_nx, S->tmap_n);
   S->solidT_dirty = 0;
+  S->countT_clean = 1;
   return true;
 }
 
@@ -560,7 +576,7 @@ int eu_launch_advect_markers(euler_sim* S, float dt) {
       if (!rc) rc = eu_count32_clean(S);
       if (rc) return rc;
       LAUNCH(S, KC_MARKER_ADVECT, k_advect_bin_a2<true>, dim3(eu_blocks((size_t)((n + 1) / 2), 256)), dim3(256), in, out, S->uT, S->vT, S->solidT, gt, dt, n, S->evmask, S->ev_theta, S->ev_delta, S->ms,
-             S->blockedT, S->count32, S->delmask, S->Y);
+             S->blockedT, S->count32, S->delmask, S->Y, S->tmap + 2 * (size_t)S->tmap_n, S->tmap_nx);
     } else
       LAUNCH(S, KC_MARKER_ADVECT, k_advect_markers_a2<true>, dim3(eu_blocks((size_t)((n + 1) / 2), 256)), dim3(256), in, out, S->uT, S->vT, S->solidT, gt, dt, n, S->evmask, S->ev_theta, S->ev_delta, S->ms);
     int rc = eu_ordered_select(S, S->evmask, (size_t)((n + 63) / 64), S->sel_idx, &S->ms->n_events);
@@ -568,11 +584,11 @@ int eu_launch_advect_markers(euler_sim* S, float dt) {
     LAUNCH(S, KC_MARKER_EVENTS, k_marker_walk, dim3(1), dim3(64), S->sel_idx, S->ev_theta, S->ev_delta, S->act_idx, S->act_dt, S->ms, dt);
     if (fuse) {
       LAUNCH(S, KC_MARKER_ADVECT, (k_advect_markers_b<true, true>), dim3(nb_b), dim3(256), in, out, S->uT, S->vT, S->solidT, gt, n, S->act_idx, S->act_dt, S->ms, (const unsigned int*)nullptr,
-             S->blockedT, S->count32, S->delmask, S->Y);
+             S->blockedT, S->count32, S->delmask, S->Y, S->tmap + 2 * (size_t)S->tmap_n, S->tmap_nx);
       S->prebin_valid = 1;      // (consumed by the refresh that follows; anything else in between drops it: driver.hip)
     } else
       LAUNCH(S, KC_MARKER_ADVECT, (k_advect_markers_b<true, false>), dim3(nb_b), dim3(256), in, out, S->uT, S->vT, S->solidT, gt, n, S->act_idx, S->act_dt, S->ms, (const unsigned int*)nullptr,
-             (const uint8_t*)nullptr, (unsigned int*)nullptr, (unsigned long long*)nullptr, 0);
+             (const uint8_t*)nullptr, (unsigned int*)nullptr, (unsigned long long*)nullptr, 0, (uint8_t*)nullptr, 0);
     S->cur ^= 1;
     return EULER_OK;
   }
@@ -583,7 +599,7 @@ int eu_launch_advect_markers(euler_sim* S, float dt) {
   LAUNCH(S, KC_MARKER_EVENTS, k_marker_walk, dim3(1), dim3(64), S->sel_idx, S->ev_theta, S->ev_delta, S->act_idx,
          S->act_dt, S->ms, dt);
   LAUNCH(S, KC_MARKER_ADVECT, (k_advect_markers_b<false, false>), dim3(nb_b), dim3(256), in, out, S->u, S->v, S->solid, g, n,
-         S->act_idx, S->act_dt, S->ms, (const unsigned int*)nullptr, (const uint8_t*)nullptr, (unsigned int*)nullptr, (unsigned long long*)nullptr, 0);
+         S->act_idx, S->act_dt, S->ms, (const unsigned int*)nullptr, (const uint8_t*)nullptr, (unsigned int*)nullptr, (unsigned long long*)nullptr, 0, (uint8_t*)nullptr, 0);
   S->cur ^= 1;
   return EULER_OK;
 }
@@ -668,25 +684,49 @@ __global__ __launch_bounds__(256) void k_compact_markers(float2* m, const unsign
 // bins for it) starts.  One pass over the cells instead of two.
 template <bool FOLD>
 __global__ __launch_bounds__(256) void k_narrow_counts(uint8_t* __restrict__ count, unsigned int* __restrict__ count32,
-                                                       int X, int y0, int y1, MarkerState* ms, int slab, uint8_t* __restrict__ prev) {
+                                                       int X, int y0, int y1, MarkerState* ms, int slab, uint8_t* __restrict__ prev,
+                                                       uint8_t* __restrict__ tmap, int tnx, int tn, int known, int known_touch) {
   __shared__ uint8_t tile[64][65];
-  const int H = y1 - y0, xb = blockIdx.x * 64, yb = blockIdx.y * 64;
+  const int bx = (int)blockIdx.x, by = (int)blockIdx.y;      // (tiles along a diagonal - the column-major side's power-of-two strides - measured: no difference)
+  const int H = y1 - y0, xb = bx * 64, yb = by * 64;
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int k = w; k < 64; k += 4) {                       // column xb + k, rows yb + l
-    const int x = xb + k, yr = yb + l;
-    const bool in = x < X && yr < H;
-    const unsigned int c = in ? count32[(size_t)x * H + yr] : 0u;
-    tile[k][l] = (uint8_t)c;   // g_marker_count is uint8_t and wraps (main.c:96,114)
-    if (FOLD && c != 0u) count32[(size_t)x * H + yr] = 0u;
-  }
-  __syncthreads();
-  for (int k = w; k < 64; k += 4) {                       // row yb + k, columns xb + l
-    const int x = xb + l, yr = yb + k;
-    if (x < X && yr < H) {
-      const size_t i = (size_t)(y0 + yr) * X + x;
-      if (FOLD) prev[i] = count[i];
-      count[i] = tile[l][k];
+  bool nz = false;
+  // (FOLD, the tile map: no water in the tile at the last refresh and no marker has entered it since - its counters are the zeros the last refresh left)
+  const bool dry = FOLD && known && known_touch && tmap[by * tnx + bx] == 0 && tmap[2 * tn + by * tnx + bx] == 0;
+  if (!dry)
+    for (int k = w; k < 64; k += 4) {                     // column xb + k, rows yb + l
+      const int x = xb + k, yr = yb + l;
+      const bool in = x < X && yr < H;
+      const unsigned int c = in ? count32[(size_t)x * H + yr] : 0u;
+      tile[k][l] = (uint8_t)c;   // g_marker_count is uint8_t and wraps (main.c:96,114)
+      if (FOLD && c != 0u) { count32[(size_t)x * H + yr] = 0u; nz = true; }
     }
+  if (!FOLD) {
+    __syncthreads();
+    for (int k = w; k < 64; k += 4) {                     // row yb + k, columns xb + l
+      const int x = xb + l, yr = yb + k;
+      if (x < X && yr < H) count[(size_t)(y0 + yr) * X + x] = tile[l][k];
+    }
+  } else {
+    // the tile map (euler_dev.h; the workgroup's tile IS a tile of the map: y0 = 0 on whole-grid handles): `known` - the flags describe the two grids as they stand;
+    // a tile that held no water in either and receives none has nothing to move (its count and prev_count cells are the zeros they would get)
+    const int t = by * tnx + bx;
+    const int had = known ? (int)tmap[t] : 1, had_prev = known ? (int)tmap[tn + t] : 1;
+    const int now = __syncthreads_or(nz ? 1 : 0);         // (a counter that wrapped to a multiple of 256 still sets the flag: a superset)
+    bool oz = false;
+    if (had | had_prev | now)
+      for (int k = w; k < 64; k += 4) {                   // row yb + k, columns xb + l
+        const int x = xb + l, yr = yb + k;
+        if (x < X && yr < H) {
+          const size_t i = (size_t)(y0 + yr) * X + x;
+          const uint8_t oc = had ? count[i] : (uint8_t)0;
+          oz = oz || oc != 0;
+          if (had | had_prev) prev[i] = oc;
+          if (had | now) count[i] = tile[l][k];
+        }
+      }
+    const int was = known ? had : __syncthreads_or(oz ? 1 : 0);      // (`known` is uniform over the launch)
+    if (threadIdx.x == 0) { tmap[tn + t] = (uint8_t)(was != 0); tmap[t] = (uint8_t)(now != 0); tmap[2 * tn + t] = 0; }
   }
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     if (slab) { ms->n -= ms->n_del_glob; ms->n_loc -= ms->n_rm; }
@@ -702,7 +742,7 @@ int eu_marker_rotate_counts(euler_sim* S) {
 }
 int eu_marker_narrow_counts(euler_sim* S) {
   LAUNCH(S, KC_MARKER_BIN, k_narrow_counts<false>, dim3((S->X + 63) / 64, (S->win_hi - S->win_lo + 63) / 64), dim3(256), S->count, S->count32, S->X,
-         S->win_lo, S->win_hi, S->ms, S->slab_on, (uint8_t*)nullptr);
+         S->win_lo, S->win_hi, S->ms, S->slab_on, (uint8_t*)nullptr, (uint8_t*)nullptr, 0, 0, 0, 0);
   return EULER_OK;
 }
 int eu_marker_advect_a(euler_sim* S, float dt, unsigned long long n) {
@@ -714,7 +754,7 @@ int eu_marker_advect_a(euler_sim* S, float dt, unsigned long long n) {
 int eu_marker_advect_b(euler_sim* S, unsigned long long n, const unsigned int* keys) {
   GridRef g{S->X, S->Y, S->count, S->interp_lim[0], S->interp_lim[1], S->interp_lim[2], S->interp_lim[3]};
   LAUNCH(S, KC_MARKER_ADVECT, (k_advect_markers_b<false, false>), dim3(eu_blocks((size_t)n, 256, 4096)), dim3(256), S->markers[S->cur], S->markers[S->cur ^ 1], S->u, S->v, S->solid, g, n,
-         S->act_idx, S->act_dt, S->ms, keys, (const uint8_t*)nullptr, (unsigned int*)nullptr, (unsigned long long*)nullptr, 0);
+         S->act_idx, S->act_dt, S->ms, keys, (const uint8_t*)nullptr, (unsigned int*)nullptr, (unsigned long long*)nullptr, 0, (uint8_t*)nullptr, 0);
   return EULER_OK;
 }
 
@@ -722,6 +762,7 @@ int eu_launch_refresh_counts(euler_sim* S) {      // (whole-grid handles; row sl
   const unsigned long long n = S->n_markers_host;
   unsigned long long* delmask = S->evmask;
   int rc;
+  const int touch_known = S->prebin_valid && S->opt[EULER_OPT_NO_TILE_MAP] == 0;      // (k_advect_bin_a2 / pass B marked every tile a marker entered)
   if (S->prebin_valid) delmask = S->delmask;      // the advection pass in front binned what it wrote (k_advect_bin_a2): the counters and the delete ballot stand
   else {
     if ((rc = eu_blocked_current(S)) || (rc = eu_count32_clean(S))) return rc;
@@ -734,7 +775,8 @@ int eu_launch_refresh_counts(euler_sim* S) {      // (whole-grid handles; row sl
   LAUNCH(S, KC_MARKER_COMPACT, k_compact_markers, dim3(256), dim3(256), S->markers[S->cur], S->sel_idx, delmask, S->ms);
   // prev <- cur, cur <- the counters, the counters <- 0
   LAUNCH(S, KC_MARKER_BIN, k_narrow_counts<true>, dim3((S->X + 63) / 64, (S->win_hi - S->win_lo + 63) / 64), dim3(256), S->count, S->count32, S->X,
-         S->win_lo, S->win_hi, S->ms, 0, S->prev_count);
+         S->win_lo, S->win_hi, S->ms, 0, S->prev_count, S->tmap, S->tmap_nx, S->tmap_n, S->tmap_valid, touch_known);
+  S->tmap_valid = 1;      // (both maps are what this pass saw; euler_set_option(EULER_OPT_NO_TILE_MAP) only stops the READERS)
   S->count32_dirty = 0;
   return EULER_OK;
 }
@@ -789,7 +831,7 @@ __global__ __launch_bounds__(256) void k_source_fill(const MarkerState* ms, cons
 
 __global__ __launch_bounds__(256) void k_source_place(float2* __restrict__ m, uint8_t* __restrict__ count,
                                                       const unsigned int* __restrict__ elig, const float* __restrict__ draws,
-                                                      const MarkerState* ms, int X) {
+                                                      const MarkerState* ms, int X, uint8_t* __restrict__ tmap, int tnx) {
   const unsigned int n_app = ms->n_append;
   const unsigned long long n0 = ms->n0_append;
   for (unsigned int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_app; k += gridDim.x * blockDim.x) {
@@ -798,6 +840,7 @@ __global__ __launch_bounds__(256) void k_source_place(float2* __restrict__ m, ui
     const float ry = draws[2 * k], rx = draws[2 * k + 1];
     m[n0 + k] = make_float2(EU_H * (x + rx), EU_H * (y + ry));
     count[c] = (uint8_t)(count[c] + 1);
+    if (tmap) tmap[(y >> 6) * tnx + (x >> 6)] = 1;      // the tile map (euler_dev.h): the tile holds water now
   }
 }
 
@@ -814,6 +857,6 @@ int eu_launch_sources(euler_sim* S) {
   LAUNCH(S, KC_SOURCES, k_source_draws, dim3(1), dim3(1), S->ms, S->rng_jump);
   eu_source_fill(S);
   LAUNCH(S, KC_SOURCES, k_source_place, dim3(eu_blocks(S->n_source_cells, 256, 2048)), dim3(256), S->markers[S->cur],
-         S->count, S->sel_idx, S->draws, S->ms, S->X);
+         S->count, S->sel_idx, S->draws, S->ms, S->X, S->slab_on ? (uint8_t*)nullptr : S->tmap, S->tmap_nx);
   return EULER_OK;
 }

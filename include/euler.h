@@ -379,6 +379,8 @@ enum {
   EULER_OPT_MARKERS_TWO_PASS = 16,  /* 1: advect_markers and refresh_marker_counts as separate passes over the marker array (rounds 1-5; A-B timing; the same bits); 0 (default): the advection pass bins what it writes */
   EULER_OPT_BUILD_TWO_PASS = 17,    /* 1: the assembly as a row-major pass + a skewed gather (rounds 3-5; A-B timing; the same bits); 0 (default): one pass over parallelograms of the band-skewed layout */
   EULER_OPT_VELOCITY_TWO_PASS = 18, /* 1: k_finish_p + k_velocity_update as in rounds 1-5 (A-B timing; the same bits); 0 (default): one pass */
+  EULER_OPT_NO_TILE_MAP = 19,       /* 1: the grid passes visit every cell as in rounds 1-5 (A-B timing; the same bits); 0 (default): tiles of 64 x 64 cells with no water in or next to them in
+                                       the count grid and the previous one are left alone by advect_u / advect_v, zero_bounds, extrapolate and the marker stage's copies (their output there is the zeros already in place) */
   EULER_OPT__COUNT
 };
 int euler_set_option(euler_sim* sim, int32_t key, int64_t value);

@@ -16,12 +16,13 @@ else:
     sim.load_text(getattr(scenarios, workload)(), upscale=True)
 if os.environ.get("EU_TWO_PASS"):      # (rounds 1-5's separate advection and binning passes)
     sim.set_option(ea.OPT_MARKERS_TWO_PASS, 1)
+if os.environ.get("EU_NO_TILE_MAP"):   # (the grid passes visit every tile)
+    sim.set_option(ea.OPT_NO_TILE_MAP, 1)
 for _ in range(3):
     sim.step()
-for _ in range(8):
-    sim.stage(ea.STAGE_ADVECT_MARKERS, 0.004)
-    sim.stage(ea.STAGE_REFRESH_COUNTS)
-    sim.stage(ea.STAGE_EXTRAPOLATE)
-    sim.stage(ea.STAGE_ADVECT_VELOCITY, 0.004)
-sim.sync()
+for _ in range(8):      # whole substeps, stage by stage (what one stage leaves for the next - the lazy flags of euler_sim - stands as in a frame)
+    dt = sim.timestep(0.1)
+    for st in (ea.STAGE_ADVECT_MARKERS, ea.STAGE_REFRESH_COUNTS, ea.STAGE_SOURCES, ea.STAGE_EXTRAPOLATE, ea.STAGE_ADVECT_VELOCITY, ea.STAGE_PROJECT):
+        sim.stage(st, dt)
+sim.get(ea.F_COUNT)      # (waits for the stream)
 print("markers", sim.stats().n_markers)

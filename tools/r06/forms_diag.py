@@ -12,7 +12,7 @@ from euler_amd import scenarios
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 a = ea.Simulation(N, N, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE).load_text(scenarios.dam_break(), upscale=True)
 b = ea.Simulation(N, N, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE).load_text(scenarios.dam_break(), upscale=True)
-for k in (ea.OPT_MARKERS_TWO_PASS, ea.OPT_BUILD_TWO_PASS, ea.OPT_VELOCITY_TWO_PASS):
+for k in (ea.OPT_MARKERS_TWO_PASS, ea.OPT_BUILD_TWO_PASS, ea.OPT_VELOCITY_TWO_PASS, ea.OPT_NO_TILE_MAP):
     b.set_option(k, 1)
 
 

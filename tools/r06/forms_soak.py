@@ -1,4 +1,4 @@
-"""Round 6 soak: rounds 1-5's stage kernels (EULER_OPT_MARKERS_TWO_PASS / _BUILD_TWO_PASS / _VELOCITY_TWO_PASS) against round 6's fused ones, two handles of one process stepping
+"""Round 6 soak: rounds 1-5's stage kernels (EULER_OPT_MARKERS_TWO_PASS / _BUILD_TWO_PASS / _VELOCITY_TWO_PASS / _NO_TILE_MAP) against round 6's fused ones, two handles of one process stepping
 side by side for hundreds of frames - the same bits in u, v, the count grids, the marker array and the pressure at every checkpoint.  (The test suite does this for 30-40 frames;
 the lean zero_bounds and the velocity update's skipped zero stores rest on an invariant - every sample without the fluid property, every wall's sample is zero at the end of
 a substep - that a long run with sources, sinks and splashes exercises far more.)
@@ -23,7 +23,7 @@ CASES = [("waterfall", 640, 512, ea.PRECOND_IC0_TILE, 100), ("dam_break", 1024, 
 
 def digest(sim):
     h = hashlib.sha1()
-    for f in (ea.F_U, ea.F_V, ea.F_COUNT, ea.F_PREV_COUNT, ea.F_MARKERS, ea.F_PRESSURE):
+    for f in (ea.F_U, ea.F_V, ea.F_UTMP, ea.F_VTMP, ea.F_COUNT, ea.F_PREV_COUNT, ea.F_MARKERS, ea.F_PRESSURE):
         h.update(np.ascontiguousarray(sim.get(f)).tobytes())
     return h.hexdigest()[:16]
 
@@ -32,7 +32,7 @@ for scn, X, Y, precond, maxit in CASES:
     kw = dict(precond=precond, dot_mode=ea.DOT_TREE, max_iterations=maxit)
     a = ea.Simulation(X, Y, **kw).load_text(getattr(scenarios, scn)(), upscale=True)
     b = ea.Simulation(X, Y, **kw).load_text(getattr(scenarios, scn)(), upscale=True)
-    for key in (ea.OPT_MARKERS_TWO_PASS, ea.OPT_BUILD_TWO_PASS, ea.OPT_VELOCITY_TWO_PASS):
+    for key in (ea.OPT_MARKERS_TWO_PASS, ea.OPT_BUILD_TWO_PASS, ea.OPT_VELOCITY_TWO_PASS, ea.OPT_NO_TILE_MAP):
         b.set_option(key, 1)
     t0 = time.perf_counter()
     checks, first_diff = 0, None
