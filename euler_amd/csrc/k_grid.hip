@@ -263,6 +263,7 @@ __global__ __launch_bounds__(256) void k_advect_velocity(const float* __restrict
     const int y = y0 + ((int)blockIdx.y * rep + r) * 4 + (int)(threadIdx.x >> 6);
     if (y >= y1) return;
     const size_t i = (size_t)y * X + x;
+    // (both faces' interpolations issued together - the v face not waiting for the u face - measured: no difference; the pass is bound by the number of its gathers)
     if (x < X - 1) {
       float out = 0.f;
       if (eu_prop_u(g.count, i) && !eu_prop_u(solid, i)) {
