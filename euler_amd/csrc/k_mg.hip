@@ -229,36 +229,71 @@ __device__ __forceinline__ double mg_w1(int Jc, int j, int fn, int cn) {
   if (j == 2 * Jc + 1) return Jc + 1 <= cn - 1 ? 0.5 : 1.0;      // (the last fine node, odd, without a node to its right: constant)
   return 0.0;
 }
-// A_(l+1) = P^T A_l P, a thread per node of level l + 1 and stencil entry: entry q of node (I, J) = sum over the fine nodes m under (I, J) and the fine nodes n under the
-// coarse neighbour (I, J) + q of w(m) A_l[m, n] w(n) - at most 3 x 3 x 3 x 3 terms, walked in a fixed order
-// (rows [r0, r1) of the coarse level)
+// A_(l+1) = P^T A_l P, per node of level l + 1 and stencil entry: entry q of node (I, J) = sum over the fine nodes m under (I, J) and the fine nodes n under the
+// coarse neighbour (I, J) + q of w(m) A_l[m, n] w(n) - at most 3 x 3 x 3 x 3 terms, walked in a fixed order (rows [r0, r1) of the coarse level).
+// A workgroup takes MGC_TI x MGC_TJ coarse nodes: the nine entries of the (2 TI + 1) x (2 TJ + 1) fine nodes under them come into LDS row by row (coalesced; the one-thread-per-
+// entry form of rounds 4-5 read every fine entry up to nine times at a stride of two nodes: 654 us per solve at 16384^2, six times its bytes' worth), the sums are formed
+// from there - the same terms in the same order, a thread per (node, entry) - and leave through LDS as rows of one entry.
+#define MGC_TI 8
+#define MGC_TJ 16
+#define MGC_PH (2 * MGC_TI + 1)
+#define MGC_PW (2 * MGC_TJ + 1)
 __global__ __launch_bounds__(256) void k_mg_coarsen(const double* __restrict__ af, int fnx, int fny, double* __restrict__ ac, int cnx, int cny, const PcgScalars* sc, int r0, int r1) {
   if (!sc->nonzero) return;
-  const int tid = blockIdx.x * 256 + threadIdx.x;
-  const int p = r0 * cnx + tid / 9, q = tid % 9;
-  if (p >= r1 * cnx) return;
-  const int I = p / cnx, J = p % cnx, I2 = I + q / 3 - 1, J2 = J + q % 3 - 1;
+  __shared__ double sa[9][MGC_PH * MGC_PW];      // 40 KB
+  __shared__ double so[9][MGC_TI * MGC_TJ];      // 9 KB: [entry][node of the tile]
+  const int tilesx = (cnx + MGC_TJ - 1) / MGC_TJ;
+  const int I0 = r0 + (int)(blockIdx.x / tilesx) * MGC_TI, J0 = (int)(blockIdx.x % tilesx) * MGC_TJ;
+  const int fi0 = 2 * I0 - 1, fj0 = 2 * J0 - 1;
   const size_t fn = (size_t)fnx * fny, cn = (size_t)cnx * cny;
-  double acc = 0.0;
-  if (I2 >= 0 && I2 < cny && J2 >= 0 && J2 < cnx) {
-    for (int dy = -1; dy <= 1; ++dy)
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int mi = 2 * I + dy, mj = 2 * J + dx;
-        const double wM = mg_w1(I, mi, fny, cny) * mg_w1(J, mj, fnx, cnx);
-        if (wM == 0.0) continue;
-        const size_t m = (size_t)mi * fnx + mj;
-        for (int ey = -1; ey <= 1; ++ey) {
-          const double wy = mg_w1(I2, mi + ey, fny, cny);
-          if (wy == 0.0) continue;
-          for (int ex = -1; ex <= 1; ++ex) {
-            const double wN = wy * mg_w1(J2, mj + ex, fnx, cnx);
-            if (wN != 0.0) acc += wM * af[(size_t)((ey + 1) * 3 + ex + 1) * fn + m] * wN;
-          }
-        }
-      }
+  for (int k = threadIdx.x; k < 9 * MGC_PH * MGC_PW; k += 256) {
+    const int e = k / (MGC_PH * MGC_PW), c = k % (MGC_PH * MGC_PW), mi = fi0 + c / MGC_PW, mj = fj0 + c % MGC_PW;
+    sa[e][c] = (mi >= 0 && mi < fny && mj >= 0 && mj < fnx) ? af[(size_t)e * fn + (size_t)mi * fnx + mj] : 0.0;      // (beyond the level: +0, and its weight is 0)
   }
-  ac[(size_t)q * cn + p] = acc;
+  __syncthreads();
+#pragma unroll 1
+  for (int k = threadIdx.x; k < 9 * MGC_TI * MGC_TJ; k += 256) {
+    const int node = k / 9, q = k % 9;
+    const int I = I0 + node / MGC_TJ, J = J0 + node % MGC_TJ, I2 = I + q / 3 - 1, J2 = J + q % 3 - 1;
+    double acc = 0.0;
+    if (I < r1 && J < cnx && I2 >= 0 && I2 < cny && J2 >= 0 && J2 < cnx) {
+      // The weights once per thread - of the fine rows 2 I + dy on node I (wmy) and, for dy + ey = -2 .. 2, on the neighbour I2 (wny); the same along x; wn = wny wnx - instead
+      // of one mg_w1 per term, and EVERY term added: the oracle's mg_build skips the terms whose weight is 0, which are +-0 here (the entries are finite) and leave a sum that
+      // started from +0 as it is - the same bits without 81 branches around 81 LDS reads (the pass was bound by exactly that: 654 -> 290 us per solve at 16384^2).
+      double wmy[3], wmx[3], wny[5], wnx[5];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { wmy[d] = mg_w1(I, 2 * I + d - 1, fny, cny); wmx[d] = mg_w1(J, 2 * J + d - 1, fnx, cnx); }
+#pragma unroll
+      for (int d = 0; d < 5; ++d) { wny[d] = mg_w1(I2, 2 * I + d - 2, fny, cny); wnx[d] = mg_w1(J2, 2 * J + d - 2, fnx, cnx); }
+      const int m0 = (2 * I - fi0) * MGC_PW + (2 * J - fj0);
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          const double wM = wmy[dy + 1] * wmx[dx + 1];
+          const int m = m0 + dy * MGC_PW + dx;
+          double a[9];
+#pragma unroll
+          for (int e = 0; e < 9; ++e) a[e] = sa[e][m];
+#pragma unroll
+          for (int ey = -1; ey <= 1; ++ey)
+#pragma unroll
+            for (int ex = -1; ex <= 1; ++ex) {
+              const double wN = wny[dy + ey + 2] * wnx[dx + ex + 2];
+              acc += wM * a[(ey + 1) * 3 + ex + 1] * wN;
+            }
+        }
+    }
+    so[q][node] = acc;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 9 * MGC_TI * MGC_TJ; k += 256) {      // rows of MGC_TJ consecutive nodes of one entry
+    const int q = k / (MGC_TI * MGC_TJ), node = k % (MGC_TI * MGC_TJ), I = I0 + node / MGC_TJ, J = J0 + node % MGC_TJ;
+    if (I < r1 && J < cnx) ac[(size_t)q * cn + (size_t)I * cnx + J] = so[q][node];
+  }
 }
+// (launch: one workgroup per tile of the coarse rows [r0, r1))
+static inline unsigned mg_coarsen_blocks(int cnx, int r0, int r1) { return (unsigned)(((cnx + MGC_TJ - 1) / MGC_TJ) * ((r1 - r0 + MGC_TI - 1) / MGC_TI)); }
 
 // ------------------------------------------------------------------------------------------ per iteration: the cycle
 struct MgRect { int i0, i1, j0, j1; };      // rows [i0, i1) x columns [j0, j1)
@@ -1674,7 +1709,7 @@ static int mg_setup_split(euler_sim* S, MgSplitState* st) {
     const size_t n = (size_t)nx * ny;
     if (l > 0) {
       const size_t cnt = (size_t)9 * (o1 - o0) * nx;
-      if (cnt) LAUNCH(S, KC_PRECON_FACTOR, k_mg_coarsen, dim3((unsigned)((cnt + 255) / 256)), dim3(256), S->mg_a + 9 * S->mg_off[l - 1], S->mg_nx[l - 1], S->mg_ny[l - 1], a, nx, ny, S->sc, o0, o1);
+      if (cnt) LAUNCH(S, KC_PRECON_FACTOR, k_mg_coarsen, dim3(mg_coarsen_blocks(nx, o0, o1)), dim3(256), S->mg_a + 9 * S->mg_off[l - 1], S->mg_nx[l - 1], S->mg_ny[l - 1], a, nx, ny, S->sc, o0, o1);
     }
     if (l == Lg) break;
     // the rows either neighbour needs of this rank / this rank of them: MG_SETUP_HALO owned rows; level 0 one more - the shared row across the boundary, as a share
@@ -1700,7 +1735,7 @@ static int mg_setup_split(euler_sim* S, MgSplitState* st) {
     hipLaunchKernelGGL(k_mg_sten_gathered, dim3((unsigned)((9 * n + 255) / 256)), dim3(256), 0, S->stream, a, n, nx, st->abuf, st->aslot, W);
   }
   for (int l = Lg + 1; l < S->mg_levels; ++l)
-    LAUNCH(S, KC_PRECON_FACTOR, k_mg_coarsen, dim3((unsigned)((9 * (size_t)S->mg_nx[l] * S->mg_ny[l] + 255) / 256)), dim3(256), S->mg_a + 9 * S->mg_off[l - 1], S->mg_nx[l - 1], S->mg_ny[l - 1],
+    LAUNCH(S, KC_PRECON_FACTOR, k_mg_coarsen, dim3(mg_coarsen_blocks(S->mg_nx[l], 0, S->mg_ny[l])), dim3(256), S->mg_a + 9 * S->mg_off[l - 1], S->mg_nx[l - 1], S->mg_ny[l - 1],
            S->mg_a + 9 * S->mg_off[l], S->mg_nx[l], S->mg_ny[l], S->sc, 0, S->mg_ny[l]);
   int i0 = st->O[0][me][0] - MG_SETUP_HALO, i1 = st->O[0][me][1] + MG_SETUP_HALO;
   if (i0 < 0) i0 = 0;
@@ -1721,7 +1756,7 @@ int eu_mg_setup(euler_sim* S) {
   // exact in any order, so ONE all-reduce makes A_0 whole and bit-identical everywhere (the split cycle, above, exchanges rows with the neighbours instead)
   if (S->has_comm) COMM_CALL(S->bulk.allreduce(S->bulk.ctx, S->mg_a, (int32_t)(9 * n0), 0));
   for (int l = 1; l < S->mg_levels; ++l)
-    LAUNCH(S, KC_PRECON_FACTOR, k_mg_coarsen, dim3((unsigned)((9 * (size_t)S->mg_nx[l] * S->mg_ny[l] + 255) / 256)), dim3(256), S->mg_a + 9 * S->mg_off[l - 1], S->mg_nx[l - 1], S->mg_ny[l - 1],
+    LAUNCH(S, KC_PRECON_FACTOR, k_mg_coarsen, dim3(mg_coarsen_blocks(S->mg_nx[l], 0, S->mg_ny[l])), dim3(256), S->mg_a + 9 * S->mg_off[l - 1], S->mg_nx[l - 1], S->mg_ny[l - 1],
            S->mg_a + 9 * S->mg_off[l], S->mg_nx[l], S->mg_ny[l], S->sc, 0, S->mg_ny[l]);
   hipLaunchKernelGGL(k_mg_inner0, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, S->stream, mg_hier(S), S->mg_inner0, (size_t)0, n0);
   // omega / diagonal per node of every level below the dense one: the cycle's Jacobi steps multiply

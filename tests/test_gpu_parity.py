@@ -503,6 +503,41 @@ def test_marker_stages_random_stress_bit_exact(shape, seed, n, solid_frac, form)
     assert st.n_markers < n                     # deletions happened
 
 
+def test_markers_entering_tiles_without_water_are_counted():
+    """The tile map (round 6): k_narrow_counts<true> reads the counters of a 64 x 64 tile only if the tile held water at the last refresh or a marker has ENTERED it since
+    (k_advect_bin_a2 marks the tile of a marker's new cell when it differs from the old one's).  A block of markers that drifts out of its tile into three empty ones, a
+    cell per substep: counts, previous counts and the marker array against the oracle after every stage - and the empty tiles do fill."""
+    X2, Y2 = 333, 257
+    rng = np.random.default_rng(11)
+    solid = np.zeros((Y2, X2), np.uint8)
+    sink = np.zeros((Y2, X2), np.uint8)
+    sink[0, :] = sink[-1, :] = sink[:, 0] = sink[:, -1] = 1
+    n = 12000
+    m = np.empty((n, 2), np.float32)
+    m[:, 0] = np.float32(66) + rng.random(n, dtype=np.float32) * np.float32(61.9)      # the tile of columns / rows 64 .. 127 only
+    m[:, 1] = np.float32(66) + rng.random(n, dtype=np.float32) * np.float32(61.9)
+    u = (3.0 + rng.random((Y2, X2))).astype(np.float32)
+    v = (2.0 + rng.random((Y2, X2))).astype(np.float32)
+    u[:, -1] = 0
+    v[-1, :] = 0
+    o, sim = _load_both(X2, Y2, solid, sink, m, u, v)
+    assert o.count[64:128, 64:128].sum() == n and o.count.sum() == n
+    for rep in range(45):
+        dt = sim.timestep(0.1)
+        assert dt == o.timestep(0.1)
+        sim.stage(ea.STAGE_ADVECT_MARKERS, dt)
+        o.lib.eo_advect_markers(o.ptr, np.float32(dt))
+        sim.stage(ea.STAGE_REFRESH_COUNTS)
+        o.lib.eo_refresh_marker_counts(o.ptr)
+        assert_bits(sim.get(ea.F_COUNT), o.count, "count rep %d" % rep)
+        assert_bits(sim.get(ea.F_PREV_COUNT), o.prev_count, "prev_count rep %d" % rep)
+        if rep % 9 == 0:
+            assert_bits(sim.get(ea.F_MARKERS), o.markers, "markers rep %d" % rep)
+    c = sim.get(ea.F_COUNT)
+    assert c[64:128, 128:192].sum() > 100 and c[128:192, 64:128].sum() > 100 and c[128:192, 128:192].sum() > 0, "the block should have drifted into the tiles beside it"
+    assert sim.stats().n_markers == o.n_markers == n
+
+
 def test_marker_count_wraps_like_uint8():
     """g_marker_count is uint8_t and simply wraps (main.c:96,114): 300 markers in one cell read 44."""
     X2, Y2 = 64, 64
