@@ -13,6 +13,8 @@ Records (tests/test_gpu_tile_precond.py::test_multilevel_mode_at_baseline_sizes_
   half_tank_8192_mg   the same at 8192^2: BASELINE configs[2]'s grid
   dam_break_2048_mg   the 2048^2 dam break (configs[1] / [3]'s scenario), free-running from frame 0; the block falls freely for most of a hundred frames (the solves that happen
                       on the way work on rounding noise, max p ~ 1e-4), the record holds the first FRAMES_AFTER frames from the impact on (max p > IMPACT_P)
+  dam_break_1024_f32  NOT the multilevel mode: configs[1] as named ("fp32") - the oracle's float restatement of the capped tile-local solve (eo_sim.pcg_f32) at 1024^2, the first
+                      three frames whose solves run into the cap (tests/test_gpu_resident.py::test_f32_variant_at_configs1_size_against_the_recorded_oracle_restatement)
 The file also carries the SHA-1 of oracle/euler_oracle.c it was generated from (tests/test_trajectories.py compares it with the source on every CPU run)."""
 import hashlib
 import os
@@ -90,7 +92,33 @@ def rec_dam_break(out, N=2048):
     o.close()
 
 
-RECS = {"half_tank_4096_mg": rec_half_tank, "half_tank_8192_mg": lambda out: rec_half_tank(out, 8192), "dam_break_2048_mg": rec_dam_break}
+def rec_f32_dam_break(out, N=1024, frames_after=3):
+    """BASELINE configs[1] "fp32" at its own size: the oracle's FLOAT restatement of the tile-local solve (eo_sim.pcg_f32: every operation rounded to float, sums in double;
+    the reference's cap of 100 iterations), free-running from frame 0; the record holds the first frames whose solves run into the cap (the block has landed)."""
+    from euler_amd import scenarios
+    o = Oracle(N, N)
+    o.c.tile_records = 16
+    o.c.pcg_f32 = 1
+    o.load_text(scenarios.dam_break(), upscale=True)
+    frames, got = 0, []
+    while len(got) < frames_after and frames < 200:
+        t0 = time.perf_counter()
+        o.step()
+        frames += 1
+        print("  dam_break_%d_f32 frame %d: %d substeps, %d iterations, %.1f s" % (N, frames, o.c.last_substeps, o.c.last_pcg_iterations, time.perf_counter() - t0), flush=True)
+        if got or o.c.last_pcg_iterations >= 100:
+            p = o.p
+            got.append((frames, o.c.last_substeps, o.c.last_pcg_iterations, float(np.abs(p).max()), o.n_markers, int((o.count > 0).sum()), float(np.abs(o.u).max()), float(np.abs(o.v).max()),
+                        sample(p), sample(o.u), sample(o.v)))
+    assert len(got) == frames_after
+    out["dam_break_%d_f32.scalars" % N] = np.array([g[:8] for g in got], np.float64)
+    out["dam_break_%d_f32.p" % N] = np.stack([g[8] for g in got])
+    out["dam_break_%d_f32.u" % N] = np.stack([g[9] for g in got])
+    out["dam_break_%d_f32.v" % N] = np.stack([g[10] for g in got])
+    o.close()
+
+
+RECS = {"half_tank_4096_mg": rec_half_tank, "half_tank_8192_mg": lambda out: rec_half_tank(out, 8192), "dam_break_2048_mg": rec_dam_break, "dam_break_1024_f32": rec_f32_dam_break}
 
 
 def main():

@@ -146,6 +146,41 @@ def test_f32_gpu_against_the_oracle_float_restatement():
     assert np.array_equal(sim.get(ea.F_PRESSURE), sim.get(ea.F_PRESSURE).astype(np.float32).astype(np.float64))      # p holds float values
 
 
+def test_f32_variant_at_configs1_size_against_the_recorded_oracle_restatement():
+    """BASELINE configs[1] as named (1024^2 dam break, "fp32") against the ORACLE's float restatement at that size (eo_sim.pcg_f32), recorded in the build container
+    (tests/golden/mg_records.npz `dam_break_1024_f32`, make_mg_records.py: 30 s of one core): both free-running from frame 0, compared on the first three frames whose solves run
+    into the reference's cap (the block has landed: frames 23 - 25).  The two differ in the order of their dot products only, which a float solve amplifies: the same substep and
+    marker counts, iteration counts within 5 %, max |p| and the pressure, u, v on a 64 x 64 sample grid within 2e-3 of their maxima (the variant's stated tolerance is 1e-3 per
+    frame), the number of fluid cells within 1e-4."""
+    import os
+    from golden_util import GOLDEN
+    from test_gpu_parity import mg_sample
+    with np.load(os.path.join(GOLDEN, "mg_records.npz")) as z:
+        sc, ps, us, vs = (z["dam_break_1024_f32." + k] for k in ("scalars", "p", "u", "v"))
+    N = 1024
+    sim = ea.Simulation(N, N, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE, pcg_precision=ea.PCG_F32).load_text(scenarios.dam_break(), upscale=True)
+    k, dev = 0, []
+    for frame in range(1, int(sc[-1][0]) + 1):
+        sim.step()
+        if frame != int(sc[k][0]):
+            continue
+        fr, nsub, its, pmax, nmark, nfluid, umax, vmax = sc[k]
+        st = sim.stats()
+        p, u, v = sim.get(ea.F_PRESSURE), sim.get(ea.F_U), sim.get(ea.F_V)
+        dev.append((frame, st.last_substeps - int(nsub), st.last_pcg_iterations, int(its), st.n_markers - int(nmark), int((sim.get(ea.F_COUNT) > 0).sum()) - int(nfluid),
+                    float(np.abs(p).max() / pmax - 1.0), float(np.abs(mg_sample(p) - ps[k]).max() / pmax),
+                    float(max(np.abs(mg_sample(u) - us[k]).max(), np.abs(mg_sample(v) - vs[k]).max()) / max(umax, vmax))))
+        k += 1
+    print(dev)
+    assert k == len(sc) == 3
+    for frame, dsub, it, it_o, dmark, dfluid, dpm, dp, duv in dev:
+        assert dsub == 0 and dmark == 0, dev
+        assert abs(it - it_o) <= 0.05 * it_o + 3 and abs(dfluid) <= 1e-4 * nfluid + 2, dev
+        assert abs(dpm) <= 2e-3 and dp <= 2e-3 and duv <= 2e-3, dev
+    assert sim.resident_info()[1] > 0 and sim.resident_info()[2] == 0      # (the one-launch solver ran them)
+    sim.close()
+
+
 def test_a_scene_that_outgrows_the_chip_moves_to_the_multi_kernel_path():
     """The resident launch is sized from the PREVIOUS solve's active chunks (no host round trip in front of it); a solve that does not fit after all says so on the
     device (error word 2), is redone with the multi-kernel path, and the following ones go there directly.  Driven here by a capacity of 8 workgroups (32 chunks,
