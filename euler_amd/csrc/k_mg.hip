@@ -133,9 +133,66 @@ void eu_mg_release(euler_sim* S) {
 #define MG_WIN_R (MG_RPB + 2)                 // node rows a band's 64 rows touch
 #define MG_WIN_C (80 / MG_G0 + 2)             // node columns a tile's 79 columns touch (8: 12, 16: 7)
 #define MG_WIN (MG_WIN_R * MG_WIN_C * 9)
+// one tile's sums into the wave's window.  SYNTH: every cell deep inside the water (CM_INTERIOR) - no mask is read
+template <bool SYNTH>
+__device__ __forceinline__ void mg_tile_window(int* win, const uint8_t* __restrict__ mask, const SkewGeom& g, int lane, int band, int k, int nx0, int ny0) {
+  const size_t base = ((size_t)band * g.TS + (size_t)k * 16) * 64 + 2 * lane;
+  // the lane's row against the node rows (weights in 1 / G0)
+  const int uy = 64 * band + lane - MG_G0 / 2, I0 = uy >> MG_LOG;
+  int wy0 = MG_G0 - (uy & (MG_G0 - 1)), wy1 = uy & (MG_G0 - 1);
+  if (I0 < 0) { wy0 = 0; wy1 = MG_G0; }
+  if (I0 >= ny0 - 1) { wy0 = MG_G0; wy1 = 0; }
+  const bool vert_ok = I0 >= 0 && I0 <= ny0 - 2;
+  const int Jb = (16 * k - lane - MG_G0 / 2) >> MG_LOG;      // node interval of the lane's first column
+  int H[MG_NSEG], C[MG_NSEG][3], V[MG_NSEG][3];
+#pragma unroll
+  for (int m = 0; m < MG_NSEG; ++m) { H[m] = 0; C[m][0] = C[m][1] = C[m][2] = 0; V[m][0] = V[m][1] = V[m][2] = 0; }
+#pragma unroll
+  for (int P = 0; P < 8; ++P) {
+    const unsigned int mm = SYNTH ? (unsigned int)(CM_INTERIOR | (CM_INTERIOR << 8)) : (unsigned int)*reinterpret_cast<const unsigned short*>(mask + base + P * 128);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const unsigned int cm = (mm >> (8 * h)) & 0xff;
+      if (!(cm & CM_FLUID)) continue;
+      const int ux = 16 * k + 2 * P + h - lane - MG_G0 / 2, J0 = ux >> MG_LOG;
+      int w0 = MG_G0 - (ux & (MG_G0 - 1)), w1 = ux & (MG_G0 - 1);
+      if (J0 < 0) { w0 = 0; w1 = MG_G0; }
+      if (J0 >= nx0 - 1) { w0 = MG_G0; w1 = 0; }
+      const int cp = (int)(cm >> CM_DIAG_SHIFT) - __popc(cm & (CM_RIGHT | CM_UP | CM_LEFT | CM_DOWN));
+      const int hh = ((cm & CM_RIGHT) && J0 >= 0 && J0 <= nx0 - 2) ? 1 : 0;
+      const int vv = (cm & CM_UP) ? 1 : 0;
+      const int q00 = w0 * w0, q01 = w0 * w1, q11 = w1 * w1;
+#pragma unroll
+      for (int m = 0; m < MG_NSEG; ++m)
+        if (J0 - Jb == m) { H[m] += hh; C[m][0] += cp * q00; C[m][1] += cp * q01; C[m][2] += cp * q11; V[m][0] += vv * q00; V[m][1] += vv * q01; V[m][2] += vv * q11; }
+    }
+  }
+  const int rI0 = I0 - (MG_RPB * band - 1);
+  const int cbase = (16 * k - 63 - MG_G0 / 2) >> MG_LOG;      // the window's first node column
+#pragma unroll
+  for (int sg = 0; sg < MG_NSEG; ++sg) {
+    const int cJ0 = Jb + sg - cbase;
+    const int Mx[2][2] = {{C[sg][0] + H[sg], C[sg][1] - H[sg]}, {C[sg][1] - H[sg], C[sg][2] + H[sg]}};
+    const int Vx[2][2] = {{V[sg][0], V[sg][1]}, {V[sg][1], V[sg][2]}};
+    const int wy[2] = {wy0, wy1};
+#pragma unroll
+    for (int ra = 0; ra < 2; ++ra)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int ca = 0; ca < 2; ++ca)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            int val = wy[ra] * wy[rb] * Mx[ca][cb];
+            if (vert_ok) val += (ra == rb ? 1 : -1) * Vx[ca][cb];
+            if (val != 0) atomicAdd(&win[((rI0 + ra) * MG_WIN_C + cJ0 + ca) * 9 + (rb - ra + 1) * 3 + (cb - ca + 1)], val);
+          }
+  }
+}
 __global__ __launch_bounds__(256) void k_mg_assemble0(const uint8_t* __restrict__ mask, SkewGeom g, const unsigned int* __restrict__ list, const PcgScalars* sc,
                                                       int band_lo, int nx0, int ny0, unsigned long long* __restrict__ a0i) {
   __shared__ int s_win[4][MG_WIN];
+  __shared__ int s_deep[MG_WIN];      // the window of a tile deep inside the water, away from the outermost nodes: the same integers whatever the tile (round 6)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int* win = s_win[wv];
   for (int e = lane; e < MG_WIN; e += 64) win[e] = 0;
@@ -144,67 +201,33 @@ __global__ __launch_bounds__(256) void k_mg_assemble0(const uint8_t* __restrict_
   const int ntb = g.T / 16, todo = (int)sc->n_chunks;
   const int n_waves = gridDim.x * 4;
   const size_t n0 = (size_t)nx0 * ny0;
-  for (int w = blockIdx.x * 4 + wv; w < todo; w += n_waves) {
-    const int tile = (int)(list[w] & ~EU_CHUNK_INTERIOR);
-    const int band = band_lo + tile / ntb, k = tile % ntb;
-    const size_t base = ((size_t)band * g.TS + (size_t)k * 16) * 64 + 2 * lane;
-    // the lane's row against the node rows (weights in 1 / G0)
-    const int uy = 64 * band + lane - MG_G0 / 2, I0 = uy >> MG_LOG;
-    int wy0 = MG_G0 - (uy & (MG_G0 - 1)), wy1 = uy & (MG_G0 - 1);
-    if (I0 < 0) { wy0 = 0; wy1 = MG_G0; }
-    if (I0 >= ny0 - 1) { wy0 = MG_G0; wy1 = 0; }
-    const bool vert_ok = I0 >= 0 && I0 <= ny0 - 2;
-    const int Jb = (16 * k - lane - MG_G0 / 2) >> MG_LOG;      // node interval of the lane's first column
-    int H[MG_NSEG], C[MG_NSEG][3], V[MG_NSEG][3];
-#pragma unroll
-    for (int m = 0; m < MG_NSEG; ++m) { H[m] = 0; C[m][0] = C[m][1] = C[m][2] = 0; V[m][0] = V[m][1] = V[m][2] = 0; }
-#pragma unroll
-    for (int P = 0; P < 8; ++P) {
-      const unsigned int mm = *reinterpret_cast<const unsigned short*>(mask + base + P * 128);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const unsigned int cm = (mm >> (8 * h)) & 0xff;
-        if (!(cm & CM_FLUID)) continue;
-        const int ux = 16 * k + 2 * P + h - lane - MG_G0 / 2, J0 = ux >> MG_LOG;
-        int w0 = MG_G0 - (ux & (MG_G0 - 1)), w1 = ux & (MG_G0 - 1);
-        if (J0 < 0) { w0 = 0; w1 = MG_G0; }
-        if (J0 >= nx0 - 1) { w0 = MG_G0; w1 = 0; }
-        const int cp = (int)(cm >> CM_DIAG_SHIFT) - __popc(cm & (CM_RIGHT | CM_UP | CM_LEFT | CM_DOWN));
-        const int hh = ((cm & CM_RIGHT) && J0 >= 0 && J0 <= nx0 - 2) ? 1 : 0;
-        const int vv = (cm & CM_UP) ? 1 : 0;
-        const int q00 = w0 * w0, q01 = w0 * w1, q11 = w1 * w1;
-#pragma unroll
-        for (int m = 0; m < MG_NSEG; ++m)
-          if (J0 - Jb == m) { H[m] += hh; C[m][0] += cp * q00; C[m][1] += cp * q01; C[m][2] += cp * q11; V[m][0] += vv * q00; V[m][1] += vv * q01; V[m][2] += vv * q11; }
-      }
-    }
-    const int rI0 = I0 - (MG_RPB * band - 1);
-    const int cbase = (16 * k - 63 - MG_G0 / 2) >> MG_LOG;      // the window's first node column
-#pragma unroll
-    for (int sg = 0; sg < MG_NSEG; ++sg) {
-      const int cJ0 = Jb + sg - cbase;
-      const int Mx[2][2] = {{C[sg][0] + H[sg], C[sg][1] - H[sg]}, {C[sg][1] - H[sg], C[sg][2] + H[sg]}};
-      const int Vx[2][2] = {{V[sg][0], V[sg][1]}, {V[sg][1], V[sg][2]}};
-      const int wy[2] = {wy0, wy1};
-#pragma unroll
-      for (int ra = 0; ra < 2; ++ra)
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-          for (int ca = 0; ca < 2; ++ca)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-              int val = wy[ra] * wy[rb] * Mx[ca][cb];
-              if (vert_ok) val += (ra == rb ? 1 : -1) * Vx[ca][cb];
-              if (val != 0) atomicAdd(&win[((rI0 + ra) * MG_WIN_C + cJ0 + ca) * 9 + (rb - ra + 1) * 3 + (cb - ca + 1)], val);
-            }
-    }
+  // A tile's rows sit at 64 band + lane, its columns at 16 k + ... - lane: against nodes 8 cells apart every tile meets them at the same offsets, so an INTERIOR tile (the
+  // chunk list's top bit: every cell CM_INTERIOR) whose cells lie between the outermost nodes adds the same 1080 integers as any other - formed ONCE per workgroup here, by
+  // the very code below on a mask of CM_INTERIOR (band 2, tile 8 of a level that is wide enough for them), and flushed without reading a mask or touching the window
+  // (most of a tank: 16384^2 dam break 563 -> 475 us per solve - what is left are the ~700 memory-side adds of a tile's window).
+  if (wv == 0) {
+    mg_tile_window<true>(win, mask, g, lane, 2, 8, 1 << 20, 1 << 20);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < MG_WIN; e += 64) { s_deep[e] = win[e]; win[e] = 0; }
+  }
+  __syncthreads();
+  for (int w = blockIdx.x * 4 + wv; w < todo; w += n_waves) {
+    const unsigned int entry = list[w];
+    const int tile = (int)(entry & ~EU_CHUNK_INTERIOR);
+    const int band = band_lo + tile / ntb, k = tile % ntb;
+    // no row of the tile below node row 0 or above the last but one, no column left of node column 0 or right of the last but one (the clamps of mg_tile_window never act)
+    const bool deep = (entry & EU_CHUNK_INTERIOR) != 0 && band >= 1 && MG_RPB * band + MG_RPB - 1 <= ny0 - 2 && 16 * k - 63 - MG_G0 / 2 >= 0 && ((16 * k + 15 - MG_G0 / 2) >> MG_LOG) <= nx0 - 2;
+    if (!deep) {
+      mg_tile_window<false>(win, mask, g, lane, band, k, nx0, ny0);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    const int cbase = (16 * k - 63 - MG_G0 / 2) >> MG_LOG;      // the window's first node column
     for (int e = lane; e < MG_WIN; e += 64) {
-      const int v = win[e];
+      const int v = deep ? s_deep[e] : win[e];
       if (v == 0) continue;
-      win[e] = 0;
+      if (!deep) win[e] = 0;
       const int kk = e % 9, cJ = (e / 9) % MG_WIN_C, rI = e / (9 * MG_WIN_C);
       const int I = MG_RPB * band - 1 + rI, J = cbase + cJ;
       if (I >= 0 && I < ny0 && J >= 0 && J < nx0) atomicAdd(&a0i[(size_t)kk * n0 + (size_t)I * nx0 + J], (unsigned long long)(long long)v);
