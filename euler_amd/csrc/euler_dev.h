@@ -148,7 +148,8 @@ struct euler_sim {
   // Round 6, the TILE MAP (whole-grid handles): per 64 x 64 cells, "some cell of the tile holds markers" for the count grid as it stands (tmap) and for the previous one
   // (tmap + tmap_n) - a superset: a set flag over an empty tile is harmless.  k_narrow_counts<true> writes both at every refresh, k_source_place sets what it fills; the
   // grid passes whose output over a tile with no water in or next to it in EITHER grid is the zeros already there leave at once (k_advect_velocity, k_zero_bounds4<true>,
-  // k_extrapolate4, k_transpose_for_markers): most of a dam break's grid.
+  // k_extrapolate4, k_transpose_for_markers; with the count grid's flags alone: k_build_system_para<true>, k_velocity_update_para; k_narrow_counts<true> with the third
+  // array, below): most of a dam break's grid.  DESIGN.md section 4 "tiles without water".
   uint8_t* tmap;
   int tmap_nx, tmap_n;     // tiles per row; tiles in all (the previous grid's flags start at tmap + tmap_n; at tmap + 2 tmap_n: a marker has entered the tile since the last refresh)
   int tmap_valid;          // both maps describe count / prev_count (0: somebody else wrote the grids since the last refresh)
