@@ -142,7 +142,7 @@ def compact_line(full, limit=LINE_LIMIT):
                 b["converged"] = _pick(v["converged_frames_multilevel"], ("value", "ms_per_step", "substeps", "pcg_iterations", "error"))
                 cs = v["converged_frames_multilevel"].get("stages")
                 if isinstance(cs, dict):      # how the converged frame's kernel time divides: iterations / the stages around them
-                    b["converged"]["stages"] = _pick(cs, ("pcg_ms_per_substep", "non_pcg_ms_per_substep", "non_pcg_share_of_kernel_time"))
+                    b["converged"]["stages"] = _pick(cs, ("pcg_ms_per_substep", "non_pcg_ms_per_substep", "non_pcg_share_of_kernel_time", "non_pcg_share_of_frame"))
             if isinstance(v.get("balance"), dict):
                 b["balance_max_over_mean"] = v["balance"].get("max_over_mean")
             summary[k] = b

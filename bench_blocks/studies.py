@@ -64,6 +64,7 @@ def strong_block(ctx, size, steps, tile_w):
                 rest = {k: round(ms / nsub, 3) for k, (ms, n) in prof.items() if k not in ITER_BYTES["ic0_tile_mg"] and n}
                 conv["stages"] = {"pcg_ms_per_substep": round(pcg / nsub, 3), "non_pcg_ms_per_substep": round(sum(rest.values()), 3),
                                   "non_pcg_share_of_kernel_time": round(sum(rest.values()) / max(sum(rest.values()) + pcg / nsub, 1e-9), 3),
+                                  "non_pcg_share_of_frame": round(sum(rest.values()) * nsub / max(1e3 * el, 1e-9), 3),      # (of the frame's wall time: the iterations, these stages, the gaps)
                                   "ms_per_substep": dict(sorted(rest.items(), key=lambda kv: -kv[1])[:8])}
         except Exception as e:      # (collective: a failure here is every rank's)
             conv = {"error": repr(e)}

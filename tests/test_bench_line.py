@@ -50,7 +50,7 @@ def canned_full(noise=0):
     full["stages"] = {"ms_per_substep": {"apply_a": 3.17, "precond_tile": 2.15, "advect_bin": 1.04, "build_system": 0.48, "velocity_update": 0.66, "transpose": 0.28,
                                          "narrow_counts": 0.05, "dt": 0.01}, "non_pcg_ms_per_substep": 4.0, "pcg_ms_per_substep": 45.9}
     full["converged"]["stages"] = dict(full["stages"])
-    full["strong_16384_dam_break"]["converged_frames_multilevel"]["stages"] = {"pcg_ms_per_substep": 18.2, "non_pcg_ms_per_substep": 12.1, "non_pcg_share_of_kernel_time": 0.399,
+    full["strong_16384_dam_break"]["converged_frames_multilevel"]["stages"] = {"pcg_ms_per_substep": 18.2, "non_pcg_ms_per_substep": 12.1, "non_pcg_share_of_kernel_time": 0.399, "non_pcg_share_of_frame": 0.387,
                                                                                "ms_per_substep": {"advect_bin": 4.1}}
     return full
 
@@ -75,6 +75,7 @@ def test_compact_line_is_small_and_carries_the_contract():
         assert d["stages"]["non_pcg_ms_per_substep"] == 4.0 and len(d["stages"]["ms_per_substep"]) == 6 and "dt" not in d["stages"]["ms_per_substep"]
         assert d["converged"]["stages"]["non_pcg_ms_per_substep"] == 4.0
         assert d["summary"]["strong_16384_dam_break"]["converged"]["stages"]["non_pcg_share_of_kernel_time"] == 0.399
+        assert d["summary"]["strong_16384_dam_break"]["converged"]["stages"]["non_pcg_share_of_frame"] == 0.387
 
 
 def test_compact_line_of_an_eight_gpu_job_carries_the_communicator():
