@@ -1031,6 +1031,29 @@ def test_round_6_stage_forms_leave_the_same_bits_as_rounds_1_to_5(precond):
 
 
 @pytest.mark.gpu
+def test_round_6_stage_forms_at_configs2_size_over_frames():
+    """The same comparison at BASELINE configs[2]'s size (8192^2 half tank, 134 M markers): the bit-exact tests against the recorded oracle run ONE substep from a fresh load,
+    where the tile map is not valid yet - on grids this large its readers take 64 rows per workgroup (`rep`), a form the small grids never run.  Three frames, the solves
+    capped at 20 iterations (the stages around them are what differs between the two handles), every field after every frame."""
+    sims = []
+    for old in (False, True):
+        s = ea.Simulation(8192, 8192, dot_mode=ea.DOT_TREE, precond=ea.PRECOND_IC0_TILE, max_iterations=20).load_half_tank()
+        if old:
+            for key in (ea.OPT_MARKERS_TWO_PASS, ea.OPT_BUILD_TWO_PASS, ea.OPT_VELOCITY_TWO_PASS, ea.OPT_NO_TILE_MAP):
+                s.set_option(key, 1)
+        sims.append(s)
+    a, b = sims
+    for f in range(3):
+        a.step(); b.step()
+        assert a.stats().last_substeps == b.stats().last_substeps and a.stats().last_pcg_iterations == b.stats().last_pcg_iterations > 0, f
+        for fld in (ea.F_U, ea.F_V, ea.F_UTMP, ea.F_VTMP, ea.F_COUNT, ea.F_PREV_COUNT, ea.F_PRESSURE, ea.F_MARKERS):
+            x, y = a.get(fld), b.get(fld)
+            assert x.shape == y.shape and np.array_equal(x.view(np.uint8), y.view(np.uint8)), "frame %d field %d" % (f, fld)
+            del x, y
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
 def test_the_lazily_finished_pressure_survives_an_option_that_forgets_the_ring():
     """k_velocity_update_para leaves the last p += alpha s and the clamp to whoever asks for EULER_F_PRESSURE (eu_pressure_current: from the search directions' ring of the
     last solve).  EULER_OPT_P_STEPS / _SA_RUN make the next solve set its ring up afresh: the pressure is finished BEFORE the ring is forgotten - two handles, one reads
