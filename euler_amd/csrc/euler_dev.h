@@ -358,6 +358,15 @@ int  eu_slab_after_restore(euler_sim* S);   // collective: the job-wide facts a 
 int  eu_slab_error_sync(euler_sim* S);      // collective: the ranks' sticky error words -> their maximum on every rank
 int  eu_slab_same_everywhere(euler_sim* S, const double* vals, int n, int* same);   // collective: do these host-side values agree on every rank?
 int  eu_slab_status_sync(euler_sim* S, int local_rc, int* worst);   // collective: a host-side status code -> non-zero on every rank if any rank failed
+// the grids of the handle were (re)written whole - allocation, a scenario load, a snapshot: nothing one stage prepared for the next describes them any more
+static inline void eu_state_replaced(euler_sim* S) {
+  S->blocked_dirty = 1; S->solidT_dirty = 1;      // (the column-major copies of the solid / sink grids)
+  S->prebin_valid = 0;
+  if (S->maxsq_state == 2) S->maxsq_state = 1;
+  S->p_pending = 0;
+  S->uv_clean = 0; S->uv_zb = 0;
+  S->tmap_valid = 0; S->utmp_clean = 0; S->countT_clean = 0;
+}
 // the tile map describes both count grids and this handle's passes may use it (EULER_OPT_NO_TILE_MAP: rounds 1-5's forms)
 static inline bool eu_tile_map_on(const euler_sim* S) { return S->tmap && S->tmap_valid && !S->slab_on && S->opt[EULER_OPT_NO_TILE_MAP] == 0; }
 // launch groups implemented in the kernel files

@@ -412,7 +412,7 @@ extern "C" int euler_load_state(euler_sim* S, const char* path) {
     if ((rc = eu_sync_marker_state(S))) return rc;
   } else if (rc) return rc;
   S->lean_ok = 0;      // the solver arrays may hold another state's pressure and masks: the next assembly writes them whole
-  S->blocked_dirty = 1; S->solidT_dirty = 1; S->prebin_valid = 0; if (S->maxsq_state == 2) S->maxsq_state = 1; S->p_pending = 0; S->uv_clean = 0; S->uv_zb = 0; S->tmap_valid = 0; S->utmp_clean = 0; S->countT_clean = 0;      // (the solid / sink grids were replaced)
+  eu_state_replaced(S);      // (the solid / sink grids were replaced)
   memset(&S->stats, 0, sizeof S->stats);
   S->stats.frames = h0.frames; S->stats.total_substeps = h0.total_substeps; S->stats.total_pcg_iterations = h0.total_pcg_iterations;
   S->loaded = 1;
