@@ -38,37 +38,53 @@ def kernel_rows(prof, precond, cells_fluid, traffic, iters):
     return rows
 
 
+PROFILE_STRIDE = 7      # large grids: every 7th launch of the dominant class carries its event pair in the timed region (coprime with the p-update's period of 8 iterations)
+
+
 def time_frames(sim, ea, grp, args, precond, steps, warmup_done, warmup, big):
-    """the timed region + per-kernel HIP-event timing.  Large grids: every PCG class is bracketed inside the timed region
-    (an event pair costs microseconds, the kernels hundreds); small grids (launches of ~10 us): only the dominant class,
-    the others in a second pass of the same length."""
+    """the timed region + per-kernel HIP-event timing.  An event pair serialises the stream for a few microseconds: with every launch of every class bracketed the 8192^2
+    headline ran 3.9 % slower than without (399.8 against 384.4 ms per frame).  So INSIDE the timed region only the dominant class is bracketed - on large grids every
+    PROFILE_STRIDE-th launch of it (EULER_OPT_PROFILE_STRIDE: ~2300 samples over the default 20 frames, every phase of the iteration's 8-cycle alike), on small grids
+    (launches of ~10 us, a handful per solve in the resident form) every one - and the other classes are timed in a second pass BEHIND it (large grids: two frames, every
+    launch; their totals are scaled to the timed region's substeps, so averages stand and per-substep sums compare)."""
     for _ in range(max(warmup - warmup_done, 0)):
         sim.step()
     dominant = {"ic0": "backward_solve", "ic0_tile": "apply_a", "ic0_tile2": "apply_a", "ic0_tile_mg": "apply_a", "jacobi": "update_pr"}[precond]
-    # round 6: on large grids EVERY kernel class is bracketed (the ~30 launches per substep outside the iterations cost their event pairs microseconds beside kernels of
-    # hundreds): the line then carries the stages around the solve as well (`stages`), not only the iteration's classes
+    # round 6: on large grids EVERY kernel class is timed (second pass): the line then carries the stages around the solve as well (`stages`), not only the iteration's classes
     classes_all = ea.profile_class_names() if (args.profile_all or big) else PCG_CLASSES
     if not big and precond == "ic0_tile" and sim.resident_info()[0]:
         dominant = "resident_pcg"
-    timed = [] if args.no_kernel_timing else (classes_all if big else [dominant])
+    timed = [] if args.no_kernel_timing else [dominant]
+    stride = PROFILE_STRIDE if (big and timed) else 1
     sim.profile_reset()
+    sim.set_option(ea.OPT_PROFILE_STRIDE, stride)
     sim.profile_enable(timed)
     st0 = sim.stats()
     elapsed = grp.timed(sim.step, steps)
     st1 = sim.stats()
     prof = sim.profile() if timed else {}
     sim.profile_enable([])
+    sim.set_option(ea.OPT_PROFILE_STRIDE, 1)
+    if stride > 1 and dominant in prof:      # the sample stands for every launch of the class: the same average, the launch count of the region
+        ms, n = prof[dominant]
+        prof[dominant] = (ms * stride, n * stride)
     iters = st1.total_pcg_iterations - st0.total_pcg_iterations
+    substeps = st1.total_substeps - st0.total_substeps
     iters2 = iters
-    if not args.no_kernel_timing and not big:
+    if not args.no_kernel_timing:
+        steps2 = min(steps, 2) if big else steps
         sim.profile_reset()
         sim.profile_enable([k for k in classes_all if k != dominant])
-        for _ in range(steps):
+        for _ in range(steps2):
             sim.step()
-        iters2 = sim.stats().total_pcg_iterations - st1.total_pcg_iterations
-        for k, v in sim.profile().items():
-            prof.setdefault(k, v)
+        st2 = sim.stats()
+        iters2 = st2.total_pcg_iterations - st1.total_pcg_iterations
+        f = (substeps / max(st2.total_substeps - st1.total_substeps, 1)) if big else 1.0
+        for k, (ms, n) in sim.profile().items():
+            prof.setdefault(k, (ms * f, n * f))
         sim.profile_enable([])
+        if big:
+            iters2 = iters      # (the second pass's counts are scaled to the timed region)
     # one iteration = the mode's per-iteration classes (ITER_BYTES); once-per-solve launches (s = z, k_finish_p, the factor) are not in it
     per_iter_ms = sum(prof[k][0] / prof[k][1] for k in ITER_BYTES[precond]
                       if k in prof and prof[k][1] >= 0.5 * max(iters if (big or k == dominant) else iters2, 1))
@@ -79,7 +95,7 @@ def time_frames(sim, ea, grp, args, precond, steps, warmup_done, warmup, big):
         if "apply_a" not in prof:
             per_iter_ms = prof["resident_pcg"][0] / max(resident["iters"], 1)
     return dict(elapsed=elapsed, st0=st0, st1=st1, prof=prof, iters=iters, per_iter_ms=per_iter_ms, dominant=dominant,
-                substeps=st1.total_substeps - st0.total_substeps, resident=resident)
+                substeps=substeps, resident=resident)
 
 
 def summarize(t, size_x, size_y, precond, tile_w, traffic, traffic_note, steps, fused_search=True, rank_cells=None, rank_fluid_share=1.0):
@@ -106,7 +122,7 @@ def summarize(t, size_x, size_y, precond, tile_w, traffic, traffic_note, steps, 
                 "frac_traffic": round(tr / sec / 1e9 / HBM_PEAK_GBPS, 4) if tr else None,
                 "traffic_over_algorithmic": round(tr / (b * fluid), 3) if tr else None,
                 "frac_dense": round(b * cells / sec / 1e9 / HBM_PEAK_GBPS, 4),
-                "achieved_is": "algorithmic bytes per cell x fluid cells of one launch / average launch time (HIP events in the timed region)",
+                "achieved_is": "algorithmic bytes per cell x fluid cells of one launch / average launch time (HIP events in the timed region; large grids: around every 7th launch of the class)",
                 "algorithmic_bytes_per_cell": b, "algorithmic_bytes_per_launch": int(b * fluid),
                 "avg_launch_us": r["avg_us"], "launches": r["launches"], "fluid_fraction": round(fluid / cells, 4),
                 "traffic_source": traffic_note,
@@ -150,7 +166,7 @@ def summarize(t, size_x, size_y, precond, tile_w, traffic, traffic_note, steps, 
         ms = {k: round(rows[k]["ms_total"] / t["substeps"], 3) for k in rows if k not in ITER_BYTES[precond] and k != "resident_pcg"}
         stages = {"ms_per_substep": dict(sorted(ms.items(), key=lambda kv: -kv[1])), "non_pcg_ms_per_substep": round(sum(ms.values()), 3),
                   "pcg_ms_per_substep": round(sum(rows[k]["ms_total"] for k in per_iter) / t["substeps"], 3),
-                  "note": "kernel time by class (HIP events in the timed region) / substeps; a solve's first k_apply_a and first k_precond_tile launch sit inside their per-iteration classes"}
+                  "note": "kernel time by class (HIP events: the dominant class sampled inside the timed region, the others in two frames behind it) / substeps; a solve's first k_apply_a and first k_precond_tile launch sit inside their per-iteration classes"}
     return {"mode": MODE_NAME[precond] % tile_w if precond in TILE_MODES else MODE_NAME[precond],
             "stages": stages,
             "value": cells_job * steps / t["elapsed"], "unit": "cells*steps/s", "ms_per_step": 1e3 * t["elapsed"] / steps,

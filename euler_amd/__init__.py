@@ -18,7 +18,7 @@ DOT_AUTO, DOT_SEQUENTIAL, DOT_TREE = 0, 1, 2
 PRECOND_IC0, PRECOND_JACOBI, PRECOND_IC0_TILE, PRECOND_IC0_TILE2, PRECOND_IC0_TILE_MG = 0, 1, 2, 3, 4
 (OPT_P_STEPS, OPT_TILE_STORE_AS, OPT_TILE_REVERSE, OPT_RESIDENT_CAP, OPT_GRID4_MIN_CELLS, OPT_SLAB_FUSION, OPT_RCCL_SMALL, OPT_RCCL_NO_EXCHANGE, OPT_MARKERS_ROWMAJOR,
  OPT_SA_RUN, OPT_NO_INTERIOR, OPT_BUILD_GATHER, OPT_RESIDENT_FORCE_TIMEOUT, OPT_MG_SPLIT_LEVEL, OPT_MG_SPLIT_ACTIVE, OPT_MARKERS_TWO_PASS, OPT_BUILD_TWO_PASS,
- OPT_VELOCITY_TWO_PASS, OPT_NO_TILE_MAP) = range(1, 20)      # include/euler.h EULER_OPT_*
+ OPT_VELOCITY_TWO_PASS, OPT_NO_TILE_MAP, OPT_PROFILE_STRIDE) = range(1, 21)      # include/euler.h EULER_OPT_*
 SWEEP_AUTO, SWEEP_BAND, SWEEP_SIMPLE = 0, 1, 2
 PCG_F64, PCG_F32 = 0, 1
 RESIDENT_AUTO, RESIDENT_OFF = 0, 1

@@ -47,6 +47,9 @@ static const char* k_class_names[KC__COUNT] = {
 
 void eu_prof_begin(euler_sim* S, int cls) {
   if (!((S->prof_mask >> cls) & 1)) return;
+  const long long stride = S->opt[EULER_OPT_PROFILE_STRIDE];
+  if (stride > 1 && (S->prof_seq[cls]++ % (unsigned int)stride) != 0) return;      // (an event pair serialises the stream for a few microseconds: every n-th launch is a sample)
+  S->prof_open |= 1ull << cls;
   if (S->ev_used + 2 > S->ev_cap) eu_prof_flush(S);
   const int k = S->ev_used / 2;
   S->ev_cls[k] = cls;
@@ -55,7 +58,8 @@ void eu_prof_begin(euler_sim* S, int cls) {
   (void)hipEventRecord(S->ev_pool[S->ev_used], S->stream);
 }
 void eu_prof_end(euler_sim* S, int cls) {
-  if (!((S->prof_mask >> cls) & 1)) return;
+  if (!((S->prof_open >> cls) & 1)) return;
+  S->prof_open &= ~(1ull << cls);
   (void)hipEventRecord(S->ev_pool[S->ev_used + 1], S->stream);
   S->ev_used += 2;
 }
@@ -91,6 +95,7 @@ extern "C" int euler_profile_enable(euler_sim* S, uint64_t mask) {
   if (!S) return EULER_EINVAL;
   int rc = eu_prof_flush(S);
   S->prof_mask = mask;
+  S->prof_open = 0;
   return rc;
 }
 extern "C" int euler_profile_get(euler_sim* S, int32_t cls, double* ms, uint64_t* launches) {
@@ -171,6 +176,7 @@ extern "C" int euler_set_option(euler_sim* S, int32_t key, int64_t value) {
     case EULER_OPT_SLAB_FUSION: ok = value == 0 || value == 1; if (S->p2p_on) when = "before euler_p2p_connect"; break;
     case EULER_OPT_RESIDENT_CAP: case EULER_OPT_GRID4_MIN_CELLS: case EULER_OPT_RESIDENT_FORCE_TIMEOUT: ok = value >= 0; break;
     case EULER_OPT_MG_SPLIT_LEVEL: ok = value >= -1 && value < 12; break;
+    case EULER_OPT_PROFILE_STRIDE: ok = value >= 1 && value <= 1024; break;
     case EULER_OPT_MG_SPLIT_ACTIVE: ok = false; break;
     default: ok = value == 0 || value == 1; break;
   }
@@ -308,7 +314,7 @@ extern "C" int euler_create(const euler_config* cfg, euler_sim** out) {
   }
 
   euler_sim* S = (euler_sim*)calloc(1, sizeof(euler_sim));
-  if (S) { S->opt[EULER_OPT_P_STEPS] = 8; S->opt[EULER_OPT_TILE_REVERSE] = 1; S->opt[EULER_OPT_GRID4_MIN_CELLS] = 1ll << 22; S->opt[EULER_OPT_SA_RUN] = 8; }      // (euler_set_option's defaults)
+  if (S) { S->opt[EULER_OPT_P_STEPS] = 8; S->opt[EULER_OPT_TILE_REVERSE] = 1; S->opt[EULER_OPT_GRID4_MIN_CELLS] = 1ll << 22; S->opt[EULER_OPT_SA_RUN] = 8; S->opt[EULER_OPT_PROFILE_STRIDE] = 1; }      // (euler_set_option's defaults)
   if (!S) return EULER_ENOMEM;
   g_alloc_bytes = 0;
   S->cfg = *cfg;

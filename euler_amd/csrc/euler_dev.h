@@ -300,6 +300,8 @@ struct euler_sim {
   // profiling: hipEvent pairs per launch; PCG launches carry (solve, iteration) so that launches
   // that returned at once (after convergence / all-zero rhs) are NOT counted
   uint64_t prof_mask;
+  uint64_t prof_open;      // classes whose current launch carries a begin event (EULER_OPT_PROFILE_STRIDE: not every launch does)
+  unsigned int prof_seq[32];      // launches of each enabled class seen so far
   double prof_ms[KC__COUNT];
   uint64_t prof_launches[KC__COUNT];
   uint64_t prof_idle[KC__COUNT];

@@ -381,6 +381,9 @@ enum {
   EULER_OPT_VELOCITY_TWO_PASS = 18, /* 1: k_finish_p + k_velocity_update as in rounds 1-5 (A-B timing; the same bits); 0 (default): one pass */
   EULER_OPT_NO_TILE_MAP = 19,       /* 1: the grid passes visit every cell as in rounds 1-5 (A-B timing; the same bits); 0 (default): tiles of 64 x 64 cells with no water in or next to them in
                                        the count grid and the previous one are left alone by advect_u / advect_v, zero_bounds, extrapolate and the marker stage's copies (their output there is the zeros already in place) */
+  EULER_OPT_PROFILE_STRIDE = 20,    /* n >= 1 (default 1): euler_profile_enable brackets every n-th launch of an enabled kernel class with its event pair (a pair costs the stream
+                                       a few microseconds of serialisation: all ~230 launches of an 8192^2 substep bracketed cost bench.py's headline 3.9 %); the class's time and
+                                       launch count are those of the bracketed launches */
   EULER_OPT__COUNT
 };
 int euler_set_option(euler_sim* sim, int32_t key, int64_t value);
