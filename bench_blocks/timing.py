@@ -44,9 +44,9 @@ PROFILE_STRIDE = 7      # large grids: every 7th launch of the dominant class ca
 def time_frames(sim, ea, grp, args, precond, steps, warmup_done, warmup, big):
     """the timed region + per-kernel HIP-event timing.  An event pair serialises the stream for a few microseconds: with every launch of every class bracketed the 8192^2
     headline ran 3.9 % slower than without (399.8 against 384.4 ms per frame).  So INSIDE the timed region only the dominant class is bracketed - on large grids every
-    PROFILE_STRIDE-th launch of it (EULER_OPT_PROFILE_STRIDE: ~2300 samples over the default 20 frames, every phase of the iteration's 8-cycle alike), on small grids
-    (launches of ~10 us, a handful per solve in the resident form) every one - and the other classes are timed in a second pass BEHIND it (large grids: two frames, every
-    launch; their totals are scaled to the timed region's substeps, so averages stand and per-substep sums compare)."""
+    PROFILE_STRIDE-th launch of it (EULER_OPT_PROFILE_STRIDE: ~2300 samples over the default 20 frames, every phase of the iteration's 8-cycle alike; the resident solver's
+    one launch per solve: every one) - and the other classes are timed in a second pass BEHIND it (large grids: two frames, every launch; their totals are scaled to the
+    timed region's substeps, so averages stand and per-substep sums compare; small grids: as many frames as the timed region)."""
     for _ in range(max(warmup - warmup_done, 0)):
         sim.step()
     dominant = {"ic0": "backward_solve", "ic0_tile": "apply_a", "ic0_tile2": "apply_a", "ic0_tile_mg": "apply_a", "jacobi": "update_pr"}[precond]
@@ -55,7 +55,7 @@ def time_frames(sim, ea, grp, args, precond, steps, warmup_done, warmup, big):
     if not big and precond == "ic0_tile" and sim.resident_info()[0]:
         dominant = "resident_pcg"
     timed = [] if args.no_kernel_timing else [dominant]
-    stride = PROFILE_STRIDE if (big and timed) else 1
+    stride = PROFILE_STRIDE if (timed and dominant != "resident_pcg") else 1      # (the resident solver is ONE launch per solve)
     sim.profile_reset()
     sim.set_option(ea.OPT_PROFILE_STRIDE, stride)
     sim.profile_enable(timed)
