@@ -36,6 +36,12 @@ def test_python_constants_mirror_the_header_enums():
                   ("DOT_TREE", "EULER_DOT_TREE"), ("DOT_SEQUENTIAL", "EULER_DOT_SEQUENTIAL")):
         assert c in values, c
         assert getattr(ea, py) == values[c], (py, getattr(ea, py), values[c])
+    # the per-handle options (euler_set_option): every EULER_OPT_* of the header has its OPT_* twin with the same number, and the wrapper invents none
+    opts = {k[len("EULER_"):]: v for k, v in values.items() if k.startswith("EULER_OPT_")}
+    assert len(opts) >= 20
+    for name, v in opts.items():
+        assert getattr(ea, name) == v, (name, getattr(ea, name, None), v)
+    assert {k for k in dir(ea) if k.startswith("OPT_")} == set(opts)
 
 
 def test_no_cpu_fallback():
